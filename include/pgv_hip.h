@@ -1,0 +1,301 @@
+/*
+ * pgv_hip.h -- C ABI of libpgv_hip.so: the MI355X (gfx950) implementation of
+ * pgvector's distance hot path.
+ *
+ * This is the drop-in boundary.  pgvector has no batch seam of its own: every
+ * distance goes through a per-pair fmgr call (src/ivfflat.h:307 `distfunc`,
+ * src/hnswutils.c:524-528 `HnswGetDistance`).  Each entry point below replaces
+ * one of the LOOPS around that call; the reference loop it replaces is cited
+ * on the declaration.  Host code inside the extension (C)
+ * stages vectors out of 8 KB pages into contiguous arrays, calls these
+ * functions, and feeds the results back into the same Postgres structures the
+ * reference uses (tuplesort, pairing heaps, page writers).
+ *
+ * Conventions
+ *   - plain C: opaque handles, plain pointers and sizes; no C++/torch types.
+ *   - every function returns PGV_OK or a PGV_ERR_* code; the message of the
+ *     last failure on the calling thread is pgv_last_error().
+ *   - buffer arguments may be HOST or DEVICE pointers; the library asks the HIP
+ *     runtime which (hipPointerGetAttributes) and stages host buffers through
+ *     its own pinned/device scratch.  A Postgres backend passes host memory; a
+ *     harness that already keeps data in HBM passes device memory and pays no
+ *     PCIe traffic.
+ *   - a handle is used by one thread at a time (a Postgres backend is single
+ *     threaded); different handles may be used concurrently.
+ *   - all work is enqueued on the context's HIP stream; functions that return
+ *     results into host memory synchronise that stream before returning,
+ *     functions whose outputs are device pointers do not (pgv_ctx_sync does).
+ *   - vectors are `dim` consecutive elements of `dtype` (float or IEEE
+ *     binary16), row-major, densely packed: the payload of the reference's
+ *     Vector / HalfVector varlenas (src/vector.h:18-24, src/halfvec.h:68-74)
+ *     without the 8-byte header.
+ *   - distances come back as the fp32 value of the reference's kernel
+ *     (src/vector.c:560-617, src/halfutils.c:29-121); the float8 widening,
+ *     sqrt, negation-for-display etc. of the fmgr wrappers is exact host work.
+ *   - there is NO CPU fallback: without a usable gfx950 device every call
+ *     fails with PGV_ERR_DEVICE.
+ */
+#ifndef PGV_HIP_H
+#define PGV_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define PGV_ABI_VERSION 1
+
+/* status codes */
+#define PGV_OK 0
+#define PGV_ERR_ARG 1			/* bad argument (NULL, negative size, ...) */
+#define PGV_ERR_DIMS 2			/* dimension limits: 1..16000 (src/vector.h:10) */
+#define PGV_ERR_DEVICE 3		/* no usable GPU / HIP runtime error */
+#define PGV_ERR_NOMEM 4			/* device or host allocation failed */
+#define PGV_ERR_STATE 5			/* handle in the wrong state */
+#define PGV_ERR_DATA 6			/* data error the reference would elog (NaN center, ...) */
+
+/* element type of an indexed column: vector (float4) or halfvec (binary16) */
+typedef enum pgv_dtype
+{
+	PGV_F32 = 0,
+	PGV_F16 = 1
+}			pgv_dtype;
+
+/*
+ * Distance computed by a kernel = FUNCTION 1 of the operator class
+ * (src/ivfflat.h:40 IVFFLAT_DISTANCE_PROC, src/hnsw.h:37 HNSW_DISTANCE_PROC):
+ *   PGV_L2SQ    vector_l2_squared_distance / halfvec_l2_squared_distance   (sql/vector.sql:409,822)
+ *   PGV_NEG_IP  vector_negative_inner_product / halfvec_...                (sql/vector.sql:415,422,828,835)
+ *   PGV_L1      l1_distance (hnsw vector_l1_ops, sql/vector.sql:445)
+ */
+typedef enum pgv_metric
+{
+	PGV_L2SQ = 0,
+	PGV_NEG_IP = 1,
+	PGV_L1 = 2
+}			pgv_metric;
+
+/*
+ * Operator-class family, for the build path where FUNCTION 3/4 matter too:
+ *   PGV_OPS_L2      k-means on l2_distance, nothing normalised
+ *   PGV_OPS_IP      spherical k-means (samples and centers normalised), rows stored as-is
+ *   PGV_OPS_COSINE  spherical k-means, rows stored normalised, zero rows skipped
+ * (sql/vector.sql:406-425; src/ivfbuild.c:69-73,154-155,174-180)
+ */
+typedef enum pgv_ops
+{
+	PGV_OPS_L2 = 0,
+	PGV_OPS_IP = 1,
+	PGV_OPS_COSINE = 2
+}			pgv_ops;
+
+typedef struct pgv_ctx pgv_ctx;		/* one GPU + stream + scratch */
+typedef struct pgv_index pgv_index;	/* device mirror of one IVFFlat index */
+typedef struct pgv_hnsw pgv_hnsw;	/* device mirror of one HNSW index's element vectors */
+
+/*
+ * Source of RandomDouble()/RandomInt() (src/ivfflat.h:86-94).  Inside Postgres
+ * the callbacks wrap pg_prng_double/pg_prng_uint32 on pg_global_prng_state so
+ * the stream of draws is the reference's.  NULL callbacks select the library's
+ * own xoroshiro128** seeded with `seed`.
+ */
+typedef struct pgv_rng
+{
+	double		(*next_double) (void *state);	/* uniform [0,1) */
+	uint32_t	(*next_u32) (void *state);
+	void	   *state;
+	uint64_t	seed;
+}			pgv_rng;
+
+/* ------------------------------------------------------------------ context */
+
+const char *pgv_last_error(void);
+int			pgv_abi_version(void);
+
+/* number of HIP devices visible (0 when there is no GPU / no driver) */
+int			pgv_device_count(void);
+
+/*
+ * Create the per-backend GPU context: lazily from _PG_init (src/vector.c:57-65)
+ * or on first use.  `stream` is an existing hipStream_t to enqueue on (as
+ * void*), or NULL to create a private non-blocking stream.
+ */
+int			pgv_ctx_create(int device, void *stream, pgv_ctx * *out);
+void		pgv_ctx_destroy(pgv_ctx * ctx);
+int			pgv_ctx_sync(pgv_ctx * ctx);
+/* the hipStream_t all work of this context is enqueued on */
+void	   *pgv_ctx_stream(pgv_ctx * ctx);
+/* time the enclosed GPU work with HIP events on the context's stream (ms) */
+int			pgv_timer_start(pgv_ctx * ctx);
+int			pgv_timer_stop(pgv_ctx * ctx, float *out_ms);
+
+/*
+ * Optional per-kernel accounting for the roofline report: when on, every
+ * launch of the row-streaming distance kernel is bracketed by HIP events on the
+ * context's stream; pgv_ctx_get_stats synchronises, resolves them and returns
+ * the totals since the last pgv_ctx_reset_stats.
+ */
+typedef struct pgv_stats
+{
+	/* the IVFFlat list scan (GetScanItems): pgv_scan_lists / pgv_search_batch */
+	double		scan_ms;		/* GPU time inside the row-streaming kernel */
+	int64_t		scan_launches;
+	double		scan_pairs;		/* (row, query) distances it produced */
+	double		scan_rows;		/* rows it streamed (a row shared by a query group counts once) */
+	/* the same kernel on other inputs: center ranking, exact scans, k-means++ rounds */
+	double		aux_ms;
+	int64_t		aux_launches;
+	double		aux_pairs;
+}			pgv_stats;
+int			pgv_ctx_set_profiling(pgv_ctx * ctx, int on);
+int			pgv_ctx_reset_stats(pgv_ctx * ctx);
+int			pgv_ctx_get_stats(pgv_ctx * ctx, pgv_stats * out);
+
+/* ------------------------------------------------------- IVFFlat scan side */
+
+/*
+ * Upload (or adopt, when the pointers are device memory the index is copied
+ * device-to-device) a list-major image of an IVFFlat index:
+ *   centers       [nlists x dim]   the Vector inside each IvfflatListData (src/ivfflat.h:270-275)
+ *   list_offsets  [nlists + 1]     row range of list l = [off[l], off[l+1]) -- its page chain, flattened
+ *   vectors       [n x dim]        index tuple payloads in page-chain order (src/ivfscan.c:139-179)
+ *   tids          [n] or NULL      heap TIDs (ItemPointerData widened to 64 bit); NULL -> results carry row slots
+ * Replaces the ReadBuffer/LockBuffer page walks of GetScanLists/GetScanItems.
+ */
+int			pgv_index_upload(pgv_ctx * ctx, pgv_metric metric, pgv_dtype dtype, int dim, int nlists,
+							 const void *centers, const int64_t *list_offsets,
+							 const void *vectors, const uint64_t *tids, pgv_index * *out);
+void		pgv_index_free(pgv_index * index);
+int64_t		pgv_index_rows(const pgv_index * index);
+int			pgv_index_lists(const pgv_index * index);
+
+/*
+ * GetScanLists (src/ivfscan.c:47-118) for a batch of queries: distance from each
+ * query to every center, keep the `maxprobes` nearest, ascending.  Ties on the
+ * boundary keep the lower list id (the reference's strict `<` at :92).
+ *   queries    [nq x dim]
+ *   out_lists  [nq x maxprobes] list ids (maxprobes is clamped to nlists by the caller, :271-278)
+ *   out_dist   [nq x maxprobes] or NULL
+ */
+int			pgv_rank_lists(pgv_index * index, const void *queries, int nq, int maxprobes,
+						   int32_t *out_lists, float *out_dist);
+
+/*
+ * GetScanItems (src/ivfscan.c:123-187) without the final sort: the distance of
+ * every tuple of the given lists to one query, in the order the reference
+ * feeds its tuplesort (lists in the given order, page-chain order inside).
+ *   out_dist  [m]  m = sum of the list lengths (query NULL -> all 0: ZeroDistance :192-196)
+ *   out_slot  [m]  row slot of each tuple (index into vectors/tids)
+ *   capacity  size of the out arrays; *out_count = m (PGV_ERR_ARG if m > capacity)
+ * The caller widens to float8 and runs the same tuplesort as the reference.
+ */
+int			pgv_scan_lists(pgv_index * index, const void *query, const int32_t *lists, int nlists,
+						   float *out_dist, int64_t *out_slot, int64_t capacity, int64_t *out_count);
+
+/*
+ * Fused query path for many backends' queries at once: GetScanLists +
+ * GetScanItems + the head of the sorted tuplesort stream (src/ivfscan.c:360-414),
+ * i.e. for each query the k nearest tuples of its `probes` nearest lists,
+ * ascending (ties: lower insertion position first).
+ *   out_dist  [nq x k]   +inf padded when fewer than k tuples were scanned
+ *   out_slot  [nq x k]   row slots, -1 padded
+ *   out_tid   [nq x k]   or NULL; heap TIDs when the index was uploaded with tids
+ */
+int			pgv_search_batch(pgv_index * index, const void *queries, int nq, int probes, int k,
+							 float *out_dist, int64_t *out_slot, uint64_t *out_tid);
+
+/* ------------------------------------------------------ IVFFlat build side */
+
+/*
+ * The argmin loop of AddTupleToSort (src/ivfbuild.c:183-192) for a batch of
+ * heap rows: list id of the nearest center under FUNCTION 1, first
+ * strictly-smallest wins.
+ *   centers [k x dim], rows [n x dim], out_list [n], out_dist [n] or NULL
+ */
+int			pgv_assign(pgv_ctx * ctx, pgv_metric metric, pgv_dtype dtype, int dim,
+					   const void *centers, int k, const void *rows, int64_t n,
+					   int32_t *out_list, float *out_dist);
+
+/*
+ * IvfflatKmeans (src/ivfkmeans.c:553-570): k-means++ seeding (:23-91) followed
+ * by Lloyd iterations to the reference's stopping rule (:347, :482-483), new
+ * centers as fp32 sums in sample order / count (:179-236), empty clusters
+ * refilled from the rng (:222-227), spherical variant for ip/cosine (:234-235),
+ * CheckCenters (:490-547).  Elkan's bounds (:391-476) are a CPU-side pruning of
+ * exactly this computation and are not reproduced: every sample is scored
+ * against every center each iteration.
+ *   samples      [n x dim] as left by SampleRows (already normalised for ip/cosine, src/ivfbuild.c:154-155)
+ *   out_centers  [k x dim] in `dtype`
+ *   out_closest  [n] final assignment, or NULL
+ *   out_iters    iterations run, or NULL
+ * n == 0 -> RandomCenters (:110-133).
+ */
+int			pgv_kmeans(pgv_ctx * ctx, pgv_ops ops, pgv_dtype dtype, int dim,
+					   const void *samples, int n, int k, int max_iterations, const pgv_rng * rng,
+					   void *out_centers, int32_t *out_closest, int *out_iters);
+
+/*
+ * The two halves of one Lloyd iteration, exposed so that a multi-GPU build can
+ * put its all-reduce between them (samples sharded by row, centers replicated):
+ *   pgv_lloyd_partial: assignment of this rank's samples to `centers` + this
+ *       rank's per-center fp32 sums [k x dim], counts [k] and the number of
+ *       samples whose center changed versus io_closest (updated in place).
+ *   pgv_lloyd_finish:  centers = sums / counts (inf clamp, empty -> rng, dtype
+ *       rounding, renormalise) from the all-reduced sums/counts.
+ * All pointers follow the host-or-device rule; with device pointers nothing
+ * synchronises, so RCCL can be enqueued on the same stream in between.
+ */
+int			pgv_lloyd_partial(pgv_ctx * ctx, pgv_ops ops, pgv_dtype dtype, int dim,
+							  const void *samples, int n, const void *centers, int k,
+							  int32_t *io_closest, float *out_sums, int32_t *out_counts,
+							  int64_t *out_changes);
+int			pgv_lloyd_finish(pgv_ctx * ctx, pgv_ops ops, pgv_dtype dtype, int dim, int k,
+							 const float *sums, const int32_t *counts, const pgv_rng * rng,
+							 void *out_centers);
+
+/*
+ * InitCenters (src/ivfkmeans.c:23-91) alone: k-means++ seeding under the
+ * FUNCTION 3 distance.  out_centers [k x dim].
+ */
+int			pgv_kmeanspp_init(pgv_ctx * ctx, pgv_ops ops, pgv_dtype dtype, int dim,
+							  const void *samples, int n, int k, const pgv_rng * rng,
+							  void *out_centers);
+
+/* ------------------------------------------------- generic candidate batch */
+
+/*
+ * One query against n contiguous rows: the exact-scan shape (one fmgr call
+ * per heap row, src/vector.c:579-589) and the building block of HNSW candidate
+ * scoring.  out[n] = kernel value (L2 squared / -ip / L1).
+ */
+int			pgv_distance_batch(pgv_ctx * ctx, pgv_metric metric, pgv_dtype dtype, int dim,
+							   const void *query, const void *rows, int64_t n, float *out);
+
+/* --------------------------------------------------------------- HNSW side */
+
+/*
+ * Device mirror of an HNSW index's element vectors (the `Vector data` at byte
+ * 72 of every HnswElementTupleData, src/hnsw.h:372-382), addressed by a dense
+ * element slot the host keeps per (blkno, offno).
+ */
+int			pgv_hnsw_upload(pgv_ctx * ctx, pgv_metric metric, pgv_dtype dtype, int dim,
+							const void *elements, int64_t n, pgv_hnsw * *out);
+void		pgv_hnsw_free(pgv_hnsw * h);
+
+/*
+ * The candidate-scoring loop of HnswSearchLayer (src/hnswutils.c:908-934,
+ * HnswLoadElementImpl :533-571): distances from queries to gathered elements.
+ * Pair i scores element slot[i] against query query_of[i] (query_of == NULL ->
+ * all pairs use query 0).  One call serves one expansion step of many
+ * concurrent searches.
+ *   queries [nq x dim], slot [npairs], query_of [npairs] or NULL, out [npairs]
+ */
+int			pgv_hnsw_score(pgv_hnsw * h, const void *queries, int nq,
+						   const int32_t *slot, const int32_t *query_of, int64_t npairs, float *out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif							/* PGV_HIP_H */

@@ -1,0 +1,257 @@
+"""ctypes face of oracle/liboracle.so (and oracle/_ref/libpgvref.so).
+
+TEST INFRASTRUCTURE ONLY: imported by tests/, __graft_entry__.smoke() and
+bench.py's cpu_baseline leg -- never by pgvector_amd.  See pgv_oracle.h.
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ORA_F32, ORA_F16 = 0, 1
+OPS_L2, OPS_IP, OPS_COSINE, OPS_L1 = 0, 1, 2, 3
+NP_OF = {ORA_F32: np.float32, ORA_F16: np.float16}
+
+
+def build(native=False):
+    """(re)build the restatement from its own sources; returns the .so path"""
+    target = "liboracle_native.so" if native else "liboracle.so"
+    subprocess.run(["make", "-s", "-C", HERE, target], check=True)
+    return os.path.join(HERE, target)
+
+
+class Prng(C.Structure):
+    _fields_ = [("s0", C.c_uint64), ("s1", C.c_uint64)]
+
+
+class IvfIndexStruct(C.Structure):
+    _fields_ = [("ops", C.c_int), ("dtype", C.c_int), ("dim", C.c_int), ("nlists", C.c_int),
+                ("centers", C.c_void_p), ("list_offsets", C.c_void_p), ("vectors", C.c_void_p),
+                ("tids", C.c_void_p)]
+
+
+def _p(a):
+    return None if a is None else C.c_void_p(a.ctypes.data)
+
+
+class Oracle:
+    def __init__(self, native=False, path=None):
+        if path is None:
+            path = os.path.join(HERE, "liboracle_native.so" if native else "liboracle.so")
+            if not os.path.exists(path):
+                path = build(native)
+        self.path = path
+        L = self.lib = C.CDLL(path)
+        F, D, I, P, I64 = C.c_float, C.c_double, C.c_int, C.c_void_p, C.c_int64
+        for name, res in [("ora_vector_l2_squared", F), ("ora_vector_inner_product", F),
+                          ("ora_vector_cosine_similarity", D), ("ora_vector_l1", F),
+                          ("ora_halfvec_l2_squared", F), ("ora_halfvec_inner_product", F),
+                          ("ora_halfvec_cosine_similarity", D), ("ora_halfvec_l1", F),
+                          ("ora_halfvec_l2_squared_default", F), ("ora_halfvec_inner_product_default", F)]:
+            fn = getattr(L, name)
+            fn.restype = res
+            fn.argtypes = [I, P, P]
+        for name in ["ora_l2_distance", "ora_l2_squared_distance", "ora_inner_product",
+                     "ora_negative_inner_product", "ora_cosine_distance", "ora_spherical_distance",
+                     "ora_l1_distance", "ora_halfvec_l2_distance", "ora_halfvec_l2_squared_distance",
+                     "ora_halfvec_inner_product_f8", "ora_halfvec_negative_inner_product",
+                     "ora_halfvec_cosine_distance", "ora_halfvec_spherical_distance",
+                     "ora_halfvec_l1_distance"]:
+            fn = getattr(L, name)
+            fn.restype = I
+            fn.argtypes = [I, P, I, P, C.POINTER(D)]
+        L.ora_last_error.restype = C.c_char_p
+        L.ora_vector_norm.restype = D
+        L.ora_vector_norm.argtypes = [I, P]
+        L.ora_halfvec_l2_norm.restype = D
+        L.ora_halfvec_l2_norm.argtypes = [I, P]
+        L.ora_l2_normalize.argtypes = [I, P, P]
+        L.ora_halfvec_l2_normalize.argtypes = [I, P, P]
+        L.ora_half_to_float.restype = F
+        L.ora_half_to_float.argtypes = [C.c_uint16]
+        L.ora_float_to_half.restype = C.c_uint16
+        L.ora_float_to_half.argtypes = [F]
+        L.ora_halfvec_uses_f16c.restype = I
+        L.ora_index_distance.restype = D
+        L.ora_index_distance.argtypes = [I, I, I, P, P]
+        L.ora_kmeans_distance.restype = D
+        L.ora_kmeans_distance.argtypes = [I, I, I, P, P]
+        L.ora_prng_seed.argtypes = [C.POINTER(Prng), C.c_uint64]
+        L.ora_prng_u32.restype = C.c_uint32
+        L.ora_prng_u32.argtypes = [C.POINTER(Prng)]
+        L.ora_prng_double.restype = D
+        L.ora_prng_double.argtypes = [C.POINTER(Prng)]
+        L.ora_ivf_get_scan_lists.restype = I
+        L.ora_ivf_get_scan_lists.argtypes = [C.POINTER(IvfIndexStruct), P, I, P, P]
+        L.ora_ivf_get_scan_items.restype = I64
+        L.ora_ivf_get_scan_items.argtypes = [C.POINTER(IvfIndexStruct), P, P, I, P, P]
+        L.ora_ivf_search.restype = I
+        L.ora_ivf_search.argtypes = [C.POINTER(IvfIndexStruct), P, I, I, P, P]
+        L.ora_ivf_assign.restype = None
+        L.ora_ivf_assign.argtypes = [I, I, I, P, I, P, I64, P, P]
+        L.ora_ivf_num_samples.restype = I
+        L.ora_ivf_num_samples.argtypes = [I, I64]
+        L.ora_kmeans_init_centers.restype = None
+        L.ora_kmeans_init_centers.argtypes = [I, I, I, P, I, P, I, P, C.POINTER(Prng)]
+        L.ora_kmeans_compute_new_centers.restype = None
+        L.ora_kmeans_compute_new_centers.argtypes = [I, I, I, P, I, P, P, I, P, C.POINTER(Prng)]
+        L.ora_kmeans.restype = I
+        L.ora_kmeans.argtypes = [I, I, I, P, I, P, I, C.POINTER(Prng), P]
+        L.ora_kmeans_lloyd_assign.restype = None
+        L.ora_kmeans_lloyd_assign.argtypes = [I, I, I, P, I, P, I, P, P]
+        self.has_hnsw = hasattr(L, "ora_hnsw_build")
+        if self.has_hnsw:
+            L.ora_hnsw_build.restype = P
+            L.ora_hnsw_build.argtypes = [I, I, I, P, I64, I, I, C.c_uint64]
+            L.ora_hnsw_free.argtypes = [P]
+            L.ora_hnsw_free.restype = None
+            L.ora_hnsw_num_elements.restype = I64
+            L.ora_hnsw_num_elements.argtypes = [P]
+            L.ora_hnsw_entry_point.restype = I
+            L.ora_hnsw_entry_point.argtypes = [P, C.POINTER(I)]
+            L.ora_hnsw_m.restype = I
+            L.ora_hnsw_m.argtypes = [P]
+            L.ora_hnsw_level.restype = I
+            L.ora_hnsw_level.argtypes = [P, I64]
+            L.ora_hnsw_neighbors.restype = I
+            L.ora_hnsw_neighbors.argtypes = [P, I64, I, P]
+            L.ora_hnsw_element_row.restype = I64
+            L.ora_hnsw_element_row.argtypes = [P, I64]
+            L.ora_hnsw_search.restype = I
+            L.ora_hnsw_search.argtypes = [P, P, I, I, P, P, C.POINTER(I64)]
+
+    # ---- helpers -------------------------------------------------------
+    @staticmethod
+    def arr(x, dtype):
+        return np.ascontiguousarray(x, dtype=NP_OF[dtype])
+
+    def last_error(self):
+        return self.lib.ora_last_error().decode()
+
+    def sql(self, name, a, b, half=False):
+        """an fmgr-level wrapper; returns (rc, value)"""
+        dt = ORA_F16 if half else ORA_F32
+        a, b = self.arr(a, dt), self.arr(b, dt)
+        out = C.c_double()
+        rc = getattr(self.lib, name)(len(a), _p(a), len(b), _p(b), C.byref(out))
+        return rc, out.value
+
+    def kernel(self, name, a, b, half=False):
+        dt = ORA_F16 if half else ORA_F32
+        a, b = self.arr(a, dt), self.arr(b, dt)
+        assert len(a) == len(b)
+        return getattr(self.lib, name)(len(a), _p(a), _p(b))
+
+    def prng(self, seed):
+        st = Prng()
+        self.lib.ora_prng_seed(C.byref(st), seed)
+        return st
+
+    def index_struct(self, ops, dtype, centers, list_offsets, vectors, tids=None):
+        """keeps the arrays alive on the returned object"""
+        centers = self.arr(centers, dtype)
+        vectors = self.arr(vectors, dtype)
+        list_offsets = np.ascontiguousarray(list_offsets, dtype=np.int64)
+        s = IvfIndexStruct()
+        s.ops, s.dtype, s.dim, s.nlists = ops, dtype, centers.shape[1], centers.shape[0]
+        s.centers, s.list_offsets, s.vectors = centers.ctypes.data, list_offsets.ctypes.data, vectors.ctypes.data
+        if tids is not None:
+            tids = np.ascontiguousarray(tids, dtype=np.uint64)
+            s.tids = tids.ctypes.data
+        s._keep = (centers, vectors, list_offsets, tids)
+        return s
+
+    def get_scan_lists(self, ix, query, maxprobes):
+        q = None if query is None else self.arr(query, ix.dtype)
+        m = min(maxprobes, ix.nlists)
+        lists = np.empty(m, dtype=np.int32)
+        dist = np.empty(m, dtype=np.float64)
+        n = self.lib.ora_ivf_get_scan_lists(C.byref(ix), _p(q), maxprobes, _p(lists), _p(dist))
+        return lists[:n], dist[:n]
+
+    def get_scan_items(self, ix, query, lists):
+        q = None if query is None else self.arr(query, ix.dtype)
+        lists = np.ascontiguousarray(lists, dtype=np.int32)
+        off = ix._keep[2]
+        total = int(sum(off[l + 1] - off[l] for l in lists))
+        dist = np.empty(max(total, 1), dtype=np.float64)
+        slot = np.empty(max(total, 1), dtype=np.int64)
+        n = self.lib.ora_ivf_get_scan_items(C.byref(ix), _p(q), _p(lists), len(lists), _p(dist), _p(slot))
+        return dist[:n], slot[:n]
+
+    def search(self, ix, query, probes, k):
+        q = None if query is None else self.arr(query, ix.dtype)
+        tids = np.empty(k, dtype=np.uint64)
+        dist = np.empty(k, dtype=np.float64)
+        n = self.lib.ora_ivf_search(C.byref(ix), _p(q), probes, k, _p(tids), _p(dist))
+        return tids[:n], dist[:n]
+
+    def assign(self, ops, dtype, centers, rows):
+        centers, rows = self.arr(centers, dtype), self.arr(rows, dtype)
+        n = rows.shape[0]
+        out = np.empty(n, dtype=np.int32)
+        dist = np.empty(n, dtype=np.float64)
+        self.lib.ora_ivf_assign(ops, dtype, centers.shape[1], _p(centers), centers.shape[0], _p(rows), n,
+                                _p(out), _p(dist))
+        return out, dist
+
+    def kmeans_init_centers(self, ops, dtype, samples, k, rng):
+        samples = self.arr(samples, dtype)
+        centers = np.zeros((k, samples.shape[1]), dtype=NP_OF[dtype])
+        self.lib.ora_kmeans_init_centers(ops, dtype, samples.shape[1], _p(samples), samples.shape[0],
+                                         _p(centers), k, None, C.byref(rng))
+        return centers
+
+    def kmeans_compute_new_centers(self, ops, dtype, samples, closest, k, rng):
+        samples = self.arr(samples, dtype)
+        closest = np.ascontiguousarray(closest, dtype=np.int32)
+        centers = np.zeros((k, samples.shape[1]), dtype=NP_OF[dtype])
+        counts = np.zeros(k, dtype=np.int32)
+        self.lib.ora_kmeans_compute_new_centers(ops, dtype, samples.shape[1], _p(samples), samples.shape[0],
+                                                _p(closest), _p(centers), k, _p(counts), C.byref(rng))
+        return centers, counts
+
+    def kmeans(self, ops, dtype, samples, k, rng):
+        samples = self.arr(samples, dtype)
+        n, dim = samples.shape if samples.ndim == 2 else (0, 0)
+        centers = np.zeros((k, dim), dtype=NP_OF[dtype])
+        closest = np.zeros(max(n, 1), dtype=np.int32)
+        it = self.lib.ora_kmeans(ops, dtype, dim, _p(samples) if n else None, n, _p(centers), k,
+                                 C.byref(rng), _p(closest))
+        return centers, closest[:n], it
+
+    def lloyd_assign(self, ops, dtype, samples, centers):
+        samples, centers = self.arr(samples, dtype), self.arr(centers, dtype)
+        n = samples.shape[0]
+        closest = np.empty(n, dtype=np.int32)
+        dist = np.empty(n, dtype=np.float32)
+        self.lib.ora_kmeans_lloyd_assign(ops, dtype, samples.shape[1], _p(samples), n, _p(centers),
+                                         centers.shape[0], _p(closest), _p(dist))
+        return closest, dist
+
+
+class Ref:
+    """oracle/_ref/libpgvref.so: the reference's src/halfutils.c compiled unmodified"""
+
+    def __init__(self):
+        path = os.path.join(HERE, "_ref", "libpgvref.so")
+        if not os.path.exists(path):
+            raise FileNotFoundError(path)
+        L = self.lib = C.CDLL(path)
+        L.pgvref_init()
+        for name, res in [("pgvref_halfvec_l2_squared", C.c_float), ("pgvref_halfvec_inner_product", C.c_float),
+                          ("pgvref_halfvec_cosine_similarity", C.c_double), ("pgvref_halfvec_l1", C.c_float)]:
+            fn = getattr(L, name)
+            fn.restype = res
+            fn.argtypes = [C.c_int, C.c_void_p, C.c_void_p]
+        L.pgvref_half_to_float.restype = C.c_float
+        L.pgvref_half_to_float.argtypes = [C.c_uint16]
+        L.pgvref_float_to_half.restype = C.c_uint16
+        L.pgvref_float_to_half.argtypes = [C.c_float]
+
+    def kernel(self, name, a, b):
+        a = np.ascontiguousarray(a, dtype=np.float16)
+        b = np.ascontiguousarray(b, dtype=np.float16)
+        return getattr(self.lib, name)(len(a), _p(a), _p(b))

@@ -1,0 +1,1 @@
+/* shim: see postgres.h in this directory */

@@ -1,0 +1,102 @@
+"""ctypes binding of libpgv_hip.so (include/pgv_hip.h).
+
+The shared library is the product; this module only declares its prototypes so
+the Python harness (tests/, bench.py, __graft_entry__.py) can call through the
+same C ABI a Postgres backend would.  There is no fallback: if the library is
+missing, import fails loudly; if there is no GPU, every call returns
+PGV_ERR_DEVICE and is raised as PgvError.
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libpgv_hip.so")
+
+PGV_OK, PGV_ERR_ARG, PGV_ERR_DIMS, PGV_ERR_DEVICE, PGV_ERR_NOMEM, PGV_ERR_STATE, PGV_ERR_DATA = range(7)
+PGV_F32, PGV_F16 = 0, 1
+PGV_L2SQ, PGV_NEG_IP, PGV_L1 = 0, 1, 2
+PGV_OPS_L2, PGV_OPS_IP, PGV_OPS_COSINE = 0, 1, 2
+
+# every symbol include/pgv_hip.h declares (tests check the library exports each)
+SYMBOLS = [
+    "pgv_last_error", "pgv_abi_version", "pgv_device_count", "pgv_ctx_create", "pgv_ctx_destroy",
+    "pgv_ctx_sync", "pgv_ctx_stream", "pgv_timer_start", "pgv_timer_stop", "pgv_ctx_set_profiling",
+    "pgv_ctx_reset_stats", "pgv_ctx_get_stats", "pgv_index_upload", "pgv_index_free",
+    "pgv_index_rows", "pgv_index_lists", "pgv_rank_lists", "pgv_scan_lists", "pgv_search_batch",
+    "pgv_assign", "pgv_kmeans", "pgv_lloyd_partial", "pgv_lloyd_finish", "pgv_kmeanspp_init",
+    "pgv_distance_batch", "pgv_hnsw_upload", "pgv_hnsw_free", "pgv_hnsw_score",
+]
+
+
+class PgvError(RuntimeError):
+    def __init__(self, code, message):
+        super().__init__("libpgv_hip error %d: %s" % (code, message))
+        self.code = code
+        self.message = message
+
+
+class PgvStats(C.Structure):
+    _fields_ = [("scan_ms", C.c_double), ("scan_launches", C.c_int64),
+                ("scan_pairs", C.c_double), ("scan_rows", C.c_double),
+                ("aux_ms", C.c_double), ("aux_launches", C.c_int64), ("aux_pairs", C.c_double)]
+
+
+NEXT_DOUBLE = C.CFUNCTYPE(C.c_double, C.c_void_p)
+NEXT_U32 = C.CFUNCTYPE(C.c_uint32, C.c_void_p)
+
+
+class PgvRng(C.Structure):
+    _fields_ = [("next_double", C.c_void_p), ("next_u32", C.c_void_p),
+                ("state", C.c_void_p), ("seed", C.c_uint64)]
+
+
+def _load():
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(
+            "libpgv_hip.so not built (%s): run `python -c 'import __graft_entry__ as g; g.build()'` "
+            "or `make -C pgvector_amd/csrc` -- there is no CPU fallback" % LIB_PATH)
+    lib = C.CDLL(LIB_PATH)
+    P, I, I64 = C.c_void_p, C.c_int, C.c_int64
+    lib.pgv_last_error.restype = C.c_char_p
+    lib.pgv_last_error.argtypes = []
+    lib.pgv_abi_version.restype = I
+    lib.pgv_device_count.restype = I
+    lib.pgv_ctx_create.argtypes = [I, P, C.POINTER(P)]
+    lib.pgv_ctx_destroy.argtypes = [P]
+    lib.pgv_ctx_destroy.restype = None
+    lib.pgv_ctx_sync.argtypes = [P]
+    lib.pgv_ctx_stream.argtypes = [P]
+    lib.pgv_ctx_stream.restype = P
+    lib.pgv_timer_start.argtypes = [P]
+    lib.pgv_timer_stop.argtypes = [P, C.POINTER(C.c_float)]
+    lib.pgv_ctx_set_profiling.argtypes = [P, I]
+    lib.pgv_ctx_reset_stats.argtypes = [P]
+    lib.pgv_ctx_get_stats.argtypes = [P, C.POINTER(PgvStats)]
+    lib.pgv_index_upload.argtypes = [P, I, I, I, I, P, P, P, P, C.POINTER(P)]
+    lib.pgv_index_free.argtypes = [P]
+    lib.pgv_index_free.restype = None
+    lib.pgv_index_rows.argtypes = [P]
+    lib.pgv_index_rows.restype = I64
+    lib.pgv_index_lists.argtypes = [P]
+    lib.pgv_rank_lists.argtypes = [P, P, I, I, P, P]
+    lib.pgv_scan_lists.argtypes = [P, P, P, I, P, P, I64, C.POINTER(I64)]
+    lib.pgv_search_batch.argtypes = [P, P, I, I, I, P, P, P]
+    lib.pgv_assign.argtypes = [P, I, I, I, P, I, P, I64, P, P]
+    lib.pgv_kmeans.argtypes = [P, I, I, I, P, I, I, I, C.POINTER(PgvRng), P, P, C.POINTER(I)]
+    lib.pgv_lloyd_partial.argtypes = [P, I, I, I, P, I, P, I, P, P, P, P]
+    lib.pgv_lloyd_finish.argtypes = [P, I, I, I, I, P, P, C.POINTER(PgvRng), P]
+    lib.pgv_kmeanspp_init.argtypes = [P, I, I, I, P, I, I, C.POINTER(PgvRng), P]
+    lib.pgv_distance_batch.argtypes = [P, I, I, I, P, P, I64, P]
+    lib.pgv_hnsw_upload.argtypes = [P, I, I, I, P, I64, C.POINTER(P)]
+    lib.pgv_hnsw_free.argtypes = [P]
+    lib.pgv_hnsw_free.restype = None
+    lib.pgv_hnsw_score.argtypes = [P, P, I, P, P, I64, P]
+    return lib
+
+
+lib = _load()
+
+
+def check(rc):
+    if rc != PGV_OK:
+        raise PgvError(rc, lib.pgv_last_error().decode("utf-8", "replace"))

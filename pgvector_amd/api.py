@@ -1,0 +1,271 @@
+"""Thin Python face of the C ABI, for the test/bench harness.
+
+Buffers may be numpy arrays (host memory) or torch tensors (host or HBM); the
+library itself decides per pointer whether to stage it.  Nothing here computes
+a distance: every function forwards to libpgv_hip.so.
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import _lib
+from ._lib import (PGV_F16, PGV_F32, PGV_L1, PGV_L2SQ, PGV_NEG_IP, PGV_OPS_COSINE, PGV_OPS_IP,
+                   PGV_OPS_L2, PgvError, PgvRng, PgvStats, check, lib)
+
+_NP_OF = {PGV_F32: np.float32, PGV_F16: np.float16}
+
+
+def _is_torch(x):
+    return type(x).__module__.startswith("torch")
+
+
+def ptr(x):
+    """raw address of a numpy array / torch tensor (None -> NULL)"""
+    if x is None:
+        return None
+    if _is_torch(x):
+        assert x.is_contiguous(), "tensor must be contiguous"
+        return C.c_void_p(x.data_ptr())
+    assert isinstance(x, np.ndarray) and x.flags["C_CONTIGUOUS"], "need a C-contiguous array"
+    return C.c_void_p(x.ctypes.data)
+
+
+def _on_device(x):
+    return _is_torch(x) and x.is_cuda
+
+
+def _empty_like_kind(ref, shape, np_dtype):
+    """output buffer living where `ref` lives"""
+    if _on_device(ref):
+        import torch
+        return torch.empty(shape, dtype=getattr(torch, np.dtype(np_dtype).name), device=ref.device)
+    return np.empty(shape, dtype=np_dtype)
+
+
+def as_dtype(x, dtype):
+    """host arrays: make sure element type and layout match what the ABI reads"""
+    if _is_torch(x):
+        return x.contiguous()
+    return np.ascontiguousarray(x, dtype=_NP_OF[dtype])
+
+
+def make_rng(seed=0, next_double=None, next_u32=None, state=None):
+    """pgv_rng: the library's own generator (seed) or caller callbacks (C function pointers)"""
+    r = PgvRng()
+    r.next_double = C.cast(next_double, C.c_void_p) if next_double is not None else None
+    r.next_u32 = C.cast(next_u32, C.c_void_p) if next_u32 is not None else None
+    r.state = state
+    r.seed = seed
+    return r
+
+
+class Context:
+    def __init__(self, device=0, stream=None):
+        h = C.c_void_p()
+        check(lib.pgv_ctx_create(device, C.c_void_p(stream) if stream else None, C.byref(h)))
+        self.h = h
+
+    def close(self):
+        if self.h:
+            lib.pgv_ctx_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def sync(self):
+        check(lib.pgv_ctx_sync(self.h))
+
+    def stream(self):
+        return lib.pgv_ctx_stream(self.h)
+
+    def timer_start(self):
+        check(lib.pgv_timer_start(self.h))
+
+    def timer_stop(self):
+        ms = C.c_float()
+        check(lib.pgv_timer_stop(self.h, C.byref(ms)))
+        return ms.value
+
+    def set_profiling(self, on):
+        check(lib.pgv_ctx_set_profiling(self.h, 1 if on else 0))
+
+    def reset_stats(self):
+        check(lib.pgv_ctx_reset_stats(self.h))
+
+    def stats(self):
+        s = PgvStats()
+        check(lib.pgv_ctx_get_stats(self.h, C.byref(s)))
+        return {"scan_ms": s.scan_ms, "scan_launches": s.scan_launches,
+                "scan_pairs": s.scan_pairs, "scan_rows": s.scan_rows,
+                "aux_ms": s.aux_ms, "aux_launches": s.aux_launches, "aux_pairs": s.aux_pairs}
+
+
+class IvfIndex:
+    """device mirror of one IVFFlat index (pgv_index_upload)"""
+
+    def __init__(self, ctx, metric, dtype, dim, centers, list_offsets, vectors, tids=None):
+        self.ctx, self.metric, self.dtype, self.dim = ctx, metric, dtype, dim
+        centers = as_dtype(centers, dtype)
+        vectors = as_dtype(vectors, dtype)
+        if not _is_torch(list_offsets):
+            list_offsets = np.ascontiguousarray(list_offsets, dtype=np.int64)
+        if tids is not None and not _is_torch(tids):
+            tids = np.ascontiguousarray(tids, dtype=np.uint64)
+        self.nlists = int(list_offsets.shape[0]) - 1
+        h = C.c_void_p()
+        check(lib.pgv_index_upload(ctx.h, metric, dtype, dim, self.nlists, ptr(centers),
+                                   ptr(list_offsets), ptr(vectors), ptr(tids), C.byref(h)))
+        self.h = h
+
+    def close(self):
+        if self.h:
+            lib.pgv_index_free(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    @property
+    def rows(self):
+        return lib.pgv_index_rows(self.h)
+
+    def rank_lists(self, queries, maxprobes, want_dist=True):
+        queries = as_dtype(queries, self.dtype)
+        nq = int(queries.shape[0])
+        lists = _empty_like_kind(queries, (nq, maxprobes), np.int32)
+        dist = _empty_like_kind(queries, (nq, maxprobes), np.float32) if want_dist else None
+        check(lib.pgv_rank_lists(self.h, ptr(queries), nq, maxprobes, ptr(lists), ptr(dist)))
+        return lists, dist
+
+    def scan_lists(self, query, lists):
+        if query is not None:
+            query = as_dtype(query, self.dtype)
+        lists = np.ascontiguousarray(lists, dtype=np.int32)
+        count = C.c_int64()
+        # first call sizes the output (capacity 0 only reports the count)
+        rc = lib.pgv_scan_lists(self.h, ptr(query), ptr(lists), len(lists), None, None, 0, C.byref(count))
+        if rc != _lib.PGV_OK and count.value == 0:
+            check(rc)
+        m = count.value
+        dist = np.empty(m, dtype=np.float32)
+        slot = np.empty(m, dtype=np.int64)
+        if m:
+            check(lib.pgv_scan_lists(self.h, ptr(query), ptr(lists), len(lists), ptr(dist), ptr(slot),
+                                     m, C.byref(count)))
+        return dist, slot
+
+    def search_batch(self, queries, probes, k, want_tid=False, out=None):
+        queries = as_dtype(queries, self.dtype)
+        nq = int(queries.shape[0])
+        if out is None:
+            dist = _empty_like_kind(queries, (nq, k), np.float32)
+            slot = _empty_like_kind(queries, (nq, k), np.int64)
+            tid = _empty_like_kind(queries, (nq, k), np.uint64 if not _on_device(queries) else np.int64) \
+                if want_tid else None
+        else:
+            dist, slot, tid = out
+        check(lib.pgv_search_batch(self.h, ptr(queries), nq, probes, k, ptr(dist), ptr(slot), ptr(tid)))
+        return dist, slot, tid
+
+
+def assign(ctx, metric, dtype, dim, centers, rows, want_dist=True):
+    centers = as_dtype(centers, dtype)
+    rows = as_dtype(rows, dtype)
+    n = int(rows.shape[0])
+    out = _empty_like_kind(rows, (n,), np.int32)
+    dist = _empty_like_kind(rows, (n,), np.float32) if want_dist else None
+    check(lib.pgv_assign(ctx.h, metric, dtype, dim, ptr(centers), int(centers.shape[0]), ptr(rows), n,
+                         ptr(out), ptr(dist)))
+    return out, dist
+
+
+def distance_batch(ctx, metric, dtype, dim, query, rows):
+    query = as_dtype(query, dtype)
+    rows = as_dtype(rows, dtype)
+    n = int(rows.shape[0])
+    out = _empty_like_kind(rows, (n,), np.float32)
+    check(lib.pgv_distance_batch(ctx.h, metric, dtype, dim, ptr(query), ptr(rows), n, ptr(out)))
+    return out
+
+
+def kmeans(ctx, ops, dtype, dim, samples, k, rng=None, max_iterations=500, want_closest=True):
+    samples = as_dtype(samples, dtype)
+    n = int(samples.shape[0])
+    centers = _empty_like_kind(samples, (k, dim), _NP_OF[dtype])
+    closest = _empty_like_kind(samples, (n,), np.int32) if want_closest and n else None
+    iters = C.c_int()
+    check(lib.pgv_kmeans(ctx.h, ops, dtype, dim, ptr(samples) if n else None, n, k, max_iterations,
+                         C.byref(rng) if rng is not None else None, ptr(centers), ptr(closest),
+                         C.byref(iters)))
+    return centers, closest, iters.value
+
+
+def kmeanspp_init(ctx, ops, dtype, dim, samples, k, rng=None):
+    samples = as_dtype(samples, dtype)
+    centers = _empty_like_kind(samples, (k, dim), _NP_OF[dtype])
+    check(lib.pgv_kmeanspp_init(ctx.h, ops, dtype, dim, ptr(samples), int(samples.shape[0]), k,
+                                C.byref(rng) if rng is not None else None, ptr(centers)))
+    return centers
+
+
+def lloyd_partial(ctx, ops, dtype, dim, samples, centers, closest):
+    """closest is updated in place; returns (sums [k x dim] fp32, counts [k], changes)"""
+    samples = as_dtype(samples, dtype)
+    centers = as_dtype(centers, dtype)
+    k = int(centers.shape[0])
+    n = int(samples.shape[0])
+    sums = _empty_like_kind(samples, (k, dim), np.float32)
+    counts = _empty_like_kind(samples, (k,), np.int32)
+    changes = _empty_like_kind(samples, (1,), np.int64)
+    check(lib.pgv_lloyd_partial(ctx.h, ops, dtype, dim, ptr(samples), n, ptr(centers), k, ptr(closest),
+                                ptr(sums), ptr(counts), ptr(changes)))
+    return sums, counts, changes
+
+
+def lloyd_finish(ctx, ops, dtype, dim, sums, counts, rng=None, like=None):
+    k = int(counts.shape[0])
+    centers = _empty_like_kind(like if like is not None else sums, (k, dim), _NP_OF[dtype])
+    check(lib.pgv_lloyd_finish(ctx.h, ops, dtype, dim, k, ptr(sums), ptr(counts),
+                               C.byref(rng) if rng is not None else None, ptr(centers)))
+    return centers
+
+
+class Hnsw:
+    """device mirror of an HNSW index's element vectors (pgv_hnsw_upload)"""
+
+    def __init__(self, ctx, metric, dtype, dim, elements):
+        self.ctx, self.metric, self.dtype, self.dim = ctx, metric, dtype, dim
+        elements = as_dtype(elements, dtype)
+        h = C.c_void_p()
+        check(lib.pgv_hnsw_upload(ctx.h, metric, dtype, dim, ptr(elements), int(elements.shape[0]),
+                                  C.byref(h)))
+        self.h = h
+
+    def close(self):
+        if self.h:
+            lib.pgv_hnsw_free(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def score(self, queries, slot, query_of=None):
+        queries = as_dtype(queries, self.dtype)
+        slot = np.ascontiguousarray(slot, dtype=np.int32) if not _is_torch(slot) else slot
+        if query_of is not None and not _is_torch(query_of):
+            query_of = np.ascontiguousarray(query_of, dtype=np.int32)
+        n = int(slot.shape[0])
+        out = _empty_like_kind(slot, (n,), np.float32)
+        check(lib.pgv_hnsw_score(self.h, ptr(queries), int(queries.shape[0]), ptr(slot), ptr(query_of),
+                                 n, ptr(out)))
+        return out

@@ -1,0 +1,373 @@
+// kernels_kmeans.hip -- the k-means pieces of IVFFlat build that are not a
+// distance kernel: k-means++ weight bookkeeping and the D^2 pick
+// (src/ivfkmeans.c:64-84), per-center fp32 sums in sample order and the
+// center update (src/ivfkmeans.c:151-236, src/ivfutils.c:301-361), the
+// spherical renormalisation (src/vector.c:785-819, src/halfvec.c:724-759) and
+// CheckCenters (src/ivfkmeans.c:490-547).  All HBM-bound byte shuffling; the
+// distances themselves come from kernels_scan.hip / kernels_pair.hip.
+#include "pgv_device.h"
+
+#include <cfloat>
+
+namespace pgv {
+
+namespace {
+
+constexpr int kKmThreads = 256;
+
+// ---------------------------------------------------------------- k-means++
+
+// raw[j] = FUNCTION-1-style kernel value of (sample j, newest center):
+//   spherical == 0: L2 squared          -> distance = sqrt((double) raw)      (vector.c:588)
+//   spherical == 1: negative inner prod -> distance = acos(clamp(ip)) / pi    (vector.c:713-721)
+// weight[j] = min(weight[j], (float) distance^2) (ivfkmeans.c:64-68); per-block sums in double.
+__global__ __launch_bounds__(kKmThreads) void kmpp_update_kernel(
+    const float *__restrict__ raw, float *__restrict__ weight, int n, int spherical,
+    double *__restrict__ block_sums) {
+    __shared__ double red[kKmThreads];
+    const int j = blockIdx.x * kKmThreads + threadIdx.x;
+    double w = 0.0;
+    if (j < n) {
+        double distance;
+        if (spherical) {
+            double ip = -(double)raw[j];
+            if (ip > 1)
+                ip = 1;
+            else if (ip < -1)
+                ip = -1;
+            distance = acos(ip) / 3.14159265358979323846;
+        } else {
+            distance = sqrt((double)raw[j]);
+        }
+        distance *= distance;
+        float cur = weight[j];
+        if (distance < (double)cur) {
+            cur = (float)distance;
+            weight[j] = cur;
+        }
+        w = (double)cur;
+    }
+    // in-order tree: the same association every run
+    red[threadIdx.x] = w;
+    __syncthreads();
+    for (int s = kKmThreads / 2; s > 0; s >>= 1) {
+        if (threadIdx.x < s) red[threadIdx.x] += red[threadIdx.x + s];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) block_sums[blockIdx.x] = red[0];
+}
+
+// choice = sum * RandomDouble(); walk the weights until it is used up
+// (ivfkmeans.c:77-84); the chosen sample becomes center `next`.
+__global__ __launch_bounds__(kKmThreads) void kmpp_pick_kernel(
+    const char *__restrict__ samples, int n, const float *__restrict__ weight,
+    const double *__restrict__ block_sums, int nblocks, const double *__restrict__ draws,
+    int round, char *__restrict__ centers, int nvec, int32_t *__restrict__ picked) {
+    __shared__ int chosen;
+    if (threadIdx.x == 0) {
+        double sum = 0.0;
+        for (int b = 0; b < nblocks; b++) sum += block_sums[b];
+        double choice = sum * draws[round];
+        int b = 0;
+        // skip whole blocks while the walk cannot end inside them
+        while (b < nblocks - 1 && choice - block_sums[b] > 0) {
+            choice -= block_sums[b];
+            b++;
+        }
+        int j = b * kKmThreads;
+        const int last = n - 1;
+        for (; j < last; j++) {
+            choice -= (double)weight[j];
+            if (choice <= 0) break;
+        }
+        chosen = j;
+        picked[round + 1] = j;
+    }
+    __syncthreads();
+    const size_t row_bytes = (size_t)nvec * sizeof(Raw16);
+    const Raw16 *src = reinterpret_cast<const Raw16 *>(samples + (size_t)chosen * row_bytes);
+    Raw16 *dst = reinterpret_cast<Raw16 *>(centers + (size_t)(round + 1) * row_bytes);
+    for (int v = threadIdx.x; v < nvec; v += kKmThreads) dst[v] = src[v];
+}
+
+// ------------------------------------------------------------- Lloyd pieces
+
+__global__ __launch_bounds__(kKmThreads) void changes_hist_kernel(
+    const int32_t *__restrict__ closest_new, int32_t *__restrict__ closest_io, int n,
+    int32_t *__restrict__ counts, unsigned long long *__restrict__ changes) {
+    const int j = blockIdx.x * kKmThreads + threadIdx.x;
+    bool changed = false;
+    if (j < n) {
+        const int c = closest_new[j];
+        changed = closest_io[j] != c;
+        closest_io[j] = c;
+        atomicAdd(&counts[c], 1);
+    }
+    const unsigned long long bal = __ballot(changed);
+    if ((threadIdx.x & (kWave - 1)) == 0 && bal) atomicAdd(changes, (unsigned long long)__popcll(bal));
+}
+
+__global__ __launch_bounds__(1024) void offsets_kernel(const int32_t *__restrict__ counts, int k,
+                                                       int32_t *__restrict__ offsets) {
+    __shared__ int scratch[1024];
+    __shared__ int carry;
+    if (threadIdx.x == 0) carry = 0;
+    __syncthreads();
+    for (int base = 0; base < k; base += 1024) {
+        const int i = base + threadIdx.x;
+        const int v = i < k ? counts[i] : 0;
+        scratch[threadIdx.x] = v;
+        __syncthreads();
+        for (int s = 1; s < 1024; s <<= 1) {
+            int t = threadIdx.x >= (unsigned)s ? scratch[threadIdx.x - s] : 0;
+            __syncthreads();
+            scratch[threadIdx.x] += t;
+            __syncthreads();
+        }
+        if (i < k) offsets[i] = carry + scratch[threadIdx.x] - v;
+        __syncthreads();
+        if (threadIdx.x == 1023) carry += scratch[1023];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) offsets[k] = carry;
+}
+
+// one wavefront per center: its members in ascending sample order (a stable
+// compaction), so the sums below add in exactly the order SumCenters does
+__global__ __launch_bounds__(kKmThreads) void members_kernel(
+    const int32_t *__restrict__ closest, int n, int k, const int32_t *__restrict__ offsets,
+    int32_t *__restrict__ members) {
+    const int c = blockIdx.x * (kKmThreads / kWave) + (threadIdx.x >> 6);
+    if (c >= k) return;
+    const int lane = threadIdx.x & (kWave - 1);
+    int at = offsets[c];
+    for (int base = 0; base < n; base += kWave) {
+        const int j = base + lane;
+        const bool mine = j < n && closest[j] == c;
+        const unsigned long long bal = __ballot(mine);
+        if (mine) members[at + __popcll(bal & ((1ull << lane) - 1ull))] = j;
+        at += __popcll(bal);
+    }
+}
+
+// sums[c][d] = fp32 sum over members of c in sample order (ivfutils.c:340-361);
+// lanes map to dimensions, so every lane runs the reference's scalar chain.
+template <typename T>
+__global__ __launch_bounds__(kKmThreads) void center_sums_kernel(
+    const char *__restrict__ samples, const int32_t *__restrict__ offsets,
+    const int32_t *__restrict__ members, int nvec, float *__restrict__ sums) {
+    constexpr int N = VecTraits<T>::N;
+    const int c = blockIdx.y;
+    const int v = blockIdx.x * kKmThreads + threadIdx.x;
+    if (v >= nvec) return;
+    const size_t row_bytes = (size_t)nvec * sizeof(Raw16);
+    float acc[N];
+#pragma unroll
+    for (int e = 0; e < N; e++) acc[e] = 0.f;
+    const int beg = offsets[c], end = offsets[c + 1];
+    for (int m = beg; m < end; m++) {
+        const Raw16 r = load16(samples + (size_t)members[m] * row_bytes + (size_t)v * sizeof(Raw16));
+        Unpacked<T> u(r);
+#pragma unroll
+        for (int e = 0; e < N; e++) acc[e] += u.v[e];
+    }
+    float *dst = sums + ((size_t)c * nvec + v) * N;
+#pragma unroll
+    for (int e = 0; e < N; e++) dst[e] = acc[e];
+}
+
+template <typename T> __device__ __forceinline__ void store_elem(char *row, int d, float x);
+template <> __device__ __forceinline__ void store_elem<float>(char *row, int d, float x) {
+    reinterpret_cast<float *>(row)[d] = x;  // VectorUpdateCenter, ivfutils.c:301-311
+}
+template <> __device__ __forceinline__ void store_elem<__half>(char *row, int d, float x) {
+    // HalfvecUpdateCenter: Float4ToHalfUnchecked = round-to-nearest-even (halfutils.h:146-152)
+    reinterpret_cast<__half *>(row)[d] = __float2half_rn(x);
+}
+
+// centers[c] = sums[c] / count (inf clamped to +-FLT_MAX), or the refill row for
+// an empty cluster (ivfkmeans.c:205-231)
+template <typename T>
+__global__ __launch_bounds__(kKmThreads) void finish_centers_kernel(
+    const float *__restrict__ sums, const int32_t *__restrict__ counts,
+    const float *__restrict__ refill, const int32_t *__restrict__ refill_row, int dim, int ld,
+    char *__restrict__ centers) {
+    const int c = blockIdx.y;
+    const int d = blockIdx.x * kKmThreads + threadIdx.x;
+    if (d >= ld) return;
+    const size_t row_bytes = (size_t)ld * sizeof(T);
+    float x = 0.f;
+    if (d < dim) {
+        const int cnt = counts[c];
+        if (cnt > 0) {
+            x = sums[(size_t)c * ld + d];
+            if (isinf(x)) x = x > 0 ? FLT_MAX : -FLT_MAX;
+            x /= (float)cnt;
+        } else {
+            x = refill[(size_t)refill_row[c] * dim + d];
+        }
+    }
+    store_elem<T>(centers + (size_t)c * row_bytes, d, x);
+}
+
+template <typename T> __device__ __forceinline__ float load_elem(const char *row, int d);
+template <> __device__ __forceinline__ float load_elem<float>(const char *row, int d) {
+    return reinterpret_cast<const float *>(row)[d];
+}
+template <> __device__ __forceinline__ float load_elem<__half>(const char *row, int d) {
+    return __half2float(reinterpret_cast<const __half *>(row)[d]);
+}
+
+// l2_normalize / halfvec_l2_normalize in place, one wavefront per row: norm in
+// double, element = (float)(x / norm), zero rows stay zero.  flag gets bit 0 on
+// an overflowing element (float_overflow_error in the reference).
+template <typename T>
+__global__ __launch_bounds__(kKmThreads) void normalize_rows_kernel(char *__restrict__ rows,
+                                                                    int64_t n, int dim, int ld,
+                                                                    int32_t *__restrict__ flag) {
+    const int64_t r = (int64_t)blockIdx.x * (kKmThreads / kWave) + (threadIdx.x >> 6);
+    if (r >= n) return;
+    const int lane = threadIdx.x & (kWave - 1);
+    char *row = rows + (size_t)r * ld * sizeof(T);
+    double acc = 0.0;
+    for (int d = lane; d < dim; d += kWave) {
+        const double x = (double)load_elem<T>(row, d);
+        acc += x * x;
+    }
+    for (int m = 32; m > 0; m >>= 1) acc += __shfl_xor(acc, m);
+    const double norm = sqrt(acc);
+    if (!(norm > 0)) return;
+    for (int d = lane; d < dim; d += kWave) {
+        const float y = (float)((double)load_elem<T>(row, d) / norm);
+        store_elem<T>(row, d, y);
+        if (isinf(load_elem<T>(row, d))) atomicOr(flag, 1);
+    }
+}
+
+// CheckElements + CheckNorms (ivfkmeans.c:490-536): bit 1 = NaN, bit 2 = inf, bit 3 = zero norm
+template <typename T>
+__global__ __launch_bounds__(kKmThreads) void check_centers_kernel(const char *__restrict__ rows,
+                                                                   int k, int dim, int ld,
+                                                                   int check_zero_norm,
+                                                                   int32_t *__restrict__ flag) {
+    const int c = blockIdx.x * (kKmThreads / kWave) + (threadIdx.x >> 6);
+    if (c >= k) return;
+    const int lane = threadIdx.x & (kWave - 1);
+    const char *row = rows + (size_t)c * ld * sizeof(T);
+    double acc = 0.0;
+    int bad = 0;
+    for (int d = lane; d < dim; d += kWave) {
+        const float x = load_elem<T>(row, d);
+        if (isnan(x)) bad |= 2;
+        if (isinf(x)) bad |= 4;
+        acc += (double)x * (double)x;
+    }
+    for (int m = 32; m > 0; m >>= 1) acc += __shfl_xor(acc, m);
+    if (check_zero_norm && lane == 0 && sqrt(acc) == 0) bad |= 8;
+    if (bad) atomicOr(flag, bad);
+}
+
+}  // namespace
+
+int kmpp_block_count(int n) { return (n + kKmThreads - 1) / kKmThreads; }
+
+int launch_kmpp_update(pgv_ctx *ctx, const float *raw, float *weight, int n, int spherical,
+                       double *block_sums) {
+    hipLaunchKernelGGL(kmpp_update_kernel, dim3(kmpp_block_count(n)), dim3(kKmThreads), 0,
+                       ctx->stream, raw, weight, n, spherical, block_sums);
+    PGV_HIP(hipGetLastError());
+    return PGV_OK;
+}
+
+int launch_kmpp_pick(pgv_ctx *ctx, const RowGeom &g, const void *samples, int n,
+                     const float *weight, const double *block_sums, const double *draws,
+                     int round, void *centers, int32_t *picked) {
+    hipLaunchKernelGGL(kmpp_pick_kernel, dim3(1), dim3(kKmThreads), 0, ctx->stream,
+                       static_cast<const char *>(samples), n, weight, block_sums,
+                       kmpp_block_count(n), draws, round, static_cast<char *>(centers), g.nvec,
+                       picked);
+    PGV_HIP(hipGetLastError());
+    return PGV_OK;
+}
+
+int launch_changes_hist(pgv_ctx *ctx, const int32_t *closest_new, int32_t *closest_io, int n,
+                        int32_t *counts, unsigned long long *changes) {
+    if (n <= 0) return PGV_OK;
+    hipLaunchKernelGGL(changes_hist_kernel, dim3((n + kKmThreads - 1) / kKmThreads),
+                       dim3(kKmThreads), 0, ctx->stream, closest_new, closest_io, n, counts,
+                       changes);
+    PGV_HIP(hipGetLastError());
+    return PGV_OK;
+}
+
+int launch_members(pgv_ctx *ctx, const int32_t *closest, int n, int k, const int32_t *counts,
+                   int32_t *offsets, int32_t *members) {
+    hipLaunchKernelGGL(offsets_kernel, dim3(1), dim3(1024), 0, ctx->stream, counts, k, offsets);
+    const int per = kKmThreads / kWave;
+    hipLaunchKernelGGL(members_kernel, dim3((k + per - 1) / per), dim3(kKmThreads), 0, ctx->stream,
+                       closest, n, k, offsets, members);
+    PGV_HIP(hipGetLastError());
+    return PGV_OK;
+}
+
+int launch_center_sums(pgv_ctx *ctx, pgv_dtype dtype, const RowGeom &g, const void *samples,
+                       const int32_t *offsets, const int32_t *members, int k, float *sums) {
+    dim3 grid((g.nvec + kKmThreads - 1) / kKmThreads, k);
+    if (dtype == PGV_F32)
+        hipLaunchKernelGGL(center_sums_kernel<float>, grid, dim3(kKmThreads), 0, ctx->stream,
+                           static_cast<const char *>(samples), offsets, members, g.nvec, sums);
+    else
+        hipLaunchKernelGGL(center_sums_kernel<__half>, grid, dim3(kKmThreads), 0, ctx->stream,
+                           static_cast<const char *>(samples), offsets, members, g.nvec, sums);
+    PGV_HIP(hipGetLastError());
+    return PGV_OK;
+}
+
+int launch_finish_centers(pgv_ctx *ctx, pgv_dtype dtype, const RowGeom &g, int k, int dim,
+                          const float *sums, const int32_t *counts, const float *refill,
+                          const int32_t *refill_row, void *centers) {
+    dim3 grid((g.ld + kKmThreads - 1) / kKmThreads, k);
+    if (dtype == PGV_F32)
+        hipLaunchKernelGGL(finish_centers_kernel<float>, grid, dim3(kKmThreads), 0, ctx->stream,
+                           sums, counts, refill, refill_row, dim, g.ld,
+                           static_cast<char *>(centers));
+    else
+        hipLaunchKernelGGL(finish_centers_kernel<__half>, grid, dim3(kKmThreads), 0, ctx->stream,
+                           sums, counts, refill, refill_row, dim, g.ld,
+                           static_cast<char *>(centers));
+    PGV_HIP(hipGetLastError());
+    return PGV_OK;
+}
+
+int launch_normalize_rows(pgv_ctx *ctx, pgv_dtype dtype, const RowGeom &g, void *rows, int64_t n,
+                          int dim, int32_t *flag) {
+    if (n <= 0) return PGV_OK;
+    const int per = kKmThreads / kWave;
+    dim3 grid((unsigned)((n + per - 1) / per));
+    if (dtype == PGV_F32)
+        hipLaunchKernelGGL(normalize_rows_kernel<float>, grid, dim3(kKmThreads), 0, ctx->stream,
+                           static_cast<char *>(rows), n, dim, g.ld, flag);
+    else
+        hipLaunchKernelGGL(normalize_rows_kernel<__half>, grid, dim3(kKmThreads), 0, ctx->stream,
+                           static_cast<char *>(rows), n, dim, g.ld, flag);
+    PGV_HIP(hipGetLastError());
+    return PGV_OK;
+}
+
+int launch_check_centers(pgv_ctx *ctx, pgv_dtype dtype, const RowGeom &g, const void *centers,
+                         int k, int dim, int check_zero_norm, int32_t *flag) {
+    const int per = kKmThreads / kWave;
+    dim3 grid((k + per - 1) / per);
+    if (dtype == PGV_F32)
+        hipLaunchKernelGGL(check_centers_kernel<float>, grid, dim3(kKmThreads), 0, ctx->stream,
+                           static_cast<const char *>(centers), k, dim, g.ld, check_zero_norm,
+                           flag);
+    else
+        hipLaunchKernelGGL(check_centers_kernel<__half>, grid, dim3(kKmThreads), 0, ctx->stream,
+                           static_cast<const char *>(centers), k, dim, g.ld, check_zero_norm,
+                           flag);
+    PGV_HIP(hipGetLastError());
+    return PGV_OK;
+}
+
+}  // namespace pgv

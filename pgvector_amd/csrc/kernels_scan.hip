@@ -1,0 +1,331 @@
+// kernels_scan.hip -- HBM-streaming distance kernels for gfx950.
+//
+// scan_kernel: the body of GetScanItems (src/ivfscan.c:157-173), GetScanLists
+// (:69-74) and k-means++'s distance-to-the-newest-center loop
+// (src/ivfkmeans.c:52-71): rows are streamed once from HBM with coalesced
+// 16-byte loads and scored against a small group of queries held in LDS.
+//
+//   * one wavefront (64 lanes) cooperates on rows: `1 << lpr_log2` adjacent
+//     lanes own one row, each lane a 16-byte slice per trip, R independent
+//     rows per lane in flight; partial sums are folded with DPP at the end.
+//   * a workgroup (4 waves) owns a ScanTask = a run of rows of one list x up
+//     to QT queries that probe that list; the rows are read from HBM once
+//     for all QT queries (query batching is where QPS beyond the single-query
+//     roofline comes from).
+//   * workgroups are persistent and pull tasks from a device counter, so
+//     ragged list lengths balance themselves.
+//   * fp32 accumulate in every case, fp16 rows converted exactly
+//     (src/halfutils.c:46-78 does the same with cvtph_ps).
+#include "pgv_device.h"
+
+namespace pgv {
+
+namespace {
+
+constexpr int kScanThreads = 256;
+constexpr int kScanWaves = kScanThreads / kWave;
+
+template <typename T, int METRIC, int QT, int R>
+__global__ __launch_bounds__(kScanThreads) void scan_kernel(
+    const char *__restrict__ rows, const char *__restrict__ queries,
+    const ScanTask *__restrict__ tasks, const int *__restrict__ ntasks_ptr,
+    int *__restrict__ task_counter, const ScanPair *__restrict__ pairs, float *__restrict__ out,
+    int nvec, int lpr_log2, int nchunks) {
+    constexpr int N = VecTraits<T>::N;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    // layout: [QT * nvec] Raw16 query slices | [QT] int64 out_rel | int task id
+    Raw16 *lds_q = reinterpret_cast<Raw16 *>(smem);
+    int64_t *lds_rel = reinterpret_cast<int64_t *>(smem + (size_t)QT * nvec * sizeof(Raw16));
+    int *lds_task = reinterpret_cast<int *>(lds_rel + QT);
+
+    const int lane = threadIdx.x & (kWave - 1);
+    const int wave = threadIdx.x >> 6;
+    const int lpr = 1 << lpr_log2;
+    const int sub = lane & (lpr - 1);  // which slice of the row
+    const int rsub = lane >> lpr_log2; // which row of the wave-load
+    const int rpw = kWave >> lpr_log2; // rows per wave-load
+    const size_t row_bytes = (size_t)nvec * sizeof(Raw16);
+    const int ntasks = *ntasks_ptr;
+
+    for (;;) {
+        if (threadIdx.x == 0) *lds_task = atomicAdd(task_counter, 1);
+        __syncthreads();
+        const int t = *lds_task;
+        if (t >= ntasks) return;
+        const ScanTask task = tasks[t];
+
+        // stage this task's queries (L2-resident) into LDS
+        for (int i = threadIdx.x; i < QT * nvec; i += kScanThreads) {
+            int q = i / nvec, v = i - q * nvec;
+            int qq = q < task.npairs ? q : task.npairs - 1;
+            int qid = pairs[task.pair0 + qq].query;
+            lds_q[i] = load16(queries + (size_t)qid * row_bytes + (size_t)v * sizeof(Raw16));
+        }
+        if (threadIdx.x < QT) {
+            int qq = threadIdx.x < task.npairs ? threadIdx.x : task.npairs - 1;
+            lds_rel[threadIdx.x] = pairs[task.pair0 + qq].out_rel;
+        }
+        __syncthreads();
+
+        const char *task_rows = rows + (size_t)task.row0 * row_bytes;
+        for (int b = wave; b * R * rpw < task.nrows; b += kScanWaves) {
+            float acc[R][QT];
+#pragma unroll
+            for (int r = 0; r < R; r++)
+#pragma unroll
+                for (int q = 0; q < QT; q++) acc[r][q] = 0.f;
+
+            const char *rp[R];
+#pragma unroll
+            for (int r = 0; r < R; r++) {
+                int row = b * R * rpw + r * rpw + rsub;
+                row = row < task.nrows ? row : task.nrows - 1;  // tail rows are computed, not stored
+                rp[r] = task_rows + (size_t)row * row_bytes;
+            }
+
+            for (int c = 0; c < nchunks; c++) {
+                const int vi = c * lpr + sub;
+                const bool ok = vi < nvec;
+                Raw16 rv[R];
+#pragma unroll
+                for (int r = 0; r < R; r++)
+                    rv[r] = ok ? load16(rp[r] + (size_t)vi * sizeof(Raw16)) : raw16_zero();
+                float rf[R][N];
+#pragma unroll
+                for (int r = 0; r < R; r++) {
+                    Unpacked<T> u(rv[r]);
+#pragma unroll
+                    for (int e = 0; e < N; e++) rf[r][e] = u.v[e];
+                }
+#pragma unroll
+                for (int q = 0; q < QT; q++) {
+                    Raw16 qraw = ok ? lds_q[q * nvec + vi] : raw16_zero();
+                    Unpacked<T> uq(qraw);
+#pragma unroll
+                    for (int r = 0; r < R; r++)
+#pragma unroll
+                        for (int e = 0; e < N; e++)
+                            acc[r][q] = accum<METRIC>(acc[r][q], rf[r][e], uq.v[e]);
+                }
+            }
+
+#pragma unroll
+            for (int r = 0; r < R; r++) {
+                const int row = b * R * rpw + r * rpw + rsub;
+#pragma unroll
+                for (int q = 0; q < QT; q++) {
+                    float s = group_sum_to_last(acc[r][q], lpr_log2);
+                    if (sub == lpr - 1 && row < task.nrows && q < task.npairs)
+                        out[lds_rel[q] + task.row0 + row] = finish<METRIC>(s);
+                }
+            }
+        }
+        __syncthreads();  // LDS is rewritten by the next task
+    }
+}
+
+// Gathered scoring (HNSW candidate batches): pair i = (slot[i], query_of[i]).
+// Both operands come from global memory; queries stay L2-resident.
+template <typename T, int METRIC, int R>
+__global__ __launch_bounds__(kScanThreads) void score_gather_kernel(
+    const char *__restrict__ rows, const char *__restrict__ queries,
+    const int32_t *__restrict__ slot, const int32_t *__restrict__ query_of, int64_t npairs,
+    float *__restrict__ out, int nvec, int lpr_log2, int nchunks) {
+    constexpr int N = VecTraits<T>::N;
+    const int lane = threadIdx.x & (kWave - 1);
+    const int wave = threadIdx.x >> 6;
+    const int lpr = 1 << lpr_log2;
+    const int sub = lane & (lpr - 1);
+    const int rsub = lane >> lpr_log2;
+    const int rpw = kWave >> lpr_log2;
+    const size_t row_bytes = (size_t)nvec * sizeof(Raw16);
+
+    const int64_t base = ((int64_t)blockIdx.x * kScanWaves + wave) * R * rpw;
+    if (base >= npairs) return;
+
+    float acc[R];
+    const char *rp[R];
+    const char *qp[R];
+#pragma unroll
+    for (int r = 0; r < R; r++) {
+        int64_t p = base + r * rpw + rsub;
+        p = p < npairs ? p : npairs - 1;
+        acc[r] = 0.f;
+        rp[r] = rows + (size_t)slot[p] * row_bytes;
+        qp[r] = queries + (size_t)(query_of ? query_of[p] : 0) * row_bytes;
+    }
+    for (int c = 0; c < nchunks; c++) {
+        const int vi = c * lpr + sub;
+        const bool ok = vi < nvec;
+        Raw16 rv[R], qv[R];
+#pragma unroll
+        for (int r = 0; r < R; r++) {
+            rv[r] = ok ? load16(rp[r] + (size_t)vi * sizeof(Raw16)) : raw16_zero();
+            qv[r] = ok ? load16(qp[r] + (size_t)vi * sizeof(Raw16)) : raw16_zero();
+        }
+#pragma unroll
+        for (int r = 0; r < R; r++) {
+            Unpacked<T> ur(rv[r]);
+            Unpacked<T> uq(qv[r]);
+#pragma unroll
+            for (int e = 0; e < N; e++) acc[r] = accum<METRIC>(acc[r], ur.v[e], uq.v[e]);
+        }
+    }
+#pragma unroll
+    for (int r = 0; r < R; r++) {
+        const int64_t p = base + r * rpw + rsub;
+        float s = group_sum_to_last(acc[r], lpr_log2);
+        if (sub == lpr - 1 && p < npairs) out[p] = finish<METRIC>(s);
+    }
+}
+
+template <typename T, int METRIC, int QT, int R>
+int launch_scan_t(pgv_ctx *ctx, const RowGeom &g, const void *rows, const void *queries,
+                  const ScanTask *tasks, const int *ntasks_dev, int ntasks_bound,
+                  const ScanPair *pairs, float *out) {
+    if (ntasks_bound <= 0) return PGV_OK;
+    PGV_TRY(ctx->counters.ensure(256));
+    int *counter = ctx->counters.as<int>();
+    PGV_HIP(hipMemsetAsync(counter, 0, sizeof(int), ctx->stream));
+    size_t lds = (size_t)QT * g.nvec * sizeof(Raw16) + QT * sizeof(int64_t) + 16;
+    // enough resident workgroups to cover HBM latency, never more than there is work
+    int per_cu = (int)(160 * 1024 / (lds + 256));
+    if (per_cu > 8) per_cu = 8;
+    if (per_cu < 1) per_cu = 1;
+    int grid = ctx->num_cus * per_cu;
+    if (grid > ntasks_bound) grid = ntasks_bound;
+    auto kern = scan_kernel<T, METRIC, QT, R>;
+    if (lds > 64 * 1024)
+        PGV_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(kScanThreads), lds, ctx->stream,
+                       static_cast<const char *>(rows), static_cast<const char *>(queries), tasks,
+                       ntasks_dev, counter, pairs, out, g.nvec, g.lpr_log2, g.nchunks);
+    PGV_HIP(hipGetLastError());
+    return PGV_OK;
+}
+
+template <typename T, int METRIC>
+int launch_scan_m(pgv_ctx *ctx, const RowGeom &g, const void *rows, const void *queries,
+                  const ScanTask *tasks, const int *ntasks_dev, int ntasks_bound,
+                  const ScanPair *pairs, int qt, float *out) {
+    switch (qt) {
+        case 1:
+            return launch_scan_t<T, METRIC, 1, 8>(ctx, g, rows, queries, tasks, ntasks_dev,
+                                                  ntasks_bound, pairs, out);
+        case 2:
+            return launch_scan_t<T, METRIC, 2, 4>(ctx, g, rows, queries, tasks, ntasks_dev,
+                                                  ntasks_bound, pairs, out);
+        case 4:
+            return launch_scan_t<T, METRIC, 4, 4>(ctx, g, rows, queries, tasks, ntasks_dev,
+                                                  ntasks_bound, pairs, out);
+        case 8:
+            return launch_scan_t<T, METRIC, 8, 4>(ctx, g, rows, queries, tasks, ntasks_dev,
+                                                  ntasks_bound, pairs, out);
+        default:
+            PGV_FAIL(PGV_ERR_ARG, "scan: unsupported query group size %d", qt);
+    }
+}
+
+template <typename T>
+int launch_scan_d(pgv_ctx *ctx, pgv_metric metric, const RowGeom &g, const void *rows,
+                  const void *queries, const ScanTask *tasks, const int *ntasks_dev,
+                  int ntasks_bound, const ScanPair *pairs, int qt, float *out) {
+    switch (metric) {
+        case PGV_L2SQ:
+            return launch_scan_m<T, 0>(ctx, g, rows, queries, tasks, ntasks_dev, ntasks_bound,
+                                       pairs, qt, out);
+        case PGV_NEG_IP:
+            return launch_scan_m<T, 1>(ctx, g, rows, queries, tasks, ntasks_dev, ntasks_bound,
+                                       pairs, qt, out);
+        case PGV_L1:
+            return launch_scan_m<T, 2>(ctx, g, rows, queries, tasks, ntasks_dev, ntasks_bound,
+                                       pairs, qt, out);
+    }
+    PGV_FAIL(PGV_ERR_ARG, "scan: unknown metric %d", (int)metric);
+}
+
+template <typename T, int METRIC>
+int launch_gather_t(pgv_ctx *ctx, const RowGeom &g, const void *rows, const void *queries,
+                    const int32_t *slot, const int32_t *query_of, int64_t npairs, float *out) {
+    constexpr int R = 4;
+    if (npairs <= 0) return PGV_OK;
+    const int rpw = kWave >> g.lpr_log2;
+    const int64_t per_block = (int64_t)kScanWaves * R * rpw;
+    int64_t grid = (npairs + per_block - 1) / per_block;
+    hipLaunchKernelGGL((score_gather_kernel<T, METRIC, R>), dim3((unsigned)grid),
+                       dim3(kScanThreads), 0, ctx->stream, static_cast<const char *>(rows),
+                       static_cast<const char *>(queries), slot, query_of, npairs, out, g.nvec,
+                       g.lpr_log2, g.nchunks);
+    PGV_HIP(hipGetLastError());
+    return PGV_OK;
+}
+
+}  // namespace
+
+// Lanes per row: the power of two that wastes the fewest lane-trips.
+RowGeom row_geom(int dim, pgv_dtype t) {
+    RowGeom g;
+    g.ld = padded_dim(dim, t);
+    g.nvec = g.ld * elem_size(t) / kVecBytes;
+    int best_lg = 6;
+    long best_cost = -1;
+    for (int lg = 6; lg >= 0; lg--) {
+        int lpr = 1 << lg;
+        int trips = (g.nvec + lpr - 1) / lpr;
+        long waste = (long)trips * lpr - g.nvec;
+        // wasted lane-trips per row, then prefer wider groups (more bytes per instruction)
+        long cost = waste * 64 / lpr;
+        if (trips > 64) continue;  // keep the trip count bounded for huge rows
+        if (best_cost < 0 || cost < best_cost) {
+            best_cost = cost;
+            best_lg = lg;
+        }
+    }
+    g.lpr_log2 = best_lg;
+    int lpr = 1 << best_lg;
+    g.nchunks = (g.nvec + lpr - 1) / lpr;
+    return g;
+}
+
+// Queries per task: as many as fit 64 KB of LDS (up to 8), never more than wanted.
+int scan_group_size(const RowGeom &g, pgv_dtype, int wanted) {
+    int qt = 8;
+    while (qt > 1 && (size_t)qt * g.nvec * sizeof(Raw16) > 64 * 1024 - 256) qt >>= 1;
+    while (qt > 1 && qt / 2 >= wanted) qt >>= 1;
+    return qt;
+}
+
+int launch_scan(pgv_ctx *ctx, pgv_metric metric, pgv_dtype dtype, const RowGeom &g,
+                const void *rows, const void *queries, const ScanTask *tasks,
+                const int *ntasks_dev, int ntasks_bound, const ScanPair *pairs, int qt,
+                float *out) {
+    if (dtype == PGV_F32)
+        return launch_scan_d<float>(ctx, metric, g, rows, queries, tasks, ntasks_dev,
+                                    ntasks_bound, pairs, qt, out);
+    return launch_scan_d<__half>(ctx, metric, g, rows, queries, tasks, ntasks_dev, ntasks_bound,
+                                 pairs, qt, out);
+}
+
+int launch_score_gather(pgv_ctx *ctx, pgv_metric metric, pgv_dtype dtype, const RowGeom &g,
+                        const void *rows, const void *queries, const int32_t *slot,
+                        const int32_t *query_of, int64_t npairs, float *out) {
+#define PGV_GATHER(T)                                                                         \
+    switch (metric) {                                                                         \
+        case PGV_L2SQ:                                                                        \
+            return launch_gather_t<T, 0>(ctx, g, rows, queries, slot, query_of, npairs, out); \
+        case PGV_NEG_IP:                                                                      \
+            return launch_gather_t<T, 1>(ctx, g, rows, queries, slot, query_of, npairs, out); \
+        case PGV_L1:                                                                          \
+            return launch_gather_t<T, 2>(ctx, g, rows, queries, slot, query_of, npairs, out); \
+    }
+    if (dtype == PGV_F32) {
+        PGV_GATHER(float)
+    } else {
+        PGV_GATHER(__half)
+    }
+#undef PGV_GATHER
+    PGV_FAIL(PGV_ERR_ARG, "score: unknown metric %d", (int)metric);
+}
+
+}  // namespace pgv

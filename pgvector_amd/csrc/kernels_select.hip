@@ -1,0 +1,440 @@
+// kernels_select.hip -- the bookkeeping either side of the streaming kernel:
+//   * plan_*: turn "query q probes lists L[q][0..P)" (the output of GetScanLists,
+//     src/ivfscan.c:114-115) into list-major work: for every list the queries
+//     that probe it, cut into ScanTasks, plus where each (query, list) run of
+//     distances lands in the query's output segment -- the order the reference
+//     feeds its tuplesort (src/ivfscan.c:134-179).
+//   * topk_kernel: the head of the ascending tuplesort stream
+//     (src/ivfscan.c:182, :238-247) / the bounded heap of GetScanLists
+//     (:76-106): k smallest of a segment by (value, position), exact and
+//     deterministic (radix select on order-preserving keys, then a bitonic sort
+//     of the k survivors).
+#include "pgv_device.h"
+
+namespace pgv {
+
+namespace {
+
+// ---------------------------------------------------------------- planning
+
+__global__ void plan_count_kernel(const int32_t *__restrict__ probe_lists,
+                                  const int64_t *__restrict__ list_off, int nq, int probes,
+                                  int *__restrict__ cnt, int64_t *__restrict__ probe_off,
+                                  int64_t *__restrict__ seg_len) {
+    const int q = blockIdx.x * blockDim.x + threadIdx.x;
+    if (q >= nq) return;
+    int64_t run = 0;
+    for (int p = 0; p < probes; p++) {
+        const int l = probe_lists[(size_t)q * probes + p];
+        probe_off[(size_t)q * probes + p] = run;
+        run += list_off[l + 1] - list_off[l];
+        atomicAdd(&cnt[l], 1);
+    }
+    seg_len[q] = run;
+}
+
+// single-block exclusive scan of an int64 sequence produced on the fly
+template <typename F>
+__device__ void block_exclusive_scan(int n, F value, int64_t *out, int64_t *scratch /*[blockDim]*/) {
+    __shared__ int64_t carry;
+    if (threadIdx.x == 0) carry = 0;
+    __syncthreads();
+    for (int base = 0; base < n; base += blockDim.x) {
+        const int i = base + threadIdx.x;
+        const int64_t v = i < n ? value(i) : 0;
+        scratch[threadIdx.x] = v;
+        __syncthreads();
+        for (int s = 1; s < (int)blockDim.x; s <<= 1) {
+            int64_t t = threadIdx.x >= (unsigned)s ? scratch[threadIdx.x - s] : 0;
+            __syncthreads();
+            scratch[threadIdx.x] += t;
+            __syncthreads();
+        }
+        if (i < n) out[i] = carry + scratch[threadIdx.x] - v;
+        __syncthreads();
+        if (threadIdx.x == blockDim.x - 1) carry += scratch[threadIdx.x];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) out[n] = carry;
+    __syncthreads();
+}
+
+__global__ __launch_bounds__(1024) void plan_scan_kernel(
+    const int *__restrict__ cnt, const int64_t *__restrict__ list_off,
+    const int64_t *__restrict__ seg_len, int nq, int nlists, int qt, int rows_per_task,
+    int64_t *__restrict__ seg_start, int64_t *__restrict__ pair_start,
+    int64_t *__restrict__ task_start, int64_t *__restrict__ totals /*[2]: out elems, tasks*/) {
+    __shared__ int64_t scratch[1024];
+    block_exclusive_scan(nq, [&](int i) { return seg_len[i]; }, seg_start, scratch);
+    block_exclusive_scan(nlists, [&](int i) { return (int64_t)cnt[i]; }, pair_start, scratch);
+    block_exclusive_scan(
+        nlists,
+        [&](int i) {
+            const int64_t len = list_off[i + 1] - list_off[i];
+            const int64_t ng = (cnt[i] + qt - 1) / qt;
+            const int64_t nc = (len + rows_per_task - 1) / rows_per_task;
+            return ng * nc;
+        },
+        task_start, scratch);
+    if (threadIdx.x == 0) {
+        totals[0] = seg_start[nq];
+        totals[1] = task_start[nlists];
+    }
+}
+
+__global__ void plan_pairs_kernel(const int32_t *__restrict__ probe_lists,
+                                  const int64_t *__restrict__ list_off,
+                                  const int64_t *__restrict__ probe_off,
+                                  const int64_t *__restrict__ seg_start,
+                                  const int64_t *__restrict__ pair_start, int *__restrict__ fill,
+                                  int nq, int probes, ScanPair *__restrict__ pairs) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (int64_t)nq * probes) return;
+    const int q = (int)(i / probes);
+    const int l = probe_lists[i];
+    const int64_t pos = pair_start[l] + atomicAdd(&fill[l], 1);
+    ScanPair pr;
+    pr.out_rel = seg_start[q] + probe_off[i] - list_off[l];
+    pr.query = q;
+    pr.pad = 0;
+    pairs[pos] = pr;
+}
+
+__global__ void plan_tasks_kernel(const int *__restrict__ cnt, const int64_t *__restrict__ list_off,
+                                  const int64_t *__restrict__ pair_start,
+                                  const int64_t *__restrict__ task_start, int nlists, int qt,
+                                  int rows_per_task, ScanTask *__restrict__ tasks) {
+    const int l = blockIdx.x * blockDim.x + threadIdx.x;
+    if (l >= nlists) return;
+    const int64_t len = list_off[l + 1] - list_off[l];
+    const int ng = (cnt[l] + qt - 1) / qt;
+    const int nc = (int)((len + rows_per_task - 1) / rows_per_task);
+    int64_t t = task_start[l];
+    // chunk-major: tasks that stream the same rows sit next to each other in the queue
+    for (int c = 0; c < nc; c++)
+        for (int g = 0; g < ng; g++) {
+            ScanTask task;
+            task.row0 = list_off[l] + (int64_t)c * rows_per_task;
+            const int64_t left = len - (int64_t)c * rows_per_task;
+            task.nrows = (int)(left < rows_per_task ? left : rows_per_task);
+            task.pair0 = (int)(pair_start[l] + (int64_t)g * qt);
+            const int pl = cnt[l] - g * qt;
+            task.npairs = pl < qt ? pl : qt;
+            task.pad = 0;
+            tasks[t++] = task;
+        }
+}
+
+// ------------------------------------------------------------------- top-k
+
+constexpr int kSelThreads = 256;
+constexpr int kBins = 2048;
+
+struct SelShared {
+    unsigned hist[kBins];
+    unsigned wave_tot[kSelThreads / kWave];
+    unsigned count;      // entries collected so far
+    unsigned bin;        // selected bin of the current pass
+    unsigned remaining;  // how many of the selected bin are still needed
+    unsigned running;    // ordered pass: equal keys seen so far
+};
+
+// find the bin holding the `want`-th (0-based) smallest element; returns the
+// bin and rewrites `want` relative to that bin
+__device__ void pick_bin(SelShared *s, int nbins, unsigned want) {
+    // each thread owns nbins/kSelThreads consecutive bins
+    const int per = nbins / kSelThreads;
+    unsigned local = 0;
+    for (int j = 0; j < per; j++) local += s->hist[threadIdx.x * per + j];
+    __shared__ unsigned scan[kSelThreads];
+    scan[threadIdx.x] = local;
+    __syncthreads();
+    for (int st = 1; st < kSelThreads; st <<= 1) {
+        unsigned t = threadIdx.x >= (unsigned)st ? scan[threadIdx.x - st] : 0;
+        __syncthreads();
+        scan[threadIdx.x] += t;
+        __syncthreads();
+    }
+    const unsigned before = scan[threadIdx.x] - local;
+    if (want >= before && want < before + local) {
+        unsigned acc = before;
+        for (int j = 0; j < per; j++) {
+            const unsigned h = s->hist[threadIdx.x * per + j];
+            if (want < acc + h) {
+                s->bin = threadIdx.x * per + j;
+                s->remaining = want - acc;  // rank inside the bin
+                break;
+            }
+            acc += h;
+        }
+    }
+    __syncthreads();
+}
+
+__device__ void sort_entries(unsigned long long *ent, int kp) {
+    for (int size = 2; size <= kp; size <<= 1)
+        for (int stride = size >> 1; stride > 0; stride >>= 1) {
+            for (int i = threadIdx.x; i < kp / 2; i += kSelThreads) {
+                const int lo = 2 * i - (i & (stride - 1));
+                const int hi = lo + stride;
+                const bool up = (lo & size) == 0;
+                const unsigned long long a = ent[lo], b = ent[hi];
+                if ((a > b) == up) {
+                    ent[lo] = b;
+                    ent[hi] = a;
+                }
+            }
+            __syncthreads();
+        }
+}
+
+__global__ __launch_bounds__(kSelThreads) void topk_kernel(
+    const float *__restrict__ vals, const int64_t *__restrict__ seg_start, int64_t fixed_len,
+    int k, int kp, float *__restrict__ out_val, int64_t *__restrict__ out_pos) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    unsigned long long *ent = reinterpret_cast<unsigned long long *>(smem);  // [kp]
+    SelShared *s = reinterpret_cast<SelShared *>(smem + (size_t)kp * 8);
+
+    const int seg = blockIdx.x;
+    const int64_t base = seg_start ? seg_start[seg] : (int64_t)seg * fixed_len;
+    const int64_t m = seg_start ? seg_start[seg + 1] - base : fixed_len;
+    const float *v = vals + base;
+
+    for (int i = threadIdx.x; i < kp; i += kSelThreads) ent[i] = ~0ull;
+    if (threadIdx.x == 0) s->count = 0;
+    __syncthreads();
+
+    if (m <= k) {
+        for (int64_t i = threadIdx.x; i < m; i += kSelThreads)
+            ent[i] = ((unsigned long long)float_to_key(v[i]) << 32) | (unsigned)i;
+        __syncthreads();
+    } else {
+        // three radix passes (11 + 11 + 10 bits) pin down the k-th smallest key exactly
+        unsigned prefix = 0;
+        unsigned want = (unsigned)(k - 1);
+        unsigned count_eq = 0;
+        for (int pass = 0; pass < 3; pass++) {
+            const int shift = pass == 0 ? 21 : (pass == 1 ? 10 : 0);
+            const int nbins = pass == 2 ? 1024 : 2048;
+            for (int i = threadIdx.x; i < kBins; i += kSelThreads) s->hist[i] = 0;
+            __syncthreads();
+            for (int64_t i = threadIdx.x; i < m; i += kSelThreads) {
+                const unsigned key = float_to_key(v[i]);
+                const bool in = pass == 0 || (pass == 1 ? (key >> 21) == (prefix >> 21)
+                                                        : (key >> 10) == (prefix >> 10));
+                if (in) atomicAdd(&s->hist[(key >> shift) & (nbins - 1)], 1u);
+            }
+            __syncthreads();
+            pick_bin(s, nbins, want);
+            prefix |= s->bin << shift;
+            want = s->remaining;
+            count_eq = s->hist[s->bin];
+            __syncthreads();
+        }
+        const unsigned thr = prefix;      // the k-th smallest key
+        const unsigned need_eq = want + 1; // how many keys == thr belong to the top k
+        if (threadIdx.x == 0) s->running = 0;
+        __syncthreads();
+        const bool ordered = count_eq > need_eq;  // ties on the boundary: lowest positions win
+        const int64_t padded = (m + kSelThreads - 1) / kSelThreads * kSelThreads;
+        for (int64_t i = threadIdx.x; i < padded; i += kSelThreads) {
+            const unsigned key = i < m ? float_to_key(v[i]) : 0xffffffffu;
+            const bool valid = i < m;
+            if (valid && key < thr) {
+                const unsigned at = atomicAdd(&s->count, 1u);
+                ent[at] = ((unsigned long long)key << 32) | (unsigned)i;
+            }
+            if (!ordered) {
+                if (valid && key == thr) {
+                    const unsigned at = atomicAdd(&s->count, 1u);
+                    ent[at] = ((unsigned long long)key << 32) | (unsigned)i;
+                }
+            } else {
+                // position-ordered rank among equal keys (block-wide, tile by tile)
+                const bool eq = valid && key == thr;
+                const unsigned long long bal = __ballot(eq);
+                const int lane = threadIdx.x & (kWave - 1), wave = threadIdx.x >> 6;
+                const unsigned before_lane = __popcll(bal & ((1ull << lane) - 1ull));
+                if (lane == 0) s->wave_tot[wave] = (unsigned)__popcll(bal);
+                __syncthreads();
+                unsigned before_wave = 0, tile_tot = 0;
+                for (int w = 0; w < kSelThreads / kWave; w++) {
+                    if (w < wave) before_wave += s->wave_tot[w];
+                    tile_tot += s->wave_tot[w];
+                }
+                const unsigned rank = s->running + before_wave + before_lane;
+                if (eq && rank < need_eq) {
+                    const unsigned at = atomicAdd(&s->count, 1u);
+                    ent[at] = ((unsigned long long)key << 32) | (unsigned)i;
+                }
+                __syncthreads();
+                if (threadIdx.x == 0) s->running += tile_tot;
+                __syncthreads();
+            }
+        }
+        __syncthreads();
+    }
+
+    sort_entries(ent, kp);
+
+    for (int i = threadIdx.x; i < k; i += kSelThreads) {
+        const unsigned long long e = ent[i];
+        const bool have = e != ~0ull && (int64_t)i < (m < k ? m : (int64_t)k);
+        out_val[(size_t)seg * k + i] = have ? key_to_float((unsigned)(e >> 32)) : INFINITY;
+        out_pos[(size_t)seg * k + i] = have ? (int64_t)(unsigned)(e & 0xffffffffu) : -1;
+    }
+}
+
+// position inside a query's segment -> row slot (and heap TID)
+__global__ void positions_to_slots_kernel(const int32_t *__restrict__ probe_lists,
+                                          const int64_t *__restrict__ probe_off,
+                                          const int64_t *__restrict__ list_off,
+                                          const uint64_t *__restrict__ tids, int nq, int probes,
+                                          int k, const int64_t *__restrict__ pos,
+                                          int64_t *__restrict__ out_slot,
+                                          uint64_t *__restrict__ out_tid) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (int64_t)nq * k) return;
+    const int q = (int)(i / k);
+    const int64_t p = pos[i];
+    int64_t slot = -1;
+    if (p >= 0) {
+        const int64_t *off = probe_off + (size_t)q * probes;
+        int lo = 0, hi = probes - 1;  // last probe whose offset <= p
+        while (lo < hi) {
+            const int mid = (lo + hi + 1) >> 1;
+            if (off[mid] <= p)
+                lo = mid;
+            else
+                hi = mid - 1;
+        }
+        const int l = probe_lists[(size_t)q * probes + lo];
+        slot = list_off[l] + (p - off[lo]);
+    }
+    if (out_slot) out_slot[i] = slot;
+    if (out_tid) out_tid[i] = (slot >= 0 && tids) ? tids[slot] : ~0ull;
+}
+
+__global__ void iota_slots_kernel(const int32_t *__restrict__ lists,
+                                  const int64_t *__restrict__ probe_off,
+                                  const int64_t *__restrict__ list_off,
+                                  int64_t *__restrict__ out_slot) {
+    const int p = blockIdx.x;
+    const int l = lists[p];
+    const int64_t beg = list_off[l], len = list_off[l + 1] - beg;
+    for (int64_t i = threadIdx.x; i < len; i += blockDim.x) out_slot[probe_off[p] + i] = beg + i;
+}
+
+__global__ void cast_pos_kernel(const int64_t *__restrict__ pos, int64_t n,
+                                int32_t *__restrict__ out) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) out[i] = (int32_t)pos[i];
+}
+
+}  // namespace
+
+int launch_cast_pos_to_i32(pgv_ctx *ctx, const int64_t *pos, int64_t n, int32_t *out) {
+    if (n <= 0) return PGV_OK;
+    hipLaunchKernelGGL(cast_pos_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0,
+                       ctx->stream, pos, n, out);
+    PGV_HIP(hipGetLastError());
+    return PGV_OK;
+}
+
+int launch_plan_batch(pgv_ctx *ctx, const pgv_index *ix, const int32_t *probe_lists, int nq,
+                      int probes, int qt, int rows_per_task, PlanResult *res) {
+    const int nlists = ix->nlists;
+    const size_t npairs = (size_t)nq * probes;
+    // plan_a: cnt[nlists] | fill[nlists]   (ints, zeroed every call)
+    PGV_TRY(ctx->plan_a.ensure(sizeof(int) * 2 * (size_t)nlists));
+    // plan_b: probe_off[nq*probes] | seg_len[nq] | seg_start[nq+1] | pair_start[nlists+1]
+    //         | task_start[nlists+1] | totals[2]
+    const size_t nb = npairs + (size_t)nq + (size_t)nq + 1 + 2 * ((size_t)nlists + 1) + 2;
+    PGV_TRY(ctx->plan_b.ensure(sizeof(int64_t) * nb));
+    PGV_TRY(ctx->pairs.ensure(sizeof(ScanPair) * npairs));
+    int *cnt = ctx->plan_a.as<int>();
+    int *fill = cnt + nlists;
+    int64_t *probe_off = ctx->plan_b.as<int64_t>();
+    int64_t *seg_len = probe_off + npairs;
+    int64_t *seg_start = seg_len + nq;
+    int64_t *pair_start = seg_start + nq + 1;
+    int64_t *task_start = pair_start + nlists + 1;
+    int64_t *totals = task_start + nlists + 1;
+
+    PGV_HIP(hipMemsetAsync(cnt, 0, sizeof(int) * 2 * (size_t)nlists, ctx->stream));
+    hipLaunchKernelGGL(plan_count_kernel, dim3((nq + 255) / 256), dim3(256), 0, ctx->stream,
+                       probe_lists, ix->list_offsets, nq, probes, cnt, probe_off, seg_len);
+    hipLaunchKernelGGL(plan_scan_kernel, dim3(1), dim3(1024), 0, ctx->stream, cnt,
+                       ix->list_offsets, seg_len, nq, nlists, qt, rows_per_task, seg_start,
+                       pair_start, task_start, totals);
+    hipLaunchKernelGGL(plan_pairs_kernel, dim3((unsigned)((npairs + 255) / 256)), dim3(256), 0,
+                       ctx->stream, probe_lists, ix->list_offsets, probe_off, seg_start,
+                       pair_start, fill, nq, probes, ctx->pairs.as<ScanPair>());
+    PGV_HIP(hipGetLastError());
+
+    // the two totals size the task queue and the output: one small readback
+    PGV_TRY(ctx->h_c.ensure(64));
+    int64_t *h_tot = ctx->h_c.as<int64_t>();
+    PGV_HIP(hipMemcpyAsync(h_tot, totals, 2 * sizeof(int64_t), hipMemcpyDeviceToHost, ctx->stream));
+    PGV_HIP(hipStreamSynchronize(ctx->stream));
+    res->total_out = h_tot[0];
+    res->ntasks = h_tot[1];
+    if (res->ntasks > 0x7fffffff) PGV_FAIL(PGV_ERR_ARG, "plan: too many tasks");
+
+    PGV_TRY(ctx->tasks.ensure(sizeof(ScanTask) * (size_t)(res->ntasks > 0 ? res->ntasks : 1) + 16));
+    ScanTask *tasks = ctx->tasks.as<ScanTask>();
+    hipLaunchKernelGGL(plan_tasks_kernel, dim3((nlists + 255) / 256), dim3(256), 0, ctx->stream,
+                       cnt, ix->list_offsets, pair_start, task_start, nlists, qt, rows_per_task,
+                       tasks);
+    PGV_HIP(hipGetLastError());
+    // device copy of the task count (an int the scan kernel reads)
+    PGV_TRY(ctx->plan_c.ensure(64));
+    int *ntasks_dev = ctx->plan_c.as<int>();
+    int *h_n = reinterpret_cast<int *>(h_tot + 4);
+    *h_n = (int)res->ntasks;
+    PGV_HIP(hipMemcpyAsync(ntasks_dev, h_n, sizeof(int), hipMemcpyHostToDevice, ctx->stream));
+
+    res->tasks = tasks;
+    res->pairs = ctx->pairs.as<ScanPair>();
+    res->ntasks_dev = ntasks_dev;
+    res->seg_start = seg_start;
+    res->probe_off = probe_off;
+    return PGV_OK;
+}
+
+int launch_topk_segments(pgv_ctx *ctx, const float *vals, const int64_t *seg_start, int nseg,
+                         int64_t fixed_len, int k, float *out_val, int64_t *out_pos) {
+    if (nseg <= 0 || k <= 0) return PGV_OK;
+    if (k > 4096) PGV_FAIL(PGV_ERR_ARG, "top-k: k = %d exceeds the supported 4096", k);
+    int kp = 1;
+    while (kp < k) kp <<= 1;
+    if (kp < 2) kp = 2;
+    const size_t lds = (size_t)kp * 8 + sizeof(SelShared);
+    hipLaunchKernelGGL(topk_kernel, dim3(nseg), dim3(kSelThreads), lds, ctx->stream, vals,
+                       seg_start, fixed_len, k, kp, out_val, out_pos);
+    PGV_HIP(hipGetLastError());
+    return PGV_OK;
+}
+
+int launch_positions_to_slots(pgv_ctx *ctx, const pgv_index *ix, const int32_t *probe_lists,
+                              const int64_t *probe_off, int nq, int probes, int k,
+                              const int64_t *pos, int64_t *out_slot, uint64_t *out_tid) {
+    const int64_t total = (int64_t)nq * k;
+    if (total <= 0) return PGV_OK;
+    hipLaunchKernelGGL(positions_to_slots_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256),
+                       0, ctx->stream, probe_lists, probe_off, ix->list_offsets, ix->tids, nq,
+                       probes, k, pos, out_slot, out_tid);
+    PGV_HIP(hipGetLastError());
+    return PGV_OK;
+}
+
+int launch_iota_slots(pgv_ctx *ctx, const pgv_index *ix, const int32_t *lists_dev, int nlists,
+                      const int64_t *probe_off, int64_t *out_slot) {
+    if (nlists <= 0) return PGV_OK;
+    hipLaunchKernelGGL(iota_slots_kernel, dim3(nlists), dim3(256), 0, ctx->stream, lists_dev,
+                       probe_off, ix->list_offsets, out_slot);
+    PGV_HIP(hipGetLastError());
+    return PGV_OK;
+}
+
+}  // namespace pgv

@@ -1,0 +1,1211 @@
+// pgv_abi.hip -- extern "C" entry points of libpgv_hip (include/pgv_hip.h):
+// argument checking, host<->device staging, work planning and kernel launches.
+// There is no CPU fallback anywhere in this file: without a GPU every entry
+// point reports PGV_ERR_DEVICE.
+#include "pgv_internal.h"
+
+#include <cmath>
+#include <cstdarg>
+#include <new>
+
+using namespace pgv;
+
+// ===================================================================== utils
+namespace pgv {
+
+static thread_local char g_err[512] = "";
+
+void set_error(const char *fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+}
+
+int DBuf::ensure(size_t bytes) {
+    if (bytes <= cap && p) return PGV_OK;
+    if (p) {
+        (void)hipFree(p);
+        p = nullptr;
+        cap = 0;
+    }
+    size_t want = bytes < 256 ? 256 : bytes;
+    want += want / 4;  // headroom so slowly growing requests do not reallocate every call
+    hipError_t e = hipMalloc(&p, want);
+    if (e != hipSuccess) {
+        p = nullptr;
+        (void)hipGetLastError();
+        set_error("hipMalloc(%zu) failed: %s", want, hipGetErrorString(e));
+        return PGV_ERR_NOMEM;
+    }
+    cap = want;
+    return PGV_OK;
+}
+void DBuf::release() {
+    if (p) (void)hipFree(p);
+    p = nullptr;
+    cap = 0;
+}
+int HBuf::ensure(size_t bytes) {
+    if (bytes <= cap && p) return PGV_OK;
+    if (p) {
+        (void)hipHostFree(p);
+        p = nullptr;
+        cap = 0;
+    }
+    size_t want = bytes < 256 ? 256 : bytes;
+    want += want / 4;
+    hipError_t e = hipHostMalloc(&p, want, hipHostMallocDefault);
+    if (e != hipSuccess) {
+        p = nullptr;
+        (void)hipGetLastError();
+        set_error("hipHostMalloc(%zu) failed: %s", want, hipGetErrorString(e));
+        return PGV_ERR_NOMEM;
+    }
+    cap = want;
+    return PGV_OK;
+}
+void HBuf::release() {
+    if (p) (void)hipHostFree(p);
+    p = nullptr;
+    cap = 0;
+}
+
+bool is_device_ptr(const void *p) {
+    if (!p) return false;
+    hipPointerAttribute_t a;
+    hipError_t e = hipPointerGetAttributes(&a, p);
+    if (e != hipSuccess) {
+        (void)hipGetLastError();  // plain malloc'ed memory: not known to the runtime
+        return false;
+    }
+    return a.type == hipMemoryTypeDevice || a.type == hipMemoryTypeManaged;
+}
+
+}  // namespace pgv
+
+namespace {
+
+int check_common(pgv_dtype dtype, int dim) {
+    if (dtype != PGV_F32 && dtype != PGV_F16) PGV_FAIL(PGV_ERR_ARG, "unknown dtype %d", (int)dtype);
+    // VECTOR_MAX_DIM / HALFVEC_MAX_DIM (src/vector.h:10, src/halfvec.h:61)
+    if (dim < 1 || dim > 16000) PGV_FAIL(PGV_ERR_DIMS, "dimensions %d outside 1..16000", dim);
+    return PGV_OK;
+}
+
+int check_metric(pgv_metric m) {
+    if (m != PGV_L2SQ && m != PGV_NEG_IP && m != PGV_L1) PGV_FAIL(PGV_ERR_ARG, "unknown metric %d", (int)m);
+    return PGV_OK;
+}
+
+// rows [n x dim] tightly packed (host or device) -> device rows [n x ld], zero padded.
+// When the source already lives on the device with ld == dim it is used in place.
+int stage_rows(pgv_ctx *ctx, const void *src, int64_t n, int dim, pgv_dtype dtype,
+               const RowGeom &g, DBuf &scratch, const void **out) {
+    const size_t es = elem_size(dtype);
+    const bool dev = is_device_ptr(src);
+    if (dev && g.ld == dim) {
+        *out = src;
+        return PGV_OK;
+    }
+    const size_t bytes = (size_t)n * g.ld * es;
+    PGV_TRY(scratch.ensure(bytes ? bytes : 16));
+    if (n == 0) {
+        *out = scratch.p;
+        return PGV_OK;
+    }
+    if (g.ld == dim) {
+        PGV_HIP(hipMemcpyAsync(scratch.p, src, bytes, hipMemcpyHostToDevice, ctx->stream));
+    } else {
+        PGV_HIP(hipMemsetAsync(scratch.p, 0, bytes, ctx->stream));
+        PGV_HIP(hipMemcpy2DAsync(scratch.p, (size_t)g.ld * es, src, (size_t)dim * es,
+                                 (size_t)dim * es, (size_t)n,
+                                 dev ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice,
+                                 ctx->stream));
+    }
+    if (!dev) PGV_HIP(hipStreamSynchronize(ctx->stream));  // the caller may reuse src right away
+    *out = scratch.p;
+    return PGV_OK;
+}
+
+// device rows [n x ld] -> caller rows [n x dim] (host or device)
+int unstage_rows(pgv_ctx *ctx, const void *src_dev, int64_t n, int dim, pgv_dtype dtype,
+                 const RowGeom &g, void *dst) {
+    const size_t es = elem_size(dtype);
+    if (n == 0) return PGV_OK;
+    const bool dev = is_device_ptr(dst);
+    PGV_HIP(hipMemcpy2DAsync(dst, (size_t)dim * es, src_dev, (size_t)g.ld * es, (size_t)dim * es,
+                             (size_t)n, dev ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost,
+                             ctx->stream));
+    if (!dev) PGV_HIP(hipStreamSynchronize(ctx->stream));
+    return PGV_OK;
+}
+
+// flat array host-or-device -> device
+int stage_flat(pgv_ctx *ctx, const void *src, size_t bytes, DBuf &scratch, const void **out) {
+    if (is_device_ptr(src)) {
+        *out = src;
+        return PGV_OK;
+    }
+    PGV_TRY(scratch.ensure(bytes ? bytes : 16));
+    if (bytes) {
+        PGV_HIP(hipMemcpyAsync(scratch.p, src, bytes, hipMemcpyHostToDevice, ctx->stream));
+        PGV_HIP(hipStreamSynchronize(ctx->stream));
+    }
+    *out = scratch.p;
+    return PGV_OK;
+}
+
+// An output the caller gave us: computed straight into it when it is device
+// memory, otherwise into scratch and copied back by finish().
+struct OutArg {
+    void *user = nullptr;
+    void *dev = nullptr;
+    size_t bytes = 0;
+    bool direct = false;
+    int init(void *user_ptr, size_t nbytes, DBuf &scratch) {
+        user = user_ptr;
+        bytes = nbytes;
+        if (!user_ptr) {
+            dev = nullptr;
+            return PGV_OK;
+        }
+        if (is_device_ptr(user_ptr)) {
+            direct = true;
+            dev = user_ptr;
+            return PGV_OK;
+        }
+        PGV_TRY(scratch.ensure(nbytes ? nbytes : 16));
+        dev = scratch.p;
+        return PGV_OK;
+    }
+    template <typename T> T *as() const { return static_cast<T *>(dev); }
+    // returns true via *need_sync when a device->host copy was enqueued
+    int finish(pgv_ctx *ctx, bool *need_sync) const {
+        if (user && !direct && bytes) {
+            PGV_HIP(hipMemcpyAsync(user, dev, bytes, hipMemcpyDeviceToHost, ctx->stream));
+            *need_sync = true;
+        }
+        return PGV_OK;
+    }
+};
+
+int sync_if(pgv_ctx *ctx, bool need) {
+    if (need) PGV_HIP(hipStreamSynchronize(ctx->stream));
+    return PGV_OK;
+}
+
+// ------------------------------------------------------------ profiling hooks
+struct ScanTimer {
+    pgv_ctx *ctx;
+    size_t slot = (size_t)-1;
+    int begin(double pairs, double rows, bool aux = false) {
+        if (!ctx->profiling) return PGV_OK;
+        if (ctx->ev_used + 2 > ctx->ev_pool.size()) {
+            for (int i = 0; i < 2; i++) {
+                hipEvent_t e;
+                PGV_HIP(hipEventCreate(&e));
+                ctx->ev_pool.push_back(e);
+            }
+        }
+        slot = ctx->ev_used;
+        ctx->ev_used += 2;
+        if (ctx->ev_is_aux.size() < ctx->ev_used / 2) ctx->ev_is_aux.resize(ctx->ev_used / 2);
+        ctx->ev_is_aux[slot / 2] = aux ? 1 : 0;
+        if (aux) {
+            ctx->aux_launches += 1;
+            ctx->aux_pairs += pairs;
+        } else {
+            ctx->scan_launches += 1;
+            ctx->scan_pairs += pairs;
+            ctx->scan_rows += rows;
+        }
+        PGV_HIP(hipEventRecord(ctx->ev_pool[slot], ctx->stream));
+        return PGV_OK;
+    }
+    int end() {
+        if (slot == (size_t)-1) return PGV_OK;
+        PGV_HIP(hipEventRecord(ctx->ev_pool[slot + 1], ctx->stream));
+        return PGV_OK;
+    }
+};
+
+int resolve_events(pgv_ctx *ctx) {
+    if (ctx->ev_used == 0) return PGV_OK;
+    PGV_HIP(hipStreamSynchronize(ctx->stream));
+    for (size_t i = 0; i + 1 < ctx->ev_used; i += 2) {
+        float ms = 0.f;
+        PGV_HIP(hipEventElapsedTime(&ms, ctx->ev_pool[i], ctx->ev_pool[i + 1]));
+        if (ctx->ev_is_aux[i / 2])
+            ctx->aux_ms += ms;
+        else
+            ctx->scan_ms += ms;
+    }
+    ctx->ev_used = 0;
+    return PGV_OK;
+}
+
+// --------------------------------------------------- dense scan (host-planned)
+// rows [0, nrows) x queries [0, nq): out[q * out_stride + r].  Used for center
+// ranking, exact scans and k-means++ rounds; tasks are planned on the host since
+// their shape depends only on sizes.
+int rows_per_task_for(pgv_ctx *ctx, int64_t total_rows, int64_t groups) {
+    // aim at >= 8 tasks per CU, 32..256 rows each
+    int64_t want_tasks = (int64_t)ctx->num_cus * 8;
+    int64_t ch = (total_rows * groups + want_tasks - 1) / want_tasks;
+    ch = (ch + 31) / 32 * 32;
+    if (ch < 32) ch = 32;
+    if (ch > 256) ch = 256;
+    return (int)ch;
+}
+
+int dense_scan(pgv_ctx *ctx, pgv_metric metric, pgv_dtype dtype, const RowGeom &g,
+               const void *rows_dev, int64_t nrows, const void *queries_dev, int nq,
+               int64_t out_stride, float *out_dev) {
+    if (nrows <= 0 || nq <= 0) return PGV_OK;
+    const int qt = scan_group_size(g, dtype, nq);
+    const int ngroups = (nq + qt - 1) / qt;
+    const int ch = rows_per_task_for(ctx, nrows, ngroups);
+    const int64_t nchunks = (nrows + ch - 1) / ch;
+    const int64_t ntasks = nchunks * ngroups;
+    if (ntasks > 0x7fffffff) PGV_FAIL(PGV_ERR_ARG, "scan: too many tasks");
+
+    const size_t tb = sizeof(ScanTask) * (size_t)ntasks, pb = sizeof(ScanPair) * (size_t)nq;
+    PGV_TRY(ctx->h_a.ensure(tb + pb + 16));
+    ScanTask *ht = ctx->h_a.as<ScanTask>();
+    ScanPair *hp = reinterpret_cast<ScanPair *>(reinterpret_cast<char *>(ht) + tb);
+    int *hn = reinterpret_cast<int *>(reinterpret_cast<char *>(hp) + pb);
+    for (int q = 0; q < nq; q++) {
+        hp[q].out_rel = (int64_t)q * out_stride;
+        hp[q].query = q;
+        hp[q].pad = 0;
+    }
+    int64_t t = 0;
+    for (int64_t c = 0; c < nchunks; c++)
+        for (int gidx = 0; gidx < ngroups; gidx++) {
+            ht[t].row0 = c * ch;
+            int64_t left = nrows - c * ch;
+            ht[t].nrows = (int)(left < ch ? left : ch);
+            ht[t].pair0 = gidx * qt;
+            int pl = nq - gidx * qt;
+            ht[t].npairs = pl < qt ? pl : qt;
+            ht[t].pad = 0;
+            t++;
+        }
+    *hn = (int)ntasks;
+    PGV_TRY(ctx->tasks.ensure(tb + pb + 16));
+    PGV_HIP(hipMemcpyAsync(ctx->tasks.p, ht, tb + pb + 16, hipMemcpyHostToDevice, ctx->stream));
+    const ScanTask *dt = ctx->tasks.as<ScanTask>();
+    const ScanPair *dp = reinterpret_cast<const ScanPair *>(ctx->tasks.as<char>() + tb);
+    const int *dn = reinterpret_cast<const int *>(ctx->tasks.as<char>() + tb + pb);
+
+    ScanTimer timer{ctx};
+    PGV_TRY(timer.begin((double)nrows * nq, (double)nrows * ngroups, true));
+    PGV_TRY(launch_scan(ctx, metric, dtype, g, rows_dev, queries_dev, dt, dn, (int)ntasks, dp, qt,
+                        out_dev));
+    PGV_TRY(timer.end());
+    // h_a is rewritten by the next call: make sure the copy has been consumed
+    PGV_HIP(hipStreamSynchronize(ctx->stream));
+    return PGV_OK;
+}
+
+// -------------------------------------------------- library-owned random source
+struct Xoro {
+    uint64_t s0, s1;
+    static uint64_t rotl(uint64_t x, int k) { return (x << k) | (x >> (64 - k)); }
+    static uint64_t splitmix(uint64_t &st) {
+        uint64_t v = (st += 0x9E3779B97f4A7C15ull);
+        v = (v ^ (v >> 30)) * 0xBF58476D1CE4E5B9ull;
+        v = (v ^ (v >> 27)) * 0x94D049BB133111EBull;
+        return v ^ (v >> 31);
+    }
+    explicit Xoro(uint64_t seed) {
+        s0 = splitmix(seed);
+        s1 = splitmix(seed);
+        if (!s0 && !s1) s0 = 1;
+    }
+    uint64_t next() {
+        uint64_t a = s0, x = s1 ^ a, out = rotl(a * 5, 7) * 9;
+        s0 = rotl(a, 24) ^ x ^ (x << 16);
+        s1 = rotl(x, 37);
+        return out;
+    }
+};
+
+struct Rng {
+    const pgv_rng *user;
+    Xoro own;
+    explicit Rng(const pgv_rng *r) : user(r), own(r ? r->seed : 0) {}
+    double next_double() {
+        if (user && user->next_double) return user->next_double(user->state);
+        return std::ldexp((double)(own.next() >> 12), -52);
+    }
+    uint32_t next_u32() {
+        if (user && user->next_u32) return user->next_u32(user->state);
+        return (uint32_t)(own.next() >> 32);
+    }
+};
+
+}  // namespace
+
+// =================================================================== context
+extern "C" {
+
+const char *pgv_last_error(void) { return pgv::g_err; }
+int pgv_abi_version(void) { return PGV_ABI_VERSION; }
+
+int pgv_device_count(void) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) {
+        (void)hipGetLastError();
+        return 0;
+    }
+    return n;
+}
+
+int pgv_ctx_create(int device, void *stream, pgv_ctx **out) {
+    if (!out) PGV_FAIL(PGV_ERR_ARG, "pgv_ctx_create: out is NULL");
+    *out = nullptr;
+    int n = pgv_device_count();
+    if (n <= 0) PGV_FAIL(PGV_ERR_DEVICE, "no HIP device available (libpgv_hip has no CPU path)");
+    if (device < 0 || device >= n) PGV_FAIL(PGV_ERR_ARG, "device %d out of range 0..%d", device, n - 1);
+    PGV_HIP(hipSetDevice(device));
+    hipDeviceProp_t prop;
+    PGV_HIP(hipGetDeviceProperties(&prop, device));
+    if (strncmp(prop.gcnArchName, "gfx950", 6) != 0)
+        PGV_FAIL(PGV_ERR_DEVICE, "device %d is %s; libpgv_hip is built for gfx950 only", device,
+                 prop.gcnArchName);
+    pgv_ctx *ctx = new (std::nothrow) pgv_ctx();
+    if (!ctx) PGV_FAIL(PGV_ERR_NOMEM, "out of host memory");
+    ctx->device = device;
+    ctx->num_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+    if (stream) {
+        ctx->stream = static_cast<hipStream_t>(stream);
+    } else {
+        hipError_t e = hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking);
+        if (e != hipSuccess) {
+            delete ctx;
+            PGV_FAIL(PGV_ERR_DEVICE, "hipStreamCreate failed: %s", hipGetErrorString(e));
+        }
+        ctx->own_stream = true;
+    }
+    if (hipEventCreate(&ctx->ev0) != hipSuccess || hipEventCreate(&ctx->ev1) != hipSuccess) {
+        pgv_ctx_destroy(ctx);
+        PGV_FAIL(PGV_ERR_DEVICE, "hipEventCreate failed");
+    }
+    *out = ctx;
+    return PGV_OK;
+}
+
+void pgv_ctx_destroy(pgv_ctx *ctx) {
+    if (!ctx) return;
+    (void)hipSetDevice(ctx->device);
+    (void)hipStreamSynchronize(ctx->stream);
+    DBuf *d[] = {&ctx->q_stage, &ctx->rows_stage, &ctx->centers_stage, &ctx->out_stage,
+                 &ctx->out_stage2, &ctx->idx_stage, &ctx->tasks, &ctx->pairs, &ctx->counters,
+                 &ctx->plan_a, &ctx->plan_b, &ctx->plan_c, &ctx->plan_d, &ctx->dist_mat,
+                 &ctx->sel_a, &ctx->sel_b, &ctx->km_a, &ctx->km_b, &ctx->km_c, &ctx->km_d,
+                 &ctx->km_e, &ctx->km_f, &ctx->km_g};
+    for (DBuf *b : d) b->release();
+    ctx->h_a.release();
+    ctx->h_b.release();
+    ctx->h_c.release();
+    for (hipEvent_t e : ctx->ev_pool) (void)hipEventDestroy(e);
+    if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
+    if (ctx->ev1) (void)hipEventDestroy(ctx->ev1);
+    if (ctx->own_stream && ctx->stream) (void)hipStreamDestroy(ctx->stream);
+    delete ctx;
+}
+
+int pgv_ctx_sync(pgv_ctx *ctx) {
+    if (!ctx) PGV_FAIL(PGV_ERR_ARG, "ctx is NULL");
+    PGV_HIP(hipStreamSynchronize(ctx->stream));
+    return PGV_OK;
+}
+
+void *pgv_ctx_stream(pgv_ctx *ctx) { return ctx ? (void *)ctx->stream : nullptr; }
+
+int pgv_timer_start(pgv_ctx *ctx) {
+    if (!ctx) PGV_FAIL(PGV_ERR_ARG, "ctx is NULL");
+    PGV_HIP(hipEventRecord(ctx->ev0, ctx->stream));
+    return PGV_OK;
+}
+
+int pgv_timer_stop(pgv_ctx *ctx, float *out_ms) {
+    if (!ctx || !out_ms) PGV_FAIL(PGV_ERR_ARG, "ctx/out_ms is NULL");
+    PGV_HIP(hipEventRecord(ctx->ev1, ctx->stream));
+    PGV_HIP(hipEventSynchronize(ctx->ev1));
+    PGV_HIP(hipEventElapsedTime(out_ms, ctx->ev0, ctx->ev1));
+    return PGV_OK;
+}
+
+int pgv_ctx_set_profiling(pgv_ctx *ctx, int on) {
+    if (!ctx) PGV_FAIL(PGV_ERR_ARG, "ctx is NULL");
+    PGV_TRY(resolve_events(ctx));
+    ctx->profiling = on != 0;
+    return PGV_OK;
+}
+
+int pgv_ctx_reset_stats(pgv_ctx *ctx) {
+    if (!ctx) PGV_FAIL(PGV_ERR_ARG, "ctx is NULL");
+    PGV_TRY(resolve_events(ctx));
+    ctx->scan_ms = 0;
+    ctx->scan_launches = 0;
+    ctx->scan_pairs = 0;
+    ctx->scan_rows = 0;
+    ctx->aux_ms = 0;
+    ctx->aux_launches = 0;
+    ctx->aux_pairs = 0;
+    return PGV_OK;
+}
+
+int pgv_ctx_get_stats(pgv_ctx *ctx, pgv_stats *out) {
+    if (!ctx || !out) PGV_FAIL(PGV_ERR_ARG, "ctx/out is NULL");
+    PGV_TRY(resolve_events(ctx));
+    out->scan_ms = ctx->scan_ms;
+    out->scan_launches = ctx->scan_launches;
+    out->scan_pairs = ctx->scan_pairs;
+    out->scan_rows = ctx->scan_rows;
+    out->aux_ms = ctx->aux_ms;
+    out->aux_launches = ctx->aux_launches;
+    out->aux_pairs = ctx->aux_pairs;
+    return PGV_OK;
+}
+
+// ============================================================== IVFFlat index
+
+int pgv_index_upload(pgv_ctx *ctx, pgv_metric metric, pgv_dtype dtype, int dim, int nlists,
+                     const void *centers, const int64_t *list_offsets, const void *vectors,
+                     const uint64_t *tids, pgv_index **out) {
+    if (!ctx || !out) PGV_FAIL(PGV_ERR_ARG, "pgv_index_upload: ctx/out is NULL");
+    *out = nullptr;
+    PGV_TRY(check_common(dtype, dim));
+    PGV_TRY(check_metric(metric));
+    // IVFFLAT_MAX_LISTS (src/ivfflat.h:56)
+    if (nlists < 1 || nlists > 32768) PGV_FAIL(PGV_ERR_ARG, "lists %d outside 1..32768", nlists);
+    if (!centers || !list_offsets) PGV_FAIL(PGV_ERR_ARG, "centers/list_offsets is NULL");
+    PGV_HIP(hipSetDevice(ctx->device));
+
+    std::vector<int64_t> off((size_t)nlists + 1);
+    if (is_device_ptr(list_offsets)) {
+        PGV_HIP(hipMemcpy(off.data(), list_offsets, sizeof(int64_t) * off.size(), hipMemcpyDeviceToHost));
+    } else {
+        memcpy(off.data(), list_offsets, sizeof(int64_t) * off.size());
+    }
+    if (off[0] != 0) PGV_FAIL(PGV_ERR_ARG, "list_offsets[0] must be 0");
+    int64_t maxlen = 0;
+    for (int l = 0; l < nlists; l++) {
+        if (off[l + 1] < off[l]) PGV_FAIL(PGV_ERR_ARG, "list_offsets not ascending at list %d", l);
+        if (off[l + 1] - off[l] > maxlen) maxlen = off[l + 1] - off[l];
+    }
+    const int64_t n = off[nlists];
+    if (n > 0 && !vectors) PGV_FAIL(PGV_ERR_ARG, "vectors is NULL");
+
+    pgv_index *ix = new (std::nothrow) pgv_index();
+    if (!ix) PGV_FAIL(PGV_ERR_NOMEM, "out of host memory");
+    ix->ctx = ctx;
+    ix->metric = metric;
+    ix->dtype = dtype;
+    ix->dim = dim;
+    ix->nlists = nlists;
+    ix->nrows = n;
+    ix->geom = row_geom(dim, dtype);
+    ix->h_offsets = off;
+    ix->max_list_len = maxlen;
+    const size_t es = elem_size(dtype);
+    const size_t row_bytes = (size_t)ix->geom.ld * es;
+
+    auto fail = [&](int rc) {
+        pgv_index_free(ix);
+        return rc;
+    };
+    auto put_rows = [&](void **dst, const void *src, int64_t rows) -> int {
+        size_t bytes = (size_t)(rows > 0 ? rows : 1) * row_bytes;
+        PGV_HIP(hipMalloc(dst, bytes));
+        if (rows == 0) return PGV_OK;
+        const bool dev = is_device_ptr(src);
+        if (ix->geom.ld == dim) {
+            PGV_HIP(hipMemcpyAsync(*dst, src, (size_t)rows * row_bytes,
+                                   dev ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, ctx->stream));
+        } else {
+            PGV_HIP(hipMemsetAsync(*dst, 0, bytes, ctx->stream));
+            PGV_HIP(hipMemcpy2DAsync(*dst, row_bytes, src, (size_t)dim * es, (size_t)dim * es,
+                                     (size_t)rows, dev ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice,
+                                     ctx->stream));
+        }
+        return PGV_OK;
+    };
+    int rc;
+    if ((rc = put_rows(&ix->centers, centers, nlists)) != PGV_OK) return fail(rc);
+    if ((rc = put_rows(&ix->vectors, vectors, n)) != PGV_OK) return fail(rc);
+    if (hipMalloc((void **)&ix->list_offsets, sizeof(int64_t) * off.size()) != hipSuccess)
+        return fail((set_error("hipMalloc(list_offsets) failed"), PGV_ERR_NOMEM));
+    if (hipMemcpyAsync(ix->list_offsets, ix->h_offsets.data(), sizeof(int64_t) * off.size(),
+                       hipMemcpyHostToDevice, ctx->stream) != hipSuccess)
+        return fail((set_error("copy of list_offsets failed"), PGV_ERR_DEVICE));
+    if (tids && n > 0) {
+        if (hipMalloc((void **)&ix->tids, sizeof(uint64_t) * (size_t)n) != hipSuccess)
+            return fail((set_error("hipMalloc(tids) failed"), PGV_ERR_NOMEM));
+        if (hipMemcpyAsync(ix->tids, tids, sizeof(uint64_t) * (size_t)n,
+                           is_device_ptr(tids) ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice,
+                           ctx->stream) != hipSuccess)
+            return fail((set_error("copy of tids failed"), PGV_ERR_DEVICE));
+    }
+    if (hipStreamSynchronize(ctx->stream) != hipSuccess)
+        return fail((set_error("index upload failed: %s", hipGetErrorString(hipGetLastError())), PGV_ERR_DEVICE));
+    *out = ix;
+    return PGV_OK;
+}
+
+void pgv_index_free(pgv_index *ix) {
+    if (!ix) return;
+    if (ix->ctx) (void)hipStreamSynchronize(ix->ctx->stream);
+    if (ix->centers) (void)hipFree(ix->centers);
+    if (ix->vectors) (void)hipFree(ix->vectors);
+    if (ix->list_offsets) (void)hipFree(ix->list_offsets);
+    if (ix->tids) (void)hipFree(ix->tids);
+    delete ix;
+}
+
+int64_t pgv_index_rows(const pgv_index *ix) { return ix ? ix->nrows : -1; }
+int pgv_index_lists(const pgv_index *ix) { return ix ? ix->nlists : -1; }
+
+// device-side core of GetScanLists for nq staged queries
+static int rank_lists_dev(pgv_index *ix, const void *q_dev, int nq, int maxprobes,
+                          int32_t *out_lists_dev, float *out_dist_dev) {
+    pgv_ctx *ctx = ix->ctx;
+    // distance matrix [nq x nlists], then the maxprobes smallest per row
+    PGV_TRY(ctx->dist_mat.ensure(sizeof(float) * (size_t)nq * ix->nlists));
+    float *mat = ctx->dist_mat.as<float>();
+    PGV_TRY(dense_scan(ctx, ix->metric, ix->dtype, ix->geom, ix->centers, ix->nlists, q_dev, nq,
+                       ix->nlists, mat));
+    PGV_TRY(ctx->sel_a.ensure(sizeof(int64_t) * (size_t)nq * maxprobes));
+    float *dist = out_dist_dev;
+    if (!dist) {
+        PGV_TRY(ctx->sel_b.ensure(sizeof(float) * (size_t)nq * maxprobes));
+        dist = ctx->sel_b.as<float>();
+    }
+    int64_t *pos = ctx->sel_a.as<int64_t>();
+    PGV_TRY(launch_topk_segments(ctx, mat, nullptr, nq, ix->nlists, maxprobes, dist, pos));
+    PGV_TRY(launch_cast_pos_to_i32(ctx, pos, (int64_t)nq * maxprobes, out_lists_dev));
+    return PGV_OK;
+}
+
+int pgv_rank_lists(pgv_index *ix, const void *queries, int nq, int maxprobes, int32_t *out_lists,
+                   float *out_dist) {
+    if (!ix || !out_lists) PGV_FAIL(PGV_ERR_ARG, "pgv_rank_lists: index/out_lists is NULL");
+    if (nq < 0) PGV_FAIL(PGV_ERR_ARG, "nq < 0");
+    if (maxprobes < 1 || maxprobes > ix->nlists)
+        PGV_FAIL(PGV_ERR_ARG, "maxprobes %d outside 1..lists (%d)", maxprobes, ix->nlists);
+    if (nq == 0) return PGV_OK;
+    if (!queries) PGV_FAIL(PGV_ERR_ARG, "queries is NULL");
+    pgv_ctx *ctx = ix->ctx;
+    PGV_HIP(hipSetDevice(ctx->device));
+    const void *q_dev;
+    PGV_TRY(stage_rows(ctx, queries, nq, ix->dim, ix->dtype, ix->geom, ctx->q_stage, &q_dev));
+    OutArg ol, od;
+    PGV_TRY(ol.init(out_lists, sizeof(int32_t) * (size_t)nq * maxprobes, ctx->out_stage));
+    PGV_TRY(od.init(out_dist, sizeof(float) * (size_t)nq * maxprobes, ctx->out_stage2));
+    PGV_TRY(rank_lists_dev(ix, q_dev, nq, maxprobes, ol.as<int32_t>(), od.as<float>()));
+    bool need = false;
+    PGV_TRY(ol.finish(ctx, &need));
+    PGV_TRY(od.finish(ctx, &need));
+    return sync_if(ctx, need);
+}
+
+int pgv_scan_lists(pgv_index *ix, const void *query, const int32_t *lists, int nlists,
+                   float *out_dist, int64_t *out_slot, int64_t capacity, int64_t *out_count) {
+    if (!ix || !out_count) PGV_FAIL(PGV_ERR_ARG, "pgv_scan_lists: index/out_count is NULL");
+    if (nlists < 0 || (nlists > 0 && !lists)) PGV_FAIL(PGV_ERR_ARG, "bad list array");
+    pgv_ctx *ctx = ix->ctx;
+    PGV_HIP(hipSetDevice(ctx->device));
+
+    std::vector<int32_t> hl((size_t)nlists);
+    if (nlists) {
+        if (is_device_ptr(lists))
+            PGV_HIP(hipMemcpy(hl.data(), lists, sizeof(int32_t) * (size_t)nlists, hipMemcpyDeviceToHost));
+        else
+            memcpy(hl.data(), lists, sizeof(int32_t) * (size_t)nlists);
+    }
+    int64_t m = 0;
+    for (int p = 0; p < nlists; p++) {
+        if (hl[p] < 0 || hl[p] >= ix->nlists) PGV_FAIL(PGV_ERR_ARG, "list id %d out of range", hl[p]);
+        m += ix->h_offsets[hl[p] + 1] - ix->h_offsets[hl[p]];
+    }
+    *out_count = m;
+    if (m > capacity) PGV_FAIL(PGV_ERR_ARG, "output capacity %lld < %lld tuples", (long long)capacity, (long long)m);
+    if (m == 0) return PGV_OK;
+    if (!out_dist || !out_slot) PGV_FAIL(PGV_ERR_ARG, "out_dist/out_slot is NULL");
+
+    OutArg od, os;
+    PGV_TRY(od.init(out_dist, sizeof(float) * (size_t)m, ctx->out_stage));
+    PGV_TRY(os.init(out_slot, sizeof(int64_t) * (size_t)m, ctx->out_stage2));
+
+    // plan on the host: per probed list a run of chunks, all for the one query
+    const int ch = rows_per_task_for(ctx, m, 1);
+    int64_t ntasks = 0;
+    for (int p = 0; p < nlists; p++) {
+        int64_t len = ix->h_offsets[hl[p] + 1] - ix->h_offsets[hl[p]];
+        ntasks += (len + ch - 1) / ch;
+    }
+    const size_t tb = sizeof(ScanTask) * (size_t)ntasks, pb = sizeof(ScanPair) * (size_t)nlists,
+                 ob = sizeof(int64_t) * (size_t)nlists, lb = sizeof(int32_t) * (size_t)nlists;
+    PGV_TRY(ctx->h_a.ensure(tb + pb + ob + lb + 16));
+    char *hb = ctx->h_a.as<char>();
+    ScanTask *ht = reinterpret_cast<ScanTask *>(hb);
+    ScanPair *hp = reinterpret_cast<ScanPair *>(hb + tb);
+    int64_t *hoff = reinterpret_cast<int64_t *>(hb + tb + pb);
+    int32_t *hlist = reinterpret_cast<int32_t *>(hb + tb + pb + ob);
+    int *hn = reinterpret_cast<int *>(hb + tb + pb + ob + lb);
+    int64_t t = 0, run = 0;
+    for (int p = 0; p < nlists; p++) {
+        const int64_t beg = ix->h_offsets[hl[p]], len = ix->h_offsets[hl[p] + 1] - beg;
+        hp[p].out_rel = run - beg;
+        hp[p].query = 0;
+        hp[p].pad = 0;
+        hoff[p] = run;
+        hlist[p] = hl[p];
+        for (int64_t c = 0; c * ch < len; c++) {
+            ht[t].row0 = beg + c * ch;
+            int64_t left = len - c * ch;
+            ht[t].nrows = (int)(left < ch ? left : ch);
+            ht[t].pair0 = p;
+            ht[t].npairs = 1;
+            ht[t].pad = 0;
+            t++;
+        }
+        run += len;
+    }
+    *hn = (int)ntasks;
+    const size_t total = tb + pb + ob + lb + 16;
+    PGV_TRY(ctx->tasks.ensure(total));
+    PGV_HIP(hipMemcpyAsync(ctx->tasks.p, hb, total, hipMemcpyHostToDevice, ctx->stream));
+    char *db = ctx->tasks.as<char>();
+
+    PGV_TRY(launch_iota_slots(ctx, ix, reinterpret_cast<int32_t *>(db + tb + pb + ob), nlists,
+                              reinterpret_cast<int64_t *>(db + tb + pb), os.as<int64_t>()));
+    if (query == nullptr) {
+        // ZeroDistance (src/ivfscan.c:192-196): every tuple at distance 0
+        PGV_HIP(hipMemsetAsync(od.dev, 0, sizeof(float) * (size_t)m, ctx->stream));
+    } else {
+        const void *q_dev;
+        PGV_TRY(stage_rows(ctx, query, 1, ix->dim, ix->dtype, ix->geom, ctx->q_stage, &q_dev));
+        ScanTimer timer{ctx};
+        PGV_TRY(timer.begin((double)m, (double)m));
+        PGV_TRY(launch_scan(ctx, ix->metric, ix->dtype, ix->geom, ix->vectors, q_dev,
+                            reinterpret_cast<ScanTask *>(db), reinterpret_cast<int *>(db + tb + pb + ob + lb),
+                            (int)ntasks, reinterpret_cast<ScanPair *>(db + tb), 1, od.as<float>()));
+        PGV_TRY(timer.end());
+    }
+    bool need = true;  // h_a must be consumed before the next call rewrites it
+    PGV_TRY(od.finish(ctx, &need));
+    PGV_TRY(os.finish(ctx, &need));
+    return sync_if(ctx, need);
+}
+
+int pgv_search_batch(pgv_index *ix, const void *queries, int nq, int probes, int k, float *out_dist,
+                     int64_t *out_slot, uint64_t *out_tid) {
+    if (!ix) PGV_FAIL(PGV_ERR_ARG, "pgv_search_batch: index is NULL");
+    if (nq < 0 || k < 1) PGV_FAIL(PGV_ERR_ARG, "bad nq/k");
+    if (probes < 1 || probes > ix->nlists)
+        PGV_FAIL(PGV_ERR_ARG, "probes %d outside 1..lists (%d)", probes, ix->nlists);
+    if (out_tid && !ix->tids) PGV_FAIL(PGV_ERR_STATE, "index was uploaded without tids");
+    if (nq == 0) return PGV_OK;
+    if (!queries || !out_dist) PGV_FAIL(PGV_ERR_ARG, "queries/out_dist is NULL");
+    pgv_ctx *ctx = ix->ctx;
+    PGV_HIP(hipSetDevice(ctx->device));
+
+    const void *q_dev;
+    PGV_TRY(stage_rows(ctx, queries, nq, ix->dim, ix->dtype, ix->geom, ctx->q_stage, &q_dev));
+
+    // 1. GetScanLists for the whole batch
+    PGV_TRY(ctx->idx_stage.ensure(sizeof(int32_t) * (size_t)nq * probes));
+    int32_t *probe_lists = ctx->idx_stage.as<int32_t>();
+    PGV_TRY(rank_lists_dev(ix, q_dev, nq, probes, probe_lists, nullptr));
+
+    // 2. invert to list-major work
+    const int qt_max = scan_group_size(ix->geom, ix->dtype, 8);
+    // queries per list on average decides how wide a group is worth
+    const double share = (double)nq * probes / (double)ix->nlists;
+    int qt = 1;
+    while (qt < qt_max && qt < share) qt <<= 1;
+    const int rows_per_task = qt >= 4 ? 128 : 64;
+    PlanResult plan;
+    PGV_TRY(launch_plan_batch(ctx, ix, probe_lists, nq, probes, qt, rows_per_task, &plan));
+
+    // 3. GetScanItems: one streaming pass
+    PGV_TRY(ctx->plan_d.ensure(sizeof(float) * (size_t)(plan.total_out > 0 ? plan.total_out : 1)));
+    float *seg_vals = ctx->plan_d.as<float>();
+    if (plan.ntasks > 0) {
+        double rows_streamed = 0.0;
+        if (ctx->profiling) {
+            // rows streamed = sum over lists of (query groups x list length); the per-list
+            // probe counts are the first nlists ints of plan_a
+            std::vector<int> cnt((size_t)ix->nlists);
+            PGV_HIP(hipMemcpyAsync(cnt.data(), ctx->plan_a.p, sizeof(int) * cnt.size(), hipMemcpyDeviceToHost, ctx->stream));
+            PGV_HIP(hipStreamSynchronize(ctx->stream));
+            for (int l = 0; l < ix->nlists; l++)
+                rows_streamed += (double)((cnt[l] + qt - 1) / qt) * (double)(ix->h_offsets[l + 1] - ix->h_offsets[l]);
+        }
+        ScanTimer timer{ctx};
+        PGV_TRY(timer.begin((double)plan.total_out, rows_streamed));
+        PGV_TRY(launch_scan(ctx, ix->metric, ix->dtype, ix->geom, ix->vectors, q_dev, plan.tasks,
+                            plan.ntasks_dev, (int)plan.ntasks, plan.pairs, qt, seg_vals));
+        PGV_TRY(timer.end());
+    }
+
+    // 4. head of the sorted stream
+    OutArg od, os, ot;
+    PGV_TRY(od.init(out_dist, sizeof(float) * (size_t)nq * k, ctx->out_stage));
+    PGV_TRY(os.init(out_slot, sizeof(int64_t) * (size_t)nq * k, ctx->out_stage2));
+    PGV_TRY(ot.init(out_tid, sizeof(uint64_t) * (size_t)nq * k, ctx->sel_b));
+    PGV_TRY(ctx->sel_a.ensure(sizeof(int64_t) * (size_t)nq * k));
+    int64_t *pos = ctx->sel_a.as<int64_t>();
+    PGV_TRY(launch_topk_segments(ctx, seg_vals, plan.seg_start, nq, 0, k, od.as<float>(), pos));
+    PGV_TRY(launch_positions_to_slots(ctx, ix, probe_lists, plan.probe_off, nq, probes, k, pos,
+                                      os.as<int64_t>(), ot.as<uint64_t>()));
+    bool need = false;
+    PGV_TRY(od.finish(ctx, &need));
+    PGV_TRY(os.finish(ctx, &need));
+    PGV_TRY(ot.finish(ctx, &need));
+    return sync_if(ctx, need);
+}
+
+// ================================================================= build side
+
+int pgv_assign(pgv_ctx *ctx, pgv_metric metric, pgv_dtype dtype, int dim, const void *centers, int k,
+               const void *rows, int64_t n, int32_t *out_list, float *out_dist) {
+    if (!ctx || !out_list) PGV_FAIL(PGV_ERR_ARG, "pgv_assign: ctx/out_list is NULL");
+    PGV_TRY(check_common(dtype, dim));
+    PGV_TRY(check_metric(metric));
+    if (k < 1 || !centers) PGV_FAIL(PGV_ERR_ARG, "need at least one center");
+    if (n < 0) PGV_FAIL(PGV_ERR_ARG, "n < 0");
+    if (n == 0) return PGV_OK;
+    if (!rows) PGV_FAIL(PGV_ERR_ARG, "rows is NULL");
+    PGV_HIP(hipSetDevice(ctx->device));
+    const RowGeom g = row_geom(dim, dtype);
+    const void *c_dev;
+    PGV_TRY(stage_rows(ctx, centers, k, dim, dtype, g, ctx->centers_stage, &c_dev));
+
+    const bool rows_dev = is_device_ptr(rows);
+    const bool out_dev = is_device_ptr(out_list);
+    const bool dist_dev = out_dist && is_device_ptr(out_dist);
+    const size_t es = elem_size(dtype);
+    // host rows are staged in slabs (BuildCallback batches); device rows go in one piece
+    const int64_t slab = (rows_dev && g.ld == dim) ? n : (int64_t)1 << 18;
+    bool need = false;
+    for (int64_t r0 = 0; r0 < n; r0 += slab) {
+        const int64_t cnt = n - r0 < slab ? n - r0 : slab;
+        const void *r_dev;
+        PGV_TRY(stage_rows(ctx, static_cast<const char *>(rows) + (size_t)r0 * dim * es, cnt, dim,
+                           dtype, g, ctx->rows_stage, &r_dev));
+        int32_t *idx = out_list + r0;
+        float *val = out_dist ? out_dist + r0 : nullptr;
+        if (!out_dev) {
+            PGV_TRY(ctx->out_stage.ensure(sizeof(int32_t) * (size_t)cnt));
+            idx = ctx->out_stage.as<int32_t>();
+        }
+        if (out_dist && !dist_dev) {
+            PGV_TRY(ctx->out_stage2.ensure(sizeof(float) * (size_t)cnt));
+            val = ctx->out_stage2.as<float>();
+        }
+        PGV_TRY(launch_argmin(ctx, metric, dtype, g, r_dev, cnt, c_dev, k, idx, val));
+        if (!out_dev) {
+            PGV_HIP(hipMemcpyAsync(out_list + r0, idx, sizeof(int32_t) * (size_t)cnt, hipMemcpyDeviceToHost, ctx->stream));
+            need = true;
+        }
+        if (out_dist && !dist_dev) {
+            PGV_HIP(hipMemcpyAsync(out_dist + r0, val, sizeof(float) * (size_t)cnt, hipMemcpyDeviceToHost, ctx->stream));
+            need = true;
+        }
+        if (need && r0 + slab < n) PGV_HIP(hipStreamSynchronize(ctx->stream));  // scratch is reused
+    }
+    return sync_if(ctx, need);
+}
+
+int pgv_distance_batch(pgv_ctx *ctx, pgv_metric metric, pgv_dtype dtype, int dim, const void *query,
+                       const void *rows, int64_t n, float *out) {
+    if (!ctx || !out) PGV_FAIL(PGV_ERR_ARG, "pgv_distance_batch: ctx/out is NULL");
+    PGV_TRY(check_common(dtype, dim));
+    PGV_TRY(check_metric(metric));
+    if (n < 0) PGV_FAIL(PGV_ERR_ARG, "n < 0");
+    if (n == 0) return PGV_OK;
+    if (!query || !rows) PGV_FAIL(PGV_ERR_ARG, "query/rows is NULL");
+    PGV_HIP(hipSetDevice(ctx->device));
+    const RowGeom g = row_geom(dim, dtype);
+    const void *q_dev, *r_dev;
+    PGV_TRY(stage_rows(ctx, query, 1, dim, dtype, g, ctx->q_stage, &q_dev));
+    PGV_TRY(stage_rows(ctx, rows, n, dim, dtype, g, ctx->rows_stage, &r_dev));
+    OutArg od;
+    PGV_TRY(od.init(out, sizeof(float) * (size_t)n, ctx->out_stage));
+    PGV_TRY(dense_scan(ctx, metric, dtype, g, r_dev, n, q_dev, 1, 0, od.as<float>()));
+    bool need = false;
+    PGV_TRY(od.finish(ctx, &need));
+    return sync_if(ctx, need);
+}
+
+// --------------------------------------------------------------------- k-means
+
+static bool spherical(pgv_ops ops) { return ops == PGV_OPS_IP || ops == PGV_OPS_COSINE; }
+
+static int check_ops(pgv_ops ops) {
+    if (ops != PGV_OPS_L2 && ops != PGV_OPS_IP && ops != PGV_OPS_COSINE)
+        PGV_FAIL(PGV_ERR_ARG, "unknown opclass family %d", (int)ops);
+    return PGV_OK;
+}
+
+// k-means++ on staged (padded, device) samples into padded device centers
+static int kmeanspp_dev(pgv_ctx *ctx, pgv_ops ops, pgv_dtype dtype, const RowGeom &g,
+                        const void *samples_dev, int n, int k, Rng &rng, void *centers_dev) {
+    const size_t row_bytes = (size_t)g.ld * elem_size(dtype);
+    const int nblocks = kmpp_block_count(n);
+    // km_a: weight[n] | raw[n]   km_b: block_sums[nblocks] | draws[k]   km_c: picked[k]
+    PGV_TRY(ctx->km_a.ensure(sizeof(float) * 2 * (size_t)n));
+    PGV_TRY(ctx->km_b.ensure(sizeof(double) * ((size_t)nblocks + (size_t)k)));
+    PGV_TRY(ctx->km_c.ensure(sizeof(int32_t) * (size_t)k));
+    float *weight = ctx->km_a.as<float>();
+    float *raw = weight + n;
+    double *block_sums = ctx->km_b.as<double>();
+    double *draws_dev = block_sums + nblocks;
+    int32_t *picked = ctx->km_c.as<int32_t>();
+
+    // the reference draws RandomInt() once, then one RandomDouble() per further center
+    // (src/ivfkmeans.c:36, :77): pre-draw them in that order
+    const uint32_t first = rng.next_u32() % (uint32_t)n;
+    PGV_TRY(ctx->h_b.ensure(sizeof(double) * (size_t)k + sizeof(float) * (size_t)n));
+    double *h_draws = ctx->h_b.as<double>();
+    for (int i = 0; i + 1 < k; i++) h_draws[i] = rng.next_double();
+    float *h_w = reinterpret_cast<float *>(h_draws + k);
+    for (int j = 0; j < n; j++) h_w[j] = 3.402823466e+38f;  // FLT_MAX (:39-40)
+    PGV_HIP(hipMemcpyAsync(draws_dev, h_draws, sizeof(double) * (size_t)k, hipMemcpyHostToDevice, ctx->stream));
+    PGV_HIP(hipMemcpyAsync(weight, h_w, sizeof(float) * (size_t)n, hipMemcpyHostToDevice, ctx->stream));
+    PGV_HIP(hipMemcpyAsync(centers_dev, static_cast<const char *>(samples_dev) + (size_t)first * row_bytes,
+                           row_bytes, hipMemcpyDeviceToDevice, ctx->stream));
+    const int32_t first_i = (int32_t)first;
+    PGV_HIP(hipMemcpyAsync(picked, &first_i, sizeof(int32_t), hipMemcpyHostToDevice, ctx->stream));
+    PGV_HIP(hipStreamSynchronize(ctx->stream));
+
+    const pgv_metric km = spherical(ops) ? PGV_NEG_IP : PGV_L2SQ;
+    for (int i = 0; i + 1 < k; i++) {
+        // distance of every sample to the newest center only (:52-60)
+        const void *center_i = static_cast<const char *>(centers_dev) + (size_t)i * row_bytes;
+        PGV_TRY(dense_scan(ctx, km, dtype, g, samples_dev, n, center_i, 1, 0, raw));
+        PGV_TRY(launch_kmpp_update(ctx, raw, weight, n, spherical(ops) ? 1 : 0, block_sums));
+        PGV_TRY(launch_kmpp_pick(ctx, g, samples_dev, n, weight, block_sums, draws_dev, i, centers_dev, picked));
+    }
+    return PGV_OK;
+}
+
+// assignment + per-center sums/counts for staged samples; all outputs device
+static int lloyd_partial_dev(pgv_ctx *ctx, pgv_ops ops, pgv_dtype dtype, const RowGeom &g,
+                             const void *samples_dev, int n, const void *centers_dev, int k,
+                             int32_t *closest_io, float *sums /*[k x ld]*/, int32_t *counts,
+                             unsigned long long *changes) {
+    // km_d: closest_new[n] | offsets[k+1] | members[n]
+    PGV_TRY(ctx->km_d.ensure(sizeof(int32_t) * (2 * (size_t)n + (size_t)k + 1)));
+    int32_t *closest_new = ctx->km_d.as<int32_t>();
+    int32_t *offsets = closest_new + n;
+    int32_t *members = offsets + k + 1;
+    PGV_HIP(hipMemsetAsync(counts, 0, sizeof(int32_t) * (size_t)k, ctx->stream));
+    PGV_HIP(hipMemsetAsync(changes, 0, sizeof(unsigned long long), ctx->stream));
+    if (n > 0) {
+        PGV_TRY(launch_argmin_mode(ctx, spherical(ops) ? 3 : 0, dtype, g, samples_dev, n, centers_dev, k,
+                                   closest_new, nullptr));
+        PGV_TRY(launch_changes_hist(ctx, closest_new, closest_io, n, counts, changes));
+    }
+    PGV_TRY(launch_members(ctx, closest_io, n, k, counts, offsets, members));
+    PGV_TRY(launch_center_sums(ctx, dtype, g, samples_dev, offsets, members, k, sums));
+    return PGV_OK;
+}
+
+// centers from (all-reduced) sums/counts; counts_host tells which clusters are empty
+static int lloyd_finish_dev(pgv_ctx *ctx, pgv_ops ops, pgv_dtype dtype, const RowGeom &g, int dim, int k,
+                            const float *sums_dev, const int32_t *counts_dev, const int32_t *counts_host,
+                            Rng &rng, void *centers_dev) {
+    // empty clusters take dim RandomDouble() draws each, in center order (src/ivfkmeans.c:222-227)
+    int nempty = 0;
+    for (int c = 0; c < k; c++)
+        if (counts_host[c] <= 0) nempty++;
+    PGV_TRY(ctx->km_e.ensure(sizeof(int32_t) * (size_t)k + sizeof(float) * ((size_t)nempty * dim + 1)));
+    int32_t *refill_row = ctx->km_e.as<int32_t>();
+    float *refill = reinterpret_cast<float *>(refill_row + k);
+    if (nempty > 0) {
+        PGV_TRY(ctx->h_b.ensure(sizeof(int32_t) * (size_t)k + sizeof(float) * (size_t)nempty * dim));
+        int32_t *h_row = ctx->h_b.as<int32_t>();
+        float *h_fill = reinterpret_cast<float *>(h_row + k);
+        int e = 0;
+        for (int c = 0; c < k; c++) {
+            h_row[c] = -1;
+            if (counts_host[c] <= 0) {
+                for (int d = 0; d < dim; d++) h_fill[(size_t)e * dim + d] = (float)rng.next_double();
+                h_row[c] = e++;
+            }
+        }
+        PGV_HIP(hipMemcpyAsync(refill_row, h_row, sizeof(int32_t) * (size_t)k + sizeof(float) * (size_t)nempty * dim,
+                               hipMemcpyHostToDevice, ctx->stream));
+        PGV_HIP(hipStreamSynchronize(ctx->stream));
+    }
+    PGV_TRY(launch_finish_centers(ctx, dtype, g, k, dim, sums_dev, counts_dev, refill, refill_row, centers_dev));
+    if (spherical(ops)) {
+        PGV_TRY(ctx->km_f.ensure(64));
+        int32_t *flag = ctx->km_f.as<int32_t>();
+        PGV_HIP(hipMemsetAsync(flag, 0, sizeof(int32_t), ctx->stream));
+        PGV_TRY(launch_normalize_rows(ctx, dtype, g, centers_dev, k, dim, flag));
+    }
+    return PGV_OK;
+}
+
+static int check_centers_dev(pgv_ctx *ctx, pgv_ops ops, pgv_dtype dtype, const RowGeom &g, int dim, int k,
+                             const void *centers_dev) {
+    PGV_TRY(ctx->km_f.ensure(64));
+    int32_t *flag = ctx->km_f.as<int32_t>();
+    PGV_HIP(hipMemsetAsync(flag, 0, sizeof(int32_t), ctx->stream));
+    PGV_TRY(launch_check_centers(ctx, dtype, g, centers_dev, k, dim, ops == PGV_OPS_COSINE ? 1 : 0, flag));
+    int32_t h = 0;
+    PGV_HIP(hipMemcpyAsync(&h, flag, sizeof(int32_t), hipMemcpyDeviceToHost, ctx->stream));
+    PGV_HIP(hipStreamSynchronize(ctx->stream));
+    // messages of src/ivfkmeans.c:507-510, :533
+    if (h & 2) PGV_FAIL(PGV_ERR_DATA, "NaN detected. Please report a bug.");
+    if (h & 4) PGV_FAIL(PGV_ERR_DATA, "Infinite value detected. Please report a bug.");
+    if (h & 8) PGV_FAIL(PGV_ERR_DATA, "Zero norm detected. Please report a bug.");
+    return PGV_OK;
+}
+
+int pgv_kmeanspp_init(pgv_ctx *ctx, pgv_ops ops, pgv_dtype dtype, int dim, const void *samples, int n,
+                      int k, const pgv_rng *rng, void *out_centers) {
+    if (!ctx || !out_centers) PGV_FAIL(PGV_ERR_ARG, "pgv_kmeanspp_init: ctx/out_centers is NULL");
+    PGV_TRY(check_common(dtype, dim));
+    PGV_TRY(check_ops(ops));
+    if (k < 1 || n < 1 || !samples) PGV_FAIL(PGV_ERR_ARG, "need samples and k >= 1");
+    PGV_HIP(hipSetDevice(ctx->device));
+    const RowGeom g = row_geom(dim, dtype);
+    const void *s_dev;
+    PGV_TRY(stage_rows(ctx, samples, n, dim, dtype, g, ctx->rows_stage, &s_dev));
+    PGV_TRY(ctx->centers_stage.ensure((size_t)k * g.ld * elem_size(dtype)));
+    PGV_HIP(hipMemsetAsync(ctx->centers_stage.p, 0, (size_t)k * g.ld * elem_size(dtype), ctx->stream));
+    Rng r(rng);
+    PGV_TRY(kmeanspp_dev(ctx, ops, dtype, g, s_dev, n, k, r, ctx->centers_stage.p));
+    PGV_TRY(unstage_rows(ctx, ctx->centers_stage.p, k, dim, dtype, g, out_centers));
+    return pgv_ctx_sync(ctx);
+}
+
+int pgv_lloyd_partial(pgv_ctx *ctx, pgv_ops ops, pgv_dtype dtype, int dim, const void *samples, int n,
+                      const void *centers, int k, int32_t *io_closest, float *out_sums,
+                      int32_t *out_counts, int64_t *out_changes) {
+    if (!ctx || !io_closest || !out_sums || !out_counts || !out_changes)
+        PGV_FAIL(PGV_ERR_ARG, "pgv_lloyd_partial: NULL argument");
+    PGV_TRY(check_common(dtype, dim));
+    PGV_TRY(check_ops(ops));
+    if (k < 1 || n < 0 || !centers || (n > 0 && !samples)) PGV_FAIL(PGV_ERR_ARG, "bad sizes");
+    PGV_HIP(hipSetDevice(ctx->device));
+    const RowGeom g = row_geom(dim, dtype);
+    const void *s_dev, *c_dev;
+    PGV_TRY(stage_rows(ctx, samples, n, dim, dtype, g, ctx->rows_stage, &s_dev));
+    PGV_TRY(stage_rows(ctx, centers, k, dim, dtype, g, ctx->centers_stage, &c_dev));
+    // closest is in/out
+    int32_t *closest_dev = io_closest;
+    const bool closest_is_dev = is_device_ptr(io_closest);
+    if (!closest_is_dev) {
+        PGV_TRY(ctx->idx_stage.ensure(sizeof(int32_t) * (size_t)(n > 0 ? n : 1)));
+        closest_dev = ctx->idx_stage.as<int32_t>();
+        if (n) PGV_HIP(hipMemcpyAsync(closest_dev, io_closest, sizeof(int32_t) * (size_t)n, hipMemcpyHostToDevice, ctx->stream));
+    }
+    // sums are produced padded [k x ld]; hand back [k x dim]
+    PGV_TRY(ctx->km_g.ensure(sizeof(float) * (size_t)k * g.ld + 64));
+    float *sums_pad = ctx->km_g.as<float>();
+    unsigned long long *changes_dev = reinterpret_cast<unsigned long long *>(sums_pad + (size_t)k * g.ld);
+    OutArg oc;
+    PGV_TRY(oc.init(out_counts, sizeof(int32_t) * (size_t)k, ctx->out_stage));
+    PGV_TRY(lloyd_partial_dev(ctx, ops, dtype, g, s_dev, n, c_dev, k, closest_dev, sums_pad, oc.as<int32_t>(), changes_dev));
+    const bool sums_dev = is_device_ptr(out_sums);
+    PGV_HIP(hipMemcpy2DAsync(out_sums, sizeof(float) * (size_t)dim, sums_pad, sizeof(float) * (size_t)g.ld,
+                             sizeof(float) * (size_t)dim, (size_t)k,
+                             sums_dev ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost, ctx->stream));
+    const bool ch_dev = is_device_ptr(out_changes);
+    PGV_HIP(hipMemcpyAsync(out_changes, changes_dev, sizeof(int64_t), ch_dev ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost, ctx->stream));
+    bool need = !sums_dev || !ch_dev;
+    if (!closest_is_dev && n) {
+        PGV_HIP(hipMemcpyAsync(io_closest, closest_dev, sizeof(int32_t) * (size_t)n, hipMemcpyDeviceToHost, ctx->stream));
+        need = true;
+    }
+    PGV_TRY(oc.finish(ctx, &need));
+    return sync_if(ctx, need);
+}
+
+int pgv_lloyd_finish(pgv_ctx *ctx, pgv_ops ops, pgv_dtype dtype, int dim, int k, const float *sums,
+                     const int32_t *counts, const pgv_rng *rng, void *out_centers) {
+    if (!ctx || !sums || !counts || !out_centers) PGV_FAIL(PGV_ERR_ARG, "pgv_lloyd_finish: NULL argument");
+    PGV_TRY(check_common(dtype, dim));
+    PGV_TRY(check_ops(ops));
+    if (k < 1) PGV_FAIL(PGV_ERR_ARG, "k < 1");
+    PGV_HIP(hipSetDevice(ctx->device));
+    const RowGeom g = row_geom(dim, dtype);
+    // sums arrive [k x dim] fp32; the kernel wants [k x ld]
+    PGV_TRY(ctx->km_g.ensure(sizeof(float) * (size_t)k * g.ld + 64));
+    float *sums_pad = ctx->km_g.as<float>();
+    const bool sums_dev = is_device_ptr(sums);
+    PGV_HIP(hipMemsetAsync(sums_pad, 0, sizeof(float) * (size_t)k * g.ld, ctx->stream));
+    PGV_HIP(hipMemcpy2DAsync(sums_pad, sizeof(float) * (size_t)g.ld, sums, sizeof(float) * (size_t)dim,
+                             sizeof(float) * (size_t)dim, (size_t)k,
+                             sums_dev ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, ctx->stream));
+    const void *counts_dev;
+    std::vector<int32_t> h_counts((size_t)k);
+    if (is_device_ptr(counts)) {
+        counts_dev = counts;
+        PGV_HIP(hipMemcpyAsync(h_counts.data(), counts, sizeof(int32_t) * (size_t)k, hipMemcpyDeviceToHost, ctx->stream));
+        PGV_HIP(hipStreamSynchronize(ctx->stream));
+    } else {
+        memcpy(h_counts.data(), counts, sizeof(int32_t) * (size_t)k);
+        PGV_TRY(stage_flat(ctx, counts, sizeof(int32_t) * (size_t)k, ctx->out_stage, &counts_dev));
+    }
+    PGV_TRY(ctx->centers_stage.ensure((size_t)k * g.ld * elem_size(dtype)));
+    Rng r(rng);
+    PGV_TRY(lloyd_finish_dev(ctx, ops, dtype, g, dim, k, sums_pad, static_cast<const int32_t *>(counts_dev),
+                             h_counts.data(), r, ctx->centers_stage.p));
+    PGV_TRY(unstage_rows(ctx, ctx->centers_stage.p, k, dim, dtype, g, out_centers));
+    return pgv_ctx_sync(ctx);
+}
+
+int pgv_kmeans(pgv_ctx *ctx, pgv_ops ops, pgv_dtype dtype, int dim, const void *samples, int n, int k,
+               int max_iterations, const pgv_rng *rng, void *out_centers, int32_t *out_closest,
+               int *out_iters) {
+    if (!ctx || !out_centers) PGV_FAIL(PGV_ERR_ARG, "pgv_kmeans: ctx/out_centers is NULL");
+    PGV_TRY(check_common(dtype, dim));
+    PGV_TRY(check_ops(ops));
+    if (k < 1 || k > 32768) PGV_FAIL(PGV_ERR_ARG, "lists %d outside 1..32768", k);
+    if (n < 0 || (n > 0 && !samples)) PGV_FAIL(PGV_ERR_ARG, "bad samples");
+    // spherical opclasses need dim > 1 (src/ivfbuild.c:375-378)
+    if (spherical(ops) && dim < 2) PGV_FAIL(PGV_ERR_DIMS, "dimensions must be greater than one for this opclass");
+    if (max_iterations <= 0) max_iterations = 500;  // src/ivfkmeans.c:347
+    PGV_HIP(hipSetDevice(ctx->device));
+    const RowGeom g = row_geom(dim, dtype);
+    const size_t row_bytes = (size_t)g.ld * elem_size(dtype);
+    Rng r(rng);
+    PGV_TRY(ctx->centers_stage.ensure((size_t)k * row_bytes));
+    void *centers_dev = ctx->centers_stage.p;
+    PGV_HIP(hipMemsetAsync(centers_dev, 0, (size_t)k * row_bytes, ctx->stream));
+    int iters = 0;
+
+    if (n == 0) {
+        // RandomCenters (src/ivfkmeans.c:110-133): as if every cluster were empty
+        std::vector<int32_t> zero((size_t)k, 0);
+        PGV_TRY(ctx->km_g.ensure(sizeof(float) * (size_t)k * g.ld + sizeof(int32_t) * (size_t)k));
+        float *sums = ctx->km_g.as<float>();
+        int32_t *counts = reinterpret_cast<int32_t *>(sums + (size_t)k * g.ld);
+        PGV_HIP(hipMemsetAsync(sums, 0, sizeof(float) * (size_t)k * g.ld + sizeof(int32_t) * (size_t)k, ctx->stream));
+        PGV_TRY(lloyd_finish_dev(ctx, ops, dtype, g, dim, k, sums, counts, zero.data(), r, centers_dev));
+    } else {
+        const void *s_dev;
+        PGV_TRY(stage_rows(ctx, samples, n, dim, dtype, g, ctx->rows_stage, &s_dev));
+        PGV_TRY(kmeanspp_dev(ctx, ops, dtype, g, s_dev, n, k, r, centers_dev));
+
+        // km_g: sums[k x ld] | counts[k] | changes | closest[n]
+        PGV_TRY(ctx->km_g.ensure(sizeof(float) * (size_t)k * g.ld + sizeof(int32_t) * ((size_t)k + (size_t)n) + 64));
+        float *sums = ctx->km_g.as<float>();
+        int32_t *counts = reinterpret_cast<int32_t *>(sums + (size_t)k * g.ld);
+        unsigned long long *changes = reinterpret_cast<unsigned long long *>(counts + k + (k & 1));
+        int32_t *closest = reinterpret_cast<int32_t *>(changes + 1);
+        PGV_HIP(hipMemsetAsync(closest, 0xff, sizeof(int32_t) * (size_t)n, ctx->stream));  // -1: everything "changes" first
+        PGV_TRY(ctx->h_a.ensure(sizeof(int32_t) * (size_t)k + 16));
+        for (int it = 0; it < max_iterations; it++) {
+            iters = it + 1;
+            PGV_TRY(lloyd_partial_dev(ctx, ops, dtype, g, s_dev, n, centers_dev, k, closest, sums, counts, changes));
+            // counts (which clusters are empty) and the change count steer the host
+            int32_t *h_counts = ctx->h_a.as<int32_t>();
+            unsigned long long *h_changes = reinterpret_cast<unsigned long long *>(h_counts + k + (k & 1));
+            PGV_HIP(hipMemcpyAsync(h_counts, counts, sizeof(int32_t) * (size_t)k, hipMemcpyDeviceToHost, ctx->stream));
+            PGV_HIP(hipMemcpyAsync(h_changes, changes, sizeof(unsigned long long), hipMemcpyDeviceToHost, ctx->stream));
+            PGV_HIP(hipStreamSynchronize(ctx->stream));
+            const unsigned long long nchanges = *h_changes;
+            PGV_TRY(lloyd_finish_dev(ctx, ops, dtype, g, dim, k, sums, counts, h_counts, r, centers_dev));
+            // stop when an iteration other than the first reassigns nothing (src/ivfkmeans.c:482-483)
+            if (nchanges == 0 && it != 0) break;
+        }
+        if (out_closest) {
+            const bool dev = is_device_ptr(out_closest);
+            PGV_HIP(hipMemcpyAsync(out_closest, closest, sizeof(int32_t) * (size_t)n,
+                                   dev ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost, ctx->stream));
+        }
+    }
+    PGV_TRY(check_centers_dev(ctx, ops, dtype, g, dim, k, centers_dev));
+    PGV_TRY(unstage_rows(ctx, centers_dev, k, dim, dtype, g, out_centers));
+    if (out_iters) *out_iters = iters;
+    return pgv_ctx_sync(ctx);
+}
+
+// ======================================================================= HNSW
+
+int pgv_hnsw_upload(pgv_ctx *ctx, pgv_metric metric, pgv_dtype dtype, int dim, const void *elements,
+                    int64_t n, pgv_hnsw **out) {
+    if (!ctx || !out) PGV_FAIL(PGV_ERR_ARG, "pgv_hnsw_upload: ctx/out is NULL");
+    *out = nullptr;
+    PGV_TRY(check_common(dtype, dim));
+    PGV_TRY(check_metric(metric));
+    if (n < 0 || (n > 0 && !elements)) PGV_FAIL(PGV_ERR_ARG, "bad elements");
+    PGV_HIP(hipSetDevice(ctx->device));
+    pgv_hnsw *h = new (std::nothrow) pgv_hnsw();
+    if (!h) PGV_FAIL(PGV_ERR_NOMEM, "out of host memory");
+    h->ctx = ctx;
+    h->metric = metric;
+    h->dtype = dtype;
+    h->dim = dim;
+    h->n = n;
+    h->geom = row_geom(dim, dtype);
+    const size_t es = elem_size(dtype), row_bytes = (size_t)h->geom.ld * es;
+    const size_t bytes = (size_t)(n > 0 ? n : 1) * row_bytes;
+    if (hipMalloc(&h->elements, bytes) != hipSuccess) {
+        delete h;
+        PGV_FAIL(PGV_ERR_NOMEM, "hipMalloc(%zu) for hnsw elements failed", bytes);
+    }
+    if (n > 0) {
+        const bool dev = is_device_ptr(elements);
+        hipError_t e;
+        if (h->geom.ld == dim) {
+            e = hipMemcpyAsync(h->elements, elements, (size_t)n * row_bytes,
+                               dev ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, ctx->stream);
+        } else {
+            e = hipMemsetAsync(h->elements, 0, bytes, ctx->stream);
+            if (e == hipSuccess)
+                e = hipMemcpy2DAsync(h->elements, row_bytes, elements, (size_t)dim * es, (size_t)dim * es,
+                                     (size_t)n, dev ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, ctx->stream);
+        }
+        if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+        if (e != hipSuccess) {
+            pgv_hnsw_free(h);
+            PGV_FAIL(PGV_ERR_DEVICE, "hnsw upload failed: %s", hipGetErrorString(e));
+        }
+    }
+    *out = h;
+    return PGV_OK;
+}
+
+void pgv_hnsw_free(pgv_hnsw *h) {
+    if (!h) return;
+    if (h->ctx) (void)hipStreamSynchronize(h->ctx->stream);
+    if (h->elements) (void)hipFree(h->elements);
+    delete h;
+}
+
+int pgv_hnsw_score(pgv_hnsw *h, const void *queries, int nq, const int32_t *slot, const int32_t *query_of,
+                   int64_t npairs, float *out) {
+    if (!h || !out) PGV_FAIL(PGV_ERR_ARG, "pgv_hnsw_score: handle/out is NULL");
+    if (npairs < 0 || nq < 1) PGV_FAIL(PGV_ERR_ARG, "bad sizes");
+    if (npairs == 0) return PGV_OK;
+    if (!queries || !slot) PGV_FAIL(PGV_ERR_ARG, "queries/slot is NULL");
+    pgv_ctx *ctx = h->ctx;
+    PGV_HIP(hipSetDevice(ctx->device));
+    const void *q_dev, *s_dev, *qo_dev = nullptr;
+    PGV_TRY(stage_rows(ctx, queries, nq, h->dim, h->dtype, h->geom, ctx->q_stage, &q_dev));
+    PGV_TRY(stage_flat(ctx, slot, sizeof(int32_t) * (size_t)npairs, ctx->idx_stage, &s_dev));
+    if (query_of) PGV_TRY(stage_flat(ctx, query_of, sizeof(int32_t) * (size_t)npairs, ctx->plan_d, &qo_dev));
+    OutArg od;
+    PGV_TRY(od.init(out, sizeof(float) * (size_t)npairs, ctx->out_stage));
+    PGV_TRY(launch_score_gather(ctx, h->metric, h->dtype, h->geom, h->elements, q_dev,
+                                static_cast<const int32_t *>(s_dev), static_cast<const int32_t *>(qo_dev),
+                                npairs, od.as<float>()));
+    bool need = false;
+    PGV_TRY(od.finish(ctx, &need));
+    return sync_if(ctx, need);
+}
+
+}  // extern "C"

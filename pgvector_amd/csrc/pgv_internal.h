@@ -1,0 +1,219 @@
+// pgv_internal.h -- shared declarations of libpgv_hip (host side + launchers).
+// gfx950 only; no other backend is supported or compiled.
+#pragma once
+
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <vector>
+
+#include "../../include/pgv_hip.h"
+
+namespace pgv {
+
+// ------------------------------------------------------------------ errors
+void set_error(const char *fmt, ...) __attribute__((format(printf, 1, 2)));
+
+#define PGV_FAIL(code, ...)            \
+    do {                               \
+        ::pgv::set_error(__VA_ARGS__); \
+        return (code);                 \
+    } while (0)
+
+#define PGV_HIP(call)                                                                  \
+    do {                                                                               \
+        hipError_t e__ = (call);                                                       \
+        if (e__ != hipSuccess) {                                                       \
+            ::pgv::set_error("%s failed: %s (%s:%d)", #call, hipGetErrorString(e__),   \
+                             __FILE__, __LINE__);                                      \
+            return e__ == hipErrorOutOfMemory ? PGV_ERR_NOMEM : PGV_ERR_DEVICE;        \
+        }                                                                              \
+    } while (0)
+
+#define PGV_TRY(call)          \
+    do {                       \
+        int rc__ = (call);     \
+        if (rc__ != PGV_OK)    \
+            return rc__;       \
+    } while (0)
+
+// ------------------------------------------------------------- device memory
+struct DBuf {  // growable device allocation, reused across calls
+    void *p = nullptr;
+    size_t cap = 0;
+    int ensure(size_t bytes);
+    void release();
+    template <typename T> T *as() const { return static_cast<T *>(p); }
+};
+
+struct HBuf {  // growable pinned host allocation
+    void *p = nullptr;
+    size_t cap = 0;
+    int ensure(size_t bytes);
+    void release();
+    template <typename T> T *as() const { return static_cast<T *>(p); }
+};
+
+bool is_device_ptr(const void *p);
+
+constexpr int kVecBytes = 16;  // every row is padded to whole 16-byte vectors in HBM
+
+inline int elem_size(pgv_dtype t) { return t == PGV_F32 ? 4 : 2; }
+// padded row length in elements
+inline int padded_dim(int dim, pgv_dtype t) {
+    int per = kVecBytes / elem_size(t);
+    return (dim + per - 1) / per * per;
+}
+
+// geometry of the streaming kernels for one row length (see kernels_scan.hip)
+struct RowGeom {
+    int ld;         // padded elements per row
+    int nvec;       // 16-byte vectors per row
+    int lpr_log2;   // lanes cooperating on one row = 1 << lpr_log2
+    int nchunks;    // loop trips over the row
+};
+RowGeom row_geom(int dim, pgv_dtype t);
+
+// one unit of streaming work: rows [row0, row0 + nrows) scored against
+// pairs [pair0, pair0 + npairs)
+struct ScanTask {
+    int64_t row0;
+    int32_t nrows;
+    int32_t pair0;
+    int32_t npairs;
+    int32_t pad;
+};
+// one (query, destination) of a task: distance of row r goes to out[out_rel + r]
+struct ScanPair {
+    int64_t out_rel;
+    int32_t query;
+    int32_t pad;
+};
+
+}  // namespace pgv
+
+// --------------------------------------------------------------- the context
+struct pgv_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    bool own_stream = false;
+    int num_cus = 256;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    // scratch (device)
+    pgv::DBuf q_stage, rows_stage, centers_stage, out_stage, out_stage2, idx_stage;
+    pgv::DBuf tasks, pairs, counters, plan_a, plan_b, plan_c, plan_d, dist_mat, sel_a, sel_b;
+    pgv::DBuf km_a, km_b, km_c, km_d, km_e, km_f, km_g;
+    // scratch (pinned host)
+    pgv::HBuf h_a, h_b, h_c;
+    // per-kernel profiling (pgv_ctx_set_profiling): HIP event pairs around the
+    // streaming kernel, resolved lazily in pgv_ctx_get_stats
+    bool profiling = false;
+    std::vector<hipEvent_t> ev_pool;  // start/stop pairs
+    size_t ev_used = 0;
+    double scan_ms = 0.0;
+    int64_t scan_launches = 0;
+    double scan_pairs = 0.0;  // (row, query) pairs scored by timed launches
+    double scan_rows = 0.0;   // rows streamed by timed launches
+    std::vector<char> ev_is_aux;  // per event pair: counts towards aux_* instead of scan_*
+    double aux_ms = 0.0;
+    int64_t aux_launches = 0;
+    double aux_pairs = 0.0;
+};
+
+struct pgv_index {
+    pgv_ctx *ctx = nullptr;
+    pgv_metric metric = PGV_L2SQ;
+    pgv_dtype dtype = PGV_F32;
+    int dim = 0;
+    int nlists = 0;
+    int64_t nrows = 0;
+    pgv::RowGeom geom{};
+    void *centers = nullptr;          // [nlists x ld]
+    void *vectors = nullptr;          // [nrows x ld]
+    int64_t *list_offsets = nullptr;  // device [nlists + 1]
+    uint64_t *tids = nullptr;         // device [nrows] or null
+    std::vector<int64_t> h_offsets;   // host copy
+    int64_t max_list_len = 0;
+};
+
+struct pgv_hnsw {
+    pgv_ctx *ctx = nullptr;
+    pgv_metric metric = PGV_L2SQ;
+    pgv_dtype dtype = PGV_F32;
+    int dim = 0;
+    int64_t n = 0;
+    pgv::RowGeom geom{};
+    void *elements = nullptr;  // [n x ld]
+};
+
+namespace pgv {
+
+// ---------------------------------------------------------------- launchers
+// kernels_scan.hip: stream rows, score them against small groups of queries
+int launch_scan(pgv_ctx *ctx, pgv_metric metric, pgv_dtype dtype, const RowGeom &g,
+                const void *rows, const void *queries, const ScanTask *tasks,
+                const int *ntasks_dev, int ntasks_bound, const ScanPair *pairs, int qt,
+                float *out);
+int scan_group_size(const RowGeom &g, pgv_dtype dtype, int wanted);
+// gathered variant (HNSW candidate scoring): pair i = (slot[i], query_of[i])
+int launch_score_gather(pgv_ctx *ctx, pgv_metric metric, pgv_dtype dtype, const RowGeom &g,
+                        const void *rows, const void *queries, const int32_t *slot,
+                        const int32_t *query_of, int64_t npairs, float *out);
+
+// kernels_pair.hip: n rows x k centers, both large: argmin per row
+int launch_argmin(pgv_ctx *ctx, pgv_metric metric, pgv_dtype dtype, const RowGeom &g,
+                  const void *rows, int64_t n, const void *centers, int k, int32_t *out_idx,
+                  float *out_val);
+// mode 0..2 = pgv_metric, 3 = spherical k-means (-clamp(ip))
+int launch_argmin_mode(pgv_ctx *ctx, int mode, pgv_dtype dtype, const RowGeom &g,
+                       const void *rows, int64_t n, const void *centers, int k,
+                       int32_t *out_idx, float *out_val);
+
+// kernels_select.hip: planning + top-k selection
+struct PlanResult {
+    ScanTask *tasks = nullptr;
+    ScanPair *pairs = nullptr;
+    int *ntasks_dev = nullptr;
+    int64_t ntasks = 0;
+    int64_t total_out = 0;        // sum of the queries' segment lengths
+    int64_t *seg_start = nullptr; // device [nq + 1]
+    int64_t *probe_off = nullptr; // device [nq x probes]
+};
+int launch_plan_batch(pgv_ctx *ctx, const pgv_index *ix, const int32_t *probe_lists, int nq,
+                      int probes, int qt, int rows_per_task, PlanResult *res);
+int launch_topk_segments(pgv_ctx *ctx, const float *vals, const int64_t *seg_start, int nseg,
+                         int64_t fixed_len, int k, float *out_val, int64_t *out_pos);
+int launch_positions_to_slots(pgv_ctx *ctx, const pgv_index *ix, const int32_t *probe_lists,
+                              const int64_t *probe_off, int nq, int probes, int k,
+                              const int64_t *pos, int64_t *out_slot, uint64_t *out_tid);
+int launch_iota_slots(pgv_ctx *ctx, const pgv_index *ix, const int32_t *lists_dev, int nlists,
+                      const int64_t *probe_off, int64_t *out_slot);
+
+// kernels_select.hip (small helpers)
+int launch_cast_pos_to_i32(pgv_ctx *ctx, const int64_t *pos, int64_t n, int32_t *out);
+
+// kernels_kmeans.hip
+int kmpp_block_count(int n);
+int launch_kmpp_update(pgv_ctx *ctx, const float *raw, float *weight, int n, int spherical,
+                       double *block_sums);
+int launch_kmpp_pick(pgv_ctx *ctx, const RowGeom &g, const void *samples, int n,
+                     const float *weight, const double *block_sums, const double *draws,
+                     int round, void *centers, int32_t *picked);
+int launch_changes_hist(pgv_ctx *ctx, const int32_t *closest_new, int32_t *closest_io, int n,
+                        int32_t *counts, unsigned long long *changes);
+int launch_members(pgv_ctx *ctx, const int32_t *closest, int n, int k, const int32_t *counts,
+                   int32_t *offsets, int32_t *members);
+int launch_center_sums(pgv_ctx *ctx, pgv_dtype dtype, const RowGeom &g, const void *samples,
+                       const int32_t *offsets, const int32_t *members, int k, float *sums);
+int launch_finish_centers(pgv_ctx *ctx, pgv_dtype dtype, const RowGeom &g, int k, int dim,
+                          const float *sums, const int32_t *counts, const float *refill,
+                          const int32_t *refill_row, void *centers);
+int launch_normalize_rows(pgv_ctx *ctx, pgv_dtype dtype, const RowGeom &g, void *rows, int64_t n,
+                          int dim, int32_t *flag);
+int launch_check_centers(pgv_ctx *ctx, pgv_dtype dtype, const RowGeom &g, const void *centers,
+                         int k, int dim, int check_zero_norm, int32_t *flag);
+
+}  // namespace pgv

@@ -1,0 +1,309 @@
+"""GPU parity: libpgv_hip (through its C ABI) against the CPU oracle on the same
+seeded inputs.  Integer/index results exact, distances within 1e-5 relative
+(north_star), row ids identical wherever the reference's order is determined."""
+import math
+
+import numpy as np
+import pytest
+
+import pgvector_amd
+from oracle import pyoracle as po
+from pgvector_amd import api
+
+from helpers import RTOL, CpuIvf, assert_close, assert_topk_equiv, gen, golden, normalize_rows
+
+pytestmark = pytest.mark.gpu
+
+DT = {po.ORA_F32: api.PGV_F32, po.ORA_F16: api.PGV_F16}
+
+
+def ora_dist(oracle, ops, dtype, q, rows):
+    return np.array([oracle.lib.ora_index_distance(ops, dtype, rows.shape[1], po._p(r), po._p(q)) for r in rows])
+
+
+# ------------------------------------------------------------ raw distances
+@pytest.mark.parametrize("dtype", [po.ORA_F32, po.ORA_F16])
+@pytest.mark.parametrize("dim", [1, 2, 3, 5, 9, 16, 31, 100, 128, 384, 768, 1000, 1536, 2000, 3072, 4000])
+def test_distance_batch_all_metrics(ctx, oracle, dtype, dim):
+    n = 257 if dim > 1000 else 1031
+    rows = gen(n, dim, seed=dim, dist="normal", dtype=dtype)
+    q = gen(1, dim, seed=dim + 1, dist="normal", dtype=dtype)[0]
+    for metric, ops in [(api.PGV_L2SQ, po.OPS_L2), (api.PGV_NEG_IP, po.OPS_IP), (api.PGV_L1, po.OPS_L1)]:
+        got = api.distance_batch(ctx, metric, DT[dtype], dim, q, rows)
+        want = ora_dist(oracle, ops, dtype, q, rows)
+        # inner products of normal data cancel: tolerance relative to the magnitude of the terms
+        scale = np.abs(rows.astype(np.float64)) @ np.abs(q.astype(np.float64)) if metric == api.PGV_NEG_IP else 0.0
+        assert_close(got, want, rtol=RTOL, atol=RTOL * np.max(scale), what="metric %d dim %d" % (metric, dim))
+
+
+def test_known_answers_through_the_gpu(ctx, oracle):
+    """the reference's SQL known answers (test/expected/vector_type.out, halfvec.out):
+    kernel value from the GPU, float8 post-processing as the fmgr wrapper does it"""
+    n_checked = 0
+    for case in golden("distance_known_answers.json")["cases"]:
+        f = case["func"]
+        if "error" in case or f not in ("l2_distance", "inner_product", "negative_inner_product", "l1_distance"):
+            continue
+        dtype = po.ORA_F16 if case["type"] == "halfvec" else po.ORA_F32
+        a = np.asarray(case["args"][0], dtype=po.NP_OF[dtype])
+        b = np.asarray(case["args"][1], dtype=po.NP_OF[dtype])
+        metric = {"l2_distance": api.PGV_L2SQ, "l1_distance": api.PGV_L1}.get(f, api.PGV_NEG_IP)
+        raw = float(api.distance_batch(ctx, metric, DT[dtype], len(a), b, a[None, :])[0])
+        got = {"l2_distance": lambda v: math.sqrt(v), "inner_product": lambda v: -v}.get(f, lambda v: v)(raw)
+        want = {"inf": math.inf, "-inf": -math.inf, "nan": math.nan}.get(case["expect"], case["expect"])
+        assert got == want or (math.isnan(got) and math.isnan(want)), (case, got)
+        n_checked += 1
+    assert n_checked >= 20
+
+
+def test_overflow_is_not_trapped(ctx):
+    """l2_distance([3e38],[-3e38]) = Infinity (vector_type.out:387-391)"""
+    rows = np.array([[-3e38], [3e38]], dtype=np.float32)
+    q = np.array([3e38], dtype=np.float32)
+    got = api.distance_batch(ctx, api.PGV_L2SQ, api.PGV_F32, 1, q, rows)
+    assert np.isinf(got[0]) and got[1] == 0.0
+
+
+def test_device_and_host_buffers_agree(ctx):
+    import torch
+    rows = gen(3000, 768, seed=5)
+    q = gen(1, 768, seed=6)[0]
+    host = api.distance_batch(ctx, api.PGV_L2SQ, api.PGV_F32, 768, q, rows)
+    dev = api.distance_batch(ctx, api.PGV_L2SQ, api.PGV_F32, 768, torch.from_numpy(q).cuda(),
+                             torch.from_numpy(rows).cuda())
+    ctx.sync()
+    np.testing.assert_array_equal(host, dev.cpu().numpy())
+
+
+# ------------------------------------------------------------------ IVF scan
+def _upload(ctx, ivf):
+    return api.IvfIndex(ctx, ivf.metric, DT[ivf.dtype], ivf.vectors.shape[1], ivf.centers, ivf.list_offsets,
+                        ivf.vectors, ivf.tids)
+
+
+@pytest.fixture(scope="module")
+def small_ivf(oracle):
+    data = gen(20000, 64, seed=11, dist="clustered", clusters=40)
+    return CpuIvf(oracle, po.OPS_L2, po.ORA_F32, data, 50)
+
+
+def test_rank_lists_matches_get_scan_lists(ctx, oracle, small_ivf):
+    ix = _upload(ctx, small_ivf)
+    queries = gen(33, 64, seed=12, dist="clustered", clusters=40)
+    for probes in (1, 7, 50):
+        lists, dist = ix.rank_lists(queries, probes)
+        for i, q in enumerate(queries):
+            wl, wd = oracle.get_scan_lists(small_ivf.struct, q, probes)
+            assert_topk_equiv(lists[i], dist[i], wl, wd, what="rank_lists probes=%d q=%d" % (probes, i))
+
+
+def test_rank_lists_tie_rule(ctx):
+    """equal distances on the boundary keep the lower list id (src/ivfscan.c:92)"""
+    centers = np.array([[0, 0], [1, 0], [1, 0], [5, 5], [0.5, 0], [1, 0]], dtype=np.float32)
+    off = np.arange(7, dtype=np.int64)
+    ix = api.IvfIndex(ctx, api.PGV_L2SQ, api.PGV_F32, 2, centers, off, centers)
+    lists, dist = ix.rank_lists(np.array([[0, 0]], dtype=np.float32), 3)
+    assert lists[0].tolist() == [0, 4, 1] and dist[0].tolist() == [0.0, 0.25, 1.0]
+    lists, _ = ix.rank_lists(np.array([[1, 0]], dtype=np.float32), 2)
+    assert lists[0].tolist() == [1, 2]
+
+
+def test_scan_lists_order_and_values(ctx, oracle, small_ivf):
+    ix = _upload(ctx, small_ivf)
+    q = gen(1, 64, seed=13, dist="clustered", clusters=40)[0]
+    lists, _ = oracle.get_scan_lists(small_ivf.struct, q, 5)
+    dist, slot = ix.scan_lists(q, lists)
+    # unsorted: exactly the order the reference feeds its tuplesort
+    want_slots = np.concatenate([np.arange(small_ivf.list_offsets[l], small_ivf.list_offsets[l + 1]) for l in lists])
+    np.testing.assert_array_equal(slot, want_slots)
+    assert_close(dist, ora_dist(oracle, po.OPS_L2, po.ORA_F32, q, small_ivf.vectors[want_slots]), what="scan_lists")
+    # after the host-side sort it is GetScanItems
+    wd, ws = oracle.get_scan_items(small_ivf.struct, q, lists)
+    order = np.argsort(dist.astype(np.float64), kind="stable")
+    assert_topk_equiv(slot[order], dist[order], ws, wd, what="scan items sorted")
+
+
+def test_scan_lists_null_query_and_empty_lists(ctx, oracle):
+    data = gen(50, 8, seed=1)
+    centers = gen(6, 8, seed=2)
+    ivf = CpuIvf(oracle, po.OPS_L2, po.ORA_F32, data, 6, centers=centers)
+    ix = _upload(ctx, ivf)
+    dist, slot = ix.scan_lists(None, np.arange(6))  # NULL query: ZeroDistance, all rows
+    assert len(dist) == 50 and (dist == 0).all() and sorted(slot.tolist()) == list(range(50))
+    empty = [l for l in range(6) if ivf.list_offsets[l + 1] == ivf.list_offsets[l]]
+    dist, slot = ix.scan_lists(data[0], np.array(empty, dtype=np.int32))
+    assert len(dist) == 0
+
+
+@pytest.mark.parametrize("ops,dtype,dim", [(po.OPS_L2, po.ORA_F32, 64), (po.OPS_IP, po.ORA_F32, 96),
+                                           (po.OPS_COSINE, po.ORA_F32, 100), (po.OPS_L2, po.ORA_F16, 128),
+                                           (po.OPS_COSINE, po.ORA_F16, 72)])
+def test_search_batch_matches_reference_scan(ctx, oracle, ops, dtype, dim):
+    data = gen(12000, dim, seed=21, dist="clustered", clusters=30, dtype=dtype)
+    ivf = CpuIvf(oracle, ops, dtype, data, 40)
+    ix = _upload(ctx, ivf)
+    queries = gen(64, dim, seed=22, dist="clustered", clusters=30, dtype=dtype)
+    gq = normalize_rows(oracle, queries, dtype) if ops == po.OPS_COSINE else queries  # GetScanValue :222-229
+    for probes, k in [(1, 10), (4, 10), (40, 25)]:
+        dist, slot, tid = ix.search_batch(gq, probes, k, want_tid=True)
+        for i in range(len(queries)):
+            wt, wd = oracle.search(ivf.struct, queries[i], probes, k)
+            got_t = tid[i][slot[i] >= 0]
+            assert_topk_equiv(got_t.tolist(), dist[i][:len(got_t)], wt.tolist(), wd,
+                              what="ops %d probes %d q %d" % (ops, probes, i))
+
+
+def test_search_batch_exact_when_probing_every_list(ctx, oracle):
+    """probes = lists is an exact scan: returned row ids must equal brute force"""
+    data = gen(5000, 32, seed=31)
+    ivf = CpuIvf(oracle, po.OPS_L2, po.ORA_F32, data, 16)
+    ix = _upload(ctx, ivf)
+    queries = gen(20, 32, seed=32)
+    dist, slot, _ = ix.search_batch(queries, 16, 10)
+    for i, q in enumerate(queries):
+        d = ((ivf.vectors.astype(np.float64) - q) ** 2).sum(axis=1)
+        want = np.argsort(d, kind="stable")[:10]
+        assert_topk_equiv(slot[i].tolist(), dist[i], want.tolist(), d[want], what="exact q %d" % i)
+
+
+def test_search_batch_short_lists_pad(ctx, oracle):
+    data = gen(30, 4, seed=41)
+    ivf = CpuIvf(oracle, po.OPS_L2, po.ORA_F32, data, 10, centers=gen(10, 4, seed=42))
+    ix = _upload(ctx, ivf)
+    dist, slot, _ = ix.search_batch(data[:3], 1, 20)
+    for i in range(3):
+        lists, _ = oracle.get_scan_lists(ivf.struct, data[i], 1)
+        m = int(ivf.list_offsets[lists[0] + 1] - ivf.list_offsets[lists[0]])
+        assert (slot[i][m:] == -1).all() and np.isinf(dist[i][m:]).all() and (slot[i][:m] >= 0).all()
+
+
+# ---------------------------------------------------------------------- build
+@pytest.mark.parametrize("ops,dtype,dim,k", [(po.OPS_L2, po.ORA_F32, 48, 37), (po.OPS_IP, po.ORA_F32, 130, 200),
+                                             (po.OPS_L2, po.ORA_F16, 64, 129), (po.OPS_L2, po.ORA_F32, 3, 5)])
+def test_assign_matches_add_tuple_to_sort(ctx, oracle, ops, dtype, dim, k):
+    rows = gen(3001, dim, seed=51, dist="clustered", dtype=dtype)
+    centers = gen(k, dim, seed=52, dist="clustered", dtype=dtype)
+    metric = api.PGV_L2SQ if ops == po.OPS_L2 else api.PGV_NEG_IP
+    got, gd = api.assign(ctx, metric, DT[dtype], dim, centers, rows)
+    want, wd = oracle.assign(ops, dtype, centers, rows)
+    assert_close(gd, wd, atol=RTOL * dim, what="assign distance")
+    diff = np.nonzero(got != want)[0]
+    for r in diff:  # a different list is only acceptable on a float-level tie
+        d = np.array([oracle.lib.ora_index_distance(ops, dtype, dim, po._p(rows[r]), po._p(centers[c]))
+                      for c in (got[r], want[r])])
+        assert abs(d[0] - d[1]) <= 4 * RTOL * max(abs(d).max(), 1e-30), (r, got[r], want[r], d)
+    assert len(diff) <= max(1, len(rows) // 500)
+
+
+def test_assign_exact_on_integer_data(ctx, oracle):
+    """integer-valued data makes fp32 arithmetic exact: list ids must be identical,
+    including the first-minimum-wins rule on real ties (src/ivfbuild.c:187-191)"""
+    rows = gen(2000, 16, seed=61, dist="int")
+    centers = gen(300, 16, seed=62, dist="int")
+    centers[7] = centers[3]  # duplicate center: the lower id must win
+    got, gd = api.assign(ctx, api.PGV_L2SQ, api.PGV_F32, 16, centers, rows)
+    want, wd = oracle.assign(po.OPS_L2, po.ORA_F32, centers, rows)
+    np.testing.assert_array_equal(got, want)
+    np.testing.assert_array_equal(gd.astype(np.float64), wd)
+
+
+def test_kmeanspp_picks_match_on_exact_data(ctx, oracle):
+    """integer data -> identical distances -> the D^2 sampling walk (src/ivfkmeans.c:77-84)
+    must pick the same samples given the same pg_prng stream"""
+    samples = gen(1500, 8, seed=71, dist="int")
+    st = oracle.prng(99)
+    import ctypes as C
+    rng = api.make_rng(next_double=oracle.lib.ora_prng_double_cb, next_u32=oracle.lib.ora_prng_u32_cb,
+                       state=C.cast(C.pointer(st), C.c_void_p))
+    got = api.kmeanspp_init(ctx, api.PGV_OPS_L2, api.PGV_F32, 8, samples, 40, rng)
+    want = oracle.kmeans_init_centers(po.OPS_L2, po.ORA_F32, samples, 40, oracle.prng(99))
+    np.testing.assert_array_equal(got, want)
+
+
+@pytest.mark.parametrize("ops,dtype", [(po.OPS_L2, po.ORA_F32), (po.OPS_IP, po.ORA_F32), (po.OPS_L2, po.ORA_F16),
+                                       (po.OPS_COSINE, po.ORA_F16)])
+def test_one_lloyd_step_from_given_centers(ctx, oracle, ops, dtype):
+    """assignment identical (up to float ties), new centers within 1e-5 (SURVEY hard part 3)"""
+    dim, k = 24, 30
+    samples = gen(4000, dim, seed=81, dist="clustered", clusters=k, dtype=dtype)
+    if ops != po.OPS_L2:
+        samples = normalize_rows(oracle, samples, dtype)
+    centers = np.ascontiguousarray(samples[np.random.default_rng(82).choice(len(samples), k, replace=False)])
+    closest = np.full(len(samples), -1, dtype=np.int32)
+    pops = {po.OPS_L2: api.PGV_OPS_L2, po.OPS_IP: api.PGV_OPS_IP, po.OPS_COSINE: api.PGV_OPS_COSINE}[ops]
+    sums, counts, changes = api.lloyd_partial(ctx, pops, DT[dtype], dim, samples, centers, closest)
+    want_closest, _ = oracle.lloyd_assign(ops, dtype, samples, centers)
+    assert (closest != want_closest).sum() <= 2
+    assert int(changes[0]) == len(samples)
+    np.testing.assert_array_equal(counts, np.bincount(closest, minlength=k))
+    # sums in sample order are bit-exact against the reference's SumCenters given the same assignment
+    want_centers, want_counts = oracle.kmeans_compute_new_centers(ops, dtype, samples, closest, k, oracle.prng(1))
+    got_centers = api.lloyd_finish(ctx, pops, DT[dtype], dim, sums, counts, api.make_rng(seed=1))
+    np.testing.assert_array_equal(counts, want_counts)
+    assert_close(got_centers.astype(np.float64), want_centers.astype(np.float64), rtol=RTOL,
+                 atol=1e-3 if dtype == po.ORA_F16 else 1e-7, what="new centers")
+
+
+def test_kmeans_end_to_end_quality_and_rules(ctx, oracle):
+    """statistical parity (SURVEY hard part 3): same stopping rule, inertia no worse than
+    the reference's Elkan k-means from the same seed stream by more than a few %"""
+    import ctypes as C
+    dim, k = 16, 25
+    samples = gen(5000, dim, seed=91, dist="clustered", clusters=k)
+    st = oracle.prng(7)
+    rng = api.make_rng(next_double=oracle.lib.ora_prng_double_cb, next_u32=oracle.lib.ora_prng_u32_cb,
+                       state=C.cast(C.pointer(st), C.c_void_p))
+    centers, closest, iters = api.kmeans(ctx, api.PGV_OPS_L2, api.PGV_F32, dim, samples, k, rng)
+    wc, wcl, wit = oracle.kmeans(po.OPS_L2, po.ORA_F32, samples, k, oracle.prng(7))
+    assert 1 <= iters <= 500 and np.isfinite(centers).all()
+
+    def inertia(c, a):
+        return float(((samples.astype(np.float64) - c[a].astype(np.float64)) ** 2).sum())
+    assert inertia(centers, closest) <= 1.05 * inertia(wc, wcl)
+    # converged: one more assignment changes nothing
+    again, _ = oracle.lloyd_assign(po.OPS_L2, po.ORA_F32, samples, centers)
+    assert (again != closest).mean() < 0.002
+
+
+def test_kmeans_degenerate_inputs(ctx):
+    """test/t/008_ivfflat_centers.pl: duplicates / more lists than points; no samples -> RandomCenters"""
+    data = np.tile(np.array([[1, 2, 3]], dtype=np.float32), (30, 1))
+    centers, closest, iters = api.kmeans(ctx, api.PGV_OPS_L2, api.PGV_F32, 3, data, 5, api.make_rng(seed=1))
+    assert np.isfinite(centers).all() and iters >= 1 and (closest == closest[0]).all()
+    centers, _, iters = api.kmeans(ctx, api.PGV_OPS_L2, api.PGV_F32, 3, np.zeros((0, 3), np.float32), 4,
+                                   api.make_rng(seed=1))
+    assert iters == 0 and (centers >= 0).all() and (centers < 1).all()
+    centers, _, _ = api.kmeans(ctx, api.PGV_OPS_COSINE, api.PGV_F32, 3, np.zeros((0, 3), np.float32), 4,
+                               api.make_rng(seed=1))
+    np.testing.assert_allclose(np.linalg.norm(centers, axis=1), 1.0, rtol=1e-6)
+
+
+# ----------------------------------------------------------------------- HNSW
+def test_hnsw_score_gathers(ctx, oracle):
+    dim = 200
+    elems = gen(5000, dim, seed=101, dist="normal")
+    queries = gen(7, dim, seed=102, dist="normal")
+    rng = np.random.default_rng(103)
+    slot = rng.integers(0, 5000, 999).astype(np.int32)
+    qof = rng.integers(0, 7, 999).astype(np.int32)
+    for metric, ops in [(api.PGV_L2SQ, po.OPS_L2), (api.PGV_NEG_IP, po.OPS_IP), (api.PGV_L1, po.OPS_L1)]:
+        h = api.Hnsw(ctx, metric, api.PGV_F32, dim, elems)
+        got = h.score(queries, slot, qof)
+        want = np.array([oracle.lib.ora_index_distance(ops, po.ORA_F32, dim, po._p(queries[q]), po._p(elems[s]))
+                         for s, q in zip(slot, qof)])
+        assert_close(got, want, rtol=RTOL, atol=RTOL * 50, what="hnsw score metric %d" % metric)
+        h.close()
+
+
+# -------------------------------------------------------------- API contracts
+def test_argument_errors(ctx):
+    with pytest.raises(pgvector_amd.PgvError) as e:
+        api.distance_batch(ctx, api.PGV_L2SQ, api.PGV_F32, 16001, np.zeros(16001, np.float32),
+                           np.zeros((1, 16001), np.float32))
+    assert e.value.code == pgvector_amd._lib.PGV_ERR_DIMS
+    centers = np.zeros((3, 4), np.float32)
+    ix = api.IvfIndex(ctx, api.PGV_L2SQ, api.PGV_F32, 4, centers, np.array([0, 1, 2, 3]), centers)
+    with pytest.raises(pgvector_amd.PgvError):
+        ix.rank_lists(np.zeros((1, 4), np.float32), 4)  # maxprobes > lists must be clamped by the caller
+    with pytest.raises(pgvector_amd.PgvError):
+        api.IvfIndex(ctx, api.PGV_L2SQ, api.PGV_F32, 4, centers, np.array([0, 2, 1, 3]), centers)

@@ -1,0 +1,230 @@
+"""CPU tests pinning the oracle: reference known-answer vectors, the reference's
+own fp16 kernels (oracle/_ref), and the index-order transcripts."""
+import math
+import os
+
+import numpy as np
+import pytest
+
+from oracle import pyoracle as po
+
+from helpers import CpuIvf, gen, golden
+
+SQL_VECTOR = {"l2_distance": "ora_l2_distance", "inner_product": "ora_inner_product",
+              "negative_inner_product": "ora_negative_inner_product",
+              "cosine_distance": "ora_cosine_distance", "l1_distance": "ora_l1_distance"}
+SQL_HALF = {"l2_distance": "ora_halfvec_l2_distance", "inner_product": "ora_halfvec_inner_product_f8",
+            "negative_inner_product": "ora_halfvec_negative_inner_product",
+            "cosine_distance": "ora_halfvec_cosine_distance", "l1_distance": "ora_halfvec_l1_distance"}
+
+
+def _expect(v):
+    return {"inf": math.inf, "-inf": -math.inf, "nan": math.nan}.get(v, v) if isinstance(v, str) else v
+
+
+def _apply_wrap(value, wrap):
+    if not wrap:
+        return value
+    if wrap[0] == "round":
+        return round(value, wrap[1])
+    if wrap[0] == "real":
+        return float(np.float32(value))
+    raise AssertionError(wrap)
+
+
+CASES = golden("distance_known_answers.json")["cases"]
+
+
+@pytest.mark.parametrize("case", CASES, ids=[c["source"].split("/")[-1] for c in CASES])
+def test_known_answers(oracle, case):
+    half = case["type"] == "halfvec"
+    dt = po.ORA_F16 if half else po.ORA_F32
+    func, args = case["func"], case["args"]
+    if func in ("vector_norm", "l2_norm"):
+        a = oracle.arr(args[0], dt)
+        got = (oracle.lib.ora_halfvec_l2_norm if half else oracle.lib.ora_vector_norm)(len(a), po._p(a))
+        assert _apply_wrap(got, case.get("wrap")) == pytest.approx(_expect(case["expect"]), rel=1e-6)
+        return
+    if func == "l2_normalize":
+        a = oracle.arr(args[0], dt)
+        out = np.zeros_like(a)
+        rc = (oracle.lib.ora_halfvec_l2_normalize if half else oracle.lib.ora_l2_normalize)(len(a), po._p(a), po._p(out))
+        if "error" in case:
+            assert rc != 0
+        else:
+            assert rc == 0
+            # psql prints the shortest decimal that round-trips in the element type
+            want = np.asarray(case["expect"], dtype=po.NP_OF[dt])
+            np.testing.assert_array_equal(out, want)
+        return
+    rc, got = oracle.sql((SQL_HALF if half else SQL_VECTOR)[func], args[0], args[1], half=half)
+    if "error" in case:
+        assert rc == 1 and oracle.last_error() == case["error"]
+        return
+    assert rc == 0
+    want = _expect(case["expect"])
+    if isinstance(want, float) and math.isnan(want):
+        assert math.isnan(got)
+    else:
+        assert got == want, (case, got)
+
+
+def test_cross_type_equality(oracle):
+    """test/t/034_distance_functions.pl:36-52: on integer-valued 5-d vectors halfvec
+    results equal vector results exactly"""
+    rng = np.random.default_rng(34)
+    data = rng.integers(0, 10, (500, 5)).astype(np.float32)
+    queries = rng.integers(0, 10, (20, 5)).astype(np.float32)
+    pairs = [("ora_l2_distance", "ora_halfvec_l2_distance"), ("ora_inner_product", "ora_halfvec_inner_product_f8"),
+             ("ora_cosine_distance", "ora_halfvec_cosine_distance"), ("ora_l1_distance", "ora_halfvec_l1_distance")]
+    for q in queries:
+        for r in data[:100]:
+            for fv, fh in pairs:
+                _, a = oracle.sql(fv, r, q)
+                _, b = oracle.sql(fh, r, q, half=True)
+                assert a == b or (math.isnan(a) and math.isnan(b)), (fv, r, q, a, b)
+
+
+@pytest.mark.skipif(not os.path.exists(os.path.join(po.HERE, "_ref", "libpgvref.so")),
+                    reason="oracle/_ref not built (reference tree absent)")
+def test_fp16_kernels_match_reference_object(oracle):
+    """the restated fp16 kernels against the reference's own halfutils.c, bit for bit"""
+    ref = po.Ref()
+    rng = np.random.default_rng(16)
+    for dim in (1, 2, 3, 7, 8, 9, 15, 16, 17, 64, 100, 127, 128, 1000, 3072):
+        for scale in (1.0, 100.0, 1e-3):
+            a = (rng.standard_normal(dim) * scale).astype(np.float16)
+            b = (rng.standard_normal(dim) * scale).astype(np.float16)
+            for mine, theirs in [("ora_halfvec_l2_squared", "pgvref_halfvec_l2_squared"),
+                                 ("ora_halfvec_inner_product", "pgvref_halfvec_inner_product"),
+                                 ("ora_halfvec_cosine_similarity", "pgvref_halfvec_cosine_similarity"),
+                                 ("ora_halfvec_l1", "pgvref_halfvec_l1")]:
+                x, y = oracle.kernel(mine, a, b, half=True), ref.kernel(theirs, a, b)
+                assert x == y or (math.isnan(x) and math.isnan(y)), (mine, dim, scale, x, y)
+    # every binary16 value converts like the reference's HalfToFloat4, and back
+    for h in range(0, 65536, 7):
+        x, y = oracle.lib.ora_half_to_float(h), ref.lib.pgvref_half_to_float(h)
+        assert x == y or (math.isnan(x) and math.isnan(y))
+    for f in np.concatenate([rng.standard_normal(2000) * 10.0 ** rng.integers(-9, 6, 2000),
+                             [0.0, -0.0, 65504.0, 65519.9, 65520.0, 1e-8, 5.96e-8, 2.98e-8, np.inf, -np.inf]]):
+        f = float(np.float32(f))
+        assert oracle.lib.ora_float_to_half(f) == ref.lib.pgvref_float_to_half(f), f
+
+
+def test_fp32_kernels_against_float64(oracle):
+    """the fp32 kernels stay within fp32 round-off of an exact float64 evaluation"""
+    rng = np.random.default_rng(32)
+    for dim in (1, 3, 9, 128, 768, 1536, 2000):
+        a, b = rng.random(dim, dtype=np.float32), rng.random(dim, dtype=np.float32)
+        a64, b64 = a.astype(np.float64), b.astype(np.float64)
+        assert oracle.kernel("ora_vector_l2_squared", a, b) == pytest.approx(((a64 - b64) ** 2).sum(), rel=1e-5)
+        assert oracle.kernel("ora_vector_inner_product", a, b) == pytest.approx((a64 * b64).sum(), rel=1e-5)
+        assert oracle.kernel("ora_vector_l1", a, b) == pytest.approx(np.abs(a64 - b64).sum(), rel=1e-5)
+
+
+def _rows_as(dtype, rows):
+    return np.asarray(rows, dtype=po.NP_OF[dtype])
+
+
+INDEX_CASES = [c for c in golden("index_order.json")["cases"] if c["am"] == "ivfflat"]
+
+
+@pytest.mark.parametrize("case", INDEX_CASES, ids=[c["source"].split("/")[-1] for c in INDEX_CASES])
+def test_ivfflat_transcripts(oracle, case):
+    """test/expected/ivfflat_vector.out / ivfflat_halfvec.out replayed on the oracle's
+    restatement of the build (k-means + assignment) and scan loops"""
+    dtype = po.ORA_F16 if case["type"] == "halfvec" else po.ORA_F32
+    ops = {"l2": po.OPS_L2, "ip": po.OPS_IP, "cosine": po.OPS_COSINE}[case["ops"]]
+    rows = _rows_as(dtype, case["rows"])
+    # the index is created over the first three rows + NULL, the 4th is inserted afterwards
+    # (src/ivfinsert.c: nearest list, appended) -- with lists=1 the layout is the same
+    built_on = rows[:3]
+    if ops == po.OPS_COSINE:
+        built_on = built_on[np.abs(built_on.astype(np.float32)).sum(axis=1) > 0]
+    samples = built_on
+    if ops in (po.OPS_IP, po.OPS_COSINE):
+        from helpers import normalize_rows
+        samples = normalize_rows(oracle, np.ascontiguousarray(samples), dtype)
+        samples = samples[np.abs(samples.astype(np.float32)).sum(axis=1) > 0]
+    centers, _, it = oracle.kmeans(ops, dtype, samples, case["lists"], oracle.prng(42))
+    assert it >= 0
+    ivf = CpuIvf(oracle, ops, dtype, rows, case["lists"], centers=centers)
+    stored = ivf.vectors
+    orig = rows[ivf.heap_ids]
+
+    def run(query, probes, k=100):
+        tids, dist = oracle.search(ivf.struct, None if query is None else _rows_as(dtype, query), probes, k)
+        slots = [int(np.where(ivf.tids == t)[0][0]) for t in tids]
+        return [orig[s].astype(np.float32).tolist() for s in slots]
+
+    if "self_nearest" in case:
+        for v in case["self_nearest"]:
+            assert run(v, case["probes"], k=1) == [[float(x) for x in v]]
+        return
+    if case.get("iterative"):
+        # relaxed_order: batches of `probes` lists until max_probes lists were scanned
+        # (src/ivfscan.c:400-406); every batch is sorted on its own
+        lists, _ = oracle.get_scan_lists(ivf.struct, _rows_as(dtype, case["query"]), case["max_probes"])
+        got = []
+        for i in range(0, len(lists), case["probes"]):
+            d, s = oracle.get_scan_items(ivf.struct, _rows_as(dtype, case["query"]), lists[i:i + case["probes"]])
+            got += [orig[x].astype(np.float32).tolist() for x in s]
+        assert got == [[float(x) for x in v] for v in case["expect"]]
+        return
+    got = run(case["query"], case["probes"])
+    if "expect_count" in case:
+        assert len(got) == case["expect_count"]
+    else:
+        assert got == [[float(x) for x in v] for v in case["expect"]]
+    assert stored.shape[0] == len(ivf.heap_ids)
+
+
+def test_scan_lists_rules(oracle):
+    """GetScanLists (src/ivfscan.c:47-118): ascending, strict-< replacement, clamp to lists"""
+    centers = np.array([[0, 0], [1, 0], [1, 0], [5, 5], [0.5, 0]], dtype=np.float32)
+    off = np.arange(6, dtype=np.int64)
+    ix = oracle.index_struct(po.OPS_L2, po.ORA_F32, centers, off, centers)
+    lists, dist = oracle.get_scan_lists(ix, np.array([1, 0], dtype=np.float32), 2)
+    assert lists.tolist() == [1, 2] and dist.tolist() == [0.0, 0.0]
+    lists, dist = oracle.get_scan_lists(ix, np.array([0, 0], dtype=np.float32), 3)
+    assert lists.tolist() == [0, 4, 1]  # the tie between lists 1 and 2 keeps the earlier one
+    lists, _ = oracle.get_scan_lists(ix, np.array([0, 0], dtype=np.float32), 99)
+    assert len(lists) == 5
+    lists, dist = oracle.get_scan_lists(ix, None, 3)  # NULL query: ZeroDistance
+    assert dist.tolist() == [0.0, 0.0, 0.0]
+
+
+def test_assign_first_minimum_wins(oracle):
+    centers = np.array([[1, 1], [1, 1], [0, 0]], dtype=np.float32)
+    rows = np.array([[1, 1], [0, 0], [0.5, 0.5]], dtype=np.float32)
+    lists, dist = oracle.assign(po.OPS_L2, po.ORA_F32, centers, rows)
+    assert lists.tolist() == [0, 2, 0] and dist.tolist() == [0.0, 0.0, 0.5]
+
+
+def test_kmeans_recall_floor(oracle):
+    """test/t/003_ivfflat_vector_build_recall.pl, scaled down: 3-d uniform data, k=20,
+    probes = lists must give recall 1.0 (exhaustive) and probes=10% a decent floor"""
+    data = gen(4000, 3, seed=1)
+    ivf = CpuIvf(oracle, po.OPS_L2, po.ORA_F32, data, 20)
+    queries = gen(10, 3, seed=2)
+    for q in queries:
+        exact = np.argsort(((data.astype(np.float64) - q) ** 2).sum(axis=1), kind="stable")[:20]
+        tids, _ = oracle.search(ivf.struct, q, 20, 20)
+        got = set(int(t >> np.uint64(16)) for t in tids)
+        assert got == set(exact.tolist())
+
+
+def test_kmeans_handles_duplicates_and_little_data(oracle):
+    """test/t/008_ivfflat_centers.pl: more lists than distinct points must not fail"""
+    data = np.tile(np.array([[1, 2, 3]], dtype=np.float32), (30, 1))
+    centers, closest, it = oracle.kmeans(po.OPS_L2, po.ORA_F32, data, 5, oracle.prng(1))
+    assert it >= 1 and np.isfinite(centers).all()
+    centers, closest, it = oracle.kmeans(po.OPS_L2, po.ORA_F32, np.zeros((0, 3), np.float32), 4, oracle.prng(1))
+    assert it == 0 and centers.shape == (4, 3) and (centers >= 0).all() and (centers < 1).all()
+
+
+def test_prng_is_deterministic(oracle):
+    a, b = oracle.prng(42), oracle.prng(42)
+    xs = [oracle.lib.ora_prng_double(a) for _ in range(5)]
+    assert xs == [oracle.lib.ora_prng_double(b) for _ in range(5)]
+    assert all(0.0 <= x < 1.0 for x in xs) and len(set(xs)) == 5
