@@ -9,6 +9,17 @@ PGV_ERR_DEVICE and is raised as PgvError.
 import ctypes as C
 import os
 
+# The Python harness keeps data in HBM through PyTorch, whose wheel bundles its
+# own HIP runtime (same soname, libamdhip64.so.7).  Two HIP runtimes cannot
+# share one process, so when torch is installed it is imported FIRST and the
+# dynamic loader then binds libpgv_hip.so to that already-loaded runtime.  A
+# Postgres backend has no torch: there the library binds to /opt/rocm's
+# runtime through its RUNPATH.  Nothing else from torch is used here.
+try:
+    import torch  # noqa: F401
+except ImportError:  # pragma: no cover
+    torch = None
+
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "lib", "libpgv_hip.so")
 

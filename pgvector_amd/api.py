@@ -5,6 +5,7 @@ library itself decides per pointer whether to stage it.  Nothing here computes
 a distance: every function forwards to libpgv_hip.so.
 """
 import ctypes as C
+import weakref
 
 import numpy as np
 
@@ -64,9 +65,18 @@ class Context:
         h = C.c_void_p()
         check(lib.pgv_ctx_create(device, C.c_void_p(stream) if stream else None, C.byref(h)))
         self.h = h
+        self._children = []  # weakrefs: index/hnsw handles must be freed before their context
+
+    def _adopt(self, child):
+        self._children.append(weakref.ref(child))
 
     def close(self):
         if self.h:
+            for ref in self._children:
+                child = ref()
+                if child is not None:
+                    child.close()
+            self._children = []
             lib.pgv_ctx_destroy(self.h)
             self.h = None
 
@@ -120,6 +130,7 @@ class IvfIndex:
         check(lib.pgv_index_upload(ctx.h, metric, dtype, dim, self.nlists, ptr(centers),
                                    ptr(list_offsets), ptr(vectors), ptr(tids), C.byref(h)))
         self.h = h
+        ctx._adopt(self)
 
     def close(self):
         if self.h:
@@ -247,6 +258,7 @@ class Hnsw:
         check(lib.pgv_hnsw_upload(ctx.h, metric, dtype, dim, ptr(elements), int(elements.shape[0]),
                                   C.byref(h)))
         self.h = h
+        ctx._adopt(self)
 
     def close(self):
         if self.h:
