@@ -83,30 +83,46 @@ __global__ __launch_bounds__(kScanThreads) void scan_kernel(
                 rp[r] = task_rows + (size_t)row * row_bytes;
             }
 
+            // Software-pipelined trip over the row: the loads of slice c+1 are in flight
+            // while slice c is scored.  Loads are never predicated (a branch around a load
+            // makes hipcc drain vmcnt per load): lanes past the end of a ragged last slice
+            // read a clamped address and their operands are zeroed afterwards.
+            Raw16 cur[R], nxt[R];
+            {
+                const int vi = sub < nvec ? sub : nvec - 1;
+#pragma unroll
+                for (int r = 0; r < R; r++) cur[r] = load16(rp[r] + (size_t)vi * sizeof(Raw16));
+            }
             for (int c = 0; c < nchunks; c++) {
                 const int vi = c * lpr + sub;
                 const bool ok = vi < nvec;
-                Raw16 rv[R];
+                {
+                    int vn = vi + lpr;
+                    vn = vn < nvec ? vn : nvec - 1;
 #pragma unroll
-                for (int r = 0; r < R; r++)
-                    rv[r] = ok ? load16(rp[r] + (size_t)vi * sizeof(Raw16)) : raw16_zero();
+                    for (int r = 0; r < R; r++) nxt[r] = load16(rp[r] + (size_t)vn * sizeof(Raw16));
+                }
+                const int vq = ok ? vi : nvec - 1;
                 float rf[R][N];
 #pragma unroll
                 for (int r = 0; r < R; r++) {
-                    Unpacked<T> u(rv[r]);
+                    Unpacked<T> u(cur[r]);
 #pragma unroll
-                    for (int e = 0; e < N; e++) rf[r][e] = u.v[e];
+                    for (int e = 0; e < N; e++) rf[r][e] = ok ? u.v[e] : 0.f;
                 }
 #pragma unroll
                 for (int q = 0; q < QT; q++) {
-                    Raw16 qraw = ok ? lds_q[q * nvec + vi] : raw16_zero();
-                    Unpacked<T> uq(qraw);
+                    Unpacked<T> uq(lds_q[q * nvec + vq]);
+#pragma unroll
+                    for (int e = 0; e < N; e++) uq.v[e] = ok ? uq.v[e] : 0.f;
 #pragma unroll
                     for (int r = 0; r < R; r++)
 #pragma unroll
                         for (int e = 0; e < N; e++)
                             acc[r][q] = accum<METRIC>(acc[r][q], rf[r][e], uq.v[e]);
                 }
+#pragma unroll
+                for (int r = 0; r < R; r++) cur[r] = nxt[r];
             }
 
 #pragma unroll
@@ -157,18 +173,20 @@ __global__ __launch_bounds__(kScanThreads) void score_gather_kernel(
     for (int c = 0; c < nchunks; c++) {
         const int vi = c * lpr + sub;
         const bool ok = vi < nvec;
+        const int vc = ok ? vi : nvec - 1;  // never predicate a load (see scan_kernel)
         Raw16 rv[R], qv[R];
 #pragma unroll
         for (int r = 0; r < R; r++) {
-            rv[r] = ok ? load16(rp[r] + (size_t)vi * sizeof(Raw16)) : raw16_zero();
-            qv[r] = ok ? load16(qp[r] + (size_t)vi * sizeof(Raw16)) : raw16_zero();
+            rv[r] = load16(rp[r] + (size_t)vc * sizeof(Raw16));
+            qv[r] = load16(qp[r] + (size_t)vc * sizeof(Raw16));
         }
 #pragma unroll
         for (int r = 0; r < R; r++) {
             Unpacked<T> ur(rv[r]);
             Unpacked<T> uq(qv[r]);
 #pragma unroll
-            for (int e = 0; e < N; e++) acc[r] = accum<METRIC>(acc[r], ur.v[e], uq.v[e]);
+            for (int e = 0; e < N; e++)
+                acc[r] = accum<METRIC>(acc[r], ok ? ur.v[e] : 0.f, ok ? uq.v[e] : 0.f);
         }
     }
 #pragma unroll
