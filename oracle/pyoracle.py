@@ -232,6 +232,75 @@ class Oracle:
         return closest, dist
 
 
+class HnswGraph:
+    """in-memory HNSW graph built by the oracle's restatement of the reference build"""
+
+    def __init__(self, ora, ops, dtype, rows, m=16, ef_construction=64, seed=0):
+        self.ora, self.ops, self.dtype = ora, ops, dtype
+        self.rows = ora.arr(rows, dtype)
+        self.h = ora.lib.ora_hnsw_build(ops, dtype, self.rows.shape[1], _p(self.rows), self.rows.shape[0],
+                                        m, ef_construction, seed)
+        self.m = m
+
+    def close(self):
+        if self.h:
+            self.ora.lib.ora_hnsw_free(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    @property
+    def nelements(self):
+        return self.ora.lib.ora_hnsw_num_elements(self.h)
+
+    def search(self, query, ef_search, k):
+        q = self.ora.arr(query, self.dtype)
+        rows = np.empty(k, dtype=np.int64)
+        dist = np.empty(k, dtype=np.float64)
+        scored = C.c_int64()
+        n = self.ora.lib.ora_hnsw_search(self.h, _p(q), ef_search, k, _p(rows), _p(dist), C.byref(scored))
+        return rows[:n], dist[:n], scored.value
+
+    def export(self):
+        """flat arrays for a device/host mirror: per element row, level, heap-tid-free neighbor table.
+        neighbors[e, lc, :] padded with -1; layer 0 has 2m slots, upper layers m (src/hnsw.h:127)"""
+        L = self.ora.lib
+        n = self.nelements
+        lvl = C.c_int()
+        entry = L.ora_hnsw_entry_point(self.h, C.byref(lvl))
+        levels = np.array([L.ora_hnsw_level(self.h, e) for e in range(n)], dtype=np.int32)
+        rows = np.array([L.ora_hnsw_element_row(self.h, e) for e in range(n)], dtype=np.int64)
+        maxl = int(levels.max()) if n else 0
+        nbr = np.full((n, maxl + 1, 2 * self.m), -1, dtype=np.int32)
+        buf = np.empty(2 * self.m, dtype=np.int32)
+        for e in range(n):
+            for lc in range(levels[e] + 1):
+                c = L.ora_hnsw_neighbors(self.h, e, lc, _p(buf))
+                nbr[e, lc, :c] = buf[:c]
+        return {"entry": entry, "entry_level": lvl.value, "levels": levels, "rows": rows, "neighbors": nbr}
+
+    def export_tuples(self):
+        """neighbor tuples as the index stores them (src/hnsw.h:384-392, src/hnswutils.c:786):
+        (level + 2) * m slots per element, layer lc at (level - lc) * m, -1 = invalid TID"""
+        ex = self.export()
+        n, m = len(ex["levels"]), self.m
+        sizes = (ex["levels"].astype(np.int64) + 2) * m
+        start = np.concatenate([[0], np.cumsum(sizes)]).astype(np.int64)
+        nbr = np.full(int(start[-1]), -1, dtype=np.int32)
+        for e in range(n):
+            lvl = int(ex["levels"][e])
+            for lc in range(lvl + 1):
+                lm = 2 * m if lc == 0 else m
+                o = int(start[e]) + (lvl - lc) * m
+                nbr[o:o + lm] = ex["neighbors"][e, lc, :lm]
+        ex.update({"nbr_start": start, "nbr": nbr})
+        return ex
+
+
 class Ref:
     """oracle/_ref/libpgvref.so: the reference's src/halfutils.c compiled unmodified"""
 

@@ -18,6 +18,8 @@
 //     (src/halfutils.c:46-78 does the same with cvtph_ps).
 #include "pgv_device.h"
 
+#include <type_traits>
+
 namespace pgv {
 
 namespace {
@@ -25,8 +27,13 @@ namespace {
 constexpr int kScanThreads = 256;
 constexpr int kScanWaves = kScanThreads / kWave;
 
-template <typename T, int METRIC, int QT, int R>
-__global__ __launch_bounds__(kScanThreads) void scan_kernel(
+// waves per SIMD the register allocator must leave room for (kernel variant table below)
+constexpr int scan_min_waves(int qt, int r) {
+    return qt * r >= 64 ? 2 : (qt * r >= 32 ? 3 : 4);
+}
+
+template <typename T, int METRIC, int QT, int R, int THREADS, int PF>
+__global__ __launch_bounds__(THREADS, scan_min_waves(QT, R)) void scan_kernel(
     const char *__restrict__ rows, const char *__restrict__ queries,
     const ScanTask *__restrict__ tasks, const int *__restrict__ ntasks_ptr,
     int *__restrict__ task_counter, const ScanPair *__restrict__ pairs, float *__restrict__ out,
@@ -55,7 +62,7 @@ __global__ __launch_bounds__(kScanThreads) void scan_kernel(
         const ScanTask task = tasks[t];
 
         // stage this task's queries (L2-resident) into LDS
-        for (int i = threadIdx.x; i < QT * nvec; i += kScanThreads) {
+        for (int i = threadIdx.x; i < QT * nvec; i += THREADS) {
             int q = i / nvec, v = i - q * nvec;
             int qq = q < task.npairs ? q : task.npairs - 1;
             int qid = pairs[task.pair0 + qq].query;
@@ -68,7 +75,7 @@ __global__ __launch_bounds__(kScanThreads) void scan_kernel(
         __syncthreads();
 
         const char *task_rows = rows + (size_t)task.row0 * row_bytes;
-        for (int b = wave; b * R * rpw < task.nrows; b += kScanWaves) {
+        for (int b = wave; b * R * rpw < task.nrows; b += THREADS / kWave) {
             float acc[R][QT];
 #pragma unroll
             for (int r = 0; r < R; r++)
@@ -85,44 +92,52 @@ __global__ __launch_bounds__(kScanThreads) void scan_kernel(
 
             // Software-pipelined trip over the row: the loads of slice c+1 are in flight
             // while slice c is scored.  Loads are never predicated (a branch around a load
-            // makes hipcc drain vmcnt per load): lanes past the end of a ragged last slice
-            // read a clamped address and their operands are zeroed afterwards.
-            Raw16 cur[R], nxt[R];
-            {
-                const int vi = sub < nvec ? sub : nvec - 1;
-#pragma unroll
-                for (int r = 0; r < R; r++) cur[r] = load16(rp[r] + (size_t)vi * sizeof(Raw16));
-            }
-            for (int c = 0; c < nchunks; c++) {
-                const int vi = c * lpr + sub;
-                const bool ok = vi < nvec;
-                {
-                    int vn = vi + lpr;
-                    vn = vn < nvec ? vn : nvec - 1;
-#pragma unroll
-                    for (int r = 0; r < R; r++) nxt[r] = load16(rp[r] + (size_t)vn * sizeof(Raw16));
-                }
-                const int vq = ok ? vi : nvec - 1;
+            // makes hipcc drain vmcnt per load).  Whole slices run without any masking; only
+            // a ragged last slice (dim not a multiple of the lane group) clamps its address
+            // and zeroes the operands of the lanes past the end.
+            const int nfull = nvec >> lpr_log2;
+            auto score = [&](const Raw16(&rowv)[R], int vq, bool ok, auto masked) {
                 float rf[R][N];
 #pragma unroll
                 for (int r = 0; r < R; r++) {
-                    Unpacked<T> u(cur[r]);
+                    Unpacked<T> u(rowv[r]);
 #pragma unroll
-                    for (int e = 0; e < N; e++) rf[r][e] = ok ? u.v[e] : 0.f;
+                    for (int e = 0; e < N; e++) rf[r][e] = (decltype(masked)::value && !ok) ? 0.f : u.v[e];
                 }
 #pragma unroll
                 for (int q = 0; q < QT; q++) {
                     Unpacked<T> uq(lds_q[q * nvec + vq]);
+                    if constexpr (decltype(masked)::value) {
 #pragma unroll
-                    for (int e = 0; e < N; e++) uq.v[e] = ok ? uq.v[e] : 0.f;
+                        for (int e = 0; e < N; e++) uq.v[e] = ok ? uq.v[e] : 0.f;
+                    }
 #pragma unroll
                     for (int r = 0; r < R; r++)
 #pragma unroll
                         for (int e = 0; e < N; e++)
                             acc[r][q] = accum<METRIC>(acc[r][q], rf[r][e], uq.v[e]);
                 }
+            };
+            Raw16 cur[R], nxt[R];
+            {
+                const int vi = sub < nvec ? sub : nvec - 1;
+#pragma unroll
+                for (int r = 0; r < R; r++) cur[r] = load16(rp[r] + (size_t)vi * sizeof(Raw16));
+            }
+            for (int c = 0; c < nfull; c++) {
+                const int vi = c * lpr + sub;
+                int vn = vi + lpr;
+                vn = vn < nvec ? vn : nvec - 1;
+#pragma unroll
+                for (int r = 0; r < R; r++) nxt[r] = load16(rp[r] + (size_t)vn * sizeof(Raw16));
+                score(cur, vi, true, std::false_type{});
 #pragma unroll
                 for (int r = 0; r < R; r++) cur[r] = nxt[r];
+            }
+            if (nfull < nchunks) {
+                const int vi = nfull * lpr + sub;
+                const bool ok = vi < nvec;
+                score(cur, ok ? vi : nvec - 1, ok, std::true_type{});
             }
 
 #pragma unroll
@@ -197,7 +212,7 @@ __global__ __launch_bounds__(kScanThreads) void score_gather_kernel(
     }
 }
 
-template <typename T, int METRIC, int QT, int R>
+template <typename T, int METRIC, int QT, int R, int THREADS, int PF>
 int launch_scan_t(pgv_ctx *ctx, const RowGeom &g, const void *rows, const void *queries,
                   const ScanTask *tasks, const int *ntasks_dev, int ntasks_bound,
                   const ScanPair *pairs, float *out) {
@@ -208,41 +223,49 @@ int launch_scan_t(pgv_ctx *ctx, const RowGeom &g, const void *rows, const void *
     size_t lds = (size_t)QT * g.nvec * sizeof(Raw16) + QT * sizeof(int64_t) + 16;
     // enough resident workgroups to cover HBM latency, never more than there is work
     int per_cu = (int)(160 * 1024 / (lds + 256));
-    if (per_cu > 8) per_cu = 8;
+    const int by_threads = 2048 / THREADS;
+    if (per_cu > by_threads) per_cu = by_threads;
     if (per_cu < 1) per_cu = 1;
     int grid = ctx->num_cus * per_cu;
     if (grid > ntasks_bound) grid = ntasks_bound;
-    auto kern = scan_kernel<T, METRIC, QT, R>;
+    auto kern = scan_kernel<T, METRIC, QT, R, THREADS, PF>;
     if (lds > 64 * 1024)
         PGV_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    hipLaunchKernelGGL(kern, dim3(grid), dim3(kScanThreads), lds, ctx->stream,
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(THREADS), lds, ctx->stream,
                        static_cast<const char *>(rows), static_cast<const char *>(queries), tasks,
                        ntasks_dev, counter, pairs, out, g.nvec, g.lpr_log2, g.nchunks);
     PGV_HIP(hipGetLastError());
     return PGV_OK;
 }
 
+// Variant table: (queries per task, rows in flight per lane, workgroup size).
+// Wide groups need a big LDS image of the queries (QT x row bytes), which limits a
+// CU to one or two workgroups -- so those workgroups are made of more waves.
 template <typename T, int METRIC>
 int launch_scan_m(pgv_ctx *ctx, const RowGeom &g, const void *rows, const void *queries,
                   const ScanTask *tasks, const int *ntasks_dev, int ntasks_bound,
                   const ScanPair *pairs, int qt, float *out) {
+    static const int variant = getenv("PGV_SCAN_VARIANT") ? atoi(getenv("PGV_SCAN_VARIANT")) : 0;
+#define PGV_SCAN(QT, R, TH, PF) \
+    return launch_scan_t<T, METRIC, QT, R, TH, PF>(ctx, g, rows, queries, tasks, ntasks_dev, ntasks_bound, pairs, out)
     switch (qt) {
         case 1:
-            return launch_scan_t<T, METRIC, 1, 8>(ctx, g, rows, queries, tasks, ntasks_dev,
-                                                  ntasks_bound, pairs, out);
+            PGV_SCAN(1, 8, 256, 1);
         case 2:
-            return launch_scan_t<T, METRIC, 2, 4>(ctx, g, rows, queries, tasks, ntasks_dev,
-                                                  ntasks_bound, pairs, out);
+            PGV_SCAN(2, 4, 256, 1);
         case 4:
-            return launch_scan_t<T, METRIC, 4, 4>(ctx, g, rows, queries, tasks, ntasks_dev,
-                                                  ntasks_bound, pairs, out);
+            PGV_SCAN(4, 4, 256, 1);
         case 8:
-            return launch_scan_t<T, METRIC, 8, 4>(ctx, g, rows, queries, tasks, ntasks_dev,
-                                                  ntasks_bound, pairs, out);
+            if (variant == 1) PGV_SCAN(8, 8, 256, 1);
+            PGV_SCAN(8, 4, 256, 1);
+        case 16:
+            // (16, 8, 512) and (16, 4, 1024) spill
+            PGV_SCAN(16, 4, 512, 1);
         default:
             PGV_FAIL(PGV_ERR_ARG, "scan: unsupported query group size %d", qt);
     }
+#undef PGV_SCAN
 }
 
 template <typename T>
@@ -306,10 +329,12 @@ RowGeom row_geom(int dim, pgv_dtype t) {
     return g;
 }
 
-// Queries per task: as many as fit 64 KB of LDS (up to 8), never more than wanted.
+// Queries per task: the smallest power of two >= wanted, capped at 16 and by the
+// LDS image of the group (<= 64 KB up to 8 queries, <= 128 KB for 16).
 int scan_group_size(const RowGeom &g, pgv_dtype, int wanted) {
-    int qt = 8;
-    while (qt > 1 && (size_t)qt * g.nvec * sizeof(Raw16) > 64 * 1024 - 256) qt >>= 1;
+    static const int cap = getenv("PGV_SCAN_MAXQT") ? atoi(getenv("PGV_SCAN_MAXQT")) : 16;
+    int qt = 16;
+    while (qt > 1 && (qt > cap || (size_t)qt * g.nvec * sizeof(Raw16) > (qt > 8 ? 128u : 64u) * 1024 - 256)) qt >>= 1;
     while (qt > 1 && qt / 2 >= wanted) qt >>= 1;
     return qt;
 }

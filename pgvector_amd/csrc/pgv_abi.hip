@@ -724,12 +724,10 @@ int pgv_search_batch(pgv_index *ix, const void *queries, int nq, int probes, int
     PGV_TRY(rank_lists_dev(ix, q_dev, nq, probes, probe_lists, nullptr));
 
     // 2. invert to list-major work
-    const int qt_max = scan_group_size(ix->geom, ix->dtype, 8);
     // queries per list on average decides how wide a group is worth
     const double share = (double)nq * probes / (double)ix->nlists;
-    int qt = 1;
-    while (qt < qt_max && qt < share) qt <<= 1;
-    const int rows_per_task = qt >= 4 ? 128 : 64;
+    const int qt = scan_group_size(ix->geom, ix->dtype, (int)std::ceil(share));
+    const int rows_per_task = qt >= 16 ? 256 : (qt >= 4 ? 128 : 64);
     PlanResult plan;
     PGV_TRY(launch_plan_batch(ctx, ix, probe_lists, nq, probes, qt, rows_per_task, &plan));
 

@@ -295,6 +295,37 @@ def test_hnsw_score_gathers(ctx, oracle):
         h.close()
 
 
+@pytest.mark.parametrize("ops,metric,dist", [(po.OPS_L2, api.PGV_L2SQ, "int"), (po.OPS_L2, api.PGV_L2SQ, "normal"),
+                                              (po.OPS_COSINE, api.PGV_NEG_IP, "normal"), (po.OPS_L1, api.PGV_L1, "int")])
+def test_hnsw_search_with_gpu_candidate_scoring(ctx, oracle, ops, metric, dist):
+    """HnswSearchLayer replayed by the C host glue with every candidate batch scored on the GPU
+    (src/hnswutils.c:888-976) against the oracle's search on the same graph"""
+    from pgvector_amd import _host
+    dim, n = 24, 3000
+    data = gen(n, dim, seed=111, dist=dist)
+    g = po.HnswGraph(oracle, ops, po.ORA_F32, data, m=8, ef_construction=32, seed=5)
+    ex = g.export_tuples()
+    stored = data[ex["rows"]]
+    if ops == po.OPS_COSINE:
+        stored = normalize_rows(oracle, np.ascontiguousarray(stored), po.ORA_F32)
+    mirror = api.Hnsw(ctx, metric, api.PGV_F32, dim, stored)
+    graph = _host.hnsw_graph(ex["levels"], ex["nbr_start"], ex["nbr"], 8, ex["entry"])
+    queries = gen(40, dim, seed=112, dist=dist)
+    gq = normalize_rows(oracle, queries, po.ORA_F32) if ops == po.OPS_COSINE else queries
+    elem, gd, scored = _host.hnsw_search(mirror, graph, gq, 40, 10)
+    same_scored = 0
+    for i, q in enumerate(queries):
+        rows, wd, wscored = g.search(q, 40, 10)
+        got_rows = ex["rows"][elem[i][elem[i] >= 0]]
+        if dist == "int":  # exact arithmetic: identical traversal
+            assert scored[i] == wscored
+        same_scored += int(scored[i] == wscored)
+        assert_topk_equiv(got_rows.tolist(), gd[i][:len(got_rows)], rows.tolist(), wd,
+                          what="hnsw ops %d q %d" % (ops, i))
+    assert same_scored >= 36
+    mirror.close()
+
+
 # -------------------------------------------------------------- API contracts
 def test_argument_errors(ctx):
     with pytest.raises(pgvector_amd.PgvError) as e:

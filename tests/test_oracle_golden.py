@@ -228,3 +228,42 @@ def test_prng_is_deterministic(oracle):
     xs = [oracle.lib.ora_prng_double(a) for _ in range(5)]
     assert xs == [oracle.lib.ora_prng_double(b) for _ in range(5)]
     assert all(0.0 <= x < 1.0 for x in xs) and len(set(xs)) == 5
+
+
+HNSW_CASES = [c for c in golden("index_order.json")["cases"] if c["am"] == "hnsw"]
+
+
+@pytest.mark.parametrize("case", HNSW_CASES, ids=[c["source"].split("/")[-1] for c in HNSW_CASES])
+def test_hnsw_transcripts(oracle, case):
+    """test/expected/hnsw_vector.out replayed on the restated in-memory build + search"""
+    ops = {"l2": po.OPS_L2, "ip": po.OPS_IP, "cosine": po.OPS_COSINE, "l1": po.OPS_L1}[case["ops"]]
+    rows = np.asarray(case["rows"], dtype=np.float32)
+    g = po.HnswGraph(oracle, ops, po.ORA_F32, rows, m=16, ef_construction=64, seed=1)
+    got, _, _ = g.search(np.asarray(case["query"], dtype=np.float32), 40, 100)
+    assert [rows[r].tolist() for r in got] == [[float(x) for x in v] for v in case["expect"]]
+
+
+def test_hnsw_recall_floor(oracle):
+    """test/t/012_hnsw_vector_build_recall.pl:94-95, scaled: 3-d uniform data, k = 20,
+    defaults m=16 ef_construction=64 ef_search=40 -> recall >= 0.99 (L2)"""
+    data = gen(3000, 3, seed=12)
+    g = po.HnswGraph(oracle, po.OPS_L2, po.ORA_F32, data, seed=12)
+    hits = total = 0
+    for q in gen(20, 3, seed=13):
+        d = ((data.astype(np.float64) - q) ** 2).sum(axis=1)
+        kth = np.sort(d)[19]
+        rows, dist, scored = g.search(q, 40, 20)
+        hits += int((d[rows] <= kth).sum())
+        total += 20
+        assert scored > 20 and (np.diff(dist) >= 0).all()
+    assert hits / total >= 0.99
+
+
+def test_hnsw_duplicates_fold_into_one_element(oracle):
+    """src/hnswbuild.c:339-364: bytewise-equal vectors share an element (up to 10 heap tids)"""
+    data = np.tile(np.array([[1, 2, 3]], dtype=np.float32), (25, 1))
+    data = np.vstack([data, gen(50, 3, seed=3)])
+    g = po.HnswGraph(oracle, po.OPS_L2, po.ORA_F32, data, seed=2)
+    assert g.nelements == 50 + 3  # 25 duplicates -> ceil(25 / 10) elements
+    rows, dist, _ = g.search(np.array([1, 2, 3], dtype=np.float32), 40, 25)
+    assert sorted(rows.tolist()) == list(range(25)) and (dist == 0).all()
