@@ -16,6 +16,16 @@ class HnswGraphStruct(C.Structure):
                 ("levels", C.c_void_p), ("nbr_start", C.c_void_p), ("nbr", C.c_void_p)]
 
 
+class Rel(C.Structure):
+    _fields_ = [("pages", C.c_void_p), ("nblocks", C.c_uint32), ("cap", C.c_uint32)]
+
+
+class IvfImage(C.Structure):
+    _fields_ = [("dtype", C.c_int), ("dim", C.c_int), ("lists", C.c_int), ("nrows", C.c_int64),
+                ("centers", C.c_void_p), ("list_offsets", C.c_void_p), ("vectors", C.c_void_p),
+                ("tids", C.c_void_p), ("start_pages", C.c_void_p)]
+
+
 def _load():
     if not os.path.exists(LIB_PATH):
         raise ImportError("libpgv_host.so not built: make -C pgvector_amd/host")
@@ -23,6 +33,24 @@ def _load():
     lib.pgv_host_last_error.restype = C.c_char_p
     lib.pgv_host_hnsw_search.argtypes = [C.c_void_p, C.POINTER(HnswGraphStruct), C.c_int, C.c_int, C.c_void_p,
                                          C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
+    P, I, I64 = C.c_void_p, C.c_int, C.c_int64
+    lib.pgv_rel_init.argtypes = [C.POINTER(Rel)]
+    lib.pgv_rel_init.restype = None
+    lib.pgv_rel_free.argtypes = [C.POINTER(Rel)]
+    lib.pgv_rel_free.restype = None
+    lib.pgv_host_ivf_write_index.argtypes = [C.POINTER(Rel), I, I, I, P, P, P, P]
+    lib.pgv_host_ivf_insert.argtypes = [C.POINTER(Rel), I, I, P, C.c_uint64]
+    lib.pgv_host_ivf_stage.argtypes = [C.POINTER(Rel), I, C.POINTER(IvfImage)]
+    lib.pgv_host_ivf_image_free.argtypes = [C.POINTER(IvfImage)]
+    lib.pgv_host_ivf_image_free.restype = None
+    lib.pgv_host_ivf_beginscan.argtypes = [P, C.POINTER(IvfImage), I, I, I, I, C.POINTER(P)]
+    lib.pgv_host_ivf_rescan.argtypes = [P, P]
+    lib.pgv_host_ivf_gettuple.argtypes = [P, C.POINTER(C.c_uint64), C.POINTER(C.c_double)]
+    lib.pgv_host_ivf_endscan.argtypes = [P]
+    lib.pgv_host_ivf_endscan.restype = None
+    lib.pgv_host_ivf_build.argtypes = [P, I, I, I, I, P, P, I64, P, I, P, C.POINTER(Rel)]
+    lib.pgv_host_float_to_half.argtypes = [C.c_float]
+    lib.pgv_host_float_to_half.restype = C.c_uint16
     return lib
 
 
@@ -58,3 +86,120 @@ def hnsw_search(mirror, graph, queries, ef_search, k):
                                         C.c_void_p(elem.ctypes.data), C.c_void_p(dist.ctypes.data),
                                         C.c_void_p(scored.ctypes.data)))
     return elem, dist, scored
+
+
+_NP = {0: np.float32, 1: np.float16}
+
+
+class Relation:
+    """an IVFFlat index as an array of 8 KB pages (pgv_rel)"""
+
+    def __init__(self):
+        self.rel = Rel()
+        lib.pgv_rel_init(C.byref(self.rel))
+
+    def __del__(self):
+        try:
+            lib.pgv_rel_free(C.byref(self.rel))
+        except Exception:
+            pass
+
+    @property
+    def nblocks(self):
+        return self.rel.nblocks
+
+    def page(self, blk):
+        return np.ctypeslib.as_array(C.cast(self.rel.pages, C.POINTER(C.c_uint8)),
+                                     shape=(self.rel.nblocks * 8192,))[blk * 8192:(blk + 1) * 8192]
+
+    def write_index(self, dtype, centers, list_offsets, vectors, tids):
+        centers = np.ascontiguousarray(centers, dtype=_NP[dtype])
+        vectors = np.ascontiguousarray(vectors, dtype=_NP[dtype])
+        list_offsets = np.ascontiguousarray(list_offsets, dtype=np.int64)
+        tids = np.ascontiguousarray(tids, dtype=np.uint64)
+        host_check(lib.pgv_host_ivf_write_index(C.byref(self.rel), dtype, centers.shape[1], centers.shape[0],
+                                                C.c_void_p(centers.ctypes.data), C.c_void_p(list_offsets.ctypes.data),
+                                                C.c_void_p(vectors.ctypes.data), C.c_void_p(tids.ctypes.data)))
+
+    def insert(self, dtype, list_id, vector, tid):
+        vector = np.ascontiguousarray(vector, dtype=_NP[dtype])
+        host_check(lib.pgv_host_ivf_insert(C.byref(self.rel), dtype, list_id, C.c_void_p(vector.ctypes.data), tid))
+
+    def stage(self, dtype):
+        return StagedImage(self, dtype)
+
+    def build(self, ctx, ops, dtype, lists, rows, tids, samples, rng=None):
+        rows = np.ascontiguousarray(rows, dtype=_NP[dtype])
+        samples = np.ascontiguousarray(samples, dtype=_NP[dtype])
+        tids = np.ascontiguousarray(tids, dtype=np.uint64)
+        host_check(lib.pgv_host_ivf_build(ctx.h, ops, dtype, rows.shape[1], lists, C.c_void_p(rows.ctypes.data),
+                                          C.c_void_p(tids.ctypes.data), rows.shape[0],
+                                          C.c_void_p(samples.ctypes.data) if len(samples) else None, len(samples),
+                                          C.byref(rng) if rng is not None else None, C.byref(self.rel)))
+
+
+class StagedImage:
+    """contiguous list-major image staged out of the pages (pgv_host_ivf_stage)"""
+
+    def __init__(self, relation, dtype):
+        self.img = IvfImage()
+        host_check(lib.pgv_host_ivf_stage(C.byref(relation.rel), dtype, C.byref(self.img)))
+        i = self.img
+        self.dtype, self.dim, self.lists, self.nrows = dtype, i.dim, i.lists, i.nrows
+
+        def view(ptr, ctype, shape):
+            return np.ctypeslib.as_array(C.cast(ptr, C.POINTER(ctype)), shape=shape)
+        et = C.c_float if dtype == 0 else C.c_uint16
+        self.centers = view(i.centers, et, (i.lists, i.dim)).view(_NP[dtype])
+        self.list_offsets = view(i.list_offsets, C.c_int64, (i.lists + 1,))
+        self.vectors = view(i.vectors, et, (max(i.nrows, 0), i.dim)).view(_NP[dtype]) if i.nrows else \
+            np.zeros((0, i.dim), _NP[dtype])
+        self.tids = view(i.tids, C.c_uint64, (max(i.nrows, 0),)) if i.nrows else np.zeros(0, np.uint64)
+        self.start_pages = view(i.start_pages, C.c_uint32, (i.lists,))
+
+    def __del__(self):
+        try:
+            lib.pgv_host_ivf_image_free(C.byref(self.img))
+        except Exception:
+            pass
+
+
+class IvfScan:
+    """ivfflatbeginscan ... endscan over a staged image and its device mirror"""
+
+    def __init__(self, mirror, staged, probes, max_probes=0, iterative=False, normalize_query=False):
+        self.staged, self.mirror = staged, mirror
+        h = C.c_void_p()
+        host_check(lib.pgv_host_ivf_beginscan(mirror.h, C.byref(staged.img), probes, max_probes, int(iterative),
+                                              int(normalize_query), C.byref(h)))
+        self.h = h
+
+    def rescan(self, query):
+        q = None if query is None else np.ascontiguousarray(query, dtype=_NP[self.staged.dtype])
+        self._q = q
+        host_check(lib.pgv_host_ivf_rescan(self.h, None if q is None else C.c_void_p(q.ctypes.data)))
+
+    def fetch(self, limit=None):
+        """pull heap TIDs like the executor does (amgettuple until exhausted or LIMIT)"""
+        tids, dists = [], []
+        tid, dist = C.c_uint64(), C.c_double()
+        while limit is None or len(tids) < limit:
+            rc = lib.pgv_host_ivf_gettuple(self.h, C.byref(tid), C.byref(dist))
+            if rc < 0:
+                host_check(_lib.PGV_ERR_DEVICE)
+            if rc == 0:
+                break
+            tids.append(tid.value)
+            dists.append(dist.value)
+        return np.array(tids, dtype=np.uint64), np.array(dists)
+
+    def close(self):
+        if self.h:
+            lib.pgv_host_ivf_endscan(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

@@ -329,10 +329,12 @@ RowGeom row_geom(int dim, pgv_dtype t) {
     return g;
 }
 
-// Queries per task: the smallest power of two >= wanted, capped at 16 and by the
-// LDS image of the group (<= 64 KB up to 8 queries, <= 128 KB for 16).
+// Queries per task: the smallest power of two >= wanted, capped by the LDS image of
+// the group (<= 64 KB up to 8 queries, <= 128 KB for 16).  Groups of 16 leave room
+// for one workgroup per CU only and measured slower than two passes of 8 (DESIGN.md
+// section 6), so 8 is the default cap; PGV_SCAN_MAXQT=16 re-enables them.
 int scan_group_size(const RowGeom &g, pgv_dtype, int wanted) {
-    static const int cap = getenv("PGV_SCAN_MAXQT") ? atoi(getenv("PGV_SCAN_MAXQT")) : 16;
+    static const int cap = getenv("PGV_SCAN_MAXQT") ? atoi(getenv("PGV_SCAN_MAXQT")) : 8;
     int qt = 16;
     while (qt > 1 && (qt > cap || (size_t)qt * g.nvec * sizeof(Raw16) > (qt > 8 ? 128u : 64u) * 1024 - 256)) qt >>= 1;
     while (qt > 1 && qt / 2 >= wanted) qt >>= 1;

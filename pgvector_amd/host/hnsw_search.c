@@ -21,8 +21,8 @@ pgv_host_last_error(void)
 	return host_err;
 }
 
-static int
-host_fail(int code, const char *fmt,...)
+int
+pgv_host_fail(int code, const char *fmt,...)
 {
 	va_list		ap;
 
@@ -327,7 +327,7 @@ pgv_host_hnsw_search(pgv_hnsw * mirror, const pgv_hnsw_graph * g, pgv_dtype dtyp
 	(void) dtype;
 	(void) dim;
 	if (!mirror || !g || !queries || !out_elem || !out_dist || nq < 0 || k < 1 || ef_search < 1)
-		return host_fail(PGV_ERR_ARG, "pgv_host_hnsw_search: bad argument");
+		return pgv_host_fail(PGV_ERR_ARG, "pgv_host_hnsw_search: bad argument");
 	for (int64_t i = 0; i < (int64_t) nq * k; i++)
 	{
 		out_elem[i] = -1;
@@ -353,7 +353,7 @@ pgv_host_hnsw_search(pgv_hnsw * mirror, const pgv_hnsw_graph * g, pgv_dtype dtyp
 	rc = pgv_hnsw_score(mirror, queries, nq, slot, qof, nq, dist);
 	if (rc != PGV_OK)
 	{
-		host_fail(rc, "%s", pgv_last_error());
+		pgv_host_fail(rc, "%s", pgv_last_error());
 		goto out;
 	}
 	for (int q = 0; q < nq; q++)
@@ -395,7 +395,7 @@ pgv_host_hnsw_search(pgv_hnsw * mirror, const pgv_hnsw_graph * g, pgv_dtype dtyp
 		rc = pgv_hnsw_score(mirror, queries, nq, slot, qof, np, dist);
 		if (rc != PGV_OK)
 		{
-			host_fail(rc, "%s", pgv_last_error());
+			pgv_host_fail(rc, "%s", pgv_last_error());
 			goto out;
 		}
 		for (int q = 0; q < nq; q++)

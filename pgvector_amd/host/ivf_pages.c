@@ -1,0 +1,495 @@
+/*
+ * ivf_pages.c -- IVFFlat on-disk format, page writers, staging and the scan/build
+ * drivers that sit between Postgres pages and the libpgv_hip ABI.
+ *
+ * The page layout is PostgreSQL's (bufpage.h: 24-byte header, 4-byte line
+ * pointers growing up, tuples growing down, special space at the end) with
+ * pgvector's special area and tuples (src/ivfflat.h:251-275).  Everything a
+ * maintainer needs inside the extension is here in plain C; Postgres itself is
+ * replaced by a pgv_rel (array of pages).  No distance is computed on the CPU.
+ */
+#include "pgv_host.h"
+
+#include <math.h>
+#include <stdarg.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+extern int	pgv_host_fail(int code, const char *fmt,...);
+
+/* ------------------------------------------------------------- page layout */
+
+#define PAGE_HEADER_SIZE 24		/* SizeOfPageHeaderData */
+#define ITEMID_SIZE 4			/* sizeof(ItemIdData) */
+#define SPECIAL_SIZE 8			/* MAXALIGN(sizeof(IvfflatPageOpaqueData)) */
+#define MAXALIGN8(x) (((size_t) (x) + 7) & ~(size_t) 7)
+#define INDEX_TUPLE_HEADER 8	/* sizeof(IndexTupleData): 6-byte t_tid + 2-byte t_info */
+#define IVFFLAT_MAGIC_NUMBER 0x14FF1A7	/* src/ivfflat.h:47 */
+#define IVFFLAT_VERSION 1
+#define IVFFLAT_PAGE_ID 0xFF84	/* src/ivfflat.h:48 */
+#define IVFFLAT_HEAD_BLKNO 1
+#define LP_NORMAL 1
+
+typedef struct
+{
+	uint64_t	pd_lsn;
+	uint16_t	pd_checksum;
+	uint16_t	pd_flags;
+	uint16_t	pd_lower;
+	uint16_t	pd_upper;
+	uint16_t	pd_special;
+	uint16_t	pd_pagesize_version;
+	uint32_t	pd_prune_xid;
+}			page_header;
+
+typedef struct
+{
+	uint32_t	nextblkno;
+	uint16_t	unused;
+	uint16_t	page_id;
+}			ivf_opaque;			/* IvfflatPageOpaqueData */
+
+typedef struct
+{
+	uint32_t	magicNumber;
+	uint32_t	version;
+	uint16_t	dimensions;
+	uint16_t	lists;
+}			ivf_meta;			/* IvfflatMetaPageData */
+
+static inline size_t
+elem_bytes(pgv_dtype t)
+{
+	return t == PGV_F32 ? 4 : 2;
+}
+
+/* VECTOR_SIZE / HALFVEC_SIZE: 4-byte varlena header + int16 dim + int16 unused + payload */
+static inline size_t
+varlena_size(pgv_dtype t, int dim)
+{
+	return 8 + (size_t) dim * elem_bytes(t);
+}
+
+static inline uint8_t *
+page_at(const pgv_rel * rel, uint32_t blk)
+{
+	return rel->pages + (size_t) blk * PGV_BLCKSZ;
+}
+
+static inline ivf_opaque *
+page_opaque(uint8_t *page)
+{
+	return (ivf_opaque *) (page + ((page_header *) page)->pd_special);
+}
+
+static inline int
+page_max_offset(const uint8_t *page)
+{
+	int			lower = ((const page_header *) page)->pd_lower;
+
+	return lower <= PAGE_HEADER_SIZE ? 0 : (lower - PAGE_HEADER_SIZE) / ITEMID_SIZE;
+}
+
+static inline size_t
+page_free_space(const uint8_t *page)
+{
+	const page_header *h = (const page_header *) page;
+	int			space = (int) h->pd_upper - (int) h->pd_lower;
+
+	return space < ITEMID_SIZE ? 0 : (size_t) (space - ITEMID_SIZE);	/* PageGetFreeSpace */
+}
+
+static inline uint8_t *
+page_item(const uint8_t *page, int offno, int *len)
+{
+	uint32_t	lp;
+
+	memcpy(&lp, page + PAGE_HEADER_SIZE + (size_t) (offno - 1) * ITEMID_SIZE, 4);
+	if (len)
+		*len = (int) (lp >> 17);	/* lp_off:15 | lp_flags:2 | lp_len:15 */
+	return (uint8_t *) page + (lp & 0x7FFF);
+}
+
+static int
+page_add_item(uint8_t *page, const void *item, size_t size)
+{
+	page_header *h = (page_header *) page;
+	size_t		aligned = MAXALIGN8(size);
+	int			offno = page_max_offset(page) + 1;
+	uint32_t	lp;
+
+	if ((size_t) h->pd_lower + ITEMID_SIZE > (size_t) h->pd_upper - aligned)
+		return 0;				/* InvalidOffsetNumber */
+	h->pd_upper = (uint16_t) (h->pd_upper - aligned);
+	memcpy(page + h->pd_upper, item, size);
+	lp = (uint32_t) h->pd_upper | ((uint32_t) LP_NORMAL << 15) | ((uint32_t) size << 17);
+	memcpy(page + h->pd_lower, &lp, 4);
+	h->pd_lower = (uint16_t) (h->pd_lower + ITEMID_SIZE);
+	return offno;
+}
+
+void
+pgv_rel_init(pgv_rel * rel)
+{
+	rel->pages = NULL;
+	rel->nblocks = rel->cap = 0;
+}
+
+void
+pgv_rel_free(pgv_rel * rel)
+{
+	free(rel->pages);
+	pgv_rel_init(rel);
+}
+
+/* IvfflatNewBuffer + IvfflatInitPage, src/ivfutils.c:135-156 */
+static uint32_t
+rel_new_page(pgv_rel * rel)
+{
+	uint8_t    *page;
+	page_header *h;
+
+	if (rel->nblocks == rel->cap)
+	{
+		rel->cap = rel->cap ? rel->cap * 2 : 64;
+		rel->pages = realloc(rel->pages, (size_t) rel->cap * PGV_BLCKSZ);
+	}
+	page = page_at(rel, rel->nblocks);
+	memset(page, 0, PGV_BLCKSZ);
+	h = (page_header *) page;
+	h->pd_lower = PAGE_HEADER_SIZE;
+	h->pd_special = PGV_BLCKSZ - SPECIAL_SIZE;
+	h->pd_upper = h->pd_special;
+	h->pd_pagesize_version = PGV_BLCKSZ | 4;	/* PG_PAGE_LAYOUT_VERSION */
+	page_opaque(page)->nextblkno = PGV_INVALID_BLOCK;
+	page_opaque(page)->page_id = IVFFLAT_PAGE_ID;
+	return rel->nblocks++;
+}
+
+/* IvfflatAppendPage, src/ivfutils.c:177-203 */
+static uint32_t
+rel_append_page(pgv_rel * rel, uint32_t cur)
+{
+	uint32_t	blk = rel_new_page(rel);
+
+	page_opaque(page_at(rel, cur))->nextblkno = blk;
+	return blk;
+}
+
+/* a Vector / HalfVector varlena as stored (4-byte header form) */
+static void
+fill_varlena(uint8_t *dst, pgv_dtype t, int dim, const void *payload)
+{
+	uint32_t	vl = (uint32_t) varlena_size(t, dim) << 2;	/* SET_VARSIZE, little endian */
+	int16_t		d = (int16_t) dim,
+				unused = 0;
+
+	memcpy(dst, &vl, 4);
+	memcpy(dst + 4, &d, 2);
+	memcpy(dst + 6, &unused, 2);
+	memcpy(dst + 8, payload, (size_t) dim * elem_bytes(t));
+}
+
+/*
+ * index_form_tuple for (vector): header + datum.  Values whose total size fits a
+ * 1-byte header (<= 127 bytes incl. header, i.e. dim <= 29 for float4) are stored
+ * short and unaligned (SURVEY A.3 staging gotcha).
+ */
+static size_t
+form_index_tuple(uint8_t *dst, pgv_dtype t, int dim, const void *payload, uint64_t tid)
+{
+	size_t		full = varlena_size(t, dim);
+	size_t		short_size = full - 4 + 1;
+	size_t		size;
+	uint16_t	hi = (uint16_t) (tid >> 32),
+				lo = (uint16_t) (tid >> 16),
+				pos = (uint16_t) tid;
+	uint16_t	info;
+
+	memset(dst, 0, INDEX_TUPLE_HEADER);
+	memcpy(dst + 0, &hi, 2);
+	memcpy(dst + 2, &lo, 2);
+	memcpy(dst + 4, &pos, 2);
+	if (short_size <= 127)
+	{
+		int16_t		d = (int16_t) dim,
+					unused = 0;
+
+		dst[INDEX_TUPLE_HEADER] = (uint8_t) ((short_size << 1) | 1);
+		memcpy(dst + INDEX_TUPLE_HEADER + 1, &d, 2);
+		memcpy(dst + INDEX_TUPLE_HEADER + 3, &unused, 2);
+		memcpy(dst + INDEX_TUPLE_HEADER + 5, payload, (size_t) dim * elem_bytes(t));
+		size = INDEX_TUPLE_HEADER + short_size;
+	}
+	else
+	{
+		fill_varlena(dst + INDEX_TUPLE_HEADER, t, dim, payload);
+		size = INDEX_TUPLE_HEADER + full;
+	}
+	size = MAXALIGN8(size);		/* index_form_tuple MAXALIGNs the tuple size */
+	info = (uint16_t) (size & 0x1FFF) | 0x4000;	/* INDEX_VAR_MASK: has a varwidth attribute */
+	memcpy(dst + 6, &info, 2);
+	return size;
+}
+
+/* ------------------------------------------------------------------ writers */
+
+int
+pgv_host_ivf_write_index(pgv_rel * rel, pgv_dtype dtype, int dim, int lists,
+						 const void *centers, const int64_t *list_offsets,
+						 const void *vectors, const uint64_t *tids)
+{
+	size_t		es = elem_bytes(dtype);
+	size_t		list_size = MAXALIGN8(8 + varlena_size(dtype, dim));	/* MAXALIGN(IVFFLAT_LIST_SIZE) */
+	uint8_t    *item = calloc(1, list_size > PGV_BLCKSZ ? list_size : PGV_BLCKSZ);
+	uint32_t   *list_blk = malloc(sizeof(uint32_t) * (size_t) lists);
+	int		   *list_off = malloc(sizeof(int) * (size_t) lists);
+	uint32_t	blk;
+	ivf_meta	meta;
+
+	pgv_rel_free(rel);
+	if (list_size + ITEMID_SIZE > PGV_BLCKSZ - PAGE_HEADER_SIZE - SPECIAL_SIZE)
+	{
+		free(item);
+		free(list_blk);
+		free(list_off);
+		return pgv_host_fail(PGV_ERR_DIMS, "vector does not fit an 8 KB page (max 2000 / 4000 dimensions)");
+	}
+
+	/* CreateMetaPage, src/ivfbuild.c:485-506 */
+	blk = rel_new_page(rel);
+	meta.magicNumber = IVFFLAT_MAGIC_NUMBER;
+	meta.version = IVFFLAT_VERSION;
+	meta.dimensions = (uint16_t) dim;
+	meta.lists = (uint16_t) lists;
+	memcpy(page_at(rel, blk) + PAGE_HEADER_SIZE, &meta, sizeof(meta));
+	((page_header *) page_at(rel, blk))->pd_lower = (uint16_t) (PAGE_HEADER_SIZE + sizeof(meta));
+
+	/* CreateListPages, :511-556 */
+	blk = rel_new_page(rel);
+	for (int i = 0; i < lists; i++)
+	{
+		uint32_t	invalid = PGV_INVALID_BLOCK;
+
+		memset(item, 0, list_size);
+		memcpy(item + 0, &invalid, 4);	/* startPage */
+		memcpy(item + 4, &invalid, 4);	/* insertPage */
+		fill_varlena(item + 8, dtype, dim, (const char *) centers + (size_t) i * dim * es);
+		if (page_free_space(page_at(rel, blk)) < list_size)
+			blk = rel_append_page(rel, blk);
+		list_off[i] = page_add_item(page_at(rel, blk), item, list_size);
+		list_blk[i] = blk;
+	}
+
+	/* InsertTuples, :271-331 */
+	for (int i = 0; i < lists; i++)
+	{
+		uint32_t	start = rel_new_page(rel),
+					cur = start;
+		uint8_t    *list_item;
+
+		for (int64_t r = list_offsets[i]; r < list_offsets[i + 1]; r++)
+		{
+			size_t		sz = form_index_tuple(item, dtype, dim, (const char *) vectors + (size_t) r * dim * es, tids[r]);
+
+			if (page_free_space(page_at(rel, cur)) < sz)
+				cur = rel_append_page(rel, cur);
+			if (!page_add_item(page_at(rel, cur), item, sz))
+			{
+				free(item);
+				free(list_blk);
+				free(list_off);
+				return pgv_host_fail(PGV_ERR_STATE, "failed to add index item");
+			}
+		}
+		/* IvfflatUpdateList: record start and insert page in the list tuple */
+		list_item = page_item(page_at(rel, list_blk[i]), list_off[i], NULL);
+		memcpy(list_item + 0, &start, 4);
+		memcpy(list_item + 4, &cur, 4);
+	}
+	free(item);
+	free(list_blk);
+	free(list_off);
+	return PGV_OK;
+}
+
+/* locate list tuple `list` (list pages hold them in id order, src/ivfbuild.c:527-551) */
+static uint8_t *
+find_list_item(const pgv_rel * rel, int list)
+{
+	uint32_t	blk = IVFFLAT_HEAD_BLKNO;
+	int			seen = 0;
+
+	while (blk != PGV_INVALID_BLOCK && blk < rel->nblocks)
+	{
+		uint8_t    *page = page_at(rel, blk);
+		int			maxoff = page_max_offset(page);
+
+		if (list < seen + maxoff)
+			return page_item(page, list - seen + 1, NULL);
+		seen += maxoff;
+		blk = page_opaque(page)->nextblkno;
+	}
+	return NULL;
+}
+
+/* the append half of ivfflatinsert (src/ivfinsert.c:107-175), list already chosen */
+int
+pgv_host_ivf_insert(pgv_rel * rel, pgv_dtype dtype, int list, const void *vector, uint64_t tid)
+{
+	ivf_meta	meta;
+	uint8_t    *li;
+	uint8_t		item[PGV_BLCKSZ];
+	uint32_t	insert_page;
+	size_t		sz;
+
+	if (rel->nblocks < 2)
+		return pgv_host_fail(PGV_ERR_STATE, "not an ivfflat index");
+	memcpy(&meta, page_at(rel, 0) + PAGE_HEADER_SIZE, sizeof(meta));
+	li = find_list_item(rel, list);
+	if (!li)
+		return pgv_host_fail(PGV_ERR_ARG, "list %d not found", list);
+	memcpy(&insert_page, li + 4, 4);
+	sz = form_index_tuple(item, dtype, meta.dimensions, vector, tid);
+	while (page_free_space(page_at(rel, insert_page)) < sz)
+	{
+		uint32_t	next = page_opaque(page_at(rel, insert_page))->nextblkno;
+
+		if (next == PGV_INVALID_BLOCK)
+		{
+			ptrdiff_t	delta = li - rel->pages;	/* pages may move when the relation grows */
+
+			next = rel_append_page(rel, insert_page);
+			li = rel->pages + delta;
+		}
+		insert_page = next;
+	}
+	page_add_item(page_at(rel, insert_page), item, sz);
+	memcpy(li + 4, &insert_page, 4);
+	return PGV_OK;
+}
+
+/* ------------------------------------------------------------------ staging */
+
+/* payload of the vector attribute of an index tuple, either header form */
+static const uint8_t *
+tuple_vector_payload(const uint8_t *itup, int *dim)
+{
+	const uint8_t *datum = itup + INDEX_TUPLE_HEADER;
+	int16_t		d;
+
+	if (datum[0] & 1)			/* VARATT_IS_1B: short header, unaligned body */
+	{
+		memcpy(&d, datum + 1, 2);
+		*dim = d;
+		return datum + 5;
+	}
+	memcpy(&d, datum + 4, 2);
+	*dim = d;
+	return datum + 8;
+}
+
+int
+pgv_host_ivf_stage(const pgv_rel * rel, pgv_dtype dtype, pgv_ivf_image * out)
+{
+	ivf_meta	meta;
+	size_t		es = elem_bytes(dtype);
+	size_t		row_bytes;
+	int			l = 0;
+	int64_t		n = 0,
+				cap = 0;
+	uint32_t	blk;
+
+	memset(out, 0, sizeof(*out));
+	if (rel->nblocks < 2)
+		return pgv_host_fail(PGV_ERR_STATE, "not an ivfflat index");
+	memcpy(&meta, page_at(rel, 0) + PAGE_HEADER_SIZE, sizeof(meta));
+	if (meta.magicNumber != IVFFLAT_MAGIC_NUMBER)
+		return pgv_host_fail(PGV_ERR_STATE, "ivfflat index is not valid");	/* src/ivfutils.c:221-222 */
+	out->dtype = dtype;
+	out->dim = meta.dimensions;
+	out->lists = meta.lists;
+	row_bytes = (size_t) out->dim * es;
+	out->centers = malloc(row_bytes * (size_t) out->lists);
+	out->list_offsets = calloc((size_t) out->lists + 1, sizeof(int64_t));
+	out->start_pages = malloc(sizeof(uint32_t) * (size_t) out->lists);
+
+	/* pass 1: the list pages (GetScanLists' walk, src/ivfscan.c:58-111) */
+	for (blk = IVFFLAT_HEAD_BLKNO; blk != PGV_INVALID_BLOCK && l < out->lists; blk = page_opaque(page_at(rel, blk))->nextblkno)
+	{
+		const uint8_t *page = page_at(rel, blk);
+		int			maxoff = page_max_offset(page);
+
+		for (int off = 1; off <= maxoff && l < out->lists; off++, l++)
+		{
+			const uint8_t *li = page_item(page, off, NULL);
+
+			memcpy(&out->start_pages[l], li, 4);
+			memcpy((char *) out->centers + (size_t) l * row_bytes, li + 8 + 8, row_bytes);	/* skip varlena hdr + dim */
+		}
+	}
+	if (l != out->lists)
+	{
+		pgv_host_ivf_image_free(out);
+		return pgv_host_fail(PGV_ERR_STATE, "list pages hold %d of %d lists", l, meta.lists);
+	}
+
+	/* pass 2: every list's entry-page chain (GetScanItems' walk, :139-179) */
+	for (l = 0; l < out->lists; l++)
+	{
+		out->list_offsets[l] = n;
+		for (blk = out->start_pages[l]; blk != PGV_INVALID_BLOCK; blk = page_opaque(page_at(rel, blk))->nextblkno)
+		{
+			const uint8_t *page = page_at(rel, blk);
+			int			maxoff = page_max_offset(page);
+
+			if (n + maxoff > cap)
+			{
+				cap = (n + maxoff) * 2 + 1024;
+				out->vectors = realloc(out->vectors, row_bytes * (size_t) cap);
+				out->tids = realloc(out->tids, sizeof(uint64_t) * (size_t) cap);
+			}
+			for (int off = 1; off <= maxoff; off++)
+			{
+				const uint8_t *itup = page_item(page, off, NULL);
+				int			dim;
+				const uint8_t *payload = tuple_vector_payload(itup, &dim);
+				uint16_t	hi,
+							lo,
+							pos;
+
+				if (dim != out->dim)
+				{
+					pgv_host_ivf_image_free(out);
+					return pgv_host_fail(PGV_ERR_DIMS, "different vector dimensions %d and %d", dim, meta.dimensions);
+				}
+				memcpy((char *) out->vectors + (size_t) n * row_bytes, payload, row_bytes);
+				memcpy(&hi, itup + 0, 2);
+				memcpy(&lo, itup + 2, 2);
+				memcpy(&pos, itup + 4, 2);
+				out->tids[n] = ((uint64_t) hi << 32) | ((uint64_t) lo << 16) | pos;
+				n++;
+			}
+		}
+	}
+	out->list_offsets[out->lists] = n;
+	out->nrows = n;
+	if (n == 0)
+	{
+		out->vectors = malloc(16);
+		out->tids = malloc(16);
+	}
+	return PGV_OK;
+}
+
+void
+pgv_host_ivf_image_free(pgv_ivf_image * img)
+{
+	free(img->centers);
+	free(img->list_offsets);
+	free(img->vectors);
+	free(img->tids);
+	free(img->start_pages);
+	memset(img, 0, sizeof(*img));
+}

@@ -61,6 +61,92 @@ int			pgv_host_hnsw_search(pgv_hnsw * mirror, const pgv_hnsw_graph * graph, pgv_
 								 const void *queries, int nq, int ef_search, int k,
 								 int64_t *out_elem, float *out_dist, int64_t *out_scored);
 
+/* ---------------------------------------------------------------- IVFFlat */
+
+/*
+ * A relation as an array of 8 KB pages in the exact on-disk format of an IVFFlat
+ * index (src/ivfflat.h:46-52, 251-275): block 0 the meta page, blocks >= 1 list
+ * pages chained by nextblkno, then per list a chain of entry pages holding
+ * standard IndexTuples.  Stands in for Relation + buffer manager.
+ */
+typedef struct pgv_rel
+{
+	uint8_t    *pages;
+	uint32_t	nblocks;
+	uint32_t	cap;
+}			pgv_rel;
+
+#define PGV_BLCKSZ 8192
+#define PGV_INVALID_BLOCK 0xFFFFFFFFu
+
+void		pgv_rel_init(pgv_rel * rel);
+void		pgv_rel_free(pgv_rel * rel);
+
+/*
+ * The page-writing tail of CREATE INDEX (src/ivfbuild.c:485-556 CreateMetaPage /
+ * CreateListPages, :271-331 InsertTuples, src/ivfutils.c:229-262 IvfflatUpdateList)
+ * from data already sorted by list:
+ *   centers      [lists x dim] payloads (become the Vector/HalfVector in IvfflatListData)
+ *   list_offsets [lists + 1]   rows of list l = [off[l], off[l+1])
+ *   vectors      [n x dim]     payloads in sort order;  tids [n] heap TIDs ((block << 16) | offset)
+ */
+int			pgv_host_ivf_write_index(pgv_rel * rel, pgv_dtype dtype, int dim, int lists,
+									 const void *centers, const int64_t *list_offsets,
+									 const void *vectors, const uint64_t *tids);
+
+/* single-row insert (src/ivfinsert.c:72-181): append to the list's insert page, extending the chain */
+int			pgv_host_ivf_insert(pgv_rel * rel, pgv_dtype dtype, int list, const void *vector, uint64_t tid);
+
+/*
+ * Staging: walk the page chains exactly as GetScanLists / GetScanItems do
+ * (src/ivfscan.c:58-111, :139-179), strip IndexTuple and varlena headers (both the
+ * 4-byte and the 1-byte short form index_form_tuple produces for dim <= 29) and
+ * emit the contiguous list-major image pgv_index_upload takes.  Output arrays are
+ * malloc'ed; free with pgv_host_ivf_image_free.
+ */
+typedef struct pgv_ivf_image
+{
+	pgv_dtype	dtype;
+	int			dim;
+	int			lists;
+	int64_t		nrows;
+	void	   *centers;		/* [lists x dim] */
+	int64_t    *list_offsets;	/* [lists + 1] */
+	void	   *vectors;		/* [nrows x dim] */
+	uint64_t   *tids;			/* [nrows] */
+	uint32_t   *start_pages;	/* [lists] list->startPage */
+}			pgv_ivf_image;
+
+int			pgv_host_ivf_stage(const pgv_rel * rel, pgv_dtype dtype, pgv_ivf_image * out);
+void		pgv_host_ivf_image_free(pgv_ivf_image * img);
+
+/*
+ * ivfflatbeginscan / ivfflatgettuple / ivfflatendscan (src/ivfscan.c:252-431) on a
+ * staged mirror: probes / max_probes / iterative_scan are the GUCs of
+ * src/ivfflat.c:38-59, normalize_query is set for opclasses with a NORM_PROC
+ * (cosine).  gettuple returns 1 and a heap TID, or 0 when the scan is exhausted.
+ */
+typedef struct pgv_ivf_scan pgv_ivf_scan;
+
+int			pgv_host_ivf_beginscan(pgv_index * mirror, const pgv_ivf_image * img, int probes, int max_probes,
+								   int iterative, int normalize_query, pgv_ivf_scan * *out);
+/* amrescan: a new ORDER BY value (NULL = SQL NULL: every tuple at distance 0, :192-196) */
+int			pgv_host_ivf_rescan(pgv_ivf_scan * scan, const void *query);
+int			pgv_host_ivf_gettuple(pgv_ivf_scan * scan, uint64_t *out_tid, double *out_distance);
+void		pgv_host_ivf_endscan(pgv_ivf_scan * scan);
+
+/*
+ * BuildIndex (src/ivfbuild.c:1040-1058) end to end on the GPU: k-means on the given
+ * samples (ComputeCenters), assignment of every heap row in batches (AssignTuples /
+ * AddTupleToSort), sort by list (tuplesort on Int4LessOperator, stable here) and the
+ * page writers above.  rows/tids are the non-NULL heap tuples in heap order; for the
+ * cosine opclass zero-norm rows are skipped and the rest stored normalised
+ * (src/ivfbuild.c:174-180).
+ */
+int			pgv_host_ivf_build(pgv_ctx * ctx, pgv_ops ops, pgv_dtype dtype, int dim, int lists,
+							   const void *rows, const uint64_t *tids, int64_t n,
+							   const void *samples, int nsamples, const pgv_rng * rng, pgv_rel * out_rel);
+
 #ifdef __cplusplus
 }
 #endif

@@ -326,6 +326,71 @@ def test_hnsw_search_with_gpu_candidate_scoring(ctx, oracle, ops, metric, dist):
     mirror.close()
 
 
+# ------------------------------------------------- pages -> mirror -> amgettuple
+@pytest.mark.parametrize("ops,dtype,dim", [(po.OPS_L2, po.ORA_F32, 40), (po.OPS_COSINE, po.ORA_F32, 20),
+                                           (po.OPS_IP, po.ORA_F16, 64)])
+def test_index_built_staged_and_scanned_through_the_host_glue(ctx, oracle, ops, dtype, dim):
+    """BuildIndex on the GPU -> 8 KB pages -> staging -> device mirror -> ivfflatgettuple,
+    against the oracle scanning the same staged image"""
+    from pgvector_amd import _host
+    n, lists = 6000, 24
+    heap = gen(n, dim, seed=121, dist="clustered", clusters=lists, dtype=dtype)
+    tids = ((np.arange(n, dtype=np.uint64) // 50) << np.uint64(16)) | (np.arange(n, dtype=np.uint64) % 50 + 1)
+    pops = {po.OPS_L2: api.PGV_OPS_L2, po.OPS_IP: api.PGV_OPS_IP, po.OPS_COSINE: api.PGV_OPS_COSINE}[ops]
+    rows = heap
+    if ops == po.OPS_COSINE:  # the caller stores normalised rows (src/ivfbuild.c:174-180)
+        rows = normalize_rows(oracle, heap, dtype)
+    samples = rows[np.random.default_rng(1).choice(n, 1200, replace=False)]
+    if ops == po.OPS_IP:
+        samples = normalize_rows(oracle, np.ascontiguousarray(samples), dtype)
+    rel = _host.Relation()
+    rel.build(ctx, pops, DT[dtype], lists, rows, tids, samples, api.make_rng(seed=3))
+    img = rel.stage(DT[dtype])
+    assert img.nrows == n and sorted(img.tids.tolist()) == sorted(tids.tolist())
+    metric = api.PGV_L2SQ if ops == po.OPS_L2 else api.PGV_NEG_IP
+    mirror = api.IvfIndex(ctx, metric, DT[dtype], dim, img.centers, img.list_offsets, img.vectors, img.tids)
+    ix = oracle.index_struct(ops, dtype, img.centers, img.list_offsets, img.vectors, img.tids)
+    # every row sits in the list of its nearest center
+    want_lists, _ = oracle.assign(ops, dtype, img.centers, img.vectors)
+    have_lists = np.repeat(np.arange(lists), np.diff(img.list_offsets))
+    assert (want_lists != have_lists).mean() < 0.002
+    scan = _host.IvfScan(mirror, img, probes=3, normalize_query=(ops == po.OPS_COSINE))
+    for q in gen(12, dim, seed=122, dist="clustered", clusters=lists, dtype=dtype):
+        scan.rescan(q)
+        got_t, got_d = scan.fetch(limit=15)
+        wt, wd = oracle.search(ix, q, 3, 15)
+        assert_topk_equiv(got_t.tolist(), got_d, wt.tolist(), wd, what="amgettuple")
+    # exhausting the scan returns every tuple of the probed lists, ascending
+    scan.rescan(heap[0])
+    all_t, all_d = scan.fetch()
+    lists_probed, _ = oracle.get_scan_lists(ix, normalize_rows(oracle, heap[:1], dtype)[0] if ops == po.OPS_COSINE else heap[0], 3)
+    assert len(all_t) == sum(int(img.list_offsets[l + 1] - img.list_offsets[l]) for l in lists_probed)
+    assert (np.diff(all_d) >= 0).all()
+    # NULL query: all tuples of the first `probes` lists at distance 0 (ZeroDistance)
+    scan.rescan(None)
+    nt, nd = scan.fetch()
+    assert len(nt) == int(img.list_offsets[3]) and (nd == 0).all()
+    scan.close()
+    # iterative scan (relaxed_order): batches of `probes` lists up to max_probes
+    it = _host.IvfScan(mirror, img, probes=2, max_probes=6, iterative=True, normalize_query=(ops == po.OPS_COSINE))
+    q = gen(1, dim, seed=123, dist="clustered", clusters=lists, dtype=dtype)[0]
+    it.rescan(q)
+    got_t, got_d = it.fetch()
+    gq = normalize_rows(oracle, q[None, :], dtype)[0] if ops == po.OPS_COSINE else q
+    pl, _ = oracle.get_scan_lists(ix, gq, 6)
+    want = []
+    for b in range(0, 6, 2):
+        d, s_ = oracle.get_scan_items(ix, gq, pl[b:b + 2])
+        want.append((img.tids[s_], d))
+    assert len(got_t) == sum(len(w[0]) for w in want)
+    at = 0
+    for wt, wd in want:  # each batch sorted on its own
+        assert_topk_equiv(got_t[at:at + len(wt)].tolist(), got_d[at:at + len(wt)], wt.tolist(), wd, what="iterative batch")
+        at += len(wt)
+    it.close()
+    mirror.close()
+
+
 # -------------------------------------------------------------- API contracts
 def test_argument_errors(ctx):
     with pytest.raises(pgvector_amd.PgvError) as e:
