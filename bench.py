@@ -42,6 +42,20 @@ WORKLOADS = {
     "small": (100_000, 256, 100, 10),          # quick functional run
 }
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy)
+SCAN_KERNEL_TAG = "scan_v3_qt8"  # which kernel build the PMC traffic entries in profiles/traffic.json belong to
+
+
+def pmc_traffic(workload, batch):
+    """HBM bytes per list-scan launch from the committed rocprofv3 PMC passes (separate runs,
+    MI355X_MICROARCH.md HBM section); None when no pass matches this kernel/workload."""
+    try:
+        t = json.load(open(os.path.join(ROOT, "profiles", "traffic.json")))
+        for e in t["entries"]:
+            if e["kernel"] == SCAN_KERNEL_TAG and e["workload"] == workload and e["batch"] == batch:
+                return e["traffic_bytes_per_launch"]
+    except Exception:
+        pass
+    return None
 
 
 def log(*a):
@@ -263,7 +277,8 @@ def main():
     roofline = {
         "kernel": "scan_kernel (IVFFlat list scan, src/ivfscan.c:123-187)",
         "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-        "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+        "frac": achieved / HBM_PEAK_GBS,
+        "traffic": pmc_traffic(args.workload, args.batch) if world == 1 else None,
         "algorithmic_bytes_per_launch": algo_bytes / launches,
         "streamed_bytes_per_launch": stream_bytes / launches,
         "streamed_GBps": stream_bytes / scan_s / 1e9 if scan_s > 0 else 0.0,
