@@ -1,0 +1,271 @@
+// kernels_tile.hip -- the list scan for rows probed by MANY queries of a batch.
+//
+// scan_kernel (kernels_scan.hip) keeps a group of <= 8 queries in LDS and streams
+// the rows through registers; a list probed by 9..16 queries is streamed twice.
+// Here the roles are swapped: a tile of rows is brought into LDS once by the
+// asynchronous global->LDS DMA (global_load_lds, no registers involved, the next
+// tile in flight while the current one is scored), and every wavefront scores the
+// whole tile against ITS OWN two queries, which it holds in registers.  A
+// 512-thread workgroup therefore serves up to 16 queries per pass over the rows:
+// the body of GetScanItems (src/ivfscan.c:157-173) for 16 backends' queries with
+// each index tuple read from HBM once.
+//
+// Requirements: rows are a whole number of 1 KiB slices (64 lanes x 16 B), i.e.
+// dim a multiple of 256 (fp32) / 512 (fp16) -- every BASELINE config.  Other
+// shapes use scan_kernel.
+#include "pgv_device.h"
+
+namespace pgv {
+
+namespace {
+
+constexpr int kTileThreads = 1024;
+constexpr int kTileWaves = kTileThreads / kWave;  // 16: four per SIMD, so a SIMD always has a busy wave
+constexpr int kQW = 1;                            // queries per wavefront -> 16 per workgroup
+constexpr int kRB = 3;                            // rows scored together (ILP for the LDS reads)
+
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+
+// LDS reads in inline asm.  They are hidden from hipcc on purpose: with a global->LDS DMA
+// in flight it cannot prove that a ds_read of the tile being scored does not alias the
+// tile being filled, and drains vmcnt(0) before every read -- which would serialise the
+// DMA of the next tile behind the scoring of this one.  The buffers are disjoint by
+// construction (double buffering, barrier between fill and use), so the only wait these
+// reads need is their own lgkmcnt: lds_issue4 starts four reads, lds_wait_* is the single
+// wait before the first consumer and names every destination register so that nothing
+// that uses them can be scheduled above it (cdna_hip_programming.md 5.7, form ii).
+__device__ __forceinline__ void lds_issue3(unsigned a0, unsigned a1, unsigned a2, u32x4 &v0, u32x4 &v1,
+                                           u32x4 &v2) {
+    asm volatile(
+        "ds_read_b128 %0, %3\n\t"
+        "ds_read_b128 %1, %4\n\t"
+        "ds_read_b128 %2, %5"
+        : "=&v"(v0), "=&v"(v1), "=&v"(v2)
+        : "v"(a0), "v"(a1), "v"(a2)
+        : "memory");
+}
+
+template <int NS> __device__ __forceinline__ void lds_wait(u32x4 (&v)[NS][3]);
+#define PGV_V3(c) "+v"(v[c][0]), "+v"(v[c][1]), "+v"(v[c][2])
+template <> __device__ __forceinline__ void lds_wait<1>(u32x4 (&v)[1][3]) {
+    asm volatile("s_waitcnt lgkmcnt(0)" : PGV_V3(0)::"memory");
+}
+template <> __device__ __forceinline__ void lds_wait<2>(u32x4 (&v)[2][3]) {
+    asm volatile("s_waitcnt lgkmcnt(0)" : PGV_V3(0), PGV_V3(1)::"memory");
+}
+template <> __device__ __forceinline__ void lds_wait<3>(u32x4 (&v)[3][3]) {
+    asm volatile("s_waitcnt lgkmcnt(0)" : PGV_V3(0), PGV_V3(1), PGV_V3(2)::"memory");
+}
+template <> __device__ __forceinline__ void lds_wait<4>(u32x4 (&v)[4][3]) {
+    asm volatile("s_waitcnt lgkmcnt(0)" : PGV_V3(0), PGV_V3(1), PGV_V3(2), PGV_V3(3)::"memory");
+}
+#undef PGV_V3
+
+template <typename T, int METRIC, int NCH>
+__global__ __launch_bounds__(kTileThreads) void tile_scan_kernel(
+    const char *__restrict__ rows, const char *__restrict__ queries,
+    const ScanTask *__restrict__ tasks, const int *__restrict__ ntasks_ptr,
+    int *__restrict__ task_counter, const ScanPair *__restrict__ pairs, float *__restrict__ out,
+    int tile_rows) {
+    constexpr int N = VecTraits<T>::N;
+    constexpr size_t ROWB = (size_t)NCH * 1024;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    // layout: [2][tile_rows * ROWB] row tiles | int task id
+    const size_t tile_bytes = (size_t)tile_rows * ROWB;
+    int *lds_task = reinterpret_cast<int *>(smem + 2 * tile_bytes);
+
+    const int lane = threadIdx.x & (kWave - 1);
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);  // provably wave-uniform
+    const int ntasks = *ntasks_ptr;
+
+    for (;;) {
+        if (threadIdx.x == 0) *lds_task = atomicAdd(task_counter, 1);
+        __syncthreads();
+        const int t = *lds_task;
+        if (t >= ntasks) return;
+        const ScanTask task = tasks[t];
+
+        // Query j of the task is served by wavefront j and, when the task has fewer than 16
+        // queries, also by the otherwise idle wavefronts j + npairs, j + 2*npairs, ...: the
+        // servers of a query take the row batches of a tile round-robin.  Waves sit on the
+        // SIMDs cyclically, so this evens out the VALU work per SIMD.  The query lives in
+        // this wavefront's registers for the whole task.
+        const int np = task.npairs;
+        const int my_q = wave % np;                        // query served (np >= 1)
+        const int my_rank = wave / np;                     // which of its servers this wave is
+        const int servers = (kTileWaves - 1 - my_q) / np + 1;
+        Raw16 qreg[kQW][NCH];
+        int64_t rel[kQW];
+        {
+            const ScanPair pr = pairs[task.pair0 + my_q];
+            rel[0] = pr.out_rel;
+            const char *qp = queries + (size_t)pr.query * ROWB + (size_t)lane * sizeof(Raw16);
+#pragma unroll
+            for (int c = 0; c < NCH; c++) qreg[0][c] = load16(qp + (size_t)c * 1024);
+        }
+
+        // DMA one tile: 1 KiB slice i of the tile goes to LDS offset i * 1024 (+ lane * 16,
+        // added by the hardware); slices are dealt round-robin to the wavefronts
+        auto issue_tile = [&](int ti, char *dst) {
+            const int r0 = ti * tile_rows;
+            const int nr = task.nrows - r0 < tile_rows ? task.nrows - r0 : tile_rows;
+            const char *src = rows + ((size_t)task.row0 + r0) * ROWB + (size_t)lane * sizeof(Raw16);
+            for (int i = wave; i < nr * NCH; i += kTileWaves)
+                __builtin_amdgcn_global_load_lds(
+                    (const __attribute__((address_space(1))) void *)(src + (size_t)i * 1024),
+                    (__attribute__((address_space(3))) void *)(dst + (size_t)i * 1024), 16, 0, 0);
+        };
+
+        const int ntiles = (task.nrows + tile_rows - 1) / tile_rows;
+        issue_tile(0, smem);
+        __syncthreads();  // vmcnt(0) + barrier: tile 0 (and the query registers) have landed
+
+        for (int ti = 0; ti < ntiles; ti++) {
+            char *cur = smem + (size_t)(ti & 1) * tile_bytes;
+            char *nxt = smem + (size_t)((ti + 1) & 1) * tile_bytes;
+            if (ti + 1 < ntiles) issue_tile(ti + 1, nxt);  // in flight while `cur` is scored
+
+            const int r_base = ti * tile_rows;
+            const int rows_here = task.nrows - r_base < tile_rows ? task.nrows - r_base : tile_rows;
+            {
+                // LDS byte address of this lane's slice of row 0 of the tile being scored
+                const unsigned lrow = (unsigned)(size_t)(__attribute__((address_space(3))) char *)cur +
+                                      (unsigned)lane * (unsigned)sizeof(Raw16);
+                for (int r0 = my_rank * kRB; r0 < rows_here; r0 += servers * kRB) {
+                    float acc[kRB];
+#pragma unroll
+                    for (int i = 0; i < kRB; i++) acc[i] = 0.f;
+                    // several slices of the three rows are requested from LDS at once (one wait
+                    // per round); rows past the end of a ragged tile read stale LDS and are
+                    // never stored.  128 VGPRs per lane: at most 4 slices (2 for fp16, whose
+                    // conversions need room) x 3 rows per round.
+                    constexpr int CAP = N == 8 ? 2 : 4;
+                    constexpr int NS = NCH % CAP == 0 ? CAP : (NCH % 3 == 0 && CAP >= 3 ? 3 : (NCH % 2 == 0 ? 2 : 1));
+#pragma unroll
+                    for (int h = 0; h < NCH / NS; h++) {
+                        u32x4 rv[NS][3];
+#pragma unroll
+                        for (int c = 0; c < NS; c++) {
+                            const unsigned a = lrow + (unsigned)r0 * (unsigned)ROWB + (unsigned)(h * NS + c) * 1024u;
+                            lds_issue3(a, a + (unsigned)ROWB, a + 2u * (unsigned)ROWB, rv[c][0], rv[c][1], rv[c][2]);
+                        }
+                        lds_wait<NS>(rv);
+                        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                        for (int c = 0; c < NS; c++) {
+                            Unpacked<T> uq(qreg[0][h * NS + c]);
+#pragma unroll
+                            for (int i = 0; i < kRB; i++) {
+                                Raw16 raw;
+#pragma unroll
+                                for (int w = 0; w < 4; w++) raw.w[w] = rv[c][i][w];
+                                Unpacked<T> ur(raw);
+#pragma unroll
+                                for (int e = 0; e < N; e++) acc[i] = accum<METRIC>(acc[i], ur.v[e], uq.v[e]);
+                            }
+                        }
+                    }
+#pragma unroll
+                    for (int i = 0; i < kRB; i++) {
+                        const float sum = group_sum_to_last(acc[i], 6);
+                        if (lane == kWave - 1 && r0 + i < rows_here)
+                            out[rel[0] + task.row0 + r_base + r0 + i] = finish<METRIC>(sum);
+                    }
+                }
+            }
+            __syncthreads();  // next tile landed (vmcnt(0)); everyone is done reading `cur`
+        }
+    }
+}
+
+template <typename T, int METRIC, int NCH>
+int launch_tile_t(pgv_ctx *ctx, const void *rows, const void *queries, const ScanTask *tasks,
+                  const int *ntasks_dev, int ntasks_bound, const ScanPair *pairs, int tile_rows,
+                  float *out) {
+    if (ntasks_bound <= 0) return PGV_OK;
+    PGV_TRY(ctx->counters.ensure(256));
+    int *counter = ctx->counters.as<int>();
+    PGV_HIP(hipMemsetAsync(counter, 0, sizeof(int), ctx->stream));
+    const size_t lds = 2 * (size_t)tile_rows * NCH * 1024 + 16;
+    auto kern = tile_scan_kernel<T, METRIC, NCH>;
+    PGV_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    int grid = ctx->num_cus * (int)(160 * 1024 / (lds + 256) > 0 ? 160 * 1024 / (lds + 256) : 1);
+    if (grid > ntasks_bound) grid = ntasks_bound;
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(kTileThreads), lds, ctx->stream,
+                       static_cast<const char *>(rows), static_cast<const char *>(queries), tasks,
+                       ntasks_dev, counter, pairs, out, tile_rows);
+    PGV_HIP(hipGetLastError());
+    return PGV_OK;
+}
+
+template <typename T, int METRIC>
+int launch_tile_n(pgv_ctx *ctx, int nch, const void *rows, const void *queries,
+                  const ScanTask *tasks, const int *ntasks_dev, int ntasks_bound,
+                  const ScanPair *pairs, int tile_rows, float *out) {
+#define PGV_TILE(NCH)                                                                          \
+    case NCH:                                                                                  \
+        return launch_tile_t<T, METRIC, NCH>(ctx, rows, queries, tasks, ntasks_dev,            \
+                                             ntasks_bound, pairs, tile_rows, out)
+    switch (nch) {
+        PGV_TILE(1);
+        PGV_TILE(2);
+        PGV_TILE(3);
+        PGV_TILE(4);
+        PGV_TILE(6);
+        PGV_TILE(8);
+    }
+#undef PGV_TILE
+    PGV_FAIL(PGV_ERR_ARG, "tile scan: unsupported row size (%d KiB)", nch);
+}
+
+}  // namespace
+
+// rows must be whole 1 KiB slices and one of the instantiated sizes
+bool tile_scan_supported(const RowGeom &g) {
+    if (g.lpr_log2 != 6 || g.nvec % kWave != 0) return false;
+    const int nch = g.nvec / kWave;
+    return nch == 1 || nch == 2 || nch == 3 || nch == 4 || nch == 6 || nch == 8;
+}
+
+int tile_scan_queries_per_task() { return kTileWaves * kQW; }
+
+// rows per LDS tile: two tiles fill ~150 KiB of the CU's 160 KiB; a multiple of 2 * kRB so
+// that two servers of a query split a tile evenly
+int tile_scan_tile_rows(const RowGeom &g) {
+    const size_t row_bytes = (size_t)g.nvec * sizeof(Raw16);
+    int tr = (int)((150 * 1024 / 2) / row_bytes);
+    tr = tr / (2 * kRB) * (2 * kRB);
+    if (tr > 60) tr = 60;
+    if (tr < kRB) tr = kRB;
+    return tr;
+}
+
+int launch_tile_scan(pgv_ctx *ctx, pgv_metric metric, pgv_dtype dtype, const RowGeom &g,
+                     const void *rows, const void *queries, const ScanTask *tasks,
+                     const int *ntasks_dev, int ntasks_bound, const ScanPair *pairs, float *out) {
+    if (!tile_scan_supported(g)) PGV_FAIL(PGV_ERR_ARG, "tile scan: row shape not supported");
+    const int nch = g.nvec / kWave;
+    const int tr = tile_scan_tile_rows(g);
+#define PGV_TILE_M(T)                                                                           \
+    switch (metric) {                                                                           \
+        case PGV_L2SQ:                                                                          \
+            return launch_tile_n<T, 0>(ctx, nch, rows, queries, tasks, ntasks_dev, ntasks_bound, \
+                                       pairs, tr, out);                                         \
+        case PGV_NEG_IP:                                                                        \
+            return launch_tile_n<T, 1>(ctx, nch, rows, queries, tasks, ntasks_dev, ntasks_bound, \
+                                       pairs, tr, out);                                         \
+        case PGV_L1:                                                                            \
+            return launch_tile_n<T, 2>(ctx, nch, rows, queries, tasks, ntasks_dev, ntasks_bound, \
+                                       pairs, tr, out);                                         \
+    }
+    if (dtype == PGV_F32) {
+        PGV_TILE_M(float)
+    } else {
+        PGV_TILE_M(__half)
+    }
+#undef PGV_TILE_M
+    PGV_FAIL(PGV_ERR_ARG, "tile scan: unknown metric %d", (int)metric);
+}
+
+}  // namespace pgv

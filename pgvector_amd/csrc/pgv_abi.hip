@@ -724,10 +724,16 @@ int pgv_search_batch(pgv_index *ix, const void *queries, int nq, int probes, int
     PGV_TRY(rank_lists_dev(ix, q_dev, nq, probes, probe_lists, nullptr));
 
     // 2. invert to list-major work
-    // queries per list on average decides how wide a group is worth
+    // queries per list on average decides how wide a group is worth.  Lists probed by more
+    // than 8 queries go to the tile kernel (16 queries per pass over the rows) when the row
+    // shape allows it; PGV_TILE=0/1 overrides for experiments.
     const double share = (double)nq * probes / (double)ix->nlists;
-    const int qt = scan_group_size(ix->geom, ix->dtype, (int)std::ceil(share));
-    const int rows_per_task = qt >= 16 ? 256 : (qt >= 4 ? 128 : 64);
+    static const int tile_env = getenv("PGV_TILE") ? atoi(getenv("PGV_TILE")) : -1;
+    const bool use_tile = tile_scan_supported(ix->geom) && (tile_env == 1 || (tile_env != 0 && share > 8.0));
+    const int qt = use_tile ? tile_scan_queries_per_task()
+                            : scan_group_size(ix->geom, ix->dtype, (int)std::ceil(share));
+    const int rows_per_task = use_tile ? 20 * tile_scan_tile_rows(ix->geom)
+                                       : (qt >= 16 ? 256 : (qt >= 4 ? 128 : 64));
     PlanResult plan;
     PGV_TRY(launch_plan_batch(ctx, ix, probe_lists, nq, probes, qt, rows_per_task, &plan));
 
@@ -747,8 +753,12 @@ int pgv_search_batch(pgv_index *ix, const void *queries, int nq, int probes, int
         }
         ScanTimer timer{ctx};
         PGV_TRY(timer.begin((double)plan.total_out, rows_streamed));
-        PGV_TRY(launch_scan(ctx, ix->metric, ix->dtype, ix->geom, ix->vectors, q_dev, plan.tasks,
-                            plan.ntasks_dev, (int)plan.ntasks, plan.pairs, qt, seg_vals));
+        if (use_tile)
+            PGV_TRY(launch_tile_scan(ctx, ix->metric, ix->dtype, ix->geom, ix->vectors, q_dev, plan.tasks,
+                                     plan.ntasks_dev, (int)plan.ntasks, plan.pairs, seg_vals));
+        else
+            PGV_TRY(launch_scan(ctx, ix->metric, ix->dtype, ix->geom, ix->vectors, q_dev, plan.tasks,
+                                plan.ntasks_dev, (int)plan.ntasks, plan.pairs, qt, seg_vals));
         PGV_TRY(timer.end());
     }
 

@@ -163,6 +163,14 @@ int launch_score_gather(pgv_ctx *ctx, pgv_metric metric, pgv_dtype dtype, const 
                         const void *rows, const void *queries, const int32_t *slot,
                         const int32_t *query_of, int64_t npairs, float *out);
 
+// kernels_tile.hip: row tiles in LDS (async DMA), queries in registers: 16 queries per pass
+bool tile_scan_supported(const RowGeom &g);
+int tile_scan_queries_per_task();
+int tile_scan_tile_rows(const RowGeom &g);
+int launch_tile_scan(pgv_ctx *ctx, pgv_metric metric, pgv_dtype dtype, const RowGeom &g,
+                     const void *rows, const void *queries, const ScanTask *tasks,
+                     const int *ntasks_dev, int ntasks_bound, const ScanPair *pairs, float *out);
+
 // kernels_pair.hip: n rows x k centers, both large: argmin per row
 int launch_argmin(pgv_ctx *ctx, pgv_metric metric, pgv_dtype dtype, const RowGeom &g,
                   const void *rows, int64_t n, const void *centers, int k, int32_t *out_idx,

@@ -153,6 +153,23 @@ def test_search_batch_matches_reference_scan(ctx, oracle, ops, dtype, dim):
                               what="ops %d probes %d q %d" % (ops, probes, i))
 
 
+@pytest.mark.parametrize("ops,dtype,dim,nq,probes", [(po.OPS_L2, po.ORA_F32, 256, 200, 4), (po.OPS_IP, po.ORA_F32, 768, 90, 3),
+                                                     (po.OPS_L2, po.ORA_F16, 512, 150, 5), (po.OPS_L2, po.ORA_F32, 1536, 64, 6)])
+def test_search_batch_many_queries_per_list(ctx, oracle, ops, dtype, dim, nq, probes):
+    """lists probed by more than 8 queries of the batch take the tile kernel (row tiles in LDS
+    by async DMA, 16 queries per pass); ragged list lengths, more than 16 queries per list"""
+    n, lists = 3000, 12
+    data = gen(n, dim, seed=141, dist="clustered", clusters=lists, dtype=dtype)
+    ivf = CpuIvf(oracle, ops, dtype, data, lists)
+    ix = _upload(ctx, ivf)
+    queries = gen(nq, dim, seed=142, dist="clustered", clusters=lists, dtype=dtype)
+    dist, slot, tid = ix.search_batch(queries, probes, 10, want_tid=True)
+    for i in range(nq):
+        wt, wd = oracle.search(ivf.struct, queries[i], probes, 10)
+        assert_topk_equiv(tid[i][slot[i] >= 0].tolist(), dist[i][:len(wt)], wt.tolist(), wd,
+                          what="tile ops %d dim %d q %d" % (ops, dim, i))
+
+
 def test_search_batch_exact_when_probing_every_list(ctx, oracle):
     """probes = lists is an exact scan: returned row ids must equal brute force"""
     data = gen(5000, 32, seed=31)
