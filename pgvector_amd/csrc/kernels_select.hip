@@ -79,6 +79,7 @@ __global__ __launch_bounds__(1024) void plan_scan_kernel(
     if (threadIdx.x == 0) {
         totals[0] = seg_start[nq];
         totals[1] = task_start[nlists];
+        *reinterpret_cast<int *>(totals + 2) = (int)task_start[nlists];  // what the scan kernels read
     }
 }
 
@@ -129,6 +130,7 @@ __global__ void plan_tasks_kernel(const int *__restrict__ cnt, const int64_t *__
 
 constexpr int kSelThreads = 256;
 constexpr int kBins = 2048;
+constexpr int kFastCap = 1024;  // candidates the threshold pre-filter may keep
 
 struct SelShared {
     unsigned hist[kBins];
@@ -190,21 +192,69 @@ __device__ void sort_entries(unsigned long long *ent, int kp) {
 
 __global__ __launch_bounds__(kSelThreads) void topk_kernel(
     const float *__restrict__ vals, const int64_t *__restrict__ seg_start, int64_t fixed_len,
-    int k, int kp, float *__restrict__ out_val, int64_t *__restrict__ out_pos) {
+    int k, int kp, int cap, float *__restrict__ out_val, int64_t *__restrict__ out_pos) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    unsigned long long *ent = reinterpret_cast<unsigned long long *>(smem);  // [kp]
-    SelShared *s = reinterpret_cast<SelShared *>(smem + (size_t)kp * 8);
+    unsigned long long *ent = reinterpret_cast<unsigned long long *>(smem);  // [cap >= kp]
+    SelShared *s = reinterpret_cast<SelShared *>(smem + (size_t)cap * 8);
 
     const int seg = blockIdx.x;
     const int64_t base = seg_start ? seg_start[seg] : (int64_t)seg * fixed_len;
     const int64_t m = seg_start ? seg_start[seg + 1] - base : fixed_len;
     const float *v = vals + base;
 
-    for (int i = threadIdx.x; i < kp; i += kSelThreads) ent[i] = ~0ull;
+    for (int i = threadIdx.x; i < cap; i += kSelThreads) ent[i] = ~0ull;
     if (threadIdx.x == 0) s->count = 0;
     __syncthreads();
 
-    if (m <= k) {
+    int sort_n = kp;     // how many entries the final sort covers
+    bool done = false;   // block-uniform: the fast path produced the candidates
+    if (m > k && k <= kSelThreads / 2 && m >= 4 * kSelThreads) {
+        // Fast path for the usual "small k of a long segment": every thread takes the minimum
+        // of its strided share; the k-th smallest of those 256 minima is a real element, hence
+        // an upper bound T0 of the k-th smallest overall.  One more sweep (L2-resident by now)
+        // keeps everything <= T0 -- a few dozen candidates -- which are then sorted by
+        // (key, position) exactly like the general path.  Falls through to the radix select
+        // if the candidates do not fit (long runs of equal keys).
+        unsigned *mins = s->hist;  // scratch
+        unsigned mine = 0xffffffffu;
+        for (int64_t i = threadIdx.x; i < m; i += kSelThreads) {
+            const unsigned key = float_to_key(v[i]);
+            mine = key < mine ? key : mine;
+        }
+        mins[threadIdx.x] = mine;
+        __syncthreads();
+        unsigned rank = 0;
+        for (int j = 0; j < kSelThreads; j++) {
+            const unsigned o = mins[j];
+            rank += (o < mine || (o == mine && j < (int)threadIdx.x)) ? 1u : 0u;
+        }
+        if (rank == (unsigned)(k - 1)) s->bin = mine;  // exactly one thread has this rank
+        __syncthreads();
+        const unsigned t0 = s->bin;
+        for (int64_t i = threadIdx.x; i < m; i += kSelThreads) {
+            const unsigned key = float_to_key(v[i]);
+            if (key <= t0) {
+                const unsigned at = atomicAdd(&s->count, 1u);
+                if (at < (unsigned)cap) ent[at] = ((unsigned long long)key << 32) | (unsigned)i;
+            }
+        }
+        __syncthreads();
+        const unsigned got = s->count;
+        if (got <= (unsigned)cap) {
+            done = true;
+            sort_n = kp;
+            while (sort_n < (int)got) sort_n <<= 1;
+        } else {
+            __syncthreads();
+            for (int i = threadIdx.x; i < cap; i += kSelThreads) ent[i] = ~0ull;
+            if (threadIdx.x == 0) s->count = 0;
+            __syncthreads();
+        }
+    }
+
+    if (done) {
+        // candidates are in ent[0, got)
+    } else if (m <= k) {
         for (int64_t i = threadIdx.x; i < m; i += kSelThreads)
             ent[i] = ((unsigned long long)float_to_key(v[i]) << 32) | (unsigned)i;
         __syncthreads();
@@ -275,7 +325,7 @@ __global__ __launch_bounds__(kSelThreads) void topk_kernel(
         __syncthreads();
     }
 
-    sort_entries(ent, kp);
+    sort_entries(ent, sort_n);
 
     for (int i = threadIdx.x; i < k; i += kSelThreads) {
         const unsigned long long e = ent[i];
@@ -325,6 +375,28 @@ __global__ void iota_slots_kernel(const int32_t *__restrict__ lists,
     for (int64_t i = threadIdx.x; i < len; i += blockDim.x) out_slot[probe_off[p] + i] = beg + i;
 }
 
+// profiling only: add this batch's pair and streamed-row counts to device accumulators
+// (read once by pgv_ctx_get_stats; no host round trip inside the timed region)
+__global__ __launch_bounds__(256) void plan_stats_kernel(const int *__restrict__ cnt,
+                                                         const int64_t *__restrict__ list_off,
+                                                         const int64_t *__restrict__ totals, int nlists,
+                                                         int qt, double *__restrict__ acc) {
+    __shared__ double red[256];
+    double rows = 0.0;
+    for (int l = threadIdx.x; l < nlists; l += 256)
+        rows += (double)((cnt[l] + qt - 1) / qt) * (double)(list_off[l + 1] - list_off[l]);
+    red[threadIdx.x] = rows;
+    __syncthreads();
+    for (int s = 128; s > 0; s >>= 1) {
+        if (threadIdx.x < s) red[threadIdx.x] += red[threadIdx.x + s];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        acc[0] += (double)totals[0];  // (row, query) pairs
+        acc[1] += red[0];             // rows streamed
+    }
+}
+
 __global__ void cast_pos_kernel(const int64_t *__restrict__ pos, int64_t n,
                                 int32_t *__restrict__ out) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -342,16 +414,32 @@ int launch_cast_pos_to_i32(pgv_ctx *ctx, const int64_t *pos, int64_t n, int32_t 
 }
 
 int launch_plan_batch(pgv_ctx *ctx, const pgv_index *ix, const int32_t *probe_lists, int nq,
-                      int probes, int qt, int rows_per_task, PlanResult *res) {
+                      int probes, int qt, int rows_per_task, bool read_totals, PlanResult *res) {
     const int nlists = ix->nlists;
     const size_t npairs = (size_t)nq * probes;
+
+    // Host-side bounds size the task queue and the output without a readback:
+    //   outputs  <= nq * (rows of the `probes` longest lists)
+    //   tasks     = sum_l chunks(l) * groups(l),  groups(l) <= cnt_l / qt + 1,  sum_l cnt_l = nq * probes
+    //            <= max_chunks * (nq * probes / qt) + sum_l chunks(l)
+    int64_t max_chunks = 0, sum_chunks = 0;
+    for (int l = 0; l < nlists; l++) {
+        const int64_t nc = (ix->h_offsets[l + 1] - ix->h_offsets[l] + rows_per_task - 1) / rows_per_task;
+        sum_chunks += nc;
+        if (nc > max_chunks) max_chunks = nc;
+    }
+    res->ntasks_bound = max_chunks * (int64_t)(npairs / qt) + sum_chunks;
+    res->out_bound = (int64_t)nq * ix->len_prefix[probes];
+    if (res->ntasks_bound > 0x7fffffff) PGV_FAIL(PGV_ERR_ARG, "plan: too many tasks");
+
     // plan_a: cnt[nlists] | fill[nlists]   (ints, zeroed every call)
     PGV_TRY(ctx->plan_a.ensure(sizeof(int) * 2 * (size_t)nlists));
     // plan_b: probe_off[nq*probes] | seg_len[nq] | seg_start[nq+1] | pair_start[nlists+1]
-    //         | task_start[nlists+1] | totals[2]
-    const size_t nb = npairs + (size_t)nq + (size_t)nq + 1 + 2 * ((size_t)nlists + 1) + 2;
+    //         | task_start[nlists+1] | totals[2] | ntasks (int)
+    const size_t nb = npairs + (size_t)nq + (size_t)nq + 1 + 2 * ((size_t)nlists + 1) + 3;
     PGV_TRY(ctx->plan_b.ensure(sizeof(int64_t) * nb));
     PGV_TRY(ctx->pairs.ensure(sizeof(ScanPair) * npairs));
+    PGV_TRY(ctx->tasks.ensure(sizeof(ScanTask) * (size_t)(res->ntasks_bound > 0 ? res->ntasks_bound : 1) + 16));
     int *cnt = ctx->plan_a.as<int>();
     int *fill = cnt + nlists;
     int64_t *probe_off = ctx->plan_b.as<int64_t>();
@@ -360,6 +448,7 @@ int launch_plan_batch(pgv_ctx *ctx, const pgv_index *ix, const int32_t *probe_li
     int64_t *pair_start = seg_start + nq + 1;
     int64_t *task_start = pair_start + nlists + 1;
     int64_t *totals = task_start + nlists + 1;
+    ScanTask *tasks = ctx->tasks.as<ScanTask>();
 
     PGV_HIP(hipMemsetAsync(cnt, 0, sizeof(int) * 2 * (size_t)nlists, ctx->stream));
     hipLaunchKernelGGL(plan_count_kernel, dim3((nq + 255) / 256), dim3(256), 0, ctx->stream,
@@ -370,33 +459,22 @@ int launch_plan_batch(pgv_ctx *ctx, const pgv_index *ix, const int32_t *probe_li
     hipLaunchKernelGGL(plan_pairs_kernel, dim3((unsigned)((npairs + 255) / 256)), dim3(256), 0,
                        ctx->stream, probe_lists, ix->list_offsets, probe_off, seg_start,
                        pair_start, fill, nq, probes, ctx->pairs.as<ScanPair>());
-    PGV_HIP(hipGetLastError());
-
-    // the two totals size the task queue and the output: one small readback
-    PGV_TRY(ctx->h_c.ensure(64));
-    int64_t *h_tot = ctx->h_c.as<int64_t>();
-    PGV_HIP(hipMemcpyAsync(h_tot, totals, 2 * sizeof(int64_t), hipMemcpyDeviceToHost, ctx->stream));
-    PGV_HIP(hipStreamSynchronize(ctx->stream));
-    res->total_out = h_tot[0];
-    res->ntasks = h_tot[1];
-    if (res->ntasks > 0x7fffffff) PGV_FAIL(PGV_ERR_ARG, "plan: too many tasks");
-
-    PGV_TRY(ctx->tasks.ensure(sizeof(ScanTask) * (size_t)(res->ntasks > 0 ? res->ntasks : 1) + 16));
-    ScanTask *tasks = ctx->tasks.as<ScanTask>();
     hipLaunchKernelGGL(plan_tasks_kernel, dim3((nlists + 255) / 256), dim3(256), 0, ctx->stream,
                        cnt, ix->list_offsets, pair_start, task_start, nlists, qt, rows_per_task,
                        tasks);
     PGV_HIP(hipGetLastError());
-    // device copy of the task count (an int the scan kernel reads)
-    PGV_TRY(ctx->plan_c.ensure(64));
-    int *ntasks_dev = ctx->plan_c.as<int>();
-    int *h_n = reinterpret_cast<int *>(h_tot + 4);
-    *h_n = (int)res->ntasks;
-    PGV_HIP(hipMemcpyAsync(ntasks_dev, h_n, sizeof(int), hipMemcpyHostToDevice, ctx->stream));
 
+    res->ntasks = res->ntasks_bound;
+    res->total_out = res->out_bound;
+    if (read_totals) {  // profiling: exact pair / streamed-row counts, accumulated on the device
+        PGV_TRY(ctx->stats_dev.ensure(2 * sizeof(double)));
+        hipLaunchKernelGGL(plan_stats_kernel, dim3(1), dim3(256), 0, ctx->stream, cnt,
+                           ix->list_offsets, totals, nlists, qt, ctx->stats_dev.as<double>());
+        PGV_HIP(hipGetLastError());
+    }
     res->tasks = tasks;
     res->pairs = ctx->pairs.as<ScanPair>();
-    res->ntasks_dev = ntasks_dev;
+    res->ntasks_dev = reinterpret_cast<int *>(totals + 2);
     res->seg_start = seg_start;
     res->probe_off = probe_off;
     return PGV_OK;
@@ -409,9 +487,10 @@ int launch_topk_segments(pgv_ctx *ctx, const float *vals, const int64_t *seg_sta
     int kp = 1;
     while (kp < k) kp <<= 1;
     if (kp < 2) kp = 2;
-    const size_t lds = (size_t)kp * 8 + sizeof(SelShared);
+    const int cap = kp > kFastCap ? kp : kFastCap;
+    const size_t lds = (size_t)cap * 8 + sizeof(SelShared);
     hipLaunchKernelGGL(topk_kernel, dim3(nseg), dim3(kSelThreads), lds, ctx->stream, vals,
-                       seg_start, fixed_len, k, kp, out_val, out_pos);
+                       seg_start, fixed_len, k, kp, cap, out_val, out_pos);
     PGV_HIP(hipGetLastError());
     return PGV_OK;
 }

@@ -4,6 +4,7 @@
 // point reports PGV_ERR_DEVICE.
 #include "pgv_internal.h"
 
+#include <algorithm>
 #include <cmath>
 #include <cstdarg>
 #include <new>
@@ -190,6 +191,22 @@ struct OutArg {
     }
 };
 
+// h_a is pinned staging for small host-planned tables; the copy out of it is asynchronous, so
+// it is only rewritten once that copy has been consumed
+int staging_acquire(pgv_ctx *ctx) {
+    if (ctx->h_a_pending) {
+        PGV_HIP(hipEventSynchronize(ctx->h_a_busy));
+        ctx->h_a_pending = false;
+    }
+    return PGV_OK;
+}
+int staging_release(pgv_ctx *ctx) {
+    if (!ctx->h_a_busy) PGV_HIP(hipEventCreateWithFlags(&ctx->h_a_busy, hipEventDisableTiming));
+    PGV_HIP(hipEventRecord(ctx->h_a_busy, ctx->stream));
+    ctx->h_a_pending = true;
+    return PGV_OK;
+}
+
 int sync_if(pgv_ctx *ctx, bool need) {
     if (need) PGV_HIP(hipStreamSynchronize(ctx->stream));
     return PGV_OK;
@@ -271,6 +288,7 @@ int dense_scan(pgv_ctx *ctx, pgv_metric metric, pgv_dtype dtype, const RowGeom &
     if (ntasks > 0x7fffffff) PGV_FAIL(PGV_ERR_ARG, "scan: too many tasks");
 
     const size_t tb = sizeof(ScanTask) * (size_t)ntasks, pb = sizeof(ScanPair) * (size_t)nq;
+    PGV_TRY(staging_acquire(ctx));
     PGV_TRY(ctx->h_a.ensure(tb + pb + 16));
     ScanTask *ht = ctx->h_a.as<ScanTask>();
     ScanPair *hp = reinterpret_cast<ScanPair *>(reinterpret_cast<char *>(ht) + tb);
@@ -295,6 +313,7 @@ int dense_scan(pgv_ctx *ctx, pgv_metric metric, pgv_dtype dtype, const RowGeom &
     *hn = (int)ntasks;
     PGV_TRY(ctx->tasks.ensure(tb + pb + 16));
     PGV_HIP(hipMemcpyAsync(ctx->tasks.p, ht, tb + pb + 16, hipMemcpyHostToDevice, ctx->stream));
+    PGV_TRY(staging_release(ctx));
     const ScanTask *dt = ctx->tasks.as<ScanTask>();
     const ScanPair *dp = reinterpret_cast<const ScanPair *>(ctx->tasks.as<char>() + tb);
     const int *dn = reinterpret_cast<const int *>(ctx->tasks.as<char>() + tb + pb);
@@ -304,8 +323,6 @@ int dense_scan(pgv_ctx *ctx, pgv_metric metric, pgv_dtype dtype, const RowGeom &
     PGV_TRY(launch_scan(ctx, metric, dtype, g, rows_dev, queries_dev, dt, dn, (int)ntasks, dp, qt,
                         out_dev));
     PGV_TRY(timer.end());
-    // h_a is rewritten by the next call: make sure the copy has been consumed
-    PGV_HIP(hipStreamSynchronize(ctx->stream));
     return PGV_OK;
 }
 
@@ -405,12 +422,13 @@ void pgv_ctx_destroy(pgv_ctx *ctx) {
                  &ctx->out_stage2, &ctx->idx_stage, &ctx->tasks, &ctx->pairs, &ctx->counters,
                  &ctx->plan_a, &ctx->plan_b, &ctx->plan_c, &ctx->plan_d, &ctx->dist_mat,
                  &ctx->sel_a, &ctx->sel_b, &ctx->km_a, &ctx->km_b, &ctx->km_c, &ctx->km_d,
-                 &ctx->km_e, &ctx->km_f, &ctx->km_g};
+                 &ctx->km_e, &ctx->km_f, &ctx->km_g, &ctx->stats_dev};
     for (DBuf *b : d) b->release();
     ctx->h_a.release();
     ctx->h_b.release();
     ctx->h_c.release();
     for (hipEvent_t e : ctx->ev_pool) (void)hipEventDestroy(e);
+    if (ctx->h_a_busy) (void)hipEventDestroy(ctx->h_a_busy);
     if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
     if (ctx->ev1) (void)hipEventDestroy(ctx->ev1);
     if (ctx->own_stream && ctx->stream) (void)hipStreamDestroy(ctx->stream);
@@ -443,6 +461,10 @@ int pgv_ctx_set_profiling(pgv_ctx *ctx, int on) {
     if (!ctx) PGV_FAIL(PGV_ERR_ARG, "ctx is NULL");
     PGV_TRY(resolve_events(ctx));
     ctx->profiling = on != 0;
+    if (ctx->profiling && !ctx->stats_dev.p) {
+        PGV_TRY(ctx->stats_dev.ensure(2 * sizeof(double)));
+        PGV_HIP(hipMemsetAsync(ctx->stats_dev.p, 0, 2 * sizeof(double), ctx->stream));
+    }
     return PGV_OK;
 }
 
@@ -453,6 +475,7 @@ int pgv_ctx_reset_stats(pgv_ctx *ctx) {
     ctx->scan_launches = 0;
     ctx->scan_pairs = 0;
     ctx->scan_rows = 0;
+    if (ctx->stats_dev.p) PGV_HIP(hipMemsetAsync(ctx->stats_dev.p, 0, 2 * sizeof(double), ctx->stream));
     ctx->aux_ms = 0;
     ctx->aux_launches = 0;
     ctx->aux_pairs = 0;
@@ -462,10 +485,15 @@ int pgv_ctx_reset_stats(pgv_ctx *ctx) {
 int pgv_ctx_get_stats(pgv_ctx *ctx, pgv_stats *out) {
     if (!ctx || !out) PGV_FAIL(PGV_ERR_ARG, "ctx/out is NULL");
     PGV_TRY(resolve_events(ctx));
+    double dev_acc[2] = {0.0, 0.0};
+    if (ctx->stats_dev.p) {
+        PGV_HIP(hipMemcpyAsync(dev_acc, ctx->stats_dev.p, sizeof(dev_acc), hipMemcpyDeviceToHost, ctx->stream));
+        PGV_HIP(hipStreamSynchronize(ctx->stream));
+    }
     out->scan_ms = ctx->scan_ms;
     out->scan_launches = ctx->scan_launches;
-    out->scan_pairs = ctx->scan_pairs;
-    out->scan_rows = ctx->scan_rows;
+    out->scan_pairs = ctx->scan_pairs + dev_acc[0];
+    out->scan_rows = ctx->scan_rows + dev_acc[1];
     out->aux_ms = ctx->aux_ms;
     out->aux_launches = ctx->aux_launches;
     out->aux_pairs = ctx->aux_pairs;
@@ -512,6 +540,13 @@ int pgv_index_upload(pgv_ctx *ctx, pgv_metric metric, pgv_dtype dtype, int dim, 
     ix->geom = row_geom(dim, dtype);
     ix->h_offsets = off;
     ix->max_list_len = maxlen;
+    {
+        std::vector<int64_t> lens((size_t)nlists);
+        for (int l = 0; l < nlists; l++) lens[l] = off[l + 1] - off[l];
+        std::sort(lens.begin(), lens.end(), [](int64_t a, int64_t b) { return a > b; });
+        ix->len_prefix.assign((size_t)nlists + 1, 0);
+        for (int l = 0; l < nlists; l++) ix->len_prefix[l + 1] = ix->len_prefix[l] + lens[l];
+    }
     const size_t es = elem_size(dtype);
     const size_t row_bytes = (size_t)ix->geom.ld * es;
 
@@ -650,6 +685,7 @@ int pgv_scan_lists(pgv_index *ix, const void *query, const int32_t *lists, int n
     }
     const size_t tb = sizeof(ScanTask) * (size_t)ntasks, pb = sizeof(ScanPair) * (size_t)nlists,
                  ob = sizeof(int64_t) * (size_t)nlists, lb = sizeof(int32_t) * (size_t)nlists;
+    PGV_TRY(staging_acquire(ctx));
     PGV_TRY(ctx->h_a.ensure(tb + pb + ob + lb + 16));
     char *hb = ctx->h_a.as<char>();
     ScanTask *ht = reinterpret_cast<ScanTask *>(hb);
@@ -735,30 +771,20 @@ int pgv_search_batch(pgv_index *ix, const void *queries, int nq, int probes, int
     const int rows_per_task = use_tile ? 20 * tile_scan_tile_rows(ix->geom)
                                        : (qt >= 16 ? 256 : (qt >= 4 ? 128 : 64));
     PlanResult plan;
-    PGV_TRY(launch_plan_batch(ctx, ix, probe_lists, nq, probes, qt, rows_per_task, &plan));
+    PGV_TRY(launch_plan_batch(ctx, ix, probe_lists, nq, probes, qt, rows_per_task, ctx->profiling, &plan));
 
     // 3. GetScanItems: one streaming pass
-    PGV_TRY(ctx->plan_d.ensure(sizeof(float) * (size_t)(plan.total_out > 0 ? plan.total_out : 1)));
+    PGV_TRY(ctx->plan_d.ensure(sizeof(float) * (size_t)(plan.out_bound > 0 ? plan.out_bound : 1)));
     float *seg_vals = ctx->plan_d.as<float>();
-    if (plan.ntasks > 0) {
-        double rows_streamed = 0.0;
-        if (ctx->profiling) {
-            // rows streamed = sum over lists of (query groups x list length); the per-list
-            // probe counts are the first nlists ints of plan_a
-            std::vector<int> cnt((size_t)ix->nlists);
-            PGV_HIP(hipMemcpyAsync(cnt.data(), ctx->plan_a.p, sizeof(int) * cnt.size(), hipMemcpyDeviceToHost, ctx->stream));
-            PGV_HIP(hipStreamSynchronize(ctx->stream));
-            for (int l = 0; l < ix->nlists; l++)
-                rows_streamed += (double)((cnt[l] + qt - 1) / qt) * (double)(ix->h_offsets[l + 1] - ix->h_offsets[l]);
-        }
+    if (plan.ntasks_bound > 0) {
         ScanTimer timer{ctx};
-        PGV_TRY(timer.begin((double)plan.total_out, rows_streamed));
+        PGV_TRY(timer.begin(0.0, 0.0));  // pairs / rows of this launch are accumulated on the device
         if (use_tile)
             PGV_TRY(launch_tile_scan(ctx, ix->metric, ix->dtype, ix->geom, ix->vectors, q_dev, plan.tasks,
-                                     plan.ntasks_dev, (int)plan.ntasks, plan.pairs, seg_vals));
+                                     plan.ntasks_dev, (int)plan.ntasks_bound, plan.pairs, seg_vals));
         else
             PGV_TRY(launch_scan(ctx, ix->metric, ix->dtype, ix->geom, ix->vectors, q_dev, plan.tasks,
-                                plan.ntasks_dev, (int)plan.ntasks, plan.pairs, qt, seg_vals));
+                                plan.ntasks_dev, (int)plan.ntasks_bound, plan.pairs, qt, seg_vals));
         PGV_TRY(timer.end());
     }
 
@@ -1114,6 +1140,7 @@ int pgv_kmeans(pgv_ctx *ctx, pgv_ops ops, pgv_dtype dtype, int dim, const void *
         unsigned long long *changes = reinterpret_cast<unsigned long long *>(counts + k + (k & 1));
         int32_t *closest = reinterpret_cast<int32_t *>(changes + 1);
         PGV_HIP(hipMemsetAsync(closest, 0xff, sizeof(int32_t) * (size_t)n, ctx->stream));  // -1: everything "changes" first
+        PGV_TRY(staging_acquire(ctx));
         PGV_TRY(ctx->h_a.ensure(sizeof(int32_t) * (size_t)k + 16));
         for (int it = 0; it < max_iterations; it++) {
             iters = it + 1;

@@ -106,8 +106,11 @@ struct pgv_ctx {
     pgv::DBuf q_stage, rows_stage, centers_stage, out_stage, out_stage2, idx_stage;
     pgv::DBuf tasks, pairs, counters, plan_a, plan_b, plan_c, plan_d, dist_mat, sel_a, sel_b;
     pgv::DBuf km_a, km_b, km_c, km_d, km_e, km_f, km_g;
-    // scratch (pinned host)
+    pgv::DBuf stats_dev;  // profiling: {pairs, rows streamed} of the batched list scans, as doubles
+    // scratch (pinned host); h_a_busy marks the last async copy out of h_a (waited before reuse)
     pgv::HBuf h_a, h_b, h_c;
+    hipEvent_t h_a_busy = nullptr;
+    bool h_a_pending = false;
     // per-kernel profiling (pgv_ctx_set_profiling): HIP event pairs around the
     // streaming kernel, resolved lazily in pgv_ctx_get_stats
     bool profiling = false;
@@ -136,6 +139,7 @@ struct pgv_index {
     int64_t *list_offsets = nullptr;  // device [nlists + 1]
     uint64_t *tids = nullptr;         // device [nrows] or null
     std::vector<int64_t> h_offsets;   // host copy
+    std::vector<int64_t> len_prefix;  // len_prefix[p] = rows in the p longest lists (output size bound)
     int64_t max_list_len = 0;
 };
 
@@ -185,13 +189,15 @@ struct PlanResult {
     ScanTask *tasks = nullptr;
     ScanPair *pairs = nullptr;
     int *ntasks_dev = nullptr;
-    int64_t ntasks = 0;
-    int64_t total_out = 0;        // sum of the queries' segment lengths
+    int64_t ntasks = 0;           // exact when the totals were read back, else the bound
+    int64_t total_out = 0;        // sum of the queries' segment lengths (exact or bound, likewise)
+    int64_t ntasks_bound = 0;
+    int64_t out_bound = 0;
     int64_t *seg_start = nullptr; // device [nq + 1]
     int64_t *probe_off = nullptr; // device [nq x probes]
 };
 int launch_plan_batch(pgv_ctx *ctx, const pgv_index *ix, const int32_t *probe_lists, int nq,
-                      int probes, int qt, int rows_per_task, PlanResult *res);
+                      int probes, int qt, int rows_per_task, bool read_totals, PlanResult *res);
 int launch_topk_segments(pgv_ctx *ctx, const float *vals, const int64_t *seg_start, int nseg,
                          int64_t fixed_len, int k, float *out_val, int64_t *out_pos);
 int launch_positions_to_slots(pgv_ctx *ctx, const pgv_index *ix, const int32_t *probe_lists,
