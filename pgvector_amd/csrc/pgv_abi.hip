@@ -280,9 +280,19 @@ int dense_scan(pgv_ctx *ctx, pgv_metric metric, pgv_dtype dtype, const RowGeom &
                const void *rows_dev, int64_t nrows, const void *queries_dev, int nq,
                int64_t out_stride, float *out_dev) {
     if (nrows <= 0 || nq <= 0) return PGV_OK;
-    const int qt = scan_group_size(g, dtype, nq);
+    // many queries against the same rows (center ranking of a batch): the tile kernel serves
+    // 16 queries per pass over the rows
+    const bool use_tile = nq > 8 && tile_scan_supported(g);
+    const int qt = use_tile ? tile_scan_queries_per_task() : scan_group_size(g, dtype, nq);
     const int ngroups = (nq + qt - 1) / qt;
-    const int ch = rows_per_task_for(ctx, nrows, ngroups);
+    int ch = rows_per_task_for(ctx, nrows, ngroups);
+    if (use_tile) {
+        // whole tiles, and long enough runs to amortise a task's prologue (query registers,
+        // first tile) when the rows are few but the query groups many
+        const int tr = tile_scan_tile_rows(g);
+        ch = (ch + tr - 1) / tr * tr;
+        if (ch < 10 * tr && (int64_t)ngroups * ((nrows + 10 * tr - 1) / (10 * tr)) >= ctx->num_cus) ch = 10 * tr;
+    }
     const int64_t nchunks = (nrows + ch - 1) / ch;
     const int64_t ntasks = nchunks * ngroups;
     if (ntasks > 0x7fffffff) PGV_FAIL(PGV_ERR_ARG, "scan: too many tasks");
@@ -320,8 +330,11 @@ int dense_scan(pgv_ctx *ctx, pgv_metric metric, pgv_dtype dtype, const RowGeom &
 
     ScanTimer timer{ctx};
     PGV_TRY(timer.begin((double)nrows * nq, (double)nrows * ngroups, true));
-    PGV_TRY(launch_scan(ctx, metric, dtype, g, rows_dev, queries_dev, dt, dn, (int)ntasks, dp, qt,
-                        out_dev));
+    if (use_tile)
+        PGV_TRY(launch_tile_scan(ctx, metric, dtype, g, rows_dev, queries_dev, dt, dn, (int)ntasks, dp, out_dev));
+    else
+        PGV_TRY(launch_scan(ctx, metric, dtype, g, rows_dev, queries_dev, dt, dn, (int)ntasks, dp, qt,
+                            out_dev));
     PGV_TRY(timer.end());
     return PGV_OK;
 }
