@@ -36,13 +36,18 @@ import pgvector_amd  # noqa: E402
 from pgvector_amd import api, sharding  # noqa: E402
 
 WORKLOADS = {
-    # name: rows, dim, lists, probes
-    "headline": (1_000_000, 1536, 1000, 10),   # BASELINE.json metric: IVFFlat 1M x 1536d
-    "c2": (1_000_000, 768, 1000, 10),          # configs[1]
-    "small": (100_000, 256, 100, 10),          # quick functional run
+    # name: rows, dim, lists, probes, element type, opclass
+    "headline": (1_000_000, 1536, 1000, 10, "f32", "l2"),   # BASELINE.json metric: IVFFlat 1M x 1536d
+    "c2": (1_000_000, 768, 1000, 10, "f32", "l2"),          # configs[1]
+    # one GPU's share of configs[2] (10M x 1536 fp32 vector_ip_ops, lists 4096, 8 GPUs, probes 64)
+    "c3shard": (1_250_000, 1536, 512, 8, "f32", "ip"),
+    # one GPU's share of configs[4] (10M x 3072 fp16 halfvec_l2_ops, lists 4096, 8 GPUs, probes 64)
+    "c5shard": (1_250_000, 3072, 512, 8, "f16", "l2"),
+    "small": (100_000, 256, 100, 10, "f32", "l2"),          # quick functional run
+    "smallh": (100_000, 512, 100, 10, "f16", "ip"),
 }
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy)
-SCAN_KERNEL_TAG = "scan_v3_qt8"  # which kernel build the PMC traffic entries in profiles/traffic.json belong to
+SCAN_KERNEL_TAG = "tile_v1"  # which kernel build the PMC traffic entries in profiles/traffic.json belong to
 
 
 def pmc_traffic(workload, batch):
@@ -79,7 +84,7 @@ def gen_mixture(n, dim, components, sigma, seed, device, means=None):
     return out, means
 
 
-def build_index(ctx, data, lists, seed, world, rank):
+def build_index(ctx, data, lists, seed, world, rank, dtype, ops, metric):
     """IVFFlat build on the GPU(s): sample, k-means, assign every row, lay out list-major.
     Returns (index handle pieces, build seconds split by phase)."""
     n, dim = data.shape
@@ -92,27 +97,31 @@ def build_index(ctx, data, lists, seed, world, rank):
     g = torch.Generator(device=dev)
     g.manual_seed(seed + 1)
     samples = data[torch.randperm(n, generator=g, device=dev)[:ns]].contiguous()
+    if ops != api.PGV_OPS_L2:
+        # spherical opclasses: SampleRows normalises the samples (src/ivfbuild.c:154-155)
+        s32 = samples.float()
+        samples = (s32 / s32.norm(dim=1, keepdim=True).clamp_min(1e-30)).to(samples.dtype).contiguous()
     if world == 1:
-        centers, _, iters = api.kmeans(ctx, api.PGV_OPS_L2, api.PGV_F32, dim, samples, lists,
+        centers, _, iters = api.kmeans(ctx, ops, dtype, dim, samples, lists,
                                        api.make_rng(seed=seed + 2), want_closest=False)
     else:
-        init = api.kmeanspp_init(ctx, api.PGV_OPS_L2, api.PGV_F32, dim, samples, lists, api.make_rng(seed=seed + 2))
+        init = api.kmeanspp_init(ctx, ops, dtype, dim, samples, lists, api.make_rng(seed=seed + 2))
         lo, hi = sharding.row_shard(ns, rank, world)
         local = samples[lo:hi].contiguous()
 
         def partial(s, c, closest):
-            return api.lloyd_partial(ctx, api.PGV_OPS_L2, api.PGV_F32, dim, s, c, closest)
+            return api.lloyd_partial(ctx, ops, dtype, dim, s, c, closest)
 
         def finish(sums, counts, it):
-            return api.lloyd_finish(ctx, api.PGV_OPS_L2, api.PGV_F32, dim, sums, counts,
-                                    api.make_rng(seed=seed + 3 + it), like=sums)
+            return api.lloyd_finish(ctx, ops, dtype, dim, sums, counts,
+                                    api.make_rng(seed=seed + 3 + it), like=local)
         centers, _, iters = sharding.sharded_kmeans(local, init, partial, finish)
     ctx.sync()
     torch.cuda.synchronize()
     t["kmeans"] = time.perf_counter() - t0
     t1 = time.perf_counter()
     lo, hi = sharding.row_shard(n, rank, world)
-    local_lists, _ = api.assign(ctx, api.PGV_L2SQ, api.PGV_F32, dim, centers, data[lo:hi], want_dist=False)
+    local_lists, _ = api.assign(ctx, metric, dtype, dim, centers, data[lo:hi], want_dist=False)
     ctx.sync()
     all_lists = sharding.gather_assignments(local_lists, n, world)
     torch.cuda.synchronize()
@@ -140,14 +149,15 @@ def recall_at_k(ivf_dist, exact_dist, k):
     return float(hit.float().mean().item() / k)
 
 
-def cpu_baseline(centers, offsets, vectors, tids, queries, probes, k, budget_s=12.0):
+def cpu_baseline(centers, offsets, vectors, tids, queries, probes, k, dtype, ops, budget_s=12.0):
     """the oracle (= the reference's loops and kernels restated, built with the reference's
     flags + -march=native) answering the same queries on the host cores of this box"""
     from concurrent.futures import ThreadPoolExecutor
 
     from oracle import pyoracle as po
     ora = po.Oracle(native=True)
-    ix = ora.index_struct(po.OPS_L2, po.ORA_F32, centers, offsets, vectors, tids)
+    ix = ora.index_struct(po.OPS_L2 if ops == api.PGV_OPS_L2 else po.OPS_IP,
+                          po.ORA_F32 if dtype == api.PGV_F32 else po.ORA_F16, centers, offsets, vectors, tids)
     cores = min(os.cpu_count() or 1, 64)
     nq = queries.shape[0]
 
@@ -190,6 +200,8 @@ def main():
     ap.add_argument("--seed", type=int, default=0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--recall-queries", type=int, default=256)
+    ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo for a functional "
+                                                     "multi-rank run on a single GPU)")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -197,13 +209,22 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world,
-                                device_id=torch.device("cuda", local_rank))
+        local_rank = local_rank % max(torch.cuda.device_count(), 1)
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world,
+                                    device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(args.backend, rank=rank, world_size=world)
     assert world == args.gpus or world == 1, "launch N > 1 through torch.distributed.run"
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
 
-    n, dim, lists, probes = WORKLOADS[args.workload]
+    n, dim, lists, probes, tname, oname = WORKLOADS[args.workload]
+    dtype = api.PGV_F32 if tname == "f32" else api.PGV_F16
+    tdtype = torch.float32 if tname == "f32" else torch.float16
+    ops = api.PGV_OPS_L2 if oname == "l2" else api.PGV_OPS_IP
+    metric = api.PGV_L2SQ if oname == "l2" else api.PGV_NEG_IP
+    esize = 4 if tname == "f32" else 2
     if args.probes:
         probes = args.probes
     k = args.k
@@ -212,16 +233,19 @@ def main():
     # ---------------------------------------------------------------- setup
     components = max(lists // 4, 1)
     data, means = gen_mixture(n, dim, components, 0.1, args.seed, dev)
-    log("data: %d x %d generated" % (n, dim))
-    centers, offsets, vectors, tids, iters, build_t = build_index(ctx, data, lists, args.seed, world, rank)
+    data = data.to(tdtype)
+    log("data: %d x %d %s generated" % (n, dim, tname))
+    centers, offsets, vectors, tids, iters, build_t = build_index(ctx, data, lists, args.seed, world, rank,
+                                                                  dtype, ops, metric)
     log("build: %s (k-means iterations %d)" % ({a: round(b, 3) for a, b in build_t.items()}, iters))
-    index = api.IvfIndex(ctx, api.PGV_L2SQ, api.PGV_F32, dim, centers, offsets, vectors, tids.view(torch.int64))
+    index = api.IvfIndex(ctx, metric, dtype, dim, centers, offsets, vectors, tids.view(torch.int64))
     local_rows = int(vectors.shape[0])
+    del data
 
     total_batch = args.batch * world
     pool = 8
     queries, _ = gen_mixture(total_batch * pool, dim, components, 0.1, args.seed + 100, dev, means=means)
-    queries = queries.view(pool, total_batch, dim)
+    queries = queries.to(tdtype).view(pool, total_batch, dim)
 
     out_d = torch.empty((total_batch, k), device=dev, dtype=torch.float32)
     out_s = torch.empty((total_batch, k), device=dev, dtype=torch.int64)
@@ -264,18 +288,18 @@ def main():
     stats = ctx.stats()
     ctx.set_profiling(False)
     if world > 1:
-        el = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        el = torch.tensor([elapsed], dtype=torch.float64, device=dev if args.backend == "nccl" else "cpu")
         dist.all_reduce(el, op=dist.ReduceOp.MAX)
         elapsed = float(el.item())
 
     qps = total_batch * args.steps / elapsed
     launches = max(stats["scan_launches"], 1)
-    algo_bytes = stats["scan_pairs"] * 4.0 * dim       # 4*d bytes per scored vector
-    stream_bytes = stats["scan_rows"] * 4.0 * dim      # rows actually streamed (shared by a query group)
+    algo_bytes = stats["scan_pairs"] * esize * dim     # 4*d (fp32) / 2*d (fp16) bytes per scored vector
+    stream_bytes = stats["scan_rows"] * esize * dim    # rows actually streamed (shared by a query group)
     scan_s = stats["scan_ms"] / 1e3
     achieved = algo_bytes / scan_s / 1e9 if scan_s > 0 else 0.0
     roofline = {
-        "kernel": "scan_kernel (IVFFlat list scan, src/ivfscan.c:123-187)",
+        "kernel": "tile_scan_kernel / scan_kernel (IVFFlat list scan, src/ivfscan.c:123-187)",
         "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
         "frac": achieved / HBM_PEAK_GBS,
         "traffic": pmc_traffic(args.workload, args.batch) if world == 1 else None,
@@ -283,7 +307,7 @@ def main():
         "streamed_bytes_per_launch": stream_bytes / launches,
         "streamed_GBps": stream_bytes / scan_s / 1e9 if scan_s > 0 else 0.0,
         "avg_launch_ms": stats["scan_ms"] / launches, "launches": launches,
-        "note": "achieved = 4*dim bytes per (query,row) pair / kernel time (HIP events on the launch "
+        "note": "achieved = elem_size*dim bytes per (query,row) pair / kernel time (HIP events on the launch "
                 "stream); rows probed by several queries of a batch are read from HBM once per query "
                 "group, so achieved may exceed the physical rate -- streamed_GBps is the physical one",
     }
@@ -292,10 +316,11 @@ def main():
                   else "QPS @ recall@10 (IVFFlat)",
         "value": qps, "unit": "queries/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
-        "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-        "config": {"workload": "%s: IVFFlat vector_l2_ops %d x %d fp32, lists=%d, probes=%d, k=%d, "
+        "vs_baseline": None, "dtype": tname, "data": "synthetic",
+        "config": {"workload": "%s: IVFFlat %s_%s_ops %d x %d %s, lists=%d, probes=%d, k=%d, "
                                "batch=%d queries/step/GPU, Gaussian mixture (%d components, sigma 0.1)"
-                               % (args.workload, n, dim, lists, probes, k, args.batch, components),
+                               % (args.workload, "vector" if tname == "f32" else "halfvec", oname, n, dim, tname,
+                                  lists, probes, k, args.batch, components),
                    "rows": n, "dim": dim, "lists": lists, "probes": probes, "k": k,
                    "batch_per_gpu": args.batch, "parallelism": "lists sharded l %% %d, top-k all-gather" % world,
                    "local_rows": local_rows},
@@ -309,7 +334,7 @@ def main():
         try:
             line["cpu_baseline"] = cpu_baseline(centers.cpu().numpy(), offsets.cpu().numpy(), vectors.cpu().numpy(),
                                                 tids.cpu().numpy().astype(np.uint64),
-                                                queries[1][:256].cpu().numpy(), probes, k)
+                                                queries[1][:256].cpu().numpy(), probes, k, dtype, ops)
         except Exception as e:  # the baseline must never sink the GPU number
             line["cpu_baseline"] = {"value": None, "unit": "queries/s", "cores": 0, "kind": "port",
                                     "sample": "failed: %r" % (e,)}

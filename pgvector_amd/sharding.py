@@ -29,6 +29,29 @@ def rank():
     return dist.get_rank() if dist.is_available() and dist.is_initialized() else 0
 
 
+def _stage(t):
+    """gloo moves host memory: device tensors take a detour through the CPU (functional
+    multi-rank runs on one GPU and the CPU tests); nccl/RCCL works on HBM directly"""
+    if t.is_cuda and dist.get_backend() == "gloo":
+        return t.cpu()
+    return t
+
+
+def _all_gather(t):
+    st = _stage(t.contiguous())
+    out = [torch.empty_like(st) for _ in range(world())]
+    dist.all_gather(out, st)
+    return [o.to(t.device) for o in out]
+
+
+def _all_reduce_sum(t):
+    st = _stage(t)
+    dist.all_reduce(st, op=dist.ReduceOp.SUM)
+    if st is not t:
+        t.copy_(st)
+    return t
+
+
 def owner_of_list(list_ids, world_size):
     """rank that stores each list (round-robin keeps sizes balanced for k-means lists)"""
     return list_ids % world_size
@@ -69,12 +92,8 @@ def merge_topk(local_dist, local_tid, k):
     w = world()
     if w == 1:
         return local_dist, local_tid
-    gd = [torch.empty_like(local_dist) for _ in range(w)]
-    gt = [torch.empty_like(local_tid) for _ in range(w)]
-    dist.all_gather(gd, local_dist.contiguous())
-    dist.all_gather(gt, local_tid.contiguous())
-    d = torch.cat(gd, dim=1)
-    t = torch.cat(gt, dim=1)
+    d = torch.cat(_all_gather(local_dist), dim=1)
+    t = torch.cat(_all_gather(local_tid), dim=1)
     order = torch.sort(d, dim=1, stable=True).indices[:, :k]
     return torch.gather(d, 1, order), torch.gather(t, 1, order)
 
@@ -82,9 +101,9 @@ def merge_topk(local_dist, local_tid, k):
 def allreduce_lloyd(sums, counts, changes):
     """the one exchange of a Lloyd iteration: k*d*4 + k*4 + 8 bytes per rank"""
     if world() > 1:
-        dist.all_reduce(sums, op=dist.ReduceOp.SUM)
-        dist.all_reduce(counts, op=dist.ReduceOp.SUM)
-        dist.all_reduce(changes, op=dist.ReduceOp.SUM)
+        _all_reduce_sum(sums)
+        _all_reduce_sum(counts)
+        _all_reduce_sum(changes)
     return sums, counts, changes
 
 
@@ -117,6 +136,4 @@ def gather_assignments(local_lists, n, world_size=None):
     per = (n + w - 1) // w
     padded = torch.full((per,), -1, dtype=local_lists.dtype, device=local_lists.device)
     padded[: local_lists.numel()] = local_lists
-    out = [torch.empty_like(padded) for _ in range(w)]
-    dist.all_gather(out, padded)
-    return torch.cat(out)[:n]
+    return torch.cat(_all_gather(padded))[:n]
