@@ -22,6 +22,9 @@ namespace {
 constexpr int kTileThreads = 1024;
 constexpr int kTileWaves = kTileThreads / kWave;  // 16: four per SIMD, so a SIMD always has a busy wave
 constexpr int kQW = 1;                            // queries per wavefront -> 16 per workgroup
+#ifndef PGV_TILE_CAP
+#define PGV_TILE_CAP 6
+#endif
 constexpr int kRB = 3;                            // rows scored together (ILP for the LDS reads)
 
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
@@ -59,6 +62,10 @@ template <> __device__ __forceinline__ void lds_wait<3>(u32x4 (&v)[3][3]) {
 template <> __device__ __forceinline__ void lds_wait<4>(u32x4 (&v)[4][3]) {
     asm volatile("s_waitcnt lgkmcnt(0)" : PGV_V3(0), PGV_V3(1), PGV_V3(2), PGV_V3(3)::"memory");
 }
+template <> __device__ __forceinline__ void lds_wait<6>(u32x4 (&v)[6][3]) {
+    asm volatile("s_waitcnt lgkmcnt(0)"
+                 : PGV_V3(0), PGV_V3(1), PGV_V3(2), PGV_V3(3), PGV_V3(4), PGV_V3(5)::"memory");
+}
 #undef PGV_V3
 
 template <typename T, int METRIC, int NCH>
@@ -67,7 +74,6 @@ __global__ __launch_bounds__(kTileThreads) void tile_scan_kernel(
     const ScanTask *__restrict__ tasks, const int *__restrict__ ntasks_ptr,
     int *__restrict__ task_counter, const ScanPair *__restrict__ pairs, float *__restrict__ out,
     int tile_rows) {
-    constexpr int N = VecTraits<T>::N;
     constexpr size_t ROWB = (size_t)NCH * 1024;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     // layout: [2][tile_rows * ROWB] row tiles | int task id
@@ -132,15 +138,14 @@ __global__ __launch_bounds__(kTileThreads) void tile_scan_kernel(
                 const unsigned lrow = (unsigned)(size_t)(__attribute__((address_space(3))) char *)cur +
                                       (unsigned)lane * (unsigned)sizeof(Raw16);
                 for (int r0 = my_rank * kRB; r0 < rows_here; r0 += servers * kRB) {
-                    float acc[kRB];
+                    f32x2 acc[kRB];
 #pragma unroll
-                    for (int i = 0; i < kRB; i++) acc[i] = 0.f;
+                    for (int i = 0; i < kRB; i++) acc[i] = f32x2{0.f, 0.f};
                     // several slices of the three rows are requested from LDS at once (one wait
                     // per round); rows past the end of a ragged tile read stale LDS and are
-                    // never stored.  128 VGPRs per lane: at most 4 slices (2 for fp16, whose
-                    // conversions need room) x 3 rows per round.
-                    constexpr int CAP = N == 8 ? 2 : 4;
-                    constexpr int NS = NCH % CAP == 0 ? CAP : (NCH % 3 == 0 && CAP >= 3 ? 3 : (NCH % 2 == 0 ? 2 : 1));
+                    // never stored.  128 VGPRs per lane bound the slices per round.
+                    constexpr int CAP = PGV_TILE_CAP;
+                    constexpr int NS = NCH <= CAP ? NCH : (NCH % 4 == 0 && CAP >= 4 ? 4 : (NCH % 3 == 0 && CAP >= 3 ? 3 : (NCH % 2 == 0 ? 2 : 1)));
 #pragma unroll
                     for (int h = 0; h < NCH / NS; h++) {
                         u32x4 rv[NS][3];
@@ -153,21 +158,18 @@ __global__ __launch_bounds__(kTileThreads) void tile_scan_kernel(
                         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
                         for (int c = 0; c < NS; c++) {
-                            Unpacked<T> uq(qreg[0][h * NS + c]);
 #pragma unroll
                             for (int i = 0; i < kRB; i++) {
                                 Raw16 raw;
 #pragma unroll
                                 for (int w = 0; w < 4; w++) raw.w[w] = rv[c][i][w];
-                                Unpacked<T> ur(raw);
-#pragma unroll
-                                for (int e = 0; e < N; e++) acc[i] = accum<METRIC>(acc[i], ur.v[e], uq.v[e]);
+                                accum_slice2<T, METRIC>(acc[i], raw, qreg[0][h * NS + c]);
                             }
                         }
                     }
 #pragma unroll
                     for (int i = 0; i < kRB; i++) {
-                        const float sum = group_sum_to_last(acc[i], 6);
+                        const float sum = group_sum_to_last(acc[i].x + acc[i].y, 6);
                         if (lane == kWave - 1 && r0 + i < rows_here)
                             out[rel[0] + task.row0 + r_base + r0 + i] = finish<METRIC>(sum);
                     }

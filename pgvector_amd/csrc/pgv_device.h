@@ -71,6 +71,136 @@ template <int METRIC> __device__ __forceinline__ float accum(float acc, float a,
     }
 }
 
+// Same updates straight from binary16 operands.  Written as fma(ext(a), 1, -ext(b)) /
+// fma(ext(a), ext(b), acc) so that hipcc can select v_fma_mix_f32 (fp16 sources converted
+// inside the FMA, fp32 result): no separate v_cvt per element.  Bit-identical to
+// converting first: a*1 - b and a - b round once, from the same exact value.
+template <int METRIC> __device__ __forceinline__ float accum_h(float acc, __half a, __half b) {
+    if constexpr (METRIC == 1) {
+        return __builtin_fmaf(__half2float(a), __half2float(b), acc);
+    } else {
+        const float d = __builtin_fmaf(__half2float(a), 1.0f, -__half2float(b));
+        if constexpr (METRIC == 0)
+            return __builtin_fmaf(d, d, acc);
+        else
+            return acc + fabsf(d);
+    }
+}
+
+// one 16-byte slice against another: N products folded into acc
+template <typename T, int METRIC> __device__ __forceinline__ float accum_slice(float acc, const Raw16 &a, const Raw16 &b);
+template <> __device__ __forceinline__ float accum_slice<float, 0>(float acc, const Raw16 &a, const Raw16 &b) {
+#pragma unroll
+    for (int i = 0; i < 4; i++) acc = accum<0>(acc, __uint_as_float(a.w[i]), __uint_as_float(b.w[i]));
+    return acc;
+}
+template <> __device__ __forceinline__ float accum_slice<float, 1>(float acc, const Raw16 &a, const Raw16 &b) {
+#pragma unroll
+    for (int i = 0; i < 4; i++) acc = accum<1>(acc, __uint_as_float(a.w[i]), __uint_as_float(b.w[i]));
+    return acc;
+}
+template <> __device__ __forceinline__ float accum_slice<float, 2>(float acc, const Raw16 &a, const Raw16 &b) {
+#pragma unroll
+    for (int i = 0; i < 4; i++) acc = accum<2>(acc, __uint_as_float(a.w[i]), __uint_as_float(b.w[i]));
+    return acc;
+}
+// fp16 difference a - b of the low / high halves of two packed words, as ONE v_fma_mix_f32
+// (a * 1.0 + (-b), fp16 sources extended inside the FMA): hipcc folds the source-level
+// fma(ext(a), 1, -ext(b)) back into two conversions and a subtract, so it is spelled in asm.
+__device__ __forceinline__ float half_diff_lo(uint32_t wa, uint32_t wb) {
+    float d;
+    asm("v_fma_mix_f32 %0, %1, 1.0, -%2 op_sel:[0,0,0] op_sel_hi:[1,0,1]" : "=v"(d) : "v"(wa), "v"(wb));
+    return d;
+}
+__device__ __forceinline__ float half_diff_hi(uint32_t wa, uint32_t wb) {
+    float d;
+    asm("v_fma_mix_f32 %0, %1, 1.0, -%2 op_sel:[1,0,1] op_sel_hi:[1,0,1]" : "=v"(d) : "v"(wa), "v"(wb));
+    return d;
+}
+template <> __device__ __forceinline__ float accum_slice<__half, 0>(float acc, const Raw16 &a, const Raw16 &b) {
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+        const float d0 = half_diff_lo(a.w[i], b.w[i]);
+        acc = __builtin_fmaf(d0, d0, acc);
+        const float d1 = half_diff_hi(a.w[i], b.w[i]);
+        acc = __builtin_fmaf(d1, d1, acc);
+    }
+    return acc;
+}
+template <> __device__ __forceinline__ float accum_slice<__half, 1>(float acc, const Raw16 &a, const Raw16 &b) {
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+        const __half2 ha = *reinterpret_cast<const __half2 *>(&a.w[i]);
+        const __half2 hb = *reinterpret_cast<const __half2 *>(&b.w[i]);
+        acc = accum_h<1>(acc, __low2half(ha), __low2half(hb));
+        acc = accum_h<1>(acc, __high2half(ha), __high2half(hb));
+    }
+    return acc;
+}
+template <> __device__ __forceinline__ float accum_slice<__half, 2>(float acc, const Raw16 &a, const Raw16 &b) {
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+        acc += fabsf(half_diff_lo(a.w[i], b.w[i]));
+        acc += fabsf(half_diff_hi(a.w[i], b.w[i]));
+    }
+    return acc;
+}
+
+// Two-lane accumulators: the fp32 vector ALU reaches its full rate only through the packed
+// instructions (v_pk_add_f32 / v_pk_fma_f32: two elements per lane per issue), so the
+// compute-bound kernels keep even and odd elements in the two halves of a float2 and add the
+// halves at the end (a different but equally valid summation order, SURVEY hard part 3).
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+
+template <typename T, int METRIC>
+__device__ __forceinline__ void accum_slice2(f32x2 &acc, const Raw16 &a, const Raw16 &b);
+
+#define PGV_SLICE2_F(M)                                                                               \
+    template <> __device__ __forceinline__ void accum_slice2<float, M>(f32x2 & acc, const Raw16 &a,  \
+                                                                       const Raw16 &b) {             \
+        _Pragma("unroll") for (int i = 0; i < 4; i += 2) {                                           \
+            const f32x2 va = {__uint_as_float(a.w[i]), __uint_as_float(a.w[i + 1])};                 \
+            const f32x2 vb = {__uint_as_float(b.w[i]), __uint_as_float(b.w[i + 1])};                 \
+            if (M == 1) {                                                                            \
+                acc = __builtin_elementwise_fma(va, vb, acc);                                        \
+            } else {                                                                                 \
+                const f32x2 d = va - vb;                                                             \
+                if (M == 0)                                                                          \
+                    acc = __builtin_elementwise_fma(d, d, acc);                                      \
+                else                                                                                 \
+                    acc += __builtin_elementwise_abs(d);                                             \
+            }                                                                                        \
+        }                                                                                            \
+    }
+PGV_SLICE2_F(0)
+PGV_SLICE2_F(1)
+PGV_SLICE2_F(2)
+#undef PGV_SLICE2_F
+
+template <> __device__ __forceinline__ void accum_slice2<__half, 0>(f32x2 &acc, const Raw16 &a, const Raw16 &b) {
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+        const f32x2 d = {half_diff_lo(a.w[i], b.w[i]), half_diff_hi(a.w[i], b.w[i])};
+        acc = __builtin_elementwise_fma(d, d, acc);
+    }
+}
+template <> __device__ __forceinline__ void accum_slice2<__half, 1>(f32x2 &acc, const Raw16 &a, const Raw16 &b) {
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+        const __half2 ha = *reinterpret_cast<const __half2 *>(&a.w[i]);
+        const __half2 hb = *reinterpret_cast<const __half2 *>(&b.w[i]);
+        acc.x = accum_h<1>(acc.x, __low2half(ha), __low2half(hb));
+        acc.y = accum_h<1>(acc.y, __high2half(ha), __high2half(hb));
+    }
+}
+template <> __device__ __forceinline__ void accum_slice2<__half, 2>(f32x2 &acc, const Raw16 &a, const Raw16 &b) {
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+        acc.x += fabsf(half_diff_lo(a.w[i], b.w[i]));
+        acc.y += fabsf(half_diff_hi(a.w[i], b.w[i]));
+    }
+}
+
 // kernel value -> FUNCTION 1 value: negative inner product is negated (src/vector.c:646)
 template <int METRIC> __device__ __forceinline__ float finish(float acc) {
     if constexpr (METRIC == 1)

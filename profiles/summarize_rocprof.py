@@ -61,12 +61,15 @@ def main():
     # the timed list-scan launches: the `steps` launches of the widest scan kernel that are
     # neither the short center-ranking ones nor the single exact-scan
     steps = bench["steps"]
-    scans = [(dur, lds, vgpr, grid) for name, dur, lds, vgpr, grid, wg in trace if name.startswith("scan_kernel<float, 0, 8")]
+    # the list-scan kernel = the *scan_kernel instantiation with the most total time
+    scan_names = [n for n in by if "scan_kernel" in n]
+    main = max(scan_names, key=lambda n: sum(by[n]))
+    scans = [(dur, lds, vgpr, grid) for name, dur, lds, vgpr, grid, wg in trace if name == main]
     timed = scans[-2 * steps:]  # alternating rank / scan launches of the timed loop
     list_scan = [s for s in timed if s[0] > 5 * min(t[0] for t in timed)]
     if list_scan:
         avg = sum(s[0] for s in list_scan) / len(list_scan)
-        lines += ["", "## timed list-scan launches (scan_kernel<float,0,8,*>)", "",
+        lines += ["", "## timed list-scan launches (%s)" % main, "",
                   "%d launches, avg %.3f ms (min %.3f, max %.3f), LDS %d B/workgroup, %d VGPRs, grid %d threads" % (
                       len(list_scan), avg / 1e6, min(s[0] for s in list_scan) / 1e6, max(s[0] for s in list_scan) / 1e6,
                       list_scan[0][1], list_scan[0][2], list_scan[0][3]),
@@ -75,7 +78,7 @@ def main():
         paths = glob.glob(os.path.join(d, tag, "*_counter_collection.csv"))
         if not paths:
             continue
-        rows = [r for r in load_pmc(paths[0], counter) if r[0].startswith("scan_kernel<float, 0, 8")]
+        rows = [r for r in load_pmc(paths[0], counter) if r[0] == main]
         if not rows:
             continue
         b = json.load(open(os.path.join(d, tag.split("_")[1] + "_bench.json")))
