@@ -194,6 +194,49 @@ def test_search_batch_short_lists_pad(ctx, oracle):
         assert (slot[i][m:] == -1).all() and np.isinf(dist[i][m:]).all() and (slot[i][:m] >= 0).all()
 
 
+def test_full_size_properties_on_device(ctx):
+    """BASELINE-scale shapes through size-independent properties (no CPU oracle at this size):
+    (1) probing every list is an exact scan: the batched path (tile / group kernels, top-k select)
+        must return exactly what a brute-force pgv_distance_batch + sort returns;
+    (2) the unsorted single-query scan holds the same multiset of distances;
+    (3) results do not depend on the batch a query travels in (idempotence)."""
+    import torch
+    n, dim, lists, k = 300_000, 768, 300, 10
+    g = torch.Generator(device="cuda")
+    g.manual_seed(7)
+    data = torch.rand((n, dim), generator=g, device="cuda")
+    centers = data[torch.randperm(n, generator=g, device="cuda")[:lists]].contiguous()
+    assign, _ = api.assign(ctx, api.PGV_L2SQ, api.PGV_F32, dim, centers, data, want_dist=False)
+    order = torch.argsort(assign.long(), stable=True)
+    off = torch.zeros(lists + 1, dtype=torch.int64, device="cuda")
+    off[1:] = torch.cumsum(torch.bincount(assign.long(), minlength=lists), 0)
+    vectors = data[order].contiguous()
+    ix = api.IvfIndex(ctx, api.PGV_L2SQ, api.PGV_F32, dim, centers, off, vectors, order)
+    queries = torch.rand((48, dim), generator=g, device="cuda")
+    dist, slot, tid = ix.search_batch(queries, lists, k, want_tid=True)
+    ctx.sync()
+    for i in (0, 17, 47):
+        brute = api.distance_batch(ctx, api.PGV_L2SQ, api.PGV_F32, dim, queries[i].contiguous(), vectors)
+        ctx.sync()
+        bd, bi = torch.sort(brute, stable=True)
+        assert torch.equal(slot[i], bi[:k]), (slot[i], bi[:k])
+        torch.testing.assert_close(dist[i], bd[:k], rtol=RTOL, atol=0)
+        assert torch.equal(tid[i], order[bi[:k]])
+    # idempotence: the same query alone, and inside another batch
+    d1, s1, _ = ix.search_batch(queries[17:18].contiguous(), 12, k)
+    d2, s2, _ = ix.search_batch(queries[10:30].contiguous(), 12, k)
+    ctx.sync()
+    assert torch.equal(s1[0], s2[7]) and torch.equal(d1[0], d2[7])
+    # unsorted scan of a few lists == the same rows scored by distance_batch
+    probe, _ = ix.rank_lists(queries[3:4].contiguous(), 5)
+    ctx.sync()
+    sd, ss = ix.scan_lists(queries[3].cpu().numpy(), probe[0].cpu().numpy())
+    brute = api.distance_batch(ctx, api.PGV_L2SQ, api.PGV_F32, dim, queries[3].contiguous(), vectors)
+    ctx.sync()
+    np.testing.assert_allclose(sd, brute.cpu().numpy()[ss], rtol=RTOL)
+    ix.close()
+
+
 # ---------------------------------------------------------------------- build
 @pytest.mark.parametrize("ops,dtype,dim,k", [(po.OPS_L2, po.ORA_F32, 48, 37), (po.OPS_IP, po.ORA_F32, 130, 200),
                                              (po.OPS_L2, po.ORA_F16, 64, 129), (po.OPS_L2, po.ORA_F32, 3, 5)])

@@ -1,0 +1,88 @@
+#!/usr/bin/env python3
+"""HNSW candidate-batch scoring (BASELINE configs[3], scaled): vector_cosine_ops, m = 16,
+ef_search = 100, 1536-d unit vectors.  The graph is built by the CPU oracle's restatement of
+the reference build (it is test infrastructure: the product path only SEARCHES); the search is
+the C host glue's lock-step HnswSearchLayer with every expansion step's candidates scored by
+one pgv_hnsw_score launch.  Prints one JSON line.
+
+usage: python tools/bench_hnsw.py [--rows 50000] [--dim 1536] [--queries 1000]
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+from pgvector_amd import _host, api  # noqa: E402
+from oracle import pyoracle as po  # noqa: E402
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--rows", type=int, default=50000)
+    ap.add_argument("--dim", type=int, default=1536)
+    ap.add_argument("--queries", type=int, default=1000)
+    ap.add_argument("--m", type=int, default=16)
+    ap.add_argument("--ef-construction", type=int, default=64)
+    ap.add_argument("--ef-search", type=int, default=100)
+    ap.add_argument("--k", type=int, default=10)
+    a = ap.parse_args()
+    rng = np.random.default_rng(0)
+    comps = rng.random((64, a.dim), dtype=np.float32)
+    data = comps[rng.integers(0, 64, a.rows)] + 0.1 * rng.standard_normal((a.rows, a.dim)).astype(np.float32)
+    queries = comps[rng.integers(0, 64, a.queries)] + 0.1 * rng.standard_normal((a.queries, a.dim)).astype(np.float32)
+    ora = po.Oracle(native=True)
+    t0 = time.perf_counter()
+    g = po.HnswGraph(ora, po.OPS_COSINE, po.ORA_F32, data, m=a.m, ef_construction=a.ef_construction, seed=1)
+    build_s = time.perf_counter() - t0
+    ex = g.export_tuples()
+    unit = data / np.linalg.norm(data.astype(np.float64), axis=1, keepdims=True)
+    stored = np.ascontiguousarray(unit[ex["rows"]].astype(np.float32))
+    qn = np.ascontiguousarray((queries / np.linalg.norm(queries.astype(np.float64), axis=1, keepdims=True)).astype(np.float32))
+
+    ctx = api.Context(0)
+    mirror = api.Hnsw(ctx, api.PGV_NEG_IP, api.PGV_F32, a.dim, stored)
+    graph = _host.hnsw_graph(ex["levels"], ex["nbr_start"], ex["nbr"], a.m, ex["entry"])
+    _host.hnsw_search(mirror, graph, qn[:8], a.ef_search, a.k)  # warm up
+    t0 = time.perf_counter()
+    elem, dist, scored = _host.hnsw_search(mirror, graph, qn, a.ef_search, a.k)
+    gpu_s = time.perf_counter() - t0
+
+    # exact ground truth on the same unit vectors (cosine distance order = -ip order)
+    ip = qn.astype(np.float64) @ stored.astype(np.float64).T
+    kth = -np.sort(-ip, axis=1)[:, a.k - 1]
+    hits = 0
+    for i in range(a.queries):
+        e = elem[i][elem[i] >= 0]
+        hits += int((ip[i, e] >= kth[i] - 1e-9).sum())
+    recall = hits / (a.queries * a.k)
+
+    # the oracle's search, one thread (one backend)
+    t0 = time.perf_counter()
+    n_cpu = min(a.queries, 200)
+    cpu_scored = 0
+    for i in range(n_cpu):
+        _, _, sc = g.search(queries[i], a.ef_search, a.k)
+        cpu_scored += sc
+    cpu_s = time.perf_counter() - t0
+    print(json.dumps({
+        "metric": "HNSW QPS (candidate-batch scoring on GPU, graph walk on host)", "value": a.queries / gpu_s,
+        "unit": "queries/s", "config": {"rows": a.rows, "dim": a.dim, "m": a.m, "ef_construction": a.ef_construction,
+                                        "ef_search": a.ef_search, "k": a.k, "queries_in_lock_step": a.queries,
+                                        "ops": "vector_cosine_ops"},
+        "recall_at_k": recall, "scored_elements_per_query": float(scored.mean()),
+        "algorithmic_GBps": float(scored.sum()) * a.dim * 4 / gpu_s / 1e9,
+        "cpu_baseline": {"value": n_cpu / cpu_s, "unit": "queries/s", "cores": 1, "kind": "port",
+                         "sample": "%d queries, oracle HnswSearchLayer on one thread" % n_cpu,
+                         "scored_elements_per_query": cpu_scored / n_cpu},
+        "graph_build_secs_cpu_oracle": build_s, "elements": int(g.nelements)}))
+
+
+if __name__ == "__main__":
+    main()
