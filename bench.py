@@ -307,6 +307,10 @@ def main():
         "streamed_bytes_per_launch": stream_bytes / launches,
         "streamed_GBps": stream_bytes / scan_s / 1e9 if scan_s > 0 else 0.0,
         "avg_launch_ms": stats["scan_ms"] / launches, "launches": launches,
+        # the batched kernel is bound by fp32 vector-ALU issue once rows are shared by many queries:
+        # 3 flop per element (subtract, multiply, add) for L2, 2 for inner product
+        "valu_tflops": stats["scan_pairs"] * dim * (3.0 if oname == "l2" else 2.0) / scan_s / 1e12 if scan_s > 0 else 0.0,
+        "valu_peak_tflops": 157.3,
         "note": "achieved = elem_size*dim bytes per (query,row) pair / kernel time (HIP events on the launch "
                 "stream); rows probed by several queries of a batch are read from HBM once per query "
                 "group, so achieved may exceed the physical rate -- streamed_GBps is the physical one",
