@@ -68,6 +68,11 @@ def log(*a):
         print(*a, file=sys.stderr, flush=True)
 
 
+def dbg(*a):
+    if os.environ.get("PGV_BENCH_DEBUG"):
+        print("[rank %s]" % os.environ.get("RANK", "0"), *a, file=sys.stderr, flush=True)
+
+
 def gen_mixture(n, dim, components, sigma, seed, device, means=None):
     """seeded Gaussian mixture, generated on the device in slabs"""
     g = torch.Generator(device=device)
@@ -105,7 +110,9 @@ def build_index(ctx, data, lists, seed, world, rank, dtype, ops, metric):
         centers, _, iters = api.kmeans(ctx, ops, dtype, dim, samples, lists,
                                        api.make_rng(seed=seed + 2), want_closest=False)
     else:
+        dbg("kmeans++ init")
         init = api.kmeanspp_init(ctx, ops, dtype, dim, samples, lists, api.make_rng(seed=seed + 2))
+        dbg("kmeans++ done")
         lo, hi = sharding.row_shard(ns, rank, world)
         local = samples[lo:hi].contiguous()
 
@@ -115,10 +122,12 @@ def build_index(ctx, data, lists, seed, world, rank, dtype, ops, metric):
         def finish(sums, counts, it):
             return api.lloyd_finish(ctx, ops, dtype, dim, sums, counts,
                                     api.make_rng(seed=seed + 3 + it), like=local)
-        centers, _, iters = sharding.sharded_kmeans(local, init, partial, finish)
+        centers, _, iters = sharding.sharded_kmeans(local, init, partial, finish,
+                                                    on_iter=(lambda *a: dbg("iter", *a)) if os.environ.get("PGV_BENCH_DEBUG") else None)
     ctx.sync()
     torch.cuda.synchronize()
     t["kmeans"] = time.perf_counter() - t0
+    dbg("kmeans done", iters)
     t1 = time.perf_counter()
     lo, hi = sharding.row_shard(n, rank, world)
     local_lists, _ = api.assign(ctx, metric, dtype, dim, centers, data[lo:hi], want_dist=False)
@@ -252,7 +261,17 @@ def main():
     out_t = torch.empty((total_batch, k), device=dev, dtype=torch.int64)
 
     def step(i):
-        index.search_batch(queries[i % pool], probes, k, want_tid=True, out=(out_d, out_s, out_t))
+        q = queries[i % pool]
+        if world == 1:
+            index.search_batch(q, probes, k, want_tid=True, out=(out_d, out_s, out_t))
+            return out_d, out_t
+        # N GPUs: each rank ranks its own slice of the batch against the replicated centers,
+        # the probe lists are all-gathered, each rank scans the lists it owns, and the
+        # per-rank top-k are merged -- per-GPU work per step does not grow with N
+        mine = q[rank * args.batch:(rank + 1) * args.batch]
+        lists_mine, _ = index.rank_lists(mine, probes, want_dist=False)
+        lists_all = sharding.gather_probe_lists(lists_mine)
+        index.scan_batch(q, lists_all, k, want_tid=True, out=(out_d, out_s, out_t))
         return sharding.merge_topk(out_d, out_t, k)
 
     # ---------------------------------------------------------------- recall

@@ -120,8 +120,12 @@ int			pgv_device_count(void);
 /*
  * Create the per-backend GPU context: lazily from _PG_init (src/vector.c:57-65)
  * or on first use.  `stream` is an existing hipStream_t to enqueue on (as
- * void*), or NULL to create a private non-blocking stream.
+ * void*), PGV_DEFAULT_STREAM for the device's default stream (whose handle is
+ * itself NULL), or NULL to create a private non-blocking stream.  A caller that
+ * produces inputs / consumes outputs in HBM on its own stream must pass that
+ * stream, or bracket calls with its own synchronisation.
  */
+#define PGV_DEFAULT_STREAM ((void *) (intptr_t) -1)	/* the device's default (NULL) hipStream_t */
 int			pgv_ctx_create(int device, void *stream, pgv_ctx * *out);
 void		pgv_ctx_destroy(pgv_ctx * ctx);
 int			pgv_ctx_sync(pgv_ctx * ctx);
@@ -205,6 +209,17 @@ int			pgv_scan_lists(pgv_index * index, const void *query, const int32_t *lists,
  */
 int			pgv_search_batch(pgv_index * index, const void *queries, int nq, int probes, int k,
 							 float *out_dist, int64_t *out_slot, uint64_t *out_tid);
+
+/*
+ * The GetScanItems half of pgv_search_batch on its own: the probe lists were chosen
+ * elsewhere (pgv_rank_lists, possibly on another GPU: with the index sharded by list,
+ * every rank ranks a slice of the queries against the replicated centers, the probe lists
+ * are all-gathered, and each rank scans the lists it owns).  Lists that are empty in this
+ * image contribute nothing.
+ *   probe_lists [nq x probes] list ids, ascending by distance per query
+ */
+int			pgv_scan_batch(pgv_index * index, const void *queries, int nq, const int32_t *probe_lists,
+						   int probes, int k, float *out_dist, int64_t *out_slot, uint64_t *out_tid);
 
 /* ------------------------------------------------------ IVFFlat build side */
 

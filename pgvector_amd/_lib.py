@@ -33,7 +33,7 @@ SYMBOLS = [
     "pgv_last_error", "pgv_abi_version", "pgv_device_count", "pgv_ctx_create", "pgv_ctx_destroy",
     "pgv_ctx_sync", "pgv_ctx_stream", "pgv_timer_start", "pgv_timer_stop", "pgv_ctx_set_profiling",
     "pgv_ctx_reset_stats", "pgv_ctx_get_stats", "pgv_index_upload", "pgv_index_free",
-    "pgv_index_rows", "pgv_index_lists", "pgv_rank_lists", "pgv_scan_lists", "pgv_search_batch",
+    "pgv_index_rows", "pgv_index_lists", "pgv_rank_lists", "pgv_scan_lists", "pgv_search_batch", "pgv_scan_batch",
     "pgv_assign", "pgv_kmeans", "pgv_lloyd_partial", "pgv_lloyd_finish", "pgv_kmeanspp_init",
     "pgv_distance_batch", "pgv_hnsw_upload", "pgv_hnsw_free", "pgv_hnsw_score",
 ]
@@ -92,6 +92,7 @@ def _load():
     lib.pgv_rank_lists.argtypes = [P, P, I, I, P, P]
     lib.pgv_scan_lists.argtypes = [P, P, P, I, P, P, I64, C.POINTER(I64)]
     lib.pgv_search_batch.argtypes = [P, P, I, I, I, P, P, P]
+    lib.pgv_scan_batch.argtypes = [P, P, I, P, I, I, P, P, P]
     lib.pgv_assign.argtypes = [P, I, I, I, P, I, P, I64, P, P]
     lib.pgv_kmeans.argtypes = [P, I, I, I, P, I, I, I, C.POINTER(PgvRng), P, P, C.POINTER(I)]
     lib.pgv_lloyd_partial.argtypes = [P, I, I, I, P, I, P, I, P, P, P, P]

@@ -62,8 +62,16 @@ def make_rng(seed=0, next_double=None, next_u32=None, state=None):
 
 class Context:
     def __init__(self, device=0, stream=None):
+        """stream: None -> a private stream; an int hipStream_t handle -> enqueue on that stream
+        (0, the handle of the default stream, is passed as PGV_DEFAULT_STREAM)"""
         h = C.c_void_p()
-        check(lib.pgv_ctx_create(device, C.c_void_p(stream) if stream else None, C.byref(h)))
+        if stream is None:
+            arg = None
+        elif stream == 0:
+            arg = C.c_void_p(-1)  # PGV_DEFAULT_STREAM
+        else:
+            arg = C.c_void_p(stream)
+        check(lib.pgv_ctx_create(device, arg, C.byref(h)))
         self.h = h
         self._children = []  # weakrefs: index/hnsw handles must be freed before their context
 
@@ -184,6 +192,28 @@ class IvfIndex:
             dist, slot, tid = out
         check(lib.pgv_search_batch(self.h, ptr(queries), nq, probes, k, ptr(dist), ptr(slot), ptr(tid)))
         return dist, slot, tid
+
+
+def _scan_batch(self, queries, probe_lists, k, want_tid=False, out=None):
+    """GetScanItems + sorted head for probe lists chosen elsewhere (pgv_scan_batch)"""
+    queries = as_dtype(queries, self.dtype)
+    nq = int(queries.shape[0])
+    if not _is_torch(probe_lists):
+        probe_lists = np.ascontiguousarray(probe_lists, dtype=np.int32)
+    probes = int(probe_lists.shape[1])
+    if out is None:
+        dist = _empty_like_kind(queries, (nq, k), np.float32)
+        slot = _empty_like_kind(queries, (nq, k), np.int64)
+        tid = _empty_like_kind(queries, (nq, k), np.uint64 if not _on_device(queries) else np.int64) \
+            if want_tid else None
+    else:
+        dist, slot, tid = out
+    check(lib.pgv_scan_batch(self.h, ptr(queries), nq, ptr(probe_lists), probes, k, ptr(dist), ptr(slot),
+                             ptr(tid)))
+    return dist, slot, tid
+
+
+IvfIndex.scan_batch = _scan_batch
 
 
 def assign(ctx, metric, dtype, dim, centers, rows, want_dist=True):

@@ -409,7 +409,9 @@ int pgv_ctx_create(int device, void *stream, pgv_ctx **out) {
     if (!ctx) PGV_FAIL(PGV_ERR_NOMEM, "out of host memory");
     ctx->device = device;
     ctx->num_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
-    if (stream) {
+    if (stream == PGV_DEFAULT_STREAM) {
+        ctx->stream = nullptr;  // the legacy default stream
+    } else if (stream) {
         ctx->stream = static_cast<hipStream_t>(stream);
     } else {
         hipError_t e = hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking);
@@ -752,30 +754,13 @@ int pgv_scan_lists(pgv_index *ix, const void *query, const int32_t *lists, int n
     return sync_if(ctx, need);
 }
 
-int pgv_search_batch(pgv_index *ix, const void *queries, int nq, int probes, int k, float *out_dist,
-                     int64_t *out_slot, uint64_t *out_tid) {
-    if (!ix) PGV_FAIL(PGV_ERR_ARG, "pgv_search_batch: index is NULL");
-    if (nq < 0 || k < 1) PGV_FAIL(PGV_ERR_ARG, "bad nq/k");
-    if (probes < 1 || probes > ix->nlists)
-        PGV_FAIL(PGV_ERR_ARG, "probes %d outside 1..lists (%d)", probes, ix->nlists);
-    if (out_tid && !ix->tids) PGV_FAIL(PGV_ERR_STATE, "index was uploaded without tids");
-    if (nq == 0) return PGV_OK;
-    if (!queries || !out_dist) PGV_FAIL(PGV_ERR_ARG, "queries/out_dist is NULL");
+// GetScanItems + head of the sorted stream for staged queries and device probe lists
+static int scan_batch_dev(pgv_index *ix, const void *q_dev, int nq, const int32_t *probe_lists, int probes,
+                          int k, float *out_dist, int64_t *out_slot, uint64_t *out_tid) {
     pgv_ctx *ctx = ix->ctx;
-    PGV_HIP(hipSetDevice(ctx->device));
-
-    const void *q_dev;
-    PGV_TRY(stage_rows(ctx, queries, nq, ix->dim, ix->dtype, ix->geom, ctx->q_stage, &q_dev));
-
-    // 1. GetScanLists for the whole batch
-    PGV_TRY(ctx->idx_stage.ensure(sizeof(int32_t) * (size_t)nq * probes));
-    int32_t *probe_lists = ctx->idx_stage.as<int32_t>();
-    PGV_TRY(rank_lists_dev(ix, q_dev, nq, probes, probe_lists, nullptr));
-
-    // 2. invert to list-major work
-    // queries per list on average decides how wide a group is worth.  Lists probed by more
-    // than 8 queries go to the tile kernel (16 queries per pass over the rows) when the row
-    // shape allows it; PGV_TILE=0/1 overrides for experiments.
+    // invert to list-major work.  Queries per list on average decides how wide a group is
+    // worth.  Lists probed by more than 8 queries go to the tile kernel (16 queries per pass
+    // over the rows) when the row shape allows it; PGV_TILE=0/1 overrides for experiments.
     const double share = (double)nq * probes / (double)ix->nlists;
     static const int tile_env = getenv("PGV_TILE") ? atoi(getenv("PGV_TILE")) : -1;
     const bool use_tile = tile_scan_supported(ix->geom) && (tile_env == 1 || (tile_env != 0 && share > 8.0));
@@ -786,7 +771,7 @@ int pgv_search_batch(pgv_index *ix, const void *queries, int nq, int probes, int
     PlanResult plan;
     PGV_TRY(launch_plan_batch(ctx, ix, probe_lists, nq, probes, qt, rows_per_task, ctx->profiling, &plan));
 
-    // 3. GetScanItems: one streaming pass
+    // GetScanItems: one streaming pass
     PGV_TRY(ctx->plan_d.ensure(sizeof(float) * (size_t)(plan.out_bound > 0 ? plan.out_bound : 1)));
     float *seg_vals = ctx->plan_d.as<float>();
     if (plan.ntasks_bound > 0) {
@@ -801,7 +786,7 @@ int pgv_search_batch(pgv_index *ix, const void *queries, int nq, int probes, int
         PGV_TRY(timer.end());
     }
 
-    // 4. head of the sorted stream
+    // head of the sorted stream
     OutArg od, os, ot;
     PGV_TRY(od.init(out_dist, sizeof(float) * (size_t)nq * k, ctx->out_stage));
     PGV_TRY(os.init(out_slot, sizeof(int64_t) * (size_t)nq * k, ctx->out_stage2));
@@ -816,6 +801,46 @@ int pgv_search_batch(pgv_index *ix, const void *queries, int nq, int probes, int
     PGV_TRY(os.finish(ctx, &need));
     PGV_TRY(ot.finish(ctx, &need));
     return sync_if(ctx, need);
+}
+
+static int check_batch_args(pgv_index *ix, const void *queries, int nq, int probes, int k, float *out_dist,
+                            uint64_t *out_tid, const char *who) {
+    if (!ix) PGV_FAIL(PGV_ERR_ARG, "%s: index is NULL", who);
+    if (nq < 0 || k < 1) PGV_FAIL(PGV_ERR_ARG, "bad nq/k");
+    if (probes < 1 || probes > ix->nlists)
+        PGV_FAIL(PGV_ERR_ARG, "probes %d outside 1..lists (%d)", probes, ix->nlists);
+    if (out_tid && !ix->tids) PGV_FAIL(PGV_ERR_STATE, "index was uploaded without tids");
+    if (nq > 0 && (!queries || !out_dist)) PGV_FAIL(PGV_ERR_ARG, "queries/out_dist is NULL");
+    return PGV_OK;
+}
+
+int pgv_search_batch(pgv_index *ix, const void *queries, int nq, int probes, int k, float *out_dist,
+                     int64_t *out_slot, uint64_t *out_tid) {
+    PGV_TRY(check_batch_args(ix, queries, nq, probes, k, out_dist, out_tid, "pgv_search_batch"));
+    if (nq == 0) return PGV_OK;
+    pgv_ctx *ctx = ix->ctx;
+    PGV_HIP(hipSetDevice(ctx->device));
+    const void *q_dev;
+    PGV_TRY(stage_rows(ctx, queries, nq, ix->dim, ix->dtype, ix->geom, ctx->q_stage, &q_dev));
+    // GetScanLists for the whole batch
+    PGV_TRY(ctx->idx_stage.ensure(sizeof(int32_t) * (size_t)nq * probes));
+    int32_t *probe_lists = ctx->idx_stage.as<int32_t>();
+    PGV_TRY(rank_lists_dev(ix, q_dev, nq, probes, probe_lists, nullptr));
+    return scan_batch_dev(ix, q_dev, nq, probe_lists, probes, k, out_dist, out_slot, out_tid);
+}
+
+int pgv_scan_batch(pgv_index *ix, const void *queries, int nq, const int32_t *probe_lists, int probes, int k,
+                   float *out_dist, int64_t *out_slot, uint64_t *out_tid) {
+    PGV_TRY(check_batch_args(ix, queries, nq, probes, k, out_dist, out_tid, "pgv_scan_batch"));
+    if (nq == 0) return PGV_OK;
+    if (!probe_lists) PGV_FAIL(PGV_ERR_ARG, "probe_lists is NULL");
+    pgv_ctx *ctx = ix->ctx;
+    PGV_HIP(hipSetDevice(ctx->device));
+    const void *q_dev, *pl_dev;
+    PGV_TRY(stage_rows(ctx, queries, nq, ix->dim, ix->dtype, ix->geom, ctx->q_stage, &q_dev));
+    PGV_TRY(stage_flat(ctx, probe_lists, sizeof(int32_t) * (size_t)nq * probes, ctx->idx_stage, &pl_dev));
+    return scan_batch_dev(ix, q_dev, nq, static_cast<const int32_t *>(pl_dev), probes, k, out_dist, out_slot,
+                          out_tid);
 }
 
 // ================================================================= build side

@@ -85,6 +85,14 @@ def local_index_arrays(vectors_sorted, tids_sorted, list_offsets, r, world_size)
     return vectors_sorted[keep].contiguous(), tids_sorted[keep].contiguous(), local_off
 
 
+def gather_probe_lists(local_lists):
+    """every rank ranked its own slice of the query batch against the replicated centers;
+    concatenate the slices' probe lists in rank order -> [nq_total x probes] on every rank"""
+    if world() == 1:
+        return local_lists
+    return torch.cat(_all_gather(local_lists), dim=0)
+
+
 def merge_topk(local_dist, local_tid, k):
     """All-gather every rank's [nq x k] (distance, tid) and keep the k nearest per
     query: the final top-k merge (ascending; ties: lower rank first, then the
@@ -107,7 +115,7 @@ def allreduce_lloyd(sums, counts, changes):
     return sums, counts, changes
 
 
-def sharded_kmeans(samples_local, init_centers, partial_fn, finish_fn, max_iterations=500):
+def sharded_kmeans(samples_local, init_centers, partial_fn, finish_fn, max_iterations=500, on_iter=None):
     """Lloyd iterations with sharded samples and replicated centers.
 
     partial_fn(samples_local, centers, closest) -> (sums [k x d] fp32, counts [k] i32, changes [1] i64)
@@ -121,7 +129,10 @@ def sharded_kmeans(samples_local, init_centers, partial_fn, finish_fn, max_itera
     it = 0
     for it in range(max_iterations):
         sums, counts, changes = partial_fn(samples_local, centers, closest)
+        local_changes = int(changes.item()) if on_iter else 0
         sums, counts, changes = allreduce_lloyd(sums, counts, changes)
+        if on_iter:
+            on_iter(it, local_changes, int(changes.item()), int(counts.sum().item()))
         centers = finish_fn(sums, counts, it)
         if int(changes.item()) == 0 and it != 0:
             break

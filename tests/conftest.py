@@ -22,6 +22,6 @@ def oracle():
 def ctx():
     """one GPU context for the whole session (gpu tests only)"""
     import pgvector_amd
-    c = pgvector_amd.api.Context(0)
+    c = pgvector_amd.api.Context(0, stream=0)  # the default stream: ordered with torch tensors made in tests
     yield c
     c.close()

@@ -170,6 +170,18 @@ def test_search_batch_many_queries_per_list(ctx, oracle, ops, dtype, dim, nq, pr
                           what="tile ops %d dim %d q %d" % (ops, dim, i))
 
 
+def test_scan_batch_with_given_probe_lists(ctx, oracle, small_ivf):
+    """pgv_scan_batch = the GetScanItems half of pgv_search_batch (multi-GPU splits the two)"""
+    ix = _upload(ctx, small_ivf)
+    queries = gen(40, 64, seed=151, dist="clustered", clusters=40)
+    lists, _ = ix.rank_lists(queries, 6)
+    d1, s1, t1 = ix.search_batch(queries, 6, 12, want_tid=True)
+    d2, s2, t2 = ix.scan_batch(queries, lists, 12, want_tid=True)
+    np.testing.assert_array_equal(s1, s2)
+    np.testing.assert_array_equal(d1, d2)
+    np.testing.assert_array_equal(t1, t2)
+
+
 def test_search_batch_exact_when_probing_every_list(ctx, oracle):
     """probes = lists is an exact scan: returned row ids must equal brute force"""
     data = gen(5000, 32, seed=31)
