@@ -8,6 +8,7 @@
 #include "pgv_device.h"
 
 #include <cfloat>
+#include <climits>
 
 namespace pgv {
 
@@ -57,33 +58,71 @@ __global__ __launch_bounds__(kKmThreads) void kmpp_update_kernel(
     if (threadIdx.x == 0) block_sums[blockIdx.x] = red[0];
 }
 
+// The reference's walk `choice -= v[j]; if (choice <= 0) break;` over [begin, end), kept in its
+// sequential association but without a data-dependent exit in the serial part: lane 0 writes the
+// running value after every step of a 256-entry batch (independent LDS loads, one dependent
+// subtraction each), then the block looks for the first non-positive one in parallel.
+// Returns that index (or `end`); *carry is the running value on entry to it.
+struct WalkLds {
+    double v[kKmThreads];
+    double r[kKmThreads];
+    double carry;
+    int first;
+};
+
+template <typename V>
+__device__ int walk_first_nonpositive(const V *__restrict__ vals, int begin, int end, WalkLds &w) {
+    const int tid = threadIdx.x;
+    for (int base = begin; base < end; base += kKmThreads) {
+        const int i = base + tid;
+        w.v[tid] = i < end ? (double)vals[i] : 0.0;
+        if (tid == 0) w.first = INT_MAX;
+        __syncthreads();
+        if (tid == 0) {
+            double c = w.carry;
+#pragma unroll 16
+            for (int j = 0; j < kKmThreads; j++) {
+                c -= w.v[j];
+                w.r[j] = c;
+            }
+        }
+        __syncthreads();
+        if (i < end && w.r[tid] <= 0) atomicMin(&w.first, tid);
+        __syncthreads();
+        const int f = w.first;
+        if (tid == 0) w.carry = f == INT_MAX ? w.r[kKmThreads - 1] : (f == 0 ? w.carry : w.r[f - 1]);
+        __syncthreads();
+        if (f != INT_MAX) return base + f;
+    }
+    return end;
+}
+
 // choice = sum * RandomDouble(); walk the weights until it is used up
 // (ivfkmeans.c:77-84); the chosen sample becomes center `next`.
 __global__ __launch_bounds__(kKmThreads) void kmpp_pick_kernel(
     const char *__restrict__ samples, int n, const float *__restrict__ weight,
     const double *__restrict__ block_sums, int nblocks, const double *__restrict__ draws,
     int round, char *__restrict__ centers, int nvec, int32_t *__restrict__ picked) {
-    __shared__ int chosen;
-    if (threadIdx.x == 0) {
-        double sum = 0.0;
-        for (int b = 0; b < nblocks; b++) sum += block_sums[b];
-        double choice = sum * draws[round];
-        int b = 0;
-        // skip whole blocks while the walk cannot end inside them
-        while (b < nblocks - 1 && choice - block_sums[b] > 0) {
-            choice -= block_sums[b];
-            b++;
+    __shared__ WalkLds w;
+    // the total: block sums added in block order
+    double sum = 0.0;
+    for (int base = 0; base < nblocks; base += kKmThreads) {
+        const int i = base + threadIdx.x;
+        __syncthreads();
+        w.v[threadIdx.x] = i < nblocks ? block_sums[i] : 0.0;
+        __syncthreads();
+        if (threadIdx.x == 0) {
+#pragma unroll 16
+            for (int j = 0; j < kKmThreads; j++) sum += w.v[j];
         }
-        int j = b * kKmThreads;
-        const int last = n - 1;
-        for (; j < last; j++) {
-            choice -= (double)weight[j];
-            if (choice <= 0) break;
-        }
-        chosen = j;
-        picked[round + 1] = j;
     }
+    if (threadIdx.x == 0) w.carry = sum * draws[round];
     __syncthreads();
+    // skip whole blocks while the walk cannot end inside them, then walk that block's weights
+    // (and on, should rounding carry the walk past it); the last sample ends it regardless
+    const int b = walk_first_nonpositive(block_sums, 0, nblocks - 1, w);
+    const int chosen = walk_first_nonpositive(weight, b * kKmThreads, n - 1, w);
+    if (threadIdx.x == 0) picked[round + 1] = chosen;
     const size_t row_bytes = (size_t)nvec * sizeof(Raw16);
     const Raw16 *src = reinterpret_cast<const Raw16 *>(samples + (size_t)chosen * row_bytes);
     Raw16 *dst = reinterpret_cast<Raw16 *>(centers + (size_t)(round + 1) * row_bytes);
