@@ -21,7 +21,8 @@ except ImportError:  # pragma: no cover
     torch = None
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libpgv_hip.so")
+# PGV_HIP_LIB points at another build of the same library (kernel experiments: tools/ablate_tile.sh)
+LIB_PATH = os.environ.get("PGV_HIP_LIB") or os.path.join(_HERE, "lib", "libpgv_hip.so")
 
 PGV_OK, PGV_ERR_ARG, PGV_ERR_DIMS, PGV_ERR_DEVICE, PGV_ERR_NOMEM, PGV_ERR_STATE, PGV_ERR_DATA = range(7)
 PGV_F32, PGV_F16 = 0, 1

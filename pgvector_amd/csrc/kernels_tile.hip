@@ -22,8 +22,11 @@ namespace {
 constexpr int kTileThreads = 1024;
 constexpr int kTileWaves = kTileThreads / kWave;  // 16: four per SIMD, so a SIMD always has a busy wave
 constexpr int kQW = 1;                            // queries per wavefront -> 16 per workgroup
+#ifndef PGV_TILE_ABLATE
+#define PGV_TILE_ABLATE 0
+#endif
 #ifndef PGV_TILE_CAP
-#define PGV_TILE_CAP 6
+#define PGV_TILE_CAP 3
 #endif
 constexpr int kRB = 3;                            // rows scored together (ILP for the LDS reads)
 
@@ -68,6 +71,19 @@ template <> __device__ __forceinline__ void lds_wait<6>(u32x4 (&v)[6][3]) {
 }
 #undef PGV_V3
 
+// what a wavefront does in one pass over a tile: which query of the task it serves, which of
+// that query's servers it is, and how many servers the query has
+struct Slot {
+    int q, rank, servers;
+    int64_t rel;  // out index of (this query, row 0 of the task)
+    __device__ __forceinline__ void init(int wave, int n, int first) {
+        const int j = wave % n;
+        q = first + j;
+        rank = wave / n;
+        servers = (kTileWaves - 1 - j) / n + 1;
+    }
+};
+
 template <typename T, int METRIC, int NCH>
 __global__ __launch_bounds__(kTileThreads) void tile_scan_kernel(
     const char *__restrict__ rows, const char *__restrict__ queries,
@@ -83,31 +99,53 @@ __global__ __launch_bounds__(kTileThreads) void tile_scan_kernel(
     const int lane = threadIdx.x & (kWave - 1);
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);  // provably wave-uniform
     const int ntasks = *ntasks_ptr;
+#ifdef PGV_TILE_TIMING  // experiment build: where a workgroup's wall time goes (printed for a few of them)
+    unsigned long long tm_start = wall_clock64(), tm_setup = 0, tm_score = 0, tm_wait = 0, tm_mark;
+    int tm_tasks = 0, tm_tiles = 0;
+#define PGV_TM(x) x
+#else
+#define PGV_TM(x)
+#endif
 
     for (;;) {
+        PGV_TM(tm_mark = wall_clock64();)
         if (threadIdx.x == 0) *lds_task = atomicAdd(task_counter, 1);
         __syncthreads();
         const int t = *lds_task;
+#ifdef PGV_TILE_TIMING
+        if (t >= ntasks) {
+            if (threadIdx.x == 0 && (blockIdx.x < 3 || blockIdx.x == 200))
+                printf("wg %d: total %llu setup %llu score %llu wait %llu (x10ns) tasks %d tiles %d\n", blockIdx.x,
+                       wall_clock64() - tm_start, tm_setup, tm_score, tm_wait, tm_tasks, tm_tiles);
+            return;
+        }
+        tm_tasks++;
+#else
         if (t >= ntasks) return;
+#endif
         const ScanTask task = tasks[t];
 
         // Query j of the task is served by wavefront j and, when the task has fewer than 16
-        // queries, also by the otherwise idle wavefronts j + npairs, j + 2*npairs, ...: the
-        // servers of a query take the row batches of a tile round-robin.  Waves sit on the
-        // SIMDs cyclically, so this evens out the VALU work per SIMD.  The query lives in
-        // this wavefront's registers for the whole task.
+        // queries, also by the otherwise idle wavefronts j + n, j + 2n, ...: the servers of a
+        // query take the row batches of a tile round-robin.  With 9..12 queries that would leave
+        // the single-server queries four batches per tile next to two for the others, so those
+        // tasks run two passes per tile instead: queries 0..7 with two servers each, then the
+        // remaining 1..4 with 4..16 servers each (three batch times instead of four).  A
+        // wavefront keeps the query of each pass in registers for the whole task.
         const int np = task.npairs;
-        const int my_q = wave % np;                        // query served (np >= 1)
-        const int my_rank = wave / np;                     // which of its servers this wave is
-        const int servers = (kTileWaves - 1 - my_q) / np + 1;
-        Raw16 qreg[kQW][NCH];
-        int64_t rel[kQW];
-        {
-            const ScanPair pr = pairs[task.pair0 + my_q];
-            rel[0] = pr.out_rel;
+        const bool two_pass = np > 8 && np <= 12;
+        Slot slot[2];
+        Raw16 qreg[2][NCH];
+        slot[0].init(wave, two_pass ? 8 : np, 0);
+        slot[1].init(wave, two_pass ? np - 8 : 1, 8);
+#pragma unroll
+        for (int s = 0; s < 2; s++) {
+            if (s == 1 && !two_pass) break;
+            const ScanPair pr = pairs[task.pair0 + slot[s].q];
+            slot[s].rel = pr.out_rel + task.row0;
             const char *qp = queries + (size_t)pr.query * ROWB + (size_t)lane * sizeof(Raw16);
 #pragma unroll
-            for (int c = 0; c < NCH; c++) qreg[0][c] = load16(qp + (size_t)c * 1024);
+            for (int c = 0; c < NCH; c++) qreg[s][c] = load16(qp + (size_t)c * 1024);
         }
 
         // DMA one tile: 1 KiB slice i of the tile goes to LDS offset i * 1024 (+ lane * 16,
@@ -125,19 +163,23 @@ __global__ __launch_bounds__(kTileThreads) void tile_scan_kernel(
         const int ntiles = (task.nrows + tile_rows - 1) / tile_rows;
         issue_tile(0, smem);
         __syncthreads();  // vmcnt(0) + barrier: tile 0 (and the query registers) have landed
+        PGV_TM(tm_setup += wall_clock64() - tm_mark;)
 
         for (int ti = 0; ti < ntiles; ti++) {
             char *cur = smem + (size_t)(ti & 1) * tile_bytes;
             char *nxt = smem + (size_t)((ti + 1) & 1) * tile_bytes;
+#if PGV_TILE_ABLATE != 1 && PGV_TILE_ABLATE != 3  // ablation build 1: score without streaming (tools/ablate_tile.sh)
             if (ti + 1 < ntiles) issue_tile(ti + 1, nxt);  // in flight while `cur` is scored
+#endif
 
             const int r_base = ti * tile_rows;
             const int rows_here = task.nrows - r_base < tile_rows ? task.nrows - r_base : tile_rows;
-            {
-                // LDS byte address of this lane's slice of row 0 of the tile being scored
-                const unsigned lrow = (unsigned)(size_t)(__attribute__((address_space(3))) char *)cur +
-                                      (unsigned)lane * (unsigned)sizeof(Raw16);
-                for (int r0 = my_rank * kRB; r0 < rows_here; r0 += servers * kRB) {
+            PGV_TM(tm_mark = wall_clock64(); tm_tiles++;)
+            // LDS byte address of this lane's slice of row 0 of the tile being scored
+            const unsigned lrow = (unsigned)(size_t)(__attribute__((address_space(3))) char *)cur +
+                                  (unsigned)lane * (unsigned)sizeof(Raw16);
+            auto score_pass = [&](const Slot &sl, const Raw16 (&q)[NCH]) {
+                for (int r0 = sl.rank * kRB; r0 < rows_here; r0 += sl.servers * kRB) {
                     f32x2 acc[kRB];
 #pragma unroll
                     for (int i = 0; i < kRB; i++) acc[i] = f32x2{0.f, 0.f};
@@ -163,19 +205,26 @@ __global__ __launch_bounds__(kTileThreads) void tile_scan_kernel(
                                 Raw16 raw;
 #pragma unroll
                                 for (int w = 0; w < 4; w++) raw.w[w] = rv[c][i][w];
-                                accum_slice2<T, METRIC>(acc[i], raw, qreg[0][h * NS + c]);
+                                accum_slice2<T, METRIC>(acc[i], raw, q[h * NS + c]);
                             }
                         }
                     }
-#pragma unroll
-                    for (int i = 0; i < kRB; i++) {
-                        const float sum = group_sum_to_last(acc[i].x + acc[i].y, 6);
-                        if (lane == kWave - 1 && r0 + i < rows_here)
-                            out[rel[0] + task.row0 + r_base + r0 + i] = finish<METRIC>(sum);
-                    }
+                    // lanes 0, 1, 2 end up with the totals of rows r0, r0 + 1, r0 + 2
+                    const float sum = wave_sum3(acc[0].x + acc[0].y, acc[1].x + acc[1].y, acc[2].x + acc[2].y);
+#if PGV_TILE_ABLATE == 3 || PGV_TILE_ABLATE == 4  // no stores (the condition is never true)
+                    if (sum == 12345.678f) out[0] = sum;
+#else
+                    if (lane < kRB && r0 + lane < rows_here) out[sl.rel + r_base + r0 + lane] = finish<METRIC>(sum);
+#endif
                 }
-            }
+            };
+#if PGV_TILE_ABLATE != 2  // ablation build 2: stream without scoring
+            score_pass(slot[0], qreg[0]);
+            if (two_pass) score_pass(slot[1], qreg[1]);
+#endif
+            PGV_TM(tm_score += wall_clock64() - tm_mark; tm_mark = wall_clock64();)
             __syncthreads();  // next tile landed (vmcnt(0)); everyone is done reading `cur`
+            PGV_TM(tm_wait += wall_clock64() - tm_mark;)
         }
     }
 }

@@ -282,7 +282,11 @@ int dense_scan(pgv_ctx *ctx, pgv_metric metric, pgv_dtype dtype, const RowGeom &
     if (nrows <= 0 || nq <= 0) return PGV_OK;
     // many queries against the same rows (center ranking of a batch): the tile kernel serves
     // 16 queries per pass over the rows
+#ifdef PGV_TILE_ABLATE  // ablation builds keep center ranking exact so that the probe sets are the real ones
+    const bool use_tile = false;
+#else
     const bool use_tile = nq > 8 && tile_scan_supported(g);
+#endif
     const int qt = use_tile ? tile_scan_queries_per_task() : scan_group_size(g, dtype, nq);
     const int ngroups = (nq + qt - 1) / qt;
     int ch = rows_per_task_for(ctx, nrows, ngroups);

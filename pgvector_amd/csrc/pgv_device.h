@@ -117,6 +117,18 @@ __device__ __forceinline__ float half_diff_hi(uint32_t wa, uint32_t wb) {
     asm("v_fma_mix_f32 %0, %1, 1.0, -%2 op_sel:[1,0,1] op_sel_hi:[1,0,1]" : "=v"(d) : "v"(wa), "v"(wb));
     return d;
 }
+// acc + a * b on the low / high fp16 halves, also one v_fma_mix_f32 (the fp16 x fp16 product is
+// exact in fp32, so this is the reference's convert-then-FMA, src/halfutils.c:81-122)
+__device__ __forceinline__ float half_fma_lo(uint32_t wa, uint32_t wb, float acc) {
+    float d;
+    asm("v_fma_mix_f32 %0, %1, %2, %3 op_sel:[0,0,0] op_sel_hi:[1,1,0]" : "=v"(d) : "v"(wa), "v"(wb), "v"(acc));
+    return d;
+}
+__device__ __forceinline__ float half_fma_hi(uint32_t wa, uint32_t wb, float acc) {
+    float d;
+    asm("v_fma_mix_f32 %0, %1, %2, %3 op_sel:[1,1,0] op_sel_hi:[1,1,0]" : "=v"(d) : "v"(wa), "v"(wb), "v"(acc));
+    return d;
+}
 template <> __device__ __forceinline__ float accum_slice<__half, 0>(float acc, const Raw16 &a, const Raw16 &b) {
 #pragma unroll
     for (int i = 0; i < 4; i++) {
@@ -130,10 +142,8 @@ template <> __device__ __forceinline__ float accum_slice<__half, 0>(float acc, c
 template <> __device__ __forceinline__ float accum_slice<__half, 1>(float acc, const Raw16 &a, const Raw16 &b) {
 #pragma unroll
     for (int i = 0; i < 4; i++) {
-        const __half2 ha = *reinterpret_cast<const __half2 *>(&a.w[i]);
-        const __half2 hb = *reinterpret_cast<const __half2 *>(&b.w[i]);
-        acc = accum_h<1>(acc, __low2half(ha), __low2half(hb));
-        acc = accum_h<1>(acc, __high2half(ha), __high2half(hb));
+        acc = half_fma_lo(a.w[i], b.w[i], acc);
+        acc = half_fma_hi(a.w[i], b.w[i], acc);
     }
     return acc;
 }
@@ -187,10 +197,8 @@ template <> __device__ __forceinline__ void accum_slice2<__half, 0>(f32x2 &acc, 
 template <> __device__ __forceinline__ void accum_slice2<__half, 1>(f32x2 &acc, const Raw16 &a, const Raw16 &b) {
 #pragma unroll
     for (int i = 0; i < 4; i++) {
-        const __half2 ha = *reinterpret_cast<const __half2 *>(&a.w[i]);
-        const __half2 hb = *reinterpret_cast<const __half2 *>(&b.w[i]);
-        acc.x = accum_h<1>(acc.x, __low2half(ha), __low2half(hb));
-        acc.y = accum_h<1>(acc.y, __high2half(ha), __high2half(hb));
+        acc.x = half_fma_lo(a.w[i], b.w[i], acc.x);
+        acc.y = half_fma_hi(a.w[i], b.w[i], acc.y);
     }
 }
 template <> __device__ __forceinline__ void accum_slice2<__half, 2>(f32x2 &acc, const Raw16 &a, const Raw16 &b) {
@@ -225,6 +233,29 @@ __device__ __forceinline__ float group_sum_to_last(float v, int lg) {
     if (lg >= 5) v += dpp_mov<0x142, 0xa>(v);    // row_bcast:15 -> rows 1,3
     if (lg >= 6) v += dpp_mov<0x143, 0xc>(v);    // row_bcast:31 -> rows 2,3
     return v;
+}
+
+// Sums of THREE per-lane values over the 64 lanes for about half the price of three
+// reductions: the first two butterfly steps also fold the values into one register (lane % 4 ==
+// 0 carries a, 1 carries b, 2 and 3 carry c), the row rotations and the gfx950 lane-swap
+// instructions finish all three at once.  Every lane returns the total of its value.
+__device__ __forceinline__ float wave_sum3(float a, float b, float c) {
+    const unsigned lane = __lane_id();
+    const bool odd = lane & 1u;
+    float keep = odd ? b : a;
+    const float send = odd ? a : b;
+    keep += dpp_mov<0xB1>(send);  // quad_perm [1,0,3,2]: even lanes a, odd lanes b, over the pair
+    c += dpp_mov<0xB1>(c);
+    const bool hi = lane & 2u;
+    float v = hi ? c : keep;
+    const float send2 = hi ? keep : c;
+    v += dpp_mov<0x4E>(send2);    // quad_perm [2,3,0,1]: over the quad
+    v += dpp_mov<0x124>(v);       // row_ror:4
+    v += dpp_mov<0x128>(v);       // row_ror:8 -> over the row of 16
+    const auto r16 = __builtin_amdgcn_permlane16_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+    v = __uint_as_float(r16[0]) + __uint_as_float(r16[1]);  // rows 0+1, 2+3
+    const auto r32 = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+    return __uint_as_float(r32[0]) + __uint_as_float(r32[1]);
 }
 
 // ---- ordered-uint keys for float selection ---------------------------------
