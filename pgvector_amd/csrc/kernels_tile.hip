@@ -5,30 +5,42 @@
 // Here the roles are swapped: a tile of rows is brought into LDS once by the
 // asynchronous global->LDS DMA (global_load_lds, no registers involved, the next
 // tile in flight while the current one is scored), and every wavefront scores the
-// whole tile against ITS OWN two queries, which it holds in registers.  A
-// 512-thread workgroup therefore serves up to 16 queries per pass over the rows:
+// tile against ITS OWN two queries, which it holds in registers -- each row slice
+// read from LDS is used twice, without which the LDS is as busy as the vector ALU.
+// A 512-thread workgroup therefore serves up to 16 queries per pass over the rows:
 // the body of GetScanItems (src/ivfscan.c:157-173) for 16 backends' queries with
-// each index tuple read from HBM once.
+// each index tuple read from HBM once.  Two such workgroups share a CU (half of
+// its LDS each): while one sits in its tile barrier or waits for its DMA, the other
+// has the ALUs.
 //
 // Requirements: rows are a whole number of 1 KiB slices (64 lanes x 16 B), i.e.
 // dim a multiple of 256 (fp32) / 512 (fp16) -- every BASELINE config.  Other
 // shapes use scan_kernel.
+//
+// Experiment builds (never the product library; tools/ablate_tile.sh, tools/variants.sh):
+//   -DPGV_TILE_ABLATE=1..4   leave out the streaming / the scoring / the stores
+//   -DPGV_TILE_TIMING        per-wavefront wall-clock breakdown, printed for a few workgroups
 #include "pgv_device.h"
+
+#include <cstdlib>
 
 namespace pgv {
 
 namespace {
 
-constexpr int kTileThreads = 1024;
-constexpr int kTileWaves = kTileThreads / kWave;  // 16: four per SIMD, so a SIMD always has a busy wave
-constexpr int kQW = 1;                            // queries per wavefront -> 16 per workgroup
+#ifndef PGV_TILE_THREADS
+#define PGV_TILE_THREADS 512
+#endif
+constexpr int kTileThreads = PGV_TILE_THREADS;
+constexpr int kTileGroupsPerCu = 1024 / kTileThreads;  // workgroups sharing a CU (and its LDS)
+constexpr int kTileWaves = kTileThreads / kWave;       // 8: with two workgroups, four per SIMD
+constexpr int kQW = 2;                                  // queries per wavefront -> 16 per workgroup
 #ifndef PGV_TILE_ABLATE
 #define PGV_TILE_ABLATE 0
 #endif
-#ifndef PGV_TILE_CAP
-#define PGV_TILE_CAP 3
+#ifndef PGV_TILE_DMA_FRONT
+#define PGV_TILE_DMA_FRONT 1
 #endif
-constexpr int kRB = 3;                            // rows scored together (ILP for the LDS reads)
 
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 
@@ -37,52 +49,33 @@ typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 // tile being filled, and drains vmcnt(0) before every read -- which would serialise the
 // DMA of the next tile behind the scoring of this one.  The buffers are disjoint by
 // construction (double buffering, barrier between fill and use), so the only wait these
-// reads need is their own lgkmcnt: lds_issue4 starts four reads, lds_wait_* is the single
-// wait before the first consumer and names every destination register so that nothing
-// that uses them can be scheduled above it (cdna_hip_programming.md 5.7, form ii).
-__device__ __forceinline__ void lds_issue3(unsigned a0, unsigned a1, unsigned a2, u32x4 &v0, u32x4 &v1,
-                                           u32x4 &v2) {
-    asm volatile(
-        "ds_read_b128 %0, %3\n\t"
-        "ds_read_b128 %1, %4\n\t"
-        "ds_read_b128 %2, %5"
-        : "=&v"(v0), "=&v"(v1), "=&v"(v2)
-        : "v"(a0), "v"(a1), "v"(a2)
-        : "memory");
+// reads need is their own lgkmcnt.  One asm statement starts the reads of all NS slices of a
+// row and waits for them, so nothing that uses the registers can be scheduled above the wait
+// (cdna_hip_programming.md 5.7).
+template <int NS> __device__ __forceinline__ void lds_read_row(unsigned a, u32x4 (&v)[NS]);
+template <> __device__ __forceinline__ void lds_read_row<1>(unsigned a, u32x4 (&v)[1]) {
+    asm volatile("ds_read_b128 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=&v"(v[0]) : "v"(a) : "memory");
 }
-
-template <int NS> __device__ __forceinline__ void lds_wait(u32x4 (&v)[NS][3]);
-#define PGV_V3(c) "+v"(v[c][0]), "+v"(v[c][1]), "+v"(v[c][2])
-template <> __device__ __forceinline__ void lds_wait<1>(u32x4 (&v)[1][3]) {
-    asm volatile("s_waitcnt lgkmcnt(0)" : PGV_V3(0)::"memory");
+template <> __device__ __forceinline__ void lds_read_row<2>(unsigned a, u32x4 (&v)[2]) {
+    asm volatile("ds_read_b128 %0, %2\n\tds_read_b128 %1, %2 offset:1024\n\ts_waitcnt lgkmcnt(0)"
+                 : "=&v"(v[0]), "=&v"(v[1]) : "v"(a) : "memory");
 }
-template <> __device__ __forceinline__ void lds_wait<2>(u32x4 (&v)[2][3]) {
-    asm volatile("s_waitcnt lgkmcnt(0)" : PGV_V3(0), PGV_V3(1)::"memory");
+template <> __device__ __forceinline__ void lds_read_row<3>(unsigned a, u32x4 (&v)[3]) {
+    asm volatile("ds_read_b128 %0, %3\n\tds_read_b128 %1, %3 offset:1024\n\tds_read_b128 %2, %3 offset:2048\n\t"
+                 "s_waitcnt lgkmcnt(0)"
+                 : "=&v"(v[0]), "=&v"(v[1]), "=&v"(v[2]) : "v"(a) : "memory");
 }
-template <> __device__ __forceinline__ void lds_wait<3>(u32x4 (&v)[3][3]) {
-    asm volatile("s_waitcnt lgkmcnt(0)" : PGV_V3(0), PGV_V3(1), PGV_V3(2)::"memory");
+template <> __device__ __forceinline__ void lds_read_row<4>(unsigned a, u32x4 (&v)[4]) {
+    asm volatile("ds_read_b128 %0, %4\n\tds_read_b128 %1, %4 offset:1024\n\tds_read_b128 %2, %4 offset:2048\n\t"
+                 "ds_read_b128 %3, %4 offset:3072\n\ts_waitcnt lgkmcnt(0)"
+                 : "=&v"(v[0]), "=&v"(v[1]), "=&v"(v[2]), "=&v"(v[3]) : "v"(a) : "memory");
 }
-template <> __device__ __forceinline__ void lds_wait<4>(u32x4 (&v)[4][3]) {
-    asm volatile("s_waitcnt lgkmcnt(0)" : PGV_V3(0), PGV_V3(1), PGV_V3(2), PGV_V3(3)::"memory");
+template <> __device__ __forceinline__ void lds_read_row<6>(unsigned a, u32x4 (&v)[6]) {
+    asm volatile("ds_read_b128 %0, %6\n\tds_read_b128 %1, %6 offset:1024\n\tds_read_b128 %2, %6 offset:2048\n\t"
+                 "ds_read_b128 %3, %6 offset:3072\n\tds_read_b128 %4, %6 offset:4096\n\tds_read_b128 %5, %6 offset:5120\n\t"
+                 "s_waitcnt lgkmcnt(0)"
+                 : "=&v"(v[0]), "=&v"(v[1]), "=&v"(v[2]), "=&v"(v[3]), "=&v"(v[4]), "=&v"(v[5]) : "v"(a) : "memory");
 }
-template <> __device__ __forceinline__ void lds_wait<6>(u32x4 (&v)[6][3]) {
-    asm volatile("s_waitcnt lgkmcnt(0)"
-                 : PGV_V3(0), PGV_V3(1), PGV_V3(2), PGV_V3(3), PGV_V3(4), PGV_V3(5)::"memory");
-}
-#undef PGV_V3
-
-// what a wavefront does in one pass over a tile: which query of the task it serves, which of
-// that query's servers it is, and how many servers the query has
-struct Slot {
-    int q, rank, servers;
-    int64_t rel;  // out index of (this query, row 0 of the task)
-    __device__ __forceinline__ void init(int wave, int n, int first) {
-        const int j = wave % n;
-        q = first + j;
-        rank = wave / n;
-        servers = (kTileWaves - 1 - j) / n + 1;
-    }
-};
 
 template <typename T, int METRIC, int NCH>
 __global__ __launch_bounds__(kTileThreads) void tile_scan_kernel(
@@ -99,8 +92,8 @@ __global__ __launch_bounds__(kTileThreads) void tile_scan_kernel(
     const int lane = threadIdx.x & (kWave - 1);
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);  // provably wave-uniform
     const int ntasks = *ntasks_ptr;
-#ifdef PGV_TILE_TIMING  // experiment build: where a workgroup's wall time goes (printed for a few of them)
-    unsigned long long tm_start = wall_clock64(), tm_setup = 0, tm_score = 0, tm_wait = 0, tm_mark;
+#ifdef PGV_TILE_TIMING
+    unsigned long long tm_start = wall_clock64(), tm_setup = 0, tm_score = 0, tm_wait = 0, tm_dma = 0, tm_mark;
     int tm_tasks = 0, tm_tiles = 0;
 #define PGV_TM(x) x
 #else
@@ -114,9 +107,9 @@ __global__ __launch_bounds__(kTileThreads) void tile_scan_kernel(
         const int t = *lds_task;
 #ifdef PGV_TILE_TIMING
         if (t >= ntasks) {
-            if (threadIdx.x == 0 && (blockIdx.x < 3 || blockIdx.x == 200))
-                printf("wg %d: total %llu setup %llu score %llu wait %llu (x10ns) tasks %d tiles %d\n", blockIdx.x,
-                       wall_clock64() - tm_start, tm_setup, tm_score, tm_wait, tm_tasks, tm_tiles);
+            if (lane == 0 && (wave == 0 || wave == kTileWaves - 1) && (blockIdx.x == 1 || blockIdx.x == 200))
+                printf("wg %d wave %d: total %llu setup %llu score %llu dma-wait %llu barrier-wait %llu (x10ns) tasks %d tiles %d\n",
+                       blockIdx.x, wave, wall_clock64() - tm_start, tm_setup, tm_score, tm_dma, tm_wait, tm_tasks, tm_tiles);
             return;
         }
         tm_tasks++;
@@ -125,104 +118,106 @@ __global__ __launch_bounds__(kTileThreads) void tile_scan_kernel(
 #endif
         const ScanTask task = tasks[t];
 
-        // Query j of the task is served by wavefront j and, when the task has fewer than 16
-        // queries, also by the otherwise idle wavefronts j + n, j + 2n, ...: the servers of a
-        // query take the row batches of a tile round-robin.  With 9..12 queries that would leave
-        // the single-server queries four batches per tile next to two for the others, so those
-        // tasks run two passes per tile instead: queries 0..7 with two servers each, then the
-        // remaining 1..4 with 4..16 servers each (three batch times instead of four).  A
-        // wavefront keeps the query of each pass in registers for the whole task.
+        // Queries 2j and 2j + 1 of the task form pair j, served by wavefront j and, when the task
+        // has fewer than 8 pairs, also by the otherwise idle wavefronts j + n, j + 2n, ...: the
+        // servers of a pair take the rows of a tile round-robin.  An odd task's last pair
+        // repeats its query and drops the copy.  The two queries live in this wavefront's
+        // registers for the whole task.
         const int np = task.npairs;
-        const bool two_pass = np > 8 && np <= 12;
-        Slot slot[2];
-        Raw16 qreg[2][NCH];
-        slot[0].init(wave, two_pass ? 8 : np, 0);
-        slot[1].init(wave, two_pass ? np - 8 : 1, 8);
+        const int npr = (np + 1) >> 1;
+        const int my_pair = wave % npr;
+        const int my_rank = wave / npr;                              // which of its servers this wave is
+        const int servers = (kTileWaves - 1 - my_pair) / npr + 1;
+        const bool q1_valid = 2 * my_pair + 1 < np;
+        Raw16 qreg[kQW][NCH];
+        int64_t rel[kQW];  // out index of (query, row 0 of the task)
 #pragma unroll
-        for (int s = 0; s < 2; s++) {
-            if (s == 1 && !two_pass) break;
-            const ScanPair pr = pairs[task.pair0 + slot[s].q];
-            slot[s].rel = pr.out_rel + task.row0;
+        for (int s = 0; s < kQW; s++) {
+            const ScanPair pr = pairs[task.pair0 + 2 * my_pair + (s == 1 && q1_valid ? 1 : 0)];
+            rel[s] = pr.out_rel + task.row0;
             const char *qp = queries + (size_t)pr.query * ROWB + (size_t)lane * sizeof(Raw16);
 #pragma unroll
             for (int c = 0; c < NCH; c++) qreg[s][c] = load16(qp + (size_t)c * 1024);
         }
 
-        // DMA one tile: 1 KiB slice i of the tile goes to LDS offset i * 1024 (+ lane * 16,
-        // added by the hardware); slices are dealt round-robin to the wavefronts
-        auto issue_tile = [&](int ti, char *dst) {
-            const int r0 = ti * tile_rows;
-            const int nr = task.nrows - r0 < tile_rows ? task.nrows - r0 : tile_rows;
-            const char *src = rows + ((size_t)task.row0 + r0) * ROWB + (size_t)lane * sizeof(Raw16);
-            for (int i = wave; i < nr * NCH; i += kTileWaves)
-                __builtin_amdgcn_global_load_lds(
-                    (const __attribute__((address_space(1))) void *)(src + (size_t)i * 1024),
-                    (__attribute__((address_space(3))) void *)(dst + (size_t)i * 1024), 16, 0, 0);
+        // DMA: 1 KiB slice i of a tile goes to LDS offset i * 1024 (+ lane * 16, added by the
+        // hardware); slices are dealt round-robin to the wavefronts
+        auto rows_in = [&](int ti) {
+            const int left = task.nrows - ti * tile_rows;
+            return left < tile_rows ? left : tile_rows;
+        };
+        auto tile_src = [&](int ti) {
+            return rows + ((size_t)task.row0 + (size_t)ti * tile_rows) * ROWB + (size_t)lane * sizeof(Raw16);
+        };
+        auto dma_slice = [&](const char *src, char *dst, int i) {
+            __builtin_amdgcn_global_load_lds(
+                (const __attribute__((address_space(1))) void *)(src + (size_t)i * 1024),
+                (__attribute__((address_space(3))) void *)(dst + (size_t)i * 1024), 16, 0, 0);
         };
 
         const int ntiles = (task.nrows + tile_rows - 1) / tile_rows;
-        issue_tile(0, smem);
+        {
+            const char *src = tile_src(0);
+            for (int i = wave; i < rows_in(0) * NCH; i += kTileWaves) dma_slice(src, smem, i);
+        }
         __syncthreads();  // vmcnt(0) + barrier: tile 0 (and the query registers) have landed
         PGV_TM(tm_setup += wall_clock64() - tm_mark;)
 
         for (int ti = 0; ti < ntiles; ti++) {
             char *cur = smem + (size_t)(ti & 1) * tile_bytes;
             char *nxt = smem + (size_t)((ti + 1) & 1) * tile_bytes;
-#if PGV_TILE_ABLATE != 1 && PGV_TILE_ABLATE != 3  // ablation build 1: score without streaming (tools/ablate_tile.sh)
-            if (ti + 1 < ntiles) issue_tile(ti + 1, nxt);  // in flight while `cur` is scored
+            // The next tile is streamed while `cur` is scored.  Its DMA instructions are not
+            // issued in one burst after the barrier -- with every wavefront doing that at once
+            // the vector-memory queue backs up and all of them stall on the issue -- but dealt
+            // out between the rows: PGV_TILE_DMA_FRONT of them up front, one more per row
+            // scored, the rest after the last row.
+            int dma_i = wave, dma_n = 0;
+            const char *dma_src = nullptr;
+#if PGV_TILE_ABLATE != 1 && PGV_TILE_ABLATE != 3  // ablation: score without streaming
+            if (ti + 1 < ntiles) {
+                dma_n = rows_in(ti + 1) * NCH;
+                dma_src = tile_src(ti + 1);
+            }
 #endif
+            auto issue_next = [&](int count) {
+                for (int c = 0; c < count && dma_i < dma_n; c++, dma_i += kTileWaves) dma_slice(dma_src, nxt, dma_i);
+            };
+            issue_next(PGV_TILE_DMA_FRONT);
 
             const int r_base = ti * tile_rows;
-            const int rows_here = task.nrows - r_base < tile_rows ? task.nrows - r_base : tile_rows;
+            const int rows_here = rows_in(ti);
             PGV_TM(tm_mark = wall_clock64(); tm_tiles++;)
+#if PGV_TILE_ABLATE != 2  // ablation: stream without scoring
             // LDS byte address of this lane's slice of row 0 of the tile being scored
             const unsigned lrow = (unsigned)(size_t)(__attribute__((address_space(3))) char *)cur +
                                   (unsigned)lane * (unsigned)sizeof(Raw16);
-            auto score_pass = [&](const Slot &sl, const Raw16 (&q)[NCH]) {
-                for (int r0 = sl.rank * kRB; r0 < rows_here; r0 += sl.servers * kRB) {
-                    f32x2 acc[kRB];
+            for (int r0 = my_rank; r0 < rows_here; r0 += servers) {
+                issue_next(1);
+                u32x4 rv[NCH];  // a whole row per round
+                lds_read_row<NCH>(lrow + (unsigned)r0 * (unsigned)ROWB, rv);
+                __builtin_amdgcn_sched_barrier(0);
+                f32x2 acc0 = {0.f, 0.f}, acc1 = {0.f, 0.f};
 #pragma unroll
-                    for (int i = 0; i < kRB; i++) acc[i] = f32x2{0.f, 0.f};
-                    // several slices of the three rows are requested from LDS at once (one wait
-                    // per round); rows past the end of a ragged tile read stale LDS and are
-                    // never stored.  128 VGPRs per lane bound the slices per round.
-                    constexpr int CAP = PGV_TILE_CAP;
-                    constexpr int NS = NCH <= CAP ? NCH : (NCH % 4 == 0 && CAP >= 4 ? 4 : (NCH % 3 == 0 && CAP >= 3 ? 3 : (NCH % 2 == 0 ? 2 : 1)));
+                for (int c = 0; c < NCH; c++) {
+                    Raw16 raw;
 #pragma unroll
-                    for (int h = 0; h < NCH / NS; h++) {
-                        u32x4 rv[NS][3];
-#pragma unroll
-                        for (int c = 0; c < NS; c++) {
-                            const unsigned a = lrow + (unsigned)r0 * (unsigned)ROWB + (unsigned)(h * NS + c) * 1024u;
-                            lds_issue3(a, a + (unsigned)ROWB, a + 2u * (unsigned)ROWB, rv[c][0], rv[c][1], rv[c][2]);
-                        }
-                        lds_wait<NS>(rv);
-                        __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-                        for (int c = 0; c < NS; c++) {
-#pragma unroll
-                            for (int i = 0; i < kRB; i++) {
-                                Raw16 raw;
-#pragma unroll
-                                for (int w = 0; w < 4; w++) raw.w[w] = rv[c][i][w];
-                                accum_slice2<T, METRIC>(acc[i], raw, q[h * NS + c]);
-                            }
-                        }
-                    }
-                    // lanes 0, 1, 2 end up with the totals of rows r0, r0 + 1, r0 + 2
-                    const float sum = wave_sum3(acc[0].x + acc[0].y, acc[1].x + acc[1].y, acc[2].x + acc[2].y);
-#if PGV_TILE_ABLATE == 3 || PGV_TILE_ABLATE == 4  // no stores (the condition is never true)
-                    if (sum == 12345.678f) out[0] = sum;
-#else
-                    if (lane < kRB && r0 + lane < rows_here) out[sl.rel + r_base + r0 + lane] = finish<METRIC>(sum);
-#endif
+                    for (int w = 0; w < 4; w++) raw.w[w] = rv[c][w];
+                    accum_slice2<T, METRIC>(acc0, raw, qreg[0][c]);
+                    accum_slice2<T, METRIC>(acc1, raw, qreg[1][c]);
                 }
-            };
-#if PGV_TILE_ABLATE != 2  // ablation build 2: stream without scoring
-            score_pass(slot[0], qreg[0]);
-            if (two_pass) score_pass(slot[1], qreg[1]);
+                // even lanes end up with the first query's total, odd lanes with the second's
+                const float sum = wave_sum2(acc0.x + acc0.y, acc1.x + acc1.y);
+#if PGV_TILE_ABLATE == 3 || PGV_TILE_ABLATE == 4  // ablation: no stores (the condition is never true)
+                if (sum == 12345.678f) out[0] = sum;
+#else
+                if (lane == 0 || (lane == 1 && q1_valid))
+                    out[(lane == 0 ? rel[0] : rel[1]) + r_base + r0] = finish<METRIC>(sum);
 #endif
+            }
+#endif
+            issue_next(1 << 20);
             PGV_TM(tm_score += wall_clock64() - tm_mark; tm_mark = wall_clock64();)
+            PGV_TM(asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); tm_dma += wall_clock64() - tm_mark; tm_mark = wall_clock64();)
             __syncthreads();  // next tile landed (vmcnt(0)); everyone is done reading `cur`
             PGV_TM(tm_wait += wall_clock64() - tm_mark;)
         }
@@ -264,7 +259,6 @@ int launch_tile_n(pgv_ctx *ctx, int nch, const void *rows, const void *queries,
         PGV_TILE(3);
         PGV_TILE(4);
         PGV_TILE(6);
-        PGV_TILE(8);
     }
 #undef PGV_TILE
     PGV_FAIL(PGV_ERR_ARG, "tile scan: unsupported row size (%d KiB)", nch);
@@ -276,19 +270,20 @@ int launch_tile_n(pgv_ctx *ctx, int nch, const void *rows, const void *queries,
 bool tile_scan_supported(const RowGeom &g) {
     if (g.lpr_log2 != 6 || g.nvec % kWave != 0) return false;
     const int nch = g.nvec / kWave;
-    return nch == 1 || nch == 2 || nch == 3 || nch == 4 || nch == 6 || nch == 8;
+    // 8 KiB rows would be 2048 fp32 / 4096 fp16 dimensions, beyond the index limits
+    // (src/ivfflat.h:37, src/ivfutils.c:401)
+    return nch == 1 || nch == 2 || nch == 3 || nch == 4 || nch == 6;
 }
 
 int tile_scan_queries_per_task() { return kTileWaves * kQW; }
 
-// rows per LDS tile: two tiles fill ~150 KiB of the CU's 160 KiB; a multiple of 2 * kRB so
-// that two servers of a query split a tile evenly
+// rows per LDS tile: the two tiles of each of a CU's workgroups fill ~150 KiB of its 160 KiB
 int tile_scan_tile_rows(const RowGeom &g) {
     const size_t row_bytes = (size_t)g.nvec * sizeof(Raw16);
-    int tr = (int)((150 * 1024 / 2) / row_bytes);
-    tr = tr / (2 * kRB) * (2 * kRB);
+    int tr = (int)((150 * 1024 / 2 / kTileGroupsPerCu) / row_bytes);
+    tr = tr / 2 * 2;
     if (tr > 60) tr = 60;
-    if (tr < kRB) tr = kRB;
+    if (tr < 2) tr = 2;
     return tr;
 }
 

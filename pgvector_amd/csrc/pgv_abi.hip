@@ -770,7 +770,8 @@ static int scan_batch_dev(pgv_index *ix, const void *q_dev, int nq, const int32_
     const bool use_tile = tile_scan_supported(ix->geom) && (tile_env == 1 || (tile_env != 0 && share > 8.0));
     const int qt = use_tile ? tile_scan_queries_per_task()
                             : scan_group_size(ix->geom, ix->dtype, (int)std::ceil(share));
-    const int rows_per_task = use_tile ? 20 * tile_scan_tile_rows(ix->geom)
+    static const int rpt_tiles = getenv("PGV_TILE_RPT") ? atoi(getenv("PGV_TILE_RPT")) : 20;  // tiles per task
+    const int rows_per_task = use_tile ? rpt_tiles * tile_scan_tile_rows(ix->geom)
                                        : (qt >= 16 ? 256 : (qt >= 4 ? 128 : 64));
     PlanResult plan;
     PGV_TRY(launch_plan_batch(ctx, ix, probe_lists, nq, probes, qt, rows_per_task, ctx->profiling, &plan));

@@ -235,25 +235,20 @@ __device__ __forceinline__ float group_sum_to_last(float v, int lg) {
     return v;
 }
 
-// Sums of THREE per-lane values over the 64 lanes for about half the price of three
-// reductions: the first two butterfly steps also fold the values into one register (lane % 4 ==
-// 0 carries a, 1 carries b, 2 and 3 carry c), the row rotations and the gfx950 lane-swap
-// instructions finish all three at once.  Every lane returns the total of its value.
-__device__ __forceinline__ float wave_sum3(float a, float b, float c) {
-    const unsigned lane = __lane_id();
-    const bool odd = lane & 1u;
-    float keep = odd ? b : a;
+// Sums of TWO per-lane values over the 64 lanes for about the price of one reduction: the first
+// butterfly step also folds the two values into one register (even lanes carry a, odd lanes b),
+// the row rotations and the gfx950 lane-swap instructions finish both at once.  Even lanes
+// return the total of a, odd lanes the total of b.
+__device__ __forceinline__ float wave_sum2(float a, float b) {
+    const bool odd = __lane_id() & 1u;
+    float v = odd ? b : a;
     const float send = odd ? a : b;
-    keep += dpp_mov<0xB1>(send);  // quad_perm [1,0,3,2]: even lanes a, odd lanes b, over the pair
-    c += dpp_mov<0xB1>(c);
-    const bool hi = lane & 2u;
-    float v = hi ? c : keep;
-    const float send2 = hi ? keep : c;
-    v += dpp_mov<0x4E>(send2);    // quad_perm [2,3,0,1]: over the quad
-    v += dpp_mov<0x124>(v);       // row_ror:4
-    v += dpp_mov<0x128>(v);       // row_ror:8 -> over the row of 16
+    v += dpp_mov<0xB1>(send);  // quad_perm [1,0,3,2]
+    v += dpp_mov<0x4E>(v);     // quad_perm [2,3,0,1]
+    v += dpp_mov<0x124>(v);    // row_ror:4
+    v += dpp_mov<0x128>(v);    // row_ror:8
     const auto r16 = __builtin_amdgcn_permlane16_swap(__float_as_uint(v), __float_as_uint(v), false, false);
-    v = __uint_as_float(r16[0]) + __uint_as_float(r16[1]);  // rows 0+1, 2+3
+    v = __uint_as_float(r16[0]) + __uint_as_float(r16[1]);
     const auto r32 = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
     return __uint_as_float(r32[0]) + __uint_as_float(r32[1]);
 }
