@@ -130,11 +130,11 @@ __global__ __launch_bounds__(kTileThreads) void tile_scan_kernel(
         const int servers = (kTileWaves - 1 - my_pair) / npr + 1;
         const bool q1_valid = 2 * my_pair + 1 < np;
         Raw16 qreg[kQW][NCH];
-        int64_t rel[kQW];  // out index of (query, row 0 of the task)
+        int64_t my_rel = 0;  // out index of (the query this LANE reports: even lanes the first, odd the second; row 0 of the task)
 #pragma unroll
         for (int s = 0; s < kQW; s++) {
             const ScanPair pr = pairs[task.pair0 + 2 * my_pair + (s == 1 && q1_valid ? 1 : 0)];
-            rel[s] = pr.out_rel + task.row0;
+            if ((lane & 1) == s) my_rel = pr.out_rel + task.row0;
             const char *qp = queries + (size_t)pr.query * ROWB + (size_t)lane * sizeof(Raw16);
 #pragma unroll
             for (int c = 0; c < NCH; c++) qreg[s][c] = load16(qp + (size_t)c * 1024);
@@ -155,6 +155,17 @@ __global__ __launch_bounds__(kTileThreads) void tile_scan_kernel(
                 (__attribute__((address_space(3))) void *)(dst + (size_t)i * 1024), 16, 0, 0);
         };
 
+        // The distances of a tile leave in ONE store per wavefront, one tile late: lane 2i
+        // (2i + 1) collects the first (second) query's distance to the i-th row this wavefront
+        // scored, and the store is issued after the next tile's barrier, so that its write
+        // acknowledgement is long in when the wavefront next drains vmcnt.
+        float res = 0.f;
+        const bool lane_reports = (lane & 1) == 0 || q1_valid;
+        auto store_tile = [&](int tp) {
+            const int row = my_rank + (lane >> 1) * servers;
+            if (lane_reports && row < rows_in(tp)) out[my_rel + (int64_t)tp * tile_rows + row] = res;
+        };
+
         const int ntiles = (task.nrows + tile_rows - 1) / tile_rows;
         {
             const char *src = tile_src(0);
@@ -166,6 +177,9 @@ __global__ __launch_bounds__(kTileThreads) void tile_scan_kernel(
         for (int ti = 0; ti < ntiles; ti++) {
             char *cur = smem + (size_t)(ti & 1) * tile_bytes;
             char *nxt = smem + (size_t)((ti + 1) & 1) * tile_bytes;
+#if PGV_TILE_ABLATE != 3 && PGV_TILE_ABLATE != 4  // ablation: no stores
+            if (ti > 0) store_tile(ti - 1);
+#endif
             // The next tile is streamed while `cur` is scored.  Its DMA instructions are not
             // issued in one burst after the barrier -- with every wavefront doing that at once
             // the vector-memory queue backs up and all of them stall on the issue -- but dealt
@@ -184,14 +198,14 @@ __global__ __launch_bounds__(kTileThreads) void tile_scan_kernel(
             };
             issue_next(PGV_TILE_DMA_FRONT);
 
-            const int r_base = ti * tile_rows;
             const int rows_here = rows_in(ti);
             PGV_TM(tm_mark = wall_clock64(); tm_tiles++;)
 #if PGV_TILE_ABLATE != 2  // ablation: stream without scoring
             // LDS byte address of this lane's slice of row 0 of the tile being scored
             const unsigned lrow = (unsigned)(size_t)(__attribute__((address_space(3))) char *)cur +
                                   (unsigned)lane * (unsigned)sizeof(Raw16);
-            for (int r0 = my_rank; r0 < rows_here; r0 += servers) {
+            int nth = 0;  // rows this wavefront has scored in this tile
+            for (int r0 = my_rank; r0 < rows_here; r0 += servers, nth++) {
                 issue_next(1);
                 u32x4 rv[NCH];  // a whole row per round
                 lds_read_row<NCH>(lrow + (unsigned)r0 * (unsigned)ROWB, rv);
@@ -207,12 +221,7 @@ __global__ __launch_bounds__(kTileThreads) void tile_scan_kernel(
                 }
                 // even lanes end up with the first query's total, odd lanes with the second's
                 const float sum = wave_sum2(acc0.x + acc0.y, acc1.x + acc1.y);
-#if PGV_TILE_ABLATE == 3 || PGV_TILE_ABLATE == 4  // ablation: no stores (the condition is never true)
-                if (sum == 12345.678f) out[0] = sum;
-#else
-                if (lane == 0 || (lane == 1 && q1_valid))
-                    out[(lane == 0 ? rel[0] : rel[1]) + r_base + r0] = finish<METRIC>(sum);
-#endif
+                if ((lane >> 1) == nth) res = finish<METRIC>(sum);
             }
 #endif
             issue_next(1 << 20);
@@ -221,6 +230,11 @@ __global__ __launch_bounds__(kTileThreads) void tile_scan_kernel(
             __syncthreads();  // next tile landed (vmcnt(0)); everyone is done reading `cur`
             PGV_TM(tm_wait += wall_clock64() - tm_mark;)
         }
+#if PGV_TILE_ABLATE != 3 && PGV_TILE_ABLATE != 4
+        store_tile(ntiles - 1);
+#else
+        if (res == 12345.678f) out[0] = res;  // keeps the scoring alive
+#endif
     }
 }
 
@@ -282,7 +296,7 @@ int tile_scan_tile_rows(const RowGeom &g) {
     const size_t row_bytes = (size_t)g.nvec * sizeof(Raw16);
     int tr = (int)((150 * 1024 / 2 / kTileGroupsPerCu) / row_bytes);
     tr = tr / 2 * 2;
-    if (tr > 60) tr = 60;
+    if (tr > 32) tr = 32;  // a wavefront reports up to tile_rows rows x 2 queries from its 64 lanes
     if (tr < 2) tr = 2;
     return tr;
 }
