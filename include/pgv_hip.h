@@ -310,6 +310,30 @@ void		pgv_hnsw_free(pgv_hnsw * h);
 int			pgv_hnsw_score(pgv_hnsw * h, const void *queries, int nq,
 						   const int32_t *slot, const int32_t *query_of, int64_t npairs, float *out);
 
+/*
+ * The graph the scan walks, flattened: the meta page's m and entry point
+ * (src/hnswutils.c:298-328) and, per element slot, its level and neighbor tuple
+ * (src/hnsw.h:384-392: (level + 2) * m slots, layer lc starting at
+ * (level - lc) * m, src/hnswutils.c:786; -1 = invalid TID).  Copied to the device.
+ *   levels [n], nbr_start [n + 1] (offsets into nbr), nbr [nbr_start[n]]
+ */
+int			pgv_hnsw_set_graph(pgv_hnsw * h, int m, int32_t entry, const int32_t *levels,
+							   const int64_t *nbr_start, const int32_t *nbr);
+
+/*
+ * hnswgettuple's first batch on the device (GetScanItems, src/hnswscan.c:25-56):
+ * greedy descent with ef = 1 through the upper layers, then HnswSearchLayer with
+ * ef_search on layer 0 (src/hnswutils.c:824-987), one workgroup per query, no host
+ * round trips.  Needs pgv_hnsw_set_graph.  Queries already normalised for cosine
+ * (src/hnswscan.c:92-114).
+ *   queries    [nq x dim]
+ *   out_elem   [nq x k] element slots nearest first, -1 padded (k <= ef_search)
+ *   out_dist   [nq x k] FUNCTION 1 distances, +inf padded
+ *   out_scored [nq] or NULL: so->tuples, the number of elements scored on layer 0
+ */
+int			pgv_hnsw_search(pgv_hnsw * h, const void *queries, int nq, int ef_search, int k,
+							int64_t *out_elem, float *out_dist, int64_t *out_scored);
+
 #ifdef __cplusplus
 }
 #endif

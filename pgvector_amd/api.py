@@ -301,6 +301,25 @@ class Hnsw:
         except Exception:
             pass
 
+    def set_graph(self, m, entry, levels, nbr_start, nbr):
+        """the graph a scan walks (pgv_hnsw_set_graph): per element slot its level and neighbor tuple"""
+        levels = np.ascontiguousarray(levels, dtype=np.int32) if not _is_torch(levels) else levels
+        nbr_start = np.ascontiguousarray(nbr_start, dtype=np.int64) if not _is_torch(nbr_start) else nbr_start
+        nbr = np.ascontiguousarray(nbr, dtype=np.int32) if not _is_torch(nbr) else nbr
+        check(lib.pgv_hnsw_set_graph(self.h, int(m), int(entry), ptr(levels), ptr(nbr_start), ptr(nbr)))
+
+    def search(self, queries, ef_search, k, want_scored=True):
+        """hnswgettuple's first batch on the device (pgv_hnsw_search) ->
+        (element slots [nq x k] nearest first / -1, distances [nq x k] / +inf, scored [nq] or None)"""
+        queries = as_dtype(queries, self.dtype)
+        nq = int(queries.shape[0])
+        elem = _empty_like_kind(queries, (nq, k), np.int64)
+        dist = _empty_like_kind(queries, (nq, k), np.float32)
+        scored = _empty_like_kind(queries, (nq,), np.int64) if want_scored else None
+        check(lib.pgv_hnsw_search(self.h, ptr(queries), nq, int(ef_search), int(k), ptr(elem), ptr(dist),
+                                  ptr(scored)))
+        return elem, dist, scored
+
     def score(self, queries, slot, query_of=None):
         queries = as_dtype(queries, self.dtype)
         slot = np.ascontiguousarray(slot, dtype=np.int32) if not _is_torch(slot) else slot

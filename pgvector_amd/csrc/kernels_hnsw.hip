@@ -1,0 +1,410 @@
+// kernels_hnsw.hip -- hnswgettuple's first batch entirely on the device: the greedy
+// descent through the upper layers and HnswSearchLayer on layer 0
+// (src/hnswscan.c:25-56, src/hnswutils.c:824-987), one workgroup per query.
+//
+// The reference keeps two pairing heaps per layer search: C, the candidates still to
+// expand (nearest first), and W, the ef nearest elements found (furthest first).
+// Every element enters both at once (:936-960); W evicts its furthest when it
+// overflows (:967-973); the search stops when the nearest unexpanded candidate is
+// strictly farther than W's furthest (:894).  A candidate that has been evicted from
+// W is at least as far as W's furthest from then on, so it can never be expanded
+// before the search stops: C is, for the purposes of the result, "the entries of W
+// not expanded yet".  Here W is therefore ONE ascending array in LDS whose entries
+// carry an `expanded` flag:
+//   next candidate  = first unexpanded entry (none left <=> the reference's loop ends)
+//   neighbours      = the candidate's neighbour tuple at this layer, in tuple order,
+//                     minus the visited ones (visited set: a bitmap in HBM)
+//   scoring         = all unvisited neighbours at once, every wavefront of the
+//                     workgroup taking rows (the distances do not depend on heap state)
+//   admission       = a stable merge of the scored batch into W truncated to ef, which
+//                     is exactly what admitting them one by one with the reference's
+//                     `eDistance < f->distance || wlen < ef` test produces: an element
+//                     rejected or evicted on the way would sit past position ef in
+//                     the merged order as well.
+// One refinement keeps this exact for distance ties: an element that was admitted and
+// then evicted from W at a distance EQUAL to W's new furthest is still a live
+// candidate in the reference (its stop test is strict).  Such elements go to a small
+// tie list T (they all share one distance); T is dropped as soon as W's furthest
+// gets nearer, and its members are expanded after W's own unexpanded entries.  The
+// ORDER among equal distances is the one thing left open -- it is unspecified in the
+// reference as well (pairing-heap internals).
+#include "pgv_device.h"
+
+namespace pgv {
+
+namespace {
+
+constexpr int kHnswThreads = 256;
+constexpr int kHnswWaves = kHnswThreads / kWave;
+constexpr uint32_t kExpanded = 0x80000000u;
+constexpr int kTieCap = 64;  // evicted candidates tied with W's furthest that are remembered
+
+struct HnswDev {
+    const char *rows;  // [n x nvec] 16-byte vectors
+    int nvec, lpr_log2, nchunks;
+    const int32_t *levels;     // [n]
+    const int64_t *nbr_start;  // [n + 1]
+    const int32_t *nbr;        // neighbour tuples, HnswNeighborTupleData layout
+    int m;
+    int32_t entry;
+    int64_t n;
+};
+
+template <typename T, int METRIC>
+__global__ __launch_bounds__(kHnswThreads) void hnsw_search_kernel(
+    HnswDev g, const char *__restrict__ queries, int nq, int ef, int k, uint32_t *__restrict__ bitmaps,
+    int words, int *__restrict__ qcounter, int64_t *__restrict__ out_elem, float *__restrict__ out_dist,
+    int64_t *__restrict__ out_scored) {
+    constexpr int N = VecTraits<T>::N;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int lm0 = 2 * g.m;
+    // layout: query row | W keys [2][ef] | W ids [2][ef] | batch keys [lm0] | batch ids [lm0] | scalars
+    Raw16 *lq = reinterpret_cast<Raw16 *>(smem);
+    uint32_t *wk = reinterpret_cast<uint32_t *>(smem + (size_t)g.nvec * sizeof(Raw16));
+    uint32_t *wi = wk + 2 * ef;
+    uint32_t *bk = wi + 2 * ef;
+    int32_t *bi = reinterpret_cast<int32_t *>(bk + lm0);
+    uint32_t *ti = reinterpret_cast<uint32_t *>(bi + lm0);  // tie list ids [kTieCap]
+    int *sc = reinterpret_cast<int *>(ti + kTieCap);
+    // sc: [0] query, [1] |W|, [2] batch size, [3] candidate element (-1: none), [4] W buffer,
+    //     [5] |T|, [6] next unread entry of T, [7] key shared by T's entries
+
+    const int tid = threadIdx.x;
+    const int lane = tid & (kWave - 1);
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int lpr = 1 << g.lpr_log2;
+    const int sub = lane & (lpr - 1);
+    const int rsub = lane >> g.lpr_log2;
+    const int rpw = kWave >> g.lpr_log2;
+    const size_t row_bytes = (size_t)g.nvec * sizeof(Raw16);
+    uint32_t *bitmap = bitmaps + (size_t)blockIdx.x * words;
+
+    // distance of the query (in LDS) to the rows bi[0 .. nb): every wavefront takes rpw rows per trip
+    auto score_batch = [&](int nb) {
+        for (int base = wave * rpw; base < nb; base += kHnswWaves * rpw) {
+            const int i = base + rsub;
+            const bool valid = i < nb;
+            const char *rp = g.rows + (size_t)bi[valid ? i : nb - 1] * row_bytes;
+            float acc = 0.f;
+#pragma unroll 4
+            for (int c = 0; c < g.nchunks; c++) {
+                const int vi = c * lpr + sub;
+                const bool ok = vi < g.nvec;
+                const int vc = ok ? vi : g.nvec - 1;  // never predicate a load (see scan_kernel)
+                const Raw16 rv = load16(rp + (size_t)vc * sizeof(Raw16));
+                const Raw16 qv = lq[vc];
+                Unpacked<T> ur(rv);
+                Unpacked<T> uq(qv);
+#pragma unroll
+                for (int e = 0; e < N; e++) acc = accum<METRIC>(acc, ok ? ur.v[e] : 0.f, ok ? uq.v[e] : 0.f);
+            }
+            acc = group_sum_to_last(acc, g.lpr_log2);
+            if (sub == lpr - 1 && valid) bk[i] = float_to_key(finish<METRIC>(acc));
+        }
+    };
+
+    for (;;) {
+        if (tid == 0) sc[0] = atomicAdd(qcounter, 1);
+        __syncthreads();
+        const int qi = sc[0];
+        if (qi >= nq) return;
+
+        int64_t scored = 0;
+        if (g.entry < 0) {  // empty index
+            for (int j = tid; j < k; j += kHnswThreads) {
+                out_elem[(size_t)qi * k + j] = -1;
+                out_dist[(size_t)qi * k + j] = __uint_as_float(0x7f800000u);
+            }
+            if (tid == 0 && out_scored) out_scored[qi] = 0;
+            __syncthreads();
+            continue;
+        }
+
+        // query into LDS; the entry point is the first batch
+        for (int v = tid; v < g.nvec; v += kHnswThreads) lq[v] = load16(queries + (size_t)qi * row_bytes + (size_t)v * sizeof(Raw16));
+        if (tid == 0) bi[0] = g.entry;
+        __syncthreads();
+        score_batch(1);
+        __syncthreads();
+        if (tid == 0) {
+            wk[0] = bk[0];
+            wi[0] = (uint32_t)g.entry;
+            sc[1] = 1;
+            sc[4] = 0;
+        }
+        const int top = g.levels[g.entry];
+
+        for (int lc = top; lc >= 0; lc--) {
+            const int ef_l = lc == 0 ? ef : 1;
+            const int lm = lc == 0 ? lm0 : g.m;
+            // a fresh visited set holding the entry points (src/hnswutils.c:866-885); the entry
+            // points are the previous layer's W, all unexpanded again
+            for (int w = tid; w < words; w += kHnswThreads) bitmap[w] = 0u;
+            __syncthreads();
+            {
+                const int cur = sc[4], wn = sc[1];
+                for (int j = tid; j < wn; j += kHnswThreads) {
+                    const uint32_t id = wi[cur * ef + j] & ~kExpanded;
+                    wi[cur * ef + j] = id;
+                    atomicOr(&bitmap[id >> 5], 1u << (id & 31));
+                }
+            }
+            if (tid == 0) sc[5] = sc[6] = 0;
+            __syncthreads();
+            if (lc == 0) scored += sc[1];  // its entry points count too (src/hnswutils.c:872-873)
+
+            for (;;) {
+                // ---- wavefront 0: next candidate and its unvisited neighbours, in tuple order
+                if (wave == 0) {
+                    const int cur = sc[4], wn = sc[1];
+                    int found = -1;
+                    for (int base = 0; base < wn && found < 0; base += kWave) {
+                        const int j = base + lane;
+                        const bool open = j < wn && !(wi[cur * ef + j] & kExpanded);
+                        const unsigned long long bal = __ballot(open);
+                        if (bal) found = base + __ffsll((long long)bal) - 1;
+                    }
+                    int nb = 0;
+                    int cand = -1;
+                    if (found >= 0) {
+                        cand = (int)wi[cur * ef + found];
+                        if (lane == 0) wi[cur * ef + found] = (uint32_t)cand | kExpanded;
+                    } else if (sc[6] < sc[5]) {  // W exhausted: an evicted candidate tied with its furthest
+                        cand = (int)ti[sc[6]];
+                        if (lane == 0) sc[6] = sc[6] + 1;
+                    }
+                    if (cand >= 0) {
+                        const uint32_t c = (uint32_t)cand;
+                        // neighbour tuple slice of layer lc (src/hnswutils.c:786)
+                        const int64_t start = g.nbr_start[c] + (int64_t)(g.levels[c] - lc) * g.m;
+                        for (int base = 0; base < lm; base += kWave) {
+                            const int j = base + lane;
+                            const int32_t e = j < lm ? g.nbr[start + j] : -1;
+                            bool fresh = false;
+                            if (e >= 0) {
+                                const uint32_t bit = 1u << (e & 31);
+                                fresh = !(atomicOr(&bitmap[e >> 5], bit) & bit);
+                            }
+                            const unsigned long long bal = __ballot(fresh);
+                            if (fresh) bi[nb + __popcll(bal & ((1ull << lane) - 1ull))] = e;
+                            nb += __popcll(bal);
+                        }
+                    }
+                    // "make robust to issues" (src/hnswutils.c:947-949): an element below this layer
+                    // is scored and stays visited but is never admitted; only upper layers can see one
+                    if (lane == 0) {
+                        sc[2] = nb;
+                        sc[3] = cand;
+                    }
+                }
+                __syncthreads();
+                const int nb = sc[2];
+                if (sc[3] < 0) break;  // every entry of W expanded: the reference's C is exhausted or too far
+                if (nb == 0) {
+                    __syncthreads();
+                    continue;
+                }
+                if (lc == 0) scored += nb;  // so->tuples: only the layer-0 search counts (src/hnswscan.c:52-55)
+
+                // ---- everyone: score the batch
+                score_batch(nb);
+                __syncthreads();
+
+                // ---- wavefront 0: stable merge of the batch into W, truncated to ef_l
+                if (wave == 0) {
+                    const int cur = sc[4], nxt = cur ^ 1, wn = sc[1];
+                    const uint32_t *ck = wk + cur * ef, *ci = wi + cur * ef;
+                    uint32_t *nk = wk + nxt * ef, *ni = wi + nxt * ef;
+                    int nbv = nb;
+                    if (lc > 0) {  // drop batch entries that do not reach this layer, keeping the order
+                        int kept = 0;
+                        for (int base = 0; base < nb; base += kWave) {
+                            const int i = base + lane;
+                            const bool keep = i < nb && g.levels[bi[i < nb ? i : 0]] >= lc;
+                            const uint32_t key = i < nb ? bk[i] : 0u;
+                            const int32_t id = i < nb ? bi[i] : 0;
+                            const unsigned long long bal = __ballot(keep);
+                            const int at = kept + __popcll(bal & ((1ull << lane) - 1ull));
+                            // in-place compaction is safe: a chunk only writes at or below its own reads
+                            if (keep) {
+                                bk[at] = key;
+                                bi[at] = id;
+                            }
+                            kept += __popcll(bal);
+                        }
+                        nbv = kept;
+                    }
+                    const int nb = nbv;
+                    const int wn_new = wn + nb < ef_l ? wn + nb : ef_l;
+                    // old entries move up by the number of batch entries strictly nearer
+                    for (int j = lane; j < wn; j += kWave) {
+                        const uint32_t key = ck[j];
+                        int s = 0;
+                        for (int b = 0; b < nb; b++) s += bk[b] < key;
+                        if (j + s < ef_l) {
+                            nk[j + s] = key;
+                            ni[j + s] = ci[j];
+                        }
+                    }
+                    // batch entries go after every old entry that is not farther and after the
+                    // batch entries that are nearer or equal-and-earlier
+                    for (int i = lane; i < nb; i += kWave) {
+                        const uint32_t key = bk[i];
+                        int lo = 0, hi = wn;  // first old entry with key > this one
+                        while (lo < hi) {
+                            const int mid = (lo + hi) >> 1;
+                            if (ck[mid] <= key)
+                                lo = mid + 1;
+                            else
+                                hi = mid;
+                        }
+                        int s = lo;
+                        for (int b = 0; b < nb; b++) s += (bk[b] < key) || (bk[b] == key && b < i);
+                        if (s < ef_l) {
+                            nk[s] = key;
+                            ni[s] = (uint32_t)bi[i];
+                        }
+                    }
+                    // The tie list.  With W full, its furthest key K is nk[ef_l - 1].  T keeps the
+                    // unexpanded candidates that were pushed out of W at exactly K: old entries, and
+                    // batch entries that had been admitted when their turn came (fewer than ef_l
+                    // entries not farther among W and the batch entries before them).  Entries of an
+                    // older T stay only if K has not moved.
+                    if (wn_new == ef_l && wn + nb > ef_l) {
+                        const uint32_t K = nk[ef_l - 1];
+                        int tn = sc[5];
+                        if (tn > 0 && (uint32_t)sc[7] != K) tn = 0;
+                        const int t0 = tn > 0 ? sc[6] : 0;
+                        for (int base = 0; base < wn; base += kWave) {
+                            const int j = base + lane;
+                            bool tie = false;
+                            uint32_t id = 0;
+                            if (j < wn && ck[j] == K && !(ci[j] & kExpanded)) {
+                                int sft = 0;
+                                for (int b = 0; b < nb; b++) sft += bk[b] < K;
+                                tie = j + sft >= ef_l;
+                                id = ci[j];
+                            }
+                            const unsigned long long bal = __ballot(tie);
+                            const int at = tn + __popcll(bal & ((1ull << lane) - 1ull));
+                            if (tie && at < kTieCap) ti[at] = id;
+                            tn += __popcll(bal);
+                        }
+                        for (int base = 0; base < nb; base += kWave) {
+                            const int i = base + lane;
+                            bool tie = false;
+                            if (i < nb && bk[i] == K) {
+                                int lo = 0, hi = wn;
+                                while (lo < hi) {
+                                    const int mid = (lo + hi) >> 1;
+                                    if (ck[mid] <= K)
+                                        lo = mid + 1;
+                                    else
+                                        hi = mid;
+                                }
+                                int before = lo, pos = lo;
+                                for (int b = 0; b < nb; b++) {
+                                    before += b < i && bk[b] <= K;
+                                    pos += (bk[b] < K) || (bk[b] == K && b < i);
+                                }
+                                tie = before < ef_l && pos >= ef_l;  // admitted in its turn, pushed out later
+                            }
+                            const unsigned long long bal = __ballot(tie);
+                            const int at = tn + __popcll(bal & ((1ull << lane) - 1ull));
+                            if (tie && at < kTieCap) ti[at] = (uint32_t)bi[i];
+                            tn += __popcll(bal);
+                        }
+                        if (lane == 0) {
+                            sc[5] = tn < kTieCap ? tn : kTieCap;
+                            sc[6] = t0;
+                            sc[7] = (int)K;
+                        }
+                    }
+                    if (lane == 0) {
+                        sc[1] = wn_new;
+                        sc[4] = nxt;
+                    }
+                }
+                __syncthreads();
+            }
+            __syncthreads();
+        }
+
+        // nearest first (src/hnswscan.c:293-311)
+        {
+            const int cur = sc[4], wn = sc[1];
+            for (int j = tid; j < k; j += kHnswThreads) {
+                const bool have = j < wn;
+                out_elem[(size_t)qi * k + j] = have ? (int64_t)(wi[cur * ef + j] & ~kExpanded) : -1;
+                out_dist[(size_t)qi * k + j] = have ? key_to_float(wk[cur * ef + j]) : __uint_as_float(0x7f800000u);
+            }
+            if (tid == 0 && out_scored) out_scored[qi] = scored;
+        }
+        __syncthreads();
+    }
+}
+
+template <typename T, int METRIC>
+int launch_hnsw_t(pgv_ctx *ctx, const HnswDev &g, const void *queries, int nq, int ef, int k,
+                  uint32_t *bitmaps, int words, int grid, int *counter, int64_t *out_elem, float *out_dist,
+                  int64_t *out_scored) {
+    const size_t lds = (size_t)g.nvec * sizeof(Raw16) + (size_t)ef * 16 + (size_t)g.m * 16 + kTieCap * 4 + 64;
+    if (lds > 150 * 1024) PGV_FAIL(PGV_ERR_ARG, "hnsw search: ef_search %d / m %d need %zu bytes of LDS", ef, g.m, lds);
+    auto kern = hnsw_search_kernel<T, METRIC>;
+    PGV_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(kHnswThreads), lds, ctx->stream, g, static_cast<const char *>(queries), nq,
+                       ef, k, bitmaps, words, counter, out_elem, out_dist, out_scored);
+    PGV_HIP(hipGetLastError());
+    return PGV_OK;
+}
+
+}  // namespace
+
+int hnsw_search_grid(pgv_ctx *ctx, int nq, int64_t n, int *words_out) {
+    const int words = (int)((n + 31) / 32) + 1;
+    int grid = ctx->num_cus * 4;
+    const int64_t cap = (int64_t)(1ll << 30) / ((int64_t)words * 4);  // visited bitmaps: <= 1 GiB
+    if (grid > cap) grid = cap > 0 ? (int)cap : 1;
+    if (grid > nq) grid = nq;
+    *words_out = words;
+    return grid;
+}
+
+int launch_hnsw_search(pgv_ctx *ctx, pgv_metric metric, pgv_dtype dtype, const RowGeom &geom, const void *rows,
+                       int64_t n, const int32_t *levels, const int64_t *nbr_start, const int32_t *nbr, int m,
+                       int32_t entry, const void *queries, int nq, int ef, int k, uint32_t *bitmaps, int words,
+                       int grid, int *counter, int64_t *out_elem, float *out_dist, int64_t *out_scored) {
+    HnswDev g;
+    g.rows = static_cast<const char *>(rows);
+    g.nvec = geom.nvec;
+    g.lpr_log2 = geom.lpr_log2;
+    g.nchunks = geom.nchunks;
+    g.levels = levels;
+    g.nbr_start = nbr_start;
+    g.nbr = nbr;
+    g.m = m;
+    g.entry = entry;
+    g.n = n;
+    PGV_HIP(hipMemsetAsync(counter, 0, sizeof(int), ctx->stream));
+#define PGV_HNSW_M(T)                                                                                         \
+    switch (metric) {                                                                                         \
+        case PGV_L2SQ:                                                                                        \
+            return launch_hnsw_t<T, 0>(ctx, g, queries, nq, ef, k, bitmaps, words, grid, counter, out_elem,  \
+                                       out_dist, out_scored);                                                 \
+        case PGV_NEG_IP:                                                                                      \
+            return launch_hnsw_t<T, 1>(ctx, g, queries, nq, ef, k, bitmaps, words, grid, counter, out_elem,  \
+                                       out_dist, out_scored);                                                 \
+        case PGV_L1:                                                                                          \
+            return launch_hnsw_t<T, 2>(ctx, g, queries, nq, ef, k, bitmaps, words, grid, counter, out_elem,  \
+                                       out_dist, out_scored);                                                 \
+    }
+    if (dtype == PGV_F32) {
+        PGV_HNSW_M(float)
+    } else {
+        PGV_HNSW_M(__half)
+    }
+#undef PGV_HNSW_M
+    PGV_FAIL(PGV_ERR_ARG, "hnsw search: unknown metric %d", (int)metric);
+}
+
+}  // namespace pgv

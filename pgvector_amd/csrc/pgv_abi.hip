@@ -1261,6 +1261,8 @@ void pgv_hnsw_free(pgv_hnsw *h) {
     if (!h) return;
     if (h->ctx) (void)hipStreamSynchronize(h->ctx->stream);
     if (h->elements) (void)hipFree(h->elements);
+    if (h->graph) (void)hipFree(h->graph);
+    h->bitmaps.release();
     delete h;
 }
 
@@ -1283,6 +1285,76 @@ int pgv_hnsw_score(pgv_hnsw *h, const void *queries, int nq, const int32_t *slot
                                 npairs, od.as<float>()));
     bool need = false;
     PGV_TRY(od.finish(ctx, &need));
+    return sync_if(ctx, need);
+}
+
+int pgv_hnsw_set_graph(pgv_hnsw *h, int m, int32_t entry, const int32_t *levels, const int64_t *nbr_start,
+                       const int32_t *nbr) {
+    if (!h) PGV_FAIL(PGV_ERR_ARG, "pgv_hnsw_set_graph: handle is NULL");
+    if (m < 2 || m > 100) PGV_FAIL(PGV_ERR_ARG, "m must be 2..100 (src/hnsw.h:55-56), got %d", m);
+    if (entry < -1 || entry >= h->n) PGV_FAIL(PGV_ERR_ARG, "entry point %d out of range", (int)entry);
+    if (h->n > 0 && (!levels || !nbr_start || !nbr)) PGV_FAIL(PGV_ERR_ARG, "levels/nbr_start/nbr is NULL");
+    pgv_ctx *ctx = h->ctx;
+    PGV_HIP(hipSetDevice(ctx->device));
+    PGV_HIP(hipStreamSynchronize(ctx->stream));  // no search may still be reading the old graph
+    if (h->graph) {
+        PGV_HIP(hipFree(h->graph));
+        h->graph = nullptr;
+    }
+    h->m = m;
+    h->entry = entry;
+    if (h->n == 0) return PGV_OK;
+    // total neighbor slots: the last offset (it may live on either side)
+    int64_t total = 0;
+    PGV_HIP(hipMemcpy(&total, nbr_start + h->n, sizeof(int64_t), hipMemcpyDefault));
+    if (total < 0) PGV_FAIL(PGV_ERR_ARG, "nbr_start is not an offset array");
+    const size_t lb = ((size_t)h->n * sizeof(int32_t) + 15) / 16 * 16;
+    const size_t sb = ((size_t)(h->n + 1) * sizeof(int64_t) + 15) / 16 * 16;
+    const size_t nb = (size_t)(total > 0 ? total : 1) * sizeof(int32_t);
+    if (hipMalloc(&h->graph, lb + sb + nb) != hipSuccess)
+        PGV_FAIL(PGV_ERR_NOMEM, "hipMalloc(%zu) for the hnsw graph failed", lb + sb + nb);
+    char *base = static_cast<char *>(h->graph);
+    PGV_HIP(hipMemcpyAsync(base, levels, (size_t)h->n * sizeof(int32_t), hipMemcpyDefault, ctx->stream));
+    PGV_HIP(hipMemcpyAsync(base + lb, nbr_start, (size_t)(h->n + 1) * sizeof(int64_t), hipMemcpyDefault, ctx->stream));
+    if (total > 0)
+        PGV_HIP(hipMemcpyAsync(base + lb + sb, nbr, (size_t)total * sizeof(int32_t), hipMemcpyDefault, ctx->stream));
+    PGV_HIP(hipStreamSynchronize(ctx->stream));
+    h->levels = reinterpret_cast<const int32_t *>(base);
+    h->nbr_start = reinterpret_cast<const int64_t *>(base + lb);
+    h->nbr = reinterpret_cast<const int32_t *>(base + lb + sb);
+    return PGV_OK;
+}
+
+int pgv_hnsw_search(pgv_hnsw *h, const void *queries, int nq, int ef_search, int k, int64_t *out_elem,
+                    float *out_dist, int64_t *out_scored) {
+    if (!h || !out_elem || !out_dist) PGV_FAIL(PGV_ERR_ARG, "pgv_hnsw_search: handle/out is NULL");
+    if (nq < 0) PGV_FAIL(PGV_ERR_ARG, "bad query count");
+    if (ef_search < 1 || ef_search > 1000)
+        PGV_FAIL(PGV_ERR_ARG, "hnsw.ef_search must be 1..1000 (src/hnsw.c:93-94), got %d", ef_search);
+    if (k < 1 || k > ef_search) PGV_FAIL(PGV_ERR_ARG, "k must be 1..ef_search, got %d", k);
+    if (h->m == 0) PGV_FAIL(PGV_ERR_ARG, "pgv_hnsw_search needs pgv_hnsw_set_graph first");
+    if (nq == 0) return PGV_OK;
+    if (!queries) PGV_FAIL(PGV_ERR_ARG, "queries is NULL");
+    pgv_ctx *ctx = h->ctx;
+    PGV_HIP(hipSetDevice(ctx->device));
+    const void *q_dev;
+    PGV_TRY(stage_rows(ctx, queries, nq, h->dim, h->dtype, h->geom, ctx->q_stage, &q_dev));
+    int words = 0;
+    const int grid = hnsw_search_grid(ctx, nq, h->n, &words);
+    PGV_TRY(h->bitmaps.ensure((size_t)grid * words * sizeof(uint32_t)));
+    PGV_TRY(ctx->counters.ensure(256));
+    OutArg oe, od, os;
+    PGV_TRY(oe.init(out_elem, sizeof(int64_t) * (size_t)nq * k, ctx->out_stage2));
+    PGV_TRY(od.init(out_dist, sizeof(float) * (size_t)nq * k, ctx->out_stage));
+    PGV_TRY(os.init(out_scored, sizeof(int64_t) * (size_t)nq, ctx->sel_b));
+    PGV_TRY(launch_hnsw_search(ctx, h->metric, h->dtype, h->geom, h->elements, h->n, h->levels, h->nbr_start,
+                               h->nbr, h->m, h->entry, q_dev, nq, ef_search, k, h->bitmaps.as<uint32_t>(), words,
+                               grid, ctx->counters.as<int>(), oe.as<int64_t>(), od.as<float>(),
+                               out_scored ? os.as<int64_t>() : nullptr));
+    bool need = false;
+    PGV_TRY(oe.finish(ctx, &need));
+    PGV_TRY(od.finish(ctx, &need));
+    PGV_TRY(os.finish(ctx, &need));
     return sync_if(ctx, need);
 }
 

@@ -151,6 +151,14 @@ struct pgv_hnsw {
     int64_t n = 0;
     pgv::RowGeom geom{};
     void *elements = nullptr;  // [n x ld]
+    // the graph (pgv_hnsw_set_graph): one allocation holding levels | nbr_start | nbr
+    void *graph = nullptr;
+    const int32_t *levels = nullptr;
+    const int64_t *nbr_start = nullptr;
+    const int32_t *nbr = nullptr;
+    int m = 0;
+    int32_t entry = -1;
+    pgv::DBuf bitmaps;  // visited sets of the search workgroups
 };
 
 namespace pgv {
@@ -166,6 +174,13 @@ int scan_group_size(const RowGeom &g, pgv_dtype dtype, int wanted);
 int launch_score_gather(pgv_ctx *ctx, pgv_metric metric, pgv_dtype dtype, const RowGeom &g,
                         const void *rows, const void *queries, const int32_t *slot,
                         const int32_t *query_of, int64_t npairs, float *out);
+
+// kernels_hnsw.hip: the whole first batch of an HNSW scan, one workgroup per query
+int hnsw_search_grid(pgv_ctx *ctx, int nq, int64_t n, int *words_out);
+int launch_hnsw_search(pgv_ctx *ctx, pgv_metric metric, pgv_dtype dtype, const RowGeom &geom, const void *rows,
+                       int64_t n, const int32_t *levels, const int64_t *nbr_start, const int32_t *nbr, int m,
+                       int32_t entry, const void *queries, int nq, int ef, int k, uint32_t *bitmaps, int words,
+                       int grid, int *counter, int64_t *out_elem, float *out_dist, int64_t *out_scored);
 
 // kernels_tile.hip: row tiles in LDS (async DMA), queries in registers: 16 queries per pass
 bool tile_scan_supported(const RowGeom &g);

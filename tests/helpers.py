@@ -29,6 +29,9 @@ def gen(n, dim, seed, dist="uniform", dtype=po.ORA_F32, clusters=16):
         x = c[rng.integers(0, clusters, n)] + 0.1 * rng.standard_normal((n, dim)).astype(np.float32)
     elif dist == "int":
         x = rng.integers(-8, 9, (n, dim)).astype(np.float32)
+    elif dist == "int10":
+        # exact fp32 arithmetic (dim <= 8: every partial sum of squares < 2^24) with few equal distances
+        x = rng.integers(0, 1024, (n, dim)).astype(np.float32)
     else:
         raise ValueError(dist)
     return np.ascontiguousarray(x.astype(NP_OF[dtype]))

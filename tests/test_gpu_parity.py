@@ -367,6 +367,89 @@ def test_hnsw_score_gathers(ctx, oracle):
         h.close()
 
 
+@pytest.mark.parametrize("ops,metric,dist,dtype,dim,m,ef", [
+    (po.OPS_L2, api.PGV_L2SQ, "int10", "f32", 8, 8, 40),
+    (po.OPS_L2, api.PGV_L2SQ, "int", "f32", 24, 8, 40),
+    (po.OPS_L2, api.PGV_L2SQ, "normal", "f32", 100, 16, 100),
+    (po.OPS_COSINE, api.PGV_NEG_IP, "normal", "f32", 256, 8, 40),
+    (po.OPS_L1, api.PGV_L1, "int10", "f32", 8, 5, 17),
+    (po.OPS_L2, api.PGV_L2SQ, "normal", "f16", 136, 8, 64),
+])
+def test_hnsw_search_on_device(ctx, oracle, ops, metric, dist, dtype, dim, m, ef):
+    """pgv_hnsw_search: the whole first batch of an HNSW scan in one kernel launch (greedy descent
+    + HnswSearchLayer, src/hnswscan.c:25-56, src/hnswutils.c:824-987) against the oracle's search on
+    the same graph; on integer-valued data the arithmetic is exact and the traversal must be
+    identical wherever no two candidates are equally far ("int10": exact arithmetic, few ties)"""
+    n = 3000
+    data = gen(n, dim, seed=211, dist=dist)
+    odt, gdt = (po.ORA_F32, api.PGV_F32) if dtype == "f32" else (po.ORA_F16, api.PGV_F16)
+    if dtype == "f16":
+        data = data.astype(np.float16).astype(np.float32)
+    g = po.HnswGraph(oracle, ops, po.ORA_F32, data, m=m, ef_construction=32, seed=7)
+    ex = g.export_tuples()
+    stored = data[ex["rows"]]
+    if ops == po.OPS_COSINE:
+        stored = normalize_rows(oracle, np.ascontiguousarray(stored), po.ORA_F32)
+    stored_dev = stored.astype(np.float16) if dtype == "f16" else stored
+    mirror = api.Hnsw(ctx, metric, gdt, dim, stored_dev)
+    mirror.set_graph(m, ex["entry"], ex["levels"], ex["nbr_start"], ex["nbr"])
+    queries = gen(48, dim, seed=212, dist=dist)
+    if dtype == "f16":
+        queries = queries.astype(np.float16).astype(np.float32)
+    gq = normalize_rows(oracle, queries, po.ORA_F32) if ops == po.OPS_COSINE else queries
+    gq_dev = gq.astype(np.float16) if dtype == "f16" else gq
+    k = min(10, ef)
+    elem, gd, scored = mirror.search(gq_dev, ef, k)
+    same_scored = 0
+    for i, q in enumerate(queries):
+        rows, wd, wscored = g.search(q, ef, k)
+        got_rows = ex["rows"][elem[i][elem[i] >= 0]]
+        # integer-valued data is full of equal distances; the order in which tied candidates are
+        # expanded is unspecified (pairing-heap internals in the reference, a binary heap in the
+        # oracle, array order here), so the walks -- and the scored counts -- legitimately differ
+        # there and only the result is compared
+        same_scored += int(scored[i] == wscored)
+        if dtype == "f32":
+            assert_topk_equiv(got_rows.tolist(), gd[i][:len(got_rows)], rows.tolist(), wd,
+                              what="hnsw device search ops %d q %d" % (ops, i))
+        else:  # the oracle graph search runs in fp32 on the fp16-rounded values: same values, same order
+            assert len(got_rows) == len(rows)
+            assert_close(gd[i][:len(rows)], wd, rtol=RTOL, atol=1e-6, what="hnsw f16 device search q %d" % i)
+    assert dist == "int" or same_scored >= 40, same_scored
+    if dist == "int10":
+        assert same_scored >= 44, same_scored
+    # the host-driven search (pgv_host_hnsw_search) walks the same graph with the same distances
+    if dtype == "f32" and dist == "normal":
+        from pgvector_amd import _host
+        graph = _host.hnsw_graph(ex["levels"], ex["nbr_start"], ex["nbr"], m, ex["entry"])
+        helem, hd, hscored = _host.hnsw_search(mirror, graph, gq, ef, k)
+        assert np.array_equal(hscored, scored)
+        assert np.array_equal(hd, gd)
+    mirror.close()
+
+
+def test_hnsw_search_on_device_edge_cases(ctx, oracle):
+    """empty index, single element, k == ef_search == 1, argument checks"""
+    dim = 16
+    one = gen(1, dim, seed=3)
+    mirror = api.Hnsw(ctx, api.PGV_L2SQ, api.PGV_F32, dim, one)
+    with pytest.raises(api.PgvError):
+        mirror.search(one, 10, 5)  # no graph yet
+    mirror.set_graph(4, 0, np.zeros(1, np.int32), np.array([0, 8], np.int64), np.full(8, -1, np.int32))
+    elem, d, scored = mirror.search(gen(3, dim, seed=4), 1, 1)
+    assert elem.ravel().tolist() == [0, 0, 0] and scored.tolist() == [1, 1, 1]
+    elem, d, scored = mirror.search(gen(3, dim, seed=4), 10, 5)
+    assert (elem[:, 0] == 0).all() and (elem[:, 1:] == -1).all() and np.isinf(d[:, 1:]).all()
+    with pytest.raises(api.PgvError):
+        mirror.search(one, 5, 6)  # k > ef_search
+    with pytest.raises(api.PgvError):
+        mirror.search(one, 1001, 5)
+    mirror.set_graph(4, -1, np.zeros(1, np.int32), np.array([0, 8], np.int64), np.full(8, -1, np.int32))
+    elem, d, scored = mirror.search(gen(2, dim, seed=4), 10, 5)
+    assert (elem == -1).all() and scored.tolist() == [0, 0]
+    mirror.close()
+
+
 @pytest.mark.parametrize("ops,metric,dist", [(po.OPS_L2, api.PGV_L2SQ, "int"), (po.OPS_L2, api.PGV_L2SQ, "normal"),
                                               (po.OPS_COSINE, api.PGV_NEG_IP, "normal"), (po.OPS_L1, api.PGV_L1, "int")])
 def test_hnsw_search_with_gpu_candidate_scoring(ctx, oracle, ops, metric, dist):

@@ -1,9 +1,10 @@
 #!/usr/bin/env python3
 """HNSW candidate-batch scoring (BASELINE configs[3], scaled): vector_cosine_ops, m = 16,
 ef_search = 100, 1536-d unit vectors.  The graph is built by the CPU oracle's restatement of
-the reference build (it is test infrastructure: the product path only SEARCHES); the search is
-the C host glue's lock-step HnswSearchLayer with every expansion step's candidates scored by
-one pgv_hnsw_score launch.  Prints one JSON line.
+the reference build (it is test infrastructure: the product path only SEARCHES).  Two searches
+are timed: pgv_hnsw_search, the whole first batch of a scan in one kernel launch (one workgroup
+per query), and the C host glue's lock-step HnswSearchLayer with every expansion step's
+candidates scored by one pgv_hnsw_score launch.  Prints one JSON line.
 
 usage: python tools/bench_hnsw.py [--rows 50000] [--dim 1536] [--queries 1000]
 """
@@ -54,6 +55,21 @@ def main():
     elem, dist, scored = _host.hnsw_search(mirror, graph, qn, a.ef_search, a.k)
     gpu_s = time.perf_counter() - t0
 
+    # the on-device search: queries resident in HBM, timed with a device sync on both sides
+    import torch
+    mirror.set_graph(a.m, ex["entry"], ex["levels"], ex["nbr_start"], ex["nbr"])
+    qd = torch.from_numpy(qn).cuda()
+    reps = max(1, 20000 // a.queries)
+    qd = qd.repeat(reps, 1).contiguous()
+    mirror.search(qd[:64], a.ef_search, a.k)
+    ctx.sync()
+    t0 = time.perf_counter()
+    delem, ddist, dscored = mirror.search(qd, a.ef_search, a.k)
+    ctx.sync()
+    dev_s = time.perf_counter() - t0
+    delem_h = delem[:a.queries].cpu().numpy()
+    same = float((np.sort(delem_h, axis=1) == np.sort(elem, axis=1)).all(axis=1).mean())
+
     # exact ground truth on the same unit vectors (cosine distance order = -ip order)
     ip = qn.astype(np.float64) @ stored.astype(np.float64).T
     kth = -np.sort(-ip, axis=1)[:, a.k - 1]
@@ -62,6 +78,10 @@ def main():
         e = elem[i][elem[i] >= 0]
         hits += int((ip[i, e] >= kth[i] - 1e-9).sum())
     recall = hits / (a.queries * a.k)
+    dhits = 0
+    for i in range(a.queries):
+        e = delem_h[i][delem_h[i] >= 0]
+        dhits += int((ip[i, e] >= kth[i] - 1e-9).sum())
 
     # the oracle's search, one thread (one backend)
     t0 = time.perf_counter()
@@ -76,6 +96,11 @@ def main():
         "unit": "queries/s", "config": {"rows": a.rows, "dim": a.dim, "m": a.m, "ef_construction": a.ef_construction,
                                         "ef_search": a.ef_search, "k": a.k, "queries_in_lock_step": a.queries,
                                         "ops": "vector_cosine_ops"},
+        "device_search": {"value": qd.shape[0] / dev_s, "unit": "queries/s", "queries_in_flight": int(qd.shape[0]),
+                          "recall_at_k": dhits / (a.queries * a.k),
+                          "scored_elements_per_query": float(dscored.float().mean().item()),
+                          "algorithmic_GBps": float(dscored.sum().item()) * a.dim * 4 / dev_s / 1e9,
+                          "same_result_set_as_host_search": same},
         "recall_at_k": recall, "scored_elements_per_query": float(scored.mean()),
         "algorithmic_GBps": float(scored.sum()) * a.dim * 4 / gpu_s / 1e9,
         "cpu_baseline": {"value": n_cpu / cpu_s, "unit": "queries/s", "cores": 1, "kind": "port",
