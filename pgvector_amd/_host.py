@@ -17,13 +17,16 @@ class HnswGraphStruct(C.Structure):
 
 
 class Rel(C.Structure):
-    _fields_ = [("pages", C.c_void_p), ("nblocks", C.c_uint32), ("cap", C.c_uint32)]
+    _fields_ = [("pages", C.c_void_p), ("nblocks", C.c_uint32), ("cap", C.c_uint32), ("generation", C.c_uint64)]
 
 
 class IvfImage(C.Structure):
     _fields_ = [("dtype", C.c_int), ("dim", C.c_int), ("lists", C.c_int), ("nrows", C.c_int64),
                 ("centers", C.c_void_p), ("list_offsets", C.c_void_p), ("vectors", C.c_void_p),
                 ("tids", C.c_void_p), ("start_pages", C.c_void_p)]
+
+
+DEAD_FN = C.CFUNCTYPE(C.c_int, C.c_uint64, C.c_void_p)  # IndexBulkDeleteCallback
 
 
 def _load():
@@ -40,6 +43,13 @@ def _load():
     lib.pgv_rel_free.restype = None
     lib.pgv_host_ivf_write_index.argtypes = [C.POINTER(Rel), I, I, I, P, P, P, P]
     lib.pgv_host_ivf_insert.argtypes = [C.POINTER(Rel), I, I, P, C.c_uint64]
+    lib.pgv_host_ivf_bulkdelete.argtypes = [C.POINTER(Rel), DEAD_FN, P, C.POINTER(I64), C.POINTER(I64)]
+    lib.pgv_host_ivf_mirror_open.argtypes = [P, I, I, C.POINTER(P)]
+    lib.pgv_host_ivf_mirror_get.argtypes = [P, C.POINTER(Rel), C.POINTER(P), C.POINTER(C.POINTER(IvfImage))]
+    lib.pgv_host_ivf_mirror_restages.argtypes = [P]
+    lib.pgv_host_ivf_mirror_restages.restype = I64
+    lib.pgv_host_ivf_mirror_close.argtypes = [P]
+    lib.pgv_host_ivf_mirror_close.restype = None
     lib.pgv_host_ivf_stage.argtypes = [C.POINTER(Rel), I, C.POINTER(IvfImage)]
     lib.pgv_host_ivf_image_free.argtypes = [C.POINTER(IvfImage)]
     lib.pgv_host_ivf_image_free.restype = None
@@ -125,6 +135,18 @@ class Relation:
         vector = np.ascontiguousarray(vector, dtype=_NP[dtype])
         host_check(lib.pgv_host_ivf_insert(C.byref(self.rel), dtype, list_id, C.c_void_p(vector.ctypes.data), tid))
 
+    @property
+    def generation(self):
+        return self.rel.generation
+
+    def bulkdelete(self, dead_tids):
+        """ambulkdelete with a callback that reports the given heap TIDs dead -> (removed, remaining)"""
+        dead = set(int(t) for t in dead_tids)
+        cb = DEAD_FN(lambda tid, _state: 1 if tid in dead else 0)
+        removed, remaining = C.c_int64(), C.c_int64()
+        host_check(lib.pgv_host_ivf_bulkdelete(C.byref(self.rel), cb, None, C.byref(removed), C.byref(remaining)))
+        return removed.value, remaining.value
+
     def stage(self, dtype):
         return StagedImage(self, dtype)
 
@@ -160,6 +182,53 @@ class StagedImage:
     def __del__(self):
         try:
             lib.pgv_host_ivf_image_free(C.byref(self.img))
+        except Exception:
+            pass
+
+
+class _BorrowedIndex:
+    """a pgv_index owned by a Mirror"""
+
+    def __init__(self, h):
+        self.h = h
+
+
+class _BorrowedImage:
+    def __init__(self, img_ptr, dtype):
+        self.img = img_ptr.contents
+        self.dtype = dtype
+        self.nrows, self.lists, self.dim = self.img.nrows, self.img.lists, self.img.dim
+
+
+class Mirror:
+    """device mirror of a Relation that restages itself when the pages changed (pgv_host_ivf_mirror_*)"""
+
+    def __init__(self, ctx, metric, dtype):
+        self.dtype = dtype
+        h = C.c_void_p()
+        host_check(lib.pgv_host_ivf_mirror_open(ctx.h, metric, dtype, C.byref(h)))
+        self.h = h
+        ctx._adopt(self)
+
+    def get(self, relation):
+        """-> (index handle wrapper, staged image wrapper), valid until the next get()/close()"""
+        ih = C.c_void_p()
+        img = C.POINTER(IvfImage)()
+        host_check(lib.pgv_host_ivf_mirror_get(self.h, C.byref(relation.rel), C.byref(ih), C.byref(img)))
+        return _BorrowedIndex(ih), _BorrowedImage(img, self.dtype)
+
+    @property
+    def restages(self):
+        return lib.pgv_host_ivf_mirror_restages(self.h)
+
+    def close(self):
+        if self.h:
+            lib.pgv_host_ivf_mirror_close(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
         except Exception:
             pass
 

@@ -132,6 +132,7 @@ page_add_item(uint8_t *page, const void *item, size_t size)
 void
 pgv_rel_init(pgv_rel * rel)
 {
+	rel->generation = 0;
 	rel->pages = NULL;
 	rel->nblocks = rel->cap = 0;
 }
@@ -139,8 +140,11 @@ pgv_rel_init(pgv_rel * rel)
 void
 pgv_rel_free(pgv_rel * rel)
 {
+	uint64_t	generation = rel->generation;
+
 	free(rel->pages);
 	pgv_rel_init(rel);
+	rel->generation = generation + 1;	/* whatever was staged from the old pages is stale */
 }
 
 /* IvfflatNewBuffer + IvfflatInitPage, src/ivfutils.c:135-156 */
@@ -311,6 +315,7 @@ pgv_host_ivf_write_index(pgv_rel * rel, pgv_dtype dtype, int dim, int lists,
 	free(item);
 	free(list_blk);
 	free(list_off);
+	rel->generation++;
 	return PGV_OK;
 }
 
@@ -367,6 +372,109 @@ pgv_host_ivf_insert(pgv_rel * rel, pgv_dtype dtype, int list, const void *vector
 	}
 	page_add_item(page_at(rel, insert_page), item, sz);
 	memcpy(li + 4, &insert_page, 4);
+	rel->generation++;
+	return PGV_OK;
+}
+
+/* ------------------------------------------------------------------- vacuum */
+
+/* PageIndexMultiDelete: drop the given (ascending) offsets; survivors keep their order */
+static void
+page_multi_delete(uint8_t *page, const int *deletable, int ndeletable)
+{
+	uint8_t		copy[PGV_BLCKSZ];
+	page_header *h = (page_header *) page;
+	int			maxoff = page_max_offset(page);
+	int			d = 0;
+
+	memcpy(copy, page, PGV_BLCKSZ);
+	h->pd_lower = PAGE_HEADER_SIZE;
+	h->pd_upper = h->pd_special;
+	for (int offno = 1; offno <= maxoff; offno++)
+	{
+		int			len;
+		uint8_t    *item;
+
+		if (d < ndeletable && deletable[d] == offno)
+		{
+			d++;
+			continue;
+		}
+		item = page_item(copy, offno, &len);
+		page_add_item(page, item, (size_t) len);
+	}
+}
+
+int
+pgv_host_ivf_bulkdelete(pgv_rel * rel, pgv_host_dead_fn dead, void *state,
+						int64_t *tuples_removed, int64_t *num_index_tuples)
+{
+	uint32_t	blkno = IVFFLAT_HEAD_BLKNO;
+	int64_t		removed = 0,
+				remaining = 0;
+
+	if (rel->nblocks < 2 || !dead)
+		return pgv_host_fail(PGV_ERR_STATE, "not an ivfflat index");
+	/* iterate over list pages (src/ivfvacuum.c:31-56) */
+	while (blkno != PGV_INVALID_BLOCK && blkno < rel->nblocks)
+	{
+		uint8_t    *cpage = page_at(rel, blkno);
+		int			cmaxoff = page_max_offset(cpage);
+
+		for (int coffno = 1; coffno <= cmaxoff; coffno++)
+		{
+			uint8_t    *list = page_item(cpage, coffno, NULL);
+			uint32_t	search_page,
+						insert_page = PGV_INVALID_BLOCK;
+
+			memcpy(&search_page, list + 0, 4);
+			/* iterate over entry pages (:63-124) */
+			while (search_page != PGV_INVALID_BLOCK && search_page < rel->nblocks)
+			{
+				uint8_t    *page = page_at(rel, search_page);
+				int			maxoff = page_max_offset(page);
+				int			deletable[PGV_BLCKSZ / ITEMID_SIZE];
+				int			ndeletable = 0;
+
+				for (int offno = 1; offno <= maxoff; offno++)
+				{
+					const uint8_t *itup = page_item(page, offno, NULL);
+					uint16_t	bi_hi,
+								bi_lo,
+								posid;
+					uint64_t	tid;
+
+					memcpy(&bi_hi, itup + 0, 2);
+					memcpy(&bi_lo, itup + 2, 2);
+					memcpy(&posid, itup + 4, 2);
+					tid = ((uint64_t) (((uint32_t) bi_hi << 16) | bi_lo) << 16) | posid;
+					if (dead(tid, state))
+					{
+						deletable[ndeletable++] = offno;
+						removed++;
+					}
+					else
+						remaining++;
+				}
+				/* set to first free page; must be set before searchPage is updated (:110-113) */
+				if (insert_page == PGV_INVALID_BLOCK && ndeletable > 0)
+					insert_page = search_page;
+				search_page = page_opaque(page)->nextblkno;
+				if (ndeletable > 0)
+					page_multi_delete(page, deletable, ndeletable);
+			}
+			/* IvfflatUpdateList(index, listInfo, insertPage, Invalid, Invalid) (:132-137) */
+			if (insert_page != PGV_INVALID_BLOCK)
+				memcpy(list + 4, &insert_page, 4);
+		}
+		blkno = page_opaque(cpage)->nextblkno;
+	}
+	if (removed > 0)
+		rel->generation++;
+	if (tuples_removed)
+		*tuples_removed = removed;
+	if (num_index_tuples)
+		*num_index_tuples = remaining;
 	return PGV_OK;
 }
 

@@ -74,6 +74,7 @@ typedef struct pgv_rel
 	uint8_t    *pages;
 	uint32_t	nblocks;
 	uint32_t	cap;
+	uint64_t	generation;		/* bumped by every page change: stands in for relcache invalidation */
 }			pgv_rel;
 
 #define PGV_BLCKSZ 8192
@@ -98,6 +99,17 @@ int			pgv_host_ivf_write_index(pgv_rel * rel, pgv_dtype dtype, int dim, int list
 int			pgv_host_ivf_insert(pgv_rel * rel, pgv_dtype dtype, int list, const void *vector, uint64_t tid);
 
 /*
+ * ivfflatbulkdelete (src/ivfvacuum.c:18-143): walk every list's entry pages, drop the index
+ * tuples whose heap TID the callback reports dead (PageIndexMultiDelete: the survivors keep
+ * their order and are renumbered), and point the list's insertPage at the first page that lost
+ * tuples so that later inserts refill it (IvfflatUpdateList with no original insert page,
+ * src/ivfutils.c:252-261).
+ */
+typedef int (*pgv_host_dead_fn) (uint64_t tid, void *state);
+int			pgv_host_ivf_bulkdelete(pgv_rel * rel, pgv_host_dead_fn dead, void *state,
+									int64_t *tuples_removed, int64_t *num_index_tuples);
+
+/*
  * Staging: walk the page chains exactly as GetScanLists / GetScanItems do
  * (src/ivfscan.c:58-111, :139-179), strip IndexTuple and varlena headers (both the
  * 4-byte and the 1-byte short form index_form_tuple produces for dim <= 29) and
@@ -119,6 +131,20 @@ typedef struct pgv_ivf_image
 
 int			pgv_host_ivf_stage(const pgv_rel * rel, pgv_dtype dtype, pgv_ivf_image * out);
 void		pgv_host_ivf_image_free(pgv_ivf_image * img);
+
+/*
+ * Device mirror lifecycle: the staged image and its pgv_index, rebuilt
+ * whenever the relation's pages changed since the last staging (insert, vacuum, rebuild) --
+ * the role a relcache invalidation callback plays inside a server.  pgv_host_ivf_mirror_get
+ * returns the current index and image; both stay valid until the next _get or _close.
+ */
+typedef struct pgv_ivf_mirror pgv_ivf_mirror;
+
+int			pgv_host_ivf_mirror_open(pgv_ctx * ctx, pgv_metric metric, pgv_dtype dtype, pgv_ivf_mirror * *out);
+int			pgv_host_ivf_mirror_get(pgv_ivf_mirror * mirror, const pgv_rel * rel,
+									pgv_index * *out_index, const pgv_ivf_image * *out_image);
+int64_t		pgv_host_ivf_mirror_restages(const pgv_ivf_mirror * mirror);	/* how many times it (re)staged */
+void		pgv_host_ivf_mirror_close(pgv_ivf_mirror * mirror);
 
 /*
  * ivfflatbeginscan / ivfflatgettuple / ivfflatendscan (src/ivfscan.c:252-431) on a

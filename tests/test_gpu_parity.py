@@ -1,7 +1,9 @@
 """GPU parity: libpgv_hip (through its C ABI) against the CPU oracle on the same
 seeded inputs.  Integer/index results exact, distances within 1e-5 relative
 (north_star), row ids identical wherever the reference's order is determined."""
+import ctypes as C
 import math
+import os
 
 import numpy as np
 import pytest
@@ -558,3 +560,63 @@ def test_argument_errors(ctx):
         ix.rank_lists(np.zeros((1, 4), np.float32), 4)  # maxprobes > lists must be clamped by the caller
     with pytest.raises(pgvector_amd.PgvError):
         api.IvfIndex(ctx, api.PGV_L2SQ, api.PGV_F32, 4, centers, np.array([0, 2, 1, 3]), centers)
+
+
+def test_c_driver(tmp_path):
+    """the boundary from C, without Python or torch in the process: tests/c/abi_driver.c is compiled
+    with gcc against include/pgv_hip.h + the host glue and run as its own program (build, stage, scan
+    through amgettuple, batched search, exact scan, on-device HNSW search, all checked against
+    brute force inside the driver)"""
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    libdir = os.path.join(root, "pgvector_amd", "lib")
+    exe = str(tmp_path / "abi_driver")
+    subprocess.run(["gcc", "-O1", "-Wall", "-I", os.path.join(root, "include"), "-I",
+                    os.path.join(root, "pgvector_amd", "host"), os.path.join(root, "tests", "c", "abi_driver.c"),
+                    "-o", exe, "-L", libdir, "-lpgv_host", "-lpgv_hip", "-lm", "-Wl,-rpath," + libdir], check=True)
+    r = subprocess.run([exe], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and "C-DRIVER OK" in r.stdout, (r.returncode, r.stdout[-500:], r.stderr[-2000:])
+
+
+def test_mirror_follows_inserts_and_vacuum(ctx, oracle):
+    """the device mirror is restaged when (and only when) the index pages changed: scans see an
+    inserted row at once and stop returning vacuumed rows (src/ivfinsert.c:72-181,
+    src/ivfvacuum.c:18-143)"""
+    from pgvector_amd import _host
+    dim, n, lists = 64, 2000, 8
+    data = gen(n, dim, seed=301, dist="clustered", clusters=8)
+    tids = ((np.arange(n, dtype=np.uint64) + 1) << np.uint64(16)) | np.uint64(1)
+    rel = _host.Relation()
+    rel.build(ctx, api.PGV_OPS_L2, api.PGV_F32, lists, data, tids, data)
+    mirror = _host.Mirror(ctx, api.PGV_L2SQ, api.PGV_F32)
+
+    def top(query, k=5):
+        ix, img = mirror.get(rel)
+        scan = _host.IvfScan(ix, img, lists)
+        scan.rescan(query)
+        t, d = scan.fetch(k)
+        scan.close()
+        return t, d
+
+    q = data[17] + 0.001
+    t0, d0 = top(q)
+    assert int(t0[0]) == int(tids[17]) and mirror.restages == 1
+    top(q)
+    assert mirror.restages == 1  # unchanged pages: the mirror is reused
+    # INSERT: a row right at the query goes into the nearest list and must come back first
+    centers = mirror.get(rel)[1].img
+    cen = np.ctypeslib.as_array(C.cast(centers.centers, C.POINTER(C.c_float)), shape=(lists, dim))
+    lst = int(np.argmin(((cen - q) ** 2).sum(1)))
+    new_tid = (np.uint64(999999) << np.uint64(16)) | np.uint64(7)
+    rel.insert(api.PGV_F32, lst, q, int(new_tid))
+    t1, d1 = top(q)
+    assert int(t1[0]) == int(new_tid) and d1[0] == 0.0 and mirror.restages == 2
+    assert int(t1[1]) == int(tids[17])
+    # VACUUM: both go away
+    removed, remaining = rel.bulkdelete([int(new_tid), int(tids[17])])
+    assert (removed, remaining) == (2, n - 1)
+    t2, d2 = top(q)
+    assert mirror.restages == 3
+    assert int(new_tid) not in set(map(int, t2)) and int(tids[17]) not in set(map(int, t2))
+    np.testing.assert_array_equal(t2[:3], t0[1:4])
+    mirror.close()

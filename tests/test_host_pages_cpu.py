@@ -87,3 +87,41 @@ def test_host_float_to_half_matches_the_oracle(oracle):
     for f in vals:
         f = float(np.float32(f))
         assert _host.lib.pgv_host_float_to_half(f) == oracle.lib.ora_float_to_half(f), f
+
+
+@pytest.mark.parametrize("dtype,dim", [(0, 3), (0, 128), (0, 768), (1, 1024)])
+def test_bulkdelete_removes_dead_tuples_and_reuses_the_page(dtype, dim):
+    """ivfflatbulkdelete (src/ivfvacuum.c:18-143): dead heap TIDs vanish, the survivors keep their
+    order, the counters are the reference's (tuples_removed / num_index_tuples), the list's insert
+    page moves to the first page that lost tuples and the next insert lands there"""
+    n, lists = 90, 4
+    np_t = np.float32 if dtype == 0 else np.float16
+    centers = gen(lists, dim, seed=1).astype(np_t)
+    vectors = gen(n, dim, seed=2).astype(np_t)
+    off = _layout(n, lists, 5)
+    tids = ((np.arange(n, dtype=np.uint64) + 1) << np.uint64(16)) | np.uint64(1)
+    rel = _host.Relation()
+    rel.write_index(dtype, centers, off, vectors, tids)
+    gen0 = rel.generation
+    blocks0 = rel.nblocks
+    dead = tids[::3]
+    removed, remaining = rel.bulkdelete(dead)
+    assert (removed, remaining) == (len(dead), n - len(dead))
+    assert rel.generation > gen0 and rel.nblocks == blocks0  # pages are emptied, not unlinked
+    img = rel.stage(dtype)
+    keep = np.ones(n, bool)
+    keep[::3] = False
+    np.testing.assert_array_equal(img.tids, tids[keep])
+    np.testing.assert_array_equal(img.vectors.view(np.uint8), vectors[keep].view(np.uint8))
+    want_off = np.concatenate([[0], np.cumsum([keep[off[i]:off[i + 1]].sum() for i in range(lists)])])
+    np.testing.assert_array_equal(img.list_offsets, want_off)
+    # nothing dead: no change, no invalidation
+    g1 = rel.generation
+    assert rel.bulkdelete([]) == (0, n - len(dead)) and rel.generation == g1
+    # the freed space is reused: inserting into a list that lost tuples does not extend the relation
+    lst = int(np.argmax(np.diff(off)))
+    new_tid = np.uint64(0xABCDEF0001)
+    rel.insert(dtype, lst, vectors[0], int(new_tid))
+    assert rel.nblocks == blocks0
+    img2 = rel.stage(dtype)
+    assert img2.nrows == n - len(dead) + 1 and int(new_tid) in set(int(t) for t in img2.tids[img2.list_offsets[lst]:img2.list_offsets[lst + 1]])
