@@ -47,7 +47,7 @@ WORKLOADS = {
     "smallh": (100_000, 512, 100, 10, "f16", "ip"),
 }
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy)
-SCAN_KERNEL_TAG = "tile_v2"  # which kernel build the PMC traffic entries in profiles/traffic.json belong to
+SCAN_KERNEL_TAG = "tile_v3"  # which kernel build the PMC traffic entries in profiles/traffic.json belong to
 
 
 def pmc_traffic(workload, batch):

@@ -62,8 +62,12 @@ def main():
     # neither the short center-ranking ones nor the single exact-scan
     steps = bench["steps"]
     # the list-scan kernel = the *scan_kernel instantiation with the most total time
-    scan_names = [n for n in by if "scan_kernel" in n]
-    main = max(scan_names, key=lambda n: sum(by[n]))
+    # (judged over the tail of the trace: the k-means++ rounds of the build use scan_kernel too)
+    tail = [(name, dur) for name, dur, lds, vgpr, grid, wg in trace if "scan_kernel" in name][-2 * steps:]
+    tail_time = defaultdict(int)
+    for name, dur in tail:
+        tail_time[name] += dur
+    main = max(tail_time, key=lambda n: tail_time[n])
     scans = [(dur, lds, vgpr, grid) for name, dur, lds, vgpr, grid, wg in trace if name == main]
     timed = scans[-2 * steps:]  # alternating rank / scan launches of the timed loop
     list_scan = [s for s in timed if s[0] > 5 * min(t[0] for t in timed)]
