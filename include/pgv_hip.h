@@ -334,6 +334,38 @@ int			pgv_hnsw_set_graph(pgv_hnsw * h, int m, int32_t entry, const int32_t *leve
 int			pgv_hnsw_search(pgv_hnsw * h, const void *queries, int nq, int ef_search, int k,
 							int64_t *out_elem, float *out_dist, int64_t *out_scored);
 
+/* ------------------------------------------------------ HNSW build side */
+
+/*
+ * HnswFindElementNeighbors' searches (src/hnswutils.c:1280-1357) for a batch of elements being
+ * inserted: from the current entry point, greedy descent (ef = 1) through the layers above each
+ * element's insert level, then HnswSearchLayer with ef_construction on every layer from
+ * min(insert level, entry level) down to 0.  The elements are slots of the mirror (their vectors
+ * are the queries); none of them is linked into the graph yet, so none can be found.  Returns each
+ * searched layer's W -- the candidate list SelectNeighbors works on -- nearest first.
+ *   elements [nq], insert_levels [nq]
+ *   out_ids / out_dist [nq x layer_cap x ef_construction], out_count [nq x layer_cap] (0 = layer not searched)
+ */
+int			pgv_hnsw_build_search(pgv_hnsw * h, const int32_t *elements, const int32_t *insert_levels, int nq,
+								  int ef_construction, int layer_cap,
+								  int32_t *out_ids, float *out_dist, int32_t *out_count);
+
+/*
+ * Distances between pairs of elements of the mirror, out[i] = d(a[i], b[i]): CheckElementCloser's
+ * HnswGetDistance between a candidate and an already selected neighbor (src/hnswutils.c:1040-1059),
+ * batched over every pair a batch of inserts can need.
+ */
+int			pgv_hnsw_score_pairs(pgv_hnsw * h, const int32_t *a, const int32_t *b, int64_t npairs, float *out);
+
+/*
+ * The graph after a batch of inserts: new entry point and the rewritten neighbor tuples
+ * (HnswUpdateNeighborsInMemory / AddConnections, src/hnswbuild.c:376-431).  Element elements[i]'s
+ * whole tuple is tuples[tuple_offsets[i] .. tuple_offsets[i + 1]) in the layout of pgv_hnsw_set_graph;
+ * tuple_offsets is host memory.  Ordered with later searches on the context's stream.
+ */
+int			pgv_hnsw_update_graph(pgv_hnsw * h, int32_t entry, const int32_t *elements, int nupd,
+								  const int64_t *tuple_offsets, const int32_t *tuples);
+
 #ifdef __cplusplus
 }
 #endif

@@ -16,6 +16,12 @@ class HnswGraphStruct(C.Structure):
                 ("levels", C.c_void_p), ("nbr_start", C.c_void_p), ("nbr", C.c_void_p)]
 
 
+class HnswBuilt(C.Structure):
+    _fields_ = [("n", C.c_int64), ("m", C.c_int), ("entry", C.c_int32), ("levels", C.c_void_p),
+                ("nbr_start", C.c_void_p), ("nbr", C.c_void_p), ("dup_of", C.c_void_p),
+                ("nelements", C.c_int64), ("device_pairs", C.c_int64), ("batches", C.c_int64)]
+
+
 class Rel(C.Structure):
     _fields_ = [("pages", C.c_void_p), ("nblocks", C.c_uint32), ("cap", C.c_uint32), ("generation", C.c_uint64)]
 
@@ -37,6 +43,9 @@ def _load():
     lib.pgv_host_hnsw_search.argtypes = [C.c_void_p, C.POINTER(HnswGraphStruct), C.c_int, C.c_int, C.c_void_p,
                                          C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
     P, I, I64 = C.c_void_p, C.c_int, C.c_int64
+    lib.pgv_host_hnsw_build.argtypes = [P, I, I, P, I64, I, I, P, I, C.POINTER(HnswBuilt)]
+    lib.pgv_host_hnsw_built_free.argtypes = [C.POINTER(HnswBuilt)]
+    lib.pgv_host_hnsw_built_free.restype = None
     lib.pgv_rel_init.argtypes = [C.POINTER(Rel)]
     lib.pgv_rel_init.restype = None
     lib.pgv_rel_free.argtypes = [C.POINTER(Rel)]
@@ -99,6 +108,26 @@ def hnsw_search(mirror, graph, queries, ef_search, k):
 
 
 _NP = {0: np.float32, 1: np.float16}
+
+
+def hnsw_build(mirror, rows, m, ef_construction, rng=None, max_batch=256):
+    """pgv_host_hnsw_build: mirror = api.Hnsw holding exactly `rows`; returns a dict with levels,
+    nbr_start, nbr, entry, dup_of (numpy copies) and the counters"""
+    rows = np.ascontiguousarray(rows, dtype=_NP[mirror.dtype])
+    b = HnswBuilt()
+    host_check(lib.pgv_host_hnsw_build(mirror.h, mirror.dtype, rows.shape[1], C.c_void_p(rows.ctypes.data),
+                                       rows.shape[0], m, ef_construction,
+                                       C.byref(rng) if rng is not None else None, max_batch, C.byref(b)))
+    n = b.n
+
+    def copy(ptr, ctype, count):
+        return np.ctypeslib.as_array(C.cast(ptr, C.POINTER(ctype)), shape=(max(count, 1),))[:count].copy()
+    nbr_start = copy(b.nbr_start, C.c_int64, n + 1)
+    out = {"levels": copy(b.levels, C.c_int32, n), "nbr_start": nbr_start,
+           "nbr": copy(b.nbr, C.c_int32, int(nbr_start[-1]) if n else 0), "dup_of": copy(b.dup_of, C.c_int32, n),
+           "entry": b.entry, "m": b.m, "nelements": b.nelements, "device_pairs": b.device_pairs, "batches": b.batches}
+    lib.pgv_host_hnsw_built_free(C.byref(b))
+    return out
 
 
 class Relation:

@@ -37,6 +37,7 @@ SYMBOLS = [
     "pgv_index_rows", "pgv_index_lists", "pgv_rank_lists", "pgv_scan_lists", "pgv_search_batch", "pgv_scan_batch",
     "pgv_assign", "pgv_kmeans", "pgv_lloyd_partial", "pgv_lloyd_finish", "pgv_kmeanspp_init",
     "pgv_distance_batch", "pgv_hnsw_upload", "pgv_hnsw_free", "pgv_hnsw_score", "pgv_hnsw_set_graph", "pgv_hnsw_search",
+    "pgv_hnsw_build_search", "pgv_hnsw_score_pairs", "pgv_hnsw_update_graph",
 ]
 
 
@@ -106,6 +107,9 @@ def _load():
     lib.pgv_hnsw_score.argtypes = [P, P, I, P, P, I64, P]
     lib.pgv_hnsw_set_graph.argtypes = [P, I, C.c_int32, P, P, P]
     lib.pgv_hnsw_search.argtypes = [P, P, I, I, I, P, P, P]
+    lib.pgv_hnsw_build_search.argtypes = [P, P, P, I, I, I, P, P, P]
+    lib.pgv_hnsw_score_pairs.argtypes = [P, P, P, I64, P]
+    lib.pgv_hnsw_update_graph.argtypes = [P, C.c_int32, P, I, P, P]
     return lib
 
 

@@ -50,11 +50,31 @@ struct HnswDev {
     int64_t n;
 };
 
+// One launch's queries and outputs.  A scan passes query vectors and wants the k nearest of
+// layer 0.  The build (HnswFindElementNeighbors, src/hnswutils.c:1280-1357) passes element slots
+// as queries plus each element's insert level: layers above it are descended greedily (ef = 1),
+// layers at or below it are searched with ef_construction and their whole W is returned.
+struct HnswRun {
+    const char *queries;      // [nq x nvec] 16-byte vectors, or NULL with qids
+    const int32_t *qids;      // query i = element qids[i] of the mirror (build), or NULL
+    const int32_t *qlevels;   // insert level per query (build), or NULL = 0
+    int nq, ef, k;
+    int64_t *out_elem;        // [nq x k] or NULL
+    float *out_dist;          // [nq x k] or NULL
+    int64_t *out_scored;      // [nq] or NULL
+    int32_t *lw_ids;          // [nq x lcap x ef] W of every searched layer <= the insert level, nearest first; or NULL
+    float *lw_dist;           // [nq x lcap x ef]
+    int32_t *lw_cnt;          // [nq x lcap] |W| (0 for layers not searched)
+    int lcap;
+};
+
 template <typename T, int METRIC>
 __global__ __launch_bounds__(kHnswThreads) void hnsw_search_kernel(
-    HnswDev g, const char *__restrict__ queries, int nq, int ef, int k, uint32_t *__restrict__ bitmaps,
-    int words, int *__restrict__ qcounter, int64_t *__restrict__ out_elem, float *__restrict__ out_dist,
-    int64_t *__restrict__ out_scored) {
+    HnswDev g, HnswRun run, uint32_t *__restrict__ bitmaps, int words, int *__restrict__ qcounter) {
+    const int nq = run.nq, ef = run.ef, k = run.k;
+    int64_t *__restrict__ out_elem = run.out_elem;
+    float *__restrict__ out_dist = run.out_dist;
+    int64_t *__restrict__ out_scored = run.out_scored;
     constexpr int N = VecTraits<T>::N;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int lm0 = 2 * g.m;
@@ -110,18 +130,25 @@ __global__ __launch_bounds__(kHnswThreads) void hnsw_search_kernel(
         if (qi >= nq) return;
 
         int64_t scored = 0;
+        const int qlevel = run.qlevels ? run.qlevels[qi] : 0;
+        if (run.lw_cnt)
+            for (int l = tid; l < run.lcap; l += kHnswThreads) run.lw_cnt[(size_t)qi * run.lcap + l] = 0;
         if (g.entry < 0) {  // empty index
-            for (int j = tid; j < k; j += kHnswThreads) {
-                out_elem[(size_t)qi * k + j] = -1;
-                out_dist[(size_t)qi * k + j] = __uint_as_float(0x7f800000u);
-            }
+            if (out_elem)
+                for (int j = tid; j < k; j += kHnswThreads) {
+                    out_elem[(size_t)qi * k + j] = -1;
+                    out_dist[(size_t)qi * k + j] = __uint_as_float(0x7f800000u);
+                }
             if (tid == 0 && out_scored) out_scored[qi] = 0;
             __syncthreads();
             continue;
         }
 
         // query into LDS; the entry point is the first batch
-        for (int v = tid; v < g.nvec; v += kHnswThreads) lq[v] = load16(queries + (size_t)qi * row_bytes + (size_t)v * sizeof(Raw16));
+        {
+            const char *qrow = run.qids ? g.rows + (size_t)run.qids[qi] * row_bytes : run.queries + (size_t)qi * row_bytes;
+            for (int v = tid; v < g.nvec; v += kHnswThreads) lq[v] = load16(qrow + (size_t)v * sizeof(Raw16));
+        }
         if (tid == 0) bi[0] = g.entry;
         __syncthreads();
         score_batch(1);
@@ -135,7 +162,7 @@ __global__ __launch_bounds__(kHnswThreads) void hnsw_search_kernel(
         const int top = g.levels[g.entry];
 
         for (int lc = top; lc >= 0; lc--) {
-            const int ef_l = lc == 0 ? ef : 1;
+            const int ef_l = lc <= qlevel ? ef : 1;
             const int lm = lc == 0 ? lm0 : g.m;
             // a fresh visited set holding the entry points (src/hnswutils.c:866-885); the entry
             // points are the previous layer's W, all unexpanded again
@@ -328,32 +355,55 @@ __global__ __launch_bounds__(kHnswThreads) void hnsw_search_kernel(
                 __syncthreads();
             }
             __syncthreads();
+            if (run.lw_ids && lc <= qlevel && lc < run.lcap) {  // this layer's W: the candidates SelectNeighbors sees
+                const int cur = sc[4], wn = sc[1];
+                const size_t o = ((size_t)qi * run.lcap + lc) * ef;
+                for (int j = tid; j < wn; j += kHnswThreads) {
+                    run.lw_ids[o + j] = (int32_t)(wi[cur * ef + j] & ~kExpanded);
+                    run.lw_dist[o + j] = key_to_float(wk[cur * ef + j]);
+                }
+                if (tid == 0) run.lw_cnt[(size_t)qi * run.lcap + lc] = wn;
+            }
         }
 
         // nearest first (src/hnswscan.c:293-311)
-        {
+        if (out_elem) {
             const int cur = sc[4], wn = sc[1];
             for (int j = tid; j < k; j += kHnswThreads) {
                 const bool have = j < wn;
                 out_elem[(size_t)qi * k + j] = have ? (int64_t)(wi[cur * ef + j] & ~kExpanded) : -1;
                 out_dist[(size_t)qi * k + j] = have ? key_to_float(wk[cur * ef + j]) : __uint_as_float(0x7f800000u);
             }
-            if (tid == 0 && out_scored) out_scored[qi] = scored;
         }
+        if (tid == 0 && out_scored) out_scored[qi] = scored;
         __syncthreads();
     }
 }
 
+// neighbour tuples of a few elements rewritten in place (the build's graph grows batch by batch);
+// a tuple the caller sized wrongly or an element out of range is skipped
+__global__ __launch_bounds__(256) void hnsw_patch_kernel(int32_t *__restrict__ nbr, const int64_t *__restrict__ nbr_start,
+                                                          int64_t n, const int32_t *__restrict__ ids,
+                                                          const int64_t *__restrict__ packed_off,
+                                                          const int32_t *__restrict__ packed, int nupd) {
+    const int wave = (blockIdx.x * 256 + threadIdx.x) >> 6, lane = threadIdx.x & 63;
+    if (wave >= nupd) return;
+    const int32_t e = ids[wave];
+    if (e < 0 || e >= n) return;
+    const int64_t dst = nbr_start[e], len = nbr_start[e + 1] - dst, src = packed_off[wave];
+    if (packed_off[wave + 1] - src != len) return;
+    for (int64_t j = lane; j < len; j += 64) nbr[dst + j] = packed[src + j];
+}
+
 template <typename T, int METRIC>
-int launch_hnsw_t(pgv_ctx *ctx, const HnswDev &g, const void *queries, int nq, int ef, int k,
-                  uint32_t *bitmaps, int words, int grid, int *counter, int64_t *out_elem, float *out_dist,
-                  int64_t *out_scored) {
-    const size_t lds = (size_t)g.nvec * sizeof(Raw16) + (size_t)ef * 16 + (size_t)g.m * 16 + kTieCap * 4 + 64;
-    if (lds > 150 * 1024) PGV_FAIL(PGV_ERR_ARG, "hnsw search: ef_search %d / m %d need %zu bytes of LDS", ef, g.m, lds);
+int launch_hnsw_t(pgv_ctx *ctx, const HnswDev &g, const HnswRun &run, uint32_t *bitmaps, int words, int grid,
+                  int *counter) {
+    const size_t lds = (size_t)g.nvec * sizeof(Raw16) + (size_t)run.ef * 16 + (size_t)g.m * 16 + kTieCap * 4 + 64;
+    if (lds > 150 * 1024)
+        PGV_FAIL(PGV_ERR_ARG, "hnsw search: ef %d / m %d need %zu bytes of LDS", run.ef, g.m, lds);
     auto kern = hnsw_search_kernel<T, METRIC>;
     PGV_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    hipLaunchKernelGGL(kern, dim3(grid), dim3(kHnswThreads), lds, ctx->stream, g, static_cast<const char *>(queries), nq,
-                       ef, k, bitmaps, words, counter, out_elem, out_dist, out_scored);
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(kHnswThreads), lds, ctx->stream, g, run, bitmaps, words, counter);
     PGV_HIP(hipGetLastError());
     return PGV_OK;
 }
@@ -372,8 +422,7 @@ int hnsw_search_grid(pgv_ctx *ctx, int nq, int64_t n, int *words_out) {
 
 int launch_hnsw_search(pgv_ctx *ctx, pgv_metric metric, pgv_dtype dtype, const RowGeom &geom, const void *rows,
                        int64_t n, const int32_t *levels, const int64_t *nbr_start, const int32_t *nbr, int m,
-                       int32_t entry, const void *queries, int nq, int ef, int k, uint32_t *bitmaps, int words,
-                       int grid, int *counter, int64_t *out_elem, float *out_dist, int64_t *out_scored) {
+                       int32_t entry, const HnswSearchArgs &a, uint32_t *bitmaps, int words, int grid, int *counter) {
     HnswDev g;
     g.rows = static_cast<const char *>(rows);
     g.nvec = geom.nvec;
@@ -385,18 +434,29 @@ int launch_hnsw_search(pgv_ctx *ctx, pgv_metric metric, pgv_dtype dtype, const R
     g.m = m;
     g.entry = entry;
     g.n = n;
+    HnswRun run;
+    run.queries = static_cast<const char *>(a.queries);
+    run.qids = a.qids;
+    run.qlevels = a.qlevels;
+    run.nq = a.nq;
+    run.ef = a.ef;
+    run.k = a.k;
+    run.out_elem = a.out_elem;
+    run.out_dist = a.out_dist;
+    run.out_scored = a.out_scored;
+    run.lw_ids = a.lw_ids;
+    run.lw_dist = a.lw_dist;
+    run.lw_cnt = a.lw_cnt;
+    run.lcap = a.lcap;
     PGV_HIP(hipMemsetAsync(counter, 0, sizeof(int), ctx->stream));
-#define PGV_HNSW_M(T)                                                                                         \
-    switch (metric) {                                                                                         \
-        case PGV_L2SQ:                                                                                        \
-            return launch_hnsw_t<T, 0>(ctx, g, queries, nq, ef, k, bitmaps, words, grid, counter, out_elem,  \
-                                       out_dist, out_scored);                                                 \
-        case PGV_NEG_IP:                                                                                      \
-            return launch_hnsw_t<T, 1>(ctx, g, queries, nq, ef, k, bitmaps, words, grid, counter, out_elem,  \
-                                       out_dist, out_scored);                                                 \
-        case PGV_L1:                                                                                          \
-            return launch_hnsw_t<T, 2>(ctx, g, queries, nq, ef, k, bitmaps, words, grid, counter, out_elem,  \
-                                       out_dist, out_scored);                                                 \
+#define PGV_HNSW_M(T)                                                                      \
+    switch (metric) {                                                                      \
+        case PGV_L2SQ:                                                                     \
+            return launch_hnsw_t<T, 0>(ctx, g, run, bitmaps, words, grid, counter);        \
+        case PGV_NEG_IP:                                                                   \
+            return launch_hnsw_t<T, 1>(ctx, g, run, bitmaps, words, grid, counter);        \
+        case PGV_L1:                                                                       \
+            return launch_hnsw_t<T, 2>(ctx, g, run, bitmaps, words, grid, counter);        \
     }
     if (dtype == PGV_F32) {
         PGV_HNSW_M(float)
@@ -405,6 +465,15 @@ int launch_hnsw_search(pgv_ctx *ctx, pgv_metric metric, pgv_dtype dtype, const R
     }
 #undef PGV_HNSW_M
     PGV_FAIL(PGV_ERR_ARG, "hnsw search: unknown metric %d", (int)metric);
+}
+
+int launch_hnsw_patch(pgv_ctx *ctx, int32_t *nbr, const int64_t *nbr_start, int64_t n, const int32_t *ids,
+                      const int64_t *packed_off, const int32_t *packed, int nupd) {
+    if (nupd <= 0) return PGV_OK;
+    hipLaunchKernelGGL(hnsw_patch_kernel, dim3((nupd + 3) / 4), dim3(256), 0, ctx->stream, nbr, nbr_start, n, ids,
+                       packed_off, packed, nupd);
+    PGV_HIP(hipGetLastError());
+    return PGV_OK;
 }
 
 }  // namespace pgv

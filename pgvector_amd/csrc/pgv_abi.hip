@@ -1321,7 +1321,7 @@ int pgv_hnsw_set_graph(pgv_hnsw *h, int m, int32_t entry, const int32_t *levels,
     PGV_HIP(hipStreamSynchronize(ctx->stream));
     h->levels = reinterpret_cast<const int32_t *>(base);
     h->nbr_start = reinterpret_cast<const int64_t *>(base + lb);
-    h->nbr = reinterpret_cast<const int32_t *>(base + lb + sb);
+    h->nbr = reinterpret_cast<int32_t *>(base + lb + sb);
     return PGV_OK;
 }
 
@@ -1347,15 +1347,110 @@ int pgv_hnsw_search(pgv_hnsw *h, const void *queries, int nq, int ef_search, int
     PGV_TRY(oe.init(out_elem, sizeof(int64_t) * (size_t)nq * k, ctx->out_stage2));
     PGV_TRY(od.init(out_dist, sizeof(float) * (size_t)nq * k, ctx->out_stage));
     PGV_TRY(os.init(out_scored, sizeof(int64_t) * (size_t)nq, ctx->sel_b));
+    HnswSearchArgs a;
+    a.queries = q_dev;
+    a.nq = nq;
+    a.ef = ef_search;
+    a.k = k;
+    a.out_elem = oe.as<int64_t>();
+    a.out_dist = od.as<float>();
+    a.out_scored = out_scored ? os.as<int64_t>() : nullptr;
     PGV_TRY(launch_hnsw_search(ctx, h->metric, h->dtype, h->geom, h->elements, h->n, h->levels, h->nbr_start,
-                               h->nbr, h->m, h->entry, q_dev, nq, ef_search, k, h->bitmaps.as<uint32_t>(), words,
-                               grid, ctx->counters.as<int>(), oe.as<int64_t>(), od.as<float>(),
-                               out_scored ? os.as<int64_t>() : nullptr));
+                               h->nbr, h->m, h->entry, a, h->bitmaps.as<uint32_t>(), words, grid,
+                               ctx->counters.as<int>()));
     bool need = false;
     PGV_TRY(oe.finish(ctx, &need));
     PGV_TRY(od.finish(ctx, &need));
     PGV_TRY(os.finish(ctx, &need));
     return sync_if(ctx, need);
+}
+
+int pgv_hnsw_build_search(pgv_hnsw *h, const int32_t *elements, const int32_t *insert_levels, int nq,
+                          int ef_construction, int layer_cap, int32_t *out_ids, float *out_dist, int32_t *out_count) {
+    if (!h || !out_ids || !out_dist || !out_count) PGV_FAIL(PGV_ERR_ARG, "pgv_hnsw_build_search: handle/out is NULL");
+    if (nq < 0 || layer_cap < 1) PGV_FAIL(PGV_ERR_ARG, "bad sizes");
+    if (ef_construction < 4 || ef_construction > 1000)
+        PGV_FAIL(PGV_ERR_ARG, "ef_construction must be 4..1000 (src/hnsw.h:58-59), got %d", ef_construction);
+    if (h->m == 0) PGV_FAIL(PGV_ERR_ARG, "pgv_hnsw_build_search needs pgv_hnsw_set_graph first");
+    if (nq == 0) return PGV_OK;
+    if (!elements || !insert_levels) PGV_FAIL(PGV_ERR_ARG, "elements/insert_levels is NULL");
+    pgv_ctx *ctx = h->ctx;
+    PGV_HIP(hipSetDevice(ctx->device));
+    const void *e_dev, *l_dev;
+    PGV_TRY(stage_flat(ctx, elements, sizeof(int32_t) * (size_t)nq, ctx->idx_stage, &e_dev));
+    PGV_TRY(stage_flat(ctx, insert_levels, sizeof(int32_t) * (size_t)nq, ctx->plan_d, &l_dev));
+    int words = 0;
+    const int grid = hnsw_search_grid(ctx, nq, h->n, &words);
+    PGV_TRY(h->bitmaps.ensure((size_t)grid * words * sizeof(uint32_t)));
+    PGV_TRY(ctx->counters.ensure(256));
+    const size_t per = (size_t)nq * layer_cap;
+    OutArg oi, od, oc;
+    PGV_TRY(oi.init(out_ids, sizeof(int32_t) * per * ef_construction, ctx->out_stage2));
+    PGV_TRY(od.init(out_dist, sizeof(float) * per * ef_construction, ctx->out_stage));
+    PGV_TRY(oc.init(out_count, sizeof(int32_t) * per, ctx->sel_b));
+    HnswSearchArgs a;
+    a.qids = static_cast<const int32_t *>(e_dev);
+    a.qlevels = static_cast<const int32_t *>(l_dev);
+    a.nq = nq;
+    a.ef = ef_construction;
+    a.k = 0;
+    a.lw_ids = oi.as<int32_t>();
+    a.lw_dist = od.as<float>();
+    a.lw_cnt = oc.as<int32_t>();
+    a.lcap = layer_cap;
+    PGV_TRY(launch_hnsw_search(ctx, h->metric, h->dtype, h->geom, h->elements, h->n, h->levels, h->nbr_start,
+                               h->nbr, h->m, h->entry, a, h->bitmaps.as<uint32_t>(), words, grid,
+                               ctx->counters.as<int>()));
+    bool need = false;
+    PGV_TRY(oi.finish(ctx, &need));
+    PGV_TRY(od.finish(ctx, &need));
+    PGV_TRY(oc.finish(ctx, &need));
+    return sync_if(ctx, need);
+}
+
+int pgv_hnsw_score_pairs(pgv_hnsw *h, const int32_t *a, const int32_t *b, int64_t npairs, float *out) {
+    if (!h || !out) PGV_FAIL(PGV_ERR_ARG, "pgv_hnsw_score_pairs: handle/out is NULL");
+    if (npairs < 0) PGV_FAIL(PGV_ERR_ARG, "bad sizes");
+    if (npairs == 0) return PGV_OK;
+    if (!a || !b) PGV_FAIL(PGV_ERR_ARG, "a/b is NULL");
+    pgv_ctx *ctx = h->ctx;
+    PGV_HIP(hipSetDevice(ctx->device));
+    const void *a_dev, *b_dev;
+    PGV_TRY(stage_flat(ctx, a, sizeof(int32_t) * (size_t)npairs, ctx->idx_stage, &a_dev));
+    PGV_TRY(stage_flat(ctx, b, sizeof(int32_t) * (size_t)npairs, ctx->plan_d, &b_dev));
+    OutArg od;
+    PGV_TRY(od.init(out, sizeof(float) * (size_t)npairs, ctx->out_stage));
+    // the element mirror is its own query array: pair i = (row a[i], "query" b[i])
+    PGV_TRY(launch_score_gather(ctx, h->metric, h->dtype, h->geom, h->elements, h->elements,
+                                static_cast<const int32_t *>(a_dev), static_cast<const int32_t *>(b_dev), npairs,
+                                od.as<float>()));
+    bool need = false;
+    PGV_TRY(od.finish(ctx, &need));
+    return sync_if(ctx, need);
+}
+
+int pgv_hnsw_update_graph(pgv_hnsw *h, int32_t entry, const int32_t *elements, int nupd,
+                          const int64_t *tuple_offsets, const int32_t *tuples) {
+    if (!h) PGV_FAIL(PGV_ERR_ARG, "pgv_hnsw_update_graph: handle is NULL");
+    if (h->m == 0) PGV_FAIL(PGV_ERR_ARG, "pgv_hnsw_update_graph needs pgv_hnsw_set_graph first");
+    if (entry < -1 || entry >= h->n) PGV_FAIL(PGV_ERR_ARG, "entry point %d out of range", (int)entry);
+    if (nupd < 0 || (nupd > 0 && (!elements || !tuple_offsets || !tuples))) PGV_FAIL(PGV_ERR_ARG, "bad update");
+    pgv_ctx *ctx = h->ctx;
+    PGV_HIP(hipSetDevice(ctx->device));
+    h->entry = entry;
+    if (nupd == 0) return PGV_OK;
+    if (is_device_ptr(tuple_offsets)) PGV_FAIL(PGV_ERR_ARG, "tuple_offsets must be host memory");
+    const int64_t total = tuple_offsets[nupd];
+    for (int i = 0; i < nupd; i++)
+        if (tuple_offsets[i] < 0 || tuple_offsets[i + 1] < tuple_offsets[i])
+            PGV_FAIL(PGV_ERR_ARG, "tuple_offsets is not an offset array");
+    const void *id_dev, *tp_dev, *of_dev;
+    PGV_TRY(stage_flat(ctx, elements, sizeof(int32_t) * (size_t)nupd, ctx->idx_stage, &id_dev));
+    PGV_TRY(stage_flat(ctx, tuples, sizeof(int32_t) * (size_t)(total > 0 ? total : 1), ctx->plan_d, &tp_dev));
+    PGV_TRY(stage_flat(ctx, tuple_offsets, sizeof(int64_t) * (size_t)(nupd + 1), ctx->plan_c, &of_dev));
+    PGV_TRY(launch_hnsw_patch(ctx, h->nbr, h->nbr_start, h->n, static_cast<const int32_t *>(id_dev),
+                              static_cast<const int64_t *>(of_dev), static_cast<const int32_t *>(tp_dev), nupd));
+    return PGV_OK;  // later launches on the context's stream see the patched graph
 }
 
 }  // extern "C"

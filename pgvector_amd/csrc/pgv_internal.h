@@ -155,7 +155,7 @@ struct pgv_hnsw {
     void *graph = nullptr;
     const int32_t *levels = nullptr;
     const int64_t *nbr_start = nullptr;
-    const int32_t *nbr = nullptr;
+    int32_t *nbr = nullptr;
     int m = 0;
     int32_t entry = -1;
     pgv::DBuf bitmaps;  // visited sets of the search workgroups
@@ -177,10 +177,24 @@ int launch_score_gather(pgv_ctx *ctx, pgv_metric metric, pgv_dtype dtype, const 
 
 // kernels_hnsw.hip: the whole first batch of an HNSW scan, one workgroup per query
 int hnsw_search_grid(pgv_ctx *ctx, int nq, int64_t n, int *words_out);
+struct HnswSearchArgs {
+    const void *queries = nullptr;     // staged query rows, or
+    const int32_t *qids = nullptr;     // element slots used as queries (build)
+    const int32_t *qlevels = nullptr;  // insert level per query (build)
+    int nq = 0, ef = 0, k = 0;
+    int64_t *out_elem = nullptr;
+    float *out_dist = nullptr;
+    int64_t *out_scored = nullptr;
+    int32_t *lw_ids = nullptr;         // per-layer W (build)
+    float *lw_dist = nullptr;
+    int32_t *lw_cnt = nullptr;
+    int lcap = 0;
+};
 int launch_hnsw_search(pgv_ctx *ctx, pgv_metric metric, pgv_dtype dtype, const RowGeom &geom, const void *rows,
                        int64_t n, const int32_t *levels, const int64_t *nbr_start, const int32_t *nbr, int m,
-                       int32_t entry, const void *queries, int nq, int ef, int k, uint32_t *bitmaps, int words,
-                       int grid, int *counter, int64_t *out_elem, float *out_dist, int64_t *out_scored);
+                       int32_t entry, const HnswSearchArgs &a, uint32_t *bitmaps, int words, int grid, int *counter);
+int launch_hnsw_patch(pgv_ctx *ctx, int32_t *nbr, const int64_t *nbr_start, int64_t n, const int32_t *ids,
+                      const int64_t *packed_off, const int32_t *packed, int nupd);
 
 // kernels_tile.hip: row tiles in LDS (async DMA), queries in registers: 16 queries per pass
 bool tile_scan_supported(const RowGeom &g);

@@ -1,0 +1,797 @@
+/*
+ * hnsw_build.c -- the in-memory phase of CREATE INDEX ... USING hnsw
+ * (src/hnswbuild.c:436-476 InsertTupleInMemory, :376-431 UpdateGraphInMemory) with every
+ * distance computed on the GPU.
+ *
+ * The reference inserts one element at a time: HnswFindElementNeighbors
+ * (src/hnswutils.c:1280-1357) searches the graph from the entry point, SelectNeighbors
+ * (:1064-1165) thins each layer's candidate list with CheckElementCloser (:1040-1059), then
+ * HnswUpdateConnection (:1183-1231) links the element into its neighbors' lists, re-running the
+ * selection on a list that is already full.  Its parallel build runs that loop in several
+ * workers at once on shared memory.  Here a BATCH of elements is inserted "at once" the same
+ * way: all of them search the graph as it stood when the batch began (one pgv_hnsw_build_search
+ * launch: none of them is linked yet, so none can find another), every distance the selections
+ * can need is fetched in one pgv_hnsw_score_pairs launch per phase, and the graph updates are
+ * applied one element after the other in heap order -- a legal interleaving of the reference's
+ * concurrent workers.  With max_batch = 1 this IS the reference's serial loop.
+ *
+ * Which distances a selection needs depends on its outcome, but never the distances
+ * themselves: for a candidate list C the whole pairwise matrix over C is fetched and the
+ * reference's loop is replayed on the host from it (the closer-flag cache of :1098-1140 is an
+ * exact shortcut of recomputing the flags, so they are recomputed).
+ */
+#include "pgv_host.h"
+
+#include <math.h>
+#include <stdlib.h>
+#include <string.h>
+
+extern int	pgv_host_fail(int code, const char *fmt,...);
+
+#define HNSW_HEAPTIDS 10		/* src/hnsw.h:69 */
+
+typedef struct
+{
+	int32_t		element;
+	float		distance;
+	int32_t		local;			/* index into the current record's matrix (valid within a batch) */
+}			cand;
+
+typedef struct
+{
+	int			length;
+	cand	   *items;			/* capacity lm */
+}			nlist;
+
+typedef struct
+{
+	int32_t		level;
+	int32_t		heaptids;		/* heap TIDs attached (duplicates), src/hnsw.h:69 */
+	nlist	   *layers;			/* [level + 1], allocated when the element is linked */
+}			elem;
+
+/* a neighbor list touched by a batch, with everything its re-selections can look up */
+typedef struct
+{
+	int32_t		owner;
+	int32_t		lc;
+	int			nstart;			/* members when the batch began: locals 0 .. nstart - 1 */
+	int			nlocal;			/* + the batch elements that selected the owner */
+	int32_t    *ids;			/* [nlocal] element of each local */
+	int64_t		pair0;			/* first of its nlocal * (nlocal - 1) / 2 pairs in the request */
+	float	   *mat;			/* [nlocal x nlocal] */
+}			record;
+
+typedef struct
+{
+	/* xoroshiro128** like the library's own source (pgv_abi.hip Xoro) when no callbacks are given */
+	uint64_t	s0,
+				s1;
+	const pgv_rng *user;
+}			rng_state;
+
+static uint64_t
+rotl64(uint64_t x, int k)
+{
+	return (x << k) | (x >> (64 - k));
+}
+
+static uint64_t
+splitmix64(uint64_t *st)
+{
+	uint64_t	v = (*st += 0x9E3779B97f4A7C15ull);
+
+	v = (v ^ (v >> 30)) * 0xBF58476D1CE4E5B9ull;
+	v = (v ^ (v >> 27)) * 0x94D049BB133111EBull;
+	return v ^ (v >> 31);
+}
+
+static void
+rng_init(rng_state * r, const pgv_rng * user)
+{
+	uint64_t	seed = user ? user->seed : 0;
+
+	r->user = user;
+	r->s0 = splitmix64(&seed);
+	r->s1 = splitmix64(&seed);
+	if (!r->s0 && !r->s1)
+		r->s0 = 1;
+}
+
+static double
+rng_double(rng_state * r)
+{
+	uint64_t	a,
+				x,
+				out;
+
+	if (r->user && r->user->next_double)
+		return r->user->next_double(r->user->state);
+	a = r->s0;
+	x = r->s1 ^ a;
+	out = rotl64(a * 5, 7) * 9;
+	r->s0 = rotl64(a, 24) ^ x ^ (x << 16);
+	r->s1 = rotl64(x, 37);
+	return ldexp((double) (out >> 12), -52);
+}
+
+static inline int
+layer_m(int m, int lc)
+{
+	return lc == 0 ? 2 * m : m; /* HnswGetLayerM, src/hnsw.h:127 */
+}
+
+/* ------------------------------------------------------------ pair requests */
+
+typedef struct
+{
+	int32_t    *a,
+			   *b;
+	int64_t		n,
+				cap;
+}			pairbuf;
+
+static int
+pairs_reserve(pairbuf * p, int64_t more)
+{
+	if (p->n + more > p->cap)
+	{
+		int64_t		cap = p->cap ? p->cap : 4096;
+
+		while (cap < p->n + more)
+			cap *= 2;
+		p->a = realloc(p->a, sizeof(int32_t) * (size_t) cap);
+		p->b = realloc(p->b, sizeof(int32_t) * (size_t) cap);
+		if (!p->a || !p->b)
+			return 0;
+		p->cap = cap;
+	}
+	return 1;
+}
+
+/* all pairs i < j of ids[0 .. n): n (n - 1) / 2 entries in row-major triangle order */
+static int
+pairs_triangle(pairbuf * p, const int32_t *ids, int n)
+{
+	if (!pairs_reserve(p, (int64_t) n * (n - 1) / 2))
+		return 0;
+	for (int i = 0; i < n; i++)
+		for (int j = i + 1; j < n; j++)
+		{
+			p->a[p->n] = ids[i];
+			p->b[p->n] = ids[j];
+			p->n++;
+		}
+	return 1;
+}
+
+static void
+fill_matrix(float *mat, int n, const float *tri)
+{
+	int64_t		t = 0;
+
+	for (int i = 0; i < n; i++)
+	{
+		mat[(size_t) i * n + i] = 0.0f;
+		for (int j = i + 1; j < n; j++, t++)
+			mat[(size_t) i * n + j] = mat[(size_t) j * n + i] = tri[t];
+	}
+}
+
+/* ---------------------------------------------------------- SelectNeighbors */
+
+/* CompareCandidateDistances, src/hnswutils.c:992-1010: descending distance, then descending
+ * pointer; element slots grow with allocation order and stand in for pointers */
+static int
+cand_desc_cmp(const void *pa, const void *pb)
+{
+	const cand *a = *(cand * const *) pa,
+			   *b = *(cand * const *) pb;
+
+	if (a->distance < b->distance)
+		return 1;
+	if (a->distance > b->distance)
+		return -1;
+	if (a->element < b->element)
+		return 1;
+	if (a->element > b->element)
+		return -1;
+	return 0;
+}
+
+/*
+ * Algorithm 4 (src/hnswutils.c:1064-1165) on a candidate list whose pairwise distances are in
+ * mat[nloc x nloc] (indexed by cand.local).  c is ordered furthest first unless sort != 0.
+ * Returns |r|; *pruned = the candidate that would be dropped.
+ */
+static int
+select_neighbors(cand * *c, int nc, int lm, const float *mat, int nloc, cand * *r, cand * *pruned, int sort,
+				 cand * *w, cand * *wd)
+{
+	int			wn = nc,
+				rn = 0,
+				wdlen = 0,
+				wdoff = 0;
+
+	if (nc <= lm)
+	{
+		for (int i = 0; i < nc; i++)
+			r[i] = c[i];
+		return nc;
+	}
+	memcpy(w, c, sizeof(*w) * (size_t) nc);
+	if (sort)
+		qsort(w, (size_t) nc, sizeof(*w), cand_desc_cmp);
+	while (wn > 0 && rn < lm)
+	{
+		cand	   *e = w[--wn];	/* closest remaining */
+		int			closer = 1;
+
+		/* CheckElementCloser, :1040-1059 */
+		for (int i = 0; i < rn; i++)
+			if (mat[(size_t) e->local * nloc + r[i]->local] <= e->distance)
+			{
+				closer = 0;
+				break;
+			}
+		if (closer)
+			r[rn++] = e;
+		else
+			wd[wdlen++] = e;
+	}
+	/* keep pruned connections (:1148-1150) */
+	while (wdoff < wdlen && rn < lm)
+		r[rn++] = wd[wdoff++];
+	if (pruned)
+		*pruned = wdoff < wdlen ? wd[wdoff] : w[0];	/* :1153-1159 */
+	return rn;
+}
+
+/* ------------------------------------------------------------------- build */
+
+void
+pgv_host_hnsw_built_free(pgv_hnsw_built * b)
+{
+	if (!b)
+		return;
+	free(b->levels);
+	free(b->nbr_start);
+	free(b->nbr);
+	free(b->dup_of);
+	memset(b, 0, sizeof(*b));
+}
+
+/* rewrite element e's neighbor tuple (HnswNeighborTupleData: layer lc at (level - lc) * m) in the flat image */
+static void
+write_tuple(const elem * el, int32_t e, int m, const int64_t *nbr_start, int32_t *nbr)
+{
+	const elem *x = &el[e];
+	int64_t		base = nbr_start[e];
+
+	for (int64_t j = base; j < nbr_start[e + 1]; j++)
+		nbr[j] = -1;
+	if (!x->layers)
+		return;
+	for (int lc = 0; lc <= x->level; lc++)
+	{
+		const nlist *l = &x->layers[lc];
+		int64_t		o = base + (int64_t) (x->level - lc) * m;
+
+		for (int i = 0; i < l->length; i++)
+			nbr[o + i] = l->items[i].element;
+	}
+}
+
+int
+pgv_host_hnsw_build(pgv_hnsw * mirror, pgv_dtype dtype, int dim, const void *rows, int64_t n, int m,
+					int ef_construction, const pgv_rng * rng, int max_batch, pgv_hnsw_built * out)
+{
+	const size_t item_bytes = (size_t) dim * (dtype == PGV_F32 ? 4 : 2);
+	/* HnswGetMaxLevel, src/hnsw.h:133 with BLCKSZ 8192 */
+	const int	by_page = (int) ((8192 - 24 - 8 - 4 - 4) / 6 / m) - 2;
+	const int	max_level = by_page < 63 ? by_page : 63;
+	const double ml = 1.0 / log((double) m);	/* HnswGetMl */
+	rng_state	rs;
+	elem	   *el = NULL;
+	int32_t		entry = -1;
+	int64_t		linked = 0;
+	int			rc = PGV_OK;
+	pairbuf		pb = {0};
+	float	   *pdist = NULL;
+	int64_t		pdist_cap = 0;
+	int32_t    *sw_ids = NULL,
+			   *sw_cnt = NULL,
+			   *dirty = NULL,
+			   *packed = NULL;
+	float	   *sw_dist = NULL;
+	int64_t    *packed_off = NULL;
+	uint8_t    *is_dirty = NULL;
+	record	   *recs = NULL;
+	int			recs_cap = 0;
+	int64_t    *rec_of = NULL;	/* hash: (owner, lc) -> record index + 1 */
+	int64_t		hash_cap = 0;
+
+	if (!mirror || !out || (n > 0 && !rows))
+		return pgv_host_fail(PGV_ERR_ARG, "pgv_host_hnsw_build: mirror/rows/out is NULL");
+	if (m < 2 || m > 100 || ef_construction < 4 || ef_construction > 1000 || ef_construction < 2 * m)
+		return pgv_host_fail(PGV_ERR_ARG, "m must be 2..100, ef_construction 4..1000 and >= 2 * m (src/hnsw.c:114-125)");
+	if (n >= INT32_MAX)
+		return pgv_host_fail(PGV_ERR_ARG, "too many elements");
+	if (max_batch < 1)
+		max_batch = 1;
+	if (max_batch > 512)
+		max_batch = 512;
+	memset(out, 0, sizeof(*out));
+	out->n = n;
+	out->m = m;
+	out->entry = -1;
+	out->levels = malloc(sizeof(int32_t) * (size_t) (n > 0 ? n : 1));
+	out->nbr_start = malloc(sizeof(int64_t) * (size_t) (n + 1));
+	out->dup_of = malloc(sizeof(int32_t) * (size_t) (n > 0 ? n : 1));
+	el = calloc((size_t) (n > 0 ? n : 1), sizeof(elem));
+	if (!out->levels || !out->nbr_start || !out->dup_of || !el)
+	{
+		rc = pgv_host_fail(PGV_ERR_NOMEM, "out of memory");
+		goto done;
+	}
+
+	/* HnswInitElement, src/hnswutils.c:243-270: one draw per heap tuple, in heap order */
+	rng_init(&rs, rng);
+	out->nbr_start[0] = 0;
+	for (int64_t i = 0; i < n; i++)
+	{
+		int			level = (int) (-log(rng_double(&rs)) * ml);
+
+		if (level > max_level)
+			level = max_level;
+		el[i].level = level;
+		el[i].heaptids = 1;
+		out->levels[i] = level;
+		out->dup_of[i] = -1;
+		out->nbr_start[i + 1] = out->nbr_start[i] + (int64_t) (level + 2) * m;
+	}
+	out->nbr = malloc(sizeof(int32_t) * (size_t) (out->nbr_start[n] > 0 ? out->nbr_start[n] : 1));
+	if (!out->nbr)
+	{
+		rc = pgv_host_fail(PGV_ERR_NOMEM, "out of memory");
+		goto done;
+	}
+	for (int64_t j = 0; j < out->nbr_start[n]; j++)
+		out->nbr[j] = -1;
+	if (n == 0)
+		goto done;
+	rc = pgv_hnsw_set_graph(mirror, m, -1, out->levels, out->nbr_start, out->nbr);
+	if (rc != PGV_OK)
+	{
+		rc = pgv_host_fail(rc, "%s", pgv_last_error());
+		goto done;
+	}
+	is_dirty = calloc((size_t) n, 1);
+	hash_cap = 1 << 16;
+	rec_of = calloc((size_t) hash_cap, sizeof(int64_t));
+
+	for (int64_t i0 = 0; i0 < n;)
+	{
+		int			B;
+		int			lcap = 1;
+		int			entry_level;
+		int			nrec = 0;
+		int			ndirty = 0;
+		int64_t		ntuple = 0;
+
+		if (entry < 0)
+		{
+			/* the first element has nothing to search: it becomes the entry point */
+			el[i0].layers = calloc((size_t) el[i0].level + 1, sizeof(nlist));
+			for (int lc = 0; lc <= el[i0].level; lc++)
+				el[i0].layers[lc].items = malloc(sizeof(cand) * (size_t) layer_m(m, lc));
+			entry = (int32_t) i0;
+			linked = 1;
+			rc = pgv_hnsw_update_graph(mirror, entry, NULL, 0, NULL, NULL);
+			if (rc != PGV_OK)
+				goto dev_fail;
+			i0++;
+			out->batches++;
+			continue;
+		}
+		/* as many concurrent inserts as the graph can absorb without the newcomers missing each other much */
+		B = (int) (linked / 16);
+		if (B < 1)
+			B = 1;
+		if (B > max_batch)
+			B = max_batch;
+		if (B > n - i0)
+			B = (int) (n - i0);
+		entry_level = el[entry].level;
+		for (int b = 0; b < B; b++)
+		{
+			int			l = el[i0 + b].level < entry_level ? el[i0 + b].level : entry_level;
+
+			if (l + 1 > lcap)
+				lcap = l + 1;
+		}
+
+		/* ---- 1. the searches of HnswFindElementNeighbors for the whole batch */
+		{
+			size_t		per = (size_t) B * lcap;
+			int32_t    *ids = malloc(sizeof(int32_t) * (size_t) B);
+			int32_t    *lv = malloc(sizeof(int32_t) * (size_t) B);
+
+			sw_ids = realloc(sw_ids, sizeof(int32_t) * per * ef_construction);
+			sw_dist = realloc(sw_dist, sizeof(float) * per * ef_construction);
+			sw_cnt = realloc(sw_cnt, sizeof(int32_t) * per);
+			for (int b = 0; b < B; b++)
+			{
+				ids[b] = (int32_t) (i0 + b);
+				lv[b] = el[i0 + b].level;
+			}
+			rc = pgv_hnsw_build_search(mirror, ids, lv, B, ef_construction, lcap, sw_ids, sw_dist, sw_cnt);
+			free(ids);
+			free(lv);
+			if (rc != PGV_OK)
+				goto dev_fail;
+		}
+
+		/* ---- 2. pairwise distances inside every candidate list that has to be thinned */
+		pb.n = 0;
+		for (int b = 0; b < B; b++)
+			for (int lc = lcap - 1; lc >= 0; lc--)	/* the order step 3 consumes them in */
+			{
+				int			nw = sw_cnt[(size_t) b * lcap + lc];
+
+				if (nw > layer_m(m, lc))
+					if (!pairs_triangle(&pb, sw_ids + ((size_t) b * lcap + lc) * ef_construction, nw))
+					{
+						rc = pgv_host_fail(PGV_ERR_NOMEM, "out of memory");
+						goto done;
+					}
+			}
+		if (pb.n > pdist_cap)
+		{
+			pdist_cap = pb.n * 2;
+			pdist = realloc(pdist, sizeof(float) * (size_t) pdist_cap);
+		}
+		if (pb.n > 0)
+		{
+			rc = pgv_hnsw_score_pairs(mirror, pb.a, pb.b, pb.n, pdist);
+			if (rc != PGV_OK)
+				goto dev_fail;
+			out->device_pairs += pb.n;
+		}
+
+		/* ---- 3. SelectNeighbors + AddConnections per element and layer; duplicates */
+		{
+			int64_t		tri = 0;
+			float	   *mat = malloc(sizeof(float) * (size_t) ef_construction * ef_construction);
+			cand	   *lw = malloc(sizeof(cand) * (size_t) ef_construction);
+			cand	  **c = malloc(sizeof(cand *) * (size_t) ef_construction * 4);
+			cand	  **r = c + ef_construction,
+					  **w = c + 2 * ef_construction,
+					  **wd = c + 3 * ef_construction;
+
+			for (int b = 0; b < B; b++)
+			{
+				int32_t		e = (int32_t) (i0 + b);
+				elem	   *x = &el[e];
+
+				x->layers = calloc((size_t) x->level + 1, sizeof(nlist));
+				for (int lc = lcap - 1; lc >= 0; lc--)
+				{
+					int			nw = sw_cnt[(size_t) b * lcap + lc];
+					int			lm = layer_m(m, lc);
+					const int32_t *wi = sw_ids + ((size_t) b * lcap + lc) * ef_construction;
+					const float *wdist = sw_dist + ((size_t) b * lcap + lc) * ef_construction;
+					int			rn;
+
+					if (nw == 0 || lc > x->level)
+						continue;
+					/* the reference's list `w` is furthest first; the device returns nearest first */
+					for (int i = 0; i < nw; i++)
+					{
+						lw[i].element = wi[nw - 1 - i];
+						lw[i].distance = wdist[nw - 1 - i];
+						lw[i].local = nw - 1 - i;
+						c[i] = &lw[i];
+					}
+					if (nw > lm)
+					{
+						fill_matrix(mat, nw, pdist + tri);
+						tri += (int64_t) nw * (nw - 1) / 2;
+					}
+					rn = select_neighbors(c, nw, lm, mat, nw, r, NULL, 0, w, wd);
+					x->layers[lc].items = malloc(sizeof(cand) * (size_t) lm);
+					x->layers[lc].length = rn;
+					for (int i = 0; i < rn; i++)
+						x->layers[lc].items[i] = *r[i];
+				}
+				for (int lc = 0; lc <= x->level; lc++)
+					if (!x->layers[lc].items)
+						x->layers[lc].items = malloc(sizeof(cand) * (size_t) layer_m(m, lc));
+
+				/* FindDuplicateInMemory, src/hnswbuild.c:313-364: neighbors are ordered by distance */
+				{
+					const nlist *l0 = &x->layers[0];
+					const char *v = (const char *) rows + (size_t) e * item_bytes;
+
+					for (int i = 0; i < l0->length; i++)
+					{
+						int32_t		ne = l0->items[i].element;
+
+						if (memcmp(v, (const char *) rows + (size_t) ne * item_bytes, item_bytes) != 0)
+							break;
+						if (el[ne].heaptids < HNSW_HEAPTIDS)
+						{
+							el[ne].heaptids++;
+							out->dup_of[e] = ne;
+							break;
+						}
+					}
+					if (out->dup_of[e] >= 0)
+					{
+						for (int lc = 0; lc <= x->level; lc++)
+							free(x->layers[lc].items);
+						free(x->layers);
+						x->layers = NULL;
+					}
+				}
+			}
+			free(mat);
+			free(lw);
+			free(c);
+		}
+
+		/* ---- 4. the lists this batch links into, and every distance their re-selections can look up */
+		pb.n = 0;
+		for (int b = 0; b < B; b++)
+		{
+			int32_t		e = (int32_t) (i0 + b);
+			elem	   *x = &el[e];
+
+			if (!x->layers)
+				continue;
+			for (int lc = x->level; lc >= 0; lc--)
+				for (int i = 0; i < x->layers[lc].length; i++)
+				{
+					int32_t		owner = x->layers[lc].items[i].element;
+					uint64_t	key = ((uint64_t) owner << 6) | (uint64_t) lc;
+					int64_t		h = (int64_t) ((key * 0x9E3779B97F4A7C15ull) >> 40) & (hash_cap - 1);
+					record	   *rcd;
+
+					while (rec_of[h] != 0 && !(recs[rec_of[h] - 1].owner == owner && recs[rec_of[h] - 1].lc == lc))
+						h = (h + 1) & (hash_cap - 1);
+					if (rec_of[h] == 0)
+					{
+						const nlist *l = &el[owner].layers[lc];
+
+						if (nrec == recs_cap)
+						{
+							recs_cap = recs_cap ? recs_cap * 2 : 1024;
+							recs = realloc(recs, sizeof(record) * (size_t) recs_cap);
+						}
+						rcd = &recs[nrec];
+						rcd->owner = owner;
+						rcd->lc = lc;
+						rcd->nstart = l->length;
+						rcd->nlocal = l->length;
+						rcd->ids = malloc(sizeof(int32_t) * (size_t) (l->length + B));
+						rcd->mat = NULL;
+						for (int j = 0; j < l->length; j++)
+						{
+							rcd->ids[j] = l->items[j].element;
+							l->items[j].local = j;
+						}
+						rec_of[h] = ++nrec;
+						if ((int64_t) nrec * 2 > hash_cap)
+						{
+							rc = pgv_host_fail(PGV_ERR_STATE, "batch touches too many lists");
+							goto done;
+						}
+					}
+					rcd = &recs[rec_of[h] - 1];
+					rcd->ids[rcd->nlocal++] = e;
+				}
+		}
+		for (int k = 0; k < nrec; k++)
+		{
+			record	   *rcd = &recs[k];
+
+			rcd->pair0 = pb.n;
+			/* a list that cannot overflow in this batch never runs a selection */
+			if (rcd->nlocal > layer_m(m, rcd->lc))
+				if (!pairs_triangle(&pb, rcd->ids, rcd->nlocal))
+				{
+					rc = pgv_host_fail(PGV_ERR_NOMEM, "out of memory");
+					goto done;
+				}
+		}
+		if (pb.n > pdist_cap)
+		{
+			pdist_cap = pb.n * 2;
+			pdist = realloc(pdist, sizeof(float) * (size_t) pdist_cap);
+		}
+		if (pb.n > 0)
+		{
+			rc = pgv_hnsw_score_pairs(mirror, pb.a, pb.b, pb.n, pdist);
+			if (rc != PGV_OK)
+				goto dev_fail;
+			out->device_pairs += pb.n;
+		}
+		for (int k = 0; k < nrec; k++)
+		{
+			record	   *rcd = &recs[k];
+
+			if (rcd->nlocal > layer_m(m, rcd->lc))
+			{
+				rcd->mat = malloc(sizeof(float) * (size_t) rcd->nlocal * rcd->nlocal);
+				fill_matrix(rcd->mat, rcd->nlocal, pdist + rcd->pair0);
+			}
+		}
+
+		/* ---- 5. HnswUpdateNeighborsInMemory, one element after the other (src/hnswbuild.c:376-405) */
+		{
+			int			lm0 = layer_m(m, 0);
+			cand	  **c = malloc(sizeof(cand *) * (size_t) (lm0 + 1) * 4);
+			cand	  **r = c + (lm0 + 1),
+					  **w = c + 2 * (lm0 + 1),
+					  **wd = c + 3 * (lm0 + 1);
+			int		   *next_local = calloc((size_t) (nrec > 0 ? nrec : 1), sizeof(int));
+
+			for (int k = 0; k < nrec; k++)
+				next_local[k] = recs[k].nstart;
+			for (int b = 0; b < B; b++)
+			{
+				int32_t		e = (int32_t) (i0 + b);
+				elem	   *x = &el[e];
+
+				if (!x->layers)
+					continue;
+				linked++;
+				if (!is_dirty[e])
+				{
+					is_dirty[e] = 1;
+					ndirty++;
+				}
+				for (int lc = x->level; lc >= 0; lc--)
+				{
+					int			lm = layer_m(m, lc);
+
+					for (int i = 0; i < x->layers[lc].length; i++)
+					{
+						cand		hc = x->layers[lc].items[i];
+						int32_t		owner = hc.element;
+						uint64_t	key = ((uint64_t) owner << 6) | (uint64_t) lc;
+						int64_t		h = (int64_t) ((key * 0x9E3779B97F4A7C15ull) >> 40) & (hash_cap - 1);
+						record	   *rcd;
+						nlist	   *l = &el[owner].layers[lc];
+						cand		new_hc;
+
+						while (!(recs[rec_of[h] - 1].owner == owner && recs[rec_of[h] - 1].lc == lc))
+							h = (h + 1) & (hash_cap - 1);
+						rcd = &recs[rec_of[h] - 1];
+						new_hc.element = e;
+						new_hc.distance = hc.distance;
+						new_hc.local = next_local[rec_of[h] - 1]++;	/* the order step 4 appended them in */
+						if (!is_dirty[owner])
+						{
+							is_dirty[owner] = 1;
+							ndirty++;
+						}
+						/* HnswUpdateConnection, src/hnswutils.c:1183-1231 */
+						if (l->length < lm)
+						{
+							l->items[l->length++] = new_hc;
+							continue;
+						}
+						{
+							int			nc = l->length + 1;
+							cand	   *pruned = NULL;
+
+							for (int j = 0; j < l->length; j++)
+								c[j] = &l->items[j];
+							c[nc - 1] = &new_hc;
+							select_neighbors(c, nc, lm, rcd->mat, rcd->nlocal, r, &pruned, 1, w, wd);
+							if (pruned != NULL && pruned != &new_hc)
+								for (int j = 0; j < l->length; j++)
+									if (l->items[j].element == pruned->element)
+									{
+										l->items[j] = new_hc;
+										break;
+									}
+						}
+					}
+				}
+				/* the entry point moves up with the tallest element (src/hnswbuild.c:425-430) */
+				if (x->level > el[entry].level)
+					entry = e;
+			}
+			free(next_local);
+			free(c);
+		}
+
+		/* ---- 6. the graph the next batch searches */
+		{
+			int			k = 0;
+
+			dirty = realloc(dirty, sizeof(int32_t) * (size_t) (ndirty > 0 ? ndirty : 1));
+			packed_off = realloc(packed_off, sizeof(int64_t) * (size_t) (ndirty + 1));
+			/* dirty elements: the batch itself and the owners of the touched lists */
+			for (int b = 0; b < B; b++)
+				if (is_dirty[i0 + b])
+				{
+					dirty[k++] = (int32_t) (i0 + b);
+					is_dirty[i0 + b] = 0;
+				}
+			for (int q = 0; q < nrec; q++)
+				if (is_dirty[recs[q].owner])
+				{
+					dirty[k++] = recs[q].owner;
+					is_dirty[recs[q].owner] = 0;
+				}
+			ndirty = k;
+			ntuple = 0;
+			for (int q = 0; q < ndirty; q++)
+			{
+				packed_off[q] = ntuple;
+				ntuple += out->nbr_start[dirty[q] + 1] - out->nbr_start[dirty[q]];
+			}
+			packed_off[ndirty] = ntuple;
+			packed = realloc(packed, sizeof(int32_t) * (size_t) (ntuple > 0 ? ntuple : 1));
+			for (int q = 0; q < ndirty; q++)
+			{
+				write_tuple(el, dirty[q], m, out->nbr_start, out->nbr);
+				memcpy(packed + packed_off[q], out->nbr + out->nbr_start[dirty[q]],
+					   sizeof(int32_t) * (size_t) (packed_off[q + 1] - packed_off[q]));
+			}
+			rc = pgv_hnsw_update_graph(mirror, entry, dirty, ndirty, packed_off, packed);
+			if (rc != PGV_OK)
+				goto dev_fail;
+		}
+
+		/* forget the batch's records */
+		for (int k = 0; k < nrec; k++)
+		{
+			uint64_t	key = ((uint64_t) recs[k].owner << 6) | (uint64_t) recs[k].lc;
+			int64_t		h = (int64_t) ((key * 0x9E3779B97F4A7C15ull) >> 40) & (hash_cap - 1);
+
+			(void) h;
+			free(recs[k].ids);
+			free(recs[k].mat);
+		}
+		memset(rec_of, 0, sizeof(int64_t) * (size_t) hash_cap);
+		i0 += B;
+		out->batches++;
+	}
+	goto done;
+
+dev_fail:
+	rc = pgv_host_fail(rc, "%s", pgv_last_error());
+done:
+	out->entry = entry;
+	out->nelements = linked;
+	if (el)
+	{
+		for (int64_t i = 0; i < n; i++)
+			if (el[i].layers)
+			{
+				for (int lc = 0; lc <= el[i].level; lc++)
+					free(el[i].layers[lc].items);
+				free(el[i].layers);
+			}
+		free(el);
+	}
+	free(pb.a);
+	free(pb.b);
+	free(pdist);
+	free(sw_ids);
+	free(sw_dist);
+	free(sw_cnt);
+	free(dirty);
+	free(packed);
+	free(packed_off);
+	free(is_dirty);
+	free(recs);
+	free(rec_of);
+	if (rc != PGV_OK)
+		pgv_host_hnsw_built_free(out);
+	return rc;
+}

@@ -61,6 +61,37 @@ int			pgv_host_hnsw_search(pgv_hnsw * mirror, const pgv_hnsw_graph * graph, pgv_
 								 const void *queries, int nq, int ef_search, int k,
 								 int64_t *out_elem, float *out_dist, int64_t *out_scored);
 
+/*
+ * The in-memory phase of CREATE INDEX ... USING hnsw (src/hnswbuild.c:436-476, :376-431) with
+ * every distance on the GPU: elements are inserted in batches of up to max_batch (all of a batch
+ * search the graph as it stood when the batch began, like the reference's parallel workers racing
+ * each other; max_batch = 1 is the reference's serial loop), see hnsw_build.c.
+ *
+ *   mirror  pgv_hnsw_upload of ALL n element vectors (what HnswFormIndexValue produced: normalised
+ *           for cosine, zero-norm rows left out by the caller); the graph is (re)set by this call
+ *   rows    the same vectors in host memory (FindDuplicateInMemory compares bytes, :313-364)
+ *   rng     HnswInitElement's level draws (src/hnswutils.c:243-270), one per row in row order
+ * Result (malloc'ed; free with pgv_host_hnsw_built_free): levels, nbr_start, nbr in the layout of
+ * pgv_hnsw_set_graph, the entry point, dup_of[row] = element that took the row's heap TID or -1.
+ */
+typedef struct pgv_hnsw_built
+{
+	int64_t		n;
+	int			m;
+	int32_t		entry;
+	int32_t    *levels;			/* [n] */
+	int64_t    *nbr_start;		/* [n + 1] */
+	int32_t    *nbr;
+	int32_t    *dup_of;			/* [n] */
+	int64_t		nelements;		/* elements linked into the graph (n minus duplicates) */
+	int64_t		device_pairs;	/* element pairs scored for SelectNeighbors */
+	int64_t		batches;
+}			pgv_hnsw_built;
+
+int			pgv_host_hnsw_build(pgv_hnsw * mirror, pgv_dtype dtype, int dim, const void *rows, int64_t n, int m,
+								int ef_construction, const pgv_rng * rng, int max_batch, pgv_hnsw_built * out);
+void		pgv_host_hnsw_built_free(pgv_hnsw_built * built);
+
 /* ---------------------------------------------------------------- IVFFlat */
 
 /*

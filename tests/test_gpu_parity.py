@@ -620,3 +620,100 @@ def test_mirror_follows_inserts_and_vacuum(ctx, oracle):
     assert int(new_tid) not in set(map(int, t2)) and int(tids[17]) not in set(map(int, t2))
     np.testing.assert_array_equal(t2[:3], t0[1:4])
     mirror.close()
+
+
+def _recall_of_graph(ctx, metric, data, levels, nbr_start, nbr, m, entry, queries, ef, k):
+    mirror = api.Hnsw(ctx, metric, api.PGV_F32, data.shape[1], data)
+    mirror.set_graph(m, entry, levels, nbr_start, nbr)
+    elem, _, _ = mirror.search(queries, ef, k)
+    mirror.close()
+    d = ((queries[:, None, :].astype(np.float64) - data[None, :, :].astype(np.float64)) ** 2).sum(-1)
+    kth = np.sort(d, axis=1)[:, k - 1]
+    hits = sum(int((d[i, e[e >= 0]] <= kth[i] + 1e-9).sum()) for i, e in enumerate(elem))
+    return hits / (len(queries) * k)
+
+
+def test_hnsw_build_serial_is_the_reference_loop(ctx, oracle):
+    """pgv_host_hnsw_build with max_batch = 1 (InsertTupleInMemory one tuple at a time,
+    src/hnswbuild.c:436-476) on data with exact fp32 arithmetic and the oracle's pg_prng stream:
+    same levels, same entry point, same neighbor tuples as the oracle's build"""
+    from pgvector_amd import _host
+    n, dim, m, efc = 1200, 8, 6, 24
+    data = gen(n, dim, seed=401, dist="int10")
+    g = po.HnswGraph(oracle, po.OPS_L2, po.ORA_F32, data, m=m, ef_construction=efc, seed=11)
+    ex = g.export_tuples()
+    assert np.array_equal(ex["rows"], np.arange(n))  # no duplicate vectors in this data
+    st = oracle.prng(11)
+    rng = api.make_rng(next_double=oracle.lib.ora_prng_double_cb, next_u32=oracle.lib.ora_prng_u32_cb,
+                       state=C.cast(C.pointer(st), C.c_void_p))
+    mirror = api.Hnsw(ctx, api.PGV_L2SQ, api.PGV_F32, dim, data)
+    built = _host.hnsw_build(mirror, data, m, efc, rng, max_batch=1)
+    assert built["nelements"] == n and built["batches"] == n
+    np.testing.assert_array_equal(built["levels"], ex["levels"])
+    np.testing.assert_array_equal(built["nbr_start"], ex["nbr_start"])
+    assert built["entry"] == ex["entry"]
+    # a tie between two candidates' distances may be walked in a different order (unspecified in the
+    # reference); everything else must be identical
+    same = np.array([np.array_equal(built["nbr"][built["nbr_start"][e]:built["nbr_start"][e + 1]],
+                                    ex["nbr"][ex["nbr_start"][e]:ex["nbr_start"][e + 1]]) for e in range(n)])
+    assert same.mean() >= 0.99, same.mean()
+    # the mirror now holds the built graph: search it
+    q = gen(32, dim, seed=402, dist="int10")
+    elem, d, _ = mirror.search(q, 40, 10)
+    for i in range(len(q)):
+        rows, wd, _ = g.search(q[i], 40, 10)
+        assert_topk_equiv(elem[i][elem[i] >= 0].tolist(), d[i][:len(rows)], rows.tolist(), wd, what="built graph q %d" % i)
+    mirror.close()
+
+
+@pytest.mark.parametrize("max_batch", [16, 256])
+def test_hnsw_build_batched_quality(ctx, oracle, max_batch):
+    """batched concurrent inserts (the reference's parallel build interleaves its workers the same
+    way): the graph differs from the serial one but must search as well"""
+    from pgvector_amd import _host
+    n, dim, m, efc = 6000, 32, 8, 40
+    data = gen(n, dim, seed=411, dist="clustered", clusters=30)
+    queries = gen(64, dim, seed=412, dist="clustered", clusters=30)
+    mirror = api.Hnsw(ctx, api.PGV_L2SQ, api.PGV_F32, dim, data)
+    built = _host.hnsw_build(mirror, data, m, efc, api.make_rng(seed=5), max_batch=max_batch)
+    assert built["nelements"] + int((built["dup_of"] >= 0).sum()) == n
+    assert built["batches"] < n / 4
+    # structural invariants: neighbors are linked elements at or above the layer, no self loops, lists within lm
+    lv, st, nb = built["levels"], built["nbr_start"], built["nbr"]
+    for e in range(0, n, 37):
+        for lc in range(lv[e] + 1):
+            lm = 2 * m if lc == 0 else m
+            o = st[e] + (lv[e] - lc) * m
+            ids = nb[o:o + lm]
+            ids = ids[ids >= 0]
+            assert len(set(ids.tolist())) == len(ids) and e not in ids
+            assert (lv[ids] >= lc).all() and (built["dup_of"][ids] < 0).all()
+    mirror.close()
+    got = _recall_of_graph(ctx, api.PGV_L2SQ, data, lv, st, nb, m, built["entry"], queries, 40, 10)
+    g = po.HnswGraph(oracle, po.OPS_L2, po.ORA_F32, data, m=m, ef_construction=efc, seed=5)
+    ex = g.export_tuples()
+    want = _recall_of_graph(ctx, api.PGV_L2SQ, data[ex["rows"]], ex["levels"], ex["nbr_start"], ex["nbr"], m,
+                            ex["entry"], queries, 40, 10)
+    assert got >= want - 0.03 and got >= 0.5, (got, want)
+
+
+def test_hnsw_build_attaches_duplicates(ctx, oracle):
+    """FindDuplicateInMemory (src/hnswbuild.c:313-364): an identical vector takes a heap-TID slot of
+    the element already in the graph instead of becoming an element (up to 10 TIDs per element)"""
+    from pgvector_amd import _host
+    base = gen(150, 12, seed=421, dist="int10")
+    data = np.ascontiguousarray(np.repeat(base, 13, axis=0))  # 13 copies: 10 fit one element, 3 the next
+    rng_perm = np.random.default_rng(3).permutation(len(data))
+    data = np.ascontiguousarray(data[rng_perm])
+    g = po.HnswGraph(oracle, po.OPS_L2, po.ORA_F32, data, m=6, ef_construction=24, seed=2)
+    st = oracle.prng(2)
+    rng = api.make_rng(next_double=oracle.lib.ora_prng_double_cb, next_u32=oracle.lib.ora_prng_u32_cb,
+                       state=C.cast(C.pointer(st), C.c_void_p))
+    mirror = api.Hnsw(ctx, api.PGV_L2SQ, api.PGV_F32, 12, data)
+    built = _host.hnsw_build(mirror, data, 6, 24, rng, max_batch=1)
+    mirror.close()
+    assert built["nelements"] == g.nelements
+    dup = built["dup_of"]
+    assert (dup >= 0).sum() == len(data) - g.nelements
+    for r in np.nonzero(dup >= 0)[0][:200]:
+        assert np.array_equal(data[r], data[dup[r]]) and dup[dup[r]] < 0
