@@ -36,6 +36,7 @@ def main():
     ap.add_argument("--graph", default="", help="npz file to load the graph from / save it to")
     ap.add_argument("--build-only", action="store_true")
     ap.add_argument("--skip-host-search", action="store_true")
+    ap.add_argument("--gpu-build", type=int, default=0, help="also build the graph on the GPU with this max_batch")
     a = ap.parse_args()
     rng = np.random.default_rng(0)
     comps = rng.random((64, a.dim), dtype=np.float32)
@@ -65,7 +66,7 @@ def main():
     stored = np.ascontiguousarray(unit[ex["rows"]].astype(np.float32))
     qn = np.ascontiguousarray((queries / np.linalg.norm(queries.astype(np.float64), axis=1, keepdims=True)).astype(np.float32))
 
-    ctx = api.Context(0)
+    ctx = api.Context(0, stream=0)  # the library runs on torch's default stream: its outputs are ordered with torch
     mirror = api.Hnsw(ctx, api.PGV_NEG_IP, api.PGV_F32, a.dim, stored)
     graph = _host.hnsw_graph(ex["levels"], ex["nbr_start"], ex["nbr"], a.m, ex["entry"])
     _host.hnsw_search(mirror, graph, qn[:8], a.ef_search, a.k)  # warm up
@@ -88,6 +89,19 @@ def main():
     delem_h = delem[:a.queries].cpu().numpy()
     same = float((np.sort(delem_h, axis=1) == np.sort(elem, axis=1)).all(axis=1).mean())
 
+    # CREATE INDEX on the GPU: the same rows through pgv_host_hnsw_build, searched the same way
+    gpu_build = None
+    if a.gpu_build:
+        m2 = api.Hnsw(ctx, api.PGV_NEG_IP, api.PGV_F32, a.dim, stored)
+        t0 = time.perf_counter()
+        built = _host.hnsw_build(m2, stored, a.m, a.ef_construction, api.make_rng(seed=1), max_batch=a.gpu_build)
+        gb_s = time.perf_counter() - t0
+        belem, _, bscored = m2.search(qd[:a.queries].contiguous(), a.ef_search, a.k)
+        gpu_build = {"secs": gb_s, "max_batch": a.gpu_build, "batches": built["batches"],
+                     "elements": built["nelements"], "pairs_scored": built["device_pairs"],
+                     "elem": belem.cpu().numpy(), "scored": float(bscored.float().mean().item())}
+        m2.close()
+
     # exact ground truth on the same unit vectors (cosine distance order = -ip order)
     ip = qn.astype(np.float64) @ stored.astype(np.float64).T
     kth = -np.sort(-ip, axis=1)[:, a.k - 1]
@@ -100,6 +114,14 @@ def main():
     for i in range(a.queries):
         e = delem_h[i][delem_h[i] >= 0]
         dhits += int((ip[i, e] >= kth[i] - 1e-9).sum())
+    if gpu_build:
+        bh = 0
+        be = gpu_build.pop("elem")
+        for i in range(a.queries):
+            e = be[i][be[i] >= 0]
+            bh += int((ip[i, e] >= kth[i] - 1e-9).sum())
+        gpu_build["recall_at_k_of_its_graph"] = bh / (a.queries * a.k)
+        gpu_build["scored_elements_per_query"] = gpu_build.pop("scored")
 
     # the oracle's search, one thread (one backend)
     t0 = time.perf_counter()
@@ -124,7 +146,7 @@ def main():
         "cpu_baseline": ({"value": n_cpu / cpu_s, "unit": "queries/s", "cores": 1, "kind": "port",
                           "sample": "%d queries, oracle HnswSearchLayer on one thread" % n_cpu,
                           "scored_elements_per_query": cpu_scored / n_cpu} if n_cpu else None),
-        "graph_build_secs_cpu_oracle": build_s, "elements": int(len(ex["levels"]))}))
+        "gpu_build": gpu_build, "graph_build_secs_cpu_oracle": build_s, "elements": int(len(ex["levels"]))}))
 
 
 if __name__ == "__main__":
