@@ -288,6 +288,29 @@ int			pgv_kmeanspp_init(pgv_ctx * ctx, pgv_ops ops, pgv_dtype dtype, int dim,
 int			pgv_distance_batch(pgv_ctx * ctx, pgv_metric metric, pgv_dtype dtype, int dim,
 							   const void *query, const void *rows, int64_t n, float *out);
 
+/*
+ * cosine_distance as the operator computes it without an index (`<=>` in a sequential scan or an
+ * executor recheck; src/vector.c:649-697, src/halfvec.c:652-700): three fp32 accumulators in one
+ * pass, `(double) sim / sqrt((double) na * (double) nb)`, clamped to [-1, 1], 1 - similarity.  A
+ * zero vector gives NaN like the reference (test/expected/vector_type.out:437-441).  out [n] float8.
+ */
+int			pgv_cosine_distance_batch(pgv_ctx * ctx, pgv_dtype dtype, int dim,
+									  const void *query, const void *rows, int64_t n, double *out);
+
+/*
+ * hamming_distance / jaccard_distance (`<~>`, `<%>`; src/bitvec.c:45-70 over src/bitutils.c:49-131)
+ * of one bit string against n bit strings of the same length: VARBITS payloads, (nbits + 7) / 8
+ * bytes each, first bit = most significant bit of byte 0, rows contiguous.  out [n] float8 (exact).
+ */
+typedef enum pgv_bit_metric
+{
+	PGV_BIT_HAMMING = 0,
+	PGV_BIT_JACCARD = 1
+}			pgv_bit_metric;
+
+int			pgv_bit_distance_batch(pgv_ctx * ctx, pgv_bit_metric metric, int nbits,
+								   const void *query, const void *rows, int64_t n, double *out);
+
 /* --------------------------------------------------------------- HNSW side */
 
 /*

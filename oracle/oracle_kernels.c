@@ -705,3 +705,117 @@ ora_kmeans_distance(int ops, int dtype, int dim, const void *a, const void *b)
 		return sqrt((double) ora_halfvec_l2_squared(dim, a, b));
 	return spherical_from_ip((double) ora_halfvec_inner_product(dim, a, b));
 }
+
+/* ------------------------------------------------------------------ bit */
+
+/* the byte popcount table PostgreSQL exports as pg_number_of_ones (built, not copied) */
+static unsigned char ones_of_byte[256];
+static int	ones_ready;
+
+static void
+ones_init(void)
+{
+	if (ones_ready)
+		return;
+	for (int i = 0; i < 256; i++)
+	{
+		int			n = 0;
+
+		for (int b = i; b; b >>= 1)
+			n += b & 1;
+		ones_of_byte[i] = (unsigned char) n;
+	}
+	ones_ready = 1;
+}
+
+/* BitHammingDistanceDefault, src/bitutils.c:49-73: 8 bytes at a time, then the byte tail */
+uint64_t
+ora_bit_hamming(uint32_t bytes, const unsigned char *ax, const unsigned char *bx)
+{
+	uint64_t	distance = 0;
+
+	ones_init();
+	for (; bytes >= sizeof(uint64_t); bytes -= sizeof(uint64_t))
+	{
+		uint64_t	axs,
+					bxs;
+
+		memcpy(&axs, ax, sizeof(uint64_t));
+		memcpy(&bxs, bx, sizeof(uint64_t));
+		distance += (uint64_t) __builtin_popcountll(axs ^ bxs);
+		ax += sizeof(uint64_t);
+		bx += sizeof(uint64_t);
+	}
+	for (uint32_t i = 0; i < bytes; i++)
+		distance += ones_of_byte[ax[i] ^ bx[i]];
+	return distance;
+}
+
+/* BitJaccardDistanceDefault, src/bitutils.c:99-131 */
+double
+ora_bit_jaccard(uint32_t bytes, const unsigned char *ax, const unsigned char *bx)
+{
+	uint64_t	ab = 0,
+				aa = 0,
+				bb = 0;
+
+	ones_init();
+	for (; bytes >= sizeof(uint64_t); bytes -= sizeof(uint64_t))
+	{
+		uint64_t	axs,
+					bxs;
+
+		memcpy(&axs, ax, sizeof(uint64_t));
+		memcpy(&bxs, bx, sizeof(uint64_t));
+		ab += (uint64_t) __builtin_popcountll(axs & bxs);
+		aa += (uint64_t) __builtin_popcountll(axs);
+		bb += (uint64_t) __builtin_popcountll(bxs);
+		ax += sizeof(uint64_t);
+		bx += sizeof(uint64_t);
+	}
+	for (uint32_t i = 0; i < bytes; i++)
+	{
+		ab += ones_of_byte[ax[i] & bx[i]];
+		aa += ones_of_byte[ax[i]];
+		bb += ones_of_byte[bx[i]];
+	}
+	if (ab == 0)
+		return 1;
+	return 1 - ((double) ab / (double) (aa + bb - ab));
+}
+
+/* CheckDims, src/bitvec.c:32-39 */
+static int
+ora_check_bits(int bits_a, int bits_b)
+{
+	if (bits_a != bits_b)
+	{
+		snprintf(ora_errbuf, sizeof(ora_errbuf), "different bit lengths %u and %u", (unsigned) bits_a, (unsigned) bits_b);
+		return ORA_ERR_DIMS;
+	}
+	return ORA_OK;
+}
+
+/* hamming_distance, src/bitvec.c:45-55; VARBITBYTES = (bits + 7) / 8 */
+int
+ora_hamming_distance(int bits_a, const unsigned char *a, int bits_b, const unsigned char *b, double *out)
+{
+	int			rc = ora_check_bits(bits_a, bits_b);
+
+	if (rc != ORA_OK)
+		return rc;
+	*out = (double) ora_bit_hamming((uint32_t) ((bits_a + 7) / 8), a, b);
+	return ORA_OK;
+}
+
+/* jaccard_distance, src/bitvec.c:60-70 */
+int
+ora_jaccard_distance(int bits_a, const unsigned char *a, int bits_b, const unsigned char *b, double *out)
+{
+	int			rc = ora_check_bits(bits_a, bits_b);
+
+	if (rc != ORA_OK)
+		return rc;
+	*out = ora_bit_jaccard((uint32_t) ((bits_a + 7) / 8), a, b);
+	return ORA_OK;
+}

@@ -82,6 +82,13 @@ int			ora_halfvec_l2_squared_distance(int da, const ora_half *a, int db, const o
 int			ora_halfvec_inner_product_f8(int da, const ora_half *a, int db, const ora_half *b, double *out);
 int			ora_halfvec_negative_inner_product(int da, const ora_half *a, int db, const ora_half *b, double *out);
 int			ora_halfvec_cosine_distance(int da, const ora_half *a, int db, const ora_half *b, double *out);
+
+/* bit vectors: src/bitutils.c:49-73 (BitHammingDistanceDefault), :99-131 (BitJaccardDistanceDefault) and
+ * their fmgr wrappers src/bitvec.c:45-70 ("different bit lengths %d and %d", :14-21) */
+uint64_t	ora_bit_hamming(uint32_t bytes, const unsigned char *ax, const unsigned char *bx);
+double		ora_bit_jaccard(uint32_t bytes, const unsigned char *ax, const unsigned char *bx);
+int			ora_hamming_distance(int bits_a, const unsigned char *a, int bits_b, const unsigned char *b, double *out);
+int			ora_jaccard_distance(int bits_a, const unsigned char *a, int bits_b, const unsigned char *b, double *out);
 int			ora_halfvec_spherical_distance(int da, const ora_half *a, int db, const ora_half *b, double *out);
 int			ora_halfvec_l1_distance(int da, const ora_half *a, int db, const ora_half *b, double *out);
 double		ora_halfvec_l2_norm(int dim, const ora_half *a);	/* halfvec.c:703-719 */

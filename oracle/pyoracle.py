@@ -138,6 +138,36 @@ class Oracle:
         rc = getattr(self.lib, name)(len(a), _p(a), len(b), _p(b), C.byref(out))
         return rc, out.value
 
+    @staticmethod
+    def pack_bits(bits):
+        """a PostgreSQL bit string ('0101...' or a 0/1 array) -> (nbits, packed bytes, first bit = MSB of byte 0)"""
+        if isinstance(bits, str):
+            bits = np.array([c == "1" for c in bits], dtype=np.uint8)
+        bits = np.asarray(bits, dtype=np.uint8)
+        return len(bits), np.ascontiguousarray(np.packbits(bits)) if len(bits) else np.zeros(0, np.uint8)
+
+    def bit_sql(self, name, a, b):
+        """ora_hamming_distance / ora_jaccard_distance on bit strings; returns (rc, value)"""
+        na, pa = self.pack_bits(a)
+        nb, pb = self.pack_bits(b)
+        fn = getattr(self.lib, name)
+        fn.restype = C.c_int
+        fn.argtypes = [C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.POINTER(C.c_double)]
+        out = C.c_double()
+        pa = np.concatenate([pa, np.zeros(8, np.uint8)])  # keep the pointers valid for empty strings
+        pb = np.concatenate([pb, np.zeros(8, np.uint8)])
+        rc = fn(na, _p(pa), nb, _p(pb), C.byref(out))
+        return rc, out.value
+
+    def bit_rows(self, name, query, rows):
+        """packed rows [n x bytes] against one packed query -> float64 [n] (ora_bit_hamming / ora_bit_jaccard)"""
+        fn = getattr(self.lib, name)
+        fn.restype = C.c_uint64 if name == "ora_bit_hamming" else C.c_double
+        fn.argtypes = [C.c_uint32, C.c_void_p, C.c_void_p]
+        rows = np.ascontiguousarray(rows, dtype=np.uint8)
+        query = np.ascontiguousarray(query, dtype=np.uint8)
+        return np.array([float(fn(rows.shape[1], _p(r), _p(query))) for r in rows], dtype=np.float64)
+
     def kernel(self, name, a, b, half=False):
         dt = ORA_F16 if half else ORA_F32
         a, b = self.arr(a, dt), self.arr(b, dt)
@@ -319,6 +349,12 @@ class Ref:
         L.pgvref_half_to_float.argtypes = [C.c_uint16]
         L.pgvref_float_to_half.restype = C.c_uint16
         L.pgvref_float_to_half.argtypes = [C.c_float]
+        if hasattr(L, "pgvref_bit_init"):  # src/bitutils.c compiled unmodified as well
+            L.pgvref_bit_init()
+            L.pgvref_bit_hamming.restype = C.c_uint64
+            L.pgvref_bit_hamming.argtypes = [C.c_uint32, C.c_void_p, C.c_void_p]
+            L.pgvref_bit_jaccard.restype = C.c_double
+            L.pgvref_bit_jaccard.argtypes = [C.c_uint32, C.c_void_p, C.c_void_p]
 
     def kernel(self, name, a, b):
         a = np.ascontiguousarray(a, dtype=np.float16)

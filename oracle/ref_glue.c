@@ -6,6 +6,8 @@
  */
 #include "postgres.h"
 #include "halfutils.h"
+#include "bitutils.h"
+#include "port/pg_bitutils.h"
 
 #include <stdio.h>
 
@@ -64,4 +66,32 @@ uint16
 pgvref_float_to_half(float f)
 {
 	return (uint16) Float4ToHalfUnchecked(f);
+}
+
+/* ---- src/bitutils.c, compiled unmodified next to halfutils.c ---- */
+
+/* the byte popcount table the reference's tail loops index (a server symbol) */
+const uint8 pg_number_of_ones[256] = {
+#define B2(n) n, n + 1, n + 1, n + 2
+#define B4(n) B2(n), B2(n + 1), B2(n + 1), B2(n + 2)
+#define B6(n) B4(n), B4(n + 1), B4(n + 1), B4(n + 2)
+	B6(0), B6(1), B6(1), B6(2)
+};
+
+void
+pgvref_bit_init(void)
+{
+	BitvecInit();
+}
+
+uint64
+pgvref_bit_hamming(uint32 bytes, unsigned char *a, unsigned char *b)
+{
+	return BitHammingDistance(bytes, a, b, 0);
+}
+
+double
+pgvref_bit_jaccard(uint32 bytes, unsigned char *a, unsigned char *b)
+{
+	return BitJaccardDistance(bytes, a, b, 0, 0, 0);
 }

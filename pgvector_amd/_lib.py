@@ -36,7 +36,7 @@ SYMBOLS = [
     "pgv_ctx_reset_stats", "pgv_ctx_get_stats", "pgv_index_upload", "pgv_index_free",
     "pgv_index_rows", "pgv_index_lists", "pgv_rank_lists", "pgv_scan_lists", "pgv_search_batch", "pgv_scan_batch",
     "pgv_assign", "pgv_kmeans", "pgv_lloyd_partial", "pgv_lloyd_finish", "pgv_kmeanspp_init",
-    "pgv_distance_batch", "pgv_hnsw_upload", "pgv_hnsw_free", "pgv_hnsw_score", "pgv_hnsw_set_graph", "pgv_hnsw_search",
+    "pgv_distance_batch", "pgv_cosine_distance_batch", "pgv_bit_distance_batch", "pgv_hnsw_upload", "pgv_hnsw_free", "pgv_hnsw_score", "pgv_hnsw_set_graph", "pgv_hnsw_search",
     "pgv_hnsw_build_search", "pgv_hnsw_score_pairs", "pgv_hnsw_update_graph",
 ]
 
@@ -105,6 +105,8 @@ def _load():
     lib.pgv_hnsw_free.argtypes = [P]
     lib.pgv_hnsw_free.restype = None
     lib.pgv_hnsw_score.argtypes = [P, P, I, P, P, I64, P]
+    lib.pgv_cosine_distance_batch.argtypes = [P, I, I, P, P, I64, P]
+    lib.pgv_bit_distance_batch.argtypes = [P, I, I, P, P, I64, P]
     lib.pgv_hnsw_set_graph.argtypes = [P, I, C.c_int32, P, P, P]
     lib.pgv_hnsw_search.argtypes = [P, P, I, I, I, P, P, P]
     lib.pgv_hnsw_build_search.argtypes = [P, P, P, I, I, I, P, P, P]

@@ -278,6 +278,29 @@ def lloyd_finish(ctx, ops, dtype, dim, sums, counts, rng=None, like=None):
     return centers
 
 
+def cosine_distance_batch(ctx, dtype, dim, query, rows):
+    """cosine_distance of one query against n rows, float8 like the operator (pgv_cosine_distance_batch)"""
+    query, rows = as_dtype(query, dtype), as_dtype(rows, dtype)
+    n = int(rows.shape[0])
+    out = _empty_like_kind(rows, (n,), np.float64)
+    check(lib.pgv_cosine_distance_batch(ctx.h, dtype, dim, ptr(query), ptr(rows), n, ptr(out)))
+    return out
+
+
+PGV_BIT_HAMMING, PGV_BIT_JACCARD = 0, 1
+
+
+def bit_distance_batch(ctx, metric, nbits, query, rows):
+    """hamming / jaccard distance of one packed bit string against n packed rows [n x (nbits + 7) // 8] uint8"""
+    if not _is_torch(rows):
+        rows = np.ascontiguousarray(rows, dtype=np.uint8)
+        query = np.ascontiguousarray(query, dtype=np.uint8)
+    n = int(rows.shape[0])
+    out = _empty_like_kind(rows, (n,), np.float64)
+    check(lib.pgv_bit_distance_batch(ctx.h, metric, nbits, ptr(query) if nbits else None, ptr(rows), n, ptr(out)))
+    return out
+
+
 class Hnsw:
     """device mirror of an HNSW index's element vectors (pgv_hnsw_upload)"""
 

@@ -921,6 +921,76 @@ int pgv_distance_batch(pgv_ctx *ctx, pgv_metric metric, pgv_dtype dtype, int dim
     return sync_if(ctx, need);
 }
 
+int pgv_cosine_distance_batch(pgv_ctx *ctx, pgv_dtype dtype, int dim, const void *query, const void *rows,
+                              int64_t n, double *out) {
+    if (!ctx || !out) PGV_FAIL(PGV_ERR_ARG, "pgv_cosine_distance_batch: ctx/out is NULL");
+    PGV_TRY(check_common(dtype, dim));
+    if (n < 0) PGV_FAIL(PGV_ERR_ARG, "n < 0");
+    if (n == 0) return PGV_OK;
+    if (!query || !rows) PGV_FAIL(PGV_ERR_ARG, "query/rows is NULL");
+    PGV_HIP(hipSetDevice(ctx->device));
+    const RowGeom g = row_geom(dim, dtype);
+    const void *q_dev, *r_dev;
+    PGV_TRY(stage_rows(ctx, query, 1, dim, dtype, g, ctx->q_stage, &q_dev));
+    PGV_TRY(stage_rows(ctx, rows, n, dim, dtype, g, ctx->rows_stage, &r_dev));
+    OutArg od;
+    PGV_TRY(od.init(out, sizeof(double) * (size_t)n, ctx->out_stage));
+    PGV_TRY(launch_cosine(ctx, dtype, g, r_dev, q_dev, n, od.as<double>()));
+    bool need = false;
+    PGV_TRY(od.finish(ctx, &need));
+    return sync_if(ctx, need);
+}
+
+int pgv_bit_distance_batch(pgv_ctx *ctx, pgv_bit_metric metric, int nbits, const void *query, const void *rows,
+                           int64_t n, double *out) {
+    if (!ctx || !out) PGV_FAIL(PGV_ERR_ARG, "pgv_bit_distance_batch: ctx/out is NULL");
+    if (metric != PGV_BIT_HAMMING && metric != PGV_BIT_JACCARD) PGV_FAIL(PGV_ERR_ARG, "unknown bit metric %d", (int)metric);
+    if (nbits < 0 || nbits > 64000 * 8) PGV_FAIL(PGV_ERR_DIMS, "bit length %d out of range", nbits);
+    if (n < 0) PGV_FAIL(PGV_ERR_ARG, "n < 0");
+    if (n == 0) return PGV_OK;
+    if (!rows || (nbits > 0 && !query)) PGV_FAIL(PGV_ERR_ARG, "query/rows is NULL");
+    PGV_HIP(hipSetDevice(ctx->device));
+    OutArg od;
+    PGV_TRY(od.init(out, sizeof(double) * (size_t)n, ctx->out_stage));
+    const int bytes = (nbits + 7) / 8;  // VARBITBYTES
+    if (bytes == 0) {
+        // empty bit strings: hamming 0, jaccard 1 (no common bit), src/bitutils.c:71, :127-128
+        std::vector<double> v((size_t)n, metric == PGV_BIT_HAMMING ? 0.0 : 1.0);
+        PGV_HIP(hipMemcpyAsync(od.as<double>(), v.data(), sizeof(double) * (size_t)n, hipMemcpyHostToDevice, ctx->stream));
+        PGV_HIP(hipStreamSynchronize(ctx->stream));
+    } else {
+        // bytes are staged like fp16 elements of a (bytes / 2)-dimensional row would be: zero-padded to whole
+        // 16-byte vectors (an odd byte count is padded by the 2-D copy as well)
+        RowGeom g;
+        g.ld = (bytes + 15) / 16 * 16;  // padded row length in BYTES
+        g.nvec = g.ld / 16;
+        g.lpr_log2 = 6;
+        while (g.lpr_log2 > 0 && (1 << (g.lpr_log2 - 1)) >= g.nvec) g.lpr_log2--;
+        g.nchunks = (g.nvec + (1 << g.lpr_log2) - 1) >> g.lpr_log2;
+        auto stage = [&](const void *src, int64_t cnt, DBuf &scratch, const void **outp) -> int {
+            const bool dev = is_device_ptr(src);
+            if (dev && g.ld == bytes) {
+                *outp = src;
+                return PGV_OK;
+            }
+            PGV_TRY(scratch.ensure((size_t)cnt * g.ld));
+            PGV_HIP(hipMemsetAsync(scratch.p, 0, (size_t)cnt * g.ld, ctx->stream));
+            PGV_HIP(hipMemcpy2DAsync(scratch.p, (size_t)g.ld, src, (size_t)bytes, (size_t)bytes, (size_t)cnt,
+                                     dev ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, ctx->stream));
+            if (!dev) PGV_HIP(hipStreamSynchronize(ctx->stream));
+            *outp = scratch.p;
+            return PGV_OK;
+        };
+        const void *q_dev, *r_dev;
+        PGV_TRY(stage(query, 1, ctx->q_stage, &q_dev));
+        PGV_TRY(stage(rows, n, ctx->rows_stage, &r_dev));
+        PGV_TRY(launch_bit_distance(ctx, metric == PGV_BIT_HAMMING ? 0 : 1, g, r_dev, q_dev, n, od.as<double>()));
+    }
+    bool need = false;
+    PGV_TRY(od.finish(ctx, &need));
+    return sync_if(ctx, need);
+}
+
 // --------------------------------------------------------------------- k-means
 
 static bool spherical(pgv_ops ops) { return ops == PGV_OPS_IP || ops == PGV_OPS_COSINE; }

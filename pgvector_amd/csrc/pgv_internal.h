@@ -175,6 +175,12 @@ int launch_score_gather(pgv_ctx *ctx, pgv_metric metric, pgv_dtype dtype, const 
                         const void *rows, const void *queries, const int32_t *slot,
                         const int32_t *query_of, int64_t npairs, float *out);
 
+// kernels_misc.hip: operator-path cosine distance and bit-vector distances, one query x n rows
+int launch_cosine(pgv_ctx *ctx, pgv_dtype dtype, const RowGeom &g, const void *rows, const void *query, int64_t n,
+                  double *out);
+int launch_bit_distance(pgv_ctx *ctx, int mode, const RowGeom &g, const void *rows, const void *query, int64_t n,
+                        double *out);
+
 // kernels_hnsw.hip: the whole first batch of an HNSW scan, one workgroup per query
 int hnsw_search_grid(pgv_ctx *ctx, int nq, int64_t n, int *words_out);
 struct HnswSearchArgs {

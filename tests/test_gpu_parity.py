@@ -717,3 +717,73 @@ def test_hnsw_build_attaches_duplicates(ctx, oracle):
     assert (dup >= 0).sum() == len(data) - g.nelements
     for r in np.nonzero(dup >= 0)[0][:200]:
         assert np.array_equal(data[r], data[dup[r]]) and dup[dup[r]] < 0
+
+
+# ---------------------------------------------- operator-path cosine, bit vectors
+@pytest.mark.parametrize("dtype", [po.ORA_F32, po.ORA_F16])
+@pytest.mark.parametrize("dim", [1, 3, 16, 129, 768, 1536, 2000])
+def test_cosine_distance_batch(ctx, oracle, dtype, dim):
+    """cosine_distance without an index (src/vector.c:649-697, src/halfvec.c:652-700): float8 results"""
+    n = 300
+    rows = gen(n, dim, seed=501, dist="normal", dtype=dtype)
+    q = gen(1, dim, seed=502, dist="normal", dtype=dtype)[0]
+    rows[7] = 0  # a zero vector: NaN (0 / 0), test/expected/vector_type.out:437-441
+    rows[8] = q  # identical: exactly 0 after the clamp unless rounding leaves it just below 1
+    rows[9] = -q
+    got = api.cosine_distance_batch(ctx, DT[dtype], dim, q, rows)
+    name = "ora_cosine_distance" if dtype == po.ORA_F32 else "ora_halfvec_cosine_distance"
+    want = np.array([oracle.sql(name, r, q, half=dtype == po.ORA_F16)[1] for r in rows])
+    assert np.isnan(got[7]) and np.isnan(want[7])
+    ok = ~np.isnan(want)
+    # 1 - similarity: compare the similarities to 1e-5 relative
+    assert_close(1.0 - got[ok], 1.0 - want[ok], rtol=RTOL, atol=1e-6, what="cosine dim %d" % dim)
+    assert abs(got[8]) <= 2e-6 and abs(got[9] - 2.0) <= 2e-6
+
+
+def test_cosine_distance_known_answers(ctx):
+    """the reference's own cosine answers (test/expected/vector_type.out / halfvec.out)"""
+    cases = [c for c in golden("distance_known_answers.json")["cases"] if c["func"] == "cosine_distance"]
+    assert len(cases) >= 6
+    for c in cases:
+        dt = api.PGV_F32 if c["type"] == "vector" else api.PGV_F16
+        if c.get("error") or len(c["args"][0]) != len(c["args"][1]):
+            continue
+        npt = np.float32 if dt == api.PGV_F32 else np.float16
+        a = np.array(c["args"][0], dtype=npt)
+        b = np.array(c["args"][1], dtype=npt)
+        got = api.cosine_distance_batch(ctx, dt, len(a), b, a[None, :])[0]
+        want = float(c["expect"])
+        if math.isnan(want):
+            assert math.isnan(got), c
+        else:
+            assert abs(got - want) <= 1e-6, (c, got)
+
+
+@pytest.mark.parametrize("nbits", [1, 3, 8, 13, 64, 127, 128, 129, 513, 1536, 4000, 64000])
+def test_bit_distance_batch(ctx, oracle, nbits):
+    """hamming_distance / jaccard_distance (src/bitvec.c:45-70): exact float8 results"""
+    rng = np.random.default_rng(nbits)
+    n = 257
+    bits = rng.integers(0, 2, (n + 1, nbits), dtype=np.uint8)
+    bits[3] = 0          # jaccard with an all-zero row: 1
+    bits[4] = bits[n]    # identical to the query
+    packed = np.packbits(bits, axis=1)
+    rows, q = np.ascontiguousarray(packed[:n]), np.ascontiguousarray(packed[n])
+    got_h = api.bit_distance_batch(ctx, api.PGV_BIT_HAMMING, nbits, q, rows)
+    got_j = api.bit_distance_batch(ctx, api.PGV_BIT_JACCARD, nbits, q, rows)
+    np.testing.assert_array_equal(got_h, oracle.bit_rows("ora_bit_hamming", q, rows))
+    np.testing.assert_array_equal(got_j, oracle.bit_rows("ora_bit_jaccard", q, rows))
+    assert got_h[4] == 0 and got_j[3] == 1.0
+
+
+def test_bit_distance_known_answers_and_edges(ctx, oracle):
+    for c in golden("bit_known_answers.json")["cases"]:
+        if "error" in c:
+            continue
+        na, pa = oracle.pack_bits(c["a"])
+        nb, pb = oracle.pack_bits(c["b"])
+        metric = api.PGV_BIT_HAMMING if c["func"] == "hamming_distance" else api.PGV_BIT_JACCARD
+        got = api.bit_distance_batch(ctx, metric, na, pb, pa.reshape(1, -1))
+        assert got[0] == c["value"], (c, got)
+    with pytest.raises(api.PgvError):
+        api.bit_distance_batch(ctx, 7, 8, np.zeros(1, np.uint8), np.zeros((1, 1), np.uint8))

@@ -3,6 +3,8 @@ own fp16 kernels (oracle/_ref), and the index-order transcripts."""
 import math
 import os
 
+import ctypes as C
+
 import numpy as np
 import pytest
 
@@ -267,3 +269,35 @@ def test_hnsw_duplicates_fold_into_one_element(oracle):
     assert g.nelements == 50 + 3  # 25 duplicates -> ceil(25 / 10) elements
     rows, dist, _ = g.search(np.array([1, 2, 3], dtype=np.float32), 40, 25)
     assert sorted(rows.tolist()) == list(range(25)) and (dist == 0).all()
+
+
+# ------------------------------------------------------------------ bit vectors
+def test_bit_distances_match_the_reference_known_answers(oracle):
+    """hamming_distance / jaccard_distance (src/bitvec.c:45-70, src/bitutils.c:49-131) against every
+    known answer of test/expected/bit.out, error texts included"""
+    cases = golden("bit_known_answers.json")["cases"]
+    assert len(cases) >= 26
+    for c in cases:
+        rc, value = oracle.bit_sql("ora_" + c["func"], c["a"], c["b"])
+        if "error" in c:
+            assert rc != 0 and oracle.last_error() == c["error"], (c, oracle.last_error())
+        else:
+            assert rc == 0 and value == c["value"], (c, value)
+
+
+def test_bit_oracle_matches_the_compiled_reference(oracle):
+    """the restatement against oracle/_ref (the reference's src/bitutils.c compiled unmodified, whichever of
+    its Default / AVX-512 variants this CPU dispatches to) on random bit vectors of every tail length"""
+    try:
+        ref = po.Ref()
+    except FileNotFoundError:
+        pytest.skip("oracle/_ref not built")
+    if not hasattr(ref.lib, "pgvref_bit_hamming"):
+        pytest.skip("oracle/_ref predates the bit kernels")
+    rng = np.random.default_rng(5)
+    for nbytes in list(range(0, 20)) + [63, 64, 65, 127, 128, 192, 500, 2000]:
+        a = rng.integers(0, 256, nbytes + 8, dtype=np.uint8)
+        b = rng.integers(0, 256, nbytes + 8, dtype=np.uint8)
+        assert oracle.lib.ora_bit_hamming(nbytes, po._p(a), po._p(b)) == ref.lib.pgvref_bit_hamming(nbytes, po._p(a), po._p(b))
+        oracle.lib.ora_bit_jaccard.restype = C.c_double
+        assert oracle.lib.ora_bit_jaccard(nbytes, po._p(a), po._p(b)) == ref.lib.pgvref_bit_jaccard(nbytes, po._p(a), po._p(b))
