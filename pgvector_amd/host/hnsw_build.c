@@ -16,9 +16,14 @@
  * concurrent workers.  With max_batch = 1 this IS the reference's serial loop.
  *
  * Which distances a selection needs depends on its outcome, but never the distances
- * themselves: for a candidate list C the whole pairwise matrix over C is fetched and the
- * reference's loop is replayed on the host from it (the closer-flag cache of :1098-1140 is an
- * exact shortcut of recomputing the flags, so they are recomputed).
+ * themselves, so they are fetched ahead of the replay: for the candidate list of a new element
+ * the whole pairwise matrix; for a neighbor list that a batch links into, what the reference's
+ * closer-flag cache (:1098-1140) makes it compute -- the whole matrix when the list has no cached
+ * flags yet (first overflow), otherwise only the distances that involve the newcomers.  The rare
+ * replay that steps outside that (a cached `closer` member losing its flag makes the reference
+ * re-check earlier rejects against the whole selection) is put aside, the missing pairs of its
+ * list are fetched in a second launch, and it is replayed then; lists are independent, so that
+ * changes nothing.
  */
 #include "pgv_host.h"
 
@@ -35,13 +40,23 @@ typedef struct
 	int32_t		element;
 	float		distance;
 	int32_t		local;			/* index into the current record's matrix (valid within a batch) */
+	uint8_t		closer;			/* HnswCandidate.closer: cached outcome of CheckElementCloser */
 }			cand;
 
 typedef struct
 {
 	int			length;
+	uint8_t		closer_set;		/* HnswNeighborArray.closerSet: the cached flags are usable */
 	cand	   *items;			/* capacity lm */
 }			nlist;
+
+/* an update of a full list that had to wait for distances (see the header comment) */
+typedef struct
+{
+	int32_t		element;
+	float		distance;
+	int32_t		local;
+}			pending;
 
 typedef struct
 {
@@ -58,8 +73,12 @@ typedef struct
 	int			nstart;			/* members when the batch began: locals 0 .. nstart - 1 */
 	int			nlocal;			/* + the batch elements that selected the owner */
 	int32_t    *ids;			/* [nlocal] element of each local */
-	int64_t		pair0;			/* first of its nlocal * (nlocal - 1) / 2 pairs in the request */
+	int64_t		pair0;			/* first of its pairs in the request */
+	int			full;			/* every pair is in mat; otherwise only those with a newcomer (local >= nstart) */
+	int			blocked;		/* an update is waiting for the member-member pairs */
 	float	   *mat;			/* [nlocal x nlocal] */
+	pending    *wait;
+	int			nwait;
 }			record;
 
 typedef struct
@@ -200,18 +219,45 @@ cand_desc_cmp(const void *pa, const void *pb)
 }
 
 /*
- * Algorithm 4 (src/hnswutils.c:1064-1165) on a candidate list whose pairwise distances are in
- * mat[nloc x nloc] (indexed by cand.local).  c is ordered furthest first unless sort != 0.
- * Returns |r|; *pruned = the candidate that would be dropped.
+ * CheckElementCloser (src/hnswutils.c:1040-1059) of e against the candidates in set[0 .. n), from
+ * the matrix; *missing is set when a pair is not in a partial matrix (both locals below nknown).
  */
 static int
-select_neighbors(cand * *c, int nc, int lm, const float *mat, int nloc, cand * *r, cand * *pruned, int sort,
-				 cand * *w, cand * *wd)
+check_closer(const cand * e, cand * *set, int n, const float *mat, int nloc, int nknown, int *missing)
+{
+	for (int i = 0; i < n; i++)
+	{
+		if (e->local < nknown && set[i]->local < nknown)
+		{
+			*missing = 1;
+			return 0;
+		}
+		if (mat[(size_t) e->local * nloc + set[i]->local] <= e->distance)
+			return 0;
+	}
+	return 1;
+}
+
+/*
+ * Algorithm 4 with the reference's closer-flag cache (src/hnswutils.c:1064-1165).  Pairwise
+ * distances come from mat[nloc x nloc] indexed by cand.local; pairs with both locals < nknown
+ * are NOT in it (nknown = 0: everything is).  c is ordered furthest first unless sort != 0.
+ * Returns |r|, or -1 when a missing pair was needed (nothing has been changed then).
+ * *pruned = the candidate that would be dropped.
+ */
+static int
+select_neighbors(cand * *c, int nc, int lm, const float *mat, int nloc, int nknown, uint8_t *closer_set,
+				 cand * new_cand, cand * *r, cand * *pruned, int sort, cand * *w, cand * *wd,
+				 cand * *added, uint8_t *flag)
 {
 	int			wn = nc,
 				rn = 0,
 				wdlen = 0,
-				wdoff = 0;
+				wdoff = 0,
+				nadded = 0;
+	int			must_calculate = !(*closer_set);
+	int			removed_any = 0;
+	int			missing = 0;
 
 	if (nc <= lm)
 	{
@@ -225,25 +271,49 @@ select_neighbors(cand * *c, int nc, int lm, const float *mat, int nloc, cand * *
 	while (wn > 0 && rn < lm)
 	{
 		cand	   *e = w[--wn];	/* closest remaining */
-		int			closer = 1;
+		uint8_t		closer = e->closer;
 
-		/* CheckElementCloser, :1040-1059 */
-		for (int i = 0; i < rn; i++)
-			if (mat[(size_t) e->local * nloc + r[i]->local] <= e->distance)
+		/* use the previous state of r and wd to skip work when possible (:1098-1140) */
+		if (must_calculate)
+			closer = (uint8_t) check_closer(e, r, rn, mat, nloc, nknown, &missing);
+		else if (nadded > 0)
+		{
+			if (closer)
 			{
-				closer = 0;
-				break;
+				closer = (uint8_t) check_closer(e, added, nadded, mat, nloc, nknown, &missing);
+				if (!closer)
+					removed_any = 1;
 			}
+			else if (removed_any)
+			{
+				closer = (uint8_t) check_closer(e, r, rn, mat, nloc, nknown, &missing);
+				if (closer)
+					added[nadded++] = e;
+			}
+		}
+		else if (e == new_cand)
+		{
+			closer = (uint8_t) check_closer(e, r, rn, mat, nloc, nknown, &missing);
+			if (closer)
+				added[nadded++] = e;
+		}
+		if (missing)
+			return -1;
+		flag[wn] = closer;		/* committed below: a replay that runs out of distances must leave no trace */
 		if (closer)
 			r[rn++] = e;
 		else
 			wd[wdlen++] = e;
 	}
-	/* keep pruned connections (:1148-1150) */
+	for (int i = wn; i < nc; i++)
+		w[i]->closer = flag[i];
+	/* cached values can only be used in future if sorted deterministically (:1143-1144) */
+	*closer_set = (uint8_t) (sort != 0);
+	/* keep pruned connections (:1146-1148) */
 	while (wdoff < wdlen && rn < lm)
 		r[rn++] = wd[wdoff++];
 	if (pruned)
-		*pruned = wdoff < wdlen ? wd[wdoff] : w[0];	/* :1153-1159 */
+		*pruned = wdoff < wdlen ? wd[wdoff] : w[0];	/* :1150-1157 */
 	return rn;
 }
 
@@ -464,10 +534,12 @@ pgv_host_hnsw_build(pgv_hnsw * mirror, pgv_dtype dtype, int dim, const void *row
 			int64_t		tri = 0;
 			float	   *mat = malloc(sizeof(float) * (size_t) ef_construction * ef_construction);
 			cand	   *lw = malloc(sizeof(cand) * (size_t) ef_construction);
-			cand	  **c = malloc(sizeof(cand *) * (size_t) ef_construction * 4);
+			cand	  **c = malloc(sizeof(cand *) * (size_t) ef_construction * 5);
 			cand	  **r = c + ef_construction,
 					  **w = c + 2 * ef_construction,
-					  **wd = c + 3 * ef_construction;
+					  **wd = c + 3 * ef_construction,
+					  **added = c + 4 * ef_construction;
+			uint8_t    *flag = malloc((size_t) ef_construction);
 
 			for (int b = 0; b < B; b++)
 			{
@@ -491,6 +563,7 @@ pgv_host_hnsw_build(pgv_hnsw * mirror, pgv_dtype dtype, int dim, const void *row
 						lw[i].element = wi[nw - 1 - i];
 						lw[i].distance = wdist[nw - 1 - i];
 						lw[i].local = nw - 1 - i;
+						lw[i].closer = 0;
 						c[i] = &lw[i];
 					}
 					if (nw > lm)
@@ -498,7 +571,13 @@ pgv_host_hnsw_build(pgv_hnsw * mirror, pgv_dtype dtype, int dim, const void *row
 						fill_matrix(mat, nw, pdist + tri);
 						tri += (int64_t) nw * (nw - 1) / 2;
 					}
-					rn = select_neighbors(c, nw, lm, mat, nw, r, NULL, 0, w, wd);
+					{
+						/* not sorted deterministically: the flags of this selection are not reusable (:1143-1144) */
+						uint8_t		closer_set = 0;
+
+						rn = select_neighbors(c, nw, lm, mat, nw, 0, &closer_set, NULL, r, NULL, 0, w, wd, added, flag);
+						x->layers[lc].closer_set = closer_set;
+					}
 					x->layers[lc].items = malloc(sizeof(cand) * (size_t) lm);
 					x->layers[lc].length = rn;
 					for (int i = 0; i < rn; i++)
@@ -538,6 +617,7 @@ pgv_host_hnsw_build(pgv_hnsw * mirror, pgv_dtype dtype, int dim, const void *row
 			free(mat);
 			free(lw);
 			free(c);
+			free(flag);
 		}
 
 		/* ---- 4. the lists this batch links into, and every distance their re-selections can look up */
@@ -575,6 +655,10 @@ pgv_host_hnsw_build(pgv_hnsw * mirror, pgv_dtype dtype, int dim, const void *row
 						rcd->nlocal = l->length;
 						rcd->ids = malloc(sizeof(int32_t) * (size_t) (l->length + B));
 						rcd->mat = NULL;
+						rcd->full = !l->closer_set;	/* no cached flags: its next selection computes everything */
+						rcd->blocked = 0;
+						rcd->wait = NULL;
+						rcd->nwait = 0;
 						for (int j = 0; j < l->length; j++)
 						{
 							rcd->ids[j] = l->items[j].element;
@@ -597,12 +681,34 @@ pgv_host_hnsw_build(pgv_hnsw * mirror, pgv_dtype dtype, int dim, const void *row
 
 			rcd->pair0 = pb.n;
 			/* a list that cannot overflow in this batch never runs a selection */
-			if (rcd->nlocal > layer_m(m, rcd->lc))
+			if (rcd->nlocal <= layer_m(m, rcd->lc))
+				continue;
+			if (rcd->full)
+			{
 				if (!pairs_triangle(&pb, rcd->ids, rcd->nlocal))
 				{
 					rc = pgv_host_fail(PGV_ERR_NOMEM, "out of memory");
 					goto done;
 				}
+			}
+			else
+			{
+				/* cached flags: only the pairs that involve a newcomer */
+				for (int u = rcd->nstart; u < rcd->nlocal; u++)
+				{
+					if (!pairs_reserve(&pb, u))
+					{
+						rc = pgv_host_fail(PGV_ERR_NOMEM, "out of memory");
+						goto done;
+					}
+					for (int v = 0; v < u; v++)
+					{
+						pb.a[pb.n] = rcd->ids[u];
+						pb.b[pb.n] = rcd->ids[v];
+						pb.n++;
+					}
+				}
+			}
 		}
 		if (pb.n > pdist_cap)
 		{
@@ -622,19 +728,31 @@ pgv_host_hnsw_build(pgv_hnsw * mirror, pgv_dtype dtype, int dim, const void *row
 
 			if (rcd->nlocal > layer_m(m, rcd->lc))
 			{
-				rcd->mat = malloc(sizeof(float) * (size_t) rcd->nlocal * rcd->nlocal);
-				fill_matrix(rcd->mat, rcd->nlocal, pdist + rcd->pair0);
+				rcd->mat = calloc((size_t) rcd->nlocal * rcd->nlocal, sizeof(float));
+				if (rcd->full)
+					fill_matrix(rcd->mat, rcd->nlocal, pdist + rcd->pair0);
+				else
+				{
+					int64_t		t = rcd->pair0;
+
+					for (int u = rcd->nstart; u < rcd->nlocal; u++)
+						for (int v = 0; v < u; v++, t++)
+							rcd->mat[(size_t) u * rcd->nlocal + v] = rcd->mat[(size_t) v * rcd->nlocal + u] = pdist[t];
+				}
 			}
 		}
 
 		/* ---- 5. HnswUpdateNeighborsInMemory, one element after the other (src/hnswbuild.c:376-405) */
 		{
 			int			lm0 = layer_m(m, 0);
-			cand	  **c = malloc(sizeof(cand *) * (size_t) (lm0 + 1) * 4);
+			cand	  **c = malloc(sizeof(cand *) * (size_t) (lm0 + 1) * 5);
 			cand	  **r = c + (lm0 + 1),
 					  **w = c + 2 * (lm0 + 1),
-					  **wd = c + 3 * (lm0 + 1);
+					  **wd = c + 3 * (lm0 + 1),
+					  **added = c + 4 * (lm0 + 1);
+			uint8_t    *flag = malloc((size_t) lm0 + 1);
 			int		   *next_local = calloc((size_t) (nrec > 0 ? nrec : 1), sizeof(int));
+			int			nblocked = 0;
 
 			for (int k = 0; k < nrec; k++)
 				next_local[k] = recs[k].nstart;
@@ -671,6 +789,7 @@ pgv_host_hnsw_build(pgv_hnsw * mirror, pgv_dtype dtype, int dim, const void *row
 						new_hc.element = e;
 						new_hc.distance = hc.distance;
 						new_hc.local = next_local[rec_of[h] - 1]++;	/* the order step 4 appended them in */
+						new_hc.closer = 0;
 						if (!is_dirty[owner])
 						{
 							is_dirty[owner] = 1;
@@ -685,11 +804,32 @@ pgv_host_hnsw_build(pgv_hnsw * mirror, pgv_dtype dtype, int dim, const void *row
 						{
 							int			nc = l->length + 1;
 							cand	   *pruned = NULL;
+							int			rn = -1;
 
-							for (int j = 0; j < l->length; j++)
-								c[j] = &l->items[j];
-							c[nc - 1] = &new_hc;
-							select_neighbors(c, nc, lm, rcd->mat, rcd->nlocal, r, &pruned, 1, w, wd);
+							if (!rcd->blocked)
+							{
+								for (int j = 0; j < l->length; j++)
+									c[j] = &l->items[j];
+								c[nc - 1] = &new_hc;
+								rn = select_neighbors(c, nc, lm, rcd->mat, rcd->nlocal, rcd->full ? 0 : rcd->nstart,
+													  &l->closer_set, &new_hc, r, &pruned, 1, w, wd, added, flag);
+							}
+							if (rn < 0)
+							{
+								/* needs member-member distances that were not fetched: this and every later
+								 * update of the list wait for the second launch */
+								if (!rcd->blocked)
+								{
+									rcd->blocked = 1;
+									nblocked++;
+								}
+								rcd->wait = realloc(rcd->wait, sizeof(pending) * (size_t) (rcd->nwait + 1));
+								rcd->wait[rcd->nwait].element = e;
+								rcd->wait[rcd->nwait].distance = new_hc.distance;
+								rcd->wait[rcd->nwait].local = new_hc.local;
+								rcd->nwait++;
+								continue;
+							}
 							if (pruned != NULL && pruned != &new_hc)
 								for (int j = 0; j < l->length; j++)
 									if (l->items[j].element == pruned->element)
@@ -704,8 +844,74 @@ pgv_host_hnsw_build(pgv_hnsw * mirror, pgv_dtype dtype, int dim, const void *row
 				if (x->level > el[entry].level)
 					entry = e;
 			}
+			/* ---- 5b. the updates that were put aside: fetch their lists' member-member pairs, replay in order */
+			if (nblocked > 0)
+			{
+				pb.n = 0;
+				for (int k = 0; k < nrec; k++)
+					if (recs[k].blocked)
+					{
+						recs[k].pair0 = pb.n;
+						if (!pairs_triangle(&pb, recs[k].ids, recs[k].nstart))
+						{
+							rc = pgv_host_fail(PGV_ERR_NOMEM, "out of memory");
+							goto done;
+						}
+					}
+				if (pb.n > pdist_cap)
+				{
+					pdist_cap = pb.n * 2;
+					pdist = realloc(pdist, sizeof(float) * (size_t) pdist_cap);
+				}
+				rc = pgv_hnsw_score_pairs(mirror, pb.a, pb.b, pb.n, pdist);
+				if (rc != PGV_OK)
+					goto dev_fail;
+				out->device_pairs += pb.n;
+				out->deferred_updates += nblocked;
+				for (int k = 0; k < nrec; k++)
+				{
+					record	   *rcd = &recs[k];
+					nlist	   *l;
+					int64_t		t;
+					int			lm;
+
+					if (!rcd->blocked)
+						continue;
+					t = rcd->pair0;
+					for (int u = 0; u < rcd->nstart; u++)
+						for (int v = u + 1; v < rcd->nstart; v++, t++)
+							rcd->mat[(size_t) u * rcd->nlocal + v] = rcd->mat[(size_t) v * rcd->nlocal + u] = pdist[t];
+					rcd->full = 1;
+					l = &el[rcd->owner].layers[rcd->lc];
+					lm = layer_m(m, rcd->lc);
+					for (int q = 0; q < rcd->nwait; q++)
+					{
+						cand		new_hc;
+						cand	   *pruned = NULL;
+						int			nc = l->length + 1;
+
+						new_hc.element = rcd->wait[q].element;
+						new_hc.distance = rcd->wait[q].distance;
+						new_hc.local = rcd->wait[q].local;
+						new_hc.closer = 0;
+						for (int j = 0; j < l->length; j++)
+							c[j] = &l->items[j];
+						c[nc - 1] = &new_hc;
+						select_neighbors(c, nc, lm, rcd->mat, rcd->nlocal, 0, &l->closer_set, &new_hc, r, &pruned, 1,
+										 w, wd, added, flag);
+						if (pruned != NULL && pruned != &new_hc)
+							for (int j = 0; j < l->length; j++)
+								if (l->items[j].element == pruned->element)
+								{
+									l->items[j] = new_hc;
+									break;
+								}
+					}
+				}
+			}
 			free(next_local);
 			free(c);
+			free(flag);
 		}
 
 		/* ---- 6. the graph the next batch searches */
@@ -756,6 +962,7 @@ pgv_host_hnsw_build(pgv_hnsw * mirror, pgv_dtype dtype, int dim, const void *row
 			(void) h;
 			free(recs[k].ids);
 			free(recs[k].mat);
+			free(recs[k].wait);
 		}
 		memset(rec_of, 0, sizeof(int64_t) * (size_t) hash_cap);
 		i0 += B;

@@ -86,6 +86,7 @@ typedef struct pgv_hnsw_built
 	int64_t		nelements;		/* elements linked into the graph (n minus duplicates) */
 	int64_t		device_pairs;	/* element pairs scored for SelectNeighbors */
 	int64_t		batches;
+	int64_t		deferred_updates;	/* lists whose re-selection needed a second distance launch */
 }			pgv_hnsw_built;
 
 int			pgv_host_hnsw_build(pgv_hnsw * mirror, pgv_dtype dtype, int dim, const void *rows, int64_t n, int m,
