@@ -325,6 +325,7 @@ def main():
         "algorithmic_bytes_per_launch": algo_bytes / launches,
         "streamed_bytes_per_launch": stream_bytes / launches,
         "streamed_GBps": stream_bytes / scan_s / 1e9 if scan_s > 0 else 0.0,
+        "frac_streamed": (stream_bytes / scan_s / 1e9 if scan_s > 0 else 0.0) / HBM_PEAK_GBS,  # physical bytes vs the HBM peak
         "avg_launch_ms": stats["scan_ms"] / launches, "launches": launches,
         # the batched kernel is bound by fp32 vector-ALU issue once rows are shared by many queries:
         # 3 flop per element (subtract, multiply, add) for L2, 2 for inner product

@@ -956,10 +956,6 @@ pgv_host_hnsw_build(pgv_hnsw * mirror, pgv_dtype dtype, int dim, const void *row
 		/* forget the batch's records */
 		for (int k = 0; k < nrec; k++)
 		{
-			uint64_t	key = ((uint64_t) recs[k].owner << 6) | (uint64_t) recs[k].lc;
-			int64_t		h = (int64_t) ((key * 0x9E3779B97F4A7C15ull) >> 40) & (hash_cap - 1);
-
-			(void) h;
 			free(recs[k].ids);
 			free(recs[k].mat);
 			free(recs[k].wait);
