@@ -23,6 +23,12 @@ class HnswBuilt(C.Structure):
                 ("deferred_updates", C.c_int64)]
 
 
+class HnswImage(C.Structure):
+    _fields_ = [("dtype", C.c_int), ("dim", C.c_int), ("m", C.c_int), ("ef_construction", C.c_int), ("n", C.c_int64),
+                ("entry", C.c_int32), ("vectors", C.c_void_p), ("levels", C.c_void_p), ("nbr_start", C.c_void_p),
+                ("nbr", C.c_void_p), ("heaptids", C.c_void_p), ("element_tids", C.c_void_p)]
+
+
 class Rel(C.Structure):
     _fields_ = [("pages", C.c_void_p), ("nblocks", C.c_uint32), ("cap", C.c_uint32), ("generation", C.c_uint64)]
 
@@ -47,6 +53,10 @@ def _load():
     lib.pgv_host_hnsw_build.argtypes = [P, I, I, P, I64, I, I, P, I, C.POINTER(HnswBuilt)]
     lib.pgv_host_hnsw_built_free.argtypes = [C.POINTER(HnswBuilt)]
     lib.pgv_host_hnsw_built_free.restype = None
+    lib.pgv_host_hnsw_write_index.argtypes = [C.POINTER(Rel), I, I, I, I, I64, P, P, P, P, P, P, C.c_int32]
+    lib.pgv_host_hnsw_stage.argtypes = [C.POINTER(Rel), I, C.POINTER(HnswImage)]
+    lib.pgv_host_hnsw_image_free.argtypes = [C.POINTER(HnswImage)]
+    lib.pgv_host_hnsw_image_free.restype = None
     lib.pgv_rel_init.argtypes = [C.POINTER(Rel)]
     lib.pgv_rel_init.restype = None
     lib.pgv_rel_free.argtypes = [C.POINTER(Rel)]
@@ -180,6 +190,40 @@ class Relation:
 
     def stage(self, dtype):
         return StagedImage(self, dtype)
+
+    def write_hnsw(self, dtype, m, ef_construction, vectors, tids, levels, nbr_start, nbr, entry, dup_of=None):
+        """FlushPages of an HNSW build (pgv_host_hnsw_write_index)"""
+        vectors = np.ascontiguousarray(vectors, dtype=_NP[dtype])
+        tids = np.ascontiguousarray(tids, dtype=np.uint64)
+        levels = np.ascontiguousarray(levels, dtype=np.int32)
+        nbr_start = np.ascontiguousarray(nbr_start, dtype=np.int64)
+        nbr = np.ascontiguousarray(nbr, dtype=np.int32)
+        dup = None if dup_of is None else np.ascontiguousarray(dup_of, dtype=np.int32)
+        host_check(lib.pgv_host_hnsw_write_index(
+            C.byref(self.rel), dtype, vectors.shape[1], m, ef_construction, vectors.shape[0],
+            C.c_void_p(vectors.ctypes.data), C.c_void_p(tids.ctypes.data), C.c_void_p(levels.ctypes.data),
+            C.c_void_p(nbr_start.ctypes.data), C.c_void_p(nbr.ctypes.data),
+            None if dup is None else C.c_void_p(dup.ctypes.data), int(entry)))
+
+    def stage_hnsw(self, dtype):
+        """pgv_host_hnsw_stage -> dict of numpy copies"""
+        img = HnswImage()
+        host_check(lib.pgv_host_hnsw_stage(C.byref(self.rel), dtype, C.byref(img)))
+        n = img.n
+
+        def copy(ptr, ctype, count, shape=None):
+            a = np.ctypeslib.as_array(C.cast(ptr, C.POINTER(ctype)), shape=(max(count, 1),))[:count].copy()
+            return a.reshape(shape) if shape else a
+        et = C.c_float if dtype == 0 else C.c_uint16
+        nbr_start = copy(img.nbr_start, C.c_int64, n + 1)
+        out = {"n": n, "dim": img.dim, "m": img.m, "ef_construction": img.ef_construction, "entry": img.entry,
+               "vectors": copy(img.vectors, et, n * img.dim, (n, img.dim)).view(_NP[dtype]),
+               "levels": copy(img.levels, C.c_int32, n), "nbr_start": nbr_start,
+               "nbr": copy(img.nbr, C.c_int32, int(nbr_start[-1]) if n else 0),
+               "heaptids": copy(img.heaptids, C.c_uint64, n * 10, (n, 10)),
+               "element_tids": copy(img.element_tids, C.c_uint64, n)}
+        lib.pgv_host_hnsw_image_free(C.byref(img))
+        return out
 
     def build(self, ctx, ops, dtype, lists, rows, tids, samples, rng=None):
         rows = np.ascontiguousarray(rows, dtype=_NP[dtype])

@@ -93,6 +93,43 @@ int			pgv_host_hnsw_build(pgv_hnsw * mirror, pgv_dtype dtype, int dim, const voi
 								int ef_construction, const pgv_rng * rng, int max_batch, pgv_hnsw_built * out);
 void		pgv_host_hnsw_built_free(pgv_hnsw_built * built);
 
+/*
+ * The HNSW index in its on-disk form (src/hnsw.h:40-47, 334-392), either side of the device path.
+ *
+ * pgv_host_hnsw_write_index: FlushPages (src/hnswbuild.c:300-312) from a built graph -- meta page,
+ *   element pages (newest element first, element and neighbor tuple on one page when they fit),
+ *   neighbor tuples.  Rows with dup_of[row] >= 0 contribute only their heap TID to that element.
+ *   rel is declared below (an array of 8 KB pages).
+ * pgv_host_hnsw_stage: one walk over the element pages instead of a tuple at a time
+ *   (HnswLoadElement / HnswLoadNeighborTids, src/hnswutils.c:533-571, :761-794): dense slots in page
+ *   order, vectors, levels, heap TIDs (UINT64_MAX = invalid) and the neighbor table that
+ *   pgv_hnsw_upload + pgv_hnsw_set_graph take.  Deleted elements are left out.
+ */
+struct pgv_rel;
+
+typedef struct pgv_hnsw_image
+{
+	pgv_dtype	dtype;
+	int			dim;
+	int			m;
+	int			ef_construction;
+	int64_t		n;
+	int32_t		entry;			/* slot of the entry point, -1 for an empty index */
+	void	   *vectors;		/* [n x dim] */
+	int32_t    *levels;			/* [n] */
+	int64_t    *nbr_start;		/* [n + 1] */
+	int32_t    *nbr;
+	uint64_t   *heaptids;		/* [n x 10] (block << 16) | offset */
+	uint64_t   *element_tids;	/* [n] index TID of each slot */
+}			pgv_hnsw_image;
+
+int			pgv_host_hnsw_write_index(struct pgv_rel * rel, pgv_dtype dtype, int dim, int m, int ef_construction,
+									  int64_t n, const void *vectors, const uint64_t *tids, const int32_t *levels,
+									  const int64_t *nbr_start, const int32_t *nbr, const int32_t *dup_of,
+									  int32_t entry);
+int			pgv_host_hnsw_stage(const struct pgv_rel * rel, pgv_dtype dtype, pgv_hnsw_image * out);
+void		pgv_host_hnsw_image_free(pgv_hnsw_image * img);
+
 /* ---------------------------------------------------------------- IVFFlat */
 
 /*

@@ -787,3 +787,36 @@ def test_bit_distance_known_answers_and_edges(ctx, oracle):
         assert got[0] == c["value"], (c, got)
     with pytest.raises(api.PgvError):
         api.bit_distance_batch(ctx, 7, 8, np.zeros(1, np.uint8), np.zeros((1, 1), np.uint8))
+
+
+def test_hnsw_build_pages_stage_search_end_to_end(ctx, oracle):
+    """CREATE INDEX ... USING hnsw through the whole chain: GPU build -> FlushPages layout (hnsw_pages.c) ->
+    staged back from the pages like a scan reads them -> device mirror -> pgv_hnsw_search; the results must be
+    those of searching the built arrays directly (only the slot numbering differs)"""
+    from pgvector_amd import _host
+    n, dim, m, efc = 2500, 48, 8, 32
+    data = gen(n, dim, seed=431, dist="clustered", clusters=12)
+    data[100] = data[7]  # one duplicate vector: shares element 7's tuple
+    tids = ((np.arange(n, dtype=np.uint64) + 1) << np.uint64(16)) | np.uint64(1)
+    mirror = api.Hnsw(ctx, api.PGV_L2SQ, api.PGV_F32, dim, data)
+    built = _host.hnsw_build(mirror, data, m, efc, api.make_rng(seed=9), max_batch=32)
+    assert built["dup_of"][100] == 7
+    queries = gen(24, dim, seed=432, dist="clustered", clusters=12)
+    e1, d1, s1 = mirror.search(queries, 40, 10)
+    mirror.close()
+    rel = _host.Relation()
+    rel.write_hnsw(api.PGV_F32, m, efc, data, tids, built["levels"], built["nbr_start"], built["nbr"], built["entry"],
+                   built["dup_of"])
+    img = rel.stage_hnsw(api.PGV_F32)
+    assert img["n"] == n - 1
+    m2 = api.Hnsw(ctx, api.PGV_L2SQ, api.PGV_F32, dim, img["vectors"])
+    m2.set_graph(img["m"], img["entry"], img["levels"], img["nbr_start"], img["nbr"])
+    e2, d2, s2 = m2.search(queries, 40, 10)
+    m2.close()
+    np.testing.assert_array_equal(d1, d2)
+    np.testing.assert_array_equal(s1, s2)
+    # same heap rows: slot -> first heap TID
+    np.testing.assert_array_equal(tids[e1], img["heaptids"][e2, 0])
+    # the duplicate's heap TID rides on element 7's tuple
+    s7 = int(np.nonzero(img["heaptids"][:, 0] == tids[7])[0][0])
+    assert img["heaptids"][s7, 1] == tids[100]

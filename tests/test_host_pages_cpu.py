@@ -125,3 +125,103 @@ def test_bulkdelete_removes_dead_tuples_and_reuses_the_page(dtype, dim):
     assert rel.nblocks == blocks0
     img2 = rel.stage(dtype)
     assert img2.nrows == n - len(dead) + 1 and int(new_tid) in set(int(t) for t in img2.tids[img2.list_offsets[lst]:img2.list_offsets[lst + 1]])
+
+
+# ------------------------------------------------------------------- HNSW pages
+def _random_graph(n, m, seed):
+    """a random but well-formed neighbor table in the HnswNeighborTupleData layout"""
+    rng = np.random.default_rng(seed)
+    levels = np.minimum((-np.log(rng.random(n)) / np.log(m)).astype(np.int32), 5)
+    nbr_start = np.concatenate([[0], np.cumsum((levels.astype(np.int64) + 2) * m)])
+    nbr = np.full(int(nbr_start[-1]), -1, np.int32)
+    for e in range(n):
+        for lc in range(levels[e] + 1):
+            lm = 2 * m if lc == 0 else m
+            pool = np.nonzero(levels >= lc)[0]
+            pool = pool[pool != e]
+            k = int(rng.integers(0, min(lm, len(pool)) + 1))
+            o = int(nbr_start[e]) + (int(levels[e]) - lc) * m
+            nbr[o:o + k] = rng.choice(pool, k, replace=False)
+    entry = int(np.argmax(levels))
+    return levels, nbr_start, nbr, entry
+
+
+@pytest.mark.parametrize("dtype,dim,m", [(0, 3, 4), (0, 128, 16), (0, 1536, 16), (1, 3072, 8), (0, 2000, 5)])
+def test_hnsw_write_then_stage_round_trip(dtype, dim, m):
+    """FlushPages (src/hnswbuild.c:300-312) then the scan-side walk: every element comes back with its
+    level, vector, heap TIDs and neighbors; slots follow page order (newest element first)"""
+    n = 83
+    np_t = np.float32 if dtype == 0 else np.float16
+    vectors = gen(n, dim, seed=7).astype(np_t)
+    tids = ((np.arange(n, dtype=np.uint64) + 5) << np.uint64(16)) | np.uint64(2)
+    levels, nbr_start, nbr, entry = _random_graph(n, m, 11)
+    # rows 10 and 20 are duplicates of element 4: only their heap TIDs are kept
+    dup = np.full(n, -1, np.int32)
+    dup[[10, 20]] = 4
+    for e in range(n):  # nobody may point at a duplicate
+        seg = nbr[nbr_start[e]:nbr_start[e + 1]]
+        seg[np.isin(seg, [10, 20])] = -1
+    rel = _host.Relation()
+    rel.write_hnsw(dtype, m, 64, vectors, tids, levels, nbr_start, nbr, entry, dup)
+    img = rel.stage_hnsw(dtype)
+    kept = [e for e in range(n - 1, -1, -1) if dup[e] < 0]  # page order
+    assert img["n"] == len(kept) and (img["dim"], img["m"], img["ef_construction"]) == (dim, m, 64)
+    slot_of = {e: s for s, e in enumerate(kept)}
+    assert img["entry"] == slot_of[entry]
+    np.testing.assert_array_equal(img["levels"], levels[kept])
+    np.testing.assert_array_equal(img["vectors"].view(np.uint8), vectors[kept].view(np.uint8))
+    np.testing.assert_array_equal(img["heaptids"][:, 0], tids[kept])
+    s4 = slot_of[4]
+    assert img["heaptids"][s4, 1] == tids[10] and img["heaptids"][s4, 2] == tids[20]
+    assert (img["heaptids"][s4, 3:] == np.uint64(0xFFFFFFFFFFFFFFFF)).all()
+    for s, e in enumerate(kept):
+        want = nbr[nbr_start[e]:nbr_start[e + 1]]
+        want = np.array([slot_of[x] if x >= 0 else -1 for x in want], np.int32)
+        np.testing.assert_array_equal(img["nbr"][img["nbr_start"][s]:img["nbr_start"][s + 1]], want)
+
+
+def test_hnsw_page_layout_matches_the_reference_format():
+    """src/hnsw.h:40-47, 334-392: meta page fields, page id 0xFF90, element tuple = 72-byte header + the
+    vector varlena (6224 bytes at 1536-d fp32), neighbor tuple = 4 + 6 * (level + 2) * m,
+    element and neighbor tuple on the same page"""
+    m, n = 16, 12
+    for dim, per_page in [(1536, 1), (128, 10)]:
+        vectors = gen(n, dim, seed=1).astype(np.float32)
+        levels = np.zeros(n, np.int32)
+        nbr_start = np.arange(n + 1, dtype=np.int64) * 2 * m
+        nbr = np.full(n * 2 * m, -1, np.int32)
+        nbr[0] = 1
+        rel = _host.Relation()
+        rel.write_hnsw(0, m, 64, vectors, np.arange(1, n + 1, dtype=np.uint64) << np.uint64(16) | np.uint64(1), levels,
+                       nbr_start, nbr, 3)
+        assert rel.nblocks == 1 + -(-n // per_page), (dim, rel.nblocks)
+        page0 = rel.page(0)
+        magic, version, dims = np.frombuffer(page0[24:36].tobytes(), dtype=np.uint32)
+        mm, efc = np.frombuffer(page0[36:40].tobytes(), dtype=np.uint16)
+        assert (magic, version, dims, mm, efc) == (0xA953A953, 1, dim, m, 64)
+        entry_blk = np.frombuffer(page0[40:44].tobytes(), dtype=np.uint32)[0]
+        entry_off, = np.frombuffer(page0[44:46].tobytes(), dtype=np.uint16)
+        entry_level, = np.frombuffer(page0[46:48].tobytes(), dtype=np.int16)
+        insert_page, = np.frombuffer(page0[48:52].tobytes(), dtype=np.uint32)
+        assert entry_level == 0 and insert_page == rel.nblocks - 1 and entry_blk >= 1 and entry_off >= 1
+        page1 = rel.page(1)
+        assert np.frombuffer(page1[8190:8192].tobytes(), dtype=np.uint16)[0] == 0xFF90
+        lp1, lp2 = np.frombuffer(page1[24:32].tobytes(), dtype=np.uint32)
+        assert lp1 >> 17 == ((72 + 8 + 4 * dim + 7) // 8) * 8 and lp2 >> 17 == 200  # 6224 at 1536-d
+        off1 = int(lp1 & 0x7FFF)
+        etup = page1[off1:off1 + 80]
+        assert etup[0] == 1 and etup[1] == 0 and etup[2] == 0 and etup[3] == 1  # type, level, deleted, version
+        nb_hi, nb_lo, nb_off = np.frombuffer(etup[64:70].tobytes(), dtype=np.uint16)
+        assert (int(nb_hi) << 16 | int(nb_lo), nb_off) == (1, 2)  # its neighbor tuple: same page, next offset
+        vl_len, = np.frombuffer(etup[72:76].tobytes(), dtype=np.uint32)
+        assert vl_len >> 2 == 8 + 4 * dim and np.frombuffer(etup[76:78].tobytes(), dtype=np.int16)[0] == dim
+        ntup = page1[int(lp2 & 0x7FFF):int(lp2 & 0x7FFF) + 8]
+        assert ntup[0] == 2 and np.frombuffer(ntup[2:4].tobytes(), dtype=np.uint16)[0] == 2 * m
+
+
+def test_hnsw_stage_rejects_other_relations():
+    rel = _host.Relation()
+    rel.write_index(0, np.zeros((1, 4), np.float32), np.array([0, 1]), np.zeros((1, 4), np.float32),
+                    np.array([1], np.uint64))
+    with pytest.raises(Exception):
+        rel.stage_hnsw(0)
