@@ -12,8 +12,11 @@
  * way: all of them search the graph as it stood when the batch began (one pgv_hnsw_build_search
  * launch: none of them is linked yet, so none can find another), every distance the selections
  * can need is fetched in one pgv_hnsw_score_pairs launch per phase, and the graph updates are
- * applied one element after the other in heap order -- a legal interleaving of the reference's
- * concurrent workers.  With max_batch = 1 this IS the reference's serial loop.
+ * applied in heap order -- a legal interleaving of the reference's concurrent workers.  With
+ * max_batch = 1 this IS the reference's serial loop.  The host replay itself is spread over
+ * OpenMP threads where the reference's steps are independent of each other (the selections of
+ * different new elements; the updates of different neighbor lists), standing in for its
+ * parallel maintenance workers.
  *
  * Which distances a selection needs depends on its outcome, but never the distances
  * themselves, so they are fetched ahead of the replay: for the candidate list of a new element
@@ -28,8 +31,10 @@
 #include "pgv_host.h"
 
 #include <math.h>
+#include <omp.h>
 #include <stdlib.h>
 #include <string.h>
+#include <time.h>
 
 extern int	pgv_host_fail(int code, const char *fmt,...);
 
@@ -50,14 +55,6 @@ typedef struct
 	cand	   *items;			/* capacity lm */
 }			nlist;
 
-/* an update of a full list that had to wait for distances (see the header comment) */
-typedef struct
-{
-	int32_t		element;
-	float		distance;
-	int32_t		local;
-}			pending;
-
 typedef struct
 {
 	int32_t		level;
@@ -77,8 +74,8 @@ typedef struct
 	int			full;			/* every pair is in mat; otherwise only those with a newcomer (local >= nstart) */
 	int			blocked;		/* an update is waiting for the member-member pairs */
 	float	   *mat;			/* [nlocal x nlocal] */
-	pending    *wait;
-	int			nwait;
+	float	   *newdist;		/* [nlocal - nstart] distance of each newcomer to the owner */
+	int			wait_from;		/* first local whose update waits for the second launch */
 }			record;
 
 typedef struct
@@ -133,6 +130,22 @@ rng_double(rng_state * r)
 	r->s1 = rotl64(x, 37);
 	return ldexp((double) (out >> 12), -52);
 }
+
+static double
+now_secs(void)
+{
+	struct timespec ts;
+
+	clock_gettime(CLOCK_MONOTONIC, &ts);
+	return (double) ts.tv_sec + 1e-9 * (double) ts.tv_nsec;
+}
+
+/* where the wall time of a build goes: out->phase_secs[] */
+enum
+{
+	PH_SEARCH, PH_PAIRS, PH_SELECT, PH_RECORDS, PH_UPDATE, PH_PATCH, PH_COUNT
+};
+#define PHASE(p) do { double t_ = now_secs(); out->phase_secs[cur_phase] += t_ - phase_t0; phase_t0 = t_; cur_phase = (p); } while (0)
 
 static inline int
 layer_m(int m, int lc)
@@ -379,6 +392,10 @@ pgv_host_hnsw_build(pgv_hnsw * mirror, pgv_dtype dtype, int dim, const void *row
 	record	   *recs = NULL;
 	int			recs_cap = 0;
 	int64_t    *rec_of = NULL;	/* hash: (owner, lc) -> record index + 1 */
+	int64_t    *tri_off = NULL;
+	int			nthreads = omp_get_max_threads() < 16 ? omp_get_max_threads() : 16;
+	double		phase_t0 = now_secs();
+	int			cur_phase = PH_RECORDS;
 	int64_t		hash_cap = 0;
 
 	if (!mirror || !out || (n > 0 && !rows))
@@ -481,6 +498,7 @@ pgv_host_hnsw_build(pgv_hnsw * mirror, pgv_dtype dtype, int dim, const void *row
 				lcap = l + 1;
 		}
 
+		PHASE(PH_SEARCH);
 		/* ---- 1. the searches of HnswFindElementNeighbors for the whole batch */
 		{
 			size_t		per = (size_t) B * lcap;
@@ -502,13 +520,16 @@ pgv_host_hnsw_build(pgv_hnsw * mirror, pgv_dtype dtype, int dim, const void *row
 				goto dev_fail;
 		}
 
+		PHASE(PH_PAIRS);
 		/* ---- 2. pairwise distances inside every candidate list that has to be thinned */
 		pb.n = 0;
+		tri_off = realloc(tri_off, sizeof(int64_t) * (size_t) B * lcap);
 		for (int b = 0; b < B; b++)
-			for (int lc = lcap - 1; lc >= 0; lc--)	/* the order step 3 consumes them in */
+			for (int lc = 0; lc < lcap; lc++)
 			{
 				int			nw = sw_cnt[(size_t) b * lcap + lc];
 
+				tri_off[(size_t) b * lcap + lc] = pb.n;
 				if (nw > layer_m(m, lc))
 					if (!pairs_triangle(&pb, sw_ids + ((size_t) b * lcap + lc) * ef_construction, nw))
 					{
@@ -529,9 +550,10 @@ pgv_host_hnsw_build(pgv_hnsw * mirror, pgv_dtype dtype, int dim, const void *row
 			out->device_pairs += pb.n;
 		}
 
-		/* ---- 3. SelectNeighbors + AddConnections per element and layer; duplicates */
+		PHASE(PH_SELECT);
+		/* ---- 3. SelectNeighbors + AddConnections per element and layer (independent: one thread each) */
+#pragma omp parallel if (B >= 8) num_threads(nthreads)
 		{
-			int64_t		tri = 0;
 			float	   *mat = malloc(sizeof(float) * (size_t) ef_construction * ef_construction);
 			cand	   *lw = malloc(sizeof(cand) * (size_t) ef_construction);
 			cand	  **c = malloc(sizeof(cand *) * (size_t) ef_construction * 5);
@@ -541,6 +563,7 @@ pgv_host_hnsw_build(pgv_hnsw * mirror, pgv_dtype dtype, int dim, const void *row
 					  **added = c + 4 * ef_construction;
 			uint8_t    *flag = malloc((size_t) ef_construction);
 
+#pragma omp for schedule(dynamic, 4)
 			for (int b = 0; b < B; b++)
 			{
 				int32_t		e = (int32_t) (i0 + b);
@@ -554,6 +577,8 @@ pgv_host_hnsw_build(pgv_hnsw * mirror, pgv_dtype dtype, int dim, const void *row
 					const int32_t *wi = sw_ids + ((size_t) b * lcap + lc) * ef_construction;
 					const float *wdist = sw_dist + ((size_t) b * lcap + lc) * ef_construction;
 					int			rn;
+					/* not sorted deterministically: the flags of this selection are not reusable (:1143-1144) */
+					uint8_t		closer_set = 0;
 
 					if (nw == 0 || lc > x->level)
 						continue;
@@ -567,17 +592,9 @@ pgv_host_hnsw_build(pgv_hnsw * mirror, pgv_dtype dtype, int dim, const void *row
 						c[i] = &lw[i];
 					}
 					if (nw > lm)
-					{
-						fill_matrix(mat, nw, pdist + tri);
-						tri += (int64_t) nw * (nw - 1) / 2;
-					}
-					{
-						/* not sorted deterministically: the flags of this selection are not reusable (:1143-1144) */
-						uint8_t		closer_set = 0;
-
-						rn = select_neighbors(c, nw, lm, mat, nw, 0, &closer_set, NULL, r, NULL, 0, w, wd, added, flag);
-						x->layers[lc].closer_set = closer_set;
-					}
+						fill_matrix(mat, nw, pdist + tri_off[(size_t) b * lcap + lc]);
+					rn = select_neighbors(c, nw, lm, mat, nw, 0, &closer_set, NULL, r, NULL, 0, w, wd, added, flag);
+					x->layers[lc].closer_set = closer_set;
 					x->layers[lc].items = malloc(sizeof(cand) * (size_t) lm);
 					x->layers[lc].length = rn;
 					for (int i = 0; i < rn; i++)
@@ -586,40 +603,43 @@ pgv_host_hnsw_build(pgv_hnsw * mirror, pgv_dtype dtype, int dim, const void *row
 				for (int lc = 0; lc <= x->level; lc++)
 					if (!x->layers[lc].items)
 						x->layers[lc].items = malloc(sizeof(cand) * (size_t) layer_m(m, lc));
-
-				/* FindDuplicateInMemory, src/hnswbuild.c:313-364: neighbors are ordered by distance */
-				{
-					const nlist *l0 = &x->layers[0];
-					const char *v = (const char *) rows + (size_t) e * item_bytes;
-
-					for (int i = 0; i < l0->length; i++)
-					{
-						int32_t		ne = l0->items[i].element;
-
-						if (memcmp(v, (const char *) rows + (size_t) ne * item_bytes, item_bytes) != 0)
-							break;
-						if (el[ne].heaptids < HNSW_HEAPTIDS)
-						{
-							el[ne].heaptids++;
-							out->dup_of[e] = ne;
-							break;
-						}
-					}
-					if (out->dup_of[e] >= 0)
-					{
-						for (int lc = 0; lc <= x->level; lc++)
-							free(x->layers[lc].items);
-						free(x->layers);
-						x->layers = NULL;
-					}
-				}
 			}
 			free(mat);
 			free(lw);
 			free(c);
 			free(flag);
 		}
+		/* FindDuplicateInMemory, src/hnswbuild.c:313-364, in heap order: neighbors are ordered by distance */
+		for (int b = 0; b < B; b++)
+		{
+			int32_t		e = (int32_t) (i0 + b);
+			elem	   *x = &el[e];
+			const nlist *l0 = &x->layers[0];
+			const char *v = (const char *) rows + (size_t) e * item_bytes;
 
+			for (int i = 0; i < l0->length; i++)
+			{
+				int32_t		ne = l0->items[i].element;
+
+				if (memcmp(v, (const char *) rows + (size_t) ne * item_bytes, item_bytes) != 0)
+					break;
+				if (el[ne].heaptids < HNSW_HEAPTIDS)
+				{
+					el[ne].heaptids++;
+					out->dup_of[e] = ne;
+					break;
+				}
+			}
+			if (out->dup_of[e] >= 0)
+			{
+				for (int lc = 0; lc <= x->level; lc++)
+					free(x->layers[lc].items);
+				free(x->layers);
+				x->layers = NULL;
+			}
+		}
+
+		PHASE(PH_RECORDS);
 		/* ---- 4. the lists this batch links into, and every distance their re-selections can look up */
 		pb.n = 0;
 		for (int b = 0; b < B; b++)
@@ -629,6 +649,12 @@ pgv_host_hnsw_build(pgv_hnsw * mirror, pgv_dtype dtype, int dim, const void *row
 
 			if (!x->layers)
 				continue;
+			linked++;
+			if (!is_dirty[e])
+			{
+				is_dirty[e] = 1;
+				ndirty++;
+			}
 			for (int lc = x->level; lc >= 0; lc--)
 				for (int i = 0; i < x->layers[lc].length; i++)
 				{
@@ -654,11 +680,11 @@ pgv_host_hnsw_build(pgv_hnsw * mirror, pgv_dtype dtype, int dim, const void *row
 						rcd->nstart = l->length;
 						rcd->nlocal = l->length;
 						rcd->ids = malloc(sizeof(int32_t) * (size_t) (l->length + B));
+						rcd->newdist = malloc(sizeof(float) * (size_t) B);
 						rcd->mat = NULL;
 						rcd->full = !l->closer_set;	/* no cached flags: its next selection computes everything */
 						rcd->blocked = 0;
-						rcd->wait = NULL;
-						rcd->nwait = 0;
+						rcd->wait_from = -1;
 						for (int j = 0; j < l->length; j++)
 						{
 							rcd->ids[j] = l->items[j].element;
@@ -670,10 +696,20 @@ pgv_host_hnsw_build(pgv_hnsw * mirror, pgv_dtype dtype, int dim, const void *row
 							rc = pgv_host_fail(PGV_ERR_STATE, "batch touches too many lists");
 							goto done;
 						}
+						if (!is_dirty[owner])
+						{
+							is_dirty[owner] = 1;
+							ndirty++;
+						}
 					}
 					rcd = &recs[rec_of[h] - 1];
+					/* the newcomers of a list, in the order the reference's loop would link them */
+					rcd->newdist[rcd->nlocal - rcd->nstart] = x->layers[lc].items[i].distance;
 					rcd->ids[rcd->nlocal++] = e;
 				}
+			/* the entry point moves up with the tallest element (src/hnswbuild.c:425-430) */
+			if (x->level > el[entry].level)
+				entry = e;
 		}
 		for (int k = 0; k < nrec; k++)
 		{
@@ -710,6 +746,7 @@ pgv_host_hnsw_build(pgv_hnsw * mirror, pgv_dtype dtype, int dim, const void *row
 				}
 			}
 		}
+		PHASE(PH_PAIRS);
 		if (pb.n > pdist_cap)
 		{
 			pdist_cap = pb.n * 2;
@@ -722,113 +759,121 @@ pgv_host_hnsw_build(pgv_hnsw * mirror, pgv_dtype dtype, int dim, const void *row
 				goto dev_fail;
 			out->device_pairs += pb.n;
 		}
-		for (int k = 0; k < nrec; k++)
+		PHASE(PH_UPDATE);
+
+		/* ---- 5. HnswUpdateNeighborsInMemory (src/hnswbuild.c:376-405).  The reference links one element after
+		 * the other; updates of different lists do not see each other, so the lists are replayed in parallel,
+		 * each with its newcomers in heap order. */
 		{
-			record	   *rcd = &recs[k];
-
-			if (rcd->nlocal > layer_m(m, rcd->lc))
-			{
-				rcd->mat = calloc((size_t) rcd->nlocal * rcd->nlocal, sizeof(float));
-				if (rcd->full)
-					fill_matrix(rcd->mat, rcd->nlocal, pdist + rcd->pair0);
-				else
-				{
-					int64_t		t = rcd->pair0;
-
-					for (int u = rcd->nstart; u < rcd->nlocal; u++)
-						for (int v = 0; v < u; v++, t++)
-							rcd->mat[(size_t) u * rcd->nlocal + v] = rcd->mat[(size_t) v * rcd->nlocal + u] = pdist[t];
-				}
-			}
-		}
-
-		/* ---- 5. HnswUpdateNeighborsInMemory, one element after the other (src/hnswbuild.c:376-405) */
-		{
-			int			lm0 = layer_m(m, 0);
-			cand	  **c = malloc(sizeof(cand *) * (size_t) (lm0 + 1) * 5);
-			cand	  **r = c + (lm0 + 1),
-					  **w = c + 2 * (lm0 + 1),
-					  **wd = c + 3 * (lm0 + 1),
-					  **added = c + 4 * (lm0 + 1);
-			uint8_t    *flag = malloc((size_t) lm0 + 1);
-			int		   *next_local = calloc((size_t) (nrec > 0 ? nrec : 1), sizeof(int));
 			int			nblocked = 0;
 
-			for (int k = 0; k < nrec; k++)
-				next_local[k] = recs[k].nstart;
-			for (int b = 0; b < B; b++)
+			for (int pass = 0; pass < 2; pass++)
 			{
-				int32_t		e = (int32_t) (i0 + b);
-				elem	   *x = &el[e];
-
-				if (!x->layers)
-					continue;
-				linked++;
-				if (!is_dirty[e])
+				if (pass == 1)
 				{
-					is_dirty[e] = 1;
-					ndirty++;
-				}
-				for (int lc = x->level; lc >= 0; lc--)
-				{
-					int			lm = layer_m(m, lc);
-
-					for (int i = 0; i < x->layers[lc].length; i++)
+					/* ---- 5b. the updates that were put aside: their lists' member-member pairs, then the replay */
+					if (nblocked == 0)
+						break;
+					pb.n = 0;
+					for (int k = 0; k < nrec; k++)
+						if (recs[k].blocked)
+						{
+							recs[k].pair0 = pb.n;
+							if (!pairs_triangle(&pb, recs[k].ids, recs[k].nstart))
+							{
+								rc = pgv_host_fail(PGV_ERR_NOMEM, "out of memory");
+								goto done;
+							}
+						}
+					if (pb.n > pdist_cap)
 					{
-						cand		hc = x->layers[lc].items[i];
-						int32_t		owner = hc.element;
-						uint64_t	key = ((uint64_t) owner << 6) | (uint64_t) lc;
-						int64_t		h = (int64_t) ((key * 0x9E3779B97F4A7C15ull) >> 40) & (hash_cap - 1);
-						record	   *rcd;
-						nlist	   *l = &el[owner].layers[lc];
-						cand		new_hc;
+						pdist_cap = pb.n * 2;
+						pdist = realloc(pdist, sizeof(float) * (size_t) pdist_cap);
+					}
+					rc = pgv_hnsw_score_pairs(mirror, pb.a, pb.b, pb.n, pdist);
+					if (rc != PGV_OK)
+						goto dev_fail;
+					out->device_pairs += pb.n;
+					out->deferred_updates += nblocked;
+				}
+#pragma omp parallel if (B >= 8) num_threads(nthreads)
+				{
+					int			lm0 = layer_m(m, 0);
+					cand	  **c = malloc(sizeof(cand *) * (size_t) (lm0 + 1) * 5);
+					cand	  **r = c + (lm0 + 1),
+							  **w = c + 2 * (lm0 + 1),
+							  **wd = c + 3 * (lm0 + 1),
+							  **added = c + 4 * (lm0 + 1);
+					uint8_t    *flag = malloc((size_t) lm0 + 1);
 
-						while (!(recs[rec_of[h] - 1].owner == owner && recs[rec_of[h] - 1].lc == lc))
-							h = (h + 1) & (hash_cap - 1);
-						rcd = &recs[rec_of[h] - 1];
-						new_hc.element = e;
-						new_hc.distance = hc.distance;
-						new_hc.local = next_local[rec_of[h] - 1]++;	/* the order step 4 appended them in */
-						new_hc.closer = 0;
-						if (!is_dirty[owner])
+#pragma omp for schedule(dynamic, 16) reduction(+:nblocked)
+					for (int k = 0; k < nrec; k++)
+					{
+						record	   *rcd = &recs[k];
+						nlist	   *l = &el[rcd->owner].layers[rcd->lc];
+						int			lm = layer_m(m, rcd->lc);
+						int			from = rcd->nstart;
+
+						if (pass == 0)
 						{
-							is_dirty[owner] = 1;
-							ndirty++;
+							if (rcd->nlocal > lm)
+							{
+								rcd->mat = calloc((size_t) rcd->nlocal * rcd->nlocal, sizeof(float));
+								if (rcd->full)
+									fill_matrix(rcd->mat, rcd->nlocal, pdist + rcd->pair0);
+								else
+								{
+									int64_t		t = rcd->pair0;
+
+									for (int u = rcd->nstart; u < rcd->nlocal; u++)
+										for (int v = 0; v < u; v++, t++)
+											rcd->mat[(size_t) u * rcd->nlocal + v] = rcd->mat[(size_t) v * rcd->nlocal + u] = pdist[t];
+								}
+							}
 						}
-						/* HnswUpdateConnection, src/hnswutils.c:1183-1231 */
-						if (l->length < lm)
+						else
 						{
-							l->items[l->length++] = new_hc;
-							continue;
-						}
-						{
-							int			nc = l->length + 1;
-							cand	   *pruned = NULL;
-							int			rn = -1;
+							int64_t		t = rcd->pair0;
 
 							if (!rcd->blocked)
+								continue;
+							for (int u = 0; u < rcd->nstart; u++)
+								for (int v = u + 1; v < rcd->nstart; v++, t++)
+									rcd->mat[(size_t) u * rcd->nlocal + v] = rcd->mat[(size_t) v * rcd->nlocal + u] = pdist[t];
+							rcd->full = 1;
+							from = rcd->wait_from;
+						}
+						for (int u = from; u < rcd->nlocal; u++)
+						{
+							cand		new_hc;
+							cand	   *pruned = NULL;
+							int			nc,
+										rn;
+
+							new_hc.element = rcd->ids[u];
+							new_hc.distance = rcd->newdist[u - rcd->nstart];
+							new_hc.local = u;
+							new_hc.closer = 0;
+							/* HnswUpdateConnection, src/hnswutils.c:1183-1231 */
+							if (l->length < lm)
 							{
-								for (int j = 0; j < l->length; j++)
-									c[j] = &l->items[j];
-								c[nc - 1] = &new_hc;
-								rn = select_neighbors(c, nc, lm, rcd->mat, rcd->nlocal, rcd->full ? 0 : rcd->nstart,
-													  &l->closer_set, &new_hc, r, &pruned, 1, w, wd, added, flag);
+								l->items[l->length++] = new_hc;
+								continue;
 							}
+							nc = l->length + 1;
+							for (int j = 0; j < l->length; j++)
+								c[j] = &l->items[j];
+							c[nc - 1] = &new_hc;
+							rn = select_neighbors(c, nc, lm, rcd->mat, rcd->nlocal, rcd->full ? 0 : rcd->nstart,
+												  &l->closer_set, &new_hc, r, &pruned, 1, w, wd, added, flag);
 							if (rn < 0)
 							{
 								/* needs member-member distances that were not fetched: this and every later
 								 * update of the list wait for the second launch */
-								if (!rcd->blocked)
-								{
-									rcd->blocked = 1;
-									nblocked++;
-								}
-								rcd->wait = realloc(rcd->wait, sizeof(pending) * (size_t) (rcd->nwait + 1));
-								rcd->wait[rcd->nwait].element = e;
-								rcd->wait[rcd->nwait].distance = new_hc.distance;
-								rcd->wait[rcd->nwait].local = new_hc.local;
-								rcd->nwait++;
-								continue;
+								rcd->blocked = 1;
+								rcd->wait_from = u;
+								nblocked++;
+								break;
 							}
 							if (pruned != NULL && pruned != &new_hc)
 								for (int j = 0; j < l->length; j++)
@@ -839,81 +884,13 @@ pgv_host_hnsw_build(pgv_hnsw * mirror, pgv_dtype dtype, int dim, const void *row
 									}
 						}
 					}
-				}
-				/* the entry point moves up with the tallest element (src/hnswbuild.c:425-430) */
-				if (x->level > el[entry].level)
-					entry = e;
-			}
-			/* ---- 5b. the updates that were put aside: fetch their lists' member-member pairs, replay in order */
-			if (nblocked > 0)
-			{
-				pb.n = 0;
-				for (int k = 0; k < nrec; k++)
-					if (recs[k].blocked)
-					{
-						recs[k].pair0 = pb.n;
-						if (!pairs_triangle(&pb, recs[k].ids, recs[k].nstart))
-						{
-							rc = pgv_host_fail(PGV_ERR_NOMEM, "out of memory");
-							goto done;
-						}
-					}
-				if (pb.n > pdist_cap)
-				{
-					pdist_cap = pb.n * 2;
-					pdist = realloc(pdist, sizeof(float) * (size_t) pdist_cap);
-				}
-				rc = pgv_hnsw_score_pairs(mirror, pb.a, pb.b, pb.n, pdist);
-				if (rc != PGV_OK)
-					goto dev_fail;
-				out->device_pairs += pb.n;
-				out->deferred_updates += nblocked;
-				for (int k = 0; k < nrec; k++)
-				{
-					record	   *rcd = &recs[k];
-					nlist	   *l;
-					int64_t		t;
-					int			lm;
-
-					if (!rcd->blocked)
-						continue;
-					t = rcd->pair0;
-					for (int u = 0; u < rcd->nstart; u++)
-						for (int v = u + 1; v < rcd->nstart; v++, t++)
-							rcd->mat[(size_t) u * rcd->nlocal + v] = rcd->mat[(size_t) v * rcd->nlocal + u] = pdist[t];
-					rcd->full = 1;
-					l = &el[rcd->owner].layers[rcd->lc];
-					lm = layer_m(m, rcd->lc);
-					for (int q = 0; q < rcd->nwait; q++)
-					{
-						cand		new_hc;
-						cand	   *pruned = NULL;
-						int			nc = l->length + 1;
-
-						new_hc.element = rcd->wait[q].element;
-						new_hc.distance = rcd->wait[q].distance;
-						new_hc.local = rcd->wait[q].local;
-						new_hc.closer = 0;
-						for (int j = 0; j < l->length; j++)
-							c[j] = &l->items[j];
-						c[nc - 1] = &new_hc;
-						select_neighbors(c, nc, lm, rcd->mat, rcd->nlocal, 0, &l->closer_set, &new_hc, r, &pruned, 1,
-										 w, wd, added, flag);
-						if (pruned != NULL && pruned != &new_hc)
-							for (int j = 0; j < l->length; j++)
-								if (l->items[j].element == pruned->element)
-								{
-									l->items[j] = new_hc;
-									break;
-								}
-					}
+					free(c);
+					free(flag);
 				}
 			}
-			free(next_local);
-			free(c);
-			free(flag);
 		}
 
+		PHASE(PH_PATCH);
 		/* ---- 6. the graph the next batch searches */
 		{
 			int			k = 0;
@@ -958,8 +935,9 @@ pgv_host_hnsw_build(pgv_hnsw * mirror, pgv_dtype dtype, int dim, const void *row
 		{
 			free(recs[k].ids);
 			free(recs[k].mat);
-			free(recs[k].wait);
+			free(recs[k].newdist);
 		}
+		PHASE(PH_RECORDS);
 		memset(rec_of, 0, sizeof(int64_t) * (size_t) hash_cap);
 		i0 += B;
 		out->batches++;
@@ -994,6 +972,7 @@ done:
 	free(is_dirty);
 	free(recs);
 	free(rec_of);
+	free(tri_off);
 	if (rc != PGV_OK)
 		pgv_host_hnsw_built_free(out);
 	return rc;

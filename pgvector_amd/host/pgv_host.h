@@ -87,6 +87,7 @@ typedef struct pgv_hnsw_built
 	int64_t		device_pairs;	/* element pairs scored for SelectNeighbors */
 	int64_t		batches;
 	int64_t		deferred_updates;	/* lists whose re-selection needed a second distance launch */
+	double		phase_secs[6];	/* wall time: search, pair scoring, SelectNeighbors, bookkeeping, list updates, graph patch */
 }			pgv_hnsw_built;
 
 int			pgv_host_hnsw_build(pgv_hnsw * mirror, pgv_dtype dtype, int dim, const void *rows, int64_t n, int m,

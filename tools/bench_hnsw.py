@@ -74,7 +74,7 @@ def big(a):
         "algorithmic_GBps": float(scored.sum().item()) * a.dim * 4 / dev_s / 1e9,
         "gpu_build": {"secs": build_s, "max_batch": a.gpu_build or 256, "batches": built["batches"],
                       "elements": built["nelements"], "pairs_scored": built["device_pairs"],
-                      "deferred_updates": built["deferred_updates"]}}))
+                      "deferred_updates": built["deferred_updates"], "phase_secs": built["phase_secs"]}}))
 
 
 def main():
