@@ -1,0 +1,325 @@
+/*
+ * host_logic_driver.c -- the C host glue (libpgv_host.so) exercised on the CPU against the
+ * stand-in device of mock_hip.c: what is tested is the HOST LOGIC around the distance calls --
+ * the HNSW build loop against the oracle's graph, the IVFFlat build / stage / scan / iterative
+ * scan drivers, vacuum and the self-invalidating mirror -- none of which needs a GPU to be wrong.
+ *
+ * TEST INFRASTRUCTURE (compiled and run by tests/test_host_logic_cpu.py).  Exit status 0 and
+ * "HOST-LOGIC OK" on success.
+ */
+#include <math.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include "pgv_hip.h"
+#include "pgv_host.h"
+#include "pgv_oracle.h"
+
+#define CHECK(call) do { int rc_ = (call); if (rc_ != PGV_OK) { \
+	fprintf(stderr, "%s:%d: %s -> %d: %s / %s\n", __FILE__, __LINE__, #call, rc_, pgv_last_error(), pgv_host_last_error()); \
+	return 1; } } while (0)
+#define EXPECT(cond) do { if (!(cond)) { fprintf(stderr, "%s:%d: EXPECT(%s) failed\n", __FILE__, __LINE__, #cond); return 1; } } while (0)
+
+static uint64_t lcg = 12345;
+static uint32_t
+urand(void)
+{
+	lcg = lcg * 6364136223846793005ull + 1442695040888963407ull;
+	return (uint32_t) (lcg >> 33);
+}
+
+static float
+l2sq(const float *a, const float *b, int dim)
+{
+	float		s = 0.0f;
+
+	for (int i = 0; i < dim; i++)
+		s += (a[i] - b[i]) * (a[i] - b[i]);
+	return s;
+}
+
+/* ---- HNSW: the serial build reproduces the oracle's graph; a batched build searches as well */
+static int
+test_hnsw_build(void)
+{
+	enum { N = 900, DIM = 8, M = 6, EFC = 24 };
+	float	   *data = malloc(sizeof(float) * N * DIM);
+	pgv_ctx    *ctx;
+	pgv_hnsw   *mirror;
+	pgv_hnsw_built built;
+	ora_hnsw   *g;
+	ora_prng	st;
+	pgv_rng		rng;
+	int			same = 0,
+				entry_level;
+	int32_t		buf[2 * M];
+
+	/* integer coordinates < 1024 in 8 dimensions: every distance is exact in fp32, ties are rare */
+	for (int i = 0; i < N * DIM; i++)
+		data[i] = (float) (urand() % 1024);
+	CHECK(pgv_ctx_create(0, NULL, &ctx));
+	CHECK(pgv_hnsw_upload(ctx, PGV_L2SQ, PGV_F32, DIM, data, N, &mirror));
+	g = ora_hnsw_build(ORA_OPS_L2, ORA_F32, DIM, data, N, M, EFC, 21);
+	EXPECT(ora_hnsw_num_elements(g) == N);
+	ora_prng_seed(&st, 21);
+	rng.next_double = ora_prng_double_cb;
+	rng.next_u32 = ora_prng_u32_cb;
+	rng.state = &st;
+	rng.seed = 0;
+	CHECK(pgv_host_hnsw_build(mirror, PGV_F32, DIM, data, N, M, EFC, &rng, 1, &built));
+	EXPECT(built.nelements == N && built.batches == N);
+	EXPECT(built.entry == ora_hnsw_entry_point(g, &entry_level));
+	for (int e = 0; e < N; e++)
+	{
+		int			ok = built.levels[e] == ora_hnsw_level(g, e);
+
+		EXPECT(ok);
+		for (int lc = 0; lc <= built.levels[e] && ok; lc++)
+		{
+			int			lm = lc == 0 ? 2 * M : M;
+			int			cnt = ora_hnsw_neighbors(g, e, lc, buf);
+			const int32_t *mine = built.nbr + built.nbr_start[e] + (int64_t) (built.levels[e] - lc) * M;
+
+			for (int i = 0; i < lm && ok; i++)
+				ok = mine[i] == (i < cnt ? buf[i] : -1);
+		}
+		same += ok;
+	}
+	/* only the order in which tied candidates are walked may differ (unspecified in the reference) */
+	EXPECT(same >= N * 99 / 100);
+	pgv_host_hnsw_built_free(&built);
+
+	/* batched inserts: structurally sound and every element reachable enough to find itself */
+	CHECK(pgv_host_hnsw_build(mirror, PGV_F32, DIM, data, N, M, EFC, NULL, 32, &built));
+	EXPECT(built.nelements == N && built.batches < N / 4);
+	for (int e = 0; e < N; e++)
+		for (int lc = 0; lc <= built.levels[e]; lc++)
+		{
+			int			lm = lc == 0 ? 2 * M : M;
+			const int32_t *mine = built.nbr + built.nbr_start[e] + (int64_t) (built.levels[e] - lc) * M;
+
+			for (int i = 0; i < lm; i++)
+			{
+				EXPECT(mine[i] >= -1 && mine[i] < N && mine[i] != e);
+				if (mine[i] >= 0)
+					EXPECT(built.levels[mine[i]] >= lc);
+				for (int j = 0; j < i; j++)
+					EXPECT(mine[i] < 0 || mine[i] != mine[j]);
+			}
+		}
+	{
+		/* search the built graph with the host-driven walk: a stored vector finds itself first */
+		pgv_hnsw_graph graph = {N, M, built.entry, built.levels, built.nbr_start, built.nbr};
+		int64_t		elem[16 * 5],
+					scored[16];
+		float		d[16 * 5];
+		int			found = 0;
+
+		CHECK(pgv_host_hnsw_search(mirror, &graph, PGV_F32, DIM, data + 100 * DIM, 16, 40, 5, elem, d, scored));
+		for (int q = 0; q < 16; q++)
+			found += elem[q * 5] == 100 + q && d[q * 5] == 0.0f;
+		EXPECT(found >= 15);
+	}
+	pgv_host_hnsw_built_free(&built);
+
+	/* the on-disk form and back: same graph under the slot renumbering */
+	{
+		pgv_rel		rel;
+		pgv_hnsw_image img;
+		uint64_t   *tids = malloc(sizeof(uint64_t) * N);
+
+		for (int i = 0; i < N; i++)
+			tids[i] = ((uint64_t) (i + 1) << 16) | 1;
+		CHECK(pgv_host_hnsw_build(mirror, PGV_F32, DIM, data, N, M, EFC, NULL, 8, &built));
+		pgv_rel_init(&rel);
+		CHECK(pgv_host_hnsw_write_index(&rel, PGV_F32, DIM, M, EFC, N, data, tids, built.levels, built.nbr_start,
+										built.nbr, built.dup_of, built.entry));
+		CHECK(pgv_host_hnsw_stage(&rel, PGV_F32, &img));
+		EXPECT(img.n == N && img.m == M && img.dim == DIM);
+		EXPECT(img.entry == N - 1 - built.entry);	/* slots are page order: newest element first */
+		for (int s = 0; s < N; s++)
+		{
+			int			e = N - 1 - s;
+
+			EXPECT(img.levels[s] == built.levels[e] && img.heaptids[(size_t) s * 10] == tids[e]);
+			EXPECT(memcmp((float *) img.vectors + (size_t) s * DIM, data + (size_t) e * DIM, sizeof(float) * DIM) == 0);
+			for (int64_t j = 0; j < img.nbr_start[s + 1] - img.nbr_start[s]; j++)
+			{
+				int32_t		want = built.nbr[built.nbr_start[e] + j];
+
+				EXPECT(img.nbr[img.nbr_start[s] + j] == (want < 0 ? -1 : N - 1 - want));
+			}
+		}
+		pgv_host_hnsw_image_free(&img);
+		pgv_rel_free(&rel);
+		pgv_host_hnsw_built_free(&built);
+		free(tids);
+	}
+	ora_hnsw_free(g);
+	pgv_hnsw_free(mirror);
+	pgv_ctx_destroy(ctx);
+	free(data);
+	return 0;
+}
+
+/* ---- IVFFlat: build -> pages -> mirror -> amgettuple, iterative scan, insert, vacuum */
+static int		dead_set[16];
+static int		ndead;
+static int
+is_dead(uint64_t tid, void *state)
+{
+	(void) state;
+	for (int i = 0; i < ndead; i++)
+		if ((uint64_t) dead_set[i] == tid)
+			return 1;
+	return 0;
+}
+
+static int
+test_ivf(void)
+{
+	enum { N = 3000, DIM = 24, LISTS = 12, K = 8 };
+	float	   *rows = malloc(sizeof(float) * N * DIM);
+	uint64_t   *tids = malloc(sizeof(uint64_t) * N);
+	pgv_ctx    *ctx;
+	pgv_rel		rel;
+	pgv_ivf_mirror *mirror;
+	pgv_index  *ix;
+	const pgv_ivf_image *img;
+	pgv_ivf_scan *scan;
+	float		q[DIM];
+
+	for (int i = 0; i < N; i++)
+	{
+		for (int d = 0; d < DIM; d++)
+			rows[i * DIM + d] = (float) ((i % 12) * 3 + (d % 4)) + (float) (urand() % 1000) / 2000.0f;
+		tids[i] = (uint64_t) (i + 1);
+	}
+	CHECK(pgv_ctx_create(0, NULL, &ctx));
+	pgv_rel_init(&rel);
+	CHECK(pgv_host_ivf_build(ctx, PGV_OPS_L2, PGV_F32, DIM, LISTS, rows, tids, N, rows, N, NULL, &rel));
+	CHECK(pgv_host_ivf_mirror_open(ctx, PGV_L2SQ, PGV_F32, &mirror));
+	CHECK(pgv_host_ivf_mirror_get(mirror, &rel, &ix, &img));
+	EXPECT(img->nrows == N && img->lists == LISTS && pgv_host_ivf_mirror_restages(mirror) == 1);
+	/* every row landed in the list of its nearest center (AddTupleToSort) */
+	for (int l = 0; l < LISTS; l++)
+		for (int64_t r = img->list_offsets[l]; r < img->list_offsets[l + 1]; r += 97)
+		{
+			const float *v = (const float *) img->vectors + (size_t) r * DIM;
+			float		mine = l2sq(v, (const float *) img->centers + (size_t) l * DIM, DIM);
+
+			for (int c = 0; c < LISTS; c++)
+				EXPECT(l2sq(v, (const float *) img->centers + (size_t) c * DIM, DIM) >= mine);
+		}
+
+	/* probes = lists: the scan is exact; ascending; every TID once */
+	for (int d = 0; d < DIM; d++)
+		q[d] = rows[77 * DIM + d] + 0.01f;
+	CHECK(pgv_host_ivf_beginscan(ix, img, LISTS, 0, 0, 0, &scan));
+	CHECK(pgv_host_ivf_rescan(scan, q));
+	{
+		double		prev = -1;
+		int			count = 0;
+		uint64_t	tid;
+		double		dist;
+		float		best = INFINITY;
+
+		for (int i = 0; i < N; i++)
+			if (l2sq(rows + i * DIM, q, DIM) < best)
+				best = l2sq(rows + i * DIM, q, DIM);
+		while (pgv_host_ivf_gettuple(scan, &tid, &dist) == 1)
+		{
+			EXPECT(dist >= prev);
+			if (count == 0)
+				EXPECT(tid == 78 && fabs(dist - (double) best) <= 1e-5 * best);
+			prev = dist;
+			count++;
+		}
+		EXPECT(count == N);
+	}
+	pgv_host_ivf_endscan(scan);
+
+	/* iterative scan (relaxed order): probes = 1, max_probes = lists -> still every tuple, in batches */
+	CHECK(pgv_host_ivf_beginscan(ix, img, 1, LISTS, 1, 0, &scan));
+	CHECK(pgv_host_ivf_rescan(scan, q));
+	{
+		int			count = 0;
+		uint64_t	tid;
+		double		dist;
+
+		while (pgv_host_ivf_gettuple(scan, &tid, &dist) == 1)
+			count++;
+		EXPECT(count == N);
+	}
+	/* a NULL query: every tuple of the probed lists at distance 0 (ZeroDistance, src/ivfscan.c:192-196) */
+	CHECK(pgv_host_ivf_rescan(scan, NULL));
+	{
+		uint64_t	tid;
+		double		dist;
+
+		EXPECT(pgv_host_ivf_gettuple(scan, &tid, &dist) == 1 && dist == 0.0);
+	}
+	pgv_host_ivf_endscan(scan);
+
+	/* insert + vacuum invalidate the mirror; an unchanged relation does not */
+	CHECK(pgv_host_ivf_mirror_get(mirror, &rel, &ix, &img));
+	EXPECT(pgv_host_ivf_mirror_restages(mirror) == 1);
+	{
+		int32_t		lst;
+
+		CHECK(pgv_assign(ctx, PGV_L2SQ, PGV_F32, DIM, img->centers, LISTS, q, 1, &lst, NULL));
+		CHECK(pgv_host_ivf_insert(&rel, PGV_F32, lst, q, 999999));
+	}
+	CHECK(pgv_host_ivf_mirror_get(mirror, &rel, &ix, &img));
+	EXPECT(pgv_host_ivf_mirror_restages(mirror) == 2 && img->nrows == N + 1);
+	CHECK(pgv_host_ivf_beginscan(ix, img, 3, 0, 0, 0, &scan));
+	CHECK(pgv_host_ivf_rescan(scan, q));
+	{
+		uint64_t	tid;
+		double		dist;
+
+		EXPECT(pgv_host_ivf_gettuple(scan, &tid, &dist) == 1 && tid == 999999 && dist == 0.0);
+		EXPECT(pgv_host_ivf_gettuple(scan, &tid, &dist) == 1 && tid == 78);
+	}
+	pgv_host_ivf_endscan(scan);
+	{
+		int64_t		removed,
+					remaining;
+
+		dead_set[0] = 999999;
+		dead_set[1] = 78;
+		ndead = 2;
+		CHECK(pgv_host_ivf_bulkdelete(&rel, is_dead, NULL, &removed, &remaining));
+		EXPECT(removed == 2 && remaining == N - 1);
+	}
+	CHECK(pgv_host_ivf_mirror_get(mirror, &rel, &ix, &img));
+	EXPECT(pgv_host_ivf_mirror_restages(mirror) == 3 && img->nrows == N - 1);
+	CHECK(pgv_host_ivf_beginscan(ix, img, 3, 0, 0, 0, &scan));
+	CHECK(pgv_host_ivf_rescan(scan, q));
+	{
+		uint64_t	tid;
+		double		dist;
+
+		EXPECT(pgv_host_ivf_gettuple(scan, &tid, &dist) == 1 && tid != 999999 && tid != 78 && dist > 0.0);
+	}
+	pgv_host_ivf_endscan(scan);
+	pgv_host_ivf_mirror_close(mirror);
+	pgv_rel_free(&rel);
+	pgv_ctx_destroy(ctx);
+	free(rows);
+	free(tids);
+	return 0;
+}
+
+int
+main(void)
+{
+	if (test_hnsw_build())
+		return 1;
+	if (test_ivf())
+		return 1;
+	printf("HOST-LOGIC OK\n");
+	return 0;
+}

@@ -1,0 +1,464 @@
+/*
+ * mock_hip.c -- a CPU stand-in for the entry points of libpgv_hip.so that the C host glue
+ * (pgvector_amd/host) calls, so that the HOST LOGIC -- page formats, scan driver, build loops,
+ * mirror lifecycle -- can be tested where there is no GPU.
+ *
+ * TEST INFRASTRUCTURE ONLY.  It is linked into tests/c/host_logic_driver ahead of the real
+ * library so that its symbols win; it never ships, the product has no CPU path.  Plain loops in
+ * fp32, the simplest implementation that honours each entry point's contract in
+ * include/pgv_hip.h; parity of the distances themselves is the GPU tests' business.
+ */
+#include <math.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include "pgv_hip.h"
+
+static char mock_err[256];
+
+const char *
+pgv_last_error(void)
+{
+	return mock_err;
+}
+
+static int
+fail(int code, const char *msg)
+{
+	snprintf(mock_err, sizeof(mock_err), "%s", msg);
+	return code;
+}
+
+struct pgv_ctx
+{
+	int			dummy;
+};
+
+struct pgv_index
+{
+	pgv_metric	metric;
+	int			dim,
+				nlists;
+	int64_t		n;
+	float	   *centers,
+			   *vectors;
+	int64_t    *offsets;
+};
+
+struct pgv_hnsw
+{
+	pgv_metric	metric;
+	int			dim;
+	int64_t		n;
+	float	   *vectors;
+	int			m;
+	int32_t		entry;
+	int32_t    *levels;
+	int64_t    *nbr_start;
+	int32_t    *nbr;
+};
+
+int
+pgv_ctx_create(int device, void *stream, pgv_ctx * *out)
+{
+	(void) device;
+	(void) stream;
+	*out = calloc(1, sizeof(pgv_ctx));
+	return PGV_OK;
+}
+
+void
+pgv_ctx_destroy(pgv_ctx * ctx)
+{
+	free(ctx);
+}
+
+static float
+dist(pgv_metric metric, int dim, const float *a, const float *b)
+{
+	float		s = 0.0f;
+
+	for (int i = 0; i < dim; i++)
+	{
+		if (metric == PGV_L2SQ)
+			s += (a[i] - b[i]) * (a[i] - b[i]);
+		else if (metric == PGV_NEG_IP)
+			s += a[i] * b[i];
+		else
+			s += fabsf(a[i] - b[i]);
+	}
+	return metric == PGV_NEG_IP ? -s : s;
+}
+
+/* ------------------------------------------------------------------ IVFFlat */
+
+int
+pgv_index_upload(pgv_ctx * ctx, pgv_metric metric, pgv_dtype dtype, int dim, int nlists,
+				 const void *centers, const int64_t *list_offsets, const void *vectors, const uint64_t *tids,
+				 pgv_index * *out)
+{
+	pgv_index  *ix;
+	int64_t		n = list_offsets[nlists];
+
+	(void) ctx;
+	(void) tids;
+	if (dtype != PGV_F32)
+		return fail(PGV_ERR_ARG, "mock: fp32 only");
+	ix = calloc(1, sizeof(*ix));
+	ix->metric = metric;
+	ix->dim = dim;
+	ix->nlists = nlists;
+	ix->n = n;
+	ix->centers = malloc(sizeof(float) * (size_t) nlists * dim);
+	memcpy(ix->centers, centers, sizeof(float) * (size_t) nlists * dim);
+	ix->offsets = malloc(sizeof(int64_t) * (size_t) (nlists + 1));
+	memcpy(ix->offsets, list_offsets, sizeof(int64_t) * (size_t) (nlists + 1));
+	ix->vectors = malloc(sizeof(float) * (size_t) (n > 0 ? n : 1) * dim);
+	memcpy(ix->vectors, vectors, sizeof(float) * (size_t) n * dim);
+	*out = ix;
+	return PGV_OK;
+}
+
+void
+pgv_index_free(pgv_index * ix)
+{
+	if (!ix)
+		return;
+	free(ix->centers);
+	free(ix->vectors);
+	free(ix->offsets);
+	free(ix);
+}
+
+/* GetScanLists: the maxprobes nearest centers, ascending; a later center never displaces an equal one */
+int
+pgv_rank_lists(pgv_index * ix, const void *queries, int nq, int maxprobes, int32_t *out_lists, float *out_dist)
+{
+	float	   *d = malloc(sizeof(float) * (size_t) ix->nlists);
+	uint8_t    *used = malloc((size_t) ix->nlists);
+
+	for (int q = 0; q < nq; q++)
+	{
+		const float *qv = (const float *) queries + (size_t) q * ix->dim;
+
+		for (int l = 0; l < ix->nlists; l++)
+			d[l] = dist(ix->metric, ix->dim, ix->centers + (size_t) l * ix->dim, qv);
+		memset(used, 0, (size_t) ix->nlists);
+		for (int p = 0; p < maxprobes; p++)
+		{
+			int			best = -1;
+
+			for (int l = 0; l < ix->nlists; l++)
+				if (!used[l] && (best < 0 || d[l] < d[best]))
+					best = l;
+			used[best] = 1;
+			out_lists[(size_t) q * maxprobes + p] = best;
+			if (out_dist)
+				out_dist[(size_t) q * maxprobes + p] = d[best];
+		}
+	}
+	free(d);
+	free(used);
+	return PGV_OK;
+}
+
+/* GetScanItems without the sort: every tuple of the given lists, in list order */
+int
+pgv_scan_lists(pgv_index * ix, const void *query, const int32_t *lists, int nlists, float *out_dist,
+			   int64_t *out_slot, int64_t capacity, int64_t *out_count)
+{
+	int64_t		m = 0;
+
+	for (int i = 0; i < nlists; i++)
+		m += ix->offsets[lists[i] + 1] - ix->offsets[lists[i]];
+	*out_count = m;
+	if (m > capacity)
+		return fail(PGV_ERR_ARG, "mock: capacity");
+	m = 0;
+	for (int i = 0; i < nlists; i++)
+		for (int64_t r = ix->offsets[lists[i]]; r < ix->offsets[lists[i] + 1]; r++, m++)
+		{
+			out_slot[m] = r;
+			out_dist[m] = query ? dist(ix->metric, ix->dim, ix->vectors + (size_t) r * ix->dim, (const float *) query) : 0.0f;
+		}
+	return PGV_OK;
+}
+
+/* AddTupleToSort's argmin: the first strictly smallest distance wins */
+int
+pgv_assign(pgv_ctx * ctx, pgv_metric metric, pgv_dtype dtype, int dim, const void *centers, int k,
+		   const void *rows, int64_t n, int32_t *out_list, float *out_dist)
+{
+	(void) ctx;
+	if (dtype != PGV_F32)
+		return fail(PGV_ERR_ARG, "mock: fp32 only");
+	for (int64_t i = 0; i < n; i++)
+	{
+		int			best = 0;
+		float		bd = INFINITY;
+
+		for (int c = 0; c < k; c++)
+		{
+			float		d = dist(metric, dim, (const float *) rows + (size_t) i * dim, (const float *) centers + (size_t) c * dim);
+
+			if (d < bd)
+			{
+				bd = d;
+				best = c;
+			}
+		}
+		out_list[i] = best;
+		if (out_dist)
+			out_dist[i] = bd;
+	}
+	return PGV_OK;
+}
+
+/* a plain Lloyd k-means from evenly spaced samples: enough for the build driver's plumbing */
+int
+pgv_kmeans(pgv_ctx * ctx, pgv_ops ops, pgv_dtype dtype, int dim, const void *samples, int n, int k,
+		   int max_iterations, const pgv_rng * rng, void *out_centers, int32_t *out_closest, int *out_iters)
+{
+	float	   *c = out_centers;
+	const float *s = samples;
+	int32_t    *closest = malloc(sizeof(int32_t) * (size_t) (n > 0 ? n : 1));
+	float	   *sum = malloc(sizeof(float) * (size_t) k * dim);
+	int		   *cnt = malloc(sizeof(int) * (size_t) k);
+	int			it = 0;
+
+	(void) ctx;
+	(void) rng;
+	if (dtype != PGV_F32 || ops != PGV_OPS_L2)
+		return fail(PGV_ERR_ARG, "mock: fp32 / l2 only");
+	for (int j = 0; j < k; j++)
+		for (int d = 0; d < dim; d++)
+			c[(size_t) j * dim + d] = n > 0 ? s[(size_t) ((int64_t) j * n / k) * dim + d] : (float) j;
+	for (it = 0; it < (max_iterations < 20 ? max_iterations : 20) && n > 0; it++)
+	{
+		pgv_assign(NULL, PGV_L2SQ, PGV_F32, dim, c, k, s, n, closest, NULL);
+		memset(sum, 0, sizeof(float) * (size_t) k * dim);
+		memset(cnt, 0, sizeof(int) * (size_t) k);
+		for (int i = 0; i < n; i++)
+		{
+			cnt[closest[i]]++;
+			for (int d = 0; d < dim; d++)
+				sum[(size_t) closest[i] * dim + d] += s[(size_t) i * dim + d];
+		}
+		for (int j = 0; j < k; j++)
+			if (cnt[j] > 0)
+				for (int d = 0; d < dim; d++)
+					c[(size_t) j * dim + d] = sum[(size_t) j * dim + d] / (float) cnt[j];
+	}
+	if (out_closest && n > 0)
+		memcpy(out_closest, closest, sizeof(int32_t) * (size_t) n);
+	if (out_iters)
+		*out_iters = it;
+	free(closest);
+	free(sum);
+	free(cnt);
+	return PGV_OK;
+}
+
+/* --------------------------------------------------------------------- HNSW */
+
+int
+pgv_hnsw_upload(pgv_ctx * ctx, pgv_metric metric, pgv_dtype dtype, int dim, const void *elements, int64_t n,
+				pgv_hnsw * *out)
+{
+	pgv_hnsw   *h;
+
+	(void) ctx;
+	if (dtype != PGV_F32)
+		return fail(PGV_ERR_ARG, "mock: fp32 only");
+	h = calloc(1, sizeof(*h));
+	h->metric = metric;
+	h->dim = dim;
+	h->n = n;
+	h->entry = -1;
+	h->vectors = malloc(sizeof(float) * (size_t) (n > 0 ? n : 1) * dim);
+	memcpy(h->vectors, elements, sizeof(float) * (size_t) n * dim);
+	*out = h;
+	return PGV_OK;
+}
+
+static void
+graph_free(pgv_hnsw * h)
+{
+	free(h->levels);
+	free(h->nbr_start);
+	free(h->nbr);
+	h->levels = NULL;
+	h->nbr_start = NULL;
+	h->nbr = NULL;
+}
+
+void
+pgv_hnsw_free(pgv_hnsw * h)
+{
+	if (!h)
+		return;
+	graph_free(h);
+	free(h->vectors);
+	free(h);
+}
+
+int
+pgv_hnsw_set_graph(pgv_hnsw * h, int m, int32_t entry, const int32_t *levels, const int64_t *nbr_start,
+				   const int32_t *nbr)
+{
+	graph_free(h);
+	h->m = m;
+	h->entry = entry;
+	h->levels = malloc(sizeof(int32_t) * (size_t) (h->n > 0 ? h->n : 1));
+	h->nbr_start = malloc(sizeof(int64_t) * (size_t) (h->n + 1));
+	memcpy(h->levels, levels, sizeof(int32_t) * (size_t) h->n);
+	memcpy(h->nbr_start, nbr_start, sizeof(int64_t) * (size_t) (h->n + 1));
+	h->nbr = malloc(sizeof(int32_t) * (size_t) (nbr_start[h->n] > 0 ? nbr_start[h->n] : 1));
+	memcpy(h->nbr, nbr, sizeof(int32_t) * (size_t) nbr_start[h->n]);
+	return PGV_OK;
+}
+
+int
+pgv_hnsw_update_graph(pgv_hnsw * h, int32_t entry, const int32_t *elements, int nupd, const int64_t *tuple_offsets,
+					  const int32_t *tuples)
+{
+	h->entry = entry;
+	for (int i = 0; i < nupd; i++)
+	{
+		int32_t		e = elements[i];
+		int64_t		len = h->nbr_start[e + 1] - h->nbr_start[e];
+
+		if (tuple_offsets[i + 1] - tuple_offsets[i] != len)
+			return fail(PGV_ERR_ARG, "mock: tuple size");
+		memcpy(h->nbr + h->nbr_start[e], tuples + tuple_offsets[i], sizeof(int32_t) * (size_t) len);
+	}
+	return PGV_OK;
+}
+
+int
+pgv_hnsw_score(pgv_hnsw * h, const void *queries, int nq, const int32_t *slot, const int32_t *query_of,
+			   int64_t npairs, float *out)
+{
+	(void) nq;
+	for (int64_t i = 0; i < npairs; i++)
+		out[i] = dist(h->metric, h->dim, h->vectors + (size_t) slot[i] * h->dim,
+					  (const float *) queries + (size_t) (query_of ? query_of[i] : 0) * h->dim);
+	return PGV_OK;
+}
+
+int
+pgv_hnsw_score_pairs(pgv_hnsw * h, const int32_t *a, const int32_t *b, int64_t npairs, float *out)
+{
+	for (int64_t i = 0; i < npairs; i++)
+		out[i] = dist(h->metric, h->dim, h->vectors + (size_t) a[i] * h->dim, h->vectors + (size_t) b[i] * h->dim);
+	return PGV_OK;
+}
+
+typedef struct
+{
+	int32_t		id;
+	float		d;
+	int			expanded;
+}			sc;
+
+/* HnswSearchLayer (src/hnswutils.c:824-987) with plain arrays: w[] ascending, C = the unexpanded entries of w */
+static int
+search_layer(const pgv_hnsw * h, const float *q, sc * w, int wn, int ef, int lc, uint8_t *visited)
+{
+	int			lm = lc == 0 ? 2 * h->m : h->m;
+
+	memset(visited, 0, (size_t) h->n);
+	for (int i = 0; i < wn; i++)
+	{
+		visited[w[i].id] = 1;
+		w[i].expanded = 0;
+	}
+	for (;;)
+	{
+		int			ci = -1;
+		int32_t		c;
+		int64_t		start;
+
+		for (int i = 0; i < wn; i++)
+			if (!w[i].expanded)
+			{
+				ci = i;
+				break;
+			}
+		if (ci < 0)
+			break;
+		w[ci].expanded = 1;
+		c = w[ci].id;
+		start = h->nbr_start[c] + (int64_t) (h->levels[c] - lc) * h->m;
+		for (int j = 0; j < lm; j++)
+		{
+			int32_t		e = h->nbr[start + j];
+			float		d;
+			int			pos;
+
+			if (e < 0 || visited[e])
+				continue;
+			visited[e] = 1;
+			d = dist(h->metric, h->dim, h->vectors + (size_t) e * h->dim, q);
+			if (h->levels[e] < lc)
+				continue;
+			if (!(wn < ef || d < w[wn - 1].d))
+				continue;
+			/* stable insertion after the entries that are not farther; drop the furthest on overflow */
+			pos = wn;
+			while (pos > 0 && w[pos - 1].d > d)
+				pos--;
+			if (wn < ef)
+				wn++;
+			for (int t = wn - 1; t > pos; t--)
+				w[t] = w[t - 1];
+			w[pos].id = e;
+			w[pos].d = d;
+			w[pos].expanded = 0;
+		}
+	}
+	return wn;
+}
+
+int
+pgv_hnsw_build_search(pgv_hnsw * h, const int32_t *elements, const int32_t *insert_levels, int nq,
+					  int ef_construction, int layer_cap, int32_t *out_ids, float *out_dist, int32_t *out_count)
+{
+	sc		   *w = malloc(sizeof(sc) * (size_t) (ef_construction + 1));
+	uint8_t    *visited = malloc((size_t) (h->n > 0 ? h->n : 1));
+
+	for (int q = 0; q < nq; q++)
+	{
+		const float *qv = h->vectors + (size_t) elements[q] * h->dim;
+		int			wn = 1;
+
+		for (int l = 0; l < layer_cap; l++)
+			out_count[(size_t) q * layer_cap + l] = 0;
+		if (h->entry < 0)
+			continue;
+		w[0].id = h->entry;
+		w[0].d = dist(h->metric, h->dim, h->vectors + (size_t) h->entry * h->dim, qv);
+		for (int lc = h->levels[h->entry]; lc >= 0; lc--)
+		{
+			int			ef = lc <= insert_levels[q] ? ef_construction : 1;
+
+			wn = search_layer(h, qv, w, wn, ef, lc, visited);
+			if (lc <= insert_levels[q] && lc < layer_cap)
+			{
+				size_t		o = ((size_t) q * layer_cap + lc) * ef_construction;
+
+				for (int i = 0; i < wn; i++)
+				{
+					out_ids[o + i] = w[i].id;
+					out_dist[o + i] = w[i].d;
+				}
+				out_count[(size_t) q * layer_cap + lc] = wn;
+			}
+		}
+	}
+	free(w);
+	free(visited);
+	return PGV_OK;
+}
