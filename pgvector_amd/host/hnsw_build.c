@@ -76,6 +76,7 @@ typedef struct
 	float	   *mat;			/* [nlocal x nlocal] */
 	float	   *newdist;		/* [nlocal - nstart] distance of each newcomer to the owner */
 	int			wait_from;		/* first local whose update waits for the second launch */
+	int			newcap;
 }			record;
 
 typedef struct
@@ -197,6 +198,18 @@ pairs_triangle(pairbuf * p, const int32_t *ids, int n)
 	return 1;
 }
 
+/* the same enumeration written at a known position of an already reserved buffer (parallel fills) */
+static void
+triangle_at(pairbuf * p, int64_t at, const int32_t *ids, int n)
+{
+	for (int i = 0; i < n; i++)
+		for (int j = i + 1; j < n; j++, at++)
+		{
+			p->a[at] = ids[i];
+			p->b[at] = ids[j];
+		}
+}
+
 static void
 fill_matrix(float *mat, int n, const float *tri)
 {
@@ -214,7 +227,7 @@ fill_matrix(float *mat, int n, const float *tri)
 
 /* CompareCandidateDistances, src/hnswutils.c:992-1010: descending distance, then descending
  * pointer; element slots grow with allocation order and stand in for pointers */
-static int
+static inline int
 cand_desc_cmp(const void *pa, const void *pb)
 {
 	const cand *a = *(cand * const *) pa,
@@ -278,9 +291,25 @@ select_neighbors(cand * *c, int nc, int lm, const float *mat, int nloc, int nkno
 			r[i] = c[i];
 		return nc;
 	}
-	memcpy(w, c, sizeof(*w) * (size_t) nc);
 	if (sort)
-		qsort(w, (size_t) nc, sizeof(*w), cand_desc_cmp);
+	{
+		/* list_sort(w, CompareCandidateDistances): a total order, so any algorithm gives the reference's
+		 * result; a neighbor list is a few dozen entries, where an insertion sort beats qsort's calls */
+		for (int i = 0; i < nc; i++)
+		{
+			cand	   *x = c[i];
+			int			j = i;
+
+			while (j > 0 && cand_desc_cmp(&x, &w[j - 1]) < 0)
+			{
+				w[j] = w[j - 1];
+				j--;
+			}
+			w[j] = x;
+		}
+	}
+	else
+		memcpy(w, c, sizeof(*w) * (size_t) nc);
 	while (wn > 0 && rn < lm)
 	{
 		cand	   *e = w[--wn];	/* closest remaining */
@@ -524,19 +553,34 @@ pgv_host_hnsw_build(pgv_hnsw * mirror, pgv_dtype dtype, int dim, const void *row
 		/* ---- 2. pairwise distances inside every candidate list that has to be thinned */
 		pb.n = 0;
 		tri_off = realloc(tri_off, sizeof(int64_t) * (size_t) B * lcap);
-		for (int b = 0; b < B; b++)
-			for (int lc = 0; lc < lcap; lc++)
-			{
-				int			nw = sw_cnt[(size_t) b * lcap + lc];
+		{
+			int64_t		total = 0;
 
-				tri_off[(size_t) b * lcap + lc] = pb.n;
-				if (nw > layer_m(m, lc))
-					if (!pairs_triangle(&pb, sw_ids + ((size_t) b * lcap + lc) * ef_construction, nw))
-					{
-						rc = pgv_host_fail(PGV_ERR_NOMEM, "out of memory");
-						goto done;
-					}
+			for (int b = 0; b < B; b++)
+				for (int lc = 0; lc < lcap; lc++)
+				{
+					int			nw = sw_cnt[(size_t) b * lcap + lc];
+
+					tri_off[(size_t) b * lcap + lc] = total;
+					if (nw > layer_m(m, lc))
+						total += (int64_t) nw * (nw - 1) / 2;
+				}
+			if (!pairs_reserve(&pb, total))
+			{
+				rc = pgv_host_fail(PGV_ERR_NOMEM, "out of memory");
+				goto done;
 			}
+			pb.n = total;
+#pragma omp parallel for if (B >= 8) num_threads(nthreads) schedule(static)
+			for (int b = 0; b < B; b++)
+				for (int lc = 0; lc < lcap; lc++)
+				{
+					int			nw = sw_cnt[(size_t) b * lcap + lc];
+
+					if (nw > layer_m(m, lc))
+						triangle_at(&pb, tri_off[(size_t) b * lcap + lc], sw_ids + ((size_t) b * lcap + lc) * ef_construction, nw);
+				}
+		}
 		if (pb.n > pdist_cap)
 		{
 			pdist_cap = pb.n * 2;
@@ -679,8 +723,9 @@ pgv_host_hnsw_build(pgv_hnsw * mirror, pgv_dtype dtype, int dim, const void *row
 						rcd->lc = lc;
 						rcd->nstart = l->length;
 						rcd->nlocal = l->length;
-						rcd->ids = malloc(sizeof(int32_t) * (size_t) (l->length + B));
-						rcd->newdist = malloc(sizeof(float) * (size_t) B);
+						rcd->newcap = 4;	/* most lists meet one or two newcomers per batch */
+						rcd->ids = malloc(sizeof(int32_t) * (size_t) (l->length + rcd->newcap));
+						rcd->newdist = malloc(sizeof(float) * (size_t) rcd->newcap);
 						rcd->mat = NULL;
 						rcd->full = !l->closer_set;	/* no cached flags: its next selection computes everything */
 						rcd->blocked = 0;
@@ -704,6 +749,12 @@ pgv_host_hnsw_build(pgv_hnsw * mirror, pgv_dtype dtype, int dim, const void *row
 					}
 					rcd = &recs[rec_of[h] - 1];
 					/* the newcomers of a list, in the order the reference's loop would link them */
+					if (rcd->nlocal - rcd->nstart == rcd->newcap)
+					{
+						rcd->newcap *= 2;
+						rcd->ids = realloc(rcd->ids, sizeof(int32_t) * (size_t) (rcd->nstart + rcd->newcap));
+						rcd->newdist = realloc(rcd->newdist, sizeof(float) * (size_t) rcd->newcap);
+					}
 					rcd->newdist[rcd->nlocal - rcd->nstart] = x->layers[lc].items[i].distance;
 					rcd->ids[rcd->nlocal++] = e;
 				}
@@ -711,39 +762,46 @@ pgv_host_hnsw_build(pgv_hnsw * mirror, pgv_dtype dtype, int dim, const void *row
 			if (x->level > el[entry].level)
 				entry = e;
 		}
-		for (int k = 0; k < nrec; k++)
 		{
-			record	   *rcd = &recs[k];
+			int64_t		total = 0;
 
-			rcd->pair0 = pb.n;
-			/* a list that cannot overflow in this batch never runs a selection */
-			if (rcd->nlocal <= layer_m(m, rcd->lc))
-				continue;
-			if (rcd->full)
+			for (int k = 0; k < nrec; k++)
 			{
-				if (!pairs_triangle(&pb, rcd->ids, rcd->nlocal))
-				{
-					rc = pgv_host_fail(PGV_ERR_NOMEM, "out of memory");
-					goto done;
-				}
+				record	   *rcd = &recs[k];
+
+				rcd->pair0 = total;
+				/* a list that cannot overflow in this batch never runs a selection */
+				if (rcd->nlocal <= layer_m(m, rcd->lc))
+					continue;
+				if (rcd->full)
+					total += (int64_t) rcd->nlocal * (rcd->nlocal - 1) / 2;
+				else			/* cached flags: only the pairs that involve a newcomer */
+					for (int u = rcd->nstart; u < rcd->nlocal; u++)
+						total += u;
 			}
-			else
+			if (!pairs_reserve(&pb, total))
 			{
-				/* cached flags: only the pairs that involve a newcomer */
-				for (int u = rcd->nstart; u < rcd->nlocal; u++)
-				{
-					if (!pairs_reserve(&pb, u))
-					{
-						rc = pgv_host_fail(PGV_ERR_NOMEM, "out of memory");
-						goto done;
-					}
-					for (int v = 0; v < u; v++)
-					{
-						pb.a[pb.n] = rcd->ids[u];
-						pb.b[pb.n] = rcd->ids[v];
-						pb.n++;
-					}
-				}
+				rc = pgv_host_fail(PGV_ERR_NOMEM, "out of memory");
+				goto done;
+			}
+			pb.n = total;
+#pragma omp parallel for if (B >= 8) num_threads(nthreads) schedule(static)
+			for (int k = 0; k < nrec; k++)
+			{
+				record	   *rcd = &recs[k];
+				int64_t		at = rcd->pair0;
+
+				if (rcd->nlocal <= layer_m(m, rcd->lc))
+					continue;
+				if (rcd->full)
+					triangle_at(&pb, at, rcd->ids, rcd->nlocal);
+				else
+					for (int u = rcd->nstart; u < rcd->nlocal; u++)
+						for (int v = 0; v < u; v++, at++)
+						{
+							pb.a[at] = rcd->ids[u];
+							pb.b[at] = rcd->ids[v];
+						}
 			}
 		}
 		PHASE(PH_PAIRS);
@@ -919,6 +977,7 @@ pgv_host_hnsw_build(pgv_hnsw * mirror, pgv_dtype dtype, int dim, const void *row
 			}
 			packed_off[ndirty] = ntuple;
 			packed = realloc(packed, sizeof(int32_t) * (size_t) (ntuple > 0 ? ntuple : 1));
+#pragma omp parallel for if (B >= 8) num_threads(nthreads) schedule(static)
 			for (int q = 0; q < ndirty; q++)
 			{
 				write_tuple(el, dirty[q], m, out->nbr_start, out->nbr);
