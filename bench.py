@@ -208,6 +208,7 @@ def main():
     ap.add_argument("--probes", type=int, default=0)
     ap.add_argument("--seed", type=int, default=0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--host-io", action="store_true", help="also time the batch with host-memory queries/results")
     ap.add_argument("--recall-queries", type=int, default=256)
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo for a functional "
                                                      "multi-rank run on a single GPU)")
@@ -354,6 +355,21 @@ def main():
         "center_rank_ms_per_step": stats["aux_ms"] / args.steps,
         "scan_ms_per_step": stats["scan_ms"] / args.steps,
     }
+    if rank == 0 and world == 1 and args.host_io:
+        # what a Postgres backend sees: queries and results in HOST memory, i.e. H2D of the batch, the same
+        # kernels, D2H of k x (distance, slot, tid) per query and a stream sync inside every call.
+        # Reported next to `value`, never as `value`.
+        qh = [queries[j].cpu().numpy() for j in range(min(pool, 4))]
+        for j in range(2):
+            index.search_batch(qh[j % len(qh)], probes, k, want_tid=True)
+        t0 = time.perf_counter()
+        for j in range(args.steps):
+            index.search_batch(qh[j % len(qh)], probes, k, want_tid=True)
+        host_s = time.perf_counter() - t0
+        line["host_buffers"] = {"value": args.batch * args.steps / host_s, "unit": "queries/s",
+                                "ms_per_step": host_s / args.steps * 1e3,
+                                "h2d_bytes_per_step": int(args.batch * dim * esize),
+                                "d2h_bytes_per_step": int(args.batch * k * 20)}
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         try:
             line["cpu_baseline"] = cpu_baseline(centers.cpu().numpy(), offsets.cpu().numpy(), vectors.cpu().numpy(),
