@@ -422,6 +422,7 @@ pgv_host_hnsw_build(pgv_hnsw * mirror, pgv_dtype dtype, int dim, const void *row
 	int			recs_cap = 0;
 	int64_t    *rec_of = NULL;	/* hash: (owner, lc) -> record index + 1 */
 	int64_t    *tri_off = NULL;
+	int			nrec = 0;		/* records of the batch in flight (freed at its end, or on the way out) */
 	int			nthreads = omp_get_max_threads() < 16 ? omp_get_max_threads() : 16;
 	double		phase_t0 = now_secs();
 	int			cur_phase = PH_RECORDS;
@@ -491,7 +492,6 @@ pgv_host_hnsw_build(pgv_hnsw * mirror, pgv_dtype dtype, int dim, const void *row
 		int			B;
 		int			lcap = 1;
 		int			entry_level;
-		int			nrec = 0;
 		int			ndirty = 0;
 		int64_t		ntuple = 0;
 
@@ -996,6 +996,7 @@ pgv_host_hnsw_build(pgv_hnsw * mirror, pgv_dtype dtype, int dim, const void *row
 			free(recs[k].mat);
 			free(recs[k].newdist);
 		}
+		nrec = 0;
 		PHASE(PH_RECORDS);
 		memset(rec_of, 0, sizeof(int64_t) * (size_t) hash_cap);
 		i0 += B;
@@ -1018,6 +1019,12 @@ done:
 				free(el[i].layers);
 			}
 		free(el);
+	}
+	for (int k = 0; k < nrec; k++)	/* a batch cut short by an error */
+	{
+		free(recs[k].ids);
+		free(recs[k].mat);
+		free(recs[k].newdist);
 	}
 	free(pb.a);
 	free(pb.b);
