@@ -263,6 +263,68 @@ test_ivf(void)
 	}
 	pgv_host_ivf_endscan(scan);
 
+	/* an opclass with a NORM_PROC (cosine): the scan normalises the query (src/ivfscan.c:222-229) and ranks by
+	 * negative inner product; with unit-length stored rows that is the cosine order */
+	{
+		pgv_index  *ipx;
+		float	   *unit = malloc(sizeof(float) * (size_t) img->nrows * DIM);
+		float	   *ucen = malloc(sizeof(float) * LISTS * DIM);
+		float		big[DIM];
+		uint64_t	tid;
+		double		dist,
+					best = -2.0;
+		int64_t		best_row = -1;
+
+		for (int64_t r = 0; r < img->nrows; r++)
+		{
+			double		nrm = 0;
+
+			for (int d = 0; d < DIM; d++)
+				nrm += (double) ((const float *) img->vectors)[r * DIM + d] * ((const float *) img->vectors)[r * DIM + d];
+			for (int d = 0; d < DIM; d++)
+				unit[r * DIM + d] = (float) (((const float *) img->vectors)[r * DIM + d] / sqrt(nrm));
+		}
+		for (int l = 0; l < LISTS; l++)
+		{
+			double		nrm = 0;
+
+			for (int d = 0; d < DIM; d++)
+				nrm += (double) ((const float *) img->centers)[l * DIM + d] * ((const float *) img->centers)[l * DIM + d];
+			for (int d = 0; d < DIM; d++)
+				ucen[l * DIM + d] = (float) (((const float *) img->centers)[l * DIM + d] / sqrt(nrm));
+		}
+		CHECK(pgv_index_upload(ctx, PGV_NEG_IP, PGV_F32, DIM, LISTS, ucen, img->list_offsets, unit, img->tids, &ipx));
+		for (int d = 0; d < DIM; d++)
+			big[d] = 1000.0f * q[d];	/* any positive multiple of q has the same cosine order */
+		CHECK(pgv_host_ivf_beginscan(ipx, img, LISTS, 0, 0, 1, &scan));
+		CHECK(pgv_host_ivf_rescan(scan, big));
+		EXPECT(pgv_host_ivf_gettuple(scan, &tid, &dist) == 1);
+		{
+			double		qn = 0;
+
+			for (int d = 0; d < DIM; d++)
+				qn += (double) q[d] * q[d];
+			for (int64_t r = 0; r < img->nrows; r++)
+			{
+				double		ip = 0;
+
+				for (int d = 0; d < DIM; d++)
+					ip += (double) unit[r * DIM + d] * q[d];
+				ip /= sqrt(qn);
+				if (ip > best)
+				{
+					best = ip;
+					best_row = r;
+				}
+			}
+		}
+		EXPECT(tid == img->tids[best_row] && fabs(dist + best) <= 1e-4);
+		pgv_host_ivf_endscan(scan);
+		pgv_index_free(ipx);
+		free(unit);
+		free(ucen);
+	}
+
 	/* insert + vacuum invalidate the mirror; an unchanged relation does not */
 	CHECK(pgv_host_ivf_mirror_get(mirror, &rel, &ix, &img));
 	EXPECT(pgv_host_ivf_mirror_restages(mirror) == 1);
