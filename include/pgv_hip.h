@@ -221,6 +221,36 @@ int			pgv_search_batch(pgv_index * index, const void *queries, int nq, int probe
 int			pgv_scan_batch(pgv_index * index, const void *queries, int nq, const int32_t *probe_lists,
 						   int probes, int k, float *out_dist, int64_t *out_slot, uint64_t *out_tid);
 
+/*
+ * One backend's index scan, device-resident between the amgettuple calls (src/ivfscan.c:361-414).
+ * This is the path a Postgres backend binds: one query at a time, LIMIT k tuples pulled.
+ *   pgv_query_rank   GetScanLists (src/ivfscan.c:47-118): ranks every center against the query
+ *                    and keeps the max_probes nearest ON THE DEVICE (one launch, nothing read back).
+ *                    query NULL = ZeroDistance (:192-196): lists 0 .. max_probes-1.
+ *   pgv_query_scan   GetScanItems + tuplesort_performsort (:123-187) for ranked lists
+ *                    [first, first + nprobes): every tuple scored (one launch, the rows spread over
+ *                    all CUs), the distances stay in HBM in tuplesort input order, and only the
+ *                    `head` nearest come back, ascending (ties: lower insertion position first):
+ *                    out_dist / out_slot / out_tid [head], *out_count = min(head, tuples),
+ *                    *out_total = tuples in the batch (what the reference's tuplesort holds).
+ *   pgv_query_more   entries [skip, skip + count) of the same batch's sorted stream, for an
+ *                    executor that pulls past the head; skip + count <= 1024.  Beyond that the
+ *                    caller fetches the whole batch with pgv_scan_lists (pgv_query_lists gives the
+ *                    ranked list ids) and sorts it like the reference does.
+ * Limits of the fused path: max_probes <= 1024, nprobes <= 256, head <= 1024 (PGV_ERR_ARG
+ * otherwise: use pgv_rank_lists / pgv_scan_lists).  Iterative scans (:400-406) call
+ * pgv_query_scan again with first += nprobes.  out_tid needs an index uploaded with tids.
+ */
+typedef struct pgv_query pgv_query;
+int			pgv_query_begin(pgv_index * index, pgv_query * *out);
+void		pgv_query_end(pgv_query * q);
+int			pgv_query_rank(pgv_query * q, const void *query, int max_probes);
+int			pgv_query_scan(pgv_query * q, int first, int nprobes, int head, float *out_dist, int64_t *out_slot,
+						   uint64_t *out_tid, int *out_count, int64_t *out_total);
+int			pgv_query_more(pgv_query * q, int skip, int count, float *out_dist, int64_t *out_slot,
+						   uint64_t *out_tid, int *out_count);
+int			pgv_query_lists(pgv_query * q, int32_t *out_lists, int n);
+
 /* ------------------------------------------------------ IVFFlat build side */
 
 /*

@@ -38,6 +38,7 @@ SYMBOLS = [
     "pgv_assign", "pgv_kmeans", "pgv_lloyd_partial", "pgv_lloyd_finish", "pgv_kmeanspp_init",
     "pgv_distance_batch", "pgv_cosine_distance_batch", "pgv_bit_distance_batch", "pgv_hnsw_upload", "pgv_hnsw_free", "pgv_hnsw_score", "pgv_hnsw_set_graph", "pgv_hnsw_search",
     "pgv_hnsw_build_search", "pgv_hnsw_score_pairs", "pgv_hnsw_update_graph",
+    "pgv_query_begin", "pgv_query_end", "pgv_query_rank", "pgv_query_scan", "pgv_query_more", "pgv_query_lists",
 ]
 
 
@@ -95,6 +96,13 @@ def _load():
     lib.pgv_scan_lists.argtypes = [P, P, P, I, P, P, I64, C.POINTER(I64)]
     lib.pgv_search_batch.argtypes = [P, P, I, I, I, P, P, P]
     lib.pgv_scan_batch.argtypes = [P, P, I, P, I, I, P, P, P]
+    lib.pgv_query_begin.argtypes = [P, C.POINTER(P)]
+    lib.pgv_query_end.argtypes = [P]
+    lib.pgv_query_end.restype = None
+    lib.pgv_query_rank.argtypes = [P, P, I]
+    lib.pgv_query_scan.argtypes = [P, I, I, I, P, P, P, C.POINTER(I), C.POINTER(I64)]
+    lib.pgv_query_more.argtypes = [P, I, I, P, P, P, C.POINTER(I)]
+    lib.pgv_query_lists.argtypes = [P, P, I]
     lib.pgv_assign.argtypes = [P, I, I, I, P, I, P, I64, P, P]
     lib.pgv_kmeans.argtypes = [P, I, I, I, P, I, I, I, C.POINTER(PgvRng), P, P, C.POINTER(I)]
     lib.pgv_lloyd_partial.argtypes = [P, I, I, I, P, I, P, I, P, P, P, P]

@@ -216,6 +216,59 @@ def _scan_batch(self, queries, probe_lists, k, want_tid=False, out=None):
 IvfIndex.scan_batch = _scan_batch
 
 
+class Query:
+    """one backend's index scan, device-resident between calls (pgv_query_*): rank() = GetScanLists,
+    scan() = GetScanItems + the sorted head, more() = deeper into the same batch's sorted stream"""
+
+    def __init__(self, index):
+        self.index = index
+        h = C.c_void_p()
+        check(lib.pgv_query_begin(index.h, C.byref(h)))
+        self.h = h
+        index.ctx._adopt(self)
+
+    def close(self):
+        if self.h:
+            lib.pgv_query_end(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def rank(self, query, max_probes):
+        if query is not None:
+            query = as_dtype(query, self.index.dtype)
+        self._q = query
+        check(lib.pgv_query_rank(self.h, ptr(query), int(max_probes)))
+
+    def lists(self, n):
+        out = np.empty(n, dtype=np.int32)
+        check(lib.pgv_query_lists(self.h, ptr(out), n))
+        return out
+
+    def scan(self, first, nprobes, head, want_tid=True):
+        dist = np.empty(head, dtype=np.float32)
+        slot = np.empty(head, dtype=np.int64)
+        tid = np.empty(head, dtype=np.uint64) if want_tid else None
+        count, total = C.c_int(), C.c_int64()
+        check(lib.pgv_query_scan(self.h, int(first), int(nprobes), int(head), ptr(dist), ptr(slot), ptr(tid),
+                                 C.byref(count), C.byref(total)))
+        n = count.value
+        return dist[:n], slot[:n], (tid[:n] if want_tid else None), total.value
+
+    def more(self, skip, count, want_tid=True):
+        dist = np.empty(count, dtype=np.float32)
+        slot = np.empty(count, dtype=np.int64)
+        tid = np.empty(count, dtype=np.uint64) if want_tid else None
+        got = C.c_int()
+        check(lib.pgv_query_more(self.h, int(skip), int(count), ptr(dist), ptr(slot), ptr(tid), C.byref(got)))
+        n = got.value
+        return dist[:n], slot[:n], (tid[:n] if want_tid else None)
+
+
 def assign(ctx, metric, dtype, dim, centers, rows, want_dist=True):
     centers = as_dtype(centers, dtype)
     rows = as_dtype(rows, dtype)

@@ -1,0 +1,433 @@
+// kernels_mfma.hip -- rows x centers on the matrix cores: nearest center per row.
+//
+// The argmin loop of AddTupleToSort (src/ivfbuild.c:183-192) and the assignment half of a
+// k-means iteration (src/ivfkmeans.c:391-451 without Elkan's pruning) are the two dense
+// contractions of the path: n x k x dim multiply-adds.  kernels_pair.hip runs them on the
+// vector ALUs in the reference's per-pair form; this file runs the inner products on MFMA:
+//
+//   vector   (fp32):  v_mfma_f32_32x32x2_f32  -- exact fp32 FMA chain, 157 TFLOP/s
+//   halfvec  (fp16):  v_mfma_f32_32x32x16_f16 -- fp16 products are exact in fp32, fp32 accumulate
+//
+// * inner-product opclasses (FUNCTION 1 = -sum(a*b), spherical k-means = -clamp(sum(a*b))):
+//   the MFMA result IS the reference's arithmetic (a different but equally valid summation
+//   order, SURVEY hard part 3); the running lexicographic (value, id) minimum is kept in the
+//   epilogue, so "first strictly smaller wins" (src/ivfbuild.c:187-191) holds exactly.
+// * L2: sum((a-b)^2) is not a contraction.  |c|^2 - 2 a.c (the |a|^2 term is the same for
+//   every center) is computed on MFMA as a PRE-FILTER that keeps the 4 best centers per row;
+//   recheck_kernel then evaluates the reference's exact sum((a-b)^2) for those 4 and picks the
+//   lexicographic minimum.  The pre-filter's rounding error is bounded by
+//   gamma * (|c|^2 + 2 |a||c|), gamma = (dim + 4) * 2^-24; a row whose 4th-best pre-filter
+//   value is not more than twice that bound above its best (more than 4 centers could be the
+//   true minimum) is put on a list and redone by the exact vector-ALU kernel.  Exact ties
+//   (duplicate centers, integer-valued data) therefore resolve exactly like the reference.
+//
+// Tiling: centers are the MFMA M dimension, data rows the N dimension, so a lane's 16
+// accumulators of a 32x32 tile are 16 centers for ONE data row and the running minimum is
+// lane-local.  A workgroup owns BN data rows and walks all centers in tiles of BM; 128-byte
+// slices of BM + BN rows are brought into LDS by the asynchronous global->LDS DMA (next slice
+// in flight while the current one is multiplied), stored XOR-swizzled in 16-byte slots so
+// that the ds_read_b128 of 32 different rows is bank-conflict free.  Each lane's 16-byte read
+// feeds 4 fp32 MFMAs (k-slots are permuted identically for A and B, which a dot product does
+// not notice) or one fp16 MFMA.
+#include "pgv_device.h"
+
+#include <cfloat>
+
+namespace pgv {
+
+namespace {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+
+constexpr int kSliceBytes = 128;  // bytes of every row per pipeline stage = 8 slots of 16 B
+constexpr int kCand = 4;          // centers kept by the L2 pre-filter
+
+// waves along M (centers) x N (rows), 32x32 tiles per wave along M x N
+template <typename T> struct MfmaCfg;
+template <> struct MfmaCfg<float> {
+    static constexpr int WM = 2, WN = 2, TM = 2, TN = 2;  // 128 x 128 per workgroup, 64 accumulators
+};
+template <> struct MfmaCfg<__half> {
+    static constexpr int WM = 2, WN = 4, TM = 4, TN = 2;  // 256 x 256 per workgroup, 128 accumulators
+};
+
+// One step of a stage: this lane's 16-byte slot of TM center rows and TN data rows.  In asm,
+// loads and wait in one statement (cdna_hip_programming.md 5.7 form i): hipcc cannot prove
+// that these reads do not alias the stage the DMA is filling and would drain vmcnt(0) first.
+template <int TM, int TN> struct OperandRead;
+template <> struct OperandRead<2, 2> {
+    static __device__ __forceinline__ void run(unsigned aa, unsigned ba, u32x4 (&a)[2], u32x4 (&b)[2]) {
+        asm volatile(
+            "ds_read_b128 %0, %4\n\tds_read_b128 %1, %4 offset:4096\n\t"
+            "ds_read_b128 %2, %5\n\tds_read_b128 %3, %5 offset:4096\n\t"
+            "s_waitcnt lgkmcnt(0)"
+            : "=&v"(a[0]), "=&v"(a[1]), "=&v"(b[0]), "=&v"(b[1])
+            : "v"(aa), "v"(ba)
+            : "memory");
+    }
+};
+template <> struct OperandRead<4, 2> {
+    static __device__ __forceinline__ void run(unsigned aa, unsigned ba, u32x4 (&a)[4], u32x4 (&b)[2]) {
+        asm volatile(
+            "ds_read_b128 %0, %6\n\tds_read_b128 %1, %6 offset:4096\n\t"
+            "ds_read_b128 %2, %6 offset:8192\n\tds_read_b128 %3, %6 offset:12288\n\t"
+            "ds_read_b128 %4, %7\n\tds_read_b128 %5, %7 offset:4096\n\t"
+            "s_waitcnt lgkmcnt(0)"
+            : "=&v"(a[0]), "=&v"(a[1]), "=&v"(a[2]), "=&v"(a[3]), "=&v"(b[0]), "=&v"(b[1])
+            : "v"(aa), "v"(ba)
+            : "memory");
+    }
+};
+
+template <typename T> struct Mma;
+template <> struct Mma<float> {
+    // 4 k-slots per 16-byte operand: one 32x32x2 MFMA per float
+    static __device__ __forceinline__ void run(f32x16 &acc, const u32x4 &a, const u32x4 &b) {
+#pragma unroll
+        for (int e = 0; e < 4; e++)
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(__uint_as_float(a[e]), __uint_as_float(b[e]), acc, 0, 0, 0);
+    }
+};
+template <> struct Mma<__half> {
+    static __device__ __forceinline__ void run(f32x16 &acc, const u32x4 &a, const u32x4 &b) {
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), acc, 0,
+                                                     0, 0);
+    }
+};
+
+// sorted insertion into a lane's best-NC list; strict '<' keeps the earlier (lower) id first
+// among equal values -- ids arrive in ascending order within a lane.  NaN and +inf never enter
+// (not < DBL_MAX, src/ivfbuild.c:187).
+template <int NC> __device__ __forceinline__ void keep_best(float (&tv)[NC], int (&ti)[NC], float s, int id) {
+    if (!(s < tv[NC - 1])) return;
+#pragma unroll
+    for (int p = NC - 1; p >= 0; p--) {
+        const bool shift = p > 0 && s < tv[p - 1];
+        if (shift) {
+            tv[p] = tv[p - 1];
+            ti[p] = ti[p - 1];
+        } else {
+            tv[p] = s;
+            ti[p] = id;
+            break;
+        }
+    }
+}
+
+// MODE 0: L2 pre-filter (bias - 2 ip, kCand kept)   1: -ip   3: -clamp(ip, -1, 1) (spherical k-means:
+// same argmin as acos(ip)/pi including the ties its clamp creates, src/vector.c:703-722)
+template <typename T, int MODE>
+__global__ __launch_bounds__(MfmaCfg<T>::WM *MfmaCfg<T>::WN * 64, 2) void mfma_argmin_kernel(
+    const char *__restrict__ rows, int64_t n, const char *__restrict__ centers, int k, int nvec,
+    const float *__restrict__ bias, const char *__restrict__ zeros16, int32_t *__restrict__ out_idx,
+    float *__restrict__ out_val) {
+    using C = MfmaCfg<T>;
+    constexpr int TM = C::TM, TN = C::TN;
+    constexpr int BM = C::WM * TM * 32, BN = C::WN * TN * 32;
+    constexpr int STAGE = (BM + BN) * kSliceBytes;
+    constexpr int NC = MODE == 0 ? kCand : 1;
+    constexpr int NSRC = C::WM * 2;  // lists per data row before the final merge: waves along M x half-waves
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    float *bias_lds = reinterpret_cast<float *>(smem + 2 * STAGE);
+
+    const int lane = threadIdx.x & (kWave - 1);
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int wm = wave / C::WN, wn = wave % C::WN;
+    const int l31 = lane & 31, half = lane >> 5;
+    const unsigned sw = (unsigned)(l31 >> 1) & 7u;
+    const int64_t row_base = (int64_t)blockIdx.x * BN;
+    const size_t row_bytes = (size_t)nvec * sizeof(Raw16);
+    const int nslices = (nvec + 7) / 8;
+
+    // DMA role of this wavefront: 64 consecutive rows of [BM center rows | BN data rows], 8 per
+    // instruction; a lane brings slot (lane & 7) of row (lane >> 3) of the group
+    const int crow0 = wave * 64;
+    const bool fills_a = crow0 < BM;
+    const int drow = lane >> 3, dpos = lane & 7;
+    const char *src_base = fills_a ? centers : rows + (size_t)row_base * row_bytes;
+    const int src_limit = fills_a ? k : (int)(n - row_base < BN ? n - row_base : BN);
+    auto src_row = [&](int cb, int j) {  // row (relative to src_base) instruction j reads; past the end: the last row
+        const int i = (fills_a ? cb + crow0 : crow0 - BM) + 8 * j + drow;
+        return i < src_limit ? i : src_limit - 1;
+    };
+    auto issue_stage = [&](int cb, int sl, int buf) {
+#pragma unroll
+        for (int j = 0; j < 8; j++) {
+            // slot position p of row i holds 16-byte vector p ^ ((i >> 1) & 7) of the slice
+            const int v = dpos ^ ((4 * j + (drow >> 1)) & 7);
+            const int vi = sl * 8 + v;
+            const char *p = vi < nvec ? src_base + (size_t)src_row(cb, j) * row_bytes + (size_t)vi * sizeof(Raw16) : zeros16;
+            char *dst = smem + (size_t)buf * STAGE + (size_t)(crow0 + 8 * j) * kSliceBytes;
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)p,
+                                             (__attribute__((address_space(3))) void *)dst, 16, 0, 0);
+        }
+    };
+
+    float tv[TN][NC];
+    int ti[TN][NC];
+#pragma unroll
+    for (int t = 0; t < TN; t++)
+#pragma unroll
+        for (int c = 0; c < NC; c++) {
+            tv[t][c] = INFINITY;
+            ti[t][c] = 0;
+        }
+
+    const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) char *)smem;
+    const unsigned a_lane = (unsigned)(wm * TM * 32 + l31) * kSliceBytes;
+    const unsigned b_lane = (unsigned)(BM + wn * TN * 32 + l31) * kSliceBytes;
+
+    for (int cb = 0; cb < k; cb += BM) {
+        if (MODE == 0) {
+            for (int i = threadIdx.x; i < BM; i += blockDim.x) bias_lds[i] = cb + i < k ? bias[cb + i] : 0.f;
+        }
+        f32x16 acc[TM][TN];
+#pragma unroll
+        for (int a = 0; a < TM; a++)
+#pragma unroll
+            for (int b = 0; b < TN; b++)
+#pragma unroll
+                for (int r = 0; r < 16; r++) acc[a][b][r] = 0.f;
+
+        issue_stage(cb, 0, 0);
+        for (int sl = 0; sl < nslices; sl++) {
+            // slice sl has landed for every wavefront (vmcnt(0) + barrier) and nobody still
+            // reads the other buffer
+            __syncthreads();
+            if (sl + 1 < nslices) issue_stage(cb, sl + 1, (sl + 1) & 1);
+            const unsigned sbase = lds0 + (unsigned)(sl & 1) * STAGE;
+#pragma unroll
+            for (int c = 0; c < 4; c++) {
+                const unsigned x = (((unsigned)(2 * c + half)) ^ sw) << 4;
+                u32x4 a[TM], b[TN];
+                OperandRead<TM, TN>::run(sbase + a_lane + x, sbase + b_lane + x, a, b);
+#pragma unroll
+                for (int tm = 0; tm < TM; tm++)
+#pragma unroll
+                    for (int tn = 0; tn < TN; tn++) Mma<T>::run(acc[tm][tn], a[tm], b[tn]);
+            }
+        }
+
+        // fold this tile of centers into the lane-local running minima
+#pragma unroll
+        for (int tn = 0; tn < TN; tn++)
+#pragma unroll
+            for (int tm = 0; tm < TM; tm++) {
+                __builtin_amdgcn_sched_barrier(0);  // one tile at a time: keeps the epilogue's live values few
+#pragma unroll
+                for (int r = 0; r < 16; r++) {
+                    const int cl = wm * TM * 32 + tm * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+                    const int cid = cb + cl;
+                    float s = acc[tm][tn][r];
+                    if constexpr (MODE == 0) {
+                        s = fmaf(-2.f, s, bias_lds[cl]);
+                    } else if constexpr (MODE == 3) {
+                        s = s > 1.f ? 1.f : (s < -1.f ? -1.f : s);
+                        s = -s;
+                    } else {
+                        s = -s;
+                    }
+                    if (cid < k) keep_best<NC>(tv[tn], ti[tn], s, cid);
+                }
+            }
+        __syncthreads();  // the last slice and the bias tile are free to be overwritten
+    }
+
+    // merge the NSRC lists of every data row (LDS reuses the stage memory)
+    float *mv = reinterpret_cast<float *>(smem);
+    int *mi = reinterpret_cast<int *>(smem + sizeof(float) * BN * NSRC * NC);
+#pragma unroll
+    for (int tn = 0; tn < TN; tn++) {
+        const int j = wn * TN * 32 + tn * 32 + l31;
+        const int s = wm * 2 + half;
+#pragma unroll
+        for (int c = 0; c < NC; c++) {
+            mv[(j * NSRC + s) * NC + c] = tv[tn][c];
+            mi[(j * NSRC + s) * NC + c] = ti[tn][c];
+        }
+    }
+    __syncthreads();
+    for (int j = threadIdx.x; j < BN; j += blockDim.x) {
+        const int64_t r = row_base + j;
+        if (r >= n) continue;
+        const float *v = mv + j * NSRC * NC;
+        const int *id = mi + j * NSRC * NC;
+        // NC rounds of lexicographic (value, id) minimum over the entries not taken yet
+        float last_v = -INFINITY;
+        int last_id = -1;
+        bool first = true;
+        for (int c = 0; c < NC; c++) {
+            float bv = INFINITY;
+            int bid = 0x7fffffff;
+            for (int e = 0; e < NSRC * NC; e++) {
+                const float ev = v[e];
+                const int eid = id[e];
+                const bool after = first || ev > last_v || (ev == last_v && eid > last_id);
+                if (after && (ev < bv || (ev == bv && eid < bid))) {
+                    bv = ev;
+                    bid = eid;
+                }
+            }
+            if (bid == 0x7fffffff) {  // nothing left (fewer finite candidates than NC)
+                bv = INFINITY;
+                bid = 0;
+            }
+            if constexpr (NC == 1) {
+                out_idx[r] = bid;
+                if (out_val) out_val[r] = bv == INFINITY ? FLT_MAX : bv;
+            } else {
+                out_idx[r * NC + c] = bid;
+                out_val[r * NC + c] = bv;
+            }
+            last_v = bv;
+            last_id = bid;
+            first = false;
+        }
+    }
+}
+
+// bias[c] = |c|^2 in fp32; *cmax2 = max_c |c|^2 (as ordered uint bits; a NaN norm ends up
+// above every number and sends all rows to the exact kernel)
+template <typename T>
+__global__ __launch_bounds__(256) void center_norms_kernel(const char *__restrict__ centers, int k, int nvec,
+                                                           float *__restrict__ bias, unsigned *__restrict__ cmax2) {
+    const int c = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (c >= k) return;
+    const int lane = threadIdx.x & (kWave - 1);
+    const char *row = centers + (size_t)c * nvec * sizeof(Raw16);
+    float acc = 0.f;
+    for (int v = lane; v < nvec; v += kWave) {
+        const Raw16 x = load16(row + (size_t)v * sizeof(Raw16));
+        acc = accum_slice<T, 1>(acc, x, x);
+    }
+    for (int m = 32; m > 0; m >>= 1) acc += __shfl_xor(acc, m);
+    if (lane == 0) {
+        bias[c] = acc;
+        atomicMax(cmax2, __float_as_uint(acc));
+    }
+}
+
+// The reference's exact sum((a-b)^2) for the kCand pre-filtered centers of every row (one
+// wavefront per row), lexicographic minimum; rows whose pre-filter could not separate its 4th
+// candidate from its best go to the fallback list.
+template <typename T>
+__global__ __launch_bounds__(256) void recheck_kernel(const char *__restrict__ rows, int64_t n,
+                                                      const char *__restrict__ centers, int k, int nvec,
+                                                      const int32_t *__restrict__ cand_idx,
+                                                      const float *__restrict__ cand_val,
+                                                      const unsigned *__restrict__ cmax2_bits, float gamma,
+                                                      int32_t *__restrict__ out_idx, float *__restrict__ out_val,
+                                                      int *__restrict__ fb_count, int32_t *__restrict__ fb_rows) {
+    const int64_t r = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (r >= n) return;
+    const int lane = threadIdx.x & (kWave - 1);
+    const size_t row_bytes = (size_t)nvec * sizeof(Raw16);
+    const char *row = rows + (size_t)r * row_bytes;
+    int id[kCand];
+    const char *cp[kCand];
+#pragma unroll
+    for (int c = 0; c < kCand; c++) {
+        id[c] = cand_idx[r * kCand + c];
+        cp[c] = centers + (size_t)id[c] * row_bytes;
+    }
+    float d[kCand] = {0.f, 0.f, 0.f, 0.f};
+    float xx = 0.f;
+    for (int v = lane; v < nvec; v += kWave) {
+        const Raw16 x = load16(row + (size_t)v * sizeof(Raw16));
+        xx = accum_slice<T, 1>(xx, x, x);
+#pragma unroll
+        for (int c = 0; c < kCand; c++) d[c] = accum_slice<T, 0>(d[c], x, load16(cp[c] + (size_t)v * sizeof(Raw16)));
+    }
+    for (int m = 32; m > 0; m >>= 1) {
+        xx += __shfl_xor(xx, m);
+#pragma unroll
+        for (int c = 0; c < kCand; c++) d[c] += __shfl_xor(d[c], m);
+    }
+    if (lane != 0) return;
+    float bv = INFINITY;
+    int bid = 0x7fffffff;
+#pragma unroll
+    for (int c = 0; c < kCand; c++)
+        if (d[c] < bv || (d[c] == bv && d[c] < INFINITY && id[c] < bid)) {
+            bv = d[c];
+            bid = id[c];
+        }
+    out_idx[r] = bid == 0x7fffffff ? 0 : bid;
+    if (out_val) out_val[r] = bv == INFINITY ? FLT_MAX : bv;
+    if (k > kCand) {
+        const float cm2 = __uint_as_float(*cmax2_bits);
+        const float margin = 2.f * gamma * (cm2 + 2.f * sqrtf(xx * cm2));
+        const float v0 = cand_val[r * kCand], v3 = cand_val[r * kCand + kCand - 1];
+        if (!(v3 < INFINITY && v3 - v0 > margin)) fb_rows[atomicAdd(fb_count, 1)] = (int32_t)r;
+    }
+}
+
+template <typename T, int MODE>
+int launch_mfma_t(pgv_ctx *ctx, const RowGeom &g, const void *rows, int64_t n, const void *centers, int k,
+                  const float *bias, int32_t *out_idx, float *out_val) {
+    using C = MfmaCfg<T>;
+    constexpr int BM = C::WM * C::TM * 32, BN = C::WN * C::TN * 32;
+    constexpr int threads = C::WM * C::WN * 64;
+    const size_t lds = 2 * (size_t)(BM + BN) * kSliceBytes + sizeof(float) * BM;
+    auto kern = mfma_argmin_kernel<T, MODE>;
+    PGV_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                (int)lds));
+    const int64_t grid = (n + BN - 1) / BN;
+    hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(threads), lds, ctx->stream, static_cast<const char *>(rows), n,
+                       static_cast<const char *>(centers), k, g.nvec, bias, static_cast<const char *>(ctx->zeros.p),
+                       out_idx, out_val);
+    PGV_HIP(hipGetLastError());
+    return PGV_OK;
+}
+
+template <typename T>
+int launch_mfma_mode(pgv_ctx *ctx, int mode, const RowGeom &g, const void *rows, int64_t n, const void *centers, int k,
+                     int32_t *out_idx, float *out_val) {
+    if (mode == 1) return launch_mfma_t<T, 1>(ctx, g, rows, n, centers, k, nullptr, out_idx, out_val);
+    if (mode == 3) return launch_mfma_t<T, 3>(ctx, g, rows, n, centers, k, nullptr, out_idx, out_val);
+
+    // L2: norms -> MFMA pre-filter -> exact recheck -> exact redo of the ambiguous rows
+    // mf_a: bias[k] | cmax2 | fb_count      mf_b: cand_idx[n x 4] | cand_val[n x 4]      mf_c: fb_rows[n]
+    PGV_TRY(ctx->mf_a.ensure(sizeof(float) * (size_t)k + 64));
+    PGV_TRY(ctx->mf_b.ensure((sizeof(int32_t) + sizeof(float)) * (size_t)n * kCand));
+    PGV_TRY(ctx->mf_c.ensure(sizeof(int32_t) * (size_t)n));
+    float *bias = ctx->mf_a.as<float>();
+    unsigned *cmax2 = reinterpret_cast<unsigned *>(bias + k);
+    int *fb_count = reinterpret_cast<int *>(cmax2 + 1);
+    int32_t *cand_idx = ctx->mf_b.as<int32_t>();
+    float *cand_val = reinterpret_cast<float *>(cand_idx + (size_t)n * kCand);
+    int32_t *fb_rows = ctx->mf_c.as<int32_t>();
+    PGV_HIP(hipMemsetAsync(cmax2, 0, 2 * sizeof(int), ctx->stream));
+    hipLaunchKernelGGL(center_norms_kernel<T>, dim3((k + 3) / 4), dim3(256), 0, ctx->stream,
+                       static_cast<const char *>(centers), k, g.nvec, bias, cmax2);
+    PGV_TRY((launch_mfma_t<T, 0>(ctx, g, rows, n, centers, k, bias, cand_idx, cand_val)));
+    const float gamma = (float)(g.ld + 4) * 5.9604645e-8f;  // (dim + 4) * 2^-24: any-order fp32 dot product bound
+    hipLaunchKernelGGL(recheck_kernel<T>, dim3((unsigned)((n + 3) / 4)), dim3(256), 0, ctx->stream,
+                       static_cast<const char *>(rows), n, static_cast<const char *>(centers), k, g.nvec, cand_idx,
+                       cand_val, cmax2, gamma, out_idx, out_val, fb_count, fb_rows);
+    PGV_HIP(hipGetLastError());
+    if (k > kCand)
+        PGV_TRY(launch_argmin_listed(ctx, 0, sizeof(T) == 4 ? PGV_F32 : PGV_F16, g, rows, n, centers, k, fb_rows,
+                                     fb_count, out_idx, out_val));
+    return PGV_OK;
+}
+
+}  // namespace
+
+// the matrix-core path pays from a few dozen centers on (a tile is 128 / 256 centers wide)
+bool mfma_argmin_supported(int mode, int64_t n, int k) { return (mode == 0 || mode == 1 || mode == 3) && k >= 64 && n >= 256; }
+
+int launch_argmin_mfma(pgv_ctx *ctx, int mode, pgv_dtype dtype, const RowGeom &g, const void *rows, int64_t n,
+                       const void *centers, int k, int32_t *out_idx, float *out_val) {
+    if (n <= 0) return PGV_OK;
+    if (!ctx->zeros.p) {
+        PGV_TRY(ctx->zeros.ensure(256));
+        PGV_HIP(hipMemsetAsync(ctx->zeros.p, 0, 256, ctx->stream));
+    }
+    if (dtype == PGV_F32) return launch_mfma_mode<float>(ctx, mode, g, rows, n, centers, k, out_idx, out_val);
+    return launch_mfma_mode<__half>(ctx, mode, g, rows, n, centers, k, out_idx, out_val);
+}
+
+}  // namespace pgv

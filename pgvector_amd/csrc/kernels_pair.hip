@@ -55,7 +55,12 @@ template <int MODE> __device__ __forceinline__ float pair_finish(float acc) {
 template <typename T, int MODE>
 __global__ __launch_bounds__(kPairThreads) void argmin_kernel(
     const char *__restrict__ rows, int64_t n, const char *__restrict__ centers, int k, int nvec,
-    int32_t *__restrict__ out_idx, float *__restrict__ out_val) {
+    int32_t *__restrict__ out_idx, float *__restrict__ out_val, const int32_t *__restrict__ row_list,
+    const int *__restrict__ row_count) {
+    // row_list != nullptr: only the *row_count rows it names (the rows the MFMA pre-filter of
+    // kernels_mfma.hip could not decide); the grid is sized for the worst case
+    if (row_list) n = *row_count;
+    if ((int64_t)blockIdx.x * BM >= n) return;
     constexpr int N = VecTraits<T>::N;            // elements per 16-byte vector
     constexpr int VPT = BK / N;                   // vectors per row per k-slice (4 or 2)
     constexpr int LOADS = BM * VPT / kPairThreads; // 16-byte loads per thread per operand (2 or 1)
@@ -96,6 +101,7 @@ __global__ __launch_bounds__(kPairThreads) void argmin_kernel(
                 if (vi < nvec) {
                     int64_t ar = row_base + r;
                     ar = ar < n ? ar : n - 1;
+                    if (row_list) ar = row_list[ar];
                     int br = cb + r;
                     br = br < k ? br : k - 1;
                     ra = load16(rows + (size_t)ar * row_bytes + (size_t)vi * sizeof(Raw16));
@@ -164,8 +170,9 @@ __global__ __launch_bounds__(kPairThreads) void argmin_kernel(
         for (int i = 0; i < 8; i++) {
             const int64_t r = row_base + ty * 8 + i;
             if (r < n) {
-                out_idx[r] = best_idx[i];
-                if (out_val) out_val[r] = best_val[i] == INFINITY ? FLT_MAX : best_val[i];
+                const int64_t o = row_list ? row_list[r] : r;
+                out_idx[o] = best_idx[i];
+                if (out_val) out_val[o] = best_val[i] == INFINITY ? FLT_MAX : best_val[i];
             }
         }
     }
@@ -173,12 +180,13 @@ __global__ __launch_bounds__(kPairThreads) void argmin_kernel(
 
 template <typename T, int MODE>
 int launch_argmin_t(pgv_ctx *ctx, const RowGeom &g, const void *rows, int64_t n,
-                    const void *centers, int k, int32_t *out_idx, float *out_val) {
+                    const void *centers, int k, int32_t *out_idx, float *out_val,
+                    const int32_t *row_list = nullptr, const int *row_count = nullptr) {
     if (n <= 0) return PGV_OK;
     const int64_t grid = (n + BM - 1) / BM;
     hipLaunchKernelGGL((argmin_kernel<T, MODE>), dim3((unsigned)grid), dim3(kPairThreads), 0,
                        ctx->stream, static_cast<const char *>(rows), n,
-                       static_cast<const char *>(centers), k, g.nvec, out_idx, out_val);
+                       static_cast<const char *>(centers), k, g.nvec, out_idx, out_val, row_list, row_count);
     PGV_HIP(hipGetLastError());
     return PGV_OK;
 }
@@ -190,6 +198,8 @@ int launch_argmin_mode(pgv_ctx *ctx, int mode, pgv_dtype dtype, const RowGeom &g
                        const void *rows, int64_t n, const void *centers, int k,
                        int32_t *out_idx, float *out_val) {
     if (k <= 0) PGV_FAIL(PGV_ERR_ARG, "argmin: need at least one center");
+    // the dense contractions go to the matrix cores (kernels_mfma.hip); L1 and small problems stay here
+    if (mfma_argmin_supported(mode, n, k)) return launch_argmin_mfma(ctx, mode, dtype, g, rows, n, centers, k, out_idx, out_val);
 #define PGV_ARGMIN(T)                                                                     \
     switch (mode) {                                                                       \
         case 0:                                                                           \
@@ -208,6 +218,16 @@ int launch_argmin_mode(pgv_ctx *ctx, int mode, pgv_dtype dtype, const RowGeom &g
     }
 #undef PGV_ARGMIN
     PGV_FAIL(PGV_ERR_ARG, "argmin: unknown mode %d", mode);
+}
+
+// the rows named by row_list[0 .. *row_count) only (both device memory; n bounds *row_count)
+int launch_argmin_listed(pgv_ctx *ctx, int mode, pgv_dtype dtype, const RowGeom &g, const void *rows, int64_t n,
+                         const void *centers, int k, const int32_t *row_list, const int *row_count,
+                         int32_t *out_idx, float *out_val) {
+    if (mode != 0) PGV_FAIL(PGV_ERR_ARG, "listed argmin: L2 only");
+    if (dtype == PGV_F32)
+        return launch_argmin_t<float, 0>(ctx, g, rows, n, centers, k, out_idx, out_val, row_list, row_count);
+    return launch_argmin_t<__half, 0>(ctx, g, rows, n, centers, k, out_idx, out_val, row_list, row_count);
 }
 
 int launch_argmin(pgv_ctx *ctx, pgv_metric metric, pgv_dtype dtype, const RowGeom &g,

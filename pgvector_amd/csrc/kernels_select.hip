@@ -10,6 +10,7 @@
 //     deterministic (radix select on order-preserving keys, then a bitonic sort
 //     of the k survivors).
 #include "pgv_device.h"
+#include "pgv_select.h"
 
 namespace pgv {
 
@@ -127,68 +128,7 @@ __global__ void plan_tasks_kernel(const int *__restrict__ cnt, const int64_t *__
 }
 
 // ------------------------------------------------------------------- top-k
-
-constexpr int kSelThreads = 256;
-constexpr int kBins = 2048;
-constexpr int kFastCap = 1024;  // candidates the threshold pre-filter may keep
-
-struct SelShared {
-    unsigned hist[kBins];
-    unsigned wave_tot[kSelThreads / kWave];
-    unsigned count;      // entries collected so far
-    unsigned bin;        // selected bin of the current pass
-    unsigned remaining;  // how many of the selected bin are still needed
-    unsigned running;    // ordered pass: equal keys seen so far
-};
-
-// find the bin holding the `want`-th (0-based) smallest element; returns the
-// bin and rewrites `want` relative to that bin
-__device__ void pick_bin(SelShared *s, int nbins, unsigned want) {
-    // each thread owns nbins/kSelThreads consecutive bins
-    const int per = nbins / kSelThreads;
-    unsigned local = 0;
-    for (int j = 0; j < per; j++) local += s->hist[threadIdx.x * per + j];
-    __shared__ unsigned scan[kSelThreads];
-    scan[threadIdx.x] = local;
-    __syncthreads();
-    for (int st = 1; st < kSelThreads; st <<= 1) {
-        unsigned t = threadIdx.x >= (unsigned)st ? scan[threadIdx.x - st] : 0;
-        __syncthreads();
-        scan[threadIdx.x] += t;
-        __syncthreads();
-    }
-    const unsigned before = scan[threadIdx.x] - local;
-    if (want >= before && want < before + local) {
-        unsigned acc = before;
-        for (int j = 0; j < per; j++) {
-            const unsigned h = s->hist[threadIdx.x * per + j];
-            if (want < acc + h) {
-                s->bin = threadIdx.x * per + j;
-                s->remaining = want - acc;  // rank inside the bin
-                break;
-            }
-            acc += h;
-        }
-    }
-    __syncthreads();
-}
-
-__device__ void sort_entries(unsigned long long *ent, int kp) {
-    for (int size = 2; size <= kp; size <<= 1)
-        for (int stride = size >> 1; stride > 0; stride >>= 1) {
-            for (int i = threadIdx.x; i < kp / 2; i += kSelThreads) {
-                const int lo = 2 * i - (i & (stride - 1));
-                const int hi = lo + stride;
-                const bool up = (lo & size) == 0;
-                const unsigned long long a = ent[lo], b = ent[hi];
-                if ((a > b) == up) {
-                    ent[lo] = b;
-                    ent[hi] = a;
-                }
-            }
-            __syncthreads();
-        }
-}
+// block_topk (pgv_select.h) does the work; this kernel runs it for one segment per workgroup
 
 __global__ __launch_bounds__(kSelThreads) void topk_kernel(
     const float *__restrict__ vals, const int64_t *__restrict__ seg_start, int64_t fixed_len,
@@ -201,131 +141,7 @@ __global__ __launch_bounds__(kSelThreads) void topk_kernel(
     const int64_t base = seg_start ? seg_start[seg] : (int64_t)seg * fixed_len;
     const int64_t m = seg_start ? seg_start[seg + 1] - base : fixed_len;
     const float *v = vals + base;
-
-    for (int i = threadIdx.x; i < cap; i += kSelThreads) ent[i] = ~0ull;
-    if (threadIdx.x == 0) s->count = 0;
-    __syncthreads();
-
-    int sort_n = kp;     // how many entries the final sort covers
-    bool done = false;   // block-uniform: the fast path produced the candidates
-    if (m > k && k <= kSelThreads / 2 && m >= 4 * kSelThreads) {
-        // Fast path for the usual "small k of a long segment": every thread takes the minimum
-        // of its strided share; the k-th smallest of those 256 minima is a real element, hence
-        // an upper bound T0 of the k-th smallest overall.  One more sweep (L2-resident by now)
-        // keeps everything <= T0 -- a few dozen candidates -- which are then sorted by
-        // (key, position) exactly like the general path.  Falls through to the radix select
-        // if the candidates do not fit (long runs of equal keys).
-        unsigned *mins = s->hist;  // scratch
-        unsigned mine = 0xffffffffu;
-        for (int64_t i = threadIdx.x; i < m; i += kSelThreads) {
-            const unsigned key = float_to_key(v[i]);
-            mine = key < mine ? key : mine;
-        }
-        mins[threadIdx.x] = mine;
-        __syncthreads();
-        unsigned rank = 0;
-        for (int j = 0; j < kSelThreads; j++) {
-            const unsigned o = mins[j];
-            rank += (o < mine || (o == mine && j < (int)threadIdx.x)) ? 1u : 0u;
-        }
-        if (rank == (unsigned)(k - 1)) s->bin = mine;  // exactly one thread has this rank
-        __syncthreads();
-        const unsigned t0 = s->bin;
-        for (int64_t i = threadIdx.x; i < m; i += kSelThreads) {
-            const unsigned key = float_to_key(v[i]);
-            if (key <= t0) {
-                const unsigned at = atomicAdd(&s->count, 1u);
-                if (at < (unsigned)cap) ent[at] = ((unsigned long long)key << 32) | (unsigned)i;
-            }
-        }
-        __syncthreads();
-        const unsigned got = s->count;
-        if (got <= (unsigned)cap) {
-            done = true;
-            sort_n = kp;
-            while (sort_n < (int)got) sort_n <<= 1;
-        } else {
-            __syncthreads();
-            for (int i = threadIdx.x; i < cap; i += kSelThreads) ent[i] = ~0ull;
-            if (threadIdx.x == 0) s->count = 0;
-            __syncthreads();
-        }
-    }
-
-    if (done) {
-        // candidates are in ent[0, got)
-    } else if (m <= k) {
-        for (int64_t i = threadIdx.x; i < m; i += kSelThreads)
-            ent[i] = ((unsigned long long)float_to_key(v[i]) << 32) | (unsigned)i;
-        __syncthreads();
-    } else {
-        // three radix passes (11 + 11 + 10 bits) pin down the k-th smallest key exactly
-        unsigned prefix = 0;
-        unsigned want = (unsigned)(k - 1);
-        unsigned count_eq = 0;
-        for (int pass = 0; pass < 3; pass++) {
-            const int shift = pass == 0 ? 21 : (pass == 1 ? 10 : 0);
-            const int nbins = pass == 2 ? 1024 : 2048;
-            for (int i = threadIdx.x; i < kBins; i += kSelThreads) s->hist[i] = 0;
-            __syncthreads();
-            for (int64_t i = threadIdx.x; i < m; i += kSelThreads) {
-                const unsigned key = float_to_key(v[i]);
-                const bool in = pass == 0 || (pass == 1 ? (key >> 21) == (prefix >> 21)
-                                                        : (key >> 10) == (prefix >> 10));
-                if (in) atomicAdd(&s->hist[(key >> shift) & (nbins - 1)], 1u);
-            }
-            __syncthreads();
-            pick_bin(s, nbins, want);
-            prefix |= s->bin << shift;
-            want = s->remaining;
-            count_eq = s->hist[s->bin];
-            __syncthreads();
-        }
-        const unsigned thr = prefix;      // the k-th smallest key
-        const unsigned need_eq = want + 1; // how many keys == thr belong to the top k
-        if (threadIdx.x == 0) s->running = 0;
-        __syncthreads();
-        const bool ordered = count_eq > need_eq;  // ties on the boundary: lowest positions win
-        const int64_t padded = (m + kSelThreads - 1) / kSelThreads * kSelThreads;
-        for (int64_t i = threadIdx.x; i < padded; i += kSelThreads) {
-            const unsigned key = i < m ? float_to_key(v[i]) : 0xffffffffu;
-            const bool valid = i < m;
-            if (valid && key < thr) {
-                const unsigned at = atomicAdd(&s->count, 1u);
-                ent[at] = ((unsigned long long)key << 32) | (unsigned)i;
-            }
-            if (!ordered) {
-                if (valid && key == thr) {
-                    const unsigned at = atomicAdd(&s->count, 1u);
-                    ent[at] = ((unsigned long long)key << 32) | (unsigned)i;
-                }
-            } else {
-                // position-ordered rank among equal keys (block-wide, tile by tile)
-                const bool eq = valid && key == thr;
-                const unsigned long long bal = __ballot(eq);
-                const int lane = threadIdx.x & (kWave - 1), wave = threadIdx.x >> 6;
-                const unsigned before_lane = __popcll(bal & ((1ull << lane) - 1ull));
-                if (lane == 0) s->wave_tot[wave] = (unsigned)__popcll(bal);
-                __syncthreads();
-                unsigned before_wave = 0, tile_tot = 0;
-                for (int w = 0; w < kSelThreads / kWave; w++) {
-                    if (w < wave) before_wave += s->wave_tot[w];
-                    tile_tot += s->wave_tot[w];
-                }
-                const unsigned rank = s->running + before_wave + before_lane;
-                if (eq && rank < need_eq) {
-                    const unsigned at = atomicAdd(&s->count, 1u);
-                    ent[at] = ((unsigned long long)key << 32) | (unsigned)i;
-                }
-                __syncthreads();
-                if (threadIdx.x == 0) s->running += tile_tot;
-                __syncthreads();
-            }
-        }
-        __syncthreads();
-    }
-
-    sort_entries(ent, sort_n);
+    block_topk([v](int64_t i) { return v[i]; }, m, k, kp, cap, ent, s);
 
     for (int i = threadIdx.x; i < k; i += kSelThreads) {
         const unsigned long long e = ent[i];

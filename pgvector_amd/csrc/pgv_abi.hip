@@ -441,7 +441,8 @@ void pgv_ctx_destroy(pgv_ctx *ctx) {
                  &ctx->out_stage2, &ctx->idx_stage, &ctx->tasks, &ctx->pairs, &ctx->counters,
                  &ctx->plan_a, &ctx->plan_b, &ctx->plan_c, &ctx->plan_d, &ctx->dist_mat,
                  &ctx->sel_a, &ctx->sel_b, &ctx->km_a, &ctx->km_b, &ctx->km_c, &ctx->km_d,
-                 &ctx->km_e, &ctx->km_f, &ctx->km_g, &ctx->stats_dev};
+                 &ctx->km_e, &ctx->km_f, &ctx->km_g, &ctx->stats_dev, &ctx->mf_a, &ctx->mf_b, &ctx->mf_c,
+                 &ctx->zeros};
     for (DBuf *b : d) b->release();
     ctx->h_a.release();
     ctx->h_b.release();
@@ -846,6 +847,168 @@ int pgv_scan_batch(pgv_index *ix, const void *queries, int nq, const int32_t *pr
     PGV_TRY(stage_flat(ctx, probe_lists, sizeof(int32_t) * (size_t)nq * probes, ctx->idx_stage, &pl_dev));
     return scan_batch_dev(ix, q_dev, nq, static_cast<const int32_t *>(pl_dev), probes, k, out_dist, out_slot,
                           out_tid);
+}
+
+// ------------------------------------------------------- one query at a time
+namespace {
+
+struct QueryHeadHost {  // mirrors QueryHead of kernels_query.hip
+    long long total;
+    int count;
+    unsigned seq;
+};
+
+// the head record lands in pinned host memory; its seq word is written last.  Spin on it for a
+// while (the kernel's own stores are the fastest completion signal there is), then fall back to
+// a stream synchronise.
+int wait_head(pgv_ctx *ctx, pgv_query *q, unsigned seq) {
+    volatile QueryHeadHost *h = static_cast<volatile QueryHeadHost *>(q->head_pinned);
+    for (int spin = 0; spin < 200000; spin++) {
+        if (__atomic_load_n(&h->seq, __ATOMIC_ACQUIRE) == seq) return PGV_OK;
+        __builtin_ia32_pause();
+    }
+    PGV_HIP(hipStreamSynchronize(ctx->stream));
+    if (__atomic_load_n(&h->seq, __ATOMIC_ACQUIRE) != seq) PGV_FAIL(PGV_ERR_DEVICE, "query kernel did not report");
+    return PGV_OK;
+}
+
+void copy_head(pgv_query *q, int stride, int n, float *out_dist, int64_t *out_slot, uint64_t *out_tid) {
+    const char *base = static_cast<const char *>(q->head_pinned) + 64;
+    if (out_slot) memcpy(out_slot, base, sizeof(int64_t) * (size_t)n);
+    if (out_tid) memcpy(out_tid, base + (size_t)stride * 8, sizeof(uint64_t) * (size_t)n);
+    if (out_dist) memcpy(out_dist, base + (size_t)stride * 16, sizeof(float) * (size_t)n);
+}
+
+}  // namespace
+
+int pgv_query_begin(pgv_index *ix, pgv_query **out) {
+    if (!ix || !out) PGV_FAIL(PGV_ERR_ARG, "pgv_query_begin: index/out is NULL");
+    *out = nullptr;
+    pgv_ctx *ctx = ix->ctx;
+    PGV_HIP(hipSetDevice(ctx->device));
+    pgv_query *q = new (std::nothrow) pgv_query();
+    if (!q) PGV_FAIL(PGV_ERR_NOMEM, "out of host memory");
+    q->ix = ix;
+    const int cap = query_head_cap(), tw = query_ticket_words();
+    const size_t state_bytes = sizeof(int32_t) * (size_t)cap + sizeof(unsigned) * 2 * (size_t)tw +
+                               sizeof(float) * (size_t)ix->nlists;
+    const size_t row_bytes = (size_t)ix->geom.ld * elem_size(ix->dtype);
+    q->head_bytes = query_head_bytes(cap);
+    int rc = q->state.ensure(state_bytes);
+    if (rc == PGV_OK) rc = q->q_dev.ensure(row_bytes);
+    if (rc == PGV_OK && hipHostMalloc(&q->q_pinned, row_bytes, hipHostMallocDefault) != hipSuccess) rc = PGV_ERR_NOMEM;
+    if (rc == PGV_OK && hipHostMalloc(&q->head_pinned, q->head_bytes, hipHostMallocDefault) != hipSuccess)
+        rc = PGV_ERR_NOMEM;
+    if (rc == PGV_OK && hipMemsetAsync(q->state.p, 0, state_bytes, ctx->stream) != hipSuccess) rc = PGV_ERR_DEVICE;
+    if (rc != PGV_OK) {
+        set_error("pgv_query_begin: allocation failed");
+        pgv_query_end(q);
+        return rc;
+    }
+    memset(q->head_pinned, 0, q->head_bytes);
+    q->lists = q->state.as<int32_t>();
+    q->ticket_rank = reinterpret_cast<unsigned *>(q->lists + cap);
+    q->ticket_scan = q->ticket_rank + tw;
+    q->cdist = reinterpret_cast<float *>(q->ticket_scan + tw);
+    *out = q;
+    return PGV_OK;
+}
+
+void pgv_query_end(pgv_query *q) {
+    if (!q) return;
+    if (q->ix && q->ix->ctx) (void)hipStreamSynchronize(q->ix->ctx->stream);
+    q->state.release();
+    q->seg.release();
+    q->q_dev.release();
+    if (q->q_pinned) (void)hipHostFree(q->q_pinned);
+    if (q->head_pinned) (void)hipHostFree(q->head_pinned);
+    delete q;
+}
+
+int pgv_query_rank(pgv_query *q, const void *query, int max_probes) {
+    if (!q) PGV_FAIL(PGV_ERR_ARG, "pgv_query_rank: q is NULL");
+    pgv_index *ix = q->ix;
+    pgv_ctx *ctx = ix->ctx;
+    if (max_probes < 1 || max_probes > ix->nlists)
+        PGV_FAIL(PGV_ERR_ARG, "maxprobes %d outside 1..lists (%d)", max_probes, ix->nlists);
+    if (max_probes > query_head_cap())
+        PGV_FAIL(PGV_ERR_ARG, "pgv_query_rank handles up to %d probes; use pgv_rank_lists", query_head_cap());
+    PGV_HIP(hipSetDevice(ctx->device));
+    q->max_probes = max_probes;
+    q->is_null = query == nullptr;
+    q->cur_n = 0;
+    if (q->is_null) return launch_query_iota(ctx, q->lists, max_probes);
+    const size_t es = elem_size(ix->dtype);
+    const size_t row_bytes = (size_t)ix->geom.ld * es;
+    if (is_device_ptr(query)) {
+        PGV_HIP(hipMemsetAsync(q->q_dev.p, 0, row_bytes, ctx->stream));
+        PGV_HIP(hipMemcpyAsync(q->q_dev.p, query, (size_t)ix->dim * es, hipMemcpyDeviceToDevice, ctx->stream));
+    } else {
+        // the previous query's kernels have finished reading q_pinned: every pgv_query_scan waits for its head
+        memcpy(q->q_pinned, query, (size_t)ix->dim * es);
+        PGV_TRY(launch_query_stage(ctx, q->q_pinned, q->q_dev.p, (size_t)ix->dim * es, row_bytes));
+    }
+    return launch_query_rank(ctx, ix, q->q_dev.p, q->cdist, q->ticket_rank, max_probes, q->lists);
+}
+
+int pgv_query_scan(pgv_query *q, int first, int nprobes, int head, float *out_dist, int64_t *out_slot,
+                   uint64_t *out_tid, int *out_count, int64_t *out_total) {
+    if (!q || !out_count) PGV_FAIL(PGV_ERR_ARG, "pgv_query_scan: q/out_count is NULL");
+    pgv_index *ix = q->ix;
+    pgv_ctx *ctx = ix->ctx;
+    if (q->max_probes <= 0) PGV_FAIL(PGV_ERR_STATE, "pgv_query_scan before pgv_query_rank");
+    if (first < 0 || nprobes < 1 || first + nprobes > q->max_probes)
+        PGV_FAIL(PGV_ERR_ARG, "lists [%d, %d) outside the %d ranked", first, first + nprobes, q->max_probes);
+    if (nprobes > query_max_batch_lists())
+        PGV_FAIL(PGV_ERR_ARG, "pgv_query_scan handles up to %d lists per batch; use pgv_scan_lists", query_max_batch_lists());
+    if (head < 1 || head > query_head_cap()) PGV_FAIL(PGV_ERR_ARG, "head %d outside 1..%d", head, query_head_cap());
+    if (out_tid && !ix->tids) PGV_FAIL(PGV_ERR_STATE, "index was uploaded without tids");
+    PGV_HIP(hipSetDevice(ctx->device));
+    const int64_t bound = ix->len_prefix[nprobes];  // rows of the nprobes longest lists
+    PGV_TRY(q->seg.ensure(sizeof(float) * (size_t)(bound > 0 ? bound : 1)));
+    const unsigned seq = ++q->seq ? q->seq : ++q->seq;  // never 0: the cleared record's value
+    PGV_TRY(launch_query_scan(ctx, ix, q->is_null ? nullptr : q->q_dev.p, q->lists + first, nprobes, bound,
+                              q->seg.as<float>(), q->ticket_scan, head, q->head_pinned, seq));
+    q->cur_first = first;
+    q->cur_n = nprobes;
+    PGV_TRY(wait_head(ctx, q, seq));
+    const QueryHeadHost *h = static_cast<const QueryHeadHost *>(q->head_pinned);
+    *out_count = h->count;
+    if (out_total) *out_total = h->total;
+    copy_head(q, head, h->count, out_dist, out_slot, out_tid);
+    return PGV_OK;
+}
+
+int pgv_query_more(pgv_query *q, int skip, int count, float *out_dist, int64_t *out_slot, uint64_t *out_tid,
+                   int *out_count) {
+    if (!q || !out_count) PGV_FAIL(PGV_ERR_ARG, "pgv_query_more: q/out_count is NULL");
+    pgv_index *ix = q->ix;
+    pgv_ctx *ctx = ix->ctx;
+    if (q->cur_n <= 0) PGV_FAIL(PGV_ERR_STATE, "pgv_query_more before pgv_query_scan");
+    if (skip < 0 || count < 1 || skip + count > query_head_cap())
+        PGV_FAIL(PGV_ERR_ARG, "skip + count = %d exceeds %d; fetch the batch with pgv_scan_lists", skip + count,
+                 query_head_cap());
+    if (out_tid && !ix->tids) PGV_FAIL(PGV_ERR_STATE, "index was uploaded without tids");
+    PGV_HIP(hipSetDevice(ctx->device));
+    const unsigned seq = ++q->seq ? q->seq : ++q->seq;
+    PGV_TRY(launch_query_more(ctx, ix, q->seg.as<float>(), q->lists + q->cur_first, q->cur_n, skip, count,
+                              q->head_pinned, seq));
+    PGV_TRY(wait_head(ctx, q, seq));
+    const QueryHeadHost *h = static_cast<const QueryHeadHost *>(q->head_pinned);
+    *out_count = h->count;
+    copy_head(q, count, h->count, out_dist, out_slot, out_tid);
+    return PGV_OK;
+}
+
+int pgv_query_lists(pgv_query *q, int32_t *out_lists, int n) {
+    if (!q || !out_lists) PGV_FAIL(PGV_ERR_ARG, "pgv_query_lists: NULL argument");
+    if (n < 0 || n > q->max_probes) PGV_FAIL(PGV_ERR_ARG, "%d lists asked, %d ranked", n, q->max_probes);
+    pgv_ctx *ctx = q->ix->ctx;
+    PGV_HIP(hipSetDevice(ctx->device));
+    PGV_HIP(hipMemcpyAsync(out_lists, q->lists, sizeof(int32_t) * (size_t)n,
+                           is_device_ptr(out_lists) ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost, ctx->stream));
+    PGV_HIP(hipStreamSynchronize(ctx->stream));
+    return PGV_OK;
 }
 
 // ================================================================= build side

@@ -15,10 +15,15 @@
 
 extern int	pgv_host_fail(int code, const char *fmt,...);
 
+#define SCAN_HEAD 64				/* sorted tuples fetched with the scan itself: covers the usual LIMIT */
+#define SCAN_REFILL 256				/* tuples per further fetch from the device-resident batch */
+#define SCAN_DEVICE_DEPTH 1024		/* deeper than this, the batch comes over whole and is sorted here */
+
 struct pgv_ivf_scan
 {
 	pgv_index  *mirror;
 	const pgv_ivf_image *img;
+	pgv_query  *dq;				/* device-resident scan state (NULL: probes beyond the fused path's limits) */
 	int			probes,
 				max_probes;
 	int			iterative;
@@ -26,16 +31,26 @@ struct pgv_ivf_scan
 	int			first;
 	int			is_null;
 	void	   *value;			/* query payload (normalised if needed) */
-	int32_t    *lists;			/* listPages equivalent: probe order */
+	int32_t    *lists;			/* listPages equivalent: probe order (host copy, fetched when needed) */
+	int			have_lists;
 	int			nlists;
 	int			list_index;
-	/* current sorted batch */
+	int			batch_first,	/* the ranked lists of the current batch */
+				batch_n;
+	/* the current batch's sorted stream: `count` tuples, position `next` is returned next */
+	int64_t		count,
+				next;
+	/* window [win_base, win_base + win_n) of it fetched from the device, already sorted */
+	float		win_dist[SCAN_REFILL];
+	int64_t		win_slot[SCAN_REFILL];
+	int64_t		win_base;
+	int			win_n;
+	/* whole batch on the host (deep pulls and the legacy path): distances, slots, sort permutation */
+	int			whole;
 	float	   *dist;
 	int64_t    *slot;
 	int64_t    *order;			/* permutation: ascending distance, stable */
-	int64_t		capacity,
-				count,
-				next;
+	int64_t		capacity;
 };
 
 /* l2_normalize / halfvec_l2_normalize (src/vector.c:785-819, src/halfvec.c:724-759) are the
@@ -116,8 +131,9 @@ pgv_host_float_to_half(float f)
 	return (uint16_t) (sign | r);
 }
 
-static void
-normalize_value(pgv_dtype t, int dim, const void *in, void *out)
+/* returns 0 for a zero-norm value (IvfflatCheckNorm, src/ivfutils.c:98-108): such a row is not indexed */
+int
+pgv_host_normalize_value(pgv_dtype t, int dim, const void *in, void *out)
 {
 	double		norm = 0;
 
@@ -137,6 +153,7 @@ normalize_value(pgv_dtype t, int dim, const void *in, void *out)
 			else
 				((uint16_t *) out)[i] = pgv_host_float_to_half((float) (half_to_float(((const uint16_t *) in)[i]) / norm));
 		}
+	return norm > 0;
 }
 
 int
@@ -156,6 +173,8 @@ pgv_host_ivf_beginscan(pgv_index * mirror, const pgv_ivf_image * img, int probes
 	if (maxp > lists)
 		maxp = lists;
 	so = calloc(1, sizeof(*so));
+	if (!so)
+		return pgv_host_fail(PGV_ERR_NOMEM, "out of memory");
 	so->mirror = mirror;
 	so->img = img;
 	so->probes = probes;
@@ -165,6 +184,22 @@ pgv_host_ivf_beginscan(pgv_index * mirror, const pgv_ivf_image * img, int probes
 	so->first = 1;
 	so->value = malloc((size_t) img->dim * 4);
 	so->lists = malloc(sizeof(int32_t) * (size_t) maxp);
+	if (!so->value || !so->lists)
+	{
+		pgv_host_ivf_endscan(so);
+		return pgv_host_fail(PGV_ERR_NOMEM, "out of memory");
+	}
+	/* the fused single-query path: GetScanLists and GetScanItems stay on the device */
+	if (probes <= 256 && maxp <= 1024)
+	{
+		int			rc = pgv_query_begin(mirror, &so->dq);
+
+		if (rc != PGV_OK)
+		{
+			pgv_host_ivf_endscan(so);
+			return pgv_host_fail(rc, "%s", pgv_last_error());
+		}
+	}
 	*out = so;
 	return PGV_OK;
 }
@@ -175,12 +210,15 @@ pgv_host_ivf_rescan(pgv_ivf_scan * so, const void *query)
 	so->first = 1;
 	so->list_index = 0;
 	so->count = so->next = 0;
+	so->win_n = 0;
+	so->whole = 0;
+	so->have_lists = 0;
 	so->is_null = query == NULL;
 	if (query)
 	{
 		/* GetScanValue, src/ivfscan.c:201-233 */
 		if (so->normalize_query)
-			normalize_value(so->img->dtype, so->img->dim, query, so->value);
+			pgv_host_normalize_value(so->img->dtype, so->img->dim, query, so->value);
 		else
 			memcpy(so->value, query, (size_t) so->img->dim * (so->img->dtype == PGV_F32 ? 4 : 2));
 	}
@@ -221,29 +259,61 @@ merge_sort(int64_t *idx, int64_t *tmp, const float *d, int64_t n)
 	}
 }
 
-/* GetScanItems for the next batch of `probes` lists (src/ivfscan.c:123-187) */
+/* the ranked list ids on the host (the legacy path and deep pulls need them) */
 static int
-get_scan_items(pgv_ivf_scan * so)
+fetch_lists(pgv_ivf_scan * so)
 {
-	int			first = so->list_index;
-	int			nl = so->nlists - so->list_index;
+	int			rc;
+
+	if (so->have_lists)
+		return PGV_OK;
+	if (so->is_null)
+	{
+		/* ZeroDistance: every center at distance 0; the strict `<` keeps the first maxProbes lists */
+		for (int i = 0; i < so->max_probes; i++)
+			so->lists[i] = i;
+	}
+	else
+	{
+		rc = so->dq ? pgv_query_lists(so->dq, so->lists, so->max_probes)
+			: pgv_rank_lists(so->mirror, so->value, 1, so->max_probes, so->lists, NULL);
+		if (rc != PGV_OK)
+			return pgv_host_fail(rc, "%s", pgv_last_error());
+	}
+	so->have_lists = 1;
+	return PGV_OK;
+}
+
+/* the whole current batch onto the host, sorted here: what the reference's tuplesort holds */
+static int
+fetch_whole_batch(pgv_ivf_scan * so)
+{
 	int64_t		m = 0,
 				got;
 	int			rc;
 
-	if (nl > so->probes)
-		nl = so->probes;
-	so->list_index += nl;
-	for (int p = 0; p < nl; p++)
-		m += so->img->list_offsets[so->lists[first + p] + 1] - so->img->list_offsets[so->lists[first + p]];
+	if (fetch_lists(so) != PGV_OK)
+		return -1;
+	for (int p = 0; p < so->batch_n; p++)
+		m += so->img->list_offsets[so->lists[so->batch_first + p] + 1] - so->img->list_offsets[so->lists[so->batch_first + p]];
 	if (m > so->capacity)
 	{
-		so->capacity = m * 2 + 64;
-		so->dist = realloc(so->dist, sizeof(float) * (size_t) so->capacity);
-		so->slot = realloc(so->slot, sizeof(int64_t) * (size_t) so->capacity);
-		so->order = realloc(so->order, sizeof(int64_t) * (size_t) so->capacity * 2);
+		int64_t		cap = m * 2 + 64;
+		float	   *nd = realloc(so->dist, sizeof(float) * (size_t) cap);
+		int64_t    *ns = nd ? realloc(so->slot, sizeof(int64_t) * (size_t) cap) : NULL;
+		int64_t    *no = ns ? realloc(so->order, sizeof(int64_t) * (size_t) cap * 2) : NULL;
+
+		if (nd)
+			so->dist = nd;
+		if (ns)
+			so->slot = ns;
+		if (no)
+			so->order = no;
+		if (!nd || !ns || !no)
+			return pgv_host_fail(PGV_ERR_NOMEM, "out of memory for a batch of %lld tuples", (long long) m);
+		so->capacity = cap;
 	}
-	rc = pgv_scan_lists(so->mirror, so->is_null ? NULL : so->value, so->lists + first, nl,
+	rc = pgv_scan_lists(so->mirror, so->is_null ? NULL : so->value, so->lists + so->batch_first, so->batch_n,
 						so->dist, so->slot, so->capacity, &got);
 	if (rc != PGV_OK)
 		return pgv_host_fail(rc, "%s", pgv_last_error());
@@ -251,8 +321,38 @@ get_scan_items(pgv_ivf_scan * so)
 		so->order[i] = i;
 	merge_sort(so->order, so->order + so->capacity, so->dist, got);	/* tuplesort_performsort */
 	so->count = got;
-	so->next = 0;
+	so->whole = 1;
 	return PGV_OK;
+}
+
+/* GetScanItems for the next batch of `probes` lists (src/ivfscan.c:123-187) */
+static int
+get_scan_items(pgv_ivf_scan * so)
+{
+	int			nl = so->nlists - so->list_index;
+
+	if (nl > so->probes)
+		nl = so->probes;
+	so->batch_first = so->list_index;
+	so->batch_n = nl;
+	so->list_index += nl;
+	so->next = 0;
+	so->whole = 0;
+	so->win_n = 0;
+	so->win_base = 0;
+	if (so->dq)
+	{
+		/* scored, sorted and kept on the device; the head of the sorted stream comes back */
+		int64_t		total;
+		int			rc = pgv_query_scan(so->dq, so->batch_first, nl, SCAN_HEAD, so->win_dist, so->win_slot, NULL,
+										&so->win_n, &total);
+
+		if (rc != PGV_OK)
+			return pgv_host_fail(rc, "%s", pgv_last_error());
+		so->count = total;
+		return PGV_OK;
+	}
+	return fetch_whole_batch(so);
 }
 
 int
@@ -261,19 +361,15 @@ pgv_host_ivf_gettuple(pgv_ivf_scan * so, uint64_t *out_tid, double *out_distance
 	if (so->first)
 	{
 		/* GetScanLists, src/ivfscan.c:47-118 */
-		if (so->is_null)
+		if (so->dq)
 		{
-			/* ZeroDistance: every center at distance 0; the strict `<` keeps the first maxProbes lists */
-			for (int i = 0; i < so->max_probes; i++)
-				so->lists[i] = i;
-		}
-		else
-		{
-			int			rc = pgv_rank_lists(so->mirror, so->value, 1, so->max_probes, so->lists, NULL);
+			int			rc = pgv_query_rank(so->dq, so->is_null ? NULL : so->value, so->max_probes);
 
 			if (rc != PGV_OK)
 				return pgv_host_fail(rc, "%s", pgv_last_error()), -1;
 		}
+		else if (fetch_lists(so) != PGV_OK)
+			return -1;
 		so->nlists = so->max_probes;
 		so->list_index = 0;
 		if (get_scan_items(so) != PGV_OK)
@@ -288,14 +384,40 @@ pgv_host_ivf_gettuple(pgv_ivf_scan * so, uint64_t *out_tid, double *out_distance
 		if (get_scan_items(so) != PGV_OK)
 			return -1;
 	}
+	if (!so->whole && so->next >= so->win_base + so->win_n)
+	{
+		/* the executor pulls past what has been fetched: the next window of the device-resident batch,
+		 * or, far into it, the whole batch (then the sort is the host's, like the reference's) */
+		if (so->next + SCAN_REFILL <= SCAN_DEVICE_DEPTH)
+		{
+			int			rc = pgv_query_more(so->dq, (int) so->next, SCAN_REFILL, so->win_dist, so->win_slot, NULL, &so->win_n);
+
+			if (rc != PGV_OK)
+				return pgv_host_fail(rc, "%s", pgv_last_error()), -1;
+			so->win_base = so->next;
+			if (so->win_n <= 0)
+				return pgv_host_fail(PGV_ERR_STATE, "device batch ended early"), -1;
+		}
+		else if (fetch_whole_batch(so) != PGV_OK)
+			return -1;
+	}
+	if (so->whole)
 	{
 		int64_t		i = so->order[so->next++];
 
 		*out_tid = so->img->tids[so->slot[i]];
 		if (out_distance)
 			*out_distance = (double) so->dist[i];
-		return 1;
 	}
+	else
+	{
+		int64_t		i = so->next++ - so->win_base;
+
+		*out_tid = so->img->tids[so->win_slot[i]];
+		if (out_distance)
+			*out_distance = (double) so->win_dist[i];
+	}
+	return 1;
 }
 
 void
@@ -303,6 +425,8 @@ pgv_host_ivf_endscan(pgv_ivf_scan * so)
 {
 	if (!so)
 		return;
+	if (so->dq)
+		pgv_query_end(so->dq);
 	free(so->value);
 	free(so->lists);
 	free(so->dist);

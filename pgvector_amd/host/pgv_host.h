@@ -235,13 +235,23 @@ void		pgv_host_ivf_endscan(pgv_ivf_scan * scan);
  * BuildIndex (src/ivfbuild.c:1040-1058) end to end on the GPU: k-means on the given
  * samples (ComputeCenters), assignment of every heap row in batches (AssignTuples /
  * AddTupleToSort), sort by list (tuplesort on Int4LessOperator, stable here) and the
- * page writers above.  rows/tids are the non-NULL heap tuples in heap order; for the
- * cosine opclass zero-norm rows are skipped and the rest stored normalised
- * (src/ivfbuild.c:174-180).
+ * page writers above.  rows/tids are the non-NULL heap tuples in heap order, samples the
+ * rows SampleRows drew; both are taken AS STORED IN THE HEAP: for the cosine opclass
+ * zero-norm rows are skipped and the rest stored normalised (BuildCallback,
+ * src/ivfbuild.c:174-180), for the inner-product and cosine opclasses zero-norm samples
+ * are skipped and the rest normalised before k-means (SampleCallback, :148-156) -- done
+ * here, not by the caller.  Already normalised input passes through unchanged up to one
+ * rounding.
  */
 int			pgv_host_ivf_build(pgv_ctx * ctx, pgv_ops ops, pgv_dtype dtype, int dim, int lists,
 							   const void *rows, const uint64_t *tids, int64_t n,
 							   const void *samples, int nsamples, const pgv_rng * rng, pgv_rel * out_rel);
+/* seconds the last pgv_host_ivf_build on this thread spent per phase:
+ * [0] normalise [1] k-means [2] assignment [3] sort by list [4] page writer */
+void		pgv_host_ivf_build_phases(double out_secs[5]);
+/* l2_normalize / halfvec_l2_normalize of one value (src/vector.c:785-819, src/halfvec.c:724-759);
+ * returns 0 when the norm is zero (the value is then all zeros) */
+int			pgv_host_normalize_value(pgv_dtype dtype, int dim, const void *in, void *out);
 
 #ifdef __cplusplus
 }

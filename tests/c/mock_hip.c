@@ -186,6 +186,131 @@ pgv_scan_lists(pgv_index * ix, const void *query, const int32_t *lists, int nlis
 	return PGV_OK;
 }
 
+/* pgv_query_*: one query's scan state; the sorted stream of the current batch is kept whole */
+struct pgv_query
+{
+	pgv_index  *ix;
+	float	   *q;
+	int			is_null,
+				max_probes;
+	int32_t    *lists;
+	int64_t		m;
+	float	   *sd;
+	int64_t    *ss;
+};
+
+int
+pgv_query_begin(pgv_index * ix, pgv_query * *out)
+{
+	pgv_query  *q = calloc(1, sizeof(*q));
+
+	q->ix = ix;
+	q->q = malloc(sizeof(float) * (size_t) ix->dim);
+	q->lists = malloc(sizeof(int32_t) * (size_t) ix->nlists);
+	*out = q;
+	return PGV_OK;
+}
+
+void
+pgv_query_end(pgv_query * q)
+{
+	if (!q)
+		return;
+	free(q->q);
+	free(q->lists);
+	free(q->sd);
+	free(q->ss);
+	free(q);
+}
+
+int
+pgv_query_rank(pgv_query * q, const void *query, int max_probes)
+{
+	if (max_probes > 1024)
+		return fail(PGV_ERR_ARG, "mock: max_probes");
+	q->is_null = query == NULL;
+	q->max_probes = max_probes;
+	if (!query)
+	{
+		for (int i = 0; i < max_probes; i++)
+			q->lists[i] = i;
+		return PGV_OK;
+	}
+	memcpy(q->q, query, sizeof(float) * (size_t) q->ix->dim);
+	return pgv_rank_lists(q->ix, query, 1, max_probes, q->lists, NULL);
+}
+
+int
+pgv_query_lists(pgv_query * q, int32_t *out_lists, int n)
+{
+	memcpy(out_lists, q->lists, sizeof(int32_t) * (size_t) n);
+	return PGV_OK;
+}
+
+static int
+emit(pgv_query * q, int skip, int count, float *out_dist, int64_t *out_slot, uint64_t *out_tid, int *out_count)
+{
+	int			n = 0;
+
+	(void) out_tid;
+	for (int64_t i = skip; i < q->m && n < count; i++, n++)
+	{
+		if (out_dist)
+			out_dist[n] = q->sd[i];
+		if (out_slot)
+			out_slot[n] = q->ss[i];
+	}
+	*out_count = n;
+	return PGV_OK;
+}
+
+int
+pgv_query_scan(pgv_query * q, int first, int nprobes, int head, float *out_dist, int64_t *out_slot,
+			   uint64_t *out_tid, int *out_count, int64_t *out_total)
+{
+	int64_t		cap = 0,
+				got;
+
+	if (nprobes > 256 || head > 1024)
+		return fail(PGV_ERR_ARG, "mock: limits");
+	for (int i = 0; i < nprobes; i++)
+		cap += q->ix->offsets[q->lists[first + i] + 1] - q->ix->offsets[q->lists[first + i]];
+	free(q->sd);
+	free(q->ss);
+	q->sd = malloc(sizeof(float) * (size_t) (cap + 1));
+	q->ss = malloc(sizeof(int64_t) * (size_t) (cap + 1));
+	pgv_scan_lists(q->ix, q->is_null ? NULL : q->q, q->lists + first, nprobes, q->sd, q->ss, cap, &got);
+	/* stable insertion sort: ascending distance, insertion order on ties */
+	for (int64_t i = 1; i < got; i++)
+	{
+		float		d = q->sd[i];
+		int64_t		s = q->ss[i],
+					j = i - 1;
+
+		while (j >= 0 && q->sd[j] > d)
+		{
+			q->sd[j + 1] = q->sd[j];
+			q->ss[j + 1] = q->ss[j];
+			j--;
+		}
+		q->sd[j + 1] = d;
+		q->ss[j + 1] = s;
+	}
+	q->m = got;
+	if (out_total)
+		*out_total = got;
+	return emit(q, 0, head, out_dist, out_slot, out_tid, out_count);
+}
+
+int
+pgv_query_more(pgv_query * q, int skip, int count, float *out_dist, int64_t *out_slot, uint64_t *out_tid,
+			   int *out_count)
+{
+	if (skip + count > 1024)
+		return fail(PGV_ERR_ARG, "mock: depth");
+	return emit(q, skip, count, out_dist, out_slot, out_tid, out_count);
+}
+
 /* AddTupleToSort's argmin: the first strictly smallest distance wins */
 int
 pgv_assign(pgv_ctx * ctx, pgv_metric metric, pgv_dtype dtype, int dim, const void *centers, int k,

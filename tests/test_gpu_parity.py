@@ -494,12 +494,10 @@ def test_index_built_staged_and_scanned_through_the_host_glue(ctx, oracle, ops, 
     heap = gen(n, dim, seed=121, dist="clustered", clusters=lists, dtype=dtype)
     tids = ((np.arange(n, dtype=np.uint64) // 50) << np.uint64(16)) | (np.arange(n, dtype=np.uint64) % 50 + 1)
     pops = {po.OPS_L2: api.PGV_OPS_L2, po.OPS_IP: api.PGV_OPS_IP, po.OPS_COSINE: api.PGV_OPS_COSINE}[ops]
+    # rows and samples go in as the heap holds them: pgv_host_ivf_build normalises what the opclass's
+    # NORM procs normalise (BuildCallback / SampleCallback, src/ivfbuild.c:148-156, :174-180)
     rows = heap
-    if ops == po.OPS_COSINE:  # the caller stores normalised rows (src/ivfbuild.c:174-180)
-        rows = normalize_rows(oracle, heap, dtype)
     samples = rows[np.random.default_rng(1).choice(n, 1200, replace=False)]
-    if ops == po.OPS_IP:
-        samples = normalize_rows(oracle, np.ascontiguousarray(samples), dtype)
     rel = _host.Relation()
     rel.build(ctx, pops, DT[dtype], lists, rows, tids, samples, api.make_rng(seed=3))
     img = rel.stage(DT[dtype])

@@ -1,0 +1,366 @@
+"""GPU parity, round 2: the fused single-query path (pgv_query_*), the MFMA assignment, the tile
+kernel instantiations BASELINE's shapes select, spherical k-means, the reference's own index-order
+transcripts through the GPU, HNSW at configs[3]'s shape.  Same contract as test_gpu_parity.py:
+integers/indexes exact, distances within 1e-5 relative, ties compared as sets."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+from oracle import pyoracle as po
+from pgvector_amd import api
+
+from helpers import RTOL, CpuIvf, assert_close, assert_topk_equiv, gen, golden, normalize_rows
+
+pytestmark = pytest.mark.gpu
+
+DT = {po.ORA_F32: api.PGV_F32, po.ORA_F16: api.PGV_F16}
+POPS = {po.OPS_L2: api.PGV_OPS_L2, po.OPS_IP: api.PGV_OPS_IP, po.OPS_COSINE: api.PGV_OPS_COSINE}
+
+
+def _upload(ctx, ivf):
+    return api.IvfIndex(ctx, ivf.metric, DT[ivf.dtype], ivf.vectors.shape[1], ivf.centers, ivf.list_offsets,
+                        ivf.vectors, ivf.tids)
+
+
+def ora_dist(oracle, ops, dtype, q, rows):
+    return np.array([oracle.lib.ora_index_distance(ops, dtype, rows.shape[1], po._p(r), po._p(q)) for r in rows])
+
+
+# ------------------------------------------------ one query at a time (amgettuple)
+@pytest.mark.parametrize("ops,dtype,dim", [
+    (po.OPS_L2, po.ORA_F32, 64),     # 16 lanes per row
+    (po.OPS_L2, po.ORA_F32, 100),    # 25 vectors: partial last slice
+    (po.OPS_IP, po.ORA_F32, 256),    # whole 1 KiB rows, query in registers
+    (po.OPS_L2, po.ORA_F32, 1536),   # BASELINE headline row shape (6 slices)
+    (po.OPS_L2, po.ORA_F16, 512),
+    (po.OPS_L2, po.ORA_F16, 3072),   # configs[4] row shape
+    (po.OPS_IP, po.ORA_F16, 72),
+    (po.OPS_L2, po.ORA_F32, 3),
+])
+def test_query_path_is_gettuple(ctx, oracle, ops, dtype, dim):
+    """pgv_query_rank / scan / more against GetScanLists + GetScanItems + the ascending tuplesort
+    stream of the oracle (src/ivfscan.c:47-187), iterative batches included"""
+    n, lists = (3000, 24) if dim > 1000 else (9000, 40)
+    data = gen(n, dim, seed=301, dist="clustered", clusters=lists, dtype=dtype)
+    ivf = CpuIvf(oracle, ops, dtype, data, lists)
+    ix = _upload(ctx, ivf)
+    qh = api.Query(ix)
+    queries = gen(9, dim, seed=302, dist="clustered", clusters=lists, dtype=dtype)
+    for qi, q in enumerate(queries):
+        probes, maxp = (1, 5) if qi % 3 == 0 else ((3, 9) if qi % 3 == 1 else (lists, lists))
+        qh.rank(q, maxp)
+        wl, wd = oracle.get_scan_lists(ivf.struct, q, maxp)
+        gl = qh.lists(maxp)
+        assert_topk_equiv(gl.tolist(), ora_dist(oracle, ops, dtype, q, ivf.centers[gl]), wl.tolist(), wd,
+                          what="query rank dim %d q %d" % (dim, qi))
+        # first batch: head of the sorted stream, then deeper
+        wd_all, ws_all = oracle.get_scan_items(ivf.struct, q, gl[:probes])
+        d, s, t, total = qh.scan(0, probes, 32)
+        assert total == len(ws_all)
+        m = min(32, total)
+        assert_topk_equiv(s.tolist(), d, ws_all[:m].tolist(), wd_all[:m], what="query head dim %d q %d" % (dim, qi))
+        np.testing.assert_array_equal(t, ivf.tids[s])
+        if total > 32:
+            d2, s2, t2 = qh.more(32, 200)
+            m2 = min(232, total)
+            assert_topk_equiv(np.concatenate([s, s2]).tolist(), np.concatenate([d, d2]), ws_all[:m2].tolist(),
+                              wd_all[:m2], what="query more dim %d q %d" % (dim, qi))
+        # iterative scan: the next batch of `probes` lists, sorted on its own (src/ivfscan.c:400-406)
+        if maxp >= 2 * probes:
+            wd_b, ws_b = oracle.get_scan_items(ivf.struct, q, gl[probes:2 * probes])
+            d, s, _, total = qh.scan(probes, probes, 64)
+            assert total == len(ws_b)
+            m = min(64, total)
+            assert_topk_equiv(s.tolist(), d, ws_b[:m].tolist(), wd_b[:m], what="query batch 2 dim %d q %d" % (dim, qi))
+    # NULL query: ZeroDistance (src/ivfscan.c:192-196) -- the first lists, every tuple at distance 0, page order
+    qh.rank(None, 3)
+    assert qh.lists(3).tolist() == [0, 1, 2]
+    d, s, _, total = qh.scan(0, 3, 50)
+    assert total == int(ivf.list_offsets[3]) and (d == 0).all() and s.tolist() == list(range(min(50, total)))
+    qh.close()
+    ix.close()
+
+
+def test_query_path_ties_and_padding(ctx, oracle):
+    """equal distances keep insertion order (page-chain order), short batches report their true count,
+    NaN distances sort last like float8"""
+    vec = np.array([[0, 0], [1, 0], [1, 0], [0, 1], [np.nan, 0], [2, 2], [1, 0]], dtype=np.float32)
+    centers = np.array([[0, 0], [5, 5]], dtype=np.float32)
+    off = np.array([0, 7, 7], dtype=np.int64)
+    tids = np.arange(100, 107, dtype=np.uint64)
+    ix = api.IvfIndex(ctx, api.PGV_L2SQ, api.PGV_F32, 2, centers, off, vec, tids)
+    qh = api.Query(ix)
+    qh.rank(np.array([0, 0], dtype=np.float32), 2)
+    assert qh.lists(2).tolist() == [0, 1]
+    d, s, t, total = qh.scan(0, 2, 64)
+    assert total == 7 and s.tolist() == [0, 1, 2, 3, 6, 5, 4] and np.isnan(d[-1]) and t.tolist() == (s + 100).tolist()
+    d, s, _, total = qh.scan(1, 1, 8)  # an empty list
+    assert total == 0 and len(s) == 0
+    with pytest.raises(api.PgvError):
+        qh.scan(0, 3, 8)
+    qh.close()
+    ix.close()
+
+
+def test_gettuple_pulls_deep_into_a_batch(ctx, oracle):
+    """the executor may pull every tuple: head (64) -> device refills (to 1024) -> the whole batch on the host;
+    the stream must be the oracle's sorted order throughout"""
+    from pgvector_amd import _host
+    n, dim, lists = 5000, 32, 4
+    data = gen(n, dim, seed=311)
+    ivf = CpuIvf(oracle, po.OPS_L2, po.ORA_F32, data, lists)
+    rel = _host.Relation()
+    rel.write_index(api.PGV_F32, ivf.centers, ivf.list_offsets, ivf.vectors, ivf.tids)
+    img = rel.stage(api.PGV_F32)
+    mirror = api.IvfIndex(ctx, api.PGV_L2SQ, api.PGV_F32, dim, img.centers, img.list_offsets, img.vectors, img.tids)
+    scan = _host.IvfScan(mirror, img, probes=2)
+    q = gen(1, dim, seed=312)[0]
+    scan.rescan(q)
+    got_t, got_d = scan.fetch()
+    wt, wd = oracle.search(ivf.struct, q, 2, n)
+    assert len(got_t) == len(wt) > 1100
+    assert_topk_equiv(got_t.tolist(), got_d, wt.tolist(), wd, what="deep pull")
+    scan.close()
+    mirror.close()
+
+
+# --------------------------------------------------------- tile kernel shapes of BASELINE
+@pytest.mark.parametrize("ops,dtype,dim,nq,probes", [(po.OPS_L2, po.ORA_F16, 3072, 70, 5),    # tile<half, L2, 6>: configs[4]
+                                                     (po.OPS_IP, po.ORA_F32, 1536, 70, 5),    # tile<float, IP, 6>: configs[2]
+                                                     (po.OPS_IP, po.ORA_F16, 1024, 100, 4)])  # tile<half, IP, 2>
+def test_tile_kernel_baseline_shapes(ctx, oracle, ops, dtype, dim, nq, probes):
+    n, lists = 2400, 10
+    data = gen(n, dim, seed=321, dist="clustered", clusters=lists, dtype=dtype)
+    ivf = CpuIvf(oracle, ops, dtype, data, lists)
+    ix = _upload(ctx, ivf)
+    queries = gen(nq, dim, seed=322, dist="clustered", clusters=lists, dtype=dtype)
+    dist, slot, tid = ix.search_batch(queries, probes, 10, want_tid=True)
+    for i in range(nq):
+        wt, wd = oracle.search(ivf.struct, queries[i], probes, 10)
+        assert_topk_equiv(tid[i][slot[i] >= 0].tolist(), dist[i][:len(wt)], wt.tolist(), wd,
+                          what="tile ops %d dim %d q %d" % (ops, dim, i))
+    ix.close()
+
+
+# ----------------------------------------------------------------- MFMA assignment
+def _check_assign(oracle, ops, dtype, dim, rows, centers, got, gd, max_ties):
+    want, wd = oracle.assign(ops, dtype, centers, rows)
+    scale = 1.0
+    if ops != po.OPS_L2:
+        scale = float(np.max(np.abs(rows.astype(np.float64)) @ np.abs(centers.astype(np.float64)).T))
+    assert_close(gd, wd, rtol=RTOL, atol=RTOL * scale if ops != po.OPS_L2 else 1e-30, what="assign distance")
+    diff = np.nonzero(got != want)[0]
+    for r in diff:  # a different list only on a float-level tie
+        d = np.array([oracle.lib.ora_index_distance(ops, dtype, dim, po._p(rows[r]), po._p(centers[c]))
+                      for c in (got[r], want[r])])
+        assert abs(d[0] - d[1]) <= 4 * RTOL * max(abs(d).max(), scale if ops != po.OPS_L2 else 1e-30), (r, got[r], want[r], d)
+    assert len(diff) <= max_ties, (len(diff), max_ties)
+
+
+@pytest.mark.parametrize("ops,dtype,dim,k,n,dist", [
+    (po.OPS_L2, po.ORA_F32, 96, 300, 2500, "clustered"),   # pre-filter + exact recheck
+    (po.OPS_L2, po.ORA_F32, 130, 257, 1111, "uniform"),    # near ties: the exact fallback list is exercised; dim tail
+    (po.OPS_IP, po.ORA_F32, 100, 200, 3001, "normal"),     # fp32 MFMA is the reference's own arithmetic
+    (po.OPS_L2, po.ORA_F16, 200, 513, 1500, "clustered"),  # 32x32x16 f16 MFMA, 256-wide tiles, ragged edges
+    (po.OPS_IP, po.ORA_F16, 64, 64, 700, "normal"),
+    (po.OPS_L2, po.ORA_F32, 1536, 128, 600, "clustered"),  # BASELINE row shape
+])
+def test_assign_on_the_matrix_cores(ctx, oracle, ops, dtype, dim, k, n, dist):
+    rows = gen(n, dim, seed=331, dist=dist, dtype=dtype, clusters=40)
+    centers = gen(k, dim, seed=332, dist=dist, dtype=dtype, clusters=40)
+    metric = api.PGV_L2SQ if ops == po.OPS_L2 else api.PGV_NEG_IP
+    got, gd = api.assign(ctx, metric, DT[dtype], dim, centers, rows)
+    _check_assign(oracle, ops, dtype, dim, rows, centers, got, gd, max(2, n // 400))
+
+
+def test_assign_mfma_exact_ties_and_specials(ctx, oracle):
+    """integer data: exact arithmetic in the pre-filter too, so every tie reaches the exact recheck and the
+    lowest id wins; a NaN / inf center is never selected; a row of NaN stays in list 0"""
+    rows = gen(1500, 32, seed=341, dist="int")
+    centers = gen(200, 32, seed=342, dist="int")
+    for a, b in [(9, 3), (150, 3), (77, 20), (199, 198)]:
+        centers[a] = centers[b]  # duplicates inside and across the 128-wide center tiles
+    got, gd = api.assign(ctx, api.PGV_L2SQ, api.PGV_F32, 32, centers, rows)
+    want, wd = oracle.assign(po.OPS_L2, po.ORA_F32, centers, rows)
+    np.testing.assert_array_equal(got, want)
+    np.testing.assert_array_equal(gd.astype(np.float64), wd)
+    got, gd = api.assign(ctx, api.PGV_NEG_IP, api.PGV_F32, 32, centers, rows)
+    want, wd = oracle.assign(po.OPS_IP, po.ORA_F32, centers, rows)
+    np.testing.assert_array_equal(got, want)
+    np.testing.assert_array_equal(gd.astype(np.float64), wd)
+    c2 = centers.copy()
+    c2[5, 3] = np.nan
+    c2[60, 0] = np.inf
+    r2 = rows.copy()
+    r2[10, :] = np.nan
+    for metric, ops in [(api.PGV_L2SQ, po.OPS_L2), (api.PGV_NEG_IP, po.OPS_IP)]:
+        got, _ = api.assign(ctx, metric, api.PGV_F32, 32, c2, r2)
+        want, _ = oracle.assign(ops, po.ORA_F32, c2, r2)
+        np.testing.assert_array_equal(got, want)
+        assert got[10] == 0 and 5 not in got.tolist()
+
+
+# ----------------------------------------------------------------- spherical k-means
+def _unit_lattice(n, dim, seed):
+    """unit vectors with four entries of +-0.5: every inner product is a multiple of 0.25, exact in fp32"""
+    rng = np.random.default_rng(seed)
+    x = np.zeros((n, dim), dtype=np.float32)
+    for i in range(n):
+        x[i, rng.choice(dim, 4, replace=False)] = rng.choice([-0.5, 0.5], 4)
+    return x
+
+
+@pytest.mark.parametrize("ops", [po.OPS_IP, po.OPS_COSINE])
+def test_kmeanspp_spherical_picks_match_on_exact_data(ctx, oracle, ops):
+    """InitCenters under vector_spherical_distance (src/ivfkmeans.c:24-91, src/vector.c:705-722): exact inner
+    products -> the same acos(ip)/pi -> the same D^2 walk given the same pg_prng stream"""
+    samples = _unit_lattice(1200, 16, seed=351)
+    st = oracle.prng(77)
+    rng = api.make_rng(next_double=oracle.lib.ora_prng_double_cb, next_u32=oracle.lib.ora_prng_u32_cb,
+                       state=C.cast(C.pointer(st), C.c_void_p))
+    got = api.kmeanspp_init(ctx, POPS[ops], api.PGV_F32, 16, samples, 30, rng)
+    want = oracle.kmeans_init_centers(ops, po.ORA_F32, samples, 30, oracle.prng(77))
+    np.testing.assert_array_equal(got, want)
+
+
+@pytest.mark.parametrize("ops,dtype,k", [(po.OPS_IP, po.ORA_F32, 25), (po.OPS_COSINE, po.ORA_F32, 80),
+                                         (po.OPS_L2, po.ORA_F16, 25), (po.OPS_IP, po.ORA_F16, 70)])
+def test_kmeans_end_to_end_other_opclasses(ctx, oracle, ops, dtype, k):
+    """statistical parity for the spherical and halfvec builds (k >= 64 takes the MFMA assignment): same
+    stopping rule, objective within a few % of the reference's Elkan run from the same seed stream"""
+    dim = 24
+    samples = gen(6000, dim, seed=361, dist="clustered", clusters=k, dtype=dtype)
+    if ops != po.OPS_L2:
+        samples = normalize_rows(oracle, samples, dtype)
+    st = oracle.prng(11)
+    rng = api.make_rng(next_double=oracle.lib.ora_prng_double_cb, next_u32=oracle.lib.ora_prng_u32_cb,
+                       state=C.cast(C.pointer(st), C.c_void_p))
+    centers, closest, iters = api.kmeans(ctx, POPS[ops], DT[dtype], dim, samples, k, rng)
+    wc, wcl, wit = oracle.kmeans(ops, dtype, samples, k, oracle.prng(11))
+    assert 1 <= iters <= 500 and np.isfinite(centers.astype(np.float32)).all()
+    s64 = samples.astype(np.float64)
+
+    def objective(c, a):
+        c = c.astype(np.float64)
+        if ops == po.OPS_L2:
+            return float(((s64 - c[a]) ** 2).sum())
+        return float((1.0 - (s64 * c[a]).sum(axis=1)).sum())  # spherical: 1 - cos
+    assert objective(centers, closest) <= 1.05 * objective(wc, wcl) + 1e-6
+    if ops != po.OPS_L2:
+        np.testing.assert_allclose(np.linalg.norm(centers.astype(np.float64), axis=1), 1.0,
+                                   rtol=2e-3 if dtype == po.ORA_F16 else 1e-6)
+    again, _ = oracle.lloyd_assign(ops, dtype, samples, centers)
+    assert (again != closest).mean() < 0.004
+
+
+# -------------------------------------------- the reference's transcripts through the GPU
+IVF_CASES = [c for c in golden("index_order.json")["cases"] if c["am"] == "ivfflat"]
+
+
+@pytest.mark.parametrize("case", IVF_CASES, ids=[c["source"].split("/")[-1] for c in IVF_CASES])
+def test_ivfflat_transcripts_on_the_gpu(ctx, oracle, case):
+    """test/expected/ivfflat_vector.out / ivfflat_halfvec.out: CREATE INDEX over the first three rows
+    (pgv_host_ivf_build: k-means + assignment on the GPU, page writer), INSERT of the fourth, then the
+    ORDER BY query through stage -> mirror -> ivfflatgettuple; the row order must be the transcript's"""
+    from pgvector_amd import _host
+    dtype = po.ORA_F16 if case["type"] == "halfvec" else po.ORA_F32
+    ops = {"l2": po.OPS_L2, "ip": po.OPS_IP, "cosine": po.OPS_COSINE}[case["ops"]]
+    rows = np.asarray(case["rows"], dtype=po.NP_OF[dtype])
+    dim = rows.shape[1]
+    tids = (np.arange(len(rows), dtype=np.uint64) << np.uint64(16)) | np.uint64(1)
+    built = rows[:3]
+    samples = built
+    if ops == po.OPS_COSINE:
+        samples = samples[np.abs(samples.astype(np.float32)).sum(axis=1) > 0]
+    if ops != po.OPS_L2:
+        samples = normalize_rows(oracle, np.ascontiguousarray(samples), dtype)
+    rel = _host.Relation()
+    rel.build(ctx, POPS[ops], DT[dtype], case["lists"], built, tids[:3], samples, api.make_rng(seed=42))
+    # aminsert of the later rows: nearest list under FUNCTION 1, appended (src/ivfinsert.c:72-181)
+    img0 = rel.stage(DT[dtype])
+    for r in range(3, len(rows)):
+        v = rows[r]
+        if ops == po.OPS_COSINE:
+            if not np.abs(v.astype(np.float32)).sum() > 0:
+                continue
+            v = normalize_rows(oracle, v[None, :], dtype)[0]
+        lst, _ = api.assign(ctx, api.PGV_L2SQ if ops == po.OPS_L2 else api.PGV_NEG_IP, DT[dtype], dim,
+                            np.ascontiguousarray(img0.centers), v[None, :])
+        rel.insert(DT[dtype], int(lst[0]), v, int(tids[r]))
+    img = rel.stage(DT[dtype])
+    metric = api.PGV_L2SQ if ops == po.OPS_L2 else api.PGV_NEG_IP
+    mirror = api.IvfIndex(ctx, metric, DT[dtype], dim, img.centers, img.list_offsets, img.vectors, img.tids)
+
+    def run(query, probes, limit=None, **kw):
+        scan = _host.IvfScan(mirror, img, probes=probes, normalize_query=(ops == po.OPS_COSINE), **kw)
+        scan.rescan(None if query is None else np.asarray(query, dtype=po.NP_OF[dtype]))
+        t, _ = scan.fetch(limit)
+        scan.close()
+        return [rows[int(x) >> 16].astype(np.float32).tolist() for x in t]
+
+    if "self_nearest" in case:
+        for v in case["self_nearest"]:
+            assert run(v, case["probes"], limit=1) == [[float(x) for x in v]]
+    elif case.get("iterative"):
+        got = run(case["query"], case["probes"], max_probes=case["max_probes"], iterative=True)
+        assert got == [[float(x) for x in v] for v in case["expect"]]
+    else:
+        got = run(case["query"], case["probes"])
+        if "expect_count" in case:
+            assert len(got) == case["expect_count"]
+        else:
+            assert got == [[float(x) for x in v] for v in case["expect"]]
+    mirror.close()
+
+
+HNSW_CASES = [c for c in golden("index_order.json")["cases"] if c["am"] == "hnsw"]
+
+
+@pytest.mark.parametrize("case", HNSW_CASES, ids=[c["source"].split("/")[-1] for c in HNSW_CASES])
+def test_hnsw_transcripts_on_the_gpu(ctx, oracle, case):
+    """test/expected/hnsw_vector.out: the graph built by the GPU build loop, searched on the device"""
+    from pgvector_amd import _host
+    ops = {"l2": po.OPS_L2, "ip": po.OPS_IP, "cosine": po.OPS_COSINE, "l1": po.OPS_L1}[case["ops"]]
+    metric = {po.OPS_L2: api.PGV_L2SQ, po.OPS_L1: api.PGV_L1}.get(ops, api.PGV_NEG_IP)
+    rows = np.asarray(case["rows"], dtype=np.float32)
+    stored = rows
+    keep = np.arange(len(rows))
+    if ops == po.OPS_COSINE:
+        keep = np.nonzero(np.abs(rows).sum(axis=1) > 0)[0]
+        stored = normalize_rows(oracle, np.ascontiguousarray(rows[keep]), po.ORA_F32)
+    mirror = api.Hnsw(ctx, metric, api.PGV_F32, rows.shape[1], stored)
+    g = _host.hnsw_build(mirror, stored, 16, 64, api.make_rng(seed=1), max_batch=1)
+    mirror.set_graph(16, g["entry"], g["levels"], g["nbr_start"], g["nbr"])
+    q = np.asarray(case["query"], dtype=np.float32)[None, :]
+    if ops == po.OPS_COSINE:
+        q = normalize_rows(oracle, q, po.ORA_F32)
+    elem, dist, _ = mirror.search(q, 40, len(stored))
+    got = [rows[keep[e]].tolist() for e in elem[0] if e >= 0]
+    assert got == [[float(x) for x in v] for v in case["expect"]]
+    mirror.close()
+
+
+# ----------------------------------------------------------- HNSW at configs[3]'s shape
+def test_hnsw_cosine_1536_m16_ef100(ctx, oracle):
+    """BASELINE configs[3] scaled in rows only: vector_cosine_ops, 1536-d, m 16, ef_search 100, the oracle's
+    graph walked on the device"""
+    n, dim, m, ef = 2500, 1536, 16, 100
+    data = gen(n, dim, seed=371, dist="clustered", clusters=50)
+    g = po.HnswGraph(oracle, po.OPS_COSINE, po.ORA_F32, data, m=m, ef_construction=64, seed=9)
+    ex = g.export_tuples()
+    stored = normalize_rows(oracle, np.ascontiguousarray(data[ex["rows"]]), po.ORA_F32)
+    mirror = api.Hnsw(ctx, api.PGV_NEG_IP, api.PGV_F32, dim, stored)
+    mirror.set_graph(m, ex["entry"], ex["levels"], ex["nbr_start"], ex["nbr"])
+    queries = gen(24, dim, seed=372, dist="clustered", clusters=50)
+    gq = normalize_rows(oracle, queries, po.ORA_F32)
+    elem, gd, scored = mirror.search(gq, ef, 10)
+    same = 0
+    for i, q in enumerate(queries):
+        rows, wd, wscored = g.search(q, ef, 10)
+        got_rows = ex["rows"][elem[i][elem[i] >= 0]]
+        assert_topk_equiv(got_rows.tolist(), gd[i][:len(got_rows)], rows.tolist(), wd, rtol=RTOL,
+                          what="hnsw cosine 1536 q %d" % i)
+        same += int(scored[i] == wscored)
+    assert same >= 20, same
+    mirror.close()
