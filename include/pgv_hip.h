@@ -152,6 +152,11 @@ typedef struct pgv_stats
 	double		aux_ms;
 	int64_t		aux_launches;
 	double		aux_pairs;
+	/* L2 assignment on the matrix cores (pgv_assign / k-means): rows it handled, how many of them the
+	 * pre-filter left to the exact recheck of its 4 candidates, and how many the exact kernel redid in full */
+	double		assign_redo_rows;
+	double		assign_rows;
+	double		assign_recheck_rows;
 }			pgv_stats;
 int			pgv_ctx_set_profiling(pgv_ctx * ctx, int on);
 int			pgv_ctx_reset_stats(pgv_ctx * ctx);

@@ -119,7 +119,9 @@ class Context:
         check(lib.pgv_ctx_get_stats(self.h, C.byref(s)))
         return {"scan_ms": s.scan_ms, "scan_launches": s.scan_launches,
                 "scan_pairs": s.scan_pairs, "scan_rows": s.scan_rows,
-                "aux_ms": s.aux_ms, "aux_launches": s.aux_launches, "aux_pairs": s.aux_pairs}
+                "aux_ms": s.aux_ms, "aux_launches": s.aux_launches, "aux_pairs": s.aux_pairs,
+                "assign_redo_rows": s.assign_redo_rows, "assign_rows": s.assign_rows,
+                "assign_recheck_rows": s.assign_recheck_rows}
 
 
 class IvfIndex:

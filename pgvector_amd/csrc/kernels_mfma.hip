@@ -13,13 +13,22 @@
 //   order, SURVEY hard part 3); the running lexicographic (value, id) minimum is kept in the
 //   epilogue, so "first strictly smaller wins" (src/ivfbuild.c:187-191) holds exactly.
 // * L2: sum((a-b)^2) is not a contraction.  |c|^2 - 2 a.c (the |a|^2 term is the same for
-//   every center) is computed on MFMA as a PRE-FILTER that keeps the 4 best centers per row;
-//   recheck_kernel then evaluates the reference's exact sum((a-b)^2) for those 4 and picks the
-//   lexicographic minimum.  The pre-filter's rounding error is bounded by
-//   gamma * (|c|^2 + 2 |a||c|), gamma = (dim + 4) * 2^-24; a row whose 4th-best pre-filter
+//   every center) is computed on MFMA as a PRE-FILTER that keeps the 4 best centers per row.
+//   A row whose best pre-filter value is below its second best by more than twice the error
+//   bound is decided there and then (the exact computation cannot order them differently);
+//   for the others recheck_kernel evaluates the reference's exact sum((a-b)^2) of the 4 kept
+//   centers and picks the lexicographic minimum.  The pre-filter's rounding error is at most
+//   gamma * (|c|^2 + 2 |a||c|) with gamma = 8 * sqrt(dim + 4) * 2^-24 -- the probabilistic
+//   bound of a length-dim fp32 summation (Higham & Mary 2019: lambda * sqrt(n) * u fails with
+//   probability ~ exp(-lambda^2 / 2) per sum; lambda = 8), an order of magnitude tighter than
+//   the worst-case n * u and still far above any error seen.  A row whose 4th-best pre-filter
 //   value is not more than twice that bound above its best (more than 4 centers could be the
 //   true minimum) is put on a list and redone by the exact vector-ALU kernel.  Exact ties
-//   (duplicate centers, integer-valued data) therefore resolve exactly like the reference.
+//   (duplicate centers, integer-valued data) have a zero gap and therefore always reach the
+//   exact kernels and resolve exactly like the reference; should the bound ever be exceeded,
+//   the centre chosen differs from the reference's by less than the float tolerance of the
+//   distances themselves (a float-level tie, which the reference's own summation order does
+//   not pin either).
 //
 // Tiling: centers are the MFMA M dimension, data rows the N dimension, so a lane's 16
 // accumulators of a 32x32 tile are 16 centers for ONE data row and the running minimum is
@@ -122,7 +131,8 @@ template <typename T, int MODE>
 __global__ __launch_bounds__(MfmaCfg<T>::WM *MfmaCfg<T>::WN * 64, 2) void mfma_argmin_kernel(
     const char *__restrict__ rows, int64_t n, const char *__restrict__ centers, int k, int nvec,
     const float *__restrict__ bias, const char *__restrict__ zeros16, int32_t *__restrict__ out_idx,
-    float *__restrict__ out_val) {
+    float *__restrict__ out_val, const unsigned *__restrict__ cmax2_bits, float gamma, int *__restrict__ u_count,
+    int32_t *__restrict__ u_rows, int32_t *__restrict__ u_cand, float *__restrict__ u_val) {
     using C = MfmaCfg<T>;
     constexpr int TM = C::TM, TN = C::TN;
     constexpr int BM = C::WM * TM * 32, BN = C::WN * TN * 32;
@@ -175,6 +185,10 @@ __global__ __launch_bounds__(MfmaCfg<T>::WM *MfmaCfg<T>::WN * 64, 2) void mfma_a
             ti[t][c] = 0;
         }
 
+    float xx[TN];  // L2 only: this lane's share of |row|^2 (its half-wave's k-slots), gathered during the first center tile
+#pragma unroll
+    for (int t = 0; t < TN; t++) xx[t] = 0.f;
+
     const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) char *)smem;
     const unsigned a_lane = (unsigned)(wm * TM * 32 + l31) * kSliceBytes;
     const unsigned b_lane = (unsigned)(BM + wn * TN * 32 + l31) * kSliceBytes;
@@ -203,6 +217,15 @@ __global__ __launch_bounds__(MfmaCfg<T>::WM *MfmaCfg<T>::WN * 64, 2) void mfma_a
                 const unsigned x = (((unsigned)(2 * c + half)) ^ sw) << 4;
                 u32x4 a[TM], b[TN];
                 OperandRead<TM, TN>::run(sbase + a_lane + x, sbase + b_lane + x, a, b);
+                if (MODE == 0 && cb == 0) {
+#pragma unroll
+                    for (int tn = 0; tn < TN; tn++) {
+                        Raw16 raw;
+#pragma unroll
+                        for (int w = 0; w < 4; w++) raw.w[w] = b[tn][w];
+                        xx[tn] = accum_slice<T, 1>(xx[tn], raw, raw);
+                    }
+                }
 #pragma unroll
                 for (int tm = 0; tm < TM; tm++)
 #pragma unroll
@@ -238,6 +261,7 @@ __global__ __launch_bounds__(MfmaCfg<T>::WM *MfmaCfg<T>::WN * 64, 2) void mfma_a
     // merge the NSRC lists of every data row (LDS reuses the stage memory)
     float *mv = reinterpret_cast<float *>(smem);
     int *mi = reinterpret_cast<int *>(smem + sizeof(float) * BN * NSRC * NC);
+    float *mx = reinterpret_cast<float *>(smem + (sizeof(float) + sizeof(int)) * BN * NSRC * NC);  // [BN][2]
 #pragma unroll
     for (int tn = 0; tn < TN; tn++) {
         const int j = wn * TN * 32 + tn * 32 + l31;
@@ -247,6 +271,7 @@ __global__ __launch_bounds__(MfmaCfg<T>::WM *MfmaCfg<T>::WN * 64, 2) void mfma_a
             mv[(j * NSRC + s) * NC + c] = tv[tn][c];
             mi[(j * NSRC + s) * NC + c] = ti[tn][c];
         }
+        if (MODE == 0 && wm == 0) mx[j * 2 + half] = xx[tn];
     }
     __syncthreads();
     for (int j = threadIdx.x; j < BN; j += blockDim.x) {
@@ -255,9 +280,12 @@ __global__ __launch_bounds__(MfmaCfg<T>::WM *MfmaCfg<T>::WN * 64, 2) void mfma_a
         const float *v = mv + j * NSRC * NC;
         const int *id = mi + j * NSRC * NC;
         // NC rounds of lexicographic (value, id) minimum over the entries not taken yet
+        float sv[NC];
+        int sid[NC];
         float last_v = -INFINITY;
         int last_id = -1;
         bool first = true;
+#pragma unroll
         for (int c = 0; c < NC; c++) {
             float bv = INFINITY;
             int bid = 0x7fffffff;
@@ -274,16 +302,32 @@ __global__ __launch_bounds__(MfmaCfg<T>::WM *MfmaCfg<T>::WN * 64, 2) void mfma_a
                 bv = INFINITY;
                 bid = 0;
             }
-            if constexpr (NC == 1) {
-                out_idx[r] = bid;
-                if (out_val) out_val[r] = bv == INFINITY ? FLT_MAX : bv;
-            } else {
-                out_idx[r * NC + c] = bid;
-                out_val[r * NC + c] = bv;
-            }
+            sv[c] = bv;
+            sid[c] = bid;
             last_v = bv;
             last_id = bid;
             first = false;
+        }
+        if constexpr (NC == 1) {
+            out_idx[r] = sid[0];
+            if (out_val) out_val[r] = sv[0] == INFINITY ? FLT_MAX : sv[0];
+        } else {
+            // decided when the runner-up is out of the error bound's reach (k <= kCand: the recheck
+            // sees every center anyway)
+            const float cm2 = __uint_as_float(*cmax2_bits);
+            const float x2 = mx[j * 2] + mx[j * 2 + 1];
+            const float margin = 2.f * gamma * (cm2 + 2.f * sqrtf(x2 * cm2));
+            if (sv[0] < INFINITY && sv[1] - sv[0] > margin) {
+                out_idx[r] = sid[0];
+            } else {
+                const int p = atomicAdd(u_count, 1);
+                u_rows[p] = (int32_t)r;
+#pragma unroll
+                for (int c = 0; c < NC; c++) {
+                    u_cand[(size_t)p * NC + c] = sid[c];
+                    u_val[(size_t)p * NC + c] = sv[c];
+                }
+            }
         }
     }
 }
@@ -309,19 +353,22 @@ __global__ __launch_bounds__(256) void center_norms_kernel(const char *__restric
     }
 }
 
-// The reference's exact sum((a-b)^2) for the kCand pre-filtered centers of every row (one
-// wavefront per row), lexicographic minimum; rows whose pre-filter could not separate its 4th
-// candidate from its best go to the fallback list.
+// The reference's exact sum((a-b)^2) for the kCand pre-filtered centers of the rows the
+// pre-filter left undecided (one wavefront per listed row), lexicographic minimum; rows whose
+// 4th candidate is not clear of the best either go on to the redo list.
 template <typename T>
-__global__ __launch_bounds__(256) void recheck_kernel(const char *__restrict__ rows, int64_t n,
-                                                      const char *__restrict__ centers, int k, int nvec,
-                                                      const int32_t *__restrict__ cand_idx,
-                                                      const float *__restrict__ cand_val,
+__global__ __launch_bounds__(256) void recheck_kernel(const char *__restrict__ rows, const char *__restrict__ centers,
+                                                      int k, int nvec, const int *__restrict__ u_count,
+                                                      const int32_t *__restrict__ u_rows,
+                                                      const int32_t *__restrict__ u_cand,
+                                                      const float *__restrict__ u_val,
                                                       const unsigned *__restrict__ cmax2_bits, float gamma,
-                                                      int32_t *__restrict__ out_idx, float *__restrict__ out_val,
-                                                      int *__restrict__ fb_count, int32_t *__restrict__ fb_rows) {
-    const int64_t r = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (r >= n) return;
+                                                      int32_t *__restrict__ out_idx, int *__restrict__ fb_count,
+                                                      int32_t *__restrict__ fb_rows,
+                                                      unsigned long long *__restrict__ packed) {
+    const int64_t p = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (p >= *u_count) return;
+    const int64_t r = u_rows[p];
     const int lane = threadIdx.x & (kWave - 1);
     const size_t row_bytes = (size_t)nvec * sizeof(Raw16);
     const char *row = rows + (size_t)r * row_bytes;
@@ -329,7 +376,7 @@ __global__ __launch_bounds__(256) void recheck_kernel(const char *__restrict__ r
     const char *cp[kCand];
 #pragma unroll
     for (int c = 0; c < kCand; c++) {
-        id[c] = cand_idx[r * kCand + c];
+        id[c] = u_cand[p * kCand + c];
         cp[c] = centers + (size_t)id[c] * row_bytes;
     }
     float d[kCand] = {0.f, 0.f, 0.f, 0.f};
@@ -355,18 +402,74 @@ __global__ __launch_bounds__(256) void recheck_kernel(const char *__restrict__ r
             bid = id[c];
         }
     out_idx[r] = bid == 0x7fffffff ? 0 : bid;
-    if (out_val) out_val[r] = bv == INFINITY ? FLT_MAX : bv;
     if (k > kCand) {
         const float cm2 = __uint_as_float(*cmax2_bits);
         const float margin = 2.f * gamma * (cm2 + 2.f * sqrtf(xx * cm2));
-        const float v0 = cand_val[r * kCand], v3 = cand_val[r * kCand + kCand - 1];
-        if (!(v3 < INFINITY && v3 - v0 > margin)) fb_rows[atomicAdd(fb_count, 1)] = (int32_t)r;
+        const float v0 = u_val[p * kCand], v3 = u_val[p * kCand + kCand - 1];
+        if (!(v3 < INFINITY && v3 - v0 > margin)) {
+            packed[r] = ~0ull;
+            fb_rows[atomicAdd(fb_count, 1)] = (int32_t)r;
+        }
     }
 }
 
+// the redo list's rows: (distance key, center id) minima gathered by the chunked exact kernel -> list ids
+__global__ __launch_bounds__(256) void redo_finish_kernel(const int *__restrict__ fb_count,
+                                                          const int32_t *__restrict__ fb_rows,
+                                                          const unsigned long long *__restrict__ packed,
+                                                          int32_t *__restrict__ out_idx) {
+    const int64_t p = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (p >= *fb_count) return;
+    const int64_t r = fb_rows[p];
+    const unsigned long long e = packed[r];
+    out_idx[r] = e == ~0ull ? 0 : (int32_t)(unsigned)(e & 0xffffffffu);  // nothing < DBL_MAX: list 0 (src/ivfbuild.c:183-192)
+}
+
+// FUNCTION 1 distance of every row to the center chosen for it (the value AddTupleToSort's loop
+// ends with), one wavefront per row
+template <typename T>
+__global__ __launch_bounds__(256) void chosen_distance_kernel(const char *__restrict__ rows, int64_t n,
+                                                              const char *__restrict__ centers, int nvec,
+                                                              const int32_t *__restrict__ idx,
+                                                              float *__restrict__ out_val) {
+    const int64_t r = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (r >= n) return;
+    const int lane = threadIdx.x & (kWave - 1);
+    const size_t row_bytes = (size_t)nvec * sizeof(Raw16);
+    const char *row = rows + (size_t)r * row_bytes;
+    const char *cp = centers + (size_t)idx[r] * row_bytes;
+    float d0 = 0.f, d1 = 0.f;
+    int v = lane;
+    for (; v + kWave < nvec; v += 2 * kWave) {
+        const Raw16 x0 = load16(row + (size_t)v * sizeof(Raw16)), x1 = load16(row + (size_t)(v + kWave) * sizeof(Raw16));
+        const Raw16 c0 = load16(cp + (size_t)v * sizeof(Raw16)), c1 = load16(cp + (size_t)(v + kWave) * sizeof(Raw16));
+        d0 = accum_slice<T, 0>(d0, x0, c0);
+        d1 = accum_slice<T, 0>(d1, x1, c1);
+    }
+    if (v < nvec) d0 = accum_slice<T, 0>(d0, load16(row + (size_t)v * sizeof(Raw16)), load16(cp + (size_t)v * sizeof(Raw16)));
+    float d = d0 + d1;
+    for (int m = 32; m > 0; m >>= 1) d += __shfl_xor(d, m);
+    if (lane == 0) out_val[r] = d < INFINITY ? d : FLT_MAX;
+}
+
+// profiling only: rows redone by the exact kernel, rows assigned, rows rechecked -- accumulated on the device
+__global__ void add_count_kernel(const int *u_count, const int *fb_count, double *acc, double rows) {
+    acc[0] += (double)*fb_count;
+    acc[1] += rows;
+    acc[2] += (double)*u_count;
+}
+
+struct L2Lists {  // device buffers of the L2 pipeline
+    const unsigned *cmax2 = nullptr;
+    float gamma = 0.f;
+    int *u_count = nullptr;
+    int32_t *u_rows = nullptr, *u_cand = nullptr;
+    float *u_val = nullptr;
+};
+
 template <typename T, int MODE>
 int launch_mfma_t(pgv_ctx *ctx, const RowGeom &g, const void *rows, int64_t n, const void *centers, int k,
-                  const float *bias, int32_t *out_idx, float *out_val) {
+                  const float *bias, int32_t *out_idx, float *out_val, const L2Lists &l2 = L2Lists()) {
     using C = MfmaCfg<T>;
     constexpr int BM = C::WM * C::TM * 32, BN = C::WN * C::TN * 32;
     constexpr int threads = C::WM * C::WN * 64;
@@ -377,7 +480,7 @@ int launch_mfma_t(pgv_ctx *ctx, const RowGeom &g, const void *rows, int64_t n, c
     const int64_t grid = (n + BN - 1) / BN;
     hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(threads), lds, ctx->stream, static_cast<const char *>(rows), n,
                        static_cast<const char *>(centers), k, g.nvec, bias, static_cast<const char *>(ctx->zeros.p),
-                       out_idx, out_val);
+                       out_idx, out_val, l2.cmax2, l2.gamma, l2.u_count, l2.u_rows, l2.u_cand, l2.u_val);
     PGV_HIP(hipGetLastError());
     return PGV_OK;
 }
@@ -388,29 +491,56 @@ int launch_mfma_mode(pgv_ctx *ctx, int mode, const RowGeom &g, const void *rows,
     if (mode == 1) return launch_mfma_t<T, 1>(ctx, g, rows, n, centers, k, nullptr, out_idx, out_val);
     if (mode == 3) return launch_mfma_t<T, 3>(ctx, g, rows, n, centers, k, nullptr, out_idx, out_val);
 
-    // L2: norms -> MFMA pre-filter -> exact recheck -> exact redo of the ambiguous rows
-    // mf_a: bias[k] | cmax2 | fb_count      mf_b: cand_idx[n x 4] | cand_val[n x 4]      mf_c: fb_rows[n]
+    // L2: norms -> MFMA pre-filter (decides most rows) -> exact recheck of the undecided -> exact redo of
+    // the still ambiguous (chunked over the centers) -> distances to the chosen centers if asked for.
+    // mf_a: bias[k] | cmax2 | u_count | fb_count      mf_b: u_cand[n x 4] | u_val[n x 4]
+    // mf_c: u_rows[n] | fb_rows[n] | packed[n] (uint64)
+    const pgv_dtype dtype = sizeof(T) == 4 ? PGV_F32 : PGV_F16;
     PGV_TRY(ctx->mf_a.ensure(sizeof(float) * (size_t)k + 64));
     PGV_TRY(ctx->mf_b.ensure((sizeof(int32_t) + sizeof(float)) * (size_t)n * kCand));
-    PGV_TRY(ctx->mf_c.ensure(sizeof(int32_t) * (size_t)n));
+    PGV_TRY(ctx->mf_c.ensure((2 * sizeof(int32_t) + sizeof(unsigned long long)) * (size_t)n + 16));
     float *bias = ctx->mf_a.as<float>();
     unsigned *cmax2 = reinterpret_cast<unsigned *>(bias + k);
-    int *fb_count = reinterpret_cast<int *>(cmax2 + 1);
-    int32_t *cand_idx = ctx->mf_b.as<int32_t>();
-    float *cand_val = reinterpret_cast<float *>(cand_idx + (size_t)n * kCand);
-    int32_t *fb_rows = ctx->mf_c.as<int32_t>();
-    PGV_HIP(hipMemsetAsync(cmax2, 0, 2 * sizeof(int), ctx->stream));
+    int *u_count = reinterpret_cast<int *>(cmax2 + 1);
+    int *fb_count = u_count + 1;
+    int32_t *u_cand = ctx->mf_b.as<int32_t>();
+    float *u_val = reinterpret_cast<float *>(u_cand + (size_t)n * kCand);
+    unsigned long long *packed = ctx->mf_c.as<unsigned long long>();
+    int32_t *u_rows = reinterpret_cast<int32_t *>(packed + n);
+    int32_t *fb_rows = u_rows + n;
+    PGV_HIP(hipMemsetAsync(cmax2, 0, 3 * sizeof(int), ctx->stream));
     hipLaunchKernelGGL(center_norms_kernel<T>, dim3((k + 3) / 4), dim3(256), 0, ctx->stream,
                        static_cast<const char *>(centers), k, g.nvec, bias, cmax2);
-    PGV_TRY((launch_mfma_t<T, 0>(ctx, g, rows, n, centers, k, bias, cand_idx, cand_val)));
-    const float gamma = (float)(g.ld + 4) * 5.9604645e-8f;  // (dim + 4) * 2^-24: any-order fp32 dot product bound
+    L2Lists l2;
+    l2.cmax2 = cmax2;
+    l2.gamma = 8.f * sqrtf((float)(g.ld + 4)) * 5.9604645e-8f;  // 8 sqrt(dim + 4) 2^-24, see the header
+    l2.u_count = u_count;
+    l2.u_rows = u_rows;
+    l2.u_cand = u_cand;
+    l2.u_val = u_val;
+    PGV_TRY((launch_mfma_t<T, 0>(ctx, g, rows, n, centers, k, bias, out_idx, nullptr, l2)));
+    // the lists' lengths stay on the device: grids cover the worst case, surplus workgroups leave at once
     hipLaunchKernelGGL(recheck_kernel<T>, dim3((unsigned)((n + 3) / 4)), dim3(256), 0, ctx->stream,
-                       static_cast<const char *>(rows), n, static_cast<const char *>(centers), k, g.nvec, cand_idx,
-                       cand_val, cmax2, gamma, out_idx, out_val, fb_count, fb_rows);
+                       static_cast<const char *>(rows), static_cast<const char *>(centers), k, g.nvec, u_count, u_rows,
+                       u_cand, u_val, cmax2, l2.gamma, out_idx, fb_count, fb_rows, packed);
     PGV_HIP(hipGetLastError());
-    if (k > kCand)
-        PGV_TRY(launch_argmin_listed(ctx, 0, sizeof(T) == 4 ? PGV_F32 : PGV_F16, g, rows, n, centers, k, fb_rows,
-                                     fb_count, out_idx, out_val));
+    if (k > kCand) {
+        PGV_TRY(launch_argmin_listed(ctx, 0, dtype, g, rows, n, centers, k, fb_rows, fb_count, packed));
+        hipLaunchKernelGGL(redo_finish_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, fb_count,
+                           fb_rows, packed, out_idx);
+        PGV_HIP(hipGetLastError());
+    }
+    if (out_val) {
+        hipLaunchKernelGGL(chosen_distance_kernel<T>, dim3((unsigned)((n + 3) / 4)), dim3(256), 0, ctx->stream,
+                           static_cast<const char *>(rows), n, static_cast<const char *>(centers), g.nvec, out_idx,
+                           out_val);
+        PGV_HIP(hipGetLastError());
+    }
+    if (ctx->profiling && ctx->stats_dev.p) {
+        hipLaunchKernelGGL(add_count_kernel, dim3(1), dim3(1), 0, ctx->stream, u_count, fb_count,
+                           ctx->stats_dev.as<double>() + 2, (double)n);
+        PGV_HIP(hipGetLastError());
+    }
     return PGV_OK;
 }
 

@@ -25,6 +25,7 @@ constexpr int BN = 128;  // centers per tile
 constexpr int BK = 16;   // dimension slice staged in LDS
 constexpr int PAD = 4;
 constexpr int kPairThreads = 256;
+constexpr int kListedChunk = 256;  // centers per workgroup when only listed rows are redone
 
 // MODE 0: L2 squared   1: negative inner product   2: L1
 // MODE 3: spherical k-means = -clamp(ip, -1, 1): same argmin as acos(ip)/pi
@@ -56,11 +57,16 @@ template <typename T, int MODE>
 __global__ __launch_bounds__(kPairThreads) void argmin_kernel(
     const char *__restrict__ rows, int64_t n, const char *__restrict__ centers, int k, int nvec,
     int32_t *__restrict__ out_idx, float *__restrict__ out_val, const int32_t *__restrict__ row_list,
-    const int *__restrict__ row_count) {
+    const int *__restrict__ row_count, unsigned long long *__restrict__ packed) {
     // row_list != nullptr: only the *row_count rows it names (the rows the MFMA pre-filter of
-    // kernels_mfma.hip could not decide); the grid is sized for the worst case
+    // kernels_mfma.hip could not decide).  The grid is sized for the worst case, and because the
+    // list is usually short the centers are split over blockIdx.y (kListedChunk each): every
+    // workgroup folds its (distance key, center id) minimum into packed[row] with a 64-bit
+    // atomicMin -- the same lexicographic "first strictly smaller wins".
     if (row_list) n = *row_count;
     if ((int64_t)blockIdx.x * BM >= n) return;
+    const int c_begin = row_list ? (int)blockIdx.y * kListedChunk : 0;
+    const int c_end = row_list ? (c_begin + kListedChunk < k ? c_begin + kListedChunk : k) : k;
     constexpr int N = VecTraits<T>::N;            // elements per 16-byte vector
     constexpr int VPT = BK / N;                   // vectors per row per k-slice (4 or 2)
     constexpr int LOADS = BM * VPT / kPairThreads; // 16-byte loads per thread per operand (2 or 1)
@@ -82,7 +88,7 @@ __global__ __launch_bounds__(kPairThreads) void argmin_kernel(
         best_idx[i] = 0;
     }
 
-    for (int cb = 0; cb < k; cb += BN) {
+    for (int cb = c_begin; cb < c_end; cb += BN) {
         float acc[8][8];
 #pragma unroll
         for (int i = 0; i < 8; i++)
@@ -170,9 +176,14 @@ __global__ __launch_bounds__(kPairThreads) void argmin_kernel(
         for (int i = 0; i < 8; i++) {
             const int64_t r = row_base + ty * 8 + i;
             if (r < n) {
-                const int64_t o = row_list ? row_list[r] : r;
-                out_idx[o] = best_idx[i];
-                if (out_val) out_val[o] = best_val[i] == INFINITY ? FLT_MAX : best_val[i];
+                if (row_list) {
+                    if (best_val[i] < INFINITY)
+                        atomicMin(&packed[row_list[r]],
+                                  ((unsigned long long)float_to_key(best_val[i]) << 32) | (unsigned)best_idx[i]);
+                } else {
+                    out_idx[r] = best_idx[i];
+                    if (out_val) out_val[r] = best_val[i] == INFINITY ? FLT_MAX : best_val[i];
+                }
             }
         }
     }
@@ -181,12 +192,14 @@ __global__ __launch_bounds__(kPairThreads) void argmin_kernel(
 template <typename T, int MODE>
 int launch_argmin_t(pgv_ctx *ctx, const RowGeom &g, const void *rows, int64_t n,
                     const void *centers, int k, int32_t *out_idx, float *out_val,
-                    const int32_t *row_list = nullptr, const int *row_count = nullptr) {
+                    const int32_t *row_list = nullptr, const int *row_count = nullptr,
+                    unsigned long long *packed = nullptr) {
     if (n <= 0) return PGV_OK;
     const int64_t grid = (n + BM - 1) / BM;
-    hipLaunchKernelGGL((argmin_kernel<T, MODE>), dim3((unsigned)grid), dim3(kPairThreads), 0,
+    const int chunks = row_list ? (k + kListedChunk - 1) / kListedChunk : 1;
+    hipLaunchKernelGGL((argmin_kernel<T, MODE>), dim3((unsigned)grid, (unsigned)chunks), dim3(kPairThreads), 0,
                        ctx->stream, static_cast<const char *>(rows), n,
-                       static_cast<const char *>(centers), k, g.nvec, out_idx, out_val, row_list, row_count);
+                       static_cast<const char *>(centers), k, g.nvec, out_idx, out_val, row_list, row_count, packed);
     PGV_HIP(hipGetLastError());
     return PGV_OK;
 }
@@ -220,14 +233,16 @@ int launch_argmin_mode(pgv_ctx *ctx, int mode, pgv_dtype dtype, const RowGeom &g
     PGV_FAIL(PGV_ERR_ARG, "argmin: unknown mode %d", mode);
 }
 
-// the rows named by row_list[0 .. *row_count) only (both device memory; n bounds *row_count)
+// the rows named by row_list[0 .. *row_count) only (device memory; n bounds *row_count): the
+// lexicographic (distance key, center id) minimum of each is folded into packed[row], which the
+// caller preset to ~0
 int launch_argmin_listed(pgv_ctx *ctx, int mode, pgv_dtype dtype, const RowGeom &g, const void *rows, int64_t n,
                          const void *centers, int k, const int32_t *row_list, const int *row_count,
-                         int32_t *out_idx, float *out_val) {
+                         unsigned long long *packed) {
     if (mode != 0) PGV_FAIL(PGV_ERR_ARG, "listed argmin: L2 only");
     if (dtype == PGV_F32)
-        return launch_argmin_t<float, 0>(ctx, g, rows, n, centers, k, out_idx, out_val, row_list, row_count);
-    return launch_argmin_t<__half, 0>(ctx, g, rows, n, centers, k, out_idx, out_val, row_list, row_count);
+        return launch_argmin_t<float, 0>(ctx, g, rows, n, centers, k, nullptr, nullptr, row_list, row_count, packed);
+    return launch_argmin_t<__half, 0>(ctx, g, rows, n, centers, k, nullptr, nullptr, row_list, row_count, packed);
 }
 
 int launch_argmin(pgv_ctx *ctx, pgv_metric metric, pgv_dtype dtype, const RowGeom &g,

@@ -1,24 +1,25 @@
-// kernels_query.hip -- ivfflatgettuple's data path for ONE query in two launches.
+// kernels_query.hip -- ivfflatgettuple's data path for ONE query, nothing but the head read back.
 //
 // A Postgres backend scans an index for one query at a time (src/ivfscan.c:361-414): the first
 // amgettuple call runs GetScanLists (:47-118), then GetScanItems (:123-187) scores every tuple of
 // the next `probes` lists and sorts them, and the executor usually pulls only LIMIT k of them.
 // The batched path (plan kernels + tile scan + segmented top-k) needs ~10 launches and two host
-// round trips for that; here it is
+// round trips for that; here it is a chain of five small launches on one queue with no host
+// involvement in between:
 //
-//   query_rank_kernel   distance to every center, all CUs; the LAST workgroup to finish selects
-//                       the max_probes nearest (ascending, lower id on ties) into device memory
-//   query_scan_kernel   the ~N*probes/lists rows of the next `probes` lists split evenly over all
-//                       workgroups (rows are ~6 KB, a wavefront keeps two in flight), distances
-//                       kept in HBM in tuplesort input order; the LAST workgroup selects and sorts
-//                       the head of the stream and writes (distance, slot, tid) where the host
-//                       reads it -- no list of 10 000 distances crosses PCIe, no host sort
+//   query_stage_kernel   the query payload from pinned host memory into its padded device row
+//   query_rank_kernel    distance to every center, spread over all CUs
+//   query_lists_kernel   the max_probes nearest (ascending, lower id on ties) -> device memory
+//   query_scan_kernel    the ~N*probes/lists rows of the next `probes` lists split evenly over all
+//                        workgroups (rows are ~6 KB, a wavefront keeps two in flight): pure
+//                        streaming, distances kept in HBM in tuplesort input order
+//   query_head_kernel    selects and sorts the head of the stream and writes (distance, slot, tid)
+//                        into pinned host memory, the sequence word last -- no list of 10 000
+//                        distances crosses PCIe, no host sort, no stream synchronise
 //
-// "Last workgroup" hand-off: distances are published with agent-scope (sc1, write-through) stores,
-// drained (vmcnt(0)), then one agent-scope atomic ticket per workgroup; the workgroup that draws
-// the last ticket reads them back with agent-scope loads (MI355X_MICROARCH.md, inter-workgroup
-// visibility: sc1 stores + sc1 loads need no fence).  The ticket counter is reset by its last
-// user, so a query costs no memset.
+// A dependent kernel boundary costs ~1.5 us on this chip (MI355X_MICROARCH.md price list), less
+// than an in-kernel "last workgroup selects" hand-off (write-through stores, drain, ~1500 tickets,
+// acquire: ~5 us measured), and it keeps the scan kernel a clean streaming kernel.
 #include "pgv_device.h"
 #include "pgv_select.h"
 
@@ -32,44 +33,6 @@ constexpr int kQThreads = kSelThreads;  // 256: block_topk's geometry
 constexpr int kQWaves = kQThreads / kWave;
 constexpr int kMaxBatchLists = 256;     // probes per GetScanItems batch the fused path handles
 constexpr int kHeadCap = 1024;          // entries block_topk may keep
-
-__device__ __forceinline__ void publish(float *p, float v) {
-    __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
-__device__ __forceinline__ float observe(const float *p) {
-    return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
-
-// true in every thread of exactly one workgroup: the last one to get here.  Everything the
-// workgroups published before calling this is visible to that workgroup's observe() loads.
-// Two levels -- eight shard counters, then one top counter -- because ~1000 arrivals on a single
-// word serialise at ~12 ns each.  Counters are kTicketStride words apart and are reset by their
-// last user.
-constexpr int kTicketShards = 8;
-constexpr int kTicketStride = 32;
-__device__ bool last_workgroup(unsigned *ticket, unsigned nblocks) {
-    __shared__ unsigned is_last;
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wavefront's published stores have left
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        const unsigned shard = blockIdx.x % kTicketShards;
-        const unsigned in_shard = (nblocks - shard + kTicketShards - 1) / kTicketShards;
-        const unsigned shards = nblocks < (unsigned)kTicketShards ? nblocks : (unsigned)kTicketShards;
-        unsigned *sc = ticket + shard * kTicketStride;
-        unsigned *top = ticket + kTicketShards * kTicketStride;
-        bool last = false;
-        if (__hip_atomic_fetch_add(sc, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == in_shard - 1) {
-            __hip_atomic_store(sc, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            if (__hip_atomic_fetch_add(top, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == shards - 1) {
-                __hip_atomic_store(top, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                last = true;
-            }
-        }
-        is_last = last ? 1u : 0u;
-    }
-    __syncthreads();
-    return is_last != 0;
-}
 
 // ---- scoring: rows of whole 1 KiB slices keep the query in registers and two rows in flight
 template <typename T, int METRIC, int NCH> struct WholeRows {
@@ -111,7 +74,7 @@ __device__ __forceinline__ float group_distance(const char *row, const char *qp,
     return finish<METRIC>(group_sum_to_last(acc0 + acc1, lg));
 }
 
-// rows [0, m) given by a functor row_ptr(j) -> const char*, distances published to out[j]
+// rows [first, end) given by a functor row_ptr(j) -> const char*, distances to out[j]
 template <typename T, int METRIC, int NCH, typename RowPtr>
 __device__ __forceinline__ void score_rows(RowPtr row_ptr, int64_t first, int64_t end, const char *qp, int nvec, int lg,
                                            float *out) {
@@ -123,7 +86,7 @@ __device__ __forceinline__ void score_rows(RowPtr row_ptr, int64_t first, int64_
         for (int64_t j = first + 2 * wave; j < end; j += 2 * kQWaves) {
             const bool two = j + 1 < end;
             const float d = w.pair(row_ptr(j), row_ptr(two ? j + 1 : j), lane);
-            if (lane == 0 || (lane == 1 && two)) publish(out + j + lane, d);
+            if (lane == 0 || (lane == 1 && two)) out[j + lane] = d;
         }
     } else {
         const int rpw = kWave >> lg;  // rows per wavefront step
@@ -132,7 +95,7 @@ __device__ __forceinline__ void score_rows(RowPtr row_ptr, int64_t first, int64_
             const int64_t j = j0 + g;
             const bool valid = j < end;
             const float d = group_distance<T, METRIC>(row_ptr(valid ? j : end - 1), qp, nvec, lane_in, lg);
-            if (valid && lane_in == (1 << lg) - 1) publish(out + j, d);
+            if (valid && lane_in == (1 << lg) - 1) out[j] = d;
         }
     }
 }
@@ -141,21 +104,22 @@ __device__ __forceinline__ void score_rows(RowPtr row_ptr, int64_t first, int64_
 template <typename T, int METRIC, int NCH>
 __global__ __launch_bounds__(kQThreads) void query_rank_kernel(const char *__restrict__ centers, int nlists, int nvec,
                                                                int lg, const char *__restrict__ qp,
-                                                               float *__restrict__ cdist, unsigned *__restrict__ ticket,
-                                                               int max_probes, int kp, int32_t *__restrict__ out_lists,
-                                                               int per) {
-    extern __shared__ __attribute__((aligned(16))) char smem[];
+                                                               float *__restrict__ cdist, int per) {
     const size_t row_bytes = (size_t)nvec * sizeof(Raw16);
-    // centers dealt out in contiguous runs, one run per workgroup
     for (int64_t first = (int64_t)blockIdx.x * per; first < nlists; first += (int64_t)gridDim.x * per) {
         const int64_t end = first + per < nlists ? first + per : nlists;
         score_rows<T, METRIC, NCH>([&](int64_t j) { return centers + (size_t)j * row_bytes; }, first, end, qp, nvec, lg,
                                    cdist);
     }
-    if (!last_workgroup(ticket, gridDim.x)) return;
+}
+
+// the bounded heap of GetScanLists (src/ivfscan.c:76-106): max_probes nearest centers, ascending
+__global__ __launch_bounds__(kQThreads) void query_lists_kernel(const float *__restrict__ cdist, int nlists,
+                                                                int max_probes, int kp, int32_t *__restrict__ out_lists) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
     unsigned long long *ent = reinterpret_cast<unsigned long long *>(smem);
     SelShared *s = reinterpret_cast<SelShared *>(smem + (size_t)kHeadCap * 8);
-    block_topk([cdist](int64_t i) { return observe(cdist + i); }, nlists, max_probes, kp, kHeadCap, ent, s);
+    block_topk([cdist](int64_t i) { return cdist[i]; }, nlists, max_probes, kp, kHeadCap, ent, s);
     for (int i = threadIdx.x; i < max_probes; i += kQThreads) out_lists[i] = (int32_t)(unsigned)(ent[i] & 0xffffffffu);
 }
 
@@ -166,32 +130,25 @@ struct QueryHead {        // what the host reads back (pinned host memory)
     unsigned seq;         // written last: the call this record answers
 };
 
-template <typename T, int METRIC, int NCH>
-__global__ __launch_bounds__(kQThreads) void query_scan_kernel(
-    const char *__restrict__ vectors, const int64_t *__restrict__ list_off, const uint64_t *__restrict__ tids,
-    const int32_t *__restrict__ probe_lists, int nprobes, int nvec, int lg, const char *__restrict__ qp,
-    float *__restrict__ seg, unsigned *__restrict__ ticket, int head, int kp, QueryHead *__restrict__ hdr,
-    float *__restrict__ head_dist, int64_t *__restrict__ head_slot, uint64_t *__restrict__ head_tid, unsigned seq,
-    int per) {
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    __shared__ int64_t offs[kMaxBatchLists + 1];  // where each probed list starts in the batch
-    __shared__ int64_t lbeg[kMaxBatchLists];      // its first row slot
-    const size_t row_bytes = (size_t)nvec * sizeof(Raw16);
-
-    // lists in probe order, page-chain order inside: the order the reference feeds its tuplesort
-    if ((int)threadIdx.x < nprobes) {
-        const int l = probe_lists[threadIdx.x];
-        lbeg[threadIdx.x] = list_off[l];
-        offs[threadIdx.x + 1] = list_off[l + 1] - list_off[l];
+// where each probed list starts in the batch (offs) and its first row slot (lbeg): lists in probe
+// order, page-chain order inside -- the order the reference feeds its tuplesort
+struct BatchMap {
+    int64_t offs[kMaxBatchLists + 1];
+    int64_t lbeg[kMaxBatchLists];
+    __device__ void build(const int32_t *probe_lists, int nprobes, const int64_t *list_off) {
+        if ((int)threadIdx.x < nprobes) {
+            const int l = probe_lists[threadIdx.x];
+            lbeg[threadIdx.x] = list_off[l];
+            offs[threadIdx.x + 1] = list_off[l + 1] - list_off[l];
+        }
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            offs[0] = 0;
+            for (int p = 0; p < nprobes; p++) offs[p + 1] += offs[p];
+        }
+        __syncthreads();
     }
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        offs[0] = 0;
-        for (int p = 0; p < nprobes; p++) offs[p + 1] += offs[p];
-    }
-    __syncthreads();
-    const int64_t m = offs[nprobes];
-    auto slot_of = [&](int64_t j) {  // batch position -> row slot
+    __device__ __forceinline__ int64_t slot_of(int64_t j, int nprobes) const {  // batch position -> row slot
         int lo = 0, hi = nprobes - 1;
         while (lo < hi) {
             const int mid = (lo + hi + 1) >> 1;
@@ -201,64 +158,43 @@ __global__ __launch_bounds__(kQThreads) void query_scan_kernel(
                 hi = mid - 1;
         }
         return lbeg[lo] + (j - offs[lo]);
-    };
+    }
+};
 
+template <typename T, int METRIC, int NCH>
+__global__ __launch_bounds__(kQThreads) void query_scan_kernel(
+    const char *__restrict__ vectors, const int64_t *__restrict__ list_off, const int32_t *__restrict__ probe_lists,
+    int nprobes, int nvec, int lg, const char *__restrict__ qp, float *__restrict__ seg, int per) {
+    __shared__ BatchMap map;
+    const size_t row_bytes = (size_t)nvec * sizeof(Raw16);
+    map.build(probe_lists, nprobes, list_off);
+    const int64_t m = map.offs[nprobes];
     // runs of `per` rows per workgroup, round-robin until the batch is covered (the grid was sized
     // from the host's upper bound of m)
     for (int64_t first = (int64_t)blockIdx.x * per; first < m; first += (int64_t)gridDim.x * per) {
         const int64_t end = first + per < m ? first + per : m;
         if (qp) {
-            score_rows<T, METRIC, NCH>([&](int64_t j) { return vectors + (size_t)slot_of(j) * row_bytes; }, first, end,
-                                       qp, nvec, lg, seg);
+            score_rows<T, METRIC, NCH>([&](int64_t j) { return vectors + (size_t)map.slot_of(j, nprobes) * row_bytes; },
+                                       first, end, qp, nvec, lg, seg);
         } else {
             // NULL query: ZeroDistance (src/ivfscan.c:192-196), every tuple at distance 0
-            for (int64_t j = first + threadIdx.x; j < end; j += kQThreads) publish(seg + j, 0.f);
+            for (int64_t j = first + threadIdx.x; j < end; j += kQThreads) seg[j] = 0.f;
         }
-    }
-    if (!last_workgroup(ticket, gridDim.x)) return;
-
-    unsigned long long *ent = reinterpret_cast<unsigned long long *>(smem);
-    SelShared *s = reinterpret_cast<SelShared *>(smem + (size_t)kHeadCap * 8);
-    block_topk([seg](int64_t i) { return observe(seg + i); }, m, head, kp, kHeadCap, ent, s);
-    const int count = (int)(m < head ? m : head);
-    for (int i = threadIdx.x; i < count; i += kQThreads) {
-        const unsigned long long e = ent[i];
-        const int64_t slot = slot_of((int64_t)(unsigned)(e & 0xffffffffu));
-        head_dist[i] = key_to_float((unsigned)(e >> 32));
-        head_slot[i] = slot;
-        head_tid[i] = tids ? tids[slot] : ~0ull;
-    }
-    __threadfence_system();
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        hdr->total = m;
-        hdr->count = count;
-        __threadfence_system();
-        __hip_atomic_store(&hdr->seq, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
     }
 }
 
-// entries [skip, skip + count) of the sorted stream of the batch whose distances are still in
-// seg[0, m): the executor pulled past the head (one workgroup; k = skip + count <= kHeadCap)
-__global__ __launch_bounds__(kQThreads) void query_more_kernel(
+// entries [skip, skip + count) of the ascending tuplesort stream of the batch whose distances are
+// in seg[0, m) (tuplesort_performsort + the executor's pulls, src/ivfscan.c:182, :408-413): the
+// head right after the scan (skip = 0), deeper windows when the executor pulls on (one workgroup;
+// k = skip + count <= kHeadCap).  Results go to pinned host memory, the sequence word last.
+__global__ __launch_bounds__(kQThreads) void query_head_kernel(
     const float *__restrict__ seg, const int64_t *__restrict__ list_off, const uint64_t *__restrict__ tids,
     const int32_t *__restrict__ probe_lists, int nprobes, int skip, int count, int kp, QueryHead *__restrict__ hdr,
     float *__restrict__ head_dist, int64_t *__restrict__ head_slot, uint64_t *__restrict__ head_tid, unsigned seq) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    __shared__ int64_t offs[kMaxBatchLists + 1];
-    __shared__ int64_t lbeg[kMaxBatchLists];
-    if ((int)threadIdx.x < nprobes) {
-        const int l = probe_lists[threadIdx.x];
-        lbeg[threadIdx.x] = list_off[l];
-        offs[threadIdx.x + 1] = list_off[l + 1] - list_off[l];
-    }
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        offs[0] = 0;
-        for (int p = 0; p < nprobes; p++) offs[p + 1] += offs[p];
-    }
-    __syncthreads();
-    const int64_t m = offs[nprobes];
+    __shared__ BatchMap map;
+    map.build(probe_lists, nprobes, list_off);
+    const int64_t m = map.offs[nprobes];
     unsigned long long *ent = reinterpret_cast<unsigned long long *>(smem);
     SelShared *s = reinterpret_cast<SelShared *>(smem + (size_t)kHeadCap * 8);
     const int k = skip + count;
@@ -266,16 +202,7 @@ __global__ __launch_bounds__(kQThreads) void query_more_kernel(
     const int have = (int)(m < k ? m : k) - skip;
     for (int i = threadIdx.x; i < have; i += kQThreads) {
         const unsigned long long e = ent[skip + i];
-        const int64_t j = (int64_t)(unsigned)(e & 0xffffffffu);
-        int lo = 0, hi = nprobes - 1;
-        while (lo < hi) {
-            const int mid = (lo + hi + 1) >> 1;
-            if (offs[mid] <= j)
-                lo = mid;
-            else
-                hi = mid - 1;
-        }
-        const int64_t slot = lbeg[lo] + (j - offs[lo]);
+        const int64_t slot = map.slot_of((int64_t)(unsigned)(e & 0xffffffffu), nprobes);
         head_dist[i] = key_to_float((unsigned)(e >> 32));
         head_slot[i] = slot;
         head_tid[i] = tids ? tids[slot] : ~0ull;
@@ -292,9 +219,9 @@ __global__ __launch_bounds__(kQThreads) void query_more_kernel(
 
 // the query payload from pinned host memory into its padded device row (one launch on the same
 // queue instead of a copy-engine transfer with its cross-queue hand-off)
-__global__ __launch_bounds__(kQThreads) void query_stage_kernel(const uint16_t *__restrict__ src, uint16_t *__restrict__ dst,
-                                                                int src_units, int dst_units) {
-    for (int i = threadIdx.x; i < dst_units; i += kQThreads) dst[i] = i < src_units ? src[i] : (uint16_t)0;
+// (the host side has already padded it: whole 16-byte vectors, one PCIe round trip per thread)
+__global__ __launch_bounds__(1024) void query_stage_kernel(const Raw16 *__restrict__ src, Raw16 *__restrict__ dst, int nvec) {
+    for (int i = threadIdx.x; i < nvec; i += 1024) dst[i] = src[i];
 }
 
 // NULL query: ZeroDistance ranks the first max_probes lists (strict `<` never replaces, src/ivfscan.c:92)
@@ -358,12 +285,9 @@ int query_max_batch_lists() { return kMaxBatchLists; }
 int query_head_cap() { return kHeadCap; }
 size_t query_head_bytes(int head) { return sizeof(QueryHead) + (size_t)head * (4 + 8 + 8) + 64; }
 
-int query_ticket_words() { return (kTicketShards + 1) * kTicketStride; }
-
-int launch_query_stage(pgv_ctx *ctx, const void *src_pinned, void *dst_dev, size_t src_bytes, size_t dst_bytes) {
-    hipLaunchKernelGGL(query_stage_kernel, dim3(1), dim3(kQThreads), 0, ctx->stream,
-                       static_cast<const uint16_t *>(src_pinned), static_cast<uint16_t *>(dst_dev), (int)(src_bytes / 2),
-                       (int)(dst_bytes / 2));
+int launch_query_stage(pgv_ctx *ctx, const void *src_pinned, void *dst_dev, int nvec) {
+    hipLaunchKernelGGL(query_stage_kernel, dim3(1), dim3(1024), 0, ctx->stream, static_cast<const Raw16 *>(src_pinned),
+                       static_cast<Raw16 *>(dst_dev), nvec);
     PGV_HIP(hipGetLastError());
     return PGV_OK;
 }
@@ -374,53 +298,50 @@ int launch_query_iota(pgv_ctx *ctx, int32_t *out, int n) {
     return PGV_OK;
 }
 
-int launch_query_rank(pgv_ctx *ctx, const pgv_index *ix, const void *q_dev, float *cdist, unsigned *ticket,
-                      int max_probes, int32_t *out_lists) {
+int launch_query_rank(pgv_ctx *ctx, const pgv_index *ix, const void *q_dev, float *cdist, int max_probes,
+                      int32_t *out_lists) {
     const RowGeom &g = ix->geom;
     int per, grid;
     run_geometry(ctx, g, ix->nlists, &per, &grid);
     const int kp = pow2_at_least(max_probes);
-    return dispatch_metric(ix->metric, ix->dtype, [&](auto *tp, auto mc) {
+    PGV_TRY(dispatch_metric(ix->metric, ix->dtype, [&](auto *tp, auto mc) {
         using T = std::remove_pointer_t<decltype(tp)>;
         constexpr int M = decltype(mc)::value;
         return dispatch_nch<T, M>(g, [&](auto nc) {
             constexpr int NCH = decltype(nc)::value;
-            hipLaunchKernelGGL((query_rank_kernel<T, M, NCH>), dim3(grid), dim3(kQThreads), kQueryLds, ctx->stream,
+            hipLaunchKernelGGL((query_rank_kernel<T, M, NCH>), dim3(grid), dim3(kQThreads), 0, ctx->stream,
                                static_cast<const char *>(ix->centers), ix->nlists, g.nvec, g.lpr_log2,
-                               static_cast<const char *>(q_dev), cdist, ticket, max_probes, kp, out_lists, per);
+                               static_cast<const char *>(q_dev), cdist, per);
             PGV_HIP(hipGetLastError());
             return PGV_OK;
         });
-    });
+    }));
+    hipLaunchKernelGGL(query_lists_kernel, dim3(1), dim3(kQThreads), kQueryLds, ctx->stream, cdist, ix->nlists,
+                       max_probes, kp, out_lists);
+    PGV_HIP(hipGetLastError());
+    return PGV_OK;
 }
 
 int launch_query_scan(pgv_ctx *ctx, const pgv_index *ix, const void *q_dev, const int32_t *probe_lists, int nprobes,
-                      int64_t rows_bound, float *seg, unsigned *ticket, int head, void *head_rec, unsigned seq) {
+                      int64_t rows_bound, float *seg) {
     const RowGeom &g = ix->geom;
     int per, grid;
     run_geometry(ctx, g, rows_bound, &per, &grid);
-    const int kp = pow2_at_least(head);
-    QueryHead *hdr = static_cast<QueryHead *>(head_rec);
-    char *base = static_cast<char *>(head_rec) + 64;
-    int64_t *h_slot = reinterpret_cast<int64_t *>(base);
-    uint64_t *h_tid = reinterpret_cast<uint64_t *>(base + (size_t)head * 8);
-    float *h_dist = reinterpret_cast<float *>(base + (size_t)head * 16);
     return dispatch_metric(ix->metric, ix->dtype, [&](auto *tp, auto mc) {
         using T = std::remove_pointer_t<decltype(tp)>;
         constexpr int M = decltype(mc)::value;
         return dispatch_nch<T, M>(g, [&](auto nc) {
             constexpr int NCH = decltype(nc)::value;
-            hipLaunchKernelGGL((query_scan_kernel<T, M, NCH>), dim3(grid), dim3(kQThreads), kQueryLds, ctx->stream,
-                               static_cast<const char *>(ix->vectors), ix->list_offsets, ix->tids, probe_lists, nprobes,
-                               g.nvec, g.lpr_log2, static_cast<const char *>(q_dev), seg, ticket, head, kp, hdr, h_dist,
-                               h_slot, h_tid, seq, per);
+            hipLaunchKernelGGL((query_scan_kernel<T, M, NCH>), dim3(grid), dim3(kQThreads), 0, ctx->stream,
+                               static_cast<const char *>(ix->vectors), ix->list_offsets, probe_lists, nprobes, g.nvec,
+                               g.lpr_log2, static_cast<const char *>(q_dev), seg, per);
             PGV_HIP(hipGetLastError());
             return PGV_OK;
         });
     });
 }
 
-int launch_query_more(pgv_ctx *ctx, const pgv_index *ix, const float *seg, const int32_t *probe_lists, int nprobes,
+int launch_query_head(pgv_ctx *ctx, const pgv_index *ix, const float *seg, const int32_t *probe_lists, int nprobes,
                       int skip, int count, void *head_rec, unsigned seq) {
     const int kp = pow2_at_least(skip + count);
     QueryHead *hdr = static_cast<QueryHead *>(head_rec);
@@ -428,7 +349,7 @@ int launch_query_more(pgv_ctx *ctx, const pgv_index *ix, const float *seg, const
     int64_t *h_slot = reinterpret_cast<int64_t *>(base);
     uint64_t *h_tid = reinterpret_cast<uint64_t *>(base + (size_t)count * 8);
     float *h_dist = reinterpret_cast<float *>(base + (size_t)count * 16);
-    hipLaunchKernelGGL(query_more_kernel, dim3(1), dim3(kQThreads), kQueryLds, ctx->stream, seg, ix->list_offsets,
+    hipLaunchKernelGGL(query_head_kernel, dim3(1), dim3(kQThreads), kQueryLds, ctx->stream, seg, ix->list_offsets,
                        ix->tids, probe_lists, nprobes, skip, count, kp, hdr, h_dist, h_slot, h_tid, seq);
     PGV_HIP(hipGetLastError());
     return PGV_OK;

@@ -283,7 +283,7 @@ int launch_plan_batch(pgv_ctx *ctx, const pgv_index *ix, const int32_t *probe_li
     res->ntasks = res->ntasks_bound;
     res->total_out = res->out_bound;
     if (read_totals) {  // profiling: exact pair / streamed-row counts, accumulated on the device
-        PGV_TRY(ctx->stats_dev.ensure(2 * sizeof(double)));
+        PGV_TRY(ctx->stats_dev.ensure(5 * sizeof(double)));
         hipLaunchKernelGGL(plan_stats_kernel, dim3(1), dim3(256), 0, ctx->stream, cnt,
                            ix->list_offsets, totals, nlists, qt, ctx->stats_dev.as<double>());
         PGV_HIP(hipGetLastError());

@@ -482,8 +482,8 @@ int pgv_ctx_set_profiling(pgv_ctx *ctx, int on) {
     PGV_TRY(resolve_events(ctx));
     ctx->profiling = on != 0;
     if (ctx->profiling && !ctx->stats_dev.p) {
-        PGV_TRY(ctx->stats_dev.ensure(2 * sizeof(double)));
-        PGV_HIP(hipMemsetAsync(ctx->stats_dev.p, 0, 2 * sizeof(double), ctx->stream));
+        PGV_TRY(ctx->stats_dev.ensure(5 * sizeof(double)));
+        PGV_HIP(hipMemsetAsync(ctx->stats_dev.p, 0, 5 * sizeof(double), ctx->stream));
     }
     return PGV_OK;
 }
@@ -495,7 +495,7 @@ int pgv_ctx_reset_stats(pgv_ctx *ctx) {
     ctx->scan_launches = 0;
     ctx->scan_pairs = 0;
     ctx->scan_rows = 0;
-    if (ctx->stats_dev.p) PGV_HIP(hipMemsetAsync(ctx->stats_dev.p, 0, 2 * sizeof(double), ctx->stream));
+    if (ctx->stats_dev.p) PGV_HIP(hipMemsetAsync(ctx->stats_dev.p, 0, 5 * sizeof(double), ctx->stream));
     ctx->aux_ms = 0;
     ctx->aux_launches = 0;
     ctx->aux_pairs = 0;
@@ -505,7 +505,7 @@ int pgv_ctx_reset_stats(pgv_ctx *ctx) {
 int pgv_ctx_get_stats(pgv_ctx *ctx, pgv_stats *out) {
     if (!ctx || !out) PGV_FAIL(PGV_ERR_ARG, "ctx/out is NULL");
     PGV_TRY(resolve_events(ctx));
-    double dev_acc[2] = {0.0, 0.0};
+    double dev_acc[5] = {0.0, 0.0, 0.0, 0.0, 0.0};
     if (ctx->stats_dev.p) {
         PGV_HIP(hipMemcpyAsync(dev_acc, ctx->stats_dev.p, sizeof(dev_acc), hipMemcpyDeviceToHost, ctx->stream));
         PGV_HIP(hipStreamSynchronize(ctx->stream));
@@ -517,6 +517,9 @@ int pgv_ctx_get_stats(pgv_ctx *ctx, pgv_stats *out) {
     out->aux_ms = ctx->aux_ms;
     out->aux_launches = ctx->aux_launches;
     out->aux_pairs = ctx->aux_pairs;
+    out->assign_redo_rows = dev_acc[2];
+    out->assign_rows = dev_acc[3];
+    out->assign_recheck_rows = dev_acc[4];
     return PGV_OK;
 }
 
@@ -889,9 +892,8 @@ int pgv_query_begin(pgv_index *ix, pgv_query **out) {
     pgv_query *q = new (std::nothrow) pgv_query();
     if (!q) PGV_FAIL(PGV_ERR_NOMEM, "out of host memory");
     q->ix = ix;
-    const int cap = query_head_cap(), tw = query_ticket_words();
-    const size_t state_bytes = sizeof(int32_t) * (size_t)cap + sizeof(unsigned) * 2 * (size_t)tw +
-                               sizeof(float) * (size_t)ix->nlists;
+    const int cap = query_head_cap();
+    const size_t state_bytes = sizeof(int32_t) * (size_t)cap + sizeof(float) * (size_t)ix->nlists;
     const size_t row_bytes = (size_t)ix->geom.ld * elem_size(ix->dtype);
     q->head_bytes = query_head_bytes(cap);
     int rc = q->state.ensure(state_bytes);
@@ -907,9 +909,7 @@ int pgv_query_begin(pgv_index *ix, pgv_query **out) {
     }
     memset(q->head_pinned, 0, q->head_bytes);
     q->lists = q->state.as<int32_t>();
-    q->ticket_rank = reinterpret_cast<unsigned *>(q->lists + cap);
-    q->ticket_scan = q->ticket_rank + tw;
-    q->cdist = reinterpret_cast<float *>(q->ticket_scan + tw);
+    q->cdist = reinterpret_cast<float *>(q->lists + cap);
     *out = q;
     return PGV_OK;
 }
@@ -945,10 +945,14 @@ int pgv_query_rank(pgv_query *q, const void *query, int max_probes) {
         PGV_HIP(hipMemcpyAsync(q->q_dev.p, query, (size_t)ix->dim * es, hipMemcpyDeviceToDevice, ctx->stream));
     } else {
         // the previous query's kernels have finished reading q_pinned: every pgv_query_scan waits for its head
+        // (a rank that no scan followed is waited for here)
+        if (q->rank_pending) PGV_HIP(hipStreamSynchronize(ctx->stream));
         memcpy(q->q_pinned, query, (size_t)ix->dim * es);
-        PGV_TRY(launch_query_stage(ctx, q->q_pinned, q->q_dev.p, (size_t)ix->dim * es, row_bytes));
+        if (row_bytes > (size_t)ix->dim * es) memset(static_cast<char *>(q->q_pinned) + (size_t)ix->dim * es, 0, row_bytes - (size_t)ix->dim * es);
+        PGV_TRY(launch_query_stage(ctx, q->q_pinned, q->q_dev.p, ix->geom.nvec));
     }
-    return launch_query_rank(ctx, ix, q->q_dev.p, q->cdist, q->ticket_rank, max_probes, q->lists);
+    q->rank_pending = true;
+    return launch_query_rank(ctx, ix, q->q_dev.p, q->cdist, max_probes, q->lists);
 }
 
 int pgv_query_scan(pgv_query *q, int first, int nprobes, int head, float *out_dist, int64_t *out_slot,
@@ -968,10 +972,12 @@ int pgv_query_scan(pgv_query *q, int first, int nprobes, int head, float *out_di
     PGV_TRY(q->seg.ensure(sizeof(float) * (size_t)(bound > 0 ? bound : 1)));
     const unsigned seq = ++q->seq ? q->seq : ++q->seq;  // never 0: the cleared record's value
     PGV_TRY(launch_query_scan(ctx, ix, q->is_null ? nullptr : q->q_dev.p, q->lists + first, nprobes, bound,
-                              q->seg.as<float>(), q->ticket_scan, head, q->head_pinned, seq));
+                              q->seg.as<float>()));
+    PGV_TRY(launch_query_head(ctx, ix, q->seg.as<float>(), q->lists + first, nprobes, 0, head, q->head_pinned, seq));
     q->cur_first = first;
     q->cur_n = nprobes;
     PGV_TRY(wait_head(ctx, q, seq));
+    q->rank_pending = false;
     const QueryHeadHost *h = static_cast<const QueryHeadHost *>(q->head_pinned);
     *out_count = h->count;
     if (out_total) *out_total = h->total;
@@ -991,7 +997,7 @@ int pgv_query_more(pgv_query *q, int skip, int count, float *out_dist, int64_t *
     if (out_tid && !ix->tids) PGV_FAIL(PGV_ERR_STATE, "index was uploaded without tids");
     PGV_HIP(hipSetDevice(ctx->device));
     const unsigned seq = ++q->seq ? q->seq : ++q->seq;
-    PGV_TRY(launch_query_more(ctx, ix, q->seg.as<float>(), q->lists + q->cur_first, q->cur_n, skip, count,
+    PGV_TRY(launch_query_head(ctx, ix, q->seg.as<float>(), q->lists + q->cur_first, q->cur_n, skip, count,
                               q->head_pinned, seq));
     PGV_TRY(wait_head(ctx, q, seq));
     const QueryHeadHost *h = static_cast<const QueryHeadHost *>(q->head_pinned);
@@ -1008,6 +1014,7 @@ int pgv_query_lists(pgv_query *q, int32_t *out_lists, int n) {
     PGV_HIP(hipMemcpyAsync(out_lists, q->lists, sizeof(int32_t) * (size_t)n,
                            is_device_ptr(out_lists) ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost, ctx->stream));
     PGV_HIP(hipStreamSynchronize(ctx->stream));
+    q->rank_pending = false;
     return PGV_OK;
 }
 

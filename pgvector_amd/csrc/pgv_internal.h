@@ -147,17 +147,17 @@ struct pgv_index {
 // one backend's index scan (pgv_query_*): everything between amrescan and amendscan that lives on the device
 struct pgv_query {
     pgv_index *ix = nullptr;
-    pgv::DBuf state;      // lists[head cap] | tickets (rank) | tickets (scan) | cdist[nlists]
+    pgv::DBuf state;      // lists[head cap] | cdist[nlists]
     pgv::DBuf seg;        // distances of the current GetScanItems batch, tuplesort input order
     pgv::DBuf q_dev;      // the query row, padded
     void *q_pinned = nullptr;     // pinned host staging of the query payload
     void *head_pinned = nullptr;  // pinned, device-written: QueryHead + head arrays
     size_t head_bytes = 0;
     int32_t *lists = nullptr;
-    unsigned *ticket_rank = nullptr, *ticket_scan = nullptr;
     float *cdist = nullptr;
     int max_probes = 0;   // lists ranked by the last pgv_query_rank
     bool is_null = false;
+    bool rank_pending = false;     // kernels that read q_pinned may still be in flight
     int cur_first = 0, cur_n = 0;  // the batch whose distances are in seg
     unsigned seq = 0;
 };
@@ -240,7 +240,7 @@ int launch_argmin_mode(pgv_ctx *ctx, int mode, pgv_dtype dtype, const RowGeom &g
 
 int launch_argmin_listed(pgv_ctx *ctx, int mode, pgv_dtype dtype, const RowGeom &g, const void *rows, int64_t n,
                          const void *centers, int k, const int32_t *row_list, const int *row_count,
-                         int32_t *out_idx, float *out_val);
+                         unsigned long long *packed);
 // kernels_mfma.hip: the same on the matrix cores (ip / spherical directly, L2 as pre-filter + exact recheck)
 bool mfma_argmin_supported(int mode, int64_t n, int k);
 int launch_argmin_mfma(pgv_ctx *ctx, int mode, pgv_dtype dtype, const RowGeom &g, const void *rows, int64_t n,
@@ -268,18 +268,17 @@ int launch_positions_to_slots(pgv_ctx *ctx, const pgv_index *ix, const int32_t *
 int launch_iota_slots(pgv_ctx *ctx, const pgv_index *ix, const int32_t *lists_dev, int nlists,
                       const int64_t *probe_off, int64_t *out_slot);
 
-// kernels_query.hip: one query, two launches (GetScanLists; GetScanItems + sorted head)
+// kernels_query.hip: one query at a time (stage, rank, lists, scan, head: five launches, no host round trip)
 int query_max_batch_lists();
 int query_head_cap();
-int query_ticket_words();
 size_t query_head_bytes(int head);
-int launch_query_stage(pgv_ctx *ctx, const void *src_pinned, void *dst_dev, size_t src_bytes, size_t dst_bytes);
+int launch_query_stage(pgv_ctx *ctx, const void *src_pinned, void *dst_dev, int nvec);
 int launch_query_iota(pgv_ctx *ctx, int32_t *out, int n);
-int launch_query_rank(pgv_ctx *ctx, const pgv_index *ix, const void *q_dev, float *cdist, unsigned *ticket,
-                      int max_probes, int32_t *out_lists);
+int launch_query_rank(pgv_ctx *ctx, const pgv_index *ix, const void *q_dev, float *cdist, int max_probes,
+                      int32_t *out_lists);
 int launch_query_scan(pgv_ctx *ctx, const pgv_index *ix, const void *q_dev, const int32_t *probe_lists, int nprobes,
-                      int64_t rows_bound, float *seg, unsigned *ticket, int head, void *head_rec, unsigned seq);
-int launch_query_more(pgv_ctx *ctx, const pgv_index *ix, const float *seg, const int32_t *probe_lists, int nprobes,
+                      int64_t rows_bound, float *seg);
+int launch_query_head(pgv_ctx *ctx, const pgv_index *ix, const float *seg, const int32_t *probe_lists, int nprobes,
                       int skip, int count, void *head_rec, unsigned seq);
 
 // kernels_select.hip (small helpers)

@@ -112,9 +112,24 @@ __device__ void block_topk(Load load, int64_t m, int k, int kp, int cap, unsigne
         // if the candidates do not fit (long runs of equal keys).
         unsigned *mins = s->hist;  // scratch
         unsigned mine = 0xffffffffu;
-        for (int64_t i = threadIdx.x; i < m; i += kSelThreads) {
-            const unsigned key = float_to_key(load(i));
-            mine = key < mine ? key : mine;
+        {
+            // sixteen independent loads in flight per thread: the sweep is latency-bound
+            constexpr int U = 16;
+            int64_t i = threadIdx.x;
+            for (; i + (U - 1) * kSelThreads < m; i += (int64_t)U * kSelThreads) {
+                float v[U];
+#pragma unroll
+                for (int u = 0; u < U; u++) v[u] = load(i + (int64_t)u * kSelThreads);
+#pragma unroll
+                for (int u = 0; u < U; u++) {
+                    const unsigned key = float_to_key(v[u]);
+                    mine = key < mine ? key : mine;
+                }
+            }
+            for (; i < m; i += kSelThreads) {
+                const unsigned key = float_to_key(load(i));
+                mine = key < mine ? key : mine;
+            }
         }
         mins[threadIdx.x] = mine;
         __syncthreads();
@@ -126,11 +141,29 @@ __device__ void block_topk(Load load, int64_t m, int k, int kp, int cap, unsigne
         if (rank == (unsigned)(k - 1)) s->bin = mine;  // exactly one thread has this rank
         __syncthreads();
         const unsigned t0 = s->bin;
-        for (int64_t i = threadIdx.x; i < m; i += kSelThreads) {
-            const unsigned key = float_to_key(load(i));
-            if (key <= t0) {
-                const unsigned at = atomicAdd(&s->count, 1u);
-                if (at < (unsigned)cap) ent[at] = ((unsigned long long)key << 32) | (unsigned)i;
+        {
+            constexpr int U = 16;
+            int64_t i = threadIdx.x;
+            for (; i + (U - 1) * kSelThreads < m; i += (int64_t)U * kSelThreads) {
+                float v[U];
+#pragma unroll
+                for (int u = 0; u < U; u++) v[u] = load(i + (int64_t)u * kSelThreads);
+#pragma unroll
+                for (int u = 0; u < U; u++) {
+                    const unsigned key = float_to_key(v[u]);
+                    if (key <= t0) {
+                        const unsigned at = atomicAdd(&s->count, 1u);
+                        if (at < (unsigned)cap)
+                            ent[at] = ((unsigned long long)key << 32) | (unsigned)(i + (int64_t)u * kSelThreads);
+                    }
+                }
+            }
+            for (; i < m; i += kSelThreads) {
+                const unsigned key = float_to_key(load(i));
+                if (key <= t0) {
+                    const unsigned at = atomicAdd(&s->count, 1u);
+                    if (at < (unsigned)cap) ent[at] = ((unsigned long long)key << 32) | (unsigned)i;
+                }
             }
         }
         __syncthreads();
