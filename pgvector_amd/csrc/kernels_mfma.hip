@@ -207,8 +207,11 @@ __global__ __launch_bounds__(MfmaCfg<T>::WM *MfmaCfg<T>::WN * 64, 2) void mfma_a
 
         issue_stage(cb, 0, 0);
         for (int sl = 0; sl < nslices; sl++) {
-            // slice sl has landed for every wavefront (vmcnt(0) + barrier) and nobody still
-            // reads the other buffer
+            // slice sl has landed for every wavefront and nobody still reads the other buffer.  The
+            // wait is spelled out: __syncthreads() alone does NOT drain an LDS-DMA (hipcc emits only
+            // lgkmcnt(0) before the barrier here; with the short fp16 stages the reads then overtook
+            // the fill)
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __syncthreads();
             if (sl + 1 < nslices) issue_stage(cb, sl + 1, (sl + 1) & 1);
             const unsigned sbase = lds0 + (unsigned)(sl & 1) * STAGE;

@@ -171,7 +171,10 @@ __global__ __launch_bounds__(kTileThreads) void tile_scan_kernel(
             const char *src = tile_src(0);
             for (int i = wave; i < rows_in(0) * NCH; i += kTileWaves) dma_slice(src, smem, i);
         }
-        __syncthreads();  // vmcnt(0) + barrier: tile 0 (and the query registers) have landed
+        // tile 0 (and the query registers) have landed: the DMA wait is spelled out, __syncthreads()
+        // by itself does not drain an LDS-DMA
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
         PGV_TM(tm_setup += wall_clock64() - tm_mark;)
 
         for (int ti = 0; ti < ntiles; ti++) {
@@ -227,7 +230,8 @@ __global__ __launch_bounds__(kTileThreads) void tile_scan_kernel(
             issue_next(1 << 20);
             PGV_TM(tm_score += wall_clock64() - tm_mark; tm_mark = wall_clock64();)
             PGV_TM(asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); tm_dma += wall_clock64() - tm_mark; tm_mark = wall_clock64();)
-            __syncthreads();  // next tile landed (vmcnt(0)); everyone is done reading `cur`
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // next tile landed (this wavefront's share)
+            __syncthreads();                                   // ... everyone's; and everyone is done reading `cur`
             PGV_TM(tm_wait += wall_clock64() - tm_mark;)
         }
 #if PGV_TILE_ABLATE != 3 && PGV_TILE_ABLATE != 4

@@ -112,22 +112,19 @@ __device__ void block_topk(Load load, int64_t m, int k, int kp, int cap, unsigne
         // if the candidates do not fit (long runs of equal keys).
         unsigned *mins = s->hist;  // scratch
         unsigned mine = 0xffffffffu;
-        {
-            // sixteen independent loads in flight per thread: the sweep is latency-bound
-            constexpr int U = 16;
-            int64_t i = threadIdx.x;
-            for (; i + (U - 1) * kSelThreads < m; i += (int64_t)U * kSelThreads) {
-                float v[U];
+        // sweeps are latency-bound: sixteen independent loads in flight per thread, the ragged end
+        // as one more full batch with clamped addresses (not one dependent load at a time)
+        constexpr int U = 16;
+        for (int64_t i = threadIdx.x; i < m; i += (int64_t)U * kSelThreads) {
+            float v[U];
 #pragma unroll
-                for (int u = 0; u < U; u++) v[u] = load(i + (int64_t)u * kSelThreads);
-#pragma unroll
-                for (int u = 0; u < U; u++) {
-                    const unsigned key = float_to_key(v[u]);
-                    mine = key < mine ? key : mine;
-                }
+            for (int u = 0; u < U; u++) {
+                const int64_t at = i + (int64_t)u * kSelThreads;
+                v[u] = load(at < m ? at : m - 1);
             }
-            for (; i < m; i += kSelThreads) {
-                const unsigned key = float_to_key(load(i));
+#pragma unroll
+            for (int u = 0; u < U; u++) {
+                const unsigned key = i + (int64_t)u * kSelThreads < m ? float_to_key(v[u]) : 0xffffffffu;
                 mine = key < mine ? key : mine;
             }
         }
@@ -141,28 +138,20 @@ __device__ void block_topk(Load load, int64_t m, int k, int kp, int cap, unsigne
         if (rank == (unsigned)(k - 1)) s->bin = mine;  // exactly one thread has this rank
         __syncthreads();
         const unsigned t0 = s->bin;
-        {
-            constexpr int U = 16;
-            int64_t i = threadIdx.x;
-            for (; i + (U - 1) * kSelThreads < m; i += (int64_t)U * kSelThreads) {
-                float v[U];
+        for (int64_t i = threadIdx.x; i < m; i += (int64_t)U * kSelThreads) {
+            float v[U];
 #pragma unroll
-                for (int u = 0; u < U; u++) v[u] = load(i + (int64_t)u * kSelThreads);
-#pragma unroll
-                for (int u = 0; u < U; u++) {
-                    const unsigned key = float_to_key(v[u]);
-                    if (key <= t0) {
-                        const unsigned at = atomicAdd(&s->count, 1u);
-                        if (at < (unsigned)cap)
-                            ent[at] = ((unsigned long long)key << 32) | (unsigned)(i + (int64_t)u * kSelThreads);
-                    }
-                }
+            for (int u = 0; u < U; u++) {
+                const int64_t at = i + (int64_t)u * kSelThreads;
+                v[u] = load(at < m ? at : m - 1);
             }
-            for (; i < m; i += kSelThreads) {
-                const unsigned key = float_to_key(load(i));
-                if (key <= t0) {
-                    const unsigned at = atomicAdd(&s->count, 1u);
-                    if (at < (unsigned)cap) ent[at] = ((unsigned long long)key << 32) | (unsigned)i;
+#pragma unroll
+            for (int u = 0; u < U; u++) {
+                const int64_t at = i + (int64_t)u * kSelThreads;
+                const unsigned key = float_to_key(v[u]);
+                if (at < m && key <= t0) {
+                    const unsigned slot = atomicAdd(&s->count, 1u);
+                    if (slot < (unsigned)cap) ent[slot] = ((unsigned long long)key << 32) | (unsigned)at;
                 }
             }
         }

@@ -364,3 +364,37 @@ def test_hnsw_cosine_1536_m16_ef100(ctx, oracle):
         same += int(scored[i] == wscored)
     assert same >= 20, same
     mirror.close()
+
+
+# ------------------------------------------------ full-size assignment through a size-independent property
+@pytest.mark.parametrize("tname,metric,n,k,dim", [("f16", api.PGV_L2SQ, 300_000, 1024, 3072),
+                                                  ("f16", api.PGV_NEG_IP, 300_000, 1024, 1024),
+                                                  ("f32", api.PGV_L2SQ, 400_000, 1000, 768)])
+def test_assign_at_scale_is_the_fp64_argmin(ctx, tname, metric, n, k, dim):
+    """BASELINE-scale assignment (no CPU oracle at this size): the chosen center of every row of two slabs must be
+    the float64 argmin up to the float tolerance of the distances.  More workgroups than CUs: a workgroup follows
+    another on the same CU, which is what exposed the missing LDS-DMA wait of the fp16 MFMA pipeline in round 2
+    (short stages: ds_read overtook the fill, ~2 % of the rows went to a neighbouring center)."""
+    import torch
+    g = torch.Generator(device="cuda")
+    g.manual_seed(5)
+    tdt = torch.float16 if tname == "f16" else torch.float32
+    dt = api.PGV_F16 if tname == "f16" else api.PGV_F32
+    means = torch.rand((k // 4, dim), generator=g, device="cuda")
+    rows = torch.empty((n, dim), device="cuda", dtype=tdt)
+    for lo in range(0, n, 1 << 16):
+        hi = min(n, lo + (1 << 16))
+        comp = torch.randint(0, k // 4, (hi - lo,), generator=g, device="cuda")
+        rows[lo:hi] = (means[comp] + 0.1 * torch.randn((hi - lo, dim), generator=g, device="cuda")).to(tdt)
+    centers = rows[torch.randperm(n, generator=g, device="cuda")[:k]].contiguous()
+    got, gd = api.assign(ctx, metric, dt, dim, centers, rows, want_dist=True)
+    ctx.sync()
+    c64 = centers.double()
+    for lo in (0, n - 5000):
+        r64 = rows[lo:lo + 5000].double()
+        ref = torch.cdist(r64, c64).pow(2) if metric == api.PGV_L2SQ else -(r64 @ c64.T)
+        best = ref.min(dim=1).values
+        mine = ref.gather(1, got[lo:lo + 5000].long()[:, None])[:, 0]
+        scale = best.abs() + (1.0 if metric == api.PGV_L2SQ else float(dim))
+        assert int(((mine - best) > 1e-5 * scale).sum()) == 0
+        torch.testing.assert_close(gd[lo:lo + 5000].double(), mine, rtol=1e-5, atol=1e-5 * float(scale.max()))
