@@ -14,15 +14,31 @@ the lists are sharded l % N, the query batch grows to N x batch ("weak": the
 per-GPU scan work per step is fixed), per-rank top-k are merged with one
 all-gather.
 
-Extra objects on the line: `roofline` (the list-scan kernel, timed with HIP
-events on its own stream inside the timed region) and `cpu_baseline` (the
-oracle's restatement of ivfflatgettuple compiled with the reference's flags and
--march=native, timed on the host cores of this box on a bounded sample).
+What the line carries besides the contract's fields (rank 0, N = 1):
+  parity       the GPU's answers for `parity_checked_queries` queries compared with the CPU oracle's
+               (tid, distance) for the SAME index and queries, tie-tolerant; a mismatch exits non-zero
+  recall_at_10 against an exact float64 brute force over all rows, not against the GPU itself
+  roofline     the list-scan kernel, timed with HIP events on its own stream inside the timed region:
+               frac = bytes actually streamed from HBM / kernel time / 8 TB/s (physical, <= 1);
+               the per-(query,row)-pair figure of SURVEY 8d is kept as algorithmic_GBps; passes =
+               streamed / unique rows; traffic = HBM bytes per launch from a live rocprofv3 PMC pass
+               of this same script (FETCH_SIZE x 2 per the gfx950 note + WRITE_SIZE), or null
+  batch_sweep  batch 1 (the amgettuple path: pgv_query_* and the C host glue), 16, 256
+  probes_sweep probes 1 / 10 / 32 / 100 with recall each; `uniform`: the same on U[0,1)^d data
+  build        kernel-only build (k-means + assignment, data resident in HBM) and build_secs_pages:
+               the product path pgv_host_ivf_build -> 8 KB pages -> stage -> upload from host memory
+  cpu_baseline the oracle's restatement of ivfflatgettuple (reference flags + -march=native) on this
+               box's host cores, bounded sample
 """
 import argparse
+import ctypes
+import glob
 import json
 import os
+import shutil
+import subprocess
 import sys
+import tempfile
 import time
 
 import numpy as np
@@ -47,20 +63,7 @@ WORKLOADS = {
     "smallh": (100_000, 512, 100, 10, "f16", "ip"),
 }
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy)
-SCAN_KERNEL_TAG = "tile_v3"  # which kernel build the PMC traffic entries in profiles/traffic.json belong to
-
-
-def pmc_traffic(workload, batch):
-    """HBM bytes per list-scan launch from the committed rocprofv3 PMC passes (separate runs,
-    MI355X_MICROARCH.md HBM section); None when no pass matches this kernel/workload."""
-    try:
-        t = json.load(open(os.path.join(ROOT, "profiles", "traffic.json")))
-        for e in t["entries"]:
-            if e["kernel"] == SCAN_KERNEL_TAG and e["workload"] == workload and e["batch"] == batch:
-                return e["traffic_bytes_per_launch"]
-    except Exception:
-        pass
-    return None
+RTOL = 1e-5            # north_star: float tolerance of the distances
 
 
 def log(*a):
@@ -89,30 +92,42 @@ def gen_mixture(n, dim, components, sigma, seed, device, means=None):
     return out, means
 
 
+def gen_uniform(n, dim, seed, device):
+    """U[0,1)^d: what every reference test uses (test/t/003_ivfflat_vector_build_recall.pl:60)"""
+    g = torch.Generator(device=device)
+    g.manual_seed(seed)
+    return torch.rand((n, dim), generator=g, device=device, dtype=torch.float32)
+
+
+def sample_rows(data, lists, seed, ops):
+    """numSamples = max(50 * lists, 10000) capped by the rows (src/ivfbuild.c:446-455); spherical
+    opclasses normalise the samples (SampleCallback, :148-156)"""
+    n = data.shape[0]
+    ns = min(max(50 * lists, 10000), n)
+    g = torch.Generator(device=data.device)
+    g.manual_seed(seed + 1)
+    samples = data[torch.randperm(n, generator=g, device=data.device)[:ns]].contiguous()
+    if ops != api.PGV_OPS_L2:
+        s32 = samples.float()
+        samples = (s32 / s32.norm(dim=1, keepdim=True).clamp_min(1e-30)).to(samples.dtype).contiguous()
+    return samples
+
+
 def build_index(ctx, data, lists, seed, world, rank, dtype, ops, metric):
-    """IVFFlat build on the GPU(s): sample, k-means, assign every row, lay out list-major.
-    Returns (index handle pieces, build seconds split by phase)."""
+    """IVFFlat build on the GPU(s), data resident in HBM: sample, k-means, assign every row, lay out
+    list-major.  Returns the image pieces and the seconds per phase."""
     n, dim = data.shape
     dev = data.device
     t = {}
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    # numSamples = max(50 * lists, 10000) capped by the rows (src/ivfbuild.c:446-455)
-    ns = min(max(50 * lists, 10000), n)
-    g = torch.Generator(device=dev)
-    g.manual_seed(seed + 1)
-    samples = data[torch.randperm(n, generator=g, device=dev)[:ns]].contiguous()
-    if ops != api.PGV_OPS_L2:
-        # spherical opclasses: SampleRows normalises the samples (src/ivfbuild.c:154-155)
-        s32 = samples.float()
-        samples = (s32 / s32.norm(dim=1, keepdim=True).clamp_min(1e-30)).to(samples.dtype).contiguous()
+    samples = sample_rows(data, lists, seed, ops)
+    ns = samples.shape[0]
     if world == 1:
         centers, _, iters = api.kmeans(ctx, ops, dtype, dim, samples, lists,
                                        api.make_rng(seed=seed + 2), want_closest=False)
     else:
-        dbg("kmeans++ init")
         init = api.kmeanspp_init(ctx, ops, dtype, dim, samples, lists, api.make_rng(seed=seed + 2))
-        dbg("kmeans++ done")
         lo, hi = sharding.row_shard(ns, rank, world)
         local = samples[lo:hi].contiguous()
 
@@ -127,7 +142,6 @@ def build_index(ctx, data, lists, seed, world, rank, dtype, ops, metric):
     ctx.sync()
     torch.cuda.synchronize()
     t["kmeans"] = time.perf_counter() - t0
-    dbg("kmeans done", iters)
     t1 = time.perf_counter()
     lo, hi = sharding.row_shard(n, rank, world)
     local_lists, _ = api.assign(ctx, metric, dtype, dim, centers, data[lo:hi], want_dist=False)
@@ -150,17 +164,67 @@ def build_index(ctx, data, lists, seed, world, rank, dtype, ops, metric):
     return centers, offsets, vectors, tids, iters, t
 
 
-def recall_at_k(ivf_dist, exact_dist, k):
-    """tie-tolerant recall (test/t/003_ivfflat_vector_build_recall.pl:85-90): a returned row
-    counts when its distance is within the exact k-th distance"""
+def exact_topk_fp64(vectors, queries, k, metric):
+    """ground truth: exact float64 brute force over every row, on the device, in slabs
+    -> (distances [nq x k] float64, row slots [nq x k])"""
+    q = queries.double()
+    nq = q.shape[0]
+    best_d = torch.full((nq, k), float("inf"), dtype=torch.float64, device=q.device)
+    best_i = torch.full((nq, k), -1, dtype=torch.int64, device=q.device)
+    qq = (q * q).sum(1)[:, None]
+    slab = 1 << 16
+    for lo in range(0, vectors.shape[0], slab):
+        v = vectors[lo:lo + slab].double()
+        if metric == api.PGV_L2SQ:
+            d = qq + (v * v).sum(1)[None, :] - 2.0 * (q @ v.T)
+        else:
+            d = -(q @ v.T)
+        cand_d = torch.cat([best_d, d], dim=1)
+        cand_i = torch.cat([best_i, torch.arange(lo, lo + v.shape[0], device=q.device)[None, :].expand(nq, -1)], dim=1)
+        top = torch.topk(cand_d, k, dim=1, largest=False)
+        best_d, best_i = top.values, torch.gather(cand_i, 1, top.indices)
+    return best_d, best_i
+
+
+def recall_at_k(got_dist, exact_dist, k):
+    """tie-tolerant recall (test/t/003_ivfflat_vector_build_recall.pl:85-90): a returned row counts
+    when its distance is within the exact k-th distance (float tolerance of the kernel)"""
     kth = exact_dist[:, k - 1:k]
-    hit = (ivf_dist <= kth * (1 + 1e-6) + 1e-12).sum(dim=1).clamp(max=k)
-    return float(hit.float().mean().item() / k)
+    tol = RTOL * kth.abs() + 1e-12
+    hit = (got_dist.double() <= kth + tol).sum(dim=1).clamp(max=k)
+    return float(hit.double().mean().item() / k)
+
+
+def topk_equiv(got_ids, got_d, want_ids, want_d, rtol=RTOL):
+    """the reference's own tie-tolerant rule: ids must match wherever the order is determined beyond
+    the float tolerance; inside a run of (near-)equal distances any order is accepted.
+    Returns None or a description of the mismatch."""
+    got_ids, want_ids = list(got_ids), list(want_ids)
+    if len(got_ids) != len(want_ids):
+        return "lengths %d vs %d" % (len(got_ids), len(want_ids))
+    gd, wd = np.asarray(got_d, np.float64), np.asarray(want_d, np.float64)
+    bad = np.abs(gd - wd) > rtol * np.abs(wd) + 1e-30
+    if bad.any():
+        return "distance %r vs %r" % (gd[bad][:3].tolist(), wd[bad][:3].tolist())
+    i, n = 0, len(want_ids)
+    while i < n:
+        j = i + 1
+        while j < n and abs(wd[j] - wd[j - 1]) <= 4 * rtol * max(abs(wd[j]), 1e-30):
+            j += 1
+        if j == n:
+            if set(got_ids[:i]) != set(want_ids[:i]):
+                return "ids before the last tie run differ"
+            break
+        if sorted(got_ids[i:j]) != sorted(want_ids[i:j]):
+            return "ids %r vs %r at %d..%d" % (got_ids[i:j], want_ids[i:j], i, j)
+        i = j
+    return None
 
 
 def cpu_baseline(centers, offsets, vectors, tids, queries, probes, k, dtype, ops, budget_s=12.0):
-    """the oracle (= the reference's loops and kernels restated, built with the reference's
-    flags + -march=native) answering the same queries on the host cores of this box"""
+    """the oracle (= the reference's loops and kernels restated, built with the reference's flags +
+    -march=native) answering the same queries on the host cores of this box.  Returns the baseline
+    record and the oracle's (tids, distances) per query for the parity check."""
     from concurrent.futures import ThreadPoolExecutor
 
     from oracle import pyoracle as po
@@ -169,13 +233,16 @@ def cpu_baseline(centers, offsets, vectors, tids, queries, probes, k, dtype, ops
                           po.ORA_F32 if dtype == api.PGV_F32 else po.ORA_F16, centers, offsets, vectors, tids)
     cores = min(os.cpu_count() or 1, 64)
     nq = queries.shape[0]
+    answers = [None] * nq
 
     def worker(w):
         done = 0
         t_end = time.perf_counter() + budget_s
         i = w
-        while time.perf_counter() < t_end:
-            ora.search(ix, queries[i % nq], probes, k)
+        while time.perf_counter() < t_end or i < nq:  # every query is answered at least once (parity)
+            r = ora.search(ix, queries[i % nq], probes, k)
+            if i < nq:
+                answers[i] = r
             done += 1
             i += cores
         return done
@@ -189,12 +256,71 @@ def cpu_baseline(centers, offsets, vectors, tids, queries, probes, k, dtype, ops
     while time.perf_counter() - t0 < 3.0:
         ora.search(ix, queries[single % nq], probes, k)
         single += 1
-    single_qps = single / (time.perf_counter() - t0)
-    return {"value": total / el, "unit": "queries/s", "cores": cores, "kind": "port",
-            "single_thread_qps": single_qps,
-            "sample": "%d queries in %.1f s on %d threads (%d more on 1 thread), same index and query "
-                      "distribution; fmgr/bufmgr/tuplesort overheads of a real server not included"
-                      % (total, el, cores, single)}
+    single_s = (time.perf_counter() - t0) / single
+    rec = {"value": total / el, "unit": "queries/s", "cores": cores, "kind": "port",
+           "single_thread_qps": 1.0 / single_s, "single_thread_ms_per_query": single_s * 1e3,
+           "layout": "contiguous list-major arrays (an upper bound of the reference: no 8 KB page walk, "
+                     "no fmgr/bufmgr/tuplesort overheads)",
+           "sample": "%d queries in %.1f s on %d threads (%d more on 1 thread), same index and queries as the "
+                     "parity check" % (total, el, cores, single)}
+    return rec, answers
+
+
+def live_traffic(args, scan_ms):
+    """HBM bytes per list-scan launch, measured NOW: two rocprofv3 PMC passes (FETCH_SIZE, WRITE_SIZE;
+    never combined, MI355X_MICROARCH.md) of this same script on a short run.  Launches of the scan
+    kernel whose duration is within 35 % of this run's average are the timed list scans."""
+    exe = shutil.which("rocprofv3")
+    if not exe:
+        return None, "rocprofv3 not on PATH"
+    out = {}
+    base = [sys.executable, os.path.abspath(__file__), "--workload", args.workload, "--batch", str(args.batch),
+            "--steps", "4", "--warmup", "1", "--seed", str(args.seed), "--child"]
+    if args.probes:
+        base += ["--probes", str(args.probes)]
+    env = dict(os.environ, TMPDIR="/tmp")
+    for counter in ("FETCH_SIZE", "WRITE_SIZE"):
+        d = tempfile.mkdtemp(prefix="pgv_pmc_", dir="/tmp")
+        try:
+            r = subprocess.run([exe, "--pmc", counter, "--kernel-trace", "-d", d, "-o", "pmc", "--output-format", "csv",
+                                "--"] + base, cwd="/tmp", env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE,
+                               timeout=600)
+            files = glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True)
+            if r.returncode != 0 or not files:
+                return None, "%s pass failed (rc %d)" % (counter, r.returncode)
+            import csv
+            vals = []
+            for row in csv.DictReader(open(files[0])):
+                if row.get("Counter_Name") != counter:
+                    continue
+                name = row["Kernel_Name"]
+                if "tile_scan_kernel" not in name and "scan_kernel" not in name:
+                    continue
+                dur = (int(row["End_Timestamp"]) - int(row["Start_Timestamp"])) / 1e6
+                if abs(dur - scan_ms) <= 0.35 * scan_ms:
+                    vals.append(float(row["Counter_Value"]))
+            if not vals:
+                return None, "no %s rows matched the scan kernel" % counter
+            out[counter] = (sum(vals) / len(vals), len(vals))
+        except Exception as e:  # profiling must never sink the number
+            return None, "%s pass: %r" % (counter, e)
+        finally:
+            shutil.rmtree(d, ignore_errors=True)
+    # rocprofv3 reports both in KB; wide coalesced reads are tallied at half their size on gfx950
+    traffic = 2.0 * out["FETCH_SIZE"][0] * 1024.0 + out["WRITE_SIZE"][0] * 1024.0
+    return traffic, "live rocprofv3 --pmc passes of this script: 2 x FETCH_SIZE (%d launches) + WRITE_SIZE (%d)" % (
+        out["FETCH_SIZE"][1], out["WRITE_SIZE"][1])
+
+
+def timed_steps(fn, steps, warmup=2):
+    for i in range(warmup):
+        fn(i)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(steps):
+        fn(warmup + i)
+    torch.cuda.synchronize()
+    return (time.perf_counter() - t0) / steps
 
 
 def main():
@@ -207,12 +333,17 @@ def main():
     ap.add_argument("--k", type=int, default=10)
     ap.add_argument("--probes", type=int, default=0)
     ap.add_argument("--seed", type=int, default=0)
-    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-cpu-baseline", action="store_true", help="skips the oracle: no cpu_baseline, no TID parity")
+    ap.add_argument("--no-sweeps", action="store_true", help="skip batch / probes sweeps, uniform data, page build")
+    ap.add_argument("--no-traffic", action="store_true", help="skip the live rocprofv3 PMC passes")
+    ap.add_argument("--child", action="store_true", help="(internal) the short run the PMC passes profile")
     ap.add_argument("--host-io", action="store_true", help="also time the batch with host-memory queries/results")
     ap.add_argument("--recall-queries", type=int, default=256)
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo for a functional "
                                                      "multi-rank run on a single GPU)")
     args = ap.parse_args()
+    if args.child:
+        args.no_cpu_baseline = args.no_sweeps = args.no_traffic = True
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -239,17 +370,24 @@ def main():
         probes = args.probes
     k = args.k
     ctx = api.Context(local_rank, stream=torch.cuda.current_stream().cuda_stream)
+    failures = []
 
     # ---------------------------------------------------------------- setup
     components = max(lists // 4, 1)
     data, means = gen_mixture(n, dim, components, 0.1, args.seed, dev)
     data = data.to(tdtype)
     log("data: %d x %d %s generated" % (n, dim, tname))
+    ctx.set_profiling(True)
+    ctx.reset_stats()
     centers, offsets, vectors, tids, iters, build_t = build_index(ctx, data, lists, args.seed, world, rank,
                                                                   dtype, ops, metric)
+    build_stats = ctx.stats()
+    ctx.set_profiling(False)
     log("build: %s (k-means iterations %d)" % ({a: round(b, 3) for a, b in build_t.items()}, iters))
     index = api.IvfIndex(ctx, metric, dtype, dim, centers, offsets, vectors, tids.view(torch.int64))
     local_rows = int(vectors.shape[0])
+    do_pages = rank == 0 and world == 1 and not args.no_sweeps
+    host_rows = data.cpu().numpy() if do_pages else None
     del data
 
     total_batch = args.batch * world
@@ -275,19 +413,25 @@ def main():
         index.scan_batch(q, lists_all, k, want_tid=True, out=(out_d, out_s, out_t))
         return sharding.merge_topk(out_d, out_t, k)
 
-    # ---------------------------------------------------------------- recall
+    # ---------------------------------------------------------------- recall vs exact fp64
     rq = min(args.recall_queries, total_batch)
+    rqueries = queries[1][:rq].contiguous()
+    exact_d = None
     if world == 1:
-        exact_d, _, _ = index.search_batch(queries[0][:rq].contiguous(), lists, k, want_tid=False)
-        got_d, _, _ = index.search_batch(queries[0][:rq].contiguous(), probes, k, want_tid=False)
+        exact_d, _ = exact_topk_fp64(vectors, rqueries, k, metric)
+        got_d, got_s, got_t = index.search_batch(rqueries, probes, k, want_tid=True)
+        recall_truth = "exact float64 brute force over all %d rows, %d queries" % (n, rq)
     else:
-        ed, _, et = index.search_batch(queries[0][:rq].contiguous(), lists, k, want_tid=True)
+        # the rows are spread over the ranks: the exact answer is the merge of every rank's exhaustive scan
+        ed, _, et = index.search_batch(rqueries, lists, k, want_tid=True)
         exact_d, _ = sharding.merge_topk(ed, et, k)
-        gd, _, gt = index.search_batch(queries[0][:rq].contiguous(), probes, k, want_tid=True)
-        got_d, _ = sharding.merge_topk(gd, gt, k)
+        gd, _, gt = index.search_batch(rqueries, probes, k, want_tid=True)
+        got_d, got_t = sharding.merge_topk(gd, gt, k)
+        exact_d = exact_d.double()
+        recall_truth = "merge of every rank's exhaustive fp32 scan (probes = lists), %d queries" % rq
     ctx.sync()
     recall = recall_at_k(got_d, exact_d, k)
-    log("recall@%d = %.4f at probes=%d" % (k, recall, probes))
+    log("recall@%d = %.4f at probes=%d (%s)" % (k, recall, probes, recall_truth))
 
     # ----------------------------------------------------------------- timed
     for i in range(args.warmup):
@@ -315,26 +459,31 @@ def main():
     qps = total_batch * args.steps / elapsed
     launches = max(stats["scan_launches"], 1)
     algo_bytes = stats["scan_pairs"] * esize * dim     # 4*d (fp32) / 2*d (fp16) bytes per scored vector
-    stream_bytes = stats["scan_rows"] * esize * dim    # rows actually streamed (shared by a query group)
+    stream_bytes = stats["scan_rows"] * esize * dim    # rows actually streamed (a row shared by a query group counts once)
+    unique_bytes = stats["scan_unique_rows"] * esize * dim  # rows of the lists somebody probes: one ideal pass
     scan_s = stats["scan_ms"] / 1e3
-    achieved = algo_bytes / scan_s / 1e9 if scan_s > 0 else 0.0
+    streamed_gbps = stream_bytes / scan_s / 1e9 if scan_s > 0 else 0.0
+    avg_launch_ms = stats["scan_ms"] / launches
     roofline = {
         "kernel": "tile_scan_kernel / scan_kernel (IVFFlat list scan, src/ivfscan.c:123-187)",
-        "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-        "frac": achieved / HBM_PEAK_GBS,
-        "traffic": pmc_traffic(args.workload, args.batch) if world == 1 else None,
-        "algorithmic_bytes_per_launch": algo_bytes / launches,
+        "bound": "hbm", "achieved": streamed_gbps, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+        "frac": streamed_gbps / HBM_PEAK_GBS,
+        "traffic": None, "traffic_source": None,
         "streamed_bytes_per_launch": stream_bytes / launches,
-        "streamed_GBps": stream_bytes / scan_s / 1e9 if scan_s > 0 else 0.0,
-        "frac_streamed": (stream_bytes / scan_s / 1e9 if scan_s > 0 else 0.0) / HBM_PEAK_GBS,  # physical bytes vs the HBM peak
-        "avg_launch_ms": stats["scan_ms"] / launches, "launches": launches,
+        "unique_bytes_per_launch": unique_bytes / launches,
+        "passes": stream_bytes / unique_bytes if unique_bytes > 0 else None,
+        "frac_unique": (unique_bytes / scan_s / 1e9) / HBM_PEAK_GBS if scan_s > 0 else 0.0,
+        "algorithmic_bytes_per_launch": algo_bytes / launches,
+        "algorithmic_GBps": algo_bytes / scan_s / 1e9 if scan_s > 0 else 0.0,
+        "avg_launch_ms": avg_launch_ms, "launches": launches,
         # the batched kernel is bound by fp32 vector-ALU issue once rows are shared by many queries:
         # 3 flop per element (subtract, multiply, add) for L2, 2 for inner product
         "valu_tflops": stats["scan_pairs"] * dim * (3.0 if oname == "l2" else 2.0) / scan_s / 1e12 if scan_s > 0 else 0.0,
         "valu_peak_tflops": 157.3,
-        "note": "achieved = elem_size*dim bytes per (query,row) pair / kernel time (HIP events on the launch "
-                "stream); rows probed by several queries of a batch are read from HBM once per query "
-                "group, so achieved may exceed the physical rate -- streamed_GBps is the physical one",
+        "note": "achieved/frac = row bytes actually streamed from HBM per kernel second (HIP events on the launch "
+                "stream) against the 8 TB/s peak; a row probed by several queries of a batch is streamed once per "
+                "query group and scored from LDS, so the per-(query,row)-pair figure of SURVEY 8d "
+                "(algorithmic_GBps) exceeds the physical rate; passes = streamed / unique rows",
     }
     line = {
         "metric": "QPS @ recall@10 (IVFFlat, 1M x 1536d)" if args.workload == "headline"
@@ -349,41 +498,223 @@ def main():
                    "rows": n, "dim": dim, "lists": lists, "probes": probes, "k": k,
                    "batch_per_gpu": args.batch, "parallelism": "lists sharded l %% %d, top-k all-gather" % world,
                    "local_rows": local_rows},
-        "recall_at_10": recall, "build_secs": build_t["total"],
-        "build_phases_secs": build_t, "kmeans_iterations": iters,
+        "recall_at_10": recall, "recall_ground_truth": recall_truth,
+        "build_secs": build_t["total"], "build_phases_secs": build_t, "kmeans_iterations": iters,
+        "build_assign": {"rows": build_stats["assign_rows"],
+                         "rechecked_fraction": build_stats["assign_recheck_rows"] / build_stats["assign_rows"]
+                         if build_stats["assign_rows"] else None,
+                         "redone_fraction": build_stats["assign_redo_rows"] / build_stats["assign_rows"]
+                         if build_stats["assign_rows"] else None,
+                         "note": "L2 assignment = MFMA pre-filter + exact recheck (k-means iterations and the heap rows)"},
         "roofline": roofline,
         "center_rank_ms_per_step": stats["aux_ms"] / args.steps,
         "scan_ms_per_step": stats["scan_ms"] / args.steps,
     }
-    if rank == 0 and world == 1 and args.host_io:
-        # what a Postgres backend sees: queries and results in HOST memory, i.e. H2D of the batch, the same
-        # kernels, D2H of k x (distance, slot, tid) per query and a stream sync inside every call.
-        # Reported next to `value`, never as `value`.
+
+    single = rank == 0 and world == 1
+    if single and args.host_io:
+        # what a Postgres backend sees for a batch: queries and results in HOST memory
         qh = [queries[j].cpu().numpy() for j in range(min(pool, 4))]
-        for j in range(2):
-            index.search_batch(qh[j % len(qh)], probes, k, want_tid=True)
-        t0 = time.perf_counter()
-        for j in range(args.steps):
-            index.search_batch(qh[j % len(qh)], probes, k, want_tid=True)
-        host_s = time.perf_counter() - t0
-        line["host_buffers"] = {"value": args.batch * args.steps / host_s, "unit": "queries/s",
-                                "ms_per_step": host_s / args.steps * 1e3,
+        s = timed_steps(lambda j: index.search_batch(qh[j % len(qh)], probes, k, want_tid=True), args.steps)
+        line["host_buffers"] = {"value": args.batch / s, "unit": "queries/s", "ms_per_step": s * 1e3,
                                 "h2d_bytes_per_step": int(args.batch * dim * esize),
                                 "d2h_bytes_per_step": int(args.batch * k * 20)}
-    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+
+    # ------------------------------------------------------------- sweeps
+    if single and not args.no_sweeps:
+        sweep = {}
+        # batch 1 is what amgettuple issues: the device-resident single-query path, host-memory query in,
+        # k (distance, tid) out
+        qhost = queries[2][:256].cpu().numpy()
+        qh = api.Query(index)
+        for j in range(20):
+            qh.rank(qhost[j], probes)
+            qh.scan(0, probes, k)
+        lat = []
+        for j in range(300):
+            t0 = time.perf_counter()
+            qh.rank(qhost[j % 256], probes)
+            qh.scan(0, probes, k)
+            lat.append(time.perf_counter() - t0)
+        lat = np.array(lat)
+        # parity of that path with the batched one
+        bd, bs, _ = index.search_batch(qhost[:32], probes, k)
+        same = 0
+        for j in range(32):
+            qh.rank(qhost[j], probes)
+            d1, s1, _, _ = qh.scan(0, probes, k)
+            same += int(np.array_equal(s1, bs[j]))
+        if same != 32:
+            failures.append("single-query path differs from the batched path on %d of 32 queries" % (32 - same))
+        qh.close()
+        sweep["1"] = {"qps": 1.0 / lat.mean(), "latency_us_p50": float(np.percentile(lat, 50) * 1e6),
+                      "latency_us_p90": float(np.percentile(lat, 90) * 1e6),
+                      "path": "pgv_query_rank + pgv_query_scan (5 launches, head of k read back through pinned memory)",
+                      "equals_batched_path": "%d/32" % same}
+        # the same through the C host glue: ivfflatrescan + k x ivfflatgettuple
         try:
-            line["cpu_baseline"] = cpu_baseline(centers.cpu().numpy(), offsets.cpu().numpy(), vectors.cpu().numpy(),
-                                                tids.cpu().numpy().astype(np.uint64),
-                                                queries[1][:256].cpu().numpy(), probes, k, dtype, ops)
-        except Exception as e:  # the baseline must never sink the GPU number
+            from pgvector_amd import _host
+            img = _host.IvfImage()
+            cen, offh = centers.cpu().numpy(), offsets.cpu().numpy()
+            tidh = tids.cpu().numpy().astype(np.uint64)
+            img.dtype, img.dim, img.lists, img.nrows = dtype, dim, lists, n
+            img.centers, img.list_offsets, img.tids, img.vectors = cen.ctypes.data, offh.ctypes.data, tidh.ctypes.data, None
+
+            class _Staged:
+                pass
+            st = _Staged()
+            st.img, st.dtype = img, dtype
+            scan = _host.IvfScan(index, st, probes=probes)
+            for j in range(20):
+                scan.rescan(qhost[j])
+                scan.fetch(limit=k)
+            lat2 = []
+            for j in range(300):
+                t0 = time.perf_counter()
+                scan.rescan(qhost[j % 256])
+                scan.fetch(limit=k)
+                lat2.append(time.perf_counter() - t0)
+            scan.close()
+            lat2 = np.array(lat2)
+            sweep["1"]["gettuple_latency_us_p50"] = float(np.percentile(lat2, 50) * 1e6)
+            sweep["1"]["gettuple_path"] = ("pgv_host_ivf_rescan + %d x pgv_host_ivf_gettuple (C host glue; the loop "
+                                           "itself is Python/ctypes)" % k)
+        except Exception as e:
+            sweep["1"]["gettuple_error"] = repr(e)
+        for b in (16, 256):
+            qb = queries[3][:b].contiguous()
+            od = torch.empty((b, k), device=dev, dtype=torch.float32)
+            os_ = torch.empty((b, k), device=dev, dtype=torch.int64)
+            ot = torch.empty((b, k), device=dev, dtype=torch.int64)
+            s = timed_steps(lambda j: index.search_batch(qb, probes, k, want_tid=True, out=(od, os_, ot)), 20)
+            sweep[str(b)] = {"qps": b / s, "ms_per_step": s * 1e3}
+        sweep[str(args.batch)] = {"qps": qps, "ms_per_step": elapsed / args.steps * 1e3}
+        line["batch_sweep"] = sweep
+
+        psweep = {}
+        for p in (1, 10, 32, 100):
+            if p > lists:
+                continue
+            s = timed_steps(lambda j: index.search_batch(queries[j % pool], p, k, want_tid=True, out=(out_d, out_s, out_t)), 6)
+            gd, _, _ = index.search_batch(rqueries, p, k)
+            psweep[str(p)] = {"qps": total_batch / s, "ms_per_step": s * 1e3, "recall_at_10": recall_at_k(gd, exact_d, k)}
+        line["probes_sweep"] = psweep
+
+    # --------------------------------------------------- parity with the CPU oracle + its speed
+    if single and not args.no_cpu_baseline:
+        try:
+            pq = min(256, total_batch)
+            pqueries = queries[1][:pq].contiguous()
+            pd, ps, pt = index.search_batch(pqueries, probes, k, want_tid=True)
+            ctx.sync()
+            base, answers = cpu_baseline(centers.cpu().numpy(), offsets.cpu().numpy(), vectors.cpu().numpy(),
+                                         tids.cpu().numpy().astype(np.uint64), pqueries.cpu().numpy(), probes, k,
+                                         dtype, ops)
+            line["cpu_baseline"] = base
+            pd, pt = pd.cpu().numpy(), pt.cpu().numpy()
+            bad = []
+            for i in range(pq):
+                wt, wd = answers[i]
+                why = topk_equiv(pt[i][:len(wt)].astype(np.uint64).tolist(), pd[i][:len(wt)], wt.tolist(), wd)
+                if why:
+                    bad.append((i, why))
+            line["parity_checked_queries"] = pq
+            line["parity"] = {"against": "CPU oracle (oracle/, restated src/ivfscan.c:47-187), same index, same queries",
+                              "rule": "row ids identical where the order is determined beyond 1e-5 relative, "
+                                      "distances within 1e-5 relative",
+                              "mismatches": len(bad)}
+            if bad:
+                failures.append("parity: %d of %d queries differ from the oracle, first: %r" % (len(bad), pq, bad[0]))
+        except Exception as e:  # an oracle that cannot run must not pass for parity
             line["cpu_baseline"] = {"value": None, "unit": "queries/s", "cores": 0, "kind": "port",
                                     "sample": "failed: %r" % (e,)}
+            line["parity_checked_queries"] = 0
+
+    # ------------------------------------------------------------- uniform data
+    if single and not args.no_sweeps:
+        try:
+            udata = gen_uniform(n, dim, args.seed + 7, dev).to(tdtype)
+            uc, uo, uv, ut, uit, ubt = build_index(ctx, udata, lists, args.seed, 1, 0, dtype, ops, metric)
+            del udata
+            uix = api.IvfIndex(ctx, metric, dtype, dim, uc, uo, uv, ut.view(torch.int64))
+            uq = gen_uniform(total_batch, dim, args.seed + 8, dev).to(tdtype)
+            ued, _ = exact_topk_fp64(uv, uq[:rq], k, metric)
+            ures = {}
+            for p in (10, 100):
+                s = timed_steps(lambda j: uix.search_batch(uq, p, k, want_tid=True, out=(out_d, out_s, out_t)), 5)
+                gd, _, _ = uix.search_batch(uq[:rq].contiguous(), p, k)
+                ures[str(p)] = {"qps": total_batch / s, "recall_at_10": recall_at_k(gd, ued, k)}
+            line["uniform"] = {"data": "U[0,1)^%d (test/t/003_ivfflat_vector_build_recall.pl:60)" % dim,
+                               "build_secs": ubt["total"], "kmeans_iterations": uit, "probes": ures,
+                               "note": "uniform high-d data has no cluster structure: IVF recall at 1 % of the lists "
+                                       "is low by construction (the reference skips such cases, t/003:101-104)"}
+            uix.close()
+            del uv, uq
+        except Exception as e:
+            line["uniform"] = {"error": repr(e)}
+
+    # ------------------------------------------------------ the product build path, through pages
+    if do_pages:
+        try:
+            from pgvector_amd import _host
+            t0 = time.perf_counter()
+            host_tids = (np.arange(n, dtype=np.uint64) << np.uint64(16)) | np.uint64(1)
+            g = np.random.default_rng(args.seed + 1)
+            ns = min(max(50 * lists, 10000), n)
+            host_samples = host_rows[np.sort(g.choice(n, ns, replace=False))]
+            t_sample = time.perf_counter() - t0
+            rel = _host.Relation()
+            t0 = time.perf_counter()
+            rel.build(ctx, ops, dtype, lists, host_rows, host_tids, host_samples, api.make_rng(seed=args.seed + 2))
+            t_build = time.perf_counter() - t0
+            ph = (ctypes.c_double * 5)()
+            _host.lib.pgv_host_ivf_build_phases(ph)
+            t0 = time.perf_counter()
+            img = rel.stage(dtype)
+            t_stage = time.perf_counter() - t0
+            t0 = time.perf_counter()
+            pix = api.IvfIndex(ctx, metric, dtype, dim, img.centers, img.list_offsets, img.vectors, img.tids)
+            ctx.sync()
+            t_upload = time.perf_counter() - t0
+            # the page-built index answers like an index should: recall against the same exact ground truth
+            gd, gs, gt = pix.search_batch(rqueries, probes, k, want_tid=True)
+            prec = recall_at_k(gd, exact_d, k)
+            line["build_secs_pages"] = t_build + t_stage + t_upload
+            line["build_pages"] = {
+                "path": "pgv_host_ivf_build (host rows -> k-means + assignment on the GPU -> sort by list -> 8 KB "
+                        "pages) -> pgv_host_ivf_stage -> pgv_index_upload",
+                "build_secs": t_build, "stage_secs": t_stage, "upload_secs": t_upload, "sample_secs": t_sample,
+                "build_phases_secs": dict(zip(("normalise", "kmeans", "assign", "sort_by_list", "page_writer"),
+                                              [float(x) for x in ph])),
+                "pages": int(rel.nblocks), "page_bytes": int(rel.nblocks) * 8192,
+                "recall_at_10": prec}
+            if prec < recall - 0.02:
+                failures.append("page-built index recall %.4f below the torch-laid-out index's %.4f" % (prec, recall))
+            pix.close()
+            del img, rel
+        except Exception as e:
+            line["build_pages"] = {"error": repr(e)}
+        host_rows = None
+
+    # ------------------------------------------------------------------ live PMC traffic
+    if single and not args.no_traffic:
+        traffic, src = live_traffic(args, avg_launch_ms)
+        roofline["traffic"] = traffic
+        roofline["traffic_source"] = src
+        if traffic and stream_bytes > 0:
+            roofline["traffic_over_streamed"] = traffic / (stream_bytes / launches)
+
+    if failures:
+        line["failures"] = failures
     if rank == 0:
         print(json.dumps(line), flush=True)
     index.close()
     ctx.close()
     if world > 1:
         dist.destroy_process_group()
+    if failures:
+        log("FAILED: " + "; ".join(failures))
+        sys.exit(2)
 
 
 if __name__ == "__main__":

@@ -157,6 +157,9 @@ typedef struct pgv_stats
 	double		assign_redo_rows;
 	double		assign_rows;
 	double		assign_recheck_rows;
+	/* batched list scans: rows of the lists at least one query of the batch probes -- what a single pass
+	 * over the probed part of the index would stream (scan_rows / scan_unique_rows = passes) */
+	double		scan_unique_rows;
 }			pgv_stats;
 int			pgv_ctx_set_profiling(pgv_ctx * ctx, int on);
 int			pgv_ctx_reset_stats(pgv_ctx * ctx);

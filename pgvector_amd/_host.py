@@ -83,6 +83,8 @@ def _load():
     lib.pgv_host_ivf_endscan.argtypes = [P]
     lib.pgv_host_ivf_endscan.restype = None
     lib.pgv_host_ivf_build.argtypes = [P, I, I, I, I, P, P, I64, P, I, P, C.POINTER(Rel)]
+    lib.pgv_host_ivf_build_phases.argtypes = [C.POINTER(C.c_double)]
+    lib.pgv_host_ivf_build_phases.restype = None
     lib.pgv_host_float_to_half.argtypes = [C.c_float]
     lib.pgv_host_float_to_half.restype = C.c_uint16
     return lib

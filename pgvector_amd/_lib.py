@@ -53,7 +53,7 @@ class PgvStats(C.Structure):
     _fields_ = [("scan_ms", C.c_double), ("scan_launches", C.c_int64),
                 ("scan_pairs", C.c_double), ("scan_rows", C.c_double),
                 ("aux_ms", C.c_double), ("aux_launches", C.c_int64), ("aux_pairs", C.c_double),
-                ("assign_redo_rows", C.c_double), ("assign_rows", C.c_double), ("assign_recheck_rows", C.c_double)]
+                ("assign_redo_rows", C.c_double), ("assign_rows", C.c_double), ("assign_recheck_rows", C.c_double), ("scan_unique_rows", C.c_double)]
 
 
 NEXT_DOUBLE = C.CFUNCTYPE(C.c_double, C.c_void_p)

@@ -207,12 +207,12 @@ __global__ __launch_bounds__(kQThreads) void query_head_kernel(
         head_slot[i] = slot;
         head_tid[i] = tids ? tids[slot] : ~0ull;
     }
-    __threadfence_system();
+    // every wavefront's stores have left before the record is declared complete; the host polls seq
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     if (threadIdx.x == 0) {
         hdr->total = m;
         hdr->count = have > 0 ? have : 0;
-        __threadfence_system();
         __hip_atomic_store(&hdr->seq, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
     }
 }

@@ -197,19 +197,27 @@ __global__ __launch_bounds__(256) void plan_stats_kernel(const int *__restrict__
                                                          const int64_t *__restrict__ list_off,
                                                          const int64_t *__restrict__ totals, int nlists,
                                                          int qt, double *__restrict__ acc) {
-    __shared__ double red[256];
-    double rows = 0.0;
-    for (int l = threadIdx.x; l < nlists; l += 256)
-        rows += (double)((cnt[l] + qt - 1) / qt) * (double)(list_off[l + 1] - list_off[l]);
+    __shared__ double red[256], red_u[256];
+    double rows = 0.0, uniq = 0.0;
+    for (int l = threadIdx.x; l < nlists; l += 256) {
+        const double len = (double)(list_off[l + 1] - list_off[l]);
+        rows += (double)((cnt[l] + qt - 1) / qt) * len;
+        uniq += cnt[l] > 0 ? len : 0.0;
+    }
     red[threadIdx.x] = rows;
+    red_u[threadIdx.x] = uniq;
     __syncthreads();
     for (int s = 128; s > 0; s >>= 1) {
-        if (threadIdx.x < s) red[threadIdx.x] += red[threadIdx.x + s];
+        if (threadIdx.x < s) {
+            red[threadIdx.x] += red[threadIdx.x + s];
+            red_u[threadIdx.x] += red_u[threadIdx.x + s];
+        }
         __syncthreads();
     }
     if (threadIdx.x == 0) {
         acc[0] += (double)totals[0];  // (row, query) pairs
         acc[1] += red[0];             // rows streamed
+        acc[5] += red_u[0];           // rows of the lists at least one query probes (what one pass would stream)
     }
 }
 
@@ -283,7 +291,7 @@ int launch_plan_batch(pgv_ctx *ctx, const pgv_index *ix, const int32_t *probe_li
     res->ntasks = res->ntasks_bound;
     res->total_out = res->out_bound;
     if (read_totals) {  // profiling: exact pair / streamed-row counts, accumulated on the device
-        PGV_TRY(ctx->stats_dev.ensure(5 * sizeof(double)));
+        PGV_TRY(ctx->stats_dev.ensure(6 * sizeof(double)));
         hipLaunchKernelGGL(plan_stats_kernel, dim3(1), dim3(256), 0, ctx->stream, cnt,
                            ix->list_offsets, totals, nlists, qt, ctx->stats_dev.as<double>());
         PGV_HIP(hipGetLastError());

@@ -482,8 +482,8 @@ int pgv_ctx_set_profiling(pgv_ctx *ctx, int on) {
     PGV_TRY(resolve_events(ctx));
     ctx->profiling = on != 0;
     if (ctx->profiling && !ctx->stats_dev.p) {
-        PGV_TRY(ctx->stats_dev.ensure(5 * sizeof(double)));
-        PGV_HIP(hipMemsetAsync(ctx->stats_dev.p, 0, 5 * sizeof(double), ctx->stream));
+        PGV_TRY(ctx->stats_dev.ensure(6 * sizeof(double)));
+        PGV_HIP(hipMemsetAsync(ctx->stats_dev.p, 0, 6 * sizeof(double), ctx->stream));
     }
     return PGV_OK;
 }
@@ -495,7 +495,7 @@ int pgv_ctx_reset_stats(pgv_ctx *ctx) {
     ctx->scan_launches = 0;
     ctx->scan_pairs = 0;
     ctx->scan_rows = 0;
-    if (ctx->stats_dev.p) PGV_HIP(hipMemsetAsync(ctx->stats_dev.p, 0, 5 * sizeof(double), ctx->stream));
+    if (ctx->stats_dev.p) PGV_HIP(hipMemsetAsync(ctx->stats_dev.p, 0, 6 * sizeof(double), ctx->stream));
     ctx->aux_ms = 0;
     ctx->aux_launches = 0;
     ctx->aux_pairs = 0;
@@ -505,7 +505,7 @@ int pgv_ctx_reset_stats(pgv_ctx *ctx) {
 int pgv_ctx_get_stats(pgv_ctx *ctx, pgv_stats *out) {
     if (!ctx || !out) PGV_FAIL(PGV_ERR_ARG, "ctx/out is NULL");
     PGV_TRY(resolve_events(ctx));
-    double dev_acc[5] = {0.0, 0.0, 0.0, 0.0, 0.0};
+    double dev_acc[6] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
     if (ctx->stats_dev.p) {
         PGV_HIP(hipMemcpyAsync(dev_acc, ctx->stats_dev.p, sizeof(dev_acc), hipMemcpyDeviceToHost, ctx->stream));
         PGV_HIP(hipStreamSynchronize(ctx->stream));
@@ -520,6 +520,7 @@ int pgv_ctx_get_stats(pgv_ctx *ctx, pgv_stats *out) {
     out->assign_redo_rows = dev_acc[2];
     out->assign_rows = dev_acc[3];
     out->assign_recheck_rows = dev_acc[4];
+    out->scan_unique_rows = dev_acc[5];
     return PGV_OK;
 }
 

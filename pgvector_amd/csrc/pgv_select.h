@@ -112,20 +112,42 @@ __device__ void block_topk(Load load, int64_t m, int k, int kp, int cap, unsigne
         // if the candidates do not fit (long runs of equal keys).
         unsigned *mins = s->hist;  // scratch
         unsigned mine = 0xffffffffu;
-        // sweeps are latency-bound: sixteen independent loads in flight per thread, the ragged end
-        // as one more full batch with clamped addresses (not one dependent load at a time)
-        constexpr int U = 16;
-        for (int64_t i = threadIdx.x; i < m; i += (int64_t)U * kSelThreads) {
-            float v[U];
+        // The sweeps are latency-bound (the values were just written by other CUs: every load
+        // misses this XCD's L2).  Up to kKeep * U values per thread are fetched ONCE, all loads in
+        // flight together, and stay in registers for the second sweep; longer sequences go
+        // through batches of U loads, the ragged end as a full batch with clamped addresses.
+        constexpr int U = 16, kKeep = 3;
+        const bool resident = m <= (int64_t)kKeep * U * kSelThreads;  // block-uniform
+        float keep[kKeep][U];
+        if (resident) {
 #pragma unroll
-            for (int u = 0; u < U; u++) {
-                const int64_t at = i + (int64_t)u * kSelThreads;
-                v[u] = load(at < m ? at : m - 1);
-            }
+            for (int b = 0; b < kKeep; b++)
 #pragma unroll
-            for (int u = 0; u < U; u++) {
-                const unsigned key = i + (int64_t)u * kSelThreads < m ? float_to_key(v[u]) : 0xffffffffu;
-                mine = key < mine ? key : mine;
+                for (int u = 0; u < U; u++) {
+                    const int64_t at = (int64_t)threadIdx.x + (int64_t)(b * U + u) * kSelThreads;
+                    keep[b][u] = load(at < m ? at : m - 1);
+                }
+#pragma unroll
+            for (int b = 0; b < kKeep; b++)
+#pragma unroll
+                for (int u = 0; u < U; u++) {
+                    const int64_t at = (int64_t)threadIdx.x + (int64_t)(b * U + u) * kSelThreads;
+                    const unsigned key = at < m ? float_to_key(keep[b][u]) : 0xffffffffu;
+                    mine = key < mine ? key : mine;
+                }
+        } else {
+            for (int64_t i = threadIdx.x; i < m; i += (int64_t)U * kSelThreads) {
+                float v[U];
+#pragma unroll
+                for (int u = 0; u < U; u++) {
+                    const int64_t at = i + (int64_t)u * kSelThreads;
+                    v[u] = load(at < m ? at : m - 1);
+                }
+#pragma unroll
+                for (int u = 0; u < U; u++) {
+                    const unsigned key = i + (int64_t)u * kSelThreads < m ? float_to_key(v[u]) : 0xffffffffu;
+                    mine = key < mine ? key : mine;
+                }
             }
         }
         mins[threadIdx.x] = mine;
@@ -138,21 +160,28 @@ __device__ void block_topk(Load load, int64_t m, int k, int kp, int cap, unsigne
         if (rank == (unsigned)(k - 1)) s->bin = mine;  // exactly one thread has this rank
         __syncthreads();
         const unsigned t0 = s->bin;
-        for (int64_t i = threadIdx.x; i < m; i += (int64_t)U * kSelThreads) {
-            float v[U];
-#pragma unroll
-            for (int u = 0; u < U; u++) {
-                const int64_t at = i + (int64_t)u * kSelThreads;
-                v[u] = load(at < m ? at : m - 1);
+        auto offer = [&](unsigned key, int64_t at) {
+            if (at < m && key <= t0) {
+                const unsigned slot = atomicAdd(&s->count, 1u);
+                if (slot < (unsigned)cap) ent[slot] = ((unsigned long long)key << 32) | (unsigned)at;
             }
+        };
+        if (resident) {
 #pragma unroll
-            for (int u = 0; u < U; u++) {
-                const int64_t at = i + (int64_t)u * kSelThreads;
-                const unsigned key = float_to_key(v[u]);
-                if (at < m && key <= t0) {
-                    const unsigned slot = atomicAdd(&s->count, 1u);
-                    if (slot < (unsigned)cap) ent[slot] = ((unsigned long long)key << 32) | (unsigned)at;
+            for (int b = 0; b < kKeep; b++)
+#pragma unroll
+                for (int u = 0; u < U; u++)
+                    offer(float_to_key(keep[b][u]), (int64_t)threadIdx.x + (int64_t)(b * U + u) * kSelThreads);
+        } else {
+            for (int64_t i = threadIdx.x; i < m; i += (int64_t)U * kSelThreads) {
+                float v[U];
+#pragma unroll
+                for (int u = 0; u < U; u++) {
+                    const int64_t at = i + (int64_t)u * kSelThreads;
+                    v[u] = load(at < m ? at : m - 1);
                 }
+#pragma unroll
+                for (int u = 0; u < U; u++) offer(float_to_key(v[u]), i + (int64_t)u * kSelThreads);
             }
         }
         __syncthreads();
