@@ -246,7 +246,6 @@ template <typename T, int METRIC>
 int launch_scan_m(pgv_ctx *ctx, const RowGeom &g, const void *rows, const void *queries,
                   const ScanTask *tasks, const int *ntasks_dev, int ntasks_bound,
                   const ScanPair *pairs, int qt, float *out) {
-    static const int variant = getenv("PGV_SCAN_VARIANT") ? atoi(getenv("PGV_SCAN_VARIANT")) : 0;
 #define PGV_SCAN(QT, R, TH, PF) \
     return launch_scan_t<T, METRIC, QT, R, TH, PF>(ctx, g, rows, queries, tasks, ntasks_dev, ntasks_bound, pairs, out)
     switch (qt) {
@@ -257,7 +256,6 @@ int launch_scan_m(pgv_ctx *ctx, const RowGeom &g, const void *rows, const void *
         case 4:
             PGV_SCAN(4, 4, 256, 1);
         case 8:
-            if (variant == 1) PGV_SCAN(8, 8, 256, 1);
             PGV_SCAN(8, 4, 256, 1);
         case 16:
             // (16, 8, 512) and (16, 4, 1024) spill
@@ -332,9 +330,9 @@ RowGeom row_geom(int dim, pgv_dtype t) {
 // Queries per task: the smallest power of two >= wanted, capped by the LDS image of
 // the group (<= 64 KB up to 8 queries, <= 128 KB for 16).  Groups of 16 leave room
 // for one workgroup per CU only and measured slower than two passes of 8 (DESIGN.md
-// section 6), so 8 is the default cap; PGV_SCAN_MAXQT=16 re-enables them.
+// section 6), so 8 is the cap.
 int scan_group_size(const RowGeom &g, pgv_dtype, int wanted) {
-    static const int cap = getenv("PGV_SCAN_MAXQT") ? atoi(getenv("PGV_SCAN_MAXQT")) : 8;
+    constexpr int cap = 8;
     int qt = 16;
     while (qt > 1 && (qt > cap || (size_t)qt * g.nvec * sizeof(Raw16) > (qt > 8 ? 128u : 64u) * 1024 - 256)) qt >>= 1;
     while (qt > 1 && qt / 2 >= wanted) qt >>= 1;

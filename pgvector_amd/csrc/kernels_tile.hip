@@ -17,9 +17,9 @@
 // dim a multiple of 256 (fp32) / 512 (fp16) -- every BASELINE config.  Other
 // shapes use scan_kernel.
 //
-// Experiment builds (never the product library; tools/ablate_tile.sh, tools/variants.sh):
-//   -DPGV_TILE_ABLATE=1..4   leave out the streaming / the scoring / the stores
-//   -DPGV_TILE_TIMING        per-wavefront wall-clock breakdown, printed for a few workgroups
+// (The ablation / per-wavefront timing builds that produced DESIGN.md's "DMA only 1.06 ms,
+// scoring only 1.00 ms" figures lived in this file through round 1 -- git history, commit
+// 088d32a -- and are gone from the product source.)
 #include "pgv_device.h"
 
 #include <cstdlib>
@@ -28,19 +28,11 @@ namespace pgv {
 
 namespace {
 
-#ifndef PGV_TILE_THREADS
-#define PGV_TILE_THREADS 512
-#endif
-constexpr int kTileThreads = PGV_TILE_THREADS;
+constexpr int kTileThreads = 512;
 constexpr int kTileGroupsPerCu = 1024 / kTileThreads;  // workgroups sharing a CU (and its LDS)
 constexpr int kTileWaves = kTileThreads / kWave;       // 8: with two workgroups, four per SIMD
 constexpr int kQW = 2;                                  // queries per wavefront -> 16 per workgroup
-#ifndef PGV_TILE_ABLATE
-#define PGV_TILE_ABLATE 0
-#endif
-#ifndef PGV_TILE_DMA_FRONT
-#define PGV_TILE_DMA_FRONT 1
-#endif
+constexpr int kDmaFront = 1;  // DMA instructions of the next tile issued before the first row is scored
 
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 
@@ -92,30 +84,12 @@ __global__ __launch_bounds__(kTileThreads) void tile_scan_kernel(
     const int lane = threadIdx.x & (kWave - 1);
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);  // provably wave-uniform
     const int ntasks = *ntasks_ptr;
-#ifdef PGV_TILE_TIMING
-    unsigned long long tm_start = wall_clock64(), tm_setup = 0, tm_score = 0, tm_wait = 0, tm_dma = 0, tm_mark;
-    int tm_tasks = 0, tm_tiles = 0;
-#define PGV_TM(x) x
-#else
-#define PGV_TM(x)
-#endif
 
     for (;;) {
-        PGV_TM(tm_mark = wall_clock64();)
         if (threadIdx.x == 0) *lds_task = atomicAdd(task_counter, 1);
         __syncthreads();
         const int t = *lds_task;
-#ifdef PGV_TILE_TIMING
-        if (t >= ntasks) {
-            if (lane == 0 && (wave == 0 || wave == kTileWaves - 1) && (blockIdx.x == 1 || blockIdx.x == 200))
-                printf("wg %d wave %d: total %llu setup %llu score %llu dma-wait %llu barrier-wait %llu (x10ns) tasks %d tiles %d\n",
-                       blockIdx.x, wave, wall_clock64() - tm_start, tm_setup, tm_score, tm_dma, tm_wait, tm_tasks, tm_tiles);
-            return;
-        }
-        tm_tasks++;
-#else
         if (t >= ntasks) return;
-#endif
         const ScanTask task = tasks[t];
 
         // Queries 2j and 2j + 1 of the task form pair j, served by wavefront j and, when the task
@@ -175,35 +149,28 @@ __global__ __launch_bounds__(kTileThreads) void tile_scan_kernel(
         // by itself does not drain an LDS-DMA
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
-        PGV_TM(tm_setup += wall_clock64() - tm_mark;)
 
         for (int ti = 0; ti < ntiles; ti++) {
             char *cur = smem + (size_t)(ti & 1) * tile_bytes;
             char *nxt = smem + (size_t)((ti + 1) & 1) * tile_bytes;
-#if PGV_TILE_ABLATE != 3 && PGV_TILE_ABLATE != 4  // ablation: no stores
             if (ti > 0) store_tile(ti - 1);
-#endif
             // The next tile is streamed while `cur` is scored.  Its DMA instructions are not
             // issued in one burst after the barrier -- with every wavefront doing that at once
             // the vector-memory queue backs up and all of them stall on the issue -- but dealt
-            // out between the rows: PGV_TILE_DMA_FRONT of them up front, one more per row
+            // out between the rows: kDmaFront of them up front, one more per row
             // scored, the rest after the last row.
             int dma_i = wave, dma_n = 0;
             const char *dma_src = nullptr;
-#if PGV_TILE_ABLATE != 1 && PGV_TILE_ABLATE != 3  // ablation: score without streaming
             if (ti + 1 < ntiles) {
                 dma_n = rows_in(ti + 1) * NCH;
                 dma_src = tile_src(ti + 1);
             }
-#endif
             auto issue_next = [&](int count) {
                 for (int c = 0; c < count && dma_i < dma_n; c++, dma_i += kTileWaves) dma_slice(dma_src, nxt, dma_i);
             };
-            issue_next(PGV_TILE_DMA_FRONT);
+            issue_next(kDmaFront);
 
             const int rows_here = rows_in(ti);
-            PGV_TM(tm_mark = wall_clock64(); tm_tiles++;)
-#if PGV_TILE_ABLATE != 2  // ablation: stream without scoring
             // LDS byte address of this lane's slice of row 0 of the tile being scored
             const unsigned lrow = (unsigned)(size_t)(__attribute__((address_space(3))) char *)cur +
                                   (unsigned)lane * (unsigned)sizeof(Raw16);
@@ -226,19 +193,11 @@ __global__ __launch_bounds__(kTileThreads) void tile_scan_kernel(
                 const float sum = wave_sum2(acc0.x + acc0.y, acc1.x + acc1.y);
                 if ((lane >> 1) == nth) res = finish<METRIC>(sum);
             }
-#endif
             issue_next(1 << 20);
-            PGV_TM(tm_score += wall_clock64() - tm_mark; tm_mark = wall_clock64();)
-            PGV_TM(asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); tm_dma += wall_clock64() - tm_mark; tm_mark = wall_clock64();)
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // next tile landed (this wavefront's share)
             __syncthreads();                                   // ... everyone's; and everyone is done reading `cur`
-            PGV_TM(tm_wait += wall_clock64() - tm_mark;)
         }
-#if PGV_TILE_ABLATE != 3 && PGV_TILE_ABLATE != 4
         store_tile(ntiles - 1);
-#else
-        if (res == 12345.678f) out[0] = res;  // keeps the scoring alive
-#endif
     }
 }
 

@@ -282,11 +282,7 @@ int dense_scan(pgv_ctx *ctx, pgv_metric metric, pgv_dtype dtype, const RowGeom &
     if (nrows <= 0 || nq <= 0) return PGV_OK;
     // many queries against the same rows (center ranking of a batch): the tile kernel serves
     // 16 queries per pass over the rows
-#ifdef PGV_TILE_ABLATE  // ablation builds keep center ranking exact so that the probe sets are the real ones
-    const bool use_tile = false;
-#else
     const bool use_tile = nq > 8 && tile_scan_supported(g);
-#endif
     const int qt = use_tile ? tile_scan_queries_per_task() : scan_group_size(g, dtype, nq);
     const int ngroups = (nq + qt - 1) / qt;
     int ch = rows_per_task_for(ctx, nrows, ngroups);
@@ -769,13 +765,12 @@ static int scan_batch_dev(pgv_index *ix, const void *q_dev, int nq, const int32_
     pgv_ctx *ctx = ix->ctx;
     // invert to list-major work.  Queries per list on average decides how wide a group is
     // worth.  Lists probed by more than 8 queries go to the tile kernel (16 queries per pass
-    // over the rows) when the row shape allows it; PGV_TILE=0/1 overrides for experiments.
+    // over the rows) when the row shape allows it.
     const double share = (double)nq * probes / (double)ix->nlists;
-    static const int tile_env = getenv("PGV_TILE") ? atoi(getenv("PGV_TILE")) : -1;
-    const bool use_tile = tile_scan_supported(ix->geom) && (tile_env == 1 || (tile_env != 0 && share > 8.0));
+    const bool use_tile = tile_scan_supported(ix->geom) && share > 8.0;
     const int qt = use_tile ? tile_scan_queries_per_task()
                             : scan_group_size(ix->geom, ix->dtype, (int)std::ceil(share));
-    static const int rpt_tiles = getenv("PGV_TILE_RPT") ? atoi(getenv("PGV_TILE_RPT")) : 20;  // tiles per task
+    constexpr int rpt_tiles = 20;  // tiles per task (measured best of 10 / 20 / 40 / 80 on the headline batch)
     const int rows_per_task = use_tile ? rpt_tiles * tile_scan_tile_rows(ix->geom)
                                        : (qt >= 16 ? 256 : (qt >= 4 ? 128 : 64));
     PlanResult plan;
@@ -846,6 +841,13 @@ int pgv_scan_batch(pgv_index *ix, const void *queries, int nq, const int32_t *pr
     if (!probe_lists) PGV_FAIL(PGV_ERR_ARG, "probe_lists is NULL");
     pgv_ctx *ctx = ix->ctx;
     PGV_HIP(hipSetDevice(ctx->device));
+    // the planner indexes list_offsets with these ids: host-side lists are checked here; lists that are
+    // already on the device must come from pgv_rank_lists (ids in range, distinct per query)
+    if (!is_device_ptr(probe_lists)) {
+        for (size_t i = 0; i < (size_t)nq * probes; i++)
+            if (probe_lists[i] < 0 || probe_lists[i] >= ix->nlists)
+                PGV_FAIL(PGV_ERR_ARG, "probe list id %d out of range 0..%d", probe_lists[i], ix->nlists - 1);
+    }
     const void *q_dev, *pl_dev;
     PGV_TRY(stage_rows(ctx, queries, nq, ix->dim, ix->dtype, ix->geom, ctx->q_stage, &q_dev));
     PGV_TRY(stage_flat(ctx, probe_lists, sizeof(int32_t) * (size_t)nq * probes, ctx->idx_stage, &pl_dev));

@@ -484,7 +484,7 @@ pgv_host_hnsw_build(pgv_hnsw * mirror, pgv_dtype dtype, int dim, const void *row
 		goto done;
 	}
 	is_dirty = calloc((size_t) n, 1);
-	hash_cap = 1 << 16;
+	hash_cap = 1 << 10;			/* grows by doubling at load factor 1/2 (see below) */
 	rec_of = calloc((size_t) hash_cap, sizeof(int64_t));
 
 	for (int64_t i0 = 0; i0 < n;)
@@ -706,10 +706,12 @@ pgv_host_hnsw_build(pgv_hnsw * mirror, pgv_dtype dtype, int dim, const void *row
 					uint64_t	key = ((uint64_t) owner << 6) | (uint64_t) lc;
 					int64_t		h = (int64_t) ((key * 0x9E3779B97F4A7C15ull) >> 40) & (hash_cap - 1);
 					record	   *rcd;
+					int64_t		ri;		/* record index + 1 (the table may be rebuilt below: h is not kept) */
 
 					while (rec_of[h] != 0 && !(recs[rec_of[h] - 1].owner == owner && recs[rec_of[h] - 1].lc == lc))
 						h = (h + 1) & (hash_cap - 1);
-					if (rec_of[h] == 0)
+					ri = rec_of[h];
+					if (ri == 0)
 					{
 						const nlist *l = &el[owner].layers[lc];
 
@@ -736,10 +738,31 @@ pgv_host_hnsw_build(pgv_hnsw * mirror, pgv_dtype dtype, int dim, const void *row
 							l->items[j].local = j;
 						}
 						rec_of[h] = ++nrec;
+						ri = nrec;
 						if ((int64_t) nrec * 2 > hash_cap)
 						{
-							rc = pgv_host_fail(PGV_ERR_STATE, "batch touches too many lists");
-							goto done;
+							/* load factor 1/2 reached (a batch touches up to B * (2m + level * m) lists; m up to
+							 * 100, src/hnsw.h:50): double the table and rehash the records made so far */
+							int64_t		ncap = hash_cap * 2;
+							int64_t    *nt = calloc((size_t) ncap, sizeof(int64_t));
+
+							if (!nt)
+							{
+								rc = pgv_host_fail(PGV_ERR_NOMEM, "out of memory growing the batch's list table");
+								goto done;
+							}
+							for (int64_t r = 0; r < nrec; r++)
+							{
+								uint64_t	k2 = ((uint64_t) recs[r].owner << 6) | (uint64_t) recs[r].lc;
+								int64_t		h2 = (int64_t) ((k2 * 0x9E3779B97F4A7C15ull) >> 40) & (ncap - 1);
+
+								while (nt[h2] != 0)
+									h2 = (h2 + 1) & (ncap - 1);
+								nt[h2] = r + 1;
+							}
+							free(rec_of);
+							rec_of = nt;
+							hash_cap = ncap;
 						}
 						if (!is_dirty[owner])
 						{
@@ -747,7 +770,7 @@ pgv_host_hnsw_build(pgv_hnsw * mirror, pgv_dtype dtype, int dim, const void *row
 							ndirty++;
 						}
 					}
-					rcd = &recs[rec_of[h] - 1];
+					rcd = &recs[ri - 1];
 					/* the newcomers of a list, in the order the reference's loop would link them */
 					if (rcd->nlocal - rcd->nstart == rcd->newcap)
 					{

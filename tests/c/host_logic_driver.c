@@ -157,6 +157,24 @@ test_hnsw_build(void)
 		pgv_host_hnsw_built_free(&built);
 		free(tids);
 	}
+	/* legal but large parameters (the reference allows m up to 100): a batch of 256 inserts with m = 64
+	 * touches more than 32768 (owner, layer) lists, which outgrows the batch's initial list table */
+	{
+		const int	bigm = 64;
+
+		CHECK(pgv_host_hnsw_build(mirror, PGV_F32, DIM, data, N, bigm, 128, NULL, 256, &built));
+		EXPECT(built.nelements == N && built.m == bigm);
+		for (int e = 0; e < N; e++)
+			for (int lc = 0; lc <= built.levels[e]; lc++)
+			{
+				int			lm = lc == 0 ? 2 * bigm : bigm;
+				const int32_t *mine = built.nbr + built.nbr_start[e] + (int64_t) (built.levels[e] - lc) * bigm;
+
+				for (int i = 0; i < lm; i++)
+					EXPECT(mine[i] >= -1 && mine[i] < N && mine[i] != e);
+			}
+		pgv_host_hnsw_built_free(&built);
+	}
 	ora_hnsw_free(g);
 	pgv_hnsw_free(mirror);
 	pgv_ctx_destroy(ctx);
