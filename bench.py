@@ -113,9 +113,11 @@ def sample_rows(data, lists, seed, ops):
     return samples
 
 
-def build_index(ctx, data, lists, seed, world, rank, dtype, ops, metric):
+def build_index(ctx, data, lists, seed, world, rank, dtype, ops, metric, comm=None):
     """IVFFlat build on the GPU(s), data resident in HBM: sample, k-means, assign every row, lay out
-    list-major.  Returns the image pieces and the seconds per phase."""
+    list-major.  With N ranks the k-means samples and the heap rows are sharded by row (the library's
+    pgv_kmeans_sharded does the exchanges), and every rank lays out only the lists it owns.
+    Returns the image pieces and the seconds per phase."""
     n, dim = data.shape
     dev = data.device
     t = {}
@@ -127,18 +129,9 @@ def build_index(ctx, data, lists, seed, world, rank, dtype, ops, metric):
         centers, _, iters = api.kmeans(ctx, ops, dtype, dim, samples, lists,
                                        api.make_rng(seed=seed + 2), want_closest=False)
     else:
-        init = api.kmeanspp_init(ctx, ops, dtype, dim, samples, lists, api.make_rng(seed=seed + 2))
         lo, hi = sharding.row_shard(ns, rank, world)
-        local = samples[lo:hi].contiguous()
-
-        def partial(s, c, closest):
-            return api.lloyd_partial(ctx, ops, dtype, dim, s, c, closest)
-
-        def finish(sums, counts, it):
-            return api.lloyd_finish(ctx, ops, dtype, dim, sums, counts,
-                                    api.make_rng(seed=seed + 3 + it), like=local)
-        centers, _, iters = sharding.sharded_kmeans(local, init, partial, finish,
-                                                    on_iter=(lambda *a: dbg("iter", *a)) if os.environ.get("PGV_BENCH_DEBUG") else None)
+        centers, _, iters = comm.kmeans(ops, dtype, dim, samples[lo:hi].contiguous(), lists,
+                                        api.make_rng(seed=seed + 2), want_closest=False)
     ctx.sync()
     torch.cuda.synchronize()
     t["kmeans"] = time.perf_counter() - t0
@@ -150,14 +143,20 @@ def build_index(ctx, data, lists, seed, world, rank, dtype, ops, metric):
     torch.cuda.synchronize()
     t["assign"] = time.perf_counter() - t1
     t2 = time.perf_counter()
-    order = torch.argsort(all_lists.to(torch.int64), stable=True)
-    counts = torch.bincount(all_lists.to(torch.int64), minlength=lists)
+    lists64 = all_lists.to(torch.int64)
+    if world > 1:
+        # only the lists this rank owns (l % world): foreign lists stay empty in the local image
+        rows_mine = torch.nonzero(sharding.owner_of_list(lists64, world) == rank)[:, 0]
+        local = lists64[rows_mine]
+        order = rows_mine[torch.argsort(local, stable=True)]
+        counts = torch.bincount(local, minlength=lists)
+    else:
+        order = torch.argsort(lists64, stable=True)
+        counts = torch.bincount(lists64, minlength=lists)
     offsets = torch.zeros(lists + 1, dtype=torch.int64, device=dev)
     offsets[1:] = torch.cumsum(counts, 0)
     vectors = data[order]
     tids = order.to(torch.int64)
-    if world > 1:
-        vectors, tids, offsets = sharding.local_index_arrays(vectors, tids, offsets, rank, world)
     torch.cuda.synchronize()
     t["layout"] = time.perf_counter() - t2
     t["total"] = time.perf_counter() - t0
@@ -370,6 +369,7 @@ def main():
         probes = args.probes
     k = args.k
     ctx = api.Context(local_rank, stream=torch.cuda.current_stream().cuda_stream)
+    comm = api.Comm(ctx, backend="rccl" if args.backend == "nccl" else "host") if world > 1 else None
     failures = []
 
     # ---------------------------------------------------------------- setup
@@ -380,7 +380,7 @@ def main():
     ctx.set_profiling(True)
     ctx.reset_stats()
     centers, offsets, vectors, tids, iters, build_t = build_index(ctx, data, lists, args.seed, world, rank,
-                                                                  dtype, ops, metric)
+                                                                  dtype, ops, metric, comm)
     build_stats = ctx.stats()
     ctx.set_profiling(False)
     log("build: %s (k-means iterations %d)" % ({a: round(b, 3) for a, b in build_t.items()}, iters))
@@ -404,14 +404,11 @@ def main():
         if world == 1:
             index.search_batch(q, probes, k, want_tid=True, out=(out_d, out_s, out_t))
             return out_d, out_t
-        # N GPUs: each rank ranks its own slice of the batch against the replicated centers,
-        # the probe lists are all-gathered, each rank scans the lists it owns, and the
-        # per-rank top-k are merged -- per-GPU work per step does not grow with N
-        mine = q[rank * args.batch:(rank + 1) * args.batch]
-        lists_mine, _ = index.rank_lists(mine, probes, want_dist=False)
-        lists_all = sharding.gather_probe_lists(lists_mine)
-        index.scan_batch(q, lists_all, k, want_tid=True, out=(out_d, out_s, out_t))
-        return sharding.merge_topk(out_d, out_t, k)
+        # N GPUs (pgv_search_batch_sharded): each rank ranks its own slice of the batch against the
+        # replicated centers, the probe lists are all-gathered, each rank scans the lists it owns, the
+        # per-rank top-k are all-gathered and merged on the device -- per-GPU work per step does not grow with N
+        comm.search_batch(index, q, probes, k, out=(out_d, out_t))
+        return out_d, out_t
 
     # ---------------------------------------------------------------- recall vs exact fp64
     rq = min(args.recall_queries, total_batch)
@@ -423,10 +420,8 @@ def main():
         recall_truth = "exact float64 brute force over all %d rows, %d queries" % (n, rq)
     else:
         # the rows are spread over the ranks: the exact answer is the merge of every rank's exhaustive scan
-        ed, _, et = index.search_batch(rqueries, lists, k, want_tid=True)
-        exact_d, _ = sharding.merge_topk(ed, et, k)
-        gd, _, gt = index.search_batch(rqueries, probes, k, want_tid=True)
-        got_d, got_t = sharding.merge_topk(gd, gt, k)
+        exact_d, _ = comm.search_batch(index, rqueries, lists, k)
+        got_d, got_t = comm.search_batch(index, rqueries, probes, k)
         exact_d = exact_d.double()
         recall_truth = "merge of every rank's exhaustive fp32 scan (probes = lists), %d queries" % rq
     ctx.sync()
@@ -496,7 +491,8 @@ def main():
                                % (args.workload, "vector" if tname == "f32" else "halfvec", oname, n, dim, tname,
                                   lists, probes, k, args.batch, components),
                    "rows": n, "dim": dim, "lists": lists, "probes": probes, "k": k,
-                   "batch_per_gpu": args.batch, "parallelism": "lists sharded l %% %d, top-k all-gather" % world,
+                   "batch_per_gpu": args.batch, "parallelism": "lists sharded l %% %d; k-means all-reduce, probe-list and top-k all-gathers inside libpgv_hip "
+                                  "(RCCL on the library's stream)" % world,
                    "local_rows": local_rows},
         "recall_at_10": recall, "recall_ground_truth": recall_truth,
         "build_secs": build_t["total"], "build_phases_secs": build_t, "kmeans_iterations": iters,
@@ -709,6 +705,8 @@ def main():
     if rank == 0:
         print(json.dumps(line), flush=True)
     index.close()
+    if comm is not None:
+        comm.close()
     ctx.close()
     if world > 1:
         dist.destroy_process_group()

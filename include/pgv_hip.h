@@ -316,6 +316,64 @@ int			pgv_kmeanspp_init(pgv_ctx * ctx, pgv_ops ops, pgv_dtype dtype, int dim,
 							  const void *samples, int n, int k, const pgv_rng * rng,
 							  void *out_centers);
 
+/* ------------------------------------------- multi-GPU: one process per GPU */
+
+/*
+ * IVFFlat shards naturally: k-means samples and heap rows by row, lists by l % nranks,
+ * centers replicated.  The exchange steps of the path live HERE, in the library, enqueued on the
+ * context's stream between the kernels that produce and consume their buffers (the reference runs
+ * its parallel build inside the extension too, src/ivfbuild.c:830-966):
+ *   k-means     per k-means++ round one all-gather of the ranks' weight totals and one of the candidate
+ *               rows; per Lloyd iteration ONE all-reduce of sums [k x dim] | counts [k] | changes as a
+ *               single fp32 buffer (k*d*4 + k*4 + 4 bytes), no host synchronisation: the host follows
+ *               the iteration through a 24-byte record in pinned memory
+ *   list scan   all-gather of the probe lists every rank chose for its slice of the query batch, and
+ *               of every rank's k x (distance, tid) per query, merged on the device
+ * pgv_comm_create uses RCCL over xGMI (librccl is resolved at run time; nothing is linked).
+ * pgv_comm_create_custom takes the two collectives from the caller instead -- a Postgres parallel
+ * build can back them with its DSM segment, the CPU-side tests with gloo.
+ * HNSW search does not shard: replicas only.
+ */
+typedef struct pgv_comm pgv_comm;
+
+#define PGV_COMM_ID_BYTES 128
+/* rank 0 makes the id of a new group (ncclGetUniqueId); the host hands it to every rank by whatever channel it has */
+int			pgv_comm_unique_id(void *out_id);
+int			pgv_comm_create(pgv_ctx * ctx, int nranks, int rank, const void *unique_id, pgv_comm * *out);
+
+/* both operate on DEVICE buffers and must be ordered after the work already enqueued on `stream` and
+ * before whatever is enqueued next (a host implementation synchronises the stream on entry) */
+typedef struct pgv_collectives
+{
+	int			(*all_reduce_sum_f32) (void *state, float *buf, size_t count, void *stream);	/* in place */
+	int			(*all_gather) (void *state, const void *send, void *recv, size_t bytes_per_rank, void *stream);
+	void	   *state;
+}			pgv_collectives;
+int			pgv_comm_create_custom(pgv_ctx * ctx, int nranks, int rank, const pgv_collectives * coll, pgv_comm * *out);
+void		pgv_comm_destroy(pgv_comm * comm);
+int			pgv_comm_size(const pgv_comm * comm);
+int			pgv_comm_rank(const pgv_comm * comm);
+
+/*
+ * pgv_kmeans with the samples sharded by row: samples_local [n_local x dim] are this rank's rows of the
+ * sample (global order = rank order), every rank gets the same centers.  Every rank must pass the same
+ * rng stream (seed or callbacks in the same state): the draws steer replicated decisions.
+ *   out_centers [k x dim], out_closest_local [n_local] or NULL
+ */
+int			pgv_kmeans_sharded(pgv_comm * comm, pgv_ops ops, pgv_dtype dtype, int dim,
+							   const void *samples_local, int n_local, int k, int max_iterations,
+							   const pgv_rng * rng, void *out_centers, int32_t *out_closest_local, int *out_iters);
+
+/*
+ * pgv_search_batch over an index whose lists are sharded l % nranks (`local_index` holds all list
+ * offsets, foreign lists empty, replicated centers, and was uploaded with tids): every rank passes the
+ * SAME batch of nq queries, ranks its slice of it against the centers, scans the probed lists it owns
+ * for all of them, and ends up with the merged k nearest (distance, tid) of every query.
+ *   out_dist [nq x k], out_tid [nq x k]  (ties: lower rank first)
+ */
+int			pgv_search_batch_sharded(pgv_comm * comm, pgv_index * local_index, const void *queries, int nq,
+									 int probes, int k, float *out_dist, uint64_t *out_tid);
+
 /* ------------------------------------------------- generic candidate batch */
 
 /*

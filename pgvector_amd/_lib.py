@@ -39,6 +39,8 @@ SYMBOLS = [
     "pgv_distance_batch", "pgv_cosine_distance_batch", "pgv_bit_distance_batch", "pgv_hnsw_upload", "pgv_hnsw_free", "pgv_hnsw_score", "pgv_hnsw_set_graph", "pgv_hnsw_search",
     "pgv_hnsw_build_search", "pgv_hnsw_score_pairs", "pgv_hnsw_update_graph",
     "pgv_query_begin", "pgv_query_end", "pgv_query_rank", "pgv_query_scan", "pgv_query_more", "pgv_query_lists",
+    "pgv_comm_unique_id", "pgv_comm_create", "pgv_comm_create_custom", "pgv_comm_destroy", "pgv_comm_size",
+    "pgv_comm_rank", "pgv_kmeans_sharded", "pgv_search_batch_sharded",
 ]
 
 
@@ -54,6 +56,14 @@ class PgvStats(C.Structure):
                 ("scan_pairs", C.c_double), ("scan_rows", C.c_double),
                 ("aux_ms", C.c_double), ("aux_launches", C.c_int64), ("aux_pairs", C.c_double),
                 ("assign_redo_rows", C.c_double), ("assign_rows", C.c_double), ("assign_recheck_rows", C.c_double), ("scan_unique_rows", C.c_double)]
+
+
+ALL_REDUCE_F32 = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p)
+ALL_GATHER = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p)
+
+
+class PgvCollectives(C.Structure):
+    _fields_ = [("all_reduce_sum_f32", ALL_REDUCE_F32), ("all_gather", ALL_GATHER), ("state", C.c_void_p)]
 
 
 NEXT_DOUBLE = C.CFUNCTYPE(C.c_double, C.c_void_p)
@@ -104,6 +114,15 @@ def _load():
     lib.pgv_query_scan.argtypes = [P, I, I, I, P, P, P, C.POINTER(I), C.POINTER(I64)]
     lib.pgv_query_more.argtypes = [P, I, I, P, P, P, C.POINTER(I)]
     lib.pgv_query_lists.argtypes = [P, P, I]
+    lib.pgv_comm_unique_id.argtypes = [P]
+    lib.pgv_comm_create.argtypes = [P, I, I, P, C.POINTER(P)]
+    lib.pgv_comm_create_custom.argtypes = [P, I, I, C.POINTER(PgvCollectives), C.POINTER(P)]
+    lib.pgv_comm_destroy.argtypes = [P]
+    lib.pgv_comm_destroy.restype = None
+    lib.pgv_comm_size.argtypes = [P]
+    lib.pgv_comm_rank.argtypes = [P]
+    lib.pgv_kmeans_sharded.argtypes = [P, I, I, I, P, I, I, I, C.POINTER(PgvRng), P, P, C.POINTER(I)]
+    lib.pgv_search_batch_sharded.argtypes = [P, P, P, I, I, I, P, P]
     lib.pgv_assign.argtypes = [P, I, I, I, P, I, P, I64, P, P]
     lib.pgv_kmeans.argtypes = [P, I, I, I, P, I, I, I, C.POINTER(PgvRng), P, P, C.POINTER(I)]
     lib.pgv_lloyd_partial.argtypes = [P, I, I, I, P, I, P, I, P, P, P, P]

@@ -271,6 +271,105 @@ class Query:
         return dist[:n], slot[:n], (tid[:n] if want_tid else None)
 
 
+class Comm:
+    """one process per GPU: the library's communicator (pgv_comm_*).  backend "rccl": RCCL over xGMI, the
+    group id travels through torch.distributed once; backend "host": the two collectives are callbacks that
+    move the device buffers through host memory and torch.distributed (gloo) -- functional runs only."""
+
+    def __init__(self, ctx, backend="rccl"):
+        import torch
+        import torch.distributed as dist
+        self.ctx = ctx
+        self.world = dist.get_world_size() if dist.is_initialized() else 1
+        self.rank = dist.get_rank() if dist.is_initialized() else 0
+        h = C.c_void_p()
+        if backend == "rccl":
+            ident = torch.zeros(128, dtype=torch.uint8)
+            if self.world > 1:
+                if self.rank == 0:
+                    buf = (C.c_uint8 * 128)()
+                    check(lib.pgv_comm_unique_id(buf))
+                    ident = torch.tensor(list(buf), dtype=torch.uint8)
+                on_dev = dist.get_backend() == "nccl"
+                t = ident.cuda() if on_dev else ident
+                dist.broadcast(t, 0)
+                ident = t.cpu()
+            if self.world == 1:  # a group of one: still through RCCL, which exercises the plumbing on one GPU
+                buf = (C.c_uint8 * 128)()
+                check(lib.pgv_comm_unique_id(buf))
+                ident = torch.tensor(list(buf), dtype=torch.uint8)
+            raw = (C.c_uint8 * 128)(*ident.tolist())
+            check(lib.pgv_comm_create(ctx.h, self.world, self.rank, raw, C.byref(h)))
+        else:
+            hip = C.CDLL("libamdhip64.so")
+            hip.hipMemcpy.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int]
+            hip.hipStreamSynchronize.argtypes = [C.c_void_p]
+            world = self.world
+
+            def all_reduce(_state, buf, count, stream):
+                try:
+                    hip.hipStreamSynchronize(stream)
+                    host = torch.empty(count, dtype=torch.float32)
+                    hip.hipMemcpy(host.data_ptr(), buf, count * 4, 2)   # device -> host
+                    dist.all_reduce(host)
+                    hip.hipMemcpy(buf, host.data_ptr(), count * 4, 1)   # host -> device
+                    return 0
+                except Exception:
+                    return 1
+
+            def all_gather(_state, send, recv, nbytes, stream):
+                try:
+                    hip.hipStreamSynchronize(stream)
+                    mine = torch.empty(nbytes, dtype=torch.uint8)
+                    hip.hipMemcpy(mine.data_ptr(), send, nbytes, 2)
+                    parts = [torch.empty(nbytes, dtype=torch.uint8) for _ in range(world)]
+                    dist.all_gather(parts, mine)
+                    full = torch.cat(parts)
+                    hip.hipMemcpy(recv, full.data_ptr(), nbytes * world, 1)
+                    return 0
+                except Exception:
+                    return 1
+            self._cbs = (_lib.ALL_REDUCE_F32(all_reduce), _lib.ALL_GATHER(all_gather))
+            coll = _lib.PgvCollectives(self._cbs[0], self._cbs[1], None)
+            self._coll = coll
+            check(lib.pgv_comm_create_custom(ctx.h, self.world, self.rank, C.byref(coll), C.byref(h)))
+        self.h = h
+        ctx._adopt(self)
+
+    def close(self):
+        if self.h:
+            lib.pgv_comm_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def kmeans(self, ops, dtype, dim, samples_local, k, rng=None, max_iterations=500, want_closest=True):
+        samples_local = as_dtype(samples_local, dtype)
+        n = int(samples_local.shape[0])
+        centers = _empty_like_kind(samples_local, (k, dim), _NP_OF[dtype])
+        closest = _empty_like_kind(samples_local, (n,), np.int32) if want_closest and n else None
+        iters = C.c_int()
+        check(lib.pgv_kmeans_sharded(self.h, ops, dtype, dim, ptr(samples_local) if n else None, n, k, max_iterations,
+                                     C.byref(rng) if rng is not None else None, ptr(centers), ptr(closest),
+                                     C.byref(iters)))
+        return centers, closest, iters.value
+
+    def search_batch(self, index, queries, probes, k, out=None):
+        queries = as_dtype(queries, index.dtype)
+        nq = int(queries.shape[0])
+        if out is None:
+            dist_ = _empty_like_kind(queries, (nq, k), np.float32)
+            tid = _empty_like_kind(queries, (nq, k), np.uint64 if not _on_device(queries) else np.int64)
+        else:
+            dist_, tid = out
+        check(lib.pgv_search_batch_sharded(self.h, index.h, ptr(queries), nq, probes, k, ptr(dist_), ptr(tid)))
+        return dist_, tid
+
+
 def assign(ctx, metric, dtype, dim, centers, rows, want_dist=True):
     centers = as_dtype(centers, dtype)
     rows = as_dtype(rows, dtype)

@@ -129,6 +129,100 @@ __global__ __launch_bounds__(kKmThreads) void kmpp_pick_kernel(
     for (int v = threadIdx.x; v < nvec; v += kKmThreads) dst[v] = src[v];
 }
 
+// The same pick with the samples sharded by row over `nranks` processes (global sample order =
+// rank order): every rank knows every rank's weight total (all-gathered); the walk first steps
+// over whole ranks, then -- on the rank it ends in -- over that rank's blocks and weights.  The
+// owner writes the chosen row into its send slot, everybody else zeros; after the all-gather of
+// the slots every rank copies slot *owner_out into centers[round + 1].
+__global__ __launch_bounds__(kKmThreads) void kmpp_pick_sharded_kernel(
+    const char *__restrict__ samples, int n, const float *__restrict__ weight,
+    const double *__restrict__ block_sums, int nblocks, const double *__restrict__ totals, int nranks, int rank,
+    const double *__restrict__ draws, int round, char *__restrict__ send_row, int nvec, int32_t *__restrict__ owner_out) {
+    __shared__ WalkLds w;
+    __shared__ int owner;
+    if (threadIdx.x == 0) {
+        double grand = 0.0;
+        for (int r = 0; r < nranks; r++) grand += totals[r];
+        double choice = grand * draws[round];
+        int o = nranks - 1;
+        for (int r = 0; r < nranks - 1; r++) {
+            // a rank without weight cannot hold the choice; the last rank with samples ends the walk regardless
+            if (choice - totals[r] <= 0 && totals[r] > 0) {
+                o = r;
+                break;
+            }
+            choice -= totals[r];
+        }
+        owner = o;
+        w.carry = choice;
+        *owner_out = o;
+    }
+    __syncthreads();
+    const size_t row_bytes = (size_t)nvec * sizeof(Raw16);
+    Raw16 *dst = reinterpret_cast<Raw16 *>(send_row);
+    if (owner != rank || n <= 0) {
+        for (int v = threadIdx.x; v < nvec; v += kKmThreads) dst[v] = raw16_zero();
+        return;
+    }
+    const int b = walk_first_nonpositive(block_sums, 0, nblocks - 1, w);
+    const int chosen = walk_first_nonpositive(weight, b * kKmThreads, n - 1, w);
+    const Raw16 *src = reinterpret_cast<const Raw16 *>(samples + (size_t)chosen * row_bytes);
+    for (int v = threadIdx.x; v < nvec; v += kKmThreads) dst[v] = src[v];
+}
+
+// this rank's weight total: block sums added in block order (the association kmpp_pick_kernel uses)
+__global__ void kmpp_total_kernel(const double *__restrict__ block_sums, int nblocks, double *__restrict__ out) {
+    double sum = 0.0;
+    for (int i = 0; i < nblocks; i++) sum += block_sums[i];
+    *out = sum;
+}
+
+// centers[round + 1] = the owner's slot of the gathered rows
+__global__ void kmpp_take_row_kernel(const char *__restrict__ gathered, const int32_t *__restrict__ owner, int nvec,
+                                     char *__restrict__ centers, int round) {
+    const size_t row_bytes = (size_t)nvec * sizeof(Raw16);
+    const Raw16 *src = reinterpret_cast<const Raw16 *>(gathered + (size_t)*owner * row_bytes);
+    Raw16 *dst = reinterpret_cast<Raw16 *>(centers + (size_t)(round + 1) * row_bytes);
+    for (int v = blockIdx.x * blockDim.x + threadIdx.x; v < nvec; v += gridDim.x * blockDim.x) dst[v] = src[v];
+}
+
+// the all-reduced Lloyd record [sums k x ld | counts k | changes 1] (all fp32: counts and the change
+// count are exact below 2^24) back into the integer counters the finish step reads; the pinned
+// host record gets (changes, empty clusters), its sequence word last -- what steers the host loop
+__global__ __launch_bounds__(kKmThreads) void lloyd_unpack_kernel(const float *__restrict__ tail, int k,
+                                                                  int32_t *__restrict__ counts,
+                                                                  unsigned long long *__restrict__ changes,
+                                                                  long long *__restrict__ host_rec, long long seq) {
+    __shared__ int empty;
+    if (threadIdx.x == 0) empty = 0;
+    __syncthreads();
+    int mine = 0;
+    for (int c = threadIdx.x; c < k; c += kKmThreads) {
+        const int v = (int)tail[c];
+        counts[c] = v;
+        mine += v <= 0 ? 1 : 0;
+    }
+    if (mine) atomicAdd(&empty, mine);
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const unsigned long long ch = (unsigned long long)tail[k];
+        *changes = ch;
+        if (host_rec) {
+            host_rec[0] = (long long)ch;
+            host_rec[1] = empty;
+            __hip_atomic_store(&host_rec[2], seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
+    }
+}
+
+// counts / changes of the local partial step appended to the sums as fp32, ready for one all-reduce
+__global__ __launch_bounds__(kKmThreads) void lloyd_pack_kernel(const int32_t *__restrict__ counts,
+                                                                const unsigned long long *__restrict__ changes, int k,
+                                                                float *__restrict__ tail) {
+    for (int c = blockIdx.x * kKmThreads + threadIdx.x; c <= k; c += gridDim.x * kKmThreads)
+        tail[c] = c < k ? (float)counts[c] : (float)*changes;
+}
+
 // ------------------------------------------------------------- Lloyd pieces
 
 __global__ __launch_bounds__(kKmThreads) void changes_hist_kernel(
@@ -325,6 +419,45 @@ int launch_kmpp_pick(pgv_ctx *ctx, const RowGeom &g, const void *samples, int n,
                        static_cast<const char *>(samples), n, weight, block_sums,
                        kmpp_block_count(n), draws, round, static_cast<char *>(centers), g.nvec,
                        picked);
+    PGV_HIP(hipGetLastError());
+    return PGV_OK;
+}
+
+int launch_kmpp_total(pgv_ctx *ctx, const double *block_sums, int nblocks, double *out) {
+    hipLaunchKernelGGL(kmpp_total_kernel, dim3(1), dim3(1), 0, ctx->stream, block_sums, nblocks, out);
+    PGV_HIP(hipGetLastError());
+    return PGV_OK;
+}
+
+int launch_kmpp_pick_sharded(pgv_ctx *ctx, const RowGeom &g, const void *samples, int n, const float *weight,
+                             const double *block_sums, const double *totals, int nranks, int rank, const double *draws,
+                             int round, void *send_row, int32_t *owner_out) {
+    hipLaunchKernelGGL(kmpp_pick_sharded_kernel, dim3(1), dim3(kKmThreads), 0, ctx->stream,
+                       static_cast<const char *>(samples), n, weight, block_sums, kmpp_block_count(n), totals, nranks,
+                       rank, draws, round, static_cast<char *>(send_row), g.nvec, owner_out);
+    PGV_HIP(hipGetLastError());
+    return PGV_OK;
+}
+
+int launch_kmpp_take_row(pgv_ctx *ctx, const RowGeom &g, const void *gathered, const int32_t *owner, void *centers,
+                         int round) {
+    hipLaunchKernelGGL(kmpp_take_row_kernel, dim3(1), dim3(kKmThreads), 0, ctx->stream,
+                       static_cast<const char *>(gathered), owner, g.nvec, static_cast<char *>(centers), round);
+    PGV_HIP(hipGetLastError());
+    return PGV_OK;
+}
+
+int launch_lloyd_pack(pgv_ctx *ctx, const int32_t *counts, const unsigned long long *changes, int k, float *tail) {
+    hipLaunchKernelGGL(lloyd_pack_kernel, dim3((k + kKmThreads) / kKmThreads), dim3(kKmThreads), 0, ctx->stream, counts,
+                       changes, k, tail);
+    PGV_HIP(hipGetLastError());
+    return PGV_OK;
+}
+
+int launch_lloyd_unpack(pgv_ctx *ctx, const float *tail, int k, int32_t *counts, unsigned long long *changes,
+                        long long *host_rec, long long seq) {
+    hipLaunchKernelGGL(lloyd_unpack_kernel, dim3(1), dim3(kKmThreads), 0, ctx->stream, tail, k, counts, changes,
+                       host_rec, seq);
     PGV_HIP(hipGetLastError());
     return PGV_OK;
 }

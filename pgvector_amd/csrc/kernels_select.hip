@@ -127,6 +127,9 @@ __global__ void plan_tasks_kernel(const int *__restrict__ cnt, const int64_t *__
         }
 }
 
+// float8 ordering: NaN after everything, strict
+__device__ __forceinline__ bool dist_before(float a, float b) { return float_to_key(a) < float_to_key(b); }
+
 // ------------------------------------------------------------------- top-k
 // block_topk (pgv_select.h) does the work; this kernel runs it for one segment per workgroup
 
@@ -221,6 +224,31 @@ __global__ __launch_bounds__(256) void plan_stats_kernel(const int *__restrict__
     }
 }
 
+// the final top-k merge of a sharded scan: per query the k nearest of the R ranks' sorted (distance, tid)
+// heads, ascending; ties: lower rank first, then the rank's own order (+inf / ~0 padding sorts last)
+__global__ void merge_heads_kernel(const float *__restrict__ dist_all, const uint64_t *__restrict__ tid_all, int nranks,
+                                   int nq, int k, float *__restrict__ out_dist, uint64_t *__restrict__ out_tid) {
+    const int q = blockIdx.x * blockDim.x + threadIdx.x;
+    if (q >= nq) return;
+    int at[16];
+    for (int r = 0; r < nranks; r++) at[r] = 0;
+    for (int i = 0; i < k; i++) {
+        int best = -1;
+        float bd = INFINITY;
+        for (int r = 0; r < nranks; r++) {
+            if (at[r] >= k) continue;
+            const float d = dist_all[((size_t)r * nq + q) * k + at[r]];
+            if (best < 0 || dist_before(d, bd)) {
+                best = r;
+                bd = d;
+            }
+        }
+        out_dist[(size_t)q * k + i] = bd;
+        out_tid[(size_t)q * k + i] = tid_all[((size_t)best * nq + q) * k + at[best]];
+        at[best]++;
+    }
+}
+
 __global__ void cast_pos_kernel(const int64_t *__restrict__ pos, int64_t n,
                                 int32_t *__restrict__ out) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -228,6 +256,16 @@ __global__ void cast_pos_kernel(const int64_t *__restrict__ pos, int64_t n,
 }
 
 }  // namespace
+
+int launch_merge_heads(pgv_ctx *ctx, const float *dist_all, const uint64_t *tid_all, int nranks, int nq, int k,
+                       float *out_dist, uint64_t *out_tid) {
+    if (nq <= 0) return PGV_OK;
+    if (nranks > 16) PGV_FAIL(PGV_ERR_ARG, "merge: more than 16 ranks");
+    hipLaunchKernelGGL(merge_heads_kernel, dim3((nq + 127) / 128), dim3(128), 0, ctx->stream, dist_all, tid_all, nranks,
+                       nq, k, out_dist, out_tid);
+    PGV_HIP(hipGetLastError());
+    return PGV_OK;
+}
 
 int launch_cast_pos_to_i32(pgv_ctx *ctx, const int64_t *pos, int64_t n, int32_t *out) {
     if (n <= 0) return PGV_OK;

@@ -281,6 +281,9 @@ int launch_query_scan(pgv_ctx *ctx, const pgv_index *ix, const void *q_dev, cons
 int launch_query_head(pgv_ctx *ctx, const pgv_index *ix, const float *seg, const int32_t *probe_lists, int nprobes,
                       int skip, int count, void *head_rec, unsigned seq);
 
+int launch_merge_heads(pgv_ctx *ctx, const float *dist_all, const uint64_t *tid_all, int nranks, int nq, int k,
+                       float *out_dist, uint64_t *out_tid);
+
 // kernels_select.hip (small helpers)
 int launch_cast_pos_to_i32(pgv_ctx *ctx, const int64_t *pos, int64_t n, int32_t *out);
 
@@ -291,6 +294,15 @@ int launch_kmpp_update(pgv_ctx *ctx, const float *raw, float *weight, int n, int
 int launch_kmpp_pick(pgv_ctx *ctx, const RowGeom &g, const void *samples, int n,
                      const float *weight, const double *block_sums, const double *draws,
                      int round, void *centers, int32_t *picked);
+int launch_kmpp_total(pgv_ctx *ctx, const double *block_sums, int nblocks, double *out);
+int launch_kmpp_pick_sharded(pgv_ctx *ctx, const RowGeom &g, const void *samples, int n, const float *weight,
+                             const double *block_sums, const double *totals, int nranks, int rank, const double *draws,
+                             int round, void *send_row, int32_t *owner_out);
+int launch_kmpp_take_row(pgv_ctx *ctx, const RowGeom &g, const void *gathered, const int32_t *owner, void *centers,
+                         int round);
+int launch_lloyd_pack(pgv_ctx *ctx, const int32_t *counts, const unsigned long long *changes, int k, float *tail);
+int launch_lloyd_unpack(pgv_ctx *ctx, const float *tail, int k, int32_t *counts, unsigned long long *changes,
+                        long long *host_rec, long long seq);
 int launch_changes_hist(pgv_ctx *ctx, const int32_t *closest_new, int32_t *closest_io, int n,
                         int32_t *counts, unsigned long long *changes);
 int launch_members(pgv_ctx *ctx, const int32_t *closest, int n, int k, const int32_t *counts,

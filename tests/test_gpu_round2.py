@@ -3,6 +3,7 @@ kernel instantiations BASELINE's shapes select, spherical k-means, the reference
 transcripts through the GPU, HNSW at configs[3]'s shape.  Same contract as test_gpu_parity.py:
 integers/indexes exact, distances within 1e-5 relative, ties compared as sets."""
 import ctypes as C
+import os
 
 import numpy as np
 import pytest
@@ -398,3 +399,40 @@ def test_assign_at_scale_is_the_fp64_argmin(ctx, tname, metric, n, k, dim):
         scale = best.abs() + (1.0 if metric == api.PGV_L2SQ else float(dim))
         assert int(((mine - best) > 1e-5 * scale).sum()) == 0
         torch.testing.assert_close(gd[lo:lo + 5000].double(), mine, rtol=1e-5, atol=1e-5 * float(scale.max()))
+
+
+# ------------------------------------------------------------------ multi-GPU path in the library
+def test_comm_group_of_one_goes_through_rccl(ctx, oracle):
+    """pgv_comm_create with a unique id and one rank: librccl is resolved, a communicator initialised and every
+    collective of pgv_kmeans_sharded / pgv_search_batch_sharded issued through it -- results identical to the
+    single-GPU entry points"""
+    comm = api.Comm(ctx, backend="rccl")
+    data = gen(5000, 32, seed=381, dist="clustered", clusters=25)
+    c1, cl1, it1 = api.kmeans(ctx, api.PGV_OPS_L2, api.PGV_F32, 32, data, 25, api.make_rng(seed=4))
+    c2, cl2, it2 = comm.kmeans(api.PGV_OPS_L2, api.PGV_F32, 32, data, 25, api.make_rng(seed=4))
+    np.testing.assert_array_equal(c1, c2)
+    np.testing.assert_array_equal(cl1, cl2)
+    assert it1 == it2
+    ivf = CpuIvf(oracle, po.OPS_L2, po.ORA_F32, data, 25, centers=c1)
+    ix = _upload(ctx, ivf)
+    q = gen(20, 32, seed=382, dist="clustered", clusters=25)
+    d1, _, t1 = ix.search_batch(q, 3, 10, want_tid=True)
+    d2, t2 = comm.search_batch(ix, q, 3, 10)
+    np.testing.assert_array_equal(d1, d2)
+    np.testing.assert_array_equal(t1, t2)
+    ix.close()
+    comm.close()
+
+
+def test_comm_two_ranks_on_one_gpu():
+    """the whole multi-GPU path of the library with two processes sharing this GPU (collectives: host callbacks
+    over gloo; RCCL itself needs two GPUs and is the driver's to run)"""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1")
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+                        "--master-addr", "127.0.0.1", "--master-port", "29611",
+                        os.path.join(root, "tests", "mp_comm_worker.py")],
+                       cwd=root, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=600)
+    assert r.returncode == 0 and "COMM-OK" in r.stdout, (r.returncode, r.stdout[-1000:], r.stderr[-3000:])
