@@ -220,7 +220,7 @@ def topk_equiv(got_ids, got_d, want_ids, want_d, rtol=RTOL):
     return None
 
 
-def cpu_baseline(centers, offsets, vectors, tids, queries, probes, k, dtype, ops, budget_s=12.0):
+def cpu_baseline(centers, offsets, vectors, tids, queries, probes, k, dtype, ops, budget_s=12.0, pages=None):
     """the oracle (= the reference's loops and kernels restated, built with the reference's flags +
     -march=native) answering the same queries on the host cores of this box.  Returns the baseline
     record and the oracle's (tids, distances) per query for the parity check."""
@@ -262,7 +262,47 @@ def cpu_baseline(centers, offsets, vectors, tids, queries, probes, k, dtype, ops
                      "no fmgr/bufmgr/tuplesort overheads)",
            "sample": "%d queries in %.1f s on %d threads (%d more on 1 thread), same index and queries as the "
                      "parity check" % (total, el, cores, single)}
-    return rec, answers
+    page_answers = None
+    if pages is not None:
+        # the same loops over the emulated 8 KB page image (oracle_pages.c): page headers, line
+        # pointers, IndexTuple headers, nextblkno chains, one 1536-d tuple per page
+        ptr, nblocks = pages
+        oops = po.OPS_L2 if ops == api.PGV_OPS_L2 else po.OPS_IP
+        odt = po.ORA_F32 if dtype == api.PGV_F32 else po.ORA_F16
+        page_answers = [None] * nq
+        half = max(budget_s / 2.0, 3.0)
+
+        def pworker(w):
+            done = 0
+            t_end = time.perf_counter() + half
+            i = w
+            while time.perf_counter() < t_end or i < nq:
+                r = ora.pages_search(ptr, nblocks, oops, odt, queries[i % nq], probes, k)
+                if i < nq:
+                    page_answers[i] = r
+                done += 1
+                i += cores
+            return done
+        t0 = time.perf_counter()
+        with ThreadPoolExecutor(cores) as ex:
+            ptotal = sum(ex.map(pworker, range(cores)))
+        pel = time.perf_counter() - t0
+        t0 = time.perf_counter()
+        psingle = 0
+        while time.perf_counter() - t0 < 3.0:
+            ora.pages_search(ptr, nblocks, oops, odt, queries[psingle % nq], probes, k)
+            psingle += 1
+        psingle_s = (time.perf_counter() - t0) / psingle
+        rec["contiguous"] = {"value": rec["value"], "single_thread_qps": rec["single_thread_qps"],
+                             "single_thread_ms_per_query": rec["single_thread_ms_per_query"], "layout": rec["layout"],
+                             "sample": rec["sample"]}
+        rec.update({"value": ptotal / pel, "single_thread_qps": 1.0 / psingle_s,
+                    "single_thread_ms_per_query": psingle_s * 1e3,
+                    "layout": "emulated 8 KB page image (oracle_pages.c walks meta / list / entry pages like "
+                              "src/ivfscan.c:47-187; no buffer pins, fmgr or tuplesort copies: still an upper bound)",
+                    "sample": "%d queries in %.1f s on %d threads (%d more on 1 thread) over the %d pages the product "
+                              "build wrote" % (ptotal, pel, cores, psingle, nblocks)})
+    return rec, answers, page_answers
 
 
 def live_traffic(args, scan_ms):
@@ -341,6 +381,10 @@ def main():
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo for a functional "
                                                      "multi-rank run on a single GPU)")
     args = ap.parse_args()
+    # fd 1 carries the ONE JSON line and nothing else: libraries that greet on stdout (RCCL's version banner)
+    # are pointed at stderr for the rest of the run
+    json_fd = os.dup(1)
+    os.dup2(2, 1)
     if args.child:
         args.no_cpu_baseline = args.no_sweeps = args.no_traffic = True
 
@@ -596,60 +640,8 @@ def main():
             psweep[str(p)] = {"qps": total_batch / s, "ms_per_step": s * 1e3, "recall_at_10": recall_at_k(gd, exact_d, k)}
         line["probes_sweep"] = psweep
 
-    # --------------------------------------------------- parity with the CPU oracle + its speed
-    if single and not args.no_cpu_baseline:
-        try:
-            pq = min(256, total_batch)
-            pqueries = queries[1][:pq].contiguous()
-            pd, ps, pt = index.search_batch(pqueries, probes, k, want_tid=True)
-            ctx.sync()
-            base, answers = cpu_baseline(centers.cpu().numpy(), offsets.cpu().numpy(), vectors.cpu().numpy(),
-                                         tids.cpu().numpy().astype(np.uint64), pqueries.cpu().numpy(), probes, k,
-                                         dtype, ops)
-            line["cpu_baseline"] = base
-            pd, pt = pd.cpu().numpy(), pt.cpu().numpy()
-            bad = []
-            for i in range(pq):
-                wt, wd = answers[i]
-                why = topk_equiv(pt[i][:len(wt)].astype(np.uint64).tolist(), pd[i][:len(wt)], wt.tolist(), wd)
-                if why:
-                    bad.append((i, why))
-            line["parity_checked_queries"] = pq
-            line["parity"] = {"against": "CPU oracle (oracle/, restated src/ivfscan.c:47-187), same index, same queries",
-                              "rule": "row ids identical where the order is determined beyond 1e-5 relative, "
-                                      "distances within 1e-5 relative",
-                              "mismatches": len(bad)}
-            if bad:
-                failures.append("parity: %d of %d queries differ from the oracle, first: %r" % (len(bad), pq, bad[0]))
-        except Exception as e:  # an oracle that cannot run must not pass for parity
-            line["cpu_baseline"] = {"value": None, "unit": "queries/s", "cores": 0, "kind": "port",
-                                    "sample": "failed: %r" % (e,)}
-            line["parity_checked_queries"] = 0
-
-    # ------------------------------------------------------------- uniform data (SURVEY 8d)
-    if single and not args.no_sweeps:
-        try:
-            udata = gen_uniform(n, dim, args.seed + 7, dev).to(tdtype)
-            uc, uo, uv, ut, uit, ubt = build_index(ctx, udata, lists, args.seed, 1, 0, dtype, ops, metric)
-            del udata
-            uix = api.IvfIndex(ctx, metric, dtype, dim, uc, uo, uv, ut.view(torch.int64))
-            uq = gen_uniform(total_batch, dim, args.seed + 8, dev).to(tdtype)
-            ued, _ = exact_topk_fp64(uv, uq[:rq], k, metric)
-            ures = {}
-            for p in (10, 100):
-                s = timed_steps(lambda j: uix.search_batch(uq, p, k, want_tid=True, out=(out_d, out_s, out_t)), 5)
-                gd, _, _ = uix.search_batch(uq[:rq].contiguous(), p, k)
-                ures[str(p)] = {"qps": total_batch / s, "recall_at_10": recall_at_k(gd, ued, k)}
-            line["uniform"] = {"data": "U[0,1)^%d (test/t/003_ivfflat_vector_build_recall.pl:60)" % dim,
-                               "build_secs": ubt["total"], "kmeans_iterations": uit, "probes": ures,
-                               "note": "uniform high-d data has no cluster structure: IVF recall at 1 % of the lists "
-                                       "is low by construction (the reference skips such cases, t/003:101-104)"}
-            uix.close()
-            del uv, uq
-        except Exception as e:
-            line["uniform"] = {"error": repr(e)}
-
     # ------------------------------------------------------ the product build path, through pages
+    pages_ctx = None
     if do_pages:
         try:
             from pgvector_amd import _host
@@ -686,11 +678,86 @@ def main():
                 "recall_at_10": prec}
             if prec < recall - 0.02:
                 failures.append("page-built index recall %.4f below the torch-laid-out index's %.4f" % (prec, recall))
-            pix.close()
-            del img, rel
+            pages_ctx = (rel, pix, img)
         except Exception as e:
             line["build_pages"] = {"error": repr(e)}
         host_rows = None
+
+    # --------------------------------------------------- parity with the CPU oracle + its speed
+    if single and not args.no_cpu_baseline:
+        try:
+            pq = min(256, total_batch)
+            pqueries = queries[1][:pq].contiguous()
+            pd, ps, pt = index.search_batch(pqueries, probes, k, want_tid=True)
+            ctx.sync()
+            pages = None
+            if pages_ctx is not None:
+                pages = (pages_ctx[0].rel.pages, int(pages_ctx[0].nblocks))
+            base, answers, page_answers = cpu_baseline(centers.cpu().numpy(), offsets.cpu().numpy(),
+                                                       vectors.cpu().numpy(), tids.cpu().numpy().astype(np.uint64),
+                                                       pqueries.cpu().numpy(), probes, k, dtype, ops, pages=pages)
+            line["cpu_baseline"] = base
+            pd, pt = pd.cpu().numpy(), pt.cpu().numpy()
+            bad = []
+            for i in range(pq):
+                wt, wd = answers[i]
+                why = topk_equiv(pt[i][:len(wt)].astype(np.uint64).tolist(), pd[i][:len(wt)], wt.tolist(), wd)
+                if why:
+                    bad.append((i, why))
+            line["parity_checked_queries"] = pq
+            line["parity"] = {"against": "CPU oracle (oracle/, restated src/ivfscan.c:47-187), same index, same queries",
+                              "rule": "row ids identical where the order is determined beyond 1e-5 relative, "
+                                      "distances within 1e-5 relative",
+                              "mismatches": len(bad)}
+            if bad:
+                failures.append("parity: %d of %d queries differ from the oracle, first: %r" % (len(bad), pq, bad[0]))
+            if page_answers is not None:
+                # the product path end to end: pages written by pgv_host_ivf_build, staged, uploaded, searched
+                # on the GPU -- against the oracle walking the very same pages
+                gd2, gs2, gt2 = pages_ctx[1].search_batch(pqueries, probes, k, want_tid=True)
+                ctx.sync()
+                gd2, gt2 = gd2.cpu().numpy(), gt2.cpu().numpy()
+                bad2 = []
+                for i in range(pq):
+                    wt, wd, _ = page_answers[i]
+                    why = topk_equiv(gt2[i][:len(wt)].astype(np.uint64).tolist(), gd2[i][:len(wt)], wt.tolist(), wd)
+                    if why:
+                        bad2.append((i, why))
+                line["parity"]["page_built_index_mismatches"] = len(bad2)
+                if bad2:
+                    failures.append("page-built index: %d of %d queries differ from the oracle walking the same "
+                                    "pages, first: %r" % (len(bad2), pq, bad2[0]))
+        except Exception as e:  # an oracle that cannot run must not pass for parity
+            line["cpu_baseline"] = {"value": None, "unit": "queries/s", "cores": 0, "kind": "port",
+                                    "sample": "failed: %r" % (e,)}
+            line["parity_checked_queries"] = 0
+
+    if pages_ctx is not None:
+        pages_ctx[1].close()
+        pages_ctx = None
+
+    # ------------------------------------------------------------- uniform data (SURVEY 8d)
+    if single and not args.no_sweeps:
+        try:
+            udata = gen_uniform(n, dim, args.seed + 7, dev).to(tdtype)
+            uc, uo, uv, ut, uit, ubt = build_index(ctx, udata, lists, args.seed, 1, 0, dtype, ops, metric)
+            del udata
+            uix = api.IvfIndex(ctx, metric, dtype, dim, uc, uo, uv, ut.view(torch.int64))
+            uq = gen_uniform(total_batch, dim, args.seed + 8, dev).to(tdtype)
+            ued, _ = exact_topk_fp64(uv, uq[:rq], k, metric)
+            ures = {}
+            for p in (10, 100):
+                s = timed_steps(lambda j: uix.search_batch(uq, p, k, want_tid=True, out=(out_d, out_s, out_t)), 5)
+                gd, _, _ = uix.search_batch(uq[:rq].contiguous(), p, k)
+                ures[str(p)] = {"qps": total_batch / s, "recall_at_10": recall_at_k(gd, ued, k)}
+            line["uniform"] = {"data": "U[0,1)^%d (test/t/003_ivfflat_vector_build_recall.pl:60)" % dim,
+                               "build_secs": ubt["total"], "kmeans_iterations": uit, "probes": ures,
+                               "note": "uniform high-d data has no cluster structure: IVF recall at 1 % of the lists "
+                                       "is low by construction (the reference skips such cases, t/003:101-104)"}
+            uix.close()
+            del uv, uq
+        except Exception as e:
+            line["uniform"] = {"error": repr(e)}
 
     # ------------------------------------------------------------------ live PMC traffic
     if single and not args.no_traffic:
@@ -703,7 +770,7 @@ def main():
     if failures:
         line["failures"] = failures
     if rank == 0:
-        print(json.dumps(line), flush=True)
+        os.write(json_fd, (json.dumps(line) + "\n").encode())
     index.close()
     if comm is not None:
         comm.close()

@@ -192,6 +192,11 @@ int64_t		ora_hnsw_element_row(const ora_hnsw * g, int64_t e);
 int			ora_hnsw_search(const ora_hnsw * g, const void *query, int ef_search, int k,
 							int64_t *out_rows, double *out_dist, int64_t *out_scored);
 
+/* ---- the same scan over the real on-disk layout: an array of 8 KB pages (oracle_pages.c) ---- */
+int			ora_pages_meta(const uint8_t *pages, uint32_t nblocks, int *dim, int *lists);
+int			ora_pages_search(const uint8_t *pages, uint32_t nblocks, int ops, int dtype, const void *query,
+							 int probes, int k, uint64_t *out_tids, double *out_dist, int64_t *out_scanned);
+
 #ifdef __cplusplus
 }
 #endif

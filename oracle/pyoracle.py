@@ -89,6 +89,8 @@ class Oracle:
         L.ora_ivf_get_scan_items.argtypes = [C.POINTER(IvfIndexStruct), P, P, I, P, P]
         L.ora_ivf_search.restype = I
         L.ora_ivf_search.argtypes = [C.POINTER(IvfIndexStruct), P, I, I, P, P]
+        L.ora_pages_meta.argtypes = [P, C.c_uint32, C.POINTER(I), C.POINTER(I)]
+        L.ora_pages_search.argtypes = [P, C.c_uint32, I, I, P, I, I, P, P, C.POINTER(C.c_int64)]
         L.ora_ivf_assign.restype = None
         L.ora_ivf_assign.argtypes = [I, I, I, P, I, P, I64, P, P]
         L.ora_ivf_num_samples.restype = I
@@ -217,6 +219,19 @@ class Oracle:
         dist = np.empty(k, dtype=np.float64)
         n = self.lib.ora_ivf_search(C.byref(ix), _p(q), probes, k, _p(tids), _p(dist))
         return tids[:n], dist[:n]
+
+    def pages_search(self, pages_ptr, nblocks, ops, dtype, query, probes, k):
+        """ivfflatgettuple's first batch over an array of 8 KB pages (oracle_pages.c); pages_ptr = address of
+        block 0 -> (tids, distances, tuples scanned)"""
+        q = None if query is None else self.arr(query, dtype)
+        tids = np.empty(k, dtype=np.uint64)
+        dist = np.empty(k, dtype=np.float64)
+        scanned = C.c_int64()
+        n = self.lib.ora_pages_search(C.c_void_p(pages_ptr), nblocks, ops, dtype, _p(q), probes, k, _p(tids), _p(dist),
+                                      C.byref(scanned))
+        if n < 0:
+            raise ValueError("not an IVFFlat page image")
+        return tids[:n], dist[:n], scanned.value
 
     def assign(self, ops, dtype, centers, rows):
         centers, rows = self.arr(centers, dtype), self.arr(rows, dtype)

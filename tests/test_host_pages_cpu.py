@@ -225,3 +225,25 @@ def test_hnsw_stage_rejects_other_relations():
                     np.array([1], np.uint64))
     with pytest.raises(Exception):
         rel.stage_hnsw(0)
+
+
+def test_oracle_walks_the_pages_like_it_walks_the_arrays(oracle):
+    """oracle_pages.c (GetScanLists / GetScanItems over the 8 KB page image, src/ivfscan.c:47-187) against
+    oracle_ivf.c over the contiguous arrays of the same index: identical tids and distances -- for rows with a
+    4-byte varlena header (dim 40), with the 1-byte short header (dim 3) and halfvec"""
+    from oracle import pyoracle as po
+    from helpers import CpuIvf
+    for ops, dtype, dim in [(po.OPS_L2, po.ORA_F32, 40), (po.OPS_L2, po.ORA_F32, 3), (po.OPS_IP, po.ORA_F16, 24)]:
+        data = gen(3000, dim, seed=61, dist="clustered", clusters=10, dtype=dtype)
+        ivf = CpuIvf(oracle, ops, dtype, data, 12)
+        rel = _host.Relation()
+        rel.write_index(0 if dtype == po.ORA_F32 else 1, ivf.centers, ivf.list_offsets, ivf.vectors, ivf.tids)
+        for q in gen(8, dim, seed=62, dist="clustered", clusters=10, dtype=dtype):
+            for probes in (1, 3, 12):
+                wt, wd = oracle.search(ivf.struct, q, probes, 25)
+                gt, gd, scanned = oracle.pages_search(rel.rel.pages, rel.nblocks, ops, dtype, q, probes, 25)
+                np.testing.assert_array_equal(gt, wt)
+                np.testing.assert_array_equal(gd, wd)
+        # NULL query: the first lists, every tuple at distance 0
+        gt, gd, scanned = oracle.pages_search(rel.rel.pages, rel.nblocks, ops, dtype, None, 2, 10 ** 6)
+        assert scanned == int(ivf.list_offsets[2]) and (gd == 0).all()
