@@ -16,9 +16,11 @@ NP_OF = {ORA_F32: np.float32, ORA_F16: np.float16}
 
 
 def build(native=False):
-    """(re)build the restatement from its own sources; returns the .so path"""
+    """(re)build the restatement from its own sources; returns the .so path.  The -march=native build is
+    ALWAYS redone on the host that uses it (a copy made elsewhere may use instructions this CPU lacks, or
+    predate the sources)."""
     target = "liboracle_native.so" if native else "liboracle.so"
-    subprocess.run(["make", "-s", "-C", HERE, target], check=True)
+    subprocess.run(["make", "-s"] + (["-B"] if native else []) + ["-C", HERE, target], check=True)
     return os.path.join(HERE, target)
 
 
@@ -40,7 +42,7 @@ class Oracle:
     def __init__(self, native=False, path=None):
         if path is None:
             path = os.path.join(HERE, "liboracle_native.so" if native else "liboracle.so")
-            if not os.path.exists(path):
+            if native or not os.path.exists(path):
                 path = build(native)
         self.path = path
         L = self.lib = C.CDLL(path)
