@@ -286,31 +286,94 @@ pgv_host_ivf_write_index(pgv_rel * rel, pgv_dtype dtype, int dim, int lists,
 		list_blk[i] = blk;
 	}
 
-	/* InsertTuples, :271-331 */
-	for (int i = 0; i < lists; i++)
+	/*
+	 * InsertTuples, :271-331.  Every index tuple of one index has the same size, so how many fit a page --
+	 * and with it every list's page range -- is known up front: the page array is grown once and the lists,
+	 * which share nothing, are written in parallel (the reference's leader writes them one after another;
+	 * the pages come out byte-identical).
+	 */
 	{
-		uint32_t	start = rel_new_page(rel),
-					cur = start;
-		uint8_t    *list_item;
+		size_t		tuple_size;
+		int			per_page = 0;
+		uint32_t   *first_blk = malloc(sizeof(uint32_t) * ((size_t) lists + 1));
+		uint32_t	base = rel->nblocks;
+		int			failed = 0;
 
-		for (int64_t r = list_offsets[i]; r < list_offsets[i + 1]; r++)
 		{
-			size_t		sz = form_index_tuple(item, dtype, dim, (const char *) vectors + (size_t) r * dim * es, tids[r]);
+			uint8_t    *probe = calloc(1, PGV_BLCKSZ);
+			page_header *h = (page_header *) probe;
+			tuple_size = form_index_tuple(item, dtype, dim, vectors ? vectors : centers, 0);
+			h->pd_lower = PAGE_HEADER_SIZE;
+			h->pd_special = PGV_BLCKSZ - SPECIAL_SIZE;
+			h->pd_upper = h->pd_special;
+			while (page_free_space(probe) >= tuple_size && page_add_item(probe, item, tuple_size))
+				per_page++;
+			free(probe);
+		}
+		if (per_page < 1)
+		{
+			free(first_blk);
+			free(item);
+			free(list_blk);
+			free(list_off);
+			return pgv_host_fail(PGV_ERR_STATE, "failed to add index item");
+		}
+		first_blk[0] = base;
+		for (int i = 0; i < lists; i++)
+		{
+			int64_t		len = list_offsets[i + 1] - list_offsets[i];
+			int64_t		np = len > 0 ? (len + per_page - 1) / per_page : 1;	/* an empty list still owns its start page */
 
-			if (page_free_space(page_at(rel, cur)) < sz)
-				cur = rel_append_page(rel, cur);
-			if (!page_add_item(page_at(rel, cur), item, sz))
+			first_blk[i + 1] = first_blk[i] + (uint32_t) np;
+		}
+		if (first_blk[lists] > rel->cap)
+		{
+			rel->cap = first_blk[lists];
+			rel->pages = realloc(rel->pages, (size_t) rel->cap * PGV_BLCKSZ);
+		}
+		if (!rel->pages)
+			failed = 1;
+		else
+		{
+			while (rel->nblocks < first_blk[lists])
+				rel_new_page(rel);	/* IvfflatInitPage of every page; cheap next to the payload copies */
+#pragma omp parallel for schedule(dynamic, 4)
+			for (int i = 0; i < lists; i++)
 			{
-				free(item);
-				free(list_blk);
-				free(list_off);
-				return pgv_host_fail(PGV_ERR_STATE, "failed to add index item");
+				uint8_t		tuple[PGV_BLCKSZ];
+				uint32_t	cur = first_blk[i];
+				uint8_t    *list_item;
+
+				for (int64_t r = list_offsets[i]; r < list_offsets[i + 1]; r++)
+				{
+					size_t		sz = form_index_tuple(tuple, dtype, dim, (const char *) vectors + (size_t) r * dim * es, tids[r]);
+
+					if (page_free_space(page_at(rel, cur)) < sz)
+					{
+						page_opaque(page_at(rel, cur))->nextblkno = cur + 1;	/* IvfflatAppendPage */
+						cur++;
+					}
+					if (cur >= first_blk[i + 1] || !page_add_item(page_at(rel, cur), tuple, sz))
+					{
+#pragma omp atomic write
+						failed = 1;
+						break;
+					}
+				}
+				/* IvfflatUpdateList: record start and insert page in the list tuple */
+				list_item = page_item(page_at(rel, list_blk[i]), list_off[i], NULL);
+				memcpy(list_item + 0, &first_blk[i], 4);
+				memcpy(list_item + 4, &cur, 4);
 			}
 		}
-		/* IvfflatUpdateList: record start and insert page in the list tuple */
-		list_item = page_item(page_at(rel, list_blk[i]), list_off[i], NULL);
-		memcpy(list_item + 0, &start, 4);
-		memcpy(list_item + 4, &cur, 4);
+		free(first_blk);
+		if (failed)
+		{
+			free(item);
+			free(list_blk);
+			free(list_off);
+			return pgv_host_fail(PGV_ERR_STATE, "failed to add index item");
+		}
 	}
 	free(item);
 	free(list_blk);
@@ -543,51 +606,65 @@ pgv_host_ivf_stage(const pgv_rel * rel, pgv_dtype dtype, pgv_ivf_image * out)
 		return pgv_host_fail(PGV_ERR_STATE, "list pages hold %d of %d lists", l, meta.lists);
 	}
 
-	/* pass 2: every list's entry-page chain (GetScanItems' walk, :139-179) */
+	/*
+	 * pass 2: every list's entry-page chain (GetScanItems' walk, :139-179).  First the chains are walked for
+	 * their line-pointer counts only (a few bytes per page), which fixes every list's row range; then the
+	 * lists, which share nothing, are copied out in parallel.
+	 */
+	(void) cap;
 	for (l = 0; l < out->lists; l++)
 	{
 		out->list_offsets[l] = n;
 		for (blk = out->start_pages[l]; blk != PGV_INVALID_BLOCK; blk = page_opaque(page_at(rel, blk))->nextblkno)
+			n += page_max_offset(page_at(rel, blk));
+	}
+	out->vectors = malloc(row_bytes * (size_t) (n > 0 ? n : 1));
+	out->tids = malloc(sizeof(uint64_t) * (size_t) (n > 0 ? n : 1));
+	{
+		int			bad_dim = 0;
+
+#pragma omp parallel for schedule(dynamic, 4)
+		for (int li = 0; li < out->lists; li++)
 		{
-			const uint8_t *page = page_at(rel, blk);
-			int			maxoff = page_max_offset(page);
+			int64_t		at = out->list_offsets[li];
 
-			if (n + maxoff > cap)
+			for (uint32_t b = out->start_pages[li]; b != PGV_INVALID_BLOCK; b = page_opaque(page_at(rel, b))->nextblkno)
 			{
-				cap = (n + maxoff) * 2 + 1024;
-				out->vectors = realloc(out->vectors, row_bytes * (size_t) cap);
-				out->tids = realloc(out->tids, sizeof(uint64_t) * (size_t) cap);
-			}
-			for (int off = 1; off <= maxoff; off++)
-			{
-				const uint8_t *itup = page_item(page, off, NULL);
-				int			dim;
-				const uint8_t *payload = tuple_vector_payload(itup, &dim);
-				uint16_t	hi,
-							lo,
-							pos;
+				const uint8_t *page = page_at(rel, b);
+				int			maxoff = page_max_offset(page);
 
-				if (dim != out->dim)
+				for (int off = 1; off <= maxoff; off++)
 				{
-					pgv_host_ivf_image_free(out);
-					return pgv_host_fail(PGV_ERR_DIMS, "different vector dimensions %d and %d", dim, meta.dimensions);
+					const uint8_t *itup = page_item(page, off, NULL);
+					int			dim;
+					const uint8_t *payload = tuple_vector_payload(itup, &dim);
+					uint16_t	hi,
+								lo,
+								pos;
+
+					if (dim != out->dim)
+					{
+#pragma omp atomic write
+						bad_dim = dim;
+						continue;
+					}
+					memcpy((char *) out->vectors + (size_t) at * row_bytes, payload, row_bytes);
+					memcpy(&hi, itup + 0, 2);
+					memcpy(&lo, itup + 2, 2);
+					memcpy(&pos, itup + 4, 2);
+					out->tids[at] = ((uint64_t) hi << 32) | ((uint64_t) lo << 16) | pos;
+					at++;
 				}
-				memcpy((char *) out->vectors + (size_t) n * row_bytes, payload, row_bytes);
-				memcpy(&hi, itup + 0, 2);
-				memcpy(&lo, itup + 2, 2);
-				memcpy(&pos, itup + 4, 2);
-				out->tids[n] = ((uint64_t) hi << 32) | ((uint64_t) lo << 16) | pos;
-				n++;
 			}
+		}
+		if (bad_dim)
+		{
+			pgv_host_ivf_image_free(out);
+			return pgv_host_fail(PGV_ERR_DIMS, "different vector dimensions %d and %d", bad_dim, meta.dimensions);
 		}
 	}
 	out->list_offsets[out->lists] = n;
 	out->nrows = n;
-	if (n == 0)
-	{
-		out->vectors = malloc(16);
-		out->tids = malloc(16);
-	}
 	return PGV_OK;
 }
 
