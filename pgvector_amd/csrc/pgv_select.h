@@ -85,7 +85,15 @@ __device__ inline void sort_entries(unsigned long long *ent, int kp) {
 __device__ inline void rank_sort_entries(unsigned long long *ent, int n) {
     const unsigned long long mine = (int)threadIdx.x < n ? ent[threadIdx.x] : ~0ull;
     int rank = 0;
-    for (int j = 0; j < n; j++) rank += ent[j] < mine ? 1 : 0;
+    // entries past n are ~0 (never smaller than a real entry): whole 16-byte reads, several in flight
+    const ulonglong2 *e2 = reinterpret_cast<const ulonglong2 *>(ent);
+    const int n2 = (n + 1) / 2;
+#pragma unroll 8
+    for (int j = 0; j < n2; j++) {
+        const ulonglong2 o = e2[j];
+        rank += o.x < mine ? 1 : 0;
+        rank += o.y < mine ? 1 : 0;
+    }
     __syncthreads();
     if ((int)threadIdx.x < n) ent[rank] = mine;
     __syncthreads();
@@ -152,10 +160,20 @@ __device__ void block_topk(Load load, int64_t m, int k, int kp, int cap, unsigne
         }
         mins[threadIdx.x] = mine;
         __syncthreads();
+        // rank of this thread's minimum among the 256: LDS broadcasts, 16 bytes a read and several reads
+        // in flight (a scalar loop of dependent ds_reads costs ~60 cycles an element: 7 us of a 10 us kernel)
         unsigned rank = 0;
-        for (int j = 0; j < kSelThreads; j++) {
-            const unsigned o = mins[j];
-            rank += (o < mine || (o == mine && j < (int)threadIdx.x)) ? 1u : 0u;
+        {
+            const uint4 *m4 = reinterpret_cast<const uint4 *>(mins);
+#pragma unroll 8
+            for (int j4 = 0; j4 < kSelThreads / 4; j4++) {
+                const uint4 o = m4[j4];
+                const int j = 4 * j4, t = (int)threadIdx.x;
+                rank += (o.x < mine || (o.x == mine && j < t)) ? 1u : 0u;
+                rank += (o.y < mine || (o.y == mine && j + 1 < t)) ? 1u : 0u;
+                rank += (o.z < mine || (o.z == mine && j + 2 < t)) ? 1u : 0u;
+                rank += (o.w < mine || (o.w == mine && j + 3 < t)) ? 1u : 0u;
+            }
         }
         if (rank == (unsigned)(k - 1)) s->bin = mine;  // exactly one thread has this rank
         __syncthreads();

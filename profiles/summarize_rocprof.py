@@ -44,10 +44,12 @@ def main():
     d, out = sys.argv[1], sys.argv[2]
     lines = ["# rocprofv3 summary: %s" % os.path.basename(os.path.normpath(d)), ""]
     bench = json.load(open(os.path.join(d, "trace_bench.json")))
+    rf = bench["roofline"]
     lines += ["bench line of the traced run: value %.0f %s, scan kernel avg %.3f ms/launch (HIP events in bench.py), "
-              "achieved %.0f GB/s algorithmic, %.0f GB/s streamed" % (
-                  bench["value"], bench["unit"], bench["roofline"]["avg_launch_ms"], bench["roofline"]["achieved"],
-                  bench["roofline"]["streamed_GBps"]), ""]
+              "%.0f GB/s streamed from HBM (frac %.3f of 8 TB/s), %.0f GB/s per-pair algorithmic, passes %s" % (
+                  bench["value"], bench["unit"], rf["avg_launch_ms"], rf.get("streamed_GBps", rf["achieved"]),
+                  rf.get("frac_streamed", rf["frac"]), rf.get("algorithmic_GBps", rf["achieved"]),
+                  "%.3f" % rf["passes"] if rf.get("passes") else "n/a"), ""]
     trace = load_trace(glob.glob(os.path.join(d, "trace", "*_kernel_trace.csv"))[0])
     by = defaultdict(list)
     for name, dur, lds, vgpr, grid, wg in trace:
@@ -103,6 +105,34 @@ def main():
         else:
             lines += ["= %.3f GB written per launch (uncalibrated on gfx950; output is 4 B per scored pair = %.3f GB)" % (
                 val * 1024 / 1e9, algo / (4.0 * b["config"]["dim"]) * 4 / 1e9)]
+    micro = glob.glob(os.path.join(d, "micro", "*_kernel_trace.csv"))
+    if micro:
+        mt = load_trace(micro[0])
+        mby = defaultdict(list)
+        for name, dur, lds, vgpr, grid, wg in mt:
+            mby[name].append(dur)
+        keep = [n for n in mby if any(t in n for t in ("mfma_argmin", "recheck", "chosen_distance", "argmin_kernel",
+                                                        "center_norms", "redo_finish", "query_"))]
+        lines += ["", "## round-2 micro-benchmarks (`tools/bench_round2.py` under `rocprofv3 --kernel-trace --stats`)", "",
+                  "| kernel | calls | avg us | min us | max us |", "|---|---|---|---|---|"]
+        for name in sorted(keep, key=lambda n: -sum(mby[n])):
+            v = mby[name]
+            lines.append("| %s | %d | %.1f | %.1f | %.1f |" % (name, len(v), sum(v) / len(v) / 1e3, min(v) / 1e3, max(v) / 1e3))
+        mj = os.path.join(d, "micro_bench.json")
+        if os.path.exists(mj):
+            try:
+                mb = json.load(open(mj))
+                lines += ["", "assignment cases (HIP-event time of the whole pgv_assign call, incl. recheck / redo / distances):", ""]
+                for c in mb.get("assign", []):
+                    lines.append("* %s: n %d, k %d, dim %d: %.2f ms = %.1f T MAC/s (%.0f TFLOP/s at 2 flop/MAC), rechecked %s, redone %s" % (
+                        c["case"], c["n"], c["k"], c["dim"], c["ms"], c["tmac_per_s"], c["tflops_2flop"],
+                        "%.3f" % c["recheck_fraction"] if c.get("recheck_fraction") is not None else "-",
+                        "%.5f" % c["redo_fraction"] if c.get("redo_fraction") is not None else "-"))
+                q = mb.get("query", {})
+                if q:
+                    lines += ["", "single-query path (1M x 1536, probes 10): " + json.dumps(q)]
+            except Exception as e:
+                lines.append("(micro_bench.json unreadable: %r)" % (e,))
     open(out, "w").write("\n".join(lines) + "\n")
     print("\n".join(lines))
 
