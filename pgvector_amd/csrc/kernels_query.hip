@@ -119,7 +119,7 @@ __global__ __launch_bounds__(kQThreads) void query_lists_kernel(const float *__r
     extern __shared__ __attribute__((aligned(16))) char smem[];
     unsigned long long *ent = reinterpret_cast<unsigned long long *>(smem);
     SelShared *s = reinterpret_cast<SelShared *>(smem + (size_t)kHeadCap * 8);
-    block_topk([cdist](int64_t i) { return cdist[i]; }, nlists, max_probes, kp, kHeadCap, ent, s);
+    block_topk_auto(cdist, nlists, max_probes, kp, kHeadCap, ent, s);
     for (int i = threadIdx.x; i < max_probes; i += kQThreads) out_lists[i] = (int32_t)(unsigned)(ent[i] & 0xffffffffu);
 }
 
@@ -198,7 +198,7 @@ __global__ __launch_bounds__(kQThreads) void query_head_kernel(
     unsigned long long *ent = reinterpret_cast<unsigned long long *>(smem);
     SelShared *s = reinterpret_cast<SelShared *>(smem + (size_t)kHeadCap * 8);
     const int k = skip + count;
-    block_topk([seg](int64_t i) { return seg[i]; }, m, k, kp, kHeadCap, ent, s);
+    block_topk_auto(seg, m, k, kp, kHeadCap, ent, s);
     const int have = (int)(m < k ? m : k) - skip;
     for (int i = threadIdx.x; i < have; i += kQThreads) {
         const unsigned long long e = ent[skip + i];

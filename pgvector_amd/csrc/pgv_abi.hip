@@ -898,7 +898,7 @@ int pgv_query_begin(pgv_index *ix, pgv_query **out) {
     if (!q) PGV_FAIL(PGV_ERR_NOMEM, "out of host memory");
     q->ix = ix;
     const int cap = query_head_cap();
-    const size_t state_bytes = sizeof(int32_t) * (size_t)cap + sizeof(float) * (size_t)ix->nlists;
+    const size_t state_bytes = sizeof(int32_t) * (size_t)cap + sizeof(float) * ((size_t)ix->nlists + 4);  // + one float4 of slack
     const size_t row_bytes = (size_t)ix->geom.ld * elem_size(ix->dtype);
     q->head_bytes = query_head_bytes(cap);
     int rc = q->state.ensure(state_bytes);
@@ -974,7 +974,7 @@ int pgv_query_scan(pgv_query *q, int first, int nprobes, int head, float *out_di
     if (out_tid && !ix->tids) PGV_FAIL(PGV_ERR_STATE, "index was uploaded without tids");
     PGV_HIP(hipSetDevice(ctx->device));
     const int64_t bound = ix->len_prefix[nprobes];  // rows of the nprobes longest lists
-    PGV_TRY(q->seg.ensure(sizeof(float) * (size_t)(bound > 0 ? bound : 1)));
+    PGV_TRY(q->seg.ensure(sizeof(float) * (size_t)(bound + 4)));  // + one float4 of slack for the vector loads of the selection
     const unsigned seq = ++q->seq ? q->seq : ++q->seq;  // never 0: the cleared record's value
     PGV_TRY(launch_query_scan(ctx, ix, q->is_null ? nullptr : q->q_dev.p, q->lists + first, nprobes, bound,
                               q->seg.as<float>()));

@@ -12,6 +12,7 @@
 
 #include "pgv_device.h"
 
+
 namespace pgv {
 
 namespace {
@@ -99,6 +100,23 @@ __device__ inline void rank_sort_entries(unsigned long long *ent, int n) {
     __syncthreads();
 }
 
+// rank of `mine` among the 256 per-thread minima (ties: lower thread first): LDS broadcasts, 16 bytes a
+// read, a few reads in flight (a scalar loop of dependent ds_reads costs ~60 cycles an element)
+__device__ inline unsigned rank_among_minima(const unsigned *mins, unsigned mine) {
+    const uint4 *m4 = reinterpret_cast<const uint4 *>(mins);
+    unsigned rank = 0;
+#pragma unroll 4
+    for (int j4 = 0; j4 < kSelThreads / 4; j4++) {
+        const uint4 o = m4[j4];
+        const int j = 4 * j4, t = (int)threadIdx.x;
+        rank += (o.x < mine || (o.x == mine && j < t)) ? 1u : 0u;
+        rank += (o.y < mine || (o.y == mine && j + 1 < t)) ? 1u : 0u;
+        rank += (o.z < mine || (o.z == mine && j + 2 < t)) ? 1u : 0u;
+        rank += (o.w < mine || (o.w == mine && j + 3 < t)) ? 1u : 0u;
+    }
+    return rank;
+}
+
 // The k smallest of load(0 .. m) by (key, position), ascending, left in ent[0, min(k, m)); the
 // rest of ent[0, kp) is ~0.  kp = k rounded up to a power of two (>= 2), cap >= max(kp, kFastCap)
 // entries of LDS behind `ent`.  An entry is (key << 32) | position.
@@ -120,86 +138,46 @@ __device__ void block_topk(Load load, int64_t m, int k, int kp, int cap, unsigne
         // if the candidates do not fit (long runs of equal keys).
         unsigned *mins = s->hist;  // scratch
         unsigned mine = 0xffffffffu;
-        // The sweeps are latency-bound (the values were just written by other CUs: every load
-        // misses this XCD's L2).  Up to kKeep * U values per thread are fetched ONCE, all loads in
-        // flight together, and stay in registers for the second sweep; longer sequences go
-        // through batches of U loads, the ragged end as a full batch with clamped addresses.
-        constexpr int U = 16, kKeep = 3;
-        const bool resident = m <= (int64_t)kKeep * U * kSelThreads;  // block-uniform
-        float keep[kKeep][U];
-        if (resident) {
+        // sweeps: eight independent loads in flight per thread and iteration, the ragged end as one more
+        // full batch with clamped addresses; the loop stays rolled -- a single workgroup running straight-line
+        // code once is bound by instruction fetch, so compact beats unrolled here (measured)
+        constexpr int U = 8;
+#pragma unroll 1
+        for (int64_t i = threadIdx.x; i < m; i += (int64_t)U * kSelThreads) {
+            float v[U];
 #pragma unroll
-            for (int b = 0; b < kKeep; b++)
+            for (int u = 0; u < U; u++) {
+                const int64_t at = i + (int64_t)u * kSelThreads;
+                v[u] = load(at < m ? at : m - 1);
+            }
 #pragma unroll
-                for (int u = 0; u < U; u++) {
-                    const int64_t at = (int64_t)threadIdx.x + (int64_t)(b * U + u) * kSelThreads;
-                    keep[b][u] = load(at < m ? at : m - 1);
-                }
-#pragma unroll
-            for (int b = 0; b < kKeep; b++)
-#pragma unroll
-                for (int u = 0; u < U; u++) {
-                    const int64_t at = (int64_t)threadIdx.x + (int64_t)(b * U + u) * kSelThreads;
-                    const unsigned key = at < m ? float_to_key(keep[b][u]) : 0xffffffffu;
-                    mine = key < mine ? key : mine;
-                }
-        } else {
-            for (int64_t i = threadIdx.x; i < m; i += (int64_t)U * kSelThreads) {
-                float v[U];
-#pragma unroll
-                for (int u = 0; u < U; u++) {
-                    const int64_t at = i + (int64_t)u * kSelThreads;
-                    v[u] = load(at < m ? at : m - 1);
-                }
-#pragma unroll
-                for (int u = 0; u < U; u++) {
-                    const unsigned key = i + (int64_t)u * kSelThreads < m ? float_to_key(v[u]) : 0xffffffffu;
-                    mine = key < mine ? key : mine;
-                }
+            for (int u = 0; u < U; u++) {
+                const unsigned key = i + (int64_t)u * kSelThreads < m ? float_to_key(v[u]) : 0xffffffffu;
+                mine = key < mine ? key : mine;
             }
         }
         mins[threadIdx.x] = mine;
         __syncthreads();
-        // rank of this thread's minimum among the 256: LDS broadcasts, 16 bytes a read and several reads
-        // in flight (a scalar loop of dependent ds_reads costs ~60 cycles an element: 7 us of a 10 us kernel)
-        unsigned rank = 0;
-        {
-            const uint4 *m4 = reinterpret_cast<const uint4 *>(mins);
-#pragma unroll 8
-            for (int j4 = 0; j4 < kSelThreads / 4; j4++) {
-                const uint4 o = m4[j4];
-                const int j = 4 * j4, t = (int)threadIdx.x;
-                rank += (o.x < mine || (o.x == mine && j < t)) ? 1u : 0u;
-                rank += (o.y < mine || (o.y == mine && j + 1 < t)) ? 1u : 0u;
-                rank += (o.z < mine || (o.z == mine && j + 2 < t)) ? 1u : 0u;
-                rank += (o.w < mine || (o.w == mine && j + 3 < t)) ? 1u : 0u;
-            }
-        }
+        const unsigned rank = rank_among_minima(mins, mine);
         if (rank == (unsigned)(k - 1)) s->bin = mine;  // exactly one thread has this rank
         __syncthreads();
         const unsigned t0 = s->bin;
-        auto offer = [&](unsigned key, int64_t at) {
-            if (at < m && key <= t0) {
-                const unsigned slot = atomicAdd(&s->count, 1u);
-                if (slot < (unsigned)cap) ent[slot] = ((unsigned long long)key << 32) | (unsigned)at;
+#pragma unroll 1
+        for (int64_t i = threadIdx.x; i < m; i += (int64_t)U * kSelThreads) {
+            float v[U];
+#pragma unroll
+            for (int u = 0; u < U; u++) {
+                const int64_t at = i + (int64_t)u * kSelThreads;
+                v[u] = load(at < m ? at : m - 1);
             }
-        };
-        if (resident) {
 #pragma unroll
-            for (int b = 0; b < kKeep; b++)
-#pragma unroll
-                for (int u = 0; u < U; u++)
-                    offer(float_to_key(keep[b][u]), (int64_t)threadIdx.x + (int64_t)(b * U + u) * kSelThreads);
-        } else {
-            for (int64_t i = threadIdx.x; i < m; i += (int64_t)U * kSelThreads) {
-                float v[U];
-#pragma unroll
-                for (int u = 0; u < U; u++) {
-                    const int64_t at = i + (int64_t)u * kSelThreads;
-                    v[u] = load(at < m ? at : m - 1);
+            for (int u = 0; u < U; u++) {
+                const int64_t at = i + (int64_t)u * kSelThreads;
+                const unsigned key = float_to_key(v[u]);
+                if (at < m && key <= t0) {
+                    const unsigned slot = atomicAdd(&s->count, 1u);
+                    if (slot < (unsigned)cap) ent[slot] = ((unsigned long long)key << 32) | (unsigned)at;
                 }
-#pragma unroll
-                for (int u = 0; u < U; u++) offer(float_to_key(v[u]), i + (int64_t)u * kSelThreads);
             }
         }
         __syncthreads();
@@ -294,6 +272,114 @@ __device__ void block_topk(Load load, int64_t m, int k, int kp, int cap, unsigne
     }
 
     sort_entries(ent, sort_n);
+}
+
+// The single-query path's selections (1000 center distances; ~12 000 tuple distances of a batch): the whole
+// sequence is fetched ONCE as twelve 16-byte loads per thread, all in flight together -- one memory round
+// trip instead of one per sweep iteration -- and both sweeps run from registers.  v must be 16-byte
+// aligned with at least ((m + 3) & ~3) floats readable.  Same result as block_topk.
+constexpr int kSmallVec = 12;
+constexpr int kSmallMax = kSmallVec * 4 * kSelThreads;  // 12288
+
+__device__ inline void block_topk_small(const float *v, int m, int k, int kp, int cap, unsigned long long *ent,
+                                        SelShared *s) {
+    // A lone workgroup runs at whatever clock an otherwise idle chip grants: what counts here is the
+    // number of instructions on the critical path (measured: ~300 instructions per microsecond), so the
+    // sweeps compare floats (one v_min / v_cmp per value, keys only where a value is kept) and the rank
+    // step compares unique 32-bit composites.
+    for (int i = threadIdx.x; i < cap; i += kSelThreads) ent[i] = ~0ull;
+    if (threadIdx.x == 0) s->count = 0;
+    const int last4 = ((m + 3) & ~3) - 4;  // the last whole float4
+    float4 r[kSmallVec];
+#pragma unroll
+    for (int b = 0; b < kSmallVec; b++) {
+        const int at = b * 4 * kSelThreads + 4 * (int)threadIdx.x;
+        r[b] = *reinterpret_cast<const float4 *>(v + (at < last4 ? at : last4));
+    }
+    // values past m read as +inf from here on; NaN never wins a float minimum (it sorts last anyway)
+    float fmine = INFINITY;
+#pragma unroll
+    for (int b = 0; b < kSmallVec; b++) {
+        const int at = b * 4 * kSelThreads + 4 * (int)threadIdx.x;
+        if (at + 3 >= m) {  // the ragged end (and everything clamped past it)
+            if (at + 0 >= m) r[b].x = INFINITY;
+            if (at + 1 >= m) r[b].y = INFINITY;
+            if (at + 2 >= m) r[b].z = INFINITY;
+            if (at + 3 >= m) r[b].w = INFINITY;
+        }
+        fmine = fminf(fminf(fmine, fminf(r[b].x, r[b].y)), fminf(r[b].z, r[b].w));
+    }
+    // unique composite: the key with its low byte replaced by the thread id.  The thread of composite
+    // rank k - 1 bounds k minima by (its key | 0xff): a valid (marginally looser) threshold.
+    const unsigned key_mine = float_to_key(fmine);
+    const unsigned comp = (key_mine & ~0xffu) | threadIdx.x;
+    unsigned *mins = s->hist;
+    __syncthreads();
+    mins[threadIdx.x] = comp;
+    __syncthreads();
+    unsigned rank = 0;
+    {
+        const uint4 *m4 = reinterpret_cast<const uint4 *>(mins);
+#pragma unroll 4
+        for (int j4 = 0; j4 < kSelThreads / 4; j4++) {
+            const uint4 o = m4[j4];
+            rank += (o.x < comp) + (o.y < comp) + (o.z < comp) + (o.w < comp);
+        }
+    }
+    if (rank == (unsigned)(k - 1)) s->bin = key_mine | 0xffu;
+    __syncthreads();
+    const unsigned t0 = s->bin;
+    // a finite threshold means k finite values exist at or below it: NaN and +inf entries (which the float
+    // comparisons below never admit) cannot belong to the answer.  Otherwise: the general path.
+    const bool general = t0 >= float_to_key(INFINITY);
+    if (!general) {
+        // count first (branch-free), reserve the slots with ONE atomic per thread that has any, then write:
+        // 64 returning atomics on one LDS word, each inside a divergent branch, cost more than the sweep
+        const float t0f = key_to_float(t0);
+        unsigned cnt = 0;
+#pragma unroll
+        for (int b = 0; b < kSmallVec; b++)
+            cnt += (r[b].x <= t0f) + (r[b].y <= t0f) + (r[b].z <= t0f) + (r[b].w <= t0f);
+        if (cnt) {
+            unsigned slot = atomicAdd(&s->count, cnt);
+#pragma unroll
+            for (int b = 0; b < kSmallVec; b++) {
+                const int at = b * 4 * kSelThreads + 4 * (int)threadIdx.x;
+                const float e[4] = {r[b].x, r[b].y, r[b].z, r[b].w};
+                if (fminf(fminf(e[0], e[1]), fminf(e[2], e[3])) <= t0f) {
+#pragma unroll
+                    for (int c = 0; c < 4; c++)
+                        if (e[c] <= t0f) {
+                            if (slot < (unsigned)cap)
+                                ent[slot] = ((unsigned long long)float_to_key(e[c]) << 32) | (unsigned)(at + c);
+                            slot++;
+                        }
+                }
+            }
+        }
+    }
+    __syncthreads();
+    const unsigned got = s->count;
+    if (!general && got <= (unsigned)kSelThreads) {
+        rank_sort_entries(ent, (int)got);
+    } else if (!general && got <= (unsigned)cap) {
+        int sort_n = kp;
+        while (sort_n < (int)got) sort_n <<= 1;
+        sort_entries(ent, sort_n);
+    } else {
+        // long runs of equal keys, or too few finite values: the general (radix) path
+        __syncthreads();
+        block_topk([v](int64_t i) { return v[i]; }, (int64_t)m, k, kp, cap, ent, s);
+    }
+}
+
+// picks the register-resident form when it applies
+__device__ inline void block_topk_auto(const float *v, int64_t m, int k, int kp, int cap, unsigned long long *ent,
+                                       SelShared *s) {
+    if (m > k && m <= kSmallMax && k <= kSelThreads / 2)  // block-uniform
+        block_topk_small(v, (int)m, k, kp, cap, ent, s);
+    else
+        block_topk([v](int64_t i) { return v[i]; }, m, k, kp, cap, ent, s);
 }
 
 }  // namespace
