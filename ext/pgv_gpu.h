@@ -1,0 +1,72 @@
+/*
+ * pgv_gpu.h -- what the pgvector extension gains to run its distance hot path on libpgv_hip.so.
+ *
+ * The files in ext/ are the glue INTEGRATION.md describes, as C a maintainer drops into src/ and
+ * adds to OBJS: they call the C ABI of include/pgv_hip.h and nothing else of this repository.  No
+ * PostgreSQL headers exist where this repository is built, so they are type-checked against the
+ * stand-in declarations of ext/shim/ (tests/test_ext_glue_cpu.py) and exercised functionally through
+ * their twins over the emulated page image (pgvector_amd/host/, tests/).
+ *
+ * Hook points in the reference (one line each; the reference code stays as the `vector.gpu = off` path):
+ *   _PG_init            src/vector.c:57-65      PgvGpuInit();
+ *   ivfflatbeginscan    src/ivfscan.c:252-317   so->gpu = PgvIvfflatBeginScan(index, so);
+ *   ivfflatrescan       src/ivfscan.c:322-356   PgvIvfflatRescan(so->gpu);
+ *   ivfflatgettuple     src/ivfscan.c:361-414   if (so->gpu) return PgvIvfflatGetTuple(scan);
+ *   ivfflatendscan      src/ivfscan.c:419-431   PgvIvfflatEndScan(so->gpu);
+ *   IvfflatKmeans       src/ivfkmeans.c:553-570 if (PgvIvfflatKmeans(index, samples, centers, typeInfo)) return;
+ *   BuildCallback       src/ivfbuild.c:224-266  if (buildstate->gpu) { PgvIvfflatBuildAdd(buildstate, tid, value); return; }
+ *   AssignTuples        src/ivfbuild.c:600-636  PgvIvfflatBuildFlush(buildstate) after the heap scan
+ */
+#ifndef PGV_GPU_H
+#define PGV_GPU_H
+
+#include "postgres.h"
+
+#include "access/relscan.h"
+#include "utils/rel.h"
+
+#include "ivfflat.h"
+#include "pgv_hip.h"
+
+extern bool vector_gpu;			/* GUC vector.gpu */
+extern int	vector_gpu_device;	/* GUC vector.gpu_device */
+
+void		PgvGpuInit(void);
+pgv_ctx    *PgvGetContext(void);
+
+/* FUNCTION 1 / element type of an ivfflat opclass (sql/vector.sql:406-425, :819-841) */
+void		PgvIvfflatOpclass(Relation index, pgv_metric * metric, pgv_dtype * dtype, pgv_ops * ops);
+
+/* device mirror of one index, cached per backend and dropped by the relcache callback */
+typedef struct PgvIvfMirror
+{
+	Oid			relid;
+	bool		valid;
+	pgv_index  *index;
+	int			lists;
+	int			dimensions;
+	pgv_dtype	dtype;
+	pgv_metric	metric;
+	int64		ntuples;
+	ItemPointerData *tids;		/* heap TID of every row slot */
+	struct PgvIvfMirror *next;
+}			PgvIvfMirror;
+
+PgvIvfMirror *PgvIvfflatGetMirror(Relation index);
+
+/* scan side (ivfscan_gpu.c) */
+void	   *PgvIvfflatBeginScan(Relation index, IvfflatScanOpaque so);
+void		PgvIvfflatRescan(void *gpu);
+bool		PgvIvfflatGetTuple(IndexScanDesc scan);
+void		PgvIvfflatEndScan(void *gpu);
+
+/* build side (ivfbuild_gpu.c) */
+bool		PgvIvfflatKmeans(Relation index, VectorArray samples, VectorArray centers, const IvfflatTypeInfo * typeInfo);
+void		PgvIvfflatBuildBegin(IvfflatBuildState * buildstate);
+void		PgvIvfflatBuildAdd(IvfflatBuildState * buildstate, ItemPointer tid, Datum value);
+void		PgvIvfflatBuildFlush(IvfflatBuildState * buildstate);
+
+/* the tuplesort feed of AddTupleToSort (src/ivfbuild.c:203-216), left in the reference's file */
+void		IvfflatAddToSort(IvfflatBuildState * buildstate, int list, ItemPointer tid, Datum value);
+
+#endif							/* PGV_GPU_H */
