@@ -378,6 +378,8 @@ def main():
     ap.add_argument("--child", action="store_true", help="(internal) the short run the PMC passes profile")
     ap.add_argument("--host-io", action="store_true", help="also time the batch with host-memory queries/results")
     ap.add_argument("--recall-queries", type=int, default=256)
+    ap.add_argument("--exact-scan", action="store_true", help="A/B: keep the batched L2 scan on the vector-ALU kernels "
+                    "(pgv_ctx_set_exact_scan)")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo for a functional "
                                                      "multi-rank run on a single GPU)")
     args = ap.parse_args()
@@ -414,6 +416,8 @@ def main():
     k = args.k
     ctx = api.Context(local_rank, stream=torch.cuda.current_stream().cuda_stream)
     comm = api.Comm(ctx, backend="rccl" if args.backend == "nccl" else "host") if world > 1 else None
+    if args.exact_scan:
+        ctx.set_exact_scan(True)
     failures = []
 
     # ---------------------------------------------------------------- setup
@@ -549,6 +553,8 @@ def main():
         "roofline": roofline,
         "center_rank_ms_per_step": stats["aux_ms"] / args.steps,
         "scan_ms_per_step": stats["scan_ms"] / args.steps,
+        "scan_redo_queries_per_step": stats["scan_redo_queries"] / args.steps,
+        "scan_path": "exact vector-ALU kernels (--exact-scan)" if args.exact_scan else "auto",
     }
 
     single = rank == 0 and world == 1

@@ -160,8 +160,18 @@ typedef struct pgv_stats
 	/* batched list scans: rows of the lists at least one query of the batch probes -- what a single pass
 	 * over the probed part of the index would stream (scan_rows / scan_unique_rows = passes) */
 	double		scan_unique_rows;
+	/* L2 batches scanned on the matrix cores: queries whose k' candidates could not be proven to hold
+	 * the whole head and took the exact pass over their segment as well */
+	double		scan_redo_queries;
 }			pgv_stats;
 int			pgv_ctx_set_profiling(pgv_ctx * ctx, int on);
+/*
+ * The batched list scan (pgv_search_batch / pgv_scan_batch) picks L2 candidates with the matrix cores'
+ * |q|^2 + |x|^2 - 2 q.x and then evaluates the reference's sum((q - x)^2) for those only; results are the
+ * same as evaluating every row exactly.  on != 0 keeps every row on the exact vector-ALU kernels (A/B
+ * measurements, and indexes whose rows mix magnitudes so widely that every query would be redone).
+ */
+int			pgv_ctx_set_exact_scan(pgv_ctx * ctx, int on);
 int			pgv_ctx_reset_stats(pgv_ctx * ctx);
 int			pgv_ctx_get_stats(pgv_ctx * ctx, pgv_stats * out);
 

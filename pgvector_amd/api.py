@@ -111,6 +111,10 @@ class Context:
     def set_profiling(self, on):
         check(lib.pgv_ctx_set_profiling(self.h, 1 if on else 0))
 
+    def set_exact_scan(self, on):
+        """Keep batched L2 scans on the exact vector-ALU kernels (no matrix-core pre-filter)."""
+        check(lib.pgv_ctx_set_exact_scan(self.h, 1 if on else 0))
+
     def reset_stats(self):
         check(lib.pgv_ctx_reset_stats(self.h))
 
@@ -121,7 +125,7 @@ class Context:
                 "scan_pairs": s.scan_pairs, "scan_rows": s.scan_rows,
                 "aux_ms": s.aux_ms, "aux_launches": s.aux_launches, "aux_pairs": s.aux_pairs,
                 "assign_redo_rows": s.assign_redo_rows, "assign_rows": s.assign_rows,
-                "assign_recheck_rows": s.assign_recheck_rows, "scan_unique_rows": s.scan_unique_rows}
+                "assign_recheck_rows": s.assign_recheck_rows, "scan_unique_rows": s.scan_unique_rows, "scan_redo_queries": s.scan_redo_queries}
 
 
 class IvfIndex:

@@ -547,6 +547,156 @@ int launch_mfma_mode(pgv_ctx *ctx, int mode, const RowGeom &g, const void *rows,
     return PGV_OK;
 }
 
+// =====================================================================================
+// The batched list scan on the matrix cores.
+//
+// tile_scan_kernel scores a row against 16 queries with sub + fma per element on the vector ALUs
+// and is bound by their issue rate, not by HBM.  A task here is <= 128 rows of
+// one list x <= 32 queries probing it: queries are the MFMA M dimension, rows the N dimension,
+// both K-streamed through LDS in 128-byte slices by the same DMA + swizzle as above, one 32x32
+// tile (32 queries x 32 rows) per wavefront.  A lane ends up with 16 queries' values for ONE row,
+// and the 32 lanes of a half-wave hold 32 consecutive rows of one query: 128-byte stores into
+// the queries' output segments.
+//   METRIC 1 (negative inner product): the value is the reference's arithmetic.
+//   METRIC 0 (L2): |q|^2 + |x|^2 - 2 q.x with precomputed norms -- an APPROXIMATION of
+//   sum((q-x)^2) (cancellation), used only to pick candidates; pgv_abi.hip's scan_batch_dev
+//   re-evaluates the exact form for the k' best and checks that nothing outside them can matter.
+constexpr int kScanQueries = 32;   // queries per task
+
+constexpr int kScanWaves = 4;      // one 32 x 32 tile each: a task is 128 rows
+
+template <typename T, int METRIC, int NW>
+__global__ __launch_bounds__(NW * 64) void mfma_scan_kernel(
+    const char *__restrict__ rows, const char *__restrict__ queries, const ScanTask *__restrict__ tasks,
+    const int *__restrict__ ntasks_ptr, int *__restrict__ task_counter, const ScanPair *__restrict__ pairs,
+    const float *__restrict__ row_norms, const float *__restrict__ query_norms, int nvec,
+    const char *__restrict__ zeros16, float *__restrict__ out) {
+    constexpr int ROWS = 32 * NW;
+    constexpr int NGROUPS = (kScanQueries + ROWS) / 8;          // DMA instructions per stage (8 rows each)
+    constexpr int NDMA = (NGROUPS + NW - 1) / NW;               // ... per wavefront, at most
+    constexpr int STAGE = (kScanQueries + ROWS) * kSliceBytes;  // 20 KB (NW 4) / 36 KB (NW 8)
+    __shared__ __attribute__((aligned(16))) char smem[2 * STAGE];
+    __shared__ int64_t pair_rel[kScanQueries];
+    __shared__ float pair_qn[kScanQueries];
+    __shared__ int lds_task;
+
+    const int lane = threadIdx.x & (kWave - 1);
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int l31 = lane & 31, half = lane >> 5;
+    const unsigned sw = (unsigned)(l31 >> 1) & 7u;
+    const size_t row_bytes = (size_t)nvec * sizeof(Raw16);
+    const int nslices = (nvec + 7) / 8;
+    const int ntasks = *ntasks_ptr;
+    const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) char *)smem;
+    // DMA: groups of 8 rows of [32 query rows | ROWS list rows]; wavefront w issues groups w, w + NW, ...;
+    // a lane brings slot (lane & 7) of row (lane >> 3) of its group
+    const int drow = lane >> 3, dpos = lane & 7;
+
+    for (;;) {
+        if (threadIdx.x == 0) lds_task = atomicAdd(task_counter, 1);
+        __syncthreads();
+        const int t = lds_task;
+        if (t >= ntasks) return;
+        const ScanTask task = tasks[t];
+        const int np = task.npairs;
+        if ((int)threadIdx.x < kScanQueries) {
+            // slots past the task's last query repeat that query
+            const ScanPair pr = pairs[task.pair0 + ((int)threadIdx.x < np ? (int)threadIdx.x : np - 1)];
+            pair_rel[threadIdx.x] = pr.out_rel + task.row0;
+            pair_qn[threadIdx.x] = METRIC == 0 ? query_norms[pr.query] : 0.f;
+        }
+        const char *src[NDMA];
+#pragma unroll
+        for (int j = 0; j < NDMA; j++) {
+            const int crow = (wave + NW * j) * 8 + drow;  // row of the concatenation
+            if (crow < kScanQueries) {
+                const ScanPair pr = pairs[task.pair0 + (crow < np ? crow : np - 1)];
+                src[j] = queries + (size_t)pr.query * row_bytes;
+            } else {
+                const int r = crow - kScanQueries;
+                src[j] = rows + ((size_t)task.row0 + (size_t)(r < task.nrows ? r : task.nrows - 1)) * row_bytes;
+            }
+        }
+        auto issue_stage = [&](int sl, int buf) {
+#pragma unroll
+            for (int j = 0; j < NDMA; j++) {
+                const int g8 = wave + NW * j;  // group of 8 rows
+                if (NGROUPS % NW != 0 && g8 >= NGROUPS) break;  // (uniform per wavefront)
+                const int v = dpos ^ ((4 * (g8 & 1) + (drow >> 1)) & 7);  // slot p of row i holds vector p ^ ((i >> 1) & 7)
+                const int vi = sl * 8 + v;
+                const char *p = vi < nvec ? src[j] + (size_t)vi * sizeof(Raw16) : zeros16;
+                char *dst = smem + (size_t)buf * STAGE + (size_t)g8 * 8 * kSliceBytes;
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)p,
+                                                 (__attribute__((address_space(3))) void *)dst, 16, 0, 0);
+            }
+        };
+        f32x16 acc;
+#pragma unroll
+        for (int r = 0; r < 16; r++) acc[r] = 0.f;
+        const unsigned a_lane = (unsigned)l31 * kSliceBytes;                                   // query l31
+        const unsigned b_lane = (unsigned)(kScanQueries + wave * 32 + l31) * kSliceBytes;      // row wave * 32 + l31
+
+        issue_stage(0, 0);
+        for (int sl = 0; sl < nslices; sl++) {
+            // the slice has landed (a bare s_barrier: __syncthreads() does not reliably drain an LDS-DMA)
+            __builtin_amdgcn_s_waitcnt(0x0070);  // vmcnt(0) lgkmcnt(0)
+            __builtin_amdgcn_s_barrier();
+            if (sl + 1 < nslices) issue_stage(sl + 1, (sl + 1) & 1);
+            const unsigned sbase = lds0 + (unsigned)(sl & 1) * STAGE;
+#pragma unroll
+            for (int c = 0; c < 4; c++) {
+                const unsigned x = (((unsigned)(2 * c + half)) ^ sw) << 4;
+                u32x4 a, b;
+                asm volatile("ds_read_b128 %0, %2\n\tds_read_b128 %1, %3\n\ts_waitcnt lgkmcnt(0)"
+                             : "=&v"(a), "=&v"(b)
+                             : "v"(sbase + a_lane + x), "v"(sbase + b_lane + x)
+                             : "memory");
+                Mma<T>::run(acc, a, b);
+            }
+        }
+        // lane: row j = wave * 32 + l31 of the task; register r: query (r & 3) + 8 (r >> 2) + 4 half.
+        // Slots past the task's last query hold copies of that query (same operands, same value, same
+        // address): they are stored too, so that the 16 stores are one straight run -- a branch per store
+        // makes hipcc wait for the previous store each time
+        int64_t rel[16];
+        float qn[16];
+#pragma unroll
+        for (int r = 0; r < 16; r++) {
+            const int qi = (r & 3) + 8 * (r >> 2) + 4 * half;
+            rel[r] = pair_rel[qi];
+            qn[r] = pair_qn[qi];
+        }
+        const int j = wave * 32 + l31;
+        if (j < task.nrows) {
+            const float rn = METRIC == 0 ? row_norms[task.row0 + j] : 0.f;
+#pragma unroll
+            for (int r = 0; r < 16; r++) out[rel[r] + j] = METRIC == 0 ? fmaf(-2.f, acc[r], rn + qn[r]) : -acc[r];
+        }
+        __builtin_amdgcn_s_waitcnt(0xc07f);  // lgkmcnt(0): the pair table has been read ...
+        __builtin_amdgcn_s_barrier();        // ... by everyone; it and the LDS slices are free again
+    }
+}
+
+// |row|^2 in fp32, one wavefront per row (the L2 scan's norms; also the queries' of a batch)
+template <typename T>
+__global__ __launch_bounds__(256) void row_norms_kernel(const char *__restrict__ rows, int64_t n, int nvec,
+                                                        float *__restrict__ out, unsigned *__restrict__ max_bits) {
+    const int64_t r = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (r >= n) return;
+    const int lane = threadIdx.x & (kWave - 1);
+    const char *row = rows + (size_t)r * nvec * sizeof(Raw16);
+    float acc = 0.f;
+    for (int v = lane; v < nvec; v += kWave) {
+        const Raw16 x = load16(row + (size_t)v * sizeof(Raw16));
+        acc = accum_slice<T, 1>(acc, x, x);
+    }
+    for (int m = 32; m > 0; m >>= 1) acc += __shfl_xor(acc, m);
+    if (lane == 0) {
+        out[r] = acc;
+        if (max_bits) atomicMax(max_bits, __float_as_uint(acc));
+    }
+}
+
 }  // namespace
 
 // the matrix-core path pays from a few dozen centers on (a tile is 128 / 256 centers wide)
@@ -561,6 +711,61 @@ int launch_argmin_mfma(pgv_ctx *ctx, int mode, pgv_dtype dtype, const RowGeom &g
     }
     if (dtype == PGV_F32) return launch_mfma_mode<float>(ctx, mode, g, rows, n, centers, k, out_idx, out_val);
     return launch_mfma_mode<__half>(ctx, mode, g, rows, n, centers, k, out_idx, out_val);
+}
+
+}  // namespace pgv
+
+namespace pgv {
+
+int mfma_scan_rows_per_task() { return 32 * kScanWaves; }
+int mfma_scan_queries_per_task() { return kScanQueries; }
+
+int launch_row_norms(pgv_ctx *ctx, pgv_dtype dtype, const RowGeom &g, const void *rows, int64_t n, float *out,
+                     unsigned *max_bits) {
+    if (n <= 0) return PGV_OK;
+    const dim3 grid((unsigned)((n + 3) / 4));
+    if (dtype == PGV_F32)
+        hipLaunchKernelGGL(row_norms_kernel<float>, grid, dim3(256), 0, ctx->stream, static_cast<const char *>(rows), n,
+                           g.nvec, out, max_bits);
+    else
+        hipLaunchKernelGGL(row_norms_kernel<__half>, grid, dim3(256), 0, ctx->stream, static_cast<const char *>(rows), n,
+                           g.nvec, out, max_bits);
+    PGV_HIP(hipGetLastError());
+    return PGV_OK;
+}
+
+int launch_mfma_scan(pgv_ctx *ctx, pgv_metric metric, pgv_dtype dtype, const RowGeom &g, const void *rows,
+                     const void *queries, const ScanTask *tasks, const int *ntasks_dev, int ntasks_bound,
+                     const ScanPair *pairs, const float *row_norms, const float *query_norms, float *out) {
+    if (ntasks_bound <= 0) return PGV_OK;
+    if (metric != PGV_L2SQ && metric != PGV_NEG_IP) PGV_FAIL(PGV_ERR_ARG, "mfma scan: L2 / inner product only");
+    if (!ctx->zeros.p) {
+        PGV_TRY(ctx->zeros.ensure(256));
+        PGV_HIP(hipMemsetAsync(ctx->zeros.p, 0, 256, ctx->stream));
+    }
+    PGV_TRY(ctx->counters.ensure(256));
+    int *counter = ctx->counters.as<int>();
+    PGV_HIP(hipMemsetAsync(counter, 0, sizeof(int), ctx->stream));
+    int grid = ctx->num_cus * 3;  // 41 KB of LDS per workgroup: three per CU
+    if (grid > ntasks_bound) grid = ntasks_bound;
+#define PGV_MSCAN(T, M)                                                                                              \
+    hipLaunchKernelGGL((mfma_scan_kernel<T, M, kScanWaves>), dim3(grid), dim3(kScanWaves * 64), 0, ctx->stream,       \
+                       static_cast<const char *>(rows), static_cast<const char *>(queries), tasks, ntasks_dev, counter, \
+                       pairs, row_norms, query_norms, g.nvec, static_cast<const char *>(ctx->zeros.p), out)
+    if (dtype == PGV_F32) {
+        if (metric == PGV_L2SQ)
+            PGV_MSCAN(float, 0);
+        else
+            PGV_MSCAN(float, 1);
+    } else {
+        if (metric == PGV_L2SQ)
+            PGV_MSCAN(__half, 0);
+        else
+            PGV_MSCAN(__half, 1);
+    }
+#undef PGV_MSCAN
+    PGV_HIP(hipGetLastError());
+    return PGV_OK;
 }
 
 }  // namespace pgv

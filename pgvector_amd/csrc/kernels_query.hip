@@ -230,6 +230,115 @@ __global__ void query_iota_kernel(int32_t *__restrict__ out, int n) {
     if (i < n) out[i] = i;
 }
 
+// ------------------------------------------------------------------- exact tail of the MFMA L2 scan
+// mfma_scan_kernel's L2 values are |q|^2 + |x|^2 - 2 q.x: they pick k' candidates per query, and this
+// kernel (one workgroup per query) re-evaluates those with the reference's arithmetic
+// (sum of (q - x)^2, src/vector.c:172-185), sorts them the way the tuplesort would (distance, then
+// position in the stream) and emits the first k.  A query is flagged for the full exact pass unless
+// the k'-th approximate value clears the k-th exact one by the rounding bound of the expansion, i.e.
+// unless no row outside the candidates can belong to the head.
+constexpr int kRecheckCap = 256;  // k' <= 256: rank_sort_entries' reach
+
+template <typename T>
+__global__ __launch_bounds__(kQThreads) void batch_recheck_kernel(
+    const char *__restrict__ vectors, const uint64_t *__restrict__ tids, int nvec, int lg,
+    const char *__restrict__ queries, int kprime, int k, const float *__restrict__ approx_val,
+    const int64_t *__restrict__ cand_pos, const int64_t *__restrict__ cand_slot,
+    const int64_t *__restrict__ seg_start, const float *__restrict__ query_norms,
+    const unsigned *__restrict__ row_norm_max, float gamma, int nq, float *__restrict__ out_dist,
+    int64_t *__restrict__ out_slot, uint64_t *__restrict__ out_tid, int32_t *__restrict__ flags) {
+    __shared__ float exact[kRecheckCap];
+    __shared__ __attribute__((aligned(16))) unsigned long long ent[kRecheckCap];
+    const int q = blockIdx.x;
+    const size_t row_bytes = (size_t)nvec * sizeof(Raw16);
+    const int64_t m = seg_start[q + 1] - seg_start[q];
+    const int cnt = (int)(m < kprime ? m : (int64_t)kprime);
+    const int64_t *slots = cand_slot + (size_t)q * kprime;
+    score_rows<T, 0, 0>([&](int64_t j) { return vectors + (size_t)slots[j] * row_bytes; }, 0, cnt,
+                        queries + (size_t)q * row_bytes, nvec, lg, exact);
+    __syncthreads();
+    if ((int)threadIdx.x < kRecheckCap)
+        ent[threadIdx.x] = (int)threadIdx.x < cnt
+                               ? ((unsigned long long)float_to_key(exact[threadIdx.x]) << 32) |
+                                     (unsigned)cand_pos[(size_t)q * kprime + threadIdx.x]
+                               : ~0ull;
+    __syncthreads();
+    // carry the candidate index through the sort: find it again by position afterwards would cost a
+    // search, so sort (key, position) and keep a parallel map position -> candidate in `exact`'s place
+    const unsigned long long mine = ent[threadIdx.x];
+    const int64_t my_slot = (int)threadIdx.x < cnt ? slots[threadIdx.x] : -1;
+    int rank = 0;
+    {
+        const ulonglong2 *e2 = reinterpret_cast<const ulonglong2 *>(ent);
+        const int n2 = (cnt + 1) / 2;
+#pragma unroll 8
+        for (int j = 0; j < n2; j++) {
+            const ulonglong2 o = e2[j];
+            rank += o.x < mine ? 1 : 0;
+            rank += o.y < mine ? 1 : 0;
+        }
+    }
+    const int kk = cnt < k ? cnt : k;
+    if ((int)threadIdx.x < cnt && rank < k) {
+        const size_t o = (size_t)q * k + rank;
+        out_dist[o] = key_to_float((unsigned)(mine >> 32));
+        if (out_slot) out_slot[o] = my_slot;
+        if (out_tid) out_tid[o] = tids ? tids[my_slot] : ~0ull;
+    }
+    if ((int)threadIdx.x >= kk && (int)threadIdx.x < k) {  // fewer tuples than the head asked for
+        const size_t o = (size_t)q * k + threadIdx.x;
+        out_dist[o] = INFINITY;
+        if (out_slot) out_slot[o] = -1;
+        if (out_tid) out_tid[o] = ~0ull;
+    }
+    if ((int)threadIdx.x < cnt && rank == kk - 1) {
+        int32_t flag = 0;
+        if (m > cnt) {
+            const float kth = key_to_float((unsigned)(mine >> 32));
+            const float qn = query_norms[q], rn = __uint_as_float(*row_norm_max);
+            const float eps = gamma * (qn + rn + 2.f * sqrtf(qn * rn));
+            const float edge = approx_val[(size_t)q * kprime + kprime - 1];  // every row outside is >= this (approx.)
+            flag = (edge - eps > kth) ? 0 : 1;                               // NaN / inf anywhere: flag
+        }
+        flags[q] = flag;
+        if (flag) flags[nq + 1 + atomicAdd(&flags[nq], 1)] = q;  // [nq] flags | count | list of flagged queries
+    }
+    if (cnt == 0 && threadIdx.x == 0) flags[q] = 0;
+}
+
+// the flagged queries' segments again, every row with the exact form (one pass of the old cost
+// for those queries only; unflagged workgroups leave at once)
+template <typename T>
+__global__ __launch_bounds__(kQThreads) void batch_redo_kernel(
+    const char *__restrict__ vectors, const int64_t *__restrict__ list_off, int nvec, int lg,
+    const char *__restrict__ queries, const int32_t *__restrict__ probe_lists,
+    const int64_t *__restrict__ probe_off, int probes, const int64_t *__restrict__ seg_start,
+    const int32_t *__restrict__ flags, int nq, float *__restrict__ seg_vals, int per) {
+    const int nflag = flags[nq];
+    const size_t row_bytes = (size_t)nvec * sizeof(Raw16);
+    for (int f = blockIdx.y; f < nflag; f += gridDim.y) {
+    const int q = flags[nq + 1 + f];
+    const int64_t base = seg_start[q], m = seg_start[q + 1] - base;
+    const int64_t *off = probe_off + (size_t)q * probes;
+    const int32_t *pl = probe_lists + (size_t)q * probes;
+    auto row_ptr = [&](int64_t j) {
+        int lo = 0, hi = probes - 1;
+        while (lo < hi) {
+            const int mid = (lo + hi + 1) >> 1;
+            if (off[mid] <= j)
+                lo = mid;
+            else
+                hi = mid - 1;
+        }
+        return vectors + (size_t)(list_off[pl[lo]] + (j - off[lo])) * row_bytes;
+    };
+    for (int64_t first = (int64_t)blockIdx.x * per; first < m; first += (int64_t)gridDim.x * per) {
+        const int64_t end = first + per < m ? first + per : m;
+        score_rows<T, 0, 0>(row_ptr, first, end, queries + (size_t)q * row_bytes, nvec, lg, seg_vals + base);
+    }
+    }
+}
+
 constexpr size_t kQueryLds = (size_t)kHeadCap * 8 + sizeof(SelShared);
 
 // rows per workgroup run and workgroups: one wavefront step per run (two rows per wavefront for
@@ -351,6 +460,47 @@ int launch_query_head(pgv_ctx *ctx, const pgv_index *ix, const float *seg, const
     float *h_dist = reinterpret_cast<float *>(base + (size_t)count * 16);
     hipLaunchKernelGGL(query_head_kernel, dim3(1), dim3(kQThreads), kQueryLds, ctx->stream, seg, ix->list_offsets,
                        ix->tids, probe_lists, nprobes, skip, count, kp, hdr, h_dist, h_slot, h_tid, seq);
+    PGV_HIP(hipGetLastError());
+    return PGV_OK;
+}
+
+int launch_batch_recheck(pgv_ctx *ctx, const pgv_index *ix, const void *q_dev, int nq, int kprime, int k,
+                         const float *approx_val, const int64_t *cand_pos, const int64_t *cand_slot,
+                         const int64_t *seg_start, const float *query_norms, float gamma, float *out_dist,
+                         int64_t *out_slot, uint64_t *out_tid, int32_t *flags) {
+    if (nq <= 0) return PGV_OK;
+    if (kprime > kRecheckCap || k > kprime) PGV_FAIL(PGV_ERR_ARG, "recheck: k' = %d outside k..%d", kprime, kRecheckCap);
+    const unsigned *nmax = reinterpret_cast<const unsigned *>(ix->row_norms + ix->nrows);
+#define PGV_RECHECK(T)                                                                                              \
+    hipLaunchKernelGGL(batch_recheck_kernel<T>, dim3(nq), dim3(kQThreads), 0, ctx->stream,                           \
+                       static_cast<const char *>(ix->vectors), ix->tids, ix->geom.nvec, ix->geom.lpr_log2,           \
+                       static_cast<const char *>(q_dev), kprime, k, approx_val, cand_pos, cand_slot, seg_start,      \
+                       query_norms, nmax, gamma, nq, out_dist, out_slot, out_tid, flags)
+    if (ix->dtype == PGV_F32)
+        PGV_RECHECK(float);
+    else
+        PGV_RECHECK(__half);
+#undef PGV_RECHECK
+    PGV_HIP(hipGetLastError());
+    return PGV_OK;
+}
+
+int launch_batch_redo(pgv_ctx *ctx, const pgv_index *ix, const void *q_dev, int nq, const int32_t *probe_lists,
+                      const int64_t *probe_off, int probes, const int64_t *seg_start, const int32_t *flags,
+                      float *seg_vals) {
+    if (nq <= 0) return PGV_OK;
+    const int per = kQWaves * (kWave >> ix->geom.lpr_log2);
+    const dim3 grid(16, (unsigned)(nq < 64 ? nq : 64));
+#define PGV_REDO(T)                                                                                                  \
+    hipLaunchKernelGGL(batch_redo_kernel<T>, grid, dim3(kQThreads), 0, ctx->stream,                                  \
+                       static_cast<const char *>(ix->vectors), ix->list_offsets, ix->geom.nvec, ix->geom.lpr_log2,   \
+                       static_cast<const char *>(q_dev), probe_lists, probe_off, probes, seg_start, flags, nq,       \
+                       seg_vals, per)
+    if (ix->dtype == PGV_F32)
+        PGV_REDO(float);
+    else
+        PGV_REDO(__half);
+#undef PGV_REDO
     PGV_HIP(hipGetLastError());
     return PGV_OK;
 }

@@ -440,7 +440,7 @@ void pgv_ctx_destroy(pgv_ctx *ctx) {
                  &ctx->plan_a, &ctx->plan_b, &ctx->plan_c, &ctx->plan_d, &ctx->dist_mat,
                  &ctx->sel_a, &ctx->sel_b, &ctx->km_a, &ctx->km_b, &ctx->km_c, &ctx->km_d,
                  &ctx->km_e, &ctx->km_f, &ctx->km_g, &ctx->stats_dev, &ctx->mf_a, &ctx->mf_b, &ctx->mf_c,
-                 &ctx->zeros};
+                 &ctx->zeros, &ctx->ms_a};
     for (DBuf *b : d) b->release();
     ctx->h_a.release();
     ctx->h_b.release();
@@ -480,9 +480,15 @@ int pgv_ctx_set_profiling(pgv_ctx *ctx, int on) {
     PGV_TRY(resolve_events(ctx));
     ctx->profiling = on != 0;
     if (ctx->profiling && !ctx->stats_dev.p) {
-        PGV_TRY(ctx->stats_dev.ensure(6 * sizeof(double)));
-        PGV_HIP(hipMemsetAsync(ctx->stats_dev.p, 0, 6 * sizeof(double), ctx->stream));
+        PGV_TRY(ctx->stats_dev.ensure(8 * sizeof(double)));
+        PGV_HIP(hipMemsetAsync(ctx->stats_dev.p, 0, 8 * sizeof(double), ctx->stream));
     }
+    return PGV_OK;
+}
+
+int pgv_ctx_set_exact_scan(pgv_ctx *ctx, int on) {
+    if (!ctx) PGV_FAIL(PGV_ERR_ARG, "pgv_ctx_set_exact_scan: ctx is NULL");
+    ctx->no_mfma_scan = on != 0;
     return PGV_OK;
 }
 
@@ -493,7 +499,7 @@ int pgv_ctx_reset_stats(pgv_ctx *ctx) {
     ctx->scan_launches = 0;
     ctx->scan_pairs = 0;
     ctx->scan_rows = 0;
-    if (ctx->stats_dev.p) PGV_HIP(hipMemsetAsync(ctx->stats_dev.p, 0, 6 * sizeof(double), ctx->stream));
+    if (ctx->stats_dev.p) PGV_HIP(hipMemsetAsync(ctx->stats_dev.p, 0, 8 * sizeof(double), ctx->stream));
     ctx->aux_ms = 0;
     ctx->aux_launches = 0;
     ctx->aux_pairs = 0;
@@ -503,7 +509,7 @@ int pgv_ctx_reset_stats(pgv_ctx *ctx) {
 int pgv_ctx_get_stats(pgv_ctx *ctx, pgv_stats *out) {
     if (!ctx || !out) PGV_FAIL(PGV_ERR_ARG, "ctx/out is NULL");
     PGV_TRY(resolve_events(ctx));
-    double dev_acc[6] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
+    double dev_acc[8] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
     if (ctx->stats_dev.p) {
         PGV_HIP(hipMemcpyAsync(dev_acc, ctx->stats_dev.p, sizeof(dev_acc), hipMemcpyDeviceToHost, ctx->stream));
         PGV_HIP(hipStreamSynchronize(ctx->stream));
@@ -519,6 +525,7 @@ int pgv_ctx_get_stats(pgv_ctx *ctx, pgv_stats *out) {
     out->assign_rows = dev_acc[3];
     out->assign_recheck_rows = dev_acc[4];
     out->scan_unique_rows = dev_acc[5];
+    out->scan_redo_queries = dev_acc[6];
     return PGV_OK;
 }
 
@@ -608,6 +615,16 @@ int pgv_index_upload(pgv_ctx *ctx, pgv_metric metric, pgv_dtype dtype, int dim, 
                            ctx->stream) != hipSuccess)
             return fail((set_error("copy of tids failed"), PGV_ERR_DEVICE));
     }
+    if (metric == PGV_L2SQ && n > 0) {
+        // |x|^2 per row and the largest of them: the MFMA scan's expansion of the L2 distance
+        if (hipMalloc((void **)&ix->row_norms, sizeof(float) * ((size_t)n + 1)) != hipSuccess)
+            return fail((set_error("hipMalloc(row_norms) failed"), PGV_ERR_NOMEM));
+        if (hipMemsetAsync(ix->row_norms + n, 0, sizeof(float), ctx->stream) != hipSuccess)
+            return fail((set_error("memset of row_norms failed"), PGV_ERR_DEVICE));
+        if ((rc = launch_row_norms(ctx, dtype, ix->geom, ix->vectors, n, ix->row_norms,
+                                   reinterpret_cast<unsigned *>(ix->row_norms + n))) != PGV_OK)
+            return fail(rc);
+    }
     if (hipStreamSynchronize(ctx->stream) != hipSuccess)
         return fail((set_error("index upload failed: %s", hipGetErrorString(hipGetLastError())), PGV_ERR_DEVICE));
     *out = ix;
@@ -621,6 +638,7 @@ void pgv_index_free(pgv_index *ix) {
     if (ix->vectors) (void)hipFree(ix->vectors);
     if (ix->list_offsets) (void)hipFree(ix->list_offsets);
     if (ix->tids) (void)hipFree(ix->tids);
+    if (ix->row_norms) (void)hipFree(ix->row_norms);
     delete ix;
 }
 
@@ -769,14 +787,42 @@ static int scan_batch_dev(pgv_index *ix, const void *q_dev, int nq, const int32_
     // worth.  Lists probed by more than 8 queries go to the tile kernel (16 queries per pass
     // over the rows) when the row shape allows it.
     const double share = (double)nq * probes / (double)ix->nlists;
-    const bool use_tile = tile_scan_supported(ix->geom) && share > 8.0;
-    const int qt = use_tile ? tile_scan_queries_per_task()
-                            : scan_group_size(ix->geom, ix->dtype, (int)std::ceil(share));
+    // ... and to the matrix cores (32 queries per pass) for L2 / inner product heads of up to 64
+    const bool use_mfma = share > 8.0 && k <= 64 && !ctx->no_mfma_scan &&
+                          (ix->metric == PGV_NEG_IP || (ix->metric == PGV_L2SQ && ix->row_norms));
+    const bool use_tile = !use_mfma && tile_scan_supported(ix->geom) && share > 8.0;
+    const int qt = use_mfma ? mfma_scan_queries_per_task()
+                            : (use_tile ? tile_scan_queries_per_task()
+                                        : scan_group_size(ix->geom, ix->dtype, (int)std::ceil(share)));
     constexpr int rpt_tiles = 20;  // tiles per task (measured best of 10 / 20 / 40 / 80 on the headline batch)
-    const int rows_per_task = use_tile ? rpt_tiles * tile_scan_tile_rows(ix->geom)
-                                       : (qt >= 16 ? 256 : (qt >= 4 ? 128 : 64));
+    const int rows_per_task = use_mfma ? mfma_scan_rows_per_task()
+                                       : (use_tile ? rpt_tiles * tile_scan_tile_rows(ix->geom)
+                                                   : (qt >= 16 ? 256 : (qt >= 4 ? 128 : 64)));
     PlanResult plan;
     PGV_TRY(launch_plan_batch(ctx, ix, probe_lists, nq, probes, qt, rows_per_task, ctx->profiling, &plan));
+
+    // MFMA L2: scratch for the candidates' exact tail
+    const bool approx = use_mfma && ix->metric == PGV_L2SQ;
+    int kprime = k;
+    float *qnorm = nullptr, *cand_val = nullptr;
+    int64_t *cand_pos = nullptr, *cand_slot = nullptr;
+    int32_t *flags = nullptr;
+    if (approx) {
+        kprime = k <= 16 ? 64 : 4 * k;  // <= 256
+        const size_t nk = (size_t)nq * kprime;
+        const size_t a0 = 0, a1 = a0 + ((sizeof(float) * (size_t)nq + 15) & ~(size_t)15),
+                     a2 = a1 + ((sizeof(float) * nk + 15) & ~(size_t)15), a3 = a2 + sizeof(int64_t) * nk,
+                     a4 = a3 + sizeof(int64_t) * nk, a5 = a4 + sizeof(int32_t) * (2 * (size_t)nq + 1);
+        PGV_TRY(ctx->ms_a.ensure(a5));
+        char *b = ctx->ms_a.as<char>();
+        qnorm = reinterpret_cast<float *>(b + a0);
+        cand_val = reinterpret_cast<float *>(b + a1);
+        cand_pos = reinterpret_cast<int64_t *>(b + a2);
+        cand_slot = reinterpret_cast<int64_t *>(b + a3);
+        flags = reinterpret_cast<int32_t *>(b + a4);
+        PGV_HIP(hipMemsetAsync(flags + nq, 0, sizeof(int32_t), ctx->stream));
+        PGV_TRY(launch_row_norms(ctx, ix->dtype, ix->geom, q_dev, nq, qnorm, nullptr));
+    }
 
     // GetScanItems: one streaming pass
     PGV_TRY(ctx->plan_d.ensure(sizeof(float) * (size_t)(plan.out_bound > 0 ? plan.out_bound : 1)));
@@ -784,7 +830,11 @@ static int scan_batch_dev(pgv_index *ix, const void *q_dev, int nq, const int32_
     if (plan.ntasks_bound > 0) {
         ScanTimer timer{ctx};
         PGV_TRY(timer.begin(0.0, 0.0));  // pairs / rows of this launch are accumulated on the device
-        if (use_tile)
+        if (use_mfma)
+            PGV_TRY(launch_mfma_scan(ctx, ix->metric, ix->dtype, ix->geom, ix->vectors, q_dev, plan.tasks,
+                                     plan.ntasks_dev, (int)plan.ntasks_bound, plan.pairs, ix->row_norms, qnorm,
+                                     seg_vals));
+        else if (use_tile)
             PGV_TRY(launch_tile_scan(ctx, ix->metric, ix->dtype, ix->geom, ix->vectors, q_dev, plan.tasks,
                                      plan.ntasks_dev, (int)plan.ntasks_bound, plan.pairs, seg_vals));
         else
@@ -800,9 +850,26 @@ static int scan_batch_dev(pgv_index *ix, const void *q_dev, int nq, const int32_
     PGV_TRY(ot.init(out_tid, sizeof(uint64_t) * (size_t)nq * k, ctx->sel_b));
     PGV_TRY(ctx->sel_a.ensure(sizeof(int64_t) * (size_t)nq * k));
     int64_t *pos = ctx->sel_a.as<int64_t>();
-    PGV_TRY(launch_topk_segments(ctx, seg_vals, plan.seg_start, nq, 0, k, od.as<float>(), pos));
-    PGV_TRY(launch_positions_to_slots(ctx, ix, probe_lists, plan.probe_off, nq, probes, k, pos,
-                                      os.as<int64_t>(), ot.as<uint64_t>()));
+    if (approx) {
+        // k' candidates by the expansion, their exact distances, the head; queries whose candidate
+        // set cannot be proven complete (flags) take the exact pass over their whole segment
+        const float gamma = 8.f * std::sqrt((float)ix->dim + 4.f) * 5.9604645e-8f;
+        PGV_TRY(launch_topk_segments(ctx, seg_vals, plan.seg_start, nq, 0, kprime, cand_val, cand_pos));
+        PGV_TRY(launch_positions_to_slots(ctx, ix, probe_lists, plan.probe_off, nq, probes, kprime, cand_pos,
+                                          cand_slot, nullptr));
+        PGV_TRY(launch_batch_recheck(ctx, ix, q_dev, nq, kprime, k, cand_val, cand_pos, cand_slot, plan.seg_start,
+                                     qnorm, gamma, od.as<float>(), os.as<int64_t>(), ot.as<uint64_t>(), flags));
+        PGV_TRY(launch_batch_redo(ctx, ix, q_dev, nq, probe_lists, plan.probe_off, probes, plan.seg_start, flags,
+                                  seg_vals));
+        PGV_TRY(launch_topk_segments(ctx, seg_vals, plan.seg_start, nq, 0, k, od.as<float>(), pos, flags));
+        PGV_TRY(launch_positions_to_slots(ctx, ix, probe_lists, plan.probe_off, nq, probes, k, pos,
+                                          os.as<int64_t>(), ot.as<uint64_t>(), flags));
+        if (ctx->profiling && ctx->stats_dev.p) PGV_TRY(launch_count_flags(ctx, flags + nq, nq));
+    } else {
+        PGV_TRY(launch_topk_segments(ctx, seg_vals, plan.seg_start, nq, 0, k, od.as<float>(), pos));
+        PGV_TRY(launch_positions_to_slots(ctx, ix, probe_lists, plan.probe_off, nq, probes, k, pos,
+                                          os.as<int64_t>(), ot.as<uint64_t>()));
+    }
     bool need = false;
     PGV_TRY(od.finish(ctx, &need));
     PGV_TRY(os.finish(ctx, &need));

@@ -106,6 +106,7 @@ struct pgv_ctx {
     pgv::DBuf q_stage, rows_stage, centers_stage, out_stage, out_stage2, idx_stage;
     pgv::DBuf tasks, pairs, counters, plan_a, plan_b, plan_c, plan_d, dist_mat, sel_a, sel_b;
     pgv::DBuf km_a, km_b, km_c, km_d, km_e, km_f, km_g;
+    pgv::DBuf ms_a;  // MFMA list scan: query norms | candidate values, positions, slots | flags
     pgv::DBuf mf_a, mf_b, mf_c, zeros;  // MFMA assignment: norms, pre-filter candidates, redo list; 16 zero bytes
     pgv::DBuf stats_dev;  // profiling: {pairs, rows streamed} of the batched list scans, as doubles
     // scratch (pinned host); h_a_busy marks the last async copy out of h_a (waited before reuse)
@@ -115,6 +116,7 @@ struct pgv_ctx {
     // per-kernel profiling (pgv_ctx_set_profiling): HIP event pairs around the
     // streaming kernel, resolved lazily in pgv_ctx_get_stats
     bool profiling = false;
+    bool no_mfma_scan = false;  // pgv_ctx_set_exact_scan
     std::vector<hipEvent_t> ev_pool;  // start/stop pairs
     size_t ev_used = 0;
     double scan_ms = 0.0;
@@ -139,6 +141,7 @@ struct pgv_index {
     void *vectors = nullptr;          // [nrows x ld]
     int64_t *list_offsets = nullptr;  // device [nlists + 1]
     uint64_t *tids = nullptr;         // device [nrows] or null
+    float *row_norms = nullptr;       // device [nrows] |x|^2 then one word: bits of the largest (L2 indexes; the MFMA scan)
     std::vector<int64_t> h_offsets;   // host copy
     std::vector<int64_t> len_prefix;  // len_prefix[p] = rows in the p longest lists (output size bound)
     int64_t max_list_len = 0;
@@ -246,6 +249,15 @@ bool mfma_argmin_supported(int mode, int64_t n, int k);
 int launch_argmin_mfma(pgv_ctx *ctx, int mode, pgv_dtype dtype, const RowGeom &g, const void *rows, int64_t n,
                        const void *centers, int k, int32_t *out_idx, float *out_val);
 
+// kernels_mfma.hip: the batched list scan on the matrix cores (<= 128 rows x <= 32 queries per task)
+int mfma_scan_rows_per_task();
+int mfma_scan_queries_per_task();
+int launch_row_norms(pgv_ctx *ctx, pgv_dtype dtype, const RowGeom &g, const void *rows, int64_t n, float *out,
+                     unsigned *max_bits);
+int launch_mfma_scan(pgv_ctx *ctx, pgv_metric metric, pgv_dtype dtype, const RowGeom &g, const void *rows,
+                     const void *queries, const ScanTask *tasks, const int *ntasks_dev, int ntasks_bound,
+                     const ScanPair *pairs, const float *row_norms, const float *query_norms, float *out);
+
 // kernels_select.hip: planning + top-k selection
 struct PlanResult {
     ScanTask *tasks = nullptr;
@@ -260,11 +272,23 @@ struct PlanResult {
 };
 int launch_plan_batch(pgv_ctx *ctx, const pgv_index *ix, const int32_t *probe_lists, int nq,
                       int probes, int qt, int rows_per_task, bool read_totals, PlanResult *res);
+// `only` (device, per segment / query; may be null): nonzero = do this one, zero = leave its outputs alone
 int launch_topk_segments(pgv_ctx *ctx, const float *vals, const int64_t *seg_start, int nseg,
-                         int64_t fixed_len, int k, float *out_val, int64_t *out_pos);
+                         int64_t fixed_len, int k, float *out_val, int64_t *out_pos,
+                         const int32_t *only = nullptr);
 int launch_positions_to_slots(pgv_ctx *ctx, const pgv_index *ix, const int32_t *probe_lists,
                               const int64_t *probe_off, int nq, int probes, int k,
-                              const int64_t *pos, int64_t *out_slot, uint64_t *out_tid);
+                              const int64_t *pos, int64_t *out_slot, uint64_t *out_tid,
+                              const int32_t *only = nullptr);
+// kernels_query.hip: the exact tail of the MFMA L2 scan
+int launch_batch_recheck(pgv_ctx *ctx, const pgv_index *ix, const void *q_dev, int nq, int kprime, int k,
+                         const float *approx_val, const int64_t *cand_pos, const int64_t *cand_slot,
+                         const int64_t *seg_start, const float *query_norms, float gamma, float *out_dist,
+                         int64_t *out_slot, uint64_t *out_tid, int32_t *flags);
+int launch_batch_redo(pgv_ctx *ctx, const pgv_index *ix, const void *q_dev, int nq, const int32_t *probe_lists,
+                      const int64_t *probe_off, int probes, const int64_t *seg_start, const int32_t *flags,
+                      float *seg_vals);
+int launch_count_flags(pgv_ctx *ctx, const int32_t *count_dev, int nq);  // profiling: stats slot 6 += *count_dev
 int launch_iota_slots(pgv_ctx *ctx, const pgv_index *ix, const int32_t *lists_dev, int nlists,
                       const int64_t *probe_off, int64_t *out_slot);
 

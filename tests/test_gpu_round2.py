@@ -436,3 +436,121 @@ def test_comm_two_ranks_on_one_gpu():
                         os.path.join(root, "tests", "mp_comm_worker.py")],
                        cwd=root, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=600)
     assert r.returncode == 0 and "COMM-OK" in r.stdout, (r.returncode, r.stdout[-1000:], r.stderr[-3000:])
+
+
+# ------------------------------------------------- the batched list scan on the matrix cores
+def _batch_vs_oracle(ctx, oracle, ivf, queries, probes, k, what, expect_redo=None, gq=None):
+    ix = _upload(ctx, ivf)
+    gq = queries if gq is None else gq  # what GetScanValue hands on (normalised for cosine); the oracle takes the raw datum
+    ctx.set_profiling(True)
+    ctx.reset_stats()
+    dist, slot, tid = ix.search_batch(gq, probes, k, want_tid=True)
+    redo = ctx.stats()["scan_redo_queries"]
+    ctx.set_profiling(False)
+    ctx.set_exact_scan(True)
+    try:
+        edist, eslot, _ = ix.search_batch(gq, probes, k, want_tid=True)
+    finally:
+        ctx.set_exact_scan(False)
+    for i in range(len(queries)):
+        wt, wd = oracle.search(ivf.struct, queries[i], probes, k)
+        have = slot[i] >= 0
+        assert have.sum() == len(wt), (what, i, have.sum(), len(wt))
+        assert_topk_equiv(tid[i][have].tolist(), dist[i][:len(wt)], wt.tolist(), wd, what="%s q %d" % (what, i))
+        # and the same head as the exact kernels give, tie for tie apart from last-bit differences
+        assert_topk_equiv(slot[i][have].tolist(), dist[i][:len(wt)], eslot[i][eslot[i] >= 0].tolist(),
+                          edist[i][:len(wt)].astype(np.float64), what="%s vs exact q %d" % (what, i))
+    if expect_redo == "none":
+        assert redo == 0, redo
+    elif expect_redo == "all":
+        assert redo == len(queries), redo
+    ix.close()
+    return redo
+
+
+@pytest.mark.parametrize("ops,dtype,dim,n,lists,nq,probes,k,dist", [
+    (po.OPS_L2, po.ORA_F32, 1536, 3000, 12, 150, 4, 10, "clustered"),   # headline row shape; ragged query groups (150 = 4 x 32 + 22)
+    (po.OPS_L2, po.ORA_F32, 100, 6000, 8, 90, 3, 10, "uniform"),        # partial last slice, near ties
+    (po.OPS_L2, po.ORA_F32, 3, 4000, 5, 80, 2, 64, "normal"),           # one vector per row; k = 64 -> k' = 256
+    (po.OPS_L2, po.ORA_F16, 3072, 2400, 10, 70, 5, 10, "clustered"),    # configs[4] row shape
+    (po.OPS_L2, po.ORA_F16, 72, 5000, 6, 64, 6, 40, "normal"),
+    (po.OPS_IP, po.ORA_F32, 1536, 2400, 10, 70, 5, 10, "clustered"),    # configs[2]: the MFMA value is the result
+    (po.OPS_IP, po.ORA_F16, 1024, 2400, 10, 100, 4, 10, "clustered"),
+    (po.OPS_COSINE, po.ORA_F32, 200, 4000, 10, 90, 3, 10, "clustered"),
+])
+def test_batched_scan_on_the_matrix_cores(ctx, oracle, ops, dtype, dim, n, lists, nq, probes, k, dist):
+    """search_batch with >8 queries per list goes through mfma_scan_kernel (+ the exact tail for L2): the head
+    must be GetScanItems + tuplesort's (src/ivfscan.c:124-187) and the exact kernels' head"""
+    data = gen(n, dim, seed=401, dist=dist, clusters=lists, dtype=dtype)
+    ivf = CpuIvf(oracle, ops, dtype, data, lists)
+    queries = gen(nq, dim, seed=402, dist=dist, clusters=lists, dtype=dtype)
+    gq = normalize_rows(oracle, queries, dtype) if ops == po.OPS_COSINE else None  # GetScanValue (src/ivfscan.c:222-229)
+    _batch_vs_oracle(ctx, oracle, ivf, queries, probes, k, "mfma scan ops %d dim %d" % (ops, dim), gq=gq)
+
+
+def test_batched_scan_mfma_ties_short_lists_and_specials(ctx, oracle):
+    """exact ties keep stream order (integer data: the expansion is exact, nothing is redone); lists shorter than
+    k'; an empty list; a NaN row and an inf row (flagged -> exact pass); a huge-norm row (the bound grows until
+    every query is redone) -- results never change"""
+    dim, lists = 8, 6
+    data = gen(900, dim, seed=411, dist="int")
+    data[100:140] = data[60]            # 40 equal rows
+    centers = gen(lists, dim, seed=412, dist="int")
+    centers[5] = 1000.0                 # nothing lands here: an empty list
+    ivf = CpuIvf(oracle, po.OPS_L2, po.ORA_F32, data, lists, centers=centers)
+    queries = gen(60, dim, seed=413, dist="int")
+    queries[7] = data[60]
+    _batch_vs_oracle(ctx, oracle, ivf, queries, lists, 10, "int ties", expect_redo="none")
+    _batch_vs_oracle(ctx, oracle, ivf, queries, lists, 64, "int ties k=64", expect_redo="none")
+    # fewer tuples than k (and than k'): a 30-row index
+    small = CpuIvf(oracle, po.OPS_L2, po.ORA_F32, data[:30], 2, centers=centers[:2])
+    _batch_vs_oracle(ctx, oracle, small, queries[:40], 2, 50, "short")
+    # specials
+    bad = gen(900, dim, seed=414, dist="normal")
+    bad[5, 0] = np.nan
+    bad[6, 1] = np.inf
+    ivf2 = CpuIvf(oracle, po.OPS_L2, po.ORA_F32, bad, 3, centers=gen(3, dim, seed=415, dist="normal"))
+    redo = _batch_vs_oracle(ctx, oracle, ivf2, gen(40, dim, seed=416, dist="normal"), 3, 10, "nan/inf rows")
+    assert redo == 40   # max |x|^2 is inf: no bound, every query takes the exact pass
+    big = gen(900, dim, seed=417, dist="normal")
+    big[11] *= 3e4
+    ivf3 = CpuIvf(oracle, po.OPS_L2, po.ORA_F32, big, 3, centers=gen(3, dim, seed=415, dist="normal"))
+    _batch_vs_oracle(ctx, oracle, ivf3, gen(40, dim, seed=418, dist="normal"), 3, 10, "huge norm", expect_redo="all")
+
+
+def test_batched_scan_mfma_at_scale_is_the_exact_scan(ctx):
+    """workgroups that follow one another on a CU (LDS reuse, many tasks per workgroup): 200k x 768 rows,
+    2000 queries -- slot for slot the exact kernels' answer, and (almost) nothing redone"""
+    import torch
+    dev = torch.device("cuda", 0)
+    g = torch.Generator(device=dev)
+    g.manual_seed(7)
+    n, dim, lists, nq, probes = 200_000, 768, 100, 2000, 5
+    means = torch.rand((50, dim), generator=g, device=dev)
+    data = means[torch.randint(0, 50, (n,), generator=g, device=dev)] + 0.1 * torch.randn((n, dim), generator=g, device=dev)
+    centers, _, _ = api.kmeans(ctx, api.PGV_OPS_L2, api.PGV_F32, dim, data[:20000].contiguous(), lists,
+                               api.make_rng(seed=3), want_closest=False)
+    assign, _ = api.assign(ctx, api.PGV_L2SQ, api.PGV_F32, dim, centers, data, want_dist=False)
+    order = torch.argsort(assign.long(), stable=True)
+    off = torch.zeros(lists + 1, dtype=torch.int64, device=dev)
+    off[1:] = torch.cumsum(torch.bincount(assign.long(), minlength=lists), 0)
+    ix = api.IvfIndex(ctx, api.PGV_L2SQ, api.PGV_F32, dim, centers, off, data[order].contiguous(), order)
+    queries = (means[torch.randint(0, 50, (nq,), generator=g, device=dev)] + 0.1 * torch.randn((nq, dim), generator=g, device=dev))
+    ctx.set_profiling(True)
+    ctx.reset_stats()
+    d, s, _ = ix.search_batch(queries, probes, 10, want_tid=True)
+    redo = ctx.stats()["scan_redo_queries"]
+    ctx.set_profiling(False)
+    ctx.set_exact_scan(True)
+    try:
+        ed, es, _ = ix.search_batch(queries, probes, 10, want_tid=True)
+    finally:
+        ctx.set_exact_scan(False)
+    d, s, ed, es = (np.asarray(x.cpu() if hasattr(x, "cpu") else x) for x in (d, s, ed, es))
+    diff = np.nonzero((s != es).any(axis=1))[0]
+    for i in diff:  # only a last-bit difference between two summation orders may swap neighbours
+        assert sorted(s[i].tolist()) == sorted(es[i].tolist()) or np.allclose(d[i], ed[i], rtol=1e-6), i
+    assert len(diff) <= nq // 100, len(diff)
+    np.testing.assert_allclose(d, ed, rtol=1e-5)
+    assert redo <= nq // 100, redo
+    ix.close()
