@@ -106,6 +106,26 @@ template <> struct Mma<__half> {
     }
 };
 
+// 16-wide forms: one A fragment against two B fragments (two independent accumulators hide the
+// 40-cycle dependent-issue latency of the 16x16 shapes)
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+template <typename T> struct Mma16;
+template <> struct Mma16<float> {
+    static __device__ __forceinline__ void run(f32x4 &c0, f32x4 &c1, const u32x4 &a, const u32x4 &b0, const u32x4 &b1) {
+#pragma unroll
+        for (int e = 0; e < 4; e++) {
+            c0 = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(a[e]), __uint_as_float(b0[e]), c0, 0, 0, 0);
+            c1 = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(a[e]), __uint_as_float(b1[e]), c1, 0, 0, 0);
+        }
+    }
+};
+template <> struct Mma16<__half> {
+    static __device__ __forceinline__ void run(f32x4 &c0, f32x4 &c1, const u32x4 &a, const u32x4 &b0, const u32x4 &b1) {
+        c0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b0), c0, 0, 0, 0);
+        c1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b1), c1, 0, 0, 0);
+    }
+};
+
 // sorted insertion into a lane's best-NC list; strict '<' keeps the earlier (lower) id first
 // among equal values -- ids arrive in ascending order within a lane.  NaN and +inf never enter
 // (not < DBL_MAX, src/ivfbuild.c:187).
@@ -617,11 +637,15 @@ __global__ __launch_bounds__(NW * 64) void mfma_scan_kernel(
                 src[j] = rows + ((size_t)task.row0 + (size_t)(r < task.nrows ? r : task.nrows - 1)) * row_bytes;
             }
         }
+        // tasks of <= 16 queries (most of them at ~10 queries per list) take the 16-wide MFMA shapes: half
+        // the matrix-core time and half the query bytes through the DMA
+        const bool narrow = np <= 16;
         auto issue_stage = [&](int sl, int buf) {
 #pragma unroll
             for (int j = 0; j < NDMA; j++) {
                 const int g8 = wave + NW * j;  // group of 8 rows
                 if (NGROUPS % NW != 0 && g8 >= NGROUPS) break;  // (uniform per wavefront)
+                if (narrow && (g8 == 2 || g8 == 3)) continue;    // query rows 16..31: not used
                 const int v = dpos ^ ((4 * (g8 & 1) + (drow >> 1)) & 7);  // slot p of row i holds vector p ^ ((i >> 1) & 7)
                 const int vi = sl * 8 + v;
                 const char *p = vi < nvec ? src[j] + (size_t)vi * sizeof(Raw16) : zeros16;
@@ -630,47 +654,94 @@ __global__ __launch_bounds__(NW * 64) void mfma_scan_kernel(
                                                  (__attribute__((address_space(3))) void *)dst, 16, 0, 0);
             }
         };
-        f32x16 acc;
+        // pair table to registers (after the loop: a store followed by an LDS read makes hipcc wait for the store)
+        const int j32 = wave * 32 + l31;
+        if (!narrow) {
+            f32x16 acc;
 #pragma unroll
-        for (int r = 0; r < 16; r++) acc[r] = 0.f;
-        const unsigned a_lane = (unsigned)l31 * kSliceBytes;                                   // query l31
-        const unsigned b_lane = (unsigned)(kScanQueries + wave * 32 + l31) * kSliceBytes;      // row wave * 32 + l31
-
-        issue_stage(0, 0);
-        for (int sl = 0; sl < nslices; sl++) {
-            // the slice has landed (a bare s_barrier: __syncthreads() does not reliably drain an LDS-DMA)
-            __builtin_amdgcn_s_waitcnt(0x0070);  // vmcnt(0) lgkmcnt(0)
-            __builtin_amdgcn_s_barrier();
-            if (sl + 1 < nslices) issue_stage(sl + 1, (sl + 1) & 1);
-            const unsigned sbase = lds0 + (unsigned)(sl & 1) * STAGE;
+            for (int r = 0; r < 16; r++) acc[r] = 0.f;
+            const unsigned a_lane = (unsigned)l31 * kSliceBytes;                                   // query l31
+            const unsigned b_lane = (unsigned)(kScanQueries + wave * 32 + l31) * kSliceBytes;      // row wave * 32 + l31
+            issue_stage(0, 0);
+            for (int sl = 0; sl < nslices; sl++) {
+                // the slice has landed (a bare s_barrier: __syncthreads() does not reliably drain an LDS-DMA)
+                __builtin_amdgcn_s_waitcnt(0x0070);  // vmcnt(0) lgkmcnt(0)
+                __builtin_amdgcn_s_barrier();
+                if (sl + 1 < nslices) issue_stage(sl + 1, (sl + 1) & 1);
+                const unsigned sbase = lds0 + (unsigned)(sl & 1) * STAGE;
 #pragma unroll
-            for (int c = 0; c < 4; c++) {
-                const unsigned x = (((unsigned)(2 * c + half)) ^ sw) << 4;
-                u32x4 a, b;
-                asm volatile("ds_read_b128 %0, %2\n\tds_read_b128 %1, %3\n\ts_waitcnt lgkmcnt(0)"
-                             : "=&v"(a), "=&v"(b)
-                             : "v"(sbase + a_lane + x), "v"(sbase + b_lane + x)
-                             : "memory");
-                Mma<T>::run(acc, a, b);
+                for (int c = 0; c < 4; c++) {
+                    const unsigned x = (((unsigned)(2 * c + half)) ^ sw) << 4;
+                    u32x4 a, b;
+                    asm volatile("ds_read_b128 %0, %2\n\tds_read_b128 %1, %3\n\ts_waitcnt lgkmcnt(0)"
+                                 : "=&v"(a), "=&v"(b)
+                                 : "v"(sbase + a_lane + x), "v"(sbase + b_lane + x)
+                                 : "memory");
+                    Mma<T>::run(acc, a, b);
+                }
             }
-        }
-        // lane: row j = wave * 32 + l31 of the task; register r: query (r & 3) + 8 (r >> 2) + 4 half.
-        // Slots past the task's last query hold copies of that query (same operands, same value, same
-        // address): they are stored too, so that the 16 stores are one straight run -- a branch per store
-        // makes hipcc wait for the previous store each time
-        int64_t rel[16];
-        float qn[16];
+            // lane: row j32 of the task; register r: query (r & 3) + 8 (r >> 2) + 4 half.  Slots past the
+            // task's last query hold copies of that query (same operands, same value, same address): they
+            // are stored too, so that the 16 stores are one straight run -- a branch per store makes hipcc
+            // wait for the previous store each time
+            int64_t rel[16];
+            float qn[16];
 #pragma unroll
-        for (int r = 0; r < 16; r++) {
-            const int qi = (r & 3) + 8 * (r >> 2) + 4 * half;
-            rel[r] = pair_rel[qi];
-            qn[r] = pair_qn[qi];
-        }
-        const int j = wave * 32 + l31;
-        if (j < task.nrows) {
-            const float rn = METRIC == 0 ? row_norms[task.row0 + j] : 0.f;
+            for (int r = 0; r < 16; r++) {
+                const int qi = (r & 3) + 8 * (r >> 2) + 4 * half;
+                rel[r] = pair_rel[qi];
+                qn[r] = pair_qn[qi];
+            }
+            if (j32 < task.nrows) {
+                const float rn = METRIC == 0 ? row_norms[task.row0 + j32] : 0.f;
 #pragma unroll
-            for (int r = 0; r < 16; r++) out[rel[r] + j] = METRIC == 0 ? fmaf(-2.f, acc[r], rn + qn[r]) : -acc[r];
+                for (int r = 0; r < 16; r++)
+                    out[rel[r] + j32] = METRIC == 0 ? fmaf(-2.f, acc[r], rn + qn[r]) : -acc[r];
+            }
+        } else {
+            // 16 x 16 tiles: lane = (row or query l15, k-group kg); two row halves per wavefront
+            const int l15 = lane & 15, kg = lane >> 4;
+            const unsigned sw15 = (unsigned)(l15 >> 1) & 7u;
+            f32x4 c0 = {0.f, 0.f, 0.f, 0.f}, c1 = {0.f, 0.f, 0.f, 0.f};
+            const unsigned a_lane = (unsigned)l15 * kSliceBytes;
+            const unsigned b_lane = (unsigned)(kScanQueries + wave * 32 + l15) * kSliceBytes;  // second half: + 16 rows
+            issue_stage(0, 0);
+            for (int sl = 0; sl < nslices; sl++) {
+                __builtin_amdgcn_s_waitcnt(0x0070);  // vmcnt(0) lgkmcnt(0)
+                __builtin_amdgcn_s_barrier();
+                if (sl + 1 < nslices) issue_stage(sl + 1, (sl + 1) & 1);
+                const unsigned sbase = lds0 + (unsigned)(sl & 1) * STAGE;
+#pragma unroll
+                for (int c = 0; c < 2; c++) {
+                    const unsigned x = (((unsigned)(kg + 4 * c)) ^ sw15) << 4;
+                    u32x4 a, b0, b1;
+                    asm volatile("ds_read_b128 %0, %3\n\tds_read_b128 %1, %4\n\tds_read_b128 %2, %4 offset:2048\n\t"
+                                 "s_waitcnt lgkmcnt(0)"
+                                 : "=&v"(a), "=&v"(b0), "=&v"(b1)
+                                 : "v"(sbase + a_lane + x), "v"(sbase + b_lane + x)
+                                 : "memory");
+                    Mma16<T>::run(c0, c1, a, b0, b1);
+                }
+            }
+            // lane: rows wave * 32 + l15 (c0) and + 16 (c1); register r: query 4 kg + r
+            int64_t rel[4];
+            float qn[4];
+#pragma unroll
+            for (int r = 0; r < 4; r++) {
+                rel[r] = pair_rel[4 * kg + r];
+                qn[r] = pair_qn[4 * kg + r];
+            }
+            const int ja = wave * 32 + l15, jb = ja + 16;
+            const float rna = (METRIC == 0 && ja < task.nrows) ? row_norms[task.row0 + ja] : 0.f;
+            const float rnb = (METRIC == 0 && jb < task.nrows) ? row_norms[task.row0 + jb] : 0.f;
+            if (ja < task.nrows) {
+#pragma unroll
+                for (int r = 0; r < 4; r++) out[rel[r] + ja] = METRIC == 0 ? fmaf(-2.f, c0[r], rna + qn[r]) : -c0[r];
+            }
+            if (jb < task.nrows) {
+#pragma unroll
+                for (int r = 0; r < 4; r++) out[rel[r] + jb] = METRIC == 0 ? fmaf(-2.f, c1[r], rnb + qn[r]) : -c1[r];
+            }
         }
         __builtin_amdgcn_s_waitcnt(0xc07f);  // lgkmcnt(0): the pair table has been read ...
         __builtin_amdgcn_s_barrier();        // ... by everyone; it and the LDS slices are free again
