@@ -244,14 +244,14 @@ __global__ __launch_bounds__(kQThreads) void batch_recheck_kernel(
     const char *__restrict__ vectors, const uint64_t *__restrict__ tids, int nvec, int lg,
     const char *__restrict__ queries, int kprime, int k, const float *__restrict__ approx_val,
     const int64_t *__restrict__ cand_pos, const int64_t *__restrict__ cand_slot,
-    const int64_t *__restrict__ seg_start, const float *__restrict__ query_norms,
+    const int64_t *__restrict__ seg_start, int64_t fixed_len, const float *__restrict__ query_norms,
     const unsigned *__restrict__ row_norm_max, float gamma, int nq, float *__restrict__ out_dist,
     int64_t *__restrict__ out_slot, uint64_t *__restrict__ out_tid, int32_t *__restrict__ flags) {
     __shared__ float exact[kRecheckCap];
     __shared__ __attribute__((aligned(16))) unsigned long long ent[kRecheckCap];
     const int q = blockIdx.x;
     const size_t row_bytes = (size_t)nvec * sizeof(Raw16);
-    const int64_t m = seg_start[q + 1] - seg_start[q];
+    const int64_t m = seg_start ? seg_start[q + 1] - seg_start[q] : fixed_len;  // rows the candidates were picked from
     const int cnt = (int)(m < kprime ? m : (int64_t)kprime);
     const int64_t *slots = cand_slot + (size_t)q * kprime;
     score_rows<T, 0, 0>([&](int64_t j) { return vectors + (size_t)slots[j] * row_bytes; }, 0, cnt,
@@ -312,16 +312,19 @@ template <typename T>
 __global__ __launch_bounds__(kQThreads) void batch_redo_kernel(
     const char *__restrict__ vectors, const int64_t *__restrict__ list_off, int nvec, int lg,
     const char *__restrict__ queries, const int32_t *__restrict__ probe_lists,
-    const int64_t *__restrict__ probe_off, int probes, const int64_t *__restrict__ seg_start,
+    const int64_t *__restrict__ probe_off, int probes, const int64_t *__restrict__ seg_start, int64_t fixed_len,
     const int32_t *__restrict__ flags, int nq, float *__restrict__ seg_vals, int per) {
     const int nflag = flags[nq];
     const size_t row_bytes = (size_t)nvec * sizeof(Raw16);
     for (int f = blockIdx.y; f < nflag; f += gridDim.y) {
     const int q = flags[nq + 1 + f];
-    const int64_t base = seg_start[q], m = seg_start[q + 1] - base;
+    // probe_lists == null: the rows are one dense run (the centers), every query's segment is all of them
+    const int64_t base = probe_lists ? seg_start[q] : (int64_t)q * fixed_len;
+    const int64_t m = probe_lists ? seg_start[q + 1] - base : fixed_len;
     const int64_t *off = probe_off + (size_t)q * probes;
     const int32_t *pl = probe_lists + (size_t)q * probes;
     auto row_ptr = [&](int64_t j) {
+        if (!probe_lists) return vectors + (size_t)j * row_bytes;
         int lo = 0, hi = probes - 1;
         while (lo < hi) {
             const int mid = (lo + hi + 1) >> 1;
@@ -464,19 +467,18 @@ int launch_query_head(pgv_ctx *ctx, const pgv_index *ix, const float *seg, const
     return PGV_OK;
 }
 
-int launch_batch_recheck(pgv_ctx *ctx, const pgv_index *ix, const void *q_dev, int nq, int kprime, int k,
+int launch_batch_recheck(pgv_ctx *ctx, const ExactRows &xr, const void *q_dev, int nq, int kprime, int k,
                          const float *approx_val, const int64_t *cand_pos, const int64_t *cand_slot,
-                         const int64_t *seg_start, const float *query_norms, float gamma, float *out_dist,
-                         int64_t *out_slot, uint64_t *out_tid, int32_t *flags) {
+                         const int64_t *seg_start, int64_t fixed_len, const float *query_norms, float gamma,
+                         float *out_dist, int64_t *out_slot, uint64_t *out_tid, int32_t *flags) {
     if (nq <= 0) return PGV_OK;
     if (kprime > kRecheckCap || k > kprime) PGV_FAIL(PGV_ERR_ARG, "recheck: k' = %d outside k..%d", kprime, kRecheckCap);
-    const unsigned *nmax = reinterpret_cast<const unsigned *>(ix->row_norms + ix->nrows);
 #define PGV_RECHECK(T)                                                                                              \
     hipLaunchKernelGGL(batch_recheck_kernel<T>, dim3(nq), dim3(kQThreads), 0, ctx->stream,                           \
-                       static_cast<const char *>(ix->vectors), ix->tids, ix->geom.nvec, ix->geom.lpr_log2,           \
+                       static_cast<const char *>(xr.vectors), xr.tids, xr.geom.nvec, xr.geom.lpr_log2,               \
                        static_cast<const char *>(q_dev), kprime, k, approx_val, cand_pos, cand_slot, seg_start,      \
-                       query_norms, nmax, gamma, nq, out_dist, out_slot, out_tid, flags)
-    if (ix->dtype == PGV_F32)
+                       fixed_len, query_norms, xr.norm_max, gamma, nq, out_dist, out_slot, out_tid, flags)
+    if (xr.dtype == PGV_F32)
         PGV_RECHECK(float);
     else
         PGV_RECHECK(__half);
@@ -485,18 +487,18 @@ int launch_batch_recheck(pgv_ctx *ctx, const pgv_index *ix, const void *q_dev, i
     return PGV_OK;
 }
 
-int launch_batch_redo(pgv_ctx *ctx, const pgv_index *ix, const void *q_dev, int nq, const int32_t *probe_lists,
-                      const int64_t *probe_off, int probes, const int64_t *seg_start, const int32_t *flags,
-                      float *seg_vals) {
+int launch_batch_redo(pgv_ctx *ctx, const ExactRows &xr, const void *q_dev, int nq, const int32_t *probe_lists,
+                      const int64_t *probe_off, int probes, const int64_t *seg_start, int64_t fixed_len,
+                      const int32_t *flags, float *seg_vals) {
     if (nq <= 0) return PGV_OK;
-    const int per = kQWaves * (kWave >> ix->geom.lpr_log2);
+    const int per = kQWaves * (kWave >> xr.geom.lpr_log2);
     const dim3 grid(16, (unsigned)(nq < 64 ? nq : 64));
 #define PGV_REDO(T)                                                                                                  \
     hipLaunchKernelGGL(batch_redo_kernel<T>, grid, dim3(kQThreads), 0, ctx->stream,                                  \
-                       static_cast<const char *>(ix->vectors), ix->list_offsets, ix->geom.nvec, ix->geom.lpr_log2,   \
-                       static_cast<const char *>(q_dev), probe_lists, probe_off, probes, seg_start, flags, nq,       \
-                       seg_vals, per)
-    if (ix->dtype == PGV_F32)
+                       static_cast<const char *>(xr.vectors), xr.list_offsets, xr.geom.nvec, xr.geom.lpr_log2,       \
+                       static_cast<const char *>(q_dev), probe_lists, probe_off, probes, seg_start, fixed_len, flags, \
+                       nq, seg_vals, per)
+    if (xr.dtype == PGV_F32)
         PGV_REDO(float);
     else
         PGV_REDO(__half);

@@ -280,14 +280,17 @@ int rows_per_task_for(pgv_ctx *ctx, int64_t total_rows, int64_t groups) {
 
 int dense_scan(pgv_ctx *ctx, pgv_metric metric, pgv_dtype dtype, const RowGeom &g,
                const void *rows_dev, int64_t nrows, const void *queries_dev, int nq,
-               int64_t out_stride, float *out_dev) {
+               int64_t out_stride, float *out_dev, bool mfma = false, const float *row_norms = nullptr,
+               const float *query_norms = nullptr) {
     if (nrows <= 0 || nq <= 0) return PGV_OK;
     // many queries against the same rows (center ranking of a batch): the tile kernel serves
-    // 16 queries per pass over the rows
-    const bool use_tile = nq > 8 && tile_scan_supported(g);
-    const int qt = use_tile ? tile_scan_queries_per_task() : scan_group_size(g, dtype, nq);
+    // 16 queries per pass over the rows, the MFMA kernel 32 (L2: the expansion with the norms given,
+    // an approximation the caller rechecks)
+    const bool use_tile = !mfma && nq > 8 && tile_scan_supported(g);
+    const int qt = mfma ? mfma_scan_queries_per_task()
+                        : (use_tile ? tile_scan_queries_per_task() : scan_group_size(g, dtype, nq));
     const int ngroups = (nq + qt - 1) / qt;
-    int ch = rows_per_task_for(ctx, nrows, ngroups);
+    int ch = mfma ? mfma_scan_rows_per_task() : rows_per_task_for(ctx, nrows, ngroups);
     if (use_tile) {
         // whole tiles, and long enough runs to amortise a task's prologue (query registers,
         // first tile) when the rows are few but the query groups many
@@ -332,7 +335,10 @@ int dense_scan(pgv_ctx *ctx, pgv_metric metric, pgv_dtype dtype, const RowGeom &
 
     ScanTimer timer{ctx};
     PGV_TRY(timer.begin((double)nrows * nq, (double)nrows * ngroups, true));
-    if (use_tile)
+    if (mfma)
+        PGV_TRY(launch_mfma_scan(ctx, metric, dtype, g, rows_dev, queries_dev, dt, dn, (int)ntasks, dp, row_norms,
+                                 query_norms, out_dev));
+    else if (use_tile)
         PGV_TRY(launch_tile_scan(ctx, metric, dtype, g, rows_dev, queries_dev, dt, dn, (int)ntasks, dp, out_dev));
     else
         PGV_TRY(launch_scan(ctx, metric, dtype, g, rows_dev, queries_dev, dt, dn, (int)ntasks, dp, qt,
@@ -440,7 +446,7 @@ void pgv_ctx_destroy(pgv_ctx *ctx) {
                  &ctx->plan_a, &ctx->plan_b, &ctx->plan_c, &ctx->plan_d, &ctx->dist_mat,
                  &ctx->sel_a, &ctx->sel_b, &ctx->km_a, &ctx->km_b, &ctx->km_c, &ctx->km_d,
                  &ctx->km_e, &ctx->km_f, &ctx->km_g, &ctx->stats_dev, &ctx->mf_a, &ctx->mf_b, &ctx->mf_c,
-                 &ctx->zeros, &ctx->ms_a};
+                 &ctx->zeros, &ctx->ms_a, &ctx->ms_b};
     for (DBuf *b : d) b->release();
     ctx->h_a.release();
     ctx->h_b.release();
@@ -625,6 +631,15 @@ int pgv_index_upload(pgv_ctx *ctx, pgv_metric metric, pgv_dtype dtype, int dim, 
                                    reinterpret_cast<unsigned *>(ix->row_norms + n))) != PGV_OK)
             return fail(rc);
     }
+    if (metric == PGV_L2SQ) {
+        if (hipMalloc((void **)&ix->center_norms, sizeof(float) * ((size_t)nlists + 1)) != hipSuccess)
+            return fail((set_error("hipMalloc(center_norms) failed"), PGV_ERR_NOMEM));
+        if (hipMemsetAsync(ix->center_norms + nlists, 0, sizeof(float), ctx->stream) != hipSuccess)
+            return fail((set_error("memset of center_norms failed"), PGV_ERR_DEVICE));
+        if ((rc = launch_row_norms(ctx, dtype, ix->geom, ix->centers, nlists, ix->center_norms,
+                                   reinterpret_cast<unsigned *>(ix->center_norms + nlists))) != PGV_OK)
+            return fail(rc);
+    }
     if (hipStreamSynchronize(ctx->stream) != hipSuccess)
         return fail((set_error("index upload failed: %s", hipGetErrorString(hipGetLastError())), PGV_ERR_DEVICE));
     *out = ix;
@@ -639,11 +654,36 @@ void pgv_index_free(pgv_index *ix) {
     if (ix->list_offsets) (void)hipFree(ix->list_offsets);
     if (ix->tids) (void)hipFree(ix->tids);
     if (ix->row_norms) (void)hipFree(ix->row_norms);
+    if (ix->center_norms) (void)hipFree(ix->center_norms);
     delete ix;
 }
 
 int64_t pgv_index_rows(const pgv_index *ix) { return ix ? ix->nrows : -1; }
 int pgv_index_lists(const pgv_index *ix) { return ix ? ix->nlists : -1; }
+
+// scratch of an approximate (MFMA) L2 pass over nq queries keeping kprime candidates each
+struct ApproxScratch {
+    float *qnorm = nullptr, *cand_val = nullptr;
+    int64_t *cand_pos = nullptr, *cand_slot = nullptr;
+    int32_t *flags = nullptr;  // [nq] flags | count | list of flagged queries
+    int carve(pgv_ctx *ctx, DBuf &buf, int nq, int kprime) {
+        const size_t nk = (size_t)nq * kprime;
+        const size_t a1 = (sizeof(float) * (size_t)nq + 15) & ~(size_t)15, a2 = a1 + ((sizeof(float) * nk + 15) & ~(size_t)15),
+                     a3 = a2 + sizeof(int64_t) * nk, a4 = a3 + sizeof(int64_t) * nk,
+                     a5 = a4 + sizeof(int32_t) * (2 * (size_t)nq + 1);
+        PGV_TRY(buf.ensure(a5));
+        char *b = buf.as<char>();
+        qnorm = reinterpret_cast<float *>(b);
+        cand_val = reinterpret_cast<float *>(b + a1);
+        cand_pos = reinterpret_cast<int64_t *>(b + a2);
+        cand_slot = reinterpret_cast<int64_t *>(b + a3);
+        flags = reinterpret_cast<int32_t *>(b + a4);
+        PGV_HIP(hipMemsetAsync(flags + nq, 0, sizeof(int32_t), ctx->stream));
+        return PGV_OK;
+    }
+};
+
+static float expansion_gamma(int dim) { return 8.f * std::sqrt((float)dim + 4.f) * 5.9604645e-8f; }
 
 // device-side core of GetScanLists for nq staged queries
 static int rank_lists_dev(pgv_index *ix, const void *q_dev, int nq, int maxprobes,
@@ -652,8 +692,6 @@ static int rank_lists_dev(pgv_index *ix, const void *q_dev, int nq, int maxprobe
     // distance matrix [nq x nlists], then the maxprobes smallest per row
     PGV_TRY(ctx->dist_mat.ensure(sizeof(float) * (size_t)nq * ix->nlists));
     float *mat = ctx->dist_mat.as<float>();
-    PGV_TRY(dense_scan(ctx, ix->metric, ix->dtype, ix->geom, ix->centers, ix->nlists, q_dev, nq,
-                       ix->nlists, mat));
     PGV_TRY(ctx->sel_a.ensure(sizeof(int64_t) * (size_t)nq * maxprobes));
     float *dist = out_dist_dev;
     if (!dist) {
@@ -661,7 +699,31 @@ static int rank_lists_dev(pgv_index *ix, const void *q_dev, int nq, int maxprobe
         dist = ctx->sel_b.as<float>();
     }
     int64_t *pos = ctx->sel_a.as<int64_t>();
-    PGV_TRY(launch_topk_segments(ctx, mat, nullptr, nq, ix->nlists, maxprobes, dist, pos));
+    // a batch against a few hundred centers or more: the matrix cores.  Inner product: the values are
+    // the result.  L2: the expansion picks maxprobes + 16 candidates, their exact distances decide, and a
+    // query whose candidates cannot be proven complete is redone exactly (same scheme as the list scan)
+    const int cand = maxprobes + 16 < ix->nlists ? maxprobes + 16 : ix->nlists;
+    const bool mfma = nq > 8 && ix->nlists >= 64 && !ctx->no_mfma_scan &&
+                      (ix->metric == PGV_NEG_IP || (ix->metric == PGV_L2SQ && ix->center_norms && cand <= 256));
+    if (mfma && ix->metric == PGV_L2SQ) {
+        ApproxScratch sc;
+        PGV_TRY(sc.carve(ctx, ctx->ms_b, nq, cand));
+        PGV_TRY(launch_row_norms(ctx, ix->dtype, ix->geom, q_dev, nq, sc.qnorm, nullptr));
+        PGV_TRY(dense_scan(ctx, ix->metric, ix->dtype, ix->geom, ix->centers, ix->nlists, q_dev, nq, ix->nlists, mat,
+                           true, ix->center_norms, sc.qnorm));
+        PGV_TRY(launch_topk_segments(ctx, mat, nullptr, nq, ix->nlists, cand, sc.cand_val, sc.cand_pos));
+        const ExactRows xr{ix->centers, nullptr, nullptr, ix->geom, ix->dtype,
+                           reinterpret_cast<const unsigned *>(ix->center_norms + ix->nlists)};
+        // a center's position in the matrix row is its id: cand_pos serves as the slots
+        PGV_TRY(launch_batch_recheck(ctx, xr, q_dev, nq, cand, maxprobes, sc.cand_val, sc.cand_pos, sc.cand_pos, nullptr,
+                                     ix->nlists, sc.qnorm, expansion_gamma(ix->dim), dist, pos, nullptr, sc.flags));
+        PGV_TRY(launch_batch_redo(ctx, xr, q_dev, nq, nullptr, nullptr, 0, nullptr, ix->nlists, sc.flags, mat));
+        PGV_TRY(launch_topk_segments(ctx, mat, nullptr, nq, ix->nlists, maxprobes, dist, pos, sc.flags));
+    } else {
+        PGV_TRY(dense_scan(ctx, ix->metric, ix->dtype, ix->geom, ix->centers, ix->nlists, q_dev, nq, ix->nlists, mat,
+                           mfma, nullptr, nullptr));
+        PGV_TRY(launch_topk_segments(ctx, mat, nullptr, nq, ix->nlists, maxprobes, dist, pos));
+    }
     PGV_TRY(launch_cast_pos_to_i32(ctx, pos, (int64_t)nq * maxprobes, out_lists_dev));
     return PGV_OK;
 }
@@ -804,25 +866,15 @@ static int scan_batch_dev(pgv_index *ix, const void *q_dev, int nq, const int32_
     // MFMA L2: scratch for the candidates' exact tail
     const bool approx = use_mfma && ix->metric == PGV_L2SQ;
     int kprime = k;
-    float *qnorm = nullptr, *cand_val = nullptr;
-    int64_t *cand_pos = nullptr, *cand_slot = nullptr;
-    int32_t *flags = nullptr;
+    ApproxScratch sc;
     if (approx) {
-        kprime = k <= 16 ? 64 : 4 * k;  // <= 256
-        const size_t nk = (size_t)nq * kprime;
-        const size_t a0 = 0, a1 = a0 + ((sizeof(float) * (size_t)nq + 15) & ~(size_t)15),
-                     a2 = a1 + ((sizeof(float) * nk + 15) & ~(size_t)15), a3 = a2 + sizeof(int64_t) * nk,
-                     a4 = a3 + sizeof(int64_t) * nk, a5 = a4 + sizeof(int32_t) * (2 * (size_t)nq + 1);
-        PGV_TRY(ctx->ms_a.ensure(a5));
-        char *b = ctx->ms_a.as<char>();
-        qnorm = reinterpret_cast<float *>(b + a0);
-        cand_val = reinterpret_cast<float *>(b + a1);
-        cand_pos = reinterpret_cast<int64_t *>(b + a2);
-        cand_slot = reinterpret_cast<int64_t *>(b + a3);
-        flags = reinterpret_cast<int32_t *>(b + a4);
-        PGV_HIP(hipMemsetAsync(flags + nq, 0, sizeof(int32_t), ctx->stream));
-        PGV_TRY(launch_row_norms(ctx, ix->dtype, ix->geom, q_dev, nq, qnorm, nullptr));
+        kprime = k <= 8 ? 32 : 4 * k;  // 32 .. 256: the head asked for and a margin the rounding bound clears easily
+        PGV_TRY(sc.carve(ctx, ctx->ms_a, nq, kprime));
+        PGV_TRY(launch_row_norms(ctx, ix->dtype, ix->geom, q_dev, nq, sc.qnorm, nullptr));
     }
+    float *qnorm = sc.qnorm, *cand_val = sc.cand_val;
+    int64_t *cand_pos = sc.cand_pos, *cand_slot = sc.cand_slot;
+    int32_t *flags = sc.flags;
 
     // GetScanItems: one streaming pass
     PGV_TRY(ctx->plan_d.ensure(sizeof(float) * (size_t)(plan.out_bound > 0 ? plan.out_bound : 1)));
@@ -853,13 +905,15 @@ static int scan_batch_dev(pgv_index *ix, const void *q_dev, int nq, const int32_
     if (approx) {
         // k' candidates by the expansion, their exact distances, the head; queries whose candidate
         // set cannot be proven complete (flags) take the exact pass over their whole segment
-        const float gamma = 8.f * std::sqrt((float)ix->dim + 4.f) * 5.9604645e-8f;
+        const float gamma = expansion_gamma(ix->dim);
         PGV_TRY(launch_topk_segments(ctx, seg_vals, plan.seg_start, nq, 0, kprime, cand_val, cand_pos));
         PGV_TRY(launch_positions_to_slots(ctx, ix, probe_lists, plan.probe_off, nq, probes, kprime, cand_pos,
                                           cand_slot, nullptr));
-        PGV_TRY(launch_batch_recheck(ctx, ix, q_dev, nq, kprime, k, cand_val, cand_pos, cand_slot, plan.seg_start,
+        const ExactRows xr{ix->vectors, ix->tids, ix->list_offsets, ix->geom, ix->dtype,
+                           reinterpret_cast<const unsigned *>(ix->row_norms + ix->nrows)};
+        PGV_TRY(launch_batch_recheck(ctx, xr, q_dev, nq, kprime, k, cand_val, cand_pos, cand_slot, plan.seg_start, 0,
                                      qnorm, gamma, od.as<float>(), os.as<int64_t>(), ot.as<uint64_t>(), flags));
-        PGV_TRY(launch_batch_redo(ctx, ix, q_dev, nq, probe_lists, plan.probe_off, probes, plan.seg_start, flags,
+        PGV_TRY(launch_batch_redo(ctx, xr, q_dev, nq, probe_lists, plan.probe_off, probes, plan.seg_start, 0, flags,
                                   seg_vals));
         PGV_TRY(launch_topk_segments(ctx, seg_vals, plan.seg_start, nq, 0, k, od.as<float>(), pos, flags));
         PGV_TRY(launch_positions_to_slots(ctx, ix, probe_lists, plan.probe_off, nq, probes, k, pos,

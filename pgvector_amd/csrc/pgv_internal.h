@@ -106,6 +106,7 @@ struct pgv_ctx {
     pgv::DBuf q_stage, rows_stage, centers_stage, out_stage, out_stage2, idx_stage;
     pgv::DBuf tasks, pairs, counters, plan_a, plan_b, plan_c, plan_d, dist_mat, sel_a, sel_b;
     pgv::DBuf km_a, km_b, km_c, km_d, km_e, km_f, km_g;
+    pgv::DBuf ms_b;  // MFMA center ranking: the same scratch as ms_a
     pgv::DBuf ms_a;  // MFMA list scan: query norms | candidate values, positions, slots | flags
     pgv::DBuf mf_a, mf_b, mf_c, zeros;  // MFMA assignment: norms, pre-filter candidates, redo list; 16 zero bytes
     pgv::DBuf stats_dev;  // profiling: {pairs, rows streamed} of the batched list scans, as doubles
@@ -142,6 +143,7 @@ struct pgv_index {
     int64_t *list_offsets = nullptr;  // device [nlists + 1]
     uint64_t *tids = nullptr;         // device [nrows] or null
     float *row_norms = nullptr;       // device [nrows] |x|^2 then one word: bits of the largest (L2 indexes; the MFMA scan)
+    float *center_norms = nullptr;    // the same for the centers [nlists + 1]
     std::vector<int64_t> h_offsets;   // host copy
     std::vector<int64_t> len_prefix;  // len_prefix[p] = rows in the p longest lists (output size bound)
     int64_t max_list_len = 0;
@@ -280,14 +282,23 @@ int launch_positions_to_slots(pgv_ctx *ctx, const pgv_index *ix, const int32_t *
                               const int64_t *probe_off, int nq, int probes, int k,
                               const int64_t *pos, int64_t *out_slot, uint64_t *out_tid,
                               const int32_t *only = nullptr);
-// kernels_query.hip: the exact tail of the MFMA L2 scan
-int launch_batch_recheck(pgv_ctx *ctx, const pgv_index *ix, const void *q_dev, int nq, int kprime, int k,
+// kernels_query.hip: the exact tail of the MFMA L2 scans.  The rows the candidates come
+// from: an index's tuples (list_offsets set) or its centers (one dense run)
+struct ExactRows {
+    const void *vectors;
+    const uint64_t *tids;          // or null
+    const int64_t *list_offsets;   // or null
+    pgv::RowGeom geom;
+    pgv_dtype dtype;
+    const unsigned *norm_max;      // bits of the largest |row|^2
+};
+int launch_batch_recheck(pgv_ctx *ctx, const ExactRows &xr, const void *q_dev, int nq, int kprime, int k,
                          const float *approx_val, const int64_t *cand_pos, const int64_t *cand_slot,
-                         const int64_t *seg_start, const float *query_norms, float gamma, float *out_dist,
-                         int64_t *out_slot, uint64_t *out_tid, int32_t *flags);
-int launch_batch_redo(pgv_ctx *ctx, const pgv_index *ix, const void *q_dev, int nq, const int32_t *probe_lists,
-                      const int64_t *probe_off, int probes, const int64_t *seg_start, const int32_t *flags,
-                      float *seg_vals);
+                         const int64_t *seg_start, int64_t fixed_len, const float *query_norms, float gamma,
+                         float *out_dist, int64_t *out_slot, uint64_t *out_tid, int32_t *flags);
+int launch_batch_redo(pgv_ctx *ctx, const ExactRows &xr, const void *q_dev, int nq, const int32_t *probe_lists,
+                      const int64_t *probe_off, int probes, const int64_t *seg_start, int64_t fixed_len,
+                      const int32_t *flags, float *seg_vals);
 int launch_count_flags(pgv_ctx *ctx, const int32_t *count_dev, int nq);  // profiling: stats slot 6 += *count_dev
 int launch_iota_slots(pgv_ctx *ctx, const pgv_index *ix, const int32_t *lists_dev, int nlists,
                       const int64_t *probe_off, int64_t *out_slot);

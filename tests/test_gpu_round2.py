@@ -500,7 +500,10 @@ def test_batched_scan_mfma_ties_short_lists_and_specials(ctx, oracle):
     ivf = CpuIvf(oracle, po.OPS_L2, po.ORA_F32, data, lists, centers=centers)
     queries = gen(60, dim, seed=413, dist="int")
     queries[7] = data[60]
-    _batch_vs_oracle(ctx, oracle, ivf, queries, lists, 10, "int ties", expect_redo="none")
+    # k = 10 -> k' = 40 candidates, inside the run of 41 equal rows for the queries near data[60]: the boundary
+    # is a tie, those queries (and only such) take the exact pass
+    redo = _batch_vs_oracle(ctx, oracle, ivf, queries, lists, 10, "int ties")
+    assert redo <= 6, redo
     _batch_vs_oracle(ctx, oracle, ivf, queries, lists, 64, "int ties k=64", expect_redo="none")
     # fewer tuples than k (and than k'): a 30-row index
     small = CpuIvf(oracle, po.OPS_L2, po.ORA_F32, data[:30], 2, centers=centers[:2])
@@ -553,4 +556,57 @@ def test_batched_scan_mfma_at_scale_is_the_exact_scan(ctx):
     assert len(diff) <= nq // 100, len(diff)
     np.testing.assert_allclose(d, ed, rtol=1e-5)
     assert redo <= nq // 100, redo
+    ix.close()
+
+
+# ------------------------------------------------- center ranking of a batch on the matrix cores
+@pytest.mark.parametrize("ops,dtype,dim,lists,dist", [
+    (po.OPS_L2, po.ORA_F32, 1536, 300, "clustered"),   # headline row shape
+    (po.OPS_L2, po.ORA_F32, 100, 1000, "uniform"),     # near ties between centers
+    (po.OPS_L2, po.ORA_F16, 72, 70, "normal"),
+    (po.OPS_IP, po.ORA_F32, 256, 200, "normal"),
+    (po.OPS_IP, po.ORA_F16, 1024, 129, "clustered"),
+])
+def test_rank_lists_on_the_matrix_cores(ctx, oracle, ops, dtype, dim, lists, dist):
+    """GetScanLists (src/ivfscan.c:47-118) for a batch: mfma_scan_kernel over the centers (+ exact recheck of
+    maxprobes + 16 candidates for L2); maxprobes + 16 > 256 and pgv_ctx_set_exact_scan stay on the exact kernels"""
+    centers = gen(lists, dim, seed=421, dist=dist, dtype=dtype, clusters=30)
+    centers[7] = centers[3]                     # equal centers: the lower id first
+    data = gen(lists * 3, dim, seed=422, dist=dist, dtype=dtype, clusters=30)
+    ivf = CpuIvf(oracle, ops, dtype, data, lists, centers=centers)
+    ix = _upload(ctx, ivf)
+    queries = gen(45, dim, seed=423, dist=dist, dtype=dtype, clusters=30)
+    queries[5] = centers[3]
+    for probes in (1, 10, min(lists, 64), min(lists, 250)):
+        lists_got, dist_got = ix.rank_lists(queries, probes)
+        ctx.set_exact_scan(True)
+        try:
+            lists_exact, _ = ix.rank_lists(queries, probes)
+        finally:
+            ctx.set_exact_scan(False)
+        for i, q in enumerate(queries):
+            wl, wd = oracle.get_scan_lists(ivf.struct, q, probes)
+            assert_topk_equiv(lists_got[i], dist_got[i], wl, wd, what="mfma rank ops %d probes %d q %d" % (ops, probes, i))
+        same = (lists_got == lists_exact).all(axis=1).mean()
+        assert same >= 0.9, same   # only last-bit near-ties may order differently
+    q5, _ = ix.rank_lists(queries, 4)
+    assert q5[5].tolist()[:2] == [3, 7] or ops != po.OPS_L2
+    ix.close()
+
+
+def test_rank_lists_mfma_specials(ctx, oracle):
+    """a center with a huge norm widens the bound until every query is redone exactly; a NaN center sorts last"""
+    dim, lists = 16, 80
+    centers = gen(lists, dim, seed=431, dist="normal")
+    centers[9] *= 1e5
+    centers[11, 0] = np.nan
+    data = gen(400, dim, seed=432, dist="normal")
+    ivf = CpuIvf(oracle, po.OPS_L2, po.ORA_F32, data, lists, centers=centers)
+    ix = _upload(ctx, ivf)
+    queries = gen(40, dim, seed=433, dist="normal")
+    for probes in (5, lists):
+        got, gd = ix.rank_lists(queries, probes)
+        for i, q in enumerate(queries):
+            wl, wd = oracle.get_scan_lists(ivf.struct, q, probes)
+            assert_topk_equiv(got[i], gd[i], wl, wd, what="rank specials probes %d q %d" % (probes, i))
     ix.close()
