@@ -508,7 +508,8 @@ def main():
     streamed_gbps = stream_bytes / scan_s / 1e9 if scan_s > 0 else 0.0
     avg_launch_ms = stats["scan_ms"] / launches
     roofline = {
-        "kernel": "tile_scan_kernel / scan_kernel (IVFFlat list scan, src/ivfscan.c:123-187)",
+        "kernel": ("tile_scan_kernel / scan_kernel" if args.exact_scan else "mfma_scan_kernel")
+                  + " (IVFFlat list scan, GetScanItems, src/ivfscan.c:123-187)",
         "bound": "hbm", "achieved": streamed_gbps, "peak": HBM_PEAK_GBS, "unit": "GB/s",
         "frac": streamed_gbps / HBM_PEAK_GBS,
         "traffic": None, "traffic_source": None,
@@ -519,14 +520,17 @@ def main():
         "algorithmic_bytes_per_launch": algo_bytes / launches,
         "algorithmic_GBps": algo_bytes / scan_s / 1e9 if scan_s > 0 else 0.0,
         "avg_launch_ms": avg_launch_ms, "launches": launches,
-        # the batched kernel is bound by fp32 vector-ALU issue once rows are shared by many queries:
-        # 3 flop per element (subtract, multiply, add) for L2, 2 for inner product
-        "valu_tflops": stats["scan_pairs"] * dim * (3.0 if oname == "l2" else 2.0) / scan_s / 1e12 if scan_s > 0 else 0.0,
-        "valu_peak_tflops": 157.3,
+        # useful multiply-adds (one per element of every scored (query, row) pair) against the dense
+        # MFMA peak of the dtype; the kernel pads a task to 16 or 32 queries, so the matrix cores do more
+        "useful_tflops": stats["scan_pairs"] * dim * 2.0 / scan_s / 1e12 if scan_s > 0 else 0.0,
+        "mfma_peak_tflops": 157.3 if tname == "f32" else 2500.0,
+        "lds_dma_fill_cap_GBps": 7500.0,
         "note": "achieved/frac = row bytes actually streamed from HBM per kernel second (HIP events on the launch "
                 "stream) against the 8 TB/s peak; a row probed by several queries of a batch is streamed once per "
-                "query group and scored from LDS, so the per-(query,row)-pair figure of SURVEY 8d "
-                "(algorithmic_GBps) exceeds the physical rate; passes = streamed / unique rows",
+                "group of <= 32 queries and scored on the matrix cores, so the per-(query,row)-pair figure of "
+                "SURVEY 8d (algorithmic_GBps) exceeds the physical rate; passes = streamed / unique rows.  Rows and "
+                "the group's query slices both enter LDS by DMA, whose measured fill rate (lds_dma_fill_cap_GBps, "
+                "DESIGN.md 4.1c) is the ceiling this kernel runs against",
     }
     line = {
         "metric": "QPS @ recall@10 (IVFFlat, 1M x 1536d)" if args.workload == "headline"

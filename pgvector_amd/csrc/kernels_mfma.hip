@@ -612,11 +612,14 @@ __global__ __launch_bounds__(NW * 64) void mfma_scan_kernel(
     // a lane brings slot (lane & 7) of row (lane >> 3) of its group
     const int drow = lane >> 3, dpos = lane & 7;
 
+    if (threadIdx.x == 0) lds_task = atomicAdd(task_counter, 1);
+    __syncthreads();
     for (;;) {
-        if (threadIdx.x == 0) lds_task = atomicAdd(task_counter, 1);
-        __syncthreads();
         const int t = lds_task;
         if (t >= ntasks) return;
+        // the task after this one is claimed now: its round trip runs under this task's streaming
+        int next = 0;
+        if (threadIdx.x == 0) next = atomicAdd(task_counter, 1);
         const ScanTask task = tasks[t];
         const int np = task.npairs;
         if ((int)threadIdx.x < kScanQueries) {
@@ -743,8 +746,10 @@ __global__ __launch_bounds__(NW * 64) void mfma_scan_kernel(
                 for (int r = 0; r < 4; r++) out[rel[r] + jb] = METRIC == 0 ? fmaf(-2.f, c1[r], rnb + qn[r]) : -c1[r];
             }
         }
-        __builtin_amdgcn_s_waitcnt(0xc07f);  // lgkmcnt(0): the pair table has been read ...
-        __builtin_amdgcn_s_barrier();        // ... by everyone; it and the LDS slices are free again
+        __builtin_amdgcn_s_waitcnt(0xc07f);  // lgkmcnt(0): the pair table and the task id have been read ...
+        __builtin_amdgcn_s_barrier();        // ... by everyone; they and the LDS slices are free again
+        if (threadIdx.x == 0) lds_task = next;
+        __syncthreads();
     }
 }
 
