@@ -703,7 +703,7 @@ static int rank_lists_dev(pgv_index *ix, const void *q_dev, int nq, int maxprobe
     // the result.  L2: the expansion picks maxprobes + 16 candidates, their exact distances decide, and a
     // query whose candidates cannot be proven complete is redone exactly (same scheme as the list scan)
     const int cand = maxprobes + 16 < ix->nlists ? maxprobes + 16 : ix->nlists;
-    const bool mfma = nq > 8 && ix->nlists >= 64 && !ctx->no_mfma_scan &&
+    const bool mfma = nq >= 128 && ix->nlists >= 64 && !ctx->no_mfma_scan &&
                       (ix->metric == PGV_NEG_IP || (ix->metric == PGV_L2SQ && ix->center_norms && cand <= 256));
     if (mfma && ix->metric == PGV_L2SQ) {
         ApproxScratch sc;
@@ -850,7 +850,7 @@ static int scan_batch_dev(pgv_index *ix, const void *q_dev, int nq, const int32_
     // over the rows) when the row shape allows it.
     const double share = (double)nq * probes / (double)ix->nlists;
     // ... and to the matrix cores (32 queries per pass) for L2 / inner product heads of up to 64
-    const bool use_mfma = share > 8.0 && k <= 64 && !ctx->no_mfma_scan &&
+    const bool use_mfma = share > 3.0 && k <= 64 && !ctx->no_mfma_scan &&
                           (ix->metric == PGV_NEG_IP || (ix->metric == PGV_L2SQ && ix->row_norms));
     const bool use_tile = !use_mfma && tile_scan_supported(ix->geom) && share > 8.0;
     const int qt = use_mfma ? mfma_scan_queries_per_task()
