@@ -524,13 +524,13 @@ def main():
         # MFMA peak of the dtype; the kernel pads a task to 16 or 32 queries, so the matrix cores do more
         "useful_tflops": stats["scan_pairs"] * dim * 2.0 / scan_s / 1e12 if scan_s > 0 else 0.0,
         "mfma_peak_tflops": 157.3 if tname == "f32" else 2500.0,
-        "lds_dma_fill_cap_GBps": 7500.0,
+        "measured_stream_ceiling_GBps": 6200.0,
         "note": "achieved/frac = row bytes actually streamed from HBM per kernel second (HIP events on the launch "
                 "stream) against the 8 TB/s peak; a row probed by several queries of a batch is streamed once per "
                 "group of <= 32 queries and scored on the matrix cores, so the per-(query,row)-pair figure of "
-                "SURVEY 8d (algorithmic_GBps) exceeds the physical rate; passes = streamed / unique rows.  Rows and "
-                "the group's query slices both enter LDS by DMA, whose measured fill rate (lds_dma_fill_cap_GBps, "
-                "DESIGN.md 4.1c) is the ceiling this kernel runs against",
+                "SURVEY 8d (algorithmic_GBps) exceeds the physical rate; passes = streamed / unique rows.  "
+                "measured_stream_ceiling_GBps: what a kernel that only stages the same 128-row tasks into LDS reaches on "
+                "this part, any access pattern (tools/stream_patterns.hip, profiles/r02b_stream_patterns.txt, DESIGN.md 4.1c)",
     }
     line = {
         "metric": "QPS @ recall@10 (IVFFlat, 1M x 1536d)" if args.workload == "headline"
