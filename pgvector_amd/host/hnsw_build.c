@@ -519,6 +519,15 @@ pgv_host_hnsw_build(pgv_hnsw * mirror, pgv_dtype dtype, int dim, const void *row
 		if (B > n - i0)
 			B = (int) (n - i0);
 		entry_level = el[entry].level;
+		/* An element taller than the entry point becomes the new entry under the reference's exclusive entry
+		 * lock (src/hnswbuild.c:398-431): the next tall element links to it on the new top layers.  The batch
+		 * therefore ends at (and includes) the first such element -- later ones search from the new entry. */
+		for (int b = 0; b < B; b++)
+			if (el[i0 + b].level > entry_level)
+			{
+				B = b + 1;
+				break;
+			}
 		for (int b = 0; b < B; b++)
 		{
 			int			l = el[i0 + b].level < entry_level ? el[i0 + b].level : entry_level;

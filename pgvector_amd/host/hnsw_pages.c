@@ -535,17 +535,35 @@ pgv_host_hnsw_stage(const pgv_rel * rel, pgv_dtype dtype, pgv_hnsw_image * out)
 						out->nbr[o + i] = -1;
 				}
 				else
-					for (int i = 0; i < count; i++)
+				{
+					/* layer slices of the tuple: level .. 1 with m entries each, then layer 0 with 2 m */
+					for (int s0 = 0; s0 < count;)
 					{
-						uint32_t	eb;
-						uint16_t	eo;
+						int			len = s0 < level * out->m ? out->m : 2 * out->m;
+						int			kept = 0,
+									ended = 0;
 
-						tid_get(ntup + NEIGHBOR_TIDS_OFFSET + (size_t) i * TID_SIZE, &eb, &eo);
-						if (eo == 0 || eb >= rel->nblocks || eo > page_max_offset(page_at(rel, eb)))
-							out->nbr[o + i] = -1;	/* ItemPointerIsValid fails: end of the layer's list */
-						else
-							out->nbr[o + i] = slot_of[first[eb] + eo - 1];
+						for (int i = 0; i < len; i++)
+						{
+							uint32_t	eb;
+							uint16_t	eo;
+							int32_t		nb = -1;
+
+							tid_get(ntup + NEIGHBOR_TIDS_OFFSET + (size_t) (s0 + i) * TID_SIZE, &eb, &eo);
+							if (ended || eo == 0 || eb >= rel->nblocks || eo > page_max_offset(page_at(rel, eb)))
+								ended = 1;	/* ItemPointerIsValid fails: end of the layer's list (:785-786) */
+							else
+								nb = slot_of[first[eb] + eo - 1];
+							/* a valid TID whose tuple is no live element (vacuumed away) is dropped and the rest
+							 * moves up: a -1 ends the slice for the host walk and the device kernel alike */
+							if (nb >= 0)
+								out->nbr[o + s0 + kept++] = nb;
+						}
+						for (int i = kept; i < len; i++)
+							out->nbr[o + s0 + i] = -1;
+						s0 += len;
 					}
+				}
 				o += count;
 				if (meta.entryBlkno == b && meta.entryOffno == off)
 					out->entry = (int32_t) slot;

@@ -175,9 +175,18 @@ def test_hnsw_write_then_stage_round_trip(dtype, dim, m):
     assert img["heaptids"][s4, 1] == tids[10] and img["heaptids"][s4, 2] == tids[20]
     assert (img["heaptids"][s4, 3:] == np.uint64(0xFFFFFFFFFFFFFFFF)).all()
     for s, e in enumerate(kept):
-        want = nbr[nbr_start[e]:nbr_start[e + 1]]
-        want = np.array([slot_of[x] if x >= 0 else -1 for x in want], np.int32)
-        np.testing.assert_array_equal(img["nbr"][img["nbr_start"][s]:img["nbr_start"][s + 1]], want)
+        raw = nbr[nbr_start[e]:nbr_start[e + 1]]
+        # an invalid TID ends a layer's list (HnswLoadNeighborTids breaks, src/hnswutils.c:785-786): per layer slice
+        # (level .. 1: m entries, layer 0: 2 m) the entries before the first -1 survive, the rest reads as -1
+        want, at = [], 0
+        for lc in range(int(levels[e]), -1, -1):
+            ln = 2 * m if lc == 0 else m
+            sl = list(raw[at:at + ln])
+            cut = sl.index(-1) if -1 in sl else ln
+            want += [slot_of[x] for x in sl[:cut]] + [-1] * (ln - cut)
+            at += ln
+        assert at == len(raw)
+        np.testing.assert_array_equal(img["nbr"][img["nbr_start"][s]:img["nbr_start"][s + 1]], np.array(want, np.int32))
 
 
 def test_hnsw_page_layout_matches_the_reference_format():
