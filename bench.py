@@ -351,6 +351,76 @@ def live_traffic(args, scan_ms):
         out["FETCH_SIZE"][1], out["WRITE_SIZE"][1])
 
 
+def hnsw_section(ctx, dev, args, failures, rows=50_000, dim=1536, m=16, efc=64, ef=100, k=10, nq=2000):
+    """vector_cosine_ops HNSW (src/hnswbuild.c:376-476 build loop, src/hnswscan.c:25-56 + src/hnswutils.c:824-987 scan):
+    graph built on the GPU by pgv_host_hnsw_build, every scan's first batch walked on the device by pgv_hnsw_search.
+    Parity: the oracle's HnswSearchLayer restatement walks the SAME graph (ora_hnsw_import) for 64 queries; recall
+    against an exact float64 scan."""
+    from pgvector_amd import _host
+    g = torch.Generator(device=dev)
+    g.manual_seed(args.seed + 21)
+    comps = torch.rand((64, dim), generator=g, device=dev)
+    data = comps[torch.randint(0, 64, (rows,), generator=g, device=dev)] + 0.1 * torch.randn((rows, dim), generator=g, device=dev)
+    data = (data / data.norm(dim=1, keepdim=True)).contiguous()  # HnswFormIndexValue normalises (src/hnswutils.c:406-428)
+    q = comps[torch.randint(0, 64, (nq,), generator=g, device=dev)] + 0.1 * torch.randn((nq, dim), generator=g, device=dev)
+    q = (q / q.norm(dim=1, keepdim=True)).contiguous()
+    host_rows = data.cpu().numpy()
+    mirror = api.Hnsw(ctx, api.PGV_NEG_IP, api.PGV_F32, dim, data)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    built = _host.hnsw_build(mirror, host_rows, m, efc, api.make_rng(seed=1), max_batch=256)
+    torch.cuda.synchronize()
+    build_s = time.perf_counter() - t0
+    qd = q.repeat(10, 1).contiguous()
+    mirror.search(qd[:64].contiguous(), ef, k)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    elem, gd, scored = mirror.search(qd, ef, k)
+    torch.cuda.synchronize()
+    dev_s = time.perf_counter() - t0
+    # exact top-k in float64
+    ip = q.double() @ data.double().T
+    kth = torch.topk(ip, k, dim=1).values[:, -1]
+    e = elem[:nq]
+    got_ip = torch.gather(ip, 1, e.clamp(min=0))
+    recall = float(((got_ip >= kth[:, None] - 1e-9) & (e >= 0)).sum().item()) / (nq * k)
+    out = {"workload": "HNSW vector_cosine_ops %d x %d f32, m %d, ef_construction %d, ef_search %d, k %d (BASELINE "
+                       "configs[3] is 1 M rows: tools/bench_hnsw.py --big)" % (rows, dim, m, efc, ef, k),
+           "qps": qd.shape[0] / dev_s, "queries_in_flight": int(qd.shape[0]), "recall_at_10": recall,
+           "recall_ground_truth": "exact float64 inner products over all rows",
+           "scored_elements_per_query": float(scored.float().mean().item()),
+           "scored_rows_GBps": float(scored.sum().item()) * dim * 4 / dev_s / 1e9,
+           "build_secs": build_s, "build": {"batches": built["batches"], "elements": built["nelements"],
+                                            "pairs_scored": built["device_pairs"], "phase_secs": built["phase_secs"]}}
+    if not args.no_cpu_baseline:
+        from oracle import pyoracle as po
+        ora = po.Oracle(native=True)
+        keep = np.nonzero(built["dup_of"] < 0)[0]  # elements in row order (duplicates folded into their first row)
+        if len(keep) != built["nelements"]:
+            raise RuntimeError("element bookkeeping: %d kept rows, %d elements" % (len(keep), built["nelements"]))
+        walk = po.HnswGraph.from_tuples(ora, po.OPS_COSINE, po.ORA_F32, host_rows, m, built["levels"], built["nbr_start"],
+                                        built["nbr"], built["entry"])
+        eh, dh = e.cpu().numpy(), gd[:nq].cpu().numpy()
+        qh = q.cpu().numpy()
+        bad, checked = [], 64
+        t0 = time.perf_counter()
+        for i in range(checked):
+            wr, wd, _ = walk.search(qh[i], ef, k)
+            # both sides report the index's FUNCTION 1 value (vector_negative_inner_product on normalised rows)
+            why = topk_equiv(eh[i][eh[i] >= 0].tolist(), dh[i][:len(wr)], wr.tolist(), wd)
+            if why:
+                bad.append((i, why))
+        cpu_s = (time.perf_counter() - t0) / checked
+        out["parity"] = {"against": "oracle HnswSearchLayer / GetScanItems restatement walking the same GPU-built graph "
+                                    "(ora_hnsw_import)", "checked_queries": checked, "mismatches": len(bad)}
+        out["cpu_search_single_thread_qps"] = 1.0 / cpu_s
+        if bad:
+            failures.append("hnsw: %d of %d queries differ from the oracle's walk, first: %r" % (len(bad), checked, bad[0]))
+        walk.close()
+    mirror.close()
+    return out
+
+
 def timed_steps(fn, steps, warmup=2):
     for i in range(warmup):
         fn(i)
@@ -768,6 +838,13 @@ def main():
             del uv, uq
         except Exception as e:
             line["uniform"] = {"error": repr(e)}
+
+    # ------------------------------------------- HNSW (BASELINE configs[3]'s shape, rows scaled down)
+    if single and not args.no_sweeps and args.workload == "headline":
+        try:
+            line["hnsw"] = hnsw_section(ctx, dev, args, failures)
+        except Exception as e:
+            line["hnsw"] = {"error": repr(e)}
 
     # ------------------------------------------------------------------ live PMC traffic
     if single and not args.no_traffic:

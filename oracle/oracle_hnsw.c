@@ -594,6 +594,60 @@ ora_hnsw_build(int ops, int dtype, int dim, const void *rows, int64_t n, int m, 
 	return g;
 }
 
+/*
+ * A graph somebody else built (the GPU build, a staged index), given the way the index stores it: per element its
+ * level and the neighbor tuple's (level + 2) * m slots, layer lc at (level - lc) * m, an invalid slot (-1) ends a
+ * layer's list (HnswLoadNeighborTids, src/hnswutils.c:761-794).  `values` are the INDEX values (already
+ * normalised for cosine); element e answers with heap row e.  Only ora_hnsw_search may be used on the result.
+ */
+ora_hnsw *
+ora_hnsw_import(int ops, int dtype, int dim, const void *values, int64_t n, int m, const int32_t *levels,
+				const int64_t *nbr_start, const int32_t *nbr, int32_t entry)
+{
+	ora_hnsw   *g = calloc(1, sizeof(ora_hnsw));
+	size_t		es = dtype == ORA_F32 ? sizeof(float) : sizeof(ora_half);
+
+	g->ops = ops;
+	g->dtype = dtype;
+	g->dim = dim;
+	g->m = m;
+	g->ml = 1.0 / log((double) m);
+	g->max_level = 63;
+	g->item_bytes = (size_t) dim * es;
+	g->values = malloc(g->item_bytes * (size_t) (n > 0 ? n : 1));
+	memcpy(g->values, values, g->item_bytes * (size_t) n);
+	g->cap = n > 0 ? n : 1;
+	g->elements = calloc((size_t) g->cap, sizeof(hnsw_element));
+	g->nelements = n;
+	g->entry_point = n > 0 ? entry : -1;
+	for (int64_t e = 0; e < n; e++)
+	{
+		hnsw_element *el = &g->elements[e];
+
+		el->level = levels[e];
+		el->row = e;
+		el->heaptids[0] = e;
+		el->heaptids_length = 1;
+		el->neighbors = calloc((size_t) el->level + 1, sizeof(neighbor_array));
+		for (int lc = 0; lc <= el->level; lc++)
+		{
+			int			lm = layer_m(m, lc);
+			const int32_t *src = nbr + nbr_start[e] + (int64_t) (el->level - lc) * m;
+			neighbor_array *a = &el->neighbors[lc];
+
+			a->items = malloc(sizeof(hnsw_candidate) * (size_t) lm);
+			a->cap = lm;
+			for (int i = 0; i < lm && src[i] >= 0; i++)
+			{
+				a->items[a->length].element = src[i];
+				a->items[a->length].distance = 0.f;	/* not used by the search */
+				a->length++;
+			}
+		}
+	}
+	return g;
+}
+
 void
 ora_hnsw_free(ora_hnsw * g)
 {

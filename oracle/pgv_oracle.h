@@ -178,6 +178,9 @@ void		ora_kmeans_lloyd_assign(int ops, int dtype, int dim, const void *samples, 
 typedef struct ora_hnsw ora_hnsw;
 ora_hnsw   *ora_hnsw_build(int ops, int dtype, int dim, const void *rows, int64_t n,
 						   int m, int ef_construction, uint64_t seed);
+/* a graph built elsewhere, as neighbor tuples (see oracle_hnsw.c); only ora_hnsw_search applies */
+ora_hnsw   *ora_hnsw_import(int ops, int dtype, int dim, const void *values, int64_t n, int m,
+							const int32_t *levels, const int64_t *nbr_start, const int32_t *nbr, int32_t entry);
 void		ora_hnsw_free(ora_hnsw * g);
 /* flat export for the device mirror: per element level, neighbor slots */
 int64_t		ora_hnsw_num_elements(const ora_hnsw * g);

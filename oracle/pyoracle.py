@@ -109,6 +109,8 @@ class Oracle:
         if self.has_hnsw:
             L.ora_hnsw_build.restype = P
             L.ora_hnsw_build.argtypes = [I, I, I, P, I64, I, I, C.c_uint64]
+            L.ora_hnsw_import.restype = P
+            L.ora_hnsw_import.argtypes = [I, I, I, P, I64, I, P, P, P, C.c_int32]
             L.ora_hnsw_free.argtypes = [P]
             L.ora_hnsw_free.restype = None
             L.ora_hnsw_num_elements.restype = I64
@@ -288,6 +290,20 @@ class HnswGraph:
         self.h = ora.lib.ora_hnsw_build(ops, dtype, self.rows.shape[1], _p(self.rows), self.rows.shape[0],
                                         m, ef_construction, seed)
         self.m = m
+
+    @classmethod
+    def from_tuples(cls, ora, ops, dtype, values, m, levels, nbr_start, nbr, entry):
+        """a graph built elsewhere (the GPU build, a staged index) in the index's neighbor-tuple layout; `values` are
+        the index values (normalised for cosine), element e answers with row e.  Only search() applies."""
+        self = cls.__new__(cls)
+        self.ora, self.ops, self.dtype, self.m = ora, ops, dtype, m
+        self.rows = ora.arr(values, dtype)
+        levels = np.ascontiguousarray(levels, dtype=np.int32)
+        nbr_start = np.ascontiguousarray(nbr_start, dtype=np.int64)
+        nbr = np.ascontiguousarray(nbr, dtype=np.int32)
+        self.h = ora.lib.ora_hnsw_import(ops, dtype, self.rows.shape[1], _p(self.rows), self.rows.shape[0], m,
+                                         _p(levels), _p(nbr_start), _p(nbr), int(entry))
+        return self
 
     def close(self):
         if self.h:

@@ -10,7 +10,7 @@ import pytest
 
 from oracle import pyoracle as po
 
-from helpers import CpuIvf, gen, golden
+from helpers import CpuIvf, gen, golden, normalize_rows
 
 SQL_VECTOR = {"l2_distance": "ora_l2_distance", "inner_product": "ora_inner_product",
               "negative_inner_product": "ora_negative_inner_product",
@@ -269,6 +269,24 @@ def test_hnsw_duplicates_fold_into_one_element(oracle):
     assert g.nelements == 50 + 3  # 25 duplicates -> ceil(25 / 10) elements
     rows, dist, _ = g.search(np.array([1, 2, 3], dtype=np.float32), 40, 25)
     assert sorted(rows.tolist()) == list(range(25)) and (dist == 0).all()
+
+
+def test_hnsw_import_walks_like_the_graph_it_was_exported_from(oracle):
+    """ora_hnsw_import (a graph given as the index's neighbor tuples: what the GPU build and the page stager
+    produce) must answer like the in-memory graph: same rows, same distances, same number of scored elements"""
+    for ops in (po.OPS_L2, po.OPS_COSINE):
+        data = gen(1500, 12, seed=31, dist="normal")
+        g = po.HnswGraph(oracle, ops, po.ORA_F32, data, m=8, ef_construction=40, seed=4)
+        ex = g.export_tuples()
+        values = data[ex["rows"]]
+        if ops == po.OPS_COSINE:
+            values = normalize_rows(oracle, np.ascontiguousarray(values), po.ORA_F32)
+        h = po.HnswGraph.from_tuples(oracle, ops, po.ORA_F32, values, 8, ex["levels"], ex["nbr_start"], ex["nbr"], ex["entry"])
+        for q in gen(25, 12, seed=32, dist="normal"):
+            rows, dist, scored = g.search(q, 40, 10)
+            erows, edist, escored = h.search(q, 40, 10)
+            assert ex["rows"][erows].tolist() == rows.tolist() and escored == scored
+            np.testing.assert_array_equal(edist, dist)
 
 
 # ------------------------------------------------------------------ bit vectors
