@@ -20,7 +20,7 @@ class HnswBuilt(C.Structure):
     _fields_ = [("n", C.c_int64), ("m", C.c_int), ("entry", C.c_int32), ("levels", C.c_void_p),
                 ("nbr_start", C.c_void_p), ("nbr", C.c_void_p), ("dup_of", C.c_void_p),
                 ("nelements", C.c_int64), ("device_pairs", C.c_int64), ("batches", C.c_int64),
-                ("deferred_updates", C.c_int64), ("phase_secs", C.c_double * 6)]
+                ("deferred_updates", C.c_int64), ("phase_secs", C.c_double * 8)]
 
 
 class HnswImage(C.Structure):
@@ -144,7 +144,7 @@ def hnsw_build(mirror, rows, m, ef_construction, rng=None, max_batch=256):
            "nbr": copy(b.nbr, C.c_int32, int(nbr_start[-1]) if n else 0), "dup_of": copy(b.dup_of, C.c_int32, n),
            "entry": b.entry, "m": b.m, "nelements": b.nelements, "device_pairs": b.device_pairs, "batches": b.batches,
            "deferred_updates": b.deferred_updates,
-           "phase_secs": dict(zip(("search", "pairs", "select", "records", "update", "patch"), list(b.phase_secs)))}
+           "phase_secs": dict(zip(("search", "pairs", "select", "records", "update", "patch", "pairlist", "free"), list(b.phase_secs)))}
     lib.pgv_host_hnsw_built_free(C.byref(b))
     return out
 

@@ -76,7 +76,7 @@ typedef struct
 	float	   *mat;			/* [nlocal x nlocal] */
 	float	   *newdist;		/* [nlocal - nstart] distance of each newcomer to the owner */
 	int			wait_from;		/* first local whose update waits for the second launch */
-	int			newcap;
+	int			newcap;			/* newcomers of the batch (counted in step 4a) */
 }			record;
 
 typedef struct
@@ -132,6 +132,84 @@ rng_double(rng_state * r)
 	return ldexp((double) (out >> 12), -52);
 }
 
+/* per-thread bump allocator for a batch's records (ids, distance matrices): reset at the end of the batch instead of
+ * a malloc/free pair per list -- a 100 k x 1536 build touched 4.3 M lists and spent 15 % of its time in free() */
+typedef struct
+{
+	char	  **chunks;
+	int			nchunks,
+				cur;
+	size_t		used;
+	void	  **big;			/* requests larger than a chunk */
+	int			nbig,
+				bigcap;
+}			arena;
+
+#define ARENA_CHUNK ((size_t) 1 << 20)
+
+static void *
+arena_alloc(arena * a, size_t bytes)
+{
+	void	   *p;
+
+	bytes = (bytes + 15) & ~(size_t) 15;
+	if (bytes > ARENA_CHUNK)
+	{
+		if (a->nbig == a->bigcap)
+		{
+			a->bigcap = a->bigcap ? a->bigcap * 2 : 8;
+			a->big = realloc(a->big, sizeof(void *) * (size_t) a->bigcap);
+		}
+		p = malloc(bytes);
+		a->big[a->nbig++] = p;
+		return p;
+	}
+	if (a->nchunks == 0 || a->used + bytes > ARENA_CHUNK)
+	{
+		if (a->nchunks > 0 && a->cur + 1 < a->nchunks)
+			a->cur++;
+		else
+		{
+			a->chunks = realloc(a->chunks, sizeof(char *) * (size_t) (a->nchunks + 1));
+			a->chunks[a->nchunks] = malloc(ARENA_CHUNK);
+			a->cur = a->nchunks++;
+		}
+		a->used = 0;
+	}
+	p = a->chunks[a->cur] + a->used;
+	a->used += bytes;
+	return p;
+}
+
+static void
+arena_reset(arena * a)
+{
+	for (int i = 0; i < a->nbig; i++)
+		free(a->big[i]);
+	a->nbig = 0;
+	a->cur = 0;
+	a->used = 0;
+}
+
+static void
+arena_free(arena * a)
+{
+	arena_reset(a);
+	for (int i = 0; i < a->nchunks; i++)
+		free(a->chunks[i]);
+	free(a->chunks);
+	free(a->big);
+	memset(a, 0, sizeof(*a));
+}
+
+/* a batch element choosing a neighbor: the owner's list (a record) meets the element as a newcomer */
+typedef struct
+{
+	int32_t		rec;
+	int32_t		element;
+	float		distance;
+}			link_req;
+
 static double
 now_secs(void)
 {
@@ -144,7 +222,7 @@ now_secs(void)
 /* where the wall time of a build goes: out->phase_secs[] */
 enum
 {
-	PH_SEARCH, PH_PAIRS, PH_SELECT, PH_RECORDS, PH_UPDATE, PH_PATCH, PH_COUNT
+	PH_SEARCH, PH_PAIRS, PH_SELECT, PH_RECORDS, PH_UPDATE, PH_PATCH, PH_PAIRLIST, PH_FREE, PH_COUNT
 };
 #define PHASE(p) do { double t_ = now_secs(); out->phase_secs[cur_phase] += t_ - phase_t0; phase_t0 = t_; cur_phase = (p); } while (0)
 
@@ -421,6 +499,12 @@ pgv_host_hnsw_build(pgv_hnsw * mirror, pgv_dtype dtype, int dim, const void *row
 	record	   *recs = NULL;
 	int			recs_cap = 0;
 	int64_t    *rec_of = NULL;	/* hash: (owner, lc) -> record index + 1 */
+	link_req   *links = NULL;	/* the batch's (list, newcomer) requests in link order, then grouped by list */
+	int64_t		links_cap = 0;
+	int32_t    *grp_elem = NULL;
+	float	   *grp_dist = NULL;
+	int64_t    *grp_off = NULL;
+	arena	   *arenas = NULL;	/* [nthreads] */
 	int64_t    *tri_off = NULL;
 	int			nrec = 0;		/* records of the batch in flight (freed at its end, or on the way out) */
 	int			nthreads = omp_get_max_threads() < 16 ? omp_get_max_threads() : 16;
@@ -486,6 +570,7 @@ pgv_host_hnsw_build(pgv_hnsw * mirror, pgv_dtype dtype, int dim, const void *row
 	is_dirty = calloc((size_t) n, 1);
 	hash_cap = 1 << 10;			/* grows by doubling at load factor 1/2 (see below) */
 	rec_of = calloc((size_t) hash_cap, sizeof(int64_t));
+	arenas = calloc((size_t) nthreads, sizeof(arena));
 
 	for (int64_t i0 = 0; i0 < n;)
 	{
@@ -693,107 +778,146 @@ pgv_host_hnsw_build(pgv_hnsw * mirror, pgv_dtype dtype, int dim, const void *row
 		}
 
 		PHASE(PH_RECORDS);
-		/* ---- 4. the lists this batch links into, and every distance their re-selections can look up */
+		/* ---- 4. the lists this batch links into, and every distance their re-selections can look up.
+		 * 4a (serial, touches only the small hash table): one request per (batch element, chosen neighbor, layer)
+		 * in the order the reference's loop would link them, and a bare record per distinct list. */
 		pb.n = 0;
-		for (int b = 0; b < B; b++)
 		{
-			int32_t		e = (int32_t) (i0 + b);
-			elem	   *x = &el[e];
+			int64_t		nlinks = 0;
 
-			if (!x->layers)
-				continue;
-			linked++;
-			if (!is_dirty[e])
+			for (int b = 0; b < B; b++)
 			{
-				is_dirty[e] = 1;
-				ndirty++;
-			}
-			for (int lc = x->level; lc >= 0; lc--)
-				for (int i = 0; i < x->layers[lc].length; i++)
+				int32_t		e = (int32_t) (i0 + b);
+				elem	   *x = &el[e];
+
+				if (!x->layers)
+					continue;
+				linked++;
+				if (!is_dirty[e])
 				{
-					int32_t		owner = x->layers[lc].items[i].element;
-					uint64_t	key = ((uint64_t) owner << 6) | (uint64_t) lc;
-					int64_t		h = (int64_t) ((key * 0x9E3779B97F4A7C15ull) >> 40) & (hash_cap - 1);
-					record	   *rcd;
-					int64_t		ri;		/* record index + 1 (the table may be rebuilt below: h is not kept) */
-
-					while (rec_of[h] != 0 && !(recs[rec_of[h] - 1].owner == owner && recs[rec_of[h] - 1].lc == lc))
-						h = (h + 1) & (hash_cap - 1);
-					ri = rec_of[h];
-					if (ri == 0)
+					is_dirty[e] = 1;
+					ndirty++;
+				}
+				for (int lc = x->level; lc >= 0; lc--)
+					for (int i = 0; i < x->layers[lc].length; i++)
 					{
-						const nlist *l = &el[owner].layers[lc];
+						int32_t		owner = x->layers[lc].items[i].element;
+						uint64_t	key = ((uint64_t) owner << 6) | (uint64_t) lc;
+						int64_t		h = (int64_t) ((key * 0x9E3779B97F4A7C15ull) >> 40) & (hash_cap - 1);
+						int64_t		ri;		/* record index + 1 (the table may be rebuilt below: h is not kept) */
 
-						if (nrec == recs_cap)
+						while (rec_of[h] != 0 && !(recs[rec_of[h] - 1].owner == owner && recs[rec_of[h] - 1].lc == lc))
+							h = (h + 1) & (hash_cap - 1);
+						ri = rec_of[h];
+						if (ri == 0)
 						{
-							recs_cap = recs_cap ? recs_cap * 2 : 1024;
-							recs = realloc(recs, sizeof(record) * (size_t) recs_cap);
-						}
-						rcd = &recs[nrec];
-						rcd->owner = owner;
-						rcd->lc = lc;
-						rcd->nstart = l->length;
-						rcd->nlocal = l->length;
-						rcd->newcap = 4;	/* most lists meet one or two newcomers per batch */
-						rcd->ids = malloc(sizeof(int32_t) * (size_t) (l->length + rcd->newcap));
-						rcd->newdist = malloc(sizeof(float) * (size_t) rcd->newcap);
-						rcd->mat = NULL;
-						rcd->full = !l->closer_set;	/* no cached flags: its next selection computes everything */
-						rcd->blocked = 0;
-						rcd->wait_from = -1;
-						for (int j = 0; j < l->length; j++)
-						{
-							rcd->ids[j] = l->items[j].element;
-							l->items[j].local = j;
-						}
-						rec_of[h] = ++nrec;
-						ri = nrec;
-						if ((int64_t) nrec * 2 > hash_cap)
-						{
-							/* load factor 1/2 reached (a batch touches up to B * (2m + level * m) lists; m up to
-							 * 100, src/hnsw.h:50): double the table and rehash the records made so far */
-							int64_t		ncap = hash_cap * 2;
-							int64_t    *nt = calloc((size_t) ncap, sizeof(int64_t));
+							record	   *rcd;
 
-							if (!nt)
+							if (nrec == recs_cap)
 							{
-								rc = pgv_host_fail(PGV_ERR_NOMEM, "out of memory growing the batch's list table");
+								recs_cap = recs_cap ? recs_cap * 2 : 1024;
+								recs = realloc(recs, sizeof(record) * (size_t) recs_cap);
+							}
+							rcd = &recs[nrec];
+							rcd->owner = owner;
+							rcd->lc = lc;
+							rcd->newcap = 0;	/* newcomers, counted here */
+							rec_of[h] = ++nrec;
+							ri = nrec;
+							if ((int64_t) nrec * 2 > hash_cap)
+							{
+								/* load factor 1/2 reached (a batch touches up to B * (2m + level * m) lists; m up to
+								 * 100, src/hnsw.h:50): double the table and rehash the records made so far */
+								int64_t		ncap = hash_cap * 2;
+								int64_t    *nt = calloc((size_t) ncap, sizeof(int64_t));
+
+								if (!nt)
+								{
+									rc = pgv_host_fail(PGV_ERR_NOMEM, "out of memory growing the batch's list table");
+									goto done;
+								}
+								for (int64_t r = 0; r < nrec; r++)
+								{
+									uint64_t	k2 = ((uint64_t) recs[r].owner << 6) | (uint64_t) recs[r].lc;
+									int64_t		h2 = (int64_t) ((k2 * 0x9E3779B97F4A7C15ull) >> 40) & (ncap - 1);
+
+									while (nt[h2] != 0)
+										h2 = (h2 + 1) & (ncap - 1);
+									nt[h2] = r + 1;
+								}
+								free(rec_of);
+								rec_of = nt;
+								hash_cap = ncap;
+							}
+							if (!is_dirty[owner])
+							{
+								is_dirty[owner] = 1;
+								ndirty++;
+							}
+						}
+						if (nlinks == links_cap)
+						{
+							links_cap = links_cap ? links_cap * 2 : 16384;
+							links = realloc(links, sizeof(link_req) * (size_t) links_cap);
+							grp_elem = realloc(grp_elem, sizeof(int32_t) * (size_t) links_cap);
+							grp_dist = realloc(grp_dist, sizeof(float) * (size_t) links_cap);
+							if (!links || !grp_elem || !grp_dist)
+							{
+								rc = pgv_host_fail(PGV_ERR_NOMEM, "out of memory");
 								goto done;
 							}
-							for (int64_t r = 0; r < nrec; r++)
-							{
-								uint64_t	k2 = ((uint64_t) recs[r].owner << 6) | (uint64_t) recs[r].lc;
-								int64_t		h2 = (int64_t) ((k2 * 0x9E3779B97F4A7C15ull) >> 40) & (ncap - 1);
+						}
+						links[nlinks].rec = (int32_t) (ri - 1);
+						links[nlinks].element = e;
+						links[nlinks].distance = x->layers[lc].items[i].distance;
+						nlinks++;
+						recs[ri - 1].newcap++;
+					}
+				/* the entry point moves up with the tallest element (src/hnswbuild.c:425-430) */
+				if (x->level > el[entry].level)
+					entry = e;
+			}
+			/* 4b: the requests grouped by list, link order kept inside a list (counting sort) */
+			grp_off = realloc(grp_off, sizeof(int64_t) * (size_t) (nrec + 1));
+			grp_off[0] = 0;
+			for (int k = 0; k < nrec; k++)
+			{
+				grp_off[k + 1] = grp_off[k] + recs[k].newcap;
+				recs[k].nlocal = 0;		/* fill cursor of 4b */
+			}
+			for (int64_t t = 0; t < nlinks; t++)
+			{
+				record	   *rcd = &recs[links[t].rec];
+				int64_t		at = grp_off[links[t].rec] + rcd->nlocal++;
 
-								while (nt[h2] != 0)
-									h2 = (h2 + 1) & (ncap - 1);
-								nt[h2] = r + 1;
-							}
-							free(rec_of);
-							rec_of = nt;
-							hash_cap = ncap;
-						}
-						if (!is_dirty[owner])
-						{
-							is_dirty[owner] = 1;
-							ndirty++;
-						}
-					}
-					rcd = &recs[ri - 1];
-					/* the newcomers of a list, in the order the reference's loop would link them */
-					if (rcd->nlocal - rcd->nstart == rcd->newcap)
-					{
-						rcd->newcap *= 2;
-						rcd->ids = realloc(rcd->ids, sizeof(int32_t) * (size_t) (rcd->nstart + rcd->newcap));
-						rcd->newdist = realloc(rcd->newdist, sizeof(float) * (size_t) rcd->newcap);
-					}
-					rcd->newdist[rcd->nlocal - rcd->nstart] = x->layers[lc].items[i].distance;
-					rcd->ids[rcd->nlocal++] = e;
+				grp_elem[at] = links[t].element;
+				grp_dist[at] = links[t].distance;
+			}
+			/* 4c (parallel: this is where the owners' lists, cold in the cache, are read): members + newcomers */
+#pragma omp parallel for if (B >= 8) num_threads(nthreads) schedule(static)
+			for (int k = 0; k < nrec; k++)
+			{
+				record	   *rcd = &recs[k];
+				nlist	   *l = &el[rcd->owner].layers[rcd->lc];
+				int			nnew = rcd->newcap;
+
+				rcd->nstart = l->length;
+				rcd->nlocal = l->length + nnew;
+				rcd->ids = arena_alloc(&arenas[omp_get_thread_num()], sizeof(int32_t) * (size_t) rcd->nlocal);
+				rcd->newdist = grp_dist + grp_off[k];
+				rcd->mat = NULL;
+				rcd->full = !l->closer_set;	/* no cached flags: its next selection computes everything */
+				rcd->blocked = 0;
+				rcd->wait_from = -1;
+				for (int j = 0; j < l->length; j++)
+				{
+					rcd->ids[j] = l->items[j].element;
+					l->items[j].local = j;
 				}
-			/* the entry point moves up with the tallest element (src/hnswbuild.c:425-430) */
-			if (x->level > el[entry].level)
-				entry = e;
+				memcpy(rcd->ids + l->length, grp_elem + grp_off[k], sizeof(int32_t) * (size_t) nnew);
+			}
 		}
+		PHASE(PH_PAIRLIST);
 		{
 			int64_t		total = 0;
 
@@ -908,7 +1032,8 @@ pgv_host_hnsw_build(pgv_hnsw * mirror, pgv_dtype dtype, int dim, const void *row
 						{
 							if (rcd->nlocal > lm)
 							{
-								rcd->mat = calloc((size_t) rcd->nlocal * rcd->nlocal, sizeof(float));
+								rcd->mat = arena_alloc(&arenas[omp_get_thread_num()], sizeof(float) * (size_t) rcd->nlocal * rcd->nlocal);
+								memset(rcd->mat, 0, sizeof(float) * (size_t) rcd->nlocal * rcd->nlocal);
 								if (rcd->full)
 									fill_matrix(rcd->mat, rcd->nlocal, pdist + rcd->pair0);
 								else
@@ -1021,13 +1146,10 @@ pgv_host_hnsw_build(pgv_hnsw * mirror, pgv_dtype dtype, int dim, const void *row
 				goto dev_fail;
 		}
 
+		PHASE(PH_FREE);
 		/* forget the batch's records */
-		for (int k = 0; k < nrec; k++)
-		{
-			free(recs[k].ids);
-			free(recs[k].mat);
-			free(recs[k].newdist);
-		}
+		for (int t = 0; t < nthreads; t++)
+			arena_reset(&arenas[t]);
 		nrec = 0;
 		PHASE(PH_RECORDS);
 		memset(rec_of, 0, sizeof(int64_t) * (size_t) hash_cap);
@@ -1052,12 +1174,16 @@ done:
 			}
 		free(el);
 	}
-	for (int k = 0; k < nrec; k++)	/* a batch cut short by an error */
+	if (arenas)					/* incl. a batch cut short by an error */
 	{
-		free(recs[k].ids);
-		free(recs[k].mat);
-		free(recs[k].newdist);
+		for (int t = 0; t < nthreads; t++)
+			arena_free(&arenas[t]);
+		free(arenas);
 	}
+	free(links);
+	free(grp_elem);
+	free(grp_dist);
+	free(grp_off);
 	free(pb.a);
 	free(pb.b);
 	free(pdist);

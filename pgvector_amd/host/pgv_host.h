@@ -87,7 +87,8 @@ typedef struct pgv_hnsw_built
 	int64_t		device_pairs;	/* element pairs scored for SelectNeighbors */
 	int64_t		batches;
 	int64_t		deferred_updates;	/* lists whose re-selection needed a second distance launch */
-	double		phase_secs[6];	/* wall time: search, pair scoring, SelectNeighbors, bookkeeping, list updates, graph patch */
+	double		phase_secs[8];	/* wall time: search, pair scoring, SelectNeighbors, list records, list updates, graph patch,
+								 * pair lists, record release */
 }			pgv_hnsw_built;
 
 int			pgv_host_hnsw_build(pgv_hnsw * mirror, pgv_dtype dtype, int dim, const void *rows, int64_t n, int m,
