@@ -368,7 +368,7 @@ def hnsw_section(ctx, dev, args, failures, rows=50_000, dim=1536, m=16, efc=64, 
     mirror = api.Hnsw(ctx, api.PGV_NEG_IP, api.PGV_F32, dim, data)
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    built = _host.hnsw_build(mirror, host_rows, m, efc, api.make_rng(seed=1), max_batch=256)
+    built = _host.hnsw_build(mirror, host_rows, m, efc, api.make_rng(seed=1), max_batch=1024)
     torch.cuda.synchronize()
     build_s = time.perf_counter() - t0
     qd = q.repeat(10, 1).contiguous()

@@ -127,7 +127,7 @@ def hnsw_search(mirror, graph, queries, ef_search, k):
 _NP = {0: np.float32, 1: np.float16}
 
 
-def hnsw_build(mirror, rows, m, ef_construction, rng=None, max_batch=256):
+def hnsw_build(mirror, rows, m, ef_construction, rng=None, max_batch=1024):
     """pgv_host_hnsw_build: mirror = api.Hnsw holding exactly `rows`; returns a dict with levels,
     nbr_start, nbr, entry, dup_of (numpy copies) and the counters"""
     rows = np.ascontiguousarray(rows, dtype=_NP[mirror.dtype])

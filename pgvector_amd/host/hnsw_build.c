@@ -520,8 +520,8 @@ pgv_host_hnsw_build(pgv_hnsw * mirror, pgv_dtype dtype, int dim, const void *row
 		return pgv_host_fail(PGV_ERR_ARG, "too many elements");
 	if (max_batch < 1)
 		max_batch = 1;
-	if (max_batch > 512)
-		max_batch = 512;
+	if (max_batch > 2048)
+		max_batch = 2048;
 	memset(out, 0, sizeof(*out));
 	out->n = n;
 	out->m = m;

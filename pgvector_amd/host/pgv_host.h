@@ -65,7 +65,8 @@ int			pgv_host_hnsw_search(pgv_hnsw * mirror, const pgv_hnsw_graph * graph, pgv_
  * The in-memory phase of CREATE INDEX ... USING hnsw (src/hnswbuild.c:436-476, :376-431) with
  * every distance on the GPU: elements are inserted in batches of up to max_batch (all of a batch
  * search the graph as it stood when the batch began, like the reference's parallel workers racing
- * each other; max_batch = 1 is the reference's serial loop), see hnsw_build.c.
+ * each other; max_batch = 1 is the reference's serial loop, the cap is 2048), see hnsw_build.c.  A batch never
+ * exceeds 1/16 of the elements already linked and ends at the first element taller than the entry point.
  *
  *   mirror  pgv_hnsw_upload of ALL n element vectors (what HnswFormIndexValue produced: normalised
  *           for cosine, zero-norm rows left out by the caller); the graph is (re)set by this call

@@ -44,7 +44,7 @@ def big(a):
     mirror = api.Hnsw(ctx, api.PGV_NEG_IP, api.PGV_F32, a.dim, data)
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    built = _host.hnsw_build(mirror, host_rows, a.m, a.ef_construction, api.make_rng(seed=1), max_batch=a.gpu_build or 256)
+    built = _host.hnsw_build(mirror, host_rows, a.m, a.ef_construction, api.make_rng(seed=1), max_batch=a.gpu_build or 1024)
     torch.cuda.synchronize()
     build_s = time.perf_counter() - t0
     reps = max(1, 20000 // a.queries)
@@ -72,7 +72,7 @@ def big(a):
                                         "ops": "vector_cosine_ops"},
         "recall_at_k": hits / (a.queries * a.k), "scored_elements_per_query": float(scored.float().mean().item()),
         "algorithmic_GBps": float(scored.sum().item()) * a.dim * 4 / dev_s / 1e9,
-        "gpu_build": {"secs": build_s, "max_batch": a.gpu_build or 256, "batches": built["batches"],
+        "gpu_build": {"secs": build_s, "max_batch": a.gpu_build or 1024, "batches": built["batches"],
                       "elements": built["nelements"], "pairs_scored": built["device_pairs"],
                       "deferred_updates": built["deferred_updates"], "phase_secs": built["phase_secs"]}}))
 
