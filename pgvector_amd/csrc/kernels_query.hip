@@ -235,7 +235,7 @@ __global__ void query_iota_kernel(int32_t *__restrict__ out, int n) {
 // kernel (one workgroup per query) re-evaluates those with the reference's arithmetic
 // (sum of (q - x)^2, src/vector.c:172-185), sorts them the way the tuplesort would (distance, then
 // position in the stream) and emits the first k.  A query is flagged for the full exact pass unless
-// the k'-th approximate value clears the k-th exact one by the rounding bound of the expansion, i.e.
+// the k'-th approximate value clears the k-th one by twice the rounding bound of the expansion, i.e.
 // unless no row outside the candidates can belong to the head.
 constexpr int kRecheckCap = 256;  // k' <= 256: rank_sort_entries' reach
 
@@ -252,7 +252,16 @@ __global__ __launch_bounds__(kQThreads) void batch_recheck_kernel(
     const int q = blockIdx.x;
     const size_t row_bytes = (size_t)nvec * sizeof(Raw16);
     const int64_t m = seg_start ? seg_start[q + 1] - seg_start[q] : fixed_len;  // rows the candidates were picked from
-    const int cnt = (int)(m < kprime ? m : (int64_t)kprime);
+    const int ncand = (int)(m < kprime ? m : (int64_t)kprime);
+    const int kk = ncand < k ? ncand : k;
+    // Only candidates within 2 eps of the k-th approximate value can be in the head: the k smallest-approx rows have
+    // exact <= approx[k] + eps, every row with approx > approx[k] + 2 eps has exact > approx[k] + eps.  The candidates
+    // come sorted (float8 order, NaN last), so the band is a prefix; it is usually k + a few of the k' rows.
+    const float *av = approx_val + (size_t)q * kprime;
+    const float qn = query_norms[q], rn = __uint_as_float(*row_norm_max);
+    const float eps = gamma * (qn + rn + 2.f * sqrtf(qn * rn));
+    const unsigned band = kk > 0 ? float_to_key(av[kk - 1] + 2.f * eps) : 0u;  // NaN / inf anywhere: everything is in the band
+    const int cnt = __syncthreads_count((int)threadIdx.x < ncand && float_to_key(av[threadIdx.x]) <= band);
     const int64_t *slots = cand_slot + (size_t)q * kprime;
     score_rows<T, 0, 0>([&](int64_t j) { return vectors + (size_t)slots[j] * row_bytes; }, 0, cnt,
                         queries + (size_t)q * row_bytes, nvec, lg, exact);
@@ -263,8 +272,7 @@ __global__ __launch_bounds__(kQThreads) void batch_recheck_kernel(
                                      (unsigned)cand_pos[(size_t)q * kprime + threadIdx.x]
                                : ~0ull;
     __syncthreads();
-    // carry the candidate index through the sort: find it again by position afterwards would cost a
-    // search, so sort (key, position) and keep a parallel map position -> candidate in `exact`'s place
+    // sort by (exact distance, position in the stream): every thread ranks its own entry
     const unsigned long long mine = ent[threadIdx.x];
     const int64_t my_slot = (int)threadIdx.x < cnt ? slots[threadIdx.x] : -1;
     int rank = 0;
@@ -278,7 +286,6 @@ __global__ __launch_bounds__(kQThreads) void batch_recheck_kernel(
             rank += o.y < mine ? 1 : 0;
         }
     }
-    const int kk = cnt < k ? cnt : k;
     if ((int)threadIdx.x < cnt && rank < k) {
         const size_t o = (size_t)q * k + rank;
         out_dist[o] = key_to_float((unsigned)(mine >> 32));
@@ -291,19 +298,12 @@ __global__ __launch_bounds__(kQThreads) void batch_recheck_kernel(
         if (out_slot) out_slot[o] = -1;
         if (out_tid) out_tid[o] = ~0ull;
     }
-    if ((int)threadIdx.x < cnt && rank == kk - 1) {
-        int32_t flag = 0;
-        if (m > cnt) {
-            const float kth = key_to_float((unsigned)(mine >> 32));
-            const float qn = query_norms[q], rn = __uint_as_float(*row_norm_max);
-            const float eps = gamma * (qn + rn + 2.f * sqrtf(qn * rn));
-            const float edge = approx_val[(size_t)q * kprime + kprime - 1];  // every row outside is >= this (approx.)
-            flag = (edge - eps > kth) ? 0 : 1;                               // NaN / inf anywhere: flag
-        }
+    if (threadIdx.x == 0) {
+        // the band reaches the end of the candidates and there are rows beyond them: one of those may be in it too
+        const int32_t flag = (m > ncand && cnt == ncand) ? 1 : 0;
         flags[q] = flag;
         if (flag) flags[nq + 1 + atomicAdd(&flags[nq], 1)] = q;  // [nq] flags | count | list of flagged queries
     }
-    if (cnt == 0 && threadIdx.x == 0) flags[q] = 0;
 }
 
 // the flagged queries' segments again, every row with the exact form (one pass of the old cost
