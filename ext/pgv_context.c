@@ -38,6 +38,7 @@ PgvRelcacheCallback(Datum arg, Oid relid)
 	for (PgvIvfMirror * m = mirrors; m != NULL; m = m->next)
 		if (m->relid == relid || relid == 0)
 			m->valid = false;
+	PgvHnswInvalidate(relid);
 }
 
 void

@@ -13,6 +13,8 @@
  *   ivfflatrescan       src/ivfscan.c:322-356   PgvIvfflatRescan(so->gpu);
  *   ivfflatgettuple     src/ivfscan.c:361-414   if (so->gpu) return PgvIvfflatGetTuple(scan);
  *   ivfflatendscan      src/ivfscan.c:419-431   PgvIvfflatEndScan(so->gpu);
+ *   hnswbeginscan       src/hnswscan.c:121-146  so->gpu = PgvHnswBeginScan(index);
+ *   hnswgettuple        src/hnswscan.c:228      so->w = so->gpu ? PgvHnswGetScanItems(scan, value) : GetScanItems(scan, value);
  *   IvfflatKmeans       src/ivfkmeans.c:553-570 if (PgvIvfflatKmeans(index, samples, centers, typeInfo)) return;
  *   BuildCallback       src/ivfbuild.c:224-266  if (buildstate->gpu) { PgvIvfflatBuildAdd(buildstate, tid, value); return; }
  *   AssignTuples        src/ivfbuild.c:600-636  PgvIvfflatBuildFlush(buildstate) after the heap scan
@@ -59,6 +61,13 @@ void	   *PgvIvfflatBeginScan(Relation index, IvfflatScanOpaque so);
 void		PgvIvfflatRescan(void *gpu);
 bool		PgvIvfflatGetTuple(IndexScanDesc scan);
 void		PgvIvfflatEndScan(void *gpu);
+
+/* HNSW scan side (hnswscan_gpu.c); List as in nodes/pg_list.h */
+void	   *PgvHnswBeginScan(Relation index);
+List	   *PgvHnswGetScanItems(IndexScanDesc scan, Datum value);
+void		PgvHnswInvalidate(Oid relid);
+/* FUNCTION 1 of an hnsw opclass that has no FUNCTION 2: L2 or inner product (by the support function's oid) */
+pgv_metric	PgvHnswMetricOf(Relation index);
 
 /* build side (ivfbuild_gpu.c) */
 bool		PgvIvfflatKmeans(Relation index, VectorArray samples, VectorArray centers, const IvfflatTypeInfo * typeInfo);

@@ -128,6 +128,16 @@ OffsetNumber PageGetMaxOffsetNumber(Page page);
 ItemId		PageGetItemId(Page page, OffsetNumber offsetNumber);
 Item		PageGetItem(Page page, ItemId itemId);
 char	   *PageGetSpecialPointer(Page page);
+char	   *PageGetContents(Page page);
+BlockNumber RelationGetNumberOfBlocks(Relation reln);
+#define ItemPointerIsValid(p) ((p) != NULL && (p)->ip_posid != 0)
+BlockNumber ItemPointerGetBlockNumber(const ItemPointerData *p);
+OffsetNumber ItemPointerGetOffsetNumber(const ItemPointerData *p);
+
+/* nodes/pg_list.h */
+typedef struct List List;
+#define NIL ((List *) NULL)
+List	   *lappend(List *list, void *datum);
 
 /* access/itup.h, access/tupdesc.h */
 typedef struct IndexTupleData
@@ -174,6 +184,12 @@ typedef struct IndexScanDescData
 typedef IndexScanDescData *IndexScanDesc;
 
 /* fmgr.h (only what the glue names) */
-typedef struct FmgrInfo FmgrInfo;
+typedef Datum (*PGFunction) (void *fcinfo);
+typedef struct FmgrInfo
+{
+	PGFunction	fn_addr;
+	Oid			fn_oid;
+}			FmgrInfo;
+FmgrInfo   *index_getprocinfo(Relation irel, int attnum, uint16 procnum);
 
 #endif							/* PGSHIM_H */
