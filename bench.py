@@ -351,6 +351,52 @@ def live_traffic(args, scan_ms):
         out["FETCH_SIZE"][1], out["WRITE_SIZE"][1])
 
 
+def concurrent_backends(index, device, qhost, queries, probes, k, args, dev):
+    """what a server looks like to the device: N backends, each with a context of its own (stream, scratch) and a
+    view of the same uploaded index.  (a) N backends (threads of a plain C driver), one query at a time each
+    (pgv_query_rank + pgv_query_scan, the amgettuple path); (b) two submitters of 1024-query batches on two streams."""
+    import ctypes as C
+    out = {"single_query": {}}
+    so = os.path.join(ROOT, "build", "tools", "libbackends.so")
+    src = os.path.join(ROOT, "tools", "backends_driver.c")
+    if not os.path.exists(so) or os.path.getmtime(so) < os.path.getmtime(src):
+        from pgvector_amd import _lib
+        os.makedirs(os.path.dirname(so), exist_ok=True)
+        libdir = os.path.dirname(_lib.LIB_PATH)
+        subprocess.run(["gcc", "-O2", "-shared", "-fPIC", "-pthread", "-I" + os.path.join(ROOT, "include"), src, "-o", so,
+                        "-L" + libdir, "-lpgv_hip", "-Wl,-rpath," + libdir], check=True)
+    drv = C.CDLL(so)
+    drv.backends_run.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_size_t, C.c_int, C.c_int,
+                                 C.POINTER(C.c_double)]
+    qh = np.ascontiguousarray(qhost)
+    res = (C.c_double * 3)()
+    for nb in (1, 2, 4, 8, 16, 32):
+        rc = drv.backends_run(index.h, device, nb, 400, qh.ctypes.data, qh.shape[0], qh.strides[0], probes, k, res)
+        if rc != 0:
+            out["single_query"][str(nb)] = {"error": "backends_run rc %d" % rc}
+            break
+        out["single_query"][str(nb)] = {"qps": res[0], "latency_us_p50": res[1], "latency_us_p90": res[2]}
+    out["single_query"]["driver"] = ("tools/backends_driver.c: pthreads over the C ABI, one pgv_ctx + pgv_index_share view + "
+                                     "pgv_query per backend, pgv_query_rank + pgv_query_scan per query")
+    # (b) batches from two submitters
+    ctx2 = api.Context(device)
+    v2 = index.share(ctx2)
+    bufs = [tuple(torch.empty((args.batch, k), device=dev, dtype=dt) for dt in (torch.float32, torch.int64, torch.int64))
+            for _ in range(2)]
+    handles = [index, v2]
+    pool = queries.shape[0]
+
+    def step(j):
+        handles[j % 2].search_batch(queries[j % pool][:args.batch], probes, k, want_tid=True, out=bufs[j % 2])
+    s = timed_steps(step, 40, warmup=4)
+    out["batches_from_two_submitters"] = {"qps": args.batch / s, "ms_per_batch": s * 1e3,
+                                          "note": "alternate %d-query batches on two contexts (two streams): the second "
+                                                  "one's ranking / planning / top-k run under the first one's scan" % args.batch}
+    v2.close()
+    ctx2.close()
+    return out
+
+
 def hnsw_section(ctx, dev, args, failures, rows=50_000, dim=1536, m=16, efc=64, ef=100, k=10, nq=2000):
     """vector_cosine_ops HNSW (src/hnswbuild.c:376-476 build loop, src/hnswscan.c:25-56 + src/hnswutils.c:824-987 scan):
     graph built on the GPU by pgv_host_hnsw_build, every scan's first batch walked on the device by pgv_hnsw_search.
@@ -710,6 +756,12 @@ def main():
             sweep[str(b)] = {"qps": b / s, "ms_per_step": s * 1e3}
         sweep[str(args.batch)] = {"qps": qps, "ms_per_step": elapsed / args.steps * 1e3}
         line["batch_sweep"] = sweep
+
+        # ---- several backends on ONE device mirror (pgv_index_share): each its own context = stream + scratch
+        try:
+            line["concurrent_backends"] = concurrent_backends(index, local_rank, qhost, queries, probes, k, args, dev)
+        except Exception as e:
+            line["concurrent_backends"] = {"error": repr(e)}
 
         psweep = {}
         for p in (1, 10, 32, 100):

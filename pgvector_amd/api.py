@@ -146,6 +146,17 @@ class IvfIndex:
         self.h = h
         ctx._adopt(self)
 
+    def share(self, ctx):
+        """a second handle for another context (its own stream and scratch) on the same device: pgv_index_share.
+        Close the views before the index they came from."""
+        v = IvfIndex.__new__(IvfIndex)
+        v.ctx, v.metric, v.dtype, v.dim, v.nlists = ctx, self.metric, self.dtype, self.dim, self.nlists
+        h = C.c_void_p()
+        check(lib.pgv_index_share(self.h, ctx.h, C.byref(h)))
+        v.h = h
+        ctx._adopt(v)
+        return v
+
     def close(self):
         if self.h:
             lib.pgv_index_free(self.h)

@@ -646,9 +646,26 @@ int pgv_index_upload(pgv_ctx *ctx, pgv_metric metric, pgv_dtype dtype, int dim, 
     return PGV_OK;
 }
 
+int pgv_index_share(pgv_index *ix, pgv_ctx *ctx, pgv_index **out) {
+    if (!ix || !ctx || !out) PGV_FAIL(PGV_ERR_ARG, "pgv_index_share: index/ctx/out is NULL");
+    *out = nullptr;
+    if (ctx->device != ix->ctx->device)
+        PGV_FAIL(PGV_ERR_ARG, "pgv_index_share: the index lives on device %d, the context on %d", ix->ctx->device, ctx->device);
+    pgv_index *v = new (std::nothrow) pgv_index(*ix);  // same device arrays, host tables copied
+    if (!v) PGV_FAIL(PGV_ERR_NOMEM, "out of host memory");
+    v->ctx = ctx;
+    v->view = true;
+    *out = v;
+    return PGV_OK;
+}
+
 void pgv_index_free(pgv_index *ix) {
     if (!ix) return;
     if (ix->ctx) (void)hipStreamSynchronize(ix->ctx->stream);
+    if (ix->view) {
+        delete ix;
+        return;
+    }
     if (ix->centers) (void)hipFree(ix->centers);
     if (ix->vectors) (void)hipFree(ix->vectors);
     if (ix->list_offsets) (void)hipFree(ix->list_offsets);

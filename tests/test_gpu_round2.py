@@ -612,3 +612,50 @@ def test_rank_lists_mfma_specials(ctx, oracle):
             wl, wd = oracle.get_scan_lists(ivf.struct, q, probes)
             assert_topk_equiv(got[i], gd[i], wl, wd, what="rank specials probes %d q %d" % (probes, i))
     ix.close()
+
+
+# ------------------------------------------------- one device mirror, several backends
+def test_index_shared_by_contexts_on_their_own_streams(ctx, oracle):
+    """pgv_index_share: a second context (own stream, own scratch) scans the same device arrays; batches and
+    single-query scans from two threads at once give the answers of the owner's serial scan"""
+    import threading
+    n, dim, lists, probes = 6000, 96, 30, 4
+    data = gen(n, dim, seed=441, dist="clustered", clusters=lists)
+    ivf = CpuIvf(oracle, po.OPS_L2, po.ORA_F32, data, lists)
+    ix = _upload(ctx, ivf)
+    queries = gen(400, dim, seed=442, dist="clustered", clusters=lists)
+    want_d, want_s, _ = ix.search_batch(queries, probes, 10, want_tid=True)
+    others = [api.Context(0) for _ in range(3)]   # streams of their own
+    views = [ix.share(c) for c in others]
+    got = [None] * len(views)
+    single = [None] * len(views)
+
+    def backend(i):
+        v = views[i]
+        for _ in range(5):
+            got[i] = v.search_batch(queries, probes, 10, want_tid=True)
+        qh = api.Query(v)
+        out = []
+        for q in queries[:60]:
+            qh.rank(q, probes)
+            d, s, t, total = qh.scan(0, probes, 10)
+            out.append((d.copy(), s.copy()))
+        qh.close()
+        single[i] = out
+    threads = [threading.Thread(target=backend, args=(i,)) for i in range(len(views))]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    for i in range(len(views)):
+        np.testing.assert_array_equal(got[i][1], want_s)
+        np.testing.assert_array_equal(got[i][0], want_d)
+        for j, (d, s) in enumerate(single[i]):
+            m = len(s)
+            assert_topk_equiv(s.tolist(), d, want_s[j][:m].tolist(), want_d[j][:m].astype(np.float64),
+                              what="shared index, backend %d query %d" % (i, j))
+    for v in views:
+        v.close()
+    for c in others:
+        c.close()
+    ix.close()
