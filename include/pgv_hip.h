@@ -193,8 +193,8 @@ void		pgv_index_free(pgv_index * index);
 /*
  * A second handle on an uploaded index for another context (= another backend's stream and scratch) on the same
  * device: many backends scan ONE device mirror concurrently, each on its own stream -- what shared_buffers is to
- * the reference's scans.  The index is read-only after upload, so no locking is involved.  The view shares the
- * owner's device arrays: free every view (pgv_index_free) before the index it came from.
+ * the reference's scans.  The index is read-only after upload, so no locking is involved.  The handles share the
+ * device arrays, which are released by the last pgv_index_free among them (in any order).
  */
 int			pgv_index_share(pgv_index * index, pgv_ctx * ctx, pgv_index * *out);
 int64_t		pgv_index_rows(const pgv_index * index);

@@ -148,7 +148,7 @@ class IvfIndex:
 
     def share(self, ctx):
         """a second handle for another context (its own stream and scratch) on the same device: pgv_index_share.
-        Close the views before the index they came from."""
+        The device arrays go with the last handle that is closed."""
         v = IvfIndex.__new__(IvfIndex)
         v.ctx, v.metric, v.dtype, v.dim, v.nlists = ctx, self.metric, self.dtype, self.dim, self.nlists
         h = C.c_void_p()

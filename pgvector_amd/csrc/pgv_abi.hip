@@ -567,6 +567,11 @@ int pgv_index_upload(pgv_ctx *ctx, pgv_metric metric, pgv_dtype dtype, int dim, 
     pgv_index *ix = new (std::nothrow) pgv_index();
     if (!ix) PGV_FAIL(PGV_ERR_NOMEM, "out of host memory");
     ix->ctx = ctx;
+    ix->refs = new (std::nothrow) int(1);
+    if (!ix->refs) {
+        delete ix;
+        PGV_FAIL(PGV_ERR_NOMEM, "out of host memory");
+    }
     ix->metric = metric;
     ix->dtype = dtype;
     ix->dim = dim;
@@ -654,15 +659,16 @@ int pgv_index_share(pgv_index *ix, pgv_ctx *ctx, pgv_index **out) {
     pgv_index *v = new (std::nothrow) pgv_index(*ix);  // same device arrays, host tables copied
     if (!v) PGV_FAIL(PGV_ERR_NOMEM, "out of host memory");
     v->ctx = ctx;
-    v->view = true;
+    __atomic_add_fetch(ix->refs, 1, __ATOMIC_RELAXED);
     *out = v;
     return PGV_OK;
 }
 
+// the device arrays go with the last handle on them (the uploaded index or a pgv_index_share view)
 void pgv_index_free(pgv_index *ix) {
     if (!ix) return;
     if (ix->ctx) (void)hipStreamSynchronize(ix->ctx->stream);
-    if (ix->view) {
+    if (ix->refs && __atomic_sub_fetch(ix->refs, 1, __ATOMIC_ACQ_REL) > 0) {
         delete ix;
         return;
     }
@@ -672,6 +678,7 @@ void pgv_index_free(pgv_index *ix) {
     if (ix->tids) (void)hipFree(ix->tids);
     if (ix->row_norms) (void)hipFree(ix->row_norms);
     if (ix->center_norms) (void)hipFree(ix->center_norms);
+    delete ix->refs;
     delete ix;
 }
 

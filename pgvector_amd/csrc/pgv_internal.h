@@ -144,7 +144,7 @@ struct pgv_index {
     uint64_t *tids = nullptr;         // device [nrows] or null
     float *row_norms = nullptr;       // device [nrows] |x|^2 then one word: bits of the largest (L2 indexes; the MFMA scan)
     float *center_norms = nullptr;    // the same for the centers [nlists + 1]
-    bool view = false;                // pgv_index_share: the device arrays belong to another pgv_index
+    int *refs = nullptr;              // handles (the uploaded index + its pgv_index_share views) on the device arrays
     std::vector<int64_t> h_offsets;   // host copy
     std::vector<int64_t> len_prefix;  // len_prefix[p] = rows in the p longest lists (output size bound)
     int64_t max_list_len = 0;

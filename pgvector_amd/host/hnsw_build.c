@@ -157,11 +157,21 @@ arena_alloc(arena * a, size_t bytes)
 	{
 		if (a->nbig == a->bigcap)
 		{
+			void	  **grown = realloc(a->big, sizeof(void *) * (size_t) (a->bigcap ? a->bigcap * 2 : 8));
+
+			if (!grown)
+				return NULL;
+			a->big = grown;
 			a->bigcap = a->bigcap ? a->bigcap * 2 : 8;
-			a->big = realloc(a->big, sizeof(void *) * (size_t) a->bigcap);
 		}
 		p = malloc(bytes);
-		a->big[a->nbig++] = p;
+		if (p && a->big)
+			a->big[a->nbig++] = p;
+		else
+		{
+			free(p);
+			p = NULL;
+		}
 		return p;
 	}
 	if (a->nchunks == 0 || a->used + bytes > ARENA_CHUNK)
@@ -170,8 +180,17 @@ arena_alloc(arena * a, size_t bytes)
 			a->cur++;
 		else
 		{
-			a->chunks = realloc(a->chunks, sizeof(char *) * (size_t) (a->nchunks + 1));
-			a->chunks[a->nchunks] = malloc(ARENA_CHUNK);
+			char	  **grown = realloc(a->chunks, sizeof(char *) * (size_t) (a->nchunks + 1));
+			char	   *chunk = malloc(ARENA_CHUNK);
+
+			if (grown)
+				a->chunks = grown;
+			if (!grown || !chunk)
+			{
+				free(chunk);
+				return NULL;
+			}
+			a->chunks[a->nchunks] = chunk;
 			a->cur = a->nchunks++;
 		}
 		a->used = 0;
@@ -505,6 +524,7 @@ pgv_host_hnsw_build(pgv_hnsw * mirror, pgv_dtype dtype, int dim, const void *row
 	float	   *grp_dist = NULL;
 	int64_t    *grp_off = NULL;
 	arena	   *arenas = NULL;	/* [nthreads] */
+	int			oom = 0;
 	int64_t    *tri_off = NULL;
 	int			nrec = 0;		/* records of the batch in flight (freed at its end, or on the way out) */
 	int			nthreads = omp_get_max_threads() < 16 ? omp_get_max_threads() : 16;	/* 32: twice as slow (measured) */
@@ -903,9 +923,16 @@ pgv_host_hnsw_build(pgv_hnsw * mirror, pgv_dtype dtype, int dim, const void *row
 
 				rcd->nstart = l->length;
 				rcd->nlocal = l->length + nnew;
-				rcd->ids = arena_alloc(&arenas[omp_get_thread_num()], sizeof(int32_t) * (size_t) rcd->nlocal);
-				rcd->newdist = grp_dist + grp_off[k];
 				rcd->mat = NULL;
+				rcd->ids = arena_alloc(&arenas[omp_get_thread_num()], sizeof(int32_t) * (size_t) rcd->nlocal);
+				if (!rcd->ids)
+				{
+#pragma omp atomic write
+					oom = 1;
+					rcd->nlocal = rcd->nstart = 0;
+					continue;
+				}
+				rcd->newdist = grp_dist + grp_off[k];
 				rcd->full = !l->closer_set;	/* no cached flags: its next selection computes everything */
 				rcd->blocked = 0;
 				rcd->wait_from = -1;
@@ -915,6 +942,11 @@ pgv_host_hnsw_build(pgv_hnsw * mirror, pgv_dtype dtype, int dim, const void *row
 					l->items[j].local = j;
 				}
 				memcpy(rcd->ids + l->length, grp_elem + grp_off[k], sizeof(int32_t) * (size_t) nnew);
+			}
+			if (oom)
+			{
+				rc = pgv_host_fail(PGV_ERR_NOMEM, "out of memory for the batch's list records");
+				goto done;
 			}
 		}
 		PHASE(PH_PAIRLIST);
@@ -1033,6 +1065,12 @@ pgv_host_hnsw_build(pgv_hnsw * mirror, pgv_dtype dtype, int dim, const void *row
 							if (rcd->nlocal > lm)
 							{
 								rcd->mat = arena_alloc(&arenas[omp_get_thread_num()], sizeof(float) * (size_t) rcd->nlocal * rcd->nlocal);
+								if (!rcd->mat)
+								{
+#pragma omp atomic write
+									oom = 1;
+									continue;
+								}
 								memset(rcd->mat, 0, sizeof(float) * (size_t) rcd->nlocal * rcd->nlocal);
 								if (rcd->full)
 									fill_matrix(rcd->mat, rcd->nlocal, pdist + rcd->pair0);
@@ -1105,6 +1143,11 @@ pgv_host_hnsw_build(pgv_hnsw * mirror, pgv_dtype dtype, int dim, const void *row
 			}
 		}
 
+		if (oom)
+		{
+			rc = pgv_host_fail(PGV_ERR_NOMEM, "out of memory for a list's distance matrix");
+			goto done;
+		}
 		PHASE(PH_PATCH);
 		/* ---- 6. the graph the next batch searches */
 		{

@@ -654,8 +654,11 @@ def test_index_shared_by_contexts_on_their_own_streams(ctx, oracle):
             m = len(s)
             assert_topk_equiv(s.tolist(), d, want_s[j][:m].tolist(), want_d[j][:m].astype(np.float64),
                               what="shared index, backend %d query %d" % (i, j))
+    # the device arrays go with the LAST handle: the uploaded index may be dropped first
+    ix.close()
+    d, s, _ = views[0].search_batch(queries, probes, 10, want_tid=True)
+    np.testing.assert_array_equal(s, want_s)
     for v in views:
         v.close()
     for c in others:
         c.close()
-    ix.close()
