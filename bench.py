@@ -363,8 +363,9 @@ def concurrent_backends(index, device, qhost, queries, probes, k, args, dev):
         from pgvector_amd import _lib
         os.makedirs(os.path.dirname(so), exist_ok=True)
         libdir = os.path.dirname(_lib.LIB_PATH)
-        subprocess.run(["gcc", "-O2", "-shared", "-fPIC", "-pthread", "-I" + os.path.join(ROOT, "include"), src, "-o", so,
-                        "-L" + libdir, "-lpgv_hip", "-Wl,-rpath," + libdir], check=True)
+        subprocess.run(["gcc", "-O2", "-shared", "-fPIC", "-pthread", "-I" + os.path.join(ROOT, "include"),
+                        "-I" + os.path.join(ROOT, "pgvector_amd", "host"), src, "-o", so,
+                        "-L" + libdir, "-lpgv_host", "-lpgv_hip", "-Wl,-rpath," + libdir], check=True)
     drv = C.CDLL(so)
     drv.backends_run.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_size_t, C.c_int, C.c_int,
                                  C.POINTER(C.c_double)]
@@ -378,6 +379,21 @@ def concurrent_backends(index, device, qhost, queries, probes, k, args, dev):
         out["single_query"][str(nb)] = {"qps": res[0], "latency_us_p50": res[1], "latency_us_p90": res[2]}
     out["single_query"]["driver"] = ("tools/backends_driver.c: pthreads over the C ABI, one pgv_ctx + pgv_index_share view + "
                                      "pgv_query per backend, pgv_query_rank + pgv_query_scan per query")
+    # (a') the same kind of clients behind the host glue's pooler (ivf_pool.c): one query each, batched on arrival
+    drv.pool_run.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_size_t,
+                             C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_double)]
+    res4 = (C.c_double * 4)()
+    out["pooled_single_query"] = {}
+    for nc in (16, 64, 256, 1024):
+        rc = drv.pool_run(index.h, device, index.dtype, index.dim, nc, max(40, 6000 // nc), qh.ctypes.data, qh.shape[0],
+                          qh.strides[0], probes, k, 1024, 50, 2, res4)
+        if rc != 0:
+            out["pooled_single_query"][str(nc)] = {"error": "pool_run rc %d" % rc}
+            break
+        out["pooled_single_query"][str(nc)] = {"qps": res4[0], "latency_us_p50": res4[1], "latency_us_p90": res4[2],
+                                               "mean_batch": res4[3]}
+    out["pooled_single_query"]["pool"] = ("pgv_host_pool_*: clients block in pgv_host_pool_search with one query each; "
+                                          "max_batch 1024, max_wait 50 us, 2 lanes (contexts); host buffers in and out")
     # (b) batches from two submitters
     ctx2 = api.Context(device)
     v2 = index.share(ctx2)

@@ -116,6 +116,13 @@ int			pgv_abi_version(void);
 
 /* number of HIP devices visible (0 when there is no GPU / no driver) */
 int			pgv_device_count(void);
+/*
+ * Page-locked host memory (hipHostMalloc) for buffers handed to the library again and again -- the lanes of
+ * the host glue's pooler (pgv_host_pool_*), a backend's query staging.  Plain host memory works everywhere
+ * too; pinned memory makes the copies in and out asynchronous and about twice as fast.
+ */
+int			pgv_pinned_alloc(size_t bytes, void **out);
+void		pgv_pinned_free(void *p);
 
 /*
  * Create the per-backend GPU context: lazily from _PG_init (src/vector.c:57-65)

@@ -80,6 +80,12 @@ def _load():
     lib.pgv_host_ivf_beginscan.argtypes = [P, C.POINTER(IvfImage), I, I, I, I, C.POINTER(P)]
     lib.pgv_host_ivf_rescan.argtypes = [P, P]
     lib.pgv_host_ivf_gettuple.argtypes = [P, C.POINTER(C.c_uint64), C.POINTER(C.c_double)]
+    lib.pgv_host_pool_create.argtypes = [P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(P)]
+    lib.pgv_host_pool_search.argtypes = [P, P, P, P]
+    lib.pgv_host_pool_stats.argtypes = [P, C.POINTER(C.c_int64), C.POINTER(C.c_int64)]
+    lib.pgv_host_pool_stats.restype = None
+    lib.pgv_host_pool_destroy.argtypes = [P]
+    lib.pgv_host_pool_destroy.restype = None
     lib.pgv_host_ivf_endscan.argtypes = [P]
     lib.pgv_host_ivf_endscan.restype = None
     lib.pgv_host_ivf_build.argtypes = [P, I, I, I, I, P, P, I64, P, I, P, C.POINTER(Rel)]
@@ -354,3 +360,32 @@ class IvfScan:
             self.close()
         except Exception:
             pass
+
+
+class Pool:
+    """pgv_host_pool_*: backends hand in one query each; arrivals within max_wait_us share one pgv_search_batch"""
+
+    def __init__(self, index, probes, k, max_batch=1024, max_wait_us=50, lanes=2, device=0):
+        self.k, self.dtype, self.dim = k, index.dtype, index.dim
+        h = C.c_void_p()
+        host_check(lib.pgv_host_pool_create(index.h, device, index.dtype, index.dim, probes, k, max_batch, max_wait_us,
+                                            lanes, C.byref(h)))
+        self.h = h
+
+    def search(self, query):
+        """blocking, thread-safe: (tids [k] uint64, distances [k] float32)"""
+        q = np.ascontiguousarray(query, dtype=_NP[self.dtype])
+        tid = np.empty(self.k, dtype=np.uint64)
+        dist = np.empty(self.k, dtype=np.float32)
+        host_check(lib.pgv_host_pool_search(self.h, q.ctypes.data, tid.ctypes.data, dist.ctypes.data))
+        return tid, dist
+
+    def stats(self):
+        b, q = C.c_int64(), C.c_int64()
+        lib.pgv_host_pool_stats(self.h, C.byref(b), C.byref(q))
+        return {"batches": b.value, "queries": q.value}
+
+    def close(self):
+        if self.h:
+            lib.pgv_host_pool_destroy(self.h)
+            self.h = None

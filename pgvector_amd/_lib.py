@@ -32,7 +32,7 @@ PGV_OPS_L2, PGV_OPS_IP, PGV_OPS_COSINE = 0, 1, 2
 # every symbol include/pgv_hip.h declares (tests check the library exports each)
 SYMBOLS = [
     "pgv_last_error", "pgv_abi_version", "pgv_device_count", "pgv_ctx_create", "pgv_ctx_destroy",
-    "pgv_ctx_sync", "pgv_ctx_stream", "pgv_timer_start", "pgv_timer_stop", "pgv_ctx_set_profiling", "pgv_ctx_set_exact_scan", "pgv_index_share",
+    "pgv_ctx_sync", "pgv_ctx_stream", "pgv_timer_start", "pgv_timer_stop", "pgv_ctx_set_profiling", "pgv_ctx_set_exact_scan", "pgv_index_share", "pgv_pinned_alloc", "pgv_pinned_free",
     "pgv_ctx_reset_stats", "pgv_ctx_get_stats", "pgv_index_upload", "pgv_index_free",
     "pgv_index_rows", "pgv_index_lists", "pgv_rank_lists", "pgv_scan_lists", "pgv_search_batch", "pgv_scan_batch",
     "pgv_assign", "pgv_kmeans", "pgv_lloyd_partial", "pgv_lloyd_finish", "pgv_kmeanspp_init",

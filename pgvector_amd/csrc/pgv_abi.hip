@@ -401,6 +401,21 @@ int pgv_device_count(void) {
     return n;
 }
 
+int pgv_pinned_alloc(size_t bytes, void **out) {
+    if (!out) PGV_FAIL(PGV_ERR_ARG, "pgv_pinned_alloc: out is NULL");
+    *out = nullptr;
+    if (pgv_device_count() <= 0) PGV_FAIL(PGV_ERR_DEVICE, "no HIP device available (libpgv_hip has no CPU path)");
+    if (hipHostMalloc(out, bytes ? bytes : 16, hipHostMallocDefault) != hipSuccess) {
+        (void)hipGetLastError();
+        PGV_FAIL(PGV_ERR_NOMEM, "hipHostMalloc(%zu) failed", bytes);
+    }
+    return PGV_OK;
+}
+
+void pgv_pinned_free(void *p) {
+    if (p) (void)hipHostFree(p);
+}
+
 int pgv_ctx_create(int device, void *stream, pgv_ctx **out) {
     if (!out) PGV_FAIL(PGV_ERR_ARG, "pgv_ctx_create: out is NULL");
     *out = nullptr;

@@ -231,6 +231,21 @@ int			pgv_host_ivf_beginscan(pgv_index * mirror, const pgv_ivf_image * img, int 
 /* amrescan: a new ORDER BY value (NULL = SQL NULL: every tuple at distance 0, :192-196) */
 int			pgv_host_ivf_rescan(pgv_ivf_scan * scan, const void *query);
 int			pgv_host_ivf_gettuple(pgv_ivf_scan * scan, uint64_t *out_tid, double *out_distance);
+
+/*
+ * A pooler in front of the batched scan (ivf_pool.c): backends hand in one query each (what ivfflatgettuple's
+ * caller has, src/ivfscan.c:361-414) and block; queries that arrive within max_wait_us of a batch's first one, or
+ * until max_batch are waiting, share one pgv_search_batch -- every pass over a probed list serves all of them.
+ * `lanes` batches are in flight at once (a context + pgv_index_share view + pinned buffers each).  Thread-safe.
+ *   out_tid / out_dist [k]: the head of GetScanItems + tuplesort for this query, padded with ~0 / +inf
+ */
+typedef struct pgv_pool pgv_pool;
+int			pgv_host_pool_create(pgv_index * index, int device, pgv_dtype dtype, int dim, int probes, int k,
+								 int max_batch, int max_wait_us, int lanes, pgv_pool * *out);
+int			pgv_host_pool_search(pgv_pool * pool, const void *query, uint64_t *out_tid, float *out_dist);
+void		pgv_host_pool_stats(pgv_pool * pool, int64_t *batches, int64_t *queries);
+void		pgv_host_pool_destroy(pgv_pool * pool);
+
 void		pgv_host_ivf_endscan(pgv_ivf_scan * scan);
 
 /*

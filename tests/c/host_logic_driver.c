@@ -393,12 +393,117 @@ test_ivf(void)
 	return 0;
 }
 
+/* ------------------------------------------------------------------ the pooler (ivf_pool.c) under threads */
+#include <pthread.h>
+
+typedef struct
+{
+	pgv_pool   *pool;
+	const float *queries;
+	int			dim,
+				nq,
+				k,
+				id,
+				nthreads;
+	uint64_t   *tid;			/* [nq x k] */
+	float	   *dist;
+	int			rc;
+}			pool_client;
+
+static void *
+pool_client_main(void *arg)
+{
+	pool_client *c = arg;
+
+	for (int round = 0; round < 3 && c->rc == PGV_OK; round++)
+		for (int j = c->id; j < c->nq && c->rc == PGV_OK; j += c->nthreads)
+			c->rc = pgv_host_pool_search(c->pool, c->queries + (size_t) j * c->dim, c->tid + (size_t) j * c->k,
+										 c->dist + (size_t) j * c->k);
+	return NULL;
+}
+
+static int
+test_pool(void)
+{
+	enum
+	{
+		N = 600, DIM = 8, LISTS = 6, NQ = 96, K = 5, THREADS = 12
+	};
+	float	   *rows = malloc(sizeof(float) * N * DIM),
+			   *centers = malloc(sizeof(float) * LISTS * DIM),
+			   *queries = malloc(sizeof(float) * NQ * DIM);
+	int64_t		off[LISTS + 1];
+	uint64_t   *tids = malloc(sizeof(uint64_t) * N);
+	uint64_t   *want_t = malloc(sizeof(uint64_t) * NQ * K),
+			   *got_t = malloc(sizeof(uint64_t) * NQ * K);
+	float	   *want_d = malloc(sizeof(float) * NQ * K),
+			   *got_d = malloc(sizeof(float) * NQ * K);
+	pgv_ctx    *ctx;
+	pgv_index  *ix;
+	pgv_pool   *pool;
+	pthread_t	th[THREADS];
+	pool_client cl[THREADS];
+	int64_t		batches,
+				nqueries;
+	unsigned	seed = 12345;
+
+	for (int i = 0; i < N * DIM; i++)
+		rows[i] = (float) (rand_r(&seed) % 1000) / 100.0f;
+	for (int i = 0; i < LISTS * DIM; i++)
+		centers[i] = (float) (rand_r(&seed) % 1000) / 100.0f;
+	for (int i = 0; i < NQ * DIM; i++)
+		queries[i] = (float) (rand_r(&seed) % 1000) / 100.0f;
+	for (int l = 0; l <= LISTS; l++)
+		off[l] = (int64_t) l * (N / LISTS);
+	for (int i = 0; i < N; i++)
+		tids[i] = 7000 + (uint64_t) i;
+	CHECK(pgv_ctx_create(0, NULL, &ctx));
+	CHECK(pgv_index_upload(ctx, PGV_L2SQ, PGV_F32, DIM, LISTS, centers, off, rows, tids, &ix));
+	CHECK(pgv_search_batch(ix, queries, NQ, 2, K, want_d, NULL, want_t));
+	/* small batches, short wait, two lanes: leaders, followers, full and timed-out batches, lanes handed on */
+	CHECK(pgv_host_pool_create(ix, 0, PGV_F32, DIM, 2, K, 5, 300, 2, &pool));
+	for (int t = 0; t < THREADS; t++)
+	{
+		cl[t] = (pool_client) {pool, queries, DIM, NQ, K, t, THREADS, got_t, got_d, PGV_OK};
+		pthread_create(&th[t], NULL, pool_client_main, &cl[t]);
+	}
+	for (int t = 0; t < THREADS; t++)
+	{
+		pthread_join(th[t], NULL);
+		EXPECT(cl[t].rc == PGV_OK);
+	}
+	pgv_host_pool_stats(pool, &batches, &nqueries);
+	EXPECT(nqueries == 3 * NQ && batches >= 3 * NQ / 5 && batches < 3 * NQ);
+	EXPECT(memcmp(got_t, want_t, sizeof(uint64_t) * NQ * K) == 0);
+	EXPECT(memcmp(got_d, want_d, sizeof(float) * NQ * K) == 0);
+	/* one backend alone: a batch of one after the wait */
+	CHECK(pgv_host_pool_search(pool, queries, got_t, got_d));
+	EXPECT(memcmp(got_t, want_t, sizeof(uint64_t) * K) == 0);
+	/* the views keep the arrays alive: drop the uploaded handle first */
+	pgv_index_free(ix);
+	CHECK(pgv_host_pool_search(pool, queries + DIM, got_t, got_d));
+	EXPECT(memcmp(got_t, want_t + K, sizeof(uint64_t) * K) == 0);
+	pgv_host_pool_destroy(pool);
+	pgv_ctx_destroy(ctx);
+	free(rows);
+	free(centers);
+	free(queries);
+	free(tids);
+	free(want_t);
+	free(got_t);
+	free(want_d);
+	free(got_d);
+	return 0;
+}
+
 int
 main(void)
 {
 	if (test_hnsw_build())
 		return 1;
 	if (test_ivf())
+		return 1;
+	if (test_pool())
 		return 1;
 	printf("HOST-LOGIC OK\n");
 	return 0;

@@ -45,6 +45,8 @@ struct pgv_index
 	float	   *centers,
 			   *vectors;
 	int64_t    *offsets;
+	uint64_t   *tids;
+	int		   *refs;			/* pgv_index_share: handles on the same arrays */
 };
 
 struct pgv_hnsw
@@ -103,10 +105,16 @@ pgv_index_upload(pgv_ctx * ctx, pgv_metric metric, pgv_dtype dtype, int dim, int
 	int64_t		n = list_offsets[nlists];
 
 	(void) ctx;
-	(void) tids;
 	if (dtype != PGV_F32)
 		return fail(PGV_ERR_ARG, "mock: fp32 only");
 	ix = calloc(1, sizeof(*ix));
+	ix->refs = malloc(sizeof(int));
+	*ix->refs = 1;
+	if (tids)
+	{
+		ix->tids = malloc(sizeof(uint64_t) * (size_t) (n > 0 ? n : 1));
+		memcpy(ix->tids, tids, sizeof(uint64_t) * (size_t) n);
+	}
 	ix->metric = metric;
 	ix->dim = dim;
 	ix->nlists = nlists;
@@ -121,11 +129,43 @@ pgv_index_upload(pgv_ctx * ctx, pgv_metric metric, pgv_dtype dtype, int dim, int
 	return PGV_OK;
 }
 
+int
+pgv_index_share(pgv_index * ix, pgv_ctx * ctx, pgv_index * *out)
+{
+	pgv_index  *v = malloc(sizeof(*v));
+
+	(void) ctx;
+	*v = *ix;
+	__atomic_add_fetch(ix->refs, 1, __ATOMIC_RELAXED);
+	*out = v;
+	return PGV_OK;
+}
+
+int
+pgv_pinned_alloc(size_t bytes, void **out)
+{
+	*out = malloc(bytes ? bytes : 16);
+	return *out ? PGV_OK : fail(PGV_ERR_NOMEM, "mock: out of memory");
+}
+
+void
+pgv_pinned_free(void *p)
+{
+	free(p);
+}
+
 void
 pgv_index_free(pgv_index * ix)
 {
 	if (!ix)
 		return;
+	if (__atomic_sub_fetch(ix->refs, 1, __ATOMIC_ACQ_REL) > 0)
+	{
+		free(ix);
+		return;
+	}
+	free(ix->refs);
+	free(ix->tids);
 	free(ix->centers);
 	free(ix->vectors);
 	free(ix->offsets);
@@ -183,6 +223,44 @@ pgv_scan_lists(pgv_index * ix, const void *query, const int32_t *lists, int nlis
 			out_slot[m] = r;
 			out_dist[m] = query ? dist(ix->metric, ix->dim, ix->vectors + (size_t) r * ix->dim, (const float *) query) : 0.0f;
 		}
+	return PGV_OK;
+}
+
+/* GetScanLists + GetScanItems + the head of the ascending sort for every query (stable: stream order on ties) */
+int
+pgv_search_batch(pgv_index * ix, const void *queries, int nq, int probes, int k, float *out_dist, int64_t *out_slot,
+				 uint64_t *out_tid)
+{
+	int32_t    *lists = malloc(sizeof(int32_t) * (size_t) probes);
+	float	   *d = malloc(sizeof(float) * (size_t) (ix->n > 0 ? ix->n : 1));
+	int64_t    *s = malloc(sizeof(int64_t) * (size_t) (ix->n > 0 ? ix->n : 1));
+
+	for (int q = 0; q < nq; q++)
+	{
+		const float *qv = (const float *) queries + (size_t) q * ix->dim;
+		int64_t		m;
+
+		pgv_rank_lists(ix, qv, 1, probes, lists, NULL);
+		pgv_scan_lists(ix, qv, lists, probes, d, s, ix->n, &m);
+		for (int r = 0; r < k; r++)
+		{
+			int64_t		best = -1;
+
+			for (int64_t i = 0; i < m; i++)
+				if (s[i] >= 0 && (best < 0 || d[i] < d[best]))
+					best = i;
+			out_dist[(size_t) q * k + r] = best >= 0 ? d[best] : INFINITY;
+			if (out_slot)
+				out_slot[(size_t) q * k + r] = best >= 0 ? s[best] : -1;
+			if (out_tid)
+				out_tid[(size_t) q * k + r] = best >= 0 && ix->tids ? ix->tids[s[best]] : ~(uint64_t) 0;
+			if (best >= 0)
+				s[best] = -1 - s[best];	/* taken */
+		}
+	}
+	free(lists);
+	free(d);
+	free(s);
 	return PGV_OK;
 }
 

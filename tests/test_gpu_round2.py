@@ -662,3 +662,47 @@ def test_index_shared_by_contexts_on_their_own_streams(ctx, oracle):
         v.close()
     for c in others:
         c.close()
+
+
+def test_pooler_batches_backends_and_answers_like_search_batch(ctx, oracle):
+    """pgv_host_pool_*: 24 threads hand in one query each, again and again; every answer is the row
+    pgv_search_batch gives for that query (= GetScanItems + tuplesort, checked against the oracle above), and the
+    queries did travel in batches"""
+    import threading
+    from pgvector_amd import _host
+    n, dim, lists, probes, k = 6000, 96, 30, 4, 10
+    data = gen(n, dim, seed=451, dist="clustered", clusters=lists)
+    ivf = CpuIvf(oracle, po.OPS_L2, po.ORA_F32, data, lists)
+    ix = _upload(ctx, ivf)
+    queries = gen(240, dim, seed=452, dist="clustered", clusters=lists)
+    want_d, _, want_t = ix.search_batch(queries, probes, k, want_tid=True)
+    for i in (0, 17, 101):   # the batched rows are the reference's
+        wt, wd = oracle.search(ivf.struct, queries[i], probes, k)
+        assert_topk_equiv(want_t[i].tolist(), want_d[i], wt.tolist(), wd, what="pool baseline q %d" % i)
+    pool = _host.Pool(ix, probes, k, max_batch=16, max_wait_us=200, lanes=2)
+    got = {}
+    errors = []
+
+    def backend(t):
+        try:
+            for j in range(t, len(queries), 24):
+                got[j] = pool.search(queries[j])
+        except Exception as e:  # noqa: BLE001
+            errors.append(e)
+    threads = [threading.Thread(target=backend, args=(t,)) for t in range(24)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    assert not errors, errors
+    st = pool.stats()
+    assert st["queries"] == len(queries) and st["batches"] < len(queries), st
+    for j in range(len(queries)):
+        tid, dist = got[j]
+        # a query may run in a batch small enough for the exact kernels or in one the MFMA path takes: same head
+        assert_topk_equiv(tid.tolist(), dist, want_t[j].tolist(), want_d[j].astype(np.float64), what="pool q %d" % j)
+    # one query alone in its batch
+    tid, dist = pool.search(queries[3])
+    assert_topk_equiv(tid.tolist(), dist, want_t[3].tolist(), want_d[3].astype(np.float64), what="pool single")
+    pool.close()
+    ix.close()

@@ -17,7 +17,7 @@ def test_host_logic_against_the_mock_device(tmp_path):
     subprocess.run(["gcc", "-O1", "-Wall", "-rdynamic", "-I", os.path.join(ROOT, "include"),
                     "-I", os.path.join(ROOT, "pgvector_amd", "host"), "-I", oradir,
                     os.path.join(ROOT, "tests", "c", "host_logic_driver.c"), os.path.join(ROOT, "tests", "c", "mock_hip.c"),
-                    "-o", exe, "-L", libdir, "-lpgv_host", "-L", oradir, "-loracle", "-lm",
+                    "-o", exe, "-L", libdir, "-lpgv_host", "-L", oradir, "-loracle", "-lm", "-lpthread",
                     "-Wl,-rpath," + libdir, "-Wl,-rpath," + oradir], check=True)
     r = subprocess.run([exe], capture_output=True, text=True, timeout=300)
     assert r.returncode == 0 and "HOST-LOGIC OK" in r.stdout, (r.returncode, r.stdout[-500:], r.stderr[-2000:])

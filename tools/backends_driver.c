@@ -12,6 +12,7 @@
 #include <time.h>
 
 #include "pgv_hip.h"
+#include "pgv_host.h"
 
 typedef struct
 {
@@ -148,5 +149,121 @@ backends_run(pgv_index * index, int device, int nbackends, int per_thread, const
 	free(lat);
 	free(th);
 	free(b);
+	return rc;
+}
+
+
+/* ---------------------------------------------------------------- the same clients behind the pooler (ivf_pool.c) */
+typedef struct
+{
+	pgv_pool   *pool;
+	int			id;
+	int			per_thread;
+	const char *queries;
+	int			nq;
+	size_t		query_bytes;
+	int			k;
+	pthread_barrier_t *start;
+	double	   *lat;
+	double		t0,
+				t1;
+	int			rc;
+}			client;
+
+static void *
+client_main(void *arg)
+{
+	client	   *c = arg;
+	uint64_t	tid[64];
+	float		dist[64];
+
+	for (int j = 0; j < 5 && c->rc == PGV_OK; j++)
+		c->rc = pgv_host_pool_search(c->pool, c->queries + (size_t) ((c->id * 7 + j) % c->nq) * c->query_bytes, tid, dist);
+	pthread_barrier_wait(c->start);
+	c->t0 = now();
+	for (int j = 0; j < c->per_thread && c->rc == PGV_OK; j++)
+	{
+		double		t = now();
+
+		c->rc = pgv_host_pool_search(c->pool, c->queries + (size_t) ((c->id * 31 + j) % c->nq) * c->query_bytes, tid, dist);
+		c->lat[j] = now() - t;
+	}
+	c->t1 = now();
+	return NULL;
+}
+
+/* out[0] = queries/s over all clients, out[1] = p50, out[2] = p90 latency (us), out[3] = mean batch size */
+int
+pool_run(pgv_index * index, int device, int dtype, int dim, int nclients, int per_thread, const void *queries, int nq,
+		 size_t query_bytes, int probes, int k, int max_batch, int max_wait_us, int lanes, double *out)
+{
+	pgv_pool   *pool = NULL;
+	client	   *c;
+	pthread_t  *th;
+	double	   *lat;
+	pthread_barrier_t start;
+	pthread_attr_t attr;
+	double		first = 1e300,
+				last = 0;
+	int64_t		batches0,
+				queries0,
+				batches1,
+				queries1;
+	int			rc;
+
+	if (k > 64)
+		k = 64;
+	rc = pgv_host_pool_create(index, device, (pgv_dtype) dtype, dim, probes, k, max_batch, max_wait_us, lanes, &pool);
+	if (rc != PGV_OK)
+		return rc;
+	c = calloc((size_t) nclients, sizeof(client));
+	th = calloc((size_t) nclients, sizeof(pthread_t));
+	lat = malloc(sizeof(double) * (size_t) nclients * per_thread);
+	pthread_barrier_init(&start, NULL, (unsigned) nclients + 1);
+	pthread_attr_init(&attr);
+	pthread_attr_setstacksize(&attr, 256 * 1024);
+	for (int i = 0; i < nclients; i++)
+	{
+		c[i].pool = pool;
+		c[i].id = i;
+		c[i].per_thread = per_thread;
+		c[i].queries = queries;
+		c[i].nq = nq;
+		c[i].query_bytes = query_bytes;
+		c[i].k = k;
+		c[i].start = &start;
+		c[i].lat = lat + (size_t) i * per_thread;
+		pthread_create(&th[i], &attr, client_main, &c[i]);
+	}
+	pgv_host_pool_stats(pool, &batches0, &queries0);	/* (the warm-up rounds are still running: an estimate) */
+	pthread_barrier_wait(&start);
+	pgv_host_pool_stats(pool, &batches0, &queries0);
+	for (int i = 0; i < nclients; i++)
+	{
+		pthread_join(th[i], NULL);
+		if (c[i].rc != PGV_OK && rc == PGV_OK)
+			rc = c[i].rc;
+		if (c[i].t0 < first)
+			first = c[i].t0;
+		if (c[i].t1 > last)
+			last = c[i].t1;
+	}
+	pgv_host_pool_stats(pool, &batches1, &queries1);
+	pthread_attr_destroy(&attr);
+	pthread_barrier_destroy(&start);
+	if (rc == PGV_OK)
+	{
+		size_t		n = (size_t) nclients * per_thread;
+
+		qsort(lat, n, sizeof(double), cmp_double);
+		out[0] = (double) n / (last - first);
+		out[1] = lat[n / 2] * 1e6;
+		out[2] = lat[n * 9 / 10] * 1e6;
+		out[3] = batches1 > batches0 ? (double) (queries1 - queries0) / (double) (batches1 - batches0) : 0.0;
+	}
+	pgv_host_pool_destroy(pool);
+	free(lat);
+	free(th);
+	free(c);
 	return rc;
 }
