@@ -616,7 +616,14 @@ __global__ __launch_bounds__(NW * 64) void mfma_scan_kernel(
     __syncthreads();
     for (;;) {
         const int t = lds_task;
-        if (t >= ntasks) return;
+        if (t >= ntasks) {
+            // the last workgroup out leaves the two words zero for the next launch (no memset in front of it)
+            if (threadIdx.x == 0 && atomicAdd(task_counter + 1, 1) == (int)gridDim.x - 1) {
+                task_counter[0] = 0;
+                task_counter[1] = 0;
+            }
+            return;
+        }
         // the task after this one is claimed now: its round trip runs under this task's streaming
         int next = 0;
         if (threadIdx.x == 0) next = atomicAdd(task_counter, 1);
@@ -820,8 +827,11 @@ int launch_mfma_scan(pgv_ctx *ctx, pgv_metric metric, pgv_dtype dtype, const Row
         PGV_HIP(hipMemsetAsync(ctx->zeros.p, 0, 256, ctx->stream));
     }
     PGV_TRY(ctx->counters.ensure(256));
-    int *counter = ctx->counters.as<int>();
-    PGV_HIP(hipMemsetAsync(counter, 0, sizeof(int), ctx->stream));
+    if (!ctx->counters_clean) {
+        PGV_HIP(hipMemsetAsync(ctx->counters.p, 0, 256, ctx->stream));
+        ctx->counters_clean = true;
+    }
+    int *counter = ctx->counters.as<int>() + 8;  // words 8, 9: claimed tasks, workgroups done (the kernel re-zeroes them)
     int grid = ctx->num_cus * 3;  // 41 KB of LDS per workgroup: three per CU
     if (grid > ntasks_bound) grid = ntasks_bound;
 #define PGV_MSCAN(T, M)                                                                                              \

@@ -303,35 +303,47 @@ int dense_scan(pgv_ctx *ctx, pgv_metric metric, pgv_dtype dtype, const RowGeom &
     if (ntasks > 0x7fffffff) PGV_FAIL(PGV_ERR_ARG, "scan: too many tasks");
 
     const size_t tb = sizeof(ScanTask) * (size_t)ntasks, pb = sizeof(ScanPair) * (size_t)nq;
-    PGV_TRY(staging_acquire(ctx));
-    PGV_TRY(ctx->h_a.ensure(tb + pb + 16));
-    ScanTask *ht = ctx->h_a.as<ScanTask>();
-    ScanPair *hp = reinterpret_cast<ScanPair *>(reinterpret_cast<char *>(ht) + tb);
-    int *hn = reinterpret_cast<int *>(reinterpret_cast<char *>(hp) + pb);
-    for (int q = 0; q < nq; q++) {
-        hp[q].out_rel = (int64_t)q * out_stride;
-        hp[q].query = q;
-        hp[q].pad = 0;
-    }
-    int64_t t = 0;
-    for (int64_t c = 0; c < nchunks; c++)
-        for (int gidx = 0; gidx < ngroups; gidx++) {
-            ht[t].row0 = c * ch;
-            int64_t left = nrows - c * ch;
-            ht[t].nrows = (int)(left < ch ? left : ch);
-            ht[t].pair0 = gidx * qt;
-            int pl = nq - gidx * qt;
-            ht[t].npairs = pl < qt ? pl : qt;
-            ht[t].pad = 0;
-            t++;
+    // the MFMA plan depends on (rows, queries, stride) only: a batch loop repeats it, so it stays on the device
+    DBuf &plan_buf = mfma ? ctx->dense_plan : ctx->tasks;
+    const bool cached = mfma && ctx->dense_plan.p && ctx->dense_plan_rows == nrows && ctx->dense_plan_nq == nq &&
+                        ctx->dense_plan_stride == out_stride;
+    if (!cached) {
+        PGV_TRY(staging_acquire(ctx));
+        PGV_TRY(ctx->h_a.ensure(tb + pb + 16));
+        ScanTask *ht = ctx->h_a.as<ScanTask>();
+        ScanPair *hp = reinterpret_cast<ScanPair *>(reinterpret_cast<char *>(ht) + tb);
+        int *hn = reinterpret_cast<int *>(reinterpret_cast<char *>(hp) + pb);
+        for (int q = 0; q < nq; q++) {
+            hp[q].out_rel = (int64_t)q * out_stride;
+            hp[q].query = q;
+            hp[q].pad = 0;
         }
-    *hn = (int)ntasks;
-    PGV_TRY(ctx->tasks.ensure(tb + pb + 16));
-    PGV_HIP(hipMemcpyAsync(ctx->tasks.p, ht, tb + pb + 16, hipMemcpyHostToDevice, ctx->stream));
-    PGV_TRY(staging_release(ctx));
-    const ScanTask *dt = ctx->tasks.as<ScanTask>();
-    const ScanPair *dp = reinterpret_cast<const ScanPair *>(ctx->tasks.as<char>() + tb);
-    const int *dn = reinterpret_cast<const int *>(ctx->tasks.as<char>() + tb + pb);
+        int64_t t = 0;
+        for (int64_t c = 0; c < nchunks; c++)
+            for (int gidx = 0; gidx < ngroups; gidx++) {
+                ht[t].row0 = c * ch;
+                int64_t left = nrows - c * ch;
+                ht[t].nrows = (int)(left < ch ? left : ch);
+                ht[t].pair0 = gidx * qt;
+                int pl = nq - gidx * qt;
+                ht[t].npairs = pl < qt ? pl : qt;
+                ht[t].pad = 0;
+                t++;
+            }
+        *hn = (int)ntasks;
+        if (mfma) ctx->dense_plan_rows = -1;  // (not valid while it is being replaced)
+        PGV_TRY(plan_buf.ensure(tb + pb + 16));
+        PGV_HIP(hipMemcpyAsync(plan_buf.p, ht, tb + pb + 16, hipMemcpyHostToDevice, ctx->stream));
+        PGV_TRY(staging_release(ctx));
+        if (mfma) {
+            ctx->dense_plan_rows = nrows;
+            ctx->dense_plan_nq = nq;
+            ctx->dense_plan_stride = out_stride;
+        }
+    }
+    const ScanTask *dt = plan_buf.as<ScanTask>();
+    const ScanPair *dp = reinterpret_cast<const ScanPair *>(plan_buf.as<char>() + tb);
+    const int *dn = reinterpret_cast<const int *>(plan_buf.as<char>() + tb + pb);
 
     ScanTimer timer{ctx};
     PGV_TRY(timer.begin((double)nrows * nq, (double)nrows * ngroups, true));
@@ -461,7 +473,7 @@ void pgv_ctx_destroy(pgv_ctx *ctx) {
                  &ctx->plan_a, &ctx->plan_b, &ctx->plan_c, &ctx->plan_d, &ctx->dist_mat,
                  &ctx->sel_a, &ctx->sel_b, &ctx->km_a, &ctx->km_b, &ctx->km_c, &ctx->km_d,
                  &ctx->km_e, &ctx->km_f, &ctx->km_g, &ctx->stats_dev, &ctx->mf_a, &ctx->mf_b, &ctx->mf_c,
-                 &ctx->zeros, &ctx->ms_a, &ctx->ms_b};
+                 &ctx->zeros, &ctx->ms_a, &ctx->ms_b, &ctx->dense_plan};
     for (DBuf *b : d) b->release();
     ctx->h_a.release();
     ctx->h_b.release();
@@ -728,6 +740,7 @@ static float expansion_gamma(int dim) { return 8.f * std::sqrt((float)dim + 4.f)
 static int rank_lists_dev(pgv_index *ix, const void *q_dev, int nq, int maxprobes,
                           int32_t *out_lists_dev, float *out_dist_dev) {
     pgv_ctx *ctx = ix->ctx;
+    ctx->qnorm_of = nullptr;
     // distance matrix [nq x nlists], then the maxprobes smallest per row
     PGV_TRY(ctx->dist_mat.ensure(sizeof(float) * (size_t)nq * ix->nlists));
     float *mat = ctx->dist_mat.as<float>();
@@ -748,6 +761,8 @@ static int rank_lists_dev(pgv_index *ix, const void *q_dev, int nq, int maxprobe
         ApproxScratch sc;
         PGV_TRY(sc.carve(ctx, ctx->ms_b, nq, cand));
         PGV_TRY(launch_row_norms(ctx, ix->dtype, ix->geom, q_dev, nq, sc.qnorm, nullptr));
+        ctx->qnorm_of = q_dev;  // the list scan of the same call reuses them (pgv_search_batch)
+        ctx->qnorm_n = nq;
         PGV_TRY(dense_scan(ctx, ix->metric, ix->dtype, ix->geom, ix->centers, ix->nlists, q_dev, nq, ix->nlists, mat,
                            true, ix->center_norms, sc.qnorm));
         PGV_TRY(launch_topk_segments(ctx, mat, nullptr, nq, ix->nlists, cand, sc.cand_val, sc.cand_pos));
@@ -783,6 +798,7 @@ int pgv_rank_lists(pgv_index *ix, const void *queries, int nq, int maxprobes, in
     PGV_TRY(ol.init(out_lists, sizeof(int32_t) * (size_t)nq * maxprobes, ctx->out_stage));
     PGV_TRY(od.init(out_dist, sizeof(float) * (size_t)nq * maxprobes, ctx->out_stage2));
     PGV_TRY(rank_lists_dev(ix, q_dev, nq, maxprobes, ol.as<int32_t>(), od.as<float>()));
+    ctx->qnorm_of = nullptr;  // the norms' reuse is for the scan of the same pgv_search_batch call only
     bool need = false;
     PGV_TRY(ol.finish(ctx, &need));
     PGV_TRY(od.finish(ctx, &need));
@@ -909,8 +925,12 @@ static int scan_batch_dev(pgv_index *ix, const void *q_dev, int nq, const int32_
     if (approx) {
         kprime = k <= 8 ? 32 : 4 * k;  // 32 .. 256: the head asked for and a margin the rounding bound clears easily
         PGV_TRY(sc.carve(ctx, ctx->ms_a, nq, kprime));
-        PGV_TRY(launch_row_norms(ctx, ix->dtype, ix->geom, q_dev, nq, sc.qnorm, nullptr));
+        if (ctx->qnorm_of == q_dev && ctx->qnorm_n == nq && ctx->ms_b.p)
+            sc.qnorm = ctx->ms_b.as<float>();  // computed by this call's center ranking
+        else
+            PGV_TRY(launch_row_norms(ctx, ix->dtype, ix->geom, q_dev, nq, sc.qnorm, nullptr));
     }
+    ctx->qnorm_of = nullptr;
     float *qnorm = sc.qnorm, *cand_val = sc.cand_val;
     int64_t *cand_pos = sc.cand_pos, *cand_slot = sc.cand_slot;
     int32_t *flags = sc.flags;
@@ -1002,6 +1022,7 @@ int pgv_scan_batch(pgv_index *ix, const void *queries, int nq, const int32_t *pr
     if (nq == 0) return PGV_OK;
     if (!probe_lists) PGV_FAIL(PGV_ERR_ARG, "probe_lists is NULL");
     pgv_ctx *ctx = ix->ctx;
+    ctx->qnorm_of = nullptr;
     PGV_HIP(hipSetDevice(ctx->device));
     // the planner indexes list_offsets with these ids: host-side lists are checked here; lists that are
     // already on the device must come from pgv_rank_lists (ids in range, distinct per query)
@@ -1970,6 +1991,7 @@ int pgv_search_batch_sharded(pgv_comm *cm, pgv_index *ix, const void *queries, i
     if (hi > lo)
         PGV_TRY(rank_lists_dev(ix, static_cast<const char *>(q_dev) + (size_t)lo * row_bytes, hi - lo, probes, lists_mine,
                                nullptr));
+    ctx->qnorm_of = nullptr;
     PGV_TRY(comm_all_gather(cm, lists_mine, lists_all, slice_bytes));
 
     // GetScanItems: the probed lists this rank owns, for the whole batch

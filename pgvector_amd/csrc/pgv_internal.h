@@ -107,6 +107,12 @@ struct pgv_ctx {
     pgv::DBuf tasks, pairs, counters, plan_a, plan_b, plan_c, plan_d, dist_mat, sel_a, sel_b;
     pgv::DBuf km_a, km_b, km_c, km_d, km_e, km_f, km_g;
     pgv::DBuf ms_b;  // MFMA center ranking: the same scratch as ms_a
+    pgv::DBuf dense_plan;  // the last dense (every row x every query) MFMA task list, reused while its shape repeats
+    int64_t dense_plan_rows = -1, dense_plan_stride = -1;
+    int dense_plan_nq = -1;
+    bool counters_clean = false;  // ctx->counters starts zeroed; mfma_scan_kernel leaves its words zero again
+    const void *qnorm_of = nullptr;  // queries whose |q|^2 (qnorm_n of them) sit at the head of ms_b: one API call's span
+    int qnorm_n = 0;
     pgv::DBuf ms_a;  // MFMA list scan: query norms | candidate values, positions, slots | flags
     pgv::DBuf mf_a, mf_b, mf_c, zeros;  // MFMA assignment: norms, pre-filter candidates, redo list; 16 zero bytes
     pgv::DBuf stats_dev;  // profiling: {pairs, rows streamed} of the batched list scans, as doubles
