@@ -499,6 +499,18 @@ int			pgv_hnsw_build_search(pgv_hnsw * h, const int32_t *elements, const int32_t
  * batched over every pair a batch of inserts can need.
  */
 int			pgv_hnsw_score_pairs(pgv_hnsw * h, const int32_t *a, const int32_t *b, int64_t npairs, float *out);
+/*
+ * The same distances for pairs given as GROUPS (the lists a batch of inserts touches): group g holds the
+ * element slots ids[ids_start[g] .. ids_start[g + 1]) = its locals 0 .. n-1 and asks for the pairs (u, v), v < u,
+ * of the locals u >= from[g], u ascending then v ascending (from = 1: the whole triangle; from = the number of old
+ * members: only the pairs that involve a newcomer).  The pairs are expanded on the device, so a list of n slots
+ * crosses the bus instead of up to n (n - 1) / 2 pairs of them.
+ *   ids [ids_start[ngroups]], ids_start [ngroups + 1], from [ngroups], pair_start [ngroups + 1] (all host or device)
+ *   out [pair_start[ngroups]]: group g's distances start at pair_start[g]
+ */
+int			pgv_hnsw_score_groups(pgv_hnsw * h, const int32_t *ids, const int64_t *ids_start, const int32_t *from,
+								  const int64_t *pair_start, int ngroups, int64_t nids, int64_t npairs, float *out);
+
 
 /*
  * The graph after a batch of inserts: new entry point and the rewritten neighbor tuples

@@ -476,4 +476,37 @@ int launch_hnsw_patch(pgv_ctx *ctx, int32_t *nbr, const int64_t *nbr_start, int6
     return PGV_OK;
 }
 
+// pgv_hnsw_score_groups: the (u, v) pairs of every group written out as the slot arrays score_gather_kernel reads.
+// One workgroup per group (grid-stride), a row u per step, the row's v spread over the threads (coalesced).
+__global__ __launch_bounds__(256) void expand_groups_kernel(const int32_t *__restrict__ ids,
+                                                            const int64_t *__restrict__ ids_start,
+                                                            const int32_t *__restrict__ from,
+                                                            const int64_t *__restrict__ pair_start, int ngroups,
+                                                            int32_t *__restrict__ a, int32_t *__restrict__ b) {
+    for (int g = blockIdx.x; g < ngroups; g += gridDim.x) {
+        const int32_t *gi = ids + ids_start[g];
+        const int n = (int)(ids_start[g + 1] - ids_start[g]);
+        const int f = from[g] < 1 ? 1 : from[g];
+        int64_t at = pair_start[g];
+        for (int u = f; u < n; u++) {
+            const int32_t iu = gi[u];
+            for (int v = threadIdx.x; v < u; v += blockDim.x) {
+                a[at + v] = iu;
+                b[at + v] = gi[v];
+            }
+            at += u;
+        }
+    }
+}
+
+int launch_expand_groups(pgv_ctx *ctx, const int32_t *ids, const int64_t *ids_start, const int32_t *from,
+                         const int64_t *pair_start, int ngroups, int32_t *a, int32_t *b) {
+    if (ngroups <= 0) return PGV_OK;
+    const int cap = ctx->num_cus * 16;
+    hipLaunchKernelGGL(expand_groups_kernel, dim3(ngroups < cap ? ngroups : cap), dim3(256), 0, ctx->stream, ids,
+                       ids_start, from, pair_start, ngroups, a, b);
+    PGV_HIP(hipGetLastError());
+    return PGV_OK;
+}
+
 }  // namespace pgv

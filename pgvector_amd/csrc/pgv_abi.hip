@@ -2234,6 +2234,45 @@ int pgv_hnsw_score_pairs(pgv_hnsw *h, const int32_t *a, const int32_t *b, int64_
     return sync_if(ctx, need);
 }
 
+int pgv_hnsw_score_groups(pgv_hnsw *h, const int32_t *ids, const int64_t *ids_start, const int32_t *from,
+                          const int64_t *pair_start, int ngroups, int64_t nids, int64_t npairs, float *out) {
+    if (!h || !out) PGV_FAIL(PGV_ERR_ARG, "pgv_hnsw_score_groups: handle/out is NULL");
+    if (ngroups < 0 || nids < 0 || npairs < 0) PGV_FAIL(PGV_ERR_ARG, "bad sizes");
+    if (ngroups == 0 || npairs == 0) return PGV_OK;
+    if (!ids || !ids_start || !from || !pair_start) PGV_FAIL(PGV_ERR_ARG, "ids/ids_start/from/pair_start is NULL");
+    pgv_ctx *ctx = h->ctx;
+    PGV_HIP(hipSetDevice(ctx->device));
+    // the four small tables in one staging buffer, the expanded slot arrays in two scratch buffers
+    const size_t b_ids = (sizeof(int32_t) * (size_t)nids + 15) & ~(size_t)15,
+                 b_start = sizeof(int64_t) * ((size_t)ngroups + 1),
+                 b_from = (sizeof(int32_t) * (size_t)ngroups + 15) & ~(size_t)15;
+    PGV_TRY(ctx->km_a.ensure(b_ids + 2 * b_start + b_from));
+    char *tab = ctx->km_a.as<char>();
+    auto put = [&](void *dst, const void *src, size_t bytes) -> int {
+        PGV_HIP(hipMemcpyAsync(dst, src, bytes, is_device_ptr(src) ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice,
+                               ctx->stream));
+        return PGV_OK;
+    };
+    PGV_TRY(put(tab, ids, sizeof(int32_t) * (size_t)nids));
+    PGV_TRY(put(tab + b_ids, ids_start, b_start));
+    PGV_TRY(put(tab + b_ids + b_start, pair_start, b_start));
+    PGV_TRY(put(tab + b_ids + 2 * b_start, from, sizeof(int32_t) * (size_t)ngroups));
+    PGV_TRY(ctx->idx_stage.ensure(sizeof(int32_t) * (size_t)npairs));
+    PGV_TRY(ctx->plan_d.ensure(sizeof(int32_t) * (size_t)npairs));
+    int32_t *a_dev = ctx->idx_stage.as<int32_t>(), *b_dev = ctx->plan_d.as<int32_t>();
+    PGV_TRY(launch_expand_groups(ctx, reinterpret_cast<const int32_t *>(tab),
+                                 reinterpret_cast<const int64_t *>(tab + b_ids),
+                                 reinterpret_cast<const int32_t *>(tab + b_ids + 2 * b_start),
+                                 reinterpret_cast<const int64_t *>(tab + b_ids + b_start), ngroups, a_dev, b_dev));
+    OutArg od;
+    PGV_TRY(od.init(out, sizeof(float) * (size_t)npairs, ctx->out_stage));
+    PGV_TRY(launch_score_gather(ctx, h->metric, h->dtype, h->geom, h->elements, h->elements, a_dev, b_dev, npairs,
+                                od.as<float>()));
+    bool need = true;  // the host tables above must have been read before the caller reuses them
+    PGV_TRY(od.finish(ctx, &need));
+    return sync_if(ctx, need);
+}
+
 int pgv_hnsw_update_graph(pgv_hnsw *h, int32_t entry, const int32_t *elements, int nupd,
                           const int64_t *tuple_offsets, const int32_t *tuples) {
     if (!h) PGV_FAIL(PGV_ERR_ARG, "pgv_hnsw_update_graph: handle is NULL");

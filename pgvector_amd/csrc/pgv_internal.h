@@ -202,6 +202,8 @@ int launch_scan(pgv_ctx *ctx, pgv_metric metric, pgv_dtype dtype, const RowGeom 
                 float *out);
 int scan_group_size(const RowGeom &g, pgv_dtype dtype, int wanted);
 // gathered variant (HNSW candidate scoring): pair i = (slot[i], query_of[i])
+int launch_expand_groups(pgv_ctx *ctx, const int32_t *ids, const int64_t *ids_start, const int32_t *from,
+                         const int64_t *pair_start, int ngroups, int32_t *a, int32_t *b);
 int launch_score_gather(pgv_ctx *ctx, pgv_metric metric, pgv_dtype dtype, const RowGeom &g,
                         const void *rows, const void *queries, const int32_t *slot,
                         const int32_t *query_of, int64_t npairs, float *out);

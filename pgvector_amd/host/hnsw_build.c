@@ -253,70 +253,91 @@ layer_m(int m, int lc)
 
 /* ------------------------------------------------------------ pair requests */
 
+/* a request to pgv_hnsw_score_groups: lists of element slots and, per list, which of its pairs are wanted */
 typedef struct
 {
-	int32_t    *a,
-			   *b;
-	int64_t		n,
-				cap;
-}			pairbuf;
+	int32_t    *ids;
+	int64_t    *ids_start;		/* [ngroups + 1] */
+	int32_t    *from;			/* [ngroups] */
+	int64_t    *pair_start;		/* [ngroups + 1] */
+	int64_t		nids,
+				ids_cap;
+	int			ngroups,
+				groups_cap;
+}			groupbuf;
 
-static int
-pairs_reserve(pairbuf * p, int64_t more)
-{
-	if (p->n + more > p->cap)
-	{
-		int64_t		cap = p->cap ? p->cap : 4096;
-
-		while (cap < p->n + more)
-			cap *= 2;
-		p->a = realloc(p->a, sizeof(int32_t) * (size_t) cap);
-		p->b = realloc(p->b, sizeof(int32_t) * (size_t) cap);
-		if (!p->a || !p->b)
-			return 0;
-		p->cap = cap;
-	}
-	return 1;
-}
-
-/* all pairs i < j of ids[0 .. n): n (n - 1) / 2 entries in row-major triangle order */
-static int
-pairs_triangle(pairbuf * p, const int32_t *ids, int n)
-{
-	if (!pairs_reserve(p, (int64_t) n * (n - 1) / 2))
-		return 0;
-	for (int i = 0; i < n; i++)
-		for (int j = i + 1; j < n; j++)
-		{
-			p->a[p->n] = ids[i];
-			p->b[p->n] = ids[j];
-			p->n++;
-		}
-	return 1;
-}
-
-/* the same enumeration written at a known position of an already reserved buffer (parallel fills) */
 static void
-triangle_at(pairbuf * p, int64_t at, const int32_t *ids, int n)
+groups_reset(groupbuf * gb)
 {
-	for (int i = 0; i < n; i++)
-		for (int j = i + 1; j < n; j++, at++)
-		{
-			p->a[at] = ids[i];
-			p->b[at] = ids[j];
-		}
+	gb->nids = 0;
+	gb->ngroups = 0;
 }
 
+/* pairs (u, v), v < u, of the locals u >= from of ids[0 .. n): they start at pair0 in the reply.  0 = out of memory */
+static int
+groups_add(groupbuf * gb, const int32_t *ids, int n, int from, int64_t pair0)
+{
+	if (gb->ngroups + 1 >= gb->groups_cap)
+	{
+		int			cap = gb->groups_cap ? gb->groups_cap * 2 : 4096;
+		int64_t    *is = realloc(gb->ids_start, sizeof(int64_t) * (size_t) (cap + 1));
+		int64_t    *ps = realloc(gb->pair_start, sizeof(int64_t) * (size_t) (cap + 1));
+		int32_t    *fr = realloc(gb->from, sizeof(int32_t) * (size_t) cap);
+
+		if (is)
+			gb->ids_start = is;
+		if (ps)
+			gb->pair_start = ps;
+		if (fr)
+			gb->from = fr;
+		if (!is || !ps || !fr)
+			return 0;
+		gb->groups_cap = cap;
+	}
+	if (gb->nids + n > gb->ids_cap)
+	{
+		int64_t		cap = gb->ids_cap ? gb->ids_cap : 65536;
+		int32_t    *grown;
+
+		while (cap < gb->nids + n)
+			cap *= 2;
+		grown = realloc(gb->ids, sizeof(int32_t) * (size_t) cap);
+		if (!grown)
+			return 0;
+		gb->ids = grown;
+		gb->ids_cap = cap;
+	}
+	memcpy(gb->ids + gb->nids, ids, sizeof(int32_t) * (size_t) n);
+	gb->ids_start[gb->ngroups] = gb->nids;
+	gb->from[gb->ngroups] = from;
+	gb->pair_start[gb->ngroups] = pair0;
+	gb->nids += n;
+	gb->ngroups++;
+	gb->ids_start[gb->ngroups] = gb->nids;
+	return 1;
+}
+
+/* pairs a group (n locals, from) asks for */
+static inline int64_t
+group_pairs(int n, int from)
+{
+	if (from < 1)
+		from = 1;
+	return n > from ? ((int64_t) n * (n - 1) - (int64_t) from * (from - 1)) / 2 : 0;
+}
+
+/* the whole triangle as pgv_hnsw_score_groups returns it (from = 1): u ascending, then v < u ascending */
 static void
 fill_matrix(float *mat, int n, const float *tri)
 {
 	int64_t		t = 0;
 
-	for (int i = 0; i < n; i++)
+	mat[0] = 0.0f;
+	for (int u = 1; u < n; u++)
 	{
-		mat[(size_t) i * n + i] = 0.0f;
-		for (int j = i + 1; j < n; j++, t++)
-			mat[(size_t) i * n + j] = mat[(size_t) j * n + i] = tri[t];
+		mat[(size_t) u * n + u] = 0.0f;
+		for (int v = 0; v < u; v++, t++)
+			mat[(size_t) u * n + v] = mat[(size_t) v * n + u] = tri[t];
 	}
 }
 
@@ -505,7 +526,8 @@ pgv_host_hnsw_build(pgv_hnsw * mirror, pgv_dtype dtype, int dim, const void *row
 	int32_t		entry = -1;
 	int64_t		linked = 0;
 	int			rc = PGV_OK;
-	pairbuf		pb = {0};
+	groupbuf	gb = {0};
+	int64_t		npairs = 0;
 	float	   *pdist = NULL;
 	int64_t		pdist_cap = 0;
 	int32_t    *sw_ids = NULL,
@@ -665,7 +687,7 @@ pgv_host_hnsw_build(pgv_hnsw * mirror, pgv_dtype dtype, int dim, const void *row
 
 		PHASE(PH_PAIRS);
 		/* ---- 2. pairwise distances inside every candidate list that has to be thinned */
-		pb.n = 0;
+		groups_reset(&gb);
 		tri_off = realloc(tri_off, sizeof(int64_t) * (size_t) B * lcap);
 		{
 			int64_t		total = 0;
@@ -677,35 +699,37 @@ pgv_host_hnsw_build(pgv_hnsw * mirror, pgv_dtype dtype, int dim, const void *row
 
 					tri_off[(size_t) b * lcap + lc] = total;
 					if (nw > layer_m(m, lc))
-						total += (int64_t) nw * (nw - 1) / 2;
+					{
+						/* the candidates as one group, the whole triangle: expanded on the device */
+						if (!groups_add(&gb, sw_ids + ((size_t) b * lcap + lc) * ef_construction, nw, 1, total))
+						{
+							rc = pgv_host_fail(PGV_ERR_NOMEM, "out of memory");
+							goto done;
+						}
+						total += group_pairs(nw, 1);
+					}
 				}
-			if (!pairs_reserve(&pb, total))
+			npairs = total;
+		}
+		if (gb.ngroups > 0)
+			gb.pair_start[gb.ngroups] = npairs;
+		if (npairs > pdist_cap)
+		{
+			pgv_pinned_free(pdist);
+			pdist = NULL;
+			pdist_cap = npairs * 2;
+			if ((rc = pgv_pinned_alloc(sizeof(float) * (size_t) pdist_cap, (void **) &pdist)) != PGV_OK)
 			{
-				rc = pgv_host_fail(PGV_ERR_NOMEM, "out of memory");
-				goto done;
+				pdist_cap = 0;
+				goto dev_fail;
 			}
-			pb.n = total;
-#pragma omp parallel for if (B >= 8) num_threads(nthreads) schedule(static)
-			for (int b = 0; b < B; b++)
-				for (int lc = 0; lc < lcap; lc++)
-				{
-					int			nw = sw_cnt[(size_t) b * lcap + lc];
-
-					if (nw > layer_m(m, lc))
-						triangle_at(&pb, tri_off[(size_t) b * lcap + lc], sw_ids + ((size_t) b * lcap + lc) * ef_construction, nw);
-				}
 		}
-		if (pb.n > pdist_cap)
+		if (npairs > 0)
 		{
-			pdist_cap = pb.n * 2;
-			pdist = realloc(pdist, sizeof(float) * (size_t) pdist_cap);
-		}
-		if (pb.n > 0)
-		{
-			rc = pgv_hnsw_score_pairs(mirror, pb.a, pb.b, pb.n, pdist);
+			rc = pgv_hnsw_score_groups(mirror, gb.ids, gb.ids_start, gb.from, gb.pair_start, gb.ngroups, gb.nids, npairs, pdist);
 			if (rc != PGV_OK)
 				goto dev_fail;
-			out->device_pairs += pb.n;
+			out->device_pairs += npairs;
 		}
 
 		PHASE(PH_SELECT);
@@ -801,7 +825,6 @@ pgv_host_hnsw_build(pgv_hnsw * mirror, pgv_dtype dtype, int dim, const void *row
 		/* ---- 4. the lists this batch links into, and every distance their re-selections can look up.
 		 * 4a (serial, touches only the small hash table): one request per (batch element, chosen neighbor, layer)
 		 * in the order the reference's loop would link them, and a bare record per distinct list. */
-		pb.n = 0;
 		{
 			int64_t		nlinks = 0;
 
@@ -950,60 +973,48 @@ pgv_host_hnsw_build(pgv_hnsw * mirror, pgv_dtype dtype, int dim, const void *row
 			}
 		}
 		PHASE(PH_PAIRLIST);
+		groups_reset(&gb);
 		{
 			int64_t		total = 0;
 
 			for (int k = 0; k < nrec; k++)
 			{
 				record	   *rcd = &recs[k];
+				int			from = rcd->full ? 1 : rcd->nstart;	/* cached flags: only the pairs that involve a newcomer */
 
 				rcd->pair0 = total;
 				/* a list that cannot overflow in this batch never runs a selection */
 				if (rcd->nlocal <= layer_m(m, rcd->lc))
 					continue;
-				if (rcd->full)
-					total += (int64_t) rcd->nlocal * (rcd->nlocal - 1) / 2;
-				else			/* cached flags: only the pairs that involve a newcomer */
-					for (int u = rcd->nstart; u < rcd->nlocal; u++)
-						total += u;
+				if (!groups_add(&gb, rcd->ids, rcd->nlocal, from, total))
+				{
+					rc = pgv_host_fail(PGV_ERR_NOMEM, "out of memory");
+					goto done;
+				}
+				total += group_pairs(rcd->nlocal, from);
 			}
-			if (!pairs_reserve(&pb, total))
-			{
-				rc = pgv_host_fail(PGV_ERR_NOMEM, "out of memory");
-				goto done;
-			}
-			pb.n = total;
-#pragma omp parallel for if (B >= 8) num_threads(nthreads) schedule(static)
-			for (int k = 0; k < nrec; k++)
-			{
-				record	   *rcd = &recs[k];
-				int64_t		at = rcd->pair0;
-
-				if (rcd->nlocal <= layer_m(m, rcd->lc))
-					continue;
-				if (rcd->full)
-					triangle_at(&pb, at, rcd->ids, rcd->nlocal);
-				else
-					for (int u = rcd->nstart; u < rcd->nlocal; u++)
-						for (int v = 0; v < u; v++, at++)
-						{
-							pb.a[at] = rcd->ids[u];
-							pb.b[at] = rcd->ids[v];
-						}
-			}
+			npairs = total;
+			if (gb.ngroups > 0)
+				gb.pair_start[gb.ngroups] = npairs;
 		}
 		PHASE(PH_PAIRS);
-		if (pb.n > pdist_cap)
+		if (npairs > pdist_cap)
 		{
-			pdist_cap = pb.n * 2;
-			pdist = realloc(pdist, sizeof(float) * (size_t) pdist_cap);
+			pgv_pinned_free(pdist);
+			pdist = NULL;
+			pdist_cap = npairs * 2;
+			if ((rc = pgv_pinned_alloc(sizeof(float) * (size_t) pdist_cap, (void **) &pdist)) != PGV_OK)
+			{
+				pdist_cap = 0;
+				goto dev_fail;
+			}
 		}
-		if (pb.n > 0)
+		if (npairs > 0)
 		{
-			rc = pgv_hnsw_score_pairs(mirror, pb.a, pb.b, pb.n, pdist);
+			rc = pgv_hnsw_score_groups(mirror, gb.ids, gb.ids_start, gb.from, gb.pair_start, gb.ngroups, gb.nids, npairs, pdist);
 			if (rc != PGV_OK)
 				goto dev_fail;
-			out->device_pairs += pb.n;
+			out->device_pairs += npairs;
 		}
 		PHASE(PH_UPDATE);
 
@@ -1020,26 +1031,35 @@ pgv_host_hnsw_build(pgv_hnsw * mirror, pgv_dtype dtype, int dim, const void *row
 					/* ---- 5b. the updates that were put aside: their lists' member-member pairs, then the replay */
 					if (nblocked == 0)
 						break;
-					pb.n = 0;
+					groups_reset(&gb);
+					npairs = 0;
 					for (int k = 0; k < nrec; k++)
 						if (recs[k].blocked)
 						{
-							recs[k].pair0 = pb.n;
-							if (!pairs_triangle(&pb, recs[k].ids, recs[k].nstart))
+							recs[k].pair0 = npairs;
+							if (!groups_add(&gb, recs[k].ids, recs[k].nstart, 1, npairs))
 							{
 								rc = pgv_host_fail(PGV_ERR_NOMEM, "out of memory");
 								goto done;
 							}
+							npairs += group_pairs(recs[k].nstart, 1);
 						}
-					if (pb.n > pdist_cap)
+					gb.pair_start[gb.ngroups] = npairs;
+					if (npairs > pdist_cap)
 					{
-						pdist_cap = pb.n * 2;
-						pdist = realloc(pdist, sizeof(float) * (size_t) pdist_cap);
+						pgv_pinned_free(pdist);
+						pdist = NULL;
+						pdist_cap = npairs * 2;
+						if ((rc = pgv_pinned_alloc(sizeof(float) * (size_t) pdist_cap, (void **) &pdist)) != PGV_OK)
+						{
+							pdist_cap = 0;
+							goto dev_fail;
+						}
 					}
-					rc = pgv_hnsw_score_pairs(mirror, pb.a, pb.b, pb.n, pdist);
+					rc = pgv_hnsw_score_groups(mirror, gb.ids, gb.ids_start, gb.from, gb.pair_start, gb.ngroups, gb.nids, npairs, pdist);
 					if (rc != PGV_OK)
 						goto dev_fail;
-					out->device_pairs += pb.n;
+					out->device_pairs += npairs;
 					out->deferred_updates += nblocked;
 				}
 #pragma omp parallel if (B >= 8) num_threads(nthreads)
@@ -1090,8 +1110,8 @@ pgv_host_hnsw_build(pgv_hnsw * mirror, pgv_dtype dtype, int dim, const void *row
 
 							if (!rcd->blocked)
 								continue;
-							for (int u = 0; u < rcd->nstart; u++)
-								for (int v = u + 1; v < rcd->nstart; v++, t++)
+							for (int u = 1; u < rcd->nstart; u++)
+								for (int v = 0; v < u; v++, t++)
 									rcd->mat[(size_t) u * rcd->nlocal + v] = rcd->mat[(size_t) v * rcd->nlocal + u] = pdist[t];
 							rcd->full = 1;
 							from = rcd->wait_from;
@@ -1227,9 +1247,11 @@ done:
 	free(grp_elem);
 	free(grp_dist);
 	free(grp_off);
-	free(pb.a);
-	free(pb.b);
-	free(pdist);
+	free(gb.ids);
+	free(gb.ids_start);
+	free(gb.from);
+	free(gb.pair_start);
+	pgv_pinned_free(pdist);
 	free(sw_ids);
 	free(sw_dist);
 	free(sw_cnt);

@@ -559,6 +559,25 @@ pgv_hnsw_score_pairs(pgv_hnsw * h, const int32_t *a, const int32_t *b, int64_t n
 	return PGV_OK;
 }
 
+int
+pgv_hnsw_score_groups(pgv_hnsw * h, const int32_t *ids, const int64_t *ids_start, const int32_t *from,
+					  const int64_t *pair_start, int ngroups, int64_t nids, int64_t npairs, float *out)
+{
+	(void) nids;
+	(void) npairs;
+	for (int g = 0; g < ngroups; g++)
+	{
+		const int32_t *gi = ids + ids_start[g];
+		int			n = (int) (ids_start[g + 1] - ids_start[g]);
+		int64_t		at = pair_start[g];
+
+		for (int u = from[g] < 1 ? 1 : from[g]; u < n; u++)
+			for (int v = 0; v < u; v++, at++)
+				out[at] = dist(h->metric, h->dim, h->vectors + (size_t) gi[u] * h->dim, h->vectors + (size_t) gi[v] * h->dim);
+	}
+	return PGV_OK;
+}
+
 typedef struct
 {
 	int32_t		id;
