@@ -11,6 +11,7 @@
 #include <time.h>
 
 extern int	pgv_host_fail(int code, const char *fmt,...);
+extern void *pgv_host_big_alloc(size_t bytes);
 
 #define ASSIGN_BATCH (1 << 18)	/* rows handed to the GPU per BuildCallback batch */
 
@@ -126,7 +127,7 @@ pgv_host_ivf_build(pgv_ctx * ctx, pgv_ops ops, pgv_dtype dtype, int dim, int lis
 	list_of = malloc(sizeof(int32_t) * (size_t) (n > 0 ? n : 1));
 	offsets = calloc((size_t) lists + 1, sizeof(int64_t));
 	dest = malloc(sizeof(int64_t) * (size_t) (n > 0 ? n : 1));
-	sorted = malloc(row_bytes * (size_t) (n > 0 ? n : 1));
+	sorted = pgv_host_big_alloc(row_bytes * (size_t) (n > 0 ? n : 1));
 	sorted_tids = malloc(sizeof(uint64_t) * (size_t) (n > 0 ? n : 1));
 	if (!centers || !list_of || !offsets || !dest || !sorted || !sorted_tids)
 	{
