@@ -281,6 +281,8 @@ __device__ void block_topk(Load load, int64_t m, int k, int kp, int cap, unsigne
 constexpr int kSmallVec = 12;
 constexpr int kSmallMax = kSmallVec * 4 * kSelThreads;  // 12288
 
+// NVEC float4 per thread: 1 (m <= 1024: the centers of a typical index), 4 (m <= 4096) or 12
+template <int NVEC>
 __device__ inline void block_topk_small(const float *v, int m, int k, int kp, int cap, unsigned long long *ent,
                                         SelShared *s) {
     // A lone workgroup runs at whatever clock an otherwise idle chip grants: what counts here is the
@@ -290,16 +292,16 @@ __device__ inline void block_topk_small(const float *v, int m, int k, int kp, in
     for (int i = threadIdx.x; i < cap; i += kSelThreads) ent[i] = ~0ull;
     if (threadIdx.x == 0) s->count = 0;
     const int last4 = ((m + 3) & ~3) - 4;  // the last whole float4
-    float4 r[kSmallVec];
+    float4 r[NVEC];
 #pragma unroll
-    for (int b = 0; b < kSmallVec; b++) {
+    for (int b = 0; b < NVEC; b++) {
         const int at = b * 4 * kSelThreads + 4 * (int)threadIdx.x;
         r[b] = *reinterpret_cast<const float4 *>(v + (at < last4 ? at : last4));
     }
     // values past m read as +inf from here on; NaN never wins a float minimum (it sorts last anyway)
     float fmine = INFINITY;
 #pragma unroll
-    for (int b = 0; b < kSmallVec; b++) {
+    for (int b = 0; b < NVEC; b++) {
         const int at = b * 4 * kSelThreads + 4 * (int)threadIdx.x;
         if (at + 3 >= m) {  // the ragged end (and everything clamped past it)
             if (at + 0 >= m) r[b].x = INFINITY;
@@ -338,12 +340,12 @@ __device__ inline void block_topk_small(const float *v, int m, int k, int kp, in
         const float t0f = key_to_float(t0);
         unsigned cnt = 0;
 #pragma unroll
-        for (int b = 0; b < kSmallVec; b++)
+        for (int b = 0; b < NVEC; b++)
             cnt += (r[b].x <= t0f) + (r[b].y <= t0f) + (r[b].z <= t0f) + (r[b].w <= t0f);
         if (cnt) {
             unsigned slot = atomicAdd(&s->count, cnt);
 #pragma unroll
-            for (int b = 0; b < kSmallVec; b++) {
+            for (int b = 0; b < NVEC; b++) {
                 const int at = b * 4 * kSelThreads + 4 * (int)threadIdx.x;
                 const float e[4] = {r[b].x, r[b].y, r[b].z, r[b].w};
                 if (fminf(fminf(e[0], e[1]), fminf(e[2], e[3])) <= t0f) {
@@ -376,9 +378,14 @@ __device__ inline void block_topk_small(const float *v, int m, int k, int kp, in
 // picks the register-resident form when it applies
 __device__ inline void block_topk_auto(const float *v, int64_t m, int k, int kp, int cap, unsigned long long *ent,
                                        SelShared *s) {
-    if (m > k && m <= kSmallMax && k <= kSelThreads / 2)  // block-uniform
-        block_topk_small(v, (int)m, k, kp, cap, ent, s);
-    else
+    if (m > k && m <= kSmallMax && k <= kSelThreads / 2) {  // block-uniform
+        if (m <= 4 * kSelThreads)
+            block_topk_small<1>(v, (int)m, k, kp, cap, ent, s);
+        else if (m <= 16 * kSelThreads)
+            block_topk_small<4>(v, (int)m, k, kp, cap, ent, s);
+        else
+            block_topk_small<kSmallVec>(v, (int)m, k, kp, cap, ent, s);
+    } else
         block_topk([v](int64_t i) { return v[i]; }, m, k, kp, cap, ent, s);
 }
 
