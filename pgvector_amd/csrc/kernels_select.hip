@@ -34,26 +34,32 @@ __global__ void plan_count_kernel(const int32_t *__restrict__ probe_lists,
     seg_len[q] = run;
 }
 
-// single-block exclusive scan of an int64 sequence produced on the fly
+// single-block exclusive scan of an int64 sequence produced on the fly: every wavefront scans its 64 values with
+// shuffles, the 16 wavefront totals are scanned by the first lanes -- two barriers per 1024 values (the
+// Hillis-Steele form over LDS took twenty, and a lone workgroup pays for each)
 template <typename F>
-__device__ void block_exclusive_scan(int n, F value, int64_t *out, int64_t *scratch /*[blockDim]*/) {
-    __shared__ int64_t carry;
-    if (threadIdx.x == 0) carry = 0;
-    __syncthreads();
+__device__ void block_exclusive_scan(int n, F value, int64_t *out, int64_t *scratch /*[blockDim / 64 + 1]*/) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nwaves = blockDim.x >> 6;
+    int64_t carry = 0;  // kept identically by every thread
     for (int base = 0; base < n; base += blockDim.x) {
         const int i = base + threadIdx.x;
         const int64_t v = i < n ? value(i) : 0;
-        scratch[threadIdx.x] = v;
-        __syncthreads();
-        for (int s = 1; s < (int)blockDim.x; s <<= 1) {
-            int64_t t = threadIdx.x >= (unsigned)s ? scratch[threadIdx.x - s] : 0;
-            __syncthreads();
-            scratch[threadIdx.x] += t;
-            __syncthreads();
+        int64_t incl = v;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            const int64_t t = __shfl_up(incl, d);
+            if (lane >= d) incl += t;
         }
-        if (i < n) out[i] = carry + scratch[threadIdx.x] - v;
+        if (lane == 63) scratch[wave] = incl;
         __syncthreads();
-        if (threadIdx.x == blockDim.x - 1) carry += scratch[threadIdx.x];
+        int64_t before = 0, total = 0;
+        for (int w = 0; w < nwaves; w++) {
+            const int64_t t = scratch[w];
+            if (w < wave) before += t;
+            total += t;
+        }
+        if (i < n) out[i] = carry + before + incl - v;
+        carry += total;
         __syncthreads();
     }
     if (threadIdx.x == 0) out[n] = carry;
@@ -65,7 +71,7 @@ __global__ __launch_bounds__(1024) void plan_scan_kernel(
     const int64_t *__restrict__ seg_len, int nq, int nlists, int qt, int rows_per_task,
     int64_t *__restrict__ seg_start, int64_t *__restrict__ pair_start,
     int64_t *__restrict__ task_start, int64_t *__restrict__ totals /*[2]: out elems, tasks*/) {
-    __shared__ int64_t scratch[1024];
+    __shared__ int64_t scratch[1024 / 64 + 1];
     block_exclusive_scan(nq, [&](int i) { return seg_len[i]; }, seg_start, scratch);
     block_exclusive_scan(nlists, [&](int i) { return (int64_t)cnt[i]; }, pair_start, scratch);
     block_exclusive_scan(
@@ -102,29 +108,37 @@ __global__ void plan_pairs_kernel(const int32_t *__restrict__ probe_lists,
     pairs[pos] = pr;
 }
 
+// one thread per task: the list by bisection of task_start (the lists' tasks are consecutive), then chunk-major
+// inside the list -- tasks that stream the same rows sit next to each other in the queue
 __global__ void plan_tasks_kernel(const int *__restrict__ cnt, const int64_t *__restrict__ list_off,
                                   const int64_t *__restrict__ pair_start,
                                   const int64_t *__restrict__ task_start, int nlists, int qt,
                                   int rows_per_task, ScanTask *__restrict__ tasks) {
-    const int l = blockIdx.x * blockDim.x + threadIdx.x;
-    if (l >= nlists) return;
-    const int64_t len = list_off[l + 1] - list_off[l];
-    const int ng = (cnt[l] + qt - 1) / qt;
-    const int nc = (int)((len + rows_per_task - 1) / rows_per_task);
-    int64_t t = task_start[l];
-    // chunk-major: tasks that stream the same rows sit next to each other in the queue
-    for (int c = 0; c < nc; c++)
-        for (int g = 0; g < ng; g++) {
-            ScanTask task;
-            task.row0 = list_off[l] + (int64_t)c * rows_per_task;
-            const int64_t left = len - (int64_t)c * rows_per_task;
-            task.nrows = (int)(left < rows_per_task ? left : rows_per_task);
-            task.pair0 = (int)(pair_start[l] + (int64_t)g * qt);
-            const int pl = cnt[l] - g * qt;
-            task.npairs = pl < qt ? pl : qt;
-            task.pad = 0;
-            tasks[t++] = task;
+    const int64_t ntasks = task_start[nlists];
+    for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < ntasks; t += (int64_t)gridDim.x * blockDim.x) {
+        int lo = 0, hi = nlists - 1;  // last list whose first task is <= t (lists without tasks share a start)
+        while (lo < hi) {
+            const int mid = (lo + hi + 1) >> 1;
+            if (task_start[mid] <= t)
+                lo = mid;
+            else
+                hi = mid - 1;
         }
+        const int l = lo;
+        const int64_t len = list_off[l + 1] - list_off[l];
+        const int ng = (cnt[l] + qt - 1) / qt;
+        const int64_t rel = t - task_start[l];
+        const int c = (int)(rel / ng), g = (int)(rel % ng);
+        ScanTask task;
+        task.row0 = list_off[l] + (int64_t)c * rows_per_task;
+        const int64_t left = len - (int64_t)c * rows_per_task;
+        task.nrows = (int)(left < rows_per_task ? left : rows_per_task);
+        task.pair0 = (int)(pair_start[l] + (int64_t)g * qt);
+        const int pl = cnt[l] - g * qt;
+        task.npairs = pl < qt ? pl : qt;
+        task.pad = 0;
+        tasks[t] = task;
+    }
 }
 
 // float8 ordering: NaN after everything, strict
@@ -325,9 +339,12 @@ int launch_plan_batch(pgv_ctx *ctx, const pgv_index *ix, const int32_t *probe_li
     hipLaunchKernelGGL(plan_pairs_kernel, dim3((unsigned)((npairs + 255) / 256)), dim3(256), 0,
                        ctx->stream, probe_lists, ix->list_offsets, probe_off, seg_start,
                        pair_start, fill, nq, probes, ctx->pairs.as<ScanPair>());
-    hipLaunchKernelGGL(plan_tasks_kernel, dim3((nlists + 255) / 256), dim3(256), 0, ctx->stream,
-                       cnt, ix->list_offsets, pair_start, task_start, nlists, qt, rows_per_task,
-                       tasks);
+    {
+        const int64_t want = (res->ntasks_bound + 255) / 256;
+        const int64_t cap = (int64_t)ctx->num_cus * 8;
+        hipLaunchKernelGGL(plan_tasks_kernel, dim3((unsigned)(want < 1 ? 1 : (want > cap ? cap : want))), dim3(256), 0,
+                           ctx->stream, cnt, ix->list_offsets, pair_start, task_start, nlists, qt, rows_per_task, tasks);
+    }
     PGV_HIP(hipGetLastError());
 
     res->ntasks = res->ntasks_bound;
