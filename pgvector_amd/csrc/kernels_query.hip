@@ -306,39 +306,60 @@ __global__ __launch_bounds__(kQThreads) void batch_recheck_kernel(
     }
 }
 
-// the flagged queries' segments again, every row with the exact form (one pass of the old cost
-// for those queries only; unflagged workgroups leave at once)
+// The flagged queries, start to end in one launch (they are rare -- none on ordinary data -- so the three launches
+// this used to be were three dependent kernel boundaries for nothing): a workgroup takes a flagged query, scores
+// every row of its segment with the exact form (the whole segment, what the exact kernels would have done),
+// selects the head like topk_kernel and writes the query's output row.  Workgroups without a flagged query leave
+// at once.
 template <typename T>
-__global__ __launch_bounds__(kQThreads) void batch_redo_kernel(
-    const char *__restrict__ vectors, const int64_t *__restrict__ list_off, int nvec, int lg,
-    const char *__restrict__ queries, const int32_t *__restrict__ probe_lists,
+__global__ __launch_bounds__(kQThreads) void batch_fix_kernel(
+    const char *__restrict__ vectors, const int64_t *__restrict__ list_off, const uint64_t *__restrict__ tids, int nvec,
+    int lg, const char *__restrict__ queries, const int32_t *__restrict__ probe_lists,
     const int64_t *__restrict__ probe_off, int probes, const int64_t *__restrict__ seg_start, int64_t fixed_len,
-    const int32_t *__restrict__ flags, int nq, float *__restrict__ seg_vals, int per) {
+    const int32_t *__restrict__ flags, int nq, float *__restrict__ seg_vals, int k, int kp, int cap,
+    float *__restrict__ out_dist, int64_t *__restrict__ out_slot, uint64_t *__restrict__ out_tid) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    unsigned long long *ent = reinterpret_cast<unsigned long long *>(smem);  // [cap >= kp]
+    SelShared *sel = reinterpret_cast<SelShared *>(smem + (size_t)cap * 8);
     const int nflag = flags[nq];
     const size_t row_bytes = (size_t)nvec * sizeof(Raw16);
-    for (int f = blockIdx.y; f < nflag; f += gridDim.y) {
-    const int q = flags[nq + 1 + f];
-    // probe_lists == null: the rows are one dense run (the centers), every query's segment is all of them
-    const int64_t base = probe_lists ? seg_start[q] : (int64_t)q * fixed_len;
-    const int64_t m = probe_lists ? seg_start[q + 1] - base : fixed_len;
-    const int64_t *off = probe_off + (size_t)q * probes;
-    const int32_t *pl = probe_lists + (size_t)q * probes;
-    auto row_ptr = [&](int64_t j) {
-        if (!probe_lists) return vectors + (size_t)j * row_bytes;
-        int lo = 0, hi = probes - 1;
-        while (lo < hi) {
-            const int mid = (lo + hi + 1) >> 1;
-            if (off[mid] <= j)
-                lo = mid;
-            else
-                hi = mid - 1;
+    for (int f = blockIdx.x; f < nflag; f += gridDim.x) {
+        const int q = flags[nq + 1 + f];
+        // probe_lists == null: the rows are one dense run (the centers), every query's segment is all of them
+        const int64_t base = probe_lists ? seg_start[q] : (int64_t)q * fixed_len;
+        const int64_t m = probe_lists ? seg_start[q + 1] - base : fixed_len;
+        const int64_t *off = probe_off + (size_t)q * probes;
+        const int32_t *pl = probe_lists + (size_t)q * probes;
+        auto slot_of = [&](int64_t j) -> int64_t {  // position in the segment -> row slot
+            if (!probe_lists) return j;
+            int lo = 0, hi = probes - 1;
+            while (lo < hi) {
+                const int mid = (lo + hi + 1) >> 1;
+                if (off[mid] <= j)
+                    lo = mid;
+                else
+                    hi = mid - 1;
+            }
+            return list_off[pl[lo]] + (j - off[lo]);
+        };
+        float *v = seg_vals + base;
+        score_rows<T, 0, 0>([&](int64_t j) { return vectors + (size_t)slot_of(j) * row_bytes; }, 0, m,
+                            queries + (size_t)q * row_bytes, nvec, lg, v);
+        __threadfence();
+        __syncthreads();
+        // the values were written by this workgroup's other wavefronts a moment ago: agent-scope loads, so that a
+        // line of the vector L1 that was cached before (a neighbouring segment's selection) cannot serve them stale
+        block_topk([v](int64_t i) { return __hip_atomic_load(v + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }, m, k, kp,
+                   cap, ent, sel);
+        for (int i = threadIdx.x; i < k; i += kQThreads) {
+            const unsigned long long e = ent[i];
+            const bool have = e != ~0ull && (int64_t)i < (m < k ? m : (int64_t)k);
+            const int64_t slot = have ? slot_of((int64_t)(unsigned)(e & 0xffffffffu)) : -1;
+            out_dist[(size_t)q * k + i] = have ? key_to_float((unsigned)(e >> 32)) : INFINITY;
+            if (out_slot) out_slot[(size_t)q * k + i] = slot;
+            if (out_tid) out_tid[(size_t)q * k + i] = (have && tids) ? tids[slot] : ~0ull;
         }
-        return vectors + (size_t)(list_off[pl[lo]] + (j - off[lo])) * row_bytes;
-    };
-    for (int64_t first = (int64_t)blockIdx.x * per; first < m; first += (int64_t)gridDim.x * per) {
-        const int64_t end = first + per < m ? first + per : m;
-        score_rows<T, 0, 0>(row_ptr, first, end, queries + (size_t)q * row_bytes, nvec, lg, seg_vals + base);
-    }
+        __syncthreads();  // ent / sel are reused by the next flagged query
     }
 }
 
@@ -487,22 +508,26 @@ int launch_batch_recheck(pgv_ctx *ctx, const ExactRows &xr, const void *q_dev, i
     return PGV_OK;
 }
 
-int launch_batch_redo(pgv_ctx *ctx, const ExactRows &xr, const void *q_dev, int nq, const int32_t *probe_lists,
-                      const int64_t *probe_off, int probes, const int64_t *seg_start, int64_t fixed_len,
-                      const int32_t *flags, float *seg_vals) {
+int launch_batch_fix(pgv_ctx *ctx, const ExactRows &xr, const void *q_dev, int nq, const int32_t *probe_lists,
+                     const int64_t *probe_off, int probes, const int64_t *seg_start, int64_t fixed_len,
+                     const int32_t *flags, float *seg_vals, int k, float *out_dist, int64_t *out_slot, uint64_t *out_tid) {
     if (nq <= 0) return PGV_OK;
-    const int per = kQWaves * (kWave >> xr.geom.lpr_log2);
-    const dim3 grid(16, (unsigned)(nq < 64 ? nq : 64));
-#define PGV_REDO(T)                                                                                                  \
-    hipLaunchKernelGGL(batch_redo_kernel<T>, grid, dim3(kQThreads), 0, ctx->stream,                                  \
-                       static_cast<const char *>(xr.vectors), xr.list_offsets, xr.geom.nvec, xr.geom.lpr_log2,       \
-                       static_cast<const char *>(q_dev), probe_lists, probe_off, probes, seg_start, fixed_len, flags, \
-                       nq, seg_vals, per)
+    if (k > 4096) PGV_FAIL(PGV_ERR_ARG, "top-k: k = %d exceeds the supported 4096", k);
+    int kp = 2;
+    while (kp < k) kp <<= 1;
+    const int cap = kp > kFastCap ? kp : kFastCap;
+    const size_t lds = (size_t)cap * 8 + sizeof(SelShared);
+    const int grid = nq < ctx->num_cus ? nq : ctx->num_cus;
+#define PGV_FIX(T)                                                                                                   \
+    hipLaunchKernelGGL(batch_fix_kernel<T>, dim3(grid), dim3(kQThreads), lds, ctx->stream,                           \
+                       static_cast<const char *>(xr.vectors), xr.list_offsets, xr.tids, xr.geom.nvec,                \
+                       xr.geom.lpr_log2, static_cast<const char *>(q_dev), probe_lists, probe_off, probes, seg_start, \
+                       fixed_len, flags, nq, seg_vals, k, kp, cap, out_dist, out_slot, out_tid)
     if (xr.dtype == PGV_F32)
-        PGV_REDO(float);
+        PGV_FIX(float);
     else
-        PGV_REDO(__half);
-#undef PGV_REDO
+        PGV_FIX(__half);
+#undef PGV_FIX
     PGV_HIP(hipGetLastError());
     return PGV_OK;
 }

@@ -149,14 +149,12 @@ __device__ __forceinline__ bool dist_before(float a, float b) { return float_to_
 
 __global__ __launch_bounds__(kSelThreads) void topk_kernel(
     const float *__restrict__ vals, const int64_t *__restrict__ seg_start, int64_t fixed_len,
-    int k, int kp, int cap, float *__restrict__ out_val, int64_t *__restrict__ out_pos,
-    const int32_t *__restrict__ only) {
+    int k, int kp, int cap, float *__restrict__ out_val, int64_t *__restrict__ out_pos) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     unsigned long long *ent = reinterpret_cast<unsigned long long *>(smem);  // [cap >= kp]
     SelShared *s = reinterpret_cast<SelShared *>(smem + (size_t)cap * 8);
 
     const int seg = blockIdx.x;
-    if (only && !only[seg]) return;
     const int64_t base = seg_start ? seg_start[seg] : (int64_t)seg * fixed_len;
     const int64_t m = seg_start ? seg_start[seg + 1] - base : fixed_len;
     const float *v = vals + base;
@@ -177,12 +175,10 @@ __global__ void positions_to_slots_kernel(const int32_t *__restrict__ probe_list
                                           const uint64_t *__restrict__ tids, int nq, int probes,
                                           int k, const int64_t *__restrict__ pos,
                                           int64_t *__restrict__ out_slot,
-                                          uint64_t *__restrict__ out_tid,
-                                          const int32_t *__restrict__ only) {
+                                          uint64_t *__restrict__ out_tid) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= (int64_t)nq * k) return;
     const int q = (int)(i / k);
-    if (only && !only[q]) return;
     const int64_t p = pos[i];
     int64_t slot = -1;
     if (p >= 0) {
@@ -364,7 +360,7 @@ int launch_plan_batch(pgv_ctx *ctx, const pgv_index *ix, const int32_t *probe_li
 }
 
 int launch_topk_segments(pgv_ctx *ctx, const float *vals, const int64_t *seg_start, int nseg,
-                         int64_t fixed_len, int k, float *out_val, int64_t *out_pos, const int32_t *only) {
+                         int64_t fixed_len, int k, float *out_val, int64_t *out_pos) {
     if (nseg <= 0 || k <= 0) return PGV_OK;
     if (k > 4096) PGV_FAIL(PGV_ERR_ARG, "top-k: k = %d exceeds the supported 4096", k);
     int kp = 1;
@@ -373,19 +369,19 @@ int launch_topk_segments(pgv_ctx *ctx, const float *vals, const int64_t *seg_sta
     const int cap = kp > kFastCap ? kp : kFastCap;
     const size_t lds = (size_t)cap * 8 + sizeof(SelShared);
     hipLaunchKernelGGL(topk_kernel, dim3(nseg), dim3(kSelThreads), lds, ctx->stream, vals,
-                       seg_start, fixed_len, k, kp, cap, out_val, out_pos, only);
+                       seg_start, fixed_len, k, kp, cap, out_val, out_pos);
     PGV_HIP(hipGetLastError());
     return PGV_OK;
 }
 
 int launch_positions_to_slots(pgv_ctx *ctx, const pgv_index *ix, const int32_t *probe_lists,
                               const int64_t *probe_off, int nq, int probes, int k,
-                              const int64_t *pos, int64_t *out_slot, uint64_t *out_tid, const int32_t *only) {
+                              const int64_t *pos, int64_t *out_slot, uint64_t *out_tid) {
     const int64_t total = (int64_t)nq * k;
     if (total <= 0) return PGV_OK;
     hipLaunchKernelGGL(positions_to_slots_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256),
                        0, ctx->stream, probe_lists, probe_off, ix->list_offsets, ix->tids, nq,
-                       probes, k, pos, out_slot, out_tid, only);
+                       probes, k, pos, out_slot, out_tid);
     PGV_HIP(hipGetLastError());
     return PGV_OK;
 }

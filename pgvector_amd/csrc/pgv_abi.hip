@@ -771,8 +771,8 @@ static int rank_lists_dev(pgv_index *ix, const void *q_dev, int nq, int maxprobe
         // a center's position in the matrix row is its id: cand_pos serves as the slots
         PGV_TRY(launch_batch_recheck(ctx, xr, q_dev, nq, cand, maxprobes, sc.cand_val, sc.cand_pos, sc.cand_pos, nullptr,
                                      ix->nlists, sc.qnorm, expansion_gamma(ix->dim), dist, pos, nullptr, sc.flags));
-        PGV_TRY(launch_batch_redo(ctx, xr, q_dev, nq, nullptr, nullptr, 0, nullptr, ix->nlists, sc.flags, mat));
-        PGV_TRY(launch_topk_segments(ctx, mat, nullptr, nq, ix->nlists, maxprobes, dist, pos, sc.flags));
+        PGV_TRY(launch_batch_fix(ctx, xr, q_dev, nq, nullptr, nullptr, 0, nullptr, ix->nlists, sc.flags, mat, maxprobes,
+                                 dist, pos, nullptr));
     } else {
         PGV_TRY(dense_scan(ctx, ix->metric, ix->dtype, ix->geom, ix->centers, ix->nlists, q_dev, nq, ix->nlists, mat,
                            mfma, nullptr, nullptr));
@@ -972,11 +972,8 @@ static int scan_batch_dev(pgv_index *ix, const void *q_dev, int nq, const int32_
                            reinterpret_cast<const unsigned *>(ix->row_norms + ix->nrows)};
         PGV_TRY(launch_batch_recheck(ctx, xr, q_dev, nq, kprime, k, cand_val, cand_pos, cand_slot, plan.seg_start, 0,
                                      qnorm, gamma, od.as<float>(), os.as<int64_t>(), ot.as<uint64_t>(), flags));
-        PGV_TRY(launch_batch_redo(ctx, xr, q_dev, nq, probe_lists, plan.probe_off, probes, plan.seg_start, 0, flags,
-                                  seg_vals));
-        PGV_TRY(launch_topk_segments(ctx, seg_vals, plan.seg_start, nq, 0, k, od.as<float>(), pos, flags));
-        PGV_TRY(launch_positions_to_slots(ctx, ix, probe_lists, plan.probe_off, nq, probes, k, pos,
-                                          os.as<int64_t>(), ot.as<uint64_t>(), flags));
+        PGV_TRY(launch_batch_fix(ctx, xr, q_dev, nq, probe_lists, plan.probe_off, probes, plan.seg_start, 0, flags,
+                                 seg_vals, k, od.as<float>(), os.as<int64_t>(), ot.as<uint64_t>()));
         if (ctx->profiling && ctx->stats_dev.p) PGV_TRY(launch_count_flags(ctx, flags + nq, nq));
     } else {
         PGV_TRY(launch_topk_segments(ctx, seg_vals, plan.seg_start, nq, 0, k, od.as<float>(), pos));

@@ -283,14 +283,11 @@ struct PlanResult {
 };
 int launch_plan_batch(pgv_ctx *ctx, const pgv_index *ix, const int32_t *probe_lists, int nq,
                       int probes, int qt, int rows_per_task, bool read_totals, PlanResult *res);
-// `only` (device, per segment / query; may be null): nonzero = do this one, zero = leave its outputs alone
 int launch_topk_segments(pgv_ctx *ctx, const float *vals, const int64_t *seg_start, int nseg,
-                         int64_t fixed_len, int k, float *out_val, int64_t *out_pos,
-                         const int32_t *only = nullptr);
+                         int64_t fixed_len, int k, float *out_val, int64_t *out_pos);
 int launch_positions_to_slots(pgv_ctx *ctx, const pgv_index *ix, const int32_t *probe_lists,
                               const int64_t *probe_off, int nq, int probes, int k,
-                              const int64_t *pos, int64_t *out_slot, uint64_t *out_tid,
-                              const int32_t *only = nullptr);
+                              const int64_t *pos, int64_t *out_slot, uint64_t *out_tid);
 // kernels_query.hip: the exact tail of the MFMA L2 scans.  The rows the candidates come
 // from: an index's tuples (list_offsets set) or its centers (one dense run)
 struct ExactRows {
@@ -305,9 +302,11 @@ int launch_batch_recheck(pgv_ctx *ctx, const ExactRows &xr, const void *q_dev, i
                          const float *approx_val, const int64_t *cand_pos, const int64_t *cand_slot,
                          const int64_t *seg_start, int64_t fixed_len, const float *query_norms, float gamma,
                          float *out_dist, int64_t *out_slot, uint64_t *out_tid, int32_t *flags);
-int launch_batch_redo(pgv_ctx *ctx, const ExactRows &xr, const void *q_dev, int nq, const int32_t *probe_lists,
-                      const int64_t *probe_off, int probes, const int64_t *seg_start, int64_t fixed_len,
-                      const int32_t *flags, float *seg_vals);
+// the flagged queries start to end: exact scores of the whole segment, head, output row (out_slot: row slots, or
+// center ids for the dense form)
+int launch_batch_fix(pgv_ctx *ctx, const ExactRows &xr, const void *q_dev, int nq, const int32_t *probe_lists,
+                     const int64_t *probe_off, int probes, const int64_t *seg_start, int64_t fixed_len,
+                     const int32_t *flags, float *seg_vals, int k, float *out_dist, int64_t *out_slot, uint64_t *out_tid);
 int launch_count_flags(pgv_ctx *ctx, const int32_t *count_dev, int nq);  // profiling: stats slot 6 += *count_dev
 int launch_iota_slots(pgv_ctx *ctx, const pgv_index *ix, const int32_t *lists_dev, int nlists,
                       const int64_t *probe_off, int64_t *out_slot);
