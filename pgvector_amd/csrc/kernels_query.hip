@@ -246,7 +246,8 @@ __global__ __launch_bounds__(kQThreads) void batch_recheck_kernel(
     const int64_t *__restrict__ cand_pos, const int64_t *__restrict__ cand_slot,
     const int64_t *__restrict__ seg_start, int64_t fixed_len, const float *__restrict__ query_norms,
     const unsigned *__restrict__ row_norm_max, float gamma, int nq, float *__restrict__ out_dist,
-    int64_t *__restrict__ out_slot, uint64_t *__restrict__ out_tid, int32_t *__restrict__ flags) {
+    int64_t *__restrict__ out_slot, uint64_t *__restrict__ out_tid, int32_t *__restrict__ out_i32,
+    int32_t *__restrict__ flags) {
     __shared__ float exact[kRecheckCap];
     __shared__ __attribute__((aligned(16))) unsigned long long ent[kRecheckCap];
     const int q = blockIdx.x;
@@ -290,12 +291,14 @@ __global__ __launch_bounds__(kQThreads) void batch_recheck_kernel(
         const size_t o = (size_t)q * k + rank;
         out_dist[o] = key_to_float((unsigned)(mine >> 32));
         if (out_slot) out_slot[o] = my_slot;
+        if (out_i32) out_i32[o] = (int32_t)my_slot;
         if (out_tid) out_tid[o] = tids ? tids[my_slot] : ~0ull;
     }
     if ((int)threadIdx.x >= kk && (int)threadIdx.x < k) {  // fewer tuples than the head asked for
         const size_t o = (size_t)q * k + threadIdx.x;
         out_dist[o] = INFINITY;
         if (out_slot) out_slot[o] = -1;
+        if (out_i32) out_i32[o] = -1;
         if (out_tid) out_tid[o] = ~0ull;
     }
     if (threadIdx.x == 0) {
@@ -317,11 +320,13 @@ __global__ __launch_bounds__(kQThreads) void batch_fix_kernel(
     int lg, const char *__restrict__ queries, const int32_t *__restrict__ probe_lists,
     const int64_t *__restrict__ probe_off, int probes, const int64_t *__restrict__ seg_start, int64_t fixed_len,
     const int32_t *__restrict__ flags, int nq, float *__restrict__ seg_vals, int k, int kp, int cap,
-    float *__restrict__ out_dist, int64_t *__restrict__ out_slot, uint64_t *__restrict__ out_tid) {
+    float *__restrict__ out_dist, int64_t *__restrict__ out_slot, uint64_t *__restrict__ out_tid,
+    int32_t *__restrict__ out_i32, double *__restrict__ stats) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     unsigned long long *ent = reinterpret_cast<unsigned long long *>(smem);  // [cap >= kp]
     SelShared *sel = reinterpret_cast<SelShared *>(smem + (size_t)cap * 8);
     const int nflag = flags[nq];
+    if (stats && blockIdx.x == 0 && threadIdx.x == 0) stats[6] += (double)nflag;  // profiling: queries redone
     const size_t row_bytes = (size_t)nvec * sizeof(Raw16);
     for (int f = blockIdx.x; f < nflag; f += gridDim.x) {
         const int q = flags[nq + 1 + f];
@@ -357,6 +362,7 @@ __global__ __launch_bounds__(kQThreads) void batch_fix_kernel(
             const int64_t slot = have ? slot_of((int64_t)(unsigned)(e & 0xffffffffu)) : -1;
             out_dist[(size_t)q * k + i] = have ? key_to_float((unsigned)(e >> 32)) : INFINITY;
             if (out_slot) out_slot[(size_t)q * k + i] = slot;
+            if (out_i32) out_i32[(size_t)q * k + i] = (int32_t)slot;
             if (out_tid) out_tid[(size_t)q * k + i] = (have && tids) ? tids[slot] : ~0ull;
         }
         __syncthreads();  // ent / sel are reused by the next flagged query
@@ -491,14 +497,14 @@ int launch_query_head(pgv_ctx *ctx, const pgv_index *ix, const float *seg, const
 int launch_batch_recheck(pgv_ctx *ctx, const ExactRows &xr, const void *q_dev, int nq, int kprime, int k,
                          const float *approx_val, const int64_t *cand_pos, const int64_t *cand_slot,
                          const int64_t *seg_start, int64_t fixed_len, const float *query_norms, float gamma,
-                         float *out_dist, int64_t *out_slot, uint64_t *out_tid, int32_t *flags) {
+                         float *out_dist, int64_t *out_slot, uint64_t *out_tid, int32_t *flags, int32_t *out_i32) {
     if (nq <= 0) return PGV_OK;
     if (kprime > kRecheckCap || k > kprime) PGV_FAIL(PGV_ERR_ARG, "recheck: k' = %d outside k..%d", kprime, kRecheckCap);
 #define PGV_RECHECK(T)                                                                                              \
     hipLaunchKernelGGL(batch_recheck_kernel<T>, dim3(nq), dim3(kQThreads), 0, ctx->stream,                           \
                        static_cast<const char *>(xr.vectors), xr.tids, xr.geom.nvec, xr.geom.lpr_log2,               \
                        static_cast<const char *>(q_dev), kprime, k, approx_val, cand_pos, cand_slot, seg_start,      \
-                       fixed_len, query_norms, xr.norm_max, gamma, nq, out_dist, out_slot, out_tid, flags)
+                       fixed_len, query_norms, xr.norm_max, gamma, nq, out_dist, out_slot, out_tid, out_i32, flags)
     if (xr.dtype == PGV_F32)
         PGV_RECHECK(float);
     else
@@ -510,8 +516,10 @@ int launch_batch_recheck(pgv_ctx *ctx, const ExactRows &xr, const void *q_dev, i
 
 int launch_batch_fix(pgv_ctx *ctx, const ExactRows &xr, const void *q_dev, int nq, const int32_t *probe_lists,
                      const int64_t *probe_off, int probes, const int64_t *seg_start, int64_t fixed_len,
-                     const int32_t *flags, float *seg_vals, int k, float *out_dist, int64_t *out_slot, uint64_t *out_tid) {
+                     const int32_t *flags, float *seg_vals, int k, float *out_dist, int64_t *out_slot, uint64_t *out_tid,
+                     int32_t *out_i32) {
     if (nq <= 0) return PGV_OK;
+    double *stats = (ctx->profiling && ctx->stats_dev.p && probe_lists) ? ctx->stats_dev.as<double>() : nullptr;
     if (k > 4096) PGV_FAIL(PGV_ERR_ARG, "top-k: k = %d exceeds the supported 4096", k);
     int kp = 2;
     while (kp < k) kp <<= 1;
@@ -522,7 +530,7 @@ int launch_batch_fix(pgv_ctx *ctx, const ExactRows &xr, const void *q_dev, int n
     hipLaunchKernelGGL(batch_fix_kernel<T>, dim3(grid), dim3(kQThreads), lds, ctx->stream,                           \
                        static_cast<const char *>(xr.vectors), xr.list_offsets, xr.tids, xr.geom.nvec,                \
                        xr.geom.lpr_log2, static_cast<const char *>(q_dev), probe_lists, probe_off, probes, seg_start, \
-                       fixed_len, flags, nq, seg_vals, k, kp, cap, out_dist, out_slot, out_tid)
+                       fixed_len, flags, nq, seg_vals, k, kp, cap, out_dist, out_slot, out_tid, out_i32, stats)
     if (xr.dtype == PGV_F32)
         PGV_FIX(float);
     else

@@ -386,15 +386,6 @@ int launch_positions_to_slots(pgv_ctx *ctx, const pgv_index *ix, const int32_t *
     return PGV_OK;
 }
 
-__global__ void count_flags_kernel(const int32_t *__restrict__ count, double *__restrict__ acc) { acc[6] += (double)*count; }
-
-int launch_count_flags(pgv_ctx *ctx, const int32_t *count_dev, int nq) {
-    (void)nq;
-    hipLaunchKernelGGL(count_flags_kernel, dim3(1), dim3(1), 0, ctx->stream, count_dev, ctx->stats_dev.as<double>());
-    PGV_HIP(hipGetLastError());
-    return PGV_OK;
-}
-
 int launch_iota_slots(pgv_ctx *ctx, const pgv_index *ix, const int32_t *lists_dev, int nlists,
                       const int64_t *probe_off, int64_t *out_slot) {
     if (nlists <= 0) return PGV_OK;

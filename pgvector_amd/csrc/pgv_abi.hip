@@ -769,10 +769,13 @@ static int rank_lists_dev(pgv_index *ix, const void *q_dev, int nq, int maxprobe
         const ExactRows xr{ix->centers, nullptr, nullptr, ix->geom, ix->dtype,
                            reinterpret_cast<const unsigned *>(ix->center_norms + ix->nlists)};
         // a center's position in the matrix row is its id: cand_pos serves as the slots
+        // the center ids leave as the int32 list ids the callers want (no conversion pass)
         PGV_TRY(launch_batch_recheck(ctx, xr, q_dev, nq, cand, maxprobes, sc.cand_val, sc.cand_pos, sc.cand_pos, nullptr,
-                                     ix->nlists, sc.qnorm, expansion_gamma(ix->dim), dist, pos, nullptr, sc.flags));
+                                     ix->nlists, sc.qnorm, expansion_gamma(ix->dim), dist, nullptr, nullptr, sc.flags,
+                                     out_lists_dev));
         PGV_TRY(launch_batch_fix(ctx, xr, q_dev, nq, nullptr, nullptr, 0, nullptr, ix->nlists, sc.flags, mat, maxprobes,
-                                 dist, pos, nullptr));
+                                 dist, nullptr, nullptr, out_lists_dev));
+        return PGV_OK;
     } else {
         PGV_TRY(dense_scan(ctx, ix->metric, ix->dtype, ix->geom, ix->centers, ix->nlists, q_dev, nq, ix->nlists, mat,
                            mfma, nullptr, nullptr));
@@ -974,7 +977,6 @@ static int scan_batch_dev(pgv_index *ix, const void *q_dev, int nq, const int32_
                                      qnorm, gamma, od.as<float>(), os.as<int64_t>(), ot.as<uint64_t>(), flags));
         PGV_TRY(launch_batch_fix(ctx, xr, q_dev, nq, probe_lists, plan.probe_off, probes, plan.seg_start, 0, flags,
                                  seg_vals, k, od.as<float>(), os.as<int64_t>(), ot.as<uint64_t>()));
-        if (ctx->profiling && ctx->stats_dev.p) PGV_TRY(launch_count_flags(ctx, flags + nq, nq));
     } else {
         PGV_TRY(launch_topk_segments(ctx, seg_vals, plan.seg_start, nq, 0, k, od.as<float>(), pos));
         PGV_TRY(launch_positions_to_slots(ctx, ix, probe_lists, plan.probe_off, nq, probes, k, pos,

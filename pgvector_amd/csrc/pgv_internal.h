@@ -301,13 +301,14 @@ struct ExactRows {
 int launch_batch_recheck(pgv_ctx *ctx, const ExactRows &xr, const void *q_dev, int nq, int kprime, int k,
                          const float *approx_val, const int64_t *cand_pos, const int64_t *cand_slot,
                          const int64_t *seg_start, int64_t fixed_len, const float *query_norms, float gamma,
-                         float *out_dist, int64_t *out_slot, uint64_t *out_tid, int32_t *flags);
+                         float *out_dist, int64_t *out_slot, uint64_t *out_tid, int32_t *flags,
+                         int32_t *out_i32 = nullptr);
 // the flagged queries start to end: exact scores of the whole segment, head, output row (out_slot: row slots, or
 // center ids for the dense form)
 int launch_batch_fix(pgv_ctx *ctx, const ExactRows &xr, const void *q_dev, int nq, const int32_t *probe_lists,
                      const int64_t *probe_off, int probes, const int64_t *seg_start, int64_t fixed_len,
-                     const int32_t *flags, float *seg_vals, int k, float *out_dist, int64_t *out_slot, uint64_t *out_tid);
-int launch_count_flags(pgv_ctx *ctx, const int32_t *count_dev, int nq);  // profiling: stats slot 6 += *count_dev
+                     const int32_t *flags, float *seg_vals, int k, float *out_dist, int64_t *out_slot, uint64_t *out_tid,
+                     int32_t *out_i32 = nullptr);
 int launch_iota_slots(pgv_ctx *ctx, const pgv_index *ix, const int32_t *lists_dev, int nlists,
                       const int64_t *probe_off, int64_t *out_slot);
 
