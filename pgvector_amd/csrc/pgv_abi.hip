@@ -907,8 +907,8 @@ static int scan_batch_dev(pgv_index *ix, const void *q_dev, int nq, const int32_
     // worth.  Lists probed by more than 8 queries go to the tile kernel (16 queries per pass
     // over the rows) when the row shape allows it.
     const double share = (double)nq * probes / (double)ix->nlists;
-    // ... and to the matrix cores (32 queries per pass) for L2 / inner product heads of up to 64
-    const bool use_mfma = share > 3.0 && k <= 64 && !ctx->no_mfma_scan &&
+    // ... and to the matrix cores (32 queries per pass) for L2 / inner product heads of up to 192
+    const bool use_mfma = share > 3.0 && k <= 192 && !ctx->no_mfma_scan &&
                           (ix->metric == PGV_NEG_IP || (ix->metric == PGV_L2SQ && ix->row_norms));
     const bool use_tile = !use_mfma && tile_scan_supported(ix->geom) && share > 8.0;
     const int qt = use_mfma ? mfma_scan_queries_per_task()
@@ -926,7 +926,9 @@ static int scan_batch_dev(pgv_index *ix, const void *q_dev, int nq, const int32_
     int kprime = k;
     ApproxScratch sc;
     if (approx) {
-        kprime = k <= 8 ? 32 : 4 * k;  // 32 .. 256: the head asked for and a margin the rounding bound clears easily
+        // 32 .. 256 candidates: the head asked for and a margin the rounding bound clears easily (4 k while that
+        // fits batch_recheck_kernel's 256, k + 64 beyond)
+        kprime = k <= 8 ? 32 : (4 * k <= 256 ? 4 * k : k + 64);
         PGV_TRY(sc.carve(ctx, ctx->ms_a, nq, kprime));
         if (ctx->qnorm_of == q_dev && ctx->qnorm_n == nq && ctx->ms_b.p)
             sc.qnorm = ctx->ms_b.as<float>();  // computed by this call's center ranking

@@ -474,6 +474,8 @@ def _batch_vs_oracle(ctx, oracle, ivf, queries, probes, k, what, expect_redo=Non
     (po.OPS_L2, po.ORA_F32, 3, 4000, 5, 80, 2, 64, "normal"),           # one vector per row; k = 64 -> k' = 256
     (po.OPS_L2, po.ORA_F16, 3072, 2400, 10, 70, 5, 10, "clustered"),    # configs[4] row shape
     (po.OPS_L2, po.ORA_F16, 72, 5000, 6, 64, 6, 40, "normal"),
+    (po.OPS_L2, po.ORA_F32, 40, 6000, 6, 70, 3, 100, "normal"),        # k = 100 -> k' = 164
+    (po.OPS_L2, po.ORA_F32, 24, 6000, 5, 60, 2, 192, "uniform"),       # the largest head of this path: k' = 256
     (po.OPS_IP, po.ORA_F32, 1536, 2400, 10, 70, 5, 10, "clustered"),    # configs[2]: the MFMA value is the result
     (po.OPS_IP, po.ORA_F16, 1024, 2400, 10, 100, 4, 10, "clustered"),
     (po.OPS_COSINE, po.ORA_F32, 200, 4000, 10, 90, 3, 10, "clustered"),
