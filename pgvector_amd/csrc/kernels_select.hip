@@ -149,12 +149,16 @@ __device__ __forceinline__ bool dist_before(float a, float b) { return float_to_
 
 __global__ __launch_bounds__(kSelThreads) void topk_kernel(
     const float *__restrict__ vals, const int64_t *__restrict__ seg_start, int64_t fixed_len,
-    int k, int kp, int cap, float *__restrict__ out_val, int64_t *__restrict__ out_pos) {
+    int k, int kp, int cap, float *__restrict__ out_val, int64_t *__restrict__ out_pos,
+    int32_t *__restrict__ zero_word) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     unsigned long long *ent = reinterpret_cast<unsigned long long *>(smem);  // [cap >= kp]
     SelShared *s = reinterpret_cast<SelShared *>(smem + (size_t)cap * 8);
 
     const int seg = blockIdx.x;
+    // a counter the NEXT kernel in the stream starts from zero (the flagged-query count of the exact tail):
+    // cleared here instead of by a memset launch of its own
+    if (zero_word && seg == 0 && threadIdx.x == 0) *zero_word = 0;
     const int64_t base = seg_start ? seg_start[seg] : (int64_t)seg * fixed_len;
     const int64_t m = seg_start ? seg_start[seg + 1] - base : fixed_len;
     const float *v = vals + base;
@@ -360,7 +364,7 @@ int launch_plan_batch(pgv_ctx *ctx, const pgv_index *ix, const int32_t *probe_li
 }
 
 int launch_topk_segments(pgv_ctx *ctx, const float *vals, const int64_t *seg_start, int nseg,
-                         int64_t fixed_len, int k, float *out_val, int64_t *out_pos) {
+                         int64_t fixed_len, int k, float *out_val, int64_t *out_pos, int32_t *zero_word) {
     if (nseg <= 0 || k <= 0) return PGV_OK;
     if (k > 4096) PGV_FAIL(PGV_ERR_ARG, "top-k: k = %d exceeds the supported 4096", k);
     int kp = 1;
@@ -369,7 +373,7 @@ int launch_topk_segments(pgv_ctx *ctx, const float *vals, const int64_t *seg_sta
     const int cap = kp > kFastCap ? kp : kFastCap;
     const size_t lds = (size_t)cap * 8 + sizeof(SelShared);
     hipLaunchKernelGGL(topk_kernel, dim3(nseg), dim3(kSelThreads), lds, ctx->stream, vals,
-                       seg_start, fixed_len, k, kp, cap, out_val, out_pos);
+                       seg_start, fixed_len, k, kp, cap, out_val, out_pos, zero_word);
     PGV_HIP(hipGetLastError());
     return PGV_OK;
 }

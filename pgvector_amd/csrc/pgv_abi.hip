@@ -728,8 +728,7 @@ struct ApproxScratch {
         cand_val = reinterpret_cast<float *>(b + a1);
         cand_pos = reinterpret_cast<int64_t *>(b + a2);
         cand_slot = reinterpret_cast<int64_t *>(b + a3);
-        flags = reinterpret_cast<int32_t *>(b + a4);
-        PGV_HIP(hipMemsetAsync(flags + nq, 0, sizeof(int32_t), ctx->stream));
+        flags = reinterpret_cast<int32_t *>(b + a4);  // flags[nq], the count, is cleared by the candidates' top-k launch
         return PGV_OK;
     }
 };
@@ -765,7 +764,7 @@ static int rank_lists_dev(pgv_index *ix, const void *q_dev, int nq, int maxprobe
         ctx->qnorm_n = nq;
         PGV_TRY(dense_scan(ctx, ix->metric, ix->dtype, ix->geom, ix->centers, ix->nlists, q_dev, nq, ix->nlists, mat,
                            true, ix->center_norms, sc.qnorm));
-        PGV_TRY(launch_topk_segments(ctx, mat, nullptr, nq, ix->nlists, cand, sc.cand_val, sc.cand_pos));
+        PGV_TRY(launch_topk_segments(ctx, mat, nullptr, nq, ix->nlists, cand, sc.cand_val, sc.cand_pos, sc.flags + nq));
         const ExactRows xr{ix->centers, nullptr, nullptr, ix->geom, ix->dtype,
                            reinterpret_cast<const unsigned *>(ix->center_norms + ix->nlists)};
         // a center's position in the matrix row is its id: cand_pos serves as the slots
@@ -970,7 +969,7 @@ static int scan_batch_dev(pgv_index *ix, const void *q_dev, int nq, const int32_
         // k' candidates by the expansion, their exact distances, the head; queries whose candidate
         // set cannot be proven complete (flags) take the exact pass over their whole segment
         const float gamma = expansion_gamma(ix->dim);
-        PGV_TRY(launch_topk_segments(ctx, seg_vals, plan.seg_start, nq, 0, kprime, cand_val, cand_pos));
+        PGV_TRY(launch_topk_segments(ctx, seg_vals, plan.seg_start, nq, 0, kprime, cand_val, cand_pos, flags + nq));
         PGV_TRY(launch_positions_to_slots(ctx, ix, probe_lists, plan.probe_off, nq, probes, kprime, cand_pos,
                                           cand_slot, nullptr));
         const ExactRows xr{ix->vectors, ix->tids, ix->list_offsets, ix->geom, ix->dtype,

@@ -284,7 +284,7 @@ struct PlanResult {
 int launch_plan_batch(pgv_ctx *ctx, const pgv_index *ix, const int32_t *probe_lists, int nq,
                       int probes, int qt, int rows_per_task, bool read_totals, PlanResult *res);
 int launch_topk_segments(pgv_ctx *ctx, const float *vals, const int64_t *seg_start, int nseg,
-                         int64_t fixed_len, int k, float *out_val, int64_t *out_pos);
+                         int64_t fixed_len, int k, float *out_val, int64_t *out_pos, int32_t *zero_word = nullptr);
 int launch_positions_to_slots(pgv_ctx *ctx, const pgv_index *ix, const int32_t *probe_lists,
                               const int64_t *probe_off, int nq, int probes, int k,
                               const int64_t *pos, int64_t *out_slot, uint64_t *out_tid);
