@@ -384,7 +384,7 @@ def concurrent_backends(index, device, qhost, queries, probes, k, args, dev):
                              C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_double)]
     res4 = (C.c_double * 4)()
     out["pooled_single_query"] = {}
-    for nc in (16, 64, 256, 1024):
+    for nc in (16, 64, 256):
         rc = drv.pool_run(index.h, device, index.dtype, index.dim, nc, max(40, 6000 // nc), qh.ctypes.data, qh.shape[0],
                           qh.strides[0], probes, k, 1024, 50, 2, res4)
         if rc != 0:
