@@ -460,6 +460,11 @@ test_pool(void)
 	CHECK(pgv_ctx_create(0, NULL, &ctx));
 	CHECK(pgv_index_upload(ctx, PGV_L2SQ, PGV_F32, DIM, LISTS, centers, off, rows, tids, &ix));
 	CHECK(pgv_search_batch(ix, queries, NQ, 2, K, want_d, NULL, want_t));
+	/* argument checks: nothing is created, the error is reported */
+	EXPECT(pgv_host_pool_create(NULL, 0, PGV_F32, DIM, 2, K, 5, 300, 2, &pool) != PGV_OK);
+	EXPECT(pgv_host_pool_create(ix, 0, PGV_F32, DIM, 2, K, 0, 300, 2, &pool) != PGV_OK && pool == NULL);
+	EXPECT(pgv_host_pool_create(ix, 0, PGV_F32, DIM, 2, K, 5, 300, 9, &pool) != PGV_OK && pool == NULL);
+	EXPECT(pgv_host_pool_search(NULL, queries, got_t, got_d) != PGV_OK);
 	/* small batches, short wait, two lanes: leaders, followers, full and timed-out batches, lanes handed on */
 	CHECK(pgv_host_pool_create(ix, 0, PGV_F32, DIM, 2, K, 5, 300, 2, &pool));
 	for (int t = 0; t < THREADS; t++)
