@@ -65,7 +65,24 @@ def big(a):
     e = elem[:a.queries]
     got_ip = (q64[:, None, :] * data[e.clamp(min=0)].double()).sum(-1)
     hits = ((got_ip >= kth[:, None] - 1e-9) & (e >= 0)).sum().item()
+    # ef_search sweep on the same graph (hnsw.ef_search is the user's recall knob, src/hnsw.c:74-77)
+    sweep = {}
+    for ef in (40, 100, 200, 400, 800):
+        if ef < a.k:
+            continue
+        mirror.search(qd[:64].contiguous(), ef, a.k)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        e2, _, sc2 = mirror.search(qd, ef, a.k)
+        torch.cuda.synchronize()
+        s2 = time.perf_counter() - t0
+        e2 = e2[:a.queries]
+        gip = (q64[:, None, :] * data[e2.clamp(min=0)].double()).sum(-1)
+        h2 = ((gip >= kth[:, None] - 1e-9) & (e2 >= 0)).sum().item()
+        sweep[str(ef)] = {"qps": qd.shape[0] / s2, "recall_at_k": h2 / (a.queries * a.k),
+                          "scored_elements_per_query": float(sc2.float().mean().item())}
     print(json.dumps({
+        "ef_search_sweep": sweep,
         "metric": "HNSW QPS (pgv_hnsw_search, graph built by pgv_host_hnsw_build)", "value": qd.shape[0] / dev_s,
         "unit": "queries/s", "config": {"rows": a.rows, "dim": a.dim, "m": a.m, "ef_construction": a.ef_construction,
                                         "ef_search": a.ef_search, "k": a.k, "queries_in_flight": int(qd.shape[0]),
