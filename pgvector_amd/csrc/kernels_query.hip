@@ -244,6 +244,8 @@ __global__ __launch_bounds__(kQThreads) void batch_recheck_kernel(
     const char *__restrict__ vectors, const uint64_t *__restrict__ tids, int nvec, int lg,
     const char *__restrict__ queries, int kprime, int k, const float *__restrict__ approx_val,
     const int64_t *__restrict__ cand_pos, const int64_t *__restrict__ cand_slot,
+    const int64_t *__restrict__ list_off, const int32_t *__restrict__ probe_lists,
+    const int64_t *__restrict__ probe_off, int probes,
     const int64_t *__restrict__ seg_start, int64_t fixed_len, const float *__restrict__ query_norms,
     const unsigned *__restrict__ row_norm_max, float gamma, int nq, float *__restrict__ out_dist,
     int64_t *__restrict__ out_slot, uint64_t *__restrict__ out_tid, int32_t *__restrict__ out_i32,
@@ -263,7 +265,29 @@ __global__ __launch_bounds__(kQThreads) void batch_recheck_kernel(
     const float eps = gamma * (qn + rn + 2.f * sqrtf(qn * rn));
     const unsigned band = kk > 0 ? float_to_key(av[kk - 1] + 2.f * eps) : 0u;  // NaN / inf anywhere: everything is in the band
     const int cnt = __syncthreads_count((int)threadIdx.x < ncand && float_to_key(av[threadIdx.x]) <= band);
-    const int64_t *slots = cand_slot + (size_t)q * kprime;
+    // the candidates' row slots: given (the center ranking: a center's position is its id), or worked out here from
+    // the positions in the query's segment (the list scan; what positions_to_slots_kernel does for the exact paths)
+    __shared__ int64_t slots[kRecheckCap];
+    if ((int)threadIdx.x < cnt) {
+        const int64_t p = cand_pos[(size_t)q * kprime + threadIdx.x];
+        int64_t slot = p;
+        if (cand_slot) {
+            slot = cand_slot[(size_t)q * kprime + threadIdx.x];
+        } else {
+            const int64_t *off = probe_off + (size_t)q * probes;
+            int lo = 0, hi = probes - 1;  // last probe whose offset <= p
+            while (lo < hi) {
+                const int mid = (lo + hi + 1) >> 1;
+                if (off[mid] <= p)
+                    lo = mid;
+                else
+                    hi = mid - 1;
+            }
+            slot = list_off[probe_lists[(size_t)q * probes + lo]] + (p - off[lo]);
+        }
+        slots[threadIdx.x] = slot;
+    }
+    __syncthreads();
     score_rows<T, 0, 0>([&](int64_t j) { return vectors + (size_t)slots[j] * row_bytes; }, 0, cnt,
                         queries + (size_t)q * row_bytes, nvec, lg, exact);
     __syncthreads();
@@ -497,14 +521,15 @@ int launch_query_head(pgv_ctx *ctx, const pgv_index *ix, const float *seg, const
 int launch_batch_recheck(pgv_ctx *ctx, const ExactRows &xr, const void *q_dev, int nq, int kprime, int k,
                          const float *approx_val, const int64_t *cand_pos, const int64_t *cand_slot,
                          const int64_t *seg_start, int64_t fixed_len, const float *query_norms, float gamma,
-                         float *out_dist, int64_t *out_slot, uint64_t *out_tid, int32_t *flags, int32_t *out_i32) {
+                         float *out_dist, int64_t *out_slot, uint64_t *out_tid, int32_t *flags, int32_t *out_i32,
+                         const int32_t *probe_lists, const int64_t *probe_off, int probes) {
     if (nq <= 0) return PGV_OK;
     if (kprime > kRecheckCap || k > kprime) PGV_FAIL(PGV_ERR_ARG, "recheck: k' = %d outside k..%d", kprime, kRecheckCap);
 #define PGV_RECHECK(T)                                                                                              \
     hipLaunchKernelGGL(batch_recheck_kernel<T>, dim3(nq), dim3(kQThreads), 0, ctx->stream,                           \
                        static_cast<const char *>(xr.vectors), xr.tids, xr.geom.nvec, xr.geom.lpr_log2,               \
-                       static_cast<const char *>(q_dev), kprime, k, approx_val, cand_pos, cand_slot, seg_start,      \
-                       fixed_len, query_norms, xr.norm_max, gamma, nq, out_dist, out_slot, out_tid, out_i32, flags)
+                       static_cast<const char *>(q_dev), kprime, k, approx_val, cand_pos, cand_slot, xr.list_offsets, \
+                       probe_lists, probe_off, probes, seg_start, fixed_len, query_norms, xr.norm_max, gamma, nq, out_dist, out_slot, out_tid, out_i32, flags)
     if (xr.dtype == PGV_F32)
         PGV_RECHECK(float);
     else

@@ -936,7 +936,7 @@ static int scan_batch_dev(pgv_index *ix, const void *q_dev, int nq, const int32_
     }
     ctx->qnorm_of = nullptr;
     float *qnorm = sc.qnorm, *cand_val = sc.cand_val;
-    int64_t *cand_pos = sc.cand_pos, *cand_slot = sc.cand_slot;
+    int64_t *cand_pos = sc.cand_pos;
     int32_t *flags = sc.flags;
 
     // GetScanItems: one streaming pass
@@ -970,12 +970,12 @@ static int scan_batch_dev(pgv_index *ix, const void *q_dev, int nq, const int32_
         // set cannot be proven complete (flags) take the exact pass over their whole segment
         const float gamma = expansion_gamma(ix->dim);
         PGV_TRY(launch_topk_segments(ctx, seg_vals, plan.seg_start, nq, 0, kprime, cand_val, cand_pos, flags + nq));
-        PGV_TRY(launch_positions_to_slots(ctx, ix, probe_lists, plan.probe_off, nq, probes, kprime, cand_pos,
-                                          cand_slot, nullptr));
         const ExactRows xr{ix->vectors, ix->tids, ix->list_offsets, ix->geom, ix->dtype,
                            reinterpret_cast<const unsigned *>(ix->row_norms + ix->nrows)};
-        PGV_TRY(launch_batch_recheck(ctx, xr, q_dev, nq, kprime, k, cand_val, cand_pos, cand_slot, plan.seg_start, 0,
-                                     qnorm, gamma, od.as<float>(), os.as<int64_t>(), ot.as<uint64_t>(), flags));
+        // (the candidates' positions become row slots inside the recheck)
+        PGV_TRY(launch_batch_recheck(ctx, xr, q_dev, nq, kprime, k, cand_val, cand_pos, nullptr, plan.seg_start, 0,
+                                     qnorm, gamma, od.as<float>(), os.as<int64_t>(), ot.as<uint64_t>(), flags, nullptr,
+                                     probe_lists, plan.probe_off, probes));
         PGV_TRY(launch_batch_fix(ctx, xr, q_dev, nq, probe_lists, plan.probe_off, probes, plan.seg_start, 0, flags,
                                  seg_vals, k, od.as<float>(), os.as<int64_t>(), ot.as<uint64_t>()));
     } else {

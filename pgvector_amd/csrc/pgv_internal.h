@@ -302,7 +302,8 @@ int launch_batch_recheck(pgv_ctx *ctx, const ExactRows &xr, const void *q_dev, i
                          const float *approx_val, const int64_t *cand_pos, const int64_t *cand_slot,
                          const int64_t *seg_start, int64_t fixed_len, const float *query_norms, float gamma,
                          float *out_dist, int64_t *out_slot, uint64_t *out_tid, int32_t *flags,
-                         int32_t *out_i32 = nullptr);
+                         int32_t *out_i32 = nullptr, const int32_t *probe_lists = nullptr,
+                         const int64_t *probe_off = nullptr, int probes = 0);  // cand_slot null: slots from the positions
 // the flagged queries start to end: exact scores of the whole segment, head, output row (out_slot: row slots, or
 // center ids for the dense form)
 int launch_batch_fix(pgv_ctx *ctx, const ExactRows &xr, const void *q_dev, int nq, const int32_t *probe_lists,
