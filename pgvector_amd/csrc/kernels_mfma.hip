@@ -578,7 +578,8 @@ int launch_mfma_mode(pgv_ctx *ctx, int mode, const RowGeom &g, const void *rows,
 // and the 32 lanes of a half-wave hold 32 consecutive rows of one query: 128-byte stores into
 // the queries' output segments.
 //   METRIC 1 (negative inner product): the value is the reference's arithmetic.
-//   METRIC 0 (L2): |q|^2 + |x|^2 - 2 q.x with precomputed norms -- an APPROXIMATION of
+//   METRIC 0 (L2): |x|^2 - 2 q.x with the rows' precomputed norms (+ |q|^2 when the caller hands the queries' in:
+//   it shifts all values of a query alike, so the selections run without it) -- an APPROXIMATION of
 //   sum((q-x)^2) (cancellation), used only to pick candidates; pgv_abi.hip's scan_batch_dev
 //   re-evaluates the exact form for the k' best and checks that nothing outside them can matter.
 constexpr int kScanQueries = 32;   // queries per task
@@ -633,7 +634,8 @@ __global__ __launch_bounds__(NW * 64) void mfma_scan_kernel(
             // slots past the task's last query repeat that query
             const ScanPair pr = pairs[task.pair0 + ((int)threadIdx.x < np ? (int)threadIdx.x : np - 1)];
             pair_rel[threadIdx.x] = pr.out_rel + task.row0;
-            pair_qn[threadIdx.x] = METRIC == 0 ? query_norms[pr.query] : 0.f;
+            // |q|^2 shifts every value of a query alike: the selection does not need it, the exact tail computes it
+            pair_qn[threadIdx.x] = (METRIC == 0 && query_norms) ? query_norms[pr.query] : 0.f;
         }
         const char *src[NDMA];
 #pragma unroll

@@ -231,7 +231,8 @@ __global__ void query_iota_kernel(int32_t *__restrict__ out, int n) {
 }
 
 // ------------------------------------------------------------------- exact tail of the MFMA L2 scan
-// mfma_scan_kernel's L2 values are |q|^2 + |x|^2 - 2 q.x: they pick k' candidates per query, and this
+// mfma_scan_kernel's L2 values are |x|^2 - 2 q.x (the expansion of the distance less its per-query constant |q|^2):
+// they pick k' candidates per query, and this
 // kernel (one workgroup per query) re-evaluates those with the reference's arithmetic
 // (sum of (q - x)^2, src/vector.c:172-185), sorts them the way the tuplesort would (distance, then
 // position in the stream) and emits the first k.  A query is flagged for the full exact pass unless
@@ -246,7 +247,7 @@ __global__ __launch_bounds__(kQThreads) void batch_recheck_kernel(
     const int64_t *__restrict__ cand_pos, const int64_t *__restrict__ cand_slot,
     const int64_t *__restrict__ list_off, const int32_t *__restrict__ probe_lists,
     const int64_t *__restrict__ probe_off, int probes,
-    const int64_t *__restrict__ seg_start, int64_t fixed_len, const float *__restrict__ query_norms,
+    const int64_t *__restrict__ seg_start, int64_t fixed_len,
     const unsigned *__restrict__ row_norm_max, float gamma, int nq, float *__restrict__ out_dist,
     int64_t *__restrict__ out_slot, uint64_t *__restrict__ out_tid, int32_t *__restrict__ out_i32,
     int32_t *__restrict__ flags) {
@@ -261,7 +262,22 @@ __global__ __launch_bounds__(kQThreads) void batch_recheck_kernel(
     // exact <= approx[k] + eps, every row with approx > approx[k] + 2 eps has exact > approx[k] + eps.  The candidates
     // come sorted (float8 order, NaN last), so the band is a prefix; it is usually k + a few of the k' rows.
     const float *av = approx_val + (size_t)q * kprime;
-    const float qn = query_norms[q], rn = __uint_as_float(*row_norm_max);
+    // |q|^2 for the bound (the approximate values carry none: it would shift a query's values alike)
+    __shared__ float qn_part[kQWaves];
+    {
+        const char *qrow = queries + (size_t)q * row_bytes;
+        float a = 0.f;
+        for (int v = threadIdx.x; v < nvec; v += kQThreads) {
+            const Raw16 x = load16(qrow + (size_t)v * sizeof(Raw16));
+            a = accum_slice<T, 1>(a, x, x);
+        }
+        for (int m2 = 32; m2 > 0; m2 >>= 1) a += __shfl_xor(a, m2);
+        if ((threadIdx.x & (kWave - 1)) == 0) qn_part[threadIdx.x >> 6] = a;
+    }
+    __syncthreads();
+    float qn = 0.f;
+    for (int w = 0; w < kQWaves; w++) qn += qn_part[w];
+    const float rn = __uint_as_float(*row_norm_max);
     const float eps = gamma * (qn + rn + 2.f * sqrtf(qn * rn));
     const unsigned band = kk > 0 ? float_to_key(av[kk - 1] + 2.f * eps) : 0u;  // NaN / inf anywhere: everything is in the band
     const int cnt = __syncthreads_count((int)threadIdx.x < ncand && float_to_key(av[threadIdx.x]) <= band);
@@ -520,7 +536,7 @@ int launch_query_head(pgv_ctx *ctx, const pgv_index *ix, const float *seg, const
 
 int launch_batch_recheck(pgv_ctx *ctx, const ExactRows &xr, const void *q_dev, int nq, int kprime, int k,
                          const float *approx_val, const int64_t *cand_pos, const int64_t *cand_slot,
-                         const int64_t *seg_start, int64_t fixed_len, const float *query_norms, float gamma,
+                         const int64_t *seg_start, int64_t fixed_len, float gamma,
                          float *out_dist, int64_t *out_slot, uint64_t *out_tid, int32_t *flags, int32_t *out_i32,
                          const int32_t *probe_lists, const int64_t *probe_off, int probes) {
     if (nq <= 0) return PGV_OK;
@@ -529,7 +545,7 @@ int launch_batch_recheck(pgv_ctx *ctx, const ExactRows &xr, const void *q_dev, i
     hipLaunchKernelGGL(batch_recheck_kernel<T>, dim3(nq), dim3(kQThreads), 0, ctx->stream,                           \
                        static_cast<const char *>(xr.vectors), xr.tids, xr.geom.nvec, xr.geom.lpr_log2,               \
                        static_cast<const char *>(q_dev), kprime, k, approx_val, cand_pos, cand_slot, xr.list_offsets, \
-                       probe_lists, probe_off, probes, seg_start, fixed_len, query_norms, xr.norm_max, gamma, nq, out_dist, out_slot, out_tid, out_i32, flags)
+                       probe_lists, probe_off, probes, seg_start, fixed_len, xr.norm_max, gamma, nq, out_dist, out_slot, out_tid, out_i32, flags)
     if (xr.dtype == PGV_F32)
         PGV_RECHECK(float);
     else

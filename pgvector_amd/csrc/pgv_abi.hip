@@ -714,21 +714,19 @@ int pgv_index_lists(const pgv_index *ix) { return ix ? ix->nlists : -1; }
 
 // scratch of an approximate (MFMA) L2 pass over nq queries keeping kprime candidates each
 struct ApproxScratch {
-    float *qnorm = nullptr, *cand_val = nullptr;
-    int64_t *cand_pos = nullptr, *cand_slot = nullptr;
-    int32_t *flags = nullptr;  // [nq] flags | count | list of flagged queries
+    float *cand_val = nullptr;   // [nq x kprime] approximate values, ascending
+    int64_t *cand_pos = nullptr; // [nq x kprime] positions in the query's segment (center ids for the ranking)
+    int32_t *flags = nullptr;    // [nq] flags | count | list of flagged queries
     int carve(pgv_ctx *ctx, DBuf &buf, int nq, int kprime) {
+        (void)ctx;
         const size_t nk = (size_t)nq * kprime;
-        const size_t a1 = (sizeof(float) * (size_t)nq + 15) & ~(size_t)15, a2 = a1 + ((sizeof(float) * nk + 15) & ~(size_t)15),
-                     a3 = a2 + sizeof(int64_t) * nk, a4 = a3 + sizeof(int64_t) * nk,
-                     a5 = a4 + sizeof(int32_t) * (2 * (size_t)nq + 1);
-        PGV_TRY(buf.ensure(a5));
+        const size_t a1 = (sizeof(float) * nk + 15) & ~(size_t)15, a2 = a1 + sizeof(int64_t) * nk,
+                     a3 = a2 + sizeof(int32_t) * (2 * (size_t)nq + 1);
+        PGV_TRY(buf.ensure(a3));
         char *b = buf.as<char>();
-        qnorm = reinterpret_cast<float *>(b);
-        cand_val = reinterpret_cast<float *>(b + a1);
-        cand_pos = reinterpret_cast<int64_t *>(b + a2);
-        cand_slot = reinterpret_cast<int64_t *>(b + a3);
-        flags = reinterpret_cast<int32_t *>(b + a4);  // flags[nq], the count, is cleared by the candidates' top-k launch
+        cand_val = reinterpret_cast<float *>(b);
+        cand_pos = reinterpret_cast<int64_t *>(b + a1);
+        flags = reinterpret_cast<int32_t *>(b + a2);  // flags[nq], the count, is cleared by the candidates' top-k launch
         return PGV_OK;
     }
 };
@@ -739,7 +737,6 @@ static float expansion_gamma(int dim) { return 8.f * std::sqrt((float)dim + 4.f)
 static int rank_lists_dev(pgv_index *ix, const void *q_dev, int nq, int maxprobes,
                           int32_t *out_lists_dev, float *out_dist_dev) {
     pgv_ctx *ctx = ix->ctx;
-    ctx->qnorm_of = nullptr;
     // distance matrix [nq x nlists], then the maxprobes smallest per row
     PGV_TRY(ctx->dist_mat.ensure(sizeof(float) * (size_t)nq * ix->nlists));
     float *mat = ctx->dist_mat.as<float>();
@@ -759,18 +756,15 @@ static int rank_lists_dev(pgv_index *ix, const void *q_dev, int nq, int maxprobe
     if (mfma && ix->metric == PGV_L2SQ) {
         ApproxScratch sc;
         PGV_TRY(sc.carve(ctx, ctx->ms_b, nq, cand));
-        PGV_TRY(launch_row_norms(ctx, ix->dtype, ix->geom, q_dev, nq, sc.qnorm, nullptr));
-        ctx->qnorm_of = q_dev;  // the list scan of the same call reuses them (pgv_search_batch)
-        ctx->qnorm_n = nq;
         PGV_TRY(dense_scan(ctx, ix->metric, ix->dtype, ix->geom, ix->centers, ix->nlists, q_dev, nq, ix->nlists, mat,
-                           true, ix->center_norms, sc.qnorm));
+                           true, ix->center_norms, nullptr));
         PGV_TRY(launch_topk_segments(ctx, mat, nullptr, nq, ix->nlists, cand, sc.cand_val, sc.cand_pos, sc.flags + nq));
         const ExactRows xr{ix->centers, nullptr, nullptr, ix->geom, ix->dtype,
                            reinterpret_cast<const unsigned *>(ix->center_norms + ix->nlists)};
         // a center's position in the matrix row is its id: cand_pos serves as the slots
         // the center ids leave as the int32 list ids the callers want (no conversion pass)
         PGV_TRY(launch_batch_recheck(ctx, xr, q_dev, nq, cand, maxprobes, sc.cand_val, sc.cand_pos, sc.cand_pos, nullptr,
-                                     ix->nlists, sc.qnorm, expansion_gamma(ix->dim), dist, nullptr, nullptr, sc.flags,
+                                     ix->nlists, expansion_gamma(ix->dim), dist, nullptr, nullptr, sc.flags,
                                      out_lists_dev));
         PGV_TRY(launch_batch_fix(ctx, xr, q_dev, nq, nullptr, nullptr, 0, nullptr, ix->nlists, sc.flags, mat, maxprobes,
                                  dist, nullptr, nullptr, out_lists_dev));
@@ -800,7 +794,6 @@ int pgv_rank_lists(pgv_index *ix, const void *queries, int nq, int maxprobes, in
     PGV_TRY(ol.init(out_lists, sizeof(int32_t) * (size_t)nq * maxprobes, ctx->out_stage));
     PGV_TRY(od.init(out_dist, sizeof(float) * (size_t)nq * maxprobes, ctx->out_stage2));
     PGV_TRY(rank_lists_dev(ix, q_dev, nq, maxprobes, ol.as<int32_t>(), od.as<float>()));
-    ctx->qnorm_of = nullptr;  // the norms' reuse is for the scan of the same pgv_search_batch call only
     bool need = false;
     PGV_TRY(ol.finish(ctx, &need));
     PGV_TRY(od.finish(ctx, &need));
@@ -929,13 +922,8 @@ static int scan_batch_dev(pgv_index *ix, const void *q_dev, int nq, const int32_
         // fits batch_recheck_kernel's 256, k + 64 beyond)
         kprime = k <= 8 ? 32 : (4 * k <= 256 ? 4 * k : k + 64);
         PGV_TRY(sc.carve(ctx, ctx->ms_a, nq, kprime));
-        if (ctx->qnorm_of == q_dev && ctx->qnorm_n == nq && ctx->ms_b.p)
-            sc.qnorm = ctx->ms_b.as<float>();  // computed by this call's center ranking
-        else
-            PGV_TRY(launch_row_norms(ctx, ix->dtype, ix->geom, q_dev, nq, sc.qnorm, nullptr));
     }
-    ctx->qnorm_of = nullptr;
-    float *qnorm = sc.qnorm, *cand_val = sc.cand_val;
+    float *cand_val = sc.cand_val;
     int64_t *cand_pos = sc.cand_pos;
     int32_t *flags = sc.flags;
 
@@ -947,7 +935,7 @@ static int scan_batch_dev(pgv_index *ix, const void *q_dev, int nq, const int32_
         PGV_TRY(timer.begin(0.0, 0.0));  // pairs / rows of this launch are accumulated on the device
         if (use_mfma)
             PGV_TRY(launch_mfma_scan(ctx, ix->metric, ix->dtype, ix->geom, ix->vectors, q_dev, plan.tasks,
-                                     plan.ntasks_dev, (int)plan.ntasks_bound, plan.pairs, ix->row_norms, qnorm,
+                                     plan.ntasks_dev, (int)plan.ntasks_bound, plan.pairs, ix->row_norms, nullptr,
                                      seg_vals));
         else if (use_tile)
             PGV_TRY(launch_tile_scan(ctx, ix->metric, ix->dtype, ix->geom, ix->vectors, q_dev, plan.tasks,
@@ -974,7 +962,7 @@ static int scan_batch_dev(pgv_index *ix, const void *q_dev, int nq, const int32_
                            reinterpret_cast<const unsigned *>(ix->row_norms + ix->nrows)};
         // (the candidates' positions become row slots inside the recheck)
         PGV_TRY(launch_batch_recheck(ctx, xr, q_dev, nq, kprime, k, cand_val, cand_pos, nullptr, plan.seg_start, 0,
-                                     qnorm, gamma, od.as<float>(), os.as<int64_t>(), ot.as<uint64_t>(), flags, nullptr,
+                                     gamma, od.as<float>(), os.as<int64_t>(), ot.as<uint64_t>(), flags, nullptr,
                                      probe_lists, plan.probe_off, probes));
         PGV_TRY(launch_batch_fix(ctx, xr, q_dev, nq, probe_lists, plan.probe_off, probes, plan.seg_start, 0, flags,
                                  seg_vals, k, od.as<float>(), os.as<int64_t>(), ot.as<uint64_t>()));
@@ -1022,7 +1010,6 @@ int pgv_scan_batch(pgv_index *ix, const void *queries, int nq, const int32_t *pr
     if (nq == 0) return PGV_OK;
     if (!probe_lists) PGV_FAIL(PGV_ERR_ARG, "probe_lists is NULL");
     pgv_ctx *ctx = ix->ctx;
-    ctx->qnorm_of = nullptr;
     PGV_HIP(hipSetDevice(ctx->device));
     // the planner indexes list_offsets with these ids: host-side lists are checked here; lists that are
     // already on the device must come from pgv_rank_lists (ids in range, distinct per query)
@@ -1991,7 +1978,6 @@ int pgv_search_batch_sharded(pgv_comm *cm, pgv_index *ix, const void *queries, i
     if (hi > lo)
         PGV_TRY(rank_lists_dev(ix, static_cast<const char *>(q_dev) + (size_t)lo * row_bytes, hi - lo, probes, lists_mine,
                                nullptr));
-    ctx->qnorm_of = nullptr;
     PGV_TRY(comm_all_gather(cm, lists_mine, lists_all, slice_bytes));
 
     // GetScanItems: the probed lists this rank owns, for the whole batch

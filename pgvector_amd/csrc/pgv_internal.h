@@ -111,8 +111,6 @@ struct pgv_ctx {
     int64_t dense_plan_rows = -1, dense_plan_stride = -1;
     int dense_plan_nq = -1;
     bool counters_clean = false;  // ctx->counters starts zeroed; mfma_scan_kernel leaves its words zero again
-    const void *qnorm_of = nullptr;  // queries whose |q|^2 (qnorm_n of them) sit at the head of ms_b: one API call's span
-    int qnorm_n = 0;
     pgv::DBuf ms_a;  // MFMA list scan: query norms | candidate values, positions, slots | flags
     pgv::DBuf mf_a, mf_b, mf_c, zeros;  // MFMA assignment: norms, pre-filter candidates, redo list; 16 zero bytes
     pgv::DBuf stats_dev;  // profiling: {pairs, rows streamed} of the batched list scans, as doubles
@@ -300,7 +298,7 @@ struct ExactRows {
 };
 int launch_batch_recheck(pgv_ctx *ctx, const ExactRows &xr, const void *q_dev, int nq, int kprime, int k,
                          const float *approx_val, const int64_t *cand_pos, const int64_t *cand_slot,
-                         const int64_t *seg_start, int64_t fixed_len, const float *query_norms, float gamma,
+                         const int64_t *seg_start, int64_t fixed_len, float gamma,
                          float *out_dist, int64_t *out_slot, uint64_t *out_tid, int32_t *flags,
                          int32_t *out_i32 = nullptr, const int32_t *probe_lists = nullptr,
                          const int64_t *probe_off = nullptr, int probes = 0);  // cand_slot null: slots from the positions
