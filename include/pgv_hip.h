@@ -116,6 +116,8 @@ int			pgv_abi_version(void);
 
 /* number of HIP devices visible (0 when there is no GPU / no driver) */
 int			pgv_device_count(void);
+/* free / total HBM of a device in bytes as the driver reports them now (all processes' allocations counted) */
+int			pgv_device_memory(int device, uint64_t *free_bytes, uint64_t *total_bytes);
 /*
  * Page-locked host memory (hipHostMalloc) for buffers handed to the library again and again -- the lanes of
  * the host glue's pooler (pgv_host_pool_*), a backend's query staging.  Plain host memory works everywhere
@@ -123,6 +125,14 @@ int			pgv_device_count(void);
  */
 int			pgv_pinned_alloc(size_t bytes, void **out);
 void		pgv_pinned_free(void *p);
+/*
+ * Page-lock memory the caller already owns -- a range of a shared-memory segment (Postgres' DSM / the main shared
+ * memory block) that several processes fill and the process that owns the GPU context hands to the library: the
+ * pooler's query and result lanes (pgv_host_pool_*).  Registration is per process and optional: an unregistered
+ * range is staged through the library's own pinned scratch.
+ */
+int			pgv_pinned_register(void *p, size_t bytes);
+void		pgv_pinned_unregister(void *p);
 
 /*
  * Create the per-backend GPU context: lazily from _PG_init (src/vector.c:57-65)
@@ -204,6 +214,26 @@ void		pgv_index_free(pgv_index * index);
  * device arrays, which are released by the last pgv_index_free among them (in any order).
  */
 int			pgv_index_share(pgv_index * index, pgv_ctx * ctx, pgv_index * *out);
+/*
+ * The same across PROCESSES -- a Postgres backend is a process (src/ivfscan.c:252-296 runs in each), and its parallel
+ * build shares state through a DSM segment (src/ivfbuild.c:830-966).  The whole mirror (centers, vectors, offsets,
+ * TIDs, norms) is one device allocation; pgv_index_export wraps its hipIpcMemHandle and the mirror's shape into a
+ * fixed-size, position-independent handle that the owner publishes in shared memory; every other process maps the
+ * SAME HBM with pgv_index_import and scans it on its own context (stream + scratch).  The index occupies HBM once,
+ * whatever the number of backends.
+ *   - the exporting process must keep its index (and itself) alive while others have it mapped: inside the server
+ *     that is the background worker that staged the index, not a backend that may exit;
+ *   - an importer releases its mapping with pgv_index_free; a handle cannot be imported by the process that
+ *     exported it (PGV_ERR_STATE: that process uses pgv_index_share);
+ *   - the ROCm driver shares memory through dmabuf here: HSA_ENABLE_IPC_MODE_LEGACY=0 in every process.
+ */
+#define PGV_INDEX_HANDLE_BYTES 256
+typedef struct pgv_index_handle
+{
+	unsigned char bytes[PGV_INDEX_HANDLE_BYTES];
+}			pgv_index_handle;
+int			pgv_index_export(pgv_index * index, pgv_index_handle * out);
+int			pgv_index_import(pgv_ctx * ctx, const pgv_index_handle * handle, pgv_index * *out);
 int64_t		pgv_index_rows(const pgv_index * index);
 int			pgv_index_lists(const pgv_index * index);
 

@@ -41,6 +41,7 @@ SYMBOLS = [
     "pgv_query_begin", "pgv_query_end", "pgv_query_rank", "pgv_query_scan", "pgv_query_more", "pgv_query_lists",
     "pgv_comm_unique_id", "pgv_comm_create", "pgv_comm_create_custom", "pgv_comm_destroy", "pgv_comm_size",
     "pgv_comm_rank", "pgv_kmeans_sharded", "pgv_search_batch_sharded",
+    "pgv_device_memory", "pgv_pinned_register", "pgv_pinned_unregister", "pgv_index_export", "pgv_index_import",
 ]
 
 
@@ -102,6 +103,12 @@ def _load():
     lib.pgv_index_free.argtypes = [P]
     lib.pgv_index_share.argtypes = [P, P, C.POINTER(P)]
     lib.pgv_index_free.restype = None
+    lib.pgv_index_export.argtypes = [P, P]
+    lib.pgv_index_import.argtypes = [P, P, C.POINTER(P)]
+    lib.pgv_device_memory.argtypes = [I, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
+    lib.pgv_pinned_register.argtypes = [P, C.c_size_t]
+    lib.pgv_pinned_unregister.argtypes = [P]
+    lib.pgv_pinned_unregister.restype = None
     lib.pgv_index_rows.argtypes = [P]
     lib.pgv_index_rows.restype = I64
     lib.pgv_index_lists.argtypes = [P]

@@ -5,6 +5,7 @@
 #include "pgv_internal.h"
 
 #include <dlfcn.h>
+#include <unistd.h>
 
 #include <algorithm>
 #include <cmath>
@@ -413,6 +414,18 @@ int pgv_device_count(void) {
     return n;
 }
 
+int pgv_device_memory(int device, uint64_t *free_bytes, uint64_t *total_bytes) {
+    int n = pgv_device_count();
+    if (n <= 0) PGV_FAIL(PGV_ERR_DEVICE, "no HIP device available (libpgv_hip has no CPU path)");
+    if (device < 0 || device >= n) PGV_FAIL(PGV_ERR_ARG, "device %d out of range 0..%d", device, n - 1);
+    PGV_HIP(hipSetDevice(device));
+    size_t f = 0, t = 0;
+    PGV_HIP(hipMemGetInfo(&f, &t));
+    if (free_bytes) *free_bytes = f;
+    if (total_bytes) *total_bytes = t;
+    return PGV_OK;
+}
+
 int pgv_pinned_alloc(size_t bytes, void **out) {
     if (!out) PGV_FAIL(PGV_ERR_ARG, "pgv_pinned_alloc: out is NULL");
     *out = nullptr;
@@ -426,6 +439,21 @@ int pgv_pinned_alloc(size_t bytes, void **out) {
 
 void pgv_pinned_free(void *p) {
     if (p) (void)hipHostFree(p);
+}
+
+int pgv_pinned_register(void *p, size_t bytes) {
+    if (!p || bytes == 0) PGV_FAIL(PGV_ERR_ARG, "pgv_pinned_register: empty range");
+    if (pgv_device_count() <= 0) PGV_FAIL(PGV_ERR_DEVICE, "no HIP device available (libpgv_hip has no CPU path)");
+    hipError_t e = hipHostRegister(p, bytes, hipHostRegisterPortable);
+    if (e != hipSuccess) {
+        (void)hipGetLastError();
+        PGV_FAIL(PGV_ERR_NOMEM, "hipHostRegister(%zu bytes) failed: %s", bytes, hipGetErrorString(e));
+    }
+    return PGV_OK;
+}
+
+void pgv_pinned_unregister(void *p) {
+    if (p) (void)hipHostUnregister(p);
 }
 
 int pgv_ctx_create(int device, void *stream, pgv_ctx **out) {
@@ -564,6 +592,52 @@ int pgv_ctx_get_stats(pgv_ctx *ctx, pgv_stats *out) {
 
 // ============================================================== IVFFlat index
 
+namespace {
+// where each device array of an IVFFlat mirror sits inside its one allocation
+struct IndexLayout {
+    size_t centers, vectors, offsets, tids, row_norms, center_norms, bytes;
+    bool has_tids, has_norms;
+};
+IndexLayout index_layout(int nlists, int64_t n, size_t row_bytes, bool has_tids, bool l2) {
+    auto up = [](size_t v) { return (v + 255) & ~(size_t)255; };
+    IndexLayout L{};
+    size_t at = 0;
+    L.centers = at; at = up(at + (size_t)nlists * row_bytes);
+    L.vectors = at; at = up(at + (size_t)(n > 0 ? n : 1) * row_bytes);
+    L.offsets = at; at = up(at + sizeof(int64_t) * ((size_t)nlists + 1));
+    L.has_tids = has_tids;
+    L.tids = at; if (has_tids) at = up(at + sizeof(uint64_t) * (size_t)n);
+    L.has_norms = l2;
+    L.row_norms = at; if (l2 && n > 0) at = up(at + sizeof(float) * ((size_t)n + 1));
+    L.center_norms = at; if (l2) at = up(at + sizeof(float) * ((size_t)nlists + 1));
+    L.bytes = at;
+    return L;
+}
+void index_carve(pgv_index *ix, const IndexLayout &L) {
+    char *b = static_cast<char *>(ix->arena);
+    ix->centers = b + L.centers;
+    ix->vectors = b + L.vectors;
+    ix->list_offsets = reinterpret_cast<int64_t *>(b + L.offsets);
+    ix->tids = L.has_tids ? reinterpret_cast<uint64_t *>(b + L.tids) : nullptr;
+    ix->row_norms = L.has_norms && ix->nrows > 0 ? reinterpret_cast<float *>(b + L.row_norms) : nullptr;
+    ix->center_norms = L.has_norms ? reinterpret_cast<float *>(b + L.center_norms) : nullptr;
+}
+// len_prefix / max_list_len from h_offsets
+void index_host_tables(pgv_index *ix) {
+    const int nlists = ix->nlists;
+    std::vector<int64_t> lens((size_t)nlists);
+    int64_t maxlen = 0;
+    for (int l = 0; l < nlists; l++) {
+        lens[l] = ix->h_offsets[l + 1] - ix->h_offsets[l];
+        if (lens[l] > maxlen) maxlen = lens[l];
+    }
+    ix->max_list_len = maxlen;
+    std::sort(lens.begin(), lens.end(), [](int64_t a, int64_t b) { return a > b; });
+    ix->len_prefix.assign((size_t)nlists + 1, 0);
+    for (int l = 0; l < nlists; l++) ix->len_prefix[l + 1] = ix->len_prefix[l] + lens[l];
+}
+}  // namespace
+
 int pgv_index_upload(pgv_ctx *ctx, pgv_metric metric, pgv_dtype dtype, int dim, int nlists,
                      const void *centers, const int64_t *list_offsets, const void *vectors,
                      const uint64_t *tids, pgv_index **out) {
@@ -606,14 +680,7 @@ int pgv_index_upload(pgv_ctx *ctx, pgv_metric metric, pgv_dtype dtype, int dim, 
     ix->nrows = n;
     ix->geom = row_geom(dim, dtype);
     ix->h_offsets = off;
-    ix->max_list_len = maxlen;
-    {
-        std::vector<int64_t> lens((size_t)nlists);
-        for (int l = 0; l < nlists; l++) lens[l] = off[l + 1] - off[l];
-        std::sort(lens.begin(), lens.end(), [](int64_t a, int64_t b) { return a > b; });
-        ix->len_prefix.assign((size_t)nlists + 1, 0);
-        for (int l = 0; l < nlists; l++) ix->len_prefix[l + 1] = ix->len_prefix[l] + lens[l];
-    }
+    index_host_tables(ix);
     const size_t es = elem_size(dtype);
     const size_t row_bytes = (size_t)ix->geom.ld * es;
 
@@ -621,51 +688,51 @@ int pgv_index_upload(pgv_ctx *ctx, pgv_metric metric, pgv_dtype dtype, int dim, 
         pgv_index_free(ix);
         return rc;
     };
-    auto put_rows = [&](void **dst, const void *src, int64_t rows) -> int {
-        size_t bytes = (size_t)(rows > 0 ? rows : 1) * row_bytes;
-        PGV_HIP(hipMalloc(dst, bytes));
+    // one allocation for the whole mirror (a single IPC handle exports it): centers | vectors | list_offsets |
+    // tids | row_norms | center_norms, each part 256-byte aligned
+    IndexLayout lay = index_layout(nlists, n, row_bytes, tids != nullptr && n > 0, metric == PGV_L2SQ);
+    if (hipMalloc(&ix->arena, lay.bytes) != hipSuccess) {
+        (void)hipGetLastError();
+        set_error("hipMalloc(%zu) for the index mirror failed", lay.bytes);
+        return fail(PGV_ERR_NOMEM);
+    }
+    ix->arena_bytes = lay.bytes;
+    index_carve(ix, lay);
+    auto put_rows = [&](void *dst, const void *src, int64_t rows) -> int {
         if (rows == 0) return PGV_OK;
         const bool dev = is_device_ptr(src);
         if (ix->geom.ld == dim) {
-            PGV_HIP(hipMemcpyAsync(*dst, src, (size_t)rows * row_bytes,
+            PGV_HIP(hipMemcpyAsync(dst, src, (size_t)rows * row_bytes,
                                    dev ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, ctx->stream));
         } else {
-            PGV_HIP(hipMemsetAsync(*dst, 0, bytes, ctx->stream));
-            PGV_HIP(hipMemcpy2DAsync(*dst, row_bytes, src, (size_t)dim * es, (size_t)dim * es,
+            PGV_HIP(hipMemsetAsync(dst, 0, (size_t)rows * row_bytes, ctx->stream));
+            PGV_HIP(hipMemcpy2DAsync(dst, row_bytes, src, (size_t)dim * es, (size_t)dim * es,
                                      (size_t)rows, dev ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice,
                                      ctx->stream));
         }
         return PGV_OK;
     };
     int rc;
-    if ((rc = put_rows(&ix->centers, centers, nlists)) != PGV_OK) return fail(rc);
-    if ((rc = put_rows(&ix->vectors, vectors, n)) != PGV_OK) return fail(rc);
-    if (hipMalloc((void **)&ix->list_offsets, sizeof(int64_t) * off.size()) != hipSuccess)
-        return fail((set_error("hipMalloc(list_offsets) failed"), PGV_ERR_NOMEM));
+    if ((rc = put_rows(ix->centers, centers, nlists)) != PGV_OK) return fail(rc);
+    if ((rc = put_rows(ix->vectors, vectors, n)) != PGV_OK) return fail(rc);
     if (hipMemcpyAsync(ix->list_offsets, ix->h_offsets.data(), sizeof(int64_t) * off.size(),
                        hipMemcpyHostToDevice, ctx->stream) != hipSuccess)
         return fail((set_error("copy of list_offsets failed"), PGV_ERR_DEVICE));
-    if (tids && n > 0) {
-        if (hipMalloc((void **)&ix->tids, sizeof(uint64_t) * (size_t)n) != hipSuccess)
-            return fail((set_error("hipMalloc(tids) failed"), PGV_ERR_NOMEM));
+    if (ix->tids) {
         if (hipMemcpyAsync(ix->tids, tids, sizeof(uint64_t) * (size_t)n,
                            is_device_ptr(tids) ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice,
                            ctx->stream) != hipSuccess)
             return fail((set_error("copy of tids failed"), PGV_ERR_DEVICE));
     }
-    if (metric == PGV_L2SQ && n > 0) {
+    if (ix->row_norms) {
         // |x|^2 per row and the largest of them: the MFMA scan's expansion of the L2 distance
-        if (hipMalloc((void **)&ix->row_norms, sizeof(float) * ((size_t)n + 1)) != hipSuccess)
-            return fail((set_error("hipMalloc(row_norms) failed"), PGV_ERR_NOMEM));
         if (hipMemsetAsync(ix->row_norms + n, 0, sizeof(float), ctx->stream) != hipSuccess)
             return fail((set_error("memset of row_norms failed"), PGV_ERR_DEVICE));
         if ((rc = launch_row_norms(ctx, dtype, ix->geom, ix->vectors, n, ix->row_norms,
                                    reinterpret_cast<unsigned *>(ix->row_norms + n))) != PGV_OK)
             return fail(rc);
     }
-    if (metric == PGV_L2SQ) {
-        if (hipMalloc((void **)&ix->center_norms, sizeof(float) * ((size_t)nlists + 1)) != hipSuccess)
-            return fail((set_error("hipMalloc(center_norms) failed"), PGV_ERR_NOMEM));
+    if (ix->center_norms) {
         if (hipMemsetAsync(ix->center_norms + nlists, 0, sizeof(float), ctx->stream) != hipSuccess)
             return fail((set_error("memset of center_norms failed"), PGV_ERR_DEVICE));
         if ((rc = launch_row_norms(ctx, dtype, ix->geom, ix->centers, nlists, ix->center_norms,
@@ -691,7 +758,114 @@ int pgv_index_share(pgv_index *ix, pgv_ctx *ctx, pgv_index **out) {
     return PGV_OK;
 }
 
-// the device arrays go with the last handle on them (the uploaded index or a pgv_index_share view)
+// What crosses the process boundary: the shape of the mirror and the IPC handle of its one allocation.
+struct IndexHandleWire {
+    uint64_t magic;
+    uint32_t abi, pid;
+    int32_t device, metric, dtype, dim, nlists, has_tids;
+    int64_t nrows;
+    uint64_t arena_bytes;
+    hipIpcMemHandle_t mem;
+};
+static_assert(sizeof(IndexHandleWire) <= PGV_INDEX_HANDLE_BYTES, "pgv_index_handle too small");
+static constexpr uint64_t kIndexHandleMagic = 0x7067765f69786831ull;  // "pgv_ixh1"
+
+int pgv_index_export(pgv_index *ix, pgv_index_handle *out) {
+    if (!ix || !out) PGV_FAIL(PGV_ERR_ARG, "pgv_index_export: index/out is NULL");
+    if (!ix->arena) PGV_FAIL(PGV_ERR_STATE, "pgv_index_export: the index has no device arrays");
+    if (ix->imported) PGV_FAIL(PGV_ERR_STATE, "pgv_index_export: export from the process that uploaded the index");
+    PGV_HIP(hipSetDevice(ix->ctx->device));
+    IndexHandleWire w;
+    memset(&w, 0, sizeof(w));
+    w.magic = kIndexHandleMagic;
+    w.abi = PGV_ABI_VERSION;
+    w.pid = (uint32_t)getpid();
+    w.device = ix->ctx->device;
+    w.metric = ix->metric;
+    w.dtype = ix->dtype;
+    w.dim = ix->dim;
+    w.nlists = ix->nlists;
+    w.has_tids = ix->tids != nullptr;
+    w.nrows = ix->nrows;
+    w.arena_bytes = ix->arena_bytes;
+    hipError_t e = hipIpcGetMemHandle(&w.mem, ix->arena);
+    if (e != hipSuccess) {
+        (void)hipGetLastError();
+        PGV_FAIL(PGV_ERR_DEVICE,
+                 "hipIpcGetMemHandle failed: %s (the driver here shares memory by dmabuf: HSA_ENABLE_IPC_MODE_LEGACY=0 "
+                 "must be in the environment of every process)", hipGetErrorString(e));
+    }
+    memset(out, 0, sizeof(*out));
+    memcpy(out->bytes, &w, sizeof(w));
+    return PGV_OK;
+}
+
+int pgv_index_import(pgv_ctx *ctx, const pgv_index_handle *handle, pgv_index **out) {
+    if (!ctx || !handle || !out) PGV_FAIL(PGV_ERR_ARG, "pgv_index_import: ctx/handle/out is NULL");
+    *out = nullptr;
+    IndexHandleWire w;
+    memcpy(&w, handle->bytes, sizeof(w));
+    if (w.magic != kIndexHandleMagic || w.abi != PGV_ABI_VERSION)
+        PGV_FAIL(PGV_ERR_ARG, "pgv_index_import: not a handle of this library version");
+    if (w.pid == (uint32_t)getpid())
+        PGV_FAIL(PGV_ERR_STATE, "pgv_index_import: the handle was exported by this process (use pgv_index_share)");
+    if (w.device != ctx->device)
+        PGV_FAIL(PGV_ERR_ARG, "pgv_index_import: the index lives on device %d, the context on %d", w.device, ctx->device);
+    PGV_TRY(check_common((pgv_dtype)w.dtype, w.dim));
+    PGV_TRY(check_metric((pgv_metric)w.metric));
+    if (w.nlists < 1 || w.nlists > 32768 || w.nrows < 0) PGV_FAIL(PGV_ERR_ARG, "pgv_index_import: corrupt handle");
+    PGV_HIP(hipSetDevice(ctx->device));
+    pgv_index *ix = new (std::nothrow) pgv_index();
+    if (!ix) PGV_FAIL(PGV_ERR_NOMEM, "out of host memory");
+    ix->refs = new (std::nothrow) int(1);
+    if (!ix->refs) {
+        delete ix;
+        PGV_FAIL(PGV_ERR_NOMEM, "out of host memory");
+    }
+    ix->ctx = ctx;
+    ix->metric = (pgv_metric)w.metric;
+    ix->dtype = (pgv_dtype)w.dtype;
+    ix->dim = w.dim;
+    ix->nlists = w.nlists;
+    ix->nrows = w.nrows;
+    ix->geom = row_geom(w.dim, ix->dtype);
+    ix->imported = true;
+    const size_t row_bytes = (size_t)ix->geom.ld * elem_size(ix->dtype);
+    IndexLayout lay = index_layout(w.nlists, w.nrows, row_bytes, w.has_tids != 0, ix->metric == PGV_L2SQ);
+    if (lay.bytes != w.arena_bytes) {
+        pgv_index_free(ix);
+        PGV_FAIL(PGV_ERR_ARG, "pgv_index_import: handle describes %llu bytes, this library lays the mirror out in %zu",
+                 (unsigned long long)w.arena_bytes, lay.bytes);
+    }
+    hipError_t e = hipIpcOpenMemHandle(&ix->arena, w.mem, hipIpcMemLazyEnablePeerAccess);
+    if (e != hipSuccess) {
+        (void)hipGetLastError();
+        ix->arena = nullptr;
+        pgv_index_free(ix);
+        PGV_FAIL(PGV_ERR_DEVICE, "hipIpcOpenMemHandle failed: %s (is the exporting process alive, and "
+                 "HSA_ENABLE_IPC_MODE_LEGACY=0 set in both?)", hipGetErrorString(e));
+    }
+    ix->arena_bytes = lay.bytes;
+    index_carve(ix, lay);
+    // the host-side tables come from the mirror itself
+    ix->h_offsets.assign((size_t)w.nlists + 1, 0);
+    if (hipMemcpy(ix->h_offsets.data(), ix->list_offsets, sizeof(int64_t) * ix->h_offsets.size(),
+                  hipMemcpyDeviceToHost) != hipSuccess) {
+        set_error("pgv_index_import: reading list_offsets failed: %s", hipGetErrorString(hipGetLastError()));
+        pgv_index_free(ix);
+        return PGV_ERR_DEVICE;
+    }
+    if (ix->h_offsets[0] != 0 || ix->h_offsets[w.nlists] != w.nrows) {
+        pgv_index_free(ix);
+        PGV_FAIL(PGV_ERR_DATA, "pgv_index_import: the shared mirror does not match its handle");
+    }
+    index_host_tables(ix);
+    *out = ix;
+    return PGV_OK;
+}
+
+// the device arrays go with the last handle on them (the uploaded index or a pgv_index_share view); an imported
+// mirror is unmapped from this process, the exporter's allocation stays
 void pgv_index_free(pgv_index *ix) {
     if (!ix) return;
     if (ix->ctx) (void)hipStreamSynchronize(ix->ctx->stream);
@@ -699,12 +873,12 @@ void pgv_index_free(pgv_index *ix) {
         delete ix;
         return;
     }
-    if (ix->centers) (void)hipFree(ix->centers);
-    if (ix->vectors) (void)hipFree(ix->vectors);
-    if (ix->list_offsets) (void)hipFree(ix->list_offsets);
-    if (ix->tids) (void)hipFree(ix->tids);
-    if (ix->row_norms) (void)hipFree(ix->row_norms);
-    if (ix->center_norms) (void)hipFree(ix->center_norms);
+    if (ix->arena) {
+        if (ix->imported)
+            (void)hipIpcCloseMemHandle(ix->arena);
+        else
+            (void)hipFree(ix->arena);
+    }
     delete ix->refs;
     delete ix;
 }

@@ -149,6 +149,11 @@ struct pgv_index {
     float *row_norms = nullptr;       // device [nrows] |x|^2 then one word: bits of the largest (L2 indexes; the MFMA scan)
     float *center_norms = nullptr;    // the same for the centers [nlists + 1]
     int *refs = nullptr;              // handles (the uploaded index + its pgv_index_share views) on the device arrays
+    // every device array above lives in ONE allocation, so that one hipIpcMemHandle carries the whole mirror to
+    // another process (pgv_index_export / pgv_index_import)
+    void *arena = nullptr;
+    size_t arena_bytes = 0;
+    bool imported = false;            // arena was opened with hipIpcOpenMemHandle: closed, not freed
     std::vector<int64_t> h_offsets;   // host copy
     std::vector<int64_t> len_prefix;  // len_prefix[p] = rows in the p longest lists (output size bound)
     int64_t max_list_len = 0;

@@ -1,25 +1,42 @@
 /*
- * ivf_pool.c -- a pooler in front of the batched IVFFlat scan.
+ * ivf_pool.c -- a pooler in front of the batched IVFFlat scan, for backends that are PROCESSES.
  *
- * The reference answers one query per backend at a time (ivfflatgettuple, src/ivfscan.c:361-414); on the GPU that
- * shape streams each query's lists alone (pgv_query_*: ~20 k queries/s per backend, ~47 k/s for many backends on
- * their own streams), while the same queries taken together share every pass over a probed list
- * (pgv_search_batch: 750 k/s).  This is the piece between the two: backends (threads here; a background worker
- * fed through shared memory inside the server) hand in ONE query each and block; whatever arrives within
- * max_wait_us of the first query of a batch -- or until max_batch are waiting -- goes to the device as one
- * pgv_search_batch.  Several lanes (a context = stream + scratch, a pgv_index_share view and pinned buffers each)
- * take batches in turn, so the next batch collects and runs its planning while the previous one scans.
+ * The reference answers one query per backend at a time (ivfflatgettuple, src/ivfscan.c:361-414), and a backend
+ * is a single-threaded process (src/ivfscan.c:252-296 runs in each).  On the GPU that shape streams each query's
+ * lists alone (pgv_query_*: ~20 k queries/s per backend), while the same queries taken together share every pass
+ * over a probed list (pgv_search_batch: 750 k/s).  This is the piece between the two.
  *
- * The first backend to enter an idle lane leads its batch (no extra thread): it waits for the batch to close,
- * runs the scan, publishes the results and wakes the others.  Results are exactly pgv_search_batch's: the head
- * of GetScanItems + tuplesort for each query (src/ivfscan.c:123-187), heap TIDs and FUNCTION 1 distances.
+ * Everything the backends and the GPU side exchange lives in ONE position-independent shared-memory segment
+ * (inside the server: a DSM segment or a ShmemInitStruct block, the pattern of the reference's parallel build,
+ * src/ivfbuild.c:830-966; here: any MAP_SHARED mapping):
+ *
+ *     header   parameters, a process-shared robust mutex over a few words, futex words, the exported mirror
+ *     lane[i]  batch state + query payloads [max_batch x row] + answers [max_batch x k] (tids, distances)
+ *
+ *   clients  (backends; no GPU context, they never call libpgv_hip) hand in ONE query each with
+ *            pgv_host_pool_search and sleep on a futex word of their lane;
+ *   servers  (one per lane; a background worker inside the server, a thread or a process here) own a pgv_ctx and a
+ *            view of the device mirror (pgv_index_share in the owner's process, pgv_index_import in any other),
+ *            close a batch when max_batch queries are waiting or max_wait_us after its first one, run ONE
+ *            pgv_search_batch over the lane's payload area (page-locked with pgv_pinned_register) and wake the
+ *            batch's clients.  Several lanes take batches in turn, so the next batch collects and plans while the
+ *            previous one scans.
+ *
+ * Answers are exactly pgv_search_batch's: the head of GetScanItems + tuplesort for each query
+ * (src/ivfscan.c:123-187), heap TIDs and FUNCTION 1 distances.
+ *
+ * Futexes are the shared kind (no FUTEX_PRIVATE_FLAG); the mutex is PTHREAD_PROCESS_SHARED + ROBUST (a client that
+ * dies inside the critical section does not wedge the pool); a lane whose clients vanished is reclaimed by its
+ * server after pool_reclaim_us.
  */
 #define _GNU_SOURCE
 #include "pgv_host.h"
 
+#include <errno.h>
 #include <limits.h>
 #include <linux/futex.h>
 #include <pthread.h>
+#include <sys/mman.h>
 #include <sys/syscall.h>
 #include <unistd.h>
 #include <stdlib.h>
@@ -28,68 +45,92 @@
 
 extern int	pgv_host_fail(int code, const char *fmt,...);
 
-typedef struct
-{
-	pgv_ctx    *ctx;
-	pgv_index  *view;
-	char	   *queries;		/* pinned [max_batch x row_bytes] */
-	uint64_t   *tids;			/* pinned [max_batch x k] */
-	float	   *dist;			/* pinned [max_batch x k] */
-	int			state;			/* LANE_* */
-	int			count;			/* queries of the batch being collected / run */
-	int			ready;			/* ... whose payload has been copied into the lane (atomic) */
-	int			readers;		/* followers that still have to copy their answer */
-	int			rc;
-	uint32_t	gen,			/* batch number of this lane */
-				done_gen;		/* last batch whose results are published (futex word) */
-	uint32_t	fill;			/* bumped when the leader may stop waiting (futex word) */
-}			lane;
+#define POOL_MAGIC 0x7067765f706f6f6cull	/* "pgv_pool" */
+#define POOL_VERSION 2
+#define POOL_MAX_LANES 8
+#define POOL_ALIGN 4096
+#define POOL_RECLAIM_US 2000000		/* a published batch nobody finished reading: its clients are gone */
+#define POOL_READY_US 200000		/* a client between taking its slot and the end of its payload copy */
 
 enum
 {
-	LANE_FREE, LANE_COLLECTING, LANE_RUNNING
+	LANE_FREE, LANE_COLLECTING, LANE_RUNNING, LANE_PUBLISHED
 };
 
-struct pgv_pool
+typedef struct
 {
-	int			probes,
+	uint32_t	state;			/* LANE_* (under the lock) */
+	int32_t		count;			/* queries of the batch being collected / run (under the lock) */
+	int32_t		ready;			/* ... whose payload has been copied into the lane (atomic) */
+	int32_t		readers;		/* clients that still have to copy their answer (atomic) */
+	int32_t		rc;
+	uint32_t	gen,			/* batch number of this lane */
+				done_gen;		/* last batch whose results are published (futex word) */
+	uint32_t	fill;			/* bumped when the lane's server should look again (futex word) */
+	int64_t		t_open;			/* now_us() of the batch's first query */
+	int64_t		t_published;
+	uint64_t	q_off,			/* offsets from the segment's base */
+				tid_off,
+				dist_off;
+	char		errmsg[160];
+	char		pad[32];
+}			shm_lane;
+
+typedef struct
+{
+	uint64_t	magic;
+	uint32_t	version;
+	uint32_t	nlanes;
+	uint64_t	bytes;
+	int32_t		probes,
 				k,
 				max_batch,
-				max_wait_us,
-				nlanes;
-	size_t		row_bytes;
-	lane	   *lanes;
-	int			collecting;		/* lane that takes arrivals, or -1 */
-	int			arriving;		/* backends inside pgv_host_pool_search that have not joined a batch yet */
-	pthread_mutex_t lock;		/* guards the few words below and the lanes' count / state: tens of nanoseconds.
+				max_wait_us;
+	uint64_t	row_bytes;
+	pthread_mutex_t lock;		/* guards collecting / arriving and the lanes' count / state: tens of nanoseconds.
 								 * Adaptive (spins briefly, then sleeps): a pure spinlock collapses once there are more
-								 * backends than cores (1024 threads: p90 latency 180 ms, measured) */
+								 * backends than cores (1024 clients: p90 latency 180 ms, measured) */
+	int32_t		collecting;		/* lane that takes arrivals, or -1 */
+	int32_t		arriving;		/* clients inside pgv_host_pool_search that have not joined a batch yet */
 	uint32_t	free_epoch;		/* bumped when a lane comes free (futex word) */
+	uint32_t	shutdown;
+	uint32_t	servers;		/* lanes with a server attached (futex word: clients of an unserved pool fail fast) */
+	uint32_t	has_index;		/* futex word: the owner published the mirror's handle */
 	int64_t		batches,
 				queries;
+	pgv_index_handle index;
+	shm_lane	lanes[POOL_MAX_LANES];
+}			shm_pool;
+
+/* a process's handle on the segment */
+struct pgv_pool
+{
+	shm_pool   *s;
+	char	   *base;
+	/* pgv_host_pool_create only: the segment and the lane servers belong to this handle */
+	int			owned;
+	int			nthreads;
+	pthread_t	threads[POOL_MAX_LANES];
+	pgv_ctx    *ctxs[POOL_MAX_LANES];
+	pgv_index  *views[POOL_MAX_LANES];
+	int			thread_rc[POOL_MAX_LANES];
 };
 
 /* Hundreds of backends wait for one word (their batch's results, a lane coming free).  A condition variable
  * wakes them one futex call and one mutex hand-over at a time -- milliseconds per batch at 256 waiters (measured);
  * spinning starves the HIP runtime's own threads.  A bare futex: sleep until the word changes, wake all at once. */
 static void
-word_wait(uint32_t *word, uint32_t seen)
-{
-	syscall(SYS_futex, word, FUTEX_WAIT_PRIVATE, seen, NULL, NULL, 0);
-}
-
-static void
 word_wait_us(uint32_t *word, uint32_t seen, long us)
 {
 	struct timespec rel = {us / 1000000L, (us % 1000000L) * 1000L};
 
-	syscall(SYS_futex, word, FUTEX_WAIT_PRIVATE, seen, &rel, NULL, 0);
+	syscall(SYS_futex, word, FUTEX_WAIT, seen, &rel, NULL, 0);
 }
 
 static void
 word_wake_all(uint32_t *word)
 {
-	syscall(SYS_futex, word, FUTEX_WAKE_PRIVATE, INT_MAX, NULL, NULL, 0);
+	syscall(SYS_futex, word, FUTEX_WAKE, INT_MAX, NULL, NULL, 0);
 }
 
 static int64_t
@@ -101,218 +142,527 @@ now_us(void)
 	return (int64_t) ts.tv_sec * 1000000 + ts.tv_nsec / 1000;
 }
 
-void
-pgv_host_pool_destroy(pgv_pool * pool)
+static void
+pool_lock(shm_pool * s)
 {
-	if (!pool)
-		return;
-	for (int i = 0; i < pool->nlanes; i++)
-	{
-		lane	   *l = &pool->lanes[i];
+	if (pthread_mutex_lock(&s->lock) == EOWNERDEAD)
+		pthread_mutex_consistent(&s->lock); /* its holder died: the words it guards are single stores, nothing is torn */
+}
 
-		if (l->view)
-			pgv_index_free(l->view);
-		if (l->ctx)
-			pgv_ctx_destroy(l->ctx);
-		pgv_pinned_free(l->queries);
-		pgv_pinned_free(l->tids);
-		pgv_pinned_free(l->dist);
-	}
-	pthread_mutex_destroy(&pool->lock);
-	free(pool->lanes);
-	free(pool);
+static void
+pool_unlock(shm_pool * s)
+{
+	pthread_mutex_unlock(&s->lock);
+}
+
+static size_t
+align_up(size_t v)
+{
+	return (v + POOL_ALIGN - 1) & ~(size_t) (POOL_ALIGN - 1);
+}
+
+size_t
+pgv_host_pool_shm_bytes(pgv_dtype dtype, int dim, int k, int max_batch, int lanes)
+{
+	size_t		row = (size_t) dim * (dtype == PGV_F32 ? 4 : 2);
+	size_t		lane = align_up(row * (size_t) max_batch) + align_up(sizeof(uint64_t) * (size_t) max_batch * k) +
+		align_up(sizeof(float) * (size_t) max_batch * k);
+
+	if (dim < 1 || k < 1 || max_batch < 1 || lanes < 1 || lanes > POOL_MAX_LANES)
+		return 0;
+	return align_up(sizeof(shm_pool)) + lane * (size_t) lanes;
 }
 
 int
-pgv_host_pool_create(pgv_index * index, int device, pgv_dtype dtype, int dim, int probes, int k, int max_batch,
-					 int max_wait_us, int lanes, pgv_pool * *out)
+pgv_host_pool_shm_init(void *shm, size_t bytes, pgv_dtype dtype, int dim, int probes, int k, int max_batch,
+					   int max_wait_us, int lanes)
 {
+	shm_pool   *s = shm;
+	size_t		need = pgv_host_pool_shm_bytes(dtype, dim, k, max_batch, lanes);
+	size_t		at;
+	pthread_mutexattr_t ma;
+
+	if (!shm)
+		return pgv_host_fail(PGV_ERR_ARG, "pgv_host_pool_shm_init: segment is NULL");
+	if (probes < 1 || k < 1 || max_batch < 1 || max_batch > 65536 || max_wait_us < 0 || lanes < 1 || lanes > POOL_MAX_LANES || dim < 1)
+		return pgv_host_fail(PGV_ERR_ARG, "pgv_host_pool_shm_init: bad probes / k / max_batch / max_wait_us / lanes");
+	if (need == 0 || bytes < need)
+		return pgv_host_fail(PGV_ERR_ARG, "pgv_host_pool_shm_init: segment of %zu bytes, %zu needed", bytes, need);
+	if (((uintptr_t) shm & 63) != 0)
+		return pgv_host_fail(PGV_ERR_ARG, "pgv_host_pool_shm_init: segment must be 64-byte aligned");
+	memset(s, 0, sizeof(shm_pool));
+	s->version = POOL_VERSION;
+	s->nlanes = (uint32_t) lanes;
+	s->bytes = need;
+	s->probes = probes;
+	s->k = k;
+	s->max_batch = max_batch;
+	s->max_wait_us = max_wait_us;
+	s->row_bytes = (uint64_t) dim * (dtype == PGV_F32 ? 4 : 2);
+	s->collecting = -1;
+	pthread_mutexattr_init(&ma);
+	pthread_mutexattr_setpshared(&ma, PTHREAD_PROCESS_SHARED);
+	pthread_mutexattr_setrobust(&ma, PTHREAD_MUTEX_ROBUST);
+	pthread_mutexattr_settype(&ma, PTHREAD_MUTEX_ADAPTIVE_NP);
+	if (pthread_mutex_init(&s->lock, &ma) != 0)
+	{
+		pthread_mutexattr_destroy(&ma);
+		return pgv_host_fail(PGV_ERR_STATE, "pgv_host_pool_shm_init: process-shared mutex unavailable");
+	}
+	pthread_mutexattr_destroy(&ma);
+	at = align_up(sizeof(shm_pool));
+	for (int i = 0; i < lanes; i++)
+	{
+		shm_lane   *l = &s->lanes[i];
+
+		l->state = LANE_FREE;
+		l->q_off = at;
+		at += align_up(s->row_bytes * (size_t) max_batch);
+		l->tid_off = at;
+		at += align_up(sizeof(uint64_t) * (size_t) max_batch * k);
+		l->dist_off = at;
+		at += align_up(sizeof(float) * (size_t) max_batch * k);
+	}
+	__atomic_store_n(&s->magic, POOL_MAGIC, __ATOMIC_RELEASE);	/* last: attachers check it */
+	return PGV_OK;
+}
+
+int
+pgv_host_pool_attach(void *shm, size_t bytes, pgv_pool * *out)
+{
+	shm_pool   *s = shm;
 	pgv_pool   *pool;
 
-	if (!index || !out)
-		return pgv_host_fail(PGV_ERR_ARG, "pgv_host_pool_create: index/out is NULL");
+	if (!shm || !out)
+		return pgv_host_fail(PGV_ERR_ARG, "pgv_host_pool_attach: segment/out is NULL");
 	*out = NULL;
-	if (probes < 1 || k < 1 || max_batch < 1 || max_batch > 65536 || max_wait_us < 0 || lanes < 1 || lanes > 8 || dim < 1)
-		return pgv_host_fail(PGV_ERR_ARG, "pgv_host_pool_create: bad probes / k / max_batch / max_wait_us / lanes");
+	if (bytes < sizeof(shm_pool) || __atomic_load_n(&s->magic, __ATOMIC_ACQUIRE) != POOL_MAGIC || s->version != POOL_VERSION)
+		return pgv_host_fail(PGV_ERR_STATE, "pgv_host_pool_attach: not an initialised pool segment of this version");
+	if (s->bytes > bytes)
+		return pgv_host_fail(PGV_ERR_ARG, "pgv_host_pool_attach: mapped %zu of the segment's %llu bytes", bytes,
+							 (unsigned long long) s->bytes);
 	pool = calloc(1, sizeof(pgv_pool));
 	if (!pool)
 		return pgv_host_fail(PGV_ERR_NOMEM, "out of memory");
-	pool->probes = probes;
-	pool->k = k;
-	pool->max_batch = max_batch;
-	pool->max_wait_us = max_wait_us;
-	pool->nlanes = lanes;
-	pool->row_bytes = (size_t) dim * (dtype == PGV_F32 ? 4 : 2);
-	pool->collecting = -1;
-	pool->lanes = calloc((size_t) lanes, sizeof(lane));
-	{
-		pthread_mutexattr_t ma;
-
-		pthread_mutexattr_init(&ma);
-		pthread_mutexattr_settype(&ma, PTHREAD_MUTEX_ADAPTIVE_NP);
-		pthread_mutex_init(&pool->lock, &ma);
-		pthread_mutexattr_destroy(&ma);
-	}
-	if (!pool->lanes)
-	{
-		pgv_host_pool_destroy(pool);
-		return pgv_host_fail(PGV_ERR_NOMEM, "out of memory");
-	}
-	for (int i = 0; i < lanes; i++)
-	{
-		lane	   *l = &pool->lanes[i];
-		int			rc = pgv_ctx_create(device, NULL, &l->ctx);
-
-		if (rc == PGV_OK)
-			rc = pgv_index_share(index, l->ctx, &l->view);
-		if (rc == PGV_OK)
-			rc = pgv_pinned_alloc(pool->row_bytes * (size_t) max_batch, (void **) &l->queries);
-		if (rc == PGV_OK)
-			rc = pgv_pinned_alloc(sizeof(uint64_t) * (size_t) max_batch * k, (void **) &l->tids);
-		if (rc == PGV_OK)
-			rc = pgv_pinned_alloc(sizeof(float) * (size_t) max_batch * k, (void **) &l->dist);
-		if (rc != PGV_OK)
-		{
-			pgv_host_pool_destroy(pool);
-			return pgv_host_fail(rc, "%s", pgv_last_error());
-		}
-	}
+	pool->s = s;
+	pool->base = shm;
 	*out = pool;
 	return PGV_OK;
 }
 
+void
+pgv_host_pool_detach(pgv_pool * pool)
+{
+	if (pool && !pool->owned)
+		free(pool);
+}
+
+int
+pgv_host_pool_publish_index(pgv_pool * pool, const pgv_index_handle * handle)
+{
+	if (!pool || !handle)
+		return pgv_host_fail(PGV_ERR_ARG, "pgv_host_pool_publish_index: pool/handle is NULL");
+	memcpy(&pool->s->index, handle, sizeof(*handle));
+	__atomic_store_n(&pool->s->has_index, 1, __ATOMIC_RELEASE);
+	word_wake_all(&pool->s->has_index);
+	return PGV_OK;
+}
+
+int
+pgv_host_pool_index_handle(pgv_pool * pool, int wait_ms, pgv_index_handle * out)
+{
+	int64_t		deadline = now_us() + (int64_t) wait_ms * 1000;
+
+	if (!pool || !out)
+		return pgv_host_fail(PGV_ERR_ARG, "pgv_host_pool_index_handle: pool/out is NULL");
+	while (__atomic_load_n(&pool->s->has_index, __ATOMIC_ACQUIRE) == 0)
+	{
+		int64_t		t = now_us();
+
+		if (t >= deadline || __atomic_load_n(&pool->s->shutdown, __ATOMIC_ACQUIRE))
+			return pgv_host_fail(PGV_ERR_STATE, "pgv_host_pool_index_handle: no mirror has been published");
+		word_wait_us(&pool->s->has_index, 0, deadline - t < 50000 ? deadline - t : 50000);
+	}
+	memcpy(out, &pool->s->index, sizeof(*out));
+	return PGV_OK;
+}
+
+void
+pgv_host_pool_shutdown(pgv_pool * pool)
+{
+	shm_pool   *s;
+
+	if (!pool)
+		return;
+	s = pool->s;
+	__atomic_store_n(&s->shutdown, 1, __ATOMIC_RELEASE);
+	for (uint32_t i = 0; i < s->nlanes; i++)
+	{
+		__atomic_add_fetch(&s->lanes[i].fill, 1, __ATOMIC_RELEASE);
+		word_wake_all(&s->lanes[i].fill);
+		word_wake_all(&s->lanes[i].done_gen);
+	}
+	__atomic_add_fetch(&s->free_epoch, 1, __ATOMIC_RELEASE);
+	word_wake_all(&s->free_epoch);
+	word_wake_all(&s->has_index);
+}
+
+/* the last reader (or the lane's server, for a batch whose clients vanished) hands the lane back */
+static void
+lane_release(shm_pool * s, shm_lane * l)
+{
+	pool_lock(s);
+	l->state = LANE_FREE;
+	__atomic_add_fetch(&s->free_epoch, 1, __ATOMIC_RELEASE);
+	pool_unlock(s);
+	word_wake_all(&s->free_epoch);	/* everyone queued joins the batch the first of them opens */
+}
+
+/*
+ * The leader loop of one lane: wait for a batch to open, let it fill, scan it, publish.  Returns PGV_OK at
+ * pgv_host_pool_shutdown, or the first error that is not a batch's own (a failed batch is reported to its clients
+ * and the lane goes on).  `view` is this process's handle on the mirror; its context's stream runs the scans.
+ */
+int
+pgv_host_pool_serve(pgv_pool * pool, int lane, pgv_index * view)
+{
+	shm_pool   *s;
+	shm_lane   *l;
+	char	   *q;
+	uint64_t   *tids;
+	float	   *dist;
+	int			pinned_q,
+				pinned_t,
+				pinned_d;
+
+	if (!pool || !view)
+		return pgv_host_fail(PGV_ERR_ARG, "pgv_host_pool_serve: pool/view is NULL");
+	s = pool->s;
+	if (lane < 0 || lane >= (int) s->nlanes)
+		return pgv_host_fail(PGV_ERR_ARG, "pgv_host_pool_serve: lane %d of %u", lane, s->nlanes);
+	l = &s->lanes[lane];
+	q = pool->base + l->q_off;
+	tids = (uint64_t *) (pool->base + l->tid_off);
+	dist = (float *) (pool->base + l->dist_off);
+	/* page-lock this lane's areas for this process's GPU context: copies in and out become asynchronous DMA.  A
+	 * mapping the driver cannot pin still works, staged through the library's own pinned scratch. */
+	pinned_q = pgv_pinned_register(q, align_up(s->row_bytes * (size_t) s->max_batch)) == PGV_OK;
+	pinned_t = pgv_pinned_register(tids, align_up(sizeof(uint64_t) * (size_t) s->max_batch * s->k)) == PGV_OK;
+	pinned_d = pgv_pinned_register(dist, align_up(sizeof(float) * (size_t) s->max_batch * s->k)) == PGV_OK;
+	__atomic_add_fetch(&s->servers, 1, __ATOMIC_RELEASE);
+	word_wake_all(&s->servers);
+
+	for (;;)
+	{
+		int			n = 0;
+		uint32_t	gen = 0;
+		int			rc;
+
+		/* a batch opens in this lane (its first client bumps `fill`), then fills until max_batch or the deadline */
+		for (;;)
+		{
+			uint32_t	seen = __atomic_load_n(&l->fill, __ATOMIC_ACQUIRE);
+			int64_t		t;
+			long		nap = 50000;
+
+			if (__atomic_load_n(&s->shutdown, __ATOMIC_ACQUIRE))
+				goto done;
+			t = now_us();
+			pool_lock(s);
+			if (l->state == LANE_COLLECTING && l->count > 0)
+			{
+				int64_t		deadline = l->t_open + s->max_wait_us;
+
+				/* everyone who queued while the lanes were busy joins (they are on their way: `arriving`), later
+				 * arrivals get max_wait_us */
+				if (l->count >= s->max_batch || (s->arriving == 0 && t >= deadline))
+				{
+					if (s->collecting == lane)
+						s->collecting = -1;
+					l->state = LANE_RUNNING;
+					n = l->count;
+					gen = l->gen;
+					s->batches++;
+					s->queries += n;
+					pool_unlock(s);
+					break;
+				}
+				/* stragglers still on their way past the deadline: short naps, bounded by their own progress */
+				nap = t < deadline ? (long) (deadline - t) : 20;
+			}
+			else if (l->state == LANE_PUBLISHED && t - l->t_published > POOL_RECLAIM_US)
+			{
+				/* nobody finished reading for two seconds: the batch's clients are gone */
+				pool_unlock(s);
+				__atomic_store_n(&l->readers, 0, __ATOMIC_RELEASE);
+				lane_release(s, l);
+				continue;
+			}
+			pool_unlock(s);
+			if (nap > 100)
+			{
+				/* a short spin first: the wake-up of a sleeping server costs more than the batch's planning */
+				int64_t		until = now_us() + 30;
+
+				while (__atomic_load_n(&l->fill, __ATOMIC_ACQUIRE) == seen && now_us() < until)
+					__builtin_ia32_pause();
+			}
+			if (__atomic_load_n(&l->fill, __ATOMIC_ACQUIRE) == seen)
+				word_wait_us(&l->fill, seen, nap);
+		}
+		{
+			int64_t		until = now_us() + POOL_READY_US;
+
+			while (__atomic_load_n(&l->ready, __ATOMIC_ACQUIRE) < n && now_us() < until)
+				__builtin_ia32_pause();	/* a client between its slot and the end of its 6 KB memcpy */
+		}
+
+		rc = pgv_search_batch(view, q, n, s->probes, s->k, dist, NULL, tids);
+
+		/* publish: the clients sleep on done_gen */
+		l->rc = rc;
+		if (rc != PGV_OK)
+		{
+			strncpy(l->errmsg, pgv_last_error(), sizeof(l->errmsg) - 1);
+			l->errmsg[sizeof(l->errmsg) - 1] = 0;
+		}
+		l->t_published = now_us();
+		pool_lock(s);
+		l->state = LANE_PUBLISHED;
+		pool_unlock(s);
+		__atomic_store_n(&l->readers, n, __ATOMIC_RELEASE);
+		__atomic_store_n(&l->done_gen, gen, __ATOMIC_RELEASE);
+		word_wake_all(&l->done_gen);
+	}
+done:
+	__atomic_sub_fetch(&s->servers, 1, __ATOMIC_RELEASE);
+	if (pinned_q)
+		pgv_pinned_unregister(q);
+	if (pinned_t)
+		pgv_pinned_unregister(tids);
+	if (pinned_d)
+		pgv_pinned_unregister(dist);
+	return PGV_OK;
+}
+
 /* One backend's query: blocks until its batch has been scanned.  out_tid / out_dist [k]: ascending, padded with
- * ~0 / +inf when the probed lists hold fewer than k tuples (exactly pgv_search_batch's row). */
+ * ~0 / +inf when the probed lists hold fewer than k tuples (exactly pgv_search_batch's row).  Touches shared
+ * memory only -- the calling process needs no GPU context. */
 int
 pgv_host_pool_search(pgv_pool * pool, const void *query, uint64_t *out_tid, float *out_dist)
 {
-	lane	   *l;
-	int			slot;
-	uint32_t	gen;
+	shm_pool   *s;
+	shm_lane   *l;
+	int			lane,
+				slot;
+	uint32_t	gen,
+				seen;
 	int			rc,
 				kick;
 
 	if (!pool || !query || !out_tid || !out_dist)
 		return pgv_host_fail(PGV_ERR_ARG, "pgv_host_pool_search: pool/query/out is NULL");
-	pthread_mutex_lock(&pool->lock);
-	pool->arriving++;
+	s = pool->s;
+	if (__atomic_load_n(&s->shutdown, __ATOMIC_ACQUIRE))
+		return pgv_host_fail(PGV_ERR_STATE, "pgv_host_pool_search: the pool is shut down");
+	pool_lock(s);
+	s->arriving++;
 	/* the batch that is collecting, or a new one in a free lane */
 	for (;;)
 	{
 		uint32_t	epoch;
 
-		if (pool->collecting >= 0)
+		if (s->collecting >= 0)
 			break;
-		for (int i = 0; i < pool->nlanes; i++)
-			if (pool->lanes[i].state == LANE_FREE)
+		for (uint32_t i = 0; i < s->nlanes; i++)
+			if (s->lanes[i].state == LANE_FREE)
 			{
-				pool->collecting = i;
-				pool->lanes[i].state = LANE_COLLECTING;
-				pool->lanes[i].count = 0;
-				pool->lanes[i].ready = 0;
-				pool->lanes[i].gen++;
+				s->collecting = (int32_t) i;
+				s->lanes[i].state = LANE_COLLECTING;
+				s->lanes[i].count = 0;
+				__atomic_store_n(&s->lanes[i].ready, 0, __ATOMIC_RELAXED);
+				s->lanes[i].gen++;
+				s->lanes[i].t_open = now_us();
 				break;
 			}
-		if (pool->collecting >= 0)
+		if (s->collecting >= 0)
 			break;
-		epoch = pool->free_epoch;
-		pthread_mutex_unlock(&pool->lock);
-		word_wait(&pool->free_epoch, epoch);
-		pthread_mutex_lock(&pool->lock);
+		epoch = __atomic_load_n(&s->free_epoch, __ATOMIC_ACQUIRE);
+		if (__atomic_load_n(&s->shutdown, __ATOMIC_ACQUIRE))
+		{
+			s->arriving--;
+			pool_unlock(s);
+			return pgv_host_fail(PGV_ERR_STATE, "pgv_host_pool_search: the pool is shut down");
+		}
+		pool_unlock(s);
+		word_wait_us(&s->free_epoch, epoch, 100000);
+		pool_lock(s);
 	}
-	pool->arriving--;
-	l = &pool->lanes[pool->collecting];
+	s->arriving--;
+	lane = s->collecting;
+	l = &s->lanes[lane];
 	slot = l->count++;
 	gen = l->gen;
-	if (l->count == pool->max_batch)
-		pool->collecting = -1;	/* closed: the next arrival opens another lane */
-	/* full, or the last of those who were queueing: the leader need not wait longer */
-	kick = slot != 0 && (l->count == pool->max_batch || pool->arriving == 0);
-	pthread_mutex_unlock(&pool->lock);
+	if (l->count == s->max_batch)
+		s->collecting = -1;		/* closed: the next arrival opens another lane */
+	/* the first query opens the batch, a full batch or the last of those who were queueing closes it: the lane's
+	 * server should look */
+	kick = slot == 0 || l->count == s->max_batch || s->arriving == 0;
+	pool_unlock(s);
 
-	/* the payload goes in outside the lock; the leader waits for `ready` to reach `count` */
-	memcpy(l->queries + (size_t) slot * pool->row_bytes, query, pool->row_bytes);
+	/* the payload goes in outside the lock; the server waits for `ready` to reach `count` */
+	memcpy(pool->base + l->q_off + (size_t) slot * s->row_bytes, query, s->row_bytes);
 	__atomic_add_fetch(&l->ready, 1, __ATOMIC_RELEASE);
 	if (kick)
 	{
 		__atomic_add_fetch(&l->fill, 1, __ATOMIC_RELEASE);
 		word_wake_all(&l->fill);
 	}
-	if (slot == 0)
+	while ((seen = __atomic_load_n(&l->done_gen, __ATOMIC_ACQUIRE)) != gen)
 	{
-		/* the leader: everyone who queued while the lanes were busy joins (they are on their way: `arriving`),
-		 * later arrivals get max_wait_us; then scan */
-		int			n;
-		int64_t		deadline = now_us() + pool->max_wait_us;
-
-		for (;;)
-		{
-			int64_t		t = now_us();
-			uint32_t	seen;
-
-			pthread_mutex_lock(&pool->lock);
-			if (l->count >= pool->max_batch || (pool->arriving == 0 && t >= deadline))
-			{
-				if (pool->collecting >= 0 && &pool->lanes[pool->collecting] == l)
-					pool->collecting = -1;
-				l->state = LANE_RUNNING;
-				n = l->count;
-				pool->batches++;
-				pool->queries += n;
-				pthread_mutex_unlock(&pool->lock);
-				break;
-			}
-			seen = __atomic_load_n(&l->fill, __ATOMIC_ACQUIRE);
-			pthread_mutex_unlock(&pool->lock);
-			/* stragglers still on their way past the deadline: short naps, bounded by their own progress */
-			word_wait_us(&l->fill, seen, t < deadline ? deadline - t : 20);
-		}
-		while (__atomic_load_n(&l->ready, __ATOMIC_ACQUIRE) < n)
-			__builtin_ia32_pause();	/* a follower between its slot and the end of its 6 KB memcpy */
-
-		rc = pgv_search_batch(l->view, l->queries, n, pool->probes, pool->k, l->dist, NULL, l->tids);
-
-		/* publish: the followers sleep on done_gen */
-		l->rc = rc;
-		__atomic_store_n(&l->readers, n, __ATOMIC_RELAXED);
-		__atomic_store_n(&l->done_gen, gen, __ATOMIC_RELEASE);
-		if (n > 1)
-			word_wake_all(&l->done_gen);
-	}
-	else
-	{
-		uint32_t	seen;
-
-		while ((seen = __atomic_load_n(&l->done_gen, __ATOMIC_ACQUIRE)) != gen)
-			word_wait(&l->done_gen, seen);
+		if (__atomic_load_n(&s->shutdown, __ATOMIC_ACQUIRE))
+			return pgv_host_fail(PGV_ERR_STATE, "pgv_host_pool_search: the pool was shut down under a waiting query");
+		if (__atomic_load_n(&s->servers, __ATOMIC_ACQUIRE) == 0 && now_us() - l->t_open > 5000000)
+			return pgv_host_fail(PGV_ERR_STATE, "pgv_host_pool_search: no server is attached to the pool");
+		word_wait_us(&l->done_gen, seen, 100000);
 	}
 	rc = l->rc;
 	if (rc == PGV_OK)
 	{
-		memcpy(out_tid, l->tids + (size_t) slot * pool->k, sizeof(uint64_t) * (size_t) pool->k);
-		memcpy(out_dist, l->dist + (size_t) slot * pool->k, sizeof(float) * (size_t) pool->k);
+		memcpy(out_tid, pool->base + l->tid_off + sizeof(uint64_t) * (size_t) slot * s->k, sizeof(uint64_t) * (size_t) s->k);
+		memcpy(out_dist, pool->base + l->dist_off + sizeof(float) * (size_t) slot * s->k, sizeof(float) * (size_t) s->k);
 	}
+	else
+		pgv_host_fail(rc, "batch failed: %s", l->errmsg);
 	/* the lane is free again when its last reader has its answer */
 	if (__atomic_sub_fetch(&l->readers, 1, __ATOMIC_ACQ_REL) == 0)
-	{
-		pthread_mutex_lock(&pool->lock);
-		l->state = LANE_FREE;
-		__atomic_add_fetch(&pool->free_epoch, 1, __ATOMIC_RELEASE);
-		pthread_mutex_unlock(&pool->lock);
-		word_wake_all(&pool->free_epoch);	/* everyone queued joins the batch the first of them opens */
-	}
-	if (rc != PGV_OK)
-		return pgv_host_fail(rc, "batch failed: %s", slot == 0 ? pgv_last_error() : "see the leading backend's error");
-	return PGV_OK;
+		lane_release(s, l);
+	return rc;
 }
 
 void
 pgv_host_pool_stats(pgv_pool * pool, int64_t *batches, int64_t *queries)
 {
-	pthread_mutex_lock(&pool->lock);
+	pool_lock(pool->s);
 	if (batches)
-		*batches = pool->batches;
+		*batches = pool->s->batches;
 	if (queries)
-		*queries = pool->queries;
-	pthread_mutex_unlock(&pool->lock);
+		*queries = pool->s->queries;
+	pool_unlock(pool->s);
+}
+
+/* -------------------------------------------------------------- one process: the segment and lane threads in it */
+
+typedef struct
+{
+	pgv_pool   *pool;
+	int			lane;
+}			serve_arg;
+
+static void *
+serve_thread(void *p)
+{
+	serve_arg  *a = p;
+	pgv_pool   *pool = a->pool;
+	int			lane = a->lane;
+
+	free(a);
+	pool->thread_rc[lane] = pgv_host_pool_serve(pool, lane, pool->views[lane]);
+	return NULL;
+}
+
+void
+pgv_host_pool_destroy(pgv_pool * pool)
+{
+	if (!pool)
+		return;
+	if (!pool->owned)
+	{
+		free(pool);
+		return;
+	}
+	pgv_host_pool_shutdown(pool);
+	for (int i = 0; i < pool->nthreads; i++)
+		pthread_join(pool->threads[i], NULL);
+	for (int i = 0; i < POOL_MAX_LANES; i++)
+	{
+		if (pool->views[i])
+			pgv_index_free(pool->views[i]);
+		if (pool->ctxs[i])
+			pgv_ctx_destroy(pool->ctxs[i]);
+	}
+	pthread_mutex_destroy(&pool->s->lock);
+	munmap(pool->s, pool->s->bytes);
+	free(pool);
+}
+
+/*
+ * Segment, lane contexts and lane servers (threads) all in the calling process, which owns `index`.  The segment
+ * is an anonymous MAP_SHARED mapping: children forked afterwards are clients of the same pool (they must not
+ * touch the GPU -- a forked HIP runtime is unusable -- and pgv_host_pool_search does not).
+ */
+int
+pgv_host_pool_create(pgv_index * index, int device, pgv_dtype dtype, int dim, int probes, int k, int max_batch,
+					 int max_wait_us, int lanes, pgv_pool * *out)
+{
+	pgv_pool   *pool;
+	size_t		bytes;
+	void	   *shm;
+	int			rc;
+
+	if (!index || !out)
+		return pgv_host_fail(PGV_ERR_ARG, "pgv_host_pool_create: index/out is NULL");
+	*out = NULL;
+	bytes = pgv_host_pool_shm_bytes(dtype, dim, k, max_batch, lanes);
+	if (bytes == 0 || probes < 1 || max_batch > 65536 || max_wait_us < 0)
+		return pgv_host_fail(PGV_ERR_ARG, "pgv_host_pool_create: bad probes / k / max_batch / max_wait_us / lanes");
+	shm = mmap(NULL, bytes, PROT_READ | PROT_WRITE, MAP_SHARED | MAP_ANONYMOUS, -1, 0);
+	if (shm == MAP_FAILED)
+		return pgv_host_fail(PGV_ERR_NOMEM, "pgv_host_pool_create: mmap of %zu shared bytes failed", bytes);
+	rc = pgv_host_pool_shm_init(shm, bytes, dtype, dim, probes, k, max_batch, max_wait_us, lanes);
+	if (rc == PGV_OK)
+		rc = pgv_host_pool_attach(shm, bytes, &pool);
+	if (rc != PGV_OK)
+	{
+		munmap(shm, bytes);
+		return rc;
+	}
+	pool->owned = 1;
+	for (int i = 0; i < lanes && rc == PGV_OK; i++)
+	{
+		rc = pgv_ctx_create(device, NULL, &pool->ctxs[i]);
+		if (rc == PGV_OK)
+			rc = pgv_index_share(index, pool->ctxs[i], &pool->views[i]);
+		if (rc != PGV_OK)
+			pgv_host_fail(rc, "%s", pgv_last_error());
+	}
+	for (int i = 0; i < lanes && rc == PGV_OK; i++)
+	{
+		serve_arg  *a = malloc(sizeof(serve_arg));
+
+		if (!a)
+		{
+			rc = pgv_host_fail(PGV_ERR_NOMEM, "out of memory");
+			break;
+		}
+		a->pool = pool;
+		a->lane = i;
+		if (pthread_create(&pool->threads[i], NULL, serve_thread, a) != 0)
+		{
+			free(a);
+			rc = pgv_host_fail(PGV_ERR_STATE, "pgv_host_pool_create: cannot start the lane's thread");
+			break;
+		}
+		pool->nthreads++;
+	}
+	if (rc != PGV_OK)
+	{
+		pgv_host_pool_destroy(pool);
+		return rc;
+	}
+	/* the lanes are serving before the first client can arrive */
+	while (__atomic_load_n(&pool->s->servers, __ATOMIC_ACQUIRE) < (uint32_t) lanes)
+		word_wait_us(&pool->s->servers, __atomic_load_n(&pool->s->servers, __ATOMIC_ACQUIRE), 1000);
+	*out = pool;
+	return PGV_OK;
 }

@@ -236,10 +236,34 @@ int			pgv_host_ivf_gettuple(pgv_ivf_scan * scan, uint64_t *out_tid, double *out_
  * A pooler in front of the batched scan (ivf_pool.c): backends hand in one query each (what ivfflatgettuple's
  * caller has, src/ivfscan.c:361-414) and block; queries that arrive within max_wait_us of a batch's first one, or
  * until max_batch are waiting, share one pgv_search_batch -- every pass over a probed list serves all of them.
- * `lanes` batches are in flight at once (a context + pgv_index_share view + pinned buffers each).  Thread-safe.
+ * `lanes` batches are in flight at once.
+ *
+ * Backends are PROCESSES (src/ivfscan.c:252-296 runs in each), so all state the two sides exchange lives in one
+ * position-independent shared segment the caller provides -- inside the server a DSM / ShmemInitStruct block, the
+ * pattern of the reference's parallel build (src/ivfbuild.c:830-966):
+ *   pgv_host_pool_shm_bytes / _shm_init   size and format a segment (no GPU involved)
+ *   pgv_host_pool_attach / _detach        a process's handle on a formatted segment mapped at any address
+ *   pgv_host_pool_search                  a backend's query: touches the segment only, needs NO GPU context
+ *   pgv_host_pool_serve                   the leader loop of one lane, run by whoever owns a GPU context and a handle
+ *                                         on the device mirror (a background worker: the owner's pgv_index_share
+ *                                         view, or a pgv_index_import view in another process); returns at shutdown
+ *   pgv_host_pool_publish_index / _index_handle   the owner of the mirror leaves its pgv_index_export handle in the
+ *                                         segment, other serving processes fetch it (waiting up to wait_ms)
+ *   pgv_host_pool_shutdown                wakes everybody; searches fail with PGV_ERR_STATE from then on
+ * pgv_host_pool_create / _destroy wrap all of it for one process: an anonymous shared segment + one serving thread
+ * per lane (context + pgv_index_share view each); children forked afterwards are clients of the same pool.
  *   out_tid / out_dist [k]: the head of GetScanItems + tuplesort for this query, padded with ~0 / +inf
  */
 typedef struct pgv_pool pgv_pool;
+size_t		pgv_host_pool_shm_bytes(pgv_dtype dtype, int dim, int k, int max_batch, int lanes);
+int			pgv_host_pool_shm_init(void *shm, size_t bytes, pgv_dtype dtype, int dim, int probes, int k, int max_batch,
+								   int max_wait_us, int lanes);
+int			pgv_host_pool_attach(void *shm, size_t bytes, pgv_pool * *out);
+void		pgv_host_pool_detach(pgv_pool * pool);
+int			pgv_host_pool_publish_index(pgv_pool * pool, const pgv_index_handle * handle);
+int			pgv_host_pool_index_handle(pgv_pool * pool, int wait_ms, pgv_index_handle * out);
+int			pgv_host_pool_serve(pgv_pool * pool, int lane, pgv_index * view);
+void		pgv_host_pool_shutdown(pgv_pool * pool);
 int			pgv_host_pool_create(pgv_index * index, int device, pgv_dtype dtype, int dim, int probes, int k,
 								 int max_batch, int max_wait_us, int lanes, pgv_pool * *out);
 int			pgv_host_pool_search(pgv_pool * pool, const void *query, uint64_t *out_tid, float *out_dist);

@@ -501,9 +501,149 @@ test_pool(void)
 	return 0;
 }
 
+/* ------------------------------------------------------- the pooler with backends that are PROCESSES
+ * The owner formats a shared segment and publishes its mirror's handle; two forked processes import the mirror and
+ * serve one lane each (the background workers' role); eight forked clients -- which never call the device library --
+ * hand in one query at a time; every answer is pgv_search_batch's row. */
+#include <sys/mman.h>
+#include <sys/wait.h>
+
+static int
+test_pool_processes(void)
+{
+	enum
+	{
+		N = 600, DIM = 8, LISTS = 6, NQ = 96, K = 5, CLIENTS = 8, LANES = 2
+	};
+	float	   *rows = malloc(sizeof(float) * N * DIM),
+			   *centers = malloc(sizeof(float) * LISTS * DIM),
+			   *queries = malloc(sizeof(float) * NQ * DIM);
+	int64_t		off[LISTS + 1];
+	uint64_t   *tids = malloc(sizeof(uint64_t) * N);
+	uint64_t   *want_t = malloc(sizeof(uint64_t) * NQ * K);
+	float	   *want_d = malloc(sizeof(float) * NQ * K);
+	size_t		shm_bytes = pgv_host_pool_shm_bytes(PGV_F32, DIM, K, 5, LANES);
+	size_t		res_bytes = (sizeof(uint64_t) + sizeof(float)) * NQ * K + sizeof(int) * (CLIENTS + LANES);
+	void	   *shm = mmap(NULL, shm_bytes, PROT_READ | PROT_WRITE, MAP_SHARED | MAP_ANONYMOUS, -1, 0);
+	char	   *res = mmap(NULL, res_bytes, PROT_READ | PROT_WRITE, MAP_SHARED | MAP_ANONYMOUS, -1, 0);
+	uint64_t   *got_t = (uint64_t *) res;
+	float	   *got_d = (float *) (res + sizeof(uint64_t) * NQ * K);
+	int		   *rcs = (int *) (res + (sizeof(uint64_t) + sizeof(float)) * NQ * K);
+	pgv_ctx    *ctx;
+	pgv_index  *ix,
+			   *self;
+	pgv_pool   *pool;
+	pgv_index_handle handle;
+	pid_t		servers[LANES],
+				clients[CLIENTS];
+	int64_t		batches,
+				nqueries;
+	unsigned	seed = 4321;
+
+	EXPECT(shm != MAP_FAILED && res != MAP_FAILED && shm_bytes > 0);
+	for (int i = 0; i < N * DIM; i++)
+		rows[i] = (float) (rand_r(&seed) % 1000) / 100.0f;
+	for (int i = 0; i < LISTS * DIM; i++)
+		centers[i] = (float) (rand_r(&seed) % 1000) / 100.0f;
+	for (int i = 0; i < NQ * DIM; i++)
+		queries[i] = (float) (rand_r(&seed) % 1000) / 100.0f;
+	for (int l = 0; l <= LISTS; l++)
+		off[l] = (int64_t) l * (N / LISTS);
+	for (int i = 0; i < N; i++)
+		tids[i] = 9000 + (uint64_t) i;
+	CHECK(pgv_ctx_create(0, NULL, &ctx));
+	CHECK(pgv_index_upload(ctx, PGV_L2SQ, PGV_F32, DIM, LISTS, centers, off, rows, tids, &ix));
+	CHECK(pgv_search_batch(ix, queries, NQ, 2, K, want_d, NULL, want_t));
+	/* segment checks */
+	EXPECT(pgv_host_pool_shm_bytes(PGV_F32, DIM, K, 5, 9) == 0);
+	EXPECT(pgv_host_pool_attach(shm, shm_bytes, &pool) != PGV_OK);	/* not formatted yet */
+	EXPECT(pgv_host_pool_shm_init(shm, shm_bytes - 1, PGV_F32, DIM, 2, K, 5, 300, LANES) != PGV_OK);
+	CHECK(pgv_host_pool_shm_init(shm, shm_bytes, PGV_F32, DIM, 2, K, 5, 300, LANES));
+	CHECK(pgv_host_pool_attach(shm, shm_bytes, &pool));
+	EXPECT(pgv_host_pool_index_handle(pool, 1, &handle) != PGV_OK);	/* nothing published yet */
+	CHECK(pgv_index_export(ix, &handle));
+	EXPECT(pgv_index_import(ctx, &handle, &self) != PGV_OK);	/* the exporter itself shares, it does not import */
+	CHECK(pgv_host_pool_publish_index(pool, &handle));
+	memset(res, 0xff, res_bytes);
+	for (int s = 0; s < LANES; s++)
+	{
+		servers[s] = fork();
+		if (servers[s] == 0)
+		{
+			pgv_ctx    *sctx;
+			pgv_index  *view;
+			pgv_pool   *mine;
+			pgv_index_handle h;
+			int			rc = pgv_ctx_create(0, NULL, &sctx);
+
+			if (rc == PGV_OK)
+				rc = pgv_host_pool_attach(shm, shm_bytes, &mine);
+			if (rc == PGV_OK)
+				rc = pgv_host_pool_index_handle(mine, 1000, &h);
+			if (rc == PGV_OK)
+				rc = pgv_index_import(sctx, &h, &view);
+			if (rc == PGV_OK)
+				rc = pgv_host_pool_serve(mine, s, view);
+			rcs[CLIENTS + s] = rc;
+			_exit(rc == PGV_OK ? 0 : 3);
+		}
+	}
+	for (int c = 0; c < CLIENTS; c++)
+	{
+		clients[c] = fork();
+		if (clients[c] == 0)
+		{
+			pgv_pool   *mine;
+			int			rc = pgv_host_pool_attach(shm, shm_bytes, &mine);
+
+			for (int round = 0; round < 3 && rc == PGV_OK; round++)
+				for (int j = c; j < NQ && rc == PGV_OK; j += CLIENTS)
+					rc = pgv_host_pool_search(mine, queries + (size_t) j * DIM, got_t + (size_t) j * K, got_d + (size_t) j * K);
+			rcs[c] = rc;
+			_exit(rc == PGV_OK ? 0 : 4);
+		}
+	}
+	for (int c = 0; c < CLIENTS; c++)
+	{
+		int			st = -1;
+
+		EXPECT(waitpid(clients[c], &st, 0) == clients[c] && WIFEXITED(st) && WEXITSTATUS(st) == 0 && rcs[c] == PGV_OK);
+	}
+	pgv_host_pool_stats(pool, &batches, &nqueries);
+	EXPECT(nqueries == 3 * NQ && batches >= 3 * NQ / 5 && batches <= 3 * NQ);
+	EXPECT(memcmp(got_t, want_t, sizeof(uint64_t) * NQ * K) == 0);
+	EXPECT(memcmp(got_d, want_d, sizeof(float) * NQ * K) == 0);
+	/* the owner is a client too */
+	CHECK(pgv_host_pool_search(pool, queries + 2 * DIM, got_t, got_d));
+	EXPECT(memcmp(got_t, want_t + 2 * K, sizeof(uint64_t) * K) == 0);
+	pgv_host_pool_shutdown(pool);
+	for (int s = 0; s < LANES; s++)
+	{
+		int			st = -1;
+
+		EXPECT(waitpid(servers[s], &st, 0) == servers[s] && WIFEXITED(st) && WEXITSTATUS(st) == 0 && rcs[CLIENTS + s] == PGV_OK);
+	}
+	EXPECT(pgv_host_pool_search(pool, queries, got_t, got_d) != PGV_OK);	/* shut down */
+	pgv_host_pool_detach(pool);
+	pgv_index_free(ix);
+	pgv_ctx_destroy(ctx);
+	munmap(shm, shm_bytes);
+	munmap(res, res_bytes);
+	free(rows);
+	free(centers);
+	free(queries);
+	free(tids);
+	free(want_t);
+	free(want_d);
+	return 0;
+}
+
 int
 main(void)
 {
+	/* first: it forks, and the later tests leave OpenMP worker threads behind */
+	if (test_pool_processes())
+		return 1;
 	if (test_hnsw_build())
 		return 1;
 	if (test_ivf())

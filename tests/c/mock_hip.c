@@ -13,6 +13,7 @@
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
+#include <unistd.h>
 
 #include "pgv_hip.h"
 
@@ -152,6 +153,51 @@ void
 pgv_pinned_free(void *p)
 {
 	free(p);
+}
+
+int
+pgv_pinned_register(void *p, size_t bytes)
+{
+	return p && bytes ? PGV_OK : fail(PGV_ERR_ARG, "mock: empty range");
+}
+
+void
+pgv_pinned_unregister(void *p)
+{
+	(void) p;
+}
+
+/* the stand-in's "IPC handle" is the address of the index: valid in a process forked from the exporter (its pages
+ * are the child's too), which is how the host-logic tests run the multi-process pooler without a GPU */
+typedef struct
+{
+	uint64_t	magic;
+	uint32_t	pid;
+	pgv_index  *ix;
+}			mock_handle;
+
+int
+pgv_index_export(pgv_index * ix, pgv_index_handle * out)
+{
+	mock_handle h = {0x6d6f636b6978ull, (uint32_t) getpid(), ix};
+
+	memset(out, 0, sizeof(*out));
+	memcpy(out->bytes, &h, sizeof(h));
+	return PGV_OK;
+}
+
+int
+pgv_index_import(pgv_ctx * ctx, const pgv_index_handle * handle, pgv_index * *out)
+{
+	mock_handle h;
+
+	memcpy(&h, handle->bytes, sizeof(h));
+	*out = NULL;
+	if (h.magic != 0x6d6f636b6978ull)
+		return fail(PGV_ERR_ARG, "mock: not a handle");
+	if (h.pid == (uint32_t) getpid())
+		return fail(PGV_ERR_STATE, "mock: the handle was exported by this process (use pgv_index_share)");
+	return pgv_index_share(h.ix, ctx, out);
 }
 
 void
