@@ -389,3 +389,85 @@ class Pool:
         if self.h:
             lib.pgv_host_pool_destroy(self.h)
             self.h = None
+
+
+# ---------------------------------------------------------------- backends that are processes (tools/)
+_ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+BACKEND_EXE = os.path.join(_ROOT, "build", "tools", "pgv_backend")
+BACKENDS_SO = os.path.join(_ROOT, "build", "tools", "libbackends.so")
+_drv = None
+
+
+def backends_driver():
+    """tools/backends_driver.c as a shared object (built by __graft_entry__.build())"""
+    global _drv
+    if _drv is None:
+        if not (os.path.exists(BACKENDS_SO) and os.path.exists(BACKEND_EXE)):
+            raise ImportError("build/tools/libbackends.so / pgv_backend not built: run __graft_entry__.build()")
+        d = C.CDLL(BACKENDS_SO)
+        P, I = C.c_void_p, C.c_int
+        d.backends_run.argtypes = [P, I, I, I, P, I, C.c_size_t, I, I, C.POINTER(C.c_double)]
+        d.pool_run.argtypes = [P, I, I, I, I, I, P, I, C.c_size_t, I, I, I, I, I, C.POINTER(C.c_double)]
+        d.backends_run_processes.argtypes = [P, C.c_char_p, I, I, I, I, I, P, I, C.c_size_t, I, I, I, I, I, I, I, I,
+                                             C.c_char_p, I, P, P, C.POINTER(C.c_double), C.c_char_p, C.c_size_t]
+        _drv = d
+    return _drv
+
+
+def write_index_image(name, metric, dtype, dim, centers, list_offsets, vectors, tids):
+    """a pgvb_image segment (tools/pgv_backend_shm.h) under /dev/shm for `pgv_backend owner`; returns its shm name"""
+    centers = np.ascontiguousarray(centers)
+    vectors = np.ascontiguousarray(vectors)
+    offs = np.ascontiguousarray(list_offsets, dtype=np.int64)
+    tids = None if tids is None else np.ascontiguousarray(tids, dtype=np.uint64)
+    head = 4096
+    parts, at = [], head
+    for a in (centers, offs, vectors, tids):
+        if a is None:
+            parts.append(0)
+            continue
+        parts.append(at)
+        at = (at + a.nbytes + 4095) & ~4095
+    path = "/dev/shm/" + name.lstrip("/")
+    with open(path, "wb") as f:
+        f.truncate(at)
+    mm = np.memmap(path, dtype=np.uint8, mode="r+")
+    hdr = np.zeros(8, dtype=np.uint64)
+    hdr[0] = 0x7067765f696d6167
+    hdr[1] = (int(metric) & 0xffffffff) | (int(dtype) << 32)
+    hdr[2] = (int(dim) & 0xffffffff) | (int(centers.shape[0]) << 32)
+    hdr[3] = int(vectors.shape[0])
+    hdr[4:8] = parts
+    mm[:64] = hdr.view(np.uint8)
+    for off, a in zip(parts, (centers, offs, vectors, tids)):
+        if a is not None:
+            mm[off:off + a.nbytes] = a.view(np.uint8).reshape(-1)
+    mm.flush()
+    del mm
+    return "/" + name.lstrip("/")
+
+
+def run_backend_processes(index, queries, probes, k, mode, nclients, per_client, warmup=5, max_batch=1024,
+                          max_wait_us=50, lanes=2, server_processes=True, verify=False, image_shm=None, device=0):
+    """N backend PROCESSES against one device mirror.  mode 0: every process imports the mirror and runs
+    pgv_query_*; mode 1: GPU-less clients behind the shared-memory pooler.  Returns a dict (qps, latencies, mean
+    batch, HBM that went to the children) and, with verify, the answers [nclients, per_client, k]."""
+    d = backends_driver()
+    q = np.ascontiguousarray(queries)
+    out = (C.c_double * 8)()
+    err = C.create_string_buffer(512)
+    k = min(k, 64)
+    ans_t = np.zeros((nclients, per_client, k), dtype=np.uint64) if verify else None
+    ans_d = np.zeros((nclients, per_client, k), dtype=np.float32) if verify else None
+    rc = d.backends_run_processes(index.h if index is not None else None, image_shm.encode() if image_shm else None,
+                                  device, mode, nclients, per_client, warmup, q.ctypes.data, q.shape[0], q.strides[0],
+                                  index.dtype if index is not None else (0 if q.dtype == np.float32 else 1), q.shape[1],
+                                  probes, k, max_batch, max_wait_us, lanes, 1 if server_processes else 0,
+                                  BACKEND_EXE.encode(), 1 if verify else 0,
+                                  ans_t.ctypes.data if verify else None, ans_d.ctypes.data if verify else None,
+                                  out, err, len(err))
+    if rc != 0:
+        raise _lib.PgvError(rc, "backends_run_processes: " + err.value.decode("utf-8", "replace"))
+    res = {"qps": out[0], "latency_us_p50": out[1], "latency_us_p90": out[2], "mean_batch": out[3],
+           "hbm_bytes_taken_by_children": out[4], "processes": int(out[5])}
+    return (res, ans_t, ans_d) if verify else res

@@ -10,8 +10,8 @@ import weakref
 import numpy as np
 
 from . import _lib
-from ._lib import (PGV_F16, PGV_F32, PGV_L1, PGV_L2SQ, PGV_NEG_IP, PGV_OPS_COSINE, PGV_OPS_IP,
-                   PGV_OPS_L2, PgvError, PgvRng, PgvStats, check, lib)
+from ._lib import (PGV_ERR_ARG, PGV_ERR_STATE, PGV_F16, PGV_F32, PGV_L1, PGV_L2SQ, PGV_NEG_IP, PGV_OPS_COSINE,  # noqa: F401
+                   PGV_OPS_IP, PGV_OPS_L2, PgvError, PgvRng, PgvStats, check, lib)
 
 _NP_OF = {PGV_F32: np.float32, PGV_F16: np.float16}
 
@@ -154,6 +154,24 @@ class IvfIndex:
         h = C.c_void_p()
         check(lib.pgv_index_share(self.h, ctx.h, C.byref(h)))
         v.h = h
+        ctx._adopt(v)
+        return v
+
+    def export(self):
+        """pgv_index_export: the 256-byte handle another PROCESS imports (pgv_index_import) to scan this mirror"""
+        buf = C.create_string_buffer(256)
+        check(lib.pgv_index_export(self.h, buf))
+        return bytes(buf.raw)
+
+    @classmethod
+    def from_handle(cls, ctx, handle, metric=None, dtype=None, dim=None):
+        """pgv_index_import: map a mirror another process exported (no copy)"""
+        v = cls.__new__(cls)
+        h = C.c_void_p()
+        buf = C.create_string_buffer(bytes(handle), 256)
+        check(lib.pgv_index_import(ctx.h, buf, C.byref(h)))
+        v.ctx, v.metric, v.dtype, v.dim, v.h = ctx, metric, dtype, dim, h
+        v.nlists = lib.pgv_index_lists(h)
         ctx._adopt(v)
         return v
 

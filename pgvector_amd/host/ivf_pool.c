@@ -44,6 +44,7 @@
 #include <time.h>
 
 extern int	pgv_host_fail(int code, const char *fmt,...);
+void		pgv_host_pool_destroy(pgv_pool * pool);
 
 #define POOL_MAGIC 0x7067765f706f6f6cull	/* "pgv_pool" */
 #define POOL_VERSION 2
@@ -253,8 +254,7 @@ pgv_host_pool_attach(void *shm, size_t bytes, pgv_pool * *out)
 void
 pgv_host_pool_detach(pgv_pool * pool)
 {
-	if (pool && !pool->owned)
-		free(pool);
+	pgv_host_pool_destroy(pool);	/* a handle that leads lanes shuts the pool down; a plain one is just freed */
 }
 
 int
@@ -305,6 +305,12 @@ pgv_host_pool_shutdown(pgv_pool * pool)
 	__atomic_add_fetch(&s->free_epoch, 1, __ATOMIC_RELEASE);
 	word_wake_all(&s->free_epoch);
 	word_wake_all(&s->has_index);
+}
+
+int
+pgv_host_pool_is_shut_down(pgv_pool * pool)
+{
+	return pool == NULL || __atomic_load_n(&pool->s->shutdown, __ATOMIC_ACQUIRE) != 0;
 }
 
 /* the last reader (or the lane's server, for a batch whose clients vanished) hands the lane back */
@@ -571,29 +577,94 @@ serve_thread(void *p)
 	return NULL;
 }
 
-void
-pgv_host_pool_destroy(pgv_pool * pool)
+/* join the lane threads this handle started (the pool must be shut down), drop their views and contexts */
+static void
+stop_threads(pgv_pool * pool)
 {
-	if (!pool)
-		return;
-	if (!pool->owned)
-	{
-		free(pool);
-		return;
-	}
-	pgv_host_pool_shutdown(pool);
 	for (int i = 0; i < pool->nthreads; i++)
 		pthread_join(pool->threads[i], NULL);
+	pool->nthreads = 0;
 	for (int i = 0; i < POOL_MAX_LANES; i++)
 	{
 		if (pool->views[i])
 			pgv_index_free(pool->views[i]);
 		if (pool->ctxs[i])
 			pgv_ctx_destroy(pool->ctxs[i]);
+		pool->views[i] = NULL;
+		pool->ctxs[i] = NULL;
 	}
-	pthread_mutex_destroy(&pool->s->lock);
-	munmap(pool->s, pool->s->bytes);
+}
+
+void
+pgv_host_pool_destroy(pgv_pool * pool)
+{
+	if (!pool)
+		return;
+	if (pool->nthreads > 0 || pool->owned)
+		pgv_host_pool_shutdown(pool);
+	stop_threads(pool);
+	if (pool->owned)
+	{
+		pthread_mutex_destroy(&pool->s->lock);
+		munmap(pool->s, pool->s->bytes);
+	}
 	free(pool);
+}
+
+/*
+ * Lead every lane of an attached pool with a thread of the calling process, which owns `index` (one context + one
+ * pgv_index_share view per lane).  The threads end at pgv_host_pool_shutdown and are joined by
+ * pgv_host_pool_destroy / _detach of this handle.
+ */
+int
+pgv_host_pool_start_threads(pgv_pool * pool, pgv_index * index, int device)
+{
+	int			lanes,
+				rc = PGV_OK;
+
+	if (!pool || !index)
+		return pgv_host_fail(PGV_ERR_ARG, "pgv_host_pool_start_threads: pool/index is NULL");
+	if (pool->nthreads > 0)
+		return pgv_host_fail(PGV_ERR_STATE, "pgv_host_pool_start_threads: this handle already leads the lanes");
+	lanes = (int) pool->s->nlanes;
+	for (int i = 0; i < lanes && rc == PGV_OK; i++)
+	{
+		rc = pgv_ctx_create(device, NULL, &pool->ctxs[i]);
+		if (rc == PGV_OK)
+			rc = pgv_index_share(index, pool->ctxs[i], &pool->views[i]);
+		if (rc != PGV_OK)
+			pgv_host_fail(rc, "%s", pgv_last_error());
+	}
+	for (int i = 0; i < lanes && rc == PGV_OK; i++)
+	{
+		serve_arg  *a = malloc(sizeof(serve_arg));
+
+		if (!a)
+		{
+			rc = pgv_host_fail(PGV_ERR_NOMEM, "out of memory");
+			break;
+		}
+		a->pool = pool;
+		a->lane = i;
+		if (pthread_create(&pool->threads[i], NULL, serve_thread, a) != 0)
+		{
+			free(a);
+			rc = pgv_host_fail(PGV_ERR_STATE, "pgv_host_pool_start_threads: cannot start the lane's thread");
+			break;
+		}
+		pool->nthreads++;
+	}
+	if (rc != PGV_OK)
+	{
+		if (pool->nthreads > 0)
+			pgv_host_pool_shutdown(pool);
+		stop_threads(pool);
+		return rc;
+	}
+	/* the lanes are serving before the first client can arrive */
+	while (__atomic_load_n(&pool->s->servers, __ATOMIC_ACQUIRE) < (uint32_t) lanes)
+		word_wait_us(&pool->s->servers, __atomic_load_n(&pool->s->servers, __ATOMIC_ACQUIRE), 1000);
+	return PGV_OK;
 }
 
 /*
@@ -628,41 +699,12 @@ pgv_host_pool_create(pgv_index * index, int device, pgv_dtype dtype, int dim, in
 		return rc;
 	}
 	pool->owned = 1;
-	for (int i = 0; i < lanes && rc == PGV_OK; i++)
-	{
-		rc = pgv_ctx_create(device, NULL, &pool->ctxs[i]);
-		if (rc == PGV_OK)
-			rc = pgv_index_share(index, pool->ctxs[i], &pool->views[i]);
-		if (rc != PGV_OK)
-			pgv_host_fail(rc, "%s", pgv_last_error());
-	}
-	for (int i = 0; i < lanes && rc == PGV_OK; i++)
-	{
-		serve_arg  *a = malloc(sizeof(serve_arg));
-
-		if (!a)
-		{
-			rc = pgv_host_fail(PGV_ERR_NOMEM, "out of memory");
-			break;
-		}
-		a->pool = pool;
-		a->lane = i;
-		if (pthread_create(&pool->threads[i], NULL, serve_thread, a) != 0)
-		{
-			free(a);
-			rc = pgv_host_fail(PGV_ERR_STATE, "pgv_host_pool_create: cannot start the lane's thread");
-			break;
-		}
-		pool->nthreads++;
-	}
+	rc = pgv_host_pool_start_threads(pool, index, device);
 	if (rc != PGV_OK)
 	{
 		pgv_host_pool_destroy(pool);
 		return rc;
 	}
-	/* the lanes are serving before the first client can arrive */
-	while (__atomic_load_n(&pool->s->servers, __ATOMIC_ACQUIRE) < (uint32_t) lanes)
-		word_wait_us(&pool->s->servers, __atomic_load_n(&pool->s->servers, __ATOMIC_ACQUIRE), 1000);
 	*out = pool;
 	return PGV_OK;
 }

@@ -263,7 +263,10 @@ void		pgv_host_pool_detach(pgv_pool * pool);
 int			pgv_host_pool_publish_index(pgv_pool * pool, const pgv_index_handle * handle);
 int			pgv_host_pool_index_handle(pgv_pool * pool, int wait_ms, pgv_index_handle * out);
 int			pgv_host_pool_serve(pgv_pool * pool, int lane, pgv_index * view);
+/* one serving thread per lane in the calling process, which owns `index` (a context + pgv_index_share view each) */
+int			pgv_host_pool_start_threads(pgv_pool * pool, pgv_index * index, int device);
 void		pgv_host_pool_shutdown(pgv_pool * pool);
+int			pgv_host_pool_is_shut_down(pgv_pool * pool);
 int			pgv_host_pool_create(pgv_index * index, int device, pgv_dtype dtype, int dim, int probes, int k,
 								 int max_batch, int max_wait_us, int lanes, pgv_pool * *out);
 int			pgv_host_pool_search(pgv_pool * pool, const void *query, uint64_t *out_tid, float *out_dist);

@@ -267,3 +267,304 @@ pool_run(pgv_index * index, int device, int dtype, int dim, int nclients, int pe
 	free(c);
 	return rc;
 }
+
+
+/* ============================================================================================================
+ * The same two experiments with backends that are PROCESSES (tools/pgv_backend.c), which is what a Postgres
+ * backend is (src/ivfscan.c:252-296 runs in each): ONE device mirror, exported by its owner and imported by every
+ * other process (pgv_index_export / pgv_index_import); ONE pooler whose state lives in a shared segment.
+ *
+ *   mode 0  every client process imports the mirror and issues pgv_query_rank + pgv_query_scan on its own context
+ *   mode 1  client processes have NO GPU context: pgv_host_pool_search over the shared segment; the lanes are led
+ *           by `lanes` server processes that import the mirror (server_processes != 0) or by threads of the
+ *           calling process (pgv_index_share views)
+ *   owner   who uploads and exports the mirror: the calling process (`index`), or -- when `image_shm` names a
+ *           pgvb_image segment -- a separate owner process (then every participant runs the same HIP runtime)
+ *
+ * out[0] queries/s, [1] p50 us, [2] p90 us, [3] mean batch (mode 1), [4] bytes of HBM that went away between "before
+ * any child" and "all children at the start line" (contexts + scratch of every process, the mirror NOT among them
+ * unless a separate owner uploaded it), [5] processes spawned.  ans_tid / ans_dist [nclients x per_client x k] or NULL.
+ */
+#include <errno.h>
+#include <fcntl.h>
+#include <limits.h>
+#include <linux/futex.h>
+#include <signal.h>
+#include <spawn.h>
+#include <stdio.h>
+#include <sys/mman.h>
+#include <sys/syscall.h>
+#include <sys/wait.h>
+#include <unistd.h>
+
+#include "pgv_backend_shm.h"
+
+extern char **environ;
+
+static void *
+make_shm(const char *name, size_t bytes)
+{
+	int			fd;
+	void	   *p;
+
+	shm_unlink(name);
+	fd = shm_open(name, O_CREAT | O_EXCL | O_RDWR, 0600);
+	if (fd < 0)
+		return NULL;
+	if (ftruncate(fd, (off_t) bytes) != 0)
+	{
+		close(fd);
+		shm_unlink(name);
+		return NULL;
+	}
+	p = mmap(NULL, bytes, PROT_READ | PROT_WRITE, MAP_SHARED, fd, 0);
+	close(fd);
+	return p == MAP_FAILED ? NULL : p;
+}
+
+static pid_t
+spawn(const char *exe, const char *a1, const char *a2, const char *a3, const char *a4)
+{
+	char	   *argv[] = {(char *) exe, (char *) a1, (char *) a2, (char *) a3, (char *) a4, NULL};
+	pid_t		pid = -1;
+
+	if (posix_spawn(&pid, exe, NULL, NULL, argv, environ) != 0)
+		return -1;
+	return pid;
+}
+
+int
+backends_run_processes(pgv_index * index, const char *image_shm, int device, int mode, int nclients, int per_client,
+					   int warmup, const void *queries, int nq, size_t query_bytes, int dtype, int dim, int probes, int k,
+					   int max_batch, int max_wait_us, int lanes, int server_processes, const char *exe, int verify,
+					   uint64_t *ans_tid, float *ans_dist, double *out, char *errbuf, size_t errcap)
+{
+	char		pool_name[64],
+				bank_name[64],
+				num[16],
+				devs[16];
+	size_t		pool_bytes,
+				bank_bytes,
+				at;
+	void	   *pool_shm = NULL;
+	pgvb_bank  *bank = NULL;
+	pgv_pool   *pool = NULL;
+	pid_t	   *pids = NULL;
+	int			npids = 0,
+				rc = PGV_OK;
+	uint64_t	free0 = 0,
+				free1 = 0,
+				total = 0;
+	int64_t		batches0 = 0,
+				queries0 = 0,
+				batches1 = 0,
+				queries1 = 0;
+
+	if (errbuf && errcap)
+		errbuf[0] = 0;
+#define FAILP(code, ...) do { rc = (code); if (errbuf) snprintf(errbuf, errcap, __VA_ARGS__); goto out; } while (0)
+	if (k > PGVB_MAX_K || nclients < 1 || per_client < 1 || lanes < 1 || lanes > 8)
+		FAILP(PGV_ERR_ARG, "bad k / nclients / per_client / lanes");
+	if (!getenv("HSA_ENABLE_IPC_MODE_LEGACY"))
+		setenv("HSA_ENABLE_IPC_MODE_LEGACY", "0", 1);	/* dmabuf IPC: the children inherit it */
+	snprintf(pool_name, sizeof(pool_name), "/pgv_pool_%d", (int) getpid());
+	snprintf(bank_name, sizeof(bank_name), "/pgv_bank_%d", (int) getpid());
+	snprintf(devs, sizeof(devs), "%d", device);
+	pgv_device_memory(device, &free0, &total);
+
+	/* the pool segment: the handle registry in both modes, the pooler's lanes in mode 1 */
+	pool_bytes = pgv_host_pool_shm_bytes((pgv_dtype) dtype, dim, k, max_batch, lanes);
+	pool_shm = make_shm(pool_name, pool_bytes);
+	if (!pool_shm)
+		FAILP(PGV_ERR_NOMEM, "shm_open(%s, %zu bytes) failed: %s", pool_name, pool_bytes, strerror(errno));
+	rc = pgv_host_pool_shm_init(pool_shm, pool_bytes, (pgv_dtype) dtype, dim, probes, k, max_batch, max_wait_us, lanes);
+	if (rc == PGV_OK)
+		rc = pgv_host_pool_attach(pool_shm, pool_bytes, &pool);
+	if (rc != PGV_OK)
+		FAILP(rc, "pool segment: %s", pgv_host_last_error());
+
+	/* the bank: queries in, latencies / answers out */
+	at = (sizeof(pgvb_bank) + 63) & ~(size_t) 63;
+	bank_bytes = at + sizeof(pgvb_client) * (size_t) nclients + sizeof(double) * (size_t) nclients * per_client +
+		(verify ? (sizeof(uint64_t) + sizeof(float)) * (size_t) nclients * per_client * k : 0) + query_bytes * (size_t) nq + 256;
+	bank = make_shm(bank_name, bank_bytes);
+	if (!bank)
+		FAILP(PGV_ERR_NOMEM, "shm_open(%s, %zu bytes) failed: %s", bank_name, bank_bytes, strerror(errno));
+	memset(bank, 0, at);
+	bank->nq = nq;
+	bank->probes = probes;
+	bank->k = k;
+	bank->per_client = per_client;
+	bank->warmup = warmup;
+	bank->nclients = nclients;
+	bank->device = device;
+	bank->verify = verify;
+	bank->query_bytes = query_bytes;
+	bank->clients_off = at;
+	at += sizeof(pgvb_client) * (size_t) nclients;
+	bank->lat_off = at;
+	at += sizeof(double) * (size_t) nclients * per_client;
+	if (verify)
+	{
+		bank->tid_off = at;
+		at += sizeof(uint64_t) * (size_t) nclients * per_client * k;
+		bank->dist_off = at;
+		at += sizeof(float) * (size_t) nclients * per_client * k;
+	}
+	at = (at + 63) & ~(size_t) 63;
+	bank->queries_off = at;
+	memcpy((char *) bank + at, queries, query_bytes * (size_t) nq);
+	memset((char *) bank + bank->clients_off, 0, sizeof(pgvb_client) * (size_t) nclients);
+	bank->magic = PGVB_BANK_MAGIC;
+
+	pids = calloc((size_t) nclients + 16, sizeof(pid_t));
+	/* who owns the mirror */
+	if (image_shm)
+	{
+		if ((pids[npids] = spawn(exe, "owner", pool_name, image_shm, devs)) < 0)
+			FAILP(PGV_ERR_STATE, "cannot spawn %s owner", exe);
+		npids++;
+	}
+	else
+	{
+		pgv_index_handle h;
+
+		if ((rc = pgv_index_export(index, &h)) != PGV_OK)
+			FAILP(rc, "pgv_index_export: %s", pgv_last_error());
+		pgv_host_pool_publish_index(pool, &h);
+	}
+	/* who leads the lanes (mode 1) */
+	if (mode == 1 && server_processes)
+	{
+		for (int l = 0; l < lanes; l++)
+		{
+			snprintf(num, sizeof(num), "%d", l);
+			if ((pids[npids] = spawn(exe, "serve", pool_name, num, devs)) < 0)
+				FAILP(PGV_ERR_STATE, "cannot spawn %s serve", exe);
+			npids++;
+		}
+	}
+	else if (mode == 1)
+	{
+		/* threads of this process over the SAME shared segment (pgv_index_share views): only possible when this
+		 * process owns the mirror */
+		if (image_shm)
+			FAILP(PGV_ERR_ARG, "lane threads need the mirror in this process");
+		rc = pgv_host_pool_start_threads(pool, index, device);
+		if (rc != PGV_OK)
+			FAILP(rc, "lane threads: %s", pgv_host_last_error());
+	}
+	for (int c = 0; c < nclients; c++)
+	{
+		snprintf(num, sizeof(num), "%d", c);
+		if ((pids[npids] = spawn(exe, mode == 1 ? "client" : "query", pool_name, bank_name, num)) < 0)
+			FAILP(PGV_ERR_STATE, "cannot spawn %s client %d", exe, c);
+		npids++;
+	}
+	/* everybody warmed up and at the start line (or somebody died on the way) */
+	{
+		double		deadline = now() + 300.0;
+
+		while (__atomic_load_n(&bank->ready, __ATOMIC_ACQUIRE) < (uint32_t) nclients)
+		{
+			struct timespec rel = {0, 20000000};
+
+			for (int i = 0; i < npids; i++)
+			{
+				int			st;
+
+				if (pids[i] > 0 && waitpid(pids[i], &st, WNOHANG) == pids[i])
+				{
+					pids[i] = 0;
+					FAILP(PGV_ERR_STATE, "child %d exited before the start (status %d, exit code %d)", i, st,
+						  WIFEXITED(st) ? WEXITSTATUS(st) : -1);
+				}
+			}
+			if (now() > deadline)
+				FAILP(PGV_ERR_STATE, "clients did not reach the start line in 300 s");
+			syscall(SYS_futex, &bank->ready, FUTEX_WAIT, __atomic_load_n(&bank->ready, __ATOMIC_ACQUIRE), &rel, NULL, 0);
+		}
+	}
+	pgv_device_memory(device, &free1, &total);
+	pgv_host_pool_stats(pool, &batches0, &queries0);
+	__atomic_store_n(&bank->go, 1, __ATOMIC_RELEASE);
+	syscall(SYS_futex, &bank->go, FUTEX_WAKE, INT_MAX, NULL, NULL, 0);
+	/* the clients are the last nclients pids */
+	for (int i = npids - nclients; i < npids; i++)
+	{
+		int			st = 0;
+
+		if (pids[i] > 0 && waitpid(pids[i], &st, 0) == pids[i])
+		{
+			pids[i] = 0;
+			if ((!WIFEXITED(st) || WEXITSTATUS(st) != 0) && rc == PGV_OK)
+			{
+				pgvb_client *cl = (pgvb_client *) ((char *) bank + bank->clients_off) + (i - (npids - nclients));
+
+				rc = cl->rc ? cl->rc : PGV_ERR_STATE;
+				if (errbuf)
+					snprintf(errbuf, errcap, "client %d: status %d: %s", i - (npids - nclients), st, cl->err);
+			}
+		}
+	}
+	pgv_host_pool_stats(pool, &batches1, &queries1);
+	if (rc == PGV_OK)
+	{
+		pgvb_client *cl = (pgvb_client *) ((char *) bank + bank->clients_off);
+		double	   *lat = (double *) ((char *) bank + bank->lat_off);
+		size_t		n = (size_t) nclients * per_client;
+		double		first = 1e300,
+					last = 0;
+
+		for (int c = 0; c < nclients; c++)
+		{
+			if (cl[c].t0 < first)
+				first = cl[c].t0;
+			if (cl[c].t1 > last)
+				last = cl[c].t1;
+		}
+		if (verify && ans_tid && ans_dist)
+		{
+			memcpy(ans_tid, (char *) bank + bank->tid_off, sizeof(uint64_t) * n * k);
+			memcpy(ans_dist, (char *) bank + bank->dist_off, sizeof(float) * n * k);
+		}
+		qsort(lat, n, sizeof(double), cmp_double);
+		out[0] = (double) n / (last - first);
+		out[1] = lat[n / 2] * 1e6;
+		out[2] = lat[n * 9 / 10] * 1e6;
+		out[3] = batches1 > batches0 ? (double) (queries1 - queries0) / (double) (batches1 - batches0) : 0.0;
+		out[4] = (double) free0 - (double) free1;
+		out[5] = (double) npids;
+	}
+out:
+	if (pool)
+		pgv_host_pool_shutdown(pool);
+	for (int i = 0; pids && i < npids; i++)
+		if (pids[i] > 0)
+		{
+			int			st;
+			double		deadline = now() + 10.0;
+
+			while (waitpid(pids[i], &st, WNOHANG) == 0)
+			{
+				if (now() > deadline)
+				{
+					kill(pids[i], SIGKILL);
+					waitpid(pids[i], &st, 0);
+					break;
+				}
+				usleep(2000);
+			}
+		}
+	free(pids);
+	if (pool)
+		pgv_host_pool_detach(pool);
+	if (pool_shm)
+		munmap(pool_shm, pool_bytes);
+	if (bank)
+		munmap(bank, bank_bytes);
+	shm_unlink(pool_name);
+	shm_unlink(bank_name);
+	return rc;
+#undef FAILP
+}
