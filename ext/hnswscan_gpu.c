@@ -207,12 +207,29 @@ PgvHnswMetricOf(Relation index)
 	return PGV_L2SQ;
 }
 
+/* vector reports HNSW_MAX_DIM, halfvec twice that (src/hnswutils.c HnswGetTypeInfo); bit reports 32 x and sparsevec
+ * SPARSEVEC_MAX_DIM: their element tuples are not dense float rows */
+bool
+PgvHnswElementType(Relation index, pgv_dtype * dtype)
+{
+	int			maxDimensions = HnswGetTypeInfo(index)->maxDimensions;
+
+	if (maxDimensions == HNSW_MAX_DIM)
+		*dtype = PGV_F32;
+	else if (maxDimensions == HNSW_MAX_DIM * 2)
+		*dtype = PGV_F16;
+	else
+		return false;
+	return true;
+}
+
 void *
 PgvHnswBeginScan(Relation index)
 {
 	PgvHnswMirror *m;
+	pgv_dtype	dtype;
 
-	if (!vector_gpu)
+	if (!vector_gpu || !PgvHnswElementType(index, &dtype))
 		return NULL;
 	for (m = hnswMirrors; m != NULL; m = m->next)
 		if (m->relid == RelationGetRelid(index))
@@ -229,7 +246,6 @@ PgvHnswBeginScan(Relation index)
 		/* FUNCTION 1 of the opclass: vector_l2_squared_distance, or vector_negative_inner_product on rows that
 		 * FUNCTION 2 normalised (cosine) or not (ip) -- sql/vector.sql:427-447, :843-865 */
 		bool		normalized = HnswOptionalProcInfo(index, HNSW_NORM_PROC) != NULL;
-		pgv_dtype	dtype = HnswGetTypeInfo(index)->maxDimensions > 2000 ? PGV_F16 : PGV_F32;
 		pgv_metric	metric = normalized ? PGV_NEG_IP : PgvHnswMetricOf(index);	/* cosine: FUNCTION 1 is the negative inner product too */
 
 		if (m->h)

@@ -19,8 +19,9 @@ typedef struct PgvIvfBuild
 	int			count;			/* rows buffered */
 	char	   *rows;			/* [PGV_ASSIGN_BATCH x dimensions] */
 	ItemPointerData *tids;
-	Datum	   *values;			/* the (normalised) datums, what the reference's tuplesort stores */
 	int32	   *lists;
+	char	   *value;			/* one Vector / HalfVector varlena, rebuilt from a buffered payload for the tuplesort */
+	Size		valueSize;
 }			PgvIvfBuild;
 
 static double
@@ -54,9 +55,8 @@ PgvIvfflatKmeans(Relation index, VectorArray samples, VectorArray centers, const
 	int			iterations;
 
 	(void) typeInfo;
-	if (!vector_gpu)
+	if (!vector_gpu || !PgvIvfflatOpclass(index, &metric, &dtype, &ops))
 		return false;
-	PgvIvfflatOpclass(index, &metric, &dtype, &ops);
 	rowBytes = (dtype == PGV_F32 ? sizeof(float) : sizeof(uint16)) * (Size) samples->dim;
 	in = palloc(rowBytes * (Size) Max(samples->length, 1));
 	out = palloc(rowBytes * (Size) centers->maxlen);
@@ -90,14 +90,20 @@ PgvIvfflatBuildBegin(IvfflatBuildState * buildstate)
 	if (!vector_gpu)
 		return;
 	gb = palloc0(sizeof(PgvIvfBuild));
-	PgvIvfflatOpclass(buildstate->index, &gb->metric, &gb->dtype, &gb->ops);
+	if (!PgvIvfflatOpclass(buildstate->index, &gb->metric, &gb->dtype, &gb->ops))
+	{
+		pfree(gb);
+		return;					/* bit opclass: the reference's AddTupleToSort */
+	}
 	gb->rowBytes = (gb->dtype == PGV_F32 ? sizeof(float) : sizeof(uint16)) * (Size) buildstate->dimensions;
 	gb->centers = palloc(gb->rowBytes * (Size) buildstate->lists);
 	for (int i = 0; i < buildstate->lists; i++)
 		memcpy(gb->centers + gb->rowBytes * (Size) i, ((Vector *) VectorArrayGet(buildstate->centers, i))->x, gb->rowBytes);
 	gb->rows = palloc(gb->rowBytes * (Size) PGV_ASSIGN_BATCH);
 	gb->tids = palloc(sizeof(ItemPointerData) * (Size) PGV_ASSIGN_BATCH);
-	gb->values = palloc(sizeof(Datum) * (Size) PGV_ASSIGN_BATCH);
+	/* Vector and HalfVector share the 8-byte header (vl_len_, dim, unused); src/vector.h:18-24, src/halfvec.h:68-74 */
+	gb->valueSize = offsetof(Vector, x) + gb->rowBytes;
+	gb->value = palloc0(gb->valueSize);
 	gb->lists = palloc(sizeof(int32) * (Size) PGV_ASSIGN_BATCH);
 	buildstate->gpu = gb;
 }
@@ -115,7 +121,19 @@ PgvIvfflatBuildFlush(IvfflatBuildState * buildstate)
 				   gb->rows, gb->count, gb->lists, NULL) != PGV_OK)
 		ereport(ERROR, (errmsg("pgvector GPU path: %s", pgv_last_error())));
 	for (int i = 0; i < gb->count; i++)
-		IvfflatAddToSort(buildstate, gb->lists[i], &gb->tids[i], gb->values[i]);
+	{
+		/* The caller's Datum is gone by now: BuildCallback detoasts and normalises inside buildstate->tmpCtx and
+		 * resets it after every row, and a non-toasted value points into the heap scan's buffer
+		 * (src/ivfbuild.c:238-249).  The tuplesort copies what it is given, so the value is rebuilt from the
+		 * payload this file kept. */
+		Vector	   *v = (Vector *) gb->value;
+
+		v->vl_len_ = (int32) (gb->valueSize << 2);	/* SET_VARSIZE */
+		v->dim = (int16) buildstate->dimensions;
+		v->unused = 0;
+		memcpy(v->x, gb->rows + gb->rowBytes * (Size) i, gb->rowBytes);
+		IvfflatAddToSort(buildstate, gb->lists[i], &gb->tids[i], PointerGetDatum(v));
+	}
 	gb->count = 0;
 }
 
@@ -125,9 +143,9 @@ PgvIvfflatBuildAdd(IvfflatBuildState * buildstate, ItemPointer tid, Datum value)
 {
 	PgvIvfBuild *gb = (PgvIvfBuild *) buildstate->gpu;
 
+	/* only the payload is kept: `value` lives in a context the caller resets after this row */
 	memcpy(gb->rows + gb->rowBytes * (Size) gb->count, ((Vector *) DatumGetPointer(value))->x, gb->rowBytes);
 	gb->tids[gb->count] = *tid;
-	gb->values[gb->count] = value;	/* stays allocated in the build's memory context until flushed */
 	if (++gb->count == PGV_ASSIGN_BATCH)
 		PgvIvfflatBuildFlush(buildstate);
 }

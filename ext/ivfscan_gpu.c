@@ -25,12 +25,14 @@ typedef struct PgvIvfScan
 	/* the window [winBase, winBase + winCount) of it that is on the host */
 	float		winDist[PGV_SCAN_REFILL];
 	int64		winSlot[PGV_SCAN_REFILL];
+	uint64		winTid[PGV_SCAN_REFILL];	/* heap TIDs come back with the results: no per-backend TID table */
 	int64		winBase;
 	int			winCount;
 	/* the whole batch on the host (deep pulls): distances, slots, sort permutation */
 	bool		whole;
 	float	   *dist;
 	int64	   *slot;
+	uint64	   *tid;
 	int64	   *order;
 	int64		capacity;
 }			PgvIvfScan;
@@ -53,8 +55,15 @@ PgvIvfflatBeginScan(Relation index, IvfflatScanOpaque so)
 	/* the fused path handles up to 256 lists per batch and 1024 ranked lists; beyond that stay on the CPU path */
 	if (!vector_gpu || so->probes > 256 || so->maxProbes > 1024)
 		return NULL;
-	gs = palloc0(sizeof(PgvIvfScan));
-	gs->mirror = PgvIvfflatGetMirror(index);
+	{
+		/* no current mirror (first use, stale after inserts, unsupported opclass): this scan runs on the CPU path */
+		PgvIvfMirror *mirror = PgvIvfflatGetMirror(index);
+
+		if (mirror == NULL)
+			return NULL;
+		gs = palloc0(sizeof(PgvIvfScan));
+		gs->mirror = mirror;
+	}
 	gs->so = so;
 	if (pgv_query_begin(gs->mirror->index, &gs->query) != PGV_OK)
 		ereport(ERROR, (errmsg("pgvector GPU path: %s", pgv_last_error())));
@@ -125,9 +134,13 @@ PgvFetchWholeBatch(PgvIvfScan * gs, const void *queryPayload)
 		gs->capacity = gs->count * 2;
 		gs->dist = gs->dist ? repalloc(gs->dist, sizeof(float) * (Size) gs->capacity) : palloc(sizeof(float) * (Size) gs->capacity);
 		gs->slot = gs->slot ? repalloc(gs->slot, sizeof(int64) * (Size) gs->capacity) : palloc(sizeof(int64) * (Size) gs->capacity);
+		gs->tid = gs->tid ? repalloc(gs->tid, sizeof(uint64) * (Size) gs->capacity) : palloc(sizeof(uint64) * (Size) gs->capacity);
 		gs->order = gs->order ? repalloc(gs->order, sizeof(int64) * (Size) gs->capacity * 2) : palloc(sizeof(int64) * (Size) gs->capacity * 2);
 	}
 	if (pgv_scan_lists(gs->mirror->index, queryPayload, lists, gs->batchLists, gs->dist, gs->slot, gs->capacity, &m) != PGV_OK)
+		ereport(ERROR, (errmsg("pgvector GPU path: %s", pgv_last_error())));
+	/* the batch's slots are one run per list: a handful of copies brings their heap TIDs */
+	if (pgv_index_tids(gs->mirror->index, gs->slot, m, gs->tid) != PGV_OK)
 		ereport(ERROR, (errmsg("pgvector GPU path: %s", pgv_last_error())));
 	for (int64 i = 0; i < m; i++)
 		gs->order[i] = i;
@@ -143,7 +156,7 @@ PgvGetScanItems(PgvIvfScan * gs)
 	int			n = Min(so->probes, so->maxProbes - so->listIndex);
 	int64		total;
 
-	if (pgv_query_scan(gs->query, so->listIndex, n, PGV_SCAN_HEAD, gs->winDist, gs->winSlot, NULL,
+	if (pgv_query_scan(gs->query, so->listIndex, n, PGV_SCAN_HEAD, gs->winDist, gs->winSlot, gs->winTid,
 					   &gs->winCount, &total) != PGV_OK)
 		ereport(ERROR, (errmsg("pgvector GPU path: %s", pgv_last_error())));
 	gs->batchFirst = so->listIndex;
@@ -161,7 +174,7 @@ PgvIvfflatGetTuple(IndexScanDesc scan)
 	IvfflatScanOpaque so = (IvfflatScanOpaque) scan->opaque;
 	PgvIvfScan *gs = (PgvIvfScan *) so->gpu;
 	const void *payload;
-	int64		slot;
+	uint64		tid;
 
 	if (scan->orderByData == NULL)
 		elog(ERROR, "cannot scan ivfflat index without order");
@@ -188,16 +201,19 @@ PgvIvfflatGetTuple(IndexScanDesc scan)
 	{
 		if (gs->next + PGV_SCAN_REFILL <= PGV_SCAN_DEVICE_DEPTH)
 		{
-			if (pgv_query_more(gs->query, (int) gs->next, PGV_SCAN_REFILL, gs->winDist, gs->winSlot, NULL, &gs->winCount) != PGV_OK)
+			if (pgv_query_more(gs->query, (int) gs->next, PGV_SCAN_REFILL, gs->winDist, gs->winSlot, gs->winTid, &gs->winCount) != PGV_OK)
 				ereport(ERROR, (errmsg("pgvector GPU path: %s", pgv_last_error())));
 			gs->winBase = gs->next;
 		}
 		else
 			PgvFetchWholeBatch(gs, payload);
 	}
-	slot = gs->whole ? gs->slot[gs->order[gs->next]] : gs->winSlot[gs->next - gs->winBase];
+	tid = gs->whole ? gs->tid[gs->order[gs->next]] : gs->winTid[gs->next - gs->winBase];
 	gs->next++;
-	scan->xs_heaptid = gs->mirror->tids[slot];
+	/* (block << 16) | offset, as staged by PgvStage */
+	scan->xs_heaptid.ip_blkid.bi_hi = (uint16) (tid >> 32);
+	scan->xs_heaptid.ip_blkid.bi_lo = (uint16) (tid >> 16);
+	scan->xs_heaptid.ip_posid = (OffsetNumber) (tid & 0xffff);
 	scan->xs_recheck = false;
 	scan->xs_recheckorderby = false;
 	return true;

@@ -1,36 +1,164 @@
 /*
- * pgv_context.c -- GUCs, the per-backend GPU context and the per-index device mirror.
- * Mirrors pgvector_amd/host/ivf_mirror.c + the stager of ivf_pages.c, over the buffer manager.
+ * pgv_context.c -- GUCs, the per-backend GPU context, and the device mirrors shared by every backend.
+ *
+ * A Postgres backend is a process (src/ivfscan.c:252-296 runs in each).  The device mirror of an index must not
+ * be uploaded per connection (6 GB and ~0.35 s for the headline index), and it must outlive the backend that
+ * first asked for it.  So mirrors are owned by a BACKGROUND WORKER per database ("pgvector gpu"): it stages the
+ * index through the buffer manager (the walks of src/ivfscan.c:58-111,139-179), uploads it with pgv_index_upload,
+ * and publishes the pgv_index_export handle in a registry in shared memory -- the DSM/shared-state pattern of the
+ * reference's parallel build (src/ivfbuild.c:830-966).  Backends map the SAME HBM with pgv_index_import and scan
+ * it on their own context; the index occupies HBM once however many backends there are.
+ *
+ * Staleness: ivfflatinsert / ivfflatbulkdelete / hnswinsert / hnswbulkdelete change pages without a relcache
+ * invalidation.  They call PgvNoteIndexChange (one atomic increment of the entry's generation); a scan that
+ * finds generation != stagedGeneration asks the worker to restage and meanwhile runs on the reference's CPU
+ * path (PgvIvfflatGetMirror returns NULL, the hook leaves so->gpu NULL) -- results are always those of the
+ * current pages, the GPU serves whenever its mirror is current.  The worker restages at most once per
+ * vector.gpu_restage_delay_ms, so an insert-heavy index does not restage per insert.
+ *
+ * Twin over the emulated page image: pgvector_amd/host/ivf_mirror.c + the stager of ivf_pages.c; the
+ * cross-process export/import is exercised by tests/test_gpu_round3.py with real processes.
  */
 #include "pgv_gpu.h"
 
+#include "access/genam.h"
+#include "access/xact.h"
 #include "miscadmin.h"
+#include "port/atomics.h"
+#include "postmaster/bgworker.h"
 #include "storage/bufmgr.h"
 #include "storage/ipc.h"
+#include "storage/latch.h"
+#include "storage/lwlock.h"
+#include "storage/shmem.h"
 #include "utils/guc.h"
 #include "utils/inval.h"
 #include "utils/memutils.h"
+#include "utils/timestamp.h"
 
 bool		vector_gpu = false;
 int			vector_gpu_device = 0;
+int			vector_gpu_stage_wait_ms = 0;
+int			vector_gpu_restage_delay_ms = 1000;
+
+#define PGV_MAX_MIRRORS 64
+
+typedef enum PgvMirrorState
+{
+	PGV_MIRROR_EMPTY = 0,
+	PGV_MIRROR_REQUESTED,		/* a backend wants it (re)staged */
+	PGV_MIRROR_STAGING,
+	PGV_MIRROR_READY,
+	PGV_MIRROR_FAILED			/* staging raised an error: stays on the CPU path until the next change */
+}			PgvMirrorState;
+
+/* one index's entry in the registry; everything but `generation` is guarded by PgvShared->lock */
+typedef struct PgvSharedMirror
+{
+	Oid			dboid;
+	Oid			relid;
+	int			state;
+	pg_atomic_uint64 generation;	/* bumped by PgvNoteIndexChange */
+	uint64		stagedGeneration;	/* value of `generation` the published mirror was staged at */
+	TimestampTz stagedAt;
+	pgv_index_handle handle;
+	int			lists;
+	int			dimensions;
+	int			dtype;
+	int			metric;
+	int64		ntuples;
+}			PgvSharedMirror;
+
+typedef struct PgvSharedState
+{
+	LWLock	   *lock;
+	Latch	   *workerLatch[PGV_MAX_MIRRORS];	/* per database: index = slot of the first entry of that database */
+	Oid			workerDb[PGV_MAX_MIRRORS];
+	PgvSharedMirror mirrors[PGV_MAX_MIRRORS];
+}			PgvSharedState;
+
+static PgvSharedState * PgvShared = NULL;
+static shmem_request_hook_type prev_shmem_request_hook = NULL;
+static shmem_startup_hook_type prev_shmem_startup_hook = NULL;
 
 static pgv_ctx *backend_ctx = NULL;
-static PgvIvfMirror *mirrors = NULL;
+static PgvIvfMirror *mirrors = NULL;	/* this backend's imported views */
+
+/* ------------------------------------------------------------------ shared memory */
 
 static void
-PgvAtExit(int code, Datum arg)
+PgvShmemRequest(void)
 {
-	(void) code;
-	(void) arg;
-	for (PgvIvfMirror * m = mirrors; m != NULL; m = m->next)
-		if (m->index)
-			pgv_index_free(m->index);
-	if (backend_ctx)
-		pgv_ctx_destroy(backend_ctx);
-	backend_ctx = NULL;
+	if (prev_shmem_request_hook)
+		prev_shmem_request_hook();
+	RequestAddinShmemSpace(sizeof(PgvSharedState));
+	RequestNamedLWLockTranche("pgvector_gpu", 1);
 }
 
-/* insert / vacuum / REINDEX change the pages: the next scan restages (src/ivfinsert.c, src/ivfvacuum.c) */
+static void
+PgvShmemStartup(void)
+{
+	bool		found;
+
+	if (prev_shmem_startup_hook)
+		prev_shmem_startup_hook();
+	LWLockAcquire(AddinShmemInitLock, LW_EXCLUSIVE);
+	PgvShared = ShmemInitStruct("pgvector gpu mirrors", sizeof(PgvSharedState), &found);
+	if (!found)
+	{
+		memset(PgvShared, 0, sizeof(PgvSharedState));
+		PgvShared->lock = &(GetNamedLWLockTranche("pgvector_gpu"))->lock;
+		for (int i = 0; i < PGV_MAX_MIRRORS; i++)
+			pg_atomic_init_u64(&PgvShared->mirrors[i].generation, 0);
+	}
+	LWLockRelease(AddinShmemInitLock);
+}
+
+/* the entry of (MyDatabaseId, relid), created on demand; NULL when the registry is full or not configured */
+static PgvSharedMirror *
+PgvFindEntry(Oid relid, bool create)
+{
+	PgvSharedMirror *free_entry = NULL;
+
+	if (PgvShared == NULL)
+		return NULL;
+	for (int i = 0; i < PGV_MAX_MIRRORS; i++)
+	{
+		PgvSharedMirror *e = &PgvShared->mirrors[i];
+
+		if (e->relid == relid && e->dboid == MyDatabaseId)
+			return e;
+		if (e->relid == 0 && free_entry == NULL)
+			free_entry = e;
+	}
+	if (create && free_entry)
+	{
+		free_entry->dboid = MyDatabaseId;
+		free_entry->relid = relid;
+		free_entry->state = PGV_MIRROR_EMPTY;
+		free_entry->stagedGeneration = 0;
+	}
+	return create ? free_entry : NULL;
+}
+
+/* ivfflatinsert (src/ivfinsert.c:72-181), ivfflatbulkdelete (src/ivfvacuum.c:18-143), hnswinsert, hnswbulkdelete and
+ * ambuild call this after changing pages: mirrors staged before now are stale */
+void
+PgvNoteIndexChange(Relation index)
+{
+	PgvSharedMirror *e;
+
+	if (PgvShared == NULL)
+		return;
+	LWLockAcquire(PgvShared->lock, LW_SHARED);
+	e = PgvFindEntry(RelationGetRelid(index), false);
+	if (e)
+		pg_atomic_fetch_add_u64(&e->generation, 1);
+	LWLockRelease(PgvShared->lock);
+}
+
+/* DROP INDEX / REINDEX reach every backend as a relcache invalidation: forget the local view (the worker drops its
+ * mirror when the entry is next requested or the relation is gone) */
 static void
 PgvRelcacheCallback(Datum arg, Oid relid)
 {
@@ -41,6 +169,19 @@ PgvRelcacheCallback(Datum arg, Oid relid)
 	PgvHnswInvalidate(relid);
 }
 
+static void
+PgvAtExit(int code, Datum arg)
+{
+	(void) code;
+	(void) arg;
+	for (PgvIvfMirror * m = mirrors; m != NULL; m = m->next)
+		if (m->index)
+			pgv_index_free(m->index);	/* unmaps the import; the worker's allocation stays */
+	if (backend_ctx)
+		pgv_ctx_destroy(backend_ctx);
+	backend_ctx = NULL;
+}
+
 void
 PgvGpuInit(void)
 {
@@ -48,8 +189,21 @@ PgvGpuInit(void)
 							 &vector_gpu, false, PGC_USERSET, 0, NULL, NULL, NULL);
 	DefineCustomIntVariable("vector.gpu_device", "HIP device of this backend", NULL,
 							&vector_gpu_device, 0, 0, 63, PGC_USERSET, 0, NULL, NULL, NULL);
+	DefineCustomIntVariable("vector.gpu_stage_wait_ms", "How long a scan waits for the GPU worker to stage a mirror before it runs on the CPU", NULL,
+							&vector_gpu_stage_wait_ms, 0, 0, 600000, PGC_USERSET, 0, NULL, NULL, NULL);
+	DefineCustomIntVariable("vector.gpu_restage_delay_ms", "Minimum time between two stagings of one index", NULL,
+							&vector_gpu_restage_delay_ms, 1000, 0, 3600000, PGC_USERSET, 0, NULL, NULL, NULL);
 	CacheRegisterRelcacheCallback(PgvRelcacheCallback, (Datum) 0);
 	on_proc_exit(PgvAtExit, (Datum) 0);
+	/* the registry needs shared memory: effective when the library is in shared_preload_libraries; otherwise
+	 * PgvShared stays NULL and every scan stays on the CPU path */
+	if (process_shared_preload_libraries_in_progress)
+	{
+		prev_shmem_request_hook = shmem_request_hook;
+		shmem_request_hook = PgvShmemRequest;
+		prev_shmem_startup_hook = shmem_startup_hook;
+		shmem_startup_hook = PgvShmemStartup;
+	}
 }
 
 pgv_ctx *
@@ -60,37 +214,59 @@ PgvGetContext(void)
 	return backend_ctx;
 }
 
-void
+/*
+ * Which kernel family serves this opclass, or false when none does.  The element type is identified EXACTLY:
+ * vector reports IVFFLAT_MAX_DIM, halfvec twice that (src/ivfutils.c:382-404); the bit opclass reports 32 x and
+ * (for hnsw) sparsevec SPARSEVEC_MAX_DIM -- their index tuples are not dense float rows and stay on the CPU path.
+ */
+bool
 PgvIvfflatOpclass(Relation index, pgv_metric * metric, pgv_dtype * dtype, pgv_ops * ops)
 {
+	int			maxDimensions = IvfflatGetTypeInfo(index)->maxDimensions;
 	bool		spherical = IvfflatOptionalProcInfo(index, IVFFLAT_KMEANS_NORM_PROC) != NULL;
 	bool		normalized = IvfflatOptionalProcInfo(index, IVFFLAT_NORM_PROC) != NULL;
 
-	/* vector: 2000 dimensions, halfvec: 4000 (src/ivfflat.h:37, src/ivfutils.c:401) */
-	*dtype = IvfflatGetTypeInfo(index)->maxDimensions > 2000 ? PGV_F16 : PGV_F32;
+	if (maxDimensions == IVFFLAT_MAX_DIM)
+		*dtype = PGV_F32;
+	else if (maxDimensions == IVFFLAT_MAX_DIM * 2)
+		*dtype = PGV_F16;
+	else
+		return false;			/* bit_hamming_ops, or a type added later */
 	*metric = spherical ? PGV_NEG_IP : PGV_L2SQ;
 	*ops = normalized ? PGV_OPS_COSINE : (spherical ? PGV_OPS_IP : PGV_OPS_L2);
+	return true;
 }
+
+/* ------------------------------------------------------------------ the worker's side */
+
+typedef struct PgvOwned
+{
+	Oid			relid;
+	pgv_index  *index;
+}			PgvOwned;
+
+static PgvOwned owned[PGV_MAX_MIRRORS];
 
 /*
  * Stage the index out of its pages: the walks of GetScanLists (src/ivfscan.c:58-111) and GetScanItems
  * (:139-179), once per mirror instead of once per query.  Centers, list-major vectors, list offsets and
- * heap TIDs go to the device with pgv_index_upload.
+ * heap TIDs go to the device with pgv_index_upload (TIDs stay on the device: scans get them back with their
+ * results, so no backend keeps a TID table).
  */
-static void
-PgvStage(Relation index, PgvIvfMirror * m)
+static pgv_index *
+PgvStage(Relation index, pgv_metric metric, pgv_dtype dtype, int lists, int dimensions, int64 *ntuples)
 {
-	Size		esize = m->dtype == PGV_F32 ? sizeof(float) : sizeof(uint16);
-	Size		rowBytes = esize * (Size) m->dimensions;
-	char	   *centers = palloc(rowBytes * (Size) m->lists);
-	BlockNumber *startPages = palloc(sizeof(BlockNumber) * (Size) m->lists);
-	int64	   *offsets = palloc(sizeof(int64) * ((Size) m->lists + 1));
+	Size		esize = dtype == PGV_F32 ? sizeof(float) : sizeof(uint16);
+	Size		rowBytes = esize * (Size) dimensions;
+	char	   *centers = palloc(rowBytes * (Size) lists);
+	BlockNumber *startPages = palloc(sizeof(BlockNumber) * (Size) lists);
+	int64	   *offsets = palloc(sizeof(int64) * ((Size) lists + 1));
 	int64		cap = 1024,
 				n = 0;
-	char	   *vectors = palloc(rowBytes * (Size) cap);
-	ItemPointerData *tids = MemoryContextAlloc(TopMemoryContext, sizeof(ItemPointerData) * (Size) cap);
-	uint64	   *tids64;
+	char	   *vectors = palloc_extended(rowBytes * (Size) cap, MCXT_ALLOC_HUGE);
+	uint64	   *tids = palloc_extended(sizeof(uint64) * (Size) cap, MCXT_ALLOC_HUGE);
 	BlockNumber nextblkno = IVFFLAT_HEAD_BLKNO;
+	pgv_index  *result = NULL;
 	int			l = 0;
 
 	/* list pages */
@@ -103,7 +279,7 @@ PgvStage(Relation index, PgvIvfMirror * m)
 		LockBuffer(buf, BUFFER_LOCK_SHARE);
 		page = BufferGetPage(buf);
 		maxoffno = PageGetMaxOffsetNumber(page);
-		for (OffsetNumber offno = FirstOffsetNumber; offno <= maxoffno && l < m->lists; offno = OffsetNumberNext(offno))
+		for (OffsetNumber offno = FirstOffsetNumber; offno <= maxoffno && l < lists; offno = OffsetNumberNext(offno))
 		{
 			IvfflatList list = (IvfflatList) PageGetItem(page, PageGetItemId(page, offno));
 
@@ -114,11 +290,11 @@ PgvStage(Relation index, PgvIvfMirror * m)
 		nextblkno = IvfflatPageGetOpaque(page)->nextblkno;
 		UnlockReleaseBuffer(buf);
 	}
-	if (l != m->lists)
+	if (l != lists)
 		elog(ERROR, "ivfflat index is not valid");
 
 	/* entry pages of every list, in page-chain order: the order the reference feeds its tuplesort */
-	for (l = 0; l < m->lists; l++)
+	for (l = 0; l < lists; l++)
 	{
 		offsets[l] = n;
 		nextblkno = startPages[l];
@@ -135,8 +311,8 @@ PgvStage(Relation index, PgvIvfMirror * m)
 			if (n + maxoffno > cap)
 			{
 				cap = (n + maxoffno) * 2;
-				vectors = repalloc(vectors, rowBytes * (Size) cap);
-				tids = repalloc(tids, sizeof(ItemPointerData) * (Size) cap);
+				vectors = repalloc_huge(vectors, rowBytes * (Size) cap);
+				tids = repalloc_huge(tids, sizeof(uint64) * (Size) cap);
 			}
 			for (OffsetNumber offno = FirstOffsetNumber; offno <= maxoffno; offno = OffsetNumberNext(offno))
 			{
@@ -147,37 +323,247 @@ PgvStage(Relation index, PgvIvfMirror * m)
 
 				/* Vector and HalfVector share the header; the payload starts at ->x */
 				memcpy(vectors + rowBytes * (Size) n, vec->x, rowBytes);
-				tids[n] = itup->t_tid;
+				/* ItemPointerData widened to 64 bits: (block << 16) | offset, what the library hands back */
+				tids[n] = ((uint64) (((uint32) itup->t_tid.ip_blkid.bi_hi << 16) | itup->t_tid.ip_blkid.bi_lo) << 16) | itup->t_tid.ip_posid;
+				if ((Pointer) vec != DatumGetPointer(datum))
+					pfree(vec);
 				n++;
 			}
 			nextblkno = IvfflatPageGetOpaque(page)->nextblkno;
 			UnlockReleaseBuffer(buf);
 		}
 	}
-	offsets[m->lists] = n;
-
-	/* ItemPointerData widened to 64 bits: (block << 16) | offset, what the library hands back */
-	tids64 = palloc(sizeof(uint64) * (Size) Max(n, 1));
-	for (int64 i = 0; i < n; i++)
-		tids64[i] = ((uint64) (((uint32) tids[i].ip_blkid.bi_hi << 16) | tids[i].ip_blkid.bi_lo) << 16) | tids[i].ip_posid;
-	if (pgv_index_upload(PgvGetContext(), m->metric, m->dtype, m->dimensions, m->lists, centers, offsets,
-						 vectors, tids64, &m->index) != PGV_OK)
+	offsets[lists] = n;
+	if (pgv_index_upload(PgvGetContext(), metric, dtype, dimensions, lists, centers, offsets, vectors, tids, &result) != PGV_OK)
 		ereport(ERROR, (errmsg("pgvector GPU path: %s", pgv_last_error())));
-	m->tids = tids;
-	m->ntuples = n;
-	m->valid = true;
-	pfree(tids64);
+	*ntuples = n;
+	pfree(tids);
 	pfree(vectors);
 	pfree(offsets);
 	pfree(startPages);
 	pfree(centers);
+	return result;
 }
 
+/* stage one requested entry inside a transaction of the worker; publishes READY or FAILED */
+static void
+PgvWorkerStageEntry(PgvSharedMirror * e)
+{
+	Oid			relid = e->relid;
+	uint64		generation = pg_atomic_read_u64(&e->generation);
+	volatile bool ok = false;
+	pgv_index  *volatile fresh = NULL;
+	pgv_index_handle handle;
+	int			lists = 0,
+				dimensions = 0;
+	int64		ntuples = 0;
+	pgv_metric	metric = PGV_L2SQ;
+	pgv_dtype	dtype = PGV_F32;
+	pgv_ops		ops;
+
+	StartTransactionCommand();
+	PG_TRY();
+	{
+		Relation	index = try_index_open(relid, AccessShareLock);
+
+		if (index != NULL)
+		{
+			if (PgvIvfflatOpclass(index, &metric, &dtype, &ops))
+			{
+				IvfflatGetMetaPageInfo(index, &lists, &dimensions);
+				fresh = PgvStage(index, metric, dtype, lists, dimensions, &ntuples);
+				if (pgv_index_export(fresh, &handle) != PGV_OK)
+					ereport(ERROR, (errmsg("pgvector GPU path: %s", pgv_last_error())));
+				ok = true;
+			}
+			index_close(index, AccessShareLock);
+		}
+		CommitTransactionCommand();
+	}
+	PG_CATCH();
+	{
+		/* a failed staging must not take the worker down: log, leave the index on the CPU path */
+		EmitErrorReport();
+		FlushErrorState();
+		AbortCurrentTransaction();
+		if (fresh)
+			pgv_index_free(fresh);
+		fresh = NULL;
+		ok = false;
+	}
+	PG_END_TRY();
+
+	LWLockAcquire(PgvShared->lock, LW_EXCLUSIVE);
+	if (ok)
+	{
+		e->handle = handle;
+		e->lists = lists;
+		e->dimensions = dimensions;
+		e->dtype = dtype;
+		e->metric = metric;
+		e->ntuples = ntuples;
+		e->stagedGeneration = generation;
+		e->stagedAt = GetCurrentTimestamp();
+		e->state = PGV_MIRROR_READY;
+	}
+	else
+		e->state = PGV_MIRROR_FAILED;
+	LWLockRelease(PgvShared->lock);
+
+	/* the previous mirror of this index goes once the new handle is out: backends holding an import of it keep
+	 * their mapping (the driver keeps the memory until the last mapping closes) and re-import at their next scan */
+	for (int i = 0; i < PGV_MAX_MIRRORS; i++)
+		if (owned[i].relid == relid || (ok && owned[i].relid == 0))
+		{
+			if (owned[i].relid == relid && owned[i].index)
+				pgv_index_free(owned[i].index);
+			owned[i].relid = ok ? relid : 0;
+			owned[i].index = ok ? fresh : NULL;
+			break;
+		}
+}
+
+/* bgw_main of the per-database worker; bgw_main_arg = the database's oid */
+void
+PgvWorkerMain(Datum main_arg)
+{
+	Oid			dboid = DatumGetObjectId(main_arg);
+	int			slot = -1;
+
+	BackgroundWorkerUnblockSignals();
+	BackgroundWorkerInitializeConnectionByOid(dboid, InvalidOid, 0);
+	LWLockAcquire(PgvShared->lock, LW_EXCLUSIVE);
+	for (int i = 0; i < PGV_MAX_MIRRORS && slot < 0; i++)
+		if (PgvShared->workerDb[i] == dboid || PgvShared->workerDb[i] == 0)
+			slot = i;
+	if (slot >= 0)
+	{
+		PgvShared->workerDb[slot] = dboid;
+		PgvShared->workerLatch[slot] = MyLatch;
+	}
+	LWLockRelease(PgvShared->lock);
+	if (slot < 0)
+		proc_exit(0);
+
+	for (;;)
+	{
+		PgvSharedMirror *todo = NULL;
+
+		CHECK_FOR_INTERRUPTS();
+		LWLockAcquire(PgvShared->lock, LW_EXCLUSIVE);
+		for (int i = 0; i < PGV_MAX_MIRRORS && todo == NULL; i++)
+		{
+			PgvSharedMirror *e = &PgvShared->mirrors[i];
+
+			if (e->dboid == dboid && e->state == PGV_MIRROR_REQUESTED &&
+				(e->stagedAt == 0 ||
+				 TimestampDifferenceExceeds(e->stagedAt, GetCurrentTimestamp(), vector_gpu_restage_delay_ms)))
+			{
+				e->state = PGV_MIRROR_STAGING;
+				todo = e;
+			}
+		}
+		LWLockRelease(PgvShared->lock);
+		if (todo)
+		{
+			PgvWorkerStageEntry(todo);
+			continue;
+		}
+		(void) WaitLatch(MyLatch, WL_LATCH_SET | WL_TIMEOUT | WL_EXIT_ON_PM_DEATH, 200L, PG_WAIT_EXTENSION);
+		ResetLatch(MyLatch);
+	}
+}
+
+/* start the worker of this database unless one is registered already */
+static void
+PgvEnsureWorker(void)
+{
+	BackgroundWorker worker;
+	BackgroundWorkerHandle *handle;
+	bool		running = false;
+
+	LWLockAcquire(PgvShared->lock, LW_SHARED);
+	for (int i = 0; i < PGV_MAX_MIRRORS; i++)
+		if (PgvShared->workerDb[i] == MyDatabaseId && PgvShared->workerLatch[i] != NULL)
+		{
+			SetLatch(PgvShared->workerLatch[i]);
+			running = true;
+		}
+	LWLockRelease(PgvShared->lock);
+	if (running)
+		return;
+	memset(&worker, 0, sizeof(worker));
+	worker.bgw_flags = BGWORKER_SHMEM_ACCESS | BGWORKER_BACKEND_DATABASE_CONNECTION;
+	worker.bgw_start_time = BgWorkerStart_RecoveryFinished;
+	worker.bgw_restart_time = BGW_NEVER_RESTART;
+	snprintf(worker.bgw_library_name, sizeof(worker.bgw_library_name), "vector");
+	snprintf(worker.bgw_function_name, sizeof(worker.bgw_function_name), "PgvWorkerMain");
+	snprintf(worker.bgw_name, sizeof(worker.bgw_name), "pgvector gpu");
+	snprintf(worker.bgw_type, sizeof(worker.bgw_type), "pgvector gpu");
+	worker.bgw_main_arg = ObjectIdGetDatum(MyDatabaseId);
+	worker.bgw_notify_pid = 0;
+	(void) RegisterDynamicBackgroundWorker(&worker, &handle);
+}
+
+/* ------------------------------------------------------------------ the backend's side */
+
+/*
+ * The current mirror of an index as this backend sees it: an import of the worker's export, cached until the
+ * registry shows a newer staging.  NULL = not available now (not staged yet, stale, unsupported opclass, no shared
+ * memory): the scan stays on the reference's CPU path and a (re)staging has been requested.
+ */
 PgvIvfMirror *
 PgvIvfflatGetMirror(Relation index)
 {
 	PgvIvfMirror *m;
+	PgvSharedMirror *e;
+	pgv_index_handle handle;
+	uint64		staged = 0;
+	bool		ready = false;
+	pgv_metric	metric;
+	pgv_dtype	dtype;
 	pgv_ops		ops;
+	TimestampTz waitUntil = TimestampTzPlusMilliseconds(GetCurrentTimestamp(), vector_gpu_stage_wait_ms);
+
+	if (PgvShared == NULL || !PgvIvfflatOpclass(index, &metric, &dtype, &ops))
+		return NULL;
+	for (;;)
+	{
+		bool		request = false;
+
+		LWLockAcquire(PgvShared->lock, LW_EXCLUSIVE);
+		e = PgvFindEntry(RelationGetRelid(index), true);
+		if (e != NULL)
+		{
+			uint64		generation = pg_atomic_read_u64(&e->generation);
+
+			if (e->state == PGV_MIRROR_READY && e->stagedGeneration == generation)
+			{
+				handle = e->handle;
+				staged = e->stagedGeneration + 1;	/* 0 = none */
+				ready = true;
+			}
+			else if (e->state == PGV_MIRROR_EMPTY || e->state == PGV_MIRROR_READY ||
+					 (e->state == PGV_MIRROR_FAILED && e->stagedGeneration != generation))
+			{
+				e->state = PGV_MIRROR_REQUESTED;
+				request = true;
+			}
+			else if (e->state == PGV_MIRROR_REQUESTED)
+				request = true;
+		}
+		LWLockRelease(PgvShared->lock);
+		if (ready || e == NULL)
+			break;
+		if (request)
+			PgvEnsureWorker();
+		if (GetCurrentTimestamp() >= waitUntil)
+			break;
+		CHECK_FOR_INTERRUPTS();
+		pg_usleep(1000L);
+	}
+	if (!ready)
+		return NULL;
 
 	for (m = mirrors; m != NULL; m = m->next)
 		if (m->relid == RelationGetRelid(index))
@@ -189,17 +575,20 @@ PgvIvfflatGetMirror(Relation index)
 		m->next = mirrors;
 		mirrors = m;
 	}
-	if (!m->valid)
+	if (!m->valid || m->staged != staged)
 	{
 		if (m->index)
 			pgv_index_free(m->index);
-		if (m->tids)
-			pfree(m->tids);
 		m->index = NULL;
-		m->tids = NULL;
+		m->valid = false;
+		if (pgv_index_import(PgvGetContext(), &handle, &m->index) != PGV_OK)
+			ereport(ERROR, (errmsg("pgvector GPU path: %s", pgv_last_error())));
 		IvfflatGetMetaPageInfo(index, &m->lists, &m->dimensions);
-		PgvIvfflatOpclass(index, &m->metric, &m->dtype, &ops);
-		PgvStage(index, m);
+		m->metric = metric;
+		m->dtype = dtype;
+		m->ntuples = pgv_index_rows(m->index);
+		m->staged = staged;
+		m->valid = true;
 	}
 	return m;
 }

@@ -8,7 +8,7 @@
  * their twins over the emulated page image (pgvector_amd/host/, tests/).
  *
  * Hook points in the reference (one line each; the reference code stays as the `vector.gpu = off` path):
- *   _PG_init            src/vector.c:57-65      PgvGpuInit();
+ *   _PG_init            src/vector.c:57-65      PgvGpuInit();   (shared_preload_libraries = 'vector' for the mirror registry)
  *   ivfflatbeginscan    src/ivfscan.c:252-317   so->gpu = PgvIvfflatBeginScan(index, so);
  *   ivfflatrescan       src/ivfscan.c:322-356   PgvIvfflatRescan(so->gpu);
  *   ivfflatgettuple     src/ivfscan.c:361-414   if (so->gpu) return PgvIvfflatGetTuple(scan);
@@ -18,6 +18,12 @@
  *   IvfflatKmeans       src/ivfkmeans.c:553-570 if (PgvIvfflatKmeans(index, samples, centers, typeInfo)) return;
  *   BuildCallback       src/ivfbuild.c:224-266  if (buildstate->gpu) { PgvIvfflatBuildAdd(buildstate, tid, value); return; }
  *   AssignTuples        src/ivfbuild.c:600-636  PgvIvfflatBuildFlush(buildstate) after the heap scan
+ *   ivfflatinsert       src/ivfinsert.c:186-205 PgvNoteIndexChange(index);   after InsertTuple
+ *   ivfflatbulkdelete   src/ivfvacuum.c:18-143  PgvNoteIndexChange(index);   when tuples were removed
+ *   ivfflatbuild        src/ivfbuild.c:1063     PgvNoteIndexChange(index);   a rebuilt index is a new image
+ *   hnswinsert / hnswbulkdelete / hnswbuild     PgvNoteIndexChange(index);   likewise
+ * Page changes do not send relcache invalidations; PgvNoteIndexChange bumps the index's generation in the shared
+ * registry (one atomic add), scans compare it with the generation their mirror was staged at (pgv_context.c).
  */
 #ifndef PGV_GPU_H
 #define PGV_GPU_H
@@ -36,25 +42,31 @@ extern int	vector_gpu_device;	/* GUC vector.gpu_device */
 void		PgvGpuInit(void);
 pgv_ctx    *PgvGetContext(void);
 
-/* FUNCTION 1 / element type of an ivfflat opclass (sql/vector.sql:406-425, :819-841) */
-void		PgvIvfflatOpclass(Relation index, pgv_metric * metric, pgv_dtype * dtype, pgv_ops * ops);
+/* FUNCTION 1 / element type of an ivfflat opclass (sql/vector.sql:406-425, :819-841); false for opclasses whose
+ * index tuples are not dense float rows (bit_hamming_ops): they stay on the CPU path */
+bool		PgvIvfflatOpclass(Relation index, pgv_metric * metric, pgv_dtype * dtype, pgv_ops * ops);
 
-/* device mirror of one index, cached per backend and dropped by the relcache callback */
+/* this backend's view of an index's device mirror: an import of what the GPU worker staged and exported */
 typedef struct PgvIvfMirror
 {
 	Oid			relid;
 	bool		valid;
+	uint64		staged;			/* the staging (registry generation + 1) this import belongs to */
 	pgv_index  *index;
 	int			lists;
 	int			dimensions;
 	pgv_dtype	dtype;
 	pgv_metric	metric;
 	int64		ntuples;
-	ItemPointerData *tids;		/* heap TID of every row slot */
 	struct PgvIvfMirror *next;
 }			PgvIvfMirror;
 
+/* NULL: no current mirror (being staged, stale, unsupported opclass) -- the scan stays on the CPU path */
 PgvIvfMirror *PgvIvfflatGetMirror(Relation index);
+/* insert / vacuum / build changed the index's pages: mirrors staged before now are stale */
+void		PgvNoteIndexChange(Relation index);
+/* bgw_main of the per-database worker that owns the mirrors */
+void		PgvWorkerMain(Datum main_arg);
 
 /* scan side (ivfscan_gpu.c) */
 void	   *PgvIvfflatBeginScan(Relation index, IvfflatScanOpaque so);
@@ -66,6 +78,8 @@ void		PgvIvfflatEndScan(void *gpu);
 void	   *PgvHnswBeginScan(Relation index);
 List	   *PgvHnswGetScanItems(IndexScanDesc scan, Datum value);
 void		PgvHnswInvalidate(Oid relid);
+/* vector / halfvec element type of an hnsw opclass; false for bit and sparsevec opclasses (CPU path) */
+bool		PgvHnswElementType(Relation index, pgv_dtype * dtype);
 /* FUNCTION 1 of an hnsw opclass that has no FUNCTION 2: L2 or inner product (by the support function's oid) */
 pgv_metric	PgvHnswMetricOf(Relation index);
 

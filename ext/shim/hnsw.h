@@ -8,6 +8,7 @@
 #include "pgshim.h"
 #include "ivfflat.h"			/* Vector */
 
+#define HNSW_MAX_DIM 2000
 #define HNSW_METAPAGE_BLKNO 0
 #define HNSW_HEAD_BLKNO 1
 #define HNSW_ELEMENT_TUPLE_TYPE 1

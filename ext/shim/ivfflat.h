@@ -7,6 +7,7 @@
 #define EXT_SHIM_IVFFLAT_H
 #include "pgshim.h"
 
+#define IVFFLAT_MAX_DIM 2000
 #define IVFFLAT_HEAD_BLKNO 1
 #define IVFFLAT_DISTANCE_PROC 1
 #define IVFFLAT_NORM_PROC 2

@@ -192,4 +192,121 @@ typedef struct FmgrInfo
 }			FmgrInfo;
 FmgrInfo   *index_getprocinfo(Relation irel, int attnum, uint16 procnum);
 
+/* ---- declarations the cross-process mirror registry touches (pgv_context.c) ---- */
+#include <stdio.h>
+
+/* postgres.h, postgres_ext.h */
+#define InvalidOid ((Oid) 0)
+#define ObjectIdGetDatum(x) ((Datum) (x))
+#define DatumGetObjectId(x) ((Oid) (x))
+
+/* utils/elog.h */
+#define PG_TRY() if (pgshim_try()) {
+#define PG_CATCH() } else {
+#define PG_END_TRY() }
+int			pgshim_try(void);
+void		EmitErrorReport(void);
+void		FlushErrorState(void);
+
+/* utils/palloc.h */
+#define MCXT_ALLOC_HUGE 0x01
+void	   *palloc_extended(Size size, int flags);
+void	   *repalloc_huge(void *pointer, Size size);
+
+/* miscadmin.h, storage/ipc.h */
+extern Oid	MyDatabaseId;
+extern bool process_shared_preload_libraries_in_progress;
+typedef void (*shmem_request_hook_type) (void);
+typedef void (*shmem_startup_hook_type) (void);
+extern shmem_request_hook_type shmem_request_hook;
+extern shmem_startup_hook_type shmem_startup_hook;
+void		proc_exit(int code) __attribute__((noreturn));
+void		pg_usleep(long microsec);
+
+/* storage/shmem.h, storage/lwlock.h */
+typedef struct LWLock
+{
+	uint16		tranche;
+}			LWLock;
+typedef union LWLockPadded
+{
+	LWLock		lock;
+	char		pad[128];
+}			LWLockPadded;
+typedef enum LWLockMode
+{
+	LW_EXCLUSIVE,
+	LW_SHARED
+}			LWLockMode;
+extern LWLock *AddinShmemInitLock;
+bool		LWLockAcquire(LWLock *lock, LWLockMode mode);
+void		LWLockRelease(LWLock *lock);
+void		RequestAddinShmemSpace(Size size);
+void		RequestNamedLWLockTranche(const char *tranche_name, int num_lwlocks);
+LWLockPadded *GetNamedLWLockTranche(const char *tranche_name);
+void	   *ShmemInitStruct(const char *name, Size size, bool *foundPtr);
+
+/* port/atomics.h */
+typedef struct pg_atomic_uint64
+{
+	volatile uint64 value;
+}			pg_atomic_uint64;
+void		pg_atomic_init_u64(volatile pg_atomic_uint64 *ptr, uint64 val);
+uint64		pg_atomic_read_u64(volatile pg_atomic_uint64 *ptr);
+uint64		pg_atomic_fetch_add_u64(volatile pg_atomic_uint64 *ptr, int64 add_);
+
+/* storage/latch.h, utils/wait_event.h */
+typedef struct Latch Latch;
+extern Latch *MyLatch;
+#define WL_LATCH_SET (1 << 0)
+#define WL_TIMEOUT (1 << 3)
+#define WL_EXIT_ON_PM_DEATH (1 << 5)
+#define PG_WAIT_EXTENSION 0x07000000U
+int			WaitLatch(Latch *latch, int wakeEvents, long timeout, uint32 wait_event_info);
+void		SetLatch(Latch *latch);
+void		ResetLatch(Latch *latch);
+
+/* utils/timestamp.h, datatype/timestamp.h */
+typedef int64 TimestampTz;
+TimestampTz GetCurrentTimestamp(void);
+bool		TimestampDifferenceExceeds(TimestampTz start_time, TimestampTz stop_time, int msec);
+#define TimestampTzPlusMilliseconds(tz, ms) ((tz) + ((ms) * (int64) 1000))
+
+/* access/xact.h, access/genam.h, storage/lockdefs.h */
+typedef int LOCKMODE;
+#define AccessShareLock 1
+void		StartTransactionCommand(void);
+void		CommitTransactionCommand(void);
+void		AbortCurrentTransaction(void);
+Relation	try_index_open(Oid relationId, LOCKMODE lockmode);
+void		index_close(Relation relation, LOCKMODE lockmode);
+
+/* postmaster/bgworker.h */
+#define BGWORKER_SHMEM_ACCESS 0x0001
+#define BGWORKER_BACKEND_DATABASE_CONNECTION 0x0002
+#define BGW_NEVER_RESTART -1
+#define BGW_MAXLEN 96
+typedef enum
+{
+	BgWorkerStart_PostmasterStart,
+	BgWorkerStart_ConsistentState,
+	BgWorkerStart_RecoveryFinished
+}			BgWorkerStartTime;
+typedef struct BackgroundWorker
+{
+	char		bgw_name[BGW_MAXLEN];
+	char		bgw_type[BGW_MAXLEN];
+	int			bgw_flags;
+	BgWorkerStartTime bgw_start_time;
+	int			bgw_restart_time;
+	char		bgw_library_name[BGW_MAXLEN];
+	char		bgw_function_name[BGW_MAXLEN];
+	Datum		bgw_main_arg;
+	int			bgw_notify_pid;
+}			BackgroundWorker;
+typedef struct BackgroundWorkerHandle BackgroundWorkerHandle;
+bool		RegisterDynamicBackgroundWorker(BackgroundWorker *worker, BackgroundWorkerHandle **handle);
+void		BackgroundWorkerUnblockSignals(void);
+void		BackgroundWorkerInitializeConnectionByOid(Oid dboid, Oid useroid, uint32 flags);
+
 #endif							/* PGSHIM_H */

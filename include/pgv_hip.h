@@ -234,6 +234,11 @@ typedef struct pgv_index_handle
 }			pgv_index_handle;
 int			pgv_index_export(pgv_index * index, pgv_index_handle * out);
 int			pgv_index_import(pgv_ctx * ctx, const pgv_index_handle * handle, pgv_index * *out);
+/*
+ * Heap TIDs of row slots (what pgv_scan_lists hands back), for a caller that keeps no TID table of its own -- a
+ * backend that imported the mirror.  slots / out are host arrays; runs of consecutive slots (a list) are one copy.
+ */
+int			pgv_index_tids(pgv_index * index, const int64_t *slots, int64_t n, uint64_t *out);
 int64_t		pgv_index_rows(const pgv_index * index);
 int			pgv_index_lists(const pgv_index * index);
 
@@ -471,6 +476,16 @@ int			pgv_bit_distance_batch(pgv_ctx * ctx, pgv_bit_metric metric, int nbits,
 int			pgv_hnsw_upload(pgv_ctx * ctx, pgv_metric metric, pgv_dtype dtype, int dim,
 							const void *elements, int64_t n, pgv_hnsw * *out);
 void		pgv_hnsw_free(pgv_hnsw * h);
+
+/*
+ * The HNSW mirror across processes, like pgv_index_export / pgv_index_import: the element vectors and the graph
+ * (set with pgv_hnsw_set_graph) stay in the exporting process's HBM, importers map them read-only and search on
+ * their own context (stream, visited bitmaps).  Graph patches by the owner (pgv_hnsw_update_graph) are seen by the
+ * importers; the entry point travels inside the handle, so a new entry point -- like a pgv_hnsw_set_graph by the owner,
+ * which reallocates the graph -- needs a new export.
+ */
+int			pgv_hnsw_export(pgv_hnsw * h, pgv_index_handle * out);
+int			pgv_hnsw_import(pgv_ctx * ctx, const pgv_index_handle * handle, pgv_hnsw * *out);
 
 /*
  * The candidate-scoring loop of HnswSearchLayer (src/hnswutils.c:908-934,

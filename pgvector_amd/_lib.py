@@ -42,6 +42,7 @@ SYMBOLS = [
     "pgv_comm_unique_id", "pgv_comm_create", "pgv_comm_create_custom", "pgv_comm_destroy", "pgv_comm_size",
     "pgv_comm_rank", "pgv_kmeans_sharded", "pgv_search_batch_sharded",
     "pgv_device_memory", "pgv_pinned_register", "pgv_pinned_unregister", "pgv_index_export", "pgv_index_import",
+    "pgv_index_tids", "pgv_hnsw_export", "pgv_hnsw_import",
 ]
 
 
@@ -105,6 +106,9 @@ def _load():
     lib.pgv_index_free.restype = None
     lib.pgv_index_export.argtypes = [P, P]
     lib.pgv_index_import.argtypes = [P, P, C.POINTER(P)]
+    lib.pgv_index_tids.argtypes = [P, P, I64, P]
+    lib.pgv_hnsw_export.argtypes = [P, P]
+    lib.pgv_hnsw_import.argtypes = [P, P, C.POINTER(P)]
     lib.pgv_device_memory.argtypes = [I, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
     lib.pgv_pinned_register.argtypes = [P, C.c_size_t]
     lib.pgv_pinned_unregister.argtypes = [P]

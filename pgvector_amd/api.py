@@ -190,6 +190,13 @@ class IvfIndex:
     def rows(self):
         return lib.pgv_index_rows(self.h)
 
+    def tids(self, slots):
+        """pgv_index_tids: heap TIDs of row slots, for a caller without a TID table (a backend that imported)"""
+        slots = np.ascontiguousarray(slots, dtype=np.int64)
+        out = np.empty(slots.shape, dtype=np.uint64)
+        check(lib.pgv_index_tids(self.h, ptr(slots), int(slots.size), ptr(out)))
+        return out
+
     def rank_lists(self, queries, maxprobes, want_dist=True):
         queries = as_dtype(queries, self.dtype)
         nq = int(queries.shape[0])
@@ -510,6 +517,23 @@ class Hnsw:
             self.close()
         except Exception:
             pass
+
+    def export(self):
+        """pgv_hnsw_export: the handle another PROCESS imports (pgv_hnsw_import) to search this mirror"""
+        buf = C.create_string_buffer(256)
+        check(lib.pgv_hnsw_export(self.h, buf))
+        return bytes(buf.raw)
+
+    @classmethod
+    def from_handle(cls, ctx, handle, dtype):
+        """pgv_hnsw_import: map the elements and the graph another process exported (no copy, read-only)"""
+        v = cls.__new__(cls)
+        h = C.c_void_p()
+        buf = C.create_string_buffer(bytes(handle), 256)
+        check(lib.pgv_hnsw_import(ctx.h, buf, C.byref(h)))
+        v.ctx, v.metric, v.dtype, v.dim, v.h = ctx, None, dtype, None, h
+        ctx._adopt(v)
+        return v
 
     def set_graph(self, m, entry, levels, nbr_start, nbr):
         """the graph a scan walks (pgv_hnsw_set_graph): per element slot its level and neighbor tuple"""

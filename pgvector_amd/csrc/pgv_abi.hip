@@ -883,6 +883,26 @@ void pgv_index_free(pgv_index *ix) {
     delete ix;
 }
 
+int pgv_index_tids(pgv_index *ix, const int64_t *slots, int64_t n, uint64_t *out) {
+    if (!ix || !out || (n > 0 && !slots)) PGV_FAIL(PGV_ERR_ARG, "pgv_index_tids: index/slots/out is NULL");
+    if (!ix->tids) PGV_FAIL(PGV_ERR_STATE, "pgv_index_tids: the index was uploaded without tids");
+    if (is_device_ptr(slots) || is_device_ptr(out)) PGV_FAIL(PGV_ERR_ARG, "pgv_index_tids: host arrays only");
+    PGV_HIP(hipSetDevice(ix->ctx->device));
+    // a scan's slots come in runs (one per list): one copy per run of consecutive slots
+    int64_t i = 0;
+    while (i < n) {
+        if (slots[i] < 0 || slots[i] >= ix->nrows) PGV_FAIL(PGV_ERR_ARG, "pgv_index_tids: slot %lld out of range", (long long)slots[i]);
+        int64_t j = i + 1;
+        while (j < n && slots[j] == slots[j - 1] + 1) j++;
+        if (slots[j - 1] >= ix->nrows) PGV_FAIL(PGV_ERR_ARG, "pgv_index_tids: slot %lld out of range", (long long)slots[j - 1]);
+        PGV_HIP(hipMemcpyAsync(out + i, ix->tids + slots[i], sizeof(uint64_t) * (size_t)(j - i), hipMemcpyDeviceToHost,
+                               ix->ctx->stream));
+        i = j;
+    }
+    PGV_HIP(hipStreamSynchronize(ix->ctx->stream));
+    return PGV_OK;
+}
+
 int64_t pgv_index_rows(const pgv_index *ix) { return ix ? ix->nrows : -1; }
 int pgv_index_lists(const pgv_index *ix) { return ix ? ix->nlists : -1; }
 
@@ -2225,10 +2245,106 @@ int pgv_hnsw_upload(pgv_ctx *ctx, pgv_metric metric, pgv_dtype dtype, int dim, c
 void pgv_hnsw_free(pgv_hnsw *h) {
     if (!h) return;
     if (h->ctx) (void)hipStreamSynchronize(h->ctx->stream);
-    if (h->elements) (void)hipFree(h->elements);
-    if (h->graph) (void)hipFree(h->graph);
+    if (h->imported) {
+        if (h->elements) (void)hipIpcCloseMemHandle(h->elements);
+        if (h->graph) (void)hipIpcCloseMemHandle(h->graph);
+    } else {
+        if (h->elements) (void)hipFree(h->elements);
+        if (h->graph) (void)hipFree(h->graph);
+    }
     h->bitmaps.release();
     delete h;
+}
+
+struct HnswHandleWire {
+    uint64_t magic;
+    uint32_t abi, pid;
+    int32_t device, metric, dtype, dim, m, entry;
+    int64_t n, nbr_total;
+    uint64_t graph_bytes;
+    hipIpcMemHandle_t elements, graph;
+};
+static_assert(sizeof(HnswHandleWire) <= PGV_INDEX_HANDLE_BYTES, "pgv_index_handle too small for an HNSW mirror");
+static constexpr uint64_t kHnswHandleMagic = 0x7067765f686e7731ull;  // "pgv_hnw1"
+
+int pgv_hnsw_export(pgv_hnsw *h, pgv_index_handle *out) {
+    if (!h || !out) PGV_FAIL(PGV_ERR_ARG, "pgv_hnsw_export: handle/out is NULL");
+    if (h->imported) PGV_FAIL(PGV_ERR_STATE, "pgv_hnsw_export: export from the process that uploaded the mirror");
+    if (!h->elements || !h->graph || h->m == 0)
+        PGV_FAIL(PGV_ERR_STATE, "pgv_hnsw_export: needs a non-empty mirror with its graph set (pgv_hnsw_set_graph)");
+    PGV_HIP(hipSetDevice(h->ctx->device));
+    PGV_HIP(hipStreamSynchronize(h->ctx->stream));
+    HnswHandleWire w;
+    memset(&w, 0, sizeof(w));
+    w.magic = kHnswHandleMagic;
+    w.abi = PGV_ABI_VERSION;
+    w.pid = (uint32_t)getpid();
+    w.device = h->ctx->device;
+    w.metric = h->metric;
+    w.dtype = h->dtype;
+    w.dim = h->dim;
+    w.m = h->m;
+    w.entry = h->entry;
+    w.n = h->n;
+    w.nbr_total = h->nbr_total;
+    w.graph_bytes = h->graph_bytes;
+    hipError_t e = hipIpcGetMemHandle(&w.elements, h->elements);
+    if (e == hipSuccess) e = hipIpcGetMemHandle(&w.graph, h->graph);
+    if (e != hipSuccess) {
+        (void)hipGetLastError();
+        PGV_FAIL(PGV_ERR_DEVICE, "hipIpcGetMemHandle failed: %s (HSA_ENABLE_IPC_MODE_LEGACY=0 must be set)", hipGetErrorString(e));
+    }
+    memset(out, 0, sizeof(*out));
+    memcpy(out->bytes, &w, sizeof(w));
+    return PGV_OK;
+}
+
+int pgv_hnsw_import(pgv_ctx *ctx, const pgv_index_handle *handle, pgv_hnsw **out) {
+    if (!ctx || !handle || !out) PGV_FAIL(PGV_ERR_ARG, "pgv_hnsw_import: ctx/handle/out is NULL");
+    *out = nullptr;
+    HnswHandleWire w;
+    memcpy(&w, handle->bytes, sizeof(w));
+    if (w.magic != kHnswHandleMagic || w.abi != PGV_ABI_VERSION)
+        PGV_FAIL(PGV_ERR_ARG, "pgv_hnsw_import: not an HNSW handle of this library version");
+    if (w.pid == (uint32_t)getpid())
+        PGV_FAIL(PGV_ERR_STATE, "pgv_hnsw_import: the handle was exported by this process");
+    if (w.device != ctx->device)
+        PGV_FAIL(PGV_ERR_ARG, "pgv_hnsw_import: the mirror lives on device %d, the context on %d", w.device, ctx->device);
+    PGV_TRY(check_common((pgv_dtype)w.dtype, w.dim));
+    PGV_TRY(check_metric((pgv_metric)w.metric));
+    if (w.n < 1 || w.m < 2 || w.m > 100 || w.entry < -1 || w.entry >= w.n || w.nbr_total < 0)
+        PGV_FAIL(PGV_ERR_ARG, "pgv_hnsw_import: corrupt handle");
+    PGV_HIP(hipSetDevice(ctx->device));
+    pgv_hnsw *h = new (std::nothrow) pgv_hnsw();
+    if (!h) PGV_FAIL(PGV_ERR_NOMEM, "out of host memory");
+    h->ctx = ctx;
+    h->metric = (pgv_metric)w.metric;
+    h->dtype = (pgv_dtype)w.dtype;
+    h->dim = w.dim;
+    h->n = w.n;
+    h->geom = row_geom(w.dim, h->dtype);
+    h->m = w.m;
+    h->entry = w.entry;
+    h->imported = true;
+    h->nbr_total = w.nbr_total;
+    h->graph_bytes = w.graph_bytes;
+    hipError_t e = hipIpcOpenMemHandle(&h->elements, w.elements, hipIpcMemLazyEnablePeerAccess);
+    if (e == hipSuccess) e = hipIpcOpenMemHandle(&h->graph, w.graph, hipIpcMemLazyEnablePeerAccess);
+    if (e != hipSuccess) {
+        (void)hipGetLastError();
+        if (h->elements && !h->graph) { (void)hipIpcCloseMemHandle(h->elements); }
+        h->elements = h->graph = nullptr;
+        delete h;
+        PGV_FAIL(PGV_ERR_DEVICE, "hipIpcOpenMemHandle failed: %s", hipGetErrorString(e));
+    }
+    const size_t lb = ((size_t)h->n * sizeof(int32_t) + 15) / 16 * 16;
+    const size_t sb = ((size_t)(h->n + 1) * sizeof(int64_t) + 15) / 16 * 16;
+    char *base = static_cast<char *>(h->graph);
+    h->levels = reinterpret_cast<const int32_t *>(base);
+    h->nbr_start = reinterpret_cast<const int64_t *>(base + lb);
+    h->nbr = reinterpret_cast<int32_t *>(base + lb + sb);
+    *out = h;
+    return PGV_OK;
 }
 
 int pgv_hnsw_score(pgv_hnsw *h, const void *queries, int nq, const int32_t *slot, const int32_t *query_of,
@@ -2256,6 +2372,7 @@ int pgv_hnsw_score(pgv_hnsw *h, const void *queries, int nq, const int32_t *slot
 int pgv_hnsw_set_graph(pgv_hnsw *h, int m, int32_t entry, const int32_t *levels, const int64_t *nbr_start,
                        const int32_t *nbr) {
     if (!h) PGV_FAIL(PGV_ERR_ARG, "pgv_hnsw_set_graph: handle is NULL");
+    if (h->imported) PGV_FAIL(PGV_ERR_STATE, "pgv_hnsw_set_graph: an imported mirror is read-only");
     if (m < 2 || m > 100) PGV_FAIL(PGV_ERR_ARG, "m must be 2..100 (src/hnsw.h:55-56), got %d", m);
     if (entry < -1 || entry >= h->n) PGV_FAIL(PGV_ERR_ARG, "entry point %d out of range", (int)entry);
     if (h->n > 0 && (!levels || !nbr_start || !nbr)) PGV_FAIL(PGV_ERR_ARG, "levels/nbr_start/nbr is NULL");
@@ -2287,6 +2404,8 @@ int pgv_hnsw_set_graph(pgv_hnsw *h, int m, int32_t entry, const int32_t *levels,
     h->levels = reinterpret_cast<const int32_t *>(base);
     h->nbr_start = reinterpret_cast<const int64_t *>(base + lb);
     h->nbr = reinterpret_cast<int32_t *>(base + lb + sb);
+    h->graph_bytes = lb + sb + nb;
+    h->nbr_total = total;
     return PGV_OK;
 }
 
@@ -2436,6 +2555,7 @@ int pgv_hnsw_score_groups(pgv_hnsw *h, const int32_t *ids, const int64_t *ids_st
 int pgv_hnsw_update_graph(pgv_hnsw *h, int32_t entry, const int32_t *elements, int nupd,
                           const int64_t *tuple_offsets, const int32_t *tuples) {
     if (!h) PGV_FAIL(PGV_ERR_ARG, "pgv_hnsw_update_graph: handle is NULL");
+    if (h->imported) PGV_FAIL(PGV_ERR_STATE, "pgv_hnsw_update_graph: an imported mirror is read-only");
     if (h->m == 0) PGV_FAIL(PGV_ERR_ARG, "pgv_hnsw_update_graph needs pgv_hnsw_set_graph first");
     if (entry < -1 || entry >= h->n) PGV_FAIL(PGV_ERR_ARG, "entry point %d out of range", (int)entry);
     if (nupd < 0 || (nupd > 0 && (!elements || !tuple_offsets || !tuples))) PGV_FAIL(PGV_ERR_ARG, "bad update");

@@ -193,6 +193,9 @@ struct pgv_hnsw {
     int m = 0;
     int32_t entry = -1;
     pgv::DBuf bitmaps;  // visited sets of the search workgroups
+    size_t graph_bytes = 0;
+    int64_t nbr_total = 0;
+    bool imported = false;  // elements / graph were opened with hipIpcOpenMemHandle (a read-only view)
 };
 
 namespace pgv {

@@ -103,3 +103,65 @@ def test_export_import_argument_errors(ctx):
         api.IvfIndex.from_handle(ctx, bytes(256))
     assert e.value.code == api.PGV_ERR_ARG
     ix.close()
+
+
+def test_index_tids_of_scanned_slots(ctx, oracle):
+    """pgv_index_tids: a backend that imported the mirror keeps no TID table; the slots of a whole-batch scan
+    (pgv_scan_lists: one run per list) come back as the heap TIDs the index was staged with"""
+    n, dim, lists = 6000, 32, 12
+    data = gen(n, dim, seed=811, dist="clustered", clusters=lists)
+    ivf = CpuIvf(oracle, po.OPS_L2, po.ORA_F32, data, lists)
+    ix = _upload(ctx, ivf)
+    rng = np.random.default_rng(1)
+    slots = np.concatenate([np.arange(ivf.list_offsets[l], ivf.list_offsets[l + 1]) for l in (7, 2, 9)] +
+                           [rng.integers(0, n, 300)]).astype(np.int64)
+    got = ix.tids(slots)
+    assert got.tolist() == np.asarray(ivf.tids, dtype=np.uint64)[slots].tolist()
+    assert ix.tids(np.zeros(0, np.int64)).size == 0
+    with pytest.raises(api.PgvError) as e:
+        ix.tids(np.array([0, n], dtype=np.int64))
+    assert e.value.code == api.PGV_ERR_ARG
+    ix.close()
+
+
+@pytest.mark.parametrize("dtype", ["f32", "f16"])
+def test_hnsw_mirror_across_processes(ctx, oracle, tmp_path, dtype):
+    """pgv_hnsw_export / pgv_hnsw_import: another PROCESS maps the elements and the graph (hipIpc, no copy) and its
+    hnswgettuple batch (src/hnswscan.c:16-66, HnswSearchLayer src/hnswutils.c:838-951) equals the oracle's walk"""
+    import subprocess
+    import sys
+    odt, gdt = (po.ORA_F32, api.PGV_F32) if dtype == "f32" else (po.ORA_F16, api.PGV_F16)
+    n, dim, m = 3000, 48, 8
+    data = gen(n, dim, seed=821, dist="normal")
+    if dtype == "f16":
+        data = data.astype(np.float16)
+    g = po.HnswGraph(oracle, po.OPS_L2, odt, data, m=m, ef_construction=40, seed=5)
+    ex = g.export_tuples()
+    mirror = api.Hnsw(ctx, api.PGV_L2SQ, gdt, dim, data[ex["rows"]])
+    with pytest.raises(api.PgvError):  # nothing to search before the graph is set
+        mirror.export()
+    mirror.set_graph(m, ex["entry"], ex["levels"], ex["nbr_start"], ex["nbr"])
+    queries = gen(12, dim, seed=822, dist="normal")
+    if dtype == "f16":
+        queries = queries.astype(np.float16)
+    handle = mirror.export()
+    with pytest.raises(api.PgvError) as e:  # the exporting process searches its own mirror
+        api.Hnsw.from_handle(ctx, handle, gdt)
+    assert e.value.code == api.PGV_ERR_STATE
+    job, res = str(tmp_path / "job.npz"), str(tmp_path / "res.npz")
+    np.savez(job, handle=np.frombuffer(handle, dtype=np.uint8), queries=queries, dtype=gdt, ef=40, k=10)
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, PYTHONPATH=root, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    r = subprocess.run([sys.executable, os.path.join(root, "tests", "mp_hnsw_import_worker.py"), job, res], env=env,
+                       stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:]
+    out = np.load(res)
+    assert int(out["readonly"]) == api.PGV_ERR_STATE  # an imported mirror is read-only
+    own_elem, own_dist, _ = mirror.search(queries, 40, 10)
+    assert out["elem"].tolist() == np.asarray(own_elem).tolist()
+    for i, q in enumerate(queries):
+        rows, wd, _ = g.search(q, 40, 10)
+        el = out["elem"][i]
+        assert_topk_equiv(ex["rows"][el[el >= 0]].tolist(), out["dist"][i][:len(rows)], rows.tolist(), wd,
+                          what="imported hnsw q%d" % i)
+    mirror.close()
