@@ -10,25 +10,38 @@ prints ONE JSON line.
 Workload (config.workload): BASELINE.json's headline -- 1,000,000 x 1536-d
 fp32, vector_l2_ops, lists = 1000, probes = 10, k = 10, synthetic Gaussian
 mixture (250 components, sigma 0.1) so that recall is meaningful.  With N GPUs
-the lists are sharded l % N, the query batch grows to N x batch ("weak": the
-per-GPU scan work per step is fixed), per-rank top-k are merged with one
-all-gather.
+every rank generates only ITS rows of the same global data set (slab-keyed
+generators), the build shards samples and heap rows by row and moves each row
+to the owner of its list (l % N), the query batch grows to N x batch ("weak":
+the per-GPU scan work per step is fixed), per-rank top-k are merged with one
+all-gather inside the library.  `--workload c3 / c5 --gpus 8` are BASELINE
+configs[2] / configs[4] at full size (10 M rows).
 
 What the line carries besides the contract's fields (rank 0, N = 1):
   parity       the GPU's answers for `parity_checked_queries` queries compared with the CPU oracle's
                (tid, distance) for the SAME index and queries, tie-tolerant; a mismatch exits non-zero
-  recall_at_10 against an exact float64 brute force over all rows, not against the GPU itself
+  recall_at_10 against an exact float64 brute force over all rows (N > 1: every rank over the rows
+               it holds, merged), never against the GPU itself
   roofline     the list-scan kernel, timed with HIP events on its own stream inside the timed region:
                frac = bytes actually streamed from HBM / kernel time / 8 TB/s (physical, <= 1);
                the per-(query,row)-pair figure of SURVEY 8d is kept as algorithmic_GBps; passes =
                streamed / unique rows; traffic = HBM bytes per launch from a live rocprofv3 PMC pass
                of this same script (FETCH_SIZE x 2 per the gfx950 note + WRITE_SIZE), or null
   batch_sweep  batch 1 (the amgettuple path: pgv_query_* and the C host glue), 16, 256
+  concurrent_backends  N independent backends / N pooled clients against ONE device mirror, as threads of one
+               process and as PROCESSES (pgv_index_export / import, pool state in a shared segment)
   probes_sweep probes 1 / 10 / 32 / 100 with recall each; `uniform`: the same on U[0,1)^d data
   build        kernel-only build (k-means + assignment, data resident in HBM) and build_secs_pages:
                the product path pgv_host_ivf_build -> 8 KB pages -> stage -> upload from host memory
   cpu_baseline the oracle's restatement of ivfflatgettuple (reference flags + -march=native) on this
-               box's host cores, bounded sample
+               box's host cores: pinned threads, spread placement, aggregate GB/s; bounded sample
+  cpu_build_baseline  the oracle's IvfflatKmeans (one thread, like the reference) on the build's own sample and
+               its assignment loop at 1 / all threads (extrapolated), beside build_secs
+  other_configs  c2, c3shard, c5shard (BASELINE configs[1], one GPU's share of [2] and [4]): QPS, recall, the scan
+               kernel's roofline, oracle parity each
+  hnsw         BASELINE configs[3] at full size (1 M x 1536, GPU-built graph): ef_search 40 / 100 / 200
+  exact_scan   BASELINE configs[0] (10 k x 128, 100 queries) through pgv_exact_topk beside the oracle's loop
+  bound_modes  the statistical and the worst-case completeness bound of the MFMA L2 paths side by side
 """
 import argparse
 import ctypes
@@ -59,6 +72,9 @@ WORKLOADS = {
     "c3shard": (1_250_000, 1536, 512, 8, "f32", "ip"),
     # one GPU's share of configs[4] (10M x 3072 fp16 halfvec_l2_ops, lists 4096, 8 GPUs, probes 64)
     "c5shard": (1_250_000, 3072, 512, 8, "f16", "l2"),
+    # BASELINE configs[2] / configs[4] at full size: for --gpus 8 (1.25 M rows per GPU; one GPU holds them too, 61 GB)
+    "c3": (10_000_000, 1536, 4096, 64, "f32", "ip"),
+    "c5": (10_000_000, 3072, 4096, 64, "f16", "l2"),
     "small": (100_000, 256, 100, 10, "f32", "l2"),          # quick functional run
     "smallh": (100_000, 512, 100, 10, "f16", "ip"),
 }
@@ -76,19 +92,27 @@ def dbg(*a):
         print("[rank %s]" % os.environ.get("RANK", "0"), *a, file=sys.stderr, flush=True)
 
 
-def gen_mixture(n, dim, components, sigma, seed, device, means=None):
-    """seeded Gaussian mixture, generated on the device in slabs"""
+SLAB = 1 << 17
+
+
+def gen_mixture(n, dim, components, sigma, seed, device, means=None, lo=0, hi=None):
+    """seeded Gaussian mixture, rows [lo, hi) of n, generated on the device in slabs of 2^17 rows.  Every slab has
+    a generator of its own keyed by (seed, slab index): any rank produces exactly its own rows of the same global
+    data set without generating anybody else's (N GPUs never hold the whole set on one rank)."""
+    hi = n if hi is None else hi
     g = torch.Generator(device=device)
     g.manual_seed(seed)
     if means is None:
         means = torch.rand((components, dim), generator=g, device=device, dtype=torch.float32)
-    out = torch.empty((n, dim), device=device, dtype=torch.float32)
-    slab = 1 << 17
-    for lo in range(0, n, slab):
-        hi = min(n, lo + slab)
-        comp = torch.randint(0, means.shape[0], (hi - lo,), generator=g, device=device)
-        out[lo:hi] = means[comp]
-        out[lo:hi].add_(torch.randn((hi - lo, dim), generator=g, device=device, dtype=torch.float32), alpha=sigma)
+    out = torch.empty((hi - lo, dim), device=device, dtype=torch.float32)
+    for s0 in range(lo // SLAB * SLAB, hi, SLAB):
+        s1 = min(n, s0 + SLAB)
+        g.manual_seed(seed * 1000003 + 7919 * (s0 // SLAB) + 1)
+        comp = torch.randint(0, means.shape[0], (s1 - s0,), generator=g, device=device)
+        slab = means[comp]
+        slab.add_(torch.randn((s1 - s0, dim), generator=g, device=device, dtype=torch.float32), alpha=sigma)
+        a, b = max(lo, s0), min(hi, s1)
+        out[a - lo:b - lo] = slab[a - s0:b - s0]
     return out, means
 
 
@@ -99,11 +123,12 @@ def gen_uniform(n, dim, seed, device):
     return torch.rand((n, dim), generator=g, device=device, dtype=torch.float32)
 
 
-def sample_rows(data, lists, seed, ops):
-    """numSamples = max(50 * lists, 10000) capped by the rows (src/ivfbuild.c:446-455); spherical
-    opclasses normalise the samples (SampleCallback, :148-156)"""
+def sample_rows(data, lists, seed, ops, n_global=None, world=1):
+    """numSamples = max(50 * lists, 10000) capped by the rows (src/ivfbuild.c:446-455), this rank's share of them
+    drawn from its own rows; spherical opclasses normalise the samples (SampleCallback, :148-156)"""
     n = data.shape[0]
-    ns = min(max(50 * lists, 10000), n)
+    ns = min(max(50 * lists, 10000), n_global or n)
+    ns = min((ns + world - 1) // world, n)
     g = torch.Generator(device=data.device)
     g.manual_seed(seed + 1)
     samples = data[torch.randperm(n, generator=g, device=data.device)[:ns]].contiguous()
@@ -113,52 +138,36 @@ def sample_rows(data, lists, seed, ops):
     return samples
 
 
-def build_index(ctx, data, lists, seed, world, rank, dtype, ops, metric, comm=None):
-    """IVFFlat build on the GPU(s), data resident in HBM: sample, k-means, assign every row, lay out
-    list-major.  With N ranks the k-means samples and the heap rows are sharded by row (the library's
-    pgv_kmeans_sharded does the exchanges), and every rank lays out only the lists it owns.
-    Returns the image pieces and the seconds per phase."""
+def build_index(ctx, data, lists, seed, world, rank, dtype, ops, metric, comm=None, row_lo=0, n_global=None):
+    """IVFFlat build on the GPU(s), data resident in HBM: sample, k-means, assign every row, lay out list-major.
+    `data` holds this rank's heap rows [row_lo, row_lo + len) of n_global.  With N ranks the k-means samples and
+    the heap rows are sharded by row (pgv_kmeans_sharded does the Lloyd exchanges inside the library), every rank
+    assigns its own rows, and one all-to-all brings each row to the rank that owns its list (l % N).
+    Returns the local image pieces and the seconds per phase."""
     n, dim = data.shape
-    dev = data.device
     t = {}
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    samples = sample_rows(data, lists, seed, ops)
-    ns = samples.shape[0]
+    samples = sample_rows(data, lists, seed + 31 * rank, ops, n_global, world)
     if world == 1:
         centers, _, iters = api.kmeans(ctx, ops, dtype, dim, samples, lists,
                                        api.make_rng(seed=seed + 2), want_closest=False)
     else:
-        lo, hi = sharding.row_shard(ns, rank, world)
-        centers, _, iters = comm.kmeans(ops, dtype, dim, samples[lo:hi].contiguous(), lists,
+        centers, _, iters = comm.kmeans(ops, dtype, dim, samples, lists,
                                         api.make_rng(seed=seed + 2), want_closest=False)
     ctx.sync()
     torch.cuda.synchronize()
     t["kmeans"] = time.perf_counter() - t0
     t1 = time.perf_counter()
-    lo, hi = sharding.row_shard(n, rank, world)
-    local_lists, _ = api.assign(ctx, metric, dtype, dim, centers, data[lo:hi], want_dist=False)
+    local_lists, _ = api.assign(ctx, metric, dtype, dim, centers, data, want_dist=False)
     ctx.sync()
-    all_lists = sharding.gather_assignments(local_lists, n, world)
     torch.cuda.synchronize()
     t["assign"] = time.perf_counter() - t1
     t2 = time.perf_counter()
-    lists64 = all_lists.to(torch.int64)
-    if world > 1:
-        # only the lists this rank owns (l % world): foreign lists stay empty in the local image
-        rows_mine = torch.nonzero(sharding.owner_of_list(lists64, world) == rank)[:, 0]
-        local = lists64[rows_mine]
-        order = rows_mine[torch.argsort(local, stable=True)]
-        counts = torch.bincount(local, minlength=lists)
-    else:
-        order = torch.argsort(lists64, stable=True)
-        counts = torch.bincount(lists64, minlength=lists)
-    offsets = torch.zeros(lists + 1, dtype=torch.int64, device=dev)
-    offsets[1:] = torch.cumsum(counts, 0)
-    vectors = data[order]
-    tids = order.to(torch.int64)
+    row_ids = torch.arange(row_lo, row_lo + n, dtype=torch.int64, device=data.device)
+    vectors, tids, offsets = sharding.exchange_rows(data, row_ids, local_lists, lists)
     torch.cuda.synchronize()
-    t["layout"] = time.perf_counter() - t2
+    t["layout"] = time.perf_counter() - t2   # N > 1: includes the all-to-all of the rows
     t["total"] = time.perf_counter() - t0
     return centers, offsets, vectors, tids, iters, t
 
@@ -222,87 +231,113 @@ def topk_equiv(got_ids, got_d, want_ids, want_d, rtol=RTOL):
 
 def cpu_baseline(centers, offsets, vectors, tids, queries, probes, k, dtype, ops, budget_s=12.0, pages=None):
     """the oracle (= the reference's loops and kernels restated, built with the reference's flags +
-    -march=native) answering the same queries on the host cores of this box.  Returns the baseline
-    record and the oracle's (tids, distances) per query for the parity check."""
-    from concurrent.futures import ThreadPoolExecutor
-
+    -march=native) answering the same queries on the host cores of this box: one pinned thread per "backend"
+    (oracle/oracle_bench.c), the index re-homed in pieces spread round the memory nodes (what numactl --interleave
+    gives shared_buffers) -- an array filled by one thread sits on one node and caps the scaling at ~5 x.
+    Returns the baseline record and the oracle's (tids, distances) per query for the parity check."""
     from oracle import pyoracle as po
     ora = po.Oracle(native=True)
-    ix = ora.index_struct(po.OPS_L2 if ops == api.PGV_OPS_L2 else po.OPS_IP,
-                          po.ORA_F32 if dtype == api.PGV_F32 else po.ORA_F16, centers, offsets, vectors, tids)
-    cores = min(os.cpu_count() or 1, 64)
-    nq = queries.shape[0]
-    answers = [None] * nq
-
-    def worker(w):
-        done = 0
-        t_end = time.perf_counter() + budget_s
-        i = w
-        while time.perf_counter() < t_end or i < nq:  # every query is answered at least once (parity)
-            r = ora.search(ix, queries[i % nq], probes, k)
-            if i < nq:
-                answers[i] = r
-            done += 1
-            i += cores
-        return done
-    t0 = time.perf_counter()
-    with ThreadPoolExecutor(cores) as ex:
-        total = sum(ex.map(worker, range(cores)))
-    el = time.perf_counter() - t0
-    # one thread alone = one Postgres backend
-    t0 = time.perf_counter()
-    single = 0
-    while time.perf_counter() - t0 < 3.0:
-        ora.search(ix, queries[single % nq], probes, k)
-        single += 1
-    single_s = (time.perf_counter() - t0) / single
+    oops = po.OPS_L2 if ops == api.PGV_OPS_L2 else po.OPS_IP
+    odt = po.ORA_F32 if dtype == api.PGV_F32 else po.ORA_F16
+    cpus = ora.lib.ora_bench_cpus()
+    cores = max(1, min(cpus, 256))
+    svec, release = ora.spread(vectors, cores)
+    ix = ora.index_struct(oops, odt, centers, offsets, svec, tids)
+    esz = 4 if dtype == api.PGV_F32 else 2
+    dim = vectors.shape[1]
+    off = np.asarray(offsets)
+    # bytes the scan of one query reads: its probed lists' rows + every center (GetScanLists)
+    rows_per_query = float(np.mean([sum(off[l + 1] - off[l] for l in ora.get_scan_lists(ix, q, probes)[0])
+                                    for q in queries[:32]]))
+    bytes_per_query = (rows_per_query + centers.shape[0]) * dim * esz
+    answers, total, el = ora.bench_search(ix, queries, probes, k, cores, budget_s)
+    _, single, single_el = ora.bench_search(ix, queries[:64], probes, k, 1, 3.0)
     rec = {"value": total / el, "unit": "queries/s", "cores": cores, "kind": "port",
-           "single_thread_qps": 1.0 / single_s, "single_thread_ms_per_query": single_s * 1e3,
+           "single_thread_qps": single / single_el, "single_thread_ms_per_query": single_el / single * 1e3,
+           "aggregate_GBps": total / el * bytes_per_query / 1e9, "single_thread_GBps": single / single_el * bytes_per_query / 1e9,
+           "scaling_over_one_thread": (total / el) / (single / single_el),
+           "placement": "one pthread per backend pinned to allowed CPU t * %d / %d (sched_getaffinity: %d CPUs allowed, "
+                        "os.cpu_count %s); index rows copied into 2 MB pieces first-touched round-robin by those "
+                        "threads (interleaved over the memory nodes)" % (cpus, cores, cpus, os.cpu_count()),
            "layout": "contiguous list-major arrays (an upper bound of the reference: no 8 KB page walk, "
                      "no fmgr/bufmgr/tuplesort overheads)",
            "sample": "%d queries in %.1f s on %d threads (%d more on 1 thread), same index and queries as the "
                      "parity check" % (total, el, cores, single)}
+    release()
     page_answers = None
     if pages is not None:
         # SURVEY 8d(ii): the same loops over the emulated 8 KB page image (oracle_pages.c): page headers, line
         # pointers, IndexTuple headers, nextblkno chains, one 1536-d tuple per page
         ptr, nblocks = pages
-        oops = po.OPS_L2 if ops == api.PGV_OPS_L2 else po.OPS_IP
-        odt = po.ORA_F32 if dtype == api.PGV_F32 else po.ORA_F16
-        page_answers = [None] * nq
-        half = max(budget_s / 2.0, 3.0)
-
-        def pworker(w):
-            done = 0
-            t_end = time.perf_counter() + half
-            i = w
-            while time.perf_counter() < t_end or i < nq:
-                r = ora.pages_search(ptr, nblocks, oops, odt, queries[i % nq], probes, k)
-                if i < nq:
-                    page_answers[i] = r
-                done += 1
-                i += cores
-            return done
-        t0 = time.perf_counter()
-        with ThreadPoolExecutor(cores) as ex:
-            ptotal = sum(ex.map(pworker, range(cores)))
-        pel = time.perf_counter() - t0
-        t0 = time.perf_counter()
-        psingle = 0
-        while time.perf_counter() - t0 < 3.0:
-            ora.pages_search(ptr, nblocks, oops, odt, queries[psingle % nq], probes, k)
-            psingle += 1
-        psingle_s = (time.perf_counter() - t0) / psingle
-        rec["contiguous"] = {"value": rec["value"], "single_thread_qps": rec["single_thread_qps"],
-                             "single_thread_ms_per_query": rec["single_thread_ms_per_query"], "layout": rec["layout"],
-                             "sample": rec["sample"]}
-        rec.update({"value": ptotal / pel, "single_thread_qps": 1.0 / psingle_s,
-                    "single_thread_ms_per_query": psingle_s * 1e3,
+        pa, ptotal, pel = ora.bench_search(None, queries, probes, k, cores, max(budget_s / 2.0, 3.0),
+                                           pages=(ptr, nblocks), ops=oops, dtype=odt)
+        _, psingle, psingle_el = ora.bench_search(None, queries[:64], probes, k, 1, 3.0, pages=(ptr, nblocks), ops=oops,
+                                                  dtype=odt)
+        page_answers = [(t, d, None) for t, d in pa]
+        rec["contiguous"] = {key: rec[key] for key in ("value", "single_thread_qps", "single_thread_ms_per_query",
+                                                       "aggregate_GBps", "scaling_over_one_thread", "layout", "sample")}
+        rec.update({"value": ptotal / pel, "single_thread_qps": psingle / psingle_el,
+                    "single_thread_ms_per_query": psingle_el / psingle * 1e3,
+                    "aggregate_GBps": ptotal / pel * bytes_per_query / 1e9,
+                    "single_thread_GBps": psingle / psingle_el * bytes_per_query / 1e9,
+                    "scaling_over_one_thread": (ptotal / pel) / (psingle / psingle_el),
                     "layout": "emulated 8 KB page image (oracle_pages.c walks meta / list / entry pages like "
-                              "src/ivfscan.c:47-187; no buffer pins, fmgr or tuplesort copies: still an upper bound)",
+                              "src/ivfscan.c:47-187; no buffer pins, fmgr or tuplesort copies: still an upper bound); "
+                              "the image is placed by the list-parallel page writer that built it",
                     "sample": "%d queries in %.1f s on %d threads (%d more on 1 thread) over the %d pages the product "
                               "build wrote" % (ptotal, pel, cores, psingle, nblocks)})
     return rec, answers, page_answers
+
+
+def cpu_build_kmeans(host_samples, lists, dtype, ops, seed, out):
+    """SURVEY 8d, first half (a background thread while the GPU sections go on; the oracle's C releases the GIL and
+    uses ONE core, like the reference: IvfflatKmeans is single-threaded whatever max_parallel_maintenance_workers
+    is): InitCenters + ElkanKmeans restated (src/ivfkmeans.c:23-91, 246-485) on the very sample the GPU build used."""
+    try:
+        from oracle import pyoracle as po
+        ora = po.Oracle(native=True)
+        oops = po.OPS_L2 if ops == api.PGV_OPS_L2 else po.OPS_IP
+        odt = po.ORA_F32 if dtype == api.PGV_F32 else po.ORA_F16
+        t0 = time.perf_counter()
+        centers, _, iters = ora.kmeans(oops, odt, host_samples, lists, ora.prng(seed))
+        out.update({"kind": "port", "kmeans_secs_one_thread": time.perf_counter() - t0, "kmeans_iterations": int(iters),
+                    "kmeans_sample_rows": int(host_samples.shape[0]), "_centers": centers})
+    except Exception as e:  # noqa: BLE001
+        out["error"] = repr(e)
+
+
+def cpu_build_assign(host_rows, dtype, ops, out):
+    """second half, in the foreground (it takes every core for a second): the argmin loop of src/ivfbuild.c:183-192 on
+    a 100k-row subsample at 1 thread and at every core (the reference's parallel build splits the heap scan between
+    workers, src/ivfbuild.c:830-966), extrapolated to all rows"""
+    centers = out.pop("_centers", None)
+    if centers is None:
+        return
+    try:
+        from oracle import pyoracle as po
+        ora = po.Oracle(native=True)
+        oops = po.OPS_L2 if ops == api.PGV_OPS_L2 else po.OPS_IP
+        odt = po.ORA_F32 if dtype == api.PGV_F32 else po.ORA_F16
+        n = host_rows.shape[0]
+        sub = np.ascontiguousarray(host_rows[:: max(n // 100_000, 1)][:100_000])
+        cores = max(1, min(ora.lib.ora_bench_cpus(), 256))
+        one_rows = sub[:4000]
+        _, one_s = ora.bench_assign(oops, odt, centers, one_rows, 1)
+        _, all_s = ora.bench_assign(oops, odt, centers, sub, cores)
+        km_s = out["kmeans_secs_one_thread"]
+        out.update({
+            "assign_rows_per_s_one_thread": one_rows.shape[0] / one_s,
+            "assign_rows_per_s_all_threads": sub.shape[0] / all_s, "assign_threads": cores,
+            "assign_sample_rows": int(sub.shape[0]),
+            "assign_secs_extrapolated_one_thread": n / (one_rows.shape[0] / one_s),
+            "assign_secs_extrapolated_all_threads": n / (sub.shape[0] / all_s),
+            "build_secs_extrapolated_one_thread": km_s + n / (one_rows.shape[0] / one_s),
+            "build_secs_extrapolated_all_threads": km_s + n / (sub.shape[0] / all_s),
+            "note": "k-means measured in full on one thread (as the reference runs it); assignment measured on a "
+                    "subsample and scaled to %d rows (labelled extrapolated); no heap scan, tuplesort or page writes "
+                    "on the CPU side" % n})
+    except Exception as e:  # noqa: BLE001
+        out["error"] = repr(e)
 
 
 def live_traffic(args, scan_ms):
@@ -377,8 +412,22 @@ def concurrent_backends(index, device, qhost, queries, probes, k, args, dev):
             out["single_query"][str(nb)] = {"error": "backends_run rc %d" % rc}
             break
         out["single_query"][str(nb)] = {"qps": res[0], "latency_us_p50": res[1], "latency_us_p90": res[2]}
-    out["single_query"]["driver"] = ("tools/backends_driver.c: pthreads over the C ABI, one pgv_ctx + pgv_index_share view + "
-                                     "pgv_query per backend, pgv_query_rank + pgv_query_scan per query")
+    out["single_query"]["driver"] = ("tools/backends_driver.c: THREADS of one process over the C ABI, one pgv_ctx + "
+                                     "pgv_index_share view + pgv_query per backend, pgv_query_rank + pgv_query_scan per query; "
+                                     "at most PGV_MAX_INFLIGHT_SCANS (16) scans in flight per process")
+    # the same with PROCESSES, which is what a Postgres backend is: every process imports the ONE device mirror
+    # (pgv_index_export / pgv_index_import: hipIpc, no copy) and scans it on a context and stream of its own
+    from pgvector_amd import _host
+    out["single_query_processes"] = {}
+    for nb in (1, 4, 8, 16, 32):
+        try:
+            out["single_query_processes"][str(nb)] = _host.run_backend_processes(index, qh, probes, k, 0, nb, 300)
+        except Exception as e:  # noqa: BLE001
+            out["single_query_processes"][str(nb)] = {"error": repr(e)}
+            break
+    out["single_query_processes"]["driver"] = ("tools/pgv_backend.c `query`: one PROCESS per backend (fork + exec), the "
+                                               "mirror imported from the owner's export handle, pgv_query_rank + "
+                                               "pgv_query_scan per query; HBM holds the index once")
     # (a') the same kind of clients behind the host glue's pooler (ivf_pool.c): one query each, batched on arrival
     drv.pool_run.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_size_t,
                              C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_double)]
@@ -392,8 +441,21 @@ def concurrent_backends(index, device, qhost, queries, probes, k, args, dev):
             break
         out["pooled_single_query"][str(nc)] = {"qps": res4[0], "latency_us_p50": res4[1], "latency_us_p90": res4[2],
                                                "mean_batch": res4[3]}
-    out["pooled_single_query"]["pool"] = ("pgv_host_pool_*: clients block in pgv_host_pool_search with one query each; "
+    out["pooled_single_query"]["pool"] = ("pgv_host_pool_*: client THREADS block in pgv_host_pool_search with one query each; "
                                           "max_batch 1024, max_wait 50 us, 2 lanes (contexts); host buffers in and out")
+    # ... and with GPU-less client PROCESSES in front of two lane-server processes: the pool's slots, lane words and
+    # payload ring live in a shared segment (non-private futexes, a robust process-shared mutex)
+    out["pooled_single_query_processes"] = {}
+    for nc in (16, 64, 256):
+        try:
+            out["pooled_single_query_processes"][str(nc)] = _host.run_backend_processes(
+                index, qh, probes, k, 1, nc, max(40, 6000 // nc), max_batch=1024, max_wait_us=50, lanes=2,
+                server_processes=True)
+        except Exception as e:  # noqa: BLE001
+            out["pooled_single_query_processes"][str(nc)] = {"error": repr(e)}
+            break
+    out["pooled_single_query_processes"]["pool"] = ("tools/pgv_backend.c `client` x N + `serve` x 2 lanes: every client and "
+                                                    "every lane leader is a process; the leaders import the mirror")
     # (b) batches from two submitters
     ctx2 = api.Context(device)
     v2 = index.share(ctx2)
@@ -413,17 +475,22 @@ def concurrent_backends(index, device, qhost, queries, probes, k, args, dev):
     return out
 
 
-def hnsw_section(ctx, dev, args, failures, rows=50_000, dim=1536, m=16, efc=64, ef=100, k=10, nq=2000):
-    """vector_cosine_ops HNSW (src/hnswbuild.c:376-476 build loop, src/hnswscan.c:25-56 + src/hnswutils.c:824-987 scan):
-    graph built on the GPU by pgv_host_hnsw_build, every scan's first batch walked on the device by pgv_hnsw_search.
-    Parity: the oracle's HnswSearchLayer restatement walks the SAME graph (ora_hnsw_import) for 64 queries; recall
-    against an exact float64 scan."""
+def hnsw_section(ctx, dev, args, failures, rows=1_000_000, dim=1536, m=16, efc=64, k=10, nq=1000, efs=(40, 100, 200)):
+    """BASELINE configs[3]: vector_cosine_ops HNSW, 1 M x 1536, m 16 (src/hnswbuild.c:376-476 build loop,
+    src/hnswscan.c:25-56 + src/hnswutils.c:824-987 scan).  The graph is built on the GPU by pgv_host_hnsw_build,
+    every scan's first batch walked on the device by pgv_hnsw_search, ef_search 40 (the reference default) / 100 / 200.
+    Parity: the oracle's HnswSearchLayer restatement walks the SAME graph (ora_hnsw_import) for 32 queries at ef 100;
+    recall against an exact float64 scan."""
     from pgvector_amd import _host
     g = torch.Generator(device=dev)
     g.manual_seed(args.seed + 21)
     comps = torch.rand((64, dim), generator=g, device=dev)
-    data = comps[torch.randint(0, 64, (rows,), generator=g, device=dev)] + 0.1 * torch.randn((rows, dim), generator=g, device=dev)
-    data = (data / data.norm(dim=1, keepdim=True)).contiguous()  # HnswFormIndexValue normalises (src/hnswutils.c:406-428)
+    data = torch.empty((rows, dim), device=dev)
+    for lo in range(0, rows, SLAB):
+        hi = min(rows, lo + SLAB)
+        data[lo:hi] = comps[torch.randint(0, 64, (hi - lo,), generator=g, device=dev)] + \
+            0.1 * torch.randn((hi - lo, dim), generator=g, device=dev)
+        data[lo:hi] /= data[lo:hi].norm(dim=1, keepdim=True)  # HnswFormIndexValue normalises (src/hnswutils.c:406-428)
     q = comps[torch.randint(0, 64, (nq,), generator=g, device=dev)] + 0.1 * torch.randn((nq, dim), generator=g, device=dev)
     q = (q / q.norm(dim=1, keepdim=True)).contiguous()
     host_rows = data.cpu().numpy()
@@ -433,53 +500,216 @@ def hnsw_section(ctx, dev, args, failures, rows=50_000, dim=1536, m=16, efc=64, 
     built = _host.hnsw_build(mirror, host_rows, m, efc, api.make_rng(seed=1), max_batch=1024)
     torch.cuda.synchronize()
     build_s = time.perf_counter() - t0
-    qd = q.repeat(10, 1).contiguous()
-    mirror.search(qd[:64].contiguous(), ef, k)
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    elem, gd, scored = mirror.search(qd, ef, k)
-    torch.cuda.synchronize()
-    dev_s = time.perf_counter() - t0
-    # exact top-k in float64
-    ip = q.double() @ data.double().T
-    kth = torch.topk(ip, k, dim=1).values[:, -1]
-    e = elem[:nq]
-    got_ip = torch.gather(ip, 1, e.clamp(min=0))
-    recall = float(((got_ip >= kth[:, None] - 1e-9) & (e >= 0)).sum().item()) / (nq * k)
-    out = {"workload": "HNSW vector_cosine_ops %d x %d f32, m %d, ef_construction %d, ef_search %d, k %d (BASELINE "
-                       "configs[3] is 1 M rows: tools/bench_hnsw.py --big)" % (rows, dim, m, efc, ef, k),
-           "qps": qd.shape[0] / dev_s, "queries_in_flight": int(qd.shape[0]), "recall_at_10": recall,
-           "recall_ground_truth": "exact float64 inner products over all rows",
-           "scored_elements_per_query": float(scored.float().mean().item()),
-           "scored_rows_GBps": float(scored.sum().item()) * dim * 4 / dev_s / 1e9,
+    # exact top-k in float64, in row slabs
+    q64 = q.double()
+    best = torch.full((nq, k), -2.0, dtype=torch.float64, device=dev)
+    for lo in range(0, rows, 100_000):
+        best = torch.topk(torch.cat([best, q64 @ data[lo:lo + 100_000].double().T], dim=1), k, dim=1).values
+    kth = best[:, -1]
+    qd = q.repeat(max(1, 20000 // nq), 1).contiguous()
+    sweep, keep = {}, None
+    for ef in efs:
+        mirror.search(qd[:64].contiguous(), ef, k)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        elem, gd, scored = mirror.search(qd, ef, k)
+        torch.cuda.synchronize()
+        dev_s = time.perf_counter() - t0
+        e = elem[:nq]
+        got_ip = (q64[:, None, :] * data[e.clamp(min=0)].double()).sum(-1)
+        recall = float(((got_ip >= kth[:, None] - 1e-9) & (e >= 0)).sum().item()) / (nq * k)
+        gbps = float(scored.sum().item()) * dim * 4 / dev_s / 1e9
+        sweep[str(ef)] = {"qps": qd.shape[0] / dev_s, "recall_at_10": recall,
+                          "scored_elements_per_query": float(scored.float().mean().item()),
+                          "scored_rows_GBps": gbps, "frac_of_hbm_peak": gbps / HBM_PEAK_GBS}
+        if ef == 100:
+            keep = (e.cpu().numpy(), gd[:nq].cpu().numpy())
+    out = {"workload": "HNSW vector_cosine_ops %d x %d f32, m %d, ef_construction %d, k %d (BASELINE configs[3])"
+                       % (rows, dim, m, efc, k),
+           "queries_in_flight": int(qd.shape[0]), "ef_search": sweep,
+           "recall_ground_truth": "exact float64 inner products over all rows, %d queries" % nq,
+           "roofline_note": "scored_rows_GBps = element rows gathered x 6 KB / search seconds: a 6 GB mirror does not "
+                            "fit the 256 MB MALL, so this is HBM traffic (gathers of whole rows)",
            "build_secs": build_s, "build": {"batches": built["batches"], "elements": built["nelements"],
                                             "pairs_scored": built["device_pairs"], "phase_secs": built["phase_secs"]}}
-    if not args.no_cpu_baseline:
+    if not args.no_cpu_baseline and keep is not None:
         from oracle import pyoracle as po
         ora = po.Oracle(native=True)
-        keep = np.nonzero(built["dup_of"] < 0)[0]  # elements in row order (duplicates folded into their first row)
-        if len(keep) != built["nelements"]:
-            raise RuntimeError("element bookkeeping: %d kept rows, %d elements" % (len(keep), built["nelements"]))
+        if int((built["dup_of"] < 0).sum()) != built["nelements"]:
+            raise RuntimeError("element bookkeeping: %d kept rows, %d elements" % (int((built["dup_of"] < 0).sum()), built["nelements"]))
         walk = po.HnswGraph.from_tuples(ora, po.OPS_COSINE, po.ORA_F32, host_rows, m, built["levels"], built["nbr_start"],
                                         built["nbr"], built["entry"])
-        eh, dh = e.cpu().numpy(), gd[:nq].cpu().numpy()
+        eh, dh = keep
         qh = q.cpu().numpy()
-        bad, checked = [], 64
+        bad, checked = [], 32
         t0 = time.perf_counter()
         for i in range(checked):
-            wr, wd, _ = walk.search(qh[i], ef, k)
+            wr, wd, _ = walk.search(qh[i], 100, k)
             # both sides report the index's FUNCTION 1 value (vector_negative_inner_product on normalised rows)
             why = topk_equiv(eh[i][eh[i] >= 0].tolist(), dh[i][:len(wr)], wr.tolist(), wd)
             if why:
                 bad.append((i, why))
         cpu_s = (time.perf_counter() - t0) / checked
         out["parity"] = {"against": "oracle HnswSearchLayer / GetScanItems restatement walking the same GPU-built graph "
-                                    "(ora_hnsw_import)", "checked_queries": checked, "mismatches": len(bad)}
+                                    "(ora_hnsw_import), ef_search 100", "checked_queries": checked, "mismatches": len(bad)}
         out["cpu_search_single_thread_qps"] = 1.0 / cpu_s
         if bad:
             failures.append("hnsw: %d of %d queries differ from the oracle's walk, first: %r" % (len(bad), checked, bad[0]))
         walk.close()
     mirror.close()
+    return out
+
+
+def roofline_record(stats, esize, dim, tname, kernel):
+    """the list-scan kernel's physical roofline from the library's device-side accounting (HIP events on the launch
+    stream): frac = row bytes actually streamed / kernel seconds / 8 TB/s"""
+    launches = max(stats["scan_launches"], 1)
+    algo_bytes = stats["scan_pairs"] * esize * dim
+    stream_bytes = stats["scan_rows"] * esize * dim
+    unique_bytes = stats["scan_unique_rows"] * esize * dim
+    scan_s = stats["scan_ms"] / 1e3
+    gbps = stream_bytes / scan_s / 1e9 if scan_s > 0 else 0.0
+    return {"kernel": kernel, "bound": "hbm", "achieved": gbps, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "frac": gbps / HBM_PEAK_GBS, "traffic": None,
+            "streamed_bytes_per_launch": stream_bytes / launches, "unique_bytes_per_launch": unique_bytes / launches,
+            "passes": stream_bytes / unique_bytes if unique_bytes > 0 else None,
+            "algorithmic_bytes_per_launch": algo_bytes / launches,
+            "algorithmic_GBps": algo_bytes / scan_s / 1e9 if scan_s > 0 else 0.0,
+            "avg_launch_ms": stats["scan_ms"] / launches, "launches": launches,
+            "useful_tflops": stats["scan_pairs"] * dim * 2.0 / scan_s / 1e12 if scan_s > 0 else 0.0,
+            "mfma_peak_tflops": 157.3 if tname == "f32" else 2500.0}
+
+
+def run_workload(ctx, dev, name, args, failures, steps=10, parity_queries=32):
+    """one of BASELINE's other IVFFlat configs end to end on this GPU: build, recall against float64, the timed
+    batch loop with the scan kernel's roofline, parity of `parity_queries` queries with the CPU oracle"""
+    n, dim, lists, probes, tname, oname = WORKLOADS[name]
+    dtype = api.PGV_F32 if tname == "f32" else api.PGV_F16
+    tdtype = torch.float32 if tname == "f32" else torch.float16
+    ops = api.PGV_OPS_L2 if oname == "l2" else api.PGV_OPS_IP
+    metric = api.PGV_L2SQ if oname == "l2" else api.PGV_NEG_IP
+    esize = 4 if tname == "f32" else 2
+    k, batch, pool = args.k, args.batch, 4
+    components = max(lists // 4, 1)
+    data, means = gen_mixture(n, dim, components, 0.1, args.seed + 50, dev)
+    data = data.to(tdtype)
+    centers, offsets, vectors, tids, iters, build_t = build_index(ctx, data, lists, args.seed, 1, 0, dtype, ops, metric)
+    del data
+    index = api.IvfIndex(ctx, metric, dtype, dim, centers, offsets, vectors, tids.view(torch.int64))
+    queries, _ = gen_mixture(batch * pool, dim, components, 0.1, args.seed + 150, dev, means=means)
+    queries = queries.to(tdtype).view(pool, batch, dim)
+    od = torch.empty((batch, k), device=dev, dtype=torch.float32)
+    os_ = torch.empty((batch, k), device=dev, dtype=torch.int64)
+    ot = torch.empty((batch, k), device=dev, dtype=torch.int64)
+    rq = min(args.recall_queries, batch)
+    rqueries = queries[1][:rq].contiguous()
+    exact_d, _ = exact_topk_fp64(vectors, rqueries, k, metric)
+    gd, _, _ = index.search_batch(rqueries, probes, k, want_tid=True)
+    recall = recall_at_k(gd, exact_d, k)
+
+    def step(j):
+        index.search_batch(queries[j % pool], probes, k, want_tid=True, out=(od, os_, ot))
+    for j in range(3):
+        step(j)
+    ctx.set_profiling(True)
+    ctx.reset_stats()
+    s = timed_steps(step, steps, warmup=0)
+    stats = ctx.stats()
+    ctx.set_profiling(False)
+    out = {"workload": "%s: IVFFlat %s_%s_ops %d x %d %s, lists=%d, probes=%d, k=%d, batch=%d, Gaussian mixture (%d "
+                       "components, sigma 0.1)" % (name, "vector" if tname == "f32" else "halfvec", oname, n, dim, tname,
+                                                   lists, probes, k, batch, components),
+           "qps": batch / s, "ms_per_step": s * 1e3, "steps": steps, "recall_at_10": recall,
+           "recall_ground_truth": "exact float64 brute force over all %d rows, %d queries" % (n, rq),
+           "build_secs": build_t["total"], "build_phases_secs": build_t, "kmeans_iterations": iters,
+           "scan_ms_per_step": stats["scan_ms"] / steps, "scan_redo_queries_per_step": stats["scan_redo_queries"] / steps,
+           "roofline": roofline_record(stats, esize, dim, tname, "mfma_scan_kernel (IVFFlat list scan)")}
+    if oname == "l2":
+        out["bound_worst_case"] = bound_mode_run(ctx, step, steps, batch)
+    if not args.no_cpu_baseline:
+        from oracle import pyoracle as po
+        ora = po.Oracle(native=True)
+        ix = ora.index_struct(po.OPS_L2 if oname == "l2" else po.OPS_IP, po.ORA_F32 if tname == "f32" else po.ORA_F16,
+                              centers.cpu().numpy(), offsets.cpu().numpy(), vectors.cpu().numpy(),
+                              tids.cpu().numpy().astype(np.uint64))
+        pq = queries[2][:parity_queries].contiguous()
+        pd, _, pt = index.search_batch(pq, probes, k, want_tid=True)
+        pd, pt, pqh = pd.cpu().numpy(), pt.cpu().numpy(), pq.cpu().numpy()
+        bad = []
+        t0 = time.perf_counter()
+        for i in range(parity_queries):
+            wt, wd = ora.search(ix, pqh[i], probes, k)
+            why = topk_equiv(pt[i][:len(wt)].astype(np.uint64).tolist(), pd[i][:len(wt)], wt.tolist(), wd)
+            if why:
+                bad.append((i, why))
+        out["parity"] = {"against": "CPU oracle, same index, same queries", "checked_queries": parity_queries,
+                         "mismatches": len(bad)}
+        out["cpu_single_thread_qps"] = parity_queries / (time.perf_counter() - t0)
+        if bad:
+            failures.append("%s: %d of %d queries differ from the oracle, first: %r" % (name, len(bad), parity_queries, bad[0]))
+    index.close()
+    return out
+
+
+def bound_mode_run(ctx, step, steps, batch):
+    """the same timed loop with PGV_BOUND_WORST_CASE (include/pgv_hip.h): QPS and queries redone exactly per step"""
+    ctx.set_bound(True)
+    try:
+        for j in range(2):
+            step(j)
+        ctx.set_profiling(True)
+        ctx.reset_stats()
+        s = timed_steps(step, steps, warmup=0)
+        st = ctx.stats()
+    finally:
+        ctx.set_profiling(False)
+        ctx.set_bound(False)
+    return {"qps": batch / s, "ms_per_step": s * 1e3, "scan_redo_queries_per_step": st["scan_redo_queries"] / steps,
+            "bound": "(gamma_(d+1) + gamma_(d+2)) (|q| + |x|max)^2, deterministic (pgv_ctx_set_bound)"}
+
+
+def exact_scan_section(ctx, dev, args, failures):
+    """BASELINE configs[0]: the index-less `ORDER BY embedding <-> q LIMIT 10` over 10 k x 128 for 100 queries --
+    pgv_exact_topk against the oracle's per-row l2 calls + sort (src/vector.c:579-589), and a 1 M x 1536 case for
+    the kernel's rate"""
+    out = {}
+    g = torch.Generator(device=dev)
+    g.manual_seed(args.seed + 61)
+    for label, n, dim, nq in (("config1_10k_x_128", 10_000, 128, 100), ("1M_x_1536", 1_000_000, 1536, 1024)):
+        rows = torch.rand((n, dim), generator=g, device=dev)
+        queries = torch.rand((nq, dim), generator=g, device=dev)
+        od = torch.empty((nq, args.k), device=dev, dtype=torch.float32)
+        oi = torch.empty((nq, args.k), device=dev, dtype=torch.int64)
+        s = timed_steps(lambda j: api.exact_topk(ctx, api.PGV_L2SQ, api.PGV_F32, dim, queries, rows, args.k, out=(od, oi)), 10)
+        rec = {"rows": n, "dim": dim, "queries": nq, "k": args.k, "ms_per_batch": s * 1e3, "qps": nq / s,
+               "rows_GBps": n * dim * 4 * ((nq + 31) // 32) / s / 1e9,
+               "path": "pgv_exact_topk: MFMA expansion + exact tail, data resident in HBM"}
+        if n <= 100_000:
+            qh, rh = queries.cpu().numpy(), rows.cpu().numpy()
+            sh = timed_steps(lambda j: api.exact_topk(ctx, api.PGV_L2SQ, api.PGV_F32, dim, qh, rh, args.k), 5)
+            rec["host_buffers_ms_per_batch"] = sh * 1e3
+            if not args.no_cpu_baseline:
+                from oracle import pyoracle as po
+                ora = po.Oracle(native=True)
+                ix = ora.index_struct(po.OPS_L2, po.ORA_F32, rh[:1], np.array([0, n], dtype=np.int64), rh,
+                                      np.arange(n, dtype=np.uint64))
+                gd, gi = od.cpu().numpy(), oi.cpu().numpy()
+                bad = []
+                t0 = time.perf_counter()
+                for i in range(nq):
+                    wt, wd = ora.search(ix, qh[i], 1, args.k)
+                    why = topk_equiv(gi[i].astype(np.uint64).tolist(), gd[i], wt.tolist(), wd)
+                    if why:
+                        bad.append((i, why))
+                cpu_s = time.perf_counter() - t0
+                rec["parity"] = {"against": "oracle: one l2 call per row + ascending sort", "checked_queries": nq,
+                                 "mismatches": len(bad)}
+                rec["cpu_baseline"] = {"value": nq / cpu_s, "unit": "queries/s", "cores": 1, "kind": "port",
+                                       "sample": "the same %d queries, one thread" % nq}
+                if bad:
+                    failures.append("exact scan: %d of %d queries differ from the oracle, first: %r" % (len(bad), nq, bad[0]))
+        out[label] = rec
+        del rows, queries
     return out
 
 
@@ -554,13 +784,14 @@ def main():
 
     # ---------------------------------------------------------------- setup
     components = max(lists // 4, 1)
-    data, means = gen_mixture(n, dim, components, 0.1, args.seed, dev)
+    row_lo, row_hi = sharding.row_shard(n, rank, world)
+    data, means = gen_mixture(n, dim, components, 0.1, args.seed, dev, lo=row_lo, hi=row_hi)
     data = data.to(tdtype)
-    log("data: %d x %d %s generated" % (n, dim, tname))
+    log("data: rows [%d, %d) of %d x %d %s generated" % (row_lo, row_hi, n, dim, tname))
     ctx.set_profiling(True)
     ctx.reset_stats()
     centers, offsets, vectors, tids, iters, build_t = build_index(ctx, data, lists, args.seed, world, rank,
-                                                                  dtype, ops, metric, comm)
+                                                                  dtype, ops, metric, comm, row_lo=row_lo, n_global=n)
     build_stats = ctx.stats()
     ctx.set_profiling(False)
     log("build: %s (k-means iterations %d)" % ({a: round(b, 3) for a, b in build_t.items()}, iters))
@@ -594,16 +825,16 @@ def main():
     rq = min(args.recall_queries, total_batch)
     rqueries = queries[1][:rq].contiguous()
     exact_d = None
+    # exact float64 brute force over every row; with N ranks each one scans the rows it holds and the per-rank
+    # exact top-k are merged (never the GPUs' own fp32 scan as its own ground truth)
+    exact_d, _ = exact_topk_fp64(vectors, rqueries, k, metric)
     if world == 1:
-        exact_d, _ = exact_topk_fp64(vectors, rqueries, k, metric)
         got_d, got_s, got_t = index.search_batch(rqueries, probes, k, want_tid=True)
         recall_truth = "exact float64 brute force over all %d rows, %d queries" % (n, rq)
     else:
-        # the rows are spread over the ranks: the exact answer is the merge of every rank's exhaustive scan
-        exact_d, _ = comm.search_batch(index, rqueries, lists, k)
+        exact_d = sharding.merge_exact_topk(exact_d, k)
         got_d, got_t = comm.search_batch(index, rqueries, probes, k)
-        exact_d = exact_d.double()
-        recall_truth = "merge of every rank's exhaustive fp32 scan (probes = lists), %d queries" % rq
+        recall_truth = "exact float64 brute force, every rank over the rows it holds, merged over %d ranks, %d queries" % (world, rq)
     ctx.sync()
     recall = recall_at_k(got_d, exact_d, k)
     log("recall@%d = %.4f at probes=%d (%s)" % (k, recall, probes, recall_truth))
@@ -790,6 +1021,7 @@ def main():
 
     # ------------------------------------------------------ the product build path, through pages
     pages_ctx = None
+    host_samples = None
     if do_pages:
         try:
             from pgvector_amd import _host
@@ -829,7 +1061,6 @@ def main():
             pages_ctx = (rel, pix, img)
         except Exception as e:
             line["build_pages"] = {"error": repr(e)}
-        host_rows = None
 
     # --------------------------------------------------- parity with the CPU oracle + its speed
     if single and not args.no_cpu_baseline:
@@ -884,6 +1115,14 @@ def main():
         pages_ctx[1].close()
         pages_ctx = None
 
+    # ---- the build's CPU loops beside build_secs, in a background thread while the GPU sections below go on
+    cpu_build, cpu_build_thread = {}, None
+    if single and not args.no_cpu_baseline and host_rows is not None and host_samples is not None:
+        import threading
+        cpu_build_thread = threading.Thread(target=cpu_build_kmeans,
+                                            args=(host_samples, lists, dtype, ops, args.seed + 2, cpu_build))
+        cpu_build_thread.start()
+
     # ------------------------------------------------------------- uniform data
     if single and not args.no_sweeps:
         try:
@@ -898,7 +1137,10 @@ def main():
                 s = timed_steps(lambda j: uix.search_batch(uq, p, k, want_tid=True, out=(out_d, out_s, out_t)), 5)
                 gd, _, _ = uix.search_batch(uq[:rq].contiguous(), p, k)
                 ures[str(p)] = {"qps": total_batch / s, "recall_at_10": recall_at_k(gd, ued, k)}
+            ubound = bound_mode_run(ctx, lambda j: uix.search_batch(uq, 10, k, want_tid=True, out=(out_d, out_s, out_t)),
+                                    5, total_batch) if metric == api.PGV_L2SQ else None
             line["uniform"] = {"data": "U[0,1)^%d (test/t/003_ivfflat_vector_build_recall.pl:60)" % dim,
+                               "bound_worst_case_probes_10": ubound,
                                "build_secs": ubt["total"], "kmeans_iterations": uit, "probes": ures,
                                "note": "uniform high-d data has no cluster structure: IVF recall at 1 % of the lists "
                                        "is low by construction (the reference skips such cases, t/003:101-104)"}
@@ -913,6 +1155,49 @@ def main():
             line["hnsw"] = hnsw_section(ctx, dev, args, failures)
         except Exception as e:
             line["hnsw"] = {"error": repr(e)}
+
+    # ------------------------------------------- the exact scan for a batch of queries (BASELINE configs[0])
+    if single and not args.no_sweeps and args.workload == "headline":
+        try:
+            line["exact_scan"] = exact_scan_section(ctx, dev, args, failures)
+        except Exception as e:
+            line["exact_scan"] = {"error": repr(e)}
+
+    # ------------------------------------------- the two completeness bounds of the MFMA L2 paths, side by side
+    if single and not args.no_sweeps and metric == api.PGV_L2SQ and not args.exact_scan:
+        try:
+            wc = bound_mode_run(ctx, step, 10, total_batch)
+            line["bound_modes"] = {
+                "statistical": {"qps": qps, "ms_per_step": elapsed / args.steps * 1e3,
+                                "scan_redo_queries_per_step": stats["scan_redo_queries"] / args.steps,
+                                "bound": "8 sqrt(d + 4) 2^-24 (|q| + |x|max)^2 (default)"},
+                "worst_case": wc,
+                "cost_of_worst_case": 1.0 - wc["qps"] / qps,
+                "note": "same index, same queries, same results; worst_case is the deterministic bound of "
+                        "include/pgv_hip.h (pgv_ctx_set_bound); uniform data and c5shard carry the same pair"}
+        except Exception as e:
+            line["bound_modes"] = {"error": repr(e)}
+
+    # ------------------------------------------- BASELINE's other IVFFlat configs on this GPU
+    if single and not args.no_sweeps and args.workload == "headline":
+        line["other_configs"] = {}
+        for wname in ("c2", "c3shard", "c5shard"):
+            try:
+                line["other_configs"][wname] = run_workload(ctx, dev, wname, args, failures)
+                log("%s: %.0f QPS, recall %.4f, roofline frac %.2f" % (
+                    wname, line["other_configs"][wname]["qps"], line["other_configs"][wname]["recall_at_10"],
+                    line["other_configs"][wname]["roofline"]["frac"]))
+            except Exception as e:
+                line["other_configs"][wname] = {"error": repr(e)}
+            torch.cuda.empty_cache()
+
+    if cpu_build_thread is not None:
+        cpu_build_thread.join()
+        cpu_build_assign(host_rows, dtype, ops, cpu_build)
+        cpu_build["gpu_build_secs"] = build_t["total"]
+        cpu_build["gpu_build_secs_pages"] = line.get("build_secs_pages")
+        line["cpu_build_baseline"] = cpu_build
+    host_rows = host_samples = None
 
     # ------------------------------------------------------------------ live PMC traffic
     if single and not args.no_traffic:

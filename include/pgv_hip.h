@@ -189,6 +189,23 @@ int			pgv_ctx_set_profiling(pgv_ctx * ctx, int on);
  * measurements, and indexes whose rows mix magnitudes so widely that every query would be redone).
  */
 int			pgv_ctx_set_exact_scan(pgv_ctx * ctx, int on);
+/*
+ * How the MFMA L2 paths (batched list scan, center ranking, assignment pre-filter, pgv_exact_topk) bound the
+ * distance between the expansion's value and the reference's fp32 sum((q - x)^2) when they decide that a candidate
+ * set is complete.  Row ids "must match the reference CPU path": with either bound every decision the bound cannot
+ * settle goes to the exact kernels; what differs is whether the bound itself can be exceeded.
+ *   PGV_BOUND_STATISTICAL (default)  8 sqrt(dim + 4) 2^-24 (|q| + |x|max)^2 -- the probabilistic model of a length-dim
+ *       fp32 summation (fails with probability ~ e^-32 per sum); 5-10 x narrower at 1536-3072 dimensions, which
+ *       keeps the recheck band at a few candidates and flags no query on ordinary data
+ *   PGV_BOUND_WORST_CASE  (gamma_(dim+1) + gamma_(dim+2)) (|q| + |x|max)^2, gamma_n = n 2^-24 / (1 - n 2^-24): the
+ *       deterministic bound of IEEE fp32 accumulation in any order, including the reference's own rounding.  Costs
+ *       more rechecks and more queries redone exactly (bench.py reports both settings side by side:
+ *       `bound_modes`); results are identical whenever the statistical bound held, which is every case measured.
+ * pgv_ctx_set_exact_scan(ctx, 1) remains the mode that uses no expansion at all.
+ */
+#define PGV_BOUND_STATISTICAL 0
+#define PGV_BOUND_WORST_CASE 1
+int			pgv_ctx_set_bound(pgv_ctx * ctx, int mode);
 int			pgv_ctx_reset_stats(pgv_ctx * ctx);
 int			pgv_ctx_get_stats(pgv_ctx * ctx, pgv_stats * out);
 
@@ -442,6 +459,19 @@ int			pgv_search_batch_sharded(pgv_comm * comm, pgv_index * local_index, const v
  */
 int			pgv_distance_batch(pgv_ctx * ctx, pgv_metric metric, pgv_dtype dtype, int dim,
 							   const void *query, const void *rows, int64_t n, float *out);
+
+/*
+ * The exact scan for a BATCH of queries: `ORDER BY embedding <op> $1 LIMIT k` without an index is one fmgr call per
+ * heap row (l2_distance src/vector.c:579-589, vector_negative_inner_product :610-620, l1_distance :715-725; the
+ * halfvec twins src/halfvec.c:605-748) feeding the executor's top-N heapsort.  nq queries against the same n rows:
+ * out_dist [nq x k] ascending kernel values (L2 squared / -ip / L1: the sqrt and the sign stay float8 post-ops of
+ * the caller, both monotonic), out_idx [nq x k] row indexes, ties by lower index; entries beyond n are +inf / -1.
+ * queries / rows / outputs may be host or device memory.  L2 and inner product batches of 64 queries or more run on
+ * the matrix cores (L2 with the exact tail of the list scan, see pgv_ctx_set_bound), everything else on the exact
+ * vector-ALU kernels.  k <= 4096.
+ */
+int			pgv_exact_topk(pgv_ctx * ctx, pgv_metric metric, pgv_dtype dtype, int dim, const void *queries, int nq,
+						   const void *rows, int64_t n, int k, float *out_dist, int64_t *out_idx);
 
 /*
  * cosine_distance as the operator computes it without an index (`<=>` in a sequential scan or an

@@ -200,6 +200,17 @@ int			ora_pages_meta(const uint8_t *pages, uint32_t nblocks, int *dim, int *list
 int			ora_pages_search(const uint8_t *pages, uint32_t nblocks, int ops, int dtype, const void *query,
 							 int probes, int k, uint64_t *out_tids, double *out_dist, int64_t *out_scanned);
 
+/* ---- bench.py's thread runners round the functions above (oracle_bench.c): pinned threads, spread placement ---- */
+int			ora_bench_cpus(void);
+void	   *ora_bench_alloc(size_t bytes);
+void		ora_bench_free(void *p, size_t bytes);
+int			ora_bench_spread_copy(void *dst, const void *src, size_t bytes, int nthreads);
+int			ora_bench_search(const ora_ivf_index * ix, const uint8_t *pages, uint32_t nblocks, int ops, int dtype,
+							 const void *queries, size_t query_bytes, int nq, int probes, int k, int nthreads,
+							 double seconds, uint64_t *out_tids, double *out_dist, int *out_count, double *out_stats);
+int			ora_bench_assign(int ops, int dtype, int dim, const void *centers, int k, const void *rows, int64_t n,
+							 int nthreads, int32_t *out_list, double *out_seconds);
+
 #ifdef __cplusplus
 }
 #endif

@@ -105,6 +105,16 @@ class Oracle:
         L.ora_kmeans.argtypes = [I, I, I, P, I, P, I, C.POINTER(Prng), P]
         L.ora_kmeans_lloyd_assign.restype = None
         L.ora_kmeans_lloyd_assign.argtypes = [I, I, I, P, I, P, I, P, P]
+        if hasattr(L, "ora_bench_search"):
+            L.ora_bench_cpus.restype = I
+            L.ora_bench_alloc.restype = P
+            L.ora_bench_alloc.argtypes = [C.c_size_t]
+            L.ora_bench_free.restype = None
+            L.ora_bench_free.argtypes = [P, C.c_size_t]
+            L.ora_bench_spread_copy.argtypes = [P, P, C.c_size_t, I]
+            L.ora_bench_search.argtypes = [C.POINTER(IvfIndexStruct), P, C.c_uint32, I, I, P, C.c_size_t, I, I, I, I, D,
+                                           P, P, P, P]
+            L.ora_bench_assign.argtypes = [I, I, I, P, I, P, I64, I, P, C.POINTER(D)]
         self.has_hnsw = hasattr(L, "ora_hnsw_build")
         if self.has_hnsw:
             L.ora_hnsw_build.restype = P
@@ -236,6 +246,52 @@ class Oracle:
         if n < 0:
             raise ValueError("not an IVFFlat page image")
         return tids[:n], dist[:n], scanned.value
+
+    # ---- bench.py's thread runners (oracle_bench.c) ---------------------
+    def spread(self, a, nthreads):
+        """a copy of the array in pages spread round the machine's memory nodes (first touch by pinned threads);
+        returns (ndarray view, release())"""
+        a = np.ascontiguousarray(a)
+        nbytes = max(a.nbytes, 1)
+        p = self.lib.ora_bench_alloc(nbytes)
+        if not p:
+            raise MemoryError("ora_bench_alloc(%d)" % nbytes)
+        self.lib.ora_bench_spread_copy(p, a.ctypes.data, a.nbytes, nthreads)
+        buf = (C.c_char * nbytes).from_address(p)
+        view = np.frombuffer(buf, dtype=a.dtype, count=a.size).reshape(a.shape)
+        return view, (lambda: self.lib.ora_bench_free(p, nbytes))
+
+    def bench_search(self, ix, queries, probes, k, nthreads, seconds, pages=None, ops=0, dtype=0):
+        """nthreads pinned threads answering the queries round-robin for `seconds` (each at least once) ->
+        (answers [(tids, dist)] per query, queries answered, wall seconds)"""
+        q = np.ascontiguousarray(queries)
+        nq = q.shape[0]
+        tids = np.zeros((nq, k), dtype=np.uint64)
+        dist = np.zeros((nq, k), dtype=np.float64)
+        cnt = np.zeros(nq, dtype=np.int32)
+        stats = np.zeros(2, dtype=np.float64)
+        if pages is None:
+            rc = self.lib.ora_bench_search(C.byref(ix), None, 0, ix.ops, ix.dtype, _p(q), q.strides[0], nq, probes, k,
+                                           nthreads, seconds, _p(tids), _p(dist), _p(cnt), _p(stats))
+        else:
+            ptr, nblocks = pages
+            rc = self.lib.ora_bench_search(None, ptr, nblocks, ops, dtype, _p(q), q.strides[0], nq, probes, k, nthreads,
+                                           seconds, _p(tids), _p(dist), _p(cnt), _p(stats))
+        if rc != 0:
+            raise RuntimeError("ora_bench_search rc %d" % rc)
+        answers = [(tids[i, :cnt[i]].copy(), dist[i, :cnt[i]].copy()) for i in range(nq)]
+        return answers, int(stats[0]), float(stats[1])
+
+    def bench_assign(self, ops, dtype, centers, rows, nthreads):
+        """rows split between nthreads pinned workers, each running the argmin loop -> (lists, wall seconds)"""
+        centers, rows = self.arr(centers, dtype), self.arr(rows, dtype)
+        out = np.empty(rows.shape[0], dtype=np.int32)
+        secs = C.c_double()
+        rc = self.lib.ora_bench_assign(ops, dtype, rows.shape[1], _p(centers), centers.shape[0], _p(rows), rows.shape[0],
+                                       nthreads, _p(out), C.byref(secs))
+        if rc != 0:
+            raise RuntimeError("ora_bench_assign rc %d" % rc)
+        return out, secs.value
 
     def assign(self, ops, dtype, centers, rows):
         centers, rows = self.arr(centers, dtype), self.arr(rows, dtype)

@@ -28,6 +28,7 @@ PGV_OK, PGV_ERR_ARG, PGV_ERR_DIMS, PGV_ERR_DEVICE, PGV_ERR_NOMEM, PGV_ERR_STATE,
 PGV_F32, PGV_F16 = 0, 1
 PGV_L2SQ, PGV_NEG_IP, PGV_L1 = 0, 1, 2
 PGV_OPS_L2, PGV_OPS_IP, PGV_OPS_COSINE = 0, 1, 2
+PGV_BOUND_STATISTICAL, PGV_BOUND_WORST_CASE = 0, 1
 
 # every symbol include/pgv_hip.h declares (tests check the library exports each)
 SYMBOLS = [
@@ -42,7 +43,7 @@ SYMBOLS = [
     "pgv_comm_unique_id", "pgv_comm_create", "pgv_comm_create_custom", "pgv_comm_destroy", "pgv_comm_size",
     "pgv_comm_rank", "pgv_kmeans_sharded", "pgv_search_batch_sharded",
     "pgv_device_memory", "pgv_pinned_register", "pgv_pinned_unregister", "pgv_index_export", "pgv_index_import",
-    "pgv_index_tids", "pgv_hnsw_export", "pgv_hnsw_import",
+    "pgv_index_tids", "pgv_hnsw_export", "pgv_hnsw_import", "pgv_exact_topk", "pgv_ctx_set_bound",
 ]
 
 
@@ -108,6 +109,8 @@ def _load():
     lib.pgv_index_import.argtypes = [P, P, C.POINTER(P)]
     lib.pgv_index_tids.argtypes = [P, P, I64, P]
     lib.pgv_hnsw_export.argtypes = [P, P]
+    lib.pgv_exact_topk.argtypes = [P, I, I, I, P, I, P, I64, I, P, P]
+    lib.pgv_ctx_set_bound.argtypes = [P, I]
     lib.pgv_hnsw_import.argtypes = [P, P, C.POINTER(P)]
     lib.pgv_device_memory.argtypes = [I, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
     lib.pgv_pinned_register.argtypes = [P, C.c_size_t]

@@ -115,6 +115,10 @@ class Context:
         """Keep batched L2 scans on the exact vector-ALU kernels (no matrix-core pre-filter)."""
         check(lib.pgv_ctx_set_exact_scan(self.h, 1 if on else 0))
 
+    def set_bound(self, worst_case):
+        """pgv_ctx_set_bound: the rounding bound the MFMA L2 paths prove completeness with (statistical / worst case)"""
+        check(lib.pgv_ctx_set_bound(self.h, _lib.PGV_BOUND_WORST_CASE if worst_case else _lib.PGV_BOUND_STATISTICAL))
+
     def reset_stats(self):
         check(lib.pgv_ctx_reset_stats(self.h))
 
@@ -428,6 +432,18 @@ def distance_batch(ctx, metric, dtype, dim, query, rows):
     out = _empty_like_kind(rows, (n,), np.float32)
     check(lib.pgv_distance_batch(ctx.h, metric, dtype, dim, ptr(query), ptr(rows), n, ptr(out)))
     return out
+
+
+def exact_topk(ctx, metric, dtype, dim, queries, rows, k, out=None):
+    """pgv_exact_topk: the index-less `ORDER BY <op> LIMIT k` for a batch of queries -> (dist [nq x k], idx [nq x k])"""
+    queries = as_dtype(queries, dtype)
+    rows = as_dtype(rows, dtype)
+    nq, n = int(queries.shape[0]), int(rows.shape[0])
+    dist, idx = out if out is not None else (_empty_like_kind(queries, (nq, k), np.float32),
+                                            _empty_like_kind(queries, (nq, k), np.int64))
+    check(lib.pgv_exact_topk(ctx.h, metric, dtype, dim, ptr(queries), nq, ptr(rows) if n else None, n, int(k),
+                             ptr(dist), ptr(idx)))
+    return dist, idx
 
 
 def kmeans(ctx, ops, dtype, dim, samples, k, rng=None, max_iterations=500, want_closest=True):

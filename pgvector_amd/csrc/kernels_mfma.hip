@@ -21,7 +21,10 @@
 //   gamma * (|c|^2 + 2 |a||c|) with gamma = 8 * sqrt(dim + 4) * 2^-24 -- the probabilistic
 //   bound of a length-dim fp32 summation (Higham & Mary 2019: lambda * sqrt(n) * u fails with
 //   probability ~ exp(-lambda^2 / 2) per sum; lambda = 8), an order of magnitude tighter than
-//   the worst-case n * u and still far above any error seen.  A row whose 4th-best pre-filter
+//   the worst-case n * u and still far above any error seen.  pgv_ctx_set_bound(PGV_BOUND_WORST_CASE)
+//   replaces it by the deterministic gamma_(dim+1) (|c|^2 + 2 |a||c|) + gamma_(dim+2) (|a| + |c|)^2, the second
+//   term being the reference's own fp32 rounding of sum((a-c)^2) (expansion_bound, pgv_internal.h).
+//   A row whose 4th-best pre-filter
 //   value is not more than twice that bound above its best (more than 4 centers could be the
 //   true minimum) is put on a list and redone by the exact vector-ALU kernel.  Exact ties
 //   (duplicate centers, integer-valued data) have a zero gap and therefore always reach the
@@ -151,7 +154,8 @@ template <typename T, int MODE>
 __global__ __launch_bounds__(MfmaCfg<T>::WM *MfmaCfg<T>::WN * 64, 2) void mfma_argmin_kernel(
     const char *__restrict__ rows, int64_t n, const char *__restrict__ centers, int k, int nvec,
     const float *__restrict__ bias, const char *__restrict__ zeros16, int32_t *__restrict__ out_idx,
-    float *__restrict__ out_val, const unsigned *__restrict__ cmax2_bits, float gamma, int *__restrict__ u_count,
+    float *__restrict__ out_val, const unsigned *__restrict__ cmax2_bits, float gamma, float gamma_x,
+    int *__restrict__ u_count,
     int32_t *__restrict__ u_rows, int32_t *__restrict__ u_cand, float *__restrict__ u_val) {
     using C = MfmaCfg<T>;
     constexpr int TM = C::TM, TN = C::TN;
@@ -339,7 +343,8 @@ __global__ __launch_bounds__(MfmaCfg<T>::WM *MfmaCfg<T>::WN * 64, 2) void mfma_a
             // sees every center anyway)
             const float cm2 = __uint_as_float(*cmax2_bits);
             const float x2 = mx[j * 2] + mx[j * 2 + 1];
-            const float margin = 2.f * gamma * (cm2 + 2.f * sqrtf(x2 * cm2));
+            const float cross = 2.f * sqrtf(x2 * cm2);
+            const float margin = 2.f * (gamma * (cm2 + cross) + gamma_x * (x2 + cm2 + cross));
             if (sv[0] < INFINITY && sv[1] - sv[0] > margin) {
                 out_idx[r] = sid[0];
             } else {
@@ -386,7 +391,8 @@ __global__ __launch_bounds__(256) void recheck_kernel(const char *__restrict__ r
                                                       const int32_t *__restrict__ u_cand,
                                                       const float *__restrict__ u_val,
                                                       const unsigned *__restrict__ cmax2_bits, float gamma,
-                                                      int32_t *__restrict__ out_idx, int *__restrict__ fb_count,
+                                                      float gamma_x, int32_t *__restrict__ out_idx,
+                                                      int *__restrict__ fb_count,
                                                       int32_t *__restrict__ fb_rows,
                                                       unsigned long long *__restrict__ packed) {
     const int64_t p = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -427,7 +433,8 @@ __global__ __launch_bounds__(256) void recheck_kernel(const char *__restrict__ r
     out_idx[r] = bid == 0x7fffffff ? 0 : bid;
     if (k > kCand) {
         const float cm2 = __uint_as_float(*cmax2_bits);
-        const float margin = 2.f * gamma * (cm2 + 2.f * sqrtf(xx * cm2));
+        const float cross = 2.f * sqrtf(xx * cm2);
+        const float margin = 2.f * (gamma * (cm2 + cross) + gamma_x * (xx + cm2 + cross));
         const float v0 = u_val[p * kCand], v3 = u_val[p * kCand + kCand - 1];
         if (!(v3 < INFINITY && v3 - v0 > margin)) {
             packed[r] = ~0ull;
@@ -484,7 +491,7 @@ __global__ void add_count_kernel(const int *u_count, const int *fb_count, double
 
 struct L2Lists {  // device buffers of the L2 pipeline
     const unsigned *cmax2 = nullptr;
-    float gamma = 0.f;
+    float gamma = 0.f, gamma_x = 0.f;
     int *u_count = nullptr;
     int32_t *u_rows = nullptr, *u_cand = nullptr;
     float *u_val = nullptr;
@@ -503,7 +510,7 @@ int launch_mfma_t(pgv_ctx *ctx, const RowGeom &g, const void *rows, int64_t n, c
     const int64_t grid = (n + BN - 1) / BN;
     hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(threads), lds, ctx->stream, static_cast<const char *>(rows), n,
                        static_cast<const char *>(centers), k, g.nvec, bias, static_cast<const char *>(ctx->zeros.p),
-                       out_idx, out_val, l2.cmax2, l2.gamma, l2.u_count, l2.u_rows, l2.u_cand, l2.u_val);
+                       out_idx, out_val, l2.cmax2, l2.gamma, l2.gamma_x, l2.u_count, l2.u_rows, l2.u_cand, l2.u_val);
     PGV_HIP(hipGetLastError());
     return PGV_OK;
 }
@@ -536,7 +543,9 @@ int launch_mfma_mode(pgv_ctx *ctx, int mode, const RowGeom &g, const void *rows,
                        static_cast<const char *>(centers), k, g.nvec, bias, cmax2);
     L2Lists l2;
     l2.cmax2 = cmax2;
-    l2.gamma = 8.f * sqrtf((float)(g.ld + 4)) * 5.9604645e-8f;  // 8 sqrt(dim + 4) 2^-24, see the header
+    const ExpansionBound eb = expansion_bound(ctx, g.ld);  // 8 sqrt(dim + 4) 2^-24 (see the header), or the worst case
+    l2.gamma = eb.gamma;
+    l2.gamma_x = eb.gamma_exact;
     l2.u_count = u_count;
     l2.u_rows = u_rows;
     l2.u_cand = u_cand;
@@ -545,7 +554,7 @@ int launch_mfma_mode(pgv_ctx *ctx, int mode, const RowGeom &g, const void *rows,
     // the lists' lengths stay on the device: grids cover the worst case, surplus workgroups leave at once
     hipLaunchKernelGGL(recheck_kernel<T>, dim3((unsigned)((n + 3) / 4)), dim3(256), 0, ctx->stream,
                        static_cast<const char *>(rows), static_cast<const char *>(centers), k, g.nvec, u_count, u_rows,
-                       u_cand, u_val, cmax2, l2.gamma, out_idx, fb_count, fb_rows, packed);
+                       u_cand, u_val, cmax2, l2.gamma, l2.gamma_x, out_idx, fb_count, fb_rows, packed);
     PGV_HIP(hipGetLastError());
     if (k > kCand) {
         PGV_TRY(launch_argmin_listed(ctx, 0, dtype, g, rows, n, centers, k, fb_rows, fb_count, packed));

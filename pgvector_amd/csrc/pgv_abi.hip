@@ -5,6 +5,8 @@
 #include "pgv_internal.h"
 
 #include <dlfcn.h>
+#include <linux/futex.h>
+#include <sys/syscall.h>
 #include <unistd.h>
 
 #include <algorithm>
@@ -501,7 +503,7 @@ void pgv_ctx_destroy(pgv_ctx *ctx) {
                  &ctx->plan_a, &ctx->plan_b, &ctx->plan_c, &ctx->plan_d, &ctx->dist_mat,
                  &ctx->sel_a, &ctx->sel_b, &ctx->km_a, &ctx->km_b, &ctx->km_c, &ctx->km_d,
                  &ctx->km_e, &ctx->km_f, &ctx->km_g, &ctx->stats_dev, &ctx->mf_a, &ctx->mf_b, &ctx->mf_c,
-                 &ctx->zeros, &ctx->ms_a, &ctx->ms_b, &ctx->dense_plan};
+                 &ctx->zeros, &ctx->ms_a, &ctx->ms_b, &ctx->dense_plan, &ctx->xt_norms};
     for (DBuf *b : d) b->release();
     ctx->h_a.release();
     ctx->h_b.release();
@@ -550,6 +552,14 @@ int pgv_ctx_set_profiling(pgv_ctx *ctx, int on) {
 int pgv_ctx_set_exact_scan(pgv_ctx *ctx, int on) {
     if (!ctx) PGV_FAIL(PGV_ERR_ARG, "pgv_ctx_set_exact_scan: ctx is NULL");
     ctx->no_mfma_scan = on != 0;
+    return PGV_OK;
+}
+
+int pgv_ctx_set_bound(pgv_ctx *ctx, int mode) {
+    if (!ctx) PGV_FAIL(PGV_ERR_ARG, "pgv_ctx_set_bound: ctx is NULL");
+    if (mode != PGV_BOUND_STATISTICAL && mode != PGV_BOUND_WORST_CASE)
+        PGV_FAIL(PGV_ERR_ARG, "pgv_ctx_set_bound: unknown mode %d", mode);
+    ctx->bound_mode = mode;
     return PGV_OK;
 }
 
@@ -925,7 +935,6 @@ struct ApproxScratch {
     }
 };
 
-static float expansion_gamma(int dim) { return 8.f * std::sqrt((float)dim + 4.f) * 5.9604645e-8f; }
 
 // device-side core of GetScanLists for nq staged queries
 static int rank_lists_dev(pgv_index *ix, const void *q_dev, int nq, int maxprobes,
@@ -958,7 +967,7 @@ static int rank_lists_dev(pgv_index *ix, const void *q_dev, int nq, int maxprobe
         // a center's position in the matrix row is its id: cand_pos serves as the slots
         // the center ids leave as the int32 list ids the callers want (no conversion pass)
         PGV_TRY(launch_batch_recheck(ctx, xr, q_dev, nq, cand, maxprobes, sc.cand_val, sc.cand_pos, sc.cand_pos, nullptr,
-                                     ix->nlists, expansion_gamma(ix->dim), dist, nullptr, nullptr, sc.flags,
+                                     ix->nlists, expansion_bound(ctx, ix->geom.ld).total(), dist, nullptr, nullptr, sc.flags,
                                      out_lists_dev));
         PGV_TRY(launch_batch_fix(ctx, xr, q_dev, nq, nullptr, nullptr, 0, nullptr, ix->nlists, sc.flags, mat, maxprobes,
                                  dist, nullptr, nullptr, out_lists_dev));
@@ -1150,7 +1159,7 @@ static int scan_batch_dev(pgv_index *ix, const void *q_dev, int nq, const int32_
     if (approx) {
         // k' candidates by the expansion, their exact distances, the head; queries whose candidate
         // set cannot be proven complete (flags) take the exact pass over their whole segment
-        const float gamma = expansion_gamma(ix->dim);
+        const float gamma = expansion_bound(ctx, ix->geom.ld).total();
         PGV_TRY(launch_topk_segments(ctx, seg_vals, plan.seg_start, nq, 0, kprime, cand_val, cand_pos, flags + nq));
         const ExactRows xr{ix->vectors, ix->tids, ix->list_offsets, ix->geom, ix->dtype,
                            reinterpret_cast<const unsigned *>(ix->row_norms + ix->nrows)};
@@ -1226,6 +1235,40 @@ struct QueryHeadHost {  // mirrors QueryHead of kernels_query.hip
     long long total;
     int count;
     unsigned seq;
+};
+
+// Admission of single-query scans (threads of ONE process; a Postgres backend is a process of its own and has one
+// scan in flight at most).  Measured on MI355X (profiles/r03_single_query_concurrency.md): the device runs ~2.5
+// kernels of different streams at a time (4 hardware queues), 16 backends reach 48 k QPS and every backend beyond
+// that LOWERS the total (32: 32 k, 64: 16 k -- co-running kernels slow each other down and the runtime interleaves
+// barrier packets for every stream switch on a queue).  So at most g_scan_gate_width scan+head pairs are in flight
+// per process; the others sleep on a futex.  PGV_MAX_INFLIGHT_SCANS overrides the width (0 = no gate).
+static int g_scan_gate_width = -1;
+static int g_scan_inflight = 0;  // also the futex word
+static void scan_gate_enter() {
+    if (g_scan_gate_width < 0) {
+        const char *e = getenv("PGV_MAX_INFLIGHT_SCANS");
+        __atomic_store_n(&g_scan_gate_width, e ? atoi(e) : 16, __ATOMIC_RELAXED);
+    }
+    const int width = g_scan_gate_width;
+    if (width <= 0) return;
+    for (;;) {
+        int cur = __atomic_load_n(&g_scan_inflight, __ATOMIC_RELAXED);
+        if (cur < width) {
+            if (__atomic_compare_exchange_n(&g_scan_inflight, &cur, cur + 1, true, __ATOMIC_ACQUIRE, __ATOMIC_RELAXED)) return;
+            continue;
+        }
+        syscall(SYS_futex, &g_scan_inflight, FUTEX_WAIT_PRIVATE, cur, nullptr, nullptr, 0);
+    }
+}
+static void scan_gate_leave() {
+    if (g_scan_gate_width <= 0) return;
+    const int before = __atomic_fetch_sub(&g_scan_inflight, 1, __ATOMIC_RELEASE);
+    if (before >= g_scan_gate_width) syscall(SYS_futex, &g_scan_inflight, FUTEX_WAKE_PRIVATE, 1, nullptr, nullptr, 0);
+}
+struct ScanGate {
+    ScanGate() { scan_gate_enter(); }
+    ~ScanGate() { scan_gate_leave(); }
 };
 
 // the head record lands in pinned host memory; its seq word is written last.  Spin on it for a
@@ -1338,6 +1381,7 @@ int pgv_query_scan(pgv_query *q, int first, int nprobes, int head, float *out_di
     const int64_t bound = ix->len_prefix[nprobes];  // rows of the nprobes longest lists
     PGV_TRY(q->seg.ensure(sizeof(float) * (size_t)(bound + 4)));  // + one float4 of slack for the vector loads of the selection
     const unsigned seq = ++q->seq ? q->seq : ++q->seq;  // never 0: the cleared record's value
+    ScanGate gate;  // held until the head is back (every return below)
     PGV_TRY(launch_query_scan(ctx, ix, q->is_null ? nullptr : q->q_dev.p, q->lists + first, nprobes, bound,
                               q->seg.as<float>()));
     PGV_TRY(launch_query_head(ctx, ix, q->seg.as<float>(), q->lists + first, nprobes, 0, head, q->head_pinned, seq));
@@ -1455,6 +1499,73 @@ int pgv_distance_batch(pgv_ctx *ctx, pgv_metric metric, pgv_dtype dtype, int dim
     PGV_TRY(dense_scan(ctx, metric, dtype, g, r_dev, n, q_dev, 1, 0, od.as<float>()));
     bool need = false;
     PGV_TRY(od.finish(ctx, &need));
+    return sync_if(ctx, need);
+}
+
+// The sequential scan + top-N heapsort of `ORDER BY embedding <op> $1 LIMIT k` without an index (the per-row
+// l2_distance / vector_negative_inner_product / l1_distance calls of src/vector.c:579-697 and their halfvec twins),
+// for a batch of queries against the same rows: one dense "list".  L2 and inner product run on the matrix cores
+// (L2: candidates by the expansion, the reference's sum((q - x)^2) for those, queries that cannot be proven
+// complete redone exactly -- the scheme of the list scan), L1 and small batches on the vector-ALU kernels.
+int pgv_exact_topk(pgv_ctx *ctx, pgv_metric metric, pgv_dtype dtype, int dim, const void *queries, int nq,
+                   const void *rows, int64_t n, int k, float *out_dist, int64_t *out_idx) {
+    if (!ctx || !out_dist || !out_idx) PGV_FAIL(PGV_ERR_ARG, "pgv_exact_topk: ctx/out_dist/out_idx is NULL");
+    PGV_TRY(check_common(dtype, dim));
+    PGV_TRY(check_metric(metric));
+    if (nq < 0 || n < 0) PGV_FAIL(PGV_ERR_ARG, "pgv_exact_topk: nq/n < 0");
+    if (k < 1 || k > 4096) PGV_FAIL(PGV_ERR_ARG, "pgv_exact_topk: k %d outside 1..4096", k);
+    if (n > 0xffffffffll) PGV_FAIL(PGV_ERR_ARG, "pgv_exact_topk: more than 2^32 rows");
+    if (nq == 0) return PGV_OK;
+    if (!queries || (n > 0 && !rows)) PGV_FAIL(PGV_ERR_ARG, "pgv_exact_topk: queries/rows is NULL");
+    PGV_HIP(hipSetDevice(ctx->device));
+    const RowGeom g = row_geom(dim, dtype);
+    const size_t row_bytes = (size_t)g.ld * elem_size(dtype);
+    const void *q_dev, *r_dev = nullptr;
+    PGV_TRY(stage_rows(ctx, queries, nq, dim, dtype, g, ctx->q_stage, &q_dev));
+    if (n > 0) PGV_TRY(stage_rows(ctx, rows, n, dim, dtype, g, ctx->rows_stage, &r_dev));
+    OutArg od, oi;
+    PGV_TRY(od.init(out_dist, sizeof(float) * (size_t)nq * k, ctx->out_stage));
+    PGV_TRY(oi.init(out_idx, sizeof(int64_t) * (size_t)nq * k, ctx->out_stage2));
+
+    // the distance matrix of a query chunk stays under 1 GiB
+    int chunk = n > 0 ? (int)std::min<int64_t>(nq, std::max<int64_t>(1, ((int64_t)1 << 28) / n)) : nq;
+    if (chunk >= 64) chunk = chunk / 32 * 32;
+    const int kprime = k <= 8 ? 32 : (4 * k <= 256 ? 4 * k : k + 64);
+    const bool l2_mfma = metric == PGV_L2SQ && kprime <= 256 && n > kprime;
+    const bool mfma_ok = !ctx->no_mfma_scan && n >= 64 && (metric == PGV_NEG_IP || l2_mfma);
+    float *norms = nullptr;
+    if (mfma_ok && l2_mfma && nq >= 64) {
+        PGV_TRY(ctx->xt_norms.ensure(sizeof(float) * ((size_t)n + 1)));
+        norms = ctx->xt_norms.as<float>();
+        PGV_HIP(hipMemsetAsync(norms + n, 0, sizeof(float), ctx->stream));
+        PGV_TRY(launch_row_norms(ctx, dtype, g, r_dev, n, norms, reinterpret_cast<unsigned *>(norms + n)));
+    }
+    for (int q0 = 0; q0 < nq; q0 += chunk) {
+        const int cn = std::min(chunk, nq - q0);
+        const char *qp = static_cast<const char *>(q_dev) + (size_t)q0 * row_bytes;
+        float *cd = od.as<float>() + (size_t)q0 * k;
+        int64_t *ci = oi.as<int64_t>() + (size_t)q0 * k;
+        PGV_TRY(ctx->dist_mat.ensure(sizeof(float) * std::max<size_t>((size_t)cn * (size_t)n, 4)));
+        float *mat = ctx->dist_mat.as<float>();
+        const bool mfma = mfma_ok && cn >= 64;
+        if (mfma && metric == PGV_L2SQ) {
+            ApproxScratch sc;
+            PGV_TRY(sc.carve(ctx, ctx->ms_b, cn, kprime));
+            PGV_TRY(dense_scan(ctx, metric, dtype, g, r_dev, n, qp, cn, n, mat, true, norms, nullptr));
+            PGV_TRY(launch_topk_segments(ctx, mat, nullptr, cn, n, kprime, sc.cand_val, sc.cand_pos, sc.flags + cn));
+            const ExactRows xr{r_dev, nullptr, nullptr, g, dtype, reinterpret_cast<const unsigned *>(norms + n)};
+            // a row's position in the matrix row is its index: cand_pos serves as the slots
+            PGV_TRY(launch_batch_recheck(ctx, xr, qp, cn, kprime, k, sc.cand_val, sc.cand_pos, sc.cand_pos, nullptr, n,
+                                         expansion_bound(ctx, g.ld).total(), cd, ci, nullptr, sc.flags));
+            PGV_TRY(launch_batch_fix(ctx, xr, qp, cn, nullptr, nullptr, 0, nullptr, n, sc.flags, mat, k, cd, ci, nullptr));
+        } else {
+            PGV_TRY(dense_scan(ctx, metric, dtype, g, r_dev, n, qp, cn, n, mat, mfma, nullptr, nullptr));
+            PGV_TRY(launch_topk_segments(ctx, mat, nullptr, cn, n, k, cd, ci));
+        }
+    }
+    bool need = false;
+    PGV_TRY(od.finish(ctx, &need));
+    PGV_TRY(oi.finish(ctx, &need));
     return sync_if(ctx, need);
 }
 

@@ -8,6 +8,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <cmath>
 #include <vector>
 
 #include "../../include/pgv_hip.h"
@@ -122,6 +123,8 @@ struct pgv_ctx {
     // streaming kernel, resolved lazily in pgv_ctx_get_stats
     bool profiling = false;
     bool no_mfma_scan = false;  // pgv_ctx_set_exact_scan
+    int bound_mode = 0;         // pgv_ctx_set_bound: PGV_BOUND_STATISTICAL / PGV_BOUND_WORST_CASE
+    pgv::DBuf xt_norms;         // pgv_exact_topk: |row|^2 of the caller's rows
     std::vector<hipEvent_t> ev_pool;  // start/stop pairs
     size_t ev_used = 0;
     double scan_ms = 0.0;
@@ -199,6 +202,26 @@ struct pgv_hnsw {
 };
 
 namespace pgv {
+
+// How far an MFMA L2 value |x|^2 - 2 q.x (fp32 accumulation of a length-dim dot product, fp32 row norm) can be from
+// the reference's fp32 sum((q - x)^2) of the same pair, as coefficients of (|q| + |x|)^2:
+//   statistical  8 sqrt(dim + 4) u: the probabilistic bound of a length-dim fp32 summation (Higham & Mary 2019,
+//                lambda sqrt(n) u fails with probability ~ exp(-lambda^2 / 2) per sum, lambda = 8), u = 2^-24
+//   worst case   gamma_(dim+1) for the expansion (dot product: gamma_dim |q||x|, row norm: gamma_dim |x|^2, one final
+//                rounding) PLUS gamma_(dim+2) for the reference's own value (dim terms of two roundings each, all
+//                positive, so relative), gamma_n = n u / (1 - n u) -- deterministic for IEEE fp32 accumulation in any
+//                order (Higham, Accuracy and Stability of Numerical Algorithms, Lemma 3.1 / eq. 3.5)
+struct ExpansionBound {
+    float gamma;        // of |x|^2 + 2 |q||x| (expansion terms)
+    float gamma_exact;  // of (|q| + |x|)^2 (the exact value's own rounding; 0 in the statistical model)
+    float total() const { return gamma + gamma_exact; }
+};
+inline ExpansionBound expansion_bound(const pgv_ctx *ctx, int dim) {
+    constexpr float u = 5.9604645e-8f;
+    if (ctx->bound_mode == 0) return {8.f * std::sqrt((float)dim + 4.f) * u, 0.f};
+    const float n1 = (float)(dim + 1) * u, n2 = (float)(dim + 2) * u;
+    return {n1 / (1.f - n1), n2 / (1.f - n2)};
+}
 
 // ---------------------------------------------------------------- launchers
 // kernels_scan.hip: stream rows, score them against small groups of queries

@@ -1,21 +1,17 @@
-"""Multi-GPU partitioning of the IVFFlat path: which rank owns which list, how
-a rank-local index image is cut out of the global one, how per-rank top-k
-answers are merged, and the k-means iteration with its all-reduce.
+"""Multi-GPU partitioning of the IVFFlat path as the HARNESS needs it (bench.py, tests): which rank owns which
+list, how a rank-local index image is cut out of a global one or assembled from row shards, how per-rank exact
+answers merge into a ground truth.
 
-Pure index/tensor bookkeeping on torch tensors (CPU or HBM) plus
-torch.distributed collectives (backend "nccl" = RCCL over xGMI on the GPU box,
-"gloo" in the CPU tests).  Distances are never computed here: the callers pass
-in the functions that do (libpgv_hip on a GPU; the tests plug in the oracle).
+The path's own exchanges live in the C library: pgv_kmeans_sharded (one fused all-reduce per Lloyd iteration) and
+pgv_search_batch_sharded (probe-list and top-k all-gathers, device merge) over pgv_comm (RCCL, or the caller's
+collectives) -- include/pgv_hip.h.  What is left here is index/tensor bookkeeping on torch tensors plus the one
+exchange the BUILD needs that the library does not own: rows move to the rank that owns their list
+(src/ivfbuild.c:830-966: parallel workers feed one shared tuplesort; here every rank sorts its own lists).
 
 Scheme
-  scan   lists are disjoint, so list l lives on rank l % world.  Centers are
-         replicated (<= 50 MB); every rank ranks all centers, scans the probed
-         lists it owns and contributes a local top-k; one all-gather of
-         k x (distance, tid) per query and a k-way merge finish the query.
-  build  k-means samples and heap rows are sharded by row, centers replicated:
-         per Lloyd iteration one all-reduce of the per-center fp32 sums [k x d],
-         counts [k] and the change counter; assignment of heap rows needs no
-         collective beyond gathering the list ids.
+  scan   lists are disjoint, so list l lives on rank l % world.  Centers are replicated (<= 50 MB).
+  build  heap rows and k-means samples are sharded by row; after assignment one all-to-all brings every row to the
+         owner of its list, which lays its lists out list-major in heap (global row) order.
 """
 import torch
 import torch.distributed as dist
@@ -85,60 +81,6 @@ def local_index_arrays(vectors_sorted, tids_sorted, list_offsets, r, world_size)
     return vectors_sorted[keep].contiguous(), tids_sorted[keep].contiguous(), local_off
 
 
-def gather_probe_lists(local_lists):
-    """every rank ranked its own slice of the query batch against the replicated centers;
-    concatenate the slices' probe lists in rank order -> [nq_total x probes] on every rank"""
-    if world() == 1:
-        return local_lists
-    return torch.cat(_all_gather(local_lists), dim=0)
-
-
-def merge_topk(local_dist, local_tid, k):
-    """All-gather every rank's [nq x k] (distance, tid) and keep the k nearest per
-    query: the final top-k merge (ascending; ties: lower rank first, then the
-    rank's own order, which is deterministic).  +inf / -1 padding sorts last."""
-    w = world()
-    if w == 1:
-        return local_dist, local_tid
-    d = torch.cat(_all_gather(local_dist), dim=1)
-    t = torch.cat(_all_gather(local_tid), dim=1)
-    order = torch.sort(d, dim=1, stable=True).indices[:, :k]
-    return torch.gather(d, 1, order), torch.gather(t, 1, order)
-
-
-def allreduce_lloyd(sums, counts, changes):
-    """the one exchange of a Lloyd iteration: k*d*4 + k*4 + 8 bytes per rank"""
-    if world() > 1:
-        _all_reduce_sum(sums)
-        _all_reduce_sum(counts)
-        _all_reduce_sum(changes)
-    return sums, counts, changes
-
-
-def sharded_kmeans(samples_local, init_centers, partial_fn, finish_fn, max_iterations=500, on_iter=None):
-    """Lloyd iterations with sharded samples and replicated centers.
-
-    partial_fn(samples_local, centers, closest) -> (sums [k x d] fp32, counts [k] i32, changes [1] i64)
-        (closest updated in place; libpgv_hip's pgv_lloyd_partial)
-    finish_fn(sums, counts, iteration) -> centers   (pgv_lloyd_finish; same on every rank)
-    Stops like src/ivfkmeans.c:482-483: an iteration other than the first with no
-    reassignment anywhere.  Returns (centers, closest_local, iterations).
-    """
-    centers = init_centers
-    closest = torch.full((samples_local.shape[0],), -1, dtype=torch.int32, device=samples_local.device)
-    it = 0
-    for it in range(max_iterations):
-        sums, counts, changes = partial_fn(samples_local, centers, closest)
-        local_changes = int(changes.item()) if on_iter else 0
-        sums, counts, changes = allreduce_lloyd(sums, counts, changes)
-        if on_iter:
-            on_iter(it, local_changes, int(changes.item()), int(counts.sum().item()))
-        centers = finish_fn(sums, counts, it)
-        if int(changes.item()) == 0 and it != 0:
-            break
-    return centers, closest, it + 1
-
-
 def gather_assignments(local_lists, n, world_size=None):
     """concatenate every rank's list ids (row shards of equal size except the last)"""
     w = world_size or world()
@@ -148,3 +90,46 @@ def gather_assignments(local_lists, n, world_size=None):
     padded = torch.full((per,), -1, dtype=local_lists.dtype, device=local_lists.device)
     padded[: local_lists.numel()] = local_lists
     return torch.cat(_all_gather(padded))[:n]
+
+
+def exchange_rows(vectors_local, tids_local, lists_local, nlists):
+    """Row-sharded build -> list-sharded image.  Every rank holds some heap rows (vectors [m x d], global row ids
+    tids [m], assigned lists [m]); row i goes to rank lists[i] % world.  Returns the local image
+    (vectors, tids, list_offsets[nlists + 1]): owned lists in list order, rows of a list in global row order
+    (the heap order a serial build feeds its tuplesort, src/ivfbuild.c:271-331); foreign lists empty.
+    One variable-size all-to-all for the rows and two small ones for tids / list ids."""
+    w, dev = world(), vectors_local.device
+    lists64 = lists_local.to(torch.int64)
+    if w > 1:
+        dest = owner_of_list(lists64, w)
+        order = torch.argsort(dest, stable=True)
+        send_counts = torch.bincount(dest, minlength=w)
+        recv_counts = torch.empty_like(send_counts)
+        sc = _stage(send_counts)
+        rc = torch.empty_like(sc)
+        dist.all_to_all_single(rc, sc)
+        recv_counts = rc.to(dev)
+        ss, rs = send_counts.tolist(), recv_counts.tolist()
+
+        def a2a(t):
+            st = _stage(t[order].contiguous())
+            out = torch.empty((sum(rs),) + tuple(st.shape[1:]), dtype=st.dtype, device=st.device)
+            dist.all_to_all_single(out, st, output_split_sizes=rs, input_split_sizes=ss)
+            return out.to(dev)
+        vectors_local, tids_local, lists64 = a2a(vectors_local), a2a(tids_local), a2a(lists64)
+    # list-major, heap order inside a list: sort by (list, global row id)
+    order = torch.argsort(tids_local, stable=True)
+    order = order[torch.argsort(lists64[order], stable=True)]
+    counts = torch.bincount(lists64, minlength=nlists)
+    offsets = torch.zeros(nlists + 1, dtype=torch.int64, device=dev)
+    offsets[1:] = torch.cumsum(counts, 0)
+    return vectors_local[order].contiguous(), tids_local[order].contiguous(), offsets
+
+
+def merge_exact_topk(local_dist, k):
+    """ground truth over row-sharded data: every rank's exact [nq x k] distances (ascending, +inf padded) ->
+    the k smallest per query over all ranks, on every rank"""
+    if world() == 1:
+        return local_dist
+    d = torch.cat(_all_gather(local_dist), dim=1)
+    return torch.sort(d, dim=1).values[:, :k].contiguous()

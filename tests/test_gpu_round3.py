@@ -165,3 +165,163 @@ def test_hnsw_mirror_across_processes(ctx, oracle, tmp_path, dtype):
         assert_topk_equiv(ex["rows"][el[el >= 0]].tolist(), out["dist"][i][:len(rows)], rows.tolist(), wd,
                           what="imported hnsw q%d" % i)
     mirror.close()
+
+
+# ------------------------------------------------- the exact scan for a batch of queries
+DT = {po.ORA_F32: api.PGV_F32, po.ORA_F16: api.PGV_F16}
+
+
+def _ora_exact_topk(oracle, ops, dtype, rows, q, k):
+    """the sequential scan as the oracle has it: GetScanItems + the sorted head over ONE list holding every row
+    (the same per-row FUNCTION 1 calls and ascending sort an index-less ORDER BY ... LIMIT k makes)"""
+    n = rows.shape[0]
+    s = oracle.index_struct(ops, dtype, rows[:1], np.array([0, n], dtype=np.int64), rows, np.arange(n, dtype=np.uint64))
+    return oracle.search(s, q, 1, k)
+
+
+@pytest.mark.parametrize("ops,dtype,dim,n,nq,k,dist", [
+    (po.OPS_L2, po.ORA_F32, 128, 10000, 100, 10, "uniform"),     # BASELINE configs[0]: 10k x 128, 100 queries
+    (po.OPS_L2, po.ORA_F32, 1536, 3000, 70, 10, "clustered"),    # matrix cores + exact tail, ragged last query group
+    (po.OPS_L2, po.ORA_F32, 96, 5000, 20, 10, "normal"),         # < 64 queries: the vector-ALU kernels
+    (po.OPS_L2, po.ORA_F32, 3, 4000, 64, 64, "normal"),          # k = 64 -> k' = 256
+    (po.OPS_L2, po.ORA_F32, 40, 3000, 64, 300, "normal"),        # k' would exceed 256: exact kernels
+    (po.OPS_L2, po.ORA_F16, 3072, 2000, 66, 10, "clustered"),
+    (po.OPS_L2, po.ORA_F16, 72, 5000, 9, 40, "normal"),
+    (po.OPS_IP, po.ORA_F32, 768, 4000, 100, 10, "clustered"),    # the MFMA value is the result
+    (po.OPS_IP, po.ORA_F16, 1024, 2400, 64, 25, "clustered"),
+    (po.OPS_IP, po.ORA_F32, 50, 2000, 5, 10, "normal"),
+])
+def test_exact_topk_is_the_sequential_scan(ctx, oracle, ops, dtype, dim, n, nq, k, dist):
+    """pgv_exact_topk against the oracle's per-row distance calls + ascending sort (src/vector.c:579-620, the
+    executor's top-N): ids exact up to float ties, distances to 1e-5"""
+    rows = gen(n, dim, seed=901, dist=dist, dtype=dtype)
+    queries = gen(nq, dim, seed=902, dist=dist, dtype=dtype)
+    metric = api.PGV_L2SQ if ops == po.OPS_L2 else api.PGV_NEG_IP
+    dist_, idx = api.exact_topk(ctx, metric, DT[dtype], dim, queries, rows, k)
+    scale = 0.0
+    for i in range(nq):
+        wt, wd = _ora_exact_topk(oracle, ops, dtype, rows, queries[i], k)
+        if metric == api.PGV_NEG_IP:  # inner products cancel: tolerance relative to the size of the terms
+            scale = 1e-5 * float(np.max(np.abs(rows.astype(np.float64)) @ np.abs(queries[i].astype(np.float64))))
+        assert_topk_equiv(idx[i].tolist(), dist_[i], wt.tolist(), wd, atol=max(scale, 1e-30),
+                          what="exact topk ops %d dim %d q %d" % (ops, dim, i))
+
+
+def test_exact_topk_l1_ties_and_edges(ctx, oracle):
+    """L1 (l1_distance, src/vector.c:715-725) goes through the exact kernels; exact ties come back by row index;
+    fewer rows than k pads with +inf / -1; n = 0; device buffers give what host buffers give"""
+    import torch
+    dim = 24
+    rows = gen(3000, dim, seed=911, dist="normal")
+    queries = gen(70, dim, seed=912, dist="normal")
+    d, ix = api.exact_topk(ctx, api.PGV_L1, api.PGV_F32, dim, queries, rows, 10)
+    for i in range(0, 70, 7):
+        want = np.array([oracle.lib.ora_index_distance(po.OPS_L1, po.ORA_F32, dim, po._p(r), po._p(queries[i])) for r in rows])
+        order = np.argsort(want, kind="stable")[:10]
+        assert_topk_equiv(ix[i].tolist(), d[i], order.tolist(), want[order], what="l1 q %d" % i)
+    # integer data: many exact ties, every one resolved towards the lower row index, on both kernel families
+    irows = gen(4000, 8, seed=913, dist="int")
+    irows[500:560] = irows[17]
+    for nq in (8, 96):
+        iq = gen(nq, 8, seed=914, dist="int")
+        iq[3] = irows[17]
+        d, ix = api.exact_topk(ctx, api.PGV_L2SQ, api.PGV_F32, 8, iq, irows, 40)
+        for i in range(nq):
+            want = ((irows.astype(np.float64) - iq[i].astype(np.float64)) ** 2).sum(1)  # exact in fp32 too
+            order = np.lexsort((np.arange(4000), want))[:40]
+            assert ix[i].tolist() == order.tolist(), (nq, i)
+            assert d[i].tolist() == want[order].tolist()
+    # fewer rows than k, and none
+    d, ix = api.exact_topk(ctx, api.PGV_L2SQ, api.PGV_F32, dim, queries, rows[:6], 10)
+    assert (ix[:, 6:] == -1).all() and np.isinf(d[:, 6:]).all() and (ix[:, :6] >= 0).all()
+    assert sorted(ix[0, :6].tolist()) == list(range(6))
+    d, ix = api.exact_topk(ctx, api.PGV_L2SQ, api.PGV_F32, dim, queries[:5], rows[:0], 3)
+    assert (ix == -1).all() and np.isinf(d).all()
+    # device buffers
+    hd, hi = api.exact_topk(ctx, api.PGV_L2SQ, api.PGV_F32, dim, queries, rows, 10)
+    dd, di = api.exact_topk(ctx, api.PGV_L2SQ, api.PGV_F32, dim, torch.from_numpy(queries).cuda(),
+                            torch.from_numpy(rows).cuda(), 10)
+    assert di.cpu().numpy().tolist() == hi.tolist() and dd.cpu().numpy().tolist() == hd.tolist()
+    with pytest.raises(api.PgvError) as e:
+        api.exact_topk(ctx, api.PGV_L2SQ, api.PGV_F32, dim, queries, rows, 5000)
+    assert e.value.code == api.PGV_ERR_ARG
+
+
+# ------------------------------------------------- the completeness bound of the MFMA L2 paths
+def _search_with_bound(ctx, ix, queries, probes, k, worst_case):
+    ctx.set_bound(worst_case)
+    ctx.set_profiling(True)
+    ctx.reset_stats()
+    try:
+        dist, slot, tid = ix.search_batch(queries, probes, k, want_tid=True)
+        redo = ctx.stats()["scan_redo_queries"]
+    finally:
+        ctx.set_profiling(False)
+        ctx.set_bound(False)
+    return dist, slot, tid, redo
+
+
+def test_the_two_bounds_where_they_differ(ctx, oracle):
+    """rows at squared distances spread over [0, 0.12 R^2] from queries of norm R: the gap between the k-th and the
+    k'-th candidate (30 rows of ~5000) clears twice the statistical bound (1.9e-5 (|q| + |x|)^2 at 1536-d) but not
+    twice the worst-case one (1.8e-4 ...): PGV_BOUND_WORST_CASE redoes those queries exactly, PGV_BOUND_STATISTICAL
+    proves them complete -- and both return the oracle's rows"""
+    dim, n, nq, lists, k = 1536, 10000, 128, 2, 10
+    rng = np.random.default_rng(77)
+    base = rng.standard_normal(dim).astype(np.float32)
+    base *= 30.0 / np.linalg.norm(base)                                     # R = 30
+    dirs = rng.standard_normal((n, dim)).astype(np.float32)
+    dirs /= np.linalg.norm(dirs, axis=1, keepdims=True)
+    radius = np.sqrt(rng.random(n) * 0.12 * 900.0).astype(np.float32)[:, None]
+    data = np.ascontiguousarray(base[None, :] + radius * dirs)
+    queries = np.ascontiguousarray(base[None, :] + 0.01 * rng.standard_normal((nq, dim)).astype(np.float32))
+    ivf = CpuIvf(oracle, po.OPS_L2, po.ORA_F32, data, lists)
+    ix = _upload(ctx, ivf)
+    out = {}
+    for wc in (False, True):
+        dist, slot, tid, redo = _search_with_bound(ctx, ix, queries, lists, k, wc)
+        out[wc] = redo
+        for i in range(nq):
+            wt, wd = oracle.search(ivf.struct, queries[i], lists, k)
+            assert_topk_equiv(tid[i].tolist(), dist[i], wt.tolist(), wd, what="bound %s q %d" % (wc, i))
+    assert out[False] == 0, out          # the statistical bound settles every query
+    assert out[True] >= nq // 2, out     # the deterministic one cannot: those queries took the exact pass
+    ix.close()
+
+
+def test_mfma_l2_under_catastrophic_cancellation(ctx, oracle):
+    """rows = b + tiny perturbations with |b| = 1000: |q|^2 + |x|^2 - 2 q.x loses every digit of distances ~ 1e-2
+    (the expansion's rounding is ~ 1), so no bound can settle anything: every query must be flagged and redone on
+    the exact kernels, whose results are the reference's.  Same through the assignment pre-filter and pgv_exact_topk."""
+    dim, n, nq, lists, k = 256, 6000, 96, 3, 10
+    rng = np.random.default_rng(78)
+    base = rng.standard_normal(dim).astype(np.float32)
+    base *= 1000.0 / np.linalg.norm(base)
+    data = np.ascontiguousarray(base[None, :] + 0.01 * rng.standard_normal((n, dim)).astype(np.float32))
+    queries = np.ascontiguousarray(base[None, :] + 0.01 * rng.standard_normal((nq, dim)).astype(np.float32))
+    centers = np.ascontiguousarray(base[None, :] + 0.01 * rng.standard_normal((lists, dim)).astype(np.float32))
+    ivf = CpuIvf(oracle, po.OPS_L2, po.ORA_F32, data, lists, centers=centers)
+    ix = _upload(ctx, ivf)
+    for wc in (False, True):
+        dist, slot, tid, redo = _search_with_bound(ctx, ix, queries, lists, k, wc)
+        assert redo == nq, (wc, redo)
+        for i in range(nq):
+            wt, wd = oracle.search(ivf.struct, queries[i], lists, k)
+            assert_topk_equiv(tid[i].tolist(), dist[i], wt.tolist(), wd, what="cancel bound %s q %d" % (wc, i))
+        ctx.set_bound(wc)
+        try:
+            d, idx = api.exact_topk(ctx, api.PGV_L2SQ, api.PGV_F32, dim, queries, data, k)
+            # 600 centers so that the assignment goes through the MFMA pre-filter
+            many = np.ascontiguousarray(base[None, :] + 0.01 * rng.standard_normal((600, dim)).astype(np.float32))
+            got, _ = api.assign(ctx, api.PGV_L2SQ, api.PGV_F32, dim, many, data[:2048])
+        finally:
+            ctx.set_bound(False)
+        for i in range(0, nq, 5):
+            wt, wd = _ora_exact_topk(oracle, po.OPS_L2, po.ORA_F32, data, queries[i], k)
+            assert_topk_equiv(idx[i].tolist(), d[i], wt.tolist(), wd, what="cancel exact_topk %s q %d" % (wc, i))
+        want, _ = oracle.assign(po.OPS_L2, po.ORA_F32, many, data[:2048])
+        for r in np.nonzero(np.asarray(got) != np.asarray(want))[0]:  # only float-level ties may differ
+            dg = oracle.lib.ora_index_distance(po.OPS_L2, po.ORA_F32, dim, po._p(data[r]), po._p(many[got[r]]))
+            dw = oracle.lib.ora_index_distance(po.OPS_L2, po.ORA_F32, dim, po._p(data[r]), po._p(many[want[r]]))
+            assert abs(dg - dw) <= 1e-5 * dw, (wc, r, dg, dw)
+    ix.close()

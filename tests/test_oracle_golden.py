@@ -319,3 +319,27 @@ def test_bit_oracle_matches_the_compiled_reference(oracle):
         assert oracle.lib.ora_bit_hamming(nbytes, po._p(a), po._p(b)) == ref.lib.pgvref_bit_hamming(nbytes, po._p(a), po._p(b))
         oracle.lib.ora_bit_jaccard.restype = C.c_double
         assert oracle.lib.ora_bit_jaccard(nbytes, po._p(a), po._p(b)) == ref.lib.pgvref_bit_jaccard(nbytes, po._p(a), po._p(b))
+
+
+def test_bench_runners_give_the_single_thread_answers(oracle):
+    """oracle_bench.c (bench.py's cpu_baseline): pinned threads round ora_ivf_search / ora_ivf_assign and the
+    spread placement copy change where and how often things run, never what they return"""
+    import numpy as np
+    from helpers import CpuIvf, gen
+    from oracle import pyoracle as po
+    data = gen(3000, 24, seed=61, dist="clustered", clusters=8)
+    ivf = CpuIvf(oracle, po.OPS_L2, po.ORA_F32, data, 8)
+    queries = gen(10, 24, seed=62, dist="clustered", clusters=8)
+    vec, release = oracle.spread(ivf.vectors, 3)
+    assert np.array_equal(vec, ivf.vectors)
+    s = oracle.index_struct(po.OPS_L2, po.ORA_F32, ivf.centers, ivf.list_offsets, vec, ivf.tids)
+    answers, done, secs = oracle.bench_search(s, queries, 3, 5, 4, 0.05)
+    assert done >= 10 and secs > 0
+    for i, q in enumerate(queries):
+        wt, wd = oracle.search(ivf.struct, q, 3, 5)
+        assert answers[i][0].tolist() == wt.tolist() and answers[i][1].tolist() == wd.tolist()
+    release()
+    got, secs = oracle.bench_assign(po.OPS_L2, po.ORA_F32, ivf.centers, data, 3)
+    want, _ = oracle.assign(po.OPS_L2, po.ORA_F32, ivf.centers, data)
+    assert got.tolist() == np.asarray(want).tolist() and secs > 0
+    assert oracle.lib.ora_bench_cpus() >= 1

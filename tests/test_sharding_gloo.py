@@ -1,6 +1,9 @@
-"""The N > 1 path on CPU: world_size-2 gloo processes run the same sharding /
-merge / all-reduce code bench.py runs on GPUs, with the oracle standing in for
-libpgv_hip as the per-rank compute.  Results must equal the single-process run."""
+"""The harness side of the N > 1 path on CPU: world_size-2 gloo processes run the bookkeeping bench.py runs on GPUs
+(row shards -> assignment -> rows to the owners of their lists -> local images; exact ground truth merged across
+ranks), with the oracle standing in for libpgv_hip as the per-rank compute.  Results must equal the single-process
+run.  The path's own collectives (pgv_kmeans_sharded, pgv_search_batch_sharded) are HIP code inside libpgv_hip:
+their 2-rank test needs a GPU (tests/test_gpu_round2.py::test_comm_two_ranks_on_one_gpu, two processes, gloo
+callbacks through pgv_comm_create_custom)."""
 import os
 import socket
 import sys
@@ -36,7 +39,7 @@ def _make_problem():
 
 def _local_search(ora, po, centers, off, vecs, tids, queries, probes, k):
     ix = ora.index_struct(po.OPS_L2, po.ORA_F32, centers, off, vecs, tids)
-    d = np.full((len(queries), k), np.inf, dtype=np.float32)
+    d = np.full((len(queries), k), np.inf, dtype=np.float64)
     t = np.full((len(queries), k), -1, dtype=np.int64)
     for i, q in enumerate(queries):
         tt, dd = ora.search(ix, q, probes, k)
@@ -52,35 +55,17 @@ def _worker(rank, world, port, out):
     try:
         from pgvector_amd import sharding
         ora, po, data, ivf, queries = _make_problem()
-        # --- scan: lists sharded l % world, local top-k, all-gather merge
-        v, t, off = sharding.local_index_arrays(torch.from_numpy(ivf.vectors), torch.from_numpy(ivf.tids.astype(np.int64)),
-                                                torch.from_numpy(ivf.list_offsets), rank, world)
-        assert int(off[-1]) == v.shape[0]
-        ld, lt = _local_search(ora, po, ivf.centers, off.numpy(), v.numpy(), t.numpy().astype(np.uint64), queries, 4, 7)
-        md, mt = sharding.merge_topk(ld, lt, 7)
-        # --- k-means: samples sharded by row, all-reduce of sums/counts/changes
-        samples = torch.from_numpy(data[:1200])
-        lo, hi = sharding.row_shard(1200, rank, world)
-        init = torch.from_numpy(np.ascontiguousarray(data[:12]))
-
-        def partial(s, c, closest):
-            new, _ = ora.lloyd_assign(po.OPS_L2, po.ORA_F32, s.numpy(), c.numpy())
-            changes = int((new != closest.numpy()).sum())
-            closest.copy_(torch.from_numpy(new))
-            sums = np.zeros((12, 16), dtype=np.float32)
-            np.add.at(sums, new, s.numpy())
-            return torch.from_numpy(sums), torch.from_numpy(np.bincount(new, minlength=12).astype(np.int32)), \
-                torch.tensor([changes], dtype=torch.int64)
-
-        def finish(sums, counts, it):
-            c = sums.numpy() / np.maximum(counts.numpy(), 1)[:, None].astype(np.float32)
-            return torch.from_numpy(c.astype(np.float32))
-        centers, closest, iters = sharding.sharded_kmeans(samples[lo:hi].contiguous(), init, partial, finish, 50)
-        # --- assignment gather
-        mine, _ = ora.assign(po.OPS_L2, po.ORA_F32, centers.numpy(), data[slice(*sharding.row_shard(3000, rank, world))])
+        # --- build: this rank's heap rows, assigned locally, every row sent to the owner of its list
+        lo, hi = sharding.row_shard(3000, rank, world)
+        mine, _ = ora.assign(po.OPS_L2, po.ORA_F32, ivf.centers, data[lo:hi])
         every = sharding.gather_assignments(torch.from_numpy(mine), 3000, world)
-        if rank == 0:
-            torch.save({"md": md, "mt": mt, "centers": centers, "iters": iters, "lists": every}, out)
+        v, t, off = sharding.exchange_rows(torch.from_numpy(data[lo:hi]), torch.arange(lo, hi, dtype=torch.int64),
+                                           torch.from_numpy(mine), 12)
+        assert int(off[-1]) == v.shape[0]
+        # --- scan of the local image + the exact ground truth merged across the ranks
+        ld, lt = _local_search(ora, po, ivf.centers, off.numpy(), v.numpy(), t.numpy().astype(np.uint64), queries, 12, 7)
+        md = sharding.merge_exact_topk(ld, 7)
+        torch.save({"v": v, "t": t, "off": off, "md": md, "lists": every}, out + ".%d" % rank)
     finally:
         dist.destroy_process_group()
 
@@ -88,28 +73,23 @@ def _worker(rank, world, port, out):
 def test_world2_matches_single_process(tmp_path):
     out = str(tmp_path / "w2.pt")
     mp.spawn(_worker, args=(2, _free_port(), out), nprocs=2, join=True)
-    got = torch.load(out)
     from pgvector_amd import sharding
     ora, po, data, ivf, queries = _make_problem()
-    sd, st = _local_search(ora, po, ivf.centers, ivf.list_offsets, ivf.vectors, ivf.tids, queries, 4, 7)
-    np.testing.assert_array_equal(got["md"].numpy(), sd.numpy())
-    np.testing.assert_array_equal(got["mt"].numpy(), st.numpy())
-    # single-process Lloyd from the same init
-    centers = np.ascontiguousarray(data[:12])
-    prev = None
-    for it in range(50):
-        new, _ = ora.lloyd_assign(po.OPS_L2, po.ORA_F32, data[:1200], centers)
-        sums = np.zeros((12, 16), dtype=np.float32)
-        np.add.at(sums, new, data[:1200])
-        centers = (sums / np.maximum(np.bincount(new, minlength=12), 1)[:, None].astype(np.float32)).astype(np.float32)
-        changed = prev is None or (new != prev).any()
-        prev = new
-        if not changed and it != 0:
-            break
-    assert got["iters"] == it + 1
-    np.testing.assert_allclose(got["centers"].numpy(), centers, rtol=1e-5, atol=1e-6)
-    want, _ = ora.assign(po.OPS_L2, po.ORA_F32, got["centers"].numpy(), data)
-    np.testing.assert_array_equal(got["lists"].numpy(), want)
+    want_lists, _ = ora.assign(po.OPS_L2, po.ORA_F32, ivf.centers, data)
+    # the serial image: list-major, heap order inside a list
+    order = np.argsort(want_lists, kind="stable")
+    gvec, gtid = torch.from_numpy(data[order]), torch.from_numpy(order.astype(np.int64))
+    goff = torch.zeros(13, dtype=torch.int64)
+    goff[1:] = torch.cumsum(torch.from_numpy(np.bincount(want_lists, minlength=12)), 0)
+    sd, _ = _local_search(ora, po, ivf.centers, goff.numpy(), gvec.numpy(), gtid.numpy().astype(np.uint64), queries, 12, 7)
+    for r in range(2):
+        got = torch.load(out + ".%d" % r)
+        np.testing.assert_array_equal(got["lists"].numpy(), want_lists)
+        v, t, off = sharding.local_index_arrays(gvec, gtid, goff, r, 2)
+        np.testing.assert_array_equal(got["off"].numpy(), off.numpy())
+        np.testing.assert_array_equal(got["t"].numpy(), t.numpy())
+        np.testing.assert_array_equal(got["v"].numpy(), v.numpy())
+        np.testing.assert_array_equal(got["md"].numpy(), sd.numpy())  # every list probed: the exact top-k
 
 
 def test_local_index_arrays_partition():
