@@ -229,6 +229,30 @@ def topk_equiv(got_ids, got_d, want_ids, want_d, rtol=RTOL):
     return None
 
 
+def cpu_quota():
+    """CPUs this container may actually burn: the cgroup's CFS quota (v2 cpu.max, v1 cpu.cfs_quota_us), or None"""
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        return None if quota == "max" else float(quota) / float(period)
+    except Exception:  # noqa: BLE001
+        pass
+    try:
+        q = float(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+        per = float(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+        return None if q <= 0 else q / per
+    except Exception:  # noqa: BLE001
+        return None
+
+
+def cpu_threads(ora):
+    """threads for the CPU baselines: the CPUs allowed by affinity, capped by the cgroup quota (pinning 256 threads
+    under a 16-CPU quota only buys throttling) and by 256"""
+    cpus = ora.lib.ora_bench_cpus()
+    quota = cpu_quota()
+    cores = cpus if quota is None else min(cpus, max(1, int(quota)))
+    return max(1, min(cores, 256)), cpus, quota
+
+
 def cpu_baseline(centers, offsets, vectors, tids, queries, probes, k, dtype, ops, budget_s=12.0, pages=None):
     """the oracle (= the reference's loops and kernels restated, built with the reference's flags +
     -march=native) answering the same queries on the host cores of this box: one pinned thread per "backend"
@@ -239,8 +263,7 @@ def cpu_baseline(centers, offsets, vectors, tids, queries, probes, k, dtype, ops
     ora = po.Oracle(native=True)
     oops = po.OPS_L2 if ops == api.PGV_OPS_L2 else po.OPS_IP
     odt = po.ORA_F32 if dtype == api.PGV_F32 else po.ORA_F16
-    cpus = ora.lib.ora_bench_cpus()
-    cores = max(1, min(cpus, 256))
+    cores, cpus, quota = cpu_threads(ora)
     svec, release = ora.spread(vectors, cores)
     ix = ora.index_struct(oops, odt, centers, offsets, svec, tids)
     esz = 4 if dtype == api.PGV_F32 else 2
@@ -258,7 +281,7 @@ def cpu_baseline(centers, offsets, vectors, tids, queries, probes, k, dtype, ops
            "scaling_over_one_thread": (total / el) / (single / single_el),
            "placement": "one pthread per backend pinned to allowed CPU t * %d / %d (sched_getaffinity: %d CPUs allowed, "
                         "os.cpu_count %s); index rows copied into 2 MB pieces first-touched round-robin by those "
-                        "threads (interleaved over the memory nodes)" % (cpus, cores, cpus, os.cpu_count()),
+                        "threads (interleaved over the memory nodes)" % (cpus, cores, cpus, os.cpu_count(), quota),
            "layout": "contiguous list-major arrays (an upper bound of the reference: no 8 KB page walk, "
                      "no fmgr/bufmgr/tuplesort overheads)",
            "sample": "%d queries in %.1f s on %d threads (%d more on 1 thread), same index and queries as the "
@@ -320,7 +343,7 @@ def cpu_build_assign(host_rows, dtype, ops, out):
         odt = po.ORA_F32 if dtype == api.PGV_F32 else po.ORA_F16
         n = host_rows.shape[0]
         sub = np.ascontiguousarray(host_rows[:: max(n // 100_000, 1)][:100_000])
-        cores = max(1, min(ora.lib.ora_bench_cpus(), 256))
+        cores = cpu_threads(ora)[0]
         one_rows = sub[:4000]
         _, one_s = ora.bench_assign(oops, odt, centers, one_rows, 1)
         _, all_s = ora.bench_assign(oops, odt, centers, sub, cores)
@@ -994,7 +1017,7 @@ def main():
                                            "itself is Python/ctypes)" % k)
         except Exception as e:
             sweep["1"]["gettuple_error"] = repr(e)
-        for b in (16, 256):
+        for b in (4, 16, 64, 256):
             qb = queries[3][:b].contiguous()
             od = torch.empty((b, k), device=dev, dtype=torch.float32)
             os_ = torch.empty((b, k), device=dev, dtype=torch.int64)

@@ -230,6 +230,92 @@ __global__ void query_iota_kernel(int32_t *__restrict__ out, int n) {
     if (i < n) out[i] = i;
 }
 
+// ------------------------------------------------------------------- a few queries at a time
+// A batch too small to share rows between its queries (nq * probes well below the list count: every probed list
+// belongs to one query) gains nothing from the list-major plan of the batched path and pays its dozen launches.
+// The same four kernels as above, one grid row (blockIdx.y) per query, results into the caller's device arrays:
+// rank, lists, scan, head -- pgv_search_batch for 16 queries in four launches.
+template <typename T, int METRIC, int NCH>
+__global__ __launch_bounds__(kQThreads) void mq_rank_kernel(const char *__restrict__ centers, int nlists, int nvec, int lg,
+                                                            const char *__restrict__ queries, float *__restrict__ cdist,
+                                                            int64_t cd_stride, int per) {
+    const size_t row_bytes = (size_t)nvec * sizeof(Raw16);
+    const char *qp = queries + (size_t)blockIdx.y * row_bytes;
+    float *cd = cdist + (size_t)blockIdx.y * cd_stride;
+    for (int64_t first = (int64_t)blockIdx.x * per; first < nlists; first += (int64_t)gridDim.x * per) {
+        const int64_t end = first + per < nlists ? first + per : nlists;
+        score_rows<T, METRIC, NCH>([&](int64_t j) { return centers + (size_t)j * row_bytes; }, first, end, qp, nvec, lg, cd);
+    }
+}
+
+__global__ __launch_bounds__(kQThreads) void mq_lists_kernel(const float *__restrict__ cdist, int64_t cd_stride, int nlists,
+                                                             int max_probes, int kp, int32_t *__restrict__ out_lists,
+                                                             float *__restrict__ out_dist) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    unsigned long long *ent = reinterpret_cast<unsigned long long *>(smem);
+    SelShared *s = reinterpret_cast<SelShared *>(smem + (size_t)kHeadCap * 8);
+    const int q = blockIdx.x;
+    block_topk_auto(cdist + (size_t)q * cd_stride, nlists, max_probes, kp, kHeadCap, ent, s);
+    for (int i = threadIdx.x; i < max_probes; i += kQThreads) {
+        out_lists[(size_t)q * max_probes + i] = (int32_t)(unsigned)(ent[i] & 0xffffffffu);
+        if (out_dist) out_dist[(size_t)q * max_probes + i] = key_to_float((unsigned)(ent[i] >> 32));
+    }
+}
+
+template <typename T, int METRIC, int NCH>
+__global__ __launch_bounds__(kQThreads) void mq_scan_kernel(
+    const char *__restrict__ vectors, const int64_t *__restrict__ list_off, const int32_t *__restrict__ probe_lists,
+    int nprobes, int nvec, int lg, const char *__restrict__ queries, float *__restrict__ seg, int64_t seg_stride, int per) {
+    __shared__ BatchMap map;
+    const size_t row_bytes = (size_t)nvec * sizeof(Raw16);
+    const int q = blockIdx.y;
+    map.build(probe_lists + (size_t)q * nprobes, nprobes, list_off);
+    const int64_t m = map.offs[nprobes];
+    const char *qp = queries + (size_t)q * row_bytes;
+    float *sg = seg + (size_t)q * seg_stride;
+    for (int64_t first = (int64_t)blockIdx.x * per; first < m; first += (int64_t)gridDim.x * per) {
+        const int64_t end = first + per < m ? first + per : m;
+        score_rows<T, METRIC, NCH>([&](int64_t j) { return vectors + (size_t)map.slot_of(j, nprobes) * row_bytes; },
+                                   first, end, qp, nvec, lg, sg);
+    }
+}
+
+// the head of each query's stream into the caller's [nq x k] arrays (+inf / -1 / ~0 past the tuples there are)
+__global__ __launch_bounds__(kQThreads) void mq_head_kernel(
+    const float *__restrict__ seg, int64_t seg_stride, const int64_t *__restrict__ list_off,
+    const uint64_t *__restrict__ tids, const int32_t *__restrict__ probe_lists, int nprobes, int k, int kp,
+    float *__restrict__ out_dist, int64_t *__restrict__ out_slot, uint64_t *__restrict__ out_tid,
+    double *__restrict__ stats) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    __shared__ BatchMap map;
+    const int q = blockIdx.x;
+    map.build(probe_lists + (size_t)q * nprobes, nprobes, list_off);
+    const int64_t m = map.offs[nprobes];
+    unsigned long long *ent = reinterpret_cast<unsigned long long *>(smem);
+    SelShared *s = reinterpret_cast<SelShared *>(smem + (size_t)kHeadCap * 8);
+    block_topk_auto(seg + (size_t)q * seg_stride, m, k, kp, kHeadCap, ent, s);
+    const int have = (int)(m < k ? m : k);
+    for (int i = threadIdx.x; i < k; i += kQThreads) {
+        const size_t o = (size_t)q * k + i;
+        if (i < have) {
+            const unsigned long long e = ent[i];
+            const int64_t slot = map.slot_of((int64_t)(unsigned)(e & 0xffffffffu), nprobes);
+            out_dist[o] = key_to_float((unsigned)(e >> 32));
+            if (out_slot) out_slot[o] = slot;
+            if (out_tid) out_tid[o] = tids ? tids[slot] : ~0ull;
+        } else {
+            out_dist[o] = INFINITY;
+            if (out_slot) out_slot[o] = -1;
+            if (out_tid) out_tid[o] = ~0ull;
+        }
+    }
+    if (stats && threadIdx.x == 0) {  // profiling: pairs scored = rows streamed = rows of probed lists (nothing is shared)
+        atomicAdd(&stats[0], (double)m);
+        atomicAdd(&stats[1], (double)m);
+        atomicAdd(&stats[5], (double)m);
+    }
+}
+
 // ------------------------------------------------------------------- exact tail of the MFMA L2 scan
 // mfma_scan_kernel's L2 values are |x|^2 - 2 q.x (the expansion of the distance less its per-query constant |q|^2):
 // they pick k' candidates per query, and this
@@ -530,6 +616,60 @@ int launch_query_head(pgv_ctx *ctx, const pgv_index *ix, const float *seg, const
     float *h_dist = reinterpret_cast<float *>(base + (size_t)count * 16);
     hipLaunchKernelGGL(query_head_kernel, dim3(1), dim3(kQThreads), kQueryLds, ctx->stream, seg, ix->list_offsets,
                        ix->tids, probe_lists, nprobes, skip, count, kp, hdr, h_dist, h_slot, h_tid, seq);
+    PGV_HIP(hipGetLastError());
+    return PGV_OK;
+}
+
+// a few queries at a time (see mq_*_kernel): GetScanLists for nq staged queries
+int launch_multi_rank(pgv_ctx *ctx, const pgv_index *ix, const void *q_dev, int nq, float *cdist, int64_t cd_stride,
+                      int max_probes, int32_t *out_lists, float *out_dist) {
+    const RowGeom &g = ix->geom;
+    int per, grid;
+    run_geometry(ctx, g, ix->nlists, &per, &grid);
+    const int kp = pow2_at_least(max_probes);
+    PGV_TRY(dispatch_metric(ix->metric, ix->dtype, [&](auto *tp, auto mc) {
+        using T = std::remove_pointer_t<decltype(tp)>;
+        constexpr int M = decltype(mc)::value;
+        return dispatch_nch<T, M>(g, [&](auto nc) {
+            constexpr int NCH = decltype(nc)::value;
+            hipLaunchKernelGGL((mq_rank_kernel<T, M, NCH>), dim3(grid, nq), dim3(kQThreads), 0, ctx->stream,
+                               static_cast<const char *>(ix->centers), ix->nlists, g.nvec, g.lpr_log2,
+                               static_cast<const char *>(q_dev), cdist, cd_stride, per);
+            PGV_HIP(hipGetLastError());
+            return PGV_OK;
+        });
+    }));
+    hipLaunchKernelGGL(mq_lists_kernel, dim3(nq), dim3(kQThreads), kQueryLds, ctx->stream, cdist, cd_stride, ix->nlists,
+                       max_probes, kp, out_lists, out_dist);
+    PGV_HIP(hipGetLastError());
+    return PGV_OK;
+}
+
+// ... and GetScanItems + the head of the sorted stream, every query over its own lists
+int launch_multi_scan(pgv_ctx *ctx, const pgv_index *ix, const void *q_dev, int nq, const int32_t *probe_lists, int nprobes,
+                      int64_t rows_bound, float *seg, int64_t seg_stride, int k, float *out_dist, int64_t *out_slot,
+                      uint64_t *out_tid) {
+    const RowGeom &g = ix->geom;
+    int per, grid;
+    run_geometry(ctx, g, rows_bound, &per, &grid);
+    // nq grid rows share the device: a row needs no more workgroups than keep every CU busy
+    const int cap = (ctx->num_cus * 8 + nq - 1) / nq;
+    if (grid > cap) grid = cap < 1 ? 1 : cap;
+    PGV_TRY(dispatch_metric(ix->metric, ix->dtype, [&](auto *tp, auto mc) {
+        using T = std::remove_pointer_t<decltype(tp)>;
+        constexpr int M = decltype(mc)::value;
+        return dispatch_nch<T, M>(g, [&](auto nc) {
+            constexpr int NCH = decltype(nc)::value;
+            hipLaunchKernelGGL((mq_scan_kernel<T, M, NCH>), dim3(grid, nq), dim3(kQThreads), 0, ctx->stream,
+                               static_cast<const char *>(ix->vectors), ix->list_offsets, probe_lists, nprobes, g.nvec,
+                               g.lpr_log2, static_cast<const char *>(q_dev), seg, seg_stride, per);
+            PGV_HIP(hipGetLastError());
+            return PGV_OK;
+        });
+    }));
+    double *stats = (ctx->profiling && ctx->stats_dev.p) ? ctx->stats_dev.as<double>() : nullptr;
+    hipLaunchKernelGGL(mq_head_kernel, dim3(nq), dim3(kQThreads), kQueryLds, ctx->stream, seg, seg_stride, ix->list_offsets,
+                       ix->tids, probe_lists, nprobes, k, pow2_at_least(k), out_dist, out_slot, out_tid, stats);
     PGV_HIP(hipGetLastError());
     return PGV_OK;
 }

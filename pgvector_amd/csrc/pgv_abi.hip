@@ -953,6 +953,13 @@ static int rank_lists_dev(pgv_index *ix, const void *q_dev, int nq, int maxprobe
     // a batch against a few hundred centers or more: the matrix cores.  Inner product: the values are
     // the result.  L2: the expansion picks maxprobes + 16 candidates, their exact distances decide, and a
     // query whose candidates cannot be proven complete is redone exactly (same scheme as the list scan)
+    // a handful of queries: one grid row per query over the centers, selection per query (two launches)
+    if (nq <= 8 && maxprobes <= query_head_cap()) {
+        const int64_t cd_stride = ((int64_t)ix->nlists + 7) / 4 * 4;  // 16-byte aligned rows + a float4 of slack
+        PGV_TRY(ctx->dist_mat.ensure(sizeof(float) * (size_t)nq * cd_stride));
+        return launch_multi_rank(ctx, ix, q_dev, nq, ctx->dist_mat.as<float>(), cd_stride, maxprobes, out_lists_dev,
+                                 out_dist_dev);
+    }
     const int cand = maxprobes + 16 < ix->nlists ? maxprobes + 16 : ix->nlists;
     const bool mfma = nq >= 128 && ix->nlists >= 64 && !ctx->no_mfma_scan &&
                       (ix->metric == PGV_NEG_IP || (ix->metric == PGV_L2SQ && ix->center_norms && cand <= 256));
@@ -1102,6 +1109,28 @@ static int scan_batch_dev(pgv_index *ix, const void *q_dev, int nq, const int32_
     // worth.  Lists probed by more than 8 queries go to the tile kernel (16 queries per pass
     // over the rows) when the row shape allows it.
     const double share = (double)nq * probes / (double)ix->nlists;
+    // Too few queries to share rows between them (every probed list belongs to one query): the list-major plan
+    // gains nothing and costs a dozen launches.  Each query scans its own lists (mq_scan_kernel) and selects
+    // its own head (mq_head_kernel): two launches, the single-query kernels with one grid row per query.
+    if ((share <= 0.4 || nq <= 4) && nq <= 1024 && probes <= query_max_batch_lists() && k <= query_head_cap()) {
+        const int64_t bound = ix->len_prefix[probes];  // rows of the `probes` longest lists
+        const int64_t seg_stride = (bound + 7) / 4 * 4;
+        PGV_TRY(ctx->plan_d.ensure(sizeof(float) * (size_t)nq * seg_stride));
+        OutArg od, os, ot;
+        PGV_TRY(od.init(out_dist, sizeof(float) * (size_t)nq * k, ctx->out_stage));
+        PGV_TRY(os.init(out_slot, sizeof(int64_t) * (size_t)nq * k, ctx->out_stage2));
+        PGV_TRY(ot.init(out_tid, sizeof(uint64_t) * (size_t)nq * k, ctx->sel_b));
+        ScanTimer timer{ctx};
+        PGV_TRY(timer.begin(0.0, 0.0));  // pairs / rows are added up on the device by mq_head_kernel
+        PGV_TRY(launch_multi_scan(ctx, ix, q_dev, nq, probe_lists, probes, bound, ctx->plan_d.as<float>(), seg_stride, k,
+                                  od.as<float>(), os.as<int64_t>(), ot.as<uint64_t>()));
+        PGV_TRY(timer.end());
+        bool need = false;
+        PGV_TRY(od.finish(ctx, &need));
+        PGV_TRY(os.finish(ctx, &need));
+        PGV_TRY(ot.finish(ctx, &need));
+        return sync_if(ctx, need);
+    }
     // ... and to the matrix cores (32 queries per pass) for L2 / inner product heads of up to 192
     const bool use_mfma = share > 3.0 && k <= 192 && !ctx->no_mfma_scan &&
                           (ix->metric == PGV_NEG_IP || (ix->metric == PGV_L2SQ && ix->row_norms));

@@ -347,6 +347,12 @@ int query_max_batch_lists();
 int query_head_cap();
 size_t query_head_bytes(int head);
 int launch_query_stage(pgv_ctx *ctx, const void *src_pinned, void *dst_dev, int nvec);
+// the same kernels for a few queries at a time (one grid row per query, results in device arrays)
+int launch_multi_rank(pgv_ctx *ctx, const pgv_index *ix, const void *q_dev, int nq, float *cdist, int64_t cd_stride,
+                      int max_probes, int32_t *out_lists, float *out_dist);
+int launch_multi_scan(pgv_ctx *ctx, const pgv_index *ix, const void *q_dev, int nq, const int32_t *probe_lists, int nprobes,
+                      int64_t rows_bound, float *seg, int64_t seg_stride, int k, float *out_dist, int64_t *out_slot,
+                      uint64_t *out_tid);
 int launch_query_iota(pgv_ctx *ctx, int32_t *out, int n);
 int launch_query_rank(pgv_ctx *ctx, const pgv_index *ix, const void *q_dev, float *cdist, int max_probes,
                       int32_t *out_lists);

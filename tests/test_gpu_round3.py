@@ -9,7 +9,7 @@ import pytest
 from oracle import pyoracle as po
 from pgvector_amd import _host, api
 
-from helpers import CpuIvf, assert_topk_equiv, gen
+from helpers import CpuIvf, assert_topk_equiv, gen, normalize_rows
 
 pytestmark = pytest.mark.gpu
 
@@ -324,4 +324,67 @@ def test_mfma_l2_under_catastrophic_cancellation(ctx, oracle):
             dg = oracle.lib.ora_index_distance(po.OPS_L2, po.ORA_F32, dim, po._p(data[r]), po._p(many[got[r]]))
             dw = oracle.lib.ora_index_distance(po.OPS_L2, po.ORA_F32, dim, po._p(data[r]), po._p(many[want[r]]))
             assert abs(dg - dw) <= 1e-5 * dw, (wc, r, dg, dw)
+    ix.close()
+
+
+# ------------------------------------------------- a few queries at a time (mq_*_kernel)
+@pytest.mark.parametrize("ops,dtype,dim,n,lists,nq,probes,k,dist", [
+    (po.OPS_L2, po.ORA_F32, 1536, 6000, 60, 2, 10, 10, "clustered"),    # nq <= 4: rank and scan both per query
+    (po.OPS_L2, po.ORA_F32, 96, 20000, 200, 7, 10, 10, "clustered"),    # share 0.35
+    (po.OPS_L2, po.ORA_F32, 100, 20000, 400, 16, 10, 64, "uniform"),    # share 0.4; near ties
+    (po.OPS_L2, po.ORA_F16, 3072, 3000, 100, 3, 8, 10, "clustered"),
+    (po.OPS_IP, po.ORA_F32, 768, 8000, 160, 6, 8, 25, "clustered"),
+    (po.OPS_COSINE, po.ORA_F16, 200, 8000, 160, 5, 10, 10, "clustered"),
+    (po.OPS_L2, po.ORA_F32, 5, 9000, 300, 12, 10, 1000, "normal"),      # deep head, more than some queries have tuples
+])
+def test_small_batches_take_the_per_query_kernels(ctx, oracle, ops, dtype, dim, n, lists, nq, probes, k, dist):
+    """nq * probes <= 0.4 lists (or nq <= 4): pgv_search_batch runs mq_rank / mq_lists / mq_scan / mq_head -- the
+    head must be GetScanLists + GetScanItems + tuplesort's (src/ivfscan.c:47-187), like every other path's"""
+    data = gen(n, dim, seed=931, dist=dist, clusters=lists, dtype=dtype)
+    ivf = CpuIvf(oracle, ops, dtype, data, lists)
+    queries = gen(nq, dim, seed=932, dist=dist, clusters=lists, dtype=dtype)
+    gq = normalize_rows(oracle, queries, dtype) if ops == po.OPS_COSINE else queries
+    ix = _upload(ctx, ivf)
+    dist_, slot, tid = ix.search_batch(gq, probes, k, want_tid=True)
+    ranked, rdist = ix.rank_lists(gq, probes)
+    for i in range(nq):
+        wt, wd = oracle.search(ivf.struct, queries[i], probes, k)
+        have = slot[i] >= 0
+        assert have.sum() == len(wt) and (tid[i][~have] == np.uint64(0xFFFFFFFFFFFFFFFF)).all()
+        assert np.isinf(dist_[i][~have]).all()
+        assert_topk_equiv(tid[i][have].tolist(), dist_[i][:len(wt)], wt.tolist(), wd, what="mq q %d" % i)
+        wl, wld = oracle.get_scan_lists(ivf.struct, queries[i], probes)
+        assert_topk_equiv(ranked[i].tolist(), rdist[i], wl.tolist(), wld, what="mq lists q %d" % i)
+    ix.close()
+
+
+def test_small_batch_ties_empty_lists_and_device_buffers(ctx, oracle):
+    """integer data (exact ties keep stream order), an empty list among the probed, torch tensors in and out"""
+    import torch
+    dim, lists = 8, 40
+    data = gen(3000, dim, seed=941, dist="int")
+    data[100:140] = data[60]
+    centers = gen(lists, dim, seed=942, dist="int")
+    centers[5] = 1000.0                  # nothing lands here: an empty list
+    ivf = CpuIvf(oracle, po.OPS_L2, po.ORA_F32, data, lists, centers=centers)
+    queries = gen(3, dim, seed=943, dist="int")
+    queries[1] = data[60]
+    ix = _upload(ctx, ivf)
+    for probes in (5, lists):            # lists = 40 probes x 3 queries: share 3 but nq <= 4 -> still per query
+        d, s, t = ix.search_batch(queries, probes, 50, want_tid=True)
+        for i in range(3):
+            wt, wd = oracle.search(ivf.struct, queries[i], probes, 50)
+            have = s[i] >= 0
+            assert_topk_equiv(t[i][have].tolist(), d[i][:len(wt)], wt.tolist(), wd, what="mq ties q %d" % i)
+            # equal distances come back in stream order (probe order, then position in the list)
+            dd, ss = d[i][have], s[i][have]
+            for a in range(len(dd) - 1):
+                if dd[a] == dd[a + 1]:
+                    la = np.searchsorted(ivf.list_offsets, ss[a], side="right") - 1
+                    lb = np.searchsorted(ivf.list_offsets, ss[a + 1], side="right") - 1
+                    assert la != lb or ss[a] < ss[a + 1]
+    qd = torch.from_numpy(queries).cuda()
+    dd, sd, td = ix.search_batch(qd, 5, 50, want_tid=True)
+    hd, hs, ht = ix.search_batch(queries, 5, 50, want_tid=True)
+    assert sd.cpu().numpy().tolist() == hs.tolist() and dd.cpu().numpy().tolist() == hd.tolist()
     ix.close()
