@@ -450,6 +450,34 @@ int			pgv_kmeans_sharded(pgv_comm * comm, pgv_ops ops, pgv_dtype dtype, int dim,
 int			pgv_search_batch_sharded(pgv_comm * comm, pgv_index * local_index, const void *queries, int nq,
 									 int probes, int k, float *out_dist, uint64_t *out_tid);
 
+/*
+ * The build's tuplesort on the device.  The reference's BuildCallback assigns every heap row to its nearest center
+ * and feeds (list, tid, vector) to a tuplesort ordered by list (AddTupleToSort src/ivfbuild.c:161-219, the sort
+ * :606-615); InsertTuples (:271-331) then walks the sorted stream list by list into pages.  With the rows in HBM
+ * anyway (pgv_assign staged them), the sort is a device gather and its result IS the device mirror:
+ *
+ *   pgv_builder_begin   centers of the index (after IvfflatKmeans); expected_rows sizes the first allocation
+ *   pgv_builder_add     a batch of heap rows (host or device, tightly packed) with their TIDs (or NULL: heap
+ *                       positions): copied to the device, assigned there (same kernel as pgv_assign), kept in heap order
+ *   pgv_builder_finish  list-major order (ascending list, heap order inside a list -- what the tuplesort delivers
+ *                       to InsertTuples), the mirror made from it without a second upload; out_offsets [lists + 1]
+ *                       and out_lists [rows, heap order] (either may be NULL) go back to the host
+ *   pgv_index_drain     the mirror's rows in list-major order, piece by piece through pinned memory (the next
+ *                       piece's copy in flight while the sink runs): what the page writer consumes
+ *
+ * The builder holds the heap-order copy until finish (2 x the rows in HBM for a moment: 12 GB at 1 M x 1536).
+ */
+typedef struct pgv_builder pgv_builder;
+int			pgv_builder_begin(pgv_ctx * ctx, pgv_metric metric, pgv_dtype dtype, int dim, int nlists, const void *centers,
+							  int64_t expected_rows, pgv_builder * *out);
+int			pgv_builder_add(pgv_builder * b, const void *rows, const uint64_t *tids, int64_t n);
+int64_t		pgv_builder_rows(const pgv_builder * b);
+int			pgv_builder_finish(pgv_builder * b, pgv_index * *out_index, int64_t *out_offsets, int32_t *out_lists);
+void		pgv_builder_free(pgv_builder * b);
+/* sink(arg, first_slot, count, vectors [count x dim] tightly packed, tids [count] or NULL) -> 0 to go on */
+typedef int (*pgv_rows_sink) (void *arg, int64_t first_slot, int64_t count, const void *vectors, const uint64_t *tids);
+int			pgv_index_drain(pgv_index * index, int64_t chunk_rows, pgv_rows_sink sink, void *arg);
+
 /* ------------------------------------------------- generic candidate batch */
 
 /*

@@ -89,6 +89,7 @@ def _load():
     lib.pgv_host_ivf_endscan.argtypes = [P]
     lib.pgv_host_ivf_endscan.restype = None
     lib.pgv_host_ivf_build.argtypes = [P, I, I, I, I, P, P, I64, P, I, P, C.POINTER(Rel)]
+    lib.pgv_host_ivf_build_mirror.argtypes = [P, I, I, I, I, P, P, I64, P, I, P, C.POINTER(Rel), C.POINTER(P)]
     lib.pgv_host_ivf_build_phases.argtypes = [C.POINTER(C.c_double)]
     lib.pgv_host_ivf_build_phases.restype = None
     lib.pgv_host_float_to_half.argtypes = [C.c_float]
@@ -246,6 +247,25 @@ class Relation:
                                           C.c_void_p(tids.ctypes.data), rows.shape[0],
                                           C.c_void_p(samples.ctypes.data) if len(samples) else None, len(samples),
                                           C.byref(rng) if rng is not None else None, C.byref(self.rel)))
+
+
+    def build_mirror(self, ctx, ops, dtype, lists, rows, tids, samples, rng=None):
+        """pgv_host_ivf_build_mirror: the pages AND the device mirror of the new index in one go -> api.IvfIndex"""
+        from . import api
+        rows = np.ascontiguousarray(rows, dtype=_NP[dtype])
+        samples = np.ascontiguousarray(samples, dtype=_NP[dtype])
+        tids = np.ascontiguousarray(tids, dtype=np.uint64)
+        h = C.c_void_p()
+        host_check(lib.pgv_host_ivf_build_mirror(ctx.h, ops, dtype, rows.shape[1], lists, C.c_void_p(rows.ctypes.data),
+                                                 C.c_void_p(tids.ctypes.data), rows.shape[0],
+                                                 C.c_void_p(samples.ctypes.data) if len(samples) else None, len(samples),
+                                                 C.byref(rng) if rng is not None else None, C.byref(self.rel), C.byref(h)))
+        ix = api.IvfIndex.__new__(api.IvfIndex)
+        ix.ctx, ix.dtype, ix.dim, ix.h = ctx, dtype, rows.shape[1], h
+        ix.metric = api.PGV_L2SQ if ops == api.PGV_OPS_L2 else api.PGV_NEG_IP
+        ix.nlists = lists
+        ctx._adopt(ix)
+        return ix
 
 
 class StagedImage:

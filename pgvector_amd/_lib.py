@@ -44,6 +44,7 @@ SYMBOLS = [
     "pgv_comm_rank", "pgv_kmeans_sharded", "pgv_search_batch_sharded",
     "pgv_device_memory", "pgv_pinned_register", "pgv_pinned_unregister", "pgv_index_export", "pgv_index_import",
     "pgv_index_tids", "pgv_hnsw_export", "pgv_hnsw_import", "pgv_exact_topk", "pgv_ctx_set_bound",
+    "pgv_builder_begin", "pgv_builder_add", "pgv_builder_rows", "pgv_builder_finish", "pgv_builder_free", "pgv_index_drain",
 ]
 
 
@@ -111,6 +112,14 @@ def _load():
     lib.pgv_hnsw_export.argtypes = [P, P]
     lib.pgv_exact_topk.argtypes = [P, I, I, I, P, I, P, I64, I, P, P]
     lib.pgv_ctx_set_bound.argtypes = [P, I]
+    lib.pgv_builder_begin.argtypes = [P, I, I, I, I, P, I64, C.POINTER(P)]
+    lib.pgv_builder_add.argtypes = [P, P, P, I64]
+    lib.pgv_builder_rows.argtypes = [P]
+    lib.pgv_builder_rows.restype = I64
+    lib.pgv_builder_finish.argtypes = [P, C.POINTER(P), P, P]
+    lib.pgv_builder_free.argtypes = [P]
+    lib.pgv_builder_free.restype = None
+    lib.pgv_index_drain.argtypes = [P, I64, P, P]
     lib.pgv_hnsw_import.argtypes = [P, P, C.POINTER(P)]
     lib.pgv_device_memory.argtypes = [I, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
     lib.pgv_pinned_register.argtypes = [P, C.c_size_t]

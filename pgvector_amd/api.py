@@ -511,6 +511,76 @@ def bit_distance_batch(ctx, metric, nbits, query, rows):
     return out
 
 
+class IvfBuilder:
+    """pgv_builder_*: heap rows assigned and kept on the device, finish() = the tuplesort by list as a device gather
+    whose result is the mirror itself"""
+
+    def __init__(self, ctx, metric, dtype, dim, centers, expected_rows=0):
+        self.ctx, self.metric, self.dtype, self.dim = ctx, metric, dtype, dim
+        centers = as_dtype(centers, dtype)
+        self.nlists = int(centers.shape[0])
+        h = C.c_void_p()
+        check(lib.pgv_builder_begin(ctx.h, metric, dtype, dim, self.nlists, ptr(centers), int(expected_rows), C.byref(h)))
+        self.h = h
+
+    def add(self, rows, tids=None):
+        rows = as_dtype(rows, self.dtype)
+        if tids is not None and not _is_torch(tids):
+            tids = np.ascontiguousarray(tids, dtype=np.uint64)
+        check(lib.pgv_builder_add(self.h, ptr(rows), ptr(tids), int(rows.shape[0])))
+
+    @property
+    def rows(self):
+        return lib.pgv_builder_rows(self.h)
+
+    def finish(self, want_lists=False):
+        """-> (IvfIndex, list_offsets [lists + 1], lists [rows, heap order] or None)"""
+        n = self.rows
+        off = np.empty(self.nlists + 1, dtype=np.int64)
+        lists = np.empty(n, dtype=np.int32) if want_lists else None
+        h = C.c_void_p()
+        check(lib.pgv_builder_finish(self.h, C.byref(h), ptr(off), ptr(lists)))
+        ix = IvfIndex.__new__(IvfIndex)
+        ix.ctx, ix.metric, ix.dtype, ix.dim, ix.h = self.ctx, self.metric, self.dtype, self.dim, h
+        ix.nlists = self.nlists
+        self.ctx._adopt(ix)
+        return ix, off, lists
+
+    def close(self):
+        if self.h:
+            lib.pgv_builder_free(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+_SINK = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_int64, C.c_int64, C.c_void_p, C.c_void_p)
+
+
+def drain_index(index, chunk_rows=0):
+    """pgv_index_drain -> (vectors [n x dim], tids [n]) in list-major order (host copies; a test helper)"""
+    n = index.rows
+    npdt = _NP_OF[index.dtype]
+    vec = np.empty((n, index.dim), dtype=npdt)
+    tids = np.zeros(n, dtype=np.uint64)
+    row_bytes = index.dim * vec.itemsize
+    seen = []
+
+    def sink(_arg, first, count, vptr, tptr):
+        C.memmove(vec.ctypes.data + first * row_bytes, vptr, count * row_bytes)
+        if tptr:
+            C.memmove(tids.ctypes.data + first * 8, tptr, count * 8)
+        seen.append((first, count))
+        return 0
+    cb = _SINK(sink)
+    check(lib.pgv_index_drain(index.h, int(chunk_rows), cb, None))
+    return vec, tids, seen
+
+
 class Hnsw:
     """device mirror of an HNSW index's element vectors (pgv_hnsw_upload)"""
 

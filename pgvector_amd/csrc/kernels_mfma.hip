@@ -148,6 +148,37 @@ template <int NC> __device__ __forceinline__ void keep_best(float (&tv)[NC], int
     }
 }
 
+// what a row's NC best (value, id) pairs turn into: the answer (NC == 1), or for the L2 pre-filter the answer when the
+// runner-up is out of the error bound's reach, else an entry of the recheck list
+template <int NC>
+__device__ __forceinline__ void finish_row(int64_t r, const float (&sv)[NC], const int (&sid)[NC], float x2,
+                                           int32_t *__restrict__ out_idx, float *__restrict__ out_val,
+                                           const unsigned *__restrict__ cmax2_bits, float gamma, float gamma_x,
+                                           int *__restrict__ u_count, int32_t *__restrict__ u_rows,
+                                           int32_t *__restrict__ u_cand, float *__restrict__ u_val) {
+    if constexpr (NC == 1) {
+        out_idx[r] = sid[0];
+        if (out_val) out_val[r] = sv[0] == INFINITY ? FLT_MAX : sv[0];
+    } else {
+        // decided when the runner-up is out of the error bound's reach (k <= kCand: the recheck
+        // sees every center anyway)
+        const float cm2 = __uint_as_float(*cmax2_bits);
+        const float cross = 2.f * sqrtf(x2 * cm2);
+        const float margin = 2.f * (gamma * (cm2 + cross) + gamma_x * (x2 + cm2 + cross));
+        if (sv[0] < INFINITY && sv[1] - sv[0] > margin) {
+            out_idx[r] = sid[0];
+        } else {
+            const int p = atomicAdd(u_count, 1);
+            u_rows[p] = (int32_t)r;
+#pragma unroll
+            for (int c = 0; c < NC; c++) {
+                u_cand[(size_t)p * NC + c] = sid[c];
+                u_val[(size_t)p * NC + c] = sv[c];
+            }
+        }
+    }
+}
+
 // MODE 0: L2 pre-filter (bias - 2 ip, kCand kept)   1: -ip   3: -clamp(ip, -1, 1) (spherical k-means:
 // same argmin as acos(ip)/pi including the ties its clamp creates, src/vector.c:703-722)
 template <typename T, int MODE>
@@ -156,7 +187,8 @@ __global__ __launch_bounds__(MfmaCfg<T>::WM *MfmaCfg<T>::WN * 64, 2) void mfma_a
     const float *__restrict__ bias, const char *__restrict__ zeros16, int32_t *__restrict__ out_idx,
     float *__restrict__ out_val, const unsigned *__restrict__ cmax2_bits, float gamma, float gamma_x,
     int *__restrict__ u_count,
-    int32_t *__restrict__ u_rows, int32_t *__restrict__ u_cand, float *__restrict__ u_val) {
+    int32_t *__restrict__ u_rows, int32_t *__restrict__ u_cand, float *__restrict__ u_val,
+    int nparts, int part_tiles, float *__restrict__ part_val, int32_t *__restrict__ part_idx, float *__restrict__ part_x2) {
     using C = MfmaCfg<T>;
     constexpr int TM = C::TM, TN = C::TN;
     constexpr int BM = C::WM * TM * 32, BN = C::WN * TN * 32;
@@ -171,7 +203,23 @@ __global__ __launch_bounds__(MfmaCfg<T>::WM *MfmaCfg<T>::WN * 64, 2) void mfma_a
     const int wm = wave / C::WN, wn = wave % C::WN;
     const int l31 = lane & 31, half = lane >> 5;
     const unsigned sw = (unsigned)(l31 >> 1) & 7u;
-    const int64_t row_base = (int64_t)blockIdx.x * BN;
+    // Which (row tile, center range) this workgroup owns.  nparts == 1: all centers for row tile blockIdx.x.
+    // nparts > 1 (XCD-aware blocking, see launch_mfma_t): workgroup ids go round the 8 XCDs, so XCD x sees ids
+    // x, x + 8, ...; its s-th workgroup takes center part s % nparts of its (s / nparts)-th row tile.  The ~32
+    // workgroups an XCD runs at a time then share a few row tiles AND walk the same center tiles: both operands
+    // are L2 hits for all but the first reader, instead of every row tile being re-read from MALL / HBM once per
+    // center tile.
+    int64_t row_tile = blockIdx.x;
+    int part = 0;
+    if (nparts > 1) {
+        const int64_t w = blockIdx.x, x = w & 7, sq = w >> 3;
+        part = (int)(sq % nparts);
+        row_tile = x + 8 * (sq / nparts);
+    }
+    const int64_t row_base = row_tile * BN;
+    if (row_base >= n) return;  // (whole workgroup: the padded tail of the XCD round-robin)
+    const int cb_first = part * part_tiles * BM;
+    const int cb_end = nparts > 1 ? (cb_first + part_tiles * BM < k ? cb_first + part_tiles * BM : k) : k;
     const size_t row_bytes = (size_t)nvec * sizeof(Raw16);
     const int nslices = (nvec + 7) / 8;
 
@@ -217,7 +265,7 @@ __global__ __launch_bounds__(MfmaCfg<T>::WM *MfmaCfg<T>::WN * 64, 2) void mfma_a
     const unsigned a_lane = (unsigned)(wm * TM * 32 + l31) * kSliceBytes;
     const unsigned b_lane = (unsigned)(BM + wn * TN * 32 + l31) * kSliceBytes;
 
-    for (int cb = 0; cb < k; cb += BM) {
+    for (int cb = cb_first; cb < cb_end; cb += BM) {
         if (MODE == 0) {
             for (int i = threadIdx.x; i < BM; i += blockDim.x) bias_lds[i] = cb + i < k ? bias[cb + i] : 0.f;
         }
@@ -244,7 +292,7 @@ __global__ __launch_bounds__(MfmaCfg<T>::WM *MfmaCfg<T>::WN * 64, 2) void mfma_a
                 const unsigned x = (((unsigned)(2 * c + half)) ^ sw) << 4;
                 u32x4 a[TM], b[TN];
                 OperandRead<TM, TN>::run(sbase + a_lane + x, sbase + b_lane + x, a, b);
-                if (MODE == 0 && cb == 0) {
+                if (MODE == 0 && cb == cb_first) {
 #pragma unroll
                     for (int tn = 0; tn < TN; tn++) {
                         Raw16 raw;
@@ -335,29 +383,66 @@ __global__ __launch_bounds__(MfmaCfg<T>::WM *MfmaCfg<T>::WN * 64, 2) void mfma_a
             last_id = bid;
             first = false;
         }
-        if constexpr (NC == 1) {
-            out_idx[r] = sid[0];
-            if (out_val) out_val[r] = sv[0] == INFINITY ? FLT_MAX : sv[0];
-        } else {
-            // decided when the runner-up is out of the error bound's reach (k <= kCand: the recheck
-            // sees every center anyway)
-            const float cm2 = __uint_as_float(*cmax2_bits);
-            const float x2 = mx[j * 2] + mx[j * 2 + 1];
-            const float cross = 2.f * sqrtf(x2 * cm2);
-            const float margin = 2.f * (gamma * (cm2 + cross) + gamma_x * (x2 + cm2 + cross));
-            if (sv[0] < INFINITY && sv[1] - sv[0] > margin) {
-                out_idx[r] = sid[0];
-            } else {
-                const int p = atomicAdd(u_count, 1);
-                u_rows[p] = (int32_t)r;
+        if (nparts > 1) {
+            // this part's best NC of its centers: argmin_merge_kernel folds the parts of a row
 #pragma unroll
-                for (int c = 0; c < NC; c++) {
-                    u_cand[(size_t)p * NC + c] = sid[c];
-                    u_val[(size_t)p * NC + c] = sv[c];
-                }
+            for (int c = 0; c < NC; c++) {
+                part_val[((size_t)r * nparts + part) * NC + c] = sv[c];
+                part_idx[((size_t)r * nparts + part) * NC + c] = sid[c];
+            }
+            if (MODE == 0 && part == 0) part_x2[r] = mx[j * 2] + mx[j * 2 + 1];
+            continue;
+        }
+        float x2 = 0.f;
+        if constexpr (NC > 1) x2 = mx[j * 2] + mx[j * 2 + 1];
+        finish_row<NC>(r, sv, sid, x2, out_idx, out_val, cmax2_bits, gamma, gamma_x, u_count, u_rows, u_cand, u_val);
+    }
+}
+
+// the parts of every row (nparts x NC sorted candidates each) -> the row's NC best by (value, id) -> finish_row
+template <int NC>
+__global__ __launch_bounds__(256) void argmin_merge_kernel(int64_t n, int nparts, const float *__restrict__ part_val,
+                                                           const int32_t *__restrict__ part_idx,
+                                                           const float *__restrict__ part_x2, int32_t *__restrict__ out_idx,
+                                                           float *__restrict__ out_val, const unsigned *__restrict__ cmax2_bits,
+                                                           float gamma, float gamma_x, int *__restrict__ u_count,
+                                                           int32_t *__restrict__ u_rows, int32_t *__restrict__ u_cand,
+                                                           float *__restrict__ u_val) {
+    const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= n) return;
+    const float *v = part_val + (size_t)r * nparts * NC;
+    const int32_t *id = part_idx + (size_t)r * nparts * NC;
+    float sv[NC];
+    int sid[NC];
+    float last_v = -INFINITY;
+    int last_id = -1;
+    bool first = true;
+#pragma unroll
+    for (int c = 0; c < NC; c++) {
+        float bv = INFINITY;
+        int bid = 0x7fffffff;
+        for (int e = 0; e < nparts * NC; e++) {
+            const float ev = v[e];
+            const int eid = id[e];
+            // +inf entries are the parts' padding (id 0): never candidates (like the lists inside a workgroup)
+            const bool after = first || ev > last_v || (ev == last_v && eid > last_id);
+            if (after && ev < INFINITY && (ev < bv || (ev == bv && eid < bid))) {
+                bv = ev;
+                bid = eid;
             }
         }
+        if (bid == 0x7fffffff) {
+            bv = INFINITY;
+            bid = 0;
+        }
+        sv[c] = bv;
+        sid[c] = bid;
+        last_v = bv;
+        last_id = bid;
+        first = false;
     }
+    finish_row<NC>(r, sv, sid, NC > 1 ? part_x2[r] : 0.f, out_idx, out_val, cmax2_bits, gamma, gamma_x, u_count, u_rows,
+                   u_cand, u_val);
 }
 
 // bias[c] = |c|^2 in fp32; *cmax2 = max_c |c|^2 (as ordered uint bits; a NaN norm ends up
@@ -503,15 +588,50 @@ int launch_mfma_t(pgv_ctx *ctx, const RowGeom &g, const void *rows, int64_t n, c
     using C = MfmaCfg<T>;
     constexpr int BM = C::WM * C::TM * 32, BN = C::WN * C::TN * 32;
     constexpr int threads = C::WM * C::WN * 64;
+    constexpr int NC = MODE == 0 ? kCand : 1;
     const size_t lds = 2 * (size_t)(BM + BN) * kSliceBytes + sizeof(float) * BM;
     auto kern = mfma_argmin_kernel<T, MODE>;
     PGV_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
                                 (int)lds));
-    const int64_t grid = (n + BN - 1) / BN;
+    const int64_t row_tiles = (n + BN - 1) / BN;
+    // XCD-aware blocking: one center tile per workgroup when there are several.  Every row tile is then read once
+    // per XCD round instead of once per center tile (the center tiles are shared by the workgroups of the round),
+    // and a short n (a Lloyd iteration over 50 k samples) still fills the device.  PGV_ARGMIN_PART_TILES overrides
+    // the center tiles per workgroup (0: all of them, the one-workgroup-per-row-tile form).
+    static const int env_tiles = [] {
+        const char *e = getenv("PGV_ARGMIN_PART_TILES");
+        return e ? atoi(e) : 1;
+    }();
+    const int center_tiles = (k + BM - 1) / BM;
+    int part_tiles = env_tiles <= 0 ? center_tiles : env_tiles;
+    int nparts = (center_tiles + part_tiles - 1) / part_tiles;
+    if (nparts > 64) {
+        part_tiles = (center_tiles + 63) / 64;
+        nparts = (center_tiles + part_tiles - 1) / part_tiles;
+    }
+    float *part_val = nullptr, *part_x2 = nullptr;
+    int32_t *part_idx = nullptr;
+    int64_t grid = row_tiles;
+    if (nparts > 1) {
+        const size_t pv = sizeof(float) * (size_t)n * nparts * NC;
+        PGV_TRY(ctx->mf_d.ensure(2 * pv + sizeof(float) * (size_t)n + 64));
+        part_val = ctx->mf_d.as<float>();
+        part_idx = reinterpret_cast<int32_t *>(ctx->mf_d.as<char>() + pv);
+        part_x2 = reinterpret_cast<float *>(ctx->mf_d.as<char>() + 2 * pv);
+        grid = 8 * ((row_tiles + 7) / 8) * nparts;
+    }
+    if (grid > 0x7fffffff) PGV_FAIL(PGV_ERR_ARG, "assignment: too many workgroups");
     hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(threads), lds, ctx->stream, static_cast<const char *>(rows), n,
                        static_cast<const char *>(centers), k, g.nvec, bias, static_cast<const char *>(ctx->zeros.p),
-                       out_idx, out_val, l2.cmax2, l2.gamma, l2.gamma_x, l2.u_count, l2.u_rows, l2.u_cand, l2.u_val);
+                       out_idx, out_val, l2.cmax2, l2.gamma, l2.gamma_x, l2.u_count, l2.u_rows, l2.u_cand, l2.u_val, nparts,
+                       part_tiles, part_val, part_idx, part_x2);
     PGV_HIP(hipGetLastError());
+    if (nparts > 1) {
+        hipLaunchKernelGGL(argmin_merge_kernel<NC>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, n, nparts,
+                           part_val, part_idx, part_x2, out_idx, out_val, l2.cmax2, l2.gamma, l2.gamma_x, l2.u_count,
+                           l2.u_rows, l2.u_cand, l2.u_val);
+        PGV_HIP(hipGetLastError());
+    }
     return PGV_OK;
 }
 

@@ -503,7 +503,7 @@ void pgv_ctx_destroy(pgv_ctx *ctx) {
                  &ctx->plan_a, &ctx->plan_b, &ctx->plan_c, &ctx->plan_d, &ctx->dist_mat,
                  &ctx->sel_a, &ctx->sel_b, &ctx->km_a, &ctx->km_b, &ctx->km_c, &ctx->km_d,
                  &ctx->km_e, &ctx->km_f, &ctx->km_g, &ctx->stats_dev, &ctx->mf_a, &ctx->mf_b, &ctx->mf_c,
-                 &ctx->zeros, &ctx->ms_a, &ctx->ms_b, &ctx->dense_plan, &ctx->xt_norms};
+                 &ctx->zeros, &ctx->ms_a, &ctx->ms_b, &ctx->dense_plan, &ctx->xt_norms, &ctx->mf_d};
     for (DBuf *b : d) b->release();
     ctx->h_a.release();
     ctx->h_b.release();
@@ -648,33 +648,15 @@ void index_host_tables(pgv_index *ix) {
 }
 }  // namespace
 
-int pgv_index_upload(pgv_ctx *ctx, pgv_metric metric, pgv_dtype dtype, int dim, int nlists,
-                     const void *centers, const int64_t *list_offsets, const void *vectors,
-                     const uint64_t *tids, pgv_index **out) {
-    if (!ctx || !out) PGV_FAIL(PGV_ERR_ARG, "pgv_index_upload: ctx/out is NULL");
-    *out = nullptr;
-    PGV_TRY(check_common(dtype, dim));
-    PGV_TRY(check_metric(metric));
-    // IVFFLAT_MAX_LISTS (src/ivfflat.h:56)
-    if (nlists < 1 || nlists > 32768) PGV_FAIL(PGV_ERR_ARG, "lists %d outside 1..32768", nlists);
-    if (!centers || !list_offsets) PGV_FAIL(PGV_ERR_ARG, "centers/list_offsets is NULL");
-    PGV_HIP(hipSetDevice(ctx->device));
+extern "C++" {
+namespace {
 
-    std::vector<int64_t> off((size_t)nlists + 1);
-    if (is_device_ptr(list_offsets)) {
-        PGV_HIP(hipMemcpy(off.data(), list_offsets, sizeof(int64_t) * off.size(), hipMemcpyDeviceToHost));
-    } else {
-        memcpy(off.data(), list_offsets, sizeof(int64_t) * off.size());
-    }
-    if (off[0] != 0) PGV_FAIL(PGV_ERR_ARG, "list_offsets[0] must be 0");
-    int64_t maxlen = 0;
-    for (int l = 0; l < nlists; l++) {
-        if (off[l + 1] < off[l]) PGV_FAIL(PGV_ERR_ARG, "list_offsets not ascending at list %d", l);
-        if (off[l + 1] - off[l] > maxlen) maxlen = off[l + 1] - off[l];
-    }
+// The mirror of an index whose list offsets are known: one allocation, host tables, the norms the MFMA paths want.
+// `fill` enqueues (on ctx->stream) whatever brings centers / vectors / tids into the carved arrays.
+template <typename Fill>
+int index_create(pgv_ctx *ctx, pgv_metric metric, pgv_dtype dtype, int dim, int nlists, const std::vector<int64_t> &off,
+                 bool has_tids, Fill fill, pgv_index **out) {
     const int64_t n = off[nlists];
-    if (n > 0 && !vectors) PGV_FAIL(PGV_ERR_ARG, "vectors is NULL");
-
     pgv_index *ix = new (std::nothrow) pgv_index();
     if (!ix) PGV_FAIL(PGV_ERR_NOMEM, "out of host memory");
     ix->ctx = ctx;
@@ -691,8 +673,7 @@ int pgv_index_upload(pgv_ctx *ctx, pgv_metric metric, pgv_dtype dtype, int dim, 
     ix->geom = row_geom(dim, dtype);
     ix->h_offsets = off;
     index_host_tables(ix);
-    const size_t es = elem_size(dtype);
-    const size_t row_bytes = (size_t)ix->geom.ld * es;
+    const size_t row_bytes = (size_t)ix->geom.ld * elem_size(dtype);
 
     auto fail = [&](int rc) {
         pgv_index_free(ix);
@@ -700,7 +681,7 @@ int pgv_index_upload(pgv_ctx *ctx, pgv_metric metric, pgv_dtype dtype, int dim, 
     };
     // one allocation for the whole mirror (a single IPC handle exports it): centers | vectors | list_offsets |
     // tids | row_norms | center_norms, each part 256-byte aligned
-    IndexLayout lay = index_layout(nlists, n, row_bytes, tids != nullptr && n > 0, metric == PGV_L2SQ);
+    IndexLayout lay = index_layout(nlists, n, row_bytes, has_tids && n > 0, metric == PGV_L2SQ);
     if (hipMalloc(&ix->arena, lay.bytes) != hipSuccess) {
         (void)hipGetLastError();
         set_error("hipMalloc(%zu) for the index mirror failed", lay.bytes);
@@ -708,32 +689,11 @@ int pgv_index_upload(pgv_ctx *ctx, pgv_metric metric, pgv_dtype dtype, int dim, 
     }
     ix->arena_bytes = lay.bytes;
     index_carve(ix, lay);
-    auto put_rows = [&](void *dst, const void *src, int64_t rows) -> int {
-        if (rows == 0) return PGV_OK;
-        const bool dev = is_device_ptr(src);
-        if (ix->geom.ld == dim) {
-            PGV_HIP(hipMemcpyAsync(dst, src, (size_t)rows * row_bytes,
-                                   dev ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, ctx->stream));
-        } else {
-            PGV_HIP(hipMemsetAsync(dst, 0, (size_t)rows * row_bytes, ctx->stream));
-            PGV_HIP(hipMemcpy2DAsync(dst, row_bytes, src, (size_t)dim * es, (size_t)dim * es,
-                                     (size_t)rows, dev ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice,
-                                     ctx->stream));
-        }
-        return PGV_OK;
-    };
     int rc;
-    if ((rc = put_rows(ix->centers, centers, nlists)) != PGV_OK) return fail(rc);
-    if ((rc = put_rows(ix->vectors, vectors, n)) != PGV_OK) return fail(rc);
+    if ((rc = fill(ix)) != PGV_OK) return fail(rc);
     if (hipMemcpyAsync(ix->list_offsets, ix->h_offsets.data(), sizeof(int64_t) * off.size(),
                        hipMemcpyHostToDevice, ctx->stream) != hipSuccess)
         return fail((set_error("copy of list_offsets failed"), PGV_ERR_DEVICE));
-    if (ix->tids) {
-        if (hipMemcpyAsync(ix->tids, tids, sizeof(uint64_t) * (size_t)n,
-                           is_device_ptr(tids) ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice,
-                           ctx->stream) != hipSuccess)
-            return fail((set_error("copy of tids failed"), PGV_ERR_DEVICE));
-    }
     if (ix->row_norms) {
         // |x|^2 per row and the largest of them: the MFMA scan's expansion of the L2 distance
         if (hipMemsetAsync(ix->row_norms + n, 0, sizeof(float), ctx->stream) != hipSuccess)
@@ -753,6 +713,301 @@ int pgv_index_upload(pgv_ctx *ctx, pgv_metric metric, pgv_dtype dtype, int dim, 
         return fail((set_error("index upload failed: %s", hipGetErrorString(hipGetLastError())), PGV_ERR_DEVICE));
     *out = ix;
     return PGV_OK;
+}
+
+// tightly packed rows (host or device) into padded device rows
+int put_rows(pgv_ctx *ctx, const RowGeom &g, pgv_dtype dtype, int dim, void *dst, const void *src, int64_t rows) {
+    if (rows == 0) return PGV_OK;
+    const size_t es = elem_size(dtype), row_bytes = (size_t)g.ld * es;
+    const bool dev = is_device_ptr(src);
+    if (g.ld == dim) {
+        PGV_HIP(hipMemcpyAsync(dst, src, (size_t)rows * row_bytes, dev ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice,
+                               ctx->stream));
+    } else {
+        PGV_HIP(hipMemsetAsync(dst, 0, (size_t)rows * row_bytes, ctx->stream));
+        PGV_HIP(hipMemcpy2DAsync(dst, row_bytes, src, (size_t)dim * es, (size_t)dim * es, (size_t)rows,
+                                 dev ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, ctx->stream));
+    }
+    return PGV_OK;
+}
+
+}  // namespace
+}  // extern "C++"
+
+int pgv_index_upload(pgv_ctx *ctx, pgv_metric metric, pgv_dtype dtype, int dim, int nlists,
+                     const void *centers, const int64_t *list_offsets, const void *vectors,
+                     const uint64_t *tids, pgv_index **out) {
+    if (!ctx || !out) PGV_FAIL(PGV_ERR_ARG, "pgv_index_upload: ctx/out is NULL");
+    *out = nullptr;
+    PGV_TRY(check_common(dtype, dim));
+    PGV_TRY(check_metric(metric));
+    // IVFFLAT_MAX_LISTS (src/ivfflat.h:56)
+    if (nlists < 1 || nlists > 32768) PGV_FAIL(PGV_ERR_ARG, "lists %d outside 1..32768", nlists);
+    if (!centers || !list_offsets) PGV_FAIL(PGV_ERR_ARG, "centers/list_offsets is NULL");
+    PGV_HIP(hipSetDevice(ctx->device));
+
+    std::vector<int64_t> off((size_t)nlists + 1);
+    if (is_device_ptr(list_offsets)) {
+        PGV_HIP(hipMemcpy(off.data(), list_offsets, sizeof(int64_t) * off.size(), hipMemcpyDeviceToHost));
+    } else {
+        memcpy(off.data(), list_offsets, sizeof(int64_t) * off.size());
+    }
+    if (off[0] != 0) PGV_FAIL(PGV_ERR_ARG, "list_offsets[0] must be 0");
+    for (int l = 0; l < nlists; l++)
+        if (off[l + 1] < off[l]) PGV_FAIL(PGV_ERR_ARG, "list_offsets not ascending at list %d", l);
+    const int64_t n = off[nlists];
+    if (n > 0 && !vectors) PGV_FAIL(PGV_ERR_ARG, "vectors is NULL");
+    return index_create(ctx, metric, dtype, dim, nlists, off, tids != nullptr, [&](pgv_index *ix) -> int {
+        PGV_TRY(put_rows(ctx, ix->geom, dtype, dim, ix->centers, centers, nlists));
+        PGV_TRY(put_rows(ctx, ix->geom, dtype, dim, ix->vectors, vectors, n));
+        if (ix->tids)
+            PGV_HIP(hipMemcpyAsync(ix->tids, tids, sizeof(uint64_t) * (size_t)n,
+                                   is_device_ptr(tids) ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, ctx->stream));
+        return PGV_OK;
+    }, out);
+}
+
+// ------------------------------------------------------------ the build's tuplesort on the device
+struct pgv_builder {
+    pgv_ctx *ctx = nullptr;
+    pgv_metric metric = PGV_L2SQ;
+    pgv_dtype dtype = PGV_F32;
+    int dim = 0, nlists = 0;
+    RowGeom geom{};
+    DBuf centers;  // [nlists x ld]
+    DBuf rows;     // [cap x ld] heap order
+    DBuf tids;     // [cap]
+    DBuf lists;    // [cap] int32
+    int64_t n = 0, cap = 0;
+    bool has_tids = true;
+};
+
+static int builder_reserve(pgv_builder *b, int64_t want) {
+    if (want <= b->cap) return PGV_OK;
+    pgv_ctx *ctx = b->ctx;
+    int64_t cap = b->cap ? b->cap + b->cap / 2 : want;
+    if (cap < want) cap = want;
+    const size_t row_bytes = (size_t)b->geom.ld * elem_size(b->dtype);
+    DBuf rows, tids, lists;
+    PGV_TRY(rows.ensure(row_bytes * (size_t)cap));
+    int rc = tids.ensure(sizeof(uint64_t) * (size_t)cap);
+    if (rc == PGV_OK) rc = lists.ensure(sizeof(int32_t) * (size_t)cap);
+    if (rc == PGV_OK && b->n > 0) {
+        hipError_t e = hipMemcpyAsync(rows.p, b->rows.p, row_bytes * (size_t)b->n, hipMemcpyDeviceToDevice, ctx->stream);
+        if (e == hipSuccess) e = hipMemcpyAsync(tids.p, b->tids.p, sizeof(uint64_t) * (size_t)b->n, hipMemcpyDeviceToDevice, ctx->stream);
+        if (e == hipSuccess) e = hipMemcpyAsync(lists.p, b->lists.p, sizeof(int32_t) * (size_t)b->n, hipMemcpyDeviceToDevice, ctx->stream);
+        if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+        if (e != hipSuccess) {
+            set_error("growing the builder failed: %s", hipGetErrorString(e));
+            rc = PGV_ERR_DEVICE;
+        }
+    }
+    if (rc != PGV_OK) {
+        rows.release();
+        tids.release();
+        lists.release();
+        return rc;
+    }
+    b->rows.release();
+    b->tids.release();
+    b->lists.release();
+    b->rows = rows;
+    b->tids = tids;
+    b->lists = lists;
+    b->cap = cap;
+    return PGV_OK;
+}
+
+int pgv_builder_begin(pgv_ctx *ctx, pgv_metric metric, pgv_dtype dtype, int dim, int nlists, const void *centers,
+                      int64_t expected_rows, pgv_builder **out) {
+    if (!ctx || !out) PGV_FAIL(PGV_ERR_ARG, "pgv_builder_begin: ctx/out is NULL");
+    *out = nullptr;
+    PGV_TRY(check_common(dtype, dim));
+    PGV_TRY(check_metric(metric));
+    if (nlists < 1 || nlists > 32768) PGV_FAIL(PGV_ERR_ARG, "lists %d outside 1..32768", nlists);
+    if (!centers) PGV_FAIL(PGV_ERR_ARG, "centers is NULL");
+    if (expected_rows < 0) PGV_FAIL(PGV_ERR_ARG, "expected_rows < 0");
+    PGV_HIP(hipSetDevice(ctx->device));
+    pgv_builder *b = new (std::nothrow) pgv_builder();
+    if (!b) PGV_FAIL(PGV_ERR_NOMEM, "out of host memory");
+    b->ctx = ctx;
+    b->metric = metric;
+    b->dtype = dtype;
+    b->dim = dim;
+    b->nlists = nlists;
+    b->geom = row_geom(dim, dtype);
+    int rc = b->centers.ensure((size_t)b->geom.ld * elem_size(dtype) * (size_t)nlists);
+    if (rc == PGV_OK) rc = put_rows(ctx, b->geom, dtype, dim, b->centers.p, centers, nlists);
+    if (rc == PGV_OK && hipStreamSynchronize(ctx->stream) != hipSuccess) rc = PGV_ERR_DEVICE;  // the caller may reuse centers
+    if (rc == PGV_OK && expected_rows > 0) rc = builder_reserve(b, expected_rows);
+    if (rc != PGV_OK) {
+        pgv_builder_free(b);
+        return rc;
+    }
+    *out = b;
+    return PGV_OK;
+}
+
+void pgv_builder_free(pgv_builder *b) {
+    if (!b) return;
+    if (b->ctx) (void)hipStreamSynchronize(b->ctx->stream);
+    b->centers.release();
+    b->rows.release();
+    b->tids.release();
+    b->lists.release();
+    delete b;
+}
+
+int64_t pgv_builder_rows(const pgv_builder *b) { return b ? b->n : -1; }
+
+int pgv_builder_add(pgv_builder *b, const void *rows, const uint64_t *tids, int64_t n) {
+    if (!b) PGV_FAIL(PGV_ERR_ARG, "pgv_builder_add: builder is NULL");
+    if (n < 0) PGV_FAIL(PGV_ERR_ARG, "n < 0");
+    if (n == 0) return PGV_OK;
+    if (!rows) PGV_FAIL(PGV_ERR_ARG, "rows is NULL");
+    if (b->n + n > 0xffffffffll) PGV_FAIL(PGV_ERR_ARG, "pgv_builder_add: more than 2^32 rows");
+    if (b->n > 0 && (tids != nullptr) != b->has_tids) PGV_FAIL(PGV_ERR_ARG, "pgv_builder_add: tids given for some batches only");
+    pgv_ctx *ctx = b->ctx;
+    PGV_HIP(hipSetDevice(ctx->device));
+    PGV_TRY(builder_reserve(b, b->n + n));
+    b->has_tids = tids != nullptr;
+    const size_t row_bytes = (size_t)b->geom.ld * elem_size(b->dtype);
+    char *dst = b->rows.as<char>() + (size_t)b->n * row_bytes;
+    PGV_TRY(put_rows(ctx, b->geom, b->dtype, b->dim, dst, rows, n));
+    if (tids)
+        PGV_HIP(hipMemcpyAsync(b->tids.as<uint64_t>() + b->n, tids, sizeof(uint64_t) * (size_t)n,
+                               is_device_ptr(tids) ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, ctx->stream));
+    // AddTupleToSort's argmin (src/ivfbuild.c:183-192) for this batch, where the rows now are
+    PGV_TRY(launch_argmin(ctx, b->metric, b->dtype, b->geom, dst, n, b->centers.p, b->nlists, b->lists.as<int32_t>() + b->n,
+                          nullptr));
+    b->n += n;
+    // host buffers may be reused by the caller right away
+    if (!is_device_ptr(rows) || (tids && !is_device_ptr(tids))) PGV_HIP(hipStreamSynchronize(ctx->stream));
+    return PGV_OK;
+}
+
+int pgv_builder_finish(pgv_builder *b, pgv_index **out_index, int64_t *out_offsets, int32_t *out_lists) {
+    if (!b || !out_index) PGV_FAIL(PGV_ERR_ARG, "pgv_builder_finish: builder/out_index is NULL");
+    *out_index = nullptr;
+    pgv_ctx *ctx = b->ctx;
+    PGV_HIP(hipSetDevice(ctx->device));
+    const int64_t n = b->n;
+    const int nlists = b->nlists;
+    int list_bits = 1;
+    while ((1 << list_bits) < nlists) list_bits++;
+    const size_t sort_bytes = n > 0 ? build_sort_scratch_bytes(n, 32 + list_bits) : 0;
+    // scratch: keys_tmp | keys_sorted | counts | offsets | bad | sort scratch
+    const size_t kb = sizeof(unsigned long long) * (size_t)(n > 0 ? n : 1), cb = sizeof(unsigned long long) * (size_t)nlists,
+                 ob = sizeof(int64_t) * ((size_t)nlists + 1);
+    auto up = [](size_t x) { return (x + 255) & ~(size_t)255; };
+    const size_t o_sorted = up(kb), o_counts = o_sorted + up(kb), o_off = o_counts + up(cb), o_bad = o_off + up(ob),
+                 o_sort = o_bad + 256;
+    DBuf scratch;
+    PGV_TRY(scratch.ensure(o_sort + sort_bytes + 256));
+    char *sp = scratch.as<char>();
+    auto *keys_tmp = reinterpret_cast<unsigned long long *>(sp);
+    auto *keys_sorted = reinterpret_cast<unsigned long long *>(sp + o_sorted);
+    auto *counts = reinterpret_cast<unsigned long long *>(sp + o_counts);
+    auto *offsets_dev = reinterpret_cast<int64_t *>(sp + o_off);
+    int *bad = reinterpret_cast<int *>(sp + o_bad);
+    int rc = launch_build_order(ctx, b->lists.as<int32_t>(), n, nlists, keys_tmp, keys_sorted, counts, offsets_dev, bad,
+                                sp + o_sort, sort_bytes);
+    std::vector<int64_t> off((size_t)nlists + 1);
+    int bad_h = 0;
+    if (rc == PGV_OK) {
+        hipError_t e = hipMemcpyAsync(off.data(), offsets_dev, ob, hipMemcpyDeviceToHost, ctx->stream);
+        if (e == hipSuccess) e = hipMemcpyAsync(&bad_h, bad, sizeof(int), hipMemcpyDeviceToHost, ctx->stream);
+        if (e == hipSuccess && out_lists && n > 0)
+            e = hipMemcpyAsync(out_lists, b->lists.p, sizeof(int32_t) * (size_t)n,
+                               is_device_ptr(out_lists) ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost, ctx->stream);
+        if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+        if (e != hipSuccess) {
+            set_error("pgv_builder_finish: %s", hipGetErrorString(e));
+            rc = PGV_ERR_DEVICE;
+        }
+    }
+    if (rc == PGV_OK && (bad_h || off[nlists] != n)) {
+        set_error("pgv_builder_finish: assignment produced a list id outside 0..%d", nlists - 1);
+        rc = PGV_ERR_STATE;
+    }
+    if (rc == PGV_OK)
+        rc = index_create(ctx, b->metric, b->dtype, b->dim, nlists, off, true, [&](pgv_index *ix) -> int {
+            const size_t row_bytes = (size_t)b->geom.ld * elem_size(b->dtype);
+            PGV_HIP(hipMemcpyAsync(ix->centers, b->centers.p, row_bytes * (size_t)nlists, hipMemcpyDeviceToDevice, ctx->stream));
+            // rows and heap TIDs (heap positions when none were given) into list-major order, heap order inside a list
+            return launch_build_gather(ctx, b->rows.p, keys_sorted, n, b->geom.nvec, ix->vectors,
+                                       b->has_tids ? b->tids.as<uint64_t>() : nullptr, ix->tids);
+        }, out_index);
+    scratch.release();
+    if (rc != PGV_OK) return rc;
+    if (out_offsets) memcpy(out_offsets, off.data(), ob);
+    // the heap-order copy has served
+    b->rows.release();
+    b->tids.release();
+    b->lists.release();
+    b->n = b->cap = 0;
+    return PGV_OK;
+}
+
+// the mirror's rows, list-major, back to the host in pieces: double-buffered D2H into pinned memory, the sink called
+// for piece i while piece i + 1 is on its way
+int pgv_index_drain(pgv_index *ix, int64_t chunk_rows, pgv_rows_sink sink, void *arg) {
+    if (!ix || !sink) PGV_FAIL(PGV_ERR_ARG, "pgv_index_drain: index/sink is NULL");
+    pgv_ctx *ctx = ix->ctx;
+    PGV_HIP(hipSetDevice(ctx->device));
+    const int64_t n = ix->nrows;
+    if (n == 0) return PGV_OK;
+    const size_t es = elem_size(ix->dtype), tight = (size_t)ix->dim * es, padded = (size_t)ix->geom.ld * es;
+    if (chunk_rows <= 0) chunk_rows = (int64_t)std::max<size_t>(1, ((size_t)64 << 20) / tight);
+    if (chunk_rows > n) chunk_rows = n;
+    void *buf[2] = {nullptr, nullptr};
+    hipEvent_t ev[2] = {nullptr, nullptr};
+    const size_t piece = tight * (size_t)chunk_rows + sizeof(uint64_t) * (size_t)chunk_rows;
+    int rc = PGV_OK;
+    for (int i = 0; i < 2 && rc == PGV_OK; i++) {
+        if (hipHostMalloc(&buf[i], piece, hipHostMallocDefault) != hipSuccess) rc = PGV_ERR_NOMEM;
+        if (rc == PGV_OK && hipEventCreateWithFlags(&ev[i], hipEventDisableTiming) != hipSuccess) rc = PGV_ERR_DEVICE;
+    }
+    auto issue = [&](int64_t c, int slot) -> int {
+        const int64_t r0 = c * chunk_rows, cnt = std::min(chunk_rows, n - r0);
+        char *dst = static_cast<char *>(buf[slot]);
+        const char *src = static_cast<const char *>(ix->vectors) + (size_t)r0 * padded;
+        if (padded == tight)
+            PGV_HIP(hipMemcpyAsync(dst, src, tight * (size_t)cnt, hipMemcpyDeviceToHost, ctx->stream));
+        else
+            PGV_HIP(hipMemcpy2DAsync(dst, tight, src, padded, tight, (size_t)cnt, hipMemcpyDeviceToHost, ctx->stream));
+        if (ix->tids)
+            PGV_HIP(hipMemcpyAsync(dst + tight * (size_t)chunk_rows, ix->tids + r0, sizeof(uint64_t) * (size_t)cnt,
+                                   hipMemcpyDeviceToHost, ctx->stream));
+        PGV_HIP(hipEventRecord(ev[slot], ctx->stream));
+        return PGV_OK;
+    };
+    const int64_t nchunks = (n + chunk_rows - 1) / chunk_rows;
+    if (rc == PGV_OK) rc = issue(0, 0);
+    for (int64_t c = 0; c < nchunks && rc == PGV_OK; c++) {
+        const int slot = (int)(c & 1);
+        if (c + 1 < nchunks) rc = issue(c + 1, slot ^ 1);
+        if (rc != PGV_OK) break;
+        if (hipEventSynchronize(ev[slot]) != hipSuccess) {
+            set_error("pgv_index_drain: copy failed");
+            rc = PGV_ERR_DEVICE;
+            break;
+        }
+        const int64_t r0 = c * chunk_rows, cnt = std::min(chunk_rows, n - r0);
+        const char *p = static_cast<const char *>(buf[slot]);
+        const int src = sink(arg, r0, cnt, p, ix->tids ? reinterpret_cast<const uint64_t *>(p + tight * (size_t)chunk_rows) : nullptr);
+        if (src != 0) {
+            set_error("pgv_index_drain: the sink returned %d", src);
+            rc = PGV_ERR_STATE;
+        }
+    }
+    (void)hipStreamSynchronize(ctx->stream);
+    for (int i = 0; i < 2; i++) {
+        if (ev[i]) (void)hipEventDestroy(ev[i]);
+        if (buf[i]) (void)hipHostFree(buf[i]);
+    }
+    if (rc == PGV_ERR_NOMEM) set_error("pgv_index_drain: pinned buffers (2 x %zu bytes) could not be allocated", piece);
+    return rc;
 }
 
 int pgv_index_share(pgv_index *ix, pgv_ctx *ctx, pgv_index **out) {

@@ -113,6 +113,7 @@ struct pgv_ctx {
     int dense_plan_nq = -1;
     bool counters_clean = false;  // ctx->counters starts zeroed; mfma_scan_kernel leaves its words zero again
     pgv::DBuf ms_a;  // MFMA list scan: query norms | candidate values, positions, slots | flags
+    pgv::DBuf mf_d;  // MFMA assignment split over center parts: the parts' candidates per row
     pgv::DBuf mf_a, mf_b, mf_c, zeros;  // MFMA assignment: norms, pre-filter candidates, redo list; 16 zero bytes
     pgv::DBuf stats_dev;  // profiling: {pairs, rows streamed} of the batched list scans, as doubles
     // scratch (pinned host); h_a_busy marks the last async copy out of h_a (waited before reuse)
@@ -297,6 +298,14 @@ int launch_row_norms(pgv_ctx *ctx, pgv_dtype dtype, const RowGeom &g, const void
 int launch_mfma_scan(pgv_ctx *ctx, pgv_metric metric, pgv_dtype dtype, const RowGeom &g, const void *rows,
                      const void *queries, const ScanTask *tasks, const int *ntasks_dev, int ntasks_bound,
                      const ScanPair *pairs, const float *row_norms, const float *query_norms, float *out);
+
+// kernels_build.hip: the build's tuplesort on the device (order by list, heap order inside; gather)
+size_t build_sort_scratch_bytes(int64_t n, int key_bits);
+int launch_build_order(pgv_ctx *ctx, const int32_t *lists, int64_t n, int nlists, unsigned long long *keys_tmp,
+                       unsigned long long *keys_sorted, unsigned long long *counts, int64_t *offsets, int *bad,
+                       void *sort_scratch, size_t sort_scratch_bytes);
+int launch_build_gather(pgv_ctx *ctx, const void *src_rows, const unsigned long long *keys_sorted, int64_t n, int nvec,
+                        void *dst_rows, const uint64_t *src_tids, uint64_t *dst_tids);
 
 // kernels_select.hip: planning + top-k selection
 struct PlanResult {

@@ -1,7 +1,7 @@
 /*
- * ivf_build.c -- BuildIndex (src/ivfbuild.c:1040-1058) with the distance loops on
- * the GPU: ComputeCenters -> pgv_kmeans, AssignTuples/AddTupleToSort -> pgv_assign
- * in batches, tuplesort by list -> stable counting sort, then the page writers.
+ * ivf_build.c -- BuildIndex (src/ivfbuild.c:1040-1058) with the distance loops and the sort on
+ * the GPU: ComputeCenters -> pgv_kmeans, AssignTuples/AddTupleToSort -> pgv_builder_add in batches,
+ * tuplesort by list -> pgv_builder_finish (its result is the device mirror), the page writers fed by pgv_index_drain.
  */
 #include "pgv_host.h"
 
@@ -69,28 +69,44 @@ normalize_all(pgv_dtype dtype, int dim, const void *in, int64_t n, int64_t *out_
 	return out;
 }
 
+typedef struct
+{
+	pgv_ivf_writer *writer;
+}			drain_sink;
+
+static int
+write_rows(void *arg, int64_t first_slot, int64_t count, const void *vectors, const uint64_t *tids)
+{
+	drain_sink *s = arg;
+
+	return pgv_host_ivf_writer_fill(s->writer, first_slot, count, vectors, tids) == PGV_OK ? 0 : 1;
+}
+
 int
-pgv_host_ivf_build(pgv_ctx * ctx, pgv_ops ops, pgv_dtype dtype, int dim, int lists,
-				   const void *rows, const uint64_t *tids, int64_t n,
-				   const void *samples, int nsamples, const pgv_rng * rng, pgv_rel * out_rel)
+pgv_host_ivf_build_mirror(pgv_ctx * ctx, pgv_ops ops, pgv_dtype dtype, int dim, int lists,
+						  const void *rows, const uint64_t *tids, int64_t n,
+						  const void *samples, int nsamples, const pgv_rng * rng, pgv_rel * out_rel,
+						  pgv_index * *out_index)
 {
 	size_t		es = dtype == PGV_F32 ? 4 : 2;
 	size_t		row_bytes = (size_t) dim * es;
 	void	   *centers = NULL;
-	int32_t    *list_of = NULL;
 	int64_t    *offsets = NULL;
-	int64_t    *dest = NULL;
-	void	   *sorted = NULL;
-	uint64_t   *sorted_tids = NULL;
+	uint64_t   *kept_tids = NULL;
 	void	   *norm_rows = NULL,
 			   *norm_samples = NULL;
 	int64_t    *row_keep = NULL,
 			   *sample_keep = NULL;
+	pgv_ivf_writer *writer = NULL;
+	pgv_builder *builder = NULL;
+	pgv_index  *index = NULL;
 	pgv_metric	metric = ops == PGV_OPS_L2 ? PGV_L2SQ : PGV_NEG_IP;
 	int			rc = PGV_OK;
 	double		t0 = now_secs(),
 				t1;
 
+	if (out_index)
+		*out_index = NULL;
 	memset(build_phase_secs, 0, sizeof(build_phase_secs));
 	/* SampleCallback / BuildCallback normalisation for opclasses with the NORM procs */
 	if (ops != PGV_OPS_L2 && nsamples > 0)
@@ -118,22 +134,32 @@ pgv_host_ivf_build(pgv_ctx * ctx, pgv_ops ops, pgv_dtype dtype, int dim, int lis
 		}
 		rows = norm_rows;
 		n = m;
+		/* rows with a zero norm are not indexed (src/ivfbuild.c:232-236): the TIDs of the kept ones */
+		kept_tids = malloc(sizeof(uint64_t) * (size_t) (n > 0 ? n : 1));
+		if (!kept_tids)
+		{
+			rc = pgv_host_fail(PGV_ERR_NOMEM, "out of memory");
+			goto out;
+		}
+		for (int64_t r = 0; r < n; r++)
+			kept_tids[r] = tids[row_keep[r]];
+		tids = kept_tids;
 	}
 	t1 = now_secs();
 	build_phase_secs[0] = t1 - t0;
 	t0 = t1;
 
 	centers = malloc(row_bytes * (size_t) lists);
-	list_of = malloc(sizeof(int32_t) * (size_t) (n > 0 ? n : 1));
 	offsets = calloc((size_t) lists + 1, sizeof(int64_t));
-	dest = malloc(sizeof(int64_t) * (size_t) (n > 0 ? n : 1));
-	sorted = pgv_host_big_alloc(row_bytes * (size_t) (n > 0 ? n : 1));
-	sorted_tids = malloc(sizeof(uint64_t) * (size_t) (n > 0 ? n : 1));
-	if (!centers || !list_of || !offsets || !dest || !sorted || !sorted_tids)
+	if (!centers || !offsets)
 	{
 		rc = pgv_host_fail(PGV_ERR_NOMEM, "out of memory");
 		goto out;
 	}
+	/* the page array is allocated now and zeroed on background threads while the device works */
+	rc = pgv_host_ivf_writer_begin(out_rel, dtype, dim, lists, n, &writer);
+	if (rc != PGV_OK)
+		goto out;
 
 	/* ComputeCenters, src/ivfbuild.c:434-480 */
 	rc = pgv_kmeans(ctx, ops, dtype, dim, samples, nsamples, lists, 500, rng, centers, NULL, NULL);
@@ -145,62 +171,73 @@ pgv_host_ivf_build(pgv_ctx * ctx, pgv_ops ops, pgv_dtype dtype, int dim, int lis
 	t1 = now_secs();
 	build_phase_secs[1] = t1 - t0;
 	t0 = t1;
-	/* AssignTuples: every heap row to its nearest center, in callback-sized batches */
-	for (int64_t r0 = 0; r0 < n; r0 += ASSIGN_BATCH)
+	/* AssignTuples: every heap row to the device and to its nearest center, in callback-sized batches */
+	rc = pgv_builder_begin(ctx, metric, dtype, dim, lists, centers, n, &builder);
+	for (int64_t r0 = 0; r0 < n && rc == PGV_OK; r0 += ASSIGN_BATCH)
 	{
 		int64_t		cnt = n - r0 < ASSIGN_BATCH ? n - r0 : ASSIGN_BATCH;
 
-		rc = pgv_assign(ctx, metric, dtype, dim, centers, lists, (const char *) rows + (size_t) r0 * row_bytes, cnt,
-						list_of + r0, NULL);
-		if (rc != PGV_OK)
-		{
-			pgv_host_fail(rc, "%s", pgv_last_error());
-			goto out;
-		}
+		rc = pgv_builder_add(builder, (const char *) rows + (size_t) r0 * row_bytes, tids + r0, cnt);
+	}
+	if (rc != PGV_OK)
+	{
+		pgv_host_fail(rc, "%s", pgv_last_error());
+		goto out;
 	}
 	t1 = now_secs();
 	build_phase_secs[2] = t1 - t0;
 	t0 = t1;
-	/* tuplesort on the list id (src/ivfbuild.c:606-615), heap order kept inside a list: destinations by a
-	 * serial counting pass (8 bytes per row), the 3-6 KB payload copies in parallel */
-	for (int64_t r = 0; r < n; r++)
-		offsets[list_of[r] + 1]++;
-	for (int l = 0; l < lists; l++)
-		offsets[l + 1] += offsets[l];
+	/* tuplesort on the list id (src/ivfbuild.c:606-615), heap order kept inside a list: a gather on the device,
+	 * whose result is the mirror */
+	rc = pgv_builder_finish(builder, &index, offsets, NULL);
+	if (rc != PGV_OK)
 	{
-		int64_t    *fill = malloc(sizeof(int64_t) * (size_t) lists);
-
-		if (!fill)
-		{
-			rc = pgv_host_fail(PGV_ERR_NOMEM, "out of memory");
-			goto out;
-		}
-		memcpy(fill, offsets, sizeof(int64_t) * (size_t) lists);
-		for (int64_t r = 0; r < n; r++)
-			dest[r] = fill[list_of[r]]++;
-		free(fill);
-	}
-#pragma omp parallel for schedule(static)
-	for (int64_t r = 0; r < n; r++)
-	{
-		memcpy((char *) sorted + (size_t) dest[r] * row_bytes, (const char *) rows + (size_t) r * row_bytes, row_bytes);
-		sorted_tids[dest[r]] = tids[row_keep ? row_keep[r] : r];
+		pgv_host_fail(rc, "%s", pgv_last_error());
+		goto out;
 	}
 	t1 = now_secs();
 	build_phase_secs[3] = t1 - t0;
 	t0 = t1;
-	rc = pgv_host_ivf_write_index(out_rel, dtype, dim, lists, centers, offsets, sorted, sorted_tids);
+	/* InsertTuples (:271-331): page headers from the list lengths, tuples as the sorted rows come back */
+	rc = pgv_host_ivf_writer_layout(writer, centers, offsets);
+	if (rc == PGV_OK && n > 0)
+	{
+		drain_sink	sink = {writer};
+
+		rc = pgv_index_drain(index, 0, write_rows, &sink);
+		if (rc != PGV_OK)
+			pgv_host_fail(rc, "%s | %s", pgv_last_error(), pgv_host_last_error());
+	}
 	build_phase_secs[4] = now_secs() - t0;
 out:
-	free(dest);
-	free(sorted);
-	free(sorted_tids);
+	pgv_host_ivf_writer_end(writer);
+	if (builder)
+		pgv_builder_free(builder);
+	if (rc != PGV_OK)
+	{
+		pgv_rel_free(out_rel);
+		if (index)
+			pgv_index_free(index);
+		index = NULL;
+	}
+	if (out_index)
+		*out_index = index;
+	else if (index)
+		pgv_index_free(index);
 	free(offsets);
-	free(list_of);
 	free(centers);
+	free(kept_tids);
 	free(norm_rows);
 	free(norm_samples);
 	free(row_keep);
 	free(sample_keep);
 	return rc;
+}
+
+int
+pgv_host_ivf_build(pgv_ctx * ctx, pgv_ops ops, pgv_dtype dtype, int dim, int lists,
+				   const void *rows, const uint64_t *tids, int64_t n,
+				   const void *samples, int nsamples, const pgv_rng * rng, pgv_rel * out_rel)
+{
+	return pgv_host_ivf_build_mirror(ctx, ops, dtype, dim, lists, rows, tids, n, samples, nsamples, rng, out_rel, NULL);
 }

@@ -263,27 +263,223 @@ form_index_tuple(uint8_t *dst, pgv_dtype t, int dim, const void *payload, uint64
 
 /* ------------------------------------------------------------------ writers */
 
-int
-pgv_host_ivf_write_index(pgv_rel * rel, pgv_dtype dtype, int dim, int lists,
-						 const void *centers, const int64_t *list_offsets,
-						 const void *vectors, const uint64_t *tids)
+/*
+ * The index's pages in three steps, so that a build can overlap them with the device's work:
+ *
+ *   pgv_host_ivf_writer_begin   (before the rows are assigned) the page array for at most max_rows tuples, being
+ *                               zeroed -- the first touch of 8 GB of fresh memory (1 M x 1536) is page-fault
+ *                               bound -- by background threads while the GPU runs k-means and the assignment
+ *   pgv_host_ivf_writer_layout  (list lengths known) CreateMetaPage, CreateListPages (src/ivfbuild.c:485-556), and
+ *                               every entry page stamped with its FINAL header, line pointers and chain link: every
+ *                               index tuple of one index has the same size, so how many fit a page, each list's page
+ *                               range and each tuple's place are known from the lengths alone
+ *   pgv_host_ivf_writer_fill    InsertTuples (:271-331) for a run of slots of the sorted stream: the tuples
+ *                               themselves, any run in any order, rows in parallel
+ *
+ * The pages come out as the reference's leader writes them one list after another.
+ */
+#include <pthread.h>
+
+#define PREFAULT_PIECE ((size_t) 2 << 20)
+#define PREFAULT_THREADS 16
+
+struct pgv_ivf_writer
 {
+	pgv_rel    *rel;
+	pgv_dtype	dtype;
+	int			dim,
+				lists;
+	size_t		tuple_size;		/* MAXALIGNed size of every index tuple */
+	int			per_page;
+	uint32_t	cap_blocks;		/* pages allocated */
+	uint32_t   *first_blk;		/* [lists + 1] page range of every list (after layout) */
+	int64_t    *offsets;		/* [lists + 1] */
+	/* prefault */
+	pthread_t	threads[PREFAULT_THREADS];
+	int			nthreads;
+	int			joined;
+};
+
+typedef struct
+{
+	uint8_t    *base;
+	size_t		bytes;
+	int			t,
+				nthreads;
+}			prefault_job;
+
+static void *
+prefault_main(void *arg)
+{
+	prefault_job *j = arg;
+
+	for (size_t off = (size_t) j->t * PREFAULT_PIECE; off < j->bytes; off += (size_t) j->nthreads * PREFAULT_PIECE)
+		memset(j->base + off, 0, j->bytes - off < PREFAULT_PIECE ? j->bytes - off : PREFAULT_PIECE);
+	free(j);
+	return NULL;
+}
+
+static void
+writer_join(pgv_ivf_writer * w)
+{
+	if (!w->joined)
+		for (int t = 0; t < w->nthreads; t++)
+			pthread_join(w->threads[t], NULL);
+	w->joined = 1;
+}
+
+/* how many index tuples of this index fit a page (PageAddItem until it refuses) and their size */
+static int
+tuples_per_page(pgv_dtype dtype, int dim, size_t *tuple_size)
+{
+	uint8_t    *probe = calloc(1, PGV_BLCKSZ);
+	uint8_t    *item = calloc(1, PGV_BLCKSZ);
+	page_header *h = (page_header *) probe;
+	int			per_page = 0;
+	void	   *payload = calloc((size_t) dim, elem_bytes(dtype));
+
+	*tuple_size = form_index_tuple(item, dtype, dim, payload, 0);
+	h->pd_lower = PAGE_HEADER_SIZE;
+	h->pd_special = PGV_BLCKSZ - SPECIAL_SIZE;
+	h->pd_upper = h->pd_special;
+	while (page_free_space(probe) >= *tuple_size && page_add_item(probe, item, *tuple_size))
+		per_page++;
+	free(payload);
+	free(item);
+	free(probe);
+	return per_page;
+}
+
+/* pages the list tuples need (CreateListPages appends a page whenever the next list tuple does not fit) */
+static uint32_t
+list_pages_needed(pgv_dtype dtype, int dim, int lists)
+{
+	size_t		list_size = MAXALIGN8(8 + varlena_size(dtype, dim));
+	size_t		room = PGV_BLCKSZ - PAGE_HEADER_SIZE - SPECIAL_SIZE;
+	int			per = (int) (room / (list_size + ITEMID_SIZE));
+
+	return per < 1 ? 0 : (uint32_t) ((lists + per - 1) / per);
+}
+
+int
+pgv_host_ivf_writer_begin(pgv_rel * rel, pgv_dtype dtype, int dim, int lists, int64_t max_rows, pgv_ivf_writer * *out)
+{
+	pgv_ivf_writer *w;
+	size_t		list_size = MAXALIGN8(8 + varlena_size(dtype, dim));
+	uint64_t	blocks;
+	size_t		bytes;
+
+	*out = NULL;
+	pgv_rel_free(rel);
+	if (list_size + ITEMID_SIZE > PGV_BLCKSZ - PAGE_HEADER_SIZE - SPECIAL_SIZE)
+		return pgv_host_fail(PGV_ERR_DIMS, "vector does not fit an 8 KB page (max 2000 / 4000 dimensions)");
+	w = calloc(1, sizeof(*w));
+	if (!w)
+		return pgv_host_fail(PGV_ERR_NOMEM, "out of memory");
+	w->rel = rel;
+	w->dtype = dtype;
+	w->dim = dim;
+	w->lists = lists;
+	w->per_page = tuples_per_page(dtype, dim, &w->tuple_size);
+	if (w->per_page < 1)
+	{
+		free(w);
+		return pgv_host_fail(PGV_ERR_STATE, "failed to add index item");
+	}
+	/* meta + list pages + at most one partly filled page per list beyond the full ones */
+	blocks = 1 + (uint64_t) list_pages_needed(dtype, dim, lists) + (uint64_t) (max_rows / w->per_page) + (uint64_t) lists + 1;
+	if (blocks >= PGV_INVALID_BLOCK)
+	{
+		free(w);
+		return pgv_host_fail(PGV_ERR_ARG, "index too large for 32-bit block numbers");
+	}
+	bytes = (size_t) blocks * PGV_BLCKSZ;
+	rel->pages = pgv_host_big_alloc(bytes);
+	if (!rel->pages)
+	{
+		free(w);
+		return pgv_host_fail(PGV_ERR_NOMEM, "out of memory for %llu pages", (unsigned long long) blocks);
+	}
+	rel->cap = (uint32_t) blocks;
+	rel->nblocks = 0;
+	w->cap_blocks = (uint32_t) blocks;
+	/* zero the array (what init_page's memset would do page by page) on threads of its own */
+	{
+		int			want = bytes >= ((size_t) 64 << 20) ? PREFAULT_THREADS : 1;
+
+		w->nthreads = 0;
+		for (int t = 0; t < want; t++)
+		{
+			prefault_job *j = malloc(sizeof(*j));
+
+			if (!j)
+			{
+				writer_join(w);
+				free(w);
+				pgv_rel_free(rel);
+				return pgv_host_fail(PGV_ERR_NOMEM, "out of memory");
+			}
+			j->base = rel->pages;
+			j->bytes = bytes;
+			j->t = t;
+			j->nthreads = want;
+			if (pthread_create(&w->threads[w->nthreads], NULL, prefault_main, j) == 0)
+				w->nthreads++;
+			else
+				prefault_main(j);	/* no thread to be had: this share is done here */
+		}
+	}
+	*out = w;
+	return PGV_OK;
+}
+
+/* IvfflatInitPage on zeroed memory: the header and the special space */
+static void
+stamp_page(uint8_t *page, int count, size_t tuple_size, uint32_t nextblkno)
+{
+	page_header *h = (page_header *) page;
+
+	h->pd_special = PGV_BLCKSZ - SPECIAL_SIZE;
+	h->pd_lower = (uint16_t) (PAGE_HEADER_SIZE + ITEMID_SIZE * count);
+	h->pd_upper = (uint16_t) (h->pd_special - (size_t) count * tuple_size);
+	h->pd_pagesize_version = PGV_BLCKSZ | 4;	/* PG_PAGE_LAYOUT_VERSION */
+	page_opaque(page)->nextblkno = nextblkno;
+	page_opaque(page)->page_id = IVFFLAT_PAGE_ID;
+	for (int j = 0; j < count; j++)
+	{
+		uint32_t	upper = (uint32_t) (h->pd_special - (size_t) (j + 1) * tuple_size);
+		uint32_t	lp = upper | ((uint32_t) LP_NORMAL << 15) | ((uint32_t) tuple_size << 17);
+
+		memcpy(page + PAGE_HEADER_SIZE + (size_t) j * ITEMID_SIZE, &lp, 4);
+	}
+}
+
+int
+pgv_host_ivf_writer_layout(pgv_ivf_writer * w, const void *centers, const int64_t *list_offsets)
+{
+	pgv_rel    *rel = w->rel;
+	pgv_dtype	dtype = w->dtype;
+	int			dim = w->dim,
+				lists = w->lists;
 	size_t		es = elem_bytes(dtype);
-	size_t		list_size = MAXALIGN8(8 + varlena_size(dtype, dim));	/* MAXALIGN(IVFFLAT_LIST_SIZE) */
+	size_t		list_size = MAXALIGN8(8 + varlena_size(dtype, dim));
 	uint8_t    *item = calloc(1, list_size > PGV_BLCKSZ ? list_size : PGV_BLCKSZ);
 	uint32_t   *list_blk = malloc(sizeof(uint32_t) * (size_t) lists);
 	int		   *list_off = malloc(sizeof(int) * (size_t) lists);
 	uint32_t	blk;
 	ivf_meta	meta;
 
-	pgv_rel_free(rel);
-	if (list_size + ITEMID_SIZE > PGV_BLCKSZ - PAGE_HEADER_SIZE - SPECIAL_SIZE)
+	writer_join(w);
+	w->first_blk = malloc(sizeof(uint32_t) * ((size_t) lists + 1));
+	w->offsets = malloc(sizeof(int64_t) * ((size_t) lists + 1));
+	if (!item || !list_blk || !list_off || !w->first_blk || !w->offsets)
 	{
 		free(item);
 		free(list_blk);
 		free(list_off);
-		return pgv_host_fail(PGV_ERR_DIMS, "vector does not fit an 8 KB page (max 2000 / 4000 dimensions)");
+		return pgv_host_fail(PGV_ERR_NOMEM, "out of memory");
 	}
+	memcpy(w->offsets, list_offsets, sizeof(int64_t) * ((size_t) lists + 1));
 
 	/* CreateMetaPage, src/ivfbuild.c:485-506 */
 	blk = rel_new_page(rel);
@@ -310,115 +506,135 @@ pgv_host_ivf_write_index(pgv_rel * rel, pgv_dtype dtype, int dim, int lists,
 		list_blk[i] = blk;
 	}
 
-	/*
-	 * InsertTuples, :271-331.  Every index tuple of one index has the same size, so how many fit a page --
-	 * and with it every list's page range -- is known up front: the page array is grown once and the lists,
-	 * which share nothing, are written in parallel (the reference's leader writes them one after another;
-	 * the pages come out byte-identical).
-	 */
+	/* every list's page range (an empty list still owns its start page) */
+	w->first_blk[0] = rel->nblocks;
+	for (int i = 0; i < lists; i++)
 	{
-		size_t		tuple_size;
-		int			per_page = 0;
-		uint32_t   *first_blk = malloc(sizeof(uint32_t) * ((size_t) lists + 1));
-		uint32_t	base = rel->nblocks;
-		int			failed = 0;
+		int64_t		len = list_offsets[i + 1] - list_offsets[i];
+		int64_t		np = len > 0 ? (len + w->per_page - 1) / w->per_page : 1;
 
-		{
-			uint8_t    *probe = calloc(1, PGV_BLCKSZ);
-			page_header *h = (page_header *) probe;
-			tuple_size = form_index_tuple(item, dtype, dim, vectors ? vectors : centers, 0);
-			h->pd_lower = PAGE_HEADER_SIZE;
-			h->pd_special = PGV_BLCKSZ - SPECIAL_SIZE;
-			h->pd_upper = h->pd_special;
-			while (page_free_space(probe) >= tuple_size && page_add_item(probe, item, tuple_size))
-				per_page++;
-			free(probe);
-		}
-		if (per_page < 1)
-		{
-			free(first_blk);
-			free(item);
-			free(list_blk);
-			free(list_off);
-			return pgv_host_fail(PGV_ERR_STATE, "failed to add index item");
-		}
-		first_blk[0] = base;
-		for (int i = 0; i < lists; i++)
-		{
-			int64_t		len = list_offsets[i + 1] - list_offsets[i];
-			int64_t		np = len > 0 ? (len + per_page - 1) / per_page : 1;	/* an empty list still owns its start page */
+		w->first_blk[i + 1] = w->first_blk[i] + (uint32_t) np;
+	}
+	if (w->first_blk[lists] > w->cap_blocks)
+	{
+		free(item);
+		free(list_blk);
+		free(list_off);
+		return pgv_host_fail(PGV_ERR_ARG, "more rows than pgv_host_ivf_writer_begin was told");
+	}
+	rel->nblocks = w->first_blk[lists];
+#pragma omp parallel for schedule(static)
+	for (int i = 0; i < lists; i++)
+	{
+		int64_t		len = list_offsets[i + 1] - list_offsets[i];
+		uint32_t	last = w->first_blk[i + 1] - 1;
+		uint8_t    *list_item;
 
-			first_blk[i + 1] = first_blk[i] + (uint32_t) np;
-		}
-		if (first_blk[lists] > rel->cap)
+		for (uint32_t b = w->first_blk[i]; b <= last; b++)
 		{
-			/* one growth to the final size, into huge-page-friendly memory (the pages so far: meta + lists) */
-			uint8_t    *grown = pgv_host_big_alloc((size_t) first_blk[lists] * PGV_BLCKSZ);
+			int64_t		left = len - (int64_t) (b - w->first_blk[i]) * w->per_page;
+			int			count = (int) (left > w->per_page ? w->per_page : (left > 0 ? left : 0));
 
-			if (grown && rel->nblocks > 0)
-				memcpy(grown, rel->pages, (size_t) rel->nblocks * PGV_BLCKSZ);
-			if (grown)
-			{
-				free(rel->pages);
-				rel->pages = grown;
-				rel->cap = first_blk[lists];
-			}
-			else
-				failed = 1;
+			stamp_page(page_at(rel, b), count, w->tuple_size, b < last ? b + 1 : PGV_INVALID_BLOCK);	/* IvfflatAppendPage links */
 		}
-		if (failed || !rel->pages)
-			failed = 1;
-		else
-		{
-			/* IvfflatInitPage of a list's pages by the thread that fills them: the first touch of 8 GB of fresh
-			 * memory (1 M x 1536) is page-fault bound and took ~1 s when one thread did it up front */
-			rel->nblocks = first_blk[lists];
-#pragma omp parallel for schedule(dynamic, 4)
-			for (int i = 0; i < lists; i++)
-			{
-				uint8_t		tuple[PGV_BLCKSZ];
-				uint32_t	cur = first_blk[i];
-				uint8_t    *list_item;
-
-				for (uint32_t b = first_blk[i]; b < first_blk[i + 1]; b++)
-					init_page(page_at(rel, b));
-
-				for (int64_t r = list_offsets[i]; r < list_offsets[i + 1]; r++)
-				{
-					size_t		sz = form_index_tuple(tuple, dtype, dim, (const char *) vectors + (size_t) r * dim * es, tids[r]);
-
-					if (page_free_space(page_at(rel, cur)) < sz)
-					{
-						page_opaque(page_at(rel, cur))->nextblkno = cur + 1;	/* IvfflatAppendPage */
-						cur++;
-					}
-					if (cur >= first_blk[i + 1] || !page_add_item(page_at(rel, cur), tuple, sz))
-					{
-#pragma omp atomic write
-						failed = 1;
-						break;
-					}
-				}
-				/* IvfflatUpdateList: record start and insert page in the list tuple */
-				list_item = page_item(page_at(rel, list_blk[i]), list_off[i], NULL);
-				memcpy(list_item + 0, &first_blk[i], 4);
-				memcpy(list_item + 4, &cur, 4);
-			}
-		}
-		free(first_blk);
-		if (failed)
-		{
-			free(item);
-			free(list_blk);
-			free(list_off);
-			return pgv_host_fail(PGV_ERR_STATE, "failed to add index item");
-		}
+		/* IvfflatUpdateList: start and insert page in the list tuple */
+		list_item = page_item(page_at(rel, list_blk[i]), list_off[i], NULL);
+		memcpy(list_item + 0, &w->first_blk[i], 4);
+		memcpy(list_item + 4, &last, 4);
 	}
 	free(item);
 	free(list_blk);
 	free(list_off);
-	rel->generation++;
 	return PGV_OK;
+}
+
+int
+pgv_host_ivf_writer_fill(pgv_ivf_writer * w, int64_t first_slot, int64_t count, const void *vectors, const uint64_t *tids)
+{
+	pgv_rel    *rel = w->rel;
+	size_t		row_bytes = (size_t) w->dim * elem_bytes(w->dtype);
+	int64_t		n = w->offsets ? w->offsets[w->lists] : -1;
+	int			lists = w->lists;
+
+	if (n < 0)
+		return pgv_host_fail(PGV_ERR_STATE, "pgv_host_ivf_writer_fill before pgv_host_ivf_writer_layout");
+	if (first_slot < 0 || count < 0 || first_slot + count > n)
+		return pgv_host_fail(PGV_ERR_ARG, "slots [%lld, %lld) outside the %lld rows laid out", (long long) first_slot,
+							 (long long) (first_slot + count), (long long) n);
+#pragma omp parallel
+	{
+		uint8_t		tuple[PGV_BLCKSZ];
+		int			l = 0;
+
+		memset(tuple, 0, sizeof(tuple));
+#pragma omp for schedule(static)
+		for (int64_t r = 0; r < count; r++)
+		{
+			int64_t		slot = first_slot + r;
+			int64_t		in_list;
+			uint8_t    *page;
+			int			j;
+			size_t		sz;
+
+			/* the list of this slot: slots arrive ascending within a thread's share, so walk; else bisect */
+			if (!(w->offsets[l] <= slot && slot < w->offsets[l + 1]))
+			{
+				int			lo = 0,
+							hi = lists - 1;
+
+				while (lo < hi)
+				{
+					int			mid = (lo + hi + 1) >> 1;
+
+					if (w->offsets[mid] <= slot)
+						lo = mid;
+					else
+						hi = mid - 1;
+				}
+				l = lo;
+				while (w->offsets[l + 1] <= slot)	/* empty lists share their offset with the next one */
+					l++;
+			}
+			in_list = slot - w->offsets[l];
+			page = page_at(rel, w->first_blk[l] + (uint32_t) (in_list / w->per_page));
+			j = (int) (in_list % w->per_page);
+			sz = form_index_tuple(tuple, w->dtype, w->dim, (const char *) vectors + (size_t) r * row_bytes, tids ? tids[r] : 0);
+			memcpy(page + (PGV_BLCKSZ - SPECIAL_SIZE) - (size_t) (j + 1) * w->tuple_size, tuple, sz);
+		}
+	}
+	return PGV_OK;
+}
+
+int
+pgv_host_ivf_writer_end(pgv_ivf_writer * w)
+{
+	if (!w)
+		return PGV_OK;
+	writer_join(w);
+	if (w->rel)
+		w->rel->generation++;
+	free(w->first_blk);
+	free(w->offsets);
+	free(w);
+	return PGV_OK;
+}
+
+int
+pgv_host_ivf_write_index(pgv_rel * rel, pgv_dtype dtype, int dim, int lists,
+						 const void *centers, const int64_t *list_offsets,
+						 const void *vectors, const uint64_t *tids)
+{
+	pgv_ivf_writer *w = NULL;
+	int			rc = pgv_host_ivf_writer_begin(rel, dtype, dim, lists, list_offsets[lists], &w);
+
+	if (rc == PGV_OK)
+		rc = pgv_host_ivf_writer_layout(w, centers, list_offsets);
+	if (rc == PGV_OK && list_offsets[lists] > 0)
+		rc = pgv_host_ivf_writer_fill(w, 0, list_offsets[lists], vectors, tids);
+	pgv_host_ivf_writer_end(w);
+	if (rc != PGV_OK)
+		pgv_rel_free(rel);
+	return rc;
 }
 
 /* locate list tuple `list` (list pages hold them in id order, src/ivfbuild.c:527-551) */

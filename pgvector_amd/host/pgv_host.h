@@ -167,6 +167,20 @@ int			pgv_host_ivf_write_index(pgv_rel * rel, pgv_dtype dtype, int dim, int list
 									 const void *centers, const int64_t *list_offsets,
 									 const void *vectors, const uint64_t *tids);
 
+/*
+ * The same in steps a build overlaps with the device's work (ivf_pages.c): begin -- the page array for at most
+ * max_rows tuples, zeroed by background threads; layout -- meta page, list pages and every entry page's final
+ * header / line pointers / chain link from the list lengths alone; fill -- the tuples of any run of slots of the
+ * sorted stream, rows in parallel; end.  pgv_host_ivf_write_index is begin + layout + one fill + end.
+ */
+typedef struct pgv_ivf_writer pgv_ivf_writer;
+int			pgv_host_ivf_writer_begin(pgv_rel * rel, pgv_dtype dtype, int dim, int lists, int64_t max_rows,
+									  pgv_ivf_writer * *out);
+int			pgv_host_ivf_writer_layout(pgv_ivf_writer * w, const void *centers, const int64_t *list_offsets);
+int			pgv_host_ivf_writer_fill(pgv_ivf_writer * w, int64_t first_slot, int64_t count, const void *vectors,
+									 const uint64_t *tids);
+int			pgv_host_ivf_writer_end(pgv_ivf_writer * w);
+
 /* single-row insert (src/ivfinsert.c:72-181): append to the list's insert page, extending the chain */
 int			pgv_host_ivf_insert(pgv_rel * rel, pgv_dtype dtype, int list, const void *vector, uint64_t tid);
 
@@ -290,8 +304,19 @@ void		pgv_host_ivf_endscan(pgv_ivf_scan * scan);
 int			pgv_host_ivf_build(pgv_ctx * ctx, pgv_ops ops, pgv_dtype dtype, int dim, int lists,
 							   const void *rows, const uint64_t *tids, int64_t n,
 							   const void *samples, int nsamples, const pgv_rng * rng, pgv_rel * out_rel);
+/*
+ * The same, and the device mirror of the new index with it: the rows never leave HBM between the assignment and the
+ * mirror (pgv_builder_*), the pages are written from the mirror's list-major rows as they come back
+ * (pgv_index_drain -> pgv_host_ivf_writer_fill) -- no host sort, no staging pass, no second upload.  *out_index is
+ * owned by the caller (pgv_index_free); it equals what pgv_host_ivf_stage + pgv_index_upload of out_rel give.
+ */
+int			pgv_host_ivf_build_mirror(pgv_ctx * ctx, pgv_ops ops, pgv_dtype dtype, int dim, int lists,
+									  const void *rows, const uint64_t *tids, int64_t n,
+									  const void *samples, int nsamples, const pgv_rng * rng, pgv_rel * out_rel,
+									  pgv_index * *out_index);
 /* seconds the last pgv_host_ivf_build on this thread spent per phase:
- * [0] normalise [1] k-means [2] assignment [3] sort by list [4] page writer */
+ * [0] normalise [1] k-means [2] copy to the device + assignment [3] order by list on the device (the mirror)
+ * [4] page writer (layout + the rows coming back + tuples) */
 void		pgv_host_ivf_build_phases(double out_secs[5]);
 /* l2_normalize / halfvec_l2_normalize of one value (src/vector.c:785-819, src/halfvec.c:724-759);
  * returns 0 when the norm is zero (the value is then all zeros) */

@@ -465,6 +465,128 @@ pgv_assign(pgv_ctx * ctx, pgv_metric metric, pgv_dtype dtype, int dim, const voi
 	return PGV_OK;
 }
 
+/* the build's tuplesort on the "device": rows kept in heap order, assigned, then ordered by list (stable) */
+struct pgv_builder
+{
+	pgv_ctx    *ctx;
+	pgv_metric	metric;
+	int			dim,
+				nlists;
+	float	   *centers,
+			   *rows;
+	uint64_t   *tids;
+	int32_t    *lists;
+	int64_t		n,
+				cap;
+	int			has_tids;
+};
+
+int
+pgv_builder_begin(pgv_ctx * ctx, pgv_metric metric, pgv_dtype dtype, int dim, int nlists, const void *centers,
+				  int64_t expected_rows, pgv_builder * *out)
+{
+	pgv_builder *b;
+
+	(void) expected_rows;
+	if (dtype != PGV_F32)
+		return fail(PGV_ERR_ARG, "mock: fp32 only");
+	b = calloc(1, sizeof(*b));
+	b->ctx = ctx;
+	b->metric = metric;
+	b->dim = dim;
+	b->nlists = nlists;
+	b->centers = malloc(sizeof(float) * (size_t) nlists * dim);
+	memcpy(b->centers, centers, sizeof(float) * (size_t) nlists * dim);
+	*out = b;
+	return PGV_OK;
+}
+
+int
+pgv_builder_add(pgv_builder * b, const void *rows, const uint64_t *tids, int64_t n)
+{
+	if (b->n + n > b->cap)
+	{
+		b->cap = (b->n + n) * 2;
+		b->rows = realloc(b->rows, sizeof(float) * (size_t) b->cap * b->dim);
+		b->tids = realloc(b->tids, sizeof(uint64_t) * (size_t) b->cap);
+		b->lists = realloc(b->lists, sizeof(int32_t) * (size_t) b->cap);
+	}
+	memcpy(b->rows + (size_t) b->n * b->dim, rows, sizeof(float) * (size_t) n * b->dim);
+	for (int64_t i = 0; i < n; i++)
+		b->tids[b->n + i] = tids ? tids[i] : (uint64_t) (b->n + i);
+	b->has_tids = tids != NULL;
+	pgv_assign(b->ctx, b->metric, PGV_F32, b->dim, b->centers, b->nlists, rows, n, b->lists + b->n, NULL);
+	b->n += n;
+	return PGV_OK;
+}
+
+int64_t
+pgv_builder_rows(const pgv_builder * b)
+{
+	return b->n;
+}
+
+int
+pgv_builder_finish(pgv_builder * b, pgv_index * *out_index, int64_t *out_offsets, int32_t *out_lists)
+{
+	int64_t    *off = calloc((size_t) b->nlists + 1, sizeof(int64_t));
+	int64_t    *fill = malloc(sizeof(int64_t) * (size_t) b->nlists);
+	float	   *sorted = malloc(sizeof(float) * (size_t) (b->n > 0 ? b->n : 1) * b->dim);
+	uint64_t   *stids = malloc(sizeof(uint64_t) * (size_t) (b->n > 0 ? b->n : 1));
+	int			rc;
+
+	for (int64_t r = 0; r < b->n; r++)
+		off[b->lists[r] + 1]++;
+	for (int l = 0; l < b->nlists; l++)
+		off[l + 1] += off[l];
+	memcpy(fill, off, sizeof(int64_t) * (size_t) b->nlists);
+	for (int64_t r = 0; r < b->n; r++)
+	{
+		int64_t		d = fill[b->lists[r]]++;
+
+		memcpy(sorted + (size_t) d * b->dim, b->rows + (size_t) r * b->dim, sizeof(float) * (size_t) b->dim);
+		stids[d] = b->tids[r];
+	}
+	rc = pgv_index_upload(b->ctx, b->metric, PGV_F32, b->dim, b->nlists, b->centers, off, sorted, stids, out_index);
+	if (rc == PGV_OK && out_offsets)
+		memcpy(out_offsets, off, sizeof(int64_t) * ((size_t) b->nlists + 1));
+	if (rc == PGV_OK && out_lists)
+		memcpy(out_lists, b->lists, sizeof(int32_t) * (size_t) b->n);
+	free(stids);
+	free(sorted);
+	free(fill);
+	free(off);
+	b->n = 0;
+	return rc;
+}
+
+void
+pgv_builder_free(pgv_builder * b)
+{
+	if (!b)
+		return;
+	free(b->centers);
+	free(b->rows);
+	free(b->tids);
+	free(b->lists);
+	free(b);
+}
+
+int
+pgv_index_drain(pgv_index * ix, int64_t chunk_rows, pgv_rows_sink sink, void *arg)
+{
+	if (chunk_rows <= 0)
+		chunk_rows = 1000;		/* several pieces even for the small test indexes */
+	for (int64_t r0 = 0; r0 < ix->n; r0 += chunk_rows)
+	{
+		int64_t		cnt = ix->n - r0 < chunk_rows ? ix->n - r0 : chunk_rows;
+
+		if (sink(arg, r0, cnt, ix->vectors + (size_t) r0 * ix->dim, ix->tids ? ix->tids + r0 : NULL) != 0)
+			return fail(PGV_ERR_STATE, "mock: the sink stopped the drain");
+	}
+	return PGV_OK;
+}
+
 /* a plain Lloyd k-means from evenly spaced samples: enough for the build driver's plumbing */
 int
 pgv_kmeans(pgv_ctx * ctx, pgv_ops ops, pgv_dtype dtype, int dim, const void *samples, int n, int k,

@@ -353,7 +353,7 @@ def test_small_batches_take_the_per_query_kernels(ctx, oracle, ops, dtype, dim, 
         assert have.sum() == len(wt) and (tid[i][~have] == np.uint64(0xFFFFFFFFFFFFFFFF)).all()
         assert np.isinf(dist_[i][~have]).all()
         assert_topk_equiv(tid[i][have].tolist(), dist_[i][:len(wt)], wt.tolist(), wd, what="mq q %d" % i)
-        wl, wld = oracle.get_scan_lists(ivf.struct, queries[i], probes)
+        wl, wld = oracle.get_scan_lists(ivf.struct, gq[i], probes)  # GetScanLists sees what GetScanValue normalised
         assert_topk_equiv(ranked[i].tolist(), rdist[i], wl.tolist(), wld, what="mq lists q %d" % i)
     ix.close()
 
@@ -388,3 +388,137 @@ def test_small_batch_ties_empty_lists_and_device_buffers(ctx, oracle):
     hd, hs, ht = ix.search_batch(queries, 5, 50, want_tid=True)
     assert sd.cpu().numpy().tolist() == hs.tolist() and dd.cpu().numpy().tolist() == hd.tolist()
     ix.close()
+
+
+# ------------------------------------------------- the build's tuplesort on the device
+@pytest.mark.parametrize("ops,dtype,dim,n,lists", [
+    (po.OPS_L2, po.ORA_F32, 1536, 5000, 40),
+    (po.OPS_L2, po.ORA_F32, 30, 20000, 300),     # padded rows (30 floats -> 32), short-varlena territory on pages
+    (po.OPS_IP, po.ORA_F16, 257, 9000, 64),      # padded fp16 rows
+    (po.OPS_L2, po.ORA_F32, 8, 4000, 2000),      # more lists than rows per list: many empty lists
+])
+def test_builder_is_assign_plus_the_tuplesort_by_list(ctx, oracle, ops, dtype, dim, n, lists):
+    """pgv_builder_add / finish / pgv_index_drain against AddTupleToSort + the sort on the list column
+    (src/ivfbuild.c:161-219, :606-615): the oracle's assignment, a stable sort by list (heap order inside a list)"""
+    data = gen(n, dim, seed=951, dist="clustered", clusters=min(lists, 64), dtype=dtype)
+    centers = np.ascontiguousarray(data[np.random.default_rng(3).choice(n, lists, replace=False)])
+    metric = api.PGV_L2SQ if ops == po.OPS_L2 else api.PGV_NEG_IP
+    tids = (np.arange(n, dtype=np.uint64) * np.uint64(7)) + np.uint64(11)
+    b = api.IvfBuilder(ctx, metric, DT[dtype], dim, centers, expected_rows=n // 3)   # grows twice
+    for lo in range(0, n, 3000):
+        b.add(data[lo:lo + 3000], tids[lo:lo + 3000])
+    assert b.rows == n
+    ix, off, got_lists = b.finish(want_lists=True)
+    b.close()
+    want_lists, _ = oracle.assign(ops, dtype, centers, data)
+    want_lists = np.asarray(want_lists)
+    diff = np.nonzero(got_lists != want_lists)[0]
+    for r in diff:  # only float-level ties may differ
+        dg = oracle.lib.ora_index_distance(ops, dtype, dim, po._p(data[r]), po._p(centers[got_lists[r]]))
+        dw = oracle.lib.ora_index_distance(ops, dtype, dim, po._p(data[r]), po._p(centers[want_lists[r]]))
+        assert abs(dg - dw) <= 1e-5 * max(abs(dw), 1e-30), (r, dg, dw)
+    order = np.argsort(got_lists, kind="stable")
+    assert off.tolist() == np.concatenate([[0], np.cumsum(np.bincount(got_lists, minlength=lists))]).tolist()
+    vec, dt, seen = api.drain_index(ix, chunk_rows=1777)
+    assert [s[0] for s in seen] == list(range(0, n, 1777)) and sum(s[1] for s in seen) == n
+    assert dt.tolist() == tids[order].tolist()
+    assert np.array_equal(vec.view(np.uint8), np.ascontiguousarray(data[order]).view(np.uint8))
+    # and the mirror answers like one uploaded from the same arrays
+    ref = api.IvfIndex(ctx, metric, DT[dtype], dim, centers, off, data[order], tids[order])
+    q = gen(20, dim, seed=952, dist="clustered", clusters=min(lists, 64), dtype=dtype)
+    p = min(lists, 6)
+    d1, s1, t1 = ix.search_batch(q, p, 10, want_tid=True)
+    d2, s2, t2 = ref.search_batch(q, p, 10, want_tid=True)
+    assert s1.tolist() == s2.tolist() and t1.tolist() == t2.tolist() and d1.tolist() == d2.tolist()
+    ref.close()
+    ix.close()
+
+
+def test_builder_without_tids_and_empty(ctx):
+    centers = gen(5, 16, seed=1, dist="normal")
+    b = api.IvfBuilder(ctx, api.PGV_L2SQ, api.PGV_F32, 16, centers)
+    ix, off, _ = b.finish()
+    assert ix.rows == 0 and off.tolist() == [0] * 6
+    ix.close()
+    b.close()
+    data = gen(700, 16, seed=2, dist="normal")
+    b = api.IvfBuilder(ctx, api.PGV_L2SQ, api.PGV_F32, 16, centers)
+    b.add(data)                      # no TIDs: heap positions
+    ix, off, lists = b.finish(want_lists=True)
+    vec, tids, _ = api.drain_index(ix)
+    assert tids.tolist() == np.argsort(lists, kind="stable").tolist()
+    assert np.array_equal(vec, data[tids.astype(np.int64)])
+    ix.close()
+    b.close()
+
+
+@pytest.mark.parametrize("ops,dtype,dim,n,lists", [
+    (po.OPS_L2, po.ORA_F32, 1536, 4000, 16),      # one tuple per page
+    (po.OPS_L2, po.ORA_F32, 20, 30000, 50),       # short varlena headers, ~80 tuples per page
+    (po.OPS_COSINE, po.ORA_F16, 384, 12000, 30),  # normalised rows, zero-norm rows dropped
+    (po.OPS_IP, po.ORA_F32, 100, 9000, 200),      # more than one list page; short lists
+])
+def test_build_mirror_pages_and_mirror_agree(ctx, oracle, ops, dtype, dim, n, lists):
+    """pgv_host_ivf_build_mirror: the pages (InsertTuples, src/ivfbuild.c:271-331) are written from the device
+    mirror's rows as they drain; staging those pages gives the mirror's arrays back, and the oracle walking the pages
+    answers like the mirror does"""
+    from pgvector_amd import _host
+    heap = gen(n, dim, seed=961, dist="clustered", clusters=min(lists, 32), dtype=dtype)
+    if ops == po.OPS_COSINE:
+        heap[17] = 0
+        heap[4000] = 0
+    tids = ((np.arange(n, dtype=np.uint64) // 50) << np.uint64(16)) | (np.arange(n, dtype=np.uint64) % 50 + 1)
+    pops = {po.OPS_L2: api.PGV_OPS_L2, po.OPS_IP: api.PGV_OPS_IP, po.OPS_COSINE: api.PGV_OPS_COSINE}[ops]
+    samples = heap[np.random.default_rng(1).choice(n, min(n, 50 * lists), replace=False)]
+    rel = _host.Relation()
+    mirror = rel.build_mirror(ctx, pops, DT[dtype], lists, heap, tids, samples, api.make_rng(seed=3))
+    img = rel.stage(DT[dtype])
+    kept = n - (2 if ops == po.OPS_COSINE else 0)
+    assert img.nrows == kept == mirror.rows
+    vec, mt, _ = api.drain_index(mirror, chunk_rows=2048)
+    assert mt.tolist() == img.tids.tolist()
+    assert np.array_equal(np.ascontiguousarray(vec).view(np.uint8), np.ascontiguousarray(img.vectors).view(np.uint8))
+    # heap order inside every list (the tuplesort's input order, which InsertTuples keeps)
+    pos = {int(t): i for i, t in enumerate(tids.tolist())}
+    for l in range(lists):
+        run = [pos[int(t)] for t in img.tids[img.list_offsets[l]:img.list_offsets[l + 1]].tolist()]
+        assert run == sorted(run)
+    queries = gen(10, dim, seed=962, dist="clustered", clusters=min(lists, 32), dtype=dtype)
+    gq = normalize_rows(oracle, queries, dtype) if ops == po.OPS_COSINE else queries
+    d, s, t = mirror.search_batch(gq, 4, 10, want_tid=True)
+    for i in range(len(queries)):
+        wt, wd, _ = oracle.pages_search(rel.rel.pages, int(rel.nblocks), ops, dtype, queries[i], 4, 10)
+        assert_topk_equiv(t[i][:len(wt)].tolist(), d[i][:len(wt)], wt.tolist(), wd, what="pages vs mirror q %d" % i)
+    mirror.close()
+
+
+def test_hnsw_device_search_is_the_oracles_walk_at_100k(ctx, oracle):
+    """configs[3]'s row shape at 100 000 rows: the graph is built on the GPU (pgv_host_hnsw_build), the oracle's
+    HnswSearchLayer / GetScanItems restatement (src/hnswutils.c:838-951, src/hnswscan.c:25-56) walks the SAME graph
+    (ora_hnsw_import) -- hnswgettuple's first batch must come out identical up to float ties"""
+    import torch
+    from pgvector_amd import _host
+    n, dim, m, efc = 100_000, 1536, 16, 64
+    dev = torch.device("cuda:0")
+    g = torch.Generator(device=dev)
+    g.manual_seed(7)
+    comps = torch.rand((64, dim), generator=g, device=dev)
+    data = comps[torch.randint(0, 64, (n,), generator=g, device=dev)] + 0.1 * torch.randn((n, dim), generator=g, device=dev)
+    data = (data / data.norm(dim=1, keepdim=True)).contiguous()
+    q = comps[torch.randint(0, 64, (24,), generator=g, device=dev)] + 0.1 * torch.randn((24, dim), generator=g, device=dev)
+    q = (q / q.norm(dim=1, keepdim=True)).contiguous()
+    host_rows = data.cpu().numpy()
+    mirror = api.Hnsw(ctx, api.PGV_NEG_IP, api.PGV_F32, dim, data)
+    built = _host.hnsw_build(mirror, host_rows, m, efc, api.make_rng(seed=1), max_batch=1024)
+    assert built["nelements"] == n
+    walk = po.HnswGraph.from_tuples(oracle, po.OPS_COSINE, po.ORA_F32, host_rows, m, built["levels"], built["nbr_start"],
+                                    built["nbr"], built["entry"])
+    qh = q.cpu().numpy()
+    for ef in (40, 100):
+        elem, dist, _ = mirror.search(q, ef, 10)
+        eh, dh = elem.cpu().numpy(), dist.cpu().numpy()
+        for i in range(len(qh)):
+            wr, wd, _ = walk.search(qh[i], ef, 10)
+            assert_topk_equiv(eh[i][eh[i] >= 0].tolist(), dh[i][:len(wr)], wr.tolist(), wd, what="hnsw 100k ef %d q %d" % (ef, i))
+    walk.close()
+    mirror.close()

@@ -27,6 +27,9 @@ def timed(ctx, fn, reps=3):
     return best
 
 
+CASES = []
+
+
 def bench_assign(ctx, out):
     dev = torch.device("cuda", 0)
     g = torch.Generator(device=dev)
@@ -42,6 +45,8 @@ def bench_assign(ctx, out):
         ("lloyd 50k L2 fp32", 50_000, 1000, 1536, torch.float32, api.PGV_F32, api.PGV_L2SQ),
         ("uniform L2 fp32 (near ties)", 200_000, 1000, 768, torch.float32, api.PGV_F32, api.PGV_L2SQ),
     ]:
+        if CASES and not any(c in name for c in CASES):
+            continue
         means = torch.rand((max(k // 4, 1), dim), generator=g, device=dev)
         if "uniform" in name:
             rows = torch.rand((n, dim), generator=g, device=dev).to(tdt)
@@ -184,7 +189,9 @@ def bench_query(ctx, out):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--what", default="assign,query")
+    ap.add_argument("--cases", default="", help="comma-separated substrings of the assign cases to run (default: all)")
     args = ap.parse_args()
+    CASES.extend(c for c in args.cases.split(",") if c)
     ctx = api.Context(0, stream=0)
     out = {}
     for w in args.what.split(","):
