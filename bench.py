@@ -280,7 +280,7 @@ def cpu_baseline(centers, offsets, vectors, tids, queries, probes, k, dtype, ops
            "aggregate_GBps": total / el * bytes_per_query / 1e9, "single_thread_GBps": single / single_el * bytes_per_query / 1e9,
            "scaling_over_one_thread": (total / el) / (single / single_el),
            "placement": "one pthread per backend pinned to allowed CPU t * %d / %d (sched_getaffinity: %d CPUs allowed, "
-                        "os.cpu_count %s); index rows copied into 2 MB pieces first-touched round-robin by those "
+                        "os.cpu_count %s, cgroup CPU quota %s); index rows copied into 2 MB pieces first-touched round-robin by those "
                         "threads (interleaved over the memory nodes)" % (cpus, cores, cpus, os.cpu_count(), quota),
            "layout": "contiguous list-major arrays (an upper bound of the reference: no 8 KB page walk, "
                      "no fmgr/bufmgr/tuplesort overheads)",

@@ -292,7 +292,7 @@ __global__ __launch_bounds__(MfmaCfg<T>::WM *MfmaCfg<T>::WN * 64, 2) void mfma_a
                 const unsigned x = (((unsigned)(2 * c + half)) ^ sw) << 4;
                 u32x4 a[TM], b[TN];
                 OperandRead<TM, TN>::run(sbase + a_lane + x, sbase + b_lane + x, a, b);
-                if (MODE == 0 && cb == cb_first) {
+                if (MODE == 0 && nparts == 1 && cb == 0) {  // (split over center parts: |row|^2 comes from row_norms_kernel)
 #pragma unroll
                     for (int tn = 0; tn < TN; tn++) {
                         Raw16 raw;
@@ -390,7 +390,6 @@ __global__ __launch_bounds__(MfmaCfg<T>::WM *MfmaCfg<T>::WN * 64, 2) void mfma_a
                 part_val[((size_t)r * nparts + part) * NC + c] = sv[c];
                 part_idx[((size_t)r * nparts + part) * NC + c] = sid[c];
             }
-            if (MODE == 0 && part == 0) part_x2[r] = mx[j * 2] + mx[j * 2 + 1];
             continue;
         }
         float x2 = 0.f;
@@ -399,50 +398,60 @@ __global__ __launch_bounds__(MfmaCfg<T>::WM *MfmaCfg<T>::WN * 64, 2) void mfma_a
     }
 }
 
-// the parts of every row (nparts x NC sorted candidates each) -> the row's NC best by (value, id) -> finish_row
+// the parts of every row (nparts x NC candidates each, ascending by (value, id)) -> the row's NC best -> finish_row.
+// G = nparts rounded up to a power of two lanes per row: a lane holds one part's list in registers (coalesced
+// 32-byte loads), the row's merge is NC rounds of "smallest head of the G lists" by shuffles; the owner of the
+// smallest head advances.  (One thread per row walking the parts' lists in memory was 17 ms for 1 M rows: every
+// load instruction touched 64 cache lines.)
 template <int NC>
-__global__ __launch_bounds__(256) void argmin_merge_kernel(int64_t n, int nparts, const float *__restrict__ part_val,
+__global__ __launch_bounds__(256) void argmin_merge_kernel(int64_t n, int nparts, int lg, const float *__restrict__ part_val,
                                                            const int32_t *__restrict__ part_idx,
                                                            const float *__restrict__ part_x2, int32_t *__restrict__ out_idx,
                                                            float *__restrict__ out_val, const unsigned *__restrict__ cmax2_bits,
                                                            float gamma, float gamma_x, int *__restrict__ u_count,
                                                            int32_t *__restrict__ u_rows, int32_t *__restrict__ u_cand,
                                                            float *__restrict__ u_val) {
-    const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (r >= n) return;
-    const float *v = part_val + (size_t)r * nparts * NC;
-    const int32_t *id = part_idx + (size_t)r * nparts * NC;
-    float sv[NC];
-    int sid[NC];
-    float last_v = -INFINITY;
-    int last_id = -1;
-    bool first = true;
+    const int G = 1 << lg;
+    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t r = t >> lg;
+    const int p = (int)(t & (G - 1));
+    const bool live = r < n && p < nparts;
+    unsigned long long list[NC];
 #pragma unroll
     for (int c = 0; c < NC; c++) {
-        float bv = INFINITY;
-        int bid = 0x7fffffff;
-        for (int e = 0; e < nparts * NC; e++) {
-            const float ev = v[e];
-            const int eid = id[e];
-            // +inf entries are the parts' padding (id 0): never candidates (like the lists inside a workgroup)
-            const bool after = first || ev > last_v || (ev == last_v && eid > last_id);
-            if (after && ev < INFINITY && (ev < bv || (ev == bv && eid < bid))) {
-                bv = ev;
-                bid = eid;
-            }
+        list[c] = ~0ull;
+        if (live) {
+            const size_t at = ((size_t)r * nparts + p) * NC + c;
+            const float v = part_val[at];
+            // +inf entries are a part's padding (fewer finite candidates than NC): never candidates
+            if (v < INFINITY) list[c] = ((unsigned long long)float_to_key(v) << 32) | (unsigned)part_idx[at];
         }
-        if (bid == 0x7fffffff) {
-            bv = INFINITY;
-            bid = 0;
-        }
-        sv[c] = bv;
-        sid[c] = bid;
-        last_v = bv;
-        last_id = bid;
-        first = false;
     }
-    finish_row<NC>(r, sv, sid, NC > 1 ? part_x2[r] : 0.f, out_idx, out_val, cmax2_bits, gamma, gamma_x, u_count, u_rows,
-                   u_cand, u_val);
+    float sv[NC];
+    int sid[NC];
+#pragma unroll
+    for (int c = 0; c < NC; c++) {
+        unsigned long long best = list[0];
+        for (int m = 1; m < G; m <<= 1) {
+            const unsigned long long o = __shfl_xor(best, m);
+            best = o < best ? o : best;
+        }
+        if (best == ~0ull) {
+            sv[c] = INFINITY;
+            sid[c] = 0;
+        } else {
+            sv[c] = key_to_float((unsigned)(best >> 32));
+            sid[c] = (int)(unsigned)(best & 0xffffffffu);
+        }
+        if (list[0] == best && best != ~0ull) {  // ids are distinct: exactly one lane owns the smallest head
+#pragma unroll
+            for (int j = 0; j + 1 < NC; j++) list[j] = list[j + 1];
+            list[NC - 1] = ~0ull;
+        }
+    }
+    if (r < n && p == 0)
+        finish_row<NC>(r, sv, sid, NC > 1 ? part_x2[r] : 0.f, out_idx, out_val, cmax2_bits, gamma, gamma_x, u_count, u_rows,
+                       u_cand, u_val);
 }
 
 // bias[c] = |c|^2 in fp32; *cmax2 = max_c |c|^2 (as ordered uint bits; a NaN norm ends up
@@ -621,14 +630,24 @@ int launch_mfma_t(pgv_ctx *ctx, const RowGeom &g, const void *rows, int64_t n, c
         grid = 8 * ((row_tiles + 7) / 8) * nparts;
     }
     if (grid > 0x7fffffff) PGV_FAIL(PGV_ERR_ARG, "assignment: too many workgroups");
+    if (nparts > 1 && MODE == 0) {
+        // |row|^2 for the error bound of the pre-filter: one streaming pass (the one-workgroup-per-row-tile form gathers
+        // it from the operands it reads anyway; here 1 / nparts of the workgroups would have to, and wait for it)
+        unsigned *max_bits = reinterpret_cast<unsigned *>(part_x2 + n);
+        PGV_HIP(hipMemsetAsync(max_bits, 0, sizeof(unsigned), ctx->stream));
+        PGV_TRY(launch_row_norms(ctx, sizeof(T) == 4 ? PGV_F32 : PGV_F16, g, rows, n, part_x2, max_bits));
+    }
     hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(threads), lds, ctx->stream, static_cast<const char *>(rows), n,
                        static_cast<const char *>(centers), k, g.nvec, bias, static_cast<const char *>(ctx->zeros.p),
                        out_idx, out_val, l2.cmax2, l2.gamma, l2.gamma_x, l2.u_count, l2.u_rows, l2.u_cand, l2.u_val, nparts,
                        part_tiles, part_val, part_idx, part_x2);
     PGV_HIP(hipGetLastError());
     if (nparts > 1) {
-        hipLaunchKernelGGL(argmin_merge_kernel<NC>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, n, nparts,
-                           part_val, part_idx, part_x2, out_idx, out_val, l2.cmax2, l2.gamma, l2.gamma_x, l2.u_count,
+        int lg = 0;
+        while ((1 << lg) < nparts) lg++;
+        const int64_t threads_total = n << lg;
+        hipLaunchKernelGGL(argmin_merge_kernel<NC>, dim3((unsigned)((threads_total + 255) / 256)), dim3(256), 0, ctx->stream, n,
+                           nparts, lg, part_val, part_idx, part_x2, out_idx, out_val, l2.cmax2, l2.gamma, l2.gamma_x, l2.u_count,
                            l2.u_rows, l2.u_cand, l2.u_val);
         PGV_HIP(hipGetLastError());
     }
@@ -907,7 +926,10 @@ __global__ __launch_bounds__(256) void row_norms_kernel(const char *__restrict__
     for (int m = 32; m > 0; m >>= 1) acc += __shfl_xor(acc, m);
     if (lane == 0) {
         out[r] = acc;
-        if (max_bits) atomicMax(max_bits, __float_as_uint(acc));
+        // a million atomics on one word take 11 ms; nearly every row is below the maximum seen so far and only looks
+        // (NaN bits compare above every number, as wanted)
+        if (max_bits && __float_as_uint(acc) > __hip_atomic_load(max_bits, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))
+            atomicMax(max_bits, __float_as_uint(acc));
     }
 }
 

@@ -958,7 +958,7 @@ int pgv_index_drain(pgv_index *ix, int64_t chunk_rows, pgv_rows_sink sink, void 
     const int64_t n = ix->nrows;
     if (n == 0) return PGV_OK;
     const size_t es = elem_size(ix->dtype), tight = (size_t)ix->dim * es, padded = (size_t)ix->geom.ld * es;
-    if (chunk_rows <= 0) chunk_rows = (int64_t)std::max<size_t>(1, ((size_t)64 << 20) / tight);
+    if (chunk_rows <= 0) chunk_rows = (int64_t)std::max<size_t>(1, ((size_t)256 << 20) / tight);
     if (chunk_rows > n) chunk_rows = n;
     void *buf[2] = {nullptr, nullptr};
     hipEvent_t ev[2] = {nullptr, nullptr};

@@ -278,7 +278,64 @@ form_index_tuple(uint8_t *dst, pgv_dtype t, int dim, const void *payload, uint64
  *
  * The pages come out as the reference's leader writes them one list after another.
  */
+#include <omp.h>
 #include <pthread.h>
+#include <stdio.h>
+
+/*
+ * Threads for the copy loops of this file: what OpenMP would use, capped by the container's CPU quota (cgroup v2
+ * cpu.max / v1 cfs quota: a box that shows 256 CPUs but grants 16 makes a 256-thread parallel region cost
+ * milliseconds of throttled barrier per region) and by 64 (a memcpy-bound loop gains nothing beyond).
+ */
+int
+pgv_host_threads(void)
+{
+	static int	cached = 0;
+	int			t;
+	FILE	   *f;
+
+	if (cached)
+		return cached;
+	t = omp_get_max_threads();
+	if ((f = fopen("/sys/fs/cgroup/cpu.max", "r")) != NULL)
+	{
+		char		quota[32];
+		double		period = 0;
+
+		if (fscanf(f, "%31s %lf", quota, &period) == 2 && quota[0] != 'm' && period > 0)
+		{
+			int			q = (int) (atof(quota) / period);
+
+			if (q >= 1 && q < t)
+				t = q;
+		}
+		fclose(f);
+	}
+	else if ((f = fopen("/sys/fs/cgroup/cpu/cpu.cfs_quota_us", "r")) != NULL)
+	{
+		double		q = -1,
+					period = 100000;
+		FILE	   *g = fopen("/sys/fs/cgroup/cpu/cpu.cfs_period_us", "r");
+
+		if (fscanf(f, "%lf", &q) != 1)
+			q = -1;
+		if (g)
+		{
+			if (fscanf(g, "%lf", &period) != 1)
+				period = 100000;
+			fclose(g);
+		}
+		fclose(f);
+		if (q > 0 && period > 0 && (int) (q / period) >= 1 && (int) (q / period) < t)
+			t = (int) (q / period);
+	}
+	if (t > 64)
+		t = 64;
+	if (t < 1)
+		t = 1;
+	cached = t;
+	return t;
+}
 
 #define PREFAULT_PIECE ((size_t) 2 << 20)
 #define PREFAULT_THREADS 16
@@ -405,7 +462,7 @@ pgv_host_ivf_writer_begin(pgv_rel * rel, pgv_dtype dtype, int dim, int lists, in
 	w->cap_blocks = (uint32_t) blocks;
 	/* zero the array (what init_page's memset would do page by page) on threads of its own */
 	{
-		int			want = bytes >= ((size_t) 64 << 20) ? PREFAULT_THREADS : 1;
+		int			want = bytes >= ((size_t) 64 << 20) ? (pgv_host_threads() < PREFAULT_THREADS ? pgv_host_threads() : PREFAULT_THREADS) : 1;
 
 		w->nthreads = 0;
 		for (int t = 0; t < want; t++)
@@ -523,7 +580,7 @@ pgv_host_ivf_writer_layout(pgv_ivf_writer * w, const void *centers, const int64_
 		return pgv_host_fail(PGV_ERR_ARG, "more rows than pgv_host_ivf_writer_begin was told");
 	}
 	rel->nblocks = w->first_blk[lists];
-#pragma omp parallel for schedule(static)
+#pragma omp parallel for schedule(static) num_threads(pgv_host_threads())
 	for (int i = 0; i < lists; i++)
 	{
 		int64_t		len = list_offsets[i + 1] - list_offsets[i];
@@ -561,7 +618,7 @@ pgv_host_ivf_writer_fill(pgv_ivf_writer * w, int64_t first_slot, int64_t count, 
 	if (first_slot < 0 || count < 0 || first_slot + count > n)
 		return pgv_host_fail(PGV_ERR_ARG, "slots [%lld, %lld) outside the %lld rows laid out", (long long) first_slot,
 							 (long long) (first_slot + count), (long long) n);
-#pragma omp parallel
+#pragma omp parallel num_threads(pgv_host_threads())
 	{
 		uint8_t		tuple[PGV_BLCKSZ];
 		int			l = 0;
@@ -878,7 +935,7 @@ pgv_host_ivf_stage(const pgv_rel * rel, pgv_dtype dtype, pgv_ivf_image * out)
 	{
 		int			bad_dim = 0;
 
-#pragma omp parallel for schedule(dynamic, 4)
+#pragma omp parallel for schedule(dynamic, 4) num_threads(pgv_host_threads())
 		for (int li = 0; li < out->lists; li++)
 		{
 			int64_t		at = out->list_offsets[li];

@@ -23,6 +23,8 @@ extern "C" {
 #endif
 
 const char *pgv_host_last_error(void);
+/* threads the host glue's copy loops use: OpenMP's, capped by the container's CPU quota and by 64 */
+int			pgv_host_threads(void);
 
 /* ------------------------------------------------------------------- HNSW */
 

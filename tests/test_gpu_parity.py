@@ -240,7 +240,10 @@ def test_full_size_properties_on_device(ctx):
     d1, s1, _ = ix.search_batch(queries[17:18].contiguous(), 12, k)
     d2, s2, _ = ix.search_batch(queries[10:30].contiguous(), 12, k)
     ctx.sync()
-    assert torch.equal(s1[0], s2[7]) and torch.equal(d1[0], d2[7])
+    # (a query alone runs the per-query kernels, inside a batch of 20 the list-major ones: the same rows in the same
+    # order; the two kernel families sum a row's terms in different lane orders, so distances agree to the last bits)
+    assert torch.equal(s1[0], s2[7])
+    torch.testing.assert_close(d1[0], d2[7], rtol=1e-6, atol=0)
     # unsorted scan of a few lists == the same rows scored by distance_batch
     probe, _ = ix.rank_lists(queries[3:4].contiguous(), 5)
     ctx.sync()

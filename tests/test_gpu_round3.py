@@ -487,7 +487,7 @@ def test_build_mirror_pages_and_mirror_agree(ctx, oracle, ops, dtype, dim, n, li
     gq = normalize_rows(oracle, queries, dtype) if ops == po.OPS_COSINE else queries
     d, s, t = mirror.search_batch(gq, 4, 10, want_tid=True)
     for i in range(len(queries)):
-        wt, wd, _ = oracle.pages_search(rel.rel.pages, int(rel.nblocks), ops, dtype, queries[i], 4, 10)
+        wt, wd, _ = oracle.pages_search(rel.rel.pages, int(rel.nblocks), ops, dtype, gq[i], 4, 10)  # what GetScanValue hands on
         assert_topk_equiv(t[i][:len(wt)].tolist(), d[i][:len(wt)], wt.tolist(), wd, what="pages vs mirror q %d" % i)
     mirror.close()
 
