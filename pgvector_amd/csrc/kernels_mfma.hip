@@ -93,6 +93,28 @@ template <> struct OperandRead<4, 2> {
     }
 };
 
+// The same reads WITHOUT the wait, and the wait on its own: the slice loop of the 4 x 2 form issues step c + 1's
+// six reads before step c's eight MFMAs and waits (counted) only for step c's.  The "+v" operands of the wait tie
+// every later use of the registers to it (an MFMA is register-only: a "memory" clobber alone does not order it).
+struct OperandPipe42 {
+    static __device__ __forceinline__ void issue(unsigned aa, unsigned ba, u32x4 (&a)[4], u32x4 (&b)[2]) {
+        asm volatile(
+            "ds_read_b128 %0, %6\n\tds_read_b128 %1, %6 offset:4096\n\t"
+            "ds_read_b128 %2, %6 offset:8192\n\tds_read_b128 %3, %6 offset:12288\n\t"
+            "ds_read_b128 %4, %7\n\tds_read_b128 %5, %7 offset:4096"
+            : "=&v"(a[0]), "=&v"(a[1]), "=&v"(a[2]), "=&v"(a[3]), "=&v"(b[0]), "=&v"(b[1])
+            : "v"(aa), "v"(ba)
+            : "memory");
+    }
+    template <int PENDING> static __device__ __forceinline__ void wait(u32x4 (&a)[4], u32x4 (&b)[2]) {
+        if constexpr (PENDING == 0)
+            asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]), "+v"(b[0]), "+v"(b[1])::"memory");
+        else
+            asm volatile("s_waitcnt lgkmcnt(6)" : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]), "+v"(b[0]), "+v"(b[1])::"memory");
+        __builtin_amdgcn_sched_barrier(0);  // hipcc would hoist the register-only MFMAs above the wait otherwise
+    }
+};
+
 template <typename T> struct Mma;
 template <> struct Mma<float> {
     // 4 k-slots per 16-byte operand: one 32x32x2 MFMA per float
@@ -234,9 +256,9 @@ __global__ __launch_bounds__(MfmaCfg<T>::WM *MfmaCfg<T>::WN * 64, 2) void mfma_a
         const int i = (fills_a ? cb + crow0 : crow0 - BM) + 8 * j + drow;
         return i < src_limit ? i : src_limit - 1;
     };
-    auto issue_stage = [&](int cb, int sl, int buf) {
+    auto issue_stage = [&](int cb, int sl, int buf, int j0 = 0, int j1 = 8) {
 #pragma unroll
-        for (int j = 0; j < 8; j++) {
+        for (int j = j0; j < j1; j++) {
             // slot position p of row i holds 16-byte vector p ^ ((i >> 1) & 7) of the slice
             const int v = dpos ^ ((4 * j + (drow >> 1)) & 7);
             const int vi = sl * 8 + v;
@@ -285,8 +307,47 @@ __global__ __launch_bounds__(MfmaCfg<T>::WM *MfmaCfg<T>::WN * 64, 2) void mfma_a
             // the fill)
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __syncthreads();
-            if (sl + 1 < nslices) issue_stage(cb, sl + 1, (sl + 1) & 1);
+            constexpr bool kPipe = TM == 4 && TN == 2 && MODE != 0;
+            const bool more = sl + 1 < nslices;
+            if (more) issue_stage(cb, sl + 1, (sl + 1) & 1);  // all eight pieces at once: spreading them behind the MFMA groups
+                                                                // was 9 % SLOWER (28.2 -> 30.9 ms) -- the fill is what the barrier waits for
             const unsigned sbase = lds0 + (unsigned)(sl & 1) * STAGE;
+            if constexpr (kPipe) {
+                // two operand sets: step c + 1's reads are in flight while step c multiplies (one exposed LDS latency
+                // per slice instead of four)
+                u32x4 a0[4], b0[2], a1[4], b1[2];
+                const unsigned x0 = (((unsigned)(0 + half)) ^ sw) << 4, x1 = (((unsigned)(2 + half)) ^ sw) << 4,
+                               x2 = (((unsigned)(4 + half)) ^ sw) << 4, x3 = (((unsigned)(6 + half)) ^ sw) << 4;
+                OperandPipe42::issue(sbase + a_lane + x0, sbase + b_lane + x0, a0, b0);
+                OperandPipe42::issue(sbase + a_lane + x1, sbase + b_lane + x1, a1, b1);
+                OperandPipe42::wait<6>(a0, b0);
+#pragma unroll
+                for (int tm = 0; tm < 4; tm++)
+#pragma unroll
+                    for (int tn = 0; tn < 2; tn++) Mma<T>::run(acc[tm][tn], a0[tm], b0[tn]);
+                __builtin_amdgcn_sched_barrier(0);
+                OperandPipe42::issue(sbase + a_lane + x2, sbase + b_lane + x2, a0, b0);
+                OperandPipe42::wait<6>(a1, b1);
+#pragma unroll
+                for (int tm = 0; tm < 4; tm++)
+#pragma unroll
+                    for (int tn = 0; tn < 2; tn++) Mma<T>::run(acc[tm][tn], a1[tm], b1[tn]);
+                __builtin_amdgcn_sched_barrier(0);
+                OperandPipe42::issue(sbase + a_lane + x3, sbase + b_lane + x3, a1, b1);
+                OperandPipe42::wait<6>(a0, b0);
+#pragma unroll
+                for (int tm = 0; tm < 4; tm++)
+#pragma unroll
+                    for (int tn = 0; tn < 2; tn++) Mma<T>::run(acc[tm][tn], a0[tm], b0[tn]);
+                __builtin_amdgcn_sched_barrier(0);
+                OperandPipe42::wait<0>(a1, b1);
+#pragma unroll
+                for (int tm = 0; tm < 4; tm++)
+#pragma unroll
+                    for (int tn = 0; tn < 2; tn++) Mma<T>::run(acc[tm][tn], a1[tm], b1[tn]);
+                __builtin_amdgcn_sched_barrier(0);
+                continue;
+            }
 #pragma unroll
             for (int c = 0; c < 4; c++) {
                 const unsigned x = (((unsigned)(2 * c + half)) ^ sw) << 4;
@@ -609,10 +670,14 @@ int launch_mfma_t(pgv_ctx *ctx, const RowGeom &g, const void *rows, int64_t n, c
     // the center tiles per workgroup (0: all of them, the one-workgroup-per-row-tile form).
     static const int env_tiles = [] {
         const char *e = getenv("PGV_ARGMIN_PART_TILES");
-        return e ? atoi(e) : 1;
+        return e ? atoi(e) : -1;
     }();
     const int center_tiles = (k + BM - 1) / BM;
-    int part_tiles = env_tiles <= 0 ? center_tiles : env_tiles;
+    // measured (profiles/r03_assign_blocking.md): the split wins 22 % for fp16 inner product (1.25 M x 4096 x 3072:
+    // 35.6 -> 29.1 ms), 3-6 % for fp16 L2, fp32 inner product and short n; the fp32 L2 pre-filter at 1 M x 1000 is
+    // compute-bound already (70 % of the fp32 MFMA peak) and loses 6-10 % to the extra norm pass and the merge
+    const bool split = MODE != 0 || sizeof(T) == 2 || row_tiles < 2 * (int64_t)ctx->num_cus;
+    int part_tiles = env_tiles < 0 ? (split ? 1 : center_tiles) : (env_tiles == 0 ? center_tiles : env_tiles);
     int nparts = (center_tiles + part_tiles - 1) / part_tiles;
     if (nparts > 64) {
         part_tiles = (center_tiles + 63) / 64;
