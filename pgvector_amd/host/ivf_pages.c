@@ -897,6 +897,11 @@ pgv_host_ivf_stage(const pgv_rel * rel, pgv_dtype dtype, pgv_ivf_image * out)
 	out->centers = malloc(row_bytes * (size_t) out->lists);
 	out->list_offsets = calloc((size_t) out->lists + 1, sizeof(int64_t));
 	out->start_pages = malloc(sizeof(uint32_t) * (size_t) out->lists);
+	if (!out->centers || !out->list_offsets || !out->start_pages)
+	{
+		pgv_host_ivf_image_free(out);
+		return pgv_host_fail(PGV_ERR_NOMEM, "out of memory staging %d lists", out->lists);
+	}
 
 	/* pass 1: the list pages (GetScanLists' walk, src/ivfscan.c:58-111) */
 	for (blk = IVFFLAT_HEAD_BLKNO; blk != PGV_INVALID_BLOCK && l < out->lists; blk = page_opaque(page_at(rel, blk))->nextblkno)
@@ -932,6 +937,11 @@ pgv_host_ivf_stage(const pgv_rel * rel, pgv_dtype dtype, pgv_ivf_image * out)
 	}
 	out->vectors = pgv_host_big_alloc(row_bytes * (size_t) (n > 0 ? n : 1));
 	out->tids = malloc(sizeof(uint64_t) * (size_t) (n > 0 ? n : 1));
+	if (!out->vectors || !out->tids)
+	{
+		pgv_host_ivf_image_free(out);
+		return pgv_host_fail(PGV_ERR_NOMEM, "out of memory staging %lld rows of %zu bytes", (long long) n, row_bytes);
+	}
 	{
 		int			bad_dim = 0;
 

@@ -71,6 +71,33 @@ die(const char *what, int rc)
 	exit(20 + rc);
 }
 
+/* experiment (PGV_BACKEND_GATE = width): at most `width` own-context queries in flight over ALL processes */
+static void
+gate_enter(pgvb_bank * bank, int width)
+{
+	for (;;)
+	{
+		uint32_t	cur = __atomic_load_n(&bank->gate, __ATOMIC_RELAXED);
+
+		if ((int) cur < width)
+		{
+			if (__atomic_compare_exchange_n(&bank->gate, &cur, cur + 1, 1, __ATOMIC_ACQUIRE, __ATOMIC_RELAXED))
+				return;
+			continue;
+		}
+		syscall(SYS_futex, &bank->gate, FUTEX_WAIT, cur, NULL, NULL, 0);
+	}
+}
+
+static void
+gate_leave(pgvb_bank * bank, int width)
+{
+	uint32_t	before = __atomic_fetch_sub(&bank->gate, 1, __ATOMIC_RELEASE);
+
+	if ((int) before >= width)
+		syscall(SYS_futex, &bank->gate, FUTEX_WAKE, 1, NULL, NULL, 0);
+}
+
 /* arrive at the start line, sleep until the driver fires */
 static void
 start_line(pgvb_bank * bank)
@@ -169,6 +196,7 @@ run_client(const char *pool_name, const char *bank_name, int id, int independent
 	int64_t		slot[PGVB_MAX_K];
 	int			k = bank->k,
 				rc;
+	int			gate_width = getenv("PGV_BACKEND_GATE") ? atoi(getenv("PGV_BACKEND_GATE")) : 0;
 
 	if (bank->magic != PGVB_BANK_MAGIC || id < 0 || id >= bank->nclients || k > PGVB_MAX_K)
 		die("bank", PGV_ERR_ARG);
@@ -207,9 +235,13 @@ run_client(const char *pool_name, const char *bank_name, int id, int independent
 				int			count;
 				int64_t		total;
 
+				if (gate_width > 0)
+					gate_enter(bank, gate_width);
 				rc = pgv_query_rank(q, query, bank->probes);
 				if (rc == PGV_OK)
 					rc = pgv_query_scan(q, 0, bank->probes, k, dist, slot, tid, &count, &total);
+				if (gate_width > 0)
+					gate_leave(bank, gate_width);
 				for (int i = count; rc == PGV_OK && i < k; i++)
 				{
 					tid[i] = ~(uint64_t) 0;

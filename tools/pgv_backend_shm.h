@@ -36,7 +36,7 @@ typedef struct
 	uint32_t	ready,			/* futex word: clients at the start line */
 				go,				/* futex word: the driver fires */
 				finished;
-	uint32_t	pad;
+	uint32_t	gate;			/* futex word: own-context queries in flight over all processes (PGV_BACKEND_GATE) */
 	uint64_t	clients_off,	/* pgvb_client [nclients] */
 				lat_off,		/* double [nclients x per_client] seconds */
 				tid_off,		/* uint64 [nclients x per_client x k] (verify) */
