@@ -677,7 +677,11 @@ int launch_mfma_t(pgv_ctx *ctx, const RowGeom &g, const void *rows, int64_t n, c
     // 35.6 -> 29.1 ms), 3-6 % for fp16 L2, fp32 inner product and short n; the fp32 L2 pre-filter at 1 M x 1000 is
     // compute-bound already (70 % of the fp32 MFMA peak) and loses 6-10 % to the extra norm pass and the merge
     const bool split = MODE != 0 || sizeof(T) == 2 || row_tiles < 2 * (int64_t)ctx->num_cus;
-    int part_tiles = env_tiles < 0 ? (split ? 1 : center_tiles) : (env_tiles == 0 ? center_tiles : env_tiles);
+    // center tiles per workgroup when split (measured, 1.25 M x 4096 x 3072 fp16: L2 pre-filter 743 / 791 / 809 TF at
+    // 1 / 2 / 4 tiles -- fewer epilogues and parts to merge --, inner product 1092 / 1124 / 1113; fp32 indifferent;
+    // a short n wants the most workgroups: 1)
+    const int auto_tiles = row_tiles < 2 * (int64_t)ctx->num_cus ? 1 : (sizeof(T) == 2 ? (MODE == 0 ? 4 : 2) : 1);
+    int part_tiles = env_tiles < 0 ? (split ? auto_tiles : center_tiles) : (env_tiles == 0 ? center_tiles : env_tiles);
     int nparts = (center_tiles + part_tiles - 1) / part_tiles;
     if (nparts > 64) {
         part_tiles = (center_tiles + 63) / 64;
