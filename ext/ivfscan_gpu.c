@@ -1,7 +1,16 @@
 /*
- * ivfscan_gpu.c -- ivfflatbeginscan / rescan / gettuple / endscan on the device-resident single-query
- * path (pgv_query_*).  Replaces the bodies of GetScanLists, GetScanItems and the tuplesort pulls of
- * src/ivfscan.c:47-187, :361-414.  Twin over the emulated page image: pgvector_amd/host/ivf_scan.c.
+ * ivfscan_gpu.c -- ivfflatbeginscan / rescan / gettuple / endscan on the GPU.  Replaces the bodies of GetScanLists,
+ * GetScanItems and the tuplesort pulls of src/ivfscan.c:47-187, :361-414.  Two ways to the device:
+ *
+ *   own context     (default) the backend imports the worker's mirror and runs the device-resident single-query
+ *                   path on a stream of its own (pgv_query_*): lowest latency, right for a handful of active backends
+ *   vector.gpu_pooled   the first batch's head (the usual LIMIT) comes from the GPU worker's pooler
+ *                   (PgvPoolSearch, pgv_context.c): the backend touches no GPU state at all; only a scan that pulls
+ *                   past that head (or iterates to further batches) falls over to the own-context path, where it
+ *                   re-creates the batch on the device and continues at the position it had reached -- both paths
+ *                   deliver the same sorted stream (ties by position in the stream)
+ *
+ * Twin over the emulated page image: pgvector_amd/host/ivf_scan.c (own context), ivf_pool.c (pooler).
  */
 #include "pgv_gpu.h"
 
@@ -13,9 +22,12 @@
 
 typedef struct PgvIvfScan
 {
-	PgvIvfMirror *mirror;
+	Relation	index;
+	PgvIvfMirror *mirror;		/* NULL until the own-context path is needed */
 	IvfflatScanOpaque so;
 	pgv_query  *query;
+	bool		fromPool;		/* the window holds the pooler's head of the current batch */
+	bool		ranked;			/* pgv_query_rank has run for the current query */
 	MemoryContextCallback cleanup;	/* an ereport(ERROR) longjmps past endscan: free the device state with the context */
 	/* the current batch's sorted stream: `count` tuples, position `next` is returned next */
 	int			batchFirst,
@@ -47,6 +59,20 @@ PgvScanCleanup(void *arg)
 	gs->query = NULL;
 }
 
+/* the own-context path's device state, made when first needed; false: no current mirror */
+static bool
+PgvEnsureOwnContext(PgvIvfScan * gs)
+{
+	if (gs->query)
+		return true;
+	gs->mirror = PgvIvfflatGetMirror(gs->index);
+	if (gs->mirror == NULL)
+		return false;
+	if (pgv_query_begin(gs->mirror->index, &gs->query) != PGV_OK)
+		ereport(ERROR, (errmsg("pgvector GPU path: %s", pgv_last_error())));
+	return true;
+}
+
 void *
 PgvIvfflatBeginScan(Relation index, IvfflatScanOpaque so)
 {
@@ -55,18 +81,17 @@ PgvIvfflatBeginScan(Relation index, IvfflatScanOpaque so)
 	/* the fused path handles up to 256 lists per batch and 1024 ranked lists; beyond that stay on the CPU path */
 	if (!vector_gpu || so->probes > 256 || so->maxProbes > 1024)
 		return NULL;
-	{
-		/* no current mirror (first use, stale after inserts, unsupported opclass): this scan runs on the CPU path */
-		PgvIvfMirror *mirror = PgvIvfflatGetMirror(index);
-
-		if (mirror == NULL)
-			return NULL;
-		gs = palloc0(sizeof(PgvIvfScan));
-		gs->mirror = mirror;
-	}
+	gs = palloc0(sizeof(PgvIvfScan));
+	gs->index = index;
 	gs->so = so;
-	if (pgv_query_begin(gs->mirror->index, &gs->query) != PGV_OK)
-		ereport(ERROR, (errmsg("pgvector GPU path: %s", pgv_last_error())));
+	/* pooled scans make their device state only if they outgrow the pooler's head; the others need it now, and a
+	 * scan without a current mirror (first use, stale after inserts, unsupported opclass) runs on the CPU path */
+	if (!vector_gpu_pooled && !PgvEnsureOwnContext(gs))
+	{
+		pfree(gs);
+		return NULL;
+	}
+	/* an ereport(ERROR) longjmps past endscan: whatever device state the scan has (or makes later) goes with the context */
 	gs->cleanup.func = PgvScanCleanup;
 	gs->cleanup.arg = gs;
 	MemoryContextRegisterResetCallback(CurrentMemoryContext, &gs->cleanup);
@@ -83,6 +108,8 @@ PgvIvfflatRescan(void *gpu)
 	gs->count = gs->next = 0;
 	gs->winCount = 0;
 	gs->whole = false;
+	gs->fromPool = false;
+	gs->ranked = false;
 }
 
 /* float8 ordering of the tuplesort (src/ivfscan.c:238-247): ascending, NaN last; stable on insertion order */
@@ -168,7 +195,26 @@ PgvGetScanItems(PgvIvfScan * gs)
 	gs->whole = false;
 }
 
-bool
+/* the pooler's head is used up and the batch holds more: the same batch again on the own-context path */
+static bool
+PgvLeavePool(PgvIvfScan * gs, const void *payload)
+{
+	IvfflatScanOpaque so = gs->so;
+	int64		reached = gs->next;
+
+	if (!PgvEnsureOwnContext(gs))
+		return false;
+	if (pgv_query_rank(gs->query, payload, so->maxProbes) != PGV_OK)
+		ereport(ERROR, (errmsg("pgvector GPU path: %s", pgv_last_error())));
+	gs->ranked = true;
+	so->listIndex = gs->batchFirst;
+	PgvGetScanItems(gs);		/* the batch, scored and sorted on the device; its head in the window */
+	gs->next = reached;
+	gs->fromPool = false;
+	return true;
+}
+
+int
 PgvIvfflatGetTuple(IndexScanDesc scan)
 {
 	IvfflatScanOpaque so = (IvfflatScanOpaque) scan->opaque;
@@ -184,17 +230,62 @@ PgvIvfflatGetTuple(IndexScanDesc scan)
 
 	if (so->first)
 	{
-		/* GetScanLists (:47-118): the maxProbes nearest lists, ranked and kept on the device */
-		if (pgv_query_rank(gs->query, payload, so->maxProbes) != PGV_OK)
-			ereport(ERROR, (errmsg("pgvector GPU path: %s", pgv_last_error())));
-		so->listIndex = 0;
-		PgvGetScanItems(gs);
+		int			n = Min(so->probes, so->maxProbes);
+		bool		complete = false;
+
+		gs->fromPool = false;
+		if (vector_gpu_pooled &&
+			PgvPoolSearch(gs->index, payload, n, gs->winDist, gs->winTid, &gs->winCount, &complete))
+		{
+			/* GetScanLists + GetScanItems + the head of the sorted stream, answered by the worker's batch */
+			gs->fromPool = true;
+			gs->batchFirst = 0;
+			gs->batchLists = n;
+			so->listIndex = n;
+			gs->count = complete ? gs->winCount : PG_INT64_MAX;	/* more than the head: how many is not known yet */
+			gs->next = 0;
+			gs->winBase = 0;
+			gs->whole = false;
+		}
+		else
+		{
+			if (!PgvEnsureOwnContext(gs))
+			{
+				/* neither the pooler nor a mirror of our own: this scan runs in the reference's code */
+				so->gpu = NULL;
+				return -1;
+			}
+			/* GetScanLists (:47-118): the maxProbes nearest lists, ranked and kept on the device */
+			if (pgv_query_rank(gs->query, payload, so->maxProbes) != PGV_OK)
+				ereport(ERROR, (errmsg("pgvector GPU path: %s", pgv_last_error())));
+			gs->ranked = true;
+			so->listIndex = 0;
+			PgvGetScanItems(gs);
+		}
 		so->first = false;
+	}
+	if (gs->fromPool && gs->next >= gs->winCount && (gs->count > gs->winCount || so->listIndex < so->maxProbes))
+	{
+		/* the executor wants more than the pooler's head holds, or the iterative scan goes on to further lists */
+		if (gs->count > gs->winCount)
+		{
+			if (!PgvLeavePool(gs, payload))
+				return 0;		/* the mirror went stale under the scan: what was returned so far is all */
+		}
+		else
+		{
+			if (!PgvEnsureOwnContext(gs))
+				return 0;
+			if (pgv_query_rank(gs->query, payload, so->maxProbes) != PGV_OK)
+				ereport(ERROR, (errmsg("pgvector GPU path: %s", pgv_last_error())));
+			gs->ranked = true;
+			gs->fromPool = false;
+		}
 	}
 	while (gs->next >= gs->count)
 	{
 		if (so->listIndex == so->maxProbes)
-			return false;
+			return 0;
 		PgvGetScanItems(gs);	/* iterative scan: the next `probes` lists (:400-406) */
 	}
 	if (!gs->whole && gs->next >= gs->winBase + gs->winCount)
@@ -216,7 +307,7 @@ PgvIvfflatGetTuple(IndexScanDesc scan)
 	scan->xs_heaptid.ip_posid = (OffsetNumber) (tid & 0xffff);
 	scan->xs_recheck = false;
 	scan->xs_recheckorderby = false;
-	return true;
+	return 1;
 }
 
 void

@@ -40,6 +40,7 @@ bool		vector_gpu = false;
 int			vector_gpu_device = 0;
 int			vector_gpu_stage_wait_ms = 0;
 int			vector_gpu_restage_delay_ms = 1000;
+bool		vector_gpu_pooled = false;
 
 #define PGV_MAX_MIRRORS 64
 
@@ -69,12 +70,51 @@ typedef struct PgvSharedMirror
 	int64		ntuples;
 }			PgvSharedMirror;
 
+/*
+ * The pooler inside the server (twin over plain processes: pgvector_amd/host/ivf_pool.c + tools/pgv_backend.c).
+ * With vector.gpu_pooled a backend needs no GPU context: it puts its query into a slot, sets the worker's latch and
+ * sleeps on its own; the worker -- the owner of the mirrors -- takes every filled slot of one (index, probes) it
+ * finds, answers them with ONE pgv_search_batch and wakes their backends.  Measured with plain processes (DESIGN
+ * 4.8b): own-context backends top out at 4 (50 k QPS) and then lower the total, pooled clients reach 75 k at 64
+ * and 120 k at 256.  The batch window is the duration of the previous batch: nothing waits for stragglers.
+ */
+#define PGV_POOL_SLOTS 256
+#define PGV_POOL_MAX_BATCH 256
+#define PGV_POOL_ROW_BYTES (IVFFLAT_MAX_DIM * sizeof(float))	/* vector 2000 x 4 = halfvec 4000 x 2 */
+
+typedef enum PgvSlotState
+{
+	PGV_SLOT_FREE = 0,
+	PGV_SLOT_CLAIMED,			/* a backend is filling it */
+	PGV_SLOT_FILLED,			/* waiting for the worker */
+	PGV_SLOT_TAKEN,				/* part of the batch being answered */
+	PGV_SLOT_DONE,				/* results are in */
+	PGV_SLOT_UNSERVED,			/* no current mirror (stale, failed): the backend runs the reference's path */
+	PGV_SLOT_ABANDONED			/* its backend was cancelled while the worker had it: the worker frees it */
+}			PgvSlotState;
+
+typedef struct PgvPoolSlot
+{
+	pg_atomic_uint32 state;
+	Oid			dboid;
+	Oid			relid;
+	int			probes;
+	int			nullQuery;		/* ZeroDistance (src/ivfscan.c:192-196): not pooled, the backend is told so */
+	Latch	   *latch;			/* the backend's (in shared memory: &MyProc->procLatch) */
+	int			count;			/* results: min(PGV_POOL_HEAD, tuples of the probed lists) */
+	int64		total;			/* tuples of the probed lists */
+	float		dist[PGV_POOL_HEAD];
+	uint64		tid[PGV_POOL_HEAD];
+	char		payload[PGV_POOL_ROW_BYTES];
+}			PgvPoolSlot;
+
 typedef struct PgvSharedState
 {
 	LWLock	   *lock;
 	Latch	   *workerLatch[PGV_MAX_MIRRORS];	/* per database: index = slot of the first entry of that database */
 	Oid			workerDb[PGV_MAX_MIRRORS];
 	PgvSharedMirror mirrors[PGV_MAX_MIRRORS];
+	PgvPoolSlot pool[PGV_POOL_SLOTS];
 }			PgvSharedState;
 
 static PgvSharedState * PgvShared = NULL;
@@ -110,6 +150,8 @@ PgvShmemStartup(void)
 		PgvShared->lock = &(GetNamedLWLockTranche("pgvector_gpu"))->lock;
 		for (int i = 0; i < PGV_MAX_MIRRORS; i++)
 			pg_atomic_init_u64(&PgvShared->mirrors[i].generation, 0);
+		for (int i = 0; i < PGV_POOL_SLOTS; i++)
+			pg_atomic_init_u32(&PgvShared->pool[i].state, PGV_SLOT_FREE);
 	}
 	LWLockRelease(AddinShmemInitLock);
 }
@@ -193,6 +235,8 @@ PgvGpuInit(void)
 							&vector_gpu_stage_wait_ms, 0, 0, 600000, PGC_USERSET, 0, NULL, NULL, NULL);
 	DefineCustomIntVariable("vector.gpu_restage_delay_ms", "Minimum time between two stagings of one index", NULL,
 							&vector_gpu_restage_delay_ms, 1000, 0, 3600000, PGC_USERSET, 0, NULL, NULL, NULL);
+	DefineCustomBoolVariable("vector.gpu_pooled", "Index scans hand their query to the GPU worker, which batches the queries of all backends", NULL,
+							 &vector_gpu_pooled, false, PGC_USERSET, 0, NULL, NULL, NULL);
 	CacheRegisterRelcacheCallback(PgvRelcacheCallback, (Datum) 0);
 	on_proc_exit(PgvAtExit, (Datum) 0);
 	/* the registry needs shared memory: effective when the library is in shared_preload_libraries; otherwise
@@ -423,6 +467,109 @@ PgvWorkerStageEntry(PgvSharedMirror * e)
 		}
 }
 
+/* hand a TAKEN slot back to its backend -- or to the free list when that backend has gone (PGV_SLOT_ABANDONED) */
+static void
+PgvSlotFinish(PgvPoolSlot * slot, PgvSlotState outcome)
+{
+	uint32		taken = PGV_SLOT_TAKEN;
+
+	if (pg_atomic_compare_exchange_u32(&slot->state, &taken, (uint32) outcome))
+		SetLatch(slot->latch);
+	else
+		pg_atomic_write_u32(&slot->state, PGV_SLOT_FREE);
+}
+
+/*
+ * One round of the pooler: every FILLED slot of this database that asks the same (index, probes) as the first one
+ * found becomes one pgv_search_batch -- GetScanLists + GetScanItems + the head of the sorted stream
+ * (src/ivfscan.c:47-187) for all of them at once.  Returns whether anything was answered.
+ */
+static bool
+PgvWorkerServePool(Oid dboid)
+{
+	static char *queries = NULL;	/* [PGV_POOL_MAX_BATCH x row bytes], the worker's lifetime */
+	static float *dist = NULL;
+	static uint64 *tid = NULL;
+	PgvPoolSlot *batch[PGV_POOL_MAX_BATCH];
+	int			n = 0;
+	Oid			relid = InvalidOid;
+	int			probes = 0;
+	pgv_index  *index = NULL;
+	Size		rowBytes = 0;
+	bool		current = false;
+
+	for (int i = 0; i < PGV_POOL_SLOTS && n < PGV_POOL_MAX_BATCH; i++)
+	{
+		PgvPoolSlot *slot = &PgvShared->pool[i];
+		uint32		filled = PGV_SLOT_FILLED;
+
+		if (pg_atomic_read_u32(&slot->state) != PGV_SLOT_FILLED || slot->dboid != dboid)
+			continue;
+		if (n > 0 && (slot->relid != relid || slot->probes != probes))
+			continue;			/* another index or another probes setting: the next round's batch */
+		if (!pg_atomic_compare_exchange_u32(&slot->state, &filled, PGV_SLOT_TAKEN))
+			continue;
+		relid = slot->relid;
+		probes = slot->probes;
+		batch[n++] = slot;
+	}
+	if (n == 0)
+		return false;
+
+	/* the mirror this worker owns for the index, if it is the current one */
+	LWLockAcquire(PgvShared->lock, LW_SHARED);
+	{
+		PgvSharedMirror *e = PgvFindEntry(relid, false);
+
+		if (e && e->state == PGV_MIRROR_READY && e->stagedGeneration == pg_atomic_read_u64(&e->generation))
+		{
+			current = true;
+			rowBytes = (e->dtype == PGV_F32 ? sizeof(float) : sizeof(uint16)) * (Size) e->dimensions;
+		}
+	}
+	LWLockRelease(PgvShared->lock);
+	for (int i = 0; current && i < PGV_MAX_MIRRORS; i++)
+		if (owned[i].relid == relid)
+			index = owned[i].index;
+	if (index == NULL || probes < 1 || probes > pgv_index_lists(index))
+	{
+		for (int i = 0; i < n; i++)
+			PgvSlotFinish(batch[i], PGV_SLOT_UNSERVED);
+		return true;
+	}
+	if (queries == NULL)
+	{
+		queries = MemoryContextAlloc(TopMemoryContext, PGV_POOL_ROW_BYTES * (Size) PGV_POOL_MAX_BATCH);
+		dist = MemoryContextAlloc(TopMemoryContext, sizeof(float) * PGV_POOL_HEAD * (Size) PGV_POOL_MAX_BATCH);
+		tid = MemoryContextAlloc(TopMemoryContext, sizeof(uint64) * PGV_POOL_HEAD * (Size) PGV_POOL_MAX_BATCH);
+	}
+	for (int i = 0; i < n; i++)
+		memcpy(queries + rowBytes * (Size) i, batch[i]->payload, rowBytes);
+	if (pgv_search_batch(index, queries, n, probes, PGV_POOL_HEAD, dist, NULL, tid) != PGV_OK)
+	{
+		/* the backends fall back to the reference's path; the worker stays up */
+		elog(LOG, "pgvector GPU path: %s", pgv_last_error());
+		for (int i = 0; i < n; i++)
+			PgvSlotFinish(batch[i], PGV_SLOT_UNSERVED);
+		return true;
+	}
+	for (int i = 0; i < n; i++)
+	{
+		PgvPoolSlot *slot = batch[i];
+		int			count = 0;
+
+		/* the head comes padded with +inf / ~0 past the tuples there are */
+		while (count < PGV_POOL_HEAD && tid[(Size) i * PGV_POOL_HEAD + count] != ~(uint64) 0)
+			count++;
+		memcpy(slot->dist, dist + (Size) i * PGV_POOL_HEAD, sizeof(float) * (Size) count);
+		memcpy(slot->tid, tid + (Size) i * PGV_POOL_HEAD, sizeof(uint64) * (Size) count);
+		slot->count = count;
+		slot->total = count < PGV_POOL_HEAD ? count : -1;	/* -1: at least PGV_POOL_HEAD, the exact number unknown */
+		PgvSlotFinish(slot, PGV_SLOT_DONE);
+	}
+	return true;
+}
+
 /* bgw_main of the per-database worker; bgw_main_arg = the database's oid */
 void
 PgvWorkerMain(Datum main_arg)
@@ -469,6 +616,8 @@ PgvWorkerMain(Datum main_arg)
 			PgvWorkerStageEntry(todo);
 			continue;
 		}
+		if (PgvWorkerServePool(dboid))
+			continue;			/* the next batch has been filling up meanwhile */
 		(void) WaitLatch(MyLatch, WL_LATCH_SET | WL_TIMEOUT | WL_EXIT_ON_PM_DEATH, 200L, PG_WAIT_EXTENSION);
 		ResetLatch(MyLatch);
 	}
@@ -512,21 +661,14 @@ PgvEnsureWorker(void)
  * registry shows a newer staging.  NULL = not available now (not staged yet, stale, unsupported opclass, no shared
  * memory): the scan stays on the reference's CPU path and a (re)staging has been requested.
  */
-PgvIvfMirror *
-PgvIvfflatGetMirror(Relation index)
+/* the registry's current staging of the index, asking the worker for one when there is none; false = none now */
+static bool
+PgvMirrorReady(Relation index, pgv_index_handle * handle, uint64 *staged)
 {
-	PgvIvfMirror *m;
 	PgvSharedMirror *e;
-	pgv_index_handle handle;
-	uint64		staged = 0;
 	bool		ready = false;
-	pgv_metric	metric;
-	pgv_dtype	dtype;
-	pgv_ops		ops;
 	TimestampTz waitUntil = TimestampTzPlusMilliseconds(GetCurrentTimestamp(), vector_gpu_stage_wait_ms);
 
-	if (PgvShared == NULL || !PgvIvfflatOpclass(index, &metric, &dtype, &ops))
-		return NULL;
 	for (;;)
 	{
 		bool		request = false;
@@ -539,8 +681,8 @@ PgvIvfflatGetMirror(Relation index)
 
 			if (e->state == PGV_MIRROR_READY && e->stagedGeneration == generation)
 			{
-				handle = e->handle;
-				staged = e->stagedGeneration + 1;	/* 0 = none */
+				*handle = e->handle;
+				*staged = e->stagedGeneration + 1;	/* 0 = none */
 				ready = true;
 			}
 			else if (e->state == PGV_MIRROR_EMPTY || e->state == PGV_MIRROR_READY ||
@@ -562,6 +704,38 @@ PgvIvfflatGetMirror(Relation index)
 		CHECK_FOR_INTERRUPTS();
 		pg_usleep(1000L);
 	}
+	return ready;
+}
+
+/* the pooled path's question: does the worker hold a current mirror of this index (asks for one otherwise) */
+bool
+PgvIvfflatMirrorIsCurrent(Relation index)
+{
+	pgv_index_handle handle;
+	uint64		staged;
+	pgv_metric	metric;
+	pgv_dtype	dtype;
+	pgv_ops		ops;
+
+	if (PgvShared == NULL || !PgvIvfflatOpclass(index, &metric, &dtype, &ops))
+		return false;
+	return PgvMirrorReady(index, &handle, &staged);
+}
+
+PgvIvfMirror *
+PgvIvfflatGetMirror(Relation index)
+{
+	PgvIvfMirror *m;
+	pgv_index_handle handle;
+	uint64		staged = 0;
+	bool		ready;
+	pgv_metric	metric;
+	pgv_dtype	dtype;
+	pgv_ops		ops;
+
+	if (PgvShared == NULL || !PgvIvfflatOpclass(index, &metric, &dtype, &ops))
+		return NULL;
+	ready = PgvMirrorReady(index, &handle, &staged);
 	if (!ready)
 		return NULL;
 
@@ -591,4 +765,89 @@ PgvIvfflatGetMirror(Relation index)
 		m->valid = true;
 	}
 	return m;
+}
+
+/*
+ * The backend's side of the pooler: one query in, the head of its sorted stream out (PGV_POOL_HEAD heap TIDs at
+ * most).  false: not served (no shared memory, no worker, mirror not current, unsupported opclass, a NULL query) --
+ * the caller runs this scan on its own context or on the reference's path.
+ */
+bool
+PgvPoolSearch(Relation index, const void *payload, int probes, float *outDist, uint64 *outTid, int *outCount, bool *outComplete)
+{
+	PgvPoolSlot *slot = NULL;
+	pgv_metric	metric;
+	pgv_dtype	dtype;
+	pgv_ops		ops;
+	int			lists,
+				dimensions;
+	Size		rowBytes;
+	uint32		state;
+
+	if (PgvShared == NULL || payload == NULL || !PgvIvfflatOpclass(index, &metric, &dtype, &ops))
+		return false;
+	/* asks the worker for a (re)staging when there is no current mirror; NULL then */
+	if (PgvIvfflatMirrorIsCurrent(index) == false)
+		return false;
+	IvfflatGetMetaPageInfo(index, &lists, &dimensions);
+	rowBytes = (dtype == PGV_F32 ? sizeof(float) : sizeof(uint16)) * (Size) dimensions;
+	if (rowBytes > PGV_POOL_ROW_BYTES)
+		return false;
+	for (int i = 0; i < PGV_POOL_SLOTS && slot == NULL; i++)
+	{
+		uint32		free_state = PGV_SLOT_FREE;
+
+		/* start at a slot of this backend's own: no two backends fight over slot 0 */
+		PgvPoolSlot *s = &PgvShared->pool[(i + MyProcPid) % PGV_POOL_SLOTS];
+
+		if (pg_atomic_compare_exchange_u32(&s->state, &free_state, PGV_SLOT_CLAIMED))
+			slot = s;
+	}
+	if (slot == NULL)
+		return false;			/* more waiting backends than slots: this one scans for itself */
+	slot->dboid = MyDatabaseId;
+	slot->relid = RelationGetRelid(index);
+	slot->probes = probes;
+	slot->nullQuery = 0;
+	slot->latch = MyLatch;
+	memcpy(slot->payload, payload, rowBytes);
+	pg_atomic_write_u32(&slot->state, PGV_SLOT_FILLED);
+	PgvEnsureWorker();			/* sets the worker's latch */
+	PG_TRY();
+	{
+		for (;;)
+		{
+			state = pg_atomic_read_u32(&slot->state);
+			if (state == PGV_SLOT_DONE || state == PGV_SLOT_UNSERVED)
+				break;
+			(void) WaitLatch(MyLatch, WL_LATCH_SET | WL_TIMEOUT | WL_EXIT_ON_PM_DEATH, 1000L, PG_WAIT_EXTENSION);
+			ResetLatch(MyLatch);
+			CHECK_FOR_INTERRUPTS();
+		}
+	}
+	PG_CATCH();
+	{
+		/* cancelled while waiting: a slot the worker has not taken yet is free again; one it is answering is marked so
+		 * that the worker frees it instead of publishing results nobody reads */
+		uint32		filled = PGV_SLOT_FILLED;
+
+		if (!pg_atomic_compare_exchange_u32(&slot->state, &filled, PGV_SLOT_FREE))
+		{
+			uint32		taken = PGV_SLOT_TAKEN;
+
+			if (!pg_atomic_compare_exchange_u32(&slot->state, &taken, PGV_SLOT_ABANDONED))
+				pg_atomic_write_u32(&slot->state, PGV_SLOT_FREE);	/* DONE / UNSERVED already */
+		}
+		PG_RE_THROW();
+	}
+	PG_END_TRY();
+	if (state == PGV_SLOT_DONE)
+	{
+		*outCount = slot->count;
+		*outComplete = slot->total >= 0;
+		memcpy(outDist, slot->dist, sizeof(float) * (Size) slot->count);
+		memcpy(outTid, slot->tid, sizeof(uint64) * (Size) slot->count);
+	}
+	pg_atomic_write_u32(&slot->state, PGV_SLOT_FREE);
+	return state == PGV_SLOT_DONE;
 }

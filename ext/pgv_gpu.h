@@ -11,7 +11,8 @@
  *   _PG_init            src/vector.c:57-65      PgvGpuInit();   (shared_preload_libraries = 'vector' for the mirror registry)
  *   ivfflatbeginscan    src/ivfscan.c:252-317   so->gpu = PgvIvfflatBeginScan(index, so);
  *   ivfflatrescan       src/ivfscan.c:322-356   PgvIvfflatRescan(so->gpu);
- *   ivfflatgettuple     src/ivfscan.c:361-414   if (so->gpu) return PgvIvfflatGetTuple(scan);
+ *   ivfflatgettuple     src/ivfscan.c:361-414   if (so->gpu) { int r = PgvIvfflatGetTuple(scan); if (r >= 0) return r != 0; }
+ *                                               (-1, before the first tuple only: this scan goes on in the reference's code)
  *   ivfflatendscan      src/ivfscan.c:419-431   PgvIvfflatEndScan(so->gpu);
  *   hnswbeginscan       src/hnswscan.c:121-146  so->gpu = PgvHnswBeginScan(index);
  *   hnswgettuple        src/hnswscan.c:228      so->w = so->gpu ? PgvHnswGetScanItems(scan, value) : GetScanItems(scan, value);
@@ -38,6 +39,7 @@
 
 extern bool vector_gpu;			/* GUC vector.gpu */
 extern int	vector_gpu_device;	/* GUC vector.gpu_device */
+extern bool vector_gpu_pooled;	/* GUC vector.gpu_pooled: scans hand their query to the GPU worker's pooler */
 
 void		PgvGpuInit(void);
 pgv_ctx    *PgvGetContext(void);
@@ -63,6 +65,15 @@ typedef struct PgvIvfMirror
 
 /* NULL: no current mirror (being staged, stale, unsupported opclass) -- the scan stays on the CPU path */
 PgvIvfMirror *PgvIvfflatGetMirror(Relation index);
+/* the worker holds a current mirror of the index (a staging is requested otherwise) */
+bool		PgvIvfflatMirrorIsCurrent(Relation index);
+/*
+ * The pooler: one query to the worker, the head of its sorted stream back (at most PGV_POOL_HEAD heap TIDs as
+ * (block << 16) | offset; *outComplete = the probed lists hold no more tuples than came back).  false = not served.
+ */
+#define PGV_POOL_HEAD 64
+bool		PgvPoolSearch(Relation index, const void *payload, int probes, float *outDist, uint64 *outTid, int *outCount,
+						  bool *outComplete);
 /* insert / vacuum / build changed the index's pages: mirrors staged before now are stale */
 void		PgvNoteIndexChange(Relation index);
 /* bgw_main of the per-database worker that owns the mirrors */
@@ -71,7 +82,7 @@ void		PgvWorkerMain(Datum main_arg);
 /* scan side (ivfscan_gpu.c) */
 void	   *PgvIvfflatBeginScan(Relation index, IvfflatScanOpaque so);
 void		PgvIvfflatRescan(void *gpu);
-bool		PgvIvfflatGetTuple(IndexScanDesc scan);
+int			PgvIvfflatGetTuple(IndexScanDesc scan);	/* 1 a tuple, 0 no more, -1 not served: the reference's path */
 void		PgvIvfflatEndScan(void *gpu);
 
 /* HNSW scan side (hnswscan_gpu.c); List as in nodes/pg_list.h */

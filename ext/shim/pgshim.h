@@ -25,6 +25,7 @@ typedef size_t Size;
 typedef uintptr_t Datum;
 typedef unsigned int Oid;
 typedef char *Pointer;
+#define PG_INT64_MAX INT64_MAX
 #define Min(a, b) ((a) < (b) ? (a) : (b))
 #define Max(a, b) ((a) > (b) ? (a) : (b))
 #define PointerGetDatum(p) ((Datum) (p))
@@ -41,6 +42,7 @@ struct varlena
 struct varlena *pg_detoast_datum(struct varlena *datum);
 
 /* utils/elog.h */
+#define LOG 15
 #define ERROR 21
 #define ereport(level, rest) pgshim_ereport(level, rest)
 #define errmsg(...) pgshim_errmsg(__VA_ARGS__)
@@ -204,6 +206,8 @@ FmgrInfo   *index_getprocinfo(Relation irel, int attnum, uint16 procnum);
 #define PG_TRY() if (pgshim_try()) {
 #define PG_CATCH() } else {
 #define PG_END_TRY() }
+#define PG_RE_THROW() pgshim_rethrow()
+void		pgshim_rethrow(void) __attribute__((noreturn));
 int			pgshim_try(void);
 void		EmitErrorReport(void);
 void		FlushErrorState(void);
@@ -215,6 +219,7 @@ void	   *repalloc_huge(void *pointer, Size size);
 
 /* miscadmin.h, storage/ipc.h */
 extern Oid	MyDatabaseId;
+extern int	MyProcPid;
 extern bool process_shared_preload_libraries_in_progress;
 typedef void (*shmem_request_hook_type) (void);
 typedef void (*shmem_startup_hook_type) (void);
@@ -254,6 +259,14 @@ typedef struct pg_atomic_uint64
 void		pg_atomic_init_u64(volatile pg_atomic_uint64 *ptr, uint64 val);
 uint64		pg_atomic_read_u64(volatile pg_atomic_uint64 *ptr);
 uint64		pg_atomic_fetch_add_u64(volatile pg_atomic_uint64 *ptr, int64 add_);
+typedef struct pg_atomic_uint32
+{
+	volatile uint32 value;
+}			pg_atomic_uint32;
+void		pg_atomic_init_u32(volatile pg_atomic_uint32 *ptr, uint32 val);
+uint32		pg_atomic_read_u32(volatile pg_atomic_uint32 *ptr);
+void		pg_atomic_write_u32(volatile pg_atomic_uint32 *ptr, uint32 val);
+bool		pg_atomic_compare_exchange_u32(volatile pg_atomic_uint32 *ptr, uint32 *expected, uint32 newval);
 
 /* storage/latch.h, utils/wait_event.h */
 typedef struct Latch Latch;
