@@ -1,12 +1,15 @@
 /*
  * hnswscan_gpu.c -- the first batch of an HNSW index scan on the device: GetScanItems (src/hnswscan.c:25-56:
  * greedy descent + HnswSearchLayer with hnsw.ef_search, src/hnswutils.c:824-987) becomes one pgv_hnsw_search call
- * over a device mirror of the graph.  Twin over the emulated page image: pgvector_amd/host/hnsw_pages.c (stager)
- * and hnsw_search.c.
+ * over a device mirror of the graph.  The mirror is staged ONCE by the GPU worker of pgv_context.c (PgvHnswStage),
+ * exported, and imported by every backend (pgv_hnsw_import: hipIpc, no copy); the element tuples' TIDs and heap
+ * TIDs ride on the device as the elements' payload, so a backend keeps no per-element table.  Twin over the emulated
+ * page image: pgvector_amd/host/hnsw_pages.c (stager) and hnsw_search.c.
  *
  * Hook points (one line each; the reference code stays as the `vector.gpu = off` path):
  *   hnswbeginscan   src/hnswscan.c:121-146   so->gpu = PgvHnswBeginScan(index);
  *   hnswgettuple    src/hnswscan.c:228        so->w = so->gpu ? PgvHnswGetScanItems(scan, value) : GetScanItems(scan, value);
+ *   hnswinsert / hnswbulkdelete / hnswbuild   PgvNoteIndexChange(index);   (the mirror is stale until restaged)
  * hnswgettuple then pops so->w one heap TID at a time exactly as before (:293-326); with hnsw.iterative_scan the
  * later batches (ResumeScanItems, :61-88) stay on the reference's code, scoring through pgv_hnsw_score
  * (INTEGRATION.md section 5).
@@ -16,19 +19,26 @@
 #include "hnsw.h"
 #include "utils/memutils.h"
 
-/* device mirror of one HNSW index, cached per backend and dropped by the relcache callback of pgv_context.c */
+/*
+ * What a backend keeps of an HNSW index's device mirror: an import of the worker's export (pgv_context.c owns the
+ * registry; the worker stages with PgvHnswStage below, uploads once and exports).  Nothing per element lives in the
+ * backend: the element tuple's own TID and its heap TIDs travel as the elements' PAYLOAD on the device and come
+ * back with a scan's results (pgv_hnsw_get_payload).
+ */
 typedef struct PgvHnswMirror
 {
 	Oid			relid;
 	bool		valid;
+	uint64		staged;			/* the staging (registry generation + 1) this import belongs to */
 	pgv_hnsw   *h;
 	int			m;
 	int64		nelements;
-	uint64	   *elementTids;	/* slot -> (blkno << 16) | offno of the element tuple, ascending */
-	ItemPointerData *heaptids;	/* [nelements x HNSW_HEAPTIDS] */
-	uint8	   *heaptidsLength;
 	struct PgvHnswMirror *next;
 }			PgvHnswMirror;
+
+/* payload words per element: the element tuple's TID, the count of heap TIDs, HNSW_HEAPTIDS heap TIDs; every TID
+ * as two words of (block << 16) | offset */
+#define PGV_HNSW_PAYLOAD_WORDS (2 + 1 + 2 * HNSW_HEAPTIDS)
 
 static PgvHnswMirror *hnswMirrors = NULL;
 
@@ -48,18 +58,18 @@ TidKey(BlockNumber blkno, OffsetNumber offno)
 
 /* element tuples were numbered in page order, so their keys ascend: (blkno, offno) -> slot by bisection */
 static int32
-SlotOf(const PgvHnswMirror * m, uint64 key)
+SlotOf(const uint64 *elementTids, int64 nelements, uint64 key)
 {
 	int64		lo = 0,
-				hi = m->nelements - 1;
+				hi = nelements - 1;
 
 	while (lo <= hi)
 	{
 		int64		mid = (lo + hi) / 2;
 
-		if (m->elementTids[mid] == key)
+		if (elementTids[mid] == key)
 			return (int32) mid;
-		if (m->elementTids[mid] < key)
+		if (elementTids[mid] < key)
 			lo = mid + 1;
 		else
 			hi = mid - 1;
@@ -68,17 +78,20 @@ SlotOf(const PgvHnswMirror * m, uint64 key)
 }
 
 /*
- * Stage the graph out of its pages once per mirror: HnswLoadElement (src/hnswutils.c:533-571) and
- * HnswLoadNeighborTids (:761-794) for every element instead of for every visited one.
+ * The WORKER's staging of the graph out of its pages, once per mirror: HnswLoadElement (src/hnswutils.c:533-571) and
+ * HnswLoadNeighborTids (:761-794) for every element instead of for every visited one.  Returns the uploaded mirror
+ * with its graph set (NULL for opclasses whose elements are not dense float rows).
  */
-static void
-PgvHnswStage(Relation index, PgvHnswMirror * m, pgv_metric metric, pgv_dtype dtype)
+pgv_hnsw *
+PgvHnswStage(Relation index, int *outM, int *outDimensions, int64 *outElements)
 {
 	BlockNumber nblocks = RelationGetNumberOfBlocks(index);
 	Buffer		buf;
 	Page		page;
 	HnswMetaPageData meta;
-	Size		esize = dtype == PGV_F32 ? sizeof(float) : sizeof(uint16);
+	pgv_dtype	dtype;
+	pgv_metric	metric;
+	Size		esize;
 	Size		rowBytes;
 	int64		cap = 1024,
 				n = 0,
@@ -86,22 +99,30 @@ PgvHnswStage(Relation index, PgvHnswMirror * m, pgv_metric metric, pgv_dtype dty
 	char	   *vectors;
 	int32	   *levels;
 	ItemPointerData *neighborTids;
+	uint64	   *elementTids;
+	uint32	   *payload;
 	int64	   *nbrStart;
 	int32	   *nbr;
 	int32		entry = -1;
+	pgv_hnsw   *h = NULL;
+
+	if (!PgvHnswElementType(index, &dtype))
+		return NULL;
+	/* FUNCTION 1 of the opclass: vector_l2_squared_distance, or vector_negative_inner_product on rows that FUNCTION 2
+	 * normalised (cosine) or not (ip) -- sql/vector.sql:427-447, :843-865 */
+	metric = HnswOptionalProcInfo(index, HNSW_NORM_PROC) != NULL ? PGV_NEG_IP : PgvHnswMetricOf(index);
+	esize = dtype == PGV_F32 ? sizeof(float) : sizeof(uint16);
 
 	buf = ReadBufferExtended(index, MAIN_FORKNUM, HNSW_METAPAGE_BLKNO, RBM_NORMAL, NULL);
 	LockBuffer(buf, BUFFER_LOCK_SHARE);
 	meta = *HnswPageGetMeta(BufferGetPage(buf));
 	UnlockReleaseBuffer(buf);
-	m->m = meta.m;
 	rowBytes = esize * (Size) meta.dimensions;
-	vectors = palloc(rowBytes * (Size) cap);
+	vectors = palloc_extended(rowBytes * (Size) cap, MCXT_ALLOC_HUGE);
 	levels = palloc(sizeof(int32) * (Size) cap);
 	neighborTids = palloc(sizeof(ItemPointerData) * (Size) cap);
-	m->elementTids = MemoryContextAlloc(TopMemoryContext, sizeof(uint64) * (Size) cap);
-	m->heaptids = MemoryContextAlloc(TopMemoryContext, sizeof(ItemPointerData) * HNSW_HEAPTIDS * (Size) cap);
-	m->heaptidsLength = MemoryContextAlloc(TopMemoryContext, (Size) cap);
+	elementTids = palloc(sizeof(uint64) * (Size) cap);
+	payload = palloc0(sizeof(uint32) * PGV_HNSW_PAYLOAD_WORDS * (Size) cap);
 
 	/* pass 1: the element tuples, slot = order of first sight */
 	for (BlockNumber blkno = HNSW_HEAD_BLKNO; blkno < nblocks; blkno++)
@@ -116,26 +137,37 @@ PgvHnswStage(Relation index, PgvHnswMirror * m, pgv_metric metric, pgv_dtype dty
 		for (OffsetNumber offno = FirstOffsetNumber; offno <= maxoffno; offno = OffsetNumberNext(offno))
 		{
 			HnswElementTuple etup = (HnswElementTuple) PageGetItem(page, PageGetItemId(page, offno));
+			uint32	   *p;
+			uint32		count = 0;
 
 			if (!HnswIsElementTuple(etup) || etup->deleted)
 				continue;
 			if (n == cap)
 			{
 				cap *= 2;
-				vectors = repalloc(vectors, rowBytes * (Size) cap);
+				vectors = repalloc_huge(vectors, rowBytes * (Size) cap);
 				levels = repalloc(levels, sizeof(int32) * (Size) cap);
 				neighborTids = repalloc(neighborTids, sizeof(ItemPointerData) * (Size) cap);
-				m->elementTids = repalloc(m->elementTids, sizeof(uint64) * (Size) cap);
-				m->heaptids = repalloc(m->heaptids, sizeof(ItemPointerData) * HNSW_HEAPTIDS * (Size) cap);
-				m->heaptidsLength = repalloc(m->heaptidsLength, (Size) cap);
+				elementTids = repalloc(elementTids, sizeof(uint64) * (Size) cap);
+				payload = repalloc_huge(payload, sizeof(uint32) * PGV_HNSW_PAYLOAD_WORDS * (Size) cap);
 			}
 			memcpy(vectors + rowBytes * (Size) n, etup->data.x, rowBytes);	/* Vector / HalfVector payload */
 			levels[n] = etup->level;
 			neighborTids[n] = etup->neighbortid;
-			m->elementTids[n] = TidKey(blkno, offno);
-			m->heaptidsLength[n] = 0;
+			elementTids[n] = TidKey(blkno, offno);
+			p = payload + PGV_HNSW_PAYLOAD_WORDS * (Size) n;
+			memset(p, 0, sizeof(uint32) * PGV_HNSW_PAYLOAD_WORDS);
+			p[0] = (uint32) elementTids[n];
+			p[1] = (uint32) (elementTids[n] >> 32);
 			for (int i = 0; i < HNSW_HEAPTIDS && ItemPointerIsValid(&etup->heaptids[i]); i++)
-				m->heaptids[n * HNSW_HEAPTIDS + m->heaptidsLength[n]++] = etup->heaptids[i];
+			{
+				uint64		t = TidKey(ItemPointerGetBlockNumber(&etup->heaptids[i]), ItemPointerGetOffsetNumber(&etup->heaptids[i]));
+
+				p[3 + 2 * count] = (uint32) t;
+				p[4 + 2 * count] = (uint32) (t >> 32);
+				count++;
+			}
+			p[2] = count;
 			if (blkno == meta.entryBlkno && offno == meta.entryOffno)
 				entry = (int32) n;
 			ntids += (int64) (etup->level + 2) * meta.m;
@@ -143,12 +175,11 @@ PgvHnswStage(Relation index, PgvHnswMirror * m, pgv_metric metric, pgv_dtype dty
 		}
 		UnlockReleaseBuffer(buf);
 	}
-	m->nelements = n;
 
 	/* pass 2: neighbor tuples -> slots; an invalid TID ends a layer's list (:785-786), a TID whose element is
 	 * gone is dropped and the rest moves up */
 	nbrStart = palloc(sizeof(int64) * ((Size) n + 1));
-	nbr = palloc(sizeof(int32) * (Size) Max(ntids, 1));
+	nbr = palloc_extended(sizeof(int32) * (Size) Max(ntids, 1), MCXT_ALLOC_HUGE);
 	nbrStart[0] = 0;
 	for (int64 e = 0; e < n; e++)
 	{
@@ -172,8 +203,8 @@ PgvHnswStage(Relation index, PgvHnswMirror * m, pgv_metric metric, pgv_dtype dty
 
 				for (int i = 0; i < len && ItemPointerIsValid(&ntup->indextids[s0 + i]); i++)
 				{
-					int32		slot = SlotOf(m, TidKey(ItemPointerGetBlockNumber(&ntup->indextids[s0 + i]),
-														ItemPointerGetOffsetNumber(&ntup->indextids[s0 + i])));
+					int32		slot = SlotOf(elementTids, n, TidKey(ItemPointerGetBlockNumber(&ntup->indextids[s0 + i]),
+																	 ItemPointerGetOffsetNumber(&ntup->indextids[s0 + i])));
 
 					if (slot >= 0)
 						out[s0 + kept++] = slot;
@@ -183,15 +214,26 @@ PgvHnswStage(Relation index, PgvHnswMirror * m, pgv_metric metric, pgv_dtype dty
 		UnlockReleaseBuffer(buf);
 	}
 
-	if (pgv_hnsw_upload(PgvGetContext(), metric, dtype, (int) meta.dimensions, vectors, n, &m->h) != PGV_OK ||
-		(n > 0 && pgv_hnsw_set_graph(m->h, meta.m, entry, levels, nbrStart, nbr) != PGV_OK))
+	if (n > 0 &&
+		(pgv_hnsw_upload_payload(PgvGetContext(), metric, dtype, (int) meta.dimensions, vectors, n, payload,
+								 (int) (sizeof(uint32) * PGV_HNSW_PAYLOAD_WORDS), &h) != PGV_OK ||
+		 pgv_hnsw_set_graph(h, meta.m, entry, levels, nbrStart, nbr) != PGV_OK))
+	{
+		if (h)
+			pgv_hnsw_free(h);
 		ereport(ERROR, (errmsg("pgvector GPU path: %s", pgv_last_error())));
-	m->valid = true;
+	}
+	*outM = meta.m;
+	*outDimensions = (int) meta.dimensions;
+	*outElements = n;
 	pfree(nbr);
 	pfree(nbrStart);
+	pfree(payload);
+	pfree(elementTids);
 	pfree(neighborTids);
 	pfree(levels);
 	pfree(vectors);
+	return h;					/* NULL for an index without elements: nothing to mirror, scans stay on the CPU path */
 }
 
 /* which kernel metric FUNCTION 1 of the opclass is (sql/vector.sql:427-447, :843-865) */
@@ -228,8 +270,16 @@ PgvHnswBeginScan(Relation index)
 {
 	PgvHnswMirror *m;
 	pgv_dtype	dtype;
+	pgv_index_handle handle;
+	uint64		staged = 0;
+	int			graphM = 0;
+	int64		nelements = 0;
 
 	if (!vector_gpu || !PgvHnswElementType(index, &dtype))
+		return NULL;
+	/* no current mirror (first use, stale after inserts / vacuum, no shared memory): this scan stays on the CPU path
+	 * and the worker has been asked to stage */
+	if (!PgvHnswMirrorHandle(index, &handle, &staged, &graphM, &nelements))
 		return NULL;
 	for (m = hnswMirrors; m != NULL; m = m->next)
 		if (m->relid == RelationGetRelid(index))
@@ -241,24 +291,18 @@ PgvHnswBeginScan(Relation index)
 		m->next = hnswMirrors;
 		hnswMirrors = m;
 	}
-	if (!m->valid)
+	if (!m->valid || m->staged != staged)
 	{
-		/* FUNCTION 1 of the opclass: vector_l2_squared_distance, or vector_negative_inner_product on rows that
-		 * FUNCTION 2 normalised (cosine) or not (ip) -- sql/vector.sql:427-447, :843-865 */
-		bool		normalized = HnswOptionalProcInfo(index, HNSW_NORM_PROC) != NULL;
-		pgv_metric	metric = normalized ? PGV_NEG_IP : PgvHnswMetricOf(index);	/* cosine: FUNCTION 1 is the negative inner product too */
-
 		if (m->h)
-			pgv_hnsw_free(m->h);
-		if (m->elementTids)
-		{
-			pfree(m->elementTids);
-			pfree(m->heaptids);
-			pfree(m->heaptidsLength);
-		}
+			pgv_hnsw_free(m->h);	/* unmaps the import; the worker's allocation stays */
 		m->h = NULL;
-		m->elementTids = NULL;
-		PgvHnswStage(index, m, metric, dtype);
+		m->valid = false;
+		if (pgv_hnsw_import(PgvGetContext(), &handle, &m->h) != PGV_OK)
+			ereport(ERROR, (errmsg("pgvector GPU path: %s", pgv_last_error())));
+		m->m = graphM;
+		m->nelements = nelements;
+		m->staged = staged;
+		m->valid = true;
 	}
 	return m;
 }
@@ -272,6 +316,7 @@ PgvHnswGetScanItems(IndexScanDesc scan, Datum value)
 	Vector	   *q = (Vector *) PG_DETOAST_DATUM(value);
 	int64		elems[HNSW_MAX_EF_SEARCH];
 	float		dists[HNSW_MAX_EF_SEARCH];
+	uint32	   *payload;
 	int64		tuples = 0;
 	List	   *w = NIL;
 
@@ -281,25 +326,38 @@ PgvHnswGetScanItems(IndexScanDesc scan, Datum value)
 	if (pgv_hnsw_search(m->h, q->x, 1, hnsw_ef_search, hnsw_ef_search, elems, dists, &tuples) != PGV_OK)
 		ereport(ERROR, (errmsg("pgvector GPU path: %s", pgv_last_error())));
 	so->tuples = tuples;
+	/* the result elements' own TIDs and heap TIDs: their payload rows, out of the worker's allocation */
+	payload = palloc(sizeof(uint32) * PGV_HNSW_PAYLOAD_WORDS * (Size) hnsw_ef_search);
+	if (pgv_hnsw_get_payload(m->h, elems, hnsw_ef_search, payload) != PGV_OK)
+		ereport(ERROR, (errmsg("pgvector GPU path: %s", pgv_last_error())));
 
 	/* HnswSearchLayer hands back its result set furthest first (hnswgettuple takes llast(so->w), :293-300) */
 	for (int i = hnsw_ef_search - 1; i >= 0; i--)
 	{
 		HnswSearchCandidate *sc;
 		HnswElement element;
-		int64		slot = elems[i];
+		const uint32 *p = payload + PGV_HNSW_PAYLOAD_WORDS * (Size) i;
+		uint64		etid = ((uint64) p[1] << 32) | p[0];
 
-		if (slot < 0)
+		if (elems[i] < 0)
 			continue;
-		element = HnswInitElementFromBlock((BlockNumber) (m->elementTids[slot] >> 16),
-										   (OffsetNumber) (m->elementTids[slot] & 0xffff));
+		element = HnswInitElementFromBlock((BlockNumber) (etid >> 16), (OffsetNumber) (etid & 0xffff));
 		element->level = 0;
-		for (int t = 0; t < m->heaptidsLength[slot]; t++)
-			HnswAddHeapTid(element, &m->heaptids[slot * HNSW_HEAPTIDS + t]);
+		for (uint32 t = 0; t < p[2] && t < HNSW_HEAPTIDS; t++)
+		{
+			uint64		ht = ((uint64) p[4 + 2 * t] << 32) | p[3 + 2 * t];
+			ItemPointerData heaptid;
+
+			heaptid.ip_blkid.bi_hi = (uint16) (ht >> 32);
+			heaptid.ip_blkid.bi_lo = (uint16) (ht >> 16);
+			heaptid.ip_posid = (OffsetNumber) (ht & 0xffff);
+			HnswAddHeapTid(element, &heaptid);
+		}
 		sc = palloc(sizeof(HnswSearchCandidate));
 		HnswPtrStore((char *) NULL, sc->element, element);
 		sc->distance = (double) dists[i];
 		w = lappend(w, sc);
 	}
+	pfree(payload);
 	return w;
 }

@@ -58,6 +58,7 @@ typedef struct PgvSharedMirror
 {
 	Oid			dboid;
 	Oid			relid;
+	int			kind;			/* PGV_KIND_IVFFLAT / PGV_KIND_HNSW: which staging the worker runs */
 	int			state;
 	pg_atomic_uint64 generation;	/* bumped by PgvNoteIndexChange */
 	uint64		stagedGeneration;	/* value of `generation` the published mirror was staged at */
@@ -158,7 +159,7 @@ PgvShmemStartup(void)
 
 /* the entry of (MyDatabaseId, relid), created on demand; NULL when the registry is full or not configured */
 static PgvSharedMirror *
-PgvFindEntry(Oid relid, bool create)
+PgvFindEntryKind(Oid relid, bool create, int kind)
 {
 	PgvSharedMirror *free_entry = NULL;
 
@@ -177,10 +178,17 @@ PgvFindEntry(Oid relid, bool create)
 	{
 		free_entry->dboid = MyDatabaseId;
 		free_entry->relid = relid;
+		free_entry->kind = kind;
 		free_entry->state = PGV_MIRROR_EMPTY;
 		free_entry->stagedGeneration = 0;
 	}
 	return create ? free_entry : NULL;
+}
+
+static PgvSharedMirror *
+PgvFindEntry(Oid relid, bool create)
+{
+	return PgvFindEntryKind(relid, create, PGV_KIND_IVFFLAT);
 }
 
 /* ivfflatinsert (src/ivfinsert.c:72-181), ivfflatbulkdelete (src/ivfvacuum.c:18-143), hnswinsert, hnswbulkdelete and
@@ -286,7 +294,8 @@ PgvIvfflatOpclass(Relation index, pgv_metric * metric, pgv_dtype * dtype, pgv_op
 typedef struct PgvOwned
 {
 	Oid			relid;
-	pgv_index  *index;
+	pgv_index  *index;			/* an ivfflat index's mirror, or */
+	pgv_hnsw   *hnsw;			/* an hnsw index's */
 }			PgvOwned;
 
 static PgvOwned owned[PGV_MAX_MIRRORS];
@@ -395,8 +404,10 @@ PgvWorkerStageEntry(PgvSharedMirror * e)
 {
 	Oid			relid = e->relid;
 	uint64		generation = pg_atomic_read_u64(&e->generation);
+	int			kind = e->kind;
 	volatile bool ok = false;
 	pgv_index  *volatile fresh = NULL;
+	pgv_hnsw   *volatile freshHnsw = NULL;
 	pgv_index_handle handle;
 	int			lists = 0,
 				dimensions = 0;
@@ -412,7 +423,18 @@ PgvWorkerStageEntry(PgvSharedMirror * e)
 
 		if (index != NULL)
 		{
-			if (PgvIvfflatOpclass(index, &metric, &dtype, &ops))
+			if (kind == PGV_KIND_HNSW)
+			{
+				/* the graph out of its pages (hnswscan_gpu.c), heap TIDs as the elements' payload: lists = m */
+				freshHnsw = PgvHnswStage(index, &lists, &dimensions, &ntuples);
+				if (freshHnsw != NULL)
+				{
+					if (pgv_hnsw_export(freshHnsw, &handle) != PGV_OK)
+						ereport(ERROR, (errmsg("pgvector GPU path: %s", pgv_last_error())));
+					ok = true;
+				}
+			}
+			else if (PgvIvfflatOpclass(index, &metric, &dtype, &ops))
 			{
 				IvfflatGetMetaPageInfo(index, &lists, &dimensions);
 				fresh = PgvStage(index, metric, dtype, lists, dimensions, &ntuples);
@@ -432,7 +454,10 @@ PgvWorkerStageEntry(PgvSharedMirror * e)
 		AbortCurrentTransaction();
 		if (fresh)
 			pgv_index_free(fresh);
+		if (freshHnsw)
+			pgv_hnsw_free(freshHnsw);
 		fresh = NULL;
+		freshHnsw = NULL;
 		ok = false;
 	}
 	PG_END_TRY();
@@ -461,8 +486,11 @@ PgvWorkerStageEntry(PgvSharedMirror * e)
 		{
 			if (owned[i].relid == relid && owned[i].index)
 				pgv_index_free(owned[i].index);
+			if (owned[i].relid == relid && owned[i].hnsw)
+				pgv_hnsw_free(owned[i].hnsw);
 			owned[i].relid = ok ? relid : 0;
 			owned[i].index = ok ? fresh : NULL;
+			owned[i].hnsw = ok ? freshHnsw : NULL;
 			break;
 		}
 }
@@ -663,7 +691,7 @@ PgvEnsureWorker(void)
  */
 /* the registry's current staging of the index, asking the worker for one when there is none; false = none now */
 static bool
-PgvMirrorReady(Relation index, pgv_index_handle * handle, uint64 *staged)
+PgvMirrorReadyKind(Relation index, int kind, pgv_index_handle * handle, uint64 *staged, int *lists, int64 *ntuples)
 {
 	PgvSharedMirror *e;
 	bool		ready = false;
@@ -674,7 +702,7 @@ PgvMirrorReady(Relation index, pgv_index_handle * handle, uint64 *staged)
 		bool		request = false;
 
 		LWLockAcquire(PgvShared->lock, LW_EXCLUSIVE);
-		e = PgvFindEntry(RelationGetRelid(index), true);
+		e = PgvFindEntryKind(RelationGetRelid(index), true, kind);
 		if (e != NULL)
 		{
 			uint64		generation = pg_atomic_read_u64(&e->generation);
@@ -683,6 +711,10 @@ PgvMirrorReady(Relation index, pgv_index_handle * handle, uint64 *staged)
 			{
 				*handle = e->handle;
 				*staged = e->stagedGeneration + 1;	/* 0 = none */
+				if (lists)
+					*lists = e->lists;
+				if (ntuples)
+					*ntuples = e->ntuples;
 				ready = true;
 			}
 			else if (e->state == PGV_MIRROR_EMPTY || e->state == PGV_MIRROR_READY ||
@@ -705,6 +737,21 @@ PgvMirrorReady(Relation index, pgv_index_handle * handle, uint64 *staged)
 		pg_usleep(1000L);
 	}
 	return ready;
+}
+
+static bool
+PgvMirrorReady(Relation index, pgv_index_handle * handle, uint64 *staged)
+{
+	return PgvMirrorReadyKind(index, PGV_KIND_IVFFLAT, handle, staged, NULL, NULL);
+}
+
+/* hnswscan_gpu.c: the worker's export of an hnsw index's mirror (m, element count with it); false = none now */
+bool
+PgvHnswMirrorHandle(Relation index, pgv_index_handle * handle, uint64 *staged, int *m, int64 *nelements)
+{
+	if (PgvShared == NULL)
+		return false;
+	return PgvMirrorReadyKind(index, PGV_KIND_HNSW, handle, staged, m, nelements);
 }
 
 /* the pooled path's question: does the worker hold a current mirror of this index (asks for one otherwise) */

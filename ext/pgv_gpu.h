@@ -85,6 +85,15 @@ void		PgvIvfflatRescan(void *gpu);
 int			PgvIvfflatGetTuple(IndexScanDesc scan);	/* 1 a tuple, 0 no more, -1 not served: the reference's path */
 void		PgvIvfflatEndScan(void *gpu);
 
+/* registry kinds (pgv_context.c) */
+#define PGV_KIND_IVFFLAT 0
+#define PGV_KIND_HNSW 1
+/* the worker's staging of an hnsw index (hnswscan_gpu.c): elements, graph, heap TIDs as the elements' payload;
+ * NULL = not a vector / halfvec opclass.  *m, *dimensions, *nelements describe it. */
+pgv_hnsw   *PgvHnswStage(Relation index, int *m, int *dimensions, int64 *nelements);
+/* a backend's way to the worker's export of it (pgv_context.c); false = none now (a staging has been requested) */
+bool		PgvHnswMirrorHandle(Relation index, pgv_index_handle * handle, uint64 *staged, int *m, int64 *nelements);
+
 /* HNSW scan side (hnswscan_gpu.c); List as in nodes/pg_list.h */
 void	   *PgvHnswBeginScan(Relation index);
 List	   *PgvHnswGetScanItems(IndexScanDesc scan, Datum value);

@@ -534,6 +534,16 @@ int			pgv_bit_distance_batch(pgv_ctx * ctx, pgv_bit_metric metric, int nbits,
 int			pgv_hnsw_upload(pgv_ctx * ctx, pgv_metric metric, pgv_dtype dtype, int dim,
 							const void *elements, int64_t n, pgv_hnsw * *out);
 void		pgv_hnsw_free(pgv_hnsw * h);
+/*
+ * The same with a PAYLOAD per element (0..4096 bytes in whole words) kept next to the vectors: what a scan needs to
+ * turn a result element into heap TIDs (HnswElementTuple's heaptids[HNSW_HEAPTIDS] and their count,
+ * src/hnsw.h:142-153, hnswgettuple src/hnswscan.c:293-311).  It rides in the elements' allocation, so an importing
+ * process (pgv_hnsw_import) sees it without a table of its own; pgv_hnsw_get_payload brings the payload rows of a
+ * scan's result elements to the host (element slots < 0 give zero bytes).
+ */
+int			pgv_hnsw_upload_payload(pgv_ctx * ctx, pgv_metric metric, pgv_dtype dtype, int dim, const void *elements,
+									int64_t n, const void *payload, int payload_bytes, pgv_hnsw * *out);
+int			pgv_hnsw_get_payload(pgv_hnsw * h, const int64_t *elements, int n, void *out);
 
 /*
  * The HNSW mirror across processes, like pgv_index_export / pgv_index_import: the element vectors and the graph

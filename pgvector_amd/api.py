@@ -584,14 +584,30 @@ def drain_index(index, chunk_rows=0):
 class Hnsw:
     """device mirror of an HNSW index's element vectors (pgv_hnsw_upload)"""
 
-    def __init__(self, ctx, metric, dtype, dim, elements):
+    def __init__(self, ctx, metric, dtype, dim, elements, payload=None):
+        """payload: [n x w] uint32 per-element words kept next to the vectors (pgv_hnsw_upload_payload)"""
         self.ctx, self.metric, self.dtype, self.dim = ctx, metric, dtype, dim
         elements = as_dtype(elements, dtype)
         h = C.c_void_p()
-        check(lib.pgv_hnsw_upload(ctx.h, metric, dtype, dim, ptr(elements), int(elements.shape[0]),
-                                  C.byref(h)))
+        if payload is None:
+            check(lib.pgv_hnsw_upload(ctx.h, metric, dtype, dim, ptr(elements), int(elements.shape[0]),
+                                      C.byref(h)))
+            self.payload_words = 0
+        else:
+            payload = np.ascontiguousarray(payload, dtype=np.uint32)
+            self.payload_words = int(payload.shape[1])
+            check(lib.pgv_hnsw_upload_payload(ctx.h, metric, dtype, dim, ptr(elements), int(elements.shape[0]),
+                                              ptr(payload), 4 * self.payload_words, C.byref(h)))
         self.h = h
         ctx._adopt(self)
+
+    def get_payload(self, elements, words=None):
+        """pgv_hnsw_get_payload: the payload rows of result elements -> [n x w] uint32 (zeros for slots < 0)"""
+        elements = np.ascontiguousarray(elements, dtype=np.int64).ravel()
+        w = words or self.payload_words
+        out = np.empty((elements.size, w), dtype=np.uint32)
+        check(lib.pgv_hnsw_get_payload(self.h, ptr(elements), int(elements.size), ptr(out)))
+        return out
 
     def close(self):
         if self.h:
@@ -618,6 +634,7 @@ class Hnsw:
         buf = C.create_string_buffer(bytes(handle), 256)
         check(lib.pgv_hnsw_import(ctx.h, buf, C.byref(h)))
         v.ctx, v.metric, v.dtype, v.dim, v.h = ctx, None, dtype, None, h
+        v.payload_words = 0
         ctx._adopt(v)
         return v
 

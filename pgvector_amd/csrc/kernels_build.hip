@@ -80,7 +80,26 @@ __global__ __launch_bounds__(256) void build_gather_kernel(const Raw16 *__restri
     if (lane == 0 && dst_tids) dst_tids[i] = src_tids ? src_tids[from] : (uint64_t)from;
 }
 
+__global__ __launch_bounds__(256) void gather_words_kernel(const uint32_t *__restrict__ src, int words, int64_t nrows,
+                                                           const int64_t *__restrict__ idx, int n, uint32_t *__restrict__ out) {
+    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= (int64_t)n * words) return;
+    const int i = (int)(t / words), w = (int)(t % words);
+    const int64_t r = idx[i];
+    out[t] = (r >= 0 && r < nrows) ? src[(size_t)r * words + w] : 0u;
+}
+
 }  // namespace
+
+int launch_gather_words(pgv_ctx *ctx, const void *src, int words_per_row, int64_t nrows, const int64_t *idx, int n,
+                        uint32_t *out) {
+    const int64_t total = (int64_t)n * words_per_row;
+    if (total <= 0) return PGV_OK;
+    hipLaunchKernelGGL(gather_words_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, ctx->stream,
+                       static_cast<const uint32_t *>(src), words_per_row, nrows, idx, n, out);
+    PGV_HIP(hipGetLastError());
+    return PGV_OK;
+}
 
 size_t build_sort_scratch_bytes(int64_t n, int key_bits) {
     size_t bytes = 0;

@@ -2595,11 +2595,23 @@ int pgv_search_batch_sharded(pgv_comm *cm, pgv_index *ix, const void *queries, i
 
 int pgv_hnsw_upload(pgv_ctx *ctx, pgv_metric metric, pgv_dtype dtype, int dim, const void *elements,
                     int64_t n, pgv_hnsw **out) {
+    return pgv_hnsw_upload_payload(ctx, metric, dtype, dim, elements, n, nullptr, 0, out);
+}
+
+// where the per-element payload starts inside the elements' allocation
+static size_t hnsw_payload_offset(int64_t n, size_t row_bytes) {
+    return ((size_t)(n > 0 ? n : 1) * row_bytes + 255) & ~(size_t)255;
+}
+
+int pgv_hnsw_upload_payload(pgv_ctx *ctx, pgv_metric metric, pgv_dtype dtype, int dim, const void *elements,
+                            int64_t n, const void *payload, int payload_bytes, pgv_hnsw **out) {
     if (!ctx || !out) PGV_FAIL(PGV_ERR_ARG, "pgv_hnsw_upload: ctx/out is NULL");
     *out = nullptr;
     PGV_TRY(check_common(dtype, dim));
     PGV_TRY(check_metric(metric));
     if (n < 0 || (n > 0 && !elements)) PGV_FAIL(PGV_ERR_ARG, "bad elements");
+    if (payload_bytes < 0 || payload_bytes > 4096 || (payload_bytes & 3) || (payload_bytes > 0 && n > 0 && !payload))
+        PGV_FAIL(PGV_ERR_ARG, "payload: 0..4096 bytes per element in whole words, got %d", payload_bytes);
     PGV_HIP(hipSetDevice(ctx->device));
     pgv_hnsw *h = new (std::nothrow) pgv_hnsw();
     if (!h) PGV_FAIL(PGV_ERR_NOMEM, "out of host memory");
@@ -2611,9 +2623,22 @@ int pgv_hnsw_upload(pgv_ctx *ctx, pgv_metric metric, pgv_dtype dtype, int dim, c
     h->geom = row_geom(dim, dtype);
     const size_t es = elem_size(dtype), row_bytes = (size_t)h->geom.ld * es;
     const size_t bytes = (size_t)(n > 0 ? n : 1) * row_bytes;
-    if (hipMalloc(&h->elements, bytes) != hipSuccess) {
+    // the payload (what a scan needs to turn an element into heap TIDs) rides in the same allocation, so that the one
+    // IPC handle of the elements carries it to importing processes
+    const size_t pay_off = hnsw_payload_offset(n, row_bytes), pay_total = (size_t)payload_bytes * (size_t)(n > 0 ? n : 0);
+    if (hipMalloc(&h->elements, payload_bytes > 0 ? pay_off + (pay_total ? pay_total : 4) : bytes) != hipSuccess) {
         delete h;
         PGV_FAIL(PGV_ERR_NOMEM, "hipMalloc(%zu) for hnsw elements failed", bytes);
+    }
+    h->payload_bytes = payload_bytes;
+    h->payload = payload_bytes > 0 ? static_cast<char *>(h->elements) + pay_off : nullptr;
+    if (pay_total) {
+        hipError_t e = hipMemcpyAsync(h->payload, payload, pay_total,
+                                      is_device_ptr(payload) ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, ctx->stream);
+        if (e != hipSuccess) {
+            pgv_hnsw_free(h);
+            PGV_FAIL(PGV_ERR_DEVICE, "hnsw payload upload failed: %s", hipGetErrorString(e));
+        }
     }
     if (n > 0) {
         const bool dev = is_device_ptr(elements);
@@ -2657,6 +2682,7 @@ struct HnswHandleWire {
     int32_t device, metric, dtype, dim, m, entry;
     int64_t n, nbr_total;
     uint64_t graph_bytes;
+    int32_t payload_bytes, pad;
     hipIpcMemHandle_t elements, graph;
 };
 static_assert(sizeof(HnswHandleWire) <= PGV_INDEX_HANDLE_BYTES, "pgv_index_handle too small for an HNSW mirror");
@@ -2683,6 +2709,7 @@ int pgv_hnsw_export(pgv_hnsw *h, pgv_index_handle *out) {
     w.n = h->n;
     w.nbr_total = h->nbr_total;
     w.graph_bytes = h->graph_bytes;
+    w.payload_bytes = h->payload_bytes;
     hipError_t e = hipIpcGetMemHandle(&w.elements, h->elements);
     if (e == hipSuccess) e = hipIpcGetMemHandle(&w.graph, h->graph);
     if (e != hipSuccess) {
@@ -2707,7 +2734,8 @@ int pgv_hnsw_import(pgv_ctx *ctx, const pgv_index_handle *handle, pgv_hnsw **out
         PGV_FAIL(PGV_ERR_ARG, "pgv_hnsw_import: the mirror lives on device %d, the context on %d", w.device, ctx->device);
     PGV_TRY(check_common((pgv_dtype)w.dtype, w.dim));
     PGV_TRY(check_metric((pgv_metric)w.metric));
-    if (w.n < 1 || w.m < 2 || w.m > 100 || w.entry < -1 || w.entry >= w.n || w.nbr_total < 0)
+    if (w.n < 1 || w.m < 2 || w.m > 100 || w.entry < -1 || w.entry >= w.n || w.nbr_total < 0 || w.payload_bytes < 0 ||
+        w.payload_bytes > 4096)
         PGV_FAIL(PGV_ERR_ARG, "pgv_hnsw_import: corrupt handle");
     PGV_HIP(hipSetDevice(ctx->device));
     pgv_hnsw *h = new (std::nothrow) pgv_hnsw();
@@ -2738,8 +2766,31 @@ int pgv_hnsw_import(pgv_ctx *ctx, const pgv_index_handle *handle, pgv_hnsw **out
     h->levels = reinterpret_cast<const int32_t *>(base);
     h->nbr_start = reinterpret_cast<const int64_t *>(base + lb);
     h->nbr = reinterpret_cast<int32_t *>(base + lb + sb);
+    h->payload_bytes = w.payload_bytes;
+    h->payload = w.payload_bytes > 0
+                     ? static_cast<char *>(h->elements) + hnsw_payload_offset(h->n, (size_t)h->geom.ld * elem_size(h->dtype))
+                     : nullptr;
     *out = h;
     return PGV_OK;
+}
+
+// the payload rows of the given element slots (a scan's results) -> host memory; slots < 0 give zero bytes
+int pgv_hnsw_get_payload(pgv_hnsw *h, const int64_t *elements, int n, void *out) {
+    if (!h || !out || (n > 0 && !elements)) PGV_FAIL(PGV_ERR_ARG, "pgv_hnsw_get_payload: handle/elements/out is NULL");
+    if (n < 0) PGV_FAIL(PGV_ERR_ARG, "n < 0");
+    if (h->payload_bytes <= 0) PGV_FAIL(PGV_ERR_STATE, "pgv_hnsw_get_payload: the mirror was uploaded without a payload");
+    if (n == 0) return PGV_OK;
+    pgv_ctx *ctx = h->ctx;
+    PGV_HIP(hipSetDevice(ctx->device));
+    const void *e_dev;
+    PGV_TRY(stage_flat(ctx, elements, sizeof(int64_t) * (size_t)n, ctx->idx_stage, &e_dev));
+    OutArg oo;
+    PGV_TRY(oo.init(out, (size_t)h->payload_bytes * (size_t)n, ctx->out_stage));
+    PGV_TRY(launch_gather_words(ctx, h->payload, h->payload_bytes / 4, h->n, static_cast<const int64_t *>(e_dev), n,
+                                oo.as<uint32_t>()));
+    bool need = false;
+    PGV_TRY(oo.finish(ctx, &need));
+    return sync_if(ctx, need);
 }
 
 int pgv_hnsw_score(pgv_hnsw *h, const void *queries, int nq, const int32_t *slot, const int32_t *query_of,

@@ -200,6 +200,8 @@ struct pgv_hnsw {
     size_t graph_bytes = 0;
     int64_t nbr_total = 0;
     bool imported = false;  // elements / graph were opened with hipIpcOpenMemHandle (a read-only view)
+    char *payload = nullptr;  // [n x payload_bytes] behind the elements, same allocation (pgv_hnsw_upload_payload)
+    int payload_bytes = 0;
 };
 
 namespace pgv {
@@ -299,6 +301,9 @@ int launch_mfma_scan(pgv_ctx *ctx, pgv_metric metric, pgv_dtype dtype, const Row
                      const void *queries, const ScanTask *tasks, const int *ntasks_dev, int ntasks_bound,
                      const ScanPair *pairs, const float *row_norms, const float *query_norms, float *out);
 
+// kernels_build.hip: rows of 32-bit words gathered by index (the HNSW mirror's per-element payload)
+int launch_gather_words(pgv_ctx *ctx, const void *src, int words_per_row, int64_t nrows, const int64_t *idx, int n,
+                        uint32_t *out);
 // kernels_build.hip: the build's tuplesort on the device (order by list, heap order inside; gather)
 size_t build_sort_scratch_bytes(int64_t n, int key_bits);
 int launch_build_order(pgv_ctx *ctx, const int32_t *lists, int64_t n, int nlists, unsigned long long *keys_tmp,

@@ -17,7 +17,8 @@ def main():
         h.set_graph(8, 0, np.zeros(1, np.int32), np.zeros(2, np.int64), np.zeros(1, np.int32))
     except api.PgvError as e:
         readonly = e.code
-    np.savez(sys.argv[2], elem=np.asarray(elem), dist=np.asarray(dist), readonly=readonly)
+    pay = h.get_payload(np.asarray(elem), words=int(job["words"])) if int(job["words"]) else np.zeros((0, 0), np.uint32)
+    np.savez(sys.argv[2], elem=np.asarray(elem), dist=np.asarray(dist), readonly=readonly, payload=pay)
     h.close()
     ctx.close()
 

@@ -137,7 +137,13 @@ def test_hnsw_mirror_across_processes(ctx, oracle, tmp_path, dtype):
         data = data.astype(np.float16)
     g = po.HnswGraph(oracle, po.OPS_L2, odt, data, m=m, ef_construction=40, seed=5)
     ex = g.export_tuples()
-    mirror = api.Hnsw(ctx, api.PGV_L2SQ, gdt, dim, data[ex["rows"]])
+    # per-element payload: what hnswgettuple needs of an element (src/hnswscan.c:293-311) -- here 10 heap TIDs' worth
+    # of words and a count, derived from the row so that the importing process can be checked
+    rows_of = np.asarray(ex["rows"], dtype=np.int64)
+    payload = np.zeros((len(rows_of), 21), dtype=np.uint32)
+    payload[:, 0] = 1 + (rows_of % 10)
+    payload[:, 1:] = (rows_of[:, None] * 31 + np.arange(20)[None, :]).astype(np.uint32)
+    mirror = api.Hnsw(ctx, api.PGV_L2SQ, gdt, dim, data[ex["rows"]], payload=payload)
     with pytest.raises(api.PgvError):  # nothing to search before the graph is set
         mirror.export()
     mirror.set_graph(m, ex["entry"], ex["levels"], ex["nbr_start"], ex["nbr"])
@@ -149,7 +155,7 @@ def test_hnsw_mirror_across_processes(ctx, oracle, tmp_path, dtype):
         api.Hnsw.from_handle(ctx, handle, gdt)
     assert e.value.code == api.PGV_ERR_STATE
     job, res = str(tmp_path / "job.npz"), str(tmp_path / "res.npz")
-    np.savez(job, handle=np.frombuffer(handle, dtype=np.uint8), queries=queries, dtype=gdt, ef=40, k=10)
+    np.savez(job, handle=np.frombuffer(handle, dtype=np.uint8), queries=queries, dtype=gdt, ef=40, k=10, words=21)
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     env = dict(os.environ, PYTHONPATH=root, HSA_ENABLE_IPC_MODE_LEGACY="0")
     r = subprocess.run([sys.executable, os.path.join(root, "tests", "mp_hnsw_import_worker.py"), job, res], env=env,
@@ -159,6 +165,11 @@ def test_hnsw_mirror_across_processes(ctx, oracle, tmp_path, dtype):
     assert int(out["readonly"]) == api.PGV_ERR_STATE  # an imported mirror is read-only
     own_elem, own_dist, _ = mirror.search(queries, 40, 10)
     assert out["elem"].tolist() == np.asarray(own_elem).tolist()
+    # the importer read the payload of its results out of the exporter's allocation: no table of its own
+    flat = out["elem"].ravel()
+    want = np.where(flat[:, None] >= 0, payload[np.clip(flat, 0, None)], 0)
+    assert out["payload"].tolist() == want.tolist()
+    assert mirror.get_payload(np.array([0, -1, 5])).tolist() == [payload[0].tolist(), [0] * 21, payload[5].tolist()]
     for i, q in enumerate(queries):
         rows, wd, _ = g.search(q, 40, 10)
         el = out["elem"][i]
