@@ -159,6 +159,26 @@ def build_index(ctx, data, lists, seed, world, rank, dtype, ops, metric, comm=No
     torch.cuda.synchronize()
     t["kmeans"] = time.perf_counter() - t0
     t1 = time.perf_counter()
+    if world == 1:
+        # the product's own build: rows assigned where they are kept, the sort by list a device gather whose result
+        # IS the mirror (pgv_builder_*); TIDs = heap positions
+        b = api.IvfBuilder(ctx, metric, dtype, dim, centers, expected_rows=n)
+        b.add(data)
+        ctx.sync()
+        torch.cuda.synchronize()
+        t["assign"] = time.perf_counter() - t1
+        t2 = time.perf_counter()
+        index, offsets_h, lists_h = b.finish(want_lists=True)
+        ctx.sync()
+        torch.cuda.synchronize()
+        t["layout"] = time.perf_counter() - t2
+        t["total"] = time.perf_counter() - t0
+        b.close()
+        # the harness's own copy of the same layout (float64 ground truth, the oracle's arrays): not part of the build
+        lists64 = torch.from_numpy(lists_h.astype(np.int64)).to(data.device)
+        order = torch.argsort(lists64, stable=True)
+        offsets = torch.from_numpy(offsets_h).to(data.device)
+        return centers, offsets, data[order], order, iters, t, index
     local_lists, _ = api.assign(ctx, metric, dtype, dim, centers, data, want_dist=False)
     ctx.sync()
     torch.cuda.synchronize()
@@ -167,9 +187,10 @@ def build_index(ctx, data, lists, seed, world, rank, dtype, ops, metric, comm=No
     row_ids = torch.arange(row_lo, row_lo + n, dtype=torch.int64, device=data.device)
     vectors, tids, offsets = sharding.exchange_rows(data, row_ids, local_lists, lists)
     torch.cuda.synchronize()
-    t["layout"] = time.perf_counter() - t2   # N > 1: includes the all-to-all of the rows
+    t["layout"] = time.perf_counter() - t2   # includes the all-to-all of the rows
     t["total"] = time.perf_counter() - t0
-    return centers, offsets, vectors, tids, iters, t
+    index = api.IvfIndex(ctx, metric, dtype, dim, centers, offsets, vectors, tids.view(torch.int64))
+    return centers, offsets, vectors, tids, iters, t, index
 
 
 def exact_topk_fp64(vectors, queries, k, metric):
@@ -616,9 +637,8 @@ def run_workload(ctx, dev, name, args, failures, steps=10, parity_queries=32):
     components = max(lists // 4, 1)
     data, means = gen_mixture(n, dim, components, 0.1, args.seed + 50, dev)
     data = data.to(tdtype)
-    centers, offsets, vectors, tids, iters, build_t = build_index(ctx, data, lists, args.seed, 1, 0, dtype, ops, metric)
+    centers, offsets, vectors, tids, iters, build_t, index = build_index(ctx, data, lists, args.seed, 1, 0, dtype, ops, metric)
     del data
-    index = api.IvfIndex(ctx, metric, dtype, dim, centers, offsets, vectors, tids.view(torch.int64))
     queries, _ = gen_mixture(batch * pool, dim, components, 0.1, args.seed + 150, dev, means=means)
     queries = queries.to(tdtype).view(pool, batch, dim)
     od = torch.empty((batch, k), device=dev, dtype=torch.float32)
@@ -813,12 +833,11 @@ def main():
     log("data: rows [%d, %d) of %d x %d %s generated" % (row_lo, row_hi, n, dim, tname))
     ctx.set_profiling(True)
     ctx.reset_stats()
-    centers, offsets, vectors, tids, iters, build_t = build_index(ctx, data, lists, args.seed, world, rank,
-                                                                  dtype, ops, metric, comm, row_lo=row_lo, n_global=n)
+    centers, offsets, vectors, tids, iters, build_t, index = build_index(ctx, data, lists, args.seed, world, rank,
+                                                                         dtype, ops, metric, comm, row_lo=row_lo, n_global=n)
     build_stats = ctx.stats()
     ctx.set_profiling(False)
     log("build: %s (k-means iterations %d)" % ({a: round(b, 3) for a, b in build_t.items()}, iters))
-    index = api.IvfIndex(ctx, metric, dtype, dim, centers, offsets, vectors, tids.view(torch.int64))
     local_rows = int(vectors.shape[0])
     do_pages = rank == 0 and world == 1 and not args.no_sweeps
     host_rows = data.cpu().numpy() if do_pages else None
@@ -1163,9 +1182,8 @@ def main():
     if single and not args.no_sweeps:
         try:
             udata = gen_uniform(n, dim, args.seed + 7, dev).to(tdtype)
-            uc, uo, uv, ut, uit, ubt = build_index(ctx, udata, lists, args.seed, 1, 0, dtype, ops, metric)
+            uc, uo, uv, ut, uit, ubt, uix = build_index(ctx, udata, lists, args.seed, 1, 0, dtype, ops, metric)
             del udata
-            uix = api.IvfIndex(ctx, metric, dtype, dim, uc, uo, uv, ut.view(torch.int64))
             uq = gen_uniform(total_batch, dim, args.seed + 8, dev).to(tdtype)
             ued, _ = exact_topk_fp64(uv, uq[:rq], k, metric)
             ures = {}
