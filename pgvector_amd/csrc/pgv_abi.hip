@@ -306,10 +306,13 @@ int dense_scan(pgv_ctx *ctx, pgv_metric metric, pgv_dtype dtype, const RowGeom &
     if (ntasks > 0x7fffffff) PGV_FAIL(PGV_ERR_ARG, "scan: too many tasks");
 
     const size_t tb = sizeof(ScanTask) * (size_t)ntasks, pb = sizeof(ScanPair) * (size_t)nq;
-    // the MFMA plan depends on (rows, queries, stride) only: a batch loop repeats it, so it stays on the device
-    DBuf &plan_buf = mfma ? ctx->dense_plan : ctx->tasks;
-    const bool cached = mfma && ctx->dense_plan.p && ctx->dense_plan_rows == nrows && ctx->dense_plan_nq == nq &&
-                        ctx->dense_plan_stride == out_stride;
+    // a dense plan depends on (rows, queries, stride, rows per task, queries per task) only: a batch loop repeats it
+    // (the center ranking of every batch; the 999 rounds of a k-means++ seeding, where re-planning cost a host-built
+    // table, a copy-engine transfer and an event wait per round), so the last one stays on the device
+    DBuf &plan_buf = ctx->dense_plan;
+    const int plan_kind = (mfma ? 1 << 30 : 0) | (use_tile ? 1 << 29 : 0) | (qt << 12) | ch;
+    const bool cached = ctx->dense_plan.p && ctx->dense_plan_rows == nrows && ctx->dense_plan_nq == nq &&
+                        ctx->dense_plan_stride == out_stride && ctx->dense_plan_kind == plan_kind;
     if (!cached) {
         PGV_TRY(staging_acquire(ctx));
         PGV_TRY(ctx->h_a.ensure(tb + pb + 16));
@@ -334,15 +337,14 @@ int dense_scan(pgv_ctx *ctx, pgv_metric metric, pgv_dtype dtype, const RowGeom &
                 t++;
             }
         *hn = (int)ntasks;
-        if (mfma) ctx->dense_plan_rows = -1;  // (not valid while it is being replaced)
+        ctx->dense_plan_rows = -1;  // (not valid while it is being replaced)
         PGV_TRY(plan_buf.ensure(tb + pb + 16));
         PGV_HIP(hipMemcpyAsync(plan_buf.p, ht, tb + pb + 16, hipMemcpyHostToDevice, ctx->stream));
         PGV_TRY(staging_release(ctx));
-        if (mfma) {
-            ctx->dense_plan_rows = nrows;
-            ctx->dense_plan_nq = nq;
-            ctx->dense_plan_stride = out_stride;
-        }
+        ctx->dense_plan_rows = nrows;
+        ctx->dense_plan_nq = nq;
+        ctx->dense_plan_stride = out_stride;
+        ctx->dense_plan_kind = plan_kind;
     }
     const ScanTask *dt = plan_buf.as<ScanTask>();
     const ScanPair *dp = reinterpret_cast<const ScanPair *>(plan_buf.as<char>() + tb);

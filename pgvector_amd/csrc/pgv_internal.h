@@ -110,7 +110,7 @@ struct pgv_ctx {
     pgv::DBuf ms_b;  // MFMA center ranking: the same scratch as ms_a
     pgv::DBuf dense_plan;  // the last dense (every row x every query) MFMA task list, reused while its shape repeats
     int64_t dense_plan_rows = -1, dense_plan_stride = -1;
-    int dense_plan_nq = -1;
+    int dense_plan_nq = -1, dense_plan_kind = -1;
     bool counters_clean = false;  // ctx->counters starts zeroed; mfma_scan_kernel leaves its words zero again
     pgv::DBuf ms_a;  // MFMA list scan: query norms | candidate values, positions, slots | flags
     pgv::DBuf mf_d;  // MFMA assignment split over center parts: the parts' candidates per row
