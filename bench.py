@@ -1099,12 +1099,13 @@ def main():
             prec = recall_at_k(gd, exact_d, k)
             line["build_secs_pages"] = t_build
             line["build_pages"] = {
-                "path": "pgv_host_ivf_build_mirror: host rows -> k-means on the GPU -> rows to the device + assignment "
-                        "(pgv_builder_add) -> order by list on the device = the mirror (pgv_builder_finish) -> 8 KB pages "
+                "path": "pgv_host_ivf_build_mirror: host rows -> k-means on the GPU (helper thread) WHILE the rows go to the "
+                        "device (pgv_builder_add without centers: copies on the builder's stream) -> assignment of all rows + "
+                        "order by list on the device = the mirror (pgv_builder_set_centers / _finish) -> 8 KB pages "
                         "written from the mirror's rows as they come back (pgv_index_drain), page array zeroed in the "
                         "background meanwhile; no host sort, no staging pass, no second upload",
                 "build_secs": t_build, "sample_secs": t_sample,
-                "build_phases_secs": dict(zip(("normalise", "kmeans", "to_device_and_assign", "order_by_list_on_device",
+                "build_phases_secs": dict(zip(("normalise", "kmeans_left_after_upload", "upload_beside_kmeans", "assign_and_order_by_list_on_device",
                                                "page_writer"), [float(x) for x in ph])),
                 "mirror_from_pages_secs": {"stage": t_stage, "upload": t_upload,
                                            "note": "what a backend pays that finds the index on disk (not part of the build)"},

@@ -456,7 +456,11 @@ int			pgv_search_batch_sharded(pgv_comm * comm, pgv_index * local_index, const v
  * :606-615); InsertTuples (:271-331) then walks the sorted stream list by list into pages.  With the rows in HBM
  * anyway (pgv_assign staged them), the sort is a device gather and its result IS the device mirror:
  *
- *   pgv_builder_begin   centers of the index (after IvfflatKmeans); expected_rows sizes the first allocation
+ *   pgv_builder_begin   centers of the index (after IvfflatKmeans); expected_rows sizes the first allocation.
+ *                       centers == NULL: they come later -- until pgv_builder_set_centers, pgv_builder_add only copies
+ *                       its rows to the device, on a stream of the builder's own, so that the upload of the heap and a
+ *                       pgv_kmeans still running on the context (called from another host thread) overlap; the rows
+ *                       are assigned in one piece once the centers are there
  *   pgv_builder_add     a batch of heap rows (host or device, tightly packed) with their TIDs (or NULL: heap
  *                       positions): copied to the device, assigned there (same kernel as pgv_assign), kept in heap order
  *   pgv_builder_finish  list-major order (ascending list, heap order inside a list -- what the tuplesort delivers
@@ -471,6 +475,8 @@ typedef struct pgv_builder pgv_builder;
 int			pgv_builder_begin(pgv_ctx * ctx, pgv_metric metric, pgv_dtype dtype, int dim, int nlists, const void *centers,
 							  int64_t expected_rows, pgv_builder * *out);
 int			pgv_builder_add(pgv_builder * b, const void *rows, const uint64_t *tids, int64_t n);
+/* the centers of a builder begun without them (PGV_ERR_STATE otherwise); called once, before pgv_builder_finish */
+int			pgv_builder_set_centers(pgv_builder * b, const void *centers);
 int64_t		pgv_builder_rows(const pgv_builder * b);
 int			pgv_builder_finish(pgv_builder * b, pgv_index * *out_index, int64_t *out_offsets, int32_t *out_lists);
 void		pgv_builder_free(pgv_builder * b);

@@ -44,7 +44,7 @@ SYMBOLS = [
     "pgv_comm_rank", "pgv_kmeans_sharded", "pgv_search_batch_sharded",
     "pgv_device_memory", "pgv_pinned_register", "pgv_pinned_unregister", "pgv_index_export", "pgv_index_import",
     "pgv_index_tids", "pgv_hnsw_export", "pgv_hnsw_import", "pgv_exact_topk", "pgv_ctx_set_bound",
-    "pgv_hnsw_upload_payload", "pgv_hnsw_get_payload", "pgv_builder_begin", "pgv_builder_add", "pgv_builder_rows", "pgv_builder_finish", "pgv_builder_free", "pgv_index_drain",
+    "pgv_hnsw_upload_payload", "pgv_hnsw_get_payload", "pgv_builder_begin", "pgv_builder_add", "pgv_builder_set_centers", "pgv_builder_rows", "pgv_builder_finish", "pgv_builder_free", "pgv_index_drain",
 ]
 
 
@@ -116,6 +116,7 @@ def _load():
     lib.pgv_ctx_set_bound.argtypes = [P, I]
     lib.pgv_builder_begin.argtypes = [P, I, I, I, I, P, I64, C.POINTER(P)]
     lib.pgv_builder_add.argtypes = [P, P, P, I64]
+    lib.pgv_builder_set_centers.argtypes = [P, P]
     lib.pgv_builder_rows.argtypes = [P]
     lib.pgv_builder_rows.restype = I64
     lib.pgv_builder_finish.argtypes = [P, C.POINTER(P), P, P]

@@ -515,13 +515,22 @@ class IvfBuilder:
     """pgv_builder_*: heap rows assigned and kept on the device, finish() = the tuplesort by list as a device gather
     whose result is the mirror itself"""
 
-    def __init__(self, ctx, metric, dtype, dim, centers, expected_rows=0):
+    def __init__(self, ctx, metric, dtype, dim, centers, expected_rows=0, nlists=None):
+        """centers None (and nlists given): they come with set_centers(); add() only uploads until then"""
         self.ctx, self.metric, self.dtype, self.dim = ctx, metric, dtype, dim
-        centers = as_dtype(centers, dtype)
-        self.nlists = int(centers.shape[0])
+        if centers is not None:
+            centers = as_dtype(centers, dtype)
+            nlists = int(centers.shape[0])
+        self.nlists = int(nlists)
         h = C.c_void_p()
         check(lib.pgv_builder_begin(ctx.h, metric, dtype, dim, self.nlists, ptr(centers), int(expected_rows), C.byref(h)))
         self.h = h
+
+    def set_centers(self, centers):
+        centers = as_dtype(centers, self.dtype)
+        if int(centers.shape[0]) != self.nlists:
+            raise ValueError("set_centers: %d centers for %d lists" % (centers.shape[0], self.nlists))
+        check(lib.pgv_builder_set_centers(self.h, ptr(centers)))
 
     def add(self, rows, tids=None):
         rows = as_dtype(rows, self.dtype)

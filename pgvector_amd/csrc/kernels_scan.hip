@@ -58,7 +58,15 @@ __global__ __launch_bounds__(THREADS, scan_min_waves(QT, R)) void scan_kernel(
         if (threadIdx.x == 0) *lds_task = atomicAdd(task_counter, 1);
         __syncthreads();
         const int t = *lds_task;
-        if (t >= ntasks) return;
+        if (t >= ntasks) {
+            // every workgroup ends here exactly once; the last one leaves both words zero for the next launch
+            // (no memset launch per scan: k-means++ issues one scan per center)
+            if (threadIdx.x == 0 && atomicAdd(task_counter + 1, 1) == (int)gridDim.x - 1) {
+                atomicExch(task_counter + 1, 0);
+                atomicExch(task_counter, 0);
+            }
+            return;
+        }
         const ScanTask task = tasks[t];
 
         // stage this task's queries (L2-resident) into LDS
@@ -218,8 +226,11 @@ int launch_scan_t(pgv_ctx *ctx, const RowGeom &g, const void *rows, const void *
                   const ScanPair *pairs, float *out) {
     if (ntasks_bound <= 0) return PGV_OK;
     PGV_TRY(ctx->counters.ensure(256));
-    int *counter = ctx->counters.as<int>();
-    PGV_HIP(hipMemsetAsync(counter, 0, sizeof(int), ctx->stream));
+    if (!ctx->counters_clean) {
+        PGV_HIP(hipMemsetAsync(ctx->counters.p, 0, 256, ctx->stream));
+        ctx->counters_clean = true;
+    }
+    int *counter = ctx->counters.as<int>() + 10;  // words 10, 11: claimed tasks, workgroups done (the kernel re-zeroes them)
     size_t lds = (size_t)QT * g.nvec * sizeof(Raw16) + QT * sizeof(int64_t) + 16;
     // enough resident workgroups to cover HBM latency, never more than there is work
     int per_cu = (int)(160 * 1024 / (lds + 256));

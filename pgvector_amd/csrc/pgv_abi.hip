@@ -718,19 +718,23 @@ int index_create(pgv_ctx *ctx, pgv_metric metric, pgv_dtype dtype, int dim, int 
 }
 
 // tightly packed rows (host or device) into padded device rows
-int put_rows(pgv_ctx *ctx, const RowGeom &g, pgv_dtype dtype, int dim, void *dst, const void *src, int64_t rows) {
+int put_rows_on(hipStream_t stream, const RowGeom &g, pgv_dtype dtype, int dim, void *dst, const void *src, int64_t rows) {
     if (rows == 0) return PGV_OK;
     const size_t es = elem_size(dtype), row_bytes = (size_t)g.ld * es;
     const bool dev = is_device_ptr(src);
     if (g.ld == dim) {
         PGV_HIP(hipMemcpyAsync(dst, src, (size_t)rows * row_bytes, dev ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice,
-                               ctx->stream));
+                               stream));
     } else {
-        PGV_HIP(hipMemsetAsync(dst, 0, (size_t)rows * row_bytes, ctx->stream));
+        PGV_HIP(hipMemsetAsync(dst, 0, (size_t)rows * row_bytes, stream));
         PGV_HIP(hipMemcpy2DAsync(dst, row_bytes, src, (size_t)dim * es, (size_t)dim * es, (size_t)rows,
-                                 dev ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, ctx->stream));
+                                 dev ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, stream));
     }
     return PGV_OK;
+}
+
+int put_rows(pgv_ctx *ctx, const RowGeom &g, pgv_dtype dtype, int dim, void *dst, const void *src, int64_t rows) {
+    return put_rows_on(ctx->stream, g, dtype, dim, dst, src, rows);
 }
 
 }  // namespace
@@ -781,12 +785,18 @@ struct pgv_builder {
     DBuf tids;     // [cap]
     DBuf lists;    // [cap] int32
     int64_t n = 0, cap = 0;
+    int64_t assigned = 0;  // rows [0, assigned) have their list id
     bool has_tids = true;
+    // centers not known yet (pgv_builder_begin with centers == NULL): rows are only copied, on a stream of the
+    // builder's own, so that the k-means which is still computing the centers on the context's stream (from another
+    // host thread) and the upload of the heap overlap; pgv_builder_set_centers ends this state
+    bool deferred = false;
+    hipStream_t copy_stream = nullptr;
+    hipStream_t stream() const { return deferred ? copy_stream : ctx->stream; }
 };
 
 static int builder_reserve(pgv_builder *b, int64_t want) {
     if (want <= b->cap) return PGV_OK;
-    pgv_ctx *ctx = b->ctx;
     int64_t cap = b->cap ? b->cap + b->cap / 2 : want;
     if (cap < want) cap = want;
     const size_t row_bytes = (size_t)b->geom.ld * elem_size(b->dtype);
@@ -795,10 +805,10 @@ static int builder_reserve(pgv_builder *b, int64_t want) {
     int rc = tids.ensure(sizeof(uint64_t) * (size_t)cap);
     if (rc == PGV_OK) rc = lists.ensure(sizeof(int32_t) * (size_t)cap);
     if (rc == PGV_OK && b->n > 0) {
-        hipError_t e = hipMemcpyAsync(rows.p, b->rows.p, row_bytes * (size_t)b->n, hipMemcpyDeviceToDevice, ctx->stream);
-        if (e == hipSuccess) e = hipMemcpyAsync(tids.p, b->tids.p, sizeof(uint64_t) * (size_t)b->n, hipMemcpyDeviceToDevice, ctx->stream);
-        if (e == hipSuccess) e = hipMemcpyAsync(lists.p, b->lists.p, sizeof(int32_t) * (size_t)b->n, hipMemcpyDeviceToDevice, ctx->stream);
-        if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+        hipError_t e = hipMemcpyAsync(rows.p, b->rows.p, row_bytes * (size_t)b->n, hipMemcpyDeviceToDevice, b->stream());
+        if (e == hipSuccess) e = hipMemcpyAsync(tids.p, b->tids.p, sizeof(uint64_t) * (size_t)b->n, hipMemcpyDeviceToDevice, b->stream());
+        if (e == hipSuccess) e = hipMemcpyAsync(lists.p, b->lists.p, sizeof(int32_t) * (size_t)b->n, hipMemcpyDeviceToDevice, b->stream());
+        if (e == hipSuccess) e = hipStreamSynchronize(b->stream());
         if (e != hipSuccess) {
             set_error("growing the builder failed: %s", hipGetErrorString(e));
             rc = PGV_ERR_DEVICE;
@@ -820,6 +830,16 @@ static int builder_reserve(pgv_builder *b, int64_t want) {
     return PGV_OK;
 }
 
+// rows [assigned, n) to their nearest center
+static int builder_assign_pending(pgv_builder *b) {
+    if (b->assigned >= b->n) return PGV_OK;
+    const size_t row_bytes = (size_t)b->geom.ld * elem_size(b->dtype);
+    PGV_TRY(launch_argmin(b->ctx, b->metric, b->dtype, b->geom, b->rows.as<char>() + (size_t)b->assigned * row_bytes,
+                          b->n - b->assigned, b->centers.p, b->nlists, b->lists.as<int32_t>() + b->assigned, nullptr));
+    b->assigned = b->n;
+    return PGV_OK;
+}
+
 int pgv_builder_begin(pgv_ctx *ctx, pgv_metric metric, pgv_dtype dtype, int dim, int nlists, const void *centers,
                       int64_t expected_rows, pgv_builder **out) {
     if (!ctx || !out) PGV_FAIL(PGV_ERR_ARG, "pgv_builder_begin: ctx/out is NULL");
@@ -827,7 +847,6 @@ int pgv_builder_begin(pgv_ctx *ctx, pgv_metric metric, pgv_dtype dtype, int dim,
     PGV_TRY(check_common(dtype, dim));
     PGV_TRY(check_metric(metric));
     if (nlists < 1 || nlists > 32768) PGV_FAIL(PGV_ERR_ARG, "lists %d outside 1..32768", nlists);
-    if (!centers) PGV_FAIL(PGV_ERR_ARG, "centers is NULL");
     if (expected_rows < 0) PGV_FAIL(PGV_ERR_ARG, "expected_rows < 0");
     PGV_HIP(hipSetDevice(ctx->device));
     pgv_builder *b = new (std::nothrow) pgv_builder();
@@ -839,8 +858,16 @@ int pgv_builder_begin(pgv_ctx *ctx, pgv_metric metric, pgv_dtype dtype, int dim,
     b->nlists = nlists;
     b->geom = row_geom(dim, dtype);
     int rc = b->centers.ensure((size_t)b->geom.ld * elem_size(dtype) * (size_t)nlists);
-    if (rc == PGV_OK) rc = put_rows(ctx, b->geom, dtype, dim, b->centers.p, centers, nlists);
-    if (rc == PGV_OK && hipStreamSynchronize(ctx->stream) != hipSuccess) rc = PGV_ERR_DEVICE;  // the caller may reuse centers
+    if (rc == PGV_OK && centers) {
+        rc = put_rows(ctx, b->geom, dtype, dim, b->centers.p, centers, nlists);
+        if (rc == PGV_OK && hipStreamSynchronize(ctx->stream) != hipSuccess) rc = PGV_ERR_DEVICE;  // the caller may reuse centers
+    } else if (rc == PGV_OK) {
+        b->deferred = true;
+        if (hipStreamCreateWithFlags(&b->copy_stream, hipStreamNonBlocking) != hipSuccess) {
+            set_error("pgv_builder_begin: no stream for the upload");
+            rc = PGV_ERR_DEVICE;
+        }
+    }
     if (rc == PGV_OK && expected_rows > 0) rc = builder_reserve(b, expected_rows);
     if (rc != PGV_OK) {
         pgv_builder_free(b);
@@ -852,6 +879,10 @@ int pgv_builder_begin(pgv_ctx *ctx, pgv_metric metric, pgv_dtype dtype, int dim,
 
 void pgv_builder_free(pgv_builder *b) {
     if (!b) return;
+    if (b->copy_stream) {
+        (void)hipStreamSynchronize(b->copy_stream);
+        (void)hipStreamDestroy(b->copy_stream);
+    }
     if (b->ctx) (void)hipStreamSynchronize(b->ctx->stream);
     b->centers.release();
     b->rows.release();
@@ -875,16 +906,30 @@ int pgv_builder_add(pgv_builder *b, const void *rows, const uint64_t *tids, int6
     b->has_tids = tids != nullptr;
     const size_t row_bytes = (size_t)b->geom.ld * elem_size(b->dtype);
     char *dst = b->rows.as<char>() + (size_t)b->n * row_bytes;
-    PGV_TRY(put_rows(ctx, b->geom, b->dtype, b->dim, dst, rows, n));
+    hipStream_t stream = b->stream();
+    PGV_TRY(put_rows_on(stream, b->geom, b->dtype, b->dim, dst, rows, n));
     if (tids)
         PGV_HIP(hipMemcpyAsync(b->tids.as<uint64_t>() + b->n, tids, sizeof(uint64_t) * (size_t)n,
-                               is_device_ptr(tids) ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, ctx->stream));
-    // AddTupleToSort's argmin (src/ivfbuild.c:183-192) for this batch, where the rows now are
-    PGV_TRY(launch_argmin(ctx, b->metric, b->dtype, b->geom, dst, n, b->centers.p, b->nlists, b->lists.as<int32_t>() + b->n,
-                          nullptr));
+                               is_device_ptr(tids) ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, stream));
     b->n += n;
-    // host buffers may be reused by the caller right away
-    if (!is_device_ptr(rows) || (tids && !is_device_ptr(tids))) PGV_HIP(hipStreamSynchronize(ctx->stream));
+    // AddTupleToSort's argmin (src/ivfbuild.c:183-192) for this batch (and what an earlier centerless phase left),
+    // where the rows now are
+    if (!b->deferred) PGV_TRY(builder_assign_pending(b));
+    // host buffers may be reused by the caller right away; device rows must have arrived before the caller's stream
+    // moves on
+    if (b->deferred || !is_device_ptr(rows) || (tids && !is_device_ptr(tids))) PGV_HIP(hipStreamSynchronize(stream));
+    return PGV_OK;
+}
+
+int pgv_builder_set_centers(pgv_builder *b, const void *centers) {
+    if (!b || !centers) PGV_FAIL(PGV_ERR_ARG, "pgv_builder_set_centers: builder/centers is NULL");
+    if (!b->deferred) PGV_FAIL(PGV_ERR_STATE, "pgv_builder_set_centers: the builder has its centers");
+    pgv_ctx *ctx = b->ctx;
+    PGV_HIP(hipSetDevice(ctx->device));
+    PGV_HIP(hipStreamSynchronize(b->copy_stream));  // every row has arrived; from here on the context's stream is used
+    b->deferred = false;
+    PGV_TRY(put_rows(ctx, b->geom, b->dtype, b->dim, b->centers.p, centers, b->nlists));
+    PGV_HIP(hipStreamSynchronize(ctx->stream));
     return PGV_OK;
 }
 
@@ -893,6 +938,8 @@ int pgv_builder_finish(pgv_builder *b, pgv_index **out_index, int64_t *out_offse
     *out_index = nullptr;
     pgv_ctx *ctx = b->ctx;
     PGV_HIP(hipSetDevice(ctx->device));
+    if (b->deferred) PGV_FAIL(PGV_ERR_STATE, "pgv_builder_finish: no centers (pgv_builder_set_centers)");
+    PGV_TRY(builder_assign_pending(b));
     const int64_t n = b->n;
     const int nlists = b->nlists;
     int list_bits = 1;
@@ -947,7 +994,7 @@ int pgv_builder_finish(pgv_builder *b, pgv_index **out_index, int64_t *out_offse
     b->rows.release();
     b->tids.release();
     b->lists.release();
-    b->n = b->cap = 0;
+    b->n = b->cap = b->assigned = 0;
     return PGV_OK;
 }
 
@@ -960,7 +1007,9 @@ int pgv_index_drain(pgv_index *ix, int64_t chunk_rows, pgv_rows_sink sink, void 
     const int64_t n = ix->nrows;
     if (n == 0) return PGV_OK;
     const size_t es = elem_size(ix->dtype), tight = (size_t)ix->dim * es, padded = (size_t)ix->geom.ld * es;
-    if (chunk_rows <= 0) chunk_rows = (int64_t)std::max<size_t>(1, ((size_t)256 << 20) / tight);
+    // 64 MB pieces: long enough for the link's full rate, short enough that pinning the two bounce buffers (which
+    // costs ~30 ms at 2 x 256 MB) does not show
+    if (chunk_rows <= 0) chunk_rows = (int64_t)std::max<size_t>(1, ((size_t)64 << 20) / tight);
     if (chunk_rows > n) chunk_rows = n;
     void *buf[2] = {nullptr, nullptr};
     hipEvent_t ev[2] = {nullptr, nullptr};

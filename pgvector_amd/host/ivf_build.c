@@ -6,6 +6,8 @@
 #include "pgv_host.h"
 
 #include <math.h>
+#include <pthread.h>
+#include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
 #include <time.h>
@@ -80,6 +82,34 @@ write_rows(void *arg, int64_t first_slot, int64_t count, const void *vectors, co
 	drain_sink *s = arg;
 
 	return pgv_host_ivf_writer_fill(s->writer, first_slot, count, vectors, tids) == PGV_OK ? 0 : 1;
+}
+
+/* pgv_kmeans on a thread of its own; the library's last error is per thread, so it is carried out by hand */
+typedef struct kmeans_job
+{
+	pgv_ctx    *ctx;
+	pgv_ops		ops;
+	pgv_dtype	dtype;
+	int			dim;
+	const void *samples;
+	int			nsamples;
+	int			lists;
+	const pgv_rng *rng;
+	void	   *centers;
+	int			rc;
+	char		err[256];
+}			kmeans_job;
+
+static void *
+kmeans_main(void *arg)
+{
+	kmeans_job *job = arg;
+
+	job->rc = pgv_kmeans(job->ctx, job->ops, job->dtype, job->dim, job->samples, job->nsamples, job->lists, 500, job->rng,
+						 job->centers, NULL, NULL);
+	if (job->rc != PGV_OK)
+		snprintf(job->err, sizeof(job->err), "%s", pgv_last_error());
+	return NULL;
 }
 
 int
@@ -161,32 +191,53 @@ pgv_host_ivf_build_mirror(pgv_ctx * ctx, pgv_ops ops, pgv_dtype dtype, int dim, 
 	if (rc != PGV_OK)
 		goto out;
 
-	/* ComputeCenters, src/ivfbuild.c:434-480 */
-	rc = pgv_kmeans(ctx, ops, dtype, dim, samples, nsamples, lists, 500, rng, centers, NULL, NULL);
-	if (rc != PGV_OK)
+	/*
+	 * ComputeCenters (src/ivfbuild.c:434-480) on a helper thread, and meanwhile the second pass over the heap: every
+	 * row to the device in callback-sized batches (a builder begun without centers only copies, on a stream of its
+	 * own).  The two overlap: k-means keeps the compute units busy, the upload the PCIe link.
+	 */
 	{
-		pgv_host_fail(rc, "%s", pgv_last_error());
-		goto out;
-	}
-	t1 = now_secs();
-	build_phase_secs[1] = t1 - t0;
-	t0 = t1;
-	/* AssignTuples: every heap row to the device and to its nearest center, in callback-sized batches */
-	rc = pgv_builder_begin(ctx, metric, dtype, dim, lists, centers, n, &builder);
-	for (int64_t r0 = 0; r0 < n && rc == PGV_OK; r0 += ASSIGN_BATCH)
-	{
-		int64_t		cnt = n - r0 < ASSIGN_BATCH ? n - r0 : ASSIGN_BATCH;
+		kmeans_job	job = {ctx, ops, dtype, dim, samples, nsamples, lists, rng, centers, PGV_OK, {0}};
+		pthread_t	th;
+		int			threaded;
 
-		rc = pgv_builder_add(builder, (const char *) rows + (size_t) r0 * row_bytes, tids + r0, cnt);
+		rc = pgv_builder_begin(ctx, metric, dtype, dim, lists, NULL, n, &builder);
+		if (rc != PGV_OK)
+		{
+			pgv_host_fail(rc, "%s", pgv_last_error());
+			goto out;
+		}
+		threaded = pthread_create(&th, NULL, kmeans_main, &job) == 0;
+		if (!threaded)
+			kmeans_main(&job);
+		for (int64_t r0 = 0; r0 < n && rc == PGV_OK; r0 += ASSIGN_BATCH)
+		{
+			int64_t		cnt = n - r0 < ASSIGN_BATCH ? n - r0 : ASSIGN_BATCH;
+
+			rc = pgv_builder_add(builder, (const char *) rows + (size_t) r0 * row_bytes, tids + r0, cnt);
+		}
+		if (rc != PGV_OK)
+			pgv_host_fail(rc, "%s", pgv_last_error());
+		t1 = now_secs();
+		build_phase_secs[2] = t1 - t0;	/* the upload (k-means running beside it) */
+		t0 = t1;
+		if (threaded)
+			pthread_join(th, NULL);
+		if (rc == PGV_OK && job.rc != PGV_OK)
+			rc = pgv_host_fail(job.rc, "%s", job.err);
+		if (rc != PGV_OK)
+			goto out;
+		t1 = now_secs();
+		build_phase_secs[1] = t1 - t0;	/* what of k-means was left when the upload had finished */
+		t0 = t1;
 	}
+	/* AssignTuples: every row to its nearest center, where it now is (with the next call) */
+	rc = pgv_builder_set_centers(builder, centers);
 	if (rc != PGV_OK)
 	{
 		pgv_host_fail(rc, "%s", pgv_last_error());
 		goto out;
 	}
-	t1 = now_secs();
-	build_phase_secs[2] = t1 - t0;
-	t0 = t1;
 	/* tuplesort on the list id (src/ivfbuild.c:606-615), heap order kept inside a list: a gather on the device,
 	 * whose result is the mirror */
 	rc = pgv_builder_finish(builder, &index, offsets, NULL);

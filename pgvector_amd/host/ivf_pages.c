@@ -19,6 +19,7 @@
 extern int	pgv_host_fail(int code, const char *fmt,...);
 
 #include <sys/mman.h>
+#include <time.h>
 
 /*
  * Gigabytes that are about to be written once (the page image, the rows sorted by list): 2 MB-aligned and
@@ -376,12 +377,29 @@ prefault_main(void *arg)
 	return NULL;
 }
 
+static double writer_wait_secs;
+
+/* how long the last writer's layout step waited for the background zeroing of the page array (diagnostics) */
+double
+pgv_host_ivf_writer_wait_secs(void)
+{
+	return writer_wait_secs;
+}
+
 static void
 writer_join(pgv_ivf_writer * w)
 {
 	if (!w->joined)
+	{
+		struct timespec a,
+					b;
+
+		clock_gettime(CLOCK_MONOTONIC, &a);
 		for (int t = 0; t < w->nthreads; t++)
 			pthread_join(w->threads[t], NULL);
+		clock_gettime(CLOCK_MONOTONIC, &b);
+		writer_wait_secs = (double) (b.tv_sec - a.tv_sec) + 1e-9 * (double) (b.tv_nsec - a.tv_nsec);
+	}
 	w->joined = 1;
 }
 
@@ -620,10 +638,8 @@ pgv_host_ivf_writer_fill(pgv_ivf_writer * w, int64_t first_slot, int64_t count, 
 							 (long long) (first_slot + count), (long long) n);
 #pragma omp parallel num_threads(pgv_host_threads())
 	{
-		uint8_t		tuple[PGV_BLCKSZ];
 		int			l = 0;
 
-		memset(tuple, 0, sizeof(tuple));
 #pragma omp for schedule(static)
 		for (int64_t r = 0; r < count; r++)
 		{
@@ -655,8 +671,11 @@ pgv_host_ivf_writer_fill(pgv_ivf_writer * w, int64_t first_slot, int64_t count, 
 			in_list = slot - w->offsets[l];
 			page = page_at(rel, w->first_blk[l] + (uint32_t) (in_list / w->per_page));
 			j = (int) (in_list % w->per_page);
-			sz = form_index_tuple(tuple, w->dtype, w->dim, (const char *) vectors + (size_t) r * row_bytes, tids ? tids[r] : 0);
-			memcpy(page + (PGV_BLCKSZ - SPECIAL_SIZE) - (size_t) (j + 1) * w->tuple_size, tuple, sz);
+			/* formed in place (the page is zeroed: the tuple's alignment padding stays zero) -- one copy of the payload,
+			 * out of the pinned piece the drain handed over, instead of two */
+			sz = form_index_tuple(page + (PGV_BLCKSZ - SPECIAL_SIZE) - (size_t) (j + 1) * w->tuple_size, w->dtype, w->dim,
+								  (const char *) vectors + (size_t) r * row_bytes, tids ? tids[r] : 0);
+			(void) sz;
 		}
 	}
 	return PGV_OK;

@@ -154,6 +154,7 @@ typedef struct pgv_rel
 #define PGV_BLCKSZ 8192
 #define PGV_INVALID_BLOCK 0xFFFFFFFFu
 
+double		pgv_host_ivf_writer_wait_secs(void);	/* diagnostics: the last page writer's wait for its zeroed page array */
 void		pgv_rel_init(pgv_rel * rel);
 void		pgv_rel_free(pgv_rel * rel);
 

@@ -479,6 +479,8 @@ struct pgv_builder
 	int64_t		n,
 				cap;
 	int			has_tids;
+	int			deferred;
+	int64_t		assigned;
 };
 
 int
@@ -496,8 +498,30 @@ pgv_builder_begin(pgv_ctx * ctx, pgv_metric metric, pgv_dtype dtype, int dim, in
 	b->dim = dim;
 	b->nlists = nlists;
 	b->centers = malloc(sizeof(float) * (size_t) nlists * dim);
-	memcpy(b->centers, centers, sizeof(float) * (size_t) nlists * dim);
+	if (centers)
+		memcpy(b->centers, centers, sizeof(float) * (size_t) nlists * dim);
+	else
+		b->deferred = 1;
 	*out = b;
+	return PGV_OK;
+}
+
+static void
+builder_assign_pending(pgv_builder * b)
+{
+	if (b->assigned < b->n)
+		pgv_assign(b->ctx, b->metric, PGV_F32, b->dim, b->centers, b->nlists, b->rows + (size_t) b->assigned * b->dim,
+				   b->n - b->assigned, b->lists + b->assigned, NULL);
+	b->assigned = b->n;
+}
+
+int
+pgv_builder_set_centers(pgv_builder * b, const void *centers)
+{
+	if (!b->deferred)
+		return fail(PGV_ERR_STATE, "mock: the builder has its centers");
+	memcpy(b->centers, centers, sizeof(float) * (size_t) b->nlists * b->dim);
+	b->deferred = 0;
 	return PGV_OK;
 }
 
@@ -515,8 +539,9 @@ pgv_builder_add(pgv_builder * b, const void *rows, const uint64_t *tids, int64_t
 	for (int64_t i = 0; i < n; i++)
 		b->tids[b->n + i] = tids ? tids[i] : (uint64_t) (b->n + i);
 	b->has_tids = tids != NULL;
-	pgv_assign(b->ctx, b->metric, PGV_F32, b->dim, b->centers, b->nlists, rows, n, b->lists + b->n, NULL);
 	b->n += n;
+	if (!b->deferred)
+		builder_assign_pending(b);
 	return PGV_OK;
 }
 
@@ -535,6 +560,15 @@ pgv_builder_finish(pgv_builder * b, pgv_index * *out_index, int64_t *out_offsets
 	uint64_t   *stids = malloc(sizeof(uint64_t) * (size_t) (b->n > 0 ? b->n : 1));
 	int			rc;
 
+	if (b->deferred)
+	{
+		free(stids);
+		free(sorted);
+		free(fill);
+		free(off);
+		return fail(PGV_ERR_STATE, "mock: no centers");
+	}
+	builder_assign_pending(b);
 	for (int64_t r = 0; r < b->n; r++)
 		off[b->lists[r] + 1]++;
 	for (int l = 0; l < b->nlists; l++)
@@ -556,7 +590,7 @@ pgv_builder_finish(pgv_builder * b, pgv_index * *out_index, int64_t *out_offsets
 	free(sorted);
 	free(fill);
 	free(off);
-	b->n = 0;
+	b->n = b->assigned = 0;
 	return rc;
 }
 

@@ -463,6 +463,53 @@ def test_builder_without_tids_and_empty(ctx):
     b.close()
 
 
+@pytest.mark.parametrize("dtype,dim", [(po.ORA_F32, 96), (po.ORA_F16, 250)])
+def test_builder_without_centers_uploads_beside_kmeans(ctx, dtype, dim):
+    """pgv_builder_begin(centers = NULL): rows are only copied (on the builder's own stream) while pgv_kmeans computes
+    the centers on the context from another host thread; set_centers + finish then give exactly what a builder that
+    knew the centers from the start gives"""
+    import threading
+    n, lists = 40000, 64
+    data = gen(n, dim, seed=971, dist="clustered", clusters=32, dtype=dtype)
+    tids = np.arange(n, dtype=np.uint64) + np.uint64(5)
+    samples = np.ascontiguousarray(data[::8])
+    box = {}
+
+    def run_kmeans():
+        try:
+            box["centers"] = api.kmeans(ctx, api.PGV_OPS_L2, DT[dtype], dim, samples, lists, api.make_rng(seed=9))[0]
+        except Exception as e:  # noqa: BLE001
+            box["error"] = e
+
+    b = api.IvfBuilder(ctx, api.PGV_L2SQ, DT[dtype], dim, None, expected_rows=n // 2, nlists=lists)
+    th = threading.Thread(target=run_kmeans)
+    th.start()
+    for lo in range(0, n, 2500):
+        b.add(data[lo:lo + 2500], tids[lo:lo + 2500])
+    with pytest.raises(api.PgvError):
+        b.finish()                     # no centers yet
+    th.join()
+    assert "error" not in box, box.get("error")
+    centers = box["centers"]
+    b.set_centers(centers)
+    with pytest.raises(api.PgvError):
+        b.set_centers(centers)         # once
+    b.add(data[:100], tids[:100] + np.uint64(1000000))   # and rows that come after the centers
+    ix, off, lists_got = b.finish(want_lists=True)
+    b.close()
+    ref_b = api.IvfBuilder(ctx, api.PGV_L2SQ, DT[dtype], dim, centers, expected_rows=n + 100)
+    ref_b.add(data, tids)
+    ref_b.add(data[:100], tids[:100] + np.uint64(1000000))
+    ref, ref_off, ref_lists = ref_b.finish(want_lists=True)
+    ref_b.close()
+    assert off.tolist() == ref_off.tolist() and lists_got.tolist() == ref_lists.tolist()
+    v1, t1, _ = api.drain_index(ix)
+    v2, t2, _ = api.drain_index(ref)
+    assert t1.tolist() == t2.tolist() and np.array_equal(v1.view(np.uint8), v2.view(np.uint8))
+    ix.close()
+    ref.close()
+
+
 @pytest.mark.parametrize("ops,dtype,dim,n,lists", [
     (po.OPS_L2, po.ORA_F32, 1536, 4000, 16),      # one tuple per page
     (po.OPS_L2, po.ORA_F32, 20, 30000, 50),       # short varlena headers, ~80 tuples per page
