@@ -788,6 +788,7 @@ def main():
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo for a functional "
                                                      "multi-rank run on a single GPU)")
     args = ap.parse_args()
+    t_program = time.perf_counter()
     # fd 1 carries the ONE JSON line and nothing else: libraries that greet on stdout (RCCL's version banner)
     # are pointed at stderr for the rest of the run
     json_fd = os.dup(1)
@@ -1264,6 +1265,7 @@ def main():
 
     if failures:
         line["failures"] = failures
+    line["bench_wall_secs"] = time.perf_counter() - t_program   # everything: data, builds, sweeps, CPU baselines, PMC passes
     if rank == 0:
         os.write(json_fd, (json.dumps(line) + "\n").encode())
     index.close()

@@ -347,6 +347,8 @@ def test_mfma_l2_under_catastrophic_cancellation(ctx, oracle):
     (po.OPS_IP, po.ORA_F32, 768, 8000, 160, 6, 8, 25, "clustered"),
     (po.OPS_COSINE, po.ORA_F16, 200, 8000, 160, 5, 10, 10, "clustered"),
     (po.OPS_L2, po.ORA_F32, 5, 9000, 300, 12, 10, 1000, "normal"),      # deep head, more than some queries have tuples
+    (po.OPS_L2, po.ORA_F32, 64, 24000, 600, 22, 10, 10, "clustered"),   # per-query center ranking up to 24 queries
+    (po.OPS_IP, po.ORA_F16, 128, 24000, 800, 30, 10, 10, "clustered"),  # past it: dense ranking, per-query scan
 ])
 def test_small_batches_take_the_per_query_kernels(ctx, oracle, ops, dtype, dim, n, lists, nq, probes, k, dist):
     """nq * probes <= 0.4 lists (or nq <= 4): pgv_search_batch runs mq_rank / mq_lists / mq_scan / mq_head -- the
