@@ -803,7 +803,10 @@ constexpr int kScanQueries = 32;   // queries per task
 
 constexpr int kScanWaves = 4;      // one 32 x 32 tile each: a task is 128 rows
 
-template <typename T, int METRIC, int NW>
+// NT: the list rows are fetched with the non-temporal policy (an index far larger than the caches is read once per
+// batch: +3.5 % on the 6 GB headline index, 1.145 -> 1.102 ms per batch, same box, alternating runs); the query rows,
+// which every task of a group re-reads, keep the default policy
+template <typename T, int METRIC, int NW, bool NT>
 __global__ __launch_bounds__(NW * 64) void mfma_scan_kernel(
     const char *__restrict__ rows, const char *__restrict__ queries, const ScanTask *__restrict__ tasks,
     const int *__restrict__ ntasks_ptr, int *__restrict__ task_counter, const ScanPair *__restrict__ pairs,
@@ -879,8 +882,12 @@ __global__ __launch_bounds__(NW * 64) void mfma_scan_kernel(
                 const int vi = sl * 8 + v;
                 const char *p = vi < nvec ? src[j] + (size_t)vi * sizeof(Raw16) : zeros16;
                 char *dst = smem + (size_t)buf * STAGE + (size_t)g8 * 8 * kSliceBytes;
-                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)p,
-                                                 (__attribute__((address_space(3))) void *)dst, 16, 0, 0);
+                if (NT && g8 >= 4)
+                    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)p,
+                                                     (__attribute__((address_space(3))) void *)dst, 16, 0, 2);
+                else
+                    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)p,
+                                                     (__attribute__((address_space(3))) void *)dst, 16, 0, 0);
             }
         };
         // pair table to registers (after the loop: a store followed by an LDS read makes hipcc wait for the store)
@@ -1041,7 +1048,8 @@ int launch_row_norms(pgv_ctx *ctx, pgv_dtype dtype, const RowGeom &g, const void
 
 int launch_mfma_scan(pgv_ctx *ctx, pgv_metric metric, pgv_dtype dtype, const RowGeom &g, const void *rows,
                      const void *queries, const ScanTask *tasks, const int *ntasks_dev, int ntasks_bound,
-                     const ScanPair *pairs, const float *row_norms, const float *query_norms, float *out) {
+                     const ScanPair *pairs, const float *row_norms, const float *query_norms, float *out,
+                     bool stream_rows) {
     if (ntasks_bound <= 0) return PGV_OK;
     if (metric != PGV_L2SQ && metric != PGV_NEG_IP) PGV_FAIL(PGV_ERR_ARG, "mfma scan: L2 / inner product only");
     if (!ctx->zeros.p) {
@@ -1056,10 +1064,17 @@ int launch_mfma_scan(pgv_ctx *ctx, pgv_metric metric, pgv_dtype dtype, const Row
     int *counter = ctx->counters.as<int>() + 8;  // words 8, 9: claimed tasks, workgroups done (the kernel re-zeroes them)
     int grid = ctx->num_cus * 3;  // 41 KB of LDS per workgroup: three per CU
     if (grid > ntasks_bound) grid = ntasks_bound;
-#define PGV_MSCAN(T, M)                                                                                              \
-    hipLaunchKernelGGL((mfma_scan_kernel<T, M, kScanWaves>), dim3(grid), dim3(kScanWaves * 64), 0, ctx->stream,       \
+#define PGV_MSCAN_NT(T, M, NT)                                                                                       \
+    hipLaunchKernelGGL((mfma_scan_kernel<T, M, kScanWaves, NT>), dim3(grid), dim3(kScanWaves * 64), 0, ctx->stream,   \
                        static_cast<const char *>(rows), static_cast<const char *>(queries), tasks, ntasks_dev, counter, \
                        pairs, row_norms, query_norms, g.nvec, static_cast<const char *>(ctx->zeros.p), out)
+#define PGV_MSCAN(T, M)              \
+    do {                             \
+        if (stream_rows)             \
+            PGV_MSCAN_NT(T, M, true); \
+        else                         \
+            PGV_MSCAN_NT(T, M, false); \
+    } while (0)
     if (dtype == PGV_F32) {
         if (metric == PGV_L2SQ)
             PGV_MSCAN(float, 0);
@@ -1072,6 +1087,7 @@ int launch_mfma_scan(pgv_ctx *ctx, pgv_metric metric, pgv_dtype dtype, const Row
             PGV_MSCAN(__half, 1);
     }
 #undef PGV_MSCAN
+#undef PGV_MSCAN_NT
     PGV_HIP(hipGetLastError());
     return PGV_OK;
 }

@@ -104,6 +104,12 @@ int check_metric(pgv_metric m) {
     return PGV_OK;
 }
 
+// rows that cannot stay in the 256 MB last-level cache between two batches anyway (four times its size and up) are
+// fetched non-temporally by the MFMA scan; smaller sets keep the default policy and the cache residency it gives them
+bool rows_stream_past_caches(const RowGeom &g, pgv_dtype dtype, int64_t nrows) {
+    return (size_t)nrows * (size_t)g.ld * elem_size(dtype) >= ((size_t)1 << 30);
+}
+
 // rows [n x dim] tightly packed (host or device) -> device rows [n x ld], zero padded.
 // When the source already lives on the device with ld == dim it is used in place.
 int stage_rows(pgv_ctx *ctx, const void *src, int64_t n, int dim, pgv_dtype dtype,
@@ -354,7 +360,7 @@ int dense_scan(pgv_ctx *ctx, pgv_metric metric, pgv_dtype dtype, const RowGeom &
     PGV_TRY(timer.begin((double)nrows * nq, (double)nrows * ngroups, true));
     if (mfma)
         PGV_TRY(launch_mfma_scan(ctx, metric, dtype, g, rows_dev, queries_dev, dt, dn, (int)ntasks, dp, row_norms,
-                                 query_norms, out_dev));
+                                 query_norms, out_dev, rows_stream_past_caches(g, dtype, nrows)));
     else if (use_tile)
         PGV_TRY(launch_tile_scan(ctx, metric, dtype, g, rows_dev, queries_dev, dt, dn, (int)ntasks, dp, out_dev));
     else
@@ -1475,7 +1481,7 @@ static int scan_batch_dev(pgv_index *ix, const void *q_dev, int nq, const int32_
         if (use_mfma)
             PGV_TRY(launch_mfma_scan(ctx, ix->metric, ix->dtype, ix->geom, ix->vectors, q_dev, plan.tasks,
                                      plan.ntasks_dev, (int)plan.ntasks_bound, plan.pairs, ix->row_norms, nullptr,
-                                     seg_vals));
+                                     seg_vals, rows_stream_past_caches(ix->geom, ix->dtype, ix->nrows)));
         else if (use_tile)
             PGV_TRY(launch_tile_scan(ctx, ix->metric, ix->dtype, ix->geom, ix->vectors, q_dev, plan.tasks,
                                      plan.ntasks_dev, (int)plan.ntasks_bound, plan.pairs, seg_vals));
