@@ -563,6 +563,27 @@ int launch_query_iota(pgv_ctx *ctx, int32_t *out, int n) {
     return PGV_OK;
 }
 
+// one query against n contiguous rows, out[j] = distance to row j: the streaming form of query_rank_kernel (whole
+// rows in flight per wavefront, the query in registers) -- a k-means++ round over the samples, pgv_distance_batch
+int launch_one_query_rows(pgv_ctx *ctx, pgv_metric metric, pgv_dtype dtype, const RowGeom &g, const void *rows, int n,
+                          const void *q_dev, float *out) {
+    if (n <= 0) return PGV_OK;
+    int per, grid;
+    run_geometry(ctx, g, n, &per, &grid);
+    return dispatch_metric(metric, dtype, [&](auto *tp, auto mc) {
+        using T = std::remove_pointer_t<decltype(tp)>;
+        constexpr int M = decltype(mc)::value;
+        return dispatch_nch<T, M>(g, [&](auto nc) {
+            constexpr int NCH = decltype(nc)::value;
+            hipLaunchKernelGGL((query_rank_kernel<T, M, NCH>), dim3(grid), dim3(kQThreads), 0, ctx->stream,
+                               static_cast<const char *>(rows), n, g.nvec, g.lpr_log2, static_cast<const char *>(q_dev),
+                               out, per);
+            PGV_HIP(hipGetLastError());
+            return PGV_OK;
+        });
+    });
+}
+
 int launch_query_rank(pgv_ctx *ctx, const pgv_index *ix, const void *q_dev, float *cdist, int max_probes,
                       int32_t *out_lists) {
     const RowGeom &g = ix->geom;

@@ -368,6 +368,8 @@ int launch_multi_scan(pgv_ctx *ctx, const pgv_index *ix, const void *q_dev, int 
                       int64_t rows_bound, float *seg, int64_t seg_stride, int k, float *out_dist, int64_t *out_slot,
                       uint64_t *out_tid);
 int launch_query_iota(pgv_ctx *ctx, int32_t *out, int n);
+int launch_one_query_rows(pgv_ctx *ctx, pgv_metric metric, pgv_dtype dtype, const RowGeom &g, const void *rows, int n,
+                          const void *q_dev, float *out);
 int launch_query_rank(pgv_ctx *ctx, const pgv_index *ix, const void *q_dev, float *cdist, int max_probes,
                       int32_t *out_lists);
 int launch_query_scan(pgv_ctx *ctx, const pgv_index *ix, const void *q_dev, const int32_t *probe_lists, int nprobes,
