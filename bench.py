@@ -61,6 +61,8 @@ import torch.distributed as dist
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
+import threading  # noqa: E402
+
 import pgvector_amd  # noqa: E402
 from pgvector_amd import api, sharding  # noqa: E402
 
@@ -402,7 +404,7 @@ def live_traffic(args, scan_ms):
         try:
             r = subprocess.run([exe, "--pmc", counter, "--kernel-trace", "-d", d, "-o", "pmc", "--output-format", "csv",
                                 "--"] + base, cwd="/tmp", env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE,
-                               timeout=600)
+                               timeout=300)
             files = glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True)
             if r.returncode != 0 or not files:
                 return None, "%s pass failed (rc %d)" % (counter, r.returncode)
@@ -463,11 +465,17 @@ def concurrent_backends(index, device, qhost, queries, probes, k, args, dev):
     # (pgv_index_export / pgv_index_import: hipIpc, no copy) and scans it on a context and stream of its own
     from pgvector_amd import _host
     out["single_query_processes"] = {}
-    for nb in (1, 4, 8, 16, 32):
+    # (32 own-context processes -- 7-10 k QPS on these boxes, profiles/r03/processes_*.json, DESIGN 4.8b -- only with
+    # --all-process-rows: that row costs the most and teaches the least in a driver run)
+    t_sec = time.perf_counter()
+    for nb in ((1, 4, 8, 16, 32) if args.all_process_rows else (1, 4, 8, 16)):
         try:
             out["single_query_processes"][str(nb)] = _host.run_backend_processes(index, qh, probes, k, 0, nb, 300)
         except Exception as e:  # noqa: BLE001
             out["single_query_processes"][str(nb)] = {"error": repr(e)}
+            break
+        if time.perf_counter() - t_sec > 60:   # a slow box: the rest of the row is not worth the driver's time
+            out["single_query_processes"]["cut_short_after_secs"] = time.perf_counter() - t_sec
             break
     out["single_query_processes"]["driver"] = ("tools/pgv_backend.c `query`: one PROCESS per backend (fork + exec), the "
                                                "mirror imported from the owner's export handle, pgv_query_rank + "
@@ -490,7 +498,11 @@ def concurrent_backends(index, device, qhost, queries, probes, k, args, dev):
     # ... and with GPU-less client PROCESSES in front of two lane-server processes: the pool's slots, lane words and
     # payload ring live in a shared segment (non-private futexes, a robust process-shared mutex)
     out["pooled_single_query_processes"] = {}
+    t_sec = time.perf_counter()
     for nc in (16, 64, 256):
+        if time.perf_counter() - t_sec > 60:
+            out["pooled_single_query_processes"]["cut_short_after_secs"] = time.perf_counter() - t_sec
+            break
         try:
             out["pooled_single_query_processes"][str(nc)] = _host.run_backend_processes(
                 index, qh, probes, k, 1, nc, max(40, 6000 // nc), max_batch=1024, max_wait_us=50, lanes=2,
@@ -767,6 +779,37 @@ def timed_steps(fn, steps, warmup=2):
     return (time.perf_counter() - t0) / steps
 
 
+# The ONE JSON line must come out whatever an optional section does.  The timed region and the parity / recall checks
+# are over long before the sections that start processes, build the HNSW graph or run rocprofv3; should one of those
+# not return (a hung child, a wedged profiler), the watchdog prints the line as far as it has got -- with a `failures`
+# entry naming the section -- and ends the process.
+WATCH = {"line": None, "fd": None, "rank": 0, "section": "setup", "done": False}
+
+
+def watchdog(deadline_s):
+    t_end = time.perf_counter() + deadline_s
+    while time.perf_counter() < t_end:
+        if WATCH["done"]:
+            return
+        time.sleep(0.5)
+    if WATCH["done"]:
+        return
+    line = WATCH["line"]
+    if line is not None and WATCH["rank"] == 0:
+        for _ in range(5):
+            try:
+                snap = dict(line)
+                snap.setdefault("failures", [])
+                snap["failures"] = list(snap["failures"]) + [
+                    "watchdog: section '%s' had not returned after %d s; the line ends here" % (WATCH["section"], deadline_s)]
+                snap["bench_wall_secs"] = deadline_s
+                os.write(WATCH["fd"], (json.dumps(snap, default=str) + "\n").encode())
+                break
+            except Exception:  # noqa: BLE001  (the dict was being written to: try again)
+                time.sleep(0.05)
+    os._exit(0 if line is not None else 3)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -780,6 +823,9 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true", help="skips the oracle: no cpu_baseline, no TID parity")
     ap.add_argument("--no-sweeps", action="store_true", help="skip batch / probes sweeps, uniform data, page build")
     ap.add_argument("--no-traffic", action="store_true", help="skip the live rocprofv3 PMC passes")
+    ap.add_argument("--all-process-rows", action="store_true", help="also 32 own-context backend processes")
+    ap.add_argument("--watchdog-secs", type=int, default=900, help="print the line as far as it has got and exit "
+                    "should the run take longer than this (0: no watchdog)")
     ap.add_argument("--child", action="store_true", help="(internal) the short run the PMC passes profile")
     ap.add_argument("--host-io", action="store_true", help="also time the batch with host-memory queries/results")
     ap.add_argument("--recall-queries", type=int, default=256)
@@ -795,6 +841,9 @@ def main():
     os.dup2(2, 1)
     if args.child:
         args.no_cpu_baseline = args.no_sweeps = args.no_traffic = True
+    WATCH["fd"] = json_fd
+    if args.watchdog_secs > 0:
+        threading.Thread(target=watchdog, args=(args.watchdog_secs,), daemon=True).start()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -938,7 +987,8 @@ def main():
                 "measured_stream_ceiling_GBps: what a kernel that only stages the same 128-row tasks into LDS reaches on "
                 "this part, any access pattern (tools/stream_patterns.hip, profiles/r02b_stream_patterns.txt, DESIGN.md 4.1c)",
     }
-    line = {
+    WATCH["rank"] = rank
+    line = WATCH["line"] = {
         "metric": "QPS @ recall@10 (IVFFlat, 1M x 1536d)" if args.workload == "headline"
                   else "QPS @ recall@10 (IVFFlat)",
         "value": qps, "unit": "queries/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -1049,6 +1099,7 @@ def main():
 
         # ---- several backends on ONE device mirror (pgv_index_share): each its own context = stream + scratch
         try:
+            WATCH["section"] = 'concurrent_backends (threads / processes / pooled clients)'
             line["concurrent_backends"] = concurrent_backends(index, local_rank, qhost, queries, probes, k, args, dev)
         except Exception as e:
             line["concurrent_backends"] = {"error": repr(e)}
@@ -1208,6 +1259,7 @@ def main():
     # ------------------------------------------- HNSW (BASELINE configs[3]'s shape, rows scaled down)
     if single and not args.no_sweeps and args.workload == "headline":
         try:
+            WATCH["section"] = 'hnsw'
             line["hnsw"] = hnsw_section(ctx, dev, args, failures)
         except Exception as e:
             line["hnsw"] = {"error": repr(e)}
@@ -1215,6 +1267,7 @@ def main():
     # ------------------------------------------- the exact scan for a batch of queries (BASELINE configs[0])
     if single and not args.no_sweeps and args.workload == "headline":
         try:
+            WATCH["section"] = 'exact_scan'
             line["exact_scan"] = exact_scan_section(ctx, dev, args, failures)
         except Exception as e:
             line["exact_scan"] = {"error": repr(e)}
@@ -1239,6 +1292,7 @@ def main():
         line["other_configs"] = {}
         for wname in ("c2", "c3shard", "c5shard"):
             try:
+                WATCH["section"] = 'other_configs'
                 line["other_configs"][wname] = run_workload(ctx, dev, wname, args, failures)
                 log("%s: %.0f QPS, recall %.4f, roofline frac %.2f" % (
                     wname, line["other_configs"][wname]["qps"], line["other_configs"][wname]["recall_at_10"],
@@ -1257,6 +1311,7 @@ def main():
 
     # ------------------------------------------------------------------ live PMC traffic
     if single and not args.no_traffic:
+        WATCH["section"] = 'live PMC traffic (rocprofv3 child runs)'
         traffic, src = live_traffic(args, avg_launch_ms)
         roofline["traffic"] = traffic
         roofline["traffic_source"] = src
@@ -1266,6 +1321,7 @@ def main():
     if failures:
         line["failures"] = failures
     line["bench_wall_secs"] = time.perf_counter() - t_program   # everything: data, builds, sweeps, CPU baselines, PMC passes
+    WATCH["done"] = True
     if rank == 0:
         os.write(json_fd, (json.dumps(line) + "\n").encode())
     index.close()

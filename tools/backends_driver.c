@@ -463,7 +463,7 @@ backends_run_processes(pgv_index * index, const char *image_shm, int device, int
 	}
 	/* everybody warmed up and at the start line (or somebody died on the way) */
 	{
-		double		deadline = now() + 300.0;
+		double		deadline = now() + 90.0;
 
 		while (__atomic_load_n(&bank->ready, __ATOMIC_ACQUIRE) < (uint32_t) nclients)
 		{
@@ -481,7 +481,7 @@ backends_run_processes(pgv_index * index, const char *image_shm, int device, int
 				}
 			}
 			if (now() > deadline)
-				FAILP(PGV_ERR_STATE, "clients did not reach the start line in 300 s");
+				FAILP(PGV_ERR_STATE, "clients did not reach the start line in 90 s");
 			syscall(SYS_futex, &bank->ready, FUTEX_WAIT, __atomic_load_n(&bank->ready, __ATOMIC_ACQUIRE), &rel, NULL, 0);
 		}
 	}
@@ -489,22 +489,40 @@ backends_run_processes(pgv_index * index, const char *image_shm, int device, int
 	pgv_host_pool_stats(pool, &batches0, &queries0);
 	__atomic_store_n(&bank->go, 1, __ATOMIC_RELEASE);
 	syscall(SYS_futex, &bank->go, FUTEX_WAKE, INT_MAX, NULL, NULL, 0);
-	/* the clients are the last nclients pids */
-	for (int i = npids - nclients; i < npids; i++)
+	/* the clients are the last nclients pids; a run that does not end in 90 s is given up (the children are killed
+	 * below) -- a measurement harness must not be able to hang its caller */
 	{
-		int			st = 0;
+		double		deadline = now() + 90.0;
+		int			left = nclients;
 
-		if (pids[i] > 0 && waitpid(pids[i], &st, 0) == pids[i])
+		while (left > 0)
 		{
-			pids[i] = 0;
-			if ((!WIFEXITED(st) || WEXITSTATUS(st) != 0) && rc == PGV_OK)
+			left = 0;
+			for (int i = npids - nclients; i < npids; i++)
 			{
-				pgvb_client *cl = (pgvb_client *) ((char *) bank + bank->clients_off) + (i - (npids - nclients));
+				int			st = 0;
 
-				rc = cl->rc ? cl->rc : PGV_ERR_STATE;
-				if (errbuf)
-					snprintf(errbuf, errcap, "client %d: status %d: %s", i - (npids - nclients), st, cl->err);
+				if (pids[i] <= 0)
+					continue;
+				if (waitpid(pids[i], &st, WNOHANG) == pids[i])
+				{
+					pids[i] = 0;
+					if ((!WIFEXITED(st) || WEXITSTATUS(st) != 0) && rc == PGV_OK)
+					{
+						pgvb_client *cl = (pgvb_client *) ((char *) bank + bank->clients_off) + (i - (npids - nclients));
+
+						rc = cl->rc ? cl->rc : PGV_ERR_STATE;
+						if (errbuf)
+							snprintf(errbuf, errcap, "client %d: status %d: %s", i - (npids - nclients), st, cl->err);
+					}
+				}
+				else
+					left++;
 			}
+			if (left > 0 && now() > deadline)
+				FAILP(PGV_ERR_STATE, "%d of %d clients had not finished after 90 s", left, nclients);
+			if (left > 0)
+				usleep(2000);
 		}
 	}
 	pgv_host_pool_stats(pool, &batches1, &queries1);
@@ -539,23 +557,28 @@ backends_run_processes(pgv_index * index, const char *image_shm, int device, int
 out:
 	if (pool)
 		pgv_host_pool_shutdown(pool);
-	for (int i = 0; pids && i < npids; i++)
-		if (pids[i] > 0)
-		{
-			int			st;
-			double		deadline = now() + 10.0;
+	{
+		/* servers and owner leave on the pool's shutdown; 10 s for all of them together after a clean run, none
+		 * after a failed one */
+		double		deadline = now() + (rc == PGV_OK ? 10.0 : 0.0);
 
-			while (waitpid(pids[i], &st, WNOHANG) == 0)
+		for (int i = 0; pids && i < npids; i++)
+			if (pids[i] > 0)
 			{
-				if (now() > deadline)
+				int			st;
+
+				while (waitpid(pids[i], &st, WNOHANG) == 0)
 				{
-					kill(pids[i], SIGKILL);
-					waitpid(pids[i], &st, 0);
-					break;
+					if (now() > deadline)
+					{
+						kill(pids[i], SIGKILL);
+						waitpid(pids[i], &st, 0);
+						break;
+					}
+					usleep(2000);
 				}
-				usleep(2000);
 			}
-		}
+	}
 	free(pids);
 	if (pool)
 		pgv_host_pool_detach(pool);
