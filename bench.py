@@ -1226,7 +1226,6 @@ def main():
     # ---- the build's CPU loops beside build_secs, in a background thread while the GPU sections below go on
     cpu_build, cpu_build_thread = {}, None
     if single and not args.no_cpu_baseline and host_rows is not None and host_samples is not None:
-        import threading
         cpu_build_thread = threading.Thread(target=cpu_build_kmeans,
                                             args=(host_samples, lists, dtype, ops, args.seed + 2, cpu_build))
         cpu_build_thread.start()
