@@ -460,7 +460,8 @@ int			pgv_search_batch_sharded(pgv_comm * comm, pgv_index * local_index, const v
  *                       centers == NULL: they come later -- until pgv_builder_set_centers, pgv_builder_add only copies
  *                       its rows to the device, on a stream of the builder's own, so that the upload of the heap and a
  *                       pgv_kmeans still running on the context (called from another host thread) overlap; the rows
- *                       are assigned in one piece once the centers are there
+ *                       are assigned in one piece once the centers are there.  (That stream is not ordered after the
+ *                       context's: device-resident rows handed to such a builder must be complete before the call.)
  *   pgv_builder_add     a batch of heap rows (host or device, tightly packed) with their TIDs (or NULL: heap
  *                       positions): copied to the device, assigned there (same kernel as pgv_assign), kept in heap order
  *   pgv_builder_finish  list-major order (ascending list, heap order inside a list -- what the tuplesort delivers
