@@ -14,6 +14,7 @@
 
 #include <float.h>
 #include <math.h>
+#include <pthread.h>
 #include <stdlib.h>
 #include <string.h>
 
@@ -38,8 +39,17 @@ typedef struct
 	int64_t		row;			/* representative row (first heap tid) */
 	int64_t		heaptids[HNSW_HEAPTIDS];
 	int			heaptids_length;
+	int			dead;			/* parallel build: a duplicate that was folded into another element (never linked) */
 	neighbor_array *neighbors;	/* [level + 1] */
 }			hnsw_element;
+
+/* the visited set of one searcher (visited_hash, src/hnswutils.c:37-44): a stamp per element */
+typedef struct
+{
+	uint32_t   *v;
+	uint32_t	stamp;
+	int64_t		cap;
+}			visit_set;
 
 struct ora_hnsw
 {
@@ -56,10 +66,11 @@ struct ora_hnsw
 	int64_t		nelements,
 				cap;
 	int32_t		entry_point;	/* -1 = empty */
-	/* search scratch */
-	uint32_t   *visited;
-	uint32_t	stamp;
-	int64_t		visited_cap;
+	/* search scratch of the single-threaded callers */
+	visit_set	vs;
+	/* the parallel in-memory build only (ora_hnsw_build_parallel): one lock per element, "held when reading or
+	 * modifying the element's neighbors or heaptids" (src/hnswbuild.c:20-21); NULL otherwise */
+	pthread_rwlock_t *locks;
 };
 
 static inline int
@@ -164,19 +175,19 @@ heap_pop(heap * h)
 /* ----------------------------------------------------------- SearchLayer */
 
 static void
-visited_begin(ora_hnsw * g)
+visited_begin(visit_set * vs, int64_t nelements)
 {
-	if (g->visited_cap < g->nelements + 1)
+	if (vs->cap < nelements + 1)
 	{
-		g->visited_cap = (g->nelements + 1) * 2;
-		g->visited = realloc(g->visited, sizeof(uint32_t) * (size_t) g->visited_cap);
-		memset(g->visited, 0, sizeof(uint32_t) * (size_t) g->visited_cap);
-		g->stamp = 0;
+		vs->cap = (nelements + 1) * 2;
+		vs->v = realloc(vs->v, sizeof(uint32_t) * (size_t) vs->cap);
+		memset(vs->v, 0, sizeof(uint32_t) * (size_t) vs->cap);
+		vs->stamp = 0;
 	}
-	if (++g->stamp == 0)
+	if (++vs->stamp == 0)
 	{
-		memset(g->visited, 0, sizeof(uint32_t) * (size_t) g->visited_cap);
-		g->stamp = 1;
+		memset(vs->v, 0, sizeof(uint32_t) * (size_t) vs->cap);
+		vs->stamp = 1;
 	}
 }
 
@@ -186,7 +197,7 @@ visited_begin(ora_hnsw * g)
  * Returns the result count; *scored (may be NULL) accumulates so->tuples (:872-873, :905-906).
  */
 static int
-search_layer(ora_hnsw * g, const void *q, const search_candidate * ep, int nep, int ef, int lc,
+search_layer(ora_hnsw * g, visit_set * vs, const void *q, const search_candidate * ep, int nep, int ef, int lc,
 			 search_candidate * *out, int64_t *scored)
 {
 	heap		C = {0},
@@ -199,11 +210,11 @@ search_layer(ora_hnsw * g, const void *q, const search_candidate * ep, int nep, 
 
 	C.nearest_first = 1;
 	W.nearest_first = 0;
-	visited_begin(g);
+	visited_begin(vs, g->nelements);
 
 	for (int i = 0; i < nep; i++)
 	{
-		g->visited[ep[i].element] = g->stamp;
+		vs->v[ep[i].element] = vs->stamp;
 		if (scored)
 			(*scored)++;
 		heap_push(&C, ep[i]);
@@ -222,21 +233,26 @@ search_layer(ora_hnsw * g, const void *q, const search_candidate * ep, int nep, 
 			break;
 
 		ce = &g->elements[c.element];
-		/* HnswLoadUnvisitedFromMemory (:742-759) / ...FromDisk (:796-819): same order */
+		/* HnswLoadUnvisitedFromMemory (:731-759) / ...FromDisk (:796-819): same order.  In the parallel build the
+		 * neighborhood is read under the element's lock (shared), :738-742 */
 		if (lc <= ce->level)
 		{
 			const neighbor_array *na = &ce->neighbors[lc];
 
+			if (g->locks)
+				pthread_rwlock_rdlock(&g->locks[c.element]);
 			for (int i = 0; i < na->length; i++)
 			{
 				int32_t		e = na->items[i].element;
 
-				if (g->visited[e] != g->stamp)
+				if (vs->v[e] != vs->stamp)
 				{
-					g->visited[e] = g->stamp;
+					vs->v[e] = vs->stamp;
 					unvisited[nun++] = e;
 				}
 			}
+			if (g->locks)
+				pthread_rwlock_unlock(&g->locks[c.element]);
 		}
 		if (scored)
 			*scored += nun;
@@ -411,7 +427,7 @@ update_connection(ora_hnsw * g, neighbor_array * neighbors, int32_t new_element,
 
 /* Algorithm 1, src/hnswutils.c:1280-1357 (in-memory, not `existing`) */
 static void
-find_element_neighbors(ora_hnsw * g, int32_t element)
+find_element_neighbors(ora_hnsw * g, visit_set * vs, int32_t element, int32_t entry_point)
 {
 	hnsw_element *el = &g->elements[element];
 	const void *q = value_of(g, element);
@@ -422,19 +438,19 @@ find_element_neighbors(ora_hnsw * g, int32_t element)
 	int			nep,
 				nw = 0;
 
-	if (g->entry_point < 0)
+	if (entry_point < 0)
 		return;
 
 	ep = malloc(sizeof(search_candidate));
-	ep[0].element = g->entry_point;
-	ep[0].distance = dist_qe(g, q, g->entry_point);	/* HnswEntryCandidate */
+	ep[0].element = entry_point;
+	ep[0].distance = dist_qe(g, q, entry_point);	/* HnswEntryCandidate */
 	nep = 1;
-	entry_level = g->elements[g->entry_point].level;
+	entry_level = g->elements[entry_point].level;
 
 	/* 1st phase: greedy search to the insert level */
 	for (int lc = entry_level; lc >= level + 1; lc--)
 	{
-		nw = search_layer(g, q, ep, nep, 1, lc, &w, NULL);
+		nw = search_layer(g, vs, q, ep, nep, 1, lc, &w, NULL);
 		free(ep);
 		ep = w;
 		nep = nw;
@@ -451,7 +467,7 @@ find_element_neighbors(ora_hnsw * g, int32_t element)
 				  **r;
 		int			rn;
 
-		nw = search_layer(g, q, ep, nep, g->ef_construction, lc, &w, NULL);
+		nw = search_layer(g, vs, q, ep, nep, g->ef_construction, lc, &w, NULL);
 		lw = malloc(sizeof(hnsw_candidate) * (size_t) (nw > 0 ? nw : 1));
 		c = malloc(sizeof(*c) * (size_t) (nw > 0 ? nw : 1));
 		r = malloc(sizeof(*r) * (size_t) (lm > nw ? lm : nw + 1));
@@ -486,13 +502,22 @@ find_duplicate(ora_hnsw * g, int32_t element)
 	{
 		hnsw_element *ne = &g->elements[na->items[i].element];
 
+		int			added = 0;
+
 		if (memcmp(v, g->values + (size_t) ne->row * g->item_bytes, g->item_bytes) != 0)
 			return 0;			/* neighbors are ordered by distance: stop at the first different value */
+		/* AddDuplicateInMemory, :322-337: under the duplicate's lock in the parallel build */
+		if (g->locks)
+			pthread_rwlock_wrlock(&g->locks[na->items[i].element]);
 		if (ne->heaptids_length < HNSW_HEAPTIDS)
 		{
 			ne->heaptids[ne->heaptids_length++] = el->heaptids[0];
-			return 1;
+			added = 1;
 		}
+		if (g->locks)
+			pthread_rwlock_unlock(&g->locks[na->items[i].element]);
+		if (added)
+			return 1;
 	}
 	return 0;
 }
@@ -562,11 +587,12 @@ ora_hnsw_build(int ops, int dtype, int dim, const void *rows, int64_t n, int m, 
 		el->row = row;
 		el->heaptids[0] = row;
 		el->heaptids_length = 1;
+		el->dead = 0;
 		el->neighbors = calloc((size_t) level + 1, sizeof(neighbor_array));
 		g->nelements++;			/* visible to the search (it is never its own neighbor: not linked yet) */
 
 		/* InsertTupleInMemory, src/hnswbuild.c:436-476 */
-		find_element_neighbors(g, id);
+		find_element_neighbors(g, &g->vs, id, g->entry_point);
 
 		/* UpdateGraphInMemory, :410-431 */
 		if (find_duplicate(g, id))
@@ -591,6 +617,220 @@ ora_hnsw_build(int ops, int dtype, int dim, const void *rows, int64_t n, int m, 
 		if (g->entry_point < 0 || el->level > g->elements[g->entry_point].level)
 			g->entry_point = id;
 	}
+	return g;
+}
+
+/* ------------------------------------------------- the parallel in-memory build
+ *
+ * src/hnswbuild.c:1-40 (the locking rules), :366-480 (InsertTupleInMemory and what it calls), :700-1100 (workers
+ * scan the heap in parallel and insert into ONE shared graph).  Restated with threads: a lock per element taken
+ * shared to read a neighborhood (src/hnswutils.c:738-742) and exclusive to update it (:403-405) or to add a heap TID
+ * (:324-334); the entry point behind a reader/writer lock that an insert takes exclusive only when it may move the
+ * entry point, announced through a gate every insert passes first (:449-470).  Levels are drawn in heap order from
+ * the one seeded stream before the threads start, so they are the serial build's; which neighbors an element finds
+ * depends on what the other threads have linked by then -- as in the reference, the graph is not deterministic.
+ * With one thread the result IS the serial build's graph (tested).
+ */
+typedef struct
+{
+	ora_hnsw   *g;
+	int64_t		next;			/* next element to insert (atomic) */
+	pthread_rwlock_t entry_lock;
+	pthread_mutex_t entry_gate;
+}			par_build;
+
+static void
+insert_element_parallel(par_build * pb, visit_set * vs, int32_t id)
+{
+	ora_hnsw   *g = pb->g;
+	hnsw_element *el = &g->elements[id];
+	int32_t		ep;
+
+	/* wait while somebody is about to take the entry lock exclusively (:449-451) */
+	pthread_mutex_lock(&pb->entry_gate);
+	pthread_mutex_unlock(&pb->entry_gate);
+	pthread_rwlock_rdlock(&pb->entry_lock);
+	ep = g->entry_point;
+	if (ep < 0 || el->level > g->elements[ep].level)
+	{
+		/* this insert is likely to move the entry point: alone from here on (:457-470) */
+		pthread_rwlock_unlock(&pb->entry_lock);
+		pthread_mutex_lock(&pb->entry_gate);
+		pthread_rwlock_wrlock(&pb->entry_lock);
+		pthread_mutex_unlock(&pb->entry_gate);
+		ep = g->entry_point;
+	}
+
+	find_element_neighbors(g, vs, id, ep);
+
+	/* UpdateGraphInMemory, :410-431 */
+	if (find_duplicate(g, id))
+		el->dead = 1;
+	else
+	{
+		/* UpdateNeighborsInMemory, :379-407: this element's lists are copied under its own lock (others may be
+		 * linking to it by now), every neighbor is updated under the neighbor's lock */
+		for (int lc = el->level; lc >= 0; lc--)
+		{
+			int			lm = layer_m(g->m, lc);
+			hnsw_candidate *mine = malloc(sizeof(hnsw_candidate) * (size_t) lm);
+			int			nmine;
+
+			pthread_rwlock_rdlock(&g->locks[id]);
+			nmine = el->neighbors[lc].length;
+			memcpy(mine, el->neighbors[lc].items, sizeof(hnsw_candidate) * (size_t) nmine);
+			pthread_rwlock_unlock(&g->locks[id]);
+			for (int i = 0; i < nmine; i++)
+			{
+				int32_t		nb = mine[i].element;
+
+				pthread_rwlock_wrlock(&g->locks[nb]);
+				update_connection(g, &g->elements[nb].neighbors[lc], id, mine[i].distance, lm);
+				pthread_rwlock_unlock(&g->locks[nb]);
+			}
+			free(mine);
+		}
+		/* the entry point moves under the exclusive lock this insert took for that case (:428-430) */
+		if (ep < 0 || el->level > g->elements[ep].level)
+			g->entry_point = id;
+	}
+	pthread_rwlock_unlock(&pb->entry_lock);
+}
+
+static void *
+par_build_worker(void *arg)
+{
+	par_build  *pb = arg;
+	visit_set	vs = {0};
+
+	for (;;)
+	{
+		int64_t		id = __atomic_fetch_add(&pb->next, 1, __ATOMIC_RELAXED);
+
+		if (id >= pb->g->nelements)
+			break;
+		insert_element_parallel(pb, &vs, (int32_t) id);
+	}
+	free(vs.v);
+	return NULL;
+}
+
+ora_hnsw *
+ora_hnsw_build_parallel(int ops, int dtype, int dim, const void *rows, int64_t n, int m, int ef_construction,
+						uint64_t seed, int nthreads)
+{
+	ora_hnsw   *g = calloc(1, sizeof(ora_hnsw));
+	ora_prng	rng;
+	size_t		es = dtype == ORA_F32 ? sizeof(float) : sizeof(ora_half);
+	int			by_page = (int) ((8192 - 24 - 8 - 4 - 4) / 6 / m) - 2;
+	par_build	pb;
+	pthread_t  *threads;
+	int64_t		live = 0;
+	int32_t    *new_id;
+
+	if (nthreads < 1)
+		nthreads = 1;
+	g->ops = ops;
+	g->dtype = dtype;
+	g->dim = dim;
+	g->m = m;
+	g->ef_construction = ef_construction;
+	g->ml = 1.0 / log((double) m);
+	g->max_level = by_page < 63 ? by_page : 63;
+	g->item_bytes = (size_t) dim * es;
+	g->values = malloc(g->item_bytes * (size_t) (n > 0 ? n : 1));
+	g->entry_point = -1;
+	g->cap = n > 0 ? n : 1;
+	g->elements = malloc(sizeof(hnsw_element) * (size_t) g->cap);
+	ora_prng_seed(&rng, seed);
+
+	/* every element formed before the first insert: index value, level (the serial build's stream), neighbor
+	 * lists at their final capacity (HnswInitNeighbors, src/hnswutils.c:218-238: no list ever moves) */
+	for (int64_t row = 0; row < n; row++)
+	{
+		const void *src = (const char *) rows + (size_t) row * g->item_bytes;
+		void	   *dst = g->values + (size_t) row * g->item_bytes;
+		hnsw_element *el;
+		int			level;
+
+		if (ops == ORA_OPS_COSINE)
+		{
+			double		norm = dtype == ORA_F32 ? ora_vector_norm(dim, src) : ora_halfvec_l2_norm(dim, src);
+
+			if (!(norm > 0))
+				continue;
+			if (dtype == ORA_F32)
+				ora_l2_normalize(dim, src, dst);
+			else
+				ora_halfvec_l2_normalize(dim, src, dst);
+		}
+		else
+			memcpy(dst, src, g->item_bytes);
+		level = (int) (-log(ora_prng_double(&rng)) * g->ml);
+		if (level > g->max_level)
+			level = g->max_level;
+		el = &g->elements[g->nelements++];
+		el->level = level;
+		el->row = row;
+		el->heaptids[0] = row;
+		el->heaptids_length = 1;
+		el->dead = 0;
+		el->neighbors = calloc((size_t) level + 1, sizeof(neighbor_array));
+		for (int lc = 0; lc <= level; lc++)
+		{
+			el->neighbors[lc].cap = layer_m(m, lc);
+			el->neighbors[lc].items = malloc(sizeof(hnsw_candidate) * (size_t) el->neighbors[lc].cap);
+		}
+	}
+
+	g->locks = malloc(sizeof(pthread_rwlock_t) * (size_t) (g->nelements > 0 ? g->nelements : 1));
+	for (int64_t e = 0; e < g->nelements; e++)
+		pthread_rwlock_init(&g->locks[e], NULL);
+	pb.g = g;
+	pb.next = 0;
+	pthread_rwlock_init(&pb.entry_lock, NULL);
+	pthread_mutex_init(&pb.entry_gate, NULL);
+	threads = malloc(sizeof(pthread_t) * (size_t) nthreads);
+	for (int t = 1; t < nthreads; t++)
+		if (pthread_create(&threads[t], NULL, par_build_worker, &pb) != 0)
+			threads[t] = 0;
+	par_build_worker(&pb);
+	for (int t = 1; t < nthreads; t++)
+		if (threads[t])
+			pthread_join(threads[t], NULL);
+	free(threads);
+	pthread_mutex_destroy(&pb.entry_gate);
+	pthread_rwlock_destroy(&pb.entry_lock);
+	for (int64_t e = 0; e < g->nelements; e++)
+		pthread_rwlock_destroy(&g->locks[e]);
+	free(g->locks);
+	g->locks = NULL;
+
+	/* duplicates were never linked: drop them and renumber, as the serial build's reuse of their slot does */
+	new_id = malloc(sizeof(int32_t) * (size_t) (g->nelements > 0 ? g->nelements : 1));
+	for (int64_t e = 0; e < g->nelements; e++)
+		new_id[e] = g->elements[e].dead ? -1 : (int32_t) live++;
+	if (live != g->nelements)
+	{
+		for (int64_t e = 0; e < g->nelements; e++)
+		{
+			hnsw_element *el = &g->elements[e];
+
+			if (el->dead)
+			{
+				free_element(el);
+				continue;
+			}
+			for (int lc = 0; lc <= el->level; lc++)
+				for (int i = 0; i < el->neighbors[lc].length; i++)
+					el->neighbors[lc].items[i].element = new_id[el->neighbors[lc].items[i].element];
+			g->elements[new_id[e]] = *el;
+		}
+		if (g->entry_point >= 0)
+			g->entry_point = new_id[g->entry_point];
+		g->nelements = live;
+	}
+	free(new_id);
 	return g;
 }
 
@@ -628,6 +868,7 @@ ora_hnsw_import(int ops, int dtype, int dim, const void *values, int64_t n, int 
 		el->row = e;
 		el->heaptids[0] = e;
 		el->heaptids_length = 1;
+		el->dead = 0;
 		el->neighbors = calloc((size_t) el->level + 1, sizeof(neighbor_array));
 		for (int lc = 0; lc <= el->level; lc++)
 		{
@@ -657,7 +898,7 @@ ora_hnsw_free(ora_hnsw * g)
 		free_element(&g->elements[e]);
 	free(g->elements);
 	free(g->values);
-	free(g->visited);
+	free(g->vs.v);
 	free(g);
 }
 
@@ -739,12 +980,12 @@ ora_hnsw_search(const ora_hnsw * gc, const void *query, int ef_search, int k,
 	nep = 1;
 	for (int lc = g->elements[g->entry_point].level; lc >= 1; lc--)
 	{
-		nw = search_layer(g, q, ep, nep, 1, lc, &w, NULL);
+		nw = search_layer(g, &g->vs, q, ep, nep, 1, lc, &w, NULL);
 		free(ep);
 		ep = w;
 		nep = nw;
 	}
-	nw = search_layer(g, q, ep, nep, ef_search, 0, &w, &scored);
+	nw = search_layer(g, &g->vs, q, ep, nep, ef_search, 0, &w, &scored);
 	free(ep);
 
 	/* nearest first = from the tail of w; each element emits its heap tids last to first */

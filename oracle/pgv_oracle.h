@@ -178,6 +178,10 @@ void		ora_kmeans_lloyd_assign(int ops, int dtype, int dim, const void *samples, 
 typedef struct ora_hnsw ora_hnsw;
 ora_hnsw   *ora_hnsw_build(int ops, int dtype, int dim, const void *rows, int64_t n,
 						   int m, int ef_construction, uint64_t seed);
+/* the same algorithm run the way the reference's parallel build runs it (src/hnswbuild.c:366-480, per-element locks):
+ * nthreads inserters into one shared graph; one thread gives ora_hnsw_build's graph */
+ora_hnsw   *ora_hnsw_build_parallel(int ops, int dtype, int dim, const void *rows, int64_t n,
+									int m, int ef_construction, uint64_t seed, int nthreads);
 /* a graph built elsewhere, as neighbor tuples (see oracle_hnsw.c); only ora_hnsw_search applies */
 ora_hnsw   *ora_hnsw_import(int ops, int dtype, int dim, const void *values, int64_t n, int m,
 							const int32_t *levels, const int64_t *nbr_start, const int32_t *nbr, int32_t entry);

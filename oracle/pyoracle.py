@@ -119,6 +119,8 @@ class Oracle:
         if self.has_hnsw:
             L.ora_hnsw_build.restype = P
             L.ora_hnsw_build.argtypes = [I, I, I, P, I64, I, I, C.c_uint64]
+            L.ora_hnsw_build_parallel.restype = P
+            L.ora_hnsw_build_parallel.argtypes = [I, I, I, P, I64, I, I, C.c_uint64, I]
             L.ora_hnsw_import.restype = P
             L.ora_hnsw_import.argtypes = [I, I, I, P, I64, I, P, P, P, C.c_int32]
             L.ora_hnsw_free.argtypes = [P]
@@ -340,11 +342,17 @@ class Oracle:
 class HnswGraph:
     """in-memory HNSW graph built by the oracle's restatement of the reference build"""
 
-    def __init__(self, ora, ops, dtype, rows, m=16, ef_construction=64, seed=0):
+    def __init__(self, ora, ops, dtype, rows, m=16, ef_construction=64, seed=0, threads=0):
+        """threads = 0: the serial build (src/hnswbuild.c without parallel workers); threads >= 1: the reference's
+        parallel build restated (per-element locks, one shared graph) -- one thread gives the serial graph"""
         self.ora, self.ops, self.dtype = ora, ops, dtype
         self.rows = ora.arr(rows, dtype)
-        self.h = ora.lib.ora_hnsw_build(ops, dtype, self.rows.shape[1], _p(self.rows), self.rows.shape[0],
-                                        m, ef_construction, seed)
+        if threads > 0:
+            self.h = ora.lib.ora_hnsw_build_parallel(ops, dtype, self.rows.shape[1], _p(self.rows), self.rows.shape[0],
+                                                     m, ef_construction, seed, int(threads))
+        else:
+            self.h = ora.lib.ora_hnsw_build(ops, dtype, self.rows.shape[1], _p(self.rows), self.rows.shape[0],
+                                            m, ef_construction, seed)
         self.m = m
 
     @classmethod

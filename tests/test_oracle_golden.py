@@ -289,6 +289,59 @@ def test_hnsw_import_walks_like_the_graph_it_was_exported_from(oracle):
             np.testing.assert_array_equal(edist, dist)
 
 
+def test_hnsw_parallel_build_with_one_thread_is_the_serial_graph(oracle):
+    """ora_hnsw_build_parallel restates the reference's parallel in-memory build (src/hnswbuild.c:366-480: element
+    locks, entry lock + gate); with a single inserter nothing is concurrent and the graph must be the serial
+    build's, element for element -- duplicates and zero-norm rows included"""
+    for ops, dim in ((po.OPS_L2, 12), (po.OPS_COSINE, 7)):
+        data = gen(1200, dim, seed=41, dist="normal")
+        data[100:112] = data[100]          # 12 bytewise duplicates: two elements (10 heap tids + 2)
+        if ops == po.OPS_COSINE:
+            data[5] = 0                    # not indexed
+        a = po.HnswGraph(oracle, ops, po.ORA_F32, data, m=8, ef_construction=40, seed=6)
+        b = po.HnswGraph(oracle, ops, po.ORA_F32, data, m=8, ef_construction=40, seed=6, threads=1)
+        ea, eb = a.export(), b.export()
+        assert a.nelements == b.nelements and ea["entry"] == eb["entry"]
+        np.testing.assert_array_equal(ea["levels"], eb["levels"])
+        np.testing.assert_array_equal(ea["rows"], eb["rows"])
+        np.testing.assert_array_equal(ea["neighbors"], eb["neighbors"])
+        q = gen(1, dim, seed=42, dist="normal")[0]
+        assert a.search(q, 40, 10)[0].tolist() == b.search(q, 40, 10)[0].tolist()
+
+
+def test_hnsw_parallel_build_with_threads_keeps_the_invariants_and_the_recall(oracle):
+    """several inserters: which neighbors an element finds depends on the interleaving (as in the reference), so the
+    graph is checked by what must hold for every interleaving -- levels from the one seeded stream, list lengths
+    within m / 2m, valid ids, no self links, every neighbor on a layer it has, an entry point of the top level,
+    each element reachable by search -- and by its recall against the serial graph's"""
+    data = gen(4000, 16, seed=51, dist="normal")
+    serial = po.HnswGraph(oracle, po.OPS_L2, po.ORA_F32, data, m=8, ef_construction=40, seed=8)
+    par = po.HnswGraph(oracle, po.OPS_L2, po.ORA_F32, data, m=8, ef_construction=40, seed=8, threads=6)
+    es, ep = serial.export(), par.export()
+    assert par.nelements == serial.nelements == 4000
+    np.testing.assert_array_equal(ep["levels"], es["levels"])
+    assert ep["entry_level"] == int(ep["levels"].max())
+    nb = ep["neighbors"]
+    for e in range(0, 4000, 7):
+        for lc in range(int(ep["levels"][e]) + 1):
+            ids = nb[e, lc][nb[e, lc] >= 0]
+            assert len(ids) <= (16 if lc == 0 else 8) and e not in ids and len(set(ids.tolist())) == len(ids)
+            assert (ids < 4000).all() and (ep["levels"][ids] >= lc).all()
+        assert (nb[e, int(ep["levels"][e]) + 1:] < 0).all()
+    hits = {"serial": 0, "parallel": 0}
+    queries = gen(40, 16, seed=52, dist="normal")
+    for q in queries:
+        d = ((data.astype(np.float64) - q) ** 2).sum(axis=1)
+        kth = np.sort(d)[9]
+        hits["serial"] += int((d[serial.search(q, 40, 10)[0]] <= kth).sum())
+        hits["parallel"] += int((d[par.search(q, 40, 10)[0]] <= kth).sum())
+    assert hits["parallel"] >= hits["serial"] - 12      # 3 points of 400
+    # every element can be found again (it was linked into the graph)
+    for e in range(0, 4000, 97):
+        rows, dist, _ = par.search(data[e], 40, 1)
+        assert dist[0] == 0.0
+
+
 # ------------------------------------------------------------------ bit vectors
 def test_bit_distances_match_the_reference_known_answers(oracle):
     """hamming_distance / jaccard_distance (src/bitvec.c:45-70, src/bitutils.c:49-131) against every

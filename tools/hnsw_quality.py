@@ -4,9 +4,9 @@ compare with the graph the reference's serial algorithm builds on the same rows?
 
 Two steps, because the serial CPU build of 500 k x 1536 takes a quarter of an hour on one core:
 
-  python tools/hnsw_quality.py --oracle-build 500000       (CPU only, anywhere)
+  python tools/hnsw_quality.py --oracle-build 500000 [--threads 8] [--oracle-recall]       (CPU only, anywhere)
       builds the graph with the oracle's restatement of the reference's in-memory build
-      (src/hnswbuild.c:376-476, serial) and saves it to build/hnsw_oracle_<rows>.npz (git-ignored; travels with gpurun)
+      (src/hnswbuild.c:376-476; serial, or with --threads the parallel build with per-element locks) and saves it to build/hnsw_oracle_<rows>.npz (git-ignored; travels with gpurun)
   python tools/hnsw_quality.py --rows 500000 --batches 16,256,1024 --small-rows 50000   (on the GPU)
       same rows (numpy generator, same seed): (a) pgv_host_hnsw_build with max_batch 16 / 256 / 1024 and, on the first
       small-rows rows, also 1 (one insert at a time: the serial algorithm on the device); (b) every graph -- the
@@ -53,19 +53,44 @@ def oracle_build(a):
     ora = po.Oracle(native=True)
     data, _ = make_rows(a.oracle_build, a.dim, 8)
     t0 = time.perf_counter()
-    g = po.HnswGraph(ora, po.OPS_COSINE, po.ORA_F32, data, m=a.m, ef_construction=a.ef_construction, seed=1)
+    g = po.HnswGraph(ora, po.OPS_COSINE, po.ORA_F32, data, m=a.m, ef_construction=a.ef_construction, seed=1,
+                     threads=a.threads)
     secs = time.perf_counter() - t0
     ex = g.export_tuples()
     os.makedirs(os.path.dirname(oracle_path(a.oracle_build)), exist_ok=True)
     np.savez_compressed(oracle_path(a.oracle_build), rows=ex["rows"].astype(np.int32), levels=ex["levels"].astype(np.int8),
                         nbr_start=ex["nbr_start"], nbr=ex["nbr"], entry=ex["entry"], build_secs=secs, n=a.oracle_build,
-                        dim=a.dim, m=a.m, ef_construction=a.ef_construction)
-    print("oracle graph of %d rows built in %.1f s -> %s" % (a.oracle_build, secs, oracle_path(a.oracle_build)))
+                        dim=a.dim, m=a.m, ef_construction=a.ef_construction, threads=a.threads)
+    print("oracle graph of %d rows built in %.1f s (%s) -> %s" % (
+        a.oracle_build, secs, "serial" if a.threads == 0 else "%d inserter threads, per-element locks" % a.threads,
+        oracle_path(a.oracle_build)))
+    if a.oracle_recall:
+        # the oracle's own search over its graph against exact float64 inner products (CPU only): a record of the
+        # graph's quality that needs no GPU
+        _, q = make_rows(a.oracle_build, a.dim, a.queries)
+        q64 = q.astype(np.float64)
+        best = np.full((a.queries, a.k), -2.0)
+        for lo in range(0, a.oracle_build, 50000):
+            ip = q64 @ data[lo:lo + 50000].astype(np.float64).T
+            best = -np.sort(-np.concatenate([best, ip], axis=1), axis=1)[:, :a.k]
+        kth = best[:, -1]
+        rec = {}
+        for ef in (40, 100, 200):
+            hits = 0
+            for i in range(a.queries):
+                rows, _, _ = g.search(q[i], ef, a.k)
+                hits += int(((data[rows].astype(np.float64) @ q64[i]) >= kth[i] - 1e-9).sum())
+            rec[str(ef)] = hits / (a.queries * a.k)
+        print(json.dumps({"oracle_rows": a.oracle_build, "threads": a.threads, "build_secs": secs, "recall_at_10": rec}))
 
 
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--oracle-build", type=int, default=0)
+    ap.add_argument("--threads", type=int, default=0, help="oracle build: 0 = serial, N = the reference's parallel "
+                    "in-memory build restated with N inserter threads (ora_hnsw_build_parallel)")
+    ap.add_argument("--oracle-recall", action="store_true", help="oracle build: also search the graph with the oracle "
+                    "and print recall@k at ef_search 40 / 100 / 200 (CPU only)")
     ap.add_argument("--rows", type=int, default=500000)
     ap.add_argument("--small-rows", type=int, default=50000)
     ap.add_argument("--dim", type=int, default=1536)
