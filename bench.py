@@ -612,6 +612,25 @@ def hnsw_section(ctx, dev, args, failures, rows=1_000_000, dim=1536, m=16, efc=6
         if bad:
             failures.append("hnsw: %d of %d queries differ from the oracle's walk, first: %r" % (len(bad), checked, bad[0]))
         walk.close()
+        # the CPU side of the build: the reference's PARALLEL in-memory build restated (ora_hnsw_build_parallel:
+        # per-element locks, src/hnswbuild.c:366-480) on a bounded prefix of the same rows, every core the container
+        # grants.  An insert's cost grows with the graph, so the rate of a 20 k-row graph FLATTERS the CPU at 1 M.
+        try:
+            threads, _, _ = cpu_threads(ora)
+            sub = min(20000, int(host_rows.shape[0]))
+            t0 = time.perf_counter()
+            cg = po.HnswGraph(ora, po.OPS_COSINE, po.ORA_F32, np.ascontiguousarray(host_rows[:sub]), m=m,
+                              ef_construction=efc, seed=1, threads=threads)
+            cs = time.perf_counter() - t0
+            cg.close()
+            out["cpu_build_baseline"] = {
+                "kind": "port", "rows": sub, "threads": threads, "secs": cs, "rows_per_sec": sub / cs,
+                "gpu_rows_per_sec_at_full_size": rows / build_s,
+                "note": "oracle parallel build of the first %d rows; per-insert cost grows with the graph (1 M rows "
+                        "on 8 cores: 486 s, profiles/r03_hnsw_quality.md), so this rate is an upper bound for the "
+                        "CPU at %d rows" % (sub, rows)}
+        except Exception as e:  # noqa: BLE001
+            out["cpu_build_baseline"] = {"error": repr(e)}
     mirror.close()
     return out
 
