@@ -17,6 +17,14 @@ the per-GPU scan work per step is fixed), per-rank top-k are merged with one
 all-gather inside the library.  `--workload c3 / c5 --gpus 8` are BASELINE
 configs[2] / configs[4] at full size (10 M rows).
 
+How the line is produced (round 3's driver run lost most of it behind one hung section): the process the driver
+starts does the MANDATORY part itself, in this order -- build, recall against float64, the timed steps, oracle parity +
+cpu_baseline -- and from there on the line exists.  Every other section runs in a CHILD of this script
+(`--section NAME`), one at a time, each in its own session with its own budget (killed as a process group when it is
+not back), writing what it has measured to a file after every step: configs (other_configs + exact_scan), hnsw,
+build (pages + CPU build baseline), the PMC traffic passes, sweeps, and the sections that start backends LAST.  A
+failed, cut or skipped section is a `failures` entry and exit code 2 -- with the whole line printed.
+
 What the line carries besides the contract's fields (rank 0, N = 1):
   parity       the GPU's answers for `parity_checked_queries` queries compared with the CPU oracle's
                (tid, distance) for the SAME index and queries, tie-tolerant; a mismatch exits non-zero
@@ -27,21 +35,23 @@ What the line carries besides the contract's fields (rank 0, N = 1):
                the per-(query,row)-pair figure of SURVEY 8d is kept as algorithmic_GBps; passes =
                streamed / unique rows; traffic = HBM bytes per launch from a live rocprofv3 PMC pass
                of this same script (FETCH_SIZE x 2 per the gfx950 note + WRITE_SIZE), or null
-  batch_sweep  batch 1 (the amgettuple path: pgv_query_* and the C host glue), 16, 256
-  concurrent_backends  N independent backends / N pooled clients against ONE device mirror, as threads of one
-               process and as PROCESSES (pgv_index_export / import, pool state in a shared segment)
-  probes_sweep probes 1 / 10 / 32 / 100 with recall each; `uniform`: the same on U[0,1)^d data
-  build        kernel-only build (k-means + assignment, data resident in HBM) and build_secs_pages:
-               the product path pgv_host_ivf_build -> 8 KB pages -> stage -> upload from host memory
   cpu_baseline the oracle's restatement of ivfflatgettuple (reference flags + -march=native) on this
                box's host cores: pinned threads, spread placement, aggregate GB/s; bounded sample
-  cpu_build_baseline  the oracle's IvfflatKmeans (one thread, like the reference) on the build's own sample and
-               its assignment loop at 1 / all threads (extrapolated), beside build_secs
+               (.page_image: the same over the 8 KB pages the product build wrote)
   other_configs  c2, c3shard, c5shard (BASELINE configs[1], one GPU's share of [2] and [4]): QPS, recall, the scan
                kernel's roofline, oracle parity each
   hnsw         BASELINE configs[3] at full size (1 M x 1536, GPU-built graph): ef_search 40 / 100 / 200
   exact_scan   BASELINE configs[0] (10 k x 128, 100 queries) through pgv_exact_topk beside the oracle's loop
+  build        kernel-only build (k-means + assignment, data resident in HBM) and build_secs_pages:
+               the product path pgv_host_ivf_build -> 8 KB pages -> stage -> upload from host memory
+  cpu_build_baseline  the oracle's IvfflatKmeans (one thread, like the reference) on the build's own sample and
+               its assignment loop at 1 / all threads (extrapolated), beside build_secs
+  batch_sweep  batch 1 (the amgettuple path: pgv_query_* and the C host glue), 4, 16, 64, 256
+  probes_sweep probes 1 / 10 / 32 / 100 with recall each; `uniform`: the same on U[0,1)^d data
   bound_modes  the statistical and the worst-case completeness bound of the MFMA L2 paths side by side
+  concurrent_backends  N independent backends / N pooled clients against ONE device mirror, as threads of one
+               process and as PROCESSES (pgv_index_export / import, pool state in a shared segment)
+  sections     seconds, exit code and budget of every child
 """
 import argparse
 import ctypes
@@ -386,133 +396,78 @@ def cpu_build_assign(host_rows, dtype, ops, out):
         out["error"] = repr(e)
 
 
-def live_traffic(args, scan_ms):
-    """HBM bytes per list-scan launch, measured NOW: two rocprofv3 PMC passes (FETCH_SIZE, WRITE_SIZE;
-    never combined, MI355X_MICROARCH.md) of this same script on a short run.  Launches of the scan
-    kernel whose duration is within 35 % of this run's average are the timed list scans."""
-    exe = shutil.which("rocprofv3")
-    if not exe:
-        return None, "rocprofv3 not on PATH"
-    out = {}
-    base = [sys.executable, os.path.abspath(__file__), "--workload", args.workload, "--batch", str(args.batch),
-            "--steps", "4", "--warmup", "1", "--seed", str(args.seed), "--child"]
-    if args.probes:
-        base += ["--probes", str(args.probes)]
-    env = dict(os.environ, TMPDIR="/tmp")
-    for counter in ("FETCH_SIZE", "WRITE_SIZE"):
-        d = tempfile.mkdtemp(prefix="pgv_pmc_", dir="/tmp")
-        try:
-            r = subprocess.run([exe, "--pmc", counter, "--kernel-trace", "-d", d, "-o", "pmc", "--output-format", "csv",
-                                "--"] + base, cwd="/tmp", env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE,
-                               timeout=300)
-            files = glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True)
-            if r.returncode != 0 or not files:
-                return None, "%s pass failed (rc %d)" % (counter, r.returncode)
-            import csv
-            vals = []
-            for row in csv.DictReader(open(files[0])):
-                if row.get("Counter_Name") != counter:
-                    continue
-                name = row["Kernel_Name"]
-                if "tile_scan_kernel" not in name and "scan_kernel" not in name:
-                    continue
-                dur = (int(row["End_Timestamp"]) - int(row["Start_Timestamp"])) / 1e6
-                if abs(dur - scan_ms) <= 0.35 * scan_ms:
-                    vals.append(float(row["Counter_Value"]))
-            if not vals:
-                return None, "no %s rows matched the scan kernel" % counter
-            out[counter] = (sum(vals) / len(vals), len(vals))
-        except Exception as e:  # profiling must never sink the number
-            return None, "%s pass: %r" % (counter, e)
-        finally:
-            shutil.rmtree(d, ignore_errors=True)
-    # rocprofv3 reports both in KB; wide coalesced reads are tallied at half their size on gfx950
-    traffic = 2.0 * out["FETCH_SIZE"][0] * 1024.0 + out["WRITE_SIZE"][0] * 1024.0
-    return traffic, "live rocprofv3 --pmc passes of this script: 2 x FETCH_SIZE (%d launches) + WRITE_SIZE (%d)" % (
-        out["FETCH_SIZE"][1], out["WRITE_SIZE"][1])
-
-
-def concurrent_backends(index, device, qhost, queries, probes, k, args, dev):
-    """what a server looks like to the device: N backends, each with a context of its own (stream, scratch) and a
-    view of the same uploaded index.  (a) N backends (threads of a plain C driver), one query at a time each
-    (pgv_query_rank + pgv_query_scan, the amgettuple path); (b) two submitters of 1024-query batches on two streams."""
-    import ctypes as C
-    out = {"single_query": {}}
-    so = os.path.join(ROOT, "build", "tools", "libbackends.so")
-    src = os.path.join(ROOT, "tools", "backends_driver.c")
-    if not os.path.exists(so) or os.path.getmtime(so) < os.path.getmtime(src):
-        from pgvector_amd import _lib
-        os.makedirs(os.path.dirname(so), exist_ok=True)
-        libdir = os.path.dirname(_lib.LIB_PATH)
-        subprocess.run(["gcc", "-O2", "-shared", "-fPIC", "-pthread", "-I" + os.path.join(ROOT, "include"),
-                        "-I" + os.path.join(ROOT, "pgvector_amd", "host"), src, "-o", so,
-                        "-L" + libdir, "-lpgv_host", "-lpgv_hip", "-Wl,-rpath," + libdir], check=True)
-    drv = C.CDLL(so)
-    drv.backends_run.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_size_t, C.c_int, C.c_int,
-                                 C.POINTER(C.c_double)]
+def concurrent_backends(index, device, qhost, queries, probes, k, args, dev, out, flush):
+    """what a server looks like to the device: N backends against ONE uploaded index.  (a) backends as threads of a
+    plain C driver, one query at a time each (pgv_query_rank + pgv_query_scan, the amgettuple path); the same as
+    PROCESSES that import the mirror; clients behind the pooler as threads and as processes; (b) two submitters of
+    1024-query batches on two streams.  Every row has a deadline of its own and says where it was stuck; `out` is
+    flushed after every row, so a run that is cut still carries the rows it finished."""
+    from pgvector_amd import _host
     qh = np.ascontiguousarray(qhost)
-    res = (C.c_double * 3)()
+    row_deadline = 25.0
+    out["single_query"] = {}
     for nb in (1, 2, 4, 8, 16, 32):
-        rc = drv.backends_run(index.h, device, nb, 400, qh.ctypes.data, qh.shape[0], qh.strides[0], probes, k, res)
-        if rc != 0:
-            out["single_query"][str(nb)] = {"error": "backends_run rc %d" % rc}
-            break
-        out["single_query"][str(nb)] = {"qps": res[0], "latency_us_p50": res[1], "latency_us_p90": res[2]}
+        log("  backends: %d threads" % nb)
+        try:
+            out["single_query"][str(nb)] = _host.run_backend_threads(index, qh, probes, k, nb, 400, device, row_deadline)
+        except Exception as e:  # noqa: BLE001
+            out["single_query"][str(nb)] = {"error": repr(e)}
+            flush()
+            raise   # a stuck thread still sits in the library: nothing after it in this process can be trusted
+        flush()
     out["single_query"]["driver"] = ("tools/backends_driver.c: THREADS of one process over the C ABI, one pgv_ctx + "
                                      "pgv_index_share view + pgv_query per backend, pgv_query_rank + pgv_query_scan per query; "
                                      "at most PGV_MAX_INFLIGHT_SCANS (16) scans in flight per process")
     # the same with PROCESSES, which is what a Postgres backend is: every process imports the ONE device mirror
     # (pgv_index_export / pgv_index_import: hipIpc, no copy) and scans it on a context and stream of its own
-    from pgvector_amd import _host
     out["single_query_processes"] = {}
     # (32 own-context processes -- 7-10 k QPS on these boxes, profiles/r03/processes_*.json, DESIGN 4.8b -- only with
     # --all-process-rows: that row costs the most and teaches the least in a driver run)
-    t_sec = time.perf_counter()
     for nb in ((1, 4, 8, 16, 32) if args.all_process_rows else (1, 4, 8, 16)):
+        log("  backends: %d processes" % nb)
         try:
-            out["single_query_processes"][str(nb)] = _host.run_backend_processes(index, qh, probes, k, 0, nb, 300)
+            out["single_query_processes"][str(nb)] = _host.run_backend_processes(index, qh, probes, k, 0, nb, 300,
+                                                                                 deadline_s=row_deadline)
         except Exception as e:  # noqa: BLE001
             out["single_query_processes"][str(nb)] = {"error": repr(e)}
+            flush()
             break
-        if time.perf_counter() - t_sec > 60:   # a slow box: the rest of the row is not worth the driver's time
-            out["single_query_processes"]["cut_short_after_secs"] = time.perf_counter() - t_sec
-            break
+        flush()
     out["single_query_processes"]["driver"] = ("tools/pgv_backend.c `query`: one PROCESS per backend (fork + exec), the "
                                                "mirror imported from the owner's export handle, pgv_query_rank + "
                                                "pgv_query_scan per query; HBM holds the index once")
     # (a') the same kind of clients behind the host glue's pooler (ivf_pool.c): one query each, batched on arrival
-    drv.pool_run.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_size_t,
-                             C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_double)]
-    res4 = (C.c_double * 4)()
     out["pooled_single_query"] = {}
     for nc in (16, 64, 256):
-        rc = drv.pool_run(index.h, device, index.dtype, index.dim, nc, max(40, 6000 // nc), qh.ctypes.data, qh.shape[0],
-                          qh.strides[0], probes, k, 1024, 50, 2, res4)
-        if rc != 0:
-            out["pooled_single_query"][str(nc)] = {"error": "pool_run rc %d" % rc}
-            break
-        out["pooled_single_query"][str(nc)] = {"qps": res4[0], "latency_us_p50": res4[1], "latency_us_p90": res4[2],
-                                               "mean_batch": res4[3]}
+        log("  backends: %d pooled client threads" % nc)
+        try:
+            out["pooled_single_query"][str(nc)] = _host.run_pooled_threads(index, qh, probes, k, nc, max(40, 6000 // nc),
+                                                                           1024, 50, 2, device, row_deadline)
+        except Exception as e:  # noqa: BLE001
+            out["pooled_single_query"][str(nc)] = {"error": repr(e)}
+            flush()
+            raise
+        flush()
     out["pooled_single_query"]["pool"] = ("pgv_host_pool_*: client THREADS block in pgv_host_pool_search with one query each; "
                                           "max_batch 1024, max_wait 50 us, 2 lanes (contexts); host buffers in and out")
     # ... and with GPU-less client PROCESSES in front of two lane-server processes: the pool's slots, lane words and
     # payload ring live in a shared segment (non-private futexes, a robust process-shared mutex)
     out["pooled_single_query_processes"] = {}
-    t_sec = time.perf_counter()
     for nc in (16, 64, 256):
-        if time.perf_counter() - t_sec > 60:
-            out["pooled_single_query_processes"]["cut_short_after_secs"] = time.perf_counter() - t_sec
-            break
+        log("  backends: %d pooled client processes" % nc)
         try:
             out["pooled_single_query_processes"][str(nc)] = _host.run_backend_processes(
                 index, qh, probes, k, 1, nc, max(40, 6000 // nc), max_batch=1024, max_wait_us=50, lanes=2,
-                server_processes=True)
+                server_processes=True, deadline_s=row_deadline)
         except Exception as e:  # noqa: BLE001
             out["pooled_single_query_processes"][str(nc)] = {"error": repr(e)}
+            flush()
             break
+        flush()
     out["pooled_single_query_processes"]["pool"] = ("tools/pgv_backend.c `client` x N + `serve` x 2 lanes: every client and "
                                                     "every lane leader is a process; the leaders import the mirror")
     # (b) batches from two submitters
+    log("  backends: two batch submitters")
     ctx2 = api.Context(device)
     v2 = index.share(ctx2)
     bufs = [tuple(torch.empty((args.batch, k), device=dev, dtype=dt) for dt in (torch.float32, torch.int64, torch.int64))
@@ -526,6 +481,7 @@ def concurrent_backends(index, device, qhost, queries, probes, k, args, dev):
     out["batches_from_two_submitters"] = {"qps": args.batch / s, "ms_per_batch": s * 1e3,
                                           "note": "alternate %d-query batches on two contexts (two streams): the second "
                                                   "one's ranking / planning / top-k run under the first one's scan" % args.batch}
+    flush()
     v2.close()
     ctx2.close()
     return out
@@ -798,11 +754,22 @@ def timed_steps(fn, steps, warmup=2):
     return (time.perf_counter() - t0) / steps
 
 
-# The ONE JSON line must come out whatever an optional section does.  The timed region and the parity / recall checks
-# are over long before the sections that start processes, build the HNSW graph or run rocprofv3; should one of those
-# not return (a hung child, a wedged profiler), the watchdog prints the line as far as it has got -- with a `failures`
-# entry naming the section -- and ends the process.
+# ---------------------------------------------------------------------------------------------------------------------
+# How the ONE JSON line is kept safe (round 3's driver run lost everything behind a section that hung):
+#   1. the parent process does only what the line cannot do without, in this order: build, recall, the timed steps,
+#      oracle parity + cpu_baseline.  From there on the line exists and is complete as far as the contract goes.
+#   2. everything else runs in CHILD processes of this same script (`--section NAME`), one after the other, each in a
+#      session of its own with a budget of its own; a child that is not back in time is killed with its whole process
+#      group and the next one starts.  A child writes what it has measured to a file after every step, so a cut
+#      section still contributes the rows it finished.  Order: other_configs + exact_scan, hnsw, build (pages, CPU
+#      build baseline), PMC traffic, sweeps, and the sections that start backends LAST.
+#   3. a failed, cut or skipped section is a `failures` entry and the exit code is 2 -- with the full line printed.
+#   4. the watchdog is the last resort for the parent itself: it prints the line as far as it has got and exits 2 (3
+#      without a line).
 WATCH = {"line": None, "fd": None, "rank": 0, "section": "setup", "done": False}
+
+SECTION_BUDGET_S = {"configs": 150, "hnsw": 150, "build": 150, "sweeps": 150, "backends": 150}
+SECTION_ORDER = ("configs", "hnsw", "build", "traffic", "sweeps", "backends")
 
 
 def watchdog(deadline_s):
@@ -820,13 +787,532 @@ def watchdog(deadline_s):
                 snap = dict(line)
                 snap.setdefault("failures", [])
                 snap["failures"] = list(snap["failures"]) + [
-                    "watchdog: section '%s' had not returned after %d s; the line ends here" % (WATCH["section"], deadline_s)]
+                    "watchdog: '%s' had not returned after %d s; the line ends here" % (WATCH["section"], deadline_s)]
                 snap["bench_wall_secs"] = deadline_s
                 os.write(WATCH["fd"], (json.dumps(snap, default=str) + "\n").encode())
                 break
             except Exception:  # noqa: BLE001  (the dict was being written to: try again)
                 time.sleep(0.05)
-    os._exit(0 if line is not None else 3)
+    # a cut line is a failed run, like any other `failures` entry (other ranks just leave)
+    os._exit((2 if WATCH["rank"] == 0 else 0) if line is not None else 3)
+
+
+class SectionOut:
+    """what a section child has measured so far, rewritten (atomically) after every step"""
+
+    def __init__(self, path):
+        self.path = path
+        self.data = {"failures": [], "_at": "start"}
+
+    def flush(self):
+        if not self.path:
+            return
+        tmp = self.path + ".tmp"
+        with open(tmp, "w") as f:
+            json.dump(self.data, f, default=str)
+        os.replace(tmp, self.path)
+
+    def at(self, what):
+        self.data["_at"] = what
+        log("[%s] %s" % (time.strftime("%H:%M:%S"), what))
+        self.flush()
+
+    def put(self, key, value):
+        self.data[key] = value
+        self.flush()
+
+
+def run_group(cmd, budget_s, env=None, cwd=None, stdout=None):
+    """a child in a session of its own; not back after budget_s: SIGKILL to its whole process group, at most 5 s of
+    waiting for the corpse (a process stuck in the driver is left to init).  Returns (rc or None, timed_out, secs)."""
+    import signal
+    t0 = time.perf_counter()
+    p = subprocess.Popen(cmd, stdin=subprocess.DEVNULL, stdout=stdout if stdout is not None else 2, stderr=2,
+                         start_new_session=True, env=env, cwd=cwd)
+    timed_out = False
+    try:
+        rc = p.wait(timeout=budget_s)
+    except subprocess.TimeoutExpired:
+        timed_out = True
+        try:
+            os.killpg(p.pid, signal.SIGKILL)
+        except OSError:
+            pass
+        try:
+            rc = p.wait(timeout=5)
+        except subprocess.TimeoutExpired:
+            rc = None
+    else:
+        try:
+            os.killpg(p.pid, signal.SIGKILL)   # stragglers of a child that is itself gone (backend processes)
+        except OSError:
+            pass
+    return rc, timed_out, time.perf_counter() - t0
+
+
+def section_cmd(name, args, path):
+    cmd = [sys.executable, os.path.abspath(__file__), "--section", name, "--section-out", path, "--workload", args.workload,
+           "--batch", str(args.batch), "--k", str(args.k), "--seed", str(args.seed), "--recall-queries", str(args.recall_queries),
+           "--watchdog-secs", "0"]
+    if args.probes:
+        cmd += ["--probes", str(args.probes)]
+    if args.no_cpu_baseline:
+        cmd.append("--no-cpu-baseline")
+    if args.all_process_rows:
+        cmd.append("--all-process-rows")
+    return cmd
+
+
+def run_section(name, args, budget_s, line, failures):
+    """one optional section in a child of this script; merges what it wrote into the line"""
+    fd, path = tempfile.mkstemp(prefix="pgv_section_%s_" % name, suffix=".json", dir="/tmp")
+    os.close(fd)
+    os.unlink(path)
+    cmd = section_cmd(name, args, path)
+    log("[%s] section %s: start (budget %d s)" % (time.strftime("%H:%M:%S"), name, budget_s))
+    rc, timed_out, secs = run_group(cmd, budget_s)
+    data = {}
+    try:
+        with open(path) as f:
+            data = json.load(f)
+    except Exception:  # noqa: BLE001
+        pass
+    for junk in (path, path + ".tmp"):
+        try:
+            os.unlink(junk)
+        except OSError:
+            pass
+    for key, val in data.items():
+        if key not in ("failures", "_at"):
+            line[key] = val
+    failures.extend("%s: %s" % (name, f) for f in data.get("failures", []))
+    line.setdefault("sections", {})[name] = {"secs": secs, "rc": rc, "timed_out": timed_out, "budget_secs": budget_s}
+    if timed_out:
+        failures.append("section %s: not back after %d s, killed (it had reached: %s)" % (name, budget_s, data.get("_at", "nothing")))
+    elif rc != 0:
+        failures.append("section %s: exit code %r (it had reached: %s)" % (name, rc, data.get("_at", "nothing")))
+    log("[%s] section %s: %.1f s, rc %r%s" % (time.strftime("%H:%M:%S"), name, secs, rc, ", CUT" if timed_out else ""))
+
+
+def live_traffic(args, scan_ms, budget_s=110):
+    """HBM bytes per list-scan launch, measured NOW: two rocprofv3 PMC passes (FETCH_SIZE, WRITE_SIZE;
+    never combined, MI355X_MICROARCH.md) of this same script on a short run.  Launches of the scan
+    kernel whose duration is within 35 % of this run's average are the timed list scans."""
+    exe = shutil.which("rocprofv3")
+    if not exe:
+        return None, "rocprofv3 not on PATH"
+    out = {}
+    base = [sys.executable, os.path.abspath(__file__), "--workload", args.workload, "--batch", str(args.batch),
+            "--steps", "4", "--warmup", "1", "--seed", str(args.seed), "--child", "--watchdog-secs", "0"]
+    if args.probes:
+        base += ["--probes", str(args.probes)]
+    env = dict(os.environ, TMPDIR="/tmp")
+    for counter in ("FETCH_SIZE", "WRITE_SIZE"):
+        d = tempfile.mkdtemp(prefix="pgv_pmc_", dir="/tmp")
+        try:
+            log("[%s] traffic: rocprofv3 --pmc %s" % (time.strftime("%H:%M:%S"), counter))
+            with open(os.path.join(d, "stdout.txt"), "w") as so:
+                rc, timed_out, _ = run_group([exe, "--pmc", counter, "--kernel-trace", "-d", d, "-o", "pmc", "--output-format",
+                                              "csv", "--"] + base, budget_s, env=env, cwd="/tmp", stdout=so)
+            if timed_out:
+                return None, "%s pass not back after %d s (killed)" % (counter, budget_s)
+            files = glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True)
+            if rc != 0 or not files:
+                return None, "%s pass failed (rc %r)" % (counter, rc)
+            import csv
+            vals = []
+            for row in csv.DictReader(open(files[0])):
+                if row.get("Counter_Name") != counter:
+                    continue
+                name = row["Kernel_Name"]
+                if "tile_scan_kernel" not in name and "scan_kernel" not in name:
+                    continue
+                dur = (int(row["End_Timestamp"]) - int(row["Start_Timestamp"])) / 1e6
+                if abs(dur - scan_ms) <= 0.35 * scan_ms:
+                    vals.append(float(row["Counter_Value"]))
+            if not vals:
+                return None, "no %s rows matched the scan kernel" % counter
+            out[counter] = (sum(vals) / len(vals), len(vals))
+        except Exception as e:  # profiling must never sink the number
+            return None, "%s pass: %r" % (counter, e)
+        finally:
+            shutil.rmtree(d, ignore_errors=True)
+    # rocprofv3 reports both in KB; wide coalesced reads are tallied at half their size on gfx950
+    traffic = 2.0 * out["FETCH_SIZE"][0] * 1024.0 + out["WRITE_SIZE"][0] * 1024.0
+    return traffic, "live rocprofv3 --pmc passes of this script: 2 x FETCH_SIZE (%d launches) + WRITE_SIZE (%d)" % (
+        out["FETCH_SIZE"][1], out["WRITE_SIZE"][1])
+
+
+class Headline:
+    """the headline workload resident on one GPU: data, the built index, the query pool"""
+
+
+def headline_setup(args, dev, ctx, world=1, rank=0, comm=None, keep_host_rows=False):
+    H = Headline()
+    H.n, H.dim, H.lists, H.probes, H.tname, H.oname = WORKLOADS[args.workload]
+    H.dtype = api.PGV_F32 if H.tname == "f32" else api.PGV_F16
+    H.tdtype = torch.float32 if H.tname == "f32" else torch.float16
+    H.ops = api.PGV_OPS_L2 if H.oname == "l2" else api.PGV_OPS_IP
+    H.metric = api.PGV_L2SQ if H.oname == "l2" else api.PGV_NEG_IP
+    H.esize = 4 if H.tname == "f32" else 2
+    if args.probes:
+        H.probes = args.probes
+    H.k = args.k
+    H.components = max(H.lists // 4, 1)
+    row_lo, row_hi = sharding.row_shard(H.n, rank, world)
+    data, H.means = gen_mixture(H.n, H.dim, H.components, 0.1, args.seed, dev, lo=row_lo, hi=row_hi)
+    data = data.to(H.tdtype)
+    log("data: rows [%d, %d) of %d x %d %s generated" % (row_lo, row_hi, H.n, H.dim, H.tname))
+    ctx.set_profiling(True)
+    ctx.reset_stats()
+    H.centers, H.offsets, H.vectors, H.tids, H.iters, H.build_t, H.index = build_index(
+        ctx, data, H.lists, args.seed, world, rank, H.dtype, H.ops, H.metric, comm, row_lo=row_lo, n_global=H.n)
+    H.build_stats = ctx.stats()
+    ctx.set_profiling(False)
+    log("build: %s (k-means iterations %d)" % ({a: round(b, 3) for a, b in H.build_t.items()}, H.iters))
+    H.local_rows = int(H.vectors.shape[0])
+    H.host_rows = data.cpu().numpy() if keep_host_rows else None
+    del data
+    H.total_batch = args.batch * world
+    H.pool = 8
+    queries, _ = gen_mixture(H.total_batch * H.pool, H.dim, H.components, 0.1, args.seed + 100, dev, means=H.means)
+    H.queries = queries.to(H.tdtype).view(H.pool, H.total_batch, H.dim)
+    return H
+
+
+# ------------------------------------------------------------------------------------------------ the section children
+def section_configs(args, dev, ctx, out):
+    """BASELINE's other IVFFlat configs on this GPU (c2 = configs[1], one GPU's share of configs[2] and configs[4]),
+    then configs[0]: the exact scan"""
+    fails = out.data["failures"]
+    oc = {}
+    for wname in ("c2", "c3shard", "c5shard"):
+        out.at("other_configs." + wname)
+        try:
+            oc[wname] = run_workload(ctx, dev, wname, args, fails)
+            log("%s: %.0f QPS, recall %.4f, roofline frac %.2f" % (
+                wname, oc[wname]["qps"], oc[wname]["recall_at_10"], oc[wname]["roofline"]["frac"]))
+        except Exception as e:  # noqa: BLE001
+            oc[wname] = {"error": repr(e)}
+            fails.append("other_configs.%s: %r" % (wname, e))
+        out.put("other_configs", oc)
+        torch.cuda.empty_cache()
+    out.at("exact_scan")
+    try:
+        out.put("exact_scan", exact_scan_section(ctx, dev, args, fails))
+    except Exception as e:  # noqa: BLE001
+        out.put("exact_scan", {"error": repr(e)})
+        fails.append("exact_scan: %r" % (e,))
+
+
+def section_hnsw(args, dev, ctx, out):
+    """BASELINE configs[3] at full size"""
+    out.at("hnsw: 1 M x 1536 build + ef_search 40 / 100 / 200")
+    out.put("hnsw", hnsw_section(ctx, dev, args, out.data["failures"]))
+
+
+def section_build(args, dev, ctx, out):
+    """the product build path through 8 KB pages (+ the oracle walking those very pages: parity and the page-image CPU
+    baseline), and the CPU build baseline beside build_secs"""
+    from pgvector_amd import _host
+    fails = out.data["failures"]
+    out.at("build: headline data + kernel-only build")
+    H = headline_setup(args, dev, ctx, keep_host_rows=True)
+    n, dim, lists, probes, k = H.n, H.dim, H.lists, H.probes, H.k
+    rq = min(args.recall_queries, H.total_batch)
+    rqueries = H.queries[1][:rq].contiguous()
+    exact_d, _ = exact_topk_fp64(H.vectors, rqueries, k, H.metric)
+    gd0, _, _ = H.index.search_batch(rqueries, probes, k, want_tid=True)
+    recall = recall_at_k(gd0, exact_d, k)
+    out.at("build: pgv_host_ivf_build_mirror through pages")
+    t0 = time.perf_counter()
+    host_tids = (np.arange(n, dtype=np.uint64) << np.uint64(16)) | np.uint64(1)
+    g = np.random.default_rng(args.seed + 1)
+    ns = min(max(50 * lists, 10000), n)
+    host_samples = H.host_rows[np.sort(g.choice(n, ns, replace=False))]
+    t_sample = time.perf_counter() - t0
+    # the CPU k-means (one core, like the reference) starts now and runs beside the GPU work below
+    cpu_build, cpu_build_thread = {}, None
+    if not args.no_cpu_baseline:
+        cpu_build_thread = threading.Thread(target=cpu_build_kmeans,
+                                            args=(host_samples, lists, H.dtype, H.ops, args.seed + 2, cpu_build))
+        cpu_build_thread.start()
+    rel = _host.Relation()
+    t0 = time.perf_counter()
+    pix = rel.build_mirror(ctx, H.ops, H.dtype, lists, H.host_rows, host_tids, host_samples, api.make_rng(seed=args.seed + 2))
+    ctx.sync()
+    t_build = time.perf_counter() - t0
+    ph = (ctypes.c_double * 5)()
+    _host.lib.pgv_host_ivf_build_phases(ph)
+    # the old route to a mirror of these pages (a backend that finds the index on disk): stage + upload
+    t0 = time.perf_counter()
+    img = rel.stage(H.dtype)
+    t_stage = time.perf_counter() - t0
+    t0 = time.perf_counter()
+    pix2 = api.IvfIndex(ctx, H.metric, H.dtype, dim, img.centers, img.list_offsets, img.vectors, img.tids)
+    ctx.sync()
+    t_upload = time.perf_counter() - t0
+    # the page-built index answers like an index should: recall against the same exact ground truth, and the
+    # mirror that came with the build equals the one staged out of the pages
+    gd, gs, gt = pix.search_batch(rqueries, probes, k, want_tid=True)
+    gd2, gs2, gt2 = pix2.search_batch(rqueries, probes, k, want_tid=True)
+    same_mirror = bool(torch.equal(gs, gs2) and torch.equal(gt, gt2) and torch.equal(gd, gd2))
+    if not same_mirror:
+        fails.append("the mirror pgv_host_ivf_build_mirror returns differs from the one staged out of its pages")
+    pix2.close()
+    prec = recall_at_k(gd, exact_d, k)
+    out.data["build_secs_pages"] = t_build
+    out.put("build_pages", {
+        "path": "pgv_host_ivf_build_mirror: host rows -> k-means on the GPU (helper thread) WHILE the rows go to the "
+                "device (pgv_builder_add without centers: copies on the builder's stream) -> assignment of all rows + "
+                "order by list on the device = the mirror (pgv_builder_set_centers / _finish) -> 8 KB pages "
+                "written from the mirror's rows as they come back (pgv_index_drain), page array zeroed in the "
+                "background meanwhile; no host sort, no staging pass, no second upload",
+        "build_secs": t_build, "sample_secs": t_sample,
+        "build_phases_secs": dict(zip(("normalise", "kmeans_left_after_upload", "upload_beside_kmeans",
+                                       "assign_and_order_by_list_on_device", "page_writer"), [float(x) for x in ph])),
+        "mirror_from_pages_secs": {"stage": t_stage, "upload": t_upload,
+                                   "note": "what a backend pays that finds the index on disk (not part of the build)"},
+        "mirror_equals_staged_pages": same_mirror,
+        "pages": int(rel.nblocks), "page_bytes": int(rel.nblocks) * 8192,
+        "recall_at_10": prec, "kernel_only_build_secs_this_process": H.build_t["total"]})
+    if prec < recall - 0.02:
+        fails.append("page-built index recall %.4f below the torch-laid-out index's %.4f" % (prec, recall))
+    if not args.no_cpu_baseline:
+        out.at("build: the oracle walking the pages the product build wrote")
+        from oracle import pyoracle as po
+        ora = po.Oracle(native=True)
+        oops = po.OPS_L2 if H.ops == api.PGV_OPS_L2 else po.OPS_IP
+        odt = po.ORA_F32 if H.dtype == api.PGV_F32 else po.ORA_F16
+        cores, cpus, quota = cpu_threads(ora)
+        pq = min(256, H.total_batch)
+        pqueries = H.queries[1][:pq].contiguous()
+        pqh = pqueries.cpu().numpy()
+        pages = (rel.rel.pages, int(rel.nblocks))
+        pa, ptotal, pel = ora.bench_search(None, pqh, probes, k, cores, 6.0, pages=pages, ops=oops, dtype=odt)
+        _, psingle, psingle_el = ora.bench_search(None, pqh[:64], probes, k, 1, 3.0, pages=pages, ops=oops, dtype=odt)
+        gd2, _, gt2 = pix.search_batch(pqueries, probes, k, want_tid=True)
+        ctx.sync()
+        gd2, gt2 = gd2.cpu().numpy(), gt2.cpu().numpy()
+        bad2 = []
+        for i in range(pq):
+            wt, wd = pa[i]
+            why = topk_equiv(gt2[i][:len(wt)].astype(np.uint64).tolist(), gd2[i][:len(wt)], wt.tolist(), wd)
+            if why:
+                bad2.append((i, why))
+        if bad2:
+            fails.append("page-built index: %d of %d queries differ from the oracle walking the same pages, first: %r"
+                         % (len(bad2), pq, bad2[0]))
+        out.put("cpu_baseline_page_image", {
+            "value": ptotal / pel, "unit": "queries/s", "cores": cores, "kind": "port",
+            "single_thread_qps": psingle / psingle_el,
+            "layout": "emulated 8 KB page image (oracle_pages.c walks meta / list / entry pages like "
+                      "src/ivfscan.c:47-187; no buffer pins, fmgr or tuplesort copies: still an upper bound)",
+            "sample": "%d queries in %.1f s on %d threads (%d more on 1 thread) over the %d pages the product build wrote"
+                      % (ptotal, pel, cores, psingle, int(rel.nblocks)),
+            "parity_of_the_page_built_index": {"checked_queries": pq, "mismatches": len(bad2)}})
+    pix.close()
+    if cpu_build_thread is not None:
+        out.at("build: CPU build baseline (k-means on one core, assignment subsample)")
+        cpu_build_thread.join()
+        cpu_build_assign(H.host_rows, H.dtype, H.ops, cpu_build)
+        cpu_build["gpu_build_secs"] = H.build_t["total"]
+        cpu_build["gpu_build_secs_pages"] = t_build
+        if "error" in cpu_build:
+            fails.append("cpu_build_baseline: %s" % cpu_build["error"])
+        out.put("cpu_build_baseline", cpu_build)
+    H.index.close()
+
+
+def section_sweeps(args, dev, ctx, out):
+    """batch 1 (the amgettuple path) / 4 / 16 / 64 / 256 / the headline batch, probes 1 / 10 / 32 / 100, the two
+    completeness bounds side by side, uniform data"""
+    fails = out.data["failures"]
+    out.at("sweeps: headline data + build")
+    H = headline_setup(args, dev, ctx)
+    index, queries, probes, k, dim, n, lists = H.index, H.queries, H.probes, H.k, H.dim, H.n, H.lists
+    total_batch, pool = H.total_batch, H.pool
+    out_d = torch.empty((total_batch, k), device=dev, dtype=torch.float32)
+    out_s = torch.empty((total_batch, k), device=dev, dtype=torch.int64)
+    out_t = torch.empty((total_batch, k), device=dev, dtype=torch.int64)
+    rq = min(args.recall_queries, total_batch)
+    rqueries = queries[1][:rq].contiguous()
+    exact_d, _ = exact_topk_fp64(H.vectors, rqueries, k, H.metric)
+
+    def step(i):
+        index.search_batch(queries[i % pool], probes, k, want_tid=True, out=(out_d, out_s, out_t))
+
+    out.at("sweeps: batch 1 (pgv_query_*)")
+    sweep = {}
+    # batch 1 is what amgettuple issues: the device-resident single-query path, host-memory query in,
+    # k (distance, tid) out
+    qhost = queries[2][:256].cpu().numpy()
+    qh = api.Query(index)
+    for j in range(20):
+        qh.rank(qhost[j], probes)
+        qh.scan(0, probes, k)
+    lat = []
+    for j in range(300):
+        t0 = time.perf_counter()
+        qh.rank(qhost[j % 256], probes)
+        qh.scan(0, probes, k)
+        lat.append(time.perf_counter() - t0)
+    lat = np.array(lat)
+    # parity of that path with the batched one
+    bd, bs, _ = index.search_batch(qhost[:32], probes, k)
+    same = 0
+    for j in range(32):
+        qh.rank(qhost[j], probes)
+        d1, s1, _, _ = qh.scan(0, probes, k)
+        same += int(np.array_equal(s1, bs[j]))
+    if same != 32:
+        fails.append("single-query path differs from the batched path on %d of 32 queries" % (32 - same))
+    qh.close()
+    sweep["1"] = {"qps": 1.0 / lat.mean(), "latency_us_p50": float(np.percentile(lat, 50) * 1e6),
+                  "latency_us_p90": float(np.percentile(lat, 90) * 1e6),
+                  "path": "pgv_query_rank + pgv_query_scan (head of k read back through pinned memory)",
+                  "equals_batched_path": "%d/32" % same}
+    # the same through the C host glue: ivfflatrescan + k x ivfflatgettuple
+    try:
+        from pgvector_amd import _host
+        img = _host.IvfImage()
+        cen, offh = H.centers.cpu().numpy(), H.offsets.cpu().numpy()
+        tidh = H.tids.cpu().numpy().astype(np.uint64)
+        img.dtype, img.dim, img.lists, img.nrows = H.dtype, dim, lists, n
+        img.centers, img.list_offsets, img.tids, img.vectors = cen.ctypes.data, offh.ctypes.data, tidh.ctypes.data, None
+
+        class _Staged:
+            pass
+        st = _Staged()
+        st.img, st.dtype = img, H.dtype
+        scan = _host.IvfScan(index, st, probes=probes)
+        for j in range(20):
+            scan.rescan(qhost[j])
+            scan.fetch(limit=k)
+        lat2 = []
+        for j in range(300):
+            t0 = time.perf_counter()
+            scan.rescan(qhost[j % 256])
+            scan.fetch(limit=k)
+            lat2.append(time.perf_counter() - t0)
+        scan.close()
+        lat2 = np.array(lat2)
+        sweep["1"]["gettuple_latency_us_p50"] = float(np.percentile(lat2, 50) * 1e6)
+        sweep["1"]["gettuple_path"] = ("pgv_host_ivf_rescan + %d x pgv_host_ivf_gettuple (C host glue; the loop "
+                                       "itself is Python/ctypes)" % k)
+    except Exception as e:  # noqa: BLE001
+        sweep["1"]["gettuple_error"] = repr(e)
+    out.put("batch_sweep", sweep)
+    out.at("sweeps: batches 4 .. %d" % args.batch)
+    for b in (4, 16, 64, 256):
+        qb = queries[3][:b].contiguous()
+        od = torch.empty((b, k), device=dev, dtype=torch.float32)
+        os_ = torch.empty((b, k), device=dev, dtype=torch.int64)
+        ot = torch.empty((b, k), device=dev, dtype=torch.int64)
+        s = timed_steps(lambda j: index.search_batch(qb, probes, k, want_tid=True, out=(od, os_, ot)), 20)
+        sweep[str(b)] = {"qps": b / s, "ms_per_step": s * 1e3}
+    ctx.set_profiling(True)
+    ctx.reset_stats()
+    s_head = timed_steps(step, 20, warmup=3)
+    head_stats = ctx.stats()
+    ctx.set_profiling(False)
+    sweep[str(args.batch)] = {"qps": total_batch / s_head, "ms_per_step": s_head * 1e3,
+                              "note": "this child's own run of the headline step"}
+    out.put("batch_sweep", sweep)
+
+    out.at("sweeps: probes 1 / 10 / 32 / 100")
+    psweep = {}
+    for p in (1, 10, 32, 100):
+        if p > lists:
+            continue
+        s = timed_steps(lambda j: index.search_batch(queries[j % pool], p, k, want_tid=True, out=(out_d, out_s, out_t)), 6)
+        gd, _, _ = index.search_batch(rqueries, p, k)
+        psweep[str(p)] = {"qps": total_batch / s, "ms_per_step": s * 1e3, "recall_at_10": recall_at_k(gd, exact_d, k)}
+    out.put("probes_sweep", psweep)
+
+    if H.metric == api.PGV_L2SQ:
+        out.at("sweeps: completeness bounds side by side")
+        try:
+            wc = bound_mode_run(ctx, step, 10, total_batch)
+            out.put("bound_modes", {
+                "statistical": {"qps": total_batch / s_head, "ms_per_step": s_head * 1e3,
+                                "scan_redo_queries_per_step": head_stats["scan_redo_queries"] / 20,
+                                "bound": "8 sqrt(d + 4) 2^-24 (|q| + |x|max)^2 (default)"},
+                "worst_case": wc,
+                "cost_of_worst_case": 1.0 - wc["qps"] / (total_batch / s_head),
+                "note": "same index, same queries, same results; worst_case is the deterministic bound of "
+                        "include/pgv_hip.h (pgv_ctx_set_bound); uniform data and c5shard carry the same pair"})
+        except Exception as e:  # noqa: BLE001
+            out.put("bound_modes", {"error": repr(e)})
+            fails.append("bound_modes: %r" % (e,))
+
+    out.at("sweeps: uniform data")
+    try:
+        index.close()
+        del H.vectors
+        udata = gen_uniform(n, dim, args.seed + 7, dev).to(H.tdtype)
+        uc, uo, uv, ut, uit, ubt, uix = build_index(ctx, udata, lists, args.seed, 1, 0, H.dtype, H.ops, H.metric)
+        del udata
+        uq = gen_uniform(total_batch, dim, args.seed + 8, dev).to(H.tdtype)
+        ued, _ = exact_topk_fp64(uv, uq[:rq], k, H.metric)
+        ures = {}
+        for p in (10, 100):
+            s = timed_steps(lambda j: uix.search_batch(uq, p, k, want_tid=True, out=(out_d, out_s, out_t)), 5)
+            gd, _, _ = uix.search_batch(uq[:rq].contiguous(), p, k)
+            ures[str(p)] = {"qps": total_batch / s, "recall_at_10": recall_at_k(gd, ued, k)}
+        ubound = bound_mode_run(ctx, lambda j: uix.search_batch(uq, 10, k, want_tid=True, out=(out_d, out_s, out_t)),
+                                5, total_batch) if H.metric == api.PGV_L2SQ else None
+        out.put("uniform", {"data": "U[0,1)^%d (test/t/003_ivfflat_vector_build_recall.pl:60)" % dim,
+                            "bound_worst_case_probes_10": ubound,
+                            "build_secs": ubt["total"], "kmeans_iterations": uit, "probes": ures,
+                            "note": "uniform high-d data has no cluster structure: IVF recall at 1 % of the lists "
+                                    "is low by construction (the reference skips such cases, t/003:101-104)"})
+        uix.close()
+    except Exception as e:  # noqa: BLE001
+        out.put("uniform", {"error": repr(e)})
+        fails.append("uniform: %r" % (e,))
+
+
+def section_backends(args, dev, ctx, out):
+    """several backends on ONE device mirror: threads, processes, pooled clients.  LAST in the run, and a child: a
+    backend that wedges costs this section its budget and nothing else."""
+    out.at("backends: headline data + build")
+    H = headline_setup(args, dev, ctx)
+    qhost = H.queries[2][:256].cpu().numpy()
+    cb = {}
+    out.data["concurrent_backends"] = cb
+    out.at("backends: rows")
+    try:
+        concurrent_backends(H.index, 0, qhost, H.queries, H.probes, H.k, args, dev, cb, out.flush)
+    except Exception as e:  # noqa: BLE001
+        cb["error"] = repr(e)
+        out.data["failures"].append("concurrent_backends: %r" % (e,))
+    out.flush()
+
+
+SECTIONS = {"configs": section_configs, "hnsw": section_hnsw, "build": section_build, "sweeps": section_sweeps,
+            "backends": section_backends}
+
+
+def section_main(args):
+    import traceback
+    torch.cuda.set_device(0)
+    dev = torch.device("cuda", 0)
+    ctx = api.Context(0, stream=torch.cuda.current_stream().cuda_stream)
+    out = SectionOut(args.section_out)
+    rc = 0
+    try:
+        SECTIONS[args.section](args, dev, ctx, out)
+        out.data["_at"] = "done"
+    except Exception as e:  # noqa: BLE001
+        traceback.print_exc()
+        out.data["failures"].append("%r (at: %s)" % (e, out.data["_at"]))
+        rc = 1
+    out.flush()
+    if not args.section_out:
+        print(json.dumps(out.data, default=str), file=sys.stderr)
+    sys.stderr.flush()
+    os._exit(rc)   # no interpreter teardown: a thread that is still inside the library cannot hold the exit up
 
 
 def main():
@@ -840,12 +1326,18 @@ def main():
     ap.add_argument("--probes", type=int, default=0)
     ap.add_argument("--seed", type=int, default=0)
     ap.add_argument("--no-cpu-baseline", action="store_true", help="skips the oracle: no cpu_baseline, no TID parity")
-    ap.add_argument("--no-sweeps", action="store_true", help="skip batch / probes sweeps, uniform data, page build")
+    ap.add_argument("--no-sweeps", action="store_true", help="skip every optional section (the child processes)")
     ap.add_argument("--no-traffic", action="store_true", help="skip the live rocprofv3 PMC passes")
+    ap.add_argument("--sections", default=",".join(SECTION_ORDER),
+                    help="optional sections to run, in this order (default: all of %s)" % ",".join(SECTION_ORDER))
     ap.add_argument("--all-process-rows", action="store_true", help="also 32 own-context backend processes")
-    ap.add_argument("--watchdog-secs", type=int, default=900, help="print the line as far as it has got and exit "
-                    "should the run take longer than this (0: no watchdog)")
+    ap.add_argument("--budget-secs", type=int, default=420, help="no optional section STARTS once the run is this old")
+    ap.add_argument("--watchdog-secs", type=int, default=720, help="last resort for the parent process: print the line as "
+                    "far as it has got and exit 2 (0: no watchdog)")
     ap.add_argument("--child", action="store_true", help="(internal) the short run the PMC passes profile")
+    ap.add_argument("--section", default=None, choices=sorted(SECTIONS), help="(internal) run ONE optional section and "
+                    "write its JSON to --section-out")
+    ap.add_argument("--section-out", default=None)
     ap.add_argument("--host-io", action="store_true", help="also time the batch with host-memory queries/results")
     ap.add_argument("--recall-queries", type=int, default=256)
     ap.add_argument("--exact-scan", action="store_true", help="A/B: keep the batched L2 scan on the vector-ALU kernels "
@@ -858,6 +1350,9 @@ def main():
     # are pointed at stderr for the rest of the run
     json_fd = os.dup(1)
     os.dup2(2, 1)
+    if args.section:
+        os.close(json_fd)
+        return section_main(args)
     if args.child:
         args.no_cpu_baseline = args.no_sweeps = args.no_traffic = True
     WATCH["fd"] = json_fd
@@ -867,6 +1362,7 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    WATCH["rank"] = rank
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         local_rank = local_rank % max(torch.cuda.device_count(), 1)
@@ -879,15 +1375,6 @@ def main():
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
 
-    n, dim, lists, probes, tname, oname = WORKLOADS[args.workload]
-    dtype = api.PGV_F32 if tname == "f32" else api.PGV_F16
-    tdtype = torch.float32 if tname == "f32" else torch.float16
-    ops = api.PGV_OPS_L2 if oname == "l2" else api.PGV_OPS_IP
-    metric = api.PGV_L2SQ if oname == "l2" else api.PGV_NEG_IP
-    esize = 4 if tname == "f32" else 2
-    if args.probes:
-        probes = args.probes
-    k = args.k
     ctx = api.Context(local_rank, stream=torch.cuda.current_stream().cuda_stream)
     comm = api.Comm(ctx, backend="rccl" if args.backend == "nccl" else "host") if world > 1 else None
     if args.exact_scan:
@@ -895,27 +1382,13 @@ def main():
     failures = []
 
     # ---------------------------------------------------------------- setup
-    components = max(lists // 4, 1)
-    row_lo, row_hi = sharding.row_shard(n, rank, world)
-    data, means = gen_mixture(n, dim, components, 0.1, args.seed, dev, lo=row_lo, hi=row_hi)
-    data = data.to(tdtype)
-    log("data: rows [%d, %d) of %d x %d %s generated" % (row_lo, row_hi, n, dim, tname))
-    ctx.set_profiling(True)
-    ctx.reset_stats()
-    centers, offsets, vectors, tids, iters, build_t, index = build_index(ctx, data, lists, args.seed, world, rank,
-                                                                         dtype, ops, metric, comm, row_lo=row_lo, n_global=n)
-    build_stats = ctx.stats()
-    ctx.set_profiling(False)
-    log("build: %s (k-means iterations %d)" % ({a: round(b, 3) for a, b in build_t.items()}, iters))
-    local_rows = int(vectors.shape[0])
-    do_pages = rank == 0 and world == 1 and not args.no_sweeps
-    host_rows = data.cpu().numpy() if do_pages else None
-    del data
-
-    total_batch = args.batch * world
-    pool = 8
-    queries, _ = gen_mixture(total_batch * pool, dim, components, 0.1, args.seed + 100, dev, means=means)
-    queries = queries.to(tdtype).view(pool, total_batch, dim)
+    WATCH["section"] = "data + build"
+    H = headline_setup(args, dev, ctx, world, rank, comm)
+    n, dim, lists, probes, tname, oname = H.n, H.dim, H.lists, H.probes, H.tname, H.oname
+    dtype, ops, metric, esize, k = H.dtype, H.ops, H.metric, H.esize, H.k
+    centers, offsets, vectors, tids, index = H.centers, H.offsets, H.vectors, H.tids, H.index
+    iters, build_t, build_stats, components = H.iters, H.build_t, H.build_stats, H.components
+    total_batch, pool, queries = H.total_batch, H.pool, H.queries
 
     out_d = torch.empty((total_batch, k), device=dev, dtype=torch.float32)
     out_s = torch.empty((total_batch, k), device=dev, dtype=torch.int64)
@@ -933,9 +1406,9 @@ def main():
         return out_d, out_t
 
     # ---------------------------------------------------------------- recall vs exact fp64
+    WATCH["section"] = "recall against float64"
     rq = min(args.recall_queries, total_batch)
     rqueries = queries[1][:rq].contiguous()
-    exact_d = None
     # exact float64 brute force over every row; with N ranks each one scans the rows it holds and the per-rank
     # exact top-k are merged (never the GPUs' own fp32 scan as its own ground truth)
     exact_d, _ = exact_topk_fp64(vectors, rqueries, k, metric)
@@ -951,6 +1424,7 @@ def main():
     log("recall@%d = %.4f at probes=%d (%s)" % (k, recall, probes, recall_truth))
 
     # ----------------------------------------------------------------- timed
+    WATCH["section"] = "timed steps"
     for i in range(args.warmup):
         step(i)
     ctx.set_profiling(True)
@@ -1006,7 +1480,6 @@ def main():
                 "measured_stream_ceiling_GBps: what a kernel that only stages the same 128-row tasks into LDS reaches on "
                 "this part, any access pattern (tools/stream_patterns.hip, profiles/r02b_stream_patterns.txt, DESIGN.md 4.1c)",
     }
-    WATCH["rank"] = rank
     line = WATCH["line"] = {
         "metric": "QPS @ recall@10 (IVFFlat, 1M x 1536d)" if args.workload == "headline"
                   else "QPS @ recall@10 (IVFFlat)",
@@ -1020,7 +1493,7 @@ def main():
                    "rows": n, "dim": dim, "lists": lists, "probes": probes, "k": k,
                    "batch_per_gpu": args.batch, "parallelism": "lists sharded l %% %d; k-means all-reduce, probe-list and top-k all-gathers inside libpgv_hip "
                                   "(RCCL on the library's stream)" % world,
-                   "local_rows": local_rows},
+                   "local_rows": H.local_rows},
         "recall_at_10": recall, "recall_ground_truth": recall_truth,
         "build_secs": build_t["total"], "build_phases_secs": build_t, "kmeans_iterations": iters,
         "build_assign": {"rows": build_stats["assign_rows"],
@@ -1035,6 +1508,19 @@ def main():
         "scan_redo_queries_per_step": stats["scan_redo_queries"] / args.steps,
         "scan_path": "exact vector-ALU kernels (--exact-scan)" if args.exact_scan else "auto",
     }
+    if world > 1:
+        # what the first real N-GPU run needs to be read: the communicator's size, the exchanges per step and per
+        # Lloyd iteration in bytes, the build's phases (build_phases_secs: kmeans = k-means++ + Lloyd with
+        # one fused all-reduce per iteration; assign; layout = the all-to-all of the rows to their lists' owners)
+        line["multi_gpu"] = {
+            "pgv_comm_size": comm.world, "backend": args.backend,
+            "kmeans_allreduce_bytes_per_iteration": int(lists * dim * 4 + lists * 4 + 8),
+            "kmeans_iterations": iters,
+            "search_allgather_bytes_per_step": {"probe_lists": int(total_batch * probes * 4),
+                                                "topk": int(total_batch * k * 12 * world)},
+            "rows_per_rank": H.local_rows}
+    log("timed: %.0f QPS, %.3f ms/step, scan %.3f ms/launch (frac %.2f)" % (qps, elapsed / args.steps * 1e3, avg_launch_ms,
+                                                                            roofline["frac"]))
 
     single = rank == 0 and world == 1
     if single and args.host_io:
@@ -1045,163 +1531,17 @@ def main():
                                 "h2d_bytes_per_step": int(args.batch * dim * esize),
                                 "d2h_bytes_per_step": int(args.batch * k * 20)}
 
-    # ------------------------------------------------------------- sweeps
-    if single and not args.no_sweeps:
-        sweep = {}
-        # batch 1 is what amgettuple issues: the device-resident single-query path, host-memory query in,
-        # k (distance, tid) out
-        qhost = queries[2][:256].cpu().numpy()
-        qh = api.Query(index)
-        for j in range(20):
-            qh.rank(qhost[j], probes)
-            qh.scan(0, probes, k)
-        lat = []
-        for j in range(300):
-            t0 = time.perf_counter()
-            qh.rank(qhost[j % 256], probes)
-            qh.scan(0, probes, k)
-            lat.append(time.perf_counter() - t0)
-        lat = np.array(lat)
-        # parity of that path with the batched one
-        bd, bs, _ = index.search_batch(qhost[:32], probes, k)
-        same = 0
-        for j in range(32):
-            qh.rank(qhost[j], probes)
-            d1, s1, _, _ = qh.scan(0, probes, k)
-            same += int(np.array_equal(s1, bs[j]))
-        if same != 32:
-            failures.append("single-query path differs from the batched path on %d of 32 queries" % (32 - same))
-        qh.close()
-        sweep["1"] = {"qps": 1.0 / lat.mean(), "latency_us_p50": float(np.percentile(lat, 50) * 1e6),
-                      "latency_us_p90": float(np.percentile(lat, 90) * 1e6),
-                      "path": "pgv_query_rank + pgv_query_scan (5 launches, head of k read back through pinned memory)",
-                      "equals_batched_path": "%d/32" % same}
-        # the same through the C host glue: ivfflatrescan + k x ivfflatgettuple
-        try:
-            from pgvector_amd import _host
-            img = _host.IvfImage()
-            cen, offh = centers.cpu().numpy(), offsets.cpu().numpy()
-            tidh = tids.cpu().numpy().astype(np.uint64)
-            img.dtype, img.dim, img.lists, img.nrows = dtype, dim, lists, n
-            img.centers, img.list_offsets, img.tids, img.vectors = cen.ctypes.data, offh.ctypes.data, tidh.ctypes.data, None
-
-            class _Staged:
-                pass
-            st = _Staged()
-            st.img, st.dtype = img, dtype
-            scan = _host.IvfScan(index, st, probes=probes)
-            for j in range(20):
-                scan.rescan(qhost[j])
-                scan.fetch(limit=k)
-            lat2 = []
-            for j in range(300):
-                t0 = time.perf_counter()
-                scan.rescan(qhost[j % 256])
-                scan.fetch(limit=k)
-                lat2.append(time.perf_counter() - t0)
-            scan.close()
-            lat2 = np.array(lat2)
-            sweep["1"]["gettuple_latency_us_p50"] = float(np.percentile(lat2, 50) * 1e6)
-            sweep["1"]["gettuple_path"] = ("pgv_host_ivf_rescan + %d x pgv_host_ivf_gettuple (C host glue; the loop "
-                                           "itself is Python/ctypes)" % k)
-        except Exception as e:
-            sweep["1"]["gettuple_error"] = repr(e)
-        for b in (4, 16, 64, 256):
-            qb = queries[3][:b].contiguous()
-            od = torch.empty((b, k), device=dev, dtype=torch.float32)
-            os_ = torch.empty((b, k), device=dev, dtype=torch.int64)
-            ot = torch.empty((b, k), device=dev, dtype=torch.int64)
-            s = timed_steps(lambda j: index.search_batch(qb, probes, k, want_tid=True, out=(od, os_, ot)), 20)
-            sweep[str(b)] = {"qps": b / s, "ms_per_step": s * 1e3}
-        sweep[str(args.batch)] = {"qps": qps, "ms_per_step": elapsed / args.steps * 1e3}
-        line["batch_sweep"] = sweep
-
-        # ---- several backends on ONE device mirror (pgv_index_share): each its own context = stream + scratch
-        try:
-            WATCH["section"] = 'concurrent_backends (threads / processes / pooled clients)'
-            line["concurrent_backends"] = concurrent_backends(index, local_rank, qhost, queries, probes, k, args, dev)
-        except Exception as e:
-            line["concurrent_backends"] = {"error": repr(e)}
-
-        psweep = {}
-        for p in (1, 10, 32, 100):
-            if p > lists:
-                continue
-            s = timed_steps(lambda j: index.search_batch(queries[j % pool], p, k, want_tid=True, out=(out_d, out_s, out_t)), 6)
-            gd, _, _ = index.search_batch(rqueries, p, k)
-            psweep[str(p)] = {"qps": total_batch / s, "ms_per_step": s * 1e3, "recall_at_10": recall_at_k(gd, exact_d, k)}
-        line["probes_sweep"] = psweep
-
-    # ------------------------------------------------------ the product build path, through pages
-    pages_ctx = None
-    host_samples = None
-    if do_pages:
-        try:
-            from pgvector_amd import _host
-            t0 = time.perf_counter()
-            host_tids = (np.arange(n, dtype=np.uint64) << np.uint64(16)) | np.uint64(1)
-            g = np.random.default_rng(args.seed + 1)
-            ns = min(max(50 * lists, 10000), n)
-            host_samples = host_rows[np.sort(g.choice(n, ns, replace=False))]
-            t_sample = time.perf_counter() - t0
-            rel = _host.Relation()
-            t0 = time.perf_counter()
-            pix = rel.build_mirror(ctx, ops, dtype, lists, host_rows, host_tids, host_samples, api.make_rng(seed=args.seed + 2))
-            ctx.sync()
-            t_build = time.perf_counter() - t0
-            ph = (ctypes.c_double * 5)()
-            _host.lib.pgv_host_ivf_build_phases(ph)
-            # the old route to a mirror of these pages (a backend that finds the index on disk): stage + upload
-            t0 = time.perf_counter()
-            img = rel.stage(dtype)
-            t_stage = time.perf_counter() - t0
-            t0 = time.perf_counter()
-            pix2 = api.IvfIndex(ctx, metric, dtype, dim, img.centers, img.list_offsets, img.vectors, img.tids)
-            ctx.sync()
-            t_upload = time.perf_counter() - t0
-            # the page-built index answers like an index should: recall against the same exact ground truth, and the
-            # mirror that came with the build equals the one staged out of the pages
-            gd, gs, gt = pix.search_batch(rqueries, probes, k, want_tid=True)
-            gd2, gs2, gt2 = pix2.search_batch(rqueries, probes, k, want_tid=True)
-            same_mirror = bool(torch.equal(gs, gs2) and torch.equal(gt, gt2) and torch.equal(gd, gd2))
-            if not same_mirror:
-                failures.append("the mirror pgv_host_ivf_build_mirror returns differs from the one staged out of its pages")
-            pix2.close()
-            prec = recall_at_k(gd, exact_d, k)
-            line["build_secs_pages"] = t_build
-            line["build_pages"] = {
-                "path": "pgv_host_ivf_build_mirror: host rows -> k-means on the GPU (helper thread) WHILE the rows go to the "
-                        "device (pgv_builder_add without centers: copies on the builder's stream) -> assignment of all rows + "
-                        "order by list on the device = the mirror (pgv_builder_set_centers / _finish) -> 8 KB pages "
-                        "written from the mirror's rows as they come back (pgv_index_drain), page array zeroed in the "
-                        "background meanwhile; no host sort, no staging pass, no second upload",
-                "build_secs": t_build, "sample_secs": t_sample,
-                "build_phases_secs": dict(zip(("normalise", "kmeans_left_after_upload", "upload_beside_kmeans", "assign_and_order_by_list_on_device",
-                                               "page_writer"), [float(x) for x in ph])),
-                "mirror_from_pages_secs": {"stage": t_stage, "upload": t_upload,
-                                           "note": "what a backend pays that finds the index on disk (not part of the build)"},
-                "mirror_equals_staged_pages": same_mirror,
-                "pages": int(rel.nblocks), "page_bytes": int(rel.nblocks) * 8192,
-                "recall_at_10": prec}
-            if prec < recall - 0.02:
-                failures.append("page-built index recall %.4f below the torch-laid-out index's %.4f" % (prec, recall))
-            pages_ctx = (rel, pix, img)
-        except Exception as e:
-            line["build_pages"] = {"error": repr(e)}
-
-    # --------------------------------------------------- parity with the CPU oracle + its speed
+    # --------------------------------------------------- parity with the CPU oracle + its speed (mandatory, in-process)
     if single and not args.no_cpu_baseline:
+        WATCH["section"] = "oracle parity + cpu_baseline"
         try:
             pq = min(256, total_batch)
             pqueries = queries[1][:pq].contiguous()
             pd, ps, pt = index.search_batch(pqueries, probes, k, want_tid=True)
             ctx.sync()
-            pages = None
-            if pages_ctx is not None:
-                pages = (pages_ctx[0].rel.pages, int(pages_ctx[0].nblocks))
-            base, answers, page_answers = cpu_baseline(centers.cpu().numpy(), offsets.cpu().numpy(),
-                                                       vectors.cpu().numpy(), tids.cpu().numpy().astype(np.uint64),
-                                                       pqueries.cpu().numpy(), probes, k, dtype, ops, pages=pages)
+            base, answers, _ = cpu_baseline(centers.cpu().numpy(), offsets.cpu().numpy(),
+                                            vectors.cpu().numpy(), tids.cpu().numpy().astype(np.uint64),
+                                            pqueries.cpu().numpy(), probes, k, dtype, ops)
             line["cpu_baseline"] = base
             pd, pt = pd.cpu().numpy(), pt.cpu().numpy()
             bad = []
@@ -1217,131 +1557,55 @@ def main():
                               "mismatches": len(bad)}
             if bad:
                 failures.append("parity: %d of %d queries differ from the oracle, first: %r" % (len(bad), pq, bad[0]))
-            if page_answers is not None:
-                # the product path end to end: pages written by pgv_host_ivf_build, staged, uploaded, searched
-                # on the GPU -- against the oracle walking the very same pages
-                gd2, gs2, gt2 = pages_ctx[1].search_batch(pqueries, probes, k, want_tid=True)
-                ctx.sync()
-                gd2, gt2 = gd2.cpu().numpy(), gt2.cpu().numpy()
-                bad2 = []
-                for i in range(pq):
-                    wt, wd, _ = page_answers[i]
-                    why = topk_equiv(gt2[i][:len(wt)].astype(np.uint64).tolist(), gd2[i][:len(wt)], wt.tolist(), wd)
-                    if why:
-                        bad2.append((i, why))
-                line["parity"]["page_built_index_mismatches"] = len(bad2)
-                if bad2:
-                    failures.append("page-built index: %d of %d queries differ from the oracle walking the same "
-                                    "pages, first: %r" % (len(bad2), pq, bad2[0]))
+            log("parity: %d mismatches of %d; cpu_baseline %.0f QPS on %d threads" % (len(bad), pq, base["value"], base["cores"]))
         except Exception as e:  # an oracle that cannot run must not pass for parity
             line["cpu_baseline"] = {"value": None, "unit": "queries/s", "cores": 0, "kind": "port",
                                     "sample": "failed: %r" % (e,)}
             line["parity_checked_queries"] = 0
+            failures.append("oracle parity / cpu_baseline did not run: %r" % (e,))
+    line["mandatory_secs"] = time.perf_counter() - t_program
 
-    if pages_ctx is not None:
-        pages_ctx[1].close()
-        pages_ctx = None
-
-    # ---- the build's CPU loops beside build_secs, in a background thread while the GPU sections below go on
-    cpu_build, cpu_build_thread = {}, None
-    if single and not args.no_cpu_baseline and host_rows is not None and host_samples is not None:
-        cpu_build_thread = threading.Thread(target=cpu_build_kmeans,
-                                            args=(host_samples, lists, dtype, ops, args.seed + 2, cpu_build))
-        cpu_build_thread.start()
-
-    # ------------------------------------------------------------- uniform data
-    if single and not args.no_sweeps:
-        try:
-            udata = gen_uniform(n, dim, args.seed + 7, dev).to(tdtype)
-            uc, uo, uv, ut, uit, ubt, uix = build_index(ctx, udata, lists, args.seed, 1, 0, dtype, ops, metric)
-            del udata
-            uq = gen_uniform(total_batch, dim, args.seed + 8, dev).to(tdtype)
-            ued, _ = exact_topk_fp64(uv, uq[:rq], k, metric)
-            ures = {}
-            for p in (10, 100):
-                s = timed_steps(lambda j: uix.search_batch(uq, p, k, want_tid=True, out=(out_d, out_s, out_t)), 5)
-                gd, _, _ = uix.search_batch(uq[:rq].contiguous(), p, k)
-                ures[str(p)] = {"qps": total_batch / s, "recall_at_10": recall_at_k(gd, ued, k)}
-            ubound = bound_mode_run(ctx, lambda j: uix.search_batch(uq, 10, k, want_tid=True, out=(out_d, out_s, out_t)),
-                                    5, total_batch) if metric == api.PGV_L2SQ else None
-            line["uniform"] = {"data": "U[0,1)^%d (test/t/003_ivfflat_vector_build_recall.pl:60)" % dim,
-                               "bound_worst_case_probes_10": ubound,
-                               "build_secs": ubt["total"], "kmeans_iterations": uit, "probes": ures,
-                               "note": "uniform high-d data has no cluster structure: IVF recall at 1 % of the lists "
-                                       "is low by construction (the reference skips such cases, t/003:101-104)"}
-            uix.close()
-            del uv, uq
-        except Exception as e:
-            line["uniform"] = {"error": repr(e)}
-
-    # ------------------------------------------- HNSW (BASELINE configs[3]'s shape, rows scaled down)
-    if single and not args.no_sweeps and args.workload == "headline":
-        try:
-            WATCH["section"] = 'hnsw'
-            line["hnsw"] = hnsw_section(ctx, dev, args, failures)
-        except Exception as e:
-            line["hnsw"] = {"error": repr(e)}
-
-    # ------------------------------------------- the exact scan for a batch of queries (BASELINE configs[0])
-    if single and not args.no_sweeps and args.workload == "headline":
-        try:
-            WATCH["section"] = 'exact_scan'
-            line["exact_scan"] = exact_scan_section(ctx, dev, args, failures)
-        except Exception as e:
-            line["exact_scan"] = {"error": repr(e)}
-
-    # ------------------------------------------- the two completeness bounds of the MFMA L2 paths, side by side
-    if single and not args.no_sweeps and metric == api.PGV_L2SQ and not args.exact_scan:
-        try:
-            wc = bound_mode_run(ctx, step, 10, total_batch)
-            line["bound_modes"] = {
-                "statistical": {"qps": qps, "ms_per_step": elapsed / args.steps * 1e3,
-                                "scan_redo_queries_per_step": stats["scan_redo_queries"] / args.steps,
-                                "bound": "8 sqrt(d + 4) 2^-24 (|q| + |x|max)^2 (default)"},
-                "worst_case": wc,
-                "cost_of_worst_case": 1.0 - wc["qps"] / qps,
-                "note": "same index, same queries, same results; worst_case is the deterministic bound of "
-                        "include/pgv_hip.h (pgv_ctx_set_bound); uniform data and c5shard carry the same pair"}
-        except Exception as e:
-            line["bound_modes"] = {"error": repr(e)}
-
-    # ------------------------------------------- BASELINE's other IVFFlat configs on this GPU
-    if single and not args.no_sweeps and args.workload == "headline":
-        line["other_configs"] = {}
-        for wname in ("c2", "c3shard", "c5shard"):
-            try:
-                WATCH["section"] = 'other_configs'
-                line["other_configs"][wname] = run_workload(ctx, dev, wname, args, failures)
-                log("%s: %.0f QPS, recall %.4f, roofline frac %.2f" % (
-                    wname, line["other_configs"][wname]["qps"], line["other_configs"][wname]["recall_at_10"],
-                    line["other_configs"][wname]["roofline"]["frac"]))
-            except Exception as e:
-                line["other_configs"][wname] = {"error": repr(e)}
-            torch.cuda.empty_cache()
-
-    if cpu_build_thread is not None:
-        cpu_build_thread.join()
-        cpu_build_assign(host_rows, dtype, ops, cpu_build)
-        cpu_build["gpu_build_secs"] = build_t["total"]
-        cpu_build["gpu_build_secs_pages"] = line.get("build_secs_pages")
-        line["cpu_build_baseline"] = cpu_build
-    host_rows = host_samples = None
-
-    # ------------------------------------------------------------------ live PMC traffic
-    if single and not args.no_traffic:
-        WATCH["section"] = 'live PMC traffic (rocprofv3 child runs)'
-        traffic, src = live_traffic(args, avg_launch_ms)
-        roofline["traffic"] = traffic
-        roofline["traffic_source"] = src
-        if traffic and stream_bytes > 0:
-            roofline["traffic_over_streamed"] = traffic / (stream_bytes / launches)
+    # ------------------------------------------------------------- optional sections: children, one at a time
+    if single and not (args.no_sweeps and args.no_traffic):
+        wanted = [s for s in args.sections.split(",") if s]
+        for name in SECTION_ORDER:
+            if name not in wanted:
+                continue
+            if name == "traffic":
+                if args.no_traffic:
+                    continue
+            elif args.no_sweeps or (name in ("configs", "hnsw") and args.workload != "headline"):
+                continue
+            WATCH["section"] = "section " + name
+            if time.perf_counter() - t_program > args.budget_secs:
+                failures.append("section %s: not started, the run was %d s old (--budget-secs %d)"
+                                % (name, time.perf_counter() - t_program, args.budget_secs))
+                continue
+            if name == "traffic":
+                t0 = time.perf_counter()
+                traffic, src = live_traffic(args, avg_launch_ms)
+                roofline["traffic"] = traffic
+                roofline["traffic_source"] = src
+                if traffic and stream_bytes > 0:
+                    roofline["traffic_over_streamed"] = traffic / (stream_bytes / launches)
+                if traffic is None:
+                    failures.append("traffic: " + src)
+                line.setdefault("sections", {})["traffic"] = {"secs": time.perf_counter() - t0}
+                continue
+            run_section(name, args, SECTION_BUDGET_S[name], line, failures)
+        if "cpu_baseline" in line and "cpu_baseline_page_image" in line:
+            line["cpu_baseline"]["page_image"] = line.pop("cpu_baseline_page_image")
+            line.setdefault("parity", {})["page_built_index_mismatches"] = \
+                line["cpu_baseline"]["page_image"]["parity_of_the_page_built_index"]["mismatches"]
+        if "batch_sweep" in line:
+            line["batch_sweep"][str(args.batch)]["timed_region_qps"] = qps
 
     if failures:
         line["failures"] = failures
-    line["bench_wall_secs"] = time.perf_counter() - t_program   # everything: data, builds, sweeps, CPU baselines, PMC passes
+    line["bench_wall_secs"] = time.perf_counter() - t_program   # everything: data, builds, sections, CPU baselines, PMC passes
     WATCH["done"] = True
     if rank == 0:
-        os.write(json_fd, (json.dumps(line) + "\n").encode())
+        os.write(json_fd, (json.dumps(line, default=str) + "\n").encode())
     index.close()
     if comm is not None:
         comm.close()

@@ -426,10 +426,11 @@ def backends_driver():
             raise ImportError("build/tools/libbackends.so / pgv_backend not built: run __graft_entry__.build()")
         d = C.CDLL(BACKENDS_SO)
         P, I = C.c_void_p, C.c_int
-        d.backends_run.argtypes = [P, I, I, I, P, I, C.c_size_t, I, I, C.POINTER(C.c_double)]
-        d.pool_run.argtypes = [P, I, I, I, I, I, P, I, C.c_size_t, I, I, I, I, I, C.POINTER(C.c_double)]
+        D = C.c_double
+        d.backends_run.argtypes = [P, I, I, I, P, I, C.c_size_t, I, I, D, C.POINTER(D), C.c_char_p, C.c_size_t]
+        d.pool_run.argtypes = [P, I, I, I, I, I, P, I, C.c_size_t, I, I, I, I, I, D, C.POINTER(D), C.c_char_p, C.c_size_t]
         d.backends_run_processes.argtypes = [P, C.c_char_p, I, I, I, I, I, P, I, C.c_size_t, I, I, I, I, I, I, I, I,
-                                             C.c_char_p, I, P, P, C.POINTER(C.c_double), C.c_char_p, C.c_size_t]
+                                             C.c_char_p, I, D, P, P, C.POINTER(D), C.c_char_p, C.c_size_t]
         _drv = d
     return _drv
 
@@ -467,8 +468,37 @@ def write_index_image(name, metric, dtype, dim, centers, list_offsets, vectors, 
     return "/" + name.lstrip("/")
 
 
+def run_backend_threads(index, queries, probes, k, nbackends, per_thread, device=0, deadline_s=60.0):
+    """N backends as THREADS of this process (one pgv_ctx + pgv_index_share view + pgv_query each), one query at a time
+    each.  A backend not back after deadline_s raises with the call it sits in."""
+    d = backends_driver()
+    q = np.ascontiguousarray(queries)
+    out = (C.c_double * 4)()
+    err = C.create_string_buffer(1024)
+    rc = d.backends_run(index.h, device, nbackends, per_thread, q.ctypes.data, q.shape[0], q.strides[0], probes, min(k, 64),
+                        float(deadline_s), out, err, len(err))
+    if rc != 0:
+        raise _lib.PgvError(rc, "backends_run: " + err.value.decode("utf-8", "replace"))
+    return {"qps": out[0], "latency_us_p50": out[1], "latency_us_p90": out[2]}
+
+
+def run_pooled_threads(index, queries, probes, k, nclients, per_thread, max_batch=1024, max_wait_us=50, lanes=2, device=0,
+                       deadline_s=60.0):
+    """N client THREADS behind pgv_host_pool_* (lane threads in this process), one query each at a time"""
+    d = backends_driver()
+    q = np.ascontiguousarray(queries)
+    out = (C.c_double * 4)()
+    err = C.create_string_buffer(1024)
+    rc = d.pool_run(index.h, device, index.dtype, index.dim, nclients, per_thread, q.ctypes.data, q.shape[0], q.strides[0],
+                    probes, min(k, 64), max_batch, max_wait_us, lanes, float(deadline_s), out, err, len(err))
+    if rc != 0:
+        raise _lib.PgvError(rc, "pool_run: " + err.value.decode("utf-8", "replace"))
+    return {"qps": out[0], "latency_us_p50": out[1], "latency_us_p90": out[2], "mean_batch": out[3]}
+
+
 def run_backend_processes(index, queries, probes, k, mode, nclients, per_client, warmup=5, max_batch=1024,
-                          max_wait_us=50, lanes=2, server_processes=True, verify=False, image_shm=None, device=0):
+                          max_wait_us=50, lanes=2, server_processes=True, verify=False, image_shm=None, device=0,
+                          deadline_s=60.0):
     """N backend PROCESSES against one device mirror.  mode 0: every process imports the mirror and runs
     pgv_query_*; mode 1: GPU-less clients behind the shared-memory pooler.  Returns a dict (qps, latencies, mean
     batch, HBM that went to the children) and, with verify, the answers [nclients, per_client, k]."""
@@ -483,7 +513,7 @@ def run_backend_processes(index, queries, probes, k, mode, nclients, per_client,
                                   device, mode, nclients, per_client, warmup, q.ctypes.data, q.shape[0], q.strides[0],
                                   index.dtype if index is not None else (0 if q.dtype == np.float32 else 1), q.shape[1],
                                   probes, k, max_batch, max_wait_us, lanes, 1 if server_processes else 0,
-                                  BACKEND_EXE.encode(), 1 if verify else 0,
+                                  BACKEND_EXE.encode(), 1 if verify else 0, float(deadline_s),
                                   ans_t.ctypes.data if verify else None, ans_d.ctypes.data if verify else None,
                                   out, err, len(err))
     if rc != 0:

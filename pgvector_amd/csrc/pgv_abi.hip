@@ -3,6 +3,7 @@
 // There is no CPU fallback anywhere in this file: without a GPU every entry
 // point reports PGV_ERR_DEVICE.
 #include "pgv_internal.h"
+#include "pgv_gate.h"
 
 #include <dlfcn.h>
 #include <linux/futex.h>
@@ -1595,28 +1596,15 @@ struct QueryHeadHost {  // mirrors QueryHead of kernels_query.hip
 // barrier packets for every stream switch on a queue).  So at most g_scan_gate_width scan+head pairs are in flight
 // per process; the others sleep on a futex.  PGV_MAX_INFLIGHT_SCANS overrides the width (0 = no gate).
 static int g_scan_gate_width = -1;
-static int g_scan_inflight = 0;  // also the futex word
+static PgvGate g_scan_gate;  // pgv_gate.h (round 3's version lost wake-ups: the hang of BENCH_r03)
 static void scan_gate_enter() {
     if (g_scan_gate_width < 0) {
         const char *e = getenv("PGV_MAX_INFLIGHT_SCANS");
         __atomic_store_n(&g_scan_gate_width, e ? atoi(e) : 16, __ATOMIC_RELAXED);
     }
-    const int width = g_scan_gate_width;
-    if (width <= 0) return;
-    for (;;) {
-        int cur = __atomic_load_n(&g_scan_inflight, __ATOMIC_RELAXED);
-        if (cur < width) {
-            if (__atomic_compare_exchange_n(&g_scan_inflight, &cur, cur + 1, true, __ATOMIC_ACQUIRE, __ATOMIC_RELAXED)) return;
-            continue;
-        }
-        syscall(SYS_futex, &g_scan_inflight, FUTEX_WAIT_PRIVATE, cur, nullptr, nullptr, 0);
-    }
+    g_scan_gate.enter(g_scan_gate_width);
 }
-static void scan_gate_leave() {
-    if (g_scan_gate_width <= 0) return;
-    const int before = __atomic_fetch_sub(&g_scan_inflight, 1, __ATOMIC_RELEASE);
-    if (before >= g_scan_gate_width) syscall(SYS_futex, &g_scan_inflight, FUTEX_WAKE_PRIVATE, 1, nullptr, nullptr, 0);
-}
+static void scan_gate_leave() { g_scan_gate.leave(g_scan_gate_width); }
 struct ScanGate {
     ScanGate() { scan_gate_enter(); }
     ~ScanGate() { scan_gate_leave(); }

@@ -27,7 +27,8 @@
  *
  * Futexes are the shared kind (no FUTEX_PRIVATE_FLAG); the mutex is PTHREAD_PROCESS_SHARED + ROBUST (a client that
  * dies inside the critical section does not wedge the pool); a lane whose clients vanished is reclaimed by its
- * server after pool_reclaim_us.
+ * server after POOL_RECLAIM_US, a batch waits for a straggler that never arrives POOL_READY_US at most, and a client
+ * that outlives its batch's reclaim gets PGV_ERR_STATE instead of another batch's answers.
  */
 #define _GNU_SOURCE
 #include "pgv_host.h"
@@ -47,7 +48,7 @@ extern int	pgv_host_fail(int code, const char *fmt,...);
 void		pgv_host_pool_destroy(pgv_pool * pool);
 
 #define POOL_MAGIC 0x7067765f706f6f6cull	/* "pgv_pool" */
-#define POOL_VERSION 2
+#define POOL_VERSION 3
 #define POOL_MAX_LANES 8
 #define POOL_ALIGN 4096
 #define POOL_RECLAIM_US 2000000		/* a published batch nobody finished reading: its clients are gone */
@@ -63,8 +64,10 @@ typedef struct
 	uint32_t	state;			/* LANE_* (under the lock) */
 	int32_t		count;			/* queries of the batch being collected / run (under the lock) */
 	int32_t		ready;			/* ... whose payload has been copied into the lane (atomic) */
-	int32_t		readers;		/* clients that still have to copy their answer (atomic) */
 	int32_t		rc;
+	uint64_t	readers;		/* (batch number << 32) | clients that still have to copy their answer (atomic): a
+								 * client whose batch was reclaimed under it finds another batch number here and
+								 * neither reads the lane nor counts itself out of somebody else's batch */
 	uint32_t	gen,			/* batch number of this lane */
 				done_gen;		/* last batch whose results are published (futex word) */
 	uint32_t	fill;			/* bumped when the lane's server should look again (futex word) */
@@ -381,7 +384,9 @@ pgv_host_pool_serve(pgv_pool * pool, int lane, pgv_index * view)
 
 				/* everyone who queued while the lanes were busy joins (they are on their way: `arriving`), later
 				 * arrivals get max_wait_us */
-				if (l->count >= s->max_batch || (s->arriving == 0 && t >= deadline))
+				/* ... but not for ever: a client that died between arriving++ and its slot leaves `arriving` above
+				 * zero for good, and a batch must not wait for it longer than a payload copy takes */
+				if (l->count >= s->max_batch || (s->arriving == 0 && t >= deadline) || t >= deadline + POOL_READY_US)
 				{
 					if (s->collecting == lane)
 						s->collecting = -1;
@@ -399,9 +404,17 @@ pgv_host_pool_serve(pgv_pool * pool, int lane, pgv_index * view)
 			else if (l->state == LANE_PUBLISHED && t - l->t_published > POOL_RECLAIM_US)
 			{
 				/* nobody finished reading for two seconds: the batch's clients are gone */
+				uint64_t	w;
+
 				pool_unlock(s);
-				__atomic_store_n(&l->readers, 0, __ATOMIC_RELEASE);
-				lane_release(s, l);
+				/* take the readers that are left out of the count in one step; the last real reader may be doing the
+				 * same this instant, and only one of us releases the lane */
+				w = __atomic_load_n(&l->readers, __ATOMIC_ACQUIRE);
+				while ((uint32_t) w != 0 &&
+					   !__atomic_compare_exchange_n(&l->readers, &w, w & ~(uint64_t) 0xffffffffu, 0, __ATOMIC_ACQ_REL, __ATOMIC_ACQUIRE))
+					;
+				if ((uint32_t) w != 0)
+					lane_release(s, l);
 				continue;
 			}
 			pool_unlock(s);
@@ -436,7 +449,7 @@ pgv_host_pool_serve(pgv_pool * pool, int lane, pgv_index * view)
 		pool_lock(s);
 		l->state = LANE_PUBLISHED;
 		pool_unlock(s);
-		__atomic_store_n(&l->readers, n, __ATOMIC_RELEASE);
+		__atomic_store_n(&l->readers, ((uint64_t) gen << 32) | (uint32_t) n, __ATOMIC_RELEASE);
 		__atomic_store_n(&l->done_gen, gen, __ATOMIC_RELEASE);
 		word_wake_all(&l->done_gen);
 	}
@@ -524,7 +537,9 @@ pgv_host_pool_search(pgv_pool * pool, const void *query, uint64_t *out_tid, floa
 		__atomic_add_fetch(&l->fill, 1, __ATOMIC_RELEASE);
 		word_wake_all(&l->fill);
 	}
-	while ((seen = __atomic_load_n(&l->done_gen, __ATOMIC_ACQUIRE)) != gen)
+	/* (signed distance: a client that stalled past its batch's reclaim sees LATER batch numbers here and must not
+	 * wait for its own to come round again) */
+	while ((int32_t) ((seen = __atomic_load_n(&l->done_gen, __ATOMIC_ACQUIRE)) - gen) < 0)
 	{
 		if (__atomic_load_n(&s->shutdown, __ATOMIC_ACQUIRE))
 			return pgv_host_fail(PGV_ERR_STATE, "pgv_host_pool_search: the pool was shut down under a waiting query");
@@ -532,6 +547,8 @@ pgv_host_pool_search(pgv_pool * pool, const void *query, uint64_t *out_tid, floa
 			return pgv_host_fail(PGV_ERR_STATE, "pgv_host_pool_search: no server is attached to the pool");
 		word_wait_us(&l->done_gen, seen, 100000);
 	}
+	if (seen != gen)
+		return pgv_host_fail(PGV_ERR_STATE, "pgv_host_pool_search: the batch was reclaimed before this client read its answer");
 	rc = l->rc;
 	if (rc == PGV_OK)
 	{
@@ -540,9 +557,22 @@ pgv_host_pool_search(pgv_pool * pool, const void *query, uint64_t *out_tid, floa
 	}
 	else
 		pgv_host_fail(rc, "batch failed: %s", l->errmsg);
-	/* the lane is free again when its last reader has its answer */
-	if (__atomic_sub_fetch(&l->readers, 1, __ATOMIC_ACQ_REL) == 0)
-		lane_release(s, l);
+	/* count this reader out -- of ITS batch only; the lane is free again when its last reader has its answer.  A
+	 * reader that finds another batch number (or no readers left) was given up on by the lane's server
+	 * (POOL_RECLAIM_US): what it copied may belong to the next batch */
+	for (;;)
+	{
+		uint64_t	w = __atomic_load_n(&l->readers, __ATOMIC_ACQUIRE);
+
+		if ((uint32_t) (w >> 32) != gen || (uint32_t) w == 0)
+			return pgv_host_fail(PGV_ERR_STATE, "pgv_host_pool_search: the batch was reclaimed while this client read its answer");
+		if (__atomic_compare_exchange_n(&l->readers, &w, w - 1, 0, __ATOMIC_ACQ_REL, __ATOMIC_ACQUIRE))
+		{
+			if ((uint32_t) (w - 1) == 0)
+				lane_release(s, l);
+			break;
+		}
+	}
 	return rc;
 }
 

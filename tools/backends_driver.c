@@ -5,8 +5,10 @@
  * (pgv_query_rank + pgv_query_scan, src/ivfscan.c:361-414).  bench.py loads this as a shared object and hands it the
  * index it built.   gcc -O2 -shared -fPIC -pthread -Iinclude tools/backends_driver.c -o build/tools/libbackends.so
  */
+#define _GNU_SOURCE
 #include <pthread.h>
 #include <stdint.h>
+#include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
 #include <time.h>
@@ -30,7 +32,37 @@ typedef struct
 	double		t0,
 				t1;
 	int			rc;
+	volatile int phase;			/* where this backend is (PH_*): what a deadline reports */
+	volatile int done;			/* queries finished */
+	char		err[200];		/* pgv_last_error() of this thread, when rc != PGV_OK */
 }			backend;
+
+enum
+{
+	PH_NEW, PH_CTX, PH_SHARE, PH_BEGIN, PH_WARM_RANK, PH_WARM_SCAN, PH_START_LINE, PH_RANK, PH_SCAN, PH_CLEANUP, PH_OVER
+};
+static const char *const phase_name[] = {"not started", "pgv_ctx_create", "pgv_index_share", "pgv_query_begin", "warm-up pgv_query_rank",
+	"warm-up pgv_query_scan", "start line", "pgv_query_rank", "pgv_query_scan", "cleanup", "over"};
+
+/* join with a deadline (CLOCK_REALTIME seconds); 0 = joined */
+static int
+join_until(pthread_t th, double deadline_rt)
+{
+	struct timespec ts;
+
+	ts.tv_sec = (time_t) deadline_rt;
+	ts.tv_nsec = (long) ((deadline_rt - (double) ts.tv_sec) * 1e9);
+	return pthread_timedjoin_np(th, NULL, &ts);
+}
+
+static double
+now_rt(void)
+{
+	struct timespec ts;
+
+	clock_gettime(CLOCK_REALTIME, &ts);
+	return (double) ts.tv_sec + 1e-9 * (double) ts.tv_nsec;
+}
 
 static double
 now(void)
@@ -54,35 +86,48 @@ backend_main(void *arg)
 	int			count;
 	int64_t		total;
 
+	b->phase = PH_CTX;
 	b->rc = pgv_ctx_create(b->device, NULL, &ctx);
+	b->phase = PH_SHARE;
 	if (b->rc == PGV_OK)
 		b->rc = pgv_index_share(b->index, ctx, &view);
+	b->phase = PH_BEGIN;
 	if (b->rc == PGV_OK)
 		b->rc = pgv_query_begin(view, &q);
 	for (int j = 0; j < 20 && b->rc == PGV_OK; j++)
 	{
+		b->phase = PH_WARM_RANK;
 		b->rc = pgv_query_rank(q, b->queries + (size_t) ((b->id * 7 + j) % b->nq) * b->query_bytes, b->probes);
+		b->phase = PH_WARM_SCAN;
 		if (b->rc == PGV_OK)
 			b->rc = pgv_query_scan(q, 0, b->probes, b->k, dist, slot, tid, &count, &total);
 	}
+	b->phase = PH_START_LINE;
 	pthread_barrier_wait(b->start);
 	b->t0 = now();
 	for (int j = 0; j < b->per_thread && b->rc == PGV_OK; j++)
 	{
 		double		t = now();
 
+		b->phase = PH_RANK;
 		b->rc = pgv_query_rank(q, b->queries + (size_t) ((b->id * 31 + j) % b->nq) * b->query_bytes, b->probes);
+		b->phase = PH_SCAN;
 		if (b->rc == PGV_OK)
 			b->rc = pgv_query_scan(q, 0, b->probes, b->k, dist, slot, tid, &count, &total);
 		b->lat[j] = now() - t;
+		b->done = j + 1;
 	}
 	b->t1 = now();
+	if (b->rc != PGV_OK)
+		snprintf(b->err, sizeof(b->err), "%s", pgv_last_error());
+	b->phase = PH_CLEANUP;
 	if (q)
 		pgv_query_end(q);
 	if (view)
 		pgv_index_free(view);
 	if (ctx)
 		pgv_ctx_destroy(ctx);
+	b->phase = PH_OVER;
 	return NULL;
 }
 
@@ -95,22 +140,27 @@ cmp_double(const void *a, const void *b)
 	return x < y ? -1 : (x > y ? 1 : 0);
 }
 
-/* returns PGV_OK or the first backend's error; out[0] = queries/s over all backends, out[1] = p50, out[2] = p90 latency (us) */
+/* returns PGV_OK or the first backend's error; out[0] = queries/s over all backends, out[1] = p50, out[2] = p90 latency (us).
+ * A backend that has not come back `deadline_s` after the start is reported in errbuf with the call it sits in
+ * (PGV_ERR_STATE; its thread and arrays are left behind -- the caller is a measurement process that ends soon). */
 int
 backends_run(pgv_index * index, int device, int nbackends, int per_thread, const void *queries, int nq,
-			 size_t query_bytes, int probes, int k, double *out)
+			 size_t query_bytes, int probes, int k, double deadline_s, double *out, char *errbuf, size_t errcap)
 {
 	backend    *b = calloc((size_t) nbackends, sizeof(backend));
 	pthread_t  *th = calloc((size_t) nbackends, sizeof(pthread_t));
 	double	   *lat = malloc(sizeof(double) * (size_t) nbackends * per_thread);
-	pthread_barrier_t start;
+	pthread_barrier_t *start = malloc(sizeof(pthread_barrier_t));
 	double		first = 1e300,
-				last = 0;
+				last = 0,
+				deadline = now_rt() + (deadline_s > 0 ? deadline_s : 60.0);
 	int			rc = PGV_OK;
 
+	if (errbuf && errcap)
+		errbuf[0] = 0;
 	if (k > 64)
 		k = 64;
-	pthread_barrier_init(&start, NULL, (unsigned) nbackends);
+	pthread_barrier_init(start, NULL, (unsigned) nbackends);
 	for (int i = 0; i < nbackends; i++)
 	{
 		b[i].index = index;
@@ -122,21 +172,39 @@ backends_run(pgv_index * index, int device, int nbackends, int per_thread, const
 		b[i].query_bytes = query_bytes;
 		b[i].probes = probes;
 		b[i].k = k;
-		b[i].start = &start;
+		b[i].start = start;
 		b[i].lat = lat + (size_t) i * per_thread;
 		pthread_create(&th[i], NULL, backend_main, &b[i]);
 	}
 	for (int i = 0; i < nbackends; i++)
 	{
-		pthread_join(th[i], NULL);
+		if (join_until(th[i], deadline) != 0)
+		{
+			/* somebody is stuck: say who and where, and leave everything they may still touch alone */
+			size_t		at = 0;
+
+			if (errbuf && errcap)
+			{
+				at += (size_t) snprintf(errbuf + at, errcap - at, "%d backends, %.0f s: not back:", nbackends, deadline_s);
+				for (int j = i; j < nbackends && at + 64 < errcap; j++)
+					if (b[j].phase != PH_OVER)
+						at += (size_t) snprintf(errbuf + at, errcap - at, " [#%d in %s after %d queries]", j, phase_name[b[j].phase], b[j].done);
+			}
+			return PGV_ERR_STATE;
+		}
 		if (b[i].rc != PGV_OK && rc == PGV_OK)
+		{
 			rc = b[i].rc;
+			if (errbuf && errcap)
+				snprintf(errbuf, errcap, "backend %d: %s", i, b[i].err);
+		}
 		if (b[i].t0 < first)
 			first = b[i].t0;
 		if (b[i].t1 > last)
 			last = b[i].t1;
 	}
-	pthread_barrier_destroy(&start);
+	pthread_barrier_destroy(start);
+	free(start);
 	if (rc == PGV_OK)
 	{
 		size_t		n = (size_t) nbackends * per_thread;
@@ -168,6 +236,9 @@ typedef struct
 	double		t0,
 				t1;
 	int			rc;
+	volatile int done;			/* -1: warming up; else queries finished */
+	volatile int over;
+	char		err[200];
 }			client;
 
 static void *
@@ -177,9 +248,11 @@ client_main(void *arg)
 	uint64_t	tid[64];
 	float		dist[64];
 
+	c->done = -1;
 	for (int j = 0; j < 5 && c->rc == PGV_OK; j++)
 		c->rc = pgv_host_pool_search(c->pool, c->queries + (size_t) ((c->id * 7 + j) % c->nq) * c->query_bytes, tid, dist);
 	pthread_barrier_wait(c->start);
+	c->done = 0;
 	c->t0 = now();
 	for (int j = 0; j < c->per_thread && c->rc == PGV_OK; j++)
 	{
@@ -187,39 +260,53 @@ client_main(void *arg)
 
 		c->rc = pgv_host_pool_search(c->pool, c->queries + (size_t) ((c->id * 31 + j) % c->nq) * c->query_bytes, tid, dist);
 		c->lat[j] = now() - t;
+		c->done = j + 1;
 	}
 	c->t1 = now();
+	if (c->rc != PGV_OK)
+		snprintf(c->err, sizeof(c->err), "%s", pgv_host_last_error());
+	c->over = 1;
 	return NULL;
 }
 
-/* out[0] = queries/s over all clients, out[1] = p50, out[2] = p90 latency (us), out[3] = mean batch size */
+/* out[0] = queries/s over all clients, out[1] = p50, out[2] = p90 latency (us), out[3] = mean batch size.  Clients not back
+ * `deadline_s` after the start are reported in errbuf (PGV_ERR_STATE; the pool and its threads are then left behind). */
 int
 pool_run(pgv_index * index, int device, int dtype, int dim, int nclients, int per_thread, const void *queries, int nq,
-		 size_t query_bytes, int probes, int k, int max_batch, int max_wait_us, int lanes, double *out)
+		 size_t query_bytes, int probes, int k, int max_batch, int max_wait_us, int lanes, double deadline_s, double *out,
+		 char *errbuf, size_t errcap)
 {
 	pgv_pool   *pool = NULL;
 	client	   *c;
 	pthread_t  *th;
 	double	   *lat;
-	pthread_barrier_t start;
+	pthread_barrier_t *start;
 	pthread_attr_t attr;
 	double		first = 1e300,
-				last = 0;
+				last = 0,
+				deadline = now_rt() + (deadline_s > 0 ? deadline_s : 60.0);
 	int64_t		batches0,
 				queries0,
 				batches1,
 				queries1;
 	int			rc;
 
+	if (errbuf && errcap)
+		errbuf[0] = 0;
 	if (k > 64)
 		k = 64;
 	rc = pgv_host_pool_create(index, device, (pgv_dtype) dtype, dim, probes, k, max_batch, max_wait_us, lanes, &pool);
 	if (rc != PGV_OK)
+	{
+		if (errbuf && errcap)
+			snprintf(errbuf, errcap, "pgv_host_pool_create: %s", pgv_host_last_error());
 		return rc;
+	}
 	c = calloc((size_t) nclients, sizeof(client));
 	th = calloc((size_t) nclients, sizeof(pthread_t));
 	lat = malloc(sizeof(double) * (size_t) nclients * per_thread);
-	pthread_barrier_init(&start, NULL, (unsigned) nclients + 1);
+	start = malloc(sizeof(pthread_barrier_t));
+	pthread_barrier_init(start, NULL, (unsigned) nclients);
 	pthread_attr_init(&attr);
 	pthread_attr_setstacksize(&attr, 256 * 1024);
 	for (int i = 0; i < nclients; i++)
@@ -231,26 +318,49 @@ pool_run(pgv_index * index, int device, int dtype, int dim, int nclients, int pe
 		c[i].nq = nq;
 		c[i].query_bytes = query_bytes;
 		c[i].k = k;
-		c[i].start = &start;
+		c[i].start = start;
 		c[i].lat = lat + (size_t) i * per_thread;
 		pthread_create(&th[i], &attr, client_main, &c[i]);
 	}
-	pgv_host_pool_stats(pool, &batches0, &queries0);	/* (the warm-up rounds are still running: an estimate) */
-	pthread_barrier_wait(&start);
+	pthread_attr_destroy(&attr);
+	/* (the warm-up rounds may still be running: the batch statistics are an estimate at the front edge) */
 	pgv_host_pool_stats(pool, &batches0, &queries0);
 	for (int i = 0; i < nclients; i++)
 	{
-		pthread_join(th[i], NULL);
+		if (join_until(th[i], deadline) != 0)
+		{
+			size_t		at = 0;
+			int			stuck = 0;
+
+			for (int j = i; j < nclients; j++)
+				stuck += !c[j].over;
+			if (errbuf && errcap)
+			{
+				at += (size_t) snprintf(errbuf + at, errcap - at, "%d pooled clients, %.0f s: %d not back:", nclients, deadline_s, stuck);
+				for (int j = i, shown = 0; j < nclients && shown < 8 && at + 64 < errcap; j++)
+					if (!c[j].over)
+					{
+						at += (size_t) snprintf(errbuf + at, errcap - at, " [#%d %s %d]", j, c[j].done < 0 ? "warming up" : "after queries:", c[j].done);
+						shown++;
+					}
+			}
+			pgv_host_pool_shutdown(pool);	/* wakes every sleeper; whoever is stuck elsewhere stays */
+			return PGV_ERR_STATE;
+		}
 		if (c[i].rc != PGV_OK && rc == PGV_OK)
+		{
 			rc = c[i].rc;
+			if (errbuf && errcap)
+				snprintf(errbuf, errcap, "client %d: %s", i, c[i].err);
+		}
 		if (c[i].t0 < first)
 			first = c[i].t0;
 		if (c[i].t1 > last)
 			last = c[i].t1;
 	}
 	pgv_host_pool_stats(pool, &batches1, &queries1);
-	pthread_attr_destroy(&attr);
-	pthread_barrier_destroy(&start);
+	pthread_barrier_destroy(start);
+	free(start);
 	if (rc == PGV_OK)
 	{
 		size_t		n = (size_t) nclients * per_thread;
@@ -337,7 +447,7 @@ int
 backends_run_processes(pgv_index * index, const char *image_shm, int device, int mode, int nclients, int per_client,
 					   int warmup, const void *queries, int nq, size_t query_bytes, int dtype, int dim, int probes, int k,
 					   int max_batch, int max_wait_us, int lanes, int server_processes, const char *exe, int verify,
-					   uint64_t *ans_tid, float *ans_dist, double *out, char *errbuf, size_t errcap)
+					   double deadline_s, uint64_t *ans_tid, float *ans_dist, double *out, char *errbuf, size_t errcap)
 {
 	char		pool_name[64],
 				bank_name[64],
@@ -463,7 +573,7 @@ backends_run_processes(pgv_index * index, const char *image_shm, int device, int
 	}
 	/* everybody warmed up and at the start line (or somebody died on the way) */
 	{
-		double		deadline = now() + 90.0;
+		double		deadline = now() + (deadline_s > 0 ? deadline_s : 90.0);
 
 		while (__atomic_load_n(&bank->ready, __ATOMIC_ACQUIRE) < (uint32_t) nclients)
 		{
@@ -481,7 +591,8 @@ backends_run_processes(pgv_index * index, const char *image_shm, int device, int
 				}
 			}
 			if (now() > deadline)
-				FAILP(PGV_ERR_STATE, "clients did not reach the start line in 90 s");
+				FAILP(PGV_ERR_STATE, "%u of %d clients at the start line after %.0f s", __atomic_load_n(&bank->ready, __ATOMIC_ACQUIRE),
+					  nclients, deadline_s > 0 ? deadline_s : 90.0);
 			syscall(SYS_futex, &bank->ready, FUTEX_WAIT, __atomic_load_n(&bank->ready, __ATOMIC_ACQUIRE), &rel, NULL, 0);
 		}
 	}
@@ -492,7 +603,7 @@ backends_run_processes(pgv_index * index, const char *image_shm, int device, int
 	/* the clients are the last nclients pids; a run that does not end in 90 s is given up (the children are killed
 	 * below) -- a measurement harness must not be able to hang its caller */
 	{
-		double		deadline = now() + 90.0;
+		double		deadline = now() + (deadline_s > 0 ? deadline_s : 90.0);
 		int			left = nclients;
 
 		while (left > 0)
@@ -520,7 +631,7 @@ backends_run_processes(pgv_index * index, const char *image_shm, int device, int
 					left++;
 			}
 			if (left > 0 && now() > deadline)
-				FAILP(PGV_ERR_STATE, "%d of %d clients had not finished after 90 s", left, nclients);
+				FAILP(PGV_ERR_STATE, "%d of %d clients had not finished after %.0f s", left, nclients, deadline_s > 0 ? deadline_s : 90.0);
 			if (left > 0)
 				usleep(2000);
 		}
@@ -571,8 +682,13 @@ out:
 				{
 					if (now() > deadline)
 					{
+						/* a killed child is reaped when it goes -- but one that sits in an uninterruptible driver call
+						 * does not go, and this harness does not wait for it (two seconds, then init inherits it) */
+						double		give_up = now() + 2.0;
+
 						kill(pids[i], SIGKILL);
-						waitpid(pids[i], &st, 0);
+						while (waitpid(pids[i], &st, WNOHANG) == 0 && now() < give_up)
+							usleep(2000);
 						break;
 					}
 					usleep(2000);

@@ -51,13 +51,12 @@ def main():
     comp = torch.randint(0, ncomp, (256,), generator=g, device=dev)
     qh = np.ascontiguousarray((means[comp] + 0.1 * torch.randn((256, dim), generator=g, device=dev)).cpu().numpy())
     out = {"GPU_MAX_HW_QUEUES": os.environ.get("GPU_MAX_HW_QUEUES"), "rows": n, "lists": lists, "threads": {}, "processes": {}}
-    drv = _host.backends_driver()
-    drv.backends_run.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_size_t, C.c_int, C.c_int,
-                                 C.POINTER(C.c_double)]
-    res = (C.c_double * 3)()
     for nb in [int(x) for x in args.threads.split(",") if x]:
-        rc = drv.backends_run(ix.h, 0, nb, args.per, qh.ctypes.data, qh.shape[0], qh.strides[0], probes, k, res)
-        out["threads"][str(nb)] = {"rc": rc, "qps": res[0], "p50_us": res[1], "p90_us": res[2]}
+        try:
+            r = _host.run_backend_threads(ix, qh, probes, k, nb, args.per)
+            out["threads"][str(nb)] = {"rc": 0, "qps": r["qps"], "p50_us": r["latency_us_p50"], "p90_us": r["latency_us_p90"]}
+        except Exception as e:  # noqa: BLE001
+            out["threads"][str(nb)] = {"error": repr(e)}
         print("threads", nb, out["threads"][str(nb)], file=sys.stderr, flush=True)
     for nb in [int(x) for x in args.procs.split(",") if x]:
         try:
