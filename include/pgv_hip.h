@@ -180,6 +180,8 @@ typedef struct pgv_stats
 	/* L2 batches scanned on the matrix cores: queries whose k' candidates could not be proven to hold
 	 * the whole head and took the exact pass over their segment as well */
 	double		scan_redo_queries;
+	/* ... and those that a wider candidate set (256 instead of k') did settle, without the exact pass */
+	double		scan_widened_queries;
 }			pgv_stats;
 int			pgv_ctx_set_profiling(pgv_ctx * ctx, int on);
 /*
@@ -191,17 +193,21 @@ int			pgv_ctx_set_profiling(pgv_ctx * ctx, int on);
 int			pgv_ctx_set_exact_scan(pgv_ctx * ctx, int on);
 /*
  * How the MFMA L2 paths (batched list scan, center ranking, assignment pre-filter, pgv_exact_topk) bound the
- * distance between the expansion's value and the reference's fp32 sum((q - x)^2) when they decide that a candidate
- * set is complete.  Row ids "must match the reference CPU path": with either bound every decision the bound cannot
- * settle goes to the exact kernels; what differs is whether the bound itself can be exceeded.
- *   PGV_BOUND_STATISTICAL (default)  8 sqrt(dim + 4) 2^-24 (|q| + |x|max)^2 -- the probabilistic model of a length-dim
- *       fp32 summation (fails with probability ~ e^-32 per sum); 5-10 x narrower at 1536-3072 dimensions, which
- *       keeps the recheck band at a few candidates and flags no query on ordinary data
- *   PGV_BOUND_WORST_CASE  (gamma_(dim+1) + gamma_(dim+2)) (|q| + |x|max)^2, gamma_n = n 2^-24 / (1 - n 2^-24): the
- *       deterministic bound of IEEE fp32 accumulation in any order, including the reference's own rounding.  Costs
- *       more rechecks and more queries redone exactly (bench.py reports both settings side by side:
- *       `bound_modes`); results are identical whenever the statistical bound held, which is every case measured.
- * pgv_ctx_set_exact_scan(ctx, 1) remains the mode that uses no expansion at all.
+ * distance between the expansion's value |x|^2 - 2 q.x and the true one when they decide that a candidate set is
+ * complete.  Row ids "must match the reference CPU path": with either bound every decision the bound cannot settle
+ * goes to the exact kernels; what differs is whether the bound itself can be exceeded.
+ *   PGV_BOUND_WORST_CASE (default)  deterministic: the list scan keeps FOUR independent accumulator chains per output,
+ *       so its dot product errs by at most gamma_(dim/4 + 4) |q||x| (Higham, Lemma 3.1: any order of n rounded
+ *       products), gamma_n = n v / (1 - n v) with v = 2^-23 per operation (twice round-to-nearest's unit roundoff, so
+ *       that a truncating step inside the matrix pipeline is covered); + the row norm's own chain; + the rounding of
+ *       the exact form sum((q - x)^2) -- the reference's and ours -- which is relative to the DISTANCE, not to
+ *       (|q| + |x|)^2.  At 1536 dimensions: 4.7e-5 x 2 |q||x|max, about the width of the statistical band, which is
+ *       why it can be the default (bench.py `bound_modes`: both side by side; round 3's form of it,
+ *       (gamma_(dim+1) + gamma_(dim+2)) (|q| + |x|max)^2 on one chain, flagged every query and cost 98 %).
+ *   PGV_BOUND_STATISTICAL  8 sqrt(dim + 4) 2^-24 (|q| + |x|max)^2 -- the probabilistic model of a length-dim fp32
+ *       summation (fails with probability ~ e^-32 per sum).
+ * The assignment pre-filter (one chain per output) uses gamma_(dim+1) (|c|^2 + 2 |a||c|) + gamma_(dim+2) d in the
+ * worst-case mode.  pgv_ctx_set_exact_scan(ctx, 1) remains the mode that uses no expansion at all.
  */
 #define PGV_BOUND_STATISTICAL 0
 #define PGV_BOUND_WORST_CASE 1

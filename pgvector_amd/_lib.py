@@ -59,7 +59,7 @@ class PgvStats(C.Structure):
     _fields_ = [("scan_ms", C.c_double), ("scan_launches", C.c_int64),
                 ("scan_pairs", C.c_double), ("scan_rows", C.c_double),
                 ("aux_ms", C.c_double), ("aux_launches", C.c_int64), ("aux_pairs", C.c_double),
-                ("assign_redo_rows", C.c_double), ("assign_rows", C.c_double), ("assign_recheck_rows", C.c_double), ("scan_unique_rows", C.c_double), ("scan_redo_queries", C.c_double)]
+                ("assign_redo_rows", C.c_double), ("assign_rows", C.c_double), ("assign_recheck_rows", C.c_double), ("scan_unique_rows", C.c_double), ("scan_redo_queries", C.c_double), ("scan_widened_queries", C.c_double)]
 
 
 ALL_REDUCE_F32 = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p)

@@ -129,7 +129,8 @@ class Context:
                 "scan_pairs": s.scan_pairs, "scan_rows": s.scan_rows,
                 "aux_ms": s.aux_ms, "aux_launches": s.aux_launches, "aux_pairs": s.aux_pairs,
                 "assign_redo_rows": s.assign_redo_rows, "assign_rows": s.assign_rows,
-                "assign_recheck_rows": s.assign_recheck_rows, "scan_unique_rows": s.scan_unique_rows, "scan_redo_queries": s.scan_redo_queries}
+                "assign_recheck_rows": s.assign_recheck_rows, "scan_unique_rows": s.scan_unique_rows, "scan_redo_queries": s.scan_redo_queries,
+                "scan_widened_queries": s.scan_widened_queries}
 
 
 class IvfIndex:

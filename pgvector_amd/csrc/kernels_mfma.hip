@@ -22,8 +22,8 @@
 //   bound of a length-dim fp32 summation (Higham & Mary 2019: lambda * sqrt(n) * u fails with
 //   probability ~ exp(-lambda^2 / 2) per sum; lambda = 8), an order of magnitude tighter than
 //   the worst-case n * u and still far above any error seen.  pgv_ctx_set_bound(PGV_BOUND_WORST_CASE)
-//   replaces it by the deterministic gamma_(dim+1) (|c|^2 + 2 |a||c|) + gamma_(dim+2) (|a| + |c|)^2, the second
-//   term being the reference's own fp32 rounding of sum((a-c)^2) (expansion_bound, pgv_internal.h).
+//   replaces it by the deterministic gamma_(dim+1) (|c|^2 + 2 |a||c|) + gamma_(dim+2) d, the second term being the
+//   reference's own fp32 rounding of d = sum((a-c)^2), relative to that distance (argmin_bound, pgv_internal.h).
 //   A row whose 4th-best pre-filter
 //   value is not more than twice that bound above its best (more than 4 centers could be the
 //   true minimum) is put on a list and redone by the exact vector-ALU kernel.  Exact ties
@@ -131,6 +131,26 @@ template <> struct Mma<__half> {
     }
 };
 
+// The list scan's forms: FOUR independent accumulators per output (chain e gets every 4th k-group), summed as
+// (c0 + c1) + (c2 + c3) in the epilogue.  Each chain adds up dim / 4 products, so the worst-case rounding error of the
+// dot product is gamma_(dim/4 + 2) sum |a_i b_i| instead of gamma_dim -- which is what makes the DETERMINISTIC
+// completeness bound of the L2 scan (scan_bound, pgv_internal.h) as tight as the statistical one was; the
+// chains are also independent MFMA issue streams (no dependent-issue stalls).
+template <typename T> struct Mma4;
+template <> struct Mma4<float> {
+    static __device__ __forceinline__ void run(f32x16 (&acc)[4], const u32x4 &a, const u32x4 &b, int) {
+#pragma unroll
+        for (int e = 0; e < 4; e++)
+            acc[e] = __builtin_amdgcn_mfma_f32_32x32x2f32(__uint_as_float(a[e]), __uint_as_float(b[e]), acc[e], 0, 0, 0);
+    }
+};
+template <> struct Mma4<__half> {
+    static __device__ __forceinline__ void run(f32x16 (&acc)[4], const u32x4 &a, const u32x4 &b, int c) {
+        acc[c] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), acc[c],
+                                                        0, 0, 0);
+    }
+};
+
 // 16-wide forms: one A fragment against two B fragments (two independent accumulators hide the
 // 40-cycle dependent-issue latency of the 16x16 shapes)
 typedef float f32x4 __attribute__((ext_vector_type(4)));
@@ -148,6 +168,29 @@ template <> struct Mma16<__half> {
     static __device__ __forceinline__ void run(f32x4 &c0, f32x4 &c1, const u32x4 &a, const u32x4 &b0, const u32x4 &b1) {
         c0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b0), c0, 0, 0, 0);
         c1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b1), c1, 0, 0, 0);
+    }
+};
+
+// ... and their four-chain variants for the list scan (chain = k-slot of the operand for fp32; read c + 2 x slice
+// parity for fp16, whose 16-wide shape takes a whole 16-byte operand per instruction)
+template <typename T> struct Mma16x4;
+template <> struct Mma16x4<float> {
+    static __device__ __forceinline__ void run(f32x4 (&c0)[4], f32x4 (&c1)[4], const u32x4 &a, const u32x4 &b0,
+                                               const u32x4 &b1, int) {
+#pragma unroll
+        for (int e = 0; e < 4; e++) {
+            c0[e] = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(a[e]), __uint_as_float(b0[e]), c0[e], 0, 0, 0);
+            c1[e] = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(a[e]), __uint_as_float(b1[e]), c1[e], 0, 0, 0);
+        }
+    }
+};
+template <> struct Mma16x4<__half> {
+    static __device__ __forceinline__ void run(f32x4 (&c0)[4], f32x4 (&c1)[4], const u32x4 &a, const u32x4 &b0,
+                                               const u32x4 &b1, int chain) {
+        c0[chain] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b0),
+                                                           c0[chain], 0, 0, 0);
+        c1[chain] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b1),
+                                                           c1[chain], 0, 0, 0);
     }
 };
 
@@ -186,7 +229,9 @@ __device__ __forceinline__ void finish_row(int64_t r, const float (&sv)[NC], con
         // sees every center anyway)
         const float cm2 = __uint_as_float(*cmax2_bits);
         const float cross = 2.f * sqrtf(x2 * cm2);
-        const float margin = 2.f * (gamma * (cm2 + cross) + gamma_x * (x2 + cm2 + cross));
+        // twice the expansion's own error + the exact form's rounding, which is RELATIVE to the distance it rounds
+        // (all its terms are positive): the runner-up's, sv[1] + |a|^2 -- every other center is further still
+        const float margin = 2.f * gamma * (cm2 + cross) + 2.02f * gamma_x * fabsf(sv[1] + x2);
         if (sv[0] < INFINITY && sv[1] - sv[0] > margin) {
             out_idx[r] = sid[0];
         } else {
@@ -589,8 +634,8 @@ __global__ __launch_bounds__(256) void recheck_kernel(const char *__restrict__ r
     if (k > kCand) {
         const float cm2 = __uint_as_float(*cmax2_bits);
         const float cross = 2.f * sqrtf(xx * cm2);
-        const float margin = 2.f * (gamma * (cm2 + cross) + gamma_x * (xx + cm2 + cross));
         const float v0 = u_val[p * kCand], v3 = u_val[p * kCand + kCand - 1];
+        const float margin = 2.f * gamma * (cm2 + cross) + 2.02f * gamma_x * fabsf(v3 + xx);
         if (!(v3 < INFINITY && v3 - v0 > margin)) {
             packed[r] = ~0ull;
             fb_rows[atomicAdd(fb_count, 1)] = (int32_t)r;
@@ -751,7 +796,7 @@ int launch_mfma_mode(pgv_ctx *ctx, int mode, const RowGeom &g, const void *rows,
                        static_cast<const char *>(centers), k, g.nvec, bias, cmax2);
     L2Lists l2;
     l2.cmax2 = cmax2;
-    const ExpansionBound eb = expansion_bound(ctx, g.ld);  // 8 sqrt(dim + 4) 2^-24 (see the header), or the worst case
+    const ExpansionBound eb = argmin_bound(ctx, g.ld);  // 8 sqrt(dim + 4) 2^-24 (see the header), or the worst case
     l2.gamma = eb.gamma;
     l2.gamma_x = eb.gamma_exact;
     l2.u_count = u_count;
@@ -795,8 +840,8 @@ int launch_mfma_mode(pgv_ctx *ctx, int mode, const RowGeom &g, const void *rows,
 // and the 32 lanes of a half-wave hold 32 consecutive rows of one query: 128-byte stores into
 // the queries' output segments.
 //   METRIC 1 (negative inner product): the value is the reference's arithmetic.
-//   METRIC 0 (L2): |x|^2 - 2 q.x with the rows' precomputed norms (+ |q|^2 when the caller hands the queries' in:
-//   it shifts all values of a query alike, so the selections run without it) -- an APPROXIMATION of
+//   METRIC 0 (L2): |x|^2 - 2 q.x with the rows' precomputed norms (no |q|^2: it shifts all values of a query alike,
+//   so the selections run without it) -- an APPROXIMATION of
 //   sum((q-x)^2) (cancellation), used only to pick candidates; pgv_abi.hip's scan_batch_dev
 //   re-evaluates the exact form for the k' best and checks that nothing outside them can matter.
 constexpr int kScanQueries = 32;   // queries per task
@@ -807,18 +852,16 @@ constexpr int kScanWaves = 4;      // one 32 x 32 tile each: a task is 128 rows
 // batch: +3.5 % on the 6 GB headline index, 1.145 -> 1.102 ms per batch, same box, alternating runs); the query rows,
 // which every task of a group re-reads, keep the default policy
 template <typename T, int METRIC, int NW, bool NT>
-__global__ __launch_bounds__(NW * 64) void mfma_scan_kernel(
+__global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(3, 3))) void mfma_scan_kernel(
     const char *__restrict__ rows, const char *__restrict__ queries, const ScanTask *__restrict__ tasks,
     const int *__restrict__ ntasks_ptr, int *__restrict__ task_counter, const ScanPair *__restrict__ pairs,
-    const float *__restrict__ row_norms, const float *__restrict__ query_norms, int nvec,
-    const char *__restrict__ zeros16, float *__restrict__ out) {
+    const float *__restrict__ row_norms, int nvec, const char *__restrict__ zeros16, float *__restrict__ out) {
     constexpr int ROWS = 32 * NW;
     constexpr int NGROUPS = (kScanQueries + ROWS) / 8;          // DMA instructions per stage (8 rows each)
     constexpr int NDMA = (NGROUPS + NW - 1) / NW;               // ... per wavefront, at most
     constexpr int STAGE = (kScanQueries + ROWS) * kSliceBytes;  // 20 KB (NW 4) / 36 KB (NW 8)
     __shared__ __attribute__((aligned(16))) char smem[2 * STAGE];
     __shared__ int64_t pair_rel[kScanQueries];
-    __shared__ float pair_qn[kScanQueries];
     __shared__ int lds_task;
 
     const int lane = threadIdx.x & (kWave - 1);
@@ -854,8 +897,6 @@ __global__ __launch_bounds__(NW * 64) void mfma_scan_kernel(
             // slots past the task's last query repeat that query
             const ScanPair pr = pairs[task.pair0 + ((int)threadIdx.x < np ? (int)threadIdx.x : np - 1)];
             pair_rel[threadIdx.x] = pr.out_rel + task.row0;
-            // |q|^2 shifts every value of a query alike: the selection does not need it, the exact tail computes it
-            pair_qn[threadIdx.x] = (METRIC == 0 && query_norms) ? query_norms[pr.query] : 0.f;
         }
         const char *src[NDMA];
 #pragma unroll
@@ -893,9 +934,11 @@ __global__ __launch_bounds__(NW * 64) void mfma_scan_kernel(
         // pair table to registers (after the loop: a store followed by an LDS read makes hipcc wait for the store)
         const int j32 = wave * 32 + l31;
         if (!narrow) {
-            f32x16 acc;
+            f32x16 acc4[4];
 #pragma unroll
-            for (int r = 0; r < 16; r++) acc[r] = 0.f;
+            for (int e = 0; e < 4; e++)
+#pragma unroll
+                for (int r = 0; r < 16; r++) acc4[e][r] = 0.f;
             const unsigned a_lane = (unsigned)l31 * kSliceBytes;                                   // query l31
             const unsigned b_lane = (unsigned)(kScanQueries + wave * 32 + l31) * kSliceBytes;      // row wave * 32 + l31
             issue_stage(0, 0);
@@ -913,32 +956,33 @@ __global__ __launch_bounds__(NW * 64) void mfma_scan_kernel(
                                  : "=&v"(a), "=&v"(b)
                                  : "v"(sbase + a_lane + x), "v"(sbase + b_lane + x)
                                  : "memory");
-                    Mma<T>::run(acc, a, b);
+                    Mma4<T>::run(acc4, a, b, c);
                 }
             }
+            const f32x16 acc = (acc4[0] + acc4[1]) + (acc4[2] + acc4[3]);
             // lane: row j32 of the task; register r: query (r & 3) + 8 (r >> 2) + 4 half.  Slots past the
             // task's last query hold copies of that query (same operands, same value, same address): they
             // are stored too, so that the 16 stores are one straight run -- a branch per store makes hipcc
             // wait for the previous store each time
             int64_t rel[16];
-            float qn[16];
 #pragma unroll
-            for (int r = 0; r < 16; r++) {
-                const int qi = (r & 3) + 8 * (r >> 2) + 4 * half;
-                rel[r] = pair_rel[qi];
-                qn[r] = pair_qn[qi];
-            }
+            for (int r = 0; r < 16; r++) rel[r] = pair_rel[(r & 3) + 8 * (r >> 2) + 4 * half];
             if (j32 < task.nrows) {
                 const float rn = METRIC == 0 ? row_norms[task.row0 + j32] : 0.f;
 #pragma unroll
                 for (int r = 0; r < 16; r++)
-                    out[rel[r] + j32] = METRIC == 0 ? fmaf(-2.f, acc[r], rn + qn[r]) : -acc[r];
+                    out[rel[r] + j32] = METRIC == 0 ? fmaf(-2.f, acc[r], rn) : -acc[r];
             }
         } else {
             // 16 x 16 tiles: lane = (row or query l15, k-group kg); two row halves per wavefront
             const int l15 = lane & 15, kg = lane >> 4;
             const unsigned sw15 = (unsigned)(l15 >> 1) & 7u;
-            f32x4 c0 = {0.f, 0.f, 0.f, 0.f}, c1 = {0.f, 0.f, 0.f, 0.f};
+            f32x4 c04[4], c14[4];
+#pragma unroll
+            for (int e = 0; e < 4; e++) {
+                c04[e] = f32x4{0.f, 0.f, 0.f, 0.f};
+                c14[e] = f32x4{0.f, 0.f, 0.f, 0.f};
+            }
             const unsigned a_lane = (unsigned)l15 * kSliceBytes;
             const unsigned b_lane = (unsigned)(kScanQueries + wave * 32 + l15) * kSliceBytes;  // second half: + 16 rows
             issue_stage(0, 0);
@@ -956,27 +1000,28 @@ __global__ __launch_bounds__(NW * 64) void mfma_scan_kernel(
                                  : "=&v"(a), "=&v"(b0), "=&v"(b1)
                                  : "v"(sbase + a_lane + x), "v"(sbase + b_lane + x)
                                  : "memory");
-                    Mma16<T>::run(c0, c1, a, b0, b1);
+                    // (a uniform branch, not an index computed at run time: the accumulators stay in registers)
+                    if (sl & 1)
+                        Mma16x4<T>::run(c04, c14, a, b0, b1, c + 2);
+                    else
+                        Mma16x4<T>::run(c04, c14, a, b0, b1, c);
                 }
             }
+            const f32x4 c0 = (c04[0] + c04[1]) + (c04[2] + c04[3]), c1 = (c14[0] + c14[1]) + (c14[2] + c14[3]);
             // lane: rows wave * 32 + l15 (c0) and + 16 (c1); register r: query 4 kg + r
             int64_t rel[4];
-            float qn[4];
 #pragma unroll
-            for (int r = 0; r < 4; r++) {
-                rel[r] = pair_rel[4 * kg + r];
-                qn[r] = pair_qn[4 * kg + r];
-            }
+            for (int r = 0; r < 4; r++) rel[r] = pair_rel[4 * kg + r];
             const int ja = wave * 32 + l15, jb = ja + 16;
             const float rna = (METRIC == 0 && ja < task.nrows) ? row_norms[task.row0 + ja] : 0.f;
             const float rnb = (METRIC == 0 && jb < task.nrows) ? row_norms[task.row0 + jb] : 0.f;
             if (ja < task.nrows) {
 #pragma unroll
-                for (int r = 0; r < 4; r++) out[rel[r] + ja] = METRIC == 0 ? fmaf(-2.f, c0[r], rna + qn[r]) : -c0[r];
+                for (int r = 0; r < 4; r++) out[rel[r] + ja] = METRIC == 0 ? fmaf(-2.f, c0[r], rna) : -c0[r];
             }
             if (jb < task.nrows) {
 #pragma unroll
-                for (int r = 0; r < 4; r++) out[rel[r] + jb] = METRIC == 0 ? fmaf(-2.f, c1[r], rnb + qn[r]) : -c1[r];
+                for (int r = 0; r < 4; r++) out[rel[r] + jb] = METRIC == 0 ? fmaf(-2.f, c1[r], rnb) : -c1[r];
             }
         }
         __builtin_amdgcn_s_waitcnt(0xc07f);  // lgkmcnt(0): the pair table and the task id have been read ...
@@ -1067,7 +1112,7 @@ int launch_mfma_scan(pgv_ctx *ctx, pgv_metric metric, pgv_dtype dtype, const Row
 #define PGV_MSCAN_NT(T, M, NT)                                                                                       \
     hipLaunchKernelGGL((mfma_scan_kernel<T, M, kScanWaves, NT>), dim3(grid), dim3(kScanWaves * 64), 0, ctx->stream,   \
                        static_cast<const char *>(rows), static_cast<const char *>(queries), tasks, ntasks_dev, counter, \
-                       pairs, row_norms, query_norms, g.nvec, static_cast<const char *>(ctx->zeros.p), out)
+                       pairs, row_norms, g.nvec, static_cast<const char *>(ctx->zeros.p), out)
 #define PGV_MSCAN(T, M)              \
     do {                             \
         if (stream_rows)             \

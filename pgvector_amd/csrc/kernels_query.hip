@@ -334,7 +334,7 @@ __global__ __launch_bounds__(kQThreads) void batch_recheck_kernel(
     const int64_t *__restrict__ list_off, const int32_t *__restrict__ probe_lists,
     const int64_t *__restrict__ probe_off, int probes,
     const int64_t *__restrict__ seg_start, int64_t fixed_len,
-    const unsigned *__restrict__ row_norm_max, float gamma, int nq, float *__restrict__ out_dist,
+    const unsigned *__restrict__ row_norm_max, ScanBound bound, int nq, float *__restrict__ out_dist,
     int64_t *__restrict__ out_slot, uint64_t *__restrict__ out_tid, int32_t *__restrict__ out_i32,
     int32_t *__restrict__ flags) {
     __shared__ float exact[kRecheckCap];
@@ -364,8 +364,16 @@ __global__ __launch_bounds__(kQThreads) void batch_recheck_kernel(
     float qn = 0.f;
     for (int w = 0; w < kQWaves; w++) qn += qn_part[w];
     const float rn = __uint_as_float(*row_norm_max);
-    const float eps = gamma * (qn + rn + 2.f * sqrtf(qn * rn));
-    const unsigned band = kk > 0 ? float_to_key(av[kk - 1] + 2.f * eps) : 0u;  // NaN / inf anywhere: everything is in the band
+    // (pgv_internal.h, ScanBound; the norms computed here and there carry a relative error of a few u themselves:
+    // one part in a thousand on top covers it)
+    const float cross = 2.f * sqrtf(qn * rn);
+    const float eps = 1.001f * (bound.g_sq * (qn + rn + cross) + bound.g_dot * cross + bound.g_norm * rn);
+    // NaN / inf anywhere: everything is in the band
+    unsigned band = 0u;
+    if (kk > 0) {
+        const float edge = av[kk - 1] + 2.f * eps;
+        band = float_to_key(edge + bound.g_ref * fabsf(edge + qn));
+    }
     const int cnt = __syncthreads_count((int)threadIdx.x < ncand && float_to_key(av[threadIdx.x]) <= band);
     // the candidates' row slots: given (the center ranking: a center's position is its id), or worked out here from
     // the positions in the query's segment (the list scan; what positions_to_slots_kernel does for the exact paths)
@@ -436,23 +444,33 @@ __global__ __launch_bounds__(kQThreads) void batch_recheck_kernel(
 }
 
 // The flagged queries, start to end in one launch (they are rare -- none on ordinary data -- so the three launches
-// this used to be were three dependent kernel boundaries for nothing): a workgroup takes a flagged query, scores
-// every row of its segment with the exact form (the whole segment, what the exact kernels would have done),
-// selects the head like topk_kernel and writes the query's output row.  Workgroups without a flagged query leave
-// at once.
+// this used to be were three dependent kernel boundaries for nothing).  A workgroup takes a flagged query and
+//   (1) WIDENS its candidate set: the kWide = 256 smallest approximate values of the segment (still in seg_vals),
+//       the rounding band around the k-th of them, the exact distances of the rows in the band.  When the band ends
+//       inside the 256 (or the segment has no more rows), the head is complete: sort by (exact distance, position),
+//       write the query's output row.  This settles a band that was a few dozen candidates too wide for k' at ~1 %
+//       of the cost of (2) (fp16 at 3072 dimensions under the deterministic bound: one query in nine).
+//   (2) otherwise scores every row of its segment with the exact form (the whole segment, what the exact kernels would
+//       have done), selects the head like topk_kernel and writes the query's output row.
+// Workgroups without a flagged query leave at once.
+constexpr int kWide = kRecheckCap;
+
 template <typename T>
 __global__ __launch_bounds__(kQThreads) void batch_fix_kernel(
     const char *__restrict__ vectors, const int64_t *__restrict__ list_off, const uint64_t *__restrict__ tids, int nvec,
     int lg, const char *__restrict__ queries, const int32_t *__restrict__ probe_lists,
     const int64_t *__restrict__ probe_off, int probes, const int64_t *__restrict__ seg_start, int64_t fixed_len,
     const int32_t *__restrict__ flags, int nq, float *__restrict__ seg_vals, int k, int kp, int cap,
+    const unsigned *__restrict__ row_norm_max, ScanBound bound, int widen,
     float *__restrict__ out_dist, int64_t *__restrict__ out_slot, uint64_t *__restrict__ out_tid,
     int32_t *__restrict__ out_i32, double *__restrict__ stats) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    unsigned long long *ent = reinterpret_cast<unsigned long long *>(smem);  // [cap >= kp]
+    unsigned long long *ent = reinterpret_cast<unsigned long long *>(smem);  // [cap >= max(kp, kWide)]
     SelShared *sel = reinterpret_cast<SelShared *>(smem + (size_t)cap * 8);
+    __shared__ float exact[kWide];
+    __shared__ int64_t slots[kWide];
+    __shared__ float qn_part[kQWaves];
     const int nflag = flags[nq];
-    if (stats && blockIdx.x == 0 && threadIdx.x == 0) stats[6] += (double)nflag;  // profiling: queries redone
     const size_t row_bytes = (size_t)nvec * sizeof(Raw16);
     for (int f = blockIdx.x; f < nflag; f += gridDim.x) {
         const int q = flags[nq + 1 + f];
@@ -474,8 +492,73 @@ __global__ __launch_bounds__(kQThreads) void batch_fix_kernel(
             return list_off[pl[lo]] + (j - off[lo]);
         };
         float *v = seg_vals + base;
-        score_rows<T, 0, 0>([&](int64_t j) { return vectors + (size_t)slot_of(j) * row_bytes; }, 0, m,
-                            queries + (size_t)q * row_bytes, nvec, lg, v);
+        const char *qrow = queries + (size_t)q * row_bytes;
+        bool settled = false;
+        if (widen && k <= kWide / 2) {
+            // (1) the kWide smallest approximate values, ascending by (value, position)
+            const int nw = (int)(m < kWide ? m : (int64_t)kWide);
+            block_topk([v](int64_t i) { return v[i]; }, m, nw, kWide, cap, ent, sel);
+            {
+                float a = 0.f;
+                for (int x = threadIdx.x; x < nvec; x += kQThreads) {
+                    const Raw16 e = load16(qrow + (size_t)x * sizeof(Raw16));
+                    a = accum_slice<T, 1>(a, e, e);
+                }
+                for (int m2 = 32; m2 > 0; m2 >>= 1) a += __shfl_xor(a, m2);
+                if ((threadIdx.x & (kWave - 1)) == 0) qn_part[threadIdx.x >> 6] = a;
+            }
+            __syncthreads();
+            float qn = 0.f;
+            for (int w = 0; w < kQWaves; w++) qn += qn_part[w];
+            const float rn = __uint_as_float(*row_norm_max);
+            const float cross = 2.f * sqrtf(qn * rn);
+            const float eps = 1.001f * (bound.g_sq * (qn + rn + cross) + bound.g_dot * cross + bound.g_norm * rn);
+            const int kk = nw < k ? nw : k;
+            unsigned band = 0u;
+            if (kk > 0) {
+                const float edge = key_to_float((unsigned)(ent[kk - 1] >> 32)) + 2.f * eps;
+                band = float_to_key(edge + bound.g_ref * fabsf(edge + qn));
+            }
+            const int cnt = __syncthreads_count((int)threadIdx.x < nw && (unsigned)(ent[threadIdx.x] >> 32) <= band);
+            settled = !(m > nw && cnt == nw);  // (block-uniform)
+            if (settled) {
+                const unsigned my_pos = (int)threadIdx.x < cnt ? (unsigned)(ent[threadIdx.x] & 0xffffffffu) : 0u;
+                if ((int)threadIdx.x < cnt) slots[threadIdx.x] = slot_of((int64_t)my_pos);
+                __syncthreads();
+                score_rows<T, 0, 0>([&](int64_t j) { return vectors + (size_t)slots[j] * row_bytes; }, 0, cnt, qrow, nvec, lg,
+                                    exact);
+                __syncthreads();
+                if ((int)threadIdx.x < kWide)
+                    ent[threadIdx.x] = (int)threadIdx.x < cnt
+                                           ? ((unsigned long long)float_to_key(exact[threadIdx.x]) << 32) | my_pos
+                                           : ~0ull;
+                __syncthreads();
+                const unsigned long long mine = ent[threadIdx.x];
+                int rank = 0;
+                for (int j = 0; j < cnt; j++) rank += ent[j] < mine ? 1 : 0;
+                const int have = (int)(m < k ? m : (int64_t)k);
+                if ((int)threadIdx.x < cnt && rank < k) {
+                    const size_t o = (size_t)q * k + rank;
+                    const int64_t slot = slots[threadIdx.x];
+                    out_dist[o] = key_to_float((unsigned)(mine >> 32));
+                    if (out_slot) out_slot[o] = slot;
+                    if (out_i32) out_i32[o] = (int32_t)slot;
+                    if (out_tid) out_tid[o] = tids ? tids[slot] : ~0ull;
+                }
+                if ((int)threadIdx.x >= have && (int)threadIdx.x < k) {
+                    const size_t o = (size_t)q * k + threadIdx.x;
+                    out_dist[o] = INFINITY;
+                    if (out_slot) out_slot[o] = -1;
+                    if (out_i32) out_i32[o] = -1;
+                    if (out_tid) out_tid[o] = ~0ull;
+                }
+                if (stats && threadIdx.x == 0) atomicAdd(&stats[7], 1.0);  // profiling: settled by the wider candidate set
+            }
+            __syncthreads();  // ent / exact / slots are reused
+        }
+        if (settled) continue;
+        if (stats && threadIdx.x == 0) atomicAdd(&stats[6], 1.0);  // profiling: queries that took the exact pass
+        score_rows<T, 0, 0>([&](int64_t j) { return vectors + (size_t)slot_of(j) * row_bytes; }, 0, m, qrow, nvec, lg, v);
         __threadfence();
         __syncthreads();
         // the values were written by this workgroup's other wavefronts a moment ago: agent-scope loads, so that a
@@ -697,7 +780,7 @@ int launch_multi_scan(pgv_ctx *ctx, const pgv_index *ix, const void *q_dev, int 
 
 int launch_batch_recheck(pgv_ctx *ctx, const ExactRows &xr, const void *q_dev, int nq, int kprime, int k,
                          const float *approx_val, const int64_t *cand_pos, const int64_t *cand_slot,
-                         const int64_t *seg_start, int64_t fixed_len, float gamma,
+                         const int64_t *seg_start, int64_t fixed_len, const ScanBound &bound,
                          float *out_dist, int64_t *out_slot, uint64_t *out_tid, int32_t *flags, int32_t *out_i32,
                          const int32_t *probe_lists, const int64_t *probe_off, int probes) {
     if (nq <= 0) return PGV_OK;
@@ -706,7 +789,7 @@ int launch_batch_recheck(pgv_ctx *ctx, const ExactRows &xr, const void *q_dev, i
     hipLaunchKernelGGL(batch_recheck_kernel<T>, dim3(nq), dim3(kQThreads), 0, ctx->stream,                           \
                        static_cast<const char *>(xr.vectors), xr.tids, xr.geom.nvec, xr.geom.lpr_log2,               \
                        static_cast<const char *>(q_dev), kprime, k, approx_val, cand_pos, cand_slot, xr.list_offsets, \
-                       probe_lists, probe_off, probes, seg_start, fixed_len, xr.norm_max, gamma, nq, out_dist, out_slot, out_tid, out_i32, flags)
+                       probe_lists, probe_off, probes, seg_start, fixed_len, xr.norm_max, bound, nq, out_dist, out_slot, out_tid, out_i32, flags)
     if (xr.dtype == PGV_F32)
         PGV_RECHECK(float);
     else
@@ -718,21 +801,23 @@ int launch_batch_recheck(pgv_ctx *ctx, const ExactRows &xr, const void *q_dev, i
 
 int launch_batch_fix(pgv_ctx *ctx, const ExactRows &xr, const void *q_dev, int nq, const int32_t *probe_lists,
                      const int64_t *probe_off, int probes, const int64_t *seg_start, int64_t fixed_len,
-                     const int32_t *flags, float *seg_vals, int k, float *out_dist, int64_t *out_slot, uint64_t *out_tid,
-                     int32_t *out_i32) {
+                     const int32_t *flags, float *seg_vals, int k, const ScanBound &bound, float *out_dist, int64_t *out_slot,
+                     uint64_t *out_tid, int32_t *out_i32) {
     if (nq <= 0) return PGV_OK;
     double *stats = (ctx->profiling && ctx->stats_dev.p && probe_lists) ? ctx->stats_dev.as<double>() : nullptr;
     if (k > 4096) PGV_FAIL(PGV_ERR_ARG, "top-k: k = %d exceeds the supported 4096", k);
     int kp = 2;
     while (kp < k) kp <<= 1;
     const int cap = kp > kFastCap ? kp : kFastCap;
+    const int widen = ctx->no_widen ? 0 : 1;
     const size_t lds = (size_t)cap * 8 + sizeof(SelShared);
     const int grid = nq < ctx->num_cus ? nq : ctx->num_cus;
 #define PGV_FIX(T)                                                                                                   \
     hipLaunchKernelGGL(batch_fix_kernel<T>, dim3(grid), dim3(kQThreads), lds, ctx->stream,                           \
                        static_cast<const char *>(xr.vectors), xr.list_offsets, xr.tids, xr.geom.nvec,                \
                        xr.geom.lpr_log2, static_cast<const char *>(q_dev), probe_lists, probe_off, probes, seg_start, \
-                       fixed_len, flags, nq, seg_vals, k, kp, cap, out_dist, out_slot, out_tid, out_i32, stats)
+                       fixed_len, flags, nq, seg_vals, k, kp, cap, xr.norm_max, bound, widen, out_dist, out_slot, out_tid,    \
+                       out_i32, stats)
     if (xr.dtype == PGV_F32)
         PGV_FIX(float);
     else

@@ -491,6 +491,10 @@ int pgv_ctx_create(int device, void *stream, pgv_ctx **out) {
     pgv_ctx *ctx = new (std::nothrow) pgv_ctx();
     if (!ctx) PGV_FAIL(PGV_ERR_NOMEM, "out of host memory");
     ctx->device = device;
+    {
+        const char *e = getenv("PGV_NO_WIDEN");
+        ctx->no_widen = e && atoi(e) != 0;
+    }
     ctx->num_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
     if (stream == PGV_DEFAULT_STREAM) {
         ctx->stream = nullptr;  // the legacy default stream
@@ -615,6 +619,7 @@ int pgv_ctx_get_stats(pgv_ctx *ctx, pgv_stats *out) {
     out->assign_recheck_rows = dev_acc[4];
     out->scan_unique_rows = dev_acc[5];
     out->scan_redo_queries = dev_acc[6];
+    out->scan_widened_queries = dev_acc[7];
     return PGV_OK;
 }
 
@@ -1297,10 +1302,10 @@ static int rank_lists_dev(pgv_index *ix, const void *q_dev, int nq, int maxprobe
         // a center's position in the matrix row is its id: cand_pos serves as the slots
         // the center ids leave as the int32 list ids the callers want (no conversion pass)
         PGV_TRY(launch_batch_recheck(ctx, xr, q_dev, nq, cand, maxprobes, sc.cand_val, sc.cand_pos, sc.cand_pos, nullptr,
-                                     ix->nlists, expansion_bound(ctx, ix->geom.ld).total(), dist, nullptr, nullptr, sc.flags,
+                                     ix->nlists, scan_bound(ctx, ix->geom.ld), dist, nullptr, nullptr, sc.flags,
                                      out_lists_dev));
         PGV_TRY(launch_batch_fix(ctx, xr, q_dev, nq, nullptr, nullptr, 0, nullptr, ix->nlists, sc.flags, mat, maxprobes,
-                                 dist, nullptr, nullptr, out_lists_dev));
+                                 scan_bound(ctx, ix->geom.ld), dist, nullptr, nullptr, out_lists_dev));
         return PGV_OK;
     } else {
         PGV_TRY(dense_scan(ctx, ix->metric, ix->dtype, ix->geom, ix->centers, ix->nlists, q_dev, nq, ix->nlists, mat,
@@ -1511,7 +1516,7 @@ static int scan_batch_dev(pgv_index *ix, const void *q_dev, int nq, const int32_
     if (approx) {
         // k' candidates by the expansion, their exact distances, the head; queries whose candidate
         // set cannot be proven complete (flags) take the exact pass over their whole segment
-        const float gamma = expansion_bound(ctx, ix->geom.ld).total();
+        const ScanBound gamma = scan_bound(ctx, ix->geom.ld);
         PGV_TRY(launch_topk_segments(ctx, seg_vals, plan.seg_start, nq, 0, kprime, cand_val, cand_pos, flags + nq));
         const ExactRows xr{ix->vectors, ix->tids, ix->list_offsets, ix->geom, ix->dtype,
                            reinterpret_cast<const unsigned *>(ix->row_norms + ix->nrows)};
@@ -1520,7 +1525,7 @@ static int scan_batch_dev(pgv_index *ix, const void *q_dev, int nq, const int32_
                                      gamma, od.as<float>(), os.as<int64_t>(), ot.as<uint64_t>(), flags, nullptr,
                                      probe_lists, plan.probe_off, probes));
         PGV_TRY(launch_batch_fix(ctx, xr, q_dev, nq, probe_lists, plan.probe_off, probes, plan.seg_start, 0, flags,
-                                 seg_vals, k, od.as<float>(), os.as<int64_t>(), ot.as<uint64_t>()));
+                                 seg_vals, k, gamma, od.as<float>(), os.as<int64_t>(), ot.as<uint64_t>()));
     } else {
         PGV_TRY(launch_topk_segments(ctx, seg_vals, plan.seg_start, nq, 0, k, od.as<float>(), pos));
         PGV_TRY(launch_positions_to_slots(ctx, ix, probe_lists, plan.probe_off, nq, probes, k, pos,
@@ -1895,8 +1900,9 @@ int pgv_exact_topk(pgv_ctx *ctx, pgv_metric metric, pgv_dtype dtype, int dim, co
             const ExactRows xr{r_dev, nullptr, nullptr, g, dtype, reinterpret_cast<const unsigned *>(norms + n)};
             // a row's position in the matrix row is its index: cand_pos serves as the slots
             PGV_TRY(launch_batch_recheck(ctx, xr, qp, cn, kprime, k, sc.cand_val, sc.cand_pos, sc.cand_pos, nullptr, n,
-                                         expansion_bound(ctx, g.ld).total(), cd, ci, nullptr, sc.flags));
-            PGV_TRY(launch_batch_fix(ctx, xr, qp, cn, nullptr, nullptr, 0, nullptr, n, sc.flags, mat, k, cd, ci, nullptr));
+                                         scan_bound(ctx, g.ld), cd, ci, nullptr, sc.flags));
+            PGV_TRY(launch_batch_fix(ctx, xr, qp, cn, nullptr, nullptr, 0, nullptr, n, sc.flags, mat, k, scan_bound(ctx, g.ld),
+                                     cd, ci, nullptr));
         } else {
             PGV_TRY(dense_scan(ctx, metric, dtype, g, r_dev, n, qp, cn, n, mat, mfma, nullptr, nullptr));
             PGV_TRY(launch_topk_segments(ctx, mat, nullptr, cn, n, k, cd, ci));

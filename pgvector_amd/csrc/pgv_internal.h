@@ -124,7 +124,8 @@ struct pgv_ctx {
     // streaming kernel, resolved lazily in pgv_ctx_get_stats
     bool profiling = false;
     bool no_mfma_scan = false;  // pgv_ctx_set_exact_scan
-    int bound_mode = 0;         // pgv_ctx_set_bound: PGV_BOUND_STATISTICAL / PGV_BOUND_WORST_CASE
+    bool no_widen = false;      // PGV_NO_WIDEN=1: flagged queries go straight to the exact pass (experiments)
+    int bound_mode = 1;         // pgv_ctx_set_bound: PGV_BOUND_STATISTICAL / PGV_BOUND_WORST_CASE (default)
     pgv::DBuf xt_norms;         // pgv_exact_topk: |row|^2 of the caller's rows
     std::vector<hipEvent_t> ev_pool;  // start/stop pairs
     size_t ev_used = 0;
@@ -206,20 +207,42 @@ struct pgv_hnsw {
 
 namespace pgv {
 
-// How far an MFMA L2 value |x|^2 - 2 q.x (fp32 accumulation of a length-dim dot product, fp32 row norm) can be from
-// the reference's fp32 sum((q - x)^2) of the same pair, as coefficients of (|q| + |x|)^2:
-//   statistical  8 sqrt(dim + 4) u: the probabilistic bound of a length-dim fp32 summation (Higham & Mary 2019,
-//                lambda sqrt(n) u fails with probability ~ exp(-lambda^2 / 2) per sum, lambda = 8), u = 2^-24
-//   worst case   gamma_(dim+1) for the expansion (dot product: gamma_dim |q||x|, row norm: gamma_dim |x|^2, one final
-//                rounding) PLUS gamma_(dim+2) for the reference's own value (dim terms of two roundings each, all
-//                positive, so relative), gamma_n = n u / (1 - n u) -- deterministic for IEEE fp32 accumulation in any
-//                order (Higham, Accuracy and Stability of Numerical Algorithms, Lemma 3.1 / eq. 3.5)
+// How far an MFMA L2 value a = |x|^2 - 2 q.x can be from the true s = |x|^2 - 2 q.x of the same pair (the distance
+// less |q|^2, which shifts all values of a query alike), and what the candidate selection must allow for.
+//
+// ScanBound -- the list scan / center ranking / exact top-k (mfma_scan_kernel + batch_recheck_kernel):
+//     eps(q, x) = g_sq (|q| + |x|)^2  +  g_dot 2 |q||x|  +  g_norm |x|^2 ,      band = a_k + 2 eps + g_ref |a_k + 2 eps + |q|^2|
+//   statistical    g_sq = 8 sqrt(dim + 4) u, the rest 0: the probabilistic bound of a length-dim fp32 summation (Higham &
+//                  Mary 2019: lambda sqrt(n) u fails with probability ~ exp(-lambda^2 / 2) per sum, lambda = 8), u = 2^-24
+//   worst case     deterministic (Higham, Accuracy and Stability of Numerical Algorithms, Lemma 3.1 / eq. 3.5: a sum of n
+//                  rounded products in ANY order errs by at most gamma_n sum |a_i b_i|, gamma_n = n v / (1 - n v)), with
+//                  v = 2^-23 per operation -- twice the unit roundoff of round-to-nearest, so that an internal
+//                  truncating step of the matrix pipeline is covered too:
+//                    g_dot   gamma_(dim/4 + 4): the kernel keeps FOUR independent accumulators per output, each adds
+//                            dim / 4 products (Cauchy-Schwarz: sum |q_i x_i| <= |q||x|), two more additions join them
+//                            and the final fma(-2, dot, |x|^2) rounds once
+//                    g_norm  gamma_(dim/64 + 10): row_norms_kernel's per-lane chains of dim / 64 fmas + 6 shuffle
+//                            additions, + the final fma
+//                    g_ref   2 gamma_(dim + 2): the exact form sum((q - x)^2) that decides among the candidates (here
+//                            and in the reference) is itself rounded -- all terms positive, so RELATIVE to the distance;
+//                            a row outside the band must stay outside when both its and the k-th row's exact values move
+//                  |x| is the largest row norm of the index (one word, kept with the norms).
+// ArgminBound -- the build's L2 pre-filter (mfma_argmin_kernel, ONE accumulator chain per output): the pair of round 3,
+//   gamma (|c|^2 + 2 |a||c|) + gamma_x (|a| + |c|)^2.
+struct ScanBound {
+    float g_sq, g_dot, g_norm, g_ref;
+};
+inline float gamma_n(double n, double v) { return (float)(n * v / (1.0 - n * v)); }
+inline ScanBound scan_bound(const pgv_ctx *ctx, int dim) {
+    if (ctx->bound_mode == 0) return {8.f * std::sqrt((float)dim + 4.f) * 5.9604645e-8f, 0.f, 0.f, 0.f};
+    constexpr double v = 1.1920929e-7;  // 2^-23
+    return {0.f, gamma_n(dim / 4.0 + 4.0, v), gamma_n(dim / 64.0 + 10.0, v), 2.f * gamma_n(dim + 2.0, v)};
+}
 struct ExpansionBound {
     float gamma;        // of |x|^2 + 2 |q||x| (expansion terms)
     float gamma_exact;  // of (|q| + |x|)^2 (the exact value's own rounding; 0 in the statistical model)
-    float total() const { return gamma + gamma_exact; }
 };
-inline ExpansionBound expansion_bound(const pgv_ctx *ctx, int dim) {
+inline ExpansionBound argmin_bound(const pgv_ctx *ctx, int dim) {
     constexpr float u = 5.9604645e-8f;
     if (ctx->bound_mode == 0) return {8.f * std::sqrt((float)dim + 4.f) * u, 0.f};
     const float n1 = (float)(dim + 1) * u, n2 = (float)(dim + 2) * u;
@@ -343,7 +366,7 @@ struct ExactRows {
 };
 int launch_batch_recheck(pgv_ctx *ctx, const ExactRows &xr, const void *q_dev, int nq, int kprime, int k,
                          const float *approx_val, const int64_t *cand_pos, const int64_t *cand_slot,
-                         const int64_t *seg_start, int64_t fixed_len, float gamma,
+                         const int64_t *seg_start, int64_t fixed_len, const ScanBound &bound,
                          float *out_dist, int64_t *out_slot, uint64_t *out_tid, int32_t *flags,
                          int32_t *out_i32 = nullptr, const int32_t *probe_lists = nullptr,
                          const int64_t *probe_off = nullptr, int probes = 0);  // cand_slot null: slots from the positions
@@ -351,8 +374,8 @@ int launch_batch_recheck(pgv_ctx *ctx, const ExactRows &xr, const void *q_dev, i
 // center ids for the dense form)
 int launch_batch_fix(pgv_ctx *ctx, const ExactRows &xr, const void *q_dev, int nq, const int32_t *probe_lists,
                      const int64_t *probe_off, int probes, const int64_t *seg_start, int64_t fixed_len,
-                     const int32_t *flags, float *seg_vals, int k, float *out_dist, int64_t *out_slot, uint64_t *out_tid,
-                     int32_t *out_i32 = nullptr);
+                     const int32_t *flags, float *seg_vals, int k, const ScanBound &bound, float *out_dist, int64_t *out_slot,
+                     uint64_t *out_tid, int32_t *out_i32 = nullptr);
 int launch_iota_slots(pgv_ctx *ctx, const pgv_index *ix, const int32_t *lists_dev, int nlists,
                       const int64_t *probe_off, int64_t *out_slot);
 

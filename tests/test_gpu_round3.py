@@ -265,39 +265,57 @@ def _search_with_bound(ctx, ix, queries, probes, k, worst_case):
     ctx.reset_stats()
     try:
         dist, slot, tid = ix.search_batch(queries, probes, k, want_tid=True)
-        redo = ctx.stats()["scan_redo_queries"]
+        st = ctx.stats()
+        redo = st["scan_redo_queries"]
+        _search_with_bound.widened = st["scan_widened_queries"]
     finally:
         ctx.set_profiling(False)
-        ctx.set_bound(False)
+        ctx.set_bound(True)      # the default
     return dist, slot, tid, redo
 
 
 def test_the_two_bounds_where_they_differ(ctx, oracle):
-    """rows at squared distances spread over [0, 0.12 R^2] from queries of norm R: the gap between the k-th and the
-    k'-th candidate (30 rows of ~5000) clears twice the statistical bound (1.9e-5 (|q| + |x|)^2 at 1536-d) but not
-    twice the worst-case one (1.8e-4 ...): PGV_BOUND_WORST_CASE redoes those queries exactly, PGV_BOUND_STATISTICAL
-    proves them complete -- and both return the oracle's rows"""
+    """rows at squared distances spread over [0, 0.12 R^2] from queries of norm R = 30: the gap between the k-th and the
+    k'-th candidate (30 rows of ~5000 per list: ~0.65) clears twice the statistical bound (1.9e-5 (|q| + |x|)^2 = 0.07
+    at 1536-d) AND twice the deterministic one of the four-chain scan kernel (gamma_(d/4+4) 2 |q||x| + ... = 0.09), so
+    both settle every query -- where round 3's deterministic form, (gamma_(d+1) + gamma_(d+2)) (|q| + |x|)^2 = 0.66 on
+    one accumulator chain, could settle none (checked numerically below) -- and both return the oracle's rows.  With the
+    rows ten times denser (~90 rows inside the deterministic band: more than k' = 40 holds, fewer than 256) the queries
+    are flagged and SETTLED BY THE WIDER CANDIDATE SET of batch_fix_kernel: nobody takes the exact pass."""
     dim, n, nq, lists, k = 1536, 10000, 128, 2, 10
     rng = np.random.default_rng(77)
     base = rng.standard_normal(dim).astype(np.float32)
     base *= 30.0 / np.linalg.norm(base)                                     # R = 30
     dirs = rng.standard_normal((n, dim)).astype(np.float32)
     dirs /= np.linalg.norm(dirs, axis=1, keepdims=True)
-    radius = np.sqrt(rng.random(n) * 0.12 * 900.0).astype(np.float32)[:, None]
-    data = np.ascontiguousarray(base[None, :] + radius * dirs)
     queries = np.ascontiguousarray(base[None, :] + 0.01 * rng.standard_normal((nq, dim)).astype(np.float32))
-    ivf = CpuIvf(oracle, po.OPS_L2, po.ORA_F32, data, lists)
-    ix = _upload(ctx, ivf)
-    out = {}
-    for wc in (False, True):
-        dist, slot, tid, redo = _search_with_bound(ctx, ix, queries, lists, k, wc)
-        out[wc] = redo
-        for i in range(nq):
-            wt, wd = oracle.search(ivf.struct, queries[i], lists, k)
-            assert_topk_equiv(tid[i].tolist(), dist[i], wt.tolist(), wd, what="bound %s q %d" % (wc, i))
-    assert out[False] == 0, out          # the statistical bound settles every query
-    assert out[True] >= nq // 2, out     # the deterministic one cannot: those queries took the exact pass
-    ix.close()
+    u = 2.0 ** -24
+    old_worst = ((dim + 1) * u + (dim + 2) * u) * (30.0 + 31.8) ** 2       # round 3's eps
+    redo, widened = {}, {}
+    for spread in (0.12, 0.012):
+        radius = np.sqrt(rng.random(n) * spread * 900.0).astype(np.float32)[:, None]
+        data = np.ascontiguousarray(base[None, :] + radius * dirs)
+        ivf = CpuIvf(oracle, po.OPS_L2, po.ORA_F32, data, lists)
+        ix = _upload(ctx, ivf)
+        gaps = []
+        for wc in (False, True):
+            dist, slot, tid, redo[(spread, wc)] = _search_with_bound(ctx, ix, queries, lists, k, wc)
+            widened[(spread, wc)] = _search_with_bound.widened
+            for i in range(nq):
+                wt, wd = oracle.search(ivf.struct, queries[i], lists, k)
+                assert_topk_equiv(tid[i].tolist(), dist[i], wt.tolist(), wd, what="spread %s bound %s q %d" % (spread, wc, i))
+                if spread == 0.12 and not wc:
+                    d40 = np.sort(((data.astype(np.float64) - queries[i].astype(np.float64)) ** 2).sum(1))[:40]
+                    gaps.append(d40[39] - d40[9])
+        if spread == 0.12:
+            assert redo[(spread, False)] == 0 and redo[(spread, True)] == 0, redo      # both settle every query
+            assert 2.0 * old_worst > np.median(gaps), (old_worst, np.median(gaps))      # round 3's form could not
+            assert widened[(spread, False)] == 0 and widened[(spread, True)] == 0, widened
+        else:
+            assert redo[(spread, False)] == 0 and redo[(spread, True)] == 0, redo       # no exact pass ...
+            assert widened[(spread, True)] >= nq // 2, widened                          # ... the wider set settled them
+            assert widened[(spread, False)] <= widened[(spread, True)], widened
+        ix.close()
 
 
 def test_mfma_l2_under_catastrophic_cancellation(ctx, oracle):
@@ -326,7 +344,7 @@ def test_mfma_l2_under_catastrophic_cancellation(ctx, oracle):
             many = np.ascontiguousarray(base[None, :] + 0.01 * rng.standard_normal((600, dim)).astype(np.float32))
             got, _ = api.assign(ctx, api.PGV_L2SQ, api.PGV_F32, dim, many, data[:2048])
         finally:
-            ctx.set_bound(False)
+            ctx.set_bound(True)
         for i in range(0, nq, 5):
             wt, wd = _ora_exact_topk(oracle, po.OPS_L2, po.ORA_F32, data, queries[i], k)
             assert_topk_equiv(idx[i].tolist(), d[i], wt.tolist(), wd, what="cancel exact_topk %s q %d" % (wc, i))
