@@ -1242,7 +1242,7 @@ def section_sweeps(args, dev, ctx, out):
                                "scan_redo_queries_per_step": head_stats["scan_redo_queries"] / 20,
                                "scan_widened_queries_per_step": head_stats["scan_widened_queries"] / 20,
                                "bound": "deterministic (default): gamma_(d/4+4) 2 |q||x|max + gamma_(d/64+10) |x|max^2 + "
-                                        "2 gamma_(d+2) distance, 2^-23 per operation, four accumulator chains per output"},
+                                        "2 gamma_(d+2) distance, u = 2^-24, four accumulator chains per output"},
                 "statistical": st,
                 "cost_of_worst_case": 1.0 - (total_batch / s_head) / st["qps"],
                 "note": "same index, same queries, same results; uniform data and the other configs carry the same pair "

@@ -1,13 +1,17 @@
 /*
  * pgshim.h -- NOT PostgreSQL.  The handful of server declarations the files in ext/ touch, spelled just
- * precisely enough for `gcc -fsyntax-only` to type-check the glue where no server headers exist
- * (tests/test_ext_glue_cpu.py).  Inside a real PGXS build these come from the server's own headers and
- * this directory is not on the include path.  Names and argument orders follow the PostgreSQL 13-17
- * headers named in each section; nothing here has a body.
+ * precisely enough for the glue to be type-checked (tests/test_ext_glue_cpu.py) AND EXECUTED where no server headers
+ * exist: tests/c/pgshim_runtime.c gives every function declared here a small body (palloc over resettable contexts
+ * with reset callbacks, ereport as a longjmp to the innermost PG_TRY, the buffer manager over an emulated page image,
+ * LWLocks / latches / atomics over futexes in a shared mapping, background workers as forked processes), and
+ * tests/c/ext_driver.c runs the glue's scans, build hooks, worker and pooler on it (tests/test_ext_runtime_*.py).
+ * Inside a real PGXS build these come from the server's own headers and this directory is not on the include path.
+ * Names and argument orders follow the PostgreSQL 13-17 headers named in each section.
  */
 #ifndef PGSHIM_H
 #define PGSHIM_H
 
+#include <setjmp.h>
 #include <stdbool.h>
 #include <stddef.h>
 #include <stdint.h>
@@ -75,6 +79,7 @@ void		MemoryContextRegisterResetCallback(MemoryContext ctx, MemoryContextCallbac
 void		pgshim_check_interrupts(void);
 typedef void (*pg_on_exit_callback) (int code, Datum arg);
 void		on_proc_exit(pg_on_exit_callback function, Datum arg);
+void		before_shmem_exit(pg_on_exit_callback function, Datum arg);
 typedef enum
 {
 	PGC_USERSET = 6
@@ -202,13 +207,26 @@ FmgrInfo   *index_getprocinfo(Relation irel, int attnum, uint16 procnum);
 #define ObjectIdGetDatum(x) ((Datum) (x))
 #define DatumGetObjectId(x) ((Oid) (x))
 
-/* utils/elog.h */
-#define PG_TRY() if (pgshim_try()) {
-#define PG_CATCH() } else {
-#define PG_END_TRY() }
+/* utils/elog.h: an ERROR longjmps to the innermost PG_TRY (or to the top-level handler of the process) */
+extern sigjmp_buf *PG_exception_stack;
+#define PG_TRY() \
+	do { \
+		sigjmp_buf *pgshim_saved_stack = PG_exception_stack; \
+		sigjmp_buf	pgshim_local_jmp; \
+		if (sigsetjmp(pgshim_local_jmp, 0) == 0) \
+		{ \
+			PG_exception_stack = &pgshim_local_jmp
+#define PG_CATCH() \
+		} \
+		else \
+		{ \
+			PG_exception_stack = pgshim_saved_stack
+#define PG_END_TRY() \
+		} \
+		PG_exception_stack = pgshim_saved_stack; \
+	} while (0)
 #define PG_RE_THROW() pgshim_rethrow()
 void		pgshim_rethrow(void) __attribute__((noreturn));
-int			pgshim_try(void);
 void		EmitErrorReport(void);
 void		FlushErrorState(void);
 
@@ -232,6 +250,7 @@ void		pg_usleep(long microsec);
 typedef struct LWLock
 {
 	uint16		tranche;
+	uint32		state;			/* (the stand-in runtime's lock word) */
 }			LWLock;
 typedef union LWLockPadded
 {

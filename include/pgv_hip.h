@@ -198,11 +198,10 @@ int			pgv_ctx_set_exact_scan(pgv_ctx * ctx, int on);
  * goes to the exact kernels; what differs is whether the bound itself can be exceeded.
  *   PGV_BOUND_WORST_CASE (default)  deterministic: the list scan keeps FOUR independent accumulator chains per output,
  *       so its dot product errs by at most gamma_(dim/4 + 4) |q||x| (Higham, Lemma 3.1: any order of n rounded
- *       products), gamma_n = n v / (1 - n v) with v = 2^-23 per operation (twice round-to-nearest's unit roundoff, so
- *       that a truncating step inside the matrix pipeline is covered); + the row norm's own chain; + the rounding of
- *       the exact form sum((q - x)^2) -- the reference's and ours -- which is relative to the DISTANCE, not to
- *       (|q| + |x|)^2.  At 1536 dimensions: 4.7e-5 x 2 |q||x|max, about the width of the statistical band, which is
- *       why it can be the default (bench.py `bound_modes`: both side by side; round 3's form of it,
+ *       products), gamma_n = n u / (1 - n u) with u = 2^-24 (the matrix pipeline rounds to nearest: pinned on the
+ *       hardware by tests/test_gpu_round4.py); + the row norm's own chain; + the rounding of the exact form
+ *       sum((q - x)^2) -- the reference's and ours -- which is relative to the DISTANCE, not to (|q| + |x|)^2.  At 1536
+ *       dimensions: 2.3e-5 x 2 |q||x|max, narrower than the statistical band, which is why it can be the default (bench.py `bound_modes`: both side by side; round 3's form of it,
  *       (gamma_(dim+1) + gamma_(dim+2)) (|q| + |x|max)^2 on one chain, flagged every query and cost 98 %).
  *   PGV_BOUND_STATISTICAL  8 sqrt(dim + 4) 2^-24 (|q| + |x|max)^2 -- the probabilistic model of a length-dim fp32
  *       summation (fails with probability ~ e^-32 per sum).

@@ -215,9 +215,9 @@ namespace pgv {
 //   statistical    g_sq = 8 sqrt(dim + 4) u, the rest 0: the probabilistic bound of a length-dim fp32 summation (Higham &
 //                  Mary 2019: lambda sqrt(n) u fails with probability ~ exp(-lambda^2 / 2) per sum, lambda = 8), u = 2^-24
 //   worst case     deterministic (Higham, Accuracy and Stability of Numerical Algorithms, Lemma 3.1 / eq. 3.5: a sum of n
-//                  rounded products in ANY order errs by at most gamma_n sum |a_i b_i|, gamma_n = n v / (1 - n v)), with
-//                  v = 2^-23 per operation -- twice the unit roundoff of round-to-nearest, so that an internal
-//                  truncating step of the matrix pipeline is covered too:
+//                  rounded products in ANY order errs by at most gamma_n sum |a_i b_i|, gamma_n = n u / (1 - n u)), with
+//                  u = 2^-24 per operation: the matrix pipeline rounds products and accumulator additions to nearest,
+//                  which tests/test_gpu_round4.py pins on the hardware (half-way cases through both MFMA shapes):
 //                    g_dot   gamma_(dim/4 + 4): the kernel keeps FOUR independent accumulators per output, each adds
 //                            dim / 4 products (Cauchy-Schwarz: sum |q_i x_i| <= |q||x|), two more additions join them
 //                            and the final fma(-2, dot, |x|^2) rounds once
@@ -235,7 +235,7 @@ struct ScanBound {
 inline float gamma_n(double n, double v) { return (float)(n * v / (1.0 - n * v)); }
 inline ScanBound scan_bound(const pgv_ctx *ctx, int dim) {
     if (ctx->bound_mode == 0) return {8.f * std::sqrt((float)dim + 4.f) * 5.9604645e-8f, 0.f, 0.f, 0.f};
-    constexpr double v = 1.1920929e-7;  // 2^-23
+    constexpr double v = 5.9604645e-8;  // 2^-24: round to nearest (tests/test_gpu_round4.py)
     return {0.f, gamma_n(dim / 4.0 + 4.0, v), gamma_n(dim / 64.0 + 10.0, v), 2.f * gamma_n(dim + 2.0, v)};
 }
 struct ExpansionBound {

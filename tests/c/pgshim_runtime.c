@@ -1,0 +1,1641 @@
+/*
+ * pgshim_runtime.c -- bodies for the server functions ext/shim/pgshim.h declares, so that the glue of ext/ RUNS:
+ *
+ *   memory     palloc & co over contexts that can be reset; reset callbacks fire first (utils/mmgr/mcxt.c's order)
+ *   errors     ereport(ERROR) longjmps to the innermost PG_TRY, or to the top-level handler of the process, which
+ *              aborts the "transaction": buffer pins and locks released, the query context reset
+ *   buffers    ReadBufferExtended / LockBuffer / page accessors over relations that are arrays of 8 KB pages in the real
+ *              on-disk layout (PageHeaderData, ItemIdData, special space), kept in a shared mapping; pins are counted
+ *   shmem      ShmemInitStruct / named LWLock tranches / pg_atomic / latches (futexes) in that same mapping
+ *   processes  a postmaster that forks backends and, on RegisterDynamicBackgroundWorker, background workers; proc_exit
+ *              runs before_shmem_exit and on_proc_exit callbacks
+ *   pgvector   the few functions of the extension itself the glue calls (IvfflatGetMetaPageInfo, type info, optional
+ *              support procs, HnswInitElementFromBlock ...), answered from the emulated catalog
+ *
+ * TEST INFRASTRUCTURE ONLY (tests/test_ext_runtime_*.py): it is neither PostgreSQL nor part of the product.  Where a
+ * behaviour of the server matters to the glue it is cited; everything else is the simplest thing that is correct.
+ */
+#define _GNU_SOURCE
+#include "pgshim_runtime.h"
+
+#include "hnsw.h"
+#include "ivfflat.h"
+
+#include <errno.h>
+#include <limits.h>
+#include <linux/futex.h>
+#include <signal.h>
+#include <stdarg.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <sys/mman.h>
+#include <sys/syscall.h>
+#include <sys/time.h>
+#include <sys/wait.h>
+#include <time.h>
+#include <unistd.h>
+
+/* ------------------------------------------------------------------------------------------------ shared state */
+struct Latch
+{
+	uint32		is_set;
+};
+
+typedef struct ShimRel
+{
+	Oid			oid;
+	ShimOpclass opc;
+	int			dimensions;
+	size_t		pages_off;
+	uint32		nblocks;
+	uint32		cap_blocks;
+	uint32		lock;			/* readers count | 0x80000000 writer */
+}			ShimRel;
+
+typedef struct ShimBgw
+{
+	uint32		state;			/* 0 free, 1 requested, 2 running */
+	char		fn[BGW_MAXLEN];
+	Datum		arg;
+	int			pid;
+}			ShimBgw;
+
+#define SHIM_MAX_STRUCTS 8
+#define SHIM_MAX_BGW 8
+
+typedef struct ShimShared
+{
+	uint64		magic;
+	int			postmaster_pid;
+	struct
+	{
+		char		name[64];
+		size_t		off,
+					size;
+	}			structs[SHIM_MAX_STRUCTS];
+	int			nstructs;
+	size_t		shmem_off,
+				shmem_end;
+	LWLock		addin_lock;
+	LWLockPadded tranche[4];
+	struct Latch latches[SHIM_MAX_PROCS];
+	uint32		next_proc;
+	ShimBgw		bgw[SHIM_MAX_BGW];
+	uint32		bgw_kick;
+	ShimRel		rels[SHIM_MAX_RELS];
+	uint32		catalog_lock;
+	size_t		page_off,
+				page_end,
+				page_used;
+	size_t		arena_off,
+				arena_bytes;
+}			ShimShared;
+
+static ShimShared * S = NULL;
+static char *Sbase = NULL;
+
+/* ------------------------------------------------------------------------------------------------ process state */
+Oid			MyDatabaseId = 5;
+int			MyProcPid = 0;
+bool		process_shared_preload_libraries_in_progress = false;
+shmem_request_hook_type shmem_request_hook = NULL;
+shmem_startup_hook_type shmem_startup_hook = NULL;
+LWLock	   *AddinShmemInitLock = NULL;
+Latch	   *MyLatch = NULL;
+sigjmp_buf *PG_exception_stack = NULL;
+int			hnsw_ef_search = 40;
+
+static char last_error[512];
+static int	last_error_level = 0;
+static volatile sig_atomic_t proc_die_pending = 0;
+static int	cancel_countdown = -1;
+static int	is_bgworker = 0;
+
+double
+shim_now(void)
+{
+	struct timespec ts;
+
+	clock_gettime(CLOCK_MONOTONIC, &ts);
+	return (double) ts.tv_sec + 1e-9 * (double) ts.tv_nsec;
+}
+
+static void
+futex_wait(uint32 *word, uint32 seen, long ms)
+{
+	struct timespec rel = {ms / 1000, (ms % 1000) * 1000000L};
+
+	syscall(SYS_futex, word, FUTEX_WAIT, seen, ms >= 0 ? &rel : NULL, NULL, 0);
+}
+
+static void
+futex_wake(uint32 *word)
+{
+	syscall(SYS_futex, word, FUTEX_WAKE, INT_MAX, NULL, NULL, 0);
+}
+
+/* ------------------------------------------------------------------------------------------------ memory contexts */
+typedef struct ShimChunk
+{
+	struct MemoryContextData *ctx;
+	struct ShimChunk *prev,
+			   *next;
+	Size		size;
+	uint64		guard;
+}			ShimChunk;
+
+struct MemoryContextData
+{
+	const char *name;
+	ShimChunk  *chunks;
+	MemoryContextCallback *callbacks;
+	size_t		bytes;
+};
+
+static struct MemoryContextData top_context = {"TopMemoryContext", NULL, NULL, 0};
+MemoryContext TopMemoryContext = &top_context;
+MemoryContext CurrentMemoryContext = &top_context;
+
+#define CHUNK_GUARD 0x70616c6c6f636b21ull
+
+void *
+MemoryContextAlloc(MemoryContext ctx, Size size)
+{
+	ShimChunk  *c = malloc(sizeof(ShimChunk) + (size ? size : 1));
+
+	if (c == NULL)
+		ereport(ERROR, (errmsg("out of memory")));
+	c->ctx = ctx;
+	c->size = size;
+	c->guard = CHUNK_GUARD;
+	c->prev = NULL;
+	c->next = ctx->chunks;
+	if (ctx->chunks)
+		ctx->chunks->prev = c;
+	ctx->chunks = c;
+	ctx->bytes += size;
+	return (char *) c + sizeof(ShimChunk);
+}
+
+void *
+MemoryContextAllocZero(MemoryContext ctx, Size size)
+{
+	void	   *p = MemoryContextAlloc(ctx, size);
+
+	memset(p, 0, size);
+	return p;
+}
+
+void *
+palloc(Size size)
+{
+	return MemoryContextAlloc(CurrentMemoryContext, size);
+}
+
+void *
+palloc0(Size size)
+{
+	return MemoryContextAllocZero(CurrentMemoryContext, size);
+}
+
+void *
+palloc_extended(Size size, int flags)
+{
+	(void) flags;
+	return palloc(size);
+}
+
+static ShimChunk *
+chunk_of(void *p)
+{
+	ShimChunk  *c = (ShimChunk *) ((char *) p - sizeof(ShimChunk));
+
+	if (c->guard != CHUNK_GUARD)
+	{
+		fprintf(stderr, "pgshim: pfree/repalloc of a pointer palloc did not return (or freed twice)\n");
+		abort();
+	}
+	return c;
+}
+
+void
+pfree(void *p)
+{
+	ShimChunk  *c = chunk_of(p);
+
+	if (c->prev)
+		c->prev->next = c->next;
+	else
+		c->ctx->chunks = c->next;
+	if (c->next)
+		c->next->prev = c->prev;
+	c->ctx->bytes -= c->size;
+	c->guard = 0;
+	memset(p, 0xDE, c->size);	/* whoever still reads it reads garbage */
+	free(c);
+}
+
+void *
+repalloc(void *p, Size size)
+{
+	ShimChunk  *c = chunk_of(p);
+	void	   *n = MemoryContextAlloc(c->ctx, size);
+
+	memcpy(n, p, c->size < size ? c->size : size);
+	pfree(p);
+	return n;
+}
+
+void *
+repalloc_huge(void *p, Size size)
+{
+	return repalloc(p, size);
+}
+
+void
+MemoryContextRegisterResetCallback(MemoryContext ctx, MemoryContextCallback *cb)
+{
+	cb->next = ctx->callbacks;
+	ctx->callbacks = cb;
+}
+
+void
+shim_context_reset(MemoryContext ctx)
+{
+	/* callbacks first, then the memory (MemoryContextResetOnly -> MemoryContextCallResetCallbacks) */
+	while (ctx->callbacks)
+	{
+		MemoryContextCallback *cb = ctx->callbacks;
+
+		ctx->callbacks = cb->next;
+		cb->func(cb->arg);
+	}
+	while (ctx->chunks)
+		pfree((char *) ctx->chunks + sizeof(ShimChunk));
+}
+
+size_t
+shim_context_bytes(MemoryContext ctx)
+{
+	return ctx->bytes;
+}
+
+static MemoryContext query_context = NULL;
+
+MemoryContext
+shim_query_context_begin(void)
+{
+	MemoryContext ctx = calloc(1, sizeof(struct MemoryContextData));
+
+	ctx->name = "query";
+	query_context = ctx;
+	CurrentMemoryContext = ctx;
+	return ctx;
+}
+
+void
+shim_query_context_end(MemoryContext ctx)
+{
+	shim_context_reset(ctx);
+	if (query_context == ctx)
+		query_context = NULL;
+	CurrentMemoryContext = TopMemoryContext;
+	free(ctx);
+}
+
+/* ------------------------------------------------------------------------------------------------ errors */
+static int
+pending_level(int level)
+{
+	last_error_level = level;
+	return level;
+}
+
+int
+pgshim_errmsg(const char *fmt,...)
+{
+	va_list		ap;
+
+	va_start(ap, fmt);
+	vsnprintf(last_error, sizeof(last_error), fmt, ap);
+	va_end(ap);
+	return 0;
+}
+
+static void throw_error(void) __attribute__((noreturn));
+static void
+throw_error(void)
+{
+	if (PG_exception_stack != NULL)
+		siglongjmp(*PG_exception_stack, 1);
+	fprintf(stderr, "pgshim: ERROR with no handler installed: %s\n", last_error);
+	abort();
+}
+
+void
+pgshim_ereport(int level, int dummy)
+{
+	(void) dummy;
+	pending_level(level);
+	if (level >= ERROR)
+		throw_error();
+	fprintf(stderr, "LOG:  %s\n", last_error);
+}
+
+void
+pgshim_elog(int level, const char *fmt,...)
+{
+	va_list		ap;
+
+	va_start(ap, fmt);
+	vsnprintf(last_error, sizeof(last_error), fmt, ap);
+	va_end(ap);
+	pgshim_ereport(level, 0);
+}
+
+void
+pgshim_rethrow(void)
+{
+	throw_error();
+}
+
+void
+EmitErrorReport(void)
+{
+	fprintf(stderr, "ERROR:  %s\n", last_error);
+}
+
+void
+FlushErrorState(void)
+{
+	last_error_level = 0;
+}
+
+const char *
+shim_last_error(void)
+{
+	return last_error;
+}
+
+/* ------------------------------------------------------------------------------------------------ exit callbacks */
+typedef struct ExitCb
+{
+	pg_on_exit_callback fn;
+	Datum		arg;
+}			ExitCb;
+static ExitCb on_exit_cbs[16],
+			before_exit_cbs[16];
+static int	n_on_exit = 0,
+			n_before_exit = 0;
+
+void
+on_proc_exit(pg_on_exit_callback function, Datum arg)
+{
+	on_exit_cbs[n_on_exit].fn = function;
+	on_exit_cbs[n_on_exit++].arg = arg;
+}
+
+void
+before_shmem_exit(pg_on_exit_callback function, Datum arg)
+{
+	before_exit_cbs[n_before_exit].fn = function;
+	before_exit_cbs[n_before_exit++].arg = arg;
+}
+
+void
+shim_run_proc_exit(int code)
+{
+	/* shmem_exit, then proc_exit's own list, each last-registered first (storage/ipc/ipc.c) */
+	while (n_before_exit > 0)
+	{
+		n_before_exit--;
+		before_exit_cbs[n_before_exit].fn(code, before_exit_cbs[n_before_exit].arg);
+	}
+	while (n_on_exit > 0)
+	{
+		n_on_exit--;
+		on_exit_cbs[n_on_exit].fn(code, on_exit_cbs[n_on_exit].arg);
+	}
+}
+
+void
+proc_exit(int code)
+{
+	shim_run_proc_exit(code);
+	fflush(NULL);
+	_exit(code);
+}
+
+/* ------------------------------------------------------------------------------------------------ interrupts */
+void
+shim_cancel_after(int after_checks)
+{
+	cancel_countdown = after_checks;
+}
+
+void
+pgshim_check_interrupts(void)
+{
+	if (proc_die_pending)
+	{
+		/* FATAL: "terminating background worker due to administrator command": the exit callbacks run */
+		fprintf(stderr, "FATAL:  terminating process %d due to administrator command\n", (int) getpid());
+		proc_exit(1);
+	}
+	if (cancel_countdown >= 0 && cancel_countdown-- == 0)
+		ereport(ERROR, (errmsg("canceling statement due to user request")));
+}
+
+static void
+handle_sigterm(int sig)
+{
+	(void) sig;
+	proc_die_pending = 1;
+	if (MyLatch)
+	{
+		__atomic_store_n(&MyLatch->is_set, 1, __ATOMIC_RELEASE);
+		futex_wake(&MyLatch->is_set);
+	}
+}
+
+void
+pg_usleep(long microsec)
+{
+	usleep((useconds_t) microsec);
+}
+
+/* ------------------------------------------------------------------------------------------------ GUCs */
+typedef struct Guc
+{
+	const char *name;
+	bool	   *b;
+	int		   *i;
+}			Guc;
+static Guc	gucs[16];
+static int	ngucs = 0;
+
+void
+DefineCustomBoolVariable(const char *name, const char *short_desc, const char *long_desc, bool *valueAddr, bool bootValue,
+						 GucContext context, int flags, void *check, void *assign, void *show)
+{
+	(void) short_desc, (void) long_desc, (void) context, (void) flags, (void) check, (void) assign, (void) show;
+	*valueAddr = bootValue;
+	gucs[ngucs].name = name;
+	gucs[ngucs].b = valueAddr;
+	gucs[ngucs++].i = NULL;
+}
+
+void
+DefineCustomIntVariable(const char *name, const char *short_desc, const char *long_desc, int *valueAddr, int bootValue,
+						int minValue, int maxValue, GucContext context, int flags, void *check, void *assign, void *show)
+{
+	(void) short_desc, (void) long_desc, (void) minValue, (void) maxValue, (void) context, (void) flags, (void) check,
+		(void) assign, (void) show;
+	*valueAddr = bootValue;
+	gucs[ngucs].name = name;
+	gucs[ngucs].b = NULL;
+	gucs[ngucs++].i = valueAddr;
+}
+
+void
+shim_set_guc_bool(const char *name, bool value)
+{
+	for (int g = 0; g < ngucs; g++)
+		if (strcmp(gucs[g].name, name) == 0 && gucs[g].b)
+		{
+			*gucs[g].b = value;
+			return;
+		}
+	fprintf(stderr, "pgshim: no bool GUC %s\n", name);
+	abort();
+}
+
+void
+shim_set_guc_int(const char *name, int value)
+{
+	for (int g = 0; g < ngucs; g++)
+		if (strcmp(gucs[g].name, name) == 0 && gucs[g].i)
+		{
+			*gucs[g].i = value;
+			return;
+		}
+	fprintf(stderr, "pgshim: no int GUC %s\n", name);
+	abort();
+}
+
+/* ------------------------------------------------------------------------------------------------ shared memory */
+static size_t requested_shmem = 0;
+
+void
+RequestAddinShmemSpace(Size size)
+{
+	requested_shmem += size;
+}
+
+void
+RequestNamedLWLockTranche(const char *tranche_name, int num_lwlocks)
+{
+	(void) tranche_name, (void) num_lwlocks;
+}
+
+LWLockPadded *
+GetNamedLWLockTranche(const char *tranche_name)
+{
+	(void) tranche_name;
+	return S->tranche;
+}
+
+void *
+ShmemInitStruct(const char *name, Size size, bool *foundPtr)
+{
+	for (int i = 0; i < S->nstructs; i++)
+		if (strcmp(S->structs[i].name, name) == 0)
+		{
+			*foundPtr = true;
+			return Sbase + S->structs[i].off;
+		}
+	if (S->nstructs == SHIM_MAX_STRUCTS || S->shmem_off + size > S->shmem_end)
+		ereport(ERROR, (errmsg("out of shared memory")));
+	snprintf(S->structs[S->nstructs].name, sizeof(S->structs[0].name), "%s", name);
+	S->structs[S->nstructs].off = S->shmem_off;
+	S->structs[S->nstructs].size = size;
+	S->nstructs++;
+	S->shmem_off += (size + 127) & ~(size_t) 127;
+	*foundPtr = false;
+	return Sbase + S->structs[S->nstructs - 1].off;
+}
+
+bool
+LWLockAcquire(LWLock *lock, LWLockMode mode)
+{
+	(void) mode;				/* shared = exclusive here: correct, only slower */
+	for (;;)
+	{
+		uint32		zero = 0;
+
+		if (__atomic_compare_exchange_n(&lock->state, &zero, 1u, 0, __ATOMIC_ACQUIRE, __ATOMIC_RELAXED))
+			return true;
+		futex_wait(&lock->state, 1u, 1);
+	}
+}
+
+void
+LWLockRelease(LWLock *lock)
+{
+	__atomic_store_n(&lock->state, 0u, __ATOMIC_RELEASE);
+	futex_wake(&lock->state);
+}
+
+void
+pg_atomic_init_u64(volatile pg_atomic_uint64 *ptr, uint64 val)
+{
+	ptr->value = val;
+}
+
+uint64
+pg_atomic_read_u64(volatile pg_atomic_uint64 *ptr)
+{
+	return __atomic_load_n(&ptr->value, __ATOMIC_SEQ_CST);
+}
+
+uint64
+pg_atomic_fetch_add_u64(volatile pg_atomic_uint64 *ptr, int64 add_)
+{
+	return __atomic_fetch_add(&ptr->value, (uint64) add_, __ATOMIC_SEQ_CST);
+}
+
+void
+pg_atomic_init_u32(volatile pg_atomic_uint32 *ptr, uint32 val)
+{
+	ptr->value = val;
+}
+
+uint32
+pg_atomic_read_u32(volatile pg_atomic_uint32 *ptr)
+{
+	return __atomic_load_n(&ptr->value, __ATOMIC_SEQ_CST);
+}
+
+void
+pg_atomic_write_u32(volatile pg_atomic_uint32 *ptr, uint32 val)
+{
+	__atomic_store_n(&ptr->value, val, __ATOMIC_SEQ_CST);
+}
+
+bool
+pg_atomic_compare_exchange_u32(volatile pg_atomic_uint32 *ptr, uint32 *expected, uint32 newval)
+{
+	return __atomic_compare_exchange_n(&ptr->value, expected, newval, 0, __ATOMIC_SEQ_CST, __ATOMIC_SEQ_CST);
+}
+
+/* ------------------------------------------------------------------------------------------------ latches, time */
+int
+WaitLatch(Latch *latch, int wakeEvents, long timeout, uint32 wait_event_info)
+{
+	double		until = shim_now() + (double) timeout / 1000.0;
+
+	(void) wait_event_info;
+	for (;;)
+	{
+		double		left;
+
+		if ((wakeEvents & WL_LATCH_SET) && __atomic_load_n(&latch->is_set, __ATOMIC_ACQUIRE))
+			return WL_LATCH_SET;
+		if ((wakeEvents & WL_EXIT_ON_PM_DEATH) && getppid() != S->postmaster_pid)
+			proc_exit(1);
+		if (!(wakeEvents & WL_TIMEOUT))
+		{
+			futex_wait(&latch->is_set, 0, 100);
+			continue;
+		}
+		left = until - shim_now();
+		if (left <= 0)
+			return WL_TIMEOUT;
+		futex_wait(&latch->is_set, 0, (long) (left * 1000.0) + 1);
+	}
+}
+
+void
+SetLatch(Latch *latch)
+{
+	__atomic_store_n(&latch->is_set, 1, __ATOMIC_RELEASE);
+	futex_wake(&latch->is_set);
+}
+
+void
+ResetLatch(Latch *latch)
+{
+	__atomic_store_n(&latch->is_set, 0, __ATOMIC_RELEASE);
+}
+
+TimestampTz
+GetCurrentTimestamp(void)
+{
+	struct timeval tv;
+
+	gettimeofday(&tv, NULL);
+	return (TimestampTz) tv.tv_sec * 1000000 + tv.tv_usec;
+}
+
+bool
+TimestampDifferenceExceeds(TimestampTz start_time, TimestampTz stop_time, int msec)
+{
+	return stop_time - start_time >= (int64) msec * 1000;
+}
+
+Datum
+float8_as_datum(double x)
+{
+	Datum		d;
+
+	memcpy(&d, &x, sizeof(d));
+	return d;
+}
+
+/* ------------------------------------------------------------------------------------------------ the catalog */
+struct TupleDescData
+{
+	int			natts;
+};
+static struct TupleDescData one_column = {1};
+static struct RelationData rel_objs[SHIM_MAX_RELS];
+
+static void
+spin_lock(uint32 *w)
+{
+	for (;;)
+	{
+		uint32		zero = 0;
+
+		if (__atomic_compare_exchange_n(w, &zero, 1u, 0, __ATOMIC_ACQUIRE, __ATOMIC_RELAXED))
+			return;
+		usleep(20);
+	}
+}
+
+static void
+spin_unlock(uint32 *w)
+{
+	__atomic_store_n(w, 0u, __ATOMIC_RELEASE);
+}
+
+static ShimRel *
+find_rel(Oid oid)
+{
+	for (int i = 0; i < SHIM_MAX_RELS; i++)
+		if (S->rels[i].oid == oid && oid != 0)
+			return &S->rels[i];
+	return NULL;
+}
+
+static void
+rel_lock_shared(ShimRel * r)
+{
+	for (;;)
+	{
+		uint32		v = __atomic_load_n(&r->lock, __ATOMIC_RELAXED);
+
+		if (!(v & 0x80000000u) && __atomic_compare_exchange_n(&r->lock, &v, v + 1, 0, __ATOMIC_ACQUIRE, __ATOMIC_RELAXED))
+			return;
+		usleep(20);
+	}
+}
+
+static void
+rel_unlock_shared(ShimRel * r)
+{
+	__atomic_sub_fetch(&r->lock, 1, __ATOMIC_RELEASE);
+}
+
+static void
+rel_lock_exclusive(ShimRel * r)
+{
+	for (;;)
+	{
+		uint32		zero = 0;
+
+		if (__atomic_compare_exchange_n(&r->lock, &zero, 0x80000000u, 0, __ATOMIC_ACQUIRE, __ATOMIC_RELAXED))
+			return;
+		usleep(50);
+	}
+}
+
+static void
+rel_unlock_exclusive(ShimRel * r)
+{
+	__atomic_store_n(&r->lock, 0u, __ATOMIC_RELEASE);
+}
+
+void
+shim_create_relation(Oid oid, const ShimOpclass * opclass, const void *pages, uint32_t nblocks, int dimensions)
+{
+	ShimRel    *r = NULL;
+	uint32		cap = nblocks * 2 + 64;
+
+	spin_lock(&S->catalog_lock);
+	for (int i = 0; i < SHIM_MAX_RELS && r == NULL; i++)
+		if (S->rels[i].oid == 0)
+			r = &S->rels[i];
+	if (r == NULL || S->page_used + (size_t) cap * SHIM_BLCKSZ > S->page_end - S->page_off)
+	{
+		fprintf(stderr, "pgshim: catalog or page store full\n");
+		abort();
+	}
+	r->opc = *opclass;
+	r->dimensions = dimensions;
+	r->pages_off = S->page_off + S->page_used;
+	r->cap_blocks = cap;
+	r->nblocks = nblocks;
+	r->lock = 0;
+	S->page_used += (size_t) cap * SHIM_BLCKSZ;
+	memcpy(Sbase + r->pages_off, pages, (size_t) nblocks * SHIM_BLCKSZ);
+	__atomic_store_n(&r->oid, oid, __ATOMIC_RELEASE);
+	spin_unlock(&S->catalog_lock);
+}
+
+void
+shim_replace_pages(Oid oid, const void *pages, uint32_t nblocks)
+{
+	ShimRel    *r = find_rel(oid);
+
+	if (r == NULL || nblocks > r->cap_blocks)
+	{
+		fprintf(stderr, "pgshim: shim_replace_pages: unknown relation or too many blocks\n");
+		abort();
+	}
+	rel_lock_exclusive(r);
+	memcpy(Sbase + r->pages_off, pages, (size_t) nblocks * SHIM_BLCKSZ);
+	r->nblocks = nblocks;
+	rel_unlock_exclusive(r);
+}
+
+const void *
+shim_relation_pages(Oid oid, uint32_t *nblocks)
+{
+	ShimRel    *r = find_rel(oid);
+
+	if (r == NULL)
+		return NULL;
+	*nblocks = r->nblocks;
+	return Sbase + r->pages_off;
+}
+
+void
+shim_drop_relation(Oid oid)
+{
+	ShimRel    *r = find_rel(oid);
+
+	if (r)
+		__atomic_store_n(&r->oid, 0, __ATOMIC_RELEASE);
+}
+
+Relation
+shim_open_relation(Oid oid)
+{
+	ShimRel    *r = find_rel(oid);
+
+	if (r == NULL)
+		return NULL;
+	rel_objs[r - S->rels].rd_id = oid;
+	rel_objs[r - S->rels].rd_att = &one_column;
+	return &rel_objs[r - S->rels];
+}
+
+static ShimRel *
+rel_of(Relation rel)
+{
+	ShimRel    *r = find_rel(rel->rd_id);
+
+	if (r == NULL)
+		ereport(ERROR, (errmsg("could not open relation with OID %u", rel->rd_id)));
+	return r;
+}
+
+Relation
+try_index_open(Oid relationId, LOCKMODE lockmode)
+{
+	(void) lockmode;
+	return shim_open_relation(relationId);
+}
+
+void
+index_close(Relation relation, LOCKMODE lockmode)
+{
+	(void) relation, (void) lockmode;
+}
+
+typedef struct RelcacheCb
+{
+	RelcacheCallbackFunction fn;
+	Datum		arg;
+}			RelcacheCb;
+static RelcacheCb relcache_cbs[8];
+static int	n_relcache_cbs = 0;
+
+void
+CacheRegisterRelcacheCallback(RelcacheCallbackFunction func, Datum arg)
+{
+	relcache_cbs[n_relcache_cbs].fn = func;
+	relcache_cbs[n_relcache_cbs++].arg = arg;
+}
+
+void
+shim_relcache_invalidate(Oid relid)
+{
+	for (int i = 0; i < n_relcache_cbs; i++)
+		relcache_cbs[i].fn(relcache_cbs[i].arg, relid);
+}
+
+/* ------------------------------------------------------------------------------------------------ buffers and pages */
+#define MAX_PINS 64
+static struct
+{
+	Buffer		buf;
+	bool		locked;
+}			pins[MAX_PINS];
+static int	npins = 0;
+
+#define BUF_REL(b) (((b) - 1) >> 24)
+#define BUF_BLK(b) ((uint32) (((b) - 1) & 0xFFFFFF))
+
+Buffer
+ReadBufferExtended(Relation reln, ForkNumber forkNum, BlockNumber blockNum, ReadBufferMode mode, BufferAccessStrategy strategy)
+{
+	ShimRel    *r = rel_of(reln);
+	Buffer		b;
+
+	(void) forkNum, (void) mode, (void) strategy;
+	if (blockNum >= __atomic_load_n(&r->nblocks, __ATOMIC_ACQUIRE))
+		ereport(ERROR, (errmsg("could not read block %u of relation %u: read only 0 of 8192 bytes", blockNum, reln->rd_id)));
+	if (npins == MAX_PINS)
+		ereport(ERROR, (errmsg("too many buffers pinned")));
+	b = (Buffer) (((int) (r - S->rels) << 24) | (int) blockNum) + 1;
+	pins[npins].buf = b;
+	pins[npins++].locked = false;
+	return b;
+}
+
+static int
+pin_index(Buffer buffer)
+{
+	for (int i = npins - 1; i >= 0; i--)
+		if (pins[i].buf == buffer)
+			return i;
+	fprintf(stderr, "pgshim: buffer %d is not pinned by this process\n", buffer);
+	abort();
+}
+
+void
+LockBuffer(Buffer buffer, int mode)
+{
+	int			i = pin_index(buffer);
+
+	(void) mode;
+	rel_lock_shared(&S->rels[BUF_REL(buffer)]);
+	pins[i].locked = true;
+}
+
+void
+UnlockReleaseBuffer(Buffer buffer)
+{
+	int			i = pin_index(buffer);
+
+	if (pins[i].locked)
+		rel_unlock_shared(&S->rels[BUF_REL(buffer)]);
+	pins[i] = pins[--npins];
+}
+
+static void
+release_all_buffers(void)
+{
+	/* what the resource owner does at transaction abort */
+	while (npins > 0)
+		UnlockReleaseBuffer(pins[npins - 1].buf);
+}
+
+int
+shim_pinned_buffers(void)
+{
+	return npins;
+}
+
+Page
+BufferGetPage(Buffer buffer)
+{
+	(void) pin_index(buffer);
+	return Sbase + S->rels[BUF_REL(buffer)].pages_off + (size_t) BUF_BLK(buffer) * SHIM_BLCKSZ;
+}
+
+BlockNumber
+RelationGetNumberOfBlocks(Relation reln)
+{
+	return __atomic_load_n(&rel_of(reln)->nblocks, __ATOMIC_ACQUIRE);
+}
+
+/* PageHeaderData: pd_lsn 8, pd_checksum 2, pd_flags 2, pd_lower 2, pd_upper 2, pd_special 2, pd_pagesize_version 2,
+ * pd_prune_xid 4 = 24 bytes, then ItemIdData[] (lp_off:15, lp_flags:2, lp_len:15) -- storage/bufpage.h, storage/itemid.h */
+#define PAGE_HEADER_SIZE 24
+
+static uint16
+page_u16(Page page, int off)
+{
+	uint16		v;
+
+	memcpy(&v, page + off, 2);
+	return v;
+}
+
+OffsetNumber
+PageGetMaxOffsetNumber(Page page)
+{
+	uint16		lower = page_u16(page, 12);
+
+	return lower <= PAGE_HEADER_SIZE ? 0 : (OffsetNumber) ((lower - PAGE_HEADER_SIZE) / 4);
+}
+
+ItemId
+PageGetItemId(Page page, OffsetNumber offsetNumber)
+{
+	return (ItemId) (page + PAGE_HEADER_SIZE + (size_t) (offsetNumber - 1) * 4);
+}
+
+Item
+PageGetItem(Page page, ItemId itemId)
+{
+	uint32		lp;
+
+	memcpy(&lp, itemId, 4);
+	return page + (lp & 0x7FFFu);
+}
+
+char *
+PageGetSpecialPointer(Page page)
+{
+	return page + page_u16(page, 16);
+}
+
+char *
+PageGetContents(Page page)
+{
+	return page + PAGE_HEADER_SIZE;	/* MAXALIGN(SizeOfPageHeaderData) */
+}
+
+BlockNumber
+ItemPointerGetBlockNumber(const ItemPointerData *p)
+{
+	return ((BlockNumber) p->ip_blkid.bi_hi << 16) | p->ip_blkid.bi_lo;
+}
+
+OffsetNumber
+ItemPointerGetOffsetNumber(const ItemPointerData *p)
+{
+	return p->ip_posid;
+}
+
+/* the one attribute of an index tuple without NULLs: right behind the 8-byte header (a short varlena needs no
+ * alignment padding, a 4-byte-header one sits MAXALIGNed there anyway) -- access/itup.h, access/tupmacs.h */
+Datum
+index_getattr(IndexTuple tup, int attnum, TupleDesc tupleDesc, bool *isnull)
+{
+	(void) attnum, (void) tupleDesc;
+	*isnull = false;
+	return PointerGetDatum((char *) tup + sizeof(IndexTupleData));
+}
+
+/*
+ * varlena forms a Datum can arrive in (postgres.h / varatt.h, little endian):
+ *   xxxxxx00  4-byte header, length << 2: plain -- returned as is
+ *   xxxxxxx1  1-byte header, length << 1 | 1 (values under 127 bytes: what index_form_tuple and heap_form_tuple
+ *             store) -- expanded into a palloc'd copy with a 4-byte header
+ *   xxxxxx10  4-byte header of a COMPRESSED value; this runtime's stand-in for "toasted": header, uint32 raw size,
+ *             then the payload uncompressed -- expanded into a palloc'd plain copy, like a detoast does
+ */
+struct varlena *
+pg_detoast_datum(struct varlena *datum)
+{
+	const unsigned char *p = (const unsigned char *) datum;
+
+	if (p[0] & 0x01)
+	{
+		Size		len = p[0] >> 1;	/* includes the header byte */
+		struct varlena *out = palloc(len - 1 + 4);
+		uint32		hdr = (uint32) (len - 1 + 4) << 2;
+
+		memcpy(out, &hdr, 4);
+		memcpy((char *) out + 4, p + 1, len - 1);
+		return out;
+	}
+	if ((p[0] & 0x03) == 0x02)
+	{
+		uint32		raw;
+		struct varlena *out;
+		uint32		hdr;
+
+		memcpy(&raw, p + 4, 4);
+		out = palloc(raw + 4);
+		hdr = (raw + 4) << 2;
+		memcpy(out, &hdr, 4);
+		memcpy((char *) out + 4, p + 8, raw);
+		return out;
+	}
+	return datum;
+}
+
+/* ------------------------------------------------------------------------------------------------ lists */
+struct List
+{
+	int			length,
+				cap;
+	void	  **elems;
+};
+
+List *
+lappend(List *list, void *datum)
+{
+	if (list == NIL)
+	{
+		list = palloc0(sizeof(List));
+		list->cap = 16;
+		list->elems = palloc(sizeof(void *) * 16);
+	}
+	if (list->length == list->cap)
+	{
+		list->cap *= 2;
+		list->elems = repalloc(list->elems, sizeof(void *) * (Size) list->cap);
+	}
+	list->elems[list->length++] = datum;
+	return list;
+}
+
+int
+shim_list_length(const List *l)
+{
+	return l ? l->length : 0;
+}
+
+void *
+shim_list_nth(const List *l, int n)
+{
+	return l->elems[n];
+}
+
+/* ------------------------------------------------------------------------------------------------ transactions */
+static MemoryContext xact_context = NULL;
+static MemoryContext xact_saved = NULL;
+
+void
+StartTransactionCommand(void)
+{
+	xact_context = calloc(1, sizeof(struct MemoryContextData));
+	xact_context->name = "transaction";
+	xact_saved = CurrentMemoryContext;
+	CurrentMemoryContext = xact_context;
+}
+
+static void
+end_transaction(void)
+{
+	release_all_buffers();
+	if (xact_context)
+	{
+		CurrentMemoryContext = xact_saved ? xact_saved : TopMemoryContext;
+		shim_context_reset(xact_context);
+		free(xact_context);
+		xact_context = NULL;
+	}
+}
+
+static int	pin_leaks = 0;
+
+void
+CommitTransactionCommand(void)
+{
+	if (npins > 0)
+	{
+		fprintf(stderr, "WARNING:  buffer refcount leak: %d buffers still pinned at commit\n", npins);
+		pin_leaks += npins;
+	}
+	end_transaction();
+}
+
+void
+AbortCurrentTransaction(void)
+{
+	end_transaction();
+}
+
+int
+shim_pin_leaks(void)
+{
+	return pin_leaks;
+}
+
+int
+shim_run_toplevel(int (*fn) (void *), void *arg, int *result)
+{
+	sigjmp_buf	top;
+	sigjmp_buf *saved = PG_exception_stack;
+
+	if (sigsetjmp(top, 0) == 0)
+	{
+		PG_exception_stack = &top;
+		*result = fn(arg);
+		PG_exception_stack = saved;
+		return 0;
+	}
+	/* PostgresMain's error recovery: report, abort the transaction (pins, locks), drop the query's memory */
+	PG_exception_stack = saved;
+	EmitErrorReport();
+	AbortCurrentTransaction();
+	if (query_context)
+		shim_query_context_end(query_context);
+	CurrentMemoryContext = TopMemoryContext;
+	cancel_countdown = -1;
+	return -1;
+}
+
+/* ------------------------------------------------------------------------------------------------ processes */
+static struct
+{
+	char		name[BGW_MAXLEN];
+	void		(*fn) (Datum);
+}			bgw_fns[4];
+static int	n_bgw_fns = 0;
+static int	my_proc_slot = -1;
+
+void
+shim_register_bgworker_function(const char *name, void (*fn) (Datum))
+{
+	snprintf(bgw_fns[n_bgw_fns].name, BGW_MAXLEN, "%s", name);
+	bgw_fns[n_bgw_fns++].fn = fn;
+}
+
+void
+shim_postmaster_init(size_t page_store_bytes, size_t arena_bytes)
+{
+	size_t		shmem_bytes = 8u << 20;
+	size_t		total = ((sizeof(ShimShared) + 4095) & ~(size_t) 4095) + shmem_bytes + page_store_bytes + arena_bytes;
+
+	Sbase = mmap(NULL, total, PROT_READ | PROT_WRITE, MAP_SHARED | MAP_ANONYMOUS | MAP_NORESERVE, -1, 0);
+	if (Sbase == MAP_FAILED)
+	{
+		perror("pgshim: mmap");
+		abort();
+	}
+	S = (ShimShared *) Sbase;
+	memset(S, 0, sizeof(ShimShared));
+	S->magic = 0x70677368696dull;
+	S->postmaster_pid = (int) getpid();
+	S->shmem_off = (sizeof(ShimShared) + 4095) & ~(size_t) 4095;
+	S->shmem_end = S->shmem_off + shmem_bytes;
+	S->page_off = S->shmem_end;
+	S->page_end = S->page_off + page_store_bytes;
+	S->arena_off = S->page_end;
+	S->arena_bytes = arena_bytes;
+	AddinShmemInitLock = &S->addin_lock;
+	MyProcPid = (int) getpid();
+}
+
+void *
+shim_arena_base(size_t *bytes)
+{
+	*bytes = S->arena_bytes;
+	return S->arena_bytes ? Sbase + S->arena_off : NULL;
+}
+
+void
+shim_postmaster_run_shmem_hooks(void)
+{
+	if (shmem_request_hook)
+		shmem_request_hook();
+	if (shmem_startup_hook)
+		shmem_startup_hook();
+	process_shared_preload_libraries_in_progress = false;
+}
+
+static void
+child_init(void)
+{
+	my_proc_slot = (int) __atomic_fetch_add(&S->next_proc, 1, __ATOMIC_SEQ_CST);
+	if (my_proc_slot >= SHIM_MAX_PROCS)
+	{
+		fprintf(stderr, "pgshim: too many processes\n");
+		_exit(99);
+	}
+	MyLatch = &S->latches[my_proc_slot];
+	MyLatch->is_set = 0;
+	MyProcPid = (int) getpid();
+	PG_exception_stack = NULL;
+}
+
+int
+shim_fork_backend(int (*fn) (void *), void *arg)
+{
+	pid_t		pid;
+
+	fflush(NULL);
+	pid = fork();
+	if (pid == 0)
+	{
+		int			result = 0;
+
+		child_init();
+		if (shim_run_toplevel(fn, arg, &result) != 0)
+		{
+			fprintf(stderr, "backend %d: ERROR reached the top level: %s\n", (int) getpid(), last_error);
+			result = 100;
+		}
+		proc_exit(result);
+	}
+	return (int) pid;
+}
+
+static int
+run_bgworker(void *arg)
+{
+	ShimBgw    *w = arg;
+
+	for (int i = 0; i < n_bgw_fns; i++)
+		if (strcmp(bgw_fns[i].name, w->fn) == 0)
+		{
+			bgw_fns[i].fn(w->arg);
+			return 0;
+		}
+	fprintf(stderr, "pgshim: no background worker function %s\n", w->fn);
+	return 98;
+}
+
+static void
+start_requested_bgworkers(void)
+{
+	for (int i = 0; i < SHIM_MAX_BGW; i++)
+	{
+		ShimBgw    *w = &S->bgw[i];
+
+		if (__atomic_load_n(&w->state, __ATOMIC_ACQUIRE) != 1)
+			continue;
+		fflush(NULL);
+		w->pid = fork();
+		if (w->pid == 0)
+		{
+			int			result = 0;
+
+			child_init();
+			is_bgworker = 1;
+			/* StartBackgroundWorker: an ERROR that reaches here is reported and the worker exits with code 1 (the
+			 * exit callbacks run) */
+			if (shim_run_toplevel(run_bgworker, w, &result) != 0)
+				result = 1;
+			proc_exit(result);
+		}
+		__atomic_store_n(&w->state, 2, __ATOMIC_RELEASE);
+	}
+}
+
+bool
+RegisterDynamicBackgroundWorker(BackgroundWorker *worker, BackgroundWorkerHandle **handle)
+{
+	for (int i = 0; i < SHIM_MAX_BGW; i++)
+	{
+		ShimBgw    *w = &S->bgw[i];
+		uint32		zero = 0;
+
+		if (!__atomic_compare_exchange_n(&w->state, &zero, 3u, 0, __ATOMIC_ACQUIRE, __ATOMIC_RELAXED))
+			continue;
+		snprintf(w->fn, BGW_MAXLEN, "%s", worker->bgw_function_name);
+		w->arg = worker->bgw_main_arg;
+		__atomic_store_n(&w->state, 1, __ATOMIC_RELEASE);
+		__atomic_add_fetch(&S->bgw_kick, 1, __ATOMIC_RELEASE);
+		futex_wake(&S->bgw_kick);
+		if (handle)
+			*handle = NULL;
+		return true;
+	}
+	return false;				/* max_worker_processes reached */
+}
+
+void
+BackgroundWorkerUnblockSignals(void)
+{
+	struct sigaction sa;
+
+	memset(&sa, 0, sizeof(sa));
+	sa.sa_handler = handle_sigterm;
+	sigaction(SIGTERM, &sa, NULL);
+}
+
+void
+BackgroundWorkerInitializeConnectionByOid(Oid dboid, Oid useroid, uint32 flags)
+{
+	(void) useroid, (void) flags;
+	MyDatabaseId = dboid;
+}
+
+static void
+reap_bgworkers(void)
+{
+	for (int i = 0; i < SHIM_MAX_BGW; i++)
+	{
+		ShimBgw    *w = &S->bgw[i];
+		int			st;
+
+		if (__atomic_load_n(&w->state, __ATOMIC_ACQUIRE) == 2 && waitpid(w->pid, &st, WNOHANG) == w->pid)
+		{
+			w->pid = 0;
+			__atomic_store_n(&w->state, 0, __ATOMIC_RELEASE);
+		}
+	}
+}
+
+int
+shim_live_bgworkers(void)
+{
+	int			n = 0;
+
+	reap_bgworkers();
+	for (int i = 0; i < SHIM_MAX_BGW; i++)
+		n += __atomic_load_n(&S->bgw[i].state, __ATOMIC_ACQUIRE) == 2;
+	return n;
+}
+
+int
+shim_postmaster_wait(const int *pids, int npids, int *codes, double timeout_s)
+{
+	double		until = shim_now() + timeout_s;
+	int			left = npids;
+	int		   *done = calloc((size_t) (npids > 0 ? npids : 1), sizeof(int));
+
+	for (int i = 0; i < npids; i++)
+		codes[i] = -1;
+	while (left > 0 && shim_now() < until)
+	{
+		uint32		kick = __atomic_load_n(&S->bgw_kick, __ATOMIC_ACQUIRE);
+
+		start_requested_bgworkers();
+		reap_bgworkers();
+		for (int i = 0; i < npids; i++)
+		{
+			int			st;
+
+			if (!done[i] && waitpid(pids[i], &st, WNOHANG) == pids[i])
+			{
+				done[i] = 1;
+				left--;
+				codes[i] = WIFEXITED(st) ? WEXITSTATUS(st) : 128 + WTERMSIG(st);
+			}
+		}
+		if (left > 0)
+			futex_wait(&S->bgw_kick, kick, 2);
+	}
+	for (int i = 0; i < npids; i++)
+		if (!done[i])
+		{
+			kill(pids[i], SIGKILL);
+			waitpid(pids[i], NULL, 0);
+		}
+	free(done);
+	return left;
+}
+
+void
+shim_kill_bgworkers(void)
+{
+	for (int i = 0; i < SHIM_MAX_BGW; i++)
+		if (__atomic_load_n(&S->bgw[i].state, __ATOMIC_ACQUIRE) == 2)
+		{
+			kill(S->bgw[i].pid, SIGKILL);
+			waitpid(S->bgw[i].pid, NULL, 0);
+			S->bgw[i].pid = 0;
+			__atomic_store_n(&S->bgw[i].state, 0, __ATOMIC_RELEASE);
+		}
+}
+
+void
+shim_postmaster_shutdown(void)
+{
+	double		until = shim_now() + 10.0;
+
+	for (int i = 0; i < SHIM_MAX_BGW; i++)
+		if (__atomic_load_n(&S->bgw[i].state, __ATOMIC_ACQUIRE) == 2)
+			kill(S->bgw[i].pid, SIGTERM);
+	while (shim_live_bgworkers() > 0 && shim_now() < until)
+		usleep(2000);
+	shim_kill_bgworkers();
+}
+
+/* ------------------------------------------------------------------------------------------------ pgvector's own */
+static Size
+vector_item_size(int dimensions)
+{
+	return offsetof(Vector, x) + sizeof(float) * (Size) dimensions;
+}
+
+static Size
+halfvec_item_size(int dimensions)
+{
+	return offsetof(Vector, x) + sizeof(uint16) * (Size) dimensions;
+}
+
+static IvfflatTypeInfo ivf_type_infos[SHIM_MAX_RELS];
+static HnswTypeInfo hnsw_type_infos[SHIM_MAX_RELS];
+static FmgrInfo proc_infos[SHIM_MAX_RELS][8];
+
+const IvfflatTypeInfo *
+IvfflatGetTypeInfo(Relation index)
+{
+	ShimRel    *r = rel_of(index);
+	IvfflatTypeInfo *t = &ivf_type_infos[r - S->rels];
+
+	t->maxDimensions = r->opc.maxDimensions;
+	t->itemSize = r->opc.maxDimensions == IVFFLAT_MAX_DIM * 2 ? halfvec_item_size : vector_item_size;
+	return t;
+}
+
+const HnswTypeInfo *
+HnswGetTypeInfo(Relation index)
+{
+	ShimRel    *r = rel_of(index);
+
+	hnsw_type_infos[r - S->rels].maxDimensions = r->opc.maxDimensions;
+	return &hnsw_type_infos[r - S->rels];
+}
+
+/* src/ivfutils.c:46-52: NULL when the opclass has no such support function */
+FmgrInfo *
+IvfflatOptionalProcInfo(Relation index, uint16 procnum)
+{
+	ShimRel    *r = rel_of(index);
+
+	if (procnum == IVFFLAT_NORM_PROC && !r->opc.hasNormProc)
+		return NULL;
+	if (procnum == IVFFLAT_KMEANS_NORM_PROC && !r->opc.hasKmeansNormProc)
+		return NULL;
+	return &proc_infos[r - S->rels][procnum & 7];
+}
+
+FmgrInfo *
+HnswOptionalProcInfo(Relation index, uint16 procnum)
+{
+	ShimRel    *r = rel_of(index);
+
+	if (procnum == HNSW_NORM_PROC && !r->opc.hasNormProc)
+		return NULL;
+	return &proc_infos[r - S->rels][procnum & 7];
+}
+
+Datum
+vector_negative_inner_product(void *fcinfo)
+{
+	(void) fcinfo;
+	return 0;
+}
+
+Datum
+halfvec_negative_inner_product(void *fcinfo)
+{
+	(void) fcinfo;
+	return 0;
+}
+
+Datum
+l1_distance(void *fcinfo)
+{
+	(void) fcinfo;
+	return 0;
+}
+
+Datum
+halfvec_l1_distance(void *fcinfo)
+{
+	(void) fcinfo;
+	return 0;
+}
+
+static Datum
+vector_l2_squared_distance_stub(void *fcinfo)
+{
+	(void) fcinfo;
+	return 0;
+}
+
+FmgrInfo *
+index_getprocinfo(Relation irel, int attnum, uint16 procnum)
+{
+	ShimRel    *r = rel_of(irel);
+	FmgrInfo   *f = &proc_infos[r - S->rels][procnum & 7];
+
+	(void) attnum;
+	if (procnum == 1)
+		f->fn_addr = r->opc.distanceFn == 1 ? vector_negative_inner_product :
+			(r->opc.distanceFn == 2 ? l1_distance : vector_l2_squared_distance_stub);
+	return f;
+}
+
+/* src/ivfutils.c:150-175: dimensions and lists off the meta page (block 0) */
+void
+IvfflatGetMetaPageInfo(Relation index, int *lists, int *dimensions)
+{
+	Buffer		buf = ReadBufferExtended(index, MAIN_FORKNUM, 0, RBM_NORMAL, NULL);
+	Page		page;
+	uint32		magic;
+	uint16		d,
+				l;
+
+	LockBuffer(buf, BUFFER_LOCK_SHARE);
+	page = BufferGetPage(buf);
+	memcpy(&magic, PageGetContents(page), 4);
+	memcpy(&d, PageGetContents(page) + 8, 2);
+	memcpy(&l, PageGetContents(page) + 10, 2);
+	UnlockReleaseBuffer(buf);
+	if (magic != 0x14FF1A7)
+		elog(ERROR, "ivfflat index is not valid");
+	if (lists)
+		*lists = l;
+	if (dimensions)
+		*dimensions = d;
+}
+
+HnswElement
+HnswInitElementFromBlock(BlockNumber blkno, OffsetNumber offno)
+{
+	HnswElement e = palloc0(sizeof(HnswElementData));
+
+	e->blkno = blkno;
+	e->offno = offno;
+	return e;
+}
+
+void
+HnswAddHeapTid(HnswElement element, ItemPointer heaptid)
+{
+	element->heaptids[element->heaptidsLength++] = *heaptid;
+}
+
+static uint64 rng_state = 0x9E3779B97F4A7C15ull;
+
+static uint64
+rng_next(void)
+{
+	rng_state ^= rng_state << 13;
+	rng_state ^= rng_state >> 7;
+	rng_state ^= rng_state << 17;
+	return rng_state;
+}
+
+void
+shim_seed_random(uint64 seed)
+{
+	rng_state = seed ? seed : 1;
+}
+
+double
+RandomDouble(void)
+{
+	return (double) (rng_next() >> 11) / 9007199254740992.0;
+}
+
+int
+RandomInt(void)
+{
+	return (int) (rng_next() >> 33);
+}

@@ -1,0 +1,75 @@
+/*
+ * pgshim_runtime.h -- what tests/c/ext_driver.c uses to play the server around the glue of ext/: a postmaster that
+ * owns one shared mapping (shmem structs, LWLocks, latches, the relation catalog with its 8 KB pages, a bump arena the
+ * mock device allocates from), forks backends and background workers, and gives every function of ext/shim/pgshim.h a
+ * body.  TEST INFRASTRUCTURE: not PostgreSQL, not part of the product.
+ */
+#ifndef PGSHIM_RUNTIME_H
+#define PGSHIM_RUNTIME_H
+
+#include "pgshim.h"
+
+#define SHIM_BLCKSZ 8192
+#define SHIM_MAX_RELS 16
+#define SHIM_MAX_PROCS 96
+
+/* which opclass an emulated index relation was "created" with: what IvfflatGetTypeInfo / IvfflatOptionalProcInfo /
+ * index_getprocinfo answer for it */
+typedef struct ShimOpclass
+{
+	int			am;				/* 0 ivfflat, 1 hnsw */
+	int			maxDimensions;	/* IVFFLAT_MAX_DIM (vector), x 2 (halfvec), x 32 (bit) */
+	bool		hasNormProc;	/* FUNCTION 2 (cosine: rows stored normalised) */
+	bool		hasKmeansNormProc;	/* FUNCTION 4 (spherical k-means) */
+	int			distanceFn;		/* 0 l2 squared, 1 negative inner product, 2 l1 */
+}			ShimOpclass;
+
+/* ---- postmaster ---- */
+void		shim_postmaster_init(size_t page_store_bytes, size_t arena_bytes);
+/* the arena the mock device carves its "device memory" from, so that an exported index is visible in every process
+ * forked from the postmaster (NULL / 0 without one) */
+void	   *shim_arena_base(size_t *bytes);
+/* runs the shmem request / startup hooks a preloaded library installed */
+void		shim_postmaster_run_shmem_hooks(void);
+void		shim_register_bgworker_function(const char *name, void (*fn) (Datum));
+/* fork a backend that runs fn(arg) under the top-level error handler; its exit code is fn's return value (or 100 for
+ * an ERROR that reached the top level, 101 for a FATAL exit) */
+int			shim_fork_backend(int (*fn) (void *), void *arg);
+/* serve background-worker requests and reap children until every pid in pids[] has exited (their exit codes go to
+ * codes[]) or timeout_s passes; returns the number still running (they are killed) */
+int			shim_postmaster_wait(const int *pids, int npids, int *codes, double timeout_s);
+/* ends every background worker (SIGTERM -> their CHECK_FOR_INTERRUPTS proc_exit) and reaps them */
+void		shim_postmaster_shutdown(void);
+int			shim_live_bgworkers(void);
+/* kill the background workers the hard way (SIGKILL): what a crashed worker looks like to the backends */
+void		shim_kill_bgworkers(void);
+
+/* ---- catalog ---- */
+/* registers relation `oid` over `nblocks` pages copied from `pages` into the shared page store */
+void		shim_create_relation(Oid oid, const ShimOpclass * opclass, const void *pages, uint32_t nblocks, int dimensions);
+/* replaces the page image of a relation (insert / vacuum happened) under the relation's exclusive lock */
+void		shim_replace_pages(Oid oid, const void *pages, uint32_t nblocks);
+const void *shim_relation_pages(Oid oid, uint32_t *nblocks);
+Relation	shim_open_relation(Oid oid);	/* this process's Relation for it (NULL when unknown) */
+void		shim_drop_relation(Oid oid);
+
+/* ---- per-process ---- */
+/* run fn(arg) with a top-level handler: an ERROR that no PG_TRY caught aborts the "transaction" (buffer pins released,
+ * the query context reset -- reset callbacks fire) and makes this return -1 with the message in shim_last_error() */
+int			shim_run_toplevel(int (*fn) (void *), void *arg, int *result);
+const char *shim_last_error(void);
+/* a fresh child of TopMemoryContext made current (what the executor's per-query context is to ivfflatbeginscan) */
+MemoryContext shim_query_context_begin(void);
+void		shim_query_context_end(MemoryContext ctx);	/* reset (callbacks fire) + delete, CurrentMemoryContext = Top */
+void		shim_context_reset(MemoryContext ctx);
+size_t		shim_context_bytes(MemoryContext ctx);
+/* the next CHECK_FOR_INTERRUPTS after `after_checks` more calls raises "canceling statement due to user request" */
+void		shim_cancel_after(int after_checks);
+int			shim_pinned_buffers(void);	/* buffers this process holds pinned right now */
+void		shim_set_guc_bool(const char *name, bool value);
+void		shim_set_guc_int(const char *name, int value);
+void		shim_relcache_invalidate(Oid relid);
+void		shim_run_proc_exit(int code);	/* before_shmem_exit + on_proc_exit callbacks (a clean backend exit) */
+double		shim_now(void);
+
+#endif
