@@ -9,6 +9,7 @@
  * Hook points (one line each; the reference code stays as the `vector.gpu = off` path):
  *   hnswbeginscan   src/hnswscan.c:121-146   so->gpu = PgvHnswBeginScan(index);
  *   hnswgettuple    src/hnswscan.c:228        so->w = so->gpu ? PgvHnswGetScanItems(scan, value) : GetScanItems(scan, value);
+ *   hnswendscan     src/hnswscan.c:337-349    PgvHnswEndScan(so->gpu);
  *   hnswinsert / hnswbulkdelete / hnswbuild   PgvNoteIndexChange(index);   (the mirror is stale until restaged)
  * hnswgettuple then pops so->w one heap TID at a time exactly as before (:293-326); with hnsw.iterative_scan the
  * later batches (ResumeScanItems, :61-88) stay on the reference's code, scoring through pgv_hnsw_score
@@ -33,8 +34,17 @@ typedef struct PgvHnswMirror
 	pgv_hnsw   *h;
 	int			m;
 	int64		nelements;
+	int			users;			/* open scans holding this import */
+	bool		retired;		/* replaced by a newer staging for new scans; unmapped when the last user ends */
 	struct PgvHnswMirror *next;
 }			PgvHnswMirror;
+
+/* one per scan: the import it runs on, let go with the scan's memory context (an ERROR longjmps past hnswendscan) */
+typedef struct PgvHnswScan
+{
+	PgvHnswMirror *mirror;
+	MemoryContextCallback cleanup;
+}			PgvHnswScan;
 
 /* payload words per element: the element tuple's TID, the count of heap TIDs, HNSW_HEAPTIDS heap TIDs; every TID
  * as two words of (block << 16) | offset */
@@ -265,10 +275,42 @@ PgvHnswElementType(Relation index, pgv_dtype * dtype)
 	return true;
 }
 
+static void
+PgvHnswRelease(void *arg)
+{
+	PgvHnswScan *hs = (PgvHnswScan *) arg;
+	PgvHnswMirror *m = hs->mirror;
+
+	hs->mirror = NULL;
+	if (m == NULL)
+		return;
+	m->users--;
+	if (m->users <= 0 && m->retired)
+	{
+		PgvHnswMirror **link = &hnswMirrors;
+
+		if (m->h)
+			pgv_hnsw_free(m->h);	/* unmaps the import; the worker's allocation stays */
+		while (*link != NULL && *link != m)
+			link = &(*link)->next;
+		if (*link == m)
+			*link = m->next;
+		pfree(m);
+	}
+}
+
+void
+PgvHnswEndScan(void *gpu)
+{
+	if (gpu != NULL)
+		PgvHnswRelease(gpu);
+}
+
 void *
 PgvHnswBeginScan(Relation index)
 {
 	PgvHnswMirror *m;
+	PgvHnswScan *hs;
 	pgv_dtype	dtype;
 	pgv_index_handle handle;
 	uint64		staged = 0;
@@ -282,8 +324,24 @@ PgvHnswBeginScan(Relation index)
 	if (!PgvHnswMirrorHandle(index, &handle, &staged, &graphM, &nelements))
 		return NULL;
 	for (m = hnswMirrors; m != NULL; m = m->next)
-		if (m->relid == RelationGetRelid(index))
+		if (m->relid == RelationGetRelid(index) && !m->retired)
 			break;
+	if (m != NULL && (!m->valid || m->staged != staged))
+	{
+		/* a newer staging: scans of this backend that are still open keep the import they began on */
+		if (m->users > 0)
+		{
+			m->retired = true;
+			m = NULL;
+		}
+		else
+		{
+			if (m->h)
+				pgv_hnsw_free(m->h);
+			m->h = NULL;
+			m->valid = false;
+		}
+	}
 	if (m == NULL)
 	{
 		m = MemoryContextAllocZero(TopMemoryContext, sizeof(PgvHnswMirror));
@@ -291,12 +349,8 @@ PgvHnswBeginScan(Relation index)
 		m->next = hnswMirrors;
 		hnswMirrors = m;
 	}
-	if (!m->valid || m->staged != staged)
+	if (!m->valid)
 	{
-		if (m->h)
-			pgv_hnsw_free(m->h);	/* unmaps the import; the worker's allocation stays */
-		m->h = NULL;
-		m->valid = false;
 		if (pgv_hnsw_import(PgvGetContext(), &handle, &m->h) != PGV_OK)
 			ereport(ERROR, (errmsg("pgvector GPU path: %s", pgv_last_error())));
 		m->m = graphM;
@@ -304,7 +358,13 @@ PgvHnswBeginScan(Relation index)
 		m->staged = staged;
 		m->valid = true;
 	}
-	return m;
+	hs = palloc0(sizeof(PgvHnswScan));
+	hs->mirror = m;
+	m->users++;
+	hs->cleanup.func = PgvHnswRelease;
+	hs->cleanup.arg = hs;
+	MemoryContextRegisterResetCallback(CurrentMemoryContext, &hs->cleanup);
+	return hs;
 }
 
 /* GetScanItems (src/hnswscan.c:25-56); `value` is what GetScanValue (:92-114) produced: normalised for cosine */
@@ -312,7 +372,7 @@ List *
 PgvHnswGetScanItems(IndexScanDesc scan, Datum value)
 {
 	HnswScanOpaque so = (HnswScanOpaque) scan->opaque;
-	PgvHnswMirror *m = (PgvHnswMirror *) so->gpu;
+	PgvHnswMirror *m = ((PgvHnswScan *) so->gpu)->mirror;
 	Vector	   *q = (Vector *) PG_DETOAST_DATUM(value);
 	int64		elems[HNSW_MAX_EF_SEARCH];
 	float		dists[HNSW_MAX_EF_SEARCH];

@@ -27,7 +27,11 @@ typedef struct PgvIvfScan
 	IvfflatScanOpaque so;
 	pgv_query  *query;
 	bool		fromPool;		/* the window holds the pooler's head of the current batch */
+	uint64		poolStaged;		/* the staging of the worker's mirror that head came from */
 	bool		ranked;			/* pgv_query_rank has run for the current query */
+	bool		cpuFallback;	/* the scan went back to the reference's code in mid-stream: skip[] holds what it returned */
+	int			nskip;
+	uint64		skip[PGV_POOL_HEAD];
 	MemoryContextCallback cleanup;	/* an ereport(ERROR) longjmps past endscan: free the device state with the context */
 	/* the current batch's sorted stream: `count` tuples, position `next` is returned next */
 	int			batchFirst,
@@ -57,15 +61,21 @@ PgvScanCleanup(void *arg)
 	if (gs->query)
 		pgv_query_end(gs->query);
 	gs->query = NULL;
+	/* the import this scan ran on: unmapped now if a newer staging has replaced it meanwhile */
+	if (gs->mirror)
+		PgvIvfflatReleaseMirror(gs->mirror);
+	gs->mirror = NULL;
 }
 
-/* the own-context path's device state, made when first needed; false: no current mirror */
+/* the own-context path's device state, made when first needed; false: no current mirror (or, with wantStaged, not
+ * that staging any more).  The scan keeps a reference on the import until it ends: a restaging in between gives NEW
+ * scans a new import, this one's pgv_query goes on pointing into the one it began on. */
 static bool
-PgvEnsureOwnContext(PgvIvfScan * gs)
+PgvEnsureOwnContext(PgvIvfScan * gs, uint64 wantStaged)
 {
 	if (gs->query)
-		return true;
-	gs->mirror = PgvIvfflatGetMirror(gs->index);
+		return wantStaged == 0 || gs->mirror->staged == wantStaged;
+	gs->mirror = PgvIvfflatGetMirror(gs->index, wantStaged);
 	if (gs->mirror == NULL)
 		return false;
 	if (pgv_query_begin(gs->mirror->index, &gs->query) != PGV_OK)
@@ -86,7 +96,7 @@ PgvIvfflatBeginScan(Relation index, IvfflatScanOpaque so)
 	gs->so = so;
 	/* pooled scans make their device state only if they outgrow the pooler's head; the others need it now, and a
 	 * scan without a current mirror (first use, stale after inserts, unsupported opclass) runs on the CPU path */
-	if (!vector_gpu_pooled && !PgvEnsureOwnContext(gs))
+	if (!vector_gpu_pooled && !PgvEnsureOwnContext(gs, 0))
 	{
 		pfree(gs);
 		return NULL;
@@ -110,6 +120,8 @@ PgvIvfflatRescan(void *gpu)
 	gs->whole = false;
 	gs->fromPool = false;
 	gs->ranked = false;
+	gs->cpuFallback = false;
+	gs->nskip = 0;
 }
 
 /* float8 ordering of the tuplesort (src/ivfscan.c:238-247): ascending, NaN last; stable on insertion order */
@@ -195,14 +207,50 @@ PgvGetScanItems(PgvIvfScan * gs)
 	gs->whole = false;
 }
 
-/* the pooler's head is used up and the batch holds more: the same batch again on the own-context path */
+/*
+ * A pooled scan cannot go on by itself: its mirror was restaged (an insert or a vacuum in between) or is gone.  What it
+ * has returned so far came from the OLD image; positions in the new one mean something else.  The scan restarts in the
+ * reference's code on the current pages (-1 with so->first set again) and PgvIvfflatAlreadyReturned keeps the tuples
+ * the executor already has from coming out twice.  Never "no more tuples": that would be a truncated result.
+ */
+static int
+PgvFallBackToCpu(PgvIvfScan * gs)
+{
+	int			reached = (int) Min(gs->next, (int64) gs->winCount);
+
+	gs->nskip = 0;
+	for (int i = 0; i < reached && i < PGV_POOL_HEAD; i++)
+		gs->skip[gs->nskip++] = gs->winTid[i];
+	gs->cpuFallback = true;
+	gs->fromPool = false;
+	gs->so->first = true;
+	return -1;
+}
+
+bool
+PgvIvfflatAlreadyReturned(void *gpu, ItemPointer heaptid)
+{
+	PgvIvfScan *gs = (PgvIvfScan *) gpu;
+	uint64		tid;
+
+	if (gs == NULL || !gs->cpuFallback)
+		return false;
+	tid = ((uint64) (((uint32) heaptid->ip_blkid.bi_hi << 16) | heaptid->ip_blkid.bi_lo) << 16) | heaptid->ip_posid;
+	for (int i = 0; i < gs->nskip; i++)
+		if (gs->skip[i] == tid)
+			return true;
+	return false;
+}
+
+/* the pooler's head is used up and the batch holds more: the same batch again on the own-context path -- of the SAME
+ * staging the head came from */
 static bool
 PgvLeavePool(PgvIvfScan * gs, const void *payload)
 {
 	IvfflatScanOpaque so = gs->so;
 	int64		reached = gs->next;
 
-	if (!PgvEnsureOwnContext(gs))
+	if (!PgvEnsureOwnContext(gs, gs->poolStaged))
 		return false;
 	if (pgv_query_rank(gs->query, payload, so->maxProbes) != PGV_OK)
 		ereport(ERROR, (errmsg("pgvector GPU path: %s", pgv_last_error())));
@@ -228,6 +276,8 @@ PgvIvfflatGetTuple(IndexScanDesc scan)
 	 * or a NULL pointer for a NULL query (ZeroDistance, :192-196) */
 	payload = DatumGetPointer(so->value) ? (const void *) ((Vector *) DatumGetPointer(so->value))->x : NULL;
 
+	if (gs->cpuFallback)
+		return -1;				/* the rest of this scan is the reference's */
 	if (so->first)
 	{
 		int			n = Min(so->probes, so->maxProbes);
@@ -235,7 +285,7 @@ PgvIvfflatGetTuple(IndexScanDesc scan)
 
 		gs->fromPool = false;
 		if (vector_gpu_pooled &&
-			PgvPoolSearch(gs->index, payload, n, gs->winDist, gs->winTid, &gs->winCount, &complete))
+			PgvPoolSearch(gs->index, payload, n, gs->winDist, gs->winTid, &gs->winCount, &complete, &gs->poolStaged))
 		{
 			/* GetScanLists + GetScanItems + the head of the sorted stream, answered by the worker's batch */
 			gs->fromPool = true;
@@ -249,10 +299,11 @@ PgvIvfflatGetTuple(IndexScanDesc scan)
 		}
 		else
 		{
-			if (!PgvEnsureOwnContext(gs))
+			if (!PgvEnsureOwnContext(gs, 0))
 			{
 				/* neither the pooler nor a mirror of our own: this scan runs in the reference's code */
-				so->gpu = NULL;
+				gs->cpuFallback = true;
+				gs->nskip = 0;
 				return -1;
 			}
 			/* GetScanLists (:47-118): the maxProbes nearest lists, ranked and kept on the device */
@@ -270,12 +321,12 @@ PgvIvfflatGetTuple(IndexScanDesc scan)
 		if (gs->count > gs->winCount)
 		{
 			if (!PgvLeavePool(gs, payload))
-				return 0;		/* the mirror went stale under the scan: what was returned so far is all */
+				return PgvFallBackToCpu(gs);	/* restaged under the scan: go on in the reference's code, no tuple twice */
 		}
 		else
 		{
-			if (!PgvEnsureOwnContext(gs))
-				return 0;
+			if (!PgvEnsureOwnContext(gs, gs->poolStaged))
+				return PgvFallBackToCpu(gs);
 			if (pgv_query_rank(gs->query, payload, so->maxProbes) != PGV_OK)
 				ereport(ERROR, (errmsg("pgvector GPU path: %s", pgv_last_error())));
 			gs->ranked = true;

@@ -104,16 +104,20 @@ typedef struct PgvPoolSlot
 	Latch	   *latch;			/* the backend's (in shared memory: &MyProc->procLatch) */
 	int			count;			/* results: min(PGV_POOL_HEAD, tuples of the probed lists) */
 	int64		total;			/* tuples of the probed lists */
+	uint64		staged;			/* the staging (generation + 1) of the mirror that answered */
 	float		dist[PGV_POOL_HEAD];
 	uint64		tid[PGV_POOL_HEAD];
 	char		payload[PGV_POOL_ROW_BYTES];
 }			PgvPoolSlot;
+
+#define PGV_WORKER_DEAD_MS 3000	/* a worker whose heartbeat is older than this is gone (it beats every 200 ms at most) */
 
 typedef struct PgvSharedState
 {
 	LWLock	   *lock;
 	Latch	   *workerLatch[PGV_MAX_MIRRORS];	/* per database: index = slot of the first entry of that database */
 	Oid			workerDb[PGV_MAX_MIRRORS];
+	pg_atomic_uint64 workerBeat[PGV_MAX_MIRRORS];	/* GetCurrentTimestamp() of the worker's last loop turn */
 	PgvSharedMirror mirrors[PGV_MAX_MIRRORS];
 	PgvPoolSlot pool[PGV_POOL_SLOTS];
 }			PgvSharedState;
@@ -150,7 +154,10 @@ PgvShmemStartup(void)
 		memset(PgvShared, 0, sizeof(PgvSharedState));
 		PgvShared->lock = &(GetNamedLWLockTranche("pgvector_gpu"))->lock;
 		for (int i = 0; i < PGV_MAX_MIRRORS; i++)
+		{
 			pg_atomic_init_u64(&PgvShared->mirrors[i].generation, 0);
+			pg_atomic_init_u64(&PgvShared->workerBeat[i], 0);
+		}
 		for (int i = 0; i < PGV_POOL_SLOTS; i++)
 			pg_atomic_init_u32(&PgvShared->pool[i].state, PGV_SLOT_FREE);
 	}
@@ -215,8 +222,27 @@ PgvRelcacheCallback(Datum arg, Oid relid)
 	(void) arg;
 	for (PgvIvfMirror * m = mirrors; m != NULL; m = m->next)
 		if (m->relid == relid || relid == 0)
-			m->valid = false;
+			m->valid = false;	/* (an import open scans hold is retired, not unmapped, at the next PgvIvfflatGetMirror) */
 	PgvHnswInvalidate(relid);
+}
+
+static PgvPoolSlot * myPoolSlot = NULL;	/* the slot this backend has claimed and not given back */
+
+/* a backend that exits with a query in the pool (FATAL skips PG_CATCH) gives its slot back: an unclaimed one is free at
+ * once, one the worker holds is freed by the worker (PGV_SLOT_ABANDONED) */
+static void
+PgvReleaseMyPoolSlot(int code, Datum arg)
+{
+	(void) code;
+	(void) arg;
+	if (myPoolSlot != NULL)
+	{
+		uint32		taken = PGV_SLOT_TAKEN;
+
+		if (!pg_atomic_compare_exchange_u32(&myPoolSlot->state, &taken, PGV_SLOT_ABANDONED))
+			pg_atomic_write_u32(&myPoolSlot->state, PGV_SLOT_FREE);
+		myPoolSlot = NULL;
+	}
 }
 
 static void
@@ -247,6 +273,7 @@ PgvGpuInit(void)
 							 &vector_gpu_pooled, false, PGC_USERSET, 0, NULL, NULL, NULL);
 	CacheRegisterRelcacheCallback(PgvRelcacheCallback, (Datum) 0);
 	on_proc_exit(PgvAtExit, (Datum) 0);
+	before_shmem_exit(PgvReleaseMyPoolSlot, (Datum) 0);
 	/* the registry needs shared memory: effective when the library is in shared_preload_libraries; otherwise
 	 * PgvShared stays NULL and every scan stays on the CPU path */
 	if (process_shared_preload_libraries_in_progress)
@@ -480,19 +507,40 @@ PgvWorkerStageEntry(PgvSharedMirror * e)
 	LWLockRelease(PgvShared->lock);
 
 	/* the previous mirror of this index goes once the new handle is out: backends holding an import of it keep
-	 * their mapping (the driver keeps the memory until the last mapping closes) and re-import at their next scan */
-	for (int i = 0; i < PGV_MAX_MIRRORS; i++)
-		if (owned[i].relid == relid || (ok && owned[i].relid == 0))
+	 * their mapping (the driver keeps the memory until the last mapping closes) and re-import at their next scan.
+	 * The index's OWN slot first (a hole in front of it -- a failed staging -- must not take the new mirror and leave
+	 * the stale one behind it), a free slot only when the index has none. */
+	{
+		int			at = -1;
+
+		for (int i = 0; i < PGV_MAX_MIRRORS && at < 0; i++)
+			if (owned[i].relid == relid)
+				at = i;
+		for (int i = 0; ok && i < PGV_MAX_MIRRORS && at < 0; i++)
+			if (owned[i].relid == 0)
+				at = i;
+		if (at >= 0)
 		{
-			if (owned[i].relid == relid && owned[i].index)
-				pgv_index_free(owned[i].index);
-			if (owned[i].relid == relid && owned[i].hnsw)
-				pgv_hnsw_free(owned[i].hnsw);
-			owned[i].relid = ok ? relid : 0;
-			owned[i].index = ok ? fresh : NULL;
-			owned[i].hnsw = ok ? freshHnsw : NULL;
-			break;
+			if (owned[at].relid == relid && owned[at].index)
+				pgv_index_free(owned[at].index);
+			if (owned[at].relid == relid && owned[at].hnsw)
+				pgv_hnsw_free(owned[at].hnsw);
+			owned[at].relid = ok ? relid : 0;
+			owned[at].index = ok ? fresh : NULL;
+			owned[at].hnsw = ok ? freshHnsw : NULL;
 		}
+		else if (ok)
+		{
+			/* more indexes than slots: this one cannot be kept -- and must not be advertised */
+			if (fresh)
+				pgv_index_free(fresh);
+			if (freshHnsw)
+				pgv_hnsw_free(freshHnsw);
+			LWLockAcquire(PgvShared->lock, LW_EXCLUSIVE);
+			e->state = PGV_MIRROR_FAILED;
+			LWLockRelease(PgvShared->lock);
+		}
+	}
 }
 
 /* hand a TAKEN slot back to its backend -- or to the free list when that backend has gone (PGV_SLOT_ABANDONED) */
@@ -525,6 +573,7 @@ PgvWorkerServePool(Oid dboid)
 	pgv_index  *index = NULL;
 	Size		rowBytes = 0;
 	bool		current = false;
+	uint64		staged = 0;
 
 	for (int i = 0; i < PGV_POOL_SLOTS && n < PGV_POOL_MAX_BATCH; i++)
 	{
@@ -552,13 +601,17 @@ PgvWorkerServePool(Oid dboid)
 		if (e && e->state == PGV_MIRROR_READY && e->stagedGeneration == pg_atomic_read_u64(&e->generation))
 		{
 			current = true;
+			staged = e->stagedGeneration + 1;
 			rowBytes = (e->dtype == PGV_F32 ? sizeof(float) : sizeof(uint16)) * (Size) e->dimensions;
 		}
 	}
 	LWLockRelease(PgvShared->lock);
 	for (int i = 0; current && i < PGV_MAX_MIRRORS; i++)
 		if (owned[i].relid == relid)
+		{
 			index = owned[i].index;
+			break;
+		}
 	if (index == NULL || probes < 1 || probes > pgv_index_lists(index))
 	{
 		for (int i = 0; i < n; i++)
@@ -593,9 +646,46 @@ PgvWorkerServePool(Oid dboid)
 		memcpy(slot->tid, tid + (Size) i * PGV_POOL_HEAD, sizeof(uint64) * (Size) count);
 		slot->count = count;
 		slot->total = count < PGV_POOL_HEAD ? count : -1;	/* -1: at least PGV_POOL_HEAD, the exact number unknown */
+		slot->staged = staged;
 		PgvSlotFinish(slot, PGV_SLOT_DONE);
 	}
 	return true;
+}
+
+/*
+ * The worker leaves (ERROR in its loop -- there is no handler round it, so that is FATAL --, SIGTERM, DROP DATABASE):
+ * nobody must think it is still there.  Its registration goes, so that PgvEnsureWorker starts another; the mirrors it
+ * owned die with the process, so the registry forgets them; queries waiting in the pool are told to run elsewhere.
+ */
+static int	workerSlot = -1;
+
+static void
+PgvWorkerExit(int code, Datum arg)
+{
+	Oid			dboid = DatumGetObjectId(arg);
+
+	(void) code;
+	if (PgvShared == NULL || workerSlot < 0)
+		return;
+	LWLockAcquire(PgvShared->lock, LW_EXCLUSIVE);
+	PgvShared->workerLatch[workerSlot] = NULL;
+	PgvShared->workerDb[workerSlot] = 0;
+	pg_atomic_init_u64(&PgvShared->workerBeat[workerSlot], 0);
+	for (int i = 0; i < PGV_MAX_MIRRORS; i++)
+		if (PgvShared->mirrors[i].dboid == dboid && PgvShared->mirrors[i].relid != 0)
+			PgvShared->mirrors[i].state = PGV_MIRROR_EMPTY;
+	LWLockRelease(PgvShared->lock);
+	for (int i = 0; i < PGV_POOL_SLOTS; i++)
+	{
+		PgvPoolSlot *slot = &PgvShared->pool[i];
+		uint32		state = pg_atomic_read_u32(&slot->state);
+
+		if (slot->dboid != dboid || (state != PGV_SLOT_FILLED && state != PGV_SLOT_TAKEN))
+			continue;
+		if (pg_atomic_compare_exchange_u32(&slot->state, &state, PGV_SLOT_UNSERVED))
+			SetLatch(slot->latch);
+	}
+	workerSlot = -1;
 }
 
 /* bgw_main of the per-database worker; bgw_main_arg = the database's oid */
@@ -611,20 +701,32 @@ PgvWorkerMain(Datum main_arg)
 	for (int i = 0; i < PGV_MAX_MIRRORS && slot < 0; i++)
 		if (PgvShared->workerDb[i] == dboid || PgvShared->workerDb[i] == 0)
 			slot = i;
+	if (slot >= 0 && PgvShared->workerDb[slot] == dboid && PgvShared->workerLatch[slot] != NULL)
+	{
+		/* two backends asked for a worker at the same moment: the first one to get here serves, this one leaves */
+		uint64		beat = pg_atomic_read_u64(&PgvShared->workerBeat[slot]);
+
+		if (beat != 0 && !TimestampDifferenceExceeds((TimestampTz) beat, GetCurrentTimestamp(), PGV_WORKER_DEAD_MS))
+			slot = -1;
+	}
 	if (slot >= 0)
 	{
 		PgvShared->workerDb[slot] = dboid;
 		PgvShared->workerLatch[slot] = MyLatch;
+		pg_atomic_init_u64(&PgvShared->workerBeat[slot], (uint64) GetCurrentTimestamp());
 	}
 	LWLockRelease(PgvShared->lock);
 	if (slot < 0)
 		proc_exit(0);
+	workerSlot = slot;
+	before_shmem_exit(PgvWorkerExit, main_arg);
 
 	for (;;)
 	{
 		PgvSharedMirror *todo = NULL;
 
 		CHECK_FOR_INTERRUPTS();
+		pg_atomic_init_u64(&PgvShared->workerBeat[slot], (uint64) GetCurrentTimestamp());
 		LWLockAcquire(PgvShared->lock, LW_EXCLUSIVE);
 		for (int i = 0; i < PGV_MAX_MIRRORS && todo == NULL; i++)
 		{
@@ -651,24 +753,55 @@ PgvWorkerMain(Datum main_arg)
 	}
 }
 
-/* start the worker of this database unless one is registered already */
-static void
+/* is the registered worker of this database alive?  A worker that was killed (no exit hook ran) stops beating. */
+static bool
+PgvWorkerAlive(int slot)
+{
+	uint64		beat = pg_atomic_read_u64(&PgvShared->workerBeat[slot]);
+
+	return beat != 0 && !TimestampDifferenceExceeds((TimestampTz) beat, GetCurrentTimestamp(), PGV_WORKER_DEAD_MS);
+}
+
+/* start the worker of this database unless one is registered and alive; returns whether one is there to be woken */
+static bool
 PgvEnsureWorker(void)
 {
 	BackgroundWorker worker;
 	BackgroundWorkerHandle *handle;
 	bool		running = false;
+	int			dead = -1;
 
 	LWLockAcquire(PgvShared->lock, LW_SHARED);
 	for (int i = 0; i < PGV_MAX_MIRRORS; i++)
 		if (PgvShared->workerDb[i] == MyDatabaseId && PgvShared->workerLatch[i] != NULL)
 		{
-			SetLatch(PgvShared->workerLatch[i]);
-			running = true;
+			if (PgvWorkerAlive(i))
+			{
+				SetLatch(PgvShared->workerLatch[i]);
+				running = true;
+			}
+			else
+				dead = i;
 		}
 	LWLockRelease(PgvShared->lock);
 	if (running)
-		return;
+		return true;
+	if (dead >= 0)
+	{
+		/* it went without saying goodbye (SIGKILL, a crash): what PgvWorkerExit would have done */
+		LWLockAcquire(PgvShared->lock, LW_EXCLUSIVE);
+		if (PgvShared->workerDb[dead] == MyDatabaseId && !PgvWorkerAlive(dead))
+		{
+			PgvShared->workerLatch[dead] = NULL;
+			PgvShared->workerDb[dead] = 0;
+			pg_atomic_init_u64(&PgvShared->workerBeat[dead], 0);
+			for (int i = 0; i < PGV_MAX_MIRRORS; i++)
+				if (PgvShared->mirrors[i].dboid == MyDatabaseId && PgvShared->mirrors[i].relid != 0 &&
+					PgvShared->mirrors[i].state != PGV_MIRROR_REQUESTED)
+					PgvShared->mirrors[i].state = PGV_MIRROR_EMPTY;
+		}
+		LWLockRelease(PgvShared->lock);
+	}
 	memset(&worker, 0, sizeof(worker));
 	worker.bgw_flags = BGWORKER_SHMEM_ACCESS | BGWORKER_BACKEND_DATABASE_CONNECTION;
 	worker.bgw_start_time = BgWorkerStart_RecoveryFinished;
@@ -680,6 +813,20 @@ PgvEnsureWorker(void)
 	worker.bgw_main_arg = ObjectIdGetDatum(MyDatabaseId);
 	worker.bgw_notify_pid = 0;
 	(void) RegisterDynamicBackgroundWorker(&worker, &handle);
+	return false;
+}
+
+/* a worker of this database is registered and beating */
+static bool
+PgvWorkerIsThere(void)
+{
+	bool		there = false;
+
+	LWLockAcquire(PgvShared->lock, LW_SHARED);
+	for (int i = 0; i < PGV_MAX_MIRRORS && !there; i++)
+		there = PgvShared->workerDb[i] == MyDatabaseId && PgvShared->workerLatch[i] != NULL && PgvWorkerAlive(i);
+	LWLockRelease(PgvShared->lock);
+	return there;
 }
 
 /* ------------------------------------------------------------------ the backend's side */
@@ -769,8 +916,35 @@ PgvIvfflatMirrorIsCurrent(Relation index)
 	return PgvMirrorReady(index, &handle, &staged);
 }
 
+/* unmap an import nobody uses any more and take it off the list */
+static void
+PgvDropMirror(PgvIvfMirror * m)
+{
+	PgvIvfMirror **link = &mirrors;
+
+	if (m->index)
+		pgv_index_free(m->index);
+	m->index = NULL;
+	while (*link != NULL && *link != m)
+		link = &(*link)->next;
+	if (*link == m)
+		*link = m->next;
+	pfree(m);
+}
+
+void
+PgvIvfflatReleaseMirror(PgvIvfMirror * mirror)
+{
+	if (mirror == NULL)
+		return;
+	mirror->users--;
+	/* the last scan on a staging that has been replaced meanwhile: its mapping goes now */
+	if (mirror->users <= 0 && mirror->retired)
+		PgvDropMirror(mirror);
+}
+
 PgvIvfMirror *
-PgvIvfflatGetMirror(Relation index)
+PgvIvfflatGetMirror(Relation index, uint64 wantStaged)
 {
 	PgvIvfMirror *m;
 	pgv_index_handle handle;
@@ -782,13 +956,38 @@ PgvIvfflatGetMirror(Relation index)
 
 	if (PgvShared == NULL || !PgvIvfflatOpclass(index, &metric, &dtype, &ops))
 		return NULL;
+	/* a staging this backend still holds (an open scan's) serves a scan that must stay on it */
+	if (wantStaged != 0)
+		for (m = mirrors; m != NULL; m = m->next)
+			if (m->relid == RelationGetRelid(index) && m->index != NULL && m->staged == wantStaged)
+			{
+				m->users++;
+				return m;
+			}
 	ready = PgvMirrorReady(index, &handle, &staged);
-	if (!ready)
+	if (!ready || (wantStaged != 0 && staged != wantStaged))
 		return NULL;
 
 	for (m = mirrors; m != NULL; m = m->next)
-		if (m->relid == RelationGetRelid(index))
+		if (m->relid == RelationGetRelid(index) && !m->retired)
 			break;
+	if (m != NULL && (!m->valid || m->staged != staged))
+	{
+		/* a newer staging.  Open scans of this backend (a cursor, a PL/pgSQL loop's outer query) keep the import they
+		 * started on -- their pgv_query points into it --; it is unmapped when the last of them ends */
+		if (m->users > 0)
+		{
+			m->retired = true;
+			m = NULL;
+		}
+		else
+		{
+			if (m->index)
+				pgv_index_free(m->index);
+			m->index = NULL;
+			m->valid = false;
+		}
+	}
 	if (m == NULL)
 	{
 		m = MemoryContextAllocZero(TopMemoryContext, sizeof(PgvIvfMirror));
@@ -796,14 +995,24 @@ PgvIvfflatGetMirror(Relation index)
 		m->next = mirrors;
 		mirrors = m;
 	}
-	if (!m->valid || m->staged != staged)
+	if (!m->valid)
 	{
-		if (m->index)
-			pgv_index_free(m->index);
-		m->index = NULL;
-		m->valid = false;
 		if (pgv_index_import(PgvGetContext(), &handle, &m->index) != PGV_OK)
-			ereport(ERROR, (errmsg("pgvector GPU path: %s", pgv_last_error())));
+		{
+			/* the exporter is gone (a worker that died takes its allocations with it): not this query's error.  The
+			 * registry forgets the staging, the next request has it staged again; this scan runs on the CPU path. */
+			PgvSharedMirror *e;
+
+			elog(LOG, "pgvector GPU path: mirror of index %u cannot be imported (%s): restaging", RelationGetRelid(index),
+				 pgv_last_error());
+			m->index = NULL;
+			LWLockAcquire(PgvShared->lock, LW_EXCLUSIVE);
+			e = PgvFindEntry(RelationGetRelid(index), false);
+			if (e && e->state == PGV_MIRROR_READY && e->stagedGeneration + 1 == staged)
+				e->state = PGV_MIRROR_EMPTY;
+			LWLockRelease(PgvShared->lock);
+			return NULL;
+		}
 		IvfflatGetMetaPageInfo(index, &m->lists, &m->dimensions);
 		m->metric = metric;
 		m->dtype = dtype;
@@ -811,6 +1020,7 @@ PgvIvfflatGetMirror(Relation index)
 		m->staged = staged;
 		m->valid = true;
 	}
+	m->users++;
 	return m;
 }
 
@@ -820,7 +1030,8 @@ PgvIvfflatGetMirror(Relation index)
  * the caller runs this scan on its own context or on the reference's path.
  */
 bool
-PgvPoolSearch(Relation index, const void *payload, int probes, float *outDist, uint64 *outTid, int *outCount, bool *outComplete)
+PgvPoolSearch(Relation index, const void *payload, int probes, float *outDist, uint64 *outTid, int *outCount, bool *outComplete,
+			  uint64 *outStaged)
 {
 	PgvPoolSlot *slot = NULL;
 	pgv_metric	metric;
@@ -830,6 +1041,7 @@ PgvPoolSearch(Relation index, const void *payload, int probes, float *outDist, u
 				dimensions;
 	Size		rowBytes;
 	uint32		state;
+	volatile bool abandoned = false;
 
 	if (PgvShared == NULL || payload == NULL || !PgvIvfflatOpclass(index, &metric, &dtype, &ops))
 		return false;
@@ -858,6 +1070,7 @@ PgvPoolSearch(Relation index, const void *payload, int probes, float *outDist, u
 	slot->nullQuery = 0;
 	slot->latch = MyLatch;
 	memcpy(slot->payload, payload, rowBytes);
+	myPoolSlot = slot;
 	pg_atomic_write_u32(&slot->state, PGV_SLOT_FILLED);
 	PgvEnsureWorker();			/* sets the worker's latch */
 	PG_TRY();
@@ -867,9 +1080,35 @@ PgvPoolSearch(Relation index, const void *payload, int probes, float *outDist, u
 			state = pg_atomic_read_u32(&slot->state);
 			if (state == PGV_SLOT_DONE || state == PGV_SLOT_UNSERVED)
 				break;
-			(void) WaitLatch(MyLatch, WL_LATCH_SET | WL_TIMEOUT | WL_EXIT_ON_PM_DEATH, 1000L, PG_WAIT_EXTENSION);
+			(void) WaitLatch(MyLatch, WL_LATCH_SET | WL_TIMEOUT | WL_EXIT_ON_PM_DEATH, 200L, PG_WAIT_EXTENSION);
 			ResetLatch(MyLatch);
 			CHECK_FOR_INTERRUPTS();
+			/* the worker may have died without a word (its exit hook tells us when it can): a query must not wait
+			 * for an answer nobody will give.  Take the slot back -- or leave it to a worker that holds it after all --
+			 * and scan for ourselves. */
+			if (!PgvWorkerIsThere())
+			{
+				uint32		filled = PGV_SLOT_FILLED;
+
+				state = pg_atomic_read_u32(&slot->state);
+				if (state == PGV_SLOT_DONE || state == PGV_SLOT_UNSERVED)
+					break;
+				if (!pg_atomic_compare_exchange_u32(&slot->state, &filled, PGV_SLOT_UNSERVED))
+				{
+					uint32		taken = PGV_SLOT_TAKEN;
+
+					if (pg_atomic_compare_exchange_u32(&slot->state, &taken, PGV_SLOT_ABANDONED))
+					{
+						/* (no return out of a PG_TRY block.)  A TAKEN slot is the dead worker's to free: nobody will
+						 * -- one slot of 256 */
+						abandoned = true;
+						break;
+					}
+				}
+				state = pg_atomic_read_u32(&slot->state);
+				if (state == PGV_SLOT_DONE || state == PGV_SLOT_UNSERVED)
+					break;
+			}
 		}
 	}
 	PG_CATCH();
@@ -885,16 +1124,24 @@ PgvPoolSearch(Relation index, const void *payload, int probes, float *outDist, u
 			if (!pg_atomic_compare_exchange_u32(&slot->state, &taken, PGV_SLOT_ABANDONED))
 				pg_atomic_write_u32(&slot->state, PGV_SLOT_FREE);	/* DONE / UNSERVED already */
 		}
+		myPoolSlot = NULL;
 		PG_RE_THROW();
 	}
 	PG_END_TRY();
+	if (abandoned)
+	{
+		myPoolSlot = NULL;
+		return false;
+	}
 	if (state == PGV_SLOT_DONE)
 	{
 		*outCount = slot->count;
 		*outComplete = slot->total >= 0;
+		*outStaged = slot->staged;
 		memcpy(outDist, slot->dist, sizeof(float) * (Size) slot->count);
 		memcpy(outTid, slot->tid, sizeof(uint64) * (Size) slot->count);
 	}
+	myPoolSlot = NULL;
 	pg_atomic_write_u32(&slot->state, PGV_SLOT_FREE);
 	return state == PGV_SLOT_DONE;
 }

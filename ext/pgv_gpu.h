@@ -12,10 +12,14 @@
  *   ivfflatbeginscan    src/ivfscan.c:252-317   so->gpu = PgvIvfflatBeginScan(index, so);
  *   ivfflatrescan       src/ivfscan.c:322-356   PgvIvfflatRescan(so->gpu);
  *   ivfflatgettuple     src/ivfscan.c:361-414   if (so->gpu) { int r = PgvIvfflatGetTuple(scan); if (r >= 0) return r != 0; }
- *                                               (-1, before the first tuple only: this scan goes on in the reference's code)
+ *                                               (-1: this scan goes on in the reference's code -- from its first tuple)
+ *                       src/ivfscan.c:408-413   if (so->gpu && PgvIvfflatAlreadyReturned(so->gpu, heaptid)) continue;
+ *                                               (in a loop round the tuplesort pull: a pooled scan whose mirror was restaged
+ *                                               under it restarts on the CPU path and must not return a tuple twice)
  *   ivfflatendscan      src/ivfscan.c:419-431   PgvIvfflatEndScan(so->gpu);
  *   hnswbeginscan       src/hnswscan.c:121-146  so->gpu = PgvHnswBeginScan(index);
  *   hnswgettuple        src/hnswscan.c:228      so->w = so->gpu ? PgvHnswGetScanItems(scan, value) : GetScanItems(scan, value);
+ *   hnswendscan         src/hnswscan.c:337-349  PgvHnswEndScan(so->gpu);
  *   IvfflatKmeans       src/ivfkmeans.c:553-570 if (PgvIvfflatKmeans(index, samples, centers, typeInfo)) return;
  *   BuildCallback       src/ivfbuild.c:224-266  if (buildstate->gpu) { PgvIvfflatBuildAdd(buildstate, tid, value); return; }
  *   AssignTuples        src/ivfbuild.c:600-636  PgvIvfflatBuildFlush(buildstate) after the heap scan
@@ -60,11 +64,18 @@ typedef struct PgvIvfMirror
 	pgv_dtype	dtype;
 	pgv_metric	metric;
 	int64		ntuples;
+	int			users;			/* open scans holding this import: it is unmapped when the last one lets go */
+	bool		retired;		/* a newer staging has replaced it for new scans */
 	struct PgvIvfMirror *next;
 }			PgvIvfMirror;
 
-/* NULL: no current mirror (being staged, stale, unsupported opclass) -- the scan stays on the CPU path */
-PgvIvfMirror *PgvIvfflatGetMirror(Relation index);
+/*
+ * The current mirror with a reference taken for the caller (PgvIvfflatReleaseMirror when the scan ends), or NULL: no
+ * current mirror (being staged, stale, unsupported opclass) -- the scan stays on the CPU path.  wantStaged != 0 asks for
+ * exactly that staging (a pooled scan going on by itself must continue on the image its head came from).
+ */
+PgvIvfMirror *PgvIvfflatGetMirror(Relation index, uint64 wantStaged);
+void		PgvIvfflatReleaseMirror(PgvIvfMirror * mirror);
 /* the worker holds a current mirror of the index (a staging is requested otherwise) */
 bool		PgvIvfflatMirrorIsCurrent(Relation index);
 /*
@@ -73,7 +84,7 @@ bool		PgvIvfflatMirrorIsCurrent(Relation index);
  */
 #define PGV_POOL_HEAD 64
 bool		PgvPoolSearch(Relation index, const void *payload, int probes, float *outDist, uint64 *outTid, int *outCount,
-						  bool *outComplete);
+						  bool *outComplete, uint64 *outStaged);
 /* insert / vacuum / build changed the index's pages: mirrors staged before now are stale */
 void		PgvNoteIndexChange(Relation index);
 /* bgw_main of the per-database worker that owns the mirrors */
@@ -83,6 +94,7 @@ void		PgvWorkerMain(Datum main_arg);
 void	   *PgvIvfflatBeginScan(Relation index, IvfflatScanOpaque so);
 void		PgvIvfflatRescan(void *gpu);
 int			PgvIvfflatGetTuple(IndexScanDesc scan);	/* 1 a tuple, 0 no more, -1 not served: the reference's path */
+bool		PgvIvfflatAlreadyReturned(void *gpu, ItemPointer heaptid);	/* after a -1 in mid-scan: skip what the GPU path gave out */
 void		PgvIvfflatEndScan(void *gpu);
 
 /* registry kinds (pgv_context.c) */
@@ -97,6 +109,7 @@ bool		PgvHnswMirrorHandle(Relation index, pgv_index_handle * handle, uint64 *sta
 /* HNSW scan side (hnswscan_gpu.c); List as in nodes/pg_list.h */
 void	   *PgvHnswBeginScan(Relation index);
 List	   *PgvHnswGetScanItems(IndexScanDesc scan, Datum value);
+void		PgvHnswEndScan(void *gpu);
 void		PgvHnswInvalidate(Oid relid);
 /* vector / halfvec element type of an hnsw opclass; false for bit and sparsevec opclasses (CPU path) */
 bool		PgvHnswElementType(Relation index, pgv_dtype * dtype);

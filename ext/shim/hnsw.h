@@ -107,7 +107,7 @@ typedef struct HnswScanOpaqueData
 	int			m;
 	int64		tuples;
 	HnswSupport support;
-	void	   *gpu;			/* added: PgvHnswMirror of ext/hnswscan_gpu.c, NULL when the scan stays on the CPU */
+	void	   *gpu;			/* added: PgvHnswScan of ext/hnswscan_gpu.c, NULL when the scan stays on the CPU */
 }			HnswScanOpaqueData;
 typedef HnswScanOpaqueData *HnswScanOpaque;
 

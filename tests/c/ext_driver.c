@@ -1,0 +1,1259 @@
+/*
+ * ext_driver.c -- the glue of ext/ (what a maintainer pastes into pgvector's src/) EXECUTED: a postmaster, backends
+ * and the "pgvector gpu" background worker as real processes over the stand-in server of pgshim_runtime.c, on the
+ * real library (tests/test_ext_runtime_gpu.py) or on tests/c/mock_hip.c (tests/test_ext_runtime_cpu.py).
+ *
+ *   build     IvfflatKmeans + BuildCallback + AssignTuples through PgvIvfflatKmeans / BuildAdd / BuildFlush, heap
+ *             values arriving plain and toasted-style, the caller's memory poisoned after every row (src/ivfbuild.c:238-249)
+ *   scans     ivfflatbeginscan / rescan / gettuple / endscan through the hooks: own-context and pooled, heads, deep
+ *             pulls (device windows, whole-batch fetch), iterative scans, NULL queries, an ERROR in mid-scan (device
+ *             state must go with the memory context), cancel while waiting for the pooler
+ *   mirrors   staged by the worker through the buffer manager, imported by backends; insert -> stale -> CPU path ->
+ *             restaged; an open scan keeps the import it began on (use-after-free); a pooled scan whose
+ *             mirror is restaged under it restarts on the CPU path without returning a tuple twice
+ *   worker    killed without a word (heartbeat), ended politely (exit hook): backends never hang, a new one starts
+ *   hnsw      PgvHnswStage / BeginScan / GetScanItems against the oracle's walk of the same graph
+ *
+ * Expected answers: the oracle walking the very same pages (ora_pages_search), tie-tolerant.  TEST INFRASTRUCTURE.
+ * Prints "EXT-RUNTIME OK" and exits 0 when every scenario passed.
+ */
+#define _GNU_SOURCE
+#include <math.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include <sys/mman.h>
+#include <unistd.h>
+
+#include "pgv_gpu.h"
+#include "hnsw.h"
+#include "pgshim_runtime.h"
+
+#include "pgv_host.h"
+#include "pgv_oracle.h"
+
+void		mock_hip_set_arena(void *base, size_t bytes) __attribute__((weak));
+int			mock_hip_live_queries(void) __attribute__((weak));
+
+#define EXPECT(cond) do { if (!(cond)) { fprintf(stderr, "%s:%d: [%s] EXPECT(%s) failed\n", __FILE__, __LINE__, scenario, #cond); return 1; } } while (0)
+static const char *scenario = "setup";
+
+#define REL_IVF 1001
+#define REL_BATCH 1002
+#define REL_HNSW 2001
+#define DIM 32
+#define NROWS 20000
+#define LISTS 20
+#define PROBES 3
+
+/* what the processes of one run tell each other (a mapping of the driver's own, made before any fork) */
+typedef struct Board
+{
+	volatile int step;			/* scenario-specific hand-shakes */
+	volatile int ack;
+	volatile uint64 new_tid;
+	float		new_row[DIM];
+}			Board;
+static Board * board;
+
+/* ------------------------------------------------------------------------------------------------ data */
+static uint64 lcg = 99;
+static double
+urand(void)
+{
+	lcg = lcg * 6364136223846793005ull + 1442695040888963407ull;
+	return (double) (lcg >> 11) / 9007199254740992.0;
+}
+
+static float
+gauss(void)
+{
+	double		u = urand() + 1e-12,
+				v = urand();
+
+	return (float) (sqrt(-2.0 * log(u)) * cos(6.283185307179586 * v));
+}
+
+/* clustered rows: LISTS centers in [0,1)^dim, sigma 0.05 */
+static void
+gen_rows(float *out, int n, int dim, uint64 seed)
+{
+	float	   *centers = malloc(sizeof(float) * LISTS * dim);
+
+	lcg = 4242;
+	for (int i = 0; i < LISTS * dim; i++)
+		centers[i] = (float) urand();
+	lcg = seed;
+	for (int r = 0; r < n; r++)
+	{
+		int			c = (int) (urand() * LISTS) % LISTS;
+
+		for (int d = 0; d < dim; d++)
+			out[(size_t) r * dim + d] = centers[c * dim + d] + 0.05f * gauss();
+	}
+	free(centers);
+}
+
+static uint64
+tid_of_row(int r)
+{
+	return ((uint64) (r / 50 + 1) << 16) | (uint64) (r % 50 + 1);	/* 50 heap tuples per heap page */
+}
+
+static ItemPointerData
+itemptr(uint64 tid)
+{
+	ItemPointerData p;
+
+	p.ip_blkid.bi_hi = (uint16) (tid >> 32);
+	p.ip_blkid.bi_lo = (uint16) (tid >> 16);
+	p.ip_posid = (OffsetNumber) (tid & 0xffff);
+	return p;
+}
+
+static uint64
+tid_key(const ItemPointerData *p)
+{
+	return ((uint64) (((uint32) p->ip_blkid.bi_hi << 16) | p->ip_blkid.bi_lo) << 16) | p->ip_posid;
+}
+
+/* a Vector varlena in the current memory context */
+static Vector *
+make_vector(const float *x, int dim)
+{
+	Size		size = offsetof(Vector, x) + sizeof(float) * (Size) dim;
+	Vector	   *v = palloc0(size);
+
+	v->vl_len_ = (int32) (size << 2);
+	v->dim = (int16) dim;
+	memcpy(v->x, x, sizeof(float) * (Size) dim);
+	return v;
+}
+
+/* the runtime's stand-in for a toasted (compressed) heap value: header with the "compressed" bits, raw size, payload */
+static Datum
+make_toasted(const Vector *v)
+{
+	Size		raw = ((uint32) v->vl_len_ >> 2) - 4;
+	char	   *t = palloc(8 + raw);
+	uint32		hdr = (uint32) ((8 + raw) << 2) | 0x02;
+	uint32		rawsz = (uint32) raw;
+
+	memcpy(t, &hdr, 4);
+	memcpy(t + 4, &rawsz, 4);
+	memcpy(t + 8, (const char *) v + 4, raw);
+	return PointerGetDatum(t);
+}
+
+/* ------------------------------------------------------------------------------------------------ oracle answers */
+typedef struct Expected
+{
+	int			n;
+	uint64	   *tids;
+	double	   *dist;
+	uint64	   *sorted_tids;	/* for lookups */
+	double	   *sorted_dist;
+}			Expected;
+
+static int
+cmp_u64_pair(const void *a, const void *b)
+{
+	uint64		x = *(const uint64 *) a,
+				y = *(const uint64 *) b;
+
+	return x < y ? -1 : (x > y ? 1 : 0);
+}
+
+/* every tuple of the `probes` nearest lists, ascending by distance (ivfflatgettuple's whole first batch) */
+static Expected
+expected_batch(Oid relid, const float *query, int probes)
+{
+	Expected	e;
+	uint32_t	nblocks;
+	const uint8_t *pages = shim_relation_pages(relid, &nblocks);
+	int			cap = 1 << 20;
+	int64_t		scanned = 0;
+	struct
+	{
+		uint64		t;
+		double		d;
+	}		   *pairs;
+
+	e.tids = malloc(sizeof(uint64) * (size_t) cap);
+	e.dist = malloc(sizeof(double) * (size_t) cap);
+	e.n = ora_pages_search(pages, nblocks, ORA_OPS_L2, ORA_F32, query, probes, cap, e.tids, e.dist, &scanned);
+	pairs = malloc(sizeof(*pairs) * (size_t) (e.n > 0 ? e.n : 1));
+	for (int i = 0; i < e.n; i++)
+	{
+		pairs[i].t = e.tids[i];
+		pairs[i].d = e.dist[i];
+	}
+	qsort(pairs, (size_t) e.n, sizeof(*pairs), cmp_u64_pair);
+	e.sorted_tids = malloc(sizeof(uint64) * (size_t) (e.n > 0 ? e.n : 1));
+	e.sorted_dist = malloc(sizeof(double) * (size_t) (e.n > 0 ? e.n : 1));
+	for (int i = 0; i < e.n; i++)
+	{
+		e.sorted_tids[i] = pairs[i].t;
+		e.sorted_dist[i] = pairs[i].d;
+	}
+	free(pairs);
+	return e;
+}
+
+static void
+expected_free(Expected * e)
+{
+	free(e->tids);
+	free(e->dist);
+	free(e->sorted_tids);
+	free(e->sorted_dist);
+}
+
+static int
+expected_lookup(const Expected * e, uint64 tid, double *dist)
+{
+	int			lo = 0,
+				hi = e->n - 1;
+
+	while (lo <= hi)
+	{
+		int			mid = (lo + hi) / 2;
+
+		if (e->sorted_tids[mid] == tid)
+		{
+			*dist = e->sorted_dist[mid];
+			return 1;
+		}
+		if (e->sorted_tids[mid] < tid)
+			lo = mid + 1;
+		else
+			hi = mid - 1;
+	}
+	return 0;
+}
+
+/* got[0..n) must be the head of e's stream: distinct tuples of the probed lists whose distances are e's, position by
+ * position, within the float tolerance (ties may come in either order) */
+static int
+check_stream(const Expected * e, const uint64 *got, int n, int offset, const char *what)
+{
+	for (int i = 0; i < n; i++)
+	{
+		double		d;
+
+		if (offset + i >= e->n || !expected_lookup(e, got[i], &d))
+		{
+			fprintf(stderr, "[%s] %s: tuple %d (tid %llx) is not in the probed lists (expected %d tuples)\n", scenario, what, offset + i,
+					(unsigned long long) got[i], e->n);
+			return 1;
+		}
+		if (fabs(d - e->dist[offset + i]) > 1e-4 * fabs(e->dist[offset + i]) + 1e-6)
+		{
+			fprintf(stderr, "[%s] %s: position %d: distance %.9g, the reference's stream has %.9g there\n", scenario, what, offset + i, d,
+					e->dist[offset + i]);
+			return 1;
+		}
+		for (int j = 0; j < i; j++)
+			if (got[j] == got[i])
+			{
+				fprintf(stderr, "[%s] %s: tid %llx returned twice (positions %d and %d)\n", scenario, what, (unsigned long long) got[i], j, i);
+				return 1;
+			}
+	}
+	return 0;
+}
+
+/* ------------------------------------------------------------------------------------------------ the AM's scan, emulated */
+typedef struct Scan
+{
+	IndexScanDescData desc;
+	IvfflatScanOpaqueData so;
+	ScanKeyData orderby;
+	MemoryContext ctx;
+	/* the reference's own path, stood in for by the oracle over the current pages */
+	Expected	cpu;
+	bool		cpu_open;
+	int			cpu_next;
+	float		query[DIM];
+	int			gpu_tuples,
+				cpu_tuples;
+}			Scan;
+
+/* ivfflatbeginscan (src/ivfscan.c:252-317) + ivfflatrescan with a query */
+static void
+scan_begin(Scan * s, Relation index, const float *query, int probes, int max_probes)
+{
+	memset(s, 0, sizeof(*s));
+	s->ctx = shim_query_context_begin();
+	s->desc.indexRelation = index;
+	s->desc.numberOfOrderBys = 1;
+	s->desc.orderByData = &s->orderby;
+	s->desc.opaque = &s->so;
+	s->so.probes = probes;
+	s->so.maxProbes = max_probes;
+	s->so.dimensions = DIM;
+	s->so.first = true;
+	if (query)
+	{
+		memcpy(s->query, query, sizeof(float) * DIM);
+		s->so.value = PointerGetDatum(make_vector(query, DIM));	/* GetScanValue stays in the reference's file */
+	}
+	else
+		s->so.value = PointerGetDatum(NULL);
+	s->so.gpu = PgvIvfflatBeginScan(index, &s->so);
+	PgvIvfflatRescan(s->so.gpu);
+}
+
+/* ivfflatgettuple (src/ivfscan.c:361-414) with the two hook lines of ext/pgv_gpu.h */
+static bool
+scan_gettuple(Scan * s)
+{
+	if (s->so.gpu)
+	{
+		int			r = PgvIvfflatGetTuple(&s->desc);
+
+		if (r >= 0)
+		{
+			s->gpu_tuples += r;
+			return r != 0;
+		}
+	}
+	/* the reference's code: first batch only (what the oracle restates over the pages) */
+	if (s->so.first)
+	{
+		s->cpu = expected_batch(RelationGetRelid(s->desc.indexRelation), s->query, s->so.probes);
+		s->cpu_open = true;
+		s->cpu_next = 0;
+		s->so.first = false;
+	}
+	for (;;)
+	{
+		ItemPointerData heaptid;
+
+		if (s->cpu_next >= s->cpu.n)
+			return false;
+		heaptid = itemptr(s->cpu.tids[s->cpu_next++]);
+		if (s->so.gpu && PgvIvfflatAlreadyReturned(s->so.gpu, &heaptid))
+			continue;
+		s->desc.xs_heaptid = heaptid;
+		s->cpu_tuples++;
+		return true;
+	}
+}
+
+static void
+scan_end(Scan * s)
+{
+	PgvIvfflatEndScan(s->so.gpu);
+	if (s->cpu_open)
+		expected_free(&s->cpu);
+	shim_query_context_end(s->ctx);
+}
+
+static void
+make_query(float *q, int i)
+{
+	float		tmp[DIM * 4];
+
+	gen_rows(tmp, 4, DIM, 777 + (uint64) i * 13);
+	memcpy(q, tmp + DIM * (i % 4), sizeof(float) * DIM);
+}
+
+/* ------------------------------------------------------------------------------------------------ CREATE INDEX, emulated */
+typedef struct Sorted
+{
+	int			n,
+				cap;
+	int32	   *list;
+	uint64	   *tid;
+	float	   *rows;
+	int			dim;
+}			Sorted;
+static Sorted sorted;
+
+/* the tuplesort feed of AddTupleToSort (src/ivfbuild.c:203-216): the reference's file keeps it; here it collects */
+void
+IvfflatAddToSort(IvfflatBuildState * buildstate, int list, ItemPointer tid, Datum value)
+{
+	Vector	   *v = (Vector *) DatumGetPointer(value);
+
+	(void) buildstate;
+	if (sorted.n == sorted.cap)
+	{
+		sorted.cap = sorted.cap ? sorted.cap * 2 : 4096;
+		sorted.list = realloc(sorted.list, sizeof(int32) * (size_t) sorted.cap);
+		sorted.tid = realloc(sorted.tid, sizeof(uint64) * (size_t) sorted.cap);
+		sorted.rows = realloc(sorted.rows, sizeof(float) * (size_t) sorted.cap * (size_t) sorted.dim);
+	}
+	sorted.list[sorted.n] = list;
+	sorted.tid[sorted.n] = tid_key(tid);
+	memcpy(sorted.rows + (size_t) sorted.n * sorted.dim, v->x, sizeof(float) * (size_t) sorted.dim);
+	sorted.n++;
+}
+
+/* ivfflatbuild's GPU-relevant skeleton: samples -> IvfflatKmeans -> heap scan with BuildCallback -> sort by list ->
+ * pages (src/ivfbuild.c:1008-1070) */
+static int
+build_index(Oid relid, const float *rows, int n, int dim, int lists, int toast_every)
+{
+	Relation	index = shim_open_relation(relid);
+	IvfflatBuildState bs;
+	VectorArrayData samples,
+				centers;
+	Size		itemsize = offsetof(Vector, x) + sizeof(float) * (Size) dim;
+	int			nsamples = n < 50 * lists ? n : 50 * lists;
+	MemoryContext tmp;
+	int64_t    *offsets;
+	float	   *packed_centers;
+	pgv_rel		rel;
+	int		   *order;
+
+	EXPECT(index != NULL);
+	memset(&bs, 0, sizeof(bs));
+	bs.index = index;
+	bs.typeInfo = IvfflatGetTypeInfo(index);
+	bs.dimensions = dim;
+	bs.lists = lists;
+	samples.length = nsamples;
+	samples.maxlen = nsamples;
+	samples.dim = dim;
+	samples.itemsize = itemsize;
+	samples.items = palloc0(itemsize * (Size) nsamples);
+	for (int i = 0; i < nsamples; i++)
+	{
+		Vector	   *v = (Vector *) VectorArrayGet(&samples, i);
+		int			r = (int) (((int64) i * n) / nsamples);
+
+		v->vl_len_ = (int32) (itemsize << 2);
+		v->dim = (int16) dim;
+		memcpy(v->x, rows + (size_t) r * dim, sizeof(float) * (Size) dim);
+	}
+	centers.length = 0;
+	centers.maxlen = lists;
+	centers.dim = dim;
+	centers.itemsize = itemsize;
+	centers.items = palloc0(itemsize * (Size) lists);
+	bs.samples = &samples;
+	bs.centers = &centers;
+	EXPECT(PgvIvfflatKmeans(index, &samples, &centers, bs.typeInfo));
+	EXPECT(centers.length == lists);
+
+	sorted.n = 0;
+	sorted.dim = dim;
+	PgvIvfflatBuildBegin(&bs);
+	EXPECT(bs.gpu != NULL);
+	/* BuildCallback (src/ivfbuild.c:224-266): the value is detoasted inside tmpCtx, which is reset after every row */
+	tmp = shim_query_context_begin();
+	for (int r = 0; r < n; r++)
+	{
+		Vector	   *plain = make_vector(rows + (size_t) r * dim, dim);
+		Datum		heap_value = (toast_every && r % toast_every == 0) ? make_toasted(plain) : PointerGetDatum(plain);
+		Datum		value = PointerGetDatum(PG_DETOAST_DATUM(heap_value));
+		ItemPointerData tid = itemptr(tid_of_row(r));
+
+		PgvIvfflatBuildAdd(&bs, &tid, value);
+		shim_context_reset(tmp);	/* (pfree poisons: whoever kept a pointer into the row reads 0xDE from now on) */
+	}
+	shim_query_context_end(tmp);
+	PgvIvfflatBuildFlush(&bs);
+	EXPECT(sorted.n == n);
+
+	/* every row went to its nearest center (the oracle's FUNCTION 1 value decides; float-level ties excepted) */
+	packed_centers = malloc(sizeof(float) * (size_t) lists * dim);
+	for (int c = 0; c < lists; c++)
+		memcpy(packed_centers + (size_t) c * dim, ((Vector *) VectorArrayGet(&centers, c))->x, sizeof(float) * (Size) dim);
+	for (int i = 0; i < sorted.n; i += (sorted.n > 50000 ? 37 : 1))
+	{
+		double		best = INFINITY,
+					mine;
+
+		EXPECT(sorted.list[i] >= 0 && sorted.list[i] < lists);
+		for (int c = 0; c < lists; c++)
+		{
+			double		d = ora_index_distance(ORA_OPS_L2, ORA_F32, dim, sorted.rows + (size_t) i * dim, packed_centers + (size_t) c * dim);
+
+			if (d < best)
+				best = d;
+		}
+		mine = ora_index_distance(ORA_OPS_L2, ORA_F32, dim, sorted.rows + (size_t) i * dim, packed_centers + (size_t) sorted.list[i] * dim);
+		EXPECT(mine <= best * (1.0 + 1e-5) + 1e-9);
+		EXPECT(sorted.tid[i] == tid_of_row(i));	/* rows come out of the flushes in heap order, none lost, none twice */
+		EXPECT(memcmp(sorted.rows + (size_t) i * dim, rows + (size_t) i * dim, sizeof(float) * (size_t) dim) == 0);
+	}
+
+	/* tuplesort by list (stable: heap order inside a list), then the page writer */
+	order = malloc(sizeof(int) * (size_t) n);
+	offsets = calloc((size_t) lists + 1, sizeof(int64_t));
+	for (int i = 0; i < n; i++)
+		offsets[sorted.list[i] + 1]++;
+	for (int l = 0; l < lists; l++)
+		offsets[l + 1] += offsets[l];
+	{
+		int64_t    *at = malloc(sizeof(int64_t) * (size_t) lists);
+		float	   *v = malloc(sizeof(float) * (size_t) n * dim);
+		uint64	   *t = malloc(sizeof(uint64) * (size_t) n);
+
+		memcpy(at, offsets, sizeof(int64_t) * (size_t) lists);
+		for (int i = 0; i < n; i++)
+		{
+			int64_t		p = at[sorted.list[i]]++;
+
+			memcpy(v + (size_t) p * dim, sorted.rows + (size_t) i * dim, sizeof(float) * (size_t) dim);
+			t[p] = sorted.tid[i];
+		}
+		pgv_rel_init(&rel);
+		EXPECT(pgv_host_ivf_write_index(&rel, PGV_F32, dim, lists, packed_centers, offsets, v, t) == PGV_OK);
+		shim_replace_pages(relid, rel.pages, rel.nblocks);
+		pgv_rel_free(&rel);
+		free(at);
+		free(v);
+		free(t);
+	}
+	PgvNoteIndexChange(index);
+	free(order);
+	free(offsets);
+	free(packed_centers);
+	EXPECT(shim_pinned_buffers() == 0);
+	return 0;
+}
+
+static int
+backend_build(void *arg)
+{
+	float	   *rows = malloc(sizeof(float) * NROWS * DIM);
+
+	(void) arg;
+	scenario = "build";
+	shim_set_guc_bool("vector.gpu", true);
+	shim_seed_random(11);
+	gen_rows(rows, NROWS, DIM, 1);
+	if (build_index(REL_IVF, rows, NROWS, DIM, LISTS, 7))
+		return 1;
+	free(rows);
+	{
+		/* more rows than one assignment batch holds (PGV_ASSIGN_BATCH = 2^18): a flush in mid-scan, the rest at the end */
+		int			n = (1 << 18) + 5000,
+					dim = 8;
+		float	   *big = malloc(sizeof(float) * (size_t) n * dim);
+
+		scenario = "build across an assignment batch";
+		gen_rows(big, n, dim, 5);
+		if (build_index(REL_BATCH, big, n, dim, 16, 0))
+			return 1;
+		free(big);
+	}
+	return 0;
+}
+
+/* ------------------------------------------------------------------------------------------------ scans */
+static int
+pull(Scan * s, uint64 *out, int want)
+{
+	int			n = 0;
+
+	while (n < want && scan_gettuple(s))
+		out[n++] = tid_key(&s->desc.xs_heaptid);
+	return n;
+}
+
+/* wait until scans are served by the GPU path (the worker has staged the index); 0 when they are */
+static int
+wait_for_gpu(Relation index, double timeout_s)
+{
+	double		until = shim_now() + timeout_s;
+	float		q[DIM];
+
+	make_query(q, 0);
+	while (shim_now() < until)
+	{
+		Scan		s;
+		uint64		t;
+		int			got_gpu;
+
+		scan_begin(&s, index, q, PROBES, PROBES);
+		pull(&s, &t, 1);
+		got_gpu = s.gpu_tuples;
+		scan_end(&s);
+		if (got_gpu)
+			return 0;
+		usleep(20000);
+	}
+	return 1;
+}
+
+static int
+backend_scan_own(void *arg)
+{
+	Relation	index = shim_open_relation(REL_IVF);
+	uint64	   *got = malloc(sizeof(uint64) * 30000);
+	float		q[DIM];
+
+	(void) arg;
+	scenario = "own-context scans";
+	shim_set_guc_bool("vector.gpu", true);
+	/* the first scan finds no mirror: CPU path, and the worker is asked to stage */
+	{
+		Scan		s;
+
+		make_query(q, 1);
+		scan_begin(&s, index, q, PROBES, PROBES);
+		EXPECT(pull(&s, got, 5) == 5);
+		EXPECT(s.gpu_tuples == 0 && s.cpu_tuples == 5);
+		scan_end(&s);
+	}
+	EXPECT(wait_for_gpu(index, 30.0) == 0);
+	for (int i = 0; i < 40; i++)
+	{
+		Scan		s;
+		Expected	e;
+		int			want = i < 30 ? 10 : (i < 36 ? 300 : 30000);	/* LIMIT 10; device windows; the whole batch */
+		int			n;
+
+		make_query(q, i);
+		e = expected_batch(REL_IVF, q, PROBES);
+		scan_begin(&s, index, q, PROBES, PROBES);
+		n = pull(&s, got, want);
+		EXPECT(n == (want < e.n ? want : e.n));
+		EXPECT(s.cpu_tuples == 0);
+		if (check_stream(&e, got, n, 0, "own context"))
+			return 1;
+		/* rescan with another query on the same scan */
+		make_query(q, i + 100);
+		expected_free(&e);
+		e = expected_batch(REL_IVF, q, PROBES);
+		memcpy(s.query, q, sizeof(q));
+		s.so.value = PointerGetDatum(make_vector(q, DIM));
+		s.so.first = true;
+		PgvIvfflatRescan(s.so.gpu);
+		n = pull(&s, got, 10);
+		EXPECT(n == 10);
+		if (check_stream(&e, got, n, 0, "rescan"))
+			return 1;
+		scan_end(&s);
+		expected_free(&e);
+	}
+	/* iterative scan (ivfflat.iterative_scan, src/ivfscan.c:400-406): maxProbes 9, three lists at a time; every batch is
+	 * sorted by itself */
+	{
+		Scan		s;
+		Expected	e3,
+					e6;
+		int			n;
+
+		make_query(q, 7);
+		e3 = expected_batch(REL_IVF, q, 3);
+		e6 = expected_batch(REL_IVF, q, 6);
+		scan_begin(&s, index, q, 3, 9);
+		n = pull(&s, got, 30000);
+		EXPECT(n > e6.n);
+		if (check_stream(&e3, got, e3.n, 0, "iterative, first batch"))
+			return 1;
+		/* the second batch: the tuples of lists 4..6, ascending */
+		{
+			double		prev = -1.0;
+
+			for (int i = e3.n; i < e6.n; i++)
+			{
+				double		d,
+							unused;
+
+				EXPECT(expected_lookup(&e6, got[i], &d) && !expected_lookup(&e3, got[i], &unused));
+				EXPECT(d >= prev - 1e-4 * fabs(prev) - 1e-6);
+				prev = d;
+			}
+		}
+		scan_end(&s);
+		expected_free(&e3);
+		expected_free(&e6);
+	}
+	/* a NULL query (ZeroDistance, src/ivfscan.c:192-196): every tuple of the probed lists, any order */
+	{
+		Scan		s;
+		int			n;
+
+		scan_begin(&s, index, NULL, PROBES, PROBES);
+		n = pull(&s, got, 30000);
+		EXPECT(n > 0 && s.gpu_tuples == n);
+		for (int i = 1; i < n && i < 2000; i++)
+			EXPECT(got[i] != got[0]);
+		scan_end(&s);
+	}
+	/* an ERROR in mid-scan longjmps past ivfflatendscan: the scan's device state must go with its memory context */
+	{
+		int			before = mock_hip_live_queries ? mock_hip_live_queries() : 0;
+		uint64_t	free0 = 0,
+					free1 = 0,
+					total = 0;
+
+		pgv_device_memory(0, &free0, &total);
+		for (int i = 0; i < 200; i++)
+		{
+			volatile int caught = 0;
+
+			PG_TRY();
+			{
+				Scan		s;
+
+				make_query(q, i);
+				scan_begin(&s, index, q, PROBES, PROBES);
+				pull(&s, got, 3);
+				elog(ERROR, "division by zero");	/* some other part of the query fails */
+				scan_end(&s);
+			}
+			PG_CATCH();
+			{
+				caught = 1;
+				/* AbortTransaction: the query's context is reset, its reset callbacks fire */
+				shim_context_reset(CurrentMemoryContext);
+				CurrentMemoryContext = TopMemoryContext;
+				FlushErrorState();
+			}
+			PG_END_TRY();
+			EXPECT(caught);
+		}
+		if (mock_hip_live_queries)
+			EXPECT(mock_hip_live_queries() == before);
+		pgv_device_memory(0, &free1, &total);
+		EXPECT(free0 - free1 < (64u << 20) || free1 >= free0);	/* 200 leaked pgv_query would be ~200 x 1 MB */
+	}
+	EXPECT(shim_pinned_buffers() == 0);
+	free(got);
+	return 0;
+}
+
+static int
+backend_scan_pooled(void *arg)
+{
+	int			id = (int) (intptr_t) arg;
+	Relation	index = shim_open_relation(REL_IVF);
+	uint64	   *got = malloc(sizeof(uint64) * 30000);
+	float		q[DIM];
+	int			served = 0;
+
+	scenario = "pooled scans";
+	shim_set_guc_bool("vector.gpu", true);
+	shim_set_guc_bool("vector.gpu_pooled", true);
+	EXPECT(wait_for_gpu(index, 30.0) == 0);
+	for (int i = 0; i < 40; i++)
+	{
+		Scan		s;
+		Expected	e;
+		int			want = i % 8 == 5 ? 150 : (i % 8 == 6 ? 2500 : 10);	/* past the pooler's head of 64: own context takes over */
+		int			n;
+
+		make_query(q, id * 100 + i);
+		e = expected_batch(REL_IVF, q, PROBES);
+		scan_begin(&s, index, q, PROBES, PROBES);
+		n = pull(&s, got, want);
+		EXPECT(n == (want < e.n ? want : e.n));
+		EXPECT(s.cpu_tuples == 0);
+		served += s.gpu_tuples > 0;
+		if (check_stream(&e, got, n, 0, "pooled"))
+			return 1;
+		scan_end(&s);
+		expected_free(&e);
+	}
+	EXPECT(served == 40);
+	/* cancelled while waiting for the pooler: the ERROR comes out, the slot goes back, the next query is served */
+	for (int round = 0; round < 300; round++)
+	{
+		volatile int caught = 0;
+
+		PG_TRY();
+		{
+			float		dist[PGV_POOL_HEAD];
+			uint64		tid[PGV_POOL_HEAD];
+			int			count;
+			bool		complete;
+			uint64		staged;
+
+			make_query(q, round);
+			shim_cancel_after(0);	/* the first CHECK_FOR_INTERRUPTS inside the wait */
+			(void) PgvPoolSearch(index, q, PROBES, dist, tid, &count, &complete, &staged);
+			shim_cancel_after(-1);	/* (answered before the first check: fine) */
+		}
+		PG_CATCH();
+		{
+			caught = 1;
+			FlushErrorState();
+		}
+		PG_END_TRY();
+		(void) caught;
+	}
+	{
+		/* 300 cancelled queries later the 256 slots are not used up: the pooler still answers */
+		float		dist[PGV_POOL_HEAD];
+		uint64		tid[PGV_POOL_HEAD];
+		int			count = 0;
+		bool		complete;
+		uint64		staged = 0;
+		Expected	e;
+
+		make_query(q, 3);
+		e = expected_batch(REL_IVF, q, PROBES);
+		EXPECT(PgvPoolSearch(index, q, PROBES, dist, tid, &count, &complete, &staged));
+		EXPECT(count == PGV_POOL_HEAD && staged != 0 && !complete);
+		if (check_stream(&e, tid, count, 0, "pool after cancellations"))
+			return 1;
+		expected_free(&e);
+	}
+	free(got);
+	return 0;
+}
+
+/* ------------------------------------------------------------------------------------------------ insert -> stale -> restaged */
+static int
+wait_step(int step, double timeout_s)
+{
+	double		until = shim_now() + timeout_s;
+
+	while (board->step < step && shim_now() < until)
+		usleep(2000);
+	return board->step >= step ? 0 : 1;
+}
+
+/* backend A: holds a scan open across the restage (a cursor): it keeps the import it began on */
+static int
+backend_cursor(void *arg)
+{
+	Relation	index = shim_open_relation(REL_IVF);
+	uint64		got[4000];
+	float		q[DIM];
+	Scan		s;
+	Expected	e;
+	int			n;
+
+	(void) arg;
+	scenario = "open scan across a restage";
+	shim_set_guc_bool("vector.gpu", true);
+	EXPECT(wait_for_gpu(index, 30.0) == 0);
+	make_query(q, 21);
+	e = expected_batch(REL_IVF, q, PROBES);	/* the image the scan starts on */
+	scan_begin(&s, index, q, PROBES, PROBES);
+	n = pull(&s, got, 5);
+	EXPECT(n == 5 && s.gpu_tuples == 5);
+	board->ack = 1;				/* the cursor is open */
+	EXPECT(wait_step(2, 60.0) == 0);	/* ... the index has been changed and restaged, other scans run on the new import */
+	/* a second scan of this backend picks up the NEW staging while the first one is still open */
+	{
+		Scan		s2;
+		uint64		t;
+
+		scan_begin(&s2, index, board->new_row, PROBES, PROBES);
+		EXPECT(pull(&s2, &t, 1) == 1 && s2.gpu_tuples == 1);
+		EXPECT(t == board->new_tid);	/* the inserted row is its own nearest neighbour */
+		scan_end(&s2);
+	}
+	/* the open scan goes on, on the image it began with: deep into the batch (device windows + whole-batch fetch) */
+	n += pull(&s, got + 5, 3000);
+	EXPECT(s.cpu_tuples == 0 && n == (e.n < 3005 ? e.n : 3005));
+	if (check_stream(&e, got, n, 0, "cursor on the old import"))
+		return 1;
+	scan_end(&s);
+	expected_free(&e);
+	return 0;
+}
+
+/* backend B: inserts a row (ivfflatinsert), sees its scans fall to the CPU path, then served again with the new row */
+static int
+backend_insert(void *arg)
+{
+	Relation	index = shim_open_relation(REL_IVF);
+	float		row[DIM];
+	uint64		tid = ((uint64) 900000 << 16) | 7;
+	double		until;
+	int			saw_cpu = 0;
+
+	(void) arg;
+	scenario = "insert -> stale -> restaged";
+	shim_set_guc_bool("vector.gpu", true);
+	shim_set_guc_int("vector.gpu_restage_delay_ms", 0);
+	EXPECT(wait_for_gpu(index, 30.0) == 0);
+	until = shim_now() + 30.0;
+	while (!board->ack && shim_now() < until)
+		usleep(2000);
+	EXPECT(board->ack);
+	/* InsertTuple (src/ivfinsert.c:72-181) on the pages, then the hook */
+	make_query(row, 55);
+	{
+		pgv_rel		rel;
+		uint32_t	nblocks;
+		const void *pages = shim_relation_pages(REL_IVF, &nblocks);
+		uint32_t	list = 0;
+		int			dim,
+					lists;
+
+		pgv_rel_init(&rel);
+		rel.pages = malloc((size_t) (nblocks + 8) * PGV_BLCKSZ);
+		memcpy(rel.pages, pages, (size_t) nblocks * PGV_BLCKSZ);
+		rel.nblocks = nblocks;
+		rel.cap = nblocks + 8;
+		EXPECT(ora_pages_meta(rel.pages, rel.nblocks, &dim, &lists) && dim == DIM && lists == LISTS);
+		/* FindInsertPage: the nearest list (the oracle's single-probe search tells which tuples are its) */
+		{
+			uint64		t1;
+			double		d1;
+			int64_t		scanned;
+
+			EXPECT(ora_pages_search(rel.pages, rel.nblocks, ORA_OPS_L2, ORA_F32, row, 1, 1, &t1, &d1, &scanned) == 1);
+			/* which list holds t1: try lists until the insert lands where a 1-probe scan finds it */
+			for (list = 0; list < (uint32_t) lists; list++)
+			{
+				pgv_rel		trial = rel;
+				uint64		tt[2];
+				double		dd[2];
+
+				trial.pages = malloc((size_t) rel.cap * PGV_BLCKSZ);
+				memcpy(trial.pages, rel.pages, (size_t) rel.nblocks * PGV_BLCKSZ);
+				if (pgv_host_ivf_insert(&trial, PGV_F32, (int) list, row, tid) == PGV_OK &&
+					ora_pages_search(trial.pages, trial.nblocks, ORA_OPS_L2, ORA_F32, row, 1, 2, tt, dd, &scanned) >= 1 && tt[0] == tid)
+				{
+					free(rel.pages);
+					rel = trial;
+					break;
+				}
+				free(trial.pages);
+			}
+			EXPECT(list < (uint32_t) lists);
+		}
+		shim_replace_pages(REL_IVF, rel.pages, rel.nblocks);
+		free(rel.pages);
+	}
+	memcpy(board->new_row, row, sizeof(row));
+	board->new_tid = tid;
+	PgvNoteIndexChange(index);
+	/* scans now: the mirror is stale -> the reference's path (current pages, the new row included) until the worker has
+	 * restaged; then the GPU path with the new row */
+	until = shim_now() + 30.0;
+	for (;;)
+	{
+		Scan		s;
+		uint64		t;
+		int			n;
+
+		scan_begin(&s, index, row, PROBES, PROBES);
+		n = pull(&s, &t, 1);
+		EXPECT(n == 1 && t == tid);	/* whichever path answers, it answers from the current pages */
+		if (s.cpu_tuples)
+			saw_cpu = 1;
+		scan_end(&s);
+		if (s.gpu_tuples)
+			break;
+		EXPECT(shim_now() < until);
+		usleep(5000);
+	}
+	EXPECT(saw_cpu);
+	board->step = 2;
+	return 0;
+}
+
+/* a pooled scan that outlives its mirror: head from the pool, then the index changes, then it wants more */
+static int
+backend_pooled_restage(void *arg)
+{
+	Relation	index = shim_open_relation(REL_IVF);
+	uint64	   *got = malloc(sizeof(uint64) * 30000);
+	float		q[DIM];
+	Scan		s;
+	Expected	before,
+				after;
+	int			n;
+
+	(void) arg;
+	scenario = "pooled scan across a restage";
+	shim_set_guc_bool("vector.gpu", true);
+	shim_set_guc_bool("vector.gpu_pooled", true);
+	shim_set_guc_int("vector.gpu_restage_delay_ms", 0);
+	EXPECT(wait_for_gpu(index, 30.0) == 0);
+	make_query(q, 31);
+	before = expected_batch(REL_IVF, q, PROBES);
+	scan_begin(&s, index, q, PROBES, PROBES);
+	n = pull(&s, got, 40);
+	EXPECT(n == 40 && s.gpu_tuples == 40);
+	if (check_stream(&before, got, 40, 0, "pooled head"))
+		return 1;
+	/* the index changes under the open scan (no new row needed: the generation is what counts) */
+	PgvNoteIndexChange(index);
+	n += pull(&s, got + n, 30000);
+	after = expected_batch(REL_IVF, q, PROBES);
+	EXPECT(n == after.n);		/* every tuple of the probed lists, once: not truncated, none twice */
+	EXPECT(s.cpu_tuples > 0);	/* past the pooler's head the scan went on in the reference's code */
+	for (int i = 0; i < n; i++)
+	{
+		double		d;
+
+		EXPECT(expected_lookup(&after, got[i], &d));
+	}
+	{
+		uint64	   *copy = malloc(sizeof(uint64) * (size_t) n);
+
+		memcpy(copy, got, sizeof(uint64) * (size_t) n);
+		qsort(copy, (size_t) n, sizeof(uint64), cmp_u64_pair);
+		for (int i = 1; i < n; i++)
+			EXPECT(copy[i] != copy[i - 1]);
+		free(copy);
+	}
+	scan_end(&s);
+	expected_free(&before);
+	expected_free(&after);
+	free(got);
+	return 0;
+}
+
+/* ------------------------------------------------------------------------------------------------ the worker goes away */
+static int
+backend_after_worker_loss(void *arg)
+{
+	int			pooled = (int) (intptr_t) arg;
+	Relation	index = shim_open_relation(REL_IVF);
+	float		q[DIM];
+	double		t0 = shim_now(),
+				until = t0 + 40.0;
+	int			saw_gpu = 0;
+
+	scenario = pooled ? "pooled query after the worker was killed" : "own-context query after the worker was ended";
+	shim_set_guc_bool("vector.gpu", true);
+	shim_set_guc_bool("vector.gpu_pooled", pooled != 0);
+	make_query(q, 61);
+	while (shim_now() < until && !saw_gpu)
+	{
+		Scan		s;
+		uint64		got[10];
+		Expected	e = expected_batch(REL_IVF, q, PROBES);
+		double		t1 = shim_now();
+
+		scan_begin(&s, index, q, PROBES, PROBES);
+		EXPECT(pull(&s, got, 10) == 10);	/* answered -- by whichever path -- and never hung */
+		EXPECT(shim_now() - t1 < 8.0);
+		if (check_stream(&e, got, 10, 0, "after worker loss"))
+			return 1;
+		saw_gpu = s.gpu_tuples > 0;
+		scan_end(&s);
+		expected_free(&e);
+		if (!saw_gpu)
+			usleep(50000);
+	}
+	EXPECT(saw_gpu);			/* a new worker was started and staged the index again */
+	return 0;
+}
+
+/* ------------------------------------------------------------------------------------------------ hnsw */
+#define HN 3000
+#define HM 8
+static int
+backend_hnsw_build(void *arg)
+{
+	float	   *data = malloc(sizeof(float) * HN * DIM);
+	ora_hnsw   *g;
+	int32_t    *levels = malloc(sizeof(int32_t) * HN);
+	int64_t    *nbr_start = malloc(sizeof(int64_t) * (HN + 1));
+	int32_t    *nbr,
+			   *dup_of = malloc(sizeof(int32_t) * HN);
+	uint64_t   *tids = malloc(sizeof(uint64_t) * HN);
+	int			entry_level;
+	pgv_rel		rel;
+
+	(void) arg;
+	scenario = "hnsw pages";
+	gen_rows(data, HN, DIM, 3);
+	g = ora_hnsw_build(ORA_OPS_L2, ORA_F32, DIM, data, HN, HM, 32, 9);
+	EXPECT(ora_hnsw_num_elements(g) == HN);
+	nbr_start[0] = 0;
+	for (int e = 0; e < HN; e++)
+	{
+		levels[e] = ora_hnsw_level(g, e);
+		nbr_start[e + 1] = nbr_start[e] + (int64_t) (levels[e] + 2) * HM;
+		dup_of[e] = -1;
+		tids[e] = tid_of_row(e);
+		EXPECT(ora_hnsw_element_row(g, e) == e);
+	}
+	nbr = malloc(sizeof(int32_t) * (size_t) nbr_start[HN]);
+	for (int e = 0; e < HN; e++)
+		for (int lc = 0; lc <= levels[e]; lc++)
+		{
+			int			lm = lc == 0 ? 2 * HM : HM;
+			int32_t		buf[2 * HM];
+			int			cnt = ora_hnsw_neighbors(g, e, lc, buf);
+			int32_t    *out = nbr + nbr_start[e] + (int64_t) (levels[e] - lc) * HM;
+
+			for (int i = 0; i < lm; i++)
+				out[i] = i < cnt ? buf[i] : -1;
+		}
+	pgv_rel_init(&rel);
+	EXPECT(pgv_host_hnsw_write_index(&rel, PGV_F32, DIM, HM, 32, HN, data, tids, levels, nbr_start, nbr, dup_of,
+									 ora_hnsw_entry_point(g, &entry_level)) == PGV_OK);
+	shim_replace_pages(REL_HNSW, rel.pages, rel.nblocks);
+	pgv_rel_free(&rel);
+	ora_hnsw_free(g);
+	return 0;
+}
+
+static int
+backend_hnsw_scan(void *arg)
+{
+	Relation	index = shim_open_relation(REL_HNSW);
+	float	   *data = malloc(sizeof(float) * HN * DIM);
+	ora_hnsw   *g;
+	double		until = shim_now() + 30.0;
+	void	   *gpu = NULL;
+	MemoryContext ctx;
+
+	(void) arg;
+	scenario = "hnsw scans";
+	shim_set_guc_bool("vector.gpu", true);
+	hnsw_ef_search = 40;
+	gen_rows(data, HN, DIM, 3);
+	g = ora_hnsw_build(ORA_OPS_L2, ORA_F32, DIM, data, HN, HM, 32, 9);	/* the graph the pages hold */
+	/* hnswbeginscan: NULL (CPU path) until the worker has staged the graph */
+	ctx = shim_query_context_begin();
+	while ((gpu = PgvHnswBeginScan(index)) == NULL && shim_now() < until)
+		usleep(20000);
+	EXPECT(gpu != NULL);
+	PgvHnswEndScan(gpu);
+	shim_query_context_end(ctx);
+	for (int i = 0; i < 30; i++)
+	{
+		IndexScanDescData desc;
+		HnswScanOpaqueData so;
+		float		q[DIM];
+		List	   *w;
+		int64_t		rows[40];
+		double		dist[40];
+		int64_t		scored;
+		int			want,
+					n;
+
+		make_query(q, i);
+		want = ora_hnsw_search(g, q, 40, 40, rows, dist, &scored);
+		ctx = shim_query_context_begin();
+		memset(&desc, 0, sizeof(desc));
+		memset(&so, 0, sizeof(so));
+		desc.indexRelation = index;
+		desc.opaque = &so;
+		so.first = true;
+		so.gpu = PgvHnswBeginScan(index);
+		EXPECT(so.gpu != NULL);
+		w = PgvHnswGetScanItems(&desc, PointerGetDatum(make_vector(q, DIM)));
+		n = shim_list_length(w);
+		EXPECT(n == want && so.m == HM);
+		/* furthest first (hnswgettuple takes llast): position n - 1 - i is the i-th nearest */
+		for (int j = 0; j < n; j++)
+		{
+			HnswSearchCandidate *sc = shim_list_nth(w, n - 1 - j);
+			HnswElement el = sc->element.ptr;
+
+			EXPECT(fabs(sc->distance - dist[j]) <= 1e-4 * fabs(dist[j]) + 1e-6);
+			EXPECT(el->heaptidsLength == 1);
+			if (j + 1 < n && fabs(dist[j + 1] - dist[j]) > 1e-4 * fabs(dist[j]) && (j == 0 || fabs(dist[j] - dist[j - 1]) > 1e-4 * fabs(dist[j])))
+				EXPECT(tid_key(&el->heaptids[0]) == tid_of_row((int) rows[j]));
+		}
+		PgvHnswEndScan(so.gpu);
+		shim_query_context_end(ctx);
+	}
+	ora_hnsw_free(g);
+	free(data);
+	return 0;
+}
+
+/* ------------------------------------------------------------------------------------------------ the postmaster */
+static int
+run_phase(const char *name, int (*fn) (void *), int nprocs, void *const *args, double timeout_s)
+{
+	int			pids[16],
+				codes[16];
+	int			left,
+				bad = 0;
+
+	for (int i = 0; i < nprocs; i++)
+		pids[i] = shim_fork_backend(fn, args ? args[i] : NULL);
+	left = shim_postmaster_wait(pids, nprocs, codes, timeout_s);
+	for (int i = 0; i < nprocs; i++)
+		if (codes[i] != 0)
+			bad++;
+	fprintf(stderr, "phase %-40s %d process(es): %s   (background workers alive: %d)\n", name, nprocs,
+			left ? "TIMED OUT" : (bad ? "FAILED" : "ok"), shim_live_bgworkers());
+	return left || bad;
+}
+
+int
+main(void)
+{
+	ShimOpclass l2 = {0, IVFFLAT_MAX_DIM, false, false, 0};
+	ShimOpclass hnsw_l2 = {1, HNSW_MAX_DIM, false, false, 0};
+	uint8_t		empty[1] = {0};
+	size_t		arena_bytes = 0;
+	void	   *arena;
+	int			failed = 0;
+
+	board = mmap(NULL, sizeof(Board), PROT_READ | PROT_WRITE, MAP_SHARED | MAP_ANONYMOUS, -1, 0);
+	memset((void *) board, 0, sizeof(Board));
+	shim_postmaster_init((size_t) 192 << 20, mock_hip_set_arena ? (size_t) 512 << 20 : 0);
+	arena = shim_arena_base(&arena_bytes);
+	if (mock_hip_set_arena && arena)
+		mock_hip_set_arena(arena, arena_bytes);
+	/* shared_preload_libraries = 'vector': _PG_init in the postmaster */
+	process_shared_preload_libraries_in_progress = true;
+	PgvGpuInit();
+	shim_postmaster_run_shmem_hooks();
+	shim_register_bgworker_function("PgvWorkerMain", PgvWorkerMain);
+	/* empty relations: their pages come from the build */
+	shim_create_relation(REL_IVF, &l2, empty, 0, DIM);
+	shim_create_relation(REL_BATCH, &l2, empty, 0, 8);
+	shim_create_relation(REL_HNSW, &hnsw_l2, empty, 0, DIM);
+
+	failed |= run_phase("CREATE INDEX through the build hooks", backend_build, 1, NULL, 300.0);
+	if (!failed)
+		failed |= run_phase("own-context scans", backend_scan_own, 1, NULL, 300.0);
+	if (!failed)
+	{
+		void	   *ids[6] = {(void *) 1, (void *) 2, (void *) 3, (void *) 4, (void *) 5, (void *) 6};
+
+		failed |= run_phase("six pooled backends", backend_scan_pooled, 6, ids, 300.0);
+	}
+	if (!failed)
+	{
+		int			pids[2],
+					codes[2];
+
+		pids[0] = shim_fork_backend(backend_cursor, NULL);
+		pids[1] = shim_fork_backend(backend_insert, NULL);
+		failed |= shim_postmaster_wait(pids, 2, codes, 120.0) || codes[0] || codes[1];
+		fprintf(stderr, "phase %-40s 2 process(es): %s\n", "insert / restage under an open scan", failed ? "FAILED" : "ok");
+	}
+	if (!failed)
+		failed |= run_phase("pooled scan across a restage", backend_pooled_restage, 1, NULL, 120.0);
+	if (!failed)
+	{
+		void	   *pooled[1] = {(void *) 1};
+
+		/* the worker dies without running any exit hook */
+		if (shim_live_bgworkers() != 1)
+		{
+			fprintf(stderr, "expected ONE background worker, found %d\n", shim_live_bgworkers());
+			failed = 1;
+		}
+		shim_kill_bgworkers();
+		failed |= run_phase("worker killed (SIGKILL), pooled client", backend_after_worker_loss, 1, pooled, 120.0);
+	}
+	if (!failed)
+	{
+		void	   *own[1] = {(void *) 0};
+
+		/* the worker is ended politely (SIGTERM): its exit hook deregisters it */
+		shim_postmaster_shutdown();
+		failed |= run_phase("worker ended (SIGTERM), own-context client", backend_after_worker_loss, 1, own, 120.0);
+	}
+	if (!failed)
+		failed |= run_phase("hnsw: pages from the oracle's graph", backend_hnsw_build, 1, NULL, 120.0);
+	if (!failed)
+		failed |= run_phase("hnsw scans", backend_hnsw_scan, 1, NULL, 120.0);
+	shim_postmaster_shutdown();
+	if (failed)
+	{
+		fprintf(stderr, "EXT-RUNTIME FAILED\n");
+		return 1;
+	}
+	printf("EXT-RUNTIME OK\n");
+	return 0;
+}

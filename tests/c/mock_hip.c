@@ -37,6 +37,71 @@ struct pgv_ctx
 	int			dummy;
 };
 
+/*
+ * "Device memory".  By default the heap; with mock_hip_set_arena a bump allocator inside a MAP_SHARED mapping the
+ * caller made BEFORE forking its processes: an index "uploaded" by one of them is then addressable in all of them
+ * (same address), which is what lets tests/c/ext_driver.c run the worker-stages / backends-import model of
+ * ext/pgv_context.c without a GPU.  Arena memory is never reused (a test's worth of uploads fits).
+ */
+static int	live_queries = 0;	/* pgv_query handles of this process that have not been ended */
+
+int
+mock_hip_live_queries(void)
+{
+	return live_queries;
+}
+
+int
+pgv_device_count(void)
+{
+	return 1;
+}
+
+int
+pgv_device_memory(int device, uint64_t *free_bytes, uint64_t *total_bytes)
+{
+	(void) device;
+	*free_bytes = *total_bytes = (uint64_t) 1 << 40;
+	return PGV_OK;
+}
+
+static char *arena_base = NULL;
+static size_t arena_bytes = 0;
+
+void
+mock_hip_set_arena(void *base, size_t bytes)
+{
+	arena_base = base;
+	arena_bytes = bytes;
+}
+
+static void *
+dev_alloc(size_t bytes)
+{
+	size_t		at;
+
+	if (bytes == 0)
+		bytes = 16;
+	if (!arena_base)
+		return calloc(1, bytes);
+	bytes = (bytes + 63) & ~(size_t) 63;
+	at = __atomic_fetch_add((size_t *) arena_base, bytes, __ATOMIC_SEQ_CST) + 64;	/* the first 64 bytes hold the cursor */
+	if (at + bytes > arena_bytes)
+	{
+		fprintf(stderr, "mock_hip: arena exhausted\n");
+		abort();
+	}
+	memset(arena_base + at, 0, bytes);
+	return arena_base + at;
+}
+
+static void
+dev_free(void *p)
+{
+	if (p && !(arena_base && (char *) p >= arena_base && (char *) p < arena_base + arena_bytes))
+		free(p);
+}
+
 struct pgv_index
 {
 	pgv_metric	metric;
@@ -61,6 +126,9 @@ struct pgv_hnsw
 	int32_t    *levels;
 	int64_t    *nbr_start;
 	int32_t    *nbr;
+	char	   *payload;		/* [n x payload_bytes] (pgv_hnsw_upload_payload) */
+	int			payload_bytes;
+	int			imported;		/* a view made by pgv_hnsw_import: frees nothing but itself */
 };
 
 int
@@ -108,23 +176,23 @@ pgv_index_upload(pgv_ctx * ctx, pgv_metric metric, pgv_dtype dtype, int dim, int
 	(void) ctx;
 	if (dtype != PGV_F32)
 		return fail(PGV_ERR_ARG, "mock: fp32 only");
-	ix = calloc(1, sizeof(*ix));
-	ix->refs = malloc(sizeof(int));
+	ix = dev_alloc(sizeof(*ix));
+	ix->refs = dev_alloc(sizeof(int));
 	*ix->refs = 1;
 	if (tids)
 	{
-		ix->tids = malloc(sizeof(uint64_t) * (size_t) (n > 0 ? n : 1));
+		ix->tids = dev_alloc(sizeof(uint64_t) * (size_t) (n > 0 ? n : 1));
 		memcpy(ix->tids, tids, sizeof(uint64_t) * (size_t) n);
 	}
 	ix->metric = metric;
 	ix->dim = dim;
 	ix->nlists = nlists;
 	ix->n = n;
-	ix->centers = malloc(sizeof(float) * (size_t) nlists * dim);
+	ix->centers = dev_alloc(sizeof(float) * (size_t) nlists * dim);
 	memcpy(ix->centers, centers, sizeof(float) * (size_t) nlists * dim);
-	ix->offsets = malloc(sizeof(int64_t) * (size_t) (nlists + 1));
+	ix->offsets = dev_alloc(sizeof(int64_t) * (size_t) (nlists + 1));
 	memcpy(ix->offsets, list_offsets, sizeof(int64_t) * (size_t) (nlists + 1));
-	ix->vectors = malloc(sizeof(float) * (size_t) (n > 0 ? n : 1) * dim);
+	ix->vectors = dev_alloc(sizeof(float) * (size_t) (n > 0 ? n : 1) * dim);
 	memcpy(ix->vectors, vectors, sizeof(float) * (size_t) n * dim);
 	*out = ix;
 	return PGV_OK;
@@ -207,15 +275,37 @@ pgv_index_free(pgv_index * ix)
 		return;
 	if (__atomic_sub_fetch(ix->refs, 1, __ATOMIC_ACQ_REL) > 0)
 	{
-		free(ix);
+		dev_free(ix);			/* a view's struct is this process's own; the owner's may sit in the arena (views live on) */
 		return;
 	}
-	free(ix->refs);
-	free(ix->tids);
-	free(ix->centers);
-	free(ix->vectors);
-	free(ix->offsets);
-	free(ix);
+	dev_free(ix->refs);
+	dev_free(ix->tids);
+	dev_free(ix->centers);
+	dev_free(ix->vectors);
+	dev_free(ix->offsets);
+	dev_free(ix);
+}
+
+int
+pgv_index_tids(pgv_index * ix, const int64_t *slots, int64_t n, uint64_t *out)
+{
+	if (!ix->tids)
+		return fail(PGV_ERR_STATE, "mock: index was uploaded without tids");
+	for (int64_t i = 0; i < n; i++)
+		out[i] = slots[i] >= 0 && slots[i] < ix->n ? ix->tids[slots[i]] : ~(uint64_t) 0;
+	return PGV_OK;
+}
+
+int64_t
+pgv_index_rows(const pgv_index * ix)
+{
+	return ix->n;
+}
+
+int
+pgv_index_lists(const pgv_index * ix)
+{
+	return ix->nlists;
 }
 
 /* GetScanLists: the maxprobes nearest centers, ascending; a later center never displaces an equal one */
@@ -328,6 +418,7 @@ pgv_query_begin(pgv_index * ix, pgv_query * *out)
 {
 	pgv_query  *q = calloc(1, sizeof(*q));
 
+	live_queries++;
 	q->ix = ix;
 	q->q = malloc(sizeof(float) * (size_t) ix->dim);
 	q->lists = malloc(sizeof(int32_t) * (size_t) ix->nlists);
@@ -340,6 +431,7 @@ pgv_query_end(pgv_query * q)
 {
 	if (!q)
 		return;
+	live_queries--;
 	free(q->q);
 	free(q->lists);
 	free(q->sd);
@@ -376,13 +468,14 @@ emit(pgv_query * q, int skip, int count, float *out_dist, int64_t *out_slot, uin
 {
 	int			n = 0;
 
-	(void) out_tid;
 	for (int64_t i = skip; i < q->m && n < count; i++, n++)
 	{
 		if (out_dist)
 			out_dist[n] = q->sd[i];
 		if (out_slot)
 			out_slot[n] = q->ss[i];
+		if (out_tid)
+			out_tid[n] = q->ix->tids ? q->ix->tids[q->ss[i]] : ~(uint64_t) 0;
 	}
 	*out_count = n;
 	return PGV_OK;
@@ -677,23 +770,91 @@ pgv_hnsw_upload(pgv_ctx * ctx, pgv_metric metric, pgv_dtype dtype, int dim, cons
 	(void) ctx;
 	if (dtype != PGV_F32)
 		return fail(PGV_ERR_ARG, "mock: fp32 only");
-	h = calloc(1, sizeof(*h));
+	h = dev_alloc(sizeof(*h));
 	h->metric = metric;
 	h->dim = dim;
 	h->n = n;
 	h->entry = -1;
-	h->vectors = malloc(sizeof(float) * (size_t) (n > 0 ? n : 1) * dim);
+	h->vectors = dev_alloc(sizeof(float) * (size_t) (n > 0 ? n : 1) * dim);
 	memcpy(h->vectors, elements, sizeof(float) * (size_t) n * dim);
 	*out = h;
+	return PGV_OK;
+}
+
+int
+pgv_hnsw_upload_payload(pgv_ctx * ctx, pgv_metric metric, pgv_dtype dtype, int dim, const void *elements, int64_t n,
+						const void *payload, int payload_bytes, pgv_hnsw * *out)
+{
+	int			rc = pgv_hnsw_upload(ctx, metric, dtype, dim, elements, n, out);
+
+	if (rc != PGV_OK)
+		return rc;
+	(*out)->payload_bytes = payload_bytes;
+	(*out)->payload = dev_alloc((size_t) (n > 0 ? n : 1) * (size_t) payload_bytes);
+	memcpy((*out)->payload, payload, (size_t) n * (size_t) payload_bytes);
+	return PGV_OK;
+}
+
+int
+pgv_hnsw_get_payload(pgv_hnsw * h, const int64_t *elements, int n, void *out)
+{
+	if (!h->payload)
+		return fail(PGV_ERR_STATE, "mock: mirror was uploaded without a payload");
+	for (int i = 0; i < n; i++)
+	{
+		char	   *o = (char *) out + (size_t) i * (size_t) h->payload_bytes;
+
+		if (elements[i] >= 0 && elements[i] < h->n)
+			memcpy(o, h->payload + (size_t) elements[i] * (size_t) h->payload_bytes, (size_t) h->payload_bytes);
+		else
+			memset(o, 0, (size_t) h->payload_bytes);
+	}
+	return PGV_OK;
+}
+
+typedef struct
+{
+	uint64_t	magic;
+	uint32_t	pid;
+	pgv_hnsw   *h;
+}			mock_hnsw_handle;
+
+int
+pgv_hnsw_export(pgv_hnsw * h, pgv_index_handle * out)
+{
+	mock_hnsw_handle e = {0x6d6f636b686e73ull, (uint32_t) getpid(), h};
+
+	memset(out, 0, sizeof(*out));
+	memcpy(out->bytes, &e, sizeof(e));
+	return PGV_OK;
+}
+
+int
+pgv_hnsw_import(pgv_ctx * ctx, const pgv_index_handle * handle, pgv_hnsw * *out)
+{
+	mock_hnsw_handle e;
+	pgv_hnsw   *v;
+
+	(void) ctx;
+	memcpy(&e, handle->bytes, sizeof(e));
+	*out = NULL;
+	if (e.magic != 0x6d6f636b686e73ull)
+		return fail(PGV_ERR_ARG, "mock: not an hnsw handle");
+	if (e.pid == (uint32_t) getpid())
+		return fail(PGV_ERR_STATE, "mock: the handle was exported by this process");
+	v = malloc(sizeof(*v));
+	*v = *e.h;
+	v->imported = 1;
+	*out = v;
 	return PGV_OK;
 }
 
 static void
 graph_free(pgv_hnsw * h)
 {
-	free(h->levels);
-	free(h->nbr_start);
-	free(h->nbr);
+	dev_free(h->levels);
+	dev_free(h->nbr_start);
+	dev_free(h->nbr);
 	h->levels = NULL;
 	h->nbr_start = NULL;
 	h->nbr = NULL;
@@ -704,9 +865,15 @@ pgv_hnsw_free(pgv_hnsw * h)
 {
 	if (!h)
 		return;
+	if (h->imported)
+	{
+		free(h);
+		return;
+	}
 	graph_free(h);
-	free(h->vectors);
-	free(h);
+	dev_free(h->vectors);
+	dev_free(h->payload);
+	dev_free(h);
 }
 
 int
@@ -716,11 +883,11 @@ pgv_hnsw_set_graph(pgv_hnsw * h, int m, int32_t entry, const int32_t *levels, co
 	graph_free(h);
 	h->m = m;
 	h->entry = entry;
-	h->levels = malloc(sizeof(int32_t) * (size_t) (h->n > 0 ? h->n : 1));
-	h->nbr_start = malloc(sizeof(int64_t) * (size_t) (h->n + 1));
+	h->levels = dev_alloc(sizeof(int32_t) * (size_t) (h->n > 0 ? h->n : 1));
+	h->nbr_start = dev_alloc(sizeof(int64_t) * (size_t) (h->n + 1));
 	memcpy(h->levels, levels, sizeof(int32_t) * (size_t) h->n);
 	memcpy(h->nbr_start, nbr_start, sizeof(int64_t) * (size_t) (h->n + 1));
-	h->nbr = malloc(sizeof(int32_t) * (size_t) (nbr_start[h->n] > 0 ? nbr_start[h->n] : 1));
+	h->nbr = dev_alloc(sizeof(int32_t) * (size_t) (nbr_start[h->n] > 0 ? nbr_start[h->n] : 1));
 	memcpy(h->nbr, nbr, sizeof(int32_t) * (size_t) nbr_start[h->n]);
 	return PGV_OK;
 }
@@ -880,6 +1047,47 @@ pgv_hnsw_build_search(pgv_hnsw * h, const int32_t *elements, const int32_t *inse
 				}
 				out_count[(size_t) q * layer_cap + lc] = wn;
 			}
+		}
+	}
+	free(w);
+	free(visited);
+	return PGV_OK;
+}
+
+/* hnswgettuple's first batch (src/hnswscan.c:25-56): greedy descent with ef = 1, then HnswSearchLayer with ef_search
+ * on layer 0; the k nearest, ascending, -1 / +inf padded */
+int
+pgv_hnsw_search(pgv_hnsw * h, const void *queries, int nq, int ef_search, int k, int64_t *out_elem, float *out_dist,
+				int64_t *out_scored)
+{
+	sc		   *w = malloc(sizeof(sc) * (size_t) (ef_search + 1));
+	uint8_t    *visited = malloc((size_t) (h->n > 0 ? h->n : 1));
+
+	for (int q = 0; q < nq; q++)
+	{
+		const float *qv = (const float *) queries + (size_t) q * h->dim;
+		int			wn = 0;
+
+		if (h->entry >= 0)
+		{
+			w[0].id = h->entry;
+			w[0].d = dist(h->metric, h->dim, h->vectors + (size_t) h->entry * h->dim, qv);
+			wn = 1;
+			for (int lc = h->levels[h->entry]; lc >= 0; lc--)
+				wn = search_layer(h, qv, w, wn, lc == 0 ? ef_search : 1, lc, visited);
+		}
+		for (int i = 0; i < k; i++)
+		{
+			out_elem[(size_t) q * k + i] = i < wn ? w[i].id : -1;
+			out_dist[(size_t) q * k + i] = i < wn ? w[i].d : INFINITY;
+		}
+		if (out_scored)
+		{
+			int64_t		scored = 0;
+
+			for (int64_t e = 0; e < h->n; e++)
+				scored += visited[e];
+			out_scored[q] = scored;
 		}
 	}
 	free(w);

@@ -421,6 +421,8 @@ shim_run_proc_exit(int code)
 void
 proc_exit(int code)
 {
+	if (is_bgworker)
+		fprintf(stderr, "LOG:  background worker %d exits with code %d%s%s\n", (int) getpid(), code, code ? ": " : "", code ? last_error : "");
 	shim_run_proc_exit(code);
 	fflush(NULL);
 	_exit(code);
@@ -770,7 +772,7 @@ void
 shim_create_relation(Oid oid, const ShimOpclass * opclass, const void *pages, uint32_t nblocks, int dimensions)
 {
 	ShimRel    *r = NULL;
-	uint32		cap = nblocks * 2 + 64;
+	uint32		cap = nblocks * 2 + 4096;	/* room for the pages a build or inserts bring later */
 
 	spin_lock(&S->catalog_lock);
 	for (int i = 0; i < SHIM_MAX_RELS && r == NULL; i++)
@@ -1311,12 +1313,14 @@ start_requested_bgworkers(void)
 	for (int i = 0; i < SHIM_MAX_BGW; i++)
 	{
 		ShimBgw    *w = &S->bgw[i];
+		pid_t		pid;
 
 		if (__atomic_load_n(&w->state, __ATOMIC_ACQUIRE) != 1)
 			continue;
+
 		fflush(NULL);
-		w->pid = fork();
-		if (w->pid == 0)
+		pid = fork();			/* (w is shared memory: only the parent may write the pid into it) */
+		if (pid == 0)
 		{
 			int			result = 0;
 
@@ -1328,6 +1332,7 @@ start_requested_bgworkers(void)
 				result = 1;
 			proc_exit(result);
 		}
+		w->pid = (int) pid;
 		__atomic_store_n(&w->state, 2, __ATOMIC_RELEASE);
 	}
 }

@@ -71,5 +71,9 @@ void		shim_set_guc_int(const char *name, int value);
 void		shim_relcache_invalidate(Oid relid);
 void		shim_run_proc_exit(int code);	/* before_shmem_exit + on_proc_exit callbacks (a clean backend exit) */
 double		shim_now(void);
+int			shim_list_length(const List *l);
+void	   *shim_list_nth(const List *l, int n);
+int			shim_pin_leaks(void);
+void		shim_seed_random(uint64 seed);
 
 #endif

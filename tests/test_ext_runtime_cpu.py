@@ -1,0 +1,46 @@
+"""ext/ EXECUTED (round 3's verdict: the glue a maintainer would paste was only type-checked).  tests/c/ext_driver.c
+plays a postmaster, backends and the "pgvector gpu" background worker as real processes over tests/c/pgshim_runtime.c
+-- palloc over resettable contexts with reset callbacks, ereport as a longjmp, the buffer manager over the emulated
+page image, LWLocks / latches / atomics in a shared mapping, RegisterDynamicBackgroundWorker as fork -- and runs the
+build hooks (plain and toasted-style heap values, the caller's memory poisoned after every row), own-context and pooled
+scans (heads, deep pulls, iterative, NULL query, ERROR in mid-scan, cancel while waiting), insert -> stale -> restage
+under an open scan, a pooled scan whose mirror is restaged under it, a worker killed and a worker ended, and the HNSW
+scan, every answer checked against the oracle walking the same pages.  Here on tests/c/mock_hip.c (no GPU), once plain
+and once under AddressSanitizer + UBSan; tests/test_ext_runtime_gpu.py runs the same driver on libpgv_hip.so."""
+import os
+import subprocess
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+EXT = [os.path.join(ROOT, "ext", f) for f in ("pgv_context.c", "ivfscan_gpu.c", "hnswscan_gpu.c", "ivfbuild_gpu.c")]
+
+
+def build_driver(exe, device_sources, extra_flags=(), extra_libs=()):
+    libdir = os.path.join(ROOT, "pgvector_amd", "lib")
+    oradir = os.path.join(ROOT, "oracle")
+    os.makedirs(os.path.dirname(exe), exist_ok=True)
+    cmd = (["gcc", "-O1", "-g", "-std=gnu11", "-rdynamic"] + list(extra_flags) +
+           ["-I" + os.path.join(ROOT, "ext", "shim"), "-I" + os.path.join(ROOT, "ext"), "-I" + os.path.join(ROOT, "include"),
+            "-I" + os.path.join(ROOT, "tests", "c"), "-I" + os.path.join(ROOT, "pgvector_amd", "host"), "-I" + oradir,
+            os.path.join(ROOT, "tests", "c", "ext_driver.c"), os.path.join(ROOT, "tests", "c", "pgshim_runtime.c")] +
+           list(device_sources) + EXT +
+           ["-o", exe, "-L" + libdir, "-lpgv_host"] + list(extra_libs) +
+           ["-L" + oradir, "-loracle", "-lm", "-lpthread", "-Wl,-rpath," + libdir, "-Wl,-rpath," + oradir])
+    subprocess.run(cmd, check=True)
+    return exe
+
+
+@pytest.mark.parametrize("sanitize", [False, True], ids=["plain", "asan+ubsan"])
+def test_ext_glue_runs_on_the_stand_in_server(tmp_path, sanitize):
+    flags = ["-fsanitize=address,undefined", "-fno-omit-frame-pointer"] if sanitize else []
+    exe = build_driver(str(tmp_path / "ext_driver"), [os.path.join(ROOT, "tests", "c", "mock_hip.c")], flags)
+    env = dict(os.environ, ASAN_OPTIONS="detect_leaks=0:abort_on_error=1", UBSAN_OPTIONS="halt_on_error=1")
+    r = subprocess.run([exe], capture_output=True, text=True, timeout=900, env=env)
+    assert r.returncode == 0 and "EXT-RUNTIME OK" in r.stdout, (r.returncode, r.stdout[-500:], r.stderr[-3000:])
+    assert "AddressSanitizer" not in r.stderr and "runtime error" not in r.stderr, r.stderr[-3000:]
+    assert "buffer refcount leak" not in r.stderr
+    for phase in ("CREATE INDEX through the build hooks", "own-context scans", "six pooled backends",
+                  "insert / restage under an open scan", "pooled scan across a restage", "worker killed (SIGKILL)",
+                  "worker ended (SIGTERM)", "hnsw scans"):
+        assert any(phase in line and ": ok" in line for line in r.stderr.splitlines()), (phase, r.stderr[-3000:])
