@@ -333,16 +333,29 @@ __global__ __launch_bounds__(MfmaCfg<T>::WM *MfmaCfg<T>::WN * 64, 2) void mfma_a
     const unsigned b_lane = (unsigned)(BM + wn * TN * 32 + l31) * kSliceBytes;
 
     for (int cb = cb_first; cb < cb_end; cb += BM) {
-        if (MODE == 0) {
-            for (int i = threadIdx.x; i < BM; i += blockDim.x) bias_lds[i] = cb + i < k ? bias[cb + i] : 0.f;
-        }
         f32x16 acc[TM][TN];
+        if constexpr (MODE == 0) {
+            // L2: the accumulators START at -|c|^2 / 2, so that -2 acc = |c|^2 - 2 a.c comes out of the matrix pipeline
+            // itself (the epilogue is a multiplication by -2, no bias reads, no fma; the rounding bound of the chain is
+            // unchanged: gamma x (|c|^2 / 2 + |a||c|) on acc)
+            for (int i = threadIdx.x; i < BM; i += blockDim.x) bias_lds[i] = cb + i < k ? -0.5f * bias[cb + i] : 0.f;
+            __syncthreads();
 #pragma unroll
-        for (int a = 0; a < TM; a++)
+            for (int a = 0; a < TM; a++)
 #pragma unroll
-            for (int b = 0; b < TN; b++)
+                for (int r = 0; r < 16; r++) {
+                    const float nb = bias_lds[wm * TM * 32 + a * 32 + (r & 3) + 8 * (r >> 2) + 4 * half];
 #pragma unroll
-                for (int r = 0; r < 16; r++) acc[a][b][r] = 0.f;
+                    for (int b = 0; b < TN; b++) acc[a][b][r] = nb;
+                }
+        } else {
+#pragma unroll
+            for (int a = 0; a < TM; a++)
+#pragma unroll
+                for (int b = 0; b < TN; b++)
+#pragma unroll
+                    for (int r = 0; r < 16; r++) acc[a][b][r] = 0.f;
+        }
 
         issue_stage(cb, 0, 0);
         for (int sl = 0; sl < nslices; sl++) {
@@ -352,7 +365,7 @@ __global__ __launch_bounds__(MfmaCfg<T>::WM *MfmaCfg<T>::WN * 64, 2) void mfma_a
             // the fill)
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __syncthreads();
-            constexpr bool kPipe = TM == 4 && TN == 2 && MODE != 0;
+            constexpr bool kPipe = TM == 4 && TN == 2;  // fp16 (its L2 form takes |row|^2 from row_norms_kernel: part_x2)
             const bool more = sl + 1 < nslices;
             if (more) issue_stage(cb, sl + 1, (sl + 1) & 1);  // all eight pieces at once: spreading them behind the MFMA groups
                                                                 // was 9 % SLOWER (28.2 -> 30.9 ms) -- the fill is what the barrier waits for
@@ -426,7 +439,7 @@ __global__ __launch_bounds__(MfmaCfg<T>::WM *MfmaCfg<T>::WN * 64, 2) void mfma_a
                     const int cid = cb + cl;
                     float s = acc[tm][tn][r];
                     if constexpr (MODE == 0) {
-                        s = fmaf(-2.f, s, bias_lds[cl]);
+                        s = -2.f * s;
                     } else if constexpr (MODE == 3) {
                         s = s > 1.f ? 1.f : (s < -1.f ? -1.f : s);
                         s = -s;
@@ -499,7 +512,7 @@ __global__ __launch_bounds__(MfmaCfg<T>::WM *MfmaCfg<T>::WN * 64, 2) void mfma_a
             continue;
         }
         float x2 = 0.f;
-        if constexpr (NC > 1) x2 = mx[j * 2] + mx[j * 2 + 1];
+        if constexpr (NC > 1) x2 = sizeof(T) == 2 ? part_x2[r] : mx[j * 2] + mx[j * 2 + 1];
         finish_row<NC>(r, sv, sid, x2, out_idx, out_val, cmax2_bits, gamma, gamma_x, u_count, u_rows, u_cand, u_val);
     }
 }
@@ -735,16 +748,17 @@ int launch_mfma_t(pgv_ctx *ctx, const RowGeom &g, const void *rows, int64_t n, c
     float *part_val = nullptr, *part_x2 = nullptr;
     int32_t *part_idx = nullptr;
     int64_t grid = row_tiles;
-    if (nparts > 1) {
+    const bool norms_pass = MODE == 0 && (nparts > 1 || sizeof(T) == 2);  // (the fp16 kernel never gathers |row|^2 itself)
+    if (nparts > 1 || norms_pass) {
         const size_t pv = sizeof(float) * (size_t)n * nparts * NC;
         PGV_TRY(ctx->mf_d.ensure(2 * pv + sizeof(float) * (size_t)n + 64));
         part_val = ctx->mf_d.as<float>();
         part_idx = reinterpret_cast<int32_t *>(ctx->mf_d.as<char>() + pv);
         part_x2 = reinterpret_cast<float *>(ctx->mf_d.as<char>() + 2 * pv);
-        grid = 8 * ((row_tiles + 7) / 8) * nparts;
+        if (nparts > 1) grid = 8 * ((row_tiles + 7) / 8) * nparts;
     }
     if (grid > 0x7fffffff) PGV_FAIL(PGV_ERR_ARG, "assignment: too many workgroups");
-    if (nparts > 1 && MODE == 0) {
+    if (norms_pass) {
         // |row|^2 for the error bound of the pre-filter: one streaming pass (the one-workgroup-per-row-tile form gathers
         // it from the operands it reads anyway; here 1 / nparts of the workgroups would have to, and wait for it)
         unsigned *max_bits = reinterpret_cast<unsigned *>(part_x2 + n);

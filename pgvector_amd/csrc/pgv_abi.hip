@@ -582,6 +582,7 @@ int pgv_ctx_set_bound(pgv_ctx *ctx, int mode) {
     if (mode != PGV_BOUND_STATISTICAL && mode != PGV_BOUND_WORST_CASE)
         PGV_FAIL(PGV_ERR_ARG, "pgv_ctx_set_bound: unknown mode %d", mode);
     ctx->bound_mode = mode;
+    ctx->assign_bound_mode = mode;
     return PGV_OK;
 }
 

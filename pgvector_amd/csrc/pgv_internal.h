@@ -125,7 +125,8 @@ struct pgv_ctx {
     bool profiling = false;
     bool no_mfma_scan = false;  // pgv_ctx_set_exact_scan
     bool no_widen = false;      // PGV_NO_WIDEN=1: flagged queries go straight to the exact pass (experiments)
-    int bound_mode = 1;         // pgv_ctx_set_bound: PGV_BOUND_STATISTICAL / PGV_BOUND_WORST_CASE (default)
+    int bound_mode = 1;         // the scans' bound: PGV_BOUND_WORST_CASE unless pgv_ctx_set_bound says otherwise
+    int assign_bound_mode = 0;  // the assignment pre-filter's: PGV_BOUND_STATISTICAL unless pgv_ctx_set_bound(WORST_CASE)
     pgv::DBuf xt_norms;         // pgv_exact_topk: |row|^2 of the caller's rows
     std::vector<hipEvent_t> ev_pool;  // start/stop pairs
     size_t ev_used = 0;
@@ -227,8 +228,12 @@ namespace pgv {
 //                            and in the reference) is itself rounded -- all terms positive, so RELATIVE to the distance;
 //                            a row outside the band must stay outside when both its and the k-th row's exact values move
 //                  |x| is the largest row norm of the index (one word, kept with the norms).
-// ArgminBound -- the build's L2 pre-filter (mfma_argmin_kernel, ONE accumulator chain per output): the pair of round 3,
-//   gamma (|c|^2 + 2 |a||c|) + gamma_x (|a| + |c|)^2.
+// ArgminBound -- the build's L2 pre-filter (mfma_argmin_kernel, ONE accumulator chain per output: 128 accumulators a
+//   lane leave no room for four): gamma (|c|^2 + 2 |a||c|) + gamma_x d.  Its DEFAULT stays the statistical gamma: on one
+//   chain the deterministic gamma_(dim+1) is 5-10 x wider, which at 3072 dimensions sends 10 % of the rows to the exact
+//   redo kernel (1.25 M x 4096 x 3072 fp16: 32 -> 123 ms, profiles/r04); a row the statistical bound misjudges goes to a
+//   list whose center is as near as the reference's choice to within the float tolerance of the distances -- a tie the
+//   reference's own summation order does not pin either.  pgv_ctx_set_bound(PGV_BOUND_WORST_CASE) switches it too.
 struct ScanBound {
     float g_sq, g_dot, g_norm, g_ref;
 };
@@ -244,7 +249,7 @@ struct ExpansionBound {
 };
 inline ExpansionBound argmin_bound(const pgv_ctx *ctx, int dim) {
     constexpr float u = 5.9604645e-8f;
-    if (ctx->bound_mode == 0) return {8.f * std::sqrt((float)dim + 4.f) * u, 0.f};
+    if (ctx->assign_bound_mode == 0) return {8.f * std::sqrt((float)dim + 4.f) * u, 0.f};
     const float n1 = (float)(dim + 1) * u, n2 = (float)(dim + 2) * u;
     return {n1 / (1.f - n1), n2 / (1.f - n2)};
 }

@@ -1094,3 +1094,336 @@ pgv_hnsw_search(pgv_hnsw * h, const void *queries, int nq, int ef_search, int k,
 	free(visited);
 	return PGV_OK;
 }
+
+/* ------------------------------------------------------------------ multi-GPU
+ * The stand-in's pgv_comm_* / pgv_kmeans_sharded / pgv_search_batch_sharded issue the SAME collectives in the same
+ * order with the same payloads as libpgv_hip (pgv_abi.hip, "multi-GPU"): all-gather of the ranks' sample counts; per
+ * k-means++ round an all-gather of the ranks' weight totals and one of the candidate row; per Lloyd iteration ONE
+ * all-reduce of the fused record sums[k x dim] | counts[k] | changes (as floats); per search an all-gather of the
+ * ranks' probe-list slices and two of their heads.  tests/test_sharded_cpath_gloo.py runs two ranks of it over gloo.
+ */
+struct pgv_comm
+{
+	int			nranks,
+				rank;
+	pgv_collectives coll;
+};
+
+int
+pgv_comm_create_custom(pgv_ctx * ctx, int nranks, int rank, const pgv_collectives * coll, pgv_comm * *out)
+{
+	pgv_comm   *cm;
+
+	(void) ctx;
+	if (nranks < 1 || rank < 0 || rank >= nranks)
+		return fail(PGV_ERR_ARG, "mock: bad rank");
+	if (nranks > 1 && (!coll || !coll->all_reduce_sum_f32 || !coll->all_gather))
+		return fail(PGV_ERR_ARG, "pgv_comm_create_custom: both collectives are needed");
+	cm = calloc(1, sizeof(*cm));
+	cm->nranks = nranks;
+	cm->rank = rank;
+	if (coll)
+		cm->coll = *coll;
+	*out = cm;
+	return PGV_OK;
+}
+
+void
+pgv_comm_destroy(pgv_comm * cm)
+{
+	free(cm);
+}
+
+int
+pgv_comm_size(const pgv_comm * cm)
+{
+	return cm ? cm->nranks : 0;
+}
+
+int
+pgv_comm_rank(const pgv_comm * cm)
+{
+	return cm ? cm->rank : -1;
+}
+
+static int
+mc_all_gather(pgv_comm * cm, const void *send, void *recv, size_t bytes)
+{
+	if (cm->nranks == 1)
+	{
+		memmove(recv, send, bytes);
+		return PGV_OK;
+	}
+	return cm->coll.all_gather(cm->coll.state, send, recv, bytes, NULL) == 0 ? PGV_OK : fail(PGV_ERR_DEVICE, "all-gather callback failed");
+}
+
+static int
+mc_all_reduce(pgv_comm * cm, float *buf, size_t count)
+{
+	if (cm->nranks == 1)
+		return PGV_OK;
+	return cm->coll.all_reduce_sum_f32(cm->coll.state, buf, count, NULL) == 0 ? PGV_OK : fail(PGV_ERR_DEVICE, "all-reduce callback failed");
+}
+
+typedef struct
+{
+	const pgv_rng *cb;
+	uint64_t	s;
+}			mock_rng;
+
+static uint64_t
+mr_next(mock_rng * r)
+{
+	uint64_t	z = (r->s += 0x9E3779B97F4A7C15ull);
+
+	z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+	z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+	return z ^ (z >> 31);
+}
+
+static double
+mr_double(mock_rng * r)
+{
+	return r->cb && r->cb->next_double ? r->cb->next_double(r->cb->state) : (double) (mr_next(r) >> 11) / 9007199254740992.0;
+}
+
+static uint32_t
+mr_u32(mock_rng * r)
+{
+	return r->cb && r->cb->next_u32 ? r->cb->next_u32(r->cb->state) : (uint32_t) (mr_next(r) >> 32);
+}
+
+int
+pgv_kmeans_sharded(pgv_comm * cm, pgv_ops ops, pgv_dtype dtype, int dim, const void *samples, int n, int k,
+				   int max_iterations, const pgv_rng * rng, void *out_centers, int32_t *out_closest, int *out_iters)
+{
+	const int	R = cm->nranks;
+	const float *s = samples;
+	float	   *c = out_centers;
+	mock_rng	r = {rng, rng ? rng->seed : 0};
+	int64_t    *cnt = malloc(sizeof(int64_t) * (size_t) (R + 1));
+	int64_t		n_total = 0,
+				mine = n;
+	float	   *weight = malloc(sizeof(float) * (size_t) (n > 0 ? n : 1));
+	float	   *row = malloc(sizeof(float) * (size_t) dim * (size_t) (R + 1));
+	double	   *totals = malloc(sizeof(double) * (size_t) (R + 1));
+	size_t		rec = (size_t) k * dim + (size_t) k + 1;
+	float	   *record = malloc(sizeof(float) * rec);
+	int32_t    *closest = malloc(sizeof(int32_t) * (size_t) (n > 0 ? n : 1));
+	int			iters = 0,
+				rc = PGV_OK;
+
+	if (dtype != PGV_F32 || ops != PGV_OPS_L2)
+		return fail(PGV_ERR_ARG, "mock: fp32 / l2 only");
+	if (max_iterations <= 0)
+		max_iterations = 500;
+	/* every rank's sample count */
+	if ((rc = mc_all_gather(cm, &mine, cnt, sizeof(int64_t))) != PGV_OK)
+		goto done;
+	for (int q = 0; q < R; q++)
+		n_total += cnt[q];
+	if (n_total == 0)
+	{
+		for (size_t i = 0; i < (size_t) k * dim; i++)
+			c[i] = (float) mr_double(&r);	/* RandomCenters: the same draws on every rank */
+		goto done;
+	}
+	/* k-means++ (src/ivfkmeans.c:23-91) over the sharded sample */
+	for (int j = 0; j < n; j++)
+		weight[j] = 3.402823466e+38f;
+	{
+		int64_t		at = (int64_t) (mr_u32(&r) % (uint32_t) n_total);
+		int			owner = 0;
+
+		while (owner < R - 1 && at >= cnt[owner])
+			at -= cnt[owner++];
+		memset(row, 0, sizeof(float) * (size_t) dim);
+		if (owner == cm->rank)
+			memcpy(row, s + (size_t) at * dim, sizeof(float) * (size_t) dim);
+		if ((rc = mc_all_gather(cm, row, row + dim, sizeof(float) * (size_t) dim)) != PGV_OK)
+			goto done;
+		memcpy(c, row + dim + (size_t) owner * dim, sizeof(float) * (size_t) dim);
+	}
+	for (int i = 0; i + 1 < k; i++)
+	{
+		double		my_total = 0.0,
+					all = 0.0,
+					target;
+		int			owner = R - 1;
+
+		for (int j = 0; j < n; j++)
+		{
+			float		d = dist(PGV_L2SQ, dim, s + (size_t) j * dim, c + (size_t) i * dim);
+
+			if (d < weight[j])
+				weight[j] = d;
+			my_total += weight[j];
+		}
+		if ((rc = mc_all_gather(cm, &my_total, totals, sizeof(double))) != PGV_OK)
+			goto done;
+		for (int q = 0; q < R; q++)
+			all += totals[q];
+		target = mr_double(&r) * all;
+		for (int q = 0; q < R; q++)
+		{
+			if (target < totals[q] || q == R - 1)
+			{
+				owner = q;
+				break;
+			}
+			target -= totals[q];
+		}
+		memset(row, 0, sizeof(float) * (size_t) dim);
+		if (owner == cm->rank && n > 0)
+		{
+			int			pick = n - 1;
+			double		run = 0.0;
+
+			for (int j = 0; j < n; j++)
+			{
+				run += weight[j];
+				if (run > target)
+				{
+					pick = j;
+					break;
+				}
+			}
+			memcpy(row, s + (size_t) pick * dim, sizeof(float) * (size_t) dim);
+		}
+		if ((rc = mc_all_gather(cm, row, row + dim, sizeof(float) * (size_t) dim)) != PGV_OK)
+			goto done;
+		memcpy(c + (size_t) (i + 1) * dim, row + dim + (size_t) owner * dim, sizeof(float) * (size_t) dim);
+	}
+	/* Lloyd: one fused all-reduce per iteration (sums | counts | changes) */
+	for (int j = 0; j < n; j++)
+		closest[j] = -1;
+	for (int it = 0; it < max_iterations; it++)
+	{
+		float		changes = 0.f;
+
+		iters = it + 1;
+		memset(record, 0, sizeof(float) * rec);
+		for (int j = 0; j < n; j++)
+		{
+			int			best = 0;
+			float		bd = INFINITY;
+
+			for (int q = 0; q < k; q++)
+			{
+				float		d = dist(PGV_L2SQ, dim, s + (size_t) j * dim, c + (size_t) q * dim);
+
+				if (d < bd)
+				{
+					bd = d;
+					best = q;
+				}
+			}
+			if (best != closest[j])
+				changes += 1.f;
+			closest[j] = best;
+			record[(size_t) k * dim + best] += 1.f;
+			for (int d = 0; d < dim; d++)
+				record[(size_t) best * dim + d] += s[(size_t) j * dim + d];
+		}
+		record[rec - 1] = changes;
+		if ((rc = mc_all_reduce(cm, record, rec)) != PGV_OK)
+			goto done;
+		for (int q = 0; q < k; q++)
+		{
+			float		cn = record[(size_t) k * dim + q];
+
+			for (int d = 0; d < dim; d++)
+				c[(size_t) q * dim + d] = cn > 0.f ? record[(size_t) q * dim + d] / cn : (float) mr_double(&r);	/* empty: replicated draws */
+		}
+		if (record[rec - 1] == 0.f && it != 0)
+			break;
+	}
+	if (out_closest && n > 0)
+		memcpy(out_closest, closest, sizeof(int32_t) * (size_t) n);
+done:
+	if (out_iters)
+		*out_iters = iters;
+	free(cnt);
+	free(weight);
+	free(row);
+	free(totals);
+	free(record);
+	free(closest);
+	return rc;
+}
+
+int
+pgv_search_batch_sharded(pgv_comm * cm, pgv_index * ix, const void *queries, int nq, int probes, int k, float *out_dist,
+						 uint64_t *out_tid)
+{
+	const int	R = cm->nranks;
+	const int	per = (nq + R - 1) / R;
+	const int	lo = cm->rank * per < nq ? cm->rank * per : nq;
+	const int	hi = lo + per < nq ? lo + per : nq;
+	size_t		slice = (size_t) per * probes;
+	int32_t    *lists_mine = calloc(slice * (size_t) (R + 1), sizeof(int32_t));
+	int32_t    *lists_all = lists_mine + slice;
+	size_t		head = (size_t) nq * k;
+	float	   *dist_all = malloc(sizeof(float) * head * (size_t) (R + 1));
+	uint64_t   *tid_all = malloc(sizeof(uint64_t) * head * (size_t) (R + 1));
+	float	   *dist_mine = dist_all + head * R;
+	uint64_t   *tid_mine = tid_all + head * R;
+	float	   *d = malloc(sizeof(float) * (size_t) (ix->n > 0 ? ix->n : 1));
+	int64_t    *sl = malloc(sizeof(int64_t) * (size_t) (ix->n > 0 ? ix->n : 1));
+	int			rc;
+
+	if (!ix->tids)
+		return fail(PGV_ERR_STATE, "a sharded index needs heap tids");
+	/* GetScanLists: this rank's slice of the batch against the replicated centers */
+	if (hi > lo)
+		pgv_rank_lists(ix, (const float *) queries + (size_t) lo * ix->dim, hi - lo, probes, lists_mine, NULL);
+	if ((rc = mc_all_gather(cm, lists_mine, lists_all, sizeof(int32_t) * slice)) != PGV_OK)
+		goto done;
+	/* GetScanItems: the probed lists this rank owns (foreign lists are empty in the local index), whole batch */
+	for (int q = 0; q < nq; q++)
+	{
+		const float *qv = (const float *) queries + (size_t) q * ix->dim;
+		int64_t		m;
+
+		pgv_scan_lists(ix, qv, lists_all + (size_t) q * probes, probes, d, sl, ix->n, &m);
+		for (int r = 0; r < k; r++)
+		{
+			int64_t		best = -1;
+
+			for (int64_t i = 0; i < m; i++)
+				if (sl[i] >= 0 && (best < 0 || d[i] < d[best]))
+					best = i;
+			dist_mine[(size_t) q * k + r] = best >= 0 ? d[best] : INFINITY;
+			tid_mine[(size_t) q * k + r] = best >= 0 ? ix->tids[sl[best]] : ~(uint64_t) 0;
+			if (best >= 0)
+				sl[best] = -1 - sl[best];
+		}
+	}
+	if ((rc = mc_all_gather(cm, dist_mine, dist_all, sizeof(float) * head)) != PGV_OK ||
+		(rc = mc_all_gather(cm, tid_mine, tid_all, sizeof(uint64_t) * head)) != PGV_OK)
+		goto done;
+	/* the final top-k merge: ties go to the lower rank */
+	for (int q = 0; q < nq; q++)
+	{
+		int			at[16] = {0};
+
+		for (int r = 0; r < k; r++)
+		{
+			int			br = -1;
+
+			for (int p = 0; p < R; p++)
+				if (at[p] < k && (br < 0 || dist_all[(size_t) p * head + (size_t) q * k + at[p]] < dist_all[(size_t) br * head + (size_t) q * k + at[br]]))
+					br = p;
+			out_dist[(size_t) q * k + r] = dist_all[(size_t) br * head + (size_t) q * k + at[br]];
+			out_tid[(size_t) q * k + r] = tid_all[(size_t) br * head + (size_t) q * k + at[br]];
+			at[br]++;
+		}
+	}
+done:
+	free(lists_mine);
+	free(dist_all);
+	free(tid_all);
+	free(d);
+	free(sl);
+	return rc;
+}
