@@ -430,7 +430,7 @@ def backends_driver():
         d.backends_run.argtypes = [P, I, I, I, P, I, C.c_size_t, I, I, D, C.POINTER(D), C.c_char_p, C.c_size_t]
         d.pool_run.argtypes = [P, I, I, I, I, I, P, I, C.c_size_t, I, I, I, I, I, D, C.POINTER(D), C.c_char_p, C.c_size_t]
         d.backends_run_processes.argtypes = [P, C.c_char_p, I, I, I, I, I, P, I, C.c_size_t, I, I, I, I, I, I, I, I,
-                                             C.c_char_p, I, D, P, P, C.POINTER(D), C.c_char_p, C.c_size_t]
+                                             C.c_char_p, I, D, I, P, P, C.POINTER(D), C.c_char_p, C.c_size_t]
         _drv = d
     return _drv
 
@@ -498,7 +498,7 @@ def run_pooled_threads(index, queries, probes, k, nclients, per_thread, max_batc
 
 def run_backend_processes(index, queries, probes, k, mode, nclients, per_client, warmup=5, max_batch=1024,
                           max_wait_us=50, lanes=2, server_processes=True, verify=False, image_shm=None, device=0,
-                          deadline_s=60.0):
+                          deadline_s=60.0, chaos=0):
     """N backend PROCESSES against one device mirror.  mode 0: every process imports the mirror and runs
     pgv_query_*; mode 1: GPU-less clients behind the shared-memory pooler.  Returns a dict (qps, latencies, mean
     batch, HBM that went to the children) and, with verify, the answers [nclients, per_client, k]."""
@@ -513,11 +513,12 @@ def run_backend_processes(index, queries, probes, k, mode, nclients, per_client,
                                   device, mode, nclients, per_client, warmup, q.ctypes.data, q.shape[0], q.strides[0],
                                   index.dtype if index is not None else (0 if q.dtype == np.float32 else 1), q.shape[1],
                                   probes, k, max_batch, max_wait_us, lanes, 1 if server_processes else 0,
-                                  BACKEND_EXE.encode(), 1 if verify else 0, float(deadline_s),
+                                  BACKEND_EXE.encode(), 1 if verify else 0, float(deadline_s), int(chaos),
                                   ans_t.ctypes.data if verify else None, ans_d.ctypes.data if verify else None,
                                   out, err, len(err))
     if rc != 0:
         raise _lib.PgvError(rc, "backends_run_processes: " + err.value.decode("utf-8", "replace"))
     res = {"qps": out[0], "latency_us_p50": out[1], "latency_us_p90": out[2], "mean_batch": out[3],
-           "hbm_bytes_taken_by_children": out[4], "processes": int(out[5])}
+           "hbm_bytes_taken_by_children": out[4], "processes": int(out[5]), "clients_completed": int(out[6]),
+           "clients_failed": int(out[7])}
     return (res, ans_t, ans_d) if verify else res

@@ -48,11 +48,12 @@ extern int	pgv_host_fail(int code, const char *fmt,...);
 void		pgv_host_pool_destroy(pgv_pool * pool);
 
 #define POOL_MAGIC 0x7067765f706f6f6cull	/* "pgv_pool" */
-#define POOL_VERSION 3
+#define POOL_VERSION 4
 #define POOL_MAX_LANES 8
 #define POOL_ALIGN 4096
 #define POOL_RECLAIM_US 2000000		/* a published batch nobody finished reading: its clients are gone */
 #define POOL_READY_US 200000		/* a client between taking its slot and the end of its payload copy */
+#define POOL_LEADER_DEAD_US 3000000	/* a lane whose server has not looked for this long has lost it (it looks every 50 ms) */
 
 enum
 {
@@ -73,11 +74,13 @@ typedef struct
 	uint32_t	fill;			/* bumped when the lane's server should look again (futex word) */
 	int64_t		t_open;			/* now_us() of the batch's first query */
 	int64_t		t_published;
+	int64_t		beat;			/* now_us() of the server's last turn of its loop: 0 = no server has led this lane yet;
+								 * stale = its server died (kill -9 runs no exit path): clients neither join nor wait */
 	uint64_t	q_off,			/* offsets from the segment's base */
 				tid_off,
 				dist_off;
 	char		errmsg[160];
-	char		pad[32];
+	char		pad[24];
 }			shm_lane;
 
 typedef struct
@@ -316,6 +319,15 @@ pgv_host_pool_is_shut_down(pgv_pool * pool)
 	return pool == NULL || __atomic_load_n(&pool->s->shutdown, __ATOMIC_ACQUIRE) != 0;
 }
 
+/* does somebody lead this lane?  (A server that was killed stops beating; one that left cleanly zeroed the word.) */
+static int
+lane_is_led(const shm_lane * l, int64_t now)
+{
+	int64_t		beat = __atomic_load_n(&l->beat, __ATOMIC_ACQUIRE);
+
+	return beat != 0 && now - beat < POOL_LEADER_DEAD_US;
+}
+
 /* the last reader (or the lane's server, for a batch whose clients vanished) hands the lane back */
 static void
 lane_release(shm_pool * s, shm_lane * l)
@@ -358,6 +370,21 @@ pgv_host_pool_serve(pgv_pool * pool, int lane, pgv_index * view)
 	pinned_q = pgv_pinned_register(q, align_up(s->row_bytes * (size_t) s->max_batch)) == PGV_OK;
 	pinned_t = pgv_pinned_register(tids, align_up(sizeof(uint64_t) * (size_t) s->max_batch * s->k)) == PGV_OK;
 	pinned_d = pgv_pinned_register(dist, align_up(sizeof(float) * (size_t) s->max_batch * s->k)) == PGV_OK;
+	/* a lane whose previous leader died in mid-batch is in whatever state it left: its clients have been told (or will
+	 * time out on the old batch number); the lane starts over */
+	pool_lock(s);
+	if (l->state != LANE_FREE)
+	{
+		if (s->collecting == lane)
+			s->collecting = -1;
+		l->state = LANE_FREE;
+		l->count = 0;
+		__atomic_store_n(&l->done_gen, l->gen, __ATOMIC_RELEASE);	/* nobody waits for a batch that will not come */
+		__atomic_store_n(&l->readers, (uint64_t) l->gen << 32, __ATOMIC_RELEASE);
+		__atomic_add_fetch(&s->free_epoch, 1, __ATOMIC_RELEASE);
+	}
+	pool_unlock(s);
+	__atomic_store_n(&l->beat, now_us(), __ATOMIC_RELEASE);	/* led from now on (clients join led lanes only) */
 	__atomic_add_fetch(&s->servers, 1, __ATOMIC_RELEASE);
 	word_wake_all(&s->servers);
 
@@ -377,6 +404,7 @@ pgv_host_pool_serve(pgv_pool * pool, int lane, pgv_index * view)
 			if (__atomic_load_n(&s->shutdown, __ATOMIC_ACQUIRE))
 				goto done;
 			t = now_us();
+			__atomic_store_n(&l->beat, t, __ATOMIC_RELEASE);
 			pool_lock(s);
 			if (l->state == LANE_COLLECTING && l->count > 0)
 			{
@@ -436,7 +464,9 @@ pgv_host_pool_serve(pgv_pool * pool, int lane, pgv_index * view)
 				__builtin_ia32_pause();	/* a client between its slot and the end of its 6 KB memcpy */
 		}
 
+		__atomic_store_n(&l->beat, now_us(), __ATOMIC_RELEASE);
 		rc = pgv_search_batch(view, q, n, s->probes, s->k, dist, NULL, tids);
+		__atomic_store_n(&l->beat, now_us(), __ATOMIC_RELEASE);
 
 		/* publish: the clients sleep on done_gen */
 		l->rc = rc;
@@ -454,6 +484,7 @@ pgv_host_pool_serve(pgv_pool * pool, int lane, pgv_index * view)
 		word_wake_all(&l->done_gen);
 	}
 done:
+	__atomic_store_n(&l->beat, 0, __ATOMIC_RELEASE);
 	__atomic_sub_fetch(&s->servers, 1, __ATOMIC_RELEASE);
 	if (pinned_q)
 		pgv_pinned_unregister(q);
@@ -478,6 +509,7 @@ pgv_host_pool_search(pgv_pool * pool, const void *query, uint64_t *out_tid, floa
 				seen;
 	int			rc,
 				kick;
+	int64_t		t_arrived = now_us();
 
 	if (!pool || !query || !out_tid || !out_dist)
 		return pgv_host_fail(PGV_ERR_ARG, "pgv_host_pool_search: pool/query/out is NULL");
@@ -491,10 +523,13 @@ pgv_host_pool_search(pgv_pool * pool, const void *query, uint64_t *out_tid, floa
 	{
 		uint32_t	epoch;
 
+		/* a batch that collects in a lane whose leader has died will never run: nobody else joins it */
+		if (s->collecting >= 0 && !lane_is_led(&s->lanes[s->collecting], now_us()))
+			s->collecting = -1;
 		if (s->collecting >= 0)
 			break;
 		for (uint32_t i = 0; i < s->nlanes; i++)
-			if (s->lanes[i].state == LANE_FREE)
+			if (s->lanes[i].state == LANE_FREE && lane_is_led(&s->lanes[i], now_us()))
 			{
 				s->collecting = (int32_t) i;
 				s->lanes[i].state = LANE_COLLECTING;
@@ -512,6 +547,21 @@ pgv_host_pool_search(pgv_pool * pool, const void *query, uint64_t *out_tid, floa
 			s->arriving--;
 			pool_unlock(s);
 			return pgv_host_fail(PGV_ERR_STATE, "pgv_host_pool_search: the pool is shut down");
+		}
+		{
+			/* no lane to join: busy ones come free.  But when NO lane has a live server (none attached for five
+			 * seconds, or every leader dead) there is nothing to wait for */
+			int64_t		t = now_us();
+			int			led = 0;
+
+			for (uint32_t i = 0; i < s->nlanes; i++)
+				led += lane_is_led(&s->lanes[i], t);
+			if (led == 0 && t - t_arrived > 5000000)
+			{
+				s->arriving--;
+				pool_unlock(s);
+				return pgv_host_fail(PGV_ERR_STATE, "pgv_host_pool_search: no server is attached to the pool");
+			}
 		}
 		pool_unlock(s);
 		word_wait_us(&s->free_epoch, epoch, 100000);
@@ -545,6 +595,15 @@ pgv_host_pool_search(pgv_pool * pool, const void *query, uint64_t *out_tid, floa
 			return pgv_host_fail(PGV_ERR_STATE, "pgv_host_pool_search: the pool was shut down under a waiting query");
 		if (__atomic_load_n(&s->servers, __ATOMIC_ACQUIRE) == 0 && now_us() - l->t_open > 5000000)
 			return pgv_host_fail(PGV_ERR_STATE, "pgv_host_pool_search: no server is attached to the pool");
+		/* the lane's leader died under the batch (kill -9, a crash): nobody will publish it */
+		if (!lane_is_led(l, now_us()) && now_us() - l->t_open > POOL_LEADER_DEAD_US)
+		{
+			pool_lock(s);
+			if (s->collecting == lane)
+				s->collecting = -1;	/* (the lane itself stays out of use: it is never FREE again) */
+			pool_unlock(s);
+			return pgv_host_fail(PGV_ERR_STATE, "pgv_host_pool_search: the lane's server is gone");
+		}
 		word_wait_us(&l->done_gen, seen, 100000);
 	}
 	if (seen != gen)

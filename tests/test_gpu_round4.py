@@ -57,3 +57,55 @@ def test_mfma_fp16_chain_rounds_to_nearest(ctx, nq):
     queries[:, 0], queries[:, 128] = 1.0, np.float16(1.5 * 2.0 ** -12)
     v = _ip_values(ctx, api.PGV_F16, rows, queries)
     assert (v[:, 0] == np.float32(1.0 + 2.0 ** -23)).all(), v[:, 0].astype(np.float64) - 1.0
+
+
+# ------------------------------------------------- nobody may hang: the gate, clients that die, leaders that die
+def _small_index(ctx, oracle):
+    from oracle import pyoracle as po
+    from helpers import CpuIvf, gen
+    n, dim, lists = 20000, 96, 40
+    data = gen(n, dim, seed=901, dist="clustered", clusters=lists)
+    ivf = CpuIvf(oracle, po.OPS_L2, po.ORA_F32, data, lists)
+    ix = api.IvfIndex(ctx, ivf.metric, api.PGV_F32, dim, ivf.centers, ivf.list_offsets, ivf.vectors, ivf.tids)
+    queries = gen(64, dim, seed=902, dist="clustered", clusters=lists)
+    return ix, queries
+
+
+def test_gate_passes_100k_queries_from_32_threads(ctx, oracle):
+    """BENCH_r03's hang: 32 backends behind a 16-wide admission gate that lost wake-ups.  102 400 single-query scans
+    from 32 threads (a thread that is not back after the deadline is named with the call it sits in)."""
+    from pgvector_amd import _host
+    ix, queries = _small_index(ctx, oracle)
+    try:
+        for _ in range(2):
+            r = _host.run_backend_threads(ix, queries, 4, 10, 32, 1600, device=0, deadline_s=120.0)
+            assert r["qps"] > 1000.0
+    finally:
+        ix.close()
+
+
+def test_a_pooled_client_killed_in_mid_query_wedges_nobody(ctx, oracle):
+    """kill -9 of a backend that waits for its batch (a robust mutex, bounded straggler waits, reclaimed lanes): the
+    other 15 clients answer every query"""
+    from pgvector_amd import _host
+    ix, queries = _small_index(ctx, oracle)
+    try:
+        r = _host.run_backend_processes(ix, queries, 4, 10, 1, 16, 2000, max_batch=8, max_wait_us=100, lanes=2,
+                                        server_processes=True, deadline_s=60.0, chaos=1)
+        assert r["clients_completed"] == 15 and r["clients_failed"] == 1, r
+    finally:
+        ix.close()
+
+
+def test_a_lane_leader_killed_under_its_batch_fails_its_clients_and_only_them(ctx, oracle):
+    """kill -9 of the process that leads lane 0: the clients whose batch sat there get PGV_ERR_STATE within seconds (the
+    lane's heartbeat stops), nobody joins that lane again, the others go on through lane 1"""
+    from pgvector_amd import _host
+    ix, queries = _small_index(ctx, oracle)
+    try:
+        r = _host.run_backend_processes(ix, queries, 4, 10, 1, 16, 3000, max_batch=4, max_wait_us=100, lanes=2,
+                                        server_processes=True, deadline_s=60.0, chaos=2)
+        assert r["clients_completed"] + r["clients_failed"] == 16, r
+        assert r["clients_completed"] >= 8 and r["clients_failed"] <= 8, r
+    finally:
+        ix.close()

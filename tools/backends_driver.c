@@ -391,6 +391,10 @@ pool_run(pgv_index * index, int device, int dtype, int dim, int nclients, int pe
  *   owner   who uploads and exports the mirror: the calling process (`index`), or -- when `image_shm` names a
  *           pgvb_image segment -- a separate owner process (then every participant runs the same HIP runtime)
  *
+ * chaos (tests): bit 0 = SIGKILL client 0 20 ms into the run, bit 1 = SIGKILL the first lane server 20 ms into the run.
+ * Nobody may hang: the other clients finish, or -- those whose batch sat in the dead server's lane -- fail with
+ * PGV_ERR_STATE; out[6] = clients that answered every query, out[7] = clients that failed or were killed.
+ *
  * out[0] queries/s, [1] p50 us, [2] p90 us, [3] mean batch (mode 1), [4] bytes of HBM that went away between "before
  * any child" and "all children at the start line" (contexts + scratch of every process, the mirror NOT among them
  * unless a separate owner uploaded it), [5] processes spawned.  ans_tid / ans_dist [nclients x per_client x k] or NULL.
@@ -447,7 +451,7 @@ int
 backends_run_processes(pgv_index * index, const char *image_shm, int device, int mode, int nclients, int per_client,
 					   int warmup, const void *queries, int nq, size_t query_bytes, int dtype, int dim, int probes, int k,
 					   int max_batch, int max_wait_us, int lanes, int server_processes, const char *exe, int verify,
-					   double deadline_s, uint64_t *ans_tid, float *ans_dist, double *out, char *errbuf, size_t errcap)
+					   double deadline_s, int chaos, uint64_t *ans_tid, float *ans_dist, double *out, char *errbuf, size_t errcap)
 {
 	char		pool_name[64],
 				bank_name[64],
@@ -469,6 +473,8 @@ backends_run_processes(pgv_index * index, const char *image_shm, int device, int
 				queries0 = 0,
 				batches1 = 0,
 				queries1 = 0;
+	int			completed = 0,
+				failed = 0;
 
 	if (errbuf && errcap)
 		errbuf[0] = 0;
@@ -600,11 +606,21 @@ backends_run_processes(pgv_index * index, const char *image_shm, int device, int
 	pgv_host_pool_stats(pool, &batches0, &queries0);
 	__atomic_store_n(&bank->go, 1, __ATOMIC_RELEASE);
 	syscall(SYS_futex, &bank->go, FUTEX_WAKE, INT_MAX, NULL, NULL, 0);
+	if (chaos)
+	{
+		usleep(20000);
+		if (chaos & 1)
+			kill(pids[npids - nclients], SIGKILL);	/* a backend dies in mid-query */
+		if ((chaos & 2) && mode == 1 && server_processes)
+			kill(pids[image_shm ? 1 : 0], SIGKILL);	/* the leader of lane 0 dies under its batch */
+	}
 	/* the clients are the last nclients pids; a run that does not end in 90 s is given up (the children are killed
 	 * below) -- a measurement harness must not be able to hang its caller */
 	{
 		double		deadline = now() + (deadline_s > 0 ? deadline_s : 90.0);
 		int			left = nclients;
+
+		completed = failed = 0;
 
 		while (left > 0)
 		{
@@ -618,6 +634,14 @@ backends_run_processes(pgv_index * index, const char *image_shm, int device, int
 				if (waitpid(pids[i], &st, WNOHANG) == pids[i])
 				{
 					pids[i] = 0;
+					if (WIFEXITED(st) && WEXITSTATUS(st) == 0)
+						completed++;
+					else
+						failed++;
+					/* under chaos a killed client and clients that were told PGV_ERR_STATE are what is expected */
+					if (chaos && ((WIFSIGNALED(st) && i == npids - nclients && (chaos & 1)) ||
+								  (WIFEXITED(st) && WEXITSTATUS(st) == 20 + PGV_ERR_STATE && (chaos & 2))))
+						continue;
 					if ((!WIFEXITED(st) || WEXITSTATUS(st) != 0) && rc == PGV_OK)
 					{
 						pgvb_client *cl = (pgvb_client *) ((char *) bank + bank->clients_off) + (i - (npids - nclients));
@@ -664,6 +688,8 @@ backends_run_processes(pgv_index * index, const char *image_shm, int device, int
 		out[3] = batches1 > batches0 ? (double) (queries1 - queries0) / (double) (batches1 - batches0) : 0.0;
 		out[4] = (double) free0 - (double) free1;
 		out[5] = (double) npids;
+		out[6] = (double) completed;
+		out[7] = (double) failed;
 	}
 out:
 	if (pool)
