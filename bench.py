@@ -87,6 +87,8 @@ WORKLOADS = {
     # BASELINE configs[2] / configs[4] at full size: for --gpus 8 (1.25 M rows per GPU; one GPU holds them too, 61 GB)
     "c3": (10_000_000, 1536, 4096, 64, "f32", "ip"),
     "c5": (10_000_000, 3072, 4096, 64, "f16", "l2"),
+    # configs[2]'s shape at reduced rows, for a functional N-rank run on ONE GPU (--gpus 8 --backend gloo)
+    "c3small": (320_000, 1536, 256, 16, "f32", "ip"),
     "small": (100_000, 256, 100, 10, "f32", "l2"),          # quick functional run
     "smallh": (100_000, 512, 100, 10, "f16", "ip"),
 }
