@@ -1430,6 +1430,18 @@ int pgv_scan_lists(pgv_index *ix, const void *query, const int32_t *lists, int n
     return sync_if(ctx, need);
 }
 
+// k' of the MFMA L2 paths: the candidates kept per query by the expansion's values.  4 k rounded UP to the power of two
+// the selection pads to anyway (k = 10: 64 instead of 40 at no cost in topk_kernel, and the recheck reads only the
+// rounding band's prefix) -- which is what lets the deterministic band of a 3072-d halfvec scan (~50 candidates wide)
+// fit without the widening pass; k + 64 past 64
+static int approx_candidates(int k) {
+    if (k <= 8) return 32;
+    if (4 * k > 256) return k + 64;
+    int kp = 64;
+    while (kp < 4 * k) kp <<= 1;
+    return kp;
+}
+
 // GetScanItems + head of the sorted stream for staged queries and device probe lists
 static int scan_batch_dev(pgv_index *ix, const void *q_dev, int nq, const int32_t *probe_lists, int probes,
                           int k, float *out_dist, int64_t *out_slot, uint64_t *out_tid) {
@@ -1481,7 +1493,7 @@ static int scan_batch_dev(pgv_index *ix, const void *q_dev, int nq, const int32_
     if (approx) {
         // 32 .. 256 candidates: the head asked for and a margin the rounding bound clears easily (4 k while that
         // fits batch_recheck_kernel's 256, k + 64 beyond)
-        kprime = k <= 8 ? 32 : (4 * k <= 256 ? 4 * k : k + 64);
+        kprime = approx_candidates(k);
         PGV_TRY(sc.carve(ctx, ctx->ms_a, nq, kprime));
     }
     float *cand_val = sc.cand_val;
@@ -1875,7 +1887,7 @@ int pgv_exact_topk(pgv_ctx *ctx, pgv_metric metric, pgv_dtype dtype, int dim, co
     // the distance matrix of a query chunk stays under 1 GiB
     int chunk = n > 0 ? (int)std::min<int64_t>(nq, std::max<int64_t>(1, ((int64_t)1 << 28) / n)) : nq;
     if (chunk >= 64) chunk = chunk / 32 * 32;
-    const int kprime = k <= 8 ? 32 : (4 * k <= 256 ? 4 * k : k + 64);
+    const int kprime = approx_candidates(k);
     const bool l2_mfma = metric == PGV_L2SQ && kprime <= 256 && n > kprime;
     const bool mfma_ok = !ctx->no_mfma_scan && n >= 64 && (metric == PGV_NEG_IP || l2_mfma);
     float *norms = nullptr;

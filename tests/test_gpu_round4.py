@@ -109,3 +109,72 @@ def test_a_lane_leader_killed_under_its_batch_fails_its_clients_and_only_them(ct
         assert r["clients_completed"] >= 8 and r["clients_failed"] <= 8, r
     finally:
         ix.close()
+
+
+# ------------------------------------------------- BASELINE-scale parity against the oracle, in the test suite
+@pytest.mark.parametrize("name,n,dim,lists,probes,tdt,metric,ops", [
+    ("headline", 1_000_000, 1536, 1000, 10, "f32", "l2", "l2"),        # BASELINE.json's metric
+    ("c5shard", 1_250_000, 3072, 512, 8, "f16", "l2", "l2"),           # one GPU's share of configs[4]
+    ("c3shard", 1_250_000, 1536, 512, 8, "f32", "ip", "ip"),           # one GPU's share of configs[2]
+])
+def test_config_scale_answers_are_the_oracles(ctx, oracle, name, n, dim, lists, probes, tdt, metric, ops):
+    """round 3's verdict: parity at the configs' full sizes was observed by bench.py only.  The index is built on the
+    GPU (k-means, assignment, the device tuplesort: pgv_builder_*), 64 queries go through the batched MFMA scan under
+    the deterministic bound AND one at a time through the single-query path; the oracle answers the same queries from
+    the same centers / rows on the CPU (GetScanLists + GetScanItems + sort, src/ivfscan.c:47-187)."""
+    import torch
+    from oracle import pyoracle as po
+    from helpers import assert_topk_equiv
+    dev = torch.device("cuda", 0)
+    g = torch.Generator(device=dev)
+    g.manual_seed(1234)
+    comps = max(lists // 4, 1)
+    means = torch.rand((comps, dim), generator=g, device=dev)
+    tdtype = torch.float32 if tdt == "f32" else torch.float16
+    data = torch.empty((n, dim), device=dev, dtype=tdtype)
+    for lo in range(0, n, 1 << 17):
+        hi = min(n, lo + (1 << 17))
+        comp = torch.randint(0, comps, (hi - lo,), generator=g, device=dev)
+        data[lo:hi] = (means[comp] + 0.1 * torch.randn((hi - lo, dim), generator=g, device=dev)).to(tdtype)
+    dtype = api.PGV_F32 if tdt == "f32" else api.PGV_F16
+    pops = api.PGV_OPS_L2 if ops == "l2" else api.PGV_OPS_IP
+    pmetric = api.PGV_L2SQ if metric == "l2" else api.PGV_NEG_IP
+    ns = min(max(50 * lists, 10000), n)
+    samples = data[torch.randperm(n, generator=g, device=dev)[:ns]].contiguous()
+    if ops != "l2":
+        s32 = samples.float()
+        samples = (s32 / s32.norm(dim=1, keepdim=True).clamp_min(1e-30)).to(tdtype).contiguous()
+    centers, _, _ = api.kmeans(ctx, pops, dtype, dim, samples, lists, api.make_rng(seed=5), want_closest=False)
+    b = api.IvfBuilder(ctx, pmetric, dtype, dim, centers, expected_rows=n)
+    b.add(data)
+    index, offsets_h, lists_h = b.finish(want_lists=True)
+    b.close()
+    order = np.argsort(lists_h.astype(np.int64), kind="stable")
+    host_rows = data.cpu().numpy()[order]
+    del data
+    nq, k = 512, 10            # enough queries per list for the matrix-core scan (nq x probes > 3 x lists)
+    comp = torch.randint(0, comps, (nq,), generator=g, device=dev)
+    queries = (means[comp] + 0.1 * torch.randn((nq, dim), generator=g, device=dev)).to(tdtype).contiguous()
+    ctx.set_profiling(True)
+    ctx.reset_stats()
+    gd, gs, gt = index.search_batch(queries, probes, k, want_tid=True)
+    st = ctx.stats()
+    ctx.set_profiling(False)
+    assert st["scan_launches"] >= 1 and st["scan_redo_queries"] == 0        # the matrix-core scan, deterministic bound
+    gd, gt = gd.cpu().numpy(), gt.cpu().numpy()
+    centers_h = centers.cpu().numpy() if hasattr(centers, "cpu") else np.asarray(centers)
+    ix = oracle.index_struct(po.OPS_L2 if ops == "l2" else po.OPS_IP, po.ORA_F32 if tdt == "f32" else po.ORA_F16, centers_h,
+                             offsets_h, host_rows, order.astype(np.uint64))
+    qh = queries.cpu().numpy()
+    single = api.Query(index)
+    for i in range(0, nq, 4):
+        wt, wd = oracle.search(ix, qh[i], probes, k)
+        assert_topk_equiv(gt[i][:len(wt)].astype(np.uint64).tolist(), gd[i][:len(wt)], wt.tolist(), wd,
+                          what="%s batched q%d" % (name, i))
+        if i < 64:
+            single.rank(qh[i], probes)
+            d1, s1, t1, _ = single.scan(0, probes, k)
+            assert_topk_equiv(np.asarray(t1)[:len(wt)].astype(np.uint64).tolist(), np.asarray(d1)[:len(wt)], wt.tolist(), wd,
+                              what="%s single q%d" % (name, i))
+    single.close()
+    index.close()
