@@ -73,6 +73,9 @@ def main():
     scans = [(dur, lds, vgpr, grid) for name, dur, lds, vgpr, grid, wg in trace if name == main]
     timed = scans[-2 * steps:]  # alternating rank / scan launches of the timed loop
     list_scan = [s for s in timed if s[0] > 5 * min(t[0] for t in timed)]
+    if not list_scan and timed and max(t[0] for t in timed) < 2 * min(t[0] for t in timed):
+        # (round 4: the center ranking runs another instantiation -- every launch of this one is a list scan)
+        list_scan = scans[-steps:]
     if list_scan:
         avg = sum(s[0] for s in list_scan) / len(list_scan)
         lines += ["", "## timed list-scan launches (%s)" % main, "",
@@ -91,6 +94,8 @@ def main():
         n = b["steps"]
         timed = rows[-2 * n:]
         big = [r for r in timed if r[2] > 5 * min(t[2] for t in timed)]
+        if not big and timed and max(t[2] for t in timed) < 2 * min(t[2] for t in timed):
+            big = rows[-n:]
         if not big:
             continue
         val = sum(r[1] for r in big) / len(big)
