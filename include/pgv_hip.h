@@ -570,6 +570,14 @@ int			pgv_hnsw_get_payload(pgv_hnsw * h, const int64_t *elements, int n, void *o
  * which reallocates the graph -- needs a new export.
  */
 int			pgv_hnsw_export(pgv_hnsw * h, pgv_index_handle * out);
+/*
+ * A read-only view of a mirror for ANOTHER context of the same process (its own stream, scratch and visited
+ * bitmaps; the element rows, the payload and the graph stay the owner's and follow the owner's pgv_hnsw_set_graph /
+ * pgv_hnsw_update_graph): pgv_index_share's twin.  The HNSW build runs the next batch's searches on one while the
+ * current batch's lists are replayed (pgvector_amd/host/hnsw_build.c).  Free the view before the owner.
+ */
+int			pgv_hnsw_share(pgv_hnsw * h, pgv_ctx * ctx, pgv_hnsw * *out);
+int			pgv_hnsw_device(const pgv_hnsw * h);	/* the device the mirror lives on (-1: NULL) */
 int			pgv_hnsw_import(pgv_ctx * ctx, const pgv_index_handle * handle, pgv_hnsw * *out);
 
 /*

@@ -43,7 +43,7 @@ SYMBOLS = [
     "pgv_comm_unique_id", "pgv_comm_create", "pgv_comm_create_custom", "pgv_comm_destroy", "pgv_comm_size",
     "pgv_comm_rank", "pgv_kmeans_sharded", "pgv_search_batch_sharded",
     "pgv_device_memory", "pgv_pinned_register", "pgv_pinned_unregister", "pgv_index_export", "pgv_index_import",
-    "pgv_index_tids", "pgv_hnsw_export", "pgv_hnsw_import", "pgv_exact_topk", "pgv_ctx_set_bound",
+    "pgv_index_tids", "pgv_hnsw_export", "pgv_hnsw_import", "pgv_hnsw_share", "pgv_hnsw_device", "pgv_exact_topk", "pgv_ctx_set_bound",
     "pgv_hnsw_upload_payload", "pgv_hnsw_get_payload", "pgv_builder_begin", "pgv_builder_add", "pgv_builder_set_centers", "pgv_builder_rows", "pgv_builder_finish", "pgv_builder_free", "pgv_index_drain",
 ]
 
@@ -110,6 +110,8 @@ def _load():
     lib.pgv_index_import.argtypes = [P, P, C.POINTER(P)]
     lib.pgv_index_tids.argtypes = [P, P, I64, P]
     lib.pgv_hnsw_export.argtypes = [P, P]
+    lib.pgv_hnsw_share.argtypes = [P, P, C.POINTER(P)]
+    lib.pgv_hnsw_device.argtypes = [P]
     lib.pgv_hnsw_upload_payload.argtypes = [P, I, I, I, P, I64, P, I, C.POINTER(P)]
     lib.pgv_hnsw_get_payload.argtypes = [P, P, I, P]
     lib.pgv_exact_topk.argtypes = [P, I, I, I, P, I, P, I64, I, P, P]

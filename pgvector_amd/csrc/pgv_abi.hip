@@ -2736,9 +2736,51 @@ int pgv_hnsw_upload_payload(pgv_ctx *ctx, pgv_metric metric, pgv_dtype dtype, in
     return PGV_OK;
 }
 
+// a view follows its owner: the graph may have been (re)set and the entry point moved since the view was made
+static void hnsw_view_refresh(pgv_hnsw *h) {
+    const pgv_hnsw *o = h->view_of;
+    if (!o) return;
+    h->graph = o->graph;
+    h->levels = o->levels;
+    h->nbr_start = o->nbr_start;
+    h->nbr = o->nbr;
+    h->m = o->m;
+    h->entry = o->entry;
+    h->graph_bytes = o->graph_bytes;
+    h->nbr_total = o->nbr_total;
+}
+
+int pgv_hnsw_device(const pgv_hnsw *h) { return h && h->ctx ? h->ctx->device : -1; }
+
+int pgv_hnsw_share(pgv_hnsw *h, pgv_ctx *ctx, pgv_hnsw **out) {
+    if (!h || !ctx || !out) PGV_FAIL(PGV_ERR_ARG, "pgv_hnsw_share: mirror/ctx/out is NULL");
+    *out = nullptr;
+    if (ctx->device != h->ctx->device) PGV_FAIL(PGV_ERR_ARG, "pgv_hnsw_share: the mirror lives on another device");
+    pgv_hnsw *v = new (std::nothrow) pgv_hnsw();
+    if (!v) PGV_FAIL(PGV_ERR_NOMEM, "out of host memory");
+    v->ctx = ctx;
+    v->metric = h->metric;
+    v->dtype = h->dtype;
+    v->dim = h->dim;
+    v->n = h->n;
+    v->geom = h->geom;
+    v->elements = h->elements;
+    v->payload = h->payload;
+    v->payload_bytes = h->payload_bytes;
+    v->view_of = h->view_of ? h->view_of : h;
+    hnsw_view_refresh(v);
+    *out = v;
+    return PGV_OK;
+}
+
 void pgv_hnsw_free(pgv_hnsw *h) {
     if (!h) return;
     if (h->ctx) (void)hipStreamSynchronize(h->ctx->stream);
+    if (h->view_of) {  // the owner's allocations stay
+        h->bitmaps.release();
+        delete h;
+        return;
+    }
     if (h->imported) {
         if (h->elements) (void)hipIpcCloseMemHandle(h->elements);
         if (h->graph) (void)hipIpcCloseMemHandle(h->graph);
@@ -2764,7 +2806,7 @@ static constexpr uint64_t kHnswHandleMagic = 0x7067765f686e7731ull;  // "pgv_hnw
 
 int pgv_hnsw_export(pgv_hnsw *h, pgv_index_handle *out) {
     if (!h || !out) PGV_FAIL(PGV_ERR_ARG, "pgv_hnsw_export: handle/out is NULL");
-    if (h->imported) PGV_FAIL(PGV_ERR_STATE, "pgv_hnsw_export: export from the process that uploaded the mirror");
+    if (h->imported || h->view_of) PGV_FAIL(PGV_ERR_STATE, "pgv_hnsw_export: export from the process that uploaded the mirror");
     if (!h->elements || !h->graph || h->m == 0)
         PGV_FAIL(PGV_ERR_STATE, "pgv_hnsw_export: needs a non-empty mirror with its graph set (pgv_hnsw_set_graph)");
     PGV_HIP(hipSetDevice(h->ctx->device));
@@ -2892,7 +2934,7 @@ int pgv_hnsw_score(pgv_hnsw *h, const void *queries, int nq, const int32_t *slot
 int pgv_hnsw_set_graph(pgv_hnsw *h, int m, int32_t entry, const int32_t *levels, const int64_t *nbr_start,
                        const int32_t *nbr) {
     if (!h) PGV_FAIL(PGV_ERR_ARG, "pgv_hnsw_set_graph: handle is NULL");
-    if (h->imported) PGV_FAIL(PGV_ERR_STATE, "pgv_hnsw_set_graph: an imported mirror is read-only");
+    if (h->imported || h->view_of) PGV_FAIL(PGV_ERR_STATE, "pgv_hnsw_set_graph: an imported mirror / a view is read-only");
     if (m < 2 || m > 100) PGV_FAIL(PGV_ERR_ARG, "m must be 2..100 (src/hnsw.h:55-56), got %d", m);
     if (entry < -1 || entry >= h->n) PGV_FAIL(PGV_ERR_ARG, "entry point %d out of range", (int)entry);
     if (h->n > 0 && (!levels || !nbr_start || !nbr)) PGV_FAIL(PGV_ERR_ARG, "levels/nbr_start/nbr is NULL");
@@ -2932,6 +2974,7 @@ int pgv_hnsw_set_graph(pgv_hnsw *h, int m, int32_t entry, const int32_t *levels,
 int pgv_hnsw_search(pgv_hnsw *h, const void *queries, int nq, int ef_search, int k, int64_t *out_elem,
                     float *out_dist, int64_t *out_scored) {
     if (!h || !out_elem || !out_dist) PGV_FAIL(PGV_ERR_ARG, "pgv_hnsw_search: handle/out is NULL");
+    hnsw_view_refresh(h);
     if (nq < 0) PGV_FAIL(PGV_ERR_ARG, "bad query count");
     if (ef_search < 1 || ef_search > 1000)
         PGV_FAIL(PGV_ERR_ARG, "hnsw.ef_search must be 1..1000 (src/hnsw.c:93-94), got %d", ef_search);
@@ -2972,6 +3015,7 @@ int pgv_hnsw_search(pgv_hnsw *h, const void *queries, int nq, int ef_search, int
 int pgv_hnsw_build_search(pgv_hnsw *h, const int32_t *elements, const int32_t *insert_levels, int nq,
                           int ef_construction, int layer_cap, int32_t *out_ids, float *out_dist, int32_t *out_count) {
     if (!h || !out_ids || !out_dist || !out_count) PGV_FAIL(PGV_ERR_ARG, "pgv_hnsw_build_search: handle/out is NULL");
+    hnsw_view_refresh(h);
     if (nq < 0 || layer_cap < 1) PGV_FAIL(PGV_ERR_ARG, "bad sizes");
     if (ef_construction < 4 || ef_construction > 1000)
         PGV_FAIL(PGV_ERR_ARG, "ef_construction must be 4..1000 (src/hnsw.h:58-59), got %d", ef_construction);
@@ -3075,7 +3119,7 @@ int pgv_hnsw_score_groups(pgv_hnsw *h, const int32_t *ids, const int64_t *ids_st
 int pgv_hnsw_update_graph(pgv_hnsw *h, int32_t entry, const int32_t *elements, int nupd,
                           const int64_t *tuple_offsets, const int32_t *tuples) {
     if (!h) PGV_FAIL(PGV_ERR_ARG, "pgv_hnsw_update_graph: handle is NULL");
-    if (h->imported) PGV_FAIL(PGV_ERR_STATE, "pgv_hnsw_update_graph: an imported mirror is read-only");
+    if (h->imported || h->view_of) PGV_FAIL(PGV_ERR_STATE, "pgv_hnsw_update_graph: an imported mirror / a view is read-only");
     if (h->m == 0) PGV_FAIL(PGV_ERR_ARG, "pgv_hnsw_update_graph needs pgv_hnsw_set_graph first");
     if (entry < -1 || entry >= h->n) PGV_FAIL(PGV_ERR_ARG, "entry point %d out of range", (int)entry);
     if (nupd < 0 || (nupd > 0 && (!elements || !tuple_offsets || !tuples))) PGV_FAIL(PGV_ERR_ARG, "bad update");

@@ -202,6 +202,7 @@ struct pgv_hnsw {
     size_t graph_bytes = 0;
     int64_t nbr_total = 0;
     bool imported = false;  // elements / graph were opened with hipIpcOpenMemHandle (a read-only view)
+    pgv_hnsw *view_of = nullptr;  // pgv_hnsw_share: a read-only view of that mirror in the same process (own context)
     char *payload = nullptr;  // [n x payload_bytes] behind the elements, same allocation (pgv_hnsw_upload_payload)
     int payload_bytes = 0;
 };

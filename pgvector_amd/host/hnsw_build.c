@@ -32,6 +32,8 @@
 
 #include <math.h>
 #include <omp.h>
+#include <pthread.h>
+#include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
 #include <time.h>
@@ -512,6 +514,233 @@ write_tuple(const elem * el, int32_t e, int m, const int64_t *nbr_start, int32_t
 	}
 }
 
+/* ------------------------------------------------------------ stage A of a batch
+ * What a batch needs from the device BEFORE any of its host work -- the searches of HnswFindElementNeighbors for all of
+ * its elements and the pairwise distances inside every candidate list that has to be thinned -- depends on the graph as
+ * the device holds it and on nothing the host replay of the PREVIOUS batch produces.  So it runs one batch ahead, on a
+ * helper thread with a context and a view (pgv_hnsw_share) of its own, while the main thread replays the current batch
+ * (SelectNeighbors, the lists' records and updates): the searches and the pair scoring, 5.1 of the 12 s of a 1 M x 1536
+ * build, leave the critical path.  The batch that runs ahead searches the graph as it stood before the current batch
+ * was linked -- the same blindness the elements of one batch have towards each other, one batch longer; the
+ * reference's own parallel workers search while others link (src/hnswbuild.c:366-480).  Only batches of the full
+ * max_batch run ahead (their composition then does not depend on how many duplicates the current one finds), never
+ * across a change of the entry point, and never with max_batch < 64: max_batch = 1 stays the reference's serial loop.
+ */
+typedef struct
+{
+	/* the batch */
+	int64_t		i0;
+	int			B,
+				lcap;
+	/* what stage A yields */
+	int32_t    *sw_ids;
+	float	   *sw_dist;
+	int32_t    *sw_cnt;
+	int64_t    *tri_off;
+	groupbuf	gb;
+	float	   *pdist;			/* pinned */
+	int64_t		pdist_cap;
+	int64_t		npairs;
+	int			rc;
+	char		err[200];
+	double		secs[2];		/* search, pairs */
+}			stage_a;
+
+static void
+stage_a_free(stage_a * a)
+{
+	free(a->sw_ids);
+	free(a->sw_dist);
+	free(a->sw_cnt);
+	free(a->tri_off);
+	free(a->gb.ids);
+	free(a->gb.ids_start);
+	free(a->gb.from);
+	free(a->gb.pair_start);
+	pgv_pinned_free(a->pdist);
+	memset(a, 0, sizeof(*a));
+}
+
+/* steps 1 and 2 of a batch on `handle` (the mirror itself, or the helper's view of it) */
+static int
+run_stage_a(pgv_hnsw * handle, stage_a * a, const elem * el, int m, int ef_construction)
+{
+	const int	B = a->B,
+				lcap = a->lcap;
+	size_t		per = (size_t) B * lcap;
+	int32_t    *ids = malloc(sizeof(int32_t) * (size_t) B);
+	int32_t    *lv = malloc(sizeof(int32_t) * (size_t) B);
+	int64_t		total = 0;
+	double		t0 = now_secs();
+	int			rc;
+
+	a->rc = PGV_OK;
+	a->err[0] = 0;
+	a->sw_ids = realloc(a->sw_ids, sizeof(int32_t) * per * ef_construction);
+	a->sw_dist = realloc(a->sw_dist, sizeof(float) * per * ef_construction);
+	a->sw_cnt = realloc(a->sw_cnt, sizeof(int32_t) * per);
+	a->tri_off = realloc(a->tri_off, sizeof(int64_t) * per);
+	if (!ids || !lv || !a->sw_ids || !a->sw_dist || !a->sw_cnt || !a->tri_off)
+	{
+		free(ids);
+		free(lv);
+		snprintf(a->err, sizeof(a->err), "out of memory");
+		return a->rc = PGV_ERR_NOMEM;
+	}
+	/* ---- 1. the searches of HnswFindElementNeighbors for the whole batch */
+	for (int b = 0; b < B; b++)
+	{
+		ids[b] = (int32_t) (a->i0 + b);
+		lv[b] = el[a->i0 + b].level;
+	}
+	rc = pgv_hnsw_build_search(handle, ids, lv, B, ef_construction, lcap, a->sw_ids, a->sw_dist, a->sw_cnt);
+	free(ids);
+	free(lv);
+	a->secs[0] = now_secs() - t0;
+	t0 = now_secs();
+	if (rc != PGV_OK)
+		goto dev_fail;
+	/* ---- 2. pairwise distances inside every candidate list that has to be thinned */
+	groups_reset(&a->gb);
+	for (int b = 0; b < B; b++)
+		for (int lc = 0; lc < lcap; lc++)
+		{
+			int			nw = a->sw_cnt[(size_t) b * lcap + lc];
+
+			a->tri_off[(size_t) b * lcap + lc] = total;
+			if (nw > layer_m(m, lc))
+			{
+				/* the candidates as one group, the whole triangle: expanded on the device */
+				if (!groups_add(&a->gb, a->sw_ids + ((size_t) b * lcap + lc) * ef_construction, nw, 1, total))
+				{
+					snprintf(a->err, sizeof(a->err), "out of memory");
+					return a->rc = PGV_ERR_NOMEM;
+				}
+				total += group_pairs(nw, 1);
+			}
+		}
+	a->npairs = total;
+	if (a->gb.ngroups > 0)
+		a->gb.pair_start[a->gb.ngroups] = total;
+	if (total > a->pdist_cap)
+	{
+		pgv_pinned_free(a->pdist);
+		a->pdist = NULL;
+		a->pdist_cap = total * 2;
+		if ((rc = pgv_pinned_alloc(sizeof(float) * (size_t) a->pdist_cap, (void **) &a->pdist)) != PGV_OK)
+		{
+			a->pdist_cap = 0;
+			goto dev_fail;
+		}
+	}
+	if (total > 0)
+	{
+		rc = pgv_hnsw_score_groups(handle, a->gb.ids, a->gb.ids_start, a->gb.from, a->gb.pair_start, a->gb.ngroups, a->gb.nids,
+								   total, a->pdist);
+		if (rc != PGV_OK)
+			goto dev_fail;
+	}
+	a->secs[1] = now_secs() - t0;
+	return PGV_OK;
+dev_fail:
+	snprintf(a->err, sizeof(a->err), "%s", pgv_last_error());
+	return a->rc = rc;
+}
+
+/* the helper thread: one job at a time */
+typedef struct
+{
+	pthread_t	thread;
+	pthread_mutex_t lock;
+	pthread_cond_t wake;
+	pgv_ctx    *ctx;
+	pgv_hnsw   *view;
+	const elem *el;
+	int			m,
+				ef_construction;
+	stage_a    *job;			/* posted by the main thread, NULL when idle */
+	int			done;			/* the posted job has been run */
+	int			quit;
+	int			started;
+}			ahead;
+
+static void *
+ahead_main(void *arg)
+{
+	ahead	   *h = arg;
+
+	pthread_mutex_lock(&h->lock);
+	for (;;)
+	{
+		while (!h->quit && (h->job == NULL || h->done))
+			pthread_cond_wait(&h->wake, &h->lock);
+		if (h->quit)
+			break;
+		pthread_mutex_unlock(&h->lock);
+		run_stage_a(h->view, h->job, h->el, h->m, h->ef_construction);
+		pthread_mutex_lock(&h->lock);
+		h->done = 1;
+		pthread_cond_broadcast(&h->wake);
+	}
+	pthread_mutex_unlock(&h->lock);
+	return NULL;
+}
+
+static void
+ahead_post(ahead * h, stage_a * job)
+{
+	pthread_mutex_lock(&h->lock);
+	h->job = job;
+	h->done = 0;
+	pthread_cond_broadcast(&h->wake);
+	pthread_mutex_unlock(&h->lock);
+}
+
+/* the posted job is over (its rc is in the job); no job posted: returns at once */
+static void
+ahead_wait(ahead * h)
+{
+	if (!h->started)
+		return;
+	pthread_mutex_lock(&h->lock);
+	while (h->job != NULL && !h->done)
+		pthread_cond_wait(&h->wake, &h->lock);
+	h->job = NULL;
+	pthread_mutex_unlock(&h->lock);
+}
+
+/* the job that runs ahead has finished (it stays posted: the next batch takes it) */
+static void
+ahead_wait_keep(ahead * h)
+{
+	if (!h->started)
+		return;
+	pthread_mutex_lock(&h->lock);
+	while (h->job != NULL && !h->done)
+		pthread_cond_wait(&h->wake, &h->lock);
+	pthread_mutex_unlock(&h->lock);
+}
+
+static void
+ahead_stop(ahead * h)
+{
+	if (!h->started)
+		return;
+	ahead_wait(h);
+	pthread_mutex_lock(&h->lock);
+	h->quit = 1;
+	pthread_cond_broadcast(&h->wake);
+	pthread_mutex_unlock(&h->lock);
+	pthread_join(h->thread, NULL);
+	if (h->view)
+		pgv_hnsw_free(h->view);
+	if (h->ctx)
+		pgv_ctx_destroy(h->ctx);
+	pthread_mutex_destroy(&h->lock);
+	pthread_cond_destroy(&h->wake);
+	h->started = 0;
+}
+
 int
 pgv_host_hnsw_build(pgv_hnsw * mirror, pgv_dtype dtype, int dim, const void *rows, int64_t n, int m,
 					int ef_construction, const pgv_rng * rng, int max_batch, pgv_hnsw_built * out)
@@ -530,12 +759,17 @@ pgv_host_hnsw_build(pgv_hnsw * mirror, pgv_dtype dtype, int dim, const void *row
 	int64_t		npairs = 0;
 	float	   *pdist = NULL;
 	int64_t		pdist_cap = 0;
-	int32_t    *sw_ids = NULL,
+	int32_t    *sw_ids = NULL,	/* (aliases of the current batch's stage A) */
 			   *sw_cnt = NULL,
 			   *dirty = NULL,
 			   *packed = NULL;
 	float	   *sw_dist = NULL;
+	const float *cdist = NULL;	/* the candidate lists' pair distances of the current batch (stage A's) */
 	int64_t    *packed_off = NULL;
+	stage_a		stages[2];
+	int			cur = 0;		/* stages[cur]: the current batch's; stages[cur ^ 1]: the one running ahead */
+	int			ahead_valid = 0;	/* stages[cur] was computed ahead for exactly this batch */
+	ahead		helper;
 	uint8_t    *is_dirty = NULL;
 	record	   *recs = NULL;
 	int			recs_cap = 0;
@@ -554,6 +788,8 @@ pgv_host_hnsw_build(pgv_hnsw * mirror, pgv_dtype dtype, int dim, const void *row
 	int			cur_phase = PH_RECORDS;
 	int64_t		hash_cap = 0;
 
+	memset(stages, 0, sizeof(stages));
+	memset(&helper, 0, sizeof(helper));
 	if (!mirror || !out || (n > 0 && !rows))
 		return pgv_host_fail(PGV_ERR_ARG, "pgv_host_hnsw_build: mirror/rows/out is NULL");
 	if (m < 2 || m > 100 || ef_construction < 4 || ef_construction > 1000 || ef_construction < 2 * m)
@@ -664,72 +900,99 @@ pgv_host_hnsw_build(pgv_hnsw * mirror, pgv_dtype dtype, int dim, const void *row
 		}
 
 		PHASE(PH_SEARCH);
-		/* ---- 1. the searches of HnswFindElementNeighbors for the whole batch */
+		/* ---- 1 + 2. stage A: the batch's searches and its candidate lists' pair distances -- computed ahead by the
+		 * helper while the previous batch was replayed, or here */
 		{
-			size_t		per = (size_t) B * lcap;
-			int32_t    *ids = malloc(sizeof(int32_t) * (size_t) B);
-			int32_t    *lv = malloc(sizeof(int32_t) * (size_t) B);
+			stage_a    *a = &stages[cur];
 
-			sw_ids = realloc(sw_ids, sizeof(int32_t) * per * ef_construction);
-			sw_dist = realloc(sw_dist, sizeof(float) * per * ef_construction);
-			sw_cnt = realloc(sw_cnt, sizeof(int32_t) * per);
-			for (int b = 0; b < B; b++)
+			if (ahead_valid && a->i0 == i0 && a->B == B && a->lcap == lcap)
+				ahead_wait(&helper);	/* (usually long over) */
+			else
 			{
-				ids[b] = (int32_t) (i0 + b);
-				lv[b] = el[i0 + b].level;
+				ahead_wait(&helper);	/* a batch that ran ahead for nothing (cannot happen by construction) */
+				a->i0 = i0;
+				a->B = B;
+				a->lcap = lcap;
+				run_stage_a(mirror, a, el, m, ef_construction);
 			}
-			rc = pgv_hnsw_build_search(mirror, ids, lv, B, ef_construction, lcap, sw_ids, sw_dist, sw_cnt);
-			free(ids);
-			free(lv);
-			if (rc != PGV_OK)
-				goto dev_fail;
-		}
+			ahead_valid = 0;
+			if (a->rc != PGV_OK)
+			{
+				rc = pgv_host_fail(a->rc, "%s", a->err);
+				goto done;
+			}
+			out->device_pairs += a->npairs;
+			sw_ids = a->sw_ids;
+			sw_dist = a->sw_dist;
+			sw_cnt = a->sw_cnt;
+			tri_off = a->tri_off;
+			cdist = a->pdist;
+			/* the NEXT batch runs ahead when its composition is already certain: a full batch follows a full batch
+			 * (linked / 16 >= max_batch holds from here on), the entry point does not change in this one, and batches
+			 * are large enough for the overlap to matter */
+			if (max_batch >= 64 && B == max_batch && linked / 16 >= max_batch && i0 + B < n)
+			{
+				int			tall = 0;
 
-		PHASE(PH_PAIRS);
-		/* ---- 2. pairwise distances inside every candidate list that has to be thinned */
-		groups_reset(&gb);
-		tri_off = realloc(tri_off, sizeof(int64_t) * (size_t) B * lcap);
-		{
-			int64_t		total = 0;
-
-			for (int b = 0; b < B; b++)
-				for (int lc = 0; lc < lcap; lc++)
+				for (int b = 0; b < B; b++)
+					tall |= el[i0 + b].level > entry_level;
+				if (!tall)
 				{
-					int			nw = sw_cnt[(size_t) b * lcap + lc];
+					stage_a    *nx = &stages[cur ^ 1];
+					int64_t		n0 = i0 + B;
+					int			nB = (int) (n - n0 < max_batch ? n - n0 : max_batch);
+					int			nlcap = 1;
 
-					tri_off[(size_t) b * lcap + lc] = total;
-					if (nw > layer_m(m, lc))
-					{
-						/* the candidates as one group, the whole triangle: expanded on the device */
-						if (!groups_add(&gb, sw_ids + ((size_t) b * lcap + lc) * ef_construction, nw, 1, total))
+					for (int b = 0; b < nB; b++)
+						if (el[n0 + b].level > entry_level)
 						{
-							rc = pgv_host_fail(PGV_ERR_NOMEM, "out of memory");
-							goto done;
+							nB = b + 1;
+							break;
 						}
-						total += group_pairs(nw, 1);
+					for (int b = 0; b < nB; b++)
+					{
+						int			l = el[n0 + b].level < entry_level ? el[n0 + b].level : entry_level;
+
+						if (l + 1 > nlcap)
+							nlcap = l + 1;
+					}
+					if (!helper.started)
+					{
+						/* a context, a stream and a view of the mirror for the helper */
+						int			hrc = pgv_ctx_create(pgv_hnsw_device(mirror), NULL, &helper.ctx);
+
+						if (hrc == PGV_OK)
+							hrc = pgv_hnsw_share(mirror, helper.ctx, &helper.view);
+						if (hrc == PGV_OK)
+						{
+							helper.el = el;
+							helper.m = m;
+							helper.ef_construction = ef_construction;
+							pthread_mutex_init(&helper.lock, NULL);
+							pthread_cond_init(&helper.wake, NULL);
+							if (pthread_create(&helper.thread, NULL, ahead_main, &helper) == 0)
+								helper.started = 1;
+						}
+						if (!helper.started)
+						{
+							if (helper.view)
+								pgv_hnsw_free(helper.view);
+							if (helper.ctx)
+								pgv_ctx_destroy(helper.ctx);
+							helper.view = NULL;
+							helper.ctx = NULL;
+						}
+					}
+					if (helper.started)
+					{
+						nx->i0 = n0;
+						nx->B = nB;
+						nx->lcap = nlcap;
+						ahead_post(&helper, nx);
+						ahead_valid = 1;
 					}
 				}
-			npairs = total;
-		}
-		if (gb.ngroups > 0)
-			gb.pair_start[gb.ngroups] = npairs;
-		if (npairs > pdist_cap)
-		{
-			pgv_pinned_free(pdist);
-			pdist = NULL;
-			pdist_cap = npairs * 2;
-			if ((rc = pgv_pinned_alloc(sizeof(float) * (size_t) pdist_cap, (void **) &pdist)) != PGV_OK)
-			{
-				pdist_cap = 0;
-				goto dev_fail;
 			}
-		}
-		if (npairs > 0)
-		{
-			rc = pgv_hnsw_score_groups(mirror, gb.ids, gb.ids_start, gb.from, gb.pair_start, gb.ngroups, gb.nids, npairs, pdist);
-			if (rc != PGV_OK)
-				goto dev_fail;
-			out->device_pairs += npairs;
 		}
 
 		PHASE(PH_SELECT);
@@ -774,7 +1037,7 @@ pgv_host_hnsw_build(pgv_hnsw * mirror, pgv_dtype dtype, int dim, const void *row
 						c[i] = &lw[i];
 					}
 					if (nw > lm)
-						fill_matrix(mat, nw, pdist + tri_off[(size_t) b * lcap + lc]);
+						fill_matrix(mat, nw, cdist + tri_off[(size_t) b * lcap + lc]);
 					rn = select_neighbors(c, nw, lm, mat, nw, 0, &closer_set, NULL, r, NULL, 0, w, wd, added, flag);
 					x->layers[lc].closer_set = closer_set;
 					x->layers[lc].items = malloc(sizeof(cand) * (size_t) lm);
@@ -1169,7 +1432,9 @@ pgv_host_hnsw_build(pgv_hnsw * mirror, pgv_dtype dtype, int dim, const void *row
 			goto done;
 		}
 		PHASE(PH_PATCH);
-		/* ---- 6. the graph the next batch searches */
+		/* ---- 6. the graph the next batch searches (the batch that runs ahead has to be through with the old one:
+		 * its kernels read the neighbor tuples this step overwrites) */
+		ahead_wait_keep(&helper);
 		{
 			int			k = 0;
 
@@ -1218,12 +1483,17 @@ pgv_host_hnsw_build(pgv_hnsw * mirror, pgv_dtype dtype, int dim, const void *row
 		memset(rec_of, 0, sizeof(int64_t) * (size_t) hash_cap);
 		i0 += B;
 		out->batches++;
+		if (ahead_valid)
+			cur ^= 1;
 	}
 	goto done;
 
 dev_fail:
 	rc = pgv_host_fail(rc, "%s", pgv_last_error());
 done:
+	ahead_stop(&helper);
+	stage_a_free(&stages[0]);
+	stage_a_free(&stages[1]);
 	out->entry = entry;
 	out->nelements = linked;
 	if (el)
@@ -1252,16 +1522,12 @@ done:
 	free(gb.from);
 	free(gb.pair_start);
 	pgv_pinned_free(pdist);
-	free(sw_ids);
-	free(sw_dist);
-	free(sw_cnt);
 	free(dirty);
 	free(packed);
 	free(packed_off);
 	free(is_dirty);
 	free(recs);
 	free(rec_of);
-	free(tri_off);
 	if (rc != PGV_OK)
 		pgv_host_hnsw_built_free(out);
 	return rc;

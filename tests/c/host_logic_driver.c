@@ -177,6 +177,52 @@ test_hnsw_build(void)
 	}
 	ora_hnsw_free(g);
 	pgv_hnsw_free(mirror);
+	/* batches that run AHEAD (round 4): full batches of 64 once 1024 elements are linked -- the next batch's searches
+	 * and candidate pairs are computed by a helper thread on a view of the mirror while this batch is replayed.  The
+	 * graph must be as sound and as searchable as one built batch by batch, and the batch count the same. */
+	{
+		enum { N2 = 12000 };
+		float	   *d2 = malloc(sizeof(float) * N2 * DIM);
+		pgv_hnsw   *m2;
+		pgv_hnsw_graph graph;
+		int64_t		elem[64 * 3],
+					scored[64];
+		float		dd[64 * 3];
+		int			found = 0;
+
+		for (int i = 0; i < N2 * DIM; i++)
+			d2[i] = (float) (urand() % 4096);
+		CHECK(pgv_hnsw_upload(ctx, PGV_L2SQ, PGV_F32, DIM, d2, N2, &m2));
+		CHECK(pgv_host_hnsw_build(m2, PGV_F32, DIM, d2, N2, M, EFC, NULL, 64, &built));
+		EXPECT(built.nelements + 0 <= N2 && built.nelements >= N2 - 8);	/* (a few exact duplicates of 4096^8 draws at most) */
+		EXPECT(built.batches >= N2 / 64 && built.batches < N2 / 64 + 400);
+		for (int e = 0; e < N2; e++)
+			for (int lc = 0; lc <= built.levels[e] && built.dup_of[e] < 0; lc++)
+			{
+				int			lm = lc == 0 ? 2 * M : M;
+				const int32_t *mine = built.nbr + built.nbr_start[e] + (int64_t) (built.levels[e] - lc) * M;
+
+				for (int i = 0; i < lm; i++)
+				{
+					EXPECT(mine[i] >= -1 && mine[i] < N2 && mine[i] != e);
+					if (mine[i] >= 0)
+						EXPECT(built.levels[mine[i]] >= lc);
+				}
+			}
+		graph.nelements = N2;
+		graph.m = M;
+		graph.entry = built.entry;
+		graph.levels = built.levels;
+		graph.nbr_start = built.nbr_start;
+		graph.nbr = built.nbr;
+		CHECK(pgv_host_hnsw_search(m2, &graph, PGV_F32, DIM, d2 + 5000 * DIM, 64, 40, 3, elem, dd, scored));
+		for (int q = 0; q < 64; q++)
+			found += dd[q * 3] == 0.0f;
+		EXPECT(found >= 62);	/* a stored vector finds itself (or its duplicate) */
+		pgv_host_hnsw_built_free(&built);
+		pgv_hnsw_free(m2);
+		free(d2);
+	}
 	pgv_ctx_destroy(ctx);
 	free(data);
 	return 0;

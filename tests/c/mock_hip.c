@@ -128,7 +128,8 @@ struct pgv_hnsw
 	int32_t    *nbr;
 	char	   *payload;		/* [n x payload_bytes] (pgv_hnsw_upload_payload) */
 	int			payload_bytes;
-	int			imported;		/* a view made by pgv_hnsw_import: frees nothing but itself */
+	int			imported;		/* a view made by pgv_hnsw_import / pgv_hnsw_share: frees nothing but itself */
+	struct pgv_hnsw *view_of;	/* pgv_hnsw_share: the owner whose graph / entry point it follows */
 };
 
 int
@@ -849,6 +850,41 @@ pgv_hnsw_import(pgv_ctx * ctx, const pgv_index_handle * handle, pgv_hnsw * *out)
 	return PGV_OK;
 }
 
+int
+pgv_hnsw_device(const pgv_hnsw * h)
+{
+	return h ? 0 : -1;
+}
+
+/* a view for another context of this process: it follows its owner's graph and entry point */
+int
+pgv_hnsw_share(pgv_hnsw * h, pgv_ctx * ctx, pgv_hnsw * *out)
+{
+	pgv_hnsw   *v = malloc(sizeof(*v));
+
+	(void) ctx;
+	*v = *h;
+	v->imported = 1;
+	v->view_of = h->view_of ? h->view_of : h;
+	*out = v;
+	return PGV_OK;
+}
+
+static void
+view_refresh(pgv_hnsw * h)
+{
+	if (h->view_of)
+	{
+		const pgv_hnsw *o = h->view_of;
+
+		h->m = o->m;
+		h->entry = o->entry;
+		h->levels = o->levels;
+		h->nbr_start = o->nbr_start;
+		h->nbr = o->nbr;
+	}
+}
+
 static void
 graph_free(pgv_hnsw * h)
 {
@@ -1017,9 +1053,12 @@ int
 pgv_hnsw_build_search(pgv_hnsw * h, const int32_t *elements, const int32_t *insert_levels, int nq,
 					  int ef_construction, int layer_cap, int32_t *out_ids, float *out_dist, int32_t *out_count)
 {
-	sc		   *w = malloc(sizeof(sc) * (size_t) (ef_construction + 1));
-	uint8_t    *visited = malloc((size_t) (h->n > 0 ? h->n : 1));
+	sc		   *w;
+	uint8_t    *visited;
 
+	view_refresh(h);
+	w = malloc(sizeof(sc) * (size_t) (ef_construction + 1));
+	visited = malloc((size_t) (h->n > 0 ? h->n : 1));
 	for (int q = 0; q < nq; q++)
 	{
 		const float *qv = h->vectors + (size_t) elements[q] * h->dim;
