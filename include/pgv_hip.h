@@ -571,10 +571,12 @@ int			pgv_hnsw_get_payload(pgv_hnsw * h, const int64_t *elements, int n, void *o
  */
 int			pgv_hnsw_export(pgv_hnsw * h, pgv_index_handle * out);
 /*
- * A read-only view of a mirror for ANOTHER context of the same process (its own stream, scratch and visited
- * bitmaps; the element rows, the payload and the graph stay the owner's and follow the owner's pgv_hnsw_set_graph /
- * pgv_hnsw_update_graph): pgv_index_share's twin.  The HNSW build runs the next batch's searches on one while the
- * current batch's lists are replayed (pgvector_amd/host/hnsw_build.c).  Free the view before the owner.
+ * A view of a mirror for ANOTHER context of the same process (its own stream, scratch and visited bitmaps; the
+ * element rows, the payload and the graph stay the owner's and follow the owner's pgv_hnsw_set_graph /
+ * pgv_hnsw_update_graph): pgv_index_share's twin.  Searches, scoring and pgv_hnsw_update_graph work through a view
+ * (the patch lands in the owner's graph); pgv_hnsw_set_graph and pgv_hnsw_export do not.  The HNSW build runs the next
+ * batch's searches and the graph patches on views while the current batch's lists are replayed
+ * (pgvector_amd/host/hnsw_build.c).  One thread per handle at a time; free the views before the owner.
  */
 int			pgv_hnsw_share(pgv_hnsw * h, pgv_ctx * ctx, pgv_hnsw * *out);
 int			pgv_hnsw_device(const pgv_hnsw * h);	/* the device the mirror lives on (-1: NULL) */
@@ -654,7 +656,9 @@ int			pgv_hnsw_score_groups(pgv_hnsw * h, const int32_t *ids, const int64_t *ids
  * The graph after a batch of inserts: new entry point and the rewritten neighbor tuples
  * (HnswUpdateNeighborsInMemory / AddConnections, src/hnswbuild.c:376-431).  Element elements[i]'s
  * whole tuple is tuples[tuple_offsets[i] .. tuple_offsets[i + 1]) in the layout of pgv_hnsw_set_graph;
- * tuple_offsets is host memory.  Ordered with later searches on the context's stream.
+ * tuple_offsets is host memory.  Ordered on the device with later searches through the mirror AND through its views
+ * (pgv_hnsw_share), whichever of them ran the patch; searches that still read the old tuples must have returned before
+ * the call (every search call ends synchronized).
  */
 int			pgv_hnsw_update_graph(pgv_hnsw * h, int32_t entry, const int32_t *elements, int nupd,
 								  const int64_t *tuple_offsets, const int32_t *tuples);

@@ -2736,6 +2736,13 @@ int pgv_hnsw_upload_payload(pgv_ctx *ctx, pgv_metric metric, pgv_dtype dtype, in
     return PGV_OK;
 }
 
+// Searches on this handle's stream see the mirror's last patch, whichever stream ran it (a device-side wait).
+static int hnsw_graph_acquire(pgv_hnsw *h) {
+    pgv_hnsw *o = h->view_of ? h->view_of : h;
+    if (o->graph_ev_set) PGV_HIP(hipStreamWaitEvent(h->ctx->stream, o->graph_ev, 0));
+    return PGV_OK;
+}
+
 // a view follows its owner: the graph may have been (re)set and the entry point moved since the view was made
 static void hnsw_view_refresh(pgv_hnsw *h) {
     const pgv_hnsw *o = h->view_of;
@@ -2781,6 +2788,7 @@ void pgv_hnsw_free(pgv_hnsw *h) {
         delete h;
         return;
     }
+    if (h->graph_ev) (void)hipEventDestroy(h->graph_ev);
     if (h->imported) {
         if (h->elements) (void)hipIpcCloseMemHandle(h->elements);
         if (h->graph) (void)hipIpcCloseMemHandle(h->graph);
@@ -2984,6 +2992,7 @@ int pgv_hnsw_search(pgv_hnsw *h, const void *queries, int nq, int ef_search, int
     if (!queries) PGV_FAIL(PGV_ERR_ARG, "queries is NULL");
     pgv_ctx *ctx = h->ctx;
     PGV_HIP(hipSetDevice(ctx->device));
+    PGV_TRY(hnsw_graph_acquire(h));
     const void *q_dev;
     PGV_TRY(stage_rows(ctx, queries, nq, h->dim, h->dtype, h->geom, ctx->q_stage, &q_dev));
     int words = 0;
@@ -3024,6 +3033,7 @@ int pgv_hnsw_build_search(pgv_hnsw *h, const int32_t *elements, const int32_t *i
     if (!elements || !insert_levels) PGV_FAIL(PGV_ERR_ARG, "elements/insert_levels is NULL");
     pgv_ctx *ctx = h->ctx;
     PGV_HIP(hipSetDevice(ctx->device));
+    PGV_TRY(hnsw_graph_acquire(h));
     const void *e_dev, *l_dev;
     PGV_TRY(stage_flat(ctx, elements, sizeof(int32_t) * (size_t)nq, ctx->idx_stage, &e_dev));
     PGV_TRY(stage_flat(ctx, insert_levels, sizeof(int32_t) * (size_t)nq, ctx->plan_d, &l_dev));
@@ -3119,26 +3129,39 @@ int pgv_hnsw_score_groups(pgv_hnsw *h, const int32_t *ids, const int64_t *ids_st
 int pgv_hnsw_update_graph(pgv_hnsw *h, int32_t entry, const int32_t *elements, int nupd,
                           const int64_t *tuple_offsets, const int32_t *tuples) {
     if (!h) PGV_FAIL(PGV_ERR_ARG, "pgv_hnsw_update_graph: handle is NULL");
-    if (h->imported || h->view_of) PGV_FAIL(PGV_ERR_STATE, "pgv_hnsw_update_graph: an imported mirror / a view is read-only");
+    if (h->imported) PGV_FAIL(PGV_ERR_STATE, "pgv_hnsw_update_graph: an imported mirror is read-only");
+    hnsw_view_refresh(h);
+    // through a view (pgv_hnsw_share) the patch lands in the owner's arrays, on the view's stream
+    pgv_hnsw *o = h->view_of ? h->view_of : h;
+    if (o->imported) PGV_FAIL(PGV_ERR_STATE, "pgv_hnsw_update_graph: an imported mirror is read-only");
     if (h->m == 0) PGV_FAIL(PGV_ERR_ARG, "pgv_hnsw_update_graph needs pgv_hnsw_set_graph first");
     if (entry < -1 || entry >= h->n) PGV_FAIL(PGV_ERR_ARG, "entry point %d out of range", (int)entry);
     if (nupd < 0 || (nupd > 0 && (!elements || !tuple_offsets || !tuples))) PGV_FAIL(PGV_ERR_ARG, "bad update");
     pgv_ctx *ctx = h->ctx;
     PGV_HIP(hipSetDevice(ctx->device));
     h->entry = entry;
+    o->entry = entry;
     if (nupd == 0) return PGV_OK;
     if (is_device_ptr(tuple_offsets)) PGV_FAIL(PGV_ERR_ARG, "tuple_offsets must be host memory");
     const int64_t total = tuple_offsets[nupd];
     for (int i = 0; i < nupd; i++)
         if (tuple_offsets[i] < 0 || tuple_offsets[i + 1] < tuple_offsets[i])
             PGV_FAIL(PGV_ERR_ARG, "tuple_offsets is not an offset array");
+    // an earlier patch that ran on another stream comes first
+    PGV_TRY(hnsw_graph_acquire(h));
     const void *id_dev, *tp_dev, *of_dev;
     PGV_TRY(stage_flat(ctx, elements, sizeof(int32_t) * (size_t)nupd, ctx->idx_stage, &id_dev));
     PGV_TRY(stage_flat(ctx, tuples, sizeof(int32_t) * (size_t)(total > 0 ? total : 1), ctx->plan_d, &tp_dev));
     PGV_TRY(stage_flat(ctx, tuple_offsets, sizeof(int64_t) * (size_t)(nupd + 1), ctx->plan_c, &of_dev));
     PGV_TRY(launch_hnsw_patch(ctx, h->nbr, h->nbr_start, h->n, static_cast<const int32_t *>(id_dev),
                               static_cast<const int64_t *>(of_dev), static_cast<const int32_t *>(tp_dev), nupd));
-    return PGV_OK;  // later launches on the context's stream see the patched graph
+    // later launches on this stream see the patched graph; searches on other streams (the owner's, other views') wait
+    // for this event on the device.  The caller keeps searches that READ the old tuples away from the patch: they have
+    // returned (every search ends with a stream synchronize) before it calls this.
+    if (!o->graph_ev) PGV_HIP(hipEventCreateWithFlags(&o->graph_ev, hipEventDisableTiming));
+    PGV_HIP(hipEventRecord(o->graph_ev, ctx->stream));
+    o->graph_ev_set = true;
+    return PGV_OK;
 }
 
 }  // extern "C"

@@ -202,7 +202,11 @@ struct pgv_hnsw {
     size_t graph_bytes = 0;
     int64_t nbr_total = 0;
     bool imported = false;  // elements / graph were opened with hipIpcOpenMemHandle (a read-only view)
-    pgv_hnsw *view_of = nullptr;  // pgv_hnsw_share: a read-only view of that mirror in the same process (own context)
+    pgv_hnsw *view_of = nullptr;  // pgv_hnsw_share: a view of that mirror in the same process (own context / stream)
+    // the last pgv_hnsw_update_graph of the mirror (through it or through a view), recorded on the stream that ran it:
+    // searches on any other stream wait for it on the device (owner's field; views look at view_of's)
+    hipEvent_t graph_ev = nullptr;
+    bool graph_ev_set = false;
     char *payload = nullptr;  // [n x payload_bytes] behind the elements, same allocation (pgv_hnsw_upload_payload)
     int payload_bytes = 0;
 };

@@ -544,6 +544,7 @@ typedef struct
 	int			rc;
 	char		err[200];
 	double		secs[2];		/* search, pairs */
+	uint64_t	seq;			/* the helper's job that computes it (run ahead) */
 }			stage_a;
 
 static void
@@ -647,7 +648,46 @@ dev_fail:
 	return a->rc = rc;
 }
 
-/* the helper thread: one job at a time */
+/* a graph patch handed to the helper (step 6): its arrays stay untouched until the job is over */
+typedef struct
+{
+	int32_t		entry;
+	int32_t    *dirty;
+	int64_t    *packed_off;
+	int32_t    *packed;
+	int			ndirty;
+	int64_t		dirty_cap,
+				packed_cap;
+	uint64_t	seq;			/* the job that last used the arrays */
+	int			rc;
+	char		err[200];
+}			patch_job;
+
+/* a slice of the batch's list records whose pair distances are wanted (step 4): offsets relative to `out` */
+typedef struct
+{
+	groupbuf	gb;
+	int64_t		npairs;
+	float	   *out;
+	int			klo,
+				khi;			/* records [klo, khi) */
+	uint64_t	seq;
+	int			rc;
+	char		err[200];
+}			score_job;
+
+typedef enum
+{
+	JOB_STAGE_A, JOB_PATCH, JOB_SCORE
+}			job_kind;
+
+/*
+ * A helper thread with a context, a stream and a view of the mirror of its own (pgv_hnsw_share): jobs run one after
+ * the other in the order they were posted, so a patch posted after the stage A that runs ahead cannot overtake it, and
+ * a stage A posted after a patch searches the patched graph.
+ */
+#define WORKER_RING 8
+#define SCORE_SLICES 4
 typedef struct
 {
 	pthread_t	thread;
@@ -658,87 +698,141 @@ typedef struct
 	const elem *el;
 	int			m,
 				ef_construction;
-	stage_a    *job;			/* posted by the main thread, NULL when idle */
-	int			done;			/* the posted job has been run */
+	struct
+	{
+		job_kind	kind;
+		void	   *arg;
+	}			ring[WORKER_RING];
+	uint64_t	posted,
+				completed;
 	int			quit;
 	int			started;
-}			ahead;
+}			worker;
 
 static void *
-ahead_main(void *arg)
+worker_main(void *arg)
 {
-	ahead	   *h = arg;
+	worker	   *w = arg;
 
-	pthread_mutex_lock(&h->lock);
+	pthread_mutex_lock(&w->lock);
 	for (;;)
 	{
-		while (!h->quit && (h->job == NULL || h->done))
-			pthread_cond_wait(&h->wake, &h->lock);
-		if (h->quit)
+		job_kind	kind;
+		void	   *ja;
+
+		while (!w->quit && w->completed == w->posted)
+			pthread_cond_wait(&w->wake, &w->lock);
+		if (w->completed == w->posted)	/* quit, nothing pending */
 			break;
-		pthread_mutex_unlock(&h->lock);
-		run_stage_a(h->view, h->job, h->el, h->m, h->ef_construction);
-		pthread_mutex_lock(&h->lock);
-		h->done = 1;
-		pthread_cond_broadcast(&h->wake);
+		kind = w->ring[w->completed % WORKER_RING].kind;
+		ja = w->ring[w->completed % WORKER_RING].arg;
+		pthread_mutex_unlock(&w->lock);
+		if (kind == JOB_STAGE_A)
+			run_stage_a(w->view, ja, w->el, w->m, w->ef_construction);
+		else if (kind == JOB_PATCH)
+		{
+			patch_job  *pj = ja;
+
+			pj->rc = pgv_hnsw_update_graph(w->view, pj->entry, pj->dirty, pj->ndirty, pj->packed_off, pj->packed);
+			if (pj->rc != PGV_OK)
+				snprintf(pj->err, sizeof(pj->err), "%s", pgv_last_error());
+		}
+		else
+		{
+			score_job  *sj = ja;
+
+			sj->rc = sj->npairs > 0 ? pgv_hnsw_score_groups(w->view, sj->gb.ids, sj->gb.ids_start, sj->gb.from, sj->gb.pair_start,
+															  sj->gb.ngroups, sj->gb.nids, sj->npairs, sj->out) : PGV_OK;
+			if (sj->rc != PGV_OK)
+				snprintf(sj->err, sizeof(sj->err), "%s", pgv_last_error());
+		}
+		pthread_mutex_lock(&w->lock);
+		w->completed++;
+		pthread_cond_broadcast(&w->wake);
 	}
-	pthread_mutex_unlock(&h->lock);
+	pthread_mutex_unlock(&w->lock);
 	return NULL;
 }
 
-static void
-ahead_post(ahead * h, stage_a * job)
+/* a context, a stream and a view of the mirror for a helper; 0 when it could not be had (the build goes on without) */
+static int
+worker_start(worker * w, pgv_hnsw * mirror, const elem * el, int m, int ef_construction)
 {
-	pthread_mutex_lock(&h->lock);
-	h->job = job;
-	h->done = 0;
-	pthread_cond_broadcast(&h->wake);
-	pthread_mutex_unlock(&h->lock);
+	if (w->started)
+		return 1;
+	if (pgv_ctx_create(pgv_hnsw_device(mirror), NULL, &w->ctx) == PGV_OK && pgv_hnsw_share(mirror, w->ctx, &w->view) == PGV_OK)
+	{
+		w->el = el;
+		w->m = m;
+		w->ef_construction = ef_construction;
+		pthread_mutex_init(&w->lock, NULL);
+		pthread_cond_init(&w->wake, NULL);
+		if (pthread_create(&w->thread, NULL, worker_main, w) == 0)
+			return w->started = 1;
+		pthread_mutex_destroy(&w->lock);
+		pthread_cond_destroy(&w->wake);
+	}
+	if (w->view)
+		pgv_hnsw_free(w->view);
+	if (w->ctx)
+		pgv_ctx_destroy(w->ctx);
+	w->view = NULL;
+	w->ctx = NULL;
+	return 0;
 }
 
-/* the posted job is over (its rc is in the job); no job posted: returns at once */
-static void
-ahead_wait(ahead * h)
+/* the job's number: worker_wait(w, that) returns once it is over */
+static uint64_t
+worker_post(worker * w, job_kind kind, void *arg)
 {
-	if (!h->started)
-		return;
-	pthread_mutex_lock(&h->lock);
-	while (h->job != NULL && !h->done)
-		pthread_cond_wait(&h->wake, &h->lock);
-	h->job = NULL;
-	pthread_mutex_unlock(&h->lock);
-}
+	uint64_t	seq;
 
-/* the job that runs ahead has finished (it stays posted: the next batch takes it) */
-static void
-ahead_wait_keep(ahead * h)
-{
-	if (!h->started)
-		return;
-	pthread_mutex_lock(&h->lock);
-	while (h->job != NULL && !h->done)
-		pthread_cond_wait(&h->wake, &h->lock);
-	pthread_mutex_unlock(&h->lock);
+	pthread_mutex_lock(&w->lock);
+	while (w->posted - w->completed >= WORKER_RING)
+		pthread_cond_wait(&w->wake, &w->lock);
+	w->ring[w->posted % WORKER_RING].kind = kind;
+	w->ring[w->posted % WORKER_RING].arg = arg;
+	seq = ++w->posted;
+	pthread_cond_broadcast(&w->wake);
+	pthread_mutex_unlock(&w->lock);
+	return seq;
 }
 
 static void
-ahead_stop(ahead * h)
+worker_wait(worker * w, uint64_t seq)
 {
-	if (!h->started)
+	if (!w->started)
 		return;
-	ahead_wait(h);
-	pthread_mutex_lock(&h->lock);
-	h->quit = 1;
-	pthread_cond_broadcast(&h->wake);
-	pthread_mutex_unlock(&h->lock);
-	pthread_join(h->thread, NULL);
-	if (h->view)
-		pgv_hnsw_free(h->view);
-	if (h->ctx)
-		pgv_ctx_destroy(h->ctx);
-	pthread_mutex_destroy(&h->lock);
-	pthread_cond_destroy(&h->wake);
-	h->started = 0;
+	pthread_mutex_lock(&w->lock);
+	while (w->completed < seq)
+		pthread_cond_wait(&w->wake, &w->lock);
+	pthread_mutex_unlock(&w->lock);
+}
+
+static void
+worker_drain(worker * w)
+{
+	if (w->started)
+		worker_wait(w, w->posted);	/* (posted is only written by this, the posting, thread) */
+}
+
+static void
+worker_stop(worker * w)
+{
+	if (!w->started)
+		return;
+	pthread_mutex_lock(&w->lock);
+	w->quit = 1;
+	pthread_cond_broadcast(&w->wake);
+	pthread_mutex_unlock(&w->lock);
+	pthread_join(w->thread, NULL);	/* pending jobs are run first */
+	if (w->view)
+		pgv_hnsw_free(w->view);
+	if (w->ctx)
+		pgv_ctx_destroy(w->ctx);
+	pthread_mutex_destroy(&w->lock);
+	pthread_cond_destroy(&w->wake);
+	w->started = 0;
 }
 
 int
@@ -760,16 +854,18 @@ pgv_host_hnsw_build(pgv_hnsw * mirror, pgv_dtype dtype, int dim, const void *row
 	float	   *pdist = NULL;
 	int64_t		pdist_cap = 0;
 	int32_t    *sw_ids = NULL,	/* (aliases of the current batch's stage A) */
-			   *sw_cnt = NULL,
-			   *dirty = NULL,
-			   *packed = NULL;
+			   *sw_cnt = NULL;
 	float	   *sw_dist = NULL;
 	const float *cdist = NULL;	/* the candidate lists' pair distances of the current batch (stage A's) */
-	int64_t    *packed_off = NULL;
 	stage_a		stages[2];
 	int			cur = 0;		/* stages[cur]: the current batch's; stages[cur ^ 1]: the one running ahead */
 	int			ahead_valid = 0;	/* stages[cur] was computed ahead for exactly this batch */
-	ahead		helper;
+	worker		helper,			/* stage A of the batch that runs ahead and the graph patches, in posting order */
+				scorer;			/* the pair distances of the batch's list records, slice by slice */
+	patch_job	patches[2];
+	int			pcur = 0;
+	score_job	slices[SCORE_SLICES];
+	int			nslices = 1;
 	uint8_t    *is_dirty = NULL;
 	record	   *recs = NULL;
 	int			recs_cap = 0;
@@ -790,6 +886,9 @@ pgv_host_hnsw_build(pgv_hnsw * mirror, pgv_dtype dtype, int dim, const void *row
 
 	memset(stages, 0, sizeof(stages));
 	memset(&helper, 0, sizeof(helper));
+	memset(&scorer, 0, sizeof(scorer));
+	memset(patches, 0, sizeof(patches));
+	memset(slices, 0, sizeof(slices));
 	if (!mirror || !out || (n > 0 && !rows))
 		return pgv_host_fail(PGV_ERR_ARG, "pgv_host_hnsw_build: mirror/rows/out is NULL");
 	if (m < 2 || m > 100 || ef_construction < 4 || ef_construction > 1000 || ef_construction < 2 * m)
@@ -906,10 +1005,12 @@ pgv_host_hnsw_build(pgv_hnsw * mirror, pgv_dtype dtype, int dim, const void *row
 			stage_a    *a = &stages[cur];
 
 			if (ahead_valid && a->i0 == i0 && a->B == B && a->lcap == lcap)
-				ahead_wait(&helper);	/* (usually long over) */
+				worker_wait(&helper, a->seq);	/* (usually long over) */
 			else
 			{
-				ahead_wait(&helper);	/* a batch that ran ahead for nothing (cannot happen by construction) */
+				/* every patch handed to the helper has been issued (a batch that ran ahead for nothing cannot happen
+				 * by construction); the device orders this search behind the patch */
+				worker_drain(&helper);
 				a->i0 = i0;
 				a->B = B;
 				a->lcap = lcap;
@@ -956,39 +1057,14 @@ pgv_host_hnsw_build(pgv_hnsw * mirror, pgv_dtype dtype, int dim, const void *row
 						if (l + 1 > nlcap)
 							nlcap = l + 1;
 					}
-					if (!helper.started)
-					{
-						/* a context, a stream and a view of the mirror for the helper */
-						int			hrc = pgv_ctx_create(pgv_hnsw_device(mirror), NULL, &helper.ctx);
-
-						if (hrc == PGV_OK)
-							hrc = pgv_hnsw_share(mirror, helper.ctx, &helper.view);
-						if (hrc == PGV_OK)
-						{
-							helper.el = el;
-							helper.m = m;
-							helper.ef_construction = ef_construction;
-							pthread_mutex_init(&helper.lock, NULL);
-							pthread_cond_init(&helper.wake, NULL);
-							if (pthread_create(&helper.thread, NULL, ahead_main, &helper) == 0)
-								helper.started = 1;
-						}
-						if (!helper.started)
-						{
-							if (helper.view)
-								pgv_hnsw_free(helper.view);
-							if (helper.ctx)
-								pgv_ctx_destroy(helper.ctx);
-							helper.view = NULL;
-							helper.ctx = NULL;
-						}
-					}
+					if (!helper.started && worker_start(&helper, mirror, el, m, ef_construction))
+						worker_start(&scorer, mirror, el, m, ef_construction);
 					if (helper.started)
 					{
 						nx->i0 = n0;
 						nx->B = nB;
 						nx->lcap = nlcap;
-						ahead_post(&helper, nx);
+						nx->seq = worker_post(&helper, JOB_STAGE_A, nx);
 						ahead_valid = 1;
 					}
 				}
@@ -1236,29 +1312,42 @@ pgv_host_hnsw_build(pgv_hnsw * mirror, pgv_dtype dtype, int dim, const void *row
 			}
 		}
 		PHASE(PH_PAIRLIST);
-		groups_reset(&gb);
+		/* the records in slices: with the scorer running, slice s + 1's pairs are scored while slice s is replayed */
+		nslices = scorer.started && nrec >= 64 * SCORE_SLICES ? SCORE_SLICES : 1;
 		{
 			int64_t		total = 0;
 
-			for (int k = 0; k < nrec; k++)
+			for (int sl = 0; sl < nslices; sl++)
 			{
-				record	   *rcd = &recs[k];
-				int			from = rcd->full ? 1 : rcd->nstart;	/* cached flags: only the pairs that involve a newcomer */
+				score_job  *sj = &slices[sl];
+				int64_t		base = total;
 
-				rcd->pair0 = total;
-				/* a list that cannot overflow in this batch never runs a selection */
-				if (rcd->nlocal <= layer_m(m, rcd->lc))
-					continue;
-				if (!groups_add(&gb, rcd->ids, rcd->nlocal, from, total))
+				sj->klo = (int) ((int64_t) nrec * sl / nslices);
+				sj->khi = (int) ((int64_t) nrec * (sl + 1) / nslices);
+				groups_reset(&sj->gb);
+				for (int k = sj->klo; k < sj->khi; k++)
 				{
-					rc = pgv_host_fail(PGV_ERR_NOMEM, "out of memory");
-					goto done;
+					record	   *rcd = &recs[k];
+					int			from = rcd->full ? 1 : rcd->nstart;	/* cached flags: only the pairs that involve a newcomer */
+
+					rcd->pair0 = total;
+					/* a list that cannot overflow in this batch never runs a selection */
+					if (rcd->nlocal <= layer_m(m, rcd->lc))
+						continue;
+					if (!groups_add(&sj->gb, rcd->ids, rcd->nlocal, from, total - base))
+					{
+						rc = pgv_host_fail(PGV_ERR_NOMEM, "out of memory");
+						goto done;
+					}
+					total += group_pairs(rcd->nlocal, from);
 				}
-				total += group_pairs(rcd->nlocal, from);
+				sj->npairs = total - base;
+				if (sj->gb.ngroups > 0)
+					sj->gb.pair_start[sj->gb.ngroups] = sj->npairs;
+				sj->rc = PGV_OK;
+				sj->seq = 0;
 			}
 			npairs = total;
-			if (gb.ngroups > 0)
-				gb.pair_start[gb.ngroups] = npairs;
 		}
 		PHASE(PH_PAIRS);
 		if (npairs > pdist_cap)
@@ -1272,11 +1361,27 @@ pgv_host_hnsw_build(pgv_hnsw * mirror, pgv_dtype dtype, int dim, const void *row
 				goto dev_fail;
 			}
 		}
-		if (npairs > 0)
 		{
-			rc = pgv_hnsw_score_groups(mirror, gb.ids, gb.ids_start, gb.from, gb.pair_start, gb.ngroups, gb.nids, npairs, pdist);
-			if (rc != PGV_OK)
-				goto dev_fail;
+			int64_t		base = 0;
+
+			for (int sl = 0; sl < nslices; sl++)
+			{
+				score_job  *sj = &slices[sl];
+
+				sj->out = pdist + base;
+				base += sj->npairs;
+				if (sj->npairs == 0)
+					continue;
+				if (nslices > 1)
+					sj->seq = worker_post(&scorer, JOB_SCORE, sj);
+				else
+				{
+					rc = pgv_hnsw_score_groups(mirror, sj->gb.ids, sj->gb.ids_start, sj->gb.from, sj->gb.pair_start, sj->gb.ngroups,
+											   sj->gb.nids, sj->npairs, sj->out);
+					if (rc != PGV_OK)
+						goto dev_fail;
+				}
+			}
 			out->device_pairs += npairs;
 		}
 		PHASE(PH_UPDATE);
@@ -1287,8 +1392,24 @@ pgv_host_hnsw_build(pgv_hnsw * mirror, pgv_dtype dtype, int dim, const void *row
 		{
 			int			nblocked = 0;
 
-			for (int pass = 0; pass < 2; pass++)
+			/* steps 0 .. nslices - 1: the first replay of slice `step`'s lists; step nslices: the second pass over all */
+			for (int step = 0; step <= nslices; step++)
 			{
+				const int	pass = step == nslices;
+				const int	klo = pass ? 0 : slices[step].klo,
+							khi = pass ? nrec : slices[step].khi;
+
+				if (!pass && slices[step].seq != 0)
+				{
+					PHASE(PH_PAIRS);
+					worker_wait(&scorer, slices[step].seq);
+					PHASE(PH_UPDATE);
+					if (slices[step].rc != PGV_OK)
+					{
+						rc = pgv_host_fail(slices[step].rc, "%s", slices[step].err);
+						goto done;
+					}
+				}
 				if (pass == 1)
 				{
 					/* ---- 5b. the updates that were put aside: their lists' member-member pairs, then the replay */
@@ -1336,7 +1457,7 @@ pgv_host_hnsw_build(pgv_hnsw * mirror, pgv_dtype dtype, int dim, const void *row
 					uint8_t    *flag = malloc((size_t) lm0 + 1);
 
 #pragma omp for schedule(dynamic, 16) reduction(+:nblocked)
-					for (int k = 0; k < nrec; k++)
+					for (int k = klo; k < khi; k++)
 					{
 						record	   *rcd = &recs[k];
 						nlist	   *l = &el[rcd->owner].layers[rcd->lc];
@@ -1432,46 +1553,82 @@ pgv_host_hnsw_build(pgv_hnsw * mirror, pgv_dtype dtype, int dim, const void *row
 			goto done;
 		}
 		PHASE(PH_PATCH);
-		/* ---- 6. the graph the next batch searches (the batch that runs ahead has to be through with the old one:
-		 * its kernels read the neighbor tuples this step overwrites) */
-		ahead_wait_keep(&helper);
+		/* ---- 6. the graph the next batch searches.  With the helper running, the patch is its job: posted behind the
+		 * stage A that runs ahead (whose kernels read the tuples this step overwrites) and in front of the next one;
+		 * the arrays of the job before last are free again by now. */
 		{
+			patch_job  *pj = &patches[pcur];
 			int			k = 0;
 
-			dirty = realloc(dirty, sizeof(int32_t) * (size_t) (ndirty > 0 ? ndirty : 1));
-			packed_off = realloc(packed_off, sizeof(int64_t) * (size_t) (ndirty + 1));
+			worker_wait(&helper, pj->seq);
+			if (pj->rc != PGV_OK)
+			{
+				rc = pgv_host_fail(pj->rc, "%s", pj->err);
+				goto done;
+			}
+			if (ndirty + 1 > pj->dirty_cap)
+			{
+				pj->dirty_cap = (int64_t) (ndirty + 1) * 2;
+				pj->dirty = realloc(pj->dirty, sizeof(int32_t) * (size_t) pj->dirty_cap);
+				pj->packed_off = realloc(pj->packed_off, sizeof(int64_t) * (size_t) pj->dirty_cap);
+			}
+			if (!pj->dirty || !pj->packed_off)
+			{
+				rc = pgv_host_fail(PGV_ERR_NOMEM, "out of memory");
+				goto done;
+			}
 			/* dirty elements: the batch itself and the owners of the touched lists */
 			for (int b = 0; b < B; b++)
 				if (is_dirty[i0 + b])
 				{
-					dirty[k++] = (int32_t) (i0 + b);
+					pj->dirty[k++] = (int32_t) (i0 + b);
 					is_dirty[i0 + b] = 0;
 				}
 			for (int q = 0; q < nrec; q++)
 				if (is_dirty[recs[q].owner])
 				{
-					dirty[k++] = recs[q].owner;
+					pj->dirty[k++] = recs[q].owner;
 					is_dirty[recs[q].owner] = 0;
 				}
 			ndirty = k;
 			ntuple = 0;
 			for (int q = 0; q < ndirty; q++)
 			{
-				packed_off[q] = ntuple;
-				ntuple += out->nbr_start[dirty[q] + 1] - out->nbr_start[dirty[q]];
+				pj->packed_off[q] = ntuple;
+				ntuple += out->nbr_start[pj->dirty[q] + 1] - out->nbr_start[pj->dirty[q]];
 			}
-			packed_off[ndirty] = ntuple;
-			packed = realloc(packed, sizeof(int32_t) * (size_t) (ntuple > 0 ? ntuple : 1));
+			pj->packed_off[ndirty] = ntuple;
+			if (ntuple + 1 > pj->packed_cap)
+			{
+				pj->packed_cap = (ntuple + 1) * 2;
+				free(pj->packed);
+				pj->packed = malloc(sizeof(int32_t) * (size_t) pj->packed_cap);
+				if (!pj->packed)
+				{
+					rc = pgv_host_fail(PGV_ERR_NOMEM, "out of memory");
+					goto done;
+				}
+			}
 #pragma omp parallel for if (B >= 8) num_threads(nthreads) schedule(static)
 			for (int q = 0; q < ndirty; q++)
 			{
-				write_tuple(el, dirty[q], m, out->nbr_start, out->nbr);
-				memcpy(packed + packed_off[q], out->nbr + out->nbr_start[dirty[q]],
-					   sizeof(int32_t) * (size_t) (packed_off[q + 1] - packed_off[q]));
+				write_tuple(el, pj->dirty[q], m, out->nbr_start, out->nbr);
+				memcpy(pj->packed + pj->packed_off[q], out->nbr + out->nbr_start[pj->dirty[q]],
+					   sizeof(int32_t) * (size_t) (pj->packed_off[q + 1] - pj->packed_off[q]));
 			}
-			rc = pgv_hnsw_update_graph(mirror, entry, dirty, ndirty, packed_off, packed);
-			if (rc != PGV_OK)
-				goto dev_fail;
+			pj->entry = entry;
+			pj->ndirty = ndirty;
+			if (helper.started)
+			{
+				pj->seq = worker_post(&helper, JOB_PATCH, pj);
+				pcur ^= 1;
+			}
+			else
+			{
+				rc = pgv_hnsw_update_graph(mirror, entry, pj->dirty, ndirty, pj->packed_off, pj->packed);
+				if (rc != PGV_OK)
+					goto dev_fail;
+			}
 		}
 
 		PHASE(PH_FREE);
@@ -1486,12 +1643,34 @@ pgv_host_hnsw_build(pgv_hnsw * mirror, pgv_dtype dtype, int dim, const void *row
 		if (ahead_valid)
 			cur ^= 1;
 	}
+	/* the last patches are on the device before the caller searches the mirror */
+	worker_drain(&helper);
+	for (int i = 0; i < 2; i++)
+		if (patches[i].rc != PGV_OK)
+		{
+			rc = pgv_host_fail(patches[i].rc, "%s", patches[i].err);
+			break;
+		}
 	goto done;
 
 dev_fail:
 	rc = pgv_host_fail(rc, "%s", pgv_last_error());
 done:
-	ahead_stop(&helper);
+	worker_stop(&helper);
+	worker_stop(&scorer);
+	for (int i = 0; i < 2; i++)
+	{
+		free(patches[i].dirty);
+		free(patches[i].packed_off);
+		free(patches[i].packed);
+	}
+	for (int i = 0; i < SCORE_SLICES; i++)
+	{
+		free(slices[i].gb.ids);
+		free(slices[i].gb.ids_start);
+		free(slices[i].gb.from);
+		free(slices[i].gb.pair_start);
+	}
 	stage_a_free(&stages[0]);
 	stage_a_free(&stages[1]);
 	out->entry = entry;
@@ -1522,9 +1701,6 @@ done:
 	free(gb.from);
 	free(gb.pair_start);
 	pgv_pinned_free(pdist);
-	free(dirty);
-	free(packed);
-	free(packed_off);
 	free(is_dirty);
 	free(recs);
 	free(rec_of);

@@ -932,7 +932,10 @@ int
 pgv_hnsw_update_graph(pgv_hnsw * h, int32_t entry, const int32_t *elements, int nupd, const int64_t *tuple_offsets,
 					  const int32_t *tuples)
 {
+	view_refresh(h);
 	h->entry = entry;
+	if (h->view_of)
+		h->view_of->entry = entry;	/* through a view the patch lands in the owner's graph */
 	for (int i = 0; i < nupd; i++)
 	{
 		int32_t		e = elements[i];
