@@ -54,8 +54,22 @@ typedef struct
 {
 	int			length;
 	uint8_t		closer_set;		/* HnswNeighborArray.closerSet: the cached flags are usable */
-	cand	   *items;			/* capacity lm */
+	uint8_t		ord_valid;		/* ord[] is the items' order by CompareCandidateDistances (furthest first) */
+	cand	   *items;			/* capacity lm; ord[lm] (item indexes) sits behind it in the same allocation */
 }			nlist;
+
+/* a list's items and, behind them, the cached sort order (layer_m <= 200 fits a byte) */
+static inline cand *
+items_alloc(int lm)
+{
+	return malloc(sizeof(cand) * (size_t) lm + (size_t) lm);
+}
+
+static inline uint8_t *
+items_ord(const nlist * l, int lm)
+{
+	return (uint8_t *) (l->items + lm);
+}
 
 typedef struct
 {
@@ -73,9 +87,10 @@ typedef struct
 	int			nlocal;			/* + the batch elements that selected the owner */
 	int32_t    *ids;			/* [nlocal] element of each local */
 	int64_t		pair0;			/* first of its pairs in the request */
-	int			full;			/* every pair is in mat; otherwise only those with a newcomer (local >= nstart) */
+	int64_t		pair0b;			/* first of its member-member pairs in the second request (blocked lists) */
+	int			full;			/* every pair was requested; otherwise only those with a newcomer (local >= nstart) */
+	int			from;			/* the pairs (u, v < u) with u >= from were requested (1: all) */
 	int			blocked;		/* an update is waiting for the member-member pairs */
-	float	   *mat;			/* [nlocal x nlocal] */
 	float	   *newdist;		/* [nlocal - nstart] distance of each newcomer to the owner */
 	int			wait_from;		/* first local whose update waits for the second launch */
 	int			newcap;			/* newcomers of the batch (counted in step 4a) */
@@ -328,19 +343,31 @@ group_pairs(int n, int from)
 	return n > from ? ((int64_t) n * (n - 1) - (int64_t) from * (from - 1)) / 2 : 0;
 }
 
-/* the whole triangle as pgv_hnsw_score_groups returns it (from = 1): u ascending, then v < u ascending */
-static void
-fill_matrix(float *mat, int n, const float *tri)
+/*
+ * Where a selection finds the distance of two locals: in the reply of pgv_hnsw_score_groups, which holds a group's
+ * pairs (u, v < u) for u >= from, u ascending, then v ascending -- no matrix is built.  mm: the member-member triangle
+ * (u < from) of a second request, or NULL when those pairs were not fetched.
+ */
+typedef struct
 {
-	int64_t		t = 0;
+	const float *tri;
+	int			from;			/* >= 1 */
+	int			base;			/* from * (from - 1) / 2 */
+	const float *mm;
+}			pairsrc;
 
-	mat[0] = 0.0f;
-	for (int u = 1; u < n; u++)
-	{
-		mat[(size_t) u * n + u] = 0.0f;
-		for (int v = 0; v < u; v++, t++)
-			mat[(size_t) u * n + v] = mat[(size_t) v * n + u] = tri[t];
-	}
+static inline pairsrc
+pairs_of(const float *tri, int from, const float *mm)
+{
+	pairsrc		ps;
+
+	if (from < 1)
+		from = 1;
+	ps.tri = tri;
+	ps.from = from;
+	ps.base = from * (from - 1) / 2;
+	ps.mm = mm;
+	return ps;
 }
 
 /* ---------------------------------------------------------- SelectNeighbors */
@@ -364,21 +391,45 @@ cand_desc_cmp(const void *pa, const void *pb)
 	return 0;
 }
 
+/* the same order as one integer: larger key = earlier in cand_desc_cmp's order (-0.0 counts as 0.0, as in a float
+ * comparison; elements are >= 0) */
+#define SORT_KEYS 208			/* > 2 * 100 + 1 (m <= 100, src/hnsw.h:56) */
+static inline uint64_t
+cand_key(const cand * x)
+{
+	float		d = x->distance + 0.0f;
+	uint32_t	u;
+
+	memcpy(&u, &d, sizeof(u));
+	u ^= (u >> 31) ? 0xFFFFFFFFu : 0x80000000u;
+	return ((uint64_t) u << 32) | (uint32_t) x->element;
+}
+
 /*
- * CheckElementCloser (src/hnswutils.c:1040-1059) of e against the candidates in set[0 .. n), from
- * the matrix; *missing is set when a pair is not in a partial matrix (both locals below nknown).
+ * CheckElementCloser (src/hnswutils.c:1040-1059) of e against the candidates in set[0 .. n); *missing is set when a
+ * pair was not fetched (both locals below ps->from, no member-member triangle).
  */
 static int
-check_closer(const cand * e, cand * *set, int n, const float *mat, int nloc, int nknown, int *missing)
+check_closer(const cand * e, cand * *set, int n, const pairsrc * ps, int *missing)
 {
 	for (int i = 0; i < n; i++)
 	{
-		if (e->local < nknown && set[i]->local < nknown)
+		const int	a = e->local,
+					b = set[i]->local;
+		const int	hi = a > b ? a : b,
+					lo = a > b ? b : a;
+		float		d;
+
+		if (hi >= ps->from)
+			d = ps->tri[hi * (hi - 1) / 2 - ps->base + lo];
+		else if (ps->mm)
+			d = ps->mm[hi * (hi - 1) / 2 + lo];
+		else
 		{
 			*missing = 1;
 			return 0;
 		}
-		if (mat[(size_t) e->local * nloc + set[i]->local] <= e->distance)
+		if (d <= e->distance)
 			return 0;
 	}
 	return 1;
@@ -386,14 +437,14 @@ check_closer(const cand * e, cand * *set, int n, const float *mat, int nloc, int
 
 /*
  * Algorithm 4 with the reference's closer-flag cache (src/hnswutils.c:1064-1165).  Pairwise
- * distances come from mat[nloc x nloc] indexed by cand.local; pairs with both locals < nknown
- * are NOT in it (nknown = 0: everything is).  c is ordered furthest first unless sort != 0.
+ * distances come from ps, indexed by cand.local.  c is ordered furthest first unless sort != 0; with sort and ord,
+ * c[ord[0 .. nc - 2]] is the sorted order of all but the last candidate.  w is left holding the sorted candidates.
  * Returns |r|, or -1 when a missing pair was needed (nothing has been changed then).
  * *pruned = the candidate that would be dropped.
  */
 static int
-select_neighbors(cand * *c, int nc, int lm, const float *mat, int nloc, int nknown, uint8_t *closer_set,
-				 cand * new_cand, cand * *r, cand * *pruned, int sort, cand * *w, cand * *wd,
+select_neighbors(cand * *c, int nc, int lm, const pairsrc * ps, uint8_t *closer_set,
+				 cand * new_cand, cand * *r, cand * *pruned, int sort, const uint8_t *ord, cand * *w, cand * *wd,
 				 cand * *added, uint8_t *flag)
 {
 	int			wn = nc,
@@ -413,20 +464,63 @@ select_neighbors(cand * *c, int nc, int lm, const float *mat, int nloc, int nkno
 	}
 	if (sort)
 	{
-		/* list_sort(w, CompareCandidateDistances): a total order, so any algorithm gives the reference's
-		 * result; a neighbor list is a few dozen entries, where an insertion sort beats qsort's calls */
-		for (int i = 0; i < nc; i++)
-		{
-			cand	   *x = c[i];
-			int			j = i;
+		/* list_sort(w, CompareCandidateDistances): a total order, so any algorithm gives the reference's result.  A
+		 * neighbor list is a few dozen entries: an insertion sort over one 64-bit key per candidate (the distance's
+		 * bits made monotonic, then the element) -- this sort is most of a list update's cost. */
+		uint64_t	key[SORT_KEYS];
 
-			while (j > 0 && cand_desc_cmp(&x, &w[j - 1]) < 0)
+		if (ord)
+		{
+			/* c[0 .. nc - 2] in sorted order is c[ord[.]] (the list as the last selection left it); c[nc - 1], the
+			 * newcomer, is merged in */
+			cand	   *nw = c[nc - 1];
+			const uint64_t k = cand_key(nw);
+			int			pos = 0,
+						placed = 0;
+
+			for (int i = 0; i < nc - 1; i++)
 			{
-				w[j] = w[j - 1];
-				j--;
+				cand	   *x = c[ord[i]];
+
+				if (!placed && cand_key(x) < k)
+				{
+					w[pos++] = nw;
+					placed = 1;
+				}
+				w[pos++] = x;
 			}
-			w[j] = x;
+			if (!placed)
+				w[pos++] = nw;
 		}
+		else if (nc <= SORT_KEYS)
+			for (int i = 0; i < nc; i++)
+			{
+				cand	   *x = c[i];
+				const uint64_t k = cand_key(x);
+				int			j = i;
+
+				while (j > 0 && key[j - 1] < k)
+				{
+					key[j] = key[j - 1];
+					w[j] = w[j - 1];
+					j--;
+				}
+				key[j] = k;
+				w[j] = x;
+			}
+		else
+			for (int i = 0; i < nc; i++)
+			{
+				cand	   *x = c[i];
+				int			j = i;
+
+				while (j > 0 && cand_desc_cmp(&x, &w[j - 1]) < 0)
+				{
+					w[j] = w[j - 1];
+					j--;
+				}
+				w[j] = x;
+			}
 	}
 	else
 		memcpy(w, c, sizeof(*w) * (size_t) nc);
@@ -437,25 +531,25 @@ select_neighbors(cand * *c, int nc, int lm, const float *mat, int nloc, int nkno
 
 		/* use the previous state of r and wd to skip work when possible (:1098-1140) */
 		if (must_calculate)
-			closer = (uint8_t) check_closer(e, r, rn, mat, nloc, nknown, &missing);
+			closer = (uint8_t) check_closer(e, r, rn, ps, &missing);
 		else if (nadded > 0)
 		{
 			if (closer)
 			{
-				closer = (uint8_t) check_closer(e, added, nadded, mat, nloc, nknown, &missing);
+				closer = (uint8_t) check_closer(e, added, nadded, ps, &missing);
 				if (!closer)
 					removed_any = 1;
 			}
 			else if (removed_any)
 			{
-				closer = (uint8_t) check_closer(e, r, rn, mat, nloc, nknown, &missing);
+				closer = (uint8_t) check_closer(e, r, rn, ps, &missing);
 				if (closer)
 					added[nadded++] = e;
 			}
 		}
 		else if (e == new_cand)
 		{
-			closer = (uint8_t) check_closer(e, r, rn, mat, nloc, nknown, &missing);
+			closer = (uint8_t) check_closer(e, r, rn, ps, &missing);
 			if (closer)
 				added[nadded++] = e;
 		}
@@ -851,8 +945,10 @@ pgv_host_hnsw_build(pgv_hnsw * mirror, pgv_dtype dtype, int dim, const void *row
 	int			rc = PGV_OK;
 	groupbuf	gb = {0};
 	int64_t		npairs = 0;
-	float	   *pdist = NULL;
-	int64_t		pdist_cap = 0;
+	float	   *pdist = NULL,	/* the list records' pairs (first request) */
+			   *pdist2 = NULL;	/* the member-member pairs of the lists whose cached flags did not suffice (second request) */
+	int64_t		pdist_cap = 0,
+				pdist2_cap = 0;
 	int32_t    *sw_ids = NULL,	/* (aliases of the current batch's stage A) */
 			   *sw_cnt = NULL;
 	float	   *sw_dist = NULL;
@@ -962,7 +1058,7 @@ pgv_host_hnsw_build(pgv_hnsw * mirror, pgv_dtype dtype, int dim, const void *row
 			/* the first element has nothing to search: it becomes the entry point */
 			el[i0].layers = calloc((size_t) el[i0].level + 1, sizeof(nlist));
 			for (int lc = 0; lc <= el[i0].level; lc++)
-				el[i0].layers[lc].items = malloc(sizeof(cand) * (size_t) layer_m(m, lc));
+				el[i0].layers[lc].items = items_alloc(layer_m(m, lc));
 			entry = (int32_t) i0;
 			linked = 1;
 			rc = pgv_hnsw_update_graph(mirror, entry, NULL, 0, NULL, NULL);
@@ -1075,7 +1171,6 @@ pgv_host_hnsw_build(pgv_hnsw * mirror, pgv_dtype dtype, int dim, const void *row
 		/* ---- 3. SelectNeighbors + AddConnections per element and layer (independent: one thread each) */
 #pragma omp parallel if (B >= 8) num_threads(nthreads)
 		{
-			float	   *mat = malloc(sizeof(float) * (size_t) ef_construction * ef_construction);
 			cand	   *lw = malloc(sizeof(cand) * (size_t) ef_construction);
 			cand	  **c = malloc(sizeof(cand *) * (size_t) ef_construction * 5);
 			cand	  **r = c + ef_construction,
@@ -1112,20 +1207,22 @@ pgv_host_hnsw_build(pgv_hnsw * mirror, pgv_dtype dtype, int dim, const void *row
 						lw[i].closer = 0;
 						c[i] = &lw[i];
 					}
-					if (nw > lm)
-						fill_matrix(mat, nw, cdist + tri_off[(size_t) b * lcap + lc]);
-					rn = select_neighbors(c, nw, lm, mat, nw, 0, &closer_set, NULL, r, NULL, 0, w, wd, added, flag);
+					{
+						/* (the triangle is only there, and only looked at, when the list has to be thinned) */
+						pairsrc		ps = pairs_of(cdist + tri_off[(size_t) b * lcap + lc], 1, NULL);
+
+						rn = select_neighbors(c, nw, lm, &ps, &closer_set, NULL, r, NULL, 0, NULL, w, wd, added, flag);
+					}
 					x->layers[lc].closer_set = closer_set;
-					x->layers[lc].items = malloc(sizeof(cand) * (size_t) lm);
+					x->layers[lc].items = items_alloc(lm);
 					x->layers[lc].length = rn;
 					for (int i = 0; i < rn; i++)
 						x->layers[lc].items[i] = *r[i];
 				}
 				for (int lc = 0; lc <= x->level; lc++)
 					if (!x->layers[lc].items)
-						x->layers[lc].items = malloc(sizeof(cand) * (size_t) layer_m(m, lc));
+						x->layers[lc].items = items_alloc(layer_m(m, lc));
 			}
-			free(mat);
 			free(lw);
 			free(c);
 			free(flag);
@@ -1285,7 +1382,6 @@ pgv_host_hnsw_build(pgv_hnsw * mirror, pgv_dtype dtype, int dim, const void *row
 
 				rcd->nstart = l->length;
 				rcd->nlocal = l->length + nnew;
-				rcd->mat = NULL;
 				rcd->ids = arena_alloc(&arenas[omp_get_thread_num()], sizeof(int32_t) * (size_t) rcd->nlocal);
 				if (!rcd->ids)
 				{
@@ -1331,6 +1427,7 @@ pgv_host_hnsw_build(pgv_hnsw * mirror, pgv_dtype dtype, int dim, const void *row
 					int			from = rcd->full ? 1 : rcd->nstart;	/* cached flags: only the pairs that involve a newcomer */
 
 					rcd->pair0 = total;
+					rcd->from = from < 1 ? 1 : from;
 					/* a list that cannot overflow in this batch never runs a selection */
 					if (rcd->nlocal <= layer_m(m, rcd->lc))
 						continue;
@@ -1420,7 +1517,7 @@ pgv_host_hnsw_build(pgv_hnsw * mirror, pgv_dtype dtype, int dim, const void *row
 					for (int k = 0; k < nrec; k++)
 						if (recs[k].blocked)
 						{
-							recs[k].pair0 = npairs;
+							recs[k].pair0b = npairs;
 							if (!groups_add(&gb, recs[k].ids, recs[k].nstart, 1, npairs))
 							{
 								rc = pgv_host_fail(PGV_ERR_NOMEM, "out of memory");
@@ -1429,18 +1526,19 @@ pgv_host_hnsw_build(pgv_hnsw * mirror, pgv_dtype dtype, int dim, const void *row
 							npairs += group_pairs(recs[k].nstart, 1);
 						}
 					gb.pair_start[gb.ngroups] = npairs;
-					if (npairs > pdist_cap)
+					/* (the first request's reply stays: the newcomers' pairs are looked up there) */
+					if (npairs > pdist2_cap)
 					{
-						pgv_pinned_free(pdist);
-						pdist = NULL;
-						pdist_cap = npairs * 2;
-						if ((rc = pgv_pinned_alloc(sizeof(float) * (size_t) pdist_cap, (void **) &pdist)) != PGV_OK)
+						pgv_pinned_free(pdist2);
+						pdist2 = NULL;
+						pdist2_cap = npairs * 2;
+						if ((rc = pgv_pinned_alloc(sizeof(float) * (size_t) pdist2_cap, (void **) &pdist2)) != PGV_OK)
 						{
-							pdist_cap = 0;
+							pdist2_cap = 0;
 							goto dev_fail;
 						}
 					}
-					rc = pgv_hnsw_score_groups(mirror, gb.ids, gb.ids_start, gb.from, gb.pair_start, gb.ngroups, gb.nids, npairs, pdist);
+					rc = pgv_hnsw_score_groups(mirror, gb.ids, gb.ids_start, gb.from, gb.pair_start, gb.ngroups, gb.nids, npairs, pdist2);
 					if (rc != PGV_OK)
 						goto dev_fail;
 					out->device_pairs += npairs;
@@ -1463,43 +1561,15 @@ pgv_host_hnsw_build(pgv_hnsw * mirror, pgv_dtype dtype, int dim, const void *row
 						nlist	   *l = &el[rcd->owner].layers[rcd->lc];
 						int			lm = layer_m(m, rcd->lc);
 						int			from = rcd->nstart;
+						pairsrc		ps;
 
-						if (pass == 0)
+						if (pass == 1)
 						{
-							if (rcd->nlocal > lm)
-							{
-								rcd->mat = arena_alloc(&arenas[omp_get_thread_num()], sizeof(float) * (size_t) rcd->nlocal * rcd->nlocal);
-								if (!rcd->mat)
-								{
-#pragma omp atomic write
-									oom = 1;
-									continue;
-								}
-								memset(rcd->mat, 0, sizeof(float) * (size_t) rcd->nlocal * rcd->nlocal);
-								if (rcd->full)
-									fill_matrix(rcd->mat, rcd->nlocal, pdist + rcd->pair0);
-								else
-								{
-									int64_t		t = rcd->pair0;
-
-									for (int u = rcd->nstart; u < rcd->nlocal; u++)
-										for (int v = 0; v < u; v++, t++)
-											rcd->mat[(size_t) u * rcd->nlocal + v] = rcd->mat[(size_t) v * rcd->nlocal + u] = pdist[t];
-								}
-							}
-						}
-						else
-						{
-							int64_t		t = rcd->pair0;
-
 							if (!rcd->blocked)
 								continue;
-							for (int u = 1; u < rcd->nstart; u++)
-								for (int v = 0; v < u; v++, t++)
-									rcd->mat[(size_t) u * rcd->nlocal + v] = rcd->mat[(size_t) v * rcd->nlocal + u] = pdist[t];
-							rcd->full = 1;
 							from = rcd->wait_from;
 						}
+						ps = pairs_of(pdist + rcd->pair0, rcd->from, pass ? pdist2 + rcd->pair0b : NULL);
 						for (int u = from; u < rcd->nlocal; u++)
 						{
 							cand		new_hc;
@@ -1515,14 +1585,15 @@ pgv_host_hnsw_build(pgv_hnsw * mirror, pgv_dtype dtype, int dim, const void *row
 							if (l->length < lm)
 							{
 								l->items[l->length++] = new_hc;
+								l->ord_valid = 0;
 								continue;
 							}
 							nc = l->length + 1;
 							for (int j = 0; j < l->length; j++)
 								c[j] = &l->items[j];
 							c[nc - 1] = &new_hc;
-							rn = select_neighbors(c, nc, lm, rcd->mat, rcd->nlocal, rcd->full ? 0 : rcd->nstart,
-												  &l->closer_set, &new_hc, r, &pruned, 1, w, wd, added, flag);
+							rn = select_neighbors(c, nc, lm, &ps, &l->closer_set, &new_hc, r, &pruned, 1,
+												  l->ord_valid ? items_ord(l, lm) : NULL, w, wd, added, flag);
 							if (rn < 0)
 							{
 								/* needs member-member distances that were not fetched: this and every later
@@ -1532,13 +1603,23 @@ pgv_host_hnsw_build(pgv_hnsw * mirror, pgv_dtype dtype, int dim, const void *row
 								nblocked++;
 								break;
 							}
-							if (pruned != NULL && pruned != &new_hc)
-								for (int j = 0; j < l->length; j++)
-									if (l->items[j].element == pruned->element)
-									{
-										l->items[j] = new_hc;
-										break;
-									}
+							{
+								/* the list keeps its members' places, the newcomer takes the dropped one's
+								 * (src/hnswutils.c:1211-1227); the sorted order w, less the dropped candidate, is kept
+								 * for the list's next selection */
+								uint8_t    *ord = items_ord(l, lm);
+								int			slot = -1,
+											o = 0;
+
+								if (pruned != NULL && pruned != &new_hc)
+									slot = (int) (pruned - l->items);
+								for (int i = 0; i < nc; i++)
+									if (w[i] != pruned)
+										ord[o++] = (uint8_t) (w[i] == &new_hc ? slot : (int) (w[i] - l->items));
+								l->ord_valid = 1;
+								if (slot >= 0)
+									l->items[slot] = new_hc;
+							}
 						}
 					}
 					free(c);
@@ -1549,7 +1630,7 @@ pgv_host_hnsw_build(pgv_hnsw * mirror, pgv_dtype dtype, int dim, const void *row
 
 		if (oom)
 		{
-			rc = pgv_host_fail(PGV_ERR_NOMEM, "out of memory for a list's distance matrix");
+			rc = pgv_host_fail(PGV_ERR_NOMEM, "out of memory for the batch's list records");
 			goto done;
 		}
 		PHASE(PH_PATCH);
@@ -1701,6 +1782,7 @@ done:
 	free(gb.from);
 	free(gb.pair_start);
 	pgv_pinned_free(pdist);
+	pgv_pinned_free(pdist2);
 	free(is_dirty);
 	free(recs);
 	free(rec_of);
