@@ -608,6 +608,21 @@ write_tuple(const elem * el, int32_t e, int m, const int64_t *nbr_start, int32_t
 	}
 }
 
+/* one layer's part of that tuple, from the list as it stands (the replay writes it while the list is in its cache) */
+static inline void
+write_segment(const elem * x, int32_t e, int lc, int m, const int64_t *nbr_start, int32_t *nbr)
+{
+	const nlist *l = &x->layers[lc];
+	const int	lm = layer_m(m, lc);
+	int32_t    *o = nbr + nbr_start[e] + (int64_t) (x->level - lc) * m;
+	int			i = 0;
+
+	for (; i < l->length; i++)
+		o[i] = l->items[i].element;
+	for (; i < lm; i++)
+		o[i] = -1;
+}
+
 /* ------------------------------------------------------------ stage A of a batch
  * What a batch needs from the device BEFORE any of its host work -- the searches of HnswFindElementNeighbors for all of
  * its elements and the pairwise distances inside every candidate list that has to be thinned -- depends on the graph as
@@ -1160,7 +1175,7 @@ pgv_host_hnsw_build(pgv_hnsw * mirror, pgv_dtype dtype, int dim, const void *row
 						nx->i0 = n0;
 						nx->B = nB;
 						nx->lcap = nlcap;
-						nx->seq = worker_post(&helper, JOB_STAGE_A, nx);
+						/* (posted in step 4, behind this batch's own scoring requests: those are waited for) */
 						ahead_valid = 1;
 					}
 				}
@@ -1418,8 +1433,9 @@ pgv_host_hnsw_build(pgv_hnsw * mirror, pgv_dtype dtype, int dim, const void *row
 				score_job  *sj = &slices[sl];
 				int64_t		base = total;
 
-				sj->klo = (int) ((int64_t) nrec * sl / nslices);
-				sj->khi = (int) ((int64_t) nrec * (sl + 1) / nslices);
+				/* a short first slice (it is the one waited for with nothing to do), the rest in equal parts */
+				sj->klo = sl == 0 ? 0 : (int) (((int64_t) nrec * (1 + (sl - 1) * 7 / (nslices - 1))) / 8);
+				sj->khi = sl == nslices - 1 ? nrec : (int) (((int64_t) nrec * (1 + sl * 7 / (nslices - 1))) / 8);
 				groups_reset(&sj->gb);
 				for (int k = sj->klo; k < sj->khi; k++)
 				{
@@ -1481,6 +1497,8 @@ pgv_host_hnsw_build(pgv_hnsw * mirror, pgv_dtype dtype, int dim, const void *row
 			}
 			out->device_pairs += npairs;
 		}
+		if (ahead_valid)
+			stages[cur ^ 1].seq = worker_post(&helper, JOB_STAGE_A, &stages[cur ^ 1]);
 		PHASE(PH_UPDATE);
 
 		/* ---- 5. HnswUpdateNeighborsInMemory (src/hnswbuild.c:376-405).  The reference links one element after
@@ -1621,6 +1639,8 @@ pgv_host_hnsw_build(pgv_hnsw * mirror, pgv_dtype dtype, int dim, const void *row
 									l->items[slot] = new_hc;
 							}
 						}
+						/* the list's part of its owner's neighbor tuple, for step 6 */
+						write_segment(&el[rcd->owner], rcd->owner, rcd->lc, m, out->nbr_start, out->nbr);
 					}
 					free(c);
 					free(flag);
@@ -1693,7 +1713,9 @@ pgv_host_hnsw_build(pgv_hnsw * mirror, pgv_dtype dtype, int dim, const void *row
 #pragma omp parallel for if (B >= 8) num_threads(nthreads) schedule(static)
 			for (int q = 0; q < ndirty; q++)
 			{
-				write_tuple(el, pj->dirty[q], m, out->nbr_start, out->nbr);
+				/* (the lists touched by the replay wrote their parts in step 5; the batch's own elements are new) */
+				if (pj->dirty[q] >= i0)
+					write_tuple(el, pj->dirty[q], m, out->nbr_start, out->nbr);
 				memcpy(pj->packed + pj->packed_off[q], out->nbr + out->nbr_start[pj->dirty[q]],
 					   sizeof(int32_t) * (size_t) (pj->packed_off[q + 1] - pj->packed_off[q]));
 			}
