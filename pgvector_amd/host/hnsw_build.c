@@ -86,7 +86,8 @@ typedef struct
 	int			nstart;			/* members when the batch began: locals 0 .. nstart - 1 */
 	int			nlocal;			/* + the batch elements that selected the owner */
 	int32_t    *ids;			/* [nlocal] element of each local */
-	int64_t		pair0;			/* first of its pairs in the request */
+	int64_t		pair0;			/* first of its pairs in its slice's request */
+	int			slice;			/* the scoring request (of step 4) that holds them */
 	int64_t		pair0b;			/* first of its member-member pairs in the second request (blocked lists) */
 	int			full;			/* every pair was requested; otherwise only those with a newcomer (local >= nstart) */
 	int			from;			/* the pairs (u, v < u) with u >= from were requested (1: all) */
@@ -245,6 +246,23 @@ typedef struct
 	int32_t		element;
 	float		distance;
 }			link_req;
+
+/* one thread's share of step 4a: the lists whose owners are dealt to it */
+typedef struct
+{
+	record	   *recs;
+	int			nrec,
+				cap;
+	link_req   *links;
+	int64_t		nlinks,
+				links_cap;
+	int32_t    *tab;			/* hash: (owner, lc) -> own record index + 1 */
+	int64_t		tab_cap;
+	int			ndirty;
+	int			oom;
+	int64_t		rec_base,		/* where its records / requests start in the batch's arrays */
+				link_base;
+}			recpart;
 
 static double
 now_secs(void)
@@ -980,8 +998,7 @@ pgv_host_hnsw_build(pgv_hnsw * mirror, pgv_dtype dtype, int dim, const void *row
 	uint8_t    *is_dirty = NULL;
 	record	   *recs = NULL;
 	int			recs_cap = 0;
-	int64_t    *rec_of = NULL;	/* hash: (owner, lc) -> record index + 1 */
-	link_req   *links = NULL;	/* the batch's (list, newcomer) requests in link order, then grouped by list */
+	recpart    *parts = NULL;	/* [nthreads] step 4a's per-thread records and requests */
 	int64_t		links_cap = 0;
 	int32_t    *grp_elem = NULL;
 	float	   *grp_dist = NULL;
@@ -993,7 +1010,6 @@ pgv_host_hnsw_build(pgv_hnsw * mirror, pgv_dtype dtype, int dim, const void *row
 	int			nthreads = omp_get_max_threads() < 16 ? omp_get_max_threads() : 16;	/* 32: twice as slow (measured) */
 	double		phase_t0 = now_secs();
 	int			cur_phase = PH_RECORDS;
-	int64_t		hash_cap = 0;
 
 	memset(stages, 0, sizeof(stages));
 	memset(&helper, 0, sizeof(helper));
@@ -1056,8 +1072,7 @@ pgv_host_hnsw_build(pgv_hnsw * mirror, pgv_dtype dtype, int dim, const void *row
 		goto done;
 	}
 	is_dirty = calloc((size_t) n, 1);
-	hash_cap = 1 << 10;			/* grows by doubling at load factor 1/2 (see below) */
-	rec_of = calloc((size_t) hash_cap, sizeof(int64_t));
+	parts = calloc((size_t) nthreads, sizeof(recpart));
 	arenas = calloc((size_t) nthreads, sizeof(arena));
 
 	for (int64_t i0 = 0; i0 < n;)
@@ -1175,7 +1190,9 @@ pgv_host_hnsw_build(pgv_hnsw * mirror, pgv_dtype dtype, int dim, const void *row
 						nx->i0 = n0;
 						nx->B = nB;
 						nx->lcap = nlcap;
-						/* (posted in step 4, behind this batch's own scoring requests: those are waited for) */
+						/* posted at once: queued behind this batch's own scoring requests instead, the build was 1.7 s
+						 * slower (measured, profiles/r04/hnsw_build_pipeline.md) */
+						nx->seq = worker_post(&helper, JOB_STAGE_A, nx);
 						ahead_valid = 1;
 					}
 				}
@@ -1274,17 +1291,18 @@ pgv_host_hnsw_build(pgv_hnsw * mirror, pgv_dtype dtype, int dim, const void *row
 
 		PHASE(PH_RECORDS);
 		/* ---- 4. the lists this batch links into, and every distance their re-selections can look up.
-		 * 4a (serial, touches only the small hash table): one request per (batch element, chosen neighbor, layer)
-		 * in the order the reference's loop would link them, and a bare record per distinct list. */
+		 * 4a: one request per (batch element, chosen neighbor, layer) in the order the reference's loop would link
+		 * them, and a bare record per distinct list.  The lists are dealt to the threads by owner: every thread walks
+		 * all requests (they are the batch's fresh lists, a few hundred KB) and keeps its own, in its own small hash
+		 * table -- the order inside a list is the walk's, whatever the number of threads. */
 		{
 			int64_t		nlinks = 0;
 
 			for (int b = 0; b < B; b++)
 			{
 				int32_t		e = (int32_t) (i0 + b);
-				elem	   *x = &el[e];
 
-				if (!x->layers)
+				if (!el[e].layers)
 					continue;
 				linked++;
 				if (!is_dirty[e])
@@ -1292,100 +1310,189 @@ pgv_host_hnsw_build(pgv_hnsw * mirror, pgv_dtype dtype, int dim, const void *row
 					is_dirty[e] = 1;
 					ndirty++;
 				}
-				for (int lc = x->level; lc >= 0; lc--)
-					for (int i = 0; i < x->layers[lc].length; i++)
-					{
-						int32_t		owner = x->layers[lc].items[i].element;
-						uint64_t	key = ((uint64_t) owner << 6) | (uint64_t) lc;
-						int64_t		h = (int64_t) ((key * 0x9E3779B97F4A7C15ull) >> 40) & (hash_cap - 1);
-						int64_t		ri;		/* record index + 1 (the table may be rebuilt below: h is not kept) */
-
-						while (rec_of[h] != 0 && !(recs[rec_of[h] - 1].owner == owner && recs[rec_of[h] - 1].lc == lc))
-							h = (h + 1) & (hash_cap - 1);
-						ri = rec_of[h];
-						if (ri == 0)
-						{
-							record	   *rcd;
-
-							if (nrec == recs_cap)
-							{
-								recs_cap = recs_cap ? recs_cap * 2 : 1024;
-								recs = realloc(recs, sizeof(record) * (size_t) recs_cap);
-							}
-							rcd = &recs[nrec];
-							rcd->owner = owner;
-							rcd->lc = lc;
-							rcd->newcap = 0;	/* newcomers, counted here */
-							rec_of[h] = ++nrec;
-							ri = nrec;
-							if ((int64_t) nrec * 2 > hash_cap)
-							{
-								/* load factor 1/2 reached (a batch touches up to B * (2m + level * m) lists; m up to
-								 * 100, src/hnsw.h:50): double the table and rehash the records made so far */
-								int64_t		ncap = hash_cap * 2;
-								int64_t    *nt = calloc((size_t) ncap, sizeof(int64_t));
-
-								if (!nt)
-								{
-									rc = pgv_host_fail(PGV_ERR_NOMEM, "out of memory growing the batch's list table");
-									goto done;
-								}
-								for (int64_t r = 0; r < nrec; r++)
-								{
-									uint64_t	k2 = ((uint64_t) recs[r].owner << 6) | (uint64_t) recs[r].lc;
-									int64_t		h2 = (int64_t) ((k2 * 0x9E3779B97F4A7C15ull) >> 40) & (ncap - 1);
-
-									while (nt[h2] != 0)
-										h2 = (h2 + 1) & (ncap - 1);
-									nt[h2] = r + 1;
-								}
-								free(rec_of);
-								rec_of = nt;
-								hash_cap = ncap;
-							}
-							if (!is_dirty[owner])
-							{
-								is_dirty[owner] = 1;
-								ndirty++;
-							}
-						}
-						if (nlinks == links_cap)
-						{
-							links_cap = links_cap ? links_cap * 2 : 16384;
-							links = realloc(links, sizeof(link_req) * (size_t) links_cap);
-							grp_elem = realloc(grp_elem, sizeof(int32_t) * (size_t) links_cap);
-							grp_dist = realloc(grp_dist, sizeof(float) * (size_t) links_cap);
-							if (!links || !grp_elem || !grp_dist)
-							{
-								rc = pgv_host_fail(PGV_ERR_NOMEM, "out of memory");
-								goto done;
-							}
-						}
-						links[nlinks].rec = (int32_t) (ri - 1);
-						links[nlinks].element = e;
-						links[nlinks].distance = x->layers[lc].items[i].distance;
-						nlinks++;
-						recs[ri - 1].newcap++;
-					}
 				/* the entry point moves up with the tallest element (src/hnswbuild.c:425-430) */
-				if (x->level > el[entry].level)
+				if (el[e].level > el[entry].level)
 					entry = e;
 			}
-			/* 4b: the requests grouped by list, link order kept inside a list (counting sort) */
-			grp_off = realloc(grp_off, sizeof(int64_t) * (size_t) (nrec + 1));
-			grp_off[0] = 0;
-			for (int k = 0; k < nrec; k++)
+#pragma omp parallel if (B >= 8) num_threads(nthreads)
 			{
-				grp_off[k + 1] = grp_off[k] + recs[k].newcap;
-				recs[k].nlocal = 0;		/* fill cursor of 4b */
-			}
-			for (int64_t t = 0; t < nlinks; t++)
-			{
-				record	   *rcd = &recs[links[t].rec];
-				int64_t		at = grp_off[links[t].rec] + rcd->nlocal++;
+				const int	T = omp_get_num_threads(),
+							me = omp_get_thread_num();
+				recpart    *rp = &parts[me];
 
-				grp_elem[at] = links[t].element;
-				grp_dist[at] = links[t].distance;
+				rp->nrec = 0;
+				rp->nlinks = 0;
+				rp->ndirty = 0;
+				if (rp->tab_cap == 0)
+				{
+					rp->tab_cap = 1 << 10;	/* grows by doubling at load factor 1/2 */
+					rp->tab = malloc(sizeof(int32_t) * (size_t) rp->tab_cap);
+				}
+				if (!rp->tab)
+					rp->oom = 1;
+				else
+					memset(rp->tab, 0, sizeof(int32_t) * (size_t) rp->tab_cap);
+				for (int b = 0; b < B && !rp->oom; b++)
+				{
+					int32_t		e = (int32_t) (i0 + b);
+					elem	   *x = &el[e];
+
+					if (!x->layers)
+						continue;
+					for (int lc = x->level; lc >= 0; lc--)
+						for (int i = 0; i < x->layers[lc].length; i++)
+						{
+							int32_t		owner = x->layers[lc].items[i].element;
+							uint64_t	key,
+										hv;
+							int64_t		h;
+							int32_t		ri;		/* record index + 1 (the table may be rebuilt below: h is not kept) */
+
+							if ((int) (((uint32_t) owner * 2654435761u) >> 16) % T != me)
+								continue;
+							key = ((uint64_t) owner << 6) | (uint64_t) lc;
+							hv = key * 0x9E3779B97F4A7C15ull;
+							h = (int64_t) (hv >> 40) & (rp->tab_cap - 1);
+							while (rp->tab[h] != 0 && !(rp->recs[rp->tab[h] - 1].owner == owner && rp->recs[rp->tab[h] - 1].lc == lc))
+								h = (h + 1) & (rp->tab_cap - 1);
+							ri = rp->tab[h];
+							if (ri == 0)
+							{
+								record	   *rcd;
+
+								if (rp->nrec == rp->cap)
+								{
+									int			cap = rp->cap ? rp->cap * 2 : 1024;
+									record	   *grown = realloc(rp->recs, sizeof(record) * (size_t) cap);
+
+									if (!grown)
+									{
+										rp->oom = 1;
+										break;
+									}
+									rp->recs = grown;
+									rp->cap = cap;
+								}
+								rcd = &rp->recs[rp->nrec];
+								rcd->owner = owner;
+								rcd->lc = lc;
+								rcd->newcap = 0;	/* newcomers, counted here */
+								rp->tab[h] = ++rp->nrec;
+								ri = rp->nrec;
+								if ((int64_t) rp->nrec * 2 > rp->tab_cap)
+								{
+									/* load factor 1/2 reached (a batch touches up to B * (2m + level * m) lists; m up to
+									 * 100, src/hnsw.h:50): double the table and rehash the records made so far */
+									int64_t		ncap = rp->tab_cap * 2;
+									int32_t    *nt = calloc((size_t) ncap, sizeof(int32_t));
+
+									if (!nt)
+									{
+										rp->oom = 1;
+										break;
+									}
+									for (int r = 0; r < rp->nrec; r++)
+									{
+										uint64_t	k2 = ((uint64_t) rp->recs[r].owner << 6) | (uint64_t) rp->recs[r].lc;
+										int64_t		h2 = (int64_t) ((k2 * 0x9E3779B97F4A7C15ull) >> 40) & (ncap - 1);
+
+										while (nt[h2] != 0)
+											h2 = (h2 + 1) & (ncap - 1);
+										nt[h2] = r + 1;
+									}
+									free(rp->tab);
+									rp->tab = nt;
+									rp->tab_cap = ncap;
+								}
+								if (!is_dirty[owner])	/* (owners are dealt to threads: no two write one flag) */
+								{
+									is_dirty[owner] = 1;
+									rp->ndirty++;
+								}
+							}
+							if (rp->nlinks == rp->links_cap)
+							{
+								int64_t		cap = rp->links_cap ? rp->links_cap * 2 : 4096;
+								link_req   *grown = realloc(rp->links, sizeof(link_req) * (size_t) cap);
+
+								if (!grown)
+								{
+									rp->oom = 1;
+									break;
+								}
+								rp->links = grown;
+								rp->links_cap = cap;
+							}
+							rp->links[rp->nlinks].rec = ri - 1;
+							rp->links[rp->nlinks].element = e;
+							rp->links[rp->nlinks].distance = x->layers[lc].items[i].distance;
+							rp->nlinks++;
+							rp->recs[ri - 1].newcap++;
+						}
+				}
+#pragma omp barrier
+#pragma omp single
+				{
+					/* where each thread's records and requests go in the batch's arrays */
+					int64_t		nr = 0,
+								nl = 0;
+
+					for (int t = 0; t < T; t++)
+					{
+						parts[t].rec_base = nr;
+						parts[t].link_base = nl;
+						nr += parts[t].nrec;
+						nl += parts[t].nlinks;
+						ndirty += parts[t].ndirty;
+						oom |= parts[t].oom;
+					}
+					if (nr + 1 > recs_cap)
+					{
+						recs_cap = (int) (nr + 1) * 2;
+						recs = realloc(recs, sizeof(record) * (size_t) recs_cap);
+						grp_off = realloc(grp_off, sizeof(int64_t) * (size_t) (recs_cap + 1));
+					}
+					if (nl + 1 > links_cap)
+					{
+						links_cap = (nl + 1) * 2;
+						grp_elem = realloc(grp_elem, sizeof(int32_t) * (size_t) links_cap);
+						grp_dist = realloc(grp_dist, sizeof(float) * (size_t) links_cap);
+					}
+					if (!recs || !grp_off || !grp_elem || !grp_dist)
+						oom = 1;
+					else
+						grp_off[nr] = nl;
+					nrec = (int) nr;
+					nlinks = nl;
+				}
+				/* 4b: the requests grouped by list, link order kept inside a list (counting sort, thread by thread) */
+				if (!oom)
+				{
+					int64_t		at = rp->link_base;
+
+					for (int k = 0; k < rp->nrec; k++)
+					{
+						grp_off[rp->rec_base + k] = at;
+						at += rp->recs[k].newcap;
+						rp->recs[k].nlocal = 0;		/* fill cursor */
+					}
+					for (int64_t t = 0; t < rp->nlinks; t++)
+					{
+						record	   *rcd = &rp->recs[rp->links[t].rec];
+						int64_t		to = grp_off[rp->rec_base + rp->links[t].rec] + rcd->nlocal++;
+
+						grp_elem[to] = rp->links[t].element;
+						grp_dist[to] = rp->links[t].distance;
+					}
+					if (rp->nrec > 0)
+						memcpy(recs + rp->rec_base, rp->recs, sizeof(record) * (size_t) rp->nrec);
+				}
+			}
+			(void) nlinks;
+			if (oom)
+			{
+				rc = pgv_host_fail(PGV_ERR_NOMEM, "out of memory for the batch's list records");
+				goto done;
 			}
 			/* 4c (parallel: this is where the owners' lists, cold in the cache, are read): members + newcomers */
 #pragma omp parallel for if (B >= 8) num_threads(nthreads) schedule(static)
@@ -1428,37 +1535,49 @@ pgv_host_hnsw_build(pgv_hnsw * mirror, pgv_dtype dtype, int dim, const void *row
 		{
 			int64_t		total = 0;
 
+			/* (one thread per slice; pair offsets are the slice's own: its reply starts at slices[.].out) */
+#pragma omp parallel for if (nslices > 1) num_threads(nslices) schedule(static, 1)
 			for (int sl = 0; sl < nslices; sl++)
 			{
 				score_job  *sj = &slices[sl];
-				int64_t		base = total;
+				int64_t		mine = 0;
 
 				/* a short first slice (it is the one waited for with nothing to do), the rest in equal parts */
 				sj->klo = sl == 0 ? 0 : (int) (((int64_t) nrec * (1 + (sl - 1) * 7 / (nslices - 1))) / 8);
 				sj->khi = sl == nslices - 1 ? nrec : (int) (((int64_t) nrec * (1 + sl * 7 / (nslices - 1))) / 8);
+				sj->rc = PGV_OK;
+				sj->seq = 0;
 				groups_reset(&sj->gb);
 				for (int k = sj->klo; k < sj->khi; k++)
 				{
 					record	   *rcd = &recs[k];
 					int			from = rcd->full ? 1 : rcd->nstart;	/* cached flags: only the pairs that involve a newcomer */
 
-					rcd->pair0 = total;
+					rcd->pair0 = mine;
+					rcd->slice = sl;
 					rcd->from = from < 1 ? 1 : from;
 					/* a list that cannot overflow in this batch never runs a selection */
 					if (rcd->nlocal <= layer_m(m, rcd->lc))
 						continue;
-					if (!groups_add(&sj->gb, rcd->ids, rcd->nlocal, from, total - base))
+					if (!groups_add(&sj->gb, rcd->ids, rcd->nlocal, from, mine))
 					{
-						rc = pgv_host_fail(PGV_ERR_NOMEM, "out of memory");
-						goto done;
+						sj->rc = PGV_ERR_NOMEM;
+						break;
 					}
-					total += group_pairs(rcd->nlocal, from);
+					mine += group_pairs(rcd->nlocal, from);
 				}
-				sj->npairs = total - base;
+				sj->npairs = mine;
 				if (sj->gb.ngroups > 0)
-					sj->gb.pair_start[sj->gb.ngroups] = sj->npairs;
-				sj->rc = PGV_OK;
-				sj->seq = 0;
+					sj->gb.pair_start[sj->gb.ngroups] = mine;
+			}
+			for (int sl = 0; sl < nslices; sl++)
+			{
+				if (slices[sl].rc != PGV_OK)
+				{
+					rc = pgv_host_fail(PGV_ERR_NOMEM, "out of memory");
+					goto done;
+				}
+				total += slices[sl].npairs;
 			}
 			npairs = total;
 		}
@@ -1497,8 +1616,6 @@ pgv_host_hnsw_build(pgv_hnsw * mirror, pgv_dtype dtype, int dim, const void *row
 			}
 			out->device_pairs += npairs;
 		}
-		if (ahead_valid)
-			stages[cur ^ 1].seq = worker_post(&helper, JOB_STAGE_A, &stages[cur ^ 1]);
 		PHASE(PH_UPDATE);
 
 		/* ---- 5. HnswUpdateNeighborsInMemory (src/hnswbuild.c:376-405).  The reference links one element after
@@ -1587,7 +1704,7 @@ pgv_host_hnsw_build(pgv_hnsw * mirror, pgv_dtype dtype, int dim, const void *row
 								continue;
 							from = rcd->wait_from;
 						}
-						ps = pairs_of(pdist + rcd->pair0, rcd->from, pass ? pdist2 + rcd->pair0b : NULL);
+						ps = pairs_of(slices[rcd->slice].out + rcd->pair0, rcd->from, pass ? pdist2 + rcd->pair0b : NULL);
 						for (int u = from; u < rcd->nlocal; u++)
 						{
 							cand		new_hc;
@@ -1740,7 +1857,6 @@ pgv_host_hnsw_build(pgv_hnsw * mirror, pgv_dtype dtype, int dim, const void *row
 			arena_reset(&arenas[t]);
 		nrec = 0;
 		PHASE(PH_RECORDS);
-		memset(rec_of, 0, sizeof(int64_t) * (size_t) hash_cap);
 		i0 += B;
 		out->batches++;
 		if (ahead_valid)
@@ -1795,7 +1911,6 @@ done:
 			arena_free(&arenas[t]);
 		free(arenas);
 	}
-	free(links);
 	free(grp_elem);
 	free(grp_dist);
 	free(grp_off);
@@ -1807,7 +1922,16 @@ done:
 	pgv_pinned_free(pdist2);
 	free(is_dirty);
 	free(recs);
-	free(rec_of);
+	if (parts)
+	{
+		for (int t = 0; t < nthreads; t++)
+		{
+			free(parts[t].recs);
+			free(parts[t].links);
+			free(parts[t].tab);
+		}
+		free(parts);
+	}
 	if (rc != PGV_OK)
 		pgv_host_hnsw_built_free(out);
 	return rc;
