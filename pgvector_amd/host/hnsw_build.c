@@ -1348,7 +1348,7 @@ pgv_host_hnsw_build(pgv_hnsw * mirror, pgv_dtype dtype, int dim, const void *row
 							int64_t		h;
 							int32_t		ri;		/* record index + 1 (the table may be rebuilt below: h is not kept) */
 
-							if ((int) (((uint32_t) owner * 2654435761u) >> 16) % T != me)
+							if ((int) (((uint64_t) ((uint32_t) owner * 2654435761u) * (uint64_t) T) >> 32) != me)
 								continue;
 							key = ((uint64_t) owner << 6) | (uint64_t) lc;
 							hv = key * 0x9E3779B97F4A7C15ull;
@@ -1501,6 +1501,22 @@ pgv_host_hnsw_build(pgv_hnsw * mirror, pgv_dtype dtype, int dim, const void *row
 				record	   *rcd = &recs[k];
 				nlist	   *l = &el[rcd->owner].layers[rcd->lc];
 				int			nnew = rcd->newcap;
+
+				/* element -> its layers -> the list's items: three dependent misses per record, fetched ahead (a
+				 * neighbouring thread's records at the chunk's end: harmless) */
+				if (k + 12 < nrec)
+					__builtin_prefetch(&el[recs[k + 12].owner]);
+				if (k + 8 < nrec)
+					__builtin_prefetch(&el[recs[k + 8].owner].layers[recs[k + 8].lc]);
+				if (k + 4 < nrec)
+				{
+					const char *it = (const char *) el[recs[k + 4].owner].layers[recs[k + 4].lc].items;
+
+					__builtin_prefetch(it);
+					__builtin_prefetch(it + 64);
+					__builtin_prefetch(it + 128);
+					__builtin_prefetch(it + 192);
+				}
 
 				rcd->nstart = l->length;
 				rcd->nlocal = l->length + nnew;
