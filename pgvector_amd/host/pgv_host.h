@@ -69,6 +69,11 @@ int			pgv_host_hnsw_search(pgv_hnsw * mirror, const pgv_hnsw_graph * graph, pgv_
  * search the graph as it stood when the batch began, like the reference's parallel workers racing
  * each other; max_batch = 1 is the reference's serial loop, the cap is 2048), see hnsw_build.c.  A batch never
  * exceeds 1/16 of the elements already linked and ends at the first element taller than the entry point.
+ * With max_batch >= 64 the loop is a pipeline once batches are full: two helper threads (each with its own pgv_ctx
+ * and a pgv_hnsw_share view of the mirror, made and freed by this call) run the NEXT batch's searches and candidate
+ * pair distances, the graph patches and the list records' pair scoring while the calling thread (and its OpenMP team,
+ * <= 16 threads) replays the current batch; a batch that runs ahead does not see the batch before it.  The mirror
+ * must not be used by other threads during the call.
  *
  *   mirror  pgv_hnsw_upload of ALL n element vectors (what HnswFormIndexValue produced: normalised
  *           for cosine, zero-norm rows left out by the caller); the graph is (re)set by this call
