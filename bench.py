@@ -1383,10 +1383,33 @@ def main():
     dev = torch.device("cuda", local_rank)
 
     ctx = api.Context(local_rank, stream=torch.cuda.current_stream().cuda_stream)
-    comm = api.Comm(ctx, backend="rccl" if args.backend == "nccl" else "host") if world > 1 else None
+    comm, comm_kind = None, None
+    if world > 1:
+        comm_kind = "rccl" if args.backend == "nccl" else "host"
+        if comm_kind == "rccl":
+            # the library's own RCCL communicator; if ANY rank cannot have it, every rank takes the callbacks into
+            # torch.distributed instead (still RCCL, driven by torch) -- agreed on, so that no rank waits in a collective
+            # the others never enter
+            try:
+                comm = api.Comm(ctx, backend="rccl")
+                ok = 1
+            except Exception as e:   # noqa: BLE001
+                log("rank %d: pgv_comm_create failed (%r)" % (rank, e))
+                comm, ok = None, 0
+            flag = torch.tensor([ok], dtype=torch.int32, device=dev)
+            dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+            if int(flag.item()) == 0:
+                if comm is not None:
+                    comm.close()
+                comm = api.Comm(ctx, backend="host")
+                comm_kind = "torch.distributed nccl callbacks (pgv_comm_create failed on some rank)"
+        else:
+            comm = api.Comm(ctx, backend="host")
     if args.exact_scan:
         ctx.set_exact_scan(True)
     failures = []
+    if comm_kind is not None and comm_kind.startswith("torch.distributed"):
+        failures.append("comm: " + comm_kind)
 
     # ---------------------------------------------------------------- setup
     WATCH["section"] = "data + build"
@@ -1521,7 +1544,7 @@ def main():
         # Lloyd iteration in bytes, the build's phases (build_phases_secs: kmeans = k-means++ + Lloyd with
         # one fused all-reduce per iteration; assign; layout = the all-to-all of the rows to their lists' owners)
         line["multi_gpu"] = {
-            "pgv_comm_size": comm.world, "backend": args.backend,
+            "pgv_comm_size": comm.world, "backend": args.backend, "communicator": comm_kind,
             "kmeans_allreduce_bytes_per_iteration": int(lists * dim * 4 + lists * 4 + 8),
             "kmeans_iterations": iters,
             "search_allgather_bytes_per_step": {"probe_lists": int(total_batch * probes * 4),

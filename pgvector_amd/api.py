@@ -73,6 +73,7 @@ class Context:
             arg = C.c_void_p(stream)
         check(lib.pgv_ctx_create(device, arg, C.byref(h)))
         self.h = h
+        self.device = device
         self._children = []  # weakrefs: index/hnsw handles must be freed before their context
 
     def _adopt(self, child):
@@ -318,8 +319,9 @@ class Query:
 
 class Comm:
     """one process per GPU: the library's communicator (pgv_comm_*).  backend "rccl": RCCL over xGMI, the
-    group id travels through torch.distributed once; backend "host": the two collectives are callbacks that
-    move the device buffers through host memory and torch.distributed (gloo) -- functional runs only."""
+    group id travels through torch.distributed once; backend "host": the two collectives are callbacks into
+    torch.distributed -- through host memory under gloo (functional runs only), through device staging tensors under
+    torch's nccl backend (RCCL driven by torch: what bench.py falls back to when pgv_comm_create fails)."""
 
     def __init__(self, ctx, backend="rccl"):
         import torch
@@ -350,14 +352,21 @@ class Comm:
             hip.hipMemcpy.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int]
             hip.hipStreamSynchronize.argtypes = [C.c_void_p]
             world = self.world
+            # the staging tensors live where torch.distributed's backend wants them: host memory for gloo, this
+            # device for nccl (= RCCL driven by torch: the fallback when pgv_comm_create itself cannot be had)
+            on_dev = dist.is_initialized() and dist.get_backend() == "nccl"
+            where = torch.device("cuda", ctx.device) if on_dev else torch.device("cpu")
+            to_stage, from_stage = (3, 3) if on_dev else (2, 1)   # hipMemcpyKind: D2D / D2H, H2D
 
             def all_reduce(_state, buf, count, stream):
                 try:
                     hip.hipStreamSynchronize(stream)
-                    host = torch.empty(count, dtype=torch.float32)
-                    hip.hipMemcpy(host.data_ptr(), buf, count * 4, 2)   # device -> host
-                    dist.all_reduce(host)
-                    hip.hipMemcpy(buf, host.data_ptr(), count * 4, 1)   # host -> device
+                    stage = torch.empty(count, dtype=torch.float32, device=where)
+                    hip.hipMemcpy(stage.data_ptr(), buf, count * 4, to_stage)
+                    dist.all_reduce(stage)
+                    if on_dev:
+                        torch.cuda.synchronize(where)
+                    hip.hipMemcpy(buf, stage.data_ptr(), count * 4, from_stage)
                     return 0
                 except Exception:
                     return 1
@@ -365,12 +374,13 @@ class Comm:
             def all_gather(_state, send, recv, nbytes, stream):
                 try:
                     hip.hipStreamSynchronize(stream)
-                    mine = torch.empty(nbytes, dtype=torch.uint8)
-                    hip.hipMemcpy(mine.data_ptr(), send, nbytes, 2)
-                    parts = [torch.empty(nbytes, dtype=torch.uint8) for _ in range(world)]
-                    dist.all_gather(parts, mine)
-                    full = torch.cat(parts)
-                    hip.hipMemcpy(recv, full.data_ptr(), nbytes * world, 1)
+                    mine = torch.empty(nbytes, dtype=torch.uint8, device=where)
+                    hip.hipMemcpy(mine.data_ptr(), send, nbytes, to_stage)
+                    full = torch.empty(nbytes * world, dtype=torch.uint8, device=where)
+                    dist.all_gather_into_tensor(full, mine) if on_dev else dist.all_gather(list(full.split(nbytes)), mine)
+                    if on_dev:
+                        torch.cuda.synchronize(where)
+                    hip.hipMemcpy(recv, full.data_ptr(), nbytes * world, from_stage)
                     return 0
                 except Exception:
                     return 1
