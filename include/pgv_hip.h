@@ -658,7 +658,8 @@ int			pgv_hnsw_score_groups(pgv_hnsw * h, const int32_t *ids, const int64_t *ids
  * whole tuple is tuples[tuple_offsets[i] .. tuple_offsets[i + 1]) in the layout of pgv_hnsw_set_graph;
  * tuple_offsets is host memory.  Ordered on the device with later searches through the mirror AND through its views
  * (pgv_hnsw_share), whichever of them ran the patch; searches that still read the old tuples must have returned before
- * the call (every search call ends synchronized).
+ * the call (every search call ends synchronized), and patches of one mirror are issued one at a time (the caller's
+ * business when several threads hold views: pgv_host_hnsw_build gives them all to one helper thread).
  */
 int			pgv_hnsw_update_graph(pgv_hnsw * h, int32_t entry, const int32_t *elements, int nupd,
 								  const int64_t *tuple_offsets, const int32_t *tuples);
