@@ -658,6 +658,27 @@ class Hnsw:
         ctx._adopt(v)
         return v
 
+    def share(self, ctx):
+        """pgv_hnsw_share: a view of this mirror for another context of the same process (own stream and scratch; the
+        vectors and the graph stay this mirror's).  Close the view before the mirror."""
+        v = Hnsw.__new__(Hnsw)
+        h = C.c_void_p()
+        check(lib.pgv_hnsw_share(self.h, ctx.h, C.byref(h)))
+        v.ctx, v.metric, v.dtype, v.dim, v.h = ctx, self.metric, self.dtype, self.dim, h
+        v.payload_words = self.payload_words
+        v._owner = self   # keeps the owner alive
+        ctx._adopt(v)
+        return v
+
+    def update_graph(self, entry, elements, tuple_offsets, tuples):
+        """pgv_hnsw_update_graph: new entry point and the rewritten neighbor tuples of `elements` (tuple i =
+        tuples[tuple_offsets[i] : tuple_offsets[i + 1]]); through a view the patch lands in the owner's graph"""
+        elements = np.ascontiguousarray(elements, dtype=np.int32)
+        tuple_offsets = np.ascontiguousarray(tuple_offsets, dtype=np.int64)
+        tuples = np.ascontiguousarray(tuples, dtype=np.int32)
+        check(lib.pgv_hnsw_update_graph(self.h, int(entry), ptr(elements), int(elements.size), ptr(tuple_offsets),
+                                        ptr(tuples)))
+
     def set_graph(self, m, entry, levels, nbr_start, nbr):
         """the graph a scan walks (pgv_hnsw_set_graph): per element slot its level and neighbor tuple"""
         levels = np.ascontiguousarray(levels, dtype=np.int32) if not _is_torch(levels) else levels

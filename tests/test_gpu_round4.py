@@ -178,3 +178,41 @@ def test_config_scale_answers_are_the_oracles(ctx, oracle, name, n, dim, lists, 
                               what="%s single q%d" % (name, i))
     single.close()
     index.close()
+
+
+def test_graph_patches_and_searches_through_views_of_one_hnsw_mirror(ctx):
+    """pgv_hnsw_share: a view (another context, another stream) searches the owner's graph, patches it
+    (pgv_hnsw_update_graph through the view lands in the owner's arrays, the entry point with it), and the owner's next
+    search -- on ITS stream -- sees the whole patch (device-side ordering by event): what the pipelined
+    pgv_host_hnsw_build relies on.  Two graphs over the same elements (same level draws, different batch sizes) are
+    swapped back and forth tuple by tuple."""
+    from pgvector_amd import _host
+    rs = np.random.RandomState(5)
+    n, dim, m, efc = 6000, 64, 8, 32
+    data = rs.randn(n, dim).astype(np.float32)
+    q = rs.randn(64, dim).astype(np.float32)
+    ga = {}
+    for name, mb in (("a", 1024), ("b", 64)):
+        mir = api.Hnsw(ctx, api.PGV_L2SQ, api.PGV_F32, dim, data)
+        built = _host.hnsw_build(mir, data, m, efc, api.make_rng(seed=3), max_batch=mb)
+        elem, dist, _ = mir.search(q, 40, 10)
+        ga[name] = (built, elem.copy(), dist.copy())
+        mir.close()
+    a, b = ga["a"][0], ga["b"][0]
+    assert (a["levels"] == b["levels"]).all() and (a["nbr_start"] == b["nbr_start"]).all()
+    assert (a["nbr"] != b["nbr"]).any() and not (ga["a"][1] == ga["b"][1]).all()   # (different graphs, different walks)
+
+    owner = api.Hnsw(ctx, api.PGV_L2SQ, api.PGV_F32, dim, data)
+    owner.set_graph(m, a["entry"], a["levels"], a["nbr_start"], a["nbr"])
+    ctx2 = api.Context(0)
+    view = owner.share(ctx2)
+    every = np.arange(n, dtype=np.int32)
+    for rnd in range(6):
+        want, other = (ga["b"], b) if rnd % 2 == 0 else (ga["a"], a)
+        patcher, searcher = (view, owner) if rnd % 4 < 2 else (owner, view)
+        patcher.update_graph(other["entry"], every, other["nbr_start"], other["nbr"])
+        elem, dist, _ = searcher.search(q, 40, 10)
+        assert (elem == want[1]).all() and np.allclose(dist, want[2], rtol=0, atol=0), "round %d" % rnd
+    view.close()
+    ctx2.close()
+    owner.close()
