@@ -86,6 +86,7 @@ typedef struct
 	int			nstart;			/* members when the batch began: locals 0 .. nstart - 1 */
 	int			nlocal;			/* + the batch elements that selected the owner */
 	int32_t    *ids;			/* [nlocal] element of each local */
+	const void *items;			/* the list's items (for fetching them ahead in step 5) */
 	int64_t		pair0;			/* first of its pairs in its slice's request */
 	int			slice;			/* the scoring request (of step 4) that holds them */
 	int64_t		pair0b;			/* first of its member-member pairs in the second request (blocked lists) */
@@ -258,7 +259,9 @@ typedef struct
 				links_cap;
 	int32_t    *tab;			/* hash: (owner, lc) -> own record index + 1 */
 	int64_t		tab_cap;
-	int			ndirty;
+	int32_t    *dirty;			/* owners whose tuples this batch rewrites, first seen by this thread */
+	int			ndirty,
+				dirty_cap;
 	int			oom;
 	int64_t		rec_base,		/* where its records / requests start in the batch's arrays */
 				link_base;
@@ -1314,6 +1317,8 @@ pgv_host_hnsw_build(pgv_hnsw * mirror, pgv_dtype dtype, int dim, const void *row
 				if (el[e].level > el[entry].level)
 					entry = e;
 			}
+			for (int t = 0; t < nthreads; t++)	/* (a short batch runs the walk on one thread: the others' stay empty) */
+				parts[t].ndirty = 0;
 #pragma omp parallel if (B >= 8) num_threads(nthreads)
 			{
 				const int	T = omp_get_num_threads(),
@@ -1406,8 +1411,21 @@ pgv_host_hnsw_build(pgv_hnsw * mirror, pgv_dtype dtype, int dim, const void *row
 								}
 								if (!is_dirty[owner])	/* (owners are dealt to threads: no two write one flag) */
 								{
+									if (rp->ndirty == rp->dirty_cap)
+									{
+										int			cap = rp->dirty_cap ? rp->dirty_cap * 2 : 1024;
+										int32_t    *grown = realloc(rp->dirty, sizeof(int32_t) * (size_t) cap);
+
+										if (!grown)
+										{
+											rp->oom = 1;
+											break;
+										}
+										rp->dirty = grown;
+										rp->dirty_cap = cap;
+									}
 									is_dirty[owner] = 1;
-									rp->ndirty++;
+									rp->dirty[rp->ndirty++] = owner;
 								}
 							}
 							if (rp->nlinks == rp->links_cap)
@@ -1529,6 +1547,7 @@ pgv_host_hnsw_build(pgv_hnsw * mirror, pgv_dtype dtype, int dim, const void *row
 					continue;
 				}
 				rcd->newdist = grp_dist + grp_off[k];
+				rcd->items = l->items;
 				rcd->full = !l->closer_set;	/* no cached flags: its next selection computes everything */
 				rcd->blocked = 0;
 				rcd->wait_from = -1;
@@ -1720,6 +1739,22 @@ pgv_host_hnsw_build(pgv_hnsw * mirror, pgv_dtype dtype, int dim, const void *row
 								continue;
 							from = rcd->wait_from;
 						}
+						else if (k + 3 < khi)
+						{
+							/* a later record's list (last touched by another thread in step 4) and its pairs (fresh
+							 * from the device: in no cache) */
+							const record *nx = &recs[k + 3];
+							const char *it = nx->items,
+									   *tr = (const char *) (slices[nx->slice].out + nx->pair0);
+
+							__builtin_prefetch(it);
+							__builtin_prefetch(it + 64);
+							__builtin_prefetch(it + 128);
+							__builtin_prefetch(it + 192);
+							__builtin_prefetch(it + 256);
+							__builtin_prefetch(tr);
+							__builtin_prefetch(tr + 64);
+						}
 						ps = pairs_of(slices[rcd->slice].out + rcd->pair0, rcd->from, pass ? pdist2 + rcd->pair0b : NULL);
 						for (int u = from; u < rcd->nlocal; u++)
 						{
@@ -1818,11 +1853,11 @@ pgv_host_hnsw_build(pgv_hnsw * mirror, pgv_dtype dtype, int dim, const void *row
 					pj->dirty[k++] = (int32_t) (i0 + b);
 					is_dirty[i0 + b] = 0;
 				}
-			for (int q = 0; q < nrec; q++)
-				if (is_dirty[recs[q].owner])
+			for (int t = 0; t < nthreads; t++)	/* the owners, as step 4a's threads met them */
+				for (int q = 0; q < parts[t].ndirty; q++)
 				{
-					pj->dirty[k++] = recs[q].owner;
-					is_dirty[recs[q].owner] = 0;
+					pj->dirty[k++] = parts[t].dirty[q];
+					is_dirty[parts[t].dirty[q]] = 0;
 				}
 			ndirty = k;
 			ntuple = 0;
@@ -1943,6 +1978,7 @@ done:
 		for (int t = 0; t < nthreads; t++)
 		{
 			free(parts[t].recs);
+			free(parts[t].dirty);
 			free(parts[t].links);
 			free(parts[t].tab);
 		}
