@@ -1739,21 +1739,23 @@ pgv_host_hnsw_build(pgv_hnsw * mirror, pgv_dtype dtype, int dim, const void *row
 								continue;
 							from = rcd->wait_from;
 						}
-						else if (k + 3 < khi)
+						else if (k + 4 < khi)
 						{
 							/* a later record's list (last touched by another thread in step 4) and its pairs (fresh
 							 * from the device: in no cache) */
-							const record *nx = &recs[k + 3];
+							const record *nx = &recs[k + 4];
 							const char *it = nx->items,
 									   *tr = (const char *) (slices[nx->slice].out + nx->pair0);
+							const int	nlm = layer_m(m, nx->lc);
 
-							__builtin_prefetch(it);
-							__builtin_prefetch(it + 64);
-							__builtin_prefetch(it + 128);
-							__builtin_prefetch(it + 192);
-							__builtin_prefetch(it + 256);
+							for (int o = 0; o < nlm * (int) sizeof(cand); o += 64)
+								__builtin_prefetch(it + o);
 							__builtin_prefetch(tr);
 							__builtin_prefetch(tr + 64);
+							/* the cached sort order behind the items, and where the list's tuple part goes */
+							__builtin_prefetch(it + nlm * (int) sizeof(cand));
+							__builtin_prefetch(out->nbr + out->nbr_start[nx->owner] + (int64_t) (el[nx->owner].level - nx->lc) * m, 1);
+							__builtin_prefetch(nx->newdist);
 						}
 						ps = pairs_of(slices[rcd->slice].out + rcd->pair0, rcd->from, pass ? pdist2 + rcd->pair0b : NULL);
 						for (int u = from; u < rcd->nlocal; u++)
