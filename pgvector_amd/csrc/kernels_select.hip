@@ -136,7 +136,7 @@ __global__ void plan_tasks_kernel(const int *__restrict__ cnt, const int64_t *__
         task.pair0 = (int)(pair_start[l] + (int64_t)g * qt);
         const int pl = cnt[l] - g * qt;
         task.npairs = pl < qt ? pl : qt;
-        task.pad = 0;
+        task.pad = ng > 1 ? 1 : 0;  // the chunk is streamed once per query group: worth keeping in the caches
         tasks[t] = task;
     }
 }
