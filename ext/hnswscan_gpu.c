@@ -8,12 +8,16 @@
  *
  * Hook points (one line each; the reference code stays as the `vector.gpu = off` path):
  *   hnswbeginscan   src/hnswscan.c:121-146   so->gpu = PgvHnswBeginScan(index);
- *   hnswgettuple    src/hnswscan.c:228        so->w = so->gpu ? PgvHnswGetScanItems(scan, value) : GetScanItems(scan, value);
+ *   hnswgettuple    src/hnswscan.c:228        if (!(so->gpu && PgvHnswGetScanItems(scan, value, &so->w))) so->w = GetScanItems(scan, value);
+ *                                             (false: a NULL query -- every distance 0, src/hnswutils.c:555 -- or
+ *                                             hnsw.iterative_scan, whose later batches resume from the visited set
+ *                                             and the discarded candidates of the first: those scans are the reference's)
  *   hnswendscan     src/hnswscan.c:337-349    PgvHnswEndScan(so->gpu);
  *   hnswinsert / hnswbulkdelete / hnswbuild   PgvNoteIndexChange(index);   (the mirror is stale until restaged)
- * hnswgettuple then pops so->w one heap TID at a time exactly as before (:293-326); with hnsw.iterative_scan the
- * later batches (ResumeScanItems, :61-88) stay on the reference's code, scoring through pgv_hnsw_score
- * (INTEGRATION.md section 5).
+ * hnswgettuple then pops so->w one heap TID at a time exactly as before (:293-326).  With hnsw.iterative_scan the
+ * whole scan stays on the reference's code (ResumeScanItems, :61-88, continues from so->v and so->discarded, which
+ * only the reference's own first batch fills); its distance loop can score through pgv_hnsw_score (INTEGRATION.md
+ * section 5).
  */
 #include "pgv_gpu.h"
 
@@ -129,10 +133,11 @@ PgvHnswStage(Relation index, int *outM, int *outDimensions, int64 *outElements)
 	UnlockReleaseBuffer(buf);
 	rowBytes = esize * (Size) meta.dimensions;
 	vectors = palloc_extended(rowBytes * (Size) cap, MCXT_ALLOC_HUGE);
-	levels = palloc(sizeof(int32) * (Size) cap);
-	neighborTids = palloc(sizeof(ItemPointerData) * (Size) cap);
-	elementTids = palloc(sizeof(uint64) * (Size) cap);
-	payload = palloc0(sizeof(uint32) * PGV_HNSW_PAYLOAD_WORDS * (Size) cap);
+	/* (the _huge forms: at 100 M elements these arrays pass palloc's 1 GB limit) */
+	levels = palloc_extended(sizeof(int32) * (Size) cap, MCXT_ALLOC_HUGE);
+	neighborTids = palloc_extended(sizeof(ItemPointerData) * (Size) cap, MCXT_ALLOC_HUGE);
+	elementTids = palloc_extended(sizeof(uint64) * (Size) cap, MCXT_ALLOC_HUGE);
+	payload = palloc_extended(sizeof(uint32) * PGV_HNSW_PAYLOAD_WORDS * (Size) cap, MCXT_ALLOC_HUGE);
 
 	/* pass 1: the element tuples, slot = order of first sight */
 	for (BlockNumber blkno = HNSW_HEAD_BLKNO; blkno < nblocks; blkno++)
@@ -140,6 +145,7 @@ PgvHnswStage(Relation index, int *outM, int *outDimensions, int64 *outElements)
 		OffsetNumber maxoffno;
 
 		CHECK_FOR_INTERRUPTS();
+		PgvWorkerBeat();
 		buf = ReadBufferExtended(index, MAIN_FORKNUM, blkno, RBM_NORMAL, NULL);
 		LockBuffer(buf, BUFFER_LOCK_SHARE);
 		page = BufferGetPage(buf);
@@ -156,9 +162,9 @@ PgvHnswStage(Relation index, int *outM, int *outDimensions, int64 *outElements)
 			{
 				cap *= 2;
 				vectors = repalloc_huge(vectors, rowBytes * (Size) cap);
-				levels = repalloc(levels, sizeof(int32) * (Size) cap);
-				neighborTids = repalloc(neighborTids, sizeof(ItemPointerData) * (Size) cap);
-				elementTids = repalloc(elementTids, sizeof(uint64) * (Size) cap);
+				levels = repalloc_huge(levels, sizeof(int32) * (Size) cap);
+				neighborTids = repalloc_huge(neighborTids, sizeof(ItemPointerData) * (Size) cap);
+				elementTids = repalloc_huge(elementTids, sizeof(uint64) * (Size) cap);
 				payload = repalloc_huge(payload, sizeof(uint32) * PGV_HNSW_PAYLOAD_WORDS * (Size) cap);
 			}
 			memcpy(vectors + rowBytes * (Size) n, etup->data.x, rowBytes);	/* Vector / HalfVector payload */
@@ -188,7 +194,7 @@ PgvHnswStage(Relation index, int *outM, int *outDimensions, int64 *outElements)
 
 	/* pass 2: neighbor tuples -> slots; an invalid TID ends a layer's list (:785-786), a TID whose element is
 	 * gone is dropped and the rest moves up */
-	nbrStart = palloc(sizeof(int64) * ((Size) n + 1));
+	nbrStart = palloc_extended(sizeof(int64) * ((Size) n + 1), MCXT_ALLOC_HUGE);
 	nbr = palloc_extended(sizeof(int32) * (Size) Max(ntids, 1), MCXT_ALLOC_HUGE);
 	nbrStart[0] = 0;
 	for (int64 e = 0; e < n; e++)
@@ -198,6 +204,11 @@ PgvHnswStage(Relation index, int *outM, int *outDimensions, int64 *outElements)
 		int32	   *out = nbr + nbrStart[e];
 
 		nbrStart[e + 1] = nbrStart[e] + count;
+		if ((e & 255) == 0)
+		{
+			CHECK_FOR_INTERRUPTS();
+			PgvWorkerBeat();
+		}
 		buf = ReadBufferExtended(index, MAIN_FORKNUM, ItemPointerGetBlockNumber(&neighborTids[e]), RBM_NORMAL, NULL);
 		LockBuffer(buf, BUFFER_LOCK_SHARE);
 		page = BufferGetPage(buf);
@@ -224,6 +235,7 @@ PgvHnswStage(Relation index, int *outM, int *outDimensions, int64 *outElements)
 		UnlockReleaseBuffer(buf);
 	}
 
+	PgvWorkerBeat();
 	if (n > 0 &&
 		(pgv_hnsw_upload_payload(PgvGetContext(), metric, dtype, (int) meta.dimensions, vectors, n, payload,
 								 (int) (sizeof(uint32) * PGV_HNSW_PAYLOAD_WORDS), &h) != PGV_OK ||
@@ -352,7 +364,13 @@ PgvHnswBeginScan(Relation index)
 	if (!m->valid)
 	{
 		if (pgv_hnsw_import(PgvGetContext(), &handle, &m->h) != PGV_OK)
-			ereport(ERROR, (errmsg("pgvector GPU path: %s", pgv_last_error())));
+		{
+			/* the exporter is gone (a worker that died): like the ivfflat twin, not this query's error -- the scan runs
+			 * on the reference's path and the index is staged again */
+			m->h = NULL;
+			PgvMirrorImportFailed(index, staged);
+			return NULL;
+		}
 		m->m = graphM;
 		m->nelements = nelements;
 		m->staged = staged;
@@ -367,22 +385,32 @@ PgvHnswBeginScan(Relation index)
 	return hs;
 }
 
-/* GetScanItems (src/hnswscan.c:25-56); `value` is what GetScanValue (:92-114) produced: normalised for cosine */
-List *
-PgvHnswGetScanItems(IndexScanDesc scan, Datum value)
+/*
+ * GetScanItems (src/hnswscan.c:25-56); `value` is what GetScanValue (:92-114) produced: normalised for cosine, a NULL
+ * pointer for a NULL query.  false = this scan is the reference's (nothing was touched): a NULL query (HnswLoadElement
+ * gives every element distance 0, src/hnswutils.c:555 -- no kernel for that), or hnsw.iterative_scan (ResumeScanItems,
+ * :61-88, continues from the visited set so->v and the discarded candidates of the first batch; a device walk leaves
+ * neither, and a scan that stopped after its first batch would be a truncated result).
+ */
+bool
+PgvHnswGetScanItems(IndexScanDesc scan, Datum value, List **out)
 {
 	HnswScanOpaque so = (HnswScanOpaque) scan->opaque;
 	PgvHnswMirror *m = ((PgvHnswScan *) so->gpu)->mirror;
-	Vector	   *q = (Vector *) PG_DETOAST_DATUM(value);
+	Vector	   *q;
 	int64		elems[HNSW_MAX_EF_SEARCH];
 	float		dists[HNSW_MAX_EF_SEARCH];
 	uint32	   *payload;
 	int64		tuples = 0;
 	List	   *w = NIL;
 
+	if (DatumGetPointer(value) == NULL || hnsw_iterative_scan != HNSW_ITERATIVE_SCAN_OFF)
+		return false;
+	q = (Vector *) PG_DETOAST_DATUM(value);
+	*out = NIL;
 	so->m = m->m;
 	if (m->nelements == 0)
-		return NIL;
+		return true;
 	if (pgv_hnsw_search(m->h, q->x, 1, hnsw_ef_search, hnsw_ef_search, elems, dists, &tuples) != PGV_OK)
 		ereport(ERROR, (errmsg("pgvector GPU path: %s", pgv_last_error())));
 	so->tuples = tuples;
@@ -419,5 +447,6 @@ PgvHnswGetScanItems(IndexScanDesc scan, Datum value)
 		w = lappend(w, sc);
 	}
 	pfree(payload);
-	return w;
+	*out = w;
+	return true;
 }

@@ -7,7 +7,8 @@
 
 #include "miscadmin.h"
 
-#define PGV_ASSIGN_BATCH (1 << 18)	/* heap rows handed to the GPU at a time */
+#define PGV_ASSIGN_BATCH (1 << 18)	/* heap rows handed to the GPU at a time, at most */
+#define PGV_ASSIGN_BATCH_BYTES ((Size) 512 << 20)	/* ... and at most this much of them (2000-d rows: 65 536) */
 
 typedef struct PgvIvfBuild
 {
@@ -17,7 +18,8 @@ typedef struct PgvIvfBuild
 	Size		rowBytes;
 	char	   *centers;		/* [lists x dimensions] payloads, densely packed */
 	int			count;			/* rows buffered */
-	char	   *rows;			/* [PGV_ASSIGN_BATCH x dimensions] */
+	int			batch;			/* rows per pgv_assign call: min(PGV_ASSIGN_BATCH, PGV_ASSIGN_BATCH_BYTES / row bytes) */
+	char	   *rows;			/* [batch x dimensions] */
 	ItemPointerData *tids;
 	int32	   *lists;
 	char	   *value;			/* one Vector / HalfVector varlena, rebuilt from a buffered payload for the tuplesort */
@@ -58,7 +60,9 @@ PgvIvfflatKmeans(Relation index, VectorArray samples, VectorArray centers, const
 	if (!vector_gpu || !PgvIvfflatOpclass(index, &metric, &dtype, &ops))
 		return false;
 	rowBytes = (dtype == PGV_F32 ? sizeof(float) : sizeof(uint16)) * (Size) samples->dim;
-	in = palloc(rowBytes * (Size) Max(samples->length, 1));
+	/* (50 samples per list: past palloc's 1 GB at 4096 lists of 1536-d rows -- the reference's own array is a
+	 * MCXT_ALLOC_HUGE allocation too, src/ivfutils.c VectorArrayInit) */
+	in = palloc_extended(rowBytes * (Size) Max(samples->length, 1), MCXT_ALLOC_HUGE);
 	out = palloc(rowBytes * (Size) centers->maxlen);
 	for (int i = 0; i < samples->length; i++)
 		memcpy(in + rowBytes * (Size) i, ((Vector *) VectorArrayGet(samples, i))->x, rowBytes);
@@ -99,12 +103,13 @@ PgvIvfflatBuildBegin(IvfflatBuildState * buildstate)
 	gb->centers = palloc(gb->rowBytes * (Size) buildstate->lists);
 	for (int i = 0; i < buildstate->lists; i++)
 		memcpy(gb->centers + gb->rowBytes * (Size) i, ((Vector *) VectorArrayGet(buildstate->centers, i))->x, gb->rowBytes);
-	gb->rows = palloc(gb->rowBytes * (Size) PGV_ASSIGN_BATCH);
-	gb->tids = palloc(sizeof(ItemPointerData) * (Size) PGV_ASSIGN_BATCH);
+	gb->batch = (int) Min((Size) PGV_ASSIGN_BATCH, Max(PGV_ASSIGN_BATCH_BYTES / gb->rowBytes, (Size) 1));
+	gb->rows = palloc_extended(gb->rowBytes * (Size) gb->batch, MCXT_ALLOC_HUGE);
+	gb->tids = palloc(sizeof(ItemPointerData) * (Size) gb->batch);
 	/* Vector and HalfVector share the 8-byte header (vl_len_, dim, unused); src/vector.h:18-24, src/halfvec.h:68-74 */
 	gb->valueSize = offsetof(Vector, x) + gb->rowBytes;
 	gb->value = palloc0(gb->valueSize);
-	gb->lists = palloc(sizeof(int32) * (Size) PGV_ASSIGN_BATCH);
+	gb->lists = palloc(sizeof(int32) * (Size) gb->batch);
 	buildstate->gpu = gb;
 }
 
@@ -146,6 +151,6 @@ PgvIvfflatBuildAdd(IvfflatBuildState * buildstate, ItemPointer tid, Datum value)
 	/* only the payload is kept: `value` lives in a context the caller resets after this row */
 	memcpy(gb->rows + gb->rowBytes * (Size) gb->count, ((Vector *) DatumGetPointer(value))->x, gb->rowBytes);
 	gb->tids[gb->count] = *tid;
-	if (++gb->count == PGV_ASSIGN_BATCH)
+	if (++gb->count == gb->batch)
 		PgvIvfflatBuildFlush(buildstate);
 }

@@ -171,10 +171,11 @@ PgvFetchWholeBatch(PgvIvfScan * gs, const void *queryPayload)
 	if (gs->count > gs->capacity)
 	{
 		gs->capacity = gs->count * 2;
-		gs->dist = gs->dist ? repalloc(gs->dist, sizeof(float) * (Size) gs->capacity) : palloc(sizeof(float) * (Size) gs->capacity);
-		gs->slot = gs->slot ? repalloc(gs->slot, sizeof(int64) * (Size) gs->capacity) : palloc(sizeof(int64) * (Size) gs->capacity);
-		gs->tid = gs->tid ? repalloc(gs->tid, sizeof(uint64) * (Size) gs->capacity) : palloc(sizeof(uint64) * (Size) gs->capacity);
-		gs->order = gs->order ? repalloc(gs->order, sizeof(int64) * (Size) gs->capacity * 2) : palloc(sizeof(int64) * (Size) gs->capacity * 2);
+		/* (a batch of many long lists passes palloc's 1 GB: the _huge forms, like the reference's tuplesort memory) */
+		gs->dist = gs->dist ? repalloc_huge(gs->dist, sizeof(float) * (Size) gs->capacity) : palloc_extended(sizeof(float) * (Size) gs->capacity, MCXT_ALLOC_HUGE);
+		gs->slot = gs->slot ? repalloc_huge(gs->slot, sizeof(int64) * (Size) gs->capacity) : palloc_extended(sizeof(int64) * (Size) gs->capacity, MCXT_ALLOC_HUGE);
+		gs->tid = gs->tid ? repalloc_huge(gs->tid, sizeof(uint64) * (Size) gs->capacity) : palloc_extended(sizeof(uint64) * (Size) gs->capacity, MCXT_ALLOC_HUGE);
+		gs->order = gs->order ? repalloc_huge(gs->order, sizeof(int64) * (Size) gs->capacity * 2) : palloc_extended(sizeof(int64) * (Size) gs->capacity * 2, MCXT_ALLOC_HUGE);
 	}
 	if (pgv_scan_lists(gs->mirror->index, queryPayload, lists, gs->batchLists, gs->dist, gs->slot, gs->capacity, &m) != PGV_OK)
 		ereport(ERROR, (errmsg("pgvector GPU path: %s", pgv_last_error())));

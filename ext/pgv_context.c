@@ -36,6 +36,9 @@
 #include "utils/memutils.h"
 #include "utils/timestamp.h"
 
+#include <errno.h>
+#include <signal.h>
+
 bool		vector_gpu = false;
 int			vector_gpu_device = 0;
 int			vector_gpu_stage_wait_ms = 0;
@@ -110,14 +113,22 @@ typedef struct PgvPoolSlot
 	char		payload[PGV_POOL_ROW_BYTES];
 }			PgvPoolSlot;
 
-#define PGV_WORKER_DEAD_MS 3000	/* a worker whose heartbeat is older than this is gone (it beats every 200 ms at most) */
+/* a worker whose heartbeat is older than this AND whose process no longer exists is gone (it beats every 200 ms in its
+ * loop and once per page while staging; a long synchronous upload keeps the process, not the beat) */
+#define PGV_WORKER_DEAD_MS 3000
+/* a pooled query the worker has not TAKEN after this long (it is staging some index: seconds) is taken back by its
+ * backend, which scans on its own context or on the reference's path */
+#define PGV_POOL_PATIENCE_MS 500
+#define PGV_SPAWN_GAP_MS 500	/* at most one RegisterDynamicBackgroundWorker per this long */
 
 typedef struct PgvSharedState
 {
 	LWLock	   *lock;
 	Latch	   *workerLatch[PGV_MAX_MIRRORS];	/* per database: index = slot of the first entry of that database */
 	Oid			workerDb[PGV_MAX_MIRRORS];
+	int			workerPid[PGV_MAX_MIRRORS];
 	pg_atomic_uint64 workerBeat[PGV_MAX_MIRRORS];	/* GetCurrentTimestamp() of the worker's last loop turn */
+	pg_atomic_uint64 lastSpawn;	/* when a backend last asked the postmaster for a worker (any database) */
 	PgvSharedMirror mirrors[PGV_MAX_MIRRORS];
 	PgvPoolSlot pool[PGV_POOL_SLOTS];
 }			PgvSharedState;
@@ -158,6 +169,7 @@ PgvShmemStartup(void)
 			pg_atomic_init_u64(&PgvShared->mirrors[i].generation, 0);
 			pg_atomic_init_u64(&PgvShared->workerBeat[i], 0);
 		}
+		pg_atomic_init_u64(&PgvShared->lastSpawn, 0);
 		for (int i = 0; i < PGV_POOL_SLOTS; i++)
 			pg_atomic_init_u32(&PgvShared->pool[i].state, PGV_SLOT_FREE);
 	}
@@ -198,6 +210,21 @@ PgvFindEntry(Oid relid, bool create)
 	return PgvFindEntryKind(relid, create, PGV_KIND_IVFFLAT);
 }
 
+/* entries of the registry in use, all databases (monitoring; 64 for the cluster: PGV_MAX_MIRRORS) */
+int
+PgvRegistryEntries(void)
+{
+	int			used = 0;
+
+	if (PgvShared == NULL)
+		return 0;
+	LWLockAcquire(PgvShared->lock, LW_SHARED);
+	for (int i = 0; i < PGV_MAX_MIRRORS; i++)
+		used += PgvShared->mirrors[i].relid != InvalidOid;
+	LWLockRelease(PgvShared->lock);
+	return used;
+}
+
 /* ivfflatinsert (src/ivfinsert.c:72-181), ivfflatbulkdelete (src/ivfvacuum.c:18-143), hnswinsert, hnswbulkdelete and
  * ambuild call this after changing pages: mirrors staged before now are stale */
 void
@@ -214,12 +241,16 @@ PgvNoteIndexChange(Relation index)
 	LWLockRelease(PgvShared->lock);
 }
 
-/* DROP INDEX / REINDEX reach every backend as a relcache invalidation: forget the local view (the worker drops its
- * mirror when the entry is next requested or the relation is gone) */
+/* DROP INDEX / REINDEX reach every backend as a relcache invalidation: forget the local view.  The worker is a backend
+ * too: it looks whether the indexes of the mirrors it owns still exist (PgvWorkerDropGone) -- a dropped index must not
+ * keep its mirror in HBM, nor its entry in the registry, for the worker's lifetime. */
+static bool ownedCheck = false;	/* (worker) some relation changed or went: see whether the owned mirrors' indexes still exist */
+
 static void
 PgvRelcacheCallback(Datum arg, Oid relid)
 {
 	(void) arg;
+	ownedCheck = true;
 	for (PgvIvfMirror * m = mirrors; m != NULL; m = m->next)
 		if (m->relid == relid || relid == 0)
 			m->valid = false;	/* (an import open scans hold is retired, not unmapped, at the next PgvIvfflatGetMirror) */
@@ -327,6 +358,20 @@ typedef struct PgvOwned
 
 static PgvOwned owned[PGV_MAX_MIRRORS];
 
+static int	workerSlot = -1;	/* this process's registration when it is a GPU worker */
+
+/*
+ * The worker's heartbeat.  Backends take a worker whose beat is older than PGV_WORKER_DEAD_MS for dead (and start
+ * another), so everything in the worker that can take seconds -- staging a large index through the buffer manager --
+ * beats on its way (once per page walked; a no-op in a backend).
+ */
+void
+PgvWorkerBeat(void)
+{
+	if (workerSlot >= 0 && PgvShared != NULL)
+		pg_atomic_write_u64(&PgvShared->workerBeat[workerSlot], (uint64) GetCurrentTimestamp());
+}
+
 /*
  * Stage the index out of its pages: the walks of GetScanLists (src/ivfscan.c:58-111) and GetScanItems
  * (:139-179), once per mirror instead of once per query.  Centers, list-major vectors, list offsets and
@@ -356,6 +401,7 @@ PgvStage(Relation index, pgv_metric metric, pgv_dtype dtype, int lists, int dime
 		Page		page;
 		OffsetNumber maxoffno;
 
+		PgvWorkerBeat();
 		LockBuffer(buf, BUFFER_LOCK_SHARE);
 		page = BufferGetPage(buf);
 		maxoffno = PageGetMaxOffsetNumber(page);
@@ -385,6 +431,7 @@ PgvStage(Relation index, pgv_metric metric, pgv_dtype dtype, int lists, int dime
 			OffsetNumber maxoffno;
 
 			CHECK_FOR_INTERRUPTS();
+			PgvWorkerBeat();
 			LockBuffer(buf, BUFFER_LOCK_SHARE);
 			page = BufferGetPage(buf);
 			maxoffno = PageGetMaxOffsetNumber(page);
@@ -414,6 +461,7 @@ PgvStage(Relation index, pgv_metric metric, pgv_dtype dtype, int lists, int dime
 		}
 	}
 	offsets[lists] = n;
+	PgvWorkerBeat();			/* (the upload itself: ~20 ms per GB) */
 	if (pgv_index_upload(PgvGetContext(), metric, dtype, dimensions, lists, centers, offsets, vectors, tids, &result) != PGV_OK)
 		ereport(ERROR, (errmsg("pgvector GPU path: %s", pgv_last_error())));
 	*ntuples = n;
@@ -425,7 +473,69 @@ PgvStage(Relation index, pgv_metric metric, pgv_dtype dtype, int lists, int dime
 	return result;
 }
 
-/* stage one requested entry inside a transaction of the worker; publishes READY or FAILED */
+/* an index that is gone gives its registry entry back (PgvShared->lock held exclusively) */
+static void
+PgvForgetEntry(PgvSharedMirror * e)
+{
+	e->relid = InvalidOid;
+	e->dboid = InvalidOid;
+	e->state = PGV_MIRROR_EMPTY;
+	e->stagedGeneration = 0;
+	e->stagedAt = 0;
+	pg_atomic_write_u64(&e->generation, 0);
+}
+
+/*
+ * A relcache invalidation arrived: DROP INDEX (or DROP TABLE, DROP DATABASE ...) may have taken an index whose mirror
+ * this worker owns.  Nobody will ever ask for that index again, so nothing else would free its HBM or its registry
+ * entry (64 of them for the cluster).
+ */
+static void
+PgvWorkerDropGone(void)
+{
+	StartTransactionCommand();
+	PG_TRY();
+	{
+		for (int i = 0; i < PGV_MAX_MIRRORS; i++)
+		{
+			Relation	index;
+
+			if (owned[i].relid == InvalidOid)
+				continue;
+			index = try_index_open(owned[i].relid, AccessShareLock);
+			if (index != NULL)
+			{
+				index_close(index, AccessShareLock);
+				continue;
+			}
+			LWLockAcquire(PgvShared->lock, LW_EXCLUSIVE);
+			{
+				PgvSharedMirror *e = PgvFindEntry(owned[i].relid, false);
+
+				if (e)
+					PgvForgetEntry(e);
+			}
+			LWLockRelease(PgvShared->lock);
+			/* backends that still hold an import keep their mapping until their scans end (the driver keeps the
+			 * memory until the last mapping closes) */
+			if (owned[i].index)
+				pgv_index_free(owned[i].index);
+			if (owned[i].hnsw)
+				pgv_hnsw_free(owned[i].hnsw);
+			memset(&owned[i], 0, sizeof(owned[i]));
+		}
+		CommitTransactionCommand();
+	}
+	PG_CATCH();
+	{
+		EmitErrorReport();
+		FlushErrorState();
+		AbortCurrentTransaction();
+	}
+	PG_END_TRY();
+}
+
+/* stage one requested entry inside a transaction of the worker; publishes READY, FAILED or (index gone) nothing */
 static void
 PgvWorkerStageEntry(PgvSharedMirror * e)
 {
@@ -433,6 +543,7 @@ PgvWorkerStageEntry(PgvSharedMirror * e)
 	uint64		generation = pg_atomic_read_u64(&e->generation);
 	int			kind = e->kind;
 	volatile bool ok = false;
+	volatile bool gone = false;	/* the relation does not exist (any more): its entry is given back */
 	pgv_index  *volatile fresh = NULL;
 	pgv_hnsw   *volatile freshHnsw = NULL;
 	pgv_index_handle handle;
@@ -471,6 +582,8 @@ PgvWorkerStageEntry(PgvSharedMirror * e)
 			}
 			index_close(index, AccessShareLock);
 		}
+		else
+			gone = true;
 		CommitTransactionCommand();
 	}
 	PG_CATCH();
@@ -502,6 +615,8 @@ PgvWorkerStageEntry(PgvSharedMirror * e)
 		e->stagedAt = GetCurrentTimestamp();
 		e->state = PGV_MIRROR_READY;
 	}
+	else if (gone)
+		PgvForgetEntry(e);
 	else
 		e->state = PGV_MIRROR_FAILED;
 	LWLockRelease(PgvShared->lock);
@@ -657,8 +772,6 @@ PgvWorkerServePool(Oid dboid)
  * nobody must think it is still there.  Its registration goes, so that PgvEnsureWorker starts another; the mirrors it
  * owned die with the process, so the registry forgets them; queries waiting in the pool are told to run elsewhere.
  */
-static int	workerSlot = -1;
-
 static void
 PgvWorkerExit(int code, Datum arg)
 {
@@ -670,7 +783,8 @@ PgvWorkerExit(int code, Datum arg)
 	LWLockAcquire(PgvShared->lock, LW_EXCLUSIVE);
 	PgvShared->workerLatch[workerSlot] = NULL;
 	PgvShared->workerDb[workerSlot] = 0;
-	pg_atomic_init_u64(&PgvShared->workerBeat[workerSlot], 0);
+	PgvShared->workerPid[workerSlot] = 0;
+	pg_atomic_write_u64(&PgvShared->workerBeat[workerSlot], 0);
 	for (int i = 0; i < PGV_MAX_MIRRORS; i++)
 		if (PgvShared->mirrors[i].dboid == dboid && PgvShared->mirrors[i].relid != 0)
 			PgvShared->mirrors[i].state = PGV_MIRROR_EMPTY;
@@ -688,6 +802,23 @@ PgvWorkerExit(int code, Datum arg)
 	workerSlot = -1;
 }
 
+/*
+ * Is the registered worker of this database alive?  A worker that was killed (no exit hook ran) stops beating AND its
+ * process is gone; one that is busy in a long synchronous call (the upload of a very large index) only stops beating.
+ */
+static bool
+PgvWorkerAlive(int slot)
+{
+	uint64		beat = pg_atomic_read_u64(&PgvShared->workerBeat[slot]);
+	int			pid = PgvShared->workerPid[slot];
+
+	if (beat == 0)
+		return false;
+	if (!TimestampDifferenceExceeds((TimestampTz) beat, GetCurrentTimestamp(), PGV_WORKER_DEAD_MS))
+		return true;
+	return pid > 0 && (kill(pid, 0) == 0 || errno == EPERM);
+}
+
 /* bgw_main of the per-database worker; bgw_main_arg = the database's oid */
 void
 PgvWorkerMain(Datum main_arg)
@@ -698,22 +829,26 @@ PgvWorkerMain(Datum main_arg)
 	BackgroundWorkerUnblockSignals();
 	BackgroundWorkerInitializeConnectionByOid(dboid, InvalidOid, 0);
 	LWLockAcquire(PgvShared->lock, LW_EXCLUSIVE);
+	/* this database's registration first (a free slot in front of it must not hide it: two workers would serve one
+	 * database), a free slot only when it has none */
 	for (int i = 0; i < PGV_MAX_MIRRORS && slot < 0; i++)
-		if (PgvShared->workerDb[i] == dboid || PgvShared->workerDb[i] == 0)
+		if (PgvShared->workerDb[i] == dboid)
+			slot = i;
+	for (int i = 0; i < PGV_MAX_MIRRORS && slot < 0; i++)
+		if (PgvShared->workerDb[i] == 0)
 			slot = i;
 	if (slot >= 0 && PgvShared->workerDb[slot] == dboid && PgvShared->workerLatch[slot] != NULL)
 	{
 		/* two backends asked for a worker at the same moment: the first one to get here serves, this one leaves */
-		uint64		beat = pg_atomic_read_u64(&PgvShared->workerBeat[slot]);
-
-		if (beat != 0 && !TimestampDifferenceExceeds((TimestampTz) beat, GetCurrentTimestamp(), PGV_WORKER_DEAD_MS))
+		if (PgvWorkerAlive(slot))
 			slot = -1;
 	}
 	if (slot >= 0)
 	{
 		PgvShared->workerDb[slot] = dboid;
+		PgvShared->workerPid[slot] = MyProcPid;
 		PgvShared->workerLatch[slot] = MyLatch;
-		pg_atomic_init_u64(&PgvShared->workerBeat[slot], (uint64) GetCurrentTimestamp());
+		pg_atomic_write_u64(&PgvShared->workerBeat[slot], (uint64) GetCurrentTimestamp());
 	}
 	LWLockRelease(PgvShared->lock);
 	if (slot < 0)
@@ -726,7 +861,14 @@ PgvWorkerMain(Datum main_arg)
 		PgvSharedMirror *todo = NULL;
 
 		CHECK_FOR_INTERRUPTS();
-		pg_atomic_init_u64(&PgvShared->workerBeat[slot], (uint64) GetCurrentTimestamp());
+		PgvWorkerBeat();
+		/* an idle worker runs no transactions: invalidations (DROP INDEX) are taken in here */
+		AcceptInvalidationMessages();
+		if (ownedCheck)
+		{
+			ownedCheck = false;
+			PgvWorkerDropGone();
+		}
 		LWLockAcquire(PgvShared->lock, LW_EXCLUSIVE);
 		for (int i = 0; i < PGV_MAX_MIRRORS && todo == NULL; i++)
 		{
@@ -753,14 +895,6 @@ PgvWorkerMain(Datum main_arg)
 	}
 }
 
-/* is the registered worker of this database alive?  A worker that was killed (no exit hook ran) stops beating. */
-static bool
-PgvWorkerAlive(int slot)
-{
-	uint64		beat = pg_atomic_read_u64(&PgvShared->workerBeat[slot]);
-
-	return beat != 0 && !TimestampDifferenceExceeds((TimestampTz) beat, GetCurrentTimestamp(), PGV_WORKER_DEAD_MS);
-}
 
 /* start the worker of this database unless one is registered and alive; returns whether one is there to be woken */
 static bool
@@ -794,13 +928,26 @@ PgvEnsureWorker(void)
 		{
 			PgvShared->workerLatch[dead] = NULL;
 			PgvShared->workerDb[dead] = 0;
-			pg_atomic_init_u64(&PgvShared->workerBeat[dead], 0);
+			PgvShared->workerPid[dead] = 0;
+			pg_atomic_write_u64(&PgvShared->workerBeat[dead], 0);
 			for (int i = 0; i < PGV_MAX_MIRRORS; i++)
 				if (PgvShared->mirrors[i].dboid == MyDatabaseId && PgvShared->mirrors[i].relid != 0 &&
 					PgvShared->mirrors[i].state != PGV_MIRROR_REQUESTED)
 					PgvShared->mirrors[i].state = PGV_MIRROR_EMPTY;
 		}
 		LWLockRelease(PgvShared->lock);
+	}
+	/* A worker needs a moment to come up and register.  Backends that find none meanwhile (every waiting scan polls,
+	 * every new scan asks) must not each have the postmaster fork another: one request per PGV_SPAWN_GAP_MS for the
+	 * cluster; the duplicates that still slip through find the registration taken and leave (PgvWorkerMain). */
+	{
+		uint64		last = pg_atomic_read_u64(&PgvShared->lastSpawn);
+		uint64		now = (uint64) GetCurrentTimestamp();
+
+		if (last != 0 && !TimestampDifferenceExceeds((TimestampTz) last, (TimestampTz) now, PGV_SPAWN_GAP_MS))
+			return false;
+		if (!pg_atomic_compare_exchange_u64(&PgvShared->lastSpawn, &last, now))
+			return false;		/* somebody else is asking right now */
 	}
 	memset(&worker, 0, sizeof(worker));
 	worker.bgw_flags = BGWORKER_SHMEM_ACCESS | BGWORKER_BACKEND_DATABASE_CONNECTION;
@@ -916,6 +1063,25 @@ PgvIvfflatMirrorIsCurrent(Relation index)
 	return PgvMirrorReady(index, &handle, &staged);
 }
 
+/*
+ * A published handle could not be imported: its exporter is gone (a worker that died takes its allocations with it).
+ * Not the query's error: the registry forgets the staging, the next request has the index staged again, this scan runs
+ * on the reference's path.
+ */
+void
+PgvMirrorImportFailed(Relation index, uint64 staged)
+{
+	PgvSharedMirror *e;
+
+	elog(LOG, "pgvector GPU path: mirror of index %u cannot be imported (%s): restaging", RelationGetRelid(index),
+		 pgv_last_error());
+	LWLockAcquire(PgvShared->lock, LW_EXCLUSIVE);
+	e = PgvFindEntry(RelationGetRelid(index), false);
+	if (e && e->state == PGV_MIRROR_READY && e->stagedGeneration + 1 == staged)
+		e->state = PGV_MIRROR_EMPTY;
+	LWLockRelease(PgvShared->lock);
+}
+
 /* unmap an import nobody uses any more and take it off the list */
 static void
 PgvDropMirror(PgvIvfMirror * m)
@@ -1001,16 +1167,8 @@ PgvIvfflatGetMirror(Relation index, uint64 wantStaged)
 		{
 			/* the exporter is gone (a worker that died takes its allocations with it): not this query's error.  The
 			 * registry forgets the staging, the next request has it staged again; this scan runs on the CPU path. */
-			PgvSharedMirror *e;
-
-			elog(LOG, "pgvector GPU path: mirror of index %u cannot be imported (%s): restaging", RelationGetRelid(index),
-				 pgv_last_error());
 			m->index = NULL;
-			LWLockAcquire(PgvShared->lock, LW_EXCLUSIVE);
-			e = PgvFindEntry(RelationGetRelid(index), false);
-			if (e && e->state == PGV_MIRROR_READY && e->stagedGeneration + 1 == staged)
-				e->state = PGV_MIRROR_EMPTY;
-			LWLockRelease(PgvShared->lock);
+			PgvMirrorImportFailed(index, staged);
 			return NULL;
 		}
 		IvfflatGetMetaPageInfo(index, &m->lists, &m->dimensions);
@@ -1042,6 +1200,7 @@ PgvPoolSearch(Relation index, const void *payload, int probes, float *outDist, u
 	Size		rowBytes;
 	uint32		state;
 	volatile bool abandoned = false;
+	TimestampTz filledAt;
 
 	if (PgvShared == NULL || payload == NULL || !PgvIvfflatOpclass(index, &metric, &dtype, &ops))
 		return false;
@@ -1073,6 +1232,7 @@ PgvPoolSearch(Relation index, const void *payload, int probes, float *outDist, u
 	myPoolSlot = slot;
 	pg_atomic_write_u32(&slot->state, PGV_SLOT_FILLED);
 	PgvEnsureWorker();			/* sets the worker's latch */
+	filledAt = GetCurrentTimestamp();
 	PG_TRY();
 	{
 		for (;;)
@@ -1080,9 +1240,21 @@ PgvPoolSearch(Relation index, const void *payload, int probes, float *outDist, u
 			state = pg_atomic_read_u32(&slot->state);
 			if (state == PGV_SLOT_DONE || state == PGV_SLOT_UNSERVED)
 				break;
-			(void) WaitLatch(MyLatch, WL_LATCH_SET | WL_TIMEOUT | WL_EXIT_ON_PM_DEATH, 200L, PG_WAIT_EXTENSION);
+			(void) WaitLatch(MyLatch, WL_LATCH_SET | WL_TIMEOUT | WL_EXIT_ON_PM_DEATH, 100L, PG_WAIT_EXTENSION);
 			ResetLatch(MyLatch);
 			CHECK_FOR_INTERRUPTS();
+			/* the worker answers a batch in about a millisecond; one that has not even TAKEN the query after
+			 * PGV_POOL_PATIENCE_MS is staging some index (seconds): take the query back and scan for ourselves */
+			if (TimestampDifferenceExceeds(filledAt, GetCurrentTimestamp(), PGV_POOL_PATIENCE_MS))
+			{
+				uint32		filled = PGV_SLOT_FILLED;
+
+				if (pg_atomic_compare_exchange_u32(&slot->state, &filled, PGV_SLOT_UNSERVED))
+				{
+					state = PGV_SLOT_UNSERVED;
+					break;
+				}
+			}
 			/* the worker may have died without a word (its exit hook tells us when it can): a query must not wait
 			 * for an answer nobody will give.  Take the slot back -- or leave it to a worker that holds it after all --
 			 * and scan for ourselves. */

@@ -18,7 +18,8 @@
  *                                               under it restarts on the CPU path and must not return a tuple twice)
  *   ivfflatendscan      src/ivfscan.c:419-431   PgvIvfflatEndScan(so->gpu);
  *   hnswbeginscan       src/hnswscan.c:121-146  so->gpu = PgvHnswBeginScan(index);
- *   hnswgettuple        src/hnswscan.c:228      so->w = so->gpu ? PgvHnswGetScanItems(scan, value) : GetScanItems(scan, value);
+ *   hnswgettuple        src/hnswscan.c:228      if (!(so->gpu && PgvHnswGetScanItems(scan, value, &so->w))) so->w = GetScanItems(scan, value);
+ *                                               (false: NULL query or hnsw.iterative_scan -- the reference's scan)
  *   hnswendscan         src/hnswscan.c:337-349  PgvHnswEndScan(so->gpu);
  *   IvfflatKmeans       src/ivfkmeans.c:553-570 if (PgvIvfflatKmeans(index, samples, centers, typeInfo)) return;
  *   BuildCallback       src/ivfbuild.c:224-266  if (buildstate->gpu) { PgvIvfflatBuildAdd(buildstate, tid, value); return; }
@@ -87,8 +88,14 @@ bool		PgvPoolSearch(Relation index, const void *payload, int probes, float *outD
 						  bool *outComplete, uint64 *outStaged);
 /* insert / vacuum / build changed the index's pages: mirrors staged before now are stale */
 void		PgvNoteIndexChange(Relation index);
+/* entries of the shared mirror registry in use (monitoring; dropped indexes give theirs back) */
+int			PgvRegistryEntries(void);
 /* bgw_main of the per-database worker that owns the mirrors */
 void		PgvWorkerMain(Datum main_arg);
+/* the worker's heartbeat, for everything of its that takes long (the stagers beat once per page; a no-op in a backend) */
+void		PgvWorkerBeat(void);
+/* a published handle could not be imported (its exporter is gone): forget the staging, have the index staged again */
+void		PgvMirrorImportFailed(Relation index, uint64 staged);
 
 /* scan side (ivfscan_gpu.c) */
 void	   *PgvIvfflatBeginScan(Relation index, IvfflatScanOpaque so);
@@ -108,7 +115,7 @@ bool		PgvHnswMirrorHandle(Relation index, pgv_index_handle * handle, uint64 *sta
 
 /* HNSW scan side (hnswscan_gpu.c); List as in nodes/pg_list.h */
 void	   *PgvHnswBeginScan(Relation index);
-List	   *PgvHnswGetScanItems(IndexScanDesc scan, Datum value);
+bool		PgvHnswGetScanItems(IndexScanDesc scan, Datum value, List **w);	/* false: not served, the reference's GetScanItems */
 void		PgvHnswEndScan(void *gpu);
 void		PgvHnswInvalidate(Oid relid);
 /* vector / halfvec element type of an hnsw opclass; false for bit and sparsevec opclasses (CPU path) */

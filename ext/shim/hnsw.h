@@ -19,6 +19,8 @@
 #define HNSW_NORM_PROC 2
 
 extern int	hnsw_ef_search;
+extern int	hnsw_iterative_scan;
+#define HNSW_ITERATIVE_SCAN_OFF 0	/* src/hnsw.h: typedef enum HnswIterativeScanMode, first member */
 
 typedef struct HnswMetaPageData
 {

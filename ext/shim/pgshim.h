@@ -166,6 +166,7 @@ struct RelationData
 #define RelationGetDescr(relation) ((relation)->rd_att)
 typedef void (*RelcacheCallbackFunction) (Datum arg, Oid relid);
 void		CacheRegisterRelcacheCallback(RelcacheCallbackFunction func, Datum arg);
+void		AcceptInvalidationMessages(void);
 
 /* access/relscan.h, access/sdir.h, access/skey.h */
 typedef enum
@@ -277,7 +278,9 @@ typedef struct pg_atomic_uint64
 }			pg_atomic_uint64;
 void		pg_atomic_init_u64(volatile pg_atomic_uint64 *ptr, uint64 val);
 uint64		pg_atomic_read_u64(volatile pg_atomic_uint64 *ptr);
+void		pg_atomic_write_u64(volatile pg_atomic_uint64 *ptr, uint64 val);
 uint64		pg_atomic_fetch_add_u64(volatile pg_atomic_uint64 *ptr, int64 add_);
+bool		pg_atomic_compare_exchange_u64(volatile pg_atomic_uint64 *ptr, uint64 *expected, uint64 newval);
 typedef struct pg_atomic_uint32
 {
 	volatile uint32 value;

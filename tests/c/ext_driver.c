@@ -1028,13 +1028,16 @@ backend_after_worker_loss(void *arg)
 		EXPECT(shim_now() - t1 < 8.0);
 		if (check_stream(&e, got, 10, 0, "after worker loss"))
 			return 1;
-		saw_gpu = s.gpu_tuples > 0;
+		/* the GPU serves again AND a worker is there: the old one's mirror died with it (an import of its handle fails:
+		 * CPU path, the registry forgets the staging), so a GPU answer means a new worker staged the index again */
+		saw_gpu = s.gpu_tuples > 0 && shim_live_bgworkers() == 1;
 		scan_end(&s);
 		expected_free(&e);
 		if (!saw_gpu)
 			usleep(50000);
 	}
 	EXPECT(saw_gpu);			/* a new worker was started and staged the index again */
+	fprintf(stderr, "   the GPU path was back %.1f s after the worker had gone\n", shim_now() - t0);
 	return 0;
 }
 
@@ -1134,7 +1137,8 @@ backend_hnsw_scan(void *arg)
 		so.first = true;
 		so.gpu = PgvHnswBeginScan(index);
 		EXPECT(so.gpu != NULL);
-		w = PgvHnswGetScanItems(&desc, PointerGetDatum(make_vector(q, DIM)));
+		w = NIL;
+		EXPECT(PgvHnswGetScanItems(&desc, PointerGetDatum(make_vector(q, DIM)), &w));
 		n = shim_list_length(w);
 		EXPECT(n == want && so.m == HM);
 		/* furthest first (hnswgettuple takes llast): position n - 1 - i is the i-th nearest */
@@ -1151,8 +1155,223 @@ backend_hnsw_scan(void *arg)
 		PgvHnswEndScan(so.gpu);
 		shim_query_context_end(ctx);
 	}
+	/* scans the device walk does not serve: they are handed back untouched (the hook then calls GetScanItems).  A NULL
+	 * query (ORDER BY embedding <-> NULL: every distance 0, src/hnswutils.c:555) used to be dereferenced; an iterative
+	 * scan's later batches need the first batch's visited set and discarded candidates (src/hnswscan.c:61-88). */
+	{
+		IndexScanDescData desc;
+		HnswScanOpaqueData so;
+		float		q[DIM];
+		List	   *w = (List *) &desc;	/* must stay as it is */
+
+		make_query(q, 99);
+		ctx = shim_query_context_begin();
+		memset(&desc, 0, sizeof(desc));
+		memset(&so, 0, sizeof(so));
+		desc.indexRelation = index;
+		desc.opaque = &so;
+		so.first = true;
+		so.m = -7;
+		so.gpu = PgvHnswBeginScan(index);
+		EXPECT(so.gpu != NULL);
+		EXPECT(!PgvHnswGetScanItems(&desc, PointerGetDatum(NULL), &w));
+		EXPECT(w == (List *) &desc && so.m == -7);
+		hnsw_iterative_scan = 1;	/* HNSW_ITERATIVE_SCAN_RELAXED */
+		EXPECT(!PgvHnswGetScanItems(&desc, PointerGetDatum(make_vector(q, DIM)), &w));
+		EXPECT(w == (List *) &desc && so.m == -7);
+		hnsw_iterative_scan = HNSW_ITERATIVE_SCAN_OFF;
+		EXPECT(PgvHnswGetScanItems(&desc, PointerGetDatum(make_vector(q, DIM)), &w));
+		EXPECT(shim_list_length(w) == 40 && so.m == HM);
+		PgvHnswEndScan(so.gpu);
+		shim_query_context_end(ctx);
+	}
 	ora_hnsw_free(g);
 	free(data);
+	return 0;
+}
+
+/* ------------------------------------------------------------------------------------------------ the worker's housekeeping */
+#define REL_SLOW 1003
+#define REL_WIDE 1005
+
+/*
+ * A staging that takes longer than the heartbeat's patience (a cold, large index: every page read of the worker sleeps).
+ * The worker must not be taken for dead meanwhile -- no second worker, no forgotten registration --, a pooled query on
+ * ANOTHER index must not wait for the staging to end, and the mirror must come out.
+ */
+static int
+backend_slow_staging(void *arg)
+{
+	Relation	slow = shim_open_relation(REL_SLOW);
+	Relation	ivf = shim_open_relation(REL_IVF);
+	float		q[DIM];
+	double		t0,
+				until;
+	int			served = 0;
+
+	(void) arg;
+	scenario = "a staging of several seconds";
+	shim_set_guc_bool("vector.gpu", true);
+	make_query(q, 7);
+	/* the other index's mirror is current (staged by the earlier phases, or staged now at full speed) */
+	shim_set_guc_bool("vector.gpu_pooled", true);
+	until = shim_now() + 30.0;
+	while (!PgvIvfflatMirrorIsCurrent(ivf) && shim_now() < until)
+		usleep(20000);
+	EXPECT(PgvIvfflatMirrorIsCurrent(ivf));
+	EXPECT(shim_live_bgworkers() == 1);
+	/* the slow index: the same image as REL_IVF (~420 pages) */
+	{
+		uint32_t	nblocks;
+		const void *pages = shim_relation_pages(REL_IVF, &nblocks);
+
+		shim_replace_pages(REL_SLOW, pages, nblocks);
+		fprintf(stderr, "   REL_SLOW: %u pages\n", nblocks);
+	}
+	/* from here on the worker's page reads crawl: REL_SLOW's staging takes ~5 s (the heartbeat's patience is 3 s) */
+	shim_set_bgworker_read_delay_us(12000);
+	EXPECT(!PgvIvfflatMirrorIsCurrent(slow));	/* requested */
+	t0 = shim_now();
+	until = t0 + 60.0;
+	while (shim_now() < until)
+	{
+		Scan		s;
+		uint64		got[10];
+		Expected	e = expected_batch(REL_IVF, q, PROBES);
+		double		t1 = shim_now();
+
+		/* pooled queries on the OTHER index while the worker is busy: answered -- taken back after the pooler's
+		 * patience and run on the backend's own context -- in well under the staging's duration, and correct */
+		scan_begin(&s, ivf, q, PROBES, PROBES);
+		EXPECT(pull(&s, got, 10) == 10);
+		EXPECT(shim_now() - t1 < 2.5);
+		if (check_stream(&e, got, 10, 0, "pooled query beside a long staging"))
+			return 1;
+		scan_end(&s);
+		expected_free(&e);
+		served++;
+		EXPECT(shim_live_bgworkers() == 1);	/* nobody took the busy worker for dead and started another */
+		if (PgvIvfflatMirrorIsCurrent(slow))
+			break;
+		usleep(100000);
+	}
+	shim_set_bgworker_read_delay_us(0);
+	EXPECT(PgvIvfflatMirrorIsCurrent(slow));
+	fprintf(stderr, "   staging took %.1f s with the worker's reads slowed; %d pooled queries on another index answered meanwhile\n",
+			shim_now() - t0, served);
+	EXPECT(shim_now() - t0 > 3.5);	/* (the scenario is only worth something past the heartbeat's patience) */
+	return 0;
+}
+
+/* DROP INDEX: the worker frees the mirror it owns and gives the registry entry back (64 for the cluster) */
+static int
+backend_drop_index(void *arg)
+{
+	ShimOpclass l2 = {0, IVFFLAT_MAX_DIM, false, false, 0};
+	const int	n = 400,
+				dim = 8,
+				lists = 4;
+	float	   *rows = malloc(sizeof(float) * (size_t) n * dim);
+	float		centers[4 * 8];
+	int64_t		offsets[5];
+	uint64	   *tids = malloc(sizeof(uint64) * (size_t) n);
+	pgv_rel		rel;
+	double		until;
+	int			before = PgvRegistryEntries();
+
+	(void) arg;
+	scenario = "dropped indexes give their mirrors and registry entries back";
+	shim_set_guc_bool("vector.gpu", true);
+	shim_set_guc_bool("vector.gpu_pooled", false);
+	/* a small index image: four lists of 100 rows */
+	gen_rows(rows, n, dim, 5);
+	for (int l = 0; l <= lists; l++)
+		offsets[l] = (int64_t) l * (n / lists);
+	for (int l = 0; l < lists; l++)
+		memcpy(centers + l * dim, rows + (size_t) offsets[l] * dim, sizeof(float) * dim);
+	for (int i = 0; i < n; i++)
+		tids[i] = tid_of_row(i);
+	pgv_rel_init(&rel);
+	EXPECT(pgv_host_ivf_write_index(&rel, PGV_F32, dim, lists, centers, offsets, rows, tids) == PGV_OK);
+	/* more create / stage / drop rounds than the registry has entries, every index with an oid of its own (what DROP +
+	 * CREATE give): without the reclamation the 65th index, and every one after it, would never get a mirror -- and
+	 * the mirrors of the dropped ones would stay in device memory for the worker's lifetime */
+	for (int r = 0; r < 70; r++)
+	{
+		Oid			oid = 3000 + (Oid) r;
+		Relation	index;
+
+		shim_create_relation(oid, &l2, rel.pages, rel.nblocks, dim);
+		index = shim_open_relation(oid);
+		EXPECT(index != NULL);
+		until = shim_now() + 30.0;
+		while (!PgvIvfflatMirrorIsCurrent(index) && shim_now() < until)
+			usleep(2000);
+		EXPECT(PgvIvfflatMirrorIsCurrent(index));
+		shim_drop_relation(oid);
+	}
+	/* the worker takes invalidations in at its next turn (200 ms at most when idle) */
+	until = shim_now() + 10.0;
+	while (PgvRegistryEntries() > before && shim_now() < until)
+		usleep(5000);
+	fprintf(stderr, "   70 create / stage / drop rounds: registry entries in use %d -> %d\n", before, PgvRegistryEntries());
+	EXPECT(PgvRegistryEntries() <= before);
+	pgv_rel_free(&rel);
+	free(rows);
+	free(tids);
+	return 0;
+}
+
+/* CREATE INDEX on 2000-d rows: the build's row buffer must not ask palloc for more than MaxAllocSize (2^18 rows of
+ * 8000 bytes are 2 GB: "invalid memory alloc request size") */
+static int
+backend_wide_build(void *arg)
+{
+	IvfflatBuildState bs;
+	VectorArrayData centers;
+	const int	dim = IVFFLAT_MAX_DIM;
+	Size		itemsize = offsetof(Vector, x) + sizeof(float) * (Size) dim;
+	float	   *row = calloc((size_t) dim, sizeof(float));
+
+	(void) arg;
+	scenario = "build state for 2000-d rows";
+	shim_set_guc_bool("vector.gpu", true);
+	memset(&bs, 0, sizeof(bs));
+	bs.index = shim_open_relation(REL_WIDE);
+	EXPECT(bs.index != NULL);
+	bs.typeInfo = IvfflatGetTypeInfo(bs.index);
+	bs.dimensions = dim;
+	bs.lists = 4;
+	centers.length = 4;
+	centers.maxlen = 4;
+	centers.dim = dim;
+	centers.itemsize = itemsize;
+	centers.items = palloc0(itemsize * 4);
+	for (int i = 0; i < 4; i++)
+	{
+		Vector	   *c = (Vector *) VectorArrayGet(&centers, i);
+
+		c->vl_len_ = (int32) (itemsize << 2);
+		c->dim = (int16) dim;
+		c->x[0] = (float) i;
+	}
+	bs.centers = &centers;
+	sorted.n = 0;
+	sorted.dim = dim;
+	PgvIvfflatBuildBegin(&bs);	/* (an ERROR here reaches the top level: exit code 100) */
+	EXPECT(bs.gpu != NULL);
+	for (int i = 0; i < 8; i++)
+	{
+		ItemPointerData tid = itemptr(tid_of_row(i));
+
+		row[0] = (float) (i % 4) + 0.1f;
+		PgvIvfflatBuildAdd(&bs, &tid, PointerGetDatum(make_vector(row, dim)));
+	}
+	PgvIvfflatBuildFlush(&bs);
+	EXPECT(sorted.n == 8);
+	for (int i = 0; i < 8; i++)
+		EXPECT(sorted.list[i] == i % 4 && sorted.tid[i] == tid_of_row(i));
+	free(row);
 	return 0;
 }
 
@@ -1188,7 +1407,7 @@ main(void)
 
 	board = mmap(NULL, sizeof(Board), PROT_READ | PROT_WRITE, MAP_SHARED | MAP_ANONYMOUS, -1, 0);
 	memset((void *) board, 0, sizeof(Board));
-	shim_postmaster_init((size_t) 192 << 20, mock_hip_set_arena ? (size_t) 512 << 20 : 0);
+	shim_postmaster_init((size_t) 384 << 20, mock_hip_set_arena ? (size_t) 512 << 20 : 0);
 	arena = shim_arena_base(&arena_bytes);
 	if (mock_hip_set_arena && arena)
 		mock_hip_set_arena(arena, arena_bytes);
@@ -1201,6 +1420,8 @@ main(void)
 	shim_create_relation(REL_IVF, &l2, empty, 0, DIM);
 	shim_create_relation(REL_BATCH, &l2, empty, 0, 8);
 	shim_create_relation(REL_HNSW, &hnsw_l2, empty, 0, DIM);
+	shim_create_relation(REL_SLOW, &l2, empty, 0, DIM);
+	shim_create_relation(REL_WIDE, &l2, empty, 0, IVFFLAT_MAX_DIM);
 
 	failed |= run_phase("CREATE INDEX through the build hooks", backend_build, 1, NULL, 300.0);
 	if (!failed)
@@ -1223,6 +1444,12 @@ main(void)
 	}
 	if (!failed)
 		failed |= run_phase("pooled scan across a restage", backend_pooled_restage, 1, NULL, 120.0);
+	if (!failed)
+		failed |= run_phase("a staging of several seconds", backend_slow_staging, 1, NULL, 180.0);
+	if (!failed)
+		failed |= run_phase("DROP INDEX x 70", backend_drop_index, 1, NULL, 300.0);
+	if (!failed)
+		failed |= run_phase("build state for 2000-d rows", backend_wide_build, 1, NULL, 120.0);
 	if (!failed)
 	{
 		void	   *pooled[1] = {(void *) 1};

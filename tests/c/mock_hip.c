@@ -8,7 +8,9 @@
  * fp32, the simplest implementation that honours each entry point's contract in
  * include/pgv_hip.h; parity of the distances themselves is the GPU tests' business.
  */
+#include <errno.h>
 #include <math.h>
+#include <signal.h>
 #include <stdint.h>
 #include <stdio.h>
 #include <stdlib.h>
@@ -266,6 +268,9 @@ pgv_index_import(pgv_ctx * ctx, const pgv_index_handle * handle, pgv_index * *ou
 		return fail(PGV_ERR_ARG, "mock: not a handle");
 	if (h.pid == (uint32_t) getpid())
 		return fail(PGV_ERR_STATE, "mock: the handle was exported by this process (use pgv_index_share)");
+	/* like hipIpcOpenMemHandle: an exporter that is gone took its allocations with it */
+	if (kill((pid_t) h.pid, 0) != 0 && errno == ESRCH)
+		return fail(PGV_ERR_DEVICE, "mock: the exporting process is gone");
 	return pgv_index_share(h.ix, ctx, out);
 }
 
@@ -843,6 +848,8 @@ pgv_hnsw_import(pgv_ctx * ctx, const pgv_index_handle * handle, pgv_hnsw * *out)
 		return fail(PGV_ERR_ARG, "mock: not an hnsw handle");
 	if (e.pid == (uint32_t) getpid())
 		return fail(PGV_ERR_STATE, "mock: the handle was exported by this process");
+	if (kill((pid_t) e.pid, 0) != 0 && errno == ESRCH)
+		return fail(PGV_ERR_DEVICE, "mock: the exporting process is gone");
 	v = malloc(sizeof(*v));
 	*v = *e.h;
 	v->imported = 1;

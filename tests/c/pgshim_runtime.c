@@ -62,6 +62,7 @@ typedef struct ShimBgw
 
 #define SHIM_MAX_STRUCTS 8
 #define SHIM_MAX_BGW 8
+#define SHIM_INVAL_RING 64
 
 typedef struct ShimShared
 {
@@ -89,6 +90,12 @@ typedef struct ShimShared
 				page_used;
 	size_t		arena_off,
 				arena_bytes;
+	/* shared invalidation queue (sinval): relcache invalidations reach every process at its next
+	 * AcceptInvalidationMessages / transaction start */
+	uint64		inval_seq;
+	Oid			inval_relid[SHIM_INVAL_RING];
+	/* test knob: every ReadBufferExtended of a background worker sleeps this long (a cold, large index) */
+	uint32		bgw_read_delay_us;
 }			ShimShared;
 
 static ShimShared * S = NULL;
@@ -104,6 +111,7 @@ LWLock	   *AddinShmemInitLock = NULL;
 Latch	   *MyLatch = NULL;
 sigjmp_buf *PG_exception_stack = NULL;
 int			hnsw_ef_search = 40;
+int			hnsw_iterative_scan = 0;	/* HNSW_ITERATIVE_SCAN_OFF */
 
 static char last_error[512];
 static int	last_error_level = 0;
@@ -157,12 +165,18 @@ MemoryContext TopMemoryContext = &top_context;
 MemoryContext CurrentMemoryContext = &top_context;
 
 #define CHUNK_GUARD 0x70616c6c6f636b21ull
+#define SHIM_MAX_ALLOC ((Size) 0x3fffffff)	/* MaxAllocSize, utils/memutils.h: 1 GB - 1 */
 
-void *
-MemoryContextAlloc(MemoryContext ctx, Size size)
+static void *
+context_alloc(MemoryContext ctx, Size size, bool huge)
 {
-	ShimChunk  *c = malloc(sizeof(ShimChunk) + (size ? size : 1));
+	ShimChunk  *c;
 
+	/* palloc / repalloc refuse requests past MaxAllocSize (mcxt.c: "invalid memory alloc request size"); only the
+	 * _huge / MCXT_ALLOC_HUGE forms take more */
+	if (!huge && size > SHIM_MAX_ALLOC)
+		ereport(ERROR, (errmsg("invalid memory alloc request size %zu", (size_t) size)));
+	c = malloc(sizeof(ShimChunk) + (size ? size : 1));
 	if (c == NULL)
 		ereport(ERROR, (errmsg("out of memory")));
 	c->ctx = ctx;
@@ -175,6 +189,12 @@ MemoryContextAlloc(MemoryContext ctx, Size size)
 	ctx->chunks = c;
 	ctx->bytes += size;
 	return (char *) c + sizeof(ShimChunk);
+}
+
+void *
+MemoryContextAlloc(MemoryContext ctx, Size size)
+{
+	return context_alloc(ctx, size, false);
 }
 
 void *
@@ -201,8 +221,7 @@ palloc0(Size size)
 void *
 palloc_extended(Size size, int flags)
 {
-	(void) flags;
-	return palloc(size);
+	return context_alloc(CurrentMemoryContext, size, (flags & MCXT_ALLOC_HUGE) != 0);
 }
 
 static ShimChunk *
@@ -235,11 +254,11 @@ pfree(void *p)
 	free(c);
 }
 
-void *
-repalloc(void *p, Size size)
+static void *
+context_realloc(void *p, Size size, bool huge)
 {
 	ShimChunk  *c = chunk_of(p);
-	void	   *n = MemoryContextAlloc(c->ctx, size);
+	void	   *n = context_alloc(c->ctx, size, huge);
 
 	memcpy(n, p, c->size < size ? c->size : size);
 	pfree(p);
@@ -247,9 +266,15 @@ repalloc(void *p, Size size)
 }
 
 void *
+repalloc(void *p, Size size)
+{
+	return context_realloc(p, size, false);
+}
+
+void *
 repalloc_huge(void *p, Size size)
 {
-	return repalloc(p, size);
+	return context_realloc(p, size, true);
 }
 
 void
@@ -600,6 +625,18 @@ pg_atomic_read_u64(volatile pg_atomic_uint64 *ptr)
 	return __atomic_load_n(&ptr->value, __ATOMIC_SEQ_CST);
 }
 
+void
+pg_atomic_write_u64(volatile pg_atomic_uint64 *ptr, uint64 val)
+{
+	__atomic_store_n(&ptr->value, val, __ATOMIC_RELAXED);
+}
+
+bool
+pg_atomic_compare_exchange_u64(volatile pg_atomic_uint64 *ptr, uint64 *expected, uint64 newval)
+{
+	return __atomic_compare_exchange_n(&ptr->value, expected, newval, false, __ATOMIC_SEQ_CST, __ATOMIC_SEQ_CST);
+}
+
 uint64
 pg_atomic_fetch_add_u64(volatile pg_atomic_uint64 *ptr, int64 add_)
 {
@@ -775,21 +812,30 @@ shim_create_relation(Oid oid, const ShimOpclass * opclass, const void *pages, ui
 	uint32		cap = nblocks * 2 + 4096;	/* room for the pages a build or inserts bring later */
 
 	spin_lock(&S->catalog_lock);
+	/* the storage of a dropped relation is used again when it is large enough (DROP INDEX / CREATE INDEX in a loop) */
 	for (int i = 0; i < SHIM_MAX_RELS && r == NULL; i++)
-		if (S->rels[i].oid == 0)
+		if (S->rels[i].oid == 0 && S->rels[i].cap_blocks >= cap)
 			r = &S->rels[i];
-	if (r == NULL || S->page_used + (size_t) cap * SHIM_BLCKSZ > S->page_end - S->page_off)
+	if (r != NULL)
+		cap = r->cap_blocks;
+	else
 	{
-		fprintf(stderr, "pgshim: catalog or page store full\n");
-		abort();
+		for (int i = 0; i < SHIM_MAX_RELS && r == NULL; i++)
+			if (S->rels[i].oid == 0 && S->rels[i].cap_blocks == 0)
+				r = &S->rels[i];
+		if (r == NULL || S->page_used + (size_t) cap * SHIM_BLCKSZ > S->page_end - S->page_off)
+		{
+			fprintf(stderr, "pgshim: catalog or page store full\n");
+			abort();
+		}
+		r->pages_off = S->page_off + S->page_used;
+		S->page_used += (size_t) cap * SHIM_BLCKSZ;
 	}
 	r->opc = *opclass;
 	r->dimensions = dimensions;
-	r->pages_off = S->page_off + S->page_used;
 	r->cap_blocks = cap;
 	r->nblocks = nblocks;
 	r->lock = 0;
-	S->page_used += (size_t) cap * SHIM_BLCKSZ;
 	memcpy(Sbase + r->pages_off, pages, (size_t) nblocks * SHIM_BLCKSZ);
 	__atomic_store_n(&r->oid, oid, __ATOMIC_RELEASE);
 	spin_unlock(&S->catalog_lock);
@@ -829,6 +875,7 @@ shim_drop_relation(Oid oid)
 
 	if (r)
 		__atomic_store_n(&r->oid, 0, __ATOMIC_RELEASE);
+	shim_broadcast_relcache_invalidate(oid);	/* DROP INDEX reaches every backend as a relcache invalidation */
 }
 
 Relation
@@ -888,6 +935,39 @@ shim_relcache_invalidate(Oid relid)
 		relcache_cbs[i].fn(relcache_cbs[i].arg, relid);
 }
 
+/* the shared invalidation queue: a message per relation, read by every process at its own pace; a reader that fell a
+ * whole ring behind gets "everything" (relid 0), like sinval's reset */
+static uint64 inval_seen = 0;
+
+void
+shim_broadcast_relcache_invalidate(Oid relid)
+{
+	uint64		at = __atomic_fetch_add(&S->inval_seq, 1, __ATOMIC_SEQ_CST);
+
+	__atomic_store_n(&S->inval_relid[at % SHIM_INVAL_RING], relid, __ATOMIC_RELEASE);
+}
+
+void
+AcceptInvalidationMessages(void)
+{
+	uint64		now = __atomic_load_n(&S->inval_seq, __ATOMIC_ACQUIRE);
+
+	if (now == inval_seen)
+		return;
+	if (now - inval_seen > SHIM_INVAL_RING / 2)
+		shim_relcache_invalidate(0);
+	else
+		for (uint64 i = inval_seen; i < now; i++)
+			shim_relcache_invalidate(__atomic_load_n(&S->inval_relid[i % SHIM_INVAL_RING], __ATOMIC_ACQUIRE));
+	inval_seen = now;
+}
+
+void
+shim_set_bgworker_read_delay_us(uint32_t us)
+{
+	__atomic_store_n(&S->bgw_read_delay_us, us, __ATOMIC_RELEASE);
+}
+
 /* ------------------------------------------------------------------------------------------------ buffers and pages */
 #define MAX_PINS 64
 static struct
@@ -907,6 +987,8 @@ ReadBufferExtended(Relation reln, ForkNumber forkNum, BlockNumber blockNum, Read
 	Buffer		b;
 
 	(void) forkNum, (void) mode, (void) strategy;
+	if (is_bgworker && __atomic_load_n(&S->bgw_read_delay_us, __ATOMIC_ACQUIRE) > 0)
+		usleep(__atomic_load_n(&S->bgw_read_delay_us, __ATOMIC_ACQUIRE));
 	if (blockNum >= __atomic_load_n(&r->nblocks, __ATOMIC_ACQUIRE))
 		ereport(ERROR, (errmsg("could not read block %u of relation %u: read only 0 of 8192 bytes", blockNum, reln->rd_id)));
 	if (npins == MAX_PINS)
@@ -1128,6 +1210,7 @@ static MemoryContext xact_saved = NULL;
 void
 StartTransactionCommand(void)
 {
+	AcceptInvalidationMessages();
 	xact_context = calloc(1, sizeof(struct MemoryContextData));
 	xact_context->name = "transaction";
 	xact_saved = CurrentMemoryContext;
@@ -1268,6 +1351,7 @@ child_init(void)
 	MyLatch->is_set = 0;
 	MyProcPid = (int) getpid();
 	PG_exception_stack = NULL;
+	inval_seen = __atomic_load_n(&S->inval_seq, __ATOMIC_ACQUIRE);	/* a new process starts with empty caches */
 }
 
 int

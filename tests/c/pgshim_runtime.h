@@ -51,7 +51,12 @@ void		shim_create_relation(Oid oid, const ShimOpclass * opclass, const void *pag
 void		shim_replace_pages(Oid oid, const void *pages, uint32_t nblocks);
 const void *shim_relation_pages(Oid oid, uint32_t *nblocks);
 Relation	shim_open_relation(Oid oid);	/* this process's Relation for it (NULL when unknown) */
-void		shim_drop_relation(Oid oid);
+void		shim_drop_relation(Oid oid);	/* + a relcache invalidation to every process */
+/* a relcache invalidation through the shared queue: every process sees it at its next AcceptInvalidationMessages or
+ * transaction start (shim_relcache_invalidate below fires the callbacks of THIS process at once) */
+void		shim_broadcast_relcache_invalidate(Oid relid);
+/* every ReadBufferExtended of a background worker sleeps this long: staging a cold, large index takes seconds */
+void		shim_set_bgworker_read_delay_us(uint32_t us);
 
 /* ---- per-process ---- */
 /* run fn(arg) with a top-level handler: an ERROR that no PG_TRY caught aborts the "transaction" (buffer pins released,

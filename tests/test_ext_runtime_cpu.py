@@ -4,8 +4,11 @@ plays a postmaster, backends and the "pgvector gpu" background worker as real pr
 page image, LWLocks / latches / atomics in a shared mapping, RegisterDynamicBackgroundWorker as fork -- and runs the
 build hooks (plain and toasted-style heap values, the caller's memory poisoned after every row), own-context and pooled
 scans (heads, deep pulls, iterative, NULL query, ERROR in mid-scan, cancel while waiting), insert -> stale -> restage
-under an open scan, a pooled scan whose mirror is restaged under it, a worker killed and a worker ended, and the HNSW
-scan, every answer checked against the oracle walking the same pages.  Here on tests/c/mock_hip.c (no GPU), once plain
+under an open scan, a pooled scan whose mirror is restaged under it, a staging that outlasts the heartbeat's patience
+(one worker stays one worker, pooled queries on another index are not held up), 70 indexes created, staged and dropped
+(mirrors and registry entries given back), a 2000-d build (no allocation past palloc's 1 GB), a worker killed and a
+worker ended, and the HNSW scan (a NULL query and an iterative scan are handed back to the reference's code), every
+answer checked against the oracle walking the same pages.  Here on tests/c/mock_hip.c (no GPU), once plain
 and once under AddressSanitizer + UBSan; tests/test_ext_runtime_gpu.py runs the same driver on libpgv_hip.so."""
 import os
 import subprocess
@@ -41,6 +44,7 @@ def test_ext_glue_runs_on_the_stand_in_server(tmp_path, sanitize):
     assert "AddressSanitizer" not in r.stderr and "runtime error" not in r.stderr, r.stderr[-3000:]
     assert "buffer refcount leak" not in r.stderr
     for phase in ("CREATE INDEX through the build hooks", "own-context scans", "six pooled backends",
-                  "insert / restage under an open scan", "pooled scan across a restage", "worker killed (SIGKILL)",
+                  "insert / restage under an open scan", "pooled scan across a restage", "a staging of several seconds",
+                  "DROP INDEX x 70", "build state for 2000-d rows", "worker killed (SIGKILL)",
                   "worker ended (SIGTERM)", "hnsw scans"):
         assert any(phase in line and ": ok" in line for line in r.stderr.splitlines()), (phase, r.stderr[-3000:])
