@@ -113,9 +113,9 @@ typedef struct PgvPoolSlot
 	char		payload[PGV_POOL_ROW_BYTES];
 }			PgvPoolSlot;
 
-/* a worker whose heartbeat is older than this AND whose process no longer exists is gone (it beats every 200 ms in its
- * loop and once per page while staging; a long synchronous upload keeps the process, not the beat) */
-#define PGV_WORKER_DEAD_MS 3000
+/* a worker whose process exists but whose heartbeat is older than this is hung (it beats every 200 ms in its loop and
+ * once per page while staging; the longest synchronous call, the upload of an index that fills the HBM, takes seconds) */
+#define PGV_WORKER_HUNG_MS 60000
 /* a pooled query the worker has not TAKEN after this long (it is staging some index: seconds) is taken back by its
  * backend, which scans on its own context or on the reference's path */
 #define PGV_POOL_PATIENCE_MS 500
@@ -361,9 +361,9 @@ static PgvOwned owned[PGV_MAX_MIRRORS];
 static int	workerSlot = -1;	/* this process's registration when it is a GPU worker */
 
 /*
- * The worker's heartbeat.  Backends take a worker whose beat is older than PGV_WORKER_DEAD_MS for dead (and start
- * another), so everything in the worker that can take seconds -- staging a large index through the buffer manager --
- * beats on its way (once per page walked; a no-op in a backend).
+ * The worker's heartbeat.  Backends take a worker whose process is gone for dead at once, and one whose beat is older
+ * than PGV_WORKER_HUNG_MS for hung; everything in the worker that can take long -- staging a large index through the
+ * buffer manager -- beats on its way (once per page walked; a no-op in a backend).
  */
 void
 PgvWorkerBeat(void)
@@ -803,8 +803,11 @@ PgvWorkerExit(int code, Datum arg)
 }
 
 /*
- * Is the registered worker of this database alive?  A worker that was killed (no exit hook ran) stops beating AND its
- * process is gone; one that is busy in a long synchronous call (the upload of a very large index) only stops beating.
+ * Is the registered worker of this database alive?  A worker that was killed (no exit hook ran) is known by its
+ * process being gone -- at once, so that no backend tries to import the handles of an exporter that no longer exists
+ * (hipIpcOpenMemHandle on those takes seconds to fail) --; one whose process is there but whose beat is older than
+ * PGV_WORKER_HUNG_MS is hung, or the pid has been given to somebody else.  A worker busy in a long synchronous call
+ * (the upload of a very large index) only stops beating for a while: alive.
  */
 static bool
 PgvWorkerAlive(int slot)
@@ -812,11 +815,11 @@ PgvWorkerAlive(int slot)
 	uint64		beat = pg_atomic_read_u64(&PgvShared->workerBeat[slot]);
 	int			pid = PgvShared->workerPid[slot];
 
-	if (beat == 0)
+	if (beat == 0 || pid <= 0)
 		return false;
-	if (!TimestampDifferenceExceeds((TimestampTz) beat, GetCurrentTimestamp(), PGV_WORKER_DEAD_MS))
-		return true;
-	return pid > 0 && (kill(pid, 0) == 0 || errno == EPERM);
+	if (kill(pid, 0) != 0 && errno == ESRCH)
+		return false;
+	return !TimestampDifferenceExceeds((TimestampTz) beat, GetCurrentTimestamp(), PGV_WORKER_HUNG_MS);
 }
 
 /* bgw_main of the per-database worker; bgw_main_arg = the database's oid */
@@ -963,15 +966,23 @@ PgvEnsureWorker(void)
 	return false;
 }
 
-/* a worker of this database is registered and beating */
+/* a worker of this database is registered and alive (PgvShared->lock held) */
+static bool
+PgvDbWorkerAlive(void)
+{
+	for (int i = 0; i < PGV_MAX_MIRRORS; i++)
+		if (PgvShared->workerDb[i] == MyDatabaseId && PgvShared->workerLatch[i] != NULL && PgvWorkerAlive(i))
+			return true;
+	return false;
+}
+
 static bool
 PgvWorkerIsThere(void)
 {
-	bool		there = false;
+	bool		there;
 
 	LWLockAcquire(PgvShared->lock, LW_SHARED);
-	for (int i = 0; i < PGV_MAX_MIRRORS && !there; i++)
-		there = PgvShared->workerDb[i] == MyDatabaseId && PgvShared->workerLatch[i] != NULL && PgvWorkerAlive(i);
+	there = PgvDbWorkerAlive();
 	LWLockRelease(PgvShared->lock);
 	return there;
 }
@@ -1001,7 +1012,13 @@ PgvMirrorReadyKind(Relation index, int kind, pgv_index_handle * handle, uint64 *
 		{
 			uint64		generation = pg_atomic_read_u64(&e->generation);
 
-			if (e->state == PGV_MIRROR_READY && e->stagedGeneration == generation)
+			if (e->state == PGV_MIRROR_READY && e->stagedGeneration == generation && !PgvDbWorkerAlive())
+			{
+				/* the handle's exporter is gone (killed: no exit hook cleared the registry): importing it would take
+				 * seconds to fail.  PgvEnsureWorker does what the exit hook would have done and starts another. */
+				request = true;
+			}
+			else if (e->state == PGV_MIRROR_READY && e->stagedGeneration == generation)
 			{
 				*handle = e->handle;
 				*staged = e->stagedGeneration + 1;	/* 0 = none */

@@ -17,5 +17,10 @@ def test_ext_glue_runs_on_the_gpu(tmp_path):
     env = dict(os.environ)
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     r = subprocess.run([exe], capture_output=True, text=True, timeout=900, env=env)
+    # the whole transcript where a gpurun call brings it back (the assertion below shows its tail only)
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    if os.path.isdir(os.path.join(root, "gpurun_out")):
+        with open(os.path.join(root, "gpurun_out", "ext_driver_gpu.log"), "w") as f:
+            f.write(r.stdout + "\n---- stderr ----\n" + r.stderr)
     assert r.returncode == 0 and "EXT-RUNTIME OK" in r.stdout, (r.returncode, r.stdout[-500:], r.stderr[-4000:])
     assert "buffer refcount leak" not in r.stderr
