@@ -21,6 +21,9 @@
  *   hnswgettuple        src/hnswscan.c:228      if (!(so->gpu && PgvHnswGetScanItems(scan, value, &so->w))) so->w = GetScanItems(scan, value);
  *                                               (false: NULL query or hnsw.iterative_scan -- the reference's scan)
  *   hnswendscan         src/hnswscan.c:337-349  PgvHnswEndScan(so->gpu);
+ *   InitBuildState      src/hnswbuild.c:660-720 buildstate->gpu = PgvHnswBuildBegin(buildstate);
+ *   InsertTuple         src/hnswbuild.c:575     if (buildstate->gpu) PgvHnswBuildDefer(buildstate, element); else InsertTupleInMemory(buildstate, element);
+ *   FlushPages          src/hnswbuild.c:304     PgvHnswBuildLink(buildstate);   (first statement: links what was deferred)
  *   IvfflatKmeans       src/ivfkmeans.c:553-570 if (PgvIvfflatKmeans(index, samples, centers, typeInfo)) return;
  *   BuildCallback       src/ivfbuild.c:224-266  if (buildstate->gpu) { PgvIvfflatBuildAdd(buildstate, tid, value); return; }
  *   AssignTuples        src/ivfbuild.c:600-636  PgvIvfflatBuildFlush(buildstate) after the heap scan
@@ -122,6 +125,14 @@ void		PgvHnswInvalidate(Oid relid);
 bool		PgvHnswElementType(Relation index, pgv_dtype * dtype);
 /* FUNCTION 1 of an hnsw opclass that has no FUNCTION 2: L2 or inner product (by the support function's oid) */
 pgv_metric	PgvHnswMetricOf(Relation index);
+
+/* HNSW build side (hnswbuild_gpu.c): the in-memory insertions deferred and linked at once before FlushPages
+ * (HnswBuildState / HnswElement of src/hnsw.h, which this header does not include) */
+struct HnswBuildState;
+struct HnswElementData;
+void	   *PgvHnswBuildBegin(struct HnswBuildState *buildstate);	/* NULL: vector.gpu off, a parallel build, a bit / sparsevec opclass */
+void		PgvHnswBuildDefer(struct HnswBuildState *buildstate, struct HnswElementData *element);
+void		PgvHnswBuildLink(struct HnswBuildState *buildstate);
 
 /* build side (ivfbuild_gpu.c) */
 bool		PgvIvfflatKmeans(Relation index, VectorArray samples, VectorArray centers, const IvfflatTypeInfo * typeInfo);

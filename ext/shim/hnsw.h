@@ -68,20 +68,64 @@ typedef struct HnswNeighborTupleData
 }			HnswNeighborTupleData;
 typedef HnswNeighborTupleData *HnswNeighborTuple;
 
-typedef struct HnswElementData
-{
-	ItemPointerData heaptids[HNSW_HEAPTIDS];
-	uint8		heaptidsLength;
-	uint8		level;
-	BlockNumber blkno;
-	OffsetNumber offno;
-}			HnswElementData;
-typedef HnswElementData *HnswElement;
+typedef struct HnswElementData HnswElementData;
+typedef struct HnswNeighborArray HnswNeighborArray;
+/* src/hnsw.h:171-180: pointers that are absolute in a serial build and relative (relptr) in a parallel one; the glue
+ * only ever goes through the macros below, here in their absolute form */
 typedef union
 {
 	HnswElementData *ptr;
 }			HnswElementPtr;
+typedef union
+{
+	HnswNeighborArray *ptr;
+}			HnswNeighborArrayPtr;
+typedef union
+{
+	HnswNeighborArrayPtr *ptr;
+}			HnswNeighborsPtr;
+typedef union
+{
+	char	   *ptr;
+}			DatumPtr;
 #define HnswPtrStore(base, hp, value) ((void) (base), (void) ((hp).ptr = (value)))
+#define HnswPtrAccess(base, hp) ((void) (base), (hp).ptr)
+#define HnswPtrIsNull(base, hp) ((void) (base), (hp).ptr == NULL)
+#define HnswGetNeighbors(base, element, lc) HnswPtrAccess(base, HnswPtrAccess(base, (element)->neighbors)[lc])
+#define HnswGetLayerM(m, layer) ((layer) == 0 ? (m) * 2 : (m))
+
+struct HnswElementData
+{
+	HnswElementPtr next;
+	ItemPointerData heaptids[HNSW_HEAPTIDS];
+	uint8		heaptidsLength;
+	uint8		level;
+	uint8		deleted;
+	uint8		version;
+	uint32		hash;
+	HnswNeighborsPtr neighbors;
+	BlockNumber blkno;
+	OffsetNumber offno;
+	OffsetNumber neighborOffno;
+	BlockNumber neighborPage;
+	DatumPtr	value;
+	LWLock		lock;
+};
+typedef HnswElementData *HnswElement;
+
+typedef struct HnswCandidate
+{
+	HnswElementPtr element;
+	float		distance;
+	bool		closer;
+}			HnswCandidate;
+
+struct HnswNeighborArray
+{
+	int			length;
+	bool		closerSet;
+	HnswCandidate items[];
+};
 
 typedef struct HnswSearchCandidate
 {
@@ -119,6 +163,46 @@ Datum		halfvec_negative_inner_product(void *fcinfo);
 Datum		l1_distance(void *fcinfo);
 Datum		halfvec_l1_distance(void *fcinfo);
 
+/* the in-memory phase of the build (src/hnsw.h:212-345): what ext/hnswbuild_gpu.c touches of it */
+typedef struct HnswGraph
+{
+	HnswElementPtr head;
+	double		indtuples;
+	HnswElementPtr entryPoint;
+	Size		memoryUsed;
+	Size		memoryTotal;
+	bool		flushed;
+}			HnswGraph;
+
+typedef struct HnswAllocator
+{
+	void	   *(*alloc) (Size size, void *state);
+	void	   *state;
+}			HnswAllocator;
+
+typedef struct HnswBuildState
+{
+	Relation	heap;
+	Relation	index;
+	const HnswTypeInfo *typeInfo;
+	int			dimensions;
+	int			m;
+	int			efConstruction;
+	double		indtuples;
+	HnswSupport support;
+	HnswGraph	graphData;
+	HnswGraph  *graph;
+	double		ml;
+	int			maxLevel;
+	MemoryContext graphCtx;
+	MemoryContext tmpCtx;
+	HnswAllocator allocator;
+	char	   *hnswarea;		/* NULL in a serial build; the shared area of a parallel one */
+	void	   *gpu;			/* added: PgvHnswBuild of ext/hnswbuild_gpu.c, NULL when the build stays on the CPU */
+}			HnswBuildState;
+
+void	   *HnswAlloc(HnswAllocator * allocator, Size size);
+HnswElement HnswInitElement(char *base, ItemPointer heaptid, int m, double ml, int maxLevel, HnswAllocator * allocator);
 HnswElement HnswInitElementFromBlock(BlockNumber blkno, OffsetNumber offno);
 void		HnswAddHeapTid(HnswElement element, ItemPointer heaptid);
 FmgrInfo   *HnswOptionalProcInfo(Relation index, uint16 procnum);

@@ -30,6 +30,7 @@ typedef uintptr_t Datum;
 typedef unsigned int Oid;
 typedef char *Pointer;
 #define PG_INT64_MAX INT64_MAX
+#define INT64_FORMAT "%ld"
 #define Min(a, b) ((a) < (b) ? (a) : (b))
 #define Max(a, b) ((a) > (b) ? (a) : (b))
 #define PointerGetDatum(p) ((Datum) (p))
@@ -64,6 +65,7 @@ void	   *palloc0(Size size);
 void	   *repalloc(void *p, Size size);
 void		pfree(void *p);
 void	   *MemoryContextAlloc(MemoryContext ctx, Size size);
+MemoryContext MemoryContextSwitchTo(MemoryContext ctx);
 void	   *MemoryContextAllocZero(MemoryContext ctx, Size size);
 typedef void (*MemoryContextCallbackFunction) (void *arg);
 typedef struct MemoryContextCallback

@@ -1190,6 +1190,288 @@ backend_hnsw_scan(void *arg)
 	return 0;
 }
 
+/* ------------------------------------------------------------------------------------------------ hnsw: CREATE INDEX */
+#define REL_HNSW2 2002
+#define HB 4000					/* heap rows of the build scenario (a few of them duplicates) */
+
+static void *
+graph_alloc(Size size, void *state)
+{
+	HnswBuildState *bs = state;	/* HnswMemoryContextAlloc, src/hnswbuild.c:646-655 */
+
+	bs->graphData.memoryUsed += size;
+	return MemoryContextAlloc(bs->graphCtx, size);
+}
+
+static int
+row_of_tid(uint64 tid)
+{
+	return (int) ((tid >> 16) - 1) * 50 + (int) (tid & 0xffff) - 1;
+}
+
+typedef struct LevelReplay
+{
+	const int32_t *levels;
+	int64_t		next;
+	double		ml;
+}			LevelReplay;
+
+static double
+replay_level(void *state)
+{
+	LevelReplay *r = state;
+
+	return exp(-((double) r->levels[r->next++] + 0.5) / r->ml);
+}
+
+/*
+ * BuildGraph's in-memory phase through the hooks of ext/hnswbuild_gpu.c: InsertTuple allocates every element the
+ * reference's way (HnswInitElement draws the level, the value is copied into graph memory, the caller's per-tuple
+ * context is reset), the hook defers the insertion, and the first statement of FlushPages links the lot.  What
+ * CreateGraphPages / WriteNeighborTuples would then serialise -- the element list, newest first, the neighbor arrays,
+ * the duplicates' heap TIDs, the entry point -- must be the graph pgv_host_hnsw_build gives for the same rows and the
+ * same levels, tuple for tuple; its pages, staged by the worker and scanned through the scan hooks, answer like the
+ * oracle walking that graph.
+ */
+static int
+backend_hnsw_gpu_build(void *arg)
+{
+	Relation	index = shim_open_relation(REL_HNSW2);
+	float	   *data = malloc(sizeof(float) * HB * DIM);
+	HnswBuildState bs;
+	HnswElement *byrow = calloc(HB, sizeof(HnswElement));
+	int32_t    *levels = malloc(sizeof(int32_t) * HB),
+			   *dup_of = malloc(sizeof(int32_t) * HB);
+	int64_t    *nbr_start = malloc(sizeof(int64_t) * (HB + 1));
+	int32_t    *nbr;
+	uint64_t   *tids = malloc(sizeof(uint64_t) * HB);
+	int32_t		entry = -1;
+	int			listed = 0,
+				prev_row = HB;
+	MemoryContext tmp;
+	pgv_hnsw   *mirror = NULL;
+	pgv_hnsw_built direct;
+	pgv_ctx    *ctx = NULL;
+	LevelReplay replay;
+	pgv_rng		rng;
+	pgv_rel		rel;
+
+	(void) arg;
+	scenario = "hnsw build hooks";
+	EXPECT(index != NULL);
+	shim_set_guc_bool("vector.gpu", true);
+	shim_seed_random(21);
+	for (int i = 0; i < 16; i++)
+		(void) RandomDouble();	/* (the stand-in generator's first draws after a small seed are tiny: row 0 would top every level) */
+	gen_rows(data, HB, DIM, 8);
+	/* duplicates: the same value under several heap TIDs (src/hnswbuild.c:318-364) */
+	for (int r = 600; r < 612; r++)
+		memcpy(data + (size_t) r * DIM, data + (size_t) 500 * DIM, sizeof(float) * DIM);	/* 12 copies: more than HNSW_HEAPTIDS */
+	memcpy(data + (size_t) 3000 * DIM, data + (size_t) 10 * DIM, sizeof(float) * DIM);
+
+	memset(&bs, 0, sizeof(bs));
+	bs.index = index;
+	bs.typeInfo = HnswGetTypeInfo(index);
+	bs.dimensions = DIM;
+	bs.m = HM;
+	bs.efConstruction = 32;
+	bs.ml = 1.0 / log((double) HM);
+	bs.maxLevel = (int) ((8192 - 24 - 8 - 4 - 4) / 6 / HM) - 2 < 63 ? (int) ((8192 - 24 - 8 - 4 - 4) / 6 / HM) - 2 : 63;
+	bs.graph = &bs.graphData;
+	bs.graphData.memoryTotal = (Size) 1 << 30;
+	bs.graphCtx = shim_query_context_begin();
+	bs.allocator.alloc = graph_alloc;
+	bs.allocator.state = &bs;
+	bs.hnswarea = NULL;
+	bs.gpu = PgvHnswBuildBegin(&bs);
+	EXPECT(bs.gpu != NULL);
+	{
+		/* a parallel build keeps the reference's code */
+		HnswBuildState par = bs;
+		char		area[8];
+
+		par.hnswarea = area;
+		EXPECT(PgvHnswBuildBegin(&par) == NULL);
+	}
+
+	/* BuildCallback + InsertTuple (src/hnswbuild.c:486-609), the hook in place of InsertTupleInMemory */
+	tmp = shim_query_context_begin();
+	for (int r = 0; r < HB; r++)
+	{
+		Vector	   *value = make_vector(data + (size_t) r * DIM, DIM);
+		Size		valueSize = offsetof(Vector, x) + sizeof(float) * DIM;
+		ItemPointerData tid = itemptr(tid_of_row(r));
+		HnswElement element = HnswInitElement(bs.hnswarea, &tid, bs.m, bs.ml, bs.maxLevel, &bs.allocator);
+		char	   *valuePtr = HnswAlloc(&bs.allocator, valueSize);
+
+		memcpy(valuePtr, value, valueSize);
+		HnswPtrStore(bs.hnswarea, element->value, valuePtr);
+		levels[r] = element->level;
+		tids[r] = tid_of_row(r);
+		PgvHnswBuildDefer(&bs, element);
+		bs.graphData.indtuples++;
+		shim_context_reset(tmp);	/* the caller's copy of the value is poison from here on */
+	}
+	shim_query_context_end(tmp);
+	CurrentMemoryContext = TopMemoryContext;
+	EXPECT(HnswPtrIsNull(bs.hnswarea, bs.graph->head));	/* nothing linked yet */
+
+	/* FlushPages, first statement */
+	PgvHnswBuildLink(&bs);
+	PgvHnswBuildLink(&bs);		/* (again: nothing deferred, nothing happens) */
+
+	/* ---- what the reference would serialise now */
+	nbr_start[0] = 0;
+	for (int r = 0; r < HB; r++)
+	{
+		nbr_start[r + 1] = nbr_start[r] + (int64_t) (levels[r] + 2) * HM;
+		dup_of[r] = -2;			/* not seen yet */
+	}
+	nbr = malloc(sizeof(int32_t) * (size_t) nbr_start[HB]);
+	for (int64_t j = 0; j < nbr_start[HB]; j++)
+		nbr[j] = -1;
+	for (HnswElementPtr it = bs.graph->head; !HnswPtrIsNull(bs.hnswarea, it);)
+	{
+		HnswElement element = HnswPtrAccess(bs.hnswarea, it);
+		int			row = row_of_tid(tid_key(&element->heaptids[0]));
+
+		it = element->next;
+		EXPECT(row >= 0 && row < HB && row < prev_row);	/* newest first (head insertion) */
+		prev_row = row;
+		EXPECT(element->level == levels[row] && element->heaptidsLength >= 1 && element->heaptidsLength <= HNSW_HEAPTIDS);
+		byrow[row] = element;
+		dup_of[row] = -1;
+		for (int t = 1; t < element->heaptidsLength; t++)
+		{
+			int			dr = row_of_tid(tid_key(&element->heaptids[t]));
+
+			EXPECT(dr > row && dr < HB && dup_of[dr] == -2);
+			EXPECT(memcmp(data + (size_t) dr * DIM, data + (size_t) row * DIM, sizeof(float) * DIM) == 0);
+			dup_of[dr] = row;
+		}
+		listed++;
+	}
+	for (int r = 0; r < HB; r++)
+		EXPECT(dup_of[r] != -2);	/* every heap row is an element of the list or a heap TID on one */
+	for (int r = 0; r < HB; r++)
+		if (dup_of[r] == -1)
+			for (int lc = levels[r]; lc >= 0; lc--)
+			{
+				HnswNeighborArray *a = HnswGetNeighbors(bs.hnswarea, byrow[r], lc);
+				int32_t    *out = nbr + nbr_start[r] + (int64_t) (levels[r] - lc) * HM;
+
+				EXPECT(a->length >= 0 && a->length <= HnswGetLayerM(HM, lc));
+				for (int i = 0; i < a->length; i++)
+				{
+					HnswElement ne = HnswPtrAccess(bs.hnswarea, a->items[i].element);
+					int			nr = row_of_tid(tid_key(&ne->heaptids[0]));
+
+					EXPECT(nr >= 0 && nr < HB && byrow[nr] == ne && levels[nr] >= lc);
+					out[i] = nr;
+				}
+			}
+	EXPECT(!HnswPtrIsNull(bs.hnswarea, bs.graph->entryPoint));
+	entry = row_of_tid(tid_key(&HnswPtrAccess(bs.hnswarea, bs.graph->entryPoint)->heaptids[0]));
+	EXPECT(dup_of[500] == -1 && dup_of[3000] == 10);
+	{
+		int			on500 = 0,
+					elsewhere = 0;
+
+		for (int r = 600; r < 612; r++)
+			if (dup_of[r] == 500)
+				on500++;
+			else
+				elsewhere++;
+		EXPECT(on500 == HNSW_HEAPTIDS - 1 && elsewhere == 3);	/* an element holds ten heap TIDs; the rest spill over */
+	}
+	EXPECT(bs.graphData.indtuples == HB);
+
+	/* ---- the same rows and levels straight through pgv_host_hnsw_build: the same graph, tuple for tuple */
+	EXPECT(pgv_ctx_create(0, NULL, &ctx) == PGV_OK);
+	EXPECT(pgv_hnsw_upload(ctx, PGV_L2SQ, PGV_F32, DIM, data, HB, &mirror) == PGV_OK);
+	replay.levels = levels;
+	replay.next = 0;
+	replay.ml = bs.ml;
+	memset(&rng, 0, sizeof(rng));
+	rng.next_double = replay_level;
+	rng.state = &replay;
+	EXPECT(pgv_host_hnsw_build(mirror, PGV_F32, DIM, data, HB, HM, 32, &rng, 1024, &direct) == PGV_OK);
+	EXPECT(direct.entry == entry && direct.nelements == listed);
+	for (int r = 0; r < HB; r++)
+		EXPECT(direct.levels[r] == levels[r] && direct.dup_of[r] == dup_of[r]);
+	EXPECT(memcmp(direct.nbr, nbr, sizeof(int32_t) * (size_t) nbr_start[HB]) == 0);
+	pgv_host_hnsw_built_free(&direct);
+	pgv_hnsw_free(mirror);
+	pgv_ctx_destroy(ctx);
+	fprintf(stderr, "   %d heap rows -> %d elements (%d duplicates), entry row %d at level %d; graph memory %zu KB\n", HB, listed,
+			HB - listed, entry, levels[entry], bs.graphData.memoryUsed >> 10);
+
+	/* ---- FlushPages proper: the pages, then scans through the scan hooks against the oracle walking this graph */
+	pgv_rel_init(&rel);
+	EXPECT(pgv_host_hnsw_write_index(&rel, PGV_F32, DIM, HM, 32, HB, data, tids, levels, nbr_start, nbr, dup_of, entry) == PGV_OK);
+	shim_replace_pages(REL_HNSW2, rel.pages, rel.nblocks);
+	pgv_rel_free(&rel);
+	PgvNoteIndexChange(index);
+	shim_query_context_end(bs.graphCtx);	/* MemoryContextReset(buildstate->graphCtx), :315 */
+	{
+		ora_hnsw   *g = ora_hnsw_import(ORA_OPS_L2, ORA_F32, DIM, data, HB, HM, levels, nbr_start, nbr, entry);
+		double		until = shim_now() + 30.0;
+		void	   *gpu = NULL;
+		MemoryContext qctx = shim_query_context_begin();
+
+		EXPECT(g != NULL);
+		hnsw_ef_search = 40;
+		while ((gpu = PgvHnswBeginScan(index)) == NULL && shim_now() < until)
+			usleep(20000);
+		EXPECT(gpu != NULL);
+		PgvHnswEndScan(gpu);
+		shim_query_context_end(qctx);
+		for (int i = 0; i < 20; i++)
+		{
+			IndexScanDescData desc;
+			HnswScanOpaqueData so;
+			float		q[DIM];
+			List	   *w = NIL;
+			int64_t		rows[40];
+			double		dist[40];
+			int64_t		scored;
+			int			want,
+						n;
+
+			make_query(q, 200 + i);
+			want = ora_hnsw_search(g, q, 40, 40, rows, dist, &scored);
+			qctx = shim_query_context_begin();
+			memset(&desc, 0, sizeof(desc));
+			memset(&so, 0, sizeof(so));
+			desc.indexRelation = index;
+			desc.opaque = &so;
+			so.first = true;
+			so.gpu = PgvHnswBeginScan(index);
+			EXPECT(so.gpu != NULL);
+			EXPECT(PgvHnswGetScanItems(&desc, PointerGetDatum(make_vector(q, DIM)), &w));
+			n = shim_list_length(w);
+			EXPECT(n == want);
+			for (int j = 0; j < n; j++)
+			{
+				HnswSearchCandidate *sc = shim_list_nth(w, n - 1 - j);
+
+				EXPECT(fabs(sc->distance - dist[j]) <= 1e-4 * fabs(dist[j]) + 1e-6);
+			}
+			PgvHnswEndScan(so.gpu);
+			shim_query_context_end(qctx);
+		}
+		ora_hnsw_free(g);
+	}
+	free(data);
+	free(byrow);
+	free(levels);
+	free(dup_of);
+	free(nbr_start);
+	free(nbr);
+	free(tids);
+	return 0;
+}
+
 /* ------------------------------------------------------------------------------------------------ the worker's housekeeping */
 #define REL_SLOW 1003
 #define REL_WIDE 1005
@@ -1421,6 +1703,7 @@ main(void)
 	shim_create_relation(REL_BATCH, &l2, empty, 0, 8);
 	shim_create_relation(REL_HNSW, &hnsw_l2, empty, 0, DIM);
 	shim_create_relation(REL_SLOW, &l2, empty, 0, DIM);
+	shim_create_relation(REL_HNSW2, &hnsw_l2, empty, 0, DIM);
 	shim_create_relation(REL_WIDE, &l2, empty, 0, IVFFLAT_MAX_DIM);
 
 	failed |= run_phase("CREATE INDEX through the build hooks", backend_build, 1, NULL, 300.0);
@@ -1475,6 +1758,8 @@ main(void)
 		failed |= run_phase("hnsw: pages from the oracle's graph", backend_hnsw_build, 1, NULL, 120.0);
 	if (!failed)
 		failed |= run_phase("hnsw scans", backend_hnsw_scan, 1, NULL, 120.0);
+	if (!failed)
+		failed |= run_phase("hnsw: CREATE INDEX through the build hooks", backend_hnsw_gpu_build, 1, NULL, 300.0);
 	shim_postmaster_shutdown();
 	if (failed)
 	{

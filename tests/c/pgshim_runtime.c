@@ -23,6 +23,7 @@
 
 #include <errno.h>
 #include <limits.h>
+#include <math.h>
 #include <linux/futex.h>
 #include <signal.h>
 #include <stdarg.h>
@@ -195,6 +196,15 @@ void *
 MemoryContextAlloc(MemoryContext ctx, Size size)
 {
 	return context_alloc(ctx, size, false);
+}
+
+MemoryContext
+MemoryContextSwitchTo(MemoryContext ctx)
+{
+	MemoryContext old = CurrentMemoryContext;
+
+	CurrentMemoryContext = ctx;
+	return old;
 }
 
 void *
@@ -1698,6 +1708,47 @@ void
 HnswAddHeapTid(HnswElement element, ItemPointer heaptid)
 {
 	element->heaptids[element->heaptidsLength++] = *heaptid;
+}
+
+/* src/hnswutils.c:229-236 */
+void *
+HnswAlloc(HnswAllocator * allocator, Size size)
+{
+	if (allocator)
+		return (*(allocator)->alloc) (size, (allocator)->state);
+	return palloc(size);
+}
+
+/* HnswInitElement + HnswInitNeighbors + HnswInitNeighborArray, src/hnswutils.c:201-266: the level is drawn here, one
+ * RandomDouble() per heap tuple */
+HnswElement
+HnswInitElement(char *base, ItemPointer heaptid, int m, double ml, int maxLevel, HnswAllocator * allocator)
+{
+	HnswElement element = HnswAlloc(allocator, sizeof(HnswElementData));
+	int			level = (int) (-log(RandomDouble()) * ml);
+	HnswNeighborArrayPtr *neighborList;
+
+	if (level > maxLevel)
+		level = maxLevel;
+	memset(element, 0x5a, sizeof(HnswElementData));	/* (the server's allocator does not zero either) */
+	element->heaptidsLength = 0;
+	HnswAddHeapTid(element, heaptid);
+	element->level = (uint8) level;
+	element->deleted = 0;
+	element->version = 1;
+	neighborList = HnswAlloc(allocator, sizeof(HnswNeighborArrayPtr) * (Size) (level + 1));
+	HnswPtrStore(base, element->neighbors, neighborList);
+	for (int lc = 0; lc <= level; lc++)
+	{
+		int			lm = HnswGetLayerM(m, lc);
+		HnswNeighborArray *a = HnswAlloc(allocator, offsetof(HnswNeighborArray, items) + sizeof(HnswCandidate) * (Size) lm);
+
+		a->length = 0;
+		a->closerSet = false;
+		HnswPtrStore(base, neighborList[lc], a);
+	}
+	HnswPtrStore(base, element->value, (char *) NULL);
+	return element;
 }
 
 static uint64 rng_state = 0x9E3779B97F4A7C15ull;

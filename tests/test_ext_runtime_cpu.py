@@ -16,7 +16,8 @@ import subprocess
 import pytest
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-EXT = [os.path.join(ROOT, "ext", f) for f in ("pgv_context.c", "ivfscan_gpu.c", "hnswscan_gpu.c", "ivfbuild_gpu.c")]
+EXT = [os.path.join(ROOT, "ext", f) for f in ("pgv_context.c", "ivfscan_gpu.c", "hnswscan_gpu.c", "ivfbuild_gpu.c",
+                                               "hnswbuild_gpu.c")]
 
 
 def build_driver(exe, device_sources, extra_flags=(), extra_libs=()):
@@ -46,5 +47,5 @@ def test_ext_glue_runs_on_the_stand_in_server(tmp_path, sanitize):
     for phase in ("CREATE INDEX through the build hooks", "own-context scans", "six pooled backends",
                   "insert / restage under an open scan", "pooled scan across a restage", "a staging of several seconds",
                   "DROP INDEX x 70", "build state for 2000-d rows", "worker killed (SIGKILL)",
-                  "worker ended (SIGTERM)", "hnsw scans"):
+                  "worker ended (SIGTERM)", "hnsw scans", "hnsw: CREATE INDEX through the build hooks"):
         assert any(phase in line and ": ok" in line for line in r.stderr.splitlines()), (phase, r.stderr[-3000:])
