@@ -11,7 +11,8 @@
  *   mirrors   staged by the worker through the buffer manager, imported by backends; insert -> stale -> CPU path ->
  *             restaged; an open scan keeps the import it began on (use-after-free); a pooled scan whose
  *             mirror is restaged under it restarts on the CPU path without returning a tuple twice
- *   worker    killed without a word (heartbeat), ended politely (exit hook): backends never hang, a new one starts
+ *   worker    killed without a word (its process is gone), ended politely (exit hook): backends never hang, a new one
+ *             starts; a staging of several seconds (no beat-based verdict while the process lives), DROP INDEX x 70
  *   hnsw      PgvHnswStage / BeginScan / GetScanItems against the oracle's walk of the same graph
  *
  * Expected answers: the oracle walking the very same pages (ora_pages_search), tie-tolerant.  TEST INFRASTRUCTURE.
@@ -1477,7 +1478,8 @@ backend_hnsw_gpu_build(void *arg)
 #define REL_WIDE 1005
 
 /*
- * A staging that takes longer than the heartbeat's patience (a cold, large index: every page read of the worker sleeps).
+ * A staging of several seconds (a cold, large index: every page read of the worker sleeps) -- longer than the 3 s after
+ * which a worker that had not beaten used to count as dead.
  * The worker must not be taken for dead meanwhile -- no second worker, no forgotten registration --, a pooled query on
  * ANOTHER index must not wait for the staging to end, and the mirror must come out.
  */
@@ -1510,7 +1512,7 @@ backend_slow_staging(void *arg)
 		shim_replace_pages(REL_SLOW, pages, nblocks);
 		fprintf(stderr, "   REL_SLOW: %u pages\n", nblocks);
 	}
-	/* from here on the worker's page reads crawl: REL_SLOW's staging takes ~5 s (the heartbeat's patience is 3 s) */
+	/* from here on the worker's page reads crawl: REL_SLOW's staging takes ~5 s */
 	shim_set_bgworker_read_delay_us(12000);
 	EXPECT(!PgvIvfflatMirrorIsCurrent(slow));	/* requested */
 	t0 = shim_now();
@@ -1541,7 +1543,7 @@ backend_slow_staging(void *arg)
 	EXPECT(PgvIvfflatMirrorIsCurrent(slow));
 	fprintf(stderr, "   staging took %.1f s with the worker's reads slowed; %d pooled queries on another index answered meanwhile\n",
 			shim_now() - t0, served);
-	EXPECT(shim_now() - t0 > 3.5);	/* (the scenario is only worth something past the heartbeat's patience) */
+	EXPECT(shim_now() - t0 > 3.5);	/* (the scenario is only worth something when the staging is long) */
 	return 0;
 }
 
