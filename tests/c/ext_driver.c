@@ -39,6 +39,7 @@ int			mock_hip_live_queries(void) __attribute__((weak));
 
 #define EXPECT(cond) do { if (!(cond)) { fprintf(stderr, "%s:%d: [%s] EXPECT(%s) failed\n", __FILE__, __LINE__, scenario, #cond); return 1; } } while (0)
 static const char *scenario = "setup";
+static int	cur_ops = ORA_OPS_L2;	/* which opclass the oracle answers for (the relation under test) */
 
 #define REL_IVF 1001
 #define REL_BATCH 1002
@@ -183,7 +184,7 @@ expected_batch(Oid relid, const float *query, int probes)
 
 	e.tids = malloc(sizeof(uint64) * (size_t) cap);
 	e.dist = malloc(sizeof(double) * (size_t) cap);
-	e.n = ora_pages_search(pages, nblocks, ORA_OPS_L2, ORA_F32, query, probes, cap, e.tids, e.dist, &scanned);
+	e.n = ora_pages_search(pages, nblocks, cur_ops, ORA_F32, query, probes, cap, e.tids, e.dist, &scanned);
 	pairs = malloc(sizeof(*pairs) * (size_t) (e.n > 0 ? e.n : 1));
 	for (int i = 0; i < e.n; i++)
 	{
@@ -429,6 +430,17 @@ build_index(Oid relid, const float *rows, int n, int dim, int lists, int toast_e
 		v->vl_len_ = (int32) (itemsize << 2);
 		v->dim = (int16) dim;
 		memcpy(v->x, rows + (size_t) r * dim, sizeof(float) * (Size) dim);
+		if (cur_ops != ORA_OPS_L2)
+		{
+			/* SampleCallback normalises the samples of opclasses with a KMEANS_NORM proc (src/ivfbuild.c:148-156) */
+			double		norm = 0.0;
+
+			for (int d = 0; d < dim; d++)
+				norm += (double) v->x[d] * (double) v->x[d];
+			norm = sqrt(norm);
+			for (int d = 0; d < dim && norm > 0.0; d++)
+				v->x[d] = (float) ((double) v->x[d] / norm);
+		}
 	}
 	centers.length = 0;
 	centers.maxlen = lists;
@@ -472,13 +484,13 @@ build_index(Oid relid, const float *rows, int n, int dim, int lists, int toast_e
 		EXPECT(sorted.list[i] >= 0 && sorted.list[i] < lists);
 		for (int c = 0; c < lists; c++)
 		{
-			double		d = ora_index_distance(ORA_OPS_L2, ORA_F32, dim, sorted.rows + (size_t) i * dim, packed_centers + (size_t) c * dim);
+			double		d = ora_index_distance(cur_ops, ORA_F32, dim, sorted.rows + (size_t) i * dim, packed_centers + (size_t) c * dim);
 
 			if (d < best)
 				best = d;
 		}
-		mine = ora_index_distance(ORA_OPS_L2, ORA_F32, dim, sorted.rows + (size_t) i * dim, packed_centers + (size_t) sorted.list[i] * dim);
-		EXPECT(mine <= best * (1.0 + 1e-5) + 1e-9);
+		mine = ora_index_distance(cur_ops, ORA_F32, dim, sorted.rows + (size_t) i * dim, packed_centers + (size_t) sorted.list[i] * dim);
+		EXPECT(mine <= best + 1e-5 * fabs(best) + 1e-9);
 		EXPECT(sorted.tid[i] == tid_of_row(i));	/* rows come out of the flushes in heap order, none lost, none twice */
 		EXPECT(memcmp(sorted.rows + (size_t) i * dim, rows + (size_t) i * dim, sizeof(float) * (size_t) dim) == 0);
 	}
@@ -1191,6 +1203,77 @@ backend_hnsw_scan(void *arg)
 	return 0;
 }
 
+/* ------------------------------------------------------------------------------------------------ vector_ip_ops */
+#define REL_IP 1006
+
+/*
+ * An inner-product opclass through the same hooks: FUNCTION 4 (KMEANS_NORM) makes the k-means spherical
+ * (src/ivfkmeans.c:553-570 on normalised samples), FUNCTION 1 is vector_negative_inner_product, rows are stored as
+ * they are (no FUNCTION 2).  PgvIvfflatOpclass must map it to PGV_OPS_IP / PGV_NEG_IP for the build, the worker's
+ * staging and the scans; the oracle walks the pages with the same opclass.
+ */
+static int
+backend_ip_opclass(void *arg)
+{
+	Relation	index = shim_open_relation(REL_IP);
+	const int	n = 6000,
+				lists = 12;
+	float	   *rows = malloc(sizeof(float) * (size_t) n * DIM);
+	uint64	   *got = malloc(sizeof(uint64) * 30000);
+	float		q[DIM];
+
+	(void) arg;
+	scenario = "vector_ip_ops: build";
+	cur_ops = ORA_OPS_IP;
+	shim_set_guc_bool("vector.gpu", true);
+	shim_set_guc_bool("vector.gpu_pooled", false);
+	shim_seed_random(17);
+	gen_rows(rows, n, DIM, 12);
+	if (build_index(REL_IP, rows, n, DIM, lists, 11))
+		return 1;
+	scenario = "vector_ip_ops: scans";
+	EXPECT(wait_for_gpu(index, 30.0) == 0);
+	for (int i = 0; i < 12; i++)
+	{
+		Scan		s;
+		Expected	e;
+		int			want = i < 8 ? 10 : 400,
+					got_n;
+
+		make_query(q, 300 + i);
+		e = expected_batch(REL_IP, q, PROBES);
+		scan_begin(&s, index, q, PROBES, PROBES);
+		got_n = pull(&s, got, want);
+		EXPECT(got_n == (want < e.n ? want : e.n));
+		EXPECT(s.cpu_tuples == 0 && s.gpu_tuples == got_n);
+		if (check_stream(&e, got, got_n, 0, "inner product, own context"))
+			return 1;
+		scan_end(&s);
+		expected_free(&e);
+	}
+	/* and through the pooler */
+	shim_set_guc_bool("vector.gpu_pooled", true);
+	for (int i = 0; i < 6; i++)
+	{
+		Scan		s;
+		Expected	e;
+		int			got_n;
+
+		make_query(q, 340 + i);
+		e = expected_batch(REL_IP, q, PROBES);
+		scan_begin(&s, index, q, PROBES, PROBES);
+		got_n = pull(&s, got, 10);
+		EXPECT(got_n == 10 && s.cpu_tuples == 0);
+		if (check_stream(&e, got, got_n, 0, "inner product, pooled"))
+			return 1;
+		scan_end(&s);
+		expected_free(&e);
+	}
+	free(rows);
+	free(got);
+	return 0;
+}
+
 /* ------------------------------------------------------------------------------------------------ hnsw: CREATE INDEX */
 #define REL_HNSW2 2002
 #define HB 4000					/* heap rows of the build scenario (a few of them duplicates) */
@@ -1684,6 +1767,7 @@ main(void)
 {
 	ShimOpclass l2 = {0, IVFFLAT_MAX_DIM, false, false, 0};
 	ShimOpclass hnsw_l2 = {1, HNSW_MAX_DIM, false, false, 0};
+	ShimOpclass ip = {0, IVFFLAT_MAX_DIM, false, true, 1};	/* vector_ip_ops: FUNCTION 4 (spherical k-means), no FUNCTION 2 */
 	uint8_t		empty[1] = {0};
 	size_t		arena_bytes = 0;
 	void	   *arena;
@@ -1706,6 +1790,7 @@ main(void)
 	shim_create_relation(REL_HNSW, &hnsw_l2, empty, 0, DIM);
 	shim_create_relation(REL_SLOW, &l2, empty, 0, DIM);
 	shim_create_relation(REL_HNSW2, &hnsw_l2, empty, 0, DIM);
+	shim_create_relation(REL_IP, &ip, empty, 0, DIM);
 	shim_create_relation(REL_WIDE, &l2, empty, 0, IVFFLAT_MAX_DIM);
 
 	failed |= run_phase("CREATE INDEX through the build hooks", backend_build, 1, NULL, 300.0);
@@ -1762,6 +1847,8 @@ main(void)
 		failed |= run_phase("hnsw scans", backend_hnsw_scan, 1, NULL, 120.0);
 	if (!failed)
 		failed |= run_phase("hnsw: CREATE INDEX through the build hooks", backend_hnsw_gpu_build, 1, NULL, 300.0);
+	if (!failed)
+		failed |= run_phase("vector_ip_ops: build + scans", backend_ip_opclass, 1, NULL, 300.0);
 	shim_postmaster_shutdown();
 	if (failed)
 	{

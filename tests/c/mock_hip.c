@@ -732,16 +732,20 @@ pgv_kmeans(pgv_ctx * ctx, pgv_ops ops, pgv_dtype dtype, int dim, const void *sam
 	int		   *cnt = malloc(sizeof(int) * (size_t) k);
 	int			it = 0;
 
+	/* inner product / cosine opclasses: spherical k-means (src/ivfkmeans.c:553-570 on samples the caller normalised):
+	 * nearest center by inner product, new centers normalised */
+	const int	sph = ops != PGV_OPS_L2;
+
 	(void) ctx;
 	(void) rng;
-	if (dtype != PGV_F32 || ops != PGV_OPS_L2)
-		return fail(PGV_ERR_ARG, "mock: fp32 / l2 only");
+	if (dtype != PGV_F32 || ops == PGV_OPS_COSINE)
+		return fail(PGV_ERR_ARG, "mock: fp32, l2 and inner product only");
 	for (int j = 0; j < k; j++)
 		for (int d = 0; d < dim; d++)
 			c[(size_t) j * dim + d] = n > 0 ? s[(size_t) ((int64_t) j * n / k) * dim + d] : (float) j;
 	for (it = 0; it < (max_iterations < 20 ? max_iterations : 20) && n > 0; it++)
 	{
-		pgv_assign(NULL, PGV_L2SQ, PGV_F32, dim, c, k, s, n, closest, NULL);
+		pgv_assign(NULL, sph ? PGV_NEG_IP : PGV_L2SQ, PGV_F32, dim, c, k, s, n, closest, NULL);
 		memset(sum, 0, sizeof(float) * (size_t) k * dim);
 		memset(cnt, 0, sizeof(int) * (size_t) k);
 		for (int i = 0; i < n; i++)
@@ -752,8 +756,18 @@ pgv_kmeans(pgv_ctx * ctx, pgv_ops ops, pgv_dtype dtype, int dim, const void *sam
 		}
 		for (int j = 0; j < k; j++)
 			if (cnt[j] > 0)
+			{
+				double		norm = 0.0;
+
 				for (int d = 0; d < dim; d++)
+				{
 					c[(size_t) j * dim + d] = sum[(size_t) j * dim + d] / (float) cnt[j];
+					norm += (double) c[(size_t) j * dim + d] * (double) c[(size_t) j * dim + d];
+				}
+				norm = sqrt(norm);
+				for (int d = 0; d < dim && sph && norm > 0.0; d++)
+					c[(size_t) j * dim + d] = (float) ((double) c[(size_t) j * dim + d] / norm);
+			}
 	}
 	if (out_closest && n > 0)
 		memcpy(out_closest, closest, sizeof(int32_t) * (size_t) n);

@@ -47,5 +47,6 @@ def test_ext_glue_runs_on_the_stand_in_server(tmp_path, sanitize):
     for phase in ("CREATE INDEX through the build hooks", "own-context scans", "six pooled backends",
                   "insert / restage under an open scan", "pooled scan across a restage", "a staging of several seconds",
                   "DROP INDEX x 70", "build state for 2000-d rows", "worker killed (SIGKILL)",
-                  "worker ended (SIGTERM)", "hnsw scans", "hnsw: CREATE INDEX through the build hooks"):
+                  "worker ended (SIGTERM)", "hnsw scans", "hnsw: CREATE INDEX through the build hooks",
+                  "vector_ip_ops: build + scans"):
         assert any(phase in line and ": ok" in line for line in r.stderr.splitlines()), (phase, r.stderr[-3000:])
