@@ -1587,6 +1587,18 @@ backend_slow_staging(void *arg)
 		usleep(20000);
 	EXPECT(PgvIvfflatMirrorIsCurrent(ivf));
 	EXPECT(shim_live_bgworkers() == 1);
+	{
+		/* this backend's own device context and import exist before the clock below starts (a process's first touch of
+		 * the device takes as long as it takes: not what the 2.5 s below are about) */
+		Scan		s;
+		uint64		got[10];
+
+		shim_set_guc_bool("vector.gpu_pooled", false);
+		scan_begin(&s, ivf, q, PROBES, PROBES);
+		EXPECT(pull(&s, got, 10) == 10 && s.gpu_tuples == 10);
+		scan_end(&s);
+		shim_set_guc_bool("vector.gpu_pooled", true);
+	}
 	/* the slow index: the same image as REL_IVF (~420 pages) */
 	{
 		uint32_t	nblocks;
