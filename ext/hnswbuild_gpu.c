@@ -74,6 +74,8 @@ PgvHnswBuildBegin(HnswBuildState * buildstate)
 	/* a parallel build's workers insert into shared memory under the reference's locks: theirs stays the CPU path */
 	if (!vector_gpu || buildstate->hnswarea != NULL || !PgvHnswElementType(buildstate->index, &dtype))
 		return NULL;
+	if (PgvTryGetContext() == NULL)
+		return NULL;			/* no device: the reference's InsertTupleInMemory */
 	gb = palloc0(sizeof(PgvHnswBuild));
 	gb->dtype = dtype;
 	/* FUNCTION 1 of the opclass; rows that FUNCTION 2 normalised (cosine) are compared by inner product */

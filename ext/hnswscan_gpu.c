@@ -363,7 +363,11 @@ PgvHnswBeginScan(Relation index)
 	}
 	if (!m->valid)
 	{
-		if (pgv_hnsw_import(PgvGetContext(), &handle, &m->h) != PGV_OK)
+		pgv_ctx    *ctx = PgvTryGetContext();
+
+		if (ctx == NULL)
+			return NULL;		/* no device in this backend: the reference's scan */
+		if (pgv_hnsw_import(ctx, &handle, &m->h) != PGV_OK)
 		{
 			/* the exporter is gone (a worker that died): like the ivfflat twin, not this query's error -- the scan runs
 			 * on the reference's path and the index is staged again */

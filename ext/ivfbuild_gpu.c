@@ -56,9 +56,13 @@ PgvIvfflatKmeans(Relation index, VectorArray samples, VectorArray centers, const
 			   *out;
 	int			iterations;
 
+	pgv_ctx    *ctx;
+
 	(void) typeInfo;
 	if (!vector_gpu || !PgvIvfflatOpclass(index, &metric, &dtype, &ops))
 		return false;
+	if ((ctx = PgvTryGetContext()) == NULL)
+		return false;			/* no device: the reference's ElkanKmeans */
 	rowBytes = (dtype == PGV_F32 ? sizeof(float) : sizeof(uint16)) * (Size) samples->dim;
 	/* (50 samples per list: past palloc's 1 GB at 4096 lists of 1536-d rows -- the reference's own array is a
 	 * MCXT_ALLOC_HUGE allocation too, src/ivfutils.c VectorArrayInit) */
@@ -67,7 +71,7 @@ PgvIvfflatKmeans(Relation index, VectorArray samples, VectorArray centers, const
 	for (int i = 0; i < samples->length; i++)
 		memcpy(in + rowBytes * (Size) i, ((Vector *) VectorArrayGet(samples, i))->x, rowBytes);
 	/* same error texts as CheckCenters (src/ivfkmeans.c:507-533) */
-	if (pgv_kmeans(PgvGetContext(), ops, dtype, samples->dim, in, samples->length, centers->maxlen, 500, &rng,
+	if (pgv_kmeans(ctx, ops, dtype, samples->dim, in, samples->length, centers->maxlen, 500, &rng,
 				   out, NULL, &iterations) != PGV_OK)
 		elog(ERROR, "%s", pgv_last_error());
 	for (int i = 0; i < centers->maxlen; i++)
@@ -91,8 +95,8 @@ PgvIvfflatBuildBegin(IvfflatBuildState * buildstate)
 	PgvIvfBuild *gb;
 
 	buildstate->gpu = NULL;
-	if (!vector_gpu)
-		return;
+	if (!vector_gpu || PgvTryGetContext() == NULL)
+		return;					/* (no device: the reference's AddTupleToSort) */
 	gb = palloc0(sizeof(PgvIvfBuild));
 	if (!PgvIvfflatOpclass(buildstate->index, &gb->metric, &gb->dtype, &gb->ops))
 	{

@@ -325,6 +325,35 @@ PgvGetContext(void)
 }
 
 /*
+ * The same for callers that have the reference's code to go back to (every scan and build hook): no device, a device
+ * that was lost, a driver that will not initialise -- `vector.gpu = on` must not turn that into failing queries.  NULL,
+ * one WARNING per backend, and no new attempt for PGV_CTX_RETRY_MS.
+ */
+#define PGV_CTX_RETRY_MS 10000
+pgv_ctx *
+PgvTryGetContext(void)
+{
+	static TimestampTz failedAt = 0;
+	static bool warned = false;
+
+	if (backend_ctx != NULL)
+		return backend_ctx;
+	if (failedAt != 0 && !TimestampDifferenceExceeds(failedAt, GetCurrentTimestamp(), PGV_CTX_RETRY_MS))
+		return NULL;
+	if (pgv_ctx_create(vector_gpu_device, NULL, &backend_ctx) == PGV_OK)
+	{
+		failedAt = 0;
+		return backend_ctx;
+	}
+	backend_ctx = NULL;
+	failedAt = GetCurrentTimestamp();
+	if (!warned)
+		ereport(WARNING, (errmsg("pgvector GPU path unavailable (%s): using the CPU path", pgv_last_error())));
+	warned = true;
+	return NULL;
+}
+
+/*
  * Which kernel family serves this opclass, or false when none does.  The element type is identified EXACTLY:
  * vector reports IVFFLAT_MAX_DIM, halfvec twice that (src/ivfutils.c:382-404); the bit opclass reports 32 x and
  * (for hnsw) sparsevec SPARSEVEC_MAX_DIM -- their index tuples are not dense float rows and stay on the CPU path.
@@ -1180,7 +1209,11 @@ PgvIvfflatGetMirror(Relation index, uint64 wantStaged)
 	}
 	if (!m->valid)
 	{
-		if (pgv_index_import(PgvGetContext(), &handle, &m->index) != PGV_OK)
+		pgv_ctx    *ctx = PgvTryGetContext();
+
+		if (ctx == NULL)
+			return NULL;		/* no device in this backend: the reference's path (a WARNING has said so) */
+		if (pgv_index_import(ctx, &handle, &m->index) != PGV_OK)
 		{
 			/* the exporter is gone (a worker that died takes its allocations with it): not this query's error.  The
 			 * registry forgets the staging, the next request has it staged again; this scan runs on the CPU path. */

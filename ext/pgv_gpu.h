@@ -50,7 +50,8 @@ extern int	vector_gpu_device;	/* GUC vector.gpu_device */
 extern bool vector_gpu_pooled;	/* GUC vector.gpu_pooled: scans hand their query to the GPU worker's pooler */
 
 void		PgvGpuInit(void);
-pgv_ctx    *PgvGetContext(void);
+pgv_ctx    *PgvGetContext(void);	/* ERROR when there is no device (the worker's staging: caught, the index stays on the CPU path) */
+pgv_ctx    *PgvTryGetContext(void);	/* NULL + one WARNING instead: the scan and build hooks go back to the reference's code */
 
 /* FUNCTION 1 / element type of an ivfflat opclass (sql/vector.sql:406-425, :819-841); false for opclasses whose
  * index tuples are not dense float rows (bit_hamming_ops): they stay on the CPU path */

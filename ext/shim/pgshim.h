@@ -48,6 +48,7 @@ struct varlena *pg_detoast_datum(struct varlena *datum);
 
 /* utils/elog.h */
 #define LOG 15
+#define WARNING 19
 #define ERROR 21
 #define ereport(level, rest) pgshim_ereport(level, rest)
 #define errmsg(...) pgshim_errmsg(__VA_ARGS__)

@@ -1274,6 +1274,100 @@ backend_ip_opclass(void *arg)
 	return 0;
 }
 
+/* ------------------------------------------------------------------------------------------------ a backend without a device */
+/*
+ * `vector.gpu = on` in a backend that cannot have a device context (none installed, lost, the driver not initialising):
+ * every hook goes back to the reference's code -- one WARNING, no failing query, no failing CREATE INDEX --, and the
+ * pooled path still serves it (the worker owns the device; a pooled backend needs none).  Stand-in device only.
+ */
+static int
+backend_no_device(void *arg)
+{
+	Relation	index = shim_open_relation(REL_IVF);
+	Relation	hnsw = shim_open_relation(REL_HNSW);
+	uint64		got[300];
+	float		q[DIM];
+
+	(void) arg;
+	scenario = "a backend without a device";
+	cur_ops = ORA_OPS_L2;
+	setenv("MOCK_HIP_NO_DEVICE", "1", 1);
+	shim_set_guc_bool("vector.gpu", true);
+	shim_set_guc_bool("vector.gpu_pooled", false);
+	EXPECT(PgvTryGetContext() == NULL);
+	for (int i = 0; i < 5; i++)
+	{
+		Scan		s;
+		Expected	e;
+
+		make_query(q, 400 + i);
+		e = expected_batch(REL_IVF, q, PROBES);
+		scan_begin(&s, index, q, PROBES, PROBES);
+		EXPECT(pull(&s, got, 10) == 10);
+		EXPECT(s.gpu_tuples == 0 && s.cpu_tuples == 10);	/* the reference's path, not an ERROR */
+		if (check_stream(&e, got, 10, 0, "no device, own context"))
+			return 1;
+		scan_end(&s);
+		expected_free(&e);
+	}
+	/* pooled: answered by the worker's device, deeper pulls than its head fall back to the reference's code without a
+	 * tuple twice */
+	shim_set_guc_bool("vector.gpu_pooled", true);
+	{
+		double		until = shim_now() + 30.0;
+
+		while (!PgvIvfflatMirrorIsCurrent(index) && shim_now() < until)
+			usleep(20000);
+		EXPECT(PgvIvfflatMirrorIsCurrent(index));
+	}
+	for (int i = 0; i < 5; i++)
+	{
+		Scan		s;
+		Expected	e;
+		int			want = i < 3 ? 10 : 200,
+					n;
+
+		make_query(q, 410 + i);
+		e = expected_batch(REL_IVF, q, PROBES);
+		scan_begin(&s, index, q, PROBES, PROBES);
+		n = pull(&s, got, want);
+		EXPECT(n == (want < e.n ? want : e.n));
+		EXPECT(s.gpu_tuples > 0);
+		if (want > PGV_POOL_HEAD)
+			EXPECT(s.gpu_tuples == PGV_POOL_HEAD && s.cpu_tuples == n - PGV_POOL_HEAD);
+		if (check_stream(&e, got, n, 0, "no device, pooled"))
+			return 1;
+		scan_end(&s);
+		expected_free(&e);
+	}
+	/* the hnsw scan and the build hooks */
+	{
+		MemoryContext ctx = shim_query_context_begin();
+		IvfflatBuildState bs;
+		HnswBuildState hbs;
+		VectorArrayData samples,
+					centers;
+
+		EXPECT(PgvHnswBeginScan(hnsw) == NULL);
+		memset(&bs, 0, sizeof(bs));
+		bs.index = index;
+		bs.dimensions = DIM;
+		bs.lists = LISTS;
+		memset(&samples, 0, sizeof(samples));
+		memset(&centers, 0, sizeof(centers));
+		samples.dim = DIM;
+		EXPECT(!PgvIvfflatKmeans(index, &samples, &centers, IvfflatGetTypeInfo(index)));
+		PgvIvfflatBuildBegin(&bs);
+		EXPECT(bs.gpu == NULL);
+		memset(&hbs, 0, sizeof(hbs));
+		hbs.index = hnsw;
+		hbs.dimensions = DIM;
+		EXPECT(PgvHnswBuildBegin(&hbs) == NULL);
+		shim_query_context_end(ctx);
+	}
+	return 0;
+}
+
 /* ------------------------------------------------------------------------------------------------ hnsw: CREATE INDEX */
 #define REL_HNSW2 2002
 #define HB 4000					/* heap rows of the build scenario (a few of them duplicates) */
@@ -1861,6 +1955,8 @@ main(void)
 		failed |= run_phase("hnsw: CREATE INDEX through the build hooks", backend_hnsw_gpu_build, 1, NULL, 300.0);
 	if (!failed)
 		failed |= run_phase("vector_ip_ops: build + scans", backend_ip_opclass, 1, NULL, 300.0);
+	if (!failed && mock_hip_set_arena)
+		failed |= run_phase("a backend without a device", backend_no_device, 1, NULL, 120.0);
 	shim_postmaster_shutdown();
 	if (failed)
 	{

@@ -139,6 +139,10 @@ pgv_ctx_create(int device, void *stream, pgv_ctx * *out)
 {
 	(void) device;
 	(void) stream;
+	*out = NULL;
+	/* test knob: a process without a usable device (none installed, lost, driver not initialising) */
+	if (getenv("MOCK_HIP_NO_DEVICE"))
+		return fail(PGV_ERR_DEVICE, "mock: no HIP device");
 	*out = calloc(1, sizeof(pgv_ctx));
 	return PGV_OK;
 }

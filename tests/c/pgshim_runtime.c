@@ -374,7 +374,7 @@ pgshim_ereport(int level, int dummy)
 	pending_level(level);
 	if (level >= ERROR)
 		throw_error();
-	fprintf(stderr, "LOG:  %s\n", last_error);
+	fprintf(stderr, "%s:  %s\n", level == WARNING ? "WARNING" : "LOG", last_error);
 }
 
 void

@@ -48,5 +48,5 @@ def test_ext_glue_runs_on_the_stand_in_server(tmp_path, sanitize):
                   "insert / restage under an open scan", "pooled scan across a restage", "a staging of several seconds",
                   "DROP INDEX x 70", "build state for 2000-d rows", "worker killed (SIGKILL)",
                   "worker ended (SIGTERM)", "hnsw scans", "hnsw: CREATE INDEX through the build hooks",
-                  "vector_ip_ops: build + scans"):
+                  "vector_ip_ops: build + scans", "a backend without a device"):
         assert any(phase in line and ": ok" in line for line in r.stderr.splitlines()), (phase, r.stderr[-3000:])
