@@ -597,7 +597,17 @@ PgvWorkerStageEntry(PgvSharedMirror * e)
 				if (freshHnsw != NULL)
 				{
 					if (pgv_hnsw_export(freshHnsw, &handle) != PGV_OK)
-						ereport(ERROR, (errmsg("pgvector GPU path: %s", pgv_last_error())));
+					{
+						/* (as for ivfflat below: once more, on a second allocation) */
+						pgv_hnsw   *again;
+
+						elog(LOG, "pgvector GPU path: %s -- staging index %u once more", pgv_last_error(), relid);
+						again = PgvHnswStage(index, &lists, &dimensions, &ntuples);
+						pgv_hnsw_free(freshHnsw);
+						freshHnsw = again;
+						if (freshHnsw == NULL || pgv_hnsw_export(freshHnsw, &handle) != PGV_OK)
+							ereport(ERROR, (errmsg("pgvector GPU path: %s", pgv_last_error())));
+					}
 					ok = true;
 				}
 			}
@@ -606,7 +616,19 @@ PgvWorkerStageEntry(PgvSharedMirror * e)
 				IvfflatGetMetaPageInfo(index, &lists, &dimensions);
 				fresh = PgvStage(index, metric, dtype, lists, dimensions, &ntuples);
 				if (pgv_index_export(fresh, &handle) != PGV_OK)
-					ereport(ERROR, (errmsg("pgvector GPU path: %s", pgv_last_error())));
+				{
+					/* seen once in ~350 exports of small mirrors that were allocated, exported and freed in quick
+					 * succession (hipIpcGetMemHandle: invalid argument): a second allocation, made while the first is
+					 * still held, gets a handle */
+					pgv_index  *again;
+
+					elog(LOG, "pgvector GPU path: %s -- staging index %u once more", pgv_last_error(), relid);
+					again = PgvStage(index, metric, dtype, lists, dimensions, &ntuples);
+					pgv_index_free(fresh);
+					fresh = again;
+					if (pgv_index_export(fresh, &handle) != PGV_OK)
+						ereport(ERROR, (errmsg("pgvector GPU path: %s", pgv_last_error())));
+				}
 				ok = true;
 			}
 			index_close(index, AccessShareLock);

@@ -1751,6 +1751,8 @@ backend_drop_index(void *arg)
 	pgv_rel		rel;
 	double		until;
 	int			before = PgvRegistryEntries();
+	int			rounds,
+				restaged = 0;
 
 	(void) arg;
 	scenario = "dropped indexes give their mirrors and registry entries back";
@@ -1769,25 +1771,39 @@ backend_drop_index(void *arg)
 	/* more create / stage / drop rounds than the registry has entries, every index with an oid of its own (what DROP +
 	 * CREATE give): without the reclamation the 65th index, and every one after it, would never get a mirror -- and
 	 * the mirrors of the dropped ones would stay in device memory for the worker's lifetime */
-	for (int r = 0; r < 70; r++)
+	/* (on the device: fewer rounds -- what is proven there is that the mirrors' memory comes back; the registry's 64
+	 * entries are the same code on either device) */
+	rounds = mock_hip_set_arena ? 70 : 12;
+	for (int r = 0; r < rounds; r++)
 	{
 		Oid			oid = 3000 + (Oid) r;
 		Relation	index;
+		bool		current = false;
 
 		shim_create_relation(oid, &l2, rel.pages, rel.nblocks, dim);
 		index = shim_open_relation(oid);
 		EXPECT(index != NULL);
-		until = shim_now() + 30.0;
-		while (!PgvIvfflatMirrorIsCurrent(index) && shim_now() < until)
-			usleep(2000);
-		EXPECT(PgvIvfflatMirrorIsCurrent(index));
+		/* a staging that failed is asked for again by the index's next change (an insert, in real life) */
+		for (int attempt = 0; attempt < 5 && !current; attempt++)
+		{
+			if (attempt > 0)
+			{
+				restaged++;
+				PgvNoteIndexChange(index);
+			}
+			until = shim_now() + 4.0;
+			while (!(current = PgvIvfflatMirrorIsCurrent(index)) && shim_now() < until)
+				usleep(2000);
+		}
+		EXPECT(current);
 		shim_drop_relation(oid);
 	}
 	/* the worker takes invalidations in at its next turn (200 ms at most when idle) */
 	until = shim_now() + 10.0;
 	while (PgvRegistryEntries() > before && shim_now() < until)
 		usleep(5000);
-	fprintf(stderr, "   70 create / stage / drop rounds: registry entries in use %d -> %d\n", before, PgvRegistryEntries());
+	fprintf(stderr, "   %d create / stage / drop rounds (%d stagings asked for again): registry entries in use %d -> %d\n", rounds, restaged,
+			before, PgvRegistryEntries());
 	EXPECT(PgvRegistryEntries() <= before);
 	pgv_rel_free(&rel);
 	free(rows);
@@ -1879,6 +1895,9 @@ main(void)
 	void	   *arena;
 	int			failed = 0;
 
+	/* (stand-in device only: every 9th export of a worker fails like hipIpcGetMemHandle did once on the device; the
+	 * worker's second try must make that invisible to every scenario below) */
+	setenv("MOCK_HIP_EXPORT_FAIL_EVERY", "9", 1);
 	board = mmap(NULL, sizeof(Board), PROT_READ | PROT_WRITE, MAP_SHARED | MAP_ANONYMOUS, -1, 0);
 	memset((void *) board, 0, sizeof(Board));
 	shim_postmaster_init((size_t) 384 << 20, mock_hip_set_arena ? (size_t) 512 << 20 : 0);

@@ -255,6 +255,12 @@ int
 pgv_index_export(pgv_index * ix, pgv_index_handle * out)
 {
 	mock_handle h = {0x6d6f636b6978ull, (uint32_t) getpid(), ix};
+	static int	exports = 0;
+	const char *every = getenv("MOCK_HIP_EXPORT_FAIL_EVERY");
+
+	/* test knob: the export that fails once in a while on the real device (hipIpcGetMemHandle: invalid argument) */
+	if (every && atoi(every) > 0 && ++exports % atoi(every) == 0)
+		return fail(PGV_ERR_DEVICE, "mock: hipIpcGetMemHandle failed: invalid argument");
 
 	memset(out, 0, sizeof(*out));
 	memcpy(out->bytes, &h, sizeof(h));
