@@ -1051,8 +1051,28 @@ PgvMirrorReadyKind(Relation index, int kind, pgv_index_handle * handle, uint64 *
 {
 	PgvSharedMirror *e;
 	bool		ready = false;
-	TimestampTz waitUntil = TimestampTzPlusMilliseconds(GetCurrentTimestamp(), vector_gpu_stage_wait_ms);
+	TimestampTz waitUntil;
 
+	/* The usual case -- a current mirror, a living worker -- changes nothing in the registry: a SHARED lock, so that
+	 * the scans of all backends (every pooled query comes through here) do not queue up behind one another. */
+	LWLockAcquire(PgvShared->lock, LW_SHARED);
+	e = PgvFindEntryKind(RelationGetRelid(index), false, kind);
+	if (e != NULL && e->state == PGV_MIRROR_READY && e->stagedGeneration == pg_atomic_read_u64(&e->generation) &&
+		PgvDbWorkerAlive())
+	{
+		*handle = e->handle;
+		*staged = e->stagedGeneration + 1;	/* 0 = none */
+		if (lists)
+			*lists = e->lists;
+		if (ntuples)
+			*ntuples = e->ntuples;
+		ready = true;
+	}
+	LWLockRelease(PgvShared->lock);
+	if (ready)
+		return true;
+
+	waitUntil = TimestampTzPlusMilliseconds(GetCurrentTimestamp(), vector_gpu_stage_wait_ms);
 	for (;;)
 	{
 		bool		request = false;
