@@ -601,9 +601,11 @@ def roofline_record(stats, esize, dim, tname, kernel):
     stream_bytes = stats["scan_rows"] * esize * dim
     unique_bytes = stats["scan_unique_rows"] * esize * dim
     scan_s = stats["scan_ms"] / 1e3
-    gbps = stream_bytes / scan_s / 1e9 if scan_s > 0 else 0.0
+    sgbps = stream_bytes / scan_s / 1e9 if scan_s > 0 else 0.0
+    gbps = unique_bytes / scan_s / 1e9 if scan_s > 0 else 0.0   # every probed row once: the floor of any batched scan
     return {"kernel": kernel, "bound": "hbm", "achieved": gbps, "peak": HBM_PEAK_GBS, "unit": "GB/s",
             "frac": gbps / HBM_PEAK_GBS, "traffic": None,
+            "achieved_streamed": sgbps, "frac_streamed": sgbps / HBM_PEAK_GBS,
             "streamed_bytes_per_launch": stream_bytes / launches, "unique_bytes_per_launch": unique_bytes / launches,
             "passes": stream_bytes / unique_bytes if unique_bytes > 0 else None,
             "algorithmic_bytes_per_launch": algo_bytes / launches,
@@ -760,6 +762,163 @@ def timed_steps(fn, steps, warmup=2):
 
 
 # ---------------------------------------------------------------------------------------------------------------------
+# The line the driver parses.  Round 4's line had grown to ~21 KB (sweeps, backends, notes) and the driver's record of it
+# came back `parsed: null`.  What goes to fd 1 now is ONE compact object, capped at LINE_CAP bytes: the contract fields,
+# roofline, cpu_baseline, parity, one summary per other config.  Everything measured (the former line, unabridged) goes
+# to bench_detail.json beside this script (and to gpurun_out/ when that exists) -- never to stdout.
+LINE_CAP = 4096
+DETAIL_NAME = "bench_detail.json"
+
+
+def _r(x, sig=5):
+    """floats to `sig` significant digits (bytes on the line are the budget); everything else untouched"""
+    if isinstance(x, bool) or x is None:
+        return x
+    if isinstance(x, float):
+        if x != x or x in (float("inf"), float("-inf")):
+            return None
+        return float("%.*g" % (sig, x))
+    return x
+
+
+def _clean(x):
+    if isinstance(x, dict):
+        return {str(k): _clean(v) for k, v in x.items()}
+    if isinstance(x, (list, tuple)):
+        return [_clean(v) for v in x]
+    return _r(x)
+
+
+def _pick(d, keys):
+    return {k: _r(d[k]) for k in keys if isinstance(d, dict) and k in d}
+
+
+def compact_line(full):
+    """the <= LINE_CAP-byte object of the contract, cut from the full record `full` (which is left untouched)"""
+    line = _pick(full, ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better",
+                        "scaling", "vs_baseline", "dtype", "data"))
+    cfg = full.get("config", {})
+    line["config"] = _pick(cfg, ("workload", "rows", "dim", "lists", "probes", "k", "batch_per_gpu"))
+    if isinstance(line["config"].get("workload"), str):
+        line["config"]["workload"] = line["config"]["workload"][:120]
+    if full.get("n_gpus", 1) > 1:
+        line["config"]["parallelism"] = str(cfg.get("parallelism", ""))[:80]
+        mg = full.get("multi_gpu", {})
+        line["multi_gpu"] = _pick(mg, ("pgv_comm_size", "backend", "kmeans_allreduce_bytes_per_iteration", "placement",
+                                       "rows_per_rank_min", "rows_per_rank_mean", "rows_per_rank_max",
+                                       "slowest_rank_scan_ms", "measured_on"))
+    ro = full.get("roofline", {})
+    line["roofline"] = _pick(ro, ("bound", "achieved", "peak", "unit", "frac", "frac_streamed", "traffic", "avg_launch_ms",
+                                  "launches", "passes"))
+    line["roofline"]["kernel"] = str(ro.get("kernel", "")).split(" ")[0]
+    cb = full.get("cpu_baseline")
+    if isinstance(cb, dict):
+        line["cpu_baseline"] = _pick(cb, ("value", "unit", "cores", "kind", "single_thread_qps"))
+        line["cpu_baseline"]["sample"] = str(cb.get("sample", ""))[:100]
+        if isinstance(cb.get("page_image"), dict):
+            line["cpu_baseline"]["page_image_qps"] = _r(cb["page_image"].get("value"))
+    pa = full.get("parity")
+    if isinstance(pa, dict):
+        line["parity"] = {"mismatches": pa.get("mismatches"), "checked": full.get("parity_checked_queries")}
+        if "page_built_index_mismatches" in pa:
+            line["parity"]["page_built_index_mismatches"] = pa["page_built_index_mismatches"]
+    for key in ("recall_at_10", "build_secs", "kmeans_iterations", "center_rank_ms_per_step", "scan_ms_per_step"):
+        if key in full:
+            line[key] = _r(full[key])
+    oc = {}
+    for name, c in (full.get("other_configs") or {}).items():
+        if not isinstance(c, dict):
+            continue
+        o = {"qps": _r(c.get("qps")), "recall": _r(c.get("recall_at_10")),
+             "frac": _r((c.get("roofline") or {}).get("frac")),
+             "parity_mismatches": (c.get("parity") or {}).get("mismatches"),
+             "parity_checked": (c.get("parity") or {}).get("checked_queries")}
+        for extra in ("build_secs", "rows", "kmeans_secs", "kmeans_iterations", "assign_secs", "center_rank_ms"):
+            if extra in c:
+                o[extra] = _r(c[extra])
+        oc[name] = o
+    hn = full.get("hnsw")
+    if isinstance(hn, dict):
+        ef = (hn.get("ef_search") or {}).get("100") or {}
+        oc["c4_hnsw"] = {"qps": _r(ef.get("qps")), "recall": _r(ef.get("recall_at_10")), "frac": _r(ef.get("frac_of_hbm_peak")),
+                         "parity_mismatches": (hn.get("parity") or {}).get("mismatches"),
+                         "parity_checked": (hn.get("parity") or {}).get("checked_queries"),
+                         "build_secs": _r(hn.get("build_secs"))}
+    ex = (full.get("exact_scan") or {}).get("config1_10k_x_128")
+    if isinstance(ex, dict):
+        oc["c1_exact"] = {"qps": _r(ex.get("qps")), "parity_mismatches": (ex.get("parity") or {}).get("mismatches"),
+                          "parity_checked": (ex.get("parity") or {}).get("checked_queries")}
+    if oc:
+        line["other_configs"] = oc
+    bs = full.get("batch_sweep")
+    if isinstance(bs, dict):
+        line["batch_ms"] = {b: _r(v.get("ms_per_step", (v.get("latency_us_p50") or 0) / 1e3), 4)
+                            for b, v in bs.items() if isinstance(v, dict)}
+    be = full.get("concurrent_backends")
+    if isinstance(be, dict):
+        s = {}
+        for key, short in (("single_query_processes", "own_ctx_procs_qps"), ("pooled_single_query_processes", "pooled_procs_qps")):
+            rows = be.get(key)
+            if isinstance(rows, dict):
+                s[short] = {n: _r(v.get("qps"), 4) for n, v in rows.items() if isinstance(v, dict) and "qps" in v}
+        top = (be.get("pooled_single_query_processes") or {}).get("256")
+        if isinstance(top, dict):
+            s["pooled_256_p50_us"] = _r(top.get("latency_us_p50"), 4)
+        if s:
+            line["backends"] = s
+    if "build_secs_pages" in full:
+        line["build_secs_pages"] = _r(full["build_secs_pages"])
+    cbb = full.get("cpu_build_baseline")
+    if isinstance(cbb, dict):
+        line["cpu_build_secs_all_threads_extrapolated"] = _r(cbb.get("build_secs_extrapolated_all_threads"))
+    line["bench_wall_secs"] = _r(full.get("bench_wall_secs"))
+    line["detail"] = DETAIL_NAME
+    fails = full.get("failures")
+    if fails:
+        line["failures"] = [str(f)[:160] for f in fails[:6]]
+        if len(fails) > 6:
+            line["failures"].append("... %d more in %s" % (len(fails) - 6, DETAIL_NAME))
+    # the cap is a contract: shed the optional summaries, least important first, until the line fits
+    for victim in ("backends", "batch_ms", "cpu_build_secs_all_threads_extrapolated", "build_secs_pages", "other_configs",
+                   "failures"):
+        if len(json.dumps(line, default=str)) < LINE_CAP:
+            break
+        if victim == "failures" and "failures" in line:
+            line["failures"] = [str(f)[:60] for f in line["failures"][:3]]
+        else:
+            line.pop(victim, None)
+    return line
+
+
+def write_detail(full):
+    """the unabridged record, beside bench.py and (when the GPU box's scratch dir exists) under gpurun_out/"""
+    here = os.path.dirname(os.path.abspath(__file__))
+    wrote = []
+    for d in (here, os.path.join(here, "gpurun_out")):
+        if not os.path.isdir(d):
+            continue
+        try:
+            p = os.path.join(d, DETAIL_NAME)
+            with open(p + ".tmp", "w") as f:
+                json.dump(full, f, default=str, indent=1)
+            os.replace(p + ".tmp", p)
+            wrote.append(p)
+        except OSError:
+            pass
+    return wrote
+
+
+def emit_line(fd, full):
+    """detail to its file(s), the compact line to stderr for the log, and LAST (and alone) on fd 1"""
+    wrote = write_detail(full)
+    text = json.dumps(_clean(compact_line(full)), default=str, allow_nan=False)
+    assert "\n" not in text
+    log("detail record: %s" % (", ".join(wrote) or "could not be written"))
+    log("line (%d bytes): %s" % (len(text), text))
+    os.write(fd, (text + "\n").encode())
+
+
+# ---------------------------------------------------------------------------------------------------------------------
 # How the ONE JSON line is kept safe (round 3's driver run lost everything behind a section that hung):
 #   1. the parent process does only what the line cannot do without, in this order: build, recall, the timed steps,
 #      oracle parity + cpu_baseline.  From there on the line exists and is complete as far as the contract goes.
@@ -794,7 +953,7 @@ def watchdog(deadline_s):
                 snap["failures"] = list(snap["failures"]) + [
                     "watchdog: '%s' had not returned after %d s; the line ends here" % (WATCH["section"], deadline_s)]
                 snap["bench_wall_secs"] = deadline_s
-                os.write(WATCH["fd"], (json.dumps(snap, default=str) + "\n").encode())
+                emit_line(WATCH["fd"], snap)
                 break
             except Exception:  # noqa: BLE001  (the dict was being written to: try again)
                 time.sleep(0.05)
@@ -1484,17 +1643,18 @@ def main():
     unique_bytes = stats["scan_unique_rows"] * esize * dim  # rows of the lists somebody probes: one ideal pass
     scan_s = stats["scan_ms"] / 1e3
     streamed_gbps = stream_bytes / scan_s / 1e9 if scan_s > 0 else 0.0
+    unique_gbps = unique_bytes / scan_s / 1e9 if scan_s > 0 else 0.0
     avg_launch_ms = stats["scan_ms"] / launches
     roofline = {
         "kernel": ("tile_scan_kernel / scan_kernel" if args.exact_scan else "mfma_scan_kernel")
                   + " (IVFFlat list scan, GetScanItems, src/ivfscan.c:123-187)",
-        "bound": "hbm", "achieved": streamed_gbps, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-        "frac": streamed_gbps / HBM_PEAK_GBS,
+        "bound": "hbm", "achieved": unique_gbps, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+        "frac": unique_gbps / HBM_PEAK_GBS,
+        "achieved_streamed": streamed_gbps, "frac_streamed": streamed_gbps / HBM_PEAK_GBS,
         "traffic": None, "traffic_source": None,
         "streamed_bytes_per_launch": stream_bytes / launches,
         "unique_bytes_per_launch": unique_bytes / launches,
         "passes": stream_bytes / unique_bytes if unique_bytes > 0 else None,
-        "frac_unique": (unique_bytes / scan_s / 1e9) / HBM_PEAK_GBS if scan_s > 0 else 0.0,
         "algorithmic_bytes_per_launch": algo_bytes / launches,
         "algorithmic_GBps": algo_bytes / scan_s / 1e9 if scan_s > 0 else 0.0,
         "avg_launch_ms": avg_launch_ms, "launches": launches,
@@ -1503,10 +1663,11 @@ def main():
         "useful_tflops": stats["scan_pairs"] * dim * 2.0 / scan_s / 1e12 if scan_s > 0 else 0.0,
         "mfma_peak_tflops": 157.3 if tname == "f32" else 2500.0,
         "measured_stream_ceiling_GBps": 6200.0,
-        "note": "achieved/frac = row bytes actually streamed from HBM per kernel second (HIP events on the launch "
-                "stream) against the 8 TB/s peak; a row probed by several queries of a batch is streamed once per "
-                "group of <= 32 queries and scored on the matrix cores, so the per-(query,row)-pair figure of "
-                "SURVEY 8d (algorithmic_GBps) exceeds the physical rate; passes = streamed / unique rows.  "
+        "note": "achieved/frac = bytes of the rows some query of the batch probes, each counted ONCE (the floor of any "
+                "batched scan), per kernel second (HIP events on the launch stream) against the 8 TB/s peak; "
+                "achieved_streamed counts a row once per group of <= 32 queries that shares it (what the kernel "
+                "really reads; passes = streamed / unique); the per-(query,row)-pair figure of SURVEY 8d "
+                "(algorithmic_GBps) exceeds the physical rate because a row is scored for many queries on the matrix cores.  "
                 "measured_stream_ceiling_GBps: what a kernel that only stages the same 128-row tasks into LDS reaches on "
                 "this part, any access pattern (tools/stream_patterns.hip, profiles/r02b_stream_patterns.txt, DESIGN.md 4.1c)",
     }
@@ -1636,7 +1797,7 @@ def main():
     line["bench_wall_secs"] = time.perf_counter() - t_program   # everything: data, builds, sections, CPU baselines, PMC passes
     WATCH["done"] = True
     if rank == 0:
-        os.write(json_fd, (json.dumps(line, default=str) + "\n").encode())
+        emit_line(json_fd, line)
     index.close()
     if comm is not None:
         comm.close()
