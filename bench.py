@@ -686,6 +686,212 @@ def run_workload(ctx, dev, name, args, failures, steps=10, parity_queries=32):
     return out
 
 
+def run_full_config(ctx, dev, name, args, failures, steps=5, parity_queries=64, host_cap_bytes=24 << 30):
+    """BASELINE configs[2] / configs[4] at their REAL shape on one GPU (10 M rows, lists 4096, probes 64; 61 GB of rows
+    + the 61 GB heap-order copy of the build fit one 288 GB MI355X).  The rows exist only as seeded slabs of 2^17 rows
+    that are regenerated whenever a pass needs them (sampling, the build, float64 ground truth, the oracle's rows):
+      k-means  numSamples = 50 * lists = 204 800 (src/ivfbuild.c:446-455), k = 4096
+      assign   every row, as the builder takes it (AddTupleToSort, src/ivfbuild.c:161-219)
+      scan     1024-query batches, 64 probes (src/ivfscan.c:47-187)
+      recall   against exact float64 brute force over all 10 M rows
+      parity   >= 64 queries against the CPU oracle over the SAME index: the oracle ranks all 4096 centers itself and is
+               handed the rows of every list it (or the GPU) probes -- lists nobody probes are never read by either side,
+               so they stay on the device (61 GB of host copies would buy nothing); the parity queries are drawn from
+               16 mixture components to keep that union under `host_cap_bytes`."""
+    n, dim, lists, probes, tname, oname = WORKLOADS[name]
+    dtype = api.PGV_F32 if tname == "f32" else api.PGV_F16
+    tdtype = torch.float32 if tname == "f32" else torch.float16
+    ops = api.PGV_OPS_L2 if oname == "l2" else api.PGV_OPS_IP
+    metric = api.PGV_L2SQ if oname == "l2" else api.PGV_NEG_IP
+    esize = 4 if tname == "f32" else 2
+    k, batch, pool = args.k, args.batch, 3
+    components = max(lists // 4, 1)
+    seed = args.seed + 70
+    g = torch.Generator(device=dev)
+    g.manual_seed(seed)
+    means = torch.rand((components, dim), generator=g, device=dev, dtype=torch.float32)
+    nslabs = (n + SLAB - 1) // SLAB
+
+    def slab(i):
+        lo, hi = i * SLAB, min(n, (i + 1) * SLAB)
+        rows, _ = gen_mixture(n, dim, components, 0.1, seed, dev, means=means, lo=lo, hi=hi)
+        return lo, rows.to(tdtype)
+    free0, total0 = torch.cuda.mem_get_info(dev)
+    out = {"workload": "%s: IVFFlat %s_%s_ops %d x %d %s, lists=%d, probes=%d, k=%d, batch=%d, Gaussian mixture (%d "
+                       "components, sigma 0.1), ONE GPU" % (name, "vector" if tname == "f32" else "halfvec", oname, n, dim,
+                                                            tname, lists, probes, k, batch, components),
+           "rows": n, "dim": dim, "lists": lists, "probes": probes}
+    t_all = time.perf_counter()
+    # ---- sampling pass
+    ns = min(max(50 * lists, 10000), n)
+    g.manual_seed(seed + 1)
+    pick = torch.sort(torch.randperm(n, generator=g, device=dev)[:ns]).values
+    samples = torch.empty((ns, dim), device=dev, dtype=tdtype)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    bounds = torch.searchsorted(pick, torch.arange(0, nslabs + 1, device=dev) * SLAB).tolist()
+    for i in range(nslabs):
+        a, b = bounds[i], bounds[i + 1]
+        if b > a:
+            lo, rows = slab(i)
+            samples[a:b] = rows[pick[a:b] - lo]
+    if ops != api.PGV_OPS_L2:
+        s32 = samples.float()
+        samples = (s32 / s32.norm(dim=1, keepdim=True).clamp_min(1e-30)).to(tdtype).contiguous()
+    torch.cuda.synchronize()
+    out["generate_pass_secs"] = time.perf_counter() - t0
+    # ---- k-means
+    t0 = time.perf_counter()
+    centers, _, iters = api.kmeans(ctx, ops, dtype, dim, samples, lists, api.make_rng(seed=seed + 2), want_closest=False)
+    ctx.sync()
+    torch.cuda.synchronize()
+    out["kmeans_secs"], out["kmeans_iterations"], out["kmeans_samples"] = time.perf_counter() - t0, int(iters), ns
+    log("%s: k-means k=%d on %d samples: %.2f s, %d iterations" % (name, lists, ns, out["kmeans_secs"], iters))
+    del samples
+    # ---- the heap rows into the builder, assigned as they arrive
+    ctx.set_profiling(True)
+    ctx.reset_stats()
+    b = api.IvfBuilder(ctx, metric, dtype, dim, centers, expected_rows=n)
+    assign_s = 0.0
+    for i in range(nslabs):
+        _, rows = slab(i)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        b.add(rows)
+        ctx.sync()
+        assign_s += time.perf_counter() - t0
+        del rows
+    bst = ctx.stats()
+    out["assign_secs"] = assign_s
+    out["assign_tflops"] = 2.0 * n * lists * dim / assign_s / 1e12
+    out["assign_rechecked_fraction"] = bst["assign_recheck_rows"] / bst["assign_rows"] if bst["assign_rows"] else None
+    t0 = time.perf_counter()
+    index, offsets_h, lists_h = b.finish(want_lists=True)
+    ctx.sync()
+    out["layout_secs"] = time.perf_counter() - t0
+    b.close()
+    torch.cuda.empty_cache()
+    out["build_secs"] = out["kmeans_secs"] + out["assign_secs"] + out["layout_secs"]
+    sizes = np.diff(offsets_h)
+    out["list_rows"] = {"min": int(sizes.min()), "mean": float(sizes.mean()), "max": int(sizes.max())}
+    free1, _ = torch.cuda.mem_get_info(dev)
+    out["hbm_bytes_in_use_after_build"] = int(total0 - free1)
+    log("%s: assign %.2f s (%.0f TFLOP/s), layout %.2f s" % (name, assign_s, out["assign_tflops"], out["layout_secs"]))
+    # ---- queries
+    queries, _ = gen_mixture(batch * pool, dim, components, 0.1, seed + 150, dev, means=means)
+    queries = queries.to(tdtype).view(pool, batch, dim)
+    od = torch.empty((batch, k), device=dev, dtype=torch.float32)
+    os_ = torch.empty((batch, k), device=dev, dtype=torch.int64)
+    ot = torch.empty((batch, k), device=dev, dtype=torch.int64)
+
+    def step(j):
+        index.search_batch(queries[j % pool], probes, k, want_tid=True, out=(od, os_, ot))
+    for j in range(2):
+        step(j)
+    ctx.reset_stats()
+    s = timed_steps(step, steps, warmup=0)
+    stats = ctx.stats()
+    ctx.set_profiling(False)
+    out.update({"qps": batch / s, "ms_per_step": s * 1e3, "steps": steps,
+                "scan_ms_per_step": stats["scan_ms"] / steps, "center_rank_ms": stats["aux_ms"] / steps,
+                "scan_redo_queries_per_step": stats["scan_redo_queries"] / steps,
+                "roofline": roofline_record(stats, esize, dim, tname, "mfma_scan_kernel (IVFFlat list scan)")})
+    log("%s: %.0f QPS, %.2f ms/step (scan %.2f, center rank %.3f), frac %.2f" % (
+        name, out["qps"], out["ms_per_step"], out["scan_ms_per_step"], out["center_rank_ms"], out["roofline"]["frac"]))
+    # ---- parity queries: from 16 components, so that the lists they probe fit the host cap
+    rq = min(args.recall_queries, batch)
+    rqueries = queries[1][:rq].contiguous()
+    g.manual_seed(seed + 5)
+    few = means[torch.randperm(components, generator=g, device=dev)[:16]]
+    pq, _ = gen_mixture(parity_queries, dim, 16, 0.1, seed + 170, dev, means=few)
+    pq = pq.to(tdtype).contiguous()
+    gd, _, _ = index.search_batch(rqueries, probes, k, want_tid=True)
+    pd, _, pt = index.search_batch(pq, probes, k, want_tid=True)
+    ctx.sync()
+    want_lists = None
+    ora = ix_rank = None
+    if not args.no_cpu_baseline:
+        from oracle import pyoracle as po
+        ora = po.Oracle(native=True)
+        o_ops, o_dt = (po.OPS_L2 if oname == "l2" else po.OPS_IP), (po.ORA_F32 if tname == "f32" else po.ORA_F16)
+        centers_h = centers.cpu().numpy()
+        pqh = pq.cpu().numpy()
+        ix_rank = ora.index_struct(o_ops, o_dt, centers_h, np.zeros(lists + 1, np.int64), np.zeros((1, dim), centers_h.dtype))
+        probed = set()
+        for i in range(parity_queries):
+            probed.update(int(x) for x in ora.get_scan_lists(ix_rank, pqh[i], probes)[0])
+        gl = index.rank_lists(pq, probes, want_dist=False)
+        gl = gl[0] if isinstance(gl, tuple) else gl
+        probed.update(int(x) for x in np.asarray(gl.cpu() if api._is_torch(gl) else gl).ravel())
+        want_lists = np.array(sorted(probed), dtype=np.int64)
+        need = int(sizes[want_lists].sum()) * dim * esize
+        out["parity_lists_on_host"] = {"lists": len(want_lists), "bytes": need}
+        if need > host_cap_bytes:
+            failures.append("%s: the parity queries probe %d lists = %.1f GB, over the host cap" % (name, len(want_lists), need / 2**30))
+            want_lists = None
+    # ---- one more pass over the slabs: float64 ground truth for recall, and the oracle's rows
+    is_wanted = None
+    if want_lists is not None:
+        is_wanted = torch.zeros(lists, dtype=torch.bool, device=dev)
+        is_wanted[torch.from_numpy(want_lists).to(dev)] = True
+    lists_dev = torch.from_numpy(lists_h.astype(np.int64)).to(dev)
+    q64 = rqueries.double()
+    qq = (q64 * q64).sum(1)[:, None]
+    best = torch.full((rq, k), float("inf"), dtype=torch.float64, device=dev)
+    host_rows, host_ids, host_list = [], [], []
+    t0 = time.perf_counter()
+    for i in range(nslabs):
+        lo, rows = slab(i)
+        for c0 in range(0, rows.shape[0], 1 << 15):
+            v = rows[c0:c0 + (1 << 15)].double()
+            d = (qq + (v * v).sum(1)[None, :] - 2.0 * (q64 @ v.T)) if metric == api.PGV_L2SQ else -(q64 @ v.T)
+            best = torch.topk(torch.cat([best, d], dim=1), k, dim=1, largest=False).values
+        if is_wanted is not None:
+            sl = lists_dev[lo:lo + rows.shape[0]]
+            m = torch.nonzero(is_wanted[sl]).squeeze(1)
+            if m.numel():
+                host_rows.append(rows[m].cpu().numpy())
+                host_ids.append((m + lo).cpu().numpy())
+                host_list.append(sl[m].cpu().numpy())
+        del rows
+    out["ground_truth_pass_secs"] = time.perf_counter() - t0
+    out["recall_at_10"] = recall_at_k(gd, best, k)
+    out["recall_ground_truth"] = "exact float64 brute force over all %d rows, %d queries" % (n, rq)
+    log("%s: recall@10 %.4f" % (name, out["recall_at_10"]))
+    if want_lists is not None:
+        hl = np.concatenate(host_list)
+        order = np.argsort(hl, kind="stable")           # list-major, heap order inside a list: the mirror's own order
+        vec = np.concatenate(host_rows)[order]
+        ids = np.concatenate(host_ids)[order].astype(np.uint64)
+        del host_rows
+        red_off = np.zeros(lists + 1, np.int64)
+        np.cumsum(np.bincount(hl, minlength=lists), out=red_off[1:])
+        ix = ora.index_struct(o_ops, o_dt, centers_h, red_off, vec, ids)
+        threads = cpu_threads(ora)
+        t0 = time.perf_counter()
+        answers, _, _ = ora.bench_search(ix, pqh, probes, k, threads, 0.0)
+        cpu_s = time.perf_counter() - t0
+        pdh, pth = pd.cpu().numpy(), pt.cpu().numpy()
+        bad = []
+        for i in range(parity_queries):
+            wt, wd = answers[i]
+            why = topk_equiv(pth[i][:len(wt)].astype(np.uint64).tolist(), pdh[i][:len(wt)], wt.tolist(), wd)
+            if why:
+                bad.append((i, why))
+        out["parity"] = {"against": "CPU oracle over the same centers and the rows of every list either side probes "
+                                    "(%d lists, %.1f GB on the host)" % (len(want_lists), vec.nbytes / 2**30),
+                         "checked_queries": parity_queries, "mismatches": len(bad)}
+        out["cpu_qps_all_threads"] = parity_queries / cpu_s
+        out["cpu_threads"] = threads
+        if bad:
+            failures.append("%s: %d of %d queries differ from the oracle, first: %r" % (name, len(bad), parity_queries, bad[0]))
+        log("%s: parity %d mismatches of %d (oracle %.1f QPS on %d threads)" % (name, len(bad), parity_queries,
+                                                                               out["cpu_qps_all_threads"], threads))
+    out["total_secs"] = time.perf_counter() - t_all
+    index.close()
+    return out
+
+
 def bound_mode_run(ctx, step, steps, batch):
     """the same timed loop with PGV_BOUND_STATISTICAL (include/pgv_hip.h; the default is the deterministic bound): QPS and
     queries redone exactly per step"""
@@ -837,6 +1043,16 @@ def compact_line(full):
             if extra in c:
                 o[extra] = _r(c[extra])
         oc[name] = o
+    for name in ("c3", "c5"):     # configs[2] / configs[4] at their real 10 M-row shape, one GPU
+        c = full.get("full_" + name)
+        if isinstance(c, dict):
+            oc[name] = {"qps": _r(c.get("qps")), "recall": _r(c.get("recall_at_10")),
+                        "frac": _r((c.get("roofline") or {}).get("frac")),
+                        "parity_mismatches": (c.get("parity") or {}).get("mismatches"),
+                        "parity_checked": (c.get("parity") or {}).get("checked_queries"),
+                        "rows": c.get("rows"), "build_secs": _r(c.get("build_secs")), "kmeans_secs": _r(c.get("kmeans_secs")),
+                        "kmeans_iterations": c.get("kmeans_iterations"), "assign_secs": _r(c.get("assign_secs")),
+                        "center_rank_ms": _r(c.get("center_rank_ms"))}
     hn = full.get("hnsw")
     if isinstance(hn, dict):
         ef = (hn.get("ef_search") or {}).get("100") or {}
@@ -932,8 +1148,8 @@ def emit_line(fd, full):
 #      without a line).
 WATCH = {"line": None, "fd": None, "rank": 0, "section": "setup", "done": False}
 
-SECTION_BUDGET_S = {"configs": 150, "hnsw": 150, "build": 150, "sweeps": 150, "backends": 150}
-SECTION_ORDER = ("configs", "hnsw", "build", "traffic", "sweeps", "backends")
+SECTION_BUDGET_S = {"configs": 150, "hnsw": 150, "build": 150, "sweeps": 150, "backends": 150, "c3full": 240, "c5full": 240}
+SECTION_ORDER = ("configs", "hnsw", "build", "traffic", "c3full", "c5full", "sweeps", "backends")
 
 
 def watchdog(deadline_s):
@@ -1456,8 +1672,16 @@ def section_backends(args, dev, ctx, out):
     out.flush()
 
 
+def section_full(which):
+    def run(args, dev, ctx, out):
+        """BASELINE configs[2] (c3) / configs[4] (c5) at their real 10 M-row shape on this one GPU"""
+        out.at("full_configs." + which)
+        out.put("full_" + which, run_full_config(ctx, dev, which, args, out.data["failures"]))
+    return run
+
+
 SECTIONS = {"configs": section_configs, "hnsw": section_hnsw, "build": section_build, "sweeps": section_sweeps,
-            "backends": section_backends}
+            "backends": section_backends, "c3full": section_full("c3"), "c5full": section_full("c5")}
 
 
 def section_main(args):
@@ -1766,7 +1990,7 @@ def main():
             if name == "traffic":
                 if args.no_traffic:
                     continue
-            elif args.no_sweeps or (name in ("configs", "hnsw") and args.workload != "headline"):
+            elif args.no_sweeps or (name in ("configs", "hnsw", "c3full", "c5full") and args.workload != "headline"):
                 continue
             WATCH["section"] = "section " + name
             if time.perf_counter() - t_program > args.budget_secs:
