@@ -867,7 +867,7 @@ def run_full_config(ctx, dev, name, args, failures, steps=5, parity_queries=64, 
         red_off = np.zeros(lists + 1, np.int64)
         np.cumsum(np.bincount(hl, minlength=lists), out=red_off[1:])
         ix = ora.index_struct(o_ops, o_dt, centers_h, red_off, vec, ids)
-        threads = cpu_threads(ora)
+        threads = cpu_threads(ora)[0]
         t0 = time.perf_counter()
         answers, _, _ = ora.bench_search(ix, pqh, probes, k, threads, 0.0)
         cpu_s = time.perf_counter() - t0
