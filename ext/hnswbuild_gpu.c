@@ -13,11 +13,15 @@
  * into the very structures FlushPages reads: the element list (newest first, :366-374), the neighbor arrays, heap TIDs
  * of duplicates on the element that took them (:318-364), the entry point.
  *
- * Hook points (one line each; `vector.gpu = off`, parallel builds and bit / sparsevec opclasses keep the reference's
- * code):
- *   InitBuildState       src/hnswbuild.c:660-720  buildstate->gpu = PgvHnswBuildBegin(buildstate);
- *   InsertTuple          src/hnswbuild.c:575      if (buildstate->gpu) PgvHnswBuildDefer(buildstate, element); else InsertTupleInMemory(buildstate, element);
+ * Hook points (ext/pgvector-0.8.6-gpu.patch; `vector.gpu = off`, parallel builds and bit / sparsevec opclasses keep the
+ * reference's code):
+ *   InitBuildState       src/hnswbuild.c:660-742  buildstate->gpu = PgvHnswBuildBegin(buildstate);
+ *   InsertTuple          src/hnswbuild.c:575      if (!PgvHnswBuildDefer(buildstate, element)) InsertTupleInMemory(buildstate, element);
  *   FlushPages           src/hnswbuild.c:304      PgvHnswBuildLink(buildstate);   (first statement; a no-op without deferred elements)
+ * A PARALLEL build is recognised where it can be: InitBuildState runs before HnswParallelScanAndInsert sets
+ * buildstate.hnswarea (:803-805), for every participant, so Begin cannot know; Defer sees hnswarea set on the first
+ * tuple, gives the GPU state up and returns false from then on -- the participants insert under the reference's
+ * locks, nothing is deferred, and the leader's FlushPages finds nothing to link.
  * Tuples that arrive after a flush go through HnswInsertTupleOnDisk as before (they search pages, not this graph).
  *
  * Unlike the other files of ext/, this one calls ONE function that is not in include/pgv_hip.h: pgv_host_hnsw_build,
@@ -71,7 +75,7 @@ PgvHnswBuildBegin(HnswBuildState * buildstate)
 	PgvHnswBuild *gb;
 	pgv_dtype	dtype;
 
-	/* a parallel build's workers insert into shared memory under the reference's locks: theirs stays the CPU path */
+	/* (hnswarea is still NULL here even for a parallel build's participants: PgvHnswBuildDefer decides that) */
 	if (!vector_gpu || buildstate->hnswarea != NULL || !PgvHnswElementType(buildstate->index, &dtype))
 		return NULL;
 	if (PgvTryGetContext() == NULL)
@@ -85,12 +89,23 @@ PgvHnswBuildBegin(HnswBuildState * buildstate)
 }
 
 /* InsertTuple has allocated `element` (level drawn, value copied, lock initialised): remember it instead of searching
- * the graph for it now */
-void
+ * the graph for it now.  false: not deferred, the caller inserts it (InsertTupleInMemory) -- the CPU path, and every
+ * participant of a parallel build: they share one graph in hnswarea under the reference's locks */
+bool
 PgvHnswBuildDefer(HnswBuildState * buildstate, HnswElement element)
 {
 	PgvHnswBuild *gb = (PgvHnswBuild *) buildstate->gpu;
 	MemoryContext old;
+
+	if (gb == NULL)
+		return false;
+	if (buildstate->hnswarea != NULL)
+	{
+		/* set after InitBuildState by HnswParallelScanAndInsert (src/hnswbuild.c:803-805): a parallel build */
+		pfree(gb);
+		buildstate->gpu = NULL;
+		return false;
+	}
 
 	if (gb->count == gb->capacity)
 	{
@@ -102,6 +117,7 @@ PgvHnswBuildDefer(HnswBuildState * buildstate, HnswElement element)
 		MemoryContextSwitchTo(old);
 	}
 	gb->elements[gb->count++] = element;
+	return true;
 }
 
 /* the levels HnswInitElement drew, handed to pgv_host_hnsw_build as the uniform draws that give them back:

@@ -258,6 +258,12 @@ PgvHnswStage(Relation index, int *outM, int *outDimensions, int64 *outElements)
 	return h;					/* NULL for an index without elements: nothing to mirror, scans stay on the CPU path */
 }
 
+/* FUNCTION 1 of the hnsw opclasses that are not L2 (src/vector.c:637, :725; src/halfvec.c; PG_FUNCTION_INFO_V1 there) */
+extern Datum vector_negative_inner_product(PG_FUNCTION_ARGS);
+extern Datum halfvec_negative_inner_product(PG_FUNCTION_ARGS);
+extern Datum l1_distance(PG_FUNCTION_ARGS);
+extern Datum halfvec_l1_distance(PG_FUNCTION_ARGS);
+
 /* which kernel metric FUNCTION 1 of the opclass is (sql/vector.sql:427-447, :843-865) */
 pgv_metric
 PgvHnswMetricOf(Relation index)

@@ -225,6 +225,7 @@ PgvFallBackToCpu(PgvIvfScan * gs)
 	gs->cpuFallback = true;
 	gs->fromPool = false;
 	gs->so->first = true;
+	gs->so->listIndex = 0;		/* GetScanLists / GetScanItems start over (src/ivfscan.c:47-187) */
 	return -1;
 }
 

@@ -131,8 +131,8 @@ pgv_metric	PgvHnswMetricOf(Relation index);
  * (HnswBuildState / HnswElement of src/hnsw.h, which this header does not include) */
 struct HnswBuildState;
 struct HnswElementData;
-void	   *PgvHnswBuildBegin(struct HnswBuildState *buildstate);	/* NULL: vector.gpu off, a parallel build, a bit / sparsevec opclass */
-void		PgvHnswBuildDefer(struct HnswBuildState *buildstate, struct HnswElementData *element);
+void	   *PgvHnswBuildBegin(struct HnswBuildState *buildstate);	/* NULL: vector.gpu off, no device, a bit / sparsevec opclass */
+bool		PgvHnswBuildDefer(struct HnswBuildState *buildstate, struct HnswElementData *element);	/* false: the caller inserts it */
 void		PgvHnswBuildLink(struct HnswBuildState *buildstate);
 
 /* build side (ivfbuild_gpu.c) */

@@ -157,12 +157,6 @@ typedef struct HnswScanOpaqueData
 }			HnswScanOpaqueData;
 typedef HnswScanOpaqueData *HnswScanOpaque;
 
-/* FUNCTION 1 of the inner-product / cosine and L1 opclasses (src/vector.c:632-646, :728-735, src/halfvec.c) */
-Datum		vector_negative_inner_product(void *fcinfo);
-Datum		halfvec_negative_inner_product(void *fcinfo);
-Datum		l1_distance(void *fcinfo);
-Datum		halfvec_l1_distance(void *fcinfo);
-
 /* the in-memory phase of the build (src/hnsw.h:212-345): what ext/hnswbuild_gpu.c touches of it */
 typedef struct HnswGraph
 {

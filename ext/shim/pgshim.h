@@ -11,6 +11,10 @@
 #ifndef PGSHIM_H
 #define PGSHIM_H
 
+#ifndef PG_VERSION_NUM
+#define PG_VERSION_NUM 170000	/* the branches of the reference's #if ladders that are type-checked */
+#endif
+
 #include <setjmp.h>
 #include <stdbool.h>
 #include <stddef.h>
@@ -120,7 +124,8 @@ typedef Pointer Item;
 typedef struct BufferAccessStrategyData *BufferAccessStrategy;
 typedef enum
 {
-	MAIN_FORKNUM = 0
+	MAIN_FORKNUM = 0,
+	INIT_FORKNUM = 3
 }			ForkNumber;
 typedef enum
 {
@@ -164,6 +169,8 @@ struct RelationData
 {
 	Oid			rd_id;
 	TupleDesc	rd_att;
+	Oid		   *rd_indcollation;
+	struct varlena *rd_options;
 };
 #define RelationGetRelid(relation) ((relation)->rd_id)
 #define RelationGetDescr(relation) ((relation)->rd_att)
@@ -185,7 +192,10 @@ typedef struct ScanKeyData
 typedef struct IndexScanDescData
 {
 	Relation	indexRelation;
+	struct SnapshotData *xs_snapshot;
+	int			numberOfKeys;
 	int			numberOfOrderBys;
+	ScanKeyData *keyData;
 	ScanKeyData *orderByData;
 	void	   *opaque;
 	ItemPointerData xs_heaptid;
@@ -195,7 +205,9 @@ typedef struct IndexScanDescData
 typedef IndexScanDescData *IndexScanDesc;
 
 /* fmgr.h (only what the glue names) */
-typedef Datum (*PGFunction) (void *fcinfo);
+typedef struct FunctionCallInfoBaseData *FunctionCallInfo;
+#define PG_FUNCTION_ARGS FunctionCallInfo fcinfo
+typedef Datum (*PGFunction) (FunctionCallInfo fcinfo);
 typedef struct FmgrInfo
 {
 	PGFunction	fn_addr;

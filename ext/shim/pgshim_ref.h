@@ -2,7 +2,7 @@
  * pgshim_ref.h -- NOT PostgreSQL.  Declarations only (no runtime stands behind them): what the REFERENCE's own files
  * name once ext/pgvector-0.8.6-gpu.patch is applied to them, so that tests/test_ext_patch_cpu.py can compile the patched
  * src/ivfscan.c, ivfbuild.c, ivfkmeans.c, ivfinsert.c, ivfvacuum.c, hnswscan.c, hnswbuild.c, hnswinsert.c, hnswvacuum.c
- * (-fsyntax-only) together with ext/*.c where no server headers exist: the hook lines are type-checked in the code
+ * (-fsyntax-only) together with the glue of ext/ where no server headers exist: the hook lines are type-checked in the code
  * they are inserted into, against the patched ivfflat.h / hnsw.h themselves.  Spelled after the PostgreSQL 17 headers
  * named in each section, just precisely enough for that.  pgshim.h is the part that also has a runtime
  * (tests/c/pgshim_runtime.c); everything here is syntax only.
@@ -91,7 +91,8 @@ bool		VARATT_IS_SHORT(const void *p);
 #define NOTICE 18
 #define FATAL 22
 #define PANIC 23
-#define errcode(c) 0
+int			pgshim_errcode(int sqlstate);
+#define errcode(c) pgshim_errcode(c)
 #define errdetail(...) pgshim_errmsg(__VA_ARGS__)
 #define errhint(...) pgshim_errmsg(__VA_ARGS__)
 #define ERRCODE_FEATURE_NOT_SUPPORTED 1
@@ -154,8 +155,6 @@ void		DefineCustomRealVariable(const char *name, const char *short_desc, const c
 void		MarkGUCPrefixReserved(const char *className);
 
 /* fmgr.h */
-typedef struct FunctionCallInfoBaseData *FunctionCallInfo;
-#define PG_FUNCTION_ARGS FunctionCallInfo fcinfo
 #define PG_FUNCTION_INFO_V1(f) extern Datum f(PG_FUNCTION_ARGS)
 #define PG_MODULE_MAGIC extern int pgshim_module_magic_
 Datum		FunctionCall1Coll(FmgrInfo *flinfo, Oid collation, Datum arg1);
@@ -225,6 +224,7 @@ TupleTableSlot *ExecStoreVirtualTuple(TupleTableSlot *slot);
 Datum		slot_getattr(TupleTableSlot *slot, int attnum, bool *isnull);
 
 /* utils/tuplesort.h, utils/sortsupport.h */
+struct dsm_segment;
 typedef struct Tuplesortstate Tuplesortstate;
 typedef struct Sharedsort Sharedsort;
 typedef struct SortCoordinateData
@@ -543,7 +543,109 @@ float8		get_float8_nan(void);
 void		float_overflow_error(void) pg_attribute_noreturn();
 void		float_underflow_error(void) pg_attribute_noreturn();
 
+/* utils/relptr.h: a pointer relative to a shared segment's base, 0 = NULL */
+#define relptr(type) union { type *relptr_type; Size relptr_off; }
+#define relptr_declare(type, relptrtype) typedef relptr(type) relptrtype
+#define relptr_access(base, rp) ((rp).relptr_off == 0 ? (__typeof__((rp).relptr_type)) NULL : (__typeof__((rp).relptr_type)) ((base) + (rp).relptr_off - 1))
+#define relptr_is_null(rp) ((rp).relptr_off == 0)
+#define relptr_offset(rp) ((rp).relptr_off - 1)
+#define relptr_store(base, rp, val) ((rp).relptr_off = ((val) == NULL ? 0 : (Size) (((char *) (val)) - (base)) + 1))
+
+/* more of utils/rel.h, storage/bufmgr.h, access/htup_details.h, storage/bufpage.h */
+const char *RelationGetRelationName(Relation relation);
+void		LockBufferForCleanup(Buffer buffer);
+bool		ConditionalLockBufferForCleanup(Buffer buffer);
+double		table_index_build_range_scan(Relation table_rel, Relation index_rel, IndexInfo *index_info, bool allow_sync,
+										 bool anyvisible, bool progress, BlockNumber start_blockno, BlockNumber numblocks,
+										 IndexBuildCallback callback, void *callback_state, TableScanDesc scan);
+#define MaxHeapTuplesPerPage 291
+typedef uint16 LocationIndex;
+typedef struct PageHeaderData
+{
+	uint64		pd_lsn;
+	uint16		pd_checksum;
+	uint16		pd_flags;
+	LocationIndex pd_lower;
+	LocationIndex pd_upper;
+	LocationIndex pd_special;
+	uint16		pd_pagesize_version;
+	TransactionId pd_prune_xid;
+	ItemIdData	pd_linp[];
+}			PageHeaderData;
+typedef PageHeaderData *PageHeader;
+
+/* lib/stringinfo.h, libpq/pqformat.h */
+typedef struct StringInfoData
+{
+	char	   *data;
+	int			len;
+	int			maxlen;
+	int			cursor;
+}			StringInfoData;
+typedef StringInfoData *StringInfo;
+typedef struct varlena bytea;
+void		pq_begintypsend(StringInfo buf);
+bytea	   *pq_endtypsend(StringInfo buf);
+void		pq_sendint16(StringInfo buf, uint16 i);
+void		pq_sendint32(StringInfo buf, uint32 i);
+void		pq_sendint(StringInfo buf, uint32 i, int b);
+void		pq_sendfloat4(StringInfo buf, float4 f);
+void		pq_sendbytes(StringInfo buf, const void *data, int datalen);
+unsigned int pq_getmsgint(StringInfo msg, int b);
+float4		pq_getmsgfloat4(StringInfo msg);
+const char *pq_getmsgbytes(StringInfo msg, int datalen);
+#define PG_RETURN_BYTEA_P(x) PG_RETURN_POINTER(x)
+
+/* utils/array.h, utils/lsyscache.h, catalog/pg_type.h, utils/fmgrprotos.h */
+typedef struct ArrayType ArrayType;
+int			ARR_NDIM(const ArrayType *a);
+bool		ARR_HASNULL(const ArrayType *a);
+Oid			ARR_ELEMTYPE(const ArrayType *a);
+int		   *ARR_DIMS(const ArrayType *a);
+char	   *ARR_DATA_PTR(const ArrayType *a);
+#define PG_GETARG_ARRAYTYPE_P(n) ((ArrayType *) PG_DETOAST_DATUM(PG_GETARG_DATUM(n)))
+#define PG_RETURN_ARRAYTYPE_P(x) PG_RETURN_POINTER(x)
+#define DatumGetArrayTypeP(d) ((ArrayType *) PG_DETOAST_DATUM(d))
+bool		array_contains_nulls(ArrayType *array);
+void		deconstruct_array(ArrayType *array, Oid elmtype, int elmlen, bool elmbyval, char elmalign, Datum **elemsp,
+							  bool **nullsp, int *nelemsp);
+ArrayType  *construct_array(Datum *elems, int nelems, Oid elmtype, int elmlen, bool elmbyval, char elmalign);
+int32	   *ArrayGetIntegerTypmods(ArrayType *arr, int *n);
+void		get_typlenbyvalalign(Oid typid, int16 *typlen, bool *typbyval, char *typalign);
+#define TYPALIGN_INT 'i'
+#define TYPALIGN_DOUBLE 'd'
+#define FLOAT8PASSBYVAL true
+#define FLOAT4PASSBYVAL true
+#define NUMERICOID 1700
+#define INT2OID 21
+Datum		numeric_float4(PG_FUNCTION_ARGS);
+Datum		float8_numeric_unused_(PG_FUNCTION_ARGS);
+
+/* utils/varbit.h */
+typedef struct VarBit
+{
+	int32		vl_len_;
+	int32		bit_len;
+	uint8		bit_dat[];
+}			VarBit;
+#define VARBITS(v) ((v)->bit_dat)
+#define VARBITLEN(v) ((v)->bit_len)
+#define VARBITBYTES(v) (VARSIZE(v) - VARHDRSZ - sizeof(int32))
+#define VARBITTOTALLEN(bitlen) (((bitlen) + 7) / 8 + VARHDRSZ + sizeof(int32))
+#define PG_GETARG_VARBIT_P(n) ((VarBit *) PG_DETOAST_DATUM(PG_GETARG_DATUM(n)))
+#define PG_RETURN_VARBIT_P(x) PG_RETURN_POINTER(x)
+
+/* common/shortest_dec.h, parser/scansup.h, port.h */
+#define FLOAT_SHORTEST_DECIMAL_LEN 16
+int			float_to_shortest_decimal_buf(float f, char *result);
+int			float_to_shortest_decimal_bufn(float f, char *result);
+bool		scanner_isspace(char ch);
+char	   *pnstrdup(const char *in, Size len);
+#include <errno.h>
+
 /* utils/datum.h */
 Datum		datumCopy(Datum value, bool typByVal, int typLen);
+bool		datumIsEqual(Datum value1, Datum value2, bool typByVal, int typLen);
+int			RelationGetParallelWorkers(Relation relation, int defaultpw);
 
 #endif							/* PGSHIM_REF_H */

@@ -1464,12 +1464,22 @@ backend_hnsw_gpu_build(void *arg)
 	bs.gpu = PgvHnswBuildBegin(&bs);
 	EXPECT(bs.gpu != NULL);
 	{
-		/* a parallel build keeps the reference's code */
+		/* a parallel build keeps the reference's code.  The reference's order: InitBuildState (hnswarea = NULL, the
+		 * hook gives the participant a GPU state) and only THEN buildstate.hnswarea = hnswarea
+		 * (HnswParallelScanAndInsert, src/hnswbuild.c:803-805); the first InsertTuple must notice, defer nothing and
+		 * leave the element to InsertTupleInMemory, and FlushPages must find nothing to link */
 		HnswBuildState par = bs;
 		char		area[8];
+		HnswElementData dummy;
 
+		par.gpu = PgvHnswBuildBegin(&par);
+		EXPECT(par.gpu != NULL);
 		par.hnswarea = area;
-		EXPECT(PgvHnswBuildBegin(&par) == NULL);
+		memset(&dummy, 0, sizeof(dummy));
+		EXPECT(!PgvHnswBuildDefer(&par, &dummy));
+		EXPECT(par.gpu == NULL);
+		EXPECT(!PgvHnswBuildDefer(&par, &dummy));
+		PgvHnswBuildLink(&par);	/* a no-op */
 	}
 
 	/* BuildCallback + InsertTuple (src/hnswbuild.c:486-609), the hook in place of InsertTupleInMemory */
@@ -1486,7 +1496,7 @@ backend_hnsw_gpu_build(void *arg)
 		HnswPtrStore(bs.hnswarea, element->value, valuePtr);
 		levels[r] = element->level;
 		tids[r] = tid_of_row(r);
-		PgvHnswBuildDefer(&bs, element);
+		EXPECT(PgvHnswBuildDefer(&bs, element));
 		bs.graphData.indtuples++;
 		shim_context_reset(tmp);	/* the caller's copy of the value is poison from here on */
 	}

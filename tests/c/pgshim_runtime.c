@@ -1623,35 +1623,35 @@ HnswOptionalProcInfo(Relation index, uint16 procnum)
 }
 
 Datum
-vector_negative_inner_product(void *fcinfo)
+vector_negative_inner_product(PG_FUNCTION_ARGS)
 {
 	(void) fcinfo;
 	return 0;
 }
 
 Datum
-halfvec_negative_inner_product(void *fcinfo)
+halfvec_negative_inner_product(PG_FUNCTION_ARGS)
 {
 	(void) fcinfo;
 	return 0;
 }
 
 Datum
-l1_distance(void *fcinfo)
+l1_distance(PG_FUNCTION_ARGS)
 {
 	(void) fcinfo;
 	return 0;
 }
 
 Datum
-halfvec_l1_distance(void *fcinfo)
+halfvec_l1_distance(PG_FUNCTION_ARGS)
 {
 	(void) fcinfo;
 	return 0;
 }
 
 static Datum
-vector_l2_squared_distance_stub(void *fcinfo)
+vector_l2_squared_distance_stub(PG_FUNCTION_ARGS)
 {
 	(void) fcinfo;
 	return 0;
