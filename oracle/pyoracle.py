@@ -457,3 +457,48 @@ class Ref:
         a = np.ascontiguousarray(a, dtype=np.float16)
         b = np.ascontiguousarray(b, dtype=np.float16)
         return getattr(self.lib, name)(len(a), _p(a), _p(b))
+
+
+class Ref32:
+    """oracle/_ref/libpgvref32.so: the reference's src/vector.c compiled unmodified (oracle/ref_glue32.c);
+    its SQL-callable fp32 distance functions by name"""
+
+    FUNCTIONS = ("l2_distance", "vector_l2_squared_distance", "inner_product", "vector_negative_inner_product",
+                 "cosine_distance", "vector_spherical_distance", "l1_distance", "vector_norm")
+
+    def __init__(self):
+        path = os.path.join(HERE, "_ref", "libpgvref32.so")
+        if not os.path.exists(path):
+            raise FileNotFoundError(path)
+        L = self.lib = C.CDLL(path)
+        L.pgvref32_call.restype = C.c_int
+        L.pgvref32_rows.restype = C.c_int
+        L.pgvref32_l2_normalize.restype = C.c_int
+        L.pgvref32_last_error.restype = C.c_char_p
+
+    def call(self, name, a, b=None):
+        """-> (rc, float8 value); rc 1 = the reference raised ERROR, text in last_error()"""
+        a = np.ascontiguousarray(a, dtype=np.float32)
+        if b is not None:
+            b = np.ascontiguousarray(b, dtype=np.float32)
+        out = C.c_double()
+        rc = self.lib.pgvref32_call(name.encode(), len(a), _p(a), 0 if b is None else len(b), _p(b), C.byref(out))
+        return rc, out.value
+
+    def rows(self, name, query, rows):
+        query = np.ascontiguousarray(query, dtype=np.float32)
+        rows = np.ascontiguousarray(rows, dtype=np.float32)
+        out = np.empty(rows.shape[0], dtype=np.float64)
+        rc = self.lib.pgvref32_rows(name.encode(), rows.shape[1], _p(query), _p(rows), C.c_long(rows.shape[0]), _p(out))
+        if rc != 0:
+            raise RuntimeError(self.last_error())
+        return out
+
+    def l2_normalize(self, a):
+        a = np.ascontiguousarray(a, dtype=np.float32)
+        out = np.empty_like(a)
+        rc = self.lib.pgvref32_l2_normalize(len(a), _p(a), _p(out))
+        return rc, out
+
+    def last_error(self):
+        return self.lib.pgvref32_last_error().decode()

@@ -1,0 +1,36 @@
+/*
+ * ref_stubs32.c -- symbols the reference's src/vector.c references from the parts of it that oracle/ref_glue32.c never
+ * calls (text / binary I/O, casts, aggregates, _PG_init): each aborts if reached.  A file of its own so that it need
+ * not agree with the stand-in headers' prototypes.  TEST INFRASTRUCTURE ONLY.
+ */
+#include <stdio.h>
+#include <stdlib.h>
+
+#define NOT_REACHED(name) void name(void) { fprintf(stderr, "pgvref32: " #name " reached\n"); abort(); }
+NOT_REACHED(ARR_DATA_PTR)
+NOT_REACHED(ARR_DIMS)
+NOT_REACHED(ARR_ELEMTYPE)
+NOT_REACHED(ARR_HASNULL)
+NOT_REACHED(ARR_NDIM)
+NOT_REACHED(ArrayGetIntegerTypmods)
+NOT_REACHED(BitvecInit)
+NOT_REACHED(DirectFunctionCall1Coll)
+NOT_REACHED(HalfvecInit)
+NOT_REACHED(HnswInit)
+NOT_REACHED(InitBitVector)
+NOT_REACHED(IvfflatInit)
+NOT_REACHED(PgvGpuInit)
+NOT_REACHED(array_contains_nulls)
+NOT_REACHED(construct_array)
+NOT_REACHED(deconstruct_array)
+NOT_REACHED(float_to_shortest_decimal_bufn)
+NOT_REACHED(get_typlenbyvalalign)
+NOT_REACHED(numeric_float4)
+NOT_REACHED(pnstrdup)
+NOT_REACHED(pq_begintypsend)
+NOT_REACHED(pq_endtypsend)
+NOT_REACHED(pq_getmsgfloat4)
+NOT_REACHED(pq_getmsgint)
+NOT_REACHED(pq_sendfloat4)
+NOT_REACHED(pq_sendint16)
+NOT_REACHED(scanner_isspace)

@@ -396,3 +396,94 @@ def test_bench_runners_give_the_single_thread_answers(oracle):
     want, _ = oracle.assign(po.OPS_L2, po.ORA_F32, ivf.centers, data)
     assert got.tolist() == np.asarray(want).tolist() and secs > 0
     assert oracle.lib.ora_bench_cpus() >= 1
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# fp32: the reference's src/vector.c ITSELF, compiled unmodified into oracle/_ref/libpgvref32.so (oracle/Makefile,
+# oracle/ref_glue32.c over the declaration-only stand-ins of ext/shim).  Its kernels are static; they are reached the way
+# SQL reaches them, through l2_distance / vector_l2_squared_distance / inner_product / ... (src/vector.c:579-780).
+REF32 = os.path.exists(os.path.join(os.path.dirname(po.__file__), "_ref", "libpgvref32.so"))
+REF_NAME = {"l2_distance": "l2_distance", "inner_product": "inner_product",
+            "negative_inner_product": "vector_negative_inner_product", "cosine_distance": "cosine_distance",
+            "l1_distance": "l1_distance"}
+
+
+@pytest.mark.skipif(not REF32, reason="oracle/_ref/libpgvref32.so not built (reference tree absent)")
+def test_fp32_kernels_match_the_references_own_vector_c_bit_for_bit(oracle):
+    """the restated fp32 kernels and wrappers against the reference's compiled src/vector.c: every dimension 1..70
+    (all vector-loop tails), the BASELINE dimensions, the maximum 16 000, three magnitudes"""
+    ref = po.Ref32()
+    rng = np.random.default_rng(32)
+    pairs = [("ora_l2_squared_distance", "vector_l2_squared_distance"), ("ora_l2_distance", "l2_distance"),
+             ("ora_inner_product", "inner_product"), ("ora_negative_inner_product", "vector_negative_inner_product"),
+             ("ora_cosine_distance", "cosine_distance"), ("ora_spherical_distance", "vector_spherical_distance"),
+             ("ora_l1_distance", "l1_distance")]
+    checked = 0
+    for dim in list(range(1, 71)) + [100, 127, 128, 129, 255, 256, 500, 768, 1000, 1536, 2000, 3072, 4096, 16000]:
+        for scale in (1.0, 1e3, 1e-3):
+            a = (rng.standard_normal(dim) * scale).astype(np.float32)
+            b = (rng.standard_normal(dim) * scale).astype(np.float32)
+            for mine, theirs in pairs:
+                rc, x = oracle.sql(mine, a, b)
+                rc2, y = ref.call(theirs, a, b)
+                assert rc == 0 and rc2 == 0
+                assert x == y or (math.isnan(x) and math.isnan(y)), (mine, dim, scale, x, y)
+                checked += 1
+            n1 = oracle.lib.ora_vector_norm(dim, po._p(a))
+            rc2, n2 = ref.call("vector_norm", a)
+            assert rc2 == 0 and n1 == n2, (dim, scale, n1, n2)
+            out = np.zeros_like(a)
+            assert oracle.lib.ora_l2_normalize(dim, po._p(a), po._p(out)) == 0
+            rc2, out2 = ref.l2_normalize(a)
+            assert rc2 == 0
+            np.testing.assert_array_equal(out, out2)
+    assert checked > 1500
+
+
+@pytest.mark.skipif(not REF32, reason="oracle/_ref/libpgvref32.so not built (reference tree absent)")
+def test_the_references_own_vector_c_gives_the_known_answers_of_its_tests():
+    """the fixture the oracle is pinned with (test/expected/vector_type.out) holds for the compiled reference too --
+    including overflow to Infinity, NaN, the clamp of cosine_distance, and the dimension-mismatch ERROR text"""
+    ref = po.Ref32()
+    seen = 0
+    for case in CASES:
+        if case["type"] != "vector":
+            continue
+        func, args = case["func"], case["args"]
+        if func == "vector_norm":
+            rc, got = ref.call("vector_norm", args[0])
+            assert rc == 0 and _apply_wrap(got, case.get("wrap")) == pytest.approx(_expect(case["expect"]), rel=1e-6)
+        elif func == "l2_normalize":
+            rc, out = ref.l2_normalize(args[0])
+            if "error" in case:
+                assert rc == 1
+            else:
+                assert rc == 0
+                np.testing.assert_array_equal(out, np.asarray(case["expect"], dtype=np.float32))
+        elif func in REF_NAME:
+            rc, got = ref.call(REF_NAME[func], args[0], args[1])
+            if "error" in case:
+                assert rc == 1 and ref.last_error() == case["error"]
+            else:
+                want = _expect(case["expect"])
+                assert rc == 0
+                assert (math.isnan(got) and math.isnan(want)) or got == want, (case, got)
+        else:
+            continue
+        seen += 1
+    assert seen >= 30
+
+
+@pytest.mark.skipif(not REF32, reason="oracle/_ref/libpgvref32.so not built (reference tree absent)")
+def test_oracle_scan_distances_are_the_references_on_real_valued_rows(oracle):
+    """GetScanItems' per-tuple call (FUNCTION 1 of the opclass) over 2000 rows x 1536: what the oracle's list scan
+    computes equals what the reference's vector_l2_squared_distance / vector_negative_inner_product return, bitwise"""
+    ref = po.Ref32()
+    rng = np.random.default_rng(7)
+    rows = rng.standard_normal((2000, 1536)).astype(np.float32)
+    q = rng.standard_normal(1536).astype(np.float32)
+    for ops, name in ((po.OPS_L2, "vector_l2_squared_distance"), (po.OPS_IP, "vector_negative_inner_product")):
+        want = ref.rows(name, q, rows)
+        oracle.lib.ora_index_distance.restype = C.c_double
+        got = np.array([oracle.lib.ora_index_distance(ops, po.ORA_F32, 1536, po._p(rows[i]), po._p(q)) for i in range(len(rows))])
+        np.testing.assert_array_equal(got, want)
