@@ -92,6 +92,7 @@ WORKLOADS = {
     "small": (100_000, 256, 100, 10, "f32", "l2"),          # quick functional run
     "smallh": (100_000, 512, 100, 10, "f16", "ip"),
 }
+PLACEMENT = {"policy": "balanced"}   # --placement: how lists go to ranks (pgvector_amd/sharding.py plan_owners)
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy)
 RTOL = 1e-5            # north_star: float tolerance of the distances
 
@@ -199,7 +200,9 @@ def build_index(ctx, data, lists, seed, world, rank, dtype, ops, metric, comm=No
     t["assign"] = time.perf_counter() - t1
     t2 = time.perf_counter()
     row_ids = torch.arange(row_lo, row_lo + n, dtype=torch.int64, device=data.device)
-    vectors, tids, offsets = sharding.exchange_rows(data, row_ids, local_lists, lists)
+    # which rank gets which list: by rows (longest list first onto the lightest rank) unless --placement modulo
+    owners = sharding.plan_owners(sharding.global_list_sizes(local_lists, lists), world, PLACEMENT["policy"])
+    vectors, tids, offsets = sharding.exchange_rows(data, row_ids, local_lists, lists, owners)
     torch.cuda.synchronize()
     t["layout"] = time.perf_counter() - t2   # includes the all-to-all of the rows
     t["total"] = time.perf_counter() - t0
@@ -444,14 +447,14 @@ def concurrent_backends(index, device, qhost, queries, probes, k, args, dev, out
         log("  backends: %d pooled client threads" % nc)
         try:
             out["pooled_single_query"][str(nc)] = _host.run_pooled_threads(index, qh, probes, k, nc, max(40, 6000 // nc),
-                                                                           1024, 50, 2, device, row_deadline)
+                                                                           1024, 50, 3, device, row_deadline)
         except Exception as e:  # noqa: BLE001
             out["pooled_single_query"][str(nc)] = {"error": repr(e)}
             flush()
             raise
         flush()
     out["pooled_single_query"]["pool"] = ("pgv_host_pool_*: client THREADS block in pgv_host_pool_search with one query each; "
-                                          "max_batch 1024, max_wait 50 us, 2 lanes (contexts); host buffers in and out")
+                                          "max_batch 1024, max_wait 50 us, 3 lanes (contexts), one scan at a time + linger 120 us; host buffers in and out")
     # ... and with GPU-less client PROCESSES in front of two lane-server processes: the pool's slots, lane words and
     # payload ring live in a shared segment (non-private futexes, a robust process-shared mutex)
     out["pooled_single_query_processes"] = {}
@@ -459,15 +462,16 @@ def concurrent_backends(index, device, qhost, queries, probes, k, args, dev, out
         log("  backends: %d pooled client processes" % nc)
         try:
             out["pooled_single_query_processes"][str(nc)] = _host.run_backend_processes(
-                index, qh, probes, k, 1, nc, max(40, 6000 // nc), max_batch=1024, max_wait_us=50, lanes=2,
+                index, qh, probes, k, 1, nc, max(60, 12000 // nc), max_batch=1024, max_wait_us=50, lanes=3,
                 server_processes=True, deadline_s=row_deadline)
         except Exception as e:  # noqa: BLE001
             out["pooled_single_query_processes"][str(nc)] = {"error": repr(e)}
             flush()
             break
         flush()
-    out["pooled_single_query_processes"]["pool"] = ("tools/pgv_backend.c `client` x N + `serve` x 2 lanes: every client and "
-                                                    "every lane leader is a process; the leaders import the mirror")
+    out["pooled_single_query_processes"]["pool"] = ("tools/pgv_backend.c `client` x N + `serve` x 3 lanes: every client and "
+                                                    "every lane leader is a process; the leaders import the mirror; "
+                                                    "one scan at a time + linger (ivf_pool.c)")
     # (b) batches from two submitters
     log("  backends: two batch submitters")
     ctx2 = api.Context(device)
@@ -555,7 +559,7 @@ def hnsw_section(ctx, dev, args, failures, rows=1_000_000, dim=1536, m=16, efc=6
                                         built["nbr"], built["entry"])
         eh, dh = keep
         qh = q.cpu().numpy()
-        bad, checked = [], 32
+        bad, checked = [], 64
         t0 = time.perf_counter()
         for i in range(checked):
             wr, wd, _ = walk.search(qh[i], 100, k)
@@ -615,7 +619,7 @@ def roofline_record(stats, esize, dim, tname, kernel):
             "mfma_peak_tflops": 157.3 if tname == "f32" else 2500.0}
 
 
-def run_workload(ctx, dev, name, args, failures, steps=10, parity_queries=32):
+def run_workload(ctx, dev, name, args, failures, steps=10, parity_queries=64):
     """one of BASELINE's other IVFFlat configs end to end on this GPU: build, recall against float64, the timed
     batch loop with the scan kernel's roofline, parity of `parity_queries` queries with the CPU oracle"""
     n, dim, lists, probes, tname, oname = WORKLOADS[name]
@@ -1732,9 +1736,12 @@ def main():
     ap.add_argument("--recall-queries", type=int, default=256)
     ap.add_argument("--exact-scan", action="store_true", help="A/B: keep the batched L2 scan on the vector-ALU kernels "
                     "(pgv_ctx_set_exact_scan)")
+    ap.add_argument("--placement", default="balanced", choices=("balanced", "modulo"),
+                    help="N GPUs: lists to ranks by rows (LPT) or l %% N")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo for a functional "
                                                      "multi-rank run on a single GPU)")
     args = ap.parse_args()
+    PLACEMENT["policy"] = args.placement
     t_program = time.perf_counter()
     # fd 1 carries the ONE JSON line and nothing else: libraries that greet on stdout (RCCL's version banner)
     # are pointed at stderr for the rest of the run
@@ -1906,8 +1913,8 @@ def main():
                                % (args.workload, "vector" if tname == "f32" else "halfvec", oname, n, dim, tname,
                                   lists, probes, k, args.batch, components),
                    "rows": n, "dim": dim, "lists": lists, "probes": probes, "k": k,
-                   "batch_per_gpu": args.batch, "parallelism": "lists sharded l %% %d; k-means all-reduce, probe-list and top-k all-gathers inside libpgv_hip "
-                                  "(RCCL on the library's stream)" % world,
+                   "batch_per_gpu": args.batch, "parallelism": "lists sharded over %d ranks (%s by rows); k-means all-reduce, probe-list and "
+                                  "top-k all-gathers inside libpgv_hip (RCCL on the library's stream)" % (world, args.placement),
                    "local_rows": H.local_rows},
         "recall_at_10": recall, "recall_ground_truth": recall_truth,
         "build_secs": build_t["total"], "build_phases_secs": build_t, "kmeans_iterations": iters,
@@ -1928,7 +1935,20 @@ def main():
         # what the first real N-GPU run needs to be read: the communicator's size, the exchanges per step and per
         # Lloyd iteration in bytes, the build's phases (build_phases_secs: kmeans = k-means++ + Lloyd with
         # one fused all-reduce per iteration; assign; layout = the all-to-all of the rows to their lists' owners)
+        # every rank's share and its own scan time: a step ends with the slowest rank
+        mine = torch.tensor([float(H.local_rows), stats["scan_ms"] / max(args.steps, 1)], dtype=torch.float64,
+                            device=dev if args.backend == "nccl" else torch.device("cpu"))
+        every = [torch.zeros_like(mine) for _ in range(world)]
+        dist.all_gather(every, mine)
+        rows_all = [float(t[0].item()) for t in every]
+        scan_all = [float(t[1].item()) for t in every]
         line["multi_gpu"] = {
+            "placement": "%s (pgvector_amd/sharding.py plan_owners)" % args.placement,
+            "rows_per_rank_min": min(rows_all), "rows_per_rank_mean": sum(rows_all) / world, "rows_per_rank_max": max(rows_all),
+            "rows_per_rank_max_over_mean": max(rows_all) / (sum(rows_all) / world),
+            "slowest_rank_scan_ms": max(scan_all), "scan_ms_by_rank": scan_all,
+            "measured_on": "RCCL over xGMI" if args.backend == "nccl" else
+                           "UNMEASURED ON HARDWARE: %d ranks on one GPU over %s (functional run)" % (world, args.backend),
             "pgv_comm_size": comm.world, "backend": args.backend, "communicator": comm_kind,
             "kmeans_allreduce_bytes_per_iteration": int(lists * dim * 4 + lists * 4 + 8),
             "kmeans_iterations": iters,

@@ -96,7 +96,7 @@ PgvIvfflatBeginScan(Relation index, IvfflatScanOpaque so)
 	gs->so = so;
 	/* pooled scans make their device state only if they outgrow the pooler's head; the others need it now, and a
 	 * scan without a current mirror (first use, stale after inserts, unsupported opclass) runs on the CPU path */
-	if (!vector_gpu_pooled && !PgvEnsureOwnContext(gs, 0))
+	if (!vector_gpu_pooled && !PgvOwnContextsExhausted() && !PgvEnsureOwnContext(gs, 0))
 	{
 		pfree(gs);
 		return NULL;
@@ -286,7 +286,7 @@ PgvIvfflatGetTuple(IndexScanDesc scan)
 		bool		complete = false;
 
 		gs->fromPool = false;
-		if (vector_gpu_pooled &&
+		if ((vector_gpu_pooled || PgvOwnContextsExhausted()) &&
 			PgvPoolSearch(gs->index, payload, n, gs->winDist, gs->winTid, &gs->winCount, &complete, &gs->poolStaged))
 		{
 			/* GetScanLists + GetScanItems + the head of the sorted stream, answered by the worker's batch */

@@ -44,6 +44,7 @@ int			vector_gpu_device = 0;
 int			vector_gpu_stage_wait_ms = 0;
 int			vector_gpu_restage_delay_ms = 1000;
 bool		vector_gpu_pooled = false;
+int			vector_gpu_max_own_contexts = 4;	/* GUC vector.gpu_max_own_contexts */
 
 #define PGV_MAX_MIRRORS 64
 
@@ -129,6 +130,7 @@ typedef struct PgvSharedState
 	int			workerPid[PGV_MAX_MIRRORS];
 	pg_atomic_uint64 workerBeat[PGV_MAX_MIRRORS];	/* GetCurrentTimestamp() of the worker's last loop turn */
 	pg_atomic_uint64 lastSpawn;	/* when a backend last asked the postmaster for a worker (any database) */
+	pg_atomic_uint64 ownContexts;	/* backends that hold a device context of their own (PgvTryGetContext) */
 	PgvSharedMirror mirrors[PGV_MAX_MIRRORS];
 	PgvPoolSlot pool[PGV_POOL_SLOTS];
 }			PgvSharedState;
@@ -138,6 +140,8 @@ static shmem_request_hook_type prev_shmem_request_hook = NULL;
 static shmem_startup_hook_type prev_shmem_startup_hook = NULL;
 
 static pgv_ctx *backend_ctx = NULL;
+static bool backend_ctx_counted = false;	/* this backend's context is in PgvShared->ownContexts */
+static int	workerSlot = -1;	/* this process's registration when it is a GPU worker */
 static PgvIvfMirror *mirrors = NULL;	/* this backend's imported views */
 
 /* ------------------------------------------------------------------ shared memory */
@@ -268,9 +272,14 @@ PgvReleaseMyPoolSlot(int code, Datum arg)
 	(void) arg;
 	if (myPoolSlot != NULL)
 	{
-		uint32		taken = PGV_SLOT_TAKEN;
+		uint32		filled = PGV_SLOT_FILLED,
+					taken = PGV_SLOT_TAKEN;
 
-		if (!pg_atomic_compare_exchange_u32(&myPoolSlot->state, &taken, PGV_SLOT_ABANDONED))
+		/* the sequence of PgvPoolSearch's PG_CATCH: a slot the worker has not taken is free at once (FILLED -> FREE by
+		 * CAS: the worker may be taking it this instant), one it holds is left for it to free (TAKEN -> ABANDONED),
+		 * anything else (CLAIMED, DONE, UNSERVED) is this backend's alone */
+		if (!pg_atomic_compare_exchange_u32(&myPoolSlot->state, &filled, PGV_SLOT_FREE) &&
+			!pg_atomic_compare_exchange_u32(&myPoolSlot->state, &taken, PGV_SLOT_ABANDONED))
 			pg_atomic_write_u32(&myPoolSlot->state, PGV_SLOT_FREE);
 		myPoolSlot = NULL;
 	}
@@ -287,6 +296,9 @@ PgvAtExit(int code, Datum arg)
 	if (backend_ctx)
 		pgv_ctx_destroy(backend_ctx);
 	backend_ctx = NULL;
+	if (backend_ctx_counted && PgvShared != NULL)
+		pg_atomic_fetch_add_u64(&PgvShared->ownContexts, -1);
+	backend_ctx_counted = false;
 }
 
 void
@@ -302,6 +314,8 @@ PgvGpuInit(void)
 							&vector_gpu_restage_delay_ms, 1000, 0, 3600000, PGC_USERSET, 0, NULL, NULL, NULL);
 	DefineCustomBoolVariable("vector.gpu_pooled", "Index scans hand their query to the GPU worker, which batches the queries of all backends", NULL,
 							 &vector_gpu_pooled, false, PGC_USERSET, 0, NULL, NULL, NULL);
+	DefineCustomIntVariable("vector.gpu_max_own_contexts", "Backends that may scan on a device context of their own; the others go through the pooler", NULL,
+							&vector_gpu_max_own_contexts, 4, 0, 64, PGC_USERSET, 0, NULL, NULL, NULL);
 	CacheRegisterRelcacheCallback(PgvRelcacheCallback, (Datum) 0);
 	on_proc_exit(PgvAtExit, (Datum) 0);
 	before_shmem_exit(PgvReleaseMyPoolSlot, (Datum) 0);
@@ -340,17 +354,44 @@ PgvTryGetContext(void)
 		return backend_ctx;
 	if (failedAt != 0 && !TimestampDifferenceExceeds(failedAt, GetCurrentTimestamp(), PGV_CTX_RETRY_MS))
 		return NULL;
+	/*
+	 * The device runs the queues of FOUR processes side by side; from the fifth on they are time-sliced and ALL of
+	 * them slow down (MI355X, 1 M x 1536, one query at a time per process: 4 processes 52 k QPS, 5: 31 k, 8: 31 k,
+	 * 16: 27 k -- profiles/r05/own_context_process_sweep.md; threads of one process share its four queues and do not
+	 * show this).  So only vector.gpu_max_own_contexts backends hold a context of their own; the others get NULL
+	 * here, quietly, and their scans go through the GPU worker's pooler (PgvOwnContextsExhausted), which needs none.
+	 */
+	if (workerSlot < 0 && PgvShared != NULL && !backend_ctx_counted)
+	{
+		if (pg_atomic_fetch_add_u64(&PgvShared->ownContexts, 1) >= (uint64) vector_gpu_max_own_contexts)
+		{
+			pg_atomic_fetch_add_u64(&PgvShared->ownContexts, -1);
+			return NULL;
+		}
+		backend_ctx_counted = true;
+	}
 	if (pgv_ctx_create(vector_gpu_device, NULL, &backend_ctx) == PGV_OK)
 	{
 		failedAt = 0;
 		return backend_ctx;
 	}
 	backend_ctx = NULL;
+	if (backend_ctx_counted)
+		pg_atomic_fetch_add_u64(&PgvShared->ownContexts, -1);
+	backend_ctx_counted = false;
 	failedAt = GetCurrentTimestamp();
 	if (!warned)
 		ereport(WARNING, (errmsg("pgvector GPU path unavailable (%s): using the CPU path", pgv_last_error())));
 	warned = true;
 	return NULL;
+}
+
+/* this backend has no context and would not be given one: its scans take the pooled path whatever vector.gpu_pooled says */
+bool
+PgvOwnContextsExhausted(void)
+{
+	return backend_ctx == NULL && workerSlot < 0 && PgvShared != NULL &&
+		pg_atomic_read_u64(&PgvShared->ownContexts) >= (uint64) vector_gpu_max_own_contexts;
 }
 
 /*
@@ -387,7 +428,6 @@ typedef struct PgvOwned
 
 static PgvOwned owned[PGV_MAX_MIRRORS];
 
-static int	workerSlot = -1;	/* this process's registration when it is a GPU worker */
 
 /*
  * The worker's heartbeat.  Backends take a worker whose process is gone for dead at once, and one whose beat is older
@@ -845,7 +885,16 @@ PgvWorkerExit(int code, Datum arg)
 		PgvPoolSlot *slot = &PgvShared->pool[i];
 		uint32		state = pg_atomic_read_u32(&slot->state);
 
-		if (slot->dboid != dboid || (state != PGV_SLOT_FILLED && state != PGV_SLOT_TAKEN))
+		if (slot->dboid != dboid)
+			continue;
+		if (state == PGV_SLOT_ABANDONED)
+		{
+			/* its backend is gone and this worker was to free it: nobody else will (the pool must not shrink by a slot
+			 * per cancelled query over the workers' lifetimes) */
+			pg_atomic_compare_exchange_u32(&slot->state, &state, PGV_SLOT_FREE);
+			continue;
+		}
+		if (state != PGV_SLOT_FILLED && state != PGV_SLOT_TAKEN)
 			continue;
 		if (pg_atomic_compare_exchange_u32(&slot->state, &state, PGV_SLOT_UNSERVED))
 			SetLatch(slot->latch);

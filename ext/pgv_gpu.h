@@ -48,6 +48,10 @@
 extern bool vector_gpu;			/* GUC vector.gpu */
 extern int	vector_gpu_device;	/* GUC vector.gpu_device */
 extern bool vector_gpu_pooled;	/* GUC vector.gpu_pooled: scans hand their query to the GPU worker's pooler */
+extern int	vector_gpu_max_own_contexts;	/* GUC: backends with a device context of their own (default 4: the device runs
+											 * four processes' queues side by side and time-slices the rest) */
+/* no context for this backend and none to be had: its scans take the pooled path whatever vector.gpu_pooled says */
+bool		PgvOwnContextsExhausted(void);
 
 void		PgvGpuInit(void);
 pgv_ctx    *PgvGetContext(void);	/* ERROR when there is no device (the worker's staging: caught, the index stays on the CPU path) */

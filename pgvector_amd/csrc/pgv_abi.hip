@@ -2414,7 +2414,12 @@ int pgv_comm_create(pgv_ctx *ctx, int nranks, int rank, const void *unique_id, p
             pgv_comm_destroy(cm);
             return rc;
         }
-        PGV_HIP(hipSetDevice(ctx->device));
+        const hipError_t he = hipSetDevice(ctx->device);
+        if (he != hipSuccess) {  // (PGV_HIP would return past the destroy: the communicator's buffers would leak)
+            (void)hipGetLastError();
+            pgv_comm_destroy(cm);
+            PGV_FAIL(PGV_ERR_DEVICE, "pgv_comm_create: hipSetDevice(%d): %s", ctx->device, hipGetErrorString(he));
+        }
         PgvNcclId id;
         memcpy(&id, unique_id, sizeof(id));
         const int nrc = cm->rccl->CommInitRank(&cm->nccl, nranks, id, rank);

@@ -19,8 +19,18 @@
  *            view of the device mirror (pgv_index_share in the owner's process, pgv_index_import in any other),
  *            close a batch when max_batch queries are waiting or max_wait_us after its first one, run ONE
  *            pgv_search_batch over the lane's payload area (page-locked with pgv_pinned_register) and wake the
- *            batch's clients.  Several lanes take batches in turn, so the next batch collects and plans while the
+ *            batch's clients.  Several lanes take batches in turn, so the next batch collects while the
  *            previous one scans.
+ *
+ * ONE SCAN AT A TIME (round 5).  A batch of b queries streams the lists its queries probe once: its time grows far
+ * slower than b (1 M x 1536, probes 10 on MI355X: 16 queries 0.26 ms, 64: 0.71, 256: 1.10, 1024: 1.27), and two scans
+ * that run side by side only share the HBM.  So a lane does not start its scan while another lane's is in flight: it
+ * goes on collecting (everything that arrives during a scan shares the next one), and when the scan ends it lingers
+ * until the clients that scan answered have come back with their next query or linger_us have passed -- with N
+ * closed-loop clients the batches grow to N instead of settling at two groups of N / 2 scanned side by side
+ * (256 client processes, round 4: two batches of ~122 in flight together, 85-120 k QPS, p50 1.7-1.9 ms).
+ * PGV_POOL_OVERLAP=1 in the environment of the process that initialises the segment brings the old behaviour back
+ * (A/B measurements); PGV_POOL_LINGER_US overrides the 120 us.
  *
  * Answers are exactly pgv_search_batch's: the head of GetScanItems + tuplesort for each query
  * (src/ivfscan.c:123-187), heap TIDs and FUNCTION 1 distances.
@@ -48,12 +58,13 @@ extern int	pgv_host_fail(int code, const char *fmt,...);
 void		pgv_host_pool_destroy(pgv_pool * pool);
 
 #define POOL_MAGIC 0x7067765f706f6f6cull	/* "pgv_pool" */
-#define POOL_VERSION 4
+#define POOL_VERSION 5
 #define POOL_MAX_LANES 8
 #define POOL_ALIGN 4096
 #define POOL_RECLAIM_US 2000000		/* a published batch nobody finished reading: its clients are gone */
 #define POOL_READY_US 200000		/* a client between taking its slot and the end of its payload copy */
 #define POOL_LEADER_DEAD_US 3000000	/* a lane whose server has not looked for this long has lost it (it looks every 50 ms) */
+#define POOL_LINGER_US 120			/* after a scan: how long the next batch waits for that scan's clients to come back */
 
 enum
 {
@@ -73,6 +84,9 @@ typedef struct
 				done_gen;		/* last batch whose results are published (futex word) */
 	uint32_t	fill;			/* bumped when the lane's server should look again (futex word) */
 	int64_t		t_open;			/* now_us() of the batch's first query */
+	int32_t		expect;			/* collecting while a scan ran: the count at which everyone that scan answered is back
+								 * (count when it ended + its batch size); 0 = nobody is awaited (under the lock) */
+	int32_t		pad0;
 	int64_t		t_published;
 	int64_t		beat;			/* now_us() of the server's last turn of its loop: 0 = no server has led this lane yet;
 								 * stale = its server died (kill -9 runs no exit path): clients neither join nor wait */
@@ -80,7 +94,7 @@ typedef struct
 				tid_off,
 				dist_off;
 	char		errmsg[160];
-	char		pad[24];
+	char		pad[16];
 }			shm_lane;
 
 typedef struct
@@ -99,6 +113,13 @@ typedef struct
 								 * backends than cores (1024 clients: p90 latency 180 ms, measured) */
 	int32_t		collecting;		/* lane that takes arrivals, or -1 */
 	int32_t		arriving;		/* clients inside pgv_host_pool_search that have not joined a batch yet */
+	int32_t		scan_lane;		/* lane whose scan is in flight, or -1 (under the lock; only with exclusive) */
+	int32_t		exclusive;		/* one scan at a time (default); 0: lanes scan side by side (PGV_POOL_OVERLAP=1) */
+	int32_t		linger_us;
+	int32_t		pad1;
+	int64_t		t_scan_done;	/* now_us() when the last scan ended (under the lock) */
+	int32_t		last_n;			/* ... and how many queries it answered */
+	int32_t		pad2;
 	uint32_t	free_epoch;		/* bumped when a lane comes free (futex word) */
 	uint32_t	shutdown;
 	uint32_t	servers;		/* lanes with a server attached (futex word: clients of an unserved pool fail fast) */
@@ -207,6 +228,11 @@ pgv_host_pool_shm_init(void *shm, size_t bytes, pgv_dtype dtype, int dim, int pr
 	s->max_wait_us = max_wait_us;
 	s->row_bytes = (uint64_t) dim * (dtype == PGV_F32 ? 4 : 2);
 	s->collecting = -1;
+	s->scan_lane = -1;
+	s->exclusive = !(getenv("PGV_POOL_OVERLAP") && atoi(getenv("PGV_POOL_OVERLAP")) != 0);
+	s->linger_us = getenv("PGV_POOL_LINGER_US") ? atoi(getenv("PGV_POOL_LINGER_US")) : POOL_LINGER_US;
+	if (s->linger_us < 0)
+		s->linger_us = 0;
 	pthread_mutexattr_init(&ma);
 	pthread_mutexattr_setpshared(&ma, PTHREAD_PROCESS_SHARED);
 	pthread_mutexattr_setrobust(&ma, PTHREAD_MUTEX_ROBUST);
@@ -409,16 +435,33 @@ pgv_host_pool_serve(pgv_pool * pool, int lane, pgv_index * view)
 			if (l->state == LANE_COLLECTING && l->count > 0)
 			{
 				int64_t		deadline = l->t_open + s->max_wait_us;
+				int			busy = 0;
 
+				if (s->exclusive && s->scan_lane >= 0 && s->scan_lane != lane)
+				{
+					/* another lane's scan is in flight: this batch goes on collecting (its server is woken when that
+					 * scan ends) -- unless that lane's server died under its scan */
+					if (lane_is_led(&s->lanes[s->scan_lane], t))
+						busy = 1;
+					else
+						s->scan_lane = -1;
+				}
+				/* the clients of the scan that has just ended are on their way back: give them linger_us to join */
+				if (!busy && s->exclusive && l->expect > 0 && l->count < l->expect && deadline < s->t_scan_done + s->linger_us)
+					deadline = s->t_scan_done + s->linger_us;
 				/* everyone who queued while the lanes were busy joins (they are on their way: `arriving`), later
 				 * arrivals get max_wait_us */
 				/* ... but not for ever: a client that died between arriving++ and its slot leaves `arriving` above
 				 * zero for good, and a batch must not wait for it longer than a payload copy takes */
-				if (l->count >= s->max_batch || (s->arriving == 0 && t >= deadline) || t >= deadline + POOL_READY_US)
+				if (!busy &&
+					(l->count >= s->max_batch || (s->arriving == 0 && t >= deadline) || t >= deadline + POOL_READY_US))
 				{
 					if (s->collecting == lane)
 						s->collecting = -1;
 					l->state = LANE_RUNNING;
+					l->expect = 0;
+					if (s->exclusive)
+						s->scan_lane = lane;
 					n = l->count;
 					gen = l->gen;
 					s->batches++;
@@ -427,7 +470,7 @@ pgv_host_pool_serve(pgv_pool * pool, int lane, pgv_index * view)
 					break;
 				}
 				/* stragglers still on their way past the deadline: short naps, bounded by their own progress */
-				nap = t < deadline ? (long) (deadline - t) : 20;
+				nap = busy ? 2000 : (t < deadline ? (long) (deadline - t) : 20);
 			}
 			else if (l->state == LANE_PUBLISHED && t - l->t_published > POOL_RECLAIM_US)
 			{
@@ -467,6 +510,28 @@ pgv_host_pool_serve(pgv_pool * pool, int lane, pgv_index * view)
 		__atomic_store_n(&l->beat, now_us(), __ATOMIC_RELEASE);
 		rc = pgv_search_batch(view, q, n, s->probes, s->k, dist, NULL, tids);
 		__atomic_store_n(&l->beat, now_us(), __ATOMIC_RELEASE);
+		if (s->exclusive)
+		{
+			/* the device is free: the batch that collected meanwhile may go -- once this scan's clients have had
+			 * linger_us to join it */
+			int			next;
+
+			pool_lock(s);
+			if (s->scan_lane == lane)
+				s->scan_lane = -1;
+			s->t_scan_done = now_us();
+			s->last_n = n;
+			next = s->collecting;
+			if (next >= 0 && next != lane)
+				s->lanes[next].expect = s->lanes[next].count + n;
+			pool_unlock(s);
+			for (uint32_t i = 0; i < s->nlanes; i++)
+				if ((int) i != lane)
+				{
+					__atomic_add_fetch(&s->lanes[i].fill, 1, __ATOMIC_RELEASE);
+					word_wake_all(&s->lanes[i].fill);
+				}
+		}
 
 		/* publish: the clients sleep on done_gen */
 		l->rc = rc;
@@ -537,6 +602,9 @@ pgv_host_pool_search(pgv_pool * pool, const void *query, uint64_t *out_tid, floa
 				__atomic_store_n(&s->lanes[i].ready, 0, __ATOMIC_RELAXED);
 				s->lanes[i].gen++;
 				s->lanes[i].t_open = now_us();
+				/* opened by the first client back from a scan that has just ended: the others are right behind */
+				s->lanes[i].expect = (s->exclusive && s->scan_lane < 0 && s->lanes[i].t_open - s->t_scan_done < s->linger_us)
+					? s->last_n : 0;
 				break;
 			}
 		if (s->collecting >= 0)
@@ -576,7 +644,7 @@ pgv_host_pool_search(pgv_pool * pool, const void *query, uint64_t *out_tid, floa
 		s->collecting = -1;		/* closed: the next arrival opens another lane */
 	/* the first query opens the batch, a full batch or the last of those who were queueing closes it: the lane's
 	 * server should look */
-	kick = slot == 0 || l->count == s->max_batch || s->arriving == 0;
+	kick = slot == 0 || l->count == s->max_batch || s->arriving == 0 || (l->expect > 0 && l->count >= l->expect);
 	pool_unlock(s);
 
 	/* the payload goes in outside the lock; the server waits for `ready` to reach `count` */

@@ -59,13 +59,15 @@ def _worker(rank, world, port, out):
         lo, hi = sharding.row_shard(3000, rank, world)
         mine, _ = ora.assign(po.OPS_L2, po.ORA_F32, ivf.centers, data[lo:hi])
         every = sharding.gather_assignments(torch.from_numpy(mine), 3000, world)
+        # lists to ranks by rows (bench.py's default): the map comes from the all-reduced list sizes, the same on every rank
+        owners = sharding.plan_owners(sharding.global_list_sizes(torch.from_numpy(mine), 12), world, "balanced")
         v, t, off = sharding.exchange_rows(torch.from_numpy(data[lo:hi]), torch.arange(lo, hi, dtype=torch.int64),
-                                           torch.from_numpy(mine), 12)
+                                           torch.from_numpy(mine), 12, owners)
         assert int(off[-1]) == v.shape[0]
         # --- scan of the local image + the exact ground truth merged across the ranks
         ld, lt = _local_search(ora, po, ivf.centers, off.numpy(), v.numpy(), t.numpy().astype(np.uint64), queries, 12, 7)
         md = sharding.merge_exact_topk(ld, 7)
-        torch.save({"v": v, "t": t, "off": off, "md": md, "lists": every}, out + ".%d" % rank)
+        torch.save({"v": v, "t": t, "off": off, "md": md, "lists": every, "owners": owners}, out + ".%d" % rank)
     finally:
         dist.destroy_process_group()
 
@@ -82,14 +84,19 @@ def test_world2_matches_single_process(tmp_path):
     goff = torch.zeros(13, dtype=torch.int64)
     goff[1:] = torch.cumsum(torch.from_numpy(np.bincount(want_lists, minlength=12)), 0)
     sd, _ = _local_search(ora, po, ivf.centers, goff.numpy(), gvec.numpy(), gtid.numpy().astype(np.uint64), queries, 12, 7)
+    owners = sharding.plan_owners(torch.from_numpy(np.bincount(want_lists, minlength=12)), 2, "balanced")
+    rows = []
     for r in range(2):
         got = torch.load(out + ".%d" % r)
         np.testing.assert_array_equal(got["lists"].numpy(), want_lists)
-        v, t, off = sharding.local_index_arrays(gvec, gtid, goff, r, 2)
+        np.testing.assert_array_equal(got["owners"].numpy(), owners.numpy())     # every rank derived the same map
+        v, t, off = sharding.local_index_arrays(gvec, gtid, goff, r, 2, owners)
+        rows.append(int(off[-1]))
         np.testing.assert_array_equal(got["off"].numpy(), off.numpy())
         np.testing.assert_array_equal(got["t"].numpy(), t.numpy())
         np.testing.assert_array_equal(got["v"].numpy(), v.numpy())
         np.testing.assert_array_equal(got["md"].numpy(), sd.numpy())  # every list probed: the exact top-k
+    assert sum(rows) == 3000 and max(rows) <= 1.05 * 1500
 
 
 def test_local_index_arrays_partition():
@@ -106,3 +113,25 @@ def test_local_index_arrays_partition():
             assert n == (int(off[l + 1] - off[l]) if l % 3 == r else 0)
         seen += t.tolist()
     assert sorted(seen) == list(range(12))
+
+
+def test_plan_owners_balances_rows_and_keeps_modulo_selectable():
+    """lists longest first onto the lightest rank: k-means list sizes are skewed (round 4's 8-rank record: l % 8 left one
+    rank with 61 % of the mean); the balanced map keeps the heaviest rank within 5 % of the mean, is a pure function of
+    the sizes, and `modulo` is still l % world"""
+    from pgvector_amd import sharding
+    rng = np.random.default_rng(8)
+    for nlists, world in ((256, 8), (4096, 8), (1000, 4), (512, 2), (13, 3)):
+        sizes = torch.from_numpy((rng.lognormal(0.0, 1.0, nlists) * 1000).astype(np.int64) + 1)
+        own = sharding.plan_owners(sizes, world, "balanced")
+        assert own.shape == (nlists,) and int(own.min()) >= 0 and int(own.max()) < world
+        load = torch.bincount(own, weights=sizes.double(), minlength=world)
+        mod = torch.bincount(torch.arange(nlists) % world, weights=sizes.double(), minlength=world)
+        if nlists >= 256:
+            assert float(load.max() / load.mean()) <= 1.05, (nlists, world, load)
+        assert float(load.max()) <= float(mod.max()) + 1e-9
+        assert torch.equal(own, sharding.plan_owners(sizes.clone(), world, "balanced"))
+        assert torch.equal(sharding.plan_owners(sizes, world, "modulo"), torch.arange(nlists) % world)
+    assert torch.equal(sharding.plan_owners(torch.tensor([5, 1, 1]), 1, "balanced"), torch.zeros(3, dtype=torch.int64))
+    with pytest.raises(ValueError):
+        sharding.plan_owners(torch.tensor([1, 2]), 2, "random")
