@@ -55,6 +55,8 @@ typedef struct pgv_hnsw_built
 extern int	pgv_host_hnsw_build(pgv_hnsw * mirror, pgv_dtype dtype, int dim, const void *rows, int64_t n, int m,
 								int ef_construction, const pgv_rng * rng, int max_batch, pgv_hnsw_built * out);
 extern void pgv_host_hnsw_built_free(pgv_hnsw_built * built);
+typedef int (*pgv_host_cancel_check) (void *arg);
+extern void pgv_host_hnsw_set_cancel_check(pgv_host_cancel_check check, void *arg);
 extern const char *pgv_host_last_error(void);
 
 #define PGV_HNSW_BUILD_BATCH 1024	/* elements inserted "at once" (the graph must hold 16 x as many: hnsw_build.c) */
@@ -129,6 +131,15 @@ typedef struct PgvLevelReplay
 	double		ml;
 }			PgvLevelReplay;
 
+/* polled by pgv_host_hnsw_build between batches, on this thread: a pending cancel / terminate ends the link phase
+ * cleanly (helpers joined, memory freed); the ERROR itself is raised here afterwards, by CHECK_FOR_INTERRUPTS() */
+static int
+PgvBuildCancelPending(void *arg)
+{
+	(void) arg;
+	return InterruptPending != 0;
+}
+
 static double
 PgvReplayLevel(void *state)
 {
@@ -176,10 +187,13 @@ PgvHnswBuildLink(HnswBuildState * buildstate)
 	memset(&rng, 0, sizeof(rng));
 	rng.next_double = PgvReplayLevel;
 	rng.state = &replay;
+	pgv_host_hnsw_set_cancel_check(PgvBuildCancelPending, NULL);
 	rc = pgv_host_hnsw_build(mirror, gb->dtype, buildstate->dimensions, rows, n, buildstate->m, buildstate->efConstruction,
 							 &rng, PGV_HNSW_BUILD_BATCH, &built);
+	pgv_host_hnsw_set_cancel_check(NULL, NULL);
 	pgv_hnsw_free(mirror);
 	pfree(rows);
+	CHECK_FOR_INTERRUPTS();		/* a cancelled build: the interrupt's own ERROR, not ours */
 	if (rc != PGV_OK)
 		ereport(ERROR, (errmsg("pgvector GPU path: %s", pgv_host_last_error())));
 

@@ -84,6 +84,8 @@ void		MemoryContextRegisterResetCallback(MemoryContext ctx, MemoryContextCallbac
 /* miscadmin.h, storage/ipc.h, utils/guc.h */
 #define CHECK_FOR_INTERRUPTS() pgshim_check_interrupts()
 void		pgshim_check_interrupts(void);
+#include <signal.h>
+extern volatile sig_atomic_t InterruptPending;	/* set by the signal handlers: something for CHECK_FOR_INTERRUPTS to do */
 typedef void (*pg_on_exit_callback) (int code, Datum arg);
 void		on_proc_exit(pg_on_exit_callback function, Datum arg);
 void		before_shmem_exit(pg_on_exit_callback function, Datum arg);

@@ -33,6 +33,7 @@
 #include <math.h>
 #include <omp.h>
 #include <pthread.h>
+#include <signal.h>
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
@@ -884,6 +885,34 @@ worker_main(void *arg)
 	return NULL;
 }
 
+/*
+ * Inside a PostgreSQL backend (ext/hnswbuild_gpu.c calls this file from FlushPages) two things are not this code's to
+ * decide: which thread runs the backend's signal handlers, and whether the statement may be cancelled.
+ *   - every thread made here (the two helpers, the OpenMP team) starts with ALL signals blocked: SIGINT / SIGTERM /
+ *     SIGUSR1 stay with the backend's main thread, where its handlers expect to run;
+ *   - pgv_host_hnsw_set_cancel_check installs a callback the build polls between batches (on the calling thread, never
+ *     from a helper): nonzero ends the build cleanly with PGV_ERR_STATE "cancelled" -- helpers joined, memory freed --
+ *     and the caller raises its own error (the glue: CHECK_FOR_INTERRUPTS()).  The callback must not longjmp.
+ */
+static __thread pgv_host_cancel_check cancel_check = NULL;
+static __thread void *cancel_arg = NULL;
+
+void
+pgv_host_hnsw_set_cancel_check(pgv_host_cancel_check check, void *arg)
+{
+	cancel_check = check;
+	cancel_arg = arg;
+}
+
+static void
+block_signals(sigset_t *old)
+{
+	sigset_t	all;
+
+	sigfillset(&all);
+	pthread_sigmask(SIG_BLOCK, &all, old);
+}
+
 /* a context, a stream and a view of the mirror for a helper; 0 when it could not be had (the build goes on without) */
 static int
 worker_start(worker * w, pgv_hnsw * mirror, const elem * el, int m, int ef_construction)
@@ -897,8 +926,16 @@ worker_start(worker * w, pgv_hnsw * mirror, const elem * el, int m, int ef_const
 		w->ef_construction = ef_construction;
 		pthread_mutex_init(&w->lock, NULL);
 		pthread_cond_init(&w->wake, NULL);
-		if (pthread_create(&w->thread, NULL, worker_main, w) == 0)
-			return w->started = 1;
+		{
+			sigset_t	old;
+			int			err;
+
+			block_signals(&old);	/* the helper inherits the mask: no handler of the backend's ever runs there */
+			err = pthread_create(&w->thread, NULL, worker_main, w);
+			pthread_sigmask(SIG_SETMASK, &old, NULL);
+			if (err == 0)
+				return w->started = 1;
+		}
 		pthread_mutex_destroy(&w->lock);
 		pthread_cond_destroy(&w->wake);
 	}
@@ -1077,6 +1114,18 @@ pgv_host_hnsw_build(pgv_hnsw * mirror, pgv_dtype dtype, int dim, const void *row
 	is_dirty = calloc((size_t) n, 1);
 	parts = calloc((size_t) nthreads, sizeof(recpart));
 	arenas = calloc((size_t) nthreads, sizeof(arena));
+	{
+		/* the OpenMP team is created by the first parallel region and keeps the mask of the thread that opened it:
+		 * open one now, with every signal blocked, so that the pool's threads never take the backend's signals */
+		sigset_t	old;
+		int			team = 0;
+
+		block_signals(&old);
+#pragma omp parallel num_threads(nthreads) reduction(+:team)
+		team += 1;
+		pthread_sigmask(SIG_SETMASK, &old, NULL);
+		(void) team;
+	}
 
 	for (int64_t i0 = 0; i0 < n;)
 	{
@@ -1086,6 +1135,12 @@ pgv_host_hnsw_build(pgv_hnsw * mirror, pgv_dtype dtype, int dim, const void *row
 		int			ndirty = 0;
 		int64_t		ntuple = 0;
 
+		/* CREATE INDEX can be cancelled between batches (a batch is milliseconds) */
+		if (cancel_check != NULL && cancel_check(cancel_arg))
+		{
+			rc = pgv_host_fail(PGV_ERR_STATE, "pgv_host_hnsw_build: cancelled after %lld of %lld rows", (long long) i0, (long long) n);
+			goto done;
+		}
 		if (entry < 0)
 		{
 			/* the first element has nothing to search: it becomes the entry point */

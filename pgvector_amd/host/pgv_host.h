@@ -102,6 +102,13 @@ typedef struct pgv_hnsw_built
 int			pgv_host_hnsw_build(pgv_hnsw * mirror, pgv_dtype dtype, int dim, const void *rows, int64_t n, int m,
 								int ef_construction, const pgv_rng * rng, int max_batch, pgv_hnsw_built * out);
 void		pgv_host_hnsw_built_free(pgv_hnsw_built * built);
+/*
+ * Inside a server: a callback pgv_host_hnsw_build polls between batches, on the calling thread (per thread; NULL
+ * removes it).  Nonzero ends the build with PGV_ERR_STATE ("cancelled ..."), everything joined and freed; the callback
+ * must not longjmp.  The build's helper threads and OpenMP team run with all signals blocked.
+ */
+typedef int (*pgv_host_cancel_check) (void *arg);
+void		pgv_host_hnsw_set_cancel_check(pgv_host_cancel_check check, void *arg);
 
 /*
  * The HNSW index in its on-disk form (src/hnsw.h:40-47, 334-392), either side of the device path.

@@ -22,6 +22,50 @@
 	return 1; } } while (0)
 #define EXPECT(cond) do { if (!(cond)) { fprintf(stderr, "%s:%d: EXPECT(%s) failed\n", __FILE__, __LINE__, #cond); return 1; } } while (0)
 
+/* ---- signals during pgv_host_hnsw_build: where do the handlers run? */
+#include <pthread.h>
+#include <signal.h>
+#include <unistd.h>
+static pthread_t main_thread;
+static volatile int signals_seen,
+			signals_off_main,
+			storm_on,
+			cancel_after,
+			cancel_polls;
+
+static void
+on_sigusr1(int sig)
+{
+	(void) sig;
+	signals_seen++;
+	if (!pthread_equal(pthread_self(), main_thread))
+		signals_off_main++;
+}
+
+/* process-directed signals: the kernel delivers each to ANY thread that has it unblocked */
+static void *
+storm_main(void *arg)
+{
+	sigset_t	all;
+
+	(void) arg;
+	sigfillset(&all);
+	pthread_sigmask(SIG_BLOCK, &all, NULL);	/* (not to this thread) */
+	while (storm_on)
+	{
+		kill(getpid(), SIGUSR1);
+		usleep(200);
+	}
+	return NULL;
+}
+
+static int
+cancel_cb(void *arg)
+{
+	(void) arg;
+	return cancel_polls++ >= cancel_after;
+}
+
 static uint64_t lcg = 12345;
 static uint32_t
 urand(void)
@@ -123,6 +167,41 @@ test_hnsw_build(void)
 		EXPECT(found >= 15);
 	}
 	pgv_host_hnsw_built_free(&built);
+
+	/* inside a server: the helpers and the OpenMP team take no signals (a handler that ran anywhere but on the calling
+	 * thread is counted), and a cancel check that fires ends the build cleanly with PGV_ERR_STATE */
+	{
+		struct sigaction sa,
+					old;
+		int			rc;
+
+		memset(&sa, 0, sizeof(sa));
+		sa.sa_handler = on_sigusr1;
+		sigaction(SIGUSR1, &sa, &old);
+		main_thread = pthread_self();
+		cancel_after = 1 << 30;
+		storm_on = 1;
+		{
+			pthread_t	stormer;
+
+			pthread_create(&stormer, NULL, storm_main, NULL);
+			pgv_host_hnsw_set_cancel_check(cancel_cb, NULL);
+			CHECK(pgv_host_hnsw_build(mirror, PGV_F32, DIM, data, N, M, EFC, NULL, 32, &built));
+			EXPECT(built.nelements == N);
+			pgv_host_hnsw_built_free(&built);
+			cancel_after = 5;		/* the sixth poll says "cancel" */
+			cancel_polls = 0;
+			rc = pgv_host_hnsw_build(mirror, PGV_F32, DIM, data, N, M, EFC, NULL, 32, &built);
+			EXPECT(rc == PGV_ERR_STATE && strstr(pgv_host_last_error(), "cancelled") != NULL);
+			EXPECT(built.levels == NULL && built.nbr == NULL);	/* freed on the way out */
+			pgv_host_hnsw_set_cancel_check(NULL, NULL);
+			storm_on = 0;
+			pthread_join(stormer, NULL);
+		}
+		EXPECT(signals_seen > 0);
+		EXPECT(signals_off_main == 0);
+		sigaction(SIGUSR1, &old, NULL);
+	}
 
 	/* the on-disk form and back: same graph under the slot renumbering */
 	{

@@ -470,6 +470,8 @@ shim_cancel_after(int after_checks)
 	cancel_countdown = after_checks;
 }
 
+volatile sig_atomic_t InterruptPending = 0;
+
 void
 pgshim_check_interrupts(void)
 {
@@ -488,6 +490,7 @@ handle_sigterm(int sig)
 {
 	(void) sig;
 	proc_die_pending = 1;
+	InterruptPending = 1;
 	if (MyLatch)
 	{
 		__atomic_store_n(&MyLatch->is_set, 1, __ATOMIC_RELEASE);

@@ -21,7 +21,7 @@ def test_ext_glue_type_checks_against_the_abi():
 
 # the one piece of host C the glue calls besides the ABI: the body of BuildGraph's insertion loop,
 # which a maintainer adds to OBJS with ext/hnswbuild_gpu.c
-HOST_BODY = {"pgv_host_hnsw_build", "pgv_host_hnsw_built_free", "pgv_host_last_error"}
+HOST_BODY = {"pgv_host_hnsw_build", "pgv_host_hnsw_built_free", "pgv_host_last_error", "pgv_host_hnsw_set_cancel_check"}
 
 
 def test_ext_glue_uses_only_the_public_abi():
