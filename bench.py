@@ -1032,7 +1032,7 @@ def compact_line(full):
         line["parity"] = {"mismatches": pa.get("mismatches"), "checked": full.get("parity_checked_queries")}
         if "page_built_index_mismatches" in pa:
             line["parity"]["page_built_index_mismatches"] = pa["page_built_index_mismatches"]
-    for key in ("recall_at_10", "build_secs", "kmeans_iterations", "center_rank_ms_per_step", "scan_ms_per_step"):
+    for key in ("recall_at_10", "build_secs", "kmeans_iterations", "center_rank_ms_per_step", "scan_ms_per_step", "overlap_lanes"):
         if key in full:
             line[key] = _r(full[key])
     oc = {}
@@ -1152,7 +1152,7 @@ def emit_line(fd, full):
 #      without a line).
 WATCH = {"line": None, "fd": None, "rank": 0, "section": "setup", "done": False}
 
-SECTION_BUDGET_S = {"configs": 150, "hnsw": 150, "build": 150, "sweeps": 150, "backends": 150, "c3full": 240, "c5full": 240}
+SECTION_BUDGET_S = {"configs": 120, "hnsw": 120, "build": 120, "sweeps": 120, "backends": 120, "c3full": 90, "c5full": 90}
 SECTION_ORDER = ("configs", "hnsw", "build", "traffic", "c3full", "c5full", "sweeps", "backends")
 
 
@@ -1287,7 +1287,8 @@ def live_traffic(args, scan_ms, budget_s=110):
         return None, "rocprofv3 not on PATH"
     out = {}
     base = [sys.executable, os.path.abspath(__file__), "--workload", args.workload, "--batch", str(args.batch),
-            "--steps", "4", "--warmup", "1", "--seed", str(args.seed), "--child", "--watchdog-secs", "0"]
+            "--steps", "4", "--warmup", "1", "--seed", str(args.seed), "--child", "--watchdog-secs", "0",
+            "--overlap", str(args.overlap)]
     if args.probes:
         base += ["--probes", str(args.probes)]
     env = dict(os.environ, TMPDIR="/tmp")
@@ -1736,6 +1737,8 @@ def main():
     ap.add_argument("--recall-queries", type=int, default=256)
     ap.add_argument("--exact-scan", action="store_true", help="A/B: keep the batched L2 scan on the vector-ALU kernels "
                     "(pgv_ctx_set_exact_scan)")
+    ap.add_argument("--overlap", type=int, default=3, help="streams consecutive batches of the timed loop alternate on "
+                    "(pgv_index_set_overlap; 1: one stream, stream-ordered)")
     ap.add_argument("--placement", default="balanced", choices=("balanced", "modulo"),
                     help="N GPUs: lists to ranks by rows (LPT) or l %% N")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo for a functional "
@@ -1845,6 +1848,11 @@ def main():
 
     # ----------------------------------------------------------------- timed
     WATCH["section"] = "timed steps"
+    if world == 1 and args.overlap > 1:
+        # consecutive batches on `overlap` internal streams of the library (pgv_index_set_overlap): one batch's center
+        # ranking / planning / top-k / recheck run under the other's list scan; every batch is complete inside the timed
+        # region (the synchronize below waits for all streams)
+        index.set_overlap(args.overlap)
     for i in range(args.warmup):
         step(i)
     ctx.set_profiling(True)
@@ -1862,6 +1870,8 @@ def main():
     elapsed = time.perf_counter() - t0
     stats = ctx.stats()
     ctx.set_profiling(False)
+    if world == 1 and args.overlap > 1:
+        index.set_overlap(1)     # everything below reads its answers in stream order again
     if world > 1:
         el = torch.tensor([elapsed], dtype=torch.float64, device=dev if args.backend == "nccl" else "cpu")
         dist.all_reduce(el, op=dist.ReduceOp.MAX)
@@ -1930,6 +1940,7 @@ def main():
         "scan_redo_queries_per_step": stats["scan_redo_queries"] / args.steps,
         "scan_widened_queries_per_step": stats["scan_widened_queries"] / args.steps,
         "scan_path": "exact vector-ALU kernels (--exact-scan)" if args.exact_scan else "auto",
+        "overlap_lanes": args.overlap if world == 1 else 1,
     }
     if world > 1:
         # what the first real N-GPU run needs to be read: the communicator's size, the exchanges per step and per

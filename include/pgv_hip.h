@@ -242,6 +242,21 @@ void		pgv_index_free(pgv_index * index);
  */
 int			pgv_index_share(pgv_index * index, pgv_ctx * ctx, pgv_index * *out);
 /*
+ * Overlapping batches.  A batch of pgv_search_batch is ~25 dependent launches on one stream: center ranking, planning,
+ * the list scan (which streams the probed lists once and is HBM-bound), top-k, exact recheck.  Two submitters on two
+ * contexts already overlap one batch's ranking / planning / top-k with the other's scan (the scans themselves cannot
+ * overlap: both want the whole HBM); lanes > 1 gives ONE caller the same: consecutive pgv_search_batch calls on this
+ * handle run on `lanes` internal streams in turn (each with scratch of its own; the index stays one).  With lanes > 1
+ *   - a call returns when its work is enqueued; device-side outputs are complete after pgv_ctx_sync(the index's
+ *     context) (which waits for the lanes too), NOT merely in the order of that context's stream;
+ *   - device-side queries are read no earlier than what the context's stream held at the call (an event orders it);
+ *   - host-side outputs make the call synchronous, as always (nothing overlaps then);
+ *   - statistics, profiling and the bound / exact-scan settings of the context include the lanes.
+ * lanes = 1 (the default) restores the stream-ordered behaviour.  Views (pgv_index_share / _import) have lanes of their
+ * own or none.  1 <= lanes <= 4.
+ */
+int			pgv_index_set_overlap(pgv_index * index, int lanes);
+/*
  * The same across PROCESSES -- a Postgres backend is a process (src/ivfscan.c:252-296 runs in each), and its parallel
  * build shares state through a DSM segment (src/ivfbuild.c:830-966).  The whole mirror (centers, vectors, offsets,
  * TIDs, norms) is one device allocation; pgv_index_export wraps its hipIpcMemHandle and the mirror's shape into a

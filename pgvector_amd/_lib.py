@@ -45,6 +45,7 @@ SYMBOLS = [
     "pgv_device_memory", "pgv_pinned_register", "pgv_pinned_unregister", "pgv_index_export", "pgv_index_import",
     "pgv_index_tids", "pgv_hnsw_export", "pgv_hnsw_import", "pgv_hnsw_share", "pgv_hnsw_device", "pgv_exact_topk", "pgv_ctx_set_bound",
     "pgv_hnsw_upload_payload", "pgv_hnsw_get_payload", "pgv_builder_begin", "pgv_builder_add", "pgv_builder_set_centers", "pgv_builder_rows", "pgv_builder_finish", "pgv_builder_free", "pgv_index_drain",
+    "pgv_index_set_overlap",
 ]
 
 
@@ -105,6 +106,7 @@ def _load():
     lib.pgv_index_upload.argtypes = [P, I, I, I, I, P, P, P, P, C.POINTER(P)]
     lib.pgv_index_free.argtypes = [P]
     lib.pgv_index_share.argtypes = [P, P, C.POINTER(P)]
+    lib.pgv_index_set_overlap.argtypes = [P, I]
     lib.pgv_index_free.restype = None
     lib.pgv_index_export.argtypes = [P, P]
     lib.pgv_index_import.argtypes = [P, P, C.POINTER(P)]

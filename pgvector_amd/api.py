@@ -152,6 +152,11 @@ class IvfIndex:
         self.h = h
         ctx._adopt(self)
 
+    def set_overlap(self, lanes):
+        """pgv_index_set_overlap: consecutive search_batch calls run on `lanes` internal streams in turn (one batch's
+        ranking / planning / top-k under the other's scan); device outputs are complete after ctx.sync().  1 = off."""
+        check(lib.pgv_index_set_overlap(self.h, int(lanes)))
+
     def share(self, ctx):
         """a second handle for another context (its own stream and scratch) on the same device: pgv_index_share.
         The device arrays go with the last handle that is closed."""

@@ -541,6 +541,7 @@ void pgv_ctx_destroy(pgv_ctx *ctx) {
 int pgv_ctx_sync(pgv_ctx *ctx) {
     if (!ctx) PGV_FAIL(PGV_ERR_ARG, "ctx is NULL");
     PGV_HIP(hipStreamSynchronize(ctx->stream));
+    for (pgv_ctx *c : ctx->children) PGV_HIP(hipStreamSynchronize(c->stream));  // lanes of overlapping batches
     return PGV_OK;
 }
 
@@ -568,12 +569,14 @@ int pgv_ctx_set_profiling(pgv_ctx *ctx, int on) {
         PGV_TRY(ctx->stats_dev.ensure(8 * sizeof(double)));
         PGV_HIP(hipMemsetAsync(ctx->stats_dev.p, 0, 8 * sizeof(double), ctx->stream));
     }
+    for (pgv_ctx *c : ctx->children) PGV_TRY(pgv_ctx_set_profiling(c, on));
     return PGV_OK;
 }
 
 int pgv_ctx_set_exact_scan(pgv_ctx *ctx, int on) {
     if (!ctx) PGV_FAIL(PGV_ERR_ARG, "pgv_ctx_set_exact_scan: ctx is NULL");
     ctx->no_mfma_scan = on != 0;
+    for (pgv_ctx *c : ctx->children) c->no_mfma_scan = ctx->no_mfma_scan;
     return PGV_OK;
 }
 
@@ -583,6 +586,7 @@ int pgv_ctx_set_bound(pgv_ctx *ctx, int mode) {
         PGV_FAIL(PGV_ERR_ARG, "pgv_ctx_set_bound: unknown mode %d", mode);
     ctx->bound_mode = mode;
     ctx->assign_bound_mode = mode;
+    for (pgv_ctx *c : ctx->children) c->bound_mode = c->assign_bound_mode = mode;
     return PGV_OK;
 }
 
@@ -597,6 +601,7 @@ int pgv_ctx_reset_stats(pgv_ctx *ctx) {
     ctx->aux_ms = 0;
     ctx->aux_launches = 0;
     ctx->aux_pairs = 0;
+    for (pgv_ctx *c : ctx->children) PGV_TRY(pgv_ctx_reset_stats(c));
     return PGV_OK;
 }
 
@@ -621,6 +626,23 @@ int pgv_ctx_get_stats(pgv_ctx *ctx, pgv_stats *out) {
     out->scan_unique_rows = dev_acc[5];
     out->scan_redo_queries = dev_acc[6];
     out->scan_widened_queries = dev_acc[7];
+    for (pgv_ctx *c : ctx->children) {  // what the lanes of overlapping batches did counts as this context's
+        pgv_stats cs;
+        PGV_TRY(pgv_ctx_get_stats(c, &cs));
+        out->scan_ms += cs.scan_ms;
+        out->scan_launches += cs.scan_launches;
+        out->scan_pairs += cs.scan_pairs;
+        out->scan_rows += cs.scan_rows;
+        out->aux_ms += cs.aux_ms;
+        out->aux_launches += cs.aux_launches;
+        out->aux_pairs += cs.aux_pairs;
+        out->assign_redo_rows += cs.assign_redo_rows;
+        out->assign_rows += cs.assign_rows;
+        out->assign_recheck_rows += cs.assign_recheck_rows;
+        out->scan_unique_rows += cs.scan_unique_rows;
+        out->scan_redo_queries += cs.scan_redo_queries;
+        out->scan_widened_queries += cs.scan_widened_queries;
+    }
     return PGV_OK;
 }
 
@@ -1083,6 +1105,38 @@ int pgv_index_drain(pgv_index *ix, int64_t chunk_rows, pgv_rows_sink sink, void 
     return rc;
 }
 
+static void index_drop_lanes(pgv_index *ix);
+
+int pgv_index_set_overlap(pgv_index *ix, int lanes) {
+    if (!ix) PGV_FAIL(PGV_ERR_ARG, "pgv_index_set_overlap: index is NULL");
+    if (lanes < 1 || lanes > 4) PGV_FAIL(PGV_ERR_ARG, "pgv_index_set_overlap: lanes %d outside 1..4", lanes);
+    PGV_HIP(hipSetDevice(ix->ctx->device));
+    PGV_TRY(pgv_ctx_sync(ix->ctx));
+    index_drop_lanes(ix);
+    if (lanes == 1) return PGV_OK;
+    PGV_HIP(hipEventCreateWithFlags(&ix->lane_event, hipEventDisableTiming));
+    PGV_HIP(hipEventCreateWithFlags(&ix->lane_scan_done, hipEventDisableTiming));
+    for (int i = 0; i < lanes; i++) {
+        pgv_ctx *lc = nullptr;
+        pgv_index *v = nullptr;
+        int rc = pgv_ctx_create(ix->ctx->device, nullptr, &lc);
+        if (rc == PGV_OK) rc = pgv_index_share(ix, lc, &v);
+        if (rc != PGV_OK) {
+            if (lc) pgv_ctx_destroy(lc);
+            index_drop_lanes(ix);
+            return rc;
+        }
+        lc->no_mfma_scan = ix->ctx->no_mfma_scan;
+        lc->bound_mode = ix->ctx->bound_mode;
+        lc->assign_bound_mode = ix->ctx->assign_bound_mode;
+        if (ix->ctx->profiling) (void)pgv_ctx_set_profiling(lc, 1);
+        lc->scan_gate = ix->lane_scan_done;
+        ix->lanes.push_back(v);
+        ix->ctx->children.push_back(lc);
+    }
+    return PGV_OK;
+}
+
 int pgv_index_share(pgv_index *ix, pgv_ctx *ctx, pgv_index **out) {
     if (!ix || !ctx || !out) PGV_FAIL(PGV_ERR_ARG, "pgv_index_share: index/ctx/out is NULL");
     *out = nullptr;
@@ -1091,6 +1145,10 @@ int pgv_index_share(pgv_index *ix, pgv_ctx *ctx, pgv_index **out) {
     pgv_index *v = new (std::nothrow) pgv_index(*ix);  // same device arrays, host tables copied
     if (!v) PGV_FAIL(PGV_ERR_NOMEM, "out of host memory");
     v->ctx = ctx;
+    v->lanes.clear();  // (the lanes of overlapping batches belong to the handle they were set on)
+    v->lane_next = 0;
+    v->lane_event = nullptr;
+    v->lane_scan_done = nullptr;
     __atomic_add_fetch(ix->refs, 1, __ATOMIC_RELAXED);
     *out = v;
     return PGV_OK;
@@ -1204,8 +1262,26 @@ int pgv_index_import(pgv_ctx *ctx, const pgv_index_handle *handle, pgv_index **o
 
 // the device arrays go with the last handle on them (the uploaded index or a pgv_index_share view); an imported
 // mirror is unmapped from this process, the exporter's allocation stays
+static void index_drop_lanes(pgv_index *ix) {
+    for (pgv_index *v : ix->lanes) {
+        pgv_ctx *lc = v->ctx;
+        if (ix->ctx) {
+            auto &ch = ix->ctx->children;
+            ch.erase(std::remove(ch.begin(), ch.end(), lc), ch.end());
+        }
+        pgv_index_free(v);  // (a view: gives its reference back)
+        pgv_ctx_destroy(lc);
+    }
+    ix->lanes.clear();
+    if (ix->lane_event) (void)hipEventDestroy(ix->lane_event);
+    ix->lane_event = nullptr;
+    if (ix->lane_scan_done) (void)hipEventDestroy(ix->lane_scan_done);
+    ix->lane_scan_done = nullptr;
+}
+
 void pgv_index_free(pgv_index *ix) {
     if (!ix) return;
+    if (!ix->lanes.empty()) index_drop_lanes(ix);
     if (ix->ctx) (void)hipStreamSynchronize(ix->ctx->stream);
     if (ix->refs && __atomic_sub_fetch(ix->refs, 1, __ATOMIC_ACQ_REL) > 0) {
         delete ix;
@@ -1443,6 +1519,16 @@ static int approx_candidates(int k) {
 }
 
 // GetScanItems + head of the sorted stream for staged queries and device probe lists
+// lanes of overlapping batches: this stream's list scan starts when the previous lane's has ended
+static int scan_turn_begin(pgv_ctx *ctx) {
+    if (ctx->scan_gate) PGV_HIP(hipStreamWaitEvent(ctx->stream, ctx->scan_gate, 0));
+    return PGV_OK;
+}
+static int scan_turn_end(pgv_ctx *ctx) {
+    if (ctx->scan_gate) PGV_HIP(hipEventRecord(ctx->scan_gate, ctx->stream));
+    return PGV_OK;
+}
+
 static int scan_batch_dev(pgv_index *ix, const void *q_dev, int nq, const int32_t *probe_lists, int probes,
                           int k, float *out_dist, int64_t *out_slot, uint64_t *out_tid) {
     pgv_ctx *ctx = ix->ctx;
@@ -1461,11 +1547,13 @@ static int scan_batch_dev(pgv_index *ix, const void *q_dev, int nq, const int32_
         PGV_TRY(od.init(out_dist, sizeof(float) * (size_t)nq * k, ctx->out_stage));
         PGV_TRY(os.init(out_slot, sizeof(int64_t) * (size_t)nq * k, ctx->out_stage2));
         PGV_TRY(ot.init(out_tid, sizeof(uint64_t) * (size_t)nq * k, ctx->sel_b));
+        PGV_TRY(scan_turn_begin(ctx));
         ScanTimer timer{ctx};
         PGV_TRY(timer.begin(0.0, 0.0));  // pairs / rows are added up on the device by mq_head_kernel
         PGV_TRY(launch_multi_scan(ctx, ix, q_dev, nq, probe_lists, probes, bound, ctx->plan_d.as<float>(), seg_stride, k,
                                   od.as<float>(), os.as<int64_t>(), ot.as<uint64_t>()));
         PGV_TRY(timer.end());
+        PGV_TRY(scan_turn_end(ctx));
         bool need = false;
         PGV_TRY(od.finish(ctx, &need));
         PGV_TRY(os.finish(ctx, &need));
@@ -1504,6 +1592,7 @@ static int scan_batch_dev(pgv_index *ix, const void *q_dev, int nq, const int32_
     PGV_TRY(ctx->plan_d.ensure(sizeof(float) * (size_t)(plan.out_bound > 0 ? plan.out_bound : 1)));
     float *seg_vals = ctx->plan_d.as<float>();
     if (plan.ntasks_bound > 0) {
+        PGV_TRY(scan_turn_begin(ctx));
         ScanTimer timer{ctx};
         PGV_TRY(timer.begin(0.0, 0.0));  // pairs / rows of this launch are accumulated on the device
         if (use_mfma)
@@ -1517,6 +1606,7 @@ static int scan_batch_dev(pgv_index *ix, const void *q_dev, int nq, const int32_
             PGV_TRY(launch_scan(ctx, ix->metric, ix->dtype, ix->geom, ix->vectors, q_dev, plan.tasks,
                                 plan.ntasks_dev, (int)plan.ntasks_bound, plan.pairs, qt, seg_vals));
         PGV_TRY(timer.end());
+        PGV_TRY(scan_turn_end(ctx));
     }
 
     // head of the sorted stream
@@ -1566,6 +1656,15 @@ int pgv_search_batch(pgv_index *ix, const void *queries, int nq, int probes, int
                      int64_t *out_slot, uint64_t *out_tid) {
     PGV_TRY(check_batch_args(ix, queries, nq, probes, k, out_dist, out_tid, "pgv_search_batch"));
     if (nq == 0) return PGV_OK;
+    if (!ix->lanes.empty()) {
+        // overlapping batches: this one runs on the next lane's stream, behind whatever the caller's stream holds now
+        // (device-side queries may still be on their way) and beside the batch the previous call put on another lane
+        pgv_index *lane = ix->lanes[ix->lane_next++ % ix->lanes.size()];
+        PGV_HIP(hipSetDevice(ix->ctx->device));
+        PGV_HIP(hipEventRecord(ix->lane_event, ix->ctx->stream));
+        PGV_HIP(hipStreamWaitEvent(lane->ctx->stream, ix->lane_event, 0));
+        return pgv_search_batch(lane, queries, nq, probes, k, out_dist, out_slot, out_tid);
+    }
     pgv_ctx *ctx = ix->ctx;
     PGV_HIP(hipSetDevice(ctx->device));
     const void *q_dev;

@@ -138,6 +138,13 @@ struct pgv_ctx {
     double aux_ms = 0.0;
     int64_t aux_launches = 0;
     double aux_pairs = 0.0;
+    // lanes of indexes whose batches overlap (pgv_index_set_overlap): contexts with streams of their own that belong to
+    // an index of this context; pgv_ctx_sync waits for them, the settings and the statistics include them
+    std::vector<pgv_ctx *> children;
+    // a lane's list scans take turns with the other lanes': two HBM-bound scans side by side only share the bandwidth,
+    // while everything else of a batch (ranking, planning, top-k, recheck) fits under another batch's scan.  The event
+    // belongs to the index (pgv_index::lane_scan_done); null outside lanes.
+    hipEvent_t scan_gate = nullptr;
 };
 
 struct pgv_index {
@@ -163,6 +170,12 @@ struct pgv_index {
     std::vector<int64_t> h_offsets;   // host copy
     std::vector<int64_t> len_prefix;  // len_prefix[p] = rows in the p longest lists (output size bound)
     int64_t max_list_len = 0;
+    // pgv_index_set_overlap: views of this index on contexts (streams, scratch) of their own; consecutive
+    // pgv_search_batch calls take them in turn
+    std::vector<pgv_index *> lanes;
+    unsigned lane_next = 0;
+    hipEvent_t lane_event = nullptr;  // orders a lane's start after what the caller's stream holds at the call
+    hipEvent_t lane_scan_done = nullptr;  // the lanes' list scans run one after the other (pgv_ctx::scan_gate)
 };
 
 // one backend's index scan (pgv_query_*): everything between amrescan and amendscan that lives on the device

@@ -1,0 +1,99 @@
+"""Round 5 on the GPU: overlapping batches (pgv_index_set_overlap) answer exactly what stream-ordered batches answer."""
+import numpy as np
+import pytest
+
+from pgvector_amd import api
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    c = api.Context(0)
+    yield c
+    c.close()
+
+
+def _index(ctx, oracle, n=60000, dim=128, lists=64, seed=11):
+    from oracle import pyoracle as po
+    from helpers import CpuIvf, gen
+    data = gen(n, dim, seed=seed, dist="clustered", clusters=lists)
+    ivf = CpuIvf(oracle, po.OPS_L2, po.ORA_F32, data, lists)
+    ix = api.IvfIndex(ctx, ivf.metric, api.PGV_F32, dim, ivf.centers, ivf.list_offsets, ivf.vectors, ivf.tids)
+    return ix, ivf
+
+
+def test_overlapping_batches_answer_what_stream_ordered_batches_answer(ctx, oracle):
+    """six different 512-query batches (the matrix-core scan: 512 x 8 probes over 64 lists), device buffers in and out:
+    stream-ordered first, then on 2 and on 3 lanes with nothing but ctx.sync() at the end -- identical distances, slots
+    and TIDs; host buffers through a lane too; the statistics of the lanes count as the context's; back to one lane"""
+    import torch
+    from helpers import gen
+    ix, ivf = _index(ctx, oracle)
+    dev = torch.device("cuda", 0)
+    nb, nq, probes, k = 6, 512, 8, 10
+    qs = [torch.from_numpy(gen(nq, 128, seed=100 + b, dist="clustered", clusters=64)).to(dev) for b in range(nb)]
+    try:
+        want = []
+        for b in range(nb):
+            d, s, t = ix.search_batch(qs[b], probes, k, want_tid=True)
+            ctx.sync()
+            want.append((d.cpu().numpy(), s.cpu().numpy(), t.cpu().numpy()))
+        for lanes in (2, 3):
+            ix.set_overlap(lanes)
+            ctx.set_profiling(True)
+            ctx.reset_stats()
+            outs = [tuple(torch.empty((nq, k), device=dev, dtype=dt) for dt in (torch.float32, torch.int64, torch.int64))
+                    for _ in range(nb)]
+            for rep in range(3):                      # the lanes are reused: a lane's next batch waits for its previous one
+                for b in range(nb):
+                    ix.search_batch(qs[b], probes, k, want_tid=True, out=outs[b])
+            ctx.sync()
+            st = ctx.stats()
+            ctx.set_profiling(False)
+            assert st["scan_launches"] == 3 * nb and st["scan_pairs"] > 0      # the lanes' work is the context's
+            for b in range(nb):
+                np.testing.assert_array_equal(outs[b][0].cpu().numpy(), want[b][0])
+                np.testing.assert_array_equal(outs[b][1].cpu().numpy(), want[b][1])
+                np.testing.assert_array_equal(outs[b][2].cpu().numpy(), want[b][2])
+            # host buffers: synchronous, as without lanes
+            d, s, t = ix.search_batch(qs[0].cpu().numpy(), probes, k, want_tid=True)
+            np.testing.assert_array_equal(np.asarray(d), want[0][0])
+            np.testing.assert_array_equal(np.asarray(t).astype(np.int64), want[0][2])
+        ix.set_overlap(1)
+        d, s, t = ix.search_batch(qs[1], probes, k, want_tid=True)
+        ctx.sync()
+        np.testing.assert_array_equal(d.cpu().numpy(), want[1][0])
+        with pytest.raises(Exception):
+            ix.set_overlap(9)
+    finally:
+        ix.close()
+
+
+def test_device_queries_written_just_before_the_call_are_seen_by_the_lane(ctx, oracle):
+    """the lane starts behind what the context's stream holds at the call: a query buffer filled by a kernel on that
+    stream right before search_batch is read after the fill, not before"""
+    import torch
+    from helpers import gen
+    tctx = api.Context(0, stream=torch.cuda.current_stream().cuda_stream)
+    ix, ivf = _index(tctx, oracle, seed=12)
+    dev = torch.device("cuda", 0)
+    try:
+        q = torch.from_numpy(gen(512, 128, seed=300, dist="clustered", clusters=64)).to(dev)
+        d0, _, t0 = ix.search_batch(q, 8, 10, want_tid=True)
+        tctx.sync()
+        ix.set_overlap(2)
+        for _ in range(4):
+            buf = torch.zeros_like(q)
+            big = torch.randn((4096, 4096), device=dev)
+            for _ in range(3):
+                big = big @ big * 1e-3                # keeps torch's stream busy: the copy below is queued behind it
+            buf.copy_(q)
+            d1, _, t1 = ix.search_batch(buf, 8, 10, want_tid=True)
+            tctx.sync()
+            torch.cuda.synchronize()
+            np.testing.assert_array_equal(d1.cpu().numpy(), d0.cpu().numpy())
+            np.testing.assert_array_equal(t1.cpu().numpy(), t0.cpu().numpy())
+    finally:
+        ix.close()
+        tctx.close()
