@@ -288,6 +288,15 @@ int rows_per_task_for(pgv_ctx *ctx, int64_t total_rows, int64_t groups) {
     return (int)ch;
 }
 
+static bool dense_keep() {
+    static int v = -1;
+    if (v < 0) {
+        const char *e = getenv("PGV_DENSE_KEEP");
+        v = e ? atoi(e) : 1;
+    }
+    return v != 0;
+}
+
 int dense_scan(pgv_ctx *ctx, pgv_metric metric, pgv_dtype dtype, const RowGeom &g,
                const void *rows_dev, int64_t nrows, const void *queries_dev, int nq,
                int64_t out_stride, float *out_dev, bool mfma = false, const float *row_norms = nullptr,
@@ -349,7 +358,8 @@ int dense_scan(pgv_ctx *ctx, pgv_metric metric, pgv_dtype dtype, const RowGeom &
                 ht[t].pair0 = gidx * qt;
                 int pl = nq - gidx * qt;
                 ht[t].npairs = pl < qt ? pl : qt;
-                ht[t].pad = 0;
+                // a chunk that several query groups stream (consecutive tasks) is worth keeping in the caches
+                ht[t].pad = (ngroups > 1 && dense_keep()) ? 1 : 0;
                 t++;
             }
         *hn = (int)ntasks;
@@ -1983,9 +1993,17 @@ int pgv_exact_topk(pgv_ctx *ctx, pgv_metric metric, pgv_dtype dtype, int dim, co
     PGV_TRY(od.init(out_dist, sizeof(float) * (size_t)nq * k, ctx->out_stage));
     PGV_TRY(oi.init(out_idx, sizeof(int64_t) * (size_t)nq * k, ctx->out_stage2));
 
-    // the distance matrix of a query chunk stays under 1 GiB
-    int chunk = n > 0 ? (int)std::min<int64_t>(nq, std::max<int64_t>(1, ((int64_t)1 << 28) / n)) : nq;
-    if (chunk >= 64) chunk = chunk / 32 * 32;
+    // the distance matrix of a query chunk stays under 4 GiB (whole 128-query tiles of the dense kernel when it is that
+    // large: 1024 queries x 1 M rows are ONE pass, every row tile read from HBM once)
+    int chunk = n > 0 ? (int)std::min<int64_t>(nq, std::max<int64_t>(1, ((int64_t)1 << 30) / n)) : nq;
+    if (chunk >= 128)
+        chunk = chunk / 128 * 128;
+    else if (chunk >= 64)
+        chunk = chunk / 32 * 32;
+    static const bool no_dense = [] {
+        const char *e = getenv("PGV_NO_DENSE128");
+        return e && atoi(e) != 0;
+    }();
     const int kprime = approx_candidates(k);
     const bool l2_mfma = metric == PGV_L2SQ && kprime <= 256 && n > kprime;
     const bool mfma_ok = !ctx->no_mfma_scan && n >= 64 && (metric == PGV_NEG_IP || l2_mfma);
@@ -2004,19 +2022,30 @@ int pgv_exact_topk(pgv_ctx *ctx, pgv_metric metric, pgv_dtype dtype, int dim, co
         PGV_TRY(ctx->dist_mat.ensure(sizeof(float) * std::max<size_t>((size_t)cn * (size_t)n, 4)));
         float *mat = ctx->dist_mat.as<float>();
         const bool mfma = mfma_ok && cn >= 64;
+        // 128 queries x 128 rows per workgroup (kernels_dense.hip) from 128 queries on: the rows are streamed once per
+        // 128 queries instead of once per 32
+        const bool dense128 = mfma && cn >= 128 && n >= 128 && !no_dense;
         if (mfma && metric == PGV_L2SQ) {
             ApproxScratch sc;
             PGV_TRY(sc.carve(ctx, ctx->ms_b, cn, kprime));
-            PGV_TRY(dense_scan(ctx, metric, dtype, g, r_dev, n, qp, cn, n, mat, true, norms, nullptr));
+            // the candidates are proven complete with the rounding bound of the kernel that produced the values
+            const ScanBound bound = dense128 ? scan_bound_chain(ctx, g.ld, dense_chain_length(g, dtype)) : scan_bound(ctx, g.ld);
+            if (dense128)
+                PGV_TRY(launch_mfma_dense(ctx, metric, dtype, g, r_dev, n, qp, cn, norms, mat, n));
+            else
+                PGV_TRY(dense_scan(ctx, metric, dtype, g, r_dev, n, qp, cn, n, mat, true, norms, nullptr));
             PGV_TRY(launch_topk_segments(ctx, mat, nullptr, cn, n, kprime, sc.cand_val, sc.cand_pos, sc.flags + cn));
             const ExactRows xr{r_dev, nullptr, nullptr, g, dtype, reinterpret_cast<const unsigned *>(norms + n)};
             // a row's position in the matrix row is its index: cand_pos serves as the slots
             PGV_TRY(launch_batch_recheck(ctx, xr, qp, cn, kprime, k, sc.cand_val, sc.cand_pos, sc.cand_pos, nullptr, n,
-                                         scan_bound(ctx, g.ld), cd, ci, nullptr, sc.flags));
-            PGV_TRY(launch_batch_fix(ctx, xr, qp, cn, nullptr, nullptr, 0, nullptr, n, sc.flags, mat, k, scan_bound(ctx, g.ld),
+                                         bound, cd, ci, nullptr, sc.flags));
+            PGV_TRY(launch_batch_fix(ctx, xr, qp, cn, nullptr, nullptr, 0, nullptr, n, sc.flags, mat, k, bound,
                                      cd, ci, nullptr));
         } else {
-            PGV_TRY(dense_scan(ctx, metric, dtype, g, r_dev, n, qp, cn, n, mat, mfma, nullptr, nullptr));
+            if (dense128)
+                PGV_TRY(launch_mfma_dense(ctx, metric, dtype, g, r_dev, n, qp, cn, nullptr, mat, n));
+            else
+                PGV_TRY(dense_scan(ctx, metric, dtype, g, r_dev, n, qp, cn, n, mat, mfma, nullptr, nullptr));
             PGV_TRY(launch_topk_segments(ctx, mat, nullptr, cn, n, k, cd, ci));
         }
     }

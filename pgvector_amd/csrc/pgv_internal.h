@@ -261,6 +261,12 @@ inline ScanBound scan_bound(const pgv_ctx *ctx, int dim) {
     constexpr double v = 5.9604645e-8;  // 2^-24: round to nearest (tests/test_gpu_round4.py)
     return {0.f, gamma_n(dim / 4.0 + 4.0, v), gamma_n(dim / 64.0 + 10.0, v), 2.f * gamma_n(dim + 2.0, v)};
 }
+// the same with the products per accumulator chain given (mfma_dense_kernel: quarters of whole 128-byte slices)
+inline ScanBound scan_bound_chain(const pgv_ctx *ctx, int dim, int chain) {
+    ScanBound b = scan_bound(ctx, dim);
+    if (ctx->bound_mode != 0) b.g_dot = gamma_n(chain + 4.0, 5.9604645e-8);
+    return b;
+}
 struct ExpansionBound {
     float gamma;        // of |x|^2 + 2 |q||x| (expansion terms)
     float gamma_exact;  // of (|q| + |x|)^2 (the exact value's own rounding; 0 in the statistical model)
@@ -341,6 +347,10 @@ int launch_argmin_mfma(pgv_ctx *ctx, int mode, pgv_dtype dtype, const RowGeom &g
 // kernels_mfma.hip: the batched list scan on the matrix cores (<= 128 rows x <= 32 queries per task)
 int mfma_scan_rows_per_task();
 int mfma_scan_queries_per_task();
+// kernels_dense.hip: every query x every row, 128 x 128 tiles (pgv_exact_topk); out[q * out_stride + row]
+int launch_mfma_dense(pgv_ctx *ctx, pgv_metric metric, pgv_dtype dtype, const RowGeom &g, const void *rows, int64_t n,
+                      const void *queries, int nq, const float *row_norms, float *out, int64_t out_stride);
+int dense_chain_length(const RowGeom &g, pgv_dtype dtype);  // products per accumulator chain, at most
 int launch_row_norms(pgv_ctx *ctx, pgv_dtype dtype, const RowGeom &g, const void *rows, int64_t n, float *out,
                      unsigned *max_bits);
 int launch_mfma_scan(pgv_ctx *ctx, pgv_metric metric, pgv_dtype dtype, const RowGeom &g, const void *rows,

@@ -97,3 +97,42 @@ def test_device_queries_written_just_before_the_call_are_seen_by_the_lane(ctx, o
     finally:
         ix.close()
         tctx.close()
+
+
+# ------------------------------------------------------------------ pgv_exact_topk on 128 x 128 tiles (kernels_dense.hip)
+@pytest.mark.parametrize("ops,dt,dim,n,nq,k,dist", [
+    ("l2", "f32", 1536, 3000, 300, 10, "clustered"),   # ragged query tile (300 = 2 x 128 + 44), ragged row tile
+    ("l2", "f32", 100, 5000, 128, 10, "normal"),       # a row of 25 vectors: the last slice is partly zeros
+    ("l2", "f32", 7, 1000, 129, 40, "normal"),         # one slice, k' = 160
+    ("l2", "f32", 2000, 129, 256, 10, "uniform"),      # the largest indexed dimension, rows barely past one tile
+    ("ip", "f32", 768, 4000, 200, 10, "clustered"),
+    ("l2", "f16", 3072, 2000, 130, 10, "clustered"),
+    ("ip", "f16", 1024, 2400, 128, 25, "clustered"),
+    ("l2", "f32", 8, 4000, 160, 40, "int"),            # exact ties: lower row index first, as the sequential scan
+])
+def test_exact_topk_on_128_tiles_is_the_sequential_scan(ctx, oracle, ops, dt, dim, n, nq, k, dist):
+    """from 128 queries on pgv_exact_topk runs mfma_dense_kernel (128 queries x 128 rows per workgroup, four accumulator
+    chains by quarters of the row) + the exact tail: ids are the oracle's per-row l2 / inner-product calls + ascending
+    sort (src/vector.c:579-620) up to float ties, distances to 1e-5; PGV_NO_DENSE128 cannot be flipped inside a process,
+    so the old kernel is the comparison of tests/test_gpu_round3.py (< 128 queries)"""
+    from oracle import pyoracle as po
+    from helpers import assert_topk_equiv, gen
+    odt = po.ORA_F32 if dt == "f32" else po.ORA_F16
+    oops = po.OPS_L2 if ops == "l2" else po.OPS_IP
+    rows = gen(n, dim, seed=951, dist=dist, dtype=odt)
+    queries = gen(nq, dim, seed=952, dist=dist, dtype=odt)
+    if dist == "int":
+        rows[500:530] = rows[17]
+        queries[3] = rows[17]
+    metric = api.PGV_L2SQ if ops == "l2" else api.PGV_NEG_IP
+    d, idx = api.exact_topk(ctx, metric, api.PGV_F32 if dt == "f32" else api.PGV_F16, dim, queries, rows, k)
+    s = oracle.index_struct(oops, odt, rows[:1], np.array([0, n], dtype=np.int64), rows, np.arange(n, dtype=np.uint64))
+    for i in range(0, nq, 3):
+        wt, wd = oracle.search(s, queries[i], 1, k)
+        scale = 0.0
+        if metric == api.PGV_NEG_IP:
+            scale = 1e-5 * float(np.max(np.abs(rows.astype(np.float64)) @ np.abs(queries[i].astype(np.float64))))
+        assert_topk_equiv(idx[i].tolist(), d[i], wt.tolist(), wd, atol=max(scale, 1e-30),
+                          what="dense128 %s %s dim %d q %d" % (ops, dt, dim, i))
+        if dist == "int":
+            assert idx[i].tolist() == wt.astype(np.int64).tolist()      # ties resolved towards the lower row index
