@@ -856,7 +856,7 @@ int launch_mfma_mode(pgv_ctx *ctx, int mode, const RowGeom &g, const void *rows,
 //   METRIC 1 (negative inner product): the value is the reference's arithmetic.
 //   METRIC 0 (L2): |x|^2 - 2 q.x with the rows' precomputed norms (no |q|^2: it shifts all values of a query alike,
 //   so the selections run without it) -- an APPROXIMATION of
-//   sum((q-x)^2) (cancellation), used only to pick candidates; pgv_abi.hip's scan_batch_dev
+//   sum((q-x)^2) (cancellation), used only to pick candidates; pgv_abi_ivf.hip's scan_batch_dev
 //   re-evaluates the exact form for the k' best and checks that nothing outside them can matter.
 constexpr int kScanQueries = 32;   // queries per task
 

@@ -1,5 +1,5 @@
 // pgv_gate.h -- a counting gate on one futex word (plain host C++, no HIP): at most `width` holders, everybody else
-// asleep.  Used by pgv_query_scan to bound the single-query scans a process has in flight (pgv_abi.hip) and compiled
+// asleep.  Used by pgv_query_scan to bound the single-query scans a process has in flight (pgv_abi_ivf.hip) and compiled
 // on its own by tests/c/gate_stress.cpp.
 //
 // Round 3's gate woke a sleeper only when the leaver saw the count AT the width (`before >= width`).  Two holders

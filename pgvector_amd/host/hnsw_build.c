@@ -101,7 +101,7 @@ typedef struct
 
 typedef struct
 {
-	/* xoroshiro128** like the library's own source (pgv_abi.hip Xoro) when no callbacks are given */
+	/* xoroshiro128** like the library's own source (pgv_abi_common.h Xoro) when no callbacks are given */
 	uint64_t	s0,
 				s1;
 	const pgv_rng *user;

@@ -1170,7 +1170,7 @@ pgv_hnsw_search(pgv_hnsw * h, const void *queries, int nq, int ef_search, int k,
 
 /* ------------------------------------------------------------------ multi-GPU
  * The stand-in's pgv_comm_* / pgv_kmeans_sharded / pgv_search_batch_sharded issue the SAME collectives in the same
- * order with the same payloads as libpgv_hip (pgv_abi.hip, "multi-GPU"): all-gather of the ranks' sample counts; per
+ * order with the same payloads as libpgv_hip (pgv_abi_comm.hip): all-gather of the ranks' sample counts; per
  * k-means++ round an all-gather of the ranks' weight totals and one of the candidate row; per Lloyd iteration ONE
  * all-reduce of the fused record sums[k x dim] | counts[k] | changes (as floats); per search an all-gather of the
  * ranks' probe-list slices and two of their heads.  tests/test_sharded_cpath_gloo.py runs two ranks of it over gloo.
