@@ -1019,7 +1019,8 @@ def compact_line(full):
                                        "slowest_rank_scan_ms", "measured_on"))
     ro = full.get("roofline", {})
     line["roofline"] = _pick(ro, ("bound", "achieved", "peak", "unit", "frac", "frac_streamed", "traffic", "avg_launch_ms",
-                                  "launches", "passes"))
+                                  "launches", "passes", "unique_bytes_per_launch", "streamed_bytes_per_launch",
+                                  "algorithmic_bytes_per_launch"))
     line["roofline"]["kernel"] = str(ro.get("kernel", "")).split(" ")[0]
     cb = full.get("cpu_baseline")
     if isinstance(cb, dict):

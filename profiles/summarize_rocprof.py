@@ -99,8 +99,14 @@ def main():
         if not big:
             continue
         val = sum(r[1] for r in big) / len(big)
-        algo = b["roofline"]["algorithmic_bytes_per_launch"]
-        stream = b["roofline"]["streamed_bytes_per_launch"]
+        rfb = b["roofline"]
+        # (round 5: bench.py's stdout line is the compact one; older lines carried the byte counts themselves)
+        stream = rfb.get("streamed_bytes_per_launch",
+                         rfb.get("frac_streamed", rfb["frac"]) * rfb["peak"] * 1e9 * rfb["avg_launch_ms"] / 1e3)
+        cfgb = b["config"]
+        algo = rfb.get("algorithmic_bytes_per_launch",
+                       # pairs scored per launch x row bytes: batch x (rows of `probes` average lists) x dim x 4
+                       cfgb["batch_per_gpu"] * cfgb["probes"] * (cfgb["rows"] / cfgb["lists"]) * cfgb["dim"] * 4.0)
         lines += ["", "## %s over the timed list-scan launches" % counter, "",
                   "%d launches, avg %s = %.0f KB per launch (rocprofv3 reports KB)" % (len(big), counter, val)]
         if counter == "FETCH_SIZE":
@@ -119,10 +125,14 @@ def main():
         keep = [n for n in mby if any(t in n for t in ("mfma_argmin", "recheck", "chosen_distance", "argmin_kernel",
                                                         "center_norms", "redo_finish", "query_"))]
         lines += ["", "## round-2 micro-benchmarks (`tools/bench_round2.py` under `rocprofv3 --kernel-trace --stats`)", "",
-                  "| kernel | calls | avg us | min us | max us |", "|---|---|---|---|---|"]
+                  "(`query_rank_kernel` also runs the 999 rounds of the micro-bench's k-means++ seeding -- one query against 50 000",
+                  "samples, ~44 us each --, so its AVERAGE is not the single-query ranking's: the median and the share of launches",
+                  "under 10 us tell them apart)", "",
+                  "| kernel | calls | avg us | median us | min us | max us | launches < 10 us |", "|---|---|---|---|---|---|---|"]
         for name in sorted(keep, key=lambda n: -sum(mby[n])):
-            v = mby[name]
-            lines.append("| %s | %d | %.1f | %.1f | %.1f |" % (name, len(v), sum(v) / len(v) / 1e3, min(v) / 1e3, max(v) / 1e3))
+            v = sorted(mby[name])
+            lines.append("| %s | %d | %.1f | %.1f | %.1f | %.1f | %d |" % (
+                name, len(v), sum(v) / len(v) / 1e3, v[len(v) // 2] / 1e3, v[0] / 1e3, v[-1] / 1e3, sum(1 for x in v if x < 10000)))
         mj = os.path.join(d, "micro_bench.json")
         if os.path.exists(mj):
             try:
