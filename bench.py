@@ -1087,6 +1087,9 @@ def compact_line(full):
             s["pooled_256_p50_us"] = _r(top.get("latency_us_p50"), 4)
         if s:
             line["backends"] = s
+    ob = full.get("overlapped_batches")
+    if isinstance(ob, dict):
+        line["overlapped_batches"] = _pick(ob, ("lanes", "qps", "ms_per_step", "scan_ms_per_launch"))
     if "build_secs_pages" in full:
         line["build_secs_pages"] = _r(full["build_secs_pages"])
     cbb = full.get("cpu_build_baseline")
@@ -1100,7 +1103,7 @@ def compact_line(full):
         if len(fails) > 6:
             line["failures"].append("... %d more in %s" % (len(fails) - 6, DETAIL_NAME))
     # the cap is a contract: shed the optional summaries, least important first, until the line fits
-    for victim in ("backends", "batch_ms", "cpu_build_secs_all_threads_extrapolated", "build_secs_pages", "other_configs",
+    for victim in ("backends", "batch_ms", "cpu_build_secs_all_threads_extrapolated", "build_secs_pages", "overlapped_batches", "other_configs",
                    "failures"):
         if len(json.dumps(line, default=str)) < LINE_CAP:
             break
@@ -1738,8 +1741,10 @@ def main():
     ap.add_argument("--recall-queries", type=int, default=256)
     ap.add_argument("--exact-scan", action="store_true", help="A/B: keep the batched L2 scan on the vector-ALU kernels "
                     "(pgv_ctx_set_exact_scan)")
-    ap.add_argument("--overlap", type=int, default=3, help="streams consecutive batches of the timed loop alternate on "
-                    "(pgv_index_set_overlap; 1: one stream, stream-ordered)")
+    ap.add_argument("--overlap", type=int, default=1, help="streams consecutive batches of the TIMED loop alternate on "
+                    "(pgv_index_set_overlap; 1, the default: one stream, stream-ordered -- the scan kernel's launches are then "
+                    "timed undisturbed; the overlapped form is measured right after as `overlapped_batches`)")
+    ap.add_argument("--overlap-lanes", type=int, default=3, help="lanes of the `overlapped_batches` measurement (0: skip it)")
     ap.add_argument("--placement", default="balanced", choices=("balanced", "modulo"),
                     help="N GPUs: lists to ranks by rows (LPT) or l %% N")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo for a functional "
@@ -1873,6 +1878,30 @@ def main():
     ctx.set_profiling(False)
     if world == 1 and args.overlap > 1:
         index.set_overlap(1)     # everything below reads its answers in stream order again
+    overlapped = None
+    if world == 1 and args.overlap == 1 and args.overlap_lanes > 1 and not args.child:
+        # the same K steps once more with one caller's consecutive batches on `overlap_lanes` internal streams
+        # (pgv_index_set_overlap: list scans take turns, everything else of a batch runs under another batch's scan).
+        # Not `value`: the scan launches of the timed region above are timed without company, these are not.
+        WATCH["section"] = "overlapped batches"
+        index.set_overlap(args.overlap_lanes)
+        for i in range(max(args.warmup, args.overlap_lanes)):
+            step(i)
+        ctx.set_profiling(True)
+        ctx.reset_stats()
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        for i in range(args.steps):
+            step(args.warmup + i)
+        torch.cuda.synchronize()
+        el2 = time.perf_counter() - t1
+        st2 = ctx.stats()
+        ctx.set_profiling(False)
+        index.set_overlap(1)
+        overlapped = {"lanes": args.overlap_lanes, "qps": total_batch * args.steps / el2, "ms_per_step": el2 / args.steps * 1e3,
+                      "scan_ms_per_launch": st2["scan_ms"] / max(st2["scan_launches"], 1), "steps": args.steps}
+        log("overlapped batches (%d lanes): %.0f QPS, %.3f ms/step, scan %.3f ms/launch" % (
+            args.overlap_lanes, overlapped["qps"], overlapped["ms_per_step"], overlapped["scan_ms_per_launch"]))
     if world > 1:
         el = torch.tensor([elapsed], dtype=torch.float64, device=dev if args.backend == "nccl" else "cpu")
         dist.all_reduce(el, op=dist.ReduceOp.MAX)
@@ -1943,6 +1972,8 @@ def main():
         "scan_path": "exact vector-ALU kernels (--exact-scan)" if args.exact_scan else "auto",
         "overlap_lanes": args.overlap if world == 1 else 1,
     }
+    if overlapped:
+        line["overlapped_batches"] = overlapped
     if world > 1:
         # what the first real N-GPU run needs to be read: the communicator's size, the exchanges per step and per
         # Lloyd iteration in bytes, the build's phases (build_phases_secs: kmeans = k-means++ + Lloyd with
