@@ -137,7 +137,9 @@ static int
 PgvBuildCancelPending(void *arg)
 {
 	(void) arg;
-	return InterruptPending != 0;
+	/* (not InterruptPending: that is also raised for catch-up and procsignal work, which CHECK_FOR_INTERRUPTS serves without
+	 * an error -- the build must not give up for those) */
+	return QueryCancelPending || ProcDiePending;
 }
 
 static double

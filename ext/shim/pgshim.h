@@ -86,6 +86,8 @@ void		MemoryContextRegisterResetCallback(MemoryContext ctx, MemoryContextCallbac
 void		pgshim_check_interrupts(void);
 #include <signal.h>
 extern volatile sig_atomic_t InterruptPending;	/* set by the signal handlers: something for CHECK_FOR_INTERRUPTS to do */
+extern volatile sig_atomic_t QueryCancelPending;	/* ... a statement cancel (SIGINT) */
+extern volatile sig_atomic_t ProcDiePending;	/* ... a termination request (SIGTERM) */
 typedef void (*pg_on_exit_callback) (int code, Datum arg);
 void		on_proc_exit(pg_on_exit_callback function, Datum arg);
 void		before_shmem_exit(pg_on_exit_callback function, Datum arg);

@@ -471,6 +471,8 @@ shim_cancel_after(int after_checks)
 }
 
 volatile sig_atomic_t InterruptPending = 0;
+volatile sig_atomic_t QueryCancelPending = 0;
+volatile sig_atomic_t ProcDiePending = 0;
 
 void
 pgshim_check_interrupts(void)
@@ -491,6 +493,7 @@ handle_sigterm(int sig)
 	(void) sig;
 	proc_die_pending = 1;
 	InterruptPending = 1;
+	ProcDiePending = 1;
 	if (MyLatch)
 	{
 		__atomic_store_n(&MyLatch->is_set, 1, __ATOMIC_RELEASE);
