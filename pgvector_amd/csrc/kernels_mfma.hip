@@ -865,17 +865,20 @@ constexpr int kScanWaves = 4;      // one 32 x 32 tile each: a task is 128 rows
 // NT: the list rows are fetched with the non-temporal policy (an index far larger than the caches is read once per
 // batch: +3.5 % on the 6 GB headline index, 1.145 -> 1.102 ms per batch, same box, alternating runs); the query rows,
 // which every task of a group re-reads, keep the default policy
-template <typename T, int METRIC, int NW, bool NT>
+// NQ: queries per task, 32 or 64.  64 (round 5) is for batches whose lists are probed by more than ~12 queries on average
+// (configs[2] / [4] at their real shape: 1024 queries x 64 probes over 4096 lists): a list probed by 33 .. 64 queries is
+// streamed ONCE instead of twice -- a wavefront then holds two 32 x 32 tiles (queries 0-31 and 32-63 against its 32 rows).
+template <typename T, int METRIC, int NW, bool NT, int NQ>
 __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(3, 3))) void mfma_scan_kernel(
     const char *__restrict__ rows, const char *__restrict__ queries, const ScanTask *__restrict__ tasks,
     const int *__restrict__ ntasks_ptr, int *__restrict__ task_counter, const ScanPair *__restrict__ pairs,
     const float *__restrict__ row_norms, int nvec, const char *__restrict__ zeros16, float *__restrict__ out) {
     constexpr int ROWS = 32 * NW;
-    constexpr int NGROUPS = (kScanQueries + ROWS) / 8;          // DMA instructions per stage (8 rows each)
+    constexpr int NGROUPS = (NQ + ROWS) / 8;          // DMA instructions per stage (8 rows each)
     constexpr int NDMA = (NGROUPS + NW - 1) / NW;               // ... per wavefront, at most
-    constexpr int STAGE = (kScanQueries + ROWS) * kSliceBytes;  // 20 KB (NW 4) / 36 KB (NW 8)
+    constexpr int STAGE = (NQ + ROWS) * kSliceBytes;  // 20 KB (NQ 32) / 24 KB (NQ 64)
     __shared__ __attribute__((aligned(16))) char smem[2 * STAGE];
-    __shared__ int64_t pair_rel[kScanQueries];
+    __shared__ int64_t pair_rel[NQ];
     __shared__ int lds_task;
 
     const int lane = threadIdx.x & (kWave - 1);
@@ -907,7 +910,7 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(3, 3)))
         if (threadIdx.x == 0) next = atomicAdd(task_counter, 1);
         const ScanTask task = tasks[t];
         const int np = task.npairs;
-        if ((int)threadIdx.x < kScanQueries) {
+        if ((int)threadIdx.x < NQ) {
             // slots past the task's last query repeat that query
             const ScanPair pr = pairs[task.pair0 + ((int)threadIdx.x < np ? (int)threadIdx.x : np - 1)];
             pair_rel[threadIdx.x] = pr.out_rel + task.row0;
@@ -916,17 +919,18 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(3, 3)))
 #pragma unroll
         for (int j = 0; j < NDMA; j++) {
             const int crow = (wave + NW * j) * 8 + drow;  // row of the concatenation
-            if (crow < kScanQueries) {
+            if (crow < NQ) {
                 const ScanPair pr = pairs[task.pair0 + (crow < np ? crow : np - 1)];
                 src[j] = queries + (size_t)pr.query * row_bytes;
             } else {
-                const int r = crow - kScanQueries;
+                const int r = crow - NQ;
                 src[j] = rows + ((size_t)task.row0 + (size_t)(r < task.nrows ? r : task.nrows - 1)) * row_bytes;
             }
         }
         // tasks of <= 16 queries (most of them at ~10 queries per list) take the 16-wide MFMA shapes: half
         // the matrix-core time and half the query bytes through the DMA
         const bool narrow = np <= 16;
+        const bool upper = NQ > 32 && np > 32;  // the task's queries 32 .. 63 exist: the second tile of every wavefront
         // rows that another task streams again (a list probed by more than 32 queries of the batch) are fetched with
         // the default policy, so that the later pass can find them in the MALL; everything else past the caches
         // (headline, alternating runs on one box: scan 1.149 / 1.148 -> 1.107 / 1.129 ms)
@@ -936,12 +940,13 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(3, 3)))
             for (int j = 0; j < NDMA; j++) {
                 const int g8 = wave + NW * j;  // group of 8 rows
                 if (NGROUPS % NW != 0 && g8 >= NGROUPS) break;  // (uniform per wavefront)
-                if (narrow && (g8 == 2 || g8 == 3)) continue;    // query rows 16..31: not used
+                if (narrow && g8 >= 2 && g8 < NQ / 8) continue;    // query rows 16 .. NQ - 1: not used
+                if (NQ > 32 && !upper && g8 >= 4 && g8 < NQ / 8) continue;  // query rows 32 .. 63: not used
                 const int v = dpos ^ ((4 * (g8 & 1) + (drow >> 1)) & 7);  // slot p of row i holds vector p ^ ((i >> 1) & 7)
                 const int vi = sl * 8 + v;
                 const char *p = vi < nvec ? src[j] + (size_t)vi * sizeof(Raw16) : zeros16;
                 char *dst = smem + (size_t)buf * STAGE + (size_t)g8 * 8 * kSliceBytes;
-                if (NT && past_caches && g8 >= 4)
+                if (NT && past_caches && g8 >= NQ / 8)
                     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)p,
                                                      (__attribute__((address_space(3))) void *)dst, 16, 0, 2);
                 else
@@ -951,14 +956,98 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(3, 3)))
         };
         // pair table to registers (after the loop: a store followed by an LDS read makes hipcc wait for the store)
         const int j32 = wave * 32 + l31;
-        if (!narrow) {
+        if constexpr (NQ > 32) {
+          if (!narrow) {
+            // The 64-query form.  Two tiles per wavefront (queries 0-31 and, when the task has them, 32-63, against its 32
+            // rows) leave no room for four interleaved accumulators per output (2 x 64 registers: spills at three waves per
+            // SIMD): the four chains are the row's slices in four consecutive QUARTERS instead -- one accumulator per tile,
+            // closed into a second register set at every quarter's end, like mfma_dense_kernel.  Each chain holds at most
+            // ceil(slices / 4) x 32 (fp32) products: the bound of the candidates is scan_bound_chain (pgv_abi_ivf.hip).
+            f32x16 accl, accu, suml, sumu;
+#pragma unroll
+            for (int r = 0; r < 16; r++) {
+                accl[r] = 0.f;
+                accu[r] = 0.f;
+                suml[r] = 0.f;
+                sumu[r] = 0.f;
+            }
+            const int quarter = (nslices + 3) >> 2;
+            int in_quarter = 0;
+            const unsigned a_lane = (unsigned)l31 * kSliceBytes;                         // query l31 (upper tile: + 32 rows)
+            const unsigned b_lane = (unsigned)(NQ + wave * 32 + l31) * kSliceBytes;      // row wave * 32 + l31
+            issue_stage(0, 0);
+            for (int sl = 0; sl < nslices; sl++) {
+                __builtin_amdgcn_s_waitcnt(0x0070);  // vmcnt(0) lgkmcnt(0)
+                __builtin_amdgcn_s_barrier();
+                if (sl + 1 < nslices) issue_stage(sl + 1, (sl + 1) & 1);
+                const unsigned sbase = lds0 + (unsigned)(sl & 1) * STAGE;
+                if (upper) {
+#pragma unroll
+                    for (int c = 0; c < 4; c++) {
+                        const unsigned x = (((unsigned)(2 * c + half)) ^ sw) << 4;
+                        u32x4 a, au, b;
+                        asm volatile("ds_read_b128 %0, %3\n\tds_read_b128 %1, %3 offset:4096\n\tds_read_b128 %2, %4\n\t"
+                                     "s_waitcnt lgkmcnt(0)"
+                                     : "=&v"(a), "=&v"(au), "=&v"(b)
+                                     : "v"(sbase + a_lane + x), "v"(sbase + b_lane + x)
+                                     : "memory");
+                        Mma<T>::run(accl, a, b);
+                        Mma<T>::run(accu, au, b);
+                    }
+                } else {
+#pragma unroll
+                    for (int c = 0; c < 4; c++) {
+                        const unsigned x = (((unsigned)(2 * c + half)) ^ sw) << 4;
+                        u32x4 a, b;
+                        asm volatile("ds_read_b128 %0, %2\n\tds_read_b128 %1, %3\n\ts_waitcnt lgkmcnt(0)"
+                                     : "=&v"(a), "=&v"(b)
+                                     : "v"(sbase + a_lane + x), "v"(sbase + b_lane + x)
+                                     : "memory");
+                        Mma<T>::run(accl, a, b);
+                    }
+                }
+                if (++in_quarter == quarter) {
+                    in_quarter = 0;
+                    suml += accl;
+                    sumu += accu;
+#pragma unroll
+                    for (int r = 0; r < 16; r++) {
+                        accl[r] = 0.f;
+                        accu[r] = 0.f;
+                    }
+                }
+            }
+            suml += accl;  // (the open chain; zeros when the last quarter closed)
+            sumu += accu;
+            const int j32w = wave * 32 + l31;
+            if (j32w < task.nrows) {
+                const float rn = METRIC == 0 ? row_norms[task.row0 + j32w] : 0.f;
+                {
+                    int64_t rel[16];
+#pragma unroll
+                    for (int r = 0; r < 16; r++) rel[r] = pair_rel[(r & 3) + 8 * (r >> 2) + 4 * half];
+#pragma unroll
+                    for (int r = 0; r < 16; r++) out[rel[r] + j32w] = METRIC == 0 ? fmaf(-2.f, suml[r], rn) : -suml[r];
+                }
+                if (upper) {
+                    // (slots past the task's last query repeat that query: same value, same address)
+                    int64_t rel[16];
+#pragma unroll
+                    for (int r = 0; r < 16; r++) rel[r] = pair_rel[32 + (r & 3) + 8 * (r >> 2) + 4 * half];
+#pragma unroll
+                    for (int r = 0; r < 16; r++) out[rel[r] + j32w] = METRIC == 0 ? fmaf(-2.f, sumu[r], rn) : -sumu[r];
+                }
+            }
+          }
+        }
+        if (NQ == 32 && !narrow) {
             f32x16 acc4[4];
 #pragma unroll
             for (int e = 0; e < 4; e++)
 #pragma unroll
                 for (int r = 0; r < 16; r++) acc4[e][r] = 0.f;
             const unsigned a_lane = (unsigned)l31 * kSliceBytes;                                   // query l31
-            const unsigned b_lane = (unsigned)(kScanQueries + wave * 32 + l31) * kSliceBytes;      // row wave * 32 + l31
+            const unsigned b_lane = (unsigned)(NQ + wave * 32 + l31) * kSliceBytes;      // row wave * 32 + l31
             issue_stage(0, 0);
             for (int sl = 0; sl < nslices; sl++) {
                 // the slice has landed (a bare s_barrier: __syncthreads() does not reliably drain an LDS-DMA)
@@ -991,7 +1080,8 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(3, 3)))
                 for (int r = 0; r < 16; r++)
                     out[rel[r] + j32] = METRIC == 0 ? fmaf(-2.f, acc[r], rn) : -acc[r];
             }
-        } else {
+        }
+        if (narrow) {
             // 16 x 16 tiles: lane = (row or query l15, k-group kg); two row halves per wavefront
             const int l15 = lane & 15, kg = lane >> 4;
             const unsigned sw15 = (unsigned)(l15 >> 1) & 7u;
@@ -1002,7 +1092,7 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(3, 3)))
                 c14[e] = f32x4{0.f, 0.f, 0.f, 0.f};
             }
             const unsigned a_lane = (unsigned)l15 * kSliceBytes;
-            const unsigned b_lane = (unsigned)(kScanQueries + wave * 32 + l15) * kSliceBytes;  // second half: + 16 rows
+            const unsigned b_lane = (unsigned)(NQ + wave * 32 + l15) * kSliceBytes;  // second half: + 16 rows
             issue_stage(0, 0);
             for (int sl = 0; sl < nslices; sl++) {
                 __builtin_amdgcn_s_waitcnt(0x0070);  // vmcnt(0) lgkmcnt(0)
@@ -1094,6 +1184,8 @@ namespace pgv {
 
 int mfma_scan_rows_per_task() { return 32 * kScanWaves; }
 int mfma_scan_queries_per_task() { return kScanQueries; }
+// ... or twice that, when the lists of a batch are probed by more than ~12 queries on average (the 64-query form)
+int mfma_scan_queries_per_task_wide() { return 2 * kScanQueries; }
 
 int launch_row_norms(pgv_ctx *ctx, pgv_dtype dtype, const RowGeom &g, const void *rows, int64_t n, float *out,
                      unsigned *max_bits) {
@@ -1112,8 +1204,9 @@ int launch_row_norms(pgv_ctx *ctx, pgv_dtype dtype, const RowGeom &g, const void
 int launch_mfma_scan(pgv_ctx *ctx, pgv_metric metric, pgv_dtype dtype, const RowGeom &g, const void *rows,
                      const void *queries, const ScanTask *tasks, const int *ntasks_dev, int ntasks_bound,
                      const ScanPair *pairs, const float *row_norms, const float *query_norms, float *out,
-                     bool stream_rows) {
+                     bool stream_rows, int queries_per_task) {
     if (ntasks_bound <= 0) return PGV_OK;
+    if (queries_per_task != 32 && queries_per_task != 64) PGV_FAIL(PGV_ERR_ARG, "mfma scan: %d queries per task", queries_per_task);
     if (metric != PGV_L2SQ && metric != PGV_NEG_IP) PGV_FAIL(PGV_ERR_ARG, "mfma scan: L2 / inner product only");
     if (!ctx->zeros.p) {
         PGV_TRY(ctx->zeros.ensure(256));
@@ -1127,10 +1220,17 @@ int launch_mfma_scan(pgv_ctx *ctx, pgv_metric metric, pgv_dtype dtype, const Row
     int *counter = ctx->counters.as<int>() + 8;  // words 8, 9: claimed tasks, workgroups done (the kernel re-zeroes them)
     int grid = ctx->num_cus * 3;  // 41 KB of LDS per workgroup: three per CU
     if (grid > ntasks_bound) grid = ntasks_bound;
-#define PGV_MSCAN_NT(T, M, NT)                                                                                       \
-    hipLaunchKernelGGL((mfma_scan_kernel<T, M, kScanWaves, NT>), dim3(grid), dim3(kScanWaves * 64), 0, ctx->stream,   \
+#define PGV_MSCAN_Q(T, M, NT, Q)                                                                                        \
+    hipLaunchKernelGGL((mfma_scan_kernel<T, M, kScanWaves, NT, Q>), dim3(grid), dim3(kScanWaves * 64), 0, ctx->stream,   \
                        static_cast<const char *>(rows), static_cast<const char *>(queries), tasks, ntasks_dev, counter, \
                        pairs, row_norms, g.nvec, static_cast<const char *>(ctx->zeros.p), out)
+#define PGV_MSCAN_NT(T, M, NT)               \
+    do {                                     \
+        if (queries_per_task == 64)          \
+            PGV_MSCAN_Q(T, M, NT, 64);        \
+        else                                 \
+            PGV_MSCAN_Q(T, M, NT, 32);        \
+    } while (0)
 #define PGV_MSCAN(T, M)              \
     do {                             \
         if (stream_rows)             \
@@ -1151,6 +1251,7 @@ int launch_mfma_scan(pgv_ctx *ctx, pgv_metric metric, pgv_dtype dtype, const Row
     }
 #undef PGV_MSCAN
 #undef PGV_MSCAN_NT
+#undef PGV_MSCAN_Q
     PGV_HIP(hipGetLastError());
     return PGV_OK;
 }

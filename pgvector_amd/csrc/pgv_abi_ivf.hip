@@ -898,7 +898,17 @@ int scan_batch_dev(pgv_index *ix, const void *q_dev, int nq, const int32_t *prob
     const bool use_mfma = share > 3.0 && k <= 192 && !ctx->no_mfma_scan &&
                           (ix->metric == PGV_NEG_IP || (ix->metric == PGV_L2SQ && ix->row_norms));
     const bool use_tile = !use_mfma && tile_scan_supported(ix->geom) && share > 8.0;
-    const int qt = use_mfma ? mfma_scan_queries_per_task()
+    // lists probed by more than 32 queries of the batch are streamed once per group of `qt` queries: from ~12 queries per
+    // list on average (configs[2] / [4]: 1024 x 64 probes over 4096 lists = 16) enough lists pass 32 for the 64-query
+    // form of the kernel to pay (PGV_SCAN_WIDE = 0 / 1 forces it off / on: A/B)
+    static const int wide_env = [] {
+        const char *e = getenv("PGV_SCAN_WIDE");
+        return e ? atoi(e) : -1;
+    }();
+    // measured (10 M rows, lists 4096, probes 64, 1024 queries): 3072-d fp16 88.5 k -> 93.3 k QPS (scan 10.81 -> 10.19 ms); 1536-d
+    // fp32 84.3 k -> 84.5 k -- two fp32 tiles per stage fill make a task MFMA-bound, so fp32 keeps the 32-query form
+    const bool wide = use_mfma && (wide_env < 0 ? (share > 12.0 && ix->dtype == PGV_F16) : wide_env != 0);
+    const int qt = use_mfma ? (wide ? mfma_scan_queries_per_task_wide() : mfma_scan_queries_per_task())
                             : (use_tile ? tile_scan_queries_per_task()
                                         : scan_group_size(ix->geom, ix->dtype, (int)std::ceil(share)));
     constexpr int rpt_tiles = 20;  // tiles per task (measured best of 10 / 20 / 40 / 80 on the headline batch)
@@ -932,7 +942,7 @@ int scan_batch_dev(pgv_index *ix, const void *q_dev, int nq, const int32_t *prob
         if (use_mfma)
             PGV_TRY(launch_mfma_scan(ctx, ix->metric, ix->dtype, ix->geom, ix->vectors, q_dev, plan.tasks,
                                      plan.ntasks_dev, (int)plan.ntasks_bound, plan.pairs, ix->row_norms, nullptr,
-                                     seg_vals, rows_stream_past_caches(ix->geom, ix->dtype, ix->nrows)));
+                                     seg_vals, rows_stream_past_caches(ix->geom, ix->dtype, ix->nrows), qt));
         else if (use_tile)
             PGV_TRY(launch_tile_scan(ctx, ix->metric, ix->dtype, ix->geom, ix->vectors, q_dev, plan.tasks,
                                      plan.ntasks_dev, (int)plan.ntasks_bound, plan.pairs, seg_vals));
@@ -953,7 +963,9 @@ int scan_batch_dev(pgv_index *ix, const void *q_dev, int nq, const int32_t *prob
     if (approx) {
         // k' candidates by the expansion, their exact distances, the head; queries whose candidate
         // set cannot be proven complete (flags) take the exact pass over their whole segment
-        const ScanBound gamma = scan_bound(ctx, ix->geom.ld);
+        // (the 64-query form of the scan keeps its four chains as consecutive quarters of the row: whole 128-byte slices)
+        const ScanBound gamma = wide ? scan_bound_chain(ctx, ix->geom.ld, dense_chain_length(ix->geom, ix->dtype))
+                                     : scan_bound(ctx, ix->geom.ld);
         PGV_TRY(launch_topk_segments(ctx, seg_vals, plan.seg_start, nq, 0, kprime, cand_val, cand_pos, flags + nq));
         const ExactRows xr{ix->vectors, ix->tids, ix->list_offsets, ix->geom, ix->dtype,
                            reinterpret_cast<const unsigned *>(ix->row_norms + ix->nrows)};

@@ -355,7 +355,9 @@ int launch_row_norms(pgv_ctx *ctx, pgv_dtype dtype, const RowGeom &g, const void
                      unsigned *max_bits);
 int launch_mfma_scan(pgv_ctx *ctx, pgv_metric metric, pgv_dtype dtype, const RowGeom &g, const void *rows,
                      const void *queries, const ScanTask *tasks, const int *ntasks_dev, int ntasks_bound,
-                     const ScanPair *pairs, const float *row_norms, const float *query_norms, float *out, bool stream_rows);
+                     const ScanPair *pairs, const float *row_norms, const float *query_norms, float *out, bool stream_rows,
+                     int queries_per_task = 32);
+int mfma_scan_queries_per_task_wide();  // 64: tasks of the batches whose lists are probed by many queries each
 
 // kernels_build.hip: rows of 32-bit words gathered by index (the HNSW mirror's per-element payload)
 int launch_gather_words(pgv_ctx *ctx, const void *src, int words_per_row, int64_t nrows, const int64_t *idx, int n,

@@ -136,3 +136,58 @@ def test_exact_topk_on_128_tiles_is_the_sequential_scan(ctx, oracle, ops, dt, di
                           what="dense128 %s %s dim %d q %d" % (ops, dt, dim, i))
         if dist == "int":
             assert idx[i].tolist() == wt.astype(np.int64).tolist()      # ties resolved towards the lower row index
+
+
+# ------------------------------------------------------------------ the 64-query form of the batched list scan
+@pytest.mark.parametrize("ops,dt,dim,lists,probes,nq", [
+    ("l2", "f32", 128, 16, 8, 700),      # 700 x 8 / 16 = 350 queries per list: every task group is full (64)
+    ("ip", "f32", 96, 32, 6, 300),       # 56 per list: groups of 64 with ragged tails, some lists under 33 (lower tile only)
+    ("l2", "f16", 264, 24, 8, 260),      # halfvec, a row that is not whole slices
+    ("l2", "f32", 1536, 40, 10, 200),    # the headline's row shape, 50 per list
+    ("l2", "f32", 8, 12, 6, 150),        # exact ties (integer data): the recheck decides, lower position first
+])
+def test_the_64_query_scan_form_answers_like_the_oracle(ctx, oracle, ops, dt, dim, lists, probes, nq):
+    """mfma_scan_kernel<.., 64> (two tiles per wavefront, chains by quarters of the row; chosen for halfvec batches with more
+    than 12 queries per list on average, forced here for fp32 too by PGV_SCAN_WIDE=1 in the fixture's environment when set):
+    heads equal the oracle's GetScanLists + GetScanItems + sort for every query (src/ivfscan.c:47-187)"""
+    import torch
+    from oracle import pyoracle as po
+    from helpers import CpuIvf, assert_topk_equiv, gen
+    odt = po.ORA_F32 if dt == "f32" else po.ORA_F16
+    oops = po.OPS_L2 if ops == "l2" else po.OPS_IP
+    n = 6000
+    dist = "int" if dim == 8 else "clustered"
+    data = gen(n, dim, seed=971, dist=dist, dtype=odt, clusters=lists)
+    ivf = CpuIvf(oracle, oops, odt, data, lists)
+    ix = api.IvfIndex(ctx, ivf.metric, api.PGV_F32 if dt == "f32" else api.PGV_F16, dim, ivf.centers, ivf.list_offsets,
+                      ivf.vectors, ivf.tids)
+    queries = gen(nq, dim, seed=972, dist=dist, dtype=odt, clusters=lists)
+    try:
+        assert nq * probes / lists > 12
+        ctx.set_profiling(True)
+        ctx.reset_stats()
+        d, s, t = ix.search_batch(queries, probes, 10, want_tid=True)
+        st = ctx.stats()
+        ctx.set_profiling(False)
+        assert st["scan_launches"] >= 1
+        for i in range(nq):
+            wt, wd = oracle.search(ivf.struct, queries[i], probes, 10)
+            scale = 0.0
+            if ops == "ip":
+                scale = 1e-5 * float(np.max(np.abs(data.astype(np.float64)) @ np.abs(queries[i].astype(np.float64))))
+            assert_topk_equiv(np.asarray(t[i])[:len(wt)].astype(np.uint64).tolist(), np.asarray(d[i])[:len(wt)], wt.tolist(), wd,
+                              atol=max(scale, 1e-30), what="wide scan %s %s dim %d q %d" % (ops, dt, dim, i))
+    finally:
+        ix.close()
+
+
+def test_the_64_query_scan_form_for_fp32_too_in_a_process_that_forces_it():
+    """the default picks the 64-query form for halfvec only (fp32 wide tasks are MFMA-bound: no gain); PGV_SCAN_WIDE=1 -- read
+    once per process -- forces it everywhere: five shapes incl. fp32 L2 / IP and exact ties, every query against the oracle"""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "tests", "mp_wide_scan_worker.py")], capture_output=True, text=True,
+                       timeout=600, env=dict(os.environ, PGV_SCAN_WIDE="1"))
+    assert r.returncode == 0 and "WIDE-OK 5" in r.stdout, (r.stdout[-500:], r.stderr[-2000:])
