@@ -1,7 +1,8 @@
 /*
  * ref_stubs32.c -- symbols the reference's src/vector.c references from the parts of it that oracle/ref_glue32.c never
  * calls (text / binary I/O, casts, aggregates, _PG_init): each aborts if reached.  A file of its own so that it need
- * not agree with the stand-in headers' prototypes.  TEST INFRASTRUCTURE ONLY.
+ * not agree with the stand-in headers' prototypes.  -DPGV_REF_STUBS_IN_DRIVER (tests/c/ext_driver.c with the reference's
+ * ivfscan.c + vector.c linked in) leaves out what that program defines itself.  TEST INFRASTRUCTURE ONLY.
  */
 #include <stdio.h>
 #include <stdlib.h>
@@ -13,13 +14,25 @@ NOT_REACHED(ARR_ELEMTYPE)
 NOT_REACHED(ARR_HASNULL)
 NOT_REACHED(ARR_NDIM)
 NOT_REACHED(ArrayGetIntegerTypmods)
+#ifndef PGV_REF_STUBS_IN_DRIVER
 NOT_REACHED(BitvecInit)
+#endif
+#ifndef PGV_REF_STUBS_IN_DRIVER
 NOT_REACHED(DirectFunctionCall1Coll)
+#endif
+#ifndef PGV_REF_STUBS_IN_DRIVER
 NOT_REACHED(HalfvecInit)
+#endif
+#ifndef PGV_REF_STUBS_IN_DRIVER
 NOT_REACHED(HnswInit)
+#endif
 NOT_REACHED(InitBitVector)
+#ifndef PGV_REF_STUBS_IN_DRIVER
 NOT_REACHED(IvfflatInit)
+#endif
+#ifndef PGV_REF_STUBS_IN_DRIVER
 NOT_REACHED(PgvGpuInit)
+#endif
 NOT_REACHED(array_contains_nulls)
 NOT_REACHED(construct_array)
 NOT_REACHED(deconstruct_array)

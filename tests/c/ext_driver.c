@@ -1878,6 +1878,142 @@ backend_wide_build(void *arg)
 }
 
 /* ------------------------------------------------------------------------------------------------ the postmaster */
+#ifdef PGV_HAVE_REF_IVFSCAN
+/* ------------------------------------------------------------------------------------------------ the reference's own scan
+ * The program holds pgvector's src/ivfscan.c with ext/pgvector-0.8.6-gpu.patch applied and src/vector.c, compiled from the
+ * reference tree (tests/test_ext_runtime_cpu.py; not on the GPU box, where the tree does not exist): the functions below
+ * are the REFERENCE'S -- nothing of this file re-types them. */
+extern IndexScanDesc ivfflatbeginscan(Relation index, int nkeys, int norderbys);
+extern void ivfflatrescan(IndexScanDesc scan, ScanKey keys, int nkeys, ScanKey orderbys, int norderbys);
+extern bool ivfflatgettuple(IndexScanDesc scan, ScanDirection dir);
+extern void ivfflatendscan(IndexScanDesc scan);
+extern int	ivfflat_probes;
+extern int	ivfflat_iterative_scan;
+extern int	ivfflat_max_probes;
+extern int64 shim_index_scans_counted(void);
+
+/* ORDER BY embedding <-> q LIMIT want through the access method's own entry points */
+static int
+ref_scan(Relation index, const float *query, int probes, int want, uint64 *got, int *used_gpu)
+{
+	MemoryContext ctx = shim_query_context_begin();
+	ScanKeyData orderby;
+	IndexScanDesc scan;
+	int			n = 0;
+
+	ivfflat_probes = probes;
+	memset(&orderby, 0, sizeof(orderby));
+	orderby.sk_argument = PointerGetDatum(make_vector(query, DIM));
+	scan = ivfflatbeginscan(index, 0, 1);
+	ivfflatrescan(scan, NULL, 0, &orderby, 1);
+	*used_gpu = ((IvfflatScanOpaque) scan->opaque)->gpu != NULL;
+	while (n < want && ivfflatgettuple(scan, ForwardScanDirection))
+		got[n++] = tid_key(&scan->xs_heaptid);
+	ivfflatendscan(scan);
+	shim_query_context_end(ctx);
+	return n;
+}
+
+static int
+backend_reference_scan(void *arg)
+{
+	Relation	index = shim_open_relation(REL_IVF);
+	uint64	   *got = malloc(sizeof(uint64) * 30000);
+	float		q[DIM];
+	int64		scans0 = shim_index_scans_counted();
+	int			used_gpu;
+
+	(void) arg;
+	scenario = "the reference's own ivfflatgettuple";
+	/* (1) vector.gpu = off: GetScanLists, GetScanItems, the distance functions of src/vector.c and the sort are the
+	 * reference's, over the pages the build hooks wrote -- the oracle's restatement over the same pages must agree */
+	shim_set_guc_bool("vector.gpu", false);
+	for (int i = 0; i < 24; i++)
+	{
+		Expected	e;
+		int			want = i % 6 == 5 ? 30000 : (i % 6 == 4 ? 200 : 10);
+		int			n;
+
+		make_query(q, 300 + i);
+		e = expected_batch(REL_IVF, q, PROBES);
+		n = ref_scan(index, q, PROBES, want, got, &used_gpu);
+		EXPECT(!used_gpu);
+		EXPECT(n == (want < e.n ? want : e.n));
+		if (check_stream(&e, got, n, 0, "reference, CPU branch"))
+			return 1;
+		expected_free(&e);
+	}
+	EXPECT(shim_index_scans_counted() - scans0 == 24);
+	EXPECT(shim_pinned_buffers() == 0);
+	/* (2) vector.gpu = on: the same entry points; the hook lines inside them hand the scan to ext/ivfscan_gpu.c (own
+	 * context: the worker's mirror imported), heads, device windows and the whole batch */
+	shim_set_guc_bool("vector.gpu", true);
+	EXPECT(wait_for_gpu(index, 30.0) == 0);
+	{
+		int			served = 0;
+
+		for (int i = 0; i < 24; i++)
+		{
+			Expected	e;
+			int			want = i % 6 == 5 ? 30000 : (i % 6 == 4 ? 300 : 10);
+			int			n;
+
+			make_query(q, 400 + i);
+			e = expected_batch(REL_IVF, q, PROBES);
+			n = ref_scan(index, q, PROBES, want, got, &used_gpu);
+			served += used_gpu;
+			EXPECT(n == (want < e.n ? want : e.n));
+			if (check_stream(&e, got, n, 0, "reference, hooks"))
+				return 1;
+			expected_free(&e);
+		}
+		EXPECT(served == 24);
+	}
+	/* (3) the pooled path through the same entry points */
+	shim_set_guc_bool("vector.gpu_pooled", true);
+	for (int i = 0; i < 12; i++)
+	{
+		Expected	e;
+		int			want = i % 4 == 3 ? 150 : 10;	/* past the pooler's head: the scan goes on by itself */
+		int			n;
+
+		make_query(q, 500 + i);
+		e = expected_batch(REL_IVF, q, PROBES);
+		n = ref_scan(index, q, PROBES, want, got, &used_gpu);
+		EXPECT(used_gpu);
+		EXPECT(n == (want < e.n ? want : e.n));
+		if (check_stream(&e, got, n, 0, "reference, pooled"))
+			return 1;
+		expected_free(&e);
+	}
+	shim_set_guc_bool("vector.gpu_pooled", false);
+	/* (4) an iterative scan of the reference (ivfflat.iterative_scan = relaxed_order, src/ivfscan.c:400-406) with the hooks:
+	 * probes 3 of max_probes 9, every batch sorted by itself */
+	{
+		Expected	e3,
+					e6;
+		int			n;
+
+		ivfflat_iterative_scan = 1;
+		ivfflat_max_probes = 9;
+		make_query(q, 7);
+		e3 = expected_batch(REL_IVF, q, 3);
+		e6 = expected_batch(REL_IVF, q, 6);
+		n = ref_scan(index, q, 3, e6.n, got, &used_gpu);
+		EXPECT(used_gpu && n == e6.n);
+		if (check_stream(&e3, got, e3.n, 0, "reference, iterative: first batch"))
+			return 1;
+		ivfflat_iterative_scan = 0;
+		ivfflat_max_probes = 32768;
+		expected_free(&e3);
+		expected_free(&e6);
+	}
+	EXPECT(shim_pinned_buffers() == 0);
+	free(got);
+	return 0;
+}
+#endif
+
 static int
 run_phase(const char *name, int (*fn) (void *), int nprocs, void *const *args, double timeout_s)
 {
@@ -1891,7 +2027,10 @@ run_phase(const char *name, int (*fn) (void *), int nprocs, void *const *args, d
 	left = shim_postmaster_wait(pids, nprocs, codes, timeout_s);
 	for (int i = 0; i < nprocs; i++)
 		if (codes[i] != 0)
+		{
 			bad++;
+			fprintf(stderr, "  process %d of phase '%s' ended with code %d\n", i, name, codes[i]);
+		}
 	fprintf(stderr, "phase %-40s %d process(es): %s   (background workers alive: %d)\n", name, nprocs,
 			left ? "TIMED OUT" : (bad ? "FAILED" : "ok"), shim_live_bgworkers());
 	return left || bad;
@@ -1934,6 +2073,10 @@ main(void)
 	failed |= run_phase("CREATE INDEX through the build hooks", backend_build, 1, NULL, 300.0);
 	if (!failed)
 		failed |= run_phase("own-context scans", backend_scan_own, 1, NULL, 300.0);
+#ifdef PGV_HAVE_REF_IVFSCAN
+	if (!failed)
+		failed |= run_phase("the reference's own ivfflatgettuple", backend_reference_scan, 1, NULL, 300.0);
+#endif
 	if (!failed)
 	{
 		void	   *ids[6] = {(void *) 1, (void *) 2, (void *) 3, (void *) 4, (void *) 5, (void *) 6};

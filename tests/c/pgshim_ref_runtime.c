@@ -1,0 +1,514 @@
+/*
+ * pgshim_ref_runtime.c -- NOT PostgreSQL.  The server functions the REFERENCE'S OWN src/ivfscan.c (with
+ * ext/pgvector-0.8.6-gpu.patch applied) and src/vector.c reach when they RUN: tuplesort over (float8, tid) slots, virtual
+ * tuple slots, the pairing heap, fmgr calls, scan descriptors, child memory contexts.  Together with
+ * tests/c/pgshim_runtime.c (palloc, ereport, the buffer manager over the emulated 8 KB pages, relations, opclasses) this
+ * is enough for the reference's ivfflatbeginscan / ivfflatrescan / ivfflatgettuple / ivfflatendscan to execute unmodified:
+ * tests/c/ext_driver.c (phase "the reference's own ivfflatgettuple", -DPGV_HAVE_REF_IVFSCAN) runs them with vector.gpu off
+ * -- GetScanLists / GetScanItems / the sort of the REFERENCE against the oracle over the same pages -- and with vector.gpu
+ * on, where the hook lines inside them hand the scan to ext/ivfscan_gpu.c.
+ *
+ * Compiled only where the reference tree is mounted (tests/test_ext_runtime_cpu.py), against the patched reference's own
+ * ivfflat.h / hnsw.h -- and so are pgshim_runtime.c, ext_driver.c and ext/ in that build: one set of struct layouts.
+ * TEST INFRASTRUCTURE ONLY.
+ */
+#include "pgshim_runtime.h"
+#include "pgshim_ref.h"
+
+#include "ivfflat.h"
+
+#include <stdio.h>
+#include <stdlib.h>
+
+/* ------------------------------------------------------------------------------------------------ fmgr */
+struct FunctionCallInfoBaseData
+{
+	Datum		args[4];
+	int			nargs;
+};
+
+Datum
+pgshim_getarg(FunctionCallInfo fcinfo, int n)
+{
+	return fcinfo->args[n];
+}
+
+bool
+pgshim_argisnull(FunctionCallInfo fcinfo, int n)
+{
+	(void) fcinfo;
+	(void) n;
+	return false;
+}
+
+Datum
+FunctionCall1Coll(FmgrInfo *flinfo, Oid collation, Datum arg1)
+{
+	struct FunctionCallInfoBaseData fc = {{arg1, 0, 0, 0}, 1};
+
+	(void) collation;
+	return flinfo->fn_addr(&fc);
+}
+
+Datum
+FunctionCall2Coll(FmgrInfo *flinfo, Oid collation, Datum arg1, Datum arg2)
+{
+	struct FunctionCallInfoBaseData fc = {{arg1, arg2, 0, 0}, 2};
+
+	(void) collation;
+	return flinfo->fn_addr(&fc);
+}
+
+Datum
+DirectFunctionCall1Coll(PGFunction func, Oid collation, Datum arg1)
+{
+	struct FunctionCallInfoBaseData fc = {{arg1, 0, 0, 0}, 1};
+
+	(void) collation;
+	return func(&fc);
+}
+
+Datum
+DirectFunctionCall2Coll(PGFunction func, Oid collation, Datum arg1, Datum arg2)
+{
+	struct FunctionCallInfoBaseData fc = {{arg1, arg2, 0, 0}, 2};
+
+	(void) collation;
+	return func(&fc);
+}
+
+float8
+DatumGetFloat8(Datum x)
+{
+	double		d;
+
+	memcpy(&d, &x, sizeof(d));
+	return d;
+}
+
+Datum
+Float4GetDatum(float4 x)
+{
+	Datum		d = 0;
+
+	memcpy(&d, &x, sizeof(x));
+	return d;
+}
+
+float4
+DatumGetFloat4(Datum x)
+{
+	float		f;
+
+	memcpy(&f, &x, sizeof(f));
+	return f;
+}
+
+int
+pgshim_errcode(int sqlstate)
+{
+	(void) sqlstate;
+	return 0;
+}
+
+void
+float_overflow_error(void)
+{
+	elog(ERROR, "value out of range: overflow");
+	abort();
+}
+
+void
+float_underflow_error(void)
+{
+	elog(ERROR, "value out of range: underflow");
+	abort();
+}
+
+Size
+VARSIZE_ANY(const void *p)
+{
+	return (Size) (*(const uint32 *) p >> 2);	/* 4-byte headers only (SET_VARSIZE of pgshim_ref.h) */
+}
+
+/* ------------------------------------------------------------------------------------------------ memory */
+Size
+add_size(Size s1, Size s2)
+{
+	return s1 + s2;
+}
+
+Size
+mul_size(Size s1, Size s2)
+{
+	return s1 * s2;
+}
+
+MemoryContext
+AllocSetContextCreate(MemoryContext parent, const char *name, Size minContextSize, Size initBlockSize, Size maxBlockSize)
+{
+	(void) parent;
+	(void) name;
+	(void) minContextSize;
+	(void) initBlockSize;
+	(void) maxBlockSize;
+	return shim_context_create();
+}
+
+void
+MemoryContextDelete(MemoryContext context)
+{
+	shim_context_delete(context);
+}
+
+/* ------------------------------------------------------------------------------------------------ tuple descriptors, slots */
+struct TupleDescData
+{
+	int			natts;
+	Oid			types[4];
+};
+
+TupleDesc
+CreateTemplateTupleDesc(int natts)
+{
+	TupleDesc	d = palloc0(sizeof(struct TupleDescData));
+
+	d->natts = natts;
+	return d;
+}
+
+void
+TupleDescInitEntry(TupleDesc desc, AttrNumber attributeNumber, const char *attributeName, Oid oidtypeid, int32 typmod, int attdim)
+{
+	(void) attributeName;
+	(void) typmod;
+	(void) attdim;
+	desc->types[attributeNumber - 1] = oidtypeid;
+}
+
+struct TupleTableSlotOps
+{
+	int			kind;
+};
+const TupleTableSlotOps TTSOpsVirtual = {1};
+const TupleTableSlotOps TTSOpsMinimalTuple = {2};
+
+TupleTableSlot *
+MakeSingleTupleTableSlot(TupleDesc tupdesc, const TupleTableSlotOps *tts_ops)
+{
+	TupleTableSlot *slot = palloc0(sizeof(TupleTableSlot));
+
+	(void) tts_ops;
+	slot->tts_values = palloc0(sizeof(Datum) * 4);
+	slot->tts_isnull = palloc0(sizeof(bool) * 4);
+	(void) tupdesc;
+	return slot;
+}
+
+TupleTableSlot *
+ExecClearTuple(TupleTableSlot *slot)
+{
+	return slot;
+}
+
+TupleTableSlot *
+ExecStoreVirtualTuple(TupleTableSlot *slot)
+{
+	return slot;
+}
+
+Datum
+slot_getattr(TupleTableSlot *slot, int attnum, bool *isnull)
+{
+	*isnull = slot->tts_isnull[attnum - 1];
+	return slot->tts_values[attnum - 1];
+}
+
+/* ------------------------------------------------------------------------------------------------ tuplesort
+ * the scan's sort (InitScanSortState, src/ivfscan.c:238-247): attribute 1 a float8 key ascending, attribute 2 a TID by
+ * reference.  "Input data is always copied".  Equal keys keep their input order here (the server leaves it unspecified). */
+typedef struct SortEntry
+{
+	double		key;
+	ItemPointerData tid;
+	int64		seq;
+}			SortEntry;
+
+struct Tuplesortstate
+{
+	SortEntry  *e;
+	int64		n,
+				cap,
+				pos;
+};
+
+Tuplesortstate *
+tuplesort_begin_heap(TupleDesc tupDesc, int nkeys, AttrNumber *attNums, Oid *sortOperators, Oid *sortCollations,
+					 bool *nullsFirstFlags, int workMem, SortCoordinate coordinate, int sortopt)
+{
+	Tuplesortstate *st = palloc0(sizeof(Tuplesortstate));
+
+	(void) tupDesc;
+	(void) attNums;
+	(void) sortCollations;
+	(void) nullsFirstFlags;
+	(void) workMem;
+	(void) coordinate;
+	(void) sortopt;
+	if (nkeys != 1 || sortOperators[0] != Float8LessOperator)
+		elog(ERROR, "stand-in tuplesort: float8 ascending on attribute 1 only");
+	return st;
+}
+
+void
+tuplesort_puttupleslot(Tuplesortstate *state, TupleTableSlot *slot)
+{
+	if (state->n == state->cap)
+	{
+		state->cap = state->cap ? state->cap * 2 : 1024;
+		state->e = state->e ? repalloc_huge(state->e, sizeof(SortEntry) * (Size) state->cap)
+			: palloc_extended(sizeof(SortEntry) * (Size) state->cap, MCXT_ALLOC_HUGE);
+	}
+	state->e[state->n].key = DatumGetFloat8(slot->tts_values[0]);
+	state->e[state->n].tid = *(ItemPointer) DatumGetPointer(slot->tts_values[1]);
+	state->e[state->n].seq = state->n;
+	state->n++;
+}
+
+static int
+sort_entry_cmp(const void *a, const void *b)
+{
+	const SortEntry *x = a,
+			   *y = b;
+
+	/* float8 ordering: NaN after everything */
+	if (isnan(x->key) || isnan(y->key))
+	{
+		if (isnan(x->key) != isnan(y->key))
+			return isnan(x->key) ? 1 : -1;
+	}
+	else if (x->key != y->key)
+		return x->key < y->key ? -1 : 1;
+	return x->seq < y->seq ? -1 : (x->seq > y->seq ? 1 : 0);
+}
+
+void
+tuplesort_performsort(Tuplesortstate *state)
+{
+	if (state->n > 1)
+		qsort(state->e, (size_t) state->n, sizeof(SortEntry), sort_entry_cmp);
+	state->pos = 0;
+}
+
+bool
+tuplesort_gettupleslot(Tuplesortstate *state, bool forward, bool copy, TupleTableSlot *slot, Datum *abbrev)
+{
+	(void) forward;
+	(void) copy;
+	(void) abbrev;
+	if (state->pos >= state->n)
+		return false;
+	slot->tts_values[0] = Float8GetDatum(state->e[state->pos].key);
+	slot->tts_isnull[0] = false;
+	slot->tts_values[1] = PointerGetDatum(&state->e[state->pos].tid);
+	slot->tts_isnull[1] = false;
+	state->pos++;
+	return true;
+}
+
+void
+tuplesort_reset(Tuplesortstate *state)
+{
+	state->n = 0;
+	state->pos = 0;
+}
+
+void
+tuplesort_end(Tuplesortstate *state)
+{
+	if (state->e)
+		pfree(state->e);
+	state->e = NULL;
+	state->n = state->cap = state->pos = 0;
+}
+
+/* ------------------------------------------------------------------------------------------------ lib/pairingheap.c
+ * a max-heap by the caller's comparator (CompareLists of src/ivfscan.c:32-41 puts the LARGEST distance first) */
+pairingheap *
+pairingheap_allocate(pairingheap_comparator compare, void *arg)
+{
+	pairingheap *h = palloc0(sizeof(pairingheap));
+
+	h->ph_compare = compare;
+	h->ph_arg = arg;
+	return h;
+}
+
+static pairingheap_node *
+ph_merge(pairingheap *h, pairingheap_node *a, pairingheap_node *b)
+{
+	if (a == NULL)
+		return b;
+	if (b == NULL)
+		return a;
+	if (h->ph_compare(a, b, h->ph_arg) < 0)
+	{
+		pairingheap_node *t = a;
+
+		a = b;
+		b = t;
+	}
+	/* b becomes the first child of a */
+	b->next_sibling = a->first_child;
+	a->first_child = b;
+	return a;
+}
+
+void
+pairingheap_add(pairingheap *heap, pairingheap_node *node)
+{
+	node->first_child = node->next_sibling = node->prev_or_parent = NULL;
+	heap->ph_root = ph_merge(heap, heap->ph_root, node);
+}
+
+pairingheap_node *
+pairingheap_first(pairingheap *heap)
+{
+	return heap->ph_root;
+}
+
+pairingheap_node *
+pairingheap_remove_first(pairingheap *heap)
+{
+	pairingheap_node *top = heap->ph_root,
+			   *list,
+			   *acc = NULL;
+
+	if (top == NULL)
+		return NULL;
+	/* pair the children up left to right, then fold the pairs right to left */
+	list = top->first_child;
+	{
+		pairingheap_node *pairs = NULL;
+
+		while (list)
+		{
+			pairingheap_node *a = list,
+					   *b = a->next_sibling;
+
+			list = b ? b->next_sibling : NULL;
+			a->next_sibling = NULL;
+			if (b)
+				b->next_sibling = NULL;
+			a = ph_merge(heap, a, b);
+			a->next_sibling = pairs;	/* (a stack of the merged pairs) */
+			pairs = a;
+		}
+		while (pairs)
+		{
+			pairingheap_node *next = pairs->next_sibling;
+
+			pairs->next_sibling = NULL;
+			acc = ph_merge(heap, acc, pairs);
+			pairs = next;
+		}
+	}
+	heap->ph_root = acc;
+	top->first_child = top->next_sibling = NULL;
+	return top;
+}
+
+/* ------------------------------------------------------------------------------------------------ scans, buffers, stats */
+static struct SnapshotDataStandIn
+{
+	int			mvcc;
+}			the_snapshot = {1};
+
+IndexScanDesc
+RelationGetIndexScan(Relation indexRelation, int nkeys, int norderbys)
+{
+	IndexScanDesc scan = palloc0(sizeof(IndexScanDescData));
+
+	scan->indexRelation = indexRelation;
+	scan->xs_snapshot = (struct SnapshotData *) &the_snapshot;
+	scan->numberOfKeys = nkeys;
+	scan->numberOfOrderBys = norderbys;
+	scan->keyData = nkeys > 0 ? palloc0(sizeof(ScanKeyData) * (Size) nkeys) : NULL;
+	scan->orderByData = norderbys > 0 ? palloc0(sizeof(ScanKeyData) * (Size) norderbys) : NULL;
+	return scan;
+}
+
+bool
+IsMVCCSnapshot(Snapshot snapshot)
+{
+	return snapshot != NULL;
+}
+
+Buffer
+ReadBuffer(Relation reln, BlockNumber blockNum)
+{
+	return ReadBufferExtended(reln, MAIN_FORKNUM, blockNum, RBM_NORMAL, NULL);
+}
+
+BufferAccessStrategy
+GetAccessStrategy(BufferAccessStrategyType btype)
+{
+	(void) btype;
+	return NULL;
+}
+
+void
+FreeAccessStrategy(BufferAccessStrategy strategy)
+{
+	(void) strategy;
+}
+
+static int64 index_scans_counted;
+
+void
+pgstat_count_index_scan(Relation rel)
+{
+	(void) rel;
+	index_scans_counted++;
+}
+
+int64
+shim_index_scans_counted(void)
+{
+	return index_scans_counted;
+}
+
+/* ------------------------------------------------------------------------------------------------ the rest of pgvector
+ * globals of src/ivfflat.c and the one function of src/ivfutils.c the scan calls that pgshim_runtime.c does not have */
+int			work_mem = 4096;
+int			ivfflat_probes = 1;
+int			ivfflat_iterative_scan = 0;
+int			ivfflat_max_probes = 32768;
+
+/* src/ivfutils.c:72-80 */
+Datum
+IvfflatNormValue(const IvfflatTypeInfo * typeInfo, Oid collation, Datum value)
+{
+	return DirectFunctionCall1Coll(typeInfo->normalize, collation, value);
+}
+
+/* src/vector.c's _PG_init names them; nothing here calls _PG_init */
+void
+BitvecInit(void)
+{
+}
+
+void
+HalfvecInit(void)
+{
+}
+
+void
+HnswInit(void)
+{
+}
+
+void
+IvfflatInit(void)
+{
+}

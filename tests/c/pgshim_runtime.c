@@ -328,6 +328,25 @@ shim_query_context_begin(void)
 	return ctx;
 }
 
+/* a context of its own for whoever asks (AllocSetContextCreate of tests/c/pgshim_ref_runtime.c) */
+MemoryContext
+shim_context_create(void)
+{
+	MemoryContext ctx = calloc(1, sizeof(struct MemoryContextData));
+
+	ctx->name = "child";
+	return ctx;
+}
+
+void
+shim_context_delete(MemoryContext ctx)
+{
+	shim_context_reset(ctx);
+	if (CurrentMemoryContext == ctx)
+		CurrentMemoryContext = TopMemoryContext;
+	free(ctx);
+}
+
 void
 shim_query_context_end(MemoryContext ctx)
 {
@@ -903,6 +922,11 @@ shim_open_relation(Oid oid)
 		return NULL;
 	rel_objs[r - S->rels].rd_id = oid;
 	rel_objs[r - S->rels].rd_att = &one_column;
+	{
+		static Oid	no_collation[1] = {InvalidOid};
+
+		rel_objs[r - S->rels].rd_indcollation = no_collation;	/* (the reference's beginscan reads rd_indcollation[0]) */
+	}
 	return &rel_objs[r - S->rels];
 }
 
@@ -1628,11 +1652,11 @@ HnswOptionalProcInfo(Relation index, uint16 procnum)
 	return &proc_infos[r - S->rels][procnum & 7];
 }
 
-Datum
+__attribute__((weak)) Datum
 vector_negative_inner_product(PG_FUNCTION_ARGS)
 {
 	(void) fcinfo;
-	return 0;
+	return 0;					/* (a stand-in: never called; weak, so that the reference's src/vector.c can be linked in) */
 }
 
 Datum
@@ -1642,11 +1666,11 @@ halfvec_negative_inner_product(PG_FUNCTION_ARGS)
 	return 0;
 }
 
-Datum
+__attribute__((weak)) Datum
 l1_distance(PG_FUNCTION_ARGS)
 {
 	(void) fcinfo;
-	return 0;
+	return 0;					/* (a stand-in: never called; weak, so that the reference's src/vector.c can be linked in) */
 }
 
 Datum
@@ -1655,6 +1679,9 @@ halfvec_l1_distance(PG_FUNCTION_ARGS)
 	(void) fcinfo;
 	return 0;
 }
+
+/* the reference's own FUNCTION 1 of vector_l2_ops when src/vector.c is part of the program (tests/c/pgshim_ref_runtime.c) */
+extern Datum vector_l2_squared_distance(PG_FUNCTION_ARGS) __attribute__((weak));
 
 static Datum
 vector_l2_squared_distance_stub(PG_FUNCTION_ARGS)
@@ -1672,7 +1699,8 @@ index_getprocinfo(Relation irel, int attnum, uint16 procnum)
 	(void) attnum;
 	if (procnum == 1)
 		f->fn_addr = r->opc.distanceFn == 1 ? vector_negative_inner_product :
-			(r->opc.distanceFn == 2 ? l1_distance : vector_l2_squared_distance_stub);
+			(r->opc.distanceFn == 2 ? l1_distance :
+			 (vector_l2_squared_distance ? vector_l2_squared_distance : vector_l2_squared_distance_stub));
 	return f;
 }
 
@@ -1774,6 +1802,7 @@ shim_seed_random(uint64 seed)
 	rng_state = seed ? seed : 1;
 }
 
+#ifndef RandomDouble				/* (compiled against the reference's own ivfflat.h / hnsw.h they are macros over pg_prng) */
 double
 RandomDouble(void)
 {
@@ -1785,3 +1814,21 @@ RandomInt(void)
 {
 	return (int) (rng_next() >> 33);
 }
+#else
+/* common/pg_prng.h, as far as RandomDouble() / RandomInt() of the reference's headers go */
+pg_prng_state pg_global_prng_state;
+
+double
+pg_prng_double(pg_prng_state *state)
+{
+	(void) state;
+	return (double) (rng_next() >> 11) / 9007199254740992.0;
+}
+
+uint32
+pg_prng_uint32(pg_prng_state *state)
+{
+	(void) state;
+	return (uint32) (rng_next() >> 32);
+}
+#endif

@@ -71,6 +71,8 @@ size_t		shim_context_bytes(MemoryContext ctx);
 /* the next CHECK_FOR_INTERRUPTS after `after_checks` more calls raises "canceling statement due to user request" */
 void		shim_cancel_after(int after_checks);
 int			shim_pinned_buffers(void);	/* buffers this process holds pinned right now */
+MemoryContext shim_context_create(void);
+void		shim_context_delete(MemoryContext ctx);
 void		shim_set_guc_bool(const char *name, bool value);
 void		shim_set_guc_int(const char *name, int value);
 void		shim_relcache_invalidate(Oid relid);

@@ -50,3 +50,44 @@ def test_ext_glue_runs_on_the_stand_in_server(tmp_path, sanitize):
                   "worker ended (SIGTERM)", "hnsw scans", "hnsw: CREATE INDEX through the build hooks",
                   "vector_ip_ops: build + scans", "a backend without a device"):
         assert any(phase in line and ": ok" in line for line in r.stderr.splitlines()), (phase, r.stderr[-3000:])
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+REF = "/root/reference"
+PATCH = os.path.join(ROOT, "ext", "pgvector-0.8.6-gpu.patch")
+
+
+@pytest.mark.skipif(not os.path.isdir(os.path.join(REF, "src")), reason="the reference tree is not mounted here")
+def test_the_references_own_ivfflatgettuple_runs_with_the_hooks(tmp_path):
+    """the REFERENCE'S src/ivfscan.c with ext/pgvector-0.8.6-gpu.patch applied, and its
+    src/vector.c, compiled from the reference tree (never copied into this repository) and linked into the stand-in server
+    program with the glue -- everything against the patched reference's own ivfflat.h / hnsw.h.  Phase "the reference's own
+    ivfflatgettuple": with vector.gpu off the reference's GetScanLists / GetScanItems / distance functions / sort run over
+    the pages the build hooks wrote and must agree with the oracle's restatement over the same pages (heads, 200- and
+    whole-batch pulls); with vector.gpu on the hook lines INSIDE the reference's ivfflatbeginscan / rescan / gettuple /
+    endscan serve the scan from the (mock) device: own context, pooled, iterative."""
+    import shutil
+    src = tmp_path / "pgvector"
+    src.mkdir()
+    shutil.copytree(os.path.join(REF, "src"), src / "src")
+    shutil.copy(os.path.join(REF, "Makefile"), src / "Makefile")
+    r = subprocess.run(["patch", "-s", "-p1", "--fuzz=0", "-i", PATCH], cwd=src, capture_output=True, text=True)
+    assert r.returncode == 0, r.stdout + r.stderr
+    libdir = os.path.join(ROOT, "pgvector_amd", "lib")
+    oradir = os.path.join(ROOT, "oracle")
+    exe = str(tmp_path / "ext_driver_ref")
+    cmd = (["gcc", "-O1", "-g", "-std=gnu11", "-rdynamic", "-DPGV_HAVE_REF_IVFSCAN", "-DPGV_REF_STUBS_IN_DRIVER",
+            # the patched reference's own headers come FIRST: ivfflat.h / hnsw.h are the reference's for every file of the program
+            "-I" + str(src / "src"), "-I" + os.path.join(ROOT, "ext", "shim"), "-I" + os.path.join(ROOT, "ext"),
+            "-I" + os.path.join(ROOT, "include"), "-I" + os.path.join(ROOT, "tests", "c"),
+            "-I" + os.path.join(ROOT, "pgvector_amd", "host"), "-I" + oradir,
+            os.path.join(ROOT, "tests", "c", "ext_driver.c"), os.path.join(ROOT, "tests", "c", "pgshim_runtime.c"),
+            os.path.join(ROOT, "tests", "c", "pgshim_ref_runtime.c"), os.path.join(ROOT, "tests", "c", "mock_hip.c"),
+            os.path.join(oradir, "ref_stubs32.c"), str(src / "src" / "ivfscan.c"), str(src / "src" / "vector.c")] + EXT +
+           ["-o", exe, "-L" + libdir, "-lpgv_host", "-L" + oradir, "-loracle", "-lm", "-lpthread",
+            "-Wl,-rpath," + libdir, "-Wl,-rpath," + oradir])
+    b = subprocess.run(cmd, capture_output=True, text=True)
+    assert b.returncode == 0, b.stderr[-4000:]
+    r = subprocess.run([exe], capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0 and "EXT-RUNTIME OK" in r.stdout, (r.returncode, r.stdout[-500:], r.stderr[-3000:])
+    assert any("the reference's own ivfflatgettuple" in line and ": ok" in line for line in r.stderr.splitlines()), r.stderr[-3000:]
