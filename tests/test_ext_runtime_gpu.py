@@ -24,3 +24,24 @@ def test_ext_glue_runs_on_the_gpu(tmp_path):
             f.write(r.stdout + "\n---- stderr ----\n" + r.stderr)
     assert r.returncode == 0 and "EXT-RUNTIME OK" in r.stdout, (r.returncode, r.stdout[-500:], r.stderr[-4000:])
     assert "buffer refcount leak" not in r.stderr
+
+
+REF_DRIVER = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "oracle", "_ref", "ext_driver_ref_gpu")
+
+
+@pytest.mark.skipif(not os.path.exists(REF_DRIVER), reason="oracle/_ref/ext_driver_ref_gpu not built (the reference tree was absent)")
+def test_the_references_own_ivfflatgettuple_drives_the_hooks_on_the_gpu():
+    """oracle/_ref/ext_driver_ref_gpu (built by __graft_entry__.build() where the reference tree is mounted): the same
+    program with the REFERENCE'S patched src/ivfscan.c and src/vector.c linked in, against libpgv_hip.so.  Its phase "the
+    reference's own ivfflatgettuple": the reference's scan code over the emulated pages = the oracle (vector.gpu off), and
+    the hook lines inside ivfflatbeginscan / rescan / gettuple / endscan serving own-context, pooled and iterative scans
+    from the real device (vector.gpu on)."""
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    r = subprocess.run([REF_DRIVER], capture_output=True, text=True, timeout=900, env=env)
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    if os.path.isdir(os.path.join(root, "gpurun_out")):
+        with open(os.path.join(root, "gpurun_out", "ext_driver_ref_gpu.log"), "w") as f:
+            f.write(r.stdout + "\n---- stderr ----\n" + r.stderr)
+    assert r.returncode == 0 and "EXT-RUNTIME OK" in r.stdout, (r.returncode, r.stdout[-500:], r.stderr[-4000:])
+    assert any("the reference's own ivfflatgettuple" in line and ": ok" in line for line in r.stderr.splitlines()), r.stderr[-3000:]
