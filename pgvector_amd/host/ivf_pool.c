@@ -25,10 +25,11 @@
  * ONE SCAN AT A TIME (round 5).  A batch of b queries streams the lists its queries probe once: its time grows far
  * slower than b (1 M x 1536, probes 10 on MI355X: 16 queries 0.26 ms, 64: 0.71, 256: 1.10, 1024: 1.27), and two scans
  * that run side by side only share the HBM.  So a lane does not start its scan while another lane's is in flight: it
- * goes on collecting (everything that arrives during a scan shares the next one), and when the scan ends it lingers
- * until the clients that scan answered have come back with their next query or linger_us have passed -- with N
- * closed-loop clients the batches grow to N instead of settling at two groups of N / 2 scanned side by side
- * (256 client processes, round 4: two batches of ~122 in flight together, 85-120 k QPS, p50 1.7-1.9 ms).
+ * goes on collecting (everything that arrives during a scan shares the next one).  Closed-loop clients then settle into
+ * two groups that alternate -- one scanning while the other is on its way back -- instead of two batches scanned side
+ * by side (256 client processes, round 4: two batches of ~122 in flight together, 73-120 k QPS, p50 1.7-1.9 ms; now
+ * 104-136 k).  From POOL_LINGER_MIN (128) queries on, the batch that collected lingers up to linger_us after the scan's
+ * end for that scan's clients to come back and join it: same throughput, a quarter less latency (p50 1.63 vs 2.05 ms).
  * PGV_POOL_OVERLAP=1 in the environment of the process that initialises the segment brings the old behaviour back
  * (A/B measurements); PGV_POOL_LINGER_US overrides the 120 us.
  *
@@ -65,6 +66,7 @@ void		pgv_host_pool_destroy(pgv_pool * pool);
 #define POOL_READY_US 200000		/* a client between taking its slot and the end of its payload copy */
 #define POOL_LEADER_DEAD_US 3000000	/* a lane whose server has not looked for this long has lost it (it looks every 50 ms) */
 #define POOL_LINGER_US 120			/* after a scan: how long the next batch waits for that scan's clients to come back */
+#define POOL_LINGER_MIN 128			/* ... when the two groups together are at least this many queries */
 
 enum
 {
@@ -446,8 +448,13 @@ pgv_host_pool_serve(pgv_pool * pool, int lane, pgv_index * view)
 					else
 						s->scan_lane = -1;
 				}
-				/* the clients of the scan that has just ended are on their way back: give them linger_us to join */
-				if (!busy && s->exclusive && l->expect > 0 && l->count < l->expect && deadline < s->t_scan_done + s->linger_us)
+				/* the clients of the scan that has just ended are on their way back: give them linger_us to join -- when the
+				 * merged batch is large enough for the scan's time to dominate.  Fewer clients do better as two groups that
+				 * alternate, one scanning while the other is on its way back (64 client processes, same box: 71.8 k QPS in two
+				 * groups of 32 against 64.3 k merged; 256: 104 k / p50 2.05 ms in two groups against 105 k / p50 1.63 ms
+				 * merged): no linger below POOL_LINGER_MIN queries */
+				if (!busy && s->exclusive && l->expect >= POOL_LINGER_MIN && l->count < l->expect &&
+					deadline < s->t_scan_done + s->linger_us)
 					deadline = s->t_scan_done + s->linger_us;
 				/* everyone who queued while the lanes were busy joins (they are on their way: `arriving`), later
 				 * arrivals get max_wait_us */

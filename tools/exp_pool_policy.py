@@ -41,15 +41,18 @@ def main():
     out = {"cpu_max": open("/sys/fs/cgroup/cpu.max").read().strip() if os.path.exists("/sys/fs/cgroup/cpu.max") else None}
     if "pool" in what:
         out["pool"] = {}
-        for label, env, lanes in (("exclusive_2lanes_linger120", {}, 2), ("exclusive_3lanes_linger120", {}, 3),
-                                  ("exclusive_3lanes_linger250", {"PGV_POOL_LINGER_US": "250"}, 3),
-                                  ("exclusive_3lanes_linger60", {"PGV_POOL_LINGER_US": "60"}, 3),
-                                  ("overlap_2lanes (round 4)", {"PGV_POOL_OVERLAP": "1"}, 2)):
+        variants = (("exclusive_2lanes_linger120", {}, 2), ("exclusive_3lanes_linger120", {}, 3),
+                    ("exclusive_3lanes_linger250", {"PGV_POOL_LINGER_US": "250"}, 3),
+                    ("exclusive_3lanes_linger60", {"PGV_POOL_LINGER_US": "60"}, 3),
+                    ("overlap_2lanes (round 4)", {"PGV_POOL_OVERLAP": "1"}, 2))
+        if "poolquick" in what:
+            variants = (("exclusive_3lanes_linger120", {}, 3), ("exclusive_3lanes_no_linger", {"PGV_POOL_LINGER_US": "0"}, 3))
+        for label, env, lanes in variants:
             for kk in ("PGV_POOL_OVERLAP", "PGV_POOL_LINGER_US"):
                 os.environ.pop(kk, None)
             os.environ.update(env)
             row = {}
-            for nc in (16, 64, 256):
+            for nc in ((8, 16, 32, 64, 256) if "poolquick" in what else (16, 64, 256)):
                 try:
                     row[str(nc)] = _host.run_backend_processes(H.index, qh, H.probes, 10, 1, nc, max(60, 12000 // nc),
                                                                max_batch=1024, max_wait_us=50, lanes=lanes,
