@@ -558,6 +558,9 @@ pool_client_main(void *arg)
 	return NULL;
 }
 
+extern int	mock_hip_search_delay_us;
+extern int	mock_hip_search_peak(int reset);
+
 static int
 test_pool(void)
 {
@@ -620,6 +623,45 @@ test_pool(void)
 	/* one backend alone: a batch of one after the wait */
 	CHECK(pgv_host_pool_search(pool, queries, got_t, got_d));
 	EXPECT(memcmp(got_t, want_t, sizeof(uint64_t) * K) == 0);
+	/* ONE SCAN AT A TIME (round 5): three lanes, scans stretched to 2 ms, twelve clients -- the lanes' pgv_search_batch
+	 * calls never overlap, the batches that collect during a scan are larger for it, answers unchanged; with
+	 * PGV_POOL_OVERLAP=1 (round 4's policy, read when the segment is initialised) the lanes do scan side by side */
+	for (int mode = 0; mode < 2; mode++)
+	{
+		pgv_pool   *p3;
+		int64_t		b3,
+					q3;
+
+		if (mode == 1)
+			setenv("PGV_POOL_OVERLAP", "1", 1);
+		CHECK(pgv_host_pool_create(ix, 0, PGV_F32, DIM, 2, K, 64, 100, 3, &p3));
+		unsetenv("PGV_POOL_OVERLAP");
+		mock_hip_search_delay_us = 2000;
+		(void) mock_hip_search_peak(1);
+		memset(got_t, 0, sizeof(uint64_t) * NQ * K);
+		for (int t = 0; t < THREADS; t++)
+		{
+			cl[t] = (pool_client) {p3, queries, DIM, NQ, K, t, THREADS, got_t, got_d, PGV_OK};
+			pthread_create(&th[t], NULL, pool_client_main, &cl[t]);
+		}
+		for (int t = 0; t < THREADS; t++)
+		{
+			pthread_join(th[t], NULL);
+			EXPECT(cl[t].rc == PGV_OK);
+		}
+		mock_hip_search_delay_us = 0;
+		pgv_host_pool_stats(p3, &b3, &q3);
+		EXPECT(q3 == 3 * NQ);
+		EXPECT(memcmp(got_t, want_t, sizeof(uint64_t) * NQ * K) == 0);
+		if (mode == 0)
+		{
+			EXPECT(mock_hip_search_peak(1) == 1);
+			EXPECT(b3 <= 3 * NQ / 4);	/* twelve closed-loop clients in two alternating groups: ~6 queries a batch */
+		}
+		else
+			EXPECT(mock_hip_search_peak(1) >= 2);
+		pgv_host_pool_destroy(p3);
+	}
 	/* the views keep the arrays alive: drop the uploaded handle first */
 	pgv_index_free(ix);
 	CHECK(pgv_host_pool_search(pool, queries + DIM, got_t, got_d));

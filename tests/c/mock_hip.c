@@ -379,11 +379,34 @@ pgv_scan_lists(pgv_index * ix, const void *query, const int32_t *lists, int nlis
 }
 
 /* GetScanLists + GetScanItems + the head of the ascending sort for every query (stable: stream order on ties) */
+/* how many pgv_search_batch calls of this process ran at the same time, at most (the pooler's lanes are threads of one
+ * process in pgv_host_pool_create: "one scan at a time" is observable here); mock_hip_search_delay_us stretches a call */
+static int	searches_now,
+			searches_peak;
+int			mock_hip_search_delay_us = 0;
+
+int
+mock_hip_search_peak(int reset)
+{
+	int			peak = __atomic_load_n(&searches_peak, __ATOMIC_ACQUIRE);
+
+	if (reset)
+		__atomic_store_n(&searches_peak, 0, __ATOMIC_RELEASE);
+	return peak;
+}
+
 int
 pgv_search_batch(pgv_index * ix, const void *queries, int nq, int probes, int k, float *out_dist, int64_t *out_slot,
 				 uint64_t *out_tid)
 {
 	int32_t    *lists = malloc(sizeof(int32_t) * (size_t) probes);
+	int			now = __atomic_add_fetch(&searches_now, 1, __ATOMIC_ACQ_REL);
+	int			peak = __atomic_load_n(&searches_peak, __ATOMIC_RELAXED);
+
+	while (now > peak && !__atomic_compare_exchange_n(&searches_peak, &peak, now, 0, __ATOMIC_ACQ_REL, __ATOMIC_RELAXED))
+		;
+	if (mock_hip_search_delay_us > 0)
+		usleep((useconds_t) mock_hip_search_delay_us);
 	float	   *d = malloc(sizeof(float) * (size_t) (ix->n > 0 ? ix->n : 1));
 	int64_t    *s = malloc(sizeof(int64_t) * (size_t) (ix->n > 0 ? ix->n : 1));
 
@@ -413,6 +436,7 @@ pgv_search_batch(pgv_index * ix, const void *queries, int nq, int probes, int k,
 	free(lists);
 	free(d);
 	free(s);
+	__atomic_sub_fetch(&searches_now, 1, __ATOMIC_ACQ_REL);
 	return PGV_OK;
 }
 
