@@ -441,6 +441,9 @@ PgvHnswGetScanItems(IndexScanDesc scan, Datum value, List **out)
 			continue;
 		element = HnswInitElementFromBlock((BlockNumber) (etid >> 16), (OffsetNumber) (etid & 0xffff));
 		element->level = 0;
+		/* HnswInitElementFromBlock (src/hnswutils.c:282-293) sets blkno, offno and the two pointers and nothing else:
+		 * the count is the loader's to zero (src/hnswutils.c:498) */
+		element->heaptidsLength = 0;
 		for (uint32 t = 0; t < p[2] && t < HNSW_HEAPTIDS; t++)
 		{
 			uint64		ht = ((uint64) p[4 + 2 * t] << 32) | p[3 + 2 * t];

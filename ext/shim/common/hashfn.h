@@ -1,0 +1,1 @@
+#include "pgshim_ref.h"

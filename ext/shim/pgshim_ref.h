@@ -643,6 +643,22 @@ bool		scanner_isspace(char ch);
 char	   *pnstrdup(const char *in, Size len);
 #include <errno.h>
 
+/* common/hashfn.h, utils/memdebug.h */
+uint32		murmurhash32(uint32 data);
+uint64		murmurhash64(uint64 data);
+uint32		hash_bytes(const unsigned char *k, int keylen);
+#define VALGRIND_MAKE_MEM_DEFINED(addr, size) ((void) 0)
+#define VALGRIND_MAKE_MEM_NOACCESS(addr, size) ((void) 0)
+#define VALGRIND_MAKE_MEM_UNDEFINED(addr, size) ((void) 0)
+
+/* more of postgres_ext.h, access/genam.h, storage/bufmgr.h, port/atomics.h, nodes/pg_list.h, fmgr.h */
+#define OidIsValid(objectId) ((bool) ((objectId) != InvalidOid))
+Oid			index_getprocid(Relation irel, AttrNumber attnum, uint16 procnum);
+Size		BufferGetPageSize(Buffer buffer);
+#define pg_memory_barrier() __sync_synchronize()
+List	   *list_copy(const List *list);
+Datum		FunctionCall0Coll(FmgrInfo *flinfo, Oid collation);
+
 /* utils/datum.h */
 Datum		datumCopy(Datum value, bool typByVal, int typLen);
 bool		datumIsEqual(Datum value1, Datum value2, bool typByVal, int typLen);

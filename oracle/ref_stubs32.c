@@ -47,3 +47,15 @@ NOT_REACHED(pq_getmsgint)
 NOT_REACHED(pq_sendfloat4)
 NOT_REACHED(pq_sendint16)
 NOT_REACHED(scanner_isspace)
+
+#ifdef PGV_HAVE_REF_HNSW
+/* with the reference's src/hnswutils.c linked in as well (tests/c/ext_driver.c, phase "the reference's own hnswgettuple"):
+ * what its insert / update-meta-page half names and a scan never reaches */
+NOT_REACHED(GenericXLogStart)
+NOT_REACHED(GenericXLogRegisterBuffer)
+NOT_REACHED(GenericXLogFinish)
+NOT_REACHED(MarkBufferDirty)
+NOT_REACHED(PageInit)
+NOT_REACHED(halfvec_l2_normalize)
+NOT_REACHED(sparsevec_l2_normalize)
+#endif

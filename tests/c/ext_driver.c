@@ -2036,6 +2036,179 @@ run_phase(const char *name, int (*fn) (void *), int nprocs, void *const *args, d
 	return left || bad;
 }
 
+#ifdef PGV_HAVE_REF_HNSW
+/* ------------------------------------------------------------------------------------------------ the reference's own hnsw scan
+ * As above for HNSW: the program holds pgvector's src/hnswscan.c (patched) and the whole of its src/hnswutils.c.  The walk
+ * of the CPU branch -- HnswGetEntryPoint, HnswSearchLayer, HnswLoadElement, the visited table, the distance calls into
+ * src/vector.c -- is the REFERENCE'S, over the pages pgv_host_hnsw_write_index laid out. */
+extern IndexScanDesc hnswbeginscan(Relation index, int nkeys, int norderbys);
+extern void hnswrescan(IndexScanDesc scan, ScanKey keys, int nkeys, ScanKey orderbys, int norderbys);
+extern bool hnswgettuple(IndexScanDesc scan, ScanDirection dir);
+extern void hnswendscan(IndexScanDesc scan);
+extern int	hnsw_max_scan_tuples;
+
+/* ORDER BY embedding <-> q through hnswbeginscan / hnswrescan / hnswgettuple / hnswendscan; *reads = pages the scan asked for */
+static int
+ref_hnsw_scan(Relation index, const float *query, int want, uint64 *got, int *had_gpu, long *reads)
+{
+	MemoryContext ctx = shim_query_context_begin();
+	ScanKeyData orderby;
+	IndexScanDesc scan;
+	long		reads0;
+	int			n = 0;
+
+	memset(&orderby, 0, sizeof(orderby));
+	if (query)
+		orderby.sk_argument = PointerGetDatum(make_vector(query, DIM));
+	else
+		orderby.sk_flags = SK_ISNULL;
+	scan = hnswbeginscan(index, 0, 1);
+	hnswrescan(scan, NULL, 0, &orderby, 1);
+	*had_gpu = ((HnswScanOpaque) scan->opaque)->gpu != NULL;
+	reads0 = shim_buffer_reads();
+	while (n < want && hnswgettuple(scan, ForwardScanDirection))
+		got[n++] = tid_key(&scan->xs_heaptid);
+	*reads = shim_buffer_reads() - reads0;
+	hnswendscan(scan);
+	shim_query_context_end(ctx);
+	return n;
+}
+
+/* the stream of heap TIDs against the oracle's walk of the same graph: the distance at every position, the row itself
+ * wherever its distance is clear of its neighbours' */
+static int
+check_hnsw_stream(const float *data, const float *q, const uint64 *got, int n, const int64_t *rows, const double *dist, int want,
+				  const char *what)
+{
+	if (n != want)
+	{
+		fprintf(stderr, "%s: %d tuples, the oracle's walk has %d\n", what, n, want);
+		return 1;
+	}
+	for (int j = 0; j < n; j++)
+	{
+		int			r = row_of_tid(got[j]);
+		double		d = 0;
+
+		if (r < 0 || r >= HN)
+		{
+			fprintf(stderr, "%s: position %d is no heap tuple (%llx)\n", what, j, (unsigned long long) got[j]);
+			return 1;
+		}
+		for (int k = 0; k < DIM; k++)
+			d += ((double) data[(size_t) r * DIM + k] - q[k]) * ((double) data[(size_t) r * DIM + k] - q[k]);
+		if (fabs(d - dist[j]) > 1e-4 * fabs(dist[j]) + 1e-6)
+		{
+			fprintf(stderr, "%s: position %d row %d at %.7g, the oracle has row %d at %.7g\n", what, j, r, d, (int) rows[j], dist[j]);
+			return 1;
+		}
+		if ((j + 1 == n || fabs(dist[j + 1] - dist[j]) > 1e-4 * fabs(dist[j])) && (j == 0 || fabs(dist[j] - dist[j - 1]) > 1e-4 * fabs(dist[j])) &&
+			r != (int) rows[j])
+		{
+			fprintf(stderr, "%s: position %d is row %d, the oracle has row %d\n", what, j, r, (int) rows[j]);
+			return 1;
+		}
+	}
+	return 0;
+}
+
+static int
+backend_reference_hnsw_scan(void *arg)
+{
+	Relation	index = shim_open_relation(REL_HNSW);
+	float	   *data = malloc(sizeof(float) * HN * DIM);
+	ora_hnsw   *g;
+	uint64		got[64];
+	float		q[DIM];
+	int64_t		rows[40];
+	double		dist[40];
+	int64_t		scored;
+	int			had_gpu,
+				n,
+				want;
+	long		reads,
+				cpu_reads = 0;
+	double		until;
+
+	(void) arg;
+	scenario = "the reference's own hnswgettuple";
+	hnsw_ef_search = 40;
+	gen_rows(data, HN, DIM, 3);
+	g = ora_hnsw_build(ORA_OPS_L2, ORA_F32, DIM, data, HN, HM, 32, 9);	/* the graph REL_HNSW's pages hold */
+	/* (1) vector.gpu = off: the reference's walk over the pages = the oracle's walk over the graph */
+	shim_set_guc_bool("vector.gpu", false);
+	for (int i = 0; i < 30; i++)
+	{
+		make_query(q, 500 + i);
+		want = ora_hnsw_search(g, q, 40, 40, rows, dist, &scored);
+		n = ref_hnsw_scan(index, q, 64, got, &had_gpu, &reads);
+		EXPECT(!had_gpu && reads > 40);
+		cpu_reads += reads;
+		if (check_hnsw_stream(data, q, got, n, rows, dist, want, "reference hnsw, CPU branch"))
+			return 1;
+	}
+	/* (2) vector.gpu = on: hnswbeginscan takes the mirror, the hook line inside hnswgettuple hands the first batch to the
+	 * device walk -- and the reference's code below it (llast, heap TIDs off the element, list_delete_last) hands out
+	 * what the glue built.  No page of the index is read. */
+	shim_set_guc_bool("vector.gpu", true);
+	until = shim_now() + 30.0;
+	for (;;)
+	{
+		make_query(q, 500);
+		n = ref_hnsw_scan(index, q, 1, got, &had_gpu, &reads);
+		if (had_gpu || shim_now() > until)
+			break;
+		usleep(20000);			/* (the worker stages the graph at the first scan that asks) */
+	}
+	EXPECT(had_gpu);
+	for (int i = 0; i < 30; i++)
+	{
+		make_query(q, 500 + i);
+		want = ora_hnsw_search(g, q, 40, 40, rows, dist, &scored);
+		n = ref_hnsw_scan(index, q, 64, got, &had_gpu, &reads);
+		EXPECT(had_gpu && reads == 0);
+		if (check_hnsw_stream(data, q, got, n, rows, dist, want, "reference hnsw, hook"))
+			return 1;
+	}
+	/* (3) what the device walk does not serve goes down the reference's walk with the mirror attached: ORDER BY <-> NULL
+	 * (every distance 0: the scan still returns ef_search tuples) and an iterative scan past its first batch */
+	n = ref_hnsw_scan(index, NULL, 64, got, &had_gpu, &reads);
+	EXPECT(had_gpu && n == 40 && reads > 0);
+	hnsw_iterative_scan = 1;	/* HNSW_ITERATIVE_SCAN_RELAXED */
+	hnsw_max_scan_tuples = 20000;
+	{
+		uint64	   *all = malloc(sizeof(uint64) * HN);
+		int			seen = 0;
+		char	   *mark = calloc(HN, 1);
+
+		make_query(q, 531);
+		want = ora_hnsw_search(g, q, 40, 40, rows, dist, &scored);
+		n = ref_hnsw_scan(index, q, 400, all, &had_gpu, &reads);
+		EXPECT(had_gpu && n == 400 && reads > 40);
+		/* the first batch is the plain walk's; later batches never repeat a tuple */
+		if (check_hnsw_stream(data, q, all, 40, rows, dist, want, "reference hnsw, iterative, first batch"))
+			return 1;
+		for (int j = 0; j < n; j++)
+		{
+			int			r = row_of_tid(all[j]);
+
+			EXPECT(r >= 0 && r < HN && !mark[r]);
+			mark[r] = 1;
+			seen++;
+		}
+		EXPECT(seen == 400);
+		free(all);
+		free(mark);
+	}
+	hnsw_iterative_scan = HNSW_ITERATIVE_SCAN_OFF;
+	fprintf(stderr, "   30 walks of the reference's HnswSearchLayer = the oracle's (%.0f pages read per scan); 30 scans served by the hook with 0 pages read\n",
+			(double) cpu_reads / 30.0);
+	ora_hnsw_free(g);
+	free(data);
+	return 0;
+}
+#endif							/* PGV_HAVE_REF_HNSW */
+
 int
 main(void)
 {
@@ -2126,6 +2299,10 @@ main(void)
 		failed |= run_phase("hnsw: pages from the oracle's graph", backend_hnsw_build, 1, NULL, 120.0);
 	if (!failed)
 		failed |= run_phase("hnsw scans", backend_hnsw_scan, 1, NULL, 120.0);
+#ifdef PGV_HAVE_REF_HNSW
+	if (!failed)
+		failed |= run_phase("the reference's own hnswgettuple", backend_reference_hnsw_scan, 1, NULL, 300.0);
+#endif
 	if (!failed)
 		failed |= run_phase("hnsw: CREATE INDEX through the build hooks", backend_hnsw_gpu_build, 1, NULL, 300.0);
 	if (!failed)

@@ -17,8 +17,10 @@
 
 #include "ivfflat.h"
 
+#include <math.h>
 #include <stdio.h>
 #include <stdlib.h>
+#include <string.h>
 
 /* ------------------------------------------------------------------------------------------------ fmgr */
 struct FunctionCallInfoBaseData
@@ -512,3 +514,196 @@ void
 IvfflatInit(void)
 {
 }
+
+#ifdef PGV_HAVE_REF_HNSW
+/* ------------------------------------------------------------------------------------------------ for src/hnswscan.c + src/hnswutils.c
+ * (-DPGV_HAVE_REF_HNSW: the reference's own hnswbeginscan / hnswrescan / hnswgettuple / hnswendscan and the whole of its
+ * src/hnswutils.c -- HnswSearchLayer, HnswLoadElement, the visited tables -- are linked into the program.)  What they reach
+ * of the server and pgshim_runtime.c does not have: the pg_list calls over the runtime's List, page locks (nothing vacuums
+ * here), the two murmur finalizers simplehash is keyed with, datumCopy of a varlena, context reset / accounting. */
+int			hnsw_max_scan_tuples = 20000;
+double		hnsw_scan_mem_multiplier = 1;
+
+Datum
+FunctionCall0Coll(FmgrInfo *flinfo, Oid collation)
+{
+	struct FunctionCallInfoBaseData fc = {{0, 0, 0, 0}, 0};
+
+	(void) collation;
+	return flinfo->fn_addr(&fc);
+}
+
+int
+list_length(const List *l)
+{
+	return l ? l->length : 0;
+}
+
+void *
+linitial(const List *l)
+{
+	return l->elems[0];
+}
+
+void *
+llast(const List *l)
+{
+	return l->elems[l->length - 1];
+}
+
+List *
+list_delete_last(List *list)
+{
+	if (list == NIL || list->length <= 1)
+		return NIL;				/* (the cells go with their memory context) */
+	list->length--;
+	return list;
+}
+
+List *
+list_copy(const List *list)
+{
+	List	   *copy = NIL;
+
+	for (int i = 0; i < list_length(list); i++)
+		copy = lappend(copy, list->elems[i]);
+	return copy;
+}
+
+/* cells are the pointers themselves: a ListCell is one void * wide */
+void
+list_sort(List *list, int (*cmp) (const ListCell *a, const ListCell *b))
+{
+	_Static_assert(sizeof(ListCell) == sizeof(void *), "ListCell");
+	if (list_length(list) > 1)
+		qsort(list->elems, (size_t) list->length, sizeof(void *), (int (*) (const void *, const void *)) cmp);
+}
+
+ListCell *
+list_head(const List *l)
+{
+	return l && l->length > 0 ? (ListCell *) &l->elems[0] : NULL;
+}
+
+ListCell *
+lnext(const List *l, const ListCell *c)
+{
+	void	  **next = (void **) c + 1;
+
+	return next < l->elems + l->length ? (ListCell *) next : NULL;
+}
+
+void *
+pgshim_lfirst(const ListCell *lc)
+{
+	return lc->ptr_value;
+}
+
+void
+ItemPointerSet(ItemPointerData *pointer, BlockNumber blockNumber, OffsetNumber offNum)
+{
+	pointer->ip_blkid.bi_hi = (uint16) (blockNumber >> 16);
+	pointer->ip_blkid.bi_lo = (uint16) (blockNumber & 0xffff);
+	pointer->ip_posid = offNum;
+}
+
+void
+ItemPointerSetInvalid(ItemPointerData *pointer)
+{
+	ItemPointerSet(pointer, InvalidBlockNumber, InvalidOffsetNumber);
+}
+
+bool
+ItemPointerEquals(ItemPointer pointer1, ItemPointer pointer2)
+{
+	return pointer1->ip_blkid.bi_hi == pointer2->ip_blkid.bi_hi && pointer1->ip_blkid.bi_lo == pointer2->ip_blkid.bi_lo &&
+		pointer1->ip_posid == pointer2->ip_posid;
+}
+
+/* HNSW_SCAN_LOCK keeps vacuum's second pass away from a walk in progress; no vacuum runs in this program */
+void
+LockPage(Relation relation, BlockNumber blkno, LOCKMODE lockmode)
+{
+	(void) relation;
+	(void) blkno;
+	(void) lockmode;
+}
+
+void
+UnlockPage(Relation relation, BlockNumber blkno, LOCKMODE lockmode)
+{
+	(void) relation;
+	(void) blkno;
+	(void) lockmode;
+}
+
+Size
+BufferGetPageSize(Buffer buffer)
+{
+	(void) buffer;
+	return BLCKSZ;
+}
+
+float8
+get_float8_infinity(void)
+{
+	return (float8) INFINITY;
+}
+
+/* common/hashfn.h: the 32- and 64-bit murmur3 finalizers */
+uint32
+murmurhash32(uint32 data)
+{
+	uint32		h = data;
+
+	h ^= h >> 16;
+	h *= 0x85ebca6b;
+	h ^= h >> 13;
+	h *= 0xc2b2ae35;
+	h ^= h >> 16;
+	return h;
+}
+
+uint64
+murmurhash64(uint64 data)
+{
+	uint64		h = data;
+
+	h ^= h >> 33;
+	h *= 0xff51afd7ed558ccdull;
+	h ^= h >> 33;
+	h *= 0xc4ceb9fe1a85ec53ull;
+	h ^= h >> 33;
+	return h;
+}
+
+/* utils/datum.h: by-reference varlena values only (typByVal false, typLen -1: what hnswrescan copies the query with) */
+Datum
+datumCopy(Datum value, bool typByVal, int typLen)
+{
+	Size		size;
+	void	   *copy;
+
+	if (typByVal)
+		return value;
+	if (typLen != -1)
+		elog(ERROR, "datumCopy: typLen %d", typLen);
+	size = VARSIZE_ANY(DatumGetPointer(value));
+	copy = palloc(size);
+	memcpy(copy, DatumGetPointer(value), size);
+	return PointerGetDatum(copy);
+}
+
+void
+MemoryContextReset(MemoryContext context)
+{
+	shim_context_reset(context);
+}
+
+Size
+MemoryContextMemAllocated(MemoryContext context, bool recurse)
+{
+	(void) recurse;
+	return shim_context_bytes(context);
+}
+#endif							/* PGV_HAVE_REF_HNSW */

@@ -1020,6 +1020,14 @@ static int	npins = 0;
 #define BUF_REL(b) (((b) - 1) >> 24)
 #define BUF_BLK(b) ((uint32) (((b) - 1) & 0xFFFFFF))
 
+static long buffer_reads;		/* pages this process asked the buffer manager for */
+
+long
+shim_buffer_reads(void)
+{
+	return buffer_reads;
+}
+
 Buffer
 ReadBufferExtended(Relation reln, ForkNumber forkNum, BlockNumber blockNum, ReadBufferMode mode, BufferAccessStrategy strategy)
 {
@@ -1034,6 +1042,7 @@ ReadBufferExtended(Relation reln, ForkNumber forkNum, BlockNumber blockNum, Read
 	if (npins == MAX_PINS)
 		ereport(ERROR, (errmsg("too many buffers pinned")));
 	b = (Buffer) (((int) (r - S->rels) << 24) | (int) blockNum) + 1;
+	buffer_reads++;
 	pins[npins].buf = b;
 	pins[npins++].locked = false;
 	return b;
@@ -1206,13 +1215,6 @@ pg_detoast_datum(struct varlena *datum)
 }
 
 /* ------------------------------------------------------------------------------------------------ lists */
-struct List
-{
-	int			length,
-				cap;
-	void	  **elems;
-};
-
 List *
 lappend(List *list, void *datum)
 {
@@ -1606,7 +1608,9 @@ halfvec_item_size(int dimensions)
 }
 
 static IvfflatTypeInfo ivf_type_infos[SHIM_MAX_RELS];
+#ifndef PGV_HAVE_REF_HNSW
 static HnswTypeInfo hnsw_type_infos[SHIM_MAX_RELS];
+#endif
 static FmgrInfo proc_infos[SHIM_MAX_RELS][8];
 
 const IvfflatTypeInfo *
@@ -1620,6 +1624,7 @@ IvfflatGetTypeInfo(Relation index)
 	return t;
 }
 
+#ifndef PGV_HAVE_REF_HNSW		/* (with -DPGV_HAVE_REF_HNSW the reference's own src/hnswutils.c is linked in and has them) */
 const HnswTypeInfo *
 HnswGetTypeInfo(Relation index)
 {
@@ -1628,6 +1633,7 @@ HnswGetTypeInfo(Relation index)
 	hnsw_type_infos[r - S->rels].maxDimensions = r->opc.maxDimensions;
 	return &hnsw_type_infos[r - S->rels];
 }
+#endif
 
 /* src/ivfutils.c:46-52: NULL when the opclass has no such support function */
 FmgrInfo *
@@ -1642,6 +1648,7 @@ IvfflatOptionalProcInfo(Relation index, uint16 procnum)
 	return &proc_infos[r - S->rels][procnum & 7];
 }
 
+#ifndef PGV_HAVE_REF_HNSW
 FmgrInfo *
 HnswOptionalProcInfo(Relation index, uint16 procnum)
 {
@@ -1651,6 +1658,7 @@ HnswOptionalProcInfo(Relation index, uint16 procnum)
 		return NULL;
 	return &proc_infos[r - S->rels][procnum & 7];
 }
+#endif
 
 __attribute__((weak)) Datum
 vector_negative_inner_product(PG_FUNCTION_ARGS)
@@ -1704,6 +1712,21 @@ index_getprocinfo(Relation irel, int attnum, uint16 procnum)
 	return f;
 }
 
+/* what the reference's HnswOptionalProcInfo (src/hnswutils.c:103-110) asks before index_getprocinfo: the vector opclasses
+ * have a distance function, a norm function where the opclass normalizes, and no type-info function (procnum 3) */
+Oid
+index_getprocid(Relation irel, int16 attnum, uint16 procnum)
+{
+	ShimRel    *r = rel_of(irel);
+
+	(void) attnum;
+	if (procnum == 1)
+		return 1;
+	if (procnum == 2)
+		return r->opc.hasNormProc ? 2 : InvalidOid;
+	return InvalidOid;
+}
+
 /* src/ivfutils.c:150-175: dimensions and lists off the meta page (block 0) */
 void
 IvfflatGetMetaPageInfo(Relation index, int *lists, int *dimensions)
@@ -1728,13 +1751,19 @@ IvfflatGetMetaPageInfo(Relation index, int *lists, int *dimensions)
 		*dimensions = d;
 }
 
+#ifndef PGV_HAVE_REF_HNSW		/* (the reference's own src/hnswutils.c otherwise) */
 HnswElement
 HnswInitElementFromBlock(BlockNumber blkno, OffsetNumber offno)
 {
-	HnswElement e = palloc0(sizeof(HnswElementData));
+	HnswElement e = palloc(sizeof(HnswElementData));
+	char	   *base = NULL;
 
+	/* src/hnswutils.c:282-293 sets these four fields of a palloc'd (NOT zeroed) element; the rest is the caller's */
+	memset(e, 0x5a, sizeof(HnswElementData));
 	e->blkno = blkno;
 	e->offno = offno;
+	HnswPtrStore(base, e->neighbors, (HnswNeighborArrayPtr *) NULL);
+	HnswPtrStore(base, e->value, (char *) NULL);
 	return e;
 }
 
@@ -1784,6 +1813,8 @@ HnswInitElement(char *base, ItemPointer heaptid, int m, double ml, int maxLevel,
 	HnswPtrStore(base, element->value, (char *) NULL);
 	return element;
 }
+
+#endif
 
 static uint64 rng_state = 0x9E3779B97F4A7C15ull;
 

@@ -78,9 +78,17 @@ void		shim_set_guc_int(const char *name, int value);
 void		shim_relcache_invalidate(Oid relid);
 void		shim_run_proc_exit(int code);	/* before_shmem_exit + on_proc_exit callbacks (a clean backend exit) */
 double		shim_now(void);
+/* the List of this runtime (lappend of pgshim_runtime.c; the list_* of pgshim_ref_runtime.c work on the same cells) */
+struct List
+{
+	int			length,
+				cap;
+	void	  **elems;
+};
 int			shim_list_length(const List *l);
 void	   *shim_list_nth(const List *l, int n);
 int			shim_pin_leaks(void);
+long		shim_buffer_reads(void);	/* ReadBuffer calls of this process so far */
 void		shim_seed_random(uint64 seed);
 
 #endif

@@ -65,7 +65,14 @@ def test_the_references_own_ivfflatgettuple_runs_with_the_hooks(tmp_path):
     ivfflatgettuple": with vector.gpu off the reference's GetScanLists / GetScanItems / distance functions / sort run over
     the pages the build hooks wrote and must agree with the oracle's restatement over the same pages (heads, 200- and
     whole-batch pulls); with vector.gpu on the hook lines INSIDE the reference's ivfflatbeginscan / rescan / gettuple /
-    endscan serve the scan from the (mock) device: own context, pooled, iterative."""
+    endscan serve the scan from the (mock) device: own context, pooled, iterative.
+
+    The same for HNSW (-DPGV_HAVE_REF_HNSW): the reference's patched src/hnswscan.c and its WHOLE src/hnswutils.c are linked
+    in too.  Phase "the reference's own hnswgettuple": the reference's HnswSearchLayer / HnswLoadElement / visited table
+    over the pages pgv_host_hnsw_write_index laid out = the oracle's walk of the same graph (which pins the page writer and
+    the oracle's walk to the reference's code), and with vector.gpu on the hook line inside hnswgettuple serves the scan
+    without one page read; NULL queries and iterative scans go down the reference's walk with the mirror attached.  The
+    build phases of the program then run on the reference's own HnswInitElement / HnswAlloc / HnswAddHeapTid."""
     import shutil
     src = tmp_path / "pgvector"
     src.mkdir()
@@ -76,14 +83,16 @@ def test_the_references_own_ivfflatgettuple_runs_with_the_hooks(tmp_path):
     libdir = os.path.join(ROOT, "pgvector_amd", "lib")
     oradir = os.path.join(ROOT, "oracle")
     exe = str(tmp_path / "ext_driver_ref")
-    cmd = (["gcc", "-O1", "-g", "-std=gnu11", "-rdynamic", "-DPGV_HAVE_REF_IVFSCAN", "-DPGV_REF_STUBS_IN_DRIVER",
+    cmd = (["gcc", "-O1", "-g", "-std=gnu11", "-rdynamic", "-DPGV_HAVE_REF_IVFSCAN", "-DPGV_HAVE_REF_HNSW",
+            "-DPGV_REF_STUBS_IN_DRIVER",
             # the patched reference's own headers come FIRST: ivfflat.h / hnsw.h are the reference's for every file of the program
             "-I" + str(src / "src"), "-I" + os.path.join(ROOT, "ext", "shim"), "-I" + os.path.join(ROOT, "ext"),
             "-I" + os.path.join(ROOT, "include"), "-I" + os.path.join(ROOT, "tests", "c"),
             "-I" + os.path.join(ROOT, "pgvector_amd", "host"), "-I" + oradir,
             os.path.join(ROOT, "tests", "c", "ext_driver.c"), os.path.join(ROOT, "tests", "c", "pgshim_runtime.c"),
             os.path.join(ROOT, "tests", "c", "pgshim_ref_runtime.c"), os.path.join(ROOT, "tests", "c", "mock_hip.c"),
-            os.path.join(oradir, "ref_stubs32.c"), str(src / "src" / "ivfscan.c"), str(src / "src" / "vector.c")] + EXT +
+            os.path.join(oradir, "ref_stubs32.c"), str(src / "src" / "ivfscan.c"), str(src / "src" / "vector.c"),
+            str(src / "src" / "hnswscan.c"), str(src / "src" / "hnswutils.c")] + EXT +
            ["-o", exe, "-L" + libdir, "-lpgv_host", "-L" + oradir, "-loracle", "-lm", "-lpthread",
             "-Wl,-rpath," + libdir, "-Wl,-rpath," + oradir])
     b = subprocess.run(cmd, capture_output=True, text=True)
@@ -91,3 +100,4 @@ def test_the_references_own_ivfflatgettuple_runs_with_the_hooks(tmp_path):
     r = subprocess.run([exe], capture_output=True, text=True, timeout=900)
     assert r.returncode == 0 and "EXT-RUNTIME OK" in r.stdout, (r.returncode, r.stdout[-500:], r.stderr[-3000:])
     assert any("the reference's own ivfflatgettuple" in line and ": ok" in line for line in r.stderr.splitlines()), r.stderr[-3000:]
+    assert any("the reference's own hnswgettuple" in line and ": ok" in line for line in r.stderr.splitlines()), r.stderr[-3000:]
