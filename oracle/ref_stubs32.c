@@ -59,3 +59,16 @@ NOT_REACHED(PageInit)
 NOT_REACHED(halfvec_l2_normalize)
 NOT_REACHED(sparsevec_l2_normalize)
 #endif
+
+#ifdef PGV_HAVE_REF_IVFUTILS
+/* src/ivfutils.c's page-append half (IvfflatAppendPage, IvfflatUpdateList): no scan or k-means reaches it */
+NOT_REACHED(GenericXLogAbort)
+NOT_REACHED(BufferGetBlockNumber)
+#ifndef PGV_HAVE_REF_HNSW
+NOT_REACHED(GenericXLogStart)
+NOT_REACHED(GenericXLogRegisterBuffer)
+NOT_REACHED(GenericXLogFinish)
+NOT_REACHED(MarkBufferDirty)
+NOT_REACHED(PageInit)
+#endif
+#endif

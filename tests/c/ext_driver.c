@@ -2209,6 +2209,155 @@ backend_reference_hnsw_scan(void *arg)
 }
 #endif							/* PGV_HAVE_REF_HNSW */
 
+#ifdef PGV_HAVE_REF_IVFUTILS
+/* ------------------------------------------------------------------------------------------------ the reference's own k-means
+ * The program holds pgvector's src/ivfkmeans.c (patched: the PgvIvfflatKmeans line in IvfflatKmeans) and the whole of its
+ * src/ivfutils.c, compiled with the reference's own OPTFLAGS.  vector.gpu off: InitCenters, ElkanKmeans, ComputeNewCenters,
+ * CheckCenters are the REFERENCE'S; handed the oracle's pg_prng stream, they must leave the centers the oracle's
+ * restatement (oracle_ivf.c ora_kmeans) leaves from the same seed -- bit for bit -- having drawn the same number of
+ * values.  vector.gpu on: the same IvfflatKmeans call is served by the hook. */
+extern void IvfflatKmeans(Relation index, VectorArray samples, VectorArray centers, const IvfflatTypeInfo * typeInfo, Size memoryUsed);
+extern VectorArray VectorArrayInit(int maxlen, int dimensions, Size itemsize);
+
+static double
+kmeans_objective(const float *rows, int n, const float *centers, int k, int spherical)
+{
+	double		total = 0;
+
+	for (int i = 0; i < n; i++)
+	{
+		double		best = DBL_MAX;
+
+		for (int c = 0; c < k; c++)
+		{
+			double		d = 0;
+
+			for (int j = 0; j < DIM; j++)
+			{
+				double		a = rows[(size_t) i * DIM + j],
+							b = centers[(size_t) c * DIM + j];
+
+				d += spherical ? -a * b : (a - b) * (a - b);
+			}
+			if (d < best)
+				best = d;
+		}
+		total += spherical ? 1.0 + best : best;
+	}
+	return total;
+}
+
+static int
+reference_kmeans_case(Oid relid, int ops, int n, int k, uint64 seed)
+{
+	Relation	index = shim_open_relation(relid);
+	MemoryContext ctx = shim_query_context_begin();
+	const IvfflatTypeInfo *typeInfo = IvfflatGetTypeInfo(index);	/* the reference's (src/ivfutils.c) */
+	Size		itemsize = typeInfo->itemSize(DIM);
+	VectorArray samples = VectorArrayInit(n > 0 ? n : 1, DIM, itemsize);
+	VectorArray centers = VectorArrayInit(k, DIM, itemsize);
+	float	   *rows = malloc(sizeof(float) * (size_t) (n > 0 ? n : 1) * DIM);
+	float	   *want = malloc(sizeof(float) * (size_t) k * DIM);
+	float	   *got = malloc(sizeof(float) * (size_t) k * DIM);
+	ora_prng	a,
+				b;
+	int			iterations;
+	double		elkan,
+				hooked;
+
+	EXPECT(itemsize == offsetof(Vector, x) + sizeof(float) * DIM);
+	gen_rows(rows, n, DIM, seed);
+	for (int i = 0; i < n; i++)
+	{
+		Vector	   *v = (Vector *) VectorArrayGet(samples, i);
+
+		if (ops != ORA_OPS_L2)
+		{
+			/* SampleCallback normalises the samples of opclasses with a KMEANS_NORM proc (src/ivfbuild.c:148-156) */
+			double		norm = 0.0;
+
+			for (int d = 0; d < DIM; d++)
+				norm += (double) rows[(size_t) i * DIM + d] * (double) rows[(size_t) i * DIM + d];
+			norm = sqrt(norm);
+			for (int d = 0; d < DIM && norm > 0.0; d++)
+				rows[(size_t) i * DIM + d] = (float) ((double) rows[(size_t) i * DIM + d] / norm);
+		}
+		v->vl_len_ = (int32) (itemsize << 2);
+		v->dim = DIM;
+		memcpy(v->x, rows + (size_t) i * DIM, sizeof(float) * DIM);
+	}
+	samples->length = n;
+
+	shim_set_guc_bool("vector.gpu", false);
+	ora_prng_seed(&a, seed);
+	shim_prng_hook(ora_prng_double_cb, ora_prng_u32_cb, &a);
+	IvfflatKmeans(index, samples, centers, typeInfo, 0);
+	shim_prng_hook(NULL, NULL, NULL);
+	EXPECT(centers->length == k);
+	ora_prng_seed(&b, seed);
+	iterations = ora_kmeans(ops, ORA_F32, DIM, rows, n, want, k, &b, NULL);
+	EXPECT(iterations >= 0);
+	EXPECT(a.s0 == b.s0 && a.s1 == b.s1);	/* the same number of draws */
+	for (int c = 0; c < k; c++)
+	{
+		Vector	   *v = (Vector *) VectorArrayGet(centers, c);
+
+		EXPECT(v->dim == DIM);
+		memcpy(got + (size_t) c * DIM, v->x, sizeof(float) * DIM);
+		if (memcmp(v->x, want + (size_t) c * DIM, sizeof(float) * DIM) != 0)
+		{
+			fprintf(stderr, "reference k-means (n %d, k %d, ops %d): center %d differs from the oracle's: %.9g vs %.9g ...\n", n, k, ops,
+					c, v->x[0], want[(size_t) c * DIM]);
+			return 1;
+		}
+	}
+	elkan = n > 0 ? kmeans_objective(rows, n, got, k, ops != ORA_OPS_L2) : 0.0;
+
+	/* the hook line: IvfflatKmeans -> PgvIvfflatKmeans -> pgv_kmeans; CheckCenters of the reference then passes over what
+	 * came back (no NaN, no duplicates, unit norm for spherical k-means) or raises */
+	if (n > 0)
+	{
+		shim_set_guc_bool("vector.gpu", true);
+		centers->length = 0;
+		IvfflatKmeans(index, samples, centers, typeInfo, 0);
+		EXPECT(centers->length == k);
+		for (int c = 0; c < k; c++)
+			memcpy(got + (size_t) c * DIM, ((Vector *) VectorArrayGet(centers, c))->x, sizeof(float) * DIM);
+		hooked = kmeans_objective(rows, n, got, k, ops != ORA_OPS_L2);
+		fprintf(stderr, "   n %5d k %3d %s: the reference's ElkanKmeans = the oracle's, bit for bit (%d iterations); objective %.6g, through the hook %.6g\n",
+				n, k, ops == ORA_OPS_L2 ? "l2" : "ip", iterations, elkan, hooked);
+		/* the device's k-means (k-means++ from the same draws, Lloyd to a fixed point) lands where Elkan's does or close
+		 * by; the mock device's is twenty Lloyd steps from a strided start and only has to be a clustering at all */
+		EXPECT(hooked <= elkan * (mock_hip_set_arena ? 8.0 : 1.10) + 1e-6);
+	}
+	else
+		fprintf(stderr, "   n %5d k %3d %s: RandomCenters = the oracle's, bit for bit\n", n, k, ops == ORA_OPS_L2 ? "l2" : "ip");
+	free(rows);
+	free(want);
+	free(got);
+	shim_query_context_end(ctx);
+	return 0;
+}
+
+static int
+backend_reference_kmeans(void *arg)
+{
+	(void) arg;
+	scenario = "the reference's own IvfflatKmeans";
+	if (reference_kmeans_case(REL_IVF, ORA_OPS_L2, 2000, 20, 77))
+		return 1;
+	if (reference_kmeans_case(REL_IVF, ORA_OPS_L2, 5000, 100, 78))
+		return 1;
+	if (reference_kmeans_case(REL_IVF, ORA_OPS_L2, 30, 64, 79))	/* fewer samples than lists: empty clusters are re-drawn */
+		return 1;
+	if (reference_kmeans_case(REL_IVF, ORA_OPS_L2, 0, 16, 80))	/* an empty table: RandomCenters */
+		return 1;
+	if (reference_kmeans_case(REL_IP, ORA_OPS_IP, 3000, 40, 81))	/* spherical k-means */
+		return 1;
+	return 0;
+}
+#endif							/* PGV_HAVE_REF_IVFUTILS */
+
 int
 main(void)
 {
@@ -2307,6 +2456,10 @@ main(void)
 		failed |= run_phase("hnsw: CREATE INDEX through the build hooks", backend_hnsw_gpu_build, 1, NULL, 300.0);
 	if (!failed)
 		failed |= run_phase("vector_ip_ops: build + scans", backend_ip_opclass, 1, NULL, 300.0);
+#ifdef PGV_HAVE_REF_IVFUTILS
+	if (!failed)
+		failed |= run_phase("the reference's own IvfflatKmeans", backend_reference_kmeans, 1, NULL, 300.0);
+#endif
 	if (!failed && mock_hip_set_arena)
 		failed |= run_phase("a backend without a device", backend_no_device, 1, NULL, 120.0);
 	shim_postmaster_shutdown();

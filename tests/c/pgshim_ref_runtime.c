@@ -487,12 +487,23 @@ int			ivfflat_probes = 1;
 int			ivfflat_iterative_scan = 0;
 int			ivfflat_max_probes = 32768;
 
+#ifndef PGV_HAVE_REF_IVFUTILS
 /* src/ivfutils.c:72-80 */
 Datum
 IvfflatNormValue(const IvfflatTypeInfo * typeInfo, Oid collation, Datum value)
 {
 	return DirectFunctionCall1Coll(typeInfo->normalize, collation, value);
 }
+#else
+/* with the reference's src/ivfutils.c + src/ivfkmeans.c linked in (-DPGV_HAVE_REF_IVFUTILS) */
+int			maintenance_work_mem = 65536;
+
+Size
+VARSIZE(const void *p)
+{
+	return VARSIZE_ANY(p);
+}
+#endif
 
 /* src/vector.c's _PG_init names them; nothing here calls _PG_init */
 void

@@ -1595,6 +1595,7 @@ shim_postmaster_shutdown(void)
 }
 
 /* ------------------------------------------------------------------------------------------------ pgvector's own */
+#ifndef PGV_HAVE_REF_IVFUTILS
 static Size
 vector_item_size(int dimensions)
 {
@@ -1606,13 +1607,17 @@ halfvec_item_size(int dimensions)
 {
 	return offsetof(Vector, x) + sizeof(uint16) * (Size) dimensions;
 }
+#endif
 
+#ifndef PGV_HAVE_REF_IVFUTILS
 static IvfflatTypeInfo ivf_type_infos[SHIM_MAX_RELS];
+#endif
 #ifndef PGV_HAVE_REF_HNSW
 static HnswTypeInfo hnsw_type_infos[SHIM_MAX_RELS];
 #endif
 static FmgrInfo proc_infos[SHIM_MAX_RELS][8];
 
+#ifndef PGV_HAVE_REF_IVFUTILS	/* (with -DPGV_HAVE_REF_IVFUTILS the reference's own src/ivfutils.c is linked in and has them) */
 const IvfflatTypeInfo *
 IvfflatGetTypeInfo(Relation index)
 {
@@ -1623,6 +1628,7 @@ IvfflatGetTypeInfo(Relation index)
 	t->itemSize = r->opc.maxDimensions == IVFFLAT_MAX_DIM * 2 ? halfvec_item_size : vector_item_size;
 	return t;
 }
+#endif
 
 #ifndef PGV_HAVE_REF_HNSW		/* (with -DPGV_HAVE_REF_HNSW the reference's own src/hnswutils.c is linked in and has them) */
 const HnswTypeInfo *
@@ -1635,6 +1641,7 @@ HnswGetTypeInfo(Relation index)
 }
 #endif
 
+#ifndef PGV_HAVE_REF_IVFUTILS
 /* src/ivfutils.c:46-52: NULL when the opclass has no such support function */
 FmgrInfo *
 IvfflatOptionalProcInfo(Relation index, uint16 procnum)
@@ -1647,6 +1654,7 @@ IvfflatOptionalProcInfo(Relation index, uint16 procnum)
 		return NULL;
 	return &proc_infos[r - S->rels][procnum & 7];
 }
+#endif
 
 #ifndef PGV_HAVE_REF_HNSW
 FmgrInfo *
@@ -1698,6 +1706,12 @@ vector_l2_squared_distance_stub(PG_FUNCTION_ARGS)
 	return 0;
 }
 
+/* FUNCTION 3 / 4 / 2 of the ivfflat vector opclasses (sql/vector.sql: l2_distance or vector_spherical_distance, vector_norm):
+ * there when the reference's src/vector.c is linked in, NULL in the plain build -- whose glue never calls through them */
+extern Datum l2_distance(PG_FUNCTION_ARGS) __attribute__((weak));
+extern Datum vector_spherical_distance(PG_FUNCTION_ARGS) __attribute__((weak));
+extern Datum vector_norm(PG_FUNCTION_ARGS) __attribute__((weak));
+
 FmgrInfo *
 index_getprocinfo(Relation irel, int attnum, uint16 procnum)
 {
@@ -1709,11 +1723,16 @@ index_getprocinfo(Relation irel, int attnum, uint16 procnum)
 		f->fn_addr = r->opc.distanceFn == 1 ? vector_negative_inner_product :
 			(r->opc.distanceFn == 2 ? l1_distance :
 			 (vector_l2_squared_distance ? vector_l2_squared_distance : vector_l2_squared_distance_stub));
+	else if (r->opc.am == 0 && procnum == 3)
+		f->fn_addr = r->opc.distanceFn == 0 ? l2_distance : vector_spherical_distance;
+	else if (procnum == 2 || (r->opc.am == 0 && procnum == 4))
+		f->fn_addr = vector_norm;
 	return f;
 }
 
-/* what the reference's HnswOptionalProcInfo (src/hnswutils.c:103-110) asks before index_getprocinfo: the vector opclasses
- * have a distance function, a norm function where the opclass normalizes, and no type-info function (procnum 3) */
+/* what the reference's IvfflatOptionalProcInfo / HnswOptionalProcInfo (src/ivfutils.c:46-52, src/hnswutils.c:103-110) ask
+ * before index_getprocinfo.  ivfflat: 1 distance, 2 norm, 3 k-means distance, 4 k-means norm, 5 type info; hnsw: 1 distance,
+ * 2 norm, 3 type info.  The vector opclasses have no type-info function. */
 Oid
 index_getprocid(Relation irel, int16 attnum, uint16 procnum)
 {
@@ -1724,9 +1743,14 @@ index_getprocid(Relation irel, int16 attnum, uint16 procnum)
 		return 1;
 	if (procnum == 2)
 		return r->opc.hasNormProc ? 2 : InvalidOid;
+	if (r->opc.am == 0 && procnum == 3)
+		return 3;
+	if (r->opc.am == 0 && procnum == 4)
+		return r->opc.hasKmeansNormProc ? 4 : InvalidOid;
 	return InvalidOid;
 }
 
+#ifndef PGV_HAVE_REF_IVFUTILS
 /* src/ivfutils.c:150-175: dimensions and lists off the meta page (block 0) */
 void
 IvfflatGetMetaPageInfo(Relation index, int *lists, int *dimensions)
@@ -1750,6 +1774,7 @@ IvfflatGetMetaPageInfo(Relation index, int *lists, int *dimensions)
 	if (dimensions)
 		*dimensions = d;
 }
+#endif
 
 #ifndef PGV_HAVE_REF_HNSW		/* (the reference's own src/hnswutils.c otherwise) */
 HnswElement
@@ -1848,11 +1873,26 @@ RandomInt(void)
 #else
 /* common/pg_prng.h, as far as RandomDouble() / RandomInt() of the reference's headers go */
 pg_prng_state pg_global_prng_state;
+static double (*prng_double_hook) (void *);
+static uint32_t (*prng_u32_hook) (void *);
+static void *prng_hook_state;
+
+/* draws come from the caller's generator from now on (NULLs: back to this file's): a test that runs the reference's
+ * k-means beside the oracle's hands both the same pg_prng stream */
+void
+shim_prng_hook(double (*next_double) (void *), uint32_t (*next_u32) (void *), void *state)
+{
+	prng_double_hook = next_double;
+	prng_u32_hook = next_u32;
+	prng_hook_state = state;
+}
 
 double
 pg_prng_double(pg_prng_state *state)
 {
 	(void) state;
+	if (prng_double_hook)
+		return prng_double_hook(prng_hook_state);
 	return (double) (rng_next() >> 11) / 9007199254740992.0;
 }
 
@@ -1860,6 +1900,8 @@ uint32
 pg_prng_uint32(pg_prng_state *state)
 {
 	(void) state;
+	if (prng_u32_hook)
+		return prng_u32_hook(prng_hook_state);
 	return (uint32) (rng_next() >> 32);
 }
 #endif

@@ -90,5 +90,7 @@ void	   *shim_list_nth(const List *l, int n);
 int			shim_pin_leaks(void);
 long		shim_buffer_reads(void);	/* ReadBuffer calls of this process so far */
 void		shim_seed_random(uint64 seed);
+/* (reference-linked builds only) pg_prng_double / pg_prng_uint32 draw from the caller's generator; NULLs restore the runtime's */
+void		shim_prng_hook(double (*next_double) (void *), uint32_t (*next_u32) (void *), void *state);
 
 #endif

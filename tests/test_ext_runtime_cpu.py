@@ -72,32 +72,20 @@ def test_the_references_own_ivfflatgettuple_runs_with_the_hooks(tmp_path):
     over the pages pgv_host_hnsw_write_index laid out = the oracle's walk of the same graph (which pins the page writer and
     the oracle's walk to the reference's code), and with vector.gpu on the hook line inside hnswgettuple serves the scan
     without one page read; NULL queries and iterative scans go down the reference's walk with the mirror attached.  The
-    build phases of the program then run on the reference's own HnswInitElement / HnswAlloc / HnswAddHeapTid."""
-    import shutil
-    src = tmp_path / "pgvector"
-    src.mkdir()
-    shutil.copytree(os.path.join(REF, "src"), src / "src")
-    shutil.copy(os.path.join(REF, "Makefile"), src / "Makefile")
-    r = subprocess.run(["patch", "-s", "-p1", "--fuzz=0", "-i", PATCH], cwd=src, capture_output=True, text=True)
-    assert r.returncode == 0, r.stdout + r.stderr
-    libdir = os.path.join(ROOT, "pgvector_amd", "lib")
-    oradir = os.path.join(ROOT, "oracle")
-    exe = str(tmp_path / "ext_driver_ref")
-    cmd = (["gcc", "-O1", "-g", "-std=gnu11", "-rdynamic", "-DPGV_HAVE_REF_IVFSCAN", "-DPGV_HAVE_REF_HNSW",
-            "-DPGV_REF_STUBS_IN_DRIVER",
-            # the patched reference's own headers come FIRST: ivfflat.h / hnsw.h are the reference's for every file of the program
-            "-I" + str(src / "src"), "-I" + os.path.join(ROOT, "ext", "shim"), "-I" + os.path.join(ROOT, "ext"),
-            "-I" + os.path.join(ROOT, "include"), "-I" + os.path.join(ROOT, "tests", "c"),
-            "-I" + os.path.join(ROOT, "pgvector_amd", "host"), "-I" + oradir,
-            os.path.join(ROOT, "tests", "c", "ext_driver.c"), os.path.join(ROOT, "tests", "c", "pgshim_runtime.c"),
-            os.path.join(ROOT, "tests", "c", "pgshim_ref_runtime.c"), os.path.join(ROOT, "tests", "c", "mock_hip.c"),
-            os.path.join(oradir, "ref_stubs32.c"), str(src / "src" / "ivfscan.c"), str(src / "src" / "vector.c"),
-            str(src / "src" / "hnswscan.c"), str(src / "src" / "hnswutils.c")] + EXT +
-           ["-o", exe, "-L" + libdir, "-lpgv_host", "-L" + oradir, "-loracle", "-lm", "-lpthread",
-            "-Wl,-rpath," + libdir, "-Wl,-rpath," + oradir])
-    b = subprocess.run(cmd, capture_output=True, text=True)
-    assert b.returncode == 0, b.stderr[-4000:]
+    build phases of the program then run on the reference's own HnswInitElement / HnswAlloc / HnswAddHeapTid.
+
+    And for the k-means (-DPGV_HAVE_REF_IVFUTILS): the reference's patched src/ivfkmeans.c and its WHOLE src/ivfutils.c,
+    compiled with the reference's own OPTFLAGS.  Phase "the reference's own IvfflatKmeans": handed the oracle's pg_prng
+    stream, the reference's InitCenters / ElkanKmeans / ComputeNewCenters / RandomCenters leave the centers the oracle's
+    ora_kmeans leaves from the same seed, BIT FOR BIT, after the same number of draws (l2 and spherical, fewer samples than
+    lists, an empty table); with vector.gpu on the hook line inside IvfflatKmeans serves the same call and the reference's
+    CheckCenters passes over the result."""
+    import __graft_entry__ as entry     # ONE recipe: the program the GPU box runs is built by the same function
+    exe = entry.build_reference_driver(dict(os.environ), out=str(tmp_path / "ext_driver_ref"), mock=True)
+    assert exe is not None
     r = subprocess.run([exe], capture_output=True, text=True, timeout=900)
     assert r.returncode == 0 and "EXT-RUNTIME OK" in r.stdout, (r.returncode, r.stdout[-500:], r.stderr[-3000:])
     assert any("the reference's own ivfflatgettuple" in line and ": ok" in line for line in r.stderr.splitlines()), r.stderr[-3000:]
     assert any("the reference's own hnswgettuple" in line and ": ok" in line for line in r.stderr.splitlines()), r.stderr[-3000:]
+    assert any("the reference's own IvfflatKmeans" in line and ": ok" in line for line in r.stderr.splitlines()), r.stderr[-3000:]
+    assert r.stderr.count("bit for bit") == 5, r.stderr[-3000:]

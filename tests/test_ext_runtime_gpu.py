@@ -32,8 +32,8 @@ REF_DRIVER = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file
 @pytest.mark.skipif(not os.path.exists(REF_DRIVER), reason="oracle/_ref/ext_driver_ref_gpu not built (the reference tree was absent)")
 def test_the_references_own_gettuple_functions_drive_the_hooks_on_the_gpu():
     """oracle/_ref/ext_driver_ref_gpu (built by __graft_entry__.build() where the reference tree is mounted): the same
-    program with the REFERENCE'S patched src/ivfscan.c and src/hnswscan.c, its src/hnswutils.c and src/vector.c linked in,
-    against libpgv_hip.so.  Its phase "the
+    program with the REFERENCE'S patched src/ivfscan.c, src/hnswscan.c and src/ivfkmeans.c, its src/ivfutils.c,
+    src/hnswutils.c and src/vector.c linked in, against libpgv_hip.so.  Its phase "the
     reference's own ivfflatgettuple": the reference's scan code over the emulated pages = the oracle (vector.gpu off), and
     the hook lines inside ivfflatbeginscan / rescan / gettuple / endscan serving own-context, pooled and iterative scans
     from the real device (vector.gpu on)."""
@@ -47,3 +47,4 @@ def test_the_references_own_gettuple_functions_drive_the_hooks_on_the_gpu():
     assert r.returncode == 0 and "EXT-RUNTIME OK" in r.stdout, (r.returncode, r.stdout[-500:], r.stderr[-4000:])
     assert any("the reference's own ivfflatgettuple" in line and ": ok" in line for line in r.stderr.splitlines()), r.stderr[-3000:]
     assert any("the reference's own hnswgettuple" in line and ": ok" in line for line in r.stderr.splitlines()), r.stderr[-3000:]
+    assert any("the reference's own IvfflatKmeans" in line and ": ok" in line for line in r.stderr.splitlines()), r.stderr[-3000:]
