@@ -649,6 +649,23 @@ int			pgv_hnsw_build_search(pgv_hnsw * h, const int32_t *elements, const int32_t
 								  int32_t *out_ids, float *out_dist, int32_t *out_count);
 
 /*
+ * HnswFindElementNeighbors whole (src/hnswutils.c:1280-1357) for a batch of elements being inserted: the searches of
+ * pgv_hnsw_build_search, then SelectNeighbors (:1064-1165; CheckElementCloser :1040-1059) over every searched layer's
+ * candidate list ON THE DEVICE -- the candidate lists and their pair distances never leave it.  A new element's list has
+ * no cached closer flags, so the selection is the plain sweep: nearest candidate first, closer(e) = no neighbor chosen so
+ * far is at distance <= d(e, element) from e; chosen while fewer than lm (2m on layer 0, m above), then the rejected ones
+ * fill up to lm, nearest first (:1146-1148); a list of at most lm candidates is taken whole in W's furthest-first order.
+ *   elements [nq], insert_levels [nq]
+ *   out_ids / out_dist / out_closer [nq x layer_cap x 2m]: the neighbors in the order the reference's r holds them (what
+ *       AddConnections stores, :1243-1251), their distances, their `closer` flags; out_count [nq x layer_cap]
+ *   out_pairs (or NULL): pair distances computed (profiling)
+ */
+int			pgv_hnsw_build_neighbors(pgv_hnsw * h, const int32_t *elements, const int32_t *insert_levels, int nq,
+									 int ef_construction, int layer_cap,
+									 int32_t *out_ids, float *out_dist, uint8_t *out_closer, int32_t *out_count,
+									 int64_t *out_pairs);
+
+/*
  * Distances between pairs of elements of the mirror, out[i] = d(a[i], b[i]): CheckElementCloser's
  * HnswGetDistance between a candidate and an already selected neighbor (src/hnswutils.c:1040-1059),
  * batched over every pair a batch of inserts can need.

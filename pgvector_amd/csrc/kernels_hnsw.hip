@@ -408,6 +408,148 @@ int launch_hnsw_t(pgv_ctx *ctx, const HnswDev &g, const HnswRun &run, uint32_t *
     return PGV_OK;
 }
 
+
+// ------------------------------------------------------------------ SelectNeighbors for the elements being inserted
+// HnswFindElementNeighbors ends each layer with SelectNeighbors(w, lm, ...) (src/hnswutils.c:1064-1165, Algorithm 4 of
+// the HNSW paper with the reference's extras) over the layer's candidate list W, and CheckElementCloser (:1040-1059)
+// inside it compares the candidate's distance to the element with its distances to the neighbors chosen so far.  For a
+// NEW element the list has no cached `closer` flags (closerSet is false: every check is computed) and W arrives ordered
+// by the search, so the selection is the plain greedy sweep, nearest candidate first:
+//     closer(e) = no neighbor r chosen so far has d(e, r) <= d(e, q)          (ties are NOT closer: `<=` at :1053)
+//     chosen while |r| < lm; the rejected ones ("pruned connections", :1146-1148) fill r up to lm, nearest first
+// and a list of at most lm candidates is taken whole, in W's own (furthest first) order (:1072-1073).
+//
+// Three launches on the searches' stream: which lists need thinning and where their pair triangles go (one workgroup:
+// an exclusive scan), the (u, v < u) slot pairs of those lists for score_gather_kernel, and -- after the scoring -- the
+// sweep itself, one lane per list: its inner loop is a dependent chain of comparisons, the lists of a batch are
+// thousands, and a wavefront's 64 lists share nothing, so lanes are the parallelism.
+
+// pairs of list g = (query, layer): cnt * (cnt - 1) / 2 when it has to be thinned, else none; start[] by exclusive scan
+__global__ __launch_bounds__(1024) void hnsw_select_plan_kernel(const int32_t *__restrict__ cnt, int ngroups, int lcap, int m,
+                                                                 int64_t *__restrict__ pair_start) {
+    __shared__ int64_t wave_tot[1024 / 64];
+    __shared__ int64_t carry_s;
+    if (threadIdx.x == 0) carry_s = 0;
+    __syncthreads();
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    for (int base = 0; base < ngroups; base += 1024) {
+        const int g = base + (int)threadIdx.x;
+        int64_t v = 0;
+        if (g < ngroups) {
+            const int lm = (g % lcap) == 0 ? 2 * m : m;
+            const int64_t c = cnt[g];
+            v = c > lm ? c * (c - 1) / 2 : 0;
+        }
+        int64_t incl = v;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            const int64_t t = __shfl_up(incl, d);
+            if (lane >= d) incl += t;
+        }
+        if (lane == 63) wave_tot[wave] = incl;
+        __syncthreads();
+        int64_t before = 0, total = 0;
+        for (int w = 0; w < 1024 / 64; w++) {
+            const int64_t t = wave_tot[w];
+            if (w < wave) before += t;
+            total += t;
+        }
+        const int64_t carry = carry_s;
+        if (g < ngroups) pair_start[g] = carry + before + incl - v;
+        __syncthreads();
+        if (threadIdx.x == 0) carry_s = carry + total;
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) pair_start[ngroups] = carry_s;
+}
+
+// the pairs (u, v < u) of every list that is thinned, u ascending then v: a[] = slot of u, b[] = slot of v
+__global__ __launch_bounds__(256) void hnsw_select_pairs_kernel(const int32_t *__restrict__ lw_ids, const int32_t *__restrict__ cnt,
+                                                                 const int64_t *__restrict__ pair_start, int ngroups, int ef,
+                                                                 int32_t *__restrict__ a, int32_t *__restrict__ b) {
+    for (int g = blockIdx.x; g < ngroups; g += gridDim.x) {
+        int64_t at = pair_start[g];
+        if (pair_start[g + 1] == at) continue;
+        const int32_t *gi = lw_ids + (size_t)g * ef;
+        const int n = cnt[g];
+        for (int u = 1; u < n; u++) {
+            const int32_t iu = gi[u];
+            for (int v = threadIdx.x; v < u; v += blockDim.x) {
+                a[at + v] = iu;
+                b[at + v] = gi[v];
+            }
+            at += u;
+        }
+    }
+}
+
+// the sweep: list g's candidates are lw_ids / lw_dist[g * ef ..), nearest first; tri = its pair distances.
+// out_* [g * stride ..): the neighbors in the order the reference's r holds them, their distances, their closer flags
+__global__ __launch_bounds__(64) void hnsw_select_kernel(const int32_t *__restrict__ lw_ids, const float *__restrict__ lw_dist,
+                                                         const int32_t *__restrict__ cnt, const int32_t *__restrict__ qlevels,
+                                                         const int64_t *__restrict__ pair_start, const float *__restrict__ tri_all,
+                                                         int ngroups, int lcap, int ef, int m, int stride,
+                                                         int32_t *__restrict__ out_ids, float *__restrict__ out_dist,
+                                                         uint8_t *__restrict__ out_closer, int32_t *__restrict__ out_cnt) {
+    const int g = blockIdx.x * 64 + threadIdx.x;
+    if (g >= ngroups) return;
+    const int lc = g % lcap, q = g / lcap;
+    const int lm = lc == 0 ? 2 * m : m;
+    const int nw = lc > qlevels[q] ? 0 : cnt[g];  // (layers above the insert level are descended, not linked)
+    const int32_t *ids = lw_ids + (size_t)g * ef;
+    const float *dist = lw_dist + (size_t)g * ef;
+    int32_t *oi = out_ids + (size_t)g * stride;
+    float *od = out_dist + (size_t)g * stride;
+    uint8_t *oc = out_closer + (size_t)g * stride;
+    if (nw <= lm) {
+        // taken whole, in W's order: furthest first
+        for (int i = 0; i < nw; i++) {
+            oi[i] = ids[nw - 1 - i];
+            od[i] = dist[nw - 1 - i];
+            oc[i] = 0;
+        }
+        out_cnt[g] = nw;
+        return;
+    }
+    const float *tri = tri_all + pair_start[g];
+    int rn = 0;
+    // the chosen ones' candidate indexes live in the output (their ids are written there anyway): oi[i] holds the
+    // INDEX until the end, then the element
+    int j = 0;
+    for (; j < nw && rn < lm; j++) {
+        const float de = dist[j];
+        bool closer = true;
+        for (int i = 0; i < rn; i++) {
+            const int r = oi[i];  // r < j: chosen earlier, nearer or equal
+            if (tri[(int64_t)j * (j - 1) / 2 + r] <= de) {
+                closer = false;
+                break;
+            }
+        }
+        if (closer) oi[rn++] = j;
+    }
+    // the candidates looked at are 0 .. j - 1; the rejected among them, nearest first, fill r up to lm.  Walk them by
+    // merging "all of 0 .. j - 1" against the chosen (ascending) indexes.
+    const int chosen = rn;
+    {
+        int ci = 0;
+        for (int x = 0; x < j && rn < lm; x++) {
+            if (ci < chosen && oi[ci] == x) {
+                ci++;
+                continue;
+            }
+            oi[rn++] = x;
+        }
+    }
+    for (int i = 0; i < rn; i++) {
+        const int x = oi[i];
+        od[i] = dist[x];
+        oc[i] = i < chosen ? 1 : 0;
+        oi[i] = ids[x];
+    }
+    out_cnt[g] = rn;
+}
+
 }  // namespace
 
 int hnsw_search_grid(pgv_ctx *ctx, int nq, int64_t n, int *words_out) {
@@ -505,6 +647,34 @@ int launch_expand_groups(pgv_ctx *ctx, const int32_t *ids, const int64_t *ids_st
     const int cap = ctx->num_cus * 16;
     hipLaunchKernelGGL(expand_groups_kernel, dim3(ngroups < cap ? ngroups : cap), dim3(256), 0, ctx->stream, ids,
                        ids_start, from, pair_start, ngroups, a, b);
+    PGV_HIP(hipGetLastError());
+    return PGV_OK;
+}
+
+// SelectNeighbors of a batch's new elements (see hnsw_select_kernel): plan -> *out_total_dev pairs at pair_start[ngroups]
+int launch_hnsw_select_plan(pgv_ctx *ctx, const int32_t *cnt, int ngroups, int lcap, int m, int64_t *pair_start) {
+    if (ngroups <= 0) return PGV_OK;
+    hipLaunchKernelGGL(hnsw_select_plan_kernel, dim3(1), dim3(1024), 0, ctx->stream, cnt, ngroups, lcap, m, pair_start);
+    PGV_HIP(hipGetLastError());
+    return PGV_OK;
+}
+
+int launch_hnsw_select_pairs(pgv_ctx *ctx, const int32_t *lw_ids, const int32_t *cnt, const int64_t *pair_start, int ngroups,
+                             int ef, int32_t *a, int32_t *b) {
+    if (ngroups <= 0) return PGV_OK;
+    const int cap = ctx->num_cus * 16;
+    hipLaunchKernelGGL(hnsw_select_pairs_kernel, dim3(ngroups < cap ? ngroups : cap), dim3(256), 0, ctx->stream, lw_ids, cnt,
+                       pair_start, ngroups, ef, a, b);
+    PGV_HIP(hipGetLastError());
+    return PGV_OK;
+}
+
+int launch_hnsw_select(pgv_ctx *ctx, const int32_t *lw_ids, const float *lw_dist, const int32_t *cnt, const int32_t *qlevels,
+                       const int64_t *pair_start, const float *tri, int ngroups, int lcap, int ef, int m, int stride,
+                       int32_t *out_ids, float *out_dist, uint8_t *out_closer, int32_t *out_cnt) {
+    if (ngroups <= 0) return PGV_OK;
+    hipLaunchKernelGGL(hnsw_select_kernel, dim3((ngroups + 63) / 64), dim3(64), 0, ctx->stream, lw_ids, lw_dist, cnt, qlevels,
+                       pair_start, tri, ngroups, lcap, ef, m, stride, out_ids, out_dist, out_closer, out_cnt);
     PGV_HIP(hipGetLastError());
     return PGV_OK;
 }

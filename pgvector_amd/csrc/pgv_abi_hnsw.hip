@@ -405,6 +405,91 @@ int pgv_hnsw_build_search(pgv_hnsw *h, const int32_t *elements, const int32_t *i
     return sync_if(ctx, need);
 }
 
+int pgv_hnsw_build_neighbors(pgv_hnsw *h, const int32_t *elements, const int32_t *insert_levels, int nq,
+                             int ef_construction, int layer_cap, int32_t *out_ids, float *out_dist, uint8_t *out_closer,
+                             int32_t *out_count, int64_t *out_pairs) {
+    if (!h || !out_ids || !out_dist || !out_closer || !out_count)
+        PGV_FAIL(PGV_ERR_ARG, "pgv_hnsw_build_neighbors: handle/out is NULL");
+    hnsw_view_refresh(h);
+    if (nq < 0 || layer_cap < 1) PGV_FAIL(PGV_ERR_ARG, "bad sizes");
+    if (ef_construction < 4 || ef_construction > 1000)
+        PGV_FAIL(PGV_ERR_ARG, "ef_construction must be 4..1000 (src/hnsw.h:58-59), got %d", ef_construction);
+    if (h->m == 0) PGV_FAIL(PGV_ERR_ARG, "pgv_hnsw_build_neighbors needs pgv_hnsw_set_graph first");
+    if (out_pairs) *out_pairs = 0;
+    if (nq == 0) return PGV_OK;
+    if (!elements || !insert_levels) PGV_FAIL(PGV_ERR_ARG, "elements/insert_levels is NULL");
+    pgv_ctx *ctx = h->ctx;
+    PGV_HIP(hipSetDevice(ctx->device));
+    PGV_TRY(hnsw_graph_acquire(h));
+    const int m = h->m, stride = 2 * m;
+    const size_t per = (size_t)nq * layer_cap;
+    if (per > 0x7fffffff / (size_t)(ef_construction > stride ? ef_construction : stride))
+        PGV_FAIL(PGV_ERR_ARG, "pgv_hnsw_build_neighbors: batch too large");
+    const int ngroups = (int)per;
+    const void *e_dev, *l_dev;
+    PGV_TRY(stage_flat(ctx, elements, sizeof(int32_t) * (size_t)nq, ctx->idx_stage, &e_dev));
+    PGV_TRY(stage_flat(ctx, insert_levels, sizeof(int32_t) * (size_t)nq, ctx->plan_c, &l_dev));
+    int words = 0;
+    const int grid = hnsw_search_grid(ctx, nq, h->n, &words);
+    PGV_TRY(h->bitmaps.ensure((size_t)grid * words * sizeof(uint32_t)));
+    PGV_TRY(ctx->counters.ensure(256));
+    // the candidate lists stay on the device: km_b ids | km_c distances | km_d counts
+    PGV_TRY(ctx->km_b.ensure(sizeof(int32_t) * per * ef_construction));
+    PGV_TRY(ctx->km_c.ensure(sizeof(float) * per * ef_construction));
+    PGV_TRY(ctx->km_d.ensure(sizeof(int32_t) * per));
+    PGV_TRY(ctx->km_e.ensure(sizeof(int64_t) * (per + 1)));
+    int32_t *lw_ids = ctx->km_b.as<int32_t>();
+    float *lw_dist = ctx->km_c.as<float>();
+    int32_t *lw_cnt = ctx->km_d.as<int32_t>();
+    int64_t *pair_start = ctx->km_e.as<int64_t>();
+    HnswSearchArgs a;
+    a.qids = static_cast<const int32_t *>(e_dev);
+    a.qlevels = static_cast<const int32_t *>(l_dev);
+    a.nq = nq;
+    a.ef = ef_construction;
+    a.k = 0;
+    a.lw_ids = lw_ids;
+    a.lw_dist = lw_dist;
+    a.lw_cnt = lw_cnt;
+    a.lcap = layer_cap;
+    PGV_TRY(launch_hnsw_search(ctx, h->metric, h->dtype, h->geom, h->elements, h->n, h->levels, h->nbr_start, h->nbr, m,
+                               h->entry, a, h->bitmaps.as<uint32_t>(), words, grid, ctx->counters.as<int>()));
+    // which lists SelectNeighbors has to thin, and where each one's pair triangle goes; the total comes back (8 bytes:
+    // it sizes the next two launches)
+    PGV_TRY(launch_hnsw_select_plan(ctx, lw_cnt, ngroups, layer_cap, m, pair_start));
+    int64_t npairs = 0;
+    PGV_HIP(hipMemcpyAsync(&npairs, pair_start + ngroups, sizeof(int64_t), hipMemcpyDeviceToHost, ctx->stream));
+    PGV_HIP(hipStreamSynchronize(ctx->stream));
+    if (npairs < 0 || npairs > (int64_t)per * ef_construction * (ef_construction - 1) / 2)
+        PGV_FAIL(PGV_ERR_STATE, "pgv_hnsw_build_neighbors: %lld pairs planned", (long long)npairs);
+    if (npairs > 0) {
+        PGV_TRY(ctx->km_f.ensure(sizeof(int32_t) * (size_t)npairs));
+        PGV_TRY(ctx->km_g.ensure(sizeof(int32_t) * (size_t)npairs));
+        PGV_TRY(ctx->dist_mat.ensure(sizeof(float) * (size_t)npairs));
+        PGV_TRY(launch_hnsw_select_pairs(ctx, lw_ids, lw_cnt, pair_start, ngroups, ef_construction, ctx->km_f.as<int32_t>(),
+                                         ctx->km_g.as<int32_t>()));
+        // CheckElementCloser's HnswGetDistance (src/hnswutils.c:1040-1059): the same kernel as pgv_hnsw_score_groups
+        PGV_TRY(launch_score_gather(ctx, h->metric, h->dtype, h->geom, h->elements, h->elements, ctx->km_f.as<int32_t>(),
+                                    ctx->km_g.as<int32_t>(), npairs, ctx->dist_mat.as<float>()));
+    } else
+        PGV_TRY(ctx->dist_mat.ensure(16));
+    OutArg oi, od, oc, on;
+    PGV_TRY(oi.init(out_ids, sizeof(int32_t) * per * stride, ctx->out_stage));
+    PGV_TRY(od.init(out_dist, sizeof(float) * per * stride, ctx->out_stage2));
+    PGV_TRY(oc.init(out_closer, per * stride, ctx->sel_a));
+    PGV_TRY(on.init(out_count, sizeof(int32_t) * per, ctx->sel_b));
+    PGV_TRY(launch_hnsw_select(ctx, lw_ids, lw_dist, lw_cnt, static_cast<const int32_t *>(l_dev), pair_start,
+                               ctx->dist_mat.as<float>(), ngroups, layer_cap, ef_construction, m, stride, oi.as<int32_t>(),
+                               od.as<float>(), oc.as<uint8_t>(), on.as<int32_t>()));
+    if (out_pairs) *out_pairs = npairs;
+    bool need = false;
+    PGV_TRY(oi.finish(ctx, &need));
+    PGV_TRY(od.finish(ctx, &need));
+    PGV_TRY(oc.finish(ctx, &need));
+    PGV_TRY(on.finish(ctx, &need));
+    return sync_if(ctx, need);
+}
+
 int pgv_hnsw_score_pairs(pgv_hnsw *h, const int32_t *a, const int32_t *b, int64_t npairs, float *out) {
     if (!h || !out) PGV_FAIL(PGV_ERR_ARG, "pgv_hnsw_score_pairs: handle/out is NULL");
     if (npairs < 0) PGV_FAIL(PGV_ERR_ARG, "bad sizes");

@@ -339,6 +339,13 @@ int launch_argmin_mode(pgv_ctx *ctx, int mode, pgv_dtype dtype, const RowGeom &g
 int launch_argmin_listed(pgv_ctx *ctx, int mode, pgv_dtype dtype, const RowGeom &g, const void *rows, int64_t n,
                          const void *centers, int k, const int32_t *row_list, const int *row_count,
                          unsigned long long *packed);
+// kernels_hnsw.hip: SelectNeighbors of a batch's new elements on the device (plan -> pairs -> [score_gather] -> sweep)
+int launch_hnsw_select_plan(pgv_ctx *ctx, const int32_t *cnt, int ngroups, int lcap, int m, int64_t *pair_start);
+int launch_hnsw_select_pairs(pgv_ctx *ctx, const int32_t *lw_ids, const int32_t *cnt, const int64_t *pair_start, int ngroups,
+                             int ef, int32_t *a, int32_t *b);
+int launch_hnsw_select(pgv_ctx *ctx, const int32_t *lw_ids, const float *lw_dist, const int32_t *cnt, const int32_t *qlevels,
+                       const int64_t *pair_start, const float *tri, int ngroups, int lcap, int ef, int m, int stride,
+                       int32_t *out_ids, float *out_dist, uint8_t *out_closer, int32_t *out_cnt);
 // kernels_mfma.hip: the same on the matrix cores (ip / spherical directly, L2 as pre-filter + exact recheck)
 bool mfma_argmin_supported(int mode, int64_t n, int k);
 int launch_argmin_mfma(pgv_ctx *ctx, int mode, pgv_dtype dtype, const RowGeom &g, const void *rows, int64_t n,

@@ -668,6 +668,13 @@ typedef struct
 	float	   *sw_dist;
 	int32_t    *sw_cnt;
 	int64_t    *tri_off;
+	/* ... or, with SelectNeighbors on the device (pgv_hnsw_build_neighbors): each searched layer's neighbor list as
+	 * AddConnections stores it, [B x lcap x 2m] */
+	int			device_select;
+	int32_t    *sel_ids;
+	float	   *sel_dist;
+	uint8_t    *sel_closer;
+	int32_t    *sel_cnt;
 	groupbuf	gb;
 	float	   *pdist;			/* pinned */
 	int64_t		pdist_cap;
@@ -685,6 +692,10 @@ stage_a_free(stage_a * a)
 	free(a->sw_dist);
 	free(a->sw_cnt);
 	free(a->tri_off);
+	free(a->sel_ids);
+	free(a->sel_dist);
+	free(a->sel_closer);
+	free(a->sel_cnt);
 	free(a->gb.ids);
 	free(a->gb.ids_start);
 	free(a->gb.from);
@@ -708,6 +719,39 @@ run_stage_a(pgv_hnsw * handle, stage_a * a, const elem * el, int m, int ef_const
 
 	a->rc = PGV_OK;
 	a->err[0] = 0;
+	if (a->device_select)
+	{
+		/* searches + SelectNeighbors in one call: what comes back is the lists themselves */
+		const size_t stride = 2 * (size_t) m;
+		int64_t		pairs = 0;
+
+		a->sel_ids = realloc(a->sel_ids, sizeof(int32_t) * per * stride);
+		a->sel_dist = realloc(a->sel_dist, sizeof(float) * per * stride);
+		a->sel_closer = realloc(a->sel_closer, per * stride);
+		a->sel_cnt = realloc(a->sel_cnt, sizeof(int32_t) * per);
+		if (!ids || !lv || !a->sel_ids || !a->sel_dist || !a->sel_closer || !a->sel_cnt)
+		{
+			free(ids);
+			free(lv);
+			snprintf(a->err, sizeof(a->err), "out of memory");
+			return a->rc = PGV_ERR_NOMEM;
+		}
+		for (int b = 0; b < B; b++)
+		{
+			ids[b] = (int32_t) (a->i0 + b);
+			lv[b] = el[a->i0 + b].level;
+		}
+		rc = pgv_hnsw_build_neighbors(handle, ids, lv, B, ef_construction, lcap, a->sel_ids, a->sel_dist, a->sel_closer,
+									  a->sel_cnt, &pairs);
+		free(ids);
+		free(lv);
+		a->npairs = pairs;
+		a->secs[0] = now_secs() - t0;
+		a->secs[1] = 0;
+		if (rc != PGV_OK)
+			goto dev_fail;
+		return PGV_OK;
+	}
 	a->sw_ids = realloc(a->sw_ids, sizeof(int32_t) * per * ef_construction);
 	a->sw_dist = realloc(a->sw_dist, sizeof(float) * per * ef_construction);
 	a->sw_cnt = realloc(a->sw_cnt, sizeof(int32_t) * per);
@@ -1050,8 +1094,12 @@ pgv_host_hnsw_build(pgv_hnsw * mirror, pgv_dtype dtype, int dim, const void *row
 	int			nthreads = omp_get_max_threads() < 16 ? omp_get_max_threads() : 16;	/* 32: twice as slow (measured) */
 	double		phase_t0 = now_secs();
 	int			cur_phase = PH_RECORDS;
+	/* SelectNeighbors of the new elements' candidate lists: on the device with the searches (the default), or here from
+	 * the lists and their pair triangles (PGV_HNSW_HOST_SELECT=1: the form the device's is tested against) */
+	const int	device_select = !(getenv("PGV_HNSW_HOST_SELECT") && atoi(getenv("PGV_HNSW_HOST_SELECT")) != 0);
 
 	memset(stages, 0, sizeof(stages));
+	stages[0].device_select = stages[1].device_select = device_select;
 	memset(&helper, 0, sizeof(helper));
 	memset(&scorer, 0, sizeof(scorer));
 	memset(patches, 0, sizeof(patches));
@@ -1276,6 +1324,37 @@ pgv_host_hnsw_build(pgv_hnsw * mirror, pgv_dtype dtype, int dim, const void *row
 				elem	   *x = &el[e];
 
 				x->layers = calloc((size_t) x->level + 1, sizeof(nlist));
+				if (device_select)
+				{
+					/* SelectNeighbors ran on the device (pgv_hnsw_build_neighbors): the lists are AddConnections' to store */
+					const stage_a *a = &stages[cur];
+
+					for (int lc = lcap - 1; lc >= 0; lc--)
+					{
+						const size_t g = (size_t) b * lcap + lc;
+						const int	rn = a->sel_cnt[g];
+						const int	lm = layer_m(m, lc);
+
+						if (rn == 0 || lc > x->level)
+							continue;
+						x->layers[lc].closer_set = 0;	/* not sorted deterministically (:1143-1144) */
+						x->layers[lc].items = items_alloc(lm);
+						x->layers[lc].length = rn;
+						for (int i = 0; i < rn; i++)
+						{
+							cand	   *it = &x->layers[lc].items[i];
+
+							it->element = a->sel_ids[g * 2 * (size_t) m + i];
+							it->distance = a->sel_dist[g * 2 * (size_t) m + i];
+							it->local = 0;
+							it->closer = a->sel_closer[g * 2 * (size_t) m + i];
+						}
+					}
+					for (int lc = 0; lc <= x->level; lc++)
+						if (!x->layers[lc].items)
+							x->layers[lc].items = items_alloc(layer_m(m, lc));
+					continue;
+				}
 				for (int lc = lcap - 1; lc >= 0; lc--)
 				{
 					int			nw = sw_cnt[(size_t) b * lcap + lc];

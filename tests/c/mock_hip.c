@@ -1151,6 +1151,82 @@ pgv_hnsw_build_search(pgv_hnsw * h, const int32_t *elements, const int32_t *inse
 	return PGV_OK;
 }
 
+/* the searches above, then SelectNeighbors for a new element's lists (src/hnswutils.c:1064-1165 without cached flags):
+ * nearest candidate first, chosen while no chosen neighbor is at distance <= its own; the rejected fill up to lm */
+int
+pgv_hnsw_build_neighbors(pgv_hnsw * h, const int32_t *elements, const int32_t *insert_levels, int nq, int ef_construction,
+						 int layer_cap, int32_t *out_ids, float *out_dist, uint8_t *out_closer, int32_t *out_count,
+						 int64_t *out_pairs)
+{
+	const size_t per = (size_t) nq * layer_cap;
+	const int	stride = 2 * h->m;
+	int32_t    *ids = malloc(sizeof(int32_t) * (per ? per : 1) * ef_construction);
+	float	   *ds = malloc(sizeof(float) * (per ? per : 1) * ef_construction);
+	int32_t    *cnt = malloc(sizeof(int32_t) * (per ? per : 1));
+	int		   *pick = malloc(sizeof(int) * (size_t) ef_construction);
+	uint8_t    *chosen = malloc((size_t) ef_construction);
+	int64_t		pairs = 0;
+	int			rc = pgv_hnsw_build_search(h, elements, insert_levels, nq, ef_construction, layer_cap, ids, ds, cnt);
+
+	for (size_t g = 0; rc == PGV_OK && g < per; g++)
+	{
+		const int	lc = (int) (g % layer_cap),
+					lm = lc == 0 ? 2 * h->m : h->m;
+		const int	nw = lc > insert_levels[g / layer_cap] ? 0 : cnt[g];
+		const int32_t *gi = ids + g * ef_construction;
+		const float *gd = ds + g * ef_construction;
+		int			rn = 0,
+					nchosen,
+					j;
+
+		if (nw <= lm)
+		{
+			for (int i = 0; i < nw; i++)
+			{
+				out_ids[g * stride + i] = gi[nw - 1 - i];
+				out_dist[g * stride + i] = gd[nw - 1 - i];
+				out_closer[g * stride + i] = 0;
+			}
+			out_count[g] = nw;
+			continue;
+		}
+		pairs += (int64_t) nw * (nw - 1) / 2;
+		memset(chosen, 0, (size_t) nw);
+		for (j = 0; j < nw && rn < lm; j++)
+		{
+			int			closer = 1;
+
+			for (int i = 0; i < rn && closer; i++)
+				if (dist(h->metric, h->dim, h->vectors + (size_t) gi[j] * h->dim, h->vectors + (size_t) gi[pick[i]] * h->dim) <= gd[j])
+					closer = 0;
+			if (closer)
+			{
+				chosen[j] = 1;
+				pick[rn++] = j;
+			}
+		}
+		nchosen = rn;
+		for (int x = 0; x < j && rn < lm; x++)
+			if (!chosen[x])
+				pick[rn++] = x;
+		for (int i = 0; i < rn; i++)
+		{
+			out_ids[g * stride + i] = gi[pick[i]];
+			out_dist[g * stride + i] = gd[pick[i]];
+			out_closer[g * stride + i] = i < nchosen;
+		}
+		out_count[g] = rn;
+	}
+	if (out_pairs)
+		*out_pairs = pairs;
+	free(ids);
+	free(ds);
+	free(cnt);
+	free(pick);
+	free(chosen);
+	return rc;
+}
+
 /* hnswgettuple's first batch (src/hnswscan.c:25-56): greedy descent with ef = 1, then HnswSearchLayer with ef_search
  * on layer 0; the k nearest, ascending, -1 / +inf padded */
 int

@@ -1,7 +1,10 @@
 """Round 5 on the GPU: overlapping batches (pgv_index_set_overlap) answer exactly what stream-ordered batches answer."""
+import os
+
 import numpy as np
 import pytest
 
+from helpers import gen
 from pgvector_amd import api
 
 pytestmark = pytest.mark.gpu
@@ -191,3 +194,113 @@ def test_the_64_query_scan_form_for_fp32_too_in_a_process_that_forces_it():
     r = subprocess.run([sys.executable, os.path.join(root, "tests", "mp_wide_scan_worker.py")], capture_output=True, text=True,
                        timeout=600, env=dict(os.environ, PGV_SCAN_WIDE="1"))
     assert r.returncode == 0 and "WIDE-OK 5" in r.stdout, (r.stdout[-500:], r.stderr[-2000:])
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# SelectNeighbors of the elements being inserted, on the device (pgv_hnsw_build_neighbors)
+def _host_select(ids, dist, tri, lm):
+    """src/hnswutils.c:1064-1165 for a list without cached flags, candidates nearest first, pair distances in the
+    (u, v < u) triangle: (neighbors, distances, closer flags) in r's order"""
+    nw = len(ids)
+    if nw <= lm:
+        return ids[::-1].tolist(), dist[::-1].tolist(), [0] * nw
+    chosen, looked = [], 0
+    for j in range(nw):
+        if len(chosen) >= lm:
+            break
+        looked = j + 1
+        if all(tri[j * (j - 1) // 2 + r] > dist[j] for r in chosen):
+            chosen.append(j)
+    order = list(chosen)
+    for x in range(looked):
+        if len(order) >= lm:
+            break
+        if x not in chosen:
+            order.append(x)
+    return [int(ids[x]) for x in order], [float(dist[x]) for x in order], [1 if i < len(chosen) else 0 for i in range(len(order))]
+
+
+@pytest.mark.parametrize("metric,dist_kind,dim", [(api.PGV_L2SQ, "clustered", 48), (api.PGV_L2SQ, "int10", 8), (api.PGV_NEG_IP, "normal", 96)])
+def test_select_neighbors_on_the_device_is_the_sweep_over_the_same_lists(ctx, metric, dist_kind, dim):
+    """pgv_hnsw_build_neighbors = pgv_hnsw_build_search + CheckElementCloser's distances + the sweep of SelectNeighbors
+    (src/hnswutils.c:1040-1165): against the same sweep done here over the lists and pair distances the two older calls
+    return -- ids, distances (bitwise: the same kernels), closer flags, counts, every layer."""
+    import ctypes as C
+    from pgvector_amd import _host
+    n, m, efc = 5000, 6, 40
+    data = gen(n, dim, seed=801, dist=dist_kind) if dist_kind != "clustered" else gen(n, dim, seed=801, dist="clustered", clusters=25)
+    mirror = api.Hnsw(ctx, metric, api.PGV_F32, dim, data)
+    # a graph over the first 4000 rows; the last 1000 are "being inserted"
+    head = api.Hnsw(ctx, metric, api.PGV_F32, dim, data[:4000])
+    built = _host.hnsw_build(head, data[:4000], m, efc, api.make_rng(seed=3), max_batch=64)
+    head.close()
+    levels = np.concatenate([built["levels"], np.zeros(1000, np.int32)])
+    rngl = np.random.default_rng(5)
+    new_levels = np.minimum((-np.log(rngl.random(1000)) / np.log(m)).astype(np.int32), int(built["levels"].max()))
+    levels[4000:] = new_levels
+    nbr_start = np.zeros(n + 1, np.int64)
+    nbr_start[1:] = np.cumsum((levels.astype(np.int64) + 2) * m)
+    nbr = np.full(int(nbr_start[-1]), -1, np.int32)
+    nbr[:len(built["nbr"])] = built["nbr"]
+    mirror.set_graph(m, built["entry"], levels, nbr_start, nbr)
+    elems = np.arange(4000, 5000, dtype=np.int32)
+    lcap = int(min(new_levels.max(), levels[built["entry"]])) + 1
+    per = len(elems) * lcap
+    ids = np.empty((per, efc), np.int32)
+    dist = np.empty((per, efc), np.float32)
+    cnt = np.empty(per, np.int32)
+    api.check(api.lib.pgv_hnsw_build_search(mirror.h, api.ptr(elems), api.ptr(new_levels), len(elems), efc, lcap, api.ptr(ids),
+                                            api.ptr(dist), api.ptr(cnt)))
+    oi = np.empty((per, 2 * m), np.int32)
+    od = np.empty((per, 2 * m), np.float32)
+    oc = np.empty((per, 2 * m), np.uint8)
+    on = np.empty(per, np.int32)
+    pairs = C.c_int64()
+    api.check(api.lib.pgv_hnsw_build_neighbors(mirror.h, api.ptr(elems), api.ptr(new_levels), len(elems), efc, lcap, api.ptr(oi),
+                                               api.ptr(od), api.ptr(oc), api.ptr(on), C.byref(pairs)))
+    thinned = 0
+    want_pairs = 0
+    for g in range(per):
+        q, lc = divmod(g, lcap)
+        lm = 2 * m if lc == 0 else m
+        nw = 0 if lc > new_levels[q] else int(cnt[g])
+        tri = None
+        if nw > lm:
+            thinned += 1
+            want_pairs += nw * (nw - 1) // 2
+            gi = ids[g, :nw]
+            a = np.concatenate([np.full(u, gi[u], np.int32) for u in range(1, nw)])
+            b = np.concatenate([gi[:u] for u in range(1, nw)])
+            tri = np.empty(len(a), np.float32)
+            api.check(api.lib.pgv_hnsw_score_pairs(mirror.h, api.ptr(a), api.ptr(b), len(a), api.ptr(tri)))
+        wi, wd, wc = _host_select(ids[g, :nw], dist[g, :nw], tri, lm)
+        assert on[g] == len(wi), (g, on[g], len(wi))
+        assert oi[g, :on[g]].tolist() == wi, (g, lc, nw)
+        assert od[g, :on[g]].tolist() == wd
+        assert oc[g, :on[g]].tolist() == wc
+    assert thinned > 300 and pairs.value == want_pairs
+    mirror.close()
+
+
+@pytest.mark.parametrize("max_batch", [1, 64, 512])
+def test_hnsw_build_with_device_select_builds_the_graph_of_the_host_select(ctx, max_batch):
+    """the whole build, SelectNeighbors of the new elements on the device (default) vs on the host from the downloaded
+    lists and triangles (PGV_HNSW_HOST_SELECT=1): the same graph, tuple for tuple"""
+    from pgvector_amd import _host
+    n, dim, m, efc = (1500, 16, 6, 24) if max_batch == 1 else (20000, 64, 8, 48)
+    data = gen(n, dim, seed=811, dist="clustered", clusters=40)
+    graphs = []
+    for host_select in ("0", "1"):
+        os.environ["PGV_HNSW_HOST_SELECT"] = host_select
+        try:
+            mirror = api.Hnsw(ctx, api.PGV_L2SQ, api.PGV_F32, dim, data)
+            built = _host.hnsw_build(mirror, data, m, efc, api.make_rng(seed=9), max_batch=max_batch)
+            mirror.close()
+        finally:
+            os.environ.pop("PGV_HNSW_HOST_SELECT", None)
+        graphs.append(built)
+    a, b = graphs
+    assert a["entry"] == b["entry"] and a["batches"] == b["batches"]
+    np.testing.assert_array_equal(a["levels"], b["levels"])
+    np.testing.assert_array_equal(a["dup_of"], b["dup_of"])
+    np.testing.assert_array_equal(a["nbr"], b["nbr"])
