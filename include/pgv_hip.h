@@ -666,6 +666,46 @@ int			pgv_hnsw_build_neighbors(pgv_hnsw * h, const int32_t *elements, const int3
 									 int64_t *out_pairs);
 
 /*
+ * pgv_hnsw_build_neighbors in two halves, for a build that overlaps them (between pgv_hnsw_link_begin and _end): the
+ * searches of a batch, whose candidate lists are kept on the device in slot 0 or 1 of the mirror's build state -- when it
+ * returns the searches are over and the tuples may be rewritten --, and SelectNeighbors over a kept slot, from any view
+ * of the mirror on that view's stream (outputs as pgv_hnsw_build_neighbors).  The searches of batch n + 2 (one view, the
+ * other slot) then run beside the selection of batch n + 1 (another view).
+ */
+int			pgv_hnsw_build_search_keep(pgv_hnsw * h, const int32_t *elements, const int32_t *insert_levels, int nq,
+									   int ef_construction, int layer_cap, int slot);
+int			pgv_hnsw_build_select_kept(pgv_hnsw * h, int slot, int32_t *out_ids, float *out_dist, uint8_t *out_closer,
+									   int32_t *out_count, int64_t *out_pairs);
+
+/*
+ * The graph updates of the in-memory build on the device: HnswUpdateNeighborsInMemory -> HnswUpdateConnection
+ * (src/hnswbuild.c:376-405, src/hnswutils.c:1183-1231) for a batch of new elements at once -- every neighbor list they
+ * chose replayed by one GPU lane with the reference's SelectNeighbors (sorted candidates, cached closer flags, pruned
+ * connections kept, the dropped neighbor's place handed to the newcomer), the pair distances CheckElementCloser looks up
+ * scored on the device next to it.  Between _begin and _end the mirror carries, per neighbor-tuple slot, the neighbor's
+ * distance and closer flag; the tuples themselves (what the searches read) are rewritten in place.
+ *
+ *   pgv_hnsw_link_begin    after pgv_hnsw_set_graph with every tuple empty (-1): allocates the state
+ *   pgv_hnsw_link_prepare  the batch: elements [nq], linked [nq] (0: a duplicate, left out) and their neighbor lists as
+ *                          pgv_hnsw_build_neighbors returned them ([nq x layer_cap x 2m] + counts).  Every (new element,
+ *                          chosen neighbor, layer) is a link request; they are grouped by neighbor list on the device,
+ *                          the newcomers of a list in heap order (as the reference's loop would meet them).  Scores
+ *                          every pair the lists' selections can look up -- a list without cached flags: all of them;
+ *                          otherwise those that involve a newcomer -- and returns while that runs
+ *   pgv_hnsw_link_apply    replays the lists, then puts the batch's own elements in place; sets the entry point.  The
+ *                          caller keeps searches that read the old tuples away (they have returned); later searches on
+ *                          any stream see the new ones
+ *   pgv_hnsw_link_end      out_nbr [total slots] (or NULL): the finished tuples; frees the state
+ * out_pairs / out_deferred (or NULL): pair distances computed, lists that needed the second round of them.
+ */
+int			pgv_hnsw_link_begin(pgv_hnsw * h);
+int			pgv_hnsw_link_prepare(pgv_hnsw * h, const int32_t *elements, const uint8_t *linked, int nq, int layer_cap,
+								  const int32_t *sel_ids, const float *sel_dist, const uint8_t *sel_closer,
+								  const int32_t *sel_count, int64_t *out_pairs);
+int			pgv_hnsw_link_apply(pgv_hnsw * h, int32_t entry, int64_t *out_pairs, int *out_deferred);
+int			pgv_hnsw_link_end(pgv_hnsw * h, int32_t *out_nbr);
+
+/*
  * Distances between pairs of elements of the mirror, out[i] = d(a[i], b[i]): CheckElementCloser's
  * HnswGetDistance between a candidate and an already selected neighbor (src/hnswutils.c:1040-1059),
  * batched over every pair a batch of inserts can need.

@@ -38,7 +38,8 @@ SYMBOLS = [
     "pgv_index_rows", "pgv_index_lists", "pgv_rank_lists", "pgv_scan_lists", "pgv_search_batch", "pgv_scan_batch",
     "pgv_assign", "pgv_kmeans", "pgv_lloyd_partial", "pgv_lloyd_finish", "pgv_kmeanspp_init",
     "pgv_distance_batch", "pgv_cosine_distance_batch", "pgv_bit_distance_batch", "pgv_hnsw_upload", "pgv_hnsw_free", "pgv_hnsw_score", "pgv_hnsw_set_graph", "pgv_hnsw_search",
-    "pgv_hnsw_build_search", "pgv_hnsw_build_neighbors", "pgv_hnsw_score_pairs", "pgv_hnsw_score_groups", "pgv_hnsw_update_graph",
+    "pgv_hnsw_build_search", "pgv_hnsw_build_neighbors", "pgv_hnsw_link_begin", "pgv_hnsw_link_prepare",
+    "pgv_hnsw_link_apply", "pgv_hnsw_link_end", "pgv_hnsw_build_search_keep", "pgv_hnsw_build_select_kept", "pgv_hnsw_score_pairs", "pgv_hnsw_score_groups", "pgv_hnsw_update_graph",
     "pgv_query_begin", "pgv_query_end", "pgv_query_rank", "pgv_query_scan", "pgv_query_more", "pgv_query_lists",
     "pgv_comm_unique_id", "pgv_comm_create", "pgv_comm_create_custom", "pgv_comm_destroy", "pgv_comm_size",
     "pgv_comm_rank", "pgv_kmeans_sharded", "pgv_search_batch_sharded",

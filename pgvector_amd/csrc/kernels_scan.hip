@@ -220,6 +220,86 @@ __global__ __launch_bounds__(kScanThreads) void score_gather_kernel(
     }
 }
 
+// Pair distances inside groups of rows (the HNSW build: CheckElementCloser's distances between the candidates of one
+// neighbor list, src/hnswutils.c:1040-1059): group g is the rows ids[at .. at + n), wanted are the pairs (u, v < u) for
+// u >= from, written u ascending then v from pair_at[g] on.  score_gather_kernel reads both rows of every pair from L2
+// -- a 64-candidate list's 2016 pairs are 4032 row reads of 64 rows, and that traffic is what bounds it; here a worker (the
+// lanes that share a row) takes a TILE of 4 x 4 pairs: 8 row reads for 16 pairs.  Each pair keeps its own accumulator
+// and the element order, the lane split and the cross-lane sum of score_gather_kernel: the values are bit for bit the
+// same.  One workgroup per group, its workers take the group's tiles round-robin.
+template <typename T, int METRIC>
+__global__ __launch_bounds__(kScanThreads) void score_groups_kernel(
+    const char *__restrict__ rows, const int32_t *__restrict__ ids, const int64_t *__restrict__ ids_at, int64_t ids_stride,
+    const int32_t *__restrict__ n_arr, const int32_t *__restrict__ from_arr, const int64_t *__restrict__ pair_at, int ngroups,
+    float *__restrict__ out, int nvec, int lpr_log2, int nchunks) {
+    constexpr int N = VecTraits<T>::N;
+    constexpr int TU = 4, TV = 4;
+    const int lane = threadIdx.x & (kWave - 1);
+    const int wave = threadIdx.x >> 6;
+    const int lpr = 1 << lpr_log2;
+    const int sub = lane & (lpr - 1);
+    const int rsub = lane >> lpr_log2;
+    const int rpw = kWave >> lpr_log2;
+    const int worker = wave * rpw + rsub, nworkers = kScanWaves * rpw;
+    const size_t row_bytes = (size_t)nvec * sizeof(Raw16);
+    for (int g = blockIdx.x; g < ngroups; g += gridDim.x) {
+        const int64_t p0 = pair_at[g];
+        if (pair_at[g + 1] == p0) continue;
+        const int64_t at = ids_at ? ids_at[g] : (int64_t)g * ids_stride;
+        const int n = n_arr ? n_arr[g] : (int)(ids_at[g + 1] - at);
+        int from = from_arr ? from_arr[g] : 1;
+        if (from < 1) from = 1;
+        if (n <= from) continue;
+        const int32_t *gi = ids + at;
+        const int64_t base = (int64_t)from * (from - 1) / 2;
+        int t = 0;  // tiles of this group, in order: u-blocks from `from`, each against the v-blocks below its last row
+        for (int u0 = from; u0 < n; u0 += TU) {
+            const int ulast = (u0 + TU - 1 < n - 1) ? u0 + TU - 1 : n - 1;
+            for (int v0 = 0; v0 < ulast; v0 += TV, t++) {
+                if (t % nworkers != worker) continue;
+                const char *up[TU], *vp[TV];
+#pragma unroll
+                for (int i = 0; i < TU; i++) up[i] = rows + (size_t)gi[u0 + i < n ? u0 + i : n - 1] * row_bytes;
+#pragma unroll
+                for (int j = 0; j < TV; j++) vp[j] = rows + (size_t)gi[v0 + j < n ? v0 + j : n - 1] * row_bytes;
+                float acc[TU][TV];
+#pragma unroll
+                for (int i = 0; i < TU; i++)
+#pragma unroll
+                    for (int j = 0; j < TV; j++) acc[i][j] = 0.f;
+                for (int c = 0; c < nchunks; c++) {
+                    const int vi = c * lpr + sub;
+                    const bool ok = vi < nvec;
+                    const int vc = ok ? vi : nvec - 1;  // never predicate a load (see scan_kernel)
+                    Raw16 ur[TU], vr[TV];
+#pragma unroll
+                    for (int i = 0; i < TU; i++) ur[i] = load16(up[i] + (size_t)vc * sizeof(Raw16));
+#pragma unroll
+                    for (int j = 0; j < TV; j++) vr[j] = load16(vp[j] + (size_t)vc * sizeof(Raw16));
+#pragma unroll
+                    for (int i = 0; i < TU; i++) {
+                        Unpacked<T> a(ur[i]);
+#pragma unroll
+                        for (int j = 0; j < TV; j++) {
+                            Unpacked<T> b(vr[j]);
+#pragma unroll
+                            for (int e = 0; e < N; e++) acc[i][j] = accum<METRIC>(acc[i][j], ok ? a.v[e] : 0.f, ok ? b.v[e] : 0.f);
+                        }
+                    }
+                }
+#pragma unroll
+                for (int i = 0; i < TU; i++)
+#pragma unroll
+                    for (int j = 0; j < TV; j++) {
+                        const float sum = group_sum_to_last(acc[i][j], lpr_log2);
+                        const int u = u0 + i, v = v0 + j;
+                        if (sub == lpr - 1 && u < n && v < u) out[p0 + (int64_t)u * (u - 1) / 2 - base + v] = finish<METRIC>(sum);
+                    }
+            }
+        }
+    }
+}
+
 template <typename T, int METRIC, int QT, int R, int THREADS, int PF>
 int launch_scan_t(pgv_ctx *ctx, const RowGeom &g, const void *rows, const void *queries,
                   const ScanTask *tasks, const int *ntasks_dev, int ntasks_bound,
@@ -311,6 +391,19 @@ int launch_gather_t(pgv_ctx *ctx, const RowGeom &g, const void *rows, const void
     return PGV_OK;
 }
 
+template <typename T, int METRIC>
+int launch_groups_t(pgv_ctx *ctx, const RowGeom &g, const void *rows, const int32_t *ids, const int64_t *ids_at,
+                    int64_t ids_stride, const int32_t *n_arr, const int32_t *from_arr, const int64_t *pair_at, int ngroups,
+                    float *out) {
+    if (ngroups <= 0) return PGV_OK;
+    const int cap = ctx->num_cus * 16;
+    hipLaunchKernelGGL((score_groups_kernel<T, METRIC>), dim3(ngroups < cap ? ngroups : cap), dim3(kScanThreads), 0, ctx->stream,
+                       static_cast<const char *>(rows), ids, ids_at, ids_stride, n_arr, from_arr, pair_at, ngroups, out, g.nvec,
+                       g.lpr_log2, g.nchunks);
+    PGV_HIP(hipGetLastError());
+    return PGV_OK;
+}
+
 }  // namespace
 
 // Lanes per row: the power of two that wastes the fewest lane-trips.
@@ -379,6 +472,27 @@ int launch_score_gather(pgv_ctx *ctx, pgv_metric metric, pgv_dtype dtype, const 
         PGV_GATHER(__half)
     }
 #undef PGV_GATHER
+    PGV_FAIL(PGV_ERR_ARG, "score: unknown metric %d", (int)metric);
+}
+
+int launch_score_groups(pgv_ctx *ctx, pgv_metric metric, pgv_dtype dtype, const RowGeom &g, const void *rows,
+                        const int32_t *ids, const int64_t *ids_at, int64_t ids_stride, const int32_t *n_arr,
+                        const int32_t *from_arr, const int64_t *pair_at, int ngroups, float *out) {
+#define PGV_GROUPS(T)                                                                                                   \
+    switch (metric) {                                                                                                   \
+        case PGV_L2SQ:                                                                                                  \
+            return launch_groups_t<T, 0>(ctx, g, rows, ids, ids_at, ids_stride, n_arr, from_arr, pair_at, ngroups, out); \
+        case PGV_NEG_IP:                                                                                                \
+            return launch_groups_t<T, 1>(ctx, g, rows, ids, ids_at, ids_stride, n_arr, from_arr, pair_at, ngroups, out); \
+        case PGV_L1:                                                                                                    \
+            return launch_groups_t<T, 2>(ctx, g, rows, ids, ids_at, ids_stride, n_arr, from_arr, pair_at, ngroups, out); \
+    }
+    if (dtype == PGV_F32) {
+        PGV_GROUPS(float)
+    } else {
+        PGV_GROUPS(__half)
+    }
+#undef PGV_GROUPS
     PGV_FAIL(PGV_ERR_ARG, "score: unknown metric %d", (int)metric);
 }
 

@@ -75,6 +75,17 @@ int pgv_hnsw_upload_payload(pgv_ctx *ctx, pgv_metric metric, pgv_dtype dtype, in
     return PGV_OK;
 }
 
+// PGV_HNSW_PAIRS_GATHER=1: the build's pair distances by the older gathered kernel (one pair a lane group, both rows from
+// L2) instead of score_groups_kernel's 4 x 4 tiles -- the same values bit for bit, for A/B runs
+static bool hnsw_pairs_by_gather() {
+    static int v = -1;
+    if (v < 0) {
+        const char *e = getenv("PGV_HNSW_PAIRS_GATHER");
+        v = e && atoi(e) != 0 ? 1 : 0;
+    }
+    return v != 0;
+}
+
 // Searches on this handle's stream see the mirror's last patch, whichever stream ran it (a device-side wait).
 static int hnsw_graph_acquire(pgv_hnsw *h) {
     pgv_hnsw *o = h->view_of ? h->view_of : h;
@@ -119,6 +130,8 @@ int pgv_hnsw_share(pgv_hnsw *h, pgv_ctx *ctx, pgv_hnsw **out) {
     return PGV_OK;
 }
 
+static void hnsw_link_free(pgv_hnsw *o);
+
 void pgv_hnsw_free(pgv_hnsw *h) {
     if (!h) return;
     if (h->ctx) (void)hipStreamSynchronize(h->ctx->stream);
@@ -127,6 +140,7 @@ void pgv_hnsw_free(pgv_hnsw *h) {
         delete h;
         return;
     }
+    hnsw_link_free(h);
     if (h->graph_ev) (void)hipEventDestroy(h->graph_ev);
     if (h->imported) {
         if (h->elements) (void)hipIpcCloseMemHandle(h->elements);
@@ -405,46 +419,17 @@ int pgv_hnsw_build_search(pgv_hnsw *h, const int32_t *elements, const int32_t *i
     return sync_if(ctx, need);
 }
 
-int pgv_hnsw_build_neighbors(pgv_hnsw *h, const int32_t *elements, const int32_t *insert_levels, int nq,
-                             int ef_construction, int layer_cap, int32_t *out_ids, float *out_dist, uint8_t *out_closer,
-                             int32_t *out_count, int64_t *out_pairs) {
-    if (!h || !out_ids || !out_dist || !out_closer || !out_count)
-        PGV_FAIL(PGV_ERR_ARG, "pgv_hnsw_build_neighbors: handle/out is NULL");
-    hnsw_view_refresh(h);
-    if (nq < 0 || layer_cap < 1) PGV_FAIL(PGV_ERR_ARG, "bad sizes");
-    if (ef_construction < 4 || ef_construction > 1000)
-        PGV_FAIL(PGV_ERR_ARG, "ef_construction must be 4..1000 (src/hnsw.h:58-59), got %d", ef_construction);
-    if (h->m == 0) PGV_FAIL(PGV_ERR_ARG, "pgv_hnsw_build_neighbors needs pgv_hnsw_set_graph first");
-    if (out_pairs) *out_pairs = 0;
-    if (nq == 0) return PGV_OK;
-    if (!elements || !insert_levels) PGV_FAIL(PGV_ERR_ARG, "elements/insert_levels is NULL");
+// the searches of a batch into lw_* (device arrays [nq x layer_cap x ef] / [nq x layer_cap]), on ctx's stream
+static int hnsw_search_into(pgv_hnsw *h, const int32_t *e_dev, const int32_t *l_dev, int nq, int ef_construction, int layer_cap,
+                            int32_t *lw_ids, float *lw_dist, int32_t *lw_cnt) {
     pgv_ctx *ctx = h->ctx;
-    PGV_HIP(hipSetDevice(ctx->device));
-    PGV_TRY(hnsw_graph_acquire(h));
-    const int m = h->m, stride = 2 * m;
-    const size_t per = (size_t)nq * layer_cap;
-    if (per > 0x7fffffff / (size_t)(ef_construction > stride ? ef_construction : stride))
-        PGV_FAIL(PGV_ERR_ARG, "pgv_hnsw_build_neighbors: batch too large");
-    const int ngroups = (int)per;
-    const void *e_dev, *l_dev;
-    PGV_TRY(stage_flat(ctx, elements, sizeof(int32_t) * (size_t)nq, ctx->idx_stage, &e_dev));
-    PGV_TRY(stage_flat(ctx, insert_levels, sizeof(int32_t) * (size_t)nq, ctx->plan_c, &l_dev));
     int words = 0;
     const int grid = hnsw_search_grid(ctx, nq, h->n, &words);
     PGV_TRY(h->bitmaps.ensure((size_t)grid * words * sizeof(uint32_t)));
     PGV_TRY(ctx->counters.ensure(256));
-    // the candidate lists stay on the device: km_b ids | km_c distances | km_d counts
-    PGV_TRY(ctx->km_b.ensure(sizeof(int32_t) * per * ef_construction));
-    PGV_TRY(ctx->km_c.ensure(sizeof(float) * per * ef_construction));
-    PGV_TRY(ctx->km_d.ensure(sizeof(int32_t) * per));
-    PGV_TRY(ctx->km_e.ensure(sizeof(int64_t) * (per + 1)));
-    int32_t *lw_ids = ctx->km_b.as<int32_t>();
-    float *lw_dist = ctx->km_c.as<float>();
-    int32_t *lw_cnt = ctx->km_d.as<int32_t>();
-    int64_t *pair_start = ctx->km_e.as<int64_t>();
     HnswSearchArgs a;
-    a.qids = static_cast<const int32_t *>(e_dev);
-    a.qlevels = static_cast<const int32_t *>(l_dev);
+    a.qids = e_dev;
+    a.qlevels = l_dev;
     a.nq = nq;
     a.ef = ef_construction;
     a.k = 0;
@@ -452,25 +437,41 @@ int pgv_hnsw_build_neighbors(pgv_hnsw *h, const int32_t *elements, const int32_t
     a.lw_dist = lw_dist;
     a.lw_cnt = lw_cnt;
     a.lcap = layer_cap;
-    PGV_TRY(launch_hnsw_search(ctx, h->metric, h->dtype, h->geom, h->elements, h->n, h->levels, h->nbr_start, h->nbr, m,
-                               h->entry, a, h->bitmaps.as<uint32_t>(), words, grid, ctx->counters.as<int>()));
+    return launch_hnsw_search(ctx, h->metric, h->dtype, h->geom, h->elements, h->n, h->levels, h->nbr_start, h->nbr, h->m,
+                              h->entry, a, h->bitmaps.as<uint32_t>(), words, grid, ctx->counters.as<int>());
+}
+
+// SelectNeighbors over the candidate lists lw_* of a batch (device arrays), on ctx's stream; outputs as pgv_hnsw_build_neighbors
+static int hnsw_select_from(pgv_hnsw *h, const int32_t *lw_ids, const float *lw_dist, const int32_t *lw_cnt, const int32_t *l_dev,
+                            int nq, int ef_construction, int layer_cap, int32_t *out_ids, float *out_dist, uint8_t *out_closer,
+                            int32_t *out_count, int64_t *out_pairs) {
+    pgv_ctx *ctx = h->ctx;
+    const int m = h->m, stride = 2 * m;
+    const size_t per = (size_t)nq * layer_cap;
+    const int ngroups = (int)per;
+    PGV_TRY(ctx->km_e.ensure(sizeof(int64_t) * (per + 1)));
+    int64_t *pair_start = ctx->km_e.as<int64_t>();
     // which lists SelectNeighbors has to thin, and where each one's pair triangle goes; the total comes back (8 bytes:
-    // it sizes the next two launches)
+    // it sizes the next launches)
     PGV_TRY(launch_hnsw_select_plan(ctx, lw_cnt, ngroups, layer_cap, m, pair_start));
     int64_t npairs = 0;
     PGV_HIP(hipMemcpyAsync(&npairs, pair_start + ngroups, sizeof(int64_t), hipMemcpyDeviceToHost, ctx->stream));
     PGV_HIP(hipStreamSynchronize(ctx->stream));
     if (npairs < 0 || npairs > (int64_t)per * ef_construction * (ef_construction - 1) / 2)
-        PGV_FAIL(PGV_ERR_STATE, "pgv_hnsw_build_neighbors: %lld pairs planned", (long long)npairs);
+        PGV_FAIL(PGV_ERR_STATE, "hnsw select: %lld pairs planned", (long long)npairs);
     if (npairs > 0) {
-        PGV_TRY(ctx->km_f.ensure(sizeof(int32_t) * (size_t)npairs));
-        PGV_TRY(ctx->km_g.ensure(sizeof(int32_t) * (size_t)npairs));
         PGV_TRY(ctx->dist_mat.ensure(sizeof(float) * (size_t)npairs));
-        PGV_TRY(launch_hnsw_select_pairs(ctx, lw_ids, lw_cnt, pair_start, ngroups, ef_construction, ctx->km_f.as<int32_t>(),
-                                         ctx->km_g.as<int32_t>()));
-        // CheckElementCloser's HnswGetDistance (src/hnswutils.c:1040-1059): the same kernel as pgv_hnsw_score_groups
-        PGV_TRY(launch_score_gather(ctx, h->metric, h->dtype, h->geom, h->elements, h->elements, ctx->km_f.as<int32_t>(),
-                                    ctx->km_g.as<int32_t>(), npairs, ctx->dist_mat.as<float>()));
+        // CheckElementCloser's HnswGetDistance (src/hnswutils.c:1040-1059), a list's triangle in 4 x 4 tiles
+        if (hnsw_pairs_by_gather()) {
+            PGV_TRY(ctx->km_f.ensure(sizeof(int32_t) * (size_t)npairs));
+            PGV_TRY(ctx->km_g.ensure(sizeof(int32_t) * (size_t)npairs));
+            PGV_TRY(launch_hnsw_select_pairs(ctx, lw_ids, lw_cnt, pair_start, ngroups, ef_construction, ctx->km_f.as<int32_t>(),
+                                             ctx->km_g.as<int32_t>()));
+            PGV_TRY(launch_score_gather(ctx, h->metric, h->dtype, h->geom, h->elements, h->elements, ctx->km_f.as<int32_t>(),
+                                        ctx->km_g.as<int32_t>(), npairs, ctx->dist_mat.as<float>()));
+        } else
+            PGV_TRY(launch_score_groups(ctx, h->metric, h->dtype, h->geom, h->elements, lw_ids, nullptr, ef_construction, lw_cnt,
+                                        nullptr, pair_start, ngroups, ctx->dist_mat.as<float>()));
     } else
         PGV_TRY(ctx->dist_mat.ensure(16));
     OutArg oi, od, oc, on;
@@ -478,9 +479,8 @@ int pgv_hnsw_build_neighbors(pgv_hnsw *h, const int32_t *elements, const int32_t
     PGV_TRY(od.init(out_dist, sizeof(float) * per * stride, ctx->out_stage2));
     PGV_TRY(oc.init(out_closer, per * stride, ctx->sel_a));
     PGV_TRY(on.init(out_count, sizeof(int32_t) * per, ctx->sel_b));
-    PGV_TRY(launch_hnsw_select(ctx, lw_ids, lw_dist, lw_cnt, static_cast<const int32_t *>(l_dev), pair_start,
-                               ctx->dist_mat.as<float>(), ngroups, layer_cap, ef_construction, m, stride, oi.as<int32_t>(),
-                               od.as<float>(), oc.as<uint8_t>(), on.as<int32_t>()));
+    PGV_TRY(launch_hnsw_select(ctx, lw_ids, lw_dist, lw_cnt, l_dev, pair_start, ctx->dist_mat.as<float>(), ngroups, layer_cap,
+                               ef_construction, m, stride, oi.as<int32_t>(), od.as<float>(), oc.as<uint8_t>(), on.as<int32_t>()));
     if (out_pairs) *out_pairs = npairs;
     bool need = false;
     PGV_TRY(oi.finish(ctx, &need));
@@ -488,6 +488,98 @@ int pgv_hnsw_build_neighbors(pgv_hnsw *h, const int32_t *elements, const int32_t
     PGV_TRY(oc.finish(ctx, &need));
     PGV_TRY(on.finish(ctx, &need));
     return sync_if(ctx, need);
+}
+
+static int hnsw_build_args(pgv_hnsw *h, const char *who, int nq, int ef_construction, int layer_cap) {
+    if (nq < 0 || layer_cap < 1) PGV_FAIL(PGV_ERR_ARG, "%s: bad sizes", who);
+    if (ef_construction < 4 || ef_construction > 1000)
+        PGV_FAIL(PGV_ERR_ARG, "ef_construction must be 4..1000 (src/hnsw.h:58-59), got %d", ef_construction);
+    if (h->m == 0) PGV_FAIL(PGV_ERR_ARG, "%s needs pgv_hnsw_set_graph first", who);
+    const int stride = 2 * h->m;
+    if ((size_t)nq * layer_cap > 0x7fffffff / (size_t)(ef_construction > stride ? ef_construction : stride))
+        PGV_FAIL(PGV_ERR_ARG, "%s: batch too large", who);
+    return PGV_OK;
+}
+
+int pgv_hnsw_build_neighbors(pgv_hnsw *h, const int32_t *elements, const int32_t *insert_levels, int nq,
+                             int ef_construction, int layer_cap, int32_t *out_ids, float *out_dist, uint8_t *out_closer,
+                             int32_t *out_count, int64_t *out_pairs) {
+    if (!h || !out_ids || !out_dist || !out_closer || !out_count)
+        PGV_FAIL(PGV_ERR_ARG, "pgv_hnsw_build_neighbors: handle/out is NULL");
+    hnsw_view_refresh(h);
+    PGV_TRY(hnsw_build_args(h, "pgv_hnsw_build_neighbors", nq, ef_construction, layer_cap));
+    if (out_pairs) *out_pairs = 0;
+    if (nq == 0) return PGV_OK;
+    if (!elements || !insert_levels) PGV_FAIL(PGV_ERR_ARG, "elements/insert_levels is NULL");
+    pgv_ctx *ctx = h->ctx;
+    PGV_HIP(hipSetDevice(ctx->device));
+    PGV_TRY(hnsw_graph_acquire(h));
+    const size_t per = (size_t)nq * layer_cap;
+    const void *e_dev, *l_dev;
+    PGV_TRY(stage_flat(ctx, elements, sizeof(int32_t) * (size_t)nq, ctx->idx_stage, &e_dev));
+    PGV_TRY(stage_flat(ctx, insert_levels, sizeof(int32_t) * (size_t)nq, ctx->plan_c, &l_dev));
+    // the candidate lists stay on the device: km_b ids | km_c distances | km_d counts
+    PGV_TRY(ctx->km_b.ensure(sizeof(int32_t) * per * ef_construction));
+    PGV_TRY(ctx->km_c.ensure(sizeof(float) * per * ef_construction));
+    PGV_TRY(ctx->km_d.ensure(sizeof(int32_t) * per));
+    PGV_TRY(hnsw_search_into(h, static_cast<const int32_t *>(e_dev), static_cast<const int32_t *>(l_dev), nq, ef_construction,
+                             layer_cap, ctx->km_b.as<int32_t>(), ctx->km_c.as<float>(), ctx->km_d.as<int32_t>()));
+    return hnsw_select_from(h, ctx->km_b.as<int32_t>(), ctx->km_c.as<float>(), ctx->km_d.as<int32_t>(),
+                            static_cast<const int32_t *>(l_dev), nq, ef_construction, layer_cap, out_ids, out_dist, out_closer,
+                            out_count, out_pairs);
+}
+
+// pgv_hnsw_build_neighbors in two halves, for a caller that overlaps them: the searches of a batch, whose candidate
+// lists are KEPT on the device in one of two slots of the mirror's build state (pgv_hnsw_link_begin), and the selection
+// over a kept slot -- from any view of the mirror, on that view's stream.  The searches of batch n + 2 (other slot, one
+// view) then run beside the selection of batch n + 1 (another view).
+int pgv_hnsw_build_search_keep(pgv_hnsw *h, const int32_t *elements, const int32_t *insert_levels, int nq, int ef_construction,
+                               int layer_cap, int slot) {
+    if (!h) PGV_FAIL(PGV_ERR_ARG, "pgv_hnsw_build_search_keep: handle is NULL");
+    hnsw_view_refresh(h);
+    pgv_hnsw *o = h->view_of ? h->view_of : h;
+    if (!o->link) PGV_FAIL(PGV_ERR_STATE, "pgv_hnsw_build_search_keep needs pgv_hnsw_link_begin");
+    if (slot < 0 || slot > 1) PGV_FAIL(PGV_ERR_ARG, "slot must be 0 or 1");
+    PGV_TRY(hnsw_build_args(h, "pgv_hnsw_build_search_keep", nq, ef_construction, layer_cap));
+    HnswLinkState::Kept &K = o->link->kept[slot];
+    K.nq = 0;
+    if (nq == 0) return PGV_OK;
+    if (!elements || !insert_levels) PGV_FAIL(PGV_ERR_ARG, "elements/insert_levels is NULL");
+    pgv_ctx *ctx = h->ctx;
+    PGV_HIP(hipSetDevice(ctx->device));
+    PGV_TRY(hnsw_graph_acquire(h));
+    const size_t per = (size_t)nq * layer_cap;
+    PGV_TRY(K.ids.ensure(sizeof(int32_t) * per * ef_construction));
+    PGV_TRY(K.dist.ensure(sizeof(float) * per * ef_construction));
+    PGV_TRY(K.cnt.ensure(sizeof(int32_t) * per));
+    PGV_TRY(K.elems.ensure(sizeof(int32_t) * 2 * (size_t)nq));
+    int32_t *e_dev = K.elems.as<int32_t>(), *l_dev = e_dev + nq;
+    PGV_HIP(hipMemcpyAsync(e_dev, elements, sizeof(int32_t) * (size_t)nq, hipMemcpyDefault, ctx->stream));
+    PGV_HIP(hipMemcpyAsync(l_dev, insert_levels, sizeof(int32_t) * (size_t)nq, hipMemcpyDefault, ctx->stream));
+    PGV_TRY(hnsw_search_into(h, e_dev, l_dev, nq, ef_construction, layer_cap, K.ids.as<int32_t>(), K.dist.as<float>(),
+                             K.cnt.as<int32_t>()));
+    PGV_HIP(hipStreamSynchronize(ctx->stream));  // the searches are over when this returns: the tuples may be rewritten
+    K.nq = nq;
+    K.ef = ef_construction;
+    K.lcap = layer_cap;
+    return PGV_OK;
+}
+
+int pgv_hnsw_build_select_kept(pgv_hnsw *h, int slot, int32_t *out_ids, float *out_dist, uint8_t *out_closer, int32_t *out_count,
+                               int64_t *out_pairs) {
+    if (!h || !out_ids || !out_dist || !out_closer || !out_count)
+        PGV_FAIL(PGV_ERR_ARG, "pgv_hnsw_build_select_kept: handle/out is NULL");
+    hnsw_view_refresh(h);
+    pgv_hnsw *o = h->view_of ? h->view_of : h;
+    if (!o->link) PGV_FAIL(PGV_ERR_STATE, "pgv_hnsw_build_select_kept needs pgv_hnsw_link_begin");
+    if (slot < 0 || slot > 1) PGV_FAIL(PGV_ERR_ARG, "slot must be 0 or 1");
+    if (out_pairs) *out_pairs = 0;
+    const HnswLinkState::Kept &K = o->link->kept[slot];
+    if (K.nq == 0) return PGV_OK;
+    PGV_HIP(hipSetDevice(h->ctx->device));
+    const int32_t *l_dev = K.elems.as<int32_t>() + K.nq;
+    return hnsw_select_from(h, K.ids.as<int32_t>(), K.dist.as<float>(), K.cnt.as<int32_t>(), l_dev, K.nq, K.ef, K.lcap, out_ids,
+                            out_dist, out_closer, out_count, out_pairs);
 }
 
 int pgv_hnsw_score_pairs(pgv_hnsw *h, const int32_t *a, const int32_t *b, int64_t npairs, float *out) {
@@ -534,20 +626,278 @@ int pgv_hnsw_score_groups(pgv_hnsw *h, const int32_t *ids, const int64_t *ids_st
     PGV_TRY(put(tab + b_ids, ids_start, b_start));
     PGV_TRY(put(tab + b_ids + b_start, pair_start, b_start));
     PGV_TRY(put(tab + b_ids + 2 * b_start, from, sizeof(int32_t) * (size_t)ngroups));
-    PGV_TRY(ctx->idx_stage.ensure(sizeof(int32_t) * (size_t)npairs));
-    PGV_TRY(ctx->plan_d.ensure(sizeof(int32_t) * (size_t)npairs));
-    int32_t *a_dev = ctx->idx_stage.as<int32_t>(), *b_dev = ctx->plan_d.as<int32_t>();
-    PGV_TRY(launch_expand_groups(ctx, reinterpret_cast<const int32_t *>(tab),
-                                 reinterpret_cast<const int64_t *>(tab + b_ids),
-                                 reinterpret_cast<const int32_t *>(tab + b_ids + 2 * b_start),
-                                 reinterpret_cast<const int64_t *>(tab + b_ids + b_start), ngroups, a_dev, b_dev));
     OutArg od;
     PGV_TRY(od.init(out, sizeof(float) * (size_t)npairs, ctx->out_stage));
-    PGV_TRY(launch_score_gather(ctx, h->metric, h->dtype, h->geom, h->elements, h->elements, a_dev, b_dev, npairs,
-                                od.as<float>()));
+    if (hnsw_pairs_by_gather()) {
+        PGV_TRY(ctx->idx_stage.ensure(sizeof(int32_t) * (size_t)npairs));
+        PGV_TRY(ctx->plan_d.ensure(sizeof(int32_t) * (size_t)npairs));
+        int32_t *a_dev = ctx->idx_stage.as<int32_t>(), *b_dev = ctx->plan_d.as<int32_t>();
+        PGV_TRY(launch_expand_groups(ctx, reinterpret_cast<const int32_t *>(tab),
+                                     reinterpret_cast<const int64_t *>(tab + b_ids),
+                                     reinterpret_cast<const int32_t *>(tab + b_ids + 2 * b_start),
+                                     reinterpret_cast<const int64_t *>(tab + b_ids + b_start), ngroups, a_dev, b_dev));
+        PGV_TRY(launch_score_gather(ctx, h->metric, h->dtype, h->geom, h->elements, h->elements, a_dev, b_dev, npairs,
+                                    od.as<float>()));
+    } else
+        PGV_TRY(launch_score_groups(ctx, h->metric, h->dtype, h->geom, h->elements, reinterpret_cast<const int32_t *>(tab),
+                                    reinterpret_cast<const int64_t *>(tab + b_ids), 0, nullptr,
+                                    reinterpret_cast<const int32_t *>(tab + b_ids + 2 * b_start),
+                                    reinterpret_cast<const int64_t *>(tab + b_ids + b_start), ngroups, od.as<float>()));
     bool need = true;  // the host tables above must have been read before the caller reuses them
     PGV_TRY(od.finish(ctx, &need));
     return sync_if(ctx, need);
+}
+
+// ------------------------------------------------------------------ the build's graph updates on the device
+static void hnsw_link_free(pgv_hnsw *o) {
+    HnswLinkState *L = o->link;
+    if (!L) return;
+    if (L->nb_dist) (void)hipFree(L->nb_dist);
+    if (L->nb_flag) (void)hipFree(L->nb_flag);
+    if (L->list_count) (void)hipFree(L->list_count);
+    L->rec.release();
+    L->links.release();
+    L->ids.release();
+    L->pa.release();
+    L->pb.release();
+    L->tri.release();
+    L->mm.release();
+    L->loc.release();
+    L->sel.release();
+    for (int i = 0; i < 2; i++) {
+        L->kept[i].ids.release();
+        L->kept[i].dist.release();
+        L->kept[i].cnt.release();
+        L->kept[i].elems.release();
+    }
+    delete L;
+    o->link = nullptr;
+}
+
+int pgv_hnsw_link_begin(pgv_hnsw *h) {
+    if (!h) PGV_FAIL(PGV_ERR_ARG, "pgv_hnsw_link_begin: handle is NULL");
+    if (h->imported || h->view_of) PGV_FAIL(PGV_ERR_STATE, "pgv_hnsw_link_begin: an imported mirror / a view is read-only");
+    if (h->m == 0) PGV_FAIL(PGV_ERR_ARG, "pgv_hnsw_link_begin needs pgv_hnsw_set_graph first");
+    pgv_ctx *ctx = h->ctx;
+    PGV_HIP(hipSetDevice(ctx->device));
+    hnsw_link_free(h);
+    HnswLinkState *L = new (std::nothrow) HnswLinkState();
+    if (!L) PGV_FAIL(PGV_ERR_NOMEM, "out of host memory");
+    const size_t total = (size_t)(h->nbr_total > 0 ? h->nbr_total : 1);
+    L->nlists = total / (size_t)h->m + 1;  // every list starts at a multiple of m
+    if (hipMalloc(&L->nb_dist, total * sizeof(float)) != hipSuccess || hipMalloc(&L->nb_flag, total) != hipSuccess ||
+        hipMalloc(&L->list_count, 2 * L->nlists * sizeof(int)) != hipSuccess) {
+        if (L->nb_dist) (void)hipFree(L->nb_dist);
+        if (L->nb_flag) (void)hipFree(L->nb_flag);
+        delete L;
+        PGV_FAIL(PGV_ERR_NOMEM, "hipMalloc(%zu) for the hnsw build state failed", total * 5 + 2 * L->nlists * sizeof(int));
+    }
+    L->list_rec = L->list_count + L->nlists;
+    h->link = L;
+    PGV_HIP(hipMemsetAsync(L->nb_dist, 0, total * sizeof(float), ctx->stream));
+    PGV_HIP(hipMemsetAsync(L->nb_flag, 0, total, ctx->stream));
+    PGV_HIP(hipMemsetAsync(L->list_count, 0, 2 * L->nlists * sizeof(int), ctx->stream));
+    PGV_HIP(hipStreamSynchronize(ctx->stream));
+    return PGV_OK;
+}
+
+int pgv_hnsw_link_prepare(pgv_hnsw *h, const int32_t *elements, const uint8_t *linked, int nq, int layer_cap,
+                          const int32_t *sel_ids, const float *sel_dist, const uint8_t *sel_closer, const int32_t *sel_count,
+                          int64_t *out_pairs) {
+    if (!h || !h->link) PGV_FAIL(PGV_ERR_STATE, "pgv_hnsw_link_prepare needs pgv_hnsw_link_begin");
+    if (nq < 0 || layer_cap < 1) PGV_FAIL(PGV_ERR_ARG, "bad sizes");
+    HnswLinkState *L = h->link;
+    pgv_ctx *ctx = h->ctx;
+    PGV_HIP(hipSetDevice(ctx->device));
+    if (out_pairs) *out_pairs = 0;
+    L->nrec = 0;
+    L->npairs = 0;
+    L->nq = nq;
+    L->lcap = layer_cap;
+    L->prepared = true;
+    if (nq == 0) return PGV_OK;
+    if (!elements || !linked || !sel_ids || !sel_dist || !sel_closer || !sel_count)
+        PGV_FAIL(PGV_ERR_ARG, "the new elements' lists are NULL");
+    const int m = h->m;
+    const size_t per = (size_t)nq * layer_cap, stride = 2 * (size_t)m;
+    if (per * stride > 0x7fffffff) PGV_FAIL(PGV_ERR_ARG, "pgv_hnsw_link_prepare: batch too large");
+    // a searcher on another stream has left the tuples as the last patch / link made them
+    PGV_TRY(hnsw_graph_acquire(h));
+    // the batch's own lists (pgv_hnsw_build_neighbors' output), kept until _apply puts them in place
+    {
+        const size_t b_ids = sizeof(int32_t) * per * stride, b_dist = sizeof(float) * per * stride, b_cnt = sizeof(int32_t) * per,
+                     b_el = sizeof(int32_t) * (size_t)nq, b_cl = (per * stride + 15) & ~(size_t)15, b_ln = ((size_t)nq + 15) & ~(size_t)15;
+        PGV_TRY(L->sel.ensure(b_ids + b_dist + b_cnt + b_el + b_cl + b_ln));
+        char *base = L->sel.as<char>();
+        L->d_sel_ids = reinterpret_cast<int32_t *>(base);
+        L->d_sel_dist = reinterpret_cast<float *>(base + b_ids);
+        L->d_sel_cnt = reinterpret_cast<int32_t *>(base + b_ids + b_dist);
+        L->d_elems = reinterpret_cast<int32_t *>(base + b_ids + b_dist + b_cnt);
+        L->d_sel_closer = reinterpret_cast<uint8_t *>(base + b_ids + b_dist + b_cnt + b_el);
+        L->d_linked = L->d_sel_closer + b_cl;
+        PGV_HIP(hipMemcpyAsync(L->d_sel_ids, sel_ids, b_ids, hipMemcpyDefault, ctx->stream));
+        PGV_HIP(hipMemcpyAsync(L->d_sel_dist, sel_dist, b_dist, hipMemcpyDefault, ctx->stream));
+        PGV_HIP(hipMemcpyAsync(L->d_sel_cnt, sel_count, b_cnt, hipMemcpyDefault, ctx->stream));
+        PGV_HIP(hipMemcpyAsync(L->d_elems, elements, b_el, hipMemcpyDefault, ctx->stream));
+        PGV_HIP(hipMemcpyAsync(L->d_sel_closer, sel_closer, per * stride, hipMemcpyDefault, ctx->stream));
+        PGV_HIP(hipMemcpyAsync(L->d_linked, linked, (size_t)nq, hipMemcpyDefault, ctx->stream));
+    }
+    // records: at most one per request
+    const size_t cap = per * stride, n1 = cap + 1;
+    const size_t b64 = sizeof(int64_t) * (5 * n1 + 4), b32 = sizeof(int32_t) * (7 * n1 + 4);
+    PGV_TRY(L->rec.ensure(b64 + b32));
+    char *base = L->rec.as<char>();
+    L->rec_off = reinterpret_cast<int64_t *>(base);
+    L->rec_pos = L->rec_off + n1;
+    L->ids_start = L->rec_pos + n1;
+    L->pair_start = L->ids_start + n1;
+    L->mm_start = L->pair_start + n1;
+    L->totals = L->mm_start + n1;
+    L->rec_owner = reinterpret_cast<int32_t *>(base + b64);
+    L->rec_lc = L->rec_owner + n1;
+    L->rec_nstart = L->rec_lc + n1;
+    L->rec_from = L->rec_nstart + n1;
+    L->rec_wait = L->rec_from + n1;
+    L->rec_list = L->rec_wait + n1;
+    L->rec_fill = reinterpret_cast<int *>(L->rec_list + n1);
+    L->blocked = L->rec_fill + n1;
+    L->nrec_dev = L->blocked + 1;
+    PGV_TRY(L->links.ensure((sizeof(int32_t) + sizeof(float)) * cap));
+    L->d_link_elem = L->links.as<int32_t>();
+    L->d_link_dist = reinterpret_cast<float *>(L->d_link_elem + cap);
+    PGV_HIP(hipMemsetAsync(L->nrec_dev, 0, sizeof(int), ctx->stream));
+    PGV_TRY(launch_hnsw_link_group(ctx, 0, L->d_elems, L->d_linked, nq, layer_cap, m, L->d_sel_ids, L->d_sel_dist, L->d_sel_cnt,
+                                   h->levels, h->nbr_start, L->list_count, L->list_rec, L->nrec_dev, L->rec_owner, L->rec_lc,
+                                   L->rec_list, nullptr, nullptr, nullptr, nullptr));
+    int nrec = 0;
+    PGV_HIP(hipMemcpyAsync(&nrec, L->nrec_dev, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
+    PGV_HIP(hipStreamSynchronize(ctx->stream));  // (also: the caller's arrays have been read)
+    if (nrec < 0 || (size_t)nrec > cap) PGV_FAIL(PGV_ERR_STATE, "pgv_hnsw_link_prepare: %d records", nrec);
+    L->nrec = nrec;
+    if (nrec == 0) return PGV_OK;
+    PGV_TRY(launch_hnsw_link_size(ctx, h->nbr, L->nb_flag, h->levels, h->nbr_start, m, L->rec_owner, L->rec_lc, L->rec_list,
+                                  L->list_count, L->rec_off, nrec, 0, L->rec_pos, L->rec_nstart, L->rec_from, nullptr,
+                                  L->ids_start, L->pair_start));
+    PGV_TRY(launch_hnsw_link_scan(ctx, L->rec_off, L->ids_start, L->pair_start, nrec, L->totals));
+    PGV_HIP(hipMemsetAsync(L->rec_fill, 0, sizeof(int) * (size_t)nrec, ctx->stream));
+    PGV_TRY(launch_hnsw_link_group(ctx, 1, L->d_elems, L->d_linked, nq, layer_cap, m, L->d_sel_ids, L->d_sel_dist, L->d_sel_cnt,
+                                   h->levels, h->nbr_start, L->list_count, L->list_rec, L->nrec_dev, L->rec_owner, L->rec_lc,
+                                   L->rec_list, L->rec_off, L->rec_fill, L->d_link_elem, L->d_link_dist));
+    int64_t totals[3] = {0, 0, 0};
+    PGV_HIP(hipMemcpyAsync(totals, L->totals, sizeof(totals), hipMemcpyDeviceToHost, ctx->stream));
+    PGV_HIP(hipStreamSynchronize(ctx->stream));
+    const int64_t nlinks = totals[0], nids = totals[1], npairs = totals[2];
+    const int64_t lm0 = 2 * (int64_t)m;
+    if (nlinks < nrec || (size_t)nlinks > cap || nids < nlinks || nids > nlinks + (int64_t)nrec * lm0 || npairs < 0)
+        PGV_FAIL(PGV_ERR_STATE, "pgv_hnsw_link_prepare: %lld links / %lld ids / %lld pairs planned for %d records",
+                 (long long)nlinks, (long long)nids, (long long)npairs, nrec);
+    PGV_TRY(L->ids.ensure(sizeof(int32_t) * (size_t)(nids > 0 ? nids : 1)));
+    PGV_TRY(L->tri.ensure(sizeof(float) * (size_t)(npairs > 0 ? npairs : 1)));
+    const bool gather = hnsw_pairs_by_gather();
+    if (gather) {
+        PGV_TRY(L->pa.ensure(sizeof(int32_t) * (size_t)(npairs > 0 ? npairs : 1)));
+        PGV_TRY(L->pb.ensure(sizeof(int32_t) * (size_t)(npairs > 0 ? npairs : 1)));
+    }
+    // the id lists (and, for the gathered form, the slot pairs)
+    PGV_TRY(launch_hnsw_link_pairs(ctx, h->nbr, L->rec_pos, L->rec_nstart, L->rec_from, L->rec_off, L->d_link_elem, L->d_link_dist,
+                                   L->rec_list, L->list_count, nrec, 0, L->ids_start, L->ids.as<int32_t>(), L->pair_start,
+                                   gather ? L->pa.as<int32_t>() : nullptr, gather ? L->pb.as<int32_t>() : nullptr));
+    if (npairs > 0) {
+        if (gather)
+            PGV_TRY(launch_score_gather(ctx, h->metric, h->dtype, h->geom, h->elements, h->elements, L->pa.as<int32_t>(),
+                                        L->pb.as<int32_t>(), npairs, L->tri.as<float>()));
+        else
+            PGV_TRY(launch_score_groups(ctx, h->metric, h->dtype, h->geom, h->elements, L->ids.as<int32_t>(), L->ids_start, 0,
+                                        nullptr, L->rec_from, L->pair_start, nrec, L->tri.as<float>()));
+    }
+    L->npairs = npairs;
+    if (out_pairs) *out_pairs = npairs;
+    return PGV_OK;  // the scoring runs on; pgv_hnsw_link_apply is ordered behind it on the same stream
+}
+
+int pgv_hnsw_link_apply(pgv_hnsw *h, int32_t entry, int64_t *out_pairs, int *out_deferred) {
+    if (!h || !h->link || !h->link->prepared) PGV_FAIL(PGV_ERR_STATE, "pgv_hnsw_link_apply needs pgv_hnsw_link_prepare");
+    if (entry < -1 || entry >= h->n) PGV_FAIL(PGV_ERR_ARG, "entry point %d out of range", (int)entry);
+    HnswLinkState *L = h->link;
+    pgv_ctx *ctx = h->ctx;
+    PGV_HIP(hipSetDevice(ctx->device));
+    if (out_pairs) *out_pairs = 0;
+    if (out_deferred) *out_deferred = 0;
+    L->prepared = false;
+    const int nrec = L->nrec, m = h->m;
+    if (nrec > 0) {
+        PGV_TRY(L->loc.ensure(sizeof(int16_t) * (size_t)nrec * (2 * (size_t)m + 1)));
+        PGV_HIP(hipMemsetAsync(L->blocked, 0, sizeof(int), ctx->stream));
+        PGV_TRY(launch_hnsw_link_replay(ctx, h->nbr, L->nb_dist, L->nb_flag, m, nrec, 0, L->rec_lc, L->rec_off, L->d_link_dist,
+                                        L->rec_pos, L->rec_nstart, L->rec_from, L->ids_start, L->ids.as<int32_t>(), L->pair_start,
+                                        L->tri.as<float>(), nullptr, nullptr, L->rec_wait, L->loc.as<int16_t>(), L->blocked));
+        int blocked = 0;
+        PGV_HIP(hipMemcpyAsync(&blocked, L->blocked, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
+        PGV_HIP(hipStreamSynchronize(ctx->stream));
+        if (blocked > 0) {
+            // the replays that stepped outside the pairs fetched for them: their lists' member-member triangles, then
+            // the rest of their newcomers
+            PGV_TRY(launch_hnsw_link_size(ctx, h->nbr, L->nb_flag, h->levels, h->nbr_start, m, L->rec_owner, L->rec_lc, L->rec_list,
+                                          L->list_count, L->rec_off, nrec, 1, L->rec_pos, L->rec_nstart, L->rec_from, L->rec_wait,
+                                          nullptr, L->mm_start));
+            PGV_TRY(launch_hnsw_link_scan(ctx, L->mm_start, nullptr, nullptr, nrec, L->totals));
+            int64_t npairs2 = 0;
+            PGV_HIP(hipMemcpyAsync(&npairs2, L->totals, sizeof(int64_t), hipMemcpyDeviceToHost, ctx->stream));
+            PGV_HIP(hipStreamSynchronize(ctx->stream));
+            if (npairs2 < 0 || npairs2 > (int64_t)blocked * (2 * (int64_t)m) * (2 * (int64_t)m))
+                PGV_FAIL(PGV_ERR_STATE, "pgv_hnsw_link_apply: %lld member pairs planned for %d lists", (long long)npairs2, blocked);
+            if (npairs2 > 0) {
+                PGV_TRY(L->mm.ensure(sizeof(float) * (size_t)npairs2));
+                if (hnsw_pairs_by_gather()) {
+                    PGV_TRY(L->pa.ensure(sizeof(int32_t) * (size_t)npairs2));
+                    PGV_TRY(L->pb.ensure(sizeof(int32_t) * (size_t)npairs2));
+                    PGV_TRY(launch_hnsw_link_pairs(ctx, h->nbr, L->rec_pos, L->rec_nstart, L->rec_from, L->rec_off, L->d_link_elem,
+                                                   L->d_link_dist, L->rec_list, L->list_count, nrec, 1, L->ids_start,
+                                                   L->ids.as<int32_t>(), L->mm_start, L->pa.as<int32_t>(), L->pb.as<int32_t>()));
+                    PGV_TRY(launch_score_gather(ctx, h->metric, h->dtype, h->geom, h->elements, h->elements, L->pa.as<int32_t>(),
+                                                L->pb.as<int32_t>(), npairs2, L->mm.as<float>()));
+                } else
+                    // the member triangles of the lists that wait: rows 0 .. nstart - 1 of their id lists
+                    PGV_TRY(launch_score_groups(ctx, h->metric, h->dtype, h->geom, h->elements, L->ids.as<int32_t>(), L->ids_start,
+                                                0, L->rec_nstart, nullptr, L->mm_start, nrec, L->mm.as<float>()));
+            } else
+                PGV_TRY(L->mm.ensure(16));
+            PGV_HIP(hipMemsetAsync(L->blocked, 0, sizeof(int), ctx->stream));
+            PGV_TRY(launch_hnsw_link_replay(ctx, h->nbr, L->nb_dist, L->nb_flag, m, nrec, 1, L->rec_lc, L->rec_off, L->d_link_dist,
+                                            L->rec_pos, L->rec_nstart, L->rec_from, L->ids_start, L->ids.as<int32_t>(),
+                                            L->pair_start, L->tri.as<float>(), L->mm_start, L->mm.as<float>(), L->rec_wait,
+                                            L->loc.as<int16_t>(), L->blocked));
+            int still = 0;
+            PGV_HIP(hipMemcpyAsync(&still, L->blocked, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
+            PGV_HIP(hipStreamSynchronize(ctx->stream));
+            if (still != 0) PGV_FAIL(PGV_ERR_STATE, "pgv_hnsw_link_apply: %d lists still wait for distances", still);
+            if (out_pairs) *out_pairs = npairs2;
+            if (out_deferred) *out_deferred = blocked;
+        }
+    }
+    // the batch's own elements (their lists were selected with their searches)
+    if (L->nq > 0)
+        PGV_TRY(launch_hnsw_link_new(ctx, h->nbr, L->nb_dist, L->nb_flag, h->levels, h->nbr_start, m, L->d_elems, L->d_linked,
+                                     L->nq, L->lcap, L->d_sel_ids, L->d_sel_dist, L->d_sel_closer, L->d_sel_cnt));
+    h->entry = entry;
+    // searches on other streams (the helper's view) wait for this on the device
+    if (!h->graph_ev) PGV_HIP(hipEventCreateWithFlags(&h->graph_ev, hipEventDisableTiming));
+    PGV_HIP(hipEventRecord(h->graph_ev, ctx->stream));
+    h->graph_ev_set = true;
+    return PGV_OK;
+}
+
+int pgv_hnsw_link_end(pgv_hnsw *h, int32_t *out_nbr) {
+    if (!h) PGV_FAIL(PGV_ERR_ARG, "pgv_hnsw_link_end: handle is NULL");
+    if (!h->link) return PGV_OK;
+    pgv_ctx *ctx = h->ctx;
+    PGV_HIP(hipSetDevice(ctx->device));
+    PGV_TRY(hnsw_graph_acquire(h));
+    if (out_nbr && h->nbr_total > 0)
+        PGV_HIP(hipMemcpyAsync(out_nbr, h->nbr, sizeof(int32_t) * (size_t)h->nbr_total, hipMemcpyDefault, ctx->stream));
+    PGV_HIP(hipStreamSynchronize(ctx->stream));
+    hnsw_link_free(h);
+    return PGV_OK;
 }
 
 int pgv_hnsw_update_graph(pgv_hnsw *h, int32_t entry, const int32_t *elements, int nupd,

@@ -222,6 +222,37 @@ struct pgv_hnsw {
     bool graph_ev_set = false;
     char *payload = nullptr;  // [n x payload_bytes] behind the elements, same allocation (pgv_hnsw_upload_payload)
     int payload_bytes = 0;
+    struct HnswLinkState *link = nullptr;  // pgv_hnsw_link_begin .. _end: the in-memory build's graph state (owner only)
+};
+
+// the state of a build whose graph updates run on the device (kernels_hnsw_link.hip): per tuple slot the neighbor's
+// distance and closer flag, and the scratch of the batch in flight
+struct HnswLinkState {
+    float *nb_dist = nullptr;     // [nbr_total]
+    uint8_t *nb_flag = nullptr;   // [nbr_total] bit 0 closer; bit 1 of a list's first slot: closerSet
+    int *list_count = nullptr;    // [nlists] link requests of the batch in flight per list (slot position / m); zero between batches
+    int *list_rec = nullptr;      // [nlists] the list's record in that batch
+    size_t nlists = 0;
+    pgv::DBuf rec, links, ids, pa, pb, tri, mm, loc, sel;
+    int nrec = 0, nq = 0, lcap = 0;
+    int64_t npairs = 0;   // of the batch prepared last
+    bool prepared = false;
+    // where the pieces of `rec` / `links` / `sel` are (set by prepare)
+    int32_t *rec_owner = nullptr, *rec_lc = nullptr, *rec_nstart = nullptr, *rec_from = nullptr, *rec_wait = nullptr,
+            *rec_list = nullptr;
+    int64_t *rec_off = nullptr, *rec_pos = nullptr, *ids_start = nullptr, *pair_start = nullptr, *mm_start = nullptr,
+            *totals = nullptr;
+    int *rec_fill = nullptr, *blocked = nullptr, *nrec_dev = nullptr;
+    int32_t *d_link_elem = nullptr;
+    float *d_link_dist = nullptr;
+    int32_t *d_sel_ids = nullptr, *d_sel_cnt = nullptr, *d_elems = nullptr;
+    float *d_sel_dist = nullptr;
+    uint8_t *d_sel_closer = nullptr, *d_linked = nullptr;
+    // pgv_hnsw_build_search_keep: the candidate lists of two batches (ids | distances | counts; elements | insert levels)
+    struct Kept {
+        pgv::DBuf ids, dist, cnt, elems;
+        int nq = 0, ef = 0, lcap = 0;
+    } kept[2];
 };
 
 namespace pgv {
@@ -291,6 +322,12 @@ int launch_expand_groups(pgv_ctx *ctx, const int32_t *ids, const int64_t *ids_st
 int launch_score_gather(pgv_ctx *ctx, pgv_metric metric, pgv_dtype dtype, const RowGeom &g,
                         const void *rows, const void *queries, const int32_t *slot,
                         const int32_t *query_of, int64_t npairs, float *out);
+// the pairs (u, v < u), u >= from, inside groups of rows, in 4 x 4 tiles (bit for bit score_gather's values).  Group g is
+// ids[ids_at[g] ..) (ids_at NULL: g * ids_stride), n_arr[g] rows (NULL: ids_at[g + 1] - ids_at[g]), from_arr[g] (NULL: 1);
+// its pairs go to out[pair_at[g] ..); pair_at[g + 1] == pair_at[g]: nothing wanted
+int launch_score_groups(pgv_ctx *ctx, pgv_metric metric, pgv_dtype dtype, const RowGeom &g, const void *rows,
+                        const int32_t *ids, const int64_t *ids_at, int64_t ids_stride, const int32_t *n_arr,
+                        const int32_t *from_arr, const int64_t *pair_at, int ngroups, float *out);
 
 // kernels_misc.hip: operator-path cosine distance and bit-vector distances, one query x n rows
 int launch_cosine(pgv_ctx *ctx, pgv_dtype dtype, const RowGeom &g, const void *rows, const void *query, int64_t n,
@@ -346,6 +383,30 @@ int launch_hnsw_select_pairs(pgv_ctx *ctx, const int32_t *lw_ids, const int32_t 
 int launch_hnsw_select(pgv_ctx *ctx, const int32_t *lw_ids, const float *lw_dist, const int32_t *cnt, const int32_t *qlevels,
                        const int64_t *pair_start, const float *tri, int ngroups, int lcap, int ef, int m, int stride,
                        int32_t *out_ids, float *out_dist, uint8_t *out_closer, int32_t *out_cnt);
+// kernels_hnsw_link.hip: a batch linked into the neighbor lists it chose, on the device
+int launch_hnsw_link_group(pgv_ctx *ctx, int step, const int32_t *elems, const uint8_t *linked, int nq, int lcap, int m,
+                           const int32_t *sel_ids, const float *sel_dist, const int32_t *sel_cnt, const int32_t *levels,
+                           const int64_t *nbr_start, int *list_count, int *list_rec, int *nrec, int32_t *rec_owner,
+                           int32_t *rec_lc, int32_t *rec_list, const int64_t *rec_off, int *rec_fill, int32_t *link_elem,
+                           float *link_dist);
+int launch_hnsw_link_size(pgv_ctx *ctx, const int32_t *nbr, const uint8_t *nb_flag, const int32_t *levels,
+                          const int64_t *nbr_start, int m, const int32_t *rec_owner, const int32_t *rec_lc,
+                          const int32_t *rec_list, const int *list_count, int64_t *rec_off, int nrec, int pass, int64_t *rec_pos,
+                          int32_t *rec_nstart, int32_t *rec_from, const int32_t *rec_wait, int64_t *size_ids,
+                          int64_t *size_pairs);
+int launch_hnsw_link_scan(pgv_ctx *ctx, int64_t *a, int64_t *b, int64_t *c, int n, int64_t *totals);
+int launch_hnsw_link_pairs(pgv_ctx *ctx, const int32_t *nbr, const int64_t *rec_pos, const int32_t *rec_nstart,
+                           const int32_t *rec_from, const int64_t *rec_off, int32_t *link_elem, float *link_dist,
+                           const int32_t *rec_list, int *list_count, int nrec, int pass,
+                           const int64_t *ids_start, int32_t *ids, const int64_t *pair_start, int32_t *a, int32_t *b);
+int launch_hnsw_link_replay(pgv_ctx *ctx, int32_t *nbr, float *nb_dist, uint8_t *nb_flag, int m, int nrec, int pass,
+                            const int32_t *rec_lc, const int64_t *rec_off, const float *link_dist, const int64_t *rec_pos,
+                            const int32_t *rec_nstart, const int32_t *rec_from, const int64_t *ids_start, const int32_t *ids,
+                            const int64_t *pair_start, const float *tri, const int64_t *mm_start, const float *mm,
+                            int32_t *rec_wait, int16_t *loc_save, int *blocked);
+int launch_hnsw_link_new(pgv_ctx *ctx, int32_t *nbr, float *nb_dist, uint8_t *nb_flag, const int32_t *levels,
+                         const int64_t *nbr_start, int m, const int32_t *elems, const uint8_t *linked, int nq, int lcap,
+                         const int32_t *sel_ids, const float *sel_dist, const uint8_t *sel_closer, const int32_t *sel_cnt);
 // kernels_mfma.hip: the same on the matrix cores (ip / spherical directly, L2 as pre-filter + exact recheck)
 bool mfma_argmin_supported(int mode, int64_t n, int k);
 int launch_argmin_mfma(pgv_ctx *ctx, int mode, pgv_dtype dtype, const RowGeom &g, const void *rows, int64_t n,

@@ -683,6 +683,12 @@ typedef struct
 	char		err[200];
 	double		secs[2];		/* search, pairs */
 	uint64_t	seq;			/* the helper's job that computes it (run ahead) */
+	/* the device-link build's two-step form: searches kept on the device in `slot`, the selection a job of its own */
+	int			slot;
+	int			s_posted,
+				t_posted;
+	uint64_t	seq_s,
+				seq_t;
 }			stage_a;
 
 static void
@@ -823,6 +829,62 @@ dev_fail:
 	return a->rc = rc;
 }
 
+/* stage A in two jobs (the device-link build): the searches, their candidate lists kept on the device ... */
+static void
+run_search_keep(pgv_hnsw * handle, stage_a * a, const elem * el, int ef_construction)
+{
+	const int	B = a->B;
+	int32_t    *ids = malloc(sizeof(int32_t) * (size_t) B * 2);
+	double		t0 = now_secs();
+
+	a->rc = PGV_OK;
+	a->err[0] = 0;
+	if (!ids)
+	{
+		snprintf(a->err, sizeof(a->err), "out of memory");
+		a->rc = PGV_ERR_NOMEM;
+		return;
+	}
+	for (int b = 0; b < B; b++)
+	{
+		ids[b] = (int32_t) (a->i0 + b);
+		ids[B + b] = el[a->i0 + b].level;
+	}
+	a->rc = pgv_hnsw_build_search_keep(handle, ids, ids + B, B, ef_construction, a->lcap, a->slot);
+	if (a->rc != PGV_OK)
+		snprintf(a->err, sizeof(a->err), "%s", pgv_last_error());
+	free(ids);
+	a->secs[0] = now_secs() - t0;
+}
+
+/* ... and SelectNeighbors over them: the lists as AddConnections stores them come back */
+static void
+run_select_kept(pgv_hnsw * handle, stage_a * a, int m)
+{
+	const size_t per = (size_t) a->B * a->lcap,
+				stride = 2 * (size_t) m;
+	int64_t		pairs = 0;
+	double		t0 = now_secs();
+
+	if (a->rc != PGV_OK)		/* (the searches failed: nothing to select from) */
+		return;
+	a->sel_ids = realloc(a->sel_ids, sizeof(int32_t) * per * stride);
+	a->sel_dist = realloc(a->sel_dist, sizeof(float) * per * stride);
+	a->sel_closer = realloc(a->sel_closer, per * stride);
+	a->sel_cnt = realloc(a->sel_cnt, sizeof(int32_t) * per);
+	if (!a->sel_ids || !a->sel_dist || !a->sel_closer || !a->sel_cnt)
+	{
+		snprintf(a->err, sizeof(a->err), "out of memory");
+		a->rc = PGV_ERR_NOMEM;
+		return;
+	}
+	a->rc = pgv_hnsw_build_select_kept(handle, a->slot, a->sel_ids, a->sel_dist, a->sel_closer, a->sel_cnt, &pairs);
+	if (a->rc != PGV_OK)
+		snprintf(a->err, sizeof(a->err), "%s", pgv_last_error());
+	a->npairs = pairs;
+	a->secs[1] = now_secs() - t0;
+}
+
 /* a graph patch handed to the helper (step 6): its arrays stay untouched until the job is over */
 typedef struct
 {
@@ -853,7 +915,7 @@ typedef struct
 
 typedef enum
 {
-	JOB_STAGE_A, JOB_PATCH, JOB_SCORE
+	JOB_STAGE_A, JOB_PATCH, JOB_SCORE, JOB_SEARCH_KEEP, JOB_SELECT_KEPT
 }			job_kind;
 
 /*
@@ -904,6 +966,10 @@ worker_main(void *arg)
 		pthread_mutex_unlock(&w->lock);
 		if (kind == JOB_STAGE_A)
 			run_stage_a(w->view, ja, w->el, w->m, w->ef_construction);
+		else if (kind == JOB_SEARCH_KEEP)
+			run_search_keep(w->view, ja, w->el, w->ef_construction);
+		else if (kind == JOB_SELECT_KEPT)
+			run_select_kept(w->view, ja, w->m);
 		else if (kind == JOB_PATCH)
 		{
 			patch_job  *pj = ja;
@@ -1046,6 +1112,284 @@ worker_stop(worker * w)
 	w->started = 0;
 }
 
+/*
+ * The batches with the graph updates ON THE DEVICE (pgv_hnsw_link_*): the host keeps the order of things and
+ * FindDuplicateInMemory; SelectNeighbors for the new elements runs on the device behind their searches, the lists they
+ * chose are replayed by GPU wavefronts (csrc/hnsw_link_core.h: the reference's HnswUpdateConnection), and the tuples the
+ * next batch searches are rewritten in place -- no list state, no pair distance and no neighbor tuple crosses PCIe until
+ * the finished graph comes back.
+ *
+ * Three streams share the GPU once batches are full (each a context of its own; S and T are helper threads):
+ *   S  searches of batch n + 2            (pgv_hnsw_build_search_keep: posted when batch n has been applied, so they see
+ *                                          the graph without batch n + 1 -- the blindness of the host-side form)
+ *   T  SelectNeighbors of batch n + 1     (pgv_hnsw_build_select_kept, over the lists S kept on the device)
+ *   main  duplicates of batch n, pgv_hnsw_link_prepare (n) -- requests grouped by list, the lists' pair distances --,
+ *         then, once the searches that read the old tuples are over (S of n + 1), pgv_hnsw_link_apply (n)
+ * The searches are the longest step and run back to back but for the apply in between.  Batches that are not full, or
+ * that move the entry point, are done in turn (pgv_hnsw_build_neighbors on the mirror itself); max_batch = 1 is the
+ * reference's serial loop.
+ */
+typedef struct
+{
+	int64_t		i0;
+	int			B,
+				lcap;
+}			batch_plan;
+
+/* the batch that starts at i0 when `linked` elements are in the graph and the entry point stands at entry_level */
+static batch_plan
+plan_batch(const elem * el, int64_t n, int64_t i0, int64_t linked, int entry_level, int max_batch)
+{
+	batch_plan	p;
+	int			B = (int) (linked / 16);
+
+	if (B < 1)
+		B = 1;
+	if (B > max_batch)
+		B = max_batch;
+	if (B > n - i0)
+		B = (int) (n - i0);
+	/* the batch ends at (and includes) the first element taller than the entry point (src/hnswbuild.c:398-431) */
+	for (int b = 0; b < B; b++)
+		if (el[i0 + b].level > entry_level)
+		{
+			B = b + 1;
+			break;
+		}
+	p.i0 = i0;
+	p.B = B;
+	p.lcap = 1;
+	for (int b = 0; b < B; b++)
+	{
+		int			l = el[i0 + b].level < entry_level ? el[i0 + b].level : entry_level;
+
+		if (l + 1 > p.lcap)
+			p.lcap = l + 1;
+	}
+	return p;
+}
+
+static int
+batch_has_tall(const elem * el, const batch_plan * p, int entry_level)
+{
+	for (int b = 0; b < p->B; b++)
+		if (el[p->i0 + b].level > entry_level)
+			return 1;
+	return 0;
+}
+
+static int
+build_linked_on_device(pgv_hnsw * mirror, size_t item_bytes, const void *rows, int64_t n, int m, int ef_construction,
+					   int max_batch, elem * el, pgv_hnsw_built * out, int32_t *entry_io, int64_t *linked_io)
+{
+	stage_a		stages[3];		/* batch number % 3 */
+	worker		srch,
+				sel;
+	int64_t		seqno = 0;		/* batches begun (the first element aside) */
+	int32_t		entry = -1;
+	int64_t		linked = 0;
+	int32_t    *ids = malloc(sizeof(int32_t) * (size_t) max_batch);
+	uint8_t    *is_linked = malloc((size_t) max_batch);
+	int			rc = PGV_OK;
+	double		phase_t0 = now_secs();
+	int			cur_phase = PH_RECORDS;
+	const int	pipelined = max_batch >= 64;
+
+	memset(stages, 0, sizeof(stages));
+	for (int i = 0; i < 3; i++)
+		stages[i].device_select = 1;
+	memset(&srch, 0, sizeof(srch));
+	memset(&sel, 0, sizeof(sel));
+	if (!ids || !is_linked)
+	{
+		rc = pgv_host_fail(PGV_ERR_NOMEM, "out of memory");
+		goto done;
+	}
+	if ((rc = pgv_hnsw_link_begin(mirror)) != PGV_OK)
+		goto dev_fail;
+	for (int64_t i0 = 0; i0 < n;)
+	{
+		batch_plan	p;
+		int			entry_level,
+					deferred = 0;
+		int64_t		pairs = 0,
+					pairs2 = 0;
+		stage_a    *a,
+				   *nx;
+
+		if (cancel_check != NULL && cancel_check(cancel_arg))
+		{
+			rc = pgv_host_fail(PGV_ERR_STATE, "pgv_host_hnsw_build: cancelled after %lld of %lld rows", (long long) i0, (long long) n);
+			goto done;
+		}
+		if (entry < 0)
+		{
+			/* the first element has nothing to search: it becomes the entry point */
+			entry = (int32_t) i0;
+			linked = 1;
+			if ((rc = pgv_hnsw_update_graph(mirror, entry, NULL, 0, NULL, NULL)) != PGV_OK)
+				goto dev_fail;
+			i0++;
+			out->batches++;
+			continue;
+		}
+		entry_level = el[entry].level;
+		p = plan_batch(el, n, i0, linked, entry_level, max_batch);
+		a = &stages[seqno % 3];
+		nx = &stages[(seqno + 1) % 3];
+
+		PHASE(PH_SEARCH);
+		if (a->s_posted && a->i0 == p.i0 && a->B == p.B && a->lcap == p.lcap)
+		{
+			/* its searches ran ahead; so did its selection unless the batch before was the first of the pipeline */
+			worker_wait(&srch, a->seq_s);
+			if (!a->t_posted)
+			{
+				a->seq_t = worker_post(&sel, JOB_SELECT_KEPT, a);
+				a->t_posted = 1;
+			}
+			worker_wait(&sel, a->seq_t);
+		}
+		else
+		{
+			/* in turn, on the mirror itself (nothing runs ahead by construction when the plan does not match) */
+			worker_drain(&srch);
+			worker_drain(&sel);
+			for (int i = 0; i < 3; i++)
+				stages[i].s_posted = stages[i].t_posted = 0;
+			a->i0 = p.i0;
+			a->B = p.B;
+			a->lcap = p.lcap;
+			run_stage_a(mirror, a, el, m, ef_construction);
+		}
+		a->s_posted = a->t_posted = 0;
+		if (a->rc != PGV_OK)
+		{
+			rc = pgv_host_fail(a->rc, "%s", a->err);
+			goto done;
+		}
+		out->device_pairs += a->npairs;
+		/* the searches of the NEXT batch, if they are not under way and its composition is certain: full batches from
+		 * here on, no change of the entry point in this one */
+		if (pipelined && !nx->s_posted && p.B == max_batch && linked / 16 >= max_batch && p.i0 + p.B < n &&
+			!batch_has_tall(el, &p, entry_level))
+		{
+			batch_plan	q = plan_batch(el, n, p.i0 + p.B, linked, entry_level, max_batch);
+
+			if (!srch.started && worker_start(&srch, mirror, el, m, ef_construction))
+				worker_start(&sel, mirror, el, m, ef_construction);
+			if (srch.started && sel.started)
+			{
+				nx->i0 = q.i0;
+				nx->B = q.B;
+				nx->lcap = q.lcap;
+				nx->slot = (int) ((seqno + 1) & 1);
+				nx->seq_s = worker_post(&srch, JOB_SEARCH_KEEP, nx);
+				nx->s_posted = 1;
+				nx->t_posted = 0;
+			}
+		}
+
+		PHASE(PH_SELECT);
+		/* FindDuplicateInMemory, src/hnswbuild.c:313-364, in heap order: an element's layer-0 neighbors are ordered by
+		 * distance, the identical ones first */
+		for (int b = 0; b < p.B; b++)
+		{
+			int32_t		e = (int32_t) (i0 + b);
+			const size_t g = (size_t) b * p.lcap;
+			const char *v = (const char *) rows + (size_t) e * item_bytes;
+
+			ids[b] = e;
+			is_linked[b] = 1;
+			for (int i = 0; i < a->sel_cnt[g]; i++)
+			{
+				int32_t		ne = a->sel_ids[g * 2 * (size_t) m + i];
+
+				if (memcmp(v, (const char *) rows + (size_t) ne * item_bytes, item_bytes) != 0)
+					break;
+				if (el[ne].heaptids < HNSW_HEAPTIDS)
+				{
+					el[ne].heaptids++;
+					out->dup_of[e] = ne;
+					is_linked[b] = 0;
+					break;
+				}
+			}
+			if (is_linked[b])
+			{
+				linked++;
+				/* the entry point moves up with the tallest element (src/hnswbuild.c:425-430) */
+				if (el[e].level > el[entry].level)
+					entry = e;
+			}
+		}
+
+		PHASE(PH_RECORDS);
+		if ((rc = pgv_hnsw_link_prepare(mirror, ids, is_linked, p.B, p.lcap, a->sel_ids, a->sel_dist, a->sel_closer, a->sel_cnt,
+										&pairs)) != PGV_OK)
+			goto dev_fail;
+		PHASE(PH_PAIRS);
+		/* the searches that run ahead read the tuples this batch is about to rewrite: they have to be over; their
+		 * selection does not touch the graph and runs on */
+		if (nx->s_posted)
+		{
+			worker_wait(&srch, nx->seq_s);
+			if (!nx->t_posted)
+			{
+				nx->seq_t = worker_post(&sel, JOB_SELECT_KEPT, nx);
+				nx->t_posted = 1;
+			}
+		}
+		PHASE(PH_UPDATE);
+		if ((rc = pgv_hnsw_link_apply(mirror, entry, &pairs2, &deferred)) != PGV_OK)
+			goto dev_fail;
+		out->device_pairs += pairs + pairs2;
+		out->deferred_updates += deferred;
+		PHASE(PH_RECORDS);
+		/* the searches of the batch after the next: they see the graph with this batch in it, without the next (whose
+		 * composition has to be certain, full and without a change of the entry point, for the one behind it to be) */
+		if (nx->s_posted && nx->B == max_batch && !batch_has_tall(el, &(batch_plan){nx->i0, nx->B, nx->lcap}, el[entry].level) &&
+			linked / 16 >= max_batch && nx->i0 + nx->B < n && entry_level == el[entry].level)
+		{
+			stage_a    *n2 = &stages[(seqno + 2) % 3];
+			batch_plan	q = plan_batch(el, n, nx->i0 + nx->B, linked, entry_level, max_batch);
+
+			n2->i0 = q.i0;
+			n2->B = q.B;
+			n2->lcap = q.lcap;
+			n2->slot = (int) ((seqno + 2) & 1);
+			n2->seq_s = worker_post(&srch, JOB_SEARCH_KEEP, n2);
+			n2->s_posted = 1;
+			n2->t_posted = 0;
+		}
+		i0 += p.B;
+		seqno++;
+		out->batches++;
+	}
+	worker_drain(&srch);
+	worker_drain(&sel);
+	PHASE(PH_PATCH);
+	if ((rc = pgv_hnsw_link_end(mirror, out->nbr)) != PGV_OK)
+		goto dev_fail;
+	PHASE(PH_RECORDS);
+	goto done;
+
+dev_fail:
+	rc = pgv_host_fail(rc, "%s", pgv_last_error());
+done:
+	worker_stop(&srch);
+	worker_stop(&sel);
+	if (rc != PGV_OK)
+		pgv_hnsw_link_end(mirror, NULL);
+	for (int i = 0; i < 3; i++)
+		stage_a_free(&stages[i]);
+	free(ids);
+	free(is_linked);
+	*entry_io = entry;
+	*linked_io = linked;
+	return rc;
+}
+
 int
 pgv_host_hnsw_build(pgv_hnsw * mirror, pgv_dtype dtype, int dim, const void *rows, int64_t n, int m,
 					int ef_construction, const pgv_rng * rng, int max_batch, pgv_hnsw_built * out)
@@ -1097,6 +1441,10 @@ pgv_host_hnsw_build(pgv_hnsw * mirror, pgv_dtype dtype, int dim, const void *row
 	/* SelectNeighbors of the new elements' candidate lists: on the device with the searches (the default), or here from
 	 * the lists and their pair triangles (PGV_HNSW_HOST_SELECT=1: the form the device's is tested against) */
 	const int	device_select = !(getenv("PGV_HNSW_HOST_SELECT") && atoi(getenv("PGV_HNSW_HOST_SELECT")) != 0);
+	/* the graph updates (HnswUpdateConnection for every list a batch links into): on the device (the default;
+	 * build_linked_on_device), or replayed here on OpenMP threads (PGV_HNSW_HOST_LINK=1, and whenever the new elements'
+	 * selection is the host's) -- the two build the same graph */
+	const int	device_link = device_select && !(getenv("PGV_HNSW_HOST_LINK") && atoi(getenv("PGV_HNSW_HOST_LINK")) != 0);
 
 	memset(stages, 0, sizeof(stages));
 	stages[0].device_select = stages[1].device_select = device_select;
@@ -1157,6 +1505,12 @@ pgv_host_hnsw_build(pgv_hnsw * mirror, pgv_dtype dtype, int dim, const void *row
 	if (rc != PGV_OK)
 	{
 		rc = pgv_host_fail(rc, "%s", pgv_last_error());
+		goto done;
+	}
+	if (device_link)
+	{
+		PHASE(PH_RECORDS);
+		rc = build_linked_on_device(mirror, item_bytes, rows, n, m, ef_construction, max_batch, el, out, &entry, &linked);
 		goto done;
 	}
 	is_dirty = calloc((size_t) n, 1);

@@ -634,7 +634,9 @@ test_pool(void)
 
 		if (mode == 1)
 			setenv("PGV_POOL_OVERLAP", "1", 1);
-		CHECK(pgv_host_pool_create(ix, 0, PGV_F32, DIM, 2, K, 64, 100, 3, &p3));
+		/* (mode 1: batches of four at most, so that twelve clients NEED three lanes at once -- with 64 they could fall
+		 * into step and share one batch after another, and no two scans would ever be in flight) */
+		CHECK(pgv_host_pool_create(ix, 0, PGV_F32, DIM, 2, K, mode == 1 ? 4 : 64, 100, 3, &p3));
 		unsetenv("PGV_POOL_OVERLAP");
 		mock_hip_search_delay_us = 2000;
 		(void) mock_hip_search_peak(1);

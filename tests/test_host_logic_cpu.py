@@ -19,5 +19,10 @@ def test_host_logic_against_the_mock_device(tmp_path):
                     os.path.join(ROOT, "tests", "c", "host_logic_driver.c"), os.path.join(ROOT, "tests", "c", "mock_hip.c"),
                     "-o", exe, "-L", libdir, "-lpgv_host", "-L", oradir, "-loracle", "-lm", "-lpthread",
                     "-Wl,-rpath," + libdir, "-Wl,-rpath," + oradir], check=True)
-    r = subprocess.run([exe], capture_output=True, text=True, timeout=300)
-    assert r.returncode == 0 and "HOST-LOGIC OK" in r.stdout, (r.returncode, r.stdout[-500:], r.stderr[-2000:])
+    # the HNSW build's graph updates: on the "device" (the default: pgv_hnsw_link_*, whose replay -- csrc/hnsw_link_core.h --
+    # the stand-in compiles from the source the GPU kernel is compiled from), the host-side replay on OpenMP threads
+    # (PGV_HNSW_HOST_LINK=1), and that one with the new elements' SelectNeighbors on the host too (PGV_HNSW_HOST_SELECT=1):
+    # every form must build the oracle's graph at batch 1 and pass the same scenarios
+    for extra in ({}, {"PGV_HNSW_HOST_LINK": "1"}, {"PGV_HNSW_HOST_SELECT": "1"}):
+        r = subprocess.run([exe], capture_output=True, text=True, timeout=300, env=dict(os.environ, **extra))
+        assert r.returncode == 0 and "HOST-LOGIC OK" in r.stdout, (extra, r.returncode, r.stdout[-500:], r.stderr[-2000:])
