@@ -425,22 +425,30 @@ int launch_hnsw_t(pgv_ctx *ctx, const HnswDev &g, const HnswRun &run, uint32_t *
 // thousands, and a wavefront's 64 lists share nothing, so lanes are the parallelism.
 
 // pairs of list g = (query, layer): cnt * (cnt - 1) / 2 when it has to be thinned, else none; start[] by exclusive scan
-__global__ __launch_bounds__(1024) void hnsw_select_plan_kernel(const int32_t *__restrict__ cnt, int ngroups, int lcap, int m,
-                                                                 int64_t *__restrict__ pair_start) {
-    __shared__ int64_t wave_tot[1024 / 64];
+// (256 threads: a larger workgroup waits for a whole CU's worth of room while another stream's searches fill the chip)
+__global__ __launch_bounds__(256) void hnsw_select_plan_kernel(const int32_t *__restrict__ cnt, int ngroups, int lcap, int m,
+                                                                int64_t *__restrict__ pair_start) {
+    constexpr int T = 256, PER = 8;
+    __shared__ int64_t wave_tot[T / 64];
     __shared__ int64_t carry_s;
     if (threadIdx.x == 0) carry_s = 0;
     __syncthreads();
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    for (int base = 0; base < ngroups; base += 1024) {
-        const int g = base + (int)threadIdx.x;
-        int64_t v = 0;
-        if (g < ngroups) {
-            const int lm = (g % lcap) == 0 ? 2 * m : m;
-            const int64_t c = cnt[g];
-            v = c > lm ? c * (c - 1) / 2 : 0;
+    for (int base = 0; base < ngroups; base += T * PER) {
+        const int g0 = base + (int)threadIdx.x * PER;
+        int64_t v[PER], mine = 0;
+#pragma unroll
+        for (int t = 0; t < PER; t++) {
+            const int g = g0 + t;
+            v[t] = 0;
+            if (g < ngroups) {
+                const int lm = (g % lcap) == 0 ? 2 * m : m;
+                const int64_t c = cnt[g];
+                v[t] = c > lm ? c * (c - 1) / 2 : 0;
+            }
+            mine += v[t];
         }
-        int64_t incl = v;
+        int64_t incl = mine;
 #pragma unroll
         for (int d = 1; d < 64; d <<= 1) {
             const int64_t t = __shfl_up(incl, d);
@@ -449,13 +457,18 @@ __global__ __launch_bounds__(1024) void hnsw_select_plan_kernel(const int32_t *_
         if (lane == 63) wave_tot[wave] = incl;
         __syncthreads();
         int64_t before = 0, total = 0;
-        for (int w = 0; w < 1024 / 64; w++) {
+        for (int w = 0; w < T / 64; w++) {
             const int64_t t = wave_tot[w];
             if (w < wave) before += t;
             total += t;
         }
         const int64_t carry = carry_s;
-        if (g < ngroups) pair_start[g] = carry + before + incl - v;
+        int64_t run = carry + before + incl - mine;
+#pragma unroll
+        for (int t = 0; t < PER; t++) {
+            if (g0 + t < ngroups) pair_start[g0 + t] = run;
+            run += v[t];
+        }
         __syncthreads();
         if (threadIdx.x == 0) carry_s = carry + total;
         __syncthreads();
@@ -654,7 +667,7 @@ int launch_expand_groups(pgv_ctx *ctx, const int32_t *ids, const int64_t *ids_st
 // SelectNeighbors of a batch's new elements (see hnsw_select_kernel): plan -> *out_total_dev pairs at pair_start[ngroups]
 int launch_hnsw_select_plan(pgv_ctx *ctx, const int32_t *cnt, int ngroups, int lcap, int m, int64_t *pair_start) {
     if (ngroups <= 0) return PGV_OK;
-    hipLaunchKernelGGL(hnsw_select_plan_kernel, dim3(1), dim3(1024), 0, ctx->stream, cnt, ngroups, lcap, m, pair_start);
+    hipLaunchKernelGGL(hnsw_select_plan_kernel, dim3(1), dim3(256), 0, ctx->stream, cnt, ngroups, lcap, m, pair_start);
     PGV_HIP(hipGetLastError());
     return PGV_OK;
 }

@@ -129,12 +129,14 @@ __global__ __launch_bounds__(256) void hnsw_link_size_kernel(const int32_t *__re
 }
 
 // exclusive scans of up to three int64 sequences in place (one workgroup); totals[0 .. 2] = their sums.  A thread takes
-// 16 consecutive values per trip (8 K values a trip: a batch's records are a few tens of thousands -- a handful of trips
-// instead of dozens, each with its two barriers)
-__global__ __launch_bounds__(1024) void hnsw_link_scan_kernel(int64_t *__restrict__ a, int64_t *__restrict__ b,
+// 16 consecutive values per trip (4 K values a trip: a batch's records are a few tens of thousands).  256 threads, not
+// 1024: the searches of the next batch fill the chip while this runs, and a workgroup of sixteen wavefronts waits until
+// one CU has room for all of them -- measured 435 us a launch, most of it waiting to start
+constexpr int kLinkScanThreads = 256;
+__global__ __launch_bounds__(kLinkScanThreads) void hnsw_link_scan_kernel(int64_t *__restrict__ a, int64_t *__restrict__ b,
                                                                int64_t *__restrict__ c, int n, int64_t *__restrict__ totals) {
     constexpr int PER = 16;
-    __shared__ int64_t wave_tot[1024 / 64];
+    __shared__ int64_t wave_tot[kLinkScanThreads / 64];
     __shared__ int64_t carry_s;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     for (int which = 0; which < 3; which++) {
@@ -142,7 +144,7 @@ __global__ __launch_bounds__(1024) void hnsw_link_scan_kernel(int64_t *__restric
         if (!x) continue;
         if (threadIdx.x == 0) carry_s = 0;
         __syncthreads();
-        for (int base = 0; base < n; base += 1024 * PER) {
+        for (int base = 0; base < n; base += kLinkScanThreads * PER) {
             const int i0 = base + (int)threadIdx.x * PER;
             int64_t v[PER];
             int64_t mine = 0;
@@ -160,7 +162,7 @@ __global__ __launch_bounds__(1024) void hnsw_link_scan_kernel(int64_t *__restric
             if (lane == 63) wave_tot[wave] = incl;
             __syncthreads();
             int64_t before = 0, total = 0;
-            for (int w = 0; w < 1024 / 64; w++) {
+            for (int w = 0; w < kLinkScanThreads / 64; w++) {
                 const int64_t t = wave_tot[w];
                 if (w < wave) before += t;
                 total += t;
@@ -571,7 +573,7 @@ int launch_hnsw_link_size(pgv_ctx *ctx, const int32_t *nbr, const uint8_t *nb_fl
 }
 
 int launch_hnsw_link_scan(pgv_ctx *ctx, int64_t *a, int64_t *b, int64_t *c, int n, int64_t *totals) {
-    hipLaunchKernelGGL(hnsw_link_scan_kernel, dim3(1), dim3(1024), 0, ctx->stream, a, b, c, n, totals);
+    hipLaunchKernelGGL(hnsw_link_scan_kernel, dim3(1), dim3(kLinkScanThreads), 0, ctx->stream, a, b, c, n, totals);
     PGV_HIP(hipGetLastError());
     return PGV_OK;
 }

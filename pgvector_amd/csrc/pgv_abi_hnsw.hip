@@ -569,7 +569,8 @@ int pgv_hnsw_build_select_kept(pgv_hnsw *h, int slot, int32_t *out_ids, float *o
                                int64_t *out_pairs) {
     if (!h || !out_ids || !out_dist || !out_closer || !out_count)
         PGV_FAIL(PGV_ERR_ARG, "pgv_hnsw_build_select_kept: handle/out is NULL");
-    hnsw_view_refresh(h);
+    // (no view refresh: the entry point may be moving under pgv_hnsw_link_apply on another thread, and nothing here looks
+    // at the graph -- the kept lists, the element rows and m, which is fixed for the build)
     pgv_hnsw *o = h->view_of ? h->view_of : h;
     if (!o->link) PGV_FAIL(PGV_ERR_STATE, "pgv_hnsw_build_select_kept needs pgv_hnsw_link_begin");
     if (slot < 0 || slot > 1) PGV_FAIL(PGV_ERR_ARG, "slot must be 0 or 1");
@@ -577,6 +578,7 @@ int pgv_hnsw_build_select_kept(pgv_hnsw *h, int slot, int32_t *out_ids, float *o
     const HnswLinkState::Kept &K = o->link->kept[slot];
     if (K.nq == 0) return PGV_OK;
     PGV_HIP(hipSetDevice(h->ctx->device));
+    h->m = o->m;
     const int32_t *l_dev = K.elems.as<int32_t>() + K.nq;
     return hnsw_select_from(h, K.ids.as<int32_t>(), K.dist.as<float>(), K.cnt.as<int32_t>(), l_dev, K.nq, K.ef, K.lcap, out_ids,
                             out_dist, out_closer, out_count, out_pairs);

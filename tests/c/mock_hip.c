@@ -1295,10 +1295,11 @@ pgv_hnsw_build_select_kept(pgv_hnsw * h, int slot, int32_t *out_ids, float *out_
 	pgv_hnsw   *o = h->view_of ? h->view_of : h;
 	int64_t		pairs;
 
-	view_refresh(h);
+	/* (no view_refresh: the entry point may be moving under pgv_hnsw_link_apply on another thread, and nothing here
+	 * looks at the graph -- the lists, the vectors and m, which is the owner's and fixed for the build) */
 	if (!o->nb_dist || slot < 0 || slot > 1)
 		return fail(PGV_ERR_STATE, "mock: pgv_hnsw_build_select_kept needs pgv_hnsw_link_begin / slot 0 or 1");
-	pairs = select_from(h, o->kept[slot].ids, o->kept[slot].dist, o->kept[slot].cnt, o->kept[slot].levels, o->kept[slot].nq,
+	pairs = select_from(o, o->kept[slot].ids, o->kept[slot].dist, o->kept[slot].cnt, o->kept[slot].levels, o->kept[slot].nq,
 						o->kept[slot].ef, o->kept[slot].lcap, out_ids, out_dist, out_closer, out_count);
 	if (out_pairs)
 		*out_pairs = pairs;
