@@ -30,6 +30,10 @@
 // reference as well (pairing-heap internals).
 #include "pgv_device.h"
 
+#include <type_traits>
+
+#include <cstdlib>
+
 namespace pgv {
 
 namespace {
@@ -66,6 +70,7 @@ struct HnswRun {
     float *lw_dist;           // [nq x lcap x ef]
     int32_t *lw_cnt;          // [nq x lcap] |W| (0 for layers not searched)
     int lcap;
+    int rows_per_trip;        // rows a lane group scores at once: 1, 2 or 4 (PGV_HNSW_ROWS_PER_TRIP, for A/B runs)
 };
 
 template <typename T, int METRIC>
@@ -99,28 +104,58 @@ __global__ __launch_bounds__(kHnswThreads) void hnsw_search_kernel(
     const size_t row_bytes = (size_t)g.nvec * sizeof(Raw16);
     uint32_t *bitmap = bitmaps + (size_t)blockIdx.x * words;
 
-    // distance of the query (in LDS) to the rows bi[0 .. nb): every wavefront takes rpw rows per trip
-    auto score_batch = [&](int nb) {
-        for (int base = wave * rpw; base < nb; base += kHnswWaves * rpw) {
-            const int i = base + rsub;
-            const bool valid = i < nb;
-            const char *rp = g.rows + (size_t)bi[valid ? i : nb - 1] * row_bytes;
-            float acc = 0.f;
-#pragma unroll 4
+    // distance of the query (in LDS) to the rows bi[0 .. nb): every wavefront takes R x rpw rows per trip -- R rows' loads
+    // in flight per lane group.  A walk is a chain of ~100 such batches, each waiting for its rows: with one row per trip
+    // a batch of 32 neighbors was eight dependent round trips to HBM per wavefront (same box, 400 k x 1536, ef 100:
+    // 352 k QPS with R = 1, 456 k with R = 2; 1 M x 1536: 366-403 k with R = 2, 385-413 k with R = 4, the default;
+    // profiles/r05/hnsw_build_device_link.md).  Each row keeps its own accumulator and element order: the distances do not
+    // depend on R.
+    auto score_rows = [&](auto rc, int nb) {
+        constexpr int R = decltype(rc)::value;
+        const int step = kHnswWaves * rpw;
+        for (int base = wave * rpw; base < nb; base += R * step) {
+            int idx[R];
+            bool valid[R];
+            const char *rp[R];
+            float acc[R];
+#pragma unroll
+            for (int r = 0; r < R; r++) {
+                idx[r] = base + rsub + r * step;
+                valid[r] = idx[r] < nb;
+                rp[r] = g.rows + (size_t)bi[valid[r] ? idx[r] : nb - 1] * row_bytes;
+                acc[r] = 0.f;
+            }
+#pragma unroll 2
             for (int c = 0; c < g.nchunks; c++) {
                 const int vi = c * lpr + sub;
                 const bool ok = vi < g.nvec;
                 const int vc = ok ? vi : g.nvec - 1;  // never predicate a load (see scan_kernel)
-                const Raw16 rv = load16(rp + (size_t)vc * sizeof(Raw16));
+                Raw16 rv[R];
+#pragma unroll
+                for (int r = 0; r < R; r++) rv[r] = load16(rp[r] + (size_t)vc * sizeof(Raw16));
                 const Raw16 qv = lq[vc];
-                Unpacked<T> ur(rv);
                 Unpacked<T> uq(qv);
 #pragma unroll
-                for (int e = 0; e < N; e++) acc = accum<METRIC>(acc, ok ? ur.v[e] : 0.f, ok ? uq.v[e] : 0.f);
+                for (int r = 0; r < R; r++) {
+                    Unpacked<T> ur(rv[r]);
+#pragma unroll
+                    for (int e = 0; e < N; e++) acc[r] = accum<METRIC>(acc[r], ok ? ur.v[e] : 0.f, ok ? uq.v[e] : 0.f);
+                }
             }
-            acc = group_sum_to_last(acc, g.lpr_log2);
-            if (sub == lpr - 1 && valid) bk[i] = float_to_key(finish<METRIC>(acc));
+#pragma unroll
+            for (int r = 0; r < R; r++) {
+                const float sum = group_sum_to_last(acc[r], g.lpr_log2);
+                if (sub == lpr - 1 && valid[r]) bk[idx[r]] = float_to_key(finish<METRIC>(sum));
+            }
         }
+    };
+    auto score_batch = [&](int nb) {
+        if (run.rows_per_trip >= 4)
+            score_rows(std::integral_constant<int, 4>{}, nb);
+        else if (run.rows_per_trip == 2)
+            score_rows(std::integral_constant<int, 2>{}, nb);
+        else
+            score_rows(std::integral_constant<int, 1>{}, nb);
     };
 
     for (;;) {
@@ -563,6 +598,72 @@ __global__ __launch_bounds__(64) void hnsw_select_kernel(const int32_t *__restri
     out_cnt[g] = rn;
 }
 
+
+// the same sweep, one WAVEFRONT per list, for ef_construction <= 64: lane j holds candidate j, the list's pair triangle sits
+// in LDS, and "no neighbor chosen so far is at distance <= mine" is one comparison per chosen lane and a ballot.  What
+// stays sequential is the walk over the candidates, nearest first.
+__global__ __launch_bounds__(256) void hnsw_select_wave_kernel(const int32_t *__restrict__ lw_ids, const float *__restrict__ lw_dist,
+                                                               const int32_t *__restrict__ cnt, const int32_t *__restrict__ qlevels,
+                                                               const int64_t *__restrict__ pair_start,
+                                                               const float *__restrict__ tri_all, int ngroups, int lcap, int ef,
+                                                               int m, int stride, int32_t *__restrict__ out_ids,
+                                                               float *__restrict__ out_dist, uint8_t *__restrict__ out_closer,
+                                                               int32_t *__restrict__ out_cnt) {
+    __shared__ float tri_lds[4][64 * 63 / 2 + 64];  // (+ 64: the lanes that are not chosen index past their row harmlessly)
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int g = blockIdx.x * 4 + wv;
+    if (g >= ngroups) return;
+    const int lc = g % lcap, q = g / lcap;
+    const int lm = lc == 0 ? 2 * m : m;
+    const int nw = lc > qlevels[q] ? 0 : cnt[g];
+    int32_t *oi = out_ids + (size_t)g * stride;
+    float *od = out_dist + (size_t)g * stride;
+    uint8_t *oc = out_closer + (size_t)g * stride;
+    const int32_t id = lane < nw ? lw_ids[(size_t)g * ef + lane] : -1;
+    const float dist = lane < nw ? lw_dist[(size_t)g * ef + lane] : 0.f;
+    if (nw <= lm) {
+        // taken whole, in W's order: furthest first
+        if (lane < nw) {
+            oi[nw - 1 - lane] = id;
+            od[nw - 1 - lane] = dist;
+            oc[nw - 1 - lane] = 0;
+        }
+        if (lane == 0) out_cnt[g] = nw;
+        return;
+    }
+    const float *tri_g = tri_all + pair_start[g];
+    const int np = nw * (nw - 1) / 2;
+    for (int i = lane; i < np; i += 64) tri_lds[wv][i] = tri_g[i];
+    __builtin_amdgcn_s_waitcnt(0xc07f);
+    __builtin_amdgcn_wave_barrier();
+    bool chosen = false;
+    int pos = -1, rn = 0, nrej = 0, rpos = -1;
+    for (int j = 0; j < nw && rn < lm; j++) {
+        const float dj = __shfl(dist, j);
+        const bool decides = chosen && tri_lds[wv][j * (j - 1) / 2 + lane] <= dj;  // (chosen lanes are < j)
+        if (__ballot(decides)) {
+            if (lane == j) rpos = nrej;
+            nrej++;
+        } else {
+            if (lane == j) {
+                chosen = true;
+                pos = rn;
+            }
+            rn++;
+        }
+    }
+    // the rejected among the candidates looked at fill r up to lm, nearest first (:1146-1148)
+    const int nchosen = rn;
+    if (rpos >= 0 && nchosen + rpos < lm) pos = nchosen + rpos;
+    const int total = nchosen + nrej < lm ? nchosen + nrej : lm;
+    if (pos >= 0) {
+        oi[pos] = id;
+        od[pos] = dist;
+        oc[pos] = chosen ? 1 : 0;
+    }
+    if (lane == 0) out_cnt[g] = total;
+}
+
 }  // namespace
 
 int hnsw_search_grid(pgv_ctx *ctx, int nq, int64_t n, int *words_out) {
@@ -603,6 +704,10 @@ int launch_hnsw_search(pgv_ctx *ctx, pgv_metric metric, pgv_dtype dtype, const R
     run.lw_dist = a.lw_dist;
     run.lw_cnt = a.lw_cnt;
     run.lcap = a.lcap;
+    {
+        static const int per_trip = getenv("PGV_HNSW_ROWS_PER_TRIP") ? atoi(getenv("PGV_HNSW_ROWS_PER_TRIP")) : 4;
+        run.rows_per_trip = per_trip >= 4 ? 4 : (per_trip == 1 ? 1 : 2);
+    }
     PGV_HIP(hipMemsetAsync(counter, 0, sizeof(int), ctx->stream));
 #define PGV_HNSW_M(T)                                                                      \
     switch (metric) {                                                                      \
@@ -686,6 +791,13 @@ int launch_hnsw_select(pgv_ctx *ctx, const int32_t *lw_ids, const float *lw_dist
                        const int64_t *pair_start, const float *tri, int ngroups, int lcap, int ef, int m, int stride,
                        int32_t *out_ids, float *out_dist, uint8_t *out_closer, int32_t *out_cnt) {
     if (ngroups <= 0) return PGV_OK;
+    static const bool serial = getenv("PGV_HNSW_SELECT_SERIAL") && atoi(getenv("PGV_HNSW_SELECT_SERIAL")) != 0;
+    if (ef <= 64 && !serial) {
+        hipLaunchKernelGGL(hnsw_select_wave_kernel, dim3((ngroups + 3) / 4), dim3(256), 0, ctx->stream, lw_ids, lw_dist, cnt,
+                           qlevels, pair_start, tri, ngroups, lcap, ef, m, stride, out_ids, out_dist, out_closer, out_cnt);
+        PGV_HIP(hipGetLastError());
+        return PGV_OK;
+    }
     hipLaunchKernelGGL(hnsw_select_kernel, dim3((ngroups + 63) / 64), dim3(64), 0, ctx->stream, lw_ids, lw_dist, cnt, qlevels,
                        pair_start, tri, ngroups, lcap, ef, m, stride, out_ids, out_dist, out_closer, out_cnt);
     PGV_HIP(hipGetLastError());
