@@ -25,8 +25,9 @@
  * Tuples that arrive after a flush go through HnswInsertTupleOnDisk as before (they search pages, not this graph).
  *
  * Unlike the other files of ext/, this one calls ONE function that is not in include/pgv_hip.h: pgv_host_hnsw_build,
- * plain C over three ABI calls (pgv_hnsw_build_search, pgv_hnsw_score_groups, pgv_hnsw_update_graph) that a maintainer
- * adds to OBJS with this file (or links as libpgv_host); INTEGRATION.md 5c.
+ * plain C over the build-side ABI calls (pgv_hnsw_build_neighbors, pgv_hnsw_link_begin / prepare / apply / end: searches,
+ * SelectNeighbors and HnswUpdateConnection all run on the device, the host keeps the batch order and the duplicates)
+ * that a maintainer adds to OBJS with this file (or links as libpgv_host); INTEGRATION.md 5c.
  */
 #include "pgv_gpu.h"
 

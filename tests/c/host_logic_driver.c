@@ -166,6 +166,41 @@ test_hnsw_build(void)
 			found += elem[q * 5] == 100 + q && d[q * 5] == 0.0f;
 		EXPECT(found >= 15);
 	}
+	/* the graph updates on the "device" (csrc/hnsw_link_core.h through the stand-in: the source the GPU kernel is compiled
+	 * from) and replayed on the host build the SAME graph, at batch 32 and with the pipeline running (batch 64 from 1024
+	 * linked elements on: searches, selection and linking on three threads) -- whichever of the two this process runs by
+	 * default, the other one is asked for here */
+	{
+		const char *was = getenv("PGV_HNSW_HOST_LINK");
+		const int	host_default = (was && atoi(was) != 0) || (getenv("PGV_HNSW_HOST_SELECT") && atoi(getenv("PGV_HNSW_HOST_SELECT")) != 0);
+
+		for (int mb = 32; mb <= 64; mb += 32)
+		{
+			pgv_hnsw_built a,
+						b;
+
+			unsetenv("PGV_HNSW_HOST_LINK");
+			if (host_default)
+				unsetenv("PGV_HNSW_HOST_SELECT");
+			CHECK(pgv_host_hnsw_build(mirror, PGV_F32, DIM, data, N, M, EFC, NULL, mb, &a));
+			setenv("PGV_HNSW_HOST_LINK", "1", 1);
+			CHECK(pgv_host_hnsw_build(mirror, PGV_F32, DIM, data, N, M, EFC, NULL, mb, &b));
+			EXPECT(a.entry == b.entry && a.batches == b.batches && a.nelements == b.nelements);
+			EXPECT(memcmp(a.levels, b.levels, sizeof(int32_t) * N) == 0);
+			EXPECT(memcmp(a.dup_of, b.dup_of, sizeof(int32_t) * N) == 0);
+			EXPECT(memcmp(a.nbr, b.nbr, sizeof(int32_t) * (size_t) a.nbr_start[N]) == 0);
+			if (mb == 32)
+				EXPECT(memcmp(a.nbr, built.nbr, sizeof(int32_t) * (size_t) a.nbr_start[N]) == 0);
+			pgv_host_hnsw_built_free(&a);
+			pgv_host_hnsw_built_free(&b);
+		}
+		if (was)
+			setenv("PGV_HNSW_HOST_LINK", was, 1);
+		else
+			unsetenv("PGV_HNSW_HOST_LINK");
+		if (host_default && !was)
+			setenv("PGV_HNSW_HOST_SELECT", "1", 1);
+	}
 	pgv_host_hnsw_built_free(&built);
 
 	/* inside a server: the helpers and the OpenMP team take no signals (a handler that ran anywhere but on the calling
