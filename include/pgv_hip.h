@@ -695,15 +695,19 @@ int			pgv_hnsw_build_select_kept(pgv_hnsw * h, int slot, int32_t *out_ids, float
  *   pgv_hnsw_link_apply    replays the lists, then puts the batch's own elements in place; sets the entry point.  The
  *                          caller keeps searches that read the old tuples away (they have returned); later searches on
  *                          any stream see the new ones
- *   pgv_hnsw_link_end      out_nbr [total slots] (or NULL): the finished tuples; frees the state
- * out_pairs / out_deferred (or NULL): pair distances computed, lists that needed the second round of them.
+ *                          Nothing in it waits for the device: it returns with everything enqueued, and a search posted
+ *                          right behind it (another view) starts on the device when the last kernel is through
+ *   pgv_hnsw_link_end      out_nbr [total slots] (or NULL): the finished tuples; out_pairs / out_deferred (or NULL): the
+ *                          member-member pair distances scored for, and the number of, lists whose replay needed the
+ *                          second round, over the whole build; frees the state
+ * pgv_hnsw_link_prepare's out_pairs (or NULL): pair distances scored for the batch's first round.
  */
 int			pgv_hnsw_link_begin(pgv_hnsw * h);
 int			pgv_hnsw_link_prepare(pgv_hnsw * h, const int32_t *elements, const uint8_t *linked, int nq, int layer_cap,
 								  const int32_t *sel_ids, const float *sel_dist, const uint8_t *sel_closer,
 								  const int32_t *sel_count, int64_t *out_pairs);
-int			pgv_hnsw_link_apply(pgv_hnsw * h, int32_t entry, int64_t *out_pairs, int *out_deferred);
-int			pgv_hnsw_link_end(pgv_hnsw * h, int32_t *out_nbr);
+int			pgv_hnsw_link_apply(pgv_hnsw * h, int32_t entry);
+int			pgv_hnsw_link_end(pgv_hnsw * h, int32_t *out_nbr, int64_t *out_pairs, int64_t *out_deferred);
 
 /*
  * Distances between pairs of elements of the mirror, out[i] = d(a[i], b[i]): CheckElementCloser's

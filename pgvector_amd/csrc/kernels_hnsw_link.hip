@@ -515,6 +515,17 @@ __global__ __launch_bounds__(256) void hnsw_link_wave_kernel(LinkArgs g) {
     }
 }
 
+// a batch's counts added to the build's: lists that needed the second round, member pairs scored for them, updates that
+// were STILL waiting after it (must stay 0)
+__global__ void hnsw_link_stats_kernel(const int *__restrict__ blocked, const int64_t *__restrict__ totals,
+                                       int64_t *__restrict__ stats) {
+    if (threadIdx.x == 0 && blockIdx.x == 0) {
+        stats[0] += blocked[0];
+        stats[1] += blocked[0] > 0 ? totals[0] : 0;
+        stats[2] += blocked[1];
+    }
+}
+
 // the batch's own elements: list (q, lc) of the lists hnsw_select_kernel made, into its place in the tuples
 __global__ __launch_bounds__(256) void hnsw_link_new_kernel(int32_t *__restrict__ nbr, float *__restrict__ nb_dist,
                                                             uint8_t *__restrict__ nb_flag, const int32_t *__restrict__ levels,
@@ -574,6 +585,12 @@ int launch_hnsw_link_size(pgv_ctx *ctx, const int32_t *nbr, const uint8_t *nb_fl
 
 int launch_hnsw_link_scan(pgv_ctx *ctx, int64_t *a, int64_t *b, int64_t *c, int n, int64_t *totals) {
     hipLaunchKernelGGL(hnsw_link_scan_kernel, dim3(1), dim3(kLinkScanThreads), 0, ctx->stream, a, b, c, n, totals);
+    PGV_HIP(hipGetLastError());
+    return PGV_OK;
+}
+
+int launch_hnsw_link_stats(pgv_ctx *ctx, const int *blocked, const int64_t *totals, int64_t *stats) {
+    hipLaunchKernelGGL(hnsw_link_stats_kernel, dim3(1), dim3(64), 0, ctx->stream, blocked, totals, stats);
     PGV_HIP(hipGetLastError());
     return PGV_OK;
 }

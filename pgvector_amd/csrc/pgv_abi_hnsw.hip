@@ -657,6 +657,8 @@ static void hnsw_link_free(pgv_hnsw *o) {
     if (L->nb_dist) (void)hipFree(L->nb_dist);
     if (L->nb_flag) (void)hipFree(L->nb_flag);
     if (L->list_count) (void)hipFree(L->list_count);
+    if (L->stats_dev) (void)hipFree(L->stats_dev);
+    if (L->stats_host) (void)hipHostFree(L->stats_host);
     L->rec.release();
     L->links.release();
     L->ids.release();
@@ -695,6 +697,14 @@ int pgv_hnsw_link_begin(pgv_hnsw *h) {
         PGV_FAIL(PGV_ERR_NOMEM, "hipMalloc(%zu) for the hnsw build state failed", total * 5 + 2 * L->nlists * sizeof(int));
     }
     L->list_rec = L->list_count + L->nlists;
+    if (hipMalloc(&L->stats_dev, 4 * sizeof(int64_t)) != hipSuccess ||
+        hipHostMalloc(reinterpret_cast<void **>(&L->stats_host), 4 * sizeof(int64_t), hipHostMallocDefault) != hipSuccess) {
+        h->link = L;
+        hnsw_link_free(h);
+        PGV_FAIL(PGV_ERR_NOMEM, "no room for the hnsw build's counters");
+    }
+    memset(L->stats_host, 0, 4 * sizeof(int64_t));
+    PGV_HIP(hipMemsetAsync(L->stats_dev, 0, 4 * sizeof(int64_t), ctx->stream));
     h->link = L;
     PGV_HIP(hipMemsetAsync(L->nb_dist, 0, total * sizeof(float), ctx->stream));
     PGV_HIP(hipMemsetAsync(L->nb_flag, 0, total, ctx->stream));
@@ -746,7 +756,7 @@ int pgv_hnsw_link_prepare(pgv_hnsw *h, const int32_t *elements, const uint8_t *l
     }
     // records: at most one per request
     const size_t cap = per * stride, n1 = cap + 1;
-    const size_t b64 = sizeof(int64_t) * (5 * n1 + 4), b32 = sizeof(int32_t) * (7 * n1 + 4);
+    const size_t b64 = sizeof(int64_t) * (5 * n1 + 4), b32 = sizeof(int32_t) * (7 * n1 + 8);
     PGV_TRY(L->rec.ensure(b64 + b32));
     char *base = L->rec.as<char>();
     L->rec_off = reinterpret_cast<int64_t *>(base);
@@ -763,7 +773,7 @@ int pgv_hnsw_link_prepare(pgv_hnsw *h, const int32_t *elements, const uint8_t *l
     L->rec_list = L->rec_wait + n1;
     L->rec_fill = reinterpret_cast<int *>(L->rec_list + n1);
     L->blocked = L->rec_fill + n1;
-    L->nrec_dev = L->blocked + 1;
+    L->nrec_dev = L->blocked + 2;
     PGV_TRY(L->links.ensure((sizeof(int32_t) + sizeof(float)) * cap));
     L->d_link_elem = L->links.as<int32_t>();
     L->d_link_dist = reinterpret_cast<float *>(L->d_link_elem + cap);
@@ -817,65 +827,61 @@ int pgv_hnsw_link_prepare(pgv_hnsw *h, const int32_t *elements, const uint8_t *l
     return PGV_OK;  // the scoring runs on; pgv_hnsw_link_apply is ordered behind it on the same stream
 }
 
-int pgv_hnsw_link_apply(pgv_hnsw *h, int32_t entry, int64_t *out_pairs, int *out_deferred) {
+int pgv_hnsw_link_apply(pgv_hnsw *h, int32_t entry) {
     if (!h || !h->link || !h->link->prepared) PGV_FAIL(PGV_ERR_STATE, "pgv_hnsw_link_apply needs pgv_hnsw_link_prepare");
     if (entry < -1 || entry >= h->n) PGV_FAIL(PGV_ERR_ARG, "entry point %d out of range", (int)entry);
     HnswLinkState *L = h->link;
     pgv_ctx *ctx = h->ctx;
     PGV_HIP(hipSetDevice(ctx->device));
-    if (out_pairs) *out_pairs = 0;
-    if (out_deferred) *out_deferred = 0;
     L->prepared = false;
     const int nrec = L->nrec, m = h->m;
     if (nrec > 0) {
         PGV_TRY(L->loc.ensure(sizeof(int16_t) * (size_t)nrec * (2 * (size_t)m + 1)));
-        PGV_HIP(hipMemsetAsync(L->blocked, 0, sizeof(int), ctx->stream));
+        PGV_HIP(hipMemsetAsync(L->blocked, 0, 2 * sizeof(int), ctx->stream));  // [0] stopped in the first round, [1] in the second
         PGV_TRY(launch_hnsw_link_replay(ctx, h->nbr, L->nb_dist, L->nb_flag, m, nrec, 0, L->rec_lc, L->rec_off, L->d_link_dist,
                                         L->rec_pos, L->rec_nstart, L->rec_from, L->ids_start, L->ids.as<int32_t>(), L->pair_start,
                                         L->tri.as<float>(), nullptr, nullptr, L->rec_wait, L->loc.as<int16_t>(), L->blocked));
-        int blocked = 0;
-        PGV_HIP(hipMemcpyAsync(&blocked, L->blocked, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
-        PGV_HIP(hipStreamSynchronize(ctx->stream));
-        if (blocked > 0) {
-            // the replays that stepped outside the pairs fetched for them: their lists' member-member triangles, then
-            // the rest of their newcomers
-            PGV_TRY(launch_hnsw_link_size(ctx, h->nbr, L->nb_flag, h->levels, h->nbr_start, m, L->rec_owner, L->rec_lc, L->rec_list,
-                                          L->list_count, L->rec_off, nrec, 1, L->rec_pos, L->rec_nstart, L->rec_from, L->rec_wait,
-                                          nullptr, L->mm_start));
-            PGV_TRY(launch_hnsw_link_scan(ctx, L->mm_start, nullptr, nullptr, nrec, L->totals));
+        // The replays that stepped outside the pairs fetched for them: their lists' member-member triangles, then the rest
+        // of their newcomers.  Everything is enqueued without waiting for a count: the triangles' room is the bound (every
+        // record, a full list), launches cover every record and the ones that did not stop leave at once -- the host is
+        // back before the first kernel has run, and the searches of the next batch but one start on the device the
+        // moment the last one is through (hnsw_graph_acquire on their stream).
+        const size_t lm0 = 2 * (size_t)m, mm_bound = (size_t)nrec * (lm0 * (lm0 - 1) / 2);
+        const bool async = !hnsw_pairs_by_gather() && mm_bound * sizeof(float) <= ((size_t)512 << 20);
+        PGV_TRY(launch_hnsw_link_size(ctx, h->nbr, L->nb_flag, h->levels, h->nbr_start, m, L->rec_owner, L->rec_lc, L->rec_list,
+                                      L->list_count, L->rec_off, nrec, 1, L->rec_pos, L->rec_nstart, L->rec_from, L->rec_wait,
+                                      nullptr, L->mm_start));
+        PGV_TRY(launch_hnsw_link_scan(ctx, L->mm_start, nullptr, nullptr, nrec, L->totals));
+        if (async) {
+            PGV_TRY(L->mm.ensure(sizeof(float) * (mm_bound > 0 ? mm_bound : 1)));
+            PGV_TRY(launch_score_groups(ctx, h->metric, h->dtype, h->geom, h->elements, L->ids.as<int32_t>(), L->ids_start, 0,
+                                        L->rec_nstart, nullptr, L->mm_start, nrec, L->mm.as<float>()));
+        } else {
             int64_t npairs2 = 0;
             PGV_HIP(hipMemcpyAsync(&npairs2, L->totals, sizeof(int64_t), hipMemcpyDeviceToHost, ctx->stream));
             PGV_HIP(hipStreamSynchronize(ctx->stream));
-            if (npairs2 < 0 || npairs2 > (int64_t)blocked * (2 * (int64_t)m) * (2 * (int64_t)m))
-                PGV_FAIL(PGV_ERR_STATE, "pgv_hnsw_link_apply: %lld member pairs planned for %d lists", (long long)npairs2, blocked);
-            if (npairs2 > 0) {
-                PGV_TRY(L->mm.ensure(sizeof(float) * (size_t)npairs2));
-                if (hnsw_pairs_by_gather()) {
-                    PGV_TRY(L->pa.ensure(sizeof(int32_t) * (size_t)npairs2));
-                    PGV_TRY(L->pb.ensure(sizeof(int32_t) * (size_t)npairs2));
-                    PGV_TRY(launch_hnsw_link_pairs(ctx, h->nbr, L->rec_pos, L->rec_nstart, L->rec_from, L->rec_off, L->d_link_elem,
-                                                   L->d_link_dist, L->rec_list, L->list_count, nrec, 1, L->ids_start,
-                                                   L->ids.as<int32_t>(), L->mm_start, L->pa.as<int32_t>(), L->pb.as<int32_t>()));
-                    PGV_TRY(launch_score_gather(ctx, h->metric, h->dtype, h->geom, h->elements, h->elements, L->pa.as<int32_t>(),
-                                                L->pb.as<int32_t>(), npairs2, L->mm.as<float>()));
-                } else
-                    // the member triangles of the lists that wait: rows 0 .. nstart - 1 of their id lists
-                    PGV_TRY(launch_score_groups(ctx, h->metric, h->dtype, h->geom, h->elements, L->ids.as<int32_t>(), L->ids_start,
-                                                0, L->rec_nstart, nullptr, L->mm_start, nrec, L->mm.as<float>()));
-            } else
-                PGV_TRY(L->mm.ensure(16));
-            PGV_HIP(hipMemsetAsync(L->blocked, 0, sizeof(int), ctx->stream));
-            PGV_TRY(launch_hnsw_link_replay(ctx, h->nbr, L->nb_dist, L->nb_flag, m, nrec, 1, L->rec_lc, L->rec_off, L->d_link_dist,
-                                            L->rec_pos, L->rec_nstart, L->rec_from, L->ids_start, L->ids.as<int32_t>(),
-                                            L->pair_start, L->tri.as<float>(), L->mm_start, L->mm.as<float>(), L->rec_wait,
-                                            L->loc.as<int16_t>(), L->blocked));
-            int still = 0;
-            PGV_HIP(hipMemcpyAsync(&still, L->blocked, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
-            PGV_HIP(hipStreamSynchronize(ctx->stream));
-            if (still != 0) PGV_FAIL(PGV_ERR_STATE, "pgv_hnsw_link_apply: %d lists still wait for distances", still);
-            if (out_pairs) *out_pairs = npairs2;
-            if (out_deferred) *out_deferred = blocked;
+            if (npairs2 < 0 || (size_t)npairs2 > mm_bound)
+                PGV_FAIL(PGV_ERR_STATE, "pgv_hnsw_link_apply: %lld member pairs planned for %d records", (long long)npairs2, nrec);
+            PGV_TRY(L->mm.ensure(sizeof(float) * (size_t)(npairs2 > 0 ? npairs2 : 1)));
+            if (npairs2 > 0 && hnsw_pairs_by_gather()) {
+                PGV_TRY(L->pa.ensure(sizeof(int32_t) * (size_t)npairs2));
+                PGV_TRY(L->pb.ensure(sizeof(int32_t) * (size_t)npairs2));
+                PGV_TRY(launch_hnsw_link_pairs(ctx, h->nbr, L->rec_pos, L->rec_nstart, L->rec_from, L->rec_off, L->d_link_elem,
+                                               L->d_link_dist, L->rec_list, L->list_count, nrec, 1, L->ids_start,
+                                               L->ids.as<int32_t>(), L->mm_start, L->pa.as<int32_t>(), L->pb.as<int32_t>()));
+                PGV_TRY(launch_score_gather(ctx, h->metric, h->dtype, h->geom, h->elements, h->elements, L->pa.as<int32_t>(),
+                                            L->pb.as<int32_t>(), npairs2, L->mm.as<float>()));
+            } else if (npairs2 > 0)
+                PGV_TRY(launch_score_groups(ctx, h->metric, h->dtype, h->geom, h->elements, L->ids.as<int32_t>(), L->ids_start, 0,
+                                            L->rec_nstart, nullptr, L->mm_start, nrec, L->mm.as<float>()));
         }
+        PGV_TRY(launch_hnsw_link_replay(ctx, h->nbr, L->nb_dist, L->nb_flag, m, nrec, 1, L->rec_lc, L->rec_off, L->d_link_dist,
+                                        L->rec_pos, L->rec_nstart, L->rec_from, L->ids_start, L->ids.as<int32_t>(), L->pair_start,
+                                        L->tri.as<float>(), L->mm_start, L->mm.as<float>(), L->rec_wait, L->loc.as<int16_t>(),
+                                        L->blocked + 1));
+        // the counts: added up on the device, copied to pinned memory behind the launches (read at the end)
+        PGV_TRY(launch_hnsw_link_stats(ctx, L->blocked, L->totals, L->stats_dev));
+        PGV_HIP(hipMemcpyAsync(L->stats_host, L->stats_dev, 3 * sizeof(int64_t), hipMemcpyDeviceToHost, ctx->stream));
     }
     // the batch's own elements (their lists were selected with their searches)
     if (L->nq > 0)
@@ -889,8 +895,10 @@ int pgv_hnsw_link_apply(pgv_hnsw *h, int32_t entry, int64_t *out_pairs, int *out
     return PGV_OK;
 }
 
-int pgv_hnsw_link_end(pgv_hnsw *h, int32_t *out_nbr) {
+int pgv_hnsw_link_end(pgv_hnsw *h, int32_t *out_nbr, int64_t *out_pairs, int64_t *out_deferred) {
     if (!h) PGV_FAIL(PGV_ERR_ARG, "pgv_hnsw_link_end: handle is NULL");
+    if (out_pairs) *out_pairs = 0;
+    if (out_deferred) *out_deferred = 0;
     if (!h->link) return PGV_OK;
     pgv_ctx *ctx = h->ctx;
     PGV_HIP(hipSetDevice(ctx->device));
@@ -898,7 +906,11 @@ int pgv_hnsw_link_end(pgv_hnsw *h, int32_t *out_nbr) {
     if (out_nbr && h->nbr_total > 0)
         PGV_HIP(hipMemcpyAsync(out_nbr, h->nbr, sizeof(int32_t) * (size_t)h->nbr_total, hipMemcpyDefault, ctx->stream));
     PGV_HIP(hipStreamSynchronize(ctx->stream));
+    const int64_t deferred = h->link->stats_host[0], pairs2 = h->link->stats_host[1], still = h->link->stats_host[2];
     hnsw_link_free(h);
+    if (still != 0) PGV_FAIL(PGV_ERR_STATE, "pgv_hnsw_link_end: %lld list updates were left waiting for distances", (long long)still);
+    if (out_pairs) *out_pairs = pairs2;
+    if (out_deferred) *out_deferred = deferred;
     return PGV_OK;
 }
 

@@ -233,6 +233,7 @@ struct HnswLinkState {
     int *list_count = nullptr;    // [nlists] link requests of the batch in flight per list (slot position / m); zero between batches
     int *list_rec = nullptr;      // [nlists] the list's record in that batch
     size_t nlists = 0;
+    int64_t *stats_dev = nullptr, *stats_host = nullptr;  // [3] lists deferred | member pairs scored | updates left waiting (sums)
     pgv::DBuf rec, links, ids, pa, pb, tri, mm, loc, sel;
     int nrec = 0, nq = 0, lcap = 0;
     int64_t npairs = 0;   // of the batch prepared last
@@ -395,6 +396,7 @@ int launch_hnsw_link_size(pgv_ctx *ctx, const int32_t *nbr, const uint8_t *nb_fl
                           int32_t *rec_nstart, int32_t *rec_from, const int32_t *rec_wait, int64_t *size_ids,
                           int64_t *size_pairs);
 int launch_hnsw_link_scan(pgv_ctx *ctx, int64_t *a, int64_t *b, int64_t *c, int n, int64_t *totals);
+int launch_hnsw_link_stats(pgv_ctx *ctx, const int *blocked, const int64_t *totals, int64_t *stats);
 int launch_hnsw_link_pairs(pgv_ctx *ctx, const int32_t *nbr, const int64_t *rec_pos, const int32_t *rec_nstart,
                            const int32_t *rec_from, const int64_t *rec_off, int32_t *link_elem, float *link_dist,
                            const int32_t *rec_list, int *list_count, int nrec, int pass,

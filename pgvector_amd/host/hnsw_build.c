@@ -1210,10 +1210,8 @@ build_linked_on_device(pgv_hnsw * mirror, size_t item_bytes, const void *rows, i
 	for (int64_t i0 = 0; i0 < n;)
 	{
 		batch_plan	p;
-		int			entry_level,
-					deferred = 0;
-		int64_t		pairs = 0,
-					pairs2 = 0;
+		int			entry_level;
+		int64_t		pairs = 0;
 		stage_a    *a,
 				   *nx;
 
@@ -1341,10 +1339,10 @@ build_linked_on_device(pgv_hnsw * mirror, size_t item_bytes, const void *rows, i
 			}
 		}
 		PHASE(PH_UPDATE);
-		if ((rc = pgv_hnsw_link_apply(mirror, entry, &pairs2, &deferred)) != PGV_OK)
+		/* (returns with everything enqueued: the searches posted below start on the device when it is through) */
+		if ((rc = pgv_hnsw_link_apply(mirror, entry)) != PGV_OK)
 			goto dev_fail;
-		out->device_pairs += pairs + pairs2;
-		out->deferred_updates += deferred;
+		out->device_pairs += pairs;
 		PHASE(PH_RECORDS);
 		/* the searches of the batch after the next: they see the graph with this batch in it, without the next (whose
 		 * composition has to be certain, full and without a change of the entry point, for the one behind it to be) */
@@ -1369,8 +1367,15 @@ build_linked_on_device(pgv_hnsw * mirror, size_t item_bytes, const void *rows, i
 	worker_drain(&srch);
 	worker_drain(&sel);
 	PHASE(PH_PATCH);
-	if ((rc = pgv_hnsw_link_end(mirror, out->nbr)) != PGV_OK)
-		goto dev_fail;
+	{
+		int64_t		pairs2 = 0,
+					deferred = 0;
+
+		if ((rc = pgv_hnsw_link_end(mirror, out->nbr, &pairs2, &deferred)) != PGV_OK)
+			goto dev_fail;
+		out->device_pairs += pairs2;
+		out->deferred_updates += deferred;
+	}
 	PHASE(PH_RECORDS);
 	goto done;
 
@@ -1380,7 +1385,7 @@ done:
 	worker_stop(&srch);
 	worker_stop(&sel);
 	if (rc != PGV_OK)
-		pgv_hnsw_link_end(mirror, NULL);
+		pgv_hnsw_link_end(mirror, NULL, NULL, NULL);
 	for (int i = 0; i < 3; i++)
 		stage_a_free(&stages[i]);
 	free(ids);

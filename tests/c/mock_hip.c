@@ -142,6 +142,8 @@ struct pgv_hnsw
 	uint8_t    *link_linked,
 			   *link_sel_closer;
 	float	   *link_sel_dist;
+	int64_t		link_pairs2,
+				link_deferred;	/* sums over the build, handed out by pgv_hnsw_link_end */
 	/* pgv_hnsw_build_search_keep: the candidate lists of two batches */
 	struct
 	{
@@ -1372,7 +1374,7 @@ pgv_hnsw_link_prepare(pgv_hnsw * h, const int32_t *elements, const uint8_t *link
 }
 
 int
-pgv_hnsw_link_apply(pgv_hnsw * h, int32_t entry, int64_t *out_pairs, int *out_deferred)
+pgv_hnsw_link_apply(pgv_hnsw * h, int32_t entry)
 {
 	const int	m = h->m,
 				nq = h->link_nq,
@@ -1389,7 +1391,8 @@ pgv_hnsw_link_apply(pgv_hnsw * h, int32_t entry, int64_t *out_pairs, int *out_de
 			   *rec_list;
 	int32_t    *req_elem;
 	float	   *req_dist;
-	int64_t		pairs = 0;
+	int64_t		pairs = 0,
+				pairs2 = 0;
 	int			deferred = 0;
 
 	/* the link requests in the reference's order: batch elements in heap order, their layers top down, their neighbors
@@ -1509,7 +1512,7 @@ pgv_hnsw_link_apply(pgv_hnsw * h, int32_t entry, int64_t *out_pairs, int *out_de
 			for (int u = 1; u < nstart; u++)
 				for (int v = 0; v < u; v++)
 					mm[at++] = dist(h->metric, h->dim, h->vectors + (size_t) ids[u] * h->dim, h->vectors + (size_t) ids[v] * h->dim);
-			pairs += at;
+			pairs2 += at;
 			deferred++;
 			ps.mm = mm;
 			stop = pgv_link_replay(le, ld, lf, loc, &len, &closer_set, lm, ids, newdist, nstart, nlocal, stop, &ps, key, scratch);
@@ -1556,16 +1559,20 @@ pgv_hnsw_link_apply(pgv_hnsw * h, int32_t entry, int64_t *out_pairs, int *out_de
 	free(req_dist);
 	free(rec_list);
 	link_batch_free(h);
-	if (out_pairs)
-		*out_pairs = pairs;
-	if (out_deferred)
-		*out_deferred = deferred;
+	(void) pairs;				/* (the first round's are pgv_hnsw_link_prepare's to report; the stand-in scores them here) */
+	h->link_pairs2 += pairs2;
+	h->link_deferred += deferred;
 	return PGV_OK;
 }
 
 int
-pgv_hnsw_link_end(pgv_hnsw * h, int32_t *out_nbr)
+pgv_hnsw_link_end(pgv_hnsw * h, int32_t *out_nbr, int64_t *out_pairs, int64_t *out_deferred)
 {
+	if (out_pairs)
+		*out_pairs = h->link_pairs2;
+	if (out_deferred)
+		*out_deferred = h->link_deferred;
+	h->link_pairs2 = h->link_deferred = 0;
 	if (h->nb_dist && out_nbr && h->nbr_start)
 		memcpy(out_nbr, h->nbr, sizeof(int32_t) * (size_t) h->nbr_start[h->n]);
 	free(h->nb_dist);
