@@ -1008,7 +1008,7 @@ def compact_line(full):
     line = _pick(full, ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better",
                         "scaling", "vs_baseline", "dtype", "data"))
     cfg = full.get("config", {})
-    line["config"] = _pick(cfg, ("workload", "rows", "dim", "lists", "probes", "k", "batch_per_gpu"))
+    line["config"] = _pick(cfg, ("workload", "rows", "dim", "lists", "probes", "k", "batch_per_gpu", "settle_steps"))
     if isinstance(line["config"].get("workload"), str):
         line["config"]["workload"] = line["config"]["workload"][:120]
     if full.get("n_gpus", 1) > 1:
@@ -1745,6 +1745,10 @@ def main():
                     "(pgv_index_set_overlap; 1, the default: one stream, stream-ordered -- the scan kernel's launches are then "
                     "timed undisturbed; the overlapped form is measured right after as `overlapped_batches`)")
     ap.add_argument("--overlap-lanes", type=int, default=3, help="lanes of the `overlapped_batches` measurement (0: skip it)")
+    ap.add_argument("--settle-ms", type=float, default=300.0,
+                    help="untimed steps for this long BEFORE the W warmup steps: the float64 ground truth just above leaves the "
+                         "chip at whatever clocks a dense fp64 pass ends with, and a 27 ms timed region would measure that "
+                         "transient instead of the scan's steady state (0: none; the count is reported as config.settle_steps)")
     ap.add_argument("--placement", default="balanced", choices=("balanced", "modulo"),
                     help="N GPUs: lists to ranks by rows (LPT) or l %% N")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo for a functional "
@@ -1859,6 +1863,20 @@ def main():
         # ranking / planning / top-k / recheck run under the other's list scan; every batch is complete inside the timed
         # region (the synchronize below waits for all streams)
         index.set_overlap(args.overlap)
+    settle_steps = 0
+    if args.settle_ms > 0:
+        # (every rank runs the same number: the sharded step has collectives in it)
+        t_settle = time.perf_counter()
+        while True:
+            for i in range(8):
+                step(settle_steps + i)
+            settle_steps += 8
+            torch.cuda.synchronize()
+            done = torch.tensor([1.0 if (time.perf_counter() - t_settle) * 1e3 >= args.settle_ms else 0.0], device=dev)
+            if world > 1:
+                dist.all_reduce(done, op=dist.ReduceOp.MIN)
+            if done.item() > 0 or settle_steps >= 4096:
+                break
     for i in range(args.warmup):
         step(i)
     ctx.set_profiling(True)
@@ -1953,7 +1971,7 @@ def main():
                                % (args.workload, "vector" if tname == "f32" else "halfvec", oname, n, dim, tname,
                                   lists, probes, k, args.batch, components),
                    "rows": n, "dim": dim, "lists": lists, "probes": probes, "k": k,
-                   "batch_per_gpu": args.batch, "parallelism": "lists sharded over %d ranks (%s by rows); k-means all-reduce, probe-list and "
+                   "batch_per_gpu": args.batch, "settle_steps": settle_steps, "parallelism": "lists sharded over %d ranks (%s by rows); k-means all-reduce, probe-list and "
                                   "top-k all-gathers inside libpgv_hip (RCCL on the library's stream)" % (world, args.placement),
                    "local_rows": H.local_rows},
         "recall_at_10": recall, "recall_ground_truth": recall_truth,
