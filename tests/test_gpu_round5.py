@@ -282,14 +282,16 @@ def test_select_neighbors_on_the_device_is_the_sweep_over_the_same_lists(ctx, me
     mirror.close()
 
 
-@pytest.mark.parametrize("max_batch,m", [(1, 6), (64, 8), (512, 8), (256, 24)])
+@pytest.mark.parametrize("max_batch,m", [(1, 6), (64, 8), (512, 8), (256, 24), (128, 36)])
 def test_hnsw_build_on_the_device_builds_the_graph_of_the_host_replay(ctx, max_batch, m):
     """the whole build three ways: the graph updates on the device (default: pgv_hnsw_link_*, HnswUpdateConnection for
     every list a batch links into replayed by GPU lanes), the host-side replay on OpenMP threads (PGV_HNSW_HOST_LINK=1),
     and that with SelectNeighbors of the new elements on the host as well (PGV_HNSW_HOST_SELECT=1): the same graph, tuple
-    for tuple, the same duplicates, the same entry point.  m = 24 takes the 64-entry lists' instantiation of the kernel."""
+    for tuple, the same duplicates, the same entry point.  m = 36 (lists of 72, ef_construction 72) takes the forms for
+    large m: one lane per list for the replay (hnsw_link_kernel<200>, hnsw_link_core.h as compiled for the device) and for the
+    new elements' selection (hnsw_select_kernel)."""
     from pgvector_amd import _host
-    n, dim, efc = (1500, 16, 24) if max_batch == 1 else (20000, 64, max(48, 2 * m))
+    n, dim, efc = (1500, 16, 24) if max_batch == 1 else (20000 if m < 30 else 8000, 64, max(48, 2 * m))
     data = gen(n, dim, seed=811, dist="clustered", clusters=40)
     data[n // 2:n // 2 + 40] = data[7]        # duplicates: eleven heap TIDs fit an element (HNSW_HEAPTIDS 10), the rest link
     graphs = []
