@@ -189,6 +189,8 @@ test_hnsw_build(void)
 			EXPECT(memcmp(a.levels, b.levels, sizeof(int32_t) * N) == 0);
 			EXPECT(memcmp(a.dup_of, b.dup_of, sizeof(int32_t) * N) == 0);
 			EXPECT(memcmp(a.nbr, b.nbr, sizeof(int32_t) * (size_t) a.nbr_start[N]) == 0);
+			/* (both forms met lists whose replay needed the member-member distances: the second round ran) */
+			EXPECT(a.deferred_updates > 0 && b.deferred_updates > 0);
 			if (mb == 32)
 				EXPECT(memcmp(a.nbr, built.nbr, sizeof(int32_t) * (size_t) a.nbr_start[N]) == 0);
 			pgv_host_hnsw_built_free(&a);
