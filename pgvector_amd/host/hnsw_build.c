@@ -1205,8 +1205,6 @@ build_linked_on_device(pgv_hnsw * mirror, size_t item_bytes, const void *rows, i
 		rc = pgv_host_fail(PGV_ERR_NOMEM, "out of memory");
 		goto done;
 	}
-	if ((rc = pgv_hnsw_link_begin(mirror)) != PGV_OK)
-		goto dev_fail;
 	for (int64_t i0 = 0; i0 < n;)
 	{
 		batch_plan	p;
@@ -1514,9 +1512,18 @@ pgv_host_hnsw_build(pgv_hnsw * mirror, pgv_dtype dtype, int dim, const void *row
 	}
 	if (device_link)
 	{
-		PHASE(PH_RECORDS);
-		rc = build_linked_on_device(mirror, item_bytes, rows, n, m, ef_construction, max_batch, el, out, &entry, &linked);
-		goto done;
+		/* the graph state beside the tuples (5 bytes a slot + a counter pair a list): when the device has no room for it
+		 * the lists are replayed on the host instead -- distances still the GPU's, the same graph */
+		rc = pgv_hnsw_link_begin(mirror);
+		if (rc == PGV_OK)
+		{
+			PHASE(PH_RECORDS);
+			rc = build_linked_on_device(mirror, item_bytes, rows, n, m, ef_construction, max_batch, el, out, &entry, &linked);
+			goto done;
+		}
+		if (rc != PGV_ERR_NOMEM)
+			goto dev_fail;
+		rc = PGV_OK;
 	}
 	is_dirty = calloc((size_t) n, 1);
 	parts = calloc((size_t) nthreads, sizeof(recpart));

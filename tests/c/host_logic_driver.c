@@ -196,6 +196,17 @@ test_hnsw_build(void)
 			pgv_host_hnsw_built_free(&a);
 			pgv_host_hnsw_built_free(&b);
 		}
+		/* a device without room for the graph state: the build goes on with the host-side replay, same graph */
+		{
+			pgv_hnsw_built c;
+
+			unsetenv("PGV_HNSW_HOST_LINK");
+			setenv("MOCK_HIP_LINK_NOMEM", "1", 1);
+			CHECK(pgv_host_hnsw_build(mirror, PGV_F32, DIM, data, N, M, EFC, NULL, 32, &c));
+			unsetenv("MOCK_HIP_LINK_NOMEM");
+			EXPECT(c.nelements == built.nelements && memcmp(c.nbr, built.nbr, sizeof(int32_t) * (size_t) c.nbr_start[N]) == 0);
+			pgv_host_hnsw_built_free(&c);
+		}
 		if (was)
 			setenv("PGV_HNSW_HOST_LINK", was, 1);
 		else

@@ -1333,6 +1333,9 @@ pgv_hnsw_link_begin(pgv_hnsw * h)
 
 	if (h->view_of || h->m == 0)
 		return fail(PGV_ERR_STATE, "mock: pgv_hnsw_link_begin on a view / without a graph");
+	/* test knob: a device without room for the build's graph state */
+	if (getenv("MOCK_HIP_LINK_NOMEM"))
+		return fail(PGV_ERR_NOMEM, "mock: no room for the hnsw build state");
 	free(h->nb_dist);
 	free(h->nb_flag);
 	h->nb_dist = calloc((size_t) (total > 0 ? total : 1), sizeof(float));
