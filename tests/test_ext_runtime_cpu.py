@@ -57,8 +57,9 @@ REF = "/root/reference"
 PATCH = os.path.join(ROOT, "ext", "pgvector-0.8.6-gpu.patch")
 
 
+@pytest.mark.parametrize("sanitize", [False, True], ids=["plain", "asan+ubsan"])
 @pytest.mark.skipif(not os.path.isdir(os.path.join(REF, "src")), reason="the reference tree is not mounted here")
-def test_the_references_own_ivfflatgettuple_runs_with_the_hooks(tmp_path):
+def test_the_references_own_ivfflatgettuple_runs_with_the_hooks(tmp_path, sanitize):
     """the REFERENCE'S src/ivfscan.c with ext/pgvector-0.8.6-gpu.patch applied, and its
     src/vector.c, compiled from the reference tree (never copied into this repository) and linked into the stand-in server
     program with the glue -- everything against the patched reference's own ivfflat.h / hnsw.h.  Phase "the reference's own
@@ -81,10 +82,13 @@ def test_the_references_own_ivfflatgettuple_runs_with_the_hooks(tmp_path):
     lists, an empty table); with vector.gpu on the hook line inside IvfflatKmeans serves the same call and the reference's
     CheckCenters passes over the result."""
     import __graft_entry__ as entry     # ONE recipe: the program the GPU box runs is built by the same function
-    exe = entry.build_reference_driver(dict(os.environ), out=str(tmp_path / "ext_driver_ref"), mock=True)
+    flags = ["-fsanitize=address,undefined", "-fno-omit-frame-pointer"] if sanitize else []
+    exe = entry.build_reference_driver(dict(os.environ), out=str(tmp_path / "ext_driver_ref"), mock=True, extra_flags=flags)
     assert exe is not None
-    r = subprocess.run([exe], capture_output=True, text=True, timeout=900)
+    env = dict(os.environ, ASAN_OPTIONS="detect_leaks=0:abort_on_error=1", UBSAN_OPTIONS="halt_on_error=1")
+    r = subprocess.run([exe], capture_output=True, text=True, timeout=1800, env=env)
     assert r.returncode == 0 and "EXT-RUNTIME OK" in r.stdout, (r.returncode, r.stdout[-500:], r.stderr[-3000:])
+    assert "AddressSanitizer" not in r.stderr and "runtime error" not in r.stderr, r.stderr[-3000:]
     assert any("the reference's own ivfflatgettuple" in line and ": ok" in line for line in r.stderr.splitlines()), r.stderr[-3000:]
     assert any("the reference's own hnswgettuple" in line and ": ok" in line for line in r.stderr.splitlines()), r.stderr[-3000:]
     assert any("the reference's own IvfflatKmeans" in line and ": ok" in line for line in r.stderr.splitlines()), r.stderr[-3000:]
