@@ -48,7 +48,10 @@ NOT_REACHED(pq_sendfloat4)
 NOT_REACHED(pq_sendint16)
 NOT_REACHED(scanner_isspace)
 
-#ifdef PGV_HAVE_REF_HNSW
+#if defined(PGV_HAVE_REF_HNSW) && defined(PGV_HAVE_REF_IVFINSERT)
+NOT_REACHED(halfvec_l2_normalize)
+NOT_REACHED(sparsevec_l2_normalize)
+#elif defined(PGV_HAVE_REF_HNSW)
 /* with the reference's src/hnswutils.c linked in as well (tests/c/ext_driver.c, phase "the reference's own hnswgettuple"):
  * what its insert / update-meta-page half names and a scan never reaches */
 NOT_REACHED(GenericXLogStart)
@@ -60,8 +63,9 @@ NOT_REACHED(halfvec_l2_normalize)
 NOT_REACHED(sparsevec_l2_normalize)
 #endif
 
-#ifdef PGV_HAVE_REF_IVFUTILS
-/* src/ivfutils.c's page-append half (IvfflatAppendPage, IvfflatUpdateList): no scan or k-means reaches it */
+#if defined(PGV_HAVE_REF_IVFUTILS) && !defined(PGV_HAVE_REF_IVFINSERT)
+/* src/ivfutils.c's page-append half (IvfflatAppendPage, IvfflatUpdateList): no scan or k-means reaches it (with the
+ * reference's src/ivfinsert.c linked in -- PGV_HAVE_REF_IVFINSERT -- tests/c/pgshim_ref_runtime.c has the real things) */
 NOT_REACHED(GenericXLogAbort)
 NOT_REACHED(BufferGetBlockNumber)
 #ifndef PGV_HAVE_REF_HNSW

@@ -2358,6 +2358,90 @@ backend_reference_kmeans(void *arg)
 }
 #endif							/* PGV_HAVE_REF_IVFUTILS */
 
+#ifdef PGV_HAVE_REF_IVFINSERT
+/* ------------------------------------------------------------------------------------------------ the reference's own insert
+ * The program also holds pgvector's src/ivfinsert.c (patched: PgvNoteIndexChange in ivfflatinsert).  Its FindInsertPage /
+ * InsertTuple and the page-append half of its src/ivfutils.c WRITE into the pages the build hooks laid out -- PageAddItem
+ * into the lists' last pages, IvfflatAppendPage past them, IvfflatUpdateList on the list tuples.  What reads those pages
+ * afterwards: the reference's own scan, the oracle's page reader, and the PRODUCT'S stager (the worker restages the index
+ * after the change) -- all three must agree, and every inserted row must be found. */
+#define REL_INS 1008
+extern bool ivfflatinsert(Relation index, Datum *values, bool *isnull, ItemPointer heap_tid, Relation heap,
+						  IndexUniqueCheck checkUnique, bool indexUnchanged, IndexInfo *indexInfo);
+
+static int
+backend_reference_insert(void *arg)
+{
+	Relation	index = shim_open_relation(REL_INS);
+	const int	n = 4000,
+				lists = 16,
+				nins = 600;
+	float	   *rows = malloc(sizeof(float) * (size_t) (n + nins) * DIM);
+	uint64	   *got = malloc(sizeof(uint64) * 30000);
+	BlockNumber blocks0;
+	int			used_gpu;
+
+	(void) arg;
+	scenario = "the reference's own ivfflatinsert";
+	cur_ops = ORA_OPS_L2;
+	shim_set_guc_bool("vector.gpu", true);
+	shim_set_guc_bool("vector.gpu_pooled", false);
+	shim_seed_random(23);
+	gen_rows(rows, n + nins, DIM, 31);
+	if (build_index(REL_INS, rows, n, DIM, lists, 7))
+		return 1;
+	EXPECT(wait_for_gpu(index, 30.0) == 0);
+	blocks0 = RelationGetNumberOfBlocks(index);
+	for (int j = 0; j < nins; j++)
+	{
+		MemoryContext ctx = shim_query_context_begin();
+		Datum		value = PointerGetDatum(make_vector(rows + (size_t) (n + j) * DIM, DIM));
+		bool		isnull = false;
+		ItemPointerData tid = itemptr(tid_of_row(n + j));
+
+		ivfflatinsert(index, &value, &isnull, &tid, NULL, UNIQUE_CHECK_NO, false, NULL);
+		shim_query_context_end(ctx);
+	}
+	/* 600 tuples of 144 bytes: the lists' last pages filled up and pages were appended */
+	EXPECT(RelationGetNumberOfBlocks(index) > blocks0);
+	/* (1) vector.gpu = off: the reference's scan over pages it partly wrote itself = the oracle's reading of them */
+	shim_set_guc_bool("vector.gpu", false);
+	for (int i = 0; i < 16; i++)
+	{
+		const int	r = n + (37 * i) % nins;
+		Expected	e = expected_batch(REL_INS, rows + (size_t) r * DIM, PROBES);
+		int			nn = ref_scan(index, rows + (size_t) r * DIM, PROBES, 10, got, &used_gpu);
+
+		EXPECT(!used_gpu && nn == 10);
+		if (check_stream(&e, got, nn, 0, "after the reference's inserts, CPU branch"))
+			return 1;
+		EXPECT(got[0] == tid_of_row(r));	/* the inserted row itself, at distance 0 */
+		expected_free(&e);
+	}
+	/* (2) vector.gpu = on: the worker stages the index again -- the product's stager over the reference's tuples -- and
+	 * the hooks inside the reference's scan serve from the device */
+	shim_set_guc_bool("vector.gpu", true);
+	EXPECT(wait_for_gpu(index, 30.0) == 0);
+	for (int i = 0; i < 16; i++)
+	{
+		const int	r = n + (37 * i + 11) % nins;
+		Expected	e = expected_batch(REL_INS, rows + (size_t) r * DIM, PROBES);
+		int			nn = ref_scan(index, rows + (size_t) r * DIM, PROBES, i % 4 == 3 ? 400 : 10, got, &used_gpu);
+
+		EXPECT(used_gpu && nn == (i % 4 == 3 ? (400 < e.n ? 400 : e.n) : 10));
+		if (check_stream(&e, got, nn, 0, "after the reference's inserts, hooks"))
+			return 1;
+		EXPECT(got[0] == tid_of_row(r));
+		expected_free(&e);
+	}
+	fprintf(stderr, "   %d rows through the reference's ivfflatinsert (%u -> %u blocks): its scan, the oracle and the restaged mirror agree\n",
+			nins, (unsigned) blocks0, (unsigned) RelationGetNumberOfBlocks(index));
+	free(rows);
+	free(got);
+	return 0;
+}
+#endif							/* PGV_HAVE_REF_IVFINSERT */
+
 int
 main(void)
 {
@@ -2391,6 +2475,9 @@ main(void)
 	shim_create_relation(REL_HNSW2, &hnsw_l2, empty, 0, DIM);
 	shim_create_relation(REL_IP, &ip, empty, 0, DIM);
 	shim_create_relation(REL_WIDE, &l2, empty, 0, IVFFLAT_MAX_DIM);
+#ifdef PGV_HAVE_REF_IVFINSERT
+	shim_create_relation(REL_INS, &l2, empty, 0, DIM);
+#endif
 
 	failed |= run_phase("CREATE INDEX through the build hooks", backend_build, 1, NULL, 300.0);
 	if (!failed)
@@ -2459,6 +2546,10 @@ main(void)
 #ifdef PGV_HAVE_REF_IVFUTILS
 	if (!failed)
 		failed |= run_phase("the reference's own IvfflatKmeans", backend_reference_kmeans, 1, NULL, 300.0);
+#endif
+#ifdef PGV_HAVE_REF_IVFINSERT
+	if (!failed)
+		failed |= run_phase("the reference's own ivfflatinsert", backend_reference_insert, 1, NULL, 300.0);
 #endif
 	if (!failed && mock_hip_set_arena)
 		failed |= run_phase("a backend without a device", backend_no_device, 1, NULL, 120.0);

@@ -718,3 +718,146 @@ MemoryContextMemAllocated(MemoryContext context, bool recurse)
 	return shim_context_bytes(context);
 }
 #endif							/* PGV_HAVE_REF_HNSW */
+
+#ifdef PGV_HAVE_REF_IVFINSERT
+/* ------------------------------------------------------------------------------------------------ for src/ivfinsert.c
+ * (-DPGV_HAVE_REF_IVFINSERT: the reference's own ivfflatinsert -- FindInsertPage, InsertTuple -- and, reached through it,
+ * the page-append half of its src/ivfutils.c WRITE into the emulated pages.)  storage/bufpage.c's PageInit / PageAddItem /
+ * PageGetFreeSpace over the real page layout, index_form_tuple for the one varlena attribute these indexes have, and a
+ * generic-xlog that hands out the page itself: nothing here crashes mid-record, so there is nothing to replay. */
+struct GenericXLogState
+{
+	int			unused;
+};
+static struct GenericXLogState the_xlog_state;
+
+GenericXLogState *
+GenericXLogStart(Relation relation)
+{
+	(void) relation;
+	return &the_xlog_state;
+}
+
+Page
+GenericXLogRegisterBuffer(GenericXLogState *state, Buffer buffer, int flags)
+{
+	(void) state;
+	(void) flags;
+	return BufferGetPage(buffer);
+}
+
+XLogRecPtr
+GenericXLogFinish(GenericXLogState *state)
+{
+	(void) state;
+	return 0;
+}
+
+void
+GenericXLogAbort(GenericXLogState *state)
+{
+	(void) state;				/* (the reference aborts only records that changed nothing: src/ivfutils.c:272-276) */
+}
+
+void
+MarkBufferDirty(Buffer buffer)
+{
+	(void) buffer;
+}
+
+void
+LockRelationForExtension(Relation relation, LOCKMODE lockmode)
+{
+	(void) relation;
+	(void) lockmode;
+}
+
+void
+UnlockRelationForExtension(Relation relation, LOCKMODE lockmode)
+{
+	(void) relation;
+	(void) lockmode;
+}
+
+const char *
+RelationGetRelationName(Relation relation)
+{
+	(void) relation;
+	return "index";
+}
+
+/* storage/bufpage.c PageInit: an empty page with `specialSize` bytes of special space at its end */
+void
+PageInit(Page page, Size pageSize, Size specialSize)
+{
+	PageHeader	p = (PageHeader) page;
+
+	specialSize = MAXALIGN(specialSize);
+	memset(page, 0, pageSize);
+	p->pd_lower = SizeOfPageHeaderData;
+	p->pd_upper = (LocationIndex) (pageSize - specialSize);
+	p->pd_special = (LocationIndex) (pageSize - specialSize);
+	p->pd_pagesize_version = (uint16) (pageSize | 4);	/* PG_PAGE_LAYOUT_VERSION */
+}
+
+/* PageGetFreeSpace: what fits between the line pointers and the tuples, less one new line pointer */
+Size
+PageGetFreeSpace(Page page)
+{
+	const PageHeader p = (PageHeader) page;
+	int			space = (int) p->pd_upper - (int) p->pd_lower;
+
+	if (space < 4)
+		return 0;
+	return (Size) (space - 4);
+}
+
+/* PageAddItemExtended, the append case (offsetNumber invalid, no overwrite): the tuple below pd_upper, a line pointer
+ * (lp_off:15 | lp_flags:2 = LP_NORMAL | lp_len:15) at pd_lower */
+OffsetNumber
+PageAddItem(Page page, Item item, Size size, OffsetNumber offsetNumber, bool overwrite, bool is_heap)
+{
+	PageHeader	p = (PageHeader) page;
+	const OffsetNumber limit = (OffsetNumber) (PageGetMaxOffsetNumber(page) + 1);
+	const int	lower = (int) p->pd_lower + 4;
+	const int	upper = (int) p->pd_upper - (int) MAXALIGN(size);
+	uint32		lp;
+
+	(void) is_heap;
+	if (overwrite || (offsetNumber != InvalidOffsetNumber && offsetNumber != limit))
+		elog(ERROR, "pgshim: PageAddItem: only appends");
+	if (lower > upper)
+		return InvalidOffsetNumber;
+	lp = (uint32) upper | (1u << 15) | ((uint32) size << 17);
+	memcpy(page + SizeOfPageHeaderData + (size_t) (limit - 1) * 4, &lp, 4);
+	memcpy(page + upper, item, size);
+	p->pd_lower = (LocationIndex) lower;
+	p->pd_upper = (LocationIndex) upper;
+	return limit;
+}
+
+/* access/common/indextuple.c for one by-reference varlena attribute with a 4-byte header (a vector of more than 30
+ * dimensions is never packed into a 1-byte header): header 8 bytes, the value behind it, t_info = size | INDEX_VAR_MASK */
+IndexTuple
+index_form_tuple(TupleDesc tupleDescriptor, const Datum *values, const bool *isnull)
+{
+	const void *v = DatumGetPointer(values[0]);
+	const Size	vsize = VARSIZE_ANY(v);
+	const Size	size = MAXALIGN(sizeof(IndexTupleData) + vsize);
+	IndexTuple	tup;
+
+	(void) tupleDescriptor;
+	if (isnull[0] || vsize < 128)
+		elog(ERROR, "pgshim: index_form_tuple: one non-null varlena of 128 bytes or more");
+	tup = palloc0(size);
+	memcpy((char *) tup + sizeof(IndexTupleData), v, vsize);
+	tup->t_info = (unsigned short) (size | 0x4000);
+	return tup;
+}
+
+Size
+IndexTupleSize(IndexTuple itup)
+{
+	return (Size) (itup->t_info & 0x1FFF);
+}
+#endif							/* PGV_HAVE_REF_IVFINSERT */

@@ -1037,6 +1037,16 @@ ReadBufferExtended(Relation reln, ForkNumber forkNum, BlockNumber blockNum, Read
 	(void) forkNum, (void) mode, (void) strategy;
 	if (is_bgworker && __atomic_load_n(&S->bgw_read_delay_us, __ATOMIC_ACQUIRE) > 0)
 		usleep(__atomic_load_n(&S->bgw_read_delay_us, __ATOMIC_ACQUIRE));
+	if (blockNum == 0xFFFFFFFFu)	/* P_NEW: the relation grows by one zeroed page (under the caller's extension lock) */
+	{
+		uint32		nb = __atomic_load_n(&r->nblocks, __ATOMIC_ACQUIRE);
+
+		if (nb >= r->cap_blocks)
+			ereport(ERROR, (errmsg("could not extend relation %u: page store full", reln->rd_id)));
+		memset(Sbase + r->pages_off + (size_t) nb * SHIM_BLCKSZ, 0, SHIM_BLCKSZ);
+		__atomic_store_n(&r->nblocks, nb + 1, __ATOMIC_RELEASE);
+		blockNum = nb;
+	}
 	if (blockNum >= __atomic_load_n(&r->nblocks, __ATOMIC_ACQUIRE))
 		ereport(ERROR, (errmsg("could not read block %u of relation %u: read only 0 of 8192 bytes", blockNum, reln->rd_id)));
 	if (npins == MAX_PINS)
@@ -1097,6 +1107,13 @@ BufferGetPage(Buffer buffer)
 {
 	(void) pin_index(buffer);
 	return Sbase + S->rels[BUF_REL(buffer)].pages_off + (size_t) BUF_BLK(buffer) * SHIM_BLCKSZ;
+}
+
+BlockNumber
+BufferGetBlockNumber(Buffer buffer)
+{
+	(void) pin_index(buffer);
+	return BUF_BLK(buffer);
 }
 
 BlockNumber
