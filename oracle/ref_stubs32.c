@@ -67,7 +67,6 @@ NOT_REACHED(sparsevec_l2_normalize)
 /* src/ivfutils.c's page-append half (IvfflatAppendPage, IvfflatUpdateList): no scan or k-means reaches it (with the
  * reference's src/ivfinsert.c linked in -- PGV_HAVE_REF_IVFINSERT -- tests/c/pgshim_ref_runtime.c has the real things) */
 NOT_REACHED(GenericXLogAbort)
-NOT_REACHED(BufferGetBlockNumber)
 #ifndef PGV_HAVE_REF_HNSW
 NOT_REACHED(GenericXLogStart)
 NOT_REACHED(GenericXLogRegisterBuffer)
