@@ -2366,6 +2366,26 @@ backend_reference_kmeans(void *arg)
  * afterwards: the reference's own scan, the oracle's page reader, and the PRODUCT'S stager (the worker restages the index
  * after the change) -- all three must agree, and every inserted row must be found. */
 #define REL_INS 1008
+#ifdef PGV_HAVE_REF_IVFVACUUM
+extern IndexBulkDeleteResult *ivfflatbulkdelete(IndexVacuumInfo *info, IndexBulkDeleteResult *stats, IndexBulkDeleteCallback callback,
+												 void *callback_state);
+extern IndexBulkDeleteResult *ivfflatvacuumcleanup(IndexVacuumInfo *info, IndexBulkDeleteResult *stats);
+static int	ins_rows_built;
+
+/* dead: every third row of the build, every other inserted row */
+static int
+ins_row_is_dead(int r, int built)
+{
+	return r < built ? r % 3 == 0 : (r - built) % 2 == 0;
+}
+
+static bool
+ins_dead_callback(ItemPointer itemptr, void *state)
+{
+	(void) state;
+	return ins_row_is_dead(row_of_tid(tid_key(itemptr)), ins_rows_built) != 0;
+}
+#endif
 extern bool ivfflatinsert(Relation index, Datum *values, bool *isnull, ItemPointer heap_tid, Relation heap,
 						  IndexUniqueCheck checkUnique, bool indexUnchanged, IndexInfo *indexInfo);
 
@@ -2436,6 +2456,47 @@ backend_reference_insert(void *arg)
 	}
 	fprintf(stderr, "   %d rows through the reference's ivfflatinsert (%u -> %u blocks): its scan, the oracle and the restaged mirror agree\n",
 			nins, (unsigned) blocks0, (unsigned) RelationGetNumberOfBlocks(index));
+#ifdef PGV_HAVE_REF_IVFVACUUM
+	/* (3) VACUUM by the reference's own ivfflatbulkdelete (src/ivfvacuum.c, patched: PgvNoteIndexChange at its end): every
+	 * third row of the build and every other inserted row are dead.  PageIndexMultiDelete compacts the pages the lists
+	 * keep, IvfflatUpdateList resets the insert pages; afterwards the three readers agree again and no dead row is seen. */
+	{
+		IndexVacuumInfo info;
+		IndexBulkDeleteResult *stats;
+		int			dead = 0;
+
+		for (int r = 0; r < n + nins; r++)
+			dead += ins_row_is_dead(r, n);
+		memset(&info, 0, sizeof(info));
+		info.index = index;
+		ins_rows_built = n;
+		stats = ivfflatbulkdelete(&info, NULL, ins_dead_callback, NULL);
+		EXPECT(stats != NULL && (int) stats->tuples_removed == dead && (int) stats->num_index_tuples == n + nins - dead);
+		stats = ivfflatvacuumcleanup(&info, stats);
+		EXPECT(stats != NULL && stats->num_pages == RelationGetNumberOfBlocks(index));
+		for (int pass = 0; pass < 2; pass++)
+		{
+			shim_set_guc_bool("vector.gpu", pass == 1);
+			if (pass == 1)
+				EXPECT(wait_for_gpu(index, 30.0) == 0);
+			for (int i = 0; i < 16; i++)
+			{
+				const int	r = n + (2 * (23 * i % (nins / 2)) + 1);	/* an inserted row that lives (odd rank) */
+				Expected	e = expected_batch(REL_INS, rows + (size_t) r * DIM, PROBES);
+				int			nn = ref_scan(index, rows + (size_t) r * DIM, PROBES, 300, got, &used_gpu);
+
+				EXPECT(used_gpu == (pass == 1) && nn == (300 < e.n ? 300 : e.n));
+				if (check_stream(&e, got, nn, 0, pass ? "after the reference's vacuum, hooks" : "after the reference's vacuum, CPU branch"))
+					return 1;
+				EXPECT(got[0] == tid_of_row(r));
+				for (int j = 0; j < nn; j++)
+					EXPECT(!ins_row_is_dead(row_of_tid(got[j]), n));
+				expected_free(&e);
+			}
+		}
+		fprintf(stderr, "   %d of %d rows removed by the reference's ivfflatbulkdelete: no reader sees one of them\n", dead, n + nins);
+	}
+#endif
 	free(rows);
 	free(got);
 	return 0;

@@ -861,3 +861,55 @@ IndexTupleSize(IndexTuple itup)
 	return (Size) (itup->t_info & 0x1FFF);
 }
 #endif							/* PGV_HAVE_REF_IVFINSERT */
+
+#ifdef PGV_HAVE_REF_IVFVACUUM
+/* ------------------------------------------------------------------------------------------------ for src/ivfvacuum.c
+ * (the reference's own ivfflatbulkdelete / ivfflatvacuumcleanup over the emulated pages) */
+void
+vacuum_delay_point(void)
+{
+}
+
+void
+LockBufferForCleanup(Buffer buffer)
+{
+	LockBuffer(buffer, BUFFER_LOCK_EXCLUSIVE);	/* (nobody else pins the page in this program while a vacuum runs) */
+}
+
+/* storage/bufpage.c PageIndexMultiDelete: the listed items (ascending) go, the others keep their order -- line pointers
+ * renumbered, tuples packed against the special space again */
+void
+PageIndexMultiDelete(Page page, OffsetNumber *itemnos, int nitems)
+{
+	PageHeader	p = (PageHeader) page;
+	const int	nline = PageGetMaxOffsetNumber(page);
+	char		old[BLCKSZ];
+	int			next = 0,
+				kept = 0,
+				upper = p->pd_special;
+
+	memcpy(old, page, BLCKSZ);
+	for (int off = 1; off <= nline; off++)
+	{
+		uint32		lp;
+		Size		size;
+
+		if (next < nitems && itemnos[next] == off)
+		{
+			next++;
+			continue;
+		}
+		memcpy(&lp, old + SizeOfPageHeaderData + (size_t) (off - 1) * 4, 4);
+		size = lp >> 17;
+		upper -= (int) MAXALIGN(size);
+		memcpy(page + upper, old + (lp & 0x7FFFu), size);
+		lp = (uint32) upper | (lp & (3u << 15)) | ((uint32) size << 17);
+		memcpy(page + SizeOfPageHeaderData + (size_t) kept * 4, &lp, 4);
+		kept++;
+	}
+	if (next != nitems)
+		elog(ERROR, "pgshim: PageIndexMultiDelete: item numbers not ascending / out of range");
+	p->pd_lower = (LocationIndex) (SizeOfPageHeaderData + 4 * kept);
+	p->pd_upper = (LocationIndex) upper;
+}
+#endif							/* PGV_HAVE_REF_IVFVACUUM */

@@ -85,7 +85,10 @@ def test_the_references_own_ivfflatgettuple_runs_with_the_hooks(tmp_path, saniti
     And for inserts (-DPGV_HAVE_REF_IVFINSERT): the reference's patched src/ivfinsert.c.  Phase "the reference's own
     ivfflatinsert": 600 rows go through its FindInsertPage / InsertTuple / IvfflatAppendPage / IvfflatUpdateList into the
     pages the build hooks laid out (PageAddItem, page appends); afterwards the reference's scan, the oracle's page reader
-    and the mirror the worker restages with the PRODUCT'S stager agree on 32 queries, each finding its inserted row first."""
+    and the mirror the worker restages with the PRODUCT'S stager agree on 32 queries, each finding its inserted row first.
+    Then its src/ivfvacuum.c (-DPGV_HAVE_REF_IVFVACUUM): ivfflatbulkdelete removes a third of the rows (PageIndexMultiDelete
+    compacts the pages, the insert pages are reset), ivfflatvacuumcleanup counts the pages; the three readers agree again on
+    300-tuple pulls and none of them sees a dead row."""
     import __graft_entry__ as entry     # ONE recipe: the program the GPU box runs is built by the same function
     flags = ["-fsanitize=address,undefined", "-fno-omit-frame-pointer"] if sanitize else []
     exe = entry.build_reference_driver(dict(os.environ), out=str(tmp_path / "ext_driver_ref"), mock=True, extra_flags=flags)
@@ -99,3 +102,4 @@ def test_the_references_own_ivfflatgettuple_runs_with_the_hooks(tmp_path, saniti
     assert any("the reference's own IvfflatKmeans" in line and ": ok" in line for line in r.stderr.splitlines()), r.stderr[-3000:]
     assert r.stderr.count("bit for bit") == 5, r.stderr[-3000:]
     assert any("the reference's own ivfflatinsert" in line and ": ok" in line for line in r.stderr.splitlines()), r.stderr[-3000:]
+    assert "removed by the reference's ivfflatbulkdelete" in r.stderr, r.stderr[-3000:]
