@@ -1073,7 +1073,6 @@ backend_hnsw_build(void *arg)
 	int			entry_level;
 	pgv_rel		rel;
 
-	(void) arg;
 	scenario = "hnsw pages";
 	gen_rows(data, HN, DIM, 3);
 	g = ora_hnsw_build(ORA_OPS_L2, ORA_F32, DIM, data, HN, HM, 32, 9);
@@ -1102,7 +1101,7 @@ backend_hnsw_build(void *arg)
 	pgv_rel_init(&rel);
 	EXPECT(pgv_host_hnsw_write_index(&rel, PGV_F32, DIM, HM, 32, HN, data, tids, levels, nbr_start, nbr, dup_of,
 									 ora_hnsw_entry_point(g, &entry_level)) == PGV_OK);
-	shim_replace_pages(REL_HNSW, rel.pages, rel.nblocks);
+	shim_replace_pages(arg ? (Oid) (uintptr_t) arg : REL_HNSW, rel.pages, rel.nblocks);	/* (arg: another relation to lay the same graph into) */
 	pgv_rel_free(&rel);
 	ora_hnsw_free(g);
 	return 0;
@@ -2077,8 +2076,8 @@ ref_hnsw_scan(Relation index, const float *query, int want, uint64 *got, int *ha
 /* the stream of heap TIDs against the oracle's walk of the same graph: the distance at every position, the row itself
  * wherever its distance is clear of its neighbours' */
 static int
-check_hnsw_stream(const float *data, const float *q, const uint64 *got, int n, const int64_t *rows, const double *dist, int want,
-				  const char *what)
+check_hnsw_stream_n(const float *data, int nrows, const float *q, const uint64 *got, int n, const int64_t *rows, const double *dist,
+					int want, const char *what)
 {
 	if (n != want)
 	{
@@ -2090,7 +2089,7 @@ check_hnsw_stream(const float *data, const float *q, const uint64 *got, int n, c
 		int			r = row_of_tid(got[j]);
 		double		d = 0;
 
-		if (r < 0 || r >= HN)
+		if (r < 0 || r >= nrows)
 		{
 			fprintf(stderr, "%s: position %d is no heap tuple (%llx)\n", what, j, (unsigned long long) got[j]);
 			return 1;
@@ -2110,6 +2109,13 @@ check_hnsw_stream(const float *data, const float *q, const uint64 *got, int n, c
 		}
 	}
 	return 0;
+}
+
+static int
+check_hnsw_stream(const float *data, const float *q, const uint64 *got, int n, const int64_t *rows, const double *dist, int want,
+				  const char *what)
+{
+	return check_hnsw_stream_n(data, HN, q, got, n, rows, dist, want, what);
 }
 
 static int
@@ -2503,6 +2509,190 @@ backend_reference_insert(void *arg)
 }
 #endif							/* PGV_HAVE_REF_IVFINSERT */
 
+#ifdef PGV_HAVE_REF_HNSWINSERT
+/* ------------------------------------------------------------------------------------------------ the reference's own hnsw insert
+ * pgvector's src/hnswinsert.c (patched: PgvNoteIndexChange in hnswinsert) is in the program too.  HnswInsertTupleOnDisk
+ * searches the pages (src/hnswutils.c), adds the element and its neighbor tuple (PageAddItem, HnswInsertAppendPage),
+ * rewrites the neighbors' tuples (PageIndexTupleOverwrite), moves the entry point in the meta page -- into the pages
+ * pgv_host_hnsw_write_index laid out.  Afterwards the reference's scan and the device walk over the mirror the worker
+ * restages (the product's stager over the reference's tuples) must return the same streams, every inserted row first
+ * for its own vector, a duplicate's heap TID beside the original's. */
+#define REL_HINS 2003
+#ifdef PGV_HAVE_REF_HNSWVACUUM
+extern IndexBulkDeleteResult *hnswbulkdelete(IndexVacuumInfo *info, IndexBulkDeleteResult *stats, IndexBulkDeleteCallback callback,
+											  void *callback_state);
+extern IndexBulkDeleteResult *hnswvacuumcleanup(IndexVacuumInfo *info, IndexBulkDeleteResult *stats);
+
+static bool
+hins_dead_callback(ItemPointer itemptr, void *state)
+{
+	(void) state;
+	return row_of_tid(tid_key(itemptr)) % 4 == 0;
+}
+#endif
+extern bool hnswinsert(Relation index, Datum *values, bool *isnull, ItemPointer heap_tid, Relation heap,
+					   IndexUniqueCheck checkUnique, bool indexUnchanged, IndexInfo *indexInfo);
+
+static int
+backend_reference_hnsw_insert(void *arg)
+{
+	Relation	index = shim_open_relation(REL_HINS);
+	const int	nins = 300,
+				ndup = 5;
+	float	   *data = malloc(sizeof(float) * (size_t) (HN + nins) * DIM);
+	uint64		cpu[64],
+				gpu[64];
+	int			had_gpu;
+	long		reads;
+	BlockNumber blocks0 = RelationGetNumberOfBlocks(index);
+	double		until;
+
+	(void) arg;
+	scenario = "the reference's own hnswinsert";
+	hnsw_ef_search = 40;
+	shim_seed_random(29);
+	gen_rows(data, HN, DIM, 3);	/* the rows of the graph the pages hold */
+	{
+		float	   *more = malloc(sizeof(float) * (size_t) (HN + nins) * DIM);
+
+		gen_rows(more, HN + nins, DIM, 41);
+		memcpy(data + (size_t) HN * DIM, more + (size_t) HN * DIM, sizeof(float) * (size_t) nins * DIM);
+		free(more);
+	}
+	for (int j = 0; j < ndup; j++)	/* the last few are copies of rows already in the graph */
+		memcpy(data + (size_t) (HN + nins - 1 - j) * DIM, data + (size_t) (100 + 7 * j) * DIM, sizeof(float) * DIM);
+	shim_set_guc_bool("vector.gpu", true);
+	for (int j = 0; j < nins; j++)
+	{
+		MemoryContext ctx = shim_query_context_begin();
+		Datum		value = PointerGetDatum(make_vector(data + (size_t) (HN + j) * DIM, DIM));
+		bool		isnull = false;
+		ItemPointerData tid = itemptr(tid_of_row(HN + j));
+
+		hnswinsert(index, &value, &isnull, &tid, NULL, UNIQUE_CHECK_NO, false, NULL);
+		shim_query_context_end(ctx);
+	}
+	EXPECT(RelationGetNumberOfBlocks(index) > blocks0);
+	/* the mirror of the changed index */
+	until = shim_now() + 30.0;
+	for (;;)
+	{
+		(void) ref_hnsw_scan(index, data, 1, gpu, &had_gpu, &reads);
+		if ((had_gpu && reads == 0) || shim_now() > until)
+			break;
+		usleep(20000);
+	}
+	EXPECT(had_gpu && reads == 0);
+	for (int i = 0; i < 40; i++)
+	{
+		const int	r = i < 30 ? HN + (11 * i) % (nins - ndup) : (i < 35 ? HN + nins - 1 - (i - 30) : 37 * i);
+		const float *q = data + (size_t) r * DIM;
+		int			nc,
+					ng;
+		int64_t		rows[64];
+		double		dist[64];
+
+		shim_set_guc_bool("vector.gpu", false);
+		nc = ref_hnsw_scan(index, q, 64, cpu, &had_gpu, &reads);
+		EXPECT(!had_gpu && reads > 0 && nc >= 40);
+		shim_set_guc_bool("vector.gpu", true);
+		ng = ref_hnsw_scan(index, q, 64, gpu, &had_gpu, &reads);
+		EXPECT(had_gpu && reads == 0);
+		/* the device walk's stream against the reference's walk of the same pages: position by position the distance,
+		 * the row wherever its distance is clear of its neighbours' */
+		for (int j = 0; j < nc; j++)
+		{
+			const int	row = row_of_tid(cpu[j]);
+			double		d = 0;
+
+			EXPECT(row >= 0 && row < HN + nins);
+			for (int k = 0; k < DIM; k++)
+				d += ((double) data[(size_t) row * DIM + k] - q[k]) * ((double) data[(size_t) row * DIM + k] - q[k]);
+			rows[j] = row;
+			dist[j] = d;
+		}
+		if (check_hnsw_stream_n(data, HN + nins, q, gpu, ng, rows, dist, nc, "after the reference's hnsw inserts"))
+			return 1;
+		if (i < 30)
+			EXPECT(cpu[0] == tid_of_row(r));	/* the inserted row, at distance 0 */
+		else if (i < 35)
+		{
+			/* a duplicate: its heap TID sits on the element of the row it copies -- both come back, at distance 0 */
+			const uint64 orig = tid_of_row(100 + 7 * (i - 30)),
+						dup = tid_of_row(r);
+
+			EXPECT((cpu[0] == orig && cpu[1] == dup) || (cpu[0] == dup && cpu[1] == orig));
+			EXPECT((gpu[0] == orig && gpu[1] == dup) || (gpu[0] == dup && gpu[1] == orig));
+		}
+	}
+	fprintf(stderr, "   %d rows (%d of them duplicates) through the reference's hnswinsert (%u -> %u blocks): its walk and the device's over the restaged pages agree\n",
+			nins, ndup, (unsigned) blocks0, (unsigned) RelationGetNumberOfBlocks(index));
+#ifdef PGV_HAVE_REF_HNSWVACUUM
+	/* VACUUM by the reference's own hnswbulkdelete (src/hnswvacuum.c, patched: PgvNoteIndexChange at its end): every
+	 * fourth row is dead.  RemoveHeapTids strips their heap TIDs, RepairGraph links the neighbors of the elements that
+	 * go anew (the on-disk search and HnswUpdateConnection of src/hnswutils.c), MarkDeleted blanks their tuples.  The
+	 * worker stages the index again; the two walks agree and no dead row comes back. */
+	{
+		IndexVacuumInfo info;
+		IndexBulkDeleteResult *stats;
+		int			dead = 0;
+
+		for (int r = 0; r < HN + nins; r++)
+			dead += r % 4 == 0;
+		memset(&info, 0, sizeof(info));
+		info.index = index;
+		stats = hnswbulkdelete(&info, NULL, hins_dead_callback, NULL);
+		EXPECT(stats != NULL && (int) stats->tuples_removed == dead);
+		stats = hnswvacuumcleanup(&info, stats);
+		EXPECT(stats != NULL && stats->num_pages == RelationGetNumberOfBlocks(index));
+		until = shim_now() + 30.0;
+		for (;;)
+		{
+			(void) ref_hnsw_scan(index, data + DIM, 1, gpu, &had_gpu, &reads);
+			if ((had_gpu && reads == 0) || shim_now() > until)
+				break;
+			usleep(20000);
+		}
+		EXPECT(had_gpu && reads == 0);
+		for (int i = 0; i < 30; i++)
+		{
+			const int	r = 4 * ((29 * i) % ((HN + nins) / 4)) + 1 + i % 3;	/* a row that lives */
+			const float *q = data + (size_t) r * DIM;
+			int			nc,
+						ng;
+			int64_t		rows[64];
+			double		dist[64];
+
+			shim_set_guc_bool("vector.gpu", false);
+			nc = ref_hnsw_scan(index, q, 64, cpu, &had_gpu, &reads);
+			EXPECT(!had_gpu && reads > 0 && nc >= 30);
+			shim_set_guc_bool("vector.gpu", true);
+			ng = ref_hnsw_scan(index, q, 64, gpu, &had_gpu, &reads);
+			EXPECT(had_gpu && reads == 0);
+			for (int j = 0; j < nc; j++)
+			{
+				const int	row = row_of_tid(cpu[j]);
+				double		d = 0;
+
+				EXPECT(row >= 0 && row < HN + nins && row % 4 != 0);
+				for (int k = 0; k < DIM; k++)
+					d += ((double) data[(size_t) row * DIM + k] - q[k]) * ((double) data[(size_t) row * DIM + k] - q[k]);
+				rows[j] = row;
+				dist[j] = d;
+			}
+			for (int j = 0; j < ng; j++)
+				EXPECT(row_of_tid(gpu[j]) % 4 != 0);
+			if (check_hnsw_stream_n(data, HN + nins, q, gpu, ng, rows, dist, nc, "after the reference's hnsw vacuum"))
+				return 1;
+		}
+		fprintf(stderr, "   %d of %d rows removed by the reference's hnswbulkdelete: neither walk returns one of them\n", dead, HN + nins);
+	}
+#endif
+	free(data);
+	return 0;
+}
+#endif							/* PGV_HAVE_REF_HNSWINSERT */
+
 int
 main(void)
 {
@@ -2538,6 +2728,9 @@ main(void)
 	shim_create_relation(REL_WIDE, &l2, empty, 0, IVFFLAT_MAX_DIM);
 #ifdef PGV_HAVE_REF_IVFINSERT
 	shim_create_relation(REL_INS, &l2, empty, 0, DIM);
+#endif
+#ifdef PGV_HAVE_REF_HNSWINSERT
+	shim_create_relation(REL_HINS, &hnsw_l2, empty, 0, DIM);
 #endif
 
 	failed |= run_phase("CREATE INDEX through the build hooks", backend_build, 1, NULL, 300.0);
@@ -2611,6 +2804,16 @@ main(void)
 #ifdef PGV_HAVE_REF_IVFINSERT
 	if (!failed)
 		failed |= run_phase("the reference's own ivfflatinsert", backend_reference_insert, 1, NULL, 300.0);
+#endif
+#ifdef PGV_HAVE_REF_HNSWINSERT
+	if (!failed)
+	{
+		void	   *rel[1] = {(void *) (uintptr_t) REL_HINS};
+
+		failed |= run_phase("hnsw: the oracle's graph into a second relation", backend_hnsw_build, 1, rel, 120.0);
+	}
+	if (!failed)
+		failed |= run_phase("the reference's own hnswinsert", backend_reference_hnsw_insert, 1, NULL, 300.0);
 #endif
 	if (!failed && mock_hip_set_arena)
 		failed |= run_phase("a backend without a device", backend_no_device, 1, NULL, 120.0);

@@ -913,3 +913,97 @@ PageIndexMultiDelete(Page page, OffsetNumber *itemnos, int nitems)
 	p->pd_upper = (LocationIndex) upper;
 }
 #endif							/* PGV_HAVE_REF_IVFVACUUM */
+
+#ifdef PGV_HAVE_REF_HNSWINSERT
+/* ------------------------------------------------------------------------------------------------ for src/hnswinsert.c
+ * (the reference's own hnswinsert -> HnswInsertTupleOnDisk: the on-disk search of src/hnswutils.c, then element and
+ * neighbor tuples added to / overwritten in the emulated pages) */
+MemoryContext
+GenerationContextCreate(MemoryContext parent, const char *name, Size minContextSize, Size initBlockSize, Size maxBlockSize)
+{
+	(void) parent;
+	(void) name;
+	(void) minContextSize;
+	(void) initBlockSize;
+	(void) maxBlockSize;
+	return shim_context_create();
+}
+
+Size
+ItemIdGetLength(ItemId itemId)
+{
+	uint32		lp;
+
+	memcpy(&lp, itemId, 4);
+	return (Size) (lp >> 17);
+}
+
+Size
+PageGetExactFreeSpace(Page page)
+{
+	const PageHeader p = (PageHeader) page;
+	int			space = (int) p->pd_upper - (int) p->pd_lower;
+
+	return space < 0 ? 0 : (Size) space;
+}
+
+/* storage/bufpage.c PageIndexTupleOverwrite: the tuple at offnum replaced by one of possibly another size; the tuples
+ * between pd_upper and it slide, their line pointers follow */
+bool
+PageIndexTupleOverwrite(Page page, OffsetNumber offnum, Item newtup, Size newsize)
+{
+	PageHeader	p = (PageHeader) page;
+	const int	nline = PageGetMaxOffsetNumber(page);
+	uint32		lp;
+	int			offset,
+				oldsize,
+				alignednew = (int) MAXALIGN(newsize),
+				diff;
+
+	if (offnum < 1 || offnum > nline)
+		elog(ERROR, "pgshim: PageIndexTupleOverwrite: invalid index offnum %u", (unsigned) offnum);
+	memcpy(&lp, page + SizeOfPageHeaderData + (size_t) (offnum - 1) * 4, 4);
+	offset = (int) (lp & 0x7FFFu);
+	oldsize = (int) MAXALIGN(lp >> 17);
+	if (alignednew > oldsize + ((int) p->pd_upper - (int) p->pd_lower))
+		return false;
+	diff = oldsize - alignednew;
+	if (diff != 0)
+	{
+		memmove(page + p->pd_upper + diff, page + p->pd_upper, (size_t) (offset - p->pd_upper));
+		p->pd_upper = (LocationIndex) (p->pd_upper + diff);
+		for (int i = 1; i <= nline; i++)
+		{
+			uint32		o;
+
+			memcpy(&o, page + SizeOfPageHeaderData + (size_t) (i - 1) * 4, 4);
+			if ((o >> 15 & 3u) != 0 && (int) (o & 0x7FFFu) <= offset)
+			{
+				o = (o & ~0x7FFFu) | (uint32) ((int) (o & 0x7FFFu) + diff);
+				memcpy(page + SizeOfPageHeaderData + (size_t) (i - 1) * 4, &o, 4);
+			}
+		}
+		memcpy(&lp, page + SizeOfPageHeaderData + (size_t) (offnum - 1) * 4, 4);	/* (moved with the others) */
+	}
+	lp = (lp & 0x1FFFFu) | ((uint32) newsize << 17);
+	memcpy(page + SizeOfPageHeaderData + (size_t) (offnum - 1) * 4, &lp, 4);
+	memcpy(page + (lp & 0x7FFFu), newtup, newsize);
+	return true;
+}
+
+/* utils/datum.c: by-reference varlena values (typLen -1) equal byte for byte */
+bool
+datumIsEqual(Datum value1, Datum value2, bool typByVal, int typLen)
+{
+	Size		s1,
+				s2;
+
+	if (typByVal)
+		return value1 == value2;
+	if (typLen != -1)
+		elog(ERROR, "datumIsEqual: typLen %d", typLen);
+	s1 = VARSIZE_ANY(DatumGetPointer(value1));
+	s2 = VARSIZE_ANY(DatumGetPointer(value2));
+	return s1 == s2 && memcmp(DatumGetPointer(value1), DatumGetPointer(value2), s1) == 0;
+}
+#endif							/* PGV_HAVE_REF_HNSWINSERT */

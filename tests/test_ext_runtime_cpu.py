@@ -88,7 +88,14 @@ def test_the_references_own_ivfflatgettuple_runs_with_the_hooks(tmp_path, saniti
     and the mirror the worker restages with the PRODUCT'S stager agree on 32 queries, each finding its inserted row first.
     Then its src/ivfvacuum.c (-DPGV_HAVE_REF_IVFVACUUM): ivfflatbulkdelete removes a third of the rows (PageIndexMultiDelete
     compacts the pages, the insert pages are reset), ivfflatvacuumcleanup counts the pages; the three readers agree again on
-    300-tuple pulls and none of them sees a dead row."""
+    300-tuple pulls and none of them sees a dead row.
+
+    And the HNSW side of both (-DPGV_HAVE_REF_HNSWINSERT / _HNSWVACUUM): the reference's patched src/hnswinsert.c puts 300
+    rows, five of them copies of rows already there, through HnswInsertTupleOnDisk into the pages pgv_host_hnsw_write_index
+    laid out (element + neighbor tuples added, neighbors' tuples overwritten, pages appended); its src/hnswvacuum.c then
+    removes every fourth row (RemoveHeapTids, RepairGraph, MarkDeleted).  After each, the reference's walk of the pages and
+    the device walk over the mirror the worker restaged (the product's stager over the reference's tuples) return the same
+    streams; a duplicate's heap TID comes back beside the original's; no dead row comes back."""
     import __graft_entry__ as entry     # ONE recipe: the program the GPU box runs is built by the same function
     flags = ["-fsanitize=address,undefined", "-fno-omit-frame-pointer"] if sanitize else []
     exe = entry.build_reference_driver(dict(os.environ), out=str(tmp_path / "ext_driver_ref"), mock=True, extra_flags=flags)
@@ -103,3 +110,5 @@ def test_the_references_own_ivfflatgettuple_runs_with_the_hooks(tmp_path, saniti
     assert r.stderr.count("bit for bit") == 5, r.stderr[-3000:]
     assert any("the reference's own ivfflatinsert" in line and ": ok" in line for line in r.stderr.splitlines()), r.stderr[-3000:]
     assert "removed by the reference's ivfflatbulkdelete" in r.stderr, r.stderr[-3000:]
+    assert any("the reference's own hnswinsert" in line and ": ok" in line for line in r.stderr.splitlines()), r.stderr[-3000:]
+    assert "removed by the reference's hnswbulkdelete" in r.stderr, r.stderr[-3000:]

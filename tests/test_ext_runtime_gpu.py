@@ -50,3 +50,5 @@ def test_the_references_own_gettuple_functions_drive_the_hooks_on_the_gpu():
     assert any("the reference's own IvfflatKmeans" in line and ": ok" in line for line in r.stderr.splitlines()), r.stderr[-3000:]
     assert any("the reference's own ivfflatinsert" in line and ": ok" in line for line in r.stderr.splitlines()), r.stderr[-3000:]
     assert "removed by the reference's ivfflatbulkdelete" in r.stderr, r.stderr[-3000:]
+    assert any("the reference's own hnswinsert" in line and ": ok" in line for line in r.stderr.splitlines()), r.stderr[-3000:]
+    assert "removed by the reference's hnswbulkdelete" in r.stderr, r.stderr[-3000:]
