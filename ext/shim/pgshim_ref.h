@@ -93,8 +93,9 @@ bool		VARATT_IS_SHORT(const void *p);
 #define PANIC 23
 int			pgshim_errcode(int sqlstate);
 #define errcode(c) pgshim_errcode(c)
-#define errdetail(...) pgshim_errmsg(__VA_ARGS__)
-#define errhint(...) pgshim_errmsg(__VA_ARGS__)
+int			pgshim_errmore(const char *fmt,...) __attribute__((format(printf, 1, 2)));	/* detail / hint: the primary message stays */
+#define errdetail(...) pgshim_errmore(__VA_ARGS__)
+#define errhint(...) pgshim_errmore(__VA_ARGS__)
 #define ERRCODE_FEATURE_NOT_SUPPORTED 1
 #define ERRCODE_INVALID_PARAMETER_VALUE 2
 #define ERRCODE_PROGRAM_LIMIT_EXCEEDED 3

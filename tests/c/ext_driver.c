@@ -374,13 +374,9 @@ typedef struct Sorted
 }			Sorted;
 static Sorted sorted;
 
-/* the tuplesort feed of AddTupleToSort (src/ivfbuild.c:203-216): the reference's file keeps it; here it collects */
-void
-IvfflatAddToSort(IvfflatBuildState * buildstate, int list, ItemPointer tid, Datum value)
+static void
+sorted_append(int list, uint64 tid, const float *x)
 {
-	Vector	   *v = (Vector *) DatumGetPointer(value);
-
-	(void) buildstate;
 	if (sorted.n == sorted.cap)
 	{
 		sorted.cap = sorted.cap ? sorted.cap * 2 : 4096;
@@ -389,9 +385,68 @@ IvfflatAddToSort(IvfflatBuildState * buildstate, int list, ItemPointer tid, Datu
 		sorted.rows = realloc(sorted.rows, sizeof(float) * (size_t) sorted.cap * (size_t) sorted.dim);
 	}
 	sorted.list[sorted.n] = list;
-	sorted.tid[sorted.n] = tid_key(tid);
-	memcpy(sorted.rows + (size_t) sorted.n * sorted.dim, v->x, sizeof(float) * (size_t) sorted.dim);
+	sorted.tid[sorted.n] = tid;
+	memcpy(sorted.rows + (size_t) sorted.n * sorted.dim, x, sizeof(float) * (size_t) sorted.dim);
 	sorted.n++;
+}
+
+#ifndef PGV_HAVE_REF_IVFBUILD
+/* the tuplesort feed of AddTupleToSort (src/ivfbuild.c:203-216): the reference's file keeps it; here it collects.  (With the
+ * reference's src/ivfbuild.c in the program, -DPGV_HAVE_REF_IVFBUILD, the function is the REFERENCE'S and the flushes of
+ * the build hooks land in the build's tuplesort, which build_index reads back.) */
+void
+IvfflatAddToSort(IvfflatBuildState * buildstate, int list, ItemPointer tid, Datum value)
+{
+	(void) buildstate;
+	sorted_append(list, tid_key(tid), ((Vector *) DatumGetPointer(value))->x);
+}
+#endif
+
+/* With the reference's src/ivfbuild.c in the program the flushes of the build hooks go through ITS IvfflatAddToSort into the
+ * build's tuplesort: set up as InitBuildState / AssignTuples do (src/ivfbuild.c:340-352, :380-390, :1040), read back in
+ * the order the tuples were put */
+static void
+build_sort_begin(IvfflatBuildState * bs)
+{
+#ifdef PGV_HAVE_REF_IVFBUILD
+	AttrNumber	attNums[] = {1};
+	Oid			sortOperators[] = {Int4LessOperator};
+	Oid			sortCollations[] = {InvalidOid};
+	bool		nullsFirstFlags[] = {false};
+
+	bs->sortdesc = CreateTemplateTupleDesc(3);
+	TupleDescInitEntry(bs->sortdesc, (AttrNumber) 1, "list", INT4OID, -1, 0);
+	TupleDescInitEntry(bs->sortdesc, (AttrNumber) 2, "tid", TIDOID, -1, 0);
+	TupleDescInitEntry(bs->sortdesc, (AttrNumber) 3, "vector", SHIM_VECTOR_TYPE_OID, -1, 0);
+	bs->slot = MakeSingleTupleTableSlot(bs->sortdesc, &TTSOpsVirtual);
+	bs->sortstate = tuplesort_begin_heap(bs->sortdesc, 1, attNums, sortOperators, sortCollations, nullsFirstFlags, 65536, NULL, 0);
+#else
+	(void) bs;
+#endif
+}
+
+static int
+build_sort_drain(IvfflatBuildState * bs)
+{
+#ifdef PGV_HAVE_REF_IVFBUILD
+	int			n = (int) shim_tuplesort_inputs(bs->sortstate);
+
+	if ((int) bs->indtuples != n)
+		return -1;
+	for (int i = 0; i < n; i++)
+	{
+		int32_t		list;
+		ItemPointerData tid;
+		const void *value;
+
+		shim_tuplesort_input(bs->sortstate, i, &list, &tid, &value);
+		sorted_append(list, tid_key(&tid), ((const Vector *) value)->x);
+	}
+	tuplesort_end(bs->sortstate);
+#else
+	(void) bs;
+#endif
+	return sorted.n;
 }
 
 /* ivfflatbuild's GPU-relevant skeleton: samples -> IvfflatKmeans -> heap scan with BuildCallback -> sort by list ->
@@ -454,6 +509,7 @@ build_index(Oid relid, const float *rows, int n, int dim, int lists, int toast_e
 
 	sorted.n = 0;
 	sorted.dim = dim;
+	build_sort_begin(&bs);
 	PgvIvfflatBuildBegin(&bs);
 	EXPECT(bs.gpu != NULL);
 	/* BuildCallback (src/ivfbuild.c:224-266): the value is detoasted inside tmpCtx, which is reset after every row */
@@ -470,6 +526,7 @@ build_index(Oid relid, const float *rows, int n, int dim, int lists, int toast_e
 	}
 	shim_query_context_end(tmp);
 	PgvIvfflatBuildFlush(&bs);
+	EXPECT(build_sort_drain(&bs) == n);
 	EXPECT(sorted.n == n);
 
 	/* every row went to its nearest center (the oracle's FUNCTION 1 value decides; float-level ties excepted) */
@@ -1859,6 +1916,7 @@ backend_wide_build(void *arg)
 	bs.centers = &centers;
 	sorted.n = 0;
 	sorted.dim = dim;
+	build_sort_begin(&bs);
 	PgvIvfflatBuildBegin(&bs);	/* (an ERROR here reaches the top level: exit code 100) */
 	EXPECT(bs.gpu != NULL);
 	for (int i = 0; i < 8; i++)
@@ -1869,7 +1927,7 @@ backend_wide_build(void *arg)
 		PgvIvfflatBuildAdd(&bs, &tid, PointerGetDatum(make_vector(row, dim)));
 	}
 	PgvIvfflatBuildFlush(&bs);
-	EXPECT(sorted.n == 8);
+	EXPECT(build_sort_drain(&bs) == 8);
 	for (int i = 0; i < 8; i++)
 		EXPECT(sorted.list[i] == i % 4 && sorted.tid[i] == tid_of_row(i));
 	free(row);
@@ -2693,6 +2751,614 @@ backend_reference_hnsw_insert(void *arg)
 }
 #endif							/* PGV_HAVE_REF_HNSWINSERT */
 
+#if defined(PGV_HAVE_REF_IVFBUILD) || defined(PGV_HAVE_REF_HNSWBUILD)
+/* ------------------------------------------------------------------------------------------------ the table under CREATE INDEX
+ * rows of the stand-in heap (pgshim_ref_runtime.c walks them for table_index_build_scan): some NULL, some toasted */
+typedef struct HeapRows
+{
+	const float *rows;
+	int			dim;
+	int			toast_every,
+				null_every;
+}			HeapRows;
+
+static int
+heap_row_is_null(const HeapRows * h, int64_t row)
+{
+	return h->null_every > 0 && row % h->null_every == h->null_every - 1;
+}
+
+static void
+heap_fetch(int64_t row, Datum *value, bool *isnull, ItemPointerData *tid, void *arg)
+{
+	const HeapRows *h = arg;
+
+	*tid = itemptr(tid_of_row((int) row));
+	*isnull = heap_row_is_null(h, row) != 0;
+	*value = (Datum) 0;
+	if (!*isnull)
+	{
+		Vector	   *plain = make_vector(h->rows + (size_t) row * h->dim, h->dim);
+
+		*value = (h->toast_every && row % h->toast_every == 0) ? make_toasted(plain) : PointerGetDatum(plain);
+	}
+}
+
+static Relation
+heap_of(HeapRows * h, int64_t nrows)
+{
+	ShimHeapDef def;
+
+	def.nrows = nrows;
+	def.rows_per_block = 50;	/* tid_of_row */
+	def.fetch = heap_fetch;
+	def.arg = h;
+	return shim_heap_relation(&def);
+}
+#endif
+
+#ifdef PGV_HAVE_REF_IVFBUILD
+/* ------------------------------------------------------------------------------------------------ the reference's own CREATE INDEX (ivfflat)
+ * The program holds pgvector's src/ivfbuild.c as well (patched: the GPU branch in AddTupleToSort, IvfflatAddToSort split
+ * off, PgvIvfflatBuildBegin / Flush round the heap scan, PgvNoteIndexChange at the end of ivfflatbuild).  ivfflatbuild()
+ * itself runs: InitBuildState, ComputeCenters (SampleRows over the stand-in heap -> IvfflatKmeans), CreateMetaPage,
+ * CreateListPages, CreateEntryPages (table_index_build_scan -> BuildCallback -> AddTupleToSort, tuplesort, InsertTuples)
+ * -- every page of the index is written by the reference.
+ *   vector.gpu = off, the oracle's pg_prng stream: the reference's whole serial build against the oracle's restatement of
+ *     it (ora_kmeans from the same draws over the same samples, ora_ivf_assign): the centers in the list pages bit for bit,
+ *     every list's tuples -- TID and vector, in heap order -- exactly the oracle's.
+ *   vector.gpu = on: the same call; k-means, the argmin of every row and nothing else come from the device, the reference
+ *     sorts and writes.  Every row is in a nearest list, once; the reference's scan, the oracle's page reader and the
+ *     device scan over the mirror the worker stages (the product's stager over the reference's pages) agree. */
+#define REL_RBUILD 1009
+extern IndexBuildResult *ivfflatbuild(Relation heap, Relation index, IndexInfo *indexInfo);
+
+static int
+staged_image(Oid relid, pgv_ivf_image * img)
+{
+	pgv_rel		rel;
+	uint32_t	nblocks;
+	const void *pages = shim_relation_pages(relid, &nblocks);
+
+	pgv_rel_init(&rel);
+	rel.pages = (uint8_t *) pages;	/* (read only: the stager never writes) */
+	rel.nblocks = nblocks;
+	rel.cap = nblocks;
+	return pgv_host_ivf_stage(&rel, PGV_F32, img);
+}
+
+static int
+backend_reference_ivfbuild(void *arg)
+{
+	Relation	index = shim_open_relation(REL_RBUILD);
+	const int	n = 6000,
+				lists = 24;
+	float	   *rows = malloc(sizeof(float) * (size_t) n * DIM);
+	float	   *live = malloc(sizeof(float) * (size_t) n * DIM);
+	int		   *live_row = malloc(sizeof(int) * (size_t) n);
+	uint64	   *got = malloc(sizeof(uint64) * 30000);
+	HeapRows	h;
+	Relation	heap;
+	IndexInfo	info;
+	IndexBuildResult *res;
+	MemoryContext ctx;
+	pgv_ivf_image img;
+	int			nlive = 0,
+				used_gpu;
+	uint8_t		empty[1] = {0};
+
+	(void) arg;
+	scenario = "the reference's own ivfflatbuild";
+	cur_ops = ORA_OPS_L2;
+	EXPECT(index != NULL);
+	gen_rows(rows, n, DIM, 51);
+	h.rows = rows;
+	h.dim = DIM;
+	h.toast_every = 7;
+	h.null_every = 13;
+	heap = heap_of(&h, n);
+	for (int r = 0; r < n; r++)
+		if (!heap_row_is_null(&h, r))
+		{
+			memcpy(live + (size_t) nlive * DIM, rows + (size_t) r * DIM, sizeof(float) * DIM);
+			live_row[nlive++] = r;
+		}
+	memset(&info, 0, sizeof(info));
+
+	/* ---- (1) the reference's serial CPU build = the oracle's */
+	{
+		ora_prng	a,
+					b;
+		float	   *want_centers = malloc(sizeof(float) * (size_t) lists * DIM);
+		int32_t    *want_list = malloc(sizeof(int32_t) * (size_t) nlive);
+		int			iterations,
+					at = 0;
+
+		shim_set_guc_bool("vector.gpu", false);
+		ora_prng_seed(&a, 91);
+		shim_prng_hook(ora_prng_double_cb, ora_prng_u32_cb, &a);
+		ctx = shim_query_context_begin();
+		res = ivfflatbuild(heap, index, &info);
+		shim_prng_hook(NULL, NULL, NULL);
+		EXPECT(res != NULL && (int) res->heap_tuples == n && (int) res->index_tuples == nlive);
+		shim_query_context_end(ctx);
+		EXPECT(shim_pinned_buffers() == 0);
+
+		/* the oracle: 6000 rows are fewer than the 10 000 samples asked for, so the sample IS the table's non-NULL rows
+		 * in heap order (src/ivfbuild.c:446-455; every block is taken, the reservoir never replaces); SampleRows draws
+		 * its block sampler's seed and the reservoir's from the global stream before k-means starts */
+		ora_prng_seed(&b, 91);
+		(void) ora_prng_u32(&b);
+		(void) ora_prng_u32(&b);
+		iterations = ora_kmeans(ORA_OPS_L2, ORA_F32, DIM, live, nlive, want_centers, lists, &b, NULL);
+		EXPECT(iterations >= 0);
+		EXPECT(a.s0 == b.s0 && a.s1 == b.s1);	/* the same number of draws */
+		ora_ivf_assign(ORA_OPS_L2, ORA_F32, DIM, want_centers, lists, live, nlive, want_list, NULL);
+
+		EXPECT(staged_image(REL_RBUILD, &img) == PGV_OK);
+		EXPECT(img.dim == DIM && img.lists == lists && img.nrows == nlive);
+		if (memcmp(img.centers, want_centers, sizeof(float) * (size_t) lists * DIM) != 0)
+		{
+			fprintf(stderr, "the centers in the reference's list pages are not the oracle's\n");
+			return 1;
+		}
+		for (int l = 0; l < lists; l++)
+		{
+			int64_t		p = img.list_offsets[l];
+
+			/* tuplesort by list, heap order inside (the stand-in's sort is stable): the oracle's rows of list l in order */
+			for (int i = 0; i < nlive; i++)
+				if (want_list[i] == l)
+				{
+					if (p >= img.list_offsets[l + 1] || img.tids[p] != tid_of_row(live_row[i]) ||
+						memcmp((const float *) img.vectors + (size_t) p * DIM, live + (size_t) i * DIM, sizeof(float) * DIM) != 0)
+					{
+						fprintf(stderr, "list %d of the reference's build: position %lld is not the oracle's row %d\n", l,
+								(long long) (p - img.list_offsets[l]), live_row[i]);
+						return 1;
+					}
+					p++;
+					at++;
+				}
+			EXPECT(p == img.list_offsets[l + 1]);
+		}
+		EXPECT(at == nlive);
+		fprintf(stderr, "   the reference's serial ivfflatbuild (%d rows, %d NULL, %d lists, %d Elkan iterations, %u blocks) = the oracle's build: centers bit for bit, every list's tuples in order\n",
+				n, n - nlive, lists, iterations, (unsigned) RelationGetNumberOfBlocks(index));
+		pgv_host_ivf_image_free(&img);
+		/* and its own scan reads what it wrote */
+		for (int i = 0; i < 8; i++)
+		{
+			const int	r = live_row[(97 * i) % nlive];
+			Expected	e = expected_batch(REL_RBUILD, rows + (size_t) r * DIM, PROBES);
+			int			nn = ref_scan(index, rows + (size_t) r * DIM, PROBES, 10, got, &used_gpu);
+
+			EXPECT(!used_gpu && nn == 10 && got[0] == tid_of_row(r));
+			if (check_stream(&e, got, nn, 0, "the reference's CPU build, CPU branch"))
+				return 1;
+			expected_free(&e);
+		}
+		free(want_centers);
+		free(want_list);
+	}
+
+	/* ---- (2) DROP + CREATE INDEX with vector.gpu = on: the hooks inside the reference's build */
+	shim_replace_pages(REL_RBUILD, empty, 0);
+	shim_set_guc_bool("vector.gpu", true);
+	shim_set_guc_bool("vector.gpu_pooled", false);
+	shim_seed_random(53);
+	ctx = shim_query_context_begin();
+	res = ivfflatbuild(heap, index, &info);
+	EXPECT(res != NULL && (int) res->heap_tuples == n && (int) res->index_tuples == nlive);
+	shim_query_context_end(ctx);
+	EXPECT(shim_pinned_buffers() == 0);
+	EXPECT(staged_image(REL_RBUILD, &img) == PGV_OK);
+	EXPECT(img.dim == DIM && img.lists == lists && img.nrows == nlive);
+	{
+		char	   *seen = calloc((size_t) n, 1);
+
+		for (int l = 0; l < lists; l++)
+		{
+			int			prev = -1;
+
+			for (int64_t p = img.list_offsets[l]; p < img.list_offsets[l + 1]; p++)
+			{
+				const int	r = row_of_tid(img.tids[p]);
+				const float *x = (const float *) img.vectors + (size_t) p * DIM;
+				double		best = INFINITY,
+							mine;
+
+				EXPECT(r > prev && r < n && !seen[r] && !heap_row_is_null(&h, r));	/* heap order inside a list, no row twice */
+				prev = r;
+				seen[r] = 1;
+				EXPECT(memcmp(x, rows + (size_t) r * DIM, sizeof(float) * DIM) == 0);
+				for (int c = 0; c < lists; c++)
+				{
+					double		d = ora_index_distance(ORA_OPS_L2, ORA_F32, DIM, x, (const float *) img.centers + (size_t) c * DIM);
+
+					if (d < best)
+						best = d;
+				}
+				mine = ora_index_distance(ORA_OPS_L2, ORA_F32, DIM, x, (const float *) img.centers + (size_t) l * DIM);
+				EXPECT(mine <= best + 1e-5 * fabs(best) + 1e-9);	/* its nearest center (float-level ties excepted) */
+			}
+		}
+		free(seen);
+	}
+	pgv_host_ivf_image_free(&img);
+	/* the three readers over pages the reference wrote from the device's answers */
+	shim_set_guc_bool("vector.gpu", false);
+	for (int i = 0; i < 12; i++)
+	{
+		const int	r = live_row[(131 * i + 5) % nlive];
+		Expected	e = expected_batch(REL_RBUILD, rows + (size_t) r * DIM, PROBES);
+		int			nn = ref_scan(index, rows + (size_t) r * DIM, PROBES, i % 4 == 3 ? 300 : 10, got, &used_gpu);
+
+		EXPECT(!used_gpu && nn == (i % 4 == 3 ? (300 < e.n ? 300 : e.n) : 10) && got[0] == tid_of_row(r));
+		if (check_stream(&e, got, nn, 0, "the reference's build with the hooks, CPU branch"))
+			return 1;
+		expected_free(&e);
+	}
+	shim_set_guc_bool("vector.gpu", true);
+	EXPECT(wait_for_gpu(index, 30.0) == 0);
+	for (int i = 0; i < 12; i++)
+	{
+		const int	r = live_row[(131 * i + 71) % nlive];
+		Expected	e = expected_batch(REL_RBUILD, rows + (size_t) r * DIM, PROBES);
+		int			nn = ref_scan(index, rows + (size_t) r * DIM, PROBES, i % 4 == 3 ? 300 : 10, got, &used_gpu);
+
+		EXPECT(used_gpu && nn == (i % 4 == 3 ? (300 < e.n ? 300 : e.n) : 10) && got[0] == tid_of_row(r));
+		if (check_stream(&e, got, nn, 0, "the reference's build with the hooks, hooks"))
+			return 1;
+		expected_free(&e);
+	}
+	fprintf(stderr, "   the reference's ivfflatbuild with the hooks (k-means and %d argmins from the device, pages by the reference): every row in a nearest list; its scan, the oracle and the staged mirror agree\n",
+			nlive);
+	free(rows);
+	free(live);
+	free(live_row);
+	free(got);
+	return 0;
+}
+#endif							/* PGV_HAVE_REF_IVFBUILD */
+
+#ifdef PGV_HAVE_REF_HNSWBUILD
+/* ------------------------------------------------------------------------------------------------ the reference's own CREATE INDEX (hnsw)
+ * pgvector's src/hnswbuild.c is in the program too (patched: PgvHnswBuildBegin at the end of InitBuildState,
+ * PgvHnswBuildDefer in InsertTuple, PgvHnswBuildLink first in FlushPages, PgvNoteIndexChange at the end of hnswbuild).
+ * hnswbuild() itself runs over the stand-in heap: InitBuildState, BuildGraph (table_index_build_scan -> BuildCallback ->
+ * InsertTuple: HnswFormIndexValue, HnswInitElement, the allocator and its memory accounting), FlushPages (CreateMetaPage,
+ * CreateGraphPages, WriteNeighborTuples) -- every page is the reference's.
+ *   vector.gpu = off, the oracle's pg_prng stream: the reference's serial in-memory build (InsertTupleInMemory,
+ *     HnswFindElementNeighbors, UpdateNeighborsInMemory, the duplicates) against the oracle's ora_hnsw_build from the same
+ *     seed: levels, every neighbor array slot for slot, the heap TIDs of duplicates, the entry point -- read back from
+ *     the reference's pages by the product's stager.
+ *   vector.gpu = on: the hooks defer every element and link them in FlushPages; the reference serialises what the device
+ *     linked.  The reference's walk of those pages and the device walk over the staged mirror return the same streams. */
+#define REL_HRBUILD 2004
+extern IndexBuildResult *hnswbuild(Relation heap, Relation index, IndexInfo *indexInfo);
+
+static int
+staged_hnsw_image(Oid relid, pgv_hnsw_image * img)
+{
+	pgv_rel		rel;
+	uint32_t	nblocks;
+	const void *pages = shim_relation_pages(relid, &nblocks);
+
+	pgv_rel_init(&rel);
+	rel.pages = (uint8_t *) pages;
+	rel.nblocks = nblocks;
+	rel.cap = nblocks;
+	return pgv_host_hnsw_stage(&rel, PGV_F32, img);
+}
+
+static int
+backend_reference_hnswbuild(void *arg)
+{
+	Relation	index = shim_open_relation(REL_HRBUILD);
+	const int	n = 2500,
+				m = HM,
+				efc = 32;
+	float	   *rows = malloc(sizeof(float) * (size_t) n * DIM);
+	float	   *live = malloc(sizeof(float) * (size_t) n * DIM);
+	int		   *live_row = malloc(sizeof(int) * (size_t) n);
+	HeapRows	h;
+	Relation	heap;
+	IndexInfo	info;
+	IndexBuildResult *res;
+	MemoryContext ctx;
+	pgv_hnsw_image img;
+	int			nlive = 0;
+	uint8_t		empty[1] = {0};
+	uint64		cpu[64],
+				gpu[64];
+	int			had_gpu;
+	long		reads;
+
+	(void) arg;
+	scenario = "the reference's own hnswbuild";
+	EXPECT(index != NULL);
+	hnsw_ef_search = 40;
+	gen_rows(rows, n, DIM, 61);
+	/* duplicates: one value under ten heap TIDs (what an element holds), another under two.  (An eleventh copy would become
+	 * a second element with the same vector: every distance to the two is an exact tie, and which of them a neighbor list
+	 * keeps is decided by the order equal keys leave the server's pairing heap in -- PostgreSQL core, not pinned by the
+	 * oracle (order among equal distances).  The hook phase above covers that case tie-tolerantly.) */
+	for (int r = 700; r < 709; r++)
+		memcpy(rows + (size_t) r * DIM, rows + (size_t) 300 * DIM, sizeof(float) * DIM);
+	memcpy(rows + (size_t) 2000 * DIM, rows + (size_t) 10 * DIM, sizeof(float) * DIM);
+	h.rows = rows;
+	h.dim = DIM;
+	h.toast_every = 9;
+	h.null_every = 17;
+	heap = heap_of(&h, n);
+	for (int r = 0; r < n; r++)
+		if (!heap_row_is_null(&h, r))
+		{
+			memcpy(live + (size_t) nlive * DIM, rows + (size_t) r * DIM, sizeof(float) * DIM);
+			live_row[nlive++] = r;
+		}
+	memset(&info, 0, sizeof(info));
+
+	/* ---- (1) the reference's serial in-memory build = the oracle's */
+	{
+		ora_prng	a;
+		ora_hnsw   *g;
+		int64_t		ne;
+		int		   *slot_of_element;
+		int			entry_level;
+
+		shim_set_guc_bool("vector.gpu", false);
+		ora_prng_seed(&a, 97);
+		shim_prng_hook(ora_prng_double_cb, ora_prng_u32_cb, &a);
+		ctx = shim_query_context_begin();
+		res = hnswbuild(heap, index, &info);
+		shim_prng_hook(NULL, NULL, NULL);
+		EXPECT(res != NULL && (int) res->heap_tuples == n && (int) res->index_tuples == nlive);
+		shim_query_context_end(ctx);
+		EXPECT(shim_pinned_buffers() == 0);
+
+		g = ora_hnsw_build(ORA_OPS_L2, ORA_F32, DIM, live, nlive, m, efc, 97);	/* one level draw per non-NULL row, from seed 97 */
+		EXPECT(g != NULL);
+		ne = ora_hnsw_num_elements(g);
+		EXPECT(staged_hnsw_image(REL_HRBUILD, &img) == PGV_OK);
+		EXPECT(img.dim == DIM && img.m == m && img.ef_construction == efc);
+		if (img.n != ne)
+		{
+			fprintf(stderr, "the reference's pages hold %lld elements, the oracle's graph %lld\n", (long long) img.n, (long long) ne);
+			return 1;
+		}
+		/* slots are in page order; an element is known by its first heap TID */
+		slot_of_element = malloc(sizeof(int) * (size_t) ne);
+		{
+			int		   *slot_of_row = malloc(sizeof(int) * (size_t) n);
+
+			for (int r = 0; r < n; r++)
+				slot_of_row[r] = -1;
+			for (int64_t s = 0; s < img.n; s++)
+			{
+				int			r = row_of_tid(img.heaptids[(size_t) s * 10]);
+
+				EXPECT(r >= 0 && r < n && slot_of_row[r] == -1);
+				slot_of_row[r] = (int) s;
+			}
+			for (int64_t e = 0; e < ne; e++)
+			{
+				const int	r = live_row[ora_hnsw_element_row(g, e)];
+
+				if (slot_of_row[r] < 0)
+				{
+					fprintf(stderr, "the oracle's element %lld (heap row %d) is no element of the reference's pages\n", (long long) e, r);
+					return 1;
+				}
+				slot_of_element[e] = slot_of_row[r];
+			}
+			free(slot_of_row);
+		}
+		for (int64_t e = 0; e < ne; e++)
+		{
+			const int	s = slot_of_element[e];
+			const int	level = ora_hnsw_level(g, e);
+
+			if (img.levels[s] != level)
+			{
+				fprintf(stderr, "element %lld: level %d in the reference's pages, %d in the oracle's graph\n", (long long) e, img.levels[s], level);
+				return 1;
+			}
+			EXPECT(memcmp((const float *) img.vectors + (size_t) s * DIM, live + (size_t) ora_hnsw_element_row(g, e) * DIM, sizeof(float) * DIM) == 0);
+			for (int lc = level; lc >= 0; lc--)
+			{
+				int32_t		want[2 * HM];
+				const int	lm = lc == 0 ? 2 * m : m;
+				const int	nw = ora_hnsw_neighbors(g, e, lc, want);
+				const int32_t *have = img.nbr + img.nbr_start[s] + (int64_t) (level - lc) * m;
+
+				for (int i = 0; i < lm; i++)
+				{
+					const int	w = i < nw ? slot_of_element[want[i]] : -1;
+
+					if (have[i] != w)
+					{
+						fprintf(stderr, "element %lld layer %d slot %d: the reference's neighbor tuple has %d, the oracle's array %d\n",
+								(long long) e, lc, i, have[i], w);
+						return 1;
+					}
+				}
+			}
+		}
+		EXPECT(img.entry == slot_of_element[ora_hnsw_entry_point(g, &entry_level)]);
+		/* the duplicates' heap TIDs sit on the elements that took them */
+		{
+			int			on300 = 0,
+						rest = 0;
+
+			for (int64_t s = 0; s < img.n; s++)
+			{
+				const int	first = row_of_tid(img.heaptids[(size_t) s * 10]);
+
+				for (int t = 1; t < 10 && img.heaptids[(size_t) s * 10 + t] != UINT64_MAX; t++)
+				{
+					const int	dr = row_of_tid(img.heaptids[(size_t) s * 10 + t]);
+
+					EXPECT(memcmp(rows + (size_t) dr * DIM, rows + (size_t) first * DIM, sizeof(float) * DIM) == 0);
+					if (first == 300)
+						on300++;
+					else
+						rest++;
+				}
+			}
+			EXPECT(on300 == 9 && rest == 1);	/* rows 700-708 on row 300's element (ten heap TIDs: full), row 2000 on row 10's */
+		}
+		fprintf(stderr, "   the reference's serial hnswbuild (%d rows, %d NULL, m %d, ef_construction %d) = the oracle's graph: %lld elements, levels, every neighbor slot, the entry point (level %d), %u blocks\n",
+				n, n - nlive, m, efc, (long long) ne, entry_level, (unsigned) RelationGetNumberOfBlocks(index));
+		free(slot_of_element);
+		pgv_host_hnsw_image_free(&img);
+		ora_hnsw_free(g);
+	}
+
+	/* ---- (2) DROP + CREATE INDEX with vector.gpu = on */
+	shim_replace_pages(REL_HRBUILD, empty, 0);
+	shim_set_guc_bool("vector.gpu", true);
+	shim_seed_random(59);
+	for (int i = 0; i < 16; i++)
+		(void) RandomDouble();
+	ctx = shim_query_context_begin();
+	res = hnswbuild(heap, index, &info);
+	EXPECT(res != NULL && (int) res->heap_tuples == n && (int) res->index_tuples == nlive);
+	shim_query_context_end(ctx);
+	EXPECT(shim_pinned_buffers() == 0);
+	EXPECT(staged_hnsw_image(REL_HRBUILD, &img) == PGV_OK);
+	EXPECT(img.n > nlive - 20 && img.n < nlive && img.entry >= 0);
+	{
+		int64_t		links = 0;
+
+		for (int64_t s = 0; s < img.n; s++)
+			for (int64_t j = img.nbr_start[s]; j < img.nbr_start[s + 1]; j++)
+			{
+				EXPECT(img.nbr[j] >= -1 && img.nbr[j] < img.n && img.nbr[j] != s);
+				links += img.nbr[j] >= 0;
+			}
+		EXPECT(links > img.n * m);	/* a linked graph, not a list of lonely elements */
+	}
+	pgv_host_hnsw_image_free(&img);
+	{
+		double		until = shim_now() + 30.0;
+
+		for (;;)
+		{
+			(void) ref_hnsw_scan(index, rows, 1, gpu, &had_gpu, &reads);
+			if ((had_gpu && reads == 0) || shim_now() > until)
+				break;
+			usleep(20000);
+		}
+		EXPECT(had_gpu && reads == 0);
+	}
+	for (int i = 0; i < 30; i++)
+	{
+		const int	r = live_row[(83 * i + 9) % nlive];
+		const float *q = rows + (size_t) r * DIM;
+		int			nc,
+					ng;
+		int64_t		wrows[64];
+		double		wdist[64];
+
+		shim_set_guc_bool("vector.gpu", false);
+		nc = ref_hnsw_scan(index, q, 64, cpu, &had_gpu, &reads);
+		EXPECT(!had_gpu && reads > 0 && nc >= 40);
+		shim_set_guc_bool("vector.gpu", true);
+		ng = ref_hnsw_scan(index, q, 64, gpu, &had_gpu, &reads);
+		EXPECT(had_gpu && reads == 0);
+		for (int j = 0; j < nc; j++)
+		{
+			const int	row = row_of_tid(cpu[j]);
+			double		d = 0;
+
+			EXPECT(row >= 0 && row < n && !heap_row_is_null(&h, row));
+			for (int k = 0; k < DIM; k++)
+				d += ((double) rows[(size_t) row * DIM + k] - q[k]) * ((double) rows[(size_t) row * DIM + k] - q[k]);
+			wrows[j] = row;
+			wdist[j] = d;
+		}
+		EXPECT(wdist[0] == 0.0);	/* the row itself (or a copy of it) comes first */
+		if (check_hnsw_stream_n(rows, n, q, gpu, ng, wrows, wdist, nc, "the reference's hnswbuild with the hooks"))
+			return 1;
+	}
+	fprintf(stderr, "   the reference's hnswbuild with the hooks (every element deferred, linked on the device in FlushPages, pages by the reference): its walk and the device walk agree\n");
+
+	/* ---- (3) the graph outgrows maintenance_work_mem halfway through the heap scan: InsertTuple raises the NOTICE and calls
+	 * FlushPages there and then -- the hook links what was deferred so far, the reference writes those pages --, and every
+	 * later row goes through the reference's HnswInsertTupleOnDisk into them (src/hnswbuild.c:520-541) */
+	{
+		extern int	maintenance_work_mem;
+		const int	saved = maintenance_work_mem;
+		int			found = 0;
+
+		shim_replace_pages(REL_HRBUILD, empty, 0);
+		maintenance_work_mem = 768;	/* kB: room for about half of the elements */
+		shim_set_guc_bool("vector.gpu", true);
+		ctx = shim_query_context_begin();
+		res = hnswbuild(heap, index, &info);
+		maintenance_work_mem = saved;
+		EXPECT(res != NULL && (int) res->heap_tuples == n && (int) res->index_tuples == nlive);
+		shim_query_context_end(ctx);
+		EXPECT(shim_pinned_buffers() == 0);
+		EXPECT(staged_hnsw_image(REL_HRBUILD, &img) == PGV_OK);
+		EXPECT(img.n > nlive - 20 && img.n < nlive && img.entry >= 0);
+		pgv_host_hnsw_image_free(&img);
+		{
+			double		until = shim_now() + 30.0;
+
+			for (;;)
+			{
+				(void) ref_hnsw_scan(index, rows, 1, gpu, &had_gpu, &reads);
+				if ((had_gpu && reads == 0) || shim_now() > until)
+					break;
+				usleep(20000);
+			}
+			EXPECT(had_gpu && reads == 0);
+		}
+		for (int i = 0; i < 40; i++)
+		{
+			const int	r = live_row[(59 * i + 3) % nlive];	/* rows from before and after the flush */
+			const float *q = rows + (size_t) r * DIM;
+			int			nc,
+						ng;
+			int64_t		wrows[64];
+			double		wdist[64];
+
+			shim_set_guc_bool("vector.gpu", false);
+			nc = ref_hnsw_scan(index, q, 64, cpu, &had_gpu, &reads);
+			EXPECT(!had_gpu && reads > 0 && nc >= 40);
+			shim_set_guc_bool("vector.gpu", true);
+			ng = ref_hnsw_scan(index, q, 64, gpu, &had_gpu, &reads);
+			EXPECT(had_gpu && reads == 0);
+			for (int j = 0; j < nc; j++)
+			{
+				const int	row = row_of_tid(cpu[j]);
+				double		d = 0;
+
+				EXPECT(row >= 0 && row < n && !heap_row_is_null(&h, row));
+				for (int k = 0; k < DIM; k++)
+					d += ((double) rows[(size_t) row * DIM + k] - q[k]) * ((double) rows[(size_t) row * DIM + k] - q[k]);
+				wrows[j] = row;
+				wdist[j] = d;
+			}
+			found += wdist[0] == 0.0;
+			if (check_hnsw_stream_n(rows, n, q, gpu, ng, wrows, wdist, nc, "the reference's hnswbuild, flushed halfway"))
+				return 1;
+		}
+		EXPECT(found >= 39);	/* (an approximate index: a row may miss itself once in a while, not often) */
+		EXPECT(shim_notices_raised("hnsw graph no longer fits into maintenance_work_mem") == 1);
+		fprintf(stderr, "   maintenance_work_mem too small: the deferred half linked at the NOTICE's FlushPages, the rest through HnswInsertTupleOnDisk; %d of 40 rows found first for their own vector, both walks agree\n",
+				found);
+	}
+	free(rows);
+	free(live);
+	free(live_row);
+	return 0;
+}
+#endif							/* PGV_HAVE_REF_HNSWBUILD */
+
 int
 main(void)
 {
@@ -2709,7 +3375,7 @@ main(void)
 	setenv("MOCK_HIP_EXPORT_FAIL_EVERY", "9", 1);
 	board = mmap(NULL, sizeof(Board), PROT_READ | PROT_WRITE, MAP_SHARED | MAP_ANONYMOUS, -1, 0);
 	memset((void *) board, 0, sizeof(Board));
-	shim_postmaster_init((size_t) 384 << 20, mock_hip_set_arena ? (size_t) 512 << 20 : 0);
+	shim_postmaster_init((size_t) 512 << 20, mock_hip_set_arena ? (size_t) 512 << 20 : 0);
 	arena = shim_arena_base(&arena_bytes);
 	if (mock_hip_set_arena && arena)
 		mock_hip_set_arena(arena, arena_bytes);
@@ -2731,6 +3397,14 @@ main(void)
 #endif
 #ifdef PGV_HAVE_REF_HNSWINSERT
 	shim_create_relation(REL_HINS, &hnsw_l2, empty, 0, DIM);
+#endif
+#ifdef PGV_HAVE_REF_IVFBUILD
+	shim_create_relation(REL_RBUILD, &l2, empty, 0, DIM);
+	shim_set_reloptions(REL_RBUILD, 24, 0);	/* WITH (lists = 24) */
+#endif
+#ifdef PGV_HAVE_REF_HNSWBUILD
+	shim_create_relation(REL_HRBUILD, &hnsw_l2, empty, 0, DIM);
+	shim_set_reloptions(REL_HRBUILD, HM, 32);	/* WITH (m = 8, ef_construction = 32) */
 #endif
 
 	failed |= run_phase("CREATE INDEX through the build hooks", backend_build, 1, NULL, 300.0);
@@ -2814,6 +3488,14 @@ main(void)
 	}
 	if (!failed)
 		failed |= run_phase("the reference's own hnswinsert", backend_reference_hnsw_insert, 1, NULL, 300.0);
+#endif
+#ifdef PGV_HAVE_REF_IVFBUILD
+	if (!failed)
+		failed |= run_phase("the reference's own ivfflatbuild", backend_reference_ivfbuild, 1, NULL, 300.0);
+#endif
+#ifdef PGV_HAVE_REF_HNSWBUILD
+	if (!failed)
+		failed |= run_phase("the reference's own hnswbuild", backend_reference_hnswbuild, 1, NULL, 300.0);
 #endif
 	if (!failed && mock_hip_set_arena)
 		failed |= run_phase("a backend without a device", backend_no_device, 1, NULL, 120.0);

@@ -164,12 +164,7 @@ MemoryContextDelete(MemoryContext context)
 }
 
 /* ------------------------------------------------------------------------------------------------ tuple descriptors, slots */
-struct TupleDescData
-{
-	int			natts;
-	Oid			types[4];
-};
-
+/* (struct TupleDescData: pgshim_runtime.h -- the relations' descriptors of pgshim_runtime.c are the same thing) */
 TupleDesc
 CreateTemplateTupleDesc(int natts)
 {
@@ -183,9 +178,20 @@ void
 TupleDescInitEntry(TupleDesc desc, AttrNumber attributeNumber, const char *attributeName, Oid oidtypeid, int32 typmod, int attdim)
 {
 	(void) attributeName;
-	(void) typmod;
 	(void) attdim;
 	desc->types[attributeNumber - 1] = oidtypeid;
+	desc->typmods[attributeNumber - 1] = typmod;
+}
+
+/* access/tupdesc.h: pg_attribute row i of a descriptor, as far as the build's InitBuildState reads it (type, typmod) */
+Form_pg_attribute
+TupleDescAttr(TupleDesc tupdesc, int i)
+{
+	static FormData_pg_attribute att[4];
+
+	att[i].atttypid = tupdesc->types[i];
+	att[i].atttypmod = tupdesc->typmods[i];
+	return &att[i];
 }
 
 struct TupleTableSlotOps
@@ -227,17 +233,24 @@ slot_getattr(TupleTableSlot *slot, int attnum, bool *isnull)
 }
 
 /* ------------------------------------------------------------------------------------------------ tuplesort
- * the scan's sort (InitScanSortState, src/ivfscan.c:238-247): attribute 1 a float8 key ascending, attribute 2 a TID by
- * reference.  "Input data is always copied".  Equal keys keep their input order here (the server leaves it unspecified). */
+ * Two shapes.  The scan's sort (InitScanSortState, src/ivfscan.c:238-247): attribute 1 a float8 key ascending, attribute 2
+ * a TID by reference.  The build's sort (InitBuildSortState, src/ivfbuild.c:340-352): attribute 1 the int4 list number
+ * ascending, attribute 2 the heap TID, attribute 3 the vector (a varlena by reference).  "Input data is always copied":
+ * TID and vector are copied into the sort's own memory context (the one current at tuplesort_begin_heap -- the callers
+ * put tuples from inside per-row contexts they reset).  Equal keys keep their input order here (the server leaves it
+ * unspecified; for the build that is heap order inside a list, what a serial CREATE INDEX produces in practice). */
 typedef struct SortEntry
 {
 	double		key;
 	ItemPointerData tid;
+	void	   *value;			/* build shape: the copied varlena */
 	int64		seq;
 }			SortEntry;
 
 struct Tuplesortstate
 {
+	MemoryContext ctx;
+	bool		build_shape;
 	SortEntry  *e;
 	int64		n,
 				cap,
@@ -250,31 +263,50 @@ tuplesort_begin_heap(TupleDesc tupDesc, int nkeys, AttrNumber *attNums, Oid *sor
 {
 	Tuplesortstate *st = palloc0(sizeof(Tuplesortstate));
 
-	(void) tupDesc;
-	(void) attNums;
 	(void) sortCollations;
 	(void) nullsFirstFlags;
 	(void) workMem;
-	(void) coordinate;
 	(void) sortopt;
-	if (nkeys != 1 || sortOperators[0] != Float8LessOperator)
-		elog(ERROR, "stand-in tuplesort: float8 ascending on attribute 1 only");
+	if (coordinate != NULL)
+		elog(ERROR, "stand-in tuplesort: no parallel sorts");
+	if (nkeys != 1 || attNums[0] != 1 || (sortOperators[0] != Float8LessOperator && sortOperators[0] != Int4LessOperator))
+		elog(ERROR, "stand-in tuplesort: float8 or int4 ascending on attribute 1 only");
+	st->build_shape = sortOperators[0] == Int4LessOperator;
+	if (st->build_shape && (tupDesc->natts != 3 || tupDesc->types[0] != INT4OID || tupDesc->types[1] != TIDOID))
+		elog(ERROR, "stand-in tuplesort: the build's sort is (int4 list, tid, vector)");
+	st->ctx = CurrentMemoryContext;
 	return st;
 }
 
 void
 tuplesort_puttupleslot(Tuplesortstate *state, TupleTableSlot *slot)
 {
+	MemoryContext old = MemoryContextSwitchTo(state->ctx);
+
 	if (state->n == state->cap)
 	{
 		state->cap = state->cap ? state->cap * 2 : 1024;
 		state->e = state->e ? repalloc_huge(state->e, sizeof(SortEntry) * (Size) state->cap)
 			: palloc_extended(sizeof(SortEntry) * (Size) state->cap, MCXT_ALLOC_HUGE);
 	}
-	state->e[state->n].key = DatumGetFloat8(slot->tts_values[0]);
 	state->e[state->n].tid = *(ItemPointer) DatumGetPointer(slot->tts_values[1]);
 	state->e[state->n].seq = state->n;
+	if (state->build_shape)
+	{
+		const void *v = DatumGetPointer(slot->tts_values[2]);
+		Size		size = VARSIZE_ANY(v);
+
+		state->e[state->n].key = (double) DatumGetInt32(slot->tts_values[0]);
+		state->e[state->n].value = palloc(size);
+		memcpy(state->e[state->n].value, v, size);
+	}
+	else
+	{
+		state->e[state->n].key = DatumGetFloat8(slot->tts_values[0]);
+		state->e[state->n].value = NULL;
+	}
 	state->n++;
+	MemoryContextSwitchTo(old);
 }
 
 static int
@@ -310,17 +342,49 @@ tuplesort_gettupleslot(Tuplesortstate *state, bool forward, bool copy, TupleTabl
 	(void) abbrev;
 	if (state->pos >= state->n)
 		return false;
-	slot->tts_values[0] = Float8GetDatum(state->e[state->pos].key);
+	slot->tts_values[0] = state->build_shape ? Int32GetDatum((int32) state->e[state->pos].key) : Float8GetDatum(state->e[state->pos].key);
 	slot->tts_isnull[0] = false;
 	slot->tts_values[1] = PointerGetDatum(&state->e[state->pos].tid);
 	slot->tts_isnull[1] = false;
+	if (state->build_shape)
+	{
+		slot->tts_values[2] = PointerGetDatum(state->e[state->pos].value);
+		slot->tts_isnull[2] = false;
+	}
 	state->pos++;
 	return true;
+}
+
+/* test access: the tuples in the order they were put (seq), wherever the sort has moved them */
+int64_t
+shim_tuplesort_inputs(Tuplesortstate *state)
+{
+	return state->n;
+}
+
+void
+shim_tuplesort_input(Tuplesortstate *state, int64_t i, int32_t *list, ItemPointerData *tid, const void **value)
+{
+	const SortEntry *e = NULL;
+
+	if (i >= 0 && i < state->n && state->e[i].seq == i)
+		e = &state->e[i];		/* not sorted yet (or left in place) */
+	for (int64 j = 0; e == NULL && j < state->n; j++)
+		if (state->e[j].seq == i)
+			e = &state->e[j];
+	if (e == NULL)
+		elog(ERROR, "stand-in tuplesort: no input tuple " INT64_FORMAT, (int64) i);
+	*list = (int32_t) e->key;
+	*tid = e->tid;
+	*value = e->value;
 }
 
 void
 tuplesort_reset(Tuplesortstate *state)
 {
+	for (int64 i = 0; i < state->n; i++)
+		if (state->e[i].value)
+			pfree(state->e[i].value);
 	state->n = 0;
 	state->pos = 0;
 }
@@ -328,6 +392,7 @@ tuplesort_reset(Tuplesortstate *state)
 void
 tuplesort_end(Tuplesortstate *state)
 {
+	tuplesort_reset(state);
 	if (state->e)
 		pfree(state->e);
 	state->e = NULL;
@@ -1007,3 +1072,374 @@ datumIsEqual(Datum value1, Datum value2, bool typByVal, int typLen)
 	return s1 == s2 && memcmp(DatumGetPointer(value1), DatumGetPointer(value2), s1) == 0;
 }
 #endif							/* PGV_HAVE_REF_HNSWINSERT */
+
+#if defined(PGV_HAVE_REF_IVFBUILD) || defined(PGV_HAVE_REF_HNSWBUILD)
+/* ------------------------------------------------------------------------------------------------ for src/ivfbuild.c + src/hnswbuild.c
+ * (the reference's own ivfflatbuild / hnswbuild: CREATE INDEX from the first sample to the last page.)  What a SERIAL
+ * build reaches of the server and the files above do not have: the table it scans (a stand-in heap the test defines:
+ * rows, NULLs, toasted values, TIDs), ANALYZE's block and reservoir samplers, the progress counters, spinlocks and lock
+ * initialisation.  plan_create_index_workers answers 0 -- no parallel workers in this program --, so everything behind
+ * IvfflatBeginParallel / HnswBeginParallel only has to LINK: those stand-ins raise an ERROR if they are ever reached. */
+static ShimHeapDef heap_def;
+static struct RelationData heap_rel;
+static struct TupleDescData heap_desc;
+extern BlockNumber (*shim_heap_blocks_hook) (void);
+
+static BlockNumber
+heap_blocks(void)
+{
+	return (BlockNumber) ((heap_def.nrows + heap_def.rows_per_block - 1) / heap_def.rows_per_block);
+}
+
+Relation
+shim_heap_relation(const ShimHeapDef * def)
+{
+	heap_def = *def;
+	memset(&heap_rel, 0, sizeof(heap_rel));
+	heap_rel.rd_id = SHIM_HEAP_OID;
+	heap_desc.natts = 1;
+	heap_desc.types[0] = SHIM_VECTOR_TYPE_OID;
+	heap_desc.typmods[0] = -1;
+	heap_rel.rd_att = &heap_desc;
+	shim_heap_blocks_hook = heap_blocks;
+	return &heap_rel;
+}
+
+/* heapam_index_build_range_scan (access/heap/heapam_handler.c) as far as an index build sees it: blocks [start, start +
+ * numblocks) in physical order, every live row handed to the callback -- NULLs too, the access method skips them --, the
+ * column value living in a per-tuple context that is reset before the next row; the return value is the number of live
+ * rows scanned */
+double
+table_index_build_range_scan(Relation table_rel, Relation index_rel, IndexInfo *index_info, bool allow_sync, bool anyvisible,
+							 bool progress, BlockNumber start_blockno, BlockNumber numblocks, IndexBuildCallback callback,
+							 void *callback_state, TableScanDesc scan)
+{
+	MemoryContext per_tuple;
+	int64		first = (int64) start_blockno * heap_def.rows_per_block;
+	int64		end = numblocks == InvalidBlockNumber ? heap_def.nrows : (int64) (start_blockno + numblocks) * heap_def.rows_per_block;
+	double		reltuples = 0;
+
+	(void) index_info;
+	(void) allow_sync;
+	(void) anyvisible;
+	(void) progress;
+	if (table_rel != &heap_rel || scan != NULL)
+		elog(ERROR, "stand-in heap: one table, serial scans");
+	if (end > heap_def.nrows)
+		end = heap_def.nrows;
+	per_tuple = AllocSetContextCreate(CurrentMemoryContext, "index build per-tuple", 0, 0, 0);
+	for (int64 row = first; row < end; row++)
+	{
+		MemoryContext old = MemoryContextSwitchTo(per_tuple);
+		Datum		values[1];
+		bool		isnull[1];
+		ItemPointerData tid;
+
+		CHECK_FOR_INTERRUPTS();
+		heap_def.fetch(row, &values[0], &isnull[0], &tid, heap_def.arg);
+		MemoryContextSwitchTo(old);
+		callback(index_rel, &tid, values, isnull, true, callback_state);
+		reltuples += 1;
+		MemoryContextReset(per_tuple);
+	}
+	MemoryContextDelete(per_tuple);
+	return reltuples;
+}
+
+double
+table_index_build_scan(Relation table_rel, Relation index_rel, IndexInfo *index_info, bool allow_sync, bool progress,
+					   IndexBuildCallback callback, void *callback_state, TableScanDesc scan)
+{
+	return table_index_build_range_scan(table_rel, index_rel, index_info, allow_sync, false, progress, 0, InvalidBlockNumber,
+										callback, callback_state, scan);
+}
+
+/* utils/misc/sampling.c.  The block sampler is Knuth's Algorithm S (choose n of N blocks in order, each subset equally
+ * likely); the row reservoir is Vitter's: the server switches from his Algorithm X to Z once t > 22 n, here X serves
+ * throughout -- the same distribution, more draws.  Each sampler owns its generator (pg_prng_state inside the struct,
+ * seeded from the global stream), as in the server. */
+double
+sampler_random_fract(pg_prng_state *randstate)
+{
+	double		r;
+
+	do
+		r = pg_prng_double(randstate);
+	while (r == 0.0);			/* (0, 1) */
+	return r;
+}
+
+BlockNumber
+BlockSampler_Init(BlockSampler bs, BlockNumber nblocks, int samplesize, uint32 randseed)
+{
+	bs->N = nblocks;
+	bs->n = samplesize;
+	bs->t = 0;
+	bs->m = 0;
+	pg_prng_seed(&bs->randstate, (uint64) randseed);
+	return (BlockNumber) bs->n < bs->N ? (BlockNumber) bs->n : bs->N;
+}
+
+bool
+BlockSampler_HasMore(BlockSampler bs)
+{
+	return bs->t < bs->N && bs->m < bs->n;
+}
+
+BlockNumber
+BlockSampler_Next(BlockSampler bs)
+{
+	BlockNumber left = bs->N - bs->t;	/* blocks not looked at yet */
+	int			want = bs->n - bs->m;	/* blocks still to choose */
+
+	if ((BlockNumber) want < left)
+	{
+		/* skip blocks while the draw says "not this one": block t is taken with probability want / left */
+		double		v = sampler_random_fract(&bs->randstate);
+		double		skip = 1.0 - (double) want / (double) left;
+
+		while (v < skip)
+		{
+			bs->t++;
+			left--;
+			skip *= 1.0 - (double) want / (double) left;
+		}
+	}
+	/* (want >= left: every remaining block is needed, no draw) */
+	bs->m++;
+	return bs->t++;
+}
+
+void
+reservoir_init_selection_state(ReservoirState rs, int n)
+{
+	pg_prng_seed(&rs->randstate, (uint64) pg_prng_uint32(&pg_global_prng_state));
+	rs->W = exp(-log(sampler_random_fract(&rs->randstate)) / n);	/* (Algorithm Z's state: drawn, never used here) */
+}
+
+/* how many of the rows after the t-th to pass over before one replaces a reservoir slot */
+double
+reservoir_get_next_S(ReservoirState rs, double t, int n)
+{
+	double		v = sampler_random_fract(&rs->randstate);
+	double		s = 0;
+	double		q;
+
+	t += 1;
+	q = (t - (double) n) / t;
+	while (q > v)
+	{
+		s += 1;
+		t += 1;
+		q *= (t - (double) n) / t;
+	}
+	return s;
+}
+
+/* ---- locks of a single process, counters, the WAL that is not written */
+void
+SpinLockInit(volatile slock_t *lock)
+{
+	*lock = 0;
+}
+
+void
+SpinLockAcquire(volatile slock_t *lock)
+{
+	while (__atomic_exchange_n(lock, 1, __ATOMIC_ACQUIRE))
+		;
+}
+
+void
+SpinLockRelease(volatile slock_t *lock)
+{
+	__atomic_store_n(lock, 0, __ATOMIC_RELEASE);
+}
+
+void
+LWLockInitialize(LWLock *lock, int tranche_id)
+{
+	lock->tranche = (uint16) tranche_id;
+	lock->state = 0;
+}
+
+int			hnsw_lock_tranche_id = 0;	/* src/hnsw.c:31 (the handler file is not in the program) */
+
+void
+HnswInitLockTranche(void)
+{
+	hnsw_lock_tranche_id = 77;	/* src/hnsw.c:36-50 registers a named tranche in shared memory */
+}
+
+static int64 progress_params[32];
+
+void
+pgstat_progress_update_param(int index, int64 val)
+{
+	if (index >= 0 && index < 32)
+		progress_params[index] = val;
+}
+
+int64_t
+shim_progress_param(int index)
+{
+	return progress_params[index];
+}
+
+void
+pgstat_report_activity(BackendState state, const char *cmd_str)
+{
+	(void) state;
+	(void) cmd_str;
+}
+
+void
+log_newpage_range(Relation rel, ForkNumber forknum, BlockNumber startblk, BlockNumber endblk, bool page_std)
+{
+	(void) rel;
+	(void) forknum;
+	(void) startblk;
+	(void) endblk;
+	(void) page_std;
+}
+
+BlockNumber
+RelationGetNumberOfBlocksInFork(Relation relation, ForkNumber forkNum)
+{
+	(void) forkNum;
+	return RelationGetNumberOfBlocks(relation);
+}
+
+bool
+RelationNeedsWAL(Relation relation)
+{
+	(void) relation;
+	return true;
+}
+
+IndexInfo *
+BuildIndexInfo(Relation index)
+{
+	(void) index;
+	return palloc0(sizeof(IndexInfo));
+}
+
+/* ---- parallel CREATE INDEX: planned away.  optimizer/plan/planner.c would look at the table's size and
+ * max_parallel_maintenance_workers; this program has no worker processes to launch. */
+int			max_parallel_maintenance_workers = 2;
+const char *debug_query_string = NULL;
+struct SnapshotData
+{
+	int			unused;
+}			SnapshotAnyData;
+
+int
+plan_create_index_workers(Oid tableOid, Oid indexOid)
+{
+	(void) tableOid;
+	(void) indexOid;
+	return 0;
+}
+
+int
+RelationGetParallelWorkers(Relation relation, int defaultpw)
+{
+	(void) relation;
+	return defaultpw;
+}
+
+static void
+no_parallel(const char *what)
+{
+	elog(ERROR, "stand-in server: %s reached, but no parallel build was planned", what);
+}
+
+#define NO_PARALLEL_VOID(name, args) void name args { no_parallel(#name); }
+NO_PARALLEL_VOID(EnterParallelMode, (void))
+NO_PARALLEL_VOID(ExitParallelMode, (void))
+NO_PARALLEL_VOID(InitializeParallelDSM, (ParallelContext *pcxt))
+NO_PARALLEL_VOID(LaunchParallelWorkers, (ParallelContext *pcxt))
+NO_PARALLEL_VOID(WaitForParallelWorkersToAttach, (ParallelContext *pcxt))
+NO_PARALLEL_VOID(WaitForParallelWorkersToFinish, (ParallelContext *pcxt))
+NO_PARALLEL_VOID(DestroyParallelContext, (ParallelContext *pcxt))
+NO_PARALLEL_VOID(ConditionVariableInit, (ConditionVariable *cv))
+NO_PARALLEL_VOID(ConditionVariableSleep, (ConditionVariable *cv, uint32 wait_event_info))
+NO_PARALLEL_VOID(ConditionVariableCancelSleep, (void))
+NO_PARALLEL_VOID(ConditionVariableSignal, (ConditionVariable *cv))
+NO_PARALLEL_VOID(shm_toc_insert, (shm_toc *toc, uint64 key, void *address))
+NO_PARALLEL_VOID(tuplesort_initialize_shared, (Sharedsort *shared, int nWorkers, struct dsm_segment *seg))
+NO_PARALLEL_VOID(tuplesort_attach_shared, (Sharedsort *shared, struct dsm_segment *seg))
+NO_PARALLEL_VOID(table_parallelscan_initialize, (Relation rel, ParallelTableScanDesc pscan, Snapshot snapshot))
+NO_PARALLEL_VOID(table_close, (Relation relation, LOCKMODE lockmode))
+NO_PARALLEL_VOID(UnregisterSnapshot, (Snapshot snapshot))
+
+ParallelContext *
+CreateParallelContext(const char *library_name, const char *function_name, int nworkers)
+{
+	no_parallel("CreateParallelContext");
+	return NULL;
+}
+
+void *
+shm_toc_allocate(shm_toc *toc, Size nbytes)
+{
+	no_parallel("shm_toc_allocate");
+	return NULL;
+}
+
+void *
+shm_toc_lookup(shm_toc *toc, uint64 key, bool noError)
+{
+	no_parallel("shm_toc_lookup");
+	return NULL;
+}
+
+Size
+tuplesort_estimate_shared(int nWorkers)
+{
+	no_parallel("tuplesort_estimate_shared");
+	return 0;
+}
+
+Size
+table_parallelscan_estimate(Relation rel, Snapshot snapshot)
+{
+	no_parallel("table_parallelscan_estimate");
+	return 0;
+}
+
+TableScanDesc
+table_beginscan_parallel(Relation relation, ParallelTableScanDesc pscan)
+{
+	no_parallel("table_beginscan_parallel");
+	return NULL;
+}
+
+Relation
+table_open(Oid relationId, LOCKMODE lockmode)
+{
+	no_parallel("table_open");
+	return NULL;
+}
+
+Relation
+index_open(Oid relationId, LOCKMODE lockmode)
+{
+	no_parallel("index_open");
+	return NULL;
+}
+
+Snapshot
+GetTransactionSnapshot(void)
+{
+	no_parallel("GetTransactionSnapshot");
+	return NULL;
+}
+
+Snapshot
+RegisterSnapshot(Snapshot snapshot)
+{
+	no_parallel("RegisterSnapshot");
+	return NULL;
+}
+#endif							/* PGV_HAVE_REF_IVFBUILD || PGV_HAVE_REF_HNSWBUILD */

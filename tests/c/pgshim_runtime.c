@@ -51,6 +51,7 @@ typedef struct ShimRel
 	uint32		nblocks;
 	uint32		cap_blocks;
 	uint32		lock;			/* readers count | 0x80000000 writer */
+	int			reloptions[2];	/* lists | m, ef_construction (0: the access method's default) */
 }			ShimRel;
 
 typedef struct ShimBgw
@@ -376,6 +377,30 @@ pgshim_errmsg(const char *fmt,...)
 	return 0;
 }
 
+/* errdetail / errhint of the reference's ereport calls: checked for their format, not kept (the primary message is what
+ * shim_last_error and shim_notices_raised report) */
+int
+pgshim_errmore(const char *fmt,...)
+{
+	(void) fmt;
+	return 0;
+}
+
+/* the last messages below ERROR, for tests that expect a NOTICE or a WARNING */
+#define SHIM_NOTICE_RING 32
+static char notice_ring[SHIM_NOTICE_RING][160];
+static int	notices_total = 0;
+
+int
+shim_notices_raised(const char *prefix)
+{
+	int			n = 0;
+
+	for (int i = 0; i < (notices_total < SHIM_NOTICE_RING ? notices_total : SHIM_NOTICE_RING); i++)
+		n += strncmp(notice_ring[i], prefix, strlen(prefix)) == 0;
+	return n;
+}
+
 static void throw_error(void) __attribute__((noreturn));
 static void
 throw_error(void)
@@ -393,7 +418,8 @@ pgshim_ereport(int level, int dummy)
 	pending_level(level);
 	if (level >= ERROR)
 		throw_error();
-	fprintf(stderr, "%s:  %s\n", level == WARNING ? "WARNING" : "LOG", last_error);
+	snprintf(notice_ring[notices_total++ % SHIM_NOTICE_RING], sizeof(notice_ring[0]), "%.159s", last_error);
+	fprintf(stderr, "%s:  %s\n", level == WARNING ? "WARNING" : (level == 18 ? "NOTICE" : "LOG"), last_error);
 }
 
 void
@@ -767,12 +793,17 @@ float8_as_datum(double x)
 }
 
 /* ------------------------------------------------------------------------------------------------ the catalog */
-struct TupleDescData
-{
-	int			natts;
-};
-static struct TupleDescData one_column = {1};
+static struct TupleDescData rel_descs[SHIM_MAX_RELS];
 static struct RelationData rel_objs[SHIM_MAX_RELS];
+/* IvfflatOptions / HnswOptions (src/ivfflat.h:138-142, src/hnsw.h:225-230): a varlena header and the ints behind it */
+static struct
+{
+	int32		vl_len_;
+	int			a,
+				b;
+}			rel_options[SHIM_MAX_RELS];
+/* (reference-linked builds) the heap stand-in of pgshim_ref_runtime.c answers for its own relation */
+BlockNumber (*shim_heap_blocks_hook) (void) = NULL;
 
 static void
 spin_lock(uint32 *w)
@@ -871,6 +902,7 @@ shim_create_relation(Oid oid, const ShimOpclass * opclass, const void *pages, ui
 	r->cap_blocks = cap;
 	r->nblocks = nblocks;
 	r->lock = 0;
+	r->reloptions[0] = r->reloptions[1] = 0;
 	memcpy(Sbase + r->pages_off, pages, (size_t) nblocks * SHIM_BLCKSZ);
 	__atomic_store_n(&r->oid, oid, __ATOMIC_RELEASE);
 	spin_unlock(&S->catalog_lock);
@@ -921,13 +953,39 @@ shim_open_relation(Oid oid)
 	if (r == NULL)
 		return NULL;
 	rel_objs[r - S->rels].rd_id = oid;
-	rel_objs[r - S->rels].rd_att = &one_column;
+	rel_descs[r - S->rels].natts = 1;
+	rel_descs[r - S->rels].types[0] = SHIM_VECTOR_TYPE_OID;
+	rel_descs[r - S->rels].typmods[0] = r->dimensions;
+	rel_objs[r - S->rels].rd_att = &rel_descs[r - S->rels];
+	if (r->reloptions[0] != 0)
+	{
+		/* WITH (lists = ..) / WITH (m = .., ef_construction = ..); rd_options stays NULL for the defaults */
+		rel_options[r - S->rels].a = r->reloptions[0];
+		rel_options[r - S->rels].b = r->reloptions[1];
+		rel_objs[r - S->rels].rd_options = (struct varlena *) &rel_options[r - S->rels];
+	}
+	else
+		rel_objs[r - S->rels].rd_options = NULL;
 	{
 		static Oid	no_collation[1] = {InvalidOid};
 
 		rel_objs[r - S->rels].rd_indcollation = no_collation;	/* (the reference's beginscan reads rd_indcollation[0]) */
 	}
 	return &rel_objs[r - S->rels];
+}
+
+void
+shim_set_reloptions(Oid oid, int a, int b)
+{
+	ShimRel    *r = find_rel(oid);
+
+	if (r == NULL)
+	{
+		fprintf(stderr, "pgshim: shim_set_reloptions: unknown relation\n");
+		abort();
+	}
+	r->reloptions[0] = a;
+	r->reloptions[1] = b;
 }
 
 static ShimRel *
@@ -1068,12 +1126,25 @@ pin_index(Buffer buffer)
 	abort();
 }
 
+#ifndef BUFFER_LOCK_UNLOCK
+#define BUFFER_LOCK_UNLOCK 0	/* storage/bufmgr.h */
+#endif
+
 void
 LockBuffer(Buffer buffer, int mode)
 {
 	int			i = pin_index(buffer);
 
-	(void) mode;
+	if (mode == BUFFER_LOCK_UNLOCK)
+	{
+		/* (src/hnswbuild.c:138: a fresh page is unlocked and locked again before it is filled) */
+		if (pins[i].locked)
+			rel_unlock_shared(&S->rels[BUF_REL(buffer)]);
+		pins[i].locked = false;
+		return;
+	}
+	if (pins[i].locked)
+		return;					/* (shared and exclusive are one lock here) */
 	rel_lock_shared(&S->rels[BUF_REL(buffer)]);
 	pins[i].locked = true;
 }
@@ -1119,6 +1190,8 @@ BufferGetBlockNumber(Buffer buffer)
 BlockNumber
 RelationGetNumberOfBlocks(Relation reln)
 {
+	if (reln->rd_id == SHIM_HEAP_OID && shim_heap_blocks_hook)
+		return shim_heap_blocks_hook();
 	return __atomic_load_n(&rel_of(reln)->nblocks, __ATOMIC_ACQUIRE);
 }
 
@@ -1904,10 +1977,32 @@ shim_prng_hook(double (*next_double) (void *), uint32_t (*next_u32) (void *), vo
 	prng_hook_state = state;
 }
 
+/* a generator of the caller's own (utils/sampling.h keeps one per BlockSampler / reservoir): a stream apart from the
+ * global one, like the server's -- xorshift128+ over the state words, nothing the tests pin */
+static uint64
+private_next(pg_prng_state *state)
+{
+	uint64		a = state->s0,
+				b = state->s1;
+
+	state->s0 = b;
+	a ^= a << 23;
+	state->s1 = a ^ b ^ (a >> 17) ^ (b >> 26);
+	return state->s1 + b;
+}
+
+void
+pg_prng_seed(pg_prng_state *state, uint64 seed)
+{
+	state->s0 = seed * 0x9E3779B97F4A7C15ull + 0x632BE59BD9B4E019ull;
+	state->s1 = (seed ^ 0xD1B54A32D192ED03ull) * 0xBF58476D1CE4E5B9ull + 1;
+}
+
 double
 pg_prng_double(pg_prng_state *state)
 {
-	(void) state;
+	if (state != &pg_global_prng_state)
+		return (double) (private_next(state) >> 11) / 9007199254740992.0;
 	if (prng_double_hook)
 		return prng_double_hook(prng_hook_state);
 	return (double) (rng_next() >> 11) / 9007199254740992.0;
@@ -1916,7 +2011,8 @@ pg_prng_double(pg_prng_state *state)
 uint32
 pg_prng_uint32(pg_prng_state *state)
 {
-	(void) state;
+	if (state != &pg_global_prng_state)
+		return (uint32) (private_next(state) >> 32);
 	if (prng_u32_hook)
 		return prng_u32_hook(prng_hook_state);
 	return (uint32) (rng_next() >> 32);

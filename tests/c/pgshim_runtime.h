@@ -58,11 +58,46 @@ void		shim_broadcast_relcache_invalidate(Oid relid);
 /* every ReadBufferExtended of a background worker sleeps this long: staging a cold, large index takes seconds */
 void		shim_set_bgworker_read_delay_us(uint32_t us);
 
+/* reloptions of an index relation: lists (ivfflat) / m, ef_construction (hnsw); 0 = the access method's default.  What
+ * the reference's IvfflatGetLists / HnswGetM / HnswGetEfConstruction read through rd_options. */
+void		shim_set_reloptions(Oid oid, int a, int b);
+/* the tuple descriptor of this runtime: one entry per column (index relations: the indexed column, typmod = dimensions) */
+struct TupleDescData
+{
+	int			natts;
+	Oid			types[4];
+	int32_t		typmods[4];
+};
+#define SHIM_VECTOR_TYPE_OID 16385	/* "vector" got some OID at CREATE EXTENSION: anything that is not a built-in type's */
+
+/* ---- the table under CREATE INDEX (reference-linked builds only: pgshim_ref_runtime.c) ----
+ * A heap of `nrows` rows, `rows_per_block` to a block; fetch() hands out row r's column value (palloc'd in the current
+ * context, toasted or NULL as the test likes) and its TID.  table_index_build_scan / table_index_build_range_scan walk
+ * it and call the access method's IndexBuildCallback the way heapam_index_build_range_scan does: every live row, NULLs
+ * included, a per-tuple context reset in between. */
+typedef struct ShimHeapDef
+{
+	int64_t		nrows;
+	int			rows_per_block;
+	void		(*fetch) (int64_t row, Datum *value, bool *isnull, ItemPointerData *tid, void *arg);
+	void	   *arg;
+}			ShimHeapDef;
+#define SHIM_HEAP_OID 999
+Relation	shim_heap_relation(const ShimHeapDef * def);
+/* input tuple i of a build's tuplesort (before or after tuplesort_performsort: the order they were put in) */
+struct Tuplesortstate;
+int64_t		shim_tuplesort_inputs(struct Tuplesortstate *state);
+void		shim_tuplesort_input(struct Tuplesortstate *state, int64_t i, int32_t *list, ItemPointerData *tid, const void **value);
+
+int64_t		shim_progress_param(int index);	/* the last pgstat_progress_update_param value of a counter */
+
 /* ---- per-process ---- */
 /* run fn(arg) with a top-level handler: an ERROR that no PG_TRY caught aborts the "transaction" (buffer pins released,
  * the query context reset -- reset callbacks fire) and makes this return -1 with the message in shim_last_error() */
 int			shim_run_toplevel(int (*fn) (void *), void *arg, int *result);
 const char *shim_last_error(void);
+/* messages below ERROR (NOTICE, WARNING, LOG) this process raised so far whose text starts with `prefix` (the last 32 are kept) */
+int			shim_notices_raised(const char *prefix);
 /* a fresh child of TopMemoryContext made current (what the executor's per-query context is to ivfflatbeginscan) */
 MemoryContext shim_query_context_begin(void);
 void		shim_query_context_end(MemoryContext ctx);	/* reset (callbacks fire) + delete, CurrentMemoryContext = Top */

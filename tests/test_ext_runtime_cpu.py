@@ -95,7 +95,20 @@ def test_the_references_own_ivfflatgettuple_runs_with_the_hooks(tmp_path, saniti
     laid out (element + neighbor tuples added, neighbors' tuples overwritten, pages appended); its src/hnswvacuum.c then
     removes every fourth row (RemoveHeapTids, RepairGraph, MarkDeleted).  After each, the reference's walk of the pages and
     the device walk over the mirror the worker restaged (the product's stager over the reference's tuples) return the same
-    streams; a duplicate's heap TID comes back beside the original's; no dead row comes back."""
+    streams; a duplicate's heap TID comes back beside the original's; no dead row comes back.
+
+    And CREATE INDEX itself (-DPGV_HAVE_REF_IVFBUILD / _HNSWBUILD): the reference's patched src/ivfbuild.c and src/hnswbuild.c
+    -- all twelve files the patch touches or the path needs are now in the program.  ivfflatbuild() and hnswbuild() run
+    over a stand-in heap (6000 / 2500 rows, some NULL, some toasted): SampleRows, IvfflatKmeans, the heap scan through
+    BuildCallback, the build's tuplesort, InsertTuples / the in-memory graph, FlushPages -- every page is written by the
+    reference.  With vector.gpu off and the oracle's pg_prng stream, the reference's WHOLE serial build equals the
+    oracle's restatement of it: ivfflat -- the centers in the list pages bit for bit (ora_kmeans), every list's tuples in
+    order (ora_ivf_assign: AddTupleToSort's argmin, a12); hnsw -- every element's level, every neighbor slot of every
+    layer, the duplicates' heap TIDs and the entry point (ora_hnsw_build: the graph C4's tests are built with).  With
+    vector.gpu on the hook lines INSIDE the reference's build serve k-means and every argmin (ivfflat) and link every
+    deferred element in FlushPages (hnsw); the reference sorts and writes, and its scan / walk, the oracle's page reader and
+    the device over the mirror the worker stages agree.  A third hnsw build with maintenance_work_mem too small takes the
+    NOTICE's FlushPages halfway through the heap scan and HnswInsertTupleOnDisk for the rest."""
     import __graft_entry__ as entry     # ONE recipe: the program the GPU box runs is built by the same function
     flags = ["-fsanitize=address,undefined", "-fno-omit-frame-pointer"] if sanitize else []
     exe = entry.build_reference_driver(dict(os.environ), out=str(tmp_path / "ext_driver_ref"), mock=True, extra_flags=flags)
@@ -107,8 +120,13 @@ def test_the_references_own_ivfflatgettuple_runs_with_the_hooks(tmp_path, saniti
     assert any("the reference's own ivfflatgettuple" in line and ": ok" in line for line in r.stderr.splitlines()), r.stderr[-3000:]
     assert any("the reference's own hnswgettuple" in line and ": ok" in line for line in r.stderr.splitlines()), r.stderr[-3000:]
     assert any("the reference's own IvfflatKmeans" in line and ": ok" in line for line in r.stderr.splitlines()), r.stderr[-3000:]
-    assert r.stderr.count("bit for bit") == 5, r.stderr[-3000:]
+    assert r.stderr.count("bit for bit") == 6, r.stderr[-3000:]
     assert any("the reference's own ivfflatinsert" in line and ": ok" in line for line in r.stderr.splitlines()), r.stderr[-3000:]
     assert "removed by the reference's ivfflatbulkdelete" in r.stderr, r.stderr[-3000:]
     assert any("the reference's own hnswinsert" in line and ": ok" in line for line in r.stderr.splitlines()), r.stderr[-3000:]
     assert "removed by the reference's hnswbulkdelete" in r.stderr, r.stderr[-3000:]
+    assert any("the reference's own ivfflatbuild" in line and ": ok" in line for line in r.stderr.splitlines()), r.stderr[-3000:]
+    assert "= the oracle's build: centers bit for bit, every list's tuples in order" in r.stderr, r.stderr[-3000:]
+    assert any("the reference's own hnswbuild" in line and ": ok" in line for line in r.stderr.splitlines()), r.stderr[-3000:]
+    assert "= the oracle's graph" in r.stderr and "levels, every neighbor slot, the entry point" in r.stderr, r.stderr[-3000:]
+    assert "NOTICE:  hnsw graph no longer fits into maintenance_work_mem" in r.stderr, r.stderr[-3000:]

@@ -36,7 +36,10 @@ def test_the_references_own_gettuple_functions_drive_the_hooks_on_the_gpu():
     src/hnswutils.c and src/vector.c linked in, against libpgv_hip.so.  Its phase "the
     reference's own ivfflatgettuple": the reference's scan code over the emulated pages = the oracle (vector.gpu off), and
     the hook lines inside ivfflatbeginscan / rescan / gettuple / endscan serving own-context, pooled and iterative scans
-    from the real device (vector.gpu on)."""
+    from the real device (vector.gpu on).  Since round 5 the program also holds the reference's patched src/ivfinsert.c,
+    src/ivfvacuum.c, src/hnswinsert.c, src/hnswvacuum.c, src/ivfbuild.c and src/hnswbuild.c: ivfflatbuild() and hnswbuild()
+    themselves run CREATE INDEX over a stand-in heap with k-means, every argmin and the graph linking served by the device
+    through the hook lines inside them (the CPU-side equalities with the oracle are tests/test_ext_runtime_cpu.py's)."""
     env = dict(os.environ)
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     r = subprocess.run([REF_DRIVER], capture_output=True, text=True, timeout=900, env=env)
@@ -52,3 +55,7 @@ def test_the_references_own_gettuple_functions_drive_the_hooks_on_the_gpu():
     assert "removed by the reference's ivfflatbulkdelete" in r.stderr, r.stderr[-3000:]
     assert any("the reference's own hnswinsert" in line and ": ok" in line for line in r.stderr.splitlines()), r.stderr[-3000:]
     assert "removed by the reference's hnswbulkdelete" in r.stderr, r.stderr[-3000:]
+    assert any("the reference's own ivfflatbuild" in line and ": ok" in line for line in r.stderr.splitlines()), r.stderr[-3000:]
+    assert "argmins from the device, pages by the reference" in r.stderr, r.stderr[-3000:]
+    assert any("the reference's own hnswbuild" in line and ": ok" in line for line in r.stderr.splitlines()), r.stderr[-3000:]
+    assert "linked on the device in FlushPages, pages by the reference" in r.stderr, r.stderr[-3000:]
