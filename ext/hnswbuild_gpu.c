@@ -105,6 +105,7 @@ PgvHnswBuildDefer(HnswBuildState * buildstate, HnswElement element)
 	if (buildstate->hnswarea != NULL)
 	{
 		/* set after InitBuildState by HnswParallelScanAndInsert (src/hnswbuild.c:803-805): a parallel build */
+		ereport(DEBUG1, (errmsg("pgvector GPU path: parallel hnsw build, this participant inserts on the CPU path")));
 		pfree(gb);
 		buildstate->gpu = NULL;
 		return false;
@@ -241,6 +242,8 @@ PgvHnswBuildLink(HnswBuildState * buildstate)
 	}
 	if (built.entry >= 0)
 		HnswPtrStore(base, graph->entryPoint, gb->elements[built.entry]);
+	ereport(DEBUG1, (errmsg("pgvector GPU path: " INT64_FORMAT " deferred elements linked on the device (" INT64_FORMAT " batches)", n,
+							(int64) built.batches)));
 	pgv_host_hnsw_built_free(&built);
 	/* the list is about to be written out and graphCtx reset with it: nothing is deferred any more */
 	gb->elements = NULL;

@@ -129,6 +129,8 @@ PgvIvfflatBuildFlush(IvfflatBuildState * buildstate)
 	if (pgv_assign(PgvGetContext(), gb->metric, gb->dtype, buildstate->dimensions, gb->centers, buildstate->lists,
 				   gb->rows, gb->count, gb->lists, NULL) != PGV_OK)
 		ereport(ERROR, (errmsg("pgvector GPU path: %s", pgv_last_error())));
+	/* (beside the reference's own "leader / worker processed N tuples": every participant of a parallel build flushes its own) */
+	ereport(DEBUG1, (errmsg("pgvector GPU path: %d rows assigned on the device", gb->count)));
 	for (int i = 0; i < gb->count; i++)
 	{
 		/* The caller's Datum is gone by now: BuildCallback detoasts and normalises inside buildstate->tmpCtx and

@@ -51,6 +51,7 @@ struct varlena
 struct varlena *pg_detoast_datum(struct varlena *datum);
 
 /* utils/elog.h */
+#define DEBUG1 14
 #define LOG 15
 #define WARNING 19
 #define ERROR 21

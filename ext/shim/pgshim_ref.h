@@ -85,7 +85,6 @@ bool		VARATT_IS_EXTENDED(const void *p);
 bool		VARATT_IS_SHORT(const void *p);
 
 /* utils/elog.h */
-#define DEBUG1 14
 #define DEBUG2 13
 #define INFO 17
 #define NOTICE 18

@@ -3359,6 +3359,257 @@ backend_reference_hnswbuild(void *arg)
 }
 #endif							/* PGV_HAVE_REF_HNSWBUILD */
 
+#if defined(PGV_HAVE_REF_IVFBUILD) && defined(PGV_HAVE_REF_HNSWBUILD)
+/* ------------------------------------------------------------------------------------------------ the reference's own PARALLEL CREATE INDEX
+ * amcanbuildparallel = true (src/ivfflat.c:203, src/hnsw.c:203): a table of more than a few MB is built by a leader and
+ * max_parallel_maintenance_workers workers.  The stand-in server launches them (pgshim_ref_runtime.c: a piece of shared
+ * memory as the DSM segment, workers forked by the postmaster that run the entry point the reference names, a shared
+ * block counter for the table scan, the workers' sorted runs merged by the leader), and the reference's own
+ * IvfflatBeginParallel / IvfflatParallelBuildMain / IvfflatParallelScanAndSort and HnswBeginParallel /
+ * HnswParallelBuildMain / HnswParallelScanAndInsert run, two workers and the leader.
+ *   ivfflat, vector.gpu = off: the lists a parallel build writes are the serial build's = the oracle's (k-means runs in
+ *     the leader before the workers start; every participant's argmin is the same function of the row).
+ *   ivfflat, vector.gpu = on: EVERY PARTICIPANT runs the build hooks -- PgvIvfflatBuildBegin / Add / Flush inside
+ *     IvfflatParallelScanAndSort, each process with its own device context -- and the index is complete and correct.
+ *   hnsw, vector.gpu = on: the participants share one graph in the DSM segment under the reference's locks; the hook gives
+ *     up on the first tuple (PgvHnswBuildDefer sees hnswarea set: ADVICE r4 high) and nothing is deferred -- the index
+ *     holds every row and both walks agree.  (A build that deferred in the participants would leave an EMPTY index: the
+ *     leader's FlushPages links only what the leader's own state holds.) */
+static int
+backend_reference_parallel_build(void *arg)
+{
+	Relation	index = shim_open_relation(REL_RBUILD);
+	Relation	hindex = shim_open_relation(REL_HRBUILD);
+	const int	n = 6000,
+				lists = 24,
+				hn = 2500;
+	float	   *rows = shim_shared_alloc(sizeof(float) * (size_t) n * DIM);	/* every process sees the table */
+	HeapRows   *h = shim_shared_alloc(sizeof(HeapRows));
+	float	   *live = malloc(sizeof(float) * (size_t) n * DIM);
+	int		   *live_row = malloc(sizeof(int) * (size_t) n);
+	uint64	   *got = malloc(sizeof(uint64) * 30000);
+	Relation	heap;
+	IndexInfo	info;
+	IndexBuildResult *res;
+	MemoryContext ctx;
+	pgv_ivf_image img;
+	pgv_hnsw_image himg;
+	int			nlive = 0,
+				used_gpu;
+	uint8_t		empty[1] = {0};
+
+	(void) arg;
+	scenario = "the reference's own parallel CREATE INDEX";
+	cur_ops = ORA_OPS_L2;
+	EXPECT(index != NULL && hindex != NULL);
+	gen_rows(rows, n, DIM, 51);
+	h->rows = rows;
+	h->dim = DIM;
+	h->toast_every = 7;
+	h->null_every = 13;
+	heap = heap_of(h, n);
+	for (int r = 0; r < n; r++)
+		if (!heap_row_is_null(h, r))
+		{
+			memcpy(live + (size_t) nlive * DIM, rows + (size_t) r * DIM, sizeof(float) * DIM);
+			live_row[nlive++] = r;
+		}
+	memset(&info, 0, sizeof(info));
+	shim_set_parallel_workers(2);
+
+	/* ---- ivfflat, the reference's CPU path in three processes */
+	{
+		ora_prng	a,
+					b;
+		float	   *want_centers = malloc(sizeof(float) * (size_t) lists * DIM);
+		int32_t    *want_list = malloc(sizeof(int32_t) * (size_t) nlive);
+
+		shim_replace_pages(REL_RBUILD, empty, 0);
+		shim_set_guc_bool("vector.gpu", false);
+		ora_prng_seed(&a, 91);
+		shim_prng_hook(ora_prng_double_cb, ora_prng_u32_cb, &a);
+		ctx = shim_query_context_begin();
+		res = ivfflatbuild(heap, index, &info);
+		shim_prng_hook(NULL, NULL, NULL);
+		EXPECT(res != NULL && (int) res->heap_tuples == n && (int) res->index_tuples == nlive);
+		shim_query_context_end(ctx);
+		EXPECT(shim_pinned_buffers() == 0);
+		EXPECT(shim_notices_raised("using 2 parallel workers") == 1);	/* (DEBUG1 in the server; the stand-in prints every level) */
+		ora_prng_seed(&b, 91);
+		(void) ora_prng_u32(&b);
+		(void) ora_prng_u32(&b);
+		EXPECT(ora_kmeans(ORA_OPS_L2, ORA_F32, DIM, live, nlive, want_centers, lists, &b, NULL) >= 0);
+		ora_ivf_assign(ORA_OPS_L2, ORA_F32, DIM, want_centers, lists, live, nlive, want_list, NULL);
+		EXPECT(staged_image(REL_RBUILD, &img) == PGV_OK);
+		EXPECT(img.lists == lists && img.nrows == nlive);
+		EXPECT(memcmp(img.centers, want_centers, sizeof(float) * (size_t) lists * DIM) == 0);
+		for (int l = 0; l < lists; l++)
+		{
+			int64_t		p = img.list_offsets[l];
+
+			for (int i = 0; i < nlive; i++)
+				if (want_list[i] == l)
+				{
+					EXPECT(p < img.list_offsets[l + 1] && img.tids[p] == tid_of_row(live_row[i]));
+					EXPECT(memcmp((const float *) img.vectors + (size_t) p * DIM, live + (size_t) i * DIM, sizeof(float) * DIM) == 0);
+					p++;
+				}
+			EXPECT(p == img.list_offsets[l + 1]);
+		}
+		pgv_host_ivf_image_free(&img);
+		fprintf(stderr, "   ivfflat, leader + 2 workers, the reference's CPU path: %d tuples in the serial build's = the oracle's lists\n", nlive);
+		free(want_centers);
+		free(want_list);
+	}
+
+	/* ---- ivfflat, the hooks in every participant */
+	shim_replace_pages(REL_RBUILD, empty, 0);
+	shim_set_guc_bool("vector.gpu", true);
+	shim_set_guc_bool("vector.gpu_pooled", false);
+	shim_seed_random(57);
+	ctx = shim_query_context_begin();
+	res = ivfflatbuild(heap, index, &info);
+	EXPECT(res != NULL && (int) res->heap_tuples == n && (int) res->index_tuples == nlive);
+	shim_query_context_end(ctx);
+	EXPECT(shim_pinned_buffers() == 0);
+	EXPECT(staged_image(REL_RBUILD, &img) == PGV_OK);
+	EXPECT(img.lists == lists && img.nrows == nlive);
+	{
+		char	   *seen = calloc((size_t) n, 1);
+
+		for (int l = 0; l < lists; l++)
+		{
+			int			prev = -1;
+
+			for (int64_t p = img.list_offsets[l]; p < img.list_offsets[l + 1]; p++)
+			{
+				const int	r = row_of_tid(img.tids[p]);
+				const float *x = (const float *) img.vectors + (size_t) p * DIM;
+				double		best = INFINITY,
+							mine;
+
+				EXPECT(r > prev && r < n && !seen[r] && !heap_row_is_null(h, r));
+				prev = r;
+				seen[r] = 1;
+				EXPECT(memcmp(x, rows + (size_t) r * DIM, sizeof(float) * DIM) == 0);
+				for (int c = 0; c < lists; c++)
+				{
+					double		d = ora_index_distance(ORA_OPS_L2, ORA_F32, DIM, x, (const float *) img.centers + (size_t) c * DIM);
+
+					if (d < best)
+						best = d;
+				}
+				mine = ora_index_distance(ORA_OPS_L2, ORA_F32, DIM, x, (const float *) img.centers + (size_t) l * DIM);
+				EXPECT(mine <= best + 1e-5 * fabs(best) + 1e-9);
+			}
+		}
+		free(seen);
+	}
+	pgv_host_ivf_image_free(&img);
+	EXPECT(wait_for_gpu(index, 30.0) == 0);
+	for (int i = 0; i < 12; i++)
+	{
+		const int	r = live_row[(151 * i + 29) % nlive];
+		Expected	e = expected_batch(REL_RBUILD, rows + (size_t) r * DIM, PROBES);
+		int			nn = ref_scan(index, rows + (size_t) r * DIM, PROBES, i % 4 == 3 ? 300 : 10, got, &used_gpu);
+
+		EXPECT(used_gpu && nn == (i % 4 == 3 ? (300 < e.n ? 300 : e.n) : 10) && got[0] == tid_of_row(r));
+		if (check_stream(&e, got, nn, 0, "parallel build with the hooks"))
+			return 1;
+		expected_free(&e);
+	}
+	fprintf(stderr, "   ivfflat, leader + 2 workers, the hooks in every participant (three device contexts): every row in a nearest list, once; scans agree\n");
+
+	/* ---- hnsw: the participants keep the reference's path */
+	{
+		extern int	maintenance_work_mem;
+		const int	saved = maintenance_work_mem;
+		uint64		cpu[64],
+					gpu[64];
+		int			had_gpu,
+					hlive = 0;
+		long		reads;
+		double		until;
+
+		for (int r = 0; r < hn; r++)
+			hlive += !heap_row_is_null(h, r);
+		heap = heap_of(h, hn);
+		shim_replace_pages(REL_HRBUILD, empty, 0);
+		hnsw_ef_search = 40;
+		maintenance_work_mem = 16384;	/* the shared graph area is maintenance_work_mem less 3 MB (src/hnswbuild.c:955-961) */
+		shim_set_guc_bool("vector.gpu", true);
+		ctx = shim_query_context_begin();
+		res = hnswbuild(heap, hindex, &info);
+		maintenance_work_mem = saved;
+		EXPECT(res != NULL && (int) res->heap_tuples == hn && (int) res->index_tuples == hlive);
+		shim_query_context_end(ctx);
+		EXPECT(shim_pinned_buffers() == 0);
+		EXPECT(staged_hnsw_image(REL_HRBUILD, &himg) == PGV_OK);
+		EXPECT(himg.n == hlive && himg.entry >= 0);	/* (no two rows of this table are equal: every row an element) */
+		{
+			int64_t		links = 0;
+
+			for (int64_t s = 0; s < himg.n; s++)
+				for (int64_t j = himg.nbr_start[s]; j < himg.nbr_start[s + 1]; j++)
+					links += himg.nbr[j] >= 0;
+			EXPECT(links > himg.n * HM);
+		}
+		pgv_host_hnsw_image_free(&himg);
+		until = shim_now() + 30.0;
+		for (;;)
+		{
+			(void) ref_hnsw_scan(hindex, rows, 1, gpu, &had_gpu, &reads);
+			if ((had_gpu && reads == 0) || shim_now() > until)
+				break;
+			usleep(20000);
+		}
+		EXPECT(had_gpu && reads == 0);
+		for (int i = 0; i < 30; i++)
+		{
+			int			r = (83 * i + 9) % hn;
+			const float *q;
+			int			nc,
+						ng,
+						found = 0;
+			int64_t		wrows[64];
+			double		wdist[64];
+
+			while (heap_row_is_null(h, r))
+				r++;
+			q = rows + (size_t) r * DIM;
+			shim_set_guc_bool("vector.gpu", false);
+			nc = ref_hnsw_scan(hindex, q, 64, cpu, &had_gpu, &reads);
+			EXPECT(!had_gpu && reads > 0 && nc >= 40);
+			shim_set_guc_bool("vector.gpu", true);
+			ng = ref_hnsw_scan(hindex, q, 64, gpu, &had_gpu, &reads);
+			EXPECT(had_gpu && reads == 0);
+			for (int j = 0; j < nc; j++)
+			{
+				const int	row = row_of_tid(cpu[j]);
+				double		d = 0;
+
+				EXPECT(row >= 0 && row < hn && !heap_row_is_null(h, row));
+				for (int k = 0; k < DIM; k++)
+					d += ((double) rows[(size_t) row * DIM + k] - q[k]) * ((double) rows[(size_t) row * DIM + k] - q[k]);
+				wrows[j] = row;
+				wdist[j] = d;
+				found |= row == r;
+			}
+			EXPECT(found);
+			if (check_hnsw_stream_n(rows, hn, q, gpu, ng, wrows, wdist, nc, "parallel hnsw build"))
+				return 1;
+		}
+		fprintf(stderr, "   hnsw, leader + 2 workers with vector.gpu on: nothing deferred, the shared graph built under the reference's locks holds all %d rows; both walks agree\n",
+				hlive);
+	}
+	shim_set_parallel_workers(0);
+	free(live);
+	free(live_row);
+	free(got);
+	return 0;
+}
+#endif
+
 int
 main(void)
 {
@@ -3384,6 +3635,9 @@ main(void)
 	PgvGpuInit();
 	shim_postmaster_run_shmem_hooks();
 	shim_register_bgworker_function("PgvWorkerMain", PgvWorkerMain);
+#if defined(PGV_HAVE_REF_IVFBUILD) || defined(PGV_HAVE_REF_HNSWBUILD)
+	shim_register_bgworker_function("ParallelWorkerMain", ParallelWorkerMain);
+#endif
 	/* empty relations: their pages come from the build */
 	shim_create_relation(REL_IVF, &l2, empty, 0, DIM);
 	shim_create_relation(REL_BATCH, &l2, empty, 0, 8);
@@ -3496,6 +3750,10 @@ main(void)
 #ifdef PGV_HAVE_REF_HNSWBUILD
 	if (!failed)
 		failed |= run_phase("the reference's own hnswbuild", backend_reference_hnswbuild, 1, NULL, 300.0);
+#endif
+#if defined(PGV_HAVE_REF_IVFBUILD) && defined(PGV_HAVE_REF_HNSWBUILD)
+	if (!failed)
+		failed |= run_phase("the reference's own parallel CREATE INDEX", backend_reference_parallel_build, 1, NULL, 300.0);
 #endif
 	if (!failed && mock_hip_set_arena)
 		failed |= run_phase("a backend without a device", backend_no_device, 1, NULL, 120.0);

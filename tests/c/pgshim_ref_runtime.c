@@ -12,15 +12,18 @@
  * ivfflat.h / hnsw.h -- and so are pgshim_runtime.c, ext_driver.c and ext/ in that build: one set of struct layouts.
  * TEST INFRASTRUCTURE ONLY.
  */
+#define _GNU_SOURCE				/* RTLD_DEFAULT */
 #include "pgshim_runtime.h"
 #include "pgshim_ref.h"
 
 #include "ivfflat.h"
 
+#include <dlfcn.h>
 #include <math.h>
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
+#include <unistd.h>
 
 /* ------------------------------------------------------------------------------------------------ fmgr */
 struct FunctionCallInfoBaseData
@@ -247,10 +250,23 @@ typedef struct SortEntry
 	int64		seq;
 }			SortEntry;
 
+#define SHIM_SORT_RUNS 8
+struct Sharedsort
+{
+	uint32		nruns;
+	struct
+	{
+		char	   *data;		/* packed entries: int32 list, ItemPointerData tid, uint32 value size, value bytes (MAXALIGNed) */
+		int64		n;
+	}			runs[SHIM_SORT_RUNS];
+};
+
 struct Tuplesortstate
 {
 	MemoryContext ctx;
 	bool		build_shape;
+	bool		parallel;		/* a participant's or the leader's sort of a parallel build */
+	SortCoordinateData coordinate;
 	SortEntry  *e;
 	int64		n,
 				cap,
@@ -268,7 +284,10 @@ tuplesort_begin_heap(TupleDesc tupDesc, int nkeys, AttrNumber *attNums, Oid *sor
 	(void) workMem;
 	(void) sortopt;
 	if (coordinate != NULL)
-		elog(ERROR, "stand-in tuplesort: no parallel sorts");
+	{
+		st->parallel = true;
+		st->coordinate = *coordinate;
+	}
 	if (nkeys != 1 || attNums[0] != 1 || (sortOperators[0] != Float8LessOperator && sortOperators[0] != Int4LessOperator))
 		elog(ERROR, "stand-in tuplesort: float8 or int4 ascending on attribute 1 only");
 	st->build_shape = sortOperators[0] == Int4LessOperator;
@@ -326,12 +345,103 @@ sort_entry_cmp(const void *a, const void *b)
 	return x->seq < y->seq ? -1 : (x->seq > y->seq ? 1 : 0);
 }
 
+static int
+sort_entry_cmp_tid(const void *a, const void *b)
+{
+	const SortEntry *x = a,
+			   *y = b;
+	uint64		tx = ((uint64) x->tid.ip_blkid.bi_hi << 32) | ((uint64) x->tid.ip_blkid.bi_lo << 16) | x->tid.ip_posid,
+				ty = ((uint64) y->tid.ip_blkid.bi_hi << 32) | ((uint64) y->tid.ip_blkid.bi_lo << 16) | y->tid.ip_posid;
+
+	if (x->key != y->key)
+		return x->key < y->key ? -1 : 1;
+	return tx < ty ? -1 : (tx > ty ? 1 : 0);
+}
+
+/* a run in shared memory: per tuple int32 list, ItemPointerData, uint32 size of the value, the value; 8-byte aligned */
+#define RUN_ENTRY_BYTES(vsize) (((Size) 16 + (vsize) + 7) & ~(Size) 7)
+
 void
 tuplesort_performsort(Tuplesortstate *state)
 {
+	if (state->parallel && !state->coordinate.isWorker)
+	{
+		/* the leader: nothing was put into THIS sort (the leader's share went through a participant's sort of its own);
+		 * its result is every participant's run merged */
+		Sharedsort *shared = state->coordinate.sharedsort;
+		MemoryContext old = MemoryContextSwitchTo(state->ctx);
+		int64		total = 0,
+					at = 0;
+
+		if (state->n != 0 || (int) shared->nruns != state->coordinate.nParticipants)
+			elog(ERROR, "stand-in tuplesort: %d runs published, %d participants", (int) shared->nruns, state->coordinate.nParticipants);
+		for (uint32 r = 0; r < shared->nruns; r++)
+			total += shared->runs[r].n;
+		state->cap = total > 0 ? total : 1;
+		state->e = palloc_extended(sizeof(SortEntry) * (Size) state->cap, MCXT_ALLOC_HUGE);
+		for (uint32 r = 0; r < shared->nruns; r++)
+		{
+			const char *p = shared->runs[r].data;
+
+			for (int64 i = 0; i < shared->runs[r].n; i++)
+			{
+				int32		list;
+				uint32		vsize;
+
+				memcpy(&list, p, 4);
+				memcpy(&state->e[at].tid, p + 4, sizeof(ItemPointerData));
+				memcpy(&vsize, p + 12, 4);
+				state->e[at].key = (double) list;
+				state->e[at].value = palloc(vsize);
+				memcpy(state->e[at].value, p + 16, vsize);
+				p += RUN_ENTRY_BYTES(vsize);
+				at++;
+			}
+		}
+		state->n = total;
+		MemoryContextSwitchTo(old);
+		if (state->n > 1)
+			qsort(state->e, (size_t) state->n, sizeof(SortEntry), sort_entry_cmp_tid);
+		for (int64 i = 0; i < state->n; i++)
+			state->e[i].seq = i;
+		state->pos = 0;
+		return;
+	}
 	if (state->n > 1)
 		qsort(state->e, (size_t) state->n, sizeof(SortEntry), sort_entry_cmp);
 	state->pos = 0;
+	if (state->parallel)
+	{
+		/* a participant: the sorted run goes where the leader finds it */
+		Sharedsort *shared = state->coordinate.sharedsort;
+		Size		bytes = 8;
+		char	   *data,
+				   *p;
+		uint32		slot;
+
+		if (!state->build_shape)
+			elog(ERROR, "stand-in tuplesort: parallel sorts are the build's");
+		for (int64 i = 0; i < state->n; i++)
+			bytes += RUN_ENTRY_BYTES(VARSIZE_ANY(state->e[i].value));
+		data = p = shim_shared_alloc(bytes);
+		for (int64 i = 0; i < state->n; i++)
+		{
+			int32		list = (int32) state->e[i].key;
+			uint32		vsize = (uint32) VARSIZE_ANY(state->e[i].value);
+
+			memcpy(p, &list, 4);
+			memcpy(p + 4, &state->e[i].tid, sizeof(ItemPointerData));
+			memcpy(p + 12, &vsize, 4);
+			memcpy(p + 16, state->e[i].value, vsize);
+			p += RUN_ENTRY_BYTES(vsize);
+		}
+		slot = __atomic_fetch_add(&shared->nruns, 1, __ATOMIC_SEQ_CST);
+		if (slot >= SHIM_SORT_RUNS)
+			elog(ERROR, "stand-in tuplesort: too many participants");
+		shared->runs[slot].data = data;
+		shared->runs[slot].n = state->n;
+		__atomic_thread_fence(__ATOMIC_RELEASE);
+	}
 }
 
 bool
@@ -1080,7 +1190,26 @@ datumIsEqual(Datum value1, Datum value2, bool typByVal, int typLen)
  * rows, NULLs, toasted values, TIDs), ANALYZE's block and reservoir samplers, the progress counters, spinlocks and lock
  * initialisation.  plan_create_index_workers answers 0 -- no parallel workers in this program --, so everything behind
  * IvfflatBeginParallel / HnswBeginParallel only has to LINK: those stand-ins raise an ERROR if they are ever reached. */
-static ShimHeapDef heap_def;
+struct ParallelTableScanDescData
+{
+	uint32		next_block;
+	uint32		attached;		/* participants that have begun their scan */
+	uint32		mode;			/* 0 undecided, 1 blocks dealt round-robin, 2 first come first served */
+	uint32		participants;
+};
+
+struct TableScanDescData
+{
+	struct ParallelTableScanDescData *pscan;
+	uint32		my_index,
+				my_next;
+};
+
+/* the definition sits in shared memory (slot 0 of the runtime's shared words) so that parallel workers -- forked from the
+ * postmaster, not from the backend that runs CREATE INDEX -- find it: table_open in a worker attaches to it.  The rows and
+ * the callback's argument must be visible there too (shim_shared_alloc; the callback is code, the same in every process). */
+static ShimHeapDef *heap_def_p = NULL;
+#define heap_def (*heap_def_p)
 static struct RelationData heap_rel;
 static struct TupleDescData heap_desc;
 extern BlockNumber (*shim_heap_blocks_hook) (void);
@@ -1092,9 +1221,11 @@ heap_blocks(void)
 }
 
 Relation
-shim_heap_relation(const ShimHeapDef * def)
+shim_heap_attach(void)
 {
-	heap_def = *def;
+	heap_def_p = *(ShimHeapDef **) shim_shared_slot(0);
+	if (heap_def_p == NULL)
+		return NULL;
 	memset(&heap_rel, 0, sizeof(heap_rel));
 	heap_rel.rd_id = SHIM_HEAP_OID;
 	heap_desc.natts = 1;
@@ -1103,6 +1234,16 @@ shim_heap_relation(const ShimHeapDef * def)
 	heap_rel.rd_att = &heap_desc;
 	shim_heap_blocks_hook = heap_blocks;
 	return &heap_rel;
+}
+
+Relation
+shim_heap_relation(const ShimHeapDef * def)
+{
+	ShimHeapDef *shared = shim_shared_alloc(sizeof(ShimHeapDef));
+
+	*shared = *def;
+	__atomic_store_n((ShimHeapDef **) shim_shared_slot(0), shared, __ATOMIC_RELEASE);
+	return shim_heap_attach();
 }
 
 /* heapam_index_build_range_scan (access/heap/heapam_handler.c) as far as an index build sees it: blocks [start, start +
@@ -1123,24 +1264,46 @@ table_index_build_range_scan(Relation table_rel, Relation index_rel, IndexInfo *
 	(void) allow_sync;
 	(void) anyvisible;
 	(void) progress;
-	if (table_rel != &heap_rel || scan != NULL)
-		elog(ERROR, "stand-in heap: one table, serial scans");
+	if (table_rel != &heap_rel)
+		elog(ERROR, "stand-in heap: one table");
 	if (end > heap_def.nrows)
 		end = heap_def.nrows;
 	per_tuple = AllocSetContextCreate(CurrentMemoryContext, "index build per-tuple", 0, 0, 0);
-	for (int64 row = first; row < end; row++)
+	for (;;)
 	{
-		MemoryContext old = MemoryContextSwitchTo(per_tuple);
-		Datum		values[1];
-		bool		isnull[1];
-		ItemPointerData tid;
+		if (scan != NULL)
+		{
+			/* a participant of a parallel scan: the next block nobody has taken yet (table_block_parallelscan_nextpage) */
+			BlockNumber blk;
 
-		CHECK_FOR_INTERRUPTS();
-		heap_def.fetch(row, &values[0], &isnull[0], &tid, heap_def.arg);
-		MemoryContextSwitchTo(old);
-		callback(index_rel, &tid, values, isnull, true, callback_state);
-		reltuples += 1;
-		MemoryContextReset(per_tuple);
+			if (__atomic_load_n(&scan->pscan->mode, __ATOMIC_ACQUIRE) == 1 && scan->my_index < scan->pscan->participants)
+			{
+				blk = scan->my_next;
+				scan->my_next += scan->pscan->participants;
+			}
+			else
+				blk = __atomic_fetch_add(&scan->pscan->next_block, 1, __ATOMIC_SEQ_CST);
+			if (blk >= heap_blocks())
+				break;
+			first = (int64) blk * heap_def.rows_per_block;
+			end = first + heap_def.rows_per_block < heap_def.nrows ? first + heap_def.rows_per_block : heap_def.nrows;
+		}
+		for (int64 row = first; row < end; row++)
+		{
+			MemoryContext old = MemoryContextSwitchTo(per_tuple);
+			Datum		values[1];
+			bool		isnull[1];
+			ItemPointerData tid;
+
+			CHECK_FOR_INTERRUPTS();
+			heap_def.fetch(row, &values[0], &isnull[0], &tid, heap_def.arg);
+			MemoryContextSwitchTo(old);
+			callback(index_rel, &tid, values, isnull, true, callback_state);
+			reltuples += 1;
+			MemoryContextReset(per_tuple);
+		}
+		if (scan == NULL)
+			break;
 	}
 	MemoryContextDelete(per_tuple);
 	return reltuples;
@@ -1324,8 +1487,21 @@ BuildIndexInfo(Relation index)
 	return palloc0(sizeof(IndexInfo));
 }
 
-/* ---- parallel CREATE INDEX: planned away.  optimizer/plan/planner.c would look at the table's size and
- * max_parallel_maintenance_workers; this program has no worker processes to launch. */
+/* ---- parallel CREATE INDEX (src/ivfbuild.c:600-990, src/hnswbuild.c:760-1100) on the stand-in server
+ *
+ * What access/transam/parallel.c, storage/ipc/dsm.c + shm_toc.c, the parallel half of utils/sort/tuplesort.c and
+ * access/table/tableam.c's parallel block scan do for a parallel index build, as small as it can be made:
+ *   - a "dynamic shared memory segment" is a piece of the postmaster's shared pool (shim_shared_alloc): every process of
+ *     this program was forked from the postmaster, so it sits at the same address in all of them; the table of contents
+ *     is a few (key, pointer) pairs at its head;
+ *   - LaunchParallelWorkers asks the postmaster for background workers running "ParallelWorkerMain", which finds the
+ *     entry point the leader named ("IvfflatParallelBuildMain", "HnswParallelBuildMain": dlsym, the program is linked
+ *     -rdynamic) and calls it; a worker that ends with an ERROR is counted, and the leader's waits raise it;
+ *   - the parallel table scan hands out the heap's blocks one at a time from a shared counter;
+ *   - a worker's tuplesort_performsort publishes its sorted run in shared memory, the leader's merges the runs (by list
+ *     number, then heap TID: inside a list the tuples come out in heap order whoever scanned them);
+ *   - condition variables are polled (their users loop on a predicate anyway).
+ * plan_create_index_workers answers what the test asked for (shim_set_parallel_workers; 0 = a serial build). */
 int			max_parallel_maintenance_workers = 2;
 const char *debug_query_string = NULL;
 struct SnapshotData
@@ -1333,12 +1509,20 @@ struct SnapshotData
 	int			unused;
 }			SnapshotAnyData;
 
+static int	planned_workers = 0;
+
+void
+shim_set_parallel_workers(int n)
+{
+	planned_workers = n;
+}
+
 int
 plan_create_index_workers(Oid tableOid, Oid indexOid)
 {
 	(void) tableOid;
 	(void) indexOid;
-	return 0;
+	return planned_workers;
 }
 
 int
@@ -1348,98 +1532,322 @@ RelationGetParallelWorkers(Relation relation, int defaultpw)
 	return defaultpw;
 }
 
-static void
-no_parallel(const char *what)
+#define SHIM_TOC_KEYS 8
+struct shm_toc
 {
-	elog(ERROR, "stand-in server: %s reached, but no parallel build was planned", what);
+	char		entry[64];		/* the worker entry point's name */
+	uint32		launched,
+				finished,
+				failed;
+	int			nkeys;
+	uint64		keys[SHIM_TOC_KEYS];
+	void	   *addr[SHIM_TOC_KEYS];
+	int			ngucs;			/* the leader's settings, restored in every worker (RestoreGUCState) */
+	int			gucs[16];
+	int			maintenance_work_mem;
+};
+
+struct dsm_segment
+{
+	shm_toc    *toc;
+};
+
+static char pending_entry[64];
+static shm_toc *leader_toc = NULL;	/* the parallel context this process leads (for the polled waits) */
+
+void
+EnterParallelMode(void)
+{
 }
 
-#define NO_PARALLEL_VOID(name, args) void name args { no_parallel(#name); }
-NO_PARALLEL_VOID(EnterParallelMode, (void))
-NO_PARALLEL_VOID(ExitParallelMode, (void))
-NO_PARALLEL_VOID(InitializeParallelDSM, (ParallelContext *pcxt))
-NO_PARALLEL_VOID(LaunchParallelWorkers, (ParallelContext *pcxt))
-NO_PARALLEL_VOID(WaitForParallelWorkersToAttach, (ParallelContext *pcxt))
-NO_PARALLEL_VOID(WaitForParallelWorkersToFinish, (ParallelContext *pcxt))
-NO_PARALLEL_VOID(DestroyParallelContext, (ParallelContext *pcxt))
-NO_PARALLEL_VOID(ConditionVariableInit, (ConditionVariable *cv))
-NO_PARALLEL_VOID(ConditionVariableSleep, (ConditionVariable *cv, uint32 wait_event_info))
-NO_PARALLEL_VOID(ConditionVariableCancelSleep, (void))
-NO_PARALLEL_VOID(ConditionVariableSignal, (ConditionVariable *cv))
-NO_PARALLEL_VOID(shm_toc_insert, (shm_toc *toc, uint64 key, void *address))
-NO_PARALLEL_VOID(tuplesort_initialize_shared, (Sharedsort *shared, int nWorkers, struct dsm_segment *seg))
-NO_PARALLEL_VOID(tuplesort_attach_shared, (Sharedsort *shared, struct dsm_segment *seg))
-NO_PARALLEL_VOID(table_parallelscan_initialize, (Relation rel, ParallelTableScanDesc pscan, Snapshot snapshot))
-NO_PARALLEL_VOID(table_close, (Relation relation, LOCKMODE lockmode))
-NO_PARALLEL_VOID(UnregisterSnapshot, (Snapshot snapshot))
+void
+ExitParallelMode(void)
+{
+}
 
 ParallelContext *
 CreateParallelContext(const char *library_name, const char *function_name, int nworkers)
 {
-	no_parallel("CreateParallelContext");
-	return NULL;
+	ParallelContext *pcxt = palloc0(sizeof(ParallelContext));
+
+	(void) library_name;
+	snprintf(pending_entry, sizeof(pending_entry), "%s", function_name);
+	pcxt->nworkers = nworkers;
+	return pcxt;
+}
+
+void
+InitializeParallelDSM(ParallelContext *pcxt)
+{
+	shm_toc    *toc = shim_shared_alloc(sizeof(shm_toc));
+
+	/* (the estimator's totals are not needed: chunks come from the pool one by one) */
+	snprintf(toc->entry, sizeof(toc->entry), "%s", pending_entry);
+	toc->ngucs = shim_guc_snapshot(toc->gucs, 16);
+	toc->maintenance_work_mem = maintenance_work_mem;
+	pcxt->seg = palloc0(sizeof(dsm_segment));
+	pcxt->seg->toc = toc;
+	pcxt->toc = toc;
 }
 
 void *
 shm_toc_allocate(shm_toc *toc, Size nbytes)
 {
-	no_parallel("shm_toc_allocate");
-	return NULL;
+	(void) toc;
+	return shim_shared_alloc(nbytes);
+}
+
+void
+shm_toc_insert(shm_toc *toc, uint64 key, void *address)
+{
+	if (toc->nkeys == SHIM_TOC_KEYS)
+		elog(ERROR, "stand-in shm_toc: too many keys");
+	toc->keys[toc->nkeys] = key;
+	toc->addr[toc->nkeys] = address;
+	__atomic_add_fetch(&toc->nkeys, 1, __ATOMIC_RELEASE);
 }
 
 void *
 shm_toc_lookup(shm_toc *toc, uint64 key, bool noError)
 {
-	no_parallel("shm_toc_lookup");
+	int			n = __atomic_load_n(&toc->nkeys, __ATOMIC_ACQUIRE);
+
+	for (int i = 0; i < n; i++)
+		if (toc->keys[i] == key)
+			return toc->addr[i];
+	if (!noError)
+		elog(ERROR, "could not find key " UINT64_FORMAT " in shm TOC", key);
 	return NULL;
 }
 
-Size
-tuplesort_estimate_shared(int nWorkers)
+/* what a parallel worker process runs (bgw_function_name "ParallelWorkerMain"; the test registers it with the postmaster) */
+void
+ParallelWorkerMain(Datum main_arg)
 {
-	no_parallel("tuplesort_estimate_shared");
-	return 0;
+	shm_toc    *toc = (shm_toc *) DatumGetPointer(main_arg);
+	void		(*entry) (dsm_segment *, shm_toc *) = (void (*) (dsm_segment *, shm_toc *)) dlsym(RTLD_DEFAULT, toc->entry);
+	dsm_segment seg;
+
+	seg.toc = toc;
+	shim_guc_restore(toc->gucs, toc->ngucs);
+	maintenance_work_mem = toc->maintenance_work_mem;
+	if (entry == NULL)
+	{
+		__atomic_add_fetch(&toc->failed, 1, __ATOMIC_SEQ_CST);
+		elog(ERROR, "parallel worker: no function \"%s\" in this program", toc->entry);
+	}
+	PG_TRY();
+	{
+		entry(&seg, toc);
+	}
+	PG_CATCH();
+	{
+		__atomic_add_fetch(&toc->failed, 1, __ATOMIC_SEQ_CST);
+		PG_RE_THROW();
+	}
+	PG_END_TRY();
+	__atomic_add_fetch(&toc->finished, 1, __ATOMIC_SEQ_CST);
 }
 
+void
+LaunchParallelWorkers(ParallelContext *pcxt)
+{
+	BackgroundWorker worker;
+
+	memset(&worker, 0, sizeof(worker));
+	snprintf(worker.bgw_function_name, BGW_MAXLEN, "ParallelWorkerMain");
+	worker.bgw_main_arg = PointerGetDatum(pcxt->toc);
+	pcxt->nworkers_launched = 0;
+	/* (the participants of the scan to come, the leader among them: known to the workers before the first of them starts) */
+	__atomic_store_n(shim_shared_slot(1), (void *) (uintptr_t) (pcxt->nworkers + 1), __ATOMIC_RELEASE);
+	for (int i = 0; i < pcxt->nworkers; i++)
+		if (RegisterDynamicBackgroundWorker(&worker, NULL))
+			pcxt->nworkers_launched++;
+	pcxt->toc->launched = (uint32) pcxt->nworkers_launched;
+	__atomic_store_n(shim_shared_slot(1), (void *) (uintptr_t) (pcxt->nworkers_launched + 1), __ATOMIC_RELEASE);
+	leader_toc = pcxt->toc;
+}
+
+static void
+check_workers(void)
+{
+	CHECK_FOR_INTERRUPTS();
+	if (leader_toc && __atomic_load_n(&leader_toc->failed, __ATOMIC_ACQUIRE) > 0)
+	{
+		leader_toc = NULL;
+		elog(ERROR, "a parallel worker of this build ended with an error");
+	}
+}
+
+void
+WaitForParallelWorkersToAttach(ParallelContext *pcxt)
+{
+	(void) pcxt;
+	check_workers();
+}
+
+void
+WaitForParallelWorkersToFinish(ParallelContext *pcxt)
+{
+	while (__atomic_load_n(&pcxt->toc->finished, __ATOMIC_ACQUIRE) < pcxt->toc->launched)
+	{
+		check_workers();
+		usleep(200);
+	}
+}
+
+void
+DestroyParallelContext(ParallelContext *pcxt)
+{
+	leader_toc = NULL;
+	pfree(pcxt->seg);
+	pfree(pcxt);
+}
+
+void
+ConditionVariableInit(ConditionVariable *cv)
+{
+	memset(cv, 0, sizeof(*cv));
+}
+
+void
+ConditionVariableSleep(ConditionVariable *cv, uint32 wait_event_info)
+{
+	(void) cv;
+	(void) wait_event_info;
+	check_workers();
+	usleep(200);				/* (callers re-test their predicate: a wakeup with nothing changed is allowed) */
+}
+
+void
+ConditionVariableCancelSleep(void)
+{
+}
+
+void
+ConditionVariableSignal(ConditionVariable *cv)
+{
+	(void) cv;
+}
+
+/* ---- the parallel block scan of the stand-in heap (heap_def lives in shared memory: see shim_heap_relation) */
 Size
 table_parallelscan_estimate(Relation rel, Snapshot snapshot)
 {
-	no_parallel("table_parallelscan_estimate");
-	return 0;
+	(void) rel;
+	(void) snapshot;
+	return sizeof(struct ParallelTableScanDescData);
+}
+
+void
+table_parallelscan_initialize(Relation rel, ParallelTableScanDesc pscan, Snapshot snapshot)
+{
+	(void) rel;
+	(void) snapshot;
+	pscan->next_block = 0;
+	pscan->attached = 0;
+	pscan->mode = 0;
+	pscan->participants = 0;
 }
 
 TableScanDesc
 table_beginscan_parallel(Relation relation, ParallelTableScanDesc pscan)
 {
-	no_parallel("table_beginscan_parallel");
-	return NULL;
+	TableScanDesc scan = palloc0(sizeof(struct TableScanDescData));
+
+	(void) relation;
+	scan->pscan = pscan;
+	/* (test determinism, not the server's behaviour: the server hands out blocks first come first served -- here the
+	 * first process would be through a small test table before the others have set up.  So the participants wait for
+	 * each other, a few seconds at most, and the blocks are then dealt round-robin in the order they arrived: a split of
+	 * the table the server could produce too, with a share for everyone.  If somebody does not turn up in time the scan
+	 * falls back to the shared counter.) */
+	{
+		const uint32 expected = (uint32) (uintptr_t) __atomic_load_n(shim_shared_slot(1), __ATOMIC_ACQUIRE);
+		double		until = shim_now() + 5.0;
+		uint32		undecided = 0;
+
+		scan->my_index = __atomic_fetch_add(&pscan->attached, 1, __ATOMIC_SEQ_CST);
+		while (__atomic_load_n(&pscan->attached, __ATOMIC_ACQUIRE) < expected && __atomic_load_n(&pscan->mode, __ATOMIC_ACQUIRE) == 0 &&
+			   shim_now() < until)
+			__builtin_ia32_pause();
+		if (__atomic_load_n(&pscan->attached, __ATOMIC_ACQUIRE) >= expected && expected > 0)
+		{
+			pscan->participants = expected;
+			__atomic_compare_exchange_n(&pscan->mode, &undecided, 1u, 0, __ATOMIC_SEQ_CST, __ATOMIC_SEQ_CST);
+		}
+		else
+			__atomic_compare_exchange_n(&pscan->mode, &undecided, 2u, 0, __ATOMIC_SEQ_CST, __ATOMIC_SEQ_CST);
+		scan->my_next = scan->my_index;
+	}
+	return scan;
 }
 
 Relation
 table_open(Oid relationId, LOCKMODE lockmode)
 {
-	no_parallel("table_open");
-	return NULL;
+	(void) lockmode;
+	if (relationId != SHIM_HEAP_OID || shim_heap_attach() == NULL)
+		elog(ERROR, "could not open relation with OID %u", relationId);
+	return shim_heap_attach();
+}
+
+void
+table_close(Relation relation, LOCKMODE lockmode)
+{
+	(void) relation;
+	(void) lockmode;
 }
 
 Relation
 index_open(Oid relationId, LOCKMODE lockmode)
 {
-	no_parallel("index_open");
-	return NULL;
+	Relation	r = shim_open_relation(relationId);
+
+	(void) lockmode;
+	if (r == NULL)
+		elog(ERROR, "could not open relation with OID %u", relationId);
+	return r;
 }
 
 Snapshot
 GetTransactionSnapshot(void)
 {
-	no_parallel("GetTransactionSnapshot");
-	return NULL;
+	return SnapshotAny;
 }
 
 Snapshot
 RegisterSnapshot(Snapshot snapshot)
 {
-	no_parallel("RegisterSnapshot");
-	return NULL;
+	return snapshot;
+}
+
+void
+UnregisterSnapshot(Snapshot snapshot)
+{
+	(void) snapshot;
+}
+
+/* ---- the shared half of the build's tuplesort */
+Size
+tuplesort_estimate_shared(int nWorkers)
+{
+	(void) nWorkers;
+	return sizeof(Sharedsort);
+}
+
+void
+tuplesort_initialize_shared(Sharedsort *shared, int nWorkers, struct dsm_segment *seg)
+{
+	(void) nWorkers;
+	(void) seg;
+	memset(shared, 0, sizeof(*shared));
+}
+
+void
+tuplesort_attach_shared(Sharedsort *shared, struct dsm_segment *seg)
+{
+	(void) shared;
+	(void) seg;
 }
 #endif							/* PGV_HAVE_REF_IVFBUILD || PGV_HAVE_REF_HNSWBUILD */

@@ -92,6 +92,12 @@ typedef struct ShimShared
 				page_used;
 	size_t		arena_off,
 				arena_bytes;
+	/* a pool the stand-in's dynamic shared memory segments (parallel CREATE INDEX) and the tests' shared data are carved
+	 * from: part of the postmaster's mapping, so at the SAME address in every process; never given back */
+	size_t		dsm_off,
+				dsm_bytes;
+	uint64		dsm_used;
+	void	   *shared_slots[8];
 	/* shared invalidation queue (sinval): relcache invalidations reach every process at its next
 	 * AcceptInvalidationMessages / transaction start */
 	uint64		inval_seq;
@@ -585,6 +591,28 @@ DefineCustomIntVariable(const char *name, const char *short_desc, const char *lo
 	gucs[ngucs++].i = valueAddr;
 }
 
+/* the GUC values of this process, for a parallel worker to start with (SerializeGUCState / RestoreGUCState): the
+ * variables were registered in the postmaster, so every process has them in the same order */
+int
+shim_guc_snapshot(int *out, int cap)
+{
+	for (int g = 0; g < ngucs && g < cap; g++)
+		out[g] = gucs[g].b ? (int) *gucs[g].b : *gucs[g].i;
+	return ngucs < cap ? ngucs : cap;
+}
+
+void
+shim_guc_restore(const int *in, int n)
+{
+	for (int g = 0; g < ngucs && g < n; g++)
+	{
+		if (gucs[g].b)
+			*gucs[g].b = in[g] != 0;
+		else
+			*gucs[g].i = in[g];
+	}
+}
+
 void
 shim_set_guc_bool(const char *name, bool value)
 {
@@ -653,24 +681,35 @@ ShmemInitStruct(const char *name, Size size, bool *foundPtr)
 	return Sbase + S->structs[S->nstructs - 1].off;
 }
 
+/* a reader-writer lock over the state word: readers count, 0x80000000 = a writer holds it.  (No queue, no fairness:
+ * writers can be kept waiting by a stream of readers -- the tests' lock traffic is light.) */
+#define LW_WRITER 0x80000000u
+
 bool
 LWLockAcquire(LWLock *lock, LWLockMode mode)
 {
-	(void) mode;				/* shared = exclusive here: correct, only slower */
 	for (;;)
 	{
-		uint32		zero = 0;
+		uint32		v = __atomic_load_n(&lock->state, __ATOMIC_RELAXED);
 
-		if (__atomic_compare_exchange_n(&lock->state, &zero, 1u, 0, __ATOMIC_ACQUIRE, __ATOMIC_RELAXED))
-			return true;
-		futex_wait(&lock->state, 1u, 1);
+		if (mode == LW_EXCLUSIVE ? v == 0 : !(v & LW_WRITER))
+		{
+			if (__atomic_compare_exchange_n(&lock->state, &v, mode == LW_EXCLUSIVE ? LW_WRITER : v + 1, 0, __ATOMIC_ACQUIRE,
+											__ATOMIC_RELAXED))
+				return true;
+			continue;
+		}
+		futex_wait(&lock->state, v, 1);
 	}
 }
 
 void
 LWLockRelease(LWLock *lock)
 {
-	__atomic_store_n(&lock->state, 0u, __ATOMIC_RELEASE);
+	if (__atomic_load_n(&lock->state, __ATOMIC_RELAXED) & LW_WRITER)
+		__atomic_store_n(&lock->state, 0u, __ATOMIC_RELEASE);
+	else
+		__atomic_sub_fetch(&lock->state, 1u, __ATOMIC_RELEASE);
 	futex_wake(&lock->state);
 }
 
@@ -1431,7 +1470,8 @@ void
 shim_postmaster_init(size_t page_store_bytes, size_t arena_bytes)
 {
 	size_t		shmem_bytes = 8u << 20;
-	size_t		total = ((sizeof(ShimShared) + 4095) & ~(size_t) 4095) + shmem_bytes + page_store_bytes + arena_bytes;
+	size_t		dsm_bytes = (size_t) 192 << 20;	/* (MAP_NORESERVE: only what is touched costs memory) */
+	size_t		total = ((sizeof(ShimShared) + 4095) & ~(size_t) 4095) + shmem_bytes + page_store_bytes + arena_bytes + dsm_bytes;
 
 	Sbase = mmap(NULL, total, PROT_READ | PROT_WRITE, MAP_SHARED | MAP_ANONYMOUS | MAP_NORESERVE, -1, 0);
 	if (Sbase == MAP_FAILED)
@@ -1449,8 +1489,31 @@ shim_postmaster_init(size_t page_store_bytes, size_t arena_bytes)
 	S->page_end = S->page_off + page_store_bytes;
 	S->arena_off = S->page_end;
 	S->arena_bytes = arena_bytes;
+	S->dsm_off = S->arena_off + arena_bytes;
+	S->dsm_bytes = dsm_bytes;
 	AddinShmemInitLock = &S->addin_lock;
 	MyProcPid = (int) getpid();
+}
+
+void *
+shim_shared_alloc(size_t bytes)
+{
+	uint64		at;
+
+	bytes = (bytes + 63) & ~(size_t) 63;
+	at = __atomic_fetch_add(&S->dsm_used, bytes, __ATOMIC_SEQ_CST);
+	if (at + bytes > S->dsm_bytes)
+	{
+		fprintf(stderr, "pgshim: shared pool exhausted (%zu more bytes asked for)\n", bytes);
+		abort();
+	}
+	return Sbase + S->dsm_off + at;	/* (fresh anonymous pages: zero) */
+}
+
+void **
+shim_shared_slot(int i)
+{
+	return &S->shared_slots[i];
 }
 
 void *

@@ -29,6 +29,10 @@ void		shim_postmaster_init(size_t page_store_bytes, size_t arena_bytes);
 /* the arena the mock device carves its "device memory" from, so that an exported index is visible in every process
  * forked from the postmaster (NULL / 0 without one) */
 void	   *shim_arena_base(size_t *bytes);
+/* bytes from a pool inside the postmaster's mapping: zeroed, at the same address in every process, never given back (the
+ * stand-in's dynamic shared memory segments; rows a test wants every process to see) */
+void	   *shim_shared_alloc(size_t bytes);
+void	  **shim_shared_slot(int i);	/* eight pointer-sized words of shared memory for whoever needs to publish an address */
 /* runs the shmem request / startup hooks a preloaded library installed */
 void		shim_postmaster_run_shmem_hooks(void);
 void		shim_register_bgworker_function(const char *name, void (*fn) (Datum));
@@ -84,6 +88,10 @@ typedef struct ShimHeapDef
 }			ShimHeapDef;
 #define SHIM_HEAP_OID 999
 Relation	shim_heap_relation(const ShimHeapDef * def);
+Relation	shim_heap_attach(void);	/* the heap another process defined (a parallel worker's table_open); NULL: none */
+/* how many workers plan_create_index_workers grants the next CREATE INDEX of this process (0: a serial build) */
+void		shim_set_parallel_workers(int n);
+void		ParallelWorkerMain(Datum main_arg);	/* register with shim_register_bgworker_function("ParallelWorkerMain", ..) */
 /* input tuple i of a build's tuplesort (before or after tuplesort_performsort: the order they were put in) */
 struct Tuplesortstate;
 int64_t		shim_tuplesort_inputs(struct Tuplesortstate *state);
@@ -110,6 +118,8 @@ MemoryContext shim_context_create(void);
 void		shim_context_delete(MemoryContext ctx);
 void		shim_set_guc_bool(const char *name, bool value);
 void		shim_set_guc_int(const char *name, int value);
+int			shim_guc_snapshot(int *out, int cap);	/* every registered GUC of this process, in registration order */
+void		shim_guc_restore(const int *in, int n);
 void		shim_relcache_invalidate(Oid relid);
 void		shim_run_proc_exit(int code);	/* before_shmem_exit + on_proc_exit callbacks (a clean backend exit) */
 double		shim_now(void);

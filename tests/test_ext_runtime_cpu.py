@@ -108,7 +108,17 @@ def test_the_references_own_ivfflatgettuple_runs_with_the_hooks(tmp_path, saniti
     vector.gpu on the hook lines INSIDE the reference's build serve k-means and every argmin (ivfflat) and link every
     deferred element in FlushPages (hnsw); the reference sorts and writes, and its scan / walk, the oracle's page reader and
     the device over the mirror the worker stages agree.  A third hnsw build with maintenance_work_mem too small takes the
-    NOTICE's FlushPages halfway through the heap scan and HnswInsertTupleOnDisk for the rest."""
+    NOTICE's FlushPages halfway through the heap scan and HnswInsertTupleOnDisk for the rest.
+
+    And PARALLEL builds (amcanbuildparallel: what the server does for any table of more than a few MB): phase "the
+    reference's own parallel CREATE INDEX" grants two workers; the reference's IvfflatBeginParallel / ParallelBuildMain /
+    ParallelScanAndSort and HnswBeginParallel / ParallelBuildMain / ParallelScanAndInsert run in a leader and two worker
+    processes the stand-in postmaster forks (shared-memory segment, parallel block scan, the workers' sorted runs merged
+    by the leader: tests/c/pgshim_ref_runtime.c).  ivfflat on the CPU path: the three processes write the serial build's
+    = the oracle's lists.  ivfflat with vector.gpu on: EVERY participant runs the build hooks on a device context of its
+    own (three "rows assigned on the device" flushes of 1840-1850 rows) and the index is complete and correct.  hnsw with
+    vector.gpu on: every participant notices the shared graph area on its first tuple and inserts on the reference's path
+    (deferring there left the index empty); the index holds every row."""
     import __graft_entry__ as entry     # ONE recipe: the program the GPU box runs is built by the same function
     flags = ["-fsanitize=address,undefined", "-fno-omit-frame-pointer"] if sanitize else []
     exe = entry.build_reference_driver(dict(os.environ), out=str(tmp_path / "ext_driver_ref"), mock=True, extra_flags=flags)
@@ -130,3 +140,13 @@ def test_the_references_own_ivfflatgettuple_runs_with_the_hooks(tmp_path, saniti
     assert any("the reference's own hnswbuild" in line and ": ok" in line for line in r.stderr.splitlines()), r.stderr[-3000:]
     assert "= the oracle's graph" in r.stderr and "levels, every neighbor slot, the entry point" in r.stderr, r.stderr[-3000:]
     assert "NOTICE:  hnsw graph no longer fits into maintenance_work_mem" in r.stderr, r.stderr[-3000:]
+    assert any("the reference's own parallel CREATE INDEX" in line and ": ok" in line for line in r.stderr.splitlines()), r.stderr[-3000:]
+    lines = r.stderr.splitlines()
+    par = lines[next(i for i, line in enumerate(lines) if "phase the reference's own hnswbuild" in line):]
+    assert sum("using 2 parallel workers" in line for line in par) == 3, r.stderr[-3000:]
+    # the stand-in deals the table's blocks round-robin: 2000 heap rows to each of the three participants, twice
+    assert sum("worker processed 2000 tuples" in line for line in par) == 4 and sum("leader processed 2000 tuples" in line for line in par) == 2
+    # vector.gpu = on: each participant flushed its share through the device (NULL rows are skipped before the hook)
+    flushed = [int(line.split("path: ")[1].split()[0]) for line in par if "rows assigned on the device" in line]
+    assert len(flushed) == 3 and sum(flushed) == 5539 and min(flushed) > 1800, flushed
+    assert sum("parallel hnsw build, this participant inserts on the CPU path" in line for line in par) == 3, r.stderr[-3000:]
