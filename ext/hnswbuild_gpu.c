@@ -88,6 +88,12 @@ PgvHnswBuildBegin(HnswBuildState * buildstate)
 	/* FUNCTION 1 of the opclass; rows that FUNCTION 2 normalised (cosine) are compared by inner product */
 	gb->metric = HnswOptionalProcInfo(buildstate->index, HNSW_NORM_PROC) != NULL ? PGV_NEG_IP : PgvHnswMetricOf(buildstate->index);
 	gb->rowBytes = (dtype == PGV_F32 ? sizeof(float) : sizeof(uint16)) * (Size) buildstate->dimensions;
+	/* maintenance_work_mem covers the link phase too: PgvHnswBuildLink copies every element's value into dense rows and
+	 * pgv_host_hnsw_build keeps its own neighbor tables -- about the graph's size again, held while the graph still is.
+	 * InitGraph (src/hnswbuild.c:615-634) has just given the graph the whole budget: it gets half, the "no longer fits"
+	 * flush comes at half the tuples, and the peak stays inside what the user allowed.  (The participants of a
+	 * parallel build switch to the shared graph after this and never link: their budget is untouched.) */
+	buildstate->graphData.memoryTotal /= 2;
 	return gb;
 }
 

@@ -3294,7 +3294,7 @@ backend_reference_hnswbuild(void *arg)
 		int			found = 0;
 
 		shim_replace_pages(REL_HRBUILD, empty, 0);
-		maintenance_work_mem = 768;	/* kB: room for about half of the elements */
+		maintenance_work_mem = 2300;	/* kB: the graph gets half of it (the hook reserves the rest for the link phase), the deferred-elements array takes 512 kB: room for about half of the elements */
 		shim_set_guc_bool("vector.gpu", true);
 		ctx = shim_query_context_begin();
 		res = hnswbuild(heap, index, &info);
