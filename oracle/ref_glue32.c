@@ -134,6 +134,13 @@ pgshim_errmsg(const char *fmt,...)
 	va_end(ap);
 	return 0;
 }
+/* errdetail / errhint (ext/shim/pgshim_ref.h): the primary message is the one the tests compare */
+int
+pgshim_errmore(const char *fmt,...)
+{
+	(void) fmt;
+	return 0;
+}
 static void
 ref_raise(void)
 {

@@ -48,7 +48,12 @@ NOT_REACHED(pq_sendfloat4)
 NOT_REACHED(pq_sendint16)
 NOT_REACHED(scanner_isspace)
 
-#if defined(PGV_HAVE_REF_HNSW) && defined(PGV_HAVE_REF_IVFINSERT)
+#if defined(PGV_HAVE_REF_HALFVEC)
+/* the reference's src/halfvec.c + src/halfutils.c are in the program too: halfvec_l2_normalize is theirs; what halfvec.c's
+ * text output names and no index path reaches */
+NOT_REACHED(float_to_shortest_decimal_buf)
+NOT_REACHED(sparsevec_l2_normalize)
+#elif defined(PGV_HAVE_REF_HNSW) && defined(PGV_HAVE_REF_IVFINSERT)
 NOT_REACHED(halfvec_l2_normalize)
 NOT_REACHED(sparsevec_l2_normalize)
 #elif defined(PGV_HAVE_REF_HNSW)

@@ -3610,6 +3610,476 @@ backend_reference_parallel_build(void *arg)
 }
 #endif
 
+#if defined(PGV_HAVE_REF_HALFVEC) && defined(PGV_HAVE_REF_IVFBUILD) && defined(PGV_HAVE_REF_HNSWBUILD)
+/* ------------------------------------------------------------------------------------------------ the reference's own halfvec opclasses
+ * halfvec_l2_ops on both access methods (sql/vector.sql:819-866): the program also holds pgvector's src/halfvec.c and
+ * src/halfutils.c (HalfvecInit has picked the F16C kernels where the CPU has them), and two relations are created with the
+ * halfvec opclass -- FUNCTION 1-4 are halfvec_l2_squared_distance / halfvec_l2_norm / halfvec_l2_distance, FUNCTION 5 / 3
+ * the type-info functions ivfflat_halfvec_support / hnsw_halfvec_support of src/ivfutils.c / src/hnswutils.c
+ * (HalfvecSumCenter, HalfvecUpdateCenter with its round-to-half, item size 8 + 2 d, 2 x the dimensions).  BASELINE's
+ * configs[4] is this type.
+ *   vector.gpu = off, the oracle's pg_prng stream: the reference's serial ivfflatbuild over fp16 rows = the oracle's
+ *     (ora_kmeans / ora_ivf_assign with ORA_F16: centers bit for bit as halves, every list in order); its scan of the pages
+ *     = the oracle's page reader; its serial hnswbuild = ora_hnsw_build's graph, slot for slot.
+ *   vector.gpu = on: the hooks see maxDimensions 2 x IVFFLAT_MAX_DIM / HNSW_MAX_DIM and take the PGV_F16 kernels: build,
+ *     staged mirror, scans and walks against the reference's CPU branch. */
+#define REL_HVIVF 1010
+#define REL_HVHNSW 2005
+#define HDIM 64					/* 8 + 128 bytes a value: a 4-byte varlena header in the index tuple, like every real halfvec index row */
+
+static void *
+make_halfvec(const uint16 *x, int dim)
+{
+	Size		size = offsetof(Vector, x) + sizeof(uint16) * (Size) dim;	/* HalfVector: the same 8-byte header (src/halfvec.h:68-74) */
+	Vector	   *v = palloc0(size);
+
+	v->vl_len_ = (int32) (size << 2);
+	v->dim = (int16) dim;
+	memcpy(v->x, x, sizeof(uint16) * (Size) dim);
+	return v;
+}
+
+typedef struct HalfRows
+{
+	const uint16 *rows;
+	int			dim;
+	int			null_every;
+}			HalfRows;
+
+static void
+half_fetch(int64_t row, Datum *value, bool *isnull, ItemPointerData *tid, void *arg)
+{
+	const HalfRows *h = arg;
+
+	*tid = itemptr(tid_of_row((int) row));
+	*isnull = h->null_every > 0 && row % h->null_every == h->null_every - 1;
+	*value = *isnull ? (Datum) 0 : PointerGetDatum(make_halfvec(h->rows + (size_t) row * h->dim, h->dim));
+}
+
+static int
+ref_scan_half(Relation index, const uint16 *query, int probes, int want, uint64 *got, int *used_gpu)
+{
+	MemoryContext ctx = shim_query_context_begin();
+	ScanKeyData orderby;
+	IndexScanDesc scan;
+	int			n = 0;
+
+	ivfflat_probes = probes;
+	memset(&orderby, 0, sizeof(orderby));
+	orderby.sk_argument = PointerGetDatum(make_halfvec(query, HDIM));
+	scan = ivfflatbeginscan(index, 0, 1);
+	ivfflatrescan(scan, NULL, 0, &orderby, 1);
+	*used_gpu = ((IvfflatScanOpaque) scan->opaque)->gpu != NULL;
+	while (n < want && ivfflatgettuple(scan, ForwardScanDirection))
+		got[n++] = tid_key(&scan->xs_heaptid);
+	ivfflatendscan(scan);
+	shim_query_context_end(ctx);
+	return n;
+}
+
+static int
+ref_hnsw_scan_half(Relation index, const uint16 *query, int want, uint64 *got, int *had_gpu, long *reads)
+{
+	MemoryContext ctx = shim_query_context_begin();
+	ScanKeyData orderby;
+	IndexScanDesc scan;
+	long		reads0;
+	int			n = 0;
+
+	memset(&orderby, 0, sizeof(orderby));
+	orderby.sk_argument = PointerGetDatum(make_halfvec(query, HDIM));
+	scan = hnswbeginscan(index, 0, 1);
+	hnswrescan(scan, NULL, 0, &orderby, 1);
+	*had_gpu = ((HnswScanOpaque) scan->opaque)->gpu != NULL;
+	reads0 = shim_buffer_reads();
+	while (n < want && hnswgettuple(scan, ForwardScanDirection))
+		got[n++] = tid_key(&scan->xs_heaptid);
+	*reads = shim_buffer_reads() - reads0;
+	hnswendscan(scan);
+	shim_query_context_end(ctx);
+	return n;
+}
+
+/* got[0..n) against the oracle's reading of the relation's pages for a halfvec query (the stream of the probed lists) */
+static int
+check_half_scan(Oid relid, const uint16 *q, int probes, const uint64 *got, int n, int want, const char *what)
+{
+	uint32_t	nblocks;
+	const uint8_t *pages = shim_relation_pages(relid, &nblocks);
+	const int	cap = 1 << 16;
+	uint64	   *tids = malloc(sizeof(uint64) * (size_t) cap);
+	double	   *dist = malloc(sizeof(double) * (size_t) cap);
+	int64_t		scanned = 0;
+	int			en = ora_pages_search(pages, nblocks, ORA_OPS_L2, ORA_F16, q, probes, cap, tids, dist, &scanned);
+	int			bad = 0;
+
+	if (n != (want < en ? want : en))
+	{
+		fprintf(stderr, "[%s] %s: %d tuples, the oracle's stream has %d (asked for %d)\n", scenario, what, n, en, want);
+		bad = 1;
+	}
+	for (int i = 0; i < n && !bad; i++)
+	{
+		double		d = -1;
+
+		for (int j = 0; j < en; j++)
+			if (tids[j] == got[i])
+			{
+				d = dist[j];
+				break;
+			}
+		if (d < 0 || fabs(d - dist[i]) > 1e-4 * fabs(dist[i]) + 1e-6)
+		{
+			fprintf(stderr, "[%s] %s: position %d (tid %llx) at %.9g, the oracle's stream has %.9g there\n", scenario, what, i,
+					(unsigned long long) got[i], d, dist[i]);
+			bad = 1;
+		}
+	}
+	free(tids);
+	free(dist);
+	return bad;
+}
+
+static int
+backend_reference_halfvec(void *arg)
+{
+	Relation	index = shim_open_relation(REL_HVIVF);
+	Relation	hindex = shim_open_relation(REL_HVHNSW);
+	const int	n = 4000,
+				lists = 16,
+				hn = 2000,
+				m = HM,
+				efc = 32;
+	float	   *frows = malloc(sizeof(float) * (size_t) n * HDIM);
+	uint16	   *rows = malloc(sizeof(uint16) * (size_t) n * HDIM);
+	uint16	   *live = malloc(sizeof(uint16) * (size_t) n * HDIM);
+	int		   *live_row = malloc(sizeof(int) * (size_t) n);
+	uint64	   *got = malloc(sizeof(uint64) * 30000);
+	HalfRows	h;
+	ShimHeapDef def;
+	Relation	heap;
+	IndexInfo	info;
+	IndexBuildResult *res;
+	MemoryContext ctx;
+	int			nlive = 0,
+				used_gpu;
+	uint8_t		empty[1] = {0};
+
+	(void) arg;
+	scenario = "the reference's own halfvec opclasses";
+	EXPECT(index != NULL && hindex != NULL);
+	EXPECT(IvfflatGetTypeInfo(index)->maxDimensions == IVFFLAT_MAX_DIM * 2 && HnswGetTypeInfo(hindex)->maxDimensions == HNSW_MAX_DIM * 2);
+	gen_rows(frows, n, HDIM, 71);
+	for (size_t i = 0; i < (size_t) n * HDIM; i++)
+		rows[i] = ora_float_to_half(frows[i]);
+	h.rows = rows;
+	h.dim = HDIM;
+	h.null_every = 19;
+	def.nrows = n;
+	def.rows_per_block = 50;
+	def.fetch = half_fetch;
+	def.arg = &h;
+	heap = shim_heap_relation(&def);
+	for (int r = 0; r < n; r++)
+		if (r % 19 != 18)
+		{
+			memcpy(live + (size_t) nlive * HDIM, rows + (size_t) r * HDIM, sizeof(uint16) * HDIM);
+			live_row[nlive++] = r;
+		}
+	memset(&info, 0, sizeof(info));
+
+	/* ---- ivfflat (halfvec_l2_ops): the reference's serial build = the oracle's, in halves */
+	{
+		ora_prng	a,
+					b;
+		uint16	   *want_centers = malloc(sizeof(uint16) * (size_t) lists * HDIM);
+		int32_t    *want_list = malloc(sizeof(int32_t) * (size_t) nlive);
+		pgv_ivf_image img;
+		pgv_rel		rel;
+		uint32_t	nblocks;
+		int			iterations;
+
+		shim_set_guc_bool("vector.gpu", false);
+		ora_prng_seed(&a, 101);
+		shim_prng_hook(ora_prng_double_cb, ora_prng_u32_cb, &a);
+		ctx = shim_query_context_begin();
+		res = ivfflatbuild(heap, index, &info);
+		shim_prng_hook(NULL, NULL, NULL);
+		EXPECT(res != NULL && (int) res->heap_tuples == n && (int) res->index_tuples == nlive);
+		shim_query_context_end(ctx);
+		EXPECT(shim_pinned_buffers() == 0);
+		ora_prng_seed(&b, 101);
+		(void) ora_prng_u32(&b);
+		(void) ora_prng_u32(&b);
+		iterations = ora_kmeans(ORA_OPS_L2, ORA_F16, HDIM, live, nlive, want_centers, lists, &b, NULL);
+		EXPECT(iterations >= 0 && a.s0 == b.s0 && a.s1 == b.s1);
+		ora_ivf_assign(ORA_OPS_L2, ORA_F16, HDIM, want_centers, lists, live, nlive, want_list, NULL);
+		pgv_rel_init(&rel);
+		rel.pages = (uint8_t *) shim_relation_pages(REL_HVIVF, &nblocks);
+		rel.nblocks = rel.cap = nblocks;
+		EXPECT(pgv_host_ivf_stage(&rel, PGV_F16, &img) == PGV_OK);
+		EXPECT(img.dim == HDIM && img.lists == lists && img.nrows == nlive);
+		if (memcmp(img.centers, want_centers, sizeof(uint16) * (size_t) lists * HDIM) != 0)
+		{
+			fprintf(stderr, "halfvec: the centers in the reference's list pages are not the oracle's\n");
+			return 1;
+		}
+		for (int l = 0; l < lists; l++)
+		{
+			int64_t		p = img.list_offsets[l];
+
+			for (int i = 0; i < nlive; i++)
+				if (want_list[i] == l)
+				{
+					if (p >= img.list_offsets[l + 1] || img.tids[p] != tid_of_row(live_row[i]) ||
+						memcmp((const uint16 *) img.vectors + (size_t) p * HDIM, live + (size_t) i * HDIM, sizeof(uint16) * HDIM) != 0)
+					{
+						fprintf(stderr, "halfvec: list %d of the reference's build: position %lld is not the oracle's row %d\n", l,
+								(long long) (p - img.list_offsets[l]), live_row[i]);
+						return 1;
+					}
+					p++;
+				}
+			EXPECT(p == img.list_offsets[l + 1]);
+		}
+		pgv_host_ivf_image_free(&img);
+		/* the reference's scan (halfvec_l2_squared_distance through the F16C or the default kernel) = the oracle's reader */
+		for (int i = 0; i < 10; i++)
+		{
+			const uint16 *q = rows + (size_t) live_row[(113 * i) % nlive] * HDIM;
+			int			want = i % 3 == 2 ? 250 : 10;
+			int			nn = ref_scan_half(index, q, PROBES, want, got, &used_gpu);
+
+			EXPECT(!used_gpu && got[0] == tid_of_row(live_row[(113 * i) % nlive]));
+			if (check_half_scan(REL_HVIVF, q, PROBES, got, nn, want, "halfvec, the reference's CPU build and scan"))
+				return 1;
+		}
+		fprintf(stderr, "   halfvec_l2_ops ivfflat: the reference's serial build (%d rows x %d halves, %d lists, %d Elkan iterations) = the oracle's: centers bit for bit, every list in order; its scan = the oracle's page reader\n",
+				n, HDIM, lists, iterations);
+		free(want_centers);
+		free(want_list);
+	}
+
+	/* ---- ivfflat with the hooks: PGV_F16 k-means, argmins, mirror, scans */
+	shim_replace_pages(REL_HVIVF, empty, 0);
+	shim_set_guc_bool("vector.gpu", true);
+	shim_set_guc_bool("vector.gpu_pooled", false);
+	shim_seed_random(103);
+	ctx = shim_query_context_begin();
+	res = ivfflatbuild(heap, index, &info);
+	EXPECT(res != NULL && (int) res->heap_tuples == n && (int) res->index_tuples == nlive);
+	shim_query_context_end(ctx);
+	EXPECT(shim_notices_raised("pgvector GPU path: 3790 rows assigned on the device") == 1);	/* 4000 less 210 NULLs */
+	{
+		pgv_ivf_image img;
+		pgv_rel		rel;
+		uint32_t	nblocks;
+		char	   *seen = calloc((size_t) n, 1);
+
+		pgv_rel_init(&rel);
+		rel.pages = (uint8_t *) shim_relation_pages(REL_HVIVF, &nblocks);
+		rel.nblocks = rel.cap = nblocks;
+		EXPECT(pgv_host_ivf_stage(&rel, PGV_F16, &img) == PGV_OK);
+		EXPECT(img.lists == lists && img.nrows == nlive);
+		for (int l = 0; l < lists; l++)
+			for (int64_t p = img.list_offsets[l]; p < img.list_offsets[l + 1]; p++)
+			{
+				const int	r = row_of_tid(img.tids[p]);
+				const uint16 *x = (const uint16 *) img.vectors + (size_t) p * HDIM;
+				double		best = INFINITY,
+							mine;
+
+				EXPECT(r >= 0 && r < n && !seen[r] && r % 19 != 18);
+				seen[r] = 1;
+				EXPECT(memcmp(x, rows + (size_t) r * HDIM, sizeof(uint16) * HDIM) == 0);
+				for (int c = 0; c < lists; c++)
+				{
+					double		d = ora_index_distance(ORA_OPS_L2, ORA_F16, HDIM, x, (const uint16 *) img.centers + (size_t) c * HDIM);
+
+					if (d < best)
+						best = d;
+				}
+				mine = ora_index_distance(ORA_OPS_L2, ORA_F16, HDIM, x, (const uint16 *) img.centers + (size_t) l * HDIM);
+				EXPECT(mine <= best + 1e-5 * fabs(best) + 1e-9);
+			}
+		pgv_host_ivf_image_free(&img);
+		free(seen);
+	}
+	{
+		double		until = shim_now() + 30.0;
+
+		for (;;)
+		{
+			(void) ref_scan_half(index, rows, PROBES, 1, got, &used_gpu);
+			if (used_gpu || shim_now() > until)
+				break;
+			usleep(20000);
+		}
+		EXPECT(used_gpu);
+	}
+	for (int i = 0; i < 12; i++)
+	{
+		const uint16 *q = rows + (size_t) live_row[(127 * i + 3) % nlive] * HDIM;
+		int			want = i % 3 == 2 ? 250 : 10;
+		int			nn = ref_scan_half(index, q, PROBES, want, got, &used_gpu);
+
+		EXPECT(used_gpu && got[0] == tid_of_row(live_row[(127 * i + 3) % nlive]));
+		if (check_half_scan(REL_HVIVF, q, PROBES, got, nn, want, "halfvec, build and scan through the hooks"))
+			return 1;
+	}
+	fprintf(stderr, "   halfvec_l2_ops ivfflat with the hooks (PGV_F16 k-means, %d argmins, mirror, scans): every row in a nearest list; device scans = the oracle's page reader\n",
+			nlive);
+
+	/* ---- hnsw (halfvec_l2_ops): the reference's serial in-memory build = the oracle's graph */
+	{
+		ora_prng	a;
+		ora_hnsw   *g;
+		pgv_hnsw_image img;
+		pgv_rel		rel;
+		uint32_t	nblocks;
+		int64_t		ne;
+		int			hlive = 0,
+					entry_level;
+		int		   *slot_of_row = malloc(sizeof(int) * (size_t) hn);
+		int		   *slot_of_element;
+		uint64		cpu[64],
+					gpu[64];
+		int			had_gpu;
+		long		reads;
+
+		for (int r = 0; r < hn; r++)
+			hlive += r % 19 != 18;
+		def.nrows = hn;
+		heap = shim_heap_relation(&def);
+		hnsw_ef_search = 40;
+		shim_set_guc_bool("vector.gpu", false);
+		ora_prng_seed(&a, 107);
+		shim_prng_hook(ora_prng_double_cb, ora_prng_u32_cb, &a);
+		ctx = shim_query_context_begin();
+		res = hnswbuild(heap, hindex, &info);
+		shim_prng_hook(NULL, NULL, NULL);
+		EXPECT(res != NULL && (int) res->heap_tuples == hn && (int) res->index_tuples == hlive);
+		shim_query_context_end(ctx);
+		g = ora_hnsw_build(ORA_OPS_L2, ORA_F16, HDIM, live, hlive, m, efc, 107);
+		EXPECT(g != NULL);
+		ne = ora_hnsw_num_elements(g);
+		pgv_rel_init(&rel);
+		rel.pages = (uint8_t *) shim_relation_pages(REL_HVHNSW, &nblocks);
+		rel.nblocks = rel.cap = nblocks;
+		EXPECT(pgv_host_hnsw_stage(&rel, PGV_F16, &img) == PGV_OK);
+		EXPECT(img.dim == HDIM && img.m == m && img.n == ne);
+		for (int r = 0; r < hn; r++)
+			slot_of_row[r] = -1;
+		for (int64_t s = 0; s < img.n; s++)
+		{
+			int			r = row_of_tid(img.heaptids[(size_t) s * 10]);
+
+			EXPECT(r >= 0 && r < hn && slot_of_row[r] == -1);
+			slot_of_row[r] = (int) s;
+		}
+		slot_of_element = malloc(sizeof(int) * (size_t) ne);
+		for (int64_t e = 0; e < ne; e++)
+		{
+			slot_of_element[e] = slot_of_row[live_row[ora_hnsw_element_row(g, e)]];
+			EXPECT(slot_of_element[e] >= 0);
+		}
+		for (int64_t e = 0; e < ne; e++)
+		{
+			const int	s = slot_of_element[e];
+			const int	level = ora_hnsw_level(g, e);
+
+			EXPECT(img.levels[s] == level);
+			EXPECT(memcmp((const uint16 *) img.vectors + (size_t) s * HDIM, live + (size_t) ora_hnsw_element_row(g, e) * HDIM, sizeof(uint16) * HDIM) == 0);
+			for (int lc = level; lc >= 0; lc--)
+			{
+				int32_t		want[2 * HM];
+				const int	lm = lc == 0 ? 2 * m : m;
+				const int	nw = ora_hnsw_neighbors(g, e, lc, want);
+				const int32_t *have = img.nbr + img.nbr_start[s] + (int64_t) (level - lc) * m;
+
+				for (int i = 0; i < lm; i++)
+					if (have[i] != (i < nw ? slot_of_element[want[i]] : -1))
+					{
+						fprintf(stderr, "halfvec hnsw: element %lld layer %d slot %d: the reference's neighbor tuple has %d, the oracle's array %d\n",
+								(long long) e, lc, i, have[i], i < nw ? slot_of_element[want[i]] : -1);
+						return 1;
+					}
+			}
+		}
+		EXPECT(img.entry == slot_of_element[ora_hnsw_entry_point(g, &entry_level)]);
+		fprintf(stderr, "   halfvec_l2_ops hnsw: the reference's serial build (%d rows, m %d) = the oracle's graph: %lld elements, levels, every neighbor slot, the entry point\n",
+				hn, m, (long long) ne);
+		pgv_host_hnsw_image_free(&img);
+		ora_hnsw_free(g);
+		free(slot_of_element);
+		free(slot_of_row);
+
+		/* the hooks: every element deferred, linked by the PGV_F16 kernels; the reference's walk of its own pages against
+		 * the device walk over the staged mirror */
+		shim_replace_pages(REL_HVHNSW, empty, 0);
+		shim_set_guc_bool("vector.gpu", true);
+		shim_seed_random(109);
+		for (int i = 0; i < 16; i++)
+			(void) RandomDouble();
+		ctx = shim_query_context_begin();
+		res = hnswbuild(heap, hindex, &info);
+		EXPECT(res != NULL && (int) res->heap_tuples == hn && (int) res->index_tuples == hlive);
+		shim_query_context_end(ctx);
+		{
+			double		until = shim_now() + 30.0;
+
+			for (;;)
+			{
+				(void) ref_hnsw_scan_half(hindex, rows, 1, gpu, &had_gpu, &reads);
+				if ((had_gpu && reads == 0) || shim_now() > until)
+					break;
+				usleep(20000);
+			}
+			EXPECT(had_gpu && reads == 0);
+		}
+		for (int i = 0; i < 24; i++)
+		{
+			int			r = (71 * i + 5) % hn;
+			const uint16 *q;
+			int			nc,
+						ng;
+
+			while (r % 19 == 18)
+				r++;
+			q = rows + (size_t) r * HDIM;
+			shim_set_guc_bool("vector.gpu", false);
+			nc = ref_hnsw_scan_half(hindex, q, 48, cpu, &had_gpu, &reads);
+			EXPECT(!had_gpu && reads > 0 && nc >= 40);
+			shim_set_guc_bool("vector.gpu", true);
+			ng = ref_hnsw_scan_half(hindex, q, 48, gpu, &had_gpu, &reads);
+			EXPECT(had_gpu && reads == 0 && ng == nc);
+			EXPECT(cpu[0] == tid_of_row(r) && gpu[0] == tid_of_row(r));
+			/* position by position the same distance (rows at float-equal distances may swap) */
+			for (int j = 0; j < nc; j++)
+			{
+				const int	rc = row_of_tid(cpu[j]),
+							rg = row_of_tid(gpu[j]);
+				double		dc = ora_index_distance(ORA_OPS_L2, ORA_F16, HDIM, q, rows + (size_t) rc * HDIM),
+							dg = ora_index_distance(ORA_OPS_L2, ORA_F16, HDIM, q, rows + (size_t) rg * HDIM);
+
+				if (fabs(dc - dg) > 1e-4 * fabs(dc) + 1e-6)
+				{
+					fprintf(stderr, "halfvec hnsw: position %d: the reference's walk has row %d at %.7g, the device's row %d at %.7g\n", j, rc, dc, rg, dg);
+					return 1;
+				}
+			}
+		}
+		fprintf(stderr, "   halfvec_l2_ops hnsw with the hooks: every element linked by the fp16 kernels; the reference's walk and the device walk agree\n");
+	}
+	free(frows);
+	free(rows);
+	free(live);
+	free(live_row);
+	free(got);
+	return 0;
+}
+#endif
+
 int
 main(void)
 {
@@ -3626,12 +4096,19 @@ main(void)
 	setenv("MOCK_HIP_EXPORT_FAIL_EVERY", "9", 1);
 	board = mmap(NULL, sizeof(Board), PROT_READ | PROT_WRITE, MAP_SHARED | MAP_ANONYMOUS, -1, 0);
 	memset((void *) board, 0, sizeof(Board));
-	shim_postmaster_init((size_t) 512 << 20, mock_hip_set_arena ? (size_t) 512 << 20 : 0);
+	shim_postmaster_init((size_t) 640 << 20, mock_hip_set_arena ? (size_t) 512 << 20 : 0);
 	arena = shim_arena_base(&arena_bytes);
 	if (mock_hip_set_arena && arena)
 		mock_hip_set_arena(arena, arena_bytes);
 	/* shared_preload_libraries = 'vector': _PG_init in the postmaster */
 	process_shared_preload_libraries_in_progress = true;
+#ifdef PGV_HAVE_REF_HALFVEC
+	{
+		extern void HalfvecInit(void);
+
+		HalfvecInit();			/* (_PG_init, src/vector.c:59: the reference's src/halfutils.c picks its kernels by CPUID) */
+	}
+#endif
 	PgvGpuInit();
 	shim_postmaster_run_shmem_hooks();
 	shim_register_bgworker_function("PgvWorkerMain", PgvWorkerMain);
@@ -3659,6 +4136,17 @@ main(void)
 #ifdef PGV_HAVE_REF_HNSWBUILD
 	shim_create_relation(REL_HRBUILD, &hnsw_l2, empty, 0, DIM);
 	shim_set_reloptions(REL_HRBUILD, HM, 32);	/* WITH (m = 8, ef_construction = 32) */
+#endif
+#if defined(PGV_HAVE_REF_HALFVEC) && defined(PGV_HAVE_REF_IVFBUILD) && defined(PGV_HAVE_REF_HNSWBUILD)
+	{
+		ShimOpclass half_l2 = {0, IVFFLAT_MAX_DIM * 2, false, false, 0, 1};	/* halfvec_l2_ops */
+		ShimOpclass hnsw_half_l2 = {1, HNSW_MAX_DIM * 2, false, false, 0, 1};
+
+		shim_create_relation(REL_HVIVF, &half_l2, empty, 0, HDIM);
+		shim_set_reloptions(REL_HVIVF, 16, 0);
+		shim_create_relation(REL_HVHNSW, &hnsw_half_l2, empty, 0, HDIM);
+		shim_set_reloptions(REL_HVHNSW, HM, 32);
+	}
 #endif
 
 	failed |= run_phase("CREATE INDEX through the build hooks", backend_build, 1, NULL, 300.0);
@@ -3750,6 +4238,10 @@ main(void)
 #ifdef PGV_HAVE_REF_HNSWBUILD
 	if (!failed)
 		failed |= run_phase("the reference's own hnswbuild", backend_reference_hnswbuild, 1, NULL, 300.0);
+#endif
+#if defined(PGV_HAVE_REF_HALFVEC) && defined(PGV_HAVE_REF_IVFBUILD) && defined(PGV_HAVE_REF_HNSWBUILD)
+	if (!failed)
+		failed |= run_phase("the reference's own halfvec opclasses", backend_reference_halfvec, 1, NULL, 300.0);
 #endif
 #if defined(PGV_HAVE_REF_IVFBUILD) && defined(PGV_HAVE_REF_HNSWBUILD)
 	if (!failed)

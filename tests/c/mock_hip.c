@@ -104,8 +104,100 @@ dev_free(void *p)
 		free(p);
 }
 
+/* ---- fp16 at the door: the stand-in computes in fp32 only.  Halves are widened (exactly) where they come in -- index and
+ * element uploads, centers, rows, samples, queries -- and narrowed (round to nearest even, src/halfutils.h:146-233) where
+ * vectors go out (k-means centers, drained rows); an index / graph remembers that its callers speak fp16. */
+static float
+half_to_float(uint16_t h)
+{
+	uint32_t	sign = (uint32_t) (h & 0x8000u) << 16,
+				exp = (h >> 10) & 0x1fu,
+				man = h & 0x3ffu,
+				bits;
+	float		f;
+
+	if (exp == 0)
+	{
+		if (man == 0)
+			bits = sign;
+		else
+		{
+			/* subnormal half: normalise */
+			exp = 127 - 15 + 1;
+			while (!(man & 0x400u))
+			{
+				man <<= 1;
+				exp--;
+			}
+			bits = sign | (exp << 23) | ((man & 0x3ffu) << 13);
+		}
+	}
+	else if (exp == 31)
+		bits = sign | 0x7f800000u | (man << 13);
+	else
+		bits = sign | ((exp + 127 - 15) << 23) | (man << 13);
+	memcpy(&f, &bits, 4);
+	return f;
+}
+
+static uint16_t
+float_to_half(float f)
+{
+	uint32_t	bits;
+	uint32_t	sign,
+				man;
+	int			exp;
+
+	memcpy(&bits, &f, 4);
+	sign = (bits >> 16) & 0x8000u;
+	exp = (int) ((bits >> 23) & 0xffu) - 127 + 15;
+	man = bits & 0x7fffffu;
+	if (((bits >> 23) & 0xffu) == 0xffu)
+		return (uint16_t) (sign | 0x7c00u | (man ? 0x200u | (man >> 13) : 0));	/* inf / nan */
+	if (exp >= 31)
+		return (uint16_t) (sign | 0x7c00u);	/* overflow: inf */
+	if (exp <= 0)
+	{
+		uint32_t	m;
+		int			shift;
+
+		if (exp < -10)
+			return (uint16_t) sign;	/* underflow: zero */
+		m = man | 0x800000u;
+		shift = 14 - exp;		/* to a 10-bit subnormal mantissa */
+		{
+			uint32_t	q = m >> shift,
+						rem = m & ((1u << shift) - 1),
+						half = 1u << (shift - 1);
+
+			if (rem > half || (rem == half && (q & 1)))
+				q++;
+			return (uint16_t) (sign | q);
+		}
+	}
+	{
+		uint32_t	q = ((uint32_t) exp << 10) | (man >> 13),
+					rem = man & 0x1fffu;
+
+		if (rem > 0x1000u || (rem == 0x1000u && (q & 1)))
+			q++;				/* (a carry out of the mantissa bumps the exponent, up to inf: the right answer) */
+		return (uint16_t) (sign | q);
+	}
+}
+
+static float *
+widen(const void *halves, size_t count)
+{
+	float	   *out = malloc(sizeof(float) * (count > 0 ? count : 1));
+
+	for (size_t i = 0; i < count; i++)
+		out[i] = half_to_float(((const uint16_t *) halves)[i]);
+	return out;
+}
+
 struct pgv_index
 {
+	int			f16;			/* its callers hand in and take out halves */
 	pgv_metric	metric;
 	int			dim,
 				nlists;
@@ -119,6 +211,7 @@ struct pgv_index
 
 struct pgv_hnsw
 {
+	int			f16;
 	pgv_metric	metric;
 	int			dim;
 	int64_t		n;
@@ -206,8 +299,18 @@ pgv_index_upload(pgv_ctx * ctx, pgv_metric metric, pgv_dtype dtype, int dim, int
 	int64_t		n = list_offsets[nlists];
 
 	(void) ctx;
-	if (dtype != PGV_F32)
-		return fail(PGV_ERR_ARG, "mock: fp32 only");
+	if (dtype == PGV_F16)
+	{
+		float	   *wc = widen(centers, (size_t) nlists * dim),
+				   *wv = widen(vectors, (size_t) n * dim);
+		int			rc = pgv_index_upload(ctx, metric, PGV_F32, dim, nlists, wc, list_offsets, wv, tids, out);
+
+		free(wc);
+		free(wv);
+		if (rc == PGV_OK)
+			(*out)->f16 = 1;
+		return rc;
+	}
 	ix = dev_alloc(sizeof(*ix));
 	ix->refs = dev_alloc(sizeof(int));
 	*ix->refs = 1;
@@ -350,8 +453,8 @@ pgv_index_lists(const pgv_index * ix)
 }
 
 /* GetScanLists: the maxprobes nearest centers, ascending; a later center never displaces an equal one */
-int
-pgv_rank_lists(pgv_index * ix, const void *queries, int nq, int maxprobes, int32_t *out_lists, float *out_dist)
+static int
+rank_lists_f32(pgv_index * ix, const void *queries, int nq, int maxprobes, int32_t *out_lists, float *out_dist)
 {
 	float	   *d = malloc(sizeof(float) * (size_t) ix->nlists);
 	uint8_t    *used = malloc((size_t) ix->nlists);
@@ -382,8 +485,8 @@ pgv_rank_lists(pgv_index * ix, const void *queries, int nq, int maxprobes, int32
 }
 
 /* GetScanItems without the sort: every tuple of the given lists, in list order */
-int
-pgv_scan_lists(pgv_index * ix, const void *query, const int32_t *lists, int nlists, float *out_dist,
+static int
+scan_lists_f32(pgv_index * ix, const void *query, const int32_t *lists, int nlists, float *out_dist,
 			   int64_t *out_slot, int64_t capacity, int64_t *out_count)
 {
 	int64_t		m = 0;
@@ -420,8 +523,8 @@ mock_hip_search_peak(int reset)
 	return peak;
 }
 
-int
-pgv_search_batch(pgv_index * ix, const void *queries, int nq, int probes, int k, float *out_dist, int64_t *out_slot,
+static int
+search_batch_f32(pgv_index * ix, const void *queries, int nq, int probes, int k, float *out_dist, int64_t *out_slot,
 				 uint64_t *out_tid)
 {
 	int32_t    *lists = malloc(sizeof(int32_t) * (size_t) probes);
@@ -440,8 +543,8 @@ pgv_search_batch(pgv_index * ix, const void *queries, int nq, int probes, int k,
 		const float *qv = (const float *) queries + (size_t) q * ix->dim;
 		int64_t		m;
 
-		pgv_rank_lists(ix, qv, 1, probes, lists, NULL);
-		pgv_scan_lists(ix, qv, lists, probes, d, s, ix->n, &m);
+		rank_lists_f32(ix, qv, 1, probes, lists, NULL);
+		scan_lists_f32(ix, qv, lists, probes, d, s, ix->n, &m);
 		for (int r = 0; r < k; r++)
 		{
 			int64_t		best = -1;
@@ -466,6 +569,39 @@ pgv_search_batch(pgv_index * ix, const void *queries, int nq, int probes, int k,
 }
 
 /* pgv_query_*: one query's scan state; the sorted stream of the current batch is kept whole */
+/* the public three: halves widened at the door */
+int
+pgv_rank_lists(pgv_index * ix, const void *queries, int nq, int maxprobes, int32_t *out_lists, float *out_dist)
+{
+	float	   *w = ix->f16 && queries ? widen(queries, (size_t) nq * ix->dim) : NULL;
+	int			rc = rank_lists_f32(ix, w ? w : queries, nq, maxprobes, out_lists, out_dist);
+
+	free(w);
+	return rc;
+}
+
+int
+pgv_scan_lists(pgv_index * ix, const void *query, const int32_t *lists, int nlists, float *out_dist,
+			   int64_t *out_slot, int64_t capacity, int64_t *out_count)
+{
+	float	   *w = ix->f16 && query ? widen(query, (size_t) ix->dim) : NULL;
+	int			rc = scan_lists_f32(ix, w ? w : query, lists, nlists, out_dist, out_slot, capacity, out_count);
+
+	free(w);
+	return rc;
+}
+
+int
+pgv_search_batch(pgv_index * ix, const void *queries, int nq, int probes, int k, float *out_dist, int64_t *out_slot,
+				 uint64_t *out_tid)
+{
+	float	   *w = ix->f16 && queries ? widen(queries, (size_t) nq * ix->dim) : NULL;
+	int			rc = search_batch_f32(ix, w ? w : queries, nq, probes, k, out_dist, out_slot, out_tid);
+
+	free(w);
+	return rc;
+}
+
 struct pgv_query
 {
 	pgv_index  *ix;
@@ -517,8 +653,12 @@ pgv_query_rank(pgv_query * q, const void *query, int max_probes)
 			q->lists[i] = i;
 		return PGV_OK;
 	}
-	memcpy(q->q, query, sizeof(float) * (size_t) q->ix->dim);
-	return pgv_rank_lists(q->ix, query, 1, max_probes, q->lists, NULL);
+	if (q->ix->f16)
+		for (int i = 0; i < q->ix->dim; i++)
+			q->q[i] = half_to_float(((const uint16_t *) query)[i]);
+	else
+		memcpy(q->q, query, sizeof(float) * (size_t) q->ix->dim);
+	return rank_lists_f32(q->ix, q->q, 1, max_probes, q->lists, NULL);
 }
 
 int
@@ -561,7 +701,7 @@ pgv_query_scan(pgv_query * q, int first, int nprobes, int head, float *out_dist,
 	free(q->ss);
 	q->sd = malloc(sizeof(float) * (size_t) (cap + 1));
 	q->ss = malloc(sizeof(int64_t) * (size_t) (cap + 1));
-	pgv_scan_lists(q->ix, q->is_null ? NULL : q->q, q->lists + first, nprobes, q->sd, q->ss, cap, &got);
+	scan_lists_f32(q->ix, q->is_null ? NULL : q->q, q->lists + first, nprobes, q->sd, q->ss, cap, &got);
 	/* stable insertion sort: ascending distance, insertion order on ties */
 	for (int64_t i = 1; i < got; i++)
 	{
@@ -599,8 +739,16 @@ pgv_assign(pgv_ctx * ctx, pgv_metric metric, pgv_dtype dtype, int dim, const voi
 		   const void *rows, int64_t n, int32_t *out_list, float *out_dist)
 {
 	(void) ctx;
-	if (dtype != PGV_F32)
-		return fail(PGV_ERR_ARG, "mock: fp32 only");
+	if (dtype == PGV_F16)
+	{
+		float	   *wc = widen(centers, (size_t) k * dim),
+				   *wr = widen(rows, (size_t) n * dim);
+		int			rc = pgv_assign(ctx, metric, PGV_F32, dim, wc, k, wr, n, out_list, out_dist);
+
+		free(wc);
+		free(wr);
+		return rc;
+	}
 	for (int64_t i = 0; i < n; i++)
 	{
 		int			best = 0;
@@ -638,6 +786,7 @@ struct pgv_builder
 				cap;
 	int			has_tids;
 	int			deferred;
+	int			f16;
 	int64_t		assigned;
 };
 
@@ -648,15 +797,17 @@ pgv_builder_begin(pgv_ctx * ctx, pgv_metric metric, pgv_dtype dtype, int dim, in
 	pgv_builder *b;
 
 	(void) expected_rows;
-	if (dtype != PGV_F32)
-		return fail(PGV_ERR_ARG, "mock: fp32 only");
 	b = calloc(1, sizeof(*b));
 	b->ctx = ctx;
 	b->metric = metric;
 	b->dim = dim;
 	b->nlists = nlists;
+	b->f16 = dtype == PGV_F16;
 	b->centers = malloc(sizeof(float) * (size_t) nlists * dim);
-	if (centers)
+	if (centers && b->f16)
+		for (size_t i = 0; i < (size_t) nlists * dim; i++)
+			b->centers[i] = half_to_float(((const uint16_t *) centers)[i]);
+	else if (centers)
 		memcpy(b->centers, centers, sizeof(float) * (size_t) nlists * dim);
 	else
 		b->deferred = 1;
@@ -678,7 +829,11 @@ pgv_builder_set_centers(pgv_builder * b, const void *centers)
 {
 	if (!b->deferred)
 		return fail(PGV_ERR_STATE, "mock: the builder has its centers");
-	memcpy(b->centers, centers, sizeof(float) * (size_t) b->nlists * b->dim);
+	if (b->f16)
+		for (size_t i = 0; i < (size_t) b->nlists * b->dim; i++)
+			b->centers[i] = half_to_float(((const uint16_t *) centers)[i]);
+	else
+		memcpy(b->centers, centers, sizeof(float) * (size_t) b->nlists * b->dim);
 	b->deferred = 0;
 	return PGV_OK;
 }
@@ -693,7 +848,11 @@ pgv_builder_add(pgv_builder * b, const void *rows, const uint64_t *tids, int64_t
 		b->tids = realloc(b->tids, sizeof(uint64_t) * (size_t) b->cap);
 		b->lists = realloc(b->lists, sizeof(int32_t) * (size_t) b->cap);
 	}
-	memcpy(b->rows + (size_t) b->n * b->dim, rows, sizeof(float) * (size_t) n * b->dim);
+	if (b->f16)
+		for (size_t i = 0; i < (size_t) n * b->dim; i++)
+			b->rows[(size_t) b->n * b->dim + i] = half_to_float(((const uint16_t *) rows)[i]);
+	else
+		memcpy(b->rows + (size_t) b->n * b->dim, rows, sizeof(float) * (size_t) n * b->dim);
 	for (int64_t i = 0; i < n; i++)
 		b->tids[b->n + i] = tids ? tids[i] : (uint64_t) (b->n + i);
 	b->has_tids = tids != NULL;
@@ -740,6 +899,8 @@ pgv_builder_finish(pgv_builder * b, pgv_index * *out_index, int64_t *out_offsets
 		stids[d] = b->tids[r];
 	}
 	rc = pgv_index_upload(b->ctx, b->metric, PGV_F32, b->dim, b->nlists, b->centers, off, sorted, stids, out_index);
+	if (rc == PGV_OK)
+		(*out_index)->f16 = b->f16;
 	if (rc == PGV_OK && out_offsets)
 		memcpy(out_offsets, off, sizeof(int64_t) * ((size_t) b->nlists + 1));
 	if (rc == PGV_OK && out_lists)
@@ -773,13 +934,45 @@ pgv_index_drain(pgv_index * ix, int64_t chunk_rows, pgv_rows_sink sink, void *ar
 	{
 		int64_t		cnt = ix->n - r0 < chunk_rows ? ix->n - r0 : chunk_rows;
 
-		if (sink(arg, r0, cnt, ix->vectors + (size_t) r0 * ix->dim, ix->tids ? ix->tids + r0 : NULL) != 0)
+		uint16_t   *narrow = NULL;
+		int			stop;
+
+		if (ix->f16)
+		{
+			narrow = malloc(sizeof(uint16_t) * (size_t) cnt * ix->dim);
+			for (size_t i = 0; i < (size_t) cnt * ix->dim; i++)
+				narrow[i] = float_to_half(ix->vectors[(size_t) r0 * ix->dim + i]);	/* (exact: they came in as halves) */
+		}
+		stop = sink(arg, r0, cnt, narrow ? (const void *) narrow : (const void *) (ix->vectors + (size_t) r0 * ix->dim),
+					ix->tids ? ix->tids + r0 : NULL);
+		free(narrow);
+		if (stop != 0)
 			return fail(PGV_ERR_STATE, "mock: the sink stopped the drain");
 	}
 	return PGV_OK;
 }
 
 /* a plain Lloyd k-means from evenly spaced samples: enough for the build driver's plumbing */
+int
+pgv_kmeans(pgv_ctx * ctx, pgv_ops ops, pgv_dtype dtype, int dim, const void *samples, int n, int k,
+		   int max_iterations, const pgv_rng * rng, void *out_centers, int32_t *out_closest, int *out_iters);
+
+static int
+kmeans_f16(pgv_ctx * ctx, pgv_ops ops, int dim, const void *samples, int n, int k, int max_iterations, const pgv_rng * rng,
+		   void *out_centers, int32_t *out_closest, int *out_iters)
+{
+	/* samples widened, the centers rounded to halves on the way out (HalfvecUpdateCenter, src/ivfutils.c:340-361) */
+	float	   *ws = widen(samples, (size_t) n * dim),
+			   *wc = malloc(sizeof(float) * (size_t) k * dim);
+	int			rc = pgv_kmeans(ctx, ops, PGV_F32, dim, ws, n, k, max_iterations, rng, wc, out_closest, out_iters);
+
+	for (size_t i = 0; rc == PGV_OK && i < (size_t) k * dim; i++)
+		((uint16_t *) out_centers)[i] = float_to_half(wc[i]);
+	free(ws);
+	free(wc);
+	return rc;
+}
+
 int
 pgv_kmeans(pgv_ctx * ctx, pgv_ops ops, pgv_dtype dtype, int dim, const void *samples, int n, int k,
 		   int max_iterations, const pgv_rng * rng, void *out_centers, int32_t *out_closest, int *out_iters)
@@ -797,8 +990,15 @@ pgv_kmeans(pgv_ctx * ctx, pgv_ops ops, pgv_dtype dtype, int dim, const void *sam
 
 	(void) ctx;
 	(void) rng;
+	if (dtype == PGV_F16 && ops != PGV_OPS_COSINE)
+	{
+		free(closest);
+		free(sum);
+		free(cnt);
+		return kmeans_f16(ctx, ops, dim, samples, n, k, max_iterations, rng, out_centers, out_closest, out_iters);
+	}
 	if (dtype != PGV_F32 || ops == PGV_OPS_COSINE)
-		return fail(PGV_ERR_ARG, "mock: fp32, l2 and inner product only");
+		return fail(PGV_ERR_ARG, "mock: l2 and inner product only");
 	for (int j = 0; j < k; j++)
 		for (int d = 0; d < dim; d++)
 			c[(size_t) j * dim + d] = n > 0 ? s[(size_t) ((int64_t) j * n / k) * dim + d] : (float) j;
@@ -847,15 +1047,18 @@ pgv_hnsw_upload(pgv_ctx * ctx, pgv_metric metric, pgv_dtype dtype, int dim, cons
 	pgv_hnsw   *h;
 
 	(void) ctx;
-	if (dtype != PGV_F32)
-		return fail(PGV_ERR_ARG, "mock: fp32 only");
 	h = dev_alloc(sizeof(*h));
+	h->f16 = dtype == PGV_F16;
 	h->metric = metric;
 	h->dim = dim;
 	h->n = n;
 	h->entry = -1;
 	h->vectors = dev_alloc(sizeof(float) * (size_t) (n > 0 ? n : 1) * dim);
-	memcpy(h->vectors, elements, sizeof(float) * (size_t) n * dim);
+	if (h->f16)
+		for (size_t i = 0; i < (size_t) n * dim; i++)
+			h->vectors[i] = half_to_float(((const uint16_t *) elements)[i]);
+	else
+		memcpy(h->vectors, elements, sizeof(float) * (size_t) n * dim);
 	*out = h;
 	return PGV_OK;
 }
@@ -1028,8 +1231,22 @@ pgv_hnsw_update_graph(pgv_hnsw * h, int32_t entry, const int32_t *elements, int 
 	return PGV_OK;
 }
 
+static int hnsw_score_f32(pgv_hnsw * h, const void *queries, int nq, const int32_t *slot, const int32_t *query_of, int64_t npairs,
+						  float *out);
+
 int
 pgv_hnsw_score(pgv_hnsw * h, const void *queries, int nq, const int32_t *slot, const int32_t *query_of,
+			   int64_t npairs, float *out)
+{
+	float	   *w = h->f16 && queries ? widen(queries, (size_t) nq * h->dim) : NULL;
+	int			rc = hnsw_score_f32(h, w ? w : queries, nq, slot, query_of, npairs, out);
+
+	free(w);
+	return rc;
+}
+
+static int
+hnsw_score_f32(pgv_hnsw * h, const void *queries, int nq, const int32_t *slot, const int32_t *query_of,
 			   int64_t npairs, float *out)
 {
 	(void) nq;
@@ -1596,8 +1813,22 @@ pgv_hnsw_link_end(pgv_hnsw * h, int32_t *out_nbr, int64_t *out_pairs, int64_t *o
 
 /* hnswgettuple's first batch (src/hnswscan.c:25-56): greedy descent with ef = 1, then HnswSearchLayer with ef_search
  * on layer 0; the k nearest, ascending, -1 / +inf padded */
+static int hnsw_search_f32(pgv_hnsw * h, const void *queries, int nq, int ef_search, int k, int64_t *out_elem, float *out_dist,
+						   int64_t *out_scored);
+
 int
 pgv_hnsw_search(pgv_hnsw * h, const void *queries, int nq, int ef_search, int k, int64_t *out_elem, float *out_dist,
+				int64_t *out_scored)
+{
+	float	   *w = h->f16 && queries ? widen(queries, (size_t) nq * h->dim) : NULL;
+	int			rc = hnsw_search_f32(h, w ? w : queries, nq, ef_search, k, out_elem, out_dist, out_scored);
+
+	free(w);
+	return rc;
+}
+
+static int
+hnsw_search_f32(pgv_hnsw * h, const void *queries, int nq, int ef_search, int k, int64_t *out_elem, float *out_dist,
 				int64_t *out_scored)
 {
 	sc		   *w = malloc(sizeof(sc) * (size_t) (ef_search + 1));
@@ -1916,7 +2147,7 @@ pgv_search_batch_sharded(pgv_comm * cm, pgv_index * ix, const void *queries, int
 		return fail(PGV_ERR_STATE, "a sharded index needs heap tids");
 	/* GetScanLists: this rank's slice of the batch against the replicated centers */
 	if (hi > lo)
-		pgv_rank_lists(ix, (const float *) queries + (size_t) lo * ix->dim, hi - lo, probes, lists_mine, NULL);
+		rank_lists_f32(ix, (const float *) queries + (size_t) lo * ix->dim, hi - lo, probes, lists_mine, NULL);
 	if ((rc = mc_all_gather(cm, lists_mine, lists_all, sizeof(int32_t) * slice)) != PGV_OK)
 		goto done;
 	/* GetScanItems: the probed lists this rank owns (foreign lists are empty in the local index), whole batch */
@@ -1925,7 +2156,7 @@ pgv_search_batch_sharded(pgv_comm * cm, pgv_index * ix, const void *queries, int
 		const float *qv = (const float *) queries + (size_t) q * ix->dim;
 		int64_t		m;
 
-		pgv_scan_lists(ix, qv, lists_all + (size_t) q * probes, probes, d, sl, ix->n, &m);
+		scan_lists_f32(ix, qv, lists_all + (size_t) q * probes, probes, d, sl, ix->n, &m);
 		for (int r = 0; r < k; r++)
 		{
 			int64_t		best = -1;

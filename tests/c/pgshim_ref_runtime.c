@@ -686,10 +686,12 @@ BitvecInit(void)
 {
 }
 
+#ifndef PGV_HAVE_REF_HALFVEC		/* (the reference's src/halfutils.c has the real one: the program's main calls it) */
 void
 HalfvecInit(void)
 {
 }
+#endif
 
 void
 HnswInit(void)

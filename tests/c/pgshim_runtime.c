@@ -1828,11 +1828,11 @@ vector_negative_inner_product(PG_FUNCTION_ARGS)
 	return 0;					/* (a stand-in: never called; weak, so that the reference's src/vector.c can be linked in) */
 }
 
-Datum
+__attribute__((weak)) Datum
 halfvec_negative_inner_product(PG_FUNCTION_ARGS)
 {
 	(void) fcinfo;
-	return 0;
+	return 0;					/* (weak like the above: the reference's src/halfvec.c has the real one) */
 }
 
 __attribute__((weak)) Datum
@@ -1842,7 +1842,7 @@ l1_distance(PG_FUNCTION_ARGS)
 	return 0;					/* (a stand-in: never called; weak, so that the reference's src/vector.c can be linked in) */
 }
 
-Datum
+__attribute__((weak)) Datum
 halfvec_l1_distance(PG_FUNCTION_ARGS)
 {
 	(void) fcinfo;
@@ -1865,6 +1865,15 @@ extern Datum l2_distance(PG_FUNCTION_ARGS) __attribute__((weak));
 extern Datum vector_spherical_distance(PG_FUNCTION_ARGS) __attribute__((weak));
 extern Datum vector_norm(PG_FUNCTION_ARGS) __attribute__((weak));
 
+/* the halfvec opclasses' support functions (sql/vector.sql:819-866), there when the reference's src/halfvec.c and
+ * src/ivfutils.c / src/hnswutils.c are part of the program */
+extern Datum halfvec_l2_squared_distance(PG_FUNCTION_ARGS) __attribute__((weak));
+extern Datum halfvec_l2_distance(PG_FUNCTION_ARGS) __attribute__((weak));
+extern Datum halfvec_spherical_distance(PG_FUNCTION_ARGS) __attribute__((weak));
+extern Datum halfvec_l2_norm(PG_FUNCTION_ARGS) __attribute__((weak));
+extern Datum ivfflat_halfvec_support(PG_FUNCTION_ARGS) __attribute__((weak));
+extern Datum hnsw_halfvec_support(PG_FUNCTION_ARGS) __attribute__((weak));
+
 FmgrInfo *
 index_getprocinfo(Relation irel, int attnum, uint16 procnum)
 {
@@ -1872,6 +1881,21 @@ index_getprocinfo(Relation irel, int attnum, uint16 procnum)
 	FmgrInfo   *f = &proc_infos[r - S->rels][procnum & 7];
 
 	(void) attnum;
+	if (r->opc.halfvec)
+	{
+		if (procnum == 1)
+			f->fn_addr = r->opc.distanceFn == 1 ? halfvec_negative_inner_product :
+				(r->opc.distanceFn == 2 ? halfvec_l1_distance : halfvec_l2_squared_distance);
+		else if (r->opc.am == 0 && procnum == 3)
+			f->fn_addr = r->opc.distanceFn == 0 ? halfvec_l2_distance : halfvec_spherical_distance;
+		else if (r->opc.am == 0 && procnum == 5)
+			f->fn_addr = ivfflat_halfvec_support;
+		else if (r->opc.am == 1 && procnum == 3)
+			f->fn_addr = hnsw_halfvec_support;
+		else if (procnum == 2 || (r->opc.am == 0 && procnum == 4))
+			f->fn_addr = halfvec_l2_norm;
+		return f;
+	}
 	if (procnum == 1)
 		f->fn_addr = r->opc.distanceFn == 1 ? vector_negative_inner_product :
 			(r->opc.distanceFn == 2 ? l1_distance :
@@ -1900,6 +1924,8 @@ index_getprocid(Relation irel, int16 attnum, uint16 procnum)
 		return 3;
 	if (r->opc.am == 0 && procnum == 4)
 		return r->opc.hasKmeansNormProc ? 4 : InvalidOid;
+	if (r->opc.halfvec && procnum == (r->opc.am == 0 ? 5 : 3))
+		return 5;				/* ivfflat_halfvec_support / hnsw_halfvec_support */
 	return InvalidOid;
 }
 

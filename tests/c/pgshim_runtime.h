@@ -22,6 +22,7 @@ typedef struct ShimOpclass
 	bool		hasNormProc;	/* FUNCTION 2 (cosine: rows stored normalised) */
 	bool		hasKmeansNormProc;	/* FUNCTION 4 (spherical k-means) */
 	int			distanceFn;		/* 0 l2 squared, 1 negative inner product, 2 l1 */
+	int			halfvec;		/* the halfvec opclasses: FUNCTION 1-4 are halfvec_*, FUNCTION 5 (ivfflat) / 3 (hnsw) the type-info function */
 }			ShimOpclass;
 
 /* ---- postmaster ---- */

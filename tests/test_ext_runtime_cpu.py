@@ -118,7 +118,17 @@ def test_the_references_own_ivfflatgettuple_runs_with_the_hooks(tmp_path, saniti
     = the oracle's lists.  ivfflat with vector.gpu on: EVERY participant runs the build hooks on a device context of its
     own (three "rows assigned on the device" flushes of 1840-1850 rows) and the index is complete and correct.  hnsw with
     vector.gpu on: every participant notices the shared graph area on its first tuple and inserts on the reference's path
-    (deferring there left the index empty); the index holds every row."""
+    (deferring there left the index empty); the index holds every row.
+
+    And the halfvec opclasses (-DPGV_HAVE_REF_HALFVEC: the reference's src/halfvec.c and src/halfutils.c are linked in as
+    well -- fourteen files --, HalfvecInit picks its kernels by CPUID): phase "the reference's own halfvec opclasses"
+    creates halfvec_l2_ops indexes of both access methods (FUNCTION 1-4 = halfvec_*, the type-info support functions
+    ivfflat_halfvec_support / hnsw_halfvec_support: HalfvecSumCenter / HalfvecUpdateCenter's round-to-half, item size
+    8 + 2 d) -- BASELINE configs[4]'s type.  vector.gpu off: the reference's serial ivfflatbuild over fp16 rows = the
+    oracle's (ORA_F16: centers bit for bit AS HALVES, every list in order), its scan = the oracle's page reader, its serial
+    hnswbuild = ora_hnsw_build's graph slot for slot.  vector.gpu on: the hooks recognise the type (2 x the dimension
+    limit) and take the PGV_F16 entry points: build, staged mirror, scans and walks against the reference's CPU branch
+    (on the stand-in device fp16 is widened at the door; the real fp16 kernels run in tests/test_ext_runtime_gpu.py)."""
     import __graft_entry__ as entry     # ONE recipe: the program the GPU box runs is built by the same function
     flags = ["-fsanitize=address,undefined", "-fno-omit-frame-pointer"] if sanitize else []
     exe = entry.build_reference_driver(dict(os.environ), out=str(tmp_path / "ext_driver_ref"), mock=True, extra_flags=flags)
@@ -130,7 +140,7 @@ def test_the_references_own_ivfflatgettuple_runs_with_the_hooks(tmp_path, saniti
     assert any("the reference's own ivfflatgettuple" in line and ": ok" in line for line in r.stderr.splitlines()), r.stderr[-3000:]
     assert any("the reference's own hnswgettuple" in line and ": ok" in line for line in r.stderr.splitlines()), r.stderr[-3000:]
     assert any("the reference's own IvfflatKmeans" in line and ": ok" in line for line in r.stderr.splitlines()), r.stderr[-3000:]
-    assert r.stderr.count("bit for bit") == 6, r.stderr[-3000:]
+    assert r.stderr.count("bit for bit") == 7, r.stderr[-3000:]
     assert any("the reference's own ivfflatinsert" in line and ": ok" in line for line in r.stderr.splitlines()), r.stderr[-3000:]
     assert "removed by the reference's ivfflatbulkdelete" in r.stderr, r.stderr[-3000:]
     assert any("the reference's own hnswinsert" in line and ": ok" in line for line in r.stderr.splitlines()), r.stderr[-3000:]
@@ -141,8 +151,11 @@ def test_the_references_own_ivfflatgettuple_runs_with_the_hooks(tmp_path, saniti
     assert "= the oracle's graph" in r.stderr and "levels, every neighbor slot, the entry point" in r.stderr, r.stderr[-3000:]
     assert "NOTICE:  hnsw graph no longer fits into maintenance_work_mem" in r.stderr, r.stderr[-3000:]
     assert any("the reference's own parallel CREATE INDEX" in line and ": ok" in line for line in r.stderr.splitlines()), r.stderr[-3000:]
+    assert any("the reference's own halfvec opclasses" in line and ": ok" in line for line in r.stderr.splitlines()), r.stderr[-3000:]
+    assert "halfvec_l2_ops ivfflat: the reference's serial build" in r.stderr and "halfvec_l2_ops hnsw: the reference's serial build" in r.stderr
+    assert "halfvec_l2_ops ivfflat with the hooks" in r.stderr and "halfvec_l2_ops hnsw with the hooks" in r.stderr
     lines = r.stderr.splitlines()
-    par = lines[next(i for i, line in enumerate(lines) if "phase the reference's own hnswbuild" in line):]
+    par = lines[next(i for i, line in enumerate(lines) if "phase the reference's own halfvec opclasses" in line):]
     assert sum("using 2 parallel workers" in line for line in par) == 3, r.stderr[-3000:]
     # the stand-in deals the table's blocks round-robin: 2000 heap rows to each of the three participants, twice
     assert sum("worker processed 2000 tuples" in line for line in par) == 4 and sum("leader processed 2000 tuples" in line for line in par) == 2

@@ -59,9 +59,12 @@ def test_the_references_own_gettuple_functions_drive_the_hooks_on_the_gpu():
     assert "argmins from the device, pages by the reference" in r.stderr, r.stderr[-3000:]
     assert any("the reference's own hnswbuild" in line and ": ok" in line for line in r.stderr.splitlines()), r.stderr[-3000:]
     assert "linked on the device in FlushPages, pages by the reference" in r.stderr, r.stderr[-3000:]
+    # halfvec_l2_ops on both access methods: the hooks take the real fp16 kernels
+    assert any("the reference's own halfvec opclasses" in line and ": ok" in line for line in r.stderr.splitlines()), r.stderr[-3000:]
+    assert "halfvec_l2_ops ivfflat with the hooks" in r.stderr and "halfvec_l2_ops hnsw with the hooks" in r.stderr
     # parallel CREATE INDEX: a leader and two workers, each with a device context of its own, flush their shares
     assert any("the reference's own parallel CREATE INDEX" in line and ": ok" in line for line in r.stderr.splitlines()), r.stderr[-3000:]
     lines = r.stderr.splitlines()
-    par = lines[next(i for i, line in enumerate(lines) if "phase the reference's own hnswbuild" in line):]
+    par = lines[next(i for i, line in enumerate(lines) if "phase the reference's own halfvec opclasses" in line):]
     flushed = [int(line.split("path: ")[1].split()[0]) for line in par if "rows assigned on the device" in line]
     assert len(flushed) == 3 and sum(flushed) == 5539 and min(flushed) > 1800, flushed
