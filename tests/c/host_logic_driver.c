@@ -392,14 +392,16 @@ test_ivf(void)
 	pgv_rel_init(&rel);
 	CHECK(pgv_host_ivf_build(ctx, PGV_OPS_L2, PGV_F32, DIM, LISTS, rows, tids, N, rows, N, NULL, &rel));
 	{
-		/* k-means runs on a helper thread while the rows go up: its failure (the stand-in knows no cosine opclass) must
-		 * come back as the build's error, text included, and leave no relation behind */
+		/* k-means runs on a helper thread while the rows go up: its failure (the stand-in's, on request) must come back as
+		 * the build's error, text included, and leave no relation behind */
 		pgv_rel		bad;
 		int			rc;
 
 		pgv_rel_init(&bad);
-		rc = pgv_host_ivf_build(ctx, PGV_OPS_COSINE, PGV_F32, DIM, LISTS, rows, tids, N, rows, N, NULL, &bad);
-		EXPECT(rc != PGV_OK && strstr(pgv_host_last_error(), "inner product only") != NULL);
+		setenv("MOCK_HIP_KMEANS_FAIL", "1", 1);
+		rc = pgv_host_ivf_build(ctx, PGV_OPS_L2, PGV_F32, DIM, LISTS, rows, tids, N, rows, N, NULL, &bad);
+		unsetenv("MOCK_HIP_KMEANS_FAIL");
+		EXPECT(rc != PGV_OK && strstr(pgv_host_last_error(), "was asked to fail") != NULL);
 		EXPECT(bad.pages == NULL && bad.nblocks == 0);
 	}
 	CHECK(pgv_host_ivf_mirror_open(ctx, PGV_L2SQ, PGV_F32, &mirror));

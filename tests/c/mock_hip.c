@@ -990,15 +990,21 @@ pgv_kmeans(pgv_ctx * ctx, pgv_ops ops, pgv_dtype dtype, int dim, const void *sam
 
 	(void) ctx;
 	(void) rng;
-	if (dtype == PGV_F16 && ops != PGV_OPS_COSINE)
+	if (dtype == PGV_F16)
 	{
 		free(closest);
 		free(sum);
 		free(cnt);
 		return kmeans_f16(ctx, ops, dim, samples, n, k, max_iterations, rng, out_centers, out_closest, out_iters);
 	}
-	if (dtype != PGV_F32 || ops == PGV_OPS_COSINE)
-		return fail(PGV_ERR_ARG, "mock: l2 and inner product only");
+	/* (PGV_OPS_COSINE: spherical like PGV_OPS_IP -- what differs is what the caller stores, include/pgv_hip.h:81-85) */
+	if (getenv("MOCK_HIP_KMEANS_FAIL"))	/* test knob: the device call that fails */
+	{
+		free(closest);
+		free(sum);
+		free(cnt);
+		return fail(PGV_ERR_DEVICE, "mock: pgv_kmeans was asked to fail");
+	}
 	for (int j = 0; j < k; j++)
 		for (int d = 0; d < dim; d++)
 			c[(size_t) j * dim + d] = n > 0 ? s[(size_t) ((int64_t) j * n / k) * dim + d] : (float) j;

@@ -1103,7 +1103,7 @@ GenerationContextCreate(MemoryContext parent, const char *name, Size minContextS
 	(void) minContextSize;
 	(void) initBlockSize;
 	(void) maxBlockSize;
-	return shim_context_create();
+	return shim_context_create_generation();
 }
 
 Size

@@ -166,6 +166,13 @@ struct MemoryContextData
 	ShimChunk  *chunks;
 	MemoryContextCallback *callbacks;
 	size_t		bytes;
+	/* a generation context (utils/mmgr/generation.c: chunks laid out one behind the other, freed all at once): chunks
+	 * are carved from ONE reserved address range, so a later allocation has a higher address -- which is what the
+	 * reference's CompareCandidateDistances falls back on when two candidates are equally far (src/hnswutils.c:992-1010
+	 * compares the elements' pointers): ties then go by insertion order, as they do inside a generation block */
+	char	   *gen_base;
+	size_t		gen_used,
+				gen_cap;
 };
 
 static struct MemoryContextData top_context = {"TopMemoryContext", NULL, NULL, 0};
@@ -184,7 +191,17 @@ context_alloc(MemoryContext ctx, Size size, bool huge)
 	 * _huge / MCXT_ALLOC_HUGE forms take more */
 	if (!huge && size > SHIM_MAX_ALLOC)
 		ereport(ERROR, (errmsg("invalid memory alloc request size %zu", (size_t) size)));
-	c = malloc(sizeof(ShimChunk) + (size ? size : 1));
+	if (ctx->gen_base)
+	{
+		size_t		need = (sizeof(ShimChunk) + (size ? size : 1) + 15) & ~(size_t) 15;
+
+		if (ctx->gen_used + need > ctx->gen_cap)
+			ereport(ERROR, (errmsg("out of memory")));
+		c = (ShimChunk *) (ctx->gen_base + ctx->gen_used);
+		ctx->gen_used += need;
+	}
+	else
+		c = malloc(sizeof(ShimChunk) + (size ? size : 1));
 	if (c == NULL)
 		ereport(ERROR, (errmsg("out of memory")));
 	c->ctx = ctx;
@@ -268,7 +285,8 @@ pfree(void *p)
 	c->ctx->bytes -= c->size;
 	c->guard = 0;
 	memset(p, 0xDE, c->size);	/* whoever still reads it reads garbage */
-	free(c);
+	if (c->ctx->gen_base == NULL)
+		free(c);				/* (a generation context gives its range back at reset) */
 }
 
 static void *
@@ -314,6 +332,11 @@ shim_context_reset(MemoryContext ctx)
 	}
 	while (ctx->chunks)
 		pfree((char *) ctx->chunks + sizeof(ShimChunk));
+	if (ctx->gen_base)
+	{
+		madvise(ctx->gen_base, ctx->gen_used, MADV_DONTNEED);
+		ctx->gen_used = 0;
+	}
 }
 
 size_t
@@ -345,12 +368,30 @@ shim_context_create(void)
 	return ctx;
 }
 
+MemoryContext
+shim_context_create_generation(void)
+{
+	MemoryContext ctx = shim_context_create();
+
+	ctx->name = "generation";
+	ctx->gen_cap = (size_t) 4 << 30;	/* address space, not memory */
+	ctx->gen_base = mmap(NULL, ctx->gen_cap, PROT_READ | PROT_WRITE, MAP_PRIVATE | MAP_ANONYMOUS | MAP_NORESERVE, -1, 0);
+	if (ctx->gen_base == MAP_FAILED)
+	{
+		perror("pgshim: mmap (generation context)");
+		abort();
+	}
+	return ctx;
+}
+
 void
 shim_context_delete(MemoryContext ctx)
 {
 	shim_context_reset(ctx);
 	if (CurrentMemoryContext == ctx)
 		CurrentMemoryContext = TopMemoryContext;
+	if (ctx->gen_base)
+		munmap(ctx->gen_base, ctx->gen_cap);
 	free(ctx);
 }
 

@@ -10,7 +10,7 @@
 #include "pgshim.h"
 
 #define SHIM_BLCKSZ 8192
-#define SHIM_MAX_RELS 16
+#define SHIM_MAX_RELS 24
 #define SHIM_MAX_PROCS 96
 
 /* which opclass an emulated index relation was "created" with: what IvfflatGetTypeInfo / IvfflatOptionalProcInfo /
@@ -116,6 +116,7 @@ size_t		shim_context_bytes(MemoryContext ctx);
 void		shim_cancel_after(int after_checks);
 int			shim_pinned_buffers(void);	/* buffers this process holds pinned right now */
 MemoryContext shim_context_create(void);
+MemoryContext shim_context_create_generation(void);	/* chunks at increasing addresses (GenerationContextCreate) */
 void		shim_context_delete(MemoryContext ctx);
 void		shim_set_guc_bool(const char *name, bool value);
 void		shim_set_guc_int(const char *name, int value);
