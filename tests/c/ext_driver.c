@@ -2812,6 +2812,7 @@ heap_of(HeapRows * h, int64_t nrows)
  *     device scan over the mirror the worker stages (the product's stager over the reference's pages) agree. */
 #define REL_RBUILD 1009
 #define REL_RBUILD_COS 1011
+#define REL_RBUILD_IP 1012
 extern IndexBuildResult *ivfflatbuild(Relation heap, Relation index, IndexInfo *indexInfo);
 
 static int
@@ -2835,8 +2836,10 @@ reference_ivfbuild_case(Oid relid, int ops, const char *opclass, uint64 seed)
 	const int	n = 6000,
 				lists = 24;
 	float	   *rows = malloc(sizeof(float) * (size_t) n * DIM);
-	float	   *live = malloc(sizeof(float) * (size_t) n * DIM);
+	float	   *live = malloc(sizeof(float) * (size_t) n * DIM);	/* what the index stores, row by row */
+	float	   *samples = malloc(sizeof(float) * (size_t) n * DIM);	/* what k-means is given */
 	int		   *live_row = malloc(sizeof(int) * (size_t) n);
+	int			nsamples = 0;
 	uint64	   *got = malloc(sizeof(uint64) * 30000);
 	HeapRows	h;
 	Relation	heap;
@@ -2852,10 +2855,12 @@ reference_ivfbuild_case(Oid relid, int ops, const char *opclass, uint64 seed)
 	cur_ops = ops;
 	EXPECT(index != NULL);
 	gen_rows(rows, n, DIM, 51);
-	if (ops == ORA_OPS_COSINE)
+	if (ops != ORA_OPS_L2)
 	{
-		/* rows without a direction: AddSample and AddTupleToSort leave them out (IvfflatCheckNorm, src/ivfbuild.c:69-73,
-		 * :174-180); every other row is stored normalised */
+		/* rows without a direction.  vector_cosine_ops (FUNCTION 2 and 4): AddSample and AddTupleToSort leave them out
+		 * (IvfflatCheckNorm, src/ivfbuild.c:69-73, :174-180), every other row is stored normalised.  vector_ip_ops
+		 * (FUNCTION 4 only): the sample leaves them out and is normalised for the spherical k-means, the index stores
+		 * every row as it is */
 		memset(rows + (size_t) 40 * DIM, 0, sizeof(float) * DIM);
 		memset(rows + (size_t) 2041 * DIM, 0, sizeof(float) * DIM);
 	}
@@ -2865,9 +2870,20 @@ reference_ivfbuild_case(Oid relid, int ops, const char *opclass, uint64 seed)
 	h.null_every = 13;
 	heap = heap_of(&h, n);
 	for (int r = 0; r < n; r++)
-		if (!heap_row_is_null(&h, r) && !(ops == ORA_OPS_COSINE && (r == 40 || r == 2041)))
+		if (!heap_row_is_null(&h, r))
 		{
-			/* what the index stores: the row, or (vector_cosine_ops: FUNCTION 2 present) the row normalised */
+			const bool	zero = ops != ORA_OPS_L2 && (r == 40 || r == 2041);
+
+			if (!zero)
+			{
+				if (ops == ORA_OPS_L2)
+					memcpy(samples + (size_t) nsamples * DIM, rows + (size_t) r * DIM, sizeof(float) * DIM);
+				else
+					ora_l2_normalize(DIM, rows + (size_t) r * DIM, samples + (size_t) nsamples * DIM);
+				nsamples++;
+			}
+			if (zero && ops == ORA_OPS_COSINE)
+				continue;
 			if (ops == ORA_OPS_COSINE)
 				ora_l2_normalize(DIM, rows + (size_t) r * DIM, live + (size_t) nlive * DIM);
 			else
@@ -2901,7 +2917,7 @@ reference_ivfbuild_case(Oid relid, int ops, const char *opclass, uint64 seed)
 		ora_prng_seed(&b, seed);
 		(void) ora_prng_u32(&b);
 		(void) ora_prng_u32(&b);
-		iterations = ora_kmeans(ops, ORA_F32, DIM, live, nlive, want_centers, lists, &b, NULL);
+		iterations = ora_kmeans(ops, ORA_F32, DIM, samples, nsamples, want_centers, lists, &b, NULL);
 		EXPECT(iterations >= 0);
 		EXPECT(a.s0 == b.s0 && a.s1 == b.s1);	/* the same number of draws */
 		ora_ivf_assign(ops, ORA_F32, DIM, want_centers, lists, live, nlive, want_list, NULL);
@@ -2958,7 +2974,7 @@ lists_done:
 			Expected	e = expected_batch(relid, rows + (size_t) r * DIM, PROBES);
 			int			nn = ref_scan(index, rows + (size_t) r * DIM, PROBES, 10, got, &used_gpu);
 
-			EXPECT(!used_gpu && nn == 10 && got[0] == tid_of_row(r));
+			EXPECT(!used_gpu && nn == 10 && (ops == ORA_OPS_IP || got[0] == tid_of_row(r)));	/* (the largest inner product need not be the row's own) */
 			if (check_stream(&e, got, nn, 0, "the reference's CPU build, CPU branch"))
 				return 1;
 			expected_free(&e);
@@ -3028,7 +3044,7 @@ lists_done:
 		Expected	e = expected_batch(relid, rows + (size_t) r * DIM, PROBES);
 		int			nn = ref_scan(index, rows + (size_t) r * DIM, PROBES, i % 4 == 3 ? 300 : 10, got, &used_gpu);
 
-		EXPECT(!used_gpu && nn == (i % 4 == 3 ? (300 < e.n ? 300 : e.n) : 10) && got[0] == tid_of_row(r));
+		EXPECT(!used_gpu && nn == (i % 4 == 3 ? (300 < e.n ? 300 : e.n) : 10) && (ops == ORA_OPS_IP || got[0] == tid_of_row(r)));
 		if (check_stream(&e, got, nn, 0, "the reference's build with the hooks, CPU branch"))
 			return 1;
 		expected_free(&e);
@@ -3041,7 +3057,7 @@ lists_done:
 		Expected	e = expected_batch(relid, rows + (size_t) r * DIM, PROBES);
 		int			nn = ref_scan(index, rows + (size_t) r * DIM, PROBES, i % 4 == 3 ? 300 : 10, got, &used_gpu);
 
-		EXPECT(used_gpu && nn == (i % 4 == 3 ? (300 < e.n ? 300 : e.n) : 10) && got[0] == tid_of_row(r));
+		EXPECT(used_gpu && nn == (i % 4 == 3 ? (300 < e.n ? 300 : e.n) : 10) && (ops == ORA_OPS_IP || got[0] == tid_of_row(r)));
 		if (check_stream(&e, got, nn, 0, "the reference's build with the hooks, hooks"))
 			return 1;
 		expected_free(&e);
@@ -3050,6 +3066,7 @@ lists_done:
 			opclass, nlive);
 	free(rows);
 	free(live);
+	free(samples);
 	free(live_row);
 	free(got);
 	return 0;
@@ -3063,7 +3080,11 @@ backend_reference_ivfbuild(void *arg)
 		return 1;
 	/* vector_cosine_ops: FUNCTION 2 (vector_norm) makes the reference normalise what it stores and what it is asked for,
 	 * FUNCTION 4 makes the k-means spherical; the hooks get PGV_OPS_COSINE / PGV_NEG_IP */
-	return reference_ivfbuild_case(REL_RBUILD_COS, ORA_OPS_COSINE, "vector_cosine_ops", 93);
+	if (reference_ivfbuild_case(REL_RBUILD_COS, ORA_OPS_COSINE, "vector_cosine_ops", 93))
+		return 1;
+	/* vector_ip_ops (BASELINE configs[2]'s opclass): FUNCTION 4 only -- spherical k-means over a normalised sample, the
+	 * rows stored as they are, FUNCTION 1 the negative inner product; the hooks get PGV_OPS_IP */
+	return reference_ivfbuild_case(REL_RBUILD_IP, ORA_OPS_IP, "vector_ip_ops", 95);
 }
 #endif							/* PGV_HAVE_REF_IVFBUILD */
 
@@ -4207,7 +4228,7 @@ main(void)
 	setenv("MOCK_HIP_EXPORT_FAIL_EVERY", "9", 1);
 	board = mmap(NULL, sizeof(Board), PROT_READ | PROT_WRITE, MAP_SHARED | MAP_ANONYMOUS, -1, 0);
 	memset((void *) board, 0, sizeof(Board));
-	shim_postmaster_init((size_t) 768 << 20, mock_hip_set_arena ? (size_t) 512 << 20 : 0);
+	shim_postmaster_init((size_t) 832 << 20, mock_hip_set_arena ? (size_t) 512 << 20 : 0);
 	arena = shim_arena_base(&arena_bytes);
 	if (mock_hip_set_arena && arena)
 		mock_hip_set_arena(arena, arena_bytes);
@@ -4248,6 +4269,8 @@ main(void)
 
 		shim_create_relation(REL_RBUILD_COS, &cosine, empty, 0, DIM);
 		shim_set_reloptions(REL_RBUILD_COS, 24, 0);
+		shim_create_relation(REL_RBUILD_IP, &ip, empty, 0, DIM);
+		shim_set_reloptions(REL_RBUILD_IP, 24, 0);
 	}
 #endif
 #ifdef PGV_HAVE_REF_HNSWBUILD
