@@ -3328,6 +3328,43 @@ reference_hnswbuild_case(Oid relid, int ops, const char *opclass, uint64 seed)
 		fprintf(stderr, "   %s: the reference's serial hnswbuild (%d rows, %d NULL or zero, m %d, ef_construction %d) = the oracle's graph: %lld elements, levels, every neighbor %s, the entry point (level %d), %u blocks; %d of %d neighbor lists hold the oracle's neighbors in another slot order, %d differ as sets\n",
 				opclass, n, n - nlive + nzero, m, efc, (long long) ne, ops == ORA_OPS_L2 ? "slot" : "list", entry_level,
 				(unsigned) RelationGetNumberOfBlocks(index), lists_reordered, lists_total, lists_different);
+		/* and the reference's walk of the pages it wrote (hnswgettuple -> GetScanItems -> HnswSearchLayer over
+		 * HnswLoadElement, vector.gpu still off) against the oracle's walk of ITS graph: the same stream, position by
+		 * position the same distance */
+		{
+			int			walks = 0;
+
+			for (int i = 0; i < 24; i++)
+			{
+				const int	r = live_row[(89 * i + 17) % nlive];
+				int64_t		orows[64],
+							scored;
+				double		odist[64],
+							wdist[64];
+				int			want,
+							nc;
+
+				if (ops != ORA_OPS_L2 && (r == 55 || r == 1500))
+					continue;
+				want = ora_hnsw_search(g, rows + (size_t) r * DIM, 40, 40, orows, odist, &scored);
+				nc = ref_hnsw_scan(index, rows + (size_t) r * DIM, 40, cpu, &had_gpu, &reads);
+				EXPECT(!had_gpu && reads > 0);
+				for (int j = 0; j < want; j++)
+				{
+					double		d = 0;
+
+					orows[j] = live_row[orows[j]];
+					for (int k = 0; k < DIM; k++)
+						d += ((double) stored[(size_t) orows[j] * DIM + k] - stored[(size_t) r * DIM + k]) *
+							((double) stored[(size_t) orows[j] * DIM + k] - stored[(size_t) r * DIM + k]);
+					wdist[j] = d;
+				}
+				if (check_hnsw_stream_n(stored, n, stored + (size_t) r * DIM, cpu, nc, orows, wdist, want, "the reference's walk of its own build"))
+					return 1;
+				walks++;
+			}
+			fprintf(stderr, "   %s: %d walks of the reference's HnswSearchLayer over its own pages = the oracle's walks of its graph\n", opclass, walks);
+		}
 		free(slot_of_element);
 		pgv_host_hnsw_image_free(&img);
 		ora_hnsw_free(g);
