@@ -14,10 +14,20 @@
  * Parity pinning: the scalar kernels and SQL-level wrappers are checked
  * against the reference's known-answer tests (test/expected/vector_type.out,
  * halfvec.out, ivfflat_vector.out, hnsw_vector.out; the JSON fixtures under tests/golden) and
- * the fp16 kernels additionally against oracle/_ref (the reference's own
- * src/halfutils.c compiled unmodified).  pg_prng is PostgreSQL core (not in
- * the reference tree): restated from its published algorithm, "parity
- * unpinned" for that one piece (it only feeds k-means seeding).
+ * the fp16 AND fp32 kernels, wrappers, norm and normalize additionally, bit
+ * for bit, against oracle/_ref (the reference's own src/halfutils.c,
+ * src/bitutils.c and src/vector.c compiled unmodified).  The loops above the
+ * kernels are pinned by the reference's own access-method files RUNNING beside
+ * them (tests/test_ext_runtime_cpu.py: fourteen reference files linked into a
+ * stand-in server program): GetScanLists / GetScanItems over the same pages,
+ * ElkanKmeans on the same pg_prng stream (centers bit for bit), the WHOLE
+ * serial ivfflatbuild (sample, k-means, AddTupleToSort's argmin: every list
+ * tuple for tuple) and the WHOLE serial hnswbuild (every level, neighbor and
+ * the entry point) for the l2, cosine, ip and halfvec opclasses, and
+ * HnswSearchLayer's walks.  pg_prng is PostgreSQL core (not in the reference
+ * tree): restated from its published algorithm, "parity unpinned" for that
+ * one piece (it only feeds k-means seeding and HNSW level draws), as is the
+ * order in which exactly equal distances leave PostgreSQL's pairing heap.
  */
 #ifndef PGV_ORACLE_H
 #define PGV_ORACLE_H
