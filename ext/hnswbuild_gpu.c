@@ -60,7 +60,8 @@ typedef int (*pgv_host_cancel_check) (void *arg);
 extern void pgv_host_hnsw_set_cancel_check(pgv_host_cancel_check check, void *arg);
 extern const char *pgv_host_last_error(void);
 
-#define PGV_HNSW_BUILD_BATCH 1024	/* elements inserted "at once" (the graph must hold 16 x as many: hnsw_build.c) */
+/* elements inserted "at once": the GUC vector.gpu_hnsw_build_batch (default 1024; pgv_host_hnsw_build falls back to smaller
+ * batches while the graph is small: it must hold 16 x as many elements) */
 
 typedef struct PgvHnswBuild
 {
@@ -199,7 +200,7 @@ PgvHnswBuildLink(HnswBuildState * buildstate)
 	rng.state = &replay;
 	pgv_host_hnsw_set_cancel_check(PgvBuildCancelPending, NULL);
 	rc = pgv_host_hnsw_build(mirror, gb->dtype, buildstate->dimensions, rows, n, buildstate->m, buildstate->efConstruction,
-							 &rng, PGV_HNSW_BUILD_BATCH, &built);
+							 &rng, vector_gpu_hnsw_build_batch, &built);
 	pgv_host_hnsw_set_cancel_check(NULL, NULL);
 	pgv_hnsw_free(mirror);
 	pfree(rows);

@@ -45,6 +45,7 @@ int			vector_gpu_stage_wait_ms = 0;
 int			vector_gpu_restage_delay_ms = 1000;
 bool		vector_gpu_pooled = false;
 int			vector_gpu_max_own_contexts = 4;	/* GUC vector.gpu_max_own_contexts */
+int			vector_gpu_hnsw_build_batch = 1024;	/* GUC vector.gpu_hnsw_build_batch */
 
 #define PGV_MAX_MIRRORS 64
 
@@ -316,6 +317,8 @@ PgvGpuInit(void)
 							 &vector_gpu_pooled, false, PGC_USERSET, 0, NULL, NULL, NULL);
 	DefineCustomIntVariable("vector.gpu_max_own_contexts", "Backends that may scan on a device context of their own; the others go through the pooler", NULL,
 							&vector_gpu_max_own_contexts, 4, 0, 64, PGC_USERSET, 0, NULL, NULL, NULL);
+	DefineCustomIntVariable("vector.gpu_hnsw_build_batch", "Elements an hnsw build links at once on the GPU (1: the serial build's insertion order exactly)", NULL,
+							&vector_gpu_hnsw_build_batch, 1024, 1, 65536, PGC_USERSET, 0, NULL, NULL, NULL);
 	CacheRegisterRelcacheCallback(PgvRelcacheCallback, (Datum) 0);
 	on_proc_exit(PgvAtExit, (Datum) 0);
 	before_shmem_exit(PgvReleaseMyPoolSlot, (Datum) 0);

@@ -3370,6 +3370,63 @@ reference_hnswbuild_case(Oid relid, int ops, const char *opclass, uint64 seed)
 		ora_hnsw_free(g);
 	}
 
+	/* ---- (1b) the same CREATE INDEX with the hooks and vector.gpu_hnsw_build_batch = 1: every element deferred and linked
+	 * on the device one at a time -- the serial build's insertion order.  Same heap, same level draws (the reference's own
+	 * HnswInitElement on the same stream): the product must hand FlushPages the reference's serial graph, and the
+	 * reference then writes the same index -- compared page for page with what its CPU build wrote above */
+	{
+		uint32_t	nb_cpu,
+					nb_gpu;
+		const uint8_t *pg = shim_relation_pages(relid, &nb_cpu);
+		uint8_t    *cpu_pages = malloc((size_t) nb_cpu * 8192);
+		ora_prng	a;
+		pgv_hnsw_image ic,
+					ig;
+		int			same_bytes;
+
+		memcpy(cpu_pages, pg, (size_t) nb_cpu * 8192);
+		EXPECT(staged_hnsw_image(relid, &ic) == PGV_OK);
+		shim_replace_pages(relid, empty, 0);
+		shim_set_guc_bool("vector.gpu", true);
+		shim_set_guc_int("vector.gpu_hnsw_build_batch", 1);
+		ora_prng_seed(&a, seed);
+		shim_prng_hook(ora_prng_double_cb, ora_prng_u32_cb, &a);
+		ctx = shim_query_context_begin();
+		res = hnswbuild(heap, index, &info);
+		shim_prng_hook(NULL, NULL, NULL);
+		shim_set_guc_int("vector.gpu_hnsw_build_batch", 1024);
+		EXPECT(res != NULL && (int) res->heap_tuples == n && (int) res->index_tuples == nlive - nzero);
+		shim_query_context_end(ctx);
+		pg = shim_relation_pages(relid, &nb_gpu);
+		EXPECT(nb_gpu == nb_cpu);
+		same_bytes = memcmp(pg, cpu_pages, (size_t) nb_cpu * 8192) == 0;
+		EXPECT(staged_hnsw_image(relid, &ig) == PGV_OK);
+		EXPECT(ig.n == ic.n && ig.entry == ic.entry && memcmp(ig.levels, ic.levels, sizeof(int32_t) * (size_t) ic.n) == 0);
+		EXPECT(memcmp(ig.heaptids, ic.heaptids, sizeof(uint64_t) * 10 * (size_t) ic.n) == 0);
+		{
+			int64_t		slots = ic.nbr_start[ic.n],
+						differing = 0;
+
+			for (int64_t j = 0; j < slots; j++)
+				differing += ig.nbr[j] != ic.nbr[j];
+			/* vector_l2_ops: every slot.  vector_cosine_ops: exact ties inside a cluster are common and the device walk
+			 * and the reference's pairing heap order equal keys each in their way (a few slots) */
+			if (ops == ORA_OPS_L2 ? differing != 0 : differing * 200 > slots)
+			{
+				fprintf(stderr, "%s: the hooks at batch 1 leave %lld of %lld neighbor slots different from the reference's serial build\n",
+						opclass, (long long) differing, (long long) slots);
+				return 1;
+			}
+			fprintf(stderr, "   %s: the hooks at vector.gpu_hnsw_build_batch = 1 hand FlushPages the reference's serial graph: %lld of %lld neighbor slots differ; the index the reference writes from it %s\n",
+					opclass, (long long) differing, (long long) slots, same_bytes ? "is the CPU build's, byte for byte" : "differs in bytes");
+			if (ops == ORA_OPS_L2)
+				EXPECT(same_bytes);
+		}
+		pgv_host_hnsw_image_free(&ic);
+		pgv_host_hnsw_image_free(&ig);
+		free(cpu_pages);
+	}
+
 	/* ---- (2) DROP + CREATE INDEX with vector.gpu = on */
 	shim_replace_pages(relid, empty, 0);
 	shim_set_guc_bool("vector.gpu", true);

@@ -138,7 +138,12 @@ def test_the_references_own_ivfflatgettuple_runs_with_the_hooks(tmp_path, saniti
     common, and the order equal keys leave PostgreSQL's pairing heap in is not pinned).  The hooks get PGV_OPS_COSINE /
     PGV_NEG_IP with rows the reference has normalised.  vector_ip_ops (BASELINE configs[2]'s opclass; FUNCTION 4 only: a
     normalised sample for the spherical k-means, rows stored as they are) goes through the reference's ivfflat build the same
-    way: the oracle's centers bit for bit, the oracle's lists."""
+    way: the oracle's centers bit for bit, the oracle's lists.
+
+    And product against reference with nothing in between: the same hnsw CREATE INDEX once on the reference's CPU path
+    and once with the hooks at vector.gpu_hnsw_build_batch = 1 (every element deferred, linked on the device one at a
+    time: the serial build's insertion order) -- vector_l2_ops: the index the reference writes from the device's graph IS
+    the CPU build's, byte for byte (97 pages); vector_cosine_ops: 16 of 40 232 neighbor slots differ (exact ties)."""
     import __graft_entry__ as entry     # ONE recipe: the program the GPU box runs is built by the same function
     flags = ["-fsanitize=address,undefined", "-fno-omit-frame-pointer"] if sanitize else []
     exe = entry.build_reference_driver(dict(os.environ), out=str(tmp_path / "ext_driver_ref"), mock=True, extra_flags=flags)
@@ -159,7 +164,9 @@ def test_the_references_own_ivfflatgettuple_runs_with_the_hooks(tmp_path, saniti
     assert "vector_l2_ops: the reference's serial ivfflatbuild" in r.stderr and "vector_cosine_ops: the reference's serial hnswbuild" in r.stderr
     assert "vector_cosine_ops: the reference's ivfflatbuild with the hooks" in r.stderr and "vector_cosine_ops: the reference's hnswbuild with the hooks" in r.stderr
     assert "0 of 2679 neighbor lists hold the oracle's neighbors in another slot order, 0 differ as sets" in r.stderr    # l2: slot for slot
+    assert "vector_l2_ops: the hooks at vector.gpu_hnsw_build_batch = 1 hand FlushPages the reference's serial graph: 0 of" in r.stderr, r.stderr[-3000:]
     if not sanitize:
+        assert "neighbor slots differ; the index the reference writes from it is the CPU build's, byte for byte" in r.stderr, r.stderr[-3000:]
         # (the sanitizer build's instrumented float loops sum in another order than the oracle library's: a spherical
         # k-means or a cosine graph that hangs on a last bit goes another way there; the plain build holds them to the bit)
         assert r.stderr.count("= the oracle's build: centers bit for bit, every list's tuples in order") == 3, r.stderr[-3000:]    # l2, cosine, ip

@@ -59,6 +59,9 @@ def test_the_references_own_gettuple_functions_drive_the_hooks_on_the_gpu():
     assert "argmins from the device, pages by the reference" in r.stderr, r.stderr[-3000:]
     assert any("the reference's own hnswbuild" in line and ": ok" in line for line in r.stderr.splitlines()), r.stderr[-3000:]
     assert "linked on the device in FlushPages, pages by the reference" in r.stderr, r.stderr[-3000:]
+    # the device's batch-1 build handed to the reference's FlushPages = the reference's serial CPU build, byte for byte
+    assert "vector_l2_ops: the hooks at vector.gpu_hnsw_build_batch = 1 hand FlushPages the reference's serial graph: 0 of" in r.stderr, r.stderr[-3000:]
+    assert "the index the reference writes from it is the CPU build's, byte for byte" in r.stderr, r.stderr[-3000:]
     # halfvec_l2_ops on both access methods: the hooks take the real fp16 kernels
     assert any("the reference's own halfvec opclasses" in line and ": ok" in line for line in r.stderr.splitlines()), r.stderr[-3000:]
     assert "halfvec_l2_ops ivfflat with the hooks" in r.stderr and "halfvec_l2_ops hnsw with the hooks" in r.stderr
