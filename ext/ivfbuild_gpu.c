@@ -59,8 +59,8 @@ PgvIvfflatKmeans(Relation index, VectorArray samples, VectorArray centers, const
 	pgv_ctx    *ctx;
 
 	(void) typeInfo;
-	if (!vector_gpu || !PgvIvfflatOpclass(index, &metric, &dtype, &ops))
-		return false;
+	if (!vector_gpu || !vector_gpu_kmeans || !PgvIvfflatOpclass(index, &metric, &dtype, &ops))
+		return false;			/* (vector.gpu_kmeans = off: the reference's ElkanKmeans, its centers to the bit) */
 	if ((ctx = PgvTryGetContext()) == NULL)
 		return false;			/* no device: the reference's ElkanKmeans */
 	rowBytes = (dtype == PGV_F32 ? sizeof(float) : sizeof(uint16)) * (Size) samples->dim;

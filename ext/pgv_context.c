@@ -46,6 +46,7 @@ int			vector_gpu_restage_delay_ms = 1000;
 bool		vector_gpu_pooled = false;
 int			vector_gpu_max_own_contexts = 4;	/* GUC vector.gpu_max_own_contexts */
 int			vector_gpu_hnsw_build_batch = 1024;	/* GUC vector.gpu_hnsw_build_batch */
+bool		vector_gpu_kmeans = true;	/* GUC vector.gpu_kmeans */
 
 #define PGV_MAX_MIRRORS 64
 
@@ -317,6 +318,8 @@ PgvGpuInit(void)
 							 &vector_gpu_pooled, false, PGC_USERSET, 0, NULL, NULL, NULL);
 	DefineCustomIntVariable("vector.gpu_max_own_contexts", "Backends that may scan on a device context of their own; the others go through the pooler", NULL,
 							&vector_gpu_max_own_contexts, 4, 0, 64, PGC_USERSET, 0, NULL, NULL, NULL);
+	DefineCustomBoolVariable("vector.gpu_kmeans", "An ivfflat build computes its centers on the GPU (off: the CPU build's Elkan k-means and its exact centers; the rows are still assigned on the GPU)", NULL,
+							 &vector_gpu_kmeans, true, PGC_USERSET, 0, NULL, NULL, NULL);
 	DefineCustomIntVariable("vector.gpu_hnsw_build_batch", "Elements an hnsw build links at once on the GPU (1: the serial build's insertion order exactly)", NULL,
 							&vector_gpu_hnsw_build_batch, 1024, 1, 65536, PGC_USERSET, 0, NULL, NULL, NULL);
 	CacheRegisterRelcacheCallback(PgvRelcacheCallback, (Datum) 0);

@@ -2983,6 +2983,67 @@ lists_done:
 		free(want_list);
 	}
 
+	/* ---- (1b) the same CREATE INDEX with vector.gpu = on and vector.gpu_kmeans = off: the reference's own ElkanKmeans
+	 * computes the centers (same sample, same draws: the CPU build's centers to the bit), the device assigns the rows.
+	 * Product against reference with nothing in between: the index must be the CPU build's -- page for page, but for a
+	 * row that is equally near two centers to the last bit of a float (the stand-in device sums in another order than
+	 * the reference's vectorised kernel; such a row may go either way) */
+	{
+		uint32_t	nb_cpu,
+					nb_gpu;
+		const uint8_t *pg = shim_relation_pages(relid, &nb_cpu);
+		uint8_t    *cpu_pages = malloc((size_t) nb_cpu * 8192);
+		pgv_ivf_image ic,
+					ig;
+		ora_prng	a;
+		int			moved = 0;
+
+		memcpy(cpu_pages, pg, (size_t) nb_cpu * 8192);
+		EXPECT(staged_image(relid, &ic) == PGV_OK);
+		shim_replace_pages(relid, empty, 0);
+		shim_set_guc_bool("vector.gpu", true);
+		shim_set_guc_bool("vector.gpu_kmeans", false);
+		ora_prng_seed(&a, seed);
+		shim_prng_hook(ora_prng_double_cb, ora_prng_u32_cb, &a);
+		ctx = shim_query_context_begin();
+		res = ivfflatbuild(heap, index, &info);
+		shim_prng_hook(NULL, NULL, NULL);
+		shim_set_guc_bool("vector.gpu_kmeans", true);
+		EXPECT(res != NULL && (int) res->heap_tuples == n && (int) res->index_tuples == nlive);
+		shim_query_context_end(ctx);
+		EXPECT(staged_image(relid, &ig) == PGV_OK);
+		EXPECT(ig.lists == ic.lists && ig.nrows == ic.nrows);
+		EXPECT(memcmp(ig.centers, ic.centers, sizeof(float) * (size_t) lists * DIM) == 0);	/* Elkan's centers, to the bit */
+		{
+			/* which list each TID is in, CPU build against device-assigned build */
+			int		   *list_cpu = malloc(sizeof(int) * (size_t) n);
+
+			for (int r = 0; r < n; r++)
+				list_cpu[r] = -1;
+			for (int l = 0; l < lists; l++)
+				for (int64_t p2 = ic.list_offsets[l]; p2 < ic.list_offsets[l + 1]; p2++)
+					list_cpu[row_of_tid(ic.tids[p2])] = l;
+			for (int l = 0; l < lists; l++)
+				for (int64_t p2 = ig.list_offsets[l]; p2 < ig.list_offsets[l + 1]; p2++)
+					moved += list_cpu[row_of_tid(ig.tids[p2])] != l;
+			free(list_cpu);
+		}
+		pg = shim_relation_pages(relid, &nb_gpu);
+		if (getenv("PGV_TEST_TRACE") && nb_gpu == nb_cpu)
+			for (size_t o = 0; o < (size_t) nb_cpu * 8192; o++)
+				if (pg[o] != cpu_pages[o])
+				{
+					fprintf(stderr, "      first differing byte: block %zu offset %zu: %02x vs %02x\n", o / 8192, o % 8192, pg[o], cpu_pages[o]);
+					break;
+				}
+		EXPECT(moved * 1000 <= nlive);	/* at most one row in a thousand on the fence */
+		fprintf(stderr, "   %s: vector.gpu_kmeans = off -- Elkan's centers to the bit, the device's argmins: %d of %d rows in another list than the CPU build's; the index %s\n",
+				opclass, moved, nlive, nb_gpu == nb_cpu && memcmp(pg, cpu_pages, (size_t) nb_cpu * 8192) == 0 ? "is the CPU build's, byte for byte" : "differs in bytes");
+		pgv_host_ivf_image_free(&ic);
+		pgv_host_ivf_image_free(&ig);
+		free(cpu_pages);
+	}
+
 	/* ---- (2) DROP + CREATE INDEX with vector.gpu = on: the hooks inside the reference's build */
 	shim_replace_pages(relid, empty, 0);
 	shim_set_guc_bool("vector.gpu", true);

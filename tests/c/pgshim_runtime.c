@@ -204,6 +204,10 @@ context_alloc(MemoryContext ctx, Size size, bool huge)
 		c = malloc(sizeof(ShimChunk) + (size ? size : 1));
 	if (c == NULL)
 		ereport(ERROR, (errmsg("out of memory")));
+	/* fresh memory is not zero in the server either: a fixed pattern (what a MEMORY_CONTEXT_CHECKING build's
+	 * randomize_mem is for) -- whoever relies on palloc zeroing shows up, and bytes nobody sets (the `unused` field of a
+	 * k-means center, src/vector.h:22, goes to the list page as it is) are the same in every build of an index */
+	memset((char *) c + sizeof(ShimChunk), 0x7F, size);
 	c->ctx = ctx;
 	c->size = size;
 	c->guard = CHUNK_GUARD;

@@ -143,7 +143,10 @@ def test_the_references_own_ivfflatgettuple_runs_with_the_hooks(tmp_path, saniti
     And product against reference with nothing in between: the same hnsw CREATE INDEX once on the reference's CPU path
     and once with the hooks at vector.gpu_hnsw_build_batch = 1 (every element deferred, linked on the device one at a
     time: the serial build's insertion order) -- vector_l2_ops: the index the reference writes from the device's graph IS
-    the CPU build's, byte for byte (97 pages); vector_cosine_ops: 16 of 40 232 neighbor slots differ (exact ties)."""
+    the CPU build's, byte for byte (97 pages); vector_cosine_ops: 16 of 40 232 neighbor slots differ (exact ties).  And the
+    ivfflat CREATE INDEX with vector.gpu_kmeans = off (the reference's Elkan computes the centers, the device assigns the
+    rows): the CPU build's centers to the bit, no row in another list, the index byte for byte the CPU build's, for
+    vector_l2_ops, vector_cosine_ops and vector_ip_ops."""
     import __graft_entry__ as entry     # ONE recipe: the program the GPU box runs is built by the same function
     flags = ["-fsanitize=address,undefined", "-fno-omit-frame-pointer"] if sanitize else []
     exe = entry.build_reference_driver(dict(os.environ), out=str(tmp_path / "ext_driver_ref"), mock=True, extra_flags=flags)
@@ -165,8 +168,10 @@ def test_the_references_own_ivfflatgettuple_runs_with_the_hooks(tmp_path, saniti
     assert "vector_cosine_ops: the reference's ivfflatbuild with the hooks" in r.stderr and "vector_cosine_ops: the reference's hnswbuild with the hooks" in r.stderr
     assert "0 of 2679 neighbor lists hold the oracle's neighbors in another slot order, 0 differ as sets" in r.stderr    # l2: slot for slot
     assert "vector_l2_ops: the hooks at vector.gpu_hnsw_build_batch = 1 hand FlushPages the reference's serial graph: 0 of" in r.stderr, r.stderr[-3000:]
+    assert r.stderr.count("vector.gpu_kmeans = off -- Elkan's centers to the bit, the device's argmins: 0 of") == 3, r.stderr[-3000:]
     if not sanitize:
         assert "neighbor slots differ; the index the reference writes from it is the CPU build's, byte for byte" in r.stderr, r.stderr[-3000:]
+        assert r.stderr.count("rows in another list than the CPU build's; the index is the CPU build's, byte for byte") == 3, r.stderr[-3000:]
         # (the sanitizer build's instrumented float loops sum in another order than the oracle library's: a spherical
         # k-means or a cosine graph that hangs on a last bit goes another way there; the plain build holds them to the bit)
         assert r.stderr.count("= the oracle's build: centers bit for bit, every list's tuples in order") == 3, r.stderr[-3000:]    # l2, cosine, ip
