@@ -4147,6 +4147,58 @@ backend_reference_halfvec(void *arg)
 		free(want_list);
 	}
 
+	/* ---- vector.gpu_kmeans = off: the reference's Elkan centers (as halves, to the bit), the fp16 argmin kernel's lists
+	 * against the CPU build's */
+	{
+		pgv_ivf_image ic,
+					ig;
+		pgv_rel		rel;
+		uint32_t	nb_cpu,
+					nb_gpu;
+		uint8_t    *cpu_pages;
+		ora_prng	a;
+		int			moved = 0;
+		int		   *list_cpu = malloc(sizeof(int) * (size_t) n);
+
+		pgv_rel_init(&rel);
+		rel.pages = (uint8_t *) shim_relation_pages(REL_HVIVF, &nb_cpu);
+		rel.nblocks = rel.cap = nb_cpu;
+		EXPECT(pgv_host_ivf_stage(&rel, PGV_F16, &ic) == PGV_OK);
+		cpu_pages = malloc((size_t) nb_cpu * 8192);
+		memcpy(cpu_pages, rel.pages, (size_t) nb_cpu * 8192);
+		shim_replace_pages(REL_HVIVF, empty, 0);
+		shim_set_guc_bool("vector.gpu", true);
+		shim_set_guc_bool("vector.gpu_kmeans", false);
+		ora_prng_seed(&a, 101);
+		shim_prng_hook(ora_prng_double_cb, ora_prng_u32_cb, &a);
+		ctx = shim_query_context_begin();
+		res = ivfflatbuild(heap, index, &info);
+		shim_prng_hook(NULL, NULL, NULL);
+		shim_set_guc_bool("vector.gpu_kmeans", true);
+		EXPECT(res != NULL && (int) res->index_tuples == nlive);
+		shim_query_context_end(ctx);
+		rel.pages = (uint8_t *) shim_relation_pages(REL_HVIVF, &nb_gpu);
+		rel.nblocks = rel.cap = nb_gpu;
+		EXPECT(pgv_host_ivf_stage(&rel, PGV_F16, &ig) == PGV_OK);
+		EXPECT(ig.lists == ic.lists && ig.nrows == ic.nrows);
+		EXPECT(memcmp(ig.centers, ic.centers, sizeof(uint16) * (size_t) lists * HDIM) == 0);
+		for (int r = 0; r < n; r++)
+			list_cpu[r] = -1;
+		for (int l = 0; l < lists; l++)
+			for (int64_t p2 = ic.list_offsets[l]; p2 < ic.list_offsets[l + 1]; p2++)
+				list_cpu[row_of_tid(ic.tids[p2])] = l;
+		for (int l = 0; l < lists; l++)
+			for (int64_t p2 = ig.list_offsets[l]; p2 < ig.list_offsets[l + 1]; p2++)
+				moved += list_cpu[row_of_tid(ig.tids[p2])] != l;
+		EXPECT(moved * 1000 <= nlive);
+		fprintf(stderr, "   halfvec_l2_ops ivfflat: vector.gpu_kmeans = off -- Elkan's centers to the bit, the device's argmins: %d of %d rows in another list than the CPU build's; the index %s\n",
+				moved, nlive, nb_gpu == nb_cpu && memcmp(rel.pages, cpu_pages, (size_t) nb_cpu * 8192) == 0 ? "is the CPU build's, byte for byte" : "differs in bytes");
+		free(list_cpu);
+		free(cpu_pages);
+		pgv_host_ivf_image_free(&ic);
+		pgv_host_ivf_image_free(&ig);
+	}
+
 	/* ---- ivfflat with the hooks: PGV_F16 k-means, argmins, mirror, scans */
 	shim_replace_pages(REL_HVIVF, empty, 0);
 	shim_set_guc_bool("vector.gpu", true);
@@ -4156,7 +4208,7 @@ backend_reference_halfvec(void *arg)
 	res = ivfflatbuild(heap, index, &info);
 	EXPECT(res != NULL && (int) res->heap_tuples == n && (int) res->index_tuples == nlive);
 	shim_query_context_end(ctx);
-	EXPECT(shim_notices_raised("pgvector GPU path: 3790 rows assigned on the device") == 1);	/* 4000 less 210 NULLs */
+	EXPECT(shim_notices_raised("pgvector GPU path: 3790 rows assigned on the device") == 2);	/* 4000 less 210 NULLs; this build and the one before */
 	{
 		pgv_ivf_image img;
 		pgv_rel		rel;
@@ -4300,6 +4352,48 @@ backend_reference_halfvec(void *arg)
 		ora_hnsw_free(g);
 		free(slot_of_element);
 		free(slot_of_row);
+
+		/* vector.gpu_hnsw_build_batch = 1 on the same level draws: the fp16 kernels' graph against the reference's serial one */
+		{
+			pgv_hnsw_image ic,
+						ig;
+			uint32_t	nb_cpu,
+						nb_gpu;
+			uint8_t    *cpu_pages;
+			int64_t		slots,
+						differing = 0;
+
+			rel.pages = (uint8_t *) shim_relation_pages(REL_HVHNSW, &nb_cpu);
+			rel.nblocks = rel.cap = nb_cpu;
+			EXPECT(pgv_host_hnsw_stage(&rel, PGV_F16, &ic) == PGV_OK);
+			cpu_pages = malloc((size_t) nb_cpu * 8192);
+			memcpy(cpu_pages, rel.pages, (size_t) nb_cpu * 8192);
+			shim_replace_pages(REL_HVHNSW, empty, 0);
+			shim_set_guc_bool("vector.gpu", true);
+			shim_set_guc_int("vector.gpu_hnsw_build_batch", 1);
+			ora_prng_seed(&a, 107);
+			shim_prng_hook(ora_prng_double_cb, ora_prng_u32_cb, &a);
+			ctx = shim_query_context_begin();
+			res = hnswbuild(heap, hindex, &info);
+			shim_prng_hook(NULL, NULL, NULL);
+			shim_set_guc_int("vector.gpu_hnsw_build_batch", 1024);
+			EXPECT(res != NULL && (int) res->index_tuples == hlive);
+			shim_query_context_end(ctx);
+			rel.pages = (uint8_t *) shim_relation_pages(REL_HVHNSW, &nb_gpu);
+			rel.nblocks = rel.cap = nb_gpu;
+			EXPECT(pgv_host_hnsw_stage(&rel, PGV_F16, &ig) == PGV_OK);
+			EXPECT(ig.n == ic.n && memcmp(ig.levels, ic.levels, sizeof(int32_t) * (size_t) ic.n) == 0);
+			slots = ic.nbr_start[ic.n];
+			for (int64_t j = 0; j < slots; j++)
+				differing += ig.nbr[j] != ic.nbr[j];
+			EXPECT(differing * 200 <= slots);	/* (halves: equal distances are likelier than among floats; a few slots at most) */
+			fprintf(stderr, "   halfvec_l2_ops hnsw: the hooks at vector.gpu_hnsw_build_batch = 1: %lld of %lld neighbor slots differ from the reference's serial build; the index %s\n",
+					(long long) differing, (long long) slots,
+					nb_gpu == nb_cpu && memcmp(rel.pages, cpu_pages, (size_t) nb_cpu * 8192) == 0 ? "is the CPU build's, byte for byte" : "differs in bytes");
+			free(cpu_pages);
+			pgv_host_hnsw_image_free(&ic);
+			pgv_host_hnsw_image_free(&ig);
+		}
 
 		/* the hooks: every element deferred, linked by the PGV_F16 kernels; the reference's walk of its own pages against
 		 * the device walk over the staged mirror */

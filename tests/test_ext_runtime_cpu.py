@@ -168,10 +168,11 @@ def test_the_references_own_ivfflatgettuple_runs_with_the_hooks(tmp_path, saniti
     assert "vector_cosine_ops: the reference's ivfflatbuild with the hooks" in r.stderr and "vector_cosine_ops: the reference's hnswbuild with the hooks" in r.stderr
     assert "0 of 2679 neighbor lists hold the oracle's neighbors in another slot order, 0 differ as sets" in r.stderr    # l2: slot for slot
     assert "vector_l2_ops: the hooks at vector.gpu_hnsw_build_batch = 1 hand FlushPages the reference's serial graph: 0 of" in r.stderr, r.stderr[-3000:]
-    assert r.stderr.count("vector.gpu_kmeans = off -- Elkan's centers to the bit, the device's argmins: 0 of") == 3, r.stderr[-3000:]
+    assert r.stderr.count("vector.gpu_kmeans = off -- Elkan's centers to the bit, the device's argmins: 0 of") == 4, r.stderr[-3000:]
     if not sanitize:
         assert "neighbor slots differ; the index the reference writes from it is the CPU build's, byte for byte" in r.stderr, r.stderr[-3000:]
-        assert r.stderr.count("rows in another list than the CPU build's; the index is the CPU build's, byte for byte") == 3, r.stderr[-3000:]
+        assert r.stderr.count("rows in another list than the CPU build's; the index is the CPU build's, byte for byte") == 4    # l2, cosine, ip, halfvec
+        assert "halfvec_l2_ops hnsw: the hooks at vector.gpu_hnsw_build_batch = 1: 0 of" in r.stderr, r.stderr[-3000:]
         # (the sanitizer build's instrumented float loops sum in another order than the oracle library's: a spherical
         # k-means or a cosine graph that hangs on a last bit goes another way there; the plain build holds them to the bit)
         assert r.stderr.count("= the oracle's build: centers bit for bit, every list's tuples in order") == 3, r.stderr[-3000:]    # l2, cosine, ip

@@ -63,7 +63,7 @@ def test_the_references_own_gettuple_functions_drive_the_hooks_on_the_gpu():
     assert "vector_l2_ops: the hooks at vector.gpu_hnsw_build_batch = 1 hand FlushPages the reference's serial graph: 0 of" in r.stderr, r.stderr[-3000:]
     assert "the index the reference writes from it is the CPU build's, byte for byte" in r.stderr, r.stderr[-3000:]
     # vector.gpu_kmeans = off: Elkan's centers, the device's argmins -- no more than a row in a thousand may sit on a fence
-    assert r.stderr.count("vector.gpu_kmeans = off -- Elkan's centers to the bit, the device's argmins:") == 3, r.stderr[-3000:]
+    assert r.stderr.count("vector.gpu_kmeans = off -- Elkan's centers to the bit, the device's argmins:") == 4, r.stderr[-3000:]
     # halfvec_l2_ops on both access methods: the hooks take the real fp16 kernels
     assert any("the reference's own halfvec opclasses" in line and ": ok" in line for line in r.stderr.splitlines()), r.stderr[-3000:]
     assert "halfvec_l2_ops ivfflat with the hooks" in r.stderr and "halfvec_l2_ops hnsw with the hooks" in r.stderr
