@@ -868,6 +868,153 @@ test_pool_processes(void)
 	return 0;
 }
 
+/* ---- the same drivers over halfvec rows (PGV_F16: 2-byte elements in the tuples, the list pages, the image and the
+ * stand-in device's door): build -> pages -> stage -> scans (exact, iterative, cosine-style normalised query) -> insert
+ * -> vacuum.  Values are multiples of 1/8 below 64: exact as halves, so a float brute force is the expectation. */
+static int
+test_ivf_f16(void)
+{
+	enum { N = 2500, DIM = 40, LISTS = 10 };	/* 8 + 80 bytes a value: under 127, so the index tuples carry SHORT varlena headers */
+	float	   *frows = malloc(sizeof(float) * N * DIM);
+	ora_half   *rows = malloc(sizeof(ora_half) * N * DIM);
+	uint64_t   *tids = malloc(sizeof(uint64_t) * N);
+	pgv_ctx    *ctx;
+	pgv_rel		rel;
+	pgv_ivf_mirror *mirror;
+	pgv_index  *ix;
+	const pgv_ivf_image *img;
+	pgv_ivf_scan *scan;
+	float		fq[DIM];
+	ora_half	q[DIM];
+
+	for (int i = 0; i < N; i++)
+	{
+		for (int d = 0; d < DIM; d++)
+		{
+			frows[i * DIM + d] = (float) ((i % 10) * 5 + (d % 3)) + (float) (urand() % 16) / 8.0f;
+			rows[i * DIM + d] = ora_float_to_half(frows[i * DIM + d]);
+			EXPECT(ora_half_to_float(rows[i * DIM + d]) == frows[i * DIM + d]);
+		}
+		tids[i] = (uint64_t) (i + 1);
+	}
+	CHECK(pgv_ctx_create(0, NULL, &ctx));
+	pgv_rel_init(&rel);
+	CHECK(pgv_host_ivf_build(ctx, PGV_OPS_L2, PGV_F16, DIM, LISTS, rows, tids, N, rows, N, NULL, &rel));
+	CHECK(pgv_host_ivf_mirror_open(ctx, PGV_L2SQ, PGV_F16, &mirror));
+	CHECK(pgv_host_ivf_mirror_get(mirror, &rel, &ix, &img));
+	EXPECT(img->nrows == N && img->lists == LISTS && img->dim == DIM && img->dtype == PGV_F16);
+	/* the image holds the rows' halves bit for bit, each in the list of its nearest center */
+	{
+		char	   *seen = calloc(N + 1, 1);
+
+		for (int l = 0; l < LISTS; l++)
+			for (int64_t r = img->list_offsets[l]; r < img->list_offsets[l + 1]; r++)
+			{
+				const ora_half *v = (const ora_half *) img->vectors + (size_t) r * DIM;
+				const int	row = (int) img->tids[r] - 1;
+				float		fv[DIM],
+							fc[DIM],
+							mine;
+
+				EXPECT(row >= 0 && row < N && !seen[row]);
+				seen[row] = 1;
+				EXPECT(memcmp(v, rows + (size_t) row * DIM, sizeof(ora_half) * DIM) == 0);
+				if (r % 53 != 0)
+					continue;
+				for (int d = 0; d < DIM; d++)
+				{
+					fv[d] = ora_half_to_float(v[d]);
+					fc[d] = ora_half_to_float(((const ora_half *) img->centers)[(size_t) l * DIM + d]);
+				}
+				mine = l2sq(fv, fc, DIM);
+				for (int c = 0; c < LISTS; c++)
+				{
+					for (int d = 0; d < DIM; d++)
+						fc[d] = ora_half_to_float(((const ora_half *) img->centers)[(size_t) c * DIM + d]);
+					EXPECT(l2sq(fv, fc, DIM) >= mine * (1.0f - 1e-5f));
+				}
+			}
+		free(seen);
+	}
+	/* probes = lists: exact, ascending, every TID once; the nearest is row 321 itself */
+	for (int d = 0; d < DIM; d++)
+	{
+		q[d] = rows[321 * DIM + d];
+		fq[d] = frows[321 * DIM + d];
+	}
+	CHECK(pgv_host_ivf_beginscan(ix, img, LISTS, 0, 0, 0, &scan));
+	CHECK(pgv_host_ivf_rescan(scan, q));
+	{
+		double		prev = -1;
+		int			count = 0;
+		uint64_t	tid;
+		double		dist;
+
+		while (pgv_host_ivf_gettuple(scan, &tid, &dist) == 1)
+		{
+			EXPECT(dist >= prev);
+			EXPECT(tid >= 1 && tid <= N);
+			EXPECT(fabs(dist - (double) l2sq(frows + (tid - 1) * DIM, fq, DIM)) <= 1e-4 * (1.0 + dist));
+			if (count == 0)
+				EXPECT(dist == 0.0);
+			prev = dist;
+			count++;
+		}
+		EXPECT(count == N);
+	}
+	pgv_host_ivf_endscan(scan);
+	/* iterative: one probe at a time up to all lists */
+	CHECK(pgv_host_ivf_beginscan(ix, img, 1, LISTS, 1, 0, &scan));
+	CHECK(pgv_host_ivf_rescan(scan, q));
+	{
+		int			count = 0;
+		uint64_t	tid;
+		double		dist;
+
+		while (pgv_host_ivf_gettuple(scan, &tid, &dist) == 1)
+			count++;
+		EXPECT(count == N);
+	}
+	pgv_host_ivf_endscan(scan);
+	/* insert (one more half row into its nearest list), restage, find it; vacuum it away again */
+	{
+		int32_t		lst;
+		ora_half	nv[DIM];
+		uint64_t	tid;
+		double		dist;
+		int64_t		removed = 0,
+					remaining = 0;
+
+		for (int d = 0; d < DIM; d++)
+			nv[d] = ora_float_to_half(frows[1000 * DIM + d] + 0.125f);
+		CHECK(pgv_assign(ctx, PGV_L2SQ, PGV_F16, DIM, img->centers, LISTS, nv, 1, &lst, NULL));
+		CHECK(pgv_host_ivf_insert(&rel, PGV_F16, lst, nv, 777777));
+		CHECK(pgv_host_ivf_mirror_get(mirror, &rel, &ix, &img));
+		EXPECT(img->nrows == N + 1 && pgv_host_ivf_mirror_restages(mirror) == 2);
+		CHECK(pgv_host_ivf_beginscan(ix, img, 3, 0, 0, 0, &scan));
+		CHECK(pgv_host_ivf_rescan(scan, nv));
+		EXPECT(pgv_host_ivf_gettuple(scan, &tid, &dist) == 1 && tid == 777777 && dist == 0.0);
+		pgv_host_ivf_endscan(scan);
+		ndead = 1;
+		dead_set[0] = 777777;
+		CHECK(pgv_host_ivf_bulkdelete(&rel, is_dead, NULL, &removed, &remaining));
+		EXPECT(removed == 1 && remaining == N);
+		CHECK(pgv_host_ivf_mirror_get(mirror, &rel, &ix, &img));
+		EXPECT(img->nrows == N);
+		CHECK(pgv_host_ivf_beginscan(ix, img, 3, 0, 0, 0, &scan));
+		CHECK(pgv_host_ivf_rescan(scan, nv));
+		EXPECT(pgv_host_ivf_gettuple(scan, &tid, &dist) == 1 && tid != 777777 && dist > 0.0);
+		pgv_host_ivf_endscan(scan);
+	}
+	pgv_host_ivf_mirror_close(mirror);
+	pgv_rel_free(&rel);
+	pgv_ctx_destroy(ctx);
+	free(frows);
+	free(rows);
+	free(tids);
+	return 0;
+}
+
 int
 main(void)
 {
@@ -877,6 +1024,8 @@ main(void)
 	if (test_hnsw_build())
 		return 1;
 	if (test_ivf())
+		return 1;
+	if (test_ivf_f16())
 		return 1;
 	if (test_pool())
 		return 1;
