@@ -356,6 +356,76 @@ test_hnsw_build(void)
 }
 
 /* ---- IVFFlat: build -> pages -> mirror -> amgettuple, iterative scan, insert, vacuum */
+/* ---- the same over halfvec elements (PGV_F16): the serial build against the oracle's fp16 graph */
+static int
+test_hnsw_build_f16(void)
+{
+	enum { N = 700, DIM = 8, M = 6, EFC = 24 };
+	ora_half   *data = malloc(sizeof(ora_half) * N * DIM);
+	pgv_ctx    *ctx;
+	pgv_hnsw   *mirror;
+	pgv_hnsw_built built;
+	ora_hnsw   *g;
+	ora_prng	st;
+	pgv_rng		rng;
+	int			same = 0,
+				entry_level;
+	int32_t		buf[2 * M];
+
+	/* integer coordinates < 512: exact as halves, every squared distance exact in fp32 whatever the order of the sum */
+	for (int i = 0; i < N * DIM; i++)
+		data[i] = ora_float_to_half((float) (urand() % 512));
+	CHECK(pgv_ctx_create(0, NULL, &ctx));
+	CHECK(pgv_hnsw_upload(ctx, PGV_L2SQ, PGV_F16, DIM, data, N, &mirror));
+	g = ora_hnsw_build(ORA_OPS_L2, ORA_F16, DIM, data, N, M, EFC, 23);
+	EXPECT(ora_hnsw_num_elements(g) == N);
+	ora_prng_seed(&st, 23);
+	rng.next_double = ora_prng_double_cb;
+	rng.next_u32 = ora_prng_u32_cb;
+	rng.state = &st;
+	rng.seed = 0;
+	CHECK(pgv_host_hnsw_build(mirror, PGV_F16, DIM, data, N, M, EFC, &rng, 1, &built));
+	EXPECT(built.nelements == N && built.batches == N);
+	EXPECT(built.entry == ora_hnsw_entry_point(g, &entry_level));
+	for (int e = 0; e < N; e++)
+	{
+		int			ok = built.levels[e] == ora_hnsw_level(g, e);
+
+		EXPECT(ok);
+		for (int lc = 0; lc <= built.levels[e] && ok; lc++)
+		{
+			int			lm = lc == 0 ? 2 * M : M;
+			int			cnt = ora_hnsw_neighbors(g, e, lc, buf);
+			const int32_t *mine = built.nbr + built.nbr_start[e] + (int64_t) (built.levels[e] - lc) * M;
+
+			for (int i = 0; i < lm && ok; i++)
+				ok = mine[i] == (i < cnt ? buf[i] : -1);
+		}
+		same += ok;
+	}
+	EXPECT(same >= N * 99 / 100);	/* (tied candidates may be walked in another order: unspecified in the reference) */
+	pgv_host_hnsw_built_free(&built);
+	/* a batched build of the same elements: sound, and every element finds itself */
+	CHECK(pgv_host_hnsw_build(mirror, PGV_F16, DIM, data, N, M, EFC, NULL, 32, &built));
+	EXPECT(built.nelements == N && built.batches < N / 4);
+	{
+		pgv_hnsw_graph graph = {N, M, built.entry, built.levels, built.nbr_start, built.nbr};
+		int64_t		elem[8 * 3],
+					scored[8];
+		float		d[8 * 3];
+
+		CHECK(pgv_host_hnsw_search(mirror, &graph, PGV_F16, DIM, data + 200 * DIM, 8, 40, 3, elem, d, scored));
+		for (int q = 0; q < 8; q++)
+			EXPECT(elem[q * 3] == 200 + q && d[q * 3] == 0.0f);
+	}
+	pgv_host_hnsw_built_free(&built);
+	ora_hnsw_free(g);
+	pgv_hnsw_free(mirror);
+	pgv_ctx_destroy(ctx);
+	free(data);
+	return 0;
+}
+
 static int		dead_set[16];
 static int		ndead;
 static int
@@ -1022,6 +1092,8 @@ main(void)
 	if (test_pool_processes())
 		return 1;
 	if (test_hnsw_build())
+		return 1;
+	if (test_hnsw_build_f16())
 		return 1;
 	if (test_ivf())
 		return 1;
