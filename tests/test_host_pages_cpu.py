@@ -256,3 +256,26 @@ def test_oracle_walks_the_pages_like_it_walks_the_arrays(oracle):
         # NULL query: the first lists, every tuple at distance 0
         gt, gd, scanned = oracle.pages_search(rel.rel.pages, rel.nblocks, ops, dtype, None, 2, 10 ** 6)
         assert scanned == int(ivf.list_offsets[2]) and (gd == 0).all()
+
+
+def test_host_normalize_matches_the_oracle_bit_for_bit(oracle):
+    """pgv_host_normalize_value (what the host scan does to a cosine query and the host build to cosine rows:
+    l2_normalize / halfvec_l2_normalize, src/vector.c:785-819, src/halfvec.c:724-759) against the oracle's restatement --
+    which tests/test_oracle_golden.py holds to the reference's compiled src/vector.c bit for bit."""
+    import ctypes as C
+    lib = _host.lib
+    lib.pgv_host_normalize_value.argtypes = [C.c_int, C.c_int, C.c_void_p, C.c_void_p]
+    lib.pgv_host_normalize_value.restype = C.c_int
+    rng = np.random.default_rng(5)
+    for dtype, np_t, fn, dims in ((0, np.float32, oracle.lib.ora_l2_normalize, [1, 2, 3, 7, 8, 16, 31, 32, 100, 768, 1536, 2000]),
+                                  (1, np.float16, oracle.lib.ora_halfvec_l2_normalize, [1, 2, 3, 7, 8, 16, 31, 32, 100, 768, 3072, 4000])):
+        for dim in dims:
+            for _ in range(20):
+                a = (rng.standard_normal(dim) * 10.0 ** rng.integers(-2, 2)).astype(np_t)
+                got, want = np.empty(dim, np_t), np.empty(dim, np_t)
+                assert lib.pgv_host_normalize_value(dtype, dim, a.ctypes.data, got.ctypes.data) == 1
+                fn(dim, a.ctypes.data, want.ctypes.data)
+                np.testing.assert_array_equal(got.view(np.uint8), want.view(np.uint8))
+        zero = np.zeros(8, np_t)
+        out = np.ones(8, np_t)
+        assert lib.pgv_host_normalize_value(dtype, 8, zero.ctypes.data, out.ctypes.data) == 0 and not out.any()
