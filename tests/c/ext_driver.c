@@ -4461,6 +4461,138 @@ backend_reference_halfvec(void *arg)
 }
 #endif
 
+#if defined(PGV_HAVE_REF_IVFBUILD) && defined(PGV_HAVE_REF_HNSWBUILD)
+/* ------------------------------------------------------------------------------------------------ the product's page writers against the reference's pages
+ * (stand-in device only: nothing here touches a device, and the GPU box's run has nothing to add.)  The reference's own
+ * CREATE INDEX writes an index; the product's stager reads it into the list-major image; the PRODUCT'S page writer
+ * (pgvector_amd/host/ivf_pages.c: the meta page, list pages, entry pages, line pointers, chain links it lays out on its
+ * own) writes that image back -- and must arrive at the reference's pages byte for byte.  That is the on-disk format of
+ * src/ivfflat.h:46-52, :251-275 pinned to what the reference's code actually writes, page headers and padding included. */
+static int
+backend_writer_against_reference(void *arg)
+{
+	static const struct
+	{
+		Oid			relid;
+		const char *opclass;
+	}			cases[] = {{REL_RBUILD_COS, "vector_cosine_ops"}, {REL_RBUILD_IP, "vector_ip_ops"}, {REL_HVIVF, "halfvec_l2_ops"}};
+
+	(void) arg;
+	scenario = "the product's page writer against the reference's pages";
+	if (!mock_hip_set_arena)
+		return 0;
+	for (int c = 0; c < 3; c++)
+	{
+		const pgv_dtype dtype = cases[c].relid == REL_HVIVF ? PGV_F16 : PGV_F32;
+		uint32_t	nblocks;
+		const uint8_t *pages = shim_relation_pages(cases[c].relid, &nblocks);
+		pgv_rel		rel,
+					mine;
+		pgv_ivf_image img;
+		size_t		differing = 0,
+					first = 0;
+
+		pgv_rel_init(&rel);
+		rel.pages = (uint8_t *) pages;
+		rel.nblocks = rel.cap = nblocks;
+		EXPECT(nblocks > 2 && pgv_host_ivf_stage(&rel, dtype, &img) == PGV_OK);
+		pgv_rel_init(&mine);
+		EXPECT(pgv_host_ivf_write_index(&mine, dtype, img.dim, img.lists, img.centers, img.list_offsets, img.vectors, img.tids) == PGV_OK);
+		EXPECT(mine.nblocks == nblocks);
+		for (size_t o = 0; o < (size_t) nblocks * 8192; o++)
+			if (mine.pages[o] != pages[o])
+			{
+				if (differing++ == 0)
+					first = o;
+			}
+		if (differing)
+		{
+			fprintf(stderr, "%s: the product's writer differs from the reference's pages in %zu bytes; first: block %zu offset %zu (%02x, the reference wrote %02x)\n",
+					cases[c].opclass, differing, first / 8192, first % 8192, mine.pages[first], pages[first]);
+			return 1;
+		}
+		fprintf(stderr, "   %s: the image staged from the reference's index, written back by the product's page writer = the reference's %u pages, byte for byte\n",
+				cases[c].opclass, (unsigned) nblocks);
+		pgv_host_ivf_image_free(&img);
+		pgv_rel_free(&mine);
+	}
+	/* the same for hnsw (src/hnsw.h:372-392: element tuples with their heap TIDs and neighbor TID, neighbor tuples, the meta
+	 * page's entry point): the halfvec index the reference's FlushPages wrote last, staged, written back by
+	 * pgvector_amd/host/hnsw_pages.c */
+	{
+		uint32_t	nblocks;
+		const uint8_t *pages = shim_relation_pages(REL_HVHNSW, &nblocks);
+		pgv_rel		rel,
+					mine;
+		pgv_hnsw_image img;
+		uint64_t   *tids;
+		size_t		differing = 0,
+					first = 0;
+
+		pgv_rel_init(&rel);
+		rel.pages = (uint8_t *) pages;
+		rel.nblocks = rel.cap = nblocks;
+		EXPECT(nblocks > 2 && pgv_host_hnsw_stage(&rel, PGV_F16, &img) == PGV_OK);
+		/* the writer takes the elements in insertion order and, like CreateGraphPages walking the list from its head
+		 * (src/hnswbuild.c:150-243: newest first), writes them last to first: the staged slots are in page order, so they
+		 * go in reversed, element s as n - 1 - s */
+		{
+			const int64_t n = img.n;
+			uint16	   *vec = malloc(sizeof(uint16) * (size_t) n * img.dim);
+			int32_t    *levels = malloc(sizeof(int32_t) * (size_t) n);
+			int64_t    *nbr_start = malloc(sizeof(int64_t) * (size_t) (n + 1));
+			int32_t    *nbr = malloc(sizeof(int32_t) * (size_t) img.nbr_start[n]);
+
+			tids = malloc(sizeof(uint64_t) * (size_t) n);
+			nbr_start[0] = 0;
+			for (int64_t r = 0; r < n; r++)
+			{
+				const int64_t s2 = n - 1 - r;
+				const int64_t len = img.nbr_start[s2 + 1] - img.nbr_start[s2];
+
+				EXPECT(img.heaptids[(size_t) s2 * 10 + 1] == UINT64_MAX);	/* (no two rows of that table are equal: one heap TID each) */
+				tids[r] = img.heaptids[(size_t) s2 * 10];
+				levels[r] = img.levels[s2];
+				memcpy(vec + (size_t) r * img.dim, (const uint16 *) img.vectors + (size_t) s2 * img.dim, sizeof(uint16) * (size_t) img.dim);
+				nbr_start[r + 1] = nbr_start[r] + len;
+				for (int64_t j = 0; j < len; j++)
+				{
+					const int32_t v = img.nbr[img.nbr_start[s2] + j];
+
+					nbr[nbr_start[r] + j] = v < 0 ? -1 : (int32_t) (n - 1 - v);
+				}
+			}
+			pgv_rel_init(&mine);
+			EXPECT(pgv_host_hnsw_write_index(&mine, PGV_F16, img.dim, img.m, img.ef_construction, n, vec, tids, levels, nbr_start, nbr, NULL,
+											 img.entry < 0 ? -1 : (int32_t) (n - 1 - img.entry)) == PGV_OK);
+			free(vec);
+			free(levels);
+			free(nbr_start);
+			free(nbr);
+		}
+		EXPECT(mine.nblocks == nblocks);
+		for (size_t o = 0; o < (size_t) nblocks * 8192; o++)
+			if (mine.pages[o] != pages[o])
+			{
+				if (differing++ == 0)
+					first = o;
+			}
+		if (differing)
+		{
+			fprintf(stderr, "halfvec_l2_ops hnsw: the product's writer differs from the reference's pages in %zu bytes; first: block %zu offset %zu (%02x, the reference wrote %02x)\n",
+					differing, first / 8192, first % 8192, mine.pages[first], pages[first]);
+			return 1;
+		}
+		fprintf(stderr, "   halfvec_l2_ops hnsw: the graph staged from the reference's index, written back by the product's page writer = the reference's %u pages, byte for byte\n",
+				(unsigned) nblocks);
+		free(tids);
+		pgv_host_hnsw_image_free(&img);
+		pgv_rel_free(&mine);
+	}
+	return 0;
+}
+#endif
+
 int
 main(void)
 {
@@ -4641,6 +4773,10 @@ main(void)
 #if defined(PGV_HAVE_REF_IVFBUILD) && defined(PGV_HAVE_REF_HNSWBUILD)
 	if (!failed)
 		failed |= run_phase("the reference's own parallel CREATE INDEX", backend_reference_parallel_build, 1, NULL, 300.0);
+#endif
+#if defined(PGV_HAVE_REF_IVFBUILD) && defined(PGV_HAVE_REF_HNSWBUILD) && defined(PGV_HAVE_REF_HALFVEC)
+	if (!failed && mock_hip_set_arena)
+		failed |= run_phase("the product's page writer against the reference's pages", backend_writer_against_reference, 1, NULL, 120.0);
 #endif
 	if (!failed && mock_hip_set_arena)
 		failed |= run_phase("a backend without a device", backend_no_device, 1, NULL, 120.0);

@@ -146,7 +146,12 @@ def test_the_references_own_ivfflatgettuple_runs_with_the_hooks(tmp_path, saniti
     the CPU build's, byte for byte (97 pages); vector_cosine_ops: 16 of 40 232 neighbor slots differ (exact ties).  And the
     ivfflat CREATE INDEX with vector.gpu_kmeans = off (the reference's Elkan computes the centers, the device assigns the
     rows): the CPU build's centers to the bit, no row in another list, the index byte for byte the CPU build's, for
-    vector_l2_ops, vector_cosine_ops and vector_ip_ops."""
+    vector_l2_ops, vector_cosine_ops and vector_ip_ops.
+
+    And the product's own page writers (pgvector_amd/host/ivf_pages.c, hnsw_pages.c) against what the reference wrote:
+    the image staged from a reference-built index, written back by the product's writer, equals the reference's pages BYTE
+    FOR BYTE -- ivfflat for vector_cosine_ops, vector_ip_ops and halfvec_l2_ops (80-115 pages), hnsw for halfvec_l2_ops
+    (79 pages): the on-disk formats of src/ivfflat.h and src/hnsw.h pinned to what the reference's code writes."""
     import __graft_entry__ as entry     # ONE recipe: the program the GPU box runs is built by the same function
     flags = ["-fsanitize=address,undefined", "-fno-omit-frame-pointer"] if sanitize else []
     exe = entry.build_reference_driver(dict(os.environ), out=str(tmp_path / "ext_driver_ref"), mock=True, extra_flags=flags)
@@ -168,6 +173,7 @@ def test_the_references_own_ivfflatgettuple_runs_with_the_hooks(tmp_path, saniti
     assert "vector_cosine_ops: the reference's ivfflatbuild with the hooks" in r.stderr and "vector_cosine_ops: the reference's hnswbuild with the hooks" in r.stderr
     assert "0 of 2679 neighbor lists hold the oracle's neighbors in another slot order, 0 differ as sets" in r.stderr    # l2: slot for slot
     assert "vector_l2_ops: the hooks at vector.gpu_hnsw_build_batch = 1 hand FlushPages the reference's serial graph: 0 of" in r.stderr, r.stderr[-3000:]
+    assert r.stderr.count("written back by the product's page writer = the reference's") == 4 and "differs from the reference's pages" not in r.stderr
     assert r.stderr.count("vector.gpu_kmeans = off -- Elkan's centers to the bit, the device's argmins: 0 of") == 4, r.stderr[-3000:]
     if not sanitize:
         assert "neighbor slots differ; the index the reference writes from it is the CPU build's, byte for byte" in r.stderr, r.stderr[-3000:]
