@@ -1014,7 +1014,8 @@ def compact_line(full):
     if full.get("n_gpus", 1) > 1:
         line["config"]["parallelism"] = str(cfg.get("parallelism", ""))[:80]
         mg = full.get("multi_gpu", {})
-        line["multi_gpu"] = _pick(mg, ("pgv_comm_size", "backend", "kmeans_allreduce_bytes_per_iteration", "placement",
+        line["multi_gpu"] = _pick(mg, ("comm_size", "pgv_comm_size", "backend", "communicator", "launcher",
+                                       "kmeans_allreduce_bytes_per_iteration", "search_allgather_bytes_per_step", "placement",
                                        "rows_per_rank_min", "rows_per_rank_mean", "rows_per_rank_max",
                                        "slowest_rank_scan_ms", "measured_on"))
     ro = full.get("roofline", {})
@@ -1714,6 +1715,190 @@ def section_main(args):
     os._exit(rc)   # no interpreter teardown: a thread that is still inside the library cannot hold the exit up
 
 
+# ---------------------------------------------------------------------------------------------------------------------
+# `python bench.py --gpus N` starts its own N ranks (one process per GPU, RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* in
+# the environment exactly as torch.distributed.run would set them; under torch.distributed.run WORLD_SIZE is already
+# there and nothing is started from here).  The launcher (this process) never touches a device: it finds a free port,
+# starts the ranks in sessions of their own, waits for every rank to report that it JOINED the group
+# (--startup-timeout), relays rank 0's ONE line after checking that the line really describes N ranks, and takes every
+# rank down with its process group when one of them fails or the watchdog's time is up.  Fewer devices than ranks over
+# RCCL, a group that formed with another size, a rank that died: a `failures` entry and exit code 2 -- never a 1-GPU
+# number under "n_gpus": N.
+LAUNCH_ENV = "PGV_BENCH_LAUNCH_DIR"
+
+
+def free_port():
+    import socket
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def launch_mark_ready(rank):
+    """a rank tells the launcher that the group formed with it in it (a file: the launcher holds no group membership)"""
+    d = os.environ.get(LAUNCH_ENV)
+    if d:
+        try:
+            with open(os.path.join(d, "ready.%d" % rank), "w") as f:
+                f.write(str(os.getpid()))
+        except OSError:
+            pass
+
+
+def launch_failure(fd, args, failures, extra=None):
+    """the contract's fields with no value, what went wrong, exit code 2"""
+    n, dim, lists, probes, tname, oname = WORKLOADS[args.workload]
+    line = {"metric": "QPS @ recall@10 (IVFFlat, 1M x 1536d)" if args.workload == "headline" else "QPS @ recall@10 (IVFFlat)",
+            "value": None, "unit": "queries/s", "n_gpus": args.gpus, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": None, "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": tname,
+            "data": "synthetic", "config": {"workload": args.workload, "rows": n, "dim": dim, "lists": lists,
+                                            "probes": args.probes or probes, "k": args.k, "batch_per_gpu": args.batch},
+            "failures": list(failures)}
+    if extra:
+        line.update(extra)
+    for f in failures:
+        log("FAILED: " + f)
+    os.write(fd, (json.dumps(_clean(line), default=str) + "\n").encode())
+    sys.exit(2)
+
+
+def dry_launch_rank(args, json_fd, world, rank):
+    """--dry-launch: form the group, agree on its size, say so.  With --backend gloo no device is touched (the
+    launcher's CPU test); with nccl every rank takes its device and the all-reduce runs over RCCL."""
+    use_dev = args.backend == "nccl"
+    fault = os.environ.get("PGV_BENCH_TEST_FAULT", "")   # the launcher's own tests: "die:R" / "hang:R" before joining
+    if fault == "die:%d" % rank:
+        os._exit(7)
+    if fault == "hang:%d" % rank:
+        time.sleep(3600)
+    if use_dev:
+        local = int(os.environ.get("LOCAL_RANK", "0"))
+        torch.cuda.set_device(local)
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
+    else:
+        dist.init_process_group(args.backend, rank=rank, world_size=world)
+    launch_mark_ready(rank)
+    one = torch.ones(1, dtype=torch.int64, device="cuda" if use_dev else "cpu")
+    dist.all_reduce(one)
+    ranks = [torch.zeros(1, dtype=torch.int64, device=one.device) for _ in range(world)]
+    dist.all_gather(ranks, torch.tensor([rank], dtype=torch.int64, device=one.device))
+    agreed = int(one.item())
+    ok = agreed == world == args.gpus and [int(r.item()) for r in ranks] == list(range(world))
+    if rank == 0:
+        line = {"dry_launch": True, "n_gpus": world, "world_agreed": agreed, "ranks_seen": [int(r.item()) for r in ranks],
+                "backend": args.backend, "launcher": os.environ.get("PGV_BENCH_LAUNCHER", "external (WORLD_SIZE was set)"),
+                "master": "%s:%s" % (os.environ.get("MASTER_ADDR"), os.environ.get("MASTER_PORT"))}
+        if not ok:
+            line["failures"] = ["the group agreed on %d ranks, --gpus is %d" % (agreed, args.gpus)]
+        os.write(json_fd, (json.dumps(line) + "\n").encode())
+    dist.barrier()
+    dist.destroy_process_group()
+    sys.exit(0 if ok else 2)
+
+
+def self_launch(args, json_fd):
+    import signal
+    n = args.gpus
+    if not args.dry_launch or args.backend == "nccl":
+        # counted without creating a context in the launcher (the library's own count; torch would initialise HIP here)
+        ndev = int(pgvector_amd.lib.pgv_device_count())
+        if ndev < 1:
+            return launch_failure(json_fd, args, ["--gpus %d: no gfx950 device on this node" % n])
+        if args.backend == "nccl" and ndev < n:
+            return launch_failure(json_fd, args, [
+                "--gpus %d over RCCL needs %d devices, this node has %d (a functional N-rank run on fewer devices: --backend gloo)"
+                % (n, n, ndev)], {"devices": ndev})
+    else:
+        ndev = 0
+    port = free_port()
+    ldir = tempfile.mkdtemp(prefix="pgv_launch_", dir="/tmp")
+    argv = [a for a in sys.argv[1:]]
+    procs, t0 = [], time.perf_counter()
+    log("[launcher] starting %d ranks of `%s` (backend %s, 127.0.0.1:%d, %d devices)" % (n, " ".join(argv), args.backend, port, ndev))
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), PGV_BENCH_LAUNCHER="bench.py self-launch")
+        env[LAUNCH_ENV] = ldir
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        env.setdefault("OMP_NUM_THREADS", "1")
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + argv, stdin=subprocess.DEVNULL,
+                                      stdout=subprocess.PIPE if r == 0 else 2, stderr=2, start_new_session=True, env=env))
+    out0 = []
+    reader = threading.Thread(target=lambda: out0.append(procs[0].stdout.read()), daemon=True)
+    reader.start()
+
+    def kill_all():
+        for p in procs:
+            if p.poll() is None:
+                try:
+                    os.killpg(p.pid, signal.SIGKILL)
+                except OSError:
+                    pass
+        for p in procs:
+            try:
+                p.wait(timeout=5)
+            except subprocess.TimeoutExpired:
+                pass
+
+    failures, joined = [], False
+    overall = (args.watchdog_secs if args.watchdog_secs > 0 else 3600) + 60
+    try:
+        while True:
+            rcs = [p.poll() for p in procs]
+            if all(rc is not None for rc in rcs):
+                break
+            el = time.perf_counter() - t0
+            if not joined:
+                ready = sum(os.path.exists(os.path.join(ldir, "ready.%d" % r)) for r in range(n))
+                if ready == n:
+                    joined = True
+                    log("[launcher] all %d ranks joined the group after %.1f s" % (n, el))
+                elif el > args.startup_timeout:
+                    failures.append("only %d of %d ranks joined the group within %.0f s (--startup-timeout)" % (ready, n, args.startup_timeout))
+                    break
+            bad = [(r, rc) for r, rc in enumerate(rcs) if rc not in (None, 0)]
+            if bad:
+                # a rank is gone: the others would wait in a collective for ever; rank 0 gets a moment to print its line
+                time.sleep(3.0 if rcs[0] is None else 0.0)
+                failures.append("rank %d exited with code %r; the other ranks were stopped" % bad[0])
+                break
+            if el > overall:
+                failures.append("the ranks were not back after %d s; stopped" % overall)
+                break
+            time.sleep(0.1)
+    finally:
+        kill_all()
+        reader.join(timeout=5)
+        shutil.rmtree(ldir, ignore_errors=True)
+    rcs = [p.returncode for p in procs]
+    text = (out0[0] if out0 else b"").decode(errors="replace").strip().splitlines()
+    line = None
+    for cand in reversed(text):
+        try:
+            line = json.loads(cand)
+            break
+        except ValueError:
+            continue
+    if line is None:
+        return launch_failure(json_fd, args, failures + ["rank 0 printed no line (exit codes by rank: %r)" % (rcs,)])
+    # the line must describe N ranks: what it says, and what the library's communicator saw
+    if line.get("n_gpus") != n:
+        failures.append("rank 0's line says n_gpus %r, --gpus is %d" % (line.get("n_gpus"), n))
+    if not args.dry_launch and n > 1 and (line.get("multi_gpu") or {}).get("pgv_comm_size") != n:
+        failures.append("pgv_comm size %r, --gpus is %d" % ((line.get("multi_gpu") or {}).get("pgv_comm_size"), n))
+    if any(rc != 0 for rc in rcs) and not failures and not line.get("failures"):
+        failures.append("exit codes by rank: %r" % (rcs,))
+    line["launcher"] = {"kind": "bench.py self-launch (one process per rank, started by the process the driver ran)",
+                        "ranks": n, "devices": ndev, "joined": joined, "exit_codes": rcs,
+                        "secs": round(time.perf_counter() - t0, 1)}
+    if failures:
+        line["failures"] = list(line.get("failures", [])) + failures
+        for f in failures:
+            log("FAILED: " + f)
+    os.write(json_fd, (json.dumps(line, default=str) + "\n").encode())
+    sys.exit(2 if line.get("failures") else 0)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -1753,6 +1938,12 @@ def main():
                     help="N GPUs: lists to ranks by rows (LPT) or l %% N")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo for a functional "
                                                      "multi-rank run on a single GPU)")
+    ap.add_argument("--dry-launch", action="store_true", help="only start the --gpus N ranks, form the group, agree on its "
+                    "size and print a short line (no device needed with --backend gloo: the launcher's own test)")
+    ap.add_argument("--startup-timeout", type=float, default=300.0, help="self-launch: seconds every rank has to join the "
+                    "group (the first `import torch` on a fresh box takes 1-2 minutes)")
+    ap.add_argument("--no-self-launch", action="store_true", help="--gpus N > 1 without WORLD_SIZE in the environment is an "
+                    "error instead of starting the N ranks from here")
     args = ap.parse_args()
     PLACEMENT["policy"] = args.placement
     t_program = time.perf_counter()
@@ -1766,6 +1957,13 @@ def main():
     if args.child:
         args.no_cpu_baseline = args.no_sweeps = args.no_traffic = True
     WATCH["fd"] = json_fd
+    if "WORLD_SIZE" not in os.environ and (args.gpus > 1 or args.dry_launch):
+        # `python bench.py --gpus N` as the driver types it: the N ranks are started from HERE (the reference's analogue:
+        # a parallel build launches its own workers, src/ivfbuild.c:830-966) -- never a silent 1-GPU run that says N
+        if args.no_self_launch:
+            return launch_failure(json_fd, args, ["--gpus %d without WORLD_SIZE and --no-self-launch: nothing started the ranks"
+                                                  % args.gpus])
+        return self_launch(args, json_fd)
     if args.watchdog_secs > 0:
         threading.Thread(target=watchdog, args=(args.watchdog_secs,), daemon=True).start()
 
@@ -1773,15 +1971,34 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     WATCH["rank"] = rank
-    if world > 1:
+    if world != args.gpus:
+        # whoever launched this (torch.distributed.run, the self-launcher) formed another group than --gpus says
+        if rank == 0:
+            launch_failure(json_fd, args, ["WORLD_SIZE is %d but --gpus is %d: refusing to report one as the other"
+                                           % (world, args.gpus)])
+        sys.exit(2)
+    if world > 1 or args.dry_launch:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        local_rank = local_rank % max(torch.cuda.device_count(), 1)
+        os.environ.setdefault("MASTER_PORT", "29500")
+        if args.dry_launch:
+            return dry_launch_rank(args, json_fd, world, rank)
+        ndev = torch.cuda.device_count()
+        if args.backend == "nccl" and ndev < world:
+            # RCCL wants one device per rank; `--backend gloo` is the functional N-ranks-on-fewer-devices run
+            if rank == 0:
+                launch_failure(json_fd, args, ["--gpus %d over RCCL needs %d devices, this node has %d" % (world, world, ndev)])
+            sys.exit(2)
+        local_rank = local_rank % max(ndev, 1)
         if args.backend == "nccl":
             dist.init_process_group("nccl", rank=rank, world_size=world,
                                     device_id=torch.device("cuda", local_rank))
         else:
             dist.init_process_group(args.backend, rank=rank, world_size=world)
-    assert world == args.gpus or world == 1, "launch N > 1 through torch.distributed.run"
+        if dist.get_world_size() != args.gpus:
+            if rank == 0:
+                launch_failure(json_fd, args, ["the process group has %d ranks, --gpus is %d" % (dist.get_world_size(), args.gpus)])
+            sys.exit(2)
+        launch_mark_ready(rank)
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
 
@@ -1813,6 +2030,8 @@ def main():
     failures = []
     if comm_kind is not None and comm_kind.startswith("torch.distributed"):
         failures.append("comm: " + comm_kind)
+    if comm is not None and comm.world != args.gpus:
+        failures.append("the library's communicator has %d ranks, --gpus is %d" % (comm.world, args.gpus))
 
     # ---------------------------------------------------------------- setup
     WATCH["section"] = "data + build"
@@ -2010,7 +2229,9 @@ def main():
             "slowest_rank_scan_ms": max(scan_all), "scan_ms_by_rank": scan_all,
             "measured_on": "RCCL over xGMI" if args.backend == "nccl" else
                            "UNMEASURED ON HARDWARE: %d ranks on one GPU over %s (functional run)" % (world, args.backend),
-            "pgv_comm_size": comm.world, "backend": args.backend, "communicator": comm_kind,
+            "comm_size": comm.world, "pgv_comm_size": comm.world, "torch_world_size": dist.get_world_size(),
+            "backend": args.backend, "communicator": comm_kind,
+            "launcher": os.environ.get("PGV_BENCH_LAUNCHER", "external (WORLD_SIZE was set: torch.distributed.run)"),
             "kmeans_allreduce_bytes_per_iteration": int(lists * dim * 4 + lists * 4 + 8),
             "kmeans_iterations": iters,
             "search_allgather_bytes_per_step": {"probe_lists": int(total_batch * probes * 4),

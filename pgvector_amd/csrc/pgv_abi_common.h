@@ -377,6 +377,18 @@ struct ApproxScratch {
 };
 
 // k' of the MFMA L2 selections: the head asked for and a margin the rounding bound clears easily
+// Device memory that another process may map (pgv_index_export / pgv_hnsw_export: hipIpcGetMemHandle, dmabuf mode).
+// The runtime carves allocations below 2 MiB out of shared 2 MiB blocks; the handle of such a fragment is the BLOCK's,
+// and on this pool's driver (round 6, two boxes, every run) hipIpcGetMemHandle of a small mirror returned "invalid
+// argument" for good once other fragments of the worker had been exported and freed (profiles/r06/ipc_export_small.md;
+// round 5 had seen it once in ~350 exports).  A mirror that can be exported therefore owns whole blocks: the size is
+// rounded up to a multiple of 2 MiB (a 20 KB test index costs 2 MiB of a 288 GB part).
+static const size_t kExportGranule = (size_t)2 << 20;
+static inline hipError_t malloc_exportable(void **p, size_t bytes) {
+    const size_t rounded = (bytes + kExportGranule - 1) / kExportGranule * kExportGranule;
+    return hipMalloc(p, rounded ? rounded : kExportGranule);
+}
+
 static int approx_candidates(int k) {
     if (k <= 8) return 32;
     if (4 * k > 256) return k + 64;

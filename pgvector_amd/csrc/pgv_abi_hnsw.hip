@@ -39,7 +39,7 @@ int pgv_hnsw_upload_payload(pgv_ctx *ctx, pgv_metric metric, pgv_dtype dtype, in
     // the payload (what a scan needs to turn an element into heap TIDs) rides in the same allocation, so that the one
     // IPC handle of the elements carries it to importing processes
     const size_t pay_off = hnsw_payload_offset(n, row_bytes), pay_total = (size_t)payload_bytes * (size_t)(n > 0 ? n : 0);
-    if (hipMalloc(&h->elements, payload_bytes > 0 ? pay_off + (pay_total ? pay_total : 4) : bytes) != hipSuccess) {
+    if (malloc_exportable(&h->elements, payload_bytes > 0 ? pay_off + (pay_total ? pay_total : 4) : bytes) != hipSuccess) {
         delete h;
         PGV_FAIL(PGV_ERR_NOMEM, "hipMalloc(%zu) for hnsw elements failed", bytes);
     }
@@ -316,7 +316,7 @@ int pgv_hnsw_set_graph(pgv_hnsw *h, int m, int32_t entry, const int32_t *levels,
     const size_t lb = ((size_t)h->n * sizeof(int32_t) + 15) / 16 * 16;
     const size_t sb = ((size_t)(h->n + 1) * sizeof(int64_t) + 15) / 16 * 16;
     const size_t nb = (size_t)(total > 0 ? total : 1) * sizeof(int32_t);
-    if (hipMalloc(&h->graph, lb + sb + nb) != hipSuccess)
+    if (malloc_exportable(&h->graph, lb + sb + nb) != hipSuccess)
         PGV_FAIL(PGV_ERR_NOMEM, "hipMalloc(%zu) for the hnsw graph failed", lb + sb + nb);
     char *base = static_cast<char *>(h->graph);
     PGV_HIP(hipMemcpyAsync(base, levels, (size_t)h->n * sizeof(int32_t), hipMemcpyDefault, ctx->stream));

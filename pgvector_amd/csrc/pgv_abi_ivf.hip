@@ -86,7 +86,7 @@ int index_create(pgv_ctx *ctx, pgv_metric metric, pgv_dtype dtype, int dim, int 
     // one allocation for the whole mirror (a single IPC handle exports it): centers | vectors | list_offsets |
     // tids | row_norms | center_norms, each part 256-byte aligned
     IndexLayout lay = index_layout(nlists, n, row_bytes, has_tids && n > 0, metric == PGV_L2SQ);
-    if (hipMalloc(&ix->arena, lay.bytes) != hipSuccess) {
+    if (malloc_exportable(&ix->arena, lay.bytes) != hipSuccess) {
         (void)hipGetLastError();
         set_error("hipMalloc(%zu) for the index mirror failed", lay.bytes);
         return fail(PGV_ERR_NOMEM);

@@ -42,6 +42,7 @@ struct Latch
 	uint32		is_set;
 };
 
+#define SHIM_LOCK_STRIPES 64
 typedef struct ShimRel
 {
 	Oid			oid;
@@ -50,8 +51,16 @@ typedef struct ShimRel
 	size_t		pages_off;
 	uint32		nblocks;
 	uint32		cap_blocks;
-	uint32		lock;			/* readers count | 0x80000000 writer */
+	uint32		lock;			/* 0x80000000: a writer holds or waits for the relation */
 	int			reloptions[2];	/* lists | m, ef_construction (0: the access method's default) */
+	/* readers by stripe (a process's pid picks its stripe), a cache line each: PostgreSQL's content locks are per BUFFER,
+	 * so backends scanning one index do not share a lock word; one reader count per relation would put every page lock
+	 * of every backend on ONE line and bound a many-process scan timing (oracle/ref_scan_bench.c) by that line */
+	struct
+	{
+		uint32		n;
+		uint32		pad[15];
+	}			readers[SHIM_LOCK_STRIPES];
 }			ShimRel;
 
 typedef struct ShimBgw
@@ -917,23 +926,32 @@ find_rel(Oid oid)
 	return NULL;
 }
 
+static uint32 *
+rel_my_readers(ShimRel * r)
+{
+	return &r->readers[(uint32) MyProcPid % SHIM_LOCK_STRIPES].n;
+}
+
 static void
 rel_lock_shared(ShimRel * r)
 {
+	uint32	   *mine = rel_my_readers(r);
+
 	for (;;)
 	{
-		uint32		v = __atomic_load_n(&r->lock, __ATOMIC_RELAXED);
-
-		if (!(v & 0x80000000u) && __atomic_compare_exchange_n(&r->lock, &v, v + 1, 0, __ATOMIC_ACQUIRE, __ATOMIC_RELAXED))
+		__atomic_add_fetch(mine, 1, __ATOMIC_SEQ_CST);
+		if (!(__atomic_load_n(&r->lock, __ATOMIC_SEQ_CST) & 0x80000000u))
 			return;
-		usleep(20);
+		__atomic_sub_fetch(mine, 1, __ATOMIC_SEQ_CST);	/* a writer is in or waiting: out of its way */
+		while (__atomic_load_n(&r->lock, __ATOMIC_ACQUIRE) & 0x80000000u)
+			usleep(20);
 	}
 }
 
 static void
 rel_unlock_shared(ShimRel * r)
 {
-	__atomic_sub_fetch(&r->lock, 1, __ATOMIC_RELEASE);
+	__atomic_sub_fetch(rel_my_readers(r), 1, __ATOMIC_RELEASE);
 }
 
 static void
@@ -943,10 +961,13 @@ rel_lock_exclusive(ShimRel * r)
 	{
 		uint32		zero = 0;
 
-		if (__atomic_compare_exchange_n(&r->lock, &zero, 0x80000000u, 0, __ATOMIC_ACQUIRE, __ATOMIC_RELAXED))
-			return;
+		if (__atomic_compare_exchange_n(&r->lock, &zero, 0x80000000u, 0, __ATOMIC_SEQ_CST, __ATOMIC_RELAXED))
+			break;
 		usleep(50);
 	}
+	for (int i = 0; i < SHIM_LOCK_STRIPES; i++)	/* the readers that were in before the flag went up */
+		while (__atomic_load_n(&r->readers[i].n, __ATOMIC_SEQ_CST) != 0)
+			usleep(20);
 }
 
 static void
@@ -986,6 +1007,7 @@ shim_create_relation(Oid oid, const ShimOpclass * opclass, const void *pages, ui
 	r->cap_blocks = cap;
 	r->nblocks = nblocks;
 	r->lock = 0;
+	memset(r->readers, 0, sizeof(r->readers));
 	r->reloptions[0] = r->reloptions[1] = 0;
 	memcpy(Sbase + r->pages_off, pages, (size_t) nblocks * SHIM_BLCKSZ);
 	__atomic_store_n(&r->oid, oid, __ATOMIC_RELEASE);
