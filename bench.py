@@ -35,9 +35,11 @@ What the line carries besides the contract's fields (rank 0, N = 1):
                the per-(query,row)-pair figure of SURVEY 8d is kept as algorithmic_GBps; passes =
                streamed / unique rows; traffic = HBM bytes per launch from a live rocprofv3 PMC pass
                of this same script (FETCH_SIZE x 2 per the gfx950 note + WRITE_SIZE), or null
-  cpu_baseline the oracle's restatement of ivfflatgettuple (reference flags + -march=native) on this
-               box's host cores: pinned threads, spread placement, aggregate GB/s; bounded sample
-               (.page_image: the same over the 8 KB pages the product build wrote)
+  cpu_baseline kind "reference": the reference's OWN compiled scan (src/ivfscan.c + ivfutils.c + vector.c, unpatched, its
+               own flags; oracle/_ref/ref_scan_bench_v4|v3) as backend processes over the 8 KB page image of this index on
+               this box's host cores, its answers checked against the oracle's; `port_value` beside it: the oracle's
+               restatement (bare loops over contiguous arrays, pinned threads); bounded samples
+               (.page_image: the port over the 8 KB pages the product build wrote)
   other_configs  c2, c3shard, c5shard (BASELINE configs[1], one GPU's share of [2] and [4]): QPS, recall, the scan
                kernel's roofline, oracle parity each
   hnsw         BASELINE configs[3] at full size (1 M x 1536, GPU-built graph): ef_search 40 / 100 / 200
@@ -348,6 +350,91 @@ def cpu_baseline(centers, offsets, vectors, tids, queries, probes, k, dtype, ops
                     "sample": "%d queries in %.1f s on %d threads (%d more on 1 thread) over the %d pages the product "
                               "build wrote" % (ptotal, pel, cores, psingle, nblocks)})
     return rec, answers, page_answers
+
+
+def reference_scan_program():
+    """oracle/_ref/ref_scan_bench_v4 where the host has AVX-512 (what the reference's -march=native enables on it), else
+    _v3 (AVX2); None when neither was built (no reference tree where build() ran)"""
+    flags = ""
+    try:
+        for ln in open("/proc/cpuinfo"):
+            if ln.startswith("flags"):
+                flags = ln
+                break
+    except OSError:
+        pass
+    have = set(flags.split())
+    order = ["v4", "v3"] if {"avx512f", "avx512bw", "avx512cd", "avx512dq", "avx512vl"} <= have else ["v3"]
+    for isa in order:
+        exe = os.path.join(ROOT, "oracle", "_ref", "ref_scan_bench_" + isa)
+        if os.path.exists(exe) and os.access(exe, os.X_OK):
+            return exe, "x86-64-" + isa
+    return None, None
+
+
+def reference_baseline(centers, offsets, vectors, tids, queries, probes, k, dtype, ops, oracle_answers, cores,
+                       secs=10.0, secs_single=5.0):
+    """cpu_baseline of kind "reference": the reference's OWN compiled scan (src/ivfscan.c:47-187,361-414 with its
+    ivfutils.c / vector.c / halfvec.c / halfutils.c, unpatched, its own flags; oracle/ref_scan_bench.c) answering the
+    parity queries over the 8 KB page image of THIS index, one single-threaded backend process per connection: `cores`
+    processes for `secs`, then one for `secs_single`.  The pages are written by the product's page writer
+    (pgv_host_ivf_write_index, byte-identical to the reference's own build: tests/c/ext_driver.c) from the same arrays the
+    oracle reads.  Returns the record (with the reference's answers checked against the oracle's) or raises."""
+    from pgvector_amd import _host
+    exe, isa = reference_scan_program()
+    if exe is None:
+        raise RuntimeError("oracle/_ref/ref_scan_bench_v* not built (the reference tree was absent where build() ran)")
+    nq, dim = queries.shape
+    procs = max(1, min(int(cores), 40))
+    t0 = time.perf_counter()
+    rel = _host.Relation()
+    page_tids = (np.asarray(tids).astype(np.uint64) << np.uint64(16)) | np.uint64(1)
+    rel.write_index(dtype, centers, offsets, vectors, page_tids)
+    nblocks = int(rel.nblocks)
+    t_write = time.perf_counter() - t0
+    shm = "/dev/shm" if os.path.isdir("/dev/shm") else "/tmp"
+    d = tempfile.mkdtemp(prefix="pgv_refscan_", dir=shm)
+    try:
+        t0 = time.perf_counter()
+        arr = np.ctypeslib.as_array((ctypes.c_uint8 * (nblocks * 8192)).from_address(rel.rel.pages))
+        arr.tofile(os.path.join(d, "pages.bin"))
+        del arr, rel
+        np.ascontiguousarray(queries).tofile(os.path.join(d, "queries.bin"))
+        t_dump = time.perf_counter() - t0
+        cmd = [exe, os.path.join(d, "pages.bin"), os.path.join(d, "queries.bin"), str(dim), str(nq), str(probes), str(k),
+               str(procs), str(secs), str(secs_single), os.path.join(d, "answers.bin"),
+               "f32" if dtype == api.PGV_F32 else "f16", "l2" if ops == api.PGV_OPS_L2 else "ip"]
+        t0 = time.perf_counter()
+        r = subprocess.run(cmd, capture_output=True, text=True, timeout=secs + secs_single + 240)
+        t_run = time.perf_counter() - t0
+        if r.returncode != 0:
+            raise RuntimeError("ref_scan_bench exit code %d: %s" % (r.returncode, r.stderr[-300:]))
+        rec = json.loads(r.stdout.strip().splitlines()[-1])
+        got = np.fromfile(os.path.join(d, "answers.bin"), dtype=np.uint64).reshape(nq, k)
+    finally:
+        shutil.rmtree(d, ignore_errors=True)
+    bad = []
+    for i in range(nq):
+        wt, wd = oracle_answers[i]
+        g = (got[i][:len(wt)] >> np.uint64(16)).tolist()
+        why = topk_equiv(g, wd, wt.tolist(), wd)
+        if why:
+            bad.append((i, why))
+    return {"value": rec["qps"], "unit": "queries/s", "cores": procs, "kind": "reference",
+            "single_thread_qps": rec["single_qps"], "isa": isa,
+            "scaling_over_one_process": rec["qps"] / rec["single_qps"] if rec["single_qps"] else None,
+            "program": "oracle/_ref/%s: the reference's src/ivfscan.c + ivfutils.c + vector.c + halfvec.c + halfutils.c, unpatched, "
+                       "compiled with its own flags (Makefile:30 + -O2) at %s (its -march=native cannot travel to this host), as %d "
+                       "single-threaded backend processes over the stand-in server runtime of tests/c (buffer manager, fmgr, slots, "
+                       "tuplesort -- all lighter than PostgreSQL's: an upper bound on the reference inside a real server)"
+                       % (os.path.basename(exe), isa, procs),
+            "sample": "%d queries in %.1f s by %d processes (%d more in %.1f s by 1), %d pages, same index and queries as the parity check"
+                      % (rec["queries"], rec["secs"], procs, rec["single_queries"], rec["single_secs"], nblocks),
+            "pages": nblocks, "page_write_secs": t_write, "page_dump_secs": t_dump, "program_secs": t_run,
+            "program_load_secs": rec["load_secs"], "answer_pass_secs": rec["answer_pass_secs"],
+            "answers_against_oracle": {"checked_queries": nq, "mismatches": len(bad), "first": repr(bad[0]) if bad else None,
+                                       "rule": "the reference returns heap TIDs in order; they must be the oracle's wherever "
+                                               "its distances differ beyond 1e-5 relative"}}
 
 
 def cpu_build_kmeans(host_samples, lists, dtype, ops, seed, out):
@@ -1025,7 +1112,10 @@ def compact_line(full):
     line["roofline"]["kernel"] = str(ro.get("kernel", "")).split(" ")[0]
     cb = full.get("cpu_baseline")
     if isinstance(cb, dict):
-        line["cpu_baseline"] = _pick(cb, ("value", "unit", "cores", "kind", "single_thread_qps"))
+        line["cpu_baseline"] = _pick(cb, ("value", "unit", "cores", "kind", "single_thread_qps", "isa", "port_value",
+                                          "port_single_thread_qps"))
+        if isinstance(cb.get("answers_against_oracle"), dict):
+            line["cpu_baseline"]["answers_vs_oracle_mismatches"] = cb["answers_against_oracle"].get("mismatches")
         line["cpu_baseline"]["sample"] = str(cb.get("sample", ""))[:100]
         if isinstance(cb.get("page_image"), dict):
             line["cpu_baseline"]["page_image_qps"] = _r(cb["page_image"].get("value"))
@@ -1910,6 +2000,10 @@ def main():
     ap.add_argument("--probes", type=int, default=0)
     ap.add_argument("--seed", type=int, default=0)
     ap.add_argument("--no-cpu-baseline", action="store_true", help="skips the oracle: no cpu_baseline, no TID parity")
+    ap.add_argument("--no-reference-baseline", action="store_true", help="cpu_baseline stays the oracle's port (no "
+                    "oracle/_ref/ref_scan_bench run)")
+    ap.add_argument("--cpu-port-secs", type=float, default=6.0, help="seconds of the oracle's threads (cpu_baseline.port)")
+    ap.add_argument("--cpu-reference-secs", type=float, default=10.0, help="seconds of the reference's backend processes")
     ap.add_argument("--no-sweeps", action="store_true", help="skip every optional section (the child processes)")
     ap.add_argument("--no-traffic", action="store_true", help="skip the live rocprofv3 PMC passes")
     ap.add_argument("--sections", default=",".join(SECTION_ORDER),
@@ -2257,10 +2351,37 @@ def main():
             pqueries = queries[1][:pq].contiguous()
             pd, ps, pt = index.search_batch(pqueries, probes, k, want_tid=True)
             ctx.sync()
-            base, answers, _ = cpu_baseline(centers.cpu().numpy(), offsets.cpu().numpy(),
-                                            vectors.cpu().numpy(), tids.cpu().numpy().astype(np.uint64),
-                                            pqueries.cpu().numpy(), probes, k, dtype, ops)
+            hc, ho, hv = centers.cpu().numpy(), offsets.cpu().numpy(), vectors.cpu().numpy()
+            ht, hq = tids.cpu().numpy().astype(np.uint64), pqueries.cpu().numpy()
+            base, answers, _ = cpu_baseline(hc, ho, hv, ht, hq, probes, k, dtype, ops, budget_s=args.cpu_port_secs)
             line["cpu_baseline"] = base
+            if not args.no_reference_baseline:
+                # the reference's own compiled scan over the page image of this index: `value` becomes
+                # ITS rate ("kind": "reference"), the port's bare loops stay beside it
+                WATCH["section"] = "cpu_baseline: the reference's own scan"
+                try:
+                    ref = reference_baseline(hc, ho, hv, ht, hq, probes, k, dtype, ops, answers, base["cores"],
+                                             secs=args.cpu_reference_secs, secs_single=args.cpu_reference_secs / 2.0)
+                    ref["port_value"] = base["value"]
+                    ref["port_single_thread_qps"] = base["single_thread_qps"]
+                    ref["port"] = base
+                    ref["stand_in_overheads"] = {
+                        "reference_over_port_all_cores": ref["value"] / base["value"] if base["value"] else None,
+                        "reference_over_port_one_core": ref["single_thread_qps"] / base["single_thread_qps"]
+                        if base["single_thread_qps"] else None,
+                        "note": "port = the oracle's bare loops over contiguous arrays (no pages, no fmgr, no tuplesort), "
+                                "threads of one process; reference = the compiled reference over 8 KB pages through the "
+                                "stand-in's buffer manager, index_getattr, fmgr, slot and tuplesort, one process per backend"}
+                    line["cpu_baseline"] = ref
+                    if ref["answers_against_oracle"]["mismatches"]:
+                        failures.append("the reference's own scan differs from the oracle on %d of %d queries, first: %s" % (
+                            ref["answers_against_oracle"]["mismatches"], pq, ref["answers_against_oracle"]["first"]))
+                    log("reference scan: %.0f QPS on %d processes, %.1f on one (%s); port %.0f / %.1f" % (
+                        ref["value"], ref["cores"], ref["single_thread_qps"], ref["isa"], base["value"], base["single_thread_qps"]))
+                except Exception as e:   # noqa: BLE001  (the port's number stands, the line says why it is not the reference's)
+                    base["reference_error"] = repr(e)
+                    failures.append("cpu_baseline kind 'reference' did not run: %r" % (e,))
+            del hv
             pd, pt = pd.cpu().numpy(), pt.cpu().numpy()
             bad = []
             for i in range(pq):
