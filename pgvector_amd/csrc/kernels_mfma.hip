@@ -54,7 +54,8 @@ typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 
 constexpr int kSliceBytes = 128;  // bytes of every row per pipeline stage = 8 slots of 16 B
-constexpr int kCand = 4;          // centers kept by the L2 pre-filter
+constexpr int kCand = 4;          // centers a lane's (and a center part's) list keeps in the L2 pre-filter
+constexpr int kWide = 8;          // centers the merged list of a row carries to the recheck (see finish_l2)
 
 // waves along M (centers) x N (rows), 32x32 tiles per wave along M x N
 template <typename T> struct MfmaCfg;
@@ -196,9 +197,15 @@ template <> struct Mma16x4<__half> {
 
 // sorted insertion into a lane's best-NC list; strict '<' keeps the earlier (lower) id first
 // among equal values -- ids arrive in ascending order within a lane.  NaN and +inf never enter
-// (not < DBL_MAX, src/ivfbuild.c:187).
-template <int NC> __device__ __forceinline__ void keep_best(float (&tv)[NC], int (&ti)[NC], float s, int id) {
-    if (!(s < tv[NC - 1])) return;
+// (not < DBL_MAX, src/ivfbuild.c:187).  `dropped` (L2 pre-filter only) is the smallest value this list ever turned away
+// or pushed out: a row whose `dropped` is out of the error band's reach of its best has ALL its in-band centers in the
+// lists, however many the lists hold.
+template <int NC> __device__ __forceinline__ void keep_best(float (&tv)[NC], int (&ti)[NC], float &dropped, float s, int id) {
+    if (!(s < tv[NC - 1])) {
+        if constexpr (NC > 1) dropped = fminf(dropped, s);
+        return;
+    }
+    if constexpr (NC > 1) dropped = fminf(dropped, tv[NC - 1]);
 #pragma unroll
     for (int p = NC - 1; p >= 0; p--) {
         const bool shift = p > 0 && s < tv[p - 1];
@@ -213,37 +220,50 @@ template <int NC> __device__ __forceinline__ void keep_best(float (&tv)[NC], int
     }
 }
 
-// what a row's NC best (value, id) pairs turn into: the answer (NC == 1), or for the L2 pre-filter the answer when the
-// runner-up is out of the error bound's reach, else an entry of the recheck list
-template <int NC>
-__device__ __forceinline__ void finish_row(int64_t r, const float (&sv)[NC], const int (&sid)[NC], float x2,
-                                           int32_t *__restrict__ out_idx, float *__restrict__ out_val,
-                                           const unsigned *__restrict__ cmax2_bits, float gamma, float gamma_x,
-                                           int *__restrict__ u_count, int32_t *__restrict__ u_rows,
-                                           int32_t *__restrict__ u_cand, float *__restrict__ u_val) {
-    if constexpr (NC == 1) {
+// the pre-filter's error band seen from a row's best value: twice the expansion's own error + the exact form's rounding,
+// which is RELATIVE to the distance it rounds (all its terms are positive) -- the distance of the value `v` that is asked
+// about, v + |a|^2; every center with a larger value is further still.  Monotone: once a value is out, all larger are.
+__device__ __forceinline__ bool out_of_band(float v, float v0, float x2, float cm2, float gamma, float gamma_x) {
+    if (!(v < INFINITY)) return true;  // (padding of a short list)
+    const float cross = 2.f * sqrtf(x2 * cm2);
+    return v - v0 > 2.f * gamma * (cm2 + cross) + 2.02f * gamma_x * fabsf(v + x2);
+}
+
+struct L2Lists {  // device buffers of the L2 pipeline
+    const unsigned *cmax2 = nullptr;
+    float gamma = 0.f, gamma_x = 0.f;
+    int *u_count = nullptr;
+    int32_t *u_rows = nullptr, *u_cand = nullptr;   // [n], [n x kWide]
+    float *u_val = nullptr, *u_drop = nullptr, *u_x2 = nullptr;  // [n x kWide], [n], [n]
+};
+
+// inner-product modes: a row's best (value, id) is the answer
+__device__ __forceinline__ void finish_ip(int64_t r, float v, int id, int32_t *__restrict__ out_idx, float *__restrict__ out_val) {
+    out_idx[r] = id;
+    if (out_val) out_val[r] = v == INFINITY ? FLT_MAX : v;
+}
+
+// L2 pre-filter: a row's kWide smallest pre-filter values (ascending by (value, id)) and `dropped`, the smallest value
+// that is in none of the lists the kWide came from.  The answer when the runner-up is out of the error band's reach of
+// the best; else an entry of the recheck list, which evaluates the reference's exact form for the in-band candidates and
+// sends the row on to the all-centers exact kernel only if the band holds more than the lists do (the kWide-th value or
+// `dropped` inside it).
+__device__ __forceinline__ void finish_l2(int64_t r, const float (&sv)[kWide], const int (&sid)[kWide], float dropped, float x2,
+                                          int32_t *__restrict__ out_idx, const L2Lists &l2) {
+    const float cm2 = __uint_as_float(*l2.cmax2);
+    if (sv[0] < INFINITY && out_of_band(sv[1], sv[0], x2, cm2, l2.gamma, l2.gamma_x)) {
         out_idx[r] = sid[0];
-        if (out_val) out_val[r] = sv[0] == INFINITY ? FLT_MAX : sv[0];
-    } else {
-        // decided when the runner-up is out of the error bound's reach (k <= kCand: the recheck
-        // sees every center anyway)
-        const float cm2 = __uint_as_float(*cmax2_bits);
-        const float cross = 2.f * sqrtf(x2 * cm2);
-        // twice the expansion's own error + the exact form's rounding, which is RELATIVE to the distance it rounds
-        // (all its terms are positive): the runner-up's, sv[1] + |a|^2 -- every other center is further still
-        const float margin = 2.f * gamma * (cm2 + cross) + 2.02f * gamma_x * fabsf(sv[1] + x2);
-        if (sv[0] < INFINITY && sv[1] - sv[0] > margin) {
-            out_idx[r] = sid[0];
-        } else {
-            const int p = atomicAdd(u_count, 1);
-            u_rows[p] = (int32_t)r;
-#pragma unroll
-            for (int c = 0; c < NC; c++) {
-                u_cand[(size_t)p * NC + c] = sid[c];
-                u_val[(size_t)p * NC + c] = sv[c];
-            }
-        }
+        return;
     }
+    const int p = atomicAdd(l2.u_count, 1);
+    l2.u_rows[p] = (int32_t)r;
+#pragma unroll
+    for (int c = 0; c < kWide; c++) {
+        l2.u_cand[(size_t)p * kWide + c] = sid[c];
+        l2.u_val[(size_t)p * kWide + c] = sv[c];
+    }
+    l2.u_drop[p] = dropped;
+    l2.u_x2[p] = x2;
 }
 
 // MODE 0: L2 pre-filter (bias - 2 ip, kCand kept)   1: -ip   3: -clamp(ip, -1, 1) (spherical k-means:
@@ -252,10 +272,9 @@ template <typename T, int MODE>
 __global__ __launch_bounds__(MfmaCfg<T>::WM *MfmaCfg<T>::WN * 64, 2) void mfma_argmin_kernel(
     const char *__restrict__ rows, int64_t n, const char *__restrict__ centers, int k, int nvec,
     const float *__restrict__ bias, const char *__restrict__ zeros16, int32_t *__restrict__ out_idx,
-    float *__restrict__ out_val, const unsigned *__restrict__ cmax2_bits, float gamma, float gamma_x,
-    int *__restrict__ u_count,
-    int32_t *__restrict__ u_rows, int32_t *__restrict__ u_cand, float *__restrict__ u_val,
-    int nparts, int part_tiles, float *__restrict__ part_val, int32_t *__restrict__ part_idx, float *__restrict__ part_x2) {
+    float *__restrict__ out_val, const L2Lists l2,
+    int nparts, int part_tiles, float *__restrict__ part_val, int32_t *__restrict__ part_idx, float *__restrict__ part_x2,
+    float *__restrict__ part_drop) {
     using C = MfmaCfg<T>;
     constexpr int TM = C::TM, TN = C::TN;
     constexpr int BM = C::WM * TM * 32, BN = C::WN * TN * 32;
@@ -316,13 +335,16 @@ __global__ __launch_bounds__(MfmaCfg<T>::WM *MfmaCfg<T>::WN * 64, 2) void mfma_a
 
     float tv[TN][NC];
     int ti[TN][NC];
+    float dm[TN];  // L2: the smallest value this lane's list of a row turned away (keep_best)
 #pragma unroll
-    for (int t = 0; t < TN; t++)
+    for (int t = 0; t < TN; t++) {
+        dm[t] = INFINITY;
 #pragma unroll
         for (int c = 0; c < NC; c++) {
             tv[t][c] = INFINITY;
             ti[t][c] = 0;
         }
+    }
 
     float xx[TN];  // L2 only: this lane's share of |row|^2 (its half-wave's k-slots), gathered during the first center tile
 #pragma unroll
@@ -446,16 +468,18 @@ __global__ __launch_bounds__(MfmaCfg<T>::WM *MfmaCfg<T>::WN * 64, 2) void mfma_a
                     } else {
                         s = -s;
                     }
-                    if (cid < k) keep_best<NC>(tv[tn], ti[tn], s, cid);
+                    if (cid < k) keep_best<NC>(tv[tn], ti[tn], dm[tn], s, cid);
                 }
             }
         __syncthreads();  // the last slice and the bias tile are free to be overwritten
     }
 
     // merge the NSRC lists of every data row (LDS reuses the stage memory)
+    constexpr int W = NC > 1 ? kWide : 1;   // what a row's merged list holds when this workgroup saw every center
     float *mv = reinterpret_cast<float *>(smem);
     int *mi = reinterpret_cast<int *>(smem + sizeof(float) * BN * NSRC * NC);
     float *mx = reinterpret_cast<float *>(smem + (sizeof(float) + sizeof(int)) * BN * NSRC * NC);  // [BN][2]
+    float *md = mx + BN * 2;                                                                        // [BN][NSRC]
 #pragma unroll
     for (int tn = 0; tn < TN; tn++) {
         const int j = wn * TN * 32 + tn * 32 + l31;
@@ -466,6 +490,7 @@ __global__ __launch_bounds__(MfmaCfg<T>::WM *MfmaCfg<T>::WN * 64, 2) void mfma_a
             mi[(j * NSRC + s) * NC + c] = ti[tn][c];
         }
         if (MODE == 0 && wm == 0) mx[j * 2 + half] = xx[tn];
+        if (MODE == 0) md[j * NSRC + s] = dm[tn];
     }
     __syncthreads();
     for (int j = threadIdx.x; j < BN; j += blockDim.x) {
@@ -473,14 +498,16 @@ __global__ __launch_bounds__(MfmaCfg<T>::WM *MfmaCfg<T>::WN * 64, 2) void mfma_a
         if (r >= n) continue;
         const float *v = mv + j * NSRC * NC;
         const int *id = mi + j * NSRC * NC;
-        // NC rounds of lexicographic (value, id) minimum over the entries not taken yet
-        float sv[NC];
-        int sid[NC];
+        // rounds of lexicographic (value, id) minimum over the entries not taken yet: NC when the parts of a row are
+        // merged later (argmin_merge_kernel), W when this is the whole row; one more round gives the smallest entry left
+        const int rounds = nparts > 1 ? NC : W;
+        float sv[W];
+        int sid[W];
         float last_v = -INFINITY;
         int last_id = -1;
         bool first = true;
-#pragma unroll
-        for (int c = 0; c < NC; c++) {
+        float dropped = INFINITY;
+        for (int c = 0; c <= rounds; c++) {
             float bv = INFINITY;
             int bid = 0x7fffffff;
             for (int e = 0; e < NSRC * NC; e++) {
@@ -492,16 +519,35 @@ __global__ __launch_bounds__(MfmaCfg<T>::WM *MfmaCfg<T>::WN * 64, 2) void mfma_a
                     bid = eid;
                 }
             }
-            if (bid == 0x7fffffff) {  // nothing left (fewer finite candidates than NC)
+            if (bid == 0x7fffffff) {  // nothing left (fewer finite candidates than asked for)
                 bv = INFINITY;
                 bid = 0;
             }
-            sv[c] = bv;
-            sid[c] = bid;
+            if (c == rounds) {
+                dropped = bv;
+                break;
+            }
+#pragma unroll
+            for (int w = 0; w < W; w++)
+                if (w == c) {
+                    sv[w] = bv;
+                    sid[w] = bid;
+                }
+            if (bv == INFINITY) {  // the rest is padding
+#pragma unroll
+                for (int w = 0; w < W; w++)
+                    if (w > c) {
+                        sv[w] = INFINITY;
+                        sid[w] = 0;
+                    }
+                break;
+            }
             last_v = bv;
             last_id = bid;
             first = false;
         }
+        if constexpr (MODE == 0)
+            for (int s = 0; s < NSRC; s++) dropped = fminf(dropped, md[j * NSRC + s]);
         if (nparts > 1) {
             // this part's best NC of its centers: argmin_merge_kernel folds the parts of a row
 #pragma unroll
@@ -509,11 +555,15 @@ __global__ __launch_bounds__(MfmaCfg<T>::WM *MfmaCfg<T>::WN * 64, 2) void mfma_a
                 part_val[((size_t)r * nparts + part) * NC + c] = sv[c];
                 part_idx[((size_t)r * nparts + part) * NC + c] = sid[c];
             }
+            if constexpr (MODE == 0) part_drop[(size_t)r * nparts + part] = dropped;
             continue;
         }
-        float x2 = 0.f;
-        if constexpr (NC > 1) x2 = sizeof(T) == 2 ? part_x2[r] : mx[j * 2] + mx[j * 2 + 1];
-        finish_row<NC>(r, sv, sid, x2, out_idx, out_val, cmax2_bits, gamma, gamma_x, u_count, u_rows, u_cand, u_val);
+        if constexpr (NC > 1) {
+            const float x2 = sizeof(T) == 2 ? part_x2[r] : mx[j * 2] + mx[j * 2 + 1];
+            finish_l2(r, sv, sid, dropped, x2, out_idx, l2);
+        } else {
+            finish_ip(r, sv[0], sid[0], out_idx, out_val);
+        }
     }
 }
 
@@ -525,11 +575,10 @@ __global__ __launch_bounds__(MfmaCfg<T>::WM *MfmaCfg<T>::WN * 64, 2) void mfma_a
 template <int NC>
 __global__ __launch_bounds__(256) void argmin_merge_kernel(int64_t n, int nparts, int lg, const float *__restrict__ part_val,
                                                            const int32_t *__restrict__ part_idx,
-                                                           const float *__restrict__ part_x2, int32_t *__restrict__ out_idx,
-                                                           float *__restrict__ out_val, const unsigned *__restrict__ cmax2_bits,
-                                                           float gamma, float gamma_x, int *__restrict__ u_count,
-                                                           int32_t *__restrict__ u_rows, int32_t *__restrict__ u_cand,
-                                                           float *__restrict__ u_val) {
+                                                           const float *__restrict__ part_x2,
+                                                           const float *__restrict__ part_drop, int32_t *__restrict__ out_idx,
+                                                           float *__restrict__ out_val, const L2Lists l2) {
+    constexpr int W = NC > 1 ? kWide : 1;
     const int G = 1 << lg;
     const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     const int64_t r = t >> lg;
@@ -546,10 +595,10 @@ __global__ __launch_bounds__(256) void argmin_merge_kernel(int64_t n, int nparts
             if (v < INFINITY) list[c] = ((unsigned long long)float_to_key(v) << 32) | (unsigned)part_idx[at];
         }
     }
-    float sv[NC];
-    int sid[NC];
+    float sv[W];
+    int sid[W];
 #pragma unroll
-    for (int c = 0; c < NC; c++) {
+    for (int c = 0; c < W; c++) {
         unsigned long long best = list[0];
         for (int m = 1; m < G; m <<= 1) {
             const unsigned long long o = __shfl_xor(best, m);
@@ -568,9 +617,15 @@ __global__ __launch_bounds__(256) void argmin_merge_kernel(int64_t n, int nparts
             list[NC - 1] = ~0ull;
         }
     }
-    if (r < n && p == 0)
-        finish_row<NC>(r, sv, sid, NC > 1 ? part_x2[r] : 0.f, out_idx, out_val, cmax2_bits, gamma, gamma_x, u_count, u_rows,
-                       u_cand, u_val);
+    if constexpr (NC > 1) {
+        // the smallest value in none of the W: what a part turned away, or a part's head that is still waiting
+        float dropped = live ? part_drop[(size_t)r * nparts + p] : INFINITY;
+        if (list[0] != ~0ull) dropped = fminf(dropped, key_to_float((unsigned)(list[0] >> 32)));
+        for (int m = 1; m < G; m <<= 1) dropped = fminf(dropped, __shfl_xor(dropped, m));
+        if (r < n && p == 0) finish_l2(r, sv, sid, dropped, part_x2[r], out_idx, l2);
+    } else {
+        if (r < n && p == 0) finish_ip(r, sv[0], sid[0], out_idx, out_val);
+    }
 }
 
 // bias[c] = |c|^2 in fp32; *cmax2 = max_c |c|^2 (as ordered uint bits; a NaN norm ends up
@@ -594,62 +649,60 @@ __global__ __launch_bounds__(256) void center_norms_kernel(const char *__restric
     }
 }
 
-// The reference's exact sum((a-b)^2) for the kCand pre-filtered centers of the rows the
-// pre-filter left undecided (one wavefront per listed row), lexicographic minimum; rows whose
-// 4th candidate is not clear of the best either go on to the redo list.
+// The reference's exact sum((a-b)^2) for the in-band candidates (<= kWide) of the rows the pre-filter left undecided
+// (one wavefront per listed row), lexicographic minimum.  A row whose band holds more than the lists do -- its kWide-th
+// value, or the smallest value the lists turned away, is not clear of the best -- goes on to the redo list.
 template <typename T>
 __global__ __launch_bounds__(256) void recheck_kernel(const char *__restrict__ rows, const char *__restrict__ centers,
-                                                      int k, int nvec, const int *__restrict__ u_count,
-                                                      const int32_t *__restrict__ u_rows,
-                                                      const int32_t *__restrict__ u_cand,
-                                                      const float *__restrict__ u_val,
-                                                      const unsigned *__restrict__ cmax2_bits, float gamma,
-                                                      float gamma_x, int32_t *__restrict__ out_idx,
+                                                      int k, int nvec, const L2Lists l2, int32_t *__restrict__ out_idx,
                                                       int *__restrict__ fb_count,
                                                       int32_t *__restrict__ fb_rows,
                                                       unsigned long long *__restrict__ packed) {
     const int64_t p = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (p >= *u_count) return;
-    const int64_t r = u_rows[p];
+    if (p >= *l2.u_count) return;
+    const int64_t r = l2.u_rows[p];
     const int lane = threadIdx.x & (kWave - 1);
     const size_t row_bytes = (size_t)nvec * sizeof(Raw16);
     const char *row = rows + (size_t)r * row_bytes;
-    int id[kCand];
-    const char *cp[kCand];
-#pragma unroll
-    for (int c = 0; c < kCand; c++) {
-        id[c] = u_cand[p * kCand + c];
-        cp[c] = centers + (size_t)id[c] * row_bytes;
-    }
-    float d[kCand] = {0.f, 0.f, 0.f, 0.f};
-    float xx = 0.f;
-    for (int v = lane; v < nvec; v += kWave) {
-        const Raw16 x = load16(row + (size_t)v * sizeof(Raw16));
-        xx = accum_slice<T, 1>(xx, x, x);
-#pragma unroll
-        for (int c = 0; c < kCand; c++) d[c] = accum_slice<T, 0>(d[c], x, load16(cp[c] + (size_t)v * sizeof(Raw16)));
-    }
-    for (int m = 32; m > 0; m >>= 1) {
-        xx += __shfl_xor(xx, m);
-#pragma unroll
-        for (int c = 0; c < kCand; c++) d[c] += __shfl_xor(d[c], m);
-    }
-    if (lane != 0) return;
+    const float cm2 = __uint_as_float(*l2.cmax2), x2 = l2.u_x2[p];
+    const float v0 = l2.u_val[p * kWide];
+    // the candidates inside the band: a prefix of the ascending list (at least the best two)
+    int ncheck = 2;
+    while (ncheck < kWide && !out_of_band(l2.u_val[p * kWide + ncheck], v0, x2, cm2, l2.gamma, l2.gamma_x)) ncheck++;
     float bv = INFINITY;
     int bid = 0x7fffffff;
+    for (int c0 = 0; c0 < ncheck; c0 += kCand) {   // (wavefront-uniform)
+        int id[kCand];
+        const char *cp[kCand];
 #pragma unroll
-    for (int c = 0; c < kCand; c++)
-        if (d[c] < bv || (d[c] == bv && d[c] < INFINITY && id[c] < bid)) {
-            bv = d[c];
-            bid = id[c];
+        for (int c = 0; c < kCand; c++) {
+            id[c] = l2.u_cand[p * kWide + (c0 + c < ncheck ? c0 + c : c0)];
+            cp[c] = centers + (size_t)id[c] * row_bytes;
         }
+        float d[kCand] = {0.f, 0.f, 0.f, 0.f};
+        for (int v = lane; v < nvec; v += kWave) {
+            const Raw16 x = load16(row + (size_t)v * sizeof(Raw16));
+#pragma unroll
+            for (int c = 0; c < kCand; c++) d[c] = accum_slice<T, 0>(d[c], x, load16(cp[c] + (size_t)v * sizeof(Raw16)));
+        }
+        for (int m = 32; m > 0; m >>= 1) {
+#pragma unroll
+            for (int c = 0; c < kCand; c++) d[c] += __shfl_xor(d[c], m);
+        }
+#pragma unroll
+        for (int c = 0; c < kCand; c++)
+            if (c0 + c < ncheck && l2.u_val[p * kWide + c0 + c] < INFINITY &&
+                (d[c] < bv || (d[c] == bv && d[c] < INFINITY && id[c] < bid))) {
+                bv = d[c];
+                bid = id[c];
+            }
+    }
+    if (lane != 0) return;
     out_idx[r] = bid == 0x7fffffff ? 0 : bid;
-    if (k > kCand) {
-        const float cm2 = __uint_as_float(*cmax2_bits);
-        const float cross = 2.f * sqrtf(xx * cm2);
-        const float v0 = u_val[p * kCand], v3 = u_val[p * kCand + kCand - 1];
-        const float margin = 2.f * gamma * (cm2 + cross) + 2.02f * gamma_x * fabsf(v3 + xx);
-        if (!(v3 < INFINITY && v3 - v0 > margin)) {
+    if (k > kWide) {
+        // complete when the first value NOT evaluated is out of the band: the next of the list, and what the lists dropped
+        const bool list_ok = ncheck < kWide;   // (ncheck == kWide: the last of the list is inside -- there may be more)
+        if (!(list_ok && out_of_band(l2.u_drop[p], v0, x2, cm2, l2.gamma, l2.gamma_x))) {
             packed[r] = ~0ull;
             fb_rows[atomicAdd(fb_count, 1)] = (int32_t)r;
         }
@@ -702,14 +755,6 @@ __global__ void add_count_kernel(const int *u_count, const int *fb_count, double
     acc[2] += (double)*u_count;
 }
 
-struct L2Lists {  // device buffers of the L2 pipeline
-    const unsigned *cmax2 = nullptr;
-    float gamma = 0.f, gamma_x = 0.f;
-    int *u_count = nullptr;
-    int32_t *u_rows = nullptr, *u_cand = nullptr;
-    float *u_val = nullptr;
-};
-
 template <typename T, int MODE>
 int launch_mfma_t(pgv_ctx *ctx, const RowGeom &g, const void *rows, int64_t n, const void *centers, int k,
                   const float *bias, int32_t *out_idx, float *out_val, const L2Lists &l2 = L2Lists()) {
@@ -745,16 +790,18 @@ int launch_mfma_t(pgv_ctx *ctx, const RowGeom &g, const void *rows, int64_t n, c
         part_tiles = (center_tiles + 63) / 64;
         nparts = (center_tiles + part_tiles - 1) / part_tiles;
     }
-    float *part_val = nullptr, *part_x2 = nullptr;
+    float *part_val = nullptr, *part_x2 = nullptr, *part_drop = nullptr;
     int32_t *part_idx = nullptr;
     int64_t grid = row_tiles;
     const bool norms_pass = MODE == 0 && (nparts > 1 || sizeof(T) == 2);  // (the fp16 kernel never gathers |row|^2 itself)
     if (nparts > 1 || norms_pass) {
         const size_t pv = sizeof(float) * (size_t)n * nparts * NC;
-        PGV_TRY(ctx->mf_d.ensure(2 * pv + sizeof(float) * (size_t)n + 64));
+        const size_t pd = sizeof(float) * (size_t)n * nparts;
+        PGV_TRY(ctx->mf_d.ensure(2 * pv + pd + sizeof(float) * (size_t)n + 64));
         part_val = ctx->mf_d.as<float>();
         part_idx = reinterpret_cast<int32_t *>(ctx->mf_d.as<char>() + pv);
-        part_x2 = reinterpret_cast<float *>(ctx->mf_d.as<char>() + 2 * pv);
+        part_drop = reinterpret_cast<float *>(ctx->mf_d.as<char>() + 2 * pv);
+        part_x2 = reinterpret_cast<float *>(ctx->mf_d.as<char>() + 2 * pv + pd);
         if (nparts > 1) grid = 8 * ((row_tiles + 7) / 8) * nparts;
     }
     if (grid > 0x7fffffff) PGV_FAIL(PGV_ERR_ARG, "assignment: too many workgroups");
@@ -767,16 +814,14 @@ int launch_mfma_t(pgv_ctx *ctx, const RowGeom &g, const void *rows, int64_t n, c
     }
     hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(threads), lds, ctx->stream, static_cast<const char *>(rows), n,
                        static_cast<const char *>(centers), k, g.nvec, bias, static_cast<const char *>(ctx->zeros.p),
-                       out_idx, out_val, l2.cmax2, l2.gamma, l2.gamma_x, l2.u_count, l2.u_rows, l2.u_cand, l2.u_val, nparts,
-                       part_tiles, part_val, part_idx, part_x2);
+                       out_idx, out_val, l2, nparts, part_tiles, part_val, part_idx, part_x2, part_drop);
     PGV_HIP(hipGetLastError());
     if (nparts > 1) {
         int lg = 0;
         while ((1 << lg) < nparts) lg++;
         const int64_t threads_total = n << lg;
         hipLaunchKernelGGL(argmin_merge_kernel<NC>, dim3((unsigned)((threads_total + 255) / 256)), dim3(256), 0, ctx->stream, n,
-                           nparts, lg, part_val, part_idx, part_x2, out_idx, out_val, l2.cmax2, l2.gamma, l2.gamma_x, l2.u_count,
-                           l2.u_rows, l2.u_cand, l2.u_val);
+                           nparts, lg, part_val, part_idx, part_x2, part_drop, out_idx, out_val, l2);
         PGV_HIP(hipGetLastError());
     }
     return PGV_OK;
@@ -790,18 +835,18 @@ int launch_mfma_mode(pgv_ctx *ctx, int mode, const RowGeom &g, const void *rows,
 
     // L2: norms -> MFMA pre-filter (decides most rows) -> exact recheck of the undecided -> exact redo of
     // the still ambiguous (chunked over the centers) -> distances to the chosen centers if asked for.
-    // mf_a: bias[k] | cmax2 | u_count | fb_count      mf_b: u_cand[n x 4] | u_val[n x 4]
+    // mf_a: bias[k] | cmax2 | u_count | fb_count      mf_b: u_cand[n x kWide] | u_val[n x kWide] | u_drop[n] | u_x2[n]
     // mf_c: u_rows[n] | fb_rows[n] | packed[n] (uint64)
     const pgv_dtype dtype = sizeof(T) == 4 ? PGV_F32 : PGV_F16;
     PGV_TRY(ctx->mf_a.ensure(sizeof(float) * (size_t)k + 64));
-    PGV_TRY(ctx->mf_b.ensure((sizeof(int32_t) + sizeof(float)) * (size_t)n * kCand));
+    PGV_TRY(ctx->mf_b.ensure((sizeof(int32_t) + sizeof(float)) * (size_t)n * kWide + 2 * sizeof(float) * (size_t)n));
     PGV_TRY(ctx->mf_c.ensure((2 * sizeof(int32_t) + sizeof(unsigned long long)) * (size_t)n + 16));
     float *bias = ctx->mf_a.as<float>();
     unsigned *cmax2 = reinterpret_cast<unsigned *>(bias + k);
     int *u_count = reinterpret_cast<int *>(cmax2 + 1);
     int *fb_count = u_count + 1;
     int32_t *u_cand = ctx->mf_b.as<int32_t>();
-    float *u_val = reinterpret_cast<float *>(u_cand + (size_t)n * kCand);
+    float *u_val = reinterpret_cast<float *>(u_cand + (size_t)n * kWide);
     unsigned long long *packed = ctx->mf_c.as<unsigned long long>();
     int32_t *u_rows = reinterpret_cast<int32_t *>(packed + n);
     int32_t *fb_rows = u_rows + n;
@@ -817,13 +862,15 @@ int launch_mfma_mode(pgv_ctx *ctx, int mode, const RowGeom &g, const void *rows,
     l2.u_rows = u_rows;
     l2.u_cand = u_cand;
     l2.u_val = u_val;
+    l2.u_drop = u_val + (size_t)n * kWide;
+    l2.u_x2 = l2.u_drop + n;
     PGV_TRY((launch_mfma_t<T, 0>(ctx, g, rows, n, centers, k, bias, out_idx, nullptr, l2)));
     // the lists' lengths stay on the device: grids cover the worst case, surplus workgroups leave at once
     hipLaunchKernelGGL(recheck_kernel<T>, dim3((unsigned)((n + 3) / 4)), dim3(256), 0, ctx->stream,
-                       static_cast<const char *>(rows), static_cast<const char *>(centers), k, g.nvec, u_count, u_rows,
-                       u_cand, u_val, cmax2, l2.gamma, l2.gamma_x, out_idx, fb_count, fb_rows, packed);
+                       static_cast<const char *>(rows), static_cast<const char *>(centers), k, g.nvec, l2, out_idx, fb_count,
+                       fb_rows, packed);
     PGV_HIP(hipGetLastError());
-    if (k > kCand) {
+    if (k > kWide) {
         PGV_TRY(launch_argmin_listed(ctx, 0, dtype, g, rows, n, centers, k, fb_rows, fb_count, packed));
         hipLaunchKernelGGL(redo_finish_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, fb_count,
                            fb_rows, packed, out_idx);

@@ -126,7 +126,7 @@ struct pgv_ctx {
     bool no_mfma_scan = false;  // pgv_ctx_set_exact_scan
     bool no_widen = false;      // PGV_NO_WIDEN=1: flagged queries go straight to the exact pass (experiments)
     int bound_mode = 1;         // the scans' bound: PGV_BOUND_WORST_CASE unless pgv_ctx_set_bound says otherwise
-    int assign_bound_mode = 0;  // the assignment pre-filter's: PGV_BOUND_STATISTICAL unless pgv_ctx_set_bound(WORST_CASE)
+    int assign_bound_mode = 1;  // the assignment pre-filter's: PGV_BOUND_WORST_CASE too since round 6 (pgv_ctx_set_bound)
     pgv::DBuf xt_norms;         // pgv_exact_topk: |row|^2 of the caller's rows
     std::vector<hipEvent_t> ev_pool;  // start/stop pairs
     size_t ev_used = 0;
@@ -279,11 +279,15 @@ namespace pgv {
 //                            a row outside the band must stay outside when both its and the k-th row's exact values move
 //                  |x| is the largest row norm of the index (one word, kept with the norms).
 // ArgminBound -- the build's L2 pre-filter (mfma_argmin_kernel, ONE accumulator chain per output: 128 accumulators a
-//   lane leave no room for four): gamma (|c|^2 + 2 |a||c|) + gamma_x d.  Its DEFAULT stays the statistical gamma: on one
-//   chain the deterministic gamma_(dim+1) is 5-10 x wider, which at 3072 dimensions sends 10 % of the rows to the exact
-//   redo kernel (1.25 M x 4096 x 3072 fp16: 32 -> 123 ms, profiles/r04); a row the statistical bound misjudges goes to a
-//   list whose center is as near as the reference's choice to within the float tolerance of the distances -- a tie the
-//   reference's own summation order does not pin either.  pgv_ctx_set_bound(PGV_BOUND_WORST_CASE) switches it too.
+//   lane leave no room for four): gamma (|c|^2 + 2 |a||c|) + gamma_x d, DETERMINISTIC by default since round 6:
+//   gamma = gamma_(dim+1), 5-10 x wider than the statistical 8 sqrt(dim + 4) u.  What made that affordable is not a
+//   tighter band but cheaper ambiguity: a row's merged list carries kWide = 8 candidates and `dropped`, the smallest value
+//   no list kept (keep_best), so the exact recheck evaluates whatever lies inside the band and only a row whose band holds
+//   MORE than the lists do (its 8th value or `dropped` inside it) goes to the all-centers exact kernel -- round 5 sent
+//   every row whose 4th value was inside (10 % of 3072-d rows: 32 -> 123 ms).  Measured (profiles/r06/assign_bounds.md):
+//   worst case over statistical +4 % (1 M x 1000 x 1536 fp32), +10 % (1.25 M x 4096 x 3072 fp16), redo 0 - 0.06 %.
+//   One unit roundoff per product of the chain is what the bound charges; tools/mfma_numerics.py shows the fp32 matrix
+//   instructions to BE an fmaf chain bit for bit and the fp16 ones to lose at most 3.2 u per 16 products (charged: 16 u).
 struct ScanBound {
     float g_sq, g_dot, g_norm, g_ref;
 };

@@ -1,0 +1,88 @@
+"""Round 6: the L2 assignment's completeness bound is deterministic by default."""
+import numpy as np
+import pytest
+
+from pgvector_amd import api
+
+from helpers import gen  # noqa: F401
+from oracle import pyoracle as po
+
+pytestmark = pytest.mark.gpu
+
+
+def _near_tie_case(seed, n, k, dim):
+    """Integer data: a row's squared distances to the two centers of ITS group are exact in fp32 in any summation order
+    (sums of integer squares below 2^24), so the reference's argmin between them is a fact, not a property of its
+    compiler's vectorisation -- and they are 0, 1 or 2 apart at magnitudes 2^23 .. 2^24, where fp32 has ulp 1.
+    Centers come in groups of two: the odd one is its left neighbour with coordinate j moved up by 1 (every fourth group:
+    coordinate l moved down by 1 as well).  A row is a center of its group + noise of amplitude A (dim A^2 / 3 ~ 1.15e7),
+    with its coordinates j (and l) set on purpose: distance to the odd center minus distance to the even one is then
+    -1 or +1 (two-coordinate groups: 0, 2 or 4) -- exact ties included, which the LOWER id must win
+    (src/ivfbuild.c:187-191).  Every other group is ~6e7 away."""
+    rng = np.random.default_rng(seed)
+    amp = int(np.sqrt(3 * 1.15e7 / dim))
+    base = rng.integers(400, 1600, (k // 2, dim)).astype(np.float32)
+    centers = np.repeat(base, 2, axis=0)
+    jj = rng.integers(0, dim, k // 2)
+    ll = (jj + 1 + rng.integers(0, dim - 1, k // 2)) % dim
+    two = (np.arange(k // 2) % 4) == 0
+    for g in range(k // 2):
+        centers[2 * g + 1, jj[g]] += 1.0
+        if two[g]:
+            centers[2 * g + 1, ll[g]] -= 1.0
+    grp = rng.integers(0, k // 2, n)
+    rows = base[grp] + rng.integers(-amp, amp + 1, (n, dim)).astype(np.float32)
+    r = np.arange(n)
+    rows[r, jj[grp]] = base[grp, jj[grp]] + rng.integers(0, 2, n)
+    rows[r, ll[grp]] = np.where(two[grp], base[grp, ll[grp]] + rng.integers(0, 2, n), rows[r, ll[grp]])
+    assert rows.min() >= 0 and rows.max() < 2048
+    return np.ascontiguousarray(rows), np.ascontiguousarray(centers), grp
+
+
+@pytest.mark.parametrize("tname", ["f32", "f16"])
+@pytest.mark.parametrize("n,k,dim", [(40_000, 256, 256), (20_000, 1024, 1024), (6_000, 40, 1536)])
+def test_adversarial_near_tie_centers_get_the_oracles_list_ids_exactly(ctx, oracle, tname, n, k, dim):
+    rows, centers, grp = _near_tie_case(7 + dim, n, k, dim)
+    dt, odt, npdt = (api.PGV_F32, po.ORA_F32, np.float32) if tname == "f32" else (api.PGV_F16, po.ORA_F16, np.float16)
+    rows, centers = rows.astype(npdt), centers.astype(npdt)       # (integers below 2048: exact in fp16 too)
+    want, wd = oracle.assign(po.OPS_L2, odt, centers, rows)
+    got, gd = api.assign(ctx, api.PGV_L2SQ, dt, dim, centers, rows, want_dist=True)
+    got, gd = np.asarray(got), np.asarray(gd)
+    # how adversarial it is: the two centers of a row's group, in float64 (exact here)
+    r64 = rows[:4000].astype(np.float64)
+    d0 = ((r64 - centers[2 * grp[:4000]].astype(np.float64)) ** 2).sum(-1)
+    d1 = ((r64 - centers[2 * grp[:4000] + 1].astype(np.float64)) ** 2).sum(-1)
+    assert d0.max() < 2 ** 24 and d1.max() < 2 ** 24 and np.median(d0) > 2 ** 23
+    gap_ulp = np.abs(d1 - d0) / np.spacing(np.minimum(d0, d1).astype(np.float32))
+    assert (gap_ulp <= 4).all() and (gap_ulp == 0).mean() > 0.03 and (gap_ulp == 1).mean() > 0.3
+    assert (np.asarray(want)[:4000] // 2 == grp[:4000]).all()         # the nearest center IS one of the two
+    np.testing.assert_array_equal(got, want)
+    np.testing.assert_array_equal(gd, wd)        # exact data: the distances are the reference's bit for bit
+
+
+def test_both_bounds_choose_alike_and_the_default_is_the_deterministic_one(ctx, oracle):
+    """real-valued data (the oracle's own summation order is one of many): ids equal the oracle's wherever its two best
+    distances differ by more than the float tolerance, under the default AND under the statistical bound; the counters say
+    which rows were rechecked / redone"""
+    n, k, dim = 30_000, 500, 768
+    rows = gen(n, dim, seed=61, dist="clustered", clusters=125)
+    centers = rows[np.random.default_rng(62).choice(n, k, replace=False)].copy()
+    want, wd = oracle.assign(po.OPS_L2, po.ORA_F32, centers, rows)
+    res = {}
+    for mode in ("default", "statistical", "worst"):
+        if mode != "default":
+            ctx.set_bound(mode == "worst")
+        ctx.set_profiling(True)
+        ctx.reset_stats()
+        got, gd = api.assign(ctx, api.PGV_L2SQ, api.PGV_F32, dim, centers, rows, want_dist=True)
+        st = ctx.stats()
+        ctx.set_profiling(False)
+        res[mode] = (np.asarray(got), st["assign_recheck_rows"], st["assign_redo_rows"])
+        diff = np.nonzero(res[mode][0] != want)[0]
+        for r in diff:       # a float-level tie on the oracle's side: both centers as near as each other to 1e-5
+            d = ((rows[r].astype(np.float64) - centers[[res[mode][0][r], want[r]]].astype(np.float64)) ** 2).sum(-1)
+            assert abs(d[0] - d[1]) <= 1e-5 * d[1], (mode, r, d)
+        assert len(diff) <= n // 1000
+    ctx.set_bound(True)      # back to the library's default for the rest of the session
+    np.testing.assert_array_equal(res["default"][0], res["worst"][0])
+    assert res["default"][1] == res["worst"][1] and res["default"][1] >= res["statistical"][1]

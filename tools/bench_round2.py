@@ -190,10 +190,14 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--what", default="assign,query")
     ap.add_argument("--cases", default="", help="comma-separated substrings of the assign cases to run (default: all)")
+    ap.add_argument("--bound", default="default", choices=("default", "statistical", "worst"),
+                    help="pgv_ctx_set_bound before the runs (default: whatever the library starts with)")
     args = ap.parse_args()
     CASES.extend(c for c in args.cases.split(",") if c)
     ctx = api.Context(0, stream=0)
-    out = {}
+    if args.bound != "default":
+        ctx.set_bound(args.bound == "worst")
+    out = {"bound": args.bound}
     for w in args.what.split(","):
         {"assign": bench_assign, "query": bench_query}[w](ctx, out)
     print(json.dumps(out))
