@@ -91,6 +91,9 @@ WORKLOADS = {
     "c5": (10_000_000, 3072, 4096, 64, "f16", "l2"),
     # configs[2]'s shape at reduced rows, for a functional N-rank run on ONE GPU (--gpus 8 --backend gloo)
     "c3small": (320_000, 1536, 256, 16, "f32", "ip"),
+    # the headline's shape on the mid-difficulty data set (gen_hard): recall@10 well below 1 at probes 10
+    "hard": (1_000_000, 1536, 1000, 10, "f32", "l2"),
+    "hardsmall": (100_000, 256, 100, 10, "f32", "l2"),
     "small": (100_000, 256, 100, 10, "f32", "l2"),          # quick functional run
     "smallh": (100_000, 512, 100, 10, "f16", "ip"),
 }
@@ -128,6 +131,43 @@ def gen_mixture(n, dim, components, sigma, seed, device, means=None, lo=0, hi=No
         comp = torch.randint(0, means.shape[0], (s1 - s0,), generator=g, device=device)
         slab = means[comp]
         slab.add_(torch.randn((s1 - s0, dim), generator=g, device=device, dtype=torch.float32), alpha=sigma)
+        a, b = max(lo, s0), min(hi, s1)
+        out[a - lo:b - lo] = slab[a - s0:b - s0]
+    return out, means
+
+
+HARD = {"sigma": 3.0, "alpha": 0.6, "zipf": 0.8}   # --hard-sigma / --hard-alpha / --hard-zipf
+
+
+def hard_scales(dim, alpha, device):
+    """per-dimension standard deviations ~ (j + 1)^(-alpha / 2), mean variance 1: a power-law spectrum (what PCA of real
+    embeddings looks like: a few dozen directions carry most of the variance -- low intrinsic dimension)"""
+    sc = torch.arange(1, dim + 1, device=device, dtype=torch.float32).pow(-alpha / 2.0)
+    return sc * (dim / (sc * sc).sum()).sqrt()
+
+
+def gen_hard(n, dim, components, seed, device, means=None, lo=0, hi=None, sigma=None, alpha=None, zipf=None):
+    """the mid-difficulty data set (SURVEY 8d "Synthetic inputs"): a Gaussian mixture whose components
+    OVERLAP (component spread `sigma` x the spread of the means, against 0.1 x a unit cube for the easy mixture), with a
+    power-law variance per dimension and Zipf-weighted components (unbalanced lists).  Slab-keyed like gen_mixture.
+    Returns (rows [lo, hi), means)."""
+    sigma = HARD["sigma"] if sigma is None else sigma
+    alpha = HARD["alpha"] if alpha is None else alpha
+    zipf = HARD["zipf"] if zipf is None else zipf
+    hi = n if hi is None else hi
+    g = torch.Generator(device=device)
+    g.manual_seed(seed)
+    sc = hard_scales(dim, alpha, device)
+    if means is None:
+        means = torch.randn((components, dim), generator=g, device=device, dtype=torch.float32) * sc
+    w = torch.arange(1, means.shape[0] + 1, device=device, dtype=torch.float32).pow(-zipf)
+    out = torch.empty((hi - lo, dim), device=device, dtype=torch.float32)
+    for s0 in range(lo // SLAB * SLAB, hi, SLAB):
+        s1 = min(n, s0 + SLAB)
+        g.manual_seed(seed * 1000003 + 7919 * (s0 // SLAB) + 1)
+        comp = torch.multinomial(w, s1 - s0, replacement=True, generator=g)
+        slab = means[comp]
+        slab.add_(torch.randn((s1 - s0, dim), generator=g, device=device, dtype=torch.float32) * sc, alpha=sigma)
         a, b = max(lo, s0), min(hi, s1)
         out[a - lo:b - lo] = slab[a - s0:b - s0]
     return out, means
@@ -613,7 +653,7 @@ def hnsw_section(ctx, dev, args, failures, rows=1_000_000, dim=1536, m=16, efc=6
     kth = best[:, -1]
     qd = q.repeat(max(1, 20000 // nq), 1).contiguous()
     sweep, keep = {}, None
-    for ef in efs:
+    def run_ef(ef):
         mirror.search(qd[:64].contiguous(), ef, k)
         torch.cuda.synchronize()
         t0 = time.perf_counter()
@@ -627,11 +667,32 @@ def hnsw_section(ctx, dev, args, failures, rows=1_000_000, dim=1536, m=16, efc=6
         sweep[str(ef)] = {"qps": qd.shape[0] / dev_s, "recall_at_10": recall,
                           "scored_elements_per_query": float(scored.float().mean().item()),
                           "scored_rows_GBps": gbps, "frac_of_hbm_peak": gbps / HBM_PEAK_GBS}
+        return e, gd, recall
+    for ef in efs:
+        e, gd, _ = run_ef(ef)
         if ef == 100:
             keep = (e.cpu().numpy(), gd[:nq].cpu().numpy())
+    # a usable operating point: the smallest ef_search of the ladder (up to the reference's maximum of 1000,
+    # src/hnsw.h HNSW_MAX_EF_SEARCH) whose recall@10 reaches 0.95, and the QPS there
+    at95 = None
+    try:
+        for ef in sorted(set(efs) | {400, 600, 800, 1000}):
+            rec = sweep[str(ef)]["recall_at_10"] if str(ef) in sweep else run_ef(ef)[2]
+            if rec >= 0.95:
+                at95 = {"ef_search": ef, "qps": sweep[str(ef)]["qps"], "recall_at_10": rec,
+                        "frac_of_hbm_peak": sweep[str(ef)]["frac_of_hbm_peak"]}
+                break
+        if at95 is None:
+            top = max(int(e_) for e_ in sweep)
+            at95 = {"ef_search": None, "highest": {"ef_search": top, "recall_at_10": sweep[str(top)]["recall_at_10"],
+                                                    "qps": sweep[str(top)]["qps"]},
+                    "note": "recall@10 %.4f at ef_search %d (the reference's maximum is 1000): 0.95 is not reached on this data "
+                            "with m %d / ef_construction %d" % (sweep[str(top)]["recall_at_10"], top, m, efc)}
+    except Exception as e_:  # noqa: BLE001
+        at95 = {"error": repr(e_)}
     out = {"workload": "HNSW vector_cosine_ops %d x %d f32, m %d, ef_construction %d, k %d (BASELINE configs[3])"
                        % (rows, dim, m, efc, k),
-           "queries_in_flight": int(qd.shape[0]), "ef_search": sweep,
+           "queries_in_flight": int(qd.shape[0]), "ef_search": sweep, "recall_0.95_at": at95,
            "recall_ground_truth": "exact float64 inner products over all rows, %d queries" % nq,
            "roofline_note": "scored_rows_GBps = element rows gathered x 6 KB / search seconds: a 6 GB mirror does not "
                             "fit the 256 MB MALL, so this is HBM traffic (gathers of whole rows)",
@@ -717,11 +778,22 @@ def run_workload(ctx, dev, name, args, failures, steps=10, parity_queries=64):
     esize = 4 if tname == "f32" else 2
     k, batch, pool = args.k, args.batch, 4
     components = max(lists // 4, 1)
-    data, means = gen_mixture(n, dim, components, 0.1, args.seed + 50, dev)
+    hard = name.startswith("hard")
+    if hard:
+        data, means = gen_hard(n, dim, components, args.seed + 50, dev)
+    else:
+        data, means = gen_mixture(n, dim, components, 0.1, args.seed + 50, dev)
     data = data.to(tdtype)
+    ctx.set_profiling(True)
+    ctx.reset_stats()
     centers, offsets, vectors, tids, iters, build_t, index = build_index(ctx, data, lists, args.seed, 1, 0, dtype, ops, metric)
+    build_stats = ctx.stats()
+    ctx.set_profiling(False)
     del data
-    queries, _ = gen_mixture(batch * pool, dim, components, 0.1, args.seed + 150, dev, means=means)
+    if hard:
+        queries, _ = gen_hard(batch * pool, dim, components, args.seed + 150, dev, means=means)
+    else:
+        queries, _ = gen_mixture(batch * pool, dim, components, 0.1, args.seed + 150, dev, means=means)
     queries = queries.to(tdtype).view(pool, batch, dim)
     od = torch.empty((batch, k), device=dev, dtype=torch.float32)
     os_ = torch.empty((batch, k), device=dev, dtype=torch.int64)
@@ -741,9 +813,11 @@ def run_workload(ctx, dev, name, args, failures, steps=10, parity_queries=64):
     s = timed_steps(step, steps, warmup=0)
     stats = ctx.stats()
     ctx.set_profiling(False)
-    out = {"workload": "%s: IVFFlat %s_%s_ops %d x %d %s, lists=%d, probes=%d, k=%d, batch=%d, Gaussian mixture (%d "
-                       "components, sigma 0.1)" % (name, "vector" if tname == "f32" else "halfvec", oname, n, dim, tname,
-                                                   lists, probes, k, batch, components),
+    what = ("overlapping Gaussian mixture (%d Zipf(%.1f)-weighted components, component sigma %.2f x the means' spread, "
+            "per-dimension variance ~ j^-%.1f)" % (components, HARD["zipf"], HARD["sigma"], HARD["alpha"])) if hard else \
+        "Gaussian mixture (%d components, sigma 0.1)" % components
+    out = {"workload": "%s: IVFFlat %s_%s_ops %d x %d %s, lists=%d, probes=%d, k=%d, batch=%d, %s"
+                       % (name, "vector" if tname == "f32" else "halfvec", oname, n, dim, tname, lists, probes, k, batch, what),
            "qps": batch / s, "ms_per_step": s * 1e3, "steps": steps, "recall_at_10": recall,
            "recall_ground_truth": "exact float64 brute force over all %d rows, %d queries" % (n, rq),
            "build_secs": build_t["total"], "build_phases_secs": build_t, "kmeans_iterations": iters,
@@ -752,6 +826,48 @@ def run_workload(ctx, dev, name, args, failures, steps=10, parity_queries=64):
            "roofline": roofline_record(stats, esize, dim, tname, "mfma_scan_kernel (IVFFlat list scan)")}
     if oname == "l2":
         out["bound_statistical"] = bound_mode_run(ctx, step, steps, batch)
+    if hard:
+        # what the easy mixture cannot show: recall below 1, lists of unequal length, Lloyd running for dozens of
+        # iterations, the completeness bounds with something to do
+        sizes = (offsets[1:] - offsets[:-1]).double()
+        out["list_rows_max_over_mean"] = float(sizes.max().item() / sizes.mean().item())
+        out["list_rows_min"], out["list_rows_max"] = int(sizes.min().item()), int(sizes.max().item())
+        out["build_assign"] = {"rows": build_stats["assign_rows"],
+                               "rechecked_fraction": build_stats["assign_recheck_rows"] / max(build_stats["assign_rows"], 1),
+                               "redone_fraction": build_stats["assign_redo_rows"] / max(build_stats["assign_rows"], 1)}
+        sweep = {}
+        for p in (1, 10, 32, 100):
+            if p > lists:
+                continue
+            ctx.set_profiling(True)
+            ctx.reset_stats()
+            sp = timed_steps(lambda j: index.search_batch(queries[j % pool], p, k, want_tid=True, out=(od, os_, ot)), 5)
+            st = ctx.stats()
+            ctx.set_profiling(False)
+            gdp, _, _ = index.search_batch(rqueries, p, k)
+            sweep[str(p)] = {"qps": batch / sp, "ms_per_step": sp * 1e3, "recall_at_10": recall_at_k(gdp, exact_d, k),
+                             "frac": roofline_record(st, esize, dim, tname, "")["frac"],
+                             "passes": roofline_record(st, esize, dim, tname, "")["passes"],
+                             "useful_tflops": roofline_record(st, esize, dim, tname, "")["useful_tflops"],
+                             "redo_queries_per_step": st["scan_redo_queries"] / 7, "widened_queries_per_step": st["scan_widened_queries"] / 7}
+        out["probes_sweep"] = sweep
+        # the assignment of every row under both bounds, same centers (the build above ran under the default)
+        ab = {}
+        for mode in ("worst_case", "statistical"):
+            ctx.set_bound(mode == "worst_case")
+            ctx.set_profiling(True)
+            ctx.reset_stats()
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            api.assign(ctx, metric, dtype, dim, centers, vectors, want_dist=False)
+            ctx.sync()
+            torch.cuda.synchronize()
+            st = ctx.stats()
+            ab[mode] = {"secs": time.perf_counter() - t0, "rechecked_fraction": st["assign_recheck_rows"] / max(st["assign_rows"], 1),
+                        "redone_fraction": st["assign_redo_rows"] / max(st["assign_rows"], 1)}
+            ctx.set_profiling(False)
+        ctx.set_bound(True)
+        out["assign_bounds"] = ab
     if not args.no_cpu_baseline:
         from oracle import pyoracle as po
         ora = po.Oracle(native=True)
@@ -1149,10 +1265,22 @@ def compact_line(full):
                         "rows": c.get("rows"), "build_secs": _r(c.get("build_secs")), "kmeans_secs": _r(c.get("kmeans_secs")),
                         "kmeans_iterations": c.get("kmeans_iterations"), "assign_secs": _r(c.get("assign_secs")),
                         "center_rank_ms": _r(c.get("center_rank_ms"))}
+    hd = full.get("hard")
+    if isinstance(hd, dict) and "qps" in hd:
+        oc["hard"] = {"qps": _r(hd.get("qps")), "recall": _r(hd.get("recall_at_10"), 4), "frac": _r((hd.get("roofline") or {}).get("frac"), 3),
+                      "parity_mismatches": (hd.get("parity") or {}).get("mismatches"),
+                      "parity_checked": (hd.get("parity") or {}).get("checked_queries"),
+                      "build_secs": _r(hd.get("build_secs"), 3), "kmeans_iterations": hd.get("kmeans_iterations"),
+                      "lists_max_over_mean": _r(hd.get("list_rows_max_over_mean"), 3),
+                      "recall_by_probes": {p: _r(v.get("recall_at_10"), 3) for p, v in (hd.get("probes_sweep") or {}).items()},
+                      "qps_by_probes": {p: _r(v.get("qps"), 3) for p, v in (hd.get("probes_sweep") or {}).items()}}
     hn = full.get("hnsw")
     if isinstance(hn, dict):
         ef = (hn.get("ef_search") or {}).get("100") or {}
+        a95 = hn.get("recall_0.95_at") or {}
         oc["c4_hnsw"] = {"qps": _r(ef.get("qps")), "recall": _r(ef.get("recall_at_10")), "frac": _r(ef.get("frac_of_hbm_peak")),
+                         "ef_for_recall_0.95": a95.get("ef_search"), "qps_at_recall_0.95": _r(a95.get("qps")),
+                         "highest_ef": _pick(a95.get("highest") or {}, ("ef_search", "recall_at_10", "qps")),
                          "parity_mismatches": (hn.get("parity") or {}).get("mismatches"),
                          "parity_checked": (hn.get("parity") or {}).get("checked_queries"),
                          "build_secs": _r(hn.get("build_secs"))}
@@ -1247,8 +1375,8 @@ def emit_line(fd, full):
 #      without a line).
 WATCH = {"line": None, "fd": None, "rank": 0, "section": "setup", "done": False}
 
-SECTION_BUDGET_S = {"configs": 120, "hnsw": 120, "build": 120, "sweeps": 120, "backends": 120, "c3full": 90, "c5full": 90}
-SECTION_ORDER = ("configs", "hnsw", "build", "traffic", "c3full", "c5full", "sweeps", "backends")
+SECTION_BUDGET_S = {"configs": 110, "hard": 80, "hnsw": 100, "build": 110, "sweeps": 100, "backends": 100, "c3full": 90, "c5full": 90}
+SECTION_ORDER = ("configs", "hard", "hnsw", "build", "traffic", "c3full", "c5full", "sweeps", "backends")
 
 
 def watchdog(deadline_s):
@@ -1440,7 +1568,11 @@ def headline_setup(args, dev, ctx, world=1, rank=0, comm=None, keep_host_rows=Fa
     H.k = args.k
     H.components = max(H.lists // 4, 1)
     row_lo, row_hi = sharding.row_shard(H.n, rank, world)
-    data, H.means = gen_mixture(H.n, H.dim, H.components, 0.1, args.seed, dev, lo=row_lo, hi=row_hi)
+    H.hard = args.workload.startswith("hard")
+    if H.hard:
+        data, H.means = gen_hard(H.n, H.dim, H.components, args.seed, dev, lo=row_lo, hi=row_hi)
+    else:
+        data, H.means = gen_mixture(H.n, H.dim, H.components, 0.1, args.seed, dev, lo=row_lo, hi=row_hi)
     data = data.to(H.tdtype)
     log("data: rows [%d, %d) of %d x %d %s generated" % (row_lo, row_hi, H.n, H.dim, H.tname))
     ctx.set_profiling(True)
@@ -1455,7 +1587,10 @@ def headline_setup(args, dev, ctx, world=1, rank=0, comm=None, keep_host_rows=Fa
     del data
     H.total_batch = args.batch * world
     H.pool = 8
-    queries, _ = gen_mixture(H.total_batch * H.pool, H.dim, H.components, 0.1, args.seed + 100, dev, means=H.means)
+    if H.hard:
+        queries, _ = gen_hard(H.total_batch * H.pool, H.dim, H.components, args.seed + 100, dev, means=H.means)
+    else:
+        queries, _ = gen_mixture(H.total_batch * H.pool, H.dim, H.components, 0.1, args.seed + 100, dev, means=H.means)
     H.queries = queries.to(H.tdtype).view(H.pool, H.total_batch, H.dim)
     return H
 
@@ -1483,6 +1618,20 @@ def section_configs(args, dev, ctx, out):
     except Exception as e:  # noqa: BLE001
         out.put("exact_scan", {"error": repr(e)})
         fails.append("exact_scan: %r" % (e,))
+
+
+def section_hard(args, dev, ctx, out):
+    """the headline's shape on the mid-difficulty data set: recall below 1, unbalanced lists, dozens of Lloyd iterations"""
+    fails = out.data["failures"]
+    out.at("other_configs.hard")
+    try:
+        r = run_workload(ctx, dev, "hard", args, fails)
+        log("hard: %.0f QPS, recall %.4f at probes 10, k-means %d iterations, lists max / mean %.2f" % (
+            r["qps"], r["recall_at_10"], r["kmeans_iterations"], r["list_rows_max_over_mean"]))
+        out.put("hard", r)
+    except Exception as e:  # noqa: BLE001
+        out.put("hard", {"error": repr(e)})
+        fails.append("hard: %r" % (e,))
 
 
 def section_hnsw(args, dev, ctx, out):
@@ -1780,7 +1929,7 @@ def section_full(which):
     return run
 
 
-SECTIONS = {"configs": section_configs, "hnsw": section_hnsw, "build": section_build, "sweeps": section_sweeps,
+SECTIONS = {"configs": section_configs, "hard": section_hard, "hnsw": section_hnsw, "build": section_build, "sweeps": section_sweeps,
             "backends": section_backends, "c3full": section_full("c3"), "c5full": section_full("c5")}
 
 
@@ -2004,6 +2153,9 @@ def main():
                     "oracle/_ref/ref_scan_bench run)")
     ap.add_argument("--cpu-port-secs", type=float, default=6.0, help="seconds of the oracle's threads (cpu_baseline.port)")
     ap.add_argument("--cpu-reference-secs", type=float, default=10.0, help="seconds of the reference's backend processes")
+    ap.add_argument("--hard-sigma", type=float, default=HARD["sigma"], help="gen_hard: component spread / spread of the means")
+    ap.add_argument("--hard-alpha", type=float, default=HARD["alpha"], help="gen_hard: per-dimension variance ~ j^-alpha")
+    ap.add_argument("--hard-zipf", type=float, default=HARD["zipf"], help="gen_hard: component weights ~ c^-zipf")
     ap.add_argument("--no-sweeps", action="store_true", help="skip every optional section (the child processes)")
     ap.add_argument("--no-traffic", action="store_true", help="skip the live rocprofv3 PMC passes")
     ap.add_argument("--sections", default=",".join(SECTION_ORDER),
@@ -2039,6 +2191,7 @@ def main():
     ap.add_argument("--no-self-launch", action="store_true", help="--gpus N > 1 without WORLD_SIZE in the environment is an "
                     "error instead of starting the N ranks from here")
     args = ap.parse_args()
+    HARD.update(sigma=args.hard_sigma, alpha=args.hard_alpha, zipf=args.hard_zipf)
     PLACEMENT["policy"] = args.placement
     t_program = time.perf_counter()
     # fd 1 carries the ONE JSON line and nothing else: libraries that greet on stdout (RCCL's version banner)
@@ -2280,9 +2433,12 @@ def main():
         "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
         "vs_baseline": None, "dtype": tname, "data": "synthetic",
         "config": {"workload": "%s: IVFFlat %s_%s_ops %d x %d %s, lists=%d, probes=%d, k=%d, "
-                               "batch=%d queries/step/GPU, Gaussian mixture (%d components, sigma 0.1)"
+                               "batch=%d queries/step/GPU, %s"
                                % (args.workload, "vector" if tname == "f32" else "halfvec", oname, n, dim, tname,
-                                  lists, probes, k, args.batch, components),
+                                  lists, probes, k, args.batch,
+                                  "overlapping Gaussian mixture (gen_hard: sigma %.2f, variance ~ j^-%.1f, Zipf %.1f)"
+                                  % (HARD["sigma"], HARD["alpha"], HARD["zipf"]) if H.hard
+                                  else "Gaussian mixture (%d components, sigma 0.1)" % components),
                    "rows": n, "dim": dim, "lists": lists, "probes": probes, "k": k,
                    "batch_per_gpu": args.batch, "settle_steps": settle_steps, "parallelism": "lists sharded over %d ranks (%s by rows); k-means all-reduce, probe-list and "
                                   "top-k all-gathers inside libpgv_hip (RCCL on the library's stream)" % (world, args.placement),
@@ -2413,7 +2569,7 @@ def main():
             if name == "traffic":
                 if args.no_traffic:
                     continue
-            elif args.no_sweeps or (name in ("configs", "hnsw", "c3full", "c5full") and args.workload != "headline"):
+            elif args.no_sweeps or (name in ("configs", "hard", "hnsw", "c3full", "c5full") and args.workload != "headline"):
                 continue
             WATCH["section"] = "section " + name
             if time.perf_counter() - t_program > args.budget_secs:
