@@ -115,6 +115,9 @@ PgvHnswBuildDefer(HnswBuildState * buildstate, HnswElement element)
 		ereport(DEBUG1, (errmsg("pgvector GPU path: parallel hnsw build, this participant inserts on the CPU path")));
 		pfree(gb);
 		buildstate->gpu = NULL;
+		/* the context PgvHnswBuildBegin made for this participant is of no use to it: give it (and its slot of
+		 * vector.gpu_max_own_contexts) back now, not at backend exit */
+		PgvReleaseIdleContext();
 		return false;
 	}
 
@@ -204,6 +207,13 @@ PgvHnswBuildLink(HnswBuildState * buildstate)
 	pgv_host_hnsw_set_cancel_check(NULL, NULL);
 	pgv_hnsw_free(mirror);
 	pfree(rows);
+	/* a cancel that arrived after the last between-batch poll: the interrupt's ERROR longjmps out of here, and `built`
+	 * (O(n m) of malloc'ed tables) would stay with the backend */
+	if (rc == PGV_OK && PgvBuildCancelPending(NULL))
+	{
+		pgv_host_hnsw_built_free(&built);
+		rc = PGV_ERR_STATE;
+	}
 	CHECK_FOR_INTERRUPTS();		/* a cancelled build: the interrupt's own ERROR, not ours */
 	if (rc != PGV_OK)
 		ereport(ERROR, (errmsg("pgvector GPU path: %s", pgv_host_last_error())));

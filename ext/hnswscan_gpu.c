@@ -56,6 +56,16 @@ typedef struct PgvHnswScan
 
 static PgvHnswMirror *hnswMirrors = NULL;
 
+/* pgv_context.c's PgvReleaseIdleContext: a context with an hnsw mirror mapped on it is not idle */
+bool
+PgvHnswHoldsImports(void)
+{
+	for (PgvHnswMirror * m = hnswMirrors; m != NULL; m = m->next)
+		if (m->h)
+			return true;
+	return false;
+}
+
 void
 PgvHnswInvalidate(Oid relid)	/* called from PgvRelcacheCallback */
 {

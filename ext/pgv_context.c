@@ -231,6 +231,8 @@ PgvRegistryEntries(void)
 	return used;
 }
 
+void		PgvReleaseIdleContext(void);
+
 /* ivfflatinsert (src/ivfinsert.c:72-181), ivfflatbulkdelete (src/ivfvacuum.c:18-143), hnswinsert, hnswbulkdelete and
  * ambuild call this after changing pages: mirrors staged before now are stale */
 void
@@ -238,6 +240,9 @@ PgvNoteIndexChange(Relation index)
 {
 	PgvSharedMirror *e;
 
+	/* ambuild ends here too (the last statement of ivfflatbuild / hnswbuild): the build's device context goes unless this
+	 * backend's scans hold imports on it (PgvReleaseIdleContext; an insert or vacuum in a scanning backend keeps it) */
+	PgvReleaseIdleContext();
 	if (PgvShared == NULL)
 		return;
 	LWLockAcquire(PgvShared->lock, LW_SHARED);
@@ -321,7 +326,7 @@ PgvGpuInit(void)
 	DefineCustomBoolVariable("vector.gpu_kmeans", "An ivfflat build computes its centers on the GPU (off: the CPU build's Elkan k-means and its exact centers; the rows are still assigned on the GPU)", NULL,
 							 &vector_gpu_kmeans, true, PGC_USERSET, 0, NULL, NULL, NULL);
 	DefineCustomIntVariable("vector.gpu_hnsw_build_batch", "Elements an hnsw build links at once on the GPU (1: the serial build's insertion order exactly)", NULL,
-							&vector_gpu_hnsw_build_batch, 1024, 1, 65536, PGC_USERSET, 0, NULL, NULL, NULL);
+							&vector_gpu_hnsw_build_batch, 1024, 1, 16384, PGC_USERSET, 0, NULL, NULL, NULL);
 	CacheRegisterRelcacheCallback(PgvRelcacheCallback, (Datum) 0);
 	on_proc_exit(PgvAtExit, (Datum) 0);
 	before_shmem_exit(PgvReleaseMyPoolSlot, (Datum) 0);
@@ -350,8 +355,8 @@ PgvGetContext(void)
  * one WARNING per backend, and no new attempt for PGV_CTX_RETRY_MS.
  */
 #define PGV_CTX_RETRY_MS 10000
-pgv_ctx *
-PgvTryGetContext(void)
+static pgv_ctx *
+PgvTryGetContextInternal(bool capped)
 {
 	static TimestampTz failedAt = 0;
 	static bool warned = false;
@@ -364,14 +369,19 @@ PgvTryGetContext(void)
 	 * The device runs the queues of FOUR processes side by side; from the fifth on they are time-sliced and ALL of
 	 * them slow down (MI355X, 1 M x 1536, one query at a time per process: 4 processes 52 k QPS, 5: 31 k, 8: 31 k,
 	 * 16: 27 k -- profiles/r05/own_context_process_sweep.md; threads of one process share its four queues and do not
-	 * show this).  So only vector.gpu_max_own_contexts backends hold a context of their own; the others get NULL
-	 * here, quietly, and their scans go through the GPU worker's pooler (PgvOwnContextsExhausted), which needs none.
+	 * show this).  Every backend that holds a context is COUNTED, but only a caller that has a pooled alternative is
+	 * CAPPED: an ivfflat scan beyond vector.gpu_max_own_contexts gets NULL here, quietly, and goes through
+	 * the GPU worker's pooler (PgvOwnContextsExhausted), which needs no context.  Builds (k-means, assignment, hnsw
+	 * linking) and hnsw scans have no pooled form -- denied a context they would silently fall back to the CPU, 10-100 x
+	 * slower -- so they are never denied; a build gives its context back when it ends (PgvReleaseIdleContext).
 	 */
 	if (workerSlot < 0 && PgvShared != NULL && !backend_ctx_counted)
 	{
-		if (pg_atomic_fetch_add_u64(&PgvShared->ownContexts, 1) >= (uint64) vector_gpu_max_own_contexts)
+		if (pg_atomic_fetch_add_u64(&PgvShared->ownContexts, 1) >= (uint64) vector_gpu_max_own_contexts && capped)
 		{
 			pg_atomic_fetch_add_u64(&PgvShared->ownContexts, -1);
+			ereport(DEBUG1, (errmsg("pgvector GPU path: %d backends hold a device context (vector.gpu_max_own_contexts): this backend's ivfflat scans pool",
+									vector_gpu_max_own_contexts)));
 			return NULL;
 		}
 		backend_ctx_counted = true;
@@ -390,6 +400,43 @@ PgvTryGetContext(void)
 		ereport(WARNING, (errmsg("pgvector GPU path unavailable (%s): using the CPU path", pgv_last_error())));
 	warned = true;
 	return NULL;
+}
+
+/* builds and hnsw scans: no pooled alternative, never denied by vector.gpu_max_own_contexts */
+pgv_ctx *
+PgvTryGetContext(void)
+{
+	return PgvTryGetContextInternal(false);
+}
+
+/* ivfflat scans: beyond the cap they pool instead */
+pgv_ctx *
+PgvTryGetScanContext(void)
+{
+	return PgvTryGetContextInternal(true);
+}
+
+/*
+ * A build is over: its backend may never touch the device again, and a context held until backend exit pins one of the
+ * device's four fast queues (four idle pooled connections that once built an index would push every other session's
+ * scans to the pooler).  Given back unless this backend's scans use it (an imported mirror) -- they would only make it
+ * again.
+ */
+void
+PgvReleaseIdleContext(void)
+{
+	if (backend_ctx == NULL || workerSlot >= 0)
+		return;
+	for (PgvIvfMirror * m = mirrors; m != NULL; m = m->next)
+		if (m->index)
+			return;
+	if (PgvHnswHoldsImports())
+		return;
+	pgv_ctx_destroy(backend_ctx);
+	backend_ctx = NULL;
+	if (backend_ctx_counted && PgvShared != NULL)
+		pg_atomic_fetch_add_u64(&PgvShared->ownContexts, -1);
+	backend_ctx_counted = false;
 }
 
 /* this backend has no context and would not be given one: its scans take the pooled path whatever vector.gpu_pooled says */
@@ -1306,10 +1353,10 @@ PgvIvfflatGetMirror(Relation index, uint64 wantStaged)
 	}
 	if (!m->valid)
 	{
-		pgv_ctx    *ctx = PgvTryGetContext();
+		pgv_ctx    *ctx = PgvTryGetScanContext();
 
 		if (ctx == NULL)
-			return NULL;		/* no device in this backend: the reference's path (a WARNING has said so) */
+			return NULL;		/* no device in this backend (a WARNING has said so), or beyond the cap: CPU path / pooler */
 		if (pgv_index_import(ctx, &handle, &m->index) != PGV_OK)
 		{
 			/* the exporter is gone (a worker that died takes its allocations with it): not this query's error.  The

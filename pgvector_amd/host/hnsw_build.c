@@ -1463,6 +1463,11 @@ pgv_host_hnsw_build(pgv_hnsw * mirror, pgv_dtype dtype, int dim, const void *row
 		return pgv_host_fail(PGV_ERR_ARG, "too many elements");
 	if (max_batch < 1)
 		max_batch = 1;
+	/* a list can receive every element of a batch as a newcomer (degenerate data: thousands of identical rows): the link
+	 * replay's record locals are int16 and its pair triangle is indexed in int (csrc/hnsw_link_core.h) -- a batch never
+	 * brings more than 16384 newcomers to one list */
+	if (max_batch > 16384)
+		max_batch = 16384;
 	if (max_batch > 2048)
 		max_batch = 2048;
 	memset(out, 0, sizeof(*out));
