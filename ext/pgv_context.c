@@ -40,7 +40,8 @@
 #include <signal.h>
 
 bool		vector_gpu = false;
-int			vector_gpu_device = 0;
+int			vector_gpu_device = -1;
+int			vector_gpu_build_devices = 0;
 int			vector_gpu_stage_wait_ms = 0;
 int			vector_gpu_restage_delay_ms = 1000;
 bool		vector_gpu_pooled = false;
@@ -313,8 +314,10 @@ PgvGpuInit(void)
 {
 	DefineCustomBoolVariable("vector.gpu", "Runs the distance hot path on the GPU (libpgv_hip)", NULL,
 							 &vector_gpu, false, PGC_USERSET, 0, NULL, NULL, NULL);
-	DefineCustomIntVariable("vector.gpu_device", "HIP device of this backend", NULL,
-							&vector_gpu_device, 0, 0, 63, PGC_USERSET, 0, NULL, NULL, NULL);
+	DefineCustomIntVariable("vector.gpu_device", "HIP device of this backend (-1: device 0, and parallel build worker w takes device (w + 1) mod the device count)", NULL,
+							&vector_gpu_device, -1, -1, 63, PGC_USERSET, 0, NULL, NULL, NULL);
+	DefineCustomIntVariable("vector.gpu_build_devices", "Devices an ivfflat build's k-means is sharded over (0: every device of the node, 1: this backend's only)", NULL,
+							&vector_gpu_build_devices, 0, 0, 16, PGC_USERSET, 0, NULL, NULL, NULL);
 	DefineCustomIntVariable("vector.gpu_stage_wait_ms", "How long a scan waits for the GPU worker to stage a mirror before it runs on the CPU", NULL,
 							&vector_gpu_stage_wait_ms, 0, 0, 600000, PGC_USERSET, 0, NULL, NULL, NULL);
 	DefineCustomIntVariable("vector.gpu_restage_delay_ms", "Minimum time between two stagings of one index", NULL,
@@ -341,10 +344,31 @@ PgvGpuInit(void)
 	}
 }
 
+/*
+ * The device of this backend.  vector.gpu_device pins it; -1 (the default) means device 0 -- except in the workers of a
+ * parallel CREATE INDEX (src/ivfbuild.c:830-966: the leader scans and assigns too), which spread over the node:
+ * worker w takes device (w + 1) mod the device count, the leader keeps 0.  Assignment, the build's dominant cost, needs
+ * no exchange between participants: every participant assigns the heap rows it scans on ITS device and
+ * feeds the shared tuplesort like the reference's workers do.  The worker that stages mirrors and the scans stay on
+ * device 0 (one mirror per index, on one device).
+ */
+int
+PgvMyDevice(void)
+{
+	int			n;
+
+	if (vector_gpu_device >= 0)
+		return vector_gpu_device;
+	if (ParallelWorkerNumber < 0)
+		return 0;
+	n = pgv_device_count();
+	return n > 1 ? (ParallelWorkerNumber + 1) % n : 0;
+}
+
 pgv_ctx *
 PgvGetContext(void)
 {
-	if (backend_ctx == NULL && pgv_ctx_create(vector_gpu_device, NULL, &backend_ctx) != PGV_OK)
+	if (backend_ctx == NULL && pgv_ctx_create(PgvMyDevice(), NULL, &backend_ctx) != PGV_OK)
 		ereport(ERROR, (errmsg("pgvector GPU path: %s", pgv_last_error())));
 	return backend_ctx;
 }
@@ -386,7 +410,7 @@ PgvTryGetContextInternal(bool capped)
 		}
 		backend_ctx_counted = true;
 	}
-	if (pgv_ctx_create(vector_gpu_device, NULL, &backend_ctx) == PGV_OK)
+	if (pgv_ctx_create(PgvMyDevice(), NULL, &backend_ctx) == PGV_OK)
 	{
 		failedAt = 0;
 		return backend_ctx;

@@ -169,6 +169,9 @@ typedef IndexTupleData *IndexTuple;
 typedef struct TupleDescData *TupleDesc;
 Datum		index_getattr(IndexTuple tup, int attnum, TupleDesc tupleDesc, bool *isnull);
 
+/* access/parallel.h */
+extern int	ParallelWorkerNumber;
+
 /* utils/rel.h, utils/inval.h */
 struct RelationData
 {

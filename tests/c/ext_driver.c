@@ -36,6 +36,7 @@
 
 void		mock_hip_set_arena(void *base, size_t bytes) __attribute__((weak));
 int			mock_hip_live_queries(void) __attribute__((weak));
+int			mock_hip_contexts_made(int device) __attribute__((weak));
 
 #define EXPECT(cond) do { if (!(cond)) { fprintf(stderr, "%s:%d: [%s] EXPECT(%s) failed\n", __FILE__, __LINE__, scenario, #cond); return 1; } } while (0)
 static const char *scenario = "setup";
@@ -2070,6 +2071,143 @@ backend_reference_scan(void *arg)
 	return 0;
 }
 #endif
+
+/* ------------------------------------------------------------------------------------------------ several devices
+ * ext/ivfbuild_gpu.c PgvKmeansOnDevices: the leader of a build shards its k-means samples over the devices of the node,
+ * one helper thread and one context per further device, pgv_comm_unique_id / pgv_comm_create / pgv_kmeans_sharded (RCCL in
+ * libpgv_hip; threads of this process meeting through the id on the stand-in device, whose node has MOCK_HIP_DEVICES = 3).
+ * The centers must be the single-device pgv_kmeans' for the same seed, to the float tolerance (the all-reduce adds the
+ * ranks' sums in another order).  PgvMyDevice: parallel build worker w takes device (w + 1) mod the device count. */
+static int
+backend_multi_device_kmeans(void *arg)
+{
+	Relation	index = shim_open_relation(REL_IVF);
+	const int	n = 6000,
+				lists = 24;
+	const Size	itemsize = offsetof(Vector, x) + sizeof(float) * DIM;
+	float	   *rows = malloc(sizeof(float) * (size_t) n * DIM);
+	float	   *single = malloc(sizeof(float) * (size_t) lists * DIM);
+	VectorArrayData samples,
+				centers;
+	pgv_rng		rng;
+	uint64		seed;
+	int			iters = 0,
+				made1,
+				made2;
+	double		worst = 0.0;
+
+	(void) arg;
+	scenario = "k-means over the devices of the node";
+	setenv("MOCK_HIP_DEVICES", "3", 1);
+	shim_set_guc_bool("vector.gpu", true);
+	/* the device of a participant */
+	EXPECT(pgv_device_count() == 3 || !mock_hip_set_arena);
+	if (mock_hip_set_arena)
+	{
+		EXPECT(PgvMyDevice() == 0);	/* the leader */
+		ParallelWorkerNumber = 0;
+		EXPECT(PgvMyDevice() == 1);
+		ParallelWorkerNumber = 1;
+		EXPECT(PgvMyDevice() == 2);
+		ParallelWorkerNumber = 2;
+		EXPECT(PgvMyDevice() == 0);
+		shim_set_guc_int("vector.gpu_device", 1);	/* pinned */
+		EXPECT(PgvMyDevice() == 1);
+		shim_set_guc_int("vector.gpu_device", -1);
+		ParallelWorkerNumber = -1;
+	}
+	gen_rows(rows, n, DIM, 31);
+	samples.length = samples.maxlen = n;
+	samples.dim = DIM;
+	samples.itemsize = itemsize;
+	samples.items = palloc0(itemsize * (Size) n);
+	for (int i = 0; i < n; i++)
+	{
+		Vector	   *v = (Vector *) VectorArrayGet(&samples, i);
+
+		v->vl_len_ = (int32) (itemsize << 2);
+		v->dim = (int16) DIM;
+		memcpy(v->x, rows + (size_t) i * DIM, sizeof(float) * DIM);
+	}
+	centers.length = 0;
+	centers.maxlen = lists;
+	centers.dim = DIM;
+	centers.itemsize = itemsize;
+	centers.items = palloc0(itemsize * (Size) lists);
+	/* the seed PgvKmeansOnDevices will draw: the first RandomInt() of this stream, in the upper half */
+	shim_seed_random(99);
+	seed = (uint64) (uint32) RandomInt() << 32;
+	shim_seed_random(99);
+	made1 = mock_hip_contexts_made ? mock_hip_contexts_made(1) : 0;
+	made2 = mock_hip_contexts_made ? mock_hip_contexts_made(2) : 0;
+	EXPECT(PgvIvfflatKmeans(index, &samples, &centers, IvfflatGetTypeInfo(index)));
+	EXPECT(centers.length == lists);
+	if (mock_hip_contexts_made)
+	{
+		/* one helper context on each of the other two devices, made for this k-means and gone with it */
+		EXPECT(mock_hip_contexts_made(1) == made1 + 1);
+		EXPECT(mock_hip_contexts_made(2) == made2 + 1);
+	}
+	{
+		/* one participant holding every sample (a group of one -- through RCCL on the real device), the same seeded stream */
+		unsigned char id[PGV_COMM_ID_BYTES];
+		pgv_comm   *solo = NULL;
+
+		memset(&rng, 0, sizeof(rng));
+		rng.seed = seed;
+		EXPECT(pgv_comm_unique_id(id) == PGV_OK);
+		EXPECT(pgv_comm_create(PgvGetContext(), 1, 0, id, &solo) == PGV_OK);
+		EXPECT(pgv_kmeans_sharded(solo, PGV_OPS_L2, PGV_F32, DIM, rows, n, lists, 500, &rng, single, NULL, &iters) == PGV_OK);
+		pgv_comm_destroy(solo);
+		for (int c = 0; c < lists; c++)
+			for (int d = 0; d < DIM; d++)
+			{
+				double		a = ((Vector *) VectorArrayGet(&centers, c))->x[d],
+							b = single[(size_t) c * DIM + d];
+				double		err = fabs(a - b) / (fabs(b) + 1e-3);
+
+				if (err > worst)
+					worst = err;
+			}
+		if (pgv_device_count() < 2)
+		{
+			/* a node with one device: PgvIvfflatKmeans above ran pgv_kmeans on the backend's RandomDouble() stream -- compare
+			 * the group of one with pgv_kmeans on the SAME seeded stream instead (libpgv_hip: identical) */
+			float	   *plain = malloc(sizeof(float) * (size_t) lists * DIM);
+			int			it2 = 0;
+
+			memset(&rng, 0, sizeof(rng));
+			rng.seed = seed;
+			EXPECT(pgv_kmeans(PgvGetContext(), PGV_OPS_L2, PGV_F32, DIM, rows, n, lists, 500, &rng, plain, NULL, &it2) == PGV_OK);
+			worst = 0.0;
+			for (int i = 0; i < lists * DIM; i++)
+			{
+				double		err = fabs((double) plain[i] - single[i]) / (fabs((double) single[i]) + 1e-3);
+
+				if (err > worst)
+					worst = err;
+			}
+			free(plain);
+			fprintf(stderr, "   one device: k-means through a communicator of one (RCCL) = pgv_kmeans on the same stream to %.2e (%d / %d iterations)\n",
+					worst, iters, it2);
+		}
+		else
+			fprintf(stderr, "   k-means of %d samples, %d lists over %d devices = the one-participant centers to %.2e (%d iterations)\n", n,
+					lists, pgv_device_count(), worst, iters);
+		EXPECT(worst <= 1e-5);
+	}
+	/* vector.gpu_build_devices = 1: this backend's device alone (no helper contexts) */
+	shim_set_guc_int("vector.gpu_build_devices", 1);
+	made1 = mock_hip_contexts_made ? mock_hip_contexts_made(1) : 0;
+	centers.length = 0;
+	EXPECT(PgvIvfflatKmeans(index, &samples, &centers, IvfflatGetTypeInfo(index)));
+	if (mock_hip_contexts_made)
+		EXPECT(mock_hip_contexts_made(1) == made1);
+	shim_set_guc_int("vector.gpu_build_devices", 0);
+	free(rows);
+	free(single);
+	return 0;
+}
 
 static int
 run_phase(const char *name, int (*fn) (void *), int nprocs, void *const *args, double timeout_s)
@@ -4707,6 +4845,8 @@ main(void)
 		failed |= run_phase("DROP INDEX x 70", backend_drop_index, 1, NULL, 300.0);
 	if (!failed)
 		failed |= run_phase("build state for 2000-d rows", backend_wide_build, 1, NULL, 120.0);
+	if (!failed)
+		failed |= run_phase("k-means over the devices of the node", backend_multi_device_kmeans, 1, NULL, 120.0);
 	if (!failed)
 	{
 		void	   *pooled[1] = {(void *) 1};

@@ -53,10 +53,22 @@ mock_hip_live_queries(void)
 	return live_queries;
 }
 
+static int	contexts_made[16];	/* contexts this process has created, by device */
+
+int
+mock_hip_contexts_made(int device)
+{
+	return device >= 0 && device < 16 ? contexts_made[device] : 0;
+}
+
+/* (MOCK_HIP_DEVICES: the stand-in node has that many devices -- contexts on any of them are the same host memory) */
 int
 pgv_device_count(void)
 {
-	return 1;
+	const char *e = getenv("MOCK_HIP_DEVICES");
+	int			n = e ? atoi(e) : 1;
+
+	return n < 1 ? 1 : (n > 16 ? 16 : n);
 }
 
 int
@@ -261,6 +273,9 @@ pgv_ctx_create(int device, void *stream, pgv_ctx * *out)
 	/* test knob: a process without a usable device (none installed, lost, driver not initialising) */
 	if (getenv("MOCK_HIP_NO_DEVICE"))
 		return fail(PGV_ERR_DEVICE, "mock: no HIP device");
+	if (device < 0 || device >= pgv_device_count())
+		return fail(PGV_ERR_DEVICE, "mock: no such device");
+	__atomic_add_fetch(&contexts_made[device], 1, __ATOMIC_SEQ_CST);
 	*out = calloc(1, sizeof(pgv_ctx));
 	return PGV_OK;
 }
@@ -1884,7 +1899,129 @@ struct pgv_comm
 	int			nranks,
 				rank;
 	pgv_collectives coll;
+	struct mock_group *group;	/* pgv_comm_create: the in-process group this rank joined */
 };
+
+/*
+ * pgv_comm_unique_id / pgv_comm_create on the stand-in: the ranks of a group are THREADS of one process (ext/ivfbuild_gpu.c:
+ * the leader of a build drives one helper thread per device), found through the id in a process-wide table; the two
+ * collectives are barriers + copies between the ranks' buffers (host memory here), the all-reduce adding in rank order.
+ * libpgv_hip forms the same group with ncclCommInitRank and runs the same collectives over RCCL.
+ */
+#include <pthread.h>
+#include <stdbool.h>
+typedef struct mock_group
+{
+	unsigned char id[PGV_COMM_ID_BYTES];
+	int			nranks,
+				joined,
+				left;
+	pthread_barrier_t bar;
+	const void *send[16];
+	void	   *recv[16];
+}			mock_group;
+static pthread_mutex_t group_lock = PTHREAD_MUTEX_INITIALIZER;
+static pthread_cond_t group_cond = PTHREAD_COND_INITIALIZER;
+static mock_group *groups[8];
+static unsigned long long next_group_id = 1;
+
+int
+pgv_comm_unique_id(void *out_id)
+{
+	unsigned long long v;
+
+	if (!out_id)
+		return fail(PGV_ERR_ARG, "out_id is NULL");
+	pthread_mutex_lock(&group_lock);
+	v = next_group_id++;
+	pthread_mutex_unlock(&group_lock);
+	memset(out_id, 0, PGV_COMM_ID_BYTES);
+	memcpy(out_id, &v, sizeof(v));
+	((unsigned char *) out_id)[8] = 0x6d;	/* 'm': a stand-in id */
+	return PGV_OK;
+}
+
+static int
+mg_all_gather(void *state, const void *send, void *recv, size_t bytes, void *stream)
+{
+	pgv_comm   *cm = state;
+	mock_group *g = cm->group;
+
+	(void) stream;
+	g->send[cm->rank] = send;
+	pthread_barrier_wait(&g->bar);
+	for (int r = 0; r < g->nranks; r++)
+		memmove((char *) recv + (size_t) r * bytes, g->send[r], bytes);
+	pthread_barrier_wait(&g->bar);
+	return 0;
+}
+
+static int
+mg_all_reduce(void *state, float *buf, size_t count, void *stream)
+{
+	pgv_comm   *cm = state;
+	mock_group *g = cm->group;
+	float	   *sum = malloc(sizeof(float) * (count ? count : 1));
+
+	(void) stream;
+	g->send[cm->rank] = buf;
+	pthread_barrier_wait(&g->bar);
+	for (size_t i = 0; i < count; i++)
+	{
+		float		acc = 0.f;
+
+		for (int r = 0; r < g->nranks; r++)
+			acc += ((const float *) g->send[r])[i];
+		sum[i] = acc;
+	}
+	pthread_barrier_wait(&g->bar);	/* everybody has read everybody's input */
+	memcpy(buf, sum, sizeof(float) * count);
+	free(sum);
+	pthread_barrier_wait(&g->bar);
+	return 0;
+}
+
+int
+pgv_comm_create(pgv_ctx * ctx, int nranks, int rank, const void *unique_id, pgv_comm * *out)
+{
+	mock_group *g = NULL;
+	pgv_comm   *cm;
+
+	(void) ctx;
+	if (!out || !unique_id || nranks < 1 || nranks > 16 || rank < 0 || rank >= nranks)
+		return fail(PGV_ERR_ARG, "mock: pgv_comm_create arguments");
+	pthread_mutex_lock(&group_lock);
+	for (int i = 0; i < 8 && g == NULL; i++)
+		if (groups[i] && memcmp(groups[i]->id, unique_id, PGV_COMM_ID_BYTES) == 0)
+			g = groups[i];
+	if (g == NULL)
+	{
+		g = calloc(1, sizeof(*g));
+		memcpy(g->id, unique_id, PGV_COMM_ID_BYTES);
+		g->nranks = nranks;
+		pthread_barrier_init(&g->bar, NULL, (unsigned) nranks);
+		for (int i = 0; i < 8; i++)
+			if (groups[i] == NULL)
+			{
+				groups[i] = g;
+				break;
+			}
+	}
+	g->joined++;
+	pthread_cond_broadcast(&group_cond);
+	while (g->joined < g->nranks)	/* ncclCommInitRank returns when every rank has called it */
+		pthread_cond_wait(&group_cond, &group_lock);
+	pthread_mutex_unlock(&group_lock);
+	cm = calloc(1, sizeof(*cm));
+	cm->nranks = nranks;
+	cm->rank = rank;
+	cm->group = g;
+	cm->coll.all_gather = mg_all_gather;
+	cm->coll.all_reduce_sum_f32 = mg_all_reduce;
+	cm->coll.state = cm;
+	*out = cm;
+	return PGV_OK;
+}
 
 int
 pgv_comm_create_custom(pgv_ctx * ctx, int nranks, int rank, const pgv_collectives * coll, pgv_comm * *out)
@@ -1908,6 +2045,24 @@ pgv_comm_create_custom(pgv_ctx * ctx, int nranks, int rank, const pgv_collective
 void
 pgv_comm_destroy(pgv_comm * cm)
 {
+	if (cm && cm->group)
+	{
+		mock_group *g = cm->group;
+		bool		last;
+
+		pthread_mutex_lock(&group_lock);
+		last = ++g->left == g->nranks;
+		if (last)
+			for (int i = 0; i < 8; i++)
+				if (groups[i] == g)
+					groups[i] = NULL;
+		pthread_mutex_unlock(&group_lock);
+		if (last)
+		{
+			pthread_barrier_destroy(&g->bar);
+			free(g);
+		}
+	}
 	free(cm);
 }
 

@@ -1547,6 +1547,7 @@ struct shm_toc
 	int			ngucs;			/* the leader's settings, restored in every worker (RestoreGUCState) */
 	int			gucs[16];
 	int			maintenance_work_mem;
+	uint32		next_worker_number;	/* ParallelWorkerNumber of the next worker to attach (access/parallel.c) */
 };
 
 struct dsm_segment
@@ -1631,6 +1632,7 @@ ParallelWorkerMain(Datum main_arg)
 	dsm_segment seg;
 
 	seg.toc = toc;
+	ParallelWorkerNumber = (int) __atomic_fetch_add(&toc->next_worker_number, 1, __ATOMIC_SEQ_CST);
 	shim_guc_restore(toc->gucs, toc->ngucs);
 	maintenance_work_mem = toc->maintenance_work_mem;
 	if (entry == NULL)

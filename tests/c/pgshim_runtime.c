@@ -121,6 +121,7 @@ static char *Sbase = NULL;
 /* ------------------------------------------------------------------------------------------------ process state */
 Oid			MyDatabaseId = 5;
 int			MyProcPid = 0;
+int			ParallelWorkerNumber = -1;	/* access/parallel.h: -1 in the leader, 0 .. n-1 in its workers (set by ParallelWorkerMain) */
 bool		process_shared_preload_libraries_in_progress = false;
 shmem_request_hook_type shmem_request_hook = NULL;
 shmem_startup_hook_type shmem_startup_hook = NULL;

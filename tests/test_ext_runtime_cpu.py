@@ -44,9 +44,11 @@ def test_ext_glue_runs_on_the_stand_in_server(tmp_path, sanitize):
     assert r.returncode == 0 and "EXT-RUNTIME OK" in r.stdout, (r.returncode, r.stdout[-500:], r.stderr[-3000:])
     assert "AddressSanitizer" not in r.stderr and "runtime error" not in r.stderr, r.stderr[-3000:]
     assert "buffer refcount leak" not in r.stderr
+    # ext/ivfbuild_gpu.c PgvKmeansOnDevices on a stand-in node of three devices: helper threads, one context per device
+    assert "k-means sharded over 3 devices" in r.stderr and "over 3 devices = the one-participant centers to" in r.stderr
     for phase in ("CREATE INDEX through the build hooks", "own-context scans", "six pooled backends",
                   "insert / restage under an open scan", "pooled scan across a restage", "a staging of several seconds",
-                  "DROP INDEX x 70", "build state for 2000-d rows", "worker killed (SIGKILL)",
+                  "DROP INDEX x 70", "build state for 2000-d rows", "k-means over the devices of the node", "worker killed (SIGKILL)",
                   "worker ended (SIGTERM)", "hnsw scans", "hnsw: CREATE INDEX through the build hooks",
                   "vector_ip_ops: build + scans", "a backend without a device"):
         assert any(phase in line and ": ok" in line for line in r.stderr.splitlines()), (phase, r.stderr[-3000:])

@@ -24,6 +24,8 @@ def test_ext_glue_runs_on_the_gpu(tmp_path):
             f.write(r.stdout + "\n---- stderr ----\n" + r.stderr)
     assert r.returncode == 0 and "EXT-RUNTIME OK" in r.stdout, (r.returncode, r.stdout[-500:], r.stderr[-4000:])
     assert "buffer refcount leak" not in r.stderr
+    # one device here: the multi-device k-means' communicator path runs as a group of one through RCCL
+    assert "k-means through a communicator of one (RCCL) = pgv_kmeans on the same stream" in r.stderr, r.stderr[-3000:]
 
 
 REF_DRIVER = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "oracle", "_ref", "ext_driver_ref_gpu")
