@@ -581,15 +581,15 @@ def concurrent_backends(index, device, qhost, queries, probes, k, args, dev, out
             raise
         flush()
     out["pooled_single_query"]["pool"] = ("pgv_host_pool_*: client THREADS block in pgv_host_pool_search with one query each; "
-                                          "max_batch 1024, max_wait 50 us, 3 lanes (contexts), one scan at a time + linger 120 us; host buffers in and out")
+                                          "max_batch 1024, max_wait 50 us, 3 lanes (contexts), one scan at a time + linger 300 us; host buffers in and out")
     # ... and with GPU-less client PROCESSES in front of two lane-server processes: the pool's slots, lane words and
     # payload ring live in a shared segment (non-private futexes, a robust process-shared mutex)
     out["pooled_single_query_processes"] = {}
-    for nc in (16, 64, 256):
+    for nc in (16, 64, 256, 1024):
         log("  backends: %d pooled client processes" % nc)
         try:
             out["pooled_single_query_processes"][str(nc)] = _host.run_backend_processes(
-                index, qh, probes, k, 1, nc, max(60, 12000 // nc), max_batch=1024, max_wait_us=50, lanes=3,
+                index, qh, probes, k, 1, nc, max(200, 48000 // nc), max_batch=1024, max_wait_us=50, lanes=3,
                 server_processes=True, deadline_s=row_deadline)
         except Exception as e:  # noqa: BLE001
             out["pooled_single_query_processes"][str(nc)] = {"error": repr(e)}
@@ -598,7 +598,11 @@ def concurrent_backends(index, device, qhost, queries, probes, k, args, dev, out
         flush()
     out["pooled_single_query_processes"]["pool"] = ("tools/pgv_backend.c `client` x N + `serve` x 3 lanes: every client and "
                                                     "every lane leader is a process; the leaders import the mirror; "
-                                                    "one scan at a time + linger (ivf_pool.c)")
+                                                    "one scan at a time + linger 300 us, baton wake (ivf_pool.c); the "
+                                                    "processes are confined to as many CPUs as the cgroup's quota pays "
+                                                    "for (tools/backends_driver.c pinned_cpus: a quota without a cpuset "
+                                                    "makes CFS bandwidth accounting the bottleneck, 200 us of system "
+                                                    "time per query)")
     # (b) batches from two submitters
     log("  backends: two batch submitters")
     ctx2 = api.Context(device)
@@ -1315,6 +1319,9 @@ def compact_line(full):
         top = (be.get("pooled_single_query_processes") or {}).get("256")
         if isinstance(top, dict):
             s["pooled_256_p50_us"] = _r(top.get("latency_us_p50"), 4)
+        top = (be.get("pooled_single_query_processes") or {}).get("1024")
+        if isinstance(top, dict):
+            s["pooled_1024_p50_us"] = _r(top.get("latency_us_p50"), 4)
         if s:
             line["backends"] = s
     ob = full.get("overlapped_batches")

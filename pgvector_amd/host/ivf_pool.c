@@ -31,7 +31,7 @@
  * 104-136 k).  From POOL_LINGER_MIN (128) queries on, the batch that collected lingers up to linger_us after the scan's
  * end for that scan's clients to come back and join it: same throughput, a quarter less latency (p50 1.63 vs 2.05 ms).
  * PGV_POOL_OVERLAP=1 in the environment of the process that initialises the segment brings the old behaviour back
- * (A/B measurements); PGV_POOL_LINGER_US overrides the 120 us.
+ * (A/B measurements); PGV_POOL_LINGER_US overrides the 300 us.
  *
  * Answers are exactly pgv_search_batch's: the head of GetScanItems + tuplesort for each query
  * (src/ivfscan.c:123-187), heap TIDs and FUNCTION 1 distances.
@@ -51,6 +51,7 @@
 #include <sys/mman.h>
 #include <sys/syscall.h>
 #include <unistd.h>
+#include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
 #include <time.h>
@@ -59,14 +60,15 @@ extern int	pgv_host_fail(int code, const char *fmt,...);
 void		pgv_host_pool_destroy(pgv_pool * pool);
 
 #define POOL_MAGIC 0x7067765f706f6f6cull	/* "pgv_pool" */
-#define POOL_VERSION 5
+#define POOL_VERSION 7
 #define POOL_MAX_LANES 8
 #define POOL_ALIGN 4096
 #define POOL_RECLAIM_US 2000000		/* a published batch nobody finished reading: its clients are gone */
 #define POOL_READY_US 200000		/* a client between taking its slot and the end of its payload copy */
 #define POOL_LEADER_DEAD_US 3000000	/* a lane whose server has not looked for this long has lost it (it looks every 50 ms) */
-#define POOL_LINGER_US 120			/* after a scan: how long the next batch waits for that scan's clients to come back */
-#define POOL_LINGER_MIN 128			/* ... when the two groups together are at least this many queries */
+#define POOL_LINGER_US 300			/* after a scan: how long the next batch waits for that scan's clients to come back (round 6: 120 -> 300, see profiles/r06/pool_baton_wake.md) */
+#define POOL_LINGER_MIN 128
+#define POOL_WAKE_STRIDE 4096		/* one page per slot's wake word: see word_of_slot */			/* ... when the two groups together are at least this many queries */
 
 enum
 {
@@ -96,7 +98,8 @@ typedef struct
 				tid_off,
 				dist_off;
 	char		errmsg[160];
-	char		pad[16];
+	uint64_t	wake_off;		/* this lane's per-slot wake words, POOL_WAKE_STRIDE apart (a page each) */
+	char		pad[8];
 }			shm_lane;
 
 typedef struct
@@ -118,7 +121,7 @@ typedef struct
 	int32_t		scan_lane;		/* lane whose scan is in flight, or -1 (under the lock; only with exclusive) */
 	int32_t		exclusive;		/* one scan at a time (default); 0: lanes scan side by side (PGV_POOL_OVERLAP=1) */
 	int32_t		linger_us;
-	int32_t		pad1;
+	int32_t		wake_fanout;	/* clients a server wakes itself when it publishes; each of them wakes one more (0: all at once) */
 	int64_t		t_scan_done;	/* now_us() when the last scan ended (under the lock) */
 	int32_t		last_n;			/* ... and how many queries it answered */
 	int32_t		pad2;
@@ -163,6 +166,48 @@ word_wake_all(uint32_t *word)
 	syscall(SYS_futex, word, FUTEX_WAKE, INT_MAX, NULL, NULL, 0);
 }
 
+static void
+word_wake_n(uint32_t *word, int n)
+{
+	syscall(SYS_futex, word, FUTEX_WAKE, n, NULL, NULL, 0);
+}
+
+/*
+ * Where the client in slot `slot` of a lane sleeps.  Every futex call on a MAP_SHARED word pins the word's PAGE for the
+ * key lookup (get_user_pages_fast: an atomic on the page's reference count): 256 backends doing their FUTEX_WAIT /
+ * FUTEX_WAKE on words of ONE page spent 107 us of SYSTEM time per query on that cache line (getrusage of the clients,
+ * profiles/r06/pool_baton_wake.md; 28 us with 64 clients).  One page per slot: nobody shares a futex page.
+ */
+static uint32_t *
+word_of_slot(char *base, const shm_lane * l, int slot)
+{
+	return (uint32_t *) (base + l->wake_off + (size_t) POOL_WAKE_STRIDE * (size_t) slot);
+}
+
+/* CPUs this process may really use: the affinity mask, capped by the cgroup's CPU quota (cpu.max) */
+static int
+usable_cpus(void)
+{
+	long		n = sysconf(_SC_NPROCESSORS_ONLN);
+	FILE	   *f = fopen("/sys/fs/cgroup/cpu.max", "r");
+
+	if (f)
+	{
+		long long	quota = 0,
+					period = 0;
+		char		first[32];
+
+		if (fscanf(f, "%31s %lld", first, &period) == 2 && strcmp(first, "max") != 0 && period > 0)
+		{
+			quota = atoll(first);
+			if (quota > 0 && (quota + period - 1) / period < n)
+				n = (long) ((quota + period - 1) / period);
+		}
+		fclose(f);
+	}
+	return n < 1 ? 1 : (int) n;
+}
+
 static int64_t
 now_us(void)
 {
@@ -196,7 +241,7 @@ pgv_host_pool_shm_bytes(pgv_dtype dtype, int dim, int k, int max_batch, int lane
 {
 	size_t		row = (size_t) dim * (dtype == PGV_F32 ? 4 : 2);
 	size_t		lane = align_up(row * (size_t) max_batch) + align_up(sizeof(uint64_t) * (size_t) max_batch * k) +
-		align_up(sizeof(float) * (size_t) max_batch * k);
+		align_up(sizeof(float) * (size_t) max_batch * k) + (size_t) POOL_WAKE_STRIDE * (size_t) max_batch;
 
 	if (dim < 1 || k < 1 || max_batch < 1 || lanes < 1 || lanes > POOL_MAX_LANES)
 		return 0;
@@ -235,6 +280,15 @@ pgv_host_pool_shm_init(void *shm, size_t bytes, pgv_dtype dtype, int dim, int pr
 	s->linger_us = getenv("PGV_POOL_LINGER_US") ? atoi(getenv("PGV_POOL_LINGER_US")) : POOL_LINGER_US;
 	if (s->linger_us < 0)
 		s->linger_us = 0;
+	/* BATON WAKE (round 6).  A published batch used to wake all its clients at once (FUTEX_WAKE INT_MAX): a few hundred
+	 * processes made runnable in one syscall -- ~1 us each inside the SERVER's critical path, a thundering herd on the pool
+	 * mutex, and under a CPU quota (a container's cpu.max: 16 CPUs here) a burst that spends the period's budget at once and
+	 * gets the whole group throttled for the rest of it (1024 clients: p90 75 ms).  Now the server wakes as many clients as
+	 * there are usable CPUs, and every client, once it has copied its answer, wakes ONE more: the runnable set stays at the
+	 * number of CPUs, the herd becomes a pipeline.  PGV_POOL_WAKE_FANOUT overrides (0: all at once, the old behaviour). */
+	s->wake_fanout = getenv("PGV_POOL_WAKE_FANOUT") ? atoi(getenv("PGV_POOL_WAKE_FANOUT")) : usable_cpus();
+	if (s->wake_fanout < 0)
+		s->wake_fanout = 0;
 	pthread_mutexattr_init(&ma);
 	pthread_mutexattr_setpshared(&ma, PTHREAD_PROCESS_SHARED);
 	pthread_mutexattr_setrobust(&ma, PTHREAD_MUTEX_ROBUST);
@@ -257,6 +311,8 @@ pgv_host_pool_shm_init(void *shm, size_t bytes, pgv_dtype dtype, int dim, int pr
 		at += align_up(sizeof(uint64_t) * (size_t) max_batch * k);
 		l->dist_off = at;
 		at += align_up(sizeof(float) * (size_t) max_batch * k);
+		l->wake_off = at;
+		at += (size_t) POOL_WAKE_STRIDE * (size_t) max_batch;
 	}
 	__atomic_store_n(&s->magic, POOL_MAGIC, __ATOMIC_RELEASE);	/* last: attachers check it */
 	return PGV_OK;
@@ -335,6 +391,14 @@ pgv_host_pool_shutdown(pgv_pool * pool)
 		__atomic_add_fetch(&s->lanes[i].fill, 1, __ATOMIC_RELEASE);
 		word_wake_all(&s->lanes[i].fill);
 		word_wake_all(&s->lanes[i].done_gen);
+		if (s->wake_fanout > 0)
+			for (int j = 0; j < s->max_batch; j++)	/* the clients asleep on their slots' words */
+			{
+				uint32_t   *w = word_of_slot(pool->base, &s->lanes[i], j);
+
+				__atomic_add_fetch(w, 1, __ATOMIC_RELEASE);
+				word_wake_n(w, 1);
+			}
 	}
 	__atomic_add_fetch(&s->free_epoch, 1, __ATOMIC_RELEASE);
 	word_wake_all(&s->free_epoch);
@@ -553,7 +617,19 @@ pgv_host_pool_serve(pgv_pool * pool, int lane, pgv_index * view)
 		pool_unlock(s);
 		__atomic_store_n(&l->readers, ((uint64_t) gen << 32) | (uint32_t) n, __ATOMIC_RELEASE);
 		__atomic_store_n(&l->done_gen, gen, __ATOMIC_RELEASE);
-		word_wake_all(&l->done_gen);
+		if (s->wake_fanout > 0)
+		{
+			/* the first wake_fanout slots; slot i wakes slot i + wake_fanout when it has its answer */
+			for (int i = 0; i < n && i < s->wake_fanout; i++)
+			{
+				uint32_t   *w = word_of_slot(pool->base, l, i);
+
+				__atomic_add_fetch(w, 1, __ATOMIC_RELEASE);
+				word_wake_n(w, 1);
+			}
+		}
+		else
+			word_wake_all(&l->done_gen);
 	}
 done:
 	__atomic_store_n(&l->beat, 0, __ATOMIC_RELEASE);
@@ -679,7 +755,19 @@ pgv_host_pool_search(pgv_pool * pool, const void *query, uint64_t *out_tid, floa
 			pool_unlock(s);
 			return pgv_host_fail(PGV_ERR_STATE, "pgv_host_pool_search: the lane's server is gone");
 		}
-		word_wait_us(&l->done_gen, seen, 100000);
+		if (s->wake_fanout > 0)
+		{
+			/* sleep on this slot's own word: whoever wakes it bumps it first, and done_gen was published before any
+			 * wake -- read the word, look at done_gen once more, then wait for the word to move */
+			uint32_t   *mine = word_of_slot(pool->base, l, slot);
+			uint32_t	w = __atomic_load_n(mine, __ATOMIC_ACQUIRE);
+
+			if ((int32_t) (__atomic_load_n(&l->done_gen, __ATOMIC_ACQUIRE) - gen) >= 0)
+				continue;
+			word_wait_us(mine, w, 100000);
+		}
+		else
+			word_wait_us(&l->done_gen, seen, 100000);
 	}
 	if (seen != gen)
 		return pgv_host_fail(PGV_ERR_STATE, "pgv_host_pool_search: the batch was reclaimed before this client read its answer");
@@ -691,6 +779,14 @@ pgv_host_pool_search(pgv_pool * pool, const void *query, uint64_t *out_tid, floa
 	}
 	else
 		pgv_host_fail(rc, "batch failed: %s", l->errmsg);
+	/* the baton: the client wake_fanout slots further on */
+	if (s->wake_fanout > 0 && slot + s->wake_fanout < l->count)
+	{
+		uint32_t   *w = word_of_slot(pool->base, l, slot + s->wake_fanout);
+
+		__atomic_add_fetch(w, 1, __ATOMIC_RELEASE);
+		word_wake_n(w, 1);
+	}
 	/* count this reader out -- of ITS batch only; the lane is free again when its last reader has its answer.  A
 	 * reader that finds another batch number (or no readers left) was given up on by the lane's server
 	 * (POOL_RECLAIM_US): what it copied may belong to the next batch */

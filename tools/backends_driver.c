@@ -131,6 +131,30 @@ backend_main(void *arg)
 	return NULL;
 }
 
+
+/* PGVB_CPU_STAT=1: the cgroup's CPU use and throttling over the TIMED phase only (the clients' start-up -- a thousand
+ * execs that each load the HIP runtime -- is not part of it), to stderr */
+static void
+read_cpu_stat(long long *usage, long long *nthr, long long *thr_usec)
+{
+	FILE	   *f = fopen("/sys/fs/cgroup/cpu.stat", "r");
+	char		key[64];
+	long long	v;
+
+	*usage = *nthr = *thr_usec = 0;
+	if (!f)
+		return;
+	while (fscanf(f, "%63s %lld", key, &v) == 2)
+	{
+		if (strcmp(key, "usage_usec") == 0)
+			*usage = v;
+		else if (strcmp(key, "nr_throttled") == 0)
+			*nthr = v;
+		else if (strcmp(key, "throttled_usec") == 0)
+			*thr_usec = v;
+	}
+	fclose(f);
+}
 static int
 cmp_double(const void *a, const void *b)
 {
@@ -404,6 +428,7 @@ pool_run(pgv_index * index, int device, int dtype, int dim, int nclients, int pe
 #include <limits.h>
 #include <linux/futex.h>
 #include <signal.h>
+#include <sched.h>
 #include <spawn.h>
 #include <stdio.h>
 #include <sys/mman.h>
@@ -436,15 +461,63 @@ make_shm(const char *name, size_t bytes)
 	return p == MAP_FAILED ? NULL : p;
 }
 
+/*
+ * Where the backend processes run.  A container's CPU QUOTA (cgroup cpu.max: 16 CPUs' worth on the GPU boxes) without a
+ * cpuset lets a few hundred processes spread over all 256 hardware threads of the host, and then CFS bandwidth control is
+ * the bottleneck: every wake-up on another CPU has to fetch a runtime slice from the group's one pool under one spinlock
+ * (256 pooled clients: 107-196 us of SYSTEM time per query in the clients' own getrusage, 21-34 throttled periods in a 2 s
+ * run; profiles/r06/pool_baton_wake.md).  The harness therefore gives the backends the cpuset the quota implies: as many CPUs
+ * (the first ones of the allowed mask) as the quota pays for.  PGVB_PIN=0 leaves them unpinned.
+ */
+static int
+pinned_cpus(cpu_set_t *set)
+{
+	cpu_set_t	allowed;
+	long		want = 0;
+	FILE	   *f;
+	int			got = 0;
+
+	CPU_ZERO(set);
+	if (getenv("PGVB_PIN") && atoi(getenv("PGVB_PIN")) == 0)
+		return 0;
+	f = fopen("/sys/fs/cgroup/cpu.max", "r");
+	if (f)
+	{
+		char		first[32];
+		long long	period = 0;
+
+		if (fscanf(f, "%31s %lld", first, &period) == 2 && strcmp(first, "max") != 0 && period > 0)
+			want = (long) ((atoll(first) + period - 1) / period);
+		fclose(f);
+	}
+	if (want < 1 || sched_getaffinity(0, sizeof(allowed), &allowed) != 0 || CPU_COUNT(&allowed) <= want)
+		return 0;				/* no quota, or not more CPUs than it pays for: nothing to confine */
+	for (int c = 0; c < CPU_SETSIZE && got < want; c++)
+		if (CPU_ISSET(c, &allowed))
+		{
+			CPU_SET(c, set);
+			got++;
+		}
+	return got;
+}
+
 static pid_t
 spawn(const char *exe, const char *a1, const char *a2, const char *a3, const char *a4)
 {
 	char	   *argv[] = {(char *) exe, (char *) a1, (char *) a2, (char *) a3, (char *) a4, NULL};
 	pid_t		pid = -1;
+	cpu_set_t	pin,
+				mine;
+	int			npin = pinned_cpus(&pin);
+	int			rc;
 
-	if (posix_spawn(&pid, exe, NULL, NULL, argv, environ) != 0)
-		return -1;
-	return pid;
+	/* the child inherits the mask of the thread that spawns it */
+	if (npin > 0 && (sched_getaffinity(0, sizeof(mine), &mine) != 0 || sched_setaffinity(0, sizeof(pin), &pin) != 0))
+		npin = 0;
+	rc = posix_spawn(&pid, exe, NULL, NULL, argv, environ);
+	if (npin > 0)
+		sched_setaffinity(0, sizeof(mine), &mine);
+	return rc != 0 ? -1 : pid;
 }
 
 int
@@ -469,6 +542,8 @@ backends_run_processes(pgv_index * index, const char *image_shm, int device, int
 	uint64_t	free0 = 0,
 				free1 = 0,
 				total = 0;
+	long long	cpu0[3] = {0, 0, 0};
+	double		t_go = 0;
 	int64_t		batches0 = 0,
 				queries0 = 0,
 				batches1 = 0,
@@ -604,6 +679,8 @@ backends_run_processes(pgv_index * index, const char *image_shm, int device, int
 	}
 	pgv_device_memory(device, &free1, &total);
 	pgv_host_pool_stats(pool, &batches0, &queries0);
+	read_cpu_stat(&cpu0[0], &cpu0[1], &cpu0[2]);
+	t_go = now();
 	__atomic_store_n(&bank->go, 1, __ATOMIC_RELEASE);
 	syscall(SYS_futex, &bank->go, FUTEX_WAKE, INT_MAX, NULL, NULL, 0);
 	if (chaos)
@@ -661,6 +738,33 @@ backends_run_processes(pgv_index * index, const char *image_shm, int device, int
 		}
 	}
 	pgv_host_pool_stats(pool, &batches1, &queries1);
+	if (getenv("PGVB_CPU_STAT"))
+	{
+		long long	cpu1[3];
+
+		read_cpu_stat(&cpu1[0], &cpu1[1], &cpu1[2]);
+		fprintf(stderr, "timed phase: %.3f s wall, cgroup CPU %.3f s (%.1f us per query), throttled %lld times for %.3f s\n", now() - t_go,
+				(cpu1[0] - cpu0[0]) / 1e6, (double) (cpu1[0] - cpu0[0]) / ((double) nclients * per_client), cpu1[1] - cpu0[1],
+				(cpu1[2] - cpu0[2]) / 1e6);
+		{
+			pgvb_client *cl = (pgvb_client *) ((char *) bank + bank->clients_off);
+			double		ut = 0,
+						st = 0,
+						v = 0,
+						iv = 0,
+						nq = (double) nclients * per_client;
+
+			for (int c = 0; c < nclients; c++)
+			{
+				ut += cl[c].utime;
+				st += cl[c].stime;
+				v += (double) cl[c].nvcsw;
+				iv += (double) cl[c].nivcsw;
+			}
+			fprintf(stderr, "clients' own getrusage over their timed loops: user %.1f us, system %.1f us, %.2f voluntary and %.2f involuntary "
+					"context switches per query\n", ut / nq * 1e6, st / nq * 1e6, v / nq, iv / nq);
+		}
+	}
 	if (rc == PGV_OK)
 	{
 		pgvb_client *cl = (pgvb_client *) ((char *) bank + bank->clients_off);

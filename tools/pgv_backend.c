@@ -24,6 +24,7 @@
 #include <string.h>
 #include <sys/mman.h>
 #include <sys/stat.h>
+#include <sys/resource.h>
 #include <sys/syscall.h>
 #include <time.h>
 #include <unistd.h>
@@ -183,6 +184,7 @@ run_client(const char *pool_name, const char *bank_name, int id, int independent
 	pgvb_bank  *bank = map_shm(bank_name, &bank_bytes);
 	char	   *bbase = (char *) bank;
 	pgvb_client *me = (pgvb_client *) (bbase + bank->clients_off) + id;
+	struct rusage ru0 = {0};
 	double	   *lat = (double *) (bbase + bank->lat_off) + (size_t) id * bank->per_client;
 	uint64_t   *ans_t = bank->verify ? (uint64_t *) (bbase + bank->tid_off) + (size_t) id * bank->per_client * bank->k : NULL;
 	float	   *ans_d = bank->verify ? (float *) (bbase + bank->dist_off) + (size_t) id * bank->per_client * bank->k : NULL;
@@ -223,6 +225,7 @@ run_client(const char *pool_name, const char *bank_name, int id, int independent
 		if (phase == 1)
 		{
 			start_line(bank);
+			getrusage(RUSAGE_SELF, &ru0);
 			me->t0 = now();
 		}
 		for (int j = 0; j < n && rc == PGV_OK; j++)
@@ -262,6 +265,15 @@ run_client(const char *pool_name, const char *bank_name, int id, int independent
 		}
 	}
 	me->t1 = now();
+	{
+		struct rusage ru1;
+
+		getrusage(RUSAGE_SELF, &ru1);
+		me->utime = (ru1.ru_utime.tv_sec - ru0.ru_utime.tv_sec) + (ru1.ru_utime.tv_usec - ru0.ru_utime.tv_usec) * 1e-6;
+		me->stime = (ru1.ru_stime.tv_sec - ru0.ru_stime.tv_sec) + (ru1.ru_stime.tv_usec - ru0.ru_stime.tv_usec) * 1e-6;
+		me->nvcsw = ru1.ru_nvcsw - ru0.ru_nvcsw;
+		me->nivcsw = ru1.ru_nivcsw - ru0.ru_nivcsw;
+	}
 	me->rc = rc;
 	if (rc != PGV_OK)
 		snprintf(me->err, sizeof(me->err), "%s | %s", pgv_last_error(), pgv_host_last_error());

@@ -17,7 +17,12 @@ typedef struct
 	double		t0,
 				t1;
 	int32_t		rc;
-	char		err[236];
+	char		err[204];
+	/* getrusage of the timed phase (PGVB_CPU_STAT): where a client's CPU time goes */
+	double		utime,
+				stime;
+	int64_t		nvcsw,
+				nivcsw;
 }			pgvb_client;
 
 /* queries in, latencies and (verify) answers out */
