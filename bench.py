@@ -195,7 +195,7 @@ def sample_rows(data, lists, seed, ops, n_global=None, world=1):
     return samples
 
 
-def build_index(ctx, data, lists, seed, world, rank, dtype, ops, metric, comm=None, row_lo=0, n_global=None):
+def build_index(ctx, data, lists, seed, world, rank, dtype, ops, metric, comm=None, row_lo=0, n_global=None, sharded=None):
     """IVFFlat build on the GPU(s), data resident in HBM: sample, k-means, assign every row, lay out list-major.
     `data` holds this rank's heap rows [row_lo, row_lo + len) of n_global.  With N ranks the k-means samples and
     the heap rows are sharded by row (pgv_kmeans_sharded does the Lloyd exchanges inside the library), every rank
@@ -203,10 +203,11 @@ def build_index(ctx, data, lists, seed, world, rank, dtype, ops, metric, comm=No
     Returns the local image pieces and the seconds per phase."""
     n, dim = data.shape
     t = {}
+    sharded = world > 1 if sharded is None else sharded
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     samples = sample_rows(data, lists, seed + 31 * rank, ops, n_global, world)
-    if world == 1:
+    if not sharded:
         centers, _, iters = api.kmeans(ctx, ops, dtype, dim, samples, lists,
                                        api.make_rng(seed=seed + 2), want_closest=False)
     else:
@@ -216,7 +217,7 @@ def build_index(ctx, data, lists, seed, world, rank, dtype, ops, metric, comm=No
     torch.cuda.synchronize()
     t["kmeans"] = time.perf_counter() - t0
     t1 = time.perf_counter()
-    if world == 1:
+    if not sharded:
         # the product's own build: rows assigned where they are kept, the sort by list a device gather whose result
         # IS the mirror (pgv_builder_*); TIDs = heap positions
         b = api.IvfBuilder(ctx, metric, dtype, dim, centers, expected_rows=n)
@@ -1573,7 +1574,7 @@ class Headline:
     """the headline workload resident on one GPU: data, the built index, the query pool"""
 
 
-def headline_setup(args, dev, ctx, world=1, rank=0, comm=None, keep_host_rows=False):
+def headline_setup(args, dev, ctx, world=1, rank=0, comm=None, keep_host_rows=False, sharded=False):
     H = Headline()
     H.n, H.dim, H.lists, H.probes, H.tname, H.oname = WORKLOADS[args.workload]
     H.dtype = api.PGV_F32 if H.tname == "f32" else api.PGV_F16
@@ -1596,7 +1597,7 @@ def headline_setup(args, dev, ctx, world=1, rank=0, comm=None, keep_host_rows=Fa
     ctx.set_profiling(True)
     ctx.reset_stats()
     H.centers, H.offsets, H.vectors, H.tids, H.iters, H.build_t, H.index = build_index(
-        ctx, data, H.lists, args.seed, world, rank, H.dtype, H.ops, H.metric, comm, row_lo=row_lo, n_global=H.n)
+        ctx, data, H.lists, args.seed, world, rank, H.dtype, H.ops, H.metric, comm, row_lo=row_lo, n_global=H.n, sharded=sharded)
     H.build_stats = ctx.stats()
     ctx.set_profiling(False)
     log("build: %s (k-means iterations %d)" % ({a: round(b, 3) for a, b in H.build_t.items()}, H.iters))
@@ -2206,6 +2207,9 @@ def main():
                     help="N GPUs: lists to ranks by rows (LPT) or l %% N")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo for a functional "
                                                      "multi-rank run on a single GPU)")
+    ap.add_argument("--sharded-path", action="store_true", help="--gpus 1 through the N-GPU code path: torch.distributed over "
+                    "RCCL with ONE rank, the library's communicator, pgv_kmeans_sharded, the row exchange, "
+                    "pgv_search_batch_sharded (the closest a one-GPU box gets to the multi-GPU run; no optional sections)")
     ap.add_argument("--dry-launch", action="store_true", help="only start the --gpus N ranks, form the group, agree on its "
                     "size and print a short line (no device needed with --backend gloo: the launcher's own test)")
     ap.add_argument("--startup-timeout", type=float, default=300.0, help="self-launch: seconds every rank has to join the "
@@ -2246,9 +2250,10 @@ def main():
             launch_failure(json_fd, args, ["WORLD_SIZE is %d but --gpus is %d: refusing to report one as the other"
                                            % (world, args.gpus)])
         sys.exit(2)
-    if world > 1 or args.dry_launch:
+    sharded = world > 1 or args.sharded_path
+    if sharded or args.dry_launch:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        os.environ.setdefault("MASTER_PORT", "29500")
+        os.environ.setdefault("MASTER_PORT", str(free_port()) if world == 1 else "29500")
         if args.dry_launch:
             return dry_launch_rank(args, json_fd, world, rank)
         ndev = torch.cuda.device_count()
@@ -2273,7 +2278,7 @@ def main():
 
     ctx = api.Context(local_rank, stream=torch.cuda.current_stream().cuda_stream)
     comm, comm_kind = None, None
-    if world > 1:
+    if sharded:
         comm_kind = "rccl" if args.backend == "nccl" else "host"
         if comm_kind == "rccl":
             # the library's own RCCL communicator; if ANY rank cannot have it, every rank takes the callbacks into
@@ -2304,7 +2309,7 @@ def main():
 
     # ---------------------------------------------------------------- setup
     WATCH["section"] = "data + build"
-    H = headline_setup(args, dev, ctx, world, rank, comm)
+    H = headline_setup(args, dev, ctx, world, rank, comm, sharded=sharded)
     n, dim, lists, probes, tname, oname = H.n, H.dim, H.lists, H.probes, H.tname, H.oname
     dtype, ops, metric, esize, k = H.dtype, H.ops, H.metric, H.esize, H.k
     centers, offsets, vectors, tids, index = H.centers, H.offsets, H.vectors, H.tids, H.index
@@ -2317,7 +2322,7 @@ def main():
 
     def step(i):
         q = queries[i % pool]
-        if world == 1:
+        if not sharded:
             index.search_batch(q, probes, k, want_tid=True, out=(out_d, out_s, out_t))
             return out_d, out_t
         # N GPUs (pgv_search_batch_sharded): each rank ranks its own slice of the batch against the
@@ -2333,7 +2338,7 @@ def main():
     # exact float64 brute force over every row; with N ranks each one scans the rows it holds and the per-rank
     # exact top-k are merged (never the GPUs' own fp32 scan as its own ground truth)
     exact_d, _ = exact_topk_fp64(vectors, rqueries, k, metric)
-    if world == 1:
+    if not sharded:
         got_d, got_s, got_t = index.search_batch(rqueries, probes, k, want_tid=True)
         recall_truth = "exact float64 brute force over all %d rows, %d queries" % (n, rq)
     else:
@@ -2346,7 +2351,7 @@ def main():
 
     # ----------------------------------------------------------------- timed
     WATCH["section"] = "timed steps"
-    if world == 1 and args.overlap > 1:
+    if not sharded and args.overlap > 1:
         # consecutive batches on `overlap` internal streams of the library (pgv_index_set_overlap): one batch's center
         # ranking / planning / top-k / recheck run under the other's list scan; every batch is complete inside the timed
         # region (the synchronize below waits for all streams)
@@ -2393,10 +2398,10 @@ def main():
     elapsed = time.perf_counter() - t0
     stats = ctx.stats()
     ctx.set_profiling(False)
-    if world == 1 and args.overlap > 1:
+    if not sharded and args.overlap > 1:
         index.set_overlap(1)     # everything below reads its answers in stream order again
     overlapped = None
-    if world == 1 and args.overlap == 1 and args.overlap_lanes > 1 and not args.child:
+    if not sharded and args.overlap == 1 and args.overlap_lanes > 1 and not args.child:
         # the same K steps once more with one caller's consecutive batches on `overlap_lanes` internal streams
         # (pgv_index_set_overlap: list scans take turns, everything else of a batch runs under another batch's scan).
         # Not `value`: the scan launches of the timed region above are timed without company, these are not.
@@ -2491,11 +2496,11 @@ def main():
         "scan_redo_queries_per_step": stats["scan_redo_queries"] / args.steps,
         "scan_widened_queries_per_step": stats["scan_widened_queries"] / args.steps,
         "scan_path": "exact vector-ALU kernels (--exact-scan)" if args.exact_scan else "auto",
-        "overlap_lanes": args.overlap if world == 1 else 1,
+        "overlap_lanes": args.overlap if not sharded else 1,
     }
     if overlapped:
         line["overlapped_batches"] = overlapped
-    if world > 1:
+    if sharded:
         # what the first real N-GPU run needs to be read: the communicator's size, the exchanges per step and per
         # Lloyd iteration in bytes, the build's phases (build_phases_secs: kmeans = k-means++ + Lloyd with
         # one fused all-reduce per iteration; assign; layout = the all-to-all of the rows to their lists' owners)
@@ -2524,7 +2529,7 @@ def main():
     log("timed: %.0f QPS, %.3f ms/step, scan %.3f ms/launch (frac %.2f)" % (qps, elapsed / args.steps * 1e3, avg_launch_ms,
                                                                             roofline["frac"]))
 
-    single = rank == 0 and world == 1
+    single = rank == 0 and not sharded
     if single and args.host_io:
         # what a Postgres backend sees for a batch: queries and results in HOST memory
         qh = [queries[j].cpu().numpy() for j in range(min(pool, 4))]
@@ -2639,7 +2644,7 @@ def main():
     if comm is not None:
         comm.close()
     ctx.close()
-    if world > 1:
+    if sharded:
         dist.destroy_process_group()
     if failures:
         log("FAILED: " + "; ".join(failures))

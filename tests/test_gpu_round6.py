@@ -86,3 +86,26 @@ def test_both_bounds_choose_alike_and_the_default_is_the_deterministic_one(ctx, 
     ctx.set_bound(True)      # back to the library's default for the rest of the session
     np.testing.assert_array_equal(res["default"][0], res["worst"][0])
     assert res["default"][1] == res["worst"][1] and res["default"][1] >= res["statistical"][1]
+
+
+def test_bench_n_gpu_code_path_with_one_rccl_rank(tmp_path):
+    """bench.py --sharded-path: the code a --gpus N run takes -- torch.distributed over RCCL, the library's own
+    communicator (pgv_comm_create through librccl), pgv_kmeans_sharded, the row exchange to the lists' owners,
+    pgv_search_batch_sharded and its device merge -- with the one rank a one-GPU box can give it.  Not a scaling number:
+    the closest rehearsal of the multi-GPU run that this pool allows."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ)
+    for k_ in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT"):
+        env.pop(k_, None)
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--sharded-path", "--workload", "small", "--steps", "3",
+                        "--warmup", "1", "--settle-ms", "0"], capture_output=True, text=True, timeout=600, env=env, cwd=str(tmp_path))
+    assert r.returncode == 0, r.stderr[-3000:]
+    line = json.loads(r.stdout.strip().splitlines()[-1])
+    assert line["n_gpus"] == 1 and line["recall_at_10"] >= 0.99 and line["value"] > 0
+    detail = json.load(open(os.path.join(root, "bench_detail.json")))
+    mg = detail["multi_gpu"]
+    assert mg["communicator"] == "rccl" and mg["comm_size"] == 1 and mg["backend"] == "nccl"
