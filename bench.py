@@ -2516,7 +2516,8 @@ def main():
             "rows_per_rank_min": min(rows_all), "rows_per_rank_mean": sum(rows_all) / world, "rows_per_rank_max": max(rows_all),
             "rows_per_rank_max_over_mean": max(rows_all) / (sum(rows_all) / world),
             "slowest_rank_scan_ms": max(scan_all), "scan_ms_by_rank": scan_all,
-            "measured_on": "RCCL over xGMI" if args.backend == "nccl" else
+            "measured_on": ("ONE rank (--sharded-path): a rehearsal of the N-GPU code path on one device, not a scaling number"
+                            if world == 1 else "RCCL over xGMI") if args.backend == "nccl" else
                            "UNMEASURED ON HARDWARE: %d ranks on one GPU over %s (functional run)" % (world, args.backend),
             "comm_size": comm.world, "pgv_comm_size": comm.world, "torch_world_size": dist.get_world_size(),
             "backend": args.backend, "communicator": comm_kind,

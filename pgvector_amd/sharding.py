@@ -27,6 +27,12 @@ def world():
     return dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
 
 
+def grouped():
+    """a process group exists: the collectives below run even with ONE rank (bench.py --sharded-path: the N-GPU code
+    path rehearsed on one device must issue the same torch.distributed calls)"""
+    return dist.is_available() and dist.is_initialized()
+
+
 def rank():
     return dist.get_rank() if dist.is_available() and dist.is_initialized() else 0
 
@@ -83,7 +89,7 @@ def plan_owners(list_sizes, world_size, policy="balanced"):
 def global_list_sizes(lists_local, nlists):
     """rows per list over all ranks (one all-reduce of nlists counts)"""
     counts = torch.bincount(lists_local.to(torch.int64), minlength=nlists)
-    return _all_reduce_sum(counts) if world() > 1 else counts
+    return _all_reduce_sum(counts) if grouped() else counts
 
 
 def row_shard(n, r, world_size):
@@ -133,7 +139,7 @@ def exchange_rows(vectors_local, tids_local, lists_local, nlists, owners=None):
     One variable-size all-to-all for the rows and two small ones for tids / list ids."""
     w, dev = world(), vectors_local.device
     lists64 = lists_local.to(torch.int64)
-    if w > 1:
+    if grouped():
         dest = owner_of_list(lists64, w, owners)
         order = torch.argsort(dest, stable=True)
         send_counts = torch.bincount(dest, minlength=w)
@@ -162,7 +168,7 @@ def exchange_rows(vectors_local, tids_local, lists_local, nlists, owners=None):
 def merge_exact_topk(local_dist, k):
     """ground truth over row-sharded data: every rank's exact [nq x k] distances (ascending, +inf padded) ->
     the k smallest per query over all ranks, on every rank"""
-    if world() == 1:
+    if not grouped():
         return local_dist
     d = torch.cat(_all_gather(local_dist), dim=1)
     return torch.sort(d, dim=1).values[:, :k].contiguous()
