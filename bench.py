@@ -1912,7 +1912,18 @@ def section_sweeps(args, dev, ctx, out):
             ures[str(p)] = {"qps": total_batch / s, "recall_at_10": recall_at_k(gd, ued, k)}
         ubound = bound_mode_run(ctx, lambda j: uix.search_batch(uq, 10, k, want_tid=True, out=(out_d, out_s, out_t)),
                                 5, total_batch) if H.metric == api.PGV_L2SQ else None
+        # the default (deterministic) bound on the same index and batch, with its counters (which of
+        # the two -- band recheck or k' widening -- a cost on concentrated distances comes from)
+        ctx.set_profiling(True)
+        ctx.reset_stats()
+        s_def = timed_steps(lambda j: uix.search_batch(uq, 10, k, want_tid=True, out=(out_d, out_s, out_t)), 5, warmup=2)
+        st_def = ctx.stats()
+        ctx.set_profiling(False)
+        udef = {"qps": total_batch / s_def, "ms_per_step": s_def * 1e3,
+                "scan_redo_queries_per_step": st_def["scan_redo_queries"] / 7, "scan_widened_queries_per_step": st_def["scan_widened_queries"] / 7,
+                "scan_ms_per_step": st_def["scan_ms"] / 7}
         out.put("uniform", {"data": "U[0,1)^%d (test/t/003_ivfflat_vector_build_recall.pl:60)" % dim,
+                            "bound_default_probes_10": udef,
                             "bound_statistical_probes_10": ubound,
                             "build_secs": ubt["total"], "kmeans_iterations": uit, "probes": ures,
                             "note": "uniform high-d data has no cluster structure: IVF recall at 1 % of the lists "
