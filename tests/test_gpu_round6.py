@@ -109,3 +109,55 @@ def test_bench_n_gpu_code_path_with_one_rccl_rank(tmp_path):
     detail = json.load(open(os.path.join(root, "bench_detail.json")))
     mg = detail["multi_gpu"]
     assert mg["communicator"] == "rccl" and mg["comm_size"] == 1 and mg["backend"] == "nccl"
+
+
+def test_hard_data_set_at_the_headline_shape_answers_like_the_oracle(ctx, oracle):
+    """bench.py's mid-difficulty data set (gen_hard: overlapping Zipf-weighted mixture, power-law spectrum) at the
+    headline's shape: it must BE mid-difficulty (recall@10 between 0.8 and 0.95 at probes 10 against float64 brute force,
+    unbalanced lists, Lloyd running for dozens of iterations) and the GPU's answers must be the oracle's row for row, at
+    probes 10 and 32 -- lists probed by hundreds of queries, re-streamed once per 32-query group, k' candidates under the
+    deterministic bound with something to decide."""
+    import os
+    import sys
+    import torch
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, root)
+    argv, sys.argv = sys.argv, ["bench.py"]
+    try:
+        import bench
+    finally:
+        sys.argv = argv
+    from helpers import assert_topk_equiv
+    dev = torch.device("cuda", 0)
+    n, dim, lists, k = 1_000_000, 1536, 1000, 10
+    data, means = bench.gen_hard(n, dim, lists // 4, 50, dev)
+    centers, offsets, vectors, tids, iters, bt, index = bench.build_index(ctx, data, lists, 0, 1, 0, api.PGV_F32, api.PGV_OPS_L2,
+                                                                          api.PGV_L2SQ)
+    del data
+    assert iters >= 10
+    sizes = (offsets[1:] - offsets[:-1]).double()
+    assert float(sizes.max() / sizes.mean()) > 3.0
+    nq = 512
+    queries, _ = bench.gen_hard(nq, dim, lists // 4, 150, dev, means=means)
+    exact_d, _ = bench.exact_topk_fp64(vectors, queries[:128].contiguous(), k, api.PGV_L2SQ)
+    ix = oracle.index_struct(po.OPS_L2, po.ORA_F32, centers.cpu().numpy(), offsets.cpu().numpy(), vectors.cpu().numpy(),
+                             tids.cpu().numpy().astype(np.uint64))
+    qh = queries.cpu().numpy()
+    for probes in (10, 32):
+        ctx.set_profiling(True)
+        ctx.reset_stats()
+        gd, gs, gt = index.search_batch(queries, probes, k, want_tid=True)
+        st = ctx.stats()
+        ctx.set_profiling(False)
+        assert st["scan_launches"] >= 1
+        recall = bench.recall_at_k(gd[:128], exact_d, k)
+        if probes == 10:
+            assert 0.8 < recall < 0.95, recall
+        else:
+            assert recall > 0.9, recall
+        gdh, gth = gd.cpu().numpy(), gt.cpu().numpy()
+        for i in range(0, nq, 8):
+            wt, wd = oracle.search(ix, qh[i], probes, k)
+            assert_topk_equiv(gth[i][:len(wt)].astype(np.uint64).tolist(), gdh[i][:len(wt)], wt.tolist(), wd,
+                              what="hard probes %d q%d" % (probes, i))
+    index.close()
