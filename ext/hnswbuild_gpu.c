@@ -94,7 +94,17 @@ PgvHnswBuildBegin(HnswBuildState * buildstate)
 	 * InitGraph (src/hnswbuild.c:615-634) has just given the graph the whole budget: it gets half, the "no longer fits"
 	 * flush comes at half the tuples, and the peak stays inside what the user allowed.  (The participants of a
 	 * parallel build switch to the shared graph after this and never link: their budget is untouched.) */
-	buildstate->graphData.memoryTotal /= 2;
+	{
+		/* per element the graph holds the element struct, its value (header + payload) and m (2 on layer 0) HnswCandidate
+		 * slots of 16 bytes per layer -- about rowBytes + 700 bytes at m = 16; the link phase adds the dense row and 4 bytes
+		 * per neighbor slot, levels, duplicates: about rowBytes + 200.  The graph's share of the budget is therefore
+		 * (rowBytes + 700) / (2 rowBytes + 900): one half for long rows, 0.63 at 128 dimensions (not a fixed half) */
+		double		share = ((double) gb->rowBytes + 700.0) / (2.0 * (double) gb->rowBytes + 900.0);
+
+		buildstate->graphData.memoryTotal = (Size) ((double) buildstate->graphData.memoryTotal * share);
+		ereport(DEBUG1, (errmsg("pgvector GPU path: hnsw build keeps %.0f %% of maintenance_work_mem for the graph, the rest for the device link phase",
+								share * 100.0)));
+	}
 	return gb;
 }
 

@@ -279,7 +279,10 @@ __device__ void block_topk(Load load, int64_t m, int k, int kp, int cap, unsigne
 // trip instead of one per sweep iteration -- and both sweeps run from registers.  v must be 16-byte
 // aligned with at least ((m + 3) & ~3) floats readable.  Same result as block_topk.
 constexpr int kSmallVec = 12;
-constexpr int kSmallMax = kSmallVec * 4 * kSelThreads;  // 12288
+// ... and twenty for the segments past 12 288 (round 6: the headline's segments average 11.8 k rows, so two queries in
+// five were over the old limit and took the general path's two sweeps from memory)
+constexpr int kLargeVec = 20;
+constexpr int kSmallMax = kLargeVec * 4 * kSelThreads;  // 20480
 
 // NVEC float4 per thread: 1 (m <= 1024: the centers of a typical index), 4 (m <= 4096) or 12
 template <int NVEC>
@@ -383,8 +386,10 @@ __device__ inline void block_topk_auto(const float *v, int64_t m, int k, int kp,
             block_topk_small<1>(v, (int)m, k, kp, cap, ent, s);
         else if (m <= 16 * kSelThreads)
             block_topk_small<4>(v, (int)m, k, kp, cap, ent, s);
-        else
+        else if (m <= kSmallVec * 4 * kSelThreads)
             block_topk_small<kSmallVec>(v, (int)m, k, kp, cap, ent, s);
+        else
+            block_topk_small<kLargeVec>(v, (int)m, k, kp, cap, ent, s);
     } else
         block_topk([v](int64_t i) { return v[i]; }, m, k, kp, cap, ent, s);
 }
