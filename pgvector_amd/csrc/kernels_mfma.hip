@@ -915,8 +915,13 @@ constexpr int kScanWaves = 4;      // one 32 x 32 tile each: a task is 128 rows
 // NQ: queries per task, 32 or 64.  64 (round 5) is for batches whose lists are probed by more than ~12 queries on average
 // (configs[2] / [4] at their real shape: 1024 queries x 64 probes over 4096 lists): a list probed by 33 .. 64 queries is
 // streamed ONCE instead of twice -- a wavefront then holds two 32 x 32 tiles (queries 0-31 and 32-63 against its 32 rows).
-template <typename T, int METRIC, int NW, bool NT, int NQ>
-__global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(3, 3))) void mfma_scan_kernel(
+// NS: LDS stages, 2 or 3.  3 (round 6) is for launches with fewer tasks than workgroup slots -- the batch's center ranking
+// (1000 centers x 1024 queries = 256 tasks), small batches: one workgroup per CU cannot hide a stage fill (an L2 / MALL
+// round trip, ~1 us) behind the others' streaming, so the 32-query form keeps TWO fills in flight (slice sl + 2 is issued
+// while slice sl is multiplied, the wait is vmcnt(5): this wavefront's five DMA instructions of the younger fill may
+// still be out).  60 KB of LDS: two workgroups per CU, which such a launch does not have anyway.
+template <typename T, int METRIC, int NW, bool NT, int NQ, int NS = 2>
+__global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(NS == 3 ? 2 : 3, NS == 3 ? 2 : 3))) void mfma_scan_kernel(
     const char *__restrict__ rows, const char *__restrict__ queries, const ScanTask *__restrict__ tasks,
     const int *__restrict__ ntasks_ptr, int *__restrict__ task_counter, const ScanPair *__restrict__ pairs,
     const float *__restrict__ row_norms, int nvec, const char *__restrict__ zeros16, float *__restrict__ out) {
@@ -924,7 +929,8 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(3, 3)))
     constexpr int NGROUPS = (NQ + ROWS) / 8;          // DMA instructions per stage (8 rows each)
     constexpr int NDMA = (NGROUPS + NW - 1) / NW;               // ... per wavefront, at most
     constexpr int STAGE = (NQ + ROWS) * kSliceBytes;  // 20 KB (NQ 32) / 24 KB (NQ 64)
-    __shared__ __attribute__((aligned(16))) char smem[2 * STAGE];
+    static_assert(NS == 2 || (NS == 3 && NQ == 32 && NGROUPS % NW == 0), "three stages: the 32-query form only");
+    __shared__ __attribute__((aligned(16))) char smem[NS * STAGE];
     __shared__ int64_t pair_rel[NQ];
     __shared__ int lds_task;
 
@@ -1096,21 +1102,61 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(3, 3)))
             const unsigned a_lane = (unsigned)l31 * kSliceBytes;                                   // query l31
             const unsigned b_lane = (unsigned)(NQ + wave * 32 + l31) * kSliceBytes;      // row wave * 32 + l31
             issue_stage(0, 0);
+            if (NS == 3 && nslices > 1) issue_stage(1, 1);
+            int buf = 0;  // stage of slice sl (NS == 3: a ring; NS == 2: sl & 1)
             for (int sl = 0; sl < nslices; sl++) {
-                // the slice has landed (a bare s_barrier: __syncthreads() does not reliably drain an LDS-DMA)
-                __builtin_amdgcn_s_waitcnt(0x0070);  // vmcnt(0) lgkmcnt(0)
+                // the slice has landed (a bare s_barrier: __syncthreads() does not reliably drain an LDS-DMA).  Three
+                // stages: the first slice of a task waits for everything (the previous task's output stores are counted
+                // in vmcnt too, and loads and stores need not retire in order); from then on only this wavefront's five
+                // DMA instructions of the NEXT slice may still be out
+                if (NS == 3 && sl > 0 && sl + 1 < nslices)
+                    __builtin_amdgcn_s_waitcnt(0x0075);  // vmcnt(5) lgkmcnt(0)
+                else
+                    __builtin_amdgcn_s_waitcnt(0x0070);  // vmcnt(0) lgkmcnt(0)
                 __builtin_amdgcn_s_barrier();
-                if (sl + 1 < nslices) issue_stage(sl + 1, (sl + 1) & 1);
-                const unsigned sbase = lds0 + (unsigned)(sl & 1) * STAGE;
-#pragma unroll
-                for (int c = 0; c < 4; c++) {
-                    const unsigned x = (((unsigned)(2 * c + half)) ^ sw) << 4;
-                    u32x4 a, b;
-                    asm volatile("ds_read_b128 %0, %2\n\tds_read_b128 %1, %3\n\ts_waitcnt lgkmcnt(0)"
-                                 : "=&v"(a), "=&v"(b)
-                                 : "v"(sbase + a_lane + x), "v"(sbase + b_lane + x)
+                if (NS == 3) {
+                    if (sl + 2 < nslices) issue_stage(sl + 2, buf == 0 ? 2 : buf - 1);   // (sl + 2) % 3
+                } else {
+                    if (sl + 1 < nslices) issue_stage(sl + 1, (sl + 1) & 1);
+                }
+                const unsigned sbase = lds0 + (unsigned)(NS == 3 ? buf : (sl & 1)) * STAGE;
+                if (NS == 3) buf = buf == 2 ? 0 : buf + 1;
+                if (NS == 3) {
+                    // one workgroup per CU: nobody else's MFMAs cover this wavefront's LDS round trips -- step c + 1's two
+                    // operand reads go out before step c's MFMAs (two register sets, a counted wait)
+                    u32x4 pa[2], pb[2];
+                    const unsigned x0 = (((unsigned)half) ^ sw) << 4;
+                    asm volatile("ds_read_b128 %0, %2\n\tds_read_b128 %1, %3"
+                                 : "=&v"(pa[0]), "=&v"(pb[0])
+                                 : "v"(sbase + a_lane + x0), "v"(sbase + b_lane + x0)
                                  : "memory");
-                    Mma4<T>::run(acc4, a, b, c);
+#pragma unroll
+                    for (int c = 0; c < 4; c++) {
+                        if (c + 1 < 4) {
+                            const unsigned x = (((unsigned)(2 * (c + 1) + half)) ^ sw) << 4;
+                            asm volatile("ds_read_b128 %0, %2\n\tds_read_b128 %1, %3"
+                                         : "=&v"(pa[(c + 1) & 1]), "=&v"(pb[(c + 1) & 1])
+                                         : "v"(sbase + a_lane + x), "v"(sbase + b_lane + x)
+                                         : "memory");
+                            asm volatile("s_waitcnt lgkmcnt(2)" : "+v"(pa[c & 1]), "+v"(pb[c & 1])::"memory");
+                        } else {
+                            asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(pa[c & 1]), "+v"(pb[c & 1])::"memory");
+                        }
+                        __builtin_amdgcn_sched_barrier(0);  // (the register-only MFMAs must stay behind the wait)
+                        Mma4<T>::run(acc4, pa[c & 1], pb[c & 1], c);
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
+                } else {
+#pragma unroll
+                    for (int c = 0; c < 4; c++) {
+                        const unsigned x = (((unsigned)(2 * c + half)) ^ sw) << 4;
+                        u32x4 a, b;
+                        asm volatile("ds_read_b128 %0, %2\n\tds_read_b128 %1, %3\n\ts_waitcnt lgkmcnt(0)"
+                                     : "=&v"(a), "=&v"(b)
+                                     : "v"(sbase + a_lane + x), "v"(sbase + b_lane + x)
+                                     : "memory");
+                        Mma4<T>::run(acc4, a, b, c);
+                    }
                 }
             }
             const f32x16 acc = (acc4[0] + acc4[1]) + (acc4[2] + acc4[3]);
@@ -1267,16 +1313,25 @@ int launch_mfma_scan(pgv_ctx *ctx, pgv_metric metric, pgv_dtype dtype, const Row
     int *counter = ctx->counters.as<int>() + 8;  // words 8, 9: claimed tasks, workgroups done (the kernel re-zeroes them)
     int grid = ctx->num_cus * 3;  // 41 KB of LDS per workgroup: three per CU
     if (grid > ntasks_bound) grid = ntasks_bound;
-#define PGV_MSCAN_Q(T, M, NT, Q)                                                                                        \
-    hipLaunchKernelGGL((mfma_scan_kernel<T, M, kScanWaves, NT, Q>), dim3(grid), dim3(kScanWaves * 64), 0, ctx->stream,   \
+    // fewer tasks than two per CU: nothing else streams through a workgroup's fill latency -> three LDS stages
+    // (PGV_SCAN_DEEP = 0 switches it off: A/B)
+    static const int deep_env = [] {
+        const char *e = getenv("PGV_SCAN_DEEP");
+        return e ? atoi(e) : -1;
+    }();
+    const bool deep = queries_per_task == 32 && deep_env != 0 && ntasks_bound <= 2 * ctx->num_cus;
+#define PGV_MSCAN_Q(T, M, NT, Q, S)                                                                                     \
+    hipLaunchKernelGGL((mfma_scan_kernel<T, M, kScanWaves, NT, Q, S>), dim3(grid), dim3(kScanWaves * 64), 0, ctx->stream, \
                        static_cast<const char *>(rows), static_cast<const char *>(queries), tasks, ntasks_dev, counter, \
                        pairs, row_norms, g.nvec, static_cast<const char *>(ctx->zeros.p), out)
-#define PGV_MSCAN_NT(T, M, NT)               \
-    do {                                     \
-        if (queries_per_task == 64)          \
-            PGV_MSCAN_Q(T, M, NT, 64);        \
-        else                                 \
-            PGV_MSCAN_Q(T, M, NT, 32);        \
+#define PGV_MSCAN_NT(T, M, NT)                   \
+    do {                                         \
+        if (queries_per_task == 64)              \
+            PGV_MSCAN_Q(T, M, NT, 64, 2);         \
+        else if (deep)                           \
+            PGV_MSCAN_Q(T, M, NT, 32, 3);         \
+        else                                     \
+            PGV_MSCAN_Q(T, M, NT, 32, 2);         \
     } while (0)
 #define PGV_MSCAN(T, M)              \
     do {                             \
