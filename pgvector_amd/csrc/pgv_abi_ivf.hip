@@ -906,8 +906,10 @@ int scan_batch_dev(pgv_index *ix, const void *q_dev, int nq, const int32_t *prob
         return e ? atoi(e) : -1;
     }();
     // measured (10 M rows, lists 4096, probes 64, 1024 queries): 3072-d fp16 88.5 k -> 93.3 k QPS (scan 10.81 -> 10.19 ms); 1536-d
-    // fp32 84.3 k -> 84.5 k -- two fp32 tiles per stage fill make a task MFMA-bound, so fp32 keeps the 32-query form
-    const bool wide = use_mfma && (wide_env < 0 ? (share > 12.0 && ix->dtype == PGV_F16) : wide_env != 0);
+    // fp32: HBM traffic -16 % (passes 1.26 -> 1.06) but the scan only 11.83 -> 11.43 ms, 81.7 k -> 84.4 k QPS (round 6; one GPU's
+    // share 612 k -> 640 k) -- a task of two fp32 tiles per stage fill runs the matrix pipes at ~90 %, so the 64-query form
+    // buys a few per cent there, not the traffic's 16; below ~12 queries per list it costs (headline, share 10: -3 %)
+    const bool wide = use_mfma && (wide_env < 0 ? share > 12.0 : wide_env != 0);
     const int qt = use_mfma ? (wide ? mfma_scan_queries_per_task_wide() : mfma_scan_queries_per_task())
                             : (use_tile ? tile_scan_queries_per_task()
                                         : scan_group_size(ix->geom, ix->dtype, (int)std::ceil(share)));

@@ -185,7 +185,7 @@ def test_the_64_query_scan_form_answers_like_the_oracle(ctx, oracle, ops, dt, di
 
 
 def test_the_64_query_scan_form_for_fp32_too_in_a_process_that_forces_it():
-    """the default picks the 64-query form for halfvec only (fp32 wide tasks are MFMA-bound: no gain); PGV_SCAN_WIDE=1 -- read
+    """the default picks the 64-query form from 12 queries per list on (fp32 too since round 6: a few per cent); PGV_SCAN_WIDE=1 -- read
     once per process -- forces it everywhere: five shapes incl. fp32 L2 / IP and exact ties, every query against the oracle"""
     import os
     import subprocess
