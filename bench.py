@@ -23,7 +23,8 @@ cpu_baseline -- and from there on the line exists.  Every other section runs in 
 (`--section NAME`), one at a time, each in its own session with its own budget (killed as a process group when it is
 not back), writing what it has measured to a file after every step: configs (other_configs + exact_scan), hnsw,
 build (pages + CPU build baseline), the PMC traffic passes, sweeps, and the sections that start backends LAST.  A
-failed, cut or skipped section is a `failures` entry and exit code 2 -- with the whole line printed.
+failed section is a `failures` entry and exit code 2 -- with the whole line printed; one that only ran out of its budget (a slow
+box) is a `failures` entry with the prefix "budget:" and leaves the exit code alone.
 
 What the line carries besides the contract's fields (rank 0, N = 1):
   parity       the GPU's answers for `parity_checked_queries` queries compared with the CPU oracle's
@@ -1389,7 +1390,9 @@ def emit_line(fd, full):
 #      group and the next one starts.  A child writes what it has measured to a file after every step, so a cut
 #      section still contributes the rows it finished.  Order: other_configs + exact_scan, hnsw, build (pages, CPU
 #      build baseline), PMC traffic, sweeps, and the sections that start backends LAST.
-#   3. a failed, cut or skipped section is a `failures` entry and the exit code is 2 -- with the full line printed.
+#   3. a failed section is a `failures` entry and the exit code is 2 -- with the full line printed; a section that was cut
+#      or not started for lack of time is a `failures` entry ("budget: ...") too, but the exit code stays 0: incomplete,
+#      not wrong.
 #   4. the watchdog is the last resort for the parent itself: it prints the line as far as it has got and exits 2 (3
 #      without a line).
 WATCH = {"line": None, "fd": None, "rank": 0, "section": "setup", "done": False}
@@ -1514,7 +1517,7 @@ def run_section(name, args, budget_s, line, failures):
     failures.extend("%s: %s" % (name, f) for f in data.get("failures", []))
     line.setdefault("sections", {})[name] = {"secs": secs, "rc": rc, "timed_out": timed_out, "budget_secs": budget_s}
     if timed_out:
-        failures.append("section %s: not back after %d s, killed (it had reached: %s)" % (name, budget_s, data.get("_at", "nothing")))
+        failures.append("budget: section %s: not back after %d s, killed (it had reached: %s)" % (name, budget_s, data.get("_at", "nothing")))
     elif rc != 0:
         failures.append("section %s: exit code %r (it had reached: %s)" % (name, rc, data.get("_at", "nothing")))
     log("[%s] section %s: %.1f s, rc %r%s" % (time.strftime("%H:%M:%S"), name, secs, rc, ", CUT" if timed_out else ""))
@@ -2624,7 +2627,7 @@ def main():
                 continue
             WATCH["section"] = "section " + name
             if time.perf_counter() - t_program > args.budget_secs:
-                failures.append("section %s: not started, the run was %d s old (--budget-secs %d)"
+                failures.append("budget: section %s: not started, the run was %d s old (--budget-secs %d)"
                                 % (name, time.perf_counter() - t_program, args.budget_secs))
                 continue
             if name == "traffic":
@@ -2659,8 +2662,13 @@ def main():
     if sharded:
         dist.destroy_process_group()
     if failures:
-        log("FAILED: " + "; ".join(failures))
-        sys.exit(2)
+        # an optional section that ran out of its budget on a slow box leaves the measurement INCOMPLETE (it is listed in
+        # `failures`, prefix "budget:"), not wrong: only everything else -- a parity mismatch, a crashed section, a baseline
+        # that did not run -- is a failed run
+        hard = [f for f in failures if not str(f).startswith("budget:")]
+        log(("FAILED: " if hard else "INCOMPLETE: ") + "; ".join(failures))
+        if hard:
+            sys.exit(2)
 
 
 if __name__ == "__main__":

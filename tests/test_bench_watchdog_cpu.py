@@ -77,7 +77,7 @@ def test_a_hung_section_is_killed_with_its_descendants_and_its_rows_are_kept(tmp
     assert line["concurrent_backends"] == {"1": {"qps": 5.0}}            # what it had finished is in the line
     assert line["sections"]["backends"]["timed_out"] is True
     assert any("a row failed" in f for f in failures)
-    assert any("not back after 3 s" in f and "row 3 of 7" in f for f in failures)
+    assert any("not back after 3 s" in f and "row 3 of 7" in f and f.startswith("budget:") for f in failures)
     gpid = int(pidfile.read_text())
     for _ in range(50):
         if not _alive(gpid):
