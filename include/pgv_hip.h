@@ -205,12 +205,13 @@ int			pgv_ctx_set_exact_scan(pgv_ctx * ctx, int on);
  *       (gamma_(dim+1) + gamma_(dim+2)) (|q| + |x|max)^2 on one chain, flagged every query and cost 98 %).
  *   PGV_BOUND_STATISTICAL  8 sqrt(dim + 4) 2^-24 (|q| + |x|max)^2 -- the probabilistic model of a length-dim fp32
  *       summation (fails with probability ~ e^-32 per sum).
- * A context starts with the deterministic bound for everything that returns row ids (list scan, center ranking,
- * pgv_exact_topk) and the statistical one for the build's assignment pre-filter: that kernel has one accumulator chain
- * per output (128 accumulators a lane leave no room for four), where gamma_(dim+1) (|c|^2 + 2 |a||c|) + gamma_(dim+2) d
- * is 5-10 x wider and sends a tenth of the rows of a 3072-d halfvec build to the exact kernel (32 -> 123 ms per 1.25 M
- * rows); a row the statistical bound misjudges lands in a list whose center is as near as the reference's choice to
- * within the float tolerance of the distances.  pgv_ctx_set_bound(mode) sets BOTH.
+ * A context starts with the deterministic bound EVERYWHERE (round 6), the build's assignment pre-filter included.  That
+ * kernel has one accumulator chain per output (128 accumulators a lane leave no room for four), so its band is
+ * gamma_(dim+1) (|c|^2 + 2 |a||c|) + gamma_(dim+2) d, 5-10 x wider than the statistical one; what makes it affordable is
+ * that an ambiguous row costs an exact recheck of the candidates inside the band (a row's merged list carries 8 of them
+ * and the smallest value no list kept) instead of a pass over all centers: +4 % at 1 M x 1000 x 1536 fp32, +10 % at
+ * 1.25 M x 4096 x 3072 fp16 over the statistical bound (round 5's form of it: 32 -> 123 ms).  pgv_ctx_set_bound(mode)
+ * sets scans and assignment alike.
  * pgv_ctx_set_exact_scan(ctx, 1) remains the mode that uses no expansion at all.
  */
 #define PGV_BOUND_STATISTICAL 0
