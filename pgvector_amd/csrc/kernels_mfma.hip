@@ -54,6 +54,9 @@ typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 
 constexpr int kSliceBytes = 128;  // bytes of every row per pipeline stage = 8 slots of 16 B
+#ifndef PGV_ARGMIN_AUX
+#define PGV_ARGMIN_AUX 0   // cache policy of the assignment kernel's fills (A/B builds: 2 = nt, 16 = sc1, 17 = sc0 sc1)
+#endif
 constexpr int kCand = 4;          // centers a lane's (and a center part's) list keeps in the L2 pre-filter
 constexpr int kWide = 8;          // centers the merged list of a row carries to the recheck (see finish_l2)
 
@@ -329,7 +332,7 @@ __global__ __launch_bounds__(MfmaCfg<T>::WM *MfmaCfg<T>::WN * 64, 2) void mfma_a
             const char *p = vi < nvec ? src_base + (size_t)src_row(cb, j) * row_bytes + (size_t)vi * sizeof(Raw16) : zeros16;
             char *dst = smem + (size_t)buf * STAGE + (size_t)(crow0 + 8 * j) * kSliceBytes;
             __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)p,
-                                             (__attribute__((address_space(3))) void *)dst, 16, 0, 0);
+                                             (__attribute__((address_space(3))) void *)dst, 16, 0, PGV_ARGMIN_AUX);
         }
     };
 
