@@ -66,11 +66,15 @@ def test_world_size_that_disagrees_with_gpus_is_refused():
 
 def test_under_torch_distributed_run_nothing_is_started_from_here():
     """the contract's own form: torch.distributed.run sets WORLD_SIZE, bench.py joins as a rank"""
+    import socket
     e = dict(os.environ)
     for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK"):
         e.pop(k, None)
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
     r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
-                        "127.0.0.1", "--master-port", "29613", BENCH, "--gpus", "2", "--backend", "gloo", "--dry-launch"],
+                        "127.0.0.1", "--master-port", str(port), BENCH, "--gpus", "2", "--backend", "gloo", "--dry-launch"],
                        capture_output=True, text=True, timeout=180, env=e)
     assert r.returncode == 0, r.stderr[-2000:]
     line = json.loads([ln for ln in r.stdout.strip().splitlines() if ln.startswith("{")][-1])
