@@ -1013,7 +1013,7 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(NS == 3
         // pair table to registers (after the loop: a store followed by an LDS read makes hipcc wait for the store)
         const int j32 = wave * 32 + l31;
         if constexpr (NQ > 32) {
-          if (!narrow) {
+          if (!narrow && upper) {
             // The 64-query form.  Two tiles per wavefront (queries 0-31 and, when the task has them, 32-63, against its 32
             // rows) leave no room for four interleaved accumulators per output (2 x 64 registers: spills at three waves per
             // SIMD): the four chains are the row's slices in four consecutive QUARTERS instead -- one accumulator per tile,
@@ -1096,7 +1096,8 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(NS == 3
             }
           }
         }
-        if (NQ == 32 && !narrow) {
+        // (the 64-query kernel's tasks of 17 .. 32 queries take this form too: the same code as the 32-query kernel's)
+        if (!narrow && !upper) {
             f32x16 acc4[4];
 #pragma unroll
             for (int e = 0; e < 4; e++)
