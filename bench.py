@@ -2642,7 +2642,7 @@ def main():
                 if traffic and stream_bytes > 0:
                     roofline["traffic_over_streamed"] = traffic / (stream_bytes / launches)
                 if traffic is None:
-                    failures.append("traffic: " + src)
+                    failures.append("incomplete: traffic: " + src)
                 line.setdefault("sections", {})["traffic"] = {"secs": time.perf_counter() - t0}
                 continue
             run_section(name, args, SECTION_BUDGET_S[name], line, failures)
