@@ -40,6 +40,9 @@ SHAPES = {
                "configs[4] at full size: 10 M x 3072 f16 L2, lists 4096, probes 64, one GPU"),
     "c4": ([PY, BENCH, "--section", "hnsw", "--section-out", "/tmp/r06prof_c4.json", "--no-cpu-baseline", "--soft-exit"], "hnsw_search_kernel",
            "configs[3]: HNSW 1 M x 1536 f32 cosine, m 16, GPU-built graph, ef_search 40 .. 1000, 20 000 queries in flight"),
+    # (A/B: the 64-query form of the scan forced on for the headline: PGV_SCAN_WIDE=1, see run_pass)
+    "headline_wide": ([PY, BENCH, "--child", "--steps", "10", "--warmup", "2", "--overlap-lanes", "0"], "mfma_scan_kernel<float, 0",
+                      "headline with the 64-query form of the scan kernel forced on (PGV_SCAN_WIDE=1)"),
     "dense": ([PY, os.path.join(ROOT, "tools", "exp_exact_topk.py")], "mfma_dense_kernel",
               "pgv_exact_topk: 1 M x 1536 f32 x 1024 queries, L2 and IP"),
 }
@@ -61,6 +64,8 @@ def run_pass(shape, pname, cmd):
     shutil.rmtree(d, ignore_errors=True)
     os.makedirs(d)
     env = dict(os.environ, TMPDIR="/tmp")
+    if shape.endswith("_wide"):
+        env["PGV_SCAN_WIDE"] = "1"
     t0 = time.time()
     with open(os.path.join(d, "stdout.txt"), "w") as so, open(os.path.join(d, "stderr.txt"), "w") as se:
         r = subprocess.run(["rocprofv3"] + PASSES[pname] + ["-d", d, "-o", "p", "--output-format", "csv", "--"] + cmd,
