@@ -1098,6 +1098,15 @@ void copy_head(pgv_query *q, int stride, int n, float *out_dist, int64_t *out_sl
 
 }  // namespace
 
+// PGV_QUERY_DIRECT=0 keeps the staging kernel (A/B switch)
+static bool query_direct_enabled() {
+    static const bool on = [] {
+        const char *e = getenv("PGV_QUERY_DIRECT");
+        return !(e && e[0] == '0');
+    }();
+    return on;
+}
+
 int pgv_query_begin(pgv_index *ix, pgv_query **out) {
     if (!ix || !out) PGV_FAIL(PGV_ERR_ARG, "pgv_query_begin: index/out is NULL");
     *out = nullptr;
@@ -1116,6 +1125,14 @@ int pgv_query_begin(pgv_index *ix, pgv_query **out) {
     if (rc == PGV_OK && hipHostMalloc(&q->head_pinned, q->head_bytes, hipHostMallocDefault) != hipSuccess)
         rc = PGV_ERR_NOMEM;
     if (rc == PGV_OK && hipMemsetAsync(q->state.p, 0, state_bytes, ctx->stream) != hipSuccess) rc = PGV_ERR_DEVICE;
+    if (rc == PGV_OK && query_direct_enabled()) {
+        // a device row the host can store into (large BAR): the query then needs no staging kernel.  Optional: without
+        // it the pinned row + query_stage_kernel carry the query
+        if (hipExtMallocWithFlags(&q->q_direct, row_bytes, hipDeviceMallocFinegrained) != hipSuccess) {
+            (void)hipGetLastError();
+            q->q_direct = nullptr;
+        }
+    }
     if (rc != PGV_OK) {
         set_error("pgv_query_begin: allocation failed");
         pgv_query_end(q);
@@ -1135,6 +1152,7 @@ void pgv_query_end(pgv_query *q) {
     q->seg.release();
     q->q_dev.release();
     if (q->q_pinned) (void)hipHostFree(q->q_pinned);
+    if (q->q_direct) (void)hipFree(q->q_direct);
     if (q->head_pinned) (void)hipHostFree(q->head_pinned);
     delete q;
 }
@@ -1157,16 +1175,25 @@ int pgv_query_rank(pgv_query *q, const void *query, int max_probes) {
     if (is_device_ptr(query)) {
         PGV_HIP(hipMemsetAsync(q->q_dev.p, 0, row_bytes, ctx->stream));
         PGV_HIP(hipMemcpyAsync(q->q_dev.p, query, (size_t)ix->dim * es, hipMemcpyDeviceToDevice, ctx->stream));
+        q->q_row = q->q_dev.p;
     } else {
         // the previous query's kernels have finished reading q_pinned: every pgv_query_scan waits for its head
         // (a rank that no scan followed is waited for here)
         if (q->rank_pending) PGV_HIP(hipStreamSynchronize(ctx->stream));
-        memcpy(q->q_pinned, query, (size_t)ix->dim * es);
-        if (row_bytes > (size_t)ix->dim * es) memset(static_cast<char *>(q->q_pinned) + (size_t)ix->dim * es, 0, row_bytes - (size_t)ix->dim * es);
-        PGV_TRY(launch_query_stage(ctx, q->q_pinned, q->q_dev.p, ix->geom.nvec));
+        void *dst = q->q_direct ? q->q_direct : q->q_pinned;
+        memcpy(dst, query, (size_t)ix->dim * es);
+        if (row_bytes > (size_t)ix->dim * es) memset(static_cast<char *>(dst) + (size_t)ix->dim * es, 0, row_bytes - (size_t)ix->dim * es);
+        if (q->q_direct) {
+            // the stores drain to the device ahead of the doorbell write of the launch below (posted writes, in order)
+            __builtin_ia32_sfence();
+            q->q_row = q->q_direct;
+        } else {
+            PGV_TRY(launch_query_stage(ctx, q->q_pinned, q->q_dev.p, ix->geom.nvec));
+            q->q_row = q->q_dev.p;
+        }
     }
     q->rank_pending = true;
-    return launch_query_rank(ctx, ix, q->q_dev.p, q->cdist, max_probes, q->lists);
+    return launch_query_rank(ctx, ix, q->q_row, q->cdist, max_probes, q->lists);
 }
 
 int pgv_query_scan(pgv_query *q, int first, int nprobes, int head, float *out_dist, int64_t *out_slot,
@@ -1186,7 +1213,7 @@ int pgv_query_scan(pgv_query *q, int first, int nprobes, int head, float *out_di
     PGV_TRY(q->seg.ensure(sizeof(float) * (size_t)(bound + 4)));  // + one float4 of slack for the vector loads of the selection
     const unsigned seq = ++q->seq ? q->seq : ++q->seq;  // never 0: the cleared record's value
     ScanGate gate;  // held until the head is back (every return below)
-    PGV_TRY(launch_query_scan(ctx, ix, q->is_null ? nullptr : q->q_dev.p, q->lists + first, nprobes, bound,
+    PGV_TRY(launch_query_scan(ctx, ix, q->is_null ? nullptr : q->q_row, q->lists + first, nprobes, bound,
                               q->seg.as<float>()));
     PGV_TRY(launch_query_head(ctx, ix, q->seg.as<float>(), q->lists + first, nprobes, 0, head, q->head_pinned, seq));
     q->cur_first = first;

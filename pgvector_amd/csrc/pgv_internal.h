@@ -185,6 +185,8 @@ struct pgv_query {
     pgv::DBuf seg;        // distances of the current GetScanItems batch, tuplesort input order
     pgv::DBuf q_dev;      // the query row, padded
     void *q_pinned = nullptr;     // pinned host staging of the query payload
+    const void *q_row = nullptr;  // where the kernels read the current query: q_direct or q_dev
+    void *q_direct = nullptr;     // fine-grained device row the host writes through the BAR (no staging kernel), or null
     void *head_pinned = nullptr;  // pinned, device-written: QueryHead + head arrays
     size_t head_bytes = 0;
     int32_t *lists = nullptr;
