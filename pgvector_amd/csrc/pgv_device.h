@@ -253,6 +253,22 @@ __device__ __forceinline__ float wave_sum2(float a, float b) {
     return __uint_as_float(r32[0]) + __uint_as_float(r32[1]);
 }
 
+// minimum of an unsigned over the 64 lanes, in every lane (same network as wave_sum2)
+template <int CTRL> __device__ __forceinline__ unsigned dpp_u32(unsigned v) {
+    return (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, CTRL, 0xf, 0xf, false);
+}
+__device__ __forceinline__ unsigned umin32(unsigned a, unsigned b) { return a < b ? a : b; }
+__device__ __forceinline__ unsigned wave_min_u32(unsigned v) {
+    v = umin32(v, dpp_u32<0xB1>(v));   // quad_perm [1,0,3,2]
+    v = umin32(v, dpp_u32<0x4E>(v));   // quad_perm [2,3,0,1]
+    v = umin32(v, dpp_u32<0x124>(v));  // row_ror:4
+    v = umin32(v, dpp_u32<0x128>(v));  // row_ror:8
+    const auto r16 = __builtin_amdgcn_permlane16_swap(v, v, false, false);
+    v = umin32(r16[0], r16[1]);
+    const auto r32 = __builtin_amdgcn_permlane32_swap(v, v, false, false);
+    return umin32(r32[0], r32[1]);
+}
+
 // ---- ordered-uint keys for float selection ---------------------------------
 // ascending float order == ascending unsigned order; every NaN maps above +inf,
 // like PostgreSQL's float8 ordering puts NaN last.

@@ -120,9 +120,11 @@ __device__ inline unsigned rank_among_minima(const unsigned *mins, unsigned mine
 // The k smallest of load(0 .. m) by (key, position), ascending, left in ent[0, min(k, m)); the
 // rest of ent[0, kp) is ~0.  kp = k rounded up to a power of two (>= 2), cap >= max(kp, kFastCap)
 // entries of LDS behind `ent`.  An entry is (key << 32) | position.
+// (everything here is inlined into its kernel: as a called function the selection saved and restored registers
+// through scratch memory on the one workgroup's critical path, and its kernels needed a private segment)
 template <typename Load>
-__device__ void block_topk(Load load, int64_t m, int k, int kp, int cap, unsigned long long *ent,
-                           SelShared *s) {
+__device__ __forceinline__ void block_topk(Load load, int64_t m, int k, int kp, int cap, unsigned long long *ent,
+                                           SelShared *s) {
     for (int i = threadIdx.x; i < cap; i += kSelThreads) ent[i] = ~0ull;
     if (threadIdx.x == 0) s->count = 0;
     __syncthreads();
@@ -283,11 +285,13 @@ constexpr int kSmallVec = 12;
 // five were over the old limit and took the general path's two sweeps from memory)
 constexpr int kLargeVec = 20;
 constexpr int kSmallMax = kLargeVec * 4 * kSelThreads;  // 20480
+constexpr int kExtractMax = 16;  // k up to which the threshold comes from per-wavefront extraction
 
-// NVEC float4 per thread: 1 (m <= 1024: the centers of a typical index), 4 (m <= 4096) or 12
+// NVEC float4 per thread: 1 (m <= 1024: the centers of a typical index), 4 (m <= 4096) or 12.  Returns false when the
+// general path has to run instead (long runs of equal keys, or too few finite values).
 template <int NVEC>
-__device__ inline void block_topk_small(const float *v, int m, int k, int kp, int cap, unsigned long long *ent,
-                                        SelShared *s) {
+__device__ __forceinline__ bool block_topk_small(const float *v, int m, int k, int kp, int cap, unsigned long long *ent,
+                                                 SelShared *s) {
     // A lone workgroup runs at whatever clock an otherwise idle chip grants: what counts here is the
     // number of instructions on the critical path (measured: ~300 instructions per microsecond), so the
     // sweeps compare floats (one v_min / v_cmp per value, keys only where a value is kept) and the rank
@@ -319,19 +323,48 @@ __device__ inline void block_topk_small(const float *v, int m, int k, int kp, in
     const unsigned key_mine = float_to_key(fmine);
     const unsigned comp = (key_mine & ~0xffu) | threadIdx.x;
     unsigned *mins = s->hist;
-    __syncthreads();
-    mins[threadIdx.x] = comp;
-    __syncthreads();
-    unsigned rank = 0;
-    {
-        const uint4 *m4 = reinterpret_cast<const uint4 *>(mins);
-#pragma unroll 4
-        for (int j4 = 0; j4 < kSelThreads / 4; j4++) {
-            const uint4 o = m4[j4];
-            rank += (o.x < comp) + (o.y < comp) + (o.z < comp) + (o.w < comp);
+    if (k <= kExtractMax) {
+        // small k: every wavefront pulls its k smallest composites out one at a time (a DPP minimum per round, ~15
+        // instructions), then the 4k survivors are ranked -- the same composite of rank k - 1 as below for a
+        // third of the instructions
+        const int lane = threadIdx.x & (kWave - 1), wave = threadIdx.x >> 6;
+        unsigned v = comp, keep = 0xffffffffu;
+#pragma unroll 1
+        for (int j = 0; j < k; j++) {
+            const unsigned mn = wave_min_u32(v);
+            keep = lane == j ? mn : keep;
+            v = v == mn ? 0xffffffffu : v;
         }
+        const int n4 = (kSelThreads / kWave) * k;
+        __syncthreads();
+        if (lane < k) mins[wave * k + lane] = keep;
+        if ((int)threadIdx.x >= n4 && (int)threadIdx.x < ((n4 + 3) & ~3)) mins[threadIdx.x] = 0xffffffffu;
+        __syncthreads();
+        if ((int)threadIdx.x < n4) {
+            const unsigned own = mins[threadIdx.x];
+            const uint4 *m4 = reinterpret_cast<const uint4 *>(mins);
+            unsigned rank = 0;
+            for (int j4 = 0; j4 < (n4 + 3) / 4; j4++) {
+                const uint4 o = m4[j4];
+                rank += (o.x < own) + (o.y < own) + (o.z < own) + (o.w < own);
+            }
+            if (rank == (unsigned)(k - 1)) s->bin = own | 0xffu;
+        }
+    } else {
+        __syncthreads();
+        mins[threadIdx.x] = comp;
+        __syncthreads();
+        unsigned rank = 0;
+        {
+            const uint4 *m4 = reinterpret_cast<const uint4 *>(mins);
+#pragma unroll 4
+            for (int j4 = 0; j4 < kSelThreads / 4; j4++) {
+                const uint4 o = m4[j4];
+                rank += (o.x < comp) + (o.y < comp) + (o.z < comp) + (o.w < comp);
+            }
+        }
+        if (rank == (unsigned)(k - 1)) s->bin = key_mine | 0xffu;
     }
-    if (rank == (unsigned)(k - 1)) s->bin = key_mine | 0xffu;
     __syncthreads();
     const unsigned t0 = s->bin;
     // a finite threshold means k finite values exist at or below it: NaN and +inf entries (which the float
@@ -372,26 +405,27 @@ __device__ inline void block_topk_small(const float *v, int m, int k, int kp, in
         while (sort_n < (int)got) sort_n <<= 1;
         sort_entries(ent, sort_n);
     } else {
-        // long runs of equal keys, or too few finite values: the general (radix) path
         __syncthreads();
-        block_topk([v](int64_t i) { return v[i]; }, (int64_t)m, k, kp, cap, ent, s);
+        return false;
     }
+    return true;
 }
 
 // picks the register-resident form when it applies
-__device__ inline void block_topk_auto(const float *v, int64_t m, int k, int kp, int cap, unsigned long long *ent,
-                                       SelShared *s) {
-    if (m > k && m <= kSmallMax && k <= kSelThreads / 2) {  // block-uniform
+__device__ __forceinline__ void block_topk_auto(const float *v, int64_t m, int k, int kp, int cap, unsigned long long *ent,
+                                                SelShared *s) {
+    bool done = false;  // block-uniform
+    if (m > k && m <= kSmallMax && k <= kSelThreads / 2) {
         if (m <= 4 * kSelThreads)
-            block_topk_small<1>(v, (int)m, k, kp, cap, ent, s);
+            done = block_topk_small<1>(v, (int)m, k, kp, cap, ent, s);
         else if (m <= 16 * kSelThreads)
-            block_topk_small<4>(v, (int)m, k, kp, cap, ent, s);
+            done = block_topk_small<4>(v, (int)m, k, kp, cap, ent, s);
         else if (m <= kSmallVec * 4 * kSelThreads)
-            block_topk_small<kSmallVec>(v, (int)m, k, kp, cap, ent, s);
+            done = block_topk_small<kSmallVec>(v, (int)m, k, kp, cap, ent, s);
         else
-            block_topk_small<kLargeVec>(v, (int)m, k, kp, cap, ent, s);
-    } else
-        block_topk([v](int64_t i) { return v[i]; }, m, k, kp, cap, ent, s);
+            done = block_topk_small<kLargeVec>(v, (int)m, k, kp, cap, ent, s);
+    }
+    if (!done) block_topk([v](int64_t i) { return v[i]; }, m, k, kp, cap, ent, s);
 }
 
 }  // namespace
