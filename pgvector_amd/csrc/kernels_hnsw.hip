@@ -110,7 +110,7 @@ __global__ __launch_bounds__(kHnswThreads) void hnsw_search_kernel(
     // 352 k QPS with R = 1, 456 k with R = 2; 1 M x 1536: 366-403 k with R = 2, 385-413 k with R = 4, the default;
     // profiles/r05/hnsw_build_device_link.md).  Each row keeps its own accumulator and element order: the distances do not
     // depend on R.
-    auto score_rows = [&](auto rc, int nb) {
+    auto score_rows = [&](auto rc, int nb) __attribute__((always_inline)) {
         constexpr int R = decltype(rc)::value;
         const int step = kHnswWaves * rpw;
         for (int base = wave * rpw; base < nb; base += R * step) {
@@ -149,7 +149,9 @@ __global__ __launch_bounds__(kHnswThreads) void hnsw_search_kernel(
             }
         }
     };
-    auto score_batch = [&](int nb) {
+    // (always inlined: as a called function -- what the fp16 instantiations got -- every batch of a walk saved and
+    // restored registers through 208 bytes of scratch)
+    auto score_batch = [&](int nb) __attribute__((always_inline)) {
         if (run.rows_per_trip >= 4)
             score_rows(std::integral_constant<int, 4>{}, nb);
         else if (run.rows_per_trip == 2)
