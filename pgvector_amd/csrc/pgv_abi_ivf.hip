@@ -1125,9 +1125,11 @@ int pgv_query_begin(pgv_index *ix, pgv_query **out) {
     if (rc == PGV_OK && hipHostMalloc(&q->head_pinned, q->head_bytes, hipHostMallocDefault) != hipSuccess)
         rc = PGV_ERR_NOMEM;
     if (rc == PGV_OK && hipMemsetAsync(q->state.p, 0, state_bytes, ctx->stream) != hipSuccess) rc = PGV_ERR_DEVICE;
-    if (rc == PGV_OK && query_direct_enabled()) {
-        // a device row the host can store into (large BAR): the query then needs no staging kernel.  Optional: without
-        // it the pinned row + query_stage_kernel carry the query
+    int large_bar = 0;
+    if (rc == PGV_OK && query_direct_enabled() &&
+        hipDeviceGetAttribute(&large_bar, hipDeviceAttributeIsLargeBar, ctx->device) == hipSuccess && large_bar) {
+        // a device row the host can store into (the whole of HBM is behind the PCIe BAR): the query then needs no
+        // staging kernel.  Optional: without it the pinned row + query_stage_kernel carry the query
         if (hipExtMallocWithFlags(&q->q_direct, row_bytes, hipDeviceMallocFinegrained) != hipSuccess) {
             (void)hipGetLastError();
             q->q_direct = nullptr;

@@ -161,3 +161,53 @@ def test_hard_data_set_at_the_headline_shape_answers_like_the_oracle(ctx, oracle
             assert_topk_equiv(gth[i][:len(wt)].astype(np.uint64).tolist(), gdh[i][:len(wt)], wt.tolist(), wd,
                               what="hard probes %d q%d" % (probes, i))
     index.close()
+
+
+_QUERY_STREAM = r'''
+import hashlib, sys, os
+sys.path.insert(0, os.getcwd()); sys.path.insert(0, os.path.join(os.getcwd(), "tests"))
+import numpy as np
+from pgvector_amd import api
+from helpers import gen
+from oracle import pyoracle as po
+from helpers import CpuIvf
+dim, lists = int(sys.argv[1]), 40
+oracle = po.Oracle()
+data = gen(9000, dim, seed=611, dist="clustered", clusters=lists)
+ivf = CpuIvf(oracle, po.OPS_L2, po.ORA_F32, data, lists)
+ctx = api.Context(0)
+ix = api.IvfIndex(ctx, ivf.metric, api.PGV_F32, dim, ivf.centers, ivf.list_offsets, ivf.vectors, ivf.tids)
+qh = api.Query(ix)
+h = hashlib.sha256()
+queries = gen(400, dim, seed=612, dist="clustered", clusters=lists)
+for i, q in enumerate(queries):
+    qh.rank(q, 6)
+    if i % 7 == 3:
+        qh.rank(queries[(i * 5) % 400], 6)   # a rank no scan followed: the row is rewritten under a pending kernel
+        qh.rank(q, 6)
+    d, s, t, total = qh.scan(0, 3, 16)
+    h.update(np.asarray(d).tobytes()); h.update(np.asarray(s).tobytes()); h.update(np.asarray(t).tobytes())
+    h.update(np.asarray(qh.lists(6)).tobytes())
+qh.close(); ix.close(); ctx.close()
+print("DIGEST", h.hexdigest())
+'''
+
+
+@pytest.mark.parametrize("dim", [256, 100])
+def test_query_rows_written_through_the_bar_answer_like_staged_ones(dim):
+    """pgv_query_rank writes the query into a fine-grained device row from the host (no staging kernel) where the
+    device is behind a large BAR; PGV_QUERY_DIRECT=0 keeps the pinned row + query_stage_kernel.  400 back-to-back
+    queries (with ranks that no scan follows in between) must answer bit for bit alike both ways: a stale or torn
+    query row would change distances."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    digests = []
+    for direct in ("1", "0"):
+        env = dict(os.environ, PGV_QUERY_DIRECT=direct)
+        r = subprocess.run([sys.executable, "-c", _QUERY_STREAM, str(dim)], cwd=root, env=env, capture_output=True,
+                           text=True, timeout=600)
+        assert r.returncode == 0, r.stderr[-2000:]
+        digests.append([ln for ln in r.stdout.splitlines() if ln.startswith("DIGEST")][-1])
+    assert digests[0] == digests[1]

@@ -10,6 +10,8 @@ int main() {
     const int n = 1536;
     float host[n]; for (int i = 0; i < n; i++) host[i] = 1.0f + i;
     float *out; hipHostMalloc((void **)&out, 64, hipHostMallocDefault);
+    int large_bar = -1; (void)hipDeviceGetAttribute(&large_bar, hipDeviceAttributeIsLargeBar, 0);
+    printf("hipDeviceAttributeIsLargeBar: %d\n", large_bar);
     for (int mode = 0; mode < 2; mode++) {
         float *dev = nullptr;
         hipError_t e = mode == 0 ? hipExtMallocWithFlags((void **)&dev, n * 4, hipDeviceMallocFinegrained) : hipMalloc((void **)&dev, n * 4);
