@@ -4,10 +4,11 @@
 // amgettuple call runs GetScanLists (:47-118), then GetScanItems (:123-187) scores every tuple of
 // the next `probes` lists and sorts them, and the executor usually pulls only LIMIT k of them.
 // The batched path (plan kernels + tile scan + segmented top-k) needs ~10 launches and two host
-// round trips for that; here it is a chain of five small launches on one queue with no host
-// involvement in between:
+// round trips for that; here it is a chain of four small launches on one queue with no host
+// involvement in between (five where the device is not behind a large PCIe BAR):
 //
-//   query_stage_kernel   the query payload from pinned host memory into its padded device row
+//   (the host stores the padded query straight into a fine-grained device row: hipDeviceAttributeIsLargeBar;
+//    otherwise query_stage_kernel copies it from pinned host memory -- one more launch, ~2 us)
 //   query_rank_kernel    distance to every center, spread over all CUs
 //   query_lists_kernel   the max_probes nearest (ascending, lower id on ties) -> device memory
 //   query_scan_kernel    the ~N*probes/lists rows of the next `probes` lists split evenly over all

@@ -490,7 +490,7 @@ int launch_batch_fix(pgv_ctx *ctx, const ExactRows &xr, const void *q_dev, int n
 int launch_iota_slots(pgv_ctx *ctx, const pgv_index *ix, const int32_t *lists_dev, int nlists,
                       const int64_t *probe_off, int64_t *out_slot);
 
-// kernels_query.hip: one query at a time (stage, rank, lists, scan, head: five launches, no host round trip)
+// kernels_query.hip: one query at a time ([stage,] rank, lists, scan, head: four or five launches, no host round trip)
 int query_max_batch_lists();
 int query_head_cap();
 size_t query_head_bytes(int head);
