@@ -211,3 +211,62 @@ def test_query_rows_written_through_the_bar_answer_like_staged_ones(dim):
         assert r.returncode == 0, r.stderr[-2000:]
         digests.append([ln for ln in r.stdout.splitlines() if ln.startswith("DIGEST")][-1])
     assert digests[0] == digests[1]
+
+
+@pytest.mark.parametrize("m", [5, 1000, 1024, 1025, 4096, 4097, 12288, 12289, 20480, 20481, 30000])
+def test_selection_edges_of_the_single_query_head(ctx, m):
+    """query_head_kernel's selection at every size class of block_topk_auto (1 / 4 / 12 / 20 vectors per thread, the
+    general path past 20 480) and at the k that switch its threshold form (<= 16: per-wavefront extraction; above: the
+    256-way rank): integer coordinates make every distance exact, most of them tied, a few rows are NaN and +inf.
+    The stream is (distance, position) ascending, NaN last -- compared element for element, ties included."""
+    rng = np.random.default_rng(900 + m)
+    vec = rng.integers(-3, 4, (m, 2)).astype(np.float32)
+    if m > 10:
+        vec[rng.integers(0, m, 3)] = np.nan
+        vec[rng.integers(0, m, 3), 0] = 3e19           # squares to +inf in fp32
+    centers = np.array([[0, 0], [50, 50]], dtype=np.float32)
+    off = np.array([0, m, m], dtype=np.int64)
+    ix = api.IvfIndex(ctx, api.PGV_L2SQ, api.PGV_F32, 2, centers, off, vec, np.arange(m, dtype=np.uint64))
+    qh = api.Query(ix)
+    q = np.array([1, -1], dtype=np.float32)
+    with np.errstate(over="ignore", invalid="ignore"):
+        want_d = ((vec - q) ** 2).sum(axis=1, dtype=np.float32)
+    key = np.where(np.isnan(want_d), np.inf, want_d)
+    order = np.lexsort((np.arange(m), np.isnan(want_d), key))   # distance, NaN after +inf, then position
+    qh.rank(q, 2)
+    for head in (1, 2, 3, 15, 16, 17, 33, 64, 128, 129, 500, 1024):
+        d, s, t, total = qh.scan(0, 1, head)
+        n = min(head, m)
+        assert total == m and len(s) == n
+        np.testing.assert_array_equal(s, order[:n], err_msg="m %d head %d" % (m, head))
+        np.testing.assert_array_equal(np.asarray(d), want_d[order[:n]])
+        np.testing.assert_array_equal(t, order[:n].astype(np.uint64))
+    qh.close()
+    ix.close()
+
+
+@pytest.mark.parametrize("m", [40, 1025, 4097, 12289, 20481])
+@pytest.mark.parametrize("nq", [3, 300])
+def test_selection_edges_of_the_batched_heads(ctx, m, nq):
+    """the same stream through pgv_search_batch: 3 queries take the few-queries path (mq_head_kernel's selection), 300
+    the list-major path (mfma scan + topk_kernel + exact recheck); k below, at and above the extraction limit.
+    Distances are exact; inside a run of equal distances any member may close the head (tuplesort's tie order is
+    unspecified), so ties are compared as sets."""
+    rng = np.random.default_rng(950 + m)
+    vec = rng.integers(-3, 4, (m, 2)).astype(np.float32)
+    centers = np.array([[0, 0], [50, 50]], dtype=np.float32)
+    off = np.array([0, m, m], dtype=np.int64)
+    ix = api.IvfIndex(ctx, api.PGV_L2SQ, api.PGV_F32, 2, centers, off, vec, np.arange(m, dtype=np.uint64))
+    queries = rng.integers(-2, 3, (nq, 2)).astype(np.float32)
+    for k in (1, 10, 16, 17, 40):
+        dist, slot, _ = ix.search_batch(queries, 1, k)
+        for qi in (0, nq // 2, nq - 1):
+            want_d = ((vec - queries[qi]) ** 2).sum(axis=1, dtype=np.float32)
+            order = np.lexsort((np.arange(m), want_d))[:k]
+            np.testing.assert_array_equal(np.asarray(dist[qi]), want_d[order], err_msg="m %d nq %d k %d" % (m, nq, k))
+            got = np.asarray(slot[qi])
+            np.testing.assert_array_equal(want_d[got], want_d[order])       # every slot carries the distance it claims
+            last = want_d[order[-1]]
+            assert set(got[want_d[got] < last]) == set(order[want_d[order] < last])   # below the last tie class: exact
+            assert len(set(got.tolist())) == k
+    ix.close()
