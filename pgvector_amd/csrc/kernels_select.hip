@@ -162,7 +162,7 @@ __global__ __launch_bounds__(kSelThreads) void topk_kernel(
     const int64_t base = seg_start ? seg_start[seg] : (int64_t)seg * fixed_len;
     const int64_t m = seg_start ? seg_start[seg + 1] - base : fixed_len;
     const float *v = vals + base;
-    block_topk([v](int64_t i) { return v[i]; }, m, k, kp, cap, ent, s);
+    block_topk_auto(v, m, k, kp, cap, ent, s);  // segments up to 20 480 values: one trip to memory, selection from registers
 
     for (int i = threadIdx.x; i < k; i += kSelThreads) {
         const unsigned long long e = ent[i];

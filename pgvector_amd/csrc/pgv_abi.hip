@@ -19,6 +19,7 @@ void set_error(const char *fmt, ...) {
 }
 
 int DBuf::ensure(size_t bytes) {
+    bytes += 64;  // slack every buffer has: the selections read whole 16-byte vectors around a ragged segment
     if (bytes <= cap && p) return PGV_OK;
     if (p) {
         (void)hipFree(p);

@@ -289,9 +289,11 @@ constexpr int kExtractMax = 16;  // k up to which the threshold comes from per-w
 
 // NVEC float4 per thread: 1 (m <= 1024: the centers of a typical index), 4 (m <= 4096) or 12.  Returns false when the
 // general path has to run instead (long runs of equal keys, or too few finite values).
+// `skip` (0..3): v is the segment's start rounded DOWN to 16 bytes, its first `skip` floats belong to whoever is in front
+// (they read as +inf and positions are counted from the segment's own first element); m counts them in.
 template <int NVEC>
-__device__ __forceinline__ bool block_topk_small(const float *v, int m, int k, int kp, int cap, unsigned long long *ent,
-                                                 SelShared *s) {
+__device__ __forceinline__ bool block_topk_small(const float *v, int m, int skip, int k, int kp, int cap,
+                                                 unsigned long long *ent, SelShared *s) {
     // A lone workgroup runs at whatever clock an otherwise idle chip grants: what counts here is the
     // number of instructions on the critical path (measured: ~300 instructions per microsecond), so the
     // sweeps compare floats (one v_min / v_cmp per value, keys only where a value is kept) and the rank
@@ -315,6 +317,11 @@ __device__ __forceinline__ bool block_topk_small(const float *v, int m, int k, i
             if (at + 1 >= m) r[b].y = INFINITY;
             if (at + 2 >= m) r[b].z = INFINITY;
             if (at + 3 >= m) r[b].w = INFINITY;
+        }
+        if (b == 0 && at == 0) {  // the ragged front
+            if (skip > 0) r[b].x = INFINITY;
+            if (skip > 1) r[b].y = INFINITY;
+            if (skip > 2) r[b].z = INFINITY;
         }
         fmine = fminf(fminf(fmine, fminf(r[b].x, r[b].y)), fminf(r[b].z, r[b].w));
     }
@@ -389,7 +396,7 @@ __device__ __forceinline__ bool block_topk_small(const float *v, int m, int k, i
                     for (int c = 0; c < 4; c++)
                         if (e[c] <= t0f) {
                             if (slot < (unsigned)cap)
-                                ent[slot] = ((unsigned long long)float_to_key(e[c]) << 32) | (unsigned)(at + c);
+                                ent[slot] = ((unsigned long long)float_to_key(e[c]) << 32) | (unsigned)(at + c - skip);
                             slot++;
                         }
                 }
@@ -411,19 +418,24 @@ __device__ __forceinline__ bool block_topk_small(const float *v, int m, int k, i
     return true;
 }
 
-// picks the register-resident form when it applies
+// picks the register-resident form when it applies.  v may start anywhere (a segment of a packed stream): the vector
+// loads start at the 16-byte boundary below it; at least 3 floats in front of a ragged v and (m + 3) & ~3 from the
+// boundary on must be readable (every DBuf has the slack; a segment that starts a buffer is aligned).
 __device__ __forceinline__ void block_topk_auto(const float *v, int64_t m, int k, int kp, int cap, unsigned long long *ent,
                                                 SelShared *s) {
     bool done = false;  // block-uniform
-    if (m > k && m <= kSmallMax && k <= kSelThreads / 2) {
-        if (m <= 4 * kSelThreads)
-            done = block_topk_small<1>(v, (int)m, k, kp, cap, ent, s);
-        else if (m <= 16 * kSelThreads)
-            done = block_topk_small<4>(v, (int)m, k, kp, cap, ent, s);
-        else if (m <= kSmallVec * 4 * kSelThreads)
-            done = block_topk_small<kSmallVec>(v, (int)m, k, kp, cap, ent, s);
+    const int skip = (int)((reinterpret_cast<uintptr_t>(v) >> 2) & 3);
+    const int64_t ma = m + skip;
+    if (m > k && ma <= kSmallMax && k <= kSelThreads / 2) {
+        const float *va = v - skip;
+        if (ma <= 4 * kSelThreads)
+            done = block_topk_small<1>(va, (int)ma, skip, k, kp, cap, ent, s);
+        else if (ma <= 16 * kSelThreads)
+            done = block_topk_small<4>(va, (int)ma, skip, k, kp, cap, ent, s);
+        else if (ma <= kSmallVec * 4 * kSelThreads)
+            done = block_topk_small<kSmallVec>(va, (int)ma, skip, k, kp, cap, ent, s);
         else
-            done = block_topk_small<kLargeVec>(v, (int)m, k, kp, cap, ent, s);
+            done = block_topk_small<kLargeVec>(va, (int)ma, skip, k, kp, cap, ent, s);
     }
     if (!done) block_topk([v](int64_t i) { return v[i]; }, m, k, kp, cap, ent, s);
 }
