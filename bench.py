@@ -561,7 +561,10 @@ def concurrent_backends(index, device, qhost, queries, probes, k, args, dev, out
     out["single_query_processes"] = {}
     # (32 own-context processes -- 7-10 k QPS on these boxes, profiles/r03/processes_*.json, DESIGN 4.8b -- only with
     # --all-process-rows: that row costs the most and teaches the least in a driver run)
-    for nb in ((1, 4, 8, 16, 32) if args.all_process_rows else (1, 4, 8, 16)):
+    proc_rows = (1, 4, 8, 16, 32) if args.all_process_rows else (1, 4, 8, 16)
+    if os.environ.get("PGV_BENCH_PROC_ROWS"):   # e.g. "5,6,7,8": where the own-context cliff sits (profiles/r06/own_context_cliff.md)
+        proc_rows = tuple(int(x) for x in os.environ["PGV_BENCH_PROC_ROWS"].split(","))
+    for nb in proc_rows:
         log("  backends: %d processes" % nb)
         try:
             out["single_query_processes"][str(nb)] = _host.run_backend_processes(index, qh, probes, k, 0, nb, 300,
