@@ -9,7 +9,7 @@ Runs ON THE GPU BOX (gpurun), one shape at a time, three rocprofv3 passes of the
 and condenses them into gpurun_out/r06prof/summary.json (+ one small CSV of per-kernel stats per shape); the raw
 traces stay on the box.  profiles/r06_summarize.py turns summary.json into profiles/r06_rocprof_summary.md.
 
-usage: python profiles/r06_profile.py [shape ...]     shapes: headline c2 hard c3full c5full c4 dense
+usage: python profiles/r06_profile.py [shape ...]     shapes: headline c2 hard c3full c5full c4 single dense
 """
 import csv
 import glob
@@ -43,6 +43,8 @@ SHAPES = {
     # (A/B: the 64-query form of the scan forced on for the headline: PGV_SCAN_WIDE=1, see run_pass)
     "headline_wide": ([PY, BENCH, "--child", "--steps", "10", "--warmup", "2", "--overlap-lanes", "0"], "mfma_scan_kernel<float, 0",
                       "headline with the 64-query form of the scan kernel forced on (PGV_SCAN_WIDE=1)"),
+    "single": ([PY, os.path.join(ROOT, "tools", "exp_single_query.py"), "--rows", "1000000", "--lists", "1000", "--threads", "1", "--per", "3000"],
+               "query_scan_kernel", "one backend, one query at a time (pgv_query_rank + pgv_query_scan): 1 M x 1536 f32, lists 1000, probes 10"),
     "dense": ([PY, os.path.join(ROOT, "tools", "exp_exact_topk.py")], "mfma_dense_kernel",
               "pgv_exact_topk: 1 M x 1536 f32 x 1024 queries, L2 and IP"),
 }

@@ -56,6 +56,9 @@ def main():
             extra = "section record of the traced run: " + ", ".join(
                 "ef %s: %.0f QPS recall %.4f (%.0f GB/s of gathered rows)" % (e, v["qps"], v["recall_at_10"], v["scored_rows_GBps"])
                 for e, v in ef.items())
+        if shape == "single":
+            extra = ("the four launches of one query: query_rank_kernel (also the k-means++ rounds of the build: its average is theirs), "
+                     "query_lists_kernel, query_scan_kernel, query_head_kernel; ~11.8 k rows x 6 KB per scan")
         if shape == "dense":
             unique = 1_000_000 * 1536 * 4.0   # the rows once; the kernel is MFMA-bound: 2 n nq dim flops
             extra = "1 M x 1536 x 1024 queries = 3.15e12 flop per launch: %.1f TFLOP/s of 157.3 (fp32 MFMA)" % (
