@@ -379,6 +379,10 @@ def test_hnsw_score_gathers(ctx, oracle):
     (po.OPS_COSINE, api.PGV_NEG_IP, "normal", "f32", 256, 8, 40),
     (po.OPS_L1, api.PGV_L1, "int10", "f32", 8, 5, 17),
     (po.OPS_L2, api.PGV_L2SQ, "normal", "f16", 136, 8, 64),
+    # the other two fp16 instantiations of the search kernel, and fp16 rows of whole 1 KiB slices (four rows per trip)
+    (po.OPS_IP, api.PGV_NEG_IP, "normal", "f16", 256, 8, 40),
+    (po.OPS_L1, api.PGV_L1, "int10", "f16", 8, 5, 17),
+    (po.OPS_L2, api.PGV_L2SQ, "normal", "f16", 1536, 16, 64),
 ])
 def test_hnsw_search_on_device(ctx, oracle, ops, metric, dist, dtype, dim, m, ef):
     """pgv_hnsw_search: the whole first batch of an HNSW scan in one kernel launch (greedy descent
